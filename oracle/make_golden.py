@@ -1,0 +1,175 @@
+"""Generate tests/golden/*.npz by running the REAL reference (imported from /root/reference) on CPU.
+
+TEST INFRASTRUCTURE ONLY. Run in the build container (the GPU box has no /root/reference):
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py
+
+Each fixture freezes: initial weights of the reference's modules, the synthetic episodes (or the seed +
+a digest when they are large), the indices sampled, what `RecPolicyBuffer.sample_inds` returned, and for
+each of K train steps the reference's loss / grad_norm / Q_tot / priorities plus the post-step weights of
+the live and target networks. The reference is unmodified except for the documented oracle patch for VDN
+(`VDNMixer.forward` must keep [T,B,1]).
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+
+from oracle.ref_import import load_reference, reference_args  # noqa: E402
+
+load_reference()
+from gym.spaces import Discrete  # noqa: E402  (the stub; the reference's isinstance checks need this class)
+from offpolicy.utils.rec_buffer import RecReplayBuffer, PrioritizedRecReplayBuffer  # noqa: E402
+from offpolicy.algorithms.qmix.algorithm.QMixPolicy import QMixPolicy  # noqa: E402
+from offpolicy.algorithms.qmix.qmix import QMix  # noqa: E402
+import offpolicy.algorithms.vdn.algorithm.vdn_mixer as vdn_mixer_mod  # noqa: E402
+
+from offpolicy_amd.utils.synth import DIMS, EnvDims, synth_episodes, as_policy_dicts  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def digest(arrs):
+    h = hashlib.sha256()
+    for a in arrs:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def patch_vdn():
+    """Oracle patch A-2: keep the [T, B, 1] shape."""
+    def forward(self, agent_q_inps, states):
+        if type(agent_q_inps) == np.ndarray:
+            agent_q_inps = torch.FloatTensor(agent_q_inps)
+        return agent_q_inps.sum(dim=-1, keepdim=True).unsqueeze(-1)  # QMix squeezes the last dim (qmix.py:155)
+    vdn_mixer_mod.VDNMixer.forward = forward
+
+
+def build(dims, argv=(), vdn=False, **over):
+    args = reference_args(argv, **over)
+    torch.manual_seed(1)
+    np.random.seed(1)
+    pinfo = {"policy_0": {"cent_obs_dim": dims.state_dim, "cent_act_dim": dims.act_dim * dims.n_agents,
+                          "obs_space": [dims.obs_dim], "share_obs_space": [dims.state_dim],
+                          "act_space": Discrete(dims.act_dim)}}
+    device = torch.device("cpu")
+    policy = QMixPolicy({"args": args, "device": device}, pinfo["policy_0"])
+    trainer = QMix(args, dims.n_agents, {"policy_0": policy}, lambda a: "policy_0", device=device,
+                   episode_length=dims.episode_length, vdn=vdn)
+    return args, pinfo, policy, trainer
+
+
+def named(module, prefix):
+    return {prefix + k: v.detach().numpy().copy() for k, v in module.named_parameters()}
+
+
+def run_case(name, dims, n_episodes, inds, steps=3, argv=(), vdn=False, avail="ones", runner_padding=False,
+             per_weights=None, store_inputs=True, cap=None, pre_insert=0, **over):
+    args, pinfo, policy, trainer = build(dims, argv, vdn=vdn, **over)
+    cap = cap or n_episodes
+    agents = {"policy_0": list(range(dims.n_agents))}
+    buf = RecReplayBuffer(pinfo, agents, cap, dims.episode_length, True, True, False)
+    rng = np.random.RandomState(0)
+    out = {}
+    if pre_insert:
+        # exercise ring wrap-around: insert a first block that will be partly overwritten
+        ep0 = synth_episodes(rng, pre_insert, dims, avail=avail, runner_padding=runner_padding)
+        d0 = as_policy_dicts(ep0)
+        rng0 = buf.insert(pre_insert, d0["obs"], d0["share_obs"], d0["acts"], d0["rewards"], d0["dones"],
+                          d0["dones_env"], d0["avail_acts"])
+        out["pre_idx_range"] = np.asarray(rng0)
+        if store_inputs:
+            for k in ("obs", "share_obs", "acts", "rewards", "dones", "dones_env", "avail_acts"):
+                out["pre_ep/" + k] = ep0[k]
+    ep = synth_episodes(rng, n_episodes, dims, avail=avail, runner_padding=runner_padding)
+    d = as_policy_dicts(ep)
+    idx_range = buf.insert(n_episodes, d["obs"], d["share_obs"], d["acts"], d["rewards"], d["dones"],
+                           d["dones_env"], d["avail_acts"])
+    out["idx_range"] = np.asarray(idx_range)
+    out["lengths"] = ep["lengths"]
+    out["filled_i"] = np.int64(buf.policy_buffers["policy_0"].filled_i)
+    out["current_i"] = np.int64(buf.policy_buffers["policy_0"].current_i)
+    keys = ("obs", "share_obs", "acts", "rewards", "dones", "dones_env", "avail_acts")
+    if store_inputs:
+        for k in keys:
+            out["ep/" + k] = ep[k]
+    out["ep_digest"] = np.array(digest([ep[k] for k in keys]))
+    inds = np.asarray(inds, dtype=np.int64)
+    out["inds"] = inds
+    sampled = buf.policy_buffers["policy_0"].sample_inds(inds)
+    if store_inputs:
+        for k, a in zip(("obs", "share_obs", "acts", "rewards", "dones", "dones_env", "avail_acts"), sampled):
+            out["batch/" + k] = np.ascontiguousarray(a)
+    out["batch_digest"] = np.array(digest(sampled))
+    out.update(named(policy.q_network, "agent/"))
+    if not vdn:
+        out.update(named(trainer.mixer, "mixer/"))
+    out["dims"] = np.array([dims.n_agents, dims.act_dim, dims.obs_dim, dims.state_dim, dims.episode_length], dtype=np.int64)
+    out["hp_gamma"], out["hp_lr"], out["hp_eps"] = np.float64(args.gamma), np.float64(args.lr), np.float64(args.opti_eps)
+    out["hp_huber"], out["hp_delta"] = np.int64(args.use_huber_loss), np.float64(args.huber_delta)
+    out["hp_per"], out["hp_nu"], out["hp_per_eps"] = np.int64(args.use_per), np.float64(args.per_nu), np.float64(args.per_eps)
+    out["hp_tau"], out["hp_maxnorm"], out["hp_double_q"] = np.float64(args.tau), np.float64(args.max_grad_norm), np.int64(args.use_double_q)
+    out["vdn"] = np.int64(vdn)
+    losses, gnorms, qtots, prios = [], [], [], []
+    for s in range(steps):
+        batch = tuple({"policy_0": a} for a in sampled) + (per_weights, inds if per_weights is not None else None)
+        info, new_prio, _ = trainer.train_policy_on_batch(batch)
+        if s == 0:
+            # param.grad after the in-place clip (qmix.py:192); fc_h stays None
+            for k, v in policy.q_network.named_parameters():
+                if v.grad is not None:
+                    out["grad0/agent/" + k] = v.grad.detach().numpy().copy()
+            if not vdn:
+                for k, v in trainer.mixer.named_parameters():
+                    out["grad0/mixer/" + k] = v.grad.detach().numpy().copy()
+        trainer.soft_target_updates()
+        losses.append(float(info["loss"])), gnorms.append(float(info["grad_norm"])), qtots.append(float(info["Q_tot"]))
+        if new_prio is not None:
+            prios.append(np.asarray(new_prio, dtype=np.float64))
+    out["loss"], out["grad_norm"], out["Q_tot"] = np.array(losses), np.array(gnorms), np.array(qtots)
+    if prios:
+        out["priorities"] = np.stack(prios)
+        out["per_weights"] = np.asarray(per_weights)
+    out.update(named(policy.q_network, "final_agent/"))
+    out.update(named(trainer.target_policies["policy_0"].q_network, "final_agent_tgt/"))
+    if not vdn:
+        out.update(named(trainer.mixer, "final_mixer/"))
+        out.update(named(trainer.target_mixer, "final_mixer_tgt/"))
+    path = os.path.join(GOLDEN, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("%-28s loss=%s grad_norm=%s Q_tot=%s  -> %s (%.0f KB)" % (
+        name, np.round(out["loss"], 7), np.round(out["grad_norm"], 6), np.round(out["Q_tot"], 7), path,
+        os.path.getsize(path) / 1024.0))
+    return out
+
+
+def main():
+    os.makedirs(GOLDEN, exist_ok=True)
+    tiny = DIMS["tiny"]
+    # 1. tiny dims, masked availability, MSE, ring wrap-around on insert, repeated index in the sample
+    run_case("qmix_tiny", tiny, n_episodes=5, inds=[3, 0, 5, 3], cap=6, pre_insert=4, avail="bernoulli")
+    # 2. tiny dims, Huber + PER weights + runner-style padding after the episode end
+    run_case("qmix_tiny_huber_per", tiny, n_episodes=6, inds=[1, 4, 2, 5, 0], avail="bernoulli",
+             runner_padding=True, per_weights=np.array([1.0, 0.5, 0.25, 0.8, 0.9]),
+             argv=["--use_huber_loss", "--huber_delta", "1.0", "--use_per"])
+    # 3. tiny dims, plain (non double-Q) targets
+    run_case("qmix_tiny_nodouble", tiny, n_episodes=4, inds=[0, 1, 2, 3], avail="bernoulli", argv=["--use_double_q"])
+    # 4. VDN (with the A-2 oracle patch)
+    patch_vdn()
+    run_case("vdn_tiny", tiny, n_episodes=4, inds=[2, 1, 0, 3], avail="bernoulli", vdn=True)
+    # 5. KAT-A of SURVEY.md Appendix C: 3m dims, E=B=8, inds=arange(8); inputs regenerate from RandomState(0)
+    k = run_case("qmix_3m_katA", DIMS["3m"], n_episodes=8, inds=np.arange(8), store_inputs=False)
+    assert list(k["lengths"]) == [38, 30, 46, 38, 60, 35, 37, 57], k["lengths"]
+    # 6. an odd-sized case (nothing a multiple of 4) to exercise the unaligned kernel paths
+    odd = EnvDims("odd", 3, 7, 18, 54, 5)
+    run_case("qmix_odd", odd, n_episodes=6, inds=[5, 1, 1, 2, 0, 4, 3], avail="bernoulli")
+
+
+if __name__ == "__main__":
+    main()

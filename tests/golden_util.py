@@ -1,0 +1,63 @@
+"""Helpers shared by parity tests: rebuild fixture inputs, build oracle objects from a fixture."""
+from collections import OrderedDict
+
+import numpy as np
+
+from offpolicy_amd.utils.synth import DIMS, EnvDims, synth_episodes
+
+EP_KEYS = ("obs", "share_obs", "acts", "rewards", "dones", "dones_env", "avail_acts")
+
+
+def fixture_dims(g, name="fixture"):
+    n, a, d, s, t = [int(x) for x in g["dims"]]
+    return EnvDims(name, n, a, d, s, t)
+
+
+def fixture_episodes(g):
+    """Episodes the fixture was generated from. Stored for small cases; regenerated from RandomState(0)
+    (and checked against the stored digest) for the 3m case."""
+    import hashlib
+    if "ep/obs" in g:
+        return {k: g["ep/" + k] for k in EP_KEYS}
+    dims = fixture_dims(g)
+    rng = np.random.RandomState(0)
+    ep = synth_episodes(rng, int(g["idx_range"].shape[0]), dims)
+    h = hashlib.sha256()
+    for k in EP_KEYS:
+        h.update(np.ascontiguousarray(ep[k]).tobytes())
+    assert h.hexdigest() == str(g["ep_digest"]), "regenerated synthetic episodes differ from the fixture's"
+    return ep
+
+
+def reference_store_from(g):
+    """Rebuild the reference's time-major ring arrays (rec_buffer.py:120-141) by replaying the inserts."""
+    dims = fixture_dims(g)
+    N, A, D, S, T = dims.n_agents, dims.act_dim, dims.obs_dim, dims.state_dim, dims.episode_length
+    n_pre = int(g["pre_idx_range"].shape[0]) if "pre_idx_range" in g else 0
+    cap = int(max(g["idx_range"].max(), g["pre_idx_range"].max() if n_pre else 0)) + 1
+    cap = max(cap, int(g["filled_i"]))
+    st = dict(obs=np.zeros((T + 1, cap, N, D), np.float32), share_obs=np.zeros((T + 1, cap, S), np.float32),
+              acts=np.zeros((T, cap, N, A), np.float32), avail_acts=np.ones((T + 1, cap, N, A), np.float32),
+              rewards=np.zeros((T, cap, N, 1), np.float32), dones=np.ones((T, cap, N, 1), np.float32),
+              dones_env=np.ones((T, cap, 1), np.float32))
+
+    def put(ep, idx):
+        for k in EP_KEYS:
+            v = ep[k][:, :, 0] if k == "share_obs" else ep[k]
+            st[k][:, idx] = v
+    if n_pre:
+        put({k: g["pre_ep/" + k] for k in EP_KEYS}, g["pre_idx_range"])
+    put(fixture_episodes(g), g["idx_range"])
+    return st, cap
+
+
+def oracle_from(g):
+    from oracle.qmix_oracle import QMixOracle, HP
+    from conftest import sub
+    dims = fixture_dims(g)
+    hp = HP(gamma=float(g["hp_gamma"]), lr=float(g["hp_lr"]), opti_eps=float(g["hp_eps"]),
+            use_huber_loss=bool(g["hp_huber"]), huber_delta=float(g["hp_delta"]), use_per=bool(g["hp_per"]),
+            per_nu=float(g["hp_nu"]), per_eps=float(g["hp_per_eps"]), tau=float(g["hp_tau"]),
+            max_grad_norm=float(g["hp_maxnorm"]), use_double_q=bool(g["hp_double_q"]), vdn=bool(g["vdn"]))
+    mixer = sub(g, "mixer/") if not bool(g["vdn"]) else None
+    return QMixOracle(sub(g, "agent/"), mixer, dims.n_agents, hp), dims
