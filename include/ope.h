@@ -1,0 +1,156 @@
+/*
+ * ope.h -- C ABI of the MI355X-native off-policy MARL update engine ("ope").
+ *
+ * The reference (marlbenchmark/off-policy) is 100 % Python and has no FFI/plugin layer; the
+ * drop-in boundary is the duck-typed Python surface of its replay buffers and trainers. This header declares
+ * the C-ABI that sits UNDER our mirrors of those classes: plain pointers and sizes, no torch types, one
+ * `extern "C"` shared library (libope.so, HIP/gfx950). Each entry point cites the reference code it replaces.
+ *
+ * Conventions
+ *   - every pointer is DEVICE memory unless the name ends in `_host`;
+ *   - pointers are borrowed for the duration of the call; the caller (Python/torch) owns all memory;
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream); calls only enqueue work on it;
+ *   - return value: 0 on success, negative OPE_E* on error; nothing throws, nothing allocates;
+ *   - all data is float32 (the reference's buffers are np.float32, rec_buffer.py:120-141), indices int64/int32.
+ */
+#ifndef OPE_H_
+#define OPE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OPE_VERSION 1
+
+#define OPE_OK 0
+#define OPE_EINVAL (-1)  /* bad argument / unsupported dimension                      */
+#define OPE_ELAUNCH (-2) /* kernel launch failed (hipGetLastError != hipSuccess)     */
+#define OPE_ENOSPC (-3)  /* caller-provided workspace too small                       */
+
+int ope_version(void);
+const char* ope_strerror(int code);
+
+/* ------------------------------------------------------------------------------------------------
+ * Episode dimensions (one policy): N agents, A actions (one-hot width), D obs, S centralized state, T steps.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ope_dims {
+  int32_t n_agents;       /* N */
+  int32_t act_dim;        /* A */
+  int32_t obs_dim;        /* D */
+  int32_t state_dim;      /* S */
+  int32_t episode_length; /* T */
+} ope_dims;
+
+/* Seven per-episode fields, in the order of RecPolicyBuffer.sample_inds' return tuple
+ * (offpolicy/utils/rec_buffer.py:192-240): obs, share_obs, acts, rewards, dones, dones_env, avail_acts. */
+typedef struct ope_fields {
+  float* obs;        /* [.., T+1, N, D]                                    */
+  float* share_obs;  /* [.., T+1, S]      (use_same_share_obs)             */
+  float* acts;       /* [.., T,   N, A]   one-hot float32                  */
+  float* rewards;    /* [.., T,   N, 1]                                    */
+  float* dones;      /* [.., T,   N, 1]                                    */
+  float* dones_env;  /* [.., T,   1]                                       */
+  float* avail_acts; /* [.., T+1, N, A]                                    */
+} ope_fields;
+
+/* ------------------------------------------------------------------------------------------------
+ * Replay store: device-resident, EPISODE-major rings  store.f[e][t][agent][dim]  (the reference keeps
+ * time-major numpy rings [T(+1), cap, N, dim], rec_buffer.py:120-141; sampling is by episode, so the device
+ * layout makes every sampled episode one contiguous run per field).
+ *
+ * ope_store_insert  replaces RecPolicyBuffer.insert's ring write (rec_buffer.py:167-185).
+ *   `staged` holds `n_insert` episodes already on the device in the layout insert() receives
+ *   ([T(+1), n_insert, N, dim]; share_obs with the agent axis already dropped: [T+1, n_insert, S]);
+ *   `slots[n_insert]` (device int64) are the ring slots (idx_range) computed by the host.
+ * ope_store_gather  replaces RecPolicyBuffer.sample_inds' fancy-index + transpose (rec_buffer.py:206-238):
+ *   out.f is written as [T(+1), N, B, dim] (agent-indexed fields) / [T(+1), B, dim] (share_obs, dones_env),
+ *   i.e. exactly the memory the reference's `[N, T(+1), B, dim]` transpose-VIEW aliases, and at the same
+ *   time the row-stacked `[T(+1), N*B, dim]` tensor QMix.train_policy_on_batch builds with torch.cat
+ *   (qmix.py:108-109). Bit-exact copy; indices may repeat.
+ * ---------------------------------------------------------------------------------------------- */
+int ope_store_insert(const ope_dims* dims, int32_t capacity, const ope_fields* store, const ope_fields* staged,
+                     const int64_t* slots, int32_t n_insert, void* stream);
+int ope_store_gather(const ope_dims* dims, int32_t capacity, const ope_fields* store, const int64_t* inds,
+                     int32_t batch, const ope_fields* out, void* stream);
+/* Bytes of one episode over all seven fields (SURVEY.md section 8(d) "episode bytes"). */
+int64_t ope_episode_bytes(const ope_dims* dims);
+
+/* ------------------------------------------------------------------------------------------------
+ * Recurrent QMIX / VDN trainer  (QMix.train_policy_on_batch, offpolicy/algorithms/qmix/qmix.py:77-200).
+ * Networks are the reference defaults: hidden 64, layer_N 1, feature-norm, 1-layer
+ * GRU, hypernet_layers 2, mixer hidden 32, hypernet hidden 64. Anything else returns OPE_EINVAL.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ope_qmix_cfg {
+  ope_dims dims;
+  int32_t batch;        /* B: episodes in this (local) batch                                   */
+  int32_t vdn;          /* 1: VDN mixing (sum over agents, SURVEY A-2 fix) -- no mixer params  */
+  int32_t use_double_q; /* args.use_double_q (config.py:144), default 1                         */
+  int32_t use_huber;    /* args.use_huber_loss (config.py:120), default 0                       */
+  int32_t use_per;      /* importance weights + priorities (qmix.py:168-181)                    */
+  float gamma;          /* 0.99 */
+  float huber_delta;    /* 10.0 */
+  float per_nu;         /* 0.9  */
+  float per_eps;        /* 1e-6 */
+} ope_qmix_cfg;
+
+/* Flat parameter vector: the reference's named_parameters() order (agent q-network, then mixer; qmix.py:67-72),
+ * every tensor padded to a multiple of 4 floats so rows can be read as float4. The gradient vector has the
+ * same layout followed by OPE_GRAD_TAIL floats: [loss_sum, mask_count, qtot_sum, 0].                        */
+#define OPE_QMIX_NPARAM_AGENT 22
+#define OPE_QMIX_NPARAM_MIXER 14
+#define OPE_GRAD_TAIL 4
+/* Fills offsets[i]/sizes[i] (floats) for the 22 (+14 unless vdn) tensors; returns the padded total length. */
+int64_t ope_qmix_param_layout(const ope_qmix_cfg* cfg, int64_t* offsets, int64_t* sizes);
+/* Workspace (bytes) ope_qmix_loss_and_grad needs. */
+int64_t ope_qmix_workspace_bytes(const ope_qmix_cfg* cfg);
+/* Named sub-buffers of the workspace, for tests/debugging: returns byte offset, writes element count. -1 if unknown. */
+int64_t ope_qmix_workspace_find(const ope_qmix_cfg* cfg, const char* name, int64_t* n_floats);
+
+/* Forward + backward of one batch (qmix.py:86-190 minus the optimizer):
+ *   batch    -- ope_store_gather output layout
+ *   theta / theta_tgt -- live / target flat parameters (read only)
+ *   per_weights[B] -- importance weights or NULL
+ *   grad     -- OUT flat gradient of the UN-normalised loss sum (divide by mask_count = grad[P+1]; done in
+ *               ope_adam_step so that data-parallel ranks can all-reduce `grad` first) + the 4-float tail
+ *   td_abs_stats[2*B] -- OUT per-episode [mean_t |err|, max_t |err|] (for priorities), or NULL
+ * All intermediates live in `workspace`. */
+int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields* batch, const float* theta,
+                           const float* theta_tgt, const float* per_weights, void* workspace,
+                           int64_t workspace_bytes, float* grad, float* td_abs_stats, void* stream);
+
+/* Forward only of the agent q-network on [L, R, D] observations with initial hidden h0 [R, 64] (NULL = zeros)
+ * (AgentQFunction.forward, agent_q_function.py:34-67): q_out [L, R, A], h_out [L, R, 64] (un-normalised GRU
+ * states; h_out[L-1] is h_final). Used by policy.get_actions / get_q_values. */
+int64_t ope_agent_forward_workspace_bytes(const ope_dims* dims, int32_t seq_len, int32_t rows);
+int ope_agent_forward(const ope_dims* dims, int32_t seq_len, int32_t rows, const float* obs, const float* h0,
+                      const float* theta, void* workspace, int64_t workspace_bytes, float* q_out, float* h_out,
+                      void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimizer: clip_grad_norm_ + Adam + (optional) Polyak target update over the flat vectors
+ * (qmix.py:190-193, torch.optim.Adam(lr, eps=opti_eps) qmix.py:71-72, soft_update util.py:123-134).
+ *   g = grad * (1/grad[n+1]);  norm = ||g||_2;  g *= min(1, max_norm/(norm+1e-6));  Adam(g);  tgt = (1-tau) tgt + tau theta
+ *   stats_out[4] = [loss, grad_norm (pre-clip), Q_tot mean, mask_count]   with loss = grad[n]/grad[n+1],
+ *   Q_tot = grad[n+2]/qtot_denominator.
+ * `scratch` must hold ope_adam_scratch_floats(n) floats.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ope_adam_cfg {
+  float lr, beta1, beta2, eps, max_grad_norm, weight_decay;
+  float tau;              /* Polyak factor; used only if do_polyak                        */
+  int32_t do_polyak;      /* fuse soft_target_updates() into this call                    */
+  int32_t step;           /* 1-based Adam step count (bias correction)                    */
+  float qtot_denominator; /* T*B_global: Q_tot is a mean over ALL steps (qmix.py:198)     */
+} ope_adam_cfg;
+int64_t ope_adam_scratch_floats(int64_t n);
+int ope_adam_step(const ope_adam_cfg* cfg, int64_t n, float* theta, float* theta_tgt, float* adam_m, float* adam_v,
+                  const float* grad, float* scratch, float* stats_out, void* stream);
+/* soft_update (util.py:123-134) / hard_update (util.py:137-145) on flat vectors. tau=1 is a hard copy. */
+int ope_polyak(int64_t n, const float* theta, float* theta_tgt, float tau, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OPE_H_ */

@@ -1,0 +1,92 @@
+"""ctypes binding of libope.so (the C-ABI in include/ope.h).
+
+The library is the ONLY implementation of the update path: if it is missing or does not load, importing this
+module raises -- there is no eager-PyTorch or CPU fallback.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libope.so")
+
+OPE_QMIX_NPARAM_AGENT = 22
+OPE_QMIX_NPARAM_MIXER = 14
+OPE_GRAD_TAIL = 4
+
+
+class OpeError(RuntimeError):
+    pass
+
+
+class Dims(C.Structure):
+    _fields_ = [("n_agents", C.c_int32), ("act_dim", C.c_int32), ("obs_dim", C.c_int32), ("state_dim", C.c_int32),
+                ("episode_length", C.c_int32)]
+
+
+class Fields(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("obs", "share_obs", "acts", "rewards", "dones", "dones_env", "avail_acts")]
+
+
+class QmixCfg(C.Structure):
+    _fields_ = [("dims", Dims), ("batch", C.c_int32), ("vdn", C.c_int32), ("use_double_q", C.c_int32),
+                ("use_huber", C.c_int32), ("use_per", C.c_int32), ("gamma", C.c_float), ("huber_delta", C.c_float),
+                ("per_nu", C.c_float), ("per_eps", C.c_float)]
+
+
+class AdamCfg(C.Structure):
+    _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("max_grad_norm", C.c_float), ("weight_decay", C.c_float), ("tau", C.c_float),
+                ("do_polyak", C.c_int32), ("step", C.c_int32), ("qtot_denominator", C.c_float)]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise OpeError("libope.so not found at %s -- build it with `python -m offpolicy_amd.build` "
+                       "(hipcc --offload-arch=gfx950). There is no fallback path." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    p = C.c_void_p
+    i32, i64 = C.c_int32, C.c_int64
+    sig = {
+        "ope_version": (C.c_int, []),
+        "ope_strerror": (C.c_char_p, [C.c_int]),
+        "ope_set_debug": (None, [C.c_int]),
+        "ope_episode_bytes": (i64, [C.POINTER(Dims)]),
+        "ope_store_insert": (C.c_int, [C.POINTER(Dims), i32, C.POINTER(Fields), C.POINTER(Fields), p, i32, p]),
+        "ope_store_gather": (C.c_int, [C.POINTER(Dims), i32, C.POINTER(Fields), p, i32, C.POINTER(Fields), p]),
+        "ope_qmix_param_layout": (i64, [C.POINTER(QmixCfg), C.POINTER(i64), C.POINTER(i64)]),
+        "ope_qmix_workspace_bytes": (i64, [C.POINTER(QmixCfg)]),
+        "ope_qmix_workspace_find": (i64, [C.POINTER(QmixCfg), C.c_char_p, C.POINTER(i64)]),
+        "ope_qmix_loss_and_grad": (C.c_int, [C.POINTER(QmixCfg), C.POINTER(Fields), p, p, p, p, i64, p, p, p]),
+        "ope_agent_forward_workspace_bytes": (i64, [C.POINTER(Dims), i32, i32]),
+        "ope_agent_forward": (C.c_int, [C.POINTER(Dims), i32, i32, p, p, p, p, i64, p, p, p]),
+        "ope_adam_scratch_floats": (i64, [i64]),
+        "ope_adam_step": (C.c_int, [C.POINTER(AdamCfg), i64, p, p, p, p, p, p, p, p]),
+        "ope_polyak": (C.c_int, [i64, p, p, C.c_float, p]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)  # AttributeError here = a symbol declared in include/ope.h is missing
+        fn.restype = res
+        fn.argtypes = args
+    return lib, sorted(sig)
+
+
+lib, EXPORTS = _load()
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise OpeError("%s failed: %s (%d)" % (what or "ope call", lib.ope_strerror(int(rc)).decode(), rc))
+
+
+def current_stream():
+    """hipStream_t of torch's current stream as an integer handle."""
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device (or host) pointer of a contiguous torch tensor, or NULL for None."""
+    if t is None:
+        return C.c_void_p(0)
+    assert t.is_contiguous(), "ope kernels need contiguous tensors"
+    return C.c_void_p(t.data_ptr())

@@ -1,0 +1,116 @@
+"""QMIX / VDN policy: per-agent recurrent Q network + epsilon-greedy action selection.
+
+Mirror of offpolicy/algorithms/qmix/algorithm/QMixPolicy.py:9-206. Q values come from the HIP forward
+(`AgentQFunction.forward` -> `ope_agent_forward`); the epsilon-greedy bookkeeping around them is host logic in the
+same order of RNG draws as the reference (QMixPolicy.py:156-166).
+"""
+import numpy as np
+import torch
+from torch.distributions import Categorical, OneHotCategorical
+
+from ....utils.spaces import get_dim_from_space
+from ....config import require_reference_architecture
+from .agent_q_function import AgentQFunction
+
+
+class DecayThenFlatSchedule(object):
+    """Linear / exponential epsilon schedule (offpolicy/utils/util.py:78-100)."""
+
+    def __init__(self, start, finish, time_length, decay="exp"):
+        self.start, self.finish, self.time_length, self.decay = start, finish, time_length, decay
+        self.delta = (self.start - self.finish) / self.time_length
+        if self.decay == "exp":
+            self.exp_scaling = (-1) * self.time_length / np.log(self.finish) if self.finish > 0 else 1
+
+    def eval(self, T):
+        if self.decay == "linear":
+            return max(self.finish, self.start - self.delta * T)
+        return min(self.start, max(self.finish, np.exp(-T / self.exp_scaling)))
+
+
+def _onehot(idx, dim):
+    idx = np.asarray(idx.detach().cpu() if torch.is_tensor(idx) else idx)
+    return np.eye(dim)[idx]
+
+
+class QMixPolicy(object):
+    def __init__(self, config, policy_config, train=True):
+        self.args = config["args"]
+        self.device = torch.device(config["device"])
+        require_reference_architecture(self.args)
+        self.obs_space = policy_config["obs_space"]
+        self.obs_dim = get_dim_from_space(self.obs_space)
+        self.act_space = policy_config["act_space"]
+        self.act_dim = get_dim_from_space(self.act_space)
+        self.output_dim = self.act_dim
+        self.hidden_size = self.args.hidden_size
+        self.central_obs_dim = policy_config["cent_obs_dim"]
+        self.discrete = True
+        self.multidiscrete = False
+        self.q_network_input_dim = self.obs_dim
+        self.q_network = AgentQFunction(self.args, self.q_network_input_dim, self.act_dim, self.device)
+        if train:
+            self.exploration = DecayThenFlatSchedule(self.args.epsilon_start, self.args.epsilon_finish,
+                                                     self.args.epsilon_anneal_time, decay="linear")
+
+    # -- q values --------------------------------------------------------------------------------------------
+    def get_q_values(self, obs_batch, prev_action_batch, rnn_states, action_batch=None):
+        q_batch, new_rnn_states = self.q_network(obs_batch, rnn_states)
+        if action_batch is not None:
+            action_batch = torch.as_tensor(action_batch).to(self.device)
+            return self.q_values_from_actions(q_batch, action_batch), new_rnn_states
+        return q_batch, new_rnn_states
+
+    def q_values_from_actions(self, q_batch, action_batch):
+        idx = torch.as_tensor(action_batch, device=q_batch.device).max(dim=-1)[1]
+        return torch.gather(q_batch, q_batch.dim() - 1, idx.unsqueeze(dim=-1))
+
+    # -- actions ---------------------------------------------------------------------------------------------
+    def get_actions(self, obs, prev_actions, rnn_states, available_actions=None, t_env=None, explore=False):
+        q_values_out, new_rnn_states = self.get_q_values(obs, prev_actions, rnn_states)
+        onehot_actions, greedy_Qs = self.actions_from_q(q_values_out, available_actions=available_actions,
+                                                        explore=explore, t_env=t_env)
+        return onehot_actions, new_rnn_states, greedy_Qs
+
+    def actions_from_q(self, q_values, available_actions=None, explore=False, t_env=None):
+        no_sequence = q_values.dim() == 2
+        batch_size = q_values.shape[0] if no_sequence else q_values.shape[1]
+        if available_actions is not None:
+            q_values = q_values.clone()
+            avail = torch.as_tensor(np.asarray(available_actions) if not torch.is_tensor(available_actions) else available_actions,
+                                    device=q_values.device)
+            q_values[avail == 0] = -1e10
+        greedy_Qs, greedy_actions = q_values.max(dim=-1)
+        if explore:
+            assert no_sequence, "Can only explore on non-sequences"
+            eps = self.exploration.eval(t_env)
+            rand_numbers = np.random.rand(batch_size)
+            logits = torch.ones(batch_size, self.act_dim)
+            if available_actions is not None:
+                logits[torch.as_tensor(np.asarray(available_actions.cpu() if torch.is_tensor(available_actions) else available_actions)) == 0] = -1e10
+            random_actions = Categorical(logits=logits).sample().numpy()
+            take_random = (rand_numbers < eps).astype(int)
+            actions = (1 - take_random) * greedy_actions.detach().cpu().numpy() + take_random * random_actions
+            onehot_actions = np.eye(self.act_dim)[actions]
+        else:
+            greedy_Qs = greedy_Qs.unsqueeze(-1)
+            onehot_actions = _onehot(greedy_actions, self.act_dim)
+        return onehot_actions, greedy_Qs
+
+    def get_random_actions(self, obs, available_actions=None):
+        batch_size = obs.shape[0]
+        logits = torch.ones(batch_size, self.act_dim)
+        if available_actions is not None:
+            logits[torch.as_tensor(np.asarray(available_actions)) == 0] = -1e10
+        return OneHotCategorical(logits=logits).sample().numpy()
+
+    def init_hidden(self, num_agents, batch_size):
+        if num_agents == -1:
+            return torch.zeros(batch_size, self.hidden_size)
+        return torch.zeros(num_agents, batch_size, self.hidden_size)
+
+    def parameters(self):
+        return self.q_network.parameters()
+
+    def load_state(self, source_policy):
+        self.q_network.load_state_dict(source_policy.q_network.state_dict())

@@ -1,0 +1,126 @@
+"""Per-agent recurrent Q network: parameter container + forward through the HIP kernels.
+
+Mirror of offpolicy/algorithms/qmix/algorithm/agent_q_function.py:8-67 (AgentQFunction) together with the bodies
+it composes (algorithms/utils/{mlp,rnn,act}.py). Same `named_parameters()`, same
+initialisation procedure and RNG consumption order as the reference's constructors, so `torch.manual_seed(s)`
+followed by construction yields the reference's initial weights. The arithmetic is `ope_agent_forward`.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .... import _lib
+from ....flat_module import FlatModule
+
+H = 64
+
+AGENT_PARAM_NAMES = [
+    "rnn.feature_norm.weight", "rnn.feature_norm.bias",
+    "rnn.mlp.fc1.0.weight", "rnn.mlp.fc1.0.bias", "rnn.mlp.fc1.2.weight", "rnn.mlp.fc1.2.bias",
+    "rnn.mlp.fc_h.0.weight", "rnn.mlp.fc_h.0.bias", "rnn.mlp.fc_h.2.weight", "rnn.mlp.fc_h.2.bias",
+    "rnn.mlp.fc2.0.0.weight", "rnn.mlp.fc2.0.0.bias", "rnn.mlp.fc2.0.2.weight", "rnn.mlp.fc2.0.2.bias",
+    "rnn.rnn.rnn.weight_ih_l0", "rnn.rnn.rnn.weight_hh_l0", "rnn.rnn.rnn.bias_ih_l0", "rnn.rnn.rnn.bias_hh_l0",
+    "rnn.rnn.norm.weight", "rnn.rnn.norm.bias",
+    "q.action_out.weight", "q.action_out.bias",
+]
+
+
+def agent_param_shapes(obs_dim, act_dim):
+    D, A = obs_dim, act_dim
+    return [(D,), (D,), (H, D), (H,), (H,), (H,), (H, H), (H,), (H,), (H,), (H, H), (H,), (H,), (H,),
+            (3 * H, H), (3 * H, H), (3 * H,), (3 * H,), (H,), (H,), (A, H), (A,)]
+
+
+def agent_layout(obs_dim, act_dim):
+    """(offsets, sizes, padded_total) of the agent block, from the library (single source of truth)."""
+    cfg = _lib.QmixCfg()
+    cfg.dims = _lib.Dims(1, act_dim, obs_dim, 1, 1)
+    cfg.batch = 1
+    cfg.vdn = 1
+    off = (C.c_int64 * 36)()
+    siz = (C.c_int64 * 36)()
+    total = _lib.lib.ope_qmix_param_layout(C.byref(cfg), off, siz)
+    if total < 0:
+        _lib.check(int(total), "ope_qmix_param_layout")
+    return list(off)[:22], list(siz)[:22], int(total)
+
+
+def init_agent_values(obs_dim, act_dim, use_orthogonal=True, gain_out=0.01, use_ReLU=True):
+    """Initial values in named_parameters() order, drawn exactly as the reference's constructors draw them:
+    nn.Linear default init then orthogonal_/xavier_uniform_ re-init (mlp.py:12-23, util.py:113-116), nn.GRU default
+    init then per-parameter re-init (rnn.py:8-16), head with gain=args.gain (act.py:10-12). Biases 0, LayerNorms 1/0."""
+    init_w = nn.init.orthogonal_ if use_orthogonal else nn.init.xavier_uniform_
+    gain = nn.init.calculate_gain("relu" if use_ReLU else "tanh")
+    fc1 = nn.Linear(obs_dim, H)
+    init_w(fc1.weight.data, gain=gain)
+    fch = nn.Linear(H, H)
+    init_w(fch.weight.data, gain=gain)
+    gru = nn.GRU(H, H, num_layers=1)
+    for name, p in gru.named_parameters():
+        if "bias" in name:
+            nn.init.constant_(p, 0)
+        elif "weight" in name:
+            init_w(p)
+    qo = nn.Linear(H, act_dim)
+    init_w(qo.weight.data, gain=gain_out)
+    one, zero = torch.ones, torch.zeros
+    vals = [one(obs_dim), zero(obs_dim), fc1.weight.data, zero(H), one(H), zero(H),
+            fch.weight.data, zero(H), one(H), zero(H),                       # fc_h (registered, unused)
+            fch.weight.data.clone(), zero(H), one(H), zero(H),               # fc2[0] = deepcopy(fc_h) (mlp.py:23)
+            gru.weight_ih_l0.data, gru.weight_hh_l0.data, zero(3 * H), zero(3 * H), one(H), zero(H),
+            qo.weight.data, zero(act_dim)]
+    return [v.detach().float() for v in vals]
+
+
+class AgentQFunction(FlatModule):
+    def __init__(self, args, input_dim, act_dim, device, flat=None, _init=True):
+        input_dim, act_dim, device = int(input_dim), int(act_dim), torch.device(device)
+        offs, sizes, total = agent_layout(input_dim, act_dim)
+        own = flat is None
+        if own:
+            flat = torch.zeros(total, dtype=torch.float32, device=device)
+        super().__init__(AGENT_PARAM_NAMES, agent_param_shapes(input_dim, act_dim), offs, flat)
+        self.input_dim, self.act_dim, self.hidden_size, self.device = input_dim, act_dim, H, device
+        self.padded_numel = total
+        self._args = args
+        if own and _init:
+            vals = init_agent_values(input_dim, act_dim, getattr(args, "use_orthogonal", True),
+                                     getattr(args, "gain", 0.01), getattr(args, "use_ReLU", True))
+            for p, v in zip(self.parameters(), vals):
+                p.data.copy_(v)
+        self._dims = _lib.Dims(1, act_dim, input_dim, 1, 1)
+        self._ws = None
+
+    def twin(self, flat):
+        """Same structure bound to another flat vector (used for target networks)."""
+        return AgentQFunction(self._args, self.input_dim, self.act_dim, self.device, flat=flat, _init=False)
+
+    def forward(self, obs, rnn_states):
+        """q values for every action and the new hidden state (agent_q_function.py:34-67).
+        obs [L, R, D] or [R, D]; rnn_states [R, H] (or [1, R, H]). Returns (q [L,R,A] or [R,A], h_final [R,H])."""
+        obs = torch.as_tensor(obs, dtype=torch.float32, device=self.device)
+        rnn_states = torch.as_tensor(rnn_states, dtype=torch.float32, device=self.device)
+        no_sequence = obs.dim() == 2
+        if no_sequence:
+            obs = obs[None]
+        if rnn_states.dim() == 3:
+            rnn_states = rnn_states[0]
+        L, R = int(obs.shape[0]), int(obs.shape[1])
+        obs = obs.contiguous()
+        h0 = rnn_states.contiguous()
+        need = _lib.lib.ope_agent_forward_workspace_bytes(C.byref(self._dims), L, R)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+        q = torch.empty((L, R, self.act_dim), dtype=torch.float32, device=self.device)
+        h = torch.empty((L, R, H), dtype=torch.float32, device=self.device)
+        flat = self._flat
+        _lib.check(_lib.lib.ope_agent_forward(C.byref(self._dims), L, R, _lib.ptr(obs), _lib.ptr(h0), _lib.ptr(flat),
+                                              _lib.ptr(self._ws), self._ws.numel(), _lib.ptr(q), _lib.ptr(h),
+                                              _lib.current_stream()), "ope_agent_forward")
+        h_final = h[-1]
+        return (q[0] if no_sequence else q), h_final
+
+    __call__ = forward

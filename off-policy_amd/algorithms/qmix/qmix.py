@@ -1,0 +1,247 @@
+"""Recurrent QMIX / VDN trainer on the HIP engine.
+
+Mirror of offpolicy/algorithms/qmix/qmix.py:10-232 (`QMix`): same constructor, `train_policy_on_batch`,
+`soft_target_updates`, `hard_target_updates`, `prep_training`, `prep_rollout`, same `train_info` keys. All
+arithmetic of `train_policy_on_batch` (qmix.py:77-200) is two C-ABI calls:
+
+    ope_qmix_loss_and_grad   forward of live+target nets, mixer, TD loss, full backward -> flat gradient
+    ope_adam_step            clip_grad_norm_ + Adam (+ optional fused Polyak)
+
+Live parameters, target parameters, Adam moments and gradients are flat CUDA vectors; `policy.q_network`,
+`trainer.mixer` and their target twins are nn.Module views onto them (FlatModule), so checkpointing and rollout
+see the same memory the kernels update. With torch.distributed initialised (one process per GPU) the flat
+gradient is summed across ranks with ONE all-reduce between the two calls (off-policy_amd/dist.py).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from ... import _lib
+from ... import dist as opdist
+from ...config import require_reference_architecture
+from .algorithm.q_mixer import QMixer, VDNMixer
+
+
+class FlatAdam(object):
+    """Adam state over the trainer's flat parameter vector (torch.optim.Adam(lr, eps), qmix.py:71-72)."""
+
+    def __init__(self, numel, lr, eps, device, betas=(0.9, 0.999), weight_decay=0.0):
+        self.lr, self.eps, self.betas, self.weight_decay = lr, eps, betas, weight_decay
+        self.exp_avg = torch.zeros(numel, dtype=torch.float32, device=device)
+        self.exp_avg_sq = torch.zeros(numel, dtype=torch.float32, device=device)
+        self.step_count = 0
+
+    def zero_grad(self):
+        pass
+
+    def state_dict(self):
+        return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
+                "lr": self.lr, "eps": self.eps, "betas": self.betas, "weight_decay": self.weight_decay}
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"])
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+
+
+class QMix(object):
+    def __init__(self, args, num_agents, policies, policy_mapping_fn, device=torch.device("cuda:0"), episode_length=None,
+                 vdn=False):
+        self.args = args
+        require_reference_architecture(args)
+        self.use_popart = getattr(args, "use_popart", False)
+        self.use_value_active_masks = getattr(args, "use_value_active_masks", False)
+        self.use_per = args.use_per
+        self.per_eps = args.per_eps
+        self.use_huber_loss = args.use_huber_loss
+        self.huber_delta = args.huber_delta
+        self.device = torch.device(device)
+        self.tpdv = dict(dtype=torch.float32, device=self.device)
+        self.lr, self.tau, self.opti_eps, self.weight_decay = args.lr, args.tau, args.opti_eps, args.weight_decay
+        self.episode_length = args.episode_length if episode_length is None else episode_length
+        self.num_agents = num_agents
+        self.policies = policies
+        self.policy_mapping_fn = policy_mapping_fn
+        self.policy_ids = sorted(list(self.policies.keys()))
+        self.policy_agents = {pid: sorted([a for a in range(num_agents) if policy_mapping_fn(a) == pid])
+                              for pid in self.policies.keys()}
+        if self.policy_ids != ["policy_0"] or len(self.policy_agents["policy_0"]) != num_agents:
+            raise NotImplementedError("the accelerated QMIX path handles one shared policy ('policy_0') for all agents")
+        self.use_same_share_obs = args.use_same_share_obs
+        if not self.use_same_share_obs:
+            raise NotImplementedError("use_same_share_obs=False is not on the accelerated path")
+        self.vdn = bool(vdn)
+        policy = self.policies["policy_0"]
+        self._dims = _lib.Dims(num_agents, policy.act_dim, policy.obs_dim, policy.central_obs_dim, self.episode_length)
+
+        # ---- flat vectors: [agent | mixer], padded per tensor to 4 floats -------------------------------
+        cfg = self._cfg(1)
+        off = (C.c_int64 * 36)()
+        siz = (C.c_int64 * 36)()
+        P = _lib.lib.ope_qmix_param_layout(C.byref(cfg), off, siz)
+        if P < 0:
+            _lib.check(int(P), "ope_qmix_param_layout")
+        self.numel = int(P)
+        self.theta = torch.zeros(self.numel, **self.tpdv)
+        agent_numel = policy.q_network.padded_numel
+        self.theta[:agent_numel].copy_(policy.q_network._flat[:agent_numel])
+        policy.q_network.rebind(self.theta)            # live weights now live inside the trainer's flat vector
+        if self.vdn:
+            self.mixer = VDNMixer(args, num_agents, policy.central_obs_dim, self.device)
+        else:
+            self.mixer = QMixer(args, num_agents, policy.central_obs_dim, self.device, self.theta,
+                                list(off)[_lib.OPE_QMIX_NPARAM_AGENT:_lib.OPE_QMIX_NPARAM_AGENT + _lib.OPE_QMIX_NPARAM_MIXER])
+        # target networks: deep copies at construction (qmix.py:63-64)
+        self.theta_tgt = self.theta.clone()
+        self.target_policies = {"policy_0": _TargetPolicy(policy, policy.q_network.twin(self.theta_tgt))}
+        if self.vdn:
+            self.target_mixer = VDNMixer(args, num_agents, policy.central_obs_dim, self.device)
+        else:
+            self.target_mixer = QMixer(args, num_agents, policy.central_obs_dim, self.device, self.theta_tgt,
+                                       list(off)[_lib.OPE_QMIX_NPARAM_AGENT:_lib.OPE_QMIX_NPARAM_AGENT + _lib.OPE_QMIX_NPARAM_MIXER],
+                                       init=False)
+        self.parameters = list(policy.parameters()) + list(self.mixer.parameters())
+        self.optimizer = FlatAdam(self.numel, self.lr, self.opti_eps, self.device)
+        self.grad = torch.zeros(self.numel + _lib.OPE_GRAD_TAIL, **self.tpdv)
+        self._scratch = torch.zeros(int(_lib.lib.ope_adam_scratch_floats(self.numel)), **self.tpdv)
+        self._stats = torch.zeros(4, **self.tpdv)
+        self._ws = {}
+        self.fuse_soft_update = False       # True: Polyak inside ope_adam_step; soft_target_updates() then skips once
+        self._polyak_done = False
+        if args.use_double_q:
+            print("double Q learning will be used")
+
+    # ---- helpers --------------------------------------------------------------------------------------------
+    def _cfg(self, batch):
+        a = self.args
+        cfg = _lib.QmixCfg()
+        cfg.dims = self._dims
+        cfg.batch = int(batch)
+        cfg.vdn = int(self.vdn)
+        cfg.use_double_q = int(bool(a.use_double_q))
+        cfg.use_huber = int(bool(a.use_huber_loss))
+        cfg.use_per = int(bool(a.use_per))
+        cfg.gamma, cfg.huber_delta = float(a.gamma), float(a.huber_delta)
+        cfg.per_nu, cfg.per_eps = float(a.per_nu), float(a.per_eps)
+        return cfg
+
+    def _workspace(self, cfg):
+        B = cfg.batch
+        if B not in self._ws:
+            need = _lib.lib.ope_qmix_workspace_bytes(C.byref(cfg))
+            if need < 0:
+                _lib.check(int(need), "ope_qmix_workspace_bytes")
+            self._ws[B] = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+        return self._ws[B]
+
+    def workspace_view(self, batch, name):
+        """Debug/test access to a named intermediate of the last step with this batch size (float32 view)."""
+        cfg = self._cfg(batch)
+        n = C.c_int64(0)
+        off = _lib.lib.ope_qmix_workspace_find(C.byref(cfg), name.encode(), C.byref(n))
+        if off < 0:
+            raise KeyError(name)
+        return self._ws[batch][off:off + 4 * n.value].view(torch.float32)
+
+    def _to_device_layout(self, x, agent_axis):
+        """Bring one batch field to the kernels' layout: [T(+1), N, B, dim] (agent fields) or [T(+1), B, dim]."""
+        if x is None:
+            return None
+        if torch.is_tensor(x):
+            t = x.to(self.device, dtype=torch.float32)
+            if agent_axis:
+                t = t.permute(1, 0, 2, 3)
+            return t if t.is_contiguous() else t.contiguous()
+        a = np.asarray(x, dtype=np.float32)
+        if agent_axis:
+            a = a.transpose(1, 0, 2, 3)
+        return torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+
+    # ---- the training step ------------------------------------------------------------------------------------
+    def train_policy_on_batch(self, batch, update_policy_id=None):
+        """See offpolicy/algorithms/qmix/qmix.py:77-200. `batch` is the 9-tuple from `buffer.sample()` (CUDA tensors
+        from our buffer, or numpy arrays from the reference's). Returns (train_info, new_priorities, idxes)."""
+        obs_b, cent_b, act_b, rew_b, dones_b, dones_env_b, avail_b, importance_weights, idxes = batch
+        pid = self.policy_ids[0]
+        obs = self._to_device_layout(obs_b[pid], True)
+        share = self._to_device_layout(cent_b[pid], False)
+        acts = self._to_device_layout(act_b[pid], True)
+        rew = self._to_device_layout(rew_b[pid], True)
+        dones_env = self._to_device_layout(dones_env_b[pid], False)
+        avail = self._to_device_layout(avail_b[pid], True) if (avail_b is not None and avail_b[pid] is not None) else None
+        T1, N, B, D = obs.shape
+        assert T1 == self.episode_length + 1 and N == self.num_agents, "batch does not match the trainer's dimensions"
+        cfg = self._cfg(B)
+        ws = self._workspace(cfg)
+        f = _lib.Fields()
+        f.obs, f.share_obs, f.acts, f.rewards = _lib.ptr(obs).value, _lib.ptr(share).value, _lib.ptr(acts).value, _lib.ptr(rew).value
+        f.dones, f.dones_env, f.avail_acts = None, _lib.ptr(dones_env).value, _lib.ptr(avail).value
+        w = None
+        td_stats = None
+        if self.use_per:
+            w = torch.as_tensor(np.asarray(importance_weights), dtype=torch.float32).to(self.device).contiguous()
+            td_stats = torch.empty(2 * B, **self.tpdv)
+        st = _lib.current_stream()
+        _lib.check(_lib.lib.ope_qmix_loss_and_grad(C.byref(cfg), C.byref(f), _lib.ptr(self.theta), _lib.ptr(self.theta_tgt),
+                                                   _lib.ptr(w), _lib.ptr(ws), ws.numel(), _lib.ptr(self.grad),
+                                                   _lib.ptr(td_stats), st), "ope_qmix_loss_and_grad")
+        _, world_size = opdist.world()
+        opdist.allreduce_flat_(self.grad)           # no-op on one GPU; ONE collective otherwise
+        self.optimizer.step_count += 1
+        ac = _lib.AdamCfg()
+        ac.lr, ac.beta1, ac.beta2, ac.eps = self.lr, self.optimizer.betas[0], self.optimizer.betas[1], self.opti_eps
+        ac.max_grad_norm, ac.weight_decay = float(self.args.max_grad_norm), 0.0   # QMix's Adam ignores weight_decay (A-8)
+        ac.tau, ac.do_polyak = float(self.tau), int(self.fuse_soft_update)
+        ac.step = self.optimizer.step_count
+        ac.qtot_denominator = float(self.episode_length * B * world_size)
+        stats = torch.empty(4, **self.tpdv)
+        _lib.check(_lib.lib.ope_adam_step(C.byref(ac), self.numel, _lib.ptr(self.theta), _lib.ptr(self.theta_tgt),
+                                          _lib.ptr(self.optimizer.exp_avg), _lib.ptr(self.optimizer.exp_avg_sq),
+                                          _lib.ptr(self.grad), _lib.ptr(self._scratch), _lib.ptr(stats), st), "ope_adam_step")
+        self._polyak_done = bool(self.fuse_soft_update)
+        train_info = {"loss": stats[0], "grad_norm": stats[1], "Q_tot": stats[2]}
+        new_priorities = None
+        if self.use_per:
+            s = td_stats.view(B, 2).cpu().numpy().astype(np.float32)
+            new_priorities = ((1 - self.args.per_nu) * s[:, 0] + self.args.per_nu * s[:, 1]).flatten() + self.per_eps
+        self._last = (obs, share, acts, rew, dones_env, avail, w, td_stats)   # keep inputs alive past the async launch
+        return train_info, new_priorities, idxes
+
+    # ---- target updates ---------------------------------------------------------------------------------------
+    def hard_target_updates(self):
+        print("hard update targets")
+        _lib.check(_lib.lib.ope_polyak(self.numel, _lib.ptr(self.theta), _lib.ptr(self.theta_tgt), 1.0,
+                                       _lib.current_stream()), "ope_polyak")
+
+    def soft_target_updates(self):
+        if self._polyak_done:            # already applied inside ope_adam_step for this step
+            self._polyak_done = False
+            return
+        _lib.check(_lib.lib.ope_polyak(self.numel, _lib.ptr(self.theta), _lib.ptr(self.theta_tgt), float(self.tau),
+                                       _lib.current_stream()), "ope_polyak")
+
+    def prep_training(self):
+        pass
+
+    def prep_rollout(self):
+        pass
+
+
+class _TargetPolicy(object):
+    """Target twin of a policy: same hyper-parameters, q_network bound to the target flat vector."""
+
+    def __init__(self, policy, q_network):
+        self.__dict__.update({k: v for k, v in policy.__dict__.items() if k != "q_network"})
+        self.q_network = q_network
+        self._cls = policy.__class__
+
+    def __getattr__(self, name):
+        fn = getattr(self._cls, name)
+        return fn.__get__(self, self._cls)
+
+    def parameters(self):
+        return self.q_network.parameters()
+
+    def load_state(self, source_policy):
+        self.q_network.load_state_dict(source_policy.q_network.state_dict())

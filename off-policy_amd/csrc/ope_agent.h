@@ -1,0 +1,205 @@
+// Argument blocks and device helpers shared by the agent-network kernels (forward and backward).
+#pragma once
+#include "ope_common.h"
+
+namespace ope {
+
+__device__ __forceinline__ int ope_round4_dev(int x) { return (x + 3) & ~3; }
+
+// ---- argument blocks (passed by value to the kernels) -----------------------------------------------------
+struct TrunkFwdArgs {
+  const float* x;      // [R][D] input rows
+  int R, D;
+  const float* theta;  // flat parameters of the net being evaluated
+  AgentLayout L;
+  float* gi;           // [R][192]  W_ih a2 + b_ih
+  // saved for backward (live net only)
+  float* mu0;          // [R] input-LN mean
+  float* rstd0;        // [R] input-LN 1/std
+  float* xhat1;        // [R][64] normalised (pre-affine) LN1 input
+  float* rstd1;        // [R]
+  uint64_t* mask1;     // [R] ReLU mask of fc1 (bit f = z1[f] > 0)
+  float* xhat2;
+  float* rstd2;
+  uint64_t* mask2;
+};
+
+struct GruFwdArgs {
+  int nets;            // 1 or 2 (live [+ target]) processed in one launch
+  int NB;              // rows per time step (agents * episodes)
+  int L;               // sequence length (T+1)
+  const float* theta0; const float* theta1;
+  const float* gi0; const float* gi1;   // [L][NB][192]
+  float* h0out; float* h1out;           // [L][NB][64]
+  const float* hinit;                   // [NB][64] or null (zeros); live net only
+  int whh_off, bhh_off;
+  float* rg; float* zg; float* ng; float* ghn;  // [L][NB][64] gate saves (live) or null
+};
+
+struct HeadFwdArgs {
+  int64_t R;           // rows = L * NB
+  int NB, B, N, T, A;
+  const float* theta0; const float* theta1;
+  AgentLayout L;
+  const float* h0; const float* h1;     // GRU states of live / target net [R][64]
+  const float* acts;                    // [T][NB][A] one-hot
+  const float* avail;                   // [T+1][NB][A] or null
+  int double_q;
+  float* agent_q;                       // [T][B][N]
+  float* agent_nq;                      // [T][B][N]
+  int* act_idx;                         // [T][NB]
+  float* xhat_o; float* rstd_o;         // [R][64], [R] saved normalised GRU output (live)
+  float* q_out;                         // MODE 1: [R][A]
+  float* q_all;                         // optional debug output [R][A]
+};
+
+struct HeadBwdArgs {
+  int64_t R;           // rows with a loss term = T * NB
+  int NB, B, N, A;
+  const float* theta;  // live
+  AgentLayout L;
+  const float* xhat_o; const float* rstd_o;
+  const int* act_idx;
+  const float* d_agent_q;               // [T][B][N]
+  float* dh_out;                        // [R][64]
+  float* dqoh;                          // [R][A16] dq placed at the chosen action, zeros elsewhere (A16 = round4(A))
+};
+
+struct GruBwdArgs {
+  int NB, T;           // backward over t = T-1 .. 0
+  const float* theta; int whh_off;
+  const float* h;      // [T+1][NB][64] forward states
+  const float* rg; const float* zg; const float* ng; const float* ghn;
+  const float* dh_out; // [T][NB][64]
+  float* dgi;          // [T][NB][192] = (dr_pre, dz_pre, dn_pre)
+  float* dghn;         // [T][NB][64]  = dn_pre * r
+};
+
+struct TrunkBwdArgs {
+  int R;               // T * NB
+  const float* theta;  // live
+  const float* thetaT; // transposed copies: wihT [64][192] at 0, fc2T [64][64] at 64*192
+  AgentLayout L;
+  const float* dgi;    // [R][192]
+  const float* xhat1; const float* rstd1; const uint64_t* mask1;
+  const float* xhat2; const float* rstd2; const uint64_t* mask2;
+  float* dz1; float* dz2;  // [R][64]
+};
+
+int launch_trunk_fwd(const TrunkFwdArgs& a, bool save, hipStream_t st);
+int launch_gru_fwd(const GruFwdArgs& a, hipStream_t st);
+int launch_head_fwd(const HeadFwdArgs& a, int mode, hipStream_t st);
+int launch_head_bwd(const HeadBwdArgs& a, hipStream_t st);
+int launch_gru_bwd(const GruBwdArgs& a, hipStream_t st);
+int launch_trunk_bwd(const TrunkBwdArgs& a, hipStream_t st);
+int launch_transpose_weights(const float* theta, const AgentLayout& L, float* thetaT, hipStream_t st);
+int launch_transpose(const float* src, int rows, int cols, float* dst, hipStream_t st);
+
+// ---- device helpers ---------------------------------------------------------------------------------------
+// 64->64 (x tiles) GEMM step of the transposed chain: acc[it] += W[16it + j][:] . act   (W row-major, ld floats)
+template <int NT>
+__device__ __forceinline__ void gemm64(const float* __restrict__ W, int ld, int j, int g, const f32x4 (&act)[4],
+                                       f32x4 (&acc)[NT]) {
+#pragma unroll
+  for (int it = 0; it < NT; ++it) {
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(W + (int64_t)(16 * it + j) * ld + 16 * ft + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[it] = mfma16(w[r], act[ft][r], acc[it]);
+    }
+  }
+}
+
+// ReLU then LayerNorm over the 64 features of a row held as acc[it][r] = feature 16it+4g+r (4 lanes per row).
+// Outputs: act = xhat*gamma+beta; if SAVE, acc is overwritten with xhat; rstd; mbits bit (4it+r) = (z > 0).
+template <bool SAVE>
+__device__ __forceinline__ void relu_ln64(f32x4 (&acc)[4], const float* __restrict__ gam, const float* __restrict__ bet,
+                                          int g, f32x4 (&act)[4], float* rstd_out, uint32_t* mbits) {
+  uint32_t mb = 0;
+  float s = 0.f;
+#pragma unroll
+  for (int it = 0; it < 4; ++it)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float z = acc[it][r];
+      if (z > 0.f) mb |= 1u << (4 * it + r);
+      const float rl = fmaxf(z, 0.f);
+      acc[it][r] = rl;
+      s += rl;
+    }
+  const float mu = rowsum4(s) * (1.0f / OPE_H);
+  float v = 0.f;
+#pragma unroll
+  for (int it = 0; it < 4; ++it)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float d = acc[it][r] - mu;
+      v = fmaf(d, d, v);
+    }
+  const float rstd = 1.0f / sqrtf(rowsum4(v) * (1.0f / OPE_H) + OPE_LN_EPS);
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const f32x4 gm = *reinterpret_cast<const f32x4*>(gam + 16 * it + 4 * g);
+    const f32x4 bt = *reinterpret_cast<const f32x4*>(bet + 16 * it + 4 * g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float xh = (acc[it][r] - mu) * rstd;
+      act[it][r] = fmaf(xh, gm[r], bt[r]);
+      if (SAVE) acc[it][r] = xh;
+    }
+  }
+  *rstd_out = rstd;
+  *mbits = mb;
+}
+
+// Merge the four lanes' 16-bit ReLU masks into one 64-bit row mask (bit f = feature f) and store with rstd.
+__device__ __forceinline__ void store_mask_rstd(uint64_t* mask, float* rstd, int row, int g, uint32_t mbits, float rs) {
+  // lane (j,g) holds bits for features 16it + 4g + r at position 4it + r
+  uint32_t lo = 0, hi = 0;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const uint32_t nib = (mbits >> (4 * it)) & 0xF;
+    const int f0 = 16 * it + 4 * g;  // 0..60
+    if (it < 2) lo |= nib << f0; else hi |= nib << (f0 - 32);
+  }
+  lo |= __shfl_xor((int)lo, 16, 64); hi |= __shfl_xor((int)hi, 16, 64);
+  lo |= __shfl_xor((int)lo, 32, 64); hi |= __shfl_xor((int)hi, 32, 64);
+  if (g == 0) {
+    mask[row] = ((uint64_t)hi << 32) | lo;
+    rstd[row] = rs;
+  }
+}
+
+// LayerNorm of one 64-float row by a single thread (head kernels). gam/bet may live in LDS.
+__device__ __forceinline__ void ln64_thread(const float* __restrict__ hrow, const float* gam, const float* bet,
+                                            float (&y)[OPE_H], float* xhat_out, float* rstd_out) {
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < OPE_H; k += 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(hrow + k);
+    y[k] = v[0]; y[k + 1] = v[1]; y[k + 2] = v[2]; y[k + 3] = v[3];
+    s += (v[0] + v[1]) + (v[2] + v[3]);
+  }
+  const float mu = s * (1.0f / OPE_H);
+  float var = 0.f;
+#pragma unroll
+  for (int k = 0; k < OPE_H; ++k) {
+    const float d = y[k] - mu;
+    var = fmaf(d, d, var);
+  }
+  const float rstd = 1.0f / sqrtf(var * (1.0f / OPE_H) + OPE_LN_EPS);
+#pragma unroll
+  for (int k = 0; k < OPE_H; k += 4) {
+    f32x4 xh;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      xh[r] = (y[k + r] - mu) * rstd;
+      y[k + r] = fmaf(xh[r], gam[k + r], bet[k + r]);
+    }
+    if (xhat_out) *reinterpret_cast<f32x4*>(xhat_out + k) = xh;
+  }
+  if (rstd_out) *rstd_out = rstd;
+}
+
+}  // namespace ope

@@ -1,0 +1,339 @@
+// Agent q-network forward kernels (AgentQFunction.forward: agent_q_function.py:34-67 -> RNNBase.forward rnn.py:33-47
+// -> MLPLayer.forward mlp.py:25-29, RNNLayer.forward rnn.py:19-23, ACTLayer.forward act.py:21-37).
+//
+//   trunk_fwd : per data row   LN_D -> fc1+ReLU+LN -> fc2+ReLU+LN -> gi = W_ih a2 + b_ih        (f32 MFMA chain)
+//   gru_fwd   : per (agent,episode) row, serial over t: h_t = GRU(gi_t, h_{t-1})                (one wave per row)
+//   head_fwd  : per data row   LN(h_t) -> q = W_q y + b_q, chosen-action q, masked greedy argmax, target q at greedy
+#include "ope_agent.h"
+
+namespace ope {
+
+// ---------------------------------------------------------------------------------------------------------
+// trunk_fwd. One wave = 16 data rows through the whole MLP trunk; weights stream from L2 as the MFMA A operand.
+// MAXKC = max number of 16-feature chunks of the input row kept in registers (D <= 16*MAXKC).
+// ---------------------------------------------------------------------------------------------------------
+template <int VEC, int MAXKC, bool SAVE>
+__global__ void __launch_bounds__(256) trunk_fwd_kernel(TrunkFwdArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int tile = blockIdx.x * 4 + wave;
+  const int row0 = tile * 16;
+  if (row0 >= a.R) return;
+  const int row = row0 + j;
+  const bool valid = row < a.R;
+  const int D = a.D;
+  const int KC = (D + 15) >> 4;
+  const float* __restrict__ th = a.theta;
+  const float* __restrict__ xrow = a.x + (int64_t)(valid ? row : row0) * D;
+
+  // ---- input LayerNorm statistics (two-pass, exact) over the row held as 4 lanes x KC float4 ----
+  f32x4 xf[MAXKC];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < MAXKC; ++c) {
+    xf[c] = (c < KC) ? load4<VEC>(xrow, 16 * c + 4 * g, D) : f32x4{0.f, 0.f, 0.f, 0.f};
+    s += (xf[c][0] + xf[c][1]) + (xf[c][2] + xf[c][3]);
+  }
+  const float mu = rowsum4(s) / (float)D;
+  float v = 0.f;
+#pragma unroll
+  for (int c = 0; c < MAXKC; ++c) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = 16 * c + 4 * g + r;
+      const float dlt = (c < KC && k < D) ? (xf[c][r] - mu) : 0.f;
+      v = fmaf(dlt, dlt, v);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(rowsum4(v) / (float)D + OPE_LN_EPS);
+  if (SAVE && valid && g == 0) {
+    a.mu0[row] = mu;
+    a.rstd0[row] = rstd;
+  }
+
+  // ---- fc1: z1 = W1 (xhat*gamma+beta) + b1 ----
+  f32x4 acc[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) acc[it] = load4<4>(th + a.L.fc1_b, 16 * it + 4 * g, OPE_H);
+#pragma unroll
+  for (int c = 0; c < MAXKC; ++c) {
+    if (c < KC) {
+      const int k = 16 * c + 4 * g;
+      const f32x4 gam = load4<VEC>(th + a.L.fn_w, k, D);
+      const f32x4 bet = load4<VEC>(th + a.L.fn_b, k, D);
+      f32x4 xn;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xn[r] = fmaf((xf[c][r] - mu) * rstd, gam[r], bet[r]);  // 0 beyond D (gam=bet=0)
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const f32x4 w = load4<VEC>(th + a.L.fc1_w + (int64_t)(16 * it + j) * D, k, D);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[it] = mfma16(w[r], xn[r], acc[it]);
+      }
+    }
+  }
+
+  // ---- ReLU + LN (64 features: 16 per lane, 4 lanes per row) ----
+  f32x4 act[4];
+  uint32_t mbits;
+  float rs;
+  relu_ln64<SAVE>(acc, th + a.L.ln1_w, th + a.L.ln1_b, g, act, &rs, &mbits);
+  if (SAVE && valid) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) *reinterpret_cast<f32x4*>(a.xhat1 + (int64_t)row * OPE_H + 16 * it + 4 * g) = acc[it];
+    store_mask_rstd(a.mask1, a.rstd1, row, g, mbits, rs);
+  }
+
+  // ---- fc2 ----
+  f32x4 acc2[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) acc2[it] = load4<4>(th + a.L.fc2_b, 16 * it + 4 * g, OPE_H);
+  gemm64<4>(th + a.L.fc2_w, OPE_H, j, g, act, acc2);
+  relu_ln64<SAVE>(acc2, th + a.L.ln2_w, th + a.L.ln2_b, g, act, &rs, &mbits);
+  if (SAVE && valid) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) *reinterpret_cast<f32x4*>(a.xhat2 + (int64_t)row * OPE_H + 16 * it + 4 * g) = acc2[it];
+    store_mask_rstd(a.mask2, a.rstd2, row, g, mbits, rs);
+  }
+
+  // ---- gi = W_ih a2 + b_ih : 192 outputs, 4 tiles at a time ----
+#pragma unroll
+  for (int grp = 0; grp < 3; ++grp) {
+    f32x4 o[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) o[it] = load4<4>(th + a.L.bih, 64 * grp + 16 * it + 4 * g, 3 * OPE_H);
+    gemm64<4>(th + a.L.wih + (int64_t)(64 * grp) * OPE_H, OPE_H, j, g, act, o);
+    if (valid) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it)
+        *reinterpret_cast<f32x4*>(a.gi + (int64_t)row * (3 * OPE_H) + 64 * grp + 16 * it + 4 * g) = o[it];
+    }
+  }
+}
+
+template <int VEC, bool SAVE>
+static int launch_trunk_vec(const TrunkFwdArgs& a, hipStream_t st) {
+  const int blocks = ope_cdiv(ope_cdiv(a.R, 16), 4);
+  const int KC = (a.D + 15) / 16;
+  if (KC <= 4)
+    hipLaunchKernelGGL((trunk_fwd_kernel<VEC, 4, SAVE>), dim3(blocks), dim3(256), 0, st, a);
+  else if (KC <= 16)
+    hipLaunchKernelGGL((trunk_fwd_kernel<VEC, 16, SAVE>), dim3(blocks), dim3(256), 0, st, a);
+  else if (KC <= 32)
+    hipLaunchKernelGGL((trunk_fwd_kernel<VEC, 32, SAVE>), dim3(blocks), dim3(256), 0, st, a);
+  else
+    return OPE_EINVAL;
+  if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
+  return OPE_OK;
+}
+
+int launch_trunk_fwd(const TrunkFwdArgs& a, bool save, hipStream_t st) {
+  if (a.R < 1 || a.D < 1) return OPE_EINVAL;
+  const int vec = ope_vec_of(a.D);
+  if (save) {
+    if (vec == 4) return launch_trunk_vec<4, true>(a, st);
+    if (vec == 2) return launch_trunk_vec<2, true>(a, st);
+    return launch_trunk_vec<1, true>(a, st);
+  }
+  if (vec == 4) return launch_trunk_vec<4, false>(a, st);
+  if (vec == 2) return launch_trunk_vec<2, false>(a, st);
+  return launch_trunk_vec<1, false>(a, st);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// gru_fwd. One wave per (agent,episode) row; lane f owns hidden feature f and keeps rows f, 64+f, 128+f of W_hh
+// (192 floats) in VGPRs. h_{t-1}[k] is broadcast from lane k with v_readlane. No LDS, no barriers: the T+1 steps
+// are a pure dependent chain per wave, and all rows of the live AND target networks run concurrently.
+//   r = sigma(gi_r + gh_r), z = sigma(gi_z + gh_z), n = tanh(gi_n + r*gh_n), h' = (1-z) n + z h      (nn.GRU)
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gru_fwd_kernel(GruFwdArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int rid = blockIdx.x * 4 + wave;  // 0 .. nets*NB
+  if (rid >= a.nets * a.NB) return;
+  const int net = rid / a.NB;
+  const int row = rid - net * a.NB;
+  const float* __restrict__ th = net == 0 ? a.theta0 : a.theta1;
+  const float* __restrict__ gi = net == 0 ? a.gi0 : a.gi1;
+  float* __restrict__ hout = net == 0 ? a.h0out : a.h1out;
+  const bool save = (net == 0) && (a.rg != nullptr);
+
+  float wr[OPE_H], wz[OPE_H], wn[OPE_H];
+  {
+    const float* w = th + a.whh_off;
+#pragma unroll
+    for (int k = 0; k < OPE_H; k += 4) {
+      const f32x4 x = *reinterpret_cast<const f32x4*>(w + (int64_t)lane * OPE_H + k);
+      const f32x4 y = *reinterpret_cast<const f32x4*>(w + (int64_t)(OPE_H + lane) * OPE_H + k);
+      const f32x4 z = *reinterpret_cast<const f32x4*>(w + (int64_t)(2 * OPE_H + lane) * OPE_H + k);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        wr[k + r] = x[r];
+        wz[k + r] = y[r];
+        wn[k + r] = z[r];
+      }
+    }
+  }
+  const float br = th[a.bhh_off + lane], bz = th[a.bhh_off + OPE_H + lane], bn = th[a.bhh_off + 2 * OPE_H + lane];
+  float h = a.hinit ? a.hinit[(int64_t)row * OPE_H + lane] : 0.f;
+
+  const int64_t stride_t = (int64_t)a.NB;
+  const float* gp = gi + (int64_t)row * (3 * OPE_H) + lane;
+  float gir = gp[0], giz = gp[OPE_H], gin = gp[2 * OPE_H];
+  for (int t = 0; t < a.L; ++t) {
+    // prefetch next step's input projections
+    float nr = 0.f, nz = 0.f, nn = 0.f;
+    if (t + 1 < a.L) {
+      const float* q = gp + (int64_t)(t + 1) * stride_t * (3 * OPE_H);
+      nr = q[0];
+      nz = q[OPE_H];
+      nn = q[2 * OPE_H];
+    }
+    float ar = br, az = bz, an = bn;
+#pragma unroll
+    for (int k = 0; k < OPE_H; ++k) {
+      const float hk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, h), k));
+      ar = fmaf(wr[k], hk, ar);
+      az = fmaf(wz[k], hk, az);
+      an = fmaf(wn[k], hk, an);
+    }
+    const float r = sigmoidf_(gir + ar);
+    const float z = sigmoidf_(giz + az);
+    const float n = tanhf(gin + r * an);
+    h = (1.0f - z) * n + z * h;
+    const int64_t o = ((int64_t)t * stride_t + row) * OPE_H + lane;
+    hout[o] = h;
+    if (save) {
+      a.rg[o] = r;
+      a.zg[o] = z;
+      a.ng[o] = n;
+      a.ghn[o] = an;
+    }
+    gir = nr;
+    giz = nz;
+    gin = nn;
+  }
+}
+
+int launch_gru_fwd(const GruFwdArgs& a, hipStream_t st) {
+  if (a.nets < 1 || a.nets > 2 || a.NB < 1 || a.L < 1) return OPE_EINVAL;
+  const int blocks = ope_cdiv((int64_t)a.nets * a.NB, 4);
+  hipLaunchKernelGGL(gru_fwd_kernel, dim3(blocks), dim3(256), 0, st, a);
+  if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
+  return OPE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// head_fwd. One thread per data row (t, agent, b).  y = LN(h_t); q_a = W_q[a].y + b_q[a].
+//   live  : q of the action taken (t < T) -> agent_q[t][b][agent]; greedy = argmax over available actions
+//           (unavailable -> -1e10, first max wins; QMixPolicy.actions_from_q, QMixPolicy.py:102-174, util.py:297-302)
+//   target: q_tgt at the live greedy action (double-Q, qmix.py:138-146) or plain max (qmix.py:148), for t >= 1
+//           -> agent_nq[t-1][b][agent]
+// Head weights of both nets sit in LDS (broadcast reads). xhat of the live net is kept for the backward pass.
+// ---------------------------------------------------------------------------------------------------------
+template <int MODE>  // 0: training heads (live+target), 1: plain q output for ope_agent_forward
+__global__ void __launch_bounds__(256) head_fwd_kernel(HeadFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int A = a.A;
+  // LDS: [Wq live A*64][bq live A][gam 64][bet 64] then the same for the target net
+  const int per = A * OPE_H + ope_round4_dev(A) + 2 * OPE_H;
+  const int nets = (MODE == 0) ? 2 : 1;
+  for (int i = threadIdx.x; i < per * nets; i += blockDim.x) {
+    const int net = i / per, o = i - net * per;
+    const float* th = net == 0 ? a.theta0 : a.theta1;
+    float v;
+    if (o < A * OPE_H) v = th[a.L.q_w + o];
+    else if (o < A * OPE_H + ope_round4_dev(A)) v = (o - A * OPE_H < A) ? th[a.L.q_b + (o - A * OPE_H)] : 0.f;
+    else if (o < A * OPE_H + ope_round4_dev(A) + OPE_H) v = th[a.L.lno_w + (o - A * OPE_H - ope_round4_dev(A))];
+    else v = th[a.L.lno_b + (o - A * OPE_H - ope_round4_dev(A) - OPE_H)];
+    sm[i] = v;
+  }
+  __syncthreads();
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= a.R) return;
+  const int NB = a.NB;
+  const int t = (int)(r / NB);
+  const int rowi = (int)(r - (int64_t)t * NB);  // agent*B + b
+  const int agent = rowi / a.B, b = rowi - agent * a.B;
+
+  float y[OPE_H];
+  ln64_thread(a.h0 + r * OPE_H, sm + A * OPE_H + ope_round4_dev(A), sm + A * OPE_H + ope_round4_dev(A) + OPE_H, y,
+              (MODE == 0 && a.xhat_o) ? a.xhat_o + r * OPE_H : nullptr, (MODE == 0 && a.rstd_o) ? a.rstd_o + r : nullptr);
+
+  if (MODE == 1) {
+    for (int k = 0; k < A; ++k) {
+      float q = sm[A * OPE_H + k];
+#pragma unroll
+      for (int f = 0; f < OPE_H; ++f) q = fmaf(sm[k * OPE_H + f], y[f], q);
+      a.q_out[r * A + k] = q;
+    }
+    return;
+  }
+
+  // chosen action = first max of the one-hot row (QMixPolicy.q_values_from_actions, QMixPolicy.py:69-93)
+  int chosen = 0;
+  if (t < a.T) {
+    const float* ac = a.acts + r * A;
+    float best = ac[0];
+    for (int k = 1; k < A; ++k) {
+      const float v = ac[k];
+      if (v > best) { best = v; chosen = k; }
+    }
+    a.act_idx[r] = chosen;
+  }
+  const float* av = a.avail ? a.avail + r * A : nullptr;
+  float qc = 0.f, best = 0.f;
+  int greedy = 0;
+  for (int k = 0; k < A; ++k) {
+    float q = sm[A * OPE_H + k];
+#pragma unroll
+    for (int f = 0; f < OPE_H; ++f) q = fmaf(sm[k * OPE_H + f], y[f], q);
+    if (k == chosen) qc = q;
+    const float qm = (av && av[k] == 0.f) ? -1e10f : q;
+    if (k == 0 || qm > best) { best = qm; greedy = k; }
+  }
+  if (t < a.T) a.agent_q[((int64_t)t * a.B + b) * a.N + agent] = qc;
+  if (a.q_all) {
+    for (int k = 0; k < A; ++k) {  // debug/test output of the full live q row
+      float q = sm[A * OPE_H + k];
+#pragma unroll
+      for (int f = 0; f < OPE_H; ++f) q = fmaf(sm[k * OPE_H + f], y[f], q);
+      a.q_all[r * A + k] = q;
+    }
+  }
+  if (t >= 1) {
+    const float* s1 = sm + per;
+    ln64_thread(a.h1 + r * OPE_H, s1 + A * OPE_H + ope_round4_dev(A), s1 + A * OPE_H + ope_round4_dev(A) + OPE_H, y, nullptr, nullptr);
+    float tq;
+    if (a.double_q) {
+      tq = s1[A * OPE_H + greedy];
+#pragma unroll
+      for (int f = 0; f < OPE_H; ++f) tq = fmaf(s1[greedy * OPE_H + f], y[f], tq);
+    } else {
+      tq = 0.f;
+      for (int k = 0; k < A; ++k) {
+        float q = s1[A * OPE_H + k];
+#pragma unroll
+        for (int f = 0; f < OPE_H; ++f) q = fmaf(s1[k * OPE_H + f], y[f], q);
+        if (k == 0 || q > tq) tq = q;
+      }
+    }
+    a.agent_nq[((int64_t)(t - 1) * a.B + b) * a.N + agent] = tq;
+  }
+}
+
+int launch_head_fwd(const HeadFwdArgs& a, int mode, hipStream_t st) {
+  if (a.R < 1 || a.A < 1 || a.A > 1024) return OPE_EINVAL;
+  const int per = a.A * OPE_H + ope_round4(a.A) + 2 * OPE_H;
+  const int nets = mode == 0 ? 2 : 1;
+  const size_t lds = (size_t)per * nets * sizeof(float);
+  if (lds > 64 * 1024) return OPE_EINVAL;
+  const int blocks = ope_cdiv(a.R, 256);
+  if (mode == 0)
+    hipLaunchKernelGGL(head_fwd_kernel<0>, dim3(blocks), dim3(256), lds, st, a);
+  else
+    hipLaunchKernelGGL(head_fwd_kernel<1>, dim3(blocks), dim3(256), lds, st, a);
+  if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
+  return OPE_OK;
+}
+
+}  // namespace ope

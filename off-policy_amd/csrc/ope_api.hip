@@ -1,0 +1,389 @@
+// C-ABI entry points that orchestrate the kernels: parameter layout, workspace carving, the QMIX/VDN
+// loss-and-gradient step (QMix.train_policy_on_batch, qmix.py:77-190) and the stand-alone agent forward.
+#include <string.h>
+
+#include "ope_mixer.h"
+#include "ope_wgrad.h"
+
+using namespace ope;
+
+namespace {
+
+int g_debug = 0;
+
+bool cfg_ok(const ope_qmix_cfg* c) {
+  if (!c) return false;
+  const ope_dims& d = c->dims;
+  return d.n_agents >= 1 && d.act_dim >= 1 && d.obs_dim >= 1 && d.obs_dim <= 512 && d.state_dim >= 1 &&
+         d.episode_length >= 1 && c->batch >= 1 && d.n_agents <= 64 && d.act_dim <= 200;
+}
+
+// ---- workspace: a list of named float regions, 256-byte aligned --------------------------------------------
+struct Region { const char* name; int64_t off; int64_t n; };
+constexpr int kMaxRegions = 64;
+struct Workspace {
+  Region r[kMaxRegions];
+  int n = 0;
+  int64_t total = 0;  // floats
+  int64_t add(const char* name, int64_t nfloats) {
+    const int64_t off = total;
+    r[n++] = Region{name, off, nfloats};
+    total += (nfloats + 63) & ~(int64_t)63;
+    return off;
+  }
+  int64_t find(const char* name, int64_t* nf) const {
+    for (int i = 0; i < n; ++i)
+      if (strcmp(r[i].name, name) == 0) {
+        if (nf) *nf = r[i].n;
+        return r[i].off;
+      }
+    return -1;
+  }
+};
+
+struct Raw {  // offsets inside one split slab, agent region then mixer region
+  int P1, s1, P2, s2, P3, s3, WHH, shh, E, sq, agent_end;
+  int mixer_size;
+};
+
+struct Plan {
+  int T, N, A, D, S, B, NB, A4, NM;
+  int64_t R, R1, TB;
+  AgentLayout AL;
+  MixerLayout ML;   // offsets in the full theta (base = AL.end)
+  int64_t P;        // padded parameter count
+  Raw raw;
+  int ns_agent, ns_mixer;
+  int n_loss_tiles;
+  Workspace ws;
+  // region offsets
+  int64_t mu0, rstd0, xhat1, rstd1, mask1, xhat2, rstd2, mask2, gi, h, rg, zg, ng, ghn, xhat_o, rstd_o, act_idx,
+      agent_q, agent_nq, gi_t, h_t, qtot, nqtot, hw1, hw2, hb2, v1, hpre, v2, loss_part, err_abs, dqtot, d_agent_q,
+      d_b1, d_v2, d_v1, d_hw1, d_hw2, d_hb2, dh_out, dqoh, dgi, dghn, dz1, dz2, thetaT, mixT, raw_agent, raw_mixer,
+      rsum, q_all;
+};
+
+int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+void make_plan(const ope_qmix_cfg* c, Plan* p) {
+  const ope_dims& d = c->dims;
+  p->T = d.episode_length; p->N = d.n_agents; p->A = d.act_dim; p->D = d.obs_dim; p->S = d.state_dim; p->B = c->batch;
+  p->NB = p->N * p->B; p->A4 = ope_round4(p->A); p->NM = p->N * OPE_MIX;
+  p->R = (int64_t)(p->T + 1) * p->NB; p->R1 = (int64_t)p->T * p->NB; p->TB = (int64_t)p->T * p->B;
+  p->AL = ope_agent_layout(p->D, p->A, 0);
+  if (c->vdn) {
+    memset(&p->ML, 0, sizeof(p->ML));
+    p->ML.end = p->AL.end;
+    p->P = p->AL.end;
+  } else {
+    p->ML = ope_mixer_layout(p->N, p->S, p->AL.end);
+    p->P = p->ML.end;
+  }
+  Raw& w = p->raw;
+  int o = 0;
+  auto take = [&](int n) { int r = o; o += ope_round4(n); return r; };
+  w.P1 = take(OPE_H * p->D); w.s1 = take(OPE_H);
+  w.P2 = take(OPE_H * OPE_H); w.s2 = take(OPE_H);
+  w.P3 = take(3 * OPE_H * OPE_H); w.s3 = take(3 * OPE_H);
+  w.WHH = take(3 * OPE_H * OPE_H); w.shh = take(3 * OPE_H);
+  w.E = take(p->A * OPE_H); w.sq = take(p->A4);
+  w.agent_end = o;
+  w.mixer_size = c->vdn ? 0 : (p->ML.end - p->AL.end);
+  p->ns_agent = clampi(ope_cdiv(p->R1, 300), 1, 128);
+  p->ns_mixer = clampi(ope_cdiv(p->TB, 150), 1, 64);
+  p->n_loss_tiles = ope_cdiv(p->TB, 16);
+
+  Workspace& W = p->ws;
+  const int64_t R = p->R, R1 = p->R1, TB = p->TB;
+  p->mu0 = W.add("mu0", R); p->rstd0 = W.add("rstd0", R);
+  p->xhat1 = W.add("xhat1", R * OPE_H); p->rstd1 = W.add("rstd1", R); p->mask1 = W.add("mask1", 2 * R);
+  p->xhat2 = W.add("xhat2", R * OPE_H); p->rstd2 = W.add("rstd2", R); p->mask2 = W.add("mask2", 2 * R);
+  p->gi = W.add("gi", R * 3 * OPE_H); p->h = W.add("h", R * OPE_H);
+  p->rg = W.add("rg", R * OPE_H); p->zg = W.add("zg", R * OPE_H); p->ng = W.add("ng", R * OPE_H); p->ghn = W.add("ghn", R * OPE_H);
+  p->xhat_o = W.add("xhat_o", R * OPE_H); p->rstd_o = W.add("rstd_o", R);
+  p->act_idx = W.add("act_idx", R1);
+  p->agent_q = W.add("agent_q", TB * p->N); p->agent_nq = W.add("agent_nq", TB * p->N);
+  p->gi_t = W.add("gi_t", R * 3 * OPE_H); p->h_t = W.add("h_t", R * OPE_H);
+  p->qtot = W.add("qtot", TB); p->nqtot = W.add("nqtot", TB);
+  p->hw1 = W.add("hw1", TB * OPE_HYP); p->hw2 = W.add("hw2", TB * OPE_HYP); p->hb2 = W.add("hb2", TB * OPE_HYP);
+  p->v1 = W.add("v1", TB * p->NM); p->hpre = W.add("hpre", TB * OPE_MIX); p->v2 = W.add("v2", TB * OPE_MIX);
+  p->loss_part = W.add("loss_part", (int64_t)p->n_loss_tiles * 4);
+  p->err_abs = W.add("err_abs", TB); p->dqtot = W.add("dqtot", TB); p->d_agent_q = W.add("d_agent_q", TB * p->N);
+  p->d_b1 = W.add("d_b1", TB * OPE_MIX); p->d_v2 = W.add("d_v2", TB * OPE_MIX); p->d_v1 = W.add("d_v1", TB * p->NM);
+  p->d_hw1 = W.add("d_hw1", TB * OPE_HYP); p->d_hw2 = W.add("d_hw2", TB * OPE_HYP); p->d_hb2 = W.add("d_hb2", TB * OPE_HYP);
+  p->dh_out = W.add("dh_out", R1 * OPE_H); p->dqoh = W.add("dqoh", R1 * p->A4);
+  p->dgi = W.add("dgi", R1 * 3 * OPE_H); p->dghn = W.add("dghn", R1 * OPE_H);
+  p->dz1 = W.add("dz1", R1 * OPE_H); p->dz2 = W.add("dz2", R1 * OPE_H);
+  p->thetaT = W.add("thetaT", OPE_H * 3 * OPE_H + OPE_H * OPE_H);
+  p->mixT = W.add("mixT", (int64_t)OPE_HYP * p->NM + OPE_HYP * OPE_MIX);
+  p->raw_agent = W.add("raw_agent", (int64_t)p->ns_agent * w.agent_end);
+  p->raw_mixer = W.add("raw_mixer", (int64_t)p->ns_mixer * (w.mixer_size > 0 ? w.mixer_size : 4));
+  p->rsum = W.add("rsum", (int64_t)w.agent_end + w.mixer_size + 4);
+  p->q_all = W.add("q_all", R * p->A);
+}
+
+}  // namespace
+
+extern "C" int ope_version(void) { return OPE_VERSION; }
+extern "C" const char* ope_strerror(int code) {
+  switch (code) {
+    case OPE_OK: return "ok";
+    case OPE_EINVAL: return "invalid argument or unsupported dimension";
+    case OPE_ELAUNCH: return "HIP kernel launch failed";
+    case OPE_ENOSPC: return "workspace too small";
+    default: return "unknown error";
+  }
+}
+extern "C" void ope_set_debug(int on) { g_debug = on; }
+
+extern "C" int64_t ope_qmix_param_layout(const ope_qmix_cfg* cfg, int64_t* offsets, int64_t* sizes) {
+  if (!cfg_ok(cfg)) return OPE_EINVAL;
+  const int D = cfg->dims.obs_dim, A = cfg->dims.act_dim, N = cfg->dims.n_agents, S = cfg->dims.state_dim;
+  const AgentLayout L = ope_agent_layout(D, A, 0);
+  const int ao[OPE_QMIX_NPARAM_AGENT] = {L.fn_w, L.fn_b, L.fc1_w, L.fc1_b, L.ln1_w, L.ln1_b, L.fch_w, L.fch_b, L.lnh_w, L.lnh_b,
+                                         L.fc2_w, L.fc2_b, L.ln2_w, L.ln2_b, L.wih, L.whh, L.bih, L.bhh, L.lno_w, L.lno_b, L.q_w, L.q_b};
+  const int as[OPE_QMIX_NPARAM_AGENT] = {D, D, OPE_H * D, OPE_H, OPE_H, OPE_H, OPE_H * OPE_H, OPE_H, OPE_H, OPE_H,
+                                         OPE_H * OPE_H, OPE_H, OPE_H, OPE_H, 3 * OPE_H * OPE_H, 3 * OPE_H * OPE_H, 3 * OPE_H, 3 * OPE_H,
+                                         OPE_H, OPE_H, A * OPE_H, A};
+  for (int i = 0; i < OPE_QMIX_NPARAM_AGENT; ++i) {
+    if (offsets) offsets[i] = ao[i];
+    if (sizes) sizes[i] = as[i];
+  }
+  if (cfg->vdn) return L.end;
+  const MixerLayout M = ope_mixer_layout(N, S, L.end);
+  const int mo[OPE_QMIX_NPARAM_MIXER] = {M.w1a_w, M.w1a_b, M.w1b_w, M.w1b_b, M.w2a_w, M.w2a_b, M.w2b_w, M.w2b_b,
+                                         M.b1_w, M.b1_b, M.b2a_w, M.b2a_b, M.b2b_w, M.b2b_b};
+  const int ms[OPE_QMIX_NPARAM_MIXER] = {OPE_HYP * S, OPE_HYP, N * OPE_MIX * OPE_HYP, N * OPE_MIX, OPE_HYP * S, OPE_HYP,
+                                         OPE_MIX * OPE_HYP, OPE_MIX, OPE_MIX * S, OPE_MIX, OPE_HYP * S, OPE_HYP, OPE_HYP, 1};
+  for (int i = 0; i < OPE_QMIX_NPARAM_MIXER; ++i) {
+    if (offsets) offsets[OPE_QMIX_NPARAM_AGENT + i] = mo[i];
+    if (sizes) sizes[OPE_QMIX_NPARAM_AGENT + i] = ms[i];
+  }
+  return M.end;
+}
+
+extern "C" int64_t ope_qmix_workspace_bytes(const ope_qmix_cfg* cfg) {
+  if (!cfg_ok(cfg)) return OPE_EINVAL;
+  Plan p;
+  make_plan(cfg, &p);
+  return p.ws.total * (int64_t)sizeof(float);
+}
+
+extern "C" int64_t ope_qmix_workspace_find(const ope_qmix_cfg* cfg, const char* name, int64_t* n_floats) {
+  if (!cfg_ok(cfg) || !name) return OPE_EINVAL;
+  Plan p;
+  make_plan(cfg, &p);
+  const int64_t off = p.ws.find(name, n_floats);
+  return off < 0 ? -1 : off * (int64_t)sizeof(float);
+}
+
+extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields* batch, const float* theta,
+                                      const float* theta_tgt, const float* per_weights, void* workspace,
+                                      int64_t workspace_bytes, float* grad, float* td_abs_stats, void* stream) {
+  if (!cfg_ok(cfg) || !batch || !theta || !theta_tgt || !workspace || !grad) return OPE_EINVAL;
+  if (!batch->obs || !batch->share_obs || !batch->acts || !batch->rewards || !batch->dones_env) return OPE_EINVAL;
+  if (cfg->use_per && !per_weights) return OPE_EINVAL;
+  Plan p;
+  make_plan(cfg, &p);
+  if (workspace_bytes < p.ws.total * (int64_t)sizeof(float)) return OPE_ENOSPC;
+  hipStream_t st = (hipStream_t)stream;
+  float* W = (float*)workspace;
+  int rc;
+
+  // ---- forward: trunks of both nets ----
+  TrunkFwdArgs tf;
+  tf.x = batch->obs; tf.R = (int)p.R; tf.D = p.D; tf.theta = theta; tf.L = p.AL; tf.gi = W + p.gi;
+  tf.mu0 = W + p.mu0; tf.rstd0 = W + p.rstd0;
+  tf.xhat1 = W + p.xhat1; tf.rstd1 = W + p.rstd1; tf.mask1 = (uint64_t*)(W + p.mask1);
+  tf.xhat2 = W + p.xhat2; tf.rstd2 = W + p.rstd2; tf.mask2 = (uint64_t*)(W + p.mask2);
+  if ((rc = launch_trunk_fwd(tf, true, st))) return rc;
+  TrunkFwdArgs tt = tf;
+  tt.theta = theta_tgt; tt.gi = W + p.gi_t;
+  if ((rc = launch_trunk_fwd(tt, false, st))) return rc;
+
+  // ---- forward: GRU scans (live + target in one launch) ----
+  GruFwdArgs gf;
+  gf.nets = 2; gf.NB = p.NB; gf.L = p.T + 1; gf.theta0 = theta; gf.theta1 = theta_tgt; gf.gi0 = W + p.gi; gf.gi1 = W + p.gi_t;
+  gf.h0out = W + p.h; gf.h1out = W + p.h_t; gf.hinit = nullptr; gf.whh_off = p.AL.whh; gf.bhh_off = p.AL.bhh;
+  gf.rg = W + p.rg; gf.zg = W + p.zg; gf.ng = W + p.ng; gf.ghn = W + p.ghn;
+  if ((rc = launch_gru_fwd(gf, st))) return rc;
+
+  // ---- forward: heads ----
+  HeadFwdArgs hf;
+  hf.R = p.R; hf.NB = p.NB; hf.B = p.B; hf.N = p.N; hf.T = p.T; hf.A = p.A; hf.theta0 = theta; hf.theta1 = theta_tgt; hf.L = p.AL;
+  hf.h0 = W + p.h; hf.h1 = W + p.h_t; hf.acts = batch->acts; hf.avail = batch->avail_acts; hf.double_q = cfg->use_double_q;
+  hf.agent_q = W + p.agent_q; hf.agent_nq = W + p.agent_nq; hf.act_idx = (int*)(W + p.act_idx);
+  hf.xhat_o = W + p.xhat_o; hf.rstd_o = W + p.rstd_o; hf.q_out = nullptr; hf.q_all = g_debug ? W + p.q_all : nullptr;
+  if ((rc = launch_head_fwd(hf, 0, st))) return rc;
+
+  // ---- mixer forward + TD + mixer backward ----
+  TdArgs td;
+  td.B = p.B; td.N = p.N; td.gamma = cfg->gamma; td.use_huber = cfg->use_huber; td.huber_delta = cfg->huber_delta;
+  td.rewards = batch->rewards; td.dones_env = batch->dones_env; td.per_weights = cfg->use_per ? per_weights : nullptr;
+  if (cfg->vdn) {
+    VdnArgs va;
+    va.TB = (int)p.TB; va.N = p.N; va.td = td; va.agent_q = W + p.agent_q; va.agent_nq = W + p.agent_nq;
+    va.loss_part = W + p.loss_part; va.err_abs = W + p.err_abs; va.d_agent_q = W + p.d_agent_q;
+    if ((rc = launch_vdn(va, st))) return rc;
+  } else {
+    MixerFwdArgs mf;
+    mf.TB = (int)p.TB; mf.B = p.B; mf.N = p.N; mf.S = p.S; mf.theta0 = theta; mf.theta1 = theta_tgt; mf.L = p.ML;
+    mf.share = batch->share_obs; mf.agent_q = W + p.agent_q; mf.agent_nq = W + p.agent_nq; mf.qtot = W + p.qtot; mf.nqtot = W + p.nqtot;
+    mf.hw1 = W + p.hw1; mf.hw2 = W + p.hw2; mf.hb2 = W + p.hb2; mf.v1 = W + p.v1; mf.hpre = W + p.hpre; mf.v2 = W + p.v2;
+    if ((rc = launch_mixer_fwd(mf, st))) return rc;
+    if ((rc = launch_transpose(theta + p.ML.w1b_w, p.NM, OPE_HYP, W + p.mixT, st))) return rc;
+    if ((rc = launch_transpose(theta + p.ML.w2b_w, OPE_MIX, OPE_HYP, W + p.mixT + (int64_t)OPE_HYP * p.NM, st))) return rc;
+    MixerBwdArgs mb;
+    mb.TB = (int)p.TB; mb.N = p.N; mb.theta = theta; mb.thetaT = W + p.mixT; mb.L = p.ML; mb.td = td;
+    mb.qtot = W + p.qtot; mb.nqtot = W + p.nqtot; mb.agent_q = W + p.agent_q;
+    mb.hw1 = W + p.hw1; mb.hw2 = W + p.hw2; mb.hb2 = W + p.hb2; mb.v1 = W + p.v1; mb.hpre = W + p.hpre; mb.v2 = W + p.v2;
+    mb.loss_part = W + p.loss_part; mb.err_abs = W + p.err_abs; mb.dqtot = W + p.dqtot; mb.d_agent_q = W + p.d_agent_q;
+    mb.d_b1 = W + p.d_b1; mb.d_v2 = W + p.d_v2; mb.d_v1 = W + p.d_v1; mb.d_hw1 = W + p.d_hw1; mb.d_hw2 = W + p.d_hw2; mb.d_hb2 = W + p.d_hb2;
+    if ((rc = launch_mixer_bwd(mb, st))) return rc;
+  }
+  if (td_abs_stats)
+    if ((rc = launch_td_stats(W + p.err_abs, p.T, p.B, td_abs_stats, st))) return rc;
+
+  // ---- agent backward ----
+  HeadBwdArgs hb;
+  hb.R = p.R1; hb.NB = p.NB; hb.B = p.B; hb.N = p.N; hb.A = p.A; hb.theta = theta; hb.L = p.AL;
+  hb.xhat_o = W + p.xhat_o; hb.rstd_o = W + p.rstd_o; hb.act_idx = (const int*)(W + p.act_idx); hb.d_agent_q = W + p.d_agent_q;
+  hb.dh_out = W + p.dh_out; hb.dqoh = W + p.dqoh;
+  if ((rc = launch_head_bwd(hb, st))) return rc;
+  GruBwdArgs gb;
+  gb.NB = p.NB; gb.T = p.T; gb.theta = theta; gb.whh_off = p.AL.whh; gb.h = W + p.h;
+  gb.rg = W + p.rg; gb.zg = W + p.zg; gb.ng = W + p.ng; gb.ghn = W + p.ghn; gb.dh_out = W + p.dh_out; gb.dgi = W + p.dgi; gb.dghn = W + p.dghn;
+  if ((rc = launch_gru_bwd(gb, st))) return rc;
+  if ((rc = launch_transpose_weights(theta, p.AL, W + p.thetaT, st))) return rc;
+  TrunkBwdArgs tb;
+  tb.R = (int)p.R1; tb.theta = theta; tb.thetaT = W + p.thetaT; tb.L = p.AL; tb.dgi = W + p.dgi;
+  tb.xhat1 = W + p.xhat1; tb.rstd1 = W + p.rstd1; tb.mask1 = (const uint64_t*)(W + p.mask1);
+  tb.xhat2 = W + p.xhat2; tb.rstd2 = W + p.rstd2; tb.mask2 = (const uint64_t*)(W + p.mask2);
+  tb.dz1 = W + p.dz1; tb.dz2 = W + p.dz2;
+  if ((rc = launch_trunk_bwd(tb, st))) return rc;
+
+  // ---- weight gradients: one batched K-reduction launch ----
+  WgTable wt;
+  memset(&wt, 0, sizeof(wt));
+  int n = 0;
+  const Raw& rw = p.raw;
+  const int K1 = (int)p.R1;
+  auto prob = [&](const float* A, int lda, int M, const float* Bm, int ldb, int N, int K, int out_off, int ldc, int s_off,
+                  int nsplit, int64_t base, int64_t stride) -> WgProb& {
+    WgProb& q = wt.p[n++];
+    q.A = A; q.lda = lda; q.M = M; q.B = Bm; q.ldb = ldb; q.N = N; q.K = K; q.b_shift = 0; q.ln_mu = nullptr; q.ln_rstd = nullptr;
+    q.out_off = out_off; q.ldc = ldc; q.s_off = s_off; q.nsplit = nsplit; q.raw_base = base; q.raw_stride = stride;
+    return q;
+  };
+  const int64_t ab = p.raw_agent, as = rw.agent_end;
+  {
+    WgProb& q = prob(W + p.dz1, OPE_H, OPE_H, batch->obs, p.D, p.D, K1, rw.P1, p.D, rw.s1, p.ns_agent, ab, as);
+    q.ln_mu = W + p.mu0; q.ln_rstd = W + p.rstd0;
+  }
+  prob(W + p.dz2, OPE_H, OPE_H, W + p.xhat1, OPE_H, OPE_H, K1, rw.P2, OPE_H, rw.s2, p.ns_agent, ab, as);
+  prob(W + p.dgi, 3 * OPE_H, 3 * OPE_H, W + p.xhat2, OPE_H, OPE_H, K1, rw.P3, OPE_H, rw.s3, p.ns_agent, ab, as);
+  {
+    WgProb& q = prob(W + p.dgi, 3 * OPE_H, 2 * OPE_H, W + p.h, OPE_H, OPE_H, K1, rw.WHH, OPE_H, rw.shh, p.ns_agent, ab, as);
+    q.b_shift = p.NB;  // h_{t-1}
+    WgProb& q2 = prob(W + p.dghn, OPE_H, OPE_H, W + p.h, OPE_H, OPE_H, K1, rw.WHH + 2 * OPE_H * OPE_H, OPE_H, rw.shh + 2 * OPE_H, p.ns_agent, ab, as);
+    q2.b_shift = p.NB;
+  }
+  prob(W + p.dqoh, p.A4, p.A, W + p.xhat_o, OPE_H, OPE_H, K1, rw.E, OPE_H, rw.sq, p.ns_agent, ab, as);
+  if (!cfg->vdn) {
+    const MixerLayout& M = p.ML;
+    const int mbase = p.AL.end;
+    const int64_t mb_ = p.raw_mixer, ms = rw.mixer_size;
+    const int TBk = (int)p.TB;
+    const float* S0 = batch->share_obs;  // rows 0..TB-1 are states at t < T
+    prob(W + p.d_hw1, OPE_HYP, OPE_HYP, S0, p.S, p.S, TBk, M.w1a_w - mbase, p.S, M.w1a_b - mbase, p.ns_mixer, mb_, ms);
+    prob(W + p.d_v1, p.NM, p.NM, W + p.hw1, OPE_HYP, OPE_HYP, TBk, M.w1b_w - mbase, OPE_HYP, M.w1b_b - mbase, p.ns_mixer, mb_, ms);
+    prob(W + p.d_hw2, OPE_HYP, OPE_HYP, S0, p.S, p.S, TBk, M.w2a_w - mbase, p.S, M.w2a_b - mbase, p.ns_mixer, mb_, ms);
+    prob(W + p.d_v2, OPE_MIX, OPE_MIX, W + p.hw2, OPE_HYP, OPE_HYP, TBk, M.w2b_w - mbase, OPE_HYP, M.w2b_b - mbase, p.ns_mixer, mb_, ms);
+    prob(W + p.d_b1, OPE_MIX, OPE_MIX, S0, p.S, p.S, TBk, M.b1_w - mbase, p.S, M.b1_b - mbase, p.ns_mixer, mb_, ms);
+    prob(W + p.d_hb2, OPE_HYP, OPE_HYP, S0, p.S, p.S, TBk, M.b2a_w - mbase, p.S, M.b2a_b - mbase, p.ns_mixer, mb_, ms);
+    prob(W + p.dqtot, 1, 1, W + p.hb2, OPE_HYP, OPE_HYP, TBk, M.b2b_w - mbase, OPE_HYP, M.b2b_b - mbase, p.ns_mixer, mb_, ms);
+  }
+  wt.n = n;
+  if ((rc = wg_finish(&wt))) return rc;
+  if ((rc = launch_wgrad(wt, W, st))) return rc;
+  if ((rc = launch_split_reduce(W + p.raw_agent, rw.agent_end, p.ns_agent, rw.agent_end, W + p.rsum, st))) return rc;
+  if (!cfg->vdn)
+    if ((rc = launch_split_reduce(W + p.raw_mixer, rw.mixer_size, p.ns_mixer, rw.mixer_size, W + p.rsum + rw.agent_end, st))) return rc;
+
+  // ---- finalize into the flat gradient ----
+  FinTable ft;
+  memset(&ft, 0, sizeof(ft));
+  int k = 0;
+  const AgentLayout& L = p.AL;
+  auto seg = [&](int begin, int size, int kind, int src, int src_s, int M, int K, int w, int gamma, int beta) {
+    FinSeg& s = ft.seg[k++];
+    s.begin = begin; s.size = size; s.kind = kind; s.src = src; s.src_s = src_s; s.M = M; s.K = K; s.w = w; s.gamma = gamma; s.beta = beta;
+  };
+  seg(L.fn_w, p.D, FIN_LNLIN_G, rw.P1, rw.s1, OPE_H, p.D, L.fc1_w, 0, 0);
+  seg(L.fn_b, p.D, FIN_LNLIN_B, rw.P1, rw.s1, OPE_H, p.D, L.fc1_w, 0, 0);
+  seg(L.fc1_w, OPE_H * p.D, FIN_LNLIN_W, rw.P1, rw.s1, OPE_H, p.D, L.fc1_w, L.fn_w, L.fn_b);
+  seg(L.fc1_b, OPE_H, FIN_COPY, rw.s1, 0, 0, 0, 0, 0, 0);
+  seg(L.ln1_w, OPE_H, FIN_LNLIN_G, rw.P2, rw.s2, OPE_H, OPE_H, L.fc2_w, 0, 0);
+  seg(L.ln1_b, OPE_H, FIN_LNLIN_B, rw.P2, rw.s2, OPE_H, OPE_H, L.fc2_w, 0, 0);
+  seg(L.fch_w, 0, FIN_ZERO, 0, 0, 0, 0, 0, 0, 0);  // fc_h.*: registered, never used (mlp.py:21-23) -> zero gradient
+  seg(L.fc2_w, OPE_H * OPE_H, FIN_LNLIN_W, rw.P2, rw.s2, OPE_H, OPE_H, L.fc2_w, L.ln1_w, L.ln1_b);
+  seg(L.fc2_b, OPE_H, FIN_COPY, rw.s2, 0, 0, 0, 0, 0, 0);
+  seg(L.ln2_w, OPE_H, FIN_LNLIN_G, rw.P3, rw.s3, 3 * OPE_H, OPE_H, L.wih, 0, 0);
+  seg(L.ln2_b, OPE_H, FIN_LNLIN_B, rw.P3, rw.s3, 3 * OPE_H, OPE_H, L.wih, 0, 0);
+  seg(L.wih, 3 * OPE_H * OPE_H, FIN_LNLIN_W, rw.P3, rw.s3, 3 * OPE_H, OPE_H, L.wih, L.ln2_w, L.ln2_b);
+  seg(L.whh, 3 * OPE_H * OPE_H, FIN_COPY, rw.WHH, 0, 0, 0, 0, 0, 0);
+  seg(L.bih, 3 * OPE_H, FIN_COPY, rw.s3, 0, 0, 0, 0, 0, 0);
+  seg(L.bhh, 3 * OPE_H, FIN_COPY, rw.shh, 0, 0, 0, 0, 0, 0);
+  seg(L.lno_w, OPE_H, FIN_LNLIN_G, rw.E, rw.sq, p.A, OPE_H, L.q_w, 0, 0);
+  seg(L.lno_b, OPE_H, FIN_LNLIN_B, rw.E, rw.sq, p.A, OPE_H, L.q_w, 0, 0);
+  seg(L.q_w, p.A * OPE_H, FIN_LNLIN_W, rw.E, rw.sq, p.A, OPE_H, L.q_w, L.lno_w, L.lno_b);
+  seg(L.q_b, p.A, FIN_COPY, rw.sq, 0, 0, 0, 0, 0, 0);
+  if (!cfg->vdn) {  // mixer gradients: raw mixer slab has the same relative layout as the parameters
+    const MixerLayout& M = p.ML;
+    const int mo[OPE_QMIX_NPARAM_MIXER] = {M.w1a_w, M.w1a_b, M.w1b_w, M.w1b_b, M.w2a_w, M.w2a_b, M.w2b_w, M.w2b_b,
+                                           M.b1_w, M.b1_b, M.b2a_w, M.b2a_b, M.b2b_w, M.b2b_b};
+    const int ms[OPE_QMIX_NPARAM_MIXER] = {OPE_HYP * p.S, OPE_HYP, p.NM * OPE_HYP, p.NM, OPE_HYP * p.S, OPE_HYP,
+                                           OPE_MIX * OPE_HYP, OPE_MIX, OPE_MIX * p.S, OPE_MIX, OPE_HYP * p.S, OPE_HYP, OPE_HYP, 1};
+    for (int q = 0; q < OPE_QMIX_NPARAM_MIXER; ++q)
+      seg(mo[q], ms[q], FIN_COPY, rw.agent_end + (mo[q] - p.AL.end), 0, 0, 0, 0, 0, 0);
+  }
+  seg((int)p.P, OPE_GRAD_TAIL, FIN_TAIL, 0, 0, 0, 0, 0, 0, 0);
+  ft.n = k;
+  ft.total = p.P + OPE_GRAD_TAIL;
+  if ((rc = launch_finalize(ft, W + p.rsum, theta, W + p.loss_part, p.n_loss_tiles, grad, st))) return rc;
+  return OPE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int64_t ope_agent_forward_workspace_bytes(const ope_dims* d, int32_t seq_len, int32_t rows) {
+  if (!d || seq_len < 1 || rows < 1) return OPE_EINVAL;
+  const int64_t R = (int64_t)seq_len * rows;
+  return (R * 3 * OPE_H + 64) * (int64_t)sizeof(float);
+}
+
+extern "C" int ope_agent_forward(const ope_dims* d, int32_t seq_len, int32_t rows, const float* obs, const float* h0,
+                                 const float* theta, void* workspace, int64_t workspace_bytes, float* q_out, float* h_out,
+                                 void* stream) {
+  if (!d || seq_len < 1 || rows < 1 || !obs || !theta || !workspace || !q_out || !h_out) return OPE_EINVAL;
+  if (d->obs_dim < 1 || d->obs_dim > 512 || d->act_dim < 1) return OPE_EINVAL;
+  if (workspace_bytes < ope_agent_forward_workspace_bytes(d, seq_len, rows)) return OPE_ENOSPC;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t R = (int64_t)seq_len * rows;
+  const AgentLayout L = ope_agent_layout(d->obs_dim, d->act_dim, 0);
+  float* gi = (float*)workspace;
+  int rc;
+  TrunkFwdArgs tf;
+  memset(&tf, 0, sizeof(tf));
+  tf.x = obs; tf.R = (int)R; tf.D = d->obs_dim; tf.theta = theta; tf.L = L; tf.gi = gi;
+  if ((rc = launch_trunk_fwd(tf, false, st))) return rc;
+  GruFwdArgs gf;
+  memset(&gf, 0, sizeof(gf));
+  gf.nets = 1; gf.NB = rows; gf.L = seq_len; gf.theta0 = theta; gf.theta1 = theta; gf.gi0 = gi; gf.gi1 = gi; gf.h0out = h_out; gf.h1out = h_out;
+  gf.hinit = h0; gf.whh_off = L.whh; gf.bhh_off = L.bhh;
+  if ((rc = launch_gru_fwd(gf, st))) return rc;
+  HeadFwdArgs hf;
+  memset(&hf, 0, sizeof(hf));
+  hf.R = R; hf.NB = rows; hf.B = rows; hf.N = 1; hf.T = seq_len; hf.A = d->act_dim; hf.theta0 = theta; hf.theta1 = theta; hf.L = L;
+  hf.h0 = h_out; hf.q_out = q_out;
+  return launch_head_fwd(hf, 1, st);
+}

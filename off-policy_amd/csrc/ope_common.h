@@ -1,0 +1,157 @@
+// Shared device helpers for the ope kernels (gfx950 / CDNA4 only, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ope.h"
+
+#define OPE_H 64          // GRU / MLP hidden width (reference default hidden_size, config.py:63)
+#define OPE_MIX 32        // mixer_hidden_dim (config.py:148)
+#define OPE_HYP 64        // hypernet_hidden_dim (config.py:150)
+#define OPE_LN_EPS 1e-5f  // nn.LayerNorm default eps
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define OPE_CHECK_LAUNCH()                          \
+  do {                                              \
+    if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH; \
+  } while (0)
+
+static inline int ope_round4(int64_t x) { return (int)((x + 3) & ~(int64_t)3); }
+static inline int ope_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------------------------------------------------
+// f32 MFMA 16x16x4 (exact fp32 FMA chain; 157 TF/s peak on MI355X).  D[i][j] += sum_{kk<4} A[i][kk] * B[kk][j]
+//   lane l supplies  a = A[i = l&15][kk = l>>4],  b = B[kk = l>>4][j = l&15]
+//   lane l holds     D[i = 4*(l>>4) + r][j = l&15]  in acc[r], r = 0..3
+//
+// "Transposed chain" convention used by every row-parallel kernel here: a wave owns 16 data rows (j = l&15),
+// weights are the A operand (i = output feature), activations the B operand. With g = l>>4 and a K-chunk of 16
+// features [16c, 16c+16), lane (j,g) reads the 4 consecutive features 16c+4g..+3 of its row (one float4) and of
+// weight row i (one float4); MFMA step r consumes element r, i.e. feature 16c+4g+r -- a permutation of the
+// chunk, identical on both operands. The result lane (j,g) holds output features 16*it + 4g + r of row j, which is
+// again "4 consecutive features at 16*it + 4g": layers chain with no shuffles and no LDS.
+// ---------------------------------------------------------------------------------------------------------
+#ifndef OPE_MFMA_EMULATE
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+#else
+// Debug fallback (same lane contract, built from shuffles) to separate layout bugs from MFMA semantics.
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  const int l = threadIdx.x & 63;
+  const int j = l & 15, g = l >> 4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float s = c[r];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      float av = __shfl(a, (4 * g + r) + 16 * kk, 64);
+      float bv = __shfl(b, j + 16 * kk, 64);
+      s = fmaf(av, bv, s);
+    }
+    c[r] = s;
+  }
+  return c;
+}
+#endif
+
+// 4 consecutive floats p[k..k+3] of a row of logical length K, zero beyond K.
+// VEC = widest aligned access the row stride allows: 4 (K%4==0), 2 (K%2==0) or 1.
+template <int VEC>
+__device__ __forceinline__ f32x4 load4(const float* __restrict__ p, int k, int K) {
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (VEC == 4) {
+    if (k < K) v = *reinterpret_cast<const f32x4*>(p + k);
+  } else if (VEC == 2) {
+    if (k < K) {
+      f32x2 a = *reinterpret_cast<const f32x2*>(p + k);
+      v[0] = a[0];
+      v[1] = a[1];
+    }
+    if (k + 2 < K) {
+      f32x2 b = *reinterpret_cast<const f32x2*>(p + k + 2);
+      v[2] = b[0];
+      v[3] = b[1];
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (k + r < K) v[r] = p[k + r];
+  }
+  return v;
+}
+
+template <int VEC>
+__device__ __forceinline__ void store4(float* __restrict__ p, int k, int K, f32x4 v) {
+  if (VEC == 4) {
+    if (k < K) *reinterpret_cast<f32x4*>(p + k) = v;
+  } else if (VEC == 2) {
+    if (k < K) {
+      f32x2 a = {v[0], v[1]};
+      *reinterpret_cast<f32x2*>(p + k) = a;
+    }
+    if (k + 2 < K) {
+      f32x2 b = {v[2], v[3]};
+      *reinterpret_cast<f32x2*>(p + k + 2) = b;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (k + r < K) p[k + r] = v[r];
+  }
+}
+
+static inline int ope_vec_of(int K) { return (K % 4 == 0) ? 4 : ((K % 2 == 0) ? 2 : 1); }
+
+// Sum over the 4 lanes (g = 0..3) that share a data row j in the transposed-chain layout.
+__device__ __forceinline__ float rowsum4(float x) {
+  x += __shfl_xor(x, 16, 64);
+  x += __shfl_xor(x, 32, 64);
+  return x;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// Flat-parameter offsets (floats) of the agent q-network and the QMixer. Order = reference named_parameters()
+// (SURVEY.md Appendix D); every tensor starts on a multiple of 4 floats.
+struct AgentLayout {
+  int fn_w, fn_b, fc1_w, fc1_b, ln1_w, ln1_b, fch_w, fch_b, lnh_w, lnh_b, fc2_w, fc2_b, ln2_w, ln2_b;
+  int wih, whh, bih, bhh, lno_w, lno_b, q_w, q_b;
+  int end;
+};
+struct MixerLayout {
+  int w1a_w, w1a_b, w1b_w, w1b_b, w2a_w, w2a_b, w2b_w, w2b_b, b1_w, b1_b, b2a_w, b2a_b, b2b_w, b2b_b;
+  int end;
+};
+
+static inline AgentLayout ope_agent_layout(int D, int A, int base) {
+  AgentLayout L;
+  int o = base;
+  auto take = [&](int n) { int r = o; o += ope_round4(n); return r; };
+  L.fn_w = take(D); L.fn_b = take(D);
+  L.fc1_w = take(OPE_H * D); L.fc1_b = take(OPE_H); L.ln1_w = take(OPE_H); L.ln1_b = take(OPE_H);
+  L.fch_w = take(OPE_H * OPE_H); L.fch_b = take(OPE_H); L.lnh_w = take(OPE_H); L.lnh_b = take(OPE_H);
+  L.fc2_w = take(OPE_H * OPE_H); L.fc2_b = take(OPE_H); L.ln2_w = take(OPE_H); L.ln2_b = take(OPE_H);
+  L.wih = take(3 * OPE_H * OPE_H); L.whh = take(3 * OPE_H * OPE_H); L.bih = take(3 * OPE_H); L.bhh = take(3 * OPE_H);
+  L.lno_w = take(OPE_H); L.lno_b = take(OPE_H);
+  L.q_w = take(A * OPE_H); L.q_b = take(A);
+  L.end = o;
+  return L;
+}
+
+static inline MixerLayout ope_mixer_layout(int N, int S, int base) {
+  MixerLayout L;
+  int o = base;
+  auto take = [&](int n) { int r = o; o += ope_round4(n); return r; };
+  L.w1a_w = take(OPE_HYP * S); L.w1a_b = take(OPE_HYP);
+  L.w1b_w = take(N * OPE_MIX * OPE_HYP); L.w1b_b = take(N * OPE_MIX);
+  L.w2a_w = take(OPE_HYP * S); L.w2a_b = take(OPE_HYP);
+  L.w2b_w = take(OPE_MIX * OPE_HYP); L.w2b_b = take(OPE_MIX);
+  L.b1_w = take(OPE_MIX * S); L.b1_b = take(OPE_MIX);
+  L.b2a_w = take(OPE_HYP * S); L.b2a_b = take(OPE_HYP);
+  L.b2b_w = take(OPE_HYP); L.b2b_b = take(1);
+  L.end = o;
+  return L;
+}

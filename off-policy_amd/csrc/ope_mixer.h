@@ -1,0 +1,58 @@
+// Argument blocks for the mixer / TD kernels.
+#pragma once
+#include "ope_agent.h"
+
+namespace ope {
+
+struct MixerFwdArgs {
+  int TB, B, N, S;                       // TB = T*B rows; both nets evaluated in one launch
+  const float* theta0; const float* theta1;
+  MixerLayout L;
+  const float* share;                    // [T+1][B][S] centralized observations
+  const float* agent_q;                  // [TB][N] live chosen-action q
+  const float* agent_nq;                 // [TB][N] target q at t+1
+  float* qtot; float* nqtot;             // [TB]
+  // saved for backward (live net)
+  float* hw1; float* hw2; float* hb2;    // [TB][64] post-ReLU hyper hidden layers
+  float* v1;                             // [TB][N*32] pre-abs w1
+  float* hpre;                           // [TB][32]   pre-ELU hidden
+  float* v2;                             // [TB][32]   pre-abs w2
+};
+
+struct TdArgs {
+  int B, N;
+  float gamma; int use_huber; float huber_delta;
+  const float* rewards;                  // [T][N][B][1]
+  const float* dones_env;                // [T][B][1]
+  const float* per_weights;              // [B] or null
+};
+
+struct MixerBwdArgs {
+  int TB, N;
+  const float* theta; const float* thetaT;  // thetaT: w1bT [64][N*32] then w2bT [64][32]
+  MixerLayout L;
+  TdArgs td;
+  const float* qtot; const float* nqtot; const float* agent_q;
+  const float* hw1; const float* hw2; const float* hb2; const float* v1; const float* hpre; const float* v2;
+  float* loss_part;                      // [tiles][4] = loss_sum, mask_count, qtot_sum, 0
+  float* err_abs;                        // [TB]
+  float* dqtot;                          // [TB]
+  float* d_agent_q;                      // [TB][N]
+  float* d_b1; float* d_v2;              // [TB][32]
+  float* d_v1;                           // [TB][N*32]
+  float* d_hw1; float* d_hw2; float* d_hb2;  // [TB][64] adjoints of the hyper hidden PRE-activations
+};
+
+struct VdnArgs {
+  int TB, N;
+  TdArgs td;
+  const float* agent_q; const float* agent_nq;
+  float* loss_part; float* err_abs; float* d_agent_q;
+};
+
+int launch_mixer_fwd(const MixerFwdArgs& a, hipStream_t st);
+int launch_mixer_bwd(const MixerBwdArgs& a, hipStream_t st);
+int launch_vdn(const VdnArgs& a, hipStream_t st);
+int launch_td_stats(const float* err_abs, int T, int B, float* out, hipStream_t st);
+
+}  // namespace ope

@@ -1,0 +1,357 @@
+// QMIX mixing network + TD target + loss, forward and backward
+//   QMixer.forward                     offpolicy/algorithms/qmix/algorithm/q_mixer.py:68-94
+//   TD target / mask / Huber|MSE / PER offpolicy/algorithms/qmix/qmix.py:158-187, utils/util.py:103-110
+//   VDN mixing (sum over agents)       offpolicy/algorithms/vdn/algorithm/vdn_mixer.py:28-40 (with the A-2 shape fix)
+//
+// One wave owns 16 (t,b) rows. The four hyper-network first layers (S -> 64,64,64,32) run as one 14-tile f32-MFMA
+// chain over the state row; the second layers (64 -> N*32, 32) chain on without leaving registers; the per-row
+// agent-Q x |w1| contraction, ELU, |w2| dot and b2 are lane-local with two cross-lane adds (4 lanes share a row).
+#include "ope_mixer.h"
+
+namespace ope {
+
+__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }
+__device__ __forceinline__ float sgn(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
+
+// first hyper-layers: tiles 0-3 hyper_w1.0, 4-7 hyper_w2.0, 8-11 hyper_b2.0, 12-13 hyper_b1
+__device__ __forceinline__ const float* stageA_row(const float* th, const MixerLayout& L, int S, int it, int i) {
+  if (it < 4) return th + L.w1a_w + (int64_t)(16 * it + i) * S;
+  if (it < 8) return th + L.w2a_w + (int64_t)(16 * (it - 4) + i) * S;
+  if (it < 12) return th + L.b2a_w + (int64_t)(16 * (it - 8) + i) * S;
+  return th + L.b1_w + (int64_t)(16 * (it - 12) + i) * S;
+}
+__device__ __forceinline__ const float* stageA_bias(const float* th, const MixerLayout& L, int it) {
+  if (it < 4) return th + L.w1a_b + 16 * it;
+  if (it < 8) return th + L.w2a_b + 16 * (it - 4);
+  if (it < 12) return th + L.b2a_b + 16 * (it - 8);
+  return th + L.b1_b + 16 * (it - 12);
+}
+
+template <int VEC>
+__global__ void __launch_bounds__(256) mixer_fwd_kernel(MixerFwdArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int tiles = (a.TB + 15) >> 4;
+  const int w = blockIdx.x * 4 + wave;
+  if (w >= 2 * tiles) return;
+  const int net = w / tiles;
+  const int m0 = (w - net * tiles) * 16;
+  const int m = m0 + j;
+  const bool valid = m < a.TB;
+  const int mm = valid ? m : m0;
+  const int t = mm / a.B, b = mm - t * a.B;
+  const float* __restrict__ th = net == 0 ? a.theta0 : a.theta1;
+  const MixerLayout& L = a.L;
+  const int S = a.S, N = a.N;
+  const float* __restrict__ srow = a.share + ((int64_t)(t + net) * a.B + b) * S;
+  const float* __restrict__ qrow = (net == 0 ? a.agent_q : a.agent_nq) + (int64_t)mm * N;
+  const bool save = (net == 0) && (a.hw1 != nullptr);
+
+  // ---- stage A: 14 output tiles over K = S ----
+  f32x4 acc[14];
+#pragma unroll
+  for (int it = 0; it < 14; ++it) acc[it] = *reinterpret_cast<const f32x4*>(stageA_bias(th, L, it) + 4 * g);
+  const int KC = (S + 15) >> 4;
+  for (int c = 0; c < KC; ++c) {
+    const int k = 16 * c + 4 * g;
+    const f32x4 xs = load4<VEC>(srow, k, S);
+#pragma unroll
+    for (int it = 0; it < 14; ++it) {
+      const f32x4 wv = load4<VEC>(stageA_row(th, L, S, it, j), k, S);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[it] = mfma16(wv[r], xs[r], acc[it]);
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < 12; ++it)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[it][r] = fmaxf(acc[it][r], 0.f);
+  if (save && valid) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      *reinterpret_cast<f32x4*>(a.hw1 + (int64_t)m * OPE_HYP + 16 * it + 4 * g) = acc[it];
+      *reinterpret_cast<f32x4*>(a.hw2 + (int64_t)m * OPE_HYP + 16 * it + 4 * g) = acc[4 + it];
+      *reinterpret_cast<f32x4*>(a.hb2 + (int64_t)m * OPE_HYP + 16 * it + 4 * g) = acc[8 + it];
+    }
+  }
+  f32x4 hw1[4] = {acc[0], acc[1], acc[2], acc[3]};
+  f32x4 hw2[4] = {acc[4], acc[5], acc[6], acc[7]};
+
+  // ---- stage B: hidden = ELU( sum_a q_a |W1b hw1 + b|[a] + b1 ) ----
+  f32x4 hid[2] = {acc[12], acc[13]};
+  for (int ag = 0; ag < N; ++ag) {
+    f32x4 v[2];
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) v[kh] = *reinterpret_cast<const f32x4*>(th + L.w1b_b + ag * OPE_MIX + 16 * kh + 4 * g);
+    gemm64<2>(th + L.w1b_w + (int64_t)(ag * OPE_MIX) * OPE_HYP, OPE_HYP, j, g, hw1, v);
+    if (save && valid) {
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh)
+        *reinterpret_cast<f32x4*>(a.v1 + (int64_t)m * (N * OPE_MIX) + ag * OPE_MIX + 16 * kh + 4 * g) = v[kh];
+    }
+    const float qa = qrow[ag];
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) hid[kh][r] = fmaf(qa, fabsf(v[kh][r]), hid[kh][r]);
+  }
+  if (save && valid) {
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) *reinterpret_cast<f32x4*>(a.hpre + (int64_t)m * OPE_MIX + 16 * kh + 4 * g) = hid[kh];
+  }
+  // ---- w2, b2, Q_tot ----
+  f32x4 v2[2];
+#pragma unroll
+  for (int kh = 0; kh < 2; ++kh) v2[kh] = *reinterpret_cast<const f32x4*>(th + L.w2b_b + 16 * kh + 4 * g);
+  gemm64<2>(th + L.w2b_w, OPE_HYP, j, g, hw2, v2);
+  if (save && valid) {
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) *reinterpret_cast<f32x4*>(a.v2 + (int64_t)m * OPE_MIX + 16 * kh + 4 * g) = v2[kh];
+  }
+  float part = 0.f;
+#pragma unroll
+  for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part = fmaf(elu1(hid[kh][r]), fabsf(v2[kh][r]), part);
+  float pb = 0.f;
+#pragma unroll
+  for (int ft = 0; ft < 4; ++ft) {
+    const f32x4 wv = *reinterpret_cast<const f32x4*>(th + L.b2b_w + 16 * ft + 4 * g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pb = fmaf(wv[r], acc[8 + ft][r], pb);
+  }
+  const float qtot = rowsum4(part) + (rowsum4(pb) + th[L.b2b_b]);
+  if (valid && g == 0) (net == 0 ? a.qtot : a.nqtot)[m] = qtot;
+}
+
+int launch_mixer_fwd(const MixerFwdArgs& a, hipStream_t st) {
+  if (a.TB < 1 || a.N < 1 || a.S < 1) return OPE_EINVAL;
+  const int waves = 2 * ope_cdiv(a.TB, 16);
+  const int blocks = ope_cdiv(waves, 4);
+  const int vec = ope_vec_of(a.S);
+  if (vec == 4) hipLaunchKernelGGL(mixer_fwd_kernel<4>, dim3(blocks), dim3(256), 0, st, a);
+  else if (vec == 2) hipLaunchKernelGGL(mixer_fwd_kernel<2>, dim3(blocks), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(mixer_fwd_kernel<1>, dim3(blocks), dim3(256), 0, st, a);
+  if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
+  return OPE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// TD target, masked error, loss terms and dQ_tot for one (t,b) row (qmix.py:158-176). The loss is NOT divided by
+// the mask count here: gradients are those of the un-normalised sum (ope.h), so data-parallel ranks can add them.
+// ---------------------------------------------------------------------------------------------------------
+struct TdOut { float err, keep, lossel, dq; };
+__device__ __forceinline__ TdOut td_row(const TdArgs& d, int t, int b, float qtot, float nqtot) {
+  TdOut o;
+  const float bad = t == 0 ? 0.f : d.dones_env[(int64_t)(t - 1) * d.B + b];
+  o.keep = 1.0f - bad;
+  const float rew = d.rewards[((int64_t)t * d.N + 0) * d.B + b];   // agents share the reward: agent 0 (qmix.py:159)
+  const float den = d.dones_env[(int64_t)t * d.B + b];
+  const float target = rew + (1.0f - den) * d.gamma * nqtot;
+  const float e = (qtot - target) * o.keep;
+  o.err = e;
+  const float wgt = d.per_weights ? d.per_weights[b] : 1.0f;
+  float fe, dfe;
+  if (d.use_huber) {
+    const float ae = fabsf(e), dl = d.huber_delta;
+    if (ae <= dl) { fe = e * e * 0.5f; dfe = e; }
+    else { fe = dl * (ae - dl * 0.5f); dfe = dl * sgn(e); }
+  } else {
+    fe = e * e;
+    dfe = 2.0f * e;
+  }
+  o.lossel = wgt * fe;
+  o.dq = wgt * dfe * o.keep;
+  return o;
+}
+
+// sum over the 16 rows (lanes j) of a wave-tile; result valid in every lane
+__device__ __forceinline__ float tilesum16(float x) {
+  x += __shfl_xor(x, 1, 64);
+  x += __shfl_xor(x, 2, 64);
+  x += __shfl_xor(x, 4, 64);
+  x += __shfl_xor(x, 8, 64);
+  return x;
+}
+
+__global__ void __launch_bounds__(256) mixer_bwd_kernel(MixerBwdArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int tile = blockIdx.x * 4 + wave;
+  const int m0 = tile * 16;
+  if (m0 >= a.TB) return;
+  const int m = m0 + j;
+  const bool valid = m < a.TB;
+  const int mm = valid ? m : m0;
+  const int t = mm / a.td.B, b = mm - t * a.td.B;
+  const float* __restrict__ th = a.theta;
+  const MixerLayout& L = a.L;
+  const int N = a.N;
+
+  TdOut td = td_row(a.td, t, b, a.qtot[mm], a.nqtot[mm]);
+  if (!valid) { td.err = 0.f; td.keep = 0.f; td.lossel = 0.f; td.dq = 0.f; }
+  {
+    const float ls = tilesum16(g == 0 ? td.lossel : 0.f);
+    const float cs = tilesum16(g == 0 ? td.keep : 0.f);
+    const float qs = tilesum16(g == 0 ? a.qtot[mm] * td.keep : 0.f);
+    if (lane == 0) {
+      a.loss_part[tile * 4 + 0] = ls;
+      a.loss_part[tile * 4 + 1] = cs;
+      a.loss_part[tile * 4 + 2] = qs;
+      a.loss_part[tile * 4 + 3] = 0.f;
+    }
+  }
+  const float dQ = td.dq;
+  if (valid && g == 0) {
+    a.err_abs[m] = fabsf(td.err);
+    a.dqtot[m] = dQ;
+  }
+
+  // lane-local 32-vectors (k = 16kh + 4g + r)
+  f32x4 hp[2], v2[2], dpre[2], dv2[2];
+#pragma unroll
+  for (int kh = 0; kh < 2; ++kh) {
+    hp[kh] = *reinterpret_cast<const f32x4*>(a.hpre + (int64_t)mm * OPE_MIX + 16 * kh + 4 * g);
+    v2[kh] = *reinterpret_cast<const f32x4*>(a.v2 + (int64_t)mm * OPE_MIX + 16 * kh + 4 * g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float hdn = elu1(hp[kh][r]);
+      dv2[kh][r] = dQ * hdn * sgn(v2[kh][r]);
+      const float dh = dQ * fabsf(v2[kh][r]);
+      dpre[kh][r] = dh * (hp[kh][r] > 0.f ? 1.0f : expf(hp[kh][r]));
+    }
+    if (valid) {
+      *reinterpret_cast<f32x4*>(a.d_b1 + (int64_t)m * OPE_MIX + 16 * kh + 4 * g) = dpre[kh];
+      *reinterpret_cast<f32x4*>(a.d_v2 + (int64_t)m * OPE_MIX + 16 * kh + 4 * g) = dv2[kh];
+    }
+  }
+  // agents: dq_a, dv1, and dhw1 += W1b^T dv1
+  f32x4 dh1[4];
+#pragma unroll
+  for (int ft = 0; ft < 4; ++ft) dh1[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int NM = N * OPE_MIX;
+  const float* w1bT = a.thetaT;                 // [64][N*32]
+  const float* w2bT = a.thetaT + OPE_HYP * NM;  // [64][32]
+  for (int ag = 0; ag < N; ++ag) {
+    const float qa = a.agent_q[(int64_t)mm * N + ag];
+    float dqa = 0.f;
+    f32x4 dv1[2];
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(a.v1 + (int64_t)mm * NM + ag * OPE_MIX + 16 * kh + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        dqa = fmaf(dpre[kh][r], fabsf(v[r]), dqa);
+        dv1[kh][r] = dpre[kh][r] * qa * sgn(v[r]);
+      }
+      if (valid) *reinterpret_cast<f32x4*>(a.d_v1 + (int64_t)m * NM + ag * OPE_MIX + 16 * kh + 4 * g) = dv1[kh];
+    }
+    dqa = rowsum4(dqa);
+    if (valid && g == 0) a.d_agent_q[(int64_t)m * N + ag] = dqa;
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(w1bT + (int64_t)(16 * ft + j) * NM + ag * OPE_MIX + 16 * kh + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dh1[ft] = mfma16(wv[r], dv1[kh][r], dh1[ft]);
+      }
+  }
+  // dhw2 = W2b^T dv2 ; ReLU masks ; dhb2 = dQ * w ; stores
+  f32x4 dh2[4];
+#pragma unroll
+  for (int ft = 0; ft < 4; ++ft) {
+    dh2[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(w2bT + (int64_t)(16 * ft + j) * OPE_MIX + 16 * kh + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dh2[ft] = mfma16(wv[r], dv2[kh][r], dh2[ft]);
+    }
+  }
+  if (valid) {
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft) {
+      const f32x4 h1 = *reinterpret_cast<const f32x4*>(a.hw1 + (int64_t)m * OPE_HYP + 16 * ft + 4 * g);
+      const f32x4 h2 = *reinterpret_cast<const f32x4*>(a.hw2 + (int64_t)m * OPE_HYP + 16 * ft + 4 * g);
+      const f32x4 h3 = *reinterpret_cast<const f32x4*>(a.hb2 + (int64_t)m * OPE_HYP + 16 * ft + 4 * g);
+      const f32x4 wb = *reinterpret_cast<const f32x4*>(th + L.b2b_w + 16 * ft + 4 * g);
+      f32x4 o1, o2, o3;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        o1[r] = h1[r] > 0.f ? dh1[ft][r] : 0.f;
+        o2[r] = h2[r] > 0.f ? dh2[ft][r] : 0.f;
+        o3[r] = h3[r] > 0.f ? dQ * wb[r] : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(a.d_hw1 + (int64_t)m * OPE_HYP + 16 * ft + 4 * g) = o1;
+      *reinterpret_cast<f32x4*>(a.d_hw2 + (int64_t)m * OPE_HYP + 16 * ft + 4 * g) = o2;
+      *reinterpret_cast<f32x4*>(a.d_hb2 + (int64_t)m * OPE_HYP + 16 * ft + 4 * g) = o3;
+    }
+  }
+}
+
+int launch_mixer_bwd(const MixerBwdArgs& a, hipStream_t st) {
+  if (a.TB < 1) return OPE_EINVAL;
+  hipLaunchKernelGGL(mixer_bwd_kernel, dim3(ope_cdiv(ope_cdiv(a.TB, 16), 4)), dim3(256), 0, st, a);
+  if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
+  return OPE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// VDN: Q_tot = sum_a q_a (both nets), TD, and d agent_q = dQ_tot broadcast. One thread per (t,b); loss partials
+// per 16-row group in the same [tile][4] format the QMIX path uses.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) vdn_kernel(VdnArgs a) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = m < a.TB;
+  const int mm = valid ? m : 0;
+  const int t = mm / a.td.B, b = mm - t * a.td.B;
+  float q = 0.f, nq = 0.f;
+  for (int ag = 0; ag < a.N; ++ag) {
+    q += a.agent_q[(int64_t)mm * a.N + ag];
+    nq += a.agent_nq[(int64_t)mm * a.N + ag];
+  }
+  TdOut td = td_row(a.td, t, b, q, nq);
+  if (!valid) { td.err = 0.f; td.keep = 0.f; td.lossel = 0.f; td.dq = 0.f; }
+  const float ls = tilesum16(td.lossel), cs = tilesum16(td.keep), qs = tilesum16(q * td.keep);
+  if ((threadIdx.x & 15) == 0 && (m >> 4) < ((a.TB + 15) >> 4)) {
+    const int tile = m >> 4;
+    a.loss_part[tile * 4 + 0] = ls;
+    a.loss_part[tile * 4 + 1] = cs;
+    a.loss_part[tile * 4 + 2] = qs;
+    a.loss_part[tile * 4 + 3] = 0.f;
+  }
+  if (valid) {
+    a.err_abs[m] = fabsf(td.err);
+    for (int ag = 0; ag < a.N; ++ag) a.d_agent_q[(int64_t)m * a.N + ag] = td.dq;
+  }
+}
+
+int launch_vdn(const VdnArgs& a, hipStream_t st) {
+  if (a.TB < 1) return OPE_EINVAL;
+  hipLaunchKernelGGL(vdn_kernel, dim3(ope_cdiv(a.TB, 256)), dim3(256), 0, st, a);
+  if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
+  return OPE_OK;
+}
+
+// per-episode [mean_t |err|, max_t |err|] for the R2D2-style priorities (qmix.py:179-181)
+__global__ void td_stats_kernel(const float* __restrict__ err_abs, int T, int B, float* __restrict__ out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float s = 0.f, mx = 0.f;
+  for (int t = 0; t < T; ++t) {
+    const float e = err_abs[(int64_t)t * B + b];
+    s += e;
+    mx = fmaxf(mx, e);
+  }
+  out[2 * b] = s / (float)T;
+  out[2 * b + 1] = mx;
+}
+
+int launch_td_stats(const float* err_abs, int T, int B, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(td_stats_kernel, dim3(ope_cdiv(B, 64)), dim3(64), 0, st, err_abs, T, B, out);
+  if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
+  return OPE_OK;
+}
+
+}  // namespace ope

@@ -1,0 +1,126 @@
+// clip_grad_norm_ + Adam + Polyak over flat vectors.
+//   torch.nn.utils.clip_grad_norm_(params, max_norm)   qmix.py:192   (coef = min(1, max/(norm+1e-6)))
+//   torch.optim.Adam(lr, betas, eps, weight_decay)     qmix.py:71-72,193 ; MADDPGPolicy.py:53-55
+//   soft_update / hard_update                          offpolicy/utils/util.py:123-145
+// Two launches: (1) per-block partial sums of grad^2; (2) every block re-adds the partials in the same fixed
+// order (deterministic), derives the clip coefficient and applies the update to its slice. Pure HBM streaming.
+#include "ope_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kPerThread = 4;
+constexpr int kPerBlock = kBlock * kPerThread;
+
+__device__ __forceinline__ float block_sum(float v, float* sm) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) sm[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int q = 0; q < kBlock / 64; ++q) t += sm[q];
+  __syncthreads();
+  return t;
+}
+
+__global__ void __launch_bounds__(kBlock) sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ part) {
+  __shared__ float sm[kBlock / 64];
+  const int64_t base = (int64_t)blockIdx.x * kPerBlock + threadIdx.x * kPerThread;
+  float s = 0.f;
+  if (base + 3 < n) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(g + base);
+    s = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+  } else {
+    for (int q = 0; q < kPerThread; ++q)
+      if (base + q < n) s = fmaf(g[base + q], g[base + q], s);
+  }
+  const float t = block_sum(s, sm);
+  if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+struct AdamK {
+  float lr_t;        // lr / (1 - beta1^t)
+  float inv_sqrt_bc2;  // 1 / sqrt(1 - beta2^t)
+  float beta1, beta2, eps, max_norm, wd, tau, qden;
+  int do_polyak;
+  int nblocks;
+};
+
+__global__ void __launch_bounds__(kBlock) adam_kernel(AdamK c, int64_t n, float* __restrict__ theta, float* __restrict__ tgt,
+                                                       float* __restrict__ m, float* __restrict__ v,
+                                                       const float* __restrict__ g, const float* __restrict__ part,
+                                                       float* __restrict__ stats) {
+  __shared__ float sm[kBlock / 64];
+  __shared__ float s_coef;
+  float s = 0.f;
+  for (int q = threadIdx.x; q < c.nblocks; q += kBlock) s += part[q];
+  // fixed-order: each thread adds a fixed subset, then the same tree everywhere -> identical in all blocks
+  const float tot = block_sum(s, sm);
+  const float cnt = g[n + 1];
+  const float inv = 1.0f / cnt;
+  const float norm = sqrtf(tot) * inv;
+  const float coef = fminf(1.0f, c.max_norm / (norm + 1e-6f));
+  if (blockIdx.x == 0 && threadIdx.x == 0 && stats) {
+    stats[0] = g[n] * inv;          // loss
+    stats[1] = norm;                // pre-clip global L2 norm
+    stats[2] = g[n + 2] / c.qden;   // mean of Q_tot*(1-mask) over ALL T*B steps
+    stats[3] = cnt;
+  }
+  (void)s_coef;
+  const float scale = coef * inv;
+  const int64_t base = (int64_t)blockIdx.x * kPerBlock + threadIdx.x * kPerThread;
+  for (int q = 0; q < kPerThread; ++q) {
+    const int64_t i = base + q;
+    if (i >= n) break;
+    float th = theta[i];
+    float gi = g[i] * scale;
+    if (c.wd != 0.f) gi = fmaf(c.wd, th, gi);
+    const float mi = c.beta1 * m[i] + (1.0f - c.beta1) * gi;
+    const float vi = c.beta2 * v[i] + (1.0f - c.beta2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float den = sqrtf(vi) * c.inv_sqrt_bc2 + c.eps;
+    th = th - c.lr_t * (mi / den);
+    theta[i] = th;
+    if (c.do_polyak) tgt[i] = tgt[i] * (1.0f - c.tau) + th * c.tau;
+  }
+}
+
+__global__ void polyak_kernel(int64_t n, const float* __restrict__ theta, float* __restrict__ tgt, float tau) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  tgt[i] = (tau >= 1.0f) ? theta[i] : tgt[i] * (1.0f - tau) + theta[i] * tau;
+}
+
+}  // namespace
+
+extern "C" int64_t ope_adam_scratch_floats(int64_t n) { return n < 1 ? OPE_EINVAL : ope_cdiv(n, kPerBlock) + 4; }
+
+extern "C" int ope_adam_step(const ope_adam_cfg* cfg, int64_t n, float* theta, float* theta_tgt, float* adam_m, float* adam_v,
+                             const float* grad, float* scratch, float* stats_out, void* stream) {
+  if (!cfg || n < 1 || (n & 3) || !theta || !adam_m || !adam_v || !grad || !scratch) return OPE_EINVAL;
+  if (cfg->do_polyak && !theta_tgt) return OPE_EINVAL;
+  if (cfg->step < 1) return OPE_EINVAL;
+  const int nb = ope_cdiv(n, kPerBlock);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(kBlock), 0, st, grad, n, scratch);
+  OPE_CHECK_LAUNCH();
+  AdamK c;
+  const double bc1 = 1.0 - pow((double)cfg->beta1, (double)cfg->step);
+  const double bc2 = 1.0 - pow((double)cfg->beta2, (double)cfg->step);
+  c.lr_t = (float)((double)cfg->lr / bc1);
+  c.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  c.beta1 = cfg->beta1; c.beta2 = cfg->beta2; c.eps = cfg->eps; c.max_norm = cfg->max_grad_norm;
+  c.wd = cfg->weight_decay; c.tau = cfg->tau; c.qden = cfg->qtot_denominator; c.do_polyak = cfg->do_polyak;
+  c.nblocks = nb;
+  hipLaunchKernelGGL(adam_kernel, dim3(nb), dim3(kBlock), 0, st, c, n, theta, theta_tgt, adam_m, adam_v, grad, scratch, stats_out);
+  OPE_CHECK_LAUNCH();
+  return OPE_OK;
+}
+
+extern "C" int ope_polyak(int64_t n, const float* theta, float* theta_tgt, float tau, void* stream) {
+  if (n < 1 || !theta || !theta_tgt) return OPE_EINVAL;
+  hipLaunchKernelGGL(polyak_kernel, dim3(ope_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, n, theta, theta_tgt, tau);
+  OPE_CHECK_LAUNCH();
+  return OPE_OK;
+}

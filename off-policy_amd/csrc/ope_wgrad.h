@@ -1,0 +1,48 @@
+// Problem / segment tables for the batched weight-gradient kernel and the gradient finalize step.
+#pragma once
+#include "ope_common.h"
+
+namespace ope {
+
+struct WgProb {
+  const float* A; int lda; int M;      // A[k][m], m < M
+  const float* B; int ldb; int N;      // B[k][n], n < N
+  int K;                               // rows reduced over
+  int b_shift;                         // B row used for k is (k - b_shift); zero contribution if negative
+  const float* ln_mu; const float* ln_rstd;  // if set: B element -> (B - mu[row]) * rstd[row]
+  int out_off; int ldc;                // offset (inside one split slab) / leading dim of C
+  int s_off;                           // slab offset of colsum(A)[M], or -1
+  int nsplit;                          // K-splits of this problem
+  int64_t raw_base; int64_t raw_stride;  // split q writes to raw[raw_base + q*raw_stride + ...]
+  int mt, nt, kchunk, wave_begin;      // filled by wg_finish
+};
+constexpr int kMaxWgProbs = 16;
+struct WgTable {
+  WgProb p[kMaxWgProbs];
+  int n, total_waves;
+};
+int wg_finish(WgTable* tb);
+int launch_wgrad(const WgTable& tb, float* raw, hipStream_t st);
+int launch_split_reduce(const float* raw, int64_t stride, int nsplit, int64_t n, float* rsum, hipStream_t st);
+
+enum FinKind { FIN_ZERO = 0, FIN_COPY = 1, FIN_LNLIN_W = 2, FIN_LNLIN_G = 3, FIN_LNLIN_B = 4, FIN_TAIL = 5 };
+struct FinSeg {
+  int begin;   // first flat-gradient index of this segment (segments are sorted, padded to x4)
+  int size;    // valid elements (rest of the slot up to the next begin is zero)
+  int kind;
+  int src;     // rsum offset of P / of the plain gradient
+  int src_s;   // rsum offset of the column-sum vector s
+  int M, K;    // shape of the Linear weight [M][K] the segment belongs to
+  int w;       // theta offset of that weight
+  int gamma, beta;  // theta offsets of the LayerNorm feeding it
+};
+constexpr int kMaxFinSegs = 40;
+struct FinTable {
+  FinSeg seg[kMaxFinSegs];
+  int n;
+  int64_t total;  // length of the flat gradient including the tail
+};
+int launch_finalize(const FinTable& ft, const float* rsum, const float* theta, const float* loss_part, int n_loss_tiles,
+                    float* grad, hipStream_t st);
+
+}  // namespace ope

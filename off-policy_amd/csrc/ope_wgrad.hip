@@ -1,0 +1,208 @@
+// Weight-gradient reductions:  C[M][N] = sum_k A[k][m] * B[k][n]   (K = number of data rows, 10^3..10^5)
+//
+// The reference obtains these from autograd's Linear backward (grad_W = grad_out^T @ input), one aten::mm per
+// layer. Here ALL of a trainer's weight gradients are one batched launch: a table of problems, each cut into
+// 64x64 output tiles x NS K-splits; one wave computes one (tile, split) with 16 f32-MFMA accumulators, reading
+// its operands straight from global memory (each operand element feeds 4 MFMAs from registers, so no LDS stage).
+// Split partials go to raw[split][...] and are summed in fixed order afterwards (deterministic, no atomics).
+//
+// Options per problem: column-sum of A (bias gradients) written next to C; LayerNorm-on-load of B
+// (xhat = (B - mu[k]) * rstd[k], for the input feature-norm whose xhat is never materialised); row shift of B
+// (B[k - shift], zero for k < shift: the h_{t-1} operand of dW_hh).
+#include "ope_wgrad.h"
+
+namespace ope {
+
+__global__ void __launch_bounds__(256) wgrad_kernel(WgTable tb, float* __restrict__ raw) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int wid = blockIdx.x * 4 + wave;
+  if (wid >= tb.total_waves) return;
+  int p = 0;
+#pragma unroll 1
+  for (int q = 1; q < tb.n; ++q)
+    if (wid >= tb.p[q].wave_begin) p = q;
+  const WgProb& P = tb.p[p];
+  const int local = wid - P.wave_begin;
+  const int split = local % P.nsplit;
+  const int tile = local / P.nsplit;
+  const int tn = tile % P.nt, tm = tile / P.nt;
+  const int m0 = 64 * tm, n0 = 64 * tn;
+  const int kchunk = P.kchunk;
+  const int k0 = split * kchunk;
+  const int k1 = min(P.K, k0 + kchunk);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
+  bool mok[4], nok[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    mok[q] = (m0 + 16 * q + i) < P.M;
+    nok[q] = (n0 + 16 * q + i) < P.N;
+  }
+  const float* __restrict__ Ap = P.A + m0 + i;
+  const float* __restrict__ Bp = P.B + n0 + i;
+  const bool ln = P.ln_mu != nullptr;
+
+#pragma unroll 2
+  for (int kb = k0; kb < k1; kb += 4) {
+    const int k = kb + g;
+    const bool kok = k < k1;
+    float av[4], bv[4];
+    const float* ar = Ap + (int64_t)k * P.lda;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) av[q] = (kok && mok[q]) ? ar[16 * q] : 0.f;
+    const int kbrow = k - P.b_shift;
+    const bool bok = kok && kbrow >= 0;
+    const float* br = Bp + (int64_t)kbrow * P.ldb;
+    float mu = 0.f, rs = 1.f;
+    if (ln && bok) {
+      mu = P.ln_mu[kbrow];
+      rs = P.ln_rstd[kbrow];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float v = (bok && nok[q]) ? br[16 * q] : 0.f;
+      if (ln) v = (bok && nok[q]) ? (v - mu) * rs : 0.f;
+      bv[q] = v;
+    }
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      cs[mi] += av[mi];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16(av[mi], bv[ni], acc[mi][ni]);
+    }
+  }
+  float* out = raw + P.raw_base + (int64_t)split * P.raw_stride;
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + 16 * mi + 4 * g + r;
+      if (m < P.M) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          const int n = n0 + 16 * ni + i;
+          if (n < P.N) out[P.out_off + (int64_t)m * P.ldc + n] = acc[mi][ni][r];
+        }
+      }
+    }
+  if (P.s_off >= 0 && tn == 0) {
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const float s = rowsum4(cs[mi]);
+      const int m = m0 + 16 * mi + i;
+      if (g == 0 && m < P.M) out[P.s_off + m] = s;
+    }
+  }
+}
+
+int wg_finish(WgTable* tb) {
+  int waves = 0;
+  for (int q = 0; q < tb->n; ++q) {
+    WgProb& P = tb->p[q];
+    if (P.M < 1 || P.N < 1 || P.K < 1 || P.nsplit < 1) return OPE_EINVAL;
+    P.mt = ope_cdiv(P.M, 64);
+    P.nt = ope_cdiv(P.N, 64);
+    P.kchunk = 4 * ope_cdiv(ope_cdiv(P.K, P.nsplit), 4);
+    P.wave_begin = waves;
+    waves += P.mt * P.nt * P.nsplit;
+  }
+  tb->total_waves = waves;
+  return OPE_OK;
+}
+
+int launch_wgrad(const WgTable& tb, float* raw, hipStream_t st) {
+  if (tb.n < 1 || tb.total_waves < 1) return OPE_EINVAL;
+  hipLaunchKernelGGL(wgrad_kernel, dim3(ope_cdiv(tb.total_waves, 4)), dim3(256), 0, st, tb, raw);
+  if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
+  return OPE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// rsum[i] = sum_s raw[s][i]  (fixed order).
+// ---------------------------------------------------------------------------------------------------------
+__global__ void split_reduce_kernel(const float* __restrict__ raw, int64_t stride, int nsplit, int64_t n, float* __restrict__ rsum) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int q = 0; q < nsplit; ++q) s += raw[(int64_t)q * stride + i];
+  rsum[i] = s;
+}
+
+int launch_split_reduce(const float* raw, int64_t stride, int nsplit, int64_t n, float* rsum, hipStream_t st) {
+  hipLaunchKernelGGL(split_reduce_kernel, dim3(ope_cdiv(n, 256)), dim3(256), 0, st, raw, stride, nsplit, n, rsum);
+  if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
+  return OPE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// finalize: map reduced raw quantities to the flat gradient vector.
+//   COPY     grad = rsum[src + local]
+//   LNLIN_W  Linear fed by a LayerNorm: dW[i][k] = P[i][k] gamma[k] + s[i] beta[k],  P = dOut^T xhat, s = colsum(dOut)
+//   LNLIN_G  that LayerNorm's weight:   dgamma[k] = sum_i W[i][k] P[i][k]
+//   LNLIN_B  that LayerNorm's bias:     dbeta[k]  = sum_i s[i] W[i][k]
+//   ZERO     registered-but-unused tensors (fc_h) and padding
+//   TAIL     [loss_sum, mask_count, qtot_sum, 0] summed over the per-tile partials
+// ---------------------------------------------------------------------------------------------------------
+__global__ void finalize_kernel(FinTable ft, const float* __restrict__ rsum, const float* __restrict__ theta,
+                                const float* __restrict__ loss_part, int n_loss_tiles, float* __restrict__ grad) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= ft.total) return;
+  int s = 0;
+#pragma unroll 1
+  for (int q = 1; q < ft.n; ++q)
+    if (idx >= ft.seg[q].begin) s = q;
+  const FinSeg& F = ft.seg[s];
+  const int local = (int)(idx - F.begin);
+  float out = 0.f;
+  if (local < F.size) {
+    switch (F.kind) {
+      case FIN_COPY:
+        out = rsum[F.src + local];
+        break;
+      case FIN_LNLIN_W: {
+        const int i = local / F.K, k = local - i * F.K;
+        out = rsum[F.src + local] * theta[F.gamma + k] + rsum[F.src_s + i] * theta[F.beta + k];
+        break;
+      }
+      case FIN_LNLIN_G: {
+        float acc = 0.f;
+        for (int i = 0; i < F.M; ++i) acc = fmaf(theta[F.w + (int64_t)i * F.K + local], rsum[F.src + (int64_t)i * F.K + local], acc);
+        out = acc;
+        break;
+      }
+      case FIN_LNLIN_B: {
+        float acc = 0.f;
+        for (int i = 0; i < F.M; ++i) acc = fmaf(rsum[F.src_s + i], theta[F.w + (int64_t)i * F.K + local], acc);
+        out = acc;
+        break;
+      }
+      case FIN_TAIL: {
+        if (local < 3) {
+          float acc = 0.f;
+          for (int q = 0; q < n_loss_tiles; ++q) acc += loss_part[q * 4 + local];
+          out = acc;
+        }
+        break;
+      }
+      default:
+        out = 0.f;
+    }
+  }
+  grad[idx] = out;
+}
+
+int launch_finalize(const FinTable& ft, const float* rsum, const float* theta, const float* loss_part, int n_loss_tiles,
+                    float* grad, hipStream_t st) {
+  hipLaunchKernelGGL(finalize_kernel, dim3(ope_cdiv(ft.total, 256)), dim3(256), 0, st, ft, rsum, theta, loss_part,
+                     n_loss_tiles, grad);
+  if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
+  return OPE_OK;
+}
+
+}  // namespace ope

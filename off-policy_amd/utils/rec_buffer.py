@@ -1,0 +1,215 @@
+"""Episode replay for recurrent policies, resident in HBM.
+
+Drop-in mirror of offpolicy/utils/rec_buffer.py (`RecReplayBuffer` 10-82, `RecPolicyBuffer` 85-240,
+`PrioritizedRecReplayBuffer` 243-324): same constructor arguments, `insert`, `sample`, `update_priorities`,
+`__len__`, same 9-tuple of `{policy_id: array}` dicts. Differences by design:
+
+* storage is EPISODE-major float32 on the GPU (`[capacity, T(+1), N, dim]`), written by `ope_store_insert`;
+* `sample()` runs `ope_store_gather` and returns torch CUDA tensors shaped exactly like the reference's arrays
+  (`[N, T(+1), B, dim]` views over `[T(+1), N, B, dim]` memory), which is also the `[T(+1), N*B, dim]` row-stacked
+  layout the trainer kernels read -- no host round trip, no `torch.cat`. `.cpu().numpy()` on any of them gives the
+  reference's array bit for bit.
+* PER `insert` gives EVERY inserted slot the max priority (the reference only touches `range(idx[0], idx[1])`, which
+  crashes for one episode and skips slots otherwise: SURVEY.md Appendix A-3).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .ring import RingIndex
+from .segment_tree import SumSegmentTree, MinSegmentTree
+from .spaces import get_dim_from_space
+
+_FIELD_ORDER = ("obs", "share_obs", "acts", "rewards", "dones", "dones_env", "avail_acts")
+
+
+def _shape_of(space):
+    name = space.__class__.__name__
+    if name == "Box":
+        return tuple(space.shape)
+    if name == "list":
+        return tuple(space)
+    raise NotImplementedError
+
+
+class RecPolicyBuffer(object):
+    def __init__(self, buffer_size, episode_length, num_agents, obs_space, share_obs_space, act_space,
+                 use_same_share_obs, use_avail_acts, use_reward_normalization=False, device=None):
+        self.buffer_size = int(buffer_size)
+        self.episode_length = int(episode_length)
+        self.num_agents = int(num_agents)
+        self.use_same_share_obs = use_same_share_obs
+        self.use_avail_acts = use_avail_acts
+        self.use_reward_normalization = use_reward_normalization
+        if not use_same_share_obs:
+            raise NotImplementedError("per-agent centralized observations are not on the accelerated path yet")
+        if use_reward_normalization:
+            raise NotImplementedError("reward normalisation (rec_buffer.py:209-223) is a SURVEY section 8(f) 'next' row")
+        self.device = torch.device(device if device is not None else "cuda:0")
+        self._ring = RingIndex(self.buffer_size)
+        obs_dim = _shape_of(obs_space)[0]
+        share_dim = _shape_of(share_obs_space)[0]
+        act_dim = int(np.sum(get_dim_from_space(act_space)))
+        T, cap, N = self.episode_length, self.buffer_size, self.num_agents
+        self.dims = _lib.Dims(N, act_dim, obs_dim, share_dim, T)
+        z = dict(dtype=torch.float32, device=self.device)
+        # same initial values as rec_buffer.py:120-141 (avail/dones/dones_env default to ones)
+        self.obs = torch.zeros((cap, T + 1, N, obs_dim), **z)
+        self.share_obs = torch.zeros((cap, T + 1, share_dim), **z)
+        self.acts = torch.zeros((cap, T, N, act_dim), **z)
+        self.avail_acts = torch.ones((cap, T + 1, N, act_dim), **z) if use_avail_acts else None
+        self.rewards = torch.zeros((cap, T, N, 1), **z)
+        self.dones = torch.ones((cap, T, N, 1), **z)
+        self.dones_env = torch.ones((cap, T, 1), **z)
+
+    # reference attribute names
+    @property
+    def filled_i(self):
+        return self._ring.filled_i
+
+    @property
+    def current_i(self):
+        return self._ring.current_i
+
+    def __len__(self):
+        return self._ring.filled_i
+
+    def _fields(self, tensors):
+        f = _lib.Fields()
+        for k in _FIELD_ORDER:
+            setattr(f, k, _lib.ptr(tensors.get(k)).value)
+        return f
+
+    def _store_fields(self):
+        return self._fields(dict(obs=self.obs, share_obs=self.share_obs, acts=self.acts, rewards=self.rewards,
+                                 dones=self.dones, dones_env=self.dones_env, avail_acts=self.avail_acts))
+
+    def insert(self, num_insert_episodes, obs, share_obs, acts, rewards, dones, dones_env, avail_acts=None):
+        """Ring write of `num_insert_episodes` episodes given in the reference's time-major layout
+        ([T(+1), n, N, dim]); returns idx_range like rec_buffer.py:146-190."""
+        acts = np.asarray(acts)
+        assert acts.shape[0] == self.episode_length, ("different dimension!")
+        n = int(num_insert_episodes)
+        idx_range = self._ring.next_slots(n)
+        share_obs = np.asarray(share_obs)
+        if share_obs.ndim == 4:
+            share_obs = share_obs[:, :, 0]          # all agents share the centralized observation
+        host = dict(obs=obs, share_obs=share_obs, acts=acts, rewards=rewards, dones=dones, dones_env=dones_env)
+        if self.use_avail_acts:
+            host["avail_acts"] = avail_acts
+        staged = {k: torch.from_numpy(np.ascontiguousarray(np.asarray(v), dtype=np.float32)).to(self.device, non_blocking=False)
+                  for k, v in host.items()}
+        slots = torch.from_numpy(np.asarray(idx_range, dtype=np.int64)).to(self.device)
+        sf, df = self._fields(staged), self._store_fields()
+        if not self.use_avail_acts:
+            sf.avail_acts = None
+        _lib.check(_lib.lib.ope_store_insert(C.byref(self.dims), self.buffer_size, C.byref(df), C.byref(sf),
+                                             _lib.ptr(slots), n, _lib.current_stream()), "ope_store_insert")
+        self._keepalive = (staged, slots)   # until the stream has consumed them
+        return idx_range
+
+    def sample_inds(self, sample_inds):
+        """Gather the given episode slots; same 7-tuple as rec_buffer.py:192-240 (CUDA tensors, reference shapes)."""
+        inds = np.asarray(sample_inds, dtype=np.int64)
+        B = int(inds.shape[0])
+        d = self.dims
+        T, N = d.episode_length, d.n_agents
+        dev_inds = torch.from_numpy(inds).to(self.device)
+        e = dict(dtype=torch.float32, device=self.device)
+        out = dict(obs=torch.empty((T + 1, N, B, d.obs_dim), **e), share_obs=torch.empty((T + 1, B, d.state_dim), **e),
+                   acts=torch.empty((T, N, B, d.act_dim), **e), rewards=torch.empty((T, N, B, 1), **e),
+                   dones=torch.empty((T, N, B, 1), **e), dones_env=torch.empty((T, B, 1), **e))
+        if self.use_avail_acts:
+            out["avail_acts"] = torch.empty((T + 1, N, B, d.act_dim), **e)
+        of, sf = self._fields(out), self._store_fields()
+        _lib.check(_lib.lib.ope_store_gather(C.byref(d), self.buffer_size, C.byref(sf), _lib.ptr(dev_inds), B,
+                                             C.byref(of), _lib.current_stream()), "ope_store_gather")
+        cast = lambda x: x.permute(1, 0, 2, 3)      # [N, T(+1), B, dim] view, as the reference's _cast
+        return (cast(out["obs"]), out["share_obs"], cast(out["acts"]), cast(out["rewards"]), cast(out["dones"]),
+                out["dones_env"], cast(out["avail_acts"]) if self.use_avail_acts else None)
+
+
+class RecReplayBuffer(object):
+    def __init__(self, policy_info, policy_agents, buffer_size, episode_length, use_same_share_obs, use_avail_acts,
+                 use_reward_normalization=False, device=None):
+        self.policy_info = policy_info
+        self.policy_buffers = {p_id: RecPolicyBuffer(buffer_size, episode_length, len(policy_agents[p_id]),
+                                                     self.policy_info[p_id]['obs_space'],
+                                                     self.policy_info[p_id]['share_obs_space'],
+                                                     self.policy_info[p_id]['act_space'],
+                                                     use_same_share_obs, use_avail_acts, use_reward_normalization,
+                                                     device=device)
+                               for p_id in self.policy_info.keys()}
+
+    def __len__(self):
+        return self.policy_buffers['policy_0'].filled_i
+
+    def insert(self, num_insert_episodes, obs, share_obs, acts, rewards, dones, dones_env, avail_acts):
+        for p_id in self.policy_info.keys():
+            idx_range = self.policy_buffers[p_id].insert(num_insert_episodes, np.array(obs[p_id]),
+                                                         np.array(share_obs[p_id]), np.array(acts[p_id]),
+                                                         np.array(rewards[p_id]), np.array(dones[p_id]),
+                                                         np.array(dones_env[p_id]), np.array(avail_acts[p_id]))
+        return idx_range
+
+    def _gather(self, inds):
+        keys = ({}, {}, {}, {}, {}, {}, {})
+        for p_id in self.policy_info.keys():
+            for dst, val in zip(keys, self.policy_buffers[p_id].sample_inds(inds)):
+                dst[p_id] = val
+        return keys
+
+    def sample(self, batch_size):
+        """Uniform sampling WITH replacement from the global numpy RNG, as rec_buffer.py:76."""
+        inds = np.random.choice(self.__len__(), batch_size)
+        return self._gather(inds) + (None, None)
+
+
+class PrioritizedRecReplayBuffer(RecReplayBuffer):
+    def __init__(self, alpha, policy_info, policy_agents, buffer_size, episode_length, use_same_share_obs,
+                 use_avail_acts, use_reward_normalization=False, device=None):
+        super(PrioritizedRecReplayBuffer, self).__init__(policy_info, policy_agents, buffer_size, episode_length,
+                                                         use_same_share_obs, use_avail_acts, use_reward_normalization,
+                                                         device=device)
+        self.alpha = alpha
+        it_capacity = 1
+        while it_capacity < buffer_size:
+            it_capacity *= 2
+        self._it_sums = {p_id: SumSegmentTree(it_capacity) for p_id in self.policy_info.keys()}
+        self._it_mins = {p_id: MinSegmentTree(it_capacity) for p_id in self.policy_info.keys()}
+        self.max_priorities = {p_id: 1.0 for p_id in self.policy_info.keys()}
+
+    def insert(self, num_insert_episodes, obs, share_obs, acts, rewards, dones, dones_env, avail_acts=None):
+        idx_range = super().insert(num_insert_episodes, obs, share_obs, acts, rewards, dones, dones_env, avail_acts)
+        for p_id in self.policy_info.keys():      # A-3 fix: every new slot, not range(idx[0], idx[1])
+            self._it_sums[p_id][idx_range] = self.max_priorities[p_id] ** self.alpha
+            self._it_mins[p_id][idx_range] = self.max_priorities[p_id] ** self.alpha
+        return idx_range
+
+    def _sample_proportional(self, batch_size, p_id=None):
+        total = self._it_sums[p_id].sum(0, len(self) - 1)
+        mass = np.random.random(size=batch_size) * total
+        return self._it_sums[p_id].find_prefixsum_idx(mass)
+
+    def sample(self, batch_size, beta=0, p_id=None):
+        assert len(self) > batch_size, "Cannot sample with no completed episodes in the buffer!"
+        assert beta > 0
+        batch_inds = self._sample_proportional(batch_size, p_id)
+        p_min = self._it_mins[p_id].min() / self._it_sums[p_id].sum()
+        max_weight = (p_min * len(self)) ** (-beta)
+        p_sample = self._it_sums[p_id][batch_inds] / self._it_sums[p_id].sum()
+        weights = (p_sample * len(self)) ** (-beta) / max_weight
+        return self._gather(batch_inds) + (weights, batch_inds)
+
+    def update_priorities(self, idxes, priorities, p_id=None):
+        priorities = np.asarray(priorities)
+        idxes = np.asarray(idxes)
+        assert len(idxes) == len(priorities)
+        assert np.min(priorities) > 0
+        assert np.min(idxes) >= 0
+        assert np.max(idxes) < len(self)
+        self._it_sums[p_id][idxes] = priorities ** self.alpha
+        self._it_mins[p_id][idxes] = priorities ** self.alpha
+        self.max_priorities[p_id] = max(self.max_priorities[p_id], np.max(priorities))

@@ -1,0 +1,107 @@
+"""CPU-only checks: the C-ABI library loads and exports everything include/ope.h declares; host-side logic
+(ring slots, segment trees, parameter layout, init stream) behaves like the reference."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden, sub
+
+
+def test_library_exports_every_declared_symbol():
+    from offpolicy_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "ope.h")).read()
+    declared = set(re.findall(r"\b(ope_[a-z_0-9]+)\s*\(", hdr))
+    declared -= {"ope_dims", "ope_fields", "ope_qmix_cfg", "ope_adam_cfg"}
+    lib = C.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libope.so lacks %s declared in include/ope.h" % name
+    assert _lib.lib.ope_version() == 1
+    assert _lib.lib.ope_strerror(-1).decode().startswith("invalid")
+
+
+def test_param_layout_and_episode_bytes_match_survey():
+    from offpolicy_amd import _lib
+    cfg = _lib.QmixCfg()
+    cfg.dims = _lib.Dims(8, 14, 252, 216, 150)
+    cfg.batch = 32
+    off, siz = (C.c_int64 * 36)(), (C.c_int64 * 36)()
+    total = _lib.lib.ope_qmix_param_layout(C.byref(cfg), off, siz)
+    assert sum(siz) == 118791            # SURVEY.md section 8 a6 (51 398 agent + 67 393 mixer)
+    assert sum(list(siz)[:22]) == 51398
+    assert total >= 118791 and total % 4 == 0 and all(o % 4 == 0 for o in off)
+    assert _lib.lib.ope_episode_bytes(C.byref(cfg.dims)) == 1493176
+    cfg.dims = _lib.Dims(3, 9, 64, 48, 60)
+    assert _lib.lib.ope_qmix_param_layout(C.byref(cfg), off, siz) > 0 and sum(siz) == 58026
+    assert _lib.lib.ope_episode_bytes(C.byref(cfg.dims)) == 73308
+    cfg.dims = _lib.Dims(3, 9, 1000, 48, 60)        # unsupported obs width -> error code, no crash
+    assert _lib.lib.ope_qmix_param_layout(C.byref(cfg), off, siz) == -1
+    assert _lib.lib.ope_qmix_workspace_bytes(C.byref(cfg)) == -1
+
+
+def test_null_arguments_are_rejected_without_a_gpu():
+    from offpolicy_amd import _lib
+    assert _lib.lib.ope_adam_step(None, 4, None, None, None, None, None, None, None, None) == -1
+    assert _lib.lib.ope_polyak(0, None, None, 0.5, None) == -1
+    d = _lib.Dims(2, 5, 12, 10, 6)
+    assert _lib.lib.ope_store_gather(C.byref(d), 4, None, None, 2, None, None) == -1
+
+
+@pytest.mark.parametrize("name", ["qmix_tiny", "qmix_3m_katA", "qmix_odd"])
+def test_initialisation_reproduces_reference_rng_stream(name):
+    """torch.manual_seed(1) + our constructors' init draws == the reference modules' initial weights, bit for bit."""
+    import torch
+    from offpolicy_amd.algorithms.qmix.algorithm.agent_q_function import init_agent_values, AGENT_PARAM_NAMES
+    from offpolicy_amd.algorithms.qmix.algorithm.q_mixer import init_mixer_values, MIXER_PARAM_NAMES
+    g = load_golden(name)
+    n, a, d, s, t = [int(x) for x in g["dims"]]
+    torch.manual_seed(1)
+    np.random.seed(1)
+    av = init_agent_values(d, a)
+    mv = init_mixer_values(n, s)
+    for v, k in zip(av, AGENT_PARAM_NAMES):
+        assert np.array_equal(v.numpy(), g["agent/" + k]), k
+    for v, k in zip(mv, MIXER_PARAM_NAMES):
+        assert np.array_equal(v.numpy(), g["mixer/" + k]), k
+
+
+def test_ring_index_matches_reference_fixture():
+    from offpolicy_amd.utils.ring import RingIndex
+    g = load_golden("qmix_tiny")
+    r = RingIndex(6)
+    assert np.array_equal(r.next_slots(4), g["pre_idx_range"])
+    assert np.array_equal(r.next_slots(5), g["idx_range"])       # wraps: [4, 5, 0, 1, 2]
+    assert r.filled_i == int(g["filled_i"]) and r.current_i == int(g["current_i"])
+    with pytest.raises(AssertionError):
+        r.next_slots(7)
+
+
+def test_segment_trees_against_bruteforce():
+    from offpolicy_amd.utils.segment_tree import SumSegmentTree, MinSegmentTree
+    rng = np.random.RandomState(0)
+    cap = 64
+    st, mt = SumSegmentTree(cap), MinSegmentTree(cap)
+    arr = np.zeros(cap)
+    arrm = np.full(cap, np.inf)
+    for _ in range(30):
+        idx = rng.randint(0, cap, size=rng.randint(1, 9))
+        val = rng.rand(len(idx)) + 0.01
+        st[idx] = val
+        mt[idx] = val
+        for i, v in zip(idx, val):
+            arr[i] = v
+            arrm[i] = v
+        lo = rng.randint(0, cap)
+        hi = rng.randint(lo + 1, cap + 1)
+        np.testing.assert_allclose(st.sum(lo, hi), arr[lo:hi].sum(), rtol=1e-12)
+        assert mt.min(lo, hi) == arrm[lo:hi].min()
+        np.testing.assert_allclose(st.sum(), arr.sum(), rtol=1e-12)
+        mass = rng.rand(7) * st.sum()
+        got = st.find_prefixsum_idx(mass)
+        cs = np.cumsum(arr)
+        want = np.searchsorted(cs, mass, side="right")
+        assert np.array_equal(got, np.minimum(want, cap - 1))
+    with pytest.raises(AssertionError):
+        SumSegmentTree(48)

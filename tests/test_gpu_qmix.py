@@ -1,0 +1,166 @@
+"""-m gpu: the HIP QMIX/VDN training step (through the C-ABI) against the reference's frozen outputs and the oracle.
+
+Tolerances (fp32, different reduction orders): loss / grad_norm / Q_tot rtol 1e-4,
+priorities rtol 1e-4, gradients rtol 2e-3 of the tensor's max magnitude, parameters after 3 Adam steps atol 3e-5.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, sub
+from golden_util import oracle_from, reference_store_from
+from gpu_util import build_from_fixture, batch_from
+
+pytestmark = pytest.mark.gpu
+CASES = ["qmix_tiny", "qmix_tiny_huber_per", "qmix_tiny_nodouble", "vdn_tiny", "qmix_odd", "qmix_3m_katA"]
+RTOL = 1e-4
+
+
+def _flat_named(trainer, flat):
+    """{group/name: np.ndarray} views of a flat vector using the trainer's modules' specs."""
+    out = {}
+    pol = trainer.policies["policy_0"]
+    for name, (shape, off) in pol.q_network.spec().items():
+        n = int(np.prod(shape))
+        out["agent/" + name] = flat[off:off + n].view(shape).cpu().numpy()
+    if not trainer.vdn:
+        for name, (shape, off) in trainer.mixer.spec().items():
+            n = int(np.prod(shape))
+            out["mixer/" + name] = flat[off:off + n].view(shape).cpu().numpy()
+    return out
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_train_steps_match_reference(name):
+    g = load_golden(name)
+    dims, buf, policy, trainer = build_from_fixture(g)
+    w = g["per_weights"] if "per_weights" in g else None
+    batch = batch_from(buf, g["inds"], w)
+    for s in range(len(g["loss"])):
+        info, prio, _ = trainer.train_policy_on_batch(batch)
+        if s == 0:
+            cnt = float(trainer.grad[trainer.numel + 1])
+            coef = min(1.0, float(g["hp_maxnorm"]) / (float(g["grad_norm"][0]) + 1e-6))
+            got = _flat_named(trainer, trainer.grad[:trainer.numel] * (coef / cnt))
+            for k, ref in sub(g, "grad0/").items():
+                tol = 2e-3 * max(np.abs(ref).max(), 1e-6)
+                np.testing.assert_allclose(got[k], ref, rtol=0, atol=tol, err_msg="grad " + k)
+            for k in got:
+                if ".fc_h." in k:
+                    assert not np.any(got[k]), k
+        trainer.soft_target_updates()
+        np.testing.assert_allclose(float(info["loss"]), g["loss"][s], rtol=RTOL)
+        np.testing.assert_allclose(float(info["grad_norm"]), g["grad_norm"][s], rtol=RTOL)
+        np.testing.assert_allclose(float(info["Q_tot"]), g["Q_tot"][s], rtol=RTOL, atol=1e-6)
+        if w is not None:
+            np.testing.assert_allclose(prio, g["priorities"][s], rtol=RTOL, atol=1e-6)
+    live, tgt = _flat_named(trainer, trainer.theta), _flat_named(trainer, trainer.theta_tgt)
+    for grp, src, key in (("final_agent/", live, "agent/"), ("final_agent_tgt/", tgt, "agent/"),
+                          ("final_mixer/", live, "mixer/"), ("final_mixer_tgt/", tgt, "mixer/")):
+        for k, ref in sub(g, grp).items():
+            np.testing.assert_allclose(src[key + k], ref, rtol=0, atol=3e-5, err_msg=grp + k)
+    # the nn.Module views see the same memory (checkpoint path of the reference runner)
+    sd = policy.q_network.state_dict()
+    assert list(sd.keys()) == list(sub(g, "agent/").keys())
+    np.testing.assert_array_equal(sd["q.action_out.weight"].cpu().numpy(), live["agent/q.action_out.weight"])
+
+
+@pytest.mark.parametrize("name", ["qmix_tiny", "qmix_odd"])
+def test_forward_intermediates_match_oracle(name):
+    """Per-stage check (helps localise a failure): live q values, chosen/target agent q, Q_tot of both mixers."""
+    from oracle import qmix_oracle as O
+    from offpolicy_amd import _lib
+    g = load_golden(name)
+    dims, buf, policy, trainer = build_from_fixture(g)
+    _lib.lib.ope_set_debug(1)
+    try:
+        batch = batch_from(buf, g["inds"])
+        trainer.train_policy_on_batch(batch)
+        torch.cuda.synchronize()
+    finally:
+        _lib.lib.ope_set_debug(0)
+    orc, _ = oracle_from(g)
+    store, _ = reference_store_from(g)
+    ob = O.sample_inds(store, g["inds"])
+    obs, share, acts, rew, dones, dones_env, avail = [torch.as_tensor(np.ascontiguousarray(x)) for x in ob]
+    N, T1, B, D = obs.shape
+    T = T1 - 1
+    s_obs = torch.cat(list(obs), dim=-2)
+    q_all, _ = O.agent_q_forward(orc.agent, s_obs, torch.zeros(N * B, 64))
+    got_q = trainer.workspace_view(B, "q_all").view(T1, N * B, dims.act_dim).cpu()
+    np.testing.assert_allclose(got_q.numpy(), q_all.numpy(), rtol=1e-4, atol=2e-6)
+    got_h = trainer.workspace_view(B, "h").view(T1, N * B, 64).cpu()
+    x = O.mlp_trunk(orc.agent, s_obs)
+    hseq, _ = O.gru_sequence(orc.agent, x, torch.zeros(N * B, 64))
+    np.testing.assert_allclose(got_h.numpy(), hseq.numpy(), rtol=1e-4, atol=2e-6)
+    _, (err, keep, q_tot) = orc.q_tot_and_error(orc.agent, orc.mixer, ob)
+    got_qtot = trainer.workspace_view(B, "qtot").view(T, B).cpu()
+    np.testing.assert_allclose(got_qtot.numpy(), q_tot[..., 0].numpy(), rtol=1e-4, atol=2e-6)
+    got_err = trainer.workspace_view(B, "err_abs").view(T, B).cpu()
+    np.testing.assert_allclose(got_err.numpy(), err.abs()[..., 0].numpy(), rtol=1e-4, atol=2e-6)
+
+
+def test_deterministic_bitwise():
+    """Same inputs twice -> bit-identical gradient vector (no atomics on the path)."""
+    g = load_golden("qmix_tiny")
+    outs = []
+    for _ in range(2):
+        dims, buf, policy, trainer = build_from_fixture(g)
+        trainer.train_policy_on_batch(batch_from(buf, g["inds"]))
+        outs.append(trainer.grad.cpu().numpy().copy())
+    assert np.array_equal(outs[0], outs[1])
+
+
+def test_policy_forward_matches_oracle_single_step_and_sequence():
+    """policy.get_q_values (ope_agent_forward) with a non-zero initial hidden state."""
+    from oracle import qmix_oracle as O
+    g = load_golden("qmix_tiny")
+    dims, buf, policy, trainer = build_from_fixture(g)
+    P = {k: torch.as_tensor(v) for k, v in sub(g, "agent/").items()}
+    torch.manual_seed(3)
+    obs = torch.randn(5, 7, dims.obs_dim)
+    h0 = torch.randn(7, 64) * 0.5
+    q_ref, h_ref = O.agent_q_forward(P, obs, h0)
+    q, h = policy.get_q_values(obs.cuda(), None, h0.cuda())
+    np.testing.assert_allclose(q.cpu().numpy(), q_ref.numpy(), rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(h.cpu().numpy(), h_ref.numpy(), rtol=1e-4, atol=2e-6)
+    q1, h1 = policy.get_q_values(obs[0].cuda(), None, h0.cuda())
+    np.testing.assert_allclose(q1.cpu().numpy(), q_ref[0].numpy(), rtol=1e-4, atol=2e-6)
+    acts, hn, gq = policy.get_actions(obs[0].cuda(), None, h0.cuda(), available_actions=np.ones((7, dims.act_dim)))
+    assert acts.shape == (7, dims.act_dim) and np.allclose(acts.sum(-1), 1)
+    assert np.array_equal(acts.argmax(-1), q_ref[0].argmax(-1).numpy())
+
+
+def test_full_size_3s5z_matches_oracle_one_step():
+    """BASELINE config 4 at full size (N=8, A=14, D=252, S=216, T=150, B=32): one step vs the oracle."""
+    from oracle import qmix_oracle as O
+    from offpolicy_amd.config import default_args
+    from offpolicy_amd.utils.synth import DIMS, synth_episodes, policy_info_for, as_policy_dicts
+    from offpolicy_amd.utils.rec_buffer import RecReplayBuffer
+    from offpolicy_amd.algorithms.qmix.algorithm.QMixPolicy import QMixPolicy
+    from offpolicy_amd.algorithms.qmix.qmix import QMix
+    dims = DIMS["3s5z"]
+    args = default_args()
+    torch.manual_seed(1)
+    np.random.seed(1)
+    dev = torch.device("cuda:0")
+    policy = QMixPolicy({"args": args, "device": dev}, policy_info_for(dims)["policy_0"])
+    trainer = QMix(args, dims.n_agents, {"policy_0": policy}, lambda a: "policy_0", device=dev, episode_length=dims.episode_length)
+    buf = RecReplayBuffer(policy_info_for(dims), {"policy_0": list(range(dims.n_agents))}, 32, dims.episode_length, True, True, device=dev)
+    ep = synth_episodes(np.random.RandomState(0), 32, dims, avail="bernoulli")
+    d = as_policy_dicts(ep)
+    buf.insert(32, d["obs"], d["share_obs"], d["acts"], d["rewards"], d["dones"], d["dones_env"], d["avail_acts"])
+    inds = np.arange(32)
+    agent0 = {k: v.detach().cpu().numpy().copy() for k, v in policy.q_network.named_parameters()}
+    mixer0 = {k: v.detach().cpu().numpy().copy() for k, v in trainer.mixer.named_parameters()}
+    info, _, _ = trainer.train_policy_on_batch(batch_from(buf, inds))
+    orc = O.QMixOracle(agent0, mixer0, dims.n_agents, O.HP())
+    st = {k: (ep[k][:, :, 0] if k == "share_obs" else ep[k]) for k in ("obs", "share_obs", "acts", "rewards", "dones", "dones_env", "avail_acts")}
+    out = orc.train_step(O.sample_inds(st, inds), fused_gru=True, soft_update=False)
+    np.testing.assert_allclose(float(info["loss"]), out["loss"], rtol=RTOL)
+    np.testing.assert_allclose(float(info["grad_norm"]), out["grad_norm"], rtol=RTOL)
+    np.testing.assert_allclose(float(info["Q_tot"]), out["Q_tot"], rtol=RTOL, atol=1e-6)
+    for k, v in policy.q_network.named_parameters():
+        np.testing.assert_allclose(v.detach().cpu().numpy(), orc.agent[k].numpy(), rtol=0, atol=2e-5, err_msg=k)
+    for k, v in trainer.mixer.named_parameters():
+        np.testing.assert_allclose(v.detach().cpu().numpy(), orc.mixer[k].numpy(), rtol=0, atol=2e-5, err_msg=k)
