@@ -1,0 +1,197 @@
+#!/usr/bin/env python
+"""Headline benchmark: training steps/sec of the QMIX-RNN update path on MI355X (BASELINE.json metric).
+
+One "step" = buffer.sample(B) + trainer.train_policy_on_batch(batch) + soft target update, the unit the reference's
+RecRunner.batch_train_q performs per training call (offpolicy/runner/rnn/base_runner.py:259-284). Replay is filled
+with synthetic episodes of the named SMAC map's dimensions; weights are random-init.
+
+    python bench.py [--gpus N --steps K --warmup W] [--workload 3s5z|3m|MMM2] [--batch 32] [--scaling weak|strong]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line. `value` = (episodes consumed per second by the whole job) / batch, i.e. batch-`B`
+training steps per second; `roofline` is for the replay gather kernel (HBM-bound); `cpu_baseline` is the CPU port
+(oracle/, same arithmetic as the reference's CPU path) timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md; ~6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="3s5z", choices=["3m", "3s5z", "MMM2"])
+    ap.add_argument("--batch", type=int, default=32, help="episodes per training step on ONE GPU (weak) / in total (strong)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--episodes", type=int, default=256, help="synthetic episodes resident in the replay store")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for each CPU-baseline leg")
+    return ap.parse_args()
+
+
+def fill_buffer(buf, dims, n_episodes, rng):
+    from offpolicy_amd.utils.synth import synth_episodes, as_policy_dicts
+    done = 0
+    while done < n_episodes:
+        n = min(32, n_episodes - done)
+        ep = synth_episodes(rng, n, dims, avail="bernoulli")
+        d = as_policy_dicts(ep)
+        buf.insert(n, d["obs"], d["share_obs"], d["acts"], d["rewards"], d["dones"], d["dones_env"], d["avail_acts"])
+        done += n
+
+
+def cpu_baseline(dims, batch, seconds):
+    """Time the CPU port (oracle: same torch-CPU ops as the reference) on a bounded sample of the same workload:
+    sample B of 64 synthetic episodes + train step + soft update, with 1 thread (the reference's default
+    n_training_threads, config.py:17) and with all host cores; report the faster, as the >=10x target demands."""
+    from oracle import qmix_oracle as O
+    from offpolicy_amd.utils.synth import synth_episodes
+    from offpolicy_amd.algorithms.qmix.algorithm.agent_q_function import init_agent_values, AGENT_PARAM_NAMES
+    from offpolicy_amd.algorithms.qmix.algorithm.q_mixer import init_mixer_values, MIXER_PARAM_NAMES
+    torch.manual_seed(1)
+    agent = dict(zip(AGENT_PARAM_NAMES, init_agent_values(dims.obs_dim, dims.act_dim)))
+    mixer = dict(zip(MIXER_PARAM_NAMES, init_mixer_values(dims.n_agents, dims.state_dim)))
+    n_ep = 64
+    ep = synth_episodes(np.random.RandomState(0), n_ep, dims, avail="bernoulli")
+    store = {k: (ep[k][:, :, 0] if k == "share_obs" else ep[k]) for k in ("obs", "share_obs", "acts", "rewards", "dones", "dones_env", "avail_acts")}
+    res = {}
+    ncores = os.cpu_count() or 1
+    for threads in (1, ncores):
+        torch.set_num_threads(threads)
+        orc = O.QMixOracle(agent, mixer, dims.n_agents, O.HP())
+        rng = np.random.RandomState(1)
+
+        def step():
+            inds = rng.choice(n_ep, batch)
+            orc.train_step(O.sample_inds(store, inds), fused_gru=True, soft_update=True)
+        step()                                   # warm-up
+        t0 = time.perf_counter()
+        n = 0
+        while True:
+            step()
+            n += 1
+            el = time.perf_counter() - t0
+            if el >= seconds or n >= 200:
+                break
+        res[threads] = (n / el, n, el)
+        if ncores == 1:
+            break
+    best = max(res, key=lambda k: res[k][0])
+    return {"value": round(res[best][0], 4), "unit": "training steps/sec", "cores": best, "kind": "port",
+            "sample": "%d steps of B=%d on %s dims, 64 synthetic episodes, %.1f s; 1-thread: %.3f steps/s (%d steps)%s" % (
+                res[best][1], batch, dims.name, res[best][2], res[1][0], res[1][1],
+                "" if ncores == 1 else "; %d-thread: %.3f steps/s" % (ncores, res[ncores][0]))}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == a.gpus, "--gpus must equal WORLD_SIZE (launch with torch.distributed.run for N > 1)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.distributed.init_process_group("nccl", device_id=dev)
+
+    from offpolicy_amd import _lib
+    from offpolicy_amd.config import default_args
+    from offpolicy_amd.utils.synth import DIMS, policy_info_for
+    from offpolicy_amd.utils.rec_buffer import RecReplayBuffer
+    from offpolicy_amd.algorithms.qmix.algorithm.QMixPolicy import QMixPolicy
+    from offpolicy_amd.algorithms.qmix.qmix import QMix
+    import ctypes as C
+
+    dims = DIMS[a.workload]
+    args = default_args()
+    if a.scaling == "weak":
+        local_batch, global_batch = a.batch, a.batch * world
+    else:
+        assert a.batch % world == 0
+        local_batch, global_batch = a.batch // world, a.batch
+    torch.manual_seed(1)                 # identical initial weights on every rank
+    np.random.seed(1)
+    pinfo = policy_info_for(dims)
+    policy = QMixPolicy({"args": args, "device": dev}, pinfo["policy_0"])
+    trainer = QMix(args, dims.n_agents, {"policy_0": policy}, lambda x: "policy_0", device=dev, episode_length=dims.episode_length)
+    trainer.fuse_soft_update = True      # Polyak inside the Adam kernel; soft_target_updates() below then skips
+    buf = RecReplayBuffer(pinfo, {"policy_0": list(range(dims.n_agents))}, a.episodes, dims.episode_length, True, True, device=dev)
+    fill_buffer(buf, dims, a.episodes, np.random.RandomState(100 + rank))   # every rank holds its own replay shard
+    np.random.seed(1000 + rank)          # ranks draw different episodes (data parallel)
+    pbuf = buf.policy_buffers["policy_0"]
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+
+    def one_step(i=None):
+        inds = np.random.choice(len(buf), local_batch)
+        s = pbuf.sample_inds(inds, timing_events=ev[i] if i is not None else None)   # ope_store_gather, current stream
+        batch = tuple({"policy_0": x} for x in s) + (None, None)
+        info, _, _ = trainer.train_policy_on_batch(batch)
+        trainer.soft_target_updates()
+        return info
+
+    for _ in range(a.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        info = one_step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tt[0])
+    gather_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
+    loss = float(info["loss"])
+    assert np.isfinite(loss), "training diverged"
+
+    if rank == 0:
+        ep_bytes = int(_lib.lib.ope_episode_bytes(C.byref(pbuf.dims)))
+        algo_bytes = 2.0 * local_batch * ep_bytes            # read from the store + write of the batch
+        achieved = algo_bytes / (gather_ms * 1e-3) / 1e9
+        steps_per_s = a.steps / elapsed
+        value = steps_per_s * (global_batch / float(a.batch))
+        out = {
+            "metric": "training steps/sec (batch=%d) QMIX-RNN %s" % (a.batch, a.workload),
+            "value": round(value, 3), "unit": "training steps/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(1e3 * elapsed / a.steps, 4), "higher_is_better": True, "scaling": a.scaling,
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "QMIX-RNN SMAC %s (N=%d A=%d D=%d S=%d T=%d), replay filled with %d synthetic episodes, "
+                                   "step = sample + train_policy_on_batch + soft target update" % (
+                                       a.workload, dims.n_agents, dims.act_dim, dims.obs_dim, dims.state_dim, dims.episode_length, a.episodes),
+                       "batch_per_gpu": local_batch, "global_batch": global_batch, "parallelism": "dp%d" % world,
+                       "optimizer_steps_per_sec": round(steps_per_s, 3), "final_loss": round(loss, 6)},
+            "roofline": {"kernel": "episode_copy_kernel<gather> (ope_store_gather)", "bound": "hbm", "achieved": round(achieved, 2),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": int(algo_bytes), "avg_launch_ms": round(gather_ms, 5),
+                         "timing": "HIP events on the launch stream recorded immediately around each gather launch in the timed region"},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(dims, a.batch, a.cpu_seconds)
+            out["config"]["speedup_vs_cpu_port"] = round(value / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -180,6 +180,7 @@ extern "C" int64_t ope_qmix_workspace_find(const ope_qmix_cfg* cfg, const char* 
 extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields* batch, const float* theta,
                                       const float* theta_tgt, const float* per_weights, void* workspace,
                                       int64_t workspace_bytes, float* grad, float* td_abs_stats, void* stream) {
+  (void)hipGetLastError();  // drop stale errors from the caller's own HIP use
   if (!cfg_ok(cfg) || !batch || !theta || !theta_tgt || !workspace || !grad) return OPE_EINVAL;
   if (!batch->obs || !batch->share_obs || !batch->acts || !batch->rewards || !batch->dones_env) return OPE_EINVAL;
   if (cfg->use_per && !per_weights) return OPE_EINVAL;
@@ -364,6 +365,7 @@ extern "C" int64_t ope_agent_forward_workspace_bytes(const ope_dims* d, int32_t 
 extern "C" int ope_agent_forward(const ope_dims* d, int32_t seq_len, int32_t rows, const float* obs, const float* h0,
                                  const float* theta, void* workspace, int64_t workspace_bytes, float* q_out, float* h_out,
                                  void* stream) {
+  (void)hipGetLastError();  // drop stale errors from the caller's own HIP use
   if (!d || seq_len < 1 || rows < 1 || !obs || !theta || !workspace || !q_out || !h_out) return OPE_EINVAL;
   if (d->obs_dim < 1 || d->obs_dim > 512 || d->act_dim < 1) return OPE_EINVAL;
   if (workspace_bytes < ope_agent_forward_workspace_bytes(d, seq_len, rows)) return OPE_ENOSPC;

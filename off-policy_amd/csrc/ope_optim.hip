@@ -98,6 +98,7 @@ extern "C" int64_t ope_adam_scratch_floats(int64_t n) { return n < 1 ? OPE_EINVA
 
 extern "C" int ope_adam_step(const ope_adam_cfg* cfg, int64_t n, float* theta, float* theta_tgt, float* adam_m, float* adam_v,
                              const float* grad, float* scratch, float* stats_out, void* stream) {
+  (void)hipGetLastError();  // drop stale errors from the caller's own HIP use
   if (!cfg || n < 1 || (n & 3) || !theta || !adam_m || !adam_v || !grad || !scratch) return OPE_EINVAL;
   if (cfg->do_polyak && !theta_tgt) return OPE_EINVAL;
   if (cfg->step < 1) return OPE_EINVAL;
@@ -119,6 +120,7 @@ extern "C" int ope_adam_step(const ope_adam_cfg* cfg, int64_t n, float* theta, f
 }
 
 extern "C" int ope_polyak(int64_t n, const float* theta, float* theta_tgt, float tau, void* stream) {
+  (void)hipGetLastError();  // drop stale errors from the caller's own HIP use
   if (n < 1 || !theta || !theta_tgt) return OPE_EINVAL;
   hipLaunchKernelGGL(polyak_kernel, dim3(ope_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, n, theta, theta_tgt, tau);
   OPE_CHECK_LAUNCH();

@@ -130,6 +130,7 @@ extern "C" int64_t ope_episode_bytes(const ope_dims* d) {
 
 extern "C" int ope_store_gather(const ope_dims* dims, int32_t capacity, const ope_fields* store, const int64_t* inds,
                                 int32_t batch, const ope_fields* out, void* stream) {
+  (void)hipGetLastError();  // drop stale errors from the caller's own HIP use
   if (capacity < 1 || !inds) return OPE_EINVAL;
   CopyArgs args;
   int rc = build_args(dims, store, out, batch, &args);
@@ -142,6 +143,7 @@ extern "C" int ope_store_gather(const ope_dims* dims, int32_t capacity, const op
 
 extern "C" int ope_store_insert(const ope_dims* dims, int32_t capacity, const ope_fields* store, const ope_fields* staged,
                                 const int64_t* slots, int32_t n_insert, void* stream) {
+  (void)hipGetLastError();  // drop stale errors from the caller's own HIP use
   if (capacity < 1 || !slots) return OPE_EINVAL;
   CopyArgs args;
   int rc = build_args(dims, staged, store, n_insert, &args);

@@ -110,8 +110,9 @@ class RecPolicyBuffer(object):
         self._keepalive = (staged, slots)   # until the stream has consumed them
         return idx_range
 
-    def sample_inds(self, sample_inds):
-        """Gather the given episode slots; same 7-tuple as rec_buffer.py:192-240 (CUDA tensors, reference shapes)."""
+    def sample_inds(self, sample_inds, timing_events=None):
+        """Gather the given episode slots; same 7-tuple as rec_buffer.py:192-240 (CUDA tensors, reference shapes).
+        `timing_events`: optional (start, end) torch.cuda.Event pair recorded tightly around the gather launch."""
         inds = np.asarray(sample_inds, dtype=np.int64)
         B = int(inds.shape[0])
         d = self.dims
@@ -124,8 +125,12 @@ class RecPolicyBuffer(object):
         if self.use_avail_acts:
             out["avail_acts"] = torch.empty((T + 1, N, B, d.act_dim), **e)
         of, sf = self._fields(out), self._store_fields()
+        if timing_events is not None:
+            timing_events[0].record()
         _lib.check(_lib.lib.ope_store_gather(C.byref(d), self.buffer_size, C.byref(sf), _lib.ptr(dev_inds), B,
                                              C.byref(of), _lib.current_stream()), "ope_store_gather")
+        if timing_events is not None:
+            timing_events[1].record()
         cast = lambda x: x.permute(1, 0, 2, 3)      # [N, T(+1), B, dim] view, as the reference's _cast
         return (cast(out["obs"]), out["share_obs"], cast(out["acts"]), cast(out["rewards"]), cast(out["dones"]),
                 out["dones_env"], cast(out["avail_acts"]) if self.use_avail_acts else None)

