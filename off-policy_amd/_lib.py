@@ -6,6 +6,9 @@ module raises -- there is no eager-PyTorch or CPU fallback.
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- MUST precede loading libope.so: torch's ROCm wheel bundles its own libamdhip64; loading
+#                          ours first would put a second HIP runtime in the process and every launch on a torch stream fails.
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libope.so")
 

@@ -65,53 +65,80 @@ int launch_head_bwd(const HeadBwdArgs& a, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// gru_bwd. Lane k owns hidden feature k and keeps COLUMN k of W_hh (192 floats) in VGPRs:
+// gru_bwd. Lane k owns hidden feature k and keeps COLUMN k of W_hh (192 floats as 96 float2) in VGPRs:
 //   dh_{t-1}[k] = dh_t[k] z[k] + sum_i ( W_hr[i][k] dr_pre[i] + W_hz[i][k] dz_pre[i] + W_hn[i][k] dghn[i] )
-// with the three 64-vectors broadcast lane-by-lane (v_readlane).
+// The three 64-vectors go through the wave's private LDS slot and come back as broadcast ds_read_b128; the
+// 192-long reduction runs as packed FMAs on 12 independent partial sums.
 // ---------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) gru_bwd_kernel(GruBwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float ds[4][3 * OPE_H];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = blockIdx.x * 4 + wave;
   if (row >= a.NB) return;
-  float wr[OPE_H], wz[OPE_H], wn[OPE_H];
+  f32x2 wr[OPE_H / 2], wz[OPE_H / 2], wn[OPE_H / 2];
   {
     const float* w = a.theta + a.whh_off;
 #pragma unroll
-    for (int i = 0; i < OPE_H; ++i) {
-      wr[i] = w[(int64_t)i * OPE_H + lane];
-      wz[i] = w[(int64_t)(OPE_H + i) * OPE_H + lane];
-      wn[i] = w[(int64_t)(2 * OPE_H + i) * OPE_H + lane];
+    for (int i = 0; i < OPE_H / 2; ++i) {
+      wr[i] = f32x2{w[(int64_t)(2 * i) * OPE_H + lane], w[(int64_t)(2 * i + 1) * OPE_H + lane]};
+      wz[i] = f32x2{w[(int64_t)(OPE_H + 2 * i) * OPE_H + lane], w[(int64_t)(OPE_H + 2 * i + 1) * OPE_H + lane]};
+      wn[i] = f32x2{w[(int64_t)(2 * OPE_H + 2 * i) * OPE_H + lane], w[(int64_t)(2 * OPE_H + 2 * i + 1) * OPE_H + lane]};
     }
   }
   float dh = 0.f;
   const int64_t NB = a.NB;
+  float* my = ds[wave];
+  // software prefetch of the per-step saved activations
+  int64_t o = ((int64_t)(a.T - 1) * NB + row) * OPE_H + lane;
+  float r = a.rg[o], z = a.zg[o], n = a.ng[o], gn = a.ghn[o], dho = a.dh_out[o];
+  float hp = a.T - 1 > 0 ? a.h[o - NB * OPE_H] : 0.f;
   for (int t = a.T - 1; t >= 0; --t) {
-    const int64_t o = ((int64_t)t * NB + row) * OPE_H + lane;
-    const float r = a.rg[o], z = a.zg[o], n = a.ng[o], gn = a.ghn[o];
-    const float hp = t > 0 ? a.h[o - NB * OPE_H] : 0.f;
-    const float dht = dh + a.dh_out[o];
+    float r2 = 0.f, z2 = 0.f, n2 = 0.f, gn2 = 0.f, dho2 = 0.f, hp2 = 0.f;
+    const int64_t o2 = o - NB * OPE_H;
+    if (t > 0) {
+      r2 = a.rg[o2]; z2 = a.zg[o2]; n2 = a.ng[o2]; gn2 = a.ghn[o2]; dho2 = a.dh_out[o2];
+      hp2 = t - 1 > 0 ? a.h[o2 - NB * OPE_H] : 0.f;
+    }
+    const float dht = dh + dho;
     const float dn = dht * (1.0f - z);
     const float dzg = dht * (hp - n);
     const float dn_pre = dn * (1.0f - n * n);
     const float dz_pre = dzg * z * (1.0f - z);
     const float dr_pre = dn_pre * gn * r * (1.0f - r);
     const float dgn = dn_pre * r;
+    my[lane] = dr_pre;
+    my[OPE_H + lane] = dz_pre;
+    my[2 * OPE_H + lane] = dgn;
+    __builtin_amdgcn_wave_barrier();
     float* gout = a.dgi + ((int64_t)t * NB + row) * (3 * OPE_H) + lane;
     gout[0] = dr_pre;
     gout[OPE_H] = dz_pre;
     gout[2 * OPE_H] = dn_pre;
     a.dghn[o] = dgn;
-    float acc = dht * z;
+    f32x2 c0 = {dht * z, 0.f}, c1 = {0.f, 0.f}, c2 = {0.f, 0.f}, c3 = {0.f, 0.f}, c4 = {0.f, 0.f}, c5 = {0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < OPE_H; ++i) {
-      const float b0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dr_pre), i));
-      const float b1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dz_pre), i));
-      const float b2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dgn), i));
-      acc = fmaf(wr[i], b0, acc);
-      acc = fmaf(wz[i], b1, acc);
-      acc = fmaf(wn[i], b2, acc);
+    for (int blk = 0; blk < 4; ++blk) {
+      f32x4 rv[4], zv[4], nv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        rv[q] = *reinterpret_cast<const f32x4*>(my + 16 * blk + 4 * q);
+        zv[q] = *reinterpret_cast<const f32x4*>(my + OPE_H + 16 * blk + 4 * q);
+        nv[q] = *reinterpret_cast<const f32x4*>(my + 2 * OPE_H + 16 * blk + 4 * q);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i2 = 8 * blk + 2 * q;
+        c0 = __builtin_elementwise_fma(wr[i2], f32x2{rv[q][0], rv[q][1]}, c0);
+        c1 = __builtin_elementwise_fma(wr[i2 + 1], f32x2{rv[q][2], rv[q][3]}, c1);
+        c2 = __builtin_elementwise_fma(wz[i2], f32x2{zv[q][0], zv[q][1]}, c2);
+        c3 = __builtin_elementwise_fma(wz[i2 + 1], f32x2{zv[q][2], zv[q][3]}, c3);
+        c4 = __builtin_elementwise_fma(wn[i2], f32x2{nv[q][0], nv[q][1]}, c4);
+        c5 = __builtin_elementwise_fma(wn[i2 + 1], f32x2{nv[q][2], nv[q][3]}, c5);
+      }
     }
-    dh = acc;
+    __builtin_amdgcn_wave_barrier();
+    dh = ((c0[0] + c0[1]) + (c1[0] + c1[1])) + ((c2[0] + c2[1]) + (c3[0] + c3[1])) + ((c4[0] + c4[1]) + (c5[0] + c5[1]));
+    r = r2; z = z2; n = n2; gn = gn2; dho = dho2; hp = hp2; o = o2;
   }
 }
 

@@ -142,11 +142,23 @@ int launch_trunk_fwd(const TrunkFwdArgs& a, bool save, hipStream_t st) {
 
 // ---------------------------------------------------------------------------------------------------------
 // gru_fwd. One wave per (agent,episode) row; lane f owns hidden feature f and keeps rows f, 64+f, 128+f of W_hh
-// (192 floats) in VGPRs. h_{t-1}[k] is broadcast from lane k with v_readlane. No LDS, no barriers: the T+1 steps
-// are a pure dependent chain per wave, and all rows of the live AND target networks run concurrently.
+// (192 floats, as 96 float2) in VGPRs. Each step the wave publishes h_{t-1} (64 floats) to its private LDS slot and
+// every lane reads it back with 16 broadcast ds_read_b128; the three 64-long dot products run as packed FMAs
+// (v_pk_fma_f32) on 12 independent partial sums so the FMA pipe never waits on a dependent accumulate. No
+// barriers: the T+1 steps are a pure dependent chain per wave, and all rows of the live AND target networks run
+// concurrently (one wave per SIMD).
 //   r = sigma(gi_r + gh_r), z = sigma(gi_z + gh_z), n = tanh(gi_n + r*gh_n), h' = (1-z) n + z h      (nn.GRU)
 // ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) {
+  // tanh(|x|) = (1 - e) / (1 + e), e = exp(-2|x|): absolute error ~1e-7 everywhere
+  const float e = __expf(-2.0f * fabsf(x));
+  const float t = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
+  return copysignf(t, x);
+}
+
 __global__ void __launch_bounds__(256) gru_fwd_kernel(GruFwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float hs[4][OPE_H];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int rid = blockIdx.x * 4 + wave;  // 0 .. nets*NB
   if (rid >= a.nets * a.NB) return;
@@ -157,20 +169,14 @@ __global__ void __launch_bounds__(256) gru_fwd_kernel(GruFwdArgs a) {
   float* __restrict__ hout = net == 0 ? a.h0out : a.h1out;
   const bool save = (net == 0) && (a.rg != nullptr);
 
-  float wr[OPE_H], wz[OPE_H], wn[OPE_H];
+  f32x2 wr[OPE_H / 2], wz[OPE_H / 2], wn[OPE_H / 2];
   {
     const float* w = th + a.whh_off;
 #pragma unroll
-    for (int k = 0; k < OPE_H; k += 4) {
-      const f32x4 x = *reinterpret_cast<const f32x4*>(w + (int64_t)lane * OPE_H + k);
-      const f32x4 y = *reinterpret_cast<const f32x4*>(w + (int64_t)(OPE_H + lane) * OPE_H + k);
-      const f32x4 z = *reinterpret_cast<const f32x4*>(w + (int64_t)(2 * OPE_H + lane) * OPE_H + k);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        wr[k + r] = x[r];
-        wz[k + r] = y[r];
-        wn[k + r] = z[r];
-      }
+    for (int k = 0; k < OPE_H / 2; ++k) {
+      wr[k] = *reinterpret_cast<const f32x2*>(w + (int64_t)lane * OPE_H + 2 * k);
+      wz[k] = *reinterpret_cast<const f32x2*>(w + (int64_t)(OPE_H + lane) * OPE_H + 2 * k);
+      wn[k] = *reinterpret_cast<const f32x2*>(w + (int64_t)(2 * OPE_H + lane) * OPE_H + 2 * k);
     }
   }
   const float br = th[a.bhh_off + lane], bz = th[a.bhh_off + OPE_H + lane], bn = th[a.bhh_off + 2 * OPE_H + lane];
@@ -179,7 +185,10 @@ __global__ void __launch_bounds__(256) gru_fwd_kernel(GruFwdArgs a) {
   const int64_t stride_t = (int64_t)a.NB;
   const float* gp = gi + (int64_t)row * (3 * OPE_H) + lane;
   float gir = gp[0], giz = gp[OPE_H], gin = gp[2 * OPE_H];
+  float* myhs = hs[wave];
   for (int t = 0; t < a.L; ++t) {
+    myhs[lane] = h;
+    __builtin_amdgcn_wave_barrier();
     // prefetch next step's input projections
     float nr = 0.f, nz = 0.f, nn = 0.f;
     if (t + 1 < a.L) {
@@ -188,17 +197,31 @@ __global__ void __launch_bounds__(256) gru_fwd_kernel(GruFwdArgs a) {
       nz = q[OPE_H];
       nn = q[2 * OPE_H];
     }
-    float ar = br, az = bz, an = bn;
+    f32x2 ar0 = {br, 0.f}, ar1 = {0.f, 0.f}, az0 = {bz, 0.f}, az1 = {0.f, 0.f}, an0 = {bn, 0.f}, an1 = {0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < OPE_H; ++k) {
-      const float hk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, h), k));
-      ar = fmaf(wr[k], hk, ar);
-      az = fmaf(wz[k], hk, az);
-      an = fmaf(wn[k], hk, an);
+    for (int half = 0; half < 2; ++half) {
+      f32x4 hv[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) hv[q] = *reinterpret_cast<const f32x4*>(myhs + 32 * half + 4 * q);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int k2 = 16 * half + 2 * q;
+        const f32x2 lo = {hv[q][0], hv[q][1]}, hi = {hv[q][2], hv[q][3]};
+        ar0 = __builtin_elementwise_fma(wr[k2], lo, ar0);
+        az0 = __builtin_elementwise_fma(wz[k2], lo, az0);
+        an0 = __builtin_elementwise_fma(wn[k2], lo, an0);
+        ar1 = __builtin_elementwise_fma(wr[k2 + 1], hi, ar1);
+        az1 = __builtin_elementwise_fma(wz[k2 + 1], hi, az1);
+        an1 = __builtin_elementwise_fma(wn[k2 + 1], hi, an1);
+      }
     }
-    const float r = sigmoidf_(gir + ar);
-    const float z = sigmoidf_(giz + az);
-    const float n = tanhf(gin + r * an);
+    __builtin_amdgcn_wave_barrier();
+    const float ar = (ar0[0] + ar0[1]) + (ar1[0] + ar1[1]);
+    const float az = (az0[0] + az0[1]) + (az1[0] + az1[1]);
+    const float an = (an0[0] + an0[1]) + (an1[0] + an1[1]);
+    const float r = fast_sigmoid(gir + ar);
+    const float z = fast_sigmoid(giz + az);
+    const float n = fast_tanh(gin + r * an);
     h = (1.0f - z) * n + z * h;
     const int64_t o = ((int64_t)t * stride_t + row) * OPE_H + lane;
     hout[o] = h;

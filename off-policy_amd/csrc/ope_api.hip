@@ -60,7 +60,7 @@ struct Plan {
   int64_t mu0, rstd0, xhat1, rstd1, mask1, xhat2, rstd2, mask2, gi, h, rg, zg, ng, ghn, xhat_o, rstd_o, act_idx,
       agent_q, agent_nq, gi_t, h_t, qtot, nqtot, hw1, hw2, hb2, v1, hpre, v2, loss_part, err_abs, dqtot, d_agent_q,
       d_b1, d_v2, d_v1, d_hw1, d_hw2, d_hb2, dh_out, dqoh, dgi, dghn, dz1, dz2, thetaT, mixT, raw_agent, raw_mixer,
-      rsum, q_all;
+      rsum, q_all, loss_tot;
 };
 
 int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
@@ -108,6 +108,7 @@ void make_plan(const ope_qmix_cfg* c, Plan* p) {
   p->hw1 = W.add("hw1", TB * OPE_HYP); p->hw2 = W.add("hw2", TB * OPE_HYP); p->hb2 = W.add("hb2", TB * OPE_HYP);
   p->v1 = W.add("v1", TB * p->NM); p->hpre = W.add("hpre", TB * OPE_MIX); p->v2 = W.add("v2", TB * OPE_MIX);
   p->loss_part = W.add("loss_part", (int64_t)p->n_loss_tiles * 4);
+  p->loss_tot = W.add("loss_tot", 4);
   p->err_abs = W.add("err_abs", TB); p->dqtot = W.add("dqtot", TB); p->d_agent_q = W.add("d_agent_q", TB * p->N);
   p->d_b1 = W.add("d_b1", TB * OPE_MIX); p->d_v2 = W.add("d_v2", TB * OPE_MIX); p->d_v1 = W.add("d_v1", TB * p->NM);
   p->d_hw1 = W.add("d_hw1", TB * OPE_HYP); p->d_hw2 = W.add("d_hw2", TB * OPE_HYP); p->d_hb2 = W.add("d_hb2", TB * OPE_HYP);
@@ -351,7 +352,8 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
   seg((int)p.P, OPE_GRAD_TAIL, FIN_TAIL, 0, 0, 0, 0, 0, 0, 0);
   ft.n = k;
   ft.total = p.P + OPE_GRAD_TAIL;
-  if ((rc = launch_finalize(ft, W + p.rsum, theta, W + p.loss_part, p.n_loss_tiles, grad, st))) return rc;
+  if ((rc = launch_loss_reduce(W + p.loss_part, p.n_loss_tiles, W + p.loss_tot, st))) return rc;
+  if ((rc = launch_finalize(ft, W + p.rsum, theta, W + p.loss_tot, p.n_loss_tiles, grad, st))) return rc;
   return OPE_OK;
 }
 

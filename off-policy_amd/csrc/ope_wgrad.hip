@@ -48,11 +48,10 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgTable tb, float* __restric
   const float* __restrict__ Bp = P.B + n0 + i;
   const bool ln = P.ln_mu != nullptr;
 
-#pragma unroll 2
-  for (int kb = k0; kb < k1; kb += 4) {
+  // operand fetch for the 4 reduction rows kb..kb+3 (lane group g takes row kb+g); software-pipelined one step ahead
+  auto fetch = [&](int kb, float (&av)[4], float (&bv)[4]) {
     const int k = kb + g;
     const bool kok = k < k1;
-    float av[4], bv[4];
     const float* ar = Ap + (int64_t)k * P.lda;
 #pragma unroll
     for (int q = 0; q < 4; ++q) av[q] = (kok && mok[q]) ? ar[16 * q] : 0.f;
@@ -70,11 +69,21 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgTable tb, float* __restric
       if (ln) v = (bok && nok[q]) ? (v - mu) * rs : 0.f;
       bv[q] = v;
     }
+  };
+  float av[4], bv[4], an[4], bn[4];
+  fetch(k0, av, bv);
+  for (int kb = k0; kb < k1; kb += 4) {
+    fetch(kb + 4, an, bn);   // rows beyond k1 come back as zeros
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
       cs[mi] += av[mi];
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16(av[mi], bv[ni], acc[mi][ni]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      av[q] = an[q];
+      bv[q] = bn[q];
     }
   }
   float* out = raw + P.raw_base + (int64_t)split * P.raw_stride;
@@ -182,19 +191,38 @@ __global__ void finalize_kernel(FinTable ft, const float* __restrict__ rsum, con
         out = acc;
         break;
       }
-      case FIN_TAIL: {
-        if (local < 3) {
-          float acc = 0.f;
-          for (int q = 0; q < n_loss_tiles; ++q) acc += loss_part[q * 4 + local];
-          out = acc;
-        }
+      case FIN_TAIL:
+        out = loss_part[local];   // already reduced by loss_reduce_kernel
         break;
-      }
       default:
         out = 0.f;
     }
   }
   grad[idx] = out;
+}
+
+// [tiles][4] loss partials -> 4 totals, one block, fixed summation tree (deterministic).
+__global__ void __launch_bounds__(256) loss_reduce_kernel(const float* __restrict__ part, int tiles, float* __restrict__ out) {
+  __shared__ float sm[4][4];
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int q = threadIdx.x; q < tiles; q += 256) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(part + 4 * q);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) s[c] += v[c];
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+    for (int o = 32; o > 0; o >>= 1) s[c] += __shfl_xor(s[c], o, 64);
+  if ((threadIdx.x & 63) == 0)
+    for (int c = 0; c < 4; ++c) sm[threadIdx.x >> 6][c] = s[c];
+  __syncthreads();
+  if (threadIdx.x < 4) out[threadIdx.x] = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+}
+
+int launch_loss_reduce(const float* part, int tiles, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, st, part, tiles, out);
+  if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
+  return OPE_OK;
 }
 
 int launch_finalize(const FinTable& ft, const float* rsum, const float* theta, const float* loss_part, int n_loss_tiles,
