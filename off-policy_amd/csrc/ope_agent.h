@@ -111,6 +111,23 @@ __device__ __forceinline__ void gemm64(const float* __restrict__ W, int ld, int 
   }
 }
 
+// Same, RT row tiles sharing every weight fragment (8 MFMAs per float4 of weights at RT = 2).
+template <int NT, int RT>
+__device__ __forceinline__ void gemm64rt(const float* __restrict__ W, int ld, int j, int g, const f32x4 (&act)[RT][4],
+                                         f32x4 (&acc)[RT][NT]) {
+#pragma unroll
+  for (int it = 0; it < NT; ++it) {
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(W + (int64_t)(16 * it + j) * ld + 16 * ft + 4 * g);
+#pragma unroll
+      for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][it] = mfma16(w[r], act[t][ft][r], acc[t][it]);
+    }
+  }
+}
+
 // ReLU then LayerNorm over the 64 features of a row held as acc[it][r] = feature 16it+4g+r (4 lanes per row).
 // Outputs: act = xhat*gamma+beta; if SAVE, acc is overwritten with xhat; rstd; mbits bit (4it+r) = (z > 0).
 template <bool SAVE>

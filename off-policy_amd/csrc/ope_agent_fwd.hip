@@ -9,126 +9,176 @@
 namespace ope {
 
 // ---------------------------------------------------------------------------------------------------------
-// trunk_fwd. One wave = 16 data rows through the whole MLP trunk; weights stream from L2 as the MFMA A operand.
-// MAXKC = max number of 16-feature chunks of the input row kept in registers (D <= 16*MAXKC).
+// trunk_fwd. One wave = RT x 16 data rows through the whole MLP trunk; weights stream from L2 as the MFMA A operand
+// and every weight fragment is reused by the RT row tiles. The K loop of the first (widest) layer is branch-free
+// (clamped loads, masked gamma/beta) and register double-buffered: the loads of chunk c+1 are in flight while the
+// 16*RT MFMAs of chunk c issue.
 // ---------------------------------------------------------------------------------------------------------
-template <int VEC, int MAXKC, bool SAVE>
+template <int VEC, int RT>
+struct TrunkChunk {
+  f32x4 w[4];       // fc1 rows 16it+j, features k..k+3
+  f32x4 gam, bet;   // feature-norm affine (zeroed beyond D)
+  f32x4 x[RT];
+};
+
+template <int VEC, int RT>
+__device__ __forceinline__ void trunk_fetch(TrunkChunk<VEC, RT>& ch, const float* __restrict__ th, const AgentLayout& L,
+                                            const float* const (&xrow)[RT], int j, int k, int D) {
+#pragma unroll
+  for (int it = 0; it < 4; ++it) ch.w[it] = load4c<VEC>(th + L.fc1_w + (int64_t)(16 * it + j) * D, k, D);
+  ch.gam = load4c<VEC>(th + L.fn_w, k, D);
+  ch.bet = load4c<VEC>(th + L.fn_b, k, D);
+#pragma unroll
+  for (int t = 0; t < RT; ++t) ch.x[t] = load4c<VEC>(xrow[t], k, D);
+}
+
+template <int VEC, int RT, bool SAVE>
 __global__ void __launch_bounds__(256) trunk_fwd_kernel(TrunkFwdArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, g = lane >> 4;
-  const int tile = blockIdx.x * 4 + wave;
-  const int row0 = tile * 16;
+  const int row0 = (blockIdx.x * 4 + wave) * (16 * RT);
   if (row0 >= a.R) return;
-  const int row = row0 + j;
-  const bool valid = row < a.R;
   const int D = a.D;
   const int KC = (D + 15) >> 4;
   const float* __restrict__ th = a.theta;
-  const float* __restrict__ xrow = a.x + (int64_t)(valid ? row : row0) * D;
-
-  // ---- input LayerNorm statistics (two-pass, exact) over the row held as 4 lanes x KC float4 ----
-  f32x4 xf[MAXKC];
-  float s = 0.f;
+  int row[RT];
+  bool valid[RT];
+  const float* xrow[RT];
 #pragma unroll
-  for (int c = 0; c < MAXKC; ++c) {
-    xf[c] = (c < KC) ? load4<VEC>(xrow, 16 * c + 4 * g, D) : f32x4{0.f, 0.f, 0.f, 0.f};
-    s += (xf[c][0] + xf[c][1]) + (xf[c][2] + xf[c][3]);
-  }
-  const float mu = rowsum4(s) / (float)D;
-  float v = 0.f;
-#pragma unroll
-  for (int c = 0; c < MAXKC; ++c) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int k = 16 * c + 4 * g + r;
-      const float dlt = (c < KC && k < D) ? (xf[c][r] - mu) : 0.f;
-      v = fmaf(dlt, dlt, v);
-    }
-  }
-  const float rstd = 1.0f / sqrtf(rowsum4(v) / (float)D + OPE_LN_EPS);
-  if (SAVE && valid && g == 0) {
-    a.mu0[row] = mu;
-    a.rstd0[row] = rstd;
+  for (int t = 0; t < RT; ++t) {
+    row[t] = row0 + 16 * t + j;
+    valid[t] = row[t] < a.R;
+    xrow[t] = a.x + (int64_t)min(row[t], a.R - 1) * D;
   }
 
-  // ---- fc1: z1 = W1 (xhat*gamma+beta) + b1 ----
-  f32x4 acc[4];
+  // ---- input LayerNorm statistics: one pass, shifted by the row's first element (stable for mean != 0) ----
+  float mu[RT], rstd[RT];
+  {
+    float s1[RT], s2[RT], sh[RT];
 #pragma unroll
-  for (int it = 0; it < 4; ++it) acc[it] = load4<4>(th + a.L.fc1_b, 16 * it + 4 * g, OPE_H);
-#pragma unroll
-  for (int c = 0; c < MAXKC; ++c) {
-    if (c < KC) {
+    for (int t = 0; t < RT; ++t) { s1[t] = 0.f; s2[t] = 0.f; sh[t] = xrow[t][0]; }
+    for (int c = 0; c < KC; ++c) {
       const int k = 16 * c + 4 * g;
-      const f32x4 gam = load4<VEC>(th + a.L.fn_w, k, D);
-      const f32x4 bet = load4<VEC>(th + a.L.fn_b, k, D);
-      f32x4 xn;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) xn[r] = fmaf((xf[c][r] - mu) * rstd, gam[r], bet[r]);  // 0 beyond D (gam=bet=0)
+      for (int t = 0; t < RT; ++t) {
+        const f32x4 v = load4c<VEC>(xrow[t], k, D);
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const f32x4 w = load4<VEC>(th + a.L.fc1_w + (int64_t)(16 * it + j) * D, k, D);
+        for (int r = 0; r < 4; ++r) {
+          const float d = (k + r < D) ? v[r] - sh[t] : 0.f;
+          s1[t] += d;
+          s2[t] = fmaf(d, d, s2[t]);
+        }
+      }
+    }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[it] = mfma16(w[r], xn[r], acc[it]);
+    for (int t = 0; t < RT; ++t) {
+      const float m = rowsum4(s1[t]) / (float)D;
+      const float var = fmaxf(rowsum4(s2[t]) / (float)D - m * m, 0.f);
+      mu[t] = sh[t] + m;
+      rstd[t] = 1.0f / sqrtf(var + OPE_LN_EPS);
+      if (SAVE && valid[t] && g == 0) {
+        a.mu0[row[t]] = mu[t];
+        a.rstd0[row[t]] = rstd[t];
       }
     }
   }
 
-  // ---- ReLU + LN (64 features: 16 per lane, 4 lanes per row) ----
-  f32x4 act[4];
-  uint32_t mbits;
-  float rs;
-  relu_ln64<SAVE>(acc, th + a.L.ln1_w, th + a.L.ln1_b, g, act, &rs, &mbits);
-  if (SAVE && valid) {
+  // ---- fc1: z1 = W1 (xhat*gamma+beta) + b1, K loop double-buffered ----
+  f32x4 acc[RT][4];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) *reinterpret_cast<f32x4*>(a.xhat1 + (int64_t)row * OPE_H + 16 * it + 4 * g) = acc[it];
-    store_mask_rstd(a.mask1, a.rstd1, row, g, mbits, rs);
+  for (int t = 0; t < RT; ++t)
+#pragma unroll
+    for (int it = 0; it < 4; ++it) acc[t][it] = *reinterpret_cast<const f32x4*>(th + a.L.fc1_b + 16 * it + 4 * g);
+  {
+    // two named chunk buffers, loop unrolled by two: no register copies, so the compiler cannot fold the prefetch away.
+    // A chunk index past KC-1 is harmless: loads are clamped and gamma/beta are masked to zero -> its MFMAs add 0.
+    TrunkChunk<VEC, RT> bufA, bufB;
+    auto compute = [&](const TrunkChunk<VEC, RT>& ch, int c) {
+      const int k = 16 * c + 4 * g;
+      const f32x4 gam = mask4(ch.gam, k, D), bet = mask4(ch.bet, k, D);
+#pragma unroll
+      for (int t = 0; t < RT; ++t) {
+        f32x4 xn;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xn[r] = fmaf((ch.x[t][r] - mu[t]) * rstd[t], gam[r], bet[r]);  // exactly 0 beyond D
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[t][it] = mfma16(ch.w[it][r], xn[r], acc[t][it]);
+      }
+    };
+    trunk_fetch<VEC, RT>(bufA, th, a.L, xrow, j, 4 * g, D);
+    for (int c = 0; c < KC; c += 2) {
+      trunk_fetch<VEC, RT>(bufB, th, a.L, xrow, j, 16 * (c + 1) + 4 * g, D);
+      __builtin_amdgcn_sched_barrier(0);   // pin: loads of one buffer issue before the MFMAs of the other
+      compute(bufA, c);
+      __builtin_amdgcn_sched_barrier(0);
+      trunk_fetch<VEC, RT>(bufA, th, a.L, xrow, j, 16 * (c + 2) + 4 * g, D);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(bufB, c + 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
 
-  // ---- fc2 ----
-  f32x4 acc2[4];
+  // ---- ReLU + LN, fc2, ReLU + LN ----
+  f32x4 act[RT][4];
+  uint32_t mbits[RT];
+  float rs[RT];
 #pragma unroll
-  for (int it = 0; it < 4; ++it) acc2[it] = load4<4>(th + a.L.fc2_b, 16 * it + 4 * g, OPE_H);
-  gemm64<4>(th + a.L.fc2_w, OPE_H, j, g, act, acc2);
-  relu_ln64<SAVE>(acc2, th + a.L.ln2_w, th + a.L.ln2_b, g, act, &rs, &mbits);
-  if (SAVE && valid) {
+  for (int t = 0; t < RT; ++t) {
+    relu_ln64<SAVE>(acc[t], th + a.L.ln1_w, th + a.L.ln1_b, g, act[t], &rs[t], &mbits[t]);
+    if (SAVE && valid[t]) {
 #pragma unroll
-    for (int it = 0; it < 4; ++it) *reinterpret_cast<f32x4*>(a.xhat2 + (int64_t)row * OPE_H + 16 * it + 4 * g) = acc2[it];
-    store_mask_rstd(a.mask2, a.rstd2, row, g, mbits, rs);
+      for (int it = 0; it < 4; ++it) *reinterpret_cast<f32x4*>(a.xhat1 + (int64_t)row[t] * OPE_H + 16 * it + 4 * g) = acc[t][it];
+      store_mask_rstd(a.mask1, a.rstd1, row[t], g, mbits[t], rs[t]);
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) acc[t][it] = *reinterpret_cast<const f32x4*>(th + a.L.fc2_b + 16 * it + 4 * g);
+  }
+  gemm64rt<4, RT>(th + a.L.fc2_w, OPE_H, j, g, act, acc);
+#pragma unroll
+  for (int t = 0; t < RT; ++t) {
+    relu_ln64<SAVE>(acc[t], th + a.L.ln2_w, th + a.L.ln2_b, g, act[t], &rs[t], &mbits[t]);
+    if (SAVE && valid[t]) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) *reinterpret_cast<f32x4*>(a.xhat2 + (int64_t)row[t] * OPE_H + 16 * it + 4 * g) = acc[t][it];
+      store_mask_rstd(a.mask2, a.rstd2, row[t], g, mbits[t], rs[t]);
+    }
   }
 
   // ---- gi = W_ih a2 + b_ih : 192 outputs, 4 tiles at a time ----
 #pragma unroll
   for (int grp = 0; grp < 3; ++grp) {
-    f32x4 o[4];
+    f32x4 o[RT][4];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) o[it] = load4<4>(th + a.L.bih, 64 * grp + 16 * it + 4 * g, 3 * OPE_H);
-    gemm64<4>(th + a.L.wih + (int64_t)(64 * grp) * OPE_H, OPE_H, j, g, act, o);
-    if (valid) {
+    for (int t = 0; t < RT; ++t)
 #pragma unroll
-      for (int it = 0; it < 4; ++it)
-        *reinterpret_cast<f32x4*>(a.gi + (int64_t)row * (3 * OPE_H) + 64 * grp + 16 * it + 4 * g) = o[it];
-    }
+      for (int it = 0; it < 4; ++it) o[t][it] = *reinterpret_cast<const f32x4*>(th + a.L.bih + 64 * grp + 16 * it + 4 * g);
+    gemm64rt<4, RT>(th + a.L.wih + (int64_t)(64 * grp) * OPE_H, OPE_H, j, g, act, o);
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+      if (valid[t]) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+          *reinterpret_cast<f32x4*>(a.gi + (int64_t)row[t] * (3 * OPE_H) + 64 * grp + 16 * it + 4 * g) = o[t][it];
+      }
   }
 }
 
 template <int VEC, bool SAVE>
 static int launch_trunk_vec(const TrunkFwdArgs& a, hipStream_t st) {
-  const int blocks = ope_cdiv(ope_cdiv(a.R, 16), 4);
-  const int KC = (a.D + 15) / 16;
-  if (KC <= 4)
-    hipLaunchKernelGGL((trunk_fwd_kernel<VEC, 4, SAVE>), dim3(blocks), dim3(256), 0, st, a);
-  else if (KC <= 16)
-    hipLaunchKernelGGL((trunk_fwd_kernel<VEC, 16, SAVE>), dim3(blocks), dim3(256), 0, st, a);
-  else if (KC <= 32)
-    hipLaunchKernelGGL((trunk_fwd_kernel<VEC, 32, SAVE>), dim3(blocks), dim3(256), 0, st, a);
-  else
-    return OPE_EINVAL;
+  // two row tiles per wave once there is enough work to fill the chip that way
+  if (a.R >= 2 * 16 * 4 * 256) {
+    hipLaunchKernelGGL((trunk_fwd_kernel<VEC, 2, SAVE>), dim3(ope_cdiv(ope_cdiv(a.R, 32), 4)), dim3(256), 0, st, a);
+  } else {
+    hipLaunchKernelGGL((trunk_fwd_kernel<VEC, 1, SAVE>), dim3(ope_cdiv(ope_cdiv(a.R, 16), 4)), dim3(256), 0, st, a);
+  }
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   return OPE_OK;
 }
 
 int launch_trunk_fwd(const TrunkFwdArgs& a, bool save, hipStream_t st) {
-  if (a.R < 1 || a.D < 1) return OPE_EINVAL;
+  if (a.R < 1 || a.D < 4) return OPE_EINVAL;
   const int vec = ope_vec_of(a.D);
   if (save) {
     if (vec == 4) return launch_trunk_vec<4, true>(a, st);

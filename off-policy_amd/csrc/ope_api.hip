@@ -60,7 +60,7 @@ struct Plan {
   int64_t mu0, rstd0, xhat1, rstd1, mask1, xhat2, rstd2, mask2, gi, h, rg, zg, ng, ghn, xhat_o, rstd_o, act_idx,
       agent_q, agent_nq, gi_t, h_t, qtot, nqtot, hw1, hw2, hb2, v1, hpre, v2, loss_part, err_abs, dqtot, d_agent_q,
       d_b1, d_v2, d_v1, d_hw1, d_hw2, d_hb2, dh_out, dqoh, dgi, dghn, dz1, dz2, thetaT, mixT, raw_agent, raw_mixer,
-      rsum, q_all, loss_tot;
+      rsum, q_all, loss_tot, ln_zero, ln_one;
 };
 
 int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
@@ -109,6 +109,8 @@ void make_plan(const ope_qmix_cfg* c, Plan* p) {
   p->v1 = W.add("v1", TB * p->NM); p->hpre = W.add("hpre", TB * OPE_MIX); p->v2 = W.add("v2", TB * OPE_MIX);
   p->loss_part = W.add("loss_part", (int64_t)p->n_loss_tiles * 4);
   p->loss_tot = W.add("loss_tot", 4);
+  p->ln_zero = W.add("ln_zero", R);   // mu = 0 / rstd = 1 vectors: "no LayerNorm" operands of the wgrad kernel
+  p->ln_one = W.add("ln_one", R);
   p->err_abs = W.add("err_abs", TB); p->dqtot = W.add("dqtot", TB); p->d_agent_q = W.add("d_agent_q", TB * p->N);
   p->d_b1 = W.add("d_b1", TB * OPE_MIX); p->d_v2 = W.add("d_v2", TB * OPE_MIX); p->d_v1 = W.add("d_v1", TB * p->NM);
   p->d_hw1 = W.add("d_hw1", TB * OPE_HYP); p->d_hw2 = W.add("d_hw2", TB * OPE_HYP); p->d_hb2 = W.add("d_hb2", TB * OPE_HYP);
@@ -265,6 +267,8 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
   if ((rc = launch_trunk_bwd(tb, st))) return rc;
 
   // ---- weight gradients: one batched K-reduction launch ----
+  if ((rc = launch_fill(W + p.ln_zero, p.R, 0.f, st))) return rc;
+  if ((rc = launch_fill(W + p.ln_one, p.R, 1.f, st))) return rc;
   WgTable wt;
   memset(&wt, 0, sizeof(wt));
   int n = 0;
@@ -273,7 +277,7 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
   auto prob = [&](const float* A, int lda, int M, const float* Bm, int ldb, int N, int K, int out_off, int ldc, int s_off,
                   int nsplit, int64_t base, int64_t stride) -> WgProb& {
     WgProb& q = wt.p[n++];
-    q.A = A; q.lda = lda; q.M = M; q.B = Bm; q.ldb = ldb; q.N = N; q.K = K; q.b_shift = 0; q.ln_mu = nullptr; q.ln_rstd = nullptr;
+    q.A = A; q.lda = lda; q.M = M; q.B = Bm; q.ldb = ldb; q.N = N; q.K = K; q.b_shift = 0; q.ln_mu = W + p.ln_zero; q.ln_rstd = W + p.ln_one;
     q.out_off = out_off; q.ldc = ldc; q.s_off = s_off; q.nsplit = nsplit; q.raw_base = base; q.raw_stride = stride;
     return q;
   };

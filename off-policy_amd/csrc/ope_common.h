@@ -83,6 +83,33 @@ __device__ __forceinline__ f32x4 load4(const float* __restrict__ p, int k, int K
   return v;
 }
 
+// Branch-free variant for hot loops: ALWAYS loads (addresses clamped into [0, K)), never zero-fills. Elements whose
+// index is >= K come back as finite duplicates of in-range data; the caller zeroes the OTHER operand of the
+// product (mask4) so they contribute nothing. No divergent control flow -> loads can be hoisted and pipelined.
+template <int VEC>
+__device__ __forceinline__ f32x4 load4c(const float* __restrict__ p, int k, int K) {
+  f32x4 v;
+  if (VEC == 4) {
+    const int kk = min(k, K - 4);  // K % 4 == 0, K >= 4
+    v = *reinterpret_cast<const f32x4*>(p + kk);
+  } else if (VEC == 2) {
+    const int k0 = min(k, K - 2), k1 = min(k + 2, K - 2);
+    const f32x2 a = *reinterpret_cast<const f32x2*>(p + k0);
+    const f32x2 b = *reinterpret_cast<const f32x2*>(p + k1);
+    v[0] = a[0]; v[1] = a[1]; v[2] = b[0]; v[3] = b[1];
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = p[min(k + r, K - 1)];
+  }
+  return v;
+}
+// zero the elements of v whose index k+r is >= K (selects, no branches)
+__device__ __forceinline__ f32x4 mask4(f32x4 v, int k, int K) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = (k + r < K) ? v[r] : 0.f;
+  return v;
+}
+
 template <int VEC>
 __device__ __forceinline__ void store4(float* __restrict__ p, int k, int K, f32x4 v) {
   if (VEC == 4) {

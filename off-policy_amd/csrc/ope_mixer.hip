@@ -47,19 +47,40 @@ __global__ void __launch_bounds__(256) mixer_fwd_kernel(MixerFwdArgs a) {
   const float* __restrict__ qrow = (net == 0 ? a.agent_q : a.agent_nq) + (int64_t)mm * N;
   const bool save = (net == 0) && (a.hw1 != nullptr);
 
-  // ---- stage A: 14 output tiles over K = S ----
+  // ---- stage A: 14 output tiles over K = S; branch-free K loop, operands of chunk c+1 in flight during chunk c ----
   f32x4 acc[14];
 #pragma unroll
   for (int it = 0; it < 14; ++it) acc[it] = *reinterpret_cast<const f32x4*>(stageA_bias(th, L, it) + 4 * g);
   const int KC = (S + 15) >> 4;
-  for (int c = 0; c < KC; ++c) {
-    const int k = 16 * c + 4 * g;
-    const f32x4 xs = load4<VEC>(srow, k, S);
+  {
+    const float* wrow[14];
 #pragma unroll
-    for (int it = 0; it < 14; ++it) {
-      const f32x4 wv = load4<VEC>(stageA_row(th, L, S, it, j), k, S);
+    for (int it = 0; it < 14; ++it) wrow[it] = stageA_row(th, L, S, it, j);
+    // ping-pong chunk buffers, loop unrolled by two (no copies); chunks past KC-1 multiply a zero-masked state vector
+    f32x4 wa[14], wb[14], xa, xb;
+    auto fetchA = [&](f32x4 (&w)[14], f32x4& x, int c) {
+      const int k = 16 * c + 4 * g;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[it] = mfma16(wv[r], xs[r], acc[it]);
+      for (int it = 0; it < 14; ++it) w[it] = load4c<VEC>(wrow[it], k, S);
+      x = load4c<VEC>(srow, k, S);
+    };
+    auto computeA = [&](const f32x4 (&w)[14], const f32x4& x, int c) {
+      const f32x4 xs = mask4(x, 16 * c + 4 * g, S);
+#pragma unroll
+      for (int it = 0; it < 14; ++it)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[it] = mfma16(w[it][r], xs[r], acc[it]);
+    };
+    fetchA(wa, xa, 0);
+    for (int c = 0; c < KC; c += 2) {
+      fetchA(wb, xb, c + 1);
+      __builtin_amdgcn_sched_barrier(0);   // pin: loads of one buffer issue before the MFMAs of the other
+      computeA(wa, xa, c);
+      __builtin_amdgcn_sched_barrier(0);
+      fetchA(wa, xa, c + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      computeA(wb, xb, c + 1);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 #pragma unroll
@@ -77,23 +98,49 @@ __global__ void __launch_bounds__(256) mixer_fwd_kernel(MixerFwdArgs a) {
   f32x4 hw1[4] = {acc[0], acc[1], acc[2], acc[3]};
   f32x4 hw2[4] = {acc[4], acc[5], acc[6], acc[7]};
 
-  // ---- stage B: hidden = ELU( sum_a q_a |W1b hw1 + b|[a] + b1 ) ----
+  // ---- stage B: hidden = ELU( sum_a q_a |W1b hw1 + b|[a] + b1 ); agent a+1's weights prefetched during agent a ----
   f32x4 hid[2] = {acc[12], acc[13]};
-  for (int ag = 0; ag < N; ++ag) {
-    f32x4 v[2];
+  {
+    f32x4 wc[2][4], wn[2][4], bc[2], bn[2];
+    float qc, qn;
+    auto fetchB = [&](int ag, f32x4 (&w)[2][4], f32x4 (&b)[2], float& q) {
+      const int agc = min(ag, N - 1);
 #pragma unroll
-    for (int kh = 0; kh < 2; ++kh) v[kh] = *reinterpret_cast<const f32x4*>(th + L.w1b_b + ag * OPE_MIX + 16 * kh + 4 * g);
-    gemm64<2>(th + L.w1b_w + (int64_t)(ag * OPE_MIX) * OPE_HYP, OPE_HYP, j, g, hw1, v);
-    if (save && valid) {
+      for (int kh = 0; kh < 2; ++kh) {
+        b[kh] = *reinterpret_cast<const f32x4*>(th + L.w1b_b + agc * OPE_MIX + 16 * kh + 4 * g);
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft)
+          w[kh][ft] = *reinterpret_cast<const f32x4*>(th + L.w1b_w + (int64_t)(agc * OPE_MIX + 16 * kh + j) * OPE_HYP + 16 * ft + 4 * g);
+      }
+      q = qrow[agc];
+    };
+    fetchB(0, wc, bc, qc);
+    for (int ag = 0; ag < N; ++ag) {
+      fetchB(ag + 1, wn, bn, qn);
+      f32x4 v[2] = {bc[0], bc[1]};
 #pragma unroll
       for (int kh = 0; kh < 2; ++kh)
-        *reinterpret_cast<f32x4*>(a.v1 + (int64_t)m * (N * OPE_MIX) + ag * OPE_MIX + 16 * kh + 4 * g) = v[kh];
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[kh] = mfma16(wc[kh][ft][r], hw1[ft][r], v[kh]);
+      if (save && valid) {
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh)
+          *reinterpret_cast<f32x4*>(a.v1 + (int64_t)m * (N * OPE_MIX) + ag * OPE_MIX + 16 * kh + 4 * g) = v[kh];
+      }
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hid[kh][r] = fmaf(qc, fabsf(v[kh][r]), hid[kh][r]);
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) {
+        bc[kh] = bn[kh];
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) wc[kh][ft] = wn[kh][ft];
+      }
+      qc = qn;
     }
-    const float qa = qrow[ag];
-#pragma unroll
-    for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) hid[kh][r] = fmaf(qa, fabsf(v[kh][r]), hid[kh][r]);
   }
   if (save && valid) {
 #pragma unroll

@@ -42,6 +42,7 @@ struct FinTable {
   int n;
   int64_t total;  // length of the flat gradient including the tail
 };
+int launch_fill(float* p, int64_t n, float v, hipStream_t st);
 int launch_loss_reduce(const float* part, int tiles, float* out, hipStream_t st);
 int launch_finalize(const FinTable& ft, const float* rsum, const float* theta, const float* loss_part, int n_loss_tiles,
                     float* grad, hipStream_t st);

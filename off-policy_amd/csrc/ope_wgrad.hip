@@ -39,52 +39,69 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgTable tb, float* __restric
     for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
   float cs[4] = {0.f, 0.f, 0.f, 0.f};
   bool mok[4], nok[4];
+  float mokf[4], nokf[4];
+  int moff[4], noff[4];   // clamped in-range column offsets: every load is unconditional, invalid lanes are zeroed after
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     mok[q] = (m0 + 16 * q + i) < P.M;
     nok[q] = (n0 + 16 * q + i) < P.N;
+    mokf[q] = mok[q] ? 1.f : 0.f;
+    nokf[q] = nok[q] ? 1.f : 0.f;
+    moff[q] = min(m0 + 16 * q + i, P.M - 1);
+    noff[q] = min(n0 + 16 * q + i, P.N - 1);
   }
-  const float* __restrict__ Ap = P.A + m0 + i;
-  const float* __restrict__ Bp = P.B + n0 + i;
-  const bool ln = P.ln_mu != nullptr;
+  const float* __restrict__ Ap = P.A;
+  const float* __restrict__ Bp = P.B;
+  const float* __restrict__ mup = P.ln_mu;     // never null: plain problems point at a zeros / ones vector
+  const float* __restrict__ rsp = P.ln_rstd;
+  const int lda = P.lda, ldb = P.ldb, shift = P.b_shift, Kmax = P.K - 1;
 
-  // operand fetch for the 4 reduction rows kb..kb+3 (lane group g takes row kb+g); software-pipelined one step ahead
-  auto fetch = [&](int kb, float (&av)[4], float (&bv)[4]) {
-    const int k = kb + g;
-    const bool kok = k < k1;
-    const float* ar = Ap + (int64_t)k * P.lda;
+  // Operand fetch for the 4 reduction rows kb..kb+3 (lane group g takes row kb+g). Raw loads are issued one step
+  // ahead and only post-processed (LayerNorm-on-load, zeroing of out-of-range lanes) when consumed, so a full step of
+  // MFMAs sits between a load and its first use.
+  struct Rawv { float a[4], b[4], mu, rs; };
+  auto fetch = [&](int kb, Rawv& r) {
+    const int kc = min(kb + g, Kmax);
+    const float* ar = Ap + (int64_t)kc * lda;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) av[q] = (kok && mok[q]) ? ar[16 * q] : 0.f;
-    const int kbrow = k - P.b_shift;
-    const bool bok = kok && kbrow >= 0;
-    const float* br = Bp + (int64_t)kbrow * P.ldb;
-    float mu = 0.f, rs = 1.f;
-    if (ln && bok) {
-      mu = P.ln_mu[kbrow];
-      rs = P.ln_rstd[kbrow];
-    }
+    for (int q = 0; q < 4; ++q) r.a[q] = ar[moff[q]];
+    const int kr = max(kc - shift, 0);
+    const float* br = Bp + (int64_t)kr * ldb;
+    r.mu = mup[kr];
+    r.rs = rsp[kr];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r.b[q] = br[noff[q]];
+  };
+  auto compute = [&](const Rawv& c, int kb) {
+    const int k = kb + g;
+    // zero invalid lanes by multiplying with a 0/1 mask (a select here gets turned back into a guarded load)
+    const float ka = (k < k1) ? 1.f : 0.f;
+    const float kbm = (k < k1 && k - shift >= 0) ? 1.f : 0.f;
+    float av[4], bv[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      float v = (bok && nok[q]) ? br[16 * q] : 0.f;
-      if (ln) v = (bok && nok[q]) ? (v - mu) * rs : 0.f;
-      bv[q] = v;
+      av[q] = c.a[q] * (ka * mokf[q]);
+      bv[q] = ((c.b[q] - c.mu) * c.rs) * (kbm * nokf[q]);
     }
-  };
-  float av[4], bv[4], an[4], bn[4];
-  fetch(k0, av, bv);
-  for (int kb = k0; kb < k1; kb += 4) {
-    fetch(kb + 4, an, bn);   // rows beyond k1 come back as zeros
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
       cs[mi] += av[mi];
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16(av[mi], bv[ni], acc[mi][ni]);
     }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      av[q] = an[q];
-      bv[q] = bn[q];
-    }
+  };
+  // ping-pong buffers, loop unrolled by two (no register copies for the compiler to fold the prefetch into)
+  Rawv bufA, bufB;
+  fetch(k0, bufA);
+  for (int kb = k0; kb < k1; kb += 8) {
+    fetch(kb + 4, bufB);
+    __builtin_amdgcn_sched_barrier(0);   // pin: these loads issue BEFORE the MFMAs of the other buffer
+    compute(bufA, kb);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(kb + 8, bufA);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(bufB, kb + 4);   // rows >= k1 are masked to zero
+    __builtin_amdgcn_sched_barrier(0);
   }
   float* out = raw + P.raw_base + (int64_t)split * P.raw_stride;
 #pragma unroll
@@ -181,12 +198,14 @@ __global__ void finalize_kernel(FinTable ft, const float* __restrict__ rsum, con
       }
       case FIN_LNLIN_G: {
         float acc = 0.f;
+#pragma unroll 16
         for (int i = 0; i < F.M; ++i) acc = fmaf(theta[F.w + (int64_t)i * F.K + local], rsum[F.src + (int64_t)i * F.K + local], acc);
         out = acc;
         break;
       }
       case FIN_LNLIN_B: {
         float acc = 0.f;
+#pragma unroll 16
         for (int i = 0; i < F.M; ++i) acc = fmaf(rsum[F.src_s + i], theta[F.w + (int64_t)i * F.K + local], acc);
         out = acc;
         break;
@@ -199,6 +218,16 @@ __global__ void finalize_kernel(FinTable ft, const float* __restrict__ rsum, con
     }
   }
   grad[idx] = out;
+}
+
+__global__ void fill_kernel(float* __restrict__ p, int64_t n, float v) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+int launch_fill(float* p, int64_t n, float v, hipStream_t st) {
+  hipLaunchKernelGGL(fill_kernel, dim3(ope_cdiv(n, 256)), dim3(256), 0, st, p, n, v);
+  if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
+  return OPE_OK;
 }
 
 // [tiles][4] loss partials -> 4 totals, one block, fixed summation tree (deterministic).
