@@ -101,13 +101,14 @@ template <int NT>
 __device__ __forceinline__ void gemm64(const float* __restrict__ W, int ld, int j, int g, const f32x4 (&act)[4],
                                        f32x4 (&acc)[NT]) {
 #pragma unroll
-  for (int it = 0; it < NT; ++it) {
+  for (int ft = 0; ft < 4; ++ft) {
+    f32x4 w[NT];
 #pragma unroll
-    for (int ft = 0; ft < 4; ++ft) {
-      const f32x4 w = *reinterpret_cast<const f32x4*>(W + (int64_t)(16 * it + j) * ld + 16 * ft + 4 * g);
+    for (int it = 0; it < NT; ++it) w[it] = *reinterpret_cast<const f32x4*>(W + (int64_t)(16 * it + j) * ld + 16 * ft + 4 * g);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[it] = mfma16(w[r], act[ft][r], acc[it]);
-    }
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int it = 0; it < NT; ++it) acc[it] = mfma16(w[it][r], act[ft][r], acc[it]);
   }
 }
 
@@ -116,15 +117,17 @@ template <int NT, int RT>
 __device__ __forceinline__ void gemm64rt(const float* __restrict__ W, int ld, int j, int g, const f32x4 (&act)[RT][4],
                                          f32x4 (&acc)[RT][NT]) {
 #pragma unroll
-  for (int it = 0; it < NT; ++it) {
+  for (int ft = 0; ft < 4; ++ft) {
+    f32x4 w[NT];
 #pragma unroll
-    for (int ft = 0; ft < 4; ++ft) {
-      const f32x4 w = *reinterpret_cast<const f32x4*>(W + (int64_t)(16 * it + j) * ld + 16 * ft + 4 * g);
+    for (int it = 0; it < NT; ++it) w[it] = *reinterpret_cast<const f32x4*>(W + (int64_t)(16 * it + j) * ld + 16 * ft + 4 * g);
+    // r outermost: consecutive MFMAs accumulate into different tiles (no back-to-back dependent pairs)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
       for (int t = 0; t < RT; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[t][it] = mfma16(w[r], act[t][ft][r], acc[t][it]);
-    }
+        for (int it = 0; it < NT; ++it) acc[t][it] = mfma16(w[it][r], act[t][ft][r], acc[t][it]);
   }
 }
 

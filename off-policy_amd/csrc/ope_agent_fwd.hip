@@ -4,6 +4,8 @@
 //   trunk_fwd : per data row   LN_D -> fc1+ReLU+LN -> fc2+ReLU+LN -> gi = W_ih a2 + b_ih        (f32 MFMA chain)
 //   gru_fwd   : per (agent,episode) row, serial over t: h_t = GRU(gi_t, h_{t-1})                (one wave per row)
 //   head_fwd  : per data row   LN(h_t) -> q = W_q y + b_q, chosen-action q, masked greedy argmax, target q at greedy
+#include <stdlib.h>
+
 #include "ope_agent.h"
 
 namespace ope {
@@ -96,16 +98,18 @@ __global__ void __launch_bounds__(256) trunk_fwd_kernel(TrunkFwdArgs a) {
     auto compute = [&](const TrunkChunk<VEC, RT>& ch, int c) {
       const int k = 16 * c + 4 * g;
       const f32x4 gam = mask4(ch.gam, k, D), bet = mask4(ch.bet, k, D);
+      f32x4 xn[RT];
 #pragma unroll
-      for (int t = 0; t < RT; ++t) {
-        f32x4 xn;
+      for (int t = 0; t < RT; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) xn[r] = fmaf((ch.x[t][r] - mu[t]) * rstd[t], gam[r], bet[r]);  // exactly 0 beyond D
+        for (int r = 0; r < 4; ++r) xn[t][r] = fmaf((ch.x[t][r] - mu[t]) * rstd[t], gam[r], bet[r]);  // exactly 0 beyond D
+      // r outermost: consecutive MFMAs hit different accumulators (a dependent 16x16x4 pair costs 40 cycles, not 32)
 #pragma unroll
-        for (int it = 0; it < 4; ++it)
+      for (int r = 0; r < 4; ++r)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc[t][it] = mfma16(ch.w[it][r], xn[r], acc[t][it]);
-      }
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+          for (int it = 0; it < 4; ++it) acc[t][it] = mfma16(ch.w[it][r], xn[t][r], acc[t][it]);
     };
     trunk_fetch<VEC, RT>(bufA, th, a.L, xrow, j, 4 * g, D);
     for (int c = 0; c < KC; c += 2) {
@@ -167,8 +171,10 @@ __global__ void __launch_bounds__(256) trunk_fwd_kernel(TrunkFwdArgs a) {
 
 template <int VEC, bool SAVE>
 static int launch_trunk_vec(const TrunkFwdArgs& a, hipStream_t st) {
-  // two row tiles per wave once there is enough work to fill the chip that way
-  if (a.R >= 2 * 16 * 4 * 256) {
+  // two row tiles per wave once there is enough work to fill the chip that way (OPE_TRUNK_RT=1|2 overrides, for A/B runs)
+  static const int forced = getenv("OPE_TRUNK_RT") ? atoi(getenv("OPE_TRUNK_RT")) : 0;
+  const bool two = forced ? forced == 2 : a.R >= 2 * 16 * 4 * 256;
+  if (two) {
     hipLaunchKernelGGL((trunk_fwd_kernel<VEC, 2, SAVE>), dim3(ope_cdiv(ope_cdiv(a.R, 32), 4)), dim3(256), 0, st, a);
   } else {
     hipLaunchKernelGGL((trunk_fwd_kernel<VEC, 1, SAVE>), dim3(ope_cdiv(ope_cdiv(a.R, 16), 4)), dim3(256), 0, st, a);
@@ -191,12 +197,17 @@ int launch_trunk_fwd(const TrunkFwdArgs& a, bool save, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// gru_fwd. One wave per (agent,episode) row; lane f owns hidden feature f and keeps rows f, 64+f, 128+f of W_hh
-// (192 floats, as 96 float2) in VGPRs. Each step the wave publishes h_{t-1} (64 floats) to its private LDS slot and
-// every lane reads it back with 16 broadcast ds_read_b128; the three 64-long dot products run as packed FMAs
-// (v_pk_fma_f32) on 12 independent partial sums so the FMA pipe never waits on a dependent accumulate. No
-// barriers: the T+1 steps are a pure dependent chain per wave, and all rows of the live AND target networks run
-// concurrently (one wave per SIMD).
+// gru_fwd. The recurrence is a serial chain of T+1 matvecs per (agent,episode) row, so the goal is minimum latency
+// per step with every SIMD busy: each row is split over WPR waves of one workgroup (WPR = 2 or 4), wave q owning the
+// K-slice [q*64/WPR, (q+1)*64/WPR) of h_{t-1} for all 192 gate outputs; lane f owns hidden feature f and keeps its
+// 3 x 64/WPR weights in VGPRs (float2 pairs -> v_pk_fma_f32 on independent partial sums). Per step:
+//   1. every wave publishes its copy of h_{t-1} to a private LDS slot and reads its K-slice back with broadcast
+//      ds_read_b128 (no barrier: same wave);
+//   2. partial gate sums go to LDS, ONE workgroup barrier, every wave adds the WPR partials in the same fixed order
+//      (so all waves of a row hold bit-identical h) and evaluates the gates redundantly.
+// Memory roles are split so that no wave mixes global loads and stores (on CDNA the two share vmcnt, and a wave that
+// does both ends up draining its stores every step): wave 0 of a row only LOADS (gi, one 8-step chunk ahead, handed to
+// the others through LDS), the last wave only STORES (h and the saved gates).
 //   r = sigma(gi_r + gh_r), z = sigma(gi_z + gh_z), n = tanh(gi_n + r*gh_n), h' = (1-z) n + z h      (nn.GRU)
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
@@ -207,23 +218,35 @@ __device__ __forceinline__ float fast_tanh(float x) {
   return copysignf(t, x);
 }
 
+constexpr int kGruChunk = 8;
+
+template <int WPR>
 __global__ void __launch_bounds__(256) gru_fwd_kernel(GruFwdArgs a) {
+  constexpr int RPW = 4 / WPR;        // rows per workgroup
+  constexpr int KW = OPE_H / WPR;     // K-slice per wave
+  constexpr int C = kGruChunk;
   __shared__ __attribute__((aligned(16))) float hs[4][OPE_H];
+  __shared__ __attribute__((aligned(16))) float part[2][RPW][WPR][3][OPE_H];
+  __shared__ __attribute__((aligned(16))) float gis[RPW][2][C][3][OPE_H];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int rid = blockIdx.x * 4 + wave;  // 0 .. nets*NB
-  if (rid >= a.nets * a.NB) return;
+  const int rl = wave / WPR, q = wave % WPR;
+  const int total = a.nets * a.NB;
+  const int rid_raw = blockIdx.x * RPW + rl;
+  const bool active = rid_raw < total;
+  const int rid = active ? rid_raw : total - 1;   // idle waves shadow the last row (they must still hit the barriers)
   const int net = rid / a.NB;
   const int row = rid - net * a.NB;
   const float* __restrict__ th = net == 0 ? a.theta0 : a.theta1;
   const float* __restrict__ gi = net == 0 ? a.gi0 : a.gi1;
   float* __restrict__ hout = net == 0 ? a.h0out : a.h1out;
   const bool save = (net == 0) && (a.rg != nullptr);
+  const bool loader = (q == 0), storer = (q == WPR - 1) && active;
 
-  f32x2 wr[OPE_H / 2], wz[OPE_H / 2], wn[OPE_H / 2];
+  f32x2 wr[KW / 2], wz[KW / 2], wn[KW / 2];
   {
-    const float* w = th + a.whh_off;
+    const float* w = th + a.whh_off + KW * q;
 #pragma unroll
-    for (int k = 0; k < OPE_H / 2; ++k) {
+    for (int k = 0; k < KW / 2; ++k) {
       wr[k] = *reinterpret_cast<const f32x2*>(w + (int64_t)lane * OPE_H + 2 * k);
       wz[k] = *reinterpret_cast<const f32x2*>(w + (int64_t)(OPE_H + lane) * OPE_H + 2 * k);
       wn[k] = *reinterpret_cast<const f32x2*>(w + (int64_t)(2 * OPE_H + lane) * OPE_H + 2 * k);
@@ -232,65 +255,96 @@ __global__ void __launch_bounds__(256) gru_fwd_kernel(GruFwdArgs a) {
   const float br = th[a.bhh_off + lane], bz = th[a.bhh_off + OPE_H + lane], bn = th[a.bhh_off + 2 * OPE_H + lane];
   float h = a.hinit ? a.hinit[(int64_t)row * OPE_H + lane] : 0.f;
 
-  const int64_t stride_t = (int64_t)a.NB;
+  const int64_t stride_t = (int64_t)a.NB * (3 * OPE_H);
   const float* gp = gi + (int64_t)row * (3 * OPE_H) + lane;
-  float gir = gp[0], giz = gp[OPE_H], gin = gp[2 * OPE_H];
-  float* myhs = hs[wave];
-  for (int t = 0; t < a.L; ++t) {
-    myhs[lane] = h;
-    __builtin_amdgcn_wave_barrier();
-    // prefetch next step's input projections
-    float nr = 0.f, nz = 0.f, nn = 0.f;
-    if (t + 1 < a.L) {
-      const float* q = gp + (int64_t)(t + 1) * stride_t * (3 * OPE_H);
-      nr = q[0];
-      nz = q[OPE_H];
-      nn = q[2 * OPE_H];
+  float pre[C][3];   // loader wave: the next chunk's gi, in flight in registers
+  auto load_chunk = [&](int t0) {
+#pragma unroll
+    for (int s = 0; s < C; ++s) {
+      const float* p = gp + (int64_t)min(t0 + s, a.L - 1) * stride_t;
+      gload_async(pre[s][0], p);
+      gload_async(pre[s][1], p + OPE_H);
+      gload_async(pre[s][2], p + 2 * OPE_H);
     }
-    f32x2 ar0 = {br, 0.f}, ar1 = {0.f, 0.f}, az0 = {bz, 0.f}, az1 = {0.f, 0.f}, an0 = {bn, 0.f}, an1 = {0.f, 0.f};
+  };
+  auto publish_chunk = [&](int buf) {
+    OPE_GWAIT24(pre);   // the loader wave issues no other global traffic, so vmcnt(0) is exactly "chunk landed"
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      f32x4 hv[8];
+    for (int s = 0; s < C; ++s) {
+      gis[rl][buf][s][0][lane] = pre[s][0];
+      gis[rl][buf][s][1][lane] = pre[s][1];
+      gis[rl][buf][s][2][lane] = pre[s][2];
+    }
+  };
+  if (loader) {
+    load_chunk(0);
+    publish_chunk(0);
+  }
+  lds_barrier();
+
+  float* myhs = hs[wave];
+  for (int c0 = 0; c0 < a.L; c0 += C) {
+    const int buf = (c0 / C) & 1;
+    if (loader && c0 + C < a.L) load_chunk(c0 + C);
+    const int ns = min(C, a.L - c0);
+    for (int s = 0; s < ns; ++s) {
+      const int t = c0 + s;
+      myhs[lane] = h;
+      __builtin_amdgcn_wave_barrier();
+      f32x2 ar0 = {0.f, 0.f}, ar1 = {0.f, 0.f}, az0 = {0.f, 0.f}, az1 = {0.f, 0.f}, an0 = {0.f, 0.f}, an1 = {0.f, 0.f};
 #pragma unroll
-      for (int q = 0; q < 8; ++q) hv[q] = *reinterpret_cast<const f32x4*>(myhs + 32 * half + 4 * q);
+      for (int v = 0; v < KW / 4; ++v) {
+        const f32x4 hv = *reinterpret_cast<const f32x4*>(myhs + KW * q + 4 * v);
+        const f32x2 lo = {hv[0], hv[1]}, hi = {hv[2], hv[3]};
+        ar0 = __builtin_elementwise_fma(wr[2 * v], lo, ar0);
+        az0 = __builtin_elementwise_fma(wz[2 * v], lo, az0);
+        an0 = __builtin_elementwise_fma(wn[2 * v], lo, an0);
+        ar1 = __builtin_elementwise_fma(wr[2 * v + 1], hi, ar1);
+        az1 = __builtin_elementwise_fma(wz[2 * v + 1], hi, az1);
+        an1 = __builtin_elementwise_fma(wn[2 * v + 1], hi, an1);
+      }
+      float(*pp)[3][OPE_H] = part[t & 1][rl];
+      pp[q][0][lane] = (ar0[0] + ar0[1]) + (ar1[0] + ar1[1]);
+      pp[q][1][lane] = (az0[0] + az0[1]) + (az1[0] + az1[1]);
+      pp[q][2][lane] = (an0[0] + an0[1]) + (an1[0] + an1[1]);
+      lds_barrier();
+      float ar = br, az = bz, an = bn;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int k2 = 16 * half + 2 * q;
-        const f32x2 lo = {hv[q][0], hv[q][1]}, hi = {hv[q][2], hv[q][3]};
-        ar0 = __builtin_elementwise_fma(wr[k2], lo, ar0);
-        az0 = __builtin_elementwise_fma(wz[k2], lo, az0);
-        an0 = __builtin_elementwise_fma(wn[k2], lo, an0);
-        ar1 = __builtin_elementwise_fma(wr[k2 + 1], hi, ar1);
-        az1 = __builtin_elementwise_fma(wz[k2 + 1], hi, az1);
-        an1 = __builtin_elementwise_fma(wn[k2 + 1], hi, an1);
+      for (int w2 = 0; w2 < WPR; ++w2) {
+        ar += pp[w2][0][lane];
+        az += pp[w2][1][lane];
+        an += pp[w2][2][lane];
+      }
+      const float gir = gis[rl][buf][s][0][lane], giz = gis[rl][buf][s][1][lane], gin = gis[rl][buf][s][2][lane];
+      const float r = fast_sigmoid(gir + ar);
+      const float z = fast_sigmoid(giz + az);
+      const float n = fast_tanh(gin + r * an);
+      h = (1.0f - z) * n + z * h;
+      if (storer) {
+        const int64_t o = ((int64_t)t * a.NB + row) * OPE_H + lane;
+        hout[o] = h;
+        if (save) {
+          a.rg[o] = r;
+          a.zg[o] = z;
+          a.ng[o] = n;
+          a.ghn[o] = an;
+        }
       }
     }
-    __builtin_amdgcn_wave_barrier();
-    const float ar = (ar0[0] + ar0[1]) + (ar1[0] + ar1[1]);
-    const float az = (az0[0] + az0[1]) + (az1[0] + az1[1]);
-    const float an = (an0[0] + an0[1]) + (an1[0] + an1[1]);
-    const float r = fast_sigmoid(gir + ar);
-    const float z = fast_sigmoid(giz + az);
-    const float n = fast_tanh(gin + r * an);
-    h = (1.0f - z) * n + z * h;
-    const int64_t o = ((int64_t)t * stride_t + row) * OPE_H + lane;
-    hout[o] = h;
-    if (save) {
-      a.rg[o] = r;
-      a.zg[o] = z;
-      a.ng[o] = n;
-      a.ghn[o] = an;
-    }
-    gir = nr;
-    giz = nz;
-    gin = nn;
+    // hand the next chunk to the row's waves: written after this chunk's last barrier, first read after the next
+    // step's barrier; the buffer being overwritten was last read one whole chunk ago.
+    if (loader && c0 + C < a.L) publish_chunk(buf ^ 1);
   }
 }
 
 int launch_gru_fwd(const GruFwdArgs& a, hipStream_t st) {
   if (a.nets < 1 || a.nets > 2 || a.NB < 1 || a.L < 1) return OPE_EINVAL;
-  const int blocks = ope_cdiv((int64_t)a.nets * a.NB, 4);
-  hipLaunchKernelGGL(gru_fwd_kernel, dim3(blocks), dim3(256), 0, st, a);
+  const int64_t rows = (int64_t)a.nets * a.NB;
+  if (rows * 4 <= 1280) {   // few rows: four waves per row
+    hipLaunchKernelGGL(gru_fwd_kernel<4>, dim3(rows), dim3(256), 0, st, a);
+  } else {
+    hipLaunchKernelGGL(gru_fwd_kernel<2>, dim3(ope_cdiv(rows, 2)), dim3(256), 0, st, a);
+  }
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   return OPE_OK;
 }

@@ -139,6 +139,26 @@ __device__ __forceinline__ float rowsum4(float x) {
   return x;
 }
 
+// Workgroup barrier that orders LDS traffic only. __syncthreads() also emits s_waitcnt vmcnt(0), which would drain a
+// wave's in-flight global prefetches / stores at every step of the scan kernels.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Global load whose completion the COMPILER does not track (inline asm): used for prefetches that must stay in flight
+// across a loop. hipcc's waitcnt pass drains every compiler-visible load before entering a loop that contains other
+// memory traffic; an asm load is invisible to it, so the wait is ours: gwait*() before the first use.
+__device__ __forceinline__ void gload_async(float& dst, const float* p) {
+  asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+// s_waitcnt vmcnt(0) that names 24 destination registers as read-write so they stay put until the data has landed
+#define OPE_GWAIT24(a)                                                                                                   \
+  asm volatile("s_waitcnt vmcnt(0)"                                                                                      \
+               : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[1][2]), "+v"(a[2][0]), \
+                 "+v"(a[2][1]), "+v"(a[2][2]), "+v"(a[3][0]), "+v"(a[3][1]), "+v"(a[3][2]), "+v"(a[4][0]), "+v"(a[4][1]), \
+                 "+v"(a[4][2]), "+v"(a[5][0]), "+v"(a[5][1]), "+v"(a[5][2]), "+v"(a[6][0]), "+v"(a[6][1]), "+v"(a[6][2]), \
+                 "+v"(a[7][0]), "+v"(a[7][1]), "+v"(a[7][2])                                                              \
+               :                                                                                                         \
+               : "memory")
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // Flat-parameter offsets (floats) of the agent q-network and the QMixer. Order = reference named_parameters()

@@ -67,9 +67,9 @@ __global__ void __launch_bounds__(256) mixer_fwd_kernel(MixerFwdArgs a) {
     auto computeA = [&](const f32x4 (&w)[14], const f32x4& x, int c) {
       const f32x4 xs = mask4(x, 16 * c + 4 * g, S);
 #pragma unroll
-      for (int it = 0; it < 14; ++it)
+      for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[it] = mfma16(w[it][r], xs[r], acc[it]);
+        for (int it = 0; it < 14; ++it) acc[it] = mfma16(w[it][r], xs[r], acc[it]);
     };
     fetchA(wa, xa, 0);
     for (int c = 0; c < KC; c += 2) {
