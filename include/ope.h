@@ -106,6 +106,9 @@ typedef struct ope_qmix_cfg {
 int64_t ope_qmix_param_layout(const ope_qmix_cfg* cfg, int64_t* offsets, int64_t* sizes);
 /* Workspace (bytes) ope_qmix_loss_and_grad needs. */
 int64_t ope_qmix_workspace_bytes(const ope_qmix_cfg* cfg);
+/* One-time initialisation of a freshly allocated workspace (constant regions the kernels only read). Must be called
+ * once per workspace buffer before the first ope_qmix_loss_and_grad on it. */
+int ope_qmix_workspace_init(const ope_qmix_cfg* cfg, void* workspace, int64_t workspace_bytes, void* stream);
 /* Named sub-buffers of the workspace, for tests/debugging: returns byte offset, writes element count. -1 if unknown. */
 int64_t ope_qmix_workspace_find(const ope_qmix_cfg* cfg, const char* name, int64_t* n_floats);
 

@@ -58,6 +58,7 @@ def _load():
         "ope_store_gather": (C.c_int, [C.POINTER(Dims), i32, C.POINTER(Fields), p, i32, C.POINTER(Fields), p]),
         "ope_qmix_param_layout": (i64, [C.POINTER(QmixCfg), C.POINTER(i64), C.POINTER(i64)]),
         "ope_qmix_workspace_bytes": (i64, [C.POINTER(QmixCfg)]),
+        "ope_qmix_workspace_init": (C.c_int, [C.POINTER(QmixCfg), p, i64, p]),
         "ope_qmix_workspace_find": (i64, [C.POINTER(QmixCfg), C.c_char_p, C.POINTER(i64)]),
         "ope_qmix_loss_and_grad": (C.c_int, [C.POINTER(QmixCfg), C.POINTER(Fields), p, p, p, p, i64, p, p, p]),
         "ope_agent_forward_workspace_bytes": (i64, [C.POINTER(Dims), i32, i32]),

@@ -132,7 +132,10 @@ class QMix(object):
             need = _lib.lib.ope_qmix_workspace_bytes(C.byref(cfg))
             if need < 0:
                 _lib.check(int(need), "ope_qmix_workspace_bytes")
-            self._ws[B] = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+            ws = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+            _lib.check(_lib.lib.ope_qmix_workspace_init(C.byref(cfg), _lib.ptr(ws), ws.numel(), _lib.current_stream()),
+                       "ope_qmix_workspace_init")
+            self._ws[B] = ws
         return self._ws[B]
 
     def workspace_view(self, batch, name):

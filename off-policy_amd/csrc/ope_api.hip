@@ -180,6 +180,18 @@ extern "C" int64_t ope_qmix_workspace_find(const ope_qmix_cfg* cfg, const char* 
   return off < 0 ? -1 : off * (int64_t)sizeof(float);
 }
 
+extern "C" int ope_qmix_workspace_init(const ope_qmix_cfg* cfg, void* workspace, int64_t workspace_bytes, void* stream) {
+  (void)hipGetLastError();
+  if (!cfg_ok(cfg) || !workspace) return OPE_EINVAL;
+  Plan p;
+  make_plan(cfg, &p);
+  if (workspace_bytes < p.ws.total * (int64_t)sizeof(float)) return OPE_ENOSPC;
+  float* W = (float*)workspace;
+  int rc;
+  if ((rc = launch_fill(W + p.ln_zero, p.R, 0.f, (hipStream_t)stream))) return rc;
+  return launch_fill(W + p.ln_one, p.R, 1.f, (hipStream_t)stream);
+}
+
 extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields* batch, const float* theta,
                                       const float* theta_tgt, const float* per_weights, void* workspace,
                                       int64_t workspace_bytes, float* grad, float* td_abs_stats, void* stream) {
@@ -224,6 +236,22 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
   TdArgs td;
   td.B = p.B; td.N = p.N; td.gamma = cfg->gamma; td.use_huber = cfg->use_huber; td.huber_delta = cfg->huber_delta;
   td.rewards = batch->rewards; td.dones_env = batch->dones_env; td.per_weights = cfg->use_per ? per_weights : nullptr;
+  {  // transposed copies of the matrices the backward chains read column-wise (one launch)
+    Transp4 tr;
+    memset(&tr, 0, sizeof(tr));
+    int nt = 0, tot = 0;
+    auto add = [&](const float* src, int rows, int cols, float* dst) {
+      tr.src[nt] = src; tr.dst[nt] = dst; tr.rows[nt] = rows; tr.cols[nt] = cols; tr.begin[nt] = tot; tot += rows * cols; ++nt;
+    };
+    add(theta + p.AL.wih, 3 * OPE_H, OPE_H, W + p.thetaT);
+    add(theta + p.AL.fc2_w, OPE_H, OPE_H, W + p.thetaT + OPE_H * 3 * OPE_H);
+    if (!cfg->vdn) {
+      add(theta + p.ML.w1b_w, p.NM, OPE_HYP, W + p.mixT);
+      add(theta + p.ML.w2b_w, OPE_MIX, OPE_HYP, W + p.mixT + (int64_t)OPE_HYP * p.NM);
+    }
+    tr.n = nt; tr.total = tot;
+    if ((rc = launch_transpose4(tr, st))) return rc;
+  }
   if (cfg->vdn) {
     VdnArgs va;
     va.TB = (int)p.TB; va.N = p.N; va.td = td; va.agent_q = W + p.agent_q; va.agent_nq = W + p.agent_nq;
@@ -235,8 +263,6 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
     mf.share = batch->share_obs; mf.agent_q = W + p.agent_q; mf.agent_nq = W + p.agent_nq; mf.qtot = W + p.qtot; mf.nqtot = W + p.nqtot;
     mf.hw1 = W + p.hw1; mf.hw2 = W + p.hw2; mf.hb2 = W + p.hb2; mf.v1 = W + p.v1; mf.hpre = W + p.hpre; mf.v2 = W + p.v2;
     if ((rc = launch_mixer_fwd(mf, st))) return rc;
-    if ((rc = launch_transpose(theta + p.ML.w1b_w, p.NM, OPE_HYP, W + p.mixT, st))) return rc;
-    if ((rc = launch_transpose(theta + p.ML.w2b_w, OPE_MIX, OPE_HYP, W + p.mixT + (int64_t)OPE_HYP * p.NM, st))) return rc;
     MixerBwdArgs mb;
     mb.TB = (int)p.TB; mb.N = p.N; mb.theta = theta; mb.thetaT = W + p.mixT; mb.L = p.ML; mb.td = td;
     mb.qtot = W + p.qtot; mb.nqtot = W + p.nqtot; mb.agent_q = W + p.agent_q;
@@ -258,7 +284,6 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
   gb.NB = p.NB; gb.T = p.T; gb.theta = theta; gb.whh_off = p.AL.whh; gb.h = W + p.h;
   gb.rg = W + p.rg; gb.zg = W + p.zg; gb.ng = W + p.ng; gb.ghn = W + p.ghn; gb.dh_out = W + p.dh_out; gb.dgi = W + p.dgi; gb.dghn = W + p.dghn;
   if ((rc = launch_gru_bwd(gb, st))) return rc;
-  if ((rc = launch_transpose_weights(theta, p.AL, W + p.thetaT, st))) return rc;
   TrunkBwdArgs tb;
   tb.R = (int)p.R1; tb.theta = theta; tb.thetaT = W + p.thetaT; tb.L = p.AL; tb.dgi = W + p.dgi;
   tb.xhat1 = W + p.xhat1; tb.rstd1 = W + p.rstd1; tb.mask1 = (const uint64_t*)(W + p.mask1);
@@ -267,8 +292,7 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
   if ((rc = launch_trunk_bwd(tb, st))) return rc;
 
   // ---- weight gradients: one batched K-reduction launch ----
-  if ((rc = launch_fill(W + p.ln_zero, p.R, 0.f, st))) return rc;
-  if ((rc = launch_fill(W + p.ln_one, p.R, 1.f, st))) return rc;
+  // (ln_zero / ln_one were filled by ope_qmix_workspace_init)
   WgTable wt;
   memset(&wt, 0, sizeof(wt));
   int n = 0;
@@ -312,9 +336,13 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
   wt.n = n;
   if ((rc = wg_finish(&wt))) return rc;
   if ((rc = launch_wgrad(wt, W, st))) return rc;
-  if ((rc = launch_split_reduce(W + p.raw_agent, rw.agent_end, p.ns_agent, rw.agent_end, W + p.rsum, st))) return rc;
-  if (!cfg->vdn)
-    if ((rc = launch_split_reduce(W + p.raw_mixer, rw.mixer_size, p.ns_mixer, rw.mixer_size, W + p.rsum + rw.agent_end, st))) return rc;
+  {
+    SplitRed sr;
+    sr.raw0 = W + p.raw_agent; sr.n0 = rw.agent_end; sr.ns0 = wg_slabs(wt, p.ns_agent);
+    sr.raw1 = W + p.raw_mixer; sr.n1 = cfg->vdn ? 0 : rw.mixer_size; sr.ns1 = wg_slabs(wt, p.ns_mixer);
+    sr.rsum = W + p.rsum;
+    if ((rc = launch_split_reduce(sr, st))) return rc;
+  }
 
   // ---- finalize into the flat gradient ----
   FinTable ft;
@@ -356,8 +384,7 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
   seg((int)p.P, OPE_GRAD_TAIL, FIN_TAIL, 0, 0, 0, 0, 0, 0, 0);
   ft.n = k;
   ft.total = p.P + OPE_GRAD_TAIL;
-  if ((rc = launch_loss_reduce(W + p.loss_part, p.n_loss_tiles, W + p.loss_tot, st))) return rc;
-  if ((rc = launch_finalize(ft, W + p.rsum, theta, W + p.loss_tot, p.n_loss_tiles, grad, st))) return rc;
+  if ((rc = launch_finalize(ft, W + p.rsum, theta, W + p.loss_part, p.n_loss_tiles, grad, st))) return rc;
   return OPE_OK;
 }
 

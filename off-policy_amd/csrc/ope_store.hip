@@ -35,35 +35,56 @@ struct CopyArgs {
 
 // GATHER: src = store[inds[b]][t][a][d]          dst = out[t][a][b][d]
 // INSERT: src = staged[t][e][a][d]               dst = store[slots[e]][t][a][d]
+//
+// Work unit = one "segment": the DD contiguous floats of one (episode, t, agent). Segments of a block are dealt to its
+// 4 waves; a wave moves a segment with its 64 lanes striding over VEC-wide pieces, UNROLL segments at a time so that
+// several independent 16-byte loads are in flight per lane before the first store. All index arithmetic is per
+// segment (wave-uniform), none per element.
 template <bool GATHER, int VEC>
 __device__ __forceinline__ void copy_field(const FieldDesc& F, const int64_t* __restrict__ idx, int E, int blk) {
-  const int chunk = F.NA * F.DD;
+  constexpr int UNROLL = 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n_items = E * F.TT;
   const int item0 = blk * F.items_per_block;
   const int n_here = min(F.items_per_block, n_items - item0);
-  const int total = n_here * chunk;
-  for (int x = threadIdx.x * VEC; x < total; x += kBlock * VEC) {
-    const int il = x / chunk;
-    const int e = x - il * chunk;  // offset inside the (episode,t) chunk: a*DD + d
+  const int nseg = n_here * F.NA;
+  const int pieces = F.DD / VEC;          // VEC-wide pieces per segment
+  typedef float vec_t __attribute__((ext_vector_type(VEC)));
+  auto seg_ptrs = [&](int sg, const float*& sp, float*& dp) {
+    const int il = sg / F.NA, a = sg - il * F.NA;
     const int item = item0 + il;
-    const int b = item / F.TT;     // episode slot in the batch / insert block
-    const int t = item - b * F.TT;
-    const int a = e / F.DD;
-    const int d = e - a * F.DD;
-    int64_t so, dof;
+    const int b = item / F.TT, t = item - b * F.TT;
     if (GATHER) {
-      so = ((int64_t)idx[b] * F.TT + t) * chunk + e;
-      dof = (((int64_t)t * F.NA + a) * E + b) * F.DD + d;
+      sp = F.src + (((int64_t)idx[b] * F.TT + t) * F.NA + a) * F.DD;
+      dp = F.dst + (((int64_t)t * F.NA + a) * E + b) * F.DD;
     } else {
-      so = (((int64_t)t * E + b) * F.NA + a) * F.DD + d;
-      dof = ((int64_t)idx[b] * F.TT + t) * chunk + e;
+      sp = F.src + (((int64_t)t * E + b) * F.NA + a) * F.DD;
+      dp = F.dst + (((int64_t)idx[b] * F.TT + t) * F.NA + a) * F.DD;
     }
-    if (VEC == 4) {
-      *reinterpret_cast<f32x4*>(F.dst + dof) = *reinterpret_cast<const f32x4*>(F.src + so);
-    } else if (VEC == 2) {
-      *reinterpret_cast<f32x2*>(F.dst + dof) = *reinterpret_cast<const f32x2*>(F.src + so);
-    } else {
-      F.dst[dof] = F.src[so];
+  };
+  if (pieces <= 16) {
+    // short segments (acts, rewards, dones ...): one lane per piece, 64/pieces... keep it simple: lane-per-piece over a
+    // flattened (segment, piece) space of this block
+    const int total = nseg * pieces;
+    for (int x = threadIdx.x; x < total; x += kBlock) {
+      const int sg = x / pieces, pc = x - sg * pieces;
+      const float* sp; float* dp;
+      seg_ptrs(sg, sp, dp);
+      *reinterpret_cast<vec_t*>(dp + pc * VEC) = *reinterpret_cast<const vec_t*>(sp + pc * VEC);
+    }
+    return;
+  }
+  for (int s0 = wave * UNROLL; s0 < nseg; s0 += 4 * UNROLL) {
+    const float* sp[UNROLL]; float* dp[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) seg_ptrs(min(s0 + u, nseg - 1), sp[u], dp[u]);
+    for (int pc = lane; pc < pieces; pc += 64) {
+      vec_t v[UNROLL];
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) v[u] = *reinterpret_cast<const vec_t*>(sp[u] + pc * VEC);
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u)
+        if (s0 + u < nseg) *reinterpret_cast<vec_t*>(dp[u] + pc * VEC) = v[u];
     }
   }
 }

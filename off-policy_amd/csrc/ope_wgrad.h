@@ -19,11 +19,15 @@ struct WgProb {
 constexpr int kMaxWgProbs = 16;
 struct WgTable {
   WgProb p[kMaxWgProbs];
-  int n, total_waves;
+  int n, total_waves, wg_reduce;
 };
 int wg_finish(WgTable* tb);
 int launch_wgrad(const WgTable& tb, float* raw, hipStream_t st);
-int launch_split_reduce(const float* raw, int64_t stride, int nsplit, int64_t n, float* rsum, hipStream_t st);
+int wg_slabs(const WgTable& tb, int nsplit);
+struct SplitRed { const float* raw0; int64_t n0; int ns0; const float* raw1; int64_t n1; int ns1; float* rsum; };
+int launch_split_reduce(const SplitRed& a, hipStream_t st);
+struct Transp4 { const float* src[4]; float* dst[4]; int rows[4], cols[4], begin[4]; int n, total; };
+int launch_transpose4(const Transp4& a, hipStream_t st);
 
 enum FinKind { FIN_ZERO = 0, FIN_COPY = 1, FIN_LNLIN_W = 2, FIN_LNLIN_G = 3, FIN_LNLIN_B = 4, FIN_TAIL = 5 };
 struct FinSeg {
@@ -43,7 +47,6 @@ struct FinTable {
   int64_t total;  // length of the flat gradient including the tail
 };
 int launch_fill(float* p, int64_t n, float v, hipStream_t st);
-int launch_loss_reduce(const float* part, int tiles, float* out, hipStream_t st);
 int launch_finalize(const FinTable& ft, const float* rsum, const float* theta, const float* loss_part, int n_loss_tiles,
                     float* grad, hipStream_t st);
 

@@ -14,6 +14,7 @@
 namespace ope {
 
 __global__ void __launch_bounds__(256) wgrad_kernel(WgTable tb, float* __restrict__ raw) {
+  __shared__ float red[3][68][64];   // partial tiles of waves 1..3: [elem][lane] (conflict-free), 64 acc + 4 colsum rows
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, g = lane >> 4;
   const int wid = blockIdx.x * 4 + wave;
@@ -103,7 +104,35 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgTable tb, float* __restric
     compute(bufB, kb + 4);   // rows >= k1 are masked to zero
     __builtin_amdgcn_sched_barrier(0);
   }
-  float* out = raw + P.raw_base + (int64_t)split * P.raw_stride;
+  // The 4 waves of a workgroup hold 4 consecutive K-splits of the same tile (nsplit % 4 == 0 for every problem when
+  // tb.wg_reduce): sum them here in a fixed order and write one slab instead of four.
+  int slab = split;
+  if (tb.wg_reduce) {
+    if (wave > 0) {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) red[wave - 1][(mi * 4 + ni) * 4 + r][lane] = acc[mi][ni][r];
+        red[wave - 1][64 + mi][lane] = cs[mi];
+      }
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w2 = 0; w2 < 3; ++w2)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[mi][ni][r] += red[w2][(mi * 4 + ni) * 4 + r][lane];
+        cs[mi] += red[w2][64 + mi][lane];
+      }
+    slab = split >> 2;
+  }
+  float* out = raw + P.raw_base + (int64_t)slab * P.raw_stride;
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -139,8 +168,13 @@ int wg_finish(WgTable* tb) {
     waves += P.mt * P.nt * P.nsplit;
   }
   tb->total_waves = waves;
+  tb->wg_reduce = 1;
+  for (int q = 0; q < tb->n; ++q)
+    if (tb->p[q].nsplit % 4 != 0) tb->wg_reduce = 0;
   return OPE_OK;
 }
+// slabs actually written per problem after the optional in-workgroup reduction
+int wg_slabs(const WgTable& tb, int nsplit) { return tb.wg_reduce ? nsplit / 4 : nsplit; }
 
 int launch_wgrad(const WgTable& tb, float* raw, hipStream_t st) {
   if (tb.n < 1 || tb.total_waves < 1) return OPE_EINVAL;
@@ -150,18 +184,23 @@ int launch_wgrad(const WgTable& tb, float* raw, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// rsum[i] = sum_s raw[s][i]  (fixed order).
+// rsum[i] = sum_s raw[s][i]  (fixed order) for two slab regions (agent, mixer) in one launch.
 // ---------------------------------------------------------------------------------------------------------
-__global__ void split_reduce_kernel(const float* __restrict__ raw, int64_t stride, int nsplit, int64_t n, float* __restrict__ rsum) {
+__global__ void split_reduce_kernel(SplitRed a) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  if (i >= a.n0 + a.n1) return;
+  const bool second = i >= a.n0;
+  const float* raw = second ? a.raw1 : a.raw0;
+  const int64_t j = second ? i - a.n0 : i, stride = second ? a.n1 : a.n0;
+  const int ns = second ? a.ns1 : a.ns0;
   float s = 0.f;
-  for (int q = 0; q < nsplit; ++q) s += raw[(int64_t)q * stride + i];
-  rsum[i] = s;
+#pragma unroll 8
+  for (int q = 0; q < ns; ++q) s += raw[(int64_t)q * stride + j];
+  a.rsum[i] = s;
 }
 
-int launch_split_reduce(const float* raw, int64_t stride, int nsplit, int64_t n, float* rsum, hipStream_t st) {
-  hipLaunchKernelGGL(split_reduce_kernel, dim3(ope_cdiv(n, 256)), dim3(256), 0, st, raw, stride, nsplit, n, rsum);
+int launch_split_reduce(const SplitRed& a, hipStream_t st) {
+  hipLaunchKernelGGL(split_reduce_kernel, dim3(ope_cdiv(a.n0 + a.n1, 256)), dim3(256), 0, st, a);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   return OPE_OK;
 }
@@ -210,9 +249,15 @@ __global__ void finalize_kernel(FinTable ft, const float* __restrict__ rsum, con
         out = acc;
         break;
       }
-      case FIN_TAIL:
-        out = loss_part[local];   // already reduced by loss_reduce_kernel
+      case FIN_TAIL: {
+        if (local < 3) {           // [loss_sum, mask_count, qtot_sum]: fixed-order sum over the per-tile partials
+          float acc = 0.f;
+#pragma unroll 16
+          for (int q = 0; q < n_loss_tiles; ++q) acc += loss_part[q * 4 + local];
+          out = acc;
+        }
         break;
+      }
       default:
         out = 0.f;
     }
@@ -230,26 +275,21 @@ int launch_fill(float* p, int64_t n, float v, hipStream_t st) {
   return OPE_OK;
 }
 
-// [tiles][4] loss partials -> 4 totals, one block, fixed summation tree (deterministic).
-__global__ void __launch_bounds__(256) loss_reduce_kernel(const float* __restrict__ part, int tiles, float* __restrict__ out) {
-  __shared__ float sm[4][4];
-  float s[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int q = threadIdx.x; q < tiles; q += 256) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(part + 4 * q);
+// dst[c][r] = src[r][c] for up to 4 matrices in one launch
+__global__ void transpose4_kernel(Transp4 a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.total) return;
+  int m = 0;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) s[c] += v[c];
-  }
-#pragma unroll
-  for (int c = 0; c < 4; ++c)
-    for (int o = 32; o > 0; o >>= 1) s[c] += __shfl_xor(s[c], o, 64);
-  if ((threadIdx.x & 63) == 0)
-    for (int c = 0; c < 4; ++c) sm[threadIdx.x >> 6][c] = s[c];
-  __syncthreads();
-  if (threadIdx.x < 4) out[threadIdx.x] = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+  for (int q = 1; q < 4; ++q)
+    if (q < a.n && i >= a.begin[q]) m = q;
+  const int j = i - a.begin[m];
+  const int rows = a.rows[m], cols = a.cols[m];
+  const int c = j / rows, r = j - c * rows;
+  a.dst[m][j] = a.src[m][(int64_t)r * cols + c];
 }
-
-int launch_loss_reduce(const float* part, int tiles, float* out, hipStream_t st) {
-  hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, st, part, tiles, out);
+int launch_transpose4(const Transp4& a, hipStream_t st) {
+  hipLaunchKernelGGL(transpose4_kernel, dim3(ope_cdiv(a.total, 256)), dim3(256), 0, st, a);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   return OPE_OK;
 }
