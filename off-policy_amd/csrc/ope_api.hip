@@ -111,7 +111,7 @@ void make_plan(const ope_qmix_cfg* c, Plan* p) {
   p->loss_tot = W.add("loss_tot", 4);
   p->ln_zero = W.add("ln_zero", R);   // mu = 0 / rstd = 1 vectors: "no LayerNorm" operands of the wgrad kernel
   p->ln_one = W.add("ln_one", R);
-  p->err_abs = W.add("err_abs", TB); p->dqtot = W.add("dqtot", TB); p->d_agent_q = W.add("d_agent_q", TB * p->N);
+  p->err_abs = W.add("err_abs", TB); p->dqtot = W.add("dqtot", 4 * TB); p->d_agent_q = W.add("d_agent_q", TB * p->N);
   p->d_b1 = W.add("d_b1", TB * OPE_MIX); p->d_v2 = W.add("d_v2", TB * OPE_MIX); p->d_v1 = W.add("d_v1", TB * p->NM);
   p->d_hw1 = W.add("d_hw1", TB * OPE_HYP); p->d_hw2 = W.add("d_hw2", TB * OPE_HYP); p->d_hb2 = W.add("d_hb2", TB * OPE_HYP);
   p->dh_out = W.add("dh_out", R1 * OPE_H); p->dqoh = W.add("dqoh", R1 * p->A4);
@@ -331,7 +331,7 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
     prob(W + p.d_v2, OPE_MIX, OPE_MIX, W + p.hw2, OPE_HYP, OPE_HYP, TBk, M.w2b_w - mbase, OPE_HYP, M.w2b_b - mbase, p.ns_mixer, mb_, ms);
     prob(W + p.d_b1, OPE_MIX, OPE_MIX, S0, p.S, p.S, TBk, M.b1_w - mbase, p.S, M.b1_b - mbase, p.ns_mixer, mb_, ms);
     prob(W + p.d_hb2, OPE_HYP, OPE_HYP, S0, p.S, p.S, TBk, M.b2a_w - mbase, p.S, M.b2a_b - mbase, p.ns_mixer, mb_, ms);
-    prob(W + p.dqtot, 1, 1, W + p.hb2, OPE_HYP, OPE_HYP, TBk, M.b2b_w - mbase, OPE_HYP, M.b2b_b - mbase, p.ns_mixer, mb_, ms);
+    prob(W + p.dqtot, 4, 1, W + p.hb2, OPE_HYP, OPE_HYP, TBk, M.b2b_w - mbase, OPE_HYP, M.b2b_b - mbase, p.ns_mixer, mb_, ms);
   }
   wt.n = n;
   if ((rc = wg_finish(&wt))) return rc;

@@ -36,7 +36,7 @@ struct MixerBwdArgs {
   const float* hw1; const float* hw2; const float* hb2; const float* v1; const float* hpre; const float* v2;
   float* loss_part;                      // [tiles][4] = loss_sum, mask_count, qtot_sum, 0
   float* err_abs;                        // [TB]
-  float* dqtot;                          // [TB]
+  float* dqtot;                          // [TB][4] (dQ_tot, 0, 0, 0)
   float* d_agent_q;                      // [TB][N]
   float* d_b1; float* d_v2;              // [TB][32]
   float* d_v1;                           // [TB][N*32]

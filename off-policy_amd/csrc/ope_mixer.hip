@@ -251,7 +251,7 @@ __global__ void __launch_bounds__(256) mixer_bwd_kernel(MixerBwdArgs a) {
   const float dQ = td.dq;
   if (valid && g == 0) {
     a.err_abs[m] = fabsf(td.err);
-    a.dqtot[m] = dQ;
+    *reinterpret_cast<f32x4*>(a.dqtot + 4 * (int64_t)m) = f32x4{dQ, 0.f, 0.f, 0.f};   // [TB][4]: lda = 4 for the wgrad kernel
   }
 
   // lane-local 32-vectors (k = 16kh + 4g + r)

@@ -16,7 +16,7 @@ namespace {
 
 constexpr int kFields = 7;
 constexpr int kBlock = 256;
-constexpr int kFloatsPerBlock = 4096;  // 16 KB of payload per workgroup
+constexpr int kFloatsPerBlock = 16384;  // 64 KB of payload per workgroup
 
 struct FieldDesc {
   const float* src;
