@@ -10,22 +10,24 @@
 //
 // HBM-bound byte movers: no arithmetic, 16-byte accesses whenever dim % 4 == 0, ~16 KB in flight per workgroup,
 // grid >> 256 workgroups. Algorithmic bytes per gather = 2 * B * episode_bytes (read + write).
+#include <stdlib.h>
+
 #include "ope_common.h"
 
 namespace {
 
 constexpr int kFields = 7;
 constexpr int kBlock = 256;
-constexpr int kFloatsPerBlock = 16384;  // 64 KB of payload per workgroup
+constexpr int kTargetFloats = 6144;  // ~24 KB of payload per workgroup
 
 struct FieldDesc {
   const float* src;
   float* dst;
-  int TT;           // time entries (T or T+1)
-  int NA;           // agent axis (1 if none)
-  int DD;           // innermost dim
-  int items_per_block;
-  int block_begin;  // first blockIdx.x of this field
+  int TT;              // time entries (T or T+1)
+  int NA;              // agent axis (1 if none)
+  int DD;              // innermost dim
+  int rows_per_block;  // destination rows (segments of DD floats) per workgroup
+  int block_begin;     // first blockIdx.x of this field
 };
 struct CopyArgs {
   FieldDesc f[kFields];
@@ -33,58 +35,60 @@ struct CopyArgs {
   int total_blocks;
 };
 
-// GATHER: src = store[inds[b]][t][a][d]          dst = out[t][a][b][d]
-// INSERT: src = staged[t][e][a][d]               dst = store[slots[e]][t][a][d]
-//
-// Work unit = one "segment": the DD contiguous floats of one (episode, t, agent). Segments of a block are dealt to its
-// 4 waves; a wave moves a segment with its 64 lanes striding over VEC-wide pieces, UNROLL segments at a time so that
-// several independent 16-byte loads are in flight per lane before the first store. All index arithmetic is per
-// segment (wave-uniform), none per element.
+// A "row" is the DD contiguous floats of one (episode, t, agent). Rows are numbered in DESTINATION order, so a block
+// owns one contiguous destination range (whole 128-byte lines when the range is a multiple of B rows: for the
+// gather, [t][a][0..B) is exactly B*DD floats) and pulls its rows from wherever they live in the source:
+//   GATHER  dst row r = (t*NA + a)*E + b   <- src row (idx[b]*TT + t)*NA + a     (store -> batch)
+//   INSERT  dst row r = (idx[e]*TT + t)*NA + a, numbered r = (e*TT + t)*NA + a  <- src row (t*E + e)*NA + a
+template <bool GATHER>
+__device__ __forceinline__ void row_ptrs(const FieldDesc& F, const int64_t* __restrict__ idx, int E, int r,
+                                         const float*& sp, float*& dp) {
+  if (GATHER) {
+    const int ta = r / E, b = r - ta * E;
+    const int t = ta / F.NA, a = ta - t * F.NA;
+    sp = F.src + (((int64_t)idx[b] * F.TT + t) * F.NA + a) * F.DD;
+    dp = F.dst + (int64_t)r * F.DD;
+  } else {
+    const int et = r / F.NA, a = r - et * F.NA;
+    const int e = et / F.TT, t = et - e * F.TT;
+    sp = F.src + (((int64_t)t * E + e) * F.NA + a) * F.DD;
+    dp = F.dst + (((int64_t)idx[e] * F.TT + t) * F.NA + a) * F.DD;
+  }
+}
+
 template <bool GATHER, int VEC>
 __device__ __forceinline__ void copy_field(const FieldDesc& F, const int64_t* __restrict__ idx, int E, int blk) {
-  constexpr int UNROLL = 4;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n_items = E * F.TT;
-  const int item0 = blk * F.items_per_block;
-  const int n_here = min(F.items_per_block, n_items - item0);
-  const int nseg = n_here * F.NA;
-  const int pieces = F.DD / VEC;          // VEC-wide pieces per segment
+  constexpr int UNROLL = 8;
   typedef float vec_t __attribute__((ext_vector_type(VEC)));
-  auto seg_ptrs = [&](int sg, const float*& sp, float*& dp) {
-    const int il = sg / F.NA, a = sg - il * F.NA;
-    const int item = item0 + il;
-    const int b = item / F.TT, t = item - b * F.TT;
-    if (GATHER) {
-      sp = F.src + (((int64_t)idx[b] * F.TT + t) * F.NA + a) * F.DD;
-      dp = F.dst + (((int64_t)t * F.NA + a) * E + b) * F.DD;
-    } else {
-      sp = F.src + (((int64_t)t * E + b) * F.NA + a) * F.DD;
-      dp = F.dst + (((int64_t)idx[b] * F.TT + t) * F.NA + a) * F.DD;
-    }
-  };
-  if (pieces <= 16) {
-    // short segments (acts, rewards, dones ...): one lane per piece, 64/pieces... keep it simple: lane-per-piece over a
-    // flattened (segment, piece) space of this block
-    const int total = nseg * pieces;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n_rows = E * F.TT * F.NA;
+  const int r0 = blk * F.rows_per_block;
+  const int nr = min(F.rows_per_block, n_rows - r0);
+  const int pieces = F.DD / VEC;          // VEC-wide pieces per row
+  if (pieces < 32) {
+    // short rows (acts, rewards, dones ...): flat (row, piece) space, one piece per thread per iteration
+    const int total = nr * pieces;
     for (int x = threadIdx.x; x < total; x += kBlock) {
-      const int sg = x / pieces, pc = x - sg * pieces;
+      const int rl = x / pieces, pc = x - rl * pieces;
       const float* sp; float* dp;
-      seg_ptrs(sg, sp, dp);
+      row_ptrs<GATHER>(F, idx, E, r0 + rl, sp, dp);
       *reinterpret_cast<vec_t*>(dp + pc * VEC) = *reinterpret_cast<const vec_t*>(sp + pc * VEC);
     }
     return;
   }
-  for (int s0 = wave * UNROLL; s0 < nseg; s0 += 4 * UNROLL) {
+  // long rows: a wave moves UNROLL rows at a time, 64 lanes striding over the pieces of each; all UNROLL loads of a
+  // lane are issued before its first store
+  for (int s0 = wave * UNROLL; s0 < nr; s0 += 4 * UNROLL) {
     const float* sp[UNROLL]; float* dp[UNROLL];
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) seg_ptrs(min(s0 + u, nseg - 1), sp[u], dp[u]);
+    for (int u = 0; u < UNROLL; ++u) row_ptrs<GATHER>(F, idx, E, r0 + min(s0 + u, nr - 1), sp[u], dp[u]);
     for (int pc = lane; pc < pieces; pc += 64) {
       vec_t v[UNROLL];
 #pragma unroll
       for (int u = 0; u < UNROLL; ++u) v[u] = *reinterpret_cast<const vec_t*>(sp[u] + pc * VEC);
 #pragma unroll
       for (int u = 0; u < UNROLL; ++u)
-        if (s0 + u < nseg) *reinterpret_cast<vec_t*>(dp[u] + pc * VEC) = v[u];
+        if (s0 + u < nr) *reinterpret_cast<vec_t*>(dp[u] + pc * VEC) = v[u];
     }
   }
 }
@@ -107,10 +111,11 @@ __global__ void __launch_bounds__(kBlock) episode_copy_kernel(CopyArgs args, con
     copy_field<GATHER, 1>(F, idx, args.n_episodes, blk);
 }
 
-int build_args(const ope_dims* d, const ope_fields* src, const ope_fields* dst, int E, CopyArgs* out) {
+int build_args(const ope_dims* d, const ope_fields* src, const ope_fields* dst, int E, bool gather, CopyArgs* out) {
   if (!d || !src || !dst) return OPE_EINVAL;
   const int T = d->episode_length, N = d->n_agents, A = d->act_dim, D = d->obs_dim, S = d->state_dim;
   if (T < 1 || N < 1 || A < 1 || D < 1 || S < 1 || E < 1) return OPE_EINVAL;
+  static const int target = getenv("OPE_GATHER_FLOATS") ? atoi(getenv("OPE_GATHER_FLOATS")) : kTargetFloats;
   const float* s[kFields] = {src->obs, src->share_obs, src->acts, src->rewards, src->dones, src->dones_env, src->avail_acts};
   float* t[kFields] = {dst->obs, dst->share_obs, dst->acts, dst->rewards, dst->dones, dst->dones_env, dst->avail_acts};
   const int TT[kFields] = {T + 1, T + 1, T, T, T, T, T + 1};
@@ -125,13 +130,17 @@ int build_args(const ope_dims* d, const ope_fields* src, const ope_fields* dst, 
     F.NA = NA[i];
     F.DD = DD[i];
     F.block_begin = blocks;
-    const int chunk = NA[i] * DD[i];
-    F.items_per_block = kFloatsPerBlock / chunk > 0 ? kFloatsPerBlock / chunk : 1;
-    if (s[i] == nullptr || t[i] == nullptr) {  // field not stored (e.g. no avail_acts): zero blocks
-      F.items_per_block = 1;
-      continue;
-    }
-    blocks += ope_cdiv((int64_t)E * TT[i], F.items_per_block);
+    // whole groups of E rows (gather: one (t, agent) over all episodes = one contiguous, line-aligned output range)
+    const int unit = gather ? E : NA[i];
+    // short rows go through the flat one-piece-per-thread path: keep those blocks to ~1 piece per thread so that they
+    // are not the tail of the launch
+    const int vecw = (DD[i] % 4 == 0) ? 4 : ((DD[i] % 2 == 0) ? 2 : 1);
+    const int tgt = (DD[i] / vecw < 32) ? kBlock * vecw : target;
+    int groups = tgt / (unit * DD[i]);
+    if (groups < 1) groups = 1;
+    F.rows_per_block = groups * unit;
+    if (s[i] == nullptr || t[i] == nullptr) continue;  // field not stored (e.g. no avail_acts): zero blocks
+    blocks += ope_cdiv((int64_t)E * TT[i] * NA[i], F.rows_per_block);
   }
   // fields with no blocks must not capture any blockIdx: give them the begin of the next one
   for (int i = kFields - 1; i >= 0; --i)
@@ -154,7 +163,7 @@ extern "C" int ope_store_gather(const ope_dims* dims, int32_t capacity, const op
   (void)hipGetLastError();  // drop stale errors from the caller's own HIP use
   if (capacity < 1 || !inds) return OPE_EINVAL;
   CopyArgs args;
-  int rc = build_args(dims, store, out, batch, &args);
+  int rc = build_args(dims, store, out, batch, true, &args);
   if (rc != OPE_OK) return rc;
   // with a hole in the middle (missing field) the "last begin <= bid" scan still works because holes alias the next begin
   hipLaunchKernelGGL(episode_copy_kernel<true>, dim3(args.total_blocks), dim3(kBlock), 0, (hipStream_t)stream, args, inds);
@@ -167,7 +176,7 @@ extern "C" int ope_store_insert(const ope_dims* dims, int32_t capacity, const op
   (void)hipGetLastError();  // drop stale errors from the caller's own HIP use
   if (capacity < 1 || !slots) return OPE_EINVAL;
   CopyArgs args;
-  int rc = build_args(dims, staged, store, n_insert, &args);
+  int rc = build_args(dims, staged, store, n_insert, false, &args);
   if (rc != OPE_OK) return rc;
   hipLaunchKernelGGL(episode_copy_kernel<false>, dim3(args.total_blocks), dim3(kBlock), 0, (hipStream_t)stream, args, slots);
   OPE_CHECK_LAUNCH();
