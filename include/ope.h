@@ -94,12 +94,16 @@ typedef struct ope_qmix_cfg {
   float huber_delta;    /* 10.0 */
   float per_nu;         /* 0.9  */
   float per_eps;        /* 1e-6 */
+  int32_t mlp;          /* 1: non-recurrent agent nets on single transitions (M_QMix / M_VDN, mqmix.py:68-218):
+                         *    dims.episode_length must be 1; batch.obs = [obs; next_obs], share_obs = [cent; next cent],
+                         *    avail_acts = [avail; next avail]                                              */
 } ope_qmix_cfg;
 
 /* Flat parameter vector: the reference's named_parameters() order (agent q-network, then mixer; qmix.py:67-72),
  * every tensor padded to a multiple of 4 floats so rows can be read as float4. The gradient vector has the
  * same layout followed by OPE_GRAD_TAIL floats: [loss_sum, mask_count, qtot_sum, 0].                        */
-#define OPE_QMIX_NPARAM_AGENT 22
+#define OPE_QMIX_NPARAM_AGENT 22      /* recurrent agent net */
+#define OPE_QMIX_NPARAM_AGENT_MLP 16  /* MLP agent net (no GRU, no rnn.norm) */
 #define OPE_QMIX_NPARAM_MIXER 14
 #define OPE_GRAD_TAIL 4
 /* Fills offsets[i]/sizes[i] (floats) for the 22 (+14 unless vdn) tensors; returns the padded total length. */
@@ -131,6 +135,12 @@ int64_t ope_agent_forward_workspace_bytes(const ope_dims* dims, int32_t seq_len,
 int ope_agent_forward(const ope_dims* dims, int32_t seq_len, int32_t rows, const float* obs, const float* h0,
                       const float* theta, void* workspace, int64_t workspace_bytes, float* q_out, float* h_out,
                       void* stream);
+
+/* Same for the MLP agent q-network of the mqmix family (AgentQFunction.forward,
+ * offpolicy/algorithms/mqmix/algorithm/agent_q_function.py:28-41): obs [rows, D] -> q_out [rows, A]. */
+int64_t ope_agent_forward_mlp_workspace_bytes(const ope_dims* dims, int32_t rows);
+int ope_agent_forward_mlp(const ope_dims* dims, int32_t rows, const float* obs, const float* theta, void* workspace,
+                          int64_t workspace_bytes, float* q_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimizer: clip_grad_norm_ + Adam + (optional) Polyak target update over the flat vectors

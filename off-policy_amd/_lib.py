@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libope.so")
 
 OPE_QMIX_NPARAM_AGENT = 22
+OPE_QMIX_NPARAM_AGENT_MLP = 16
 OPE_QMIX_NPARAM_MIXER = 14
 OPE_GRAD_TAIL = 4
 
@@ -33,7 +34,7 @@ class Fields(C.Structure):
 class QmixCfg(C.Structure):
     _fields_ = [("dims", Dims), ("batch", C.c_int32), ("vdn", C.c_int32), ("use_double_q", C.c_int32),
                 ("use_huber", C.c_int32), ("use_per", C.c_int32), ("gamma", C.c_float), ("huber_delta", C.c_float),
-                ("per_nu", C.c_float), ("per_eps", C.c_float)]
+                ("per_nu", C.c_float), ("per_eps", C.c_float), ("mlp", C.c_int32)]
 
 
 class AdamCfg(C.Structure):
@@ -63,6 +64,8 @@ def _load():
         "ope_qmix_loss_and_grad": (C.c_int, [C.POINTER(QmixCfg), C.POINTER(Fields), p, p, p, p, i64, p, p, p]),
         "ope_agent_forward_workspace_bytes": (i64, [C.POINTER(Dims), i32, i32]),
         "ope_agent_forward": (C.c_int, [C.POINTER(Dims), i32, i32, p, p, p, p, i64, p, p, p]),
+        "ope_agent_forward_mlp_workspace_bytes": (i64, [C.POINTER(Dims), i32]),
+        "ope_agent_forward_mlp": (C.c_int, [C.POINTER(Dims), i32, p, p, p, i64, p, p]),
         "ope_adam_scratch_floats": (i64, [i64]),
         "ope_adam_step": (C.c_int, [C.POINTER(AdamCfg), i64, p, p, p, p, p, p, p, p]),
         "ope_polyak": (C.c_int, [i64, p, p, C.c_float, p]),

@@ -1,0 +1,87 @@
+"""MLP per-agent Q network (mirror of offpolicy/algorithms/mqmix/algorithm/agent_q_function.py:8-41): MLPBase trunk +
+Linear head, parameters under `mlp.*` / `q.*`. Same init RNG stream as the reference's constructor."""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from .... import _lib
+from ....flat_module import FlatModule
+
+H = 64
+
+MLP_AGENT_PARAM_NAMES = [
+    "mlp.feature_norm.weight", "mlp.feature_norm.bias",
+    "mlp.mlp.fc1.0.weight", "mlp.mlp.fc1.0.bias", "mlp.mlp.fc1.2.weight", "mlp.mlp.fc1.2.bias",
+    "mlp.mlp.fc_h.0.weight", "mlp.mlp.fc_h.0.bias", "mlp.mlp.fc_h.2.weight", "mlp.mlp.fc_h.2.bias",
+    "mlp.mlp.fc2.0.0.weight", "mlp.mlp.fc2.0.0.bias", "mlp.mlp.fc2.0.2.weight", "mlp.mlp.fc2.0.2.bias",
+    "q.action_out.weight", "q.action_out.bias",
+]
+
+
+def mlp_agent_param_shapes(obs_dim, act_dim):
+    D, A = obs_dim, act_dim
+    return [(D,), (D,), (H, D), (H,), (H,), (H,), (H, H), (H,), (H,), (H,), (H, H), (H,), (H,), (H,), (A, H), (A,)]
+
+
+def mlp_agent_layout(obs_dim, act_dim):
+    cfg = _lib.QmixCfg()
+    cfg.dims = _lib.Dims(1, act_dim, obs_dim, 1, 1)
+    cfg.batch, cfg.vdn, cfg.mlp = 1, 1, 1
+    off, siz = (C.c_int64 * 36)(), (C.c_int64 * 36)()
+    total = _lib.lib.ope_qmix_param_layout(C.byref(cfg), off, siz)
+    if total < 0:
+        _lib.check(int(total), "ope_qmix_param_layout")
+    return list(off)[:16], list(siz)[:16], int(total)
+
+
+def init_mlp_agent_values(obs_dim, act_dim, use_orthogonal=True, gain_out=0.01, use_ReLU=True):
+    """MLPBase (mlp.py:52-74) then ACTLayer (act.py:5-19), drawn in the reference's order."""
+    init_w = nn.init.orthogonal_ if use_orthogonal else nn.init.xavier_uniform_
+    gain = nn.init.calculate_gain("relu" if use_ReLU else "tanh")
+    fc1 = nn.Linear(obs_dim, H)
+    init_w(fc1.weight.data, gain=gain)
+    fch = nn.Linear(H, H)
+    init_w(fch.weight.data, gain=gain)
+    qo = nn.Linear(H, act_dim)
+    init_w(qo.weight.data, gain=gain_out)
+    one, zero = torch.ones, torch.zeros
+    vals = [one(obs_dim), zero(obs_dim), fc1.weight.data, zero(H), one(H), zero(H), fch.weight.data, zero(H), one(H), zero(H),
+            fch.weight.data.clone(), zero(H), one(H), zero(H), qo.weight.data, zero(act_dim)]
+    return [v.detach().float() for v in vals]
+
+
+class AgentQFunction(FlatModule):
+    def __init__(self, args, input_dim, act_dim, device, flat=None, _init=True):
+        input_dim, act_dim, device = int(input_dim), int(act_dim), torch.device(device)
+        offs, sizes, total = mlp_agent_layout(input_dim, act_dim)
+        own = flat is None
+        if own:
+            flat = torch.zeros(total, dtype=torch.float32, device=device)
+        super().__init__(MLP_AGENT_PARAM_NAMES, mlp_agent_param_shapes(input_dim, act_dim), offs, flat)
+        self.input_dim, self.act_dim, self.hidden_size, self.device = input_dim, act_dim, H, device
+        self.padded_numel = total
+        self._args = args
+        if own and _init:
+            vals = init_mlp_agent_values(input_dim, act_dim, getattr(args, "use_orthogonal", True), getattr(args, "gain", 0.01),
+                                         getattr(args, "use_ReLU", True))
+            for p, v in zip(self.parameters(), vals):
+                p.data.copy_(v)
+        self._dims = _lib.Dims(1, act_dim, input_dim, 1, 1)
+        self._ws = None
+
+    def twin(self, flat):
+        return AgentQFunction(self._args, self.input_dim, self.act_dim, self.device, flat=flat, _init=False)
+
+    def forward(self, x):
+        x = torch.as_tensor(x, dtype=torch.float32, device=self.device).contiguous()
+        rows = int(x.shape[0])
+        need = _lib.lib.ope_agent_forward_mlp_workspace_bytes(C.byref(self._dims), rows)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+        q = torch.empty((rows, self.act_dim), dtype=torch.float32, device=self.device)
+        _lib.check(_lib.lib.ope_agent_forward_mlp(C.byref(self._dims), rows, _lib.ptr(x), _lib.ptr(self._flat), _lib.ptr(self._ws),
+                                                  self._ws.numel(), _lib.ptr(q), _lib.current_stream()), "ope_agent_forward_mlp")
+        return q
+
+    __call__ = forward

@@ -46,6 +46,8 @@ class FlatAdam(object):
 
 
 class QMix(object):
+    _mlp = False      # M_QMix overrides: non-recurrent agent nets on single transitions
+
     def __init__(self, args, num_agents, policies, policy_mapping_fn, device=torch.device("cuda:0"), episode_length=None,
                  vdn=False):
         self.args = args
@@ -84,6 +86,7 @@ class QMix(object):
             _lib.check(int(P), "ope_qmix_param_layout")
         self.numel = int(P)
         self.theta = torch.zeros(self.numel, **self.tpdv)
+        n_agent_tensors = _lib.OPE_QMIX_NPARAM_AGENT_MLP if self._mlp else _lib.OPE_QMIX_NPARAM_AGENT
         agent_numel = policy.q_network.padded_numel
         self.theta[:agent_numel].copy_(policy.q_network._flat[:agent_numel])
         policy.q_network.rebind(self.theta)            # live weights now live inside the trainer's flat vector
@@ -91,7 +94,7 @@ class QMix(object):
             self.mixer = VDNMixer(args, num_agents, policy.central_obs_dim, self.device)
         else:
             self.mixer = QMixer(args, num_agents, policy.central_obs_dim, self.device, self.theta,
-                                list(off)[_lib.OPE_QMIX_NPARAM_AGENT:_lib.OPE_QMIX_NPARAM_AGENT + _lib.OPE_QMIX_NPARAM_MIXER])
+                                list(off)[n_agent_tensors:n_agent_tensors + _lib.OPE_QMIX_NPARAM_MIXER])
         # target networks: deep copies at construction (qmix.py:63-64)
         self.theta_tgt = self.theta.clone()
         self.target_policies = {"policy_0": _TargetPolicy(policy, policy.q_network.twin(self.theta_tgt))}
@@ -99,8 +102,7 @@ class QMix(object):
             self.target_mixer = VDNMixer(args, num_agents, policy.central_obs_dim, self.device)
         else:
             self.target_mixer = QMixer(args, num_agents, policy.central_obs_dim, self.device, self.theta_tgt,
-                                       list(off)[_lib.OPE_QMIX_NPARAM_AGENT:_lib.OPE_QMIX_NPARAM_AGENT + _lib.OPE_QMIX_NPARAM_MIXER],
-                                       init=False)
+                                       list(off)[n_agent_tensors:n_agent_tensors + _lib.OPE_QMIX_NPARAM_MIXER], init=False)
         self.parameters = list(policy.parameters()) + list(self.mixer.parameters())
         self.optimizer = FlatAdam(self.numel, self.lr, self.opti_eps, self.device)
         self.grad = torch.zeros(self.numel + _lib.OPE_GRAD_TAIL, **self.tpdv)
@@ -124,6 +126,7 @@ class QMix(object):
         cfg.use_per = int(bool(a.use_per))
         cfg.gamma, cfg.huber_delta = float(a.gamma), float(a.huber_delta)
         cfg.per_nu, cfg.per_eps = float(a.per_nu), float(a.per_eps)
+        cfg.mlp = int(self._mlp)
         return cfg
 
     def _workspace(self, cfg):
@@ -173,6 +176,9 @@ class QMix(object):
         rew = self._to_device_layout(rew_b[pid], True)
         dones_env = self._to_device_layout(dones_env_b[pid], False)
         avail = self._to_device_layout(avail_b[pid], True) if (avail_b is not None and avail_b[pid] is not None) else None
+        return self._train_on_device_batch(obs, share, acts, rew, dones_env, avail, importance_weights, idxes)
+
+    def _train_on_device_batch(self, obs, share, acts, rew, dones_env, avail, importance_weights, idxes):
         T1, N, B, D = obs.shape
         assert T1 == self.episode_length + 1 and N == self.num_agents, "batch does not match the trainer's dimensions"
         cfg = self._cfg(B)

@@ -12,7 +12,8 @@ struct TrunkFwdArgs {
   int R, D;
   const float* theta;  // flat parameters of the net being evaluated
   AgentLayout L;
-  float* gi;           // [R][192]  W_ih a2 + b_ih
+  float* gi;           // [R][192]  W_ih a2 + b_ih (recurrent nets)
+  float* a2_out;       // [R][64]   trunk output (LN2 output) -- MLP nets: written instead of gi when non-null
   // saved for backward (live net only)
   float* mu0;          // [R] input-LN mean
   float* rstd0;        // [R] input-LN 1/std
@@ -45,6 +46,8 @@ struct HeadFwdArgs {
   const float* acts;                    // [T][NB][A] one-hot
   const float* avail;                   // [T+1][NB][A] or null
   int double_q;
+  int no_ln;                            // MLP nets: the head reads the trunk output directly (no rnn.norm)
+  int target_mask_avail;                // plain (non double-Q) targets: mask unavailable actions (mqmix.py:167-170)
   float* agent_q;                       // [T][B][N]
   float* agent_nq;                      // [T][B][N]
   int* act_idx;                         // [T][NB]
@@ -60,6 +63,7 @@ struct HeadBwdArgs {
   AgentLayout L;
   const float* xhat_o; const float* rstd_o;
   const int* act_idx;
+  int no_ln;                            // MLP nets: dh_out = dq * Wq[a] (adjoint of the trunk output)
   const float* d_agent_q;               // [T][B][N]
   float* dh_out;                        // [R][64]
   float* dqoh;                          // [R][A16] dq placed at the chosen action, zeros elsewhere (A16 = round4(A))
@@ -81,6 +85,7 @@ struct TrunkBwdArgs {
   const float* thetaT; // transposed copies: wihT [64][192] at 0, fc2T [64][64] at 64*192
   AgentLayout L;
   const float* dgi;    // [R][192]
+  const float* da2_in; // MLP nets: adjoint of the trunk output given directly (dgi unused)
   const float* xhat1; const float* rstd1; const uint64_t* mask1;
   const float* xhat2; const float* rstd2; const uint64_t* mask2;
   float* dz1; float* dz2;  // [R][64]

@@ -16,7 +16,7 @@ __global__ void __launch_bounds__(256) head_bwd_kernel(HeadBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];  // [Wq A*64][gamma 64]
   const int A = a.A;
   for (int i = threadIdx.x; i < A * OPE_H + OPE_H; i += blockDim.x)
-    sm[i] = (i < A * OPE_H) ? a.theta[a.L.q_w + i] : a.theta[a.L.lno_w + (i - A * OPE_H)];
+    sm[i] = (i < A * OPE_H) ? a.theta[a.L.q_w + i] : (a.no_ln ? 1.0f : a.theta[a.L.lno_w + (i - A * OPE_H)]);
   __syncthreads();
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= a.R) return;
@@ -27,6 +27,14 @@ __global__ void __launch_bounds__(256) head_bwd_kernel(HeadBwdArgs a) {
   const int act = a.act_idx[r];
   const float* wq = sm + act * OPE_H;
   const float* gam = sm + A * OPE_H;
+  const int A4 = ope_round4_dev(A);
+  for (int k = 0; k < A4; ++k) a.dqoh[r * A4 + k] = (k == act) ? dq : 0.f;
+  if (a.no_ln) {   // no LayerNorm between trunk and head: dh_out = dq * Wq[act]
+#pragma unroll
+    for (int k = 0; k < OPE_H; k += 4)
+      *reinterpret_cast<f32x4*>(a.dh_out + r * OPE_H + k) = f32x4{dq * wq[k], dq * wq[k + 1], dq * wq[k + 2], dq * wq[k + 3]};
+    return;
+  }
   const float rstd = a.rstd_o[r];
   float xh[OPE_H], dyh[OPE_H];
   float m1 = 0.f, m2 = 0.f;
@@ -51,8 +59,6 @@ __global__ void __launch_bounds__(256) head_bwd_kernel(HeadBwdArgs a) {
     for (int q = 0; q < 4; ++q) o[q] = rstd * (dyh[k + q] - m1 - xh[k + q] * m2);
     *reinterpret_cast<f32x4*>(a.dh_out + r * OPE_H + k) = o;
   }
-  const int A4 = ope_round4_dev(A);
-  for (int k = 0; k < A4; ++k) a.dqoh[r * A4 + k] = (k == act) ? dq : 0.f;
 }
 
 int launch_head_bwd(const HeadBwdArgs& a, hipStream_t st) {
@@ -247,13 +253,18 @@ __global__ void __launch_bounds__(256) trunk_bwd_kernel(TrunkBwdArgs a) {
   const float* wihT = a.thetaT;                       // [64][192]
   const float* fc2T = a.thetaT + OPE_H * 3 * OPE_H;   // [64][64]
 
-  // da2 = W_ih^T dgi   (K = 192)
+  // da2 = W_ih^T dgi   (K = 192), or given directly for MLP nets
   f32x4 d[4];
 #pragma unroll
   for (int it = 0; it < 4; ++it) d[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const float* grow = a.dgi + rr * (3 * OPE_H);
+  if (a.da2_in) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) d[it] = *reinterpret_cast<const f32x4*>(a.da2_in + rr * OPE_H + 16 * it + 4 * g);
+  }
+  const float* grow = a.dgi ? a.dgi + rr * (3 * OPE_H) : nullptr;
 #pragma unroll
   for (int c = 0; c < 12; ++c) {
+    if (a.da2_in) break;
     f32x4 bv = *reinterpret_cast<const f32x4*>(grow + 16 * c + 4 * g);
     if (!valid) bv = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll

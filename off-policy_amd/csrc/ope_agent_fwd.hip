@@ -150,6 +150,15 @@ __global__ void __launch_bounds__(256) trunk_fwd_kernel(TrunkFwdArgs a) {
     }
   }
 
+  if (a.a2_out) {   // MLP nets stop here: the trunk output feeds the head directly
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+      if (valid[t]) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) *reinterpret_cast<f32x4*>(a.a2_out + (int64_t)row[t] * OPE_H + 16 * it + 4 * g) = act[t][it];
+      }
+    return;
+  }
   // ---- gi = W_ih a2 + b_ih : 192 outputs, 4 tiles at a time ----
 #pragma unroll
   for (int grp = 0; grp < 3; ++grp) {
@@ -184,7 +193,7 @@ static int launch_trunk_vec(const TrunkFwdArgs& a, hipStream_t st) {
 }
 
 int launch_trunk_fwd(const TrunkFwdArgs& a, bool save, hipStream_t st) {
-  if (a.R < 1 || a.D < 4) return OPE_EINVAL;
+  if (a.R < 1 || a.D < 1) return OPE_EINVAL;
   const int vec = ope_vec_of(a.D);
   if (save) {
     if (vec == 4) return launch_trunk_vec<4, true>(a, st);
@@ -370,6 +379,7 @@ __global__ void __launch_bounds__(256) head_fwd_kernel(HeadFwdArgs a) {
     float v;
     if (o < A * OPE_H) v = th[a.L.q_w + o];
     else if (o < A * OPE_H + ope_round4_dev(A)) v = (o - A * OPE_H < A) ? th[a.L.q_b + (o - A * OPE_H)] : 0.f;
+    else if (a.no_ln) v = 0.f;
     else if (o < A * OPE_H + ope_round4_dev(A) + OPE_H) v = th[a.L.lno_w + (o - A * OPE_H - ope_round4_dev(A))];
     else v = th[a.L.lno_b + (o - A * OPE_H - ope_round4_dev(A) - OPE_H)];
     sm[i] = v;
@@ -383,8 +393,16 @@ __global__ void __launch_bounds__(256) head_fwd_kernel(HeadFwdArgs a) {
   const int agent = rowi / a.B, b = rowi - agent * a.B;
 
   float y[OPE_H];
-  ln64_thread(a.h0 + r * OPE_H, sm + A * OPE_H + ope_round4_dev(A), sm + A * OPE_H + ope_round4_dev(A) + OPE_H, y,
-              (MODE == 0 && a.xhat_o) ? a.xhat_o + r * OPE_H : nullptr, (MODE == 0 && a.rstd_o) ? a.rstd_o + r : nullptr);
+  if (a.no_ln) {
+#pragma unroll
+    for (int k = 0; k < OPE_H; k += 4) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(a.h0 + r * OPE_H + k);
+      y[k] = v[0]; y[k + 1] = v[1]; y[k + 2] = v[2]; y[k + 3] = v[3];
+    }
+  } else {
+    ln64_thread(a.h0 + r * OPE_H, sm + A * OPE_H + ope_round4_dev(A), sm + A * OPE_H + ope_round4_dev(A) + OPE_H, y,
+                (MODE == 0 && a.xhat_o) ? a.xhat_o + r * OPE_H : nullptr, (MODE == 0 && a.rstd_o) ? a.rstd_o + r : nullptr);
+  }
 
   if (MODE == 1) {
     for (int k = 0; k < A; ++k) {
@@ -429,7 +447,15 @@ __global__ void __launch_bounds__(256) head_fwd_kernel(HeadFwdArgs a) {
   }
   if (t >= 1) {
     const float* s1 = sm + per;
-    ln64_thread(a.h1 + r * OPE_H, s1 + A * OPE_H + ope_round4_dev(A), s1 + A * OPE_H + ope_round4_dev(A) + OPE_H, y, nullptr, nullptr);
+    if (a.no_ln) {
+#pragma unroll
+      for (int k = 0; k < OPE_H; k += 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(a.h1 + r * OPE_H + k);
+        y[k] = v[0]; y[k + 1] = v[1]; y[k + 2] = v[2]; y[k + 3] = v[3];
+      }
+    } else {
+      ln64_thread(a.h1 + r * OPE_H, s1 + A * OPE_H + ope_round4_dev(A), s1 + A * OPE_H + ope_round4_dev(A) + OPE_H, y, nullptr, nullptr);
+    }
     float tq;
     if (a.double_q) {
       tq = s1[A * OPE_H + greedy];
@@ -441,6 +467,7 @@ __global__ void __launch_bounds__(256) head_fwd_kernel(HeadFwdArgs a) {
         float q = s1[A * OPE_H + k];
 #pragma unroll
         for (int f = 0; f < OPE_H; ++f) q = fmaf(s1[k * OPE_H + f], y[f], q);
+        if (a.target_mask_avail && av && av[k] == 0.f) q = -1e10f;
         if (k == 0 || q > tq) tq = q;
       }
     }

@@ -14,6 +14,7 @@ int g_debug = 0;
 bool cfg_ok(const ope_qmix_cfg* c) {
   if (!c) return false;
   const ope_dims& d = c->dims;
+  if (c->mlp && d.episode_length != 1) return false;   // MLP (transition) mode = one-step "episodes"
   return d.n_agents >= 1 && d.act_dim >= 1 && d.obs_dim >= 1 && d.obs_dim <= 512 && d.state_dim >= 1 &&
          d.episode_length >= 1 && c->batch >= 1 && d.n_agents <= 64 && d.act_dim <= 200;
 }
@@ -47,7 +48,7 @@ struct Raw {  // offsets inside one split slab, agent region then mixer region
 };
 
 struct Plan {
-  int T, N, A, D, S, B, NB, A4, NM;
+  int T, N, A, D, S, B, NB, A4, NM, mlp;
   int64_t R, R1, TB;
   AgentLayout AL;
   MixerLayout ML;   // offsets in the full theta (base = AL.end)
@@ -70,7 +71,8 @@ void make_plan(const ope_qmix_cfg* c, Plan* p) {
   p->T = d.episode_length; p->N = d.n_agents; p->A = d.act_dim; p->D = d.obs_dim; p->S = d.state_dim; p->B = c->batch;
   p->NB = p->N * p->B; p->A4 = ope_round4(p->A); p->NM = p->N * OPE_MIX;
   p->R = (int64_t)(p->T + 1) * p->NB; p->R1 = (int64_t)p->T * p->NB; p->TB = (int64_t)p->T * p->B;
-  p->AL = ope_agent_layout(p->D, p->A, 0);
+  p->mlp = c->mlp;
+  p->AL = c->mlp ? ope_agent_layout_mlp(p->D, p->A, 0) : ope_agent_layout(p->D, p->A, 0);
   if (c->vdn) {
     memset(&p->ML, 0, sizeof(p->ML));
     p->ML.end = p->AL.end;
@@ -142,26 +144,28 @@ extern "C" void ope_set_debug(int on) { g_debug = on; }
 extern "C" int64_t ope_qmix_param_layout(const ope_qmix_cfg* cfg, int64_t* offsets, int64_t* sizes) {
   if (!cfg_ok(cfg)) return OPE_EINVAL;
   const int D = cfg->dims.obs_dim, A = cfg->dims.act_dim, N = cfg->dims.n_agents, S = cfg->dims.state_dim;
-  const AgentLayout L = ope_agent_layout(D, A, 0);
-  const int ao[OPE_QMIX_NPARAM_AGENT] = {L.fn_w, L.fn_b, L.fc1_w, L.fc1_b, L.ln1_w, L.ln1_b, L.fch_w, L.fch_b, L.lnh_w, L.lnh_b,
-                                         L.fc2_w, L.fc2_b, L.ln2_w, L.ln2_b, L.wih, L.whh, L.bih, L.bhh, L.lno_w, L.lno_b, L.q_w, L.q_b};
-  const int as[OPE_QMIX_NPARAM_AGENT] = {D, D, OPE_H * D, OPE_H, OPE_H, OPE_H, OPE_H * OPE_H, OPE_H, OPE_H, OPE_H,
-                                         OPE_H * OPE_H, OPE_H, OPE_H, OPE_H, 3 * OPE_H * OPE_H, 3 * OPE_H * OPE_H, 3 * OPE_H, 3 * OPE_H,
-                                         OPE_H, OPE_H, A * OPE_H, A};
-  for (int i = 0; i < OPE_QMIX_NPARAM_AGENT; ++i) {
-    if (offsets) offsets[i] = ao[i];
-    if (sizes) sizes[i] = as[i];
+  const AgentLayout L = cfg->mlp ? ope_agent_layout_mlp(D, A, 0) : ope_agent_layout(D, A, 0);
+  int na = 0;
+  auto put = [&](int off, int size) {
+    if (offsets) offsets[na] = off;
+    if (sizes) sizes[na] = size;
+    ++na;
+  };
+  put(L.fn_w, D); put(L.fn_b, D); put(L.fc1_w, OPE_H * D); put(L.fc1_b, OPE_H); put(L.ln1_w, OPE_H); put(L.ln1_b, OPE_H);
+  put(L.fch_w, OPE_H * OPE_H); put(L.fch_b, OPE_H); put(L.lnh_w, OPE_H); put(L.lnh_b, OPE_H);
+  put(L.fc2_w, OPE_H * OPE_H); put(L.fc2_b, OPE_H); put(L.ln2_w, OPE_H); put(L.ln2_b, OPE_H);
+  if (!cfg->mlp) {
+    put(L.wih, 3 * OPE_H * OPE_H); put(L.whh, 3 * OPE_H * OPE_H); put(L.bih, 3 * OPE_H); put(L.bhh, 3 * OPE_H);
+    put(L.lno_w, OPE_H); put(L.lno_b, OPE_H);
   }
+  put(L.q_w, A * OPE_H); put(L.q_b, A);
   if (cfg->vdn) return L.end;
   const MixerLayout M = ope_mixer_layout(N, S, L.end);
   const int mo[OPE_QMIX_NPARAM_MIXER] = {M.w1a_w, M.w1a_b, M.w1b_w, M.w1b_b, M.w2a_w, M.w2a_b, M.w2b_w, M.w2b_b,
                                          M.b1_w, M.b1_b, M.b2a_w, M.b2a_b, M.b2b_w, M.b2b_b};
   const int ms[OPE_QMIX_NPARAM_MIXER] = {OPE_HYP * S, OPE_HYP, N * OPE_MIX * OPE_HYP, N * OPE_MIX, OPE_HYP * S, OPE_HYP,
                                          OPE_MIX * OPE_HYP, OPE_MIX, OPE_MIX * S, OPE_MIX, OPE_HYP * S, OPE_HYP, OPE_HYP, 1};
-  for (int i = 0; i < OPE_QMIX_NPARAM_MIXER; ++i) {
-    if (offsets) offsets[OPE_QMIX_NPARAM_AGENT + i] = mo[i];
-    if (sizes) sizes[OPE_QMIX_NPARAM_AGENT + i] = ms[i];
-  }
+  for (int i = 0; i < OPE_QMIX_NPARAM_MIXER; ++i) put(mo[i], ms[i]);
   return M.end;
 }
 
@@ -208,13 +212,14 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
 
   // ---- forward: trunks of both nets ----
   TrunkFwdArgs tf;
-  tf.x = batch->obs; tf.R = (int)p.R; tf.D = p.D; tf.theta = theta; tf.L = p.AL; tf.gi = W + p.gi;
+  tf.x = batch->obs; tf.R = (int)p.R; tf.D = p.D; tf.theta = theta; tf.L = p.AL;
+  tf.gi = p.mlp ? nullptr : W + p.gi; tf.a2_out = p.mlp ? W + p.h : nullptr;
   tf.mu0 = W + p.mu0; tf.rstd0 = W + p.rstd0;
   tf.xhat1 = W + p.xhat1; tf.rstd1 = W + p.rstd1; tf.mask1 = (uint64_t*)(W + p.mask1);
   tf.xhat2 = W + p.xhat2; tf.rstd2 = W + p.rstd2; tf.mask2 = (uint64_t*)(W + p.mask2);
   if ((rc = launch_trunk_fwd(tf, true, st))) return rc;
   TrunkFwdArgs tt = tf;
-  tt.theta = theta_tgt; tt.gi = W + p.gi_t;
+  tt.theta = theta_tgt; tt.gi = p.mlp ? nullptr : W + p.gi_t; tt.a2_out = p.mlp ? W + p.h_t : nullptr;
   if ((rc = launch_trunk_fwd(tt, false, st))) return rc;
 
   // ---- forward: GRU scans (live + target in one launch) ----
@@ -222,12 +227,14 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
   gf.nets = 2; gf.NB = p.NB; gf.L = p.T + 1; gf.theta0 = theta; gf.theta1 = theta_tgt; gf.gi0 = W + p.gi; gf.gi1 = W + p.gi_t;
   gf.h0out = W + p.h; gf.h1out = W + p.h_t; gf.hinit = nullptr; gf.whh_off = p.AL.whh; gf.bhh_off = p.AL.bhh;
   gf.rg = W + p.rg; gf.zg = W + p.zg; gf.ng = W + p.ng; gf.ghn = W + p.ghn;
-  if ((rc = launch_gru_fwd(gf, st))) return rc;
+  if (!p.mlp)
+    if ((rc = launch_gru_fwd(gf, st))) return rc;
 
   // ---- forward: heads ----
   HeadFwdArgs hf;
   hf.R = p.R; hf.NB = p.NB; hf.B = p.B; hf.N = p.N; hf.T = p.T; hf.A = p.A; hf.theta0 = theta; hf.theta1 = theta_tgt; hf.L = p.AL;
   hf.h0 = W + p.h; hf.h1 = W + p.h_t; hf.acts = batch->acts; hf.avail = batch->avail_acts; hf.double_q = cfg->use_double_q;
+  hf.no_ln = p.mlp; hf.target_mask_avail = p.mlp;
   hf.agent_q = W + p.agent_q; hf.agent_nq = W + p.agent_nq; hf.act_idx = (int*)(W + p.act_idx);
   hf.xhat_o = W + p.xhat_o; hf.rstd_o = W + p.rstd_o; hf.q_out = nullptr; hf.q_all = g_debug ? W + p.q_all : nullptr;
   if ((rc = launch_head_fwd(hf, 0, st))) return rc;
@@ -243,7 +250,7 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
     auto add = [&](const float* src, int rows, int cols, float* dst) {
       tr.src[nt] = src; tr.dst[nt] = dst; tr.rows[nt] = rows; tr.cols[nt] = cols; tr.begin[nt] = tot; tot += rows * cols; ++nt;
     };
-    add(theta + p.AL.wih, 3 * OPE_H, OPE_H, W + p.thetaT);
+    if (!p.mlp) add(theta + p.AL.wih, 3 * OPE_H, OPE_H, W + p.thetaT);
     add(theta + p.AL.fc2_w, OPE_H, OPE_H, W + p.thetaT + OPE_H * 3 * OPE_H);
     if (!cfg->vdn) {
       add(theta + p.ML.w1b_w, p.NM, OPE_HYP, W + p.mixT);
@@ -277,15 +284,17 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
   // ---- agent backward ----
   HeadBwdArgs hb;
   hb.R = p.R1; hb.NB = p.NB; hb.B = p.B; hb.N = p.N; hb.A = p.A; hb.theta = theta; hb.L = p.AL;
+  hb.no_ln = p.mlp;
   hb.xhat_o = W + p.xhat_o; hb.rstd_o = W + p.rstd_o; hb.act_idx = (const int*)(W + p.act_idx); hb.d_agent_q = W + p.d_agent_q;
   hb.dh_out = W + p.dh_out; hb.dqoh = W + p.dqoh;
   if ((rc = launch_head_bwd(hb, st))) return rc;
   GruBwdArgs gb;
   gb.NB = p.NB; gb.T = p.T; gb.theta = theta; gb.whh_off = p.AL.whh; gb.h = W + p.h;
   gb.rg = W + p.rg; gb.zg = W + p.zg; gb.ng = W + p.ng; gb.ghn = W + p.ghn; gb.dh_out = W + p.dh_out; gb.dgi = W + p.dgi; gb.dghn = W + p.dghn;
-  if ((rc = launch_gru_bwd(gb, st))) return rc;
+  if (!p.mlp)
+    if ((rc = launch_gru_bwd(gb, st))) return rc;
   TrunkBwdArgs tb;
-  tb.R = (int)p.R1; tb.theta = theta; tb.thetaT = W + p.thetaT; tb.L = p.AL; tb.dgi = W + p.dgi;
+  tb.R = (int)p.R1; tb.theta = theta; tb.thetaT = W + p.thetaT; tb.L = p.AL; tb.dgi = p.mlp ? nullptr : W + p.dgi; tb.da2_in = p.mlp ? W + p.dh_out : nullptr;
   tb.xhat1 = W + p.xhat1; tb.rstd1 = W + p.rstd1; tb.mask1 = (const uint64_t*)(W + p.mask1);
   tb.xhat2 = W + p.xhat2; tb.rstd2 = W + p.rstd2; tb.mask2 = (const uint64_t*)(W + p.mask2);
   tb.dz1 = W + p.dz1; tb.dz2 = W + p.dz2;
@@ -311,14 +320,15 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
     q.ln_mu = W + p.mu0; q.ln_rstd = W + p.rstd0;
   }
   prob(W + p.dz2, OPE_H, OPE_H, W + p.xhat1, OPE_H, OPE_H, K1, rw.P2, OPE_H, rw.s2, p.ns_agent, ab, as);
-  prob(W + p.dgi, 3 * OPE_H, 3 * OPE_H, W + p.xhat2, OPE_H, OPE_H, K1, rw.P3, OPE_H, rw.s3, p.ns_agent, ab, as);
-  {
+  if (!p.mlp) {
+    prob(W + p.dgi, 3 * OPE_H, 3 * OPE_H, W + p.xhat2, OPE_H, OPE_H, K1, rw.P3, OPE_H, rw.s3, p.ns_agent, ab, as);
     WgProb& q = prob(W + p.dgi, 3 * OPE_H, 2 * OPE_H, W + p.h, OPE_H, OPE_H, K1, rw.WHH, OPE_H, rw.shh, p.ns_agent, ab, as);
     q.b_shift = p.NB;  // h_{t-1}
     WgProb& q2 = prob(W + p.dghn, OPE_H, OPE_H, W + p.h, OPE_H, OPE_H, K1, rw.WHH + 2 * OPE_H * OPE_H, OPE_H, rw.shh + 2 * OPE_H, p.ns_agent, ab, as);
     q2.b_shift = p.NB;
   }
-  prob(W + p.dqoh, p.A4, p.A, W + p.xhat_o, OPE_H, OPE_H, K1, rw.E, OPE_H, rw.sq, p.ns_agent, ab, as);
+  // q head: fed by rnn.norm (recurrent) or directly by the trunk's LN2 (MLP) -- both "Linear after LayerNorm"
+  prob(W + p.dqoh, p.A4, p.A, p.mlp ? W + p.xhat2 : W + p.xhat_o, OPE_H, OPE_H, K1, rw.E, OPE_H, rw.sq, p.ns_agent, ab, as);
   if (!cfg->vdn) {
     const MixerLayout& M = p.ML;
     const int mbase = p.AL.end;
@@ -362,15 +372,21 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
   seg(L.fch_w, 0, FIN_ZERO, 0, 0, 0, 0, 0, 0, 0);  // fc_h.*: registered, never used (mlp.py:21-23) -> zero gradient
   seg(L.fc2_w, OPE_H * OPE_H, FIN_LNLIN_W, rw.P2, rw.s2, OPE_H, OPE_H, L.fc2_w, L.ln1_w, L.ln1_b);
   seg(L.fc2_b, OPE_H, FIN_COPY, rw.s2, 0, 0, 0, 0, 0, 0);
-  seg(L.ln2_w, OPE_H, FIN_LNLIN_G, rw.P3, rw.s3, 3 * OPE_H, OPE_H, L.wih, 0, 0);
-  seg(L.ln2_b, OPE_H, FIN_LNLIN_B, rw.P3, rw.s3, 3 * OPE_H, OPE_H, L.wih, 0, 0);
-  seg(L.wih, 3 * OPE_H * OPE_H, FIN_LNLIN_W, rw.P3, rw.s3, 3 * OPE_H, OPE_H, L.wih, L.ln2_w, L.ln2_b);
-  seg(L.whh, 3 * OPE_H * OPE_H, FIN_COPY, rw.WHH, 0, 0, 0, 0, 0, 0);
-  seg(L.bih, 3 * OPE_H, FIN_COPY, rw.s3, 0, 0, 0, 0, 0, 0);
-  seg(L.bhh, 3 * OPE_H, FIN_COPY, rw.shh, 0, 0, 0, 0, 0, 0);
-  seg(L.lno_w, OPE_H, FIN_LNLIN_G, rw.E, rw.sq, p.A, OPE_H, L.q_w, 0, 0);
-  seg(L.lno_b, OPE_H, FIN_LNLIN_B, rw.E, rw.sq, p.A, OPE_H, L.q_w, 0, 0);
-  seg(L.q_w, p.A * OPE_H, FIN_LNLIN_W, rw.E, rw.sq, p.A, OPE_H, L.q_w, L.lno_w, L.lno_b);
+  if (!p.mlp) {
+    seg(L.ln2_w, OPE_H, FIN_LNLIN_G, rw.P3, rw.s3, 3 * OPE_H, OPE_H, L.wih, 0, 0);
+    seg(L.ln2_b, OPE_H, FIN_LNLIN_B, rw.P3, rw.s3, 3 * OPE_H, OPE_H, L.wih, 0, 0);
+    seg(L.wih, 3 * OPE_H * OPE_H, FIN_LNLIN_W, rw.P3, rw.s3, 3 * OPE_H, OPE_H, L.wih, L.ln2_w, L.ln2_b);
+    seg(L.whh, 3 * OPE_H * OPE_H, FIN_COPY, rw.WHH, 0, 0, 0, 0, 0, 0);
+    seg(L.bih, 3 * OPE_H, FIN_COPY, rw.s3, 0, 0, 0, 0, 0, 0);
+    seg(L.bhh, 3 * OPE_H, FIN_COPY, rw.shh, 0, 0, 0, 0, 0, 0);
+    seg(L.lno_w, OPE_H, FIN_LNLIN_G, rw.E, rw.sq, p.A, OPE_H, L.q_w, 0, 0);
+    seg(L.lno_b, OPE_H, FIN_LNLIN_B, rw.E, rw.sq, p.A, OPE_H, L.q_w, 0, 0);
+    seg(L.q_w, p.A * OPE_H, FIN_LNLIN_W, rw.E, rw.sq, p.A, OPE_H, L.q_w, L.lno_w, L.lno_b);
+  } else {   // MLP nets: LN2 feeds the q head
+    seg(L.ln2_w, OPE_H, FIN_LNLIN_G, rw.E, rw.sq, p.A, OPE_H, L.q_w, 0, 0);
+    seg(L.ln2_b, OPE_H, FIN_LNLIN_B, rw.E, rw.sq, p.A, OPE_H, L.q_w, 0, 0);
+    seg(L.q_w, p.A * OPE_H, FIN_LNLIN_W, rw.E, rw.sq, p.A, OPE_H, L.q_w, L.ln2_w, L.ln2_b);
+  }
   seg(L.q_b, p.A, FIN_COPY, rw.sq, 0, 0, 0, 0, 0, 0);
   if (!cfg->vdn) {  // mixer gradients: raw mixer slab has the same relative layout as the parameters
     const MixerLayout& M = p.ML;
@@ -420,5 +436,32 @@ extern "C" int ope_agent_forward(const ope_dims* d, int32_t seq_len, int32_t row
   memset(&hf, 0, sizeof(hf));
   hf.R = R; hf.NB = rows; hf.B = rows; hf.N = 1; hf.T = seq_len; hf.A = d->act_dim; hf.theta0 = theta; hf.theta1 = theta; hf.L = L;
   hf.h0 = h_out; hf.q_out = q_out;
+  return launch_head_fwd(hf, 1, st);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int64_t ope_agent_forward_mlp_workspace_bytes(const ope_dims* d, int32_t rows) {
+  if (!d || rows < 1) return OPE_EINVAL;
+  return ((int64_t)rows * OPE_H + 64) * (int64_t)sizeof(float);
+}
+
+extern "C" int ope_agent_forward_mlp(const ope_dims* d, int32_t rows, const float* obs, const float* theta, void* workspace,
+                                     int64_t workspace_bytes, float* q_out, void* stream) {
+  (void)hipGetLastError();
+  if (!d || rows < 1 || !obs || !theta || !workspace || !q_out) return OPE_EINVAL;
+  if (d->obs_dim < 1 || d->obs_dim > 512 || d->act_dim < 1) return OPE_EINVAL;
+  if (workspace_bytes < ope_agent_forward_mlp_workspace_bytes(d, rows)) return OPE_ENOSPC;
+  hipStream_t st = (hipStream_t)stream;
+  const AgentLayout L = ope_agent_layout_mlp(d->obs_dim, d->act_dim, 0);
+  float* a2 = (float*)workspace;
+  int rc;
+  TrunkFwdArgs tf;
+  memset(&tf, 0, sizeof(tf));
+  tf.x = obs; tf.R = rows; tf.D = d->obs_dim; tf.theta = theta; tf.L = L; tf.a2_out = a2;
+  if ((rc = launch_trunk_fwd(tf, false, st))) return rc;
+  HeadFwdArgs hf;
+  memset(&hf, 0, sizeof(hf));
+  hf.R = rows; hf.NB = rows; hf.B = rows; hf.N = 1; hf.T = 1; hf.A = d->act_dim; hf.theta0 = theta; hf.theta1 = theta; hf.L = L;
+  hf.h0 = a2; hf.q_out = q_out; hf.no_ln = 1;
   return launch_head_fwd(hf, 1, st);
 }

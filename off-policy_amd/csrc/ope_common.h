@@ -188,6 +188,22 @@ static inline AgentLayout ope_agent_layout(int D, int A, int base) {
   return L;
 }
 
+// MLP (non-recurrent) agent network of the mqmix / maddpg families: same trunk, head fed directly by LN2; the GRU and
+// rnn.norm tensors do not exist (offsets -1).
+static inline AgentLayout ope_agent_layout_mlp(int D, int A, int base) {
+  AgentLayout L;
+  int o = base;
+  auto take = [&](int n) { int r = o; o += ope_round4(n); return r; };
+  L.fn_w = take(D); L.fn_b = take(D);
+  L.fc1_w = take(OPE_H * D); L.fc1_b = take(OPE_H); L.ln1_w = take(OPE_H); L.ln1_b = take(OPE_H);
+  L.fch_w = take(OPE_H * OPE_H); L.fch_b = take(OPE_H); L.lnh_w = take(OPE_H); L.lnh_b = take(OPE_H);
+  L.fc2_w = take(OPE_H * OPE_H); L.fc2_b = take(OPE_H); L.ln2_w = take(OPE_H); L.ln2_b = take(OPE_H);
+  L.wih = L.whh = L.bih = L.bhh = L.lno_w = L.lno_b = -1;
+  L.q_w = take(A * OPE_H); L.q_b = take(A);
+  L.end = o;
+  return L;
+}
+
 static inline MixerLayout ope_mixer_layout(int N, int S, int base) {
   MixerLayout L;
   int o = base;

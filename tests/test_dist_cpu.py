@@ -1,0 +1,76 @@
+"""CPU, world_size 2 over gloo: the data-parallel algebra and plumbing of off-policy_amd/dist.py.
+
+Each rank back-propagates the UN-normalised loss sum of its half of the sampled episodes (here with the CPU oracle
+standing in for the HIP step, which needs a GPU), the flat [grads | loss_sum | mask_count | qtot_sum] vector goes
+through ONE all-reduce, and the result must equal the single-process full-batch quantities -- which is exactly what
+QMix.train_policy_on_batch relies on when torch.distributed is initialised."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, name, out_q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from conftest import load_golden
+        from golden_util import oracle_from, reference_store_from
+        from oracle import qmix_oracle as O
+        from offpolicy_amd import dist as opdist
+        g = load_golden(name)
+        orc, dims = oracle_from(g)
+        store, _ = reference_store_from(g)
+        inds = np.asarray(g["inds"])[:4]
+        assert opdist.is_distributed() and opdist.world() == (rank, world)
+        mine = opdist.shard_indices(inds)
+        assert len(mine) == len(inds) // world and np.array_equal(mine, inds[rank * 2:(rank + 1) * 2])
+        grads, ls, cnt, qs = orc.loss_sum_and_grads(O.sample_inds(store, mine))
+        flat = torch.cat([v.flatten() for v in grads.values()] + [torch.tensor([ls, cnt, qs, 0.0])])
+        opdist.allreduce_flat_(flat)
+        out_q.put((rank, flat.numpy()))
+    finally:
+        torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["qmix_tiny"])
+def test_sharded_gradients_allreduce_to_full_batch(name):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import load_golden
+    from golden_util import oracle_from, reference_store_from
+    from oracle import qmix_oracle as O
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert np.array_equal(res[0], res[1]), "ranks disagree after the all-reduce"
+    g = load_golden(name)
+    orc, _ = oracle_from(g)
+    store, _ = reference_store_from(g)
+    grads, ls, cnt, qs = orc.loss_sum_and_grads(O.sample_inds(store, np.asarray(g["inds"])[:4]))
+    want = torch.cat([v.flatten() for v in grads.values()] + [torch.tensor([ls, cnt, qs, 0.0])]).numpy()
+    np.testing.assert_allclose(res[0], want, rtol=2e-4, atol=1e-5)
+
+
+def test_single_process_helpers_are_noops():
+    from offpolicy_amd import dist as opdist
+    assert not opdist.is_distributed() and opdist.world() == (0, 1)
+    t = torch.arange(4.0)
+    assert opdist.allreduce_flat_(t) is t and torch.equal(t, torch.arange(4.0))
+    assert np.array_equal(opdist.shard_indices(np.arange(6), 1, 3), [2, 3])
+    with pytest.raises(AssertionError):
+        opdist.shard_indices(np.arange(5), 0, 2)

@@ -182,3 +182,35 @@ def test_full_size_3s5z_matches_oracle_one_step():
             d = np.abs(v.detach().cpu().numpy() - ref[k].numpy())
             assert d.max() <= lr * 1.01, k
             assert (d <= 2e-5).mean() >= 0.995, (k, float((d <= 2e-5).mean()))
+
+
+def test_runner_call_sequence_with_per():
+    """The call sequence of RecRunner.batch_train_q (offpolicy/runner/rnn/base_runner.py:259-284) against our classes:
+    sample(beta, p_id) -> train_policy_on_batch -> update_priorities -> soft_target_updates, repeated; loss goes down."""
+    from offpolicy_amd.config import default_args
+    from offpolicy_amd.utils.synth import DIMS, synth_episodes, policy_info_for, as_policy_dicts
+    from offpolicy_amd.utils.rec_buffer import PrioritizedRecReplayBuffer
+    from offpolicy_amd.algorithms.qmix.algorithm.QMixPolicy import QMixPolicy
+    from offpolicy_amd.algorithms.qmix.qmix import QMix
+    dims = DIMS["tiny"]
+    args = default_args(use_per=True, lr=1e-3)
+    torch.manual_seed(2)
+    np.random.seed(2)
+    dev = torch.device("cuda:0")
+    pinfo = policy_info_for(dims)
+    policy = QMixPolicy({"args": args, "device": dev}, pinfo["policy_0"])
+    trainer = QMix(args, dims.n_agents, {"policy_0": policy}, lambda a: "policy_0", device=dev, episode_length=dims.episode_length)
+    buf = PrioritizedRecReplayBuffer(args.per_alpha, pinfo, {"policy_0": [0, 1]}, 24, dims.episode_length, True, True, device=dev)
+    d = as_policy_dicts(synth_episodes(np.random.RandomState(0), 24, dims, avail="bernoulli", runner_padding=True))
+    buf.insert(24, d["obs"], d["share_obs"], d["acts"], d["rewards"], d["dones"], d["dones_env"], d["avail_acts"])
+    losses = []
+    for it in range(30):
+        trainer.prep_training()
+        sample = buf.sample(8, 0.4, "policy_0")
+        info, new_priorities, idxes = trainer.train_policy_on_batch(sample)
+        buf.update_priorities(idxes, new_priorities, "policy_0")
+        trainer.soft_target_updates()
+        losses.append(float(info["loss"]))
+        assert np.isfinite(losses[-1]) and new_priorities.shape == (8,) and (new_priorities > 0).all()
+    assert np.mean(losses[-5:]) < np.mean(losses[:5])
+    assert buf.max_priorities["policy_0"] >= 1.0

@@ -62,3 +62,47 @@ def test_gather_untouched_slots_keep_reference_defaults():
     obs, share, acts, rew, dones, dones_env, avail = buf.policy_buffers["policy_0"].sample_inds(np.array([0, 3]))
     assert float(obs.abs().sum()) == 0 and float(acts.abs().sum()) == 0 and float(rew.abs().sum()) == 0
     assert bool((avail == 1).all()) and bool((dones == 1).all()) and bool((dones_env == 1).all())
+
+
+def test_prioritized_buffer_flow():
+    """PrioritizedRecReplayBuffer: every inserted slot gets max_priority**alpha (SURVEY A-3 fix), proportional sampling
+    and importance weights follow rec_buffer.py:278-304, update_priorities follows 306-324 incl. its assertions."""
+    from offpolicy_amd.utils.synth import DIMS, synth_episodes, policy_info_for, as_policy_dicts
+    from offpolicy_amd.utils.rec_buffer import PrioritizedRecReplayBuffer
+    dims = DIMS["tiny"]
+    alpha, beta = 0.6, 0.4
+    buf = PrioritizedRecReplayBuffer(alpha, policy_info_for(dims), {"policy_0": [0, 1]}, 6, dims.episode_length, True, True,
+                                     device="cuda:0")
+    rng = np.random.RandomState(0)
+    for n in (1, 4, 3):               # a single-episode insert (crashes upstream), then a wrap-around
+        d = as_policy_dicts(synth_episodes(rng, n, dims))
+        idx = buf.insert(n, d["obs"], d["share_obs"], d["acts"], d["rewards"], d["dones"], d["dones_env"], d["avail_acts"])
+        assert np.allclose(buf._it_sums["policy_0"][idx], 1.0)
+    assert len(buf) == 6
+    np.testing.assert_allclose(buf._it_sums["policy_0"].sum(), 6.0)
+    np.random.seed(4)
+    out = buf.sample(4, beta=beta, p_id="policy_0")
+    weights, inds = out[7], out[8]
+    assert out[0]["policy_0"].shape == (dims.n_agents, dims.episode_length + 1, 4, dims.obs_dim)
+    np.testing.assert_allclose(weights, np.ones(4))           # equal priorities -> all weights 1
+    prios = np.array([0.5, 2.0, 1.0, 3.0])
+    buf.update_priorities(inds, prios, p_id="policy_0")
+    assert buf.max_priorities["policy_0"] == 3.0
+    want = np.ones(6)
+    for i, p in zip(inds, prios):
+        want[i] = p ** alpha
+    np.testing.assert_allclose(buf._it_sums["policy_0"][np.arange(6)], want)
+    np.testing.assert_allclose(buf._it_mins["policy_0"].min(), want.min())
+    np.random.seed(5)
+    w2, i2 = buf.sample(5, beta=beta, p_id="policy_0")[7:]
+    p_s = want[i2] / want.sum()
+    np.testing.assert_allclose(w2, (p_s * 6) ** (-beta) / ((want.min() / want.sum() * 6) ** (-beta)))
+    with pytest.raises(AssertionError):
+        buf.update_priorities(inds, np.array([1.0, 0.0, 1.0, 1.0]), p_id="policy_0")     # priorities must be > 0
+    with pytest.raises(AssertionError):
+        buf.sample(6, beta=beta, p_id="policy_0")                                        # needs len > batch_size
+    with pytest.raises(AssertionError):
+        buf.sample(2, beta=0, p_id="policy_0")
+    d = as_policy_dicts(synth_episodes(rng, 2, dims))
+    new_idx = buf.insert(2, d["obs"], d["share_obs"], d["acts"], d["rewards"], d["dones"], d["dones_env"], d["avail_acts"])
+    np.testing.assert_allclose(buf._it_sums["policy_0"][new_idx], 3.0 ** alpha)          # new episodes get the running max
