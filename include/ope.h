@@ -156,12 +156,64 @@ typedef struct ope_adam_cfg {
   int32_t do_polyak;      /* fuse soft_target_updates() into this call                    */
   int32_t step;           /* 1-based Adam step count (bias correction)                    */
   float qtot_denominator; /* T*B_global: Q_tot is a mean over ALL steps (qmix.py:198)     */
+  int32_t tail_offset;    /* index of the 4-float tail inside `grad`; <= 0 means n. Lets a PREFIX of a parameter vector
+                           * be optimised (n < full length) while the tail stays behind the full gradient: MADDPG's
+                           * critic, whose q heads are unregistered upstream (SURVEY A-4) and therefore frozen.     */
 } ope_adam_cfg;
 int64_t ope_adam_scratch_floats(int64_t n);
 int ope_adam_step(const ope_adam_cfg* cfg, int64_t n, float* theta, float* theta_tgt, float* adam_m, float* adam_v,
                   const float* grad, float* scratch, float* stats_out, void* stream);
 /* soft_update (util.py:123-134) / hard_update (util.py:137-145) on flat vectors. tau=1 is a hard copy. */
 int ope_polyak(int64_t n, const float* theta, float* theta_tgt, float tau, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * MLP MADDPG / MATD3  (offpolicy/algorithms/maddpg/maddpg.py:90-249; matd3 = num_q 2 + target_gumbel 1).
+ * One shared policy for all N agents. Actor: MLPBase(D) -> Linear(64, A). Critic: MLPBase(S + N*A) -> num_q x Linear(64, 1).
+ * Flat vectors use the MLP agent layout (16 tensors; the head = last two); for the critic the head block is
+ * [num_q][64] weights then [num_q] biases.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ope_ddpg_cfg {
+  ope_dims dims;         /* episode_length unused */
+  int32_t batch;         /* B transitions */
+  int32_t num_q;         /* critic heads: 1 (MADDPG) or 2 (MATD3, min over heads in the target) */
+  int32_t target_gumbel; /* 1: target actions by hard gumbel-softmax with caller-provided uniform noise (MATD3);
+                            0: onehot_from_logits argmax (MADDPG)  -- MADDPGPolicy.py:94-105 */
+  int32_t use_huber, use_per;
+  float gamma, huber_delta, per_eps;
+} ope_ddpg_cfg;
+
+/* One sampled batch in MlpPolicyBuffer.sample_inds order/shapes (mlp_buffer.py:213-257), device pointers. */
+typedef struct ope_mlp_batch {
+  const float* obs;              /* [N][B][D] */
+  const float* share_obs;        /* [B][S]    */
+  const float* acts;             /* [N][B][A] */
+  const float* rewards;          /* [N][B][1] */
+  const float* next_obs;         /* [N][B][D] */
+  const float* next_share_obs;   /* [B][S]    */
+  const float* dones_env;        /* [B][1]    */
+  const float* valid_transition; /* [N][B][1] */
+  const float* avail_acts;       /* [N][B][A] or NULL */
+  const float* next_avail_acts;  /* [N][B][A] or NULL */
+} ope_mlp_batch;
+
+/* which = 0 actor, 1 critic: offsets/sizes of its 16 tensors; returns the padded length. */
+int64_t ope_ddpg_param_layout(const ope_ddpg_cfg* cfg, int32_t which, int64_t* offsets, int64_t* sizes);
+int64_t ope_ddpg_workspace_bytes(const ope_ddpg_cfg* cfg);
+int ope_ddpg_workspace_init(const ope_ddpg_cfg* cfg, void* workspace, int64_t workspace_bytes, void* stream);
+int64_t ope_ddpg_workspace_find(const ope_ddpg_cfg* cfg, const char* name, int64_t* n_floats);
+/* Critic update (maddpg.py:100-157 + get_update_info 38-81): grad = d(sum_k sum_b f(target - Q_k) w_b)/d theta_critic
+ * + tail [loss_sum, B, sum Q, 0]; prio_out[B] = mean_k |err_k| + per_eps (or NULL).
+ * target_noise_u [N*B][A]: uniform(0,1) noise for the MATD3 target gumbel (NULL unless target_gumbel). */
+int ope_ddpg_critic_loss_and_grad(const ope_ddpg_cfg* cfg, const ope_mlp_batch* batch, const float* theta_actor_tgt,
+                                  const float* theta_critic, const float* theta_critic_tgt, const float* target_noise_u,
+                                  const float* per_weights, void* workspace, int64_t workspace_bytes, float* grad,
+                                  float* prio_out, void* stream);
+/* Actor update (maddpg.py:162-247): hard gumbel-softmax actions (noise gumbel_noise_u [N*B][A]) spliced into N stacked
+ * copies of the joint action, -sum(Q_1 * valid) objective through the (frozen) critic; grad w.r.t. theta_actor + tail
+ * [loss_sum, sum(valid), ...]. */
+int ope_ddpg_actor_loss_and_grad(const ope_ddpg_cfg* cfg, const ope_mlp_batch* batch, const float* theta_actor,
+                                 const float* theta_critic, const float* gumbel_noise_u, void* workspace,
+                                 int64_t workspace_bytes, float* grad, void* stream);
 
 #ifdef __cplusplus
 }

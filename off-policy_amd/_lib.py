@@ -40,7 +40,18 @@ class QmixCfg(C.Structure):
 class AdamCfg(C.Structure):
     _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
                 ("max_grad_norm", C.c_float), ("weight_decay", C.c_float), ("tau", C.c_float),
-                ("do_polyak", C.c_int32), ("step", C.c_int32), ("qtot_denominator", C.c_float)]
+                ("do_polyak", C.c_int32), ("step", C.c_int32), ("qtot_denominator", C.c_float), ("tail_offset", C.c_int32)]
+
+
+class DdpgCfg(C.Structure):
+    _fields_ = [("dims", Dims), ("batch", C.c_int32), ("num_q", C.c_int32), ("target_gumbel", C.c_int32),
+                ("use_huber", C.c_int32), ("use_per", C.c_int32), ("gamma", C.c_float), ("huber_delta", C.c_float),
+                ("per_eps", C.c_float)]
+
+
+class MlpBatch(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("obs", "share_obs", "acts", "rewards", "next_obs", "next_share_obs", "dones_env",
+                                          "valid_transition", "avail_acts", "next_avail_acts")]
 
 
 def _load():
@@ -66,6 +77,12 @@ def _load():
         "ope_agent_forward": (C.c_int, [C.POINTER(Dims), i32, i32, p, p, p, p, i64, p, p, p]),
         "ope_agent_forward_mlp_workspace_bytes": (i64, [C.POINTER(Dims), i32]),
         "ope_agent_forward_mlp": (C.c_int, [C.POINTER(Dims), i32, p, p, p, i64, p, p]),
+        "ope_ddpg_param_layout": (i64, [C.POINTER(DdpgCfg), i32, C.POINTER(i64), C.POINTER(i64)]),
+        "ope_ddpg_workspace_bytes": (i64, [C.POINTER(DdpgCfg)]),
+        "ope_ddpg_workspace_init": (C.c_int, [C.POINTER(DdpgCfg), p, i64, p]),
+        "ope_ddpg_workspace_find": (i64, [C.POINTER(DdpgCfg), C.c_char_p, C.POINTER(i64)]),
+        "ope_ddpg_critic_loss_and_grad": (C.c_int, [C.POINTER(DdpgCfg), C.POINTER(MlpBatch), p, p, p, p, p, p, i64, p, p, p]),
+        "ope_ddpg_actor_loss_and_grad": (C.c_int, [C.POINTER(DdpgCfg), C.POINTER(MlpBatch), p, p, p, p, i64, p, p]),
         "ope_adam_scratch_floats": (i64, [i64]),
         "ope_adam_step": (C.c_int, [C.POINTER(AdamCfg), i64, p, p, p, p, p, p, p, p]),
         "ope_polyak": (C.c_int, [i64, p, p, C.c_float, p]),

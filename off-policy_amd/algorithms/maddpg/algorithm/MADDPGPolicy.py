@@ -1,0 +1,125 @@
+"""MADDPG / MATD3 policy: actor + centralised critic (+ targets, optimizer state) on flat CUDA vectors.
+
+Mirror of offpolicy/algorithms/maddpg/algorithm/MADDPGPolicy.py:11-151 for discrete (one-hot) action spaces. The four
+networks are drawn in the reference's construction order (actor, critic, target actor, target critic) so equal seeds
+give equal weights -- including the target critic's own random Q heads, which upstream never synchronises (A-4).
+"""
+import numpy as np
+import torch
+from torch.distributions import OneHotCategorical
+
+from .... import _lib
+from ....config import require_reference_architecture
+from ....utils.spaces import get_dim_from_space
+from ...qmix.algorithm.QMixPolicy import DecayThenFlatSchedule
+from ...qmix.qmix import FlatAdam
+from .actor_critic import MADDPG_Actor, MADDPG_Critic, draw_actor_values, draw_critic_values
+
+
+def sample_gumbel_uniform(shape):
+    """The uniform draw inside sample_gumbel (util.py:178-181): CPU generator, torch.FloatTensor(*shape).uniform_()."""
+    return torch.FloatTensor(*shape).uniform_()
+
+
+def onehot_from_logits(logits, avail=None):
+    logits = logits.clone()
+    if avail is not None:
+        logits[torch.as_tensor(np.asarray(avail), device=logits.device) == 0] = -1e10
+    return (logits == logits.max(-1, keepdim=True)[0]).float()
+
+
+def gumbel_softmax_hard(logits, avail, u):
+    y = logits + (-torch.log(-torch.log(u.to(logits.device) + 1e-20) + 1e-20))
+    if avail is not None:
+        y[torch.as_tensor(np.asarray(avail), device=y.device) == 0] = -1e10
+    y = torch.softmax(y, dim=-1)
+    y_hard = (y == y.max(-1, keepdim=True)[0]).float()
+    return (y_hard - y) + y
+
+
+class MADDPGPolicy(object):
+    def __init__(self, config, policy_config, target_noise=None, td3=False, train=True, frozen_q_head=True):
+        self.config = config
+        self.device = torch.device(config["device"])
+        self.args = config["args"]
+        require_reference_architecture(self.args)
+        self.tau, self.lr, self.opti_eps, self.weight_decay = self.args.tau, self.args.lr, self.args.opti_eps, self.args.weight_decay
+        if self.weight_decay != 0:
+            raise NotImplementedError("weight_decay != 0: upstream skips grad-less tensors (fc_h); not replicated yet")
+        self.central_obs_dim, self.central_act_dim = policy_config["cent_obs_dim"], policy_config["cent_act_dim"]
+        self.obs_space, self.act_space = policy_config["obs_space"], policy_config["act_space"]
+        self.obs_dim, self.act_dim = get_dim_from_space(self.obs_space), get_dim_from_space(self.act_space)
+        self.output_dim = self.act_dim
+        self.discrete, self.multidiscrete = True, False
+        self.target_noise = target_noise
+        self.td3 = bool(td3)
+        self.num_q = 2 if td3 else 1
+        assert self.central_act_dim % self.act_dim == 0
+        self.num_agents = self.central_act_dim // self.act_dim
+        self.frozen_q_head = bool(frozen_q_head)
+        cfg = self.ddpg_cfg(1)
+        dev, a = self.device, self.args
+        mk_c = lambda vals: MADDPG_Critic(a, self.central_obs_dim, self.central_act_dim, dev, cfg, self.num_q, values=vals,
+                                          frozen_q_head=self.frozen_q_head)
+        # construction order = RNG order of MADDPGPolicy.py:38-46
+        self.actor = MADDPG_Actor(a, self.obs_dim, self.act_dim, dev, cfg, values=draw_actor_values(a, self.obs_dim, self.act_dim))
+        self.critic = mk_c(draw_critic_values(a, self.central_obs_dim + self.central_act_dim, self.num_q))
+        self.target_actor = MADDPG_Actor(a, self.obs_dim, self.act_dim, dev, cfg, values=draw_actor_values(a, self.obs_dim, self.act_dim))
+        self.target_critic = mk_c(draw_critic_values(a, self.central_obs_dim + self.central_act_dim, self.num_q))
+        self.hard_target_updates()          # load_state_dict of the REGISTERED tensors (heads stay apart when frozen)
+        if train:
+            self.actor_optimizer = FlatAdam(self.actor.padded_numel, self.lr, self.opti_eps, dev)
+            self.critic_optimizer = FlatAdam(self.critic.padded_numel, self.lr, self.opti_eps, dev)
+            self.exploration = DecayThenFlatSchedule(a.epsilon_start, a.epsilon_finish, a.epsilon_anneal_time, decay="linear")
+
+    def ddpg_cfg(self, batch):
+        a = self.args
+        cfg = _lib.DdpgCfg()
+        cfg.dims = _lib.Dims(self.num_agents, self.act_dim, self.obs_dim, self.central_obs_dim, 1)
+        cfg.batch, cfg.num_q = int(batch), self.num_q
+        cfg.target_gumbel = int(self.target_noise is not None)
+        cfg.use_huber, cfg.use_per = int(bool(a.use_huber_loss)), int(bool(a.use_per))
+        cfg.gamma, cfg.huber_delta, cfg.per_eps = float(a.gamma), float(a.huber_delta), float(a.per_eps)
+        return cfg
+
+    # ---- rollout-side API (host logic around the HIP actor forward) ---------------------------------------
+    def get_actions(self, obs, available_actions=None, t_env=None, explore=False, use_target=False, use_gumbel=False):
+        batch_size = obs.shape[0]
+        eps = None
+        actor_out = (self.target_actor if use_target else self.actor)(obs)
+        if use_gumbel or (use_target and self.target_noise is not None):
+            actions = gumbel_softmax_hard(actor_out, available_actions, sample_gumbel_uniform(actor_out.shape))
+        elif explore:
+            onehot = gumbel_softmax_hard(actor_out, available_actions, sample_gumbel_uniform(actor_out.shape))
+            eps = self.exploration.eval(t_env)
+            rand_numbers = np.random.rand(batch_size, 1)
+            logits = torch.ones(batch_size, self.act_dim)
+            if available_actions is not None:
+                logits[torch.as_tensor(np.asarray(available_actions)) == 0] = -1e10
+            random_actions = OneHotCategorical(logits=logits).sample().numpy()
+            take_random = (rand_numbers < eps).astype(int)
+            actions = (1 - take_random) * onehot.detach().cpu().numpy() + take_random * random_actions
+        else:
+            actions = onehot_from_logits(actor_out, available_actions)
+        return actions, eps
+
+    def get_random_actions(self, obs, available_actions=None):
+        batch_size = obs.shape[0]
+        logits = torch.ones(batch_size, self.act_dim)
+        if available_actions is not None:
+            logits[torch.as_tensor(np.asarray(available_actions)) == 0] = -1e10
+        return OneHotCategorical(logits=logits).sample().numpy()
+
+    # ---- target updates (MADDPGPolicy.py:141-151) ------------------------------------------------------------
+    def _polyak(self, tau):
+        st = _lib.current_stream()
+        _lib.check(_lib.lib.ope_polyak(self.critic.trainable_numel, _lib.ptr(self.critic._flat), _lib.ptr(self.target_critic._flat),
+                                       float(tau), st), "ope_polyak")
+        _lib.check(_lib.lib.ope_polyak(self.actor.padded_numel, _lib.ptr(self.actor._flat), _lib.ptr(self.target_actor._flat),
+                                       float(tau), st), "ope_polyak")
+
+    def soft_target_updates(self):
+        self._polyak(self.args.tau)
+
+    def hard_target_updates(self):
+        self._polyak(1.0)

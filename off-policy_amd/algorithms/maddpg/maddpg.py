@@ -1,0 +1,137 @@
+"""MLP MADDPG / MATD3 trainer on the HIP engine.
+
+Mirror of offpolicy/algorithms/maddpg/maddpg.py:9-249 (`MADDPG`, shared-observation path
+`shared_train_policy_on_batch`): critic update, then (every `actor_update_interval` updates) the actor update through
+the freshly updated critic. Four C-ABI calls per policy update:
+
+    ope_ddpg_critic_loss_and_grad -> ope_adam_step(critic) -> ope_ddpg_actor_loss_and_grad -> ope_adam_step(actor)
+
+Upstream defects kept by default so that results are the reference's:
+  A-4  critic Q heads are unregistered -> frozen (`MADDPGPolicy(frozen_q_head=True)`);
+  A-5  `num_updates` is never incremented -> the actor is updated on EVERY call, also for MATD3
+       (`count_updates=False`; pass True to get the intended delayed actor update).
+The gumbel noise is drawn on the CPU generator in the reference's order (target noise first, then actor noise).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from ... import _lib
+from ... import dist as opdist
+from .algorithm.MADDPGPolicy import sample_gumbel_uniform
+
+
+class MADDPG(object):
+    def __init__(self, args, num_agents, policies, policy_mapping_fn, device=None, actor_update_interval=1, count_updates=False):
+        self.args = args
+        self.use_per, self.per_eps = args.use_per, args.per_eps
+        self.use_huber_loss, self.huber_delta = args.use_huber_loss, args.huber_delta
+        self.device = torch.device(device if device is not None else "cuda:0")
+        self.tpdv = dict(dtype=torch.float32, device=self.device)
+        self.num_agents, self.policies, self.policy_mapping_fn = num_agents, policies, policy_mapping_fn
+        self.policy_ids = sorted(list(self.policies.keys()))
+        self.policy_agents = {pid: sorted([a for a in range(num_agents) if policy_mapping_fn(a) == pid]) for pid in self.policies}
+        if self.policy_ids != ["policy_0"] or len(self.policy_agents["policy_0"]) != num_agents:
+            raise NotImplementedError("the accelerated MADDPG path handles one shared policy ('policy_0') for all agents")
+        self.num_updates = {p_id: 0 for p_id in self.policy_ids}
+        self.use_same_share_obs = args.use_same_share_obs
+        self.actor_update_interval = actor_update_interval
+        self.count_updates = bool(count_updates)
+        self._ws, self._grads = {}, {}
+
+    def _workspace(self, policy, cfg):
+        B = cfg.batch
+        if B not in self._ws:
+            need = _lib.lib.ope_ddpg_workspace_bytes(C.byref(cfg))
+            if need < 0:
+                _lib.check(int(need), "ope_ddpg_workspace_bytes")
+            ws = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+            _lib.check(_lib.lib.ope_ddpg_workspace_init(C.byref(cfg), _lib.ptr(ws), ws.numel(), _lib.current_stream()),
+                       "ope_ddpg_workspace_init")
+            self._ws[B] = ws
+            self._grads[B] = (torch.zeros(policy.critic.padded_numel + 4, **self.tpdv), torch.zeros(policy.actor.padded_numel + 4, **self.tpdv),
+                              torch.zeros(int(_lib.lib.ope_adam_scratch_floats(max(policy.critic.padded_numel, policy.actor.padded_numel))), **self.tpdv))
+        return self._ws[B], self._grads[B]
+
+    def workspace_view(self, batch, name, policy_id="policy_0"):
+        cfg = self.policies[policy_id].ddpg_cfg(batch)
+        n = C.c_int64(0)
+        off = _lib.lib.ope_ddpg_workspace_find(C.byref(cfg), name.encode(), C.byref(n))
+        if off < 0:
+            raise KeyError(name)
+        return self._ws[batch][off:off + 4 * n.value].view(torch.float32)
+
+    def train_policy_on_batch(self, update_policy_id, batch):
+        if self.use_same_share_obs:
+            return self.shared_train_policy_on_batch(update_policy_id, batch)
+        raise NotImplementedError("cent_train_policy_on_batch is broken upstream (SURVEY A-5) and not on the accelerated path")
+
+    def _adam(self, opt, n, flat, flat_tgt, grad, scratch, tail):
+        opt.step_count += 1
+        ac = _lib.AdamCfg()
+        ac.lr, ac.beta1, ac.beta2, ac.eps = opt.lr, opt.betas[0], opt.betas[1], opt.eps
+        ac.max_grad_norm, ac.weight_decay, ac.tau, ac.do_polyak = float(self.args.max_grad_norm), 0.0, 0.0, 0
+        ac.step, ac.qtot_denominator, ac.tail_offset = opt.step_count, 1.0, int(tail)
+        stats = torch.empty(4, **self.tpdv)
+        _lib.check(_lib.lib.ope_adam_step(C.byref(ac), int(n), _lib.ptr(flat), _lib.ptr(flat_tgt), _lib.ptr(opt.exp_avg),
+                                          _lib.ptr(opt.exp_avg_sq), _lib.ptr(grad), _lib.ptr(scratch), _lib.ptr(stats),
+                                          _lib.current_stream()), "ope_adam_step")
+        return stats
+
+    def shared_train_policy_on_batch(self, update_policy_id, batch):
+        """See maddpg.py:90-249. `batch` = 13-tuple of MlpReplayBuffer.sample()."""
+        (obs_b, cent_b, act_b, rew_b, nobs_b, cent_nobs_b, dones_b, dones_env_b, valid_b, avail_b, navail_b,
+         importance_weights, idxes) = batch
+        pid = update_policy_id
+        policy = self.policies[pid]
+        f = lambda x: None if x is None else torch.as_tensor(x, dtype=torch.float32).to(self.device).contiguous()
+        obs, cent, acts, rew = f(obs_b[pid]), f(cent_b[pid]), f(act_b[pid]), f(rew_b[pid])
+        nobs, ncent, dones_env, valid = f(nobs_b[pid]), f(cent_nobs_b[pid]), f(dones_env_b[pid]), f(valid_b[pid])
+        avail = f(avail_b[pid]) if avail_b is not None else None
+        navail = f(navail_b[pid]) if navail_b is not None else None
+        N, B, D = obs.shape
+        assert N == self.num_agents
+        cfg = policy.ddpg_cfg(B)
+        ws, (gc, ga, scratch) = self._workspace(policy, cfg)
+        mb = _lib.MlpBatch()
+        for k, v in dict(obs=obs, share_obs=cent, acts=acts, rewards=rew, next_obs=nobs, next_share_obs=ncent, dones_env=dones_env,
+                         valid_transition=valid, avail_acts=avail, next_avail_acts=navail).items():
+            setattr(mb, k, _lib.ptr(v).value)
+        st = _lib.current_stream()
+        train_info = {}
+        update_actor = self.num_updates[pid] % self.actor_update_interval == 0
+        # ---- critic ----
+        u_t = sample_gumbel_uniform((N * B, policy.act_dim)).to(self.device) if policy.target_noise is not None else None
+        w = torch.as_tensor(np.asarray(importance_weights), dtype=torch.float32).to(self.device).contiguous() if self.use_per else None
+        prio = torch.empty(B, **self.tpdv) if self.use_per else None
+        _lib.check(_lib.lib.ope_ddpg_critic_loss_and_grad(C.byref(cfg), C.byref(mb), _lib.ptr(policy.target_actor._flat),
+                                                          _lib.ptr(policy.critic._flat), _lib.ptr(policy.target_critic._flat),
+                                                          _lib.ptr(u_t), _lib.ptr(w), _lib.ptr(ws), ws.numel(), _lib.ptr(gc),
+                                                          _lib.ptr(prio), st), "ope_ddpg_critic_loss_and_grad")
+        opdist.allreduce_flat_(gc)
+        cs = self._adam(policy.critic_optimizer, policy.critic.trainable_numel, policy.critic._flat, policy.target_critic._flat, gc,
+                        scratch, policy.critic.padded_numel)
+        train_info["critic_loss"], train_info["critic_grad_norm"] = cs[0], cs[1]
+        new_priorities = prio.cpu().numpy() if self.use_per else None
+        # ---- actor ----
+        if update_actor:
+            u_a = sample_gumbel_uniform((N * B, policy.act_dim)).to(self.device)
+            _lib.check(_lib.lib.ope_ddpg_actor_loss_and_grad(C.byref(cfg), C.byref(mb), _lib.ptr(policy.actor._flat),
+                                                             _lib.ptr(policy.critic._flat), _lib.ptr(u_a), _lib.ptr(ws), ws.numel(),
+                                                             _lib.ptr(ga), st), "ope_ddpg_actor_loss_and_grad")
+            opdist.allreduce_flat_(ga)
+            as_ = self._adam(policy.actor_optimizer, policy.actor.padded_numel, policy.actor._flat, policy.target_actor._flat, ga,
+                             scratch, policy.actor.padded_numel)
+            train_info["actor_loss"], train_info["actor_grad_norm"] = as_[0], as_[1]
+            train_info["update_actor"] = update_actor
+        if self.count_updates:
+            self.num_updates[pid] += 1
+        self._last = (obs, cent, acts, rew, nobs, ncent, dones_env, valid, avail, navail, u_t, w)
+        return train_info, new_priorities, idxes
+
+    def prep_training(self):
+        pass
+
+    def prep_rollout(self):
+        pass

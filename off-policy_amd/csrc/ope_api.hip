@@ -4,6 +4,7 @@
 
 #include "ope_mixer.h"
 #include "ope_wgrad.h"
+#include "ope_workspace.h"
 
 using namespace ope;
 
@@ -18,29 +19,6 @@ bool cfg_ok(const ope_qmix_cfg* c) {
   return d.n_agents >= 1 && d.act_dim >= 1 && d.obs_dim >= 1 && d.obs_dim <= 512 && d.state_dim >= 1 &&
          d.episode_length >= 1 && c->batch >= 1 && d.n_agents <= 64 && d.act_dim <= 200;
 }
-
-// ---- workspace: a list of named float regions, 256-byte aligned --------------------------------------------
-struct Region { const char* name; int64_t off; int64_t n; };
-constexpr int kMaxRegions = 64;
-struct Workspace {
-  Region r[kMaxRegions];
-  int n = 0;
-  int64_t total = 0;  // floats
-  int64_t add(const char* name, int64_t nfloats) {
-    const int64_t off = total;
-    r[n++] = Region{name, off, nfloats};
-    total += (nfloats + 63) & ~(int64_t)63;
-    return off;
-  }
-  int64_t find(const char* name, int64_t* nf) const {
-    for (int i = 0; i < n; ++i)
-      if (strcmp(r[i].name, name) == 0) {
-        if (nf) *nf = r[i].n;
-        return r[i].off;
-      }
-    return -1;
-  }
-};
 
 struct Raw {  // offsets inside one split slab, agent region then mixer region
   int P1, s1, P2, s2, P3, s3, WHH, shh, E, sq, agent_end;

@@ -1,0 +1,519 @@
+// MLP MADDPG / MATD3 update (centralised critic over [cent_obs || all agents' actions], gumbel-softmax actor).
+//   MADDPG.get_update_info / shared_train_policy_on_batch   offpolicy/algorithms/maddpg/maddpg.py:38-81, 90-249
+//   MADDPG_Actor / MADDPG_Critic                            offpolicy/algorithms/maddpg/algorithm/actor_critic.py:7-87
+//   MADDPGPolicy.get_actions (target / gumbel paths)         offpolicy/algorithms/maddpg/algorithm/MADDPGPolicy.py:63-119
+//   onehot_from_logits / gumbel_softmax                     offpolicy/utils/util.py:156-214
+// Both networks are MLPBase trunks + a Linear head, so the heavy lifting is the shared trunk_fwd / trunk_bwd / wgrad /
+// finalize kernels in "mlp" mode; this file adds the small row-parallel pieces around them and the two C-ABI steps.
+#include <string.h>
+
+#include "ope_ddpg.h"
+
+namespace ope {
+
+// ---------------------------------------------------------------------------------------------------------
+// rows of the critic input:  out[r] = [ cent[b] (S) | joint action (N*A) ],  r = rep*B + b
+//   joint action block a = acts[a][b]  unless  (repl != null and a == rep): then repl[rep*B + b]
+// (maddpg.py:128 for the critic update, 207-227 for the actor update: "mask * actor + (1 - mask) * buffer")
+// ---------------------------------------------------------------------------------------------------------
+__global__ void build_cin_kernel(const float* __restrict__ cent, const float* __restrict__ acts, const float* __restrict__ repl,
+                                 int B, int N, int A, int S, int reps, float* __restrict__ out) {
+  const int Din = S + N * A;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)reps * B * Din) return;
+  const int r = (int)(i / Din), c = (int)(i - (int64_t)r * Din);
+  const int rep = r / B, b = r - rep * B;
+  float v;
+  if (c < S) {
+    v = cent[(int64_t)b * S + c];
+  } else {
+    const int a = (c - S) / A, j = (c - S) - a * A;
+    v = (repl && a == rep) ? repl[((int64_t)rep * B + b) * A + j] : acts[((int64_t)a * B + b) * A + j];
+  }
+  out[i] = v;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Target actions. mode 0: onehot_from_logits (util.py:156-175): unavailable -> -1e10, one-hot of (== max), ties give
+// several ones. mode 1 (MATD3 target smoothing, MADDPGPolicy.py:94-95): hard gumbel-softmax with the caller's
+// uniform noise U: g = -log(-log(U+1e-20)+1e-20); y = softmax(logits+g masked); value (y_hard - y) + y.
+// Output is scattered into the joint next action cent_nact[b][a*A + j] (maddpg.py:67-74).
+// With `soft_out` non-null (actor update, mode 1 only) the soft sample y is kept for the backward pass and the
+// straight-through value goes to act_out[row][A] instead.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void action_kernel(const float* __restrict__ logits, const float* __restrict__ avail, const float* __restrict__ U,
+                              int rows, int B, int A, int N, int mode, float* __restrict__ cent_nact, float* __restrict__ act_out,
+                              float* __restrict__ soft_out) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const int a = r / B, b = r - a * B;
+  const float* lg = logits + (int64_t)r * A;
+  const float* av = avail ? avail + (int64_t)r * A : nullptr;
+  float mx = -3.0e38f;
+  for (int j = 0; j < A; ++j) {
+    float v = lg[j];
+    if (mode == 1) v += -logf(-logf(U[(int64_t)r * A + j] + 1e-20f) + 1e-20f);
+    if (av && av[j] == 0.f) v = -1e10f;
+    mx = fmaxf(mx, v);
+  }
+  float den = 0.f;
+  if (mode == 1) {
+    for (int j = 0; j < A; ++j) {
+      float v = lg[j] + -logf(-logf(U[(int64_t)r * A + j] + 1e-20f) + 1e-20f);
+      if (av && av[j] == 0.f) v = -1e10f;
+      den += expf(v - mx);
+    }
+  }
+  // second pass: values. For mode 1 the one-hot is taken on the softmax output y (onehot_from_logits(y)): y == max(y).
+  float ymax = 0.f;
+  if (mode == 1) {
+    for (int j = 0; j < A; ++j) {
+      float v = lg[j] + -logf(-logf(U[(int64_t)r * A + j] + 1e-20f) + 1e-20f);
+      if (av && av[j] == 0.f) v = -1e10f;
+      ymax = fmaxf(ymax, expf(v - mx) / den);
+    }
+  }
+  for (int j = 0; j < A; ++j) {
+    float v = lg[j];
+    if (mode == 1) v += -logf(-logf(U[(int64_t)r * A + j] + 1e-20f) + 1e-20f);
+    if (av && av[j] == 0.f) v = -1e10f;
+    float out;
+    if (mode == 0) {
+      out = (v == mx) ? 1.f : 0.f;
+    } else {
+      const float y = expf(v - mx) / den;
+      const float hard = (y == ymax) ? 1.f : 0.f;
+      out = (hard - y) + y;
+      if (soft_out) soft_out[(int64_t)r * A + j] = y;
+    }
+    if (act_out) act_out[(int64_t)r * A + j] = out;
+    if (cent_nact) cent_nact[(int64_t)b * (N * A) + a * A + j] = out;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Critic TD (maddpg.py:112-157): target = r + gamma (1 - done) min_k Q'_k ; err_k = target - Q_k ;
+//   loss = sum_k mean_b f(err_k) [* w_b] ; dQ_k = -f'(err_k) w_b (un-normalised; mask_count = B) ; priority = mean_k |err_k| + eps
+// One thread per transition; per-16-row loss partials in the [tile][4] format finalize expects.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) critic_td_kernel(CriticTdArgs a) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = b < a.B;
+  const int bb = valid ? b : 0;
+  float qn = a.q_tgt[(int64_t)bb * a.K4];
+  for (int k = 1; k < a.K; ++k) qn = fminf(qn, a.q_tgt[(int64_t)bb * a.K4 + k]);
+  const float rew = a.rewards[bb];   // agent 0's reward: rewards[0][b] (maddpg.py:106)
+  const float den = a.dones_env[bb];
+  const float target = rew + a.gamma * (1.0f - den) * qn;
+  const float w = a.per_weights ? a.per_weights[bb] : 1.0f;
+  float ls = 0.f, pr = 0.f, qs = 0.f;
+  for (int k = 0; k < a.K; ++k) {
+    const float q = a.q[(int64_t)bb * a.K4 + k];
+    const float e = target - q;
+    float fe, dfe;
+    if (a.use_huber) {
+      const float ae = fabsf(e), dl = a.huber_delta;
+      if (ae <= dl) { fe = e * e * 0.5f; dfe = e; } else { fe = dl * (ae - dl * 0.5f); dfe = dl * (e > 0.f ? 1.f : -1.f); }
+    } else {
+      fe = e * e;
+      dfe = 2.0f * e;
+    }
+    ls += w * fe;
+    pr += fabsf(e);
+    qs += q;
+    if (valid) a.dq[(int64_t)b * a.K4 + k] = -dfe * w;   // d loss_sum / d Q_k  (e = target - Q)
+  }
+  if (valid) {
+    for (int k = a.K; k < a.K4; ++k) a.dq[(int64_t)b * a.K4 + k] = 0.f;
+    if (a.prio_out) a.prio_out[b] = pr / (float)a.K + a.per_eps;
+  }
+  if (!valid) { ls = 0.f; qs = 0.f; }
+  float cs = valid ? 1.f : 0.f;
+  for (int o = 1; o < 16; o <<= 1) {
+    ls += __shfl_xor(ls, o, 64);
+    cs += __shfl_xor(cs, o, 64);
+    qs += __shfl_xor(qs, o, 64);
+  }
+  if ((threadIdx.x & 15) == 0 && (b >> 4) < ((a.B + 15) >> 4)) {
+    float* lp = a.loss_part + (b >> 4) * 4;
+    lp[0] = ls; lp[1] = cs; lp[2] = qs; lp[3] = 0.f;
+  }
+}
+
+// Actor objective (maddpg.py:229-232): loss = -sum(Q_1 * valid) / sum(valid)  ->  dQ_1 = -valid (un-normalised)
+__global__ void __launch_bounds__(256) actor_obj_kernel(const float* __restrict__ q, int K4, const float* __restrict__ valid_tr,
+                                                         int rows, float* __restrict__ dq, float* __restrict__ loss_part) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool ok = r < rows;
+  const float v = ok ? valid_tr[r] : 0.f;
+  const float q1 = ok ? q[(int64_t)r * K4] : 0.f;
+  if (ok) {
+    dq[(int64_t)r * K4] = -v;
+    for (int k = 1; k < K4; ++k) dq[(int64_t)r * K4 + k] = 0.f;
+  }
+  float ls = -q1 * v, cs = v, qs = q1 * v;
+  for (int o = 1; o < 16; o <<= 1) {
+    ls += __shfl_xor(ls, o, 64);
+    cs += __shfl_xor(cs, o, 64);
+    qs += __shfl_xor(qs, o, 64);
+  }
+  if ((threadIdx.x & 15) == 0 && (r >> 4) < ((rows + 15) >> 4)) {
+    float* lp = loss_part + (r >> 4) * 4;
+    lp[0] = ls; lp[1] = cs; lp[2] = qs; lp[3] = 0.f;
+  }
+}
+
+// da2[row][f] = sum_k dout[row][k] * W[k][f]   (adjoint of a Linear(64 -> K) head w.r.t. its input)
+__global__ void __launch_bounds__(256) head_in_grad_kernel(const float* __restrict__ dout, int ldk, int K, const float* __restrict__ W,
+                                                            int rows, float* __restrict__ da2) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)rows * OPE_H) return;
+  const int r = (int)(i / OPE_H), f = (int)(i - (int64_t)r * OPE_H);
+  float s = 0.f;
+  for (int k = 0; k < K; ++k) s = fmaf(dout[(int64_t)r * ldk + k], W[(int64_t)k * OPE_H + f], s);
+  da2[i] = s;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Gradient w.r.t. the trunk INPUT (needed by the actor update: the critic is differentiated w.r.t. the action part of
+// its input, maddpg.py:225-236). One wave per row; lane <-> input feature k (strided):
+//   dxn[k] = sum_i fc1_w[i][k] dz1[i] ;  dyh = dxn*gamma ;  dx = rstd (dyh - mean(dyh) - xhat mean(dyh xhat))
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) input_grad_kernel(InGradArgs a) {
+  __shared__ float dz[4][OPE_H];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  const bool ok = row < a.R;
+  const int rr = ok ? row : a.R - 1;
+  dz[wave][lane] = a.dz1[(int64_t)rr * OPE_H + lane];
+  __builtin_amdgcn_wave_barrier();
+  const float mu = a.mu0[rr], rs = a.rstd0[rr];
+  const float* xr = a.x + (int64_t)rr * a.D;
+  float m1 = 0.f, m2 = 0.f;
+  for (int k = lane; k < a.D; k += 64) {
+    float s = 0.f;
+#pragma unroll 8
+    for (int i = 0; i < OPE_H; ++i) s = fmaf(a.fc1_w[(int64_t)i * a.D + k], dz[wave][i], s);
+    const float dy = s * a.gamma[k];
+    const float xh = (xr[k] - mu) * rs;
+    m1 += dy;
+    m2 = fmaf(dy, xh, m2);
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    m1 += __shfl_xor(m1, o, 64);
+    m2 += __shfl_xor(m2, o, 64);
+  }
+  m1 /= (float)a.D;
+  m2 /= (float)a.D;
+  if (!ok) return;
+  for (int k = lane; k < a.D; k += 64) {
+    float s = 0.f;
+#pragma unroll 8
+    for (int i = 0; i < OPE_H; ++i) s = fmaf(a.fc1_w[(int64_t)i * a.D + k], dz[wave][i], s);
+    const float dy = s * a.gamma[k];
+    const float xh = (xr[k] - mu) * rs;
+    a.dx[(int64_t)row * a.D + k] = rs * (dy - m1 - xh * m2);
+  }
+}
+
+// Straight-through hard gumbel-softmax adjoint (util.py:210-213: out = (y_hard - y).detach() + y): the gradient goes
+// through the soft sample y = softmax(.): dlogit_j = y_j (dy_j - sum_m dy_m y_m). dy is the action block of agent
+// `rep = row / B` inside the critic-input gradient dx[row][S + rep*A + j].
+__global__ void gumbel_bwd_kernel(const float* __restrict__ dx, int Din, int S, const float* __restrict__ y, int rows, int B, int A,
+                                  int A4, float* __restrict__ dlogits) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const int rep = r / B;
+  const float* dy = dx + (int64_t)r * Din + S + rep * A;
+  const float* yy = y + (int64_t)r * A;
+  float dot = 0.f;
+  for (int j = 0; j < A; ++j) dot = fmaf(dy[j], yy[j], dot);
+  for (int j = 0; j < A4; ++j) dlogits[(int64_t)r * A4 + j] = j < A ? yy[j] * (dy[j] - dot) : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+static int launch1d(int64_t n) { return ope_cdiv(n, 256); }
+#define OPE_L(call)                                            \
+  do {                                                         \
+    call;                                                      \
+    if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;   \
+  } while (0)
+
+struct DdpgPlan {
+  int N, A, D, S, B, K, K4, A4, Din, Ra;
+  AgentLayout AL, CL;       // actor (D -> A), critic (Din -> K)
+  Workspace ws;
+  int ns_c, ns_a;
+  int raw_size_c, raw_size_a;
+  int P1, s1, P2, s2, E, sq;    // raw slab offsets (same recipe for actor and critic, sized by the larger)
+  int64_t xin_t, xin, a2n, lgn, cnact, a2t, qt, a2c, qc, dq, da2, dz1, dz2, mu0, rstd0, xhat1, rstd1, mask1, xhat2, rstd2, mask2,
+      thetaT, raw, rsum, loss_part, lnz, lno, xin_a, a2a, lga, ysoft, actout, W1T_unused, dx, dlg, err;
+};
+
+static int ddpg_cfg_ok(const ope_ddpg_cfg* c) {
+  if (!c) return 0;
+  const ope_dims& d = c->dims;
+  if (d.n_agents < 1 || d.n_agents > 64 || d.act_dim < 1 || d.act_dim > 64 || d.obs_dim < 1 || d.obs_dim > 512 || d.state_dim < 1) return 0;
+  if (d.state_dim + d.n_agents * d.act_dim > 512) return 0;
+  if (c->batch < 1 || c->num_q < 1 || c->num_q > 4) return 0;
+  return 1;
+}
+
+static void ddpg_plan(const ope_ddpg_cfg* c, DdpgPlan* p) {
+  const ope_dims& d = c->dims;
+  p->N = d.n_agents; p->A = d.act_dim; p->D = d.obs_dim; p->S = d.state_dim; p->B = c->batch; p->K = c->num_q;
+  p->K4 = ope_round4(p->K); p->A4 = ope_round4(p->A); p->Din = p->S + p->N * p->A; p->Ra = p->N * p->B;
+  p->AL = ope_agent_layout_mlp(p->D, p->A, 0);
+  p->CL = ope_agent_layout_mlp(p->Din, p->K, 0);
+  const int Dmax = p->D > p->Din ? p->D : p->Din;
+  const int Hmax = p->A > p->K ? p->A : p->K;
+  int o = 0;
+  auto take = [&](int n) { int r = o; o += ope_round4(n); return r; };
+  p->P1 = take(OPE_H * Dmax); p->s1 = take(OPE_H); p->P2 = take(OPE_H * OPE_H); p->s2 = take(OPE_H);
+  p->E = take(Hmax * OPE_H); p->sq = take(ope_round4(Hmax));
+  p->raw_size_c = p->raw_size_a = o;
+  auto splits = [](int64_t rows) { int s = ope_cdiv(rows, 128); s = s < 1 ? 1 : (s > 64 ? 64 : s); return s >= 4 ? (s / 4) * 4 : s; };
+  p->ns_c = splits(p->B);
+  p->ns_a = splits(p->Ra);
+  Workspace& W = p->ws;
+  const int64_t B = p->B, Ra = p->Ra, R = Ra;   // save buffers sized for the larger (actor-side) row count
+  p->xin_t = W.add("xin_t", B * p->Din); p->xin = W.add("xin", B * p->Din);
+  p->a2n = W.add("a2n", Ra * OPE_H); p->lgn = W.add("logits_n", Ra * p->A); p->cnact = W.add("cent_nact", B * p->N * p->A);
+  p->a2t = W.add("a2t", B * OPE_H); p->qt = W.add("q_tgt", B * p->K4);
+  p->a2c = W.add("a2c", R * OPE_H); p->qc = W.add("q", R * p->K4);
+  p->dq = W.add("dq", R * p->K4); p->da2 = W.add("da2", R * OPE_H); p->dz1 = W.add("dz1", R * OPE_H); p->dz2 = W.add("dz2", R * OPE_H);
+  p->mu0 = W.add("mu0", R); p->rstd0 = W.add("rstd0", R); p->xhat1 = W.add("xhat1", R * OPE_H); p->rstd1 = W.add("rstd1", R);
+  p->mask1 = W.add("mask1", 2 * R); p->xhat2 = W.add("xhat2", R * OPE_H); p->rstd2 = W.add("rstd2", R); p->mask2 = W.add("mask2", 2 * R);
+  p->thetaT = W.add("thetaT", OPE_H * 3 * OPE_H + OPE_H * OPE_H);
+  const int nsmax = p->ns_c > p->ns_a ? p->ns_c : p->ns_a;
+  p->raw = W.add("raw", (int64_t)nsmax * o); p->rsum = W.add("rsum", o + 4);
+  p->loss_part = W.add("loss_part", (int64_t)ope_cdiv(R, 16) * 4);
+  p->lnz = W.add("ln_zero", R); p->lno = W.add("ln_one", R);
+  p->xin_a = W.add("xin_a", Ra * p->Din); p->a2a = W.add("a2a", Ra * OPE_H); p->lga = W.add("logits", Ra * p->A);
+  p->ysoft = W.add("y_soft", Ra * p->A); p->actout = W.add("act_out", Ra * p->A);
+  p->dx = W.add("dx", Ra * p->Din); p->dlg = W.add("dlogits", Ra * p->A4);
+  // second set of trunk saves for the actor's own backward (the critic pass of the actor step reuses the first set)
+  p->err = W.add("saves2", Ra * (2 * OPE_H + 8));
+}
+
+// trunk forward in mlp mode on `rows` rows of width Dw; saves go to the plan's first save set unless `alt` is given
+static int trunk_mlp(const DdpgPlan& p, float* W, const float* x, int rows, int Dw, const float* theta, const AgentLayout& L,
+                     float* a2_out, bool save, float* alt, hipStream_t st) {
+  TrunkFwdArgs tf;
+  memset(&tf, 0, sizeof(tf));
+  tf.x = x; tf.R = rows; tf.D = Dw; tf.theta = theta; tf.L = L; tf.a2_out = a2_out;
+  if (save) {
+    if (!alt) {
+      tf.mu0 = W + p.mu0; tf.rstd0 = W + p.rstd0; tf.xhat1 = W + p.xhat1; tf.rstd1 = W + p.rstd1; tf.mask1 = (uint64_t*)(W + p.mask1);
+      tf.xhat2 = W + p.xhat2; tf.rstd2 = W + p.rstd2; tf.mask2 = (uint64_t*)(W + p.mask2);
+    } else {   // packed alternate save set: [mu0 R][rstd0 R][rstd1 R][rstd2 R][mask1 2R][mask2 2R][xhat1 64R][xhat2 64R]
+      const int64_t R = p.Ra;
+      tf.mu0 = alt; tf.rstd0 = alt + R; tf.rstd1 = alt + 2 * R; tf.rstd2 = alt + 3 * R;
+      tf.mask1 = (uint64_t*)(alt + 4 * R); tf.mask2 = (uint64_t*)(alt + 6 * R); tf.xhat1 = alt + 8 * R; tf.xhat2 = alt + 8 * R + R * OPE_H;
+    }
+  }
+  return launch_trunk_fwd(tf, save, st);
+}
+
+static int linear_head(const float* a2, int rows, int Aout, const float* theta, const AgentLayout& L, float* out, hipStream_t st) {
+  HeadFwdArgs hf;
+  memset(&hf, 0, sizeof(hf));
+  hf.R = rows; hf.NB = rows; hf.B = rows; hf.N = 1; hf.T = 1; hf.A = Aout; hf.theta0 = theta; hf.theta1 = theta; hf.L = L;
+  hf.h0 = a2; hf.q_out = out; hf.no_ln = 1;
+  return launch_head_fwd(hf, 1, st);
+}
+
+// backward of one MLP net given d(head output) [rows][ldk]: da2 -> trunk_bwd -> weight gradients -> flat grad (+tail)
+static int mlp_backward(const DdpgPlan& p, float* W, const float* x, int rows, int Dw, int Hout, int ldk, const float* dout,
+                        const float* theta, const AgentLayout& L, const float* saves_alt, int nsplit, int n_loss_tiles,
+                        float* grad, hipStream_t st) {
+  int rc;
+  OPE_L(hipLaunchKernelGGL(head_in_grad_kernel, dim3(launch1d((int64_t)rows * OPE_H)), dim3(256), 0, st, dout, ldk, Hout,
+                           theta + L.q_w, rows, W + p.da2));
+  if ((rc = launch_transpose(theta + L.fc2_w, OPE_H, OPE_H, W + p.thetaT + OPE_H * 3 * OPE_H, st))) return rc;
+  const float *mu0, *rstd0, *xhat1, *rstd1, *xhat2, *rstd2;
+  const uint64_t *mask1, *mask2;
+  if (!saves_alt) {
+    mu0 = W + p.mu0; rstd0 = W + p.rstd0; xhat1 = W + p.xhat1; rstd1 = W + p.rstd1; mask1 = (const uint64_t*)(W + p.mask1);
+    xhat2 = W + p.xhat2; rstd2 = W + p.rstd2; mask2 = (const uint64_t*)(W + p.mask2);
+  } else {
+    const int64_t R = p.Ra;
+    mu0 = saves_alt; rstd0 = saves_alt + R; rstd1 = saves_alt + 2 * R; rstd2 = saves_alt + 3 * R;
+    mask1 = (const uint64_t*)(saves_alt + 4 * R); mask2 = (const uint64_t*)(saves_alt + 6 * R);
+    xhat1 = saves_alt + 8 * R; xhat2 = saves_alt + 8 * R + R * OPE_H;
+  }
+  TrunkBwdArgs tb;
+  memset(&tb, 0, sizeof(tb));
+  tb.R = rows; tb.theta = theta; tb.thetaT = W + p.thetaT; tb.L = L; tb.da2_in = W + p.da2;
+  tb.xhat1 = xhat1; tb.rstd1 = rstd1; tb.mask1 = mask1; tb.xhat2 = xhat2; tb.rstd2 = rstd2; tb.mask2 = mask2;
+  tb.dz1 = W + p.dz1; tb.dz2 = W + p.dz2;
+  if ((rc = launch_trunk_bwd(tb, st))) return rc;
+  if (!grad) return OPE_OK;   // input-gradient-only pass (critic inside the actor update)
+  WgTable wt;
+  memset(&wt, 0, sizeof(wt));
+  int n = 0;
+  auto prob = [&](const float* A_, int lda, int M, const float* B_, int ldb, int N_, int out_off, int ldc, int s_off) -> WgProb& {
+    WgProb& q = wt.p[n++];
+    q.A = A_; q.lda = lda; q.M = M; q.B = B_; q.ldb = ldb; q.N = N_; q.K = rows; q.b_shift = 0; q.ln_mu = W + p.lnz; q.ln_rstd = W + p.lno;
+    q.out_off = out_off; q.ldc = ldc; q.s_off = s_off; q.nsplit = nsplit; q.raw_base = p.raw; q.raw_stride = p.raw_size_c;
+    return q;
+  };
+  {
+    WgProb& q = prob(W + p.dz1, OPE_H, OPE_H, x, Dw, Dw, p.P1, Dw, p.s1);
+    q.ln_mu = mu0; q.ln_rstd = rstd0;
+  }
+  prob(W + p.dz2, OPE_H, OPE_H, xhat1, OPE_H, OPE_H, p.P2, OPE_H, p.s2);
+  prob(dout, ldk, Hout, xhat2, OPE_H, OPE_H, p.E, OPE_H, p.sq);
+  wt.n = n;
+  if ((rc = wg_finish(&wt))) return rc;
+  if ((rc = launch_wgrad(wt, W, st))) return rc;
+  SplitRed sr;
+  sr.raw0 = W + p.raw; sr.n0 = p.raw_size_c; sr.ns0 = wg_slabs(wt, nsplit); sr.raw1 = W + p.raw; sr.n1 = 0; sr.ns1 = 0; sr.rsum = W + p.rsum;
+  if ((rc = launch_split_reduce(sr, st))) return rc;
+  FinTable ft;
+  memset(&ft, 0, sizeof(ft));
+  int k = 0;
+  auto seg = [&](int begin, int size, int kind, int src, int src_s, int M, int K_, int w, int gamma, int beta) {
+    FinSeg& s = ft.seg[k++];
+    s.begin = begin; s.size = size; s.kind = kind; s.src = src; s.src_s = src_s; s.M = M; s.K = K_; s.w = w; s.gamma = gamma; s.beta = beta;
+  };
+  seg(L.fn_w, Dw, FIN_LNLIN_G, p.P1, p.s1, OPE_H, Dw, L.fc1_w, 0, 0);
+  seg(L.fn_b, Dw, FIN_LNLIN_B, p.P1, p.s1, OPE_H, Dw, L.fc1_w, 0, 0);
+  seg(L.fc1_w, OPE_H * Dw, FIN_LNLIN_W, p.P1, p.s1, OPE_H, Dw, L.fc1_w, L.fn_w, L.fn_b);
+  seg(L.fc1_b, OPE_H, FIN_COPY, p.s1, 0, 0, 0, 0, 0, 0);
+  seg(L.ln1_w, OPE_H, FIN_LNLIN_G, p.P2, p.s2, OPE_H, OPE_H, L.fc2_w, 0, 0);
+  seg(L.ln1_b, OPE_H, FIN_LNLIN_B, p.P2, p.s2, OPE_H, OPE_H, L.fc2_w, 0, 0);
+  seg(L.fch_w, 0, FIN_ZERO, 0, 0, 0, 0, 0, 0, 0);
+  seg(L.fc2_w, OPE_H * OPE_H, FIN_LNLIN_W, p.P2, p.s2, OPE_H, OPE_H, L.fc2_w, L.ln1_w, L.ln1_b);
+  seg(L.fc2_b, OPE_H, FIN_COPY, p.s2, 0, 0, 0, 0, 0, 0);
+  seg(L.ln2_w, OPE_H, FIN_LNLIN_G, p.E, p.sq, Hout, OPE_H, L.q_w, 0, 0);
+  seg(L.ln2_b, OPE_H, FIN_LNLIN_B, p.E, p.sq, Hout, OPE_H, L.q_w, 0, 0);
+  seg(L.q_w, Hout * OPE_H, FIN_LNLIN_W, p.E, p.sq, Hout, OPE_H, L.q_w, L.ln2_w, L.ln2_b);
+  seg(L.q_b, Hout, FIN_COPY, p.sq, 0, 0, 0, 0, 0, 0);
+  seg(L.end, OPE_GRAD_TAIL, FIN_TAIL, 0, 0, 0, 0, 0, 0, 0);
+  ft.n = k;
+  ft.total = L.end + OPE_GRAD_TAIL;
+  return launch_finalize(ft, W + p.rsum, theta, W + p.loss_part, n_loss_tiles, grad, st);
+}
+
+}  // namespace ope
+
+using namespace ope;
+
+extern "C" int64_t ope_ddpg_param_layout(const ope_ddpg_cfg* cfg, int32_t which, int64_t* offsets, int64_t* sizes) {
+  if (!ddpg_cfg_ok(cfg) || which < 0 || which > 1) return OPE_EINVAL;
+  DdpgPlan p;
+  ddpg_plan(cfg, &p);
+  const AgentLayout& L = which == 0 ? p.AL : p.CL;
+  const int Dw = which == 0 ? p.D : p.Din, Ho = which == 0 ? p.A : p.K;
+  const int off[16] = {L.fn_w, L.fn_b, L.fc1_w, L.fc1_b, L.ln1_w, L.ln1_b, L.fch_w, L.fch_b, L.lnh_w, L.lnh_b, L.fc2_w, L.fc2_b, L.ln2_w, L.ln2_b, L.q_w, L.q_b};
+  const int siz[16] = {Dw, Dw, OPE_H * Dw, OPE_H, OPE_H, OPE_H, OPE_H * OPE_H, OPE_H, OPE_H, OPE_H, OPE_H * OPE_H, OPE_H, OPE_H, OPE_H, Ho * OPE_H, Ho};
+  for (int i = 0; i < 16; ++i) {
+    if (offsets) offsets[i] = off[i];
+    if (sizes) sizes[i] = siz[i];
+  }
+  return L.end;
+}
+
+extern "C" int64_t ope_ddpg_workspace_bytes(const ope_ddpg_cfg* cfg) {
+  if (!ddpg_cfg_ok(cfg)) return OPE_EINVAL;
+  DdpgPlan p;
+  ddpg_plan(cfg, &p);
+  return p.ws.total * (int64_t)sizeof(float);
+}
+
+extern "C" int64_t ope_ddpg_workspace_find(const ope_ddpg_cfg* cfg, const char* name, int64_t* n_floats) {
+  if (!ddpg_cfg_ok(cfg) || !name) return OPE_EINVAL;
+  DdpgPlan p;
+  ddpg_plan(cfg, &p);
+  const int64_t off = p.ws.find(name, n_floats);
+  return off < 0 ? -1 : off * (int64_t)sizeof(float);
+}
+
+extern "C" int ope_ddpg_workspace_init(const ope_ddpg_cfg* cfg, void* workspace, int64_t workspace_bytes, void* stream) {
+  (void)hipGetLastError();
+  if (!ddpg_cfg_ok(cfg) || !workspace) return OPE_EINVAL;
+  DdpgPlan p;
+  ddpg_plan(cfg, &p);
+  if (workspace_bytes < p.ws.total * (int64_t)sizeof(float)) return OPE_ENOSPC;
+  float* W = (float*)workspace;
+  int rc;
+  if ((rc = launch_fill(W + p.lnz, p.Ra, 0.f, (hipStream_t)stream))) return rc;
+  return launch_fill(W + p.lno, p.Ra, 1.f, (hipStream_t)stream);
+}
+
+extern "C" int ope_ddpg_critic_loss_and_grad(const ope_ddpg_cfg* cfg, const ope_mlp_batch* bt, const float* theta_actor_tgt,
+                                             const float* theta_critic, const float* theta_critic_tgt, const float* target_noise_u,
+                                             const float* per_weights, void* workspace, int64_t workspace_bytes, float* grad,
+                                             float* prio_out, void* stream) {
+  (void)hipGetLastError();
+  if (!ddpg_cfg_ok(cfg) || !bt || !theta_actor_tgt || !theta_critic || !theta_critic_tgt || !workspace || !grad) return OPE_EINVAL;
+  if (!bt->share_obs || !bt->acts || !bt->rewards || !bt->next_obs || !bt->next_share_obs || !bt->dones_env) return OPE_EINVAL;
+  if (cfg->target_gumbel && !target_noise_u) return OPE_EINVAL;
+  if (cfg->use_per && !per_weights) return OPE_EINVAL;
+  DdpgPlan p;
+  ddpg_plan(cfg, &p);
+  if (workspace_bytes < p.ws.total * (int64_t)sizeof(float)) return OPE_ENOSPC;
+  hipStream_t st = (hipStream_t)stream;
+  float* W = (float*)workspace;
+  int rc;
+  // target actor on the next observations -> joint next action
+  if ((rc = trunk_mlp(p, W, bt->next_obs, p.Ra, p.D, theta_actor_tgt, p.AL, W + p.a2n, false, nullptr, st))) return rc;
+  if ((rc = linear_head(W + p.a2n, p.Ra, p.A, theta_actor_tgt, p.AL, W + p.lgn, st))) return rc;
+  OPE_L(hipLaunchKernelGGL(action_kernel, dim3(launch1d(p.Ra)), dim3(256), 0, st, W + p.lgn, bt->next_avail_acts, target_noise_u, p.Ra,
+                           p.B, p.A, p.N, cfg->target_gumbel ? 1 : 0, W + p.cnact, (float*)nullptr, (float*)nullptr));
+  // critic inputs
+  OPE_L(hipLaunchKernelGGL(build_cin_kernel, dim3(launch1d((int64_t)p.B * p.Din)), dim3(256), 0, st, bt->next_share_obs, W + p.cnact,
+                           (const float*)nullptr, p.B, 1, p.N * p.A, p.S, 1, W + p.xin_t));
+  OPE_L(hipLaunchKernelGGL(build_cin_kernel, dim3(launch1d((int64_t)p.B * p.Din)), dim3(256), 0, st, bt->share_obs, bt->acts,
+                           (const float*)nullptr, p.B, p.N, p.A, p.S, 1, W + p.xin));
+  // target critic, live critic
+  if ((rc = trunk_mlp(p, W, W + p.xin_t, p.B, p.Din, theta_critic_tgt, p.CL, W + p.a2t, false, nullptr, st))) return rc;
+  if ((rc = linear_head(W + p.a2t, p.B, p.K, theta_critic_tgt, p.CL, W + p.qt, st))) return rc;   // [B][K] (K4 == K when K%4==0)
+  if ((rc = trunk_mlp(p, W, W + p.xin, p.B, p.Din, theta_critic, p.CL, W + p.a2c, true, nullptr, st))) return rc;
+  if ((rc = linear_head(W + p.a2c, p.B, p.K, theta_critic, p.CL, W + p.qc, st))) return rc;
+  CriticTdArgs td;
+  td.B = p.B; td.K = p.K; td.K4 = p.K; td.gamma = cfg->gamma; td.use_huber = cfg->use_huber; td.huber_delta = cfg->huber_delta;
+  td.per_eps = cfg->per_eps; td.q = W + p.qc; td.q_tgt = W + p.qt; td.rewards = bt->rewards; td.dones_env = bt->dones_env;
+  td.per_weights = cfg->use_per ? per_weights : nullptr; td.dq = W + p.dq; td.prio_out = prio_out; td.loss_part = W + p.loss_part;
+  OPE_L(hipLaunchKernelGGL(critic_td_kernel, dim3(launch1d(p.B)), dim3(256), 0, st, td));
+  return mlp_backward(p, W, W + p.xin, p.B, p.Din, p.K, p.K, W + p.dq, theta_critic, p.CL, nullptr, p.ns_c, ope_cdiv(p.B, 16), grad, st);
+}
+
+extern "C" int ope_ddpg_actor_loss_and_grad(const ope_ddpg_cfg* cfg, const ope_mlp_batch* bt, const float* theta_actor,
+                                            const float* theta_critic, const float* gumbel_noise_u, void* workspace,
+                                            int64_t workspace_bytes, float* grad, void* stream) {
+  (void)hipGetLastError();
+  if (!ddpg_cfg_ok(cfg) || !bt || !theta_actor || !theta_critic || !gumbel_noise_u || !workspace || !grad) return OPE_EINVAL;
+  if (!bt->obs || !bt->share_obs || !bt->acts || !bt->valid_transition) return OPE_EINVAL;
+  DdpgPlan p;
+  ddpg_plan(cfg, &p);
+  if (workspace_bytes < p.ws.total * (int64_t)sizeof(float)) return OPE_ENOSPC;
+  hipStream_t st = (hipStream_t)stream;
+  float* W = (float*)workspace;
+  int rc;
+  float* saves2 = W + p.err;
+  // actor forward (saves -> alternate set) and straight-through hard gumbel sample
+  if ((rc = trunk_mlp(p, W, bt->obs, p.Ra, p.D, theta_actor, p.AL, W + p.a2a, true, saves2, st))) return rc;
+  if ((rc = linear_head(W + p.a2a, p.Ra, p.A, theta_actor, p.AL, W + p.lga, st))) return rc;
+  OPE_L(hipLaunchKernelGGL(action_kernel, dim3(launch1d(p.Ra)), dim3(256), 0, st, W + p.lga, bt->avail_acts, gumbel_noise_u, p.Ra, p.B,
+                           p.A, p.N, 1, (float*)nullptr, W + p.actout, W + p.ysoft));
+  // N stacked copies of the joint action, copy i carrying the actor's action for agent i
+  OPE_L(hipLaunchKernelGGL(build_cin_kernel, dim3(launch1d((int64_t)p.Ra * p.Din)), dim3(256), 0, st, bt->share_obs, bt->acts,
+                           W + p.actout, p.B, p.N, p.A, p.S, p.N, W + p.xin_a));
+  // critic (parameters frozen) on the stacked input; only head 0 enters the objective
+  if ((rc = trunk_mlp(p, W, W + p.xin_a, p.Ra, p.Din, theta_critic, p.CL, W + p.a2c, true, nullptr, st))) return rc;
+  if ((rc = linear_head(W + p.a2c, p.Ra, p.K, theta_critic, p.CL, W + p.qc, st))) return rc;
+  OPE_L(hipLaunchKernelGGL(actor_obj_kernel, dim3(launch1d(p.Ra)), dim3(256), 0, st, W + p.qc, p.K, bt->valid_transition, p.Ra,
+                           W + p.dq, W + p.loss_part));
+  // critic backward down to its input, then through the gumbel-softmax into the actor logits
+  if ((rc = mlp_backward(p, W, W + p.xin_a, p.Ra, p.Din, p.K, p.K, W + p.dq, theta_critic, p.CL, nullptr, p.ns_a, 0, nullptr, st))) return rc;
+  InGradArgs ig;
+  ig.R = p.Ra; ig.D = p.Din; ig.dz1 = W + p.dz1; ig.fc1_w = theta_critic + p.CL.fc1_w; ig.gamma = theta_critic + p.CL.fn_w;
+  ig.x = W + p.xin_a; ig.mu0 = W + p.mu0; ig.rstd0 = W + p.rstd0; ig.dx = W + p.dx;
+  OPE_L(hipLaunchKernelGGL(input_grad_kernel, dim3(ope_cdiv(p.Ra, 4)), dim3(256), 0, st, ig));
+  OPE_L(hipLaunchKernelGGL(gumbel_bwd_kernel, dim3(launch1d(p.Ra)), dim3(256), 0, st, W + p.dx, p.Din, p.S, W + p.ysoft, p.Ra, p.B, p.A,
+                           p.A4, W + p.dlg));
+  // actor backward and gradients
+  return mlp_backward(p, W, bt->obs, p.Ra, p.D, p.A, p.A4, W + p.dlg, theta_actor, p.AL, saves2, p.ns_a, ope_cdiv(p.Ra, 16), grad, st);
+}

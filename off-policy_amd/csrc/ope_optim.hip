@@ -44,6 +44,7 @@ struct AdamK {
   float beta1, beta2, eps, max_norm, wd, tau, qden;
   int do_polyak;
   int nblocks;
+  long long tail;   // index of [loss_sum, mask_count, qtot_sum] in g
 };
 
 __global__ void __launch_bounds__(kBlock) adam_kernel(AdamK c, int64_t n, float* __restrict__ theta, float* __restrict__ tgt,
@@ -56,14 +57,14 @@ __global__ void __launch_bounds__(kBlock) adam_kernel(AdamK c, int64_t n, float*
   for (int q = threadIdx.x; q < c.nblocks; q += kBlock) s += part[q];
   // fixed-order: each thread adds a fixed subset, then the same tree everywhere -> identical in all blocks
   const float tot = block_sum(s, sm);
-  const float cnt = g[n + 1];
+  const float cnt = g[c.tail + 1];
   const float inv = 1.0f / cnt;
   const float norm = sqrtf(tot) * inv;
   const float coef = fminf(1.0f, c.max_norm / (norm + 1e-6f));
   if (blockIdx.x == 0 && threadIdx.x == 0 && stats) {
-    stats[0] = g[n] * inv;          // loss
+    stats[0] = g[c.tail] * inv;     // loss
     stats[1] = norm;                // pre-clip global L2 norm
-    stats[2] = g[n + 2] / c.qden;   // mean of Q_tot*(1-mask) over ALL T*B steps
+    stats[2] = g[c.tail + 2] / c.qden;   // mean of Q_tot*(1-mask) over ALL T*B steps
     stats[3] = cnt;
   }
   (void)s_coef;
@@ -114,6 +115,7 @@ extern "C" int ope_adam_step(const ope_adam_cfg* cfg, int64_t n, float* theta, f
   c.beta1 = cfg->beta1; c.beta2 = cfg->beta2; c.eps = cfg->eps; c.max_norm = cfg->max_grad_norm;
   c.wd = cfg->weight_decay; c.tau = cfg->tau; c.qden = cfg->qtot_denominator; c.do_polyak = cfg->do_polyak;
   c.nblocks = nb;
+  c.tail = cfg->tail_offset > 0 ? cfg->tail_offset : n;
   hipLaunchKernelGGL(adam_kernel, dim3(nb), dim3(kBlock), 0, st, c, n, theta, theta_tgt, adam_m, adam_v, grad, scratch, stats_out);
   OPE_CHECK_LAUNCH();
   return OPE_OK;

@@ -1,0 +1,127 @@
+"""CPU oracle for the MLP MADDPG / MATD3 update path. TEST INFRASTRUCTURE ONLY (same rules as qmix_oracle.py).
+
+Restates in functional torch-CPU fp32:
+    MADDPG.get_update_info / shared_train_policy_on_batch   offpolicy/algorithms/maddpg/maddpg.py:38-81, 90-249
+    MADDPG_Actor / MADDPG_Critic                            offpolicy/algorithms/maddpg/algorithm/actor_critic.py:28-41, 69-87
+    MADDPGPolicy.get_actions (use_target / use_gumbel)      offpolicy/algorithms/maddpg/algorithm/MADDPGPolicy.py:63-105
+    onehot_from_logits / gumbel_softmax                     offpolicy/utils/util.py:156-214
+    MADDPGPolicy.soft_target_updates                        MADDPGPolicy.py:141-145
+including the upstream behaviours a drop-in must keep: the critic's Q heads are frozen and the
+target critic has its own heads; the actor is updated on every call. Uniform noise tensors are inputs.
+Pinned by tests/golden/maddpg_*.npz / matd3_*.npz (outputs of the real reference).
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .mqmix_oracle import mlp_base
+from .qmix_oracle import huber, HP
+
+
+def gumbel_hard(logits, avail, u):
+    y = logits + (-torch.log(-torch.log(u + 1e-20) + 1e-20))
+    if avail is not None:
+        y = y.masked_fill(avail == 0, -1e10)
+    y = F.softmax(y, dim=-1)
+    y_hard = (y == y.max(-1, keepdim=True)[0]).float()
+    return (y_hard - y).detach() + y
+
+
+def onehot_argmax(logits, avail):
+    if avail is not None:
+        logits = logits.masked_fill(avail == 0, -1e10)
+    return (logits == logits.max(-1, keepdim=True)[0]).float()
+
+
+class MaddpgOracle(object):
+    def __init__(self, actor, critic, critic_heads, actor_tgt, critic_tgt, critic_heads_tgt, n_agents, hp=None, td3=False):
+        """actor/critic: {name: array} trunks (+ 'act.action_out.*' for the actor); critic_heads: (W [K,64], b [K])."""
+        self.hp = hp or HP()
+        self.N, self.td3 = n_agents, td3
+        f = lambda d: OrderedDict((k, torch.as_tensor(np.asarray(v), dtype=torch.float32).clone()) for k, v in d.items())
+        h = lambda wb: (torch.as_tensor(np.asarray(wb[0]), dtype=torch.float32).clone(), torch.as_tensor(np.asarray(wb[1]), dtype=torch.float32).clone())
+        self.actor, self.critic, self.actor_tgt, self.critic_tgt = f(actor), f(critic), f(actor_tgt), f(critic_tgt)
+        self.heads, self.heads_tgt = h(critic_heads), h(critic_heads_tgt)
+        self.adam = {"actor": [OrderedDict(), OrderedDict(), 0], "critic": [OrderedDict(), OrderedDict(), 0]}
+
+    @staticmethod
+    def actor_logits(P, x):
+        return F.linear(mlp_base(P, x), P["act.action_out.weight"], P["act.action_out.bias"])
+
+    @staticmethod
+    def critic_q(P, heads, cent, joint):
+        a2 = mlp_base(P, torch.cat([cent, joint], dim=1))
+        return F.linear(a2, heads[0], heads[1])                       # [rows, K]
+
+    def _adam_step(self, which, params, grads):
+        hp = self.hp
+        names = [k for k in params if ".fc_h." not in k]
+        g_list = [grads[k] for k in names]
+        total = torch.sqrt(sum((g.double() ** 2).sum() for g in g_list)).float()
+        coef = min(1.0, hp.max_grad_norm / (float(total) + 1e-6))
+        st = self.adam[which]
+        st[2] += 1
+        b1, b2 = 0.9, 0.999
+        bc1, bc2 = 1 - b1 ** st[2], 1 - b2 ** st[2]
+        for k, g in zip(names, g_list):
+            g = g * coef
+            if k not in st[0]:
+                st[0][k], st[1][k] = torch.zeros_like(g), torch.zeros_like(g)
+            m = st[0][k].mul_(b1).add_(g, alpha=1 - b1)
+            v = st[1][k].mul_(b2).addcmul_(g, g, value=1 - b2)
+            params[k] = params[k] - (hp.lr / bc1) * (m / (v.sqrt() / np.sqrt(bc2)).add_(hp.opti_eps))
+        return float(total)
+
+    def train_step(self, batch, u_target=None, u_actor=None, weights=None, soft_update=True):
+        hp, N = self.hp, self.N
+        obs, cent, acts, rew, nobs, ncent, dones, dones_env, valid, avail, navail = [
+            torch.as_tensor(np.ascontiguousarray(x)) if x is not None else None for x in batch]
+        B = obs.shape[1]
+        s_obs, s_nobs = torch.cat(list(obs), 0), torch.cat(list(nobs), 0)
+        s_av = torch.cat(list(avail), 0) if avail is not None else None
+        s_nav = torch.cat(list(navail), 0) if navail is not None else None
+        with torch.no_grad():
+            lg = self.actor_logits(self.actor_tgt, s_nobs)
+            nact = gumbel_hard(lg, s_nav, torch.as_tensor(u_target)) if self.td3 else onehot_argmax(lg, s_nav)
+            cent_nact = torch.cat(nact.split(B, dim=0), dim=-1)
+            nq = self.critic_q(self.critic_tgt, self.heads_tgt, ncent, cent_nact).min(dim=-1, keepdim=True)[0]
+            target = rew[0].view(-1, 1) + hp.gamma * (1 - dones_env.view(-1, 1)) * nq
+        cent_act = torch.cat(list(acts), dim=-1)
+        live = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in self.critic.items())
+        q = self.critic_q(live, self.heads, cent, cent_act)
+        errs = [target - q[:, k:k + 1] for k in range(q.shape[1])]
+        f = (lambda e: huber(e, hp.huber_delta)) if hp.use_huber_loss else (lambda e: e ** 2)
+        if hp.use_per:
+            w = torch.as_tensor(np.asarray(weights), dtype=torch.float32)
+            closs = sum((f(e).flatten() * w).mean() for e in errs)
+            prio = np.stack([e.abs().detach().numpy().flatten() for e in errs]).mean(axis=0) + hp.per_eps
+        else:
+            closs = sum(f(e).mean() for e in errs)
+            prio = None
+        names = [k for k in live if ".fc_h." not in k]
+        cg = dict(zip(names, torch.autograd.grad(closs, [live[k] for k in names])))
+        cnorm = self._adam_step("critic", self.critic, cg)
+        # ---- actor (through the UPDATED critic, whose parameters are frozen here) ----
+        la = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in self.actor.items())
+        pol = gumbel_hard(self.actor_logits(la, s_obs), s_av, torch.as_tensor(u_actor))
+        agent_acts = pol.split(B, dim=0)
+        rows = []
+        for i in range(N):
+            parts = [agent_acts[i] if a == i else acts[a] for a in range(N)]
+            rows.append(torch.cat(parts, dim=-1))
+        joint = torch.cat(rows, dim=0)
+        q1 = self.critic_q(self.critic, self.heads, cent.repeat(N, 1), joint)[:, 0:1]
+        vmask = torch.cat(list(valid), dim=0)
+        aloss = -(q1 * vmask).sum() / vmask.sum()
+        anames = [k for k in la if ".fc_h." not in k]
+        ag = dict(zip(anames, torch.autograd.grad(aloss, [la[k] for k in anames])))
+        anorm = self._adam_step("actor", self.actor, ag)
+        if soft_update:
+            tau = hp.tau
+            for src, dst in ((self.critic, self.critic_tgt), (self.actor, self.actor_tgt)):
+                for k in src:
+                    dst[k] = dst[k] * (1 - tau) + src[k] * tau
+        return dict(critic_loss=float(closs.detach()), critic_grad_norm=cnorm, actor_loss=float(aloss.detach()), actor_grad_norm=anorm,
+                    priorities=prio, critic_grads={k: v.numpy() for k, v in cg.items()}, actor_grads={k: v.numpy() for k, v in ag.items()})

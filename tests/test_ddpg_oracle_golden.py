@@ -1,0 +1,73 @@
+"""Pin oracle/maddpg_oracle.py against outputs of the REAL reference (tests/golden/maddpg_*.npz, matd3_*.npz)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, sub
+from oracle import maddpg_oracle as DO
+from oracle.qmix_oracle import HP
+from test_mlp_oracle_golden import T_KEYS
+
+CASES = ["maddpg_spread", "matd3_spread", "maddpg_small_huber_per", "matd3_small"]
+
+
+def ddpg_oracle_from(g):
+    hp = HP(gamma=float(g["hp_gamma"]), lr=float(g["hp_lr"]), opti_eps=float(g["hp_eps"]), use_huber_loss=bool(g["hp_huber"]),
+            huber_delta=float(g["hp_delta"]), use_per=bool(g["hp_per"]), per_eps=float(g["hp_per_eps"]), tau=float(g["hp_tau"]),
+            max_grad_norm=float(g["hp_maxnorm"]))
+    return DO.MaddpgOracle(sub(g, "actor/"), sub(g, "critic/"), (g["heads/w"], g["heads/b"]), sub(g, "actor_tgt/"),
+                           sub(g, "critic_tgt/"), (g["heads_tgt/w"], g["heads_tgt/b"]), int(g["dims"][0]), hp, td3=bool(g["td3"]))
+
+
+def noise_for(g, step):
+    """The uniform draws the reference consumed at `step` (torch.manual_seed(1000 + step), target noise first)."""
+    n, a = int(g["dims"][0]), int(g["dims"][1])
+    B = len(g["inds"])
+    torch.manual_seed(1000 + step)
+    u_t = torch.FloatTensor(n * B, a).uniform_() if bool(g["td3"]) else None
+    u_a = torch.FloatTensor(n * B, a).uniform_()
+    return u_t, u_a
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_train_steps_match_reference(name):
+    g = load_golden(name)
+    orc = ddpg_oracle_from(g)
+    batch = tuple(g["batch/" + k] for k in T_KEYS)
+    w = g["per_weights"] if "per_weights" in g else None
+    for s in range(len(g["critic_loss"])):
+        u_t, u_a = noise_for(g, s)
+        out = orc.train_step(batch, u_t, u_a, weights=w)
+        np.testing.assert_allclose(out["critic_loss"], g["critic_loss"][s], rtol=3e-5)
+        np.testing.assert_allclose(out["critic_grad_norm"], g["critic_grad_norm"][s], rtol=3e-5)
+        np.testing.assert_allclose(out["actor_loss"], g["actor_loss"][s], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(out["actor_grad_norm"], g["actor_grad_norm"][s], rtol=1e-4)
+        if w is not None:
+            np.testing.assert_allclose(out["priorities"], g["priorities"][s], rtol=3e-5)
+    for grp, dst in (("final_actor/", orc.actor), ("final_critic/", orc.critic), ("final_actor_tgt/", orc.actor_tgt),
+                     ("final_critic_tgt/", orc.critic_tgt)):
+        for k, ref in sub(g, grp).items():
+            np.testing.assert_allclose(dst[k].numpy(), ref, rtol=0, atol=2e-5, err_msg=grp + k)
+
+
+@pytest.mark.parametrize("name", ["maddpg_spread", "matd3_small"])
+def test_policy_construction_reproduces_reference_rng_stream(name):
+    """actor, critic (+heads), target actor, target critic (+its OWN heads) drawn in the reference's order."""
+    from offpolicy_amd.config import default_args
+    from offpolicy_amd.algorithms.maddpg.algorithm.actor_critic import draw_actor_values, draw_critic_values
+    g = load_golden(name)
+    n, a, d, s, _ = [int(x) for x in g["dims"]]
+    K = 2 if bool(g["td3"]) else 1
+    args = default_args()
+    torch.manual_seed(1)
+    np.random.seed(1)
+    av = draw_actor_values(args, d, a)
+    cv = draw_critic_values(args, s + n * a, K)
+    draw_actor_values(args, d, a)
+    tv = draw_critic_values(args, s + n * a, K)
+    for v, (k, ref) in zip(av, sub(g, "actor/").items()):
+        assert np.array_equal(v.numpy(), ref), k
+    for v, (k, ref) in zip(cv[:14], sub(g, "critic/").items()):
+        assert np.array_equal(v.numpy(), ref), k
+    assert np.array_equal(cv[14].numpy(), g["heads/w"]) and np.array_equal(tv[14].numpy(), g["heads_tgt/w"])
+    assert not np.array_equal(g["heads/w"], g["heads_tgt/w"])          # A-4: live and target heads differ forever

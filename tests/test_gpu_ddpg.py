@@ -1,0 +1,99 @@
+"""-m gpu: MLP MADDPG / MATD3 through the C-ABI vs the reference's frozen outputs (same gumbel noise stream)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, sub
+from test_mlp_oracle_golden import T_KEYS
+from test_ddpg_oracle_golden import CASES
+
+pytestmark = pytest.mark.gpu
+RTOL = 2e-4
+
+
+def build(g, device="cuda:0"):
+    from offpolicy_amd.config import default_args
+    from offpolicy_amd.utils.synth import EnvDims, policy_info_for
+    from offpolicy_amd.utils.mlp_buffer import MlpReplayBuffer
+    from offpolicy_amd.algorithms.maddpg.algorithm.MADDPGPolicy import MADDPGPolicy
+    from offpolicy_amd.algorithms.matd3.algorithm.MATD3Policy import MATD3Policy
+    from offpolicy_amd.algorithms.maddpg.maddpg import MADDPG
+    from offpolicy_amd.algorithms.matd3.matd3 import MATD3
+    n, a, d, s, _ = [int(x) for x in g["dims"]]
+    dims = EnvDims("fx", n, a, d, s, 1)
+    args = default_args(gamma=float(g["hp_gamma"]), lr=float(g["hp_lr"]), opti_eps=float(g["hp_eps"]), use_huber_loss=bool(g["hp_huber"]),
+                        huber_delta=float(g["hp_delta"]), use_per=bool(g["hp_per"]), per_eps=float(g["hp_per_eps"]), tau=float(g["hp_tau"]),
+                        max_grad_norm=float(g["hp_maxnorm"]))
+    pinfo = policy_info_for(dims)
+    dev = torch.device(device)
+    torch.manual_seed(1)
+    np.random.seed(1)
+    td3 = bool(g["td3"])
+    policy = (MATD3Policy if td3 else MADDPGPolicy)({"args": args, "device": dev}, pinfo["policy_0"])
+    trainer = (MATD3 if td3 else MADDPG)(args, n, {"policy_0": policy}, lambda x: "policy_0", device=dev)
+    buf = MlpReplayBuffer(pinfo, {"policy_0": list(range(n))}, int(g["cap"]), True, True, False, device=device)
+    buf.insert(len(g["idx_range"]), *[{"policy_0": g["tr/" + k]} for k in T_KEYS])
+    return dims, buf, policy, trainer
+
+
+def params_of(mod):
+    return {k: v.detach().cpu().numpy() for k, v in mod.named_parameters()}
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_construction_and_train_steps_match_reference(name):
+    g = load_golden(name)
+    dims, buf, policy, trainer = build(g)
+    # same seed -> same initial networks as the reference built, including the unsynchronised target heads
+    for grp, mod in (("actor/", policy.actor), ("critic/", policy.critic), ("actor_tgt/", policy.target_actor), ("critic_tgt/", policy.target_critic)):
+        got = params_of(mod)
+        for k, ref in sub(g, grp).items():
+            assert np.array_equal(got[k], ref), grp + k
+    assert np.array_equal(policy.critic._head_w.cpu().numpy(), g["heads/w"])
+    assert np.array_equal(policy.target_critic._head_w.cpu().numpy(), g["heads_tgt/w"])
+    assert list(policy.critic.state_dict().keys()) == list(sub(g, "critic/").keys())     # heads absent, as upstream
+    s = buf.policy_buffers["policy_0"].sample_inds(g["inds"])
+    w = g["per_weights"] if "per_weights" in g else None
+    batch = tuple({"policy_0": a} for a in s) + (w, g["inds"] if w is not None else None)
+    for st in range(len(g["critic_loss"])):
+        torch.manual_seed(1000 + st)
+        info, prio, _ = trainer.shared_train_policy_on_batch("policy_0", batch)
+        assert info["update_actor"]
+        policy.soft_target_updates()
+        np.testing.assert_allclose(float(info["critic_loss"]), g["critic_loss"][st], rtol=RTOL)
+        np.testing.assert_allclose(float(info["critic_grad_norm"]), g["critic_grad_norm"][st], rtol=RTOL)
+        np.testing.assert_allclose(float(info["actor_loss"]), g["actor_loss"][st], rtol=5e-4, atol=2e-6)
+        np.testing.assert_allclose(float(info["actor_grad_norm"]), g["actor_grad_norm"][st], rtol=5e-4)
+        if w is not None:
+            np.testing.assert_allclose(prio, g["priorities"][st], rtol=RTOL)
+    for grp, mod in (("final_actor/", policy.actor), ("final_critic/", policy.critic), ("final_actor_tgt/", policy.target_actor),
+                     ("final_critic_tgt/", policy.target_critic)):
+        got = params_of(mod)
+        for k, ref in sub(g, grp).items():
+            np.testing.assert_allclose(got[k], ref, rtol=0, atol=3e-5, err_msg=grp + k)
+    assert np.array_equal(policy.critic._head_w.cpu().numpy(), g["final_heads/w"])          # frozen (A-4)
+    assert np.array_equal(policy.target_critic._head_w.cpu().numpy(), g["final_heads_tgt/w"])
+
+
+def test_fixed_mode_trains_heads_and_delays_actor():
+    """The documented non-reference mode: registered (trainable) Q heads and a real update counter."""
+    from offpolicy_amd.config import default_args
+    from offpolicy_amd.utils.synth import EnvDims, policy_info_for
+    from offpolicy_amd.algorithms.matd3.algorithm.MATD3Policy import MATD3Policy
+    from offpolicy_amd.algorithms.matd3.matd3 import MATD3
+    g = load_golden("matd3_small")
+    n, a, d, s, _ = [int(x) for x in g["dims"]]
+    dims = EnvDims("fx", n, a, d, s, 1)
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    policy = MATD3Policy({"args": default_args(), "device": dev}, policy_info_for(dims)["policy_0"], frozen_q_head=False)
+    trainer = MATD3(default_args(), n, {"policy_0": policy}, lambda x: "policy_0", device=dev, count_updates=True)
+    assert "q_outs.weight" in policy.critic.state_dict()
+    assert torch.equal(policy.critic._head_w, policy.target_critic._head_w)          # targets synchronised, heads included
+    batch = tuple({"policy_0": g["batch/" + k]} for k in T_KEYS) + (None, None)
+    h0 = policy.critic._head_w.clone()
+    info0, _, _ = trainer.shared_train_policy_on_batch("policy_0", batch)
+    info1, _, _ = trainer.shared_train_policy_on_batch("policy_0", batch)
+    assert "actor_loss" in info0 and "actor_loss" not in info1                       # every 2nd update only
+    assert not torch.equal(policy.critic._head_w, h0)
+    assert np.isfinite(float(info1["critic_loss"]))
