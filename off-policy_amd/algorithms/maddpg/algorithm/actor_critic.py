@@ -122,7 +122,8 @@ class MADDPG_Critic(FlatModule):
         self.head_offset = int(offs[14])                 # everything before this is what Adam / Polyak touch when frozen
         hw = flat[offs[14]:offs[14] + num_q_outs * H].view(num_q_outs, H)
         hb = flat[offs[15]:offs[15] + num_q_outs]
-        self.q_outs = [_Head(hw[k], hb[k:k + 1]) for k in range(num_q_outs)]
+        if self.frozen_q_head:   # upstream's plain (unregistered) list; in fixed mode `q_outs` is the registered sub-module
+            self.q_outs = [_Head(hw[k], hb[k:k + 1]) for k in range(num_q_outs)]
         self._head_w, self._head_b = hw, hb
         if values is not None:
             for p, v in zip(list(self.parameters())[:14], values[:14]):
