@@ -32,8 +32,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="3s5z", choices=["3m", "3s5z", "MMM2"])
-    ap.add_argument("--batch", type=int, default=32, help="episodes per training step on ONE GPU (weak) / in total (strong)")
+    ap.add_argument("--workload", default="3s5z", choices=["3m", "3s5z", "MMM2", "maddpg_spread", "matd3_spread"],
+                    help="QMIX-RNN on a SMAC map's dimensions (default 3s5z = the headline config), or MLP MADDPG/MATD3 on MPE simple_spread")
+    ap.add_argument("--batch", type=int, default=None, help="samples per training step on ONE GPU (weak) / in total (strong); "
+                    "default 32 episodes (QMIX) or 256 transitions (MADDPG)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--episodes", type=int, default=256, help="synthetic episodes resident in the replay store")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -97,6 +99,10 @@ def cpu_baseline(dims, batch, seconds):
 
 def main():
     a = parse()
+    if a.workload in ("maddpg_spread", "matd3_spread"):
+        return main_ddpg(a)
+    if a.batch is None:
+        a.batch = 32
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -187,6 +193,161 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dims, a.batch, a.cpu_seconds)
+            out["config"]["speedup_vs_cpu_port"] = round(value / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def ddpg_transitions(rng, n, dims):
+    N, A, D, S = dims.n_agents, dims.act_dim, dims.obs_dim, dims.state_dim
+    f = np.float32
+    dones_env = (rng.random_sample((n, 1)) < 0.1).astype(f)
+    avail = np.ones((n, N, A), f)
+    return dict(obs=rng.standard_normal((n, N, D)).astype(f), share_obs=rng.standard_normal((n, S)).astype(f),
+                acts=np.eye(A, dtype=f)[rng.randint(0, A, size=(n, N))], rewards=np.repeat(rng.standard_normal((n, 1, 1)).astype(f), N, 1),
+                next_obs=rng.standard_normal((n, N, D)).astype(f), next_share_obs=rng.standard_normal((n, S)).astype(f),
+                dones=np.repeat(dones_env[:, None], N, 1), dones_env=dones_env, valid_transition=np.ones((n, N, 1), f),
+                avail_acts=avail, next_avail_acts=avail)
+
+
+DDPG_KEYS = ("obs", "share_obs", "acts", "rewards", "next_obs", "next_share_obs", "dones", "dones_env", "valid_transition",
+             "avail_acts", "next_avail_acts")
+
+
+def ddpg_cpu_baseline(dims, batch, td3, seconds):
+    """CPU port (oracle/maddpg_oracle.py) of one MADDPG update: sample + critic step + actor step + soft updates."""
+    from oracle import maddpg_oracle as DO
+    from oracle import mqmix_oracle as MO
+    from offpolicy_amd.config import default_args
+    from offpolicy_amd.algorithms.maddpg.algorithm.actor_critic import draw_actor_values, draw_critic_values, _TRUNK
+    args = default_args()
+    torch.manual_seed(1)
+    N, A, D, S = dims.n_agents, dims.act_dim, dims.obs_dim, dims.state_dim
+    K = 2 if td3 else 1
+    an = _TRUNK + ["act.action_out.weight", "act.action_out.bias"]
+    av, cv = draw_actor_values(args, D, A), draw_critic_values(args, S + N * A, K)
+    av2, cv2 = draw_actor_values(args, D, A), draw_critic_values(args, S + N * A, K)
+    tr = ddpg_transitions(np.random.RandomState(0), 4096, dims)
+    res = {}
+    ncores = os.cpu_count() or 1
+    counts = [t for t in (1, 8) if t <= ncores]
+    for threads in counts:
+        torch.set_num_threads(threads)
+        orc = DO.MaddpgOracle(dict(zip(an, av)), dict(zip(_TRUNK, cv[:14])), (cv[14], cv[15]), dict(zip(an, av)), dict(zip(_TRUNK, cv[:14])),
+                              (cv2[14], cv2[15]), N, td3=td3)
+        rng = np.random.RandomState(1)
+
+        def step():
+            inds = rng.choice(4096, batch)
+            b = MO.sample_inds(tr, inds)
+            u_t = torch.FloatTensor(N * batch, A).uniform_() if td3 else None
+            orc.train_step(b, u_t, torch.FloatTensor(N * batch, A).uniform_())
+        step()
+        t0 = time.perf_counter()
+        n = 0
+        while True:
+            step()
+            n += 1
+            el = time.perf_counter() - t0
+            if el >= seconds or n >= 5000:
+                break
+        res[threads] = (n / el, n)
+    best = max(res, key=lambda k: res[k][0])
+    return {"value": round(res[best][0], 3), "unit": "training steps/sec", "cores": best, "kind": "port",
+            "sample": "B=%d transitions of 4096 synthetic, ~%.0f s per thread count; steps/s by threads: %s" % (
+                batch, seconds, ", ".join("%d: %.2f (%d steps)" % (t, res[t][0], res[t][1]) for t in counts))}
+
+
+def main_ddpg(a):
+    """MLP MADDPG / MATD3 on MPE simple_spread dimensions (BASELINE.json config 3): step = buffer.sample(B) +
+    shared_train_policy_on_batch (critic + actor update) + soft target updates (runner/mlp/base_runner.py:188-218)."""
+    import ctypes as C
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == a.gpus
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        torch.distributed.init_process_group("nccl", device_id=dev)
+    from offpolicy_amd import _lib
+    from offpolicy_amd.config import default_args
+    from offpolicy_amd.utils.synth import DIMS, policy_info_for
+    from offpolicy_amd.utils.mlp_buffer import MlpReplayBuffer
+    from offpolicy_amd.algorithms.maddpg.algorithm.MADDPGPolicy import MADDPGPolicy
+    from offpolicy_amd.algorithms.matd3.algorithm.MATD3Policy import MATD3Policy
+    from offpolicy_amd.algorithms.maddpg.maddpg import MADDPG
+    from offpolicy_amd.algorithms.matd3.matd3 import MATD3
+    td3 = a.workload == "matd3_spread"
+    dims = DIMS["simple_spread"]
+    batch = a.batch or 256
+    local_batch = batch if a.scaling == "weak" else batch // world
+    global_batch = batch * world if a.scaling == "weak" else batch
+    args = default_args()
+    torch.manual_seed(1)
+    np.random.seed(1)
+    pinfo = policy_info_for(dims)
+    policy = (MATD3Policy if td3 else MADDPGPolicy)({"args": args, "device": dev}, pinfo["policy_0"])
+    trainer = (MATD3 if td3 else MADDPG)(args, dims.n_agents, {"policy_0": policy}, lambda x: "policy_0", device=dev)
+    cap = 16384
+    buf = MlpReplayBuffer(pinfo, {"policy_0": list(range(dims.n_agents))}, cap, True, True, False, device=dev)
+    tr = ddpg_transitions(np.random.RandomState(100 + rank), cap, dims)
+    buf.insert(cap, *[{"policy_0": tr[k]} for k in DDPG_KEYS])
+    np.random.seed(1000 + rank)
+    torch.manual_seed(1000 + rank)
+    pbuf = buf.policy_buffers["policy_0"]
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+
+    def one_step(i=None):
+        inds = np.random.choice(len(buf), local_batch)
+        s = pbuf.sample_inds(inds, timing_events=ev[i] if i is not None else None)
+        info, _, _ = trainer.shared_train_policy_on_batch("policy_0", tuple({"policy_0": x} for x in s) + (None, None))
+        policy.soft_target_updates()
+        return info
+
+    for _ in range(a.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        info = one_step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tt[0])
+    gather_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
+    assert np.isfinite(float(info["critic_loss"]))
+    if rank == 0:
+        # algorithmic bytes of the transition gather: every field of a transition once in, once out (SURVEY 8(d): 964 B/transition)
+        N, A, D, S = dims.n_agents, dims.act_dim, dims.obs_dim, dims.state_dim
+        tr_bytes = 4 * (2 * N * D + 2 * S + N * A + 2 * N * A + N + N + 1 + N)
+        algo = 2.0 * local_batch * tr_bytes
+        steps_per_s = a.steps / elapsed
+        value = steps_per_s * (global_batch / float(batch))
+        out = {"metric": "training steps/sec (batch=%d) %s-MLP simple_spread" % (batch, "MATD3" if td3 else "MADDPG"),
+               "value": round(value, 2), "unit": "training steps/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": round(1e3 * elapsed / a.steps, 4), "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "%s-MLP MPE simple_spread (N=%d A=%d D=%d S=%d), replay filled with %d synthetic transitions, "
+                                      "step = sample + critic update + actor update + soft target updates; reference semantics "
+                                      "(frozen critic heads A-4, actor updated every call A-5)" % ("MATD3" if td3 else "MADDPG", N, A, D, S, cap),
+                          "batch_per_gpu": local_batch, "global_batch": global_batch, "parallelism": "dp%d" % world,
+                          "optimizer_steps_per_sec": round(steps_per_s, 2)},
+               "roofline": {"kernel": "episode_copy_kernel<gather> (transition gather)", "bound": "hbm", "achieved": round(algo / (gather_ms * 1e-3) / 1e9, 3),
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(algo / (gather_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
+                            "algorithmic_bytes_per_launch": int(algo), "avg_launch_ms": round(gather_ms, 5),
+                            "note": "247 KB per step: launch-latency bound, not bandwidth bound (SURVEY 8(a) a17)"}}
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = ddpg_cpu_baseline(dims, batch, td3, a.cpu_seconds)
             out["config"]["speedup_vs_cpu_port"] = round(value / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
     if world > 1:
