@@ -215,6 +215,49 @@ int ope_ddpg_actor_loss_and_grad(const ope_ddpg_cfg* cfg, const ope_mlp_batch* b
                                  const float* theta_critic, const float* gumbel_noise_u, void* workspace,
                                  int64_t workspace_bytes, float* grad, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Recurrent MADDPG / MATD3 update on sampled EPISODES (use_same_share_obs path, one shared policy).
+ * Replaces, for discrete one-hot actions:
+ *   R_MADDPG.get_update_info               offpolicy/algorithms/r_maddpg/r_maddpg.py:44-105
+ *   R_MADDPG.shared_train_policy_on_batch  offpolicy/algorithms/r_maddpg/r_maddpg.py:114-331
+ *   R_MADDPG_Actor / R_MADDPG_Critic       offpolicy/algorithms/r_maddpg/algorithm/r_actor_critic.py:7-129
+ *   R_MADDPGPolicy.get_actions (target / gumbel branches)  .../algorithm/rMADDPGPolicy.py:61-131
+ * Networks: RNNBase (feature LN -> fc1 -> fc2 -> GRU -> LN) + Linear head; flat vectors use the 22-tensor recurrent
+ * agent layout (ope_qmix_param_layout order); the critic head block is [num_q][64] weights then [num_q] biases
+ * (q_outs.k.weight / q_outs.k.bias, registered and trained -- unlike the MLP family).
+ * The episode batch is the ope_fields block of ope_store_gather (time-major, rows agent*B + b); prev_act_inp = False.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ope_rddpg_cfg {
+  ope_dims dims;         /* episode_length = T */
+  int32_t batch;         /* B episodes */
+  int32_t num_q;         /* 1 (R_MADDPG) or 2 (R_MATD3) */
+  int32_t target_gumbel; /* 1: hard gumbel-softmax target actions (target_noise is not None, rMADDPGPolicy.py:108) */
+  int32_t use_huber, use_per;
+  float gamma, huber_delta;
+} ope_rddpg_cfg;
+
+/* which = 0 actor, 1 critic: offsets/sizes of its OPE_QMIX_NPARAM_AGENT tensors; returns the padded length. */
+int64_t ope_rddpg_param_layout(const ope_rddpg_cfg* cfg, int32_t which, int64_t* offsets, int64_t* sizes);
+int64_t ope_rddpg_workspace_bytes(const ope_rddpg_cfg* cfg);
+int ope_rddpg_workspace_init(const ope_rddpg_cfg* cfg, void* workspace, int64_t workspace_bytes, void* stream);
+int64_t ope_rddpg_workspace_find(const ope_rddpg_cfg* cfg, const char* name, int64_t* n_floats);
+/* Critic update (r_maddpg.py:134-224): target actor scanned over the T+1 observations from a zero state, first action
+ * dropped; target critic state follows the BUFFER sequence and branches one cell step per t on the target actions;
+ * err_k = (Q_k - target)(1 - shifted dones_env). grad = d(sum_k sum f(err_k) w_b)/d theta_critic + tail
+ * [loss_sum, sum(1 - shifted dones_env), sum Q_0, 0]. td_abs_stats [num_q][B][2] = per head, per episode
+ * (mean_t |err|, max_t |err|) or NULL. target_noise_u [(T+1)*N*B][A] uniform noise (NULL unless target_gumbel). */
+int ope_rddpg_critic_loss_and_grad(const ope_rddpg_cfg* cfg, const ope_fields* batch, const float* theta_actor_tgt,
+                                   const float* theta_critic, const float* theta_critic_tgt, const float* target_noise_u,
+                                   const float* per_weights, void* workspace, int64_t workspace_bytes, float* grad,
+                                   float* td_abs_stats, void* stream);
+/* Actor update (r_maddpg.py:236-327): actor scanned over obs[:-1], hard gumbel-softmax (noise gumbel_noise_u [T*N*B][A]),
+ * actions spliced into N stacked copies of the joint action; Q_t = head 0 of one critic cell step from the critic's
+ * buffer-sequence state; loss = -sum(Q (1 - shifted agent dones)) / sum(1 - shifted agent dones). grad w.r.t.
+ * theta_actor + tail [loss_sum, mask_count, sum Q, 0]. */
+int ope_rddpg_actor_loss_and_grad(const ope_rddpg_cfg* cfg, const ope_fields* batch, const float* theta_actor,
+                                  const float* theta_critic, const float* gumbel_noise_u, void* workspace,
+                                  int64_t workspace_bytes, float* grad, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

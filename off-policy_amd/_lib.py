@@ -49,6 +49,11 @@ class DdpgCfg(C.Structure):
                 ("per_eps", C.c_float)]
 
 
+class RddpgCfg(C.Structure):
+    _fields_ = [("dims", Dims), ("batch", C.c_int32), ("num_q", C.c_int32), ("target_gumbel", C.c_int32),
+                ("use_huber", C.c_int32), ("use_per", C.c_int32), ("gamma", C.c_float), ("huber_delta", C.c_float)]
+
+
 class MlpBatch(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("obs", "share_obs", "acts", "rewards", "next_obs", "next_share_obs", "dones_env",
                                           "valid_transition", "avail_acts", "next_avail_acts")]
@@ -83,6 +88,12 @@ def _load():
         "ope_ddpg_workspace_find": (i64, [C.POINTER(DdpgCfg), C.c_char_p, C.POINTER(i64)]),
         "ope_ddpg_critic_loss_and_grad": (C.c_int, [C.POINTER(DdpgCfg), C.POINTER(MlpBatch), p, p, p, p, p, p, i64, p, p, p]),
         "ope_ddpg_actor_loss_and_grad": (C.c_int, [C.POINTER(DdpgCfg), C.POINTER(MlpBatch), p, p, p, p, i64, p, p]),
+        "ope_rddpg_param_layout": (i64, [C.POINTER(RddpgCfg), i32, C.POINTER(i64), C.POINTER(i64)]),
+        "ope_rddpg_workspace_bytes": (i64, [C.POINTER(RddpgCfg)]),
+        "ope_rddpg_workspace_init": (C.c_int, [C.POINTER(RddpgCfg), p, i64, p]),
+        "ope_rddpg_workspace_find": (i64, [C.POINTER(RddpgCfg), C.c_char_p, C.POINTER(i64)]),
+        "ope_rddpg_critic_loss_and_grad": (C.c_int, [C.POINTER(RddpgCfg), C.POINTER(Fields), p, p, p, p, p, p, i64, p, p, p]),
+        "ope_rddpg_actor_loss_and_grad": (C.c_int, [C.POINTER(RddpgCfg), C.POINTER(Fields), p, p, p, p, i64, p, p]),
         "ope_adam_scratch_floats": (i64, [i64]),
         "ope_adam_step": (C.c_int, [C.POINTER(AdamCfg), i64, p, p, p, p, p, p, p, p]),
         "ope_polyak": (C.c_int, [i64, p, p, C.c_float, p]),

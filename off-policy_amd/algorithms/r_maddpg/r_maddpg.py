@@ -1,0 +1,167 @@
+"""Recurrent MADDPG / MATD3 trainer on the HIP engine.
+
+Mirror of offpolicy/algorithms/r_maddpg/r_maddpg.py:9-331 (`R_MADDPG`, shared-observation path
+`shared_train_policy_on_batch`) for one shared policy and discrete one-hot actions. Per update:
+
+    ope_rddpg_critic_loss_and_grad -> ope_adam_step(critic)
+    [every actor_update_interval-th update]  ope_rddpg_actor_loss_and_grad -> ope_adam_step(actor)
+
+The reference walks the target critic (critic update) and the live critic (actor update) through the episode with a
+Python loop of 2*T network calls; the engine runs the buffer-sequence scan once and all "sideways" steps as one
+row-parallel GRU-cell launch (csrc/ope_rddpg.hip). Gumbel noise is drawn on the CPU generator in the reference's
+order and shapes: target noise [(T+1), N*B, A] first (only when target_noise is set), then actor noise [T, N*B, A].
+Unlike the MLP trainer, `num_updates` IS incremented here (r_maddpg.py:330), so R_MATD3 really
+delays its actor update.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from ... import _lib
+from ... import dist as opdist
+from ..maddpg.algorithm.MADDPGPolicy import sample_gumbel_uniform
+
+
+class R_MADDPG(object):
+    def __init__(self, args, num_agents, policies, policy_mapping_fn, device=None, episode_length=None, actor_update_interval=1):
+        self.args = args
+        if getattr(args, "use_popart", False):
+            raise NotImplementedError("use_popart is not on the accelerated path")
+        self.use_per, self.per_eps = args.use_per, args.per_eps
+        self.use_huber_loss, self.huber_delta = args.use_huber_loss, args.huber_delta
+        self.device = torch.device(device if device is not None else "cuda:0")
+        self.tpdv = dict(dtype=torch.float32, device=self.device)
+        self.episode_length = args.episode_length if episode_length is None else episode_length
+        self.num_agents, self.policies, self.policy_mapping_fn = num_agents, policies, policy_mapping_fn
+        self.policy_ids = sorted(list(self.policies.keys()))
+        self.policy_agents = {pid: sorted([a for a in range(num_agents) if policy_mapping_fn(a) == pid]) for pid in self.policies}
+        if self.policy_ids != ["policy_0"] or len(self.policy_agents["policy_0"]) != num_agents:
+            raise NotImplementedError("the accelerated R_MADDPG path handles one shared policy ('policy_0') for all agents")
+        self.actor_update_interval = actor_update_interval
+        self.num_updates = {p_id: 0 for p_id in self.policy_ids}
+        self.use_same_share_obs = args.use_same_share_obs
+        self._ws, self._grads = {}, {}
+
+    def _workspace(self, policy, cfg):
+        B = cfg.batch
+        if B not in self._ws:
+            need = _lib.lib.ope_rddpg_workspace_bytes(C.byref(cfg))
+            if need < 0:
+                _lib.check(int(need), "ope_rddpg_workspace_bytes")
+            ws = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+            _lib.check(_lib.lib.ope_rddpg_workspace_init(C.byref(cfg), _lib.ptr(ws), ws.numel(), _lib.current_stream()),
+                       "ope_rddpg_workspace_init")
+            self._ws[B] = ws
+            nmax = max(policy.critic.padded_numel, policy.actor.padded_numel)
+            self._grads[B] = (torch.zeros(policy.critic.padded_numel + 4, **self.tpdv), torch.zeros(policy.actor.padded_numel + 4, **self.tpdv),
+                              torch.zeros(int(_lib.lib.ope_adam_scratch_floats(nmax)), **self.tpdv))
+        return self._ws[B], self._grads[B]
+
+    def workspace_view(self, batch, name, policy_id="policy_0"):
+        cfg = self.policies[policy_id].rddpg_cfg(batch, self.episode_length)
+        n = C.c_int64(0)
+        off = _lib.lib.ope_rddpg_workspace_find(C.byref(cfg), name.encode(), C.byref(n))
+        if off < 0:
+            raise KeyError(name)
+        return self._ws[batch][off:off + 4 * n.value].view(torch.float32)
+
+    def train_policy_on_batch(self, update_policy_id, batch):
+        if self.use_same_share_obs:
+            return self.shared_train_policy_on_batch(update_policy_id, batch)
+        raise NotImplementedError("cent_train_policy_on_batch (per-agent centralized observations) is not on the accelerated path")
+
+    def _adam(self, opt, n, flat, flat_tgt, grad, scratch, qden):
+        opt.step_count += 1
+        ac = _lib.AdamCfg()
+        ac.lr, ac.beta1, ac.beta2, ac.eps = opt.lr, opt.betas[0], opt.betas[1], opt.eps
+        ac.max_grad_norm, ac.weight_decay, ac.tau, ac.do_polyak = float(self.args.max_grad_norm), 0.0, 0.0, 0
+        ac.step, ac.qtot_denominator, ac.tail_offset = opt.step_count, float(qden), int(n)
+        stats = torch.empty(4, **self.tpdv)
+        _lib.check(_lib.lib.ope_adam_step(C.byref(ac), int(n), _lib.ptr(flat), _lib.ptr(flat_tgt), _lib.ptr(opt.exp_avg),
+                                          _lib.ptr(opt.exp_avg_sq), _lib.ptr(grad), _lib.ptr(scratch), _lib.ptr(stats),
+                                          _lib.current_stream()), "ope_adam_step")
+        return stats
+
+    def _to_device_layout(self, x, agent_axis):
+        """[N, T(+1), B, dim] (reference's per-agent stacking) -> the kernels' [T(+1), N, B, dim]; [T(+1), B, dim] as is."""
+        if x is None:
+            return None
+        if torch.is_tensor(x):
+            t = x.to(self.device, dtype=torch.float32)
+            if agent_axis:
+                t = t.permute(1, 0, 2, 3)
+            return t if t.is_contiguous() else t.contiguous()
+        a = np.asarray(x, dtype=np.float32)
+        if agent_axis:
+            a = a.transpose(1, 0, 2, 3)
+        return torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+
+    def shared_train_policy_on_batch(self, update_policy_id, batch):
+        """See r_maddpg.py:114-331. `batch` = 9-tuple of RecReplayBuffer.sample()."""
+        obs_b, cent_b, act_b, rew_b, dones_b, dones_env_b, avail_b, importance_weights, idxes = batch
+        pid = update_policy_id
+        policy = self.policies[pid]
+        obs = self._to_device_layout(obs_b[pid], True)
+        share = self._to_device_layout(cent_b[pid], False)
+        acts = self._to_device_layout(act_b[pid], True)
+        rew = self._to_device_layout(rew_b[pid], True)
+        dones = self._to_device_layout(dones_b[pid], True)
+        dones_env = self._to_device_layout(dones_env_b[pid], False)
+        avail = self._to_device_layout(avail_b[pid], True) if (avail_b is not None and avail_b[pid] is not None) else None
+        return self._train_on_device_batch(policy, pid, obs, share, acts, rew, dones, dones_env, avail, importance_weights, idxes)
+
+    def _train_on_device_batch(self, policy, pid, obs, share, acts, rew, dones, dones_env, avail, importance_weights, idxes):
+        T1, N, B, D = obs.shape
+        T = self.episode_length
+        assert T1 == T + 1 and N == self.num_agents, "batch does not match the trainer's dimensions"
+        A = policy.act_dim
+        cfg = policy.rddpg_cfg(B, T)
+        ws, (gc, ga, scratch) = self._workspace(policy, cfg)
+        f = _lib.Fields()
+        f.obs, f.share_obs, f.acts, f.rewards = _lib.ptr(obs).value, _lib.ptr(share).value, _lib.ptr(acts).value, _lib.ptr(rew).value
+        f.dones, f.dones_env, f.avail_acts = _lib.ptr(dones).value, _lib.ptr(dones_env).value, _lib.ptr(avail).value
+        st = _lib.current_stream()
+        _, world_size = opdist.world()
+        train_info = {}
+        update_actor = self.num_updates[pid] % self.actor_update_interval == 0
+        # ---- critic ----
+        u_t = sample_gumbel_uniform((T + 1, N * B, A)).to(self.device) if policy.target_noise is not None else None
+        w = torch.as_tensor(np.asarray(importance_weights), dtype=torch.float32).to(self.device).contiguous() if self.use_per else None
+        K = policy.num_q
+        td_stats = torch.empty(K * 2 * B, **self.tpdv) if self.use_per else None
+        _lib.check(_lib.lib.ope_rddpg_critic_loss_and_grad(C.byref(cfg), C.byref(f), _lib.ptr(policy.target_actor._flat),
+                                                           _lib.ptr(policy.critic._flat), _lib.ptr(policy.target_critic._flat),
+                                                           _lib.ptr(u_t), _lib.ptr(w), _lib.ptr(ws), ws.numel(), _lib.ptr(gc),
+                                                           _lib.ptr(td_stats), st), "ope_rddpg_critic_loss_and_grad")
+        opdist.allreduce_flat_(gc)
+        cs = self._adam(policy.critic_optimizer, policy.critic.padded_numel, policy.critic._flat, policy.target_critic._flat, gc, scratch,
+                        T * B * world_size)
+        train_info["critic_loss"], train_info["critic_grad_norm"] = cs[0], cs[1]
+        new_priorities = None
+        if self.use_per:        # r_maddpg.py:216-218: eps is added per head AND after the mean over heads
+            s = td_stats.view(K, B, 2).cpu().numpy().astype(np.float32)
+            nu = self.args.per_nu
+            per_head = [((1 - nu) * s[k, :, 0] + nu * s[k, :, 1]).flatten() + self.per_eps for k in range(K)]
+            new_priorities = np.stack(per_head).mean(axis=0) + self.per_eps
+        # ---- actor (through the freshly updated critic) ----
+        u_a = None
+        if update_actor:
+            u_a = sample_gumbel_uniform((T, N * B, A)).to(self.device)
+            _lib.check(_lib.lib.ope_rddpg_actor_loss_and_grad(C.byref(cfg), C.byref(f), _lib.ptr(policy.actor._flat),
+                                                              _lib.ptr(policy.critic._flat), _lib.ptr(u_a), _lib.ptr(ws), ws.numel(),
+                                                              _lib.ptr(ga), st), "ope_rddpg_actor_loss_and_grad")
+            opdist.allreduce_flat_(ga)
+            as_ = self._adam(policy.actor_optimizer, policy.actor.padded_numel, policy.actor._flat, policy.target_actor._flat, ga, scratch,
+                             1.0)
+            train_info["actor_grad_norm"], train_info["actor_loss"] = as_[1], as_[0]
+        train_info["update_actor"] = update_actor
+        self.num_updates[pid] += 1
+        self._last = (obs, share, acts, rew, dones, dones_env, avail, u_t, u_a, w, td_stats)   # keep alive past the async launches
+        return train_info, new_priorities, idxes
+
+    def prep_training(self):
+        pass
+
+    def prep_rollout(self):
+        pass

@@ -401,7 +401,7 @@ __global__ void __launch_bounds__(256) head_fwd_kernel(HeadFwdArgs a) {
     }
   } else {
     ln64_thread(a.h0 + r * OPE_H, sm + A * OPE_H + ope_round4_dev(A), sm + A * OPE_H + ope_round4_dev(A) + OPE_H, y,
-                (MODE == 0 && a.xhat_o) ? a.xhat_o + r * OPE_H : nullptr, (MODE == 0 && a.rstd_o) ? a.rstd_o + r : nullptr);
+                a.xhat_o ? a.xhat_o + r * OPE_H : nullptr, a.rstd_o ? a.rstd_o + r : nullptr);
   }
 
   if (MODE == 1) {

@@ -26,4 +26,13 @@ struct InGradArgs {
   float* dx;                                 // [R][D]
 };
 
+// shared with the recurrent family (ope_rddpg.hip)
+int launch_build_cin(const float* cent, const float* acts, const float* repl, int T, int B, int N, int A, int S, int reps, float* out,
+                     hipStream_t st);
+int launch_action(const float* logits, const float* avail, const float* U, int rows, int B, int A, int N, int mode, int t_shift,
+                  float* cent_nact, float* act_out, float* soft_out, hipStream_t st);
+int launch_input_grad(const InGradArgs& ig, hipStream_t st);
+int launch_gumbel_bwd(const float* dx, int Din, int S, const float* y, int rows, int B, int A, int A4, int N, float* dlogits,
+                      hipStream_t st);
+
 }  // namespace ope

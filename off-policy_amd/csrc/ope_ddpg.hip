@@ -12,23 +12,26 @@
 namespace ope {
 
 // ---------------------------------------------------------------------------------------------------------
-// rows of the critic input:  out[r] = [ cent[b] (S) | joint action (N*A) ],  r = rep*B + b
-//   joint action block a = acts[a][b]  unless  (repl != null and a == rep): then repl[rep*B + b]
-// (maddpg.py:128 for the critic update, 207-227 for the actor update: "mask * actor + (1 - mask) * buffer")
+// rows of the critic input:  out[r] = [ cent[t][b] (S) | joint action (N*A) ],  r = (t*reps + rep)*B + b
+//   joint action block a = acts[t][a][b]  unless  (repl != null and a == rep): then repl[r]   (reps == N in that case)
+// (maddpg.py:128 for the critic update, 207-227 for the actor update: "mask * actor + (1 - mask) * buffer";
+//  r_maddpg.py:162, 291-301 for the sequence form; the MLP family is T = 1)
 // ---------------------------------------------------------------------------------------------------------
 __global__ void build_cin_kernel(const float* __restrict__ cent, const float* __restrict__ acts, const float* __restrict__ repl,
-                                 int B, int N, int A, int S, int reps, float* __restrict__ out) {
+                                 int T, int B, int N, int A, int S, int reps, float* __restrict__ out) {
   const int Din = S + N * A;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (int64_t)reps * B * Din) return;
+  if (i >= (int64_t)T * reps * B * Din) return;
   const int r = (int)(i / Din), c = (int)(i - (int64_t)r * Din);
-  const int rep = r / B, b = r - rep * B;
+  const int t = r / (reps * B);
+  const int rem = r - t * (reps * B);
+  const int rep = rem / B, b = rem - rep * B;
   float v;
   if (c < S) {
-    v = cent[(int64_t)b * S + c];
+    v = cent[((int64_t)t * B + b) * S + c];
   } else {
     const int a = (c - S) / A, j = (c - S) - a * A;
-    v = (repl && a == rep) ? repl[((int64_t)rep * B + b) * A + j] : acts[((int64_t)a * B + b) * A + j];
+    v = (repl && a == rep) ? repl[(int64_t)r * A + j] : acts[(((int64_t)t * N + a) * B + b) * A + j];
   }
   out[i] = v;
 }
@@ -41,12 +44,18 @@ __global__ void build_cin_kernel(const float* __restrict__ cent, const float* __
 // With `soft_out` non-null (actor update, mode 1 only) the soft sample y is kept for the backward pass and the
 // straight-through value goes to act_out[row][A] instead.
 // ---------------------------------------------------------------------------------------------------------
+// Rows are (t, agent, b) with t < rows / (N*B) (t = 0 only for the MLP family); the joint action of step t goes to
+// cent_nact[t - t_shift] and steps t < t_shift are dropped (the recurrent trainer discards the first target action,
+// r_maddpg.py:88).
 __global__ void action_kernel(const float* __restrict__ logits, const float* __restrict__ avail, const float* __restrict__ U,
-                              int rows, int B, int A, int N, int mode, float* __restrict__ cent_nact, float* __restrict__ act_out,
-                              float* __restrict__ soft_out) {
+                              int rows, int B, int A, int N, int mode, int t_shift, float* __restrict__ cent_nact,
+                              float* __restrict__ act_out, float* __restrict__ soft_out) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= rows) return;
-  const int a = r / B, b = r - a * B;
+  const int t = r / (N * B);
+  const int rem = r - t * (N * B);
+  const int a = rem / B, b = rem - a * B;
+  float* cn = (cent_nact && t >= t_shift) ? cent_nact + ((int64_t)(t - t_shift) * B + b) * (N * A) + a * A : nullptr;
   const float* lg = logits + (int64_t)r * A;
   const float* av = avail ? avail + (int64_t)r * A : nullptr;
   float mx = -3.0e38f;
@@ -87,7 +96,7 @@ __global__ void action_kernel(const float* __restrict__ logits, const float* __r
       if (soft_out) soft_out[(int64_t)r * A + j] = y;
     }
     if (act_out) act_out[(int64_t)r * A + j] = out;
-    if (cent_nact) cent_nact[(int64_t)b * (N * A) + a * A + j] = out;
+    if (cn) cn[j] = out;
   }
 }
 
@@ -220,10 +229,10 @@ __global__ void __launch_bounds__(256) input_grad_kernel(InGradArgs a) {
 // through the soft sample y = softmax(.): dlogit_j = y_j (dy_j - sum_m dy_m y_m). dy is the action block of agent
 // `rep = row / B` inside the critic-input gradient dx[row][S + rep*A + j].
 __global__ void gumbel_bwd_kernel(const float* __restrict__ dx, int Din, int S, const float* __restrict__ y, int rows, int B, int A,
-                                  int A4, float* __restrict__ dlogits) {
+                                  int A4, int N, float* __restrict__ dlogits) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= rows) return;
-  const int rep = r / B;
+  const int rep = (r / B) % N;   // rows are (t, agent, b)
   const float* dy = dx + (int64_t)r * Din + S + rep * A;
   const float* yy = y + (int64_t)r * A;
   float dot = 0.f;
@@ -238,6 +247,28 @@ static int launch1d(int64_t n) { return ope_cdiv(n, 256); }
     call;                                                      \
     if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;   \
   } while (0)
+
+int launch_build_cin(const float* cent, const float* acts, const float* repl, int T, int B, int N, int A, int S, int reps, float* out,
+                     hipStream_t st) {
+  OPE_L(hipLaunchKernelGGL(build_cin_kernel, dim3(launch1d((int64_t)T * reps * B * (S + N * A))), dim3(256), 0, st, cent, acts, repl, T,
+                           B, N, A, S, reps, out));
+  return OPE_OK;
+}
+int launch_action(const float* logits, const float* avail, const float* U, int rows, int B, int A, int N, int mode, int t_shift,
+                  float* cent_nact, float* act_out, float* soft_out, hipStream_t st) {
+  OPE_L(hipLaunchKernelGGL(action_kernel, dim3(launch1d(rows)), dim3(256), 0, st, logits, avail, U, rows, B, A, N, mode, t_shift,
+                           cent_nact, act_out, soft_out));
+  return OPE_OK;
+}
+int launch_input_grad(const InGradArgs& ig, hipStream_t st) {
+  OPE_L(hipLaunchKernelGGL(input_grad_kernel, dim3(ope_cdiv(ig.R, 4)), dim3(256), 0, st, ig));
+  return OPE_OK;
+}
+int launch_gumbel_bwd(const float* dx, int Din, int S, const float* y, int rows, int B, int A, int A4, int N, float* dlogits,
+                      hipStream_t st) {
+  OPE_L(hipLaunchKernelGGL(gumbel_bwd_kernel, dim3(launch1d(rows)), dim3(256), 0, st, dx, Din, S, y, rows, B, A, A4, N, dlogits));
+  return OPE_OK;
+}
 
 struct DdpgPlan {
   int N, A, D, S, B, K, K4, A4, Din, Ra;
@@ -461,12 +492,12 @@ extern "C" int ope_ddpg_critic_loss_and_grad(const ope_ddpg_cfg* cfg, const ope_
   if ((rc = trunk_mlp(p, W, bt->next_obs, p.Ra, p.D, theta_actor_tgt, p.AL, W + p.a2n, false, nullptr, st))) return rc;
   if ((rc = linear_head(W + p.a2n, p.Ra, p.A, theta_actor_tgt, p.AL, W + p.lgn, st))) return rc;
   OPE_L(hipLaunchKernelGGL(action_kernel, dim3(launch1d(p.Ra)), dim3(256), 0, st, W + p.lgn, bt->next_avail_acts, target_noise_u, p.Ra,
-                           p.B, p.A, p.N, cfg->target_gumbel ? 1 : 0, W + p.cnact, (float*)nullptr, (float*)nullptr));
+                           p.B, p.A, p.N, cfg->target_gumbel ? 1 : 0, 0, W + p.cnact, (float*)nullptr, (float*)nullptr));
   // critic inputs
   OPE_L(hipLaunchKernelGGL(build_cin_kernel, dim3(launch1d((int64_t)p.B * p.Din)), dim3(256), 0, st, bt->next_share_obs, W + p.cnact,
-                           (const float*)nullptr, p.B, 1, p.N * p.A, p.S, 1, W + p.xin_t));
+                           (const float*)nullptr, 1, p.B, 1, p.N * p.A, p.S, 1, W + p.xin_t));
   OPE_L(hipLaunchKernelGGL(build_cin_kernel, dim3(launch1d((int64_t)p.B * p.Din)), dim3(256), 0, st, bt->share_obs, bt->acts,
-                           (const float*)nullptr, p.B, p.N, p.A, p.S, 1, W + p.xin));
+                           (const float*)nullptr, 1, p.B, p.N, p.A, p.S, 1, W + p.xin));
   // target critic, live critic
   if ((rc = trunk_mlp(p, W, W + p.xin_t, p.B, p.Din, theta_critic_tgt, p.CL, W + p.a2t, false, nullptr, st))) return rc;
   if ((rc = linear_head(W + p.a2t, p.B, p.K, theta_critic_tgt, p.CL, W + p.qt, st))) return rc;   // [B][K] (K4 == K when K%4==0)
@@ -497,10 +528,10 @@ extern "C" int ope_ddpg_actor_loss_and_grad(const ope_ddpg_cfg* cfg, const ope_m
   if ((rc = trunk_mlp(p, W, bt->obs, p.Ra, p.D, theta_actor, p.AL, W + p.a2a, true, saves2, st))) return rc;
   if ((rc = linear_head(W + p.a2a, p.Ra, p.A, theta_actor, p.AL, W + p.lga, st))) return rc;
   OPE_L(hipLaunchKernelGGL(action_kernel, dim3(launch1d(p.Ra)), dim3(256), 0, st, W + p.lga, bt->avail_acts, gumbel_noise_u, p.Ra, p.B,
-                           p.A, p.N, 1, (float*)nullptr, W + p.actout, W + p.ysoft));
+                           p.A, p.N, 1, 0, (float*)nullptr, W + p.actout, W + p.ysoft));
   // N stacked copies of the joint action, copy i carrying the actor's action for agent i
   OPE_L(hipLaunchKernelGGL(build_cin_kernel, dim3(launch1d((int64_t)p.Ra * p.Din)), dim3(256), 0, st, bt->share_obs, bt->acts,
-                           W + p.actout, p.B, p.N, p.A, p.S, p.N, W + p.xin_a));
+                           W + p.actout, 1, p.B, p.N, p.A, p.S, p.N, W + p.xin_a));
   // critic (parameters frozen) on the stacked input; only head 0 enters the objective
   if ((rc = trunk_mlp(p, W, W + p.xin_a, p.Ra, p.Din, theta_critic, p.CL, W + p.a2c, true, nullptr, st))) return rc;
   if ((rc = linear_head(W + p.a2c, p.Ra, p.K, theta_critic, p.CL, W + p.qc, st))) return rc;
@@ -513,7 +544,7 @@ extern "C" int ope_ddpg_actor_loss_and_grad(const ope_ddpg_cfg* cfg, const ope_m
   ig.x = W + p.xin_a; ig.mu0 = W + p.mu0; ig.rstd0 = W + p.rstd0; ig.dx = W + p.dx;
   OPE_L(hipLaunchKernelGGL(input_grad_kernel, dim3(ope_cdiv(p.Ra, 4)), dim3(256), 0, st, ig));
   OPE_L(hipLaunchKernelGGL(gumbel_bwd_kernel, dim3(launch1d(p.Ra)), dim3(256), 0, st, W + p.dx, p.Din, p.S, W + p.ysoft, p.Ra, p.B, p.A,
-                           p.A4, W + p.dlg));
+                           p.A4, p.N, W + p.dlg));
   // actor backward and gradients
   return mlp_backward(p, W, bt->obs, p.Ra, p.D, p.A, p.A4, W + p.dlg, theta_actor, p.AL, saves2, p.ns_a, ope_cdiv(p.Ra, 16), grad, st);
 }

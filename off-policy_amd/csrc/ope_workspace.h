@@ -7,7 +7,7 @@ namespace ope {
 
 // ---- workspace: a list of named float regions, 256-byte aligned --------------------------------------------
 struct Region { const char* name; int64_t off; int64_t n; };
-constexpr int kMaxRegions = 64;
+constexpr int kMaxRegions = 160;
 struct Workspace {
   Region r[kMaxRegions];
   int n = 0;

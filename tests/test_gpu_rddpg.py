@@ -1,0 +1,207 @@
+"""-m gpu: recurrent MADDPG / MATD3 through the C-ABI vs the reference's frozen outputs (same gumbel noise stream),
+vs the oracle's per-tensor gradients, and through the additivity of the un-normalised gradient over episodes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, sub
+from golden_util import EP_KEYS, fixture_dims
+from test_rddpg_oracle_golden import CASES, rddpg_oracle_from, rnoise_for
+
+pytestmark = pytest.mark.gpu
+RTOL = 3e-4
+
+
+def build(g, device="cuda:0", dims=None, args=None, td3=None, cap=None):
+    from offpolicy_amd.config import default_args
+    from offpolicy_amd.utils.synth import policy_info_for
+    from offpolicy_amd.utils.rec_buffer import RecReplayBuffer
+    from offpolicy_amd.algorithms.r_maddpg.algorithm.rMADDPGPolicy import R_MADDPGPolicy
+    from offpolicy_amd.algorithms.r_matd3.algorithm.rMATD3Policy import R_MATD3Policy
+    from offpolicy_amd.algorithms.r_maddpg.r_maddpg import R_MADDPG
+    from offpolicy_amd.algorithms.r_matd3.r_matd3 import R_MATD3
+    if g is not None:
+        dims = fixture_dims(g)
+        args = default_args(gamma=float(g["hp_gamma"]), lr=float(g["hp_lr"]), opti_eps=float(g["hp_eps"]), use_huber_loss=bool(g["hp_huber"]),
+                            huber_delta=float(g["hp_delta"]), use_per=bool(g["hp_per"]), per_nu=float(g["hp_nu"]),
+                            per_eps=float(g["hp_per_eps"]), tau=float(g["hp_tau"]), max_grad_norm=float(g["hp_maxnorm"]))
+        td3 = bool(g["td3"])
+        cap = len(g["idx_range"])
+    pinfo = policy_info_for(dims)
+    dev = torch.device(device)
+    torch.manual_seed(1)
+    np.random.seed(1)
+    policy = (R_MATD3Policy if td3 else R_MADDPGPolicy)({"args": args, "device": dev}, pinfo["policy_0"])
+    trainer = (R_MATD3 if td3 else R_MADDPG)(args, dims.n_agents, {"policy_0": policy}, lambda x: "policy_0", device=dev,
+                                            episode_length=dims.episode_length)
+    buf = RecReplayBuffer(pinfo, {"policy_0": list(range(dims.n_agents))}, cap, dims.episode_length, True, True, False, device=device)
+    return dims, buf, policy, trainer
+
+
+def params_of(mod):
+    return {k: v.detach().cpu().numpy() for k, v in mod.named_parameters()}
+
+
+def load_fixture_weights(g, policy, check=True):
+    for grp, mod in (("actor/", policy.actor), ("critic/", policy.critic), ("actor_tgt/", policy.target_actor), ("critic_tgt/", policy.target_critic)):
+        if check:   # same seed -> same draws (to rounding across CPUs: orthogonal_ runs a host LAPACK QR)
+            got = params_of(mod)
+            for k, ref in sub(g, grp).items():
+                np.testing.assert_allclose(got[k], ref, rtol=0, atol=3e-5, err_msg=grp + k)
+        mod.load_state_dict({k: torch.as_tensor(v) for k, v in sub(g, grp).items()})
+
+
+def fixture_batch(g, buf):
+    d = {k: {"policy_0": g["ep/" + k]} for k in EP_KEYS}
+    r = buf.insert(len(g["idx_range"]), *[d[k] for k in EP_KEYS])
+    assert np.array_equal(r, g["idx_range"])
+    s = buf.policy_buffers["policy_0"].sample_inds(g["inds"])
+    for k, a in zip(EP_KEYS, s):          # the HIP gather returns what the reference's sample_inds returned
+        assert np.array_equal(a.cpu().numpy() if torch.is_tensor(a) else np.asarray(a), g["batch/" + k]), k
+    w = g["per_weights"] if "per_weights" in g else None
+    return tuple({"policy_0": a} for a in s) + (w, g["inds"] if w is not None else None), w
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_construction_and_train_steps_match_reference(name):
+    g = load_golden(name)
+    dims, buf, policy, trainer = build(g)
+    load_fixture_weights(g, policy)
+    assert list(policy.critic.state_dict().keys()) == list(sub(g, "critic/").keys())
+    assert list(policy.actor.state_dict().keys()) == list(sub(g, "actor/").keys())
+    batch, w = fixture_batch(g, buf)
+    for st in range(len(g["critic_loss"])):
+        torch.manual_seed(1000 + st)
+        info, prio, _ = trainer.shared_train_policy_on_batch("policy_0", batch)
+        policy.soft_target_updates()
+        assert bool(info["update_actor"]) == bool(g["update_actor"][st])
+        np.testing.assert_allclose(float(info["critic_loss"]), g["critic_loss"][st], rtol=RTOL)
+        np.testing.assert_allclose(float(info["critic_grad_norm"]), g["critic_grad_norm"][st], rtol=RTOL)
+        if info["update_actor"]:
+            np.testing.assert_allclose(float(info["actor_loss"]), g["actor_loss"][st], rtol=1e-3, atol=3e-6)
+            np.testing.assert_allclose(float(info["actor_grad_norm"]), g["actor_grad_norm"][st], rtol=1e-3)
+        if w is not None:
+            np.testing.assert_allclose(prio, g["priorities"][st], rtol=RTOL)
+    for grp, mod in (("final_actor/", policy.actor), ("final_critic/", policy.critic), ("final_actor_tgt/", policy.target_actor),
+                     ("final_critic_tgt/", policy.target_critic)):
+        got = params_of(mod)
+        for k, ref in sub(g, grp).items():
+            np.testing.assert_allclose(got[k], ref, rtol=0, atol=3e-5, err_msg=grp + k)
+
+
+def _flat_grads(mod, gvec):
+    """Per-tensor normalised gradients out of a flat gradient vector (+tail [loss_sum, count, ...])."""
+    n = mod.padded_numel
+    g = gvec.cpu().numpy()
+    cnt = g[n + 1]
+    out = {}
+    for name, (shape, off) in mod.spec().items():
+        out[name] = g[off:off + int(np.prod(shape))].reshape(shape) / cnt
+    return out, g[n] / cnt
+
+
+@pytest.mark.parametrize("name", ["rmatd3_tiny", "rmaddpg_odd_huber_per", "rmaddpg_3m"])
+def test_gradients_match_oracle_per_tensor(name):
+    g = load_golden(name)
+    dims, buf, policy, trainer = build(g)
+    load_fixture_weights(g, policy, check=False)
+    batch, w = fixture_batch(g, buf)
+    orc = rddpg_oracle_from(g)
+    np_batch = tuple(g["batch/" + k] for k in EP_KEYS)
+    u_t, u_a = rnoise_for(g, 0)
+    ref = orc.train_step(np_batch, u_t, u_a, weights=w)
+    torch.manual_seed(1000)
+    trainer.shared_train_policy_on_batch("policy_0", batch)
+    B = len(g["inds"])
+    gc, ga, _ = trainer._grads[B]
+    for mod, gvec, rg, loss in ((policy.critic, gc, ref["critic_grads"], ref["critic_loss"]), (policy.actor, ga, ref["actor_grads"], ref["actor_loss"])):
+        got, got_loss = _flat_grads(mod, gvec)
+        np.testing.assert_allclose(got_loss, loss, rtol=2e-4, atol=2e-6)
+        for k, r in rg.items():
+            scale = max(np.abs(r).max(), 1e-6)
+            np.testing.assert_allclose(got[k], r, rtol=0, atol=2e-3 * scale + 1e-7, err_msg=k)
+        for k in got:
+            if ".fc_h." in k:
+                assert not got[k].any()
+
+
+def test_rollout_forward_matches_oracle():
+    """actor(obs, None, h) / critic(cent_obs, cent_act, h): sequences and single steps with carried state."""
+    from oracle import rmaddpg_oracle as RO
+    g = load_golden("rmatd3_tiny")
+    dims, buf, policy, trainer = build(g)
+    load_fixture_weights(g, policy, check=False)
+    N, A, D, S, T = dims.n_agents, dims.act_dim, dims.obs_dim, dims.state_dim, dims.episode_length
+    rng = np.random.RandomState(3)
+    obs = rng.standard_normal((T, 7, D)).astype(np.float32)
+    h0 = rng.standard_normal((7, 64)).astype(np.float32) * 0.3
+    P = {k: torch.as_tensor(v) for k, v in sub(g, "actor/").items()}
+    ref_lg, ref_h = RO.actor_logits(P, torch.as_tensor(obs), torch.as_tensor(h0))
+    lg, h = policy.actor(obs, None, h0)
+    np.testing.assert_allclose(lg.cpu().numpy(), ref_lg.numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(h.cpu().numpy(), ref_h.numpy(), rtol=0, atol=2e-5)
+    lg1, h1 = policy.actor(obs[0], None, h0)
+    np.testing.assert_allclose(lg1.cpu().numpy(), ref_lg[0].numpy(), rtol=0, atol=2e-5)
+    acts, h2, eps = policy.get_actions(obs[0], None, h0)
+    assert acts.shape == (7, A) and eps is None and np.all(acts.cpu().numpy().sum(-1) >= 1)
+    co = rng.standard_normal((T, 5, S)).astype(np.float32)
+    ca = np.eye(A, dtype=np.float32)[rng.randint(0, A, size=(T, 5, N))].reshape(T, 5, N * A)
+    hc = rng.standard_normal((5, 64)).astype(np.float32) * 0.3
+    Pc = {k: torch.as_tensor(v) for k, v in sub(g, "critic/").items()}
+    ref_q, ref_hc = RO.critic_q(Pc, 2, torch.as_tensor(co), torch.as_tensor(ca), torch.as_tensor(hc))
+    qs, hcn = policy.critic(co, ca, hc)
+    assert len(qs) == 2 and qs[0].shape == (T, 5, 1)
+    np.testing.assert_allclose(torch.cat(qs, -1).cpu().numpy(), ref_q.numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(hcn.cpu().numpy(), ref_hc.numpy(), rtol=0, atol=2e-5)
+
+
+def test_unnormalised_gradient_is_additive_over_episodes():
+    """Size-independent property at a realistic shape (3s5z dims, T=60): the critic and actor gradient SUMS (and loss
+    sums / mask counts in the tail) of a batch equal the sums over its two halves -- what makes the one-all-reduce
+    data-parallel split exact."""
+    from offpolicy_amd import _lib
+    from offpolicy_amd.config import default_args
+    from offpolicy_amd.utils.synth import DIMS, EnvDims, synth_episodes
+    d0 = DIMS["3s5z"]
+    dims = EnvDims("3s5z_t60", d0.n_agents, d0.act_dim, d0.obs_dim, d0.state_dim, 60)
+    B = 16
+    _, buf, policy, trainer = build(None, dims=dims, args=default_args(), td3=True, cap=B)
+    rng = np.random.RandomState(5)
+    ep = synth_episodes(rng, B, dims, avail="bernoulli", runner_padding=True)
+    buf.insert(B, *[{"policy_0": ep[k]} for k in EP_KEYS])
+    T, N, A = dims.episode_length, dims.n_agents, dims.act_dim
+    torch.manual_seed(7)
+    u_t = torch.rand(T + 1, N, B, A)
+    u_a = torch.rand(T, N, B, A)
+
+    def grads(inds):
+        s = buf.policy_buffers["policy_0"].sample_inds(np.asarray(inds))
+        dev = [trainer._to_device_layout(x, ax) for x, ax in zip(s, (True, False, True, True, True, False, True))]
+        obs, share, acts, rew, dones, dones_env, avail = dev
+        b = len(inds)
+        cfg = policy.rddpg_cfg(b, T)
+        ws, (gc, ga, _) = trainer._workspace(policy, cfg)
+        f = _lib.Fields()
+        f.obs, f.share_obs, f.acts, f.rewards = _lib.ptr(obs).value, _lib.ptr(share).value, _lib.ptr(acts).value, _lib.ptr(rew).value
+        f.dones, f.dones_env, f.avail_acts = _lib.ptr(dones).value, _lib.ptr(dones_env).value, _lib.ptr(avail).value
+        ut = u_t[:, :, inds].reshape(T + 1, N * b, A).contiguous().cuda()
+        ua = u_a[:, :, inds].reshape(T, N * b, A).contiguous().cuda()
+        st = _lib.current_stream()
+        _lib.check(_lib.lib.ope_rddpg_critic_loss_and_grad(C.byref(cfg), C.byref(f), _lib.ptr(policy.target_actor._flat), _lib.ptr(policy.critic._flat),
+                                                           _lib.ptr(policy.target_critic._flat), _lib.ptr(ut), None, _lib.ptr(ws), ws.numel(),
+                                                           _lib.ptr(gc), None, st), "critic")
+        _lib.check(_lib.lib.ope_rddpg_actor_loss_and_grad(C.byref(cfg), C.byref(f), _lib.ptr(policy.actor._flat), _lib.ptr(policy.critic._flat),
+                                                          _lib.ptr(ua), _lib.ptr(ws), ws.numel(), _lib.ptr(ga), st), "actor")
+        torch.cuda.synchronize()
+        return gc.double().cpu().numpy().copy(), ga.double().cpu().numpy().copy()
+
+    # perturb the critic away from its (targets == live) initial state so the TD errors are not degenerate
+    policy.critic._flat.add_(0.01 * torch.randn_like(policy.critic._flat))
+    full_c, full_a = grads(list(range(B)))
+    h1c, h1a = grads(list(range(B // 2)))
+    h2c, h2a = grads(list(range(B // 2, B)))
+    for full, parts in ((full_c, h1c + h2c), (full_a, h1a + h2a)):
+        assert np.isfinite(full).all() and np.abs(full).max() > 0
+        np.testing.assert_allclose(full, parts, rtol=0, atol=2e-4 * np.abs(full).max())

@@ -1,0 +1,79 @@
+"""Pin oracle/rmaddpg_oracle.py against outputs of the REAL reference (tests/golden/rmaddpg_*.npz, rmatd3_*.npz)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, sub
+from golden_util import EP_KEYS
+from oracle import rmaddpg_oracle as RO
+from oracle.qmix_oracle import HP
+
+CASES = ["rmaddpg_tiny", "rmatd3_tiny", "rmaddpg_odd_huber_per", "rmatd3_odd_per", "rmaddpg_3m"]
+
+
+def rddpg_oracle_from(g):
+    hp = HP(gamma=float(g["hp_gamma"]), lr=float(g["hp_lr"]), opti_eps=float(g["hp_eps"]), use_huber_loss=bool(g["hp_huber"]),
+            huber_delta=float(g["hp_delta"]), use_per=bool(g["hp_per"]), per_nu=float(g["hp_nu"]), per_eps=float(g["hp_per_eps"]),
+            tau=float(g["hp_tau"]), max_grad_norm=float(g["hp_maxnorm"]))
+    return RO.RMaddpgOracle(sub(g, "actor/"), sub(g, "critic/"), sub(g, "actor_tgt/"), sub(g, "critic_tgt/"), int(g["dims"][0]), hp,
+                            td3=bool(g["td3"]))
+
+
+def rnoise_for(g, step, update_actor=True):
+    """The uniform draws the reference consumed at `step` (torch.manual_seed(1000 + step)): target noise [T+1, N*B, A]
+    first (MATD3 only), then actor noise [T, N*B, A] when the actor is updated."""
+    n, a, _, _, T = [int(x) for x in g["dims"]]
+    B = len(g["inds"])
+    torch.manual_seed(1000 + step)
+    u_t = torch.FloatTensor(T + 1, n * B, a).uniform_() if bool(g["td3"]) else None
+    u_a = torch.FloatTensor(T, n * B, a).uniform_() if update_actor else None
+    return u_t, u_a
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_train_steps_match_reference(name):
+    g = load_golden(name)
+    orc = rddpg_oracle_from(g)
+    batch = tuple(g["batch/" + k] for k in EP_KEYS)
+    w = g["per_weights"] if "per_weights" in g else None
+    for s in range(len(g["critic_loss"])):
+        upd = bool(g["update_actor"][s])
+        u_t, u_a = rnoise_for(g, s, upd)
+        out = orc.train_step(batch, u_t, u_a, weights=w)
+        assert out["update_actor"] == upd
+        np.testing.assert_allclose(out["critic_loss"], g["critic_loss"][s], rtol=3e-5)
+        np.testing.assert_allclose(out["critic_grad_norm"], g["critic_grad_norm"][s], rtol=5e-5)
+        if upd:
+            np.testing.assert_allclose(out["actor_loss"], g["actor_loss"][s], rtol=1e-4, atol=1e-6)
+            np.testing.assert_allclose(out["actor_grad_norm"], g["actor_grad_norm"][s], rtol=2e-4)
+        if w is not None:
+            np.testing.assert_allclose(out["priorities"], g["priorities"][s], rtol=3e-5)
+    for grp, dst in (("final_actor/", orc.actor), ("final_critic/", orc.critic), ("final_actor_tgt/", orc.actor_tgt),
+                     ("final_critic_tgt/", orc.critic_tgt)):
+        for k, ref in sub(g, grp).items():
+            np.testing.assert_allclose(dst[k].numpy(), ref, rtol=0, atol=2e-5, err_msg=grp + k)
+
+
+@pytest.mark.parametrize("name", ["rmaddpg_tiny", "rmatd3_tiny"])
+def test_policy_construction_reproduces_reference_rng_stream(name):
+    """actor, critic (K registered heads), target actor, target critic drawn in the reference's order."""
+    from offpolicy_amd.config import default_args
+    from offpolicy_amd.algorithms.r_maddpg.algorithm.r_actor_critic import draw_ractor_values, draw_rcritic_values
+    g = load_golden(name)
+    n, a, d, s, _ = [int(x) for x in g["dims"]]
+    K = 2 if bool(g["td3"]) else 1
+    args = default_args()
+    torch.manual_seed(1)
+    np.random.seed(1)
+    av = draw_ractor_values(args, d, a)
+    cv = draw_rcritic_values(args, s + n * a, K)
+    for v, (k, ref) in zip(av, sub(g, "actor/").items()):
+        assert np.array_equal(v.numpy(), ref), k
+    crit = sub(g, "critic/")
+    for v, (k, ref) in zip(cv[:20], list(crit.items())[:20]):
+        assert np.array_equal(v.numpy(), ref), k
+    for k in range(K):
+        assert np.array_equal(cv[20][k].numpy(), crit["q_outs.%d.weight" % k].reshape(-1))
+    # the targets take the live weights (rMADDPGPolicy.py:50-51)
+    for k, ref in sub(g, "critic_tgt/").items():
+        assert np.array_equal(ref, crit[k])
