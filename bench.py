@@ -32,13 +32,16 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="3s5z", choices=["3m", "3s5z", "MMM2", "maddpg_spread", "matd3_spread"],
+    ap.add_argument("--workload", default="3s5z", choices=["3m", "3s5z", "MMM2", "maddpg_spread", "matd3_spread", "rmaddpg_3m", "rmatd3_3m", "rmaddpg_3s5z",
+                             "rmatd3_3s5z", "rmaddpg_MMM2", "rmatd3_MMM2"],
                     help="QMIX-RNN on a SMAC map's dimensions (default 3s5z = the headline config), or MLP MADDPG/MATD3 on MPE simple_spread")
     ap.add_argument("--batch", type=int, default=None, help="samples per training step on ONE GPU (weak) / in total (strong); "
                     "default 32 episodes (QMIX) or 256 transitions (MADDPG)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--episodes", type=int, default=256, help="synthetic episodes resident in the replay store")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-noise", action="store_true", help="MADDPG family: draw the gumbel noise on the reference's CPU generator "
+                    "stream (what the parity tests use) instead of on the device")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="budget for each CPU-baseline leg")
     return ap.parse_args()
 
@@ -101,6 +104,8 @@ def main():
     a = parse()
     if a.workload in ("maddpg_spread", "matd3_spread"):
         return main_ddpg(a)
+    if a.workload.startswith("rma"):
+        return main_rddpg(a)
     if a.batch is None:
         a.batch = 32
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -290,6 +295,7 @@ def main_ddpg(a):
     pinfo = policy_info_for(dims)
     policy = (MATD3Policy if td3 else MADDPGPolicy)({"args": args, "device": dev}, pinfo["policy_0"])
     trainer = (MATD3 if td3 else MADDPG)(args, dims.n_agents, {"policy_0": policy}, lambda x: "policy_0", device=dev)
+    trainer.device_noise = not a.host_noise
     cap = 16384
     buf = MlpReplayBuffer(pinfo, {"policy_0": list(range(dims.n_agents))}, cap, True, True, False, device=dev)
     tr = ddpg_transitions(np.random.RandomState(100 + rank), cap, dims)
@@ -339,7 +345,8 @@ def main_ddpg(a):
                "dtype": "f32", "data": "synthetic",
                "config": {"workload": "%s-MLP MPE simple_spread (N=%d A=%d D=%d S=%d), replay filled with %d synthetic transitions, "
                                       "step = sample + critic update + actor update + soft target updates; reference semantics "
-                                      "(frozen critic heads A-4, actor updated every call A-5)" % ("MATD3" if td3 else "MADDPG", N, A, D, S, cap),
+                                      "(frozen critic heads A-4, actor updated every call A-5); gumbel noise drawn on the %s" % (
+                                          "MATD3" if td3 else "MADDPG", N, A, D, S, cap, "host (reference stream)" if a.host_noise else "device"),
                           "batch_per_gpu": local_batch, "global_batch": global_batch, "parallelism": "dp%d" % world,
                           "optimizer_steps_per_sec": round(steps_per_s, 2)},
                "roofline": {"kernel": "episode_copy_kernel<gather> (transition gather)", "bound": "hbm", "achieved": round(algo / (gather_ms * 1e-3) / 1e9, 3),
@@ -348,6 +355,166 @@ def main_ddpg(a):
                             "note": "247 KB per step: launch-latency bound, not bandwidth bound (SURVEY 8(a) a17)"}}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = ddpg_cpu_baseline(dims, batch, td3, a.cpu_seconds)
+            out["config"]["speedup_vs_cpu_port"] = round(value / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+def rddpg_cpu_baseline(dims, batch, td3, seconds):
+    """CPU port (oracle/rmaddpg_oracle.py) of one recurrent MADDPG/MATD3 update. The oracle walks the 2*T per-timestep
+    critic calls like the reference; a full-size MMM2 step takes ~70 s on one thread and ~10 s on 8, so the bounded sample
+    is ONE or a few full-batch steps with 8 and 32 threads (single-thread is skipped to keep the default run short)."""
+    from oracle import rmaddpg_oracle as RO
+    from oracle.qmix_oracle import HP, sample_inds
+    from offpolicy_amd.config import default_args
+    from offpolicy_amd.utils.synth import synth_episodes
+    from offpolicy_amd.algorithms.qmix.algorithm.agent_q_function import AGENT_PARAM_NAMES
+    from offpolicy_amd.algorithms.r_maddpg.algorithm.r_actor_critic import draw_ractor_values, draw_rcritic_values
+    args = default_args()
+    torch.manual_seed(1)
+    N, A, D, S, T = dims.n_agents, dims.act_dim, dims.obs_dim, dims.state_dim, dims.episode_length
+    K = 2 if td3 else 1
+    an = AGENT_PARAM_NAMES[:20] + ["act.action_out.weight", "act.action_out.bias"]
+    av, cv = draw_ractor_values(args, D, A), draw_rcritic_values(args, S + N * A, K)
+    cdict = dict(zip(AGENT_PARAM_NAMES[:20], cv[:20]))
+    for k in range(K):
+        cdict["q_outs.%d.weight" % k], cdict["q_outs.%d.bias" % k] = cv[20][k:k + 1], cv[21][k:k + 1]
+    b = min(batch, int(os.environ.get('OPE_CPU_BASELINE_EPISODES', batch)))
+    n_ep = max(16, b)
+    ep = synth_episodes(np.random.RandomState(0), n_ep, dims, avail="bernoulli")
+    store = {k: (ep[k][:, :, 0] if k == "share_obs" else ep[k]) for k in ("obs", "share_obs", "acts", "rewards", "dones", "dones_env", "avail_acts")}
+    res = {}
+    ncores = os.cpu_count() or 1
+    counts = [t for t in (8, 32) if t <= ncores] or [1]
+    for threads in counts:
+        torch.set_num_threads(threads)
+        orc = RO.RMaddpgOracle(dict(zip(an, av)), cdict, dict(zip(an, av)), cdict, N, HP(use_per=True), td3=td3, actor_update_interval=1)
+        rng = np.random.RandomState(1)
+
+        def step():
+            inds = rng.choice(n_ep, b)
+            u_t = torch.FloatTensor(T + 1, N * b, A).uniform_() if td3 else None
+            orc.train_step(sample_inds(store, inds), u_t, torch.FloatTensor(T, N * b, A).uniform_(), weights=np.ones(b, np.float32))
+        t0 = time.perf_counter()
+        n = 0
+        while True:
+            step()
+            n += 1
+            el = time.perf_counter() - t0
+            if el >= seconds or n >= 200:
+                break
+        res[threads] = (n / el * b / float(batch), n, el)
+    best = max(res, key=lambda k: res[k][0])
+    return {"value": round(res[best][0], 5), "unit": "training steps/sec", "cores": best, "kind": "port",
+            "sample": "critic+actor update on b=%d of %d synthetic %s episodes (T=%d), scaled by b/B to B=%d; ~%.0f s per thread count; "
+                      "full-batch steps/s by threads: %s" % (b, n_ep, dims.name, T, batch, seconds, ", ".join(
+                          "%d: %.5f (%d steps of b, %.1f s)" % (t, res[t][0], res[t][1], res[t][2]) for t in counts))}
+
+
+def main_rddpg(a):
+    """Recurrent MADDPG / MATD3 with prioritized replay on SMAC dimensions (BASELINE.json config 5 = rmatd3_MMM2, B=128):
+    step = PrioritizedRecReplayBuffer.sample(B, beta) + shared_train_policy_on_batch (critic update + actor update every
+    `actor_update_interval`-th step) + update_priorities + soft target updates (runner/rnn/base_runner.py:226-258)."""
+    import ctypes as C
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == a.gpus
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.distributed.init_process_group("nccl", device_id=dev)
+    from offpolicy_amd import _lib
+    from offpolicy_amd.config import default_args
+    from offpolicy_amd.utils.synth import DIMS, policy_info_for
+    from offpolicy_amd.utils.rec_buffer import PrioritizedRecReplayBuffer
+    from offpolicy_amd.algorithms.r_maddpg.algorithm.rMADDPGPolicy import R_MADDPGPolicy
+    from offpolicy_amd.algorithms.r_matd3.algorithm.rMATD3Policy import R_MATD3Policy
+    from offpolicy_amd.algorithms.r_maddpg.r_maddpg import R_MADDPG
+    from offpolicy_amd.algorithms.r_matd3.r_matd3 import R_MATD3
+    algo, mapname = a.workload.split("_", 1)
+    td3 = algo == "rmatd3"
+    dims = DIMS[mapname]
+    batch = a.batch or 128
+    if a.scaling == "weak":
+        local_batch, global_batch = batch, batch * world
+    else:
+        assert batch % world == 0
+        local_batch, global_batch = batch // world, batch
+    args = default_args(use_per=True)
+    torch.manual_seed(1)
+    np.random.seed(1)
+    pinfo = policy_info_for(dims)
+    policy = (R_MATD3Policy if td3 else R_MADDPGPolicy)({"args": args, "device": dev}, pinfo["policy_0"])
+    trainer = (R_MATD3 if td3 else R_MADDPG)(args, dims.n_agents, {"policy_0": policy}, lambda x: "policy_0", device=dev,
+                                            episode_length=dims.episode_length)
+    trainer.device_noise = not a.host_noise
+    buf = PrioritizedRecReplayBuffer(args.per_alpha, pinfo, {"policy_0": list(range(dims.n_agents))}, a.episodes, dims.episode_length,
+                                     True, True, device=dev)
+    fill_buffer(buf, dims, a.episodes, np.random.RandomState(100 + rank))
+    np.random.seed(1000 + rank)
+    torch.manual_seed(1000 + rank)
+    import random
+    random.seed(1000 + rank)
+
+    def one_step(i=None):
+        batch_t = buf.sample(local_batch, beta=0.4, p_id="policy_0")
+        info, prio, idxes = trainer.shared_train_policy_on_batch("policy_0", batch_t)
+        buf.update_priorities(idxes, prio, "policy_0")
+        policy.soft_target_updates()
+        return info
+
+    for _ in range(a.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        info = one_step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tt[0])
+    assert np.isfinite(float(info["critic_loss"]))
+    # gather roofline leg measured on its own (same launch, HIP events on the launch stream)
+    pbuf = buf.policy_buffers["policy_0"]
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+    for e in ev:
+        pbuf.sample_inds(np.random.choice(len(buf), local_batch), timing_events=e)
+    torch.cuda.synchronize()
+    gather_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
+    if rank == 0:
+        N, A, D, S, T = dims.n_agents, dims.act_dim, dims.obs_dim, dims.state_dim, dims.episode_length
+        ep_bytes = int(_lib.lib.ope_episode_bytes(C.byref(pbuf.dims)))
+        algo_bytes = 2.0 * local_batch * ep_bytes
+        achieved = algo_bytes / (gather_ms * 1e-3) / 1e9
+        steps_per_s = a.steps / elapsed
+        value = steps_per_s * (global_batch / float(batch))
+        name = "MATD3" if td3 else "MADDPG"
+        out = {"metric": "training steps/sec (batch=%d) %s-RNN + PER %s" % (batch, name, mapname),
+               "value": round(value, 3), "unit": "training steps/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": round(1e3 * elapsed / a.steps, 4), "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "%s-RNN + prioritized replay, SMAC %s (N=%d A=%d D=%d S=%d T=%d), replay filled with %d synthetic "
+                                      "episodes, step = PER sample + critic update + actor update (every %d) + update_priorities + "
+                                      "soft target updates; gumbel noise drawn on the %s" % (name, mapname, N, A, D, S, T, a.episodes,
+                                                                                               trainer.actor_update_interval, "host (reference stream)" if a.host_noise else "device"),
+                          "batch_per_gpu": local_batch, "global_batch": global_batch, "parallelism": "dp%d" % world,
+                          "optimizer_steps_per_sec": round(steps_per_s, 3)},
+               "roofline": {"kernel": "episode_copy_kernel<gather> (ope_store_gather)", "bound": "hbm", "achieved": round(achieved, 2),
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                            "algorithmic_bytes_per_launch": int(algo_bytes), "avg_launch_ms": round(gather_ms, 5),
+                            "timing": "HIP events on the launch stream around 20 gather launches of the same batch size"}}
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = rddpg_cpu_baseline(dims, batch, td3, a.cpu_seconds)
             out["config"]["speedup_vs_cpu_port"] = round(value / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -38,6 +38,7 @@ class MADDPG(object):
         self.use_same_share_obs = args.use_same_share_obs
         self.actor_update_interval = actor_update_interval
         self.count_updates = bool(count_updates)
+        self.device_noise = False     # True: gumbel noise drawn on the device instead of the reference's CPU generator stream
         self._ws, self._grads = {}, {}
 
     def _workspace(self, policy, cfg):
@@ -102,7 +103,8 @@ class MADDPG(object):
         train_info = {}
         update_actor = self.num_updates[pid] % self.actor_update_interval == 0
         # ---- critic ----
-        u_t = sample_gumbel_uniform((N * B, policy.act_dim)).to(self.device) if policy.target_noise is not None else None
+        draw = (lambda shape: torch.rand(shape, **self.tpdv)) if self.device_noise else (lambda shape: sample_gumbel_uniform(shape).to(self.device))
+        u_t = draw((N * B, policy.act_dim)) if policy.target_noise is not None else None
         w = torch.as_tensor(np.asarray(importance_weights), dtype=torch.float32).to(self.device).contiguous() if self.use_per else None
         prio = torch.empty(B, **self.tpdv) if self.use_per else None
         _lib.check(_lib.lib.ope_ddpg_critic_loss_and_grad(C.byref(cfg), C.byref(mb), _lib.ptr(policy.target_actor._flat),
@@ -116,7 +118,7 @@ class MADDPG(object):
         new_priorities = prio.cpu().numpy() if self.use_per else None
         # ---- actor ----
         if update_actor:
-            u_a = sample_gumbel_uniform((N * B, policy.act_dim)).to(self.device)
+            u_a = draw((N * B, policy.act_dim))
             _lib.check(_lib.lib.ope_ddpg_actor_loss_and_grad(C.byref(cfg), C.byref(mb), _lib.ptr(policy.actor._flat),
                                                              _lib.ptr(policy.critic._flat), _lib.ptr(u_a), _lib.ptr(ws), ws.numel(),
                                                              _lib.ptr(ga), st), "ope_ddpg_actor_loss_and_grad")

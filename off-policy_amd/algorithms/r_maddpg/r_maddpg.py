@@ -41,6 +41,9 @@ class R_MADDPG(object):
         self.actor_update_interval = actor_update_interval
         self.num_updates = {p_id: 0 for p_id in self.policy_ids}
         self.use_same_share_obs = args.use_same_share_obs
+        # False: gumbel noise from torch's CPU generator in the reference's order (bit-comparable runs, ~2x(T*N*B*A) floats
+        # drawn on the host and copied per update). True: same distribution drawn on the device (no host work).
+        self.device_noise = False
         self._ws, self._grads = {}, {}
 
     def _workspace(self, policy, cfg):
@@ -126,7 +129,8 @@ class R_MADDPG(object):
         train_info = {}
         update_actor = self.num_updates[pid] % self.actor_update_interval == 0
         # ---- critic ----
-        u_t = sample_gumbel_uniform((T + 1, N * B, A)).to(self.device) if policy.target_noise is not None else None
+        draw = (lambda shape: torch.rand(shape, **self.tpdv)) if self.device_noise else (lambda shape: sample_gumbel_uniform(shape).to(self.device))
+        u_t = draw((T + 1, N * B, A)) if policy.target_noise is not None else None
         w = torch.as_tensor(np.asarray(importance_weights), dtype=torch.float32).to(self.device).contiguous() if self.use_per else None
         K = policy.num_q
         td_stats = torch.empty(K * 2 * B, **self.tpdv) if self.use_per else None
@@ -147,7 +151,7 @@ class R_MADDPG(object):
         # ---- actor (through the freshly updated critic) ----
         u_a = None
         if update_actor:
-            u_a = sample_gumbel_uniform((T, N * B, A)).to(self.device)
+            u_a = draw((T, N * B, A))
             _lib.check(_lib.lib.ope_rddpg_actor_loss_and_grad(C.byref(cfg), C.byref(f), _lib.ptr(policy.actor._flat),
                                                               _lib.ptr(policy.critic._flat), _lib.ptr(u_a), _lib.ptr(ws), ws.numel(),
                                                               _lib.ptr(ga), st), "ope_rddpg_actor_loss_and_grad")

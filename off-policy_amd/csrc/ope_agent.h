@@ -19,6 +19,7 @@ struct TrunkFwdArgs {
   float* rstd0;        // [R] input-LN 1/std
   float* xhat1;        // [R][64] normalised (pre-affine) LN1 input
   float* rstd1;        // [R]
+  float* mu1;          // [R] mean of relu(fc1) (optional; lets a backward pass rebuild relu(z1) = xhat1/rstd1 + mu1)
   uint64_t* mask1;     // [R] ReLU mask of fc1 (bit f = z1[f] > 0)
   float* xhat2;
   float* rstd2;
@@ -140,7 +141,7 @@ __device__ __forceinline__ void gemm64rt(const float* __restrict__ W, int ld, in
 // Outputs: act = xhat*gamma+beta; if SAVE, acc is overwritten with xhat; rstd; mbits bit (4it+r) = (z > 0).
 template <bool SAVE>
 __device__ __forceinline__ void relu_ln64(f32x4 (&acc)[4], const float* __restrict__ gam, const float* __restrict__ bet,
-                                          int g, f32x4 (&act)[4], float* rstd_out, uint32_t* mbits) {
+                                          int g, f32x4 (&act)[4], float* rstd_out, uint32_t* mbits, float* mu_out = nullptr) {
   uint32_t mb = 0;
   float s = 0.f;
 #pragma unroll
@@ -176,6 +177,7 @@ __device__ __forceinline__ void relu_ln64(f32x4 (&acc)[4], const float* __restri
   }
   *rstd_out = rstd;
   *mbits = mb;
+  if (mu_out) *mu_out = mu;
 }
 
 // Merge the four lanes' 16-bit ReLU masks into one 64-bit row mask (bit f = feature f) and store with rstd.

@@ -130,11 +130,13 @@ __global__ void __launch_bounds__(256) trunk_fwd_kernel(TrunkFwdArgs a) {
   float rs[RT];
 #pragma unroll
   for (int t = 0; t < RT; ++t) {
-    relu_ln64<SAVE>(acc[t], th + a.L.ln1_w, th + a.L.ln1_b, g, act[t], &rs[t], &mbits[t]);
+    float mu1v;
+    relu_ln64<SAVE>(acc[t], th + a.L.ln1_w, th + a.L.ln1_b, g, act[t], &rs[t], &mbits[t], &mu1v);
     if (SAVE && valid[t]) {
 #pragma unroll
       for (int it = 0; it < 4; ++it) *reinterpret_cast<f32x4*>(a.xhat1 + (int64_t)row[t] * OPE_H + 16 * it + 4 * g) = acc[t][it];
       store_mask_rstd(a.mask1, a.rstd1, row[t], g, mbits[t], rs[t]);
+      if (a.mu1 && g == 0) a.mu1[row[t]] = mu1v;
     }
 #pragma unroll
     for (int it = 0; it < 4; ++it) acc[t][it] = *reinterpret_cast<const f32x4*>(th + a.L.fc2_b + 16 * it + 4 * g);

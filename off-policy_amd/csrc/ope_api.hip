@@ -192,7 +192,7 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
   TrunkFwdArgs tf;
   tf.x = batch->obs; tf.R = (int)p.R; tf.D = p.D; tf.theta = theta; tf.L = p.AL;
   tf.gi = p.mlp ? nullptr : W + p.gi; tf.a2_out = p.mlp ? W + p.h : nullptr;
-  tf.mu0 = W + p.mu0; tf.rstd0 = W + p.rstd0;
+  tf.mu0 = W + p.mu0; tf.rstd0 = W + p.rstd0; tf.mu1 = nullptr;
   tf.xhat1 = W + p.xhat1; tf.rstd1 = W + p.rstd1; tf.mask1 = (uint64_t*)(W + p.mask1);
   tf.xhat2 = W + p.xhat2; tf.rstd2 = W + p.rstd2; tf.mask2 = (uint64_t*)(W + p.mask2);
   if ((rc = launch_trunk_fwd(tf, true, st))) return rc;

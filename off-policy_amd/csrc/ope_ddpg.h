@@ -26,6 +26,20 @@ struct InGradArgs {
   float* dx;                                 // [R][D]
 };
 
+// Fused "critic input gradient restricted to the updating agent's action block" + straight-through gumbel adjoint.
+struct ActGradArgs {
+  int R, B, N, A, A4, S, Din;
+  const float* dz1;                          // [R][64] adjoint of the fc1 pre-activation (zero where ReLU is off)
+  const float* xhat1; const float* rstd1; const float* mu1;   // LN1 saves: relu(z1) = xhat1/rstd1 + mu1
+  const float* mu0; const float* rstd0;      // input-LN saves
+  const float* act;                          // [R][A] the actor's (straight-through) action = the row's own action block
+  const float* y;                            // [R][A] soft sample
+  const float* theta; int fc1_w, fc1_b, fn_w, fn_b;
+  float* cvec;                               // [128] scratch: c_i = sum_k gamma_k W_ik ; cb_i = b_i + sum_k W_ik beta_k
+  float* dlogits;                            // [R][A4]
+};
+int launch_action_grad(const ActGradArgs& a, hipStream_t st);
+
 // shared with the recurrent family (ope_rddpg.hip)
 int launch_build_cin(const float* cent, const float* acts, const float* repl, int T, int B, int N, int A, int S, int reps, float* out,
                      hipStream_t st);

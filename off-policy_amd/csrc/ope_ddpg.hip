@@ -47,56 +47,63 @@ __global__ void build_cin_kernel(const float* __restrict__ cent, const float* __
 // Rows are (t, agent, b) with t < rows / (N*B) (t = 0 only for the MLP family); the joint action of step t goes to
 // cent_nact[t - t_shift] and steps t < t_shift are dropped (the recurrent trainer discards the first target action,
 // r_maddpg.py:88).
-__global__ void action_kernel(const float* __restrict__ logits, const float* __restrict__ avail, const float* __restrict__ U,
-                              int rows, int B, int A, int N, int mode, int t_shift, float* __restrict__ cent_nact,
-                              float* __restrict__ act_out, float* __restrict__ soft_out) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= rows) return;
-  const int t = r / (N * B);
-  const int rem = r - t * (N * B);
-  const int a = rem / B, b = rem - a * B;
-  float* cn = (cent_nact && t >= t_shift) ? cent_nact + ((int64_t)(t - t_shift) * B + b) * (N * A) + a * A : nullptr;
-  const float* lg = logits + (int64_t)r * A;
-  const float* av = avail ? avail + (int64_t)r * A : nullptr;
-  float mx = -3.0e38f;
-  for (int j = 0; j < A; ++j) {
-    float v = lg[j];
-    if (mode == 1) v += -logf(-logf(U[(int64_t)r * A + j] + 1e-20f) + 1e-20f);
-    if (av && av[j] == 0.f) v = -1e10f;
-    mx = fmaxf(mx, v);
+// Blocks stage `rpb` rows through LDS so that all global traffic is coalesced and the gumbel transform (two logs per
+// element) is evaluated once; one thread then owns one row in LDS.
+__global__ void __launch_bounds__(256) action_kernel(const float* __restrict__ logits, const float* __restrict__ avail,
+                                                      const float* __restrict__ U, int rows, int B, int A, int N, int mode, int t_shift,
+                                                      int rpb, float* __restrict__ cent_nact, float* __restrict__ act_out,
+                                                      float* __restrict__ soft_out) {
+  extern __shared__ float sm[];
+  const int pitch = A | 1;
+  float* val = sm;                      // [rpb][pitch] masked (noisy) logits, overwritten by the output values
+  float* soft = sm + rpb * pitch;       // [rpb][pitch] soft sample (mode 1 with soft_out only)
+  const int r0 = blockIdx.x * rpb;
+  const int nrows = min(rpb, rows - r0);
+  const int64_t base = (int64_t)r0 * A;
+  for (int e = threadIdx.x; e < nrows * A; e += blockDim.x) {
+    const int rr = e / A, j = e - rr * A;
+    float v = logits[base + e];
+    if (mode == 1) v += -logf(-logf(U[base + e] + 1e-20f) + 1e-20f);
+    if (avail && avail[base + e] == 0.f) v = -1e10f;
+    val[rr * pitch + j] = v;
   }
-  float den = 0.f;
-  if (mode == 1) {
-    for (int j = 0; j < A; ++j) {
-      float v = lg[j] + -logf(-logf(U[(int64_t)r * A + j] + 1e-20f) + 1e-20f);
-      if (av && av[j] == 0.f) v = -1e10f;
-      den += expf(v - mx);
-    }
-  }
-  // second pass: values. For mode 1 the one-hot is taken on the softmax output y (onehot_from_logits(y)): y == max(y).
-  float ymax = 0.f;
-  if (mode == 1) {
-    for (int j = 0; j < A; ++j) {
-      float v = lg[j] + -logf(-logf(U[(int64_t)r * A + j] + 1e-20f) + 1e-20f);
-      if (av && av[j] == 0.f) v = -1e10f;
-      ymax = fmaxf(ymax, expf(v - mx) / den);
-    }
-  }
-  for (int j = 0; j < A; ++j) {
-    float v = lg[j];
-    if (mode == 1) v += -logf(-logf(U[(int64_t)r * A + j] + 1e-20f) + 1e-20f);
-    if (av && av[j] == 0.f) v = -1e10f;
-    float out;
+  __syncthreads();
+  if ((int)threadIdx.x < nrows) {
+    float* vr = val + threadIdx.x * pitch;
+    float* sr = soft + threadIdx.x * pitch;
+    float mx = -3.0e38f;
+    for (int j = 0; j < A; ++j) mx = fmaxf(mx, vr[j]);
     if (mode == 0) {
-      out = (v == mx) ? 1.f : 0.f;
+      for (int j = 0; j < A; ++j) vr[j] = (vr[j] == mx) ? 1.f : 0.f;
     } else {
-      const float y = expf(v - mx) / den;
-      const float hard = (y == ymax) ? 1.f : 0.f;
-      out = (hard - y) + y;
-      if (soft_out) soft_out[(int64_t)r * A + j] = y;
+      float den = 0.f;
+      for (int j = 0; j < A; ++j) den += expf(vr[j] - mx);
+      // the one-hot is taken on the softmax output y (onehot_from_logits(y)): y == max(y)
+      float ymax = 0.f;
+      for (int j = 0; j < A; ++j) ymax = fmaxf(ymax, expf(vr[j] - mx) / den);
+      for (int j = 0; j < A; ++j) {
+        const float y = expf(vr[j] - mx) / den;
+        const float hard = (y == ymax) ? 1.f : 0.f;
+        vr[j] = (hard - y) + y;
+        if (soft_out) sr[j] = y;
+      }
     }
-    if (act_out) act_out[(int64_t)r * A + j] = out;
-    if (cn) cn[j] = out;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < nrows * A; e += blockDim.x) {
+    const int rr = e / A, j = e - rr * A;
+    const float out = val[rr * pitch + j];
+    if (act_out) act_out[base + e] = out;
+    if (soft_out) soft_out[base + e] = soft[rr * pitch + j];
+    if (cent_nact) {
+      const int r = r0 + rr;
+      const int t = r / (N * B);
+      if (t >= t_shift) {
+        const int rem = r - t * (N * B);
+        const int a = rem / B, b = rem - a * B;
+        cent_nact[((int64_t)(t - t_shift) * B + b) * (N * A) + a * A + j] = out;
+      }
+    }
   }
 }
 
@@ -241,6 +248,73 @@ __global__ void gumbel_bwd_kernel(const float* __restrict__ dx, int Din, int S, 
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Actor update, critic side, fused: the actor only needs d(loss)/d(action block of "its" agent) of the critic input,
+// so the full input gradient dx [R][Din] is never formed. With dy_k = gamma_k sum_i W_ik dz_i (k over ALL inputs) the
+// input-LayerNorm adjoint needs two row scalars that collapse to 64-long dot products:
+//   m1 = mean_k dy_k      = (1/D) sum_i dz_i c_i ,          c_i = sum_k gamma_k W_ik
+//   m2 = mean_k dy_k xh_k = (1/D) sum_i dz_i (z1_i - cb_i), cb_i = b_i + sum_k W_ik beta_k ,  z1_i = xhat1_i/rstd1 + mu1
+// (z1 is only needed where the ReLU is on; elsewhere dz_i = 0). Then for the A columns k of the agent's action block
+//   dx_k = rstd0 (dy_k - m1 - xh_k m2) ,   dlogit_j = y_j (dx_j - sum_m dx_m y_m)        (util.py:210-213)
+// One thread per row (t, agent copy, b); weight reads are wave-uniform (rows of a wave share the agent copy).
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) fc1_colsum_kernel(ActGradArgs a) {
+  const int i = blockIdx.x, lane = threadIdx.x;
+  float c = 0.f, e = 0.f;
+  for (int k = lane; k < a.Din; k += 64) {
+    const float w = a.theta[a.fc1_w + (int64_t)i * a.Din + k];
+    c = fmaf(w, a.theta[a.fn_w + k], c);
+    e = fmaf(w, a.theta[a.fn_b + k], e);
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    c += __shfl_xor(c, o, 64);
+    e += __shfl_xor(e, o, 64);
+  }
+  if (lane == 0) {
+    a.cvec[i] = c;
+    a.cvec[OPE_H + i] = e + a.theta[a.fc1_b + i];
+  }
+}
+
+__global__ void __launch_bounds__(256) action_grad_kernel(ActGradArgs a) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= a.R) return;
+  const int rep = (r / a.B) % a.N;
+  const float rs1 = a.rstd1[r], m1u = a.mu1[r], rs0 = a.rstd0[r], mu0 = a.mu0[r];
+  const float inv_rs1 = 1.0f / rs1;
+  float dz[OPE_H];
+  float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < OPE_H; i += 4) {
+    const f32x4 d = *reinterpret_cast<const f32x4*>(a.dz1 + (int64_t)r * OPE_H + i);
+    const f32x4 xh = *reinterpret_cast<const f32x4*>(a.xhat1 + (int64_t)r * OPE_H + i);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      dz[i + q] = d[q];
+      m1 = fmaf(d[q], a.cvec[i + q], m1);
+      m2 = fmaf(d[q], fmaf(xh[q], inv_rs1, m1u) - a.cvec[OPE_H + i + q], m2);
+    }
+  }
+  const float invD = 1.0f / (float)a.Din;
+  m1 *= invD;
+  m2 *= invD;
+  const int col0 = a.S + rep * a.A;
+  const float* W = a.theta + a.fc1_w + col0;
+  float* out = a.dlogits + (int64_t)r * a.A4;
+  float dot = 0.f;
+  for (int j = 0; j < a.A; ++j) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < OPE_H; ++i) s = fmaf(W[(int64_t)i * a.Din + j], dz[i], s);
+    const float dy = s * a.theta[a.fn_w + col0 + j];
+    const float xh = (a.act[(int64_t)r * a.A + j] - mu0) * rs0;
+    const float dx = rs0 * (dy - m1 - xh * m2);
+    dot = fmaf(dx, a.y[(int64_t)r * a.A + j], dot);
+    out[j] = dx;
+  }
+  for (int j = 0; j < a.A4; ++j) out[j] = j < a.A ? a.y[(int64_t)r * a.A + j] * (out[j] - dot) : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 static int launch1d(int64_t n) { return ope_cdiv(n, 256); }
 #define OPE_L(call)                                            \
   do {                                                         \
@@ -256,8 +330,16 @@ int launch_build_cin(const float* cent, const float* acts, const float* repl, in
 }
 int launch_action(const float* logits, const float* avail, const float* U, int rows, int B, int A, int N, int mode, int t_shift,
                   float* cent_nact, float* act_out, float* soft_out, hipStream_t st) {
-  OPE_L(hipLaunchKernelGGL(action_kernel, dim3(launch1d(rows)), dim3(256), 0, st, logits, avail, U, rows, B, A, N, mode, t_shift,
-                           cent_nact, act_out, soft_out));
+  const int pitch = A | 1;
+  const int rpb = pitch <= 31 ? 256 : 64;
+  const size_t lds = (size_t)2 * rpb * pitch * sizeof(float);
+  OPE_L(hipLaunchKernelGGL(action_kernel, dim3(ope_cdiv(rows, rpb)), dim3(256), lds, st, logits, avail, U, rows, B, A, N, mode, t_shift,
+                           rpb, cent_nact, act_out, soft_out));
+  return OPE_OK;
+}
+int launch_action_grad(const ActGradArgs& a, hipStream_t st) {
+  OPE_L(hipLaunchKernelGGL(fc1_colsum_kernel, dim3(OPE_H), dim3(64), 0, st, a));
+  OPE_L(hipLaunchKernelGGL(action_grad_kernel, dim3(launch1d(a.R)), dim3(256), 0, st, a));
   return OPE_OK;
 }
 int launch_input_grad(const InGradArgs& ig, hipStream_t st) {
@@ -278,7 +360,7 @@ struct DdpgPlan {
   int raw_size_c, raw_size_a;
   int P1, s1, P2, s2, E, sq;    // raw slab offsets (same recipe for actor and critic, sized by the larger)
   int64_t xin_t, xin, a2n, lgn, cnact, a2t, qt, a2c, qc, dq, da2, dz1, dz2, mu0, rstd0, xhat1, rstd1, mask1, xhat2, rstd2, mask2,
-      thetaT, raw, rsum, loss_part, lnz, lno, xin_a, a2a, lga, ysoft, actout, W1T_unused, dx, dlg, err;
+      thetaT, raw, rsum, loss_part, lnz, lno, xin_a, a2a, lga, ysoft, actout, mu1, cvec, dlg, err;
 };
 
 static int ddpg_cfg_ok(const ope_ddpg_cfg* c) {
@@ -322,7 +404,7 @@ static void ddpg_plan(const ope_ddpg_cfg* c, DdpgPlan* p) {
   p->lnz = W.add("ln_zero", R); p->lno = W.add("ln_one", R);
   p->xin_a = W.add("xin_a", Ra * p->Din); p->a2a = W.add("a2a", Ra * OPE_H); p->lga = W.add("logits", Ra * p->A);
   p->ysoft = W.add("y_soft", Ra * p->A); p->actout = W.add("act_out", Ra * p->A);
-  p->dx = W.add("dx", Ra * p->Din); p->dlg = W.add("dlogits", Ra * p->A4);
+  p->mu1 = W.add("mu1", R); p->cvec = W.add("fc1_colsums", 2 * OPE_H); p->dlg = W.add("dlogits", Ra * p->A4);
   // second set of trunk saves for the actor's own backward (the critic pass of the actor step reuses the first set)
   p->err = W.add("saves2", Ra * (2 * OPE_H + 8));
 }
@@ -336,6 +418,7 @@ static int trunk_mlp(const DdpgPlan& p, float* W, const float* x, int rows, int 
   if (save) {
     if (!alt) {
       tf.mu0 = W + p.mu0; tf.rstd0 = W + p.rstd0; tf.xhat1 = W + p.xhat1; tf.rstd1 = W + p.rstd1; tf.mask1 = (uint64_t*)(W + p.mask1);
+      tf.mu1 = W + p.mu1;
       tf.xhat2 = W + p.xhat2; tf.rstd2 = W + p.rstd2; tf.mask2 = (uint64_t*)(W + p.mask2);
     } else {   // packed alternate save set: [mu0 R][rstd0 R][rstd1 R][rstd2 R][mask1 2R][mask2 2R][xhat1 64R][xhat2 64R]
       const int64_t R = p.Ra;
@@ -491,8 +574,8 @@ extern "C" int ope_ddpg_critic_loss_and_grad(const ope_ddpg_cfg* cfg, const ope_
   // target actor on the next observations -> joint next action
   if ((rc = trunk_mlp(p, W, bt->next_obs, p.Ra, p.D, theta_actor_tgt, p.AL, W + p.a2n, false, nullptr, st))) return rc;
   if ((rc = linear_head(W + p.a2n, p.Ra, p.A, theta_actor_tgt, p.AL, W + p.lgn, st))) return rc;
-  OPE_L(hipLaunchKernelGGL(action_kernel, dim3(launch1d(p.Ra)), dim3(256), 0, st, W + p.lgn, bt->next_avail_acts, target_noise_u, p.Ra,
-                           p.B, p.A, p.N, cfg->target_gumbel ? 1 : 0, 0, W + p.cnact, (float*)nullptr, (float*)nullptr));
+  if ((rc = launch_action(W + p.lgn, bt->next_avail_acts, target_noise_u, p.Ra, p.B, p.A, p.N, cfg->target_gumbel ? 1 : 0, 0, W + p.cnact,
+                          nullptr, nullptr, st))) return rc;
   // critic inputs
   OPE_L(hipLaunchKernelGGL(build_cin_kernel, dim3(launch1d((int64_t)p.B * p.Din)), dim3(256), 0, st, bt->next_share_obs, W + p.cnact,
                            (const float*)nullptr, 1, p.B, 1, p.N * p.A, p.S, 1, W + p.xin_t));
@@ -527,8 +610,8 @@ extern "C" int ope_ddpg_actor_loss_and_grad(const ope_ddpg_cfg* cfg, const ope_m
   // actor forward (saves -> alternate set) and straight-through hard gumbel sample
   if ((rc = trunk_mlp(p, W, bt->obs, p.Ra, p.D, theta_actor, p.AL, W + p.a2a, true, saves2, st))) return rc;
   if ((rc = linear_head(W + p.a2a, p.Ra, p.A, theta_actor, p.AL, W + p.lga, st))) return rc;
-  OPE_L(hipLaunchKernelGGL(action_kernel, dim3(launch1d(p.Ra)), dim3(256), 0, st, W + p.lga, bt->avail_acts, gumbel_noise_u, p.Ra, p.B,
-                           p.A, p.N, 1, 0, (float*)nullptr, W + p.actout, W + p.ysoft));
+  if ((rc = launch_action(W + p.lga, bt->avail_acts, gumbel_noise_u, p.Ra, p.B, p.A, p.N, 1, 0, nullptr, W + p.actout, W + p.ysoft, st)))
+    return rc;
   // N stacked copies of the joint action, copy i carrying the actor's action for agent i
   OPE_L(hipLaunchKernelGGL(build_cin_kernel, dim3(launch1d((int64_t)p.Ra * p.Din)), dim3(256), 0, st, bt->share_obs, bt->acts,
                            W + p.actout, 1, p.B, p.N, p.A, p.S, p.N, W + p.xin_a));
@@ -539,12 +622,12 @@ extern "C" int ope_ddpg_actor_loss_and_grad(const ope_ddpg_cfg* cfg, const ope_m
                            W + p.dq, W + p.loss_part));
   // critic backward down to its input, then through the gumbel-softmax into the actor logits
   if ((rc = mlp_backward(p, W, W + p.xin_a, p.Ra, p.Din, p.K, p.K, W + p.dq, theta_critic, p.CL, nullptr, p.ns_a, 0, nullptr, st))) return rc;
-  InGradArgs ig;
-  ig.R = p.Ra; ig.D = p.Din; ig.dz1 = W + p.dz1; ig.fc1_w = theta_critic + p.CL.fc1_w; ig.gamma = theta_critic + p.CL.fn_w;
-  ig.x = W + p.xin_a; ig.mu0 = W + p.mu0; ig.rstd0 = W + p.rstd0; ig.dx = W + p.dx;
-  OPE_L(hipLaunchKernelGGL(input_grad_kernel, dim3(ope_cdiv(p.Ra, 4)), dim3(256), 0, st, ig));
-  OPE_L(hipLaunchKernelGGL(gumbel_bwd_kernel, dim3(launch1d(p.Ra)), dim3(256), 0, st, W + p.dx, p.Din, p.S, W + p.ysoft, p.Ra, p.B, p.A,
-                           p.A4, p.N, W + p.dlg));
+  ActGradArgs ag;
+  ag.R = p.Ra; ag.B = p.B; ag.N = p.N; ag.A = p.A; ag.A4 = p.A4; ag.S = p.S; ag.Din = p.Din; ag.dz1 = W + p.dz1;
+  ag.xhat1 = W + p.xhat1; ag.rstd1 = W + p.rstd1; ag.mu1 = W + p.mu1; ag.mu0 = W + p.mu0; ag.rstd0 = W + p.rstd0;
+  ag.act = W + p.actout; ag.y = W + p.ysoft; ag.theta = theta_critic; ag.fc1_w = p.CL.fc1_w; ag.fc1_b = p.CL.fc1_b; ag.fn_w = p.CL.fn_w;
+  ag.fn_b = p.CL.fn_b; ag.cvec = W + p.cvec; ag.dlogits = W + p.dlg;
+  if ((rc = launch_action_grad(ag, st))) return rc;
   // actor backward and gradients
   return mlp_backward(p, W, bt->obs, p.Ra, p.D, p.A, p.A4, W + p.dlg, theta_actor, p.AL, saves2, p.ns_a, ope_cdiv(p.Ra, 16), grad, st);
 }

@@ -243,7 +243,7 @@ static int launch1d(int64_t n) { return ope_cdiv(n, 256); }
 
 // forward saves of one recurrent net over a row set
 struct SaveSet {
-  int64_t mu0, rstd0, xhat1, rstd1, mask1, xhat2, rstd2, mask2, gi, h, rg, zg, ng, ghn, xhat_o, rstd_o;
+  int64_t mu0, rstd0, xhat1, rstd1, mu1, mask1, xhat2, rstd2, mask2, gi, h, rg, zg, ng, ghn, xhat_o, rstd_o;
 };
 #define OPE_ADD_SET(W, s, pre, R)                                                                                          \
   do {                                                                                                                     \
@@ -252,7 +252,7 @@ struct SaveSet {
     s.rstd2 = W.add(pre "rstd2", R); s.mask2 = W.add(pre "mask2", 2 * (R)); s.gi = W.add(pre "gi", (R) * 3 * OPE_H);       \
     s.h = W.add(pre "h", (R) * OPE_H); s.rg = W.add(pre "rg", (R) * OPE_H); s.zg = W.add(pre "zg", (R) * OPE_H);           \
     s.ng = W.add(pre "ng", (R) * OPE_H); s.ghn = W.add(pre "ghn", (R) * OPE_H); s.xhat_o = W.add(pre "xhat_o", (R) * OPE_H); \
-    s.rstd_o = W.add(pre "rstd_o", R);                                                                                     \
+    s.rstd_o = W.add(pre "rstd_o", R); s.mu1 = W.add(pre "mu1", R);                                                        \
   } while (0)
 
 struct RPlan {
@@ -264,7 +264,7 @@ struct RPlan {
   Workspace ws;
   SaveSet SA, SC;               // actor saves (Ra rows) / critic saves (max(TB, Ra) rows)
   int64_t gi_t, h_t, lg_t, cnact, xin, xin_n, gi_n, h_n, nq, q, dq, err_abs, loss_part, lnz, lno, thetaT, raw, rsum,
-      dh_out, dgi, dghn, dz1, dz2, lga, ysoft, actout, xin_a, h_b, dx, dlg, c_gi, c_h;
+      dh_out, dgi, dghn, dz1, dz2, lga, ysoft, actout, xin_a, h_b, cvec, dlg, c_gi, c_h;
 };
 
 static int rddpg_cfg_ok(const ope_rddpg_cfg* c) {
@@ -322,11 +322,12 @@ static void rddpg_plan(const ope_rddpg_cfg* c, RPlan* p) {
   // actor update
   p->lga = W.add("logits", Ra * p->A); p->ysoft = W.add("y_soft", Ra * p->A); p->actout = W.add("act_out", Ra * p->A);
   p->xin_a = W.add("xin_a", Ra * p->Din); p->h_b = W.add("h_branch", Ra * OPE_H);
-  p->dx = W.add("dx", Ra * p->Din); p->dlg = W.add("dlogits", Ra * p->A4);
+  p->cvec = W.add("fc1_colsums", 2 * OPE_H); p->dlg = W.add("dlogits", Ra * p->A4);
 }
 
 static void set_trunk_saves(TrunkFwdArgs& tf, float* W, const SaveSet& s) {
   tf.mu0 = W + s.mu0; tf.rstd0 = W + s.rstd0; tf.xhat1 = W + s.xhat1; tf.rstd1 = W + s.rstd1; tf.mask1 = (uint64_t*)(W + s.mask1);
+  tf.mu1 = W + s.mu1;
   tf.xhat2 = W + s.xhat2; tf.rstd2 = W + s.rstd2; tf.mask2 = (uint64_t*)(W + s.mask2);
 }
 
@@ -604,11 +605,12 @@ extern "C" int ope_rddpg_actor_loss_and_grad(const ope_rddpg_cfg* cfg, const ope
   tb.xhat2 = W + p.SC.xhat2; tb.rstd2 = W + p.SC.rstd2; tb.mask2 = (const uint64_t*)(W + p.SC.mask2);
   tb.dz1 = W + p.dz1; tb.dz2 = W + p.dz2;
   if ((rc = launch_trunk_bwd(tb, st))) return rc;
-  InGradArgs ig;
-  ig.R = Ra; ig.D = p.Din; ig.dz1 = W + p.dz1; ig.fc1_w = theta_critic + p.CL.fc1_w; ig.gamma = theta_critic + p.CL.fn_w;
-  ig.x = W + p.xin_a; ig.mu0 = W + p.SC.mu0; ig.rstd0 = W + p.SC.rstd0; ig.dx = W + p.dx;
-  if ((rc = launch_input_grad(ig, st))) return rc;
-  if ((rc = launch_gumbel_bwd(W + p.dx, p.Din, p.S, W + p.ysoft, Ra, p.B, p.A, p.A4, p.N, W + p.dlg, st))) return rc;
+  ActGradArgs ag;
+  ag.R = Ra; ag.B = p.B; ag.N = p.N; ag.A = p.A; ag.A4 = p.A4; ag.S = p.S; ag.Din = p.Din; ag.dz1 = W + p.dz1;
+  ag.xhat1 = W + p.SC.xhat1; ag.rstd1 = W + p.SC.rstd1; ag.mu1 = W + p.SC.mu1; ag.mu0 = W + p.SC.mu0; ag.rstd0 = W + p.SC.rstd0;
+  ag.act = W + p.actout; ag.y = W + p.ysoft; ag.theta = theta_critic; ag.fc1_w = p.CL.fc1_w; ag.fc1_b = p.CL.fc1_b; ag.fn_w = p.CL.fn_w;
+  ag.fn_b = p.CL.fn_b; ag.cvec = W + p.cvec; ag.dlogits = W + p.dlg;
+  if ((rc = launch_action_grad(ag, st))) return rc;
   // actor BPTT and gradients
   return rnn_backward(p, W, p.SA, bt->obs, p.NB, p.T, p.D, p.A, p.A4, W + p.dlg, theta_actor, p.AL, p.ns_a, ope_cdiv(Ra, 16), grad, st);
 }

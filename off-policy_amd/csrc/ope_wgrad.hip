@@ -235,6 +235,24 @@ int launch_split_reduce(const SplitRed& a, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------------------
 __global__ void finalize_kernel(FinTable ft, const float* __restrict__ rsum, const float* __restrict__ theta,
                                 const float* __restrict__ loss_part, int n_loss_tiles, float* __restrict__ grad) {
+  if (blockIdx.x == gridDim.x - 1) {
+    // extra block: [loss_sum, mask_count, qtot_sum, 0] = fixed-order strided sums over the per-tile partials, then a tree
+    __shared__ float red[256][3];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int q = threadIdx.x; q < n_loss_tiles; q += 256) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(loss_part + (int64_t)q * 4);
+      a0 += v[0]; a1 += v[1]; a2 += v[2];
+    }
+    red[threadIdx.x][0] = a0; red[threadIdx.x][1] = a1; red[threadIdx.x][2] = a2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o)
+        for (int c = 0; c < 3; ++c) red[threadIdx.x][c] += red[threadIdx.x + o][c];
+      __syncthreads();
+    }
+    if (threadIdx.x < 4) grad[ft.total - OPE_GRAD_TAIL + threadIdx.x] = threadIdx.x < 3 ? red[0][threadIdx.x] : 0.f;
+    return;
+  }
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= ft.total) return;
   int s = 0;
@@ -268,15 +286,8 @@ __global__ void finalize_kernel(FinTable ft, const float* __restrict__ rsum, con
         out = acc;
         break;
       }
-      case FIN_TAIL: {
-        if (local < 3) {           // [loss_sum, mask_count, qtot_sum]: fixed-order sum over the per-tile partials
-          float acc = 0.f;
-#pragma unroll 16
-          for (int q = 0; q < n_loss_tiles; ++q) acc += loss_part[q * 4 + local];
-          out = acc;
-        }
-        break;
-      }
+      case FIN_TAIL:
+        return;                    // written by the extra block
       default:
         out = 0.f;
     }
@@ -315,7 +326,7 @@ int launch_transpose4(const Transp4& a, hipStream_t st) {
 
 int launch_finalize(const FinTable& ft, const float* rsum, const float* theta, const float* loss_part, int n_loss_tiles,
                     float* grad, hipStream_t st) {
-  hipLaunchKernelGGL(finalize_kernel, dim3(ope_cdiv(ft.total, 256)), dim3(256), 0, st, ft, rsum, theta, loss_part,
+  hipLaunchKernelGGL(finalize_kernel, dim3(ope_cdiv(ft.total, 256) + 1), dim3(256), 0, st, ft, rsum, theta, loss_part,
                      n_loss_tiles, grad);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   return OPE_OK;
