@@ -71,6 +71,16 @@ typedef struct ope_fields {
  *   time the row-stacked `[T(+1), N*B, dim]` tensor QMix.train_policy_on_batch builds with torch.cat
  *   (qmix.py:108-109). Bit-exact copy; indices may repeat.
  * ---------------------------------------------------------------------------------------------- */
+/* Reward normalisation (use_reward_normalization): statistics over the FILLED part of the reward ring
+ *   episodes  (rec_buffer.py:209-222): nanmean / nanstd over steps whose previous step did not end the episode
+ *             (dones_env[t-1] != 1; step 0 always counts), all agents;  pass the store's dones_env ring
+ *   transitions (mlp_buffer.py:229-231): plain mean / std over rewards[:filled];  pass dones_env = NULL (T = 1)
+ * stats_out (device float[4]) = {mean, population std, count, 0}; accumulation in double, fixed order.
+ * ope_reward_normalize applies (r - mean) / std in place to a gathered reward block (rec_buffer.py:221-222). */
+int64_t ope_reward_stats_scratch_bytes(void);
+int ope_store_reward_stats(const ope_dims* dims, int32_t filled, const float* rewards, const float* dones_env, void* scratch,
+                           float* stats_out, void* stream);
+int ope_reward_normalize(float* rewards, int64_t n, const float* stats, void* stream);
 int ope_store_insert(const ope_dims* dims, int32_t capacity, const ope_fields* store, const ope_fields* staged,
                      const int64_t* slots, int32_t n_insert, void* stream);
 int ope_store_gather(const ope_dims* dims, int32_t capacity, const ope_fields* store, const int64_t* inds,

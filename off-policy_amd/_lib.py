@@ -73,6 +73,9 @@ def _load():
         "ope_episode_bytes": (i64, [C.POINTER(Dims)]),
         "ope_store_insert": (C.c_int, [C.POINTER(Dims), i32, C.POINTER(Fields), C.POINTER(Fields), p, i32, p]),
         "ope_store_gather": (C.c_int, [C.POINTER(Dims), i32, C.POINTER(Fields), p, i32, C.POINTER(Fields), p]),
+        "ope_reward_stats_scratch_bytes": (i64, []),
+        "ope_store_reward_stats": (C.c_int, [C.POINTER(Dims), i32, p, p, p, p, p]),
+        "ope_reward_normalize": (C.c_int, [p, i64, p, p]),
         "ope_qmix_param_layout": (i64, [C.POINTER(QmixCfg), C.POINTER(i64), C.POINTER(i64)]),
         "ope_qmix_workspace_bytes": (i64, [C.POINTER(QmixCfg)]),
         "ope_qmix_workspace_init": (C.c_int, [C.POINTER(QmixCfg), p, i64, p]),

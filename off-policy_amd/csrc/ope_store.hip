@@ -150,7 +150,80 @@ int build_args(const ope_dims* d, const ope_fields* src, const ope_fields* dst, 
   return OPE_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Reward normalisation statistics (rec_buffer.py:209-222, mlp_buffer.py:229-231). Two launches, fixed summation order:
+// kStatBlocks blocks accumulate (count, sum, sum of squares) in double over strided slices of the reward ring, one
+// block folds the partials and writes {mean, population std, count}.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kStatBlocks = 512;
+
+__global__ void __launch_bounds__(256) reward_stats_partial_kernel(const float* __restrict__ rewards, const float* __restrict__ dones_env,
+                                                                   int64_t n, int T, int N, double* __restrict__ part) {
+  __shared__ double red[256][3];
+  double c = 0.0, s = 0.0, q = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    bool ok = true;
+    if (dones_env) {   // step t of episode e counts unless the PREVIOUS step ended the episode
+      const int64_t et = i / N;
+      const int t = (int)(et % T);
+      ok = (t == 0) || (dones_env[et - 1] != 1.0f);
+    }
+    if (ok) {
+      const double r = (double)rewards[i];
+      c += 1.0; s += r; q += r * r;
+    }
+  }
+  red[threadIdx.x][0] = c; red[threadIdx.x][1] = s; red[threadIdx.x][2] = q;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o)
+      for (int k = 0; k < 3; ++k) red[threadIdx.x][k] += red[threadIdx.x + o][k];
+    __syncthreads();
+  }
+  if (threadIdx.x < 3) part[blockIdx.x * 3 + threadIdx.x] = red[0][threadIdx.x];
+}
+
+__global__ void __launch_bounds__(64) reward_stats_final_kernel(const double* __restrict__ part, int nblocks, float* __restrict__ out) {
+  if (threadIdx.x != 0) return;
+  double c = 0.0, s = 0.0, q = 0.0;
+  for (int b = 0; b < nblocks; ++b) { c += part[b * 3]; s += part[b * 3 + 1]; q += part[b * 3 + 2]; }
+  const double mean = s / c;
+  double var = q / c - mean * mean;
+  if (var < 0.0) var = 0.0;
+  out[0] = (float)mean; out[1] = (float)sqrt(var); out[2] = (float)c; out[3] = 0.f;
+}
+
+__global__ void reward_normalize_kernel(float* __restrict__ r, int64_t n, const float* __restrict__ stats) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) r[i] = (r[i] - stats[0]) / stats[1];
+}
+
 }  // namespace
+
+extern "C" int64_t ope_reward_stats_scratch_bytes(void) { return (int64_t)kStatBlocks * 3 * sizeof(double); }
+
+extern "C" int ope_store_reward_stats(const ope_dims* dims, int32_t filled, const float* rewards, const float* dones_env,
+                                      void* scratch, float* stats_out, void* stream) {
+  (void)hipGetLastError();
+  if (!dims || filled < 1 || !rewards || !scratch || !stats_out || dims->episode_length < 1 || dims->n_agents < 1) return OPE_EINVAL;
+  const int64_t n = (int64_t)filled * dims->episode_length * dims->n_agents;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > kStatBlocks) blocks = kStatBlocks;
+  hipLaunchKernelGGL(reward_stats_partial_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rewards, dones_env, n,
+                     dims->episode_length, dims->n_agents, (double*)scratch);
+  OPE_CHECK_LAUNCH();
+  hipLaunchKernelGGL(reward_stats_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const double*)scratch, blocks, stats_out);
+  OPE_CHECK_LAUNCH();
+  return OPE_OK;
+}
+
+extern "C" int ope_reward_normalize(float* rewards, int64_t n, const float* stats, void* stream) {
+  (void)hipGetLastError();
+  if (!rewards || n < 1 || !stats) return OPE_EINVAL;
+  hipLaunchKernelGGL(reward_normalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rewards, n, stats);
+  OPE_CHECK_LAUNCH();
+  return OPE_OK;
+}
 
 extern "C" int64_t ope_episode_bytes(const ope_dims* d) {
   if (!d) return OPE_EINVAL;

@@ -23,10 +23,9 @@ from .segment_tree import SumSegmentTree, MinSegmentTree
 class MlpPolicyBuffer(object):
     def __init__(self, buffer_size, num_agents, obs_space, share_obs_space, act_space, use_same_share_obs, use_avail_acts,
                  use_reward_normalization=False, device=None):
-        if use_reward_normalization:
-            raise NotImplementedError("reward normalisation (mlp_buffer.py:229-233) is a SURVEY section 8(f) 'next' row")
+        # transitions are one-step episodes of the device store; reward normalisation = plain mean/std (mlp_buffer.py:229-233)
         self._ep = RecPolicyBuffer(buffer_size, 1, num_agents, obs_space, share_obs_space, act_space, use_same_share_obs,
-                                   use_avail_acts, False, device=device)
+                                   use_avail_acts, use_reward_normalization, device=device, _reward_mask=False)
         self.buffer_size, self.num_agents = int(buffer_size), int(num_agents)
         self.use_same_share_obs, self.use_avail_acts = use_same_share_obs, use_avail_acts
         self.use_reward_normalization = use_reward_normalization

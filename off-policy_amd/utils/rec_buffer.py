@@ -36,7 +36,7 @@ def _shape_of(space):
 
 class RecPolicyBuffer(object):
     def __init__(self, buffer_size, episode_length, num_agents, obs_space, share_obs_space, act_space,
-                 use_same_share_obs, use_avail_acts, use_reward_normalization=False, device=None):
+                 use_same_share_obs, use_avail_acts, use_reward_normalization=False, device=None, _reward_mask=True):
         self.buffer_size = int(buffer_size)
         self.episode_length = int(episode_length)
         self.num_agents = int(num_agents)
@@ -45,9 +45,9 @@ class RecPolicyBuffer(object):
         self.use_reward_normalization = use_reward_normalization
         if not use_same_share_obs:
             raise NotImplementedError("per-agent centralized observations are not on the accelerated path yet")
-        if use_reward_normalization:
-            raise NotImplementedError("reward normalisation (rec_buffer.py:209-223) is a SURVEY section 8(f) 'next' row")
         self.device = torch.device(device if device is not None else "cuda:0")
+        self._reward_mask = bool(_reward_mask)      # episodes: skip steps after the episode end; transitions: plain mean/std
+        self._stats_dirty = True
         self._ring = RingIndex(self.buffer_size)
         obs_dim = _shape_of(obs_space)[0]
         share_dim = _shape_of(share_obs_space)[0]
@@ -63,6 +63,20 @@ class RecPolicyBuffer(object):
         self.rewards = torch.zeros((cap, T, N, 1), **z)
         self.dones = torch.ones((cap, T, N, 1), **z)
         self.dones_env = torch.ones((cap, T, 1), **z)
+        if use_reward_normalization:
+            self._stats = torch.zeros(4, **z)
+            self._stats_scratch = torch.empty(int(_lib.lib.ope_reward_stats_scratch_bytes()), dtype=torch.uint8, device=self.device)
+
+    def reward_stats(self):
+        """Device tensor [mean, std, count, 0] of the rewards currently stored (rec_buffer.py:209-220); recomputed after
+        every insert, on the device, without a host round trip."""
+        if self._stats_dirty:
+            _lib.check(_lib.lib.ope_store_reward_stats(C.byref(self.dims), self.filled_i, _lib.ptr(self.rewards),
+                                                       _lib.ptr(self.dones_env) if self._reward_mask else None,
+                                                       _lib.ptr(self._stats_scratch), _lib.ptr(self._stats), _lib.current_stream()),
+                       "ope_store_reward_stats")
+            self._stats_dirty = False
+        return self._stats
 
     # reference attribute names
     @property
@@ -108,6 +122,7 @@ class RecPolicyBuffer(object):
         _lib.check(_lib.lib.ope_store_insert(C.byref(self.dims), self.buffer_size, C.byref(df), C.byref(sf),
                                              _lib.ptr(slots), n, _lib.current_stream()), "ope_store_insert")
         self._keepalive = (staged, slots)   # until the stream has consumed them
+        self._stats_dirty = True
         return idx_range
 
     def sample_inds(self, sample_inds, timing_events=None):
@@ -131,6 +146,9 @@ class RecPolicyBuffer(object):
                                              C.byref(of), _lib.current_stream()), "ope_store_gather")
         if timing_events is not None:
             timing_events[1].record()
+        if self.use_reward_normalization:
+            _lib.check(_lib.lib.ope_reward_normalize(_lib.ptr(out["rewards"]), out["rewards"].numel(), _lib.ptr(self.reward_stats()),
+                                                     _lib.current_stream()), "ope_reward_normalize")
         cast = lambda x: x.permute(1, 0, 2, 3)      # [N, T(+1), B, dim] view, as the reference's _cast
         return (cast(out["obs"]), out["share_obs"], cast(out["acts"]), cast(out["rewards"]), cast(out["dones"]),
                 out["dones_env"], cast(out["avail_acts"]) if self.use_avail_acts else None)

@@ -106,3 +106,36 @@ def test_prioritized_buffer_flow():
     d = as_policy_dicts(synth_episodes(rng, 2, dims))
     new_idx = buf.insert(2, d["obs"], d["share_obs"], d["acts"], d["rewards"], d["dones"], d["dones_env"], d["avail_acts"])
     np.testing.assert_allclose(buf._it_sums["policy_0"][new_idx], 3.0 ** alpha)          # new episodes get the running max
+
+
+def test_reward_normalisation_matches_reference_buffers():
+    """use_reward_normalization=True: device statistics + in-place normalisation vs the real reference buffers' output
+    (partially filled ring, wrapped ring, transitions)."""
+    from conftest import load_golden
+    from offpolicy_amd.utils.synth import EnvDims, policy_info_for
+    from offpolicy_amd.utils.rec_buffer import RecReplayBuffer
+    from offpolicy_amd.utils.mlp_buffer import MlpReplayBuffer
+    from oracle import reward_norm as RN
+    g = load_golden("reward_norm")
+    n, a, d, s, T = [int(x) for x in g["rec_dims"]]
+    dims = EnvDims("rn", n, a, d, s, T)
+    buf = RecReplayBuffer(policy_info_for(dims), {"policy_0": list(range(n))}, 8, T, True, True, True, device="cuda:0")
+    keys = ("obs", "share_obs", "acts", "rewards", "dones", "dones_env", "avail_acts")
+    for tag in ("a", "b"):
+        r = buf.insert(len(g["rec_%s/idx_range" % tag]), *[{"policy_0": g["rec_%s/ep/%s" % (tag, k)]} for k in keys])
+        assert np.array_equal(r, g["rec_%s/idx_range" % tag])
+        pb = buf.policy_buffers["policy_0"]
+        got = pb.sample_inds(g["rec_%s/inds" % tag])[3].cpu().numpy()
+        np.testing.assert_allclose(got, g["rec_%s/rewards" % tag], rtol=2e-5, atol=2e-6)
+        # statistics against the oracle on the reference's time-major view of our store
+        mean, std = RN.episode_reward_stats(pb.rewards.cpu().numpy().transpose(1, 0, 2, 3), pb.dones_env.cpu().numpy().transpose(1, 0, 2),
+                                            pb.filled_i)
+        st = pb.reward_stats().cpu().numpy()
+        np.testing.assert_allclose(st[:2], [mean, std], rtol=1e-6)
+    n, a, d, s, _ = [int(x) for x in g["mlp_dims"]]
+    tdims = EnvDims("rnt", n, a, d, s, 1)
+    from test_mlp_oracle_golden import T_KEYS
+    mbuf = MlpReplayBuffer(policy_info_for(tdims), {"policy_0": list(range(n))}, 16, True, True, True, device="cuda:0")
+    mbuf.insert(len(g["mlp/idx_range"]), *[{"policy_0": g["mlp/tr/" + k]} for k in T_KEYS])
+    got = mbuf.policy_buffers["policy_0"].sample_inds(g["mlp/inds"])[3].cpu().numpy()
+    np.testing.assert_allclose(got, g["mlp/rewards"], rtol=2e-5, atol=2e-6)
