@@ -46,6 +46,18 @@ def parse():
     return ap.parse_args()
 
 
+def gather_traffic(workload, batch):
+    """HBM bytes per gather launch from the committed PMC passes (profiles/gather_traffic.json: rocprofv3 --pmc FETCH_SIZE and
+    --pmc WRITE_SIZE in separate runs of this same command, corrected as MI355X_MICROARCH.md prescribes); None if that
+    configuration was not measured. PMC collection cannot run inside the timed bench, hence the file."""
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "gather_traffic.json")) as f:
+            e = json.load(f)["entries"].get("%s:%d" % (workload, batch))
+        return int(e["traffic_bytes"]) if e else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def fill_buffer(buf, dims, n_episodes, rng):
     from offpolicy_amd.utils.synth import synth_episodes, as_policy_dicts
     done = 0
@@ -192,9 +204,11 @@ def main():
                        "batch_per_gpu": local_batch, "global_batch": global_batch, "parallelism": "dp%d" % world,
                        "optimizer_steps_per_sec": round(steps_per_s, 3), "final_loss": round(loss, 6)},
             "roofline": {"kernel": "episode_copy_kernel<gather> (ope_store_gather)", "bound": "hbm", "achieved": round(achieved, 2),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": gather_traffic(a.workload, local_batch),
                          "algorithmic_bytes_per_launch": int(algo_bytes), "avg_launch_ms": round(gather_ms, 5),
-                         "timing": "HIP events on the launch stream recorded immediately around each gather launch in the timed region"},
+                         "timing": "HIP events on the launch stream recorded immediately around each gather launch in the timed region",
+                         "traffic_source": "profiles/gather_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)"},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dims, a.batch, a.cpu_seconds)
