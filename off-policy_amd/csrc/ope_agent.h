@@ -33,7 +33,8 @@ struct GruFwdArgs {
   const float* theta0; const float* theta1;
   const float* gi0; const float* gi1;   // [L][NB][192]
   float* h0out; float* h1out;           // [L][NB][64]
-  const float* hinit;                   // [NB][64] or null (zeros); live net only
+  const float* hinit;                   // [NB][64] or null (zeros): initial state of net 0
+  const float* hinit1;                  // same for net 1 (time-chunked scans continue from the previous chunk's last state)
   int whh_off, bhh_off;
   float* rg; float* zg; float* ng; float* ghn;  // [L][NB][64] gate saves (live) or null
 };
@@ -55,6 +56,7 @@ struct HeadFwdArgs {
   float* xhat_o; float* rstd_o;         // [R][64], [R] saved normalised GRU output (live)
   float* q_out;                         // MODE 1: [R][A]
   float* q_all;                         // optional debug output [R][A]
+  int64_t r_begin;                      // first row handled by this launch (time-chunked launches); rows [r_begin, R)
 };
 
 struct HeadBwdArgs {
@@ -78,6 +80,9 @@ struct GruBwdArgs {
   const float* dh_out; // [T][NB][64]
   float* dgi;          // [T][NB][192] = (dr_pre, dz_pre, dn_pre)
   float* dghn;         // [T][NB][64]  = dn_pre * r
+  int t_lo;            // this launch covers t = T-1 .. t_lo (time-chunked BPTT); 0 = to the start
+  const float* dh_in;  // [NB][64] adjoint carried in from the later chunk, or null (zeros)
+  float* dh_carry;     // [NB][64] adjoint w.r.t. h_{t_lo - 1} handed to the earlier chunk, or null
 };
 
 struct TrunkBwdArgs {
@@ -93,6 +98,7 @@ struct TrunkBwdArgs {
 };
 
 int launch_trunk_fwd(const TrunkFwdArgs& a, bool save, hipStream_t st);
+int launch_trunk_fwd2(const TrunkFwdArgs& a, bool save, hipStream_t st);   // workgroup-cooperative form (ope_trunk2.hip)
 int launch_gru_fwd(const GruFwdArgs& a, hipStream_t st);
 int launch_head_fwd(const HeadFwdArgs& a, int mode, hipStream_t st);
 int launch_head_bwd(const HeadBwdArgs& a, hipStream_t st);

@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(256) gru_bwd_kernel(GruBwdArgs a) {
   auto load_chunk = [&](int c) {
 #pragma unroll
     for (int s2 = 0; s2 < C; ++s2) {
-      const int t = max(a.T - 1 - (c * C + s2), 0);
+      const int t = max(a.T - 1 - (c * C + s2), a.t_lo);
       const int64_t o = ((int64_t)t * NB + row) * OPE_H + lane;
       gload_async(preA[s2][0], a.rg + o);
       gload_async(preA[s2][1], a.zg + o);
@@ -144,13 +144,14 @@ __global__ void __launch_bounds__(256) gru_bwd_kernel(GruBwdArgs a) {
   }
   lds_barrier();
 
-  float dh = 0.f;
+  float dh = a.dh_in ? a.dh_in[(int64_t)row * OPE_H + lane] : 0.f;
   float(*myds)[OPE_H] = ds[wave];
-  const int nchunks = (a.T + C - 1) / C;
+  const int nsteps = a.T - a.t_lo;
+  const int nchunks = (nsteps + C - 1) / C;
   for (int c = 0; c < nchunks; ++c) {
     const int buf = c & 1;
     if (loader && c + 1 < nchunks) load_chunk(c + 1);
-    const int ns = min(C, a.T - c * C);
+    const int ns = min(C, nsteps - c * C);
     for (int s2 = 0; s2 < ns; ++s2) {
       const int t = a.T - 1 - (c * C + s2);
       const float r = sav[rl][buf][s2][0][lane], z = sav[rl][buf][s2][1][lane], n = sav[rl][buf][s2][2][lane];
@@ -195,12 +196,19 @@ __global__ void __launch_bounds__(256) gru_bwd_kernel(GruBwdArgs a) {
       for (int w2 = 0; w2 < WPR; ++w2) acc += pp[w2][lane];
       dh = acc;
     }
-    if (loader && c + 1 < nchunks) publish_chunk(c + 1, buf ^ 1);
+    // Hand the next chunk over. Its first use is at the top of the next step, BEFORE that step's barrier, so the
+    // publish needs a barrier of its own (one per 8 steps); without it the readers race the loader whenever its
+    // prefetch lands late, e.g. under memory contention from a kernel running concurrently on another stream.
+    if (c + 1 < nchunks) {
+      if (loader) publish_chunk(c + 1, buf ^ 1);
+      lds_barrier();
+    }
   }
+  if (storer && a.dh_carry) a.dh_carry[(int64_t)row * OPE_H + lane] = dh;
 }
 
 int launch_gru_bwd(const GruBwdArgs& a, hipStream_t st) {
-  if (a.NB < 1 || a.T < 1) return OPE_EINVAL;
+  if (a.NB < 1 || a.T < 1 || a.t_lo < 0 || a.t_lo >= a.T) return OPE_EINVAL;
   if ((int64_t)a.NB * 4 <= 1280) {
     hipLaunchKernelGGL(gru_bwd_kernel<4>, dim3(a.NB), dim3(256), 0, st, a);
   } else {

@@ -196,6 +196,9 @@ static int launch_trunk_vec(const TrunkFwdArgs& a, hipStream_t st) {
 
 int launch_trunk_fwd(const TrunkFwdArgs& a, bool save, hipStream_t st) {
   if (a.R < 1 || a.D < 1) return OPE_EINVAL;
+  // default: the workgroup-cooperative form; OPE_TRUNK2=0 selects the one-wave-per-row-tile form below (A/B runs)
+  static const int v2 = getenv("OPE_TRUNK2") ? atoi(getenv("OPE_TRUNK2")) : 1;
+  if (v2 && a.D <= 512) return launch_trunk_fwd2(a, save, st);
   const int vec = ope_vec_of(a.D);
   if (save) {
     if (vec == 4) return launch_trunk_vec<4, true>(a, st);
@@ -264,7 +267,8 @@ __global__ void __launch_bounds__(256) gru_fwd_kernel(GruFwdArgs a) {
     }
   }
   const float br = th[a.bhh_off + lane], bz = th[a.bhh_off + OPE_H + lane], bn = th[a.bhh_off + 2 * OPE_H + lane];
-  float h = a.hinit ? a.hinit[(int64_t)row * OPE_H + lane] : 0.f;
+  const float* hin = net == 0 ? a.hinit : a.hinit1;
+  float h = hin ? hin[(int64_t)row * OPE_H + lane] : 0.f;
 
   const int64_t stride_t = (int64_t)a.NB * (3 * OPE_H);
   const float* gp = gi + (int64_t)row * (3 * OPE_H) + lane;
@@ -387,7 +391,7 @@ __global__ void __launch_bounds__(256) head_fwd_kernel(HeadFwdArgs a) {
     sm[i] = v;
   }
   __syncthreads();
-  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t r = a.r_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= a.R) return;
   const int NB = a.NB;
   const int t = (int)(r / NB);
@@ -483,7 +487,8 @@ int launch_head_fwd(const HeadFwdArgs& a, int mode, hipStream_t st) {
   const int nets = mode == 0 ? 2 : 1;
   const size_t lds = (size_t)per * nets * sizeof(float);
   if (lds > 64 * 1024) return OPE_EINVAL;
-  const int blocks = ope_cdiv(a.R, 256);
+  if (a.r_begin < 0 || a.r_begin >= a.R) return OPE_EINVAL;
+  const int blocks = ope_cdiv(a.R - a.r_begin, 256);
   if (mode == 0)
     hipLaunchKernelGGL(head_fwd_kernel<0>, dim3(blocks), dim3(256), lds, st, a);
   else

@@ -25,6 +25,33 @@ struct Raw {  // offsets inside one split slab, agent region then mixer region
   int mixer_size;
 };
 
+constexpr int kMaxChunks = 8;
+constexpr int kSideEvents = 16;
+
+// One non-blocking side stream + events per device, created on first use and kept for the life of the process.
+struct SidePool {
+  hipStream_t s;
+  hipEvent_t ev[kSideEvents];
+  hipEvent_t scan_done[kMaxChunks], bptt_done[kMaxChunks];
+};
+SidePool* side_pool() {
+  static SidePool pools[16];
+  static bool made[16] = {false};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  if (!made[dev]) {
+    SidePool& P = pools[dev];
+    if (hipStreamCreateWithFlags(&P.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    for (int i = 0; i < kSideEvents; ++i)
+      if (hipEventCreateWithFlags(&P.ev[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+    for (int i = 0; i < kMaxChunks; ++i)
+      if (hipEventCreateWithFlags(&P.scan_done[i], hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&P.bptt_done[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+    made[dev] = true;
+  }
+  return &pools[dev];
+}
+
 struct Plan {
   int T, N, A, D, S, B, NB, A4, NM, mlp;
   int64_t R, R1, TB;
@@ -33,13 +60,16 @@ struct Plan {
   int64_t P;        // padded parameter count
   Raw raw;
   int ns_agent, ns_mixer;
+  int chunks;                   // time chunks of the two-stream schedule (1 = whole episodes on one stream)
+  int tb[kMaxChunks + 1];       // chunk c covers time steps [tb[c], tb[c+1]) of the T+1 forward steps
+  int ns_chunk[kMaxChunks];     // weight-gradient K-splits of chunk c
   int n_loss_tiles;
   Workspace ws;
   // region offsets
   int64_t mu0, rstd0, xhat1, rstd1, mask1, xhat2, rstd2, mask2, gi, h, rg, zg, ng, ghn, xhat_o, rstd_o, act_idx,
       agent_q, agent_nq, gi_t, h_t, qtot, nqtot, hw1, hw2, hb2, v1, hpre, v2, loss_part, err_abs, dqtot, d_agent_q,
       d_b1, d_v2, d_v1, d_hw1, d_hw2, d_hb2, dh_out, dqoh, dgi, dghn, dz1, dz2, thetaT, mixT, raw_agent, raw_mixer,
-      rsum, q_all, loss_tot, ln_zero, ln_one;
+      rsum, q_all, loss_tot, ln_zero, ln_one, dh_carry;
 };
 
 int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
@@ -72,6 +102,28 @@ void make_plan(const ope_qmix_cfg* c, Plan* p) {
   p->ns_agent = clampi(ope_cdiv(p->R1, 300), 1, 128);
   p->ns_mixer = clampi(ope_cdiv(p->TB, 150), 1, 64);
   p->n_loss_tiles = ope_cdiv(p->TB, 16);
+  // time chunks: boundaries on multiples of 8 steps (the scans prefetch in 8-step groups); short episodes stay whole
+  {
+    // Measured on MI355X (3s5z, B = 32): at this size every kernel is a latency-bound chain with ~1 wave per SIMD, so
+    // cutting the time axis (C > 1) makes each piece barely faster while adding launches and ~7 us cross-stream hand-offs
+    // (0.61 -> 0.73 ms at C = 2, 1.0 ms at C = 4), and kernels run side by side slow each other down about as much as
+    // the overlap saves (BPTT beside a weight-gradient launch: 80 -> 150 us). Default: whole episodes, one stream; the
+    // chunked two-stream schedule stays available for larger batches (OPE_CHUNKS).
+    int C = 1;
+    if (const char* e = getenv("OPE_CHUNKS")) C = atoi(e);
+    C = clampi(C, 1, kMaxChunks);
+    const int L = p->T + 1;
+    if (c->mlp) C = 1;
+    while (C > 1 && L / C < 16) --C;
+    p->chunks = C;
+    for (int q = 0; q <= C; ++q) p->tb[q] = q == C ? L : ((int)((int64_t)q * L / C) / 8) * 8;
+    for (int q = 0; q < C; ++q) {
+      const int hi = p->tb[q + 1] < p->T ? p->tb[q + 1] : p->T;
+      const int64_t rows = (int64_t)(hi - p->tb[q]) * p->NB;
+      (void)rows;
+      p->ns_chunk[q] = p->ns_agent;   // every chunk keeps the full split count: shorter K per wave, same number of waves
+    }
+  }
 
   Workspace& W = p->ws;
   const int64_t R = p->R, R1 = p->R1, TB = p->TB;
@@ -99,7 +151,8 @@ void make_plan(const ope_qmix_cfg* c, Plan* p) {
   p->dz1 = W.add("dz1", R1 * OPE_H); p->dz2 = W.add("dz2", R1 * OPE_H);
   p->thetaT = W.add("thetaT", OPE_H * 3 * OPE_H + OPE_H * OPE_H);
   p->mixT = W.add("mixT", (int64_t)OPE_HYP * p->NM + OPE_HYP * OPE_MIX);
-  p->raw_agent = W.add("raw_agent", (int64_t)p->ns_agent * w.agent_end);
+  p->dh_carry = W.add("dh_carry", (int64_t)p->NB * OPE_H);
+  p->raw_agent = W.add("raw_agent", (int64_t)p->ns_agent * p->chunks * w.agent_end);
   p->raw_mixer = W.add("raw_mixer", (int64_t)p->ns_mixer * (w.mixer_size > 0 ? w.mixer_size : 4));
   p->rsum = W.add("rsum", (int64_t)w.agent_end + w.mixer_size + 4);
   p->q_all = W.add("q_all", R * p->A);
@@ -188,34 +241,70 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
   float* W = (float*)workspace;
   int rc;
 
-  // ---- forward: trunks of both nets ----
-  TrunkFwdArgs tf;
-  tf.x = batch->obs; tf.R = (int)p.R; tf.D = p.D; tf.theta = theta; tf.L = p.AL;
-  tf.gi = p.mlp ? nullptr : W + p.gi; tf.a2_out = p.mlp ? W + p.h : nullptr;
-  tf.mu0 = W + p.mu0; tf.rstd0 = W + p.rstd0; tf.mu1 = nullptr;
-  tf.xhat1 = W + p.xhat1; tf.rstd1 = W + p.rstd1; tf.mask1 = (uint64_t*)(W + p.mask1);
-  tf.xhat2 = W + p.xhat2; tf.rstd2 = W + p.rstd2; tf.mask2 = (uint64_t*)(W + p.mask2);
-  if ((rc = launch_trunk_fwd(tf, true, st))) return rc;
-  TrunkFwdArgs tt = tf;
-  tt.theta = theta_tgt; tt.gi = p.mlp ? nullptr : W + p.gi_t; tt.a2_out = p.mlp ? W + p.h_t : nullptr;
-  if ((rc = launch_trunk_fwd(tt, false, st))) return rc;
+  // Time-chunked, two-stream schedule (recurrent nets). The GRU scans are latency-bound chains that occupy a fraction
+  // of the machine; the trunk / head / weight-gradient kernels are row-parallel over time. The episode is cut into C
+  // time chunks: the scan of chunk c runs on a side stream while the main stream computes the trunks of chunk c+1 (and
+  // the heads of chunk c-1); in the backward pass the BPTT of chunk c overlaps the trunk adjoint and the weight-gradient
+  // K-slices of chunk c+1. Results are identical to the unchunked schedule (same kernels, same per-row arithmetic; the
+  // weight-gradient K-splits are summed in a fixed order either way).
+  const int C = p.chunks;
+  const bool use_side = C > 1;
+  SidePool* sp = nullptr;
+  hipStream_t side = st;
+  if (use_side) {
+    sp = side_pool();
+    if (!sp) return OPE_ELAUNCH;
+    side = sp->s;
+  }
+  int ev_i = 0;
+  auto sync_to = [&](hipStream_t from, hipStream_t to) -> int {   // `to` waits for everything issued so far on `from`
+    if (from == to) return OPE_OK;
+    hipEvent_t e = sp->ev[ev_i++ % kSideEvents];
+    if (hipEventRecord(e, from) != hipSuccess || hipStreamWaitEvent(to, e, 0) != hipSuccess) return OPE_ELAUNCH;
+    return OPE_OK;
+  };
+  if ((rc = sync_to(st, side))) return rc;   // fork: the side stream starts after the caller's prior work (the gather)
 
-  // ---- forward: GRU scans (live + target in one launch) ----
-  GruFwdArgs gf;
-  gf.nets = 2; gf.NB = p.NB; gf.L = p.T + 1; gf.theta0 = theta; gf.theta1 = theta_tgt; gf.gi0 = W + p.gi; gf.gi1 = W + p.gi_t;
-  gf.h0out = W + p.h; gf.h1out = W + p.h_t; gf.hinit = nullptr; gf.whh_off = p.AL.whh; gf.bhh_off = p.AL.bhh;
-  gf.rg = W + p.rg; gf.zg = W + p.zg; gf.ng = W + p.ng; gf.ghn = W + p.ghn;
-  if (!p.mlp)
-    if ((rc = launch_gru_fwd(gf, st))) return rc;
-
-  // ---- forward: heads ----
-  HeadFwdArgs hf;
-  hf.R = p.R; hf.NB = p.NB; hf.B = p.B; hf.N = p.N; hf.T = p.T; hf.A = p.A; hf.theta0 = theta; hf.theta1 = theta_tgt; hf.L = p.AL;
-  hf.h0 = W + p.h; hf.h1 = W + p.h_t; hf.acts = batch->acts; hf.avail = batch->avail_acts; hf.double_q = cfg->use_double_q;
-  hf.no_ln = p.mlp; hf.target_mask_avail = p.mlp;
-  hf.agent_q = W + p.agent_q; hf.agent_nq = W + p.agent_nq; hf.act_idx = (int*)(W + p.act_idx);
-  hf.xhat_o = W + p.xhat_o; hf.rstd_o = W + p.rstd_o; hf.q_out = nullptr; hf.q_all = g_debug ? W + p.q_all : nullptr;
-  if ((rc = launch_head_fwd(hf, 0, st))) return rc;
+  // ---- forward ----
+  for (int c = 0; c < C; ++c) {
+    const int64_t r0 = (int64_t)p.tb[c] * p.NB, rows = (int64_t)(p.tb[c + 1] - p.tb[c]) * p.NB;
+    TrunkFwdArgs tf;
+    memset(&tf, 0, sizeof(tf));
+    tf.x = batch->obs + r0 * p.D; tf.R = (int)rows; tf.D = p.D; tf.theta = theta; tf.L = p.AL;
+    tf.gi = p.mlp ? nullptr : W + p.gi + r0 * 3 * OPE_H; tf.a2_out = p.mlp ? W + p.h + r0 * OPE_H : nullptr;
+    tf.mu0 = W + p.mu0 + r0; tf.rstd0 = W + p.rstd0 + r0;
+    tf.xhat1 = W + p.xhat1 + r0 * OPE_H; tf.rstd1 = W + p.rstd1 + r0; tf.mask1 = (uint64_t*)(W + p.mask1) + r0;
+    tf.xhat2 = W + p.xhat2 + r0 * OPE_H; tf.rstd2 = W + p.rstd2 + r0; tf.mask2 = (uint64_t*)(W + p.mask2) + r0;
+    if ((rc = launch_trunk_fwd(tf, true, st))) return rc;
+    TrunkFwdArgs tt = tf;
+    tt.theta = theta_tgt; tt.gi = p.mlp ? nullptr : W + p.gi_t + r0 * 3 * OPE_H; tt.a2_out = p.mlp ? W + p.h_t + r0 * OPE_H : nullptr;
+    if ((rc = launch_trunk_fwd(tt, false, st))) return rc;
+    if (p.mlp) continue;
+    hipStream_t scan_st = side;
+    if ((rc = sync_to(st, side))) return rc;
+    GruFwdArgs gf;   // live + target in one launch
+    memset(&gf, 0, sizeof(gf));
+    gf.nets = 2; gf.NB = p.NB; gf.L = p.tb[c + 1] - p.tb[c]; gf.theta0 = theta; gf.theta1 = theta_tgt;
+    gf.gi0 = W + p.gi + r0 * 3 * OPE_H; gf.gi1 = W + p.gi_t + r0 * 3 * OPE_H;
+    gf.h0out = W + p.h + r0 * OPE_H; gf.h1out = W + p.h_t + r0 * OPE_H;
+    if (c > 0) { gf.hinit = W + p.h + (r0 - p.NB) * OPE_H; gf.hinit1 = W + p.h_t + (r0 - p.NB) * OPE_H; }
+    gf.whh_off = p.AL.whh; gf.bhh_off = p.AL.bhh;
+    gf.rg = W + p.rg + r0 * OPE_H; gf.zg = W + p.zg + r0 * OPE_H; gf.ng = W + p.ng + r0 * OPE_H; gf.ghn = W + p.ghn + r0 * OPE_H;
+    if ((rc = launch_gru_fwd(gf, scan_st))) return rc;
+    if (C > 1 && hipEventRecord(sp->scan_done[c], side) != hipSuccess) return OPE_ELAUNCH;
+  }
+  for (int c = 0; c < C; ++c) {   // heads of chunk c as soon as its scan is done
+    if (C > 1 && hipStreamWaitEvent(st, sp->scan_done[c], 0) != hipSuccess) return OPE_ELAUNCH;
+    HeadFwdArgs hf;
+    memset(&hf, 0, sizeof(hf));
+    hf.r_begin = (int64_t)p.tb[c] * p.NB; hf.R = (int64_t)p.tb[c + 1] * p.NB;
+    hf.NB = p.NB; hf.B = p.B; hf.N = p.N; hf.T = p.T; hf.A = p.A; hf.theta0 = theta; hf.theta1 = theta_tgt; hf.L = p.AL;
+    hf.h0 = W + p.h; hf.h1 = W + p.h_t; hf.acts = batch->acts; hf.avail = batch->avail_acts; hf.double_q = cfg->use_double_q;
+    hf.no_ln = p.mlp; hf.target_mask_avail = p.mlp;
+    hf.agent_q = W + p.agent_q; hf.agent_nq = W + p.agent_nq; hf.act_idx = (int*)(W + p.act_idx);
+    hf.xhat_o = W + p.xhat_o; hf.rstd_o = W + p.rstd_o; hf.q_out = nullptr; hf.q_all = g_debug ? W + p.q_all : nullptr;
+    if ((rc = launch_head_fwd(hf, 0, st))) return rc;
+  }
 
   // ---- mixer forward + TD + mixer backward ----
   TdArgs td;
@@ -266,68 +355,101 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
   hb.xhat_o = W + p.xhat_o; hb.rstd_o = W + p.rstd_o; hb.act_idx = (const int*)(W + p.act_idx); hb.d_agent_q = W + p.d_agent_q;
   hb.dh_out = W + p.dh_out; hb.dqoh = W + p.dqoh;
   if ((rc = launch_head_bwd(hb, st))) return rc;
-  GruBwdArgs gb;
-  gb.NB = p.NB; gb.T = p.T; gb.theta = theta; gb.whh_off = p.AL.whh; gb.h = W + p.h;
-  gb.rg = W + p.rg; gb.zg = W + p.zg; gb.ng = W + p.ng; gb.ghn = W + p.ghn; gb.dh_out = W + p.dh_out; gb.dgi = W + p.dgi; gb.dghn = W + p.dghn;
-  if (!p.mlp)
-    if ((rc = launch_gru_bwd(gb, st))) return rc;
-  TrunkBwdArgs tb;
-  tb.R = (int)p.R1; tb.theta = theta; tb.thetaT = W + p.thetaT; tb.L = p.AL; tb.dgi = p.mlp ? nullptr : W + p.dgi; tb.da2_in = p.mlp ? W + p.dh_out : nullptr;
-  tb.xhat1 = W + p.xhat1; tb.rstd1 = W + p.rstd1; tb.mask1 = (const uint64_t*)(W + p.mask1);
-  tb.xhat2 = W + p.xhat2; tb.rstd2 = W + p.rstd2; tb.mask2 = (const uint64_t*)(W + p.mask2);
-  tb.dz1 = W + p.dz1; tb.dz2 = W + p.dz2;
-  if ((rc = launch_trunk_bwd(tb, st))) return rc;
+  if ((rc = sync_to(st, side))) return rc;
 
-  // ---- weight gradients: one batched K-reduction launch ----
-  // (ln_zero / ln_one were filled by ope_qmix_workspace_init)
-  WgTable wt;
-  memset(&wt, 0, sizeof(wt));
-  int n = 0;
+  // weight-gradient problem tables: mixer problems (K = T*B) go first, on the main stream, while the side stream runs the
+  // BPTT of the last chunk; the agent problems are cut into the same time chunks (each chunk = its own K-splits/slabs)
   const Raw& rw = p.raw;
-  const int K1 = (int)p.R1;
-  auto prob = [&](const float* A, int lda, int M, const float* Bm, int ldb, int N, int K, int out_off, int ldc, int s_off,
+  auto prob = [&](WgTable& wt, const float* A, int lda, int M, const float* Bm, int ldb, int N, int K, int out_off, int ldc, int s_off,
                   int nsplit, int64_t base, int64_t stride) -> WgProb& {
-    WgProb& q = wt.p[n++];
+    WgProb& q = wt.p[wt.n++];
     q.A = A; q.lda = lda; q.M = M; q.B = Bm; q.ldb = ldb; q.N = N; q.K = K; q.b_shift = 0; q.ln_mu = W + p.ln_zero; q.ln_rstd = W + p.ln_one;
     q.out_off = out_off; q.ldc = ldc; q.s_off = s_off; q.nsplit = nsplit; q.raw_base = base; q.raw_stride = stride;
     return q;
   };
-  const int64_t ab = p.raw_agent, as = rw.agent_end;
-  {
-    WgProb& q = prob(W + p.dz1, OPE_H, OPE_H, batch->obs, p.D, p.D, K1, rw.P1, p.D, rw.s1, p.ns_agent, ab, as);
-    q.ln_mu = W + p.mu0; q.ln_rstd = W + p.rstd0;
-  }
-  prob(W + p.dz2, OPE_H, OPE_H, W + p.xhat1, OPE_H, OPE_H, K1, rw.P2, OPE_H, rw.s2, p.ns_agent, ab, as);
-  if (!p.mlp) {
-    prob(W + p.dgi, 3 * OPE_H, 3 * OPE_H, W + p.xhat2, OPE_H, OPE_H, K1, rw.P3, OPE_H, rw.s3, p.ns_agent, ab, as);
-    WgProb& q = prob(W + p.dgi, 3 * OPE_H, 2 * OPE_H, W + p.h, OPE_H, OPE_H, K1, rw.WHH, OPE_H, rw.shh, p.ns_agent, ab, as);
-    q.b_shift = p.NB;  // h_{t-1}
-    WgProb& q2 = prob(W + p.dghn, OPE_H, OPE_H, W + p.h, OPE_H, OPE_H, K1, rw.WHH + 2 * OPE_H * OPE_H, OPE_H, rw.shh + 2 * OPE_H, p.ns_agent, ab, as);
-    q2.b_shift = p.NB;
-  }
-  // q head: fed by rnn.norm (recurrent) or directly by the trunk's LN2 (MLP) -- both "Linear after LayerNorm"
-  prob(W + p.dqoh, p.A4, p.A, p.mlp ? W + p.xhat2 : W + p.xhat_o, OPE_H, OPE_H, K1, rw.E, OPE_H, rw.sq, p.ns_agent, ab, as);
-  if (!cfg->vdn) {
+  auto add_mixer_problems = [&](WgTable& wt) {
     const MixerLayout& M = p.ML;
     const int mbase = p.AL.end;
     const int64_t mb_ = p.raw_mixer, ms = rw.mixer_size;
     const int TBk = (int)p.TB;
     const float* S0 = batch->share_obs;  // rows 0..TB-1 are states at t < T
-    prob(W + p.d_hw1, OPE_HYP, OPE_HYP, S0, p.S, p.S, TBk, M.w1a_w - mbase, p.S, M.w1a_b - mbase, p.ns_mixer, mb_, ms);
-    prob(W + p.d_v1, p.NM, p.NM, W + p.hw1, OPE_HYP, OPE_HYP, TBk, M.w1b_w - mbase, OPE_HYP, M.w1b_b - mbase, p.ns_mixer, mb_, ms);
-    prob(W + p.d_hw2, OPE_HYP, OPE_HYP, S0, p.S, p.S, TBk, M.w2a_w - mbase, p.S, M.w2a_b - mbase, p.ns_mixer, mb_, ms);
-    prob(W + p.d_v2, OPE_MIX, OPE_MIX, W + p.hw2, OPE_HYP, OPE_HYP, TBk, M.w2b_w - mbase, OPE_HYP, M.w2b_b - mbase, p.ns_mixer, mb_, ms);
-    prob(W + p.d_b1, OPE_MIX, OPE_MIX, S0, p.S, p.S, TBk, M.b1_w - mbase, p.S, M.b1_b - mbase, p.ns_mixer, mb_, ms);
-    prob(W + p.d_hb2, OPE_HYP, OPE_HYP, S0, p.S, p.S, TBk, M.b2a_w - mbase, p.S, M.b2a_b - mbase, p.ns_mixer, mb_, ms);
-    prob(W + p.dqtot, 4, 1, W + p.hb2, OPE_HYP, OPE_HYP, TBk, M.b2b_w - mbase, OPE_HYP, M.b2b_b - mbase, p.ns_mixer, mb_, ms);
+    prob(wt, W + p.d_hw1, OPE_HYP, OPE_HYP, S0, p.S, p.S, TBk, M.w1a_w - mbase, p.S, M.w1a_b - mbase, p.ns_mixer, mb_, ms);
+    prob(wt, W + p.d_v1, p.NM, p.NM, W + p.hw1, OPE_HYP, OPE_HYP, TBk, M.w1b_w - mbase, OPE_HYP, M.w1b_b - mbase, p.ns_mixer, mb_, ms);
+    prob(wt, W + p.d_hw2, OPE_HYP, OPE_HYP, S0, p.S, p.S, TBk, M.w2a_w - mbase, p.S, M.w2a_b - mbase, p.ns_mixer, mb_, ms);
+    prob(wt, W + p.d_v2, OPE_MIX, OPE_MIX, W + p.hw2, OPE_HYP, OPE_HYP, TBk, M.w2b_w - mbase, OPE_HYP, M.w2b_b - mbase, p.ns_mixer, mb_, ms);
+    prob(wt, W + p.d_b1, OPE_MIX, OPE_MIX, S0, p.S, p.S, TBk, M.b1_w - mbase, p.S, M.b1_b - mbase, p.ns_mixer, mb_, ms);
+    prob(wt, W + p.d_hb2, OPE_HYP, OPE_HYP, S0, p.S, p.S, TBk, M.b2a_w - mbase, p.S, M.b2a_b - mbase, p.ns_mixer, mb_, ms);
+    prob(wt, W + p.dqtot, 4, 1, W + p.hb2, OPE_HYP, OPE_HYP, TBk, M.b2b_w - mbase, OPE_HYP, M.b2b_b - mbase, p.ns_mixer, mb_, ms);
+  };
+  // agent problems over the rows [r0, r0 + K1) (whole time steps), slabs starting at `slab0`
+  auto add_agent_problems = [&](WgTable& wt, int64_t r0, int K1, int nsplit, int slab0) {
+    const int64_t ab = p.raw_agent + (int64_t)slab0 * rw.agent_end, as = rw.agent_end;
+    {
+      WgProb& q = prob(wt, W + p.dz1 + r0 * OPE_H, OPE_H, OPE_H, batch->obs + r0 * p.D, p.D, p.D, K1, rw.P1, p.D, rw.s1, nsplit, ab, as);
+      q.ln_mu = W + p.mu0 + r0; q.ln_rstd = W + p.rstd0 + r0;
+    }
+    prob(wt, W + p.dz2 + r0 * OPE_H, OPE_H, OPE_H, W + p.xhat1 + r0 * OPE_H, OPE_H, OPE_H, K1, rw.P2, OPE_H, rw.s2, nsplit, ab, as);
+    if (!p.mlp) {
+      const float* dgi = W + p.dgi + r0 * 3 * OPE_H;
+      prob(wt, dgi, 3 * OPE_H, 3 * OPE_H, W + p.xhat2 + r0 * OPE_H, OPE_H, OPE_H, K1, rw.P3, OPE_H, rw.s3, nsplit, ab, as);
+      // h_{t-1}: the first chunk shifts inside the kernel (rows of t = 0 see zeros), later chunks start one step back
+      const float* hprev = r0 > 0 ? W + p.h + (r0 - p.NB) * OPE_H : W + p.h;
+      const int shift = r0 > 0 ? 0 : p.NB;
+      prob(wt, dgi, 3 * OPE_H, 2 * OPE_H, hprev, OPE_H, OPE_H, K1, rw.WHH, OPE_H, rw.shh, nsplit, ab, as).b_shift = shift;
+      prob(wt, W + p.dghn + r0 * OPE_H, OPE_H, OPE_H, hprev, OPE_H, OPE_H, K1, rw.WHH + 2 * OPE_H * OPE_H, OPE_H, rw.shh + 2 * OPE_H, nsplit, ab,
+           as).b_shift = shift;
+    }
+    // q head: fed by rnn.norm (recurrent) or directly by the trunk's LN2 (MLP) -- both "Linear after LayerNorm"
+    prob(wt, W + p.dqoh + r0 * p.A4, p.A4, p.A, (p.mlp ? W + p.xhat2 : W + p.xhat_o) + r0 * OPE_H, OPE_H, OPE_H, K1, rw.E, OPE_H, rw.sq, nsplit, ab, as);
+  };
+  int agent_slabs = 0, mixer_slabs = 0;
+  if (use_side && !cfg->vdn) {   // main stream, beside the BPTT of the last chunk on the side stream
+    WgTable wm;
+    memset(&wm, 0, sizeof(wm));
+    add_mixer_problems(wm);
+    if ((rc = wg_finish(&wm))) return rc;
+    if ((rc = launch_wgrad(wm, W, st))) return rc;
+    mixer_slabs = wg_slabs(wm, p.ns_mixer);
   }
-  wt.n = n;
-  if ((rc = wg_finish(&wt))) return rc;
-  if ((rc = launch_wgrad(wt, W, st))) return rc;
+  for (int c = C - 1; c >= 0; --c) {   // BPTT, last chunk first, on the side stream
+    const int lo = p.tb[c], hi = p.tb[c + 1] < p.T ? p.tb[c + 1] : p.T;
+    if (p.mlp || lo >= hi) continue;
+    GruBwdArgs gb;
+    memset(&gb, 0, sizeof(gb));
+    gb.NB = p.NB; gb.T = hi; gb.t_lo = lo; gb.theta = theta; gb.whh_off = p.AL.whh; gb.h = W + p.h;
+    gb.rg = W + p.rg; gb.zg = W + p.zg; gb.ng = W + p.ng; gb.ghn = W + p.ghn; gb.dh_out = W + p.dh_out; gb.dgi = W + p.dgi; gb.dghn = W + p.dghn;
+    gb.dh_in = hi < p.T ? W + p.dh_carry : nullptr;
+    gb.dh_carry = lo > 0 ? W + p.dh_carry : nullptr;
+    if ((rc = launch_gru_bwd(gb, side))) return rc;
+    if (use_side && hipEventRecord(sp->bptt_done[c], side) != hipSuccess) return OPE_ELAUNCH;
+  }
+  for (int c = C - 1; c >= 0; --c) {   // trunk adjoint + weight-gradient K-slices of chunk c behind its BPTT
+    const int lo = p.tb[c], hi = p.tb[c + 1] < p.T ? p.tb[c + 1] : p.T;
+    if (lo >= hi) continue;
+    if (use_side && !p.mlp && hipStreamWaitEvent(st, sp->bptt_done[c], 0) != hipSuccess) return OPE_ELAUNCH;
+    const int64_t r0 = (int64_t)lo * p.NB;
+    const int K1 = (hi - lo) * p.NB;
+    TrunkBwdArgs tb;
+    memset(&tb, 0, sizeof(tb));
+    tb.R = K1; tb.theta = theta; tb.thetaT = W + p.thetaT; tb.L = p.AL;
+    tb.dgi = p.mlp ? nullptr : W + p.dgi + r0 * 3 * OPE_H; tb.da2_in = p.mlp ? W + p.dh_out + r0 * OPE_H : nullptr;
+    tb.xhat1 = W + p.xhat1 + r0 * OPE_H; tb.rstd1 = W + p.rstd1 + r0; tb.mask1 = (const uint64_t*)(W + p.mask1) + r0;
+    tb.xhat2 = W + p.xhat2 + r0 * OPE_H; tb.rstd2 = W + p.rstd2 + r0; tb.mask2 = (const uint64_t*)(W + p.mask2) + r0;
+    tb.dz1 = W + p.dz1 + r0 * OPE_H; tb.dz2 = W + p.dz2 + r0 * OPE_H;
+    if ((rc = launch_trunk_bwd(tb, st))) return rc;
+    WgTable wt;
+    memset(&wt, 0, sizeof(wt));
+    add_agent_problems(wt, r0, K1, p.ns_chunk[c], agent_slabs);
+    if (!use_side && !cfg->vdn) add_mixer_problems(wt);
+    if ((rc = wg_finish(&wt))) return rc;
+    if ((rc = launch_wgrad(wt, W, st))) return rc;
+    agent_slabs += wg_slabs(wt, p.ns_chunk[c]);
+    if (!use_side && !cfg->vdn) mixer_slabs = wg_slabs(wt, p.ns_mixer);
+  }
   {
     SplitRed sr;
-    sr.raw0 = W + p.raw_agent; sr.n0 = rw.agent_end; sr.ns0 = wg_slabs(wt, p.ns_agent);
-    sr.raw1 = W + p.raw_mixer; sr.n1 = cfg->vdn ? 0 : rw.mixer_size; sr.ns1 = wg_slabs(wt, p.ns_mixer);
+    sr.raw0 = W + p.raw_agent; sr.n0 = rw.agent_end; sr.ns0 = agent_slabs;
+    sr.raw1 = W + p.raw_mixer; sr.n1 = cfg->vdn ? 0 : rw.mixer_size; sr.ns1 = mixer_slabs;
     sr.rsum = W + p.rsum;
     if ((rc = launch_split_reduce(sr, st))) return rc;
   }
@@ -337,6 +459,7 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
   memset(&ft, 0, sizeof(ft));
   int k = 0;
   const AgentLayout& L = p.AL;
+  const int srcE = rw.E, srcSq = rw.sq;
   auto seg = [&](int begin, int size, int kind, int src, int src_s, int M, int K, int w, int gamma, int beta) {
     FinSeg& s = ft.seg[k++];
     s.begin = begin; s.size = size; s.kind = kind; s.src = src; s.src_s = src_s; s.M = M; s.K = K; s.w = w; s.gamma = gamma; s.beta = beta;
@@ -357,15 +480,15 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
     seg(L.whh, 3 * OPE_H * OPE_H, FIN_COPY, rw.WHH, 0, 0, 0, 0, 0, 0);
     seg(L.bih, 3 * OPE_H, FIN_COPY, rw.s3, 0, 0, 0, 0, 0, 0);
     seg(L.bhh, 3 * OPE_H, FIN_COPY, rw.shh, 0, 0, 0, 0, 0, 0);
-    seg(L.lno_w, OPE_H, FIN_LNLIN_G, rw.E, rw.sq, p.A, OPE_H, L.q_w, 0, 0);
-    seg(L.lno_b, OPE_H, FIN_LNLIN_B, rw.E, rw.sq, p.A, OPE_H, L.q_w, 0, 0);
-    seg(L.q_w, p.A * OPE_H, FIN_LNLIN_W, rw.E, rw.sq, p.A, OPE_H, L.q_w, L.lno_w, L.lno_b);
+    seg(L.lno_w, OPE_H, FIN_LNLIN_G, srcE, srcSq, p.A, OPE_H, L.q_w, 0, 0);
+    seg(L.lno_b, OPE_H, FIN_LNLIN_B, srcE, srcSq, p.A, OPE_H, L.q_w, 0, 0);
+    seg(L.q_w, p.A * OPE_H, FIN_LNLIN_W, srcE, srcSq, p.A, OPE_H, L.q_w, L.lno_w, L.lno_b);
   } else {   // MLP nets: LN2 feeds the q head
-    seg(L.ln2_w, OPE_H, FIN_LNLIN_G, rw.E, rw.sq, p.A, OPE_H, L.q_w, 0, 0);
-    seg(L.ln2_b, OPE_H, FIN_LNLIN_B, rw.E, rw.sq, p.A, OPE_H, L.q_w, 0, 0);
-    seg(L.q_w, p.A * OPE_H, FIN_LNLIN_W, rw.E, rw.sq, p.A, OPE_H, L.q_w, L.ln2_w, L.ln2_b);
+    seg(L.ln2_w, OPE_H, FIN_LNLIN_G, srcE, srcSq, p.A, OPE_H, L.q_w, 0, 0);
+    seg(L.ln2_b, OPE_H, FIN_LNLIN_B, srcE, srcSq, p.A, OPE_H, L.q_w, 0, 0);
+    seg(L.q_w, p.A * OPE_H, FIN_LNLIN_W, srcE, srcSq, p.A, OPE_H, L.q_w, L.ln2_w, L.ln2_b);
   }
-  seg(L.q_b, p.A, FIN_COPY, rw.sq, 0, 0, 0, 0, 0, 0);
+  seg(L.q_b, p.A, FIN_COPY, srcSq, 0, 0, 0, 0, 0, 0);
   if (!cfg->vdn) {  // mixer gradients: raw mixer slab has the same relative layout as the parameters
     const MixerLayout& M = p.ML;
     const int mo[OPE_QMIX_NPARAM_MIXER] = {M.w1a_w, M.w1a_b, M.w1b_w, M.w1b_b, M.w2a_w, M.w2a_b, M.w2b_w, M.w2b_b,

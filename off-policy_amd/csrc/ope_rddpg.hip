@@ -394,6 +394,7 @@ static int rnn_backward(const RPlan& p, float* W, const SaveSet& s, const float*
   OPE_L(hipLaunchKernelGGL(head_bwd_dense_kernel, dim3(ope_cdiv(rows, 4)), dim3(256), 0, st, dout, ldk, Hout, theta + L.q_w,
                            theta + L.lno_w, W + s.xhat_o, W + s.rstd_o, (int)rows, W + p.dh_out));
   GruBwdArgs gb;
+  memset(&gb, 0, sizeof(gb));
   gb.NB = rps; gb.T = steps; gb.theta = theta; gb.whh_off = L.whh; gb.h = W + s.h;
   gb.rg = W + s.rg; gb.zg = W + s.zg; gb.ng = W + s.ng; gb.ghn = W + s.ghn; gb.dh_out = W + p.dh_out; gb.dgi = W + p.dgi; gb.dghn = W + p.dghn;
   if ((rc = launch_gru_bwd(gb, st))) return rc;

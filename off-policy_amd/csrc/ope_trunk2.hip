@@ -1,0 +1,333 @@
+// trunk_fwd, workgroup-cooperative form (default). Same arithmetic as trunk_fwd_kernel (ope_agent_fwd.hip):
+//   LN_D(x) -> fc1 + ReLU + LN -> fc2 + ReLU + LN -> gi = W_ih a2 + b_ih      (RNNBase.forward rnn.py:33-47, mlp.py:25-29)
+//
+// Why a second form: with one wave carrying 16*RT rows through all 64 output features, a 3s5z batch is only ~1200 waves
+// -- about one per SIMD -- and each of them is a ~60 us serial chain (PMC: f32-MFMA pipe 22 % busy, the wave stalled or
+// waiting the rest of the time). Here the 64 output features of every layer are split over the 4 waves of a workgroup
+// (one 16-feature MFMA tile each; 3 tiles each for the 192-wide W_ih), so the same batch is ~4800 much shorter waves and
+// the SIMDs have 3-4 of them to interleave:
+//   phase 0  each wave normalises TR/4 input rows (two-pass LayerNorm, coalesced row reads) into LDS  xn[TR][Dp]
+//   fc1      wave w: z1[:, 16w..16w+15] = W1[16w.., :] xn   -- A operand = weight rows from L2 (4-deep register
+//            prefetch ring), B operand = ds_read_b128 from LDS, shared by the 4 waves
+//   LN       per-row sums of the 4 waves meet through LDS (two barriers: mean, then centred second moment)
+//   fc2, LN, W_ih the same way from an LDS copy of the activations.
+// Transposed-chain lane convention as everywhere else: lane (j = l & 15, g = l >> 4) holds features 16*tile + 4g + r of
+// data row j.
+#include <stdlib.h>
+
+#include "ope_agent.h"
+
+namespace ope {
+
+constexpr int kActPitch = OPE_H + 4;   // LDS row pitch of the 64-wide activations (bank shift of 4 per row)
+
+template <int VEC, int RT, bool SAVE>
+__global__ void __launch_bounds__(256) trunk_fwd2_kernel(TrunkFwdArgs a, int Dp) {
+  constexpr int TR = 16 * RT;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* xn = sm;                          // [TR][Dp]   normalised input (zero beyond D)
+  float* actb = sm + TR * Dp;              // [TR][kActPitch]
+  float* stat = actb + TR * kActPitch;     // [4][TR]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int row0 = blockIdx.x * TR;
+  const int D = a.D;
+  const int KC = (D + 15) >> 4;
+  const float* __restrict__ th = a.theta;
+
+  // ---- phase 0: input LayerNorm of this wave's TR/4 rows -> LDS. All row loads are issued before the first reduction,
+  // so the HBM latency is paid once per wave, not once per row. ----
+  {
+    constexpr int NI = 8;                  // D <= 512
+    constexpr int NR = TR / 4;             // rows per wave
+    float v[NR][NI];
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+      const int row = row0 + wave * NR + q;
+      const float* xr = a.x + (int64_t)(row < a.R ? row : a.R - 1) * D;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int k = lane + 64 * i;
+        v[q][i] = xr[k < D ? k : D - 1];
+      }
+    }
+    float gam[NI], bet[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int k = lane + 64 * i;
+      const int kc = k < D ? k : D - 1;
+      gam[i] = k < D ? th[a.L.fn_w + kc] : 0.f;
+      bet[i] = k < D ? th[a.L.fn_b + kc] : 0.f;
+    }
+    float mean[NR], rstd[NR];
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        if (lane + 64 * i >= D) v[q][i] = 0.f;
+        s += v[q][i];
+      }
+      mean[q] = s;
+    }
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int q = 0; q < NR; ++q) mean[q] += __shfl_xor(mean[q], o, 64);
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+      mean[q] /= (float)D;
+      float sq = 0.f;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const float d = (lane + 64 * i < D) ? v[q][i] - mean[q] : 0.f;
+        sq = fmaf(d, d, sq);
+      }
+      rstd[q] = sq;
+    }
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int q = 0; q < NR; ++q) rstd[q] += __shfl_xor(rstd[q], o, 64);
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+      rstd[q] = 1.0f / sqrtf(rstd[q] / (float)D + OPE_LN_EPS);
+      const int rr = wave * NR + q;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int k = lane + 64 * i;
+        if (k < 16 * KC) xn[rr * Dp + k] = fmaf((v[q][i] - mean[q]) * rstd[q], gam[i], bet[i]);   // gam = bet = 0 beyond D -> exactly 0
+      }
+      if (SAVE && lane == 0 && row0 + rr < a.R) {
+        a.mu0[row0 + rr] = mean[q];
+        a.rstd0[row0 + rr] = rstd[q];
+      }
+    }
+  }
+  __syncthreads();
+
+  int row[RT];
+  bool valid[RT];
+#pragma unroll
+  for (int t = 0; t < RT; ++t) {
+    row[t] = row0 + 16 * t + j;
+    valid[t] = row[t] < a.R;
+  }
+
+  // ---- fc1: this wave's 16 output features, K = D ----
+  f32x4 acc[RT];
+#pragma unroll
+  for (int t = 0; t < RT; ++t) acc[t] = *reinterpret_cast<const f32x4*>(th + a.L.fc1_b + 16 * wave + 4 * g);
+  {
+    const float* __restrict__ Wr = th + a.L.fc1_w + (int64_t)(16 * wave + j) * D;
+    auto wload = [&](int c) { return load4c<VEC>(Wr, 16 * c + 4 * g, D); };   // clamped: chunks past KC-1 re-read the last one
+    auto step = [&](const f32x4& wv, int c) {
+      if (c >= KC) return;
+      const int k = 16 * c + 4 * g;
+      f32x4 xv[RT];
+#pragma unroll
+      for (int t = 0; t < RT; ++t) xv[t] = *reinterpret_cast<const f32x4*>(xn + (16 * t + j) * Dp + k);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int t = 0; t < RT; ++t) acc[t] = mfma16(wv[r], xv[t][r], acc[t]);
+    };
+    f32x4 w0 = wload(0), w1 = wload(1), w2 = wload(2), w3;
+    for (int c = 0; c < KC; c += 4) {
+      w3 = wload(c + 3);
+      __builtin_amdgcn_sched_barrier(0);
+      step(w0, c);
+      __builtin_amdgcn_sched_barrier(0);
+      w0 = wload(c + 4);
+      __builtin_amdgcn_sched_barrier(0);
+      step(w1, c + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      w1 = wload(c + 5);
+      __builtin_amdgcn_sched_barrier(0);
+      step(w2, c + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      w2 = wload(c + 6);
+      __builtin_amdgcn_sched_barrier(0);
+      step(w3, c + 3);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // ReLU + LayerNorm over the 64 features of a row whose 16-feature slices live in the 4 waves. Leaves act (affine
+  // output) in `o`, xhat in `xh`; returns rstd / mean / this wave's 16 ReLU bits per row through the references.
+  auto relu_ln = [&](f32x4 (&z)[RT], const float* gamv, const float* betv, f32x4 (&xh)[RT], f32x4 (&o)[RT], float (&rs)[RT], float (&mu)[RT],
+                     uint32_t (&bits)[RT]) {
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      uint32_t mb = 0;
+      float s = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (z[t][r] > 0.f) mb |= 1u << (4 * g + r);
+        z[t][r] = fmaxf(z[t][r], 0.f);
+        s += z[t][r];
+      }
+      bits[t] = mb;
+      s = rowsum4(s);
+      if (g == 0) stat[wave * TR + 16 * t + j] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      const int rr = 16 * t + j;
+      mu[t] = ((stat[rr] + stat[TR + rr]) + (stat[2 * TR + rr] + stat[3 * TR + rr])) * (1.0f / OPE_H);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      float q = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float d = z[t][r] - mu[t];
+        q = fmaf(d, d, q);
+      }
+      q = rowsum4(q);
+      if (g == 0) stat[wave * TR + 16 * t + j] = q;
+    }
+    __syncthreads();
+    const f32x4 gm = *reinterpret_cast<const f32x4*>(gamv + 16 * wave + 4 * g);
+    const f32x4 bt = *reinterpret_cast<const f32x4*>(betv + 16 * wave + 4 * g);
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      const int rr = 16 * t + j;
+      const float var = ((stat[rr] + stat[TR + rr]) + (stat[2 * TR + rr] + stat[3 * TR + rr])) * (1.0f / OPE_H);
+      rs[t] = 1.0f / sqrtf(var + OPE_LN_EPS);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        xh[t][r] = (z[t][r] - mu[t]) * rs[t];
+        o[t][r] = fmaf(xh[t][r], gm[r], bt[r]);
+      }
+    }
+    // (the next write to `stat` happens after at least one more barrier)
+  };
+  // 16 ReLU bits of this wave -> its quarter of the row's 64-bit mask (bit f = feature f), plus rstd (and mean) once per row
+  auto save_row = [&](uint64_t* mask, float* rstd_out, float* mu_out, const uint32_t (&bits)[RT], const float (&rs)[RT], const float (&mu)[RT]) {
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      uint32_t b = bits[t];
+      b |= __shfl_xor((int)b, 16, 64);
+      b |= __shfl_xor((int)b, 32, 64);
+      if (g == 0 && valid[t]) {
+        reinterpret_cast<uint16_t*>(mask + row[t])[wave] = (uint16_t)b;
+        if (wave == 0) {
+          rstd_out[row[t]] = rs[t];
+          if (mu_out) mu_out[row[t]] = mu[t];
+        }
+      }
+    }
+  };
+
+  f32x4 xh[RT], act[RT];
+  float rs[RT], mu[RT];
+  uint32_t bits[RT];
+  relu_ln(acc, th + a.L.ln1_w, th + a.L.ln1_b, xh, act, rs, mu, bits);
+  if (SAVE) {
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+      if (valid[t]) *reinterpret_cast<f32x4*>(a.xhat1 + (int64_t)row[t] * OPE_H + 16 * wave + 4 * g) = xh[t];
+    save_row(a.mask1, a.rstd1, a.mu1, bits, rs, mu);
+  }
+#pragma unroll
+  for (int t = 0; t < RT; ++t) *reinterpret_cast<f32x4*>(actb + (16 * t + j) * kActPitch + 16 * wave + 4 * g) = act[t];
+  __syncthreads();
+
+  // ---- fc2 ----
+#pragma unroll
+  for (int t = 0; t < RT; ++t) acc[t] = *reinterpret_cast<const f32x4*>(th + a.L.fc2_b + 16 * wave + 4 * g);
+  {
+    const float* __restrict__ Wr = th + a.L.fc2_w + (int64_t)(16 * wave + j) * OPE_H + 4 * g;
+    f32x4 wv[4];
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft) wv[ft] = *reinterpret_cast<const f32x4*>(Wr + 16 * ft);
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft) {
+      f32x4 xv[RT];
+#pragma unroll
+      for (int t = 0; t < RT; ++t) xv[t] = *reinterpret_cast<const f32x4*>(actb + (16 * t + j) * kActPitch + 16 * ft + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int t = 0; t < RT; ++t) acc[t] = mfma16(wv[ft][r], xv[t][r], acc[t]);
+    }
+  }
+  relu_ln(acc, th + a.L.ln2_w, th + a.L.ln2_b, xh, act, rs, mu, bits);   // its first barrier also fences the fc2 reads of actb
+  if (SAVE) {
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+      if (valid[t]) *reinterpret_cast<f32x4*>(a.xhat2 + (int64_t)row[t] * OPE_H + 16 * wave + 4 * g) = xh[t];
+    save_row(a.mask2, a.rstd2, nullptr, bits, rs, mu);
+  }
+  if (a.a2_out) {   // MLP nets stop here: the trunk output feeds the head directly
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+      if (valid[t]) *reinterpret_cast<f32x4*>(a.a2_out + (int64_t)row[t] * OPE_H + 16 * wave + 4 * g) = act[t];
+    return;
+  }
+#pragma unroll
+  for (int t = 0; t < RT; ++t) *reinterpret_cast<f32x4*>(actb + (16 * t + j) * kActPitch + 16 * wave + 4 * g) = act[t];
+  __syncthreads();
+
+  // ---- gi = W_ih a2 + b_ih : 12 output tiles, 3 per wave ----
+  f32x4 o[RT][3];
+#pragma unroll
+  for (int u = 0; u < 3; ++u)
+#pragma unroll
+    for (int t = 0; t < RT; ++t) o[t][u] = *reinterpret_cast<const f32x4*>(th + a.L.bih + 16 * (3 * wave + u) + 4 * g);
+#pragma unroll
+  for (int ft = 0; ft < 4; ++ft) {
+    f32x4 wv[3], xv[RT];
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+      wv[u] = *reinterpret_cast<const f32x4*>(th + a.L.wih + (int64_t)(16 * (3 * wave + u) + j) * OPE_H + 16 * ft + 4 * g);
+#pragma unroll
+    for (int t = 0; t < RT; ++t) xv[t] = *reinterpret_cast<const f32x4*>(actb + (16 * t + j) * kActPitch + 16 * ft + 4 * g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int u = 0; u < 3; ++u) o[t][u] = mfma16(wv[u][r], xv[t][r], o[t][u]);
+  }
+#pragma unroll
+  for (int t = 0; t < RT; ++t)
+    if (valid[t]) {
+#pragma unroll
+      for (int u = 0; u < 3; ++u) *reinterpret_cast<f32x4*>(a.gi + (int64_t)row[t] * (3 * OPE_H) + 16 * (3 * wave + u) + 4 * g) = o[t][u];
+    }
+}
+
+template <int VEC, bool SAVE>
+static int launch2(const TrunkFwdArgs& a, hipStream_t st) {
+  static const int forced = getenv("OPE_TRUNK_RT") ? atoi(getenv("OPE_TRUNK_RT")) : 0;
+  const int KC = (a.D + 15) >> 4;
+  const int Dp = 16 * KC + 4;
+  // measured: 16-row workgroups win at QMIX sizes (3s5z, 38 k rows: 0.544 vs 0.562 ms/step), 32-row ones at the recurrent
+  // MADDPG sizes (MMM2 B=128, 230 k rows: 3.51 vs 3.62 ms/step) where the weight re-reads per workgroup start to matter
+  const bool two = forced ? forced == 2 : a.R >= 65536;
+  const int TR = two ? 32 : 16;
+  const size_t lds = (size_t)(TR * Dp + TR * kActPitch + 4 * TR) * sizeof(float);
+  if (two)
+    hipLaunchKernelGGL((trunk_fwd2_kernel<VEC, 2, SAVE>), dim3(ope_cdiv(a.R, 32)), dim3(256), lds, st, a, Dp);
+  else
+    hipLaunchKernelGGL((trunk_fwd2_kernel<VEC, 1, SAVE>), dim3(ope_cdiv(a.R, 16)), dim3(256), lds, st, a, Dp);
+  if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
+  return OPE_OK;
+}
+
+int launch_trunk_fwd2(const TrunkFwdArgs& a, bool save, hipStream_t st) {
+  if (a.R < 1 || a.D < 1 || a.D > 512) return OPE_EINVAL;
+  const int vec = ope_vec_of(a.D);
+  if (save) {
+    if (vec == 4) return launch2<4, true>(a, st);
+    if (vec == 2) return launch2<2, true>(a, st);
+    return launch2<1, true>(a, st);
+  }
+  if (vec == 4) return launch2<4, false>(a, st);
+  if (vec == 2) return launch2<2, false>(a, st);
+  return launch2<1, false>(a, st);
+}
+
+}  // namespace ope

@@ -20,7 +20,7 @@ namespace ope {
 // the four consecutive outputs C[m0+16g+4r+mi][n0+4i .. +3]: float4 stores.
 // VEC4 = every problem's lda / ldb is a multiple of 4 (then rows are 16-byte aligned); otherwise 4 scalar loads.
 template <bool VEC4>
-__global__ void __launch_bounds__(256) wgrad_kernel(WgTable tb, float* __restrict__ raw) {
+__global__ void __launch_bounds__(256, 3) wgrad_kernel(WgTable tb, float* __restrict__ raw) {
   __shared__ __attribute__((aligned(16))) float red[3][17][64][4];   // partial tiles of waves 1..3: [quad][lane][4]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, g = lane >> 4;
@@ -96,17 +96,30 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgTable tb, float* __restric
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16(av[mi], bv[ni], acc[mi][ni]);
   };
-  // ping-pong buffers, loop unrolled by two (no register copies for the compiler to fold the prefetch into)
-  Rawv bufA, bufB;
-  fetch(k0, bufA);
-  for (int kb = k0; kb < k1; kb += 8) {
-    fetch(kb + 4, bufB);
-    __builtin_amdgcn_sched_barrier(0);   // pin: these loads issue BEFORE the MFMAs of the other buffer
-    compute(bufA, kb);
+  // Four-deep ring of operand buffers, loop unrolled by four: three fetches (12 loads per lane) stay in flight behind
+  // every MFMA group. With ~2 waves per SIMD at these problem sizes the loop is bound by memory latency, not by the
+  // matrix pipe, so prefetch depth is what sets the speed. The sched_barriers pin each fetch BEFORE the MFMAs of the
+  // buffer being consumed (the compiler otherwise sinks the loads next to their uses).
+  Rawv b0, b1, b2, b3;
+  fetch(k0, b0);
+  fetch(k0 + 4, b1);
+  fetch(k0 + 8, b2);
+  for (int kb = k0; kb < k1; kb += 16) {
+    fetch(kb + 12, b3);
     __builtin_amdgcn_sched_barrier(0);
-    fetch(kb + 8, bufA);
+    compute(b0, kb);
     __builtin_amdgcn_sched_barrier(0);
-    compute(bufB, kb + 4);   // rows >= k1 are masked to zero
+    fetch(kb + 16, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(b1, kb + 4);   // rows >= k1 are masked to zero
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(kb + 20, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(b2, kb + 8);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(kb + 24, b2);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(b3, kb + 12);
     __builtin_amdgcn_sched_barrier(0);
   }
 

@@ -81,7 +81,7 @@ class MlpPolicyBuffer(object):
         obs, share, acts, rew, dones, dones_env, avail = self._ep.sample_inds(inds, timing_events=timing_events)
         # the episode gather returns [N, T(+1), B, dim] views of [T(+1), N, B, dim] memory; T = 1 here
         valid = torch.empty((1, self.num_agents, B, 1), dtype=torch.float32, device=self.device)
-        dev_inds = torch.from_numpy(inds).to(self.device)
+        dev_inds = self._ep._upload_inds(inds)
         sf, of = self._only_dones(self.valid_transition), self._only_dones(valid)
         _lib.check(_lib.lib.ope_store_gather(C.byref(self._ep.dims), self.buffer_size, C.byref(sf), _lib.ptr(dev_inds), B,
                                              C.byref(of), _lib.current_stream()), "ope_store_gather")

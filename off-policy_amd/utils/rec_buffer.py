@@ -67,6 +67,28 @@ class RecPolicyBuffer(object):
             self._stats = torch.zeros(4, **z)
             self._stats_scratch = torch.empty(int(_lib.lib.ope_reward_stats_scratch_bytes()), dtype=torch.uint8, device=self.device)
 
+    def _upload_inds(self, inds):
+        """Episode indices -> device without stalling the host: a pageable `.to(device)` is a synchronous copy that makes
+        the host wait for all queued GPU work every step. Instead the indices go through a small ring of pinned staging
+        buffers with asynchronous copies; a slot is reused only after its previous copy has completed."""
+        B = int(inds.shape[0])
+        ring = getattr(self, "_ind_ring", None)
+        if ring is None or ring[0][0].numel() < B:
+            n = max(B, 256)
+            ring = [(torch.empty(n, dtype=torch.int64).pin_memory(), torch.cuda.Event()) for _ in range(8)]
+            self._ind_ring, self._ind_slot, self._ind_used = ring, 0, [False] * 8
+        k = self._ind_slot
+        self._ind_slot = (k + 1) % len(ring)
+        host, ev = ring[k]
+        if self._ind_used[k]:
+            ev.synchronize()
+        host[:B].copy_(torch.from_numpy(inds))
+        dev = torch.empty(B, dtype=torch.int64, device=self.device)
+        dev.copy_(host[:B], non_blocking=True)
+        ev.record()
+        self._ind_used[k] = True
+        return dev
+
     def reward_stats(self):
         """Device tensor [mean, std, count, 0] of the rewards currently stored (rec_buffer.py:209-220); recomputed after
         every insert, on the device, without a host round trip."""
@@ -132,7 +154,7 @@ class RecPolicyBuffer(object):
         B = int(inds.shape[0])
         d = self.dims
         T, N = d.episode_length, d.n_agents
-        dev_inds = torch.from_numpy(inds).to(self.device)
+        dev_inds = self._upload_inds(inds)
         e = dict(dtype=torch.float32, device=self.device)
         out = dict(obs=torch.empty((T + 1, N, B, d.obs_dim), **e), share_obs=torch.empty((T + 1, B, d.state_dim), **e),
                    acts=torch.empty((T, N, B, d.act_dim), **e), rewards=torch.empty((T, N, B, 1), **e),

@@ -105,3 +105,27 @@ def test_segment_trees_against_bruteforce():
         assert np.array_equal(got, np.minimum(want, cap - 1))
     with pytest.raises(AssertionError):
         SumSegmentTree(48)
+
+
+def test_runner_hook_redirects_reference_imports():
+    """after install(), the import statements the reference's runners execute resolve to the engine."""
+    import importlib
+    import sys
+    import offpolicy_amd.runner_hook as hook
+    before = {k: sys.modules.get(k) for k in hook.MODULE_MAP}
+    try:
+        done = hook.install(only=("qmix", "rmatd3"))
+        assert "offpolicy.algorithms.qmix.qmix" in done and "offpolicy.algorithms.maddpg.maddpg" not in done
+        from offpolicy_amd.algorithms.qmix.qmix import QMix
+        from offpolicy_amd.utils.rec_buffer import PrioritizedRecReplayBuffer
+        assert importlib.import_module("offpolicy.algorithms.qmix.qmix").QMix is QMix
+        assert importlib.import_module("offpolicy.utils.rec_buffer").PrioritizedRecReplayBuffer is PrioritizedRecReplayBuffer
+        m = importlib.import_module("offpolicy.algorithms.r_matd3.algorithm.rMATD3Policy")
+        assert m.R_MATD3Policy.__module__.startswith("offpolicy_amd")
+        hook.install()          # everything: every mapped module must import
+        for ref_name in hook.MODULE_MAP:
+            assert sys.modules[ref_name].__name__.startswith("offpolicy_amd"), ref_name
+    finally:
+        hook.uninstall()
+    for k, v in before.items():
+        assert sys.modules.get(k) is v
