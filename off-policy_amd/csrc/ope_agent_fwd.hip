@@ -355,7 +355,8 @@ __global__ void __launch_bounds__(256) gru_fwd_kernel(GruFwdArgs a) {
 int launch_gru_fwd(const GruFwdArgs& a, hipStream_t st) {
   if (a.nets < 1 || a.nets > 2 || a.NB < 1 || a.L < 1) return OPE_EINVAL;
   const int64_t rows = (int64_t)a.nets * a.NB;
-  if (rows * 4 <= 1280) {   // few rows: four waves per row
+  static const int forced_wpr = getenv("OPE_GRU_WPR") ? atoi(getenv("OPE_GRU_WPR")) : 0;
+  if (forced_wpr ? forced_wpr == 4 : rows <= 512) {   // up to two workgroups per CU: four waves per row (3s5z, 512 rows: 82 vs 87 us)
     hipLaunchKernelGGL(gru_fwd_kernel<4>, dim3(rows), dim3(256), 0, st, a);
   } else {
     hipLaunchKernelGGL(gru_fwd_kernel<2>, dim3(ope_cdiv(rows, 2)), dim3(256), 0, st, a);

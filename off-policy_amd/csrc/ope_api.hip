@@ -99,8 +99,11 @@ void make_plan(const ope_qmix_cfg* c, Plan* p) {
   w.E = take(p->A * OPE_H); w.sq = take(p->A4);
   w.agent_end = o;
   w.mixer_size = c->vdn ? 0 : (p->ML.end - p->AL.end);
-  p->ns_agent = clampi(ope_cdiv(p->R1, 300), 1, 128);
-  p->ns_mixer = clampi(ope_cdiv(p->TB, 150), 1, 64);
+  // K-splits: every wave reduces ~160 rows whatever the problem, so workgroups are equally long and spread evenly over
+  // the CUs (multiples of 4: the four waves of a workgroup hold consecutive splits and pre-reduce them)
+  auto splits_for = [](int64_t K, int cap) { int s = (int)((K + 159) / 160); s = s >= 4 ? ((s + 3) / 4) * 4 : s; return clampi(s, 1, cap); };
+  p->ns_agent = splits_for(p->R1, 256);
+  p->ns_mixer = splits_for(p->TB, 64);
   p->n_loss_tiles = ope_cdiv(p->TB, 16);
   // time chunks: boundaries on multiples of 8 steps (the scans prefetch in 8-step groups); short episodes stay whole
   {

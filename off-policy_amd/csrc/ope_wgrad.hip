@@ -21,7 +21,7 @@ namespace ope {
 // VEC4 = every problem's lda / ldb is a multiple of 4 (then rows are 16-byte aligned); otherwise 4 scalar loads.
 template <bool VEC4>
 __global__ void __launch_bounds__(256, 3) wgrad_kernel(WgTable tb, float* __restrict__ raw) {
-  __shared__ __attribute__((aligned(16))) float red[3][17][64][4];   // partial tiles of waves 1..3: [quad][lane][4]
+  __shared__ __attribute__((aligned(16))) float red[2][17][64][4];   // two partial-tile slots: [quad][lane][4]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, g = lane >> 4;
   const int wid = blockIdx.x * 4 + wave;
@@ -128,28 +128,35 @@ __global__ void __launch_bounds__(256, 3) wgrad_kernel(WgTable tb, float* __rest
   // tb.wg_reduce): sum them here in a fixed order and write one slab instead of four.
   int slab = split;
   if (tb.wg_reduce) {
-    if (wave > 0) {
+    // two-level tree through a 2-slot buffer (35 KB of LDS instead of 52 KB: one more workgroup per CU):
+    //   waves 2,3 publish | waves 0,1 add (w0 += w2, w1 += w3) | wave 1 publishes | wave 0 adds, writes the slab
+    auto publish = [&](int slot) {
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          *reinterpret_cast<f32x4*>(red[wave - 1][mi * 4 + r][lane]) = f32x4{acc[mi][0][r], acc[mi][1][r], acc[mi][2][r], acc[mi][3][r]};
-      *reinterpret_cast<f32x4*>(red[wave - 1][16][lane]) = cs;
-    }
-    __syncthreads();
-    if (wave > 0) return;
-#pragma unroll
-    for (int w2 = 0; w2 < 3; ++w2) {
+          *reinterpret_cast<f32x4*>(red[slot][mi * 4 + r][lane]) = f32x4{acc[mi][0][r], acc[mi][1][r], acc[mi][2][r], acc[mi][3][r]};
+      *reinterpret_cast<f32x4*>(red[slot][16][lane]) = cs;
+    };
+    auto absorb = [&](int slot) {
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(red[w2][mi * 4 + r][lane]);
+          const f32x4 v = *reinterpret_cast<const f32x4*>(red[slot][mi * 4 + r][lane]);
 #pragma unroll
           for (int ni = 0; ni < 4; ++ni) acc[mi][ni][r] += v[ni];
         }
-      cs += *reinterpret_cast<const f32x4*>(red[w2][16][lane]);
-    }
+      cs += *reinterpret_cast<const f32x4*>(red[slot][16][lane]);
+    };
+    if (wave >= 2) publish(wave - 2);
+    __syncthreads();
+    if (wave < 2) absorb(wave);
+    __syncthreads();
+    if (wave == 1) publish(0);
+    __syncthreads();
+    if (wave > 0) return;
+    absorb(0);
     slab = split >> 2;
   }
   float* out = raw + P.raw_base + (int64_t)slab * P.raw_stride;
