@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--episodes", type=int, default=256, help="synthetic episodes resident in the replay store")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="MLP MADDPG/MATD3: launch the ~45 kernels of an update one by one instead "
+                    "of replaying the captured HIP graph")
     ap.add_argument("--host-noise", action="store_true", help="MADDPG family: draw the gumbel noise on the reference's CPU generator "
                     "stream (what the parity tests use) instead of on the device")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="budget for each CPU-baseline leg")
@@ -319,8 +321,13 @@ def main_ddpg(a):
     pbuf = buf.policy_buffers["policy_0"]
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
 
+    use_graph = world == 1 and not a.no_graph and not a.host_noise
+    graphed = trainer.make_graphed_step(buf, local_batch) if use_graph else None
+
     def one_step(i=None):
         inds = np.random.choice(len(buf), local_batch)
+        if graphed is not None:
+            return graphed(inds)           # gather + critic update + actor update + soft target updates: one graph launch
         s = pbuf.sample_inds(inds, timing_events=ev[i] if i is not None else None)
         info, _, _ = trainer.shared_train_policy_on_batch("policy_0", tuple({"policy_0": x} for x in s) + (None, None))
         policy.soft_target_updates()
@@ -344,6 +351,11 @@ def main_ddpg(a):
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt[0])
+    if graphed is not None:    # the gather inside the graph cannot carry events: time the same launch on its own afterwards
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(50)]
+        for e in ev:
+            pbuf.sample_inds(np.random.choice(len(buf), local_batch), timing_events=e)
+        torch.cuda.synchronize()
     gather_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
     assert np.isfinite(float(info["critic_loss"]))
     if rank == 0:
@@ -359,8 +371,9 @@ def main_ddpg(a):
                "dtype": "f32", "data": "synthetic",
                "config": {"workload": "%s-MLP MPE simple_spread (N=%d A=%d D=%d S=%d), replay filled with %d synthetic transitions, "
                                       "step = sample + critic update + actor update + soft target updates; reference semantics "
-                                      "(frozen critic heads A-4, actor updated every call A-5); gumbel noise drawn on the %s" % (
-                                          "MATD3" if td3 else "MADDPG", N, A, D, S, cap, "host (reference stream)" if a.host_noise else "device"),
+                                      "(frozen critic heads A-4, actor updated every call A-5); gumbel noise drawn on the %s; %s" % (
+                                          "MATD3" if td3 else "MADDPG", N, A, D, S, cap, "host (reference stream)" if a.host_noise else "device",
+                                          "whole update replayed as one captured HIP graph" if use_graph else "kernels launched one by one"),
                           "batch_per_gpu": local_batch, "global_batch": global_batch, "parallelism": "dp%d" % world,
                           "optimizer_steps_per_sec": round(steps_per_s, 2)},
                "roofline": {"kernel": "episode_copy_kernel<gather> (transition gather)", "bound": "hbm", "achieved": round(algo / (gather_ms * 1e-3) / 1e9, 3),

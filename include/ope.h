@@ -169,6 +169,9 @@ typedef struct ope_adam_cfg {
   int32_t tail_offset;    /* index of the 4-float tail inside `grad`; <= 0 means n. Lets a PREFIX of a parameter vector
                            * be optimised (n < full length) while the tail stays behind the full gradient: MADDPG's
                            * critic, whose q heads are unregistered upstream (SURVEY A-4) and therefore frozen.     */
+  int32_t* step_counter;  /* optional DEVICE int32 holding the number of Adam steps taken so far. When non-NULL, `step` is
+                           * ignored: the call increments the counter on the device and uses the new value as t, so a
+                           * captured HIP graph of the update can be replayed with advancing bias correction.          */
 } ope_adam_cfg;
 int64_t ope_adam_scratch_floats(int64_t n);
 int ope_adam_step(const ope_adam_cfg* cfg, int64_t n, float* theta, float* theta_tgt, float* adam_m, float* adam_v,

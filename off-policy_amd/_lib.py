@@ -40,7 +40,8 @@ class QmixCfg(C.Structure):
 class AdamCfg(C.Structure):
     _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
                 ("max_grad_norm", C.c_float), ("weight_decay", C.c_float), ("tau", C.c_float),
-                ("do_polyak", C.c_int32), ("step", C.c_int32), ("qtot_denominator", C.c_float), ("tail_offset", C.c_int32)]
+                ("do_polyak", C.c_int32), ("step", C.c_int32), ("qtot_denominator", C.c_float), ("tail_offset", C.c_int32),
+                ("step_counter", C.c_void_p)]
 
 
 class DdpgCfg(C.Structure):

@@ -119,6 +119,9 @@ class MADDPGPolicy(object):
                                        float(tau), st), "ope_polyak")
 
     def soft_target_updates(self):
+        if getattr(self, "_polyak_done", False):     # already applied inside the trainer's Adam kernels for this update
+            self._polyak_done = False
+            return
         self._polyak(self.args.tau)
 
     def hard_target_updates(self):

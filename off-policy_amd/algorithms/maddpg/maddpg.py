@@ -39,6 +39,8 @@ class MADDPG(object):
         self.actor_update_interval = actor_update_interval
         self.count_updates = bool(count_updates)
         self.device_noise = False     # True: gumbel noise drawn on the device instead of the reference's CPU generator stream
+        self.fuse_soft_update = False  # True: Polyak of both target nets inside the Adam kernels; the next
+                                       # policy.soft_target_updates() call is then skipped (same values, two launches fewer)
         self._ws, self._grads = {}, {}
 
     def _workspace(self, policy, cfg):
@@ -72,8 +74,11 @@ class MADDPG(object):
         opt.step_count += 1
         ac = _lib.AdamCfg()
         ac.lr, ac.beta1, ac.beta2, ac.eps = opt.lr, opt.betas[0], opt.betas[1], opt.eps
-        ac.max_grad_norm, ac.weight_decay, ac.tau, ac.do_polyak = float(self.args.max_grad_norm), 0.0, 0.0, 0
+        ac.max_grad_norm, ac.weight_decay = float(self.args.max_grad_norm), 0.0
+        ac.tau, ac.do_polyak = (float(self.args.tau), 1) if self.fuse_soft_update else (0.0, 0)
         ac.step, ac.qtot_denominator, ac.tail_offset = opt.step_count, 1.0, int(tail)
+        if opt.step_dev is not None:
+            ac.step_counter = _lib.ptr(opt.step_dev).value
         stats = torch.empty(4, **self.tpdv)
         _lib.check(_lib.lib.ope_adam_step(C.byref(ac), int(n), _lib.ptr(flat), _lib.ptr(flat_tgt), _lib.ptr(opt.exp_avg),
                                           _lib.ptr(opt.exp_avg_sq), _lib.ptr(grad), _lib.ptr(scratch), _lib.ptr(stats),
@@ -127,10 +132,72 @@ class MADDPG(object):
                              scratch, policy.actor.padded_numel)
             train_info["actor_loss"], train_info["actor_grad_norm"] = as_[0], as_[1]
             train_info["update_actor"] = update_actor
+        elif self.fuse_soft_update:      # no actor step this time: its target still takes its Polyak step
+            _lib.check(_lib.lib.ope_polyak(policy.actor.padded_numel, _lib.ptr(policy.actor._flat), _lib.ptr(policy.target_actor._flat),
+                                           float(self.args.tau), st), "ope_polyak")
+        if self.fuse_soft_update:
+            policy._polyak_done = True
         if self.count_updates:
             self.num_updates[pid] += 1
         self._last = (obs, cent, acts, rew, nobs, ncent, dones_env, valid, avail, navail, u_t, w)
         return train_info, new_priorities, idxes
+
+    def make_graphed_step(self, buffer, batch_size, policy_id="policy_0"):
+        """One whole update -- gather of `batch_size` transitions, critic update, actor update, soft target updates -- captured
+        once as a HIP graph and replayed with one launch per step. This path is ~45 kernels of a few microseconds each:
+        eagerly it is bound by launch latency and host work, not by the GPU (csrc/ope_ddpg.hip). Returns
+        `step(inds) -> train_info` where `inds` are the transition indices to train on (numpy int64 [batch_size], e.g.
+        np.random.choice(len(buffer), batch_size)) and train_info holds device tensors overwritten by every replay.
+        Restrictions: uniform replay (no PER: priorities need the host tree), one process (no gradient all-reduce inside the
+        graph), gumbel noise drawn on the device (`device_noise`), the Adam step counters live on the device."""
+        if self.use_per or opdist.is_distributed():
+            raise NotImplementedError("graphed step: uniform replay on a single GPU only")
+        pid = policy_id
+        policy, pbuf = self.policies[pid], buffer.policy_buffers[pid]
+        B = int(batch_size)
+        self.device_noise = True
+        self.fuse_soft_update = True
+        for opt in (policy.critic_optimizer, policy.actor_optimizer):
+            opt.step_dev = torch.tensor([opt.step_count], dtype=torch.int32, device=self.device)
+        static_inds = torch.zeros(B, dtype=torch.int64, device=self.device)
+
+        def body():
+            s = pbuf.sample_inds(static_inds)
+            info, _, _ = self.shared_train_policy_on_batch(pid, tuple({pid: x} for x in s) + (None, None))
+            policy.soft_target_updates()
+            return info
+        side = torch.cuda.Stream(device=self.device)     # warm-up off the capture: workspaces, allocator pools, lazy init
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            static_inds.copy_(torch.from_numpy(np.random.choice(len(buffer), B)).to(self.device))
+            for _ in range(2):
+                body()
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            info = body()
+        for opt in (policy.critic_optimizer, policy.actor_optimizer):      # capture ran the host code but no kernels
+            opt.step_count = int(opt.step_dev.item())
+        ring = [(torch.empty(B, dtype=torch.int64).pin_memory(), torch.cuda.Event()) for _ in range(8)]
+        state = {"k": 0, "used": [False] * 8}
+
+        def step(inds):
+            k = state["k"]
+            state["k"] = (k + 1) % 8
+            host, ev = ring[k]
+            if state["used"][k]:
+                ev.synchronize()
+            host.copy_(torch.from_numpy(np.asarray(inds, dtype=np.int64)))
+            static_inds.copy_(host, non_blocking=True)
+            ev.record()
+            state["used"][k] = True
+            graph.replay()
+            for opt in (policy.critic_optimizer, policy.actor_optimizer):
+                opt.step_count += 1
+            return info
+        self._graph = (graph, static_inds, ring)      # keep alive
+        return step
 
     def prep_training(self):
         pass

@@ -31,6 +31,7 @@ class FlatAdam(object):
         self.exp_avg = torch.zeros(numel, dtype=torch.float32, device=device)
         self.exp_avg_sq = torch.zeros(numel, dtype=torch.float32, device=device)
         self.step_count = 0
+        self.step_dev = None        # device int32 step counter (HIP-graph replays); None = host-side `step_count`
 
     def zero_grad(self):
         pass

@@ -14,6 +14,8 @@ struct TrunkFwdArgs {
   AgentLayout L;
   float* gi;           // [R][192]  W_ih a2 + b_ih (recurrent nets)
   float* a2_out;       // [R][64]   trunk output (LN2 output) -- MLP nets: written instead of gi when non-null
+  float* head_out;     // MLP nets, optional: [R][head_dim] = W_head a2 + b_head (L.q_w / L.q_b) fused into the same launch
+  int head_dim;        //   (head_dim <= 16; the small MADDPG-family heads)
   // saved for backward (live net only)
   float* mu0;          // [R] input-LN mean
   float* rstd0;        // [R] input-LN 1/std
@@ -92,6 +94,8 @@ struct TrunkBwdArgs {
   AgentLayout L;
   const float* dgi;    // [R][192]
   const float* da2_in; // MLP nets: adjoint of the trunk output given directly (dgi unused)
+  const float* dout;   // MLP nets, optional instead of da2_in: adjoint of the Linear head's output [R][ldk]; the trunk-output
+  int ldk, hdim;       //   adjoint da2 = dout W_head (L.q_w, [hdim][64]) is then formed in-kernel
   const float* xhat1; const float* rstd1; const uint64_t* mask1;
   const float* xhat2; const float* rstd2; const uint64_t* mask2;
   float* dz1; float* dz2;  // [R][64]

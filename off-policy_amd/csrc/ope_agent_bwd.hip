@@ -268,11 +268,21 @@ __global__ void __launch_bounds__(256) trunk_bwd_kernel(TrunkBwdArgs a) {
   if (a.da2_in) {
 #pragma unroll
     for (int it = 0; it < 4; ++it) d[it] = *reinterpret_cast<const f32x4*>(a.da2_in + rr * OPE_H + 16 * it + 4 * g);
+  } else if (a.dout) {   // da2 = dout W_head, a handful of FMAs per feature (small heads)
+    for (int k = 0; k < a.hdim; ++k) {
+      const float dk = a.dout[rr * a.ldk + k];
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(a.theta + a.L.q_w + (int64_t)k * OPE_H + 16 * it + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d[it][r] = fmaf(dk, w[r], d[it][r]);
+      }
+    }
   }
   const float* grow = a.dgi ? a.dgi + rr * (3 * OPE_H) : nullptr;
 #pragma unroll
   for (int c = 0; c < 12; ++c) {
-    if (a.da2_in) break;
+    if (a.da2_in || a.dout) break;
     f32x4 bv = *reinterpret_cast<const f32x4*>(grow + 16 * c + 4 * g);
     if (!valid) bv = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll

@@ -5,6 +5,7 @@
 //   gru_fwd   : per (agent,episode) row, serial over t: h_t = GRU(gi_t, h_{t-1})                (one wave per row)
 //   head_fwd  : per data row   LN(h_t) -> q = W_q y + b_q, chosen-action q, masked greedy argmax, target q at greedy
 #include <stdlib.h>
+#include <string.h>
 
 #include "ope_agent.h"
 
@@ -198,7 +199,19 @@ int launch_trunk_fwd(const TrunkFwdArgs& a, bool save, hipStream_t st) {
   if (a.R < 1 || a.D < 1) return OPE_EINVAL;
   // default: the workgroup-cooperative form; OPE_TRUNK2=0 selects the one-wave-per-row-tile form below (A/B runs)
   static const int v2 = getenv("OPE_TRUNK2") ? atoi(getenv("OPE_TRUNK2")) : 1;
+  if (a.head_out && (!a.a2_out || a.head_dim < 1 || a.head_dim > 16)) return OPE_EINVAL;
   if (v2 && a.D <= 512) return launch_trunk_fwd2(a, save, st);
+  if (a.head_out) {   // one-wave form: the head is a second launch
+    TrunkFwdArgs b = a;
+    b.head_out = nullptr;
+    int rc = launch_trunk_fwd(b, save, st);
+    if (rc) return rc;
+    HeadFwdArgs hf;
+    memset(&hf, 0, sizeof(hf));
+    hf.R = a.R; hf.NB = a.R; hf.B = a.R; hf.N = 1; hf.T = 1; hf.A = a.head_dim; hf.theta0 = a.theta; hf.theta1 = a.theta; hf.L = a.L;
+    hf.h0 = a.a2_out; hf.q_out = a.head_out; hf.no_ln = 1;
+    return launch_head_fwd(hf, 1, st);
+  }
   const int vec = ope_vec_of(a.D);
   if (save) {
     if (vec == 4) return launch_trunk_vec<4, true>(a, st);

@@ -18,14 +18,6 @@ struct CriticTdArgs {
   float* loss_part;                          // [tiles][4]
 };
 
-struct InGradArgs {
-  int R, D;
-  const float* dz1;                          // [R][64]
-  const float* fc1_w; const float* gamma;    // [64][D], [D]
-  const float* x; const float* mu0; const float* rstd0;
-  float* dx;                                 // [R][D]
-};
-
 // Fused "critic input gradient restricted to the updating agent's action block" + straight-through gumbel adjoint.
 struct ActGradArgs {
   int R, B, N, A, A4, S, Din;
@@ -45,8 +37,5 @@ int launch_build_cin(const float* cent, const float* acts, const float* repl, in
                      hipStream_t st);
 int launch_action(const float* logits, const float* avail, const float* U, int rows, int B, int A, int N, int mode, int t_shift,
                   float* cent_nact, float* act_out, float* soft_out, hipStream_t st);
-int launch_input_grad(const InGradArgs& ig, hipStream_t st);
-int launch_gumbel_bwd(const float* dx, int Din, int S, const float* y, int rows, int B, int A, int A4, int N, float* dlogits,
-                      hipStream_t st);
 
 }  // namespace ope

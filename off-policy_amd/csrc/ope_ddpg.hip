@@ -179,74 +179,6 @@ __global__ void __launch_bounds__(256) actor_obj_kernel(const float* __restrict_
   }
 }
 
-// da2[row][f] = sum_k dout[row][k] * W[k][f]   (adjoint of a Linear(64 -> K) head w.r.t. its input)
-__global__ void __launch_bounds__(256) head_in_grad_kernel(const float* __restrict__ dout, int ldk, int K, const float* __restrict__ W,
-                                                            int rows, float* __restrict__ da2) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (int64_t)rows * OPE_H) return;
-  const int r = (int)(i / OPE_H), f = (int)(i - (int64_t)r * OPE_H);
-  float s = 0.f;
-  for (int k = 0; k < K; ++k) s = fmaf(dout[(int64_t)r * ldk + k], W[(int64_t)k * OPE_H + f], s);
-  da2[i] = s;
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Gradient w.r.t. the trunk INPUT (needed by the actor update: the critic is differentiated w.r.t. the action part of
-// its input, maddpg.py:225-236). One wave per row; lane <-> input feature k (strided):
-//   dxn[k] = sum_i fc1_w[i][k] dz1[i] ;  dyh = dxn*gamma ;  dx = rstd (dyh - mean(dyh) - xhat mean(dyh xhat))
-// ---------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) input_grad_kernel(InGradArgs a) {
-  __shared__ float dz[4][OPE_H];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int row = blockIdx.x * 4 + wave;
-  const bool ok = row < a.R;
-  const int rr = ok ? row : a.R - 1;
-  dz[wave][lane] = a.dz1[(int64_t)rr * OPE_H + lane];
-  __builtin_amdgcn_wave_barrier();
-  const float mu = a.mu0[rr], rs = a.rstd0[rr];
-  const float* xr = a.x + (int64_t)rr * a.D;
-  float m1 = 0.f, m2 = 0.f;
-  for (int k = lane; k < a.D; k += 64) {
-    float s = 0.f;
-#pragma unroll 8
-    for (int i = 0; i < OPE_H; ++i) s = fmaf(a.fc1_w[(int64_t)i * a.D + k], dz[wave][i], s);
-    const float dy = s * a.gamma[k];
-    const float xh = (xr[k] - mu) * rs;
-    m1 += dy;
-    m2 = fmaf(dy, xh, m2);
-  }
-  for (int o = 32; o > 0; o >>= 1) {
-    m1 += __shfl_xor(m1, o, 64);
-    m2 += __shfl_xor(m2, o, 64);
-  }
-  m1 /= (float)a.D;
-  m2 /= (float)a.D;
-  if (!ok) return;
-  for (int k = lane; k < a.D; k += 64) {
-    float s = 0.f;
-#pragma unroll 8
-    for (int i = 0; i < OPE_H; ++i) s = fmaf(a.fc1_w[(int64_t)i * a.D + k], dz[wave][i], s);
-    const float dy = s * a.gamma[k];
-    const float xh = (xr[k] - mu) * rs;
-    a.dx[(int64_t)row * a.D + k] = rs * (dy - m1 - xh * m2);
-  }
-}
-
-// Straight-through hard gumbel-softmax adjoint (util.py:210-213: out = (y_hard - y).detach() + y): the gradient goes
-// through the soft sample y = softmax(.): dlogit_j = y_j (dy_j - sum_m dy_m y_m). dy is the action block of agent
-// `rep = row / B` inside the critic-input gradient dx[row][S + rep*A + j].
-__global__ void gumbel_bwd_kernel(const float* __restrict__ dx, int Din, int S, const float* __restrict__ y, int rows, int B, int A,
-                                  int A4, int N, float* __restrict__ dlogits) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= rows) return;
-  const int rep = (r / B) % N;   // rows are (t, agent, b)
-  const float* dy = dx + (int64_t)r * Din + S + rep * A;
-  const float* yy = y + (int64_t)r * A;
-  float dot = 0.f;
-  for (int j = 0; j < A; ++j) dot = fmaf(dy[j], yy[j], dot);
-  for (int j = 0; j < A4; ++j) dlogits[(int64_t)r * A4 + j] = j < A ? yy[j] * (dy[j] - dot) : 0.f;
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // Actor update, critic side, fused: the actor only needs d(loss)/d(action block of "its" agent) of the critic input,
 // so the full input gradient dx [R][Din] is never formed. With dy_k = gamma_k sum_i W_ik dz_i (k over ALL inputs) the
@@ -314,6 +246,39 @@ __global__ void __launch_bounds__(256) action_grad_kernel(ActGradArgs a) {
   for (int j = 0; j < a.A4; ++j) out[j] = j < a.A ? a.y[(int64_t)r * a.A + j] * (out[j] - dot) : 0.f;
 }
 
+// Same computation, one wave per row: lane i owns hidden unit i, the 2 + A dot products over the 64 units are wave
+// reductions. Used when there are too few rows for the thread-per-row form to fill the machine.
+__global__ void __launch_bounds__(256) action_grad_wave_kernel(ActGradArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= a.R) return;
+  const int rep = (r / a.B) % a.N;
+  const float rs1 = a.rstd1[r], rs0 = a.rstd0[r], mu0 = a.mu0[r];
+  const float dz = a.dz1[(int64_t)r * OPE_H + lane];
+  const float z1 = a.xhat1[(int64_t)r * OPE_H + lane] / rs1 + a.mu1[r];
+  float m1 = dz * a.cvec[lane], m2 = dz * (z1 - a.cvec[OPE_H + lane]);
+  for (int o = 32; o > 0; o >>= 1) {
+    m1 += __shfl_xor(m1, o, 64);
+    m2 += __shfl_xor(m2, o, 64);
+  }
+  const float invD = 1.0f / (float)a.Din;
+  m1 *= invD;
+  m2 *= invD;
+  const int col0 = a.S + rep * a.A;
+  const float* W = a.theta + a.fc1_w + (int64_t)lane * a.Din + col0;
+  float mine = 0.f, dot = 0.f;   // lane j (< A) keeps dx_j
+  for (int j = 0; j < a.A; ++j) {
+    float s = W[j] * dz;
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float dy = s * a.theta[a.fn_w + col0 + j];
+    const float xh = (a.act[(int64_t)r * a.A + j] - mu0) * rs0;
+    const float dx = rs0 * (dy - m1 - xh * m2);
+    dot = fmaf(dx, a.y[(int64_t)r * a.A + j], dot);
+    if (lane == j) mine = dx;
+  }
+  if (lane < a.A4) a.dlogits[(int64_t)r * a.A4 + lane] = lane < a.A ? a.y[(int64_t)r * a.A + lane] * (mine - dot) : 0.f;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 static int launch1d(int64_t n) { return ope_cdiv(n, 256); }
 #define OPE_L(call)                                            \
@@ -339,16 +304,10 @@ int launch_action(const float* logits, const float* avail, const float* U, int r
 }
 int launch_action_grad(const ActGradArgs& a, hipStream_t st) {
   OPE_L(hipLaunchKernelGGL(fc1_colsum_kernel, dim3(OPE_H), dim3(64), 0, st, a));
-  OPE_L(hipLaunchKernelGGL(action_grad_kernel, dim3(launch1d(a.R)), dim3(256), 0, st, a));
-  return OPE_OK;
-}
-int launch_input_grad(const InGradArgs& ig, hipStream_t st) {
-  OPE_L(hipLaunchKernelGGL(input_grad_kernel, dim3(ope_cdiv(ig.R, 4)), dim3(256), 0, st, ig));
-  return OPE_OK;
-}
-int launch_gumbel_bwd(const float* dx, int Din, int S, const float* y, int rows, int B, int A, int A4, int N, float* dlogits,
-                      hipStream_t st) {
-  OPE_L(hipLaunchKernelGGL(gumbel_bwd_kernel, dim3(launch1d(rows)), dim3(256), 0, st, dx, Din, S, y, rows, B, A, A4, N, dlogits));
+  if (a.R <= 16384)   // few rows (MLP family): one wave per row, lane = hidden unit -- a 64-long serial chain per thread otherwise
+    OPE_L(hipLaunchKernelGGL(action_grad_wave_kernel, dim3(ope_cdiv(a.R, 4)), dim3(256), 0, st, a));
+  else
+    OPE_L(hipLaunchKernelGGL(action_grad_kernel, dim3(launch1d(a.R)), dim3(256), 0, st, a));
   return OPE_OK;
 }
 
@@ -385,7 +344,8 @@ static void ddpg_plan(const ope_ddpg_cfg* c, DdpgPlan* p) {
   p->P1 = take(OPE_H * Dmax); p->s1 = take(OPE_H); p->P2 = take(OPE_H * OPE_H); p->s2 = take(OPE_H);
   p->E = take(Hmax * OPE_H); p->sq = take(ope_round4(Hmax));
   p->raw_size_c = p->raw_size_a = o;
-  auto splits = [](int64_t rows) { int s = ope_cdiv(rows, 128); s = s < 1 ? 1 : (s > 64 ? 64 : s); return s >= 4 ? (s / 4) * 4 : s; };
+  auto splits = [](int64_t rows) { int s = ope_cdiv(rows, 32);   // short K per wave: these launches are latency-bound
+    s = s < 1 ? 1 : (s > 64 ? 64 : s); return s >= 4 ? (s / 4) * 4 : s; };
   p->ns_c = splits(p->B);
   p->ns_a = splits(p->Ra);
   Workspace& W = p->ws;
@@ -410,11 +370,12 @@ static void ddpg_plan(const ope_ddpg_cfg* c, DdpgPlan* p) {
 }
 
 // trunk forward in mlp mode on `rows` rows of width Dw; saves go to the plan's first save set unless `alt` is given
+// (+ the net's small Linear head fused into the same launch: head_out [rows][head_dim])
 static int trunk_mlp(const DdpgPlan& p, float* W, const float* x, int rows, int Dw, const float* theta, const AgentLayout& L,
-                     float* a2_out, bool save, float* alt, hipStream_t st) {
+                     float* a2_out, bool save, float* alt, float* head_out, int head_dim, hipStream_t st) {
   TrunkFwdArgs tf;
   memset(&tf, 0, sizeof(tf));
-  tf.x = x; tf.R = rows; tf.D = Dw; tf.theta = theta; tf.L = L; tf.a2_out = a2_out;
+  tf.x = x; tf.R = rows; tf.D = Dw; tf.theta = theta; tf.L = L; tf.a2_out = a2_out; tf.head_out = head_out; tf.head_dim = head_dim;
   if (save) {
     if (!alt) {
       tf.mu0 = W + p.mu0; tf.rstd0 = W + p.rstd0; tf.xhat1 = W + p.xhat1; tf.rstd1 = W + p.rstd1; tf.mask1 = (uint64_t*)(W + p.mask1);
@@ -429,21 +390,11 @@ static int trunk_mlp(const DdpgPlan& p, float* W, const float* x, int rows, int 
   return launch_trunk_fwd(tf, save, st);
 }
 
-static int linear_head(const float* a2, int rows, int Aout, const float* theta, const AgentLayout& L, float* out, hipStream_t st) {
-  HeadFwdArgs hf;
-  memset(&hf, 0, sizeof(hf));
-  hf.R = rows; hf.NB = rows; hf.B = rows; hf.N = 1; hf.T = 1; hf.A = Aout; hf.theta0 = theta; hf.theta1 = theta; hf.L = L;
-  hf.h0 = a2; hf.q_out = out; hf.no_ln = 1;
-  return launch_head_fwd(hf, 1, st);
-}
-
 // backward of one MLP net given d(head output) [rows][ldk]: da2 -> trunk_bwd -> weight gradients -> flat grad (+tail)
 static int mlp_backward(const DdpgPlan& p, float* W, const float* x, int rows, int Dw, int Hout, int ldk, const float* dout,
                         const float* theta, const AgentLayout& L, const float* saves_alt, int nsplit, int n_loss_tiles,
                         float* grad, hipStream_t st) {
   int rc;
-  OPE_L(hipLaunchKernelGGL(head_in_grad_kernel, dim3(launch1d((int64_t)rows * OPE_H)), dim3(256), 0, st, dout, ldk, Hout,
-                           theta + L.q_w, rows, W + p.da2));
   if ((rc = launch_transpose(theta + L.fc2_w, OPE_H, OPE_H, W + p.thetaT + OPE_H * 3 * OPE_H, st))) return rc;
   const float *mu0, *rstd0, *xhat1, *rstd1, *xhat2, *rstd2;
   const uint64_t *mask1, *mask2;
@@ -458,7 +409,7 @@ static int mlp_backward(const DdpgPlan& p, float* W, const float* x, int rows, i
   }
   TrunkBwdArgs tb;
   memset(&tb, 0, sizeof(tb));
-  tb.R = rows; tb.theta = theta; tb.thetaT = W + p.thetaT; tb.L = L; tb.da2_in = W + p.da2;
+  tb.R = rows; tb.theta = theta; tb.thetaT = W + p.thetaT; tb.L = L; tb.dout = dout; tb.ldk = ldk; tb.hdim = Hout;   // head adjoint fused
   tb.xhat1 = xhat1; tb.rstd1 = rstd1; tb.mask1 = mask1; tb.xhat2 = xhat2; tb.rstd2 = rstd2; tb.mask2 = mask2;
   tb.dz1 = W + p.dz1; tb.dz2 = W + p.dz2;
   if ((rc = launch_trunk_bwd(tb, st))) return rc;
@@ -572,8 +523,7 @@ extern "C" int ope_ddpg_critic_loss_and_grad(const ope_ddpg_cfg* cfg, const ope_
   float* W = (float*)workspace;
   int rc;
   // target actor on the next observations -> joint next action
-  if ((rc = trunk_mlp(p, W, bt->next_obs, p.Ra, p.D, theta_actor_tgt, p.AL, W + p.a2n, false, nullptr, st))) return rc;
-  if ((rc = linear_head(W + p.a2n, p.Ra, p.A, theta_actor_tgt, p.AL, W + p.lgn, st))) return rc;
+  if ((rc = trunk_mlp(p, W, bt->next_obs, p.Ra, p.D, theta_actor_tgt, p.AL, W + p.a2n, false, nullptr, W + p.lgn, p.A, st))) return rc;
   if ((rc = launch_action(W + p.lgn, bt->next_avail_acts, target_noise_u, p.Ra, p.B, p.A, p.N, cfg->target_gumbel ? 1 : 0, 0, W + p.cnact,
                           nullptr, nullptr, st))) return rc;
   // critic inputs
@@ -582,10 +532,8 @@ extern "C" int ope_ddpg_critic_loss_and_grad(const ope_ddpg_cfg* cfg, const ope_
   OPE_L(hipLaunchKernelGGL(build_cin_kernel, dim3(launch1d((int64_t)p.B * p.Din)), dim3(256), 0, st, bt->share_obs, bt->acts,
                            (const float*)nullptr, 1, p.B, p.N, p.A, p.S, 1, W + p.xin));
   // target critic, live critic
-  if ((rc = trunk_mlp(p, W, W + p.xin_t, p.B, p.Din, theta_critic_tgt, p.CL, W + p.a2t, false, nullptr, st))) return rc;
-  if ((rc = linear_head(W + p.a2t, p.B, p.K, theta_critic_tgt, p.CL, W + p.qt, st))) return rc;   // [B][K] (K4 == K when K%4==0)
-  if ((rc = trunk_mlp(p, W, W + p.xin, p.B, p.Din, theta_critic, p.CL, W + p.a2c, true, nullptr, st))) return rc;
-  if ((rc = linear_head(W + p.a2c, p.B, p.K, theta_critic, p.CL, W + p.qc, st))) return rc;
+  if ((rc = trunk_mlp(p, W, W + p.xin_t, p.B, p.Din, theta_critic_tgt, p.CL, W + p.a2t, false, nullptr, W + p.qt, p.K, st))) return rc;   // [B][K]
+  if ((rc = trunk_mlp(p, W, W + p.xin, p.B, p.Din, theta_critic, p.CL, W + p.a2c, true, nullptr, W + p.qc, p.K, st))) return rc;
   CriticTdArgs td;
   td.B = p.B; td.K = p.K; td.K4 = p.K; td.gamma = cfg->gamma; td.use_huber = cfg->use_huber; td.huber_delta = cfg->huber_delta;
   td.per_eps = cfg->per_eps; td.q = W + p.qc; td.q_tgt = W + p.qt; td.rewards = bt->rewards; td.dones_env = bt->dones_env;
@@ -608,16 +556,14 @@ extern "C" int ope_ddpg_actor_loss_and_grad(const ope_ddpg_cfg* cfg, const ope_m
   int rc;
   float* saves2 = W + p.err;
   // actor forward (saves -> alternate set) and straight-through hard gumbel sample
-  if ((rc = trunk_mlp(p, W, bt->obs, p.Ra, p.D, theta_actor, p.AL, W + p.a2a, true, saves2, st))) return rc;
-  if ((rc = linear_head(W + p.a2a, p.Ra, p.A, theta_actor, p.AL, W + p.lga, st))) return rc;
+  if ((rc = trunk_mlp(p, W, bt->obs, p.Ra, p.D, theta_actor, p.AL, W + p.a2a, true, saves2, W + p.lga, p.A, st))) return rc;
   if ((rc = launch_action(W + p.lga, bt->avail_acts, gumbel_noise_u, p.Ra, p.B, p.A, p.N, 1, 0, nullptr, W + p.actout, W + p.ysoft, st)))
     return rc;
   // N stacked copies of the joint action, copy i carrying the actor's action for agent i
   OPE_L(hipLaunchKernelGGL(build_cin_kernel, dim3(launch1d((int64_t)p.Ra * p.Din)), dim3(256), 0, st, bt->share_obs, bt->acts,
                            W + p.actout, 1, p.B, p.N, p.A, p.S, p.N, W + p.xin_a));
   // critic (parameters frozen) on the stacked input; only head 0 enters the objective
-  if ((rc = trunk_mlp(p, W, W + p.xin_a, p.Ra, p.Din, theta_critic, p.CL, W + p.a2c, true, nullptr, st))) return rc;
-  if ((rc = linear_head(W + p.a2c, p.Ra, p.K, theta_critic, p.CL, W + p.qc, st))) return rc;
+  if ((rc = trunk_mlp(p, W, W + p.xin_a, p.Ra, p.Din, theta_critic, p.CL, W + p.a2c, true, nullptr, W + p.qc, p.K, st))) return rc;
   OPE_L(hipLaunchKernelGGL(actor_obj_kernel, dim3(launch1d(p.Ra)), dim3(256), 0, st, W + p.qc, p.K, bt->valid_transition, p.Ra,
                            W + p.dq, W + p.loss_part));
   // critic backward down to its input, then through the gumbel-softmax into the actor logits

@@ -23,8 +23,10 @@ __device__ __forceinline__ float block_sum(float v, float* sm) {
   return t;
 }
 
-__global__ void __launch_bounds__(kBlock) sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ part) {
+__global__ void __launch_bounds__(kBlock) sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ part,
+                                                        int* __restrict__ step_counter) {
   __shared__ float sm[kBlock / 64];
+  if (step_counter && blockIdx.x == 0 && threadIdx.x == 0) step_counter[0] += 1;   // read by adam_kernel (next launch)
   const int64_t base = (int64_t)blockIdx.x * kPerBlock + threadIdx.x * kPerThread;
   float s = 0.f;
   if (base + 3 < n) {
@@ -45,6 +47,8 @@ struct AdamK {
   int do_polyak;
   int nblocks;
   long long tail;   // index of [loss_sum, mask_count, qtot_sum] in g
+  float lr;                 // with a device step counter the bias corrections are formed in the kernel
+  const int* step_counter;
 };
 
 __global__ void __launch_bounds__(kBlock) adam_kernel(AdamK c, int64_t n, float* __restrict__ theta, float* __restrict__ tgt,
@@ -52,7 +56,17 @@ __global__ void __launch_bounds__(kBlock) adam_kernel(AdamK c, int64_t n, float*
                                                        const float* __restrict__ g, const float* __restrict__ part,
                                                        float* __restrict__ stats) {
   __shared__ float sm[kBlock / 64];
-  __shared__ float s_coef;
+  __shared__ float s_bc[2];
+  if (c.step_counter) {
+    if (threadIdx.x == 0) {
+      const double t = (double)c.step_counter[0];
+      s_bc[0] = (float)((double)c.lr / (1.0 - pow((double)c.beta1, t)));
+      s_bc[1] = (float)(1.0 / sqrt(1.0 - pow((double)c.beta2, t)));
+    }
+    __syncthreads();
+    c.lr_t = s_bc[0];
+    c.inv_sqrt_bc2 = s_bc[1];
+  }
   float s = 0.f;
   for (int q = threadIdx.x; q < c.nblocks; q += kBlock) s += part[q];
   // fixed-order: each thread adds a fixed subset, then the same tree everywhere -> identical in all blocks
@@ -67,7 +81,6 @@ __global__ void __launch_bounds__(kBlock) adam_kernel(AdamK c, int64_t n, float*
     stats[2] = g[c.tail + 2] / c.qden;   // mean of Q_tot*(1-mask) over ALL T*B steps
     stats[3] = cnt;
   }
-  (void)s_coef;
   const float scale = coef * inv;
   const int64_t base = (int64_t)blockIdx.x * kPerBlock + threadIdx.x * kPerThread;
   for (int q = 0; q < kPerThread; ++q) {
@@ -102,19 +115,21 @@ extern "C" int ope_adam_step(const ope_adam_cfg* cfg, int64_t n, float* theta, f
   (void)hipGetLastError();  // drop stale errors from the caller's own HIP use
   if (!cfg || n < 1 || (n & 3) || !theta || !adam_m || !adam_v || !grad || !scratch) return OPE_EINVAL;
   if (cfg->do_polyak && !theta_tgt) return OPE_EINVAL;
-  if (cfg->step < 1) return OPE_EINVAL;
+  if (!cfg->step_counter && cfg->step < 1) return OPE_EINVAL;
   const int nb = ope_cdiv(n, kPerBlock);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(kBlock), 0, st, grad, n, scratch);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(kBlock), 0, st, grad, n, scratch, cfg->step_counter);
   OPE_CHECK_LAUNCH();
   AdamK c;
-  const double bc1 = 1.0 - pow((double)cfg->beta1, (double)cfg->step);
-  const double bc2 = 1.0 - pow((double)cfg->beta2, (double)cfg->step);
+  const double tstep = cfg->step_counter ? 1.0 : (double)cfg->step;   // placeholder when the kernel reads the device counter
+  const double bc1 = 1.0 - pow((double)cfg->beta1, tstep);
+  const double bc2 = 1.0 - pow((double)cfg->beta2, tstep);
   c.lr_t = (float)((double)cfg->lr / bc1);
   c.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
   c.beta1 = cfg->beta1; c.beta2 = cfg->beta2; c.eps = cfg->eps; c.max_norm = cfg->max_grad_norm;
   c.wd = cfg->weight_decay; c.tau = cfg->tau; c.qden = cfg->qtot_denominator; c.do_polyak = cfg->do_polyak;
   c.nblocks = nb;
+  c.lr = cfg->lr; c.step_counter = cfg->step_counter;
   c.tail = cfg->tail_offset > 0 ? cfg->tail_offset : n;
   hipLaunchKernelGGL(adam_kernel, dim3(nb), dim3(kBlock), 0, st, c, n, theta, theta_tgt, adam_m, adam_v, grad, scratch, stats_out);
   OPE_CHECK_LAUNCH();

@@ -264,6 +264,35 @@ __global__ void __launch_bounds__(256) trunk_fwd2_kernel(TrunkFwdArgs a, int Dp)
 #pragma unroll
     for (int t = 0; t < RT; ++t)
       if (valid[t]) *reinterpret_cast<f32x4*>(a.a2_out + (int64_t)row[t] * OPE_H + 16 * wave + 4 * g) = act[t];
+    if (!a.head_out) return;
+    // fused small Linear head (<= 16 outputs = one MFMA tile): the activations meet in LDS, wave 0 does the 16 MFMAs
+#pragma unroll
+    for (int t = 0; t < RT; ++t) *reinterpret_cast<f32x4*>(actb + (16 * t + j) * kActPitch + 16 * wave + 4 * g) = act[t];
+    __syncthreads();
+    if (wave != 0) return;
+    const int hd = a.head_dim;
+    f32x4 ho[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ho[t][r] = (4 * g + r < hd) ? th[a.L.q_b + 4 * g + r] : 0.f;
+    const float* __restrict__ Wh = th + a.L.q_w + (int64_t)(j < hd ? j : hd - 1) * OPE_H + 4 * g;   // rows >= hd: clamped, discarded below
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft) {
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(Wh + 16 * ft);
+#pragma unroll
+      for (int t = 0; t < RT; ++t) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(actb + (16 * t + j) * kActPitch + 16 * ft + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ho[t] = mfma16(wv[r], xv[r], ho[t]);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+      if (valid[t])
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (4 * g + r < hd) a.head_out[(int64_t)row[t] * hd + 4 * g + r] = ho[t][r];
     return;
   }
 #pragma unroll

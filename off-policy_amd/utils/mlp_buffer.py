@@ -76,12 +76,15 @@ class MlpPolicyBuffer(object):
     def sample_inds(self, sample_inds, timing_events=None):
         """11-tuple of mlp_buffer.py:213-257: obs, share_obs, acts, rewards, next_obs, next_share_obs, dones, dones_env,
         valid_transition, avail_acts, next_avail_acts (CUDA tensors, reference shapes)."""
-        inds = np.asarray(sample_inds, dtype=np.int64)
-        B = int(inds.shape[0])
+        if torch.is_tensor(sample_inds):
+            inds, B = sample_inds, int(sample_inds.shape[0])
+        else:
+            inds = np.asarray(sample_inds, dtype=np.int64)
+            B = int(inds.shape[0])
         obs, share, acts, rew, dones, dones_env, avail = self._ep.sample_inds(inds, timing_events=timing_events)
         # the episode gather returns [N, T(+1), B, dim] views of [T(+1), N, B, dim] memory; T = 1 here
         valid = torch.empty((1, self.num_agents, B, 1), dtype=torch.float32, device=self.device)
-        dev_inds = self._ep._upload_inds(inds)
+        dev_inds = inds if torch.is_tensor(inds) else self._ep._upload_inds(inds)
         sf, of = self._only_dones(self.valid_transition), self._only_dones(valid)
         _lib.check(_lib.lib.ope_store_gather(C.byref(self._ep.dims), self.buffer_size, C.byref(sf), _lib.ptr(dev_inds), B,
                                              C.byref(of), _lib.current_stream()), "ope_store_gather")

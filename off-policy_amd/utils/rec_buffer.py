@@ -150,11 +150,15 @@ class RecPolicyBuffer(object):
     def sample_inds(self, sample_inds, timing_events=None):
         """Gather the given episode slots; same 7-tuple as rec_buffer.py:192-240 (CUDA tensors, reference shapes).
         `timing_events`: optional (start, end) torch.cuda.Event pair recorded tightly around the gather launch."""
-        inds = np.asarray(sample_inds, dtype=np.int64)
-        B = int(inds.shape[0])
+        if torch.is_tensor(sample_inds):     # indices already on the device (HIP-graph replays keep them in a static tensor)
+            assert sample_inds.dtype == torch.int64 and sample_inds.device == self.device
+            dev_inds, B = sample_inds.contiguous(), int(sample_inds.shape[0])
+        else:
+            inds = np.asarray(sample_inds, dtype=np.int64)
+            B = int(inds.shape[0])
+            dev_inds = self._upload_inds(inds)
         d = self.dims
         T, N = d.episode_length, d.n_agents
-        dev_inds = self._upload_inds(inds)
         e = dict(dtype=torch.float32, device=self.device)
         out = dict(obs=torch.empty((T + 1, N, B, d.obs_dim), **e), share_obs=torch.empty((T + 1, B, d.state_dim), **e),
                    acts=torch.empty((T, N, B, d.act_dim), **e), rewards=torch.empty((T, N, B, 1), **e),

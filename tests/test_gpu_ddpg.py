@@ -103,3 +103,37 @@ def test_fixed_mode_trains_heads_and_delays_actor():
     assert "actor_loss" in info0 and "actor_loss" not in info1                       # every 2nd update only
     assert not torch.equal(policy.critic._head_w, h0)
     assert np.isfinite(float(info1["critic_loss"]))
+
+
+def test_graphed_step_matches_eager_step():
+    """The captured HIP graph of one update (gather + critic + actor + soft updates) replays the same computation as the
+    eager calls: first-replay critic loss / grad norm equal the eager ones on the same indices, Adam's device step counter
+    advances, and repeated replays keep training."""
+    import copy
+    g = load_golden("maddpg_spread")
+    res = {}
+    for mode in ("eager", "graph"):
+        dims, buf, policy, trainer = build(g)
+        trainer.device_noise = True
+        inds = np.asarray(g["inds"])
+        if mode == "eager":
+            s = buf.policy_buffers["policy_0"].sample_inds(inds)
+            info, _, _ = trainer.shared_train_policy_on_batch("policy_0", tuple({"policy_0": a} for a in s) + (None, None))
+            res[mode] = (float(info["critic_loss"]), float(info["critic_grad_norm"]))
+        else:
+            theta0 = {k: m._flat.clone() for k, m in (("a", policy.actor), ("c", policy.critic), ("ta", policy.target_actor), ("tc", policy.target_critic))}
+            step = trainer.make_graphed_step(buf, len(inds))
+            # capture warm-up trained two steps: restore the initial state so that the first replay is "step 1"
+            for k, m in (("a", policy.actor), ("c", policy.critic), ("ta", policy.target_actor), ("tc", policy.target_critic)):
+                m._flat.copy_(theta0[k])
+            for opt in (policy.critic_optimizer, policy.actor_optimizer):
+                opt.exp_avg.zero_(); opt.exp_avg_sq.zero_(); opt.step_dev.zero_(); opt.step_count = 0
+            info = step(inds)
+            res[mode] = (float(info["critic_loss"]), float(info["critic_grad_norm"]))
+            assert int(policy.critic_optimizer.step_dev.item()) == 1 and policy.critic_optimizer.step_count == 1
+            before = policy.actor._flat.clone()
+            losses = [float(step(np.random.RandomState(s).choice(len(buf), len(inds)))["critic_loss"]) for s in range(5)]
+            assert np.all(np.isfinite(losses)) and int(policy.actor_optimizer.step_dev.item()) == 6
+            assert not torch.equal(before, policy.actor._flat)
+    np.testing.assert_allclose(res["graph"], res["eager"], rtol=1e-5)
+    np.testing.assert_allclose(res["eager"][0], g["critic_loss"][0], rtol=RTOL)
