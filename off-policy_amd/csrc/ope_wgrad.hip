@@ -18,8 +18,9 @@ namespace ope {
 // reduction row k = kb+g, the FOUR CONSECUTIVE floats A[k][m0+4i .. +3] and B[k][n0+4i .. +3]: one 16-byte load per
 // operand per step (16 lanes x 16 B = two full 128-B lines per k-row), and it ends up holding, for each (mi, r),
 // the four consecutive outputs C[m0+16g+4r+mi][n0+4i .. +3]: float4 stores.
-// VEC4 = every problem's lda / ldb is a multiple of 4 (then rows are 16-byte aligned); otherwise 4 scalar loads.
-template <bool VEC4>
+// VEC = 4: every problem's lda / ldb is a multiple of 4 (rows 16-byte aligned, one 16-byte load per operand per step);
+// VEC = 2: multiples of 2 (two 8-byte loads); VEC = 1: four scalar loads.
+template <int VEC>
 __global__ void __launch_bounds__(256, 3) wgrad_kernel(WgTable tb, float* __restrict__ raw) {
   __shared__ __attribute__((aligned(16))) float red[2][17][64][4];   // two partial-tile slots: [quad][lane][4]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -53,8 +54,11 @@ __global__ void __launch_bounds__(256, 3) wgrad_kernel(WgTable tb, float* __rest
     mokf[q] = (m0 + 4 * i + q < P.M) ? 1.f : 0.f;
     nokf[q] = (n0 + 4 * i + q < P.N) ? 1.f : 0.f;
   }
-  const int moff = VEC4 ? min(m0 + 4 * i, lda - 4) : m0 + 4 * i;
-  const int noff = VEC4 ? min(n0 + 4 * i, ldb - 4) : n0 + 4 * i;
+  // vector loads are clamped so that they stay inside the row (lda/ldb >= 4 whenever VEC > 1 is selected)
+  // (VEC = 4: a group of 4 columns is either entirely inside the row or entirely masked; VEC = 2: each 2-column half is)
+  const int moff = VEC == 4 ? min(m0 + 4 * i, lda - 4) : (VEC == 2 ? min(m0 + 4 * i, lda - 2) : m0 + 4 * i);
+  const int noff = VEC == 4 ? min(n0 + 4 * i, ldb - 4) : (VEC == 2 ? min(n0 + 4 * i, ldb - 2) : n0 + 4 * i);
+  const int moff1 = min(m0 + 4 * i + 2, lda - 2), noff1 = min(n0 + 4 * i + 2, ldb - 2);   // second halves (VEC = 2)
   const float* __restrict__ Ap = P.A;
   const float* __restrict__ Bp = P.B;
   const float* __restrict__ mup = P.ln_mu;     // never null: plain problems point at a zeros / ones vector
@@ -66,9 +70,14 @@ __global__ void __launch_bounds__(256, 3) wgrad_kernel(WgTable tb, float* __rest
     const int kr = max(kc - shift, 0);
     const float* ar = Ap + (int64_t)kc * lda;
     const float* br = Bp + (int64_t)kr * ldb;
-    if (VEC4) {
+    if (VEC == 4) {
       r.a = *reinterpret_cast<const f32x4*>(ar + moff);
       r.b = *reinterpret_cast<const f32x4*>(br + noff);
+    } else if (VEC == 2) {
+      const f32x2 a0 = *reinterpret_cast<const f32x2*>(ar + moff), a1 = *reinterpret_cast<const f32x2*>(ar + moff1);
+      const f32x2 b0 = *reinterpret_cast<const f32x2*>(br + noff), b1 = *reinterpret_cast<const f32x2*>(br + noff1);
+      r.a = f32x4{a0[0], a0[1], a1[0], a1[1]};
+      r.b = f32x4{b0[0], b0[1], b1[0], b1[1]};
     } else {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -161,7 +170,7 @@ __global__ void __launch_bounds__(256, 3) wgrad_kernel(WgTable tb, float* __rest
   }
   float* out = raw + P.raw_base + (int64_t)slab * P.raw_stride;
   const int nb = n0 + 4 * i;
-  const bool n4 = VEC4 && (P.ldc % 4 == 0) && (P.out_off % 4 == 0) && (nb + 3 < P.N);
+  const bool n4 = VEC == 4 && (P.ldc % 4 == 0) && (P.out_off % 4 == 0) && (nb + 3 < P.N);
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -211,13 +220,20 @@ int wg_slabs(const WgTable& tb, int nsplit) { return tb.wg_reduce ? nsplit / 4 :
 
 int launch_wgrad(const WgTable& tb, float* raw, hipStream_t st) {
   if (tb.n < 1 || tb.total_waves < 1) return OPE_EINVAL;
-  bool vec4 = true;
-  for (int q = 0; q < tb.n; ++q)
-    if (tb.p[q].lda % 4 != 0 || tb.p[q].ldb % 4 != 0 || ((uintptr_t)tb.p[q].A & 15) || ((uintptr_t)tb.p[q].B & 15)) vec4 = false;
-  if (vec4)
-    hipLaunchKernelGGL(wgrad_kernel<true>, dim3(ope_cdiv(tb.total_waves, 4)), dim3(256), 0, st, tb, raw);
+  int vec = 4;
+  for (int q = 0; q < tb.n; ++q) {
+    const WgProb& P = tb.p[q];
+    int v = 1;
+    if (P.lda % 4 == 0 && P.ldb % 4 == 0 && !((uintptr_t)P.A & 15) && !((uintptr_t)P.B & 15)) v = 4;
+    else if (P.lda % 2 == 0 && P.ldb % 2 == 0 && P.lda >= 4 && P.ldb >= 4 && !((uintptr_t)P.A & 7) && !((uintptr_t)P.B & 7)) v = 2;
+    if (v < vec) vec = v;
+  }
+  if (vec == 4)
+    hipLaunchKernelGGL(wgrad_kernel<4>, dim3(ope_cdiv(tb.total_waves, 4)), dim3(256), 0, st, tb, raw);
+  else if (vec == 2)
+    hipLaunchKernelGGL(wgrad_kernel<2>, dim3(ope_cdiv(tb.total_waves, 4)), dim3(256), 0, st, tb, raw);
   else
-    hipLaunchKernelGGL(wgrad_kernel<false>, dim3(ope_cdiv(tb.total_waves, 4)), dim3(256), 0, st, tb, raw);
+    hipLaunchKernelGGL(wgrad_kernel<1>, dim3(ope_cdiv(tb.total_waves, 4)), dim3(256), 0, st, tb, raw);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   return OPE_OK;
 }
