@@ -279,17 +279,23 @@ __global__ void __launch_bounds__(256) trunk_bwd_kernel(TrunkBwdArgs a) {
       }
     }
   }
-  const float* grow = a.dgi ? a.dgi + rr * (3 * OPE_H) : nullptr;
+  if (a.dgi) {
+    // the whole dgi row slice of this lane (12 x 16 B) and the LayerNorm operands are requested up front: at ~2 waves per
+    // SIMD the kernel is bound by load latency, so it is paid once instead of once per 16-column chunk
+    const float* grow = a.dgi + rr * (3 * OPE_H);
+    f32x4 bv[12];
 #pragma unroll
-  for (int c = 0; c < 12; ++c) {
-    if (a.da2_in || a.dout) break;
-    f32x4 bv = *reinterpret_cast<const f32x4*>(grow + 16 * c + 4 * g);
-    if (!valid) bv = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < 12; ++c) bv[c] = *reinterpret_cast<const f32x4*>(grow + 16 * c + 4 * g);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const f32x4 w = *reinterpret_cast<const f32x4*>(wihT + (int64_t)(16 * it + j) * (3 * OPE_H) + 16 * c + 4 * g);
+    for (int c = 0; c < 12; ++c) {
+      if (!valid) bv[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) d[it] = mfma16(w[r], bv[r], d[it]);
+      for (int it = 0; it < 4; ++it) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(wihT + (int64_t)(16 * it + j) * (3 * OPE_H) + 16 * c + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d[it] = mfma16(w[r], bv[c][r], d[it]);
+      }
     }
   }
   ln_relu_bwd64(d, a.xhat2 + rr * OPE_H, a.rstd2[rr], a.theta + a.L.ln2_w, a.mask2[rr], g);

@@ -6,6 +6,8 @@
 // One wave owns 16 (t,b) rows. The four hyper-network first layers (S -> 64,64,64,32) run as one 14-tile f32-MFMA
 // chain over the state row; the second layers (64 -> N*32, 32) chain on without leaving registers; the per-row
 // agent-Q x |w1| contraction, ELU, |w2| dot and b2 are lane-local with two cross-lane adds (4 lanes share a row).
+#include <stdlib.h>
+
 #include "ope_mixer.h"
 
 namespace ope {
@@ -171,11 +173,196 @@ __global__ void __launch_bounds__(256) mixer_fwd_kernel(MixerFwdArgs a) {
   if (valid && g == 0) (net == 0 ? a.qtot : a.nqtot)[m] = qtot;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// mixer_fwd, workgroup-cooperative form (default; OPE_MIXER2=0 selects the one-wave form above). The one-wave form is
+// ~600 waves for 3s5z/B=32 -- 0.6 per SIMD -- each a chain of ~1050 dependent-issue MFMAs. Here a workgroup owns the 16
+// (t,b) rows and its four waves split the hyper-networks:
+//   stage A   wave 0: hyper_w1.0 (4 tiles)   wave 1: hyper_w2.0 (4)   wave 2: hyper_b2.0 (4)   wave 3: hyper_b1 (2)
+//   stage B   hw1 goes through LDS; wave w takes agents w, w+4, ...: v1_a = W1b_a hw1 + b, hidden partial += q_a |v1_a|
+//             (wave 3's partial starts from b1); wave 1 also forms v2 = W2b hw2 + b; wave 2 the b2 head dot
+//   combine   wave 1 adds the four hidden partials in fixed order, ELU, dot with |v2|, + b2  ->  Q_tot
+// Two workgroup barriers. Same arithmetic per row as the one-wave form up to the order of the hidden-layer sum.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kHwPitch = OPE_HYP + 4;
+constexpr int kHidPitch = OPE_MIX + 4;
+
+template <int VEC>
+__global__ void __launch_bounds__(256) mixer_fwd2_kernel(MixerFwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float hw1s[16 * kHwPitch];
+  __shared__ __attribute__((aligned(16))) float hidp[4][16 * kHidPitch];
+  __shared__ float pbs[16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int tiles = (a.TB + 15) >> 4;
+  const int net = blockIdx.x / tiles;
+  const int m0 = (blockIdx.x - net * tiles) * 16;
+  const int m = m0 + j;
+  const bool valid = m < a.TB;
+  const int mm = valid ? m : m0;
+  const int t = mm / a.B, b = mm - t * a.B;
+  const float* __restrict__ th = net == 0 ? a.theta0 : a.theta1;
+  const MixerLayout& L = a.L;
+  const int S = a.S, N = a.N;
+  const float* __restrict__ srow = a.share + ((int64_t)(t + net) * a.B + b) * S;
+  const float* __restrict__ qrow = (net == 0 ? a.agent_q : a.agent_nq) + (int64_t)mm * N;
+  const bool save = (net == 0) && (a.hw1 != nullptr);
+
+  // ---- stage A: this wave's tiles (wave 3 owns only two: it computes them twice, the copies are discarded) ----
+  int tile[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) tile[q] = wave < 3 ? 4 * wave + q : 12 + (q & 1);
+  f32x4 acc[4];
+  const float* wrow[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    acc[q] = *reinterpret_cast<const f32x4*>(stageA_bias(th, L, tile[q]) + 4 * g);
+    wrow[q] = stageA_row(th, L, S, tile[q], j);
+  }
+  const int KC = (S + 15) >> 4;
+  {
+    struct Chunk { f32x4 w[4]; f32x4 x; };
+    auto fetch = [&](Chunk& c, int ci) {
+      const int k = 16 * ci + 4 * g;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) c.w[q] = load4c<VEC>(wrow[q], k, S);
+      c.x = load4c<VEC>(srow, k, S);
+    };
+    auto compute = [&](const Chunk& c, int ci) {
+      const f32x4 xs = mask4(c.x, 16 * ci + 4 * g, S);   // chunks past KC-1 multiply a zero-masked state vector
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = mfma16(c.w[q][r], xs[r], acc[q]);
+    };
+    Chunk c0, c1, c2;
+    fetch(c0, 0);
+    fetch(c1, 1);
+    for (int ci = 0; ci < KC; ci += 3) {
+      fetch(c2, ci + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(c0, ci);
+      __builtin_amdgcn_sched_barrier(0);
+      fetch(c0, ci + 3);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(c1, ci + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      fetch(c1, ci + 4);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(c2, ci + 2);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (wave < 3) {   // ReLU of the three hidden layers; saved for backward
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[q][r] = fmaxf(acc[q][r], 0.f);
+    if (save && valid) {
+      float* dst = wave == 0 ? a.hw1 : (wave == 1 ? a.hw2 : a.hb2);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(dst + (int64_t)m * OPE_HYP + 16 * q + 4 * g) = acc[q];
+    }
+  }
+  if (wave == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(hw1s + j * kHwPitch + 16 * q + 4 * g) = acc[q];
+  }
+  if (wave == 2) {   // b2 head: b2b_w . relu(hb2) per row
+    float pb = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(th + L.b2b_w + 16 * q + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pb = fmaf(wv[r], acc[q][r], pb);
+    }
+    pb = rowsum4(pb);
+    if (g == 0) pbs[j] = pb;
+  }
+  __syncthreads();
+
+  // ---- stage B: agents wave, wave+4, ... ----
+  f32x4 hid[2];
+  if (wave == 3) { hid[0] = acc[0]; hid[1] = acc[1]; }
+  else { hid[0] = f32x4{0.f, 0.f, 0.f, 0.f}; hid[1] = hid[0]; }
+  {
+    f32x4 hv[4];
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft) hv[ft] = *reinterpret_cast<const f32x4*>(hw1s + j * kHwPitch + 16 * ft + 4 * g);
+    for (int ag = wave; ag < N; ag += 4) {
+      f32x4 v[2], w[2][4];
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) {
+        v[kh] = *reinterpret_cast<const f32x4*>(th + L.w1b_b + ag * OPE_MIX + 16 * kh + 4 * g);
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft)
+          w[kh][ft] = *reinterpret_cast<const f32x4*>(th + L.w1b_w + (int64_t)(ag * OPE_MIX + 16 * kh + j) * OPE_HYP + 16 * ft + 4 * g);
+      }
+      const float qa = qrow[ag];
+#pragma unroll
+      for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int kh = 0; kh < 2; ++kh) v[kh] = mfma16(w[kh][ft][r], hv[ft][r], v[kh]);
+      if (save && valid) {
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh)
+          *reinterpret_cast<f32x4*>(a.v1 + (int64_t)m * (N * OPE_MIX) + ag * OPE_MIX + 16 * kh + 4 * g) = v[kh];
+      }
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hid[kh][r] = fmaf(qa, fabsf(v[kh][r]), hid[kh][r]);
+    }
+  }
+#pragma unroll
+  for (int kh = 0; kh < 2; ++kh) *reinterpret_cast<f32x4*>(hidp[wave] + j * kHidPitch + 16 * kh + 4 * g) = hid[kh];
+  f32x4 v2[2];
+  if (wave == 1) {   // w2 = |W2b hw2 + b| (hw2 is this wave's stage-A result)
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) v2[kh] = *reinterpret_cast<const f32x4*>(th + L.w2b_b + 16 * kh + 4 * g);
+    gemm64<2>(th + L.w2b_w, OPE_HYP, j, g, acc, v2);
+    if (save && valid) {
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) *reinterpret_cast<f32x4*>(a.v2 + (int64_t)m * OPE_MIX + 16 * kh + 4 * g) = v2[kh];
+    }
+  }
+  __syncthreads();
+  if (wave != 1) return;
+
+  // ---- combine (wave 1) ----
+  float part = 0.f;
+#pragma unroll
+  for (int kh = 0; kh < 2; ++kh) {
+    f32x4 h = *reinterpret_cast<const f32x4*>(hidp[3] + j * kHidPitch + 16 * kh + 4 * g);   // b1 + agents 3, 7, ..
+#pragma unroll
+    for (int w2 = 0; w2 < 3; ++w2) {
+      const f32x4 o = *reinterpret_cast<const f32x4*>(hidp[w2] + j * kHidPitch + 16 * kh + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h[r] += o[r];
+    }
+    if (save && valid) *reinterpret_cast<f32x4*>(a.hpre + (int64_t)m * OPE_MIX + 16 * kh + 4 * g) = h;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part = fmaf(elu1(h[r]), fabsf(v2[kh][r]), part);
+  }
+  const float qtot = rowsum4(part) + (pbs[j] + th[L.b2b_b]);
+  if (valid && g == 0) (net == 0 ? a.qtot : a.nqtot)[m] = qtot;
+}
+
 int launch_mixer_fwd(const MixerFwdArgs& a, hipStream_t st) {
   if (a.TB < 1 || a.N < 1 || a.S < 1) return OPE_EINVAL;
   const int waves = 2 * ope_cdiv(a.TB, 16);
   const int blocks = ope_cdiv(waves, 4);
   const int vec = ope_vec_of(a.S);
+  static const int v2 = getenv("OPE_MIXER2") ? atoi(getenv("OPE_MIXER2")) : 1;
+  if (v2) {
+    if (vec == 4) hipLaunchKernelGGL(mixer_fwd2_kernel<4>, dim3(waves), dim3(256), 0, st, a);
+    else if (vec == 2) hipLaunchKernelGGL(mixer_fwd2_kernel<2>, dim3(waves), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(mixer_fwd2_kernel<1>, dim3(waves), dim3(256), 0, st, a);
+    if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
+    return OPE_OK;
+  }
   if (vec == 4) hipLaunchKernelGGL(mixer_fwd_kernel<4>, dim3(blocks), dim3(256), 0, st, a);
   else if (vec == 2) hipLaunchKernelGGL(mixer_fwd_kernel<2>, dim3(blocks), dim3(256), 0, st, a);
   else hipLaunchKernelGGL(mixer_fwd_kernel<1>, dim3(blocks), dim3(256), 0, st, a);
