@@ -16,6 +16,7 @@ struct TrunkFwdArgs {
   float* a2_out;       // [R][64]   trunk output (LN2 output) -- MLP nets: written instead of gi when non-null
   float* head_out;     // MLP nets, optional: [R][head_dim] = W_head a2 + b_head (L.q_w / L.q_b) fused into the same launch
   int head_dim;        //   (head_dim <= 16; the small MADDPG-family heads)
+  long long* dbg;      // optional per-wave s_memtime stamps [waves][16] (ope_set_debug)
   // saved for backward (live net only)
   float* mu0;          // [R] input-LN mean
   float* rstd0;        // [R] input-LN 1/std
@@ -103,6 +104,7 @@ struct TrunkBwdArgs {
 
 int launch_trunk_fwd(const TrunkFwdArgs& a, bool save, hipStream_t st);
 int launch_trunk_fwd2(const TrunkFwdArgs& a, bool save, hipStream_t st);   // workgroup-cooperative form (ope_trunk2.hip)
+int launch_trunk_fwd3(const TrunkFwdArgs& a, bool save, hipStream_t st);   // persistent, weights in registers (ope_trunk2.hip)
 int launch_gru_fwd(const GruFwdArgs& a, hipStream_t st);
 int launch_head_fwd(const HeadFwdArgs& a, int mode, hipStream_t st);
 int launch_head_bwd(const HeadBwdArgs& a, hipStream_t st);

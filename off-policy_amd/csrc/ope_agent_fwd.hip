@@ -197,9 +197,11 @@ static int launch_trunk_vec(const TrunkFwdArgs& a, hipStream_t st) {
 
 int launch_trunk_fwd(const TrunkFwdArgs& a, bool save, hipStream_t st) {
   if (a.R < 1 || a.D < 1) return OPE_EINVAL;
-  // default: the workgroup-cooperative form; OPE_TRUNK2=0 selects the one-wave-per-row-tile form below (A/B runs)
-  static const int v2 = getenv("OPE_TRUNK2") ? atoi(getenv("OPE_TRUNK2")) : 1;
+  // default (OPE_TRUNK2 unset or 3): persistent workgroups with the weights in registers; 2: the non-persistent cooperative
+  // form; 0: the one-wave-per-row-tile form below (A/B runs)
+  static const int v2 = getenv("OPE_TRUNK2") ? atoi(getenv("OPE_TRUNK2")) : 3;
   if (a.head_out && (!a.a2_out || a.head_dim < 1 || a.head_dim > 16)) return OPE_EINVAL;
+  if (v2 == 3 && a.D <= 256) return launch_trunk_fwd3(a, save, st);   // wider inputs: the weight fragments no longer fit in registers
   if (v2 && a.D <= 512) return launch_trunk_fwd2(a, save, st);
   if (a.head_out) {   // one-wave form: the head is a second launch
     TrunkFwdArgs b = a;

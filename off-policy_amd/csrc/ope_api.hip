@@ -69,7 +69,7 @@ struct Plan {
   int64_t mu0, rstd0, xhat1, rstd1, mask1, xhat2, rstd2, mask2, gi, h, rg, zg, ng, ghn, xhat_o, rstd_o, act_idx,
       agent_q, agent_nq, gi_t, h_t, qtot, nqtot, hw1, hw2, hb2, v1, hpre, v2, loss_part, err_abs, dqtot, d_agent_q,
       d_b1, d_v2, d_v1, d_hw1, d_hw2, d_hb2, dh_out, dqoh, dgi, dghn, dz1, dz2, thetaT, mixT, raw_agent, raw_mixer,
-      rsum, q_all, loss_tot, ln_zero, ln_one, dh_carry;
+      rsum, q_all, loss_tot, ln_zero, ln_one, dh_carry, dbg;
 };
 
 int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
@@ -159,6 +159,7 @@ void make_plan(const ope_qmix_cfg* c, Plan* p) {
   p->raw_mixer = W.add("raw_mixer", (int64_t)p->ns_mixer * (w.mixer_size > 0 ? w.mixer_size : 4));
   p->rsum = W.add("rsum", (int64_t)w.agent_end + w.mixer_size + 4);
   p->q_all = W.add("q_all", R * p->A);
+  p->dbg = W.add("dbg", 2 * 16 * 4096 + 2 * 16 * 2400);   // per-wave s_memtime stamps (ope_set_debug)
 }
 
 }  // namespace
@@ -278,8 +279,10 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
     tf.mu0 = W + p.mu0 + r0; tf.rstd0 = W + p.rstd0 + r0;
     tf.xhat1 = W + p.xhat1 + r0 * OPE_H; tf.rstd1 = W + p.rstd1 + r0; tf.mask1 = (uint64_t*)(W + p.mask1) + r0;
     tf.xhat2 = W + p.xhat2 + r0 * OPE_H; tf.rstd2 = W + p.rstd2 + r0; tf.mask2 = (uint64_t*)(W + p.mask2) + r0;
+    tf.dbg = g_debug ? (long long*)(W + p.dbg) + 16 * 2400 : nullptr;
     if ((rc = launch_trunk_fwd(tf, true, st))) return rc;
     TrunkFwdArgs tt = tf;
+    tt.dbg = nullptr;
     tt.theta = theta_tgt; tt.gi = p.mlp ? nullptr : W + p.gi_t + r0 * 3 * OPE_H; tt.a2_out = p.mlp ? W + p.h_t + r0 * OPE_H : nullptr;
     if ((rc = launch_trunk_fwd(tt, false, st))) return rc;
     if (p.mlp) continue;
@@ -339,6 +342,7 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
     mf.TB = (int)p.TB; mf.B = p.B; mf.N = p.N; mf.S = p.S; mf.theta0 = theta; mf.theta1 = theta_tgt; mf.L = p.ML;
     mf.share = batch->share_obs; mf.agent_q = W + p.agent_q; mf.agent_nq = W + p.agent_nq; mf.qtot = W + p.qtot; mf.nqtot = W + p.nqtot;
     mf.hw1 = W + p.hw1; mf.hw2 = W + p.hw2; mf.hb2 = W + p.hb2; mf.v1 = W + p.v1; mf.hpre = W + p.hpre; mf.v2 = W + p.v2;
+    mf.dbg = g_debug ? (long long*)(W + p.dbg) : nullptr;
     if ((rc = launch_mixer_fwd(mf, st))) return rc;
     MixerBwdArgs mb;
     mb.TB = (int)p.TB; mb.N = p.N; mb.theta = theta; mb.thetaT = W + p.mixT; mb.L = p.ML; mb.td = td;

@@ -17,6 +17,7 @@ struct MixerFwdArgs {
   float* v1;                             // [TB][N*32] pre-abs w1
   float* hpre;                           // [TB][32]   pre-ELU hidden
   float* v2;                             // [TB][32]   pre-abs w2
+  long long* dbg;                        // optional per-wave s_memtime stamps [waves][8] (profiling builds of the schedule)
 };
 
 struct TdArgs {

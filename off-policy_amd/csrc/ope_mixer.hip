@@ -207,6 +207,8 @@ __global__ void __launch_bounds__(256) mixer_fwd2_kernel(MixerFwdArgs a) {
   const float* __restrict__ srow = a.share + ((int64_t)(t + net) * a.B + b) * S;
   const float* __restrict__ qrow = (net == 0 ? a.agent_q : a.agent_nq) + (int64_t)mm * N;
   const bool save = (net == 0) && (a.hw1 != nullptr);
+  long long* dbg = a.dbg ? a.dbg + ((int64_t)blockIdx.x * 4 + wave) * 8 : nullptr;
+  if (dbg && lane == 0) dbg[0] = __builtin_amdgcn_s_memtime();
 
   // ---- stage A: this wave's tiles (wave 3 owns only two: it computes them twice, the copies are discarded) ----
   int tile[4];
@@ -253,6 +255,7 @@ __global__ void __launch_bounds__(256) mixer_fwd2_kernel(MixerFwdArgs a) {
       __builtin_amdgcn_sched_barrier(0);
     }
   }
+  if (dbg && lane == 0) dbg[1] = __builtin_amdgcn_s_memtime();
   if (wave < 3) {   // ReLU of the three hidden layers; saved for backward
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -280,6 +283,7 @@ __global__ void __launch_bounds__(256) mixer_fwd2_kernel(MixerFwdArgs a) {
     if (g == 0) pbs[j] = pb;
   }
   __syncthreads();
+  if (dbg && lane == 0) dbg[2] = __builtin_amdgcn_s_memtime();
 
   // ---- stage B: agents wave, wave+4, ... ----
   f32x4 hid[2];
@@ -328,7 +332,9 @@ __global__ void __launch_bounds__(256) mixer_fwd2_kernel(MixerFwdArgs a) {
       for (int kh = 0; kh < 2; ++kh) *reinterpret_cast<f32x4*>(a.v2 + (int64_t)m * OPE_MIX + 16 * kh + 4 * g) = v2[kh];
     }
   }
+  if (dbg && lane == 0) dbg[3] = __builtin_amdgcn_s_memtime();
   __syncthreads();
+  if (dbg && lane == 0) dbg[4] = __builtin_amdgcn_s_memtime();
   if (wave != 1) return;
 
   // ---- combine (wave 1) ----
@@ -348,6 +354,7 @@ __global__ void __launch_bounds__(256) mixer_fwd2_kernel(MixerFwdArgs a) {
   }
   const float qtot = rowsum4(part) + (pbs[j] + th[L.b2b_b]);
   if (valid && g == 0) (net == 0 ? a.qtot : a.nqtot)[m] = qtot;
+  if (dbg && lane == 0) dbg[5] = __builtin_amdgcn_s_memtime();
 }
 
 int launch_mixer_fwd(const MixerFwdArgs& a, hipStream_t st) {

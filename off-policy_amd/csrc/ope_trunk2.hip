@@ -359,4 +359,274 @@ int launch_trunk_fwd2(const TrunkFwdArgs& a, bool save, hipStream_t st) {
   return launch2<1, false>(a, st);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// trunk_fwd3: weights stationary in registers, row tiles streamed (default).
+// s_memtime stamps in the cooperative kernels showed where their time goes: every workgroup re-streams the layer weights
+// (128 KB per 16-row tile at 3s5z, 310 MB per launch) through the CU's L1/TA path in 64-byte row segments, and a 16-k chunk
+// of the first layer costs ~2 800 cycles against 512 cycles of MFMA. Weights per wave are small, though: with the feature
+// split of trunk_fwd2 a wave needs 16 rows of W1 (D/4 <= 128 VGPRs), 16 rows of W2 (16 VGPRs) and 48 rows of W_ih
+// (48 VGPRs) as MFMA A-operand fragments. So here the grid is persistent (2 workgroups per CU), every wave loads its
+// fragments ONCE and then walks over 16-row tiles: per tile only the observations (HBM -> LDS, normalised) and the
+// outputs move. KCM = compile-time bound on D/16 (register array size); chunks beyond D multiply zero-padded activations.
+// ---------------------------------------------------------------------------------------------------------
+// Sum over the 16 lanes of a DPP row (lanes 16q .. 16q+15), result in every lane of the row; VALU only (no LDS pipe):
+// quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror.
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));
+  return v;
+}
+
+template <int VEC, int KCM, bool SAVE>
+__global__ void __launch_bounds__(256, 2) trunk_fwd3_kernel(TrunkFwdArgs a) {
+  constexpr int TR = 16;
+  constexpr int Dp = 16 * KCM + 4;
+  __shared__ __attribute__((aligned(16))) float xn[TR * Dp];
+  __shared__ __attribute__((aligned(16))) float actb[TR * kActPitch];
+  __shared__ __attribute__((aligned(8))) float stat[2 * 4 * TR];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int D = a.D;
+  const float* __restrict__ th = a.theta;
+  const int ntiles = (a.R + TR - 1) / TR;
+
+  long long* dbg = a.dbg ? a.dbg + ((int64_t)blockIdx.x * 4 + wave) * 16 : nullptr;
+  int dbi = 0;
+#define OPE_STAMP() do { if (dbg && lane == 0 && dbi < 16) dbg[dbi] = __builtin_amdgcn_s_memtime(); ++dbi; } while (0)
+  OPE_STAMP();
+  // ---- this wave's weight fragments, loaded once ----
+  f32x4 w1[KCM], w2[4], w3[3][4];
+  {
+    const float* __restrict__ Wr = th + a.L.fc1_w + (int64_t)(16 * wave + j) * D;
+#pragma unroll
+    for (int c = 0; c < KCM; ++c) w1[c] = load4c<VEC>(Wr, 16 * c + 4 * g, D);   // clamped; columns >= D meet zero activations
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft) w2[ft] = *reinterpret_cast<const f32x4*>(th + a.L.fc2_w + (int64_t)(16 * wave + j) * OPE_H + 16 * ft + 4 * g);
+    if (!a.a2_out) {
+#pragma unroll
+      for (int u = 0; u < 3; ++u)
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft)
+          w3[u][ft] = *reinterpret_cast<const f32x4*>(th + a.L.wih + (int64_t)(16 * (3 * wave + u) + j) * OPE_H + 16 * ft + 4 * g);
+    }
+  }
+  const f32x4 b1 = *reinterpret_cast<const f32x4*>(th + a.L.fc1_b + 16 * wave + 4 * g);
+  const f32x4 b2 = *reinterpret_cast<const f32x4*>(th + a.L.fc2_b + 16 * wave + 4 * g);
+  const f32x4 g1 = *reinterpret_cast<const f32x4*>(th + a.L.ln1_w + 16 * wave + 4 * g), e1 = *reinterpret_cast<const f32x4*>(th + a.L.ln1_b + 16 * wave + 4 * g);
+  const f32x4 g2 = *reinterpret_cast<const f32x4*>(th + a.L.ln2_w + 16 * wave + 4 * g), e2 = *reinterpret_cast<const f32x4*>(th + a.L.ln2_b + 16 * wave + 4 * g);
+  // ReLU + LayerNorm over the 64 features of a row whose 16-feature slices live in the 4 waves (see trunk_fwd2)
+  // One pass: per-row sum and sum of squares of the post-ReLU values (O(1) magnitudes: E[x^2] - mean^2 loses nothing that
+  // matters at fp32), the 4 waves' partials meet through LDS behind ONE barrier.
+  auto relu_ln = [&](f32x4& z, const f32x4& gm, const f32x4& bt, f32x4& xh, f32x4& o, float& rs, float& mu, uint32_t& bits) {
+    uint32_t mb = 0;
+    float s = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (z[r] > 0.f) mb |= 1u << (4 * g + r);
+      z[r] = fmaxf(z[r], 0.f);
+      s += z[r];
+      s2 = fmaf(z[r], z[r], s2);
+    }
+    bits = mb;
+    s = rowsum4(s);
+    s2 = rowsum4(s2);
+    if (g == 0) *reinterpret_cast<f32x2*>(stat + 2 * (wave * TR + j)) = f32x2{s, s2};
+    __syncthreads();
+    const f32x2 p0 = *reinterpret_cast<const f32x2*>(stat + 2 * j), p1 = *reinterpret_cast<const f32x2*>(stat + 2 * (TR + j));
+    const f32x2 p2 = *reinterpret_cast<const f32x2*>(stat + 2 * (2 * TR + j)), p3 = *reinterpret_cast<const f32x2*>(stat + 2 * (3 * TR + j));
+    mu = ((p0[0] + p1[0]) + (p2[0] + p3[0])) * (1.0f / OPE_H);
+    const float var = fmaxf(((p0[1] + p1[1]) + (p2[1] + p3[1])) * (1.0f / OPE_H) - mu * mu, 0.f);
+    rs = 1.0f / sqrtf(var + OPE_LN_EPS);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      xh[r] = (z[r] - mu) * rs;
+      o[r] = fmaf(xh[r], gm[r], bt[r]);
+    }
+    // (stat is rewritten only after the next workgroup barrier: the actb hand-off)
+  };
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int row0 = tile * TR;
+    // ---- phase 0: input LayerNorm of this wave's 4 rows -> LDS. 16 lanes per row (one DPP row): each lane keeps
+    // 4*KCM/4 = KCM values of its row, row sums are four DPP adds; every global access is a 16-byte (VEC-wide) piece of a
+    // 256-byte contiguous run.
+    {
+      constexpr int NI4 = KCM / 4;
+      const int q = lane >> 4, c = lane & 15;
+      const int rr = wave * 4 + q;
+      const int row = row0 + rr;
+      const float* xr = a.x + (int64_t)(row < a.R ? row : a.R - 1) * D;
+      f32x4 xv[NI4], gv[NI4], bv[NI4];
+#pragma unroll
+      for (int i = 0; i < NI4; ++i) xv[i] = load4c<VEC>(xr, 4 * c + 64 * i, D);
+#pragma unroll
+      for (int i = 0; i < NI4; ++i) {
+        gv[i] = load4c<VEC>(th + a.L.fn_w, 4 * c + 64 * i, D);
+        bv[i] = load4c<VEC>(th + a.L.fn_b, 4 * c + 64 * i, D);
+      }
+      OPE_STAMP();
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < NI4; ++i) {
+        xv[i] = mask4(xv[i], 4 * c + 64 * i, D);
+        s += (xv[i][0] + xv[i][1]) + (xv[i][2] + xv[i][3]);
+      }
+      const float mean = row16_sum(s) / (float)D;
+      float sq = 0.f;
+#pragma unroll
+      for (int i = 0; i < NI4; ++i) {
+        const int k = 4 * c + 64 * i;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float d = (k + r < D) ? xv[i][r] - mean : 0.f;
+          xv[i][r] = d;
+          sq = fmaf(d, d, sq);
+        }
+      }
+      const float rstd = 1.0f / sqrtf(row16_sum(sq) / (float)D + OPE_LN_EPS);
+#pragma unroll
+      for (int i = 0; i < NI4; ++i) {
+        const int k = 4 * c + 64 * i;
+        const f32x4 gm = mask4(gv[i], k, D), bt = mask4(bv[i], k, D);
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = fmaf(xv[i][r] * rstd, gm[r], bt[r]);   // exactly 0 beyond D
+        *reinterpret_cast<f32x4*>(xn + rr * Dp + k) = o;
+      }
+      if (SAVE && c == 0 && row < a.R) {
+        a.mu0[row] = mean;
+        a.rstd0[row] = rstd;
+      }
+    }
+    OPE_STAMP();   // phase 0 done (before barrier)
+    __syncthreads();
+    const int row = row0 + j;
+    const bool valid = row < a.R;
+
+    OPE_STAMP();   // after barrier
+    // ---- fc1 from registers ----
+    f32x4 acc = b1;
+#pragma unroll
+    for (int c = 0; c < KCM; ++c) {
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(xn + j * Dp + 16 * c + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc = mfma16(w1[c][r], xv[r], acc);
+    }
+    OPE_STAMP();   // fc1 done
+    f32x4 xh, act;
+    float rs, mu;
+    uint32_t bits;
+    auto save_row = [&](uint64_t* mask, float* rstd_out, float* mu_out) {
+      uint32_t b = bits;
+      b |= __shfl_xor((int)b, 16, 64);
+      b |= __shfl_xor((int)b, 32, 64);
+      if (g == 0 && valid) {
+        reinterpret_cast<uint16_t*>(mask + row)[wave] = (uint16_t)b;
+        if (wave == 0) {
+          rstd_out[row] = rs;
+          if (mu_out) mu_out[row] = mu;
+        }
+      }
+    };
+    relu_ln(acc, g1, e1, xh, act, rs, mu, bits);
+    if (SAVE) {
+      if (valid) *reinterpret_cast<f32x4*>(a.xhat1 + (int64_t)row * OPE_H + 16 * wave + 4 * g) = xh;
+      save_row(a.mask1, a.rstd1, a.mu1);
+    }
+    *reinterpret_cast<f32x4*>(actb + j * kActPitch + 16 * wave + 4 * g) = act;
+    __syncthreads();
+
+    OPE_STAMP();   // LN1 + saves + actb + barrier
+    // ---- fc2 ----
+    acc = b2;
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft) {
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(actb + j * kActPitch + 16 * ft + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc = mfma16(w2[ft][r], xv[r], acc);
+    }
+    relu_ln(acc, g2, e2, xh, act, rs, mu, bits);   // its first barrier also fences the fc2 reads of actb
+    if (SAVE) {
+      if (valid) *reinterpret_cast<f32x4*>(a.xhat2 + (int64_t)row * OPE_H + 16 * wave + 4 * g) = xh;
+      save_row(a.mask2, a.rstd2, nullptr);
+    }
+    OPE_STAMP();   // fc2 + LN2 + saves
+    if (a.a2_out) {   // MLP nets: the trunk output feeds the head directly
+      if (valid) *reinterpret_cast<f32x4*>(a.a2_out + (int64_t)row * OPE_H + 16 * wave + 4 * g) = act;
+      if (!a.head_out) continue;
+      *reinterpret_cast<f32x4*>(actb + j * kActPitch + 16 * wave + 4 * g) = act;
+      __syncthreads();
+      if (wave == 0) {   // fused small Linear head (<= 16 outputs = one MFMA tile)
+        const int hd = a.head_dim;
+        f32x4 ho;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ho[r] = (4 * g + r < hd) ? th[a.L.q_b + 4 * g + r] : 0.f;
+        const float* __restrict__ Wh = th + a.L.q_w + (int64_t)(j < hd ? j : hd - 1) * OPE_H + 4 * g;
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) {
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(Wh + 16 * ft);
+          const f32x4 xv = *reinterpret_cast<const f32x4*>(actb + j * kActPitch + 16 * ft + 4 * g);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ho = mfma16(wv[r], xv[r], ho);
+        }
+        if (valid)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (4 * g + r < hd) a.head_out[(int64_t)row * hd + 4 * g + r] = ho[r];
+      }
+      continue;   // the next tile's first barrier orders wave 0's actb reads before anyone overwrites actb
+    }
+    *reinterpret_cast<f32x4*>(actb + j * kActPitch + 16 * wave + 4 * g) = act;
+    __syncthreads();
+
+    // ---- gi = W_ih a2 + b_ih : 3 of the 12 output tiles ----
+    f32x4 o[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) o[u] = *reinterpret_cast<const f32x4*>(th + a.L.bih + 16 * (3 * wave + u) + 4 * g);
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft) {
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(actb + j * kActPitch + 16 * ft + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int u = 0; u < 3; ++u) o[u] = mfma16(w3[u][ft][r], xv[r], o[u]);
+    }
+    if (valid) {
+#pragma unroll
+      for (int u = 0; u < 3; ++u) *reinterpret_cast<f32x4*>(a.gi + (int64_t)row * (3 * OPE_H) + 16 * (3 * wave + u) + 4 * g) = o[u];
+    }
+    OPE_STAMP();   // wih + stores issued
+  }
+#undef OPE_STAMP
+}
+
+template <int VEC, bool SAVE>
+static int launch3(const TrunkFwdArgs& a, hipStream_t st) {
+  const int KC = (a.D + 15) >> 4;
+  const int ntiles = ope_cdiv(a.R, 16);
+  const int blocks = ntiles < 512 ? ntiles : 512;   // persistent: two workgroups per CU
+  if (KC <= 8) hipLaunchKernelGGL((trunk_fwd3_kernel<VEC, 8, SAVE>), dim3(blocks), dim3(256), 0, st, a);
+  else if (KC <= 16) hipLaunchKernelGGL((trunk_fwd3_kernel<VEC, 16, SAVE>), dim3(blocks), dim3(256), 0, st, a);
+  else if (KC <= 24) hipLaunchKernelGGL((trunk_fwd3_kernel<VEC, 24, SAVE>), dim3(blocks), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((trunk_fwd3_kernel<VEC, 32, SAVE>), dim3(blocks), dim3(256), 0, st, a);
+  if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
+  return OPE_OK;
+}
+
+int launch_trunk_fwd3(const TrunkFwdArgs& a, bool save, hipStream_t st) {
+  if (a.R < 1 || a.D < 1 || a.D > 512) return OPE_EINVAL;
+  const int vec = ope_vec_of(a.D);
+  if (save) {
+    if (vec == 4) return launch3<4, true>(a, st);
+    if (vec == 2) return launch3<2, true>(a, st);
+    return launch3<1, true>(a, st);
+  }
+  if (vec == 4) return launch3<4, false>(a, st);
+  if (vec == 2) return launch3<2, false>(a, st);
+  return launch3<1, false>(a, st);
+}
+
 }  // namespace ope
