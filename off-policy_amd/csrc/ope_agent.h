@@ -110,6 +110,7 @@ int launch_head_fwd(const HeadFwdArgs& a, int mode, hipStream_t st);
 int launch_head_bwd(const HeadBwdArgs& a, hipStream_t st);
 int launch_gru_bwd(const GruBwdArgs& a, hipStream_t st);
 int launch_trunk_bwd(const TrunkBwdArgs& a, hipStream_t st);
+int launch_trunk_bwd3(const TrunkBwdArgs& a, hipStream_t st);   // persistent cooperative form (ope_trunk_bwd3.hip)
 int launch_transpose_weights(const float* theta, const AgentLayout& L, float* thetaT, hipStream_t st);
 int launch_transpose(const float* src, int rows, int cols, float* dst, hipStream_t st);
 

@@ -7,6 +7,8 @@
 //
 // Weight gradients are K-reductions over all rows and are done by ope_wgrad.hip from the per-row adjoints
 // stored here (dz1, dz2, dgi, dghn, dqoh).
+#include <stdlib.h>
+
 #include "ope_agent.h"
 
 namespace ope {
@@ -317,6 +319,8 @@ __global__ void __launch_bounds__(256) trunk_bwd_kernel(TrunkBwdArgs a) {
 
 int launch_trunk_bwd(const TrunkBwdArgs& a, hipStream_t st) {
   if (a.R < 1) return OPE_EINVAL;
+  static const int v3 = getenv("OPE_TRUNKB3") ? atoi(getenv("OPE_TRUNKB3")) : 1;
+  if (v3) return launch_trunk_bwd3(a, st);
   hipLaunchKernelGGL(trunk_bwd_kernel, dim3(ope_cdiv(ope_cdiv(a.R, 16), 4)), dim3(256), 0, st, a);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   return OPE_OK;
