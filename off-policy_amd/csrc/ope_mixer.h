@@ -18,6 +18,7 @@ struct MixerFwdArgs {
   float* hpre;                           // [TB][32]   pre-ELU hidden
   float* v2;                             // [TB][32]   pre-abs w2
   long long* dbg;                        // optional per-wave s_memtime stamps [waves][8] (profiling builds of the schedule)
+  int k_stagger;                         // cooperative form: workgroups start their K loops at different chunks
 };
 
 struct TdArgs {

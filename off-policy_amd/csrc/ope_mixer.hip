@@ -187,26 +187,37 @@ __global__ void __launch_bounds__(256) mixer_fwd_kernel(MixerFwdArgs a) {
 constexpr int kHwPitch = OPE_HYP + 4;
 constexpr int kHidPitch = OPE_MIX + 4;
 
-template <int VEC>
+template <int VEC, int RT>
 __global__ void __launch_bounds__(256) mixer_fwd2_kernel(MixerFwdArgs a) {
-  __shared__ __attribute__((aligned(16))) float hw1s[16 * kHwPitch];
-  __shared__ __attribute__((aligned(16))) float hidp[4][16 * kHidPitch];
-  __shared__ float pbs[16];
+  // RT row tiles (16*RT rows) per workgroup: every weight fragment a wave loads feeds RT MFMAs. The weights of the four
+  // hyper-networks are ~260 KB per workgroup pass through the CU's L1 in 64-byte row segments, which (s_memtime stamps)
+  // is what the one-tile form spends its time on: 14 state chunks at ~2 800 cycles each against 512 cycles of MFMA.
+  constexpr int TR = 16 * RT;
+  __shared__ __attribute__((aligned(16))) float hw1s[TR * kHwPitch];
+  __shared__ __attribute__((aligned(16))) float hidp[4][TR * kHidPitch];
+  __shared__ float pbs[TR];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, g = lane >> 4;
-  const int tiles = (a.TB + 15) >> 4;
-  const int net = blockIdx.x / tiles;
-  const int m0 = (blockIdx.x - net * tiles) * 16;
-  const int m = m0 + j;
-  const bool valid = m < a.TB;
-  const int mm = valid ? m : m0;
-  const int t = mm / a.B, b = mm - t * a.B;
+  const int groups = (a.TB + TR - 1) / TR;
+  const int net = blockIdx.x / groups;
+  const int m0 = (blockIdx.x - net * groups) * TR;
   const float* __restrict__ th = net == 0 ? a.theta0 : a.theta1;
   const MixerLayout& L = a.L;
   const int S = a.S, N = a.N;
-  const float* __restrict__ srow = a.share + ((int64_t)(t + net) * a.B + b) * S;
-  const float* __restrict__ qrow = (net == 0 ? a.agent_q : a.agent_nq) + (int64_t)mm * N;
   const bool save = (net == 0) && (a.hw1 != nullptr);
+  int m[RT];
+  bool valid[RT];
+  const float* srow[RT];
+  const float* qrow[RT];
+#pragma unroll
+  for (int t = 0; t < RT; ++t) {
+    m[t] = m0 + 16 * t + j;
+    valid[t] = m[t] < a.TB;
+    const int mm = valid[t] ? m[t] : a.TB - 1;
+    const int tt = mm / a.B, b = mm - tt * a.B;
+    srow[t] = a.share + ((int64_t)(tt + net) * a.B + b) * S;
+    qrow[t] = (net == 0 ? a.agent_q : a.agent_nq) + (int64_t)mm * N;
+  }
   long long* dbg = a.dbg ? a.dbg + ((int64_t)blockIdx.x * 4 + wave) * 8 : nullptr;
   if (dbg && lane == 0) dbg[0] = __builtin_amdgcn_s_memtime();
 
@@ -214,122 +225,151 @@ __global__ void __launch_bounds__(256) mixer_fwd2_kernel(MixerFwdArgs a) {
   int tile[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) tile[q] = wave < 3 ? 4 * wave + q : 12 + (q & 1);
-  f32x4 acc[4];
+  f32x4 acc[RT][4];
   const float* wrow[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    acc[q] = *reinterpret_cast<const f32x4*>(stageA_bias(th, L, tile[q]) + 4 * g);
+    const f32x4 bq = *reinterpret_cast<const f32x4*>(stageA_bias(th, L, tile[q]) + 4 * g);
+#pragma unroll
+    for (int t = 0; t < RT; ++t) acc[t][q] = bq;
     wrow[q] = stageA_row(th, L, S, tile[q], j);
   }
   const int KC = (S + 15) >> 4;
   {
-    struct Chunk { f32x4 w[4]; f32x4 x; };
+    struct Chunk { f32x4 w[4]; f32x4 x[RT]; };
     auto fetch = [&](Chunk& c, int ci) {
       const int k = 16 * ci + 4 * g;
 #pragma unroll
       for (int q = 0; q < 4; ++q) c.w[q] = load4c<VEC>(wrow[q], k, S);
-      c.x = load4c<VEC>(srow, k, S);
+#pragma unroll
+      for (int t = 0; t < RT; ++t) c.x[t] = load4c<VEC>(srow[t], k, S);
     };
     auto compute = [&](const Chunk& c, int ci) {
-      const f32x4 xs = mask4(c.x, 16 * ci + 4 * g, S);   // chunks past KC-1 multiply a zero-masked state vector
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
+      for (int t = 0; t < RT; ++t) {
+        const f32x4 xs = mask4(c.x[t], 16 * ci + 4 * g, S);   // chunks past KC-1 multiply a zero-masked state vector
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = mfma16(c.w[q][r], xs[r], acc[q]);
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[t][q] = mfma16(c.w[q][r], xs[r], acc[t][q]);
+      }
     };
+    // All workgroups walk the SAME weight rows; started together they would hit the same L2 lines in the same cycles.
+    // Each workgroup therefore starts its K loop at a different chunk and wraps around (summation order per row depends on
+    // the workgroup index only: still deterministic).
+    const int NIT = ((KC + 2) / 3) * 3;
+    const int rot = a.k_stagger ? (int)(blockIdx.x % (unsigned)NIT) : 0;
+    auto cid = [&](int ci) { const int c = ci + rot; return c >= NIT ? c - NIT : c; };
     Chunk c0, c1, c2;
-    fetch(c0, 0);
-    fetch(c1, 1);
-    for (int ci = 0; ci < KC; ci += 3) {
-      fetch(c2, ci + 2);
+    fetch(c0, cid(0));
+    fetch(c1, cid(1));
+    for (int ci = 0; ci < NIT; ci += 3) {
+      fetch(c2, cid(ci + 2));
       __builtin_amdgcn_sched_barrier(0);
-      compute(c0, ci);
+      compute(c0, cid(ci));
       __builtin_amdgcn_sched_barrier(0);
-      fetch(c0, ci + 3);
+      fetch(c0, cid(ci + 3 < NIT ? ci + 3 : 0));
       __builtin_amdgcn_sched_barrier(0);
-      compute(c1, ci + 1);
+      compute(c1, cid(ci + 1));
       __builtin_amdgcn_sched_barrier(0);
-      fetch(c1, ci + 4);
+      fetch(c1, cid(ci + 4 < NIT ? ci + 4 : 0));
       __builtin_amdgcn_sched_barrier(0);
-      compute(c2, ci + 2);
+      compute(c2, cid(ci + 2));
       __builtin_amdgcn_sched_barrier(0);
     }
   }
   if (dbg && lane == 0) dbg[1] = __builtin_amdgcn_s_memtime();
   if (wave < 3) {   // ReLU of the three hidden layers; saved for backward
+    float* dst = wave == 0 ? a.hw1 : (wave == 1 ? a.hw2 : a.hb2);
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int t = 0; t < RT; ++t) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[q][r] = fmaxf(acc[q][r], 0.f);
-    if (save && valid) {
-      float* dst = wave == 0 ? a.hw1 : (wave == 1 ? a.hw2 : a.hb2);
+      for (int q = 0; q < 4; ++q)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(dst + (int64_t)m * OPE_HYP + 16 * q + 4 * g) = acc[q];
+        for (int r = 0; r < 4; ++r) acc[t][q][r] = fmaxf(acc[t][q][r], 0.f);
+      if (save && valid[t]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(dst + (int64_t)m[t] * OPE_HYP + 16 * q + 4 * g) = acc[t][q];
+      }
     }
   }
   if (wave == 0) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(hw1s + j * kHwPitch + 16 * q + 4 * g) = acc[q];
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(hw1s + (16 * t + j) * kHwPitch + 16 * q + 4 * g) = acc[t][q];
   }
   if (wave == 2) {   // b2 head: b2b_w . relu(hb2) per row
-    float pb = 0.f;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 wv = *reinterpret_cast<const f32x4*>(th + L.b2b_w + 16 * q + 4 * g);
+    for (int t = 0; t < RT; ++t) {
+      float pb = 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) pb = fmaf(wv[r], acc[q][r], pb);
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(th + L.b2b_w + 16 * q + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pb = fmaf(wv[r], acc[t][q][r], pb);
+      }
+      pb = rowsum4(pb);
+      if (g == 0) pbs[16 * t + j] = pb;
     }
-    pb = rowsum4(pb);
-    if (g == 0) pbs[j] = pb;
   }
   __syncthreads();
   if (dbg && lane == 0) dbg[2] = __builtin_amdgcn_s_memtime();
 
   // ---- stage B: agents wave, wave+4, ... ----
-  f32x4 hid[2];
-  if (wave == 3) { hid[0] = acc[0]; hid[1] = acc[1]; }
-  else { hid[0] = f32x4{0.f, 0.f, 0.f, 0.f}; hid[1] = hid[0]; }
-  {
-    f32x4 hv[4];
+  f32x4 hid[RT][2];
 #pragma unroll
-    for (int ft = 0; ft < 4; ++ft) hv[ft] = *reinterpret_cast<const f32x4*>(hw1s + j * kHwPitch + 16 * ft + 4 * g);
-    for (int ag = wave; ag < N; ag += 4) {
-      f32x4 v[2], w[2][4];
+  for (int t = 0; t < RT; ++t) {
+    if (wave == 3) { hid[t][0] = acc[t][0]; hid[t][1] = acc[t][1]; }
+    else { hid[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; hid[t][1] = hid[t][0]; }
+  }
+  for (int ag = wave; ag < N; ag += 4) {
+    f32x4 w[2][4], bq[2];
 #pragma unroll
-      for (int kh = 0; kh < 2; ++kh) {
-        v[kh] = *reinterpret_cast<const f32x4*>(th + L.w1b_b + ag * OPE_MIX + 16 * kh + 4 * g);
-#pragma unroll
-        for (int ft = 0; ft < 4; ++ft)
-          w[kh][ft] = *reinterpret_cast<const f32x4*>(th + L.w1b_w + (int64_t)(ag * OPE_MIX + 16 * kh + j) * OPE_HYP + 16 * ft + 4 * g);
-      }
-      const float qa = qrow[ag];
+    for (int kh = 0; kh < 2; ++kh) {
+      bq[kh] = *reinterpret_cast<const f32x4*>(th + L.w1b_b + ag * OPE_MIX + 16 * kh + 4 * g);
 #pragma unroll
       for (int ft = 0; ft < 4; ++ft)
+        w[kh][ft] = *reinterpret_cast<const f32x4*>(th + L.w1b_w + (int64_t)(ag * OPE_MIX + 16 * kh + j) * OPE_HYP + 16 * ft + 4 * g);
+    }
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      f32x4 v[2] = {bq[0], bq[1]};
+#pragma unroll
+      for (int ft = 0; ft < 4; ++ft) {
+        const f32x4 hv = *reinterpret_cast<const f32x4*>(hw1s + (16 * t + j) * kHwPitch + 16 * ft + 4 * g);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-          for (int kh = 0; kh < 2; ++kh) v[kh] = mfma16(w[kh][ft][r], hv[ft][r], v[kh]);
-      if (save && valid) {
+          for (int kh = 0; kh < 2; ++kh) v[kh] = mfma16(w[kh][ft][r], hv[r], v[kh]);
+      }
+      if (save && valid[t]) {
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh)
-          *reinterpret_cast<f32x4*>(a.v1 + (int64_t)m * (N * OPE_MIX) + ag * OPE_MIX + 16 * kh + 4 * g) = v[kh];
+          *reinterpret_cast<f32x4*>(a.v1 + (int64_t)m[t] * (N * OPE_MIX) + ag * OPE_MIX + 16 * kh + 4 * g) = v[kh];
       }
+      const float qa = qrow[t][ag];
 #pragma unroll
       for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) hid[kh][r] = fmaf(qa, fabsf(v[kh][r]), hid[kh][r]);
+        for (int r = 0; r < 4; ++r) hid[t][kh][r] = fmaf(qa, fabsf(v[kh][r]), hid[t][kh][r]);
     }
   }
 #pragma unroll
-  for (int kh = 0; kh < 2; ++kh) *reinterpret_cast<f32x4*>(hidp[wave] + j * kHidPitch + 16 * kh + 4 * g) = hid[kh];
-  f32x4 v2[2];
+  for (int t = 0; t < RT; ++t)
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) *reinterpret_cast<f32x4*>(hidp[wave] + (16 * t + j) * kHidPitch + 16 * kh + 4 * g) = hid[t][kh];
+  f32x4 v2[RT][2];
   if (wave == 1) {   // w2 = |W2b hw2 + b| (hw2 is this wave's stage-A result)
 #pragma unroll
-    for (int kh = 0; kh < 2; ++kh) v2[kh] = *reinterpret_cast<const f32x4*>(th + L.w2b_b + 16 * kh + 4 * g);
-    gemm64<2>(th + L.w2b_w, OPE_HYP, j, g, acc, v2);
-    if (save && valid) {
+    for (int t = 0; t < RT; ++t) {
 #pragma unroll
-      for (int kh = 0; kh < 2; ++kh) *reinterpret_cast<f32x4*>(a.v2 + (int64_t)m * OPE_MIX + 16 * kh + 4 * g) = v2[kh];
+      for (int kh = 0; kh < 2; ++kh) v2[t][kh] = *reinterpret_cast<const f32x4*>(th + L.w2b_b + 16 * kh + 4 * g);
+      gemm64<2>(th + L.w2b_w, OPE_HYP, j, g, acc[t], v2[t]);
+      if (save && valid[t]) {
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) *reinterpret_cast<f32x4*>(a.v2 + (int64_t)m[t] * OPE_MIX + 16 * kh + 4 * g) = v2[t][kh];
+      }
     }
   }
   if (dbg && lane == 0) dbg[3] = __builtin_amdgcn_s_memtime();
@@ -338,23 +378,38 @@ __global__ void __launch_bounds__(256) mixer_fwd2_kernel(MixerFwdArgs a) {
   if (wave != 1) return;
 
   // ---- combine (wave 1) ----
-  float part = 0.f;
 #pragma unroll
-  for (int kh = 0; kh < 2; ++kh) {
-    f32x4 h = *reinterpret_cast<const f32x4*>(hidp[3] + j * kHidPitch + 16 * kh + 4 * g);   // b1 + agents 3, 7, ..
+  for (int t = 0; t < RT; ++t) {
+    float part = 0.f;
 #pragma unroll
-    for (int w2 = 0; w2 < 3; ++w2) {
-      const f32x4 o = *reinterpret_cast<const f32x4*>(hidp[w2] + j * kHidPitch + 16 * kh + 4 * g);
+    for (int kh = 0; kh < 2; ++kh) {
+      f32x4 h = *reinterpret_cast<const f32x4*>(hidp[3] + (16 * t + j) * kHidPitch + 16 * kh + 4 * g);   // b1 + agents 3, 7, ..
 #pragma unroll
-      for (int r = 0; r < 4; ++r) h[r] += o[r];
+      for (int w2 = 0; w2 < 3; ++w2) {
+        const f32x4 o = *reinterpret_cast<const f32x4*>(hidp[w2] + (16 * t + j) * kHidPitch + 16 * kh + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] += o[r];
+      }
+      if (save && valid[t]) *reinterpret_cast<f32x4*>(a.hpre + (int64_t)m[t] * OPE_MIX + 16 * kh + 4 * g) = h;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part = fmaf(elu1(h[r]), fabsf(v2[t][kh][r]), part);
     }
-    if (save && valid) *reinterpret_cast<f32x4*>(a.hpre + (int64_t)m * OPE_MIX + 16 * kh + 4 * g) = h;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) part = fmaf(elu1(h[r]), fabsf(v2[kh][r]), part);
+    const float qtot = rowsum4(part) + (pbs[16 * t + j] + th[L.b2b_b]);
+    if (valid[t] && g == 0) (net == 0 ? a.qtot : a.nqtot)[m[t]] = qtot;
   }
-  const float qtot = rowsum4(part) + (pbs[j] + th[L.b2b_b]);
-  if (valid && g == 0) (net == 0 ? a.qtot : a.nqtot)[m] = qtot;
   if (dbg && lane == 0) dbg[5] = __builtin_amdgcn_s_memtime();
+}
+
+template <int VEC>
+static void launch_mixer2(const MixerFwdArgs& a0, hipStream_t st) {
+  MixerFwdArgs a = a0;
+  static const int stag = getenv("OPE_STAGGER") ? atoi(getenv("OPE_STAGGER")) : 1;
+  a.k_stagger = stag;
+  static const int forced = getenv("OPE_MIXER_RT") ? atoi(getenv("OPE_MIXER_RT")) : 0;
+  const int rt = forced ? forced : 1;
+  if (rt == 4) hipLaunchKernelGGL((mixer_fwd2_kernel<VEC, 4>), dim3(2 * ope_cdiv(a.TB, 64)), dim3(256), 0, st, a);
+  else if (rt == 2) hipLaunchKernelGGL((mixer_fwd2_kernel<VEC, 2>), dim3(2 * ope_cdiv(a.TB, 32)), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((mixer_fwd2_kernel<VEC, 1>), dim3(2 * ope_cdiv(a.TB, 16)), dim3(256), 0, st, a);
 }
 
 int launch_mixer_fwd(const MixerFwdArgs& a, hipStream_t st) {
@@ -364,9 +419,9 @@ int launch_mixer_fwd(const MixerFwdArgs& a, hipStream_t st) {
   const int vec = ope_vec_of(a.S);
   static const int v2 = getenv("OPE_MIXER2") ? atoi(getenv("OPE_MIXER2")) : 1;
   if (v2) {
-    if (vec == 4) hipLaunchKernelGGL(mixer_fwd2_kernel<4>, dim3(waves), dim3(256), 0, st, a);
-    else if (vec == 2) hipLaunchKernelGGL(mixer_fwd2_kernel<2>, dim3(waves), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(mixer_fwd2_kernel<1>, dim3(waves), dim3(256), 0, st, a);
+    if (vec == 4) launch_mixer2<4>(a, st);
+    else if (vec == 2) launch_mixer2<2>(a, st);
+    else launch_mixer2<1>(a, st);
     if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
     return OPE_OK;
   }
