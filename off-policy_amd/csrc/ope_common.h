@@ -132,6 +132,32 @@ __device__ __forceinline__ void store4(float* __restrict__ p, int k, int K, f32x
 
 static inline int ope_vec_of(int K) { return (K % 4 == 0) ? 4 : ((K % 2 == 0) ? 2 : 1); }
 
+// Reductions over the 16 lanes of a DPP row (lanes 16q .. 16q+15), result in every lane of the row; VALU only (no LDS
+// pipe, unlike __shfl_xor = ds_bpermute): quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror.
+#define OPE_DPP_F(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xF, 0xF, false))
+#define OPE_DPP_I(v, ctrl) __builtin_amdgcn_update_dpp(0, (v), (ctrl), 0xF, 0xF, false)
+__device__ __forceinline__ float row16_sum(float v) {
+  v += OPE_DPP_F(v, 0xB1);
+  v += OPE_DPP_F(v, 0x4E);
+  v += OPE_DPP_F(v, 0x141);
+  v += OPE_DPP_F(v, 0x140);
+  return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, OPE_DPP_F(v, 0xB1));
+  v = fmaxf(v, OPE_DPP_F(v, 0x4E));
+  v = fmaxf(v, OPE_DPP_F(v, 0x141));
+  v = fmaxf(v, OPE_DPP_F(v, 0x140));
+  return v;
+}
+__device__ __forceinline__ int row16_min_i(int v) {
+  v = min(v, OPE_DPP_I(v, 0xB1));
+  v = min(v, OPE_DPP_I(v, 0x4E));
+  v = min(v, OPE_DPP_I(v, 0x141));
+  v = min(v, OPE_DPP_I(v, 0x140));
+  return v;
+}
+
 // Sum over the 4 lanes (g = 0..3) that share a data row j in the transposed-chain layout.
 __device__ __forceinline__ float rowsum4(float x) {
   x += __shfl_xor(x, 16, 64);

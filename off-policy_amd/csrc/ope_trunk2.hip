@@ -370,16 +370,6 @@ int launch_trunk_fwd2(const TrunkFwdArgs& a, bool save, hipStream_t st) {
 // fragments ONCE and then walks over 16-row tiles: per tile only the observations (HBM -> LDS, normalised) and the
 // outputs move. KCM = compile-time bound on D/16 (register array size); chunks beyond D multiply zero-padded activations.
 // ---------------------------------------------------------------------------------------------------------
-// Sum over the 16 lanes of a DPP row (lanes 16q .. 16q+15), result in every lane of the row; VALU only (no LDS pipe):
-// quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror.
-__device__ __forceinline__ float row16_sum(float v) {
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));
-  return v;
-}
-
 template <int VEC, int KCM, bool SAVE>
 __global__ void __launch_bounds__(256, 2) trunk_fwd3_kernel(TrunkFwdArgs a) {
   constexpr int TR = 16;
