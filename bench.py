@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="MLP MADDPG/MATD3: launch the ~45 kernels of an update one by one instead "
                     "of replaying the captured HIP graph")
+    ap.add_argument("--host-per", action="store_true", help="prioritized workloads: keep the sum/min trees on the host (numpy, as the "
+                    "reference) instead of in HBM")
     ap.add_argument("--host-noise", action="store_true", help="MADDPG family: draw the gumbel noise on the reference's CPU generator "
                     "stream (what the parity tests use) instead of on the device")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="budget for each CPU-baseline leg")
@@ -478,7 +480,7 @@ def main_rddpg(a):
                                             episode_length=dims.episode_length)
     trainer.device_noise = not a.host_noise
     buf = PrioritizedRecReplayBuffer(args.per_alpha, pinfo, {"policy_0": list(range(dims.n_agents))}, a.episodes, dims.episode_length,
-                                     True, True, device=dev)
+                                     True, True, device=dev, device_tree=not a.host_per)
     fill_buffer(buf, dims, a.episodes, np.random.RandomState(100 + rank))
     np.random.seed(1000 + rank)
     torch.manual_seed(1000 + rank)
@@ -532,8 +534,9 @@ def main_rddpg(a):
                "dtype": "f32", "data": "synthetic",
                "config": {"workload": "%s-RNN + prioritized replay, SMAC %s (N=%d A=%d D=%d S=%d T=%d), replay filled with %d synthetic "
                                       "episodes, step = PER sample + critic update + actor update (every %d) + update_priorities + "
-                                      "soft target updates; gumbel noise drawn on the %s" % (name, mapname, N, A, D, S, T, a.episodes,
-                                                                                               trainer.actor_update_interval, "host (reference stream)" if a.host_noise else "device"),
+                                      "soft target updates; gumbel noise drawn on the %s; PER trees on the %s" % (
+                                          name, mapname, N, A, D, S, T, a.episodes, trainer.actor_update_interval,
+                                          "host (reference stream)" if a.host_noise else "device", "host" if a.host_per else "device"),
                           "batch_per_gpu": local_batch, "global_batch": global_batch, "parallelism": "dp%d" % world,
                           "optimizer_steps_per_sec": round(steps_per_s, 3)},
                "roofline": {"kernel": "episode_copy_kernel<gather> (ope_store_gather)", "bound": "hbm", "achieved": round(achieved, 2),

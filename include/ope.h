@@ -71,6 +71,21 @@ typedef struct ope_fields {
  *   time the row-stacked `[T(+1), N*B, dim]` tensor QMix.train_policy_on_batch builds with torch.cat
  *   (qmix.py:108-109). Bit-exact copy; indices may repeat.
  * ---------------------------------------------------------------------------------------------- */
+/* Device-resident prioritized replay bookkeeping: float64 sum / min segment trees + running max priority.
+ * Replaces SumSegmentTree / MinSegmentTree (offpolicy/utils/segment_tree.py:18-165) and the tree traffic of
+ * PrioritizedRecReplayBuffer.insert / sample / update_priorities (rec_buffer.py:262-324; mlp_buffer.py likewise), so the
+ * prioritized configurations need no host round trip per update. capacity must be a power of two.
+ *   ope_per_tree_set     leaves[idx[i]] = v_i ** alpha, v_i = priorities[i] (update_priorities; also raises the running max)
+ *                        or, with priorities == NULL, the running max priority (insert); touched paths re-reduced.
+ *                        Duplicate indices: the last one wins (numpy fancy assignment).
+ *   ope_per_tree_sample  idx[i] = find_prefixsum_idx(mass01[i] * sum(leaves[0, filled-1))) with mass01 in [0,1) drawn by the
+ *                        caller (the reference uses np.random.random); weights[i] = (p_i filled)^-beta / max_w (or NULL). */
+int64_t ope_per_tree_bytes(int32_t capacity);
+int ope_per_tree_init(void* trees, int32_t capacity, void* stream);
+int ope_per_tree_set(void* trees, int32_t capacity, const int64_t* idx, const float* priorities, double alpha, int32_t n, void* stream);
+int ope_per_tree_sample(const void* trees, int32_t capacity, int32_t filled, const double* mass01, double beta, int32_t n,
+                        int64_t* idx_out, float* weights_out, void* stream);
+
 /* Reward normalisation (use_reward_normalization): statistics over the FILLED part of the reward ring
  *   episodes  (rec_buffer.py:209-222): nanmean / nanstd over steps whose previous step did not end the episode
  *             (dones_env[t-1] != 1; step 0 always counts), all agents;  pass the store's dones_env ring

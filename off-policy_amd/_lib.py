@@ -74,6 +74,10 @@ def _load():
         "ope_episode_bytes": (i64, [C.POINTER(Dims)]),
         "ope_store_insert": (C.c_int, [C.POINTER(Dims), i32, C.POINTER(Fields), C.POINTER(Fields), p, i32, p]),
         "ope_store_gather": (C.c_int, [C.POINTER(Dims), i32, C.POINTER(Fields), p, i32, C.POINTER(Fields), p]),
+        "ope_per_tree_bytes": (i64, [i32]),
+        "ope_per_tree_init": (C.c_int, [p, i32, p]),
+        "ope_per_tree_set": (C.c_int, [p, i32, p, p, C.c_double, i32, p]),
+        "ope_per_tree_sample": (C.c_int, [p, i32, i32, p, C.c_double, i32, p, p, p]),
         "ope_reward_stats_scratch_bytes": (i64, []),
         "ope_store_reward_stats": (C.c_int, [C.POINTER(Dims), i32, p, p, p, p, p]),
         "ope_reward_normalize": (C.c_int, [p, i64, p, p]),

@@ -110,7 +110,11 @@ class MADDPG(object):
         # ---- critic ----
         draw = (lambda shape: torch.rand(shape, **self.tpdv)) if self.device_noise else (lambda shape: sample_gumbel_uniform(shape).to(self.device))
         u_t = draw((N * B, policy.act_dim)) if policy.target_noise is not None else None
-        w = torch.as_tensor(np.asarray(importance_weights), dtype=torch.float32).to(self.device).contiguous() if self.use_per else None
+        dev_prio = torch.is_tensor(importance_weights)
+        w = None
+        if self.use_per:
+            w = (importance_weights.to(self.device, dtype=torch.float32).contiguous() if dev_prio else
+                 torch.as_tensor(np.asarray(importance_weights), dtype=torch.float32).to(self.device).contiguous())
         prio = torch.empty(B, **self.tpdv) if self.use_per else None
         _lib.check(_lib.lib.ope_ddpg_critic_loss_and_grad(C.byref(cfg), C.byref(mb), _lib.ptr(policy.target_actor._flat),
                                                           _lib.ptr(policy.critic._flat), _lib.ptr(policy.target_critic._flat),
@@ -120,7 +124,7 @@ class MADDPG(object):
         cs = self._adam(policy.critic_optimizer, policy.critic.trainable_numel, policy.critic._flat, policy.target_critic._flat, gc,
                         scratch, policy.critic.padded_numel)
         train_info["critic_loss"], train_info["critic_grad_norm"] = cs[0], cs[1]
-        new_priorities = prio.cpu().numpy() if self.use_per else None
+        new_priorities = (prio if dev_prio else prio.cpu().numpy()) if self.use_per else None
         # ---- actor ----
         if update_actor:
             u_a = draw((N * B, policy.act_dim))

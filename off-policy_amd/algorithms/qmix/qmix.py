@@ -190,7 +190,8 @@ class QMix(object):
         w = None
         td_stats = None
         if self.use_per:
-            w = torch.as_tensor(np.asarray(importance_weights), dtype=torch.float32).to(self.device).contiguous()
+            w = (importance_weights.to(self.device, dtype=torch.float32).contiguous() if torch.is_tensor(importance_weights) else
+                 torch.as_tensor(np.asarray(importance_weights), dtype=torch.float32).to(self.device).contiguous())
             td_stats = torch.empty(2 * B, **self.tpdv)
         st = _lib.current_stream()
         _lib.check(_lib.lib.ope_qmix_loss_and_grad(C.byref(cfg), C.byref(f), _lib.ptr(self.theta), _lib.ptr(self.theta_tgt),
@@ -212,7 +213,10 @@ class QMix(object):
         self._polyak_done = bool(self.fuse_soft_update)
         train_info = {"loss": stats[0], "grad_norm": stats[1], "Q_tot": stats[2]}
         new_priorities = None
-        if self.use_per:
+        if self.use_per and torch.is_tensor(importance_weights):   # device trees (device_tree=True): priorities stay in HBM
+            s = td_stats.view(B, 2)
+            new_priorities = ((1 - self.args.per_nu) * s[:, 0] + self.args.per_nu * s[:, 1]) + self.per_eps
+        elif self.use_per:
             s = td_stats.view(B, 2).cpu().numpy().astype(np.float32)
             new_priorities = ((1 - self.args.per_nu) * s[:, 0] + self.args.per_nu * s[:, 1]).flatten() + self.per_eps
         self._last = (obs, share, acts, rew, dones_env, avail, w, td_stats)   # keep inputs alive past the async launch

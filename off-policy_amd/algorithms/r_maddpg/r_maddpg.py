@@ -131,7 +131,11 @@ class R_MADDPG(object):
         # ---- critic ----
         draw = (lambda shape: torch.rand(shape, **self.tpdv)) if self.device_noise else (lambda shape: sample_gumbel_uniform(shape).to(self.device))
         u_t = draw((T + 1, N * B, A)) if policy.target_noise is not None else None
-        w = torch.as_tensor(np.asarray(importance_weights), dtype=torch.float32).to(self.device).contiguous() if self.use_per else None
+        dev_prio = torch.is_tensor(importance_weights)     # device trees: weights in, priorities out stay in HBM
+        w = None
+        if self.use_per:
+            w = (importance_weights.to(self.device, dtype=torch.float32).contiguous() if dev_prio else
+                 torch.as_tensor(np.asarray(importance_weights), dtype=torch.float32).to(self.device).contiguous())
         K = policy.num_q
         td_stats = torch.empty(K * 2 * B, **self.tpdv) if self.use_per else None
         _lib.check(_lib.lib.ope_rddpg_critic_loss_and_grad(C.byref(cfg), C.byref(f), _lib.ptr(policy.target_actor._flat),
@@ -143,7 +147,11 @@ class R_MADDPG(object):
                         T * B * world_size)
         train_info["critic_loss"], train_info["critic_grad_norm"] = cs[0], cs[1]
         new_priorities = None
-        if self.use_per:        # r_maddpg.py:216-218: eps is added per head AND after the mean over heads
+        if self.use_per and dev_prio:
+            s = td_stats.view(K, B, 2)
+            nu = self.args.per_nu
+            new_priorities = (((1 - nu) * s[:, :, 0] + nu * s[:, :, 1]) + self.per_eps).mean(dim=0) + self.per_eps
+        elif self.use_per:        # r_maddpg.py:216-218: eps is added per head AND after the mean over heads
             s = td_stats.view(K, B, 2).cpu().numpy().astype(np.float32)
             nu = self.args.per_nu
             per_head = [((1 - nu) * s[k, :, 0] + nu * s[k, :, 1]).flatten() + self.per_eps for k in range(K)]

@@ -132,15 +132,21 @@ class MlpReplayBuffer(object):
 
 class PrioritizedMlpReplayBuffer(MlpReplayBuffer):
     def __init__(self, alpha, policy_info, policy_agents, buffer_size, use_same_share_obs, use_avail_acts,
-                 use_reward_normalization=False, device=None):
+                 use_reward_normalization=False, device=None, device_tree=False):
         super(PrioritizedMlpReplayBuffer, self).__init__(policy_info, policy_agents, buffer_size, use_same_share_obs,
                                                          use_avail_acts, use_reward_normalization, device=device)
         self.alpha = alpha
+        self.device_tree = bool(device_tree)
         it_capacity = 1
         while it_capacity < buffer_size:
             it_capacity *= 2
-        self._it_sums = {p_id: SumSegmentTree(it_capacity) for p_id in self.policy_info.keys()}
-        self._it_mins = {p_id: MinSegmentTree(it_capacity) for p_id in self.policy_info.keys()}
+        if self.device_tree:
+            from .device_per import DevicePerTree
+            dev = self.policy_buffers[next(iter(self.policy_info))].device
+            self._dtrees = {p_id: DevicePerTree(it_capacity, alpha, dev) for p_id in self.policy_info.keys()}
+        else:
+            self._it_sums = {p_id: SumSegmentTree(it_capacity) for p_id in self.policy_info.keys()}
+            self._it_mins = {p_id: MinSegmentTree(it_capacity) for p_id in self.policy_info.keys()}
         self.max_priorities = {p_id: 1.0 for p_id in self.policy_info.keys()}
 
     def insert(self, num_insert_steps, obs, share_obs, acts, rewards, next_obs, next_share_obs, dones, dones_env,
@@ -148,6 +154,9 @@ class PrioritizedMlpReplayBuffer(MlpReplayBuffer):
         idx_range = super().insert(num_insert_steps, obs, share_obs, acts, rewards, next_obs, next_share_obs, dones,
                                    dones_env, valid_transition, avail_acts, next_avail_acts)
         for p_id in self.policy_info.keys():       # every new slot (A-3 fix)
+            if self.device_tree:
+                self._dtrees[p_id].set_to_max(idx_range)
+                continue
             self._it_sums[p_id][idx_range] = self.max_priorities[p_id] ** self.alpha
             self._it_mins[p_id][idx_range] = self.max_priorities[p_id] ** self.alpha
         return idx_range
@@ -160,6 +169,9 @@ class PrioritizedMlpReplayBuffer(MlpReplayBuffer):
     def sample(self, batch_size, beta=0, p_id=None):
         assert len(self) > batch_size, "Not enough samples in the buffer!"
         assert beta > 0
+        if self.device_tree:    # same host RNG draw as _sample_proportional; tree walk and weights on the device
+            inds, weights = self._dtrees[p_id].sample(np.random.random(size=batch_size), len(self), beta)
+            return self._gather(inds) + (weights, inds)
         batch_inds = self._sample_proportional(batch_size, p_id)
         p_min = self._it_mins[p_id].min() / self._it_sums[p_id].sum()
         max_weight = (p_min * len(self)) ** (-beta)
@@ -168,6 +180,9 @@ class PrioritizedMlpReplayBuffer(MlpReplayBuffer):
         return self._gather(batch_inds) + (weights, batch_inds)
 
     def update_priorities(self, idxes, priorities, p_id=None):
+        if self.device_tree:    # range checks of the host path would force a device sync; the kernels clamp nothing: callers pass
+            self._dtrees[p_id].set(idxes, priorities)   # indices returned by sample()
+            return
         priorities, idxes = np.asarray(priorities), np.asarray(idxes)
         assert len(idxes) == len(priorities)
         assert np.min(priorities) > 0

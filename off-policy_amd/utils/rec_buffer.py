@@ -218,21 +218,32 @@ class RecReplayBuffer(object):
 
 class PrioritizedRecReplayBuffer(RecReplayBuffer):
     def __init__(self, alpha, policy_info, policy_agents, buffer_size, episode_length, use_same_share_obs,
-                 use_avail_acts, use_reward_normalization=False, device=None):
+                 use_avail_acts, use_reward_normalization=False, device=None, device_tree=False):
+        """device_tree=True keeps the sum/min trees in HBM (utils/device_per.py): sample() then returns the importance weights and
+        the indices as device tensors, and update_priorities() takes device tensors, so a prioritized update has no host sync."""
         super(PrioritizedRecReplayBuffer, self).__init__(policy_info, policy_agents, buffer_size, episode_length,
                                                          use_same_share_obs, use_avail_acts, use_reward_normalization,
                                                          device=device)
         self.alpha = alpha
+        self.device_tree = bool(device_tree)
         it_capacity = 1
         while it_capacity < buffer_size:
             it_capacity *= 2
-        self._it_sums = {p_id: SumSegmentTree(it_capacity) for p_id in self.policy_info.keys()}
-        self._it_mins = {p_id: MinSegmentTree(it_capacity) for p_id in self.policy_info.keys()}
+        if self.device_tree:
+            from .device_per import DevicePerTree
+            dev = self.policy_buffers[next(iter(self.policy_info))].device
+            self._dtrees = {p_id: DevicePerTree(it_capacity, alpha, dev) for p_id in self.policy_info.keys()}
+        else:
+            self._it_sums = {p_id: SumSegmentTree(it_capacity) for p_id in self.policy_info.keys()}
+            self._it_mins = {p_id: MinSegmentTree(it_capacity) for p_id in self.policy_info.keys()}
         self.max_priorities = {p_id: 1.0 for p_id in self.policy_info.keys()}
 
     def insert(self, num_insert_episodes, obs, share_obs, acts, rewards, dones, dones_env, avail_acts=None):
         idx_range = super().insert(num_insert_episodes, obs, share_obs, acts, rewards, dones, dones_env, avail_acts)
         for p_id in self.policy_info.keys():      # A-3 fix: every new slot, not range(idx[0], idx[1])
+            if self.device_tree:
+                self._dtrees[p_id].set_to_max(idx_range)
+                continue
             self._it_sums[p_id][idx_range] = self.max_priorities[p_id] ** self.alpha
             self._it_mins[p_id][idx_range] = self.max_priorities[p_id] ** self.alpha
         return idx_range
@@ -245,6 +256,9 @@ class PrioritizedRecReplayBuffer(RecReplayBuffer):
     def sample(self, batch_size, beta=0, p_id=None):
         assert len(self) > batch_size, "Cannot sample with no completed episodes in the buffer!"
         assert beta > 0
+        if self.device_tree:    # same host RNG draw as _sample_proportional; tree walk and weights on the device
+            inds, weights = self._dtrees[p_id].sample(np.random.random(size=batch_size), len(self), beta)
+            return self._gather(inds) + (weights, inds)
         batch_inds = self._sample_proportional(batch_size, p_id)
         p_min = self._it_mins[p_id].min() / self._it_sums[p_id].sum()
         max_weight = (p_min * len(self)) ** (-beta)
@@ -253,6 +267,9 @@ class PrioritizedRecReplayBuffer(RecReplayBuffer):
         return self._gather(batch_inds) + (weights, batch_inds)
 
     def update_priorities(self, idxes, priorities, p_id=None):
+        if self.device_tree:    # range checks of the host path would force a device sync; the kernels clamp nothing: callers pass
+            self._dtrees[p_id].set(idxes, priorities)   # indices returned by sample()
+            return
         priorities = np.asarray(priorities)
         idxes = np.asarray(idxes)
         assert len(idxes) == len(priorities)

@@ -139,3 +139,85 @@ def test_reward_normalisation_matches_reference_buffers():
     mbuf.insert(len(g["mlp/idx_range"]), *[{"policy_0": g["mlp/tr/" + k]} for k in T_KEYS])
     got = mbuf.policy_buffers["policy_0"].sample_inds(g["mlp/inds"])[3].cpu().numpy()
     np.testing.assert_allclose(got, g["mlp/rewards"], rtol=2e-5, atol=2e-6)
+
+
+def test_device_per_trees_match_host_trees():
+    """Device sum/min trees (ope_per_tree_*) against the host segment trees through a random sequence of inserts, priority
+    updates with duplicate indices, and proportional samples driven by the same uniform draws."""
+    from offpolicy_amd.utils.device_per import DevicePerTree
+    from offpolicy_amd.utils.segment_tree import SumSegmentTree, MinSegmentTree
+    cap, alpha = 64, 0.6
+    dt = DevicePerTree(cap, alpha, "cuda:0")
+    hs, hm = SumSegmentTree(cap), MinSegmentTree(cap)
+    rng = np.random.RandomState(4)
+    max_prio = 1.0
+    filled = 0
+    for it in range(12):
+        n = int(rng.randint(1, 9))
+        idx = (np.arange(n) + filled) % cap                 # ring insert
+        filled = min(cap, filled + n)
+        dt.set_to_max(idx)
+        hs[idx] = max_prio ** alpha
+        hm[idx] = max_prio ** alpha
+        upd = rng.randint(0, filled, size=int(rng.randint(2, 12)))   # duplicates on purpose
+        pr = rng.uniform(0.05, 3.0, size=len(upd)).astype(np.float32)
+        dt.set(upd, pr)
+        hs[upd] = pr.astype(np.float64) ** alpha
+        hm[upd] = pr.astype(np.float64) ** alpha
+        max_prio = max(max_prio, float(pr.max()))
+        sl, ml, mp = dt.leaves()
+        np.testing.assert_allclose(sl, hs[np.arange(cap)], rtol=1e-12)
+        np.testing.assert_allclose(ml[:filled], hm[np.arange(filled)], rtol=1e-12)
+        np.testing.assert_allclose(mp, max_prio, rtol=1e-7)
+        rs, rm = dt.roots()
+        np.testing.assert_allclose([rs, rm], [hs.sum(), hm.min()], rtol=1e-12)
+        if filled > 4:
+            B, beta = 7, 0.4 + 0.05 * it
+            mass01 = rng.random_sample(B)
+            inds, w = dt.sample(mass01, filled, beta)
+            ref = hs.find_prefixsum_idx(mass01 * hs.sum(0, filled - 1))
+            assert np.array_equal(inds.cpu().numpy(), ref)
+            p_min = hm.min() / hs.sum()
+            ref_w = (hs[ref] / hs.sum() * filled) ** (-beta) / (p_min * filled) ** (-beta)
+            np.testing.assert_allclose(w.cpu().numpy(), ref_w, rtol=2e-6)
+
+
+def test_prioritized_buffer_with_device_trees_trains_without_host_round_trip():
+    """PrioritizedRecReplayBuffer(device_tree=True): sample -> QMix.train_policy_on_batch -> update_priorities with every PER
+    quantity a device tensor; same indices / weights / priorities as the host-tree buffer fed the same random draws."""
+    from conftest import load_golden
+    from gpu_util import build_from_fixture, make_args
+    from golden_util import fixture_dims, fixture_episodes, EP_KEYS
+    from offpolicy_amd.utils.synth import policy_info_for, as_policy_dicts
+    from offpolicy_amd.utils.rec_buffer import PrioritizedRecReplayBuffer
+    g = load_golden("qmix_tiny_huber_per")
+    dims, _, policy, trainer = build_from_fixture(g)
+    pinfo = policy_info_for(dims)
+    ep = as_policy_dicts(fixture_episodes(g))
+    bufs = {}
+    for mode in (False, True):
+        b = PrioritizedRecReplayBuffer(0.6, pinfo, {"policy_0": list(range(dims.n_agents))}, len(g["idx_range"]), dims.episode_length, True, True,
+                                       device="cuda:0", device_tree=mode)
+        b.insert(len(g["idx_range"]), *[ep[k] for k in EP_KEYS])
+        bufs[mode] = b
+    theta0, tgt0 = trainer.theta.clone(), trainer.theta_tgt.clone()
+    out = {}
+    for mode in (False, True):
+        trainer.theta.copy_(theta0); trainer.theta_tgt.copy_(tgt0)
+        trainer.optimizer.exp_avg.zero_(); trainer.optimizer.exp_avg_sq.zero_(); trainer.optimizer.step_count = 0
+        np.random.seed(11)
+        rec = []
+        for step in range(3):
+            batch = bufs[mode].sample(3, beta=0.5, p_id="policy_0")
+            info, prio, idxes = trainer.train_policy_on_batch(batch)
+            if mode:
+                assert torch.is_tensor(prio) and prio.is_cuda and torch.is_tensor(idxes) and idxes.is_cuda and torch.is_tensor(batch[7])
+            bufs[mode].update_priorities(idxes, prio, "policy_0")
+            to_np = lambda x: x.cpu().numpy() if torch.is_tensor(x) else np.asarray(x)
+            rec.append((to_np(idxes), to_np(batch[7]), to_np(prio), float(info["loss"])))
+        out[mode] = rec
+    for a, b in zip(out[False], out[True]):
+        assert np.array_equal(a[0], b[0])
+        np.testing.assert_allclose(a[1], b[1], rtol=2e-6)
+        np.testing.assert_allclose(a[2], b[2], rtol=2e-6)
+        np.testing.assert_allclose(a[3], b[3], rtol=1e-6)
