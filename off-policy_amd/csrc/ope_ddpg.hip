@@ -5,6 +5,7 @@
 //   onehot_from_logits / gumbel_softmax                     offpolicy/utils/util.py:156-214
 // Both networks are MLPBase trunks + a Linear head, so the heavy lifting is the shared trunk_fwd / trunk_bwd / wgrad /
 // finalize kernels in "mlp" mode; this file adds the small row-parallel pieces around them and the two C-ABI steps.
+#include <stdlib.h>
 #include <string.h>
 
 #include "ope_ddpg.h"
@@ -17,23 +18,24 @@ namespace ope {
 // (maddpg.py:128 for the critic update, 207-227 for the actor update: "mask * actor + (1 - mask) * buffer";
 //  r_maddpg.py:162, 291-301 for the sequence form; the MLP family is T = 1)
 // ---------------------------------------------------------------------------------------------------------
-__global__ void build_cin_kernel(const float* __restrict__ cent, const float* __restrict__ acts, const float* __restrict__ repl,
-                                 int T, int B, int N, int A, int S, int reps, float* __restrict__ out) {
+__global__ void __launch_bounds__(256) build_cin_kernel(const float* __restrict__ cent, const float* __restrict__ acts,
+                                                         const float* __restrict__ repl, int T, int B, int N, int A, int S, int reps,
+                                                         float* __restrict__ out) {
+  // one wave per output row: the row decode (t, rep, b) is done once, lanes stride over the Din columns
   const int Din = S + N * A;
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (int64_t)T * reps * B * Din) return;
-  const int r = (int)(i / Din), c = (int)(i - (int64_t)r * Din);
-  const int t = r / (reps * B);
-  const int rem = r - t * (reps * B);
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= (int64_t)T * reps * B) return;
+  const int t = (int)(r / (reps * B));
+  const int rem = (int)(r - (int64_t)t * (reps * B));
   const int rep = rem / B, b = rem - rep * B;
-  float v;
-  if (c < S) {
-    v = cent[((int64_t)t * B + b) * S + c];
-  } else {
-    const int a = (c - S) / A, j = (c - S) - a * A;
-    v = (repl && a == rep) ? repl[(int64_t)r * A + j] : acts[(((int64_t)t * N + a) * B + b) * A + j];
+  const float* crow = cent + ((int64_t)t * B + b) * S;
+  float* orow = out + r * Din;
+  for (int c = lane; c < S; c += 64) orow[c] = crow[c];
+  for (int c = lane; c < N * A; c += 64) {
+    const int a = c / A, j = c - a * A;
+    orow[S + c] = (repl && a == rep) ? repl[r * A + j] : acts[(((int64_t)t * N + a) * B + b) * A + j];
   }
-  out[i] = v;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -246,6 +248,81 @@ __global__ void __launch_bounds__(256) action_grad_kernel(ActGradArgs a) {
   for (int j = 0; j < a.A4; ++j) out[j] = j < a.A ? a.y[(int64_t)r * a.A + j] * (out[j] - dot) : 0.f;
 }
 
+// Same computation on the matrix pipe, for many rows: a wave owns 16 consecutive rows that share the agent copy (B % 16 == 0),
+// dy[row][action] = sum_i dz[row][i] W[i][col0 + action] is one or two 16x16 MFMA tiles over K = 64 (transposed-chain lane
+// convention: lane (j, g) holds hidden units / actions 16*tile + 4g + r of row j); the two row scalars are lane-local dot
+// products + a 4-lane sum. 230 k rows (MMM2, B = 128): 370 us thread-per-row -> this form.
+__global__ void __launch_bounds__(256) action_grad_mfma_kernel(ActGradArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int row0 = (blockIdx.x * 4 + wave) * 16;
+  if (row0 >= a.R) return;
+  const int row = row0 + j;
+  const bool valid = row < a.R;
+  const int64_t rr = valid ? row : a.R - 1;
+  const int rep = (row0 / a.B) % a.N;          // uniform over the tile
+  const int col0 = a.S + rep * a.A;
+  const float rs1 = a.rstd1[rr], mu1 = a.mu1[rr], rs0 = a.rstd0[rr], mu0 = a.mu0[rr];
+  const float inv_rs1 = 1.0f / rs1;
+  f32x4 dz[4];
+  float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+  for (int ft = 0; ft < 4; ++ft) {
+    dz[ft] = *reinterpret_cast<const f32x4*>(a.dz1 + rr * OPE_H + 16 * ft + 4 * g);
+    const f32x4 xh = *reinterpret_cast<const f32x4*>(a.xhat1 + rr * OPE_H + 16 * ft + 4 * g);
+    const f32x4 cv = *reinterpret_cast<const f32x4*>(a.cvec + 16 * ft + 4 * g);
+    const f32x4 cb = *reinterpret_cast<const f32x4*>(a.cvec + OPE_H + 16 * ft + 4 * g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      m1 = fmaf(dz[ft][r], cv[r], m1);
+      m2 = fmaf(dz[ft][r], fmaf(xh[r], inv_rs1, mu1) - cb[r], m2);
+    }
+  }
+  const float invD = 1.0f / (float)a.Din;
+  m1 = rowsum4(m1) * invD;
+  m2 = rowsum4(m2) * invD;
+  const int ntile = (a.A + 15) >> 4;           // 1 or 2
+  f32x4 dy[2];
+  dy[0] = dy[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* W = a.theta + a.fc1_w;
+  for (int u = 0; u < ntile; ++u) {
+    const int o = 16 * u + j;                   // output (action) index supplied by this lane as the A-operand row
+    const int oc = col0 + (o < a.A ? o : a.A - 1);
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft) {
+      f32x4 wv;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) wv[r] = W[(int64_t)(16 * ft + 4 * g + r) * a.Din + oc];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dy[u] = mfma16(wv[r], dz[ft][r], dy[u]);
+    }
+  }
+  // this lane now holds dy for row j, actions 16u + 4g + r
+  float dx[2][4], yv[2][4];
+  float dot = 0.f;
+  for (int u = 0; u < ntile; ++u)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = 16 * u + 4 * g + r;
+      const bool ok = k < a.A;
+      const int kc = ok ? k : 0;
+      const float y = a.y[rr * a.A + kc];
+      const float xh = (a.act[rr * a.A + kc] - mu0) * rs0;
+      const float v = rs0 * (dy[u][r] * a.theta[a.fn_w + col0 + kc] - m1 - xh * m2);
+      dx[u][r] = ok ? v : 0.f;
+      yv[u][r] = ok ? y : 0.f;
+      dot = fmaf(dx[u][r], yv[u][r], dot);
+    }
+  dot = rowsum4(dot);
+  if (!valid) return;
+  for (int u = 0; u < ntile; ++u)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = 16 * u + 4 * g + r;
+      if (k < a.A4) a.dlogits[(int64_t)row * a.A4 + k] = k < a.A ? yv[u][r] * (dx[u][r] - dot) : 0.f;
+    }
+}
+
 // Same computation, one wave per row: lane i owns hidden unit i, the 2 + A dot products over the 64 units are wave
 // reductions. Used when there are too few rows for the thread-per-row form to fill the machine.
 __global__ void __launch_bounds__(256) action_grad_wave_kernel(ActGradArgs a) {
@@ -289,8 +366,8 @@ static int launch1d(int64_t n) { return ope_cdiv(n, 256); }
 
 int launch_build_cin(const float* cent, const float* acts, const float* repl, int T, int B, int N, int A, int S, int reps, float* out,
                      hipStream_t st) {
-  OPE_L(hipLaunchKernelGGL(build_cin_kernel, dim3(launch1d((int64_t)T * reps * B * (S + N * A))), dim3(256), 0, st, cent, acts, repl, T,
-                           B, N, A, S, reps, out));
+  OPE_L(hipLaunchKernelGGL(build_cin_kernel, dim3(ope_cdiv((int64_t)T * reps * B, 4)), dim3(256), 0, st, cent, acts, repl, T, B, N, A, S,
+                           reps, out));
   return OPE_OK;
 }
 int launch_action(const float* logits, const float* avail, const float* U, int rows, int B, int A, int N, int mode, int t_shift,
@@ -304,8 +381,14 @@ int launch_action(const float* logits, const float* avail, const float* U, int r
 }
 int launch_action_grad(const ActGradArgs& a, hipStream_t st) {
   OPE_L(hipLaunchKernelGGL(fc1_colsum_kernel, dim3(OPE_H), dim3(64), 0, st, a));
-  if (a.R <= 16384)   // few rows (MLP family): one wave per row, lane = hidden unit -- a 64-long serial chain per thread otherwise
+  // OPE_ACTGRAD = wave | mfma | thread forces a form (tests); default by size
+  const char* f = getenv("OPE_ACTGRAD");
+  const bool mfma_ok = a.B % 16 == 0 && a.A <= 32;
+  const int form = f ? (f[0] == 'w' ? 0 : (f[0] == 'm' && mfma_ok ? 1 : 2)) : (a.R <= 16384 ? 0 : (mfma_ok ? 1 : 2));
+  if (form == 0)   // few rows (MLP family): one wave per row, lane = hidden unit -- a 64-long serial chain per thread otherwise
     OPE_L(hipLaunchKernelGGL(action_grad_wave_kernel, dim3(ope_cdiv(a.R, 4)), dim3(256), 0, st, a));
+  else if (form == 1)
+    OPE_L(hipLaunchKernelGGL(action_grad_mfma_kernel, dim3(ope_cdiv(ope_cdiv(a.R, 16), 4)), dim3(256), 0, st, a));
   else
     OPE_L(hipLaunchKernelGGL(action_grad_kernel, dim3(launch1d(a.R)), dim3(256), 0, st, a));
   return OPE_OK;
@@ -527,10 +610,8 @@ extern "C" int ope_ddpg_critic_loss_and_grad(const ope_ddpg_cfg* cfg, const ope_
   if ((rc = launch_action(W + p.lgn, bt->next_avail_acts, target_noise_u, p.Ra, p.B, p.A, p.N, cfg->target_gumbel ? 1 : 0, 0, W + p.cnact,
                           nullptr, nullptr, st))) return rc;
   // critic inputs
-  OPE_L(hipLaunchKernelGGL(build_cin_kernel, dim3(launch1d((int64_t)p.B * p.Din)), dim3(256), 0, st, bt->next_share_obs, W + p.cnact,
-                           (const float*)nullptr, 1, p.B, 1, p.N * p.A, p.S, 1, W + p.xin_t));
-  OPE_L(hipLaunchKernelGGL(build_cin_kernel, dim3(launch1d((int64_t)p.B * p.Din)), dim3(256), 0, st, bt->share_obs, bt->acts,
-                           (const float*)nullptr, 1, p.B, p.N, p.A, p.S, 1, W + p.xin));
+  if ((rc = launch_build_cin(bt->next_share_obs, W + p.cnact, nullptr, 1, p.B, 1, p.N * p.A, p.S, 1, W + p.xin_t, st))) return rc;
+  if ((rc = launch_build_cin(bt->share_obs, bt->acts, nullptr, 1, p.B, p.N, p.A, p.S, 1, W + p.xin, st))) return rc;
   // target critic, live critic
   if ((rc = trunk_mlp(p, W, W + p.xin_t, p.B, p.Din, theta_critic_tgt, p.CL, W + p.a2t, false, nullptr, W + p.qt, p.K, st))) return rc;   // [B][K]
   if ((rc = trunk_mlp(p, W, W + p.xin, p.B, p.Din, theta_critic, p.CL, W + p.a2c, true, nullptr, W + p.qc, p.K, st))) return rc;
@@ -560,8 +641,7 @@ extern "C" int ope_ddpg_actor_loss_and_grad(const ope_ddpg_cfg* cfg, const ope_m
   if ((rc = launch_action(W + p.lga, bt->avail_acts, gumbel_noise_u, p.Ra, p.B, p.A, p.N, 1, 0, nullptr, W + p.actout, W + p.ysoft, st)))
     return rc;
   // N stacked copies of the joint action, copy i carrying the actor's action for agent i
-  OPE_L(hipLaunchKernelGGL(build_cin_kernel, dim3(launch1d((int64_t)p.Ra * p.Din)), dim3(256), 0, st, bt->share_obs, bt->acts,
-                           W + p.actout, 1, p.B, p.N, p.A, p.S, p.N, W + p.xin_a));
+  if ((rc = launch_build_cin(bt->share_obs, bt->acts, W + p.actout, 1, p.B, p.N, p.A, p.S, p.N, W + p.xin_a, st))) return rc;
   // critic (parameters frozen) on the stacked input; only head 0 enters the objective
   if ((rc = trunk_mlp(p, W, W + p.xin_a, p.Ra, p.Din, theta_critic, p.CL, W + p.a2c, true, nullptr, W + p.qc, p.K, st))) return rc;
   OPE_L(hipLaunchKernelGGL(actor_obj_kernel, dim3(launch1d(p.Ra)), dim3(256), 0, st, W + p.qc, p.K, bt->valid_transition, p.Ra,

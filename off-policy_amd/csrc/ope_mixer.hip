@@ -630,22 +630,30 @@ int launch_vdn(const VdnArgs& a, hipStream_t st) {
   return OPE_OK;
 }
 
-// per-episode [mean_t |err|, max_t |err|] for the R2D2-style priorities (qmix.py:179-181)
-__global__ void td_stats_kernel(const float* __restrict__ err_abs, int T, int B, float* __restrict__ out) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+// per-episode [mean_t |err|, max_t |err|] for the R2D2-style priorities (qmix.py:179-181): one wave per episode, lanes stride
+// over time, fixed-order tree (the thread-per-episode form walked T strided loads serially: 43 us at T = 180)
+__global__ void __launch_bounds__(256) td_stats_kernel(const float* __restrict__ err_abs, int T, int B, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;
   float s = 0.f, mx = 0.f;
-  for (int t = 0; t < T; ++t) {
+  for (int t = lane; t < T; t += 64) {
     const float e = err_abs[(int64_t)t * B + b];
     s += e;
     mx = fmaxf(mx, e);
   }
-  out[2 * b] = s / (float)T;
-  out[2 * b + 1] = mx;
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o, 64);
+    mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  }
+  if (lane == 0) {
+    out[2 * b] = s / (float)T;
+    out[2 * b + 1] = mx;
+  }
 }
 
 int launch_td_stats(const float* err_abs, int T, int B, float* out, hipStream_t st) {
-  hipLaunchKernelGGL(td_stats_kernel, dim3(ope_cdiv(B, 64)), dim3(64), 0, st, err_abs, T, B, out);
+  hipLaunchKernelGGL(td_stats_kernel, dim3(ope_cdiv(B, 4)), dim3(256), 0, st, err_abs, T, B, out);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   return OPE_OK;
 }

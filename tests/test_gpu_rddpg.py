@@ -205,3 +205,35 @@ def test_unnormalised_gradient_is_additive_over_episodes():
     for full, parts in ((full_c, h1c + h2c), (full_a, h1a + h2a)):
         assert np.isfinite(full).all() and np.abs(full).max() > 0
         np.testing.assert_allclose(full, parts, rtol=0, atol=2e-4 * np.abs(full).max())
+
+
+def test_action_gradient_kernel_forms_agree(monkeypatch):
+    """The critic-side action gradient has three forms (one wave per row, thread per row, MFMA tiles for many rows); all must
+    give the same actor gradient. B = 16 so that the MFMA form's 16-row tiles share an agent copy."""
+    from offpolicy_amd.config import default_args
+    from offpolicy_amd.utils.synth import DIMS, EnvDims, synth_episodes
+    d0 = DIMS["MMM2"]
+    dims = EnvDims("mmm2_t12", d0.n_agents, d0.act_dim, d0.obs_dim, d0.state_dim, 12)     # A = 18: two action tiles
+    B = 16
+    _, buf, policy, trainer = build(None, dims=dims, args=default_args(), td3=False, cap=B)
+    ep = synth_episodes(np.random.RandomState(2), B, dims, avail="bernoulli", runner_padding=True)
+    buf.insert(B, *[{"policy_0": ep[k]} for k in EP_KEYS])
+    s = buf.policy_buffers["policy_0"].sample_inds(np.arange(B))
+    batch = tuple({"policy_0": a} for a in s) + (None, None)
+    a0, c0 = policy.actor._flat.clone(), policy.critic._flat.clone()
+    grads = {}
+    for form in ("wave", "thread", "mfma"):
+        monkeypatch.setenv("OPE_ACTGRAD", form)
+        policy.actor._flat.copy_(a0); policy.critic._flat.copy_(c0)
+        policy.target_actor._flat.copy_(a0); policy.target_critic._flat.copy_(c0)
+        for opt in (policy.actor_optimizer, policy.critic_optimizer):
+            opt.exp_avg.zero_(); opt.exp_avg_sq.zero_(); opt.step_count = 0
+        trainer.num_updates["policy_0"] = 0
+        torch.manual_seed(5)
+        trainer.shared_train_policy_on_batch("policy_0", batch)
+        torch.cuda.synchronize()
+        grads[form] = trainer._grads[B][1].cpu().numpy().copy()
+    scale = np.abs(grads["wave"]).max()
+    assert scale > 0
+    for form in ("thread", "mfma"):
+        np.testing.assert_allclose(grads[form], grads["wave"], rtol=0, atol=3e-6 * scale, err_msg=form)
