@@ -388,14 +388,19 @@ __global__ void __launch_bounds__(256, 2) trunk_fwd3_kernel(TrunkFwdArgs a) {
 #define OPE_STAMP() do { if (dbg && lane == 0 && dbi < 16) dbg[dbi] = __builtin_amdgcn_s_memtime(); ++dbi; } while (0)
   OPE_STAMP();
   // ---- this wave's weight fragments, loaded once ----
+  // wide inputs (KCM > 16): only the first-layer fragments stay resident; W2 / W_ih fragments (16 loads per tile) are
+  // fetched where they are used, otherwise the register file spills
+  constexpr bool WREG = KCM <= 16;
   f32x4 w1[KCM], w2[4], w3[3][4];
   {
     const float* __restrict__ Wr = th + a.L.fc1_w + (int64_t)(16 * wave + j) * D;
 #pragma unroll
     for (int c = 0; c < KCM; ++c) w1[c] = load4c<VEC>(Wr, 16 * c + 4 * g, D);   // clamped; columns >= D meet zero activations
+    if (WREG) {
 #pragma unroll
-    for (int ft = 0; ft < 4; ++ft) w2[ft] = *reinterpret_cast<const f32x4*>(th + a.L.fc2_w + (int64_t)(16 * wave + j) * OPE_H + 16 * ft + 4 * g);
-    if (!a.a2_out) {
+      for (int ft = 0; ft < 4; ++ft) w2[ft] = *reinterpret_cast<const f32x4*>(th + a.L.fc2_w + (int64_t)(16 * wave + j) * OPE_H + 16 * ft + 4 * g);
+    }
+    if (WREG && !a.a2_out) {
 #pragma unroll
       for (int u = 0; u < 3; ++u)
 #pragma unroll
@@ -449,14 +454,9 @@ __global__ void __launch_bounds__(256, 2) trunk_fwd3_kernel(TrunkFwdArgs a) {
       const int rr = wave * 4 + q;
       const int row = row0 + rr;
       const float* xr = a.x + (int64_t)(row < a.R ? row : a.R - 1) * D;
-      f32x4 xv[NI4], gv[NI4], bv[NI4];
+      f32x4 xv[NI4];
 #pragma unroll
       for (int i = 0; i < NI4; ++i) xv[i] = load4c<VEC>(xr, 4 * c + 64 * i, D);
-#pragma unroll
-      for (int i = 0; i < NI4; ++i) {
-        gv[i] = load4c<VEC>(th + a.L.fn_w, 4 * c + 64 * i, D);
-        bv[i] = load4c<VEC>(th + a.L.fn_b, 4 * c + 64 * i, D);
-      }
       OPE_STAMP();
       float s = 0.f;
 #pragma unroll
@@ -480,7 +480,7 @@ __global__ void __launch_bounds__(256, 2) trunk_fwd3_kernel(TrunkFwdArgs a) {
 #pragma unroll
       for (int i = 0; i < NI4; ++i) {
         const int k = 4 * c + 64 * i;
-        const f32x4 gm = mask4(gv[i], k, D), bt = mask4(bv[i], k, D);
+        const f32x4 gm = mask4(load4c<VEC>(th + a.L.fn_w, k, D), k, D), bt = mask4(load4c<VEC>(th + a.L.fn_b, k, D), k, D);   // L1-resident
         f32x4 o;
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = fmaf(xv[i][r] * rstd, gm[r], bt[r]);   // exactly 0 beyond D
@@ -501,10 +501,13 @@ __global__ void __launch_bounds__(256, 2) trunk_fwd3_kernel(TrunkFwdArgs a) {
     f32x4 acc = b1;
 #pragma unroll
     for (int c = 0; c < KCM; ++c) {
+      // keep the LDS operand reads at most 4 chunks ahead of their MFMAs (hoisting all KCM of them costs 4*KCM registers)
+      if ((c & 3) == 0) __builtin_amdgcn_sched_barrier(0);
       const f32x4 xv = *reinterpret_cast<const f32x4*>(xn + j * Dp + 16 * c + 4 * g);
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc = mfma16(w1[c][r], xv[r], acc);
     }
+    __builtin_amdgcn_sched_barrier(0);
     OPE_STAMP();   // fc1 done
     f32x4 xh, act;
     float rs, mu;
@@ -532,6 +535,10 @@ __global__ void __launch_bounds__(256, 2) trunk_fwd3_kernel(TrunkFwdArgs a) {
     OPE_STAMP();   // LN1 + saves + actb + barrier
     // ---- fc2 ----
     acc = b2;
+    if (!WREG) {
+#pragma unroll
+      for (int ft = 0; ft < 4; ++ft) w2[ft] = *reinterpret_cast<const f32x4*>(th + a.L.fc2_w + (int64_t)(16 * wave + j) * OPE_H + 16 * ft + 4 * g);
+    }
 #pragma unroll
     for (int ft = 0; ft < 4; ++ft) {
       const f32x4 xv = *reinterpret_cast<const f32x4*>(actb + j * kActPitch + 16 * ft + 4 * g);
@@ -573,6 +580,13 @@ __global__ void __launch_bounds__(256, 2) trunk_fwd3_kernel(TrunkFwdArgs a) {
     __syncthreads();
 
     // ---- gi = W_ih a2 + b_ih : 3 of the 12 output tiles ----
+    if (!WREG) {
+#pragma unroll
+      for (int u = 0; u < 3; ++u)
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft)
+          w3[u][ft] = *reinterpret_cast<const f32x4*>(th + a.L.wih + (int64_t)(16 * (3 * wave + u) + j) * OPE_H + 16 * ft + 4 * g);
+    }
     f32x4 o[3];
 #pragma unroll
     for (int u = 0; u < 3; ++u) o[u] = *reinterpret_cast<const f32x4*>(th + a.L.bih + 16 * (3 * wave + u) + 4 * g);
