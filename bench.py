@@ -153,7 +153,9 @@ def main():
     np.random.seed(1)
     pinfo = policy_info_for(dims)
     policy = QMixPolicy({"args": args, "device": dev}, pinfo["policy_0"])
-    trainer = QMix(args, dims.n_agents, {"policy_0": policy}, lambda x: "policy_0", device=dev, episode_length=dims.episode_length)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):     # the trainer echoes the reference's "double Q learning will be used" line
+        trainer = QMix(args, dims.n_agents, {"policy_0": policy}, lambda x: "policy_0", device=dev, episode_length=dims.episode_length)
     trainer.fuse_soft_update = True      # Polyak inside the Adam kernel; soft_target_updates() below then skips
     buf = RecReplayBuffer(pinfo, {"policy_0": list(range(dims.n_agents))}, a.episodes, dims.episode_length, True, True, device=dev)
     fill_buffer(buf, dims, a.episodes, np.random.RandomState(100 + rank))   # every rank holds its own replay shard
