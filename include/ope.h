@@ -138,6 +138,13 @@ int64_t ope_qmix_workspace_bytes(const ope_qmix_cfg* cfg);
 /* One-time initialisation of a freshly allocated workspace (constant regions the kernels only read). Must be called
  * once per workspace buffer before the first ope_qmix_loss_and_grad on it. */
 int ope_qmix_workspace_init(const ope_qmix_cfg* cfg, void* workspace, int64_t workspace_bytes, void* stream);
+/* Diagnostics (tests, tools/): ope_set_debug(1) makes the step functions keep extra intermediates and per-wave phase
+ * stamps in the workspace ("q_all", "dbg"). ope_set_scan_kernel(family, waves) pins the GRU-scan kernel family
+ * (4: ope_gru4.hip, 1: ope_gru1.hip, 0: by row count) and, for family 4, the compute waves per row (2, 4, 0: by row
+ * count); the environment variables OPE_GRU / OPE_GRU4_W set the initial values. */
+void ope_set_debug(int on);
+void ope_set_scan_kernel(int family, int waves_per_row);
+
 /* Named sub-buffers of the workspace, for tests/debugging: returns byte offset, writes element count. -1 if unknown. */
 int64_t ope_qmix_workspace_find(const ope_qmix_cfg* cfg, const char* name, int64_t* n_floats);
 

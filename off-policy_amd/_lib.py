@@ -71,6 +71,7 @@ def _load():
         "ope_version": (C.c_int, []),
         "ope_strerror": (C.c_char_p, [C.c_int]),
         "ope_set_debug": (None, [C.c_int]),
+        "ope_set_scan_kernel": (None, [C.c_int, C.c_int]),
         "ope_episode_bytes": (i64, [C.POINTER(Dims)]),
         "ope_store_insert": (C.c_int, [C.POINTER(Dims), i32, C.POINTER(Fields), C.POINTER(Fields), p, i32, p]),
         "ope_store_gather": (C.c_int, [C.POINTER(Dims), i32, C.POINTER(Fields), p, i32, C.POINTER(Fields), p]),

@@ -38,6 +38,7 @@ struct GruFwdArgs {
   float* h0out; float* h1out;           // [L][NB][64]
   const float* hinit;                   // [NB][64] or null (zeros): initial state of net 0
   const float* hinit1;                  // same for net 1 (time-chunked scans continue from the previous chunk's last state)
+  long long* dbg;                       // optional per-compute-wave phase cycle sums [rows][4][8] (ope_set_debug; gru4 only)
   int whh_off, bhh_off;
   float* rg; float* zg; float* ng; float* ghn;  // [L][NB][64] gate saves (live) or null
 };
@@ -86,6 +87,7 @@ struct GruBwdArgs {
   int t_lo;            // this launch covers t = T-1 .. t_lo (time-chunked BPTT); 0 = to the start
   const float* dh_in;  // [NB][64] adjoint carried in from the later chunk, or null (zeros)
   float* dh_carry;     // [NB][64] adjoint w.r.t. h_{t_lo - 1} handed to the earlier chunk, or null
+  long long* dbg;      // optional per-compute-wave phase cycle sums [NB][4][8] (ope_set_debug; gru4 only)
 };
 
 struct TrunkBwdArgs {
@@ -105,10 +107,18 @@ struct TrunkBwdArgs {
 int launch_trunk_fwd(const TrunkFwdArgs& a, bool save, hipStream_t st);
 int launch_trunk_fwd2(const TrunkFwdArgs& a, bool save, hipStream_t st);   // workgroup-cooperative form (ope_trunk2.hip)
 int launch_trunk_fwd3(const TrunkFwdArgs& a, bool save, hipStream_t st);   // persistent, weights in registers (ope_trunk2.hip)
+// scans with at most this many rows use the latency-oriented four-waves-per-row kernels (ope_gru4.hip)
+constexpr int kGru4MaxRows = 1024;
+extern int g_scan_family;   // 0 auto | 1 | 4   (ope_set_scan_kernel / OPE_GRU)
+extern int g_scan_waves;    // 0 auto | 2 | 4   (ope_set_scan_kernel / OPE_GRU4_W)
 int launch_gru_fwd(const GruFwdArgs& a, hipStream_t st);
+int launch_gru_fwd1(const GruFwdArgs& a, hipStream_t st);   // one wave per row (ope_gru1.hip)
+int launch_gru_fwd4(const GruFwdArgs& a, hipStream_t st);   // output-split over four waves per row (ope_gru4.hip)
 int launch_head_fwd(const HeadFwdArgs& a, int mode, hipStream_t st);
 int launch_head_bwd(const HeadBwdArgs& a, hipStream_t st);
 int launch_gru_bwd(const GruBwdArgs& a, hipStream_t st);
+int launch_gru_bwd1(const GruBwdArgs& a, hipStream_t st);
+int launch_gru_bwd4(const GruBwdArgs& a, hipStream_t st);
 int launch_trunk_bwd(const TrunkBwdArgs& a, hipStream_t st);
 int launch_trunk_bwd3(const TrunkBwdArgs& a, hipStream_t st);   // persistent cooperative form (ope_trunk_bwd3.hip)
 int launch_transpose_weights(const float* theta, const AgentLayout& L, float* thetaT, hipStream_t st);

@@ -2,7 +2,7 @@
 // (loss.backward(), qmix.py:191); here every op's adjoint is written out:
 //
 //   head_bwd  : d agent_q -> dq at the chosen action -> LN backward -> dh_out[t]             (thread per row)
-//   gru_bwd   : BPTT over t = T-1..0 (one wave per (agent,episode) row, W_hh^T columns in VGPRs)
+//   gru_bwd   : BPTT over t = T-1..0 (ope_gru4.hip / ope_gru1.hip)
 //   trunk_bwd : dgi -> W_ih^T -> LN2 bwd -> ReLU -> fc2^T -> LN1 bwd -> ReLU -> dz1           (f32 MFMA chain)
 //
 // Weight gradients are K-reductions over all rows and are done by ope_wgrad.hip from the per-row adjoints
@@ -73,151 +73,12 @@ int launch_head_bwd(const HeadBwdArgs& a, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// gru_bwd: BPTT over t = T-1 .. 0. Same decomposition as gru_fwd: a row is split over WPR waves, wave q owning the
-// slice i in [q*64/WPR, (q+1)*64/WPR) of the reduction
-//   dh_{t-1}[k] = dh_t[k] z[k] + sum_i ( W_hr[i][k] dr_pre[i] + W_hz[i][k] dz_pre[i] + W_hn[i][k] dghn[i] )
-// with lane k holding its 3 x 64/WPR weights (column k of W_hh) in VGPRs. Every wave evaluates the gate adjoints
-// redundantly (bit-identical), broadcasts its i-slice of them through a private LDS slot, and the WPR partial sums
-// meet behind one LDS barrier per step. Wave 0 only loads (the saved activations, one 8-step chunk ahead, via
-// compiler-invisible asm loads), the last wave only stores (dgi, dghn).
+// gru_bwd: BPTT over t = T-1 .. t_lo; kernels in ope_gru4.hip / ope_gru1.hip, chosen like launch_gru_fwd.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kGruChunkB = 8;
-
-template <int WPR>
-__global__ void __launch_bounds__(256) gru_bwd_kernel(GruBwdArgs a) {
-  constexpr int RPW = 4 / WPR;
-  constexpr int IW = OPE_H / WPR;
-  constexpr int C = kGruChunkB;
-  __shared__ __attribute__((aligned(16))) float ds[4][3][OPE_H];
-  __shared__ __attribute__((aligned(16))) float part[2][RPW][WPR][OPE_H];
-  __shared__ __attribute__((aligned(16))) float sav[RPW][2][C][6][OPE_H];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int rl = wave / WPR, q = wave % WPR;
-  const int row_raw = blockIdx.x * RPW + rl;
-  const bool active = row_raw < a.NB;
-  const int row = active ? row_raw : a.NB - 1;
-  const bool loader = (q == 0), storer = (q == WPR - 1) && active;
-
-  f32x2 wr[IW / 2], wz[IW / 2], wn[IW / 2];
-  {
-    const float* w = a.theta + a.whh_off + (int64_t)(IW * q) * OPE_H + lane;
-#pragma unroll
-    for (int i = 0; i < IW / 2; ++i) {
-      wr[i] = f32x2{w[(int64_t)(2 * i) * OPE_H], w[(int64_t)(2 * i + 1) * OPE_H]};
-      wz[i] = f32x2{w[(int64_t)(OPE_H + 2 * i) * OPE_H], w[(int64_t)(OPE_H + 2 * i + 1) * OPE_H]};
-      wn[i] = f32x2{w[(int64_t)(2 * OPE_H + 2 * i) * OPE_H], w[(int64_t)(2 * OPE_H + 2 * i + 1) * OPE_H]};
-    }
-  }
-  const int64_t NB = a.NB;
-  float preA[C][3], preB[C][3];   // loader: r,z,n | ghn,dh_out,h_prev of the next chunk
-  auto load_chunk = [&](int c) {
-#pragma unroll
-    for (int s2 = 0; s2 < C; ++s2) {
-      const int t = max(a.T - 1 - (c * C + s2), a.t_lo);
-      const int64_t o = ((int64_t)t * NB + row) * OPE_H + lane;
-      gload_async(preA[s2][0], a.rg + o);
-      gload_async(preA[s2][1], a.zg + o);
-      gload_async(preA[s2][2], a.ng + o);
-      gload_async(preB[s2][0], a.ghn + o);
-      gload_async(preB[s2][1], a.dh_out + o);
-      gload_async(preB[s2][2], a.h + (t > 0 ? o - NB * OPE_H : o));
-    }
-  };
-  auto publish_chunk = [&](int c, int buf) {
-    OPE_GWAIT24(preA);
-    asm volatile("" : "+v"(preB[0][0]), "+v"(preB[0][1]), "+v"(preB[0][2]), "+v"(preB[1][0]), "+v"(preB[1][1]), "+v"(preB[1][2]),
-                 "+v"(preB[2][0]), "+v"(preB[2][1]), "+v"(preB[2][2]), "+v"(preB[3][0]), "+v"(preB[3][1]), "+v"(preB[3][2]),
-                 "+v"(preB[4][0]), "+v"(preB[4][1]), "+v"(preB[4][2]), "+v"(preB[5][0]), "+v"(preB[5][1]), "+v"(preB[5][2]),
-                 "+v"(preB[6][0]), "+v"(preB[6][1]), "+v"(preB[6][2]), "+v"(preB[7][0]), "+v"(preB[7][1]), "+v"(preB[7][2]));
-#pragma unroll
-    for (int s2 = 0; s2 < C; ++s2) {
-      const int t = a.T - 1 - (c * C + s2);
-      sav[rl][buf][s2][0][lane] = preA[s2][0];
-      sav[rl][buf][s2][1][lane] = preA[s2][1];
-      sav[rl][buf][s2][2][lane] = preA[s2][2];
-      sav[rl][buf][s2][3][lane] = preB[s2][0];
-      sav[rl][buf][s2][4][lane] = preB[s2][1];
-      sav[rl][buf][s2][5][lane] = t > 0 ? preB[s2][2] : 0.f;   // h_{-1} = 0
-    }
-  };
-  if (loader) {
-    load_chunk(0);
-    publish_chunk(0, 0);
-  }
-  lds_barrier();
-
-  float dh = a.dh_in ? a.dh_in[(int64_t)row * OPE_H + lane] : 0.f;
-  float(*myds)[OPE_H] = ds[wave];
-  const int nsteps = a.T - a.t_lo;
-  const int nchunks = (nsteps + C - 1) / C;
-  for (int c = 0; c < nchunks; ++c) {
-    const int buf = c & 1;
-    if (loader && c + 1 < nchunks) load_chunk(c + 1);
-    const int ns = min(C, nsteps - c * C);
-    for (int s2 = 0; s2 < ns; ++s2) {
-      const int t = a.T - 1 - (c * C + s2);
-      const float r = sav[rl][buf][s2][0][lane], z = sav[rl][buf][s2][1][lane], n = sav[rl][buf][s2][2][lane];
-      const float gn = sav[rl][buf][s2][3][lane], dho = sav[rl][buf][s2][4][lane], hp = sav[rl][buf][s2][5][lane];
-      const float dht = dh + dho;
-      const float dn = dht * (1.0f - z);
-      const float dzg = dht * (hp - n);
-      const float dn_pre = dn * (1.0f - n * n);
-      const float dz_pre = dzg * z * (1.0f - z);
-      const float dr_pre = dn_pre * gn * r * (1.0f - r);
-      const float dgn = dn_pre * r;
-      myds[0][lane] = dr_pre;
-      myds[1][lane] = dz_pre;
-      myds[2][lane] = dgn;
-      __builtin_amdgcn_wave_barrier();
-      if (storer) {
-        const int64_t o = ((int64_t)t * NB + row) * OPE_H + lane;
-        float* gout = a.dgi + ((int64_t)t * NB + row) * (3 * OPE_H) + lane;
-        gout[0] = dr_pre;
-        gout[OPE_H] = dz_pre;
-        gout[2 * OPE_H] = dn_pre;
-        a.dghn[o] = dgn;
-      }
-      f32x2 c0 = {0.f, 0.f}, c1 = {0.f, 0.f}, c2 = {0.f, 0.f}, c3 = {0.f, 0.f}, c4 = {0.f, 0.f}, c5 = {0.f, 0.f};
-#pragma unroll
-      for (int v = 0; v < IW / 4; ++v) {
-        const f32x4 rv = *reinterpret_cast<const f32x4*>(&myds[0][IW * q + 4 * v]);
-        const f32x4 zv = *reinterpret_cast<const f32x4*>(&myds[1][IW * q + 4 * v]);
-        const f32x4 nv = *reinterpret_cast<const f32x4*>(&myds[2][IW * q + 4 * v]);
-        c0 = __builtin_elementwise_fma(wr[2 * v], f32x2{rv[0], rv[1]}, c0);
-        c1 = __builtin_elementwise_fma(wr[2 * v + 1], f32x2{rv[2], rv[3]}, c1);
-        c2 = __builtin_elementwise_fma(wz[2 * v], f32x2{zv[0], zv[1]}, c2);
-        c3 = __builtin_elementwise_fma(wz[2 * v + 1], f32x2{zv[2], zv[3]}, c3);
-        c4 = __builtin_elementwise_fma(wn[2 * v], f32x2{nv[0], nv[1]}, c4);
-        c5 = __builtin_elementwise_fma(wn[2 * v + 1], f32x2{nv[2], nv[3]}, c5);
-      }
-      float(*pp)[OPE_H] = part[t & 1][rl];
-      pp[q][lane] = ((c0[0] + c0[1]) + (c1[0] + c1[1])) + ((c2[0] + c2[1]) + (c3[0] + c3[1])) + ((c4[0] + c4[1]) + (c5[0] + c5[1]));
-      lds_barrier();
-      float acc = dht * z;
-#pragma unroll
-      for (int w2 = 0; w2 < WPR; ++w2) acc += pp[w2][lane];
-      dh = acc;
-    }
-    // Hand the next chunk over. Its first use is at the top of the next step, BEFORE that step's barrier, so the
-    // publish needs a barrier of its own (one per 8 steps); without it the readers race the loader whenever its
-    // prefetch lands late, e.g. under memory contention from a kernel running concurrently on another stream.
-    if (c + 1 < nchunks) {
-      if (loader) publish_chunk(c + 1, buf ^ 1);
-      lds_barrier();
-    }
-  }
-  if (storer && a.dh_carry) a.dh_carry[(int64_t)row * OPE_H + lane] = dh;
-}
-
 int launch_gru_bwd(const GruBwdArgs& a, hipStream_t st) {
   if (a.NB < 1 || a.T < 1 || a.t_lo < 0 || a.t_lo >= a.T) return OPE_EINVAL;
-  if ((int64_t)a.NB * 4 <= 1280) {
-    hipLaunchKernelGGL(gru_bwd_kernel<4>, dim3(a.NB), dim3(256), 0, st, a);
-  } else {
-    hipLaunchKernelGGL(gru_bwd_kernel<2>, dim3(ope_cdiv(a.NB, 2)), dim3(256), 0, st, a);
-  }
-  if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
-  return OPE_OK;
+  const int kind = g_scan_family ? g_scan_family : (a.NB <= kGru4MaxRows ? 4 : 1);
+  return kind == 4 ? launch_gru_bwd4(a, st) : launch_gru_bwd1(a, st);
 }
 
 // ---------------------------------------------------------------------------------------------------------

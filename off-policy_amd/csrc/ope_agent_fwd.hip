@@ -2,7 +2,7 @@
 // -> MLPLayer.forward mlp.py:25-29, RNNLayer.forward rnn.py:19-23, ACTLayer.forward act.py:21-37).
 //
 //   trunk_fwd : per data row   LN_D -> fc1+ReLU+LN -> fc2+ReLU+LN -> gi = W_ih a2 + b_ih        (f32 MFMA chain)
-//   gru_fwd   : per (agent,episode) row, serial over t: h_t = GRU(gi_t, h_{t-1})                (one wave per row)
+//   gru_fwd   : per (agent,episode) row, serial over t: h_t = GRU(gi_t, h_{t-1})                (ope_gru4.hip / ope_gru1.hip)
 //   head_fwd  : per data row   LN(h_t) -> q = W_q y + b_q, chosen-action q, masked greedy argmax, target q at greedy
 #include <stdlib.h>
 #include <string.h>
@@ -229,158 +229,24 @@ int launch_trunk_fwd(const TrunkFwdArgs& a, bool save, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// gru_fwd. The recurrence is a serial chain of T+1 matvecs per (agent,episode) row, so the goal is minimum latency
-// per step with every SIMD busy: each row is split over WPR waves of one workgroup (WPR = 2 or 4), wave q owning the
-// K-slice [q*64/WPR, (q+1)*64/WPR) of h_{t-1} for all 192 gate outputs; lane f owns hidden feature f and keeps its
-// 3 x 64/WPR weights in VGPRs (float2 pairs -> v_pk_fma_f32 on independent partial sums). Per step:
-//   1. every wave publishes its copy of h_{t-1} to a private LDS slot and reads its K-slice back with broadcast
-//      ds_read_b128 (no barrier: same wave);
-//   2. partial gate sums go to LDS, ONE workgroup barrier, every wave adds the WPR partials in the same fixed order
-//      (so all waves of a row hold bit-identical h) and evaluates the gates redundantly.
-// Memory roles are split so that no wave mixes global loads and stores (on CDNA the two share vmcnt, and a wave that
-// does both ends up draining its stores every step): wave 0 of a row only LOADS (gi, one 8-step chunk ahead, handed to
-// the others through LDS), the last wave only STORES (h and the saved gates).
-//   r = sigma(gi_r + gh_r), z = sigma(gi_z + gh_z), n = tanh(gi_n + r*gh_n), h' = (1-z) n + z h      (nn.GRU)
+// gru_fwd: h_t = GRU(gi_t, h_{t-1}) over the T+1 entries of every (agent, episode) row. Two kernel families, chosen by
+// the number of rows in the launch (OPE_GRU = 4 | 1 forces one): ope_gru4.hip splits a row over 2 or 4 compute waves
+// (latency-bound launches: QMIX at B = 32 has 512 rows), ope_gru1.hip runs one compute wave per row (more rows than
+// SIMDs: the MATD3 actor at B = 128 has 1 280 per net).
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
-__device__ __forceinline__ float fast_tanh(float x) {
-  // tanh(|x|) = (1 - e) / (1 + e), e = exp(-2|x|): absolute error ~1e-7 everywhere
-  const float e = __expf(-2.0f * fabsf(x));
-  const float t = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
-  return copysignf(t, x);
+static int env_choice(const char* name, int a, int b) {
+  const char* v = getenv(name);
+  const int x = v ? atoi(v) : 0;
+  return (x == a || x == b) ? x : 0;
 }
-
-constexpr int kGruChunk = 8;
-
-template <int WPR>
-__global__ void __launch_bounds__(256) gru_fwd_kernel(GruFwdArgs a) {
-  constexpr int RPW = 4 / WPR;        // rows per workgroup
-  constexpr int KW = OPE_H / WPR;     // K-slice per wave
-  constexpr int C = kGruChunk;
-  __shared__ __attribute__((aligned(16))) float hs[4][OPE_H];
-  __shared__ __attribute__((aligned(16))) float part[2][RPW][WPR][3][OPE_H];
-  __shared__ __attribute__((aligned(16))) float gis[RPW][2][C][3][OPE_H];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int rl = wave / WPR, q = wave % WPR;
-  const int total = a.nets * a.NB;
-  const int rid_raw = blockIdx.x * RPW + rl;
-  const bool active = rid_raw < total;
-  const int rid = active ? rid_raw : total - 1;   // idle waves shadow the last row (they must still hit the barriers)
-  const int net = rid / a.NB;
-  const int row = rid - net * a.NB;
-  const float* __restrict__ th = net == 0 ? a.theta0 : a.theta1;
-  const float* __restrict__ gi = net == 0 ? a.gi0 : a.gi1;
-  float* __restrict__ hout = net == 0 ? a.h0out : a.h1out;
-  const bool save = (net == 0) && (a.rg != nullptr);
-  const bool loader = (q == 0), storer = (q == WPR - 1) && active;
-
-  f32x2 wr[KW / 2], wz[KW / 2], wn[KW / 2];
-  {
-    const float* w = th + a.whh_off + KW * q;
-#pragma unroll
-    for (int k = 0; k < KW / 2; ++k) {
-      wr[k] = *reinterpret_cast<const f32x2*>(w + (int64_t)lane * OPE_H + 2 * k);
-      wz[k] = *reinterpret_cast<const f32x2*>(w + (int64_t)(OPE_H + lane) * OPE_H + 2 * k);
-      wn[k] = *reinterpret_cast<const f32x2*>(w + (int64_t)(2 * OPE_H + lane) * OPE_H + 2 * k);
-    }
-  }
-  const float br = th[a.bhh_off + lane], bz = th[a.bhh_off + OPE_H + lane], bn = th[a.bhh_off + 2 * OPE_H + lane];
-  const float* hin = net == 0 ? a.hinit : a.hinit1;
-  float h = hin ? hin[(int64_t)row * OPE_H + lane] : 0.f;
-
-  const int64_t stride_t = (int64_t)a.NB * (3 * OPE_H);
-  const float* gp = gi + (int64_t)row * (3 * OPE_H) + lane;
-  float pre[C][3];   // loader wave: the next chunk's gi, in flight in registers
-  auto load_chunk = [&](int t0) {
-#pragma unroll
-    for (int s = 0; s < C; ++s) {
-      const float* p = gp + (int64_t)min(t0 + s, a.L - 1) * stride_t;
-      gload_async(pre[s][0], p);
-      gload_async(pre[s][1], p + OPE_H);
-      gload_async(pre[s][2], p + 2 * OPE_H);
-    }
-  };
-  auto publish_chunk = [&](int buf) {
-    OPE_GWAIT24(pre);   // the loader wave issues no other global traffic, so vmcnt(0) is exactly "chunk landed"
-#pragma unroll
-    for (int s = 0; s < C; ++s) {
-      gis[rl][buf][s][0][lane] = pre[s][0];
-      gis[rl][buf][s][1][lane] = pre[s][1];
-      gis[rl][buf][s][2][lane] = pre[s][2];
-    }
-  };
-  if (loader) {
-    load_chunk(0);
-    publish_chunk(0);
-  }
-  lds_barrier();
-
-  float* myhs = hs[wave];
-  for (int c0 = 0; c0 < a.L; c0 += C) {
-    const int buf = (c0 / C) & 1;
-    if (loader && c0 + C < a.L) load_chunk(c0 + C);
-    const int ns = min(C, a.L - c0);
-    for (int s = 0; s < ns; ++s) {
-      const int t = c0 + s;
-      myhs[lane] = h;
-      __builtin_amdgcn_wave_barrier();
-      f32x2 ar0 = {0.f, 0.f}, ar1 = {0.f, 0.f}, az0 = {0.f, 0.f}, az1 = {0.f, 0.f}, an0 = {0.f, 0.f}, an1 = {0.f, 0.f};
-#pragma unroll
-      for (int v = 0; v < KW / 4; ++v) {
-        const f32x4 hv = *reinterpret_cast<const f32x4*>(myhs + KW * q + 4 * v);
-        const f32x2 lo = {hv[0], hv[1]}, hi = {hv[2], hv[3]};
-        ar0 = __builtin_elementwise_fma(wr[2 * v], lo, ar0);
-        az0 = __builtin_elementwise_fma(wz[2 * v], lo, az0);
-        an0 = __builtin_elementwise_fma(wn[2 * v], lo, an0);
-        ar1 = __builtin_elementwise_fma(wr[2 * v + 1], hi, ar1);
-        az1 = __builtin_elementwise_fma(wz[2 * v + 1], hi, az1);
-        an1 = __builtin_elementwise_fma(wn[2 * v + 1], hi, an1);
-      }
-      float(*pp)[3][OPE_H] = part[t & 1][rl];
-      pp[q][0][lane] = (ar0[0] + ar0[1]) + (ar1[0] + ar1[1]);
-      pp[q][1][lane] = (az0[0] + az0[1]) + (az1[0] + az1[1]);
-      pp[q][2][lane] = (an0[0] + an0[1]) + (an1[0] + an1[1]);
-      lds_barrier();
-      float ar = br, az = bz, an = bn;
-#pragma unroll
-      for (int w2 = 0; w2 < WPR; ++w2) {
-        ar += pp[w2][0][lane];
-        az += pp[w2][1][lane];
-        an += pp[w2][2][lane];
-      }
-      const float gir = gis[rl][buf][s][0][lane], giz = gis[rl][buf][s][1][lane], gin = gis[rl][buf][s][2][lane];
-      const float r = fast_sigmoid(gir + ar);
-      const float z = fast_sigmoid(giz + az);
-      const float n = fast_tanh(gin + r * an);
-      h = (1.0f - z) * n + z * h;
-      if (storer) {
-        const int64_t o = ((int64_t)t * a.NB + row) * OPE_H + lane;
-        hout[o] = h;
-        if (save) {
-          a.rg[o] = r;
-          a.zg[o] = z;
-          a.ng[o] = n;
-          a.ghn[o] = an;
-        }
-      }
-    }
-    // hand the next chunk to the row's waves: written after this chunk's last barrier, first read after the next
-    // step's barrier; the buffer being overwritten was last read one whole chunk ago.
-    if (loader && c0 + C < a.L) publish_chunk(buf ^ 1);
-  }
-}
+int g_scan_family = env_choice("OPE_GRU", 1, 4);
+int g_scan_waves = env_choice("OPE_GRU4_W", 2, 4);
 
 int launch_gru_fwd(const GruFwdArgs& a, hipStream_t st) {
   if (a.nets < 1 || a.nets > 2 || a.NB < 1 || a.L < 1) return OPE_EINVAL;
   const int64_t rows = (int64_t)a.nets * a.NB;
-  static const int forced_wpr = getenv("OPE_GRU_WPR") ? atoi(getenv("OPE_GRU_WPR")) : 0;
-  if (forced_wpr ? forced_wpr == 4 : rows <= 512) {   // up to two workgroups per CU: four waves per row (3s5z, 512 rows: 82 vs 87 us)
-    hipLaunchKernelGGL(gru_fwd_kernel<4>, dim3(rows), dim3(256), 0, st, a);
-  } else {
-    hipLaunchKernelGGL(gru_fwd_kernel<2>, dim3(ope_cdiv(rows, 2)), dim3(256), 0, st, a);
-  }
-  if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
-  return OPE_OK;
+  const int kind = g_scan_family ? g_scan_family : (rows <= kGru4MaxRows ? 4 : 1);
+  return kind == 4 ? launch_gru_fwd4(a, st) : launch_gru_fwd1(a, st);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -175,6 +175,10 @@ extern "C" const char* ope_strerror(int code) {
   }
 }
 extern "C" void ope_set_debug(int on) { g_debug = on; }
+extern "C" void ope_set_scan_kernel(int family, int waves_per_row) {
+  ope::g_scan_family = (family == 1 || family == 4) ? family : 0;
+  ope::g_scan_waves = (waves_per_row == 2 || waves_per_row == 4) ? waves_per_row : 0;
+}
 
 extern "C" int64_t ope_qmix_param_layout(const ope_qmix_cfg* cfg, int64_t* offsets, int64_t* sizes) {
   if (!cfg_ok(cfg)) return OPE_EINVAL;
@@ -296,6 +300,7 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
     if (c > 0) { gf.hinit = W + p.h + (r0 - p.NB) * OPE_H; gf.hinit1 = W + p.h_t + (r0 - p.NB) * OPE_H; }
     gf.whh_off = p.AL.whh; gf.bhh_off = p.AL.bhh;
     gf.rg = W + p.rg + r0 * OPE_H; gf.zg = W + p.zg + r0 * OPE_H; gf.ng = W + p.ng + r0 * OPE_H; gf.ghn = W + p.ghn + r0 * OPE_H;
+    gf.dbg = g_debug ? (long long*)(W + p.dbg) + 71168 : nullptr;
     if ((rc = launch_gru_fwd(gf, scan_st))) return rc;
     if (C > 1 && hipEventRecord(sp->scan_done[c], side) != hipSuccess) return OPE_ELAUNCH;
   }
@@ -427,6 +432,7 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
     gb.rg = W + p.rg; gb.zg = W + p.zg; gb.ng = W + p.ng; gb.ghn = W + p.ghn; gb.dh_out = W + p.dh_out; gb.dgi = W + p.dgi; gb.dghn = W + p.dghn;
     gb.dh_in = hi < p.T ? W + p.dh_carry : nullptr;
     gb.dh_carry = lo > 0 ? W + p.dh_carry : nullptr;
+    gb.dbg = g_debug ? (long long*)(W + p.dbg) + 87552 : nullptr;
     if ((rc = launch_gru_bwd(gb, side))) return rc;
     if (use_side && hipEventRecord(sp->bptt_done[c], side) != hipSuccess) return OPE_ELAUNCH;
   }

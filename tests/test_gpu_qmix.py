@@ -65,6 +65,29 @@ def test_train_steps_match_reference(name):
     np.testing.assert_array_equal(sd["q.action_out.weight"].cpu().numpy(), live["agent/q.action_out.weight"])
 
 
+@pytest.mark.parametrize("family,waves", [(4, 4), (4, 2), (1, 0)])
+@pytest.mark.parametrize("name", ["qmix_tiny", "qmix_odd"])
+def test_every_scan_kernel_family_matches_reference(name, family, waves):
+    """The GRU scans have three kernel shapes chosen by row count (ope_gru4.hip with 4 or 2 compute waves per row,
+    ope_gru1.hip); the fixtures are small, so pin each shape in turn and repeat the reference comparison."""
+    from offpolicy_amd import _lib
+    g = load_golden(name)
+    _lib.lib.ope_set_scan_kernel(family, waves)
+    try:
+        dims, buf, policy, trainer = build_from_fixture(g)
+        batch = batch_from(buf, g["inds"])
+        for s in range(len(g["loss"])):
+            info, _, _ = trainer.train_policy_on_batch(batch)
+            trainer.soft_target_updates()
+            np.testing.assert_allclose(float(info["loss"]), g["loss"][s], rtol=RTOL)
+            np.testing.assert_allclose(float(info["grad_norm"]), g["grad_norm"][s], rtol=RTOL)
+        live = _flat_named(trainer, trainer.theta)
+        for k, ref in sub(g, "final_agent/").items():
+            np.testing.assert_allclose(live["agent/" + k], ref, rtol=0, atol=3e-5, err_msg=k)
+    finally:
+        _lib.lib.ope_set_scan_kernel(0, 0)
+
+
 @pytest.mark.parametrize("name", ["qmix_tiny", "qmix_odd"])
 def test_forward_intermediates_match_oracle(name):
     """Per-stage check (helps localise a failure): live q values, chosen/target agent q, Q_tot of both mixers."""
