@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--episodes", type=int, default=256, help="synthetic episodes resident in the replay store")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="QMIX workloads: replay the training kernels of a step as one captured HIP graph")
     ap.add_argument("--no-graph", action="store_true", help="MLP MADDPG/MATD3: launch the ~45 kernels of an update one by one instead "
                     "of replaying the captured HIP graph")
     ap.add_argument("--host-per", action="store_true", help="prioritized workloads: keep the sum/min trees on the host (numpy, as the "
@@ -163,8 +164,14 @@ def main():
     pbuf = buf.policy_buffers["policy_0"]
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
 
+    # Eager launches by default: the host enqueues a step in ~150 us against 0.46 ms of kernels, so it runs ahead and a
+    # HIP-graph replay of the 16 training kernels (--graph; QMix.make_graphed_step) is 1-4 % SLOWER here (measured).
+    graphed = trainer.make_graphed_step(buf, local_batch, gather_in_graph=False) if (a.graph and world == 1) else None
+
     def one_step(i=None):
         inds = np.random.choice(len(buf), local_batch)
+        if graphed is not None:
+            return graphed(inds, timing_events=ev[i] if i is not None else None)
         s = pbuf.sample_inds(inds, timing_events=ev[i] if i is not None else None)   # ope_store_gather, current stream
         batch = tuple({"policy_0": x} for x in s) + (None, None)
         info, _, _ = trainer.train_policy_on_batch(batch)
@@ -208,6 +215,7 @@ def main():
                                    "step = sample + train_policy_on_batch + soft target update" % (
                                        a.workload, dims.n_agents, dims.act_dim, dims.obs_dim, dims.state_dim, dims.episode_length, a.episodes),
                        "batch_per_gpu": local_batch, "global_batch": global_batch, "parallelism": "dp%d" % world,
+                       "launch": "eager gather + HIP graph of the training kernels" if graphed is not None else "eager",
                        "optimizer_steps_per_sec": round(steps_per_s, 3), "final_loss": round(loss, 6)},
             "roofline": {"kernel": "episode_copy_kernel<gather> (ope_store_gather)", "bound": "hbm", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),

@@ -205,6 +205,8 @@ class QMix(object):
         ac.max_grad_norm, ac.weight_decay = float(self.args.max_grad_norm), 0.0   # QMix's Adam ignores weight_decay (A-8)
         ac.tau, ac.do_polyak = float(self.tau), int(self.fuse_soft_update)
         ac.step = self.optimizer.step_count
+        if self.optimizer.step_dev is not None:     # HIP-graph replays: the count advances on the device
+            ac.step_counter = _lib.ptr(self.optimizer.step_dev).value
         ac.qtot_denominator = float(self.episode_length * B * world_size)
         stats = torch.empty(4, **self.tpdv)
         _lib.check(_lib.lib.ope_adam_step(C.byref(ac), self.numel, _lib.ptr(self.theta), _lib.ptr(self.theta_tgt),
@@ -221,6 +223,71 @@ class QMix(object):
             new_priorities = ((1 - self.args.per_nu) * s[:, 0] + self.args.per_nu * s[:, 1]).flatten() + self.per_eps
         self._last = (obs, share, acts, rew, dones_env, avail, w, td_stats)   # keep inputs alive past the async launch
         return train_info, new_priorities, idxes
+
+    def make_graphed_step(self, buffer, batch_size, policy_id="policy_0", gather_in_graph=True):
+        """`buffer.sample` on given episode indices + `train_policy_on_batch` + `soft_target_updates`, captured ONCE as a HIP
+        graph and replayed with one launch per step. The eager step is 17 kernels whose enqueueing costs the host about as
+        long as they run (0.47 ms at 3s5z, B=32), so the GPU idles ~20 us per step waiting for the first launches; a replay
+        removes the host from the loop. Returns `step(inds) -> train_info` (`inds`: numpy int64 [batch_size], e.g.
+        np.random.choice(len(buffer), batch_size); train_info: device tensors overwritten by every replay).
+        With gather_in_graph=False the gather stays an eager launch into a fixed batch (so it can be bracketed by timing
+        events: `step(inds, timing_events=(start, end))`) and the graph holds the 16 training kernels.
+        Restrictions: uniform replay (PER's importance weights come from the caller per step), one process (the gradient
+        all-reduce is not captured), Adam's step count lives on the device."""
+        if self.use_per or opdist.is_distributed():
+            raise NotImplementedError("graphed step: uniform replay on a single GPU only")
+        pbuf = buffer.policy_buffers[policy_id]
+        B = int(batch_size)
+        self.fuse_soft_update = True
+        opt = self.optimizer
+        opt.step_dev = torch.tensor([opt.step_count], dtype=torch.int32, device=self.device)
+        static_inds = torch.zeros(B, dtype=torch.int64, device=self.device)
+
+        static_batch = None if gather_in_graph else pbuf.alloc_batch(B)
+
+        def train(s):
+            info, _, _ = self.train_policy_on_batch(tuple({policy_id: x} for x in s) + (None, None))
+            self.soft_target_updates()
+            return info
+
+        def body():
+            if gather_in_graph:
+                return train(pbuf.sample_inds(static_inds))
+            return train(self._static_sample)
+        side = torch.cuda.Stream(device=self.device)     # warm-up off the capture: workspace, allocator pools, lazy init
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            static_inds.copy_(torch.from_numpy(np.random.choice(len(buffer), B)).to(self.device))
+            if not gather_in_graph:
+                self._static_sample = pbuf.sample_inds(static_inds, out=static_batch)
+            for _ in range(2):
+                body()
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            info = body()
+        opt.step_count = int(opt.step_dev.item())      # capture ran the host code but no kernels
+        ring = [(torch.empty(B, dtype=torch.int64).pin_memory(), torch.cuda.Event()) for _ in range(8)]
+        state = {"k": 0, "used": [False] * 8}
+
+        def step(inds, timing_events=None):
+            k = state["k"]
+            state["k"] = (k + 1) % 8
+            host, ev = ring[k]
+            if state["used"][k]:
+                ev.synchronize()
+            host.copy_(torch.from_numpy(np.asarray(inds, dtype=np.int64)))
+            static_inds.copy_(host, non_blocking=True)
+            ev.record()
+            state["used"][k] = True
+            if not gather_in_graph:
+                pbuf.sample_inds(static_inds, timing_events=timing_events, out=static_batch)
+            graph.replay()
+            opt.step_count += 1
+            return info
+        self._graph = (graph, static_inds, ring, static_batch)      # keep alive
+        return step
 
     # ---- target updates ---------------------------------------------------------------------------------------
     def hard_target_updates(self):

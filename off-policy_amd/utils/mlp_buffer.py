@@ -88,6 +88,8 @@ class MlpPolicyBuffer(object):
         sf, of = self._only_dones(self.valid_transition), self._only_dones(valid)
         _lib.check(_lib.lib.ope_store_gather(C.byref(self._ep.dims), self.buffer_size, C.byref(sf), _lib.ptr(dev_inds), B,
                                              C.byref(of), _lib.current_stream()), "ope_store_gather")
+        if not torch.is_tensor(inds):
+            self._ep._release_inds()
         return (obs[:, 0], share[0], acts[:, 0], rew[:, 0], obs[:, 1], share[1], dones[:, 0], dones_env[0], valid[0],
                 avail[:, 0] if avail is not None else None, avail[:, 1] if avail is not None else None)
 

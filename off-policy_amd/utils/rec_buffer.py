@@ -13,6 +13,7 @@ Drop-in mirror of offpolicy/utils/rec_buffer.py (`RecReplayBuffer` 10-82, `RecPo
   crashes for one episode and skips slots otherwise: SURVEY.md Appendix A-3).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -21,6 +22,8 @@ from .. import _lib
 from .ring import RingIndex
 from .segment_tree import SumSegmentTree, MinSegmentTree
 from .spaces import get_dim_from_space
+
+_INDS_MODE = os.environ.get("OPE_INDS_MODE", "copy")    # copy | zerocopy (RecPolicyBuffer._upload_inds)
 
 _FIELD_ORDER = ("obs", "share_obs", "acts", "rewards", "dones", "dones_env", "avail_acts")
 
@@ -70,24 +73,37 @@ class RecPolicyBuffer(object):
     def _upload_inds(self, inds):
         """Episode indices -> device without stalling the host: a pageable `.to(device)` is a synchronous copy that makes
         the host wait for all queued GPU work every step. Instead the indices go through a small ring of pinned staging
-        buffers with asynchronous copies; a slot is reused only after its previous copy has completed."""
+        buffers with asynchronous copies into a ring of device tensors. OPE_INDS_MODE=zerocopy skips the copy and lets the
+        gather read the pinned buffer itself (hipHostMalloc memory is mapped into the device's address space): the step
+        loses the blit kernel and its barrier (~1 % faster at 3s5z, ~6 % for the eager MLP-MADDPG step), the gather pays
+        the host-link latency (~6 % slower), so it is opt-in. A copy on a side stream was measured too: no gain, the
+        cross-stream wait costs what the barrier did. A slot is reused only after the last launch that read it has
+        completed (`_release_inds`)."""
         B = int(inds.shape[0])
         ring = getattr(self, "_ind_ring", None)
         if ring is None or ring[0][0].numel() < B:
             n = max(B, 256)
-            ring = [(torch.empty(n, dtype=torch.int64).pin_memory(), torch.cuda.Event()) for _ in range(8)]
+            ring = [(torch.empty(n, dtype=torch.int64).pin_memory(), torch.cuda.Event(),
+                     torch.empty(n, dtype=torch.int64, device=self.device)) for _ in range(8)]
             self._ind_ring, self._ind_slot, self._ind_used = ring, 0, [False] * 8
         k = self._ind_slot
         self._ind_slot = (k + 1) % len(ring)
-        host, ev = ring[k]
+        host, consumed, dev = ring[k]
         if self._ind_used[k]:
-            ev.synchronize()
+            consumed.synchronize()
         host[:B].copy_(torch.from_numpy(inds))
-        dev = torch.empty(B, dtype=torch.int64, device=self.device)
-        dev.copy_(host[:B], non_blocking=True)
-        ev.record()
-        self._ind_used[k] = True
-        return dev
+        self._ind_last = k
+        if _INDS_MODE == "zerocopy":
+            return host[:B]
+        dev[:B].copy_(host[:B], non_blocking=True)
+        return dev[:B]
+
+    def _release_inds(self):
+        """Mark the point on the current stream after which the last staged index slot may be overwritten."""
+        k = getattr(self, "_ind_last", None)
+        if k is not None:
+            self._ind_ring[k][1].record()
+            self._ind_used[k] = True
 
     def reward_stats(self):
         """Device tensor [mean, std, count, 0] of the rewards currently stored (rec_buffer.py:209-220); recomputed after
@@ -147,9 +163,23 @@ class RecPolicyBuffer(object):
         self._stats_dirty = True
         return idx_range
 
-    def sample_inds(self, sample_inds, timing_events=None):
+    def alloc_batch(self, batch_size):
+        """Destination tensors of one gather of `batch_size` episodes, in the kernels' [T(+1), N, B, dim] layout."""
+        d, B = self.dims, int(batch_size)
+        T, N = d.episode_length, d.n_agents
+        e = dict(dtype=torch.float32, device=self.device)
+        out = dict(obs=torch.empty((T + 1, N, B, d.obs_dim), **e), share_obs=torch.empty((T + 1, B, d.state_dim), **e),
+                   acts=torch.empty((T, N, B, d.act_dim), **e), rewards=torch.empty((T, N, B, 1), **e),
+                   dones=torch.empty((T, N, B, 1), **e), dones_env=torch.empty((T, B, 1), **e))
+        if self.use_avail_acts:
+            out["avail_acts"] = torch.empty((T + 1, N, B, d.act_dim), **e)
+        return out
+
+    def sample_inds(self, sample_inds, timing_events=None, out=None):
         """Gather the given episode slots; same 7-tuple as rec_buffer.py:192-240 (CUDA tensors, reference shapes).
-        `timing_events`: optional (start, end) torch.cuda.Event pair recorded tightly around the gather launch."""
+        `timing_events`: optional (start, end) torch.cuda.Event pair recorded tightly around the gather launch.
+        `out`: optional destination from `alloc_batch` (HIP-graph replays read the batch from fixed addresses); the
+        default is a fresh batch per call, like the reference's fancy-index copy."""
         if torch.is_tensor(sample_inds):     # indices already on the device (HIP-graph replays keep them in a static tensor)
             assert sample_inds.dtype == torch.int64 and sample_inds.device == self.device
             dev_inds, B = sample_inds.contiguous(), int(sample_inds.shape[0])
@@ -158,13 +188,10 @@ class RecPolicyBuffer(object):
             B = int(inds.shape[0])
             dev_inds = self._upload_inds(inds)
         d = self.dims
-        T, N = d.episode_length, d.n_agents
-        e = dict(dtype=torch.float32, device=self.device)
-        out = dict(obs=torch.empty((T + 1, N, B, d.obs_dim), **e), share_obs=torch.empty((T + 1, B, d.state_dim), **e),
-                   acts=torch.empty((T, N, B, d.act_dim), **e), rewards=torch.empty((T, N, B, 1), **e),
-                   dones=torch.empty((T, N, B, 1), **e), dones_env=torch.empty((T, B, 1), **e))
-        if self.use_avail_acts:
-            out["avail_acts"] = torch.empty((T + 1, N, B, d.act_dim), **e)
+        if out is None:
+            out = self.alloc_batch(B)
+        else:
+            assert out["obs"].shape[2] == B, "destination batch does not match the number of indices"
         of, sf = self._fields(out), self._store_fields()
         if timing_events is not None:
             timing_events[0].record()
@@ -172,6 +199,8 @@ class RecPolicyBuffer(object):
                                              C.byref(of), _lib.current_stream()), "ope_store_gather")
         if timing_events is not None:
             timing_events[1].record()
+        if not torch.is_tensor(sample_inds):
+            self._release_inds()
         if self.use_reward_normalization:
             _lib.check(_lib.lib.ope_reward_normalize(_lib.ptr(out["rewards"]), out["rewards"].numel(), _lib.ptr(self.reward_stats()),
                                                      _lib.current_stream()), "ope_reward_normalize")
