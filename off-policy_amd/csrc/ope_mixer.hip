@@ -313,7 +313,7 @@ __global__ void __launch_bounds__(256) mixer_fwd2_kernel(MixerFwdArgs a) {
       if (g == 0) pbs[16 * t + j] = pb;
     }
   }
-  __syncthreads();
+  lds_barrier();
   if (dbg && lane == 0) dbg[2] = __builtin_amdgcn_s_memtime();
 
   // ---- stage B: agents wave, wave+4, ... ----
@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(256) mixer_fwd2_kernel(MixerFwdArgs a) {
     }
   }
   if (dbg && lane == 0) dbg[3] = __builtin_amdgcn_s_memtime();
-  __syncthreads();
+  lds_barrier();
   if (dbg && lane == 0) dbg[4] = __builtin_amdgcn_s_memtime();
   if (wave != 1) return;
 

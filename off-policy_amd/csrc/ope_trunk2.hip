@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(256) trunk_fwd2_kernel(TrunkFwdArgs a, int Dp)
       }
     }
   }
-  __syncthreads();
+  lds_barrier();
 
   int row[RT];
   bool valid[RT];
@@ -169,13 +169,13 @@ __global__ void __launch_bounds__(256) trunk_fwd2_kernel(TrunkFwdArgs a, int Dp)
       s = rowsum4(s);
       if (g == 0) stat[wave * TR + 16 * t + j] = s;
     }
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
       const int rr = 16 * t + j;
       mu[t] = ((stat[rr] + stat[TR + rr]) + (stat[2 * TR + rr] + stat[3 * TR + rr])) * (1.0f / OPE_H);
     }
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
       float q = 0.f;
@@ -187,7 +187,7 @@ __global__ void __launch_bounds__(256) trunk_fwd2_kernel(TrunkFwdArgs a, int Dp)
       q = rowsum4(q);
       if (g == 0) stat[wave * TR + 16 * t + j] = q;
     }
-    __syncthreads();
+    lds_barrier();
     const f32x4 gm = *reinterpret_cast<const f32x4*>(gamv + 16 * wave + 4 * g);
     const f32x4 bt = *reinterpret_cast<const f32x4*>(betv + 16 * wave + 4 * g);
 #pragma unroll
@@ -232,7 +232,7 @@ __global__ void __launch_bounds__(256) trunk_fwd2_kernel(TrunkFwdArgs a, int Dp)
   }
 #pragma unroll
   for (int t = 0; t < RT; ++t) *reinterpret_cast<f32x4*>(actb + (16 * t + j) * kActPitch + 16 * wave + 4 * g) = act[t];
-  __syncthreads();
+  lds_barrier();
 
   // ---- fc2 ----
 #pragma unroll
@@ -268,7 +268,7 @@ __global__ void __launch_bounds__(256) trunk_fwd2_kernel(TrunkFwdArgs a, int Dp)
     // fused small Linear head (<= 16 outputs = one MFMA tile): the activations meet in LDS, wave 0 does the 16 MFMAs
 #pragma unroll
     for (int t = 0; t < RT; ++t) *reinterpret_cast<f32x4*>(actb + (16 * t + j) * kActPitch + 16 * wave + 4 * g) = act[t];
-    __syncthreads();
+    lds_barrier();
     if (wave != 0) return;
     const int hd = a.head_dim;
     f32x4 ho[RT];
@@ -297,7 +297,7 @@ __global__ void __launch_bounds__(256) trunk_fwd2_kernel(TrunkFwdArgs a, int Dp)
   }
 #pragma unroll
   for (int t = 0; t < RT; ++t) *reinterpret_cast<f32x4*>(actb + (16 * t + j) * kActPitch + 16 * wave + 4 * g) = act[t];
-  __syncthreads();
+  lds_barrier();
 
   // ---- gi = W_ih a2 + b_ih : 12 output tiles, 3 per wave ----
   f32x4 o[RT][3];
@@ -408,10 +408,25 @@ __global__ void __launch_bounds__(256, 2) trunk_fwd3_kernel(TrunkFwdArgs a) {
           w3[u][ft] = *reinterpret_cast<const f32x4*>(th + a.L.wih + (int64_t)(16 * (3 * wave + u) + j) * OPE_H + 16 * ft + 4 * g);
     }
   }
-  const f32x4 b1 = *reinterpret_cast<const f32x4*>(th + a.L.fc1_b + 16 * wave + 4 * g);
-  const f32x4 b2 = *reinterpret_cast<const f32x4*>(th + a.L.fc2_b + 16 * wave + 4 * g);
-  const f32x4 g1 = *reinterpret_cast<const f32x4*>(th + a.L.ln1_w + 16 * wave + 4 * g), e1 = *reinterpret_cast<const f32x4*>(th + a.L.ln1_b + 16 * wave + 4 * g);
-  const f32x4 g2 = *reinterpret_cast<const f32x4*>(th + a.L.ln2_w + 16 * wave + 4 * g), e2 = *reinterpret_cast<const f32x4*>(th + a.L.ln2_b + 16 * wave + 4 * g);
+  // biases and LayerNorm affine parameters of the two hidden layers: 6 x 64 floats kept in LDS and re-read (one
+  // ds_read_b128 each) where they are used, instead of 24 VGPRs held across the whole tile loop
+  // (likewise b_ih and the input LayerNorm's affine parameters, zero-padded to 16*KCM: no compiler-tracked global load is
+  // left inside the tile loop, whose vmcnt waits would drain the next tile's prefetched rows)
+  __shared__ __attribute__((aligned(16))) float lnp[6][OPE_H];
+  __shared__ __attribute__((aligned(16))) float bihs[3 * OPE_H];
+  __shared__ __attribute__((aligned(16))) float fnp[2][16 * KCM];
+  if (threadIdx.x < OPE_H) {
+    const int f = threadIdx.x;
+    lnp[0][f] = th[a.L.fc1_b + f]; lnp[1][f] = th[a.L.ln1_w + f]; lnp[2][f] = th[a.L.ln1_b + f];
+    lnp[3][f] = th[a.L.fc2_b + f]; lnp[4][f] = th[a.L.ln2_w + f]; lnp[5][f] = th[a.L.ln2_b + f];
+  }
+  if (!a.a2_out)
+    for (int f = threadIdx.x; f < 3 * OPE_H; f += blockDim.x) bihs[f] = th[a.L.bih + f];
+  for (int f = threadIdx.x; f < 16 * KCM; f += blockDim.x) {
+    fnp[0][f] = f < D ? th[a.L.fn_w + f] : 0.f;
+    fnp[1][f] = f < D ? th[a.L.fn_b + f] : 0.f;
+  }
+  auto lnp4 = [&](int i) { return *reinterpret_cast<const f32x4*>(&lnp[i][16 * wave + 4 * g]); };
   // ReLU + LayerNorm over the 64 features of a row whose 16-feature slices live in the 4 waves (see trunk_fwd2)
   // One pass: per-row sum and sum of squares of the post-ReLU values (O(1) magnitudes: E[x^2] - mean^2 loses nothing that
   // matters at fp32), the 4 waves' partials meet through LDS behind ONE barrier.
@@ -429,7 +444,7 @@ __global__ void __launch_bounds__(256, 2) trunk_fwd3_kernel(TrunkFwdArgs a) {
     s = rowsum4(s);
     s2 = rowsum4(s2);
     if (g == 0) *reinterpret_cast<f32x2*>(stat + 2 * (wave * TR + j)) = f32x2{s, s2};
-    __syncthreads();
+    lds_barrier();
     const f32x2 p0 = *reinterpret_cast<const f32x2*>(stat + 2 * j), p1 = *reinterpret_cast<const f32x2*>(stat + 2 * (TR + j));
     const f32x2 p2 = *reinterpret_cast<const f32x2*>(stat + 2 * (2 * TR + j)), p3 = *reinterpret_cast<const f32x2*>(stat + 2 * (3 * TR + j));
     mu = ((p0[0] + p1[0]) + (p2[0] + p3[0])) * (1.0f / OPE_H);
@@ -443,20 +458,77 @@ __global__ void __launch_bounds__(256, 2) trunk_fwd3_kernel(TrunkFwdArgs a) {
     // (stat is rewritten only after the next workgroup barrier: the actb hand-off)
   };
 
+  // Touch every weight fragment once: the compiler then knows the prologue loads have landed and leaves no vmcnt wait of
+  // its own inside the tile loop (it cannot see the asm prefetch loads, so such a wait would stall on them every tile).
+#pragma unroll
+  for (int c = 0; c < KCM; ++c) asm volatile("" : "+v"(w1[c]));
+  if (WREG) {
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft) asm volatile("" : "+v"(w2[ft]));
+    if (!a.a2_out) {
+#pragma unroll
+      for (int u = 0; u < 3; ++u)
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) asm volatile("" : "+v"(w3[u][ft]));
+    }
+  }
+  constexpr bool PF = (VEC == 4) && (KCM <= 16);    // wider inputs go through trunk_fwd2 by default
+  constexpr int XP = 16 * KCM;                      // floats per staged row
+  __shared__ __attribute__((aligned(16))) float xraw[PF ? TR * XP : 4];
+  // one LDS-DMA instruction moves 64 lanes x 16 B = 1 KB to [wave-uniform LDS base + 16 * lane]: 256 / XP whole rows
+  auto request_rows = [&](int t0) {
+    constexpr int RPI = PF ? 256 / XP : 1;          // rows per instruction (1 at KCM = 16, 2 at KCM = 8)
+    const int sub = lane / (64 / RPI), pc = lane % (64 / RPI);
+    const int k = 4 * pc;
+#pragma unroll
+    for (int u = 0; u < 4 / RPI; ++u) {
+      const int rl = wave * 4 + u * RPI;            // first staged row of this instruction
+      const int rw = t0 * TR + rl + sub;
+      const float* src = a.x + (int64_t)(rw < a.R ? rw : a.R - 1) * D + (k + 4 <= D ? k : D - 4);   // clamped; masked below
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(xraw + rl * XP), 16, 0, 0);
+    }
+  };
+  if (PF && (int)blockIdx.x < ntiles) request_rows(blockIdx.x);
+  f32x4 go[3];        // gi of the previous tile (this lane's row j, output tiles 3 wave .. 3 wave + 2), not yet stored
+  int go_row = -1;
+  auto flush_gi = [&]() {
+    if (go_row >= 0) {
+#pragma unroll
+      for (int u = 0; u < 3; ++u) *reinterpret_cast<f32x4*>(a.gi + (int64_t)go_row * (3 * OPE_H) + 16 * (3 * wave + u) + 4 * g) = go[u];
+    }
+    go_row = -1;
+  };
+  lds_barrier();   // lnp / bihs / fnp are complete (phase 0 of the first tile reads fnp before any other barrier)
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int row0 = tile * TR;
     // ---- phase 0: input LayerNorm of this wave's 4 rows -> LDS. 16 lanes per row (one DPP row): each lane keeps
     // 4*KCM/4 = KCM values of its row, row sums are four DPP adds; every global access is a 16-byte (VEC-wide) piece of a
-    // 256-byte contiguous run.
+    // 256-byte contiguous run. With 16-byte pieces (PF) the raw rows arrive by LDS-DMA (global_load_lds_dwordx4, 1 KB per
+    // wave instruction, no VGPRs): a wave requests ITS four rows of the next tile as soon as it has read this tile's, the
+    // request stays in flight for the whole tile (the barriers of this kernel wait on LDS traffic only, and no other
+    // load is left in the loop), and the compiler's vmcnt wait sits in front of the reads of `xraw` one tile later.
     {
       constexpr int NI4 = KCM / 4;
       const int q = lane >> 4, c = lane & 15;
       const int rr = wave * 4 + q;
       const int row = row0 + rr;
-      const float* xr = a.x + (int64_t)(row < a.R ? row : a.R - 1) * D;
       f32x4 xv[NI4];
+      if (PF) {
+        // Rows landed? hipcc puts its own vmcnt wait only in front of the FIRST tile's reads of xraw, not on the loop's
+        // back edge, so the wait is ours. It has to be vmcnt(0): loads and stores do not retire in order relative to each
+        // other (a wait that allowed the previous tile's youngest stores to stay in flight read stale rows), so the
+        // stores a wave issues last in a tile -- gi -- are held back and issued right AFTER this wait (below), which
+        // leaves them a whole tile to retire; the mid-tile stores (xhat, masks, statistics) are half a tile old here.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-      for (int i = 0; i < NI4; ++i) xv[i] = load4c<VEC>(xr, 4 * c + 64 * i, D);
+        for (int i = 0; i < NI4; ++i) xv[i] = *reinterpret_cast<const f32x4*>(xraw + rr * XP + 4 * c + 64 * i);
+      } else {
+        const float* xr = a.x + (int64_t)(row < a.R ? row : a.R - 1) * D;
+#pragma unroll
+        for (int i = 0; i < NI4; ++i) xv[i] = load4c<VEC>(xr, 4 * c + 64 * i, D);
+      }
+      flush_gi();   // the previous tile's gi rows leave now
       OPE_STAMP();
       float s = 0.f;
 #pragma unroll
@@ -465,6 +537,10 @@ __global__ void __launch_bounds__(256, 2) trunk_fwd3_kernel(TrunkFwdArgs a) {
         s += (xv[i][0] + xv[i][1]) + (xv[i][2] + xv[i][3]);
       }
       const float mean = row16_sum(s) / (float)D;
+      if (PF) {   // xraw rows of this wave are in registers now: refill them with the next tile's
+        const int nxt = tile + (int)gridDim.x;
+        if (nxt < ntiles) request_rows(nxt);
+      }
       float sq = 0.f;
 #pragma unroll
       for (int i = 0; i < NI4; ++i) {
@@ -480,7 +556,7 @@ __global__ void __launch_bounds__(256, 2) trunk_fwd3_kernel(TrunkFwdArgs a) {
 #pragma unroll
       for (int i = 0; i < NI4; ++i) {
         const int k = 4 * c + 64 * i;
-        const f32x4 gm = mask4(load4c<VEC>(th + a.L.fn_w, k, D), k, D), bt = mask4(load4c<VEC>(th + a.L.fn_b, k, D), k, D);   // L1-resident
+        const f32x4 gm = *reinterpret_cast<const f32x4*>(&fnp[0][k]), bt = *reinterpret_cast<const f32x4*>(&fnp[1][k]);   // 0 beyond D
         f32x4 o;
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = fmaf(xv[i][r] * rstd, gm[r], bt[r]);   // exactly 0 beyond D
@@ -492,13 +568,13 @@ __global__ void __launch_bounds__(256, 2) trunk_fwd3_kernel(TrunkFwdArgs a) {
       }
     }
     OPE_STAMP();   // phase 0 done (before barrier)
-    __syncthreads();
+    lds_barrier();
     const int row = row0 + j;
     const bool valid = row < a.R;
 
     OPE_STAMP();   // after barrier
     // ---- fc1 from registers ----
-    f32x4 acc = b1;
+    f32x4 acc = lnp4(0);
 #pragma unroll
     for (int c = 0; c < KCM; ++c) {
       // keep the LDS operand reads at most 4 chunks ahead of their MFMAs (hoisting all KCM of them costs 4*KCM registers)
@@ -524,17 +600,17 @@ __global__ void __launch_bounds__(256, 2) trunk_fwd3_kernel(TrunkFwdArgs a) {
         }
       }
     };
-    relu_ln(acc, g1, e1, xh, act, rs, mu, bits);
+    relu_ln(acc, lnp4(1), lnp4(2), xh, act, rs, mu, bits);
     if (SAVE) {
       if (valid) *reinterpret_cast<f32x4*>(a.xhat1 + (int64_t)row * OPE_H + 16 * wave + 4 * g) = xh;
       save_row(a.mask1, a.rstd1, a.mu1);
     }
     *reinterpret_cast<f32x4*>(actb + j * kActPitch + 16 * wave + 4 * g) = act;
-    __syncthreads();
+    lds_barrier();
 
     OPE_STAMP();   // LN1 + saves + actb + barrier
     // ---- fc2 ----
-    acc = b2;
+    acc = lnp4(3);
     if (!WREG) {
 #pragma unroll
       for (int ft = 0; ft < 4; ++ft) w2[ft] = *reinterpret_cast<const f32x4*>(th + a.L.fc2_w + (int64_t)(16 * wave + j) * OPE_H + 16 * ft + 4 * g);
@@ -545,7 +621,7 @@ __global__ void __launch_bounds__(256, 2) trunk_fwd3_kernel(TrunkFwdArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc = mfma16(w2[ft][r], xv[r], acc);
     }
-    relu_ln(acc, g2, e2, xh, act, rs, mu, bits);   // its first barrier also fences the fc2 reads of actb
+    relu_ln(acc, lnp4(4), lnp4(5), xh, act, rs, mu, bits);   // its first barrier also fences the fc2 reads of actb
     if (SAVE) {
       if (valid) *reinterpret_cast<f32x4*>(a.xhat2 + (int64_t)row * OPE_H + 16 * wave + 4 * g) = xh;
       save_row(a.mask2, a.rstd2, nullptr);
@@ -555,7 +631,7 @@ __global__ void __launch_bounds__(256, 2) trunk_fwd3_kernel(TrunkFwdArgs a) {
       if (valid) *reinterpret_cast<f32x4*>(a.a2_out + (int64_t)row * OPE_H + 16 * wave + 4 * g) = act;
       if (!a.head_out) continue;
       *reinterpret_cast<f32x4*>(actb + j * kActPitch + 16 * wave + 4 * g) = act;
-      __syncthreads();
+      lds_barrier();
       if (wave == 0) {   // fused small Linear head (<= 16 outputs = one MFMA tile)
         const int hd = a.head_dim;
         f32x4 ho;
@@ -577,7 +653,7 @@ __global__ void __launch_bounds__(256, 2) trunk_fwd3_kernel(TrunkFwdArgs a) {
       continue;   // the next tile's first barrier orders wave 0's actb reads before anyone overwrites actb
     }
     *reinterpret_cast<f32x4*>(actb + j * kActPitch + 16 * wave + 4 * g) = act;
-    __syncthreads();
+    lds_barrier();
 
     // ---- gi = W_ih a2 + b_ih : 3 of the 12 output tiles ----
     if (!WREG) {
@@ -589,7 +665,7 @@ __global__ void __launch_bounds__(256, 2) trunk_fwd3_kernel(TrunkFwdArgs a) {
     }
     f32x4 o[3];
 #pragma unroll
-    for (int u = 0; u < 3; ++u) o[u] = *reinterpret_cast<const f32x4*>(th + a.L.bih + 16 * (3 * wave + u) + 4 * g);
+    for (int u = 0; u < 3; ++u) o[u] = *reinterpret_cast<const f32x4*>(&bihs[16 * (3 * wave + u) + 4 * g]);
 #pragma unroll
     for (int ft = 0; ft < 4; ++ft) {
       const f32x4 xv = *reinterpret_cast<const f32x4*>(actb + j * kActPitch + 16 * ft + 4 * g);
@@ -598,12 +674,12 @@ __global__ void __launch_bounds__(256, 2) trunk_fwd3_kernel(TrunkFwdArgs a) {
 #pragma unroll
         for (int u = 0; u < 3; ++u) o[u] = mfma16(w3[u][ft][r], xv[r], o[u]);
     }
-    if (valid) {
 #pragma unroll
-      for (int u = 0; u < 3; ++u) *reinterpret_cast<f32x4*>(a.gi + (int64_t)row * (3 * OPE_H) + 16 * (3 * wave + u) + 4 * g) = o[u];
-    }
-    OPE_STAMP();   // wih + stores issued
+    for (int u = 0; u < 3; ++u) go[u] = o[u];
+    go_row = valid ? row : -1;
+    OPE_STAMP();   // wih done (gi stores deferred to the next tile's phase 0)
   }
+  flush_gi();
 #undef OPE_STAMP
 }
 

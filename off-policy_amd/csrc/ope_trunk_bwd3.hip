@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(256, 2) trunk_bwd3_kernel(TrunkBwdArgs a) {
     m1 = rowsum4(m1);
     m2 = rowsum4(m2);
     if (g == 0) *reinterpret_cast<f32x2*>(stat + 2 * (wave * TR + j)) = f32x2{m1, m2};
-    __syncthreads();
+    lds_barrier();
     const f32x2 p0 = *reinterpret_cast<const f32x2*>(stat + 2 * j), p1 = *reinterpret_cast<const f32x2*>(stat + 2 * (TR + j));
     const f32x2 p2 = *reinterpret_cast<const f32x2*>(stat + 2 * (2 * TR + j)), p3 = *reinterpret_cast<const f32x2*>(stat + 2 * (3 * TR + j));
     m1 = ((p0[0] + p1[0]) + (p2[0] + p3[0])) * (1.0f / OPE_H);
@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(256, 2) trunk_bwd3_kernel(TrunkBwdArgs a) {
         const int64_t src = (int64_t)(row0 + r < a.R ? row0 + r : a.R - 1);
         *reinterpret_cast<f32x4*>(dg + r * kDgPitch + 4 * c4) = *reinterpret_cast<const f32x4*>(a.dgi + src * (3 * OPE_H) + 4 * c4);
       }
-      __syncthreads();
+      lds_barrier();
 #pragma unroll
       for (int c = 0; c < 12; ++c) {
         const f32x4 bv = *reinterpret_cast<const f32x4*>(dg + j * kDgPitch + 16 * c + 4 * g);
@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(256, 2) trunk_bwd3_kernel(TrunkBwdArgs a) {
     ln_relu_bwd(d, gm2, a.xhat2, a.rstd2, a.mask2, rr, stat2[0]);
     if (valid) *reinterpret_cast<f32x4*>(a.dz2 + (int64_t)row * OPE_H + fo) = d;
     *reinterpret_cast<f32x4*>(dzb + j * kDzPitch + fo) = d;
-    __syncthreads();
+    lds_barrier();
     f32x4 e = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ft = 0; ft < 4; ++ft) {
