@@ -201,10 +201,11 @@ int launch_trunk_fwd(const TrunkFwdArgs& a, bool save, hipStream_t st) {
   // form; 0: the one-wave-per-row-tile form below (A/B runs)
   static const int v2 = getenv("OPE_TRUNK2") ? atoi(getenv("OPE_TRUNK2")) : 3;
   if (a.head_out && (!a.a2_out || a.head_dim < 1 || a.head_dim > 16)) return OPE_EINVAL;
-  // inputs wider than 256: the first-layer fragments alone are 96-128 VGPRs and the kernel spills (measured slower than the
-  // re-streaming cooperative form: MMM2 QMIX 1082 vs 1199 steps/s), so those stay on trunk_fwd2 unless forced
-  static const int wide = getenv("OPE_TRUNK3_WIDE") ? atoi(getenv("OPE_TRUNK3_WIDE")) : 0;
-  if (v2 == 3 && (a.D <= 256 || (wide && a.D <= 512))) return launch_trunk_fwd3(a, save, st);
+  // inputs wider than 384: the first-layer fragments alone are 128 VGPRs and the kernel spills ~100 registers, so those stay
+  // on the re-streaming cooperative form. Up to 384 (96 VGPRs of fragments, fc2 / W_ih fragments re-fetched per tile) the
+  // persistent kernel wins since its biases and LayerNorm parameters moved to LDS: MMM2 (D = 370) QMIX 1 308 -> 1 383 steps/s.
+  static const int maxd3 = getenv("OPE_TRUNK3_MAXD") ? atoi(getenv("OPE_TRUNK3_MAXD")) : 384;
+  if (v2 == 3 && a.D <= maxd3 && a.D <= 512) return launch_trunk_fwd3(a, save, st);
   if (v2 && a.D <= 512) return launch_trunk_fwd2(a, save, st);
   if (a.head_out) {   // one-wave form: the head is a second launch
     TrunkFwdArgs b = a;

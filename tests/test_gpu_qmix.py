@@ -154,26 +154,28 @@ def test_policy_forward_matches_oracle_single_step_and_sequence():
     assert np.array_equal(acts.argmax(-1), q_ref[0].argmax(-1).numpy())
 
 
-def test_full_size_3s5z_matches_oracle_one_step():
-    """BASELINE config 4 at full size (N=8, A=14, D=252, S=216, T=150, B=32): one step vs the oracle."""
+@pytest.mark.parametrize("workload,nb", [("3s5z", 32), ("MMM2", 8)])
+def test_full_size_3s5z_matches_oracle_one_step(workload, nb):
+    """BASELINE config 4 at full size (N=8, A=14, D=252, S=216, T=150, B=32): one step vs the oracle; and the MMM2
+    dimensions (N=10, A=18, D=370, S=322, T=180: 8-byte vector paths, the 24-chunk trunk) at B=8."""
     from oracle import qmix_oracle as O
     from offpolicy_amd.config import default_args
     from offpolicy_amd.utils.synth import DIMS, synth_episodes, policy_info_for, as_policy_dicts
     from offpolicy_amd.utils.rec_buffer import RecReplayBuffer
     from offpolicy_amd.algorithms.qmix.algorithm.QMixPolicy import QMixPolicy
     from offpolicy_amd.algorithms.qmix.qmix import QMix
-    dims = DIMS["3s5z"]
+    dims = DIMS[workload]
     args = default_args()
     torch.manual_seed(1)
     np.random.seed(1)
     dev = torch.device("cuda:0")
     policy = QMixPolicy({"args": args, "device": dev}, policy_info_for(dims)["policy_0"])
     trainer = QMix(args, dims.n_agents, {"policy_0": policy}, lambda a: "policy_0", device=dev, episode_length=dims.episode_length)
-    buf = RecReplayBuffer(policy_info_for(dims), {"policy_0": list(range(dims.n_agents))}, 32, dims.episode_length, True, True, device=dev)
-    ep = synth_episodes(np.random.RandomState(0), 32, dims, avail="bernoulli")
+    buf = RecReplayBuffer(policy_info_for(dims), {"policy_0": list(range(dims.n_agents))}, nb, dims.episode_length, True, True, device=dev)
+    ep = synth_episodes(np.random.RandomState(0), nb, dims, avail="bernoulli")
     d = as_policy_dicts(ep)
-    buf.insert(32, d["obs"], d["share_obs"], d["acts"], d["rewards"], d["dones"], d["dones_env"], d["avail_acts"])
-    inds = np.arange(32)
+    buf.insert(nb, d["obs"], d["share_obs"], d["acts"], d["rewards"], d["dones"], d["dones_env"], d["avail_acts"])
+    inds = np.arange(nb)
     agent0 = {k: v.detach().cpu().numpy().copy() for k, v in policy.q_network.named_parameters()}
     mixer0 = {k: v.detach().cpu().numpy().copy() for k, v in trainer.mixer.named_parameters()}
     info, _, _ = trainer.train_policy_on_batch(batch_from(buf, inds))
