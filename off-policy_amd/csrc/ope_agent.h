@@ -111,6 +111,8 @@ int launch_trunk_fwd3(const TrunkFwdArgs& a, bool save, hipStream_t st);   // pe
 constexpr int kGru4MaxRows = 1024;
 extern int g_scan_family;   // 0 auto | 1 | 4   (ope_set_scan_kernel / OPE_GRU)
 extern int g_scan_waves;    // 0 auto | 2 | 4   (ope_set_scan_kernel / OPE_GRU4_W)
+int launch_head_fwd_mfma(const HeadFwdArgs& a, hipStream_t st);   // ope_head.hip: 16 rows per wave, q on the matrix pipe
+int launch_head_bwd_rows(const HeadBwdArgs& a, hipStream_t st);
 int launch_gru_fwd(const GruFwdArgs& a, hipStream_t st);
 int launch_gru_fwd1(const GruFwdArgs& a, hipStream_t st);   // one wave per row (ope_gru1.hip)
 int launch_gru_fwd4(const GruFwdArgs& a, hipStream_t st);   // output-split over four waves per row (ope_gru4.hip)

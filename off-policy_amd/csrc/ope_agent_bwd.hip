@@ -65,6 +65,8 @@ __global__ void __launch_bounds__(256) head_bwd_kernel(HeadBwdArgs a) {
 
 int launch_head_bwd(const HeadBwdArgs& a, hipStream_t st) {
   if (a.R < 1) return OPE_EINVAL;
+  static const int rows16 = getenv("OPE_HEAD") ? atoi(getenv("OPE_HEAD")) : 1;   // 0: thread-per-row kernel (A/B runs)
+  if (rows16) return launch_head_bwd_rows(a, st);
   const size_t lds = (size_t)(a.A * OPE_H + OPE_H) * sizeof(float);
   if (lds > 64 * 1024) return OPE_EINVAL;
   hipLaunchKernelGGL(head_bwd_kernel, dim3(ope_cdiv(a.R, 256)), dim3(256), lds, st, a);
