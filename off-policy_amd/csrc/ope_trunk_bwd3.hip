@@ -38,8 +38,8 @@ __global__ void __launch_bounds__(256, 2) trunk_bwd3_kernel(TrunkBwdArgs a) {
   const f32x4 gm2 = *reinterpret_cast<const f32x4*>(th + a.L.ln2_w + fo), gm1 = *reinterpret_cast<const f32x4*>(th + a.L.ln1_w + fo);
 
   // LayerNorm + ReLU adjoint for this lane's 4 features of row j; the row means over all 64 features meet through LDS
-  auto ln_relu_bwd = [&](f32x4& d, const f32x4& gm, const float* xhat, const float* rstd, const uint64_t* mask, int64_t rr, float* stat) {
-    const f32x4 xh = *reinterpret_cast<const f32x4*>(xhat + rr * OPE_H + fo);
+  // (xh, rs, bits: the row's saved normalised values, 1/std and this wave's 16 ReLU bits, loaded at the top of the tile)
+  auto ln_relu_bwd = [&](f32x4& d, const f32x4& gm, const f32x4& xh, float rs, uint32_t bits, float* stat) {
     float m1 = 0.f, m2 = 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -55,8 +55,6 @@ __global__ void __launch_bounds__(256, 2) trunk_bwd3_kernel(TrunkBwdArgs a) {
     const f32x2 p2 = *reinterpret_cast<const f32x2*>(stat + 2 * (2 * TR + j)), p3 = *reinterpret_cast<const f32x2*>(stat + 2 * (3 * TR + j));
     m1 = ((p0[0] + p1[0]) + (p2[0] + p3[0])) * (1.0f / OPE_H);
     m2 = ((p0[1] + p1[1]) + (p2[1] + p3[1])) * (1.0f / OPE_H);
-    const float rs = rstd[rr];
-    const uint32_t bits = reinterpret_cast<const uint16_t*>(mask + rr)[wave];   // this wave's 16 ReLU bits of the row
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float v = rs * (d[r] - m1 - xh[r] * m2);
@@ -69,6 +67,13 @@ __global__ void __launch_bounds__(256, 2) trunk_bwd3_kernel(TrunkBwdArgs a) {
     const int row = row0 + j;
     const bool valid = row < a.R;
     const int64_t rr = valid ? row : a.R - 1;
+    // every global load of the tile is issued here, so that the tile pays ONE memory round trip (the saved activations
+    // used to be fetched inside the two LayerNorm adjoints: three dependent round trips per tile)
+    const f32x4 xh2 = *reinterpret_cast<const f32x4*>(a.xhat2 + rr * OPE_H + fo);
+    const f32x4 xh1 = *reinterpret_cast<const f32x4*>(a.xhat1 + rr * OPE_H + fo);
+    const float rs2 = a.rstd2[rr], rs1 = a.rstd1[rr];
+    const uint32_t bits2 = reinterpret_cast<const uint16_t*>(a.mask2 + rr)[wave];   // this wave's 16 ReLU bits of the row
+    const uint32_t bits1 = reinterpret_cast<const uint16_t*>(a.mask1 + rr)[wave];
     f32x4 d = {0.f, 0.f, 0.f, 0.f};
     if (recurrent) {
       // stage the tile's dgi rows (16 x 192 floats, contiguous in memory) in LDS: 3 x 16-byte pieces per thread
@@ -96,7 +101,7 @@ __global__ void __launch_bounds__(256, 2) trunk_bwd3_kernel(TrunkBwdArgs a) {
         for (int r = 0; r < 4; ++r) d[r] = fmaf(dk, w[r], d[r]);
       }
     }
-    ln_relu_bwd(d, gm2, a.xhat2, a.rstd2, a.mask2, rr, stat2[0]);
+    ln_relu_bwd(d, gm2, xh2, rs2, bits2, stat2[0]);
     if (valid) *reinterpret_cast<f32x4*>(a.dz2 + (int64_t)row * OPE_H + fo) = d;
     *reinterpret_cast<f32x4*>(dzb + j * kDzPitch + fo) = d;
     lds_barrier();
@@ -107,7 +112,7 @@ __global__ void __launch_bounds__(256, 2) trunk_bwd3_kernel(TrunkBwdArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) e = mfma16(wB[ft][r], bv[r], e);
     }
-    ln_relu_bwd(e, gm1, a.xhat1, a.rstd1, a.mask1, rr, stat2[1]);   // its barrier also orders the dzb reads before the next tile's writes
+    ln_relu_bwd(e, gm1, xh1, rs1, bits1, stat2[1]);   // its barrier also orders the dzb reads before the next tile's writes
     if (valid) *reinterpret_cast<f32x4*>(a.dz1 + (int64_t)row * OPE_H + fo) = e;
   }
 }
