@@ -586,9 +586,139 @@ __global__ void __launch_bounds__(256) mixer_bwd_kernel(MixerBwdArgs a) {
   }
 }
 
+// The same adjoint with a 16-row tile spread over the 4 waves of a workgroup (default). The one-wave-per-tile kernel
+// above is 300 waves at 3s5z, each a serial chain over the N agents (2 + 8 loads and 8 MFMAs per agent, every load waited
+// for in turn): 25 us of one wave's latency on a third of the SIMDs. Here wave w takes agents w, w+4, ..., the four
+// partial W1b^T dv1 tiles meet in LDS (fixed order), and wave w finishes feature tile w of the three hyper-net adjoints.
+constexpr int kPartPitch = OPE_HYP + 4;
+__global__ void __launch_bounds__(256) mixer_bwd4_kernel(MixerBwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float part[4][16][kPartPitch];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int tile = blockIdx.x;
+  const int m0 = tile * 16;
+  const int m = m0 + j;
+  const bool valid = m < a.TB;
+  const int mm = valid ? m : m0;
+  const int t = mm / a.td.B, b = mm - t * a.td.B;
+  const float* __restrict__ th = a.theta;
+  const MixerLayout& L = a.L;
+  const int N = a.N;
+  const int NM = N * OPE_MIX;
+  const float* w1bT = a.thetaT;                 // [64][N*32]
+  const float* w2bT = a.thetaT + OPE_HYP * NM;  // [64][32]
+  const int fo = 16 * wave + 4 * g;             // the 4 hyper-net features this lane finishes
+
+  // loads with no dependency on the TD error go out first: this wave's share of the final stage
+  const f32x4 h1 = *reinterpret_cast<const f32x4*>(a.hw1 + (int64_t)mm * OPE_HYP + fo);
+  const f32x4 h2 = *reinterpret_cast<const f32x4*>(a.hw2 + (int64_t)mm * OPE_HYP + fo);
+  const f32x4 h3 = *reinterpret_cast<const f32x4*>(a.hb2 + (int64_t)mm * OPE_HYP + fo);
+  const f32x4 wb = *reinterpret_cast<const f32x4*>(th + L.b2b_w + fo);
+  f32x4 hp[2], v2[2];
+#pragma unroll
+  for (int kh = 0; kh < 2; ++kh) {
+    hp[kh] = *reinterpret_cast<const f32x4*>(a.hpre + (int64_t)mm * OPE_MIX + 16 * kh + 4 * g);
+    v2[kh] = *reinterpret_cast<const f32x4*>(a.v2 + (int64_t)mm * OPE_MIX + 16 * kh + 4 * g);
+  }
+  const float qtot = a.qtot[mm];
+  TdOut td = td_row(a.td, t, b, qtot, a.nqtot[mm]);
+  if (!valid) { td.err = 0.f; td.keep = 0.f; td.lossel = 0.f; td.dq = 0.f; }
+  const float dQ = td.dq;
+  if (wave == 0) {
+    const float ls = tilesum16(g == 0 ? td.lossel : 0.f);
+    const float cs = tilesum16(g == 0 ? td.keep : 0.f);
+    const float qs = tilesum16(g == 0 ? qtot * td.keep : 0.f);
+    if (lane == 0) {
+      a.loss_part[tile * 4 + 0] = ls;
+      a.loss_part[tile * 4 + 1] = cs;
+      a.loss_part[tile * 4 + 2] = qs;
+      a.loss_part[tile * 4 + 3] = 0.f;
+    }
+    if (valid && g == 0) {
+      a.err_abs[m] = fabsf(td.err);
+      *reinterpret_cast<f32x4*>(a.dqtot + 4 * (int64_t)m) = f32x4{dQ, 0.f, 0.f, 0.f};   // [TB][4]: lda = 4 for the wgrad kernel
+    }
+  }
+  // lane-local 32-vectors (k = 16kh + 4g + r), evaluated by every wave; wave 0 stores them
+  f32x4 dpre[2], dv2[2];
+#pragma unroll
+  for (int kh = 0; kh < 2; ++kh) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float hdn = elu1(hp[kh][r]);
+      dv2[kh][r] = dQ * hdn * sgn(v2[kh][r]);
+      const float dh = dQ * fabsf(v2[kh][r]);
+      dpre[kh][r] = dh * (hp[kh][r] > 0.f ? 1.0f : expf(hp[kh][r]));
+    }
+    if (valid && wave == 0) {
+      *reinterpret_cast<f32x4*>(a.d_b1 + (int64_t)m * OPE_MIX + 16 * kh + 4 * g) = dpre[kh];
+      *reinterpret_cast<f32x4*>(a.d_v2 + (int64_t)m * OPE_MIX + 16 * kh + 4 * g) = dv2[kh];
+    }
+  }
+  // this wave's agents: dq_a, dv1, and its partial of dhw1 = W1b^T dv1
+  f32x4 dh1[4];
+#pragma unroll
+  for (int ft = 0; ft < 4; ++ft) dh1[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int ag = wave; ag < N; ag += 4) {
+    const float qa = a.agent_q[(int64_t)mm * N + ag];
+    float dqa = 0.f;
+    f32x4 dv1[2];
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(a.v1 + (int64_t)mm * NM + ag * OPE_MIX + 16 * kh + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        dqa = fmaf(dpre[kh][r], fabsf(v[r]), dqa);
+        dv1[kh][r] = dpre[kh][r] * qa * sgn(v[r]);
+      }
+      if (valid) *reinterpret_cast<f32x4*>(a.d_v1 + (int64_t)m * NM + ag * OPE_MIX + 16 * kh + 4 * g) = dv1[kh];
+    }
+    dqa = rowsum4(dqa);
+    if (valid && g == 0) a.d_agent_q[(int64_t)m * N + ag] = dqa;
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(w1bT + (int64_t)(16 * ft + j) * NM + ag * OPE_MIX + 16 * kh + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dh1[ft] = mfma16(wv[r], dv1[kh][r], dh1[ft]);
+      }
+  }
+#pragma unroll
+  for (int ft = 0; ft < 4; ++ft) *reinterpret_cast<f32x4*>(&part[wave][j][16 * ft + 4 * g]) = dh1[ft];
+  // feature tile `wave` of dhw2 = W2b^T dv2 while the partials settle
+  f32x4 dh2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kh = 0; kh < 2; ++kh) {
+    const f32x4 wv = *reinterpret_cast<const f32x4*>(w2bT + (int64_t)(16 * wave + j) * OPE_MIX + 16 * kh + 4 * g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dh2 = mfma16(wv[r], dv2[kh][r], dh2);
+  }
+  lds_barrier();
+  if (valid) {
+    const f32x4 p0 = *reinterpret_cast<const f32x4*>(&part[0][j][fo]), p1 = *reinterpret_cast<const f32x4*>(&part[1][j][fo]);
+    const f32x4 p2 = *reinterpret_cast<const f32x4*>(&part[2][j][fo]), p3 = *reinterpret_cast<const f32x4*>(&part[3][j][fo]);
+    f32x4 o1, o2, o3;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float s1 = (p0[r] + p1[r]) + (p2[r] + p3[r]);
+      o1[r] = h1[r] > 0.f ? s1 : 0.f;
+      o2[r] = h2[r] > 0.f ? dh2[r] : 0.f;
+      o3[r] = h3[r] > 0.f ? dQ * wb[r] : 0.f;
+    }
+    *reinterpret_cast<f32x4*>(a.d_hw1 + (int64_t)m * OPE_HYP + fo) = o1;
+    *reinterpret_cast<f32x4*>(a.d_hw2 + (int64_t)m * OPE_HYP + fo) = o2;
+    *reinterpret_cast<f32x4*>(a.d_hb2 + (int64_t)m * OPE_HYP + fo) = o3;
+  }
+}
+
 int launch_mixer_bwd(const MixerBwdArgs& a, hipStream_t st) {
   if (a.TB < 1) return OPE_EINVAL;
-  hipLaunchKernelGGL(mixer_bwd_kernel, dim3(ope_cdiv(ope_cdiv(a.TB, 16), 4)), dim3(256), 0, st, a);
+  static const int coop = getenv("OPE_MIXER_BWD4") ? atoi(getenv("OPE_MIXER_BWD4")) : 1;   // 0: one wave per tile (A/B runs)
+  if (coop)
+    hipLaunchKernelGGL(mixer_bwd4_kernel, dim3(ope_cdiv(a.TB, 16)), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(mixer_bwd_kernel, dim3(ope_cdiv(ope_cdiv(a.TB, 16), 4)), dim3(256), 0, st, a);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   return OPE_OK;
 }
