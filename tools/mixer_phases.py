@@ -21,7 +21,11 @@ _lib.lib.ope_set_debug(1)
 for _ in range(3):
     trainer.train_policy_on_batch(batch)
 torch.cuda.synchronize()
-d = trainer.workspace_view(B, "dbg").view(torch.int64).cpu().numpy().reshape(-1, 8)
+trainer.workspace_view(B, "dbg").zero_()          # stale stamps of other kernels / earlier steps would pollute the table
+trainer.train_policy_on_batch(batch)
+torch.cuda.synchronize()
+nw = 2 * ((dims.episode_length * B + 15) // 16) * 4   # waves of mixer_fwd2 (RT = 1): 2 nets x row tiles x 4
+d = trainer.workspace_view(B, "dbg").view(torch.int64).cpu().numpy()[:8 * nw].reshape(-1, 8)
 d = d[d[:, 0] > 0]
 t0 = d[:, 0].min()
 rel = (d[:, :6] - t0).astype(np.float64)
