@@ -374,8 +374,7 @@ int launch_head_fwd(const HeadFwdArgs& a, int mode, hipStream_t st) {
   const size_t lds = (size_t)per * nets * sizeof(float);
   if (lds > 64 * 1024) return OPE_EINVAL;
   if (a.r_begin < 0 || a.r_begin >= a.R) return OPE_EINVAL;
-  static const int rows16 = getenv("OPE_HEAD") ? atoi(getenv("OPE_HEAD")) : 1;   // 0: thread-per-row kernels (A/B runs)
-  if (mode == 0 && rows16 && a.A <= 32) return launch_head_fwd_mfma(a, st);
+  if (mode == 0 && a.A <= 32) return launch_head_fwd_mfma(a, st);   // ope_head.hip; wider action spaces: thread per row below
   const int blocks = ope_cdiv(a.R - a.r_begin, 256);
   if (mode == 0)
     hipLaunchKernelGGL(head_fwd_kernel<0>, dim3(blocks), dim3(256), lds, st, a);

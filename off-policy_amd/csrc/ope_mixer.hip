@@ -3,9 +3,9 @@
 //   TD target / mask / Huber|MSE / PER offpolicy/algorithms/qmix/qmix.py:158-187, utils/util.py:103-110
 //   VDN mixing (sum over agents)       offpolicy/algorithms/vdn/algorithm/vdn_mixer.py:28-40 (with the A-2 shape fix)
 //
-// One wave owns 16 (t,b) rows. The four hyper-network first layers (S -> 64,64,64,32) run as one 14-tile f32-MFMA
-// chain over the state row; the second layers (64 -> N*32, 32) chain on without leaving registers; the per-row
-// agent-Q x |w1| contraction, ELU, |w2| dot and b2 are lane-local with two cross-lane adds (4 lanes share a row).
+// A workgroup owns 16 (t,b) rows of one net. The four hyper-network first layers (S -> 64,64,64,32) are 14 f32-MFMA
+// output tiles over the state row, split over the 4 waves; the second layers (64 -> N*32, 32), the per-row agent-Q x |w1|
+// contraction, ELU, |w2| dot and b2 follow with the agents split over the waves (4 lanes share a row: two cross-lane adds).
 #include <stdlib.h>
 
 #include "ope_mixer.h"
@@ -29,160 +29,14 @@ __device__ __forceinline__ const float* stageA_bias(const float* th, const Mixer
   return th + L.b1_b + 16 * (it - 12);
 }
 
-template <int VEC>
-__global__ void __launch_bounds__(256) mixer_fwd_kernel(MixerFwdArgs a) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int j = lane & 15, g = lane >> 4;
-  const int tiles = (a.TB + 15) >> 4;
-  const int w = blockIdx.x * 4 + wave;
-  if (w >= 2 * tiles) return;
-  const int net = w / tiles;
-  const int m0 = (w - net * tiles) * 16;
-  const int m = m0 + j;
-  const bool valid = m < a.TB;
-  const int mm = valid ? m : m0;
-  const int t = mm / a.B, b = mm - t * a.B;
-  const float* __restrict__ th = net == 0 ? a.theta0 : a.theta1;
-  const MixerLayout& L = a.L;
-  const int S = a.S, N = a.N;
-  const float* __restrict__ srow = a.share + ((int64_t)(t + net) * a.B + b) * S;
-  const float* __restrict__ qrow = (net == 0 ? a.agent_q : a.agent_nq) + (int64_t)mm * N;
-  const bool save = (net == 0) && (a.hw1 != nullptr);
-
-  // ---- stage A: 14 output tiles over K = S; branch-free K loop, operands of chunk c+1 in flight during chunk c ----
-  f32x4 acc[14];
-#pragma unroll
-  for (int it = 0; it < 14; ++it) acc[it] = *reinterpret_cast<const f32x4*>(stageA_bias(th, L, it) + 4 * g);
-  const int KC = (S + 15) >> 4;
-  {
-    const float* wrow[14];
-#pragma unroll
-    for (int it = 0; it < 14; ++it) wrow[it] = stageA_row(th, L, S, it, j);
-    // ping-pong chunk buffers, loop unrolled by two (no copies); chunks past KC-1 multiply a zero-masked state vector
-    f32x4 wa[14], wb[14], xa, xb;
-    auto fetchA = [&](f32x4 (&w)[14], f32x4& x, int c) {
-      const int k = 16 * c + 4 * g;
-#pragma unroll
-      for (int it = 0; it < 14; ++it) w[it] = load4c<VEC>(wrow[it], k, S);
-      x = load4c<VEC>(srow, k, S);
-    };
-    auto computeA = [&](const f32x4 (&w)[14], const f32x4& x, int c) {
-      const f32x4 xs = mask4(x, 16 * c + 4 * g, S);
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int it = 0; it < 14; ++it) acc[it] = mfma16(w[it][r], xs[r], acc[it]);
-    };
-    fetchA(wa, xa, 0);
-    for (int c = 0; c < KC; c += 2) {
-      fetchA(wb, xb, c + 1);
-      __builtin_amdgcn_sched_barrier(0);   // pin: loads of one buffer issue before the MFMAs of the other
-      computeA(wa, xa, c);
-      __builtin_amdgcn_sched_barrier(0);
-      fetchA(wa, xa, c + 2);
-      __builtin_amdgcn_sched_barrier(0);
-      computeA(wb, xb, c + 1);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-#pragma unroll
-  for (int it = 0; it < 12; ++it)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc[it][r] = fmaxf(acc[it][r], 0.f);
-  if (save && valid) {
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      *reinterpret_cast<f32x4*>(a.hw1 + (int64_t)m * OPE_HYP + 16 * it + 4 * g) = acc[it];
-      *reinterpret_cast<f32x4*>(a.hw2 + (int64_t)m * OPE_HYP + 16 * it + 4 * g) = acc[4 + it];
-      *reinterpret_cast<f32x4*>(a.hb2 + (int64_t)m * OPE_HYP + 16 * it + 4 * g) = acc[8 + it];
-    }
-  }
-  f32x4 hw1[4] = {acc[0], acc[1], acc[2], acc[3]};
-  f32x4 hw2[4] = {acc[4], acc[5], acc[6], acc[7]};
-
-  // ---- stage B: hidden = ELU( sum_a q_a |W1b hw1 + b|[a] + b1 ); agent a+1's weights prefetched during agent a ----
-  f32x4 hid[2] = {acc[12], acc[13]};
-  {
-    f32x4 wc[2][4], wn[2][4], bc[2], bn[2];
-    float qc, qn;
-    auto fetchB = [&](int ag, f32x4 (&w)[2][4], f32x4 (&b)[2], float& q) {
-      const int agc = min(ag, N - 1);
-#pragma unroll
-      for (int kh = 0; kh < 2; ++kh) {
-        b[kh] = *reinterpret_cast<const f32x4*>(th + L.w1b_b + agc * OPE_MIX + 16 * kh + 4 * g);
-#pragma unroll
-        for (int ft = 0; ft < 4; ++ft)
-          w[kh][ft] = *reinterpret_cast<const f32x4*>(th + L.w1b_w + (int64_t)(agc * OPE_MIX + 16 * kh + j) * OPE_HYP + 16 * ft + 4 * g);
-      }
-      q = qrow[agc];
-    };
-    fetchB(0, wc, bc, qc);
-    for (int ag = 0; ag < N; ++ag) {
-      fetchB(ag + 1, wn, bn, qn);
-      f32x4 v[2] = {bc[0], bc[1]};
-#pragma unroll
-      for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-        for (int ft = 0; ft < 4; ++ft)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[kh] = mfma16(wc[kh][ft][r], hw1[ft][r], v[kh]);
-      if (save && valid) {
-#pragma unroll
-        for (int kh = 0; kh < 2; ++kh)
-          *reinterpret_cast<f32x4*>(a.v1 + (int64_t)m * (N * OPE_MIX) + ag * OPE_MIX + 16 * kh + 4 * g) = v[kh];
-      }
-#pragma unroll
-      for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) hid[kh][r] = fmaf(qc, fabsf(v[kh][r]), hid[kh][r]);
-#pragma unroll
-      for (int kh = 0; kh < 2; ++kh) {
-        bc[kh] = bn[kh];
-#pragma unroll
-        for (int ft = 0; ft < 4; ++ft) wc[kh][ft] = wn[kh][ft];
-      }
-      qc = qn;
-    }
-  }
-  if (save && valid) {
-#pragma unroll
-    for (int kh = 0; kh < 2; ++kh) *reinterpret_cast<f32x4*>(a.hpre + (int64_t)m * OPE_MIX + 16 * kh + 4 * g) = hid[kh];
-  }
-  // ---- w2, b2, Q_tot ----
-  f32x4 v2[2];
-#pragma unroll
-  for (int kh = 0; kh < 2; ++kh) v2[kh] = *reinterpret_cast<const f32x4*>(th + L.w2b_b + 16 * kh + 4 * g);
-  gemm64<2>(th + L.w2b_w, OPE_HYP, j, g, hw2, v2);
-  if (save && valid) {
-#pragma unroll
-    for (int kh = 0; kh < 2; ++kh) *reinterpret_cast<f32x4*>(a.v2 + (int64_t)m * OPE_MIX + 16 * kh + 4 * g) = v2[kh];
-  }
-  float part = 0.f;
-#pragma unroll
-  for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) part = fmaf(elu1(hid[kh][r]), fabsf(v2[kh][r]), part);
-  float pb = 0.f;
-#pragma unroll
-  for (int ft = 0; ft < 4; ++ft) {
-    const f32x4 wv = *reinterpret_cast<const f32x4*>(th + L.b2b_w + 16 * ft + 4 * g);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) pb = fmaf(wv[r], acc[8 + ft][r], pb);
-  }
-  const float qtot = rowsum4(part) + (rowsum4(pb) + th[L.b2b_b]);
-  if (valid && g == 0) (net == 0 ? a.qtot : a.nqtot)[m] = qtot;
-}
-
-
 // ---------------------------------------------------------------------------------------------------------
-// mixer_fwd, workgroup-cooperative form (default; OPE_MIXER2=0 selects the one-wave form above). The one-wave form is
-// ~600 waves for 3s5z/B=32 -- 0.6 per SIMD -- each a chain of ~1050 dependent-issue MFMAs. Here a workgroup owns the 16
-// (t,b) rows and its four waves split the hyper-networks:
+// mixer_fwd, workgroup-cooperative form. (One wave per 16 rows was ~600 waves for 3s5z/B=32 -- 0.6 per SIMD -- each a
+// chain of ~1050 dependent-issue MFMAs.) A workgroup owns the 16 (t,b) rows and its four waves split the hyper-networks:
 //   stage A   wave 0: hyper_w1.0 (4 tiles)   wave 1: hyper_w2.0 (4)   wave 2: hyper_b2.0 (4)   wave 3: hyper_b1 (2)
 //   stage B   hw1 goes through LDS; wave w takes agents w, w+4, ...: v1_a = W1b_a hw1 + b, hidden partial += q_a |v1_a|
 //             (wave 3's partial starts from b1); wave 1 also forms v2 = W2b hw2 + b; wave 2 the b2 head dot
 //   combine   wave 1 adds the four hidden partials in fixed order, ELU, dot with |v2|, + b2  ->  Q_tot
-// Two workgroup barriers. Same arithmetic per row as the one-wave form up to the order of the hidden-layer sum.
+// Two workgroup barriers.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kHwPitch = OPE_HYP + 4;
 constexpr int kHidPitch = OPE_MIX + 4;
@@ -414,20 +268,10 @@ static void launch_mixer2(const MixerFwdArgs& a0, hipStream_t st) {
 
 int launch_mixer_fwd(const MixerFwdArgs& a, hipStream_t st) {
   if (a.TB < 1 || a.N < 1 || a.S < 1) return OPE_EINVAL;
-  const int waves = 2 * ope_cdiv(a.TB, 16);
-  const int blocks = ope_cdiv(waves, 4);
   const int vec = ope_vec_of(a.S);
-  static const int v2 = getenv("OPE_MIXER2") ? atoi(getenv("OPE_MIXER2")) : 1;
-  if (v2) {
-    if (vec == 4) launch_mixer2<4>(a, st);
-    else if (vec == 2) launch_mixer2<2>(a, st);
-    else launch_mixer2<1>(a, st);
-    if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
-    return OPE_OK;
-  }
-  if (vec == 4) hipLaunchKernelGGL(mixer_fwd_kernel<4>, dim3(blocks), dim3(256), 0, st, a);
-  else if (vec == 2) hipLaunchKernelGGL(mixer_fwd_kernel<2>, dim3(blocks), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(mixer_fwd_kernel<1>, dim3(blocks), dim3(256), 0, st, a);
+  if (vec == 4) launch_mixer2<4>(a, st);
+  else if (vec == 2) launch_mixer2<2>(a, st);
+  else launch_mixer2<1>(a, st);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   return OPE_OK;
 }
@@ -470,126 +314,10 @@ __device__ __forceinline__ float tilesum16(float x) {
   return x;
 }
 
-__global__ void __launch_bounds__(256) mixer_bwd_kernel(MixerBwdArgs a) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int j = lane & 15, g = lane >> 4;
-  const int tile = blockIdx.x * 4 + wave;
-  const int m0 = tile * 16;
-  if (m0 >= a.TB) return;
-  const int m = m0 + j;
-  const bool valid = m < a.TB;
-  const int mm = valid ? m : m0;
-  const int t = mm / a.td.B, b = mm - t * a.td.B;
-  const float* __restrict__ th = a.theta;
-  const MixerLayout& L = a.L;
-  const int N = a.N;
-
-  TdOut td = td_row(a.td, t, b, a.qtot[mm], a.nqtot[mm]);
-  if (!valid) { td.err = 0.f; td.keep = 0.f; td.lossel = 0.f; td.dq = 0.f; }
-  {
-    const float ls = tilesum16(g == 0 ? td.lossel : 0.f);
-    const float cs = tilesum16(g == 0 ? td.keep : 0.f);
-    const float qs = tilesum16(g == 0 ? a.qtot[mm] * td.keep : 0.f);
-    if (lane == 0) {
-      a.loss_part[tile * 4 + 0] = ls;
-      a.loss_part[tile * 4 + 1] = cs;
-      a.loss_part[tile * 4 + 2] = qs;
-      a.loss_part[tile * 4 + 3] = 0.f;
-    }
-  }
-  const float dQ = td.dq;
-  if (valid && g == 0) {
-    a.err_abs[m] = fabsf(td.err);
-    *reinterpret_cast<f32x4*>(a.dqtot + 4 * (int64_t)m) = f32x4{dQ, 0.f, 0.f, 0.f};   // [TB][4]: lda = 4 for the wgrad kernel
-  }
-
-  // lane-local 32-vectors (k = 16kh + 4g + r)
-  f32x4 hp[2], v2[2], dpre[2], dv2[2];
-#pragma unroll
-  for (int kh = 0; kh < 2; ++kh) {
-    hp[kh] = *reinterpret_cast<const f32x4*>(a.hpre + (int64_t)mm * OPE_MIX + 16 * kh + 4 * g);
-    v2[kh] = *reinterpret_cast<const f32x4*>(a.v2 + (int64_t)mm * OPE_MIX + 16 * kh + 4 * g);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float hdn = elu1(hp[kh][r]);
-      dv2[kh][r] = dQ * hdn * sgn(v2[kh][r]);
-      const float dh = dQ * fabsf(v2[kh][r]);
-      dpre[kh][r] = dh * (hp[kh][r] > 0.f ? 1.0f : expf(hp[kh][r]));
-    }
-    if (valid) {
-      *reinterpret_cast<f32x4*>(a.d_b1 + (int64_t)m * OPE_MIX + 16 * kh + 4 * g) = dpre[kh];
-      *reinterpret_cast<f32x4*>(a.d_v2 + (int64_t)m * OPE_MIX + 16 * kh + 4 * g) = dv2[kh];
-    }
-  }
-  // agents: dq_a, dv1, and dhw1 += W1b^T dv1
-  f32x4 dh1[4];
-#pragma unroll
-  for (int ft = 0; ft < 4; ++ft) dh1[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int NM = N * OPE_MIX;
-  const float* w1bT = a.thetaT;                 // [64][N*32]
-  const float* w2bT = a.thetaT + OPE_HYP * NM;  // [64][32]
-  for (int ag = 0; ag < N; ++ag) {
-    const float qa = a.agent_q[(int64_t)mm * N + ag];
-    float dqa = 0.f;
-    f32x4 dv1[2];
-#pragma unroll
-    for (int kh = 0; kh < 2; ++kh) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(a.v1 + (int64_t)mm * NM + ag * OPE_MIX + 16 * kh + 4 * g);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        dqa = fmaf(dpre[kh][r], fabsf(v[r]), dqa);
-        dv1[kh][r] = dpre[kh][r] * qa * sgn(v[r]);
-      }
-      if (valid) *reinterpret_cast<f32x4*>(a.d_v1 + (int64_t)m * NM + ag * OPE_MIX + 16 * kh + 4 * g) = dv1[kh];
-    }
-    dqa = rowsum4(dqa);
-    if (valid && g == 0) a.d_agent_q[(int64_t)m * N + ag] = dqa;
-#pragma unroll
-    for (int ft = 0; ft < 4; ++ft)
-#pragma unroll
-      for (int kh = 0; kh < 2; ++kh) {
-        const f32x4 wv = *reinterpret_cast<const f32x4*>(w1bT + (int64_t)(16 * ft + j) * NM + ag * OPE_MIX + 16 * kh + 4 * g);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dh1[ft] = mfma16(wv[r], dv1[kh][r], dh1[ft]);
-      }
-  }
-  // dhw2 = W2b^T dv2 ; ReLU masks ; dhb2 = dQ * w ; stores
-  f32x4 dh2[4];
-#pragma unroll
-  for (int ft = 0; ft < 4; ++ft) {
-    dh2[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kh = 0; kh < 2; ++kh) {
-      const f32x4 wv = *reinterpret_cast<const f32x4*>(w2bT + (int64_t)(16 * ft + j) * OPE_MIX + 16 * kh + 4 * g);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) dh2[ft] = mfma16(wv[r], dv2[kh][r], dh2[ft]);
-    }
-  }
-  if (valid) {
-#pragma unroll
-    for (int ft = 0; ft < 4; ++ft) {
-      const f32x4 h1 = *reinterpret_cast<const f32x4*>(a.hw1 + (int64_t)m * OPE_HYP + 16 * ft + 4 * g);
-      const f32x4 h2 = *reinterpret_cast<const f32x4*>(a.hw2 + (int64_t)m * OPE_HYP + 16 * ft + 4 * g);
-      const f32x4 h3 = *reinterpret_cast<const f32x4*>(a.hb2 + (int64_t)m * OPE_HYP + 16 * ft + 4 * g);
-      const f32x4 wb = *reinterpret_cast<const f32x4*>(th + L.b2b_w + 16 * ft + 4 * g);
-      f32x4 o1, o2, o3;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        o1[r] = h1[r] > 0.f ? dh1[ft][r] : 0.f;
-        o2[r] = h2[r] > 0.f ? dh2[ft][r] : 0.f;
-        o3[r] = h3[r] > 0.f ? dQ * wb[r] : 0.f;
-      }
-      *reinterpret_cast<f32x4*>(a.d_hw1 + (int64_t)m * OPE_HYP + 16 * ft + 4 * g) = o1;
-      *reinterpret_cast<f32x4*>(a.d_hw2 + (int64_t)m * OPE_HYP + 16 * ft + 4 * g) = o2;
-      *reinterpret_cast<f32x4*>(a.d_hb2 + (int64_t)m * OPE_HYP + 16 * ft + 4 * g) = o3;
-    }
-  }
-}
-
-// The same adjoint with a 16-row tile spread over the 4 waves of a workgroup (default). The one-wave-per-tile kernel
-// above is 300 waves at 3s5z, each a serial chain over the N agents (2 + 8 loads and 8 MFMAs per agent, every load waited
-// for in turn): 25 us of one wave's latency on a third of the SIMDs. Here wave w takes agents w, w+4, ..., the four
-// partial W1b^T dv1 tiles meet in LDS (fixed order), and wave w finishes feature tile w of the three hyper-net adjoints.
+// Mixer adjoint: a 16-row tile spread over the 4 waves of a workgroup. (One wave per tile was 300 waves at 3s5z, each a
+// serial chain over the N agents -- 2 + 8 loads and 8 MFMAs per agent, every load waited for in turn: 25 us of one wave's
+// latency on a third of the SIMDs.) Wave w takes agents w, w+4, ..., the four partial W1b^T dv1 tiles meet in LDS (fixed
+// order), and wave w finishes feature tile w of the three hyper-net adjoints.
 constexpr int kPartPitch = OPE_HYP + 4;
 __global__ void __launch_bounds__(256) mixer_bwd4_kernel(MixerBwdArgs a) {
   __shared__ __attribute__((aligned(16))) float part[4][16][kPartPitch];
@@ -714,11 +442,7 @@ __global__ void __launch_bounds__(256) mixer_bwd4_kernel(MixerBwdArgs a) {
 
 int launch_mixer_bwd(const MixerBwdArgs& a, hipStream_t st) {
   if (a.TB < 1) return OPE_EINVAL;
-  static const int coop = getenv("OPE_MIXER_BWD4") ? atoi(getenv("OPE_MIXER_BWD4")) : 1;   // 0: one wave per tile (A/B runs)
-  if (coop)
-    hipLaunchKernelGGL(mixer_bwd4_kernel, dim3(ope_cdiv(a.TB, 16)), dim3(256), 0, st, a);
-  else
-    hipLaunchKernelGGL(mixer_bwd_kernel, dim3(ope_cdiv(ope_cdiv(a.TB, 16), 4)), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(mixer_bwd4_kernel, dim3(ope_cdiv(a.TB, 16)), dim3(256), 0, st, a);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   return OPE_OK;
 }

@@ -687,7 +687,8 @@ template <int VEC, bool SAVE>
 static int launch3(const TrunkFwdArgs& a, hipStream_t st) {
   const int KC = (a.D + 15) >> 4;
   const int ntiles = ope_cdiv(a.R, 16);
-  const int blocks = ntiles < 512 ? ntiles : 512;   // persistent: two workgroups per CU
+  static const int cap = getenv("OPE_TRUNK3_BLOCKS") ? atoi(getenv("OPE_TRUNK3_BLOCKS")) : 512;   // persistent: two workgroups per CU
+  const int blocks = ntiles < cap ? ntiles : cap;
   if (KC <= 8) hipLaunchKernelGGL((trunk_fwd3_kernel<VEC, 8, SAVE>), dim3(blocks), dim3(256), 0, st, a);
   else if (KC <= 16) hipLaunchKernelGGL((trunk_fwd3_kernel<VEC, 16, SAVE>), dim3(blocks), dim3(256), 0, st, a);
   else if (KC <= 24) hipLaunchKernelGGL((trunk_fwd3_kernel<VEC, 24, SAVE>), dim3(blocks), dim3(256), 0, st, a);

@@ -1,4 +1,4 @@
-// trunk_bwd, persistent workgroup-cooperative form (default; OPE_TRUNKB3=0 selects trunk_bwd_kernel in ope_agent_bwd.hip).
+// trunk_bwd, persistent workgroup-cooperative form.
 // Adjoint of the trunk:  dgi -> da2 = W_ih^T dgi -> LN2/ReLU adjoint -> dz2 -> da1 = fc2^T dz2 -> LN1/ReLU adjoint -> dz1
 // (the weight gradients are taken from dz1 / dz2 / dgi by the batched wgrad launch).
 // Same decomposition as trunk_fwd3 (ope_trunk2.hip): the 64 features of each layer are split over the 4 waves of a
