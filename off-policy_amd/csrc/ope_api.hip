@@ -101,7 +101,12 @@ void make_plan(const ope_qmix_cfg* c, Plan* p) {
   w.mixer_size = c->vdn ? 0 : (p->ML.end - p->AL.end);
   // K-splits: every wave reduces ~160 rows whatever the problem, so workgroups are equally long and spread evenly over
   // the CUs (multiples of 4: the four waves of a workgroup hold consecutive splits and pre-reduce them)
-  auto splits_for = [](int64_t K, int cap) { int s = (int)((K + 159) / 160); s = s >= 4 ? ((s + 3) / 4) * 4 : s; return clampi(s, 1, cap); };
+  static const int rows_per_split = getenv("OPE_WGRAD_ROWS") ? atoi(getenv("OPE_WGRAD_ROWS")) : 160;
+  auto splits_for = [](int64_t K, int cap) {
+    int s = (int)((K + rows_per_split - 1) / rows_per_split);
+    s = s >= 4 ? ((s + 3) / 4) * 4 : s;
+    return clampi(s, 1, cap);
+  };
   p->ns_agent = splits_for(p->R1, 256);
   p->ns_mixer = splits_for(p->TB, 64);
   p->n_loss_tiles = ope_cdiv(p->TB, 16);
