@@ -270,8 +270,38 @@ int launch_split_reduce(const SplitRed& a, hipStream_t st) {
 //   TAIL     [loss_sum, mask_count, qtot_sum, 0] summed over the per-tile partials
 // ---------------------------------------------------------------------------------------------------------
 __global__ void finalize_kernel(FinTable ft, const float* __restrict__ rsum, const float* __restrict__ theta,
-                                const float* __restrict__ loss_part, int n_loss_tiles, float* __restrict__ grad) {
-  if (blockIdx.x == gridDim.x - 1) {
+                                const float* __restrict__ loss_part, int n_loss_tiles, float* __restrict__ grad, int n_main) {
+  if ((int)blockIdx.x > n_main) {
+    // Column reductions of the LayerNorm-fed Linears (LNLIN_G / LNLIN_B: M = 14 .. 192 rows, two loads per row). With one
+    // thread per element these were the longest threads of the launch (hipcc emits load / wait / fma per row); here 16
+    // adjacent lanes share an element, lane `sub` takes rows sub, sub + 16, ... and the 16 partial sums meet by DPP
+    // (fixed order): 17.9 -> 15.2 us for the launch at 3s5z.
+    const int gid = ((int)blockIdx.x - n_main - 1) * 256 + (int)threadIdx.x;
+    const int sub = gid & 15;
+    int e = gid >> 4, s = -1, local = 0;
+#pragma unroll 1
+    for (int q = 0; q < ft.n; ++q) {
+      const int kind = ft.seg[q].kind;
+      if (kind != FIN_LNLIN_G && kind != FIN_LNLIN_B) continue;
+      if (s < 0) {
+        if (e < ft.seg[q].size) { s = q; local = e; }
+        else e -= ft.seg[q].size;
+      }
+    }
+    const bool live = s >= 0;
+    const FinSeg& F = ft.seg[live ? s : 0];
+    const int M = live ? F.M : 0, K = F.K;
+    const bool colsum = F.kind == FIN_LNLIN_B;
+    float acc = 0.f;
+    for (int i = sub; i < M; i += 16) {
+      const float w = theta[F.w + (int64_t)i * K + local];
+      acc = colsum ? fmaf(rsum[F.src_s + i], w, acc) : fmaf(w, rsum[F.src + (int64_t)i * K + local], acc);
+    }
+    acc = row16_sum(acc);
+    if (live && sub == 0) grad[F.begin + local] = acc;
+    return;
+  }
+  if ((int)blockIdx.x == n_main) {
     // extra block: [loss_sum, mask_count, qtot_sum, 0] = fixed-order strided sums over the per-tile partials, then a tree
     __shared__ float red[256][3];
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
@@ -308,20 +338,9 @@ __global__ void finalize_kernel(FinTable ft, const float* __restrict__ rsum, con
         out = rsum[F.src + local] * theta[F.gamma + k] + rsum[F.src_s + i] * theta[F.beta + k];
         break;
       }
-      case FIN_LNLIN_G: {
-        float acc = 0.f;
-#pragma unroll 16
-        for (int i = 0; i < F.M; ++i) acc = fmaf(theta[F.w + (int64_t)i * F.K + local], rsum[F.src + (int64_t)i * F.K + local], acc);
-        out = acc;
-        break;
-      }
-      case FIN_LNLIN_B: {
-        float acc = 0.f;
-#pragma unroll 16
-        for (int i = 0; i < F.M; ++i) acc = fmaf(rsum[F.src_s + i], theta[F.w + (int64_t)i * F.K + local], acc);
-        out = acc;
-        break;
-      }
+      case FIN_LNLIN_G:
+      case FIN_LNLIN_B:
+        return;                    // written by the reduction blocks above
       case FIN_TAIL:
         return;                    // written by the extra block
       default:
@@ -362,8 +381,13 @@ int launch_transpose4(const Transp4& a, hipStream_t st) {
 
 int launch_finalize(const FinTable& ft, const float* rsum, const float* theta, const float* loss_part, int n_loss_tiles,
                     float* grad, hipStream_t st) {
-  hipLaunchKernelGGL(finalize_kernel, dim3(ope_cdiv(ft.total, 256) + 1), dim3(256), 0, st, ft, rsum, theta, loss_part,
-                     n_loss_tiles, grad);
+  const int n_main = (int)ope_cdiv(ft.total, 256);
+  int64_t n_red = 0;
+  for (int q = 0; q < ft.n; ++q)
+    if (ft.seg[q].kind == FIN_LNLIN_G || ft.seg[q].kind == FIN_LNLIN_B) n_red += ft.seg[q].size;
+  // blocks [0, n_main): one thread per element; block n_main: the loss tail; the rest: 16 lanes per column reduction
+  hipLaunchKernelGGL(finalize_kernel, dim3(n_main + 1 + (int)ope_cdiv(n_red * 16, 256)), dim3(256), 0, st, ft, rsum, theta,
+                     loss_part, n_loss_tiles, grad, n_main);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   return OPE_OK;
 }
