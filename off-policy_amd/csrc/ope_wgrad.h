@@ -43,6 +43,7 @@ struct FinSeg {
 constexpr int kMaxFinSegs = 40;
 struct FinTable {
   FinSeg seg[kMaxFinSegs];
+  int begin[kMaxFinSegs];   // seg[q].begin again, INT_MAX beyond n: filled by launch_finalize (one scalar load burst finds a segment)
   int n;
   int64_t total;  // length of the flat gradient including the tail
 };

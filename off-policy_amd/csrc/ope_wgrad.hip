@@ -321,11 +321,13 @@ __global__ void finalize_kernel(FinTable ft, const float* __restrict__ rsum, con
   }
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= ft.total) return;
+  // (the segment table lives in kernel-argument memory: its starts are compared from one burst of scalar loads, and the
+  // record is copied whole, so that the thread pays two memory round trips -- record, then data -- instead of one per field)
   int s = 0;
-#pragma unroll 1
-  for (int q = 1; q < ft.n; ++q)
-    if (idx >= ft.seg[q].begin) s = q;
-  const FinSeg& F = ft.seg[s];
+#pragma unroll
+  for (int q = 1; q < kMaxFinSegs; ++q)
+    if (idx >= ft.begin[q]) s = q;
+  const FinSeg F = ft.seg[s];
   const int local = (int)(idx - F.begin);
   float out = 0.f;
   if (local < F.size) {
@@ -379,8 +381,11 @@ int launch_transpose4(const Transp4& a, hipStream_t st) {
   return OPE_OK;
 }
 
-int launch_finalize(const FinTable& ft, const float* rsum, const float* theta, const float* loss_part, int n_loss_tiles,
+int launch_finalize(const FinTable& ft0, const float* rsum, const float* theta, const float* loss_part, int n_loss_tiles,
                     float* grad, hipStream_t st) {
+  FinTable t = ft0;
+  for (int q = 0; q < kMaxFinSegs; ++q) t.begin[q] = q < t.n ? t.seg[q].begin : 0x7fffffff;
+  const FinTable& ft = t;
   const int n_main = (int)ope_cdiv(ft.total, 256);
   int64_t n_red = 0;
   for (int q = 0; q < ft.n; ++q)
