@@ -129,3 +129,21 @@ def test_runner_hook_redirects_reference_imports():
         hook.uninstall()
     for k, v in before.items():
         assert sys.modules.get(k) is v
+
+
+def test_every_environment_switch_is_documented():
+    """Kernels and host code read a few OPE_* environment switches (A/B knobs, defaults = measured best). Each must be named
+    in INTEGRATION.md / DESIGN.md so that no hidden mode exists."""
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = set()
+    for f in glob.glob(os.path.join(root, "off-policy_amd", "csrc", "*.h*")):
+        src = open(f).read()
+        names |= set(re.findall(r'getenv\("(OPE_[A-Z0-9_]+)"\)', src))
+        names |= set(re.findall(r'env_choice\("(OPE_[A-Z0-9_]+)"', src))
+    for f in glob.glob(os.path.join(root, "off-policy_amd", "**", "*.py"), recursive=True) + [os.path.join(root, "bench.py")]:
+        names |= set(re.findall(r'environ\.get\("(OPE_[A-Z0-9_]+)"', open(f).read()))
+    docs = open(os.path.join(root, "INTEGRATION.md")).read() + open(os.path.join(root, "DESIGN.md")).read()
+    assert names, "scan found nothing: pattern out of date"
+    missing = sorted(n for n in names if n not in docs)
+    assert not missing, "undocumented switches: %s" % missing
