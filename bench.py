@@ -117,6 +117,24 @@ def cpu_baseline(dims, batch, seconds):
                 batch, dims.name, seconds, ", ".join("%d: %.3f (%d steps)" % (t, res[t][0], res[t][1]) for t in thread_counts))}
 
 
+def dist_setup():
+    """(world, rank, device) of this process; one rank per GPU over RCCL. OPE_BENCH_SELFTEST=1 (plumbing check on a 1-GPU
+    box): every rank uses cuda:0 and the gloo backend, so the N > 1 branches of this script can be exercised without a node."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    selftest = os.environ.get("OPE_BENCH_SELFTEST", "0") == "1"
+    local_rank = 0 if selftest else int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if selftest:
+            torch.distributed.init_process_group("gloo")
+        else:
+            torch.distributed.init_process_group("nccl", device_id=dev)
+    return world, rank, dev
+
+
 def main():
     a = parse()
     if a.workload in ("maddpg_spread", "matd3_spread"):
@@ -125,15 +143,8 @@ def main():
         return main_rddpg(a)
     if a.batch is None:
         a.batch = 32
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world, rank, dev = dist_setup()
     assert world == a.gpus, "--gpus must equal WORLD_SIZE (launch with torch.distributed.run for N > 1)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.distributed.init_process_group("nccl", device_id=dev)
 
     from offpolicy_amd import _lib
     from offpolicy_amd.config import default_args
@@ -296,14 +307,8 @@ def main_ddpg(a):
     """MLP MADDPG / MATD3 on MPE simple_spread dimensions (BASELINE.json config 3): step = buffer.sample(B) +
     shared_train_policy_on_batch (critic + actor update) + soft target updates (runner/mlp/base_runner.py:188-218)."""
     import ctypes as C
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world, rank, dev = dist_setup()
     assert world == a.gpus
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        torch.distributed.init_process_group("nccl", device_id=dev)
     from offpolicy_amd import _lib
     from offpolicy_amd.config import default_args
     from offpolicy_amd.utils.synth import DIMS, policy_info_for
@@ -455,15 +460,8 @@ def main_rddpg(a):
     step = PrioritizedRecReplayBuffer.sample(B, beta) + shared_train_policy_on_batch (critic update + actor update every
     `actor_update_interval`-th step) + update_priorities + soft target updates (runner/rnn/base_runner.py:226-258)."""
     import ctypes as C
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world, rank, dev = dist_setup()
     assert world == a.gpus
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.distributed.init_process_group("nccl", device_id=dev)
     from offpolicy_amd import _lib
     from offpolicy_amd.config import default_args
     from offpolicy_amd.utils.synth import DIMS, policy_info_for
