@@ -14,7 +14,9 @@
 //     DPP adds per sum (no LDS), and the gates / gate adjoints of feature f evaluated once per quad lane;
 //   * the exchange is the step's 64-vector itself (h_t, or the three gate adjoints): every wave publishes its 16
 //     features to a parity-double-buffered LDS vector, ONE workgroup barrier per step, everybody reads its K-quarter;
-//   * wave 4 only loads (8 steps ahead, compiler-invisible asm loads, s_waitcnt vmcnt(N) counted in loads only) and
+//   * wave 4 only loads (8 steps ahead, compiler-invisible asm loads, s_waitcnt vmcnt(N) counted in loads only; the idiom
+//     relies on hipcc never copying a destination register between the load and its wait -- true in this low-pressure
+//     branch, check the ISA for v_mov of the `pre` registers after any change: DESIGN.md section 4) and
 //     hands one step per step to the compute waves through LDS; wave 5 only stores (the previous step's results, read
 //     back from LDS), so no wave's vmcnt mixes loads and stores and nothing waits on HBM inside the chain.
 // Fixed summation order (four partial sums per lane, pairwise; quad reduction commutative-symmetric), so all four lanes
