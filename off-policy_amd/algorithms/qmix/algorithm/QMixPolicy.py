@@ -37,7 +37,7 @@ class QMixPolicy(object):
     def __init__(self, config, policy_config, train=True):
         self.args = config["args"]
         self.device = torch.device(config["device"])
-        require_reference_architecture(self.args)
+        require_reference_architecture(self.args, allow_prev_act_inp=True)
         self.obs_space = policy_config["obs_space"]
         self.obs_dim = get_dim_from_space(self.obs_space)
         self.act_space = policy_config["act_space"]
@@ -47,7 +47,9 @@ class QMixPolicy(object):
         self.central_obs_dim = policy_config["cent_obs_dim"]
         self.discrete = True
         self.multidiscrete = False
-        self.q_network_input_dim = self.obs_dim
+        # previous action as an extra input of the (decentralised) agent network: QMixPolicy.py:29-33
+        self.prev_act_inp = bool(getattr(self.args, "prev_act_inp", False))
+        self.q_network_input_dim = self.obs_dim + self.act_dim if self.prev_act_inp else self.obs_dim
         self.q_network = AgentQFunction(self.args, self.q_network_input_dim, self.act_dim, self.device)
         if train:
             self.exploration = DecayThenFlatSchedule(self.args.epsilon_start, self.args.epsilon_finish,
@@ -55,6 +57,9 @@ class QMixPolicy(object):
 
     # -- q values --------------------------------------------------------------------------------------------
     def get_q_values(self, obs_batch, prev_action_batch, rnn_states, action_batch=None):
+        if self.prev_act_inp:      # QMixPolicy.py:54-58
+            obs_batch = torch.cat((torch.as_tensor(obs_batch, dtype=torch.float32, device=self.device),
+                                   torch.as_tensor(prev_action_batch, dtype=torch.float32, device=self.device)), dim=-1)
         q_batch, new_rnn_states = self.q_network(obs_batch, rnn_states)
         if action_batch is not None:
             action_batch = torch.as_tensor(action_batch).to(self.device)

@@ -52,7 +52,7 @@ class QMix(object):
     def __init__(self, args, num_agents, policies, policy_mapping_fn, device=torch.device("cuda:0"), episode_length=None,
                  vdn=False):
         self.args = args
-        require_reference_architecture(args)
+        require_reference_architecture(args, allow_prev_act_inp=not self._mlp)   # (the policies check their own support)
         self.use_popart = getattr(args, "use_popart", False)
         self.use_value_active_masks = getattr(args, "use_value_active_masks", False)
         self.use_per = args.use_per
@@ -76,7 +76,8 @@ class QMix(object):
             raise NotImplementedError("use_same_share_obs=False is not on the accelerated path")
         self.vdn = bool(vdn)
         policy = self.policies["policy_0"]
-        self._dims = _lib.Dims(num_agents, policy.act_dim, policy.obs_dim, policy.central_obs_dim, self.episode_length)
+        # the kernels see the network's input width: observation (+ previous one-hot action with prev_act_inp)
+        self._dims = _lib.Dims(num_agents, policy.act_dim, policy.q_network_input_dim, policy.central_obs_dim, self.episode_length)
 
         # ---- flat vectors: [agent | mixer], padded per tensor to 4 floats -------------------------------
         cfg = self._cfg(1)
@@ -177,6 +178,10 @@ class QMix(object):
         rew = self._to_device_layout(rew_b[pid], True)
         dones_env = self._to_device_layout(dones_env_b[pid], False)
         avail = self._to_device_layout(avail_b[pid], True) if (avail_b is not None and avail_b[pid] is not None) else None
+        if getattr(self.policies[pid], "prev_act_inp", False):
+            # qmix.py:123-124: the network input at step t is [obs_t | action taken at t-1], zeros at t = 0
+            prev = torch.cat((torch.zeros_like(acts[:1]), acts), dim=0)
+            obs = torch.cat((obs, prev), dim=-1).contiguous()
         return self._train_on_device_batch(obs, share, acts, rew, dones_env, avail, importance_weights, idxes)
 
     def _train_on_device_batch(self, obs, share, acts, rew, dones_env, avail, importance_weights, idxes):

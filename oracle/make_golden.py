@@ -116,6 +116,7 @@ def run_case(name, dims, n_episodes, inds, steps=3, argv=(), vdn=False, avail="o
     out["hp_per"], out["hp_nu"], out["hp_per_eps"] = np.int64(args.use_per), np.float64(args.per_nu), np.float64(args.per_eps)
     out["hp_tau"], out["hp_maxnorm"], out["hp_double_q"] = np.float64(args.tau), np.float64(args.max_grad_norm), np.int64(args.use_double_q)
     out["vdn"] = np.int64(vdn)
+    out["hp_prev_act_inp"] = np.int64(bool(getattr(args, "prev_act_inp", False)))
     losses, gnorms, qtots, prios = [], [], [], []
     for s in range(steps):
         batch = tuple({"policy_0": a} for a in sampled) + (per_weights, inds if per_weights is not None else None)
@@ -169,6 +170,8 @@ def main():
     # 6. an odd-sized case (nothing a multiple of 4) to exercise the unaligned kernel paths
     odd = EnvDims("odd", 3, 7, 18, 54, 5)
     run_case("qmix_odd", odd, n_episodes=6, inds=[5, 1, 1, 2, 0, 4, 3], avail="bernoulli")
+    # 7. previous action as a network input (config.py:81, QMixPolicy.py:29-33, qmix.py:123-124)
+    run_case("qmix_tiny_prevact", tiny, n_episodes=5, inds=[4, 2, 0, 1], avail="bernoulli", argv=["--prev_act_inp"])
 
 
 if __name__ == "__main__":

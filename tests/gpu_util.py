@@ -11,7 +11,8 @@ def make_args(g, **over):
     a = default_args(gamma=float(g["hp_gamma"]), lr=float(g["hp_lr"]), opti_eps=float(g["hp_eps"]),
                      use_huber_loss=bool(g["hp_huber"]), huber_delta=float(g["hp_delta"]), use_per=bool(g["hp_per"]),
                      per_nu=float(g["hp_nu"]), per_eps=float(g["hp_per_eps"]), tau=float(g["hp_tau"]),
-                     max_grad_norm=float(g["hp_maxnorm"]), use_double_q=bool(g["hp_double_q"]))
+                     max_grad_norm=float(g["hp_maxnorm"]), use_double_q=bool(g["hp_double_q"]),
+                     prev_act_inp=bool(g["hp_prev_act_inp"]) if "hp_prev_act_inp" in g else False)
     for k, v in over.items():
         setattr(a, k, v)
     return a

@@ -12,7 +12,7 @@ from golden_util import oracle_from, reference_store_from
 from gpu_util import build_from_fixture, batch_from
 
 pytestmark = pytest.mark.gpu
-CASES = ["qmix_tiny", "qmix_tiny_huber_per", "qmix_tiny_nodouble", "vdn_tiny", "qmix_odd", "qmix_3m_katA"]
+CASES = ["qmix_tiny", "qmix_tiny_huber_per", "qmix_tiny_nodouble", "vdn_tiny", "qmix_odd", "qmix_3m_katA", "qmix_tiny_prevact"]
 RTOL = 1e-4
 
 
@@ -152,6 +152,23 @@ def test_policy_forward_matches_oracle_single_step_and_sequence():
     acts, hn, gq = policy.get_actions(obs[0].cuda(), None, h0.cuda(), available_actions=np.ones((7, dims.act_dim)))
     assert acts.shape == (7, dims.act_dim) and np.allclose(acts.sum(-1), 1)
     assert np.array_equal(acts.argmax(-1), q_ref[0].argmax(-1).numpy())
+
+
+def test_policy_forward_with_previous_action_input():
+    """prev_act_inp (QMixPolicy.py:29-33, 54-58): the rollout forward feeds [obs | previous one-hot action] to the network."""
+    from oracle import qmix_oracle as O
+    g = load_golden("qmix_tiny_prevact")
+    dims, buf, policy, trainer = build_from_fixture(g)
+    assert policy.prev_act_inp and policy.q_network_input_dim == dims.obs_dim + dims.act_dim
+    P = {k: torch.as_tensor(v) for k, v in sub(g, "agent/").items()}
+    torch.manual_seed(4)
+    obs = torch.randn(4, 6, dims.obs_dim)
+    prev = torch.eye(dims.act_dim)[torch.randint(0, dims.act_dim, (4, 6))]
+    h0 = torch.randn(6, 64) * 0.5
+    q_ref, h_ref = O.agent_q_forward(P, torch.cat((obs, prev), dim=-1), h0)
+    q, h = policy.get_q_values(obs.numpy(), prev.numpy(), h0.cuda())          # numpy inputs, as the runner passes them
+    np.testing.assert_allclose(q.cpu().numpy(), q_ref.numpy(), rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(h.cpu().numpy(), h_ref.numpy(), rtol=1e-4, atol=2e-6)
 
 
 @pytest.mark.parametrize("workload,nb", [("3s5z", 32), ("MMM2", 8)])

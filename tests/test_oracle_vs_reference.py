@@ -27,7 +27,7 @@ def _build_reference(dims, argv=()):
     return args, policy, trainer, buf
 
 
-@pytest.mark.parametrize("argv", [(), ("--use_huber_loss", "--huber_delta", "0.5")])
+@pytest.mark.parametrize("argv", [(), ("--use_huber_loss", "--huber_delta", "0.5"), ("--prev_act_inp",)])
 def test_oracle_tracks_reference_on_fresh_random_problem(argv):
     from oracle import qmix_oracle as O
     from offpolicy_amd.utils.synth import EnvDims, synth_episodes, as_policy_dicts
@@ -46,7 +46,7 @@ def test_oracle_tracks_reference_on_fresh_random_problem(argv):
     ora_batch = O.sample_inds(store, inds)
     for a, b in zip(ref_batch, ora_batch):
         assert np.array_equal(a, b)
-    hp = O.HP(use_huber_loss=bool(args.use_huber_loss), huber_delta=float(args.huber_delta))
+    hp = O.HP(use_huber_loss=bool(args.use_huber_loss), huber_delta=float(args.huber_delta), prev_act_inp=bool(args.prev_act_inp))
     orc = O.QMixOracle({k: v.detach().numpy() for k, v in policy.q_network.named_parameters()},
                        {k: v.detach().numpy() for k, v in trainer.mixer.named_parameters()}, dims.n_agents, hp)
     for _ in range(2):
