@@ -137,3 +137,91 @@ def test_graphed_step_matches_eager_step():
             assert not torch.equal(before, policy.actor._flat)
     np.testing.assert_allclose(res["graph"], res["eager"], rtol=1e-5)
     np.testing.assert_allclose(res["eager"][0], g["critic_loss"][0], rtol=RTOL)
+
+
+def _flat_grads(mod, gvec, n_tail):
+    """Per-tensor normalised gradients out of a flat gradient vector; tail at n_tail = [loss_sum, count, ...]."""
+    g = gvec.cpu().numpy()
+    cnt = g[n_tail + 1]
+    return {name: g[off:off + int(np.prod(shape))].reshape(shape) / cnt for name, (shape, off) in mod.spec().items()}
+
+
+@pytest.mark.parametrize("td3,per", [(False, False), (True, True)])
+def test_config3_batch256_matches_oracle(td3, per):
+    """BASELINE config 3 AT ITS OWN SIZE: MADDPG-MLP (and MATD3-MLP + prioritized replay) on MPE simple_spread
+    (N=3, A=5, D=18, S=54), B=256 transitions: 768 actor rows / 256 and 768 critic rows per update, i.e. the row counts
+    the benchmark runs at (the reference fixtures stop at B=32). Two updates vs oracle/maddpg_oracle.py on the
+    reference's gumbel noise stream: losses, gradient norms, priorities, every gradient tensor of the first update and
+    the parameters after both. (reference: maddpg.py:90-249)"""
+    from oracle import maddpg_oracle as DO
+    from oracle.qmix_oracle import HP
+    from offpolicy_amd.config import default_args
+    from offpolicy_amd.utils.synth import DIMS, policy_info_for
+    from offpolicy_amd.utils.mlp_buffer import MlpReplayBuffer
+    from offpolicy_amd.algorithms.maddpg.algorithm.MADDPGPolicy import MADDPGPolicy
+    from offpolicy_amd.algorithms.matd3.algorithm.MATD3Policy import MATD3Policy
+    from offpolicy_amd.algorithms.maddpg.maddpg import MADDPG
+    from offpolicy_amd.algorithms.matd3.matd3 import MATD3
+    dims = DIMS["simple_spread"]
+    N, A, D, S = dims.n_agents, dims.act_dim, dims.obs_dim, dims.state_dim
+    B, cap = 256, 1024
+    args = default_args(use_per=per)
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    np.random.seed(1)
+    pinfo = policy_info_for(dims)
+    policy = (MATD3Policy if td3 else MADDPGPolicy)({"args": args, "device": dev}, pinfo["policy_0"])
+    trainer = (MATD3 if td3 else MADDPG)(args, N, {"policy_0": policy}, lambda x: "policy_0", device=dev)
+    rng = np.random.RandomState(21)
+    f = np.float32
+    dones_env = (rng.random_sample((cap, 1)) < 0.1).astype(f)
+    avail = (rng.random_sample((cap, N, A)) < 0.8).astype(f)
+    avail[..., 0] = 1.0
+    navail = (rng.random_sample((cap, N, A)) < 0.8).astype(f)
+    navail[..., 0] = 1.0
+    tr = dict(obs=rng.standard_normal((cap, N, D)).astype(f), share_obs=rng.standard_normal((cap, S)).astype(f),
+              acts=np.eye(A, dtype=f)[rng.randint(0, A, size=(cap, N))], rewards=np.repeat(rng.standard_normal((cap, 1, 1)).astype(f), N, 1),
+              next_obs=rng.standard_normal((cap, N, D)).astype(f), next_share_obs=rng.standard_normal((cap, S)).astype(f),
+              dones=np.repeat(dones_env[:, None], N, 1), dones_env=dones_env,
+              valid_transition=(rng.random_sample((cap, N, 1)) < 0.9).astype(f), avail_acts=avail, next_avail_acts=navail)
+    buf = MlpReplayBuffer(pinfo, {"policy_0": list(range(N))}, cap, True, True, False, device=dev)
+    buf.insert(cap, *[{"policy_0": tr[k]} for k in T_KEYS])
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    for mod in (policy.critic, policy.actor):      # away from the targets and the gain-0.01 output layers
+        mod._flat.add_((0.05 * torch.randn(mod._flat.numel(), generator=gen)).to(dev))
+    torch.cuda.synchronize()
+    heads = lambda c: (c._head_w.cpu().numpy().reshape(-1, 64).copy(), c._head_b.cpu().numpy().reshape(-1).copy())
+    orc = DO.MaddpgOracle(params_of(policy.actor), params_of(policy.critic), heads(policy.critic), params_of(policy.target_actor),
+                          params_of(policy.target_critic), heads(policy.target_critic), N, HP(use_per=per), td3=td3)
+    for st in range(2):
+        inds = np.random.RandomState(30 + st).choice(cap, B)
+        w = np.random.RandomState(40 + st).uniform(0.4, 1.0, size=B).astype(f) if per else None
+        s = buf.policy_buffers["policy_0"].sample_inds(inds)
+        np_batch = tuple(a.cpu().numpy() if torch.is_tensor(a) else np.asarray(a) for a in s)
+        torch.manual_seed(1000 + st)
+        info, prio, _ = trainer.shared_train_policy_on_batch("policy_0", tuple({"policy_0": a} for a in s) + (w, inds if per else None))
+        policy.soft_target_updates()
+        torch.cuda.synchronize()
+        torch.manual_seed(1000 + st)
+        u_t = torch.FloatTensor(N * B, A).uniform_() if td3 else None
+        u_a = torch.FloatTensor(N * B, A).uniform_()
+        ref = orc.train_step(np_batch, u_t, u_a, weights=w)
+        np.testing.assert_allclose(float(info["critic_loss"]), ref["critic_loss"], rtol=RTOL)
+        np.testing.assert_allclose(float(info["critic_grad_norm"]), ref["critic_grad_norm"], rtol=RTOL)
+        np.testing.assert_allclose(float(info["actor_loss"]), ref["actor_loss"], rtol=5e-4, atol=2e-6)
+        np.testing.assert_allclose(float(info["actor_grad_norm"]), ref["actor_grad_norm"], rtol=5e-4)
+        if per:
+            np.testing.assert_allclose(np.asarray(prio), ref["priorities"], rtol=RTOL)
+        if st == 0:
+            gc, ga, _ = trainer._grads[B]
+            for mod, gvec, rg in ((policy.critic, gc, ref["critic_grads"]), (policy.actor, ga, ref["actor_grads"])):
+                got = _flat_grads(mod, gvec, mod.padded_numel)
+                for k, r in rg.items():
+                    if k not in got:
+                        continue
+                    scale = max(np.abs(r).max(), 1e-9)
+                    np.testing.assert_allclose(got[k], r, rtol=0, atol=2e-3 * scale + 1e-9, err_msg=k)
+    for mod, refp in ((policy.critic, orc.critic), (policy.actor, orc.actor), (policy.target_critic, orc.critic_tgt),
+                      (policy.target_actor, orc.actor_tgt)):
+        for k, v in params_of(mod).items():
+            np.testing.assert_allclose(v, refp[k].numpy(), rtol=0, atol=3e-5, err_msg=k)

@@ -1,6 +1,7 @@
 """-m gpu: recurrent MADDPG / MATD3 through the C-ABI vs the reference's frozen outputs (same gumbel noise stream),
 vs the oracle's per-tensor gradients, and through the additivity of the un-normalised gradient over episodes."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -237,3 +238,79 @@ def test_action_gradient_kernel_forms_agree(monkeypatch):
     assert scale > 0
     for form in ("thread", "mfma"):
         np.testing.assert_allclose(grads[form], grads["wave"], rtol=0, atol=3e-6 * scale, err_msg=form)
+
+
+def _assert_grads_close(got, ref, what):
+    """Full-size comparison rule (same as the QMIX full-size test): a handful of ReLU / argmax / gumbel decisions per step
+    sit within float rounding of their threshold and may fall on the other side on the GPU, so: >= 99.5 % of every
+    tensor within 2e-3 of the tensor's max magnitude and every element within 2e-2 of it."""
+    for k, r in ref.items():
+        scale = max(np.abs(r).max(), 1e-9)
+        d = np.abs(got[k] - r) / scale
+        assert d.max() <= 2e-2, (what, k, float(d.max()))
+        assert (d <= 2e-3).mean() >= 0.995, (what, k, float((d <= 2e-3).mean()))
+
+
+@pytest.mark.parametrize("td3,B", [(True, 128), (False, 112)])
+def test_full_size_mmm2_matches_oracle_one_update(td3, B):
+    """BASELINE config 5 AT ITS OWN SIZE (MATD3-RNN + prioritized replay, MMM2: N=10, A=18, D=370, S=322, T=180, B=128;
+    and the MADDPG form at B=112): one critic update + one actor update against oracle/rmaddpg_oracle.py, on the
+    reference's gumbel noise stream. At this size the engine takes the kernel variants that no small fixture reaches:
+    trunk_fwd3<2,24> / trunk_fwd2<2,2> (D = 502 critic input, >= 65 536 rows), gru_fwd1 / gru_bwd1 (N*B > 1 024 rows),
+    gru_cell_fwd / gru_cell_bwd at T*N*B = 230 400 rows, head_bwd_dense, action_grad_mfma, wgrad<2>. Compared: losses,
+    pre-clip gradient norms, per-episode priorities, EVERY gradient tensor of critic and actor, and the parameters after
+    the Adam steps. (reference: r_maddpg.py:114-331)"""
+    from oracle import rmaddpg_oracle as RO
+    from oracle.qmix_oracle import HP
+    from offpolicy_amd.config import default_args
+    from offpolicy_amd.utils.synth import DIMS, synth_episodes
+    dims = DIMS["MMM2"]
+    T, N, A = dims.episode_length, dims.n_agents, dims.act_dim
+    args = default_args(use_per=True)
+    _, buf, policy, trainer = build(None, dims=dims, args=args, td3=td3, cap=B)
+    ep = synth_episodes(np.random.RandomState(11), B, dims, avail="bernoulli", runner_padding=True)
+    buf.insert(B, *[{"policy_0": ep[k]} for k in EP_KEYS])
+    # move the live nets away from their targets and from the gain-0.01 output layers so that TD errors, the critic's
+    # action gradient and the actor gradient are all well away from zero
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    for mod in (policy.critic, policy.actor):
+        mod._flat.add_((0.03 * torch.randn(mod._flat.numel(), generator=gen)).to(mod._flat.device))
+    torch.cuda.synchronize()
+    inds = np.random.RandomState(4).permutation(B)
+    w = np.random.RandomState(5).uniform(0.4, 1.0, size=B).astype(np.float32)
+    s = buf.policy_buffers["policy_0"].sample_inds(inds)
+    batch = tuple({"policy_0": a} for a in s) + (w, inds)
+    np_batch = tuple(a.cpu().numpy() if torch.is_tensor(a) else np.asarray(a) for a in s)
+    orc = RO.RMaddpgOracle(params_of(policy.actor), params_of(policy.critic), params_of(policy.target_actor), params_of(policy.target_critic),
+                           N, HP(use_per=True), td3=td3, actor_update_interval=1)
+    # GPU
+    torch.manual_seed(1000)
+    info, prio, _ = trainer.shared_train_policy_on_batch("policy_0", batch)
+    torch.cuda.synchronize()
+    assert bool(info["update_actor"])
+    gc, ga, _ = trainer._grads[B]
+    got_c, got_closs = _flat_grads(policy.critic, gc)
+    got_a, got_aloss = _flat_grads(policy.actor, ga)
+    # oracle, same noise stream (rnoise_for's order: target noise first, then actor noise)
+    torch.manual_seed(1000)
+    u_t = torch.FloatTensor(T + 1, N * B, A).uniform_() if td3 else None
+    u_a = torch.FloatTensor(T, N * B, A).uniform_()
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    ref = orc.train_step(np_batch, u_t, u_a, weights=w, soft_update=False)
+    np.testing.assert_allclose(float(info["critic_loss"]), ref["critic_loss"], rtol=RTOL)
+    np.testing.assert_allclose(float(info["critic_grad_norm"]), ref["critic_grad_norm"], rtol=RTOL)
+    np.testing.assert_allclose(float(info["actor_loss"]), ref["actor_loss"], rtol=1e-3, atol=3e-6)
+    np.testing.assert_allclose(float(info["actor_grad_norm"]), ref["actor_grad_norm"], rtol=1e-3)
+    np.testing.assert_allclose(np.asarray(prio), ref["priorities"], rtol=RTOL)
+    np.testing.assert_allclose(got_closs, ref["critic_loss"], rtol=RTOL)
+    _assert_grads_close(got_c, ref["critic_grads"], "critic")
+    _assert_grads_close(got_a, ref["actor_grads"], "actor")
+    for k in got_c:
+        if ".fc_h." in k:
+            assert not got_c[k].any()
+    lr = args.lr
+    for mod, refp in ((policy.critic, orc.critic), (policy.actor, orc.actor)):
+        for k, v in params_of(mod).items():
+            d = np.abs(v - refp[k].numpy())
+            assert d.max() <= lr * 1.01, k
+            assert (d <= 2e-5).mean() >= 0.995, (k, float((d <= 2e-5).mean()))

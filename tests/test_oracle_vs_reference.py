@@ -100,3 +100,69 @@ def test_ring_bookkeeping_matches_reference_buffer():
         assert np.array_equal(got, want)
         assert ring.filled_i == buf.policy_buffers["policy_0"].filled_i
         assert ring.current_i == buf.policy_buffers["policy_0"].current_i
+
+
+def test_timed_oracle_path_runs_at_reference_speed():
+    """bench.py's cpu_baseline times oracle.qmix_oracle under `reference_speed_ops()` + `fused_gru=True` because the
+    GPU box has no /root/reference. That timed path must (a) give the values of the explicit-formula oracle and (b) run
+    at the real reference's speed: >= 0.9x its steps/s here, interleaved best-of-5, same data, same indices, 1 thread
+    (the reference's default n_training_threads, config.py:17). SMAC 3m dimensions, B=32."""
+    import time
+    from oracle import qmix_oracle as O
+    from offpolicy_amd.utils.synth import DIMS, synth_episodes, as_policy_dicts
+    dims = DIMS["3m"]
+    n_ep, B = 64, 32
+    load_reference()
+    from gym.spaces import Discrete
+    from offpolicy.algorithms.qmix.algorithm.QMixPolicy import QMixPolicy
+    from offpolicy.algorithms.qmix.qmix import QMix
+    from offpolicy.utils.rec_buffer import RecReplayBuffer
+    args = reference_args(())
+    torch.manual_seed(7)
+    np.random.seed(7)
+    pinfo = {"policy_0": {"cent_obs_dim": dims.state_dim, "cent_act_dim": dims.act_dim * dims.n_agents,
+                          "obs_space": [dims.obs_dim], "share_obs_space": [dims.state_dim], "act_space": Discrete(dims.act_dim)}}
+    policy = QMixPolicy({"args": args, "device": torch.device("cpu")}, pinfo["policy_0"])
+    trainer = QMix(args, dims.n_agents, {"policy_0": policy}, lambda a: "policy_0", device=torch.device("cpu"),
+                   episode_length=dims.episode_length)
+    buf = RecReplayBuffer(pinfo, {"policy_0": list(range(dims.n_agents))}, n_ep, dims.episode_length, True, True, False)
+    d = as_policy_dicts(synth_episodes(np.random.RandomState(0), n_ep, dims, avail="bernoulli"))
+    buf.insert(n_ep, d["obs"], d["share_obs"], d["acts"], d["rewards"], d["dones"], d["dones_env"], d["avail_acts"])
+    pb = buf.policy_buffers["policy_0"]
+    store = dict(obs=pb.obs, share_obs=pb.share_obs, acts=pb.acts, rewards=pb.rewards, dones=pb.dones, dones_env=pb.dones_env,
+                 avail_acts=pb.avail_acts)
+    P = ({k: v.detach().numpy().copy() for k, v in policy.q_network.named_parameters()},
+         {k: v.detach().numpy().copy() for k, v in trainer.mixer.named_parameters()})
+    slow, fast = O.QMixOracle(P[0], P[1], dims.n_agents, O.HP()), O.QMixOracle(P[0], P[1], dims.n_agents, O.HP())
+    inds = np.random.RandomState(1).choice(n_ep, B)
+    a = slow.train_step(O.sample_inds(store, inds))
+    with O.reference_speed_ops():
+        b = fast.train_step(O.sample_inds(store, inds), fused_gru=True)
+    np.testing.assert_allclose(b["loss"], a["loss"], rtol=1e-5)
+    np.testing.assert_allclose(b["grad_norm"], a["grad_norm"], rtol=1e-5)
+    for k in slow.agent:
+        np.testing.assert_allclose(fast.agent[k].numpy(), slow.agent[k].numpy(), atol=1e-6, err_msg=k)
+
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        rng = np.random.RandomState(2)
+
+        def ref_step():
+            s = pb.sample_inds(rng.choice(n_ep, B))
+            trainer.train_policy_on_batch(tuple({"policy_0": x} for x in s) + (None, None))
+            trainer.soft_target_updates()
+
+        def orc_step():
+            with O.reference_speed_ops():
+                fast.train_step(O.sample_inds(store, rng.choice(n_ep, B)), fused_gru=True, soft_update=True)
+        best = {"ref": 1e9, "orc": 1e9}
+        ref_step(); orc_step()
+        for _ in range(5):
+            for name, f in (("ref", ref_step), ("orc", orc_step)):
+                t0 = time.perf_counter()
+                f(); f()
+                best[name] = min(best[name], (time.perf_counter() - t0) / 2)
+    finally:
+        torch.set_num_threads(threads)
+    assert best["ref"] / best["orc"] >= 0.9, "timed oracle path %.1f ms/step vs reference %.1f ms/step" % (1e3 * best["orc"], 1e3 * best["ref"])
