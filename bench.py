@@ -37,7 +37,10 @@ def parse():
                     help="QMIX-RNN on a SMAC map's dimensions (default 3s5z = the headline config), or MLP MADDPG/MATD3 on MPE simple_spread")
     ap.add_argument("--batch", type=int, default=None, help="samples per training step on ONE GPU (weak) / in total (strong); "
                     "default 32 episodes (QMIX) or 256 transitions (MADDPG)")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="N > 1: what `value` reports. Default strong = BASELINE.json's multi-GPU configs (ONE batch of B samples "
+                         "sharded over the N GPUs, B/N per GPU); the weak-scaling throughput (B per GPU) is measured in the same run "
+                         "and reported beside it as `weak_scaling`. --scaling weak swaps the two.")
     ap.add_argument("--episodes", type=int, default=256, help="synthetic episodes resident in the replay store")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="QMIX workloads: replay the training kernels of a step as one captured HIP graph")
@@ -51,13 +54,16 @@ def parse():
     return ap.parse_args()
 
 
-def gather_traffic(workload, batch):
+def gather_traffic(workload, batch, episodes=256):
     """HBM bytes per gather launch from the committed PMC passes (profiles/gather_traffic.json: rocprofv3 --pmc FETCH_SIZE and
     --pmc WRITE_SIZE in separate runs of this same command, corrected as MI355X_MICROARCH.md prescribes); None if that
-    configuration was not measured. PMC collection cannot run inside the timed bench, hence the file."""
+    configuration was not measured. PMC collection cannot run inside the timed bench, hence the file. Entries are keyed
+    "workload:batch:episodes" (store size matters: a 256-episode store fits the 256 MiB Infinity Cache, 5000 do not), with
+    the round-1 "workload:batch" key meaning 256 episodes."""
     try:
         with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "gather_traffic.json")) as f:
-            e = json.load(f)["entries"].get("%s:%d" % (workload, batch))
+            ent = json.load(f)["entries"]
+        e = ent.get("%s:%d:%d" % (workload, batch, episodes)) or (ent.get("%s:%d" % (workload, batch)) if episodes == 256 else None)
         return int(e["traffic_bytes"]) if e else None
     except (OSError, ValueError, KeyError):
         return None
@@ -137,11 +143,70 @@ def dist_setup():
             torch.distributed.init_process_group("gloo")
         else:
             torch.distributed.init_process_group("nccl", device_id=dev)
+        from offpolicy_amd import dist as opdist
+        opdist.setup_fast_allreduce(dev)      # one-shot xGMI all-reduce when it verifies against RCCL, else RCCL
     return world, rank, dev
+
+
+def _spawned_rank(rank, world, port, argv):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.argv = [sys.argv[0]] + list(argv)
+    main()
+
+
+def self_spawn(a):
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): start the N ranks ourselves, one per GPU."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_spawned_rank, args=(a.gpus, port, sys.argv[1:]), nprocs=a.gpus, join=True)
+
+
+def timed_steps(one_step, steps, warmup, world, dev):
+    """W untimed warm-up steps, then EXACTLY K steps bracketed by barrier + synchronize on both sides; seconds = MAX over ranks."""
+    for _ in range(warmup):
+        one_step(None)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    info = None
+    for i in range(steps):
+        info = one_step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tt[0])
+    return elapsed, info
+
+
+def scaling_legs(a, batch, world):
+    """[(name, local_batch, global_batch)]: the leg `value` is quoted on first. One GPU: a single leg."""
+    if world == 1:
+        return [("weak", batch, batch)]
+    assert batch % world == 0, "--batch must be a multiple of --gpus for the strong-scaling leg"
+    legs = [("strong", batch // world, batch), ("weak", batch, batch * world)]
+    return legs[::-1] if a.scaling == "weak" else legs
+
+
+def allreduce_name():
+    from offpolicy_amd import dist as opdist
+    return opdist.allreduce_backend()
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_spawn(a)
     if a.workload in ("maddpg_spread", "matd3_spread"):
         return main_ddpg(a)
     if a.workload.startswith("rma"):
@@ -149,7 +214,7 @@ def main():
     if a.batch is None:
         a.batch = 32
     world, rank, dev = dist_setup()
-    assert world == a.gpus, "--gpus must equal WORLD_SIZE (launch with torch.distributed.run for N > 1)"
+    assert world == a.gpus, "--gpus must equal WORLD_SIZE"
 
     from offpolicy_amd import _lib
     from offpolicy_amd.config import default_args
@@ -161,11 +226,6 @@ def main():
 
     dims = DIMS[a.workload]
     args = default_args()
-    if a.scaling == "weak":
-        local_batch, global_batch = a.batch, a.batch * world
-    else:
-        assert a.batch % world == 0
-        local_batch, global_batch = a.batch // world, a.batch
     torch.manual_seed(1)                 # identical initial weights on every rank
     np.random.seed(1)
     pinfo = policy_info_for(dims)
@@ -175,74 +235,76 @@ def main():
         trainer = QMix(args, dims.n_agents, {"policy_0": policy}, lambda x: "policy_0", device=dev, episode_length=dims.episode_length)
     trainer.fuse_soft_update = True      # Polyak inside the Adam kernel; soft_target_updates() below then skips
     buf = RecReplayBuffer(pinfo, {"policy_0": list(range(dims.n_agents))}, a.episodes, dims.episode_length, True, True, device=dev)
-    fill_buffer(buf, dims, a.episodes, np.random.RandomState(100 + rank))   # every rank holds its own replay shard
-    np.random.seed(1000 + rank)          # ranks draw different episodes (data parallel)
+    # every rank holds the SAME replay store (a full replica) and draws the same global index list
+    # (same seed); rank r trains on its contiguous share of it (offpolicy_amd.dist.shard_indices)
+    fill_buffer(buf, dims, a.episodes, np.random.RandomState(100))
     pbuf = buf.policy_buffers["policy_0"]
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    from offpolicy_amd import dist as opdist
 
-    # Eager launches by default: the host enqueues a step in ~150 us against 0.46 ms of kernels, so it runs ahead and a
-    # HIP-graph replay of the 16 training kernels (--graph; QMix.make_graphed_step) is 1-4 % SLOWER here (measured).
-    graphed = trainer.make_graphed_step(buf, local_batch, gather_in_graph=False) if (a.graph and world == 1) else None
+    results = []
+    for leg, local_batch, global_batch in scaling_legs(a, a.batch, world):
+        np.random.seed(1000)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+        # Eager launches by default: the host enqueues a step in ~150 us against 0.4 ms of kernels, so it runs ahead and a
+        # HIP-graph replay of the training kernels (--graph; QMix.make_graphed_step) is 1-4 % SLOWER here (measured).
+        graphed = trainer.make_graphed_step(buf, local_batch, gather_in_graph=False) if (a.graph and world == 1) else None
 
-    def one_step(i=None):
-        inds = np.random.choice(len(buf), local_batch)
-        if graphed is not None:
-            return graphed(inds, timing_events=ev[i] if i is not None else None)
-        s = pbuf.sample_inds(inds, timing_events=ev[i] if i is not None else None)   # ope_store_gather, current stream
-        batch = tuple({"policy_0": x} for x in s) + (None, None)
-        info, _, _ = trainer.train_policy_on_batch(batch)
-        trainer.soft_target_updates()
-        return info
-
-    for _ in range(a.warmup):
-        one_step()
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        info = one_step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(tt[0])
-    gather_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
-    loss = float(info["loss"])
-    assert np.isfinite(loss), "training diverged"
+        def one_step(i=None):
+            inds = opdist.shard_indices(np.random.choice(len(buf), global_batch), rank, world)
+            if graphed is not None:
+                return graphed(inds, timing_events=ev[i] if i is not None else None)
+            s = pbuf.sample_inds(inds, timing_events=ev[i] if i is not None else None)   # ope_store_gather, current stream
+            batch = tuple({"policy_0": x} for x in s) + (None, None)
+            info, _, _ = trainer.train_policy_on_batch(batch)
+            trainer.soft_target_updates()
+            return info
+        elapsed, info = timed_steps(one_step, a.steps, a.warmup, world, dev)
+        gather_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
+        loss = float(info["loss"])
+        assert np.isfinite(loss), "training diverged"
+        results.append(dict(leg=leg, local_batch=local_batch, global_batch=global_batch, elapsed=elapsed, gather_ms=gather_ms, loss=loss,
+                            graphed=graphed is not None))
 
     if rank == 0:
+        r0 = results[0]
         ep_bytes = int(_lib.lib.ope_episode_bytes(C.byref(pbuf.dims)))
-        algo_bytes = 2.0 * local_batch * ep_bytes            # read from the store + write of the batch
-        achieved = algo_bytes / (gather_ms * 1e-3) / 1e9
-        steps_per_s = a.steps / elapsed
-        value = steps_per_s * (global_batch / float(a.batch))
+        algo_bytes = 2.0 * r0["local_batch"] * ep_bytes            # read from the store + write of the batch
+        achieved = algo_bytes / (r0["gather_ms"] * 1e-3) / 1e9
+        steps_per_s = a.steps / r0["elapsed"]
+        value = steps_per_s * (r0["global_batch"] / float(a.batch))
+        store_gb = a.episodes * ep_bytes / 1e9
         out = {
             "metric": "training steps/sec (batch=%d) QMIX-RNN %s" % (a.batch, a.workload),
             "value": round(value, 3), "unit": "training steps/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(1e3 * elapsed / a.steps, 4), "higher_is_better": True, "scaling": a.scaling,
+            "ms_per_step": round(1e3 * r0["elapsed"] / a.steps, 4), "higher_is_better": True, "scaling": r0["leg"],
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "QMIX-RNN SMAC %s (N=%d A=%d D=%d S=%d T=%d), replay filled with %d synthetic episodes, "
-                                   "step = sample + train_policy_on_batch + soft target update" % (
-                                       a.workload, dims.n_agents, dims.act_dim, dims.obs_dim, dims.state_dim, dims.episode_length, a.episodes),
-                       "batch_per_gpu": local_batch, "global_batch": global_batch, "parallelism": "dp%d" % world,
-                       "launch": "eager gather + HIP graph of the training kernels" if graphed is not None else "eager",
-                       "optimizer_steps_per_sec": round(steps_per_s, 3), "final_loss": round(loss, 6)},
+            "config": {"workload": "QMIX-RNN SMAC %s (N=%d A=%d D=%d S=%d T=%d), replay filled with %d synthetic episodes (%.2f GB "
+                                   "resident in HBM), step = sample + train_policy_on_batch + soft target update" % (
+                                       a.workload, dims.n_agents, dims.act_dim, dims.obs_dim, dims.state_dim, dims.episode_length,
+                                       a.episodes, store_gb),
+                       "batch_per_gpu": r0["local_batch"], "global_batch": r0["global_batch"], "parallelism": "dp%d" % world,
+                       "launch": "eager gather + HIP graph of the training kernels" if r0["graphed"] else "eager",
+                       "allreduce": allreduce_name() if world > 1 else None,
+                       "optimizer_steps_per_sec": round(steps_per_s, 3), "final_loss": round(r0["loss"], 6)},
             "roofline": {"kernel": "episode_copy_kernel<gather> (ope_store_gather)", "bound": "hbm", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": gather_traffic(a.workload, local_batch),
-                         "algorithmic_bytes_per_launch": int(algo_bytes), "avg_launch_ms": round(gather_ms, 5),
+                         "traffic": gather_traffic(a.workload, r0["local_batch"], a.episodes),
+                         "algorithmic_bytes_per_launch": int(algo_bytes), "avg_launch_ms": round(r0["gather_ms"], 5),
+                         "store_bytes": int(a.episodes * ep_bytes),
+                         "hbm_resident": bool(a.episodes * ep_bytes > 4 * 256 * 2 ** 20),
                          "timing": "HIP events on the launch stream recorded immediately around each gather launch in the timed region",
                          "traffic_source": "profiles/gather_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)"},
         }
+        if len(results) > 1:
+            r1 = results[1]
+            sps1 = a.steps / r1["elapsed"]
+            out["%s_scaling" % r1["leg"]] = {
+                "value": round(sps1 * (r1["global_batch"] / float(a.batch)), 3), "unit": "batch-%d training steps/sec (episodes/s / %d)" % (a.batch, a.batch),
+                "batch_per_gpu": r1["local_batch"], "global_batch": r1["global_batch"], "ms_per_step": round(1e3 * r1["elapsed"] / a.steps, 4),
+                "optimizer_steps_per_sec": round(sps1, 3), "steps": a.steps, "warmup": a.warmup}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dims, a.batch, a.cpu_seconds, min(a.episodes, 256))
-            out["config"]["speedup_vs_cpu_port"] = round(value / out["cpu_baseline"]["value"], 1)
+            out["config"]["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
@@ -317,6 +379,7 @@ def main_ddpg(a):
     world, rank, dev = dist_setup()
     assert world == a.gpus
     from offpolicy_amd import _lib
+    from offpolicy_amd import dist as opdist
     from offpolicy_amd.config import default_args
     from offpolicy_amd.utils.synth import DIMS, policy_info_for
     from offpolicy_amd.utils.mlp_buffer import MlpReplayBuffer
@@ -327,8 +390,6 @@ def main_ddpg(a):
     td3 = a.workload == "matd3_spread"
     dims = DIMS["simple_spread"]
     batch = a.batch or 256
-    local_batch = batch if a.scaling == "weak" else batch // world
-    global_batch = batch * world if a.scaling == "weak" else batch
     args = default_args()
     torch.manual_seed(1)
     np.random.seed(1)
@@ -338,78 +399,71 @@ def main_ddpg(a):
     trainer.device_noise = not a.host_noise
     cap = 16384
     buf = MlpReplayBuffer(pinfo, {"policy_0": list(range(dims.n_agents))}, cap, True, True, False, device=dev)
-    tr = ddpg_transitions(np.random.RandomState(100 + rank), cap, dims)
+    tr = ddpg_transitions(np.random.RandomState(100), cap, dims)       # identical replica on every rank
     buf.insert(cap, *[{"policy_0": tr[k]} for k in DDPG_KEYS])
-    np.random.seed(1000 + rank)
-    torch.manual_seed(1000 + rank)
     pbuf = buf.policy_buffers["policy_0"]
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
-
     use_graph = world == 1 and not a.no_graph and not a.host_noise
-    graphed = trainer.make_graphed_step(buf, local_batch) if use_graph else None
+    results = []
+    for leg, local_batch, global_batch in scaling_legs(a, batch, world):
+        np.random.seed(1000)
+        torch.manual_seed(1000 + rank)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+        graphed = trainer.make_graphed_step(buf, local_batch) if use_graph else None
 
-    def one_step(i=None):
-        inds = np.random.choice(len(buf), local_batch)
-        if graphed is not None:
-            return graphed(inds)           # gather + critic update + actor update + soft target updates: one graph launch
-        s = pbuf.sample_inds(inds, timing_events=ev[i] if i is not None else None)
-        info, _, _ = trainer.shared_train_policy_on_batch("policy_0", tuple({"policy_0": x} for x in s) + (None, None))
-        policy.soft_target_updates()
-        return info
-
-    for _ in range(a.warmup):
-        one_step()
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        info = one_step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(tt[0])
-    if graphed is not None:    # the gather inside the graph cannot carry events: time the same launch on its own afterwards
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(50)]
-        for e in ev:
-            pbuf.sample_inds(np.random.choice(len(buf), local_batch), timing_events=e)
-        torch.cuda.synchronize()
-    gather_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
-    assert np.isfinite(float(info["critic_loss"]))
+        def one_step(i=None):
+            inds = opdist.shard_indices(np.random.choice(len(buf), global_batch), rank, world)
+            if graphed is not None:
+                return graphed(inds)           # gather + critic update + actor update + soft target updates: one graph launch
+            s_ = pbuf.sample_inds(inds, timing_events=ev[i] if i is not None else None)
+            info, _, _ = trainer.shared_train_policy_on_batch("policy_0", tuple({"policy_0": x} for x in s_) + (None, None))
+            policy.soft_target_updates()
+            return info
+        elapsed, info = timed_steps(one_step, a.steps, a.warmup, world, dev)
+        if graphed is not None:    # the gather inside the graph cannot carry events: time the same launch on its own afterwards
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(50)]
+            for e in ev:
+                pbuf.sample_inds(np.random.choice(len(buf), local_batch), timing_events=e)
+            torch.cuda.synchronize()
+        gather_ms = float(np.mean([s_.elapsed_time(e) for s_, e in ev]))
+        assert np.isfinite(float(info["critic_loss"]))
+        results.append(dict(leg=leg, local_batch=local_batch, global_batch=global_batch, elapsed=elapsed, gather_ms=gather_ms))
     if rank == 0:
+        r0 = results[0]
         # algorithmic bytes of the transition gather: every field of a transition once in, once out (964 B/transition)
         N, A, D, S = dims.n_agents, dims.act_dim, dims.obs_dim, dims.state_dim
         tr_bytes = 4 * (2 * N * D + 2 * S + N * A + 2 * N * A + N + N + 1 + N)
-        algo = 2.0 * local_batch * tr_bytes
-        steps_per_s = a.steps / elapsed
-        value = steps_per_s * (global_batch / float(batch))
+        algo = 2.0 * r0["local_batch"] * tr_bytes
+        steps_per_s = a.steps / r0["elapsed"]
+        value = steps_per_s * (r0["global_batch"] / float(batch))
         out = {"metric": "training steps/sec (batch=%d) %s-MLP simple_spread" % (batch, "MATD3" if td3 else "MADDPG"),
                "value": round(value, 2), "unit": "training steps/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-               "ms_per_step": round(1e3 * elapsed / a.steps, 4), "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
+               "ms_per_step": round(1e3 * r0["elapsed"] / a.steps, 4), "higher_is_better": True, "scaling": r0["leg"], "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
                "config": {"workload": "%s-MLP MPE simple_spread (N=%d A=%d D=%d S=%d), replay filled with %d synthetic transitions, "
                                       "step = sample + critic update + actor update + soft target updates; reference semantics "
                                       "(frozen critic heads A-4, actor updated every call A-5); gumbel noise drawn on the %s; %s" % (
                                           "MATD3" if td3 else "MADDPG", N, A, D, S, cap, "host (reference stream)" if a.host_noise else "device",
                                           "whole update replayed as one captured HIP graph" if use_graph else "kernels launched one by one"),
-                          "batch_per_gpu": local_batch, "global_batch": global_batch, "parallelism": "dp%d" % world,
+                          "batch_per_gpu": r0["local_batch"], "global_batch": r0["global_batch"], "parallelism": "dp%d" % world,
+                          "allreduce": allreduce_name() if world > 1 else None,
                           "optimizer_steps_per_sec": round(steps_per_s, 2)},
-               "roofline": {"kernel": "episode_copy_kernel<gather> (transition gather)", "bound": "hbm", "achieved": round(algo / (gather_ms * 1e-3) / 1e9, 3),
-                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(algo / (gather_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
-                            "algorithmic_bytes_per_launch": int(algo), "avg_launch_ms": round(gather_ms, 5),
+               "roofline": {"kernel": "episode_copy_kernel<gather> (transition gather)", "bound": "hbm", "achieved": round(algo / (r0["gather_ms"] * 1e-3) / 1e9, 3),
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(algo / (r0["gather_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
+                            "algorithmic_bytes_per_launch": int(algo), "avg_launch_ms": round(r0["gather_ms"], 5),
                             "note": "247 KB per step: launch-latency bound, not bandwidth bound (SURVEY 8(a) a17)"}}
+        if len(results) > 1:
+            r1 = results[1]
+            sps1 = a.steps / r1["elapsed"]
+            out["%s_scaling" % r1["leg"]] = {"value": round(sps1 * (r1["global_batch"] / float(batch)), 2), "batch_per_gpu": r1["local_batch"],
+                                             "global_batch": r1["global_batch"], "ms_per_step": round(1e3 * r1["elapsed"] / a.steps, 4),
+                                             "optimizer_steps_per_sec": round(sps1, 2), "steps": a.steps, "warmup": a.warmup}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = ddpg_cpu_baseline(dims, batch, td3, a.cpu_seconds)
-            out["config"]["speedup_vs_cpu_port"] = round(value / out["cpu_baseline"]["value"], 1)
+            out["config"]["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
+
 
 def rddpg_cpu_baseline(dims, batch, td3, seconds):
     """CPU port (oracle/rmaddpg_oracle.py) of one recurrent MADDPG/MATD3 update. The oracle walks the 2*T per-timestep
@@ -467,11 +521,14 @@ def rddpg_cpu_baseline(dims, batch, td3, seconds):
 def main_rddpg(a):
     """Recurrent MADDPG / MATD3 with prioritized replay on SMAC dimensions (BASELINE.json config 5 = rmatd3_MMM2, B=128):
     step = PrioritizedRecReplayBuffer.sample(B, beta) + shared_train_policy_on_batch (critic update + actor update every
-    `actor_update_interval`-th step) + update_priorities + soft target updates (runner/rnn/base_runner.py:226-258)."""
+    `actor_update_interval`-th step) + update_priorities + soft target updates (runner/rnn/base_runner.py:226-258).
+    N > 1: every rank holds a replica of the store and of the sum/min trees, draws the same B global indices, trains on its
+    share, and the per-episode priorities are all-gathered so that every replica of the trees gets the same update."""
     import ctypes as C
     world, rank, dev = dist_setup()
     assert world == a.gpus
     from offpolicy_amd import _lib
+    from offpolicy_amd import dist as opdist
     from offpolicy_amd.config import default_args
     from offpolicy_amd.utils.synth import DIMS, policy_info_for
     from offpolicy_amd.utils.rec_buffer import PrioritizedRecReplayBuffer
@@ -483,11 +540,6 @@ def main_rddpg(a):
     td3 = algo == "rmatd3"
     dims = DIMS[mapname]
     batch = a.batch or 128
-    if a.scaling == "weak":
-        local_batch, global_batch = batch, batch * world
-    else:
-        assert batch % world == 0
-        local_batch, global_batch = batch // world, batch
     args = default_args(use_per=True)
     torch.manual_seed(1)
     np.random.seed(1)
@@ -498,71 +550,66 @@ def main_rddpg(a):
     trainer.device_noise = not a.host_noise
     buf = PrioritizedRecReplayBuffer(args.per_alpha, pinfo, {"policy_0": list(range(dims.n_agents))}, a.episodes, dims.episode_length,
                                      True, True, device=dev, device_tree=not a.host_per)
-    fill_buffer(buf, dims, a.episodes, np.random.RandomState(100 + rank))
-    np.random.seed(1000 + rank)
-    torch.manual_seed(1000 + rank)
+    fill_buffer(buf, dims, a.episodes, np.random.RandomState(100))
     import random
-    random.seed(1000 + rank)
+    results = []
+    for leg, local_batch, global_batch in scaling_legs(a, batch, world):
+        np.random.seed(1000)              # same global index draws on every rank
+        random.seed(1000)
+        torch.manual_seed(1000 + rank)    # different gumbel noise per rank
 
-    def one_step(i=None):
-        batch_t = buf.sample(local_batch, beta=0.4, p_id="policy_0")
-        info, prio, idxes = trainer.shared_train_policy_on_batch("policy_0", batch_t)
-        buf.update_priorities(idxes, prio, "policy_0")
-        policy.soft_target_updates()
-        return info
-
-    for _ in range(a.warmup):
-        one_step()
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        info = one_step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(tt[0])
-    assert np.isfinite(float(info["critic_loss"]))
-    # gather roofline leg measured on its own (same launch, HIP events on the launch stream)
-    pbuf = buf.policy_buffers["policy_0"]
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
-    for e in ev:
-        pbuf.sample_inds(np.random.choice(len(buf), local_batch), timing_events=e)
-    torch.cuda.synchronize()
-    gather_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
+        def one_step(i=None):
+            batch_t = buf.sample(global_batch, beta=0.4, p_id="policy_0", shard=(rank, world) if world > 1 else None)
+            info, prio, idxes = trainer.shared_train_policy_on_batch("policy_0", batch_t)
+            buf.update_priorities(idxes, opdist.allgather_cat(prio), "policy_0")
+            policy.soft_target_updates()
+            return info
+        elapsed, info = timed_steps(one_step, a.steps, a.warmup, world, dev)
+        assert np.isfinite(float(info["critic_loss"]))
+        # gather roofline leg measured on its own (same launch, HIP events on the launch stream)
+        pbuf = buf.policy_buffers["policy_0"]
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+        for e in ev:
+            pbuf.sample_inds(np.random.choice(len(buf), local_batch), timing_events=e)
+        torch.cuda.synchronize()
+        gather_ms = float(np.mean([s_.elapsed_time(e) for s_, e in ev]))
+        results.append(dict(leg=leg, local_batch=local_batch, global_batch=global_batch, elapsed=elapsed, gather_ms=gather_ms))
     if rank == 0:
+        r0 = results[0]
         N, A, D, S, T = dims.n_agents, dims.act_dim, dims.obs_dim, dims.state_dim, dims.episode_length
         ep_bytes = int(_lib.lib.ope_episode_bytes(C.byref(pbuf.dims)))
-        algo_bytes = 2.0 * local_batch * ep_bytes
-        achieved = algo_bytes / (gather_ms * 1e-3) / 1e9
-        steps_per_s = a.steps / elapsed
-        value = steps_per_s * (global_batch / float(batch))
+        algo_bytes = 2.0 * r0["local_batch"] * ep_bytes
+        achieved = algo_bytes / (r0["gather_ms"] * 1e-3) / 1e9
+        steps_per_s = a.steps / r0["elapsed"]
+        value = steps_per_s * (r0["global_batch"] / float(batch))
         name = "MATD3" if td3 else "MADDPG"
         out = {"metric": "training steps/sec (batch=%d) %s-RNN + PER %s" % (batch, name, mapname),
                "value": round(value, 3), "unit": "training steps/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-               "ms_per_step": round(1e3 * elapsed / a.steps, 4), "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
+               "ms_per_step": round(1e3 * r0["elapsed"] / a.steps, 4), "higher_is_better": True, "scaling": r0["leg"], "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
                "config": {"workload": "%s-RNN + prioritized replay, SMAC %s (N=%d A=%d D=%d S=%d T=%d), replay filled with %d synthetic "
-                                      "episodes, step = PER sample + critic update + actor update (every %d) + update_priorities + "
-                                      "soft target updates; gumbel noise drawn on the %s; PER trees on the %s" % (
-                                          name, mapname, N, A, D, S, T, a.episodes, trainer.actor_update_interval,
+                                      "episodes (%.2f GB resident in HBM), step = PER sample + critic update + actor update (every %d) + "
+                                      "update_priorities + soft target updates; gumbel noise drawn on the %s; PER trees on the %s" % (
+                                          name, mapname, N, A, D, S, T, a.episodes, a.episodes * ep_bytes / 1e9, trainer.actor_update_interval,
                                           "host (reference stream)" if a.host_noise else "device", "host" if a.host_per else "device"),
-                          "batch_per_gpu": local_batch, "global_batch": global_batch, "parallelism": "dp%d" % world,
+                          "batch_per_gpu": r0["local_batch"], "global_batch": r0["global_batch"], "parallelism": "dp%d" % world,
+                          "allreduce": allreduce_name() if world > 1 else None,
                           "optimizer_steps_per_sec": round(steps_per_s, 3)},
                "roofline": {"kernel": "episode_copy_kernel<gather> (ope_store_gather)", "bound": "hbm", "achieved": round(achieved, 2),
-                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                            "algorithmic_bytes_per_launch": int(algo_bytes), "avg_launch_ms": round(gather_ms, 5),
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                            "traffic": gather_traffic(mapname, r0["local_batch"], a.episodes),
+                            "algorithmic_bytes_per_launch": int(algo_bytes), "avg_launch_ms": round(r0["gather_ms"], 5),
+                            "store_bytes": int(a.episodes * ep_bytes), "hbm_resident": bool(a.episodes * ep_bytes > 4 * 256 * 2 ** 20),
                             "timing": "HIP events on the launch stream around 20 gather launches of the same batch size"}}
+        if len(results) > 1:
+            r1 = results[1]
+            sps1 = a.steps / r1["elapsed"]
+            out["%s_scaling" % r1["leg"]] = {"value": round(sps1 * (r1["global_batch"] / float(batch)), 3), "batch_per_gpu": r1["local_batch"],
+                                             "global_batch": r1["global_batch"], "ms_per_step": round(1e3 * r1["elapsed"] / a.steps, 4),
+                                             "optimizer_steps_per_sec": round(sps1, 3), "steps": a.steps, "warmup": a.warmup}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = rddpg_cpu_baseline(dims, batch, td3, a.cpu_seconds)
-            out["config"]["speedup_vs_cpu_port"] = round(value / out["cpu_baseline"]["value"], 1)
+            out["config"]["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

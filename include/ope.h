@@ -29,6 +29,7 @@ extern "C" {
 #define OPE_EINVAL (-1)  /* bad argument / unsupported dimension                      */
 #define OPE_ELAUNCH (-2) /* kernel launch failed (hipGetLastError != hipSuccess)     */
 #define OPE_ENOSPC (-3)  /* caller-provided workspace too small                       */
+#define OPE_EHIP (-4)    /* a HIP runtime call (allocation, IPC) failed                */
 
 int ope_version(void);
 const char* ope_strerror(int code);
@@ -292,6 +293,39 @@ int ope_rddpg_critic_loss_and_grad(const ope_rddpg_cfg* cfg, const ope_fields* b
 int ope_rddpg_actor_loss_and_grad(const ope_rddpg_cfg* cfg, const ope_fields* batch, const float* theta_actor,
                                   const float* theta_critic, const float* gumbel_noise_u, void* workspace,
                                   int64_t workspace_bytes, float* grad, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * One-shot gradient all-reduce over xGMI (SURVEY.md section 8(b) `ope_allreduce_*`, 8(e)).
+ * The reference has no distributed training (its only collective, `average_gradients`, offpolicy/utils/util.py:148-153,
+ * is dead code); the data-parallel step exchanges ONE flat float32 vector [grads | loss_sum | mask_count | qtot_sum | 0]
+ * of ~0.5 MB per update, far below the xGMI bandwidth-delay product, inside a 0.4 ms step -- so instead of a ring
+ * (2(W-1) hops) every rank PUSHES its vector straight into a slot of every peer's exchange buffer (7 links in parallel,
+ * one hop), raises per-chunk flags, waits for its peers' flags and sums the W slots in FIXED RANK ORDER, all in one
+ * kernel launch on the caller's stream: results are bitwise identical on every rank and from run to run.
+ *
+ * Exchange buffer (one per rank, fine-grained device memory, shared with the peers of the node through HIP IPC):
+ *   [2 parities][world][chunks] uint32 flags, then [2 parities][world][max_floats] float32 slots.
+ * Exception to "the caller owns all memory": the buffer needs an uncached (fine-grained) allocation and an IPC handle,
+ * which torch cannot provide, so the library allocates it (ope_allreduce_alloc / _free); handles travel between the
+ * processes by whatever the host side has (torch.distributed.all_gather_object in off-policy_amd/dist.py).
+ *   epoch   call counter, identical on all ranks, 1, 2, 3, ... (parity = epoch & 1 picks the half of the buffer);
+ *   status  device int32, OR-ed with 1 if a peer's flag did not arrive within ~100 ms (bounded spin: never hangs).
+ * world == 1 degenerates to a copy through the own slot. Not capturable in a HIP graph (epoch is a launch argument).
+ * ---------------------------------------------------------------------------------------------- */
+#define OPE_AR_MAX_WORLD 16
+#define OPE_AR_IPC_HANDLE_BYTES 64
+typedef struct ope_allreduce_ctx {
+  int32_t rank, world;
+  int64_t max_floats;            /* capacity of one slot (floats), multiple of 1024                                  */
+  void* peer[OPE_AR_MAX_WORLD];  /* peer[q] = rank q's exchange buffer as mapped in THIS process; peer[rank] = own     */
+} ope_allreduce_ctx;
+int64_t ope_allreduce_buffer_bytes(int64_t max_floats, int32_t world);
+int ope_allreduce_alloc(int64_t bytes, void** buf_out);                 /* zero-filled, fine-grained, on the current device */
+int ope_allreduce_free(void* buf);
+int ope_allreduce_ipc_export(void* buf, void* handle_host);            /* OPE_AR_IPC_HANDLE_BYTES bytes out                */
+int ope_allreduce_ipc_import(const void* handle_host, void** mapped_out);
+int ope_allreduce_ipc_close(void* mapped);
+int ope_allreduce_flat(const ope_allreduce_ctx* ctx_host, uint32_t epoch, float* flat, int64_t n, int32_t* status, void* stream);
 
 #ifdef __cplusplus
 }

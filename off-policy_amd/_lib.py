@@ -55,6 +55,10 @@ class RddpgCfg(C.Structure):
                 ("use_huber", C.c_int32), ("use_per", C.c_int32), ("gamma", C.c_float), ("huber_delta", C.c_float)]
 
 
+class AllreduceCtx(C.Structure):
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("max_floats", C.c_int64), ("peer", C.c_void_p * 16)]
+
+
 class MlpBatch(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("obs", "share_obs", "acts", "rewards", "next_obs", "next_share_obs", "dones_env",
                                           "valid_transition", "avail_acts", "next_avail_acts")]
@@ -106,6 +110,13 @@ def _load():
         "ope_adam_scratch_floats": (i64, [i64]),
         "ope_adam_step": (C.c_int, [C.POINTER(AdamCfg), i64, p, p, p, p, p, p, p, p]),
         "ope_polyak": (C.c_int, [i64, p, p, C.c_float, p]),
+        "ope_allreduce_buffer_bytes": (i64, [i64, i32]),
+        "ope_allreduce_alloc": (C.c_int, [i64, C.POINTER(p)]),
+        "ope_allreduce_free": (C.c_int, [p]),
+        "ope_allreduce_ipc_export": (C.c_int, [p, p]),
+        "ope_allreduce_ipc_import": (C.c_int, [p, C.POINTER(p)]),
+        "ope_allreduce_ipc_close": (C.c_int, [p]),
+        "ope_allreduce_flat": (C.c_int, [C.POINTER(AllreduceCtx), C.c_uint32, p, i64, p, p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError here = a symbol declared in include/ope.h is missing

@@ -44,6 +44,9 @@ class R_MADDPG(object):
         # False: gumbel noise from torch's CPU generator in the reference's order (bit-comparable runs, ~2x(T*N*B*A) floats
         # drawn on the host and copied per update). True: same distribution drawn on the device (no host work).
         self.device_noise = False
+        # (target noise [(T+1), N*B, A] or None, actor noise [T, N*B, A]) uniform draws to consume INSTEAD of drawing: lets a
+        # sharded (data-parallel) run use the columns of one full-batch realisation; consumed by one update, then cleared
+        self._noise_override = None
         self._ws, self._grads = {}, {}
 
     def _workspace(self, policy, cfg):
@@ -130,7 +133,11 @@ class R_MADDPG(object):
         update_actor = self.num_updates[pid] % self.actor_update_interval == 0
         # ---- critic ----
         draw = (lambda shape: torch.rand(shape, **self.tpdv)) if self.device_noise else (lambda shape: sample_gumbel_uniform(shape).to(self.device))
-        u_t = draw((T + 1, N * B, A)) if policy.target_noise is not None else None
+        override, self._noise_override = self._noise_override, None
+        if override is not None:
+            u_t = None if override[0] is None else override[0].to(self.device, dtype=torch.float32).contiguous()
+        else:
+            u_t = draw((T + 1, N * B, A)) if policy.target_noise is not None else None
         dev_prio = torch.is_tensor(importance_weights)     # device trees: weights in, priorities out stay in HBM
         w = None
         if self.use_per:
@@ -159,7 +166,7 @@ class R_MADDPG(object):
         # ---- actor (through the freshly updated critic) ----
         u_a = None
         if update_actor:
-            u_a = draw((T, N * B, A))
+            u_a = override[1].to(self.device, dtype=torch.float32).contiguous() if override is not None else draw((T, N * B, A))
             _lib.check(_lib.lib.ope_rddpg_actor_loss_and_grad(C.byref(cfg), C.byref(f), _lib.ptr(policy.actor._flat),
                                                               _lib.ptr(policy.critic._flat), _lib.ptr(u_a), _lib.ptr(ws), ws.numel(),
                                                               _lib.ptr(ga), st), "ope_rddpg_actor_loss_and_grad")

@@ -176,6 +176,7 @@ extern "C" const char* ope_strerror(int code) {
     case OPE_EINVAL: return "invalid argument or unsupported dimension";
     case OPE_ELAUNCH: return "HIP kernel launch failed";
     case OPE_ENOSPC: return "workspace too small";
+    case OPE_EHIP: return "HIP runtime call failed (allocation / IPC)";
     default: return "unknown error";
   }
 }

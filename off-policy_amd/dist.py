@@ -30,8 +30,145 @@ def shard_indices(inds, rank=None, world_size=None):
     return inds[rank * per:(rank + 1) * per]
 
 
+class OneShotAllreduce(object):
+    """Host side of csrc/ope_allreduce.hip: every rank allocates one fine-grained exchange buffer, the HIP IPC handles
+    travel through torch.distributed.all_gather_object, every rank maps its peers' buffers, and `__call__` is ONE kernel
+    launch on the current stream (push to all peers over xGMI, flag, wait, fixed-rank-order sum). Also usable with
+    world == 1 (no process group needed): the vector makes a round trip through the own slot."""
+    MAX_FLOATS = 1 << 18      # 1 MiB slots: every flat gradient vector of the BASELINE configs is < 0.6 MB
+
+    def __init__(self, device, rank=0, world_size=1, max_floats=None, group=None):
+        import ctypes as C
+        from . import _lib
+        self._lib, self._C = _lib, C
+        self.device = torch.device(device)
+        self.rank, self.world = int(rank), int(world_size)
+        self.max_floats = int(max_floats or self.MAX_FLOATS)
+        self.epoch = 0
+        self._mapped = []
+        with torch.cuda.device(self.device):
+            nbytes = int(_lib.lib.ope_allreduce_buffer_bytes(self.max_floats, self.world))
+            if nbytes < 0:
+                _lib.check(nbytes, "ope_allreduce_buffer_bytes")
+            buf = C.c_void_p(0)
+            _lib.check(_lib.lib.ope_allreduce_alloc(nbytes, C.byref(buf)), "ope_allreduce_alloc")
+            self._buf = buf
+            handle = (C.c_ubyte * 64)()
+            peers = [None] * self.world
+            if self.world > 1:
+                # every rank takes part in the handle exchange even if its own export failed (None), so that a local failure
+                # cannot leave the other ranks stuck in the collective
+                rc = _lib.lib.ope_allreduce_ipc_export(buf, handle)
+                handles = [None] * self.world
+                torch.distributed.all_gather_object(handles, bytes(handle) if rc == 0 else None, group=group)
+                if any(h is None for h in handles):
+                    raise _lib.OpeError("hipIpcGetMemHandle failed on rank(s) %s" % [q for q, h in enumerate(handles) if h is None])
+                for q, h in enumerate(handles):
+                    if q == self.rank:
+                        continue
+                    m = C.c_void_p(0)
+                    hb = (C.c_ubyte * 64).from_buffer_copy(h)
+                    _lib.check(_lib.lib.ope_allreduce_ipc_import(hb, C.byref(m)), "ope_allreduce_ipc_import")
+                    self._mapped.append(m)
+                    peers[q] = m.value
+            peers[self.rank] = buf.value
+            self.ctx = _lib.AllreduceCtx()
+            self.ctx.rank, self.ctx.world, self.ctx.max_floats = self.rank, self.world, self.max_floats
+            for q in range(self.world):
+                self.ctx.peer[q] = peers[q]
+            self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
+
+    def __call__(self, flat):
+        assert flat.dtype == torch.float32 and flat.is_contiguous() and flat.device == self.device and flat.numel() <= self.max_floats
+        self.epoch += 1
+        self._lib.check(self._lib.lib.ope_allreduce_flat(self._C.byref(self.ctx), self.epoch, self._lib.ptr(flat), flat.numel(),
+                                                         self._lib.ptr(self.status), self._lib.current_stream()), "ope_allreduce_flat")
+        return flat
+
+    def timed_out(self):
+        """True if any call so far gave up waiting for a peer (synchronises the stream)."""
+        return bool(int(self.status.item()) != 0)
+
+    def close(self):
+        torch.cuda.synchronize(self.device)
+        for m in self._mapped:
+            self._lib.lib.ope_allreduce_ipc_close(m)
+        self._mapped = []
+        if self._buf is not None:
+            self._lib.lib.ope_allreduce_free(self._buf)
+            self._buf = None
+
+
+_fast = None          # OneShotAllreduce once setup_fast_allreduce() has verified it, else None (torch.distributed / RCCL)
+_fast_note = "rccl (torch.distributed all_reduce)"
+
+
+def allreduce_backend():
+    return "one-shot xGMI push (ope_allreduce_flat)" if _fast is not None else _fast_note
+
+
+def setup_fast_allreduce(device, group=None):
+    """Try to switch `allreduce_flat_` to the one-shot xGMI kernel. It is only used if, on EVERY rank, three all-reduces
+    of random vectors (two sizes) agree with torch.distributed's result and no wait timed out; otherwise the process group's
+    all_reduce (RCCL) stays. OPE_ALLREDUCE=rccl skips the attempt, OPE_ALLREDUCE=oneshot makes a failure fatal."""
+    global _fast, _fast_note
+    import os
+    import sys
+    mode = os.environ.get("OPE_ALLREDUCE", "auto")
+    if not is_distributed() or mode == "rccl":
+        return False
+    rank, world_size = world()
+    ok, err, ar = 1, "", None
+    try:
+        ar = OneShotAllreduce(device, rank, world_size, group=group)
+    except Exception as e:     # allocation / IPC not available on this system
+        ok, err = 0, repr(e)
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    for n in (118795, 5, 1 << 18):          # every rank runs the same collectives whatever its local state
+        x = torch.randn(n, generator=g).to(device)
+        ref = x.clone()
+        torch.distributed.all_reduce(ref, op=torch.distributed.ReduceOp.SUM, group=group)
+        if ar is not None:
+            ar(x)
+            if not torch.allclose(x, ref, rtol=1e-5, atol=1e-5):
+                ok, err = 0, "mismatch vs torch.distributed at n=%d" % n
+    if ar is not None and ar.timed_out():
+        ok, err = 0, "peer flags timed out"
+    t = torch.tensor([ok], dtype=torch.int32, device=device)
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN, group=group)
+    if int(t.item()) == 1:
+        _fast = ar
+        return True
+    _fast_note = "rccl (one-shot xGMI path not verified: %s)" % (err or "another rank failed")
+    if rank == 0:
+        print("[ope.dist] one-shot all-reduce disabled: %s" % (err or "another rank failed"), file=sys.stderr)
+    if mode == "oneshot":
+        raise RuntimeError("OPE_ALLREDUCE=oneshot but the one-shot all-reduce did not verify: " + err)
+    return False
+
+
 def allreduce_flat_(flat, group=None):
     """In-place SUM all-reduce of one flat tensor; a single collective per training step."""
     if is_distributed():
+        if _fast is not None and group is None and flat.dtype == torch.float32 and flat.numel() <= _fast.max_floats and flat.is_cuda:
+            return _fast(flat)
         torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.SUM, group=group)
     return flat
+
+
+def allgather_cat(x, group=None):
+    """Concatenation over ranks (rank order) of a per-sample vector: the per-episode priorities of a sharded prioritized
+    batch, so that every rank updates its replica of the sum/min trees with the same B values."""
+    if not is_distributed() or x is None:
+        return x
+    _, world_size = world()
+    if torch.is_tensor(x):
+        out = [torch.empty_like(x) for _ in range(world_size)]
+        torch.distributed.all_gather(out, x.contiguous(), group=group)
+        return torch.cat(out)
+    t = torch.as_tensor(np.asarray(x))
+    dev = torch.device("cuda", torch.cuda.current_device()) if torch.distributed.get_backend(group) == "nccl" else t.device
+    t = t.to(dev)
+    out = [torch.empty_like(t) for _ in range(world_size)]
+    torch.distributed.all_gather(out, t, group=group)
+    return torch.cat(out).cpu().numpy()

@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from .. import _lib
-from .rec_buffer import RecPolicyBuffer
+from .rec_buffer import RecPolicyBuffer, _shard
 from .segment_tree import SumSegmentTree, MinSegmentTree
 
 
@@ -127,8 +127,11 @@ class MlpReplayBuffer(object):
                 dst[p_id] = val
         return out
 
-    def sample(self, batch_size):
+    def sample(self, batch_size, shard=None):
+        """mlp_buffer.py:76-96. `shard=(rank, world)`: see RecReplayBuffer.sample (same global draw on every rank, own share gathered)."""
         inds = np.random.choice(len(self), batch_size)
+        if shard is not None:
+            inds = _shard(inds, *shard)
         return self._gather(inds) + (None, None)
 
 
@@ -168,17 +171,22 @@ class PrioritizedMlpReplayBuffer(MlpReplayBuffer):
         mass = np.random.random(size=batch_size) * total
         return self._it_sums[p_id].find_prefixsum_idx(mass)
 
-    def sample(self, batch_size, beta=0, p_id=None):
+    def sample(self, batch_size, beta=0, p_id=None, shard=None):
+        """`shard=(rank, world)`: see PrioritizedRecReplayBuffer.sample (own share of episodes / weights, GLOBAL indices)."""
         assert len(self) > batch_size, "Not enough samples in the buffer!"
         assert beta > 0
         if self.device_tree:    # same host RNG draw as _sample_proportional; tree walk and weights on the device
             inds, weights = self._dtrees[p_id].sample(np.random.random(size=batch_size), len(self), beta)
+            if shard is not None:
+                return self._gather(_shard(inds, *shard).contiguous()) + (_shard(weights, *shard).contiguous(), inds)
             return self._gather(inds) + (weights, inds)
         batch_inds = self._sample_proportional(batch_size, p_id)
         p_min = self._it_mins[p_id].min() / self._it_sums[p_id].sum()
         max_weight = (p_min * len(self)) ** (-beta)
         p_sample = self._it_sums[p_id][batch_inds] / self._it_sums[p_id].sum()
         weights = (p_sample * len(self)) ** (-beta) / max_weight
+        if shard is not None:
+            return self._gather(_shard(batch_inds, *shard)) + (_shard(weights, *shard), batch_inds)
         return self._gather(batch_inds) + (weights, batch_inds)
 
     def update_priorities(self, idxes, priorities, p_id=None):

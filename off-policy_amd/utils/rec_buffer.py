@@ -28,6 +28,14 @@ _INDS_MODE = os.environ.get("OPE_INDS_MODE", "copy")    # copy | zerocopy (RecPo
 _FIELD_ORDER = ("obs", "share_obs", "acts", "rewards", "dones", "dones_env", "avail_acts")
 
 
+def _shard(x, rank, world):
+    """Rank `rank`'s contiguous share of a per-sample vector (numpy or tensor)."""
+    n = len(x)
+    assert n % world == 0, "the global batch must be a multiple of the number of ranks"
+    per = n // world
+    return x[rank * per:(rank + 1) * per]
+
+
 def _shape_of(space):
     name = space.__class__.__name__
     if name == "Box":
@@ -239,9 +247,13 @@ class RecReplayBuffer(object):
                 dst[p_id] = val
         return keys
 
-    def sample(self, batch_size):
-        """Uniform sampling WITH replacement from the global numpy RNG, as rec_buffer.py:76."""
+    def sample(self, batch_size, shard=None):
+        """Uniform sampling WITH replacement from the global numpy RNG, as rec_buffer.py:76.
+        Data-parallel use (no reference counterpart): with `shard=(rank, world)` every rank draws the SAME `batch_size`
+        global indices (equal seeds, equal store replicas) and gathers only its contiguous share of them."""
         inds = np.random.choice(self.__len__(), batch_size)
+        if shard is not None:
+            inds = _shard(inds, *shard)
         return self._gather(inds) + (None, None)
 
 
@@ -282,17 +294,25 @@ class PrioritizedRecReplayBuffer(RecReplayBuffer):
         mass = np.random.random(size=batch_size) * total
         return self._it_sums[p_id].find_prefixsum_idx(mass)
 
-    def sample(self, batch_size, beta=0, p_id=None):
+    def sample(self, batch_size, beta=0, p_id=None, shard=None):
+        """rec_buffer.py:285-304. Data-parallel use: with `shard=(rank, world)` every rank draws the same `batch_size` global
+        indices from its replica of the trees and gets back the episodes and importance weights of ITS contiguous share
+        plus the GLOBAL index list; after the update, `dist.allgather_cat(new_priorities)` rebuilds the global priority
+        vector so that `update_priorities(global_idxes, ...)` changes every replica identically."""
         assert len(self) > batch_size, "Cannot sample with no completed episodes in the buffer!"
         assert beta > 0
         if self.device_tree:    # same host RNG draw as _sample_proportional; tree walk and weights on the device
             inds, weights = self._dtrees[p_id].sample(np.random.random(size=batch_size), len(self), beta)
+            if shard is not None:
+                return self._gather(_shard(inds, *shard).contiguous()) + (_shard(weights, *shard).contiguous(), inds)
             return self._gather(inds) + (weights, inds)
         batch_inds = self._sample_proportional(batch_size, p_id)
         p_min = self._it_mins[p_id].min() / self._it_sums[p_id].sum()
         max_weight = (p_min * len(self)) ** (-beta)
         p_sample = self._it_sums[p_id][batch_inds] / self._it_sums[p_id].sum()
         weights = (p_sample * len(self)) ** (-beta) / max_weight
+        if shard is not None:
+            return self._gather(_shard(batch_inds, *shard)) + (_shard(weights, *shard), batch_inds)
         return self._gather(batch_inds) + (weights, batch_inds)
 
     def update_priorities(self, idxes, priorities, p_id=None):

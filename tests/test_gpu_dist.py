@@ -1,0 +1,171 @@
+"""-m gpu: the data-parallel path with the HIP trainers. Two ranks share cuda:0 (the GPU box has one GPU) over gloo; each
+back-propagates its half of the sampled episodes through the C-ABI, the flat [grads | loss_sum | mask_count | qtot_sum]
+vector goes through ONE all-reduce (the one-shot xGMI kernel through HIP IPC when it verifies on this box, else the process
+group's), and the post-step parameters must equal the single-process full-batch step."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_one_shot_allreduce_world1_roundtrip_is_exact():
+    """world == 1: the vector goes out to the own slot and back (both parities, ragged tail, max size): bit-exact."""
+    from offpolicy_amd.dist import OneShotAllreduce
+    dev = torch.device("cuda:0")
+    ar = OneShotAllreduce(dev, 0, 1)
+    g = torch.Generator(device="cpu").manual_seed(0)
+    for n in (1, 5, 1023, 1024, 118795, 1 << 18, 7, 118795):
+        x = torch.randn(n, generator=g).to(dev)
+        want = x.clone()
+        ar(x)
+        assert torch.equal(x, want), n
+    assert not ar.timed_out() and ar.epoch == 8
+    ar.close()
+
+
+def _qmix_worker(rank, world, port, name, mode, out_q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", OPE_ALLREDUCE=mode)
+    torch.cuda.set_device(0)
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from conftest import load_golden
+        from gpu_util import build_from_fixture, batch_from
+        from offpolicy_amd import dist as opdist
+        fast = opdist.setup_fast_allreduce(torch.device("cuda:0"))
+        g = load_golden(name)
+        dims, buf, policy, trainer = build_from_fixture(g)
+        inds = np.asarray(g["inds"])[:4]
+        infos = []
+        for _ in range(2):
+            info, _, _ = trainer.train_policy_on_batch(batch_from(buf, opdist.shard_indices(inds)))
+            trainer.soft_target_updates()
+            infos.append([float(info[k]) for k in ("loss", "grad_norm", "Q_tot")])
+        torch.cuda.synchronize()
+        bad = opdist._fast.timed_out() if fast else False
+        out_q.put((rank, bool(fast), bad, trainer.theta.cpu().numpy(), trainer.theta_tgt.cpu().numpy(), np.asarray(infos)))
+    finally:
+        torch.distributed.destroy_process_group()
+
+
+def _rddpg_worker(rank, world, port, name, mode, out_q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", OPE_ALLREDUCE=mode)
+    torch.cuda.set_device(0)
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from offpolicy_amd import dist as opdist
+        fast = opdist.setup_fast_allreduce(torch.device("cuda:0"))
+        res = _rddpg_steps(name, (rank, world))
+        torch.cuda.synchronize()
+        bad = opdist._fast.timed_out() if fast else False
+        out_q.put((rank, bool(fast), bad) + res)
+    finally:
+        torch.distributed.destroy_process_group()
+
+
+def _rddpg_steps(name, shard):
+    """Two R_MATD3 updates (+ PER priorities) on the fixture's batch; shard = (rank, world) trains on that share."""
+    from conftest import load_golden
+    from golden_util import EP_KEYS
+    import test_gpu_rddpg as R
+    from offpolicy_amd import dist as opdist
+    g = load_golden(name)
+    dims, buf, policy, trainer = R.build(g)
+    R.load_fixture_weights(g, policy, check=False)
+    trainer.device_noise = False
+    d = {k: {"policy_0": g["ep/" + k]} for k in EP_KEYS}
+    buf.insert(len(g["idx_range"]), *[d[k] for k in EP_KEYS])
+    inds = np.asarray(g["inds"])
+    B = len(inds) - len(inds) % 2
+    inds = inds[:B]
+    w = (np.asarray(g["per_weights"])[:B] if "per_weights" in g else None)
+    rank, world = shard
+    per = B // world
+    mine = slice(rank * per, (rank + 1) * per)
+    T, N, A = dims.episode_length, dims.n_agents, dims.act_dim
+    prios = []
+    for st in range(2):
+        # the reference's noise stream is laid out [T(+1), N*B, A] with row = agent*B + b: draw the FULL batch's noise and
+        # hand each rank the columns of its episodes, so that sharded and full-batch runs consume identical numbers
+        torch.manual_seed(1000 + st)
+        u_t = torch.FloatTensor(T + 1, N, B, A).uniform_() if policy.target_noise is not None else None
+        u_a = torch.FloatTensor(T, N, B, A).uniform_()
+        trainer._noise_override = (None if u_t is None else u_t[:, :, mine].reshape(T + 1, N * per, A).contiguous(),
+                                   u_a[:, :, mine].reshape(T, N * per, A).contiguous())
+        s = buf.policy_buffers["policy_0"].sample_inds(inds[mine])
+        batch = tuple({"policy_0": a} for a in s) + (None if w is None else w[mine], inds if w is not None else None)
+        info, prio, _ = trainer.shared_train_policy_on_batch("policy_0", batch)
+        policy.soft_target_updates()
+        prios.append(opdist.allgather_cat(prio))
+    torch.cuda.synchronize()
+    return (policy.critic._flat.cpu().numpy(), policy.actor._flat.cpu().numpy(), policy.target_critic._flat.cpu().numpy(),
+            None if prios[0] is None else np.asarray(prios))
+
+
+def _spawn(worker, name, mode):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=worker, args=(r, 2, port, name, mode, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        item = q.get(timeout=600)
+        res[item[0]] = item[1:]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.parametrize("mode", ["auto", "rccl"])
+def test_two_rank_qmix_step_equals_full_batch_step(mode):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import load_golden
+    from gpu_util import build_from_fixture, batch_from
+    name = "qmix_tiny"
+    res = _spawn(_qmix_worker, name, mode)
+    fast0, bad0, th0, tg0, info0 = res[0]
+    fast1, bad1, th1, tg1, info1 = res[1]
+    assert fast0 == fast1 and not bad0 and not bad1
+    if mode == "rccl":
+        assert not fast0
+    print("one-shot all-reduce verified on this box:", fast0)
+    # ranks hold identical parameters after the redundant optimizer steps (fixed-order sums: bitwise)
+    assert np.array_equal(th0, th1) and np.array_equal(tg0, tg1) and np.array_equal(info0, info1)
+    g = load_golden(name)
+    dims, buf, policy, trainer = build_from_fixture(g)
+    inds = np.asarray(g["inds"])[:4]
+    want = []
+    for _ in range(2):
+        info, _, _ = trainer.train_policy_on_batch(batch_from(buf, inds))
+        trainer.soft_target_updates()
+        want.append([float(info[k]) for k in ("loss", "grad_norm", "Q_tot")])
+    np.testing.assert_allclose(info0, np.asarray(want), rtol=2e-5)
+    np.testing.assert_allclose(th0, trainer.theta.cpu().numpy(), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(tg0, trainer.theta_tgt.cpu().numpy(), rtol=0, atol=2e-6)
+
+
+def test_two_rank_rmatd3_per_step_equals_full_batch_step():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    name = "rmatd3_odd_per"
+    res = _spawn(_rddpg_worker, name, "auto")
+    fast0, bad0, c0, a0, tc0, p0 = res[0]
+    fast1, bad1, c1, a1, tc1, p1 = res[1]
+    assert fast0 == fast1 and not bad0 and not bad1
+    assert np.array_equal(c0, c1) and np.array_equal(a0, a1) and np.array_equal(tc0, tc1) and np.array_equal(p0, p1)
+    wc, wa, wtc, wp = _rddpg_steps(name, (0, 1))
+    np.testing.assert_allclose(c0, wc, rtol=0, atol=3e-6)
+    np.testing.assert_allclose(a0, wa, rtol=0, atol=3e-6)
+    np.testing.assert_allclose(tc0, wtc, rtol=0, atol=3e-6)
+    np.testing.assert_allclose(p0, wp, rtol=2e-5)
