@@ -97,10 +97,18 @@ int64_t ope_reward_stats_scratch_bytes(void);
 int ope_store_reward_stats(const ope_dims* dims, int32_t filled, const float* rewards, const float* dones_env, void* scratch,
                            float* stats_out, void* stream);
 int ope_reward_normalize(float* rewards, int64_t n, const float* stats, void* stream);
+/* Index checking: `slots` / `inds` are device data, so a bad value cannot be rejected on the host without a sync. Every
+ * index is checked against [0, capacity) IN the kernel: rows of an out-of-range index are skipped (nothing is read or
+ * written out of bounds) and *bad_index_flag (device int32, may be NULL, never cleared by the library) is set to 1; the
+ * host mirrors read it lazily (RecPolicyBuffer.check_indices()). */
 int ope_store_insert(const ope_dims* dims, int32_t capacity, const ope_fields* store, const ope_fields* staged,
-                     const int64_t* slots, int32_t n_insert, void* stream);
+                     const int64_t* slots, int32_t n_insert, int32_t* bad_index_flag, void* stream);
 int ope_store_gather(const ope_dims* dims, int32_t capacity, const ope_fields* store, const int64_t* inds,
-                     int32_t batch, const ope_fields* out, void* stream);
+                     int32_t batch, const ope_fields* out, int32_t* bad_index_flag, void* stream);
+/* A/B knobs of the gather / insert kernels (tools/bench_gather.py); negative or 0 = keep. Defaults are the measured best:
+ * floats_per_block 6144, xcd_run 8, unroll 8, nontemporal 0 (bit 0 loads, bit 1 stores), small_tiles 1. Environment twins:
+ * OPE_GATHER_FLOATS, OPE_GATHER_XCD, OPE_GATHER_UNROLL, OPE_GATHER_NT, OPE_GATHER_SMALL (read once, at the first call). */
+void ope_set_gather_params(int floats_per_block, int xcd_run, int unroll, int nontemporal, int small_tiles);
 /* Bytes of one episode over all seven fields (SURVEY.md section 8(d) "episode bytes"). */
 int64_t ope_episode_bytes(const ope_dims* dims);
 

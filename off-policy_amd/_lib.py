@@ -77,8 +77,9 @@ def _load():
         "ope_set_debug": (None, [C.c_int]),
         "ope_set_scan_kernel": (None, [C.c_int, C.c_int]),
         "ope_episode_bytes": (i64, [C.POINTER(Dims)]),
-        "ope_store_insert": (C.c_int, [C.POINTER(Dims), i32, C.POINTER(Fields), C.POINTER(Fields), p, i32, p]),
-        "ope_store_gather": (C.c_int, [C.POINTER(Dims), i32, C.POINTER(Fields), p, i32, C.POINTER(Fields), p]),
+        "ope_store_insert": (C.c_int, [C.POINTER(Dims), i32, C.POINTER(Fields), C.POINTER(Fields), p, i32, p, p]),
+        "ope_store_gather": (C.c_int, [C.POINTER(Dims), i32, C.POINTER(Fields), p, i32, C.POINTER(Fields), p, p]),
+        "ope_set_gather_params": (None, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
         "ope_per_tree_bytes": (i64, [i32]),
         "ope_per_tree_init": (C.c_int, [p, i32, p]),
         "ope_per_tree_set": (C.c_int, [p, i32, p, p, C.c_double, i32, p]),

@@ -19,6 +19,30 @@ namespace {
 constexpr int kFields = 7;
 constexpr int kBlock = 256;
 constexpr int kTargetFloats = 6144;  // ~24 KB of payload per workgroup
+constexpr int kTileFloats = 7168;    // short-row tiles staged in LDS (28 KB + padding)
+constexpr int kLdsFloats = kTileFloats + 512;
+
+// tuning knobs (defaults = measured best; ope_set_gather_params / OPE_GATHER_* for A/B runs)
+struct GatherTune {
+  int floats = kTargetFloats;  // long rows: payload floats per workgroup
+  int xcd = 8;                 // G > 1: runs of G consecutive logical blocks share an XCD (and its L2)
+  int unroll = 8;              // long rows: rows (16-byte loads per lane) in flight per wave: 4, 8 or 16
+  int nt = 0;                  // bit 0: non-temporal loads from the store, bit 1: non-temporal stores of the batch
+  int small = 1;               // 1: short rows (dim < 128 floats) go through the LDS-transposing tile path
+  bool env_read = false;
+};
+GatherTune g_tune;
+
+void read_env_once() {
+  if (g_tune.env_read) return;
+  g_tune.env_read = true;
+  const char* e;
+  if ((e = getenv("OPE_GATHER_FLOATS"))) g_tune.floats = atoi(e);
+  if ((e = getenv("OPE_GATHER_XCD"))) g_tune.xcd = atoi(e);
+  if ((e = getenv("OPE_GATHER_UNROLL"))) g_tune.unroll = atoi(e);
+  if ((e = getenv("OPE_GATHER_NT"))) g_tune.nt = atoi(e);
+  if ((e = getenv("OPE_GATHER_SMALL"))) g_tune.small = atoi(e);
+}
 
 struct FieldDesc {
   const float* src;
@@ -26,40 +50,73 @@ struct FieldDesc {
   int TT;              // time entries (T or T+1)
   int NA;              // agent axis (1 if none)
   int DD;              // innermost dim
-  int rows_per_block;  // destination rows (segments of DD floats) per workgroup
+  int rows_per_block;  // long rows: destination rows (segments of DD floats) per workgroup; tiles: (t, agent) rows per tile
   int block_begin;     // first blockIdx.x of this field
+  int tiled;           // 1: LDS-transposing tile path
 };
 struct CopyArgs {
   FieldDesc f[kFields];
   int n_episodes;    // B (gather) or n_insert (insert)
+  int capacity;      // ring slots: every index must lie in [0, capacity)
   int total_blocks;
-  int xcd_swizzle;   // G > 1: runs of G consecutive logical blocks share an XCD (and its L2)
+  int xcd_swizzle;
+  int unroll;
+  int nt;
+  int* bad_index;    // device flag: set to 1 if an index was out of range (the offending rows are skipped)
 };
+
+__device__ __forceinline__ int64_t checked_index(const int64_t* __restrict__ idx, int i, int capacity, int* bad) {
+  const int64_t v = idx[i];
+  if (v < 0 || v >= capacity) {
+    if (bad) *bad = 1;
+    return -1;
+  }
+  return v;
+}
 
 // A "row" is the DD contiguous floats of one (episode, t, agent). Rows are numbered in DESTINATION order, so a block
 // owns one contiguous destination range (whole 128-byte lines when the range is a multiple of B rows: for the
 // gather, [t][a][0..B) is exactly B*DD floats) and pulls its rows from wherever they live in the source:
 //   GATHER  dst row r = (t*NA + a)*E + b   <- src row (idx[b]*TT + t)*NA + a     (store -> batch)
 //   INSERT  dst row r = (idx[e]*TT + t)*NA + a, numbered r = (e*TT + t)*NA + a  <- src row (t*E + e)*NA + a
+// Returns false (row skipped) if the episode index is out of range.
 template <bool GATHER>
-__device__ __forceinline__ void row_ptrs(const FieldDesc& F, const int64_t* __restrict__ idx, int E, int r,
+__device__ __forceinline__ bool row_ptrs(const FieldDesc& F, const CopyArgs& A, const int64_t* __restrict__ idx, int E, int r,
                                          const float*& sp, float*& dp) {
   if (GATHER) {
     const int ta = r / E, b = r - ta * E;
     const int t = ta / F.NA, a = ta - t * F.NA;
-    sp = F.src + (((int64_t)idx[b] * F.TT + t) * F.NA + a) * F.DD;
+    const int64_t e = checked_index(idx, b, A.capacity, A.bad_index);
+    sp = F.src + ((((e < 0 ? 0 : e)) * F.TT + t) * F.NA + a) * F.DD;
     dp = F.dst + (int64_t)r * F.DD;
+    return e >= 0;
   } else {
     const int et = r / F.NA, a = r - et * F.NA;
     const int e = et / F.TT, t = et - e * F.TT;
+    const int64_t slot = checked_index(idx, e, A.capacity, A.bad_index);
     sp = F.src + (((int64_t)t * E + e) * F.NA + a) * F.DD;
-    dp = F.dst + (((int64_t)idx[e] * F.TT + t) * F.NA + a) * F.DD;
+    dp = F.dst + ((((slot < 0 ? 0 : slot)) * F.TT + t) * F.NA + a) * F.DD;
+    return slot >= 0;
   }
 }
 
-template <bool GATHER, int VEC>
-__device__ __forceinline__ void copy_field(const FieldDesc& F, const int64_t* __restrict__ idx, int E, int blk) {
-  constexpr int UNROLL = 8;
+template <int VEC, bool NT>
+__device__ __forceinline__ float __attribute__((ext_vector_type(VEC))) ld_vec(const float* p) {
+  typedef float vec_t __attribute__((ext_vector_type(VEC)));
+  if (NT) return __builtin_nontemporal_load(reinterpret_cast<const vec_t*>(p));
+  return *reinterpret_cast<const vec_t*>(p);
+}
+template <int VEC, bool NT>
+__device__ __forceinline__ void st_vec(float* p, float __attribute__((ext_vector_type(VEC))) v) {
+  typedef float vec_t __attribute__((ext_vector_type(VEC)));
+  if (NT) __builtin_nontemporal_store(v, reinterpret_cast<vec_t*>(p));
+  else *reinterpret_cast<vec_t*>(p) = v;
+}
+
+// long rows: a wave moves UNROLL rows at a time, 64 lanes striding over the pieces of each; all UNROLL loads of a lane
+// are issued before its first store
+template <bool GATHER, int VEC, int UNROLL, bool NTL, bool NTS>
+__device__ __forceinline__ void copy_rows(const FieldDesc& F, const CopyArgs& A, const int64_t* __restrict__ idx, int E, int blk) {
   typedef float vec_t __attribute__((ext_vector_type(VEC)));
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n_rows = E * F.TT * F.NA;
@@ -67,35 +124,113 @@ __device__ __forceinline__ void copy_field(const FieldDesc& F, const int64_t* __
   const int nr = min(F.rows_per_block, n_rows - r0);
   const int pieces = F.DD / VEC;          // VEC-wide pieces per row
   if (pieces < 32) {
-    // short rows (acts, rewards, dones ...): flat (row, piece) space, one piece per thread per iteration
+    // short rows without a tile path (odd sizes): flat (row, piece) space, one piece per thread per iteration
     const int total = nr * pieces;
     for (int x = threadIdx.x; x < total; x += kBlock) {
       const int rl = x / pieces, pc = x - rl * pieces;
       const float* sp; float* dp;
-      row_ptrs<GATHER>(F, idx, E, r0 + rl, sp, dp);
-      *reinterpret_cast<vec_t*>(dp + pc * VEC) = *reinterpret_cast<const vec_t*>(sp + pc * VEC);
+      if (row_ptrs<GATHER>(F, A, idx, E, r0 + rl, sp, dp)) st_vec<VEC, NTS>(dp + pc * VEC, ld_vec<VEC, NTL>(sp + pc * VEC));
     }
     return;
   }
-  // long rows: a wave moves UNROLL rows at a time, 64 lanes striding over the pieces of each; all UNROLL loads of a
-  // lane are issued before its first store
   for (int s0 = wave * UNROLL; s0 < nr; s0 += 4 * UNROLL) {
-    const float* sp[UNROLL]; float* dp[UNROLL];
+    const float* sp[UNROLL]; float* dp[UNROLL]; bool ok[UNROLL];
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) row_ptrs<GATHER>(F, idx, E, r0 + min(s0 + u, nr - 1), sp[u], dp[u]);
+    for (int u = 0; u < UNROLL; ++u) ok[u] = row_ptrs<GATHER>(F, A, idx, E, r0 + min(s0 + u, nr - 1), sp[u], dp[u]) && (s0 + u < nr);
     for (int pc = lane; pc < pieces; pc += 64) {
       vec_t v[UNROLL];
 #pragma unroll
-      for (int u = 0; u < UNROLL; ++u) v[u] = *reinterpret_cast<const vec_t*>(sp[u] + pc * VEC);
+      for (int u = 0; u < UNROLL; ++u) v[u] = ld_vec<VEC, NTL>(sp[u] + pc * VEC);
 #pragma unroll
       for (int u = 0; u < UNROLL; ++u)
-        if (s0 + u < nr) *reinterpret_cast<vec_t*>(dp[u] + pc * VEC) = v[u];
+        if (ok[u]) st_vec<VEC, NTS>(dp[u] + pc * VEC, v[u]);
     }
   }
 }
 
-template <bool GATHER>
+// Short rows (acts, avail_acts: A floats; rewards, dones, dones_env: 1 float): a (t, agent) row of ONE episode is a few
+// bytes, but the KR consecutive rows [ta0, ta0+KR) of an episode are one contiguous run of L = KR*DD floats in the store,
+// and the same rows of all E episodes are one contiguous run of KR*E*DD floats in the batch ([ta][b][dim]). So a
+// workgroup moves one such tile through LDS: E coalesced runs in (16-byte loads when the run is 16-byte aligned), LDS as
+// [b][L] with an odd row stride (conflict-free for the transposing reads), one contiguous run out in 16-byte stores
+// (gather only: the staged side of an insert is [t][episode][agent][dim], not [t][agent][episode][dim], and inserts are
+// off the training step -- they keep the row path).
+// x / d for 0 <= x < 2^15, 1 <= d < 512 via a float reciprocal: (x + 0.5) / d is at least 0.5/d away from an integer
+// and the float error is below 2^15 * 2^-23, so the truncation is exact. (A runtime integer division costs ~40 instructions.)
+__device__ __forceinline__ int fast_div(int x, float inv_d) { return (int)(((float)x + 0.5f) * inv_d); }
+
+__device__ __forceinline__ void gather_tile(const FieldDesc& F, const CopyArgs& A, const int64_t* __restrict__ idx, int E, int blk,
+                                            float* lds) {
+  const int R = F.TT * F.NA;                   // (t, agent) rows per episode
+  const int ta0 = blk * F.rows_per_block;
+  const int KR = min(F.rows_per_block, R - ta0);
+  const int DD = F.DD;
+  const int L = KR * DD;                       // floats per episode in this tile
+  const int LS = L | 1;                        // odd LDS row stride
+  const int tid = threadIdx.x;
+  const float* ring = F.src;                   // E runs of L contiguous floats, run e at ring[(slot_e * R + ta0) * DD]
+  float* flat = F.dst + (int64_t)ta0 * E * DD;  // ONE run of KR*E*DD floats, element (k, e, j) at (k*E + e)*DD + j
+  const bool ring_al = (((int64_t)R * DD) % 4 == 0) && (((int64_t)ta0 * DD) % 4 == 0) && ((reinterpret_cast<uintptr_t>(ring) & 15) == 0);
+  const bool flat_al = (((int64_t)ta0 * E * DD) % 4 == 0) && ((reinterpret_cast<uintptr_t>(F.dst) & 15) == 0);
+  const int total = E * L;
+  const float inv_dd = 1.0f / (float)DD, inv_e = 1.0f / (float)E;
+  // phase 1: ring -> LDS[e][x]
+  const int L4 = ring_al ? (L >> 2) : 0;       // whole float4 pieces per run
+  if (L4 > 0) {
+    const float inv_l4 = 1.0f / (float)L4;
+    for (int q = tid; q < E * L4; q += kBlock) {
+      const int e = fast_div(q, inv_l4), x4 = q - e * L4;
+      const int64_t slot = checked_index(idx, e, A.capacity, A.bad_index);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (slot >= 0) v = *reinterpret_cast<const f32x4*>(ring + (slot * R + ta0) * DD + 4 * x4);
+      float* d = lds + e * LS + 4 * x4;
+      d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+    }
+  }
+  const int rem0 = 4 * L4, rem = L - rem0;     // scalar tail of every run (everything if unaligned)
+  if (rem > 0) {
+    const float inv_rem = 1.0f / (float)rem;
+    for (int q = tid; q < E * rem; q += kBlock) {
+      const int e = fast_div(q, inv_rem), x = rem0 + (q - e * rem);
+      const int64_t slot = checked_index(idx, e, A.capacity, A.bad_index);
+      lds[e * LS + x] = slot >= 0 ? ring[(slot * R + ta0) * DD + x] : 0.f;
+    }
+  }
+  __syncthreads();
+  // phase 2: LDS -> flat, 4 consecutive output floats per thread
+  const int T4 = flat_al ? (total >> 2) : 0;
+  for (int q = tid; q < T4; q += kBlock) {
+    f32x4 v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int o = 4 * q + r;
+      const int ke = fast_div(o, inv_dd), j = o - ke * DD;
+      const int k = fast_div(ke, inv_e), e = ke - k * E;
+      v[r] = lds[e * LS + k * DD + j];
+    }
+    *reinterpret_cast<f32x4*>(flat + 4 * q) = v;
+  }
+  for (int o = 4 * T4 + tid; o < total; o += kBlock) {
+    const int ke = fast_div(o, inv_dd), j = o - ke * DD;
+    const int k = fast_div(ke, inv_e), e = ke - k * E;
+    flat[o] = lds[e * LS + k * DD + j];
+  }
+}
+
+template <bool GATHER, int UNROLL, bool NTL, bool NTS>
+__device__ __forceinline__ void copy_dispatch(const FieldDesc& F, const CopyArgs& A, const int64_t* __restrict__ idx, int blk) {
+  const int vec = (F.DD % 4 == 0) ? 4 : ((F.DD % 2 == 0) ? 2 : 1);
+  if (vec == 4)
+    copy_rows<GATHER, 4, UNROLL, NTL, NTS>(F, A, idx, A.n_episodes, blk);
+  else if (vec == 2)
+    copy_rows<GATHER, 2, UNROLL, NTL, NTS>(F, A, idx, A.n_episodes, blk);
+  else
+    copy_rows<GATHER, 1, UNROLL, NTL, NTS>(F, A, idx, A.n_episodes, blk);
+}
+
+template <bool GATHER, int UNROLL, int NT>
 __global__ void __launch_bounds__(kBlock) episode_copy_kernel(CopyArgs args, const int64_t* __restrict__ idx) {
+  __shared__ float lds[GATHER ? kLdsFloats : 4];
   // Hardware deals workgroups round-robin over the 8 XCDs, each with a private L2. Neighbouring destination ranges read
   // neighbouring (line-sharing) source rows of the same episodes, so runs of G consecutive logical blocks are remapped onto
   // ONE XCD (the G blocks of a run are dispatched 8 apart, i.e. close in time), runs interleaved over the XCDs so that
@@ -112,20 +247,31 @@ __global__ void __launch_bounds__(kBlock) episode_copy_kernel(CopyArgs args, con
     if (bid >= args.f[i].block_begin) f = i;
   const FieldDesc& F = args.f[f];
   const int blk = bid - F.block_begin;
-  const int vec = (F.DD % 4 == 0) ? 4 : ((F.DD % 2 == 0) ? 2 : 1);
-  if (vec == 4)
-    copy_field<GATHER, 4>(F, idx, args.n_episodes, blk);
-  else if (vec == 2)
-    copy_field<GATHER, 2>(F, idx, args.n_episodes, blk);
-  else
-    copy_field<GATHER, 1>(F, idx, args.n_episodes, blk);
+  if (GATHER && F.tiled) {
+    gather_tile(F, args, idx, args.n_episodes, blk, lds);
+    return;
+  }
+  copy_dispatch<GATHER, UNROLL, (NT & 1) != 0, (NT & 2) != 0>(F, args, idx, blk);
 }
 
-int build_args(const ope_dims* d, const ope_fields* src, const ope_fields* dst, int E, bool gather, CopyArgs* out) {
+template <bool GATHER>
+void launch_copy(const CopyArgs& args, const int64_t* idx, hipStream_t st) {
+  const dim3 grid(args.total_blocks), block(kBlock);
+  // one instantiation per variant: a single kernel holding all of them would be allocated the registers of the largest
+  if (args.unroll == 4) hipLaunchKernelGGL((episode_copy_kernel<GATHER, 4, 0>), grid, block, 0, st, args, idx);
+  else if (args.unroll == 16) hipLaunchKernelGGL((episode_copy_kernel<GATHER, 16, 0>), grid, block, 0, st, args, idx);
+  else if (args.nt == 1) hipLaunchKernelGGL((episode_copy_kernel<GATHER, 8, 1>), grid, block, 0, st, args, idx);
+  else if (args.nt == 2) hipLaunchKernelGGL((episode_copy_kernel<GATHER, 8, 2>), grid, block, 0, st, args, idx);
+  else if (args.nt == 3) hipLaunchKernelGGL((episode_copy_kernel<GATHER, 8, 3>), grid, block, 0, st, args, idx);
+  else hipLaunchKernelGGL((episode_copy_kernel<GATHER, 8, 0>), grid, block, 0, st, args, idx);
+}
+
+int build_args(const ope_dims* d, const ope_fields* src, const ope_fields* dst, int E, int capacity, bool gather, CopyArgs* out) {
   if (!d || !src || !dst) return OPE_EINVAL;
   const int T = d->episode_length, N = d->n_agents, A = d->act_dim, D = d->obs_dim, S = d->state_dim;
   if (T < 1 || N < 1 || A < 1 || D < 1 || S < 1 || E < 1) return OPE_EINVAL;
-  static const int target = getenv("OPE_GATHER_FLOATS") ? atoi(getenv("OPE_GATHER_FLOATS")) : kTargetFloats;
+  read_env_once();
+  const int target = g_tune.floats;
   const float* s[kFields] = {src->obs, src->share_obs, src->acts, src->rewards, src->dones, src->dones_env, src->avail_acts};
   float* t[kFields] = {dst->obs, dst->share_obs, dst->acts, dst->rewards, dst->dones, dst->dones_env, dst->avail_acts};
   const int TT[kFields] = {T + 1, T + 1, T, T, T, T, T + 1};
@@ -140,11 +286,24 @@ int build_args(const ope_dims* d, const ope_fields* src, const ope_fields* dst, 
     F.NA = NA[i];
     F.DD = DD[i];
     F.block_begin = blocks;
+    F.tiled = 0;
+    const int vecw = (DD[i] % 4 == 0) ? 4 : ((DD[i] % 2 == 0) ? 2 : 1);
+    // short rows: LDS-transposing tiles of KR (t, agent) rows x all E episodes, ~kTileFloats each
+    if (gather && g_tune.small && DD[i] / vecw < 32 && E <= 512 && (int64_t)E * DD[i] <= kTileFloats) {
+      int KR = kTileFloats / (E * DD[i]);
+      if (KR > 256) KR = 256;
+      // keep the tile starts 16-byte aligned on both sides whenever the dimensions allow: KR*DD % 4 == 0
+      while (KR > 1 && ((int64_t)KR * DD[i]) % 4 != 0) --KR;
+      F.tiled = 1;
+      F.rows_per_block = KR;
+      if (s[i] == nullptr || t[i] == nullptr) continue;
+      blocks += ope_cdiv((int64_t)TT[i] * NA[i], KR);
+      continue;
+    }
     // whole groups of E rows (gather: one (t, agent) over all episodes = one contiguous, line-aligned output range)
     const int unit = gather ? E : NA[i];
     // short rows go through the flat one-piece-per-thread path: keep those blocks to ~1 piece per thread so that they
     // are not the tail of the launch
-    const int vecw = (DD[i] % 4 == 0) ? 4 : ((DD[i] % 2 == 0) ? 2 : 1);
     const int tgt = (DD[i] / vecw < 32) ? kBlock * vecw : target;
     int groups = tgt / (unit * DD[i]);
     if (groups < 1) groups = 1;
@@ -156,9 +315,12 @@ int build_args(const ope_dims* d, const ope_fields* src, const ope_fields* dst, 
   for (int i = kFields - 1; i >= 0; --i)
     if (s[i] == nullptr || t[i] == nullptr) out->f[i].block_begin = (i + 1 < kFields) ? out->f[i + 1].block_begin : blocks;
   out->n_episodes = E;
+  out->capacity = capacity;
   out->total_blocks = blocks;
-  const char* sw = getenv("OPE_GATHER_XCD");
-  out->xcd_swizzle = sw ? atoi(sw) : 8;   // G = 8: -21 % HBM read traffic at equal or better time
+  out->xcd_swizzle = g_tune.xcd;   // G = 8: -21 % HBM read traffic at equal or better time
+  out->unroll = g_tune.unroll;
+  out->nt = g_tune.nt;
+  out->bad_index = nullptr;
   return OPE_OK;
 }
 
@@ -243,27 +405,38 @@ extern "C" int64_t ope_episode_bytes(const ope_dims* d) {
   return 4 * ((T + 1) * N * D + (T + 1) * S + T * N * A + (T + 1) * N * A + T * N + T * N + T);
 }
 
+extern "C" void ope_set_gather_params(int floats_per_block, int xcd_run, int unroll, int nontemporal, int small_tiles) {
+  read_env_once();
+  if (floats_per_block > 0) g_tune.floats = floats_per_block;
+  if (xcd_run >= 0) g_tune.xcd = xcd_run;
+  if (unroll == 4 || unroll == 8 || unroll == 16) g_tune.unroll = unroll;
+  if (nontemporal >= 0) g_tune.nt = nontemporal & 3;
+  if (small_tiles >= 0) g_tune.small = small_tiles ? 1 : 0;
+}
+
 extern "C" int ope_store_gather(const ope_dims* dims, int32_t capacity, const ope_fields* store, const int64_t* inds,
-                                int32_t batch, const ope_fields* out, void* stream) {
+                                int32_t batch, const ope_fields* out, int32_t* bad_index_flag, void* stream) {
   (void)hipGetLastError();  // drop stale errors from the caller's own HIP use
   if (capacity < 1 || !inds) return OPE_EINVAL;
   CopyArgs args;
-  int rc = build_args(dims, store, out, batch, true, &args);
+  int rc = build_args(dims, store, out, batch, capacity, true, &args);
   if (rc != OPE_OK) return rc;
+  args.bad_index = bad_index_flag;
   // with a hole in the middle (missing field) the "last begin <= bid" scan still works because holes alias the next begin
-  hipLaunchKernelGGL(episode_copy_kernel<true>, dim3(args.total_blocks), dim3(kBlock), 0, (hipStream_t)stream, args, inds);
+  launch_copy<true>(args, inds, (hipStream_t)stream);
   OPE_CHECK_LAUNCH();
   return OPE_OK;
 }
 
 extern "C" int ope_store_insert(const ope_dims* dims, int32_t capacity, const ope_fields* store, const ope_fields* staged,
-                                const int64_t* slots, int32_t n_insert, void* stream) {
+                                const int64_t* slots, int32_t n_insert, int32_t* bad_index_flag, void* stream) {
   (void)hipGetLastError();  // drop stale errors from the caller's own HIP use
   if (capacity < 1 || !slots) return OPE_EINVAL;
   CopyArgs args;
-  int rc = build_args(dims, staged, store, n_insert, false, &args);
+  int rc = build_args(dims, staged, store, n_insert, capacity, false, &args);
   if (rc != OPE_OK) return rc;
-  hipLaunchKernelGGL(episode_copy_kernel<false>, dim3(args.total_blocks), dim3(kBlock), 0, (hipStream_t)stream, args, slots);
+  args.bad_index = bad_index_flag;
+  launch_copy<false>(args, slots, (hipStream_t)stream);
   OPE_CHECK_LAUNCH();
   return OPE_OK;
 }

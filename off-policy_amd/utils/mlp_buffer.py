@@ -69,7 +69,7 @@ class MlpPolicyBuffer(object):
         slots = torch.from_numpy(np.asarray(idx_range, dtype=np.int64)).to(self.device)
         sf, df = self._only_dones(staged), self._only_dones(self.valid_transition)
         _lib.check(_lib.lib.ope_store_insert(C.byref(self._ep.dims), self.buffer_size, C.byref(df), C.byref(sf),
-                                             _lib.ptr(slots), n, _lib.current_stream()), "ope_store_insert")
+                                             _lib.ptr(slots), n, _lib.ptr(self._ep._bad_index), _lib.current_stream()), "ope_store_insert")
         self._keep = (staged, slots)
         return idx_range
 
@@ -87,7 +87,7 @@ class MlpPolicyBuffer(object):
         dev_inds = inds if torch.is_tensor(inds) else self._ep._upload_inds(inds)
         sf, of = self._only_dones(self.valid_transition), self._only_dones(valid)
         _lib.check(_lib.lib.ope_store_gather(C.byref(self._ep.dims), self.buffer_size, C.byref(sf), _lib.ptr(dev_inds), B,
-                                             C.byref(of), _lib.current_stream()), "ope_store_gather")
+                                             C.byref(of), _lib.ptr(self._ep._bad_index), _lib.current_stream()), "ope_store_gather")
         if not torch.is_tensor(inds):
             self._ep._release_inds()
         return (obs[:, 0], share[0], acts[:, 0], rew[:, 0], obs[:, 1], share[1], dones[:, 0], dones_env[0], valid[0],

@@ -56,7 +56,9 @@ class RecPolicyBuffer(object):
         self.use_reward_normalization = use_reward_normalization
         if not use_same_share_obs:
             raise NotImplementedError("per-agent centralized observations are not on the accelerated path yet")
-        self.device = torch.device(device if device is not None else "cuda:0")
+        # normalised to an indexed device ("cuda" -> "cuda:0") so that device comparisons with tensors hold
+        self.device = torch.empty(0, device=torch.device(device if device is not None else "cuda:0")).device
+        self._bad_index = torch.zeros(1, dtype=torch.int32, device=self.device)   # set by the kernels on an out-of-range index
         self._reward_mask = bool(_reward_mask)      # episodes: skip steps after the episode end; transitions: plain mean/std
         self._stats_dirty = True
         self._ring = RingIndex(self.buffer_size)
@@ -166,10 +168,18 @@ class RecPolicyBuffer(object):
         if not self.use_avail_acts:
             sf.avail_acts = None
         _lib.check(_lib.lib.ope_store_insert(C.byref(self.dims), self.buffer_size, C.byref(df), C.byref(sf),
-                                             _lib.ptr(slots), n, _lib.current_stream()), "ope_store_insert")
+                                             _lib.ptr(slots), n, _lib.ptr(self._bad_index), _lib.current_stream()), "ope_store_insert")
         self._keepalive = (staged, slots)   # until the stream has consumed them
         self._stats_dirty = True
         return idx_range
+
+    def check_indices(self):
+        """Host-array indices are range-checked before upload (the reference's numpy indexing raises IndexError there);
+        DEVICE index tensors (device PER trees, graph replays) cannot be checked without a sync, so the kernels skip the rows
+        of an out-of-range index and raise a flag in HBM. This reads the flag (one sync) and raises like numpy would."""
+        if int(self._bad_index.item()) != 0:
+            self._bad_index.zero_()
+            raise IndexError("an episode index passed to sample_inds()/insert() was outside [0, %d)" % self.buffer_size)
 
     def alloc_batch(self, batch_size):
         """Destination tensors of one gather of `batch_size` episodes, in the kernels' [T(+1), N, B, dim] layout."""
@@ -189,11 +199,15 @@ class RecPolicyBuffer(object):
         `out`: optional destination from `alloc_batch` (HIP-graph replays read the batch from fixed addresses); the
         default is a fresh batch per call, like the reference's fancy-index copy."""
         if torch.is_tensor(sample_inds):     # indices already on the device (HIP-graph replays keep them in a static tensor)
-            assert sample_inds.dtype == torch.int64 and sample_inds.device == self.device
+            assert sample_inds.dtype == torch.int64 and sample_inds.device == self.device, (sample_inds.dtype, sample_inds.device)
             dev_inds, B = sample_inds.contiguous(), int(sample_inds.shape[0])
         else:
             inds = np.asarray(sample_inds, dtype=np.int64)
             B = int(inds.shape[0])
+            if B and (inds.min() < -self.buffer_size or inds.max() >= self.buffer_size):
+                raise IndexError("index out of bounds for a buffer of %d episodes" % self.buffer_size)   # as numpy fancy indexing
+            if B and inds.min() < 0:
+                inds = np.where(inds < 0, inds + self.buffer_size, inds)
             dev_inds = self._upload_inds(inds)
         d = self.dims
         if out is None:
@@ -204,7 +218,7 @@ class RecPolicyBuffer(object):
         if timing_events is not None:
             timing_events[0].record()
         _lib.check(_lib.lib.ope_store_gather(C.byref(d), self.buffer_size, C.byref(sf), _lib.ptr(dev_inds), B,
-                                             C.byref(of), _lib.current_stream()), "ope_store_gather")
+                                             C.byref(of), _lib.ptr(self._bad_index), _lib.current_stream()), "ope_store_gather")
         if timing_events is not None:
             timing_events[1].record()
         if not torch.is_tensor(sample_inds):

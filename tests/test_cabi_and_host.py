@@ -46,7 +46,7 @@ def test_null_arguments_are_rejected_without_a_gpu():
     assert _lib.lib.ope_adam_step(None, 4, None, None, None, None, None, None, None, None) == -1
     assert _lib.lib.ope_polyak(0, None, None, 0.5, None) == -1
     d = _lib.Dims(2, 5, 12, 10, 6)
-    assert _lib.lib.ope_store_gather(C.byref(d), 4, None, None, 2, None, None) == -1
+    assert _lib.lib.ope_store_gather(C.byref(d), 4, None, None, 2, None, None, None) == -1
 
 
 @pytest.mark.parametrize("name", ["qmix_tiny", "qmix_3m_katA", "qmix_odd"])

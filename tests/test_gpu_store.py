@@ -221,3 +221,69 @@ def test_prioritized_buffer_with_device_trees_trains_without_host_round_trip():
         np.testing.assert_allclose(a[1], b[1], rtol=2e-6)
         np.testing.assert_allclose(a[2], b[2], rtol=2e-6)
         np.testing.assert_allclose(a[3], b[3], rtol=1e-6)
+
+
+@pytest.mark.parametrize("dims_name,B", [("MMM2", 128), ("3m", 7), ("3s5z", 33), ("simple_spread", 256)])
+def test_gather_kernel_variants_and_tile_path_are_bit_identical(dims_name, B):
+    """Every A/B variant of the gather (row path for short rows vs the LDS-transposing tile path, non-temporal loads /
+    stores, 4 / 8 / 16 rows in flight, block sizes, XCD run lengths) returns the same bytes as a torch index_select of
+    the store -- at config 5's batch (B=128: tiles with E=128), an odd batch, and dims whose runs are not 16-byte aligned."""
+    from offpolicy_amd import _lib
+    from offpolicy_amd.utils.synth import DIMS, policy_info_for
+    from offpolicy_amd.utils.rec_buffer import RecReplayBuffer
+    dims = DIMS[dims_name]
+    cap = 48 if dims_name != "simple_spread" else 512
+    buf = RecReplayBuffer(policy_info_for(dims), {"policy_0": list(range(dims.n_agents))}, cap, dims.episode_length, True, True, device="cuda:0")
+    pb = buf.policy_buffers["policy_0"]
+    pb._ring.filled_i = cap
+    gen = torch.Generator(device="cuda:0").manual_seed(1)
+    for k in FIELDS:
+        getattr(pb, k).normal_(generator=gen)
+    inds = np.random.RandomState(3).randint(0, cap, size=B)
+    di = torch.as_tensor(inds, device="cuda:0")
+    want = [getattr(pb, k).index_select(0, di) for k in FIELDS]      # [B, T(+1), (N,) dim]
+    want = [w.permute(2, 1, 0, 3) if w.dim() == 4 else w.permute(1, 0, 2) for w in want]   # -> [N, T(+1), B, dim] / [T(+1), B, dim]
+    try:
+        for floats, xcd, unroll, nt, small in [(6144, 8, 8, 0, 1), (6144, 8, 8, 0, 0), (3072, 1, 4, 0, 1), (12288, 4, 16, 0, 1), (6144, 8, 8, 1, 1),
+                                               (6144, 8, 8, 2, 1), (6144, 16, 8, 3, 0)]:
+            _lib.lib.ope_set_gather_params(floats, xcd, unroll, nt, small)
+            got = pb.sample_inds(inds)
+            for k, a, w in zip(FIELDS, got, want):
+                assert tuple(a.shape) == tuple(w.shape), (k, a.shape, w.shape)
+                assert torch.equal(a, w), (k, floats, xcd, unroll, nt, small)
+    finally:
+        _lib.lib.ope_set_gather_params(6144, 8, 8, 0, 1)
+
+
+def test_out_of_range_indices_are_skipped_and_flagged():
+    """Host index arrays are range-checked like numpy fancy indexing (IndexError, negatives wrap); DEVICE index tensors are
+    checked in the kernel: the offending rows are not read (no out-of-bounds access), the rest of the batch is right, and
+    check_indices() raises afterwards."""
+    from offpolicy_amd.utils.synth import DIMS, policy_info_for
+    from offpolicy_amd.utils.rec_buffer import RecReplayBuffer
+    dims = DIMS["tiny"]
+    cap = 6
+    buf = RecReplayBuffer(policy_info_for(dims), {"policy_0": list(range(dims.n_agents))}, cap, dims.episode_length, True, True, device="cuda:0")
+    pb = buf.policy_buffers["policy_0"]
+    pb._ring.filled_i = cap
+    for k in FIELDS:
+        getattr(pb, k).normal_()
+    with pytest.raises(IndexError):
+        pb.sample_inds(np.array([0, cap]))
+    a = pb.sample_inds(np.array([-1, 2]))
+    b = pb.sample_inds(np.array([cap - 1, 2]))
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    pb.check_indices()                                      # nothing flagged so far
+    good = pb.sample_inds(np.array([1, 3, 5, 0]))
+    out = pb.alloc_batch(4)
+    for v in out.values():
+        v.fill_(-7.0)
+    got = pb.sample_inds(torch.tensor([1, 3, 10 ** 9, 0], dtype=torch.int64, device="cuda:0"), out=out)
+    torch.cuda.synchronize()
+    for k, g, w in zip(FIELDS, got, good):
+        bdim = g.dim() - 2
+        keep = [0, 1, 3]
+        assert torch.equal(g.index_select(bdim, torch.tensor(keep, device=g.device)), w.index_select(bdim, torch.tensor(keep, device=g.device))), k
+    with pytest.raises(IndexError):
+        pb.check_indices()
+    pb.check_indices()                                      # flag cleared by the raise
