@@ -170,6 +170,14 @@ class MADDPG(object):
             info, _, _ = self.shared_train_policy_on_batch(pid, tuple({pid: x} for x in s) + (None, None))
             policy.soft_target_updates()
             return info
+        # The warm-up below really trains (two critic + actor + Polyak updates on a throw-away batch): snapshot networks,
+        # targets, Adam moments and step counters and restore them afterwards, so that building a graphed step leaves the
+        # trainer where an eager run would be. (Sticky by design: device_noise and fuse_soft_update stay switched on.)
+        nets = (policy.actor, policy.critic, policy.target_actor, policy.target_critic)
+        opts = (policy.critic_optimizer, policy.actor_optimizer)
+        snap_nets = [m._flat.clone() for m in nets]
+        snap_opts = [(o.exp_avg.clone(), o.exp_avg_sq.clone(), o.step_dev.clone(), o.step_count) for o in opts]
+        snap_misc = (dict(self.num_updates), getattr(policy, "_polyak_done", False), np.random.get_state())
         side = torch.cuda.Stream(device=self.device)     # warm-up off the capture: workspaces, allocator pools, lazy init
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
@@ -177,6 +185,14 @@ class MADDPG(object):
             for _ in range(2):
                 body()
         torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        for m, v in zip(nets, snap_nets):      # the (frozen) Q heads are views into _flat: restored with it
+            m._flat.copy_(v)
+        for o, (m1, m2, sd, sc) in zip(opts, snap_opts):
+            o.exp_avg.copy_(m1); o.exp_avg_sq.copy_(m2); o.step_dev.copy_(sd); o.step_count = sc
+        self.num_updates.update(snap_misc[0])
+        policy._polyak_done = snap_misc[1]
+        np.random.set_state(snap_misc[2])
         torch.cuda.synchronize(self.device)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):

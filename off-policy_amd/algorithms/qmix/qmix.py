@@ -259,6 +259,12 @@ class QMix(object):
             if gather_in_graph:
                 return train(pbuf.sample_inds(static_inds))
             return train(self._static_sample)
+        # The warm-up below really trains (two optimizer + Polyak updates on a throw-away batch): snapshot the model and
+        # optimizer state and put it back afterwards, so that building a graphed step leaves the trainer exactly where an
+        # eager run would be. (Sticky by design: fuse_soft_update stays on -- later eager calls fold Polyak into Adam too.)
+        snap = (self.theta.clone(), self.theta_tgt.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), opt.step_dev.clone(),
+                opt.step_count, self._polyak_done)
+        host_rng = np.random.get_state()
         side = torch.cuda.Stream(device=self.device)     # warm-up off the capture: workspace, allocator pools, lazy init
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
@@ -268,6 +274,10 @@ class QMix(object):
             for _ in range(2):
                 body()
         torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        np.random.set_state(host_rng)                    # the throw-away index draw is not part of the caller's stream
+        self.theta.copy_(snap[0]); self.theta_tgt.copy_(snap[1]); opt.exp_avg.copy_(snap[2]); opt.exp_avg_sq.copy_(snap[3])
+        opt.step_dev.copy_(snap[4]); opt.step_count = snap[5]; self._polyak_done = snap[6]
         torch.cuda.synchronize(self.device)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):

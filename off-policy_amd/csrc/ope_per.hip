@@ -38,13 +38,20 @@ __global__ void __launch_bounds__(1024) per_set_kernel(void* trees, int cap, con
   const PerView v = per_view(trees, cap);
   __shared__ double red[1024];
   const int i = threadIdx.x;
-  const bool on = i < n;
   int64_t pos = 0;
   double pr = 0.0;
+  // The host path asserts priorities > 0 and 0 <= idx < len (rec_buffer.py:306-324); device data cannot be asserted on
+  // without a sync, so the kernel makes bad input harmless instead: an index outside [0, capacity) is skipped (nothing is
+  // written, its thread keeps recomputing the path of leaf 0, which is idempotent), a NaN / non-positive / infinite priority
+  // from a diverged step is replaced by the running maximum (what a freshly inserted sample gets), so neither can poison
+  // the sum/min trees.
+  bool on = i < n;
+  const bool in_range = on && idx[i] >= 0 && idx[i] < cap;
   if (on) {
-    pos = idx[i] + cap;
+    pos = (in_range ? idx[i] : 0) + cap;
     pr = prio ? (double)prio[i] : v.maxp[0];
-    bool last = true;                       // duplicates: only the last occurrence writes
+    if (!(pr > 0.0) || isinf(pr)) pr = v.maxp[0];
+    bool last = in_range;                   // duplicates: only the last occurrence writes
     for (int j = i + 1; j < n; ++j) last = last && (idx[j] != idx[i]);
     if (last) {
       const double val = pow(pr, alpha);
@@ -52,7 +59,7 @@ __global__ void __launch_bounds__(1024) per_set_kernel(void* trees, int cap, con
       v.mn[pos] = val;
     }
   }
-  red[i] = on && prio ? pr : 0.0;
+  red[i] = in_range && prio ? pr : 0.0;
   __syncthreads();
   for (int o = 512; o > 0; o >>= 1) {
     if (i < o) red[i] = fmax(red[i], red[i + o]);

@@ -30,13 +30,38 @@ def mse_loss(e):
     return e ** 2
 
 
+def _param_pairs(target, source):
+    """zip(target.parameters(), source.parameters()) as the reference does (util.py:131-134); policy objects (anything
+    with .parameters()) and FlatModule networks are both accepted."""
+    tp, sp = list(target.parameters()), list(source.parameters())
+    assert len(tp) == len(sp), "target and source hold different numbers of parameters"
+    return zip(tp, sp)
+
+
 def soft_update(target, source, tau):
-    """target <- (1 - tau) target + tau source for two FlatModule networks (util.py:123-134)."""
-    n = min(target._flat.numel(), source._flat.numel())
-    _lib.check(_lib.lib.ope_polyak(n, _lib.ptr(source._flat), _lib.ptr(target._flat), float(tau), _lib.current_stream()), "ope_polyak")
+    """target <- (1 - tau) target + tau source, parameter by parameter (util.py:123-134). Acts on the registered
+    parameters only -- i.e. on the MODULE's own slices of a shared flat vector: the agent q-network's update leaves the
+    mixer block that lives in the same trainer vector alone, and a MADDPG critic with frozen (unregistered, SURVEY A-4)
+    Q heads keeps its target heads untouched, exactly like the reference's zip over .parameters(). One `ope_polyak`
+    launch per contiguous run of parameters."""
+    runs = []          # (target tensor slice start ptr, source ptr, numel) merged over adjacent parameters
+    for t, s_ in _param_pairs(target, source):
+        assert t.shape == s_.shape and t.is_contiguous() and s_.is_contiguous()
+        n = t.numel()
+        if n == 0:
+            continue
+        if runs and runs[-1][0].data_ptr() + 4 * runs[-1][2] == t.data_ptr() and runs[-1][1].data_ptr() + 4 * runs[-1][2] == s_.data_ptr():
+            runs[-1][2] += n
+        else:
+            runs.append([t.data, s_.data, n])
+    st = _lib.current_stream()
+    import ctypes as C
+    for t, s_, n in runs:
+        _lib.check(_lib.lib.ope_polyak(n, C.c_void_p(s_.data_ptr()), C.c_void_p(t.data_ptr()), float(tau), st), "ope_polyak")
 
 
 def hard_update(target, source):
+    """target <- source, parameter by parameter (util.py:137-146)."""
     soft_update(target, source, 1.0)
 
 

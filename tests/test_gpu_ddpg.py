@@ -122,12 +122,14 @@ def test_graphed_step_matches_eager_step():
             res[mode] = (float(info["critic_loss"]), float(info["critic_grad_norm"]))
         else:
             theta0 = {k: m._flat.clone() for k, m in (("a", policy.actor), ("c", policy.critic), ("ta", policy.target_actor), ("tc", policy.target_critic))}
+            rng_before = np.random.get_state()[1].copy()
             step = trainer.make_graphed_step(buf, len(inds))
-            # capture warm-up trained two steps: restore the initial state so that the first replay is "step 1"
+            # the capture warm-up trains two throw-away steps; make_graphed_step must put everything back
             for k, m in (("a", policy.actor), ("c", policy.critic), ("ta", policy.target_actor), ("tc", policy.target_critic)):
-                m._flat.copy_(theta0[k])
+                assert torch.equal(m._flat, theta0[k]), k
             for opt in (policy.critic_optimizer, policy.actor_optimizer):
-                opt.exp_avg.zero_(); opt.exp_avg_sq.zero_(); opt.step_dev.zero_(); opt.step_count = 0
+                assert not opt.exp_avg.any() and not opt.exp_avg_sq.any() and int(opt.step_dev.item()) == 0 and opt.step_count == 0
+            assert np.array_equal(np.random.get_state()[1], rng_before)
             info = step(inds)
             res[mode] = (float(info["critic_loss"]), float(info["critic_grad_norm"]))
             assert int(policy.critic_optimizer.step_dev.item()) == 1 and policy.critic_optimizer.step_count == 1
@@ -225,3 +227,26 @@ def test_config3_batch256_matches_oracle(td3, per):
                       (policy.target_actor, orc.actor_tgt)):
         for k, v in params_of(mod).items():
             np.testing.assert_allclose(v, refp[k].numpy(), rtol=0, atol=3e-5, err_msg=k)
+
+
+def test_soft_and_hard_update_helpers_act_per_parameter():
+    """utils.util.soft_update / hard_update (reference util.py:123-146) Polyak the registered parameters of the module
+    they are given and nothing else: the frozen (unregistered, A-4) Q heads of a MADDPG critic keep their target values,
+    and a policy object (anything with .parameters()) is accepted like upstream's soft_update(target_policy, policy, tau)."""
+    from offpolicy_amd.utils.util import soft_update, hard_update
+    g = load_golden("matd3_small")
+    dims, buf, policy, trainer = build(g)
+    policy.critic._flat.add_(0.5)
+    policy.actor._flat.add_(0.25)
+    tgt0, src = policy.target_critic._flat.clone(), policy.critic._flat.clone()
+    soft_update(policy.target_critic, policy.critic, 0.1)
+    n = policy.critic.head_offset
+    want = tgt0.clone()
+    for name, (shape, off) in policy.critic.spec().items():
+        k = int(np.prod(shape))
+        want[off:off + k] = tgt0[off:off + k] * 0.9 + src[off:off + k] * 0.1
+    np.testing.assert_allclose(policy.target_critic._flat.cpu().numpy(), want.cpu().numpy(), rtol=1e-6, atol=1e-7)
+    assert torch.equal(policy.target_critic._flat[n:], tgt0[n:])            # frozen heads (and padding) untouched
+    hard_update(policy.target_actor, policy.actor)
+    for (k, a), (_, b) in zip(policy.target_actor.named_parameters(), policy.actor.named_parameters()):
+        assert torch.equal(a, b), k

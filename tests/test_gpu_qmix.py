@@ -306,9 +306,10 @@ def test_graphed_step_matches_reference(gather_in_graph):
     theta0, tgt0 = trainer.theta.clone(), trainer.theta_tgt.clone()
     inds = np.asarray(g["inds"])
     step = trainer.make_graphed_step(buf, len(inds), gather_in_graph=gather_in_graph)
-    trainer.theta.copy_(theta0); trainer.theta_tgt.copy_(tgt0)
     opt = trainer.optimizer
-    opt.exp_avg.zero_(); opt.exp_avg_sq.zero_(); opt.step_dev.zero_(); opt.step_count = 0
+    # the capture warm-up trains two throw-away steps; make_graphed_step itself must put the state back
+    assert torch.equal(trainer.theta, theta0) and torch.equal(trainer.theta_tgt, tgt0)
+    assert not opt.exp_avg.any() and not opt.exp_avg_sq.any() and int(opt.step_dev.item()) == 0 and opt.step_count == 0
     for s in range(len(g["loss"])):
         info = step(inds)
         np.testing.assert_allclose(float(info["loss"]), g["loss"][s], rtol=RTOL)
