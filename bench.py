@@ -183,6 +183,8 @@ def timed_steps(one_step, steps, warmup, world, dev):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
+        from offpolicy_amd import dist as opdist
+        assert not opdist.fast_allreduce_failed(), "one-shot all-reduce timed out waiting for a peer: results invalid"
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt[0])

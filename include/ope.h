@@ -105,10 +105,18 @@ int ope_store_insert(const ope_dims* dims, int32_t capacity, const ope_fields* s
                      const int64_t* slots, int32_t n_insert, int32_t* bad_index_flag, void* stream);
 int ope_store_gather(const ope_dims* dims, int32_t capacity, const ope_fields* store, const int64_t* inds,
                      int32_t batch, const ope_fields* out, int32_t* bad_index_flag, void* stream);
-/* A/B knobs of the gather / insert kernels (tools/bench_gather.py); negative or 0 = keep. Defaults are the measured best:
- * floats_per_block 6144, xcd_run 8, unroll 8, nontemporal 0 (bit 0 loads, bit 1 stores), small_tiles 1. Environment twins:
- * OPE_GATHER_FLOATS, OPE_GATHER_XCD, OPE_GATHER_UNROLL, OPE_GATHER_NT, OPE_GATHER_SMALL (read once, at the first call). */
-void ope_set_gather_params(int floats_per_block, int xcd_run, int unroll, int nontemporal, int small_tiles);
+/* The same gather with the indices in HOST memory (what sample() draws with numpy): they travel inside the kernel-argument
+ * block, so there is no index upload and no copy -> kernel dependency in front of the launch. batch <= 512; an index
+ * outside [0, capacity) returns OPE_EINVAL (numpy's IndexError). */
+int ope_store_gather_host_inds(const ope_dims* dims, int32_t capacity, const ope_fields* store, const int64_t* inds_host,
+                               int32_t batch, const ope_fields* out, void* stream);
+/* A/B knobs of the gather kernel (tools/bench_gather.py); negative or 0 = keep. Defaults are the measured best:
+ * floats_per_block 2048 (contiguous floats of one episode a workgroup reads: whole time steps), xcd_run 8 (> 1: the B
+ * workgroups writing one [t][agent][0..B) range share an XCD), unroll 8 (16-byte loads in flight per thread), nontemporal 0
+ * (bit 0 loads, bit 1 stores), small_tiles 1 (short rows through LDS-transposing tiles), tile_floats 2048. Environment
+ * twins: OPE_GATHER_FLOATS, OPE_GATHER_XCD, OPE_GATHER_UNROLL, OPE_GATHER_NT, OPE_GATHER_SMALL, OPE_GATHER_TILE (read once,
+ * at the first call). */
+void ope_set_gather_params(int floats_per_block, int xcd_run, int unroll, int nontemporal, int small_tiles, int tile_floats);
 /* Bytes of one episode over all seven fields (SURVEY.md section 8(d) "episode bytes"). */
 int64_t ope_episode_bytes(const ope_dims* dims);
 
@@ -317,7 +325,8 @@ int ope_rddpg_actor_loss_and_grad(const ope_rddpg_cfg* cfg, const ope_fields* ba
  * which torch cannot provide, so the library allocates it (ope_allreduce_alloc / _free); handles travel between the
  * processes by whatever the host side has (torch.distributed.all_gather_object in off-policy_amd/dist.py).
  *   epoch   call counter, identical on all ranks, 1, 2, 3, ... (parity = epoch & 1 picks the half of the buffer);
- *   status  device int32, OR-ed with 1 if a peer's flag did not arrive within ~100 ms (bounded spin: never hangs).
+ *   status  device int32, OR-ed with 1 if a peer's flag did not arrive within ctx.timeout_ms (default 10 s; ranks may be
+ *           skewed by host work or lazy initialisation) -- a bounded spin: a dead peer cannot hang the GPU forever.
  * world == 1 degenerates to a copy through the own slot. Not capturable in a HIP graph (epoch is a launch argument).
  * ---------------------------------------------------------------------------------------------- */
 #define OPE_AR_MAX_WORLD 16
@@ -326,6 +335,7 @@ typedef struct ope_allreduce_ctx {
   int32_t rank, world;
   int64_t max_floats;            /* capacity of one slot (floats), multiple of 1024                                  */
   void* peer[OPE_AR_MAX_WORLD];  /* peer[q] = rank q's exchange buffer as mapped in THIS process; peer[rank] = own     */
+  int32_t timeout_ms;            /* 0 = default (10 000)                                                               */
 } ope_allreduce_ctx;
 int64_t ope_allreduce_buffer_bytes(int64_t max_floats, int32_t world);
 int ope_allreduce_alloc(int64_t bytes, void** buf_out);                 /* zero-filled, fine-grained, on the current device */

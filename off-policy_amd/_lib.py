@@ -56,7 +56,7 @@ class RddpgCfg(C.Structure):
 
 
 class AllreduceCtx(C.Structure):
-    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("max_floats", C.c_int64), ("peer", C.c_void_p * 16)]
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("max_floats", C.c_int64), ("peer", C.c_void_p * 16), ("timeout_ms", C.c_int32)]
 
 
 class MlpBatch(C.Structure):
@@ -79,7 +79,8 @@ def _load():
         "ope_episode_bytes": (i64, [C.POINTER(Dims)]),
         "ope_store_insert": (C.c_int, [C.POINTER(Dims), i32, C.POINTER(Fields), C.POINTER(Fields), p, i32, p, p]),
         "ope_store_gather": (C.c_int, [C.POINTER(Dims), i32, C.POINTER(Fields), p, i32, C.POINTER(Fields), p, p]),
-        "ope_set_gather_params": (None, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+        "ope_store_gather_host_inds": (C.c_int, [C.POINTER(Dims), i32, C.POINTER(Fields), p, i32, C.POINTER(Fields), p]),
+        "ope_set_gather_params": (None, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
         "ope_per_tree_bytes": (i64, [i32]),
         "ope_per_tree_init": (C.c_int, [p, i32, p]),
         "ope_per_tree_set": (C.c_int, [p, i32, p, p, C.c_double, i32, p]),

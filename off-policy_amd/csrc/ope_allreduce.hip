@@ -20,7 +20,7 @@ namespace {
 
 constexpr int kChunk = 1024;      // floats per workgroup: 256 threads x float4
 constexpr int kBlock = 256;
-constexpr unsigned long long kTimeoutTicks = 10000000ull;   // wall_clock64 runs at 100 MHz: 100 ms
+constexpr int kDefaultTimeoutMs = 10000;   // ranks may be skewed by lazy initialisation or host work: wait up to 10 s
 
 struct ArArgs {
   float* peer[OPE_AR_MAX_WORLD];
@@ -28,6 +28,7 @@ struct ArArgs {
   int64_t max_floats;
   int chunks_max;
   uint32_t epoch;
+  unsigned long long timeout_ticks;   // wall_clock64 ticks (100 MHz)
 };
 
 __device__ __forceinline__ uint32_t* flag_ptr(float* base, int chunks_max, int world, int parity, int src, int chunk) {
@@ -67,7 +68,7 @@ __global__ void __launch_bounds__(kBlock) allreduce_push_kernel(ArArgs a, float*
     const unsigned long long t0 = wall_clock64();
     while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != a.epoch) {
       __builtin_amdgcn_s_sleep(2);
-      if (wall_clock64() - t0 > kTimeoutTicks) {
+      if (wall_clock64() - t0 > a.timeout_ticks) {
         atomicOr(status, 1);
         break;
       }
@@ -167,6 +168,7 @@ extern "C" int ope_allreduce_flat(const ope_allreduce_ctx* ctx, uint32_t epoch, 
   }
   a.rank = ctx->rank; a.world = ctx->world; a.max_floats = ctx->max_floats; a.chunks_max = (int)chunks_of(ctx->max_floats);
   a.epoch = epoch;
+  a.timeout_ticks = (unsigned long long)(ctx->timeout_ms > 0 ? ctx->timeout_ms : kDefaultTimeoutMs) * 100000ull;
   hipLaunchKernelGGL(allreduce_push_kernel, dim3(ope_cdiv(n, kChunk)), dim3(kBlock), 0, (hipStream_t)stream, a, flat, n, status);
   OPE_CHECK_LAUNCH();
   return OPE_OK;

@@ -18,17 +18,18 @@ namespace {
 
 constexpr int kFields = 7;
 constexpr int kBlock = 256;
-constexpr int kTargetFloats = 6144;  // ~24 KB of payload per workgroup
-constexpr int kTileFloats = 7168;    // short-row tiles staged in LDS (28 KB + padding)
-constexpr int kLdsFloats = kTileFloats + 512;
+constexpr int kTargetFloats = 6144;  // insert (row path): ~24 KB of payload per workgroup
+constexpr int kStepBytes = 8192;     // gather: a workgroup reads about this many contiguous bytes of ONE episode
+constexpr int kTileMax = 7168;       // short-row tiles staged in LDS: at most 28 KB (+ padding)
 
 // tuning knobs (defaults = measured best; ope_set_gather_params / OPE_GATHER_* for A/B runs)
 struct GatherTune {
-  int floats = kTargetFloats;  // long rows: payload floats per workgroup
-  int xcd = 8;                 // G > 1: runs of G consecutive logical blocks share an XCD (and its L2)
-  int unroll = 8;              // long rows: rows (16-byte loads per lane) in flight per wave: 4, 8 or 16
+  int floats = kStepBytes / 4;  // gather: contiguous floats of one episode per workgroup (whole time steps)
+  int xcd = 8;                 // > 1: the B workgroups that write one [t][agent][0..B) range run on ONE XCD (one L2)
+  int unroll = 8;              // 16-byte loads in flight per thread: 4, 8 or 16
   int nt = 0;                  // bit 0: non-temporal loads from the store, bit 1: non-temporal stores of the batch
   int small = 1;               // 1: short rows (dim < 128 floats) go through the LDS-transposing tile path
+  int tile = 2048;             // floats per short-row tile (<= kTileMax)
   bool env_read = false;
 };
 GatherTune g_tune;
@@ -42,6 +43,11 @@ void read_env_once() {
   if ((e = getenv("OPE_GATHER_UNROLL"))) g_tune.unroll = atoi(e);
   if ((e = getenv("OPE_GATHER_NT"))) g_tune.nt = atoi(e);
   if ((e = getenv("OPE_GATHER_SMALL"))) g_tune.small = atoi(e);
+  if ((e = getenv("OPE_GATHER_TILE"))) g_tune.tile = atoi(e);
+  if (g_tune.tile < 256) g_tune.tile = 256;
+  if (g_tune.tile > kTileMax) g_tune.tile = kTileMax;
+  if (g_tune.floats < 64) g_tune.floats = 64;
+  if (g_tune.floats > 65536) g_tune.floats = 65536;
 }
 
 struct FieldDesc {
@@ -50,9 +56,12 @@ struct FieldDesc {
   int TT;              // time entries (T or T+1)
   int NA;              // agent axis (1 if none)
   int DD;              // innermost dim
-  int rows_per_block;  // long rows: destination rows (segments of DD floats) per workgroup; tiles: (t, agent) rows per tile
+  int rows_per_block;  // insert (row path): destination rows per workgroup; gather tiles: (t, agent) rows per tile;
+                       // gather steps: time steps per workgroup
   int block_begin;     // first blockIdx.x of this field
-  int tiled;           // 1: LDS-transposing tile path
+  int block_end;       // one past its last blockIdx.x (the range may be padded to a multiple of the XCD run)
+  int block_count;     // workgroups of this field that have work
+  int tiled;           // gather: 1 = LDS-transposing tile path, 0 = episode-contiguous step path
 };
 struct CopyArgs {
   FieldDesc f[kFields];
@@ -63,9 +72,24 @@ struct CopyArgs {
   int unroll;
   int nt;
   int* bad_index;    // device flag: set to 1 if an index was out of range (the offending rows are skipped)
+  int lds_bytes;     // dynamic LDS the tile fields need
 };
 
-__device__ __forceinline__ int64_t checked_index(const int64_t* __restrict__ idx, int i, int capacity, int* bad) {
+// Where the episode indices come from: device memory (device-resident index tensors: prioritized sampling on the device,
+// HIP-graph replays) or the kernel-argument block itself (host index arrays: no upload, no copy-engine -> compute
+// dependency in front of the launch, and the per-workgroup index becomes a scalar load).
+constexpr int kMaxArgIdx = 512;
+struct DevIdx {
+  const int64_t* p;
+  __device__ __forceinline__ int64_t operator[](int i) const { return p[i]; }
+};
+struct ArgIdx {
+  int32_t v[kMaxArgIdx];
+  __device__ __forceinline__ int64_t operator[](int i) const { return (int64_t)v[i]; }
+};
+
+template <class IDX>
+__device__ __forceinline__ int64_t checked_index(const IDX& idx, int i, int capacity, int* bad) {
   const int64_t v = idx[i];
   if (v < 0 || v >= capacity) {
     if (bad) *bad = 1;
@@ -80,8 +104,8 @@ __device__ __forceinline__ int64_t checked_index(const int64_t* __restrict__ idx
 //   GATHER  dst row r = (t*NA + a)*E + b   <- src row (idx[b]*TT + t)*NA + a     (store -> batch)
 //   INSERT  dst row r = (idx[e]*TT + t)*NA + a, numbered r = (e*TT + t)*NA + a  <- src row (t*E + e)*NA + a
 // Returns false (row skipped) if the episode index is out of range.
-template <bool GATHER>
-__device__ __forceinline__ bool row_ptrs(const FieldDesc& F, const CopyArgs& A, const int64_t* __restrict__ idx, int E, int r,
+template <bool GATHER, class IDX>
+__device__ __forceinline__ bool row_ptrs(const FieldDesc& F, const CopyArgs& A, const IDX& idx, int E, int r,
                                          const float*& sp, float*& dp) {
   if (GATHER) {
     const int ta = r / E, b = r - ta * E;
@@ -115,8 +139,8 @@ __device__ __forceinline__ void st_vec(float* p, float __attribute__((ext_vector
 
 // long rows: a wave moves UNROLL rows at a time, 64 lanes striding over the pieces of each; all UNROLL loads of a lane
 // are issued before its first store
-template <bool GATHER, int VEC, int UNROLL, bool NTL, bool NTS>
-__device__ __forceinline__ void copy_rows(const FieldDesc& F, const CopyArgs& A, const int64_t* __restrict__ idx, int E, int blk) {
+template <bool GATHER, int VEC, int UNROLL, bool NTL, bool NTS, class IDX>
+__device__ __forceinline__ void copy_rows(const FieldDesc& F, const CopyArgs& A, const IDX& idx, int E, int blk) {
   typedef float vec_t __attribute__((ext_vector_type(VEC)));
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n_rows = E * F.TT * F.NA;
@@ -155,12 +179,13 @@ __device__ __forceinline__ void copy_rows(const FieldDesc& F, const CopyArgs& A,
 // [b][L] with an odd row stride (conflict-free for the transposing reads), one contiguous run out in 16-byte stores
 // (gather only: the staged side of an insert is [t][episode][agent][dim], not [t][agent][episode][dim], and inserts are
 // off the training step -- they keep the row path).
-// x / d for 0 <= x < 2^15, 1 <= d < 512 via a float reciprocal: (x + 0.5) / d is at least 0.5/d away from an integer
-// and the float error is below 2^15 * 2^-23, so the truncation is exact. (A runtime integer division costs ~40 instructions.)
+// x / d for 0 <= x < 2^20 via a float reciprocal: (x + 0.5) / d is at least 0.5/d away from an integer and the float
+// error is below (x/d) * 2^-22, so the truncation is exact (checked exhaustively for x < 2^20 over d = 1..600 and a set of
+// larger d). A runtime integer division costs ~40 instructions; every use here keeps x below 2^17.
 __device__ __forceinline__ int fast_div(int x, float inv_d) { return (int)(((float)x + 0.5f) * inv_d); }
 
-__device__ __forceinline__ void gather_tile(const FieldDesc& F, const CopyArgs& A, const int64_t* __restrict__ idx, int E, int blk,
-                                            float* lds) {
+template <class IDX>
+__device__ __forceinline__ void gather_tile(const FieldDesc& F, const CopyArgs& A, const IDX& idx, int E, int blk, float* lds) {
   const int R = F.TT * F.NA;                   // (t, agent) rows per episode
   const int ta0 = blk * F.rows_per_block;
   const int KR = min(F.rows_per_block, R - ta0);
@@ -217,8 +242,45 @@ __device__ __forceinline__ void gather_tile(const FieldDesc& F, const CopyArgs& 
   }
 }
 
-template <bool GATHER, int UNROLL, bool NTL, bool NTS>
-__device__ __forceinline__ void copy_dispatch(const FieldDesc& F, const CopyArgs& A, const int64_t* __restrict__ idx, int blk) {
+// Gather, long rows (and short rows when the tile path is off): a workgroup = (KT consecutive time steps, ONE sampled
+// episode b). Its source is ONE contiguous, line-aligned run of KT*NA*DD floats of episode idx[b] (an episode-major store
+// makes every time step of an episode contiguous over agents and features), read with every lane busy; its destination is
+// KT*NA rows of DD floats at [t][agent][b]. Workgroups are numbered (time-block major, b minor), and the XCD remap in the
+// kernel puts the B workgroups of one time block -- whose destination rows are neighbours in memory and share their
+// boundary cache lines -- on the same XCD, so the partial lines meet in one L2. Measured against the round-1 mapping
+// (workgroup = one contiguous destination range, 1008-byte source rows from B different episodes): 3s5z obs 17.2 -> 14.5 us
+// (5.4 TB/s, 96 % of a plain contiguous copy of the same bytes), MMM2 obs (8-byte vectors) 183 -> 130 us
+// (tools/microbench_gather.hip, profiles/r02_microbench_gather_*.txt).
+template <int VEC, int UNROLL, bool NTL, bool NTS, class IDX>
+__device__ __forceinline__ void gather_steps(const FieldDesc& F, const CopyArgs& A, const IDX& idx, int E, int blk) {
+  typedef float vec_t __attribute__((ext_vector_type(VEC)));
+  const int KT = F.rows_per_block;
+  const int tb = blk / E, b = blk - tb * E;
+  const int t0 = tb * KT, nt = min(KT, F.TT - t0);
+  const int64_t e = checked_index(idx, b, A.capacity, A.bad_index);
+  if (e < 0) return;
+  const int pieces = F.DD / VEC, total = nt * F.NA * pieces;
+  const float* sbase = F.src + ((int64_t)e * F.TT + t0) * F.NA * F.DD;
+  float* dbase = F.dst + ((int64_t)t0 * F.NA * E + b) * F.DD;      // row (k = (t - t0)*NA + a) at dbase + k*E*DD
+  const float inv_p = 1.0f / (float)pieces;
+  const int64_t row_stride = (int64_t)E * F.DD;
+  for (int q0 = threadIdx.x; q0 < total; q0 += kBlock * UNROLL) {
+    vec_t v[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) v[u] = ld_vec<VEC, NTL>(sbase + (int64_t)min(q0 + kBlock * u, total - 1) * VEC);
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int q = q0 + kBlock * u;
+      if (q < total) {
+        const int row = fast_div(q, inv_p), pc = q - row * pieces;
+        st_vec<VEC, NTS>(dbase + row * row_stride + pc * VEC, v[u]);
+      }
+    }
+  }
+}
+
+template <bool GATHER, int UNROLL, bool NTL, bool NTS, class IDX>
+__device__ __forceinline__ void copy_dispatch(const FieldDesc& F, const CopyArgs& A, const IDX& idx, int blk) {
   const int vec = (F.DD % 4 == 0) ? 4 : ((F.DD % 2 == 0) ? 2 : 1);
   if (vec == 4)
     copy_rows<GATHER, 4, UNROLL, NTL, NTS>(F, A, idx, A.n_episodes, blk);
@@ -228,42 +290,51 @@ __device__ __forceinline__ void copy_dispatch(const FieldDesc& F, const CopyArgs
     copy_rows<GATHER, 1, UNROLL, NTL, NTS>(F, A, idx, A.n_episodes, blk);
 }
 
-template <bool GATHER, int UNROLL, int NT>
-__global__ void __launch_bounds__(kBlock) episode_copy_kernel(CopyArgs args, const int64_t* __restrict__ idx) {
-  __shared__ float lds[GATHER ? kLdsFloats : 4];
+template <bool GATHER, int UNROLL, int NT, class IDX>
+__global__ void __launch_bounds__(kBlock) episode_copy_kernel(CopyArgs args, IDX idx) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // sized by the launch: what the tile fields need, else nothing
   // Hardware deals workgroups round-robin over the 8 XCDs, each with a private L2. Neighbouring destination ranges read
   // neighbouring (line-sharing) source rows of the same episodes, so runs of G consecutive logical blocks are remapped onto
   // ONE XCD (the G blocks of a run are dispatched 8 apart, i.e. close in time), runs interleaved over the XCDs so that
   // every XCD still sees every field.
   int bid = blockIdx.x;
-  const int G = args.xcd_swizzle;
+  const int G = args.xcd_swizzle;     // gather: B (runs of B consecutive logical workgroups on one XCD); insert: the knob
   if (G > 1 && bid < (args.total_blocks / (8 * G)) * (8 * G)) {
     const int super = bid / (8 * G), w = bid - super * (8 * G);
     bid = (super * 8 + (w & 7)) * G + (w >> 3);
   }
   int f = 0;
 #pragma unroll
-  for (int i = 1; i < kFields; ++i)
-    if (bid >= args.f[i].block_begin) f = i;
+  for (int i = 0; i < kFields; ++i)
+    if (bid >= args.f[i].block_begin && bid < args.f[i].block_end) f = i;
   const FieldDesc& F = args.f[f];
   const int blk = bid - F.block_begin;
-  if (GATHER && F.tiled) {
-    gather_tile(F, args, idx, args.n_episodes, blk, lds);
+  if (GATHER) {
+    if (blk >= F.block_count) return;            // padding that keeps the fields' XCD runs aligned
+    if (F.tiled) {
+      gather_tile(F, args, idx, args.n_episodes, blk, lds);
+      return;
+    }
+    const int vec = (F.DD % 4 == 0) ? 4 : ((F.DD % 2 == 0) ? 2 : 1);
+    if (vec == 4) gather_steps<4, UNROLL, (NT & 1) != 0, (NT & 2) != 0>(F, args, idx, args.n_episodes, blk);
+    else if (vec == 2) gather_steps<2, UNROLL, (NT & 1) != 0, (NT & 2) != 0>(F, args, idx, args.n_episodes, blk);
+    else gather_steps<1, UNROLL, (NT & 1) != 0, (NT & 2) != 0>(F, args, idx, args.n_episodes, blk);
     return;
   }
   copy_dispatch<GATHER, UNROLL, (NT & 1) != 0, (NT & 2) != 0>(F, args, idx, blk);
 }
 
-template <bool GATHER>
-void launch_copy(const CopyArgs& args, const int64_t* idx, hipStream_t st) {
+template <bool GATHER, class IDX>
+void launch_copy(const CopyArgs& args, const IDX& idx, hipStream_t st) {
   const dim3 grid(args.total_blocks), block(kBlock);
+  const size_t lds = (size_t)args.lds_bytes;
   // one instantiation per variant: a single kernel holding all of them would be allocated the registers of the largest
-  if (args.unroll == 4) hipLaunchKernelGGL((episode_copy_kernel<GATHER, 4, 0>), grid, block, 0, st, args, idx);
-  else if (args.unroll == 16) hipLaunchKernelGGL((episode_copy_kernel<GATHER, 16, 0>), grid, block, 0, st, args, idx);
-  else if (args.nt == 1) hipLaunchKernelGGL((episode_copy_kernel<GATHER, 8, 1>), grid, block, 0, st, args, idx);
-  else if (args.nt == 2) hipLaunchKernelGGL((episode_copy_kernel<GATHER, 8, 2>), grid, block, 0, st, args, idx);
-  else if (args.nt == 3) hipLaunchKernelGGL((episode_copy_kernel<GATHER, 8, 3>), grid, block, 0, st, args, idx);
-  else hipLaunchKernelGGL((episode_copy_kernel<GATHER, 8, 0>), grid, block, 0, st, args, idx);
+  if (args.unroll == 4) hipLaunchKernelGGL((episode_copy_kernel<GATHER, 4, 0, IDX>), grid, block, lds, st, args, idx);
+  else if (args.unroll == 16) hipLaunchKernelGGL((episode_copy_kernel<GATHER, 16, 0, IDX>), grid, block, lds, st, args, idx);
+  else if (args.nt == 1) hipLaunchKernelGGL((episode_copy_kernel<GATHER, 8, 1, IDX>), grid, block, lds, st, args, idx);
+  else if (args.nt == 2) hipLaunchKernelGGL((episode_copy_kernel<GATHER, 8, 2, IDX>), grid, block, lds, st, args, idx);
+  else if (args.nt == 3) hipLaunchKernelGGL((episode_copy_kernel<GATHER, 8, 3, IDX>), grid, block, lds, st, args, idx);
+  else hipLaunchKernelGGL((episode_copy_kernel<GATHER, 8, 0, IDX>), grid, block, lds, st, args, idx);
 }
 
 int build_args(const ope_dims* d, const ope_fields* src, const ope_fields* dst, int E, int capacity, bool gather, CopyArgs* out) {
@@ -271,14 +342,27 @@ int build_args(const ope_dims* d, const ope_fields* src, const ope_fields* dst, 
   const int T = d->episode_length, N = d->n_agents, A = d->act_dim, D = d->obs_dim, S = d->state_dim;
   if (T < 1 || N < 1 || A < 1 || D < 1 || S < 1 || E < 1) return OPE_EINVAL;
   read_env_once();
-  const int target = g_tune.floats;
   const float* s[kFields] = {src->obs, src->share_obs, src->acts, src->rewards, src->dones, src->dones_env, src->avail_acts};
   float* t[kFields] = {dst->obs, dst->share_obs, dst->acts, dst->rewards, dst->dones, dst->dones_env, dst->avail_acts};
   const int TT[kFields] = {T + 1, T + 1, T, T, T, T, T + 1};
   const int NA[kFields] = {N, 1, N, N, N, 1, N};
   const int DD[kFields] = {D, S, A, 1, 1, 1, A};
-  int blocks = 0;
-  for (int i = 0; i < kFields; ++i) {
+  int blocks = 0, lds_bytes = 0;
+  const int G = gather ? ((g_tune.xcd > 1) ? E : 1) : g_tune.xcd;
+  // gather: short-row (tile) fields first -- their workgroups run two dependent phases and must not be the tail of the
+  // launch -- then the step-path fields in size order; every field's range is padded to a multiple of the XCD run G
+  int order[kFields] = {0, 1, 2, 3, 4, 5, 6};
+  if (gather) {
+    int n = 0;
+    for (int pass = 0; pass < 2; ++pass)
+      for (int i = 0; i < kFields; ++i) {
+        const int vecw = (DD[i] % 4 == 0) ? 4 : ((DD[i] % 2 == 0) ? 2 : 1);
+        const bool tile = g_tune.small && DD[i] / vecw < 32 && E <= 512 && (int64_t)E * DD[i] <= g_tune.tile;
+        if ((pass == 0) == tile) order[n++] = i;
+      }
+  }
+  for (int oi = 0; oi < kFields; ++oi) {
+    const int i = order[oi];
     FieldDesc& F = out->f[i];
     F.src = s[i];
     F.dst = t[i];
@@ -286,41 +370,60 @@ int build_args(const ope_dims* d, const ope_fields* src, const ope_fields* dst, 
     F.NA = NA[i];
     F.DD = DD[i];
     F.block_begin = blocks;
+    F.block_end = blocks;
+    F.block_count = 0;
     F.tiled = 0;
     const int vecw = (DD[i] % 4 == 0) ? 4 : ((DD[i] % 2 == 0) ? 2 : 1);
-    // short rows: LDS-transposing tiles of KR (t, agent) rows x all E episodes, ~kTileFloats each
-    if (gather && g_tune.small && DD[i] / vecw < 32 && E <= 512 && (int64_t)E * DD[i] <= kTileFloats) {
-      int KR = kTileFloats / (E * DD[i]);
-      if (KR > 256) KR = 256;
-      // keep the tile starts 16-byte aligned on both sides whenever the dimensions allow: KR*DD % 4 == 0
-      while (KR > 1 && ((int64_t)KR * DD[i]) % 4 != 0) --KR;
-      F.tiled = 1;
-      F.rows_per_block = KR;
-      if (s[i] == nullptr || t[i] == nullptr) continue;
-      blocks += ope_cdiv((int64_t)TT[i] * NA[i], KR);
+    const bool present = s[i] != nullptr && t[i] != nullptr;   // field not stored (e.g. no avail_acts): zero blocks
+    if (gather) {
+      if (g_tune.small && DD[i] / vecw < 32 && E <= 512 && (int64_t)E * DD[i] <= g_tune.tile) {
+        // short rows: LDS-transposing tiles of KR (t, agent) rows x all E episodes
+        int KR = g_tune.tile / (E * DD[i]);
+        if (KR > 256) KR = 256;
+        // keep the tile starts 16-byte aligned on both sides whenever the dimensions allow: KR*DD % 4 == 0
+        while (KR > 1 && ((int64_t)KR * DD[i]) % 4 != 0) --KR;
+        F.tiled = 1;
+        F.rows_per_block = KR;
+        if (present) {
+          F.block_count = ope_cdiv((int64_t)TT[i] * NA[i], KR);
+          const int need = E * ((KR * DD[i]) | 1) * (int)sizeof(float);
+          if (need > lds_bytes) lds_bytes = need;
+        }
+      } else {
+        // whole time steps of one episode, about g_tune.floats contiguous floats per workgroup
+        const int step = NA[i] * DD[i];
+        int KT = (g_tune.floats + step / 2) / step;
+        if (KT < 1) KT = 1;
+        if (KT > TT[i]) KT = TT[i];
+        F.rows_per_block = KT;
+        if (present) F.block_count = ope_cdiv(TT[i], KT) * E;
+      }
+      blocks += ope_cdiv(F.block_count, G) * G;
+      F.block_end = blocks;
       continue;
     }
-    // whole groups of E rows (gather: one (t, agent) over all episodes = one contiguous, line-aligned output range)
-    const int unit = gather ? E : NA[i];
+    // insert: whole groups of NA rows
+    const int unit = NA[i];
     // short rows go through the flat one-piece-per-thread path: keep those blocks to ~1 piece per thread so that they
     // are not the tail of the launch
-    const int tgt = (DD[i] / vecw < 32) ? kBlock * vecw : target;
+    const int tgt = (DD[i] / vecw < 32) ? kBlock * vecw : kTargetFloats;
     int groups = tgt / (unit * DD[i]);
     if (groups < 1) groups = 1;
     F.rows_per_block = groups * unit;
-    if (s[i] == nullptr || t[i] == nullptr) continue;  // field not stored (e.g. no avail_acts): zero blocks
-    blocks += ope_cdiv((int64_t)E * TT[i] * NA[i], F.rows_per_block);
+    F.block_end = blocks;
+    if (!present) continue;
+    F.block_count = ope_cdiv((int64_t)E * TT[i] * NA[i], F.rows_per_block);
+    blocks += F.block_count;
+    F.block_end = blocks;
   }
-  // fields with no blocks must not capture any blockIdx: give them the begin of the next one
-  for (int i = kFields - 1; i >= 0; --i)
-    if (s[i] == nullptr || t[i] == nullptr) out->f[i].block_begin = (i + 1 < kFields) ? out->f[i + 1].block_begin : blocks;
   out->n_episodes = E;
   out->capacity = capacity;
   out->total_blocks = blocks;
-  out->xcd_swizzle = g_tune.xcd;   // G = 8: -21 % HBM read traffic at equal or better time
+  out->xcd_swizzle = G;
   out->unroll = g_tune.unroll;
   out->nt = g_tune.nt;
   out->bad_index = nullptr;
+  out->lds_bytes = (lds_bytes + 15) & ~15;
   return OPE_OK;
 }
 
@@ -405,9 +508,10 @@ extern "C" int64_t ope_episode_bytes(const ope_dims* d) {
   return 4 * ((T + 1) * N * D + (T + 1) * S + T * N * A + (T + 1) * N * A + T * N + T * N + T);
 }
 
-extern "C" void ope_set_gather_params(int floats_per_block, int xcd_run, int unroll, int nontemporal, int small_tiles) {
+extern "C" void ope_set_gather_params(int floats_per_block, int xcd_run, int unroll, int nontemporal, int small_tiles, int tile_floats) {
   read_env_once();
-  if (floats_per_block > 0) g_tune.floats = floats_per_block;
+  if (tile_floats > 0) g_tune.tile = tile_floats < 256 ? 256 : (tile_floats > kTileMax ? kTileMax : tile_floats);
+  if (floats_per_block > 0) g_tune.floats = floats_per_block < 64 ? 64 : (floats_per_block > 65536 ? 65536 : floats_per_block);
   if (xcd_run >= 0) g_tune.xcd = xcd_run;
   if (unroll == 4 || unroll == 8 || unroll == 16) g_tune.unroll = unroll;
   if (nontemporal >= 0) g_tune.nt = nontemporal & 3;
@@ -422,8 +526,24 @@ extern "C" int ope_store_gather(const ope_dims* dims, int32_t capacity, const op
   int rc = build_args(dims, store, out, batch, capacity, true, &args);
   if (rc != OPE_OK) return rc;
   args.bad_index = bad_index_flag;
-  // with a hole in the middle (missing field) the "last begin <= bid" scan still works because holes alias the next begin
-  launch_copy<true>(args, inds, (hipStream_t)stream);
+  launch_copy<true>(args, DevIdx{inds}, (hipStream_t)stream);
+  OPE_CHECK_LAUNCH();
+  return OPE_OK;
+}
+
+extern "C" int ope_store_gather_host_inds(const ope_dims* dims, int32_t capacity, const ope_fields* store, const int64_t* inds_host,
+                                          int32_t batch, const ope_fields* out, void* stream) {
+  (void)hipGetLastError();
+  if (capacity < 1 || !inds_host || batch < 1 || batch > kMaxArgIdx) return OPE_EINVAL;
+  ArgIdx ai;
+  for (int i = 0; i < batch; ++i) {
+    if (inds_host[i] < 0 || inds_host[i] >= capacity) return OPE_EINVAL;   // host data: rejected here, like numpy's IndexError
+    ai.v[i] = (int32_t)inds_host[i];
+  }
+  CopyArgs args;
+  int rc = build_args(dims, store, out, batch, capacity, true, &args);
+  if (rc != OPE_OK) return rc;
+  launch_copy<true>(args, ai, (hipStream_t)stream);
   OPE_CHECK_LAUNCH();
   return OPE_OK;
 }
@@ -436,7 +556,7 @@ extern "C" int ope_store_insert(const ope_dims* dims, int32_t capacity, const op
   int rc = build_args(dims, staged, store, n_insert, capacity, false, &args);
   if (rc != OPE_OK) return rc;
   args.bad_index = bad_index_flag;
-  launch_copy<false>(args, slots, (hipStream_t)stream);
+  launch_copy<false>(args, DevIdx{slots}, (hipStream_t)stream);
   OPE_CHECK_LAUNCH();
   return OPE_OK;
 }

@@ -37,7 +37,7 @@ class OneShotAllreduce(object):
     world == 1 (no process group needed): the vector makes a round trip through the own slot."""
     MAX_FLOATS = 1 << 18      # 1 MiB slots: every flat gradient vector of the BASELINE configs is < 0.6 MB
 
-    def __init__(self, device, rank=0, world_size=1, max_floats=None, group=None):
+    def __init__(self, device, rank=0, world_size=1, max_floats=None, group=None, timeout_ms=0):
         import ctypes as C
         from . import _lib
         self._lib, self._C = _lib, C
@@ -74,6 +74,7 @@ class OneShotAllreduce(object):
             peers[self.rank] = buf.value
             self.ctx = _lib.AllreduceCtx()
             self.ctx.rank, self.ctx.world, self.ctx.max_floats = self.rank, self.world, self.max_floats
+            self.ctx.timeout_ms = int(timeout_ms)
             for q in range(self.world):
                 self.ctx.peer[q] = peers[q]
             self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
@@ -103,6 +104,11 @@ _fast = None          # OneShotAllreduce once setup_fast_allreduce() has verifie
 _fast_note = "rccl (torch.distributed all_reduce)"
 
 
+def fast_allreduce_failed():
+    """True if the one-shot all-reduce is active and any of its calls gave up waiting for a peer (results then invalid)."""
+    return _fast is not None and _fast.timed_out()
+
+
 def allreduce_backend():
     return "one-shot xGMI push (ope_allreduce_flat)" if _fast is not None else _fast_note
 
@@ -120,7 +126,7 @@ def setup_fast_allreduce(device, group=None):
     rank, world_size = world()
     ok, err, ar = 1, "", None
     try:
-        ar = OneShotAllreduce(device, rank, world_size, group=group)
+        ar = OneShotAllreduce(device, rank, world_size, group=group, timeout_ms=500)    # verification: fail fast
     except Exception as e:     # allocation / IPC not available on this system
         ok, err = 0, repr(e)
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
@@ -137,6 +143,7 @@ def setup_fast_allreduce(device, group=None):
     t = torch.tensor([ok], dtype=torch.int32, device=device)
     torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN, group=group)
     if int(t.item()) == 1:
+        ar.ctx.timeout_ms = 0      # default (10 s) from here on: training ranks may be skewed by host work
         _fast = ar
         return True
     _fast_note = "rccl (one-shot xGMI path not verified: %s)" % (err or "another rank failed")

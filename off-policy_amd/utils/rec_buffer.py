@@ -23,7 +23,7 @@ from .ring import RingIndex
 from .segment_tree import SumSegmentTree, MinSegmentTree
 from .spaces import get_dim_from_space
 
-_INDS_MODE = os.environ.get("OPE_INDS_MODE", "copy")    # copy | zerocopy (RecPolicyBuffer._upload_inds)
+_INDS_MODE = os.environ.get("OPE_INDS_MODE", "args")    # args (kernel-argument block, B <= 512) | copy | zerocopy (RecPolicyBuffer._upload_inds)
 
 _FIELD_ORDER = ("obs", "share_obs", "acts", "rewards", "dones", "dones_env", "avail_acts")
 
@@ -198,17 +198,21 @@ class RecPolicyBuffer(object):
         `timing_events`: optional (start, end) torch.cuda.Event pair recorded tightly around the gather launch.
         `out`: optional destination from `alloc_batch` (HIP-graph replays read the batch from fixed addresses); the
         default is a fresh batch per call, like the reference's fancy-index copy."""
+        host_inds = None
         if torch.is_tensor(sample_inds):     # indices already on the device (HIP-graph replays keep them in a static tensor)
             assert sample_inds.dtype == torch.int64 and sample_inds.device == self.device, (sample_inds.dtype, sample_inds.device)
             dev_inds, B = sample_inds.contiguous(), int(sample_inds.shape[0])
         else:
-            inds = np.asarray(sample_inds, dtype=np.int64)
+            inds = np.ascontiguousarray(np.asarray(sample_inds, dtype=np.int64))
             B = int(inds.shape[0])
             if B and (inds.min() < -self.buffer_size or inds.max() >= self.buffer_size):
                 raise IndexError("index out of bounds for a buffer of %d episodes" % self.buffer_size)   # as numpy fancy indexing
             if B and inds.min() < 0:
                 inds = np.where(inds < 0, inds + self.buffer_size, inds)
-            dev_inds = self._upload_inds(inds)
+            if B <= 512 and _INDS_MODE != "copy":
+                host_inds = inds            # travel inside the kernel-argument block: no upload at all
+            else:
+                dev_inds = self._upload_inds(inds)
         d = self.dims
         if out is None:
             out = self.alloc_batch(B)
@@ -217,11 +221,15 @@ class RecPolicyBuffer(object):
         of, sf = self._fields(out), self._store_fields()
         if timing_events is not None:
             timing_events[0].record()
-        _lib.check(_lib.lib.ope_store_gather(C.byref(d), self.buffer_size, C.byref(sf), _lib.ptr(dev_inds), B,
-                                             C.byref(of), _lib.ptr(self._bad_index), _lib.current_stream()), "ope_store_gather")
+        if host_inds is not None:
+            _lib.check(_lib.lib.ope_store_gather_host_inds(C.byref(d), self.buffer_size, C.byref(sf), host_inds.ctypes.data_as(C.c_void_p), B,
+                                                           C.byref(of), _lib.current_stream()), "ope_store_gather_host_inds")
+        else:
+            _lib.check(_lib.lib.ope_store_gather(C.byref(d), self.buffer_size, C.byref(sf), _lib.ptr(dev_inds), B,
+                                                 C.byref(of), _lib.ptr(self._bad_index), _lib.current_stream()), "ope_store_gather")
         if timing_events is not None:
             timing_events[1].record()
-        if not torch.is_tensor(sample_inds):
+        if host_inds is None and not torch.is_tensor(sample_inds):
             self._release_inds()
         if self.use_reward_normalization:
             _lib.check(_lib.lib.ope_reward_normalize(_lib.ptr(out["rewards"]), out["rewards"].numel(), _lib.ptr(self.reward_stats()),

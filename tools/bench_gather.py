@@ -30,20 +30,20 @@ for k in ("obs", "share_obs", "acts", "rewards", "dones", "dones_env", "avail_ac
     getattr(pb, k).normal_()
 ep_bytes = int(_lib.lib.ope_episode_bytes(C.byref(pb.dims)))
 byt = 2.0 * B * ep_bytes
-DEFAULT = dict(floats=6144, xcd=8, unroll=8, nt=0, small=1)
-cfgs = [("default", {})]
+DEFAULT = dict(floats=2048, xcd=8, unroll=8, nt=0, small=1, tile=2048)
+cfgs = [("default", {}), ("default, device-resident indices", dict(dev=1))]
 if sweep:
-    cfgs += [("small=0 (r01 short-row path)", dict(small=0)), ("nt loads", dict(nt=1)), ("nt stores", dict(nt=2)), ("nt both", dict(nt=3)),
-             ("unroll 4", dict(unroll=4)), ("unroll 16", dict(unroll=16)), ("floats 3072", dict(floats=3072)),
-             ("floats 12288", dict(floats=12288)), ("floats 24576", dict(floats=24576)), ("xcd 1", dict(xcd=1)), ("xcd 4", dict(xcd=4)),
-             ("xcd 16", dict(xcd=16)), ("unroll 4 + floats 3072", dict(unroll=4, floats=3072)),
-             ("unroll 16 + floats 12288", dict(unroll=16, floats=12288))]
+    cfgs += [("small=0 (short rows through the step path)", dict(small=0)), ("tile 1024", dict(tile=1024)), ("tile 4096", dict(tile=4096)),
+             ("tile 7168", dict(tile=7168)), ("nt loads", dict(nt=1)), ("nt stores", dict(nt=2)), ("nt both", dict(nt=3)),
+             ("unroll 4", dict(unroll=4)), ("unroll 16", dict(unroll=16)), ("floats 1024", dict(floats=1024)),
+             ("floats 4096", dict(floats=4096)), ("floats 8192", dict(floats=8192)), ("xcd off", dict(xcd=1)),
+             ("small=0 + floats 4096", dict(small=0, floats=4096))]
 
 
 def apply(over):
     c = dict(DEFAULT)
-    c.update(over)
-    _lib.lib.ope_set_gather_params(c["floats"], c["xcd"], c["unroll"], c["nt"], c["small"])
+    c.update({k: v for k, v in over.items() if k != "dev"})
+    _lib.lib.ope_set_gather_params(c["floats"], c["xcd"], c["unroll"], c["nt"], c["small"], c["tile"])
 
 
 rng = np.random.RandomState(0)
@@ -70,7 +70,8 @@ for r in range(ROUNDS):
         apply(over)
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(PER)]
         for i in range(PER):
-            pb.sample_inds(rng.randint(0, NEP, B), timing_events=ev[i], out=out)
+            ii = rng.randint(0, NEP, B)
+            pb.sample_inds(torch.as_tensor(ii, device="cuda:0") if over.get("dev") else ii, timing_events=ev[i], out=out)
         torch.cuda.synchronize()
         times[name] += [a.elapsed_time(b) for a, b in ev[3:]]
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(PER)]
