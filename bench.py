@@ -41,7 +41,9 @@ def parse():
                     help="N > 1: what `value` reports. Default strong = BASELINE.json's multi-GPU configs (ONE batch of B samples "
                          "sharded over the N GPUs, B/N per GPU); the weak-scaling throughput (B per GPU) is measured in the same run "
                          "and reported beside it as `weak_scaling`. --scaling weak swaps the two.")
-    ap.add_argument("--episodes", type=int, default=256, help="synthetic episodes resident in the replay store")
+    ap.add_argument("--episodes", type=int, default=None, help="synthetic episodes resident in the replay store; default 5000 for the QMIX "
+                    "workloads (the reference default buffer_size, config.py:37: 7.5 GB at 3s5z, far beyond the 256 MiB Infinity Cache), 512 "
+                    "for the recurrent MADDPG family at MMM2 size (6.5 GB)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="QMIX workloads: replay the training kernels of a step as one captured HIP graph")
     ap.add_argument("--no-graph", action="store_true", help="MLP MADDPG/MATD3: launch the ~45 kernels of an update one by one instead "
@@ -215,6 +217,8 @@ def main():
         return main_rddpg(a)
     if a.batch is None:
         a.batch = 32
+    if a.episodes is None:
+        a.episodes = 5000
     world, rank, dev = dist_setup()
     assert world == a.gpus, "--gpus must equal WORLD_SIZE"
 
@@ -542,6 +546,8 @@ def main_rddpg(a):
     td3 = algo == "rmatd3"
     dims = DIMS[mapname]
     batch = a.batch or 128
+    if a.episodes is None:
+        a.episodes = 512
     args = default_args(use_per=True)
     torch.manual_seed(1)
     np.random.seed(1)

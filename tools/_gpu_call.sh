@@ -1,17 +1,13 @@
-mkdir -p gpurun_out/r02g
+mkdir -p gpurun_out/r02h
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_gpu_store.py -m gpu -q --timeout 600 -p no:cacheprovider 2>&1 | tail -3
-for v in "default" "OPE_GATHER_SMALL=0" "OPE_GATHER_TILE=1024" "OPE_GATHER_TILE=4096" "OPE_GATHER_UNROLL=4" "OPE_GATHER_FLOATS=4096"; do
-  if [ "$v" = default ]; then envs=""; else envs="$v"; fi
-  env $envs rocprofv3 --kernel-trace --stats -d gpurun_out/r02g/prof_$v -o q -- python bench.py --steps 60 --warmup 10 --episodes 5000 --no-cpu-baseline > gpurun_out/r02g/bench_$v.json 2> gpurun_out/r02g/bench_$v.err
-  db=$(find gpurun_out/r02g/prof_$v -name "*.db" | head -1)
-  echo "== $v"; python tools/rocprof_db_stats.py $db | grep "episode_copy_kernel<true\|^void  \|total kernel" | head -3
-  python - "$db" <<'PY'
-import sqlite3,sys
-c=sqlite3.connect(sys.argv[1])
-for r in c.execute("select name,count(*),avg(end-start),min(end-start) from kernels where name like '%episode_copy_kernel<true%' group by name"):
-    print("   gather:", r[1], "calls avg %.2f us min %.2f us" % (r[2]/1e3, r[3]/1e3))
-PY
-  rm -rf gpurun_out/r02g/prof_$v
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/r02h/q_$c -o x -- python bench.py --steps 12 --warmup 4 --no-cpu-baseline > gpurun_out/r02h/q_$c.json 2> gpurun_out/r02h/q_$c.err
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/r02h/r_$c -o x -- python bench.py --workload rmatd3_MMM2 --steps 8 --warmup 3 --no-cpu-baseline > gpurun_out/r02h/r_$c.json 2> gpurun_out/r02h/r_$c.err
 done
+find gpurun_out/r02h -name "*counter_collection.csv" | head
+for d in q r; do for c in FETCH_SIZE WRITE_SIZE; do f=$(find gpurun_out/r02h/${d}_$c -name "*counter_collection.csv" | head -1); grep "episode_copy_kernel<true" $f > gpurun_out/r02h/${d}_$c.csv.tmp; head -1 $f > gpurun_out/r02h/${d}_$c.csv; cat gpurun_out/r02h/${d}_$c.csv.tmp >> gpurun_out/r02h/${d}_$c.csv; rm gpurun_out/r02h/${d}_$c.csv.tmp; rm -rf gpurun_out/r02h/${d}_$c; done; done
+python tools/gather_traffic.py 3s5z:32:5000 95563264 gpurun_out/r02h/q_FETCH_SIZE.csv gpurun_out/r02h/q_WRITE_SIZE.csv
+python tools/gather_traffic.py MMM2:128:512 $(python -c "print(2*128*3186968)") gpurun_out/r02h/r_FETCH_SIZE.csv gpurun_out/r02h/r_WRITE_SIZE.csv
+cp profiles/gather_traffic.json gpurun_out/r02h/
+cat gpurun_out/r02h/q_WRITE_SIZE.json; cat gpurun_out/r02h/r_WRITE_SIZE.json | cut -c1-600
