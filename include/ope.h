@@ -211,6 +211,11 @@ typedef struct ope_adam_cfg {
   int32_t* step_counter;  /* optional DEVICE int32 holding the number of Adam steps taken so far. When non-NULL, `step` is
                            * ignored: the call increments the counter on the device and uses the new value as t, so a
                            * captured HIP graph of the update can be replayed with advancing bias correction.          */
+  const float* sumsq_partials; /* optional DEVICE array of n_sumsq_partials floats whose sum is sum_i grad[i]^2 over the n    */
+  int32_t n_sumsq_partials;    /* optimised elements, produced together with `grad` (ope_qmix_loss_and_grad leaves them in
+                                * its workspace region "gsq_part", see ope_qmix_workspace_find). When given (and
+                                * step_counter is NULL) the call skips its own norm pass over the gradient. ONLY valid if
+                                * `grad` was not modified since (i.e. not on the all-reduced gradient of a multi-GPU run). */
 } ope_adam_cfg;
 int64_t ope_adam_scratch_floats(int64_t n);
 int ope_adam_step(const ope_adam_cfg* cfg, int64_t n, float* theta, float* theta_tgt, float* adam_m, float* adam_v,

@@ -111,6 +111,7 @@ class QMix(object):
         self._scratch = torch.zeros(int(_lib.lib.ope_adam_scratch_floats(self.numel)), **self.tpdv)
         self._stats = torch.zeros(4, **self.tpdv)
         self._ws = {}
+        self._gsq = {}
         self.fuse_soft_update = False       # True: Polyak inside ope_adam_step; soft_target_updates() then skips once
         self._polyak_done = False
         if args.use_double_q:
@@ -213,6 +214,17 @@ class QMix(object):
         if self.optimizer.step_dev is not None:     # HIP-graph replays: the count advances on the device
             ac.step_counter = _lib.ptr(self.optimizer.step_dev).value
         ac.qtot_denominator = float(self.episode_length * B * world_size)
+        if world_size == 1 and self.optimizer.step_dev is None:
+            # the finalize launch of ope_qmix_loss_and_grad left per-workgroup partial sums of grad^2 in the workspace: the
+            # optimizer call then needs no norm pass of its own (not valid for an all-reduced gradient)
+            gsq = self._gsq.get(B)
+            if gsq is None:
+                n = C.c_int64(0)
+                off = _lib.lib.ope_qmix_workspace_find(C.byref(cfg), b"gsq_part", C.byref(n))
+                gsq = self._gsq[B] = (int(off), int(n.value)) if off >= 0 else (-1, 0)
+            if gsq[0] >= 0:
+                ac.sumsq_partials = ws.data_ptr() + gsq[0]
+                ac.n_sumsq_partials = gsq[1]
         stats = torch.empty(4, **self.tpdv)
         _lib.check(_lib.lib.ope_adam_step(C.byref(ac), self.numel, _lib.ptr(self.theta), _lib.ptr(self.theta_tgt),
                                           _lib.ptr(self.optimizer.exp_avg), _lib.ptr(self.optimizer.exp_avg_sq),

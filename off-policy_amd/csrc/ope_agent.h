@@ -1,6 +1,7 @@
 // Argument blocks and device helpers shared by the agent-network kernels (forward and backward).
 #pragma once
 #include "ope_common.h"
+#include "ope_wgrad.h"
 
 namespace ope {
 
@@ -61,6 +62,8 @@ struct HeadFwdArgs {
   float* q_out;                         // MODE 1: [R][A]
   float* q_all;                         // optional debug output [R][A]
   int64_t r_begin;                      // first row handled by this launch (time-chunked launches); rows [r_begin, R)
+  Transp4 side;                         // weight transposes carried as extra workgroups of this launch (side.total = 0: none)
+  int main_blocks;                      // workgroups doing head work; blockIdx.x >= main_blocks run `side` (set by the launcher)
 };
 
 struct HeadBwdArgs {

@@ -69,7 +69,8 @@ struct Plan {
   int64_t mu0, rstd0, xhat1, rstd1, mask1, xhat2, rstd2, mask2, gi, h, rg, zg, ng, ghn, xhat_o, rstd_o, act_idx,
       agent_q, agent_nq, gi_t, h_t, qtot, nqtot, hw1, hw2, hb2, v1, hpre, v2, loss_part, err_abs, dqtot, d_agent_q,
       d_b1, d_v2, d_v1, d_hw1, d_hw2, d_hb2, dh_out, dqoh, dgi, dghn, dz1, dz2, thetaT, mixT, raw_agent, raw_mixer,
-      rsum, q_all, loss_tot, ln_zero, ln_one, dh_carry, dbg;
+      rsum, q_all, loss_tot, ln_zero, ln_one, dh_carry, dbg, gsq_part;
+  int n_gsq;
 };
 
 int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
@@ -151,6 +152,10 @@ void make_plan(const ope_qmix_cfg* c, Plan* p) {
   p->loss_tot = W.add("loss_tot", 4);
   p->ln_zero = W.add("ln_zero", R);   // mu = 0 / rstd = 1 vectors: "no LayerNorm" operands of the wgrad kernel
   p->ln_one = W.add("ln_one", R);
+  // per-workgroup partial sums of grad^2 written by the finalize launch (zero beyond the launch's workgroups: the region
+  // is zero-filled once at workspace_init); upper bound of finalize_blocks()
+  p->n_gsq = ope_cdiv((int64_t)p->P + OPE_GRAD_TAIL, 256) + 1 + ope_cdiv((int64_t)2 * (p->D + 3 * OPE_H) * 64, 256) + 4;
+  p->gsq_part = W.add("gsq_part", p->n_gsq);
   p->err_abs = W.add("err_abs", TB); p->dqtot = W.add("dqtot", 4 * TB); p->d_agent_q = W.add("d_agent_q", TB * p->N);
   p->d_b1 = W.add("d_b1", TB * OPE_MIX); p->d_v2 = W.add("d_v2", TB * OPE_MIX); p->d_v1 = W.add("d_v1", TB * p->NM);
   p->d_hw1 = W.add("d_hw1", TB * OPE_HYP); p->d_hw2 = W.add("d_hw2", TB * OPE_HYP); p->d_hb2 = W.add("d_hb2", TB * OPE_HYP);
@@ -238,6 +243,7 @@ extern "C" int ope_qmix_workspace_init(const ope_qmix_cfg* cfg, void* workspace,
   float* W = (float*)workspace;
   int rc;
   if ((rc = launch_fill(W + p.ln_zero, p.R, 0.f, (hipStream_t)stream))) return rc;
+  if ((rc = launch_fill(W + p.gsq_part, p.n_gsq, 0.f, (hipStream_t)stream))) return rc;
   return launch_fill(W + p.ln_one, p.R, 1.f, (hipStream_t)stream);
 }
 
@@ -310,26 +316,11 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
     if ((rc = launch_gru_fwd(gf, scan_st))) return rc;
     if (C > 1 && hipEventRecord(sp->scan_done[c], side) != hipSuccess) return OPE_ELAUNCH;
   }
-  for (int c = 0; c < C; ++c) {   // heads of chunk c as soon as its scan is done
-    if (C > 1 && hipStreamWaitEvent(st, sp->scan_done[c], 0) != hipSuccess) return OPE_ELAUNCH;
-    HeadFwdArgs hf;
-    memset(&hf, 0, sizeof(hf));
-    hf.r_begin = (int64_t)p.tb[c] * p.NB; hf.R = (int64_t)p.tb[c + 1] * p.NB;
-    hf.NB = p.NB; hf.B = p.B; hf.N = p.N; hf.T = p.T; hf.A = p.A; hf.theta0 = theta; hf.theta1 = theta_tgt; hf.L = p.AL;
-    hf.h0 = W + p.h; hf.h1 = W + p.h_t; hf.acts = batch->acts; hf.avail = batch->avail_acts; hf.double_q = cfg->use_double_q;
-    hf.no_ln = p.mlp; hf.target_mask_avail = p.mlp;
-    hf.agent_q = W + p.agent_q; hf.agent_nq = W + p.agent_nq; hf.act_idx = (int*)(W + p.act_idx);
-    hf.xhat_o = W + p.xhat_o; hf.rstd_o = W + p.rstd_o; hf.q_out = nullptr; hf.q_all = g_debug ? W + p.q_all : nullptr;
-    if ((rc = launch_head_fwd(hf, 0, st))) return rc;
-  }
-
-  // ---- mixer forward + TD + mixer backward ----
-  TdArgs td;
-  td.B = p.B; td.N = p.N; td.gamma = cfg->gamma; td.use_huber = cfg->use_huber; td.huber_delta = cfg->huber_delta;
-  td.rewards = batch->rewards; td.dones_env = batch->dones_env; td.per_weights = cfg->use_per ? per_weights : nullptr;
-  {  // transposed copies of the matrices the backward chains read column-wise (one launch)
-    Transp4 tr;
-    memset(&tr, 0, sizeof(tr));
+  // transposed copies of the matrices the backward chains read column-wise: carried by the head launch as extra
+  // workgroups when that is the MFMA head kernel in one piece, else one launch of their own
+  Transp4 tr;
+  memset(&tr, 0, sizeof(tr));
+  {
     int nt = 0, tot = 0;
     auto add = [&](const float* src, int rows, int cols, float* dst) {
       tr.src[nt] = src; tr.dst[nt] = dst; tr.rows[nt] = rows; tr.cols[nt] = cols; tr.begin[nt] = tot; tot += rows * cols; ++nt;
@@ -341,8 +332,28 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
       add(theta + p.ML.w2b_w, OPE_MIX, OPE_HYP, W + p.mixT + (int64_t)OPE_HYP * p.NM);
     }
     tr.n = nt; tr.total = tot;
-    if ((rc = launch_transpose4(tr, st))) return rc;
   }
+  const bool ride = C == 1 && p.A <= 32;       // launch_head_fwd(mode 0) picks head_fwd_mfma for A <= 32
+  if (!ride)
+    if ((rc = launch_transpose4(tr, st))) return rc;
+  for (int c = 0; c < C; ++c) {   // heads of chunk c as soon as its scan is done
+    if (C > 1 && hipStreamWaitEvent(st, sp->scan_done[c], 0) != hipSuccess) return OPE_ELAUNCH;
+    HeadFwdArgs hf;
+    memset(&hf, 0, sizeof(hf));
+    hf.r_begin = (int64_t)p.tb[c] * p.NB; hf.R = (int64_t)p.tb[c + 1] * p.NB;
+    hf.NB = p.NB; hf.B = p.B; hf.N = p.N; hf.T = p.T; hf.A = p.A; hf.theta0 = theta; hf.theta1 = theta_tgt; hf.L = p.AL;
+    hf.h0 = W + p.h; hf.h1 = W + p.h_t; hf.acts = batch->acts; hf.avail = batch->avail_acts; hf.double_q = cfg->use_double_q;
+    hf.no_ln = p.mlp; hf.target_mask_avail = p.mlp;
+    hf.agent_q = W + p.agent_q; hf.agent_nq = W + p.agent_nq; hf.act_idx = (int*)(W + p.act_idx);
+    hf.xhat_o = W + p.xhat_o; hf.rstd_o = W + p.rstd_o; hf.q_out = nullptr; hf.q_all = g_debug ? W + p.q_all : nullptr;
+    if (ride) hf.side = tr;
+    if ((rc = launch_head_fwd(hf, 0, st))) return rc;
+  }
+
+  // ---- mixer forward + TD + mixer backward ----
+  TdArgs td;
+  td.B = p.B; td.N = p.N; td.gamma = cfg->gamma; td.use_huber = cfg->use_huber; td.huber_delta = cfg->huber_delta;
+  td.rewards = batch->rewards; td.dones_env = batch->dones_env; td.per_weights = cfg->use_per ? per_weights : nullptr;
   if (cfg->vdn) {
     VdnArgs va;
     va.TB = (int)p.TB; va.N = p.N; va.td = td; va.agent_q = W + p.agent_q; va.agent_nq = W + p.agent_nq;
@@ -520,7 +531,8 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
   seg((int)p.P, OPE_GRAD_TAIL, FIN_TAIL, 0, 0, 0, 0, 0, 0, 0);
   ft.n = k;
   ft.total = p.P + OPE_GRAD_TAIL;
-  if ((rc = launch_finalize(ft, W + p.rsum, theta, W + p.loss_part, p.n_loss_tiles, grad, st))) return rc;
+  if (finalize_blocks(ft) > p.n_gsq) return OPE_ENOSPC;
+  if ((rc = launch_finalize(ft, W + p.rsum, theta, W + p.loss_part, p.n_loss_tiles, grad, st, W + p.gsq_part))) return rc;
   return OPE_OK;
 }
 

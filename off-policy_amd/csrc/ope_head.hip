@@ -90,6 +90,10 @@ __device__ __forceinline__ void row_argmax4(float& v, int& k) {
 
 template <int NT>
 __global__ void __launch_bounds__(256) head_fwd_mfma_kernel(HeadFwdArgs a) {
+  if ((int)blockIdx.x >= a.main_blocks) {   // passengers: weight transposes for the backward kernels of this step
+    transpose4_element(a.side, ((int)blockIdx.x - a.main_blocks) * 256 + (int)threadIdx.x);
+    return;
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, g = lane >> 4;
   const int A = a.A;
@@ -232,8 +236,10 @@ __global__ void __launch_bounds__(256) head_bwd_rows_kernel(HeadBwdArgs a) {
 }  // namespace
 
 // training heads (live + target) for up to 32 actions; wider action spaces stay on the thread-per-row kernel
-int launch_head_fwd_mfma(const HeadFwdArgs& a, hipStream_t st) {
-  const int blocks = (int)ope_cdiv(a.R - a.r_begin, 64);
+int launch_head_fwd_mfma(const HeadFwdArgs& a0, hipStream_t st) {
+  HeadFwdArgs a = a0;
+  a.main_blocks = (int)ope_cdiv(a.R - a.r_begin, 64);
+  const int blocks = a.main_blocks + (a.side.total > 0 ? ope_cdiv(a.side.total, 256) : 0);
   if (a.A <= 16)
     hipLaunchKernelGGL(head_fwd_mfma_kernel<1>, dim3(blocks), dim3(256), 0, st, a);
   else

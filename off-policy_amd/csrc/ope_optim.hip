@@ -118,8 +118,11 @@ extern "C" int ope_adam_step(const ope_adam_cfg* cfg, int64_t n, float* theta, f
   if (!cfg->step_counter && cfg->step < 1) return OPE_EINVAL;
   const int nb = ope_cdiv(n, kPerBlock);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(kBlock), 0, st, grad, n, scratch, cfg->step_counter);
-  OPE_CHECK_LAUNCH();
+  const bool have_parts = cfg->sumsq_partials != nullptr && cfg->n_sumsq_partials > 0 && cfg->step_counter == nullptr;
+  if (!have_parts) {
+    hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(kBlock), 0, st, grad, n, scratch, cfg->step_counter);
+    OPE_CHECK_LAUNCH();
+  }
   AdamK c;
   const double tstep = cfg->step_counter ? 1.0 : (double)cfg->step;   // placeholder when the kernel reads the device counter
   const double bc1 = 1.0 - pow((double)cfg->beta1, tstep);
@@ -128,10 +131,11 @@ extern "C" int ope_adam_step(const ope_adam_cfg* cfg, int64_t n, float* theta, f
   c.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
   c.beta1 = cfg->beta1; c.beta2 = cfg->beta2; c.eps = cfg->eps; c.max_norm = cfg->max_grad_norm;
   c.wd = cfg->weight_decay; c.tau = cfg->tau; c.qden = cfg->qtot_denominator; c.do_polyak = cfg->do_polyak;
-  c.nblocks = nb;
+  c.nblocks = have_parts ? cfg->n_sumsq_partials : nb;
   c.lr = cfg->lr; c.step_counter = cfg->step_counter;
   c.tail = cfg->tail_offset > 0 ? cfg->tail_offset : n;
-  hipLaunchKernelGGL(adam_kernel, dim3(nb), dim3(kBlock), 0, st, c, n, theta, theta_tgt, adam_m, adam_v, grad, scratch, stats_out);
+  hipLaunchKernelGGL(adam_kernel, dim3(nb), dim3(kBlock), 0, st, c, n, theta, theta_tgt, adam_m, adam_v, grad,
+                     have_parts ? cfg->sumsq_partials : scratch, stats_out);
   OPE_CHECK_LAUNCH();
   return OPE_OK;
 }

@@ -28,6 +28,20 @@ struct SplitRed { const float* raw0; int64_t n0; int ns0; const float* raw1; int
 int launch_split_reduce(const SplitRed& a, hipStream_t st);
 struct Transp4 { const float* src[4]; float* dst[4]; int rows[4], cols[4], begin[4]; int n, total; };
 int launch_transpose4(const Transp4& a, hipStream_t st);
+// dst[c][r] = src[r][c] for up to 4 small matrices; `i` = flat element index over all of them. Shared by the stand-alone
+// kernel and by kernels that carry the transposes as extra workgroups (a weight transpose costs nothing beside a launch that
+// leaves CU slots free, but ~5 us + a kernel boundary on its own in a serial stream).
+__device__ __forceinline__ void transpose4_element(const Transp4& a, int i) {
+  if (i >= a.total) return;
+  int m = 0;
+#pragma unroll
+  for (int q = 1; q < 4; ++q)
+    if (q < a.n && i >= a.begin[q]) m = q;
+  const int j = i - a.begin[m];
+  const int rows = a.rows[m], cols = a.cols[m];
+  const int c = j / rows, r = j - c * rows;
+  a.dst[m][j] = a.src[m][(int64_t)r * cols + c];
+}
 
 enum FinKind { FIN_ZERO = 0, FIN_COPY = 1, FIN_LNLIN_W = 2, FIN_LNLIN_G = 3, FIN_LNLIN_B = 4, FIN_TAIL = 5 };
 struct FinSeg {
@@ -48,7 +62,9 @@ struct FinTable {
   int64_t total;  // length of the flat gradient including the tail
 };
 int launch_fill(float* p, int64_t n, float v, hipStream_t st);
+// workgroups of a finalize launch = number of floats `gsq_part` must hold
+int finalize_blocks(const FinTable& ft);
 int launch_finalize(const FinTable& ft, const float* rsum, const float* theta, const float* loss_part, int n_loss_tiles,
-                    float* grad, hipStream_t st);
+                    float* grad, hipStream_t st, float* gsq_part = nullptr);
 
 }  // namespace ope

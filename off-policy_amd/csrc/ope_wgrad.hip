@@ -269,16 +269,27 @@ int launch_split_reduce(const SplitRed& a, hipStream_t st) {
 //   ZERO     registered-but-unused tensors (fc_h) and padding
 //   TAIL     [loss_sum, mask_count, qtot_sum, 0] summed over the per-tile partials
 // ---------------------------------------------------------------------------------------------------------
-__global__ void finalize_kernel(FinTable ft, const float* __restrict__ rsum, const float* __restrict__ theta,
-                                const float* __restrict__ loss_part, int n_loss_tiles, float* __restrict__ grad, int n_main) {
+// Sum over the 64 lanes of a wave (fixed order: DPP row sums, then the four rows through readlane), result uniform.
+__device__ __forceinline__ float wave64_sum(float v) {
+  v = row16_sum(v);
+  return (__shfl(v, 0, 64) + __shfl(v, 16, 64)) + (__shfl(v, 32, 64) + __shfl(v, 48, 64));
+}
+
+// gsq_part (optional): per-workgroup partial sums of grad[i]^2 over the elements THIS workgroup wrote (tail excluded), one
+// float per workgroup of the launch in blockIdx order. With them ope_adam_step needs no separate norm pass over the gradient
+// (single-GPU path only: a multi-GPU run all-reduces the gradient between this kernel and the optimizer).
+__global__ void __launch_bounds__(256) finalize_kernel(FinTable ft, const float* __restrict__ rsum, const float* __restrict__ theta,
+                                                       const float* __restrict__ loss_part, int n_loss_tiles, float* __restrict__ grad,
+                                                       int n_main, float* __restrict__ gsq_part) {
+  __shared__ float sq[4];
   if ((int)blockIdx.x > n_main) {
-    // Column reductions of the LayerNorm-fed Linears (LNLIN_G / LNLIN_B: M = 14 .. 192 rows, two loads per row). With one
-    // thread per element these were the longest threads of the launch (hipcc emits load / wait / fma per row); here 16
-    // adjacent lanes share an element, lane `sub` takes rows sub, sub + 16, ... and the 16 partial sums meet by DPP
-    // (fixed order): 17.9 -> 15.2 us for the launch at 3s5z.
+    // Column reductions of the LayerNorm-fed Linears (LNLIN_G / LNLIN_B: M = 14 .. 192 rows, two loads per row). One WAVE
+    // per element: lane l takes rows l, l + 64, ... (at most 3) and the 64 partial sums meet by DPP + readlane (fixed
+    // order). hipcc emits load / wait / fma per row of such a loop, so the rows a lane walks serially are what the launch
+    // waits for: 16 lanes per element (up to 12 rows each) made these blocks the 13 us tail of the launch.
     const int gid = ((int)blockIdx.x - n_main - 1) * 256 + (int)threadIdx.x;
-    const int sub = gid & 15;
-    int e = gid >> 4, s = -1, local = 0;
+    const int sub = gid & 63;
+    int e = gid >> 6, s = -1, local = 0;
 #pragma unroll 1
     for (int q = 0; q < ft.n; ++q) {
       const int kind = ft.seg[q].kind;
@@ -293,12 +304,17 @@ __global__ void finalize_kernel(FinTable ft, const float* __restrict__ rsum, con
     const int M = live ? F.M : 0, K = F.K;
     const bool colsum = F.kind == FIN_LNLIN_B;
     float acc = 0.f;
-    for (int i = sub; i < M; i += 16) {
+    for (int i = sub; i < M; i += 64) {
       const float w = theta[F.w + (int64_t)i * K + local];
       acc = colsum ? fmaf(rsum[F.src_s + i], w, acc) : fmaf(w, rsum[F.src + (int64_t)i * K + local], acc);
     }
-    acc = row16_sum(acc);
+    acc = wave64_sum(acc);
     if (live && sub == 0) grad[F.begin + local] = acc;
+    if (gsq_part) {
+      if (sub == 0) sq[threadIdx.x >> 6] = live ? acc * acc : 0.f;
+      __syncthreads();
+      if (threadIdx.x == 0) gsq_part[blockIdx.x] = (sq[0] + sq[1]) + (sq[2] + sq[3]);
+    }
     return;
   }
   if ((int)blockIdx.x == n_main) {
@@ -317,10 +333,10 @@ __global__ void finalize_kernel(FinTable ft, const float* __restrict__ rsum, con
       __syncthreads();
     }
     if (threadIdx.x < 4) grad[ft.total - OPE_GRAD_TAIL + threadIdx.x] = threadIdx.x < 3 ? red[0][threadIdx.x] : 0.f;
+    if (gsq_part && threadIdx.x == 0) gsq_part[blockIdx.x] = 0.f;   // the tail is not part of the gradient norm
     return;
   }
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= ft.total) return;
   // (the segment table lives in kernel-argument memory: its starts are compared from one burst of scalar loads, and the
   // record is copied whole, so that the thread pays two memory round trips -- record, then data -- instead of one per field)
   int s = 0;
@@ -330,7 +346,8 @@ __global__ void finalize_kernel(FinTable ft, const float* __restrict__ rsum, con
   const FinSeg F = ft.seg[s];
   const int local = (int)(idx - F.begin);
   float out = 0.f;
-  if (local < F.size) {
+  bool write = idx < ft.total;
+  if (write && local < F.size) {
     switch (F.kind) {
       case FIN_COPY:
         out = rsum[F.src + local];
@@ -342,14 +359,23 @@ __global__ void finalize_kernel(FinTable ft, const float* __restrict__ rsum, con
       }
       case FIN_LNLIN_G:
       case FIN_LNLIN_B:
-        return;                    // written by the reduction blocks above
+        write = false;             // written by the reduction blocks above
+        break;
       case FIN_TAIL:
-        return;                    // written by the extra block
+        write = false;             // written by the extra block
+        break;
       default:
         out = 0.f;
     }
   }
-  grad[idx] = out;
+  if (write) grad[idx] = out;
+  if (gsq_part) {
+    float v = write ? out * out : 0.f;
+    v = wave64_sum(v);
+    if ((threadIdx.x & 63) == 0) sq[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) gsq_part[blockIdx.x] = (sq[0] + sq[1]) + (sq[2] + sq[3]);
+  }
 }
 
 __global__ void fill_kernel(float* __restrict__ p, int64_t n, float v) {
@@ -363,36 +389,29 @@ int launch_fill(float* p, int64_t n, float v, hipStream_t st) {
 }
 
 // dst[c][r] = src[r][c] for up to 4 matrices in one launch
-__global__ void transpose4_kernel(Transp4 a) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.total) return;
-  int m = 0;
-#pragma unroll
-  for (int q = 1; q < 4; ++q)
-    if (q < a.n && i >= a.begin[q]) m = q;
-  const int j = i - a.begin[m];
-  const int rows = a.rows[m], cols = a.cols[m];
-  const int c = j / rows, r = j - c * rows;
-  a.dst[m][j] = a.src[m][(int64_t)r * cols + c];
-}
+__global__ void transpose4_kernel(Transp4 a) { transpose4_element(a, blockIdx.x * blockDim.x + threadIdx.x); }
 int launch_transpose4(const Transp4& a, hipStream_t st) {
   hipLaunchKernelGGL(transpose4_kernel, dim3(ope_cdiv(a.total, 256)), dim3(256), 0, st, a);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   return OPE_OK;
 }
 
+int finalize_blocks(const FinTable& ft) {
+  int64_t n_red = 0;
+  for (int q = 0; q < ft.n; ++q)
+    if (ft.seg[q].kind == FIN_LNLIN_G || ft.seg[q].kind == FIN_LNLIN_B) n_red += ft.seg[q].size;
+  return (int)ope_cdiv(ft.total, 256) + 1 + (int)ope_cdiv(n_red * 64, 256);
+}
+
 int launch_finalize(const FinTable& ft0, const float* rsum, const float* theta, const float* loss_part, int n_loss_tiles,
-                    float* grad, hipStream_t st) {
+                    float* grad, hipStream_t st, float* gsq_part) {
   FinTable t = ft0;
   for (int q = 0; q < kMaxFinSegs; ++q) t.begin[q] = q < t.n ? t.seg[q].begin : 0x7fffffff;
   const FinTable& ft = t;
   const int n_main = (int)ope_cdiv(ft.total, 256);
-  int64_t n_red = 0;
-  for (int q = 0; q < ft.n; ++q)
-    if (ft.seg[q].kind == FIN_LNLIN_G || ft.seg[q].kind == FIN_LNLIN_B) n_red += ft.seg[q].size;
-  // blocks [0, n_main): one thread per element; block n_main: the loss tail; the rest: 16 lanes per column reduction
-  hipLaunchKernelGGL(finalize_kernel, dim3(n_main + 1 + (int)ope_cdiv(n_red * 16, 256)), dim3(256), 0, st, ft, rsum, theta,
-                     loss_part, n_loss_tiles, grad, n_main);
+  // blocks [0, n_main): one thread per element; block n_main: the loss tail; the rest: one wave per column reduction
+  hipLaunchKernelGGL(finalize_kernel, dim3(finalize_blocks(ft)), dim3(256), 0, st, ft, rsum, theta, loss_part, n_loss_tiles, grad, n_main,
+                     gsq_part);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   return OPE_OK;
 }
