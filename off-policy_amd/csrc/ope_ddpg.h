@@ -38,4 +38,13 @@ int launch_build_cin(const float* cent, const float* acts, const float* repl, in
 int launch_action(const float* logits, const float* avail, const float* U, int rows, int B, int A, int N, int mode, int t_shift,
                   float* cent_nact, float* act_out, float* soft_out, hipStream_t st);
 
+// fused small-network path (ope_ddpg_fused.hip): one launch per network update + one slab reduction
+bool ddpg_fused_ok(int N, int A, int D, int S, int K);
+int64_t ddpg_fused_slab_floats(int N, int A, int D, int S, int K, int B);
+int launch_ddpg_critic_fused(const ope_ddpg_cfg* cfg, const ope_mlp_batch* bt, const float* theta_actor_tgt, const float* theta_critic,
+                             const float* theta_critic_tgt, const float* U, const float* per_w, float* slabs, float* grad, float* prio_out,
+                             hipStream_t st);
+int launch_ddpg_actor_fused(const ope_ddpg_cfg* cfg, const ope_mlp_batch* bt, const float* theta_actor, const float* theta_critic,
+                            const float* U, float* slabs, float* grad, hipStream_t st);
+
 }  // namespace ope

@@ -402,7 +402,8 @@ struct DdpgPlan {
   int raw_size_c, raw_size_a;
   int P1, s1, P2, s2, E, sq;    // raw slab offsets (same recipe for actor and critic, sized by the larger)
   int64_t xin_t, xin, a2n, lgn, cnact, a2t, qt, a2c, qc, dq, da2, dz1, dz2, mu0, rstd0, xhat1, rstd1, mask1, xhat2, rstd2, mask2,
-      thetaT, raw, rsum, loss_part, lnz, lno, xin_a, a2a, lga, ysoft, actout, mu1, cvec, dlg, err;
+      thetaT, raw, rsum, loss_part, lnz, lno, xin_a, a2a, lga, ysoft, actout, mu1, cvec, dlg, err, fused_slabs;
+  bool fused;
 };
 
 static int ddpg_cfg_ok(const ope_ddpg_cfg* c) {
@@ -450,6 +451,8 @@ static void ddpg_plan(const ope_ddpg_cfg* c, DdpgPlan* p) {
   p->mu1 = W.add("mu1", R); p->cvec = W.add("fc1_colsums", 2 * OPE_H); p->dlg = W.add("dlogits", Ra * p->A4);
   // second set of trunk saves for the actor's own backward (the critic pass of the actor step reuses the first set)
   p->err = W.add("saves2", Ra * (2 * OPE_H + 8));
+  p->fused = ddpg_fused_ok(p->N, p->A, p->D, p->S, p->K);
+  p->fused_slabs = W.add("fused_slabs", p->fused ? ddpg_fused_slab_floats(p->N, p->A, p->D, p->S, p->K, p->B) + 64 : 4);   // + debug stamps
 }
 
 // trunk forward in mlp mode on `rows` rows of width Dw; saves go to the plan's first save set unless `alt` is given
@@ -605,6 +608,9 @@ extern "C" int ope_ddpg_critic_loss_and_grad(const ope_ddpg_cfg* cfg, const ope_
   hipStream_t st = (hipStream_t)stream;
   float* W = (float*)workspace;
   int rc;
+  if (p.fused)   // small networks: the whole critic update in one launch + a slab reduction (ope_ddpg_fused.hip)
+    return launch_ddpg_critic_fused(cfg, bt, theta_actor_tgt, theta_critic, theta_critic_tgt, target_noise_u, per_weights,
+                                    W + p.fused_slabs, grad, prio_out, st);
   // target actor on the next observations -> joint next action
   if ((rc = trunk_mlp(p, W, bt->next_obs, p.Ra, p.D, theta_actor_tgt, p.AL, W + p.a2n, false, nullptr, W + p.lgn, p.A, st))) return rc;
   if ((rc = launch_action(W + p.lgn, bt->next_avail_acts, target_noise_u, p.Ra, p.B, p.A, p.N, cfg->target_gumbel ? 1 : 0, 0, W + p.cnact,
@@ -635,6 +641,7 @@ extern "C" int ope_ddpg_actor_loss_and_grad(const ope_ddpg_cfg* cfg, const ope_m
   hipStream_t st = (hipStream_t)stream;
   float* W = (float*)workspace;
   int rc;
+  if (p.fused) return launch_ddpg_actor_fused(cfg, bt, theta_actor, theta_critic, gumbel_noise_u, W + p.fused_slabs, grad, st);
   float* saves2 = W + p.err;
   // actor forward (saves -> alternate set) and straight-through hard gumbel sample
   if ((rc = trunk_mlp(p, W, bt->obs, p.Ra, p.D, theta_actor, p.AL, W + p.a2a, true, saves2, W + p.lga, p.A, st))) return rc;

@@ -1,0 +1,30 @@
+"""Phase stamps (s_memtime, shader cycles) of workgroup 0 / wave 0 of the fused MADDPG critic kernel (OPE_DDPG_DBG=1).
+Usage: OPE_DDPG_DBG=1 python tools/ddpg_phases.py"""
+import ctypes as C, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["OPE_DDPG_DBG"] = "1"
+import bench
+from offpolicy_amd import _lib
+from offpolicy_amd.config import default_args
+from offpolicy_amd.utils.synth import DIMS, policy_info_for
+from offpolicy_amd.utils.mlp_buffer import MlpReplayBuffer
+from offpolicy_amd.algorithms.maddpg.algorithm.MADDPGPolicy import MADDPGPolicy
+from offpolicy_amd.algorithms.maddpg.maddpg import MADDPG
+dims = DIMS["simple_spread"]; dev = torch.device("cuda:0"); B = 256
+pinfo = policy_info_for(dims)
+policy = MADDPGPolicy({"args": default_args(), "device": dev}, pinfo["policy_0"])
+trainer = MADDPG(default_args(), dims.n_agents, {"policy_0": policy}, lambda x: "policy_0", device=dev)
+trainer.device_noise = True
+buf = MlpReplayBuffer(pinfo, {"policy_0": list(range(dims.n_agents))}, 4096, True, True, False, device=dev)
+tr = bench.ddpg_transitions(np.random.RandomState(0), 4096, dims)
+buf.insert(4096, *[{"policy_0": tr[k]} for k in bench.DDPG_KEYS])
+for _ in range(5):
+    s = buf.policy_buffers["policy_0"].sample_inds(np.random.choice(4096, B))
+    trainer.shared_train_policy_on_batch("policy_0", tuple({"policy_0": x} for x in s) + (None, None))
+torch.cuda.synchronize()
+v = trainer.workspace_view(B, "fused_slabs")
+st = v[-64:].view(torch.int64).cpu().numpy()[:9]
+names = ["stage 3 nets", "target actor x N", "target critic fwd", "live critic fwd", "TD + critic bwd", "barrier", "dump", "wg sum + slab"]
+print("cycles:", {n: int(st[i + 1] - st[i]) for i, n in enumerate(names)})
+print("total cycles", int(st[8] - st[0]), "= %.1f us at 2.4 GHz" % ((st[8] - st[0]) / 2400.0))
