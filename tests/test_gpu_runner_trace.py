@@ -1,0 +1,124 @@
+"""-m gpu: replay of what the REFERENCE's SMACRunner did to its buffer / policy / trainer (tests/golden/runner_trace_qmix.npz,
+recorded by oracle/make_runner_trace.py from the real runner -- constructor, warm-up with random actions, three run() cycles
+of epsilon-greedy collection + insert + sample + train_policy_on_batch + soft update, save_q) against the ENGINE's classes:
+same call order, same arguments (the numpy arrays the runner built), same numpy / torch RNG states, every return value
+compared with what the reference's own classes returned to the runner. (the runner drives the engine.)"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _set_rng(c):
+    np.random.set_state(("MT19937", c["in/np_keys"], int(c["in/np_pos"][0]), int(c["in/np_pos"][1]), float(c["in/np_gauss"][0])))
+    torch.set_rng_state(torch.from_numpy(c["in/torch"]))
+
+
+def _call(g, i):
+    pre = "c%03d/" % i
+    return {k[len(pre):]: v for k, v in g.items() if k.startswith(pre)}
+
+
+def test_reference_runner_call_trace_replays_on_the_engine():
+    from offpolicy_amd.config import default_args
+    from offpolicy_amd.utils.spaces import Discrete
+    from offpolicy_amd.utils.rec_buffer import RecReplayBuffer
+    from offpolicy_amd.algorithms.qmix.algorithm.QMixPolicy import QMixPolicy
+    from offpolicy_amd.algorithms.qmix.qmix import QMix
+    g = load_golden("runner_trace_qmix")
+    calls = [str(x) for x in g["calls"]]
+    N, A, D, S, T = [int(x) for x in g["dims"]]
+    batch_size, buffer_size, lr, eps0, eps1, eps_t = g["hp"]
+    args = default_args(batch_size=int(batch_size), buffer_size=int(buffer_size), lr=float(lr), epsilon_start=float(eps0),
+                        epsilon_finish=float(eps1), epsilon_anneal_time=float(eps_t), episode_length=T)
+    dev = torch.device("cuda:0")
+    pinfo = {"policy_0": {"cent_obs_dim": S, "cent_act_dim": A * N, "obs_space": [D], "share_obs_space": [S], "act_space": Discrete(A)}}
+    policy = trainer = buf = None
+    last_sample = None
+    seen = {k: 0 for k in set(calls)}
+    for i, name in enumerate(calls):
+        c = _call(g, i)
+        seen[name] += 1
+        if name == "policy.__init__":
+            _set_rng(c)
+            policy = QMixPolicy({"args": args, "device": dev}, pinfo["policy_0"])
+            sd = {k[len("out/sd/"):]: v for k, v in c.items() if k.startswith("out/sd/")}
+            ours = policy.q_network.state_dict()
+            assert list(ours.keys()) == list(sd.keys())
+            for k, v in sd.items():      # same RNG stream -> same initial weights (to LAPACK-QR rounding across hosts)
+                np.testing.assert_allclose(ours[k].cpu().numpy(), v, rtol=0, atol=3e-5, err_msg=k)
+            policy.q_network.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+            assert policy.output_dim == A and policy.obs_dim == D and policy.central_obs_dim == S     # attributes the runner reads
+        elif name == "trainer.__init__":
+            _set_rng(c)
+            trainer = QMix(args, N, {"policy_0": policy}, lambda a: "policy_0", device=dev, episode_length=T)
+            sd = {k[len("out/sd/"):]: v for k, v in c.items() if k.startswith("out/sd/")}
+            ours = trainer.mixer.state_dict()
+            assert list(ours.keys()) == list(sd.keys())
+            for k, v in sd.items():
+                np.testing.assert_allclose(ours[k].cpu().numpy(), v, rtol=0, atol=3e-5, err_msg=k)
+            trainer.mixer.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+            trainer.hard_target_updates()       # targets = copies of the (just loaded) live networks, as at construction
+            buf = RecReplayBuffer(pinfo, {"policy_0": list(range(N))}, int(buffer_size), T, True, True, False, device=dev)
+        elif name == "trainer.prep_rollout":
+            trainer.prep_rollout()
+        elif name == "trainer.prep_training":
+            trainer.prep_training()
+        elif name == "policy.get_random_actions":
+            _set_rng(c)
+            acts = policy.get_random_actions(c["in/obs"], c["in/available_actions"])
+            assert np.array_equal(np.asarray(acts), c["out/actions"]), i
+        elif name == "policy.get_actions":
+            _set_rng(c)
+            explore = bool(c["in/explore"])
+            t_env = int(c["in/t_env"]) if "in/t_env" in c else None
+            acts, h, gq = policy.get_actions(c["in/obs"], c["in/prev_actions"], c["in/rnn_states"], c["in/available_actions"],
+                                             t_env=t_env, explore=explore)
+            np.testing.assert_allclose(h.cpu().numpy() if torch.is_tensor(h) else h, c["out/rnn_states"], rtol=1e-4, atol=2e-5, err_msg=str(i))
+            gq = gq.cpu().numpy() if torch.is_tensor(gq) else np.asarray(gq)
+            assert gq.shape == c["out/greedy_Qs"].shape, (i, gq.shape, c["out/greedy_Qs"].shape)
+            np.testing.assert_allclose(gq, c["out/greedy_Qs"], rtol=1e-3, atol=3e-5, err_msg=str(i))
+            acts = np.asarray(acts)
+            assert acts.shape == c["out/actions"].shape
+            if not np.array_equal(acts, c["out/actions"]):
+                # only a near-tie between two Q values may flip a greedy action
+                q, _ = policy.get_q_values(c["in/obs"], c["in/prev_actions"], c["in/rnn_states"])
+                q = q.cpu().numpy()
+                q[c["in/available_actions"] == 0] = -1e10
+                for r in np.nonzero((acts != c["out/actions"]).any(-1))[0]:
+                    top = np.sort(q[r])[-2:]
+                    assert top[1] - top[0] < 1e-4, (i, r, q[r])
+        elif name == "buffer.insert":
+            d = {k: {"policy_0": c["in/" + k]} for k in ("obs", "share_obs", "acts", "rewards", "dones", "dones_env", "avail_acts")}
+            idx = buf.insert(int(c["in/n"]), d["obs"], d["share_obs"], d["acts"], d["rewards"], d["dones"], d["dones_env"], d["avail_acts"])
+            assert np.array_equal(np.asarray(idx), c["out/idx_range"]), i
+        elif name == "buffer.sample":
+            _set_rng(c)
+            last_sample = buf.sample(int(c["in/batch_size"]))
+            for j, k in enumerate(("obs", "share_obs", "acts", "rewards", "dones", "dones_env", "avail_acts")):
+                got = last_sample[j]["policy_0"]
+                assert tuple(got.shape) == c["out/" + k].shape, (k, got.shape)
+                assert np.array_equal(got.cpu().numpy(), c["out/" + k]), (i, k)      # the HIP gather returns the reference's batch
+            assert last_sample[7] is None and last_sample[8] is None
+        elif name == "trainer.train_policy_on_batch":
+            info, prio, idxes = trainer.train_policy_on_batch(last_sample)
+            assert prio is None and idxes is None
+            np.testing.assert_allclose(float(info["loss"]), float(c["out/loss"]), rtol=2e-3, err_msg=str(i))
+            np.testing.assert_allclose(float(info["grad_norm"]), float(c["out/grad_norm"]), rtol=2e-3, err_msg=str(i))
+            np.testing.assert_allclose(float(info["Q_tot"]), float(c["out/Q_tot"]), rtol=2e-3, atol=1e-5, err_msg=str(i))
+        elif name == "trainer.soft_target_updates":
+            trainer.soft_target_updates()
+        elif name == "runner.save_q":
+            q_sd, m_sd = policy.q_network.state_dict(), trainer.mixer.state_dict()
+            ref_q = {k[len("out/q/"):]: v for k, v in c.items() if k.startswith("out/q/")}
+            ref_m = {k[len("out/m/"):]: v for k, v in c.items() if k.startswith("out/m/")}
+            assert list(q_sd.keys()) == list(ref_q.keys()) and list(m_sd.keys()) == list(ref_m.keys())
+            for ours, ref in ((q_sd, ref_q), (m_sd, ref_m)):
+                for k, v in ref.items():
+                    np.testing.assert_allclose(ours[k].cpu().numpy(), v, rtol=0, atol=1e-4, err_msg=k)
+        else:
+            raise AssertionError("unknown call in the trace: " + name)
+    assert seen["policy.get_actions"] > 20 and seen["buffer.insert"] >= 8 and seen["trainer.train_policy_on_batch"] == 3
