@@ -1,5 +1,6 @@
+mkdir -p gpurun_out/r02m
 cd $GRAFT_REPO_ROOT
-python tools/ddpg_phases.py 2>&1 | tail -2
-timeout 600 python -m pytest tests/test_gpu_ddpg.py -m gpu -q --timeout 600 -p no:cacheprovider -x 2>&1 | tail -3
-python bench.py --workload maddpg_spread --steps 300 --warmup 30 --no-cpu-baseline 2>/dev/null | cut -c1-200
-python bench.py --workload maddpg_spread --steps 300 --warmup 30 --no-cpu-baseline --no-graph 2>/dev/null | cut -c1-200
+timeout 1500 python -m pytest tests -m gpu -q --timeout 900 -p no:cacheprovider > gpurun_out/r02m/pytest_gpu.txt 2>&1; tail -8 gpurun_out/r02m/pytest_gpu.txt
+python bench.py --workload rmatd3_MMM2 --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | cut -c1-300
+python bench.py --workload MMM2 --steps 60 --warmup 10 --no-cpu-baseline --episodes 512 2>/dev/null | cut -c1-300
+python bench.py --workload 3m --steps 200 --warmup 20 --no-cpu-baseline 2>/dev/null | cut -c1-300
