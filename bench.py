@@ -193,6 +193,23 @@ def timed_steps(one_step, steps, warmup, world, dev):
     return elapsed, info
 
 
+def gather_profile(enable):
+    from offpolicy_amd import _lib
+    _lib.check(_lib.lib.ope_store_gather_profile(1 if enable else 0), "ope_store_gather_profile")
+
+
+def gather_profile_read():
+    """Kernel durations (ms) of the gathers launched since gather_profile(True): hipExtLaunchKernel start / stop events attached to
+    each gather dispatch on its launch stream -- the dispatch's own duration, as rocprofv3's kernel trace reports it."""
+    import ctypes as C
+    from offpolicy_amd import _lib
+    buf = (C.c_float * 512)()
+    n = _lib.lib.ope_store_gather_profile_read(buf, 512)
+    if n < 0:
+        _lib.check(n, "ope_store_gather_profile_read")
+    return [float(buf[i]) for i in range(n)]
+
+
 def scaling_legs(a, batch, world):
     """[(name, local_batch, global_batch)]: the leg `value` is quoted on first. One GPU: a single leg."""
     if world == 1:
@@ -250,7 +267,7 @@ def main():
     results = []
     for leg, local_batch, global_batch in scaling_legs(a, a.batch, world):
         np.random.seed(1000)
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
         # Eager launches by default: the host enqueues a step in ~150 us against 0.4 ms of kernels, so it runs ahead and a
         # HIP-graph replay of the training kernels (--graph; QMix.make_graphed_step) is 1-4 % SLOWER here (measured).
         graphed = trainer.make_graphed_step(buf, local_batch, gather_in_graph=False) if (a.graph and world == 1) else None
@@ -258,18 +275,28 @@ def main():
         def one_step(i=None):
             inds = opdist.shard_indices(np.random.choice(len(buf), global_batch), rank, world)
             if graphed is not None:
-                return graphed(inds, timing_events=ev[i] if i is not None else None)
-            s = pbuf.sample_inds(inds, timing_events=ev[i] if i is not None else None)   # ope_store_gather, current stream
+                return graphed(inds)
+            s = pbuf.sample_inds(inds)                       # ope_store_gather, current stream
             batch = tuple({"policy_0": x} for x in s) + (None, None)
             info, _, _ = trainer.train_policy_on_batch(batch)
             trainer.soft_target_updates()
             return info
-        elapsed, info = timed_steps(one_step, a.steps, a.warmup, world, dev)
-        gather_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
+        for _ in range(a.warmup):        # (timed_steps warms up again: these make the profiled window start warm)
+            one_step(None)
+        gather_profile(True)
+        elapsed, info = timed_steps(one_step, a.steps, 0, world, dev)
+        kernel_ms = gather_profile_read()[-a.steps:]
+        gather_profile(False)
+        # for reference, the round-1 style measurement on 20 more gathers outside the timed region: two event markers around a launch
+        for e0, e1 in ev[:20]:
+            pbuf.sample_inds(opdist.shard_indices(np.random.choice(len(buf), global_batch), rank, world), timing_events=(e0, e1))
+        torch.cuda.synchronize()
+        bracket_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev[:20]]))
+        gather_ms = float(np.mean(kernel_ms)) if kernel_ms else bracket_ms
         loss = float(info["loss"])
         assert np.isfinite(loss), "training diverged"
         results.append(dict(leg=leg, local_batch=local_batch, global_batch=global_batch, elapsed=elapsed, gather_ms=gather_ms, loss=loss,
-                            graphed=graphed is not None))
+                            graphed=graphed is not None, bracket_ms=bracket_ms, n_kernel_ms=len(kernel_ms)))
 
     if rank == 0:
         r0 = results[0]
@@ -298,7 +325,13 @@ def main():
                          "algorithmic_bytes_per_launch": int(algo_bytes), "avg_launch_ms": round(r0["gather_ms"], 5),
                          "store_bytes": int(a.episodes * ep_bytes),
                          "hbm_resident": bool(a.episodes * ep_bytes > 4 * 256 * 2 ** 20),
-                         "timing": "HIP events on the launch stream recorded immediately around each gather launch in the timed region",
+                         "timing": "mean kernel duration of the %d gather dispatches of the timed region, from HIP start/stop events "
+                                   "attached to each dispatch on its launch stream (hipExtLaunchKernel): the quantity rocprofv3's kernel "
+                                   "trace reports" % r0["n_kernel_ms"],
+                         "avg_event_bracket_ms": round(r0["bracket_ms"], 5),
+                         "frac_event_bracket": round(algo_bytes / (r0["bracket_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "event_bracket_note": "20 gathers after the timed region, interval between two HIP event markers recorded around "
+                                               "the launch: the kernel plus two command-processor boundaries (what round 1 reported)",
                          "traffic_source": "profiles/gather_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)"},
         }
         if len(results) > 1:
@@ -576,11 +609,12 @@ def main_rddpg(a):
         assert np.isfinite(float(info["critic_loss"]))
         # gather roofline leg measured on its own (same launch, HIP events on the launch stream)
         pbuf = buf.policy_buffers["policy_0"]
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
-        for e in ev:
-            pbuf.sample_inds(np.random.choice(len(buf), local_batch), timing_events=e)
+        gather_profile(True)
+        for _ in range(20):
+            pbuf.sample_inds(np.random.choice(len(buf), local_batch))
         torch.cuda.synchronize()
-        gather_ms = float(np.mean([s_.elapsed_time(e) for s_, e in ev]))
+        gather_ms = float(np.mean(gather_profile_read()))
+        gather_profile(False)
         results.append(dict(leg=leg, local_batch=local_batch, global_batch=global_batch, elapsed=elapsed, gather_ms=gather_ms))
     if rank == 0:
         r0 = results[0]
@@ -608,7 +642,8 @@ def main_rddpg(a):
                             "traffic": gather_traffic(mapname, r0["local_batch"], a.episodes),
                             "algorithmic_bytes_per_launch": int(algo_bytes), "avg_launch_ms": round(r0["gather_ms"], 5),
                             "store_bytes": int(a.episodes * ep_bytes), "hbm_resident": bool(a.episodes * ep_bytes > 4 * 256 * 2 ** 20),
-                            "timing": "HIP events on the launch stream around 20 gather launches of the same batch size"}}
+                            "timing": "mean kernel duration of 20 gather dispatches of the same batch size after the timed region, from HIP "
+                                      "start/stop events attached to each dispatch (hipExtLaunchKernel)"}}
         if len(results) > 1:
             r1 = results[1]
             sps1 = a.steps / r1["elapsed"]

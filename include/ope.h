@@ -110,6 +110,12 @@ int ope_store_gather(const ope_dims* dims, int32_t capacity, const ope_fields* s
  * outside [0, capacity) returns OPE_EINVAL (numpy's IndexError). */
 int ope_store_gather_host_inds(const ope_dims* dims, int32_t capacity, const ope_fields* store, const int64_t* inds_host,
                                int32_t batch, const ope_fields* out, void* stream);
+/* Per-dispatch timing of the gather (the roofline leg of bench.py): after ope_store_gather_profile(1) every gather launch
+ * carries hipExtLaunchKernel start / stop events (up to 512 launches are kept); ope_store_gather_profile_read waits for them
+ * and writes the kernel durations in milliseconds, oldest first, into HOST memory, returns how many (and clears the ring).
+ * These time the dispatch itself -- what rocprofv3's kernel trace reports -- not the gap between two event markers. */
+int ope_store_gather_profile(int32_t enable);
+int ope_store_gather_profile_read(float* ms_out_host, int32_t max_n);
 /* A/B knobs of the gather kernel (tools/bench_gather.py); negative or 0 = keep. Defaults are the measured best:
  * floats_per_block 2048 (contiguous floats of one episode a workgroup reads: whole time steps), xcd_run 8 (> 1: the B
  * workgroups writing one [t][agent][0..B) range share an XCD), unroll 8 (16-byte loads in flight per thread), nontemporal 0

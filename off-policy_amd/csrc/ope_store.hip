@@ -12,6 +12,8 @@
 // grid >> 256 workgroups. Algorithmic bytes per gather = 2 * B * episode_bytes (read + write).
 #include <stdlib.h>
 
+#include <hip/hip_ext.h>
+
 #include "ope_common.h"
 
 namespace {
@@ -324,10 +326,28 @@ __global__ void __launch_bounds__(kBlock) episode_copy_kernel(CopyArgs args, IDX
   copy_dispatch<GATHER, UNROLL, (NT & 1) != 0, (NT & 2) != 0>(F, args, idx, blk);
 }
 
+// Per-dispatch timing of the gather (bench.py's roofline leg): when enabled, every gather is launched with
+// hipExtLaunchKernel's start / stop events, which time the DISPATCH itself (what rocprofv3's kernel trace reports) instead of
+// the interval between two event markers around it (that interval carries two command-processor boundaries, ~4.7 us).
+constexpr int kProfRing = 512;
+struct GatherProf {
+  bool on = false;
+  hipEvent_t ev[kProfRing][2];
+  bool made = false;
+  int n = 0;           // pairs recorded since the last read (capped at kProfRing)
+};
+GatherProf g_prof;
+
 template <bool GATHER, class IDX>
 void launch_copy(const CopyArgs& args, const IDX& idx, hipStream_t st) {
   const dim3 grid(args.total_blocks), block(kBlock);
   const size_t lds = (size_t)args.lds_bytes;
+  if (GATHER && g_prof.on && g_prof.n < kProfRing && args.unroll == 8 && args.nt == 0) {
+    hipEvent_t e0 = g_prof.ev[g_prof.n][0], e1 = g_prof.ev[g_prof.n][1];
+    ++g_prof.n;
+    hipExtLaunchKernelGGL((episode_copy_kernel<GATHER, 8, 0, IDX>), grid, block, (uint32_t)lds, st, e0, e1, 0, args, idx);
+    return;
+  }
   // one instantiation per variant: a single kernel holding all of them would be allocated the registers of the largest
   if (args.unroll == 4) hipLaunchKernelGGL((episode_copy_kernel<GATHER, 4, 0, IDX>), grid, block, lds, st, args, idx);
   else if (args.unroll == 16) hipLaunchKernelGGL((episode_copy_kernel<GATHER, 16, 0, IDX>), grid, block, lds, st, args, idx);
@@ -506,6 +526,29 @@ extern "C" int64_t ope_episode_bytes(const ope_dims* d) {
   if (!d) return OPE_EINVAL;
   const int64_t T = d->episode_length, N = d->n_agents, A = d->act_dim, D = d->obs_dim, S = d->state_dim;
   return 4 * ((T + 1) * N * D + (T + 1) * S + T * N * A + (T + 1) * N * A + T * N + T * N + T);
+}
+
+extern "C" int ope_store_gather_profile(int32_t enable) {
+  if (enable && !g_prof.made) {
+    for (int i = 0; i < kProfRing; ++i)
+      for (int k = 0; k < 2; ++k)
+        if (hipEventCreate(&g_prof.ev[i][k]) != hipSuccess) return OPE_EHIP;
+    g_prof.made = true;
+  }
+  g_prof.on = enable != 0;
+  g_prof.n = 0;
+  return OPE_OK;
+}
+
+extern "C" int ope_store_gather_profile_read(float* ms_out_host, int32_t max_n) {
+  if (!ms_out_host || max_n < 0) return OPE_EINVAL;
+  const int n = g_prof.n < max_n ? g_prof.n : max_n;
+  for (int i = 0; i < n; ++i) {
+    if (hipEventSynchronize(g_prof.ev[i][1]) != hipSuccess) return OPE_EHIP;
+    if (hipEventElapsedTime(&ms_out_host[i], g_prof.ev[i][0], g_prof.ev[i][1]) != hipSuccess) return OPE_EHIP;
+  }
+  g_prof.n = 0;
+  return n;
 }
 
 extern "C" void ope_set_gather_params(int floats_per_block, int xcd_run, int unroll, int nontemporal, int small_tiles, int tile_floats) {
