@@ -579,8 +579,8 @@ def main_rddpg(a):
     td3 = algo == "rmatd3"
     dims = DIMS[mapname]
     batch = a.batch or 128
-    if a.episodes is None:
-        a.episodes = 512
+    if a.episodes is None:    # prioritized sampling needs more stored episodes than the (global, weak-scaling) batch
+        a.episodes = max(512, 2 * batch * int(os.environ.get("WORLD_SIZE", "1")))
     args = default_args(use_per=True)
     torch.manual_seed(1)
     np.random.seed(1)
@@ -595,6 +595,10 @@ def main_rddpg(a):
     import random
     results = []
     for leg, local_batch, global_batch in scaling_legs(a, batch, world):
+        if global_batch >= a.episodes:
+            if rank == 0:
+                print("[bench] %s leg skipped: global batch %d needs more than --episodes %d" % (leg, global_batch, a.episodes), file=sys.stderr)
+            continue
         np.random.seed(1000)              # same global index draws on every rank
         random.seed(1000)
         torch.manual_seed(1000 + rank)    # different gumbel noise per rank

@@ -354,6 +354,9 @@ int ope_allreduce_free(void* buf);
 int ope_allreduce_ipc_export(void* buf, void* handle_host);            /* OPE_AR_IPC_HANDLE_BYTES bytes out                */
 int ope_allreduce_ipc_import(const void* handle_host, void** mapped_out);
 int ope_allreduce_ipc_close(void* mapped);
+/* Peer access from the current device to `peer_device` (hipDeviceCanAccessPeer + hipDeviceEnablePeerAccess; already
+ * enabled counts as success). Called for every peer before its buffer is imported. */
+int ope_allreduce_enable_peer(int32_t peer_device);
 int ope_allreduce_flat(const ope_allreduce_ctx* ctx_host, uint32_t epoch, float* flat, int64_t n, int32_t* status, void* stream);
 
 #ifdef __cplusplus

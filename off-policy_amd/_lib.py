@@ -120,6 +120,7 @@ def _load():
         "ope_allreduce_ipc_export": (C.c_int, [p, p]),
         "ope_allreduce_ipc_import": (C.c_int, [p, C.POINTER(p)]),
         "ope_allreduce_ipc_close": (C.c_int, [p]),
+        "ope_allreduce_enable_peer": (C.c_int, [i32]),
         "ope_allreduce_flat": (C.c_int, [C.POINTER(AllreduceCtx), C.c_uint32, p, i64, p, p]),
     }
     for name, (res, args) in sig.items():

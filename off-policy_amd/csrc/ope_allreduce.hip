@@ -151,6 +151,20 @@ extern "C" int ope_allreduce_ipc_import(const void* handle_host, void** mapped_o
   return OPE_OK;
 }
 
+extern "C" int ope_allreduce_enable_peer(int32_t peer_device) {
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess) return OPE_EHIP;
+  if (peer_device == cur) return OPE_OK;
+  int can = 0;
+  if (hipDeviceCanAccessPeer(&can, cur, peer_device) != hipSuccess || !can) {
+    (void)hipGetLastError();
+    return OPE_EHIP;
+  }
+  const hipError_t e = hipDeviceEnablePeerAccess(peer_device, 0);
+  (void)hipGetLastError();
+  return (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) ? OPE_OK : OPE_EHIP;
+}
+
 extern "C" int ope_allreduce_ipc_close(void* mapped) {
   if (!mapped) return OPE_EINVAL;
   return hipIpcCloseMemHandle(mapped) == hipSuccess ? OPE_OK : OPE_EHIP;

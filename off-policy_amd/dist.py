@@ -60,12 +60,14 @@ class OneShotAllreduce(object):
                 # cannot leave the other ranks stuck in the collective
                 rc = _lib.lib.ope_allreduce_ipc_export(buf, handle)
                 handles = [None] * self.world
-                torch.distributed.all_gather_object(handles, bytes(handle) if rc == 0 else None, group=group)
+                me = (bytes(handle), int(self.device.index if self.device.index is not None else torch.cuda.current_device())) if rc == 0 else None
+                torch.distributed.all_gather_object(handles, me, group=group)
                 if any(h is None for h in handles):
                     raise _lib.OpeError("hipIpcGetMemHandle failed on rank(s) %s" % [q for q, h in enumerate(handles) if h is None])
-                for q, h in enumerate(handles):
+                for q, (h, peer_dev) in enumerate(handles):
                     if q == self.rank:
                         continue
+                    _lib.check(_lib.lib.ope_allreduce_enable_peer(peer_dev), "ope_allreduce_enable_peer(%d)" % peer_dev)
                     m = C.c_void_p(0)
                     hb = (C.c_ubyte * 64).from_buffer_copy(h)
                     _lib.check(_lib.lib.ope_allreduce_ipc_import(hb, C.byref(m)), "ope_allreduce_ipc_import")
