@@ -217,6 +217,10 @@ typedef struct ope_adam_cfg {
   int32_t* step_counter;  /* optional DEVICE int32 holding the number of Adam steps taken so far. When non-NULL, `step` is
                            * ignored: the call increments the counter on the device and uses the new value as t, so a
                            * captured HIP graph of the update can be replayed with advancing bias correction.          */
+  int32_t skip_begin, skip_end; /* elements [skip_begin, skip_end) are left untouched by Adam (no moment update, no step, no weight
+                                 * decay) but still follow Polyak: tensors that never receive a gradient -- torch's Adam skips
+                                 * them (the registered-but-unused fc_h block, SURVEY A-8). Only matters with weight_decay != 0:
+                                 * with a zero gradient and zero moments the plain update is already a no-op. 0, 0 = none. */
   const float* sumsq_partials; /* optional DEVICE array of n_sumsq_partials floats whose sum is sum_i grad[i]^2 over the n    */
   int32_t n_sumsq_partials;    /* optimised elements, produced together with `grad` (ope_qmix_loss_and_grad leaves them in
                                 * its workspace region "gsq_part", see ope_qmix_workspace_find). When given (and

@@ -41,7 +41,8 @@ class AdamCfg(C.Structure):
     _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
                 ("max_grad_norm", C.c_float), ("weight_decay", C.c_float), ("tau", C.c_float),
                 ("do_polyak", C.c_int32), ("step", C.c_int32), ("qtot_denominator", C.c_float), ("tail_offset", C.c_int32),
-                ("step_counter", C.c_void_p), ("sumsq_partials", C.c_void_p), ("n_sumsq_partials", C.c_int32)]
+                ("step_counter", C.c_void_p), ("skip_begin", C.c_int32), ("skip_end", C.c_int32),
+                ("sumsq_partials", C.c_void_p), ("n_sumsq_partials", C.c_int32)]
 
 
 class DdpgCfg(C.Structure):

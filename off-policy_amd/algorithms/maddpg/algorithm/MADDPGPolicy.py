@@ -44,8 +44,6 @@ class MADDPGPolicy(object):
         self.args = config["args"]
         require_reference_architecture(self.args)
         self.tau, self.lr, self.opti_eps, self.weight_decay = self.args.tau, self.args.lr, self.args.opti_eps, self.args.weight_decay
-        if self.weight_decay != 0:
-            raise NotImplementedError("weight_decay != 0: upstream skips grad-less tensors (fc_h); not replicated yet")
         self.central_obs_dim, self.central_act_dim = policy_config["cent_obs_dim"], policy_config["cent_act_dim"]
         self.obs_space, self.act_space = policy_config["obs_space"], policy_config["act_space"]
         self.obs_dim, self.act_dim = get_dim_from_space(self.obs_space), get_dim_from_space(self.act_space)

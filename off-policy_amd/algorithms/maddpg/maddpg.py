@@ -70,11 +70,12 @@ class MADDPG(object):
             return self.shared_train_policy_on_batch(update_policy_id, batch)
         raise NotImplementedError("cent_train_policy_on_batch is broken upstream (SURVEY A-5) and not on the accelerated path")
 
-    def _adam(self, opt, n, flat, flat_tgt, grad, scratch, tail):
+    def _adam(self, opt, n, flat, flat_tgt, grad, scratch, tail, skip=(0, 0)):
         opt.step_count += 1
         ac = _lib.AdamCfg()
         ac.lr, ac.beta1, ac.beta2, ac.eps = opt.lr, opt.betas[0], opt.betas[1], opt.eps
-        ac.max_grad_norm, ac.weight_decay = float(self.args.max_grad_norm), 0.0
+        ac.max_grad_norm, ac.weight_decay = float(self.args.max_grad_norm), float(getattr(self.args, "weight_decay", 0.0))
+        ac.skip_begin, ac.skip_end = skip          # the unused fc_h block: torch's Adam never touches grad-less tensors
         ac.tau, ac.do_polyak = (float(self.args.tau), 1) if self.fuse_soft_update else (0.0, 0)
         ac.step, ac.qtot_denominator, ac.tail_offset = opt.step_count, 1.0, int(tail)
         if opt.step_dev is not None:
@@ -122,7 +123,7 @@ class MADDPG(object):
                                                           _lib.ptr(prio), st), "ope_ddpg_critic_loss_and_grad")
         opdist.allreduce_flat_(gc)
         cs = self._adam(policy.critic_optimizer, policy.critic.trainable_numel, policy.critic._flat, policy.target_critic._flat, gc,
-                        scratch, policy.critic.padded_numel)
+                        scratch, policy.critic.padded_numel, policy.critic.unused_range)
         train_info["critic_loss"], train_info["critic_grad_norm"] = cs[0], cs[1]
         new_priorities = (prio if dev_prio else prio.cpu().numpy()) if self.use_per else None
         # ---- actor ----
@@ -133,7 +134,7 @@ class MADDPG(object):
                                                              _lib.ptr(ga), st), "ope_ddpg_actor_loss_and_grad")
             opdist.allreduce_flat_(ga)
             as_ = self._adam(policy.actor_optimizer, policy.actor.padded_numel, policy.actor._flat, policy.target_actor._flat, ga,
-                             scratch, policy.actor.padded_numel)
+                             scratch, policy.actor.padded_numel, policy.actor.unused_range)
             train_info["actor_loss"], train_info["actor_grad_norm"] = as_[0], as_[1]
             train_info["update_actor"] = update_actor
         elif self.fuse_soft_update:      # no actor step this time: its target still takes its Polyak step

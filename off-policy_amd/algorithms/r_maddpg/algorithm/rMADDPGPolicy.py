@@ -25,8 +25,6 @@ class R_MADDPGPolicy(object):
         require_reference_architecture(self.args)
         a = self.args
         self.tau, self.lr, self.opti_eps, self.weight_decay = a.tau, a.lr, a.opti_eps, a.weight_decay
-        if self.weight_decay != 0:
-            raise NotImplementedError("weight_decay != 0: upstream skips grad-less tensors (fc_h); not replicated yet")
         self.prev_act_inp = bool(getattr(a, "prev_act_inp", False))
         if self.prev_act_inp:
             raise NotImplementedError("prev_act_inp=True is not on the accelerated path")

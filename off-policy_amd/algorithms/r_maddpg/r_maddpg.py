@@ -77,11 +77,12 @@ class R_MADDPG(object):
             return self.shared_train_policy_on_batch(update_policy_id, batch)
         raise NotImplementedError("cent_train_policy_on_batch (per-agent centralized observations) is not on the accelerated path")
 
-    def _adam(self, opt, n, flat, flat_tgt, grad, scratch, qden):
+    def _adam(self, opt, n, flat, flat_tgt, grad, scratch, qden, skip=(0, 0)):
         opt.step_count += 1
         ac = _lib.AdamCfg()
         ac.lr, ac.beta1, ac.beta2, ac.eps = opt.lr, opt.betas[0], opt.betas[1], opt.eps
-        ac.max_grad_norm, ac.weight_decay, ac.tau, ac.do_polyak = float(self.args.max_grad_norm), 0.0, 0.0, 0
+        ac.max_grad_norm, ac.weight_decay, ac.tau, ac.do_polyak = float(self.args.max_grad_norm), float(getattr(self.args, "weight_decay", 0.0)), 0.0, 0
+        ac.skip_begin, ac.skip_end = skip          # the unused fc_h block: torch's Adam never touches grad-less tensors
         ac.step, ac.qtot_denominator, ac.tail_offset = opt.step_count, float(qden), int(n)
         stats = torch.empty(4, **self.tpdv)
         _lib.check(_lib.lib.ope_adam_step(C.byref(ac), int(n), _lib.ptr(flat), _lib.ptr(flat_tgt), _lib.ptr(opt.exp_avg),
@@ -151,7 +152,7 @@ class R_MADDPG(object):
                                                            _lib.ptr(td_stats), st), "ope_rddpg_critic_loss_and_grad")
         opdist.allreduce_flat_(gc)
         cs = self._adam(policy.critic_optimizer, policy.critic.padded_numel, policy.critic._flat, policy.target_critic._flat, gc, scratch,
-                        T * B * world_size)
+                        T * B * world_size, policy.critic.unused_range)
         train_info["critic_loss"], train_info["critic_grad_norm"] = cs[0], cs[1]
         new_priorities = None
         if self.use_per and dev_prio:
@@ -172,7 +173,7 @@ class R_MADDPG(object):
                                                               _lib.ptr(ga), st), "ope_rddpg_actor_loss_and_grad")
             opdist.allreduce_flat_(ga)
             as_ = self._adam(policy.actor_optimizer, policy.actor.padded_numel, policy.actor._flat, policy.target_actor._flat, ga, scratch,
-                             1.0)
+                             1.0, policy.actor.unused_range)
             train_info["actor_grad_norm"], train_info["actor_loss"] = as_[1], as_[0]
         train_info["update_actor"] = update_actor
         self.num_updates[pid] += 1

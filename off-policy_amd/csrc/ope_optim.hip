@@ -48,6 +48,7 @@ struct AdamK {
   int nblocks;
   long long tail;   // index of [loss_sum, mask_count, qtot_sum] in g
   float lr;                 // with a device step counter the bias corrections are formed in the kernel
+  long long skip_begin, skip_end;   // elements Adam leaves alone (grad-less tensors); Polyak still applies
   const int* step_counter;
 };
 
@@ -87,6 +88,10 @@ __global__ void __launch_bounds__(kBlock) adam_kernel(AdamK c, int64_t n, float*
     const int64_t i = base + q;
     if (i >= n) break;
     float th = theta[i];
+    if (i >= c.skip_begin && i < c.skip_end) {      // grad-less tensor: torch's Adam does not touch it
+      if (c.do_polyak) tgt[i] = tgt[i] * (1.0f - c.tau) + th * c.tau;
+      continue;
+    }
     float gi = g[i] * scale;
     if (c.wd != 0.f) gi = fmaf(c.wd, th, gi);
     const float mi = c.beta1 * m[i] + (1.0f - c.beta1) * gi;
@@ -133,6 +138,7 @@ extern "C" int ope_adam_step(const ope_adam_cfg* cfg, int64_t n, float* theta, f
   c.wd = cfg->weight_decay; c.tau = cfg->tau; c.qden = cfg->qtot_denominator; c.do_polyak = cfg->do_polyak;
   c.nblocks = have_parts ? cfg->n_sumsq_partials : nb;
   c.lr = cfg->lr; c.step_counter = cfg->step_counter;
+  c.skip_begin = cfg->skip_begin; c.skip_end = cfg->skip_end;
   c.tail = cfg->tail_offset > 0 ? cfg->tail_offset : n;
   hipLaunchKernelGGL(adam_kernel, dim3(nb), dim3(kBlock), 0, st, c, n, theta, theta_tgt, adam_m, adam_v, grad,
                      have_parts ? cfg->sumsq_partials : scratch, stats_out);

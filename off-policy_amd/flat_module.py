@@ -51,3 +51,16 @@ class FlatModule(_Node):
 
     def spec(self):
         return OrderedDict((n, (s, o)) for n, s, o in self._spec)
+
+    @property
+    def unused_range(self):
+        """[begin, end) of the registered-but-unused `fc_h` block in the flat vector (mlp.py:21-23): tensors that never get a
+        gradient, which torch's Adam therefore never touches (no weight decay either). (0, 0) if the module has none."""
+        spans = []
+        for name, shape, off in self._spec:
+            if ".fc_h." in name:
+                n = 1
+                for d in shape:
+                    n *= d
+                spans.append((off, off + n))
+        return (min(a for a, _ in spans), max(b for _, b in spans)) if spans else (0, 0)

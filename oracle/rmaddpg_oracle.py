@@ -60,6 +60,8 @@ class RMaddpgOracle(object):
         bc1, bc2 = 1 - b1 ** st[2], 1 - b2 ** st[2]
         for k, g in zip(names, g_list):
             g = g * coef
+            if hp.weight_decay != 0:      # torch.optim.Adam: L2 term added to the (already clipped) gradient of tensors that have one
+                g = g + hp.weight_decay * params[k]
             if k not in st[0]:
                 st[0][k], st[1][k] = torch.zeros_like(g), torch.zeros_like(g)
             m = st[0][k].mul_(b1).add_(g, alpha=1 - b1)

@@ -8,13 +8,13 @@ from oracle import maddpg_oracle as DO
 from oracle.qmix_oracle import HP
 from test_mlp_oracle_golden import T_KEYS
 
-CASES = ["maddpg_spread", "matd3_spread", "maddpg_small_huber_per", "matd3_small"]
+CASES = ["maddpg_spread", "matd3_spread", "maddpg_small_huber_per", "matd3_small", "maddpg_small_wd"]
 
 
 def ddpg_oracle_from(g):
     hp = HP(gamma=float(g["hp_gamma"]), lr=float(g["hp_lr"]), opti_eps=float(g["hp_eps"]), use_huber_loss=bool(g["hp_huber"]),
             huber_delta=float(g["hp_delta"]), use_per=bool(g["hp_per"]), per_eps=float(g["hp_per_eps"]), tau=float(g["hp_tau"]),
-            max_grad_norm=float(g["hp_maxnorm"]))
+            max_grad_norm=float(g["hp_maxnorm"]), weight_decay=float(g["hp_wd"]) if "hp_wd" in g else 0.0)
     return DO.MaddpgOracle(sub(g, "actor/"), sub(g, "critic/"), (g["heads/w"], g["heads/b"]), sub(g, "actor_tgt/"),
                            sub(g, "critic_tgt/"), (g["heads_tgt/w"], g["heads_tgt/b"]), int(g["dims"][0]), hp, td3=bool(g["td3"]))
 

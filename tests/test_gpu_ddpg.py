@@ -23,7 +23,7 @@ def build(g, device="cuda:0"):
     dims = EnvDims("fx", n, a, d, s, 1)
     args = default_args(gamma=float(g["hp_gamma"]), lr=float(g["hp_lr"]), opti_eps=float(g["hp_eps"]), use_huber_loss=bool(g["hp_huber"]),
                         huber_delta=float(g["hp_delta"]), use_per=bool(g["hp_per"]), per_eps=float(g["hp_per_eps"]), tau=float(g["hp_tau"]),
-                        max_grad_norm=float(g["hp_maxnorm"]))
+                        max_grad_norm=float(g["hp_maxnorm"]), weight_decay=float(g["hp_wd"]) if "hp_wd" in g else 0.0)
     pinfo = policy_info_for(dims)
     dev = torch.device(device)
     torch.manual_seed(1)
