@@ -32,15 +32,15 @@ class M_QMix(QMix):
 
     def train_policy_on_batch(self, batch, use_same_share_obs=True):
         """See mqmix.py:68-218. `batch` is the 13-tuple of MlpReplayBuffer.sample()."""
-        if not use_same_share_obs:
-            raise NotImplementedError("use_same_share_obs=False is not on the accelerated path")
         (obs_b, cent_b, act_b, rew_b, nobs_b, cent_nobs_b, dones_b, dones_env_b, valid_b, avail_b, navail_b,
          importance_weights, idxes) = batch
         pid = self.policy_ids[0]
         dev = self.device
         f = lambda x: torch.as_tensor(x, dtype=torch.float32).to(dev)
         obs = _stack_pair(obs_b[pid], nobs_b[pid], dev)                      # [2, N, B, D]
-        share = _stack_pair(cent_b[pid], cent_nobs_b[pid], dev)              # [2, B, S]
+        # the mixer's state: the shared centralized observation, or agent 0's when every agent has its own (mqmix.py:78-84)
+        cent, ncent = (cent_b[pid], cent_nobs_b[pid]) if use_same_share_obs else (cent_b[pid][0], cent_nobs_b[pid][0])
+        share = _stack_pair(cent, ncent, dev)                                # [2, B, S]
         acts = f(act_b[pid])[None].contiguous()                              # [1, N, B, A]
         rew = f(rew_b[pid])[None].contiguous()                               # [1, N, B, 1]
         dones_env = f(dones_env_b[pid])[None].contiguous()                   # [1, B, 1]

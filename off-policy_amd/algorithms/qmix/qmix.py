@@ -72,8 +72,6 @@ class QMix(object):
         if self.policy_ids != ["policy_0"] or len(self.policy_agents["policy_0"]) != num_agents:
             raise NotImplementedError("the accelerated QMIX path handles one shared policy ('policy_0') for all agents")
         self.use_same_share_obs = args.use_same_share_obs
-        if not self.use_same_share_obs:
-            raise NotImplementedError("use_same_share_obs=False is not on the accelerated path")
         self.vdn = bool(vdn)
         policy = self.policies["policy_0"]
         # the kernels see the network's input width: observation (+ previous one-hot action with prev_act_inp)
@@ -174,7 +172,9 @@ class QMix(object):
         obs_b, cent_b, act_b, rew_b, dones_b, dones_env_b, avail_b, importance_weights, idxes = batch
         pid = self.policy_ids[0]
         obs = self._to_device_layout(obs_b[pid], True)
-        share = self._to_device_layout(cent_b[pid], False)
+        # the mixer's state: the shared centralized observation, or agent 0's when every agent has its own (qmix.py:86-90)
+        cent = cent_b[pid] if self.use_same_share_obs else cent_b[pid][0]
+        share = self._to_device_layout(cent, False)
         acts = self._to_device_layout(act_b[pid], True)
         rew = self._to_device_layout(rew_b[pid], True)
         dones_env = self._to_device_layout(dones_env_b[pid], False)

@@ -58,7 +58,7 @@ class MlpPolicyBuffer(object):
         obs = np.asarray(obs)
         assert obs.shape[0] == num_insert_steps, ("different size!")
         share_obs, next_share_obs = np.asarray(share_obs), np.asarray(next_share_obs)
-        if share_obs.ndim == 3:       # per-agent copies of the shared observation
+        if self.use_same_share_obs and share_obs.ndim == 3:       # per-agent copies of the shared observation (mlp_buffer.py:176-178)
             share_obs, next_share_obs = share_obs[:, 0], next_share_obs[:, 0]
         av = np.stack((np.asarray(avail_acts), np.asarray(next_avail_acts))) if self.use_avail_acts else None
         idx_range = self._ep.insert(num_insert_steps, np.stack((obs, np.asarray(next_obs))),
@@ -96,6 +96,8 @@ class MlpPolicyBuffer(object):
                                                  C.byref(of), _lib.ptr(self._ep._bad_index), _lib.current_stream()), "ope_store_gather")
             if not torch.is_tensor(inds):
                 self._ep._release_inds()
+        if not self.use_same_share_obs:   # per-agent centralized observations: [N, B, S] like the reference's _cast
+            share = (share[:, 0], share[:, 1])
         return (obs[:, 0], share[0], acts[:, 0], rew[:, 0], obs[:, 1], share[1], dones[:, 0], dones_env[0], valid[0],
                 avail[:, 0] if avail is not None else None, avail[:, 1] if avail is not None else None)
 

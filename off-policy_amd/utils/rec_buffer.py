@@ -54,8 +54,6 @@ class RecPolicyBuffer(object):
         self.use_same_share_obs = use_same_share_obs
         self.use_avail_acts = use_avail_acts
         self.use_reward_normalization = use_reward_normalization
-        if not use_same_share_obs:
-            raise NotImplementedError("per-agent centralized observations are not on the accelerated path yet")
         # normalised to an indexed device ("cuda" -> "cuda:0") so that device comparisons with tensors hold
         self.device = torch.empty(0, device=torch.device(device if device is not None else "cuda:0")).device
         self._bad_index = torch.zeros(1, dtype=torch.int32, device=self.device)   # set by the kernels on an out-of-range index
@@ -70,7 +68,10 @@ class RecPolicyBuffer(object):
         z = dict(dtype=torch.float32, device=self.device)
         # same initial values as rec_buffer.py:120-141 (avail/dones/dones_env default to ones)
         self.obs = torch.zeros((cap, T + 1, N, obs_dim), **z)
-        self.share_obs = torch.zeros((cap, T + 1, share_dim), **z)
+        # shared centralized observation [cap, T+1, S], or one per agent [cap, T+1, N, S] (rec_buffer.py:120-125). The
+        # per-agent form rides the kernels' agent-indexed `obs` slot in a second launch (dims with obs_dim = S): no ABI change.
+        self.share_obs = torch.zeros((cap, T + 1, share_dim) if use_same_share_obs else (cap, T + 1, N, share_dim), **z)
+        self._share_dims = _lib.Dims(N, act_dim, share_dim, share_dim, T)
         self.acts = torch.zeros((cap, T, N, act_dim), **z)
         self.avail_acts = torch.ones((cap, T + 1, N, act_dim), **z) if use_avail_acts else None
         self.rewards = torch.zeros((cap, T, N, 1), **z)
@@ -145,8 +146,14 @@ class RecPolicyBuffer(object):
         return f
 
     def _store_fields(self):
-        return self._fields(dict(obs=self.obs, share_obs=self.share_obs, acts=self.acts, rewards=self.rewards,
-                                 dones=self.dones, dones_env=self.dones_env, avail_acts=self.avail_acts))
+        return self._fields(dict(obs=self.obs, share_obs=self.share_obs if self.use_same_share_obs else None, acts=self.acts,
+                                 rewards=self.rewards, dones=self.dones, dones_env=self.dones_env, avail_acts=self.avail_acts))
+
+    def _obs_slot(self, t):
+        """Fields block with only the agent-indexed `obs` slot set (per-agent centralized observations use it with obs_dim = S)."""
+        f = _lib.Fields()
+        f.obs = _lib.ptr(t).value
+        return f
 
     def insert(self, num_insert_episodes, obs, share_obs, acts, rewards, dones, dones_env, avail_acts=None):
         """Ring write of `num_insert_episodes` episodes given in the reference's time-major layout
@@ -156,9 +163,11 @@ class RecPolicyBuffer(object):
         n = int(num_insert_episodes)
         idx_range = self._ring.next_slots(n)
         share_obs = np.asarray(share_obs)
-        if share_obs.ndim == 4:
-            share_obs = share_obs[:, :, 0]          # all agents share the centralized observation
-        host = dict(obs=obs, share_obs=share_obs, acts=acts, rewards=rewards, dones=dones, dones_env=dones_env)
+        if self.use_same_share_obs and share_obs.ndim == 4:
+            share_obs = share_obs[:, :, 0]          # all agents share the centralized observation (rec_buffer.py:176-177)
+        host = dict(obs=obs, acts=acts, rewards=rewards, dones=dones, dones_env=dones_env)
+        if self.use_same_share_obs:
+            host["share_obs"] = share_obs
         if self.use_avail_acts:
             host["avail_acts"] = avail_acts
         staged = {k: torch.from_numpy(np.ascontiguousarray(np.asarray(v), dtype=np.float32)).to(self.device, non_blocking=False)
@@ -169,6 +178,12 @@ class RecPolicyBuffer(object):
             sf.avail_acts = None
         _lib.check(_lib.lib.ope_store_insert(C.byref(self.dims), self.buffer_size, C.byref(df), C.byref(sf),
                                              _lib.ptr(slots), n, _lib.ptr(self._bad_index), _lib.current_stream()), "ope_store_insert")
+        if not self.use_same_share_obs:   # [T+1, n, N, S] -> the per-agent ring, through the obs slot
+            assert share_obs.ndim == 4, "per-agent centralized observations expected ([T+1, n, N, S])"
+            staged["share_obs"] = torch.from_numpy(np.ascontiguousarray(share_obs, dtype=np.float32)).to(self.device)
+            _lib.check(_lib.lib.ope_store_insert(C.byref(self._share_dims), self.buffer_size, C.byref(self._obs_slot(self.share_obs)),
+                                                 C.byref(self._obs_slot(staged["share_obs"])), _lib.ptr(slots), n, _lib.ptr(self._bad_index),
+                                                 _lib.current_stream()), "ope_store_insert(share_obs)")
         self._keepalive = (staged, slots)   # until the stream has consumed them
         self._stats_dirty = True
         return idx_range
@@ -186,7 +201,8 @@ class RecPolicyBuffer(object):
         d, B = self.dims, int(batch_size)
         T, N = d.episode_length, d.n_agents
         e = dict(dtype=torch.float32, device=self.device)
-        out = dict(obs=torch.empty((T + 1, N, B, d.obs_dim), **e), share_obs=torch.empty((T + 1, B, d.state_dim), **e),
+        out = dict(obs=torch.empty((T + 1, N, B, d.obs_dim), **e),
+                   share_obs=torch.empty((T + 1, B, d.state_dim) if self.use_same_share_obs else (T + 1, N, B, d.state_dim), **e),
                    acts=torch.empty((T, N, B, d.act_dim), **e), rewards=torch.empty((T, N, B, 1), **e),
                    dones=torch.empty((T, N, B, 1), **e), dones_env=torch.empty((T, B, 1), **e))
         if self.use_avail_acts:
@@ -218,7 +234,7 @@ class RecPolicyBuffer(object):
             out = self.alloc_batch(B)
         else:
             assert out["obs"].shape[2] == B, "destination batch does not match the number of indices"
-        of, sf = self._fields(out), self._store_fields()
+        of, sf = self._fields(out if self.use_same_share_obs else {k: v for k, v in out.items() if k != "share_obs"}), self._store_fields()
         if timing_events is not None:
             timing_events[0].record()
         if host_inds is not None:
@@ -227,6 +243,15 @@ class RecPolicyBuffer(object):
         else:
             _lib.check(_lib.lib.ope_store_gather(C.byref(d), self.buffer_size, C.byref(sf), _lib.ptr(dev_inds), B,
                                                  C.byref(of), _lib.ptr(self._bad_index), _lib.current_stream()), "ope_store_gather")
+        if not self.use_same_share_obs:   # per-agent centralized observations: second gather through the obs slot
+            so, ss = self._obs_slot(out["share_obs"]), self._obs_slot(self.share_obs)
+            if host_inds is not None:
+                _lib.check(_lib.lib.ope_store_gather_host_inds(C.byref(self._share_dims), self.buffer_size, C.byref(ss),
+                                                               host_inds.ctypes.data_as(C.c_void_p), B, C.byref(so), _lib.current_stream()),
+                           "ope_store_gather_host_inds(share_obs)")
+            else:
+                _lib.check(_lib.lib.ope_store_gather(C.byref(self._share_dims), self.buffer_size, C.byref(ss), _lib.ptr(dev_inds), B,
+                                                     C.byref(so), _lib.ptr(self._bad_index), _lib.current_stream()), "ope_store_gather(share_obs)")
         if timing_events is not None:
             timing_events[1].record()
         if host_inds is None and not torch.is_tensor(sample_inds):
@@ -235,7 +260,8 @@ class RecPolicyBuffer(object):
             _lib.check(_lib.lib.ope_reward_normalize(_lib.ptr(out["rewards"]), out["rewards"].numel(), _lib.ptr(self.reward_stats()),
                                                      _lib.current_stream()), "ope_reward_normalize")
         cast = lambda x: x.permute(1, 0, 2, 3)      # [N, T(+1), B, dim] view, as the reference's _cast
-        return (cast(out["obs"]), out["share_obs"], cast(out["acts"]), cast(out["rewards"]), cast(out["dones"]),
+        return (cast(out["obs"]), out["share_obs"] if self.use_same_share_obs else cast(out["share_obs"]), cast(out["acts"]),
+                cast(out["rewards"]), cast(out["dones"]),
                 out["dones_env"], cast(out["avail_acts"]) if self.use_avail_acts else None)
 
 

@@ -70,11 +70,13 @@ def named(module, prefix):
 
 
 def run_case(name, dims, n_episodes, inds, steps=3, argv=(), vdn=False, avail="ones", runner_padding=False,
-             per_weights=None, store_inputs=True, cap=None, pre_insert=0, **over):
+             per_weights=None, store_inputs=True, cap=None, pre_insert=0, per_agent_share=False, **over):
+    if per_agent_share:      # every agent has its own centralized observation; QMix's mixer reads agent 0's (qmix.py:86-90)
+        over = dict(over, use_same_share_obs=False)
     args, pinfo, policy, trainer = build(dims, argv, vdn=vdn, **over)
     cap = cap or n_episodes
     agents = {"policy_0": list(range(dims.n_agents))}
-    buf = RecReplayBuffer(pinfo, agents, cap, dims.episode_length, True, True, False)
+    buf = RecReplayBuffer(pinfo, agents, cap, dims.episode_length, not per_agent_share, True, False)
     rng = np.random.RandomState(0)
     out = {}
     if pre_insert:
@@ -88,6 +90,8 @@ def run_case(name, dims, n_episodes, inds, steps=3, argv=(), vdn=False, avail="o
             for k in ("obs", "share_obs", "acts", "rewards", "dones", "dones_env", "avail_acts"):
                 out["pre_ep/" + k] = ep0[k]
     ep = synth_episodes(rng, n_episodes, dims, avail=avail, runner_padding=runner_padding)
+    if per_agent_share:      # make the agents' copies differ, so that using any other than agent 0's shows
+        ep["share_obs"] = ep["share_obs"] + 0.25 * np.arange(dims.n_agents, dtype=np.float32)[None, None, :, None]
     d = as_policy_dicts(ep)
     idx_range = buf.insert(n_episodes, d["obs"], d["share_obs"], d["acts"], d["rewards"], d["dones"],
                            d["dones_env"], d["avail_acts"])
@@ -117,6 +121,7 @@ def run_case(name, dims, n_episodes, inds, steps=3, argv=(), vdn=False, avail="o
     out["hp_tau"], out["hp_maxnorm"], out["hp_double_q"] = np.float64(args.tau), np.float64(args.max_grad_norm), np.int64(args.use_double_q)
     out["vdn"] = np.int64(vdn)
     out["hp_prev_act_inp"] = np.int64(bool(getattr(args, "prev_act_inp", False)))
+    out["hp_same_share"] = np.int64(not per_agent_share)
     losses, gnorms, qtots, prios = [], [], [], []
     for s in range(steps):
         batch = tuple({"policy_0": a} for a in sampled) + (per_weights, inds if per_weights is not None else None)
@@ -153,6 +158,9 @@ def run_case(name, dims, n_episodes, inds, steps=3, argv=(), vdn=False, avail="o
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     tiny = DIMS["tiny"]
+    if os.environ.get("OPE_GOLDEN_ONLY") == "pershare":      # add the round-2 fixture without rewriting the committed ones
+        run_case("qmix_tiny_pershare", tiny, n_episodes=5, inds=[4, 1, 1, 0, 2], cap=6, pre_insert=3, avail="bernoulli", per_agent_share=True)
+        return
     # 1. tiny dims, masked availability, MSE, ring wrap-around on insert, repeated index in the sample
     run_case("qmix_tiny", tiny, n_episodes=5, inds=[3, 0, 5, 3], cap=6, pre_insert=4, avail="bernoulli")
     # 2. tiny dims, Huber + PER weights + runner-style padding after the episode end
@@ -172,6 +180,8 @@ def main():
     run_case("qmix_odd", odd, n_episodes=6, inds=[5, 1, 1, 2, 0, 4, 3], avail="bernoulli")
     # 7. previous action as a network input (config.py:81, QMixPolicy.py:29-33, qmix.py:123-124)
     run_case("qmix_tiny_prevact", tiny, n_episodes=5, inds=[4, 2, 0, 1], avail="bernoulli", argv=["--prev_act_inp"])
+    # use_same_share_obs = False: per-agent centralized observations in the buffer, agent 0's feeds the mixer
+    run_case("qmix_tiny_pershare", tiny, n_episodes=5, inds=[4, 1, 1, 0, 2], cap=6, pre_insert=3, avail="bernoulli", per_agent_share=True)
 
 
 if __name__ == "__main__":

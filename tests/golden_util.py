@@ -36,14 +36,15 @@ def reference_store_from(g):
     n_pre = int(g["pre_idx_range"].shape[0]) if "pre_idx_range" in g else 0
     cap = int(max(g["idx_range"].max(), g["pre_idx_range"].max() if n_pre else 0)) + 1
     cap = max(cap, int(g["filled_i"]))
-    st = dict(obs=np.zeros((T + 1, cap, N, D), np.float32), share_obs=np.zeros((T + 1, cap, S), np.float32),
+    same = bool(g["hp_same_share"]) if "hp_same_share" in g else True
+    st = dict(obs=np.zeros((T + 1, cap, N, D), np.float32), share_obs=np.zeros((T + 1, cap, S) if same else (T + 1, cap, N, S), np.float32),
               acts=np.zeros((T, cap, N, A), np.float32), avail_acts=np.ones((T + 1, cap, N, A), np.float32),
               rewards=np.zeros((T, cap, N, 1), np.float32), dones=np.ones((T, cap, N, 1), np.float32),
               dones_env=np.ones((T, cap, 1), np.float32))
 
     def put(ep, idx):
         for k in EP_KEYS:
-            v = ep[k][:, :, 0] if k == "share_obs" else ep[k]
+            v = ep[k][:, :, 0] if (k == "share_obs" and same) else ep[k]
             st[k][:, idx] = v
     if n_pre:
         put({k: g["pre_ep/" + k] for k in EP_KEYS}, g["pre_idx_range"])

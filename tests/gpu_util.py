@@ -12,7 +12,8 @@ def make_args(g, **over):
                      use_huber_loss=bool(g["hp_huber"]), huber_delta=float(g["hp_delta"]), use_per=bool(g["hp_per"]),
                      per_nu=float(g["hp_nu"]), per_eps=float(g["hp_per_eps"]), tau=float(g["hp_tau"]),
                      max_grad_norm=float(g["hp_maxnorm"]), use_double_q=bool(g["hp_double_q"]),
-                     prev_act_inp=bool(g["hp_prev_act_inp"]) if "hp_prev_act_inp" in g else False)
+                     prev_act_inp=bool(g["hp_prev_act_inp"]) if "hp_prev_act_inp" in g else False,
+                     use_same_share_obs=bool(g["hp_same_share"]) if "hp_same_share" in g else True)
     for k, v in over.items():
         setattr(a, k, v)
     return a
@@ -29,8 +30,8 @@ def build_from_fixture(g, device="cuda:0"):
     pinfo = policy_info_for(dims)
     n_pre = int(g["pre_idx_range"].shape[0]) if "pre_idx_range" in g else 0
     cap = max(int(g["filled_i"]), int(g["idx_range"].max()) + 1)
-    buf = RecReplayBuffer(pinfo, {"policy_0": list(range(dims.n_agents))}, cap, dims.episode_length, True, True, False,
-                          device=device)
+    buf = RecReplayBuffer(pinfo, {"policy_0": list(range(dims.n_agents))}, cap, dims.episode_length, bool(args.use_same_share_obs), True,
+                          False, device=device)
     if n_pre:
         d0 = as_policy_dicts({k: g["pre_ep/" + k] for k in EP_KEYS})
         r0 = buf.insert(n_pre, d0["obs"], d0["share_obs"], d0["acts"], d0["rewards"], d0["dones"], d0["dones_env"], d0["avail_acts"])

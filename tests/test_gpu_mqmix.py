@@ -94,3 +94,36 @@ def test_policy_q_values_match_oracle():
     np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=2e-6)
     acts, gq = policy.get_actions(x.cuda())
     assert np.array_equal(acts.argmax(-1), ref.argmax(-1).numpy())
+
+
+def test_per_agent_centralized_observations_use_agent_zero():
+    """use_same_share_obs = False (mlp_buffer.py:135-139, mqmix.py:78-84): the buffer keeps one centralized observation per
+    agent and returns it as [N, B, S]; the mixer reads agent 0's. So a per-agent run whose agent-0 copies equal the shared
+    observations of the reference fixture -- and whose other agents' copies are garbage -- must reproduce the fixture."""
+    from offpolicy_amd.utils.mlp_buffer import MlpReplayBuffer
+    from offpolicy_amd.utils.synth import policy_info_for
+    g = load_golden("mqmix_spread")
+    dims, _, policy, trainer = build(g)
+    n = dims.n_agents
+    buf = MlpReplayBuffer(policy_info_for(dims), {"policy_0": list(range(n))}, int(g["cap"]), False, True, False, device="cuda:0")
+    rng = np.random.RandomState(1)
+
+    def per_agent(x):           # [n_steps, S] -> [n_steps, N, S]: agent 0 = the shared observation, the rest noise
+        out = rng.standard_normal((x.shape[0], n, x.shape[-1])).astype(np.float32)
+        out[:, 0] = x if x.ndim == 2 else x[:, 0]
+        return out
+    for pre in (["pre_tr/"] if "pre_idx_range" in g else []) + ["tr/"]:
+        d = {k: g[pre + k] for k in T_KEYS}
+        d["share_obs"], d["next_share_obs"] = per_agent(d["share_obs"]), per_agent(d["next_share_obs"])
+        buf.insert(d["obs"].shape[0], *[{"policy_0": d[k]} for k in T_KEYS])
+    s = buf.policy_buffers["policy_0"].sample_inds(g["inds"])
+    B = len(g["inds"])
+    assert tuple(s[1].shape) == (n, B, dims.state_dim) and tuple(s[5].shape) == (n, B, dims.state_dim)
+    ref_share = g["batch/share_obs"] if g["batch/share_obs"].ndim == 2 else g["batch/share_obs"][:, 0]
+    assert np.array_equal(s[1][0].cpu().numpy(), ref_share)
+    batch = tuple({"policy_0": a} for a in s) + (None, None)
+    for st in range(len(g["loss"])):
+        info, _, _ = trainer.train_policy_on_batch(batch, False)
+        trainer.soft_target_updates()
+        np.testing.assert_allclose(float(info["loss"]), g["loss"][st], rtol=RTOL)
+        np.testing.assert_allclose(float(info["grad_norm"]), g["grad_norm"][st], rtol=RTOL)

@@ -12,7 +12,7 @@ from golden_util import oracle_from, reference_store_from
 from gpu_util import build_from_fixture, batch_from
 
 pytestmark = pytest.mark.gpu
-CASES = ["qmix_tiny", "qmix_tiny_huber_per", "qmix_tiny_nodouble", "vdn_tiny", "qmix_odd", "qmix_3m_katA", "qmix_tiny_prevact"]
+CASES = ["qmix_tiny", "qmix_tiny_huber_per", "qmix_tiny_nodouble", "vdn_tiny", "qmix_odd", "qmix_3m_katA", "qmix_tiny_prevact", "qmix_tiny_pershare"]
 RTOL = 1e-4
 
 

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 FIELDS = ("obs", "share_obs", "acts", "rewards", "dones", "dones_env", "avail_acts")
 
 
-@pytest.mark.parametrize("name", ["qmix_tiny", "qmix_tiny_huber_per", "qmix_odd", "vdn_tiny"])
+@pytest.mark.parametrize("name", ["qmix_tiny", "qmix_tiny_huber_per", "qmix_odd", "vdn_tiny", "qmix_tiny_pershare"])
 def test_gather_bit_exact_vs_reference_fixture(name):
     """insert (with ring wrap) + sample_inds == what the reference's RecPolicyBuffer returned, bit for bit."""
     g = load_golden(name)
