@@ -46,7 +46,9 @@ typedef struct ope_dims {
 } ope_dims;
 
 /* Seven per-episode fields, in the order of RecPolicyBuffer.sample_inds' return tuple
- * (offpolicy/utils/rec_buffer.py:192-240): obs, share_obs, acts, rewards, dones, dones_env, avail_acts. */
+ * (offpolicy/utils/rec_buffer.py:192-240): obs, share_obs, acts, rewards, dones, dones_env, avail_acts -- plus the
+ * transition buffers' valid_transition flag (offpolicy/utils/mlp_buffer.py:94,196), which the store copies in the same launch.
+ * A NULL pointer = field not stored / not wanted. */
 typedef struct ope_fields {
   float* obs;        /* [.., T+1, N, D]                                    */
   float* share_obs;  /* [.., T+1, S]      (use_same_share_obs)             */
@@ -55,6 +57,7 @@ typedef struct ope_fields {
   float* dones;      /* [.., T,   N, 1]                                    */
   float* dones_env;  /* [.., T,   1]                                       */
   float* avail_acts; /* [.., T+1, N, A]                                    */
+  float* valid_transition; /* [.., T, N, 1]   MlpPolicyBuffer only; the training entry points ignore it */
 } ope_fields;
 
 /* ------------------------------------------------------------------------------------------------
@@ -214,17 +217,19 @@ typedef struct ope_adam_cfg {
   int32_t tail_offset;    /* index of the 4-float tail inside `grad`; <= 0 means n. Lets a PREFIX of a parameter vector
                            * be optimised (n < full length) while the tail stays behind the full gradient: MADDPG's
                            * critic, whose q heads are unregistered upstream (SURVEY A-4) and therefore frozen.     */
-  int32_t* step_counter;  /* optional DEVICE int32 holding the number of Adam steps taken so far. When non-NULL, `step` is
-                           * ignored: the call increments the counter on the device and uses the new value as t, so a
-                           * captured HIP graph of the update can be replayed with advancing bias correction.          */
+  int32_t* step_counter;  /* optional DEVICE int32[2]: [0] = number of Adam steps taken so far, [1] = 0 (scratch ticket, zero
+                           * between calls). When non-NULL, `step` is ignored: the update uses t = [0] + 1 and its last
+                           * workgroup stores t back, so a captured HIP graph of the update replays with an advancing bias
+                           * correction and without a separate "count += 1" launch.                                        */
   int32_t skip_begin, skip_end; /* elements [skip_begin, skip_end) are left untouched by Adam (no moment update, no step, no weight
                                  * decay) but still follow Polyak: tensors that never receive a gradient -- torch's Adam skips
                                  * them (the registered-but-unused fc_h block, SURVEY A-8). Only matters with weight_decay != 0:
                                  * with a zero gradient and zero moments the plain update is already a no-op. 0, 0 = none. */
   const float* sumsq_partials; /* optional DEVICE array of n_sumsq_partials floats whose sum is sum_i grad[i]^2 over the n    */
   int32_t n_sumsq_partials;    /* optimised elements, produced together with `grad` (ope_qmix_loss_and_grad leaves them in
-                                * its workspace region "gsq_part", see ope_qmix_workspace_find). When given (and
-                                * step_counter is NULL) the call skips its own norm pass over the gradient. ONLY valid if
+                                * its workspace region "gsq_part", see ope_qmix_workspace_find; the fused MADDPG path leaves them
+                                * in "gsq_critic" / "gsq_actor", see ope_ddpg_workspace_find). When given, the call skips
+                                * its own norm pass over the gradient. ONLY valid if
                                 * `grad` was not modified since (i.e. not on the all-reduced gradient of a multi-GPU run). */
 } ope_adam_cfg;
 int64_t ope_adam_scratch_floats(int64_t n);
@@ -247,6 +252,11 @@ typedef struct ope_ddpg_cfg {
                             0: onehot_from_logits argmax (MADDPG)  -- MADDPGPolicy.py:94-105 */
   int32_t use_huber, use_per;
   float gamma, huber_delta, per_eps;
+  uint64_t noise_seed;          /* != 0: when a call's uniform-noise argument is NULL the kernels draw it themselves -- Philox4x32-10 */
+  const int32_t* noise_counter; /* keyed by this seed, counter = (row, column, DEVICE int32 *noise_counter (0 if NULL), stream: 0 =
+                                 * target noise, 1 = actor noise). Same distribution as the reference's torch.rand, not the same
+                                 * stream; a captured graph replays with fresh noise if the counter advances on the device (e.g.
+                                 * the critic's ope_adam_cfg.step_counter). 0 = noise arguments are required as before.          */
 } ope_ddpg_cfg;
 
 /* One sampled batch in MlpPolicyBuffer.sample_inds order/shapes (mlp_buffer.py:213-257), device pointers. */
@@ -268,6 +278,9 @@ int64_t ope_ddpg_param_layout(const ope_ddpg_cfg* cfg, int32_t which, int64_t* o
 int64_t ope_ddpg_workspace_bytes(const ope_ddpg_cfg* cfg);
 int ope_ddpg_workspace_init(const ope_ddpg_cfg* cfg, void* workspace, int64_t workspace_bytes, void* stream);
 int64_t ope_ddpg_workspace_find(const ope_ddpg_cfg* cfg, const char* name, int64_t* n_floats);
+/* Regions "gsq_critic" / "gsq_actor" (present only on the fused small-network path; find returns < 0 otherwise): after a
+ * critic / actor loss_and_grad call they hold n_floats = 2m per-workgroup sums of grad^2 -- the first m over the trunk
+ * (MLPBase) elements, the last m over the head block -- for ope_adam_cfg.sumsq_partials. */
 /* Critic update (maddpg.py:100-157 + get_update_info 38-81): grad = d(sum_k sum_b f(target - Q_k) w_b)/d theta_critic
  * + tail [loss_sum, B, sum Q, 0]; prio_out[B] = mean_k |err_k| + per_eps (or NULL).
  * target_noise_u [N*B][A]: uniform(0,1) noise for the MATD3 target gumbel (NULL unless target_gumbel). */

@@ -28,7 +28,7 @@ class Dims(C.Structure):
 
 
 class Fields(C.Structure):
-    _fields_ = [(k, C.c_void_p) for k in ("obs", "share_obs", "acts", "rewards", "dones", "dones_env", "avail_acts")]
+    _fields_ = [(k, C.c_void_p) for k in ("obs", "share_obs", "acts", "rewards", "dones", "dones_env", "avail_acts", "valid_transition")]
 
 
 class QmixCfg(C.Structure):
@@ -48,7 +48,7 @@ class AdamCfg(C.Structure):
 class DdpgCfg(C.Structure):
     _fields_ = [("dims", Dims), ("batch", C.c_int32), ("num_q", C.c_int32), ("target_gumbel", C.c_int32),
                 ("use_huber", C.c_int32), ("use_per", C.c_int32), ("gamma", C.c_float), ("huber_delta", C.c_float),
-                ("per_eps", C.c_float)]
+                ("per_eps", C.c_float), ("noise_seed", C.c_uint64), ("noise_counter", C.c_void_p)]
 
 
 class RddpgCfg(C.Structure):

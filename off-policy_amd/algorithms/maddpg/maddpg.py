@@ -38,10 +38,11 @@ class MADDPG(object):
         self.use_same_share_obs = args.use_same_share_obs
         self.actor_update_interval = actor_update_interval
         self.count_updates = bool(count_updates)
+        self._noise_ctr = None
         self.device_noise = False     # True: gumbel noise drawn on the device instead of the reference's CPU generator stream
         self.fuse_soft_update = False  # True: Polyak of both target nets inside the Adam kernels; the next
                                        # policy.soft_target_updates() call is then skipped (same values, two launches fewer)
-        self._ws, self._grads = {}, {}
+        self._ws, self._grads, self._gsq = {}, {}, {}
 
     def _workspace(self, policy, cfg):
         B = cfg.batch
@@ -70,7 +71,22 @@ class MADDPG(object):
             return self.shared_train_policy_on_batch(update_policy_id, batch)
         raise NotImplementedError("cent_train_policy_on_batch is broken upstream (SURVEY A-5) and not on the accelerated path")
 
-    def _adam(self, opt, n, flat, flat_tgt, grad, scratch, tail, skip=(0, 0)):
+    def _gsq_region(self, cfg, ws, name, n_opt, n_all):
+        """(pointer, count) of the sum-of-squares partials the fused path left for the gradient just computed, or None.
+        Only usable on the un-reduced gradient (one process). `n_opt < n_all`: the head block is frozen, take the trunk half."""
+        if opdist.is_distributed():
+            return None
+        key = (cfg.batch, name)
+        if key not in self._gsq:
+            n = C.c_int64(0)
+            off = _lib.lib.ope_ddpg_workspace_find(C.byref(cfg), name.encode(), C.byref(n))
+            self._gsq[key] = (int(off), int(n.value)) if off >= 0 else None
+        r = self._gsq[key]
+        if r is None:
+            return None
+        return ws.data_ptr() + r[0], (r[1] // 2 if n_opt < n_all else r[1])
+
+    def _adam(self, opt, n, flat, flat_tgt, grad, scratch, tail, skip=(0, 0), gsq=None):
         opt.step_count += 1
         ac = _lib.AdamCfg()
         ac.lr, ac.beta1, ac.beta2, ac.eps = opt.lr, opt.betas[0], opt.betas[1], opt.eps
@@ -80,6 +96,8 @@ class MADDPG(object):
         ac.step, ac.qtot_denominator, ac.tail_offset = opt.step_count, 1.0, int(tail)
         if opt.step_dev is not None:
             ac.step_counter = _lib.ptr(opt.step_dev).value
+        if gsq is not None:
+            ac.sumsq_partials, ac.n_sumsq_partials = gsq
         stats = torch.empty(4, **self.tpdv)
         _lib.check(_lib.lib.ope_adam_step(C.byref(ac), int(n), _lib.ptr(flat), _lib.ptr(flat_tgt), _lib.ptr(opt.exp_avg),
                                           _lib.ptr(opt.exp_avg_sq), _lib.ptr(grad), _lib.ptr(scratch), _lib.ptr(stats),
@@ -109,7 +127,20 @@ class MADDPG(object):
         train_info = {}
         update_actor = self.num_updates[pid] % self.actor_update_interval == 0
         # ---- critic ----
-        draw = (lambda shape: torch.rand(shape, **self.tpdv)) if self.device_noise else (lambda shape: sample_gumbel_uniform(shape).to(self.device))
+        if self.device_noise:      # the kernels draw the gumbel noise themselves (Philox keyed by seed, step count, row)
+            draw = lambda shape: None
+            opt = policy.critic_optimizer
+            if opt.step_dev is not None:
+                ctr = opt.step_dev
+            else:
+                if self._noise_ctr is None:
+                    self._noise_ctr = torch.zeros(1, dtype=torch.int32, device=self.device)
+                self._noise_ctr += 1
+                ctr = self._noise_ctr
+            cfg.noise_seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + 0x1234567) % (1 << 64) | 1
+            cfg.noise_counter = _lib.ptr(ctr).value
+        else:
+            draw = lambda shape: sample_gumbel_uniform(shape).to(self.device)
         u_t = draw((N * B, policy.act_dim)) if policy.target_noise is not None else None
         dev_prio = torch.is_tensor(importance_weights)
         w = None
@@ -123,7 +154,8 @@ class MADDPG(object):
                                                           _lib.ptr(prio), st), "ope_ddpg_critic_loss_and_grad")
         opdist.allreduce_flat_(gc)
         cs = self._adam(policy.critic_optimizer, policy.critic.trainable_numel, policy.critic._flat, policy.target_critic._flat, gc,
-                        scratch, policy.critic.padded_numel, policy.critic.unused_range)
+                        scratch, policy.critic.padded_numel, policy.critic.unused_range,
+                        self._gsq_region(cfg, ws, "gsq_critic", policy.critic.trainable_numel, policy.critic.padded_numel))
         train_info["critic_loss"], train_info["critic_grad_norm"] = cs[0], cs[1]
         new_priorities = (prio if dev_prio else prio.cpu().numpy()) if self.use_per else None
         # ---- actor ----
@@ -134,7 +166,8 @@ class MADDPG(object):
                                                              _lib.ptr(ga), st), "ope_ddpg_actor_loss_and_grad")
             opdist.allreduce_flat_(ga)
             as_ = self._adam(policy.actor_optimizer, policy.actor.padded_numel, policy.actor._flat, policy.target_actor._flat, ga,
-                             scratch, policy.actor.padded_numel, policy.actor.unused_range)
+                             scratch, policy.actor.padded_numel, policy.actor.unused_range,
+                             self._gsq_region(cfg, ws, "gsq_actor", policy.actor.padded_numel, policy.actor.padded_numel))
             train_info["actor_loss"], train_info["actor_grad_norm"] = as_[0], as_[1]
             train_info["update_actor"] = update_actor
         elif self.fuse_soft_update:      # no actor step this time: its target still takes its Polyak step
@@ -163,7 +196,7 @@ class MADDPG(object):
         self.device_noise = True
         self.fuse_soft_update = True
         for opt in (policy.critic_optimizer, policy.actor_optimizer):
-            opt.step_dev = torch.tensor([opt.step_count], dtype=torch.int32, device=self.device)
+            opt.step_dev = torch.tensor([opt.step_count, 0], dtype=torch.int32, device=self.device)    # [count, ticket]
         static_inds = torch.zeros(B, dtype=torch.int64, device=self.device)
 
         def body():
@@ -199,7 +232,7 @@ class MADDPG(object):
         with torch.cuda.graph(graph):
             info = body()
         for opt in (policy.critic_optimizer, policy.actor_optimizer):      # capture ran the host code but no kernels
-            opt.step_count = int(opt.step_dev.item())
+            opt.step_count = int(opt.step_dev[0].item())
         ring = [(torch.empty(B, dtype=torch.int64).pin_memory(), torch.cuda.Event()) for _ in range(8)]
         state = {"k": 0, "used": [False] * 8}
 

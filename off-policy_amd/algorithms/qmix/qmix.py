@@ -214,7 +214,7 @@ class QMix(object):
         if self.optimizer.step_dev is not None:     # HIP-graph replays: the count advances on the device
             ac.step_counter = _lib.ptr(self.optimizer.step_dev).value
         ac.qtot_denominator = float(self.episode_length * B * world_size)
-        if world_size == 1 and self.optimizer.step_dev is None:
+        if world_size == 1:
             # the finalize launch of ope_qmix_loss_and_grad left per-workgroup partial sums of grad^2 in the workspace: the
             # optimizer call then needs no norm pass of its own (not valid for an all-reduced gradient)
             gsq = self._gsq.get(B)
@@ -257,7 +257,7 @@ class QMix(object):
         B = int(batch_size)
         self.fuse_soft_update = True
         opt = self.optimizer
-        opt.step_dev = torch.tensor([opt.step_count], dtype=torch.int32, device=self.device)
+        opt.step_dev = torch.tensor([opt.step_count, 0], dtype=torch.int32, device=self.device)    # [count, ticket]
         static_inds = torch.zeros(B, dtype=torch.int64, device=self.device)
 
         static_batch = None if gather_in_graph else pbuf.alloc_batch(B)
@@ -294,7 +294,7 @@ class QMix(object):
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             info = body()
-        opt.step_count = int(opt.step_dev.item())      # capture ran the host code but no kernels
+        opt.step_count = int(opt.step_dev[0].item())      # capture ran the host code but no kernels
         ring = [(torch.empty(B, dtype=torch.int64).pin_memory(), torch.cuda.Event()) for _ in range(8)]
         state = {"k": 0, "used": [False] * 8}
 

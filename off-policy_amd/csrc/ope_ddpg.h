@@ -1,6 +1,7 @@
 // Argument blocks of the MADDPG / MATD3 kernels.
 #pragma once
 #include "ope_mixer.h"
+#include "ope_rng.h"
 #include "ope_wgrad.h"
 #include "ope_workspace.h"
 
@@ -35,16 +36,18 @@ int launch_action_grad(const ActGradArgs& a, hipStream_t st);
 // shared with the recurrent family (ope_rddpg.hip)
 int launch_build_cin(const float* cent, const float* acts, const float* repl, int T, int B, int N, int A, int S, int reps, float* out,
                      hipStream_t st);
-int launch_action(const float* logits, const float* avail, const float* U, int rows, int B, int A, int N, int mode, int t_shift,
+int launch_action(const float* logits, const float* avail, NoiseSrc U, int rows, int B, int A, int N, int mode, int t_shift,
                   float* cent_nact, float* act_out, float* soft_out, hipStream_t st);
 
 // fused small-network path (ope_ddpg_fused.hip): one launch per network update + one slab reduction
 bool ddpg_fused_ok(int N, int A, int D, int S, int K);
+// workgroups of the slab reduction = half the floats of the "gsq_critic" / "gsq_actor" region ([trunk partials | head partials])
+int ddpg_fused_gsq_blocks(int N, int A, int D, int S, int K, bool critic);
 int64_t ddpg_fused_slab_floats(int N, int A, int D, int S, int K, int B);
 int launch_ddpg_critic_fused(const ope_ddpg_cfg* cfg, const ope_mlp_batch* bt, const float* theta_actor_tgt, const float* theta_critic,
                              const float* theta_critic_tgt, const float* U, const float* per_w, float* slabs, float* grad, float* prio_out,
-                             hipStream_t st);
+                             float* gsq, hipStream_t st);
 int launch_ddpg_actor_fused(const ope_ddpg_cfg* cfg, const ope_mlp_batch* bt, const float* theta_actor, const float* theta_critic,
-                            const float* U, float* slabs, float* grad, hipStream_t st);
+                            const float* U, float* slabs, float* grad, float* gsq, hipStream_t st);
 
 }  // namespace ope

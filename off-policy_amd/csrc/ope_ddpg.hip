@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(256) build_cin_kernel(const float* __restrict_
 // Blocks stage `rpb` rows through LDS so that all global traffic is coalesced and the gumbel transform (two logs per
 // element) is evaluated once; one thread then owns one row in LDS.
 __global__ void __launch_bounds__(256) action_kernel(const float* __restrict__ logits, const float* __restrict__ avail,
-                                                      const float* __restrict__ U, int rows, int B, int A, int N, int mode, int t_shift,
+                                                      NoiseSrc U, int rows, int B, int A, int N, int mode, int t_shift,
                                                       int rpb, float* __restrict__ cent_nact, float* __restrict__ act_out,
                                                       float* __restrict__ soft_out) {
   extern __shared__ float sm[];
@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(256) action_kernel(const float* __restrict__ l
   for (int e = threadIdx.x; e < nrows * A; e += blockDim.x) {
     const int rr = e / A, j = e - rr * A;
     float v = logits[base + e];
-    if (mode == 1) v += -logf(-logf(U[base + e] + 1e-20f) + 1e-20f);
+    if (mode == 1) v += -logf(-logf(U.at(r0 + rr, A, j) + 1e-20f) + 1e-20f);
     if (avail && avail[base + e] == 0.f) v = -1e10f;
     val[rr * pitch + j] = v;
   }
@@ -370,7 +370,7 @@ int launch_build_cin(const float* cent, const float* acts, const float* repl, in
                            reps, out));
   return OPE_OK;
 }
-int launch_action(const float* logits, const float* avail, const float* U, int rows, int B, int A, int N, int mode, int t_shift,
+int launch_action(const float* logits, const float* avail, NoiseSrc U, int rows, int B, int A, int N, int mode, int t_shift,
                   float* cent_nact, float* act_out, float* soft_out, hipStream_t st) {
   const int pitch = A | 1;
   const int rpb = pitch <= 31 ? 256 : 64;
@@ -402,7 +402,7 @@ struct DdpgPlan {
   int raw_size_c, raw_size_a;
   int P1, s1, P2, s2, E, sq;    // raw slab offsets (same recipe for actor and critic, sized by the larger)
   int64_t xin_t, xin, a2n, lgn, cnact, a2t, qt, a2c, qc, dq, da2, dz1, dz2, mu0, rstd0, xhat1, rstd1, mask1, xhat2, rstd2, mask2,
-      thetaT, raw, rsum, loss_part, lnz, lno, xin_a, a2a, lga, ysoft, actout, mu1, cvec, dlg, err, fused_slabs;
+      thetaT, raw, rsum, loss_part, lnz, lno, xin_a, a2a, lga, ysoft, actout, mu1, cvec, dlg, err, fused_slabs, gsq_critic, gsq_actor;
   bool fused;
 };
 
@@ -453,6 +453,10 @@ static void ddpg_plan(const ope_ddpg_cfg* c, DdpgPlan* p) {
   p->err = W.add("saves2", Ra * (2 * OPE_H + 8));
   p->fused = ddpg_fused_ok(p->N, p->A, p->D, p->S, p->K);
   p->fused_slabs = W.add("fused_slabs", p->fused ? ddpg_fused_slab_floats(p->N, p->A, p->D, p->S, p->K, p->B) + 64 : 4);   // + debug stamps
+  if (p->fused) {    // per-workgroup sums of squares of the gradient the slab reduction wrote (only the fused path produces them)
+    p->gsq_critic = W.add("gsq_critic", 2 * ddpg_fused_gsq_blocks(p->N, p->A, p->D, p->S, p->K, true));
+    p->gsq_actor = W.add("gsq_actor", 2 * ddpg_fused_gsq_blocks(p->N, p->A, p->D, p->S, p->K, false));
+  }
 }
 
 // trunk forward in mlp mode on `rows` rows of width Dw; saves go to the plan's first save set unless `alt` is given
@@ -600,7 +604,7 @@ extern "C" int ope_ddpg_critic_loss_and_grad(const ope_ddpg_cfg* cfg, const ope_
   (void)hipGetLastError();
   if (!ddpg_cfg_ok(cfg) || !bt || !theta_actor_tgt || !theta_critic || !theta_critic_tgt || !workspace || !grad) return OPE_EINVAL;
   if (!bt->share_obs || !bt->acts || !bt->rewards || !bt->next_obs || !bt->next_share_obs || !bt->dones_env) return OPE_EINVAL;
-  if (cfg->target_gumbel && !target_noise_u) return OPE_EINVAL;
+  if (cfg->target_gumbel && !target_noise_u && !cfg->noise_seed) return OPE_EINVAL;
   if (cfg->use_per && !per_weights) return OPE_EINVAL;
   DdpgPlan p;
   ddpg_plan(cfg, &p);
@@ -610,10 +614,10 @@ extern "C" int ope_ddpg_critic_loss_and_grad(const ope_ddpg_cfg* cfg, const ope_
   int rc;
   if (p.fused)   // small networks: the whole critic update in one launch + a slab reduction (ope_ddpg_fused.hip)
     return launch_ddpg_critic_fused(cfg, bt, theta_actor_tgt, theta_critic, theta_critic_tgt, target_noise_u, per_weights,
-                                    W + p.fused_slabs, grad, prio_out, st);
+                                    W + p.fused_slabs, grad, prio_out, W + p.gsq_critic, st);
   // target actor on the next observations -> joint next action
   if ((rc = trunk_mlp(p, W, bt->next_obs, p.Ra, p.D, theta_actor_tgt, p.AL, W + p.a2n, false, nullptr, W + p.lgn, p.A, st))) return rc;
-  if ((rc = launch_action(W + p.lgn, bt->next_avail_acts, target_noise_u, p.Ra, p.B, p.A, p.N, cfg->target_gumbel ? 1 : 0, 0, W + p.cnact,
+  if ((rc = launch_action(W + p.lgn, bt->next_avail_acts, NoiseSrc{target_noise_u, cfg->noise_seed, cfg->noise_counter, 0}, p.Ra, p.B, p.A, p.N, cfg->target_gumbel ? 1 : 0, 0, W + p.cnact,
                           nullptr, nullptr, st))) return rc;
   // critic inputs
   if ((rc = launch_build_cin(bt->next_share_obs, W + p.cnact, nullptr, 1, p.B, 1, p.N * p.A, p.S, 1, W + p.xin_t, st))) return rc;
@@ -633,7 +637,7 @@ extern "C" int ope_ddpg_actor_loss_and_grad(const ope_ddpg_cfg* cfg, const ope_m
                                             const float* theta_critic, const float* gumbel_noise_u, void* workspace,
                                             int64_t workspace_bytes, float* grad, void* stream) {
   (void)hipGetLastError();
-  if (!ddpg_cfg_ok(cfg) || !bt || !theta_actor || !theta_critic || !gumbel_noise_u || !workspace || !grad) return OPE_EINVAL;
+  if (!ddpg_cfg_ok(cfg) || !bt || !theta_actor || !theta_critic || (!gumbel_noise_u && !cfg->noise_seed) || !workspace || !grad) return OPE_EINVAL;
   if (!bt->obs || !bt->share_obs || !bt->acts || !bt->valid_transition) return OPE_EINVAL;
   DdpgPlan p;
   ddpg_plan(cfg, &p);
@@ -641,11 +645,11 @@ extern "C" int ope_ddpg_actor_loss_and_grad(const ope_ddpg_cfg* cfg, const ope_m
   hipStream_t st = (hipStream_t)stream;
   float* W = (float*)workspace;
   int rc;
-  if (p.fused) return launch_ddpg_actor_fused(cfg, bt, theta_actor, theta_critic, gumbel_noise_u, W + p.fused_slabs, grad, st);
+  if (p.fused) return launch_ddpg_actor_fused(cfg, bt, theta_actor, theta_critic, gumbel_noise_u, W + p.fused_slabs, grad, W + p.gsq_actor, st);
   float* saves2 = W + p.err;
   // actor forward (saves -> alternate set) and straight-through hard gumbel sample
   if ((rc = trunk_mlp(p, W, bt->obs, p.Ra, p.D, theta_actor, p.AL, W + p.a2a, true, saves2, W + p.lga, p.A, st))) return rc;
-  if ((rc = launch_action(W + p.lga, bt->avail_acts, gumbel_noise_u, p.Ra, p.B, p.A, p.N, 1, 0, nullptr, W + p.actout, W + p.ysoft, st)))
+  if ((rc = launch_action(W + p.lga, bt->avail_acts, NoiseSrc{gumbel_noise_u, cfg->noise_seed, cfg->noise_counter, 1}, p.Ra, p.B, p.A, p.N, 1, 0, nullptr, W + p.actout, W + p.ysoft, st)))
     return rc;
   // N stacked copies of the joint action, copy i carrying the actor's action for agent i
   if ((rc = launch_build_cin(bt->share_obs, bt->acts, W + p.actout, 1, p.B, p.N, p.A, p.S, p.N, W + p.xin_a, st))) return rc;

@@ -23,10 +23,8 @@ __device__ __forceinline__ float block_sum(float v, float* sm) {
   return t;
 }
 
-__global__ void __launch_bounds__(kBlock) sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ part,
-                                                        int* __restrict__ step_counter) {
+__global__ void __launch_bounds__(kBlock) sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ part) {
   __shared__ float sm[kBlock / 64];
-  if (step_counter && blockIdx.x == 0 && threadIdx.x == 0) step_counter[0] += 1;   // read by adam_kernel (next launch)
   const int64_t base = (int64_t)blockIdx.x * kPerBlock + threadIdx.x * kPerThread;
   float s = 0.f;
   if (base + 3 < n) {
@@ -49,7 +47,7 @@ struct AdamK {
   long long tail;   // index of [loss_sum, mask_count, qtot_sum] in g
   float lr;                 // with a device step counter the bias corrections are formed in the kernel
   long long skip_begin, skip_end;   // elements Adam leaves alone (grad-less tensors); Polyak still applies
-  const int* step_counter;
+  int* step_counter;        // [0] steps taken so far, [1] ticket of the blocks that are done with the current step
 };
 
 __global__ void __launch_bounds__(kBlock) adam_kernel(AdamK c, int64_t n, float* __restrict__ theta, float* __restrict__ tgt,
@@ -58,9 +56,11 @@ __global__ void __launch_bounds__(kBlock) adam_kernel(AdamK c, int64_t n, float*
                                                        float* __restrict__ stats) {
   __shared__ float sm[kBlock / 64];
   __shared__ float s_bc[2];
+  __shared__ int s_t;
   if (c.step_counter) {
     if (threadIdx.x == 0) {
-      const double t = (double)c.step_counter[0];
+      s_t = c.step_counter[0] + 1;       // every block reads the count before it takes its ticket below
+      const double t = (double)s_t;
       s_bc[0] = (float)((double)c.lr / (1.0 - pow((double)c.beta1, t)));
       s_bc[1] = (float)(1.0 / sqrt(1.0 - pow((double)c.beta2, t)));
     }
@@ -103,6 +103,14 @@ __global__ void __launch_bounds__(kBlock) adam_kernel(AdamK c, int64_t n, float*
     theta[i] = th;
     if (c.do_polyak) tgt[i] = tgt[i] * (1.0f - c.tau) + th * c.tau;
   }
+  // Device step counter: the LAST block to finish publishes t and resets the ticket, so the update needs no separate
+  // "count += 1" launch (and a captured graph of it replays with an advancing bias correction).
+  if (c.step_counter && threadIdx.x == 0) {
+    if (atomicAdd(&c.step_counter[1], 1) == (int)gridDim.x - 1) {
+      c.step_counter[1] = 0;
+      c.step_counter[0] = s_t;
+    }
+  }
 }
 
 __global__ void polyak_kernel(int64_t n, const float* __restrict__ theta, float* __restrict__ tgt, float tau) {
@@ -123,9 +131,9 @@ extern "C" int ope_adam_step(const ope_adam_cfg* cfg, int64_t n, float* theta, f
   if (!cfg->step_counter && cfg->step < 1) return OPE_EINVAL;
   const int nb = ope_cdiv(n, kPerBlock);
   hipStream_t st = (hipStream_t)stream;
-  const bool have_parts = cfg->sumsq_partials != nullptr && cfg->n_sumsq_partials > 0 && cfg->step_counter == nullptr;
+  const bool have_parts = cfg->sumsq_partials != nullptr && cfg->n_sumsq_partials > 0;
   if (!have_parts) {
-    hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(kBlock), 0, st, grad, n, scratch, cfg->step_counter);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(kBlock), 0, st, grad, n, scratch);
     OPE_CHECK_LAUNCH();
   }
   AdamK c;

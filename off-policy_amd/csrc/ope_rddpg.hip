@@ -534,7 +534,7 @@ extern "C" int ope_rddpg_critic_loss_and_grad(const ope_rddpg_cfg* cfg, const op
   if ((rc = rtrunk(bt->obs, p.Ra1, p.D, theta_actor_tgt, p.AL, W + p.gi_t, W, nullptr, st))) return rc;
   if ((rc = rscan(W + p.gi_t, p.NB, p.T + 1, theta_actor_tgt, p.AL, W + p.h_t, W, nullptr, st))) return rc;
   if ((rc = rhead(W + p.h_t, p.Ra1, p.A, theta_actor_tgt, p.AL, W + p.lg_t, W, nullptr, st))) return rc;
-  if ((rc = launch_action(W + p.lg_t, bt->avail_acts, target_noise_u, (int)p.Ra1, p.B, p.A, p.N, cfg->target_gumbel ? 1 : 0, 1,
+  if ((rc = launch_action(W + p.lg_t, bt->avail_acts, NoiseSrc{target_noise_u, 0, nullptr, 0}, (int)p.Ra1, p.B, p.A, p.N, cfg->target_gumbel ? 1 : 0, 1,
                           W + p.cnact, nullptr, nullptr, st))) return rc;
   // critic inputs: buffer sequence [cent_obs[t] | acts[t]] and branch rows [cent_obs[t+1] | target actions]
   if ((rc = launch_build_cin(bt->share_obs, bt->acts, nullptr, p.T, p.B, p.N, p.A, p.S, 1, W + p.xin, st))) return rc;
@@ -578,7 +578,7 @@ extern "C" int ope_rddpg_actor_loss_and_grad(const ope_rddpg_cfg* cfg, const ope
   if ((rc = rtrunk(bt->obs, p.Ra, p.D, theta_actor, p.AL, W + p.SA.gi, W, &p.SA, st))) return rc;
   if ((rc = rscan(W + p.SA.gi, p.NB, p.T, theta_actor, p.AL, W + p.SA.h, W, &p.SA, st))) return rc;
   if ((rc = rhead(W + p.SA.h, p.Ra, p.A, theta_actor, p.AL, W + p.lga, W, &p.SA, st))) return rc;
-  if ((rc = launch_action(W + p.lga, bt->avail_acts, gumbel_noise_u, Ra, p.B, p.A, p.N, 1, 0, nullptr, W + p.actout, W + p.ysoft, st)))
+  if ((rc = launch_action(W + p.lga, bt->avail_acts, NoiseSrc{gumbel_noise_u, 0, nullptr, 0}, Ra, p.B, p.A, p.N, 1, 0, nullptr, W + p.actout, W + p.ysoft, st)))
     return rc;
   // critic state along the buffer sequence (identical for the N stacked copies)
   if ((rc = launch_build_cin(bt->share_obs, bt->acts, nullptr, p.T, p.B, p.N, p.A, p.S, 1, W + p.xin, st))) return rc;

@@ -18,7 +18,7 @@
 
 namespace {
 
-constexpr int kFields = 7;
+constexpr int kFields = 8;
 constexpr int kBlock = 256;
 constexpr int kTargetFloats = 6144;  // insert (row path): ~24 KB of payload per workgroup
 constexpr int kStepBytes = 8192;     // gather: a workgroup reads about this many contiguous bytes of ONE episode
@@ -362,16 +362,18 @@ int build_args(const ope_dims* d, const ope_fields* src, const ope_fields* dst, 
   const int T = d->episode_length, N = d->n_agents, A = d->act_dim, D = d->obs_dim, S = d->state_dim;
   if (T < 1 || N < 1 || A < 1 || D < 1 || S < 1 || E < 1) return OPE_EINVAL;
   read_env_once();
-  const float* s[kFields] = {src->obs, src->share_obs, src->acts, src->rewards, src->dones, src->dones_env, src->avail_acts};
-  float* t[kFields] = {dst->obs, dst->share_obs, dst->acts, dst->rewards, dst->dones, dst->dones_env, dst->avail_acts};
-  const int TT[kFields] = {T + 1, T + 1, T, T, T, T, T + 1};
-  const int NA[kFields] = {N, 1, N, N, N, 1, N};
-  const int DD[kFields] = {D, S, A, 1, 1, 1, A};
+  const float* s[kFields] = {src->obs, src->share_obs, src->acts, src->rewards, src->dones, src->dones_env, src->avail_acts,
+                             src->valid_transition};
+  float* t[kFields] = {dst->obs, dst->share_obs, dst->acts, dst->rewards, dst->dones, dst->dones_env, dst->avail_acts,
+                       dst->valid_transition};
+  const int TT[kFields] = {T + 1, T + 1, T, T, T, T, T + 1, T};
+  const int NA[kFields] = {N, 1, N, N, N, 1, N, N};
+  const int DD[kFields] = {D, S, A, 1, 1, 1, A, 1};
   int blocks = 0, lds_bytes = 0;
   const int G = gather ? ((g_tune.xcd > 1) ? E : 1) : g_tune.xcd;
   // gather: short-row (tile) fields first -- their workgroups run two dependent phases and must not be the tail of the
   // launch -- then the step-path fields in size order; every field's range is padded to a multiple of the XCD run G
-  int order[kFields] = {0, 1, 2, 3, 4, 5, 6};
+  int order[kFields] = {0, 1, 2, 3, 4, 5, 6, 7};
   if (gather) {
     int n = 0;
     for (int pass = 0; pass < 2; ++pass)

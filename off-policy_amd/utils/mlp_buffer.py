@@ -81,21 +81,11 @@ class MlpPolicyBuffer(object):
         else:
             inds = np.asarray(sample_inds, dtype=np.int64)
             B = int(inds.shape[0])
-        obs, share, acts, rew, dones, dones_env, avail = self._ep.sample_inds(inds, timing_events=timing_events)
-        # the episode gather returns [N, T(+1), B, dim] views of [T(+1), N, B, dim] memory; T = 1 here
+        # the episode gather returns [N, T(+1), B, dim] views of [T(+1), N, B, dim] memory; T = 1 here. valid_transition rides in
+        # the same launch as the 8th field.
         valid = torch.empty((1, self.num_agents, B, 1), dtype=torch.float32, device=self.device)
-        sf, of = self._only_dones(self.valid_transition), self._only_dones(valid)
-        from .rec_buffer import _INDS_MODE
-        if not torch.is_tensor(inds) and B <= 512 and _INDS_MODE == "args":     # indices inside the kernel-argument block
-            hi = np.ascontiguousarray(np.where(inds < 0, inds + self.buffer_size, inds))
-            _lib.check(_lib.lib.ope_store_gather_host_inds(C.byref(self._ep.dims), self.buffer_size, C.byref(sf), hi.ctypes.data_as(C.c_void_p), B,
-                                                           C.byref(of), _lib.current_stream()), "ope_store_gather_host_inds")
-        else:
-            dev_inds = inds if torch.is_tensor(inds) else self._ep._upload_inds(inds)
-            _lib.check(_lib.lib.ope_store_gather(C.byref(self._ep.dims), self.buffer_size, C.byref(sf), _lib.ptr(dev_inds), B,
-                                                 C.byref(of), _lib.ptr(self._ep._bad_index), _lib.current_stream()), "ope_store_gather")
-            if not torch.is_tensor(inds):
-                self._ep._release_inds()
+        obs, share, acts, rew, dones, dones_env, avail = self._ep.sample_inds(inds, timing_events=timing_events,
+                                                                             extra=(self.valid_transition, valid))
         if not self.use_same_share_obs:   # per-agent centralized observations: [N, B, S] like the reference's _cast
             share = (share[:, 0], share[:, 1])
         return (obs[:, 0], share[0], acts[:, 0], rew[:, 0], obs[:, 1], share[1], dones[:, 0], dones_env[0], valid[0],

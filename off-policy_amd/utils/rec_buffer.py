@@ -209,11 +209,13 @@ class RecPolicyBuffer(object):
             out["avail_acts"] = torch.empty((T + 1, N, B, d.act_dim), **e)
         return out
 
-    def sample_inds(self, sample_inds, timing_events=None, out=None):
+    def sample_inds(self, sample_inds, timing_events=None, out=None, extra=None):
         """Gather the given episode slots; same 7-tuple as rec_buffer.py:192-240 (CUDA tensors, reference shapes).
         `timing_events`: optional (start, end) torch.cuda.Event pair recorded tightly around the gather launch.
         `out`: optional destination from `alloc_batch` (HIP-graph replays read the batch from fixed addresses); the
-        default is a fresh batch per call, like the reference's fancy-index copy."""
+        default is a fresh batch per call, like the reference's fancy-index copy.
+        `extra`: optional (store, out) pair of [cap, T, N, 1] / [T, N, B, 1] tensors copied by the same launch (the transition
+        buffers' valid_transition flag)."""
         host_inds = None
         if torch.is_tensor(sample_inds):     # indices already on the device (HIP-graph replays keep them in a static tensor)
             assert sample_inds.dtype == torch.int64 and sample_inds.device == self.device, (sample_inds.dtype, sample_inds.device)
@@ -235,6 +237,8 @@ class RecPolicyBuffer(object):
         else:
             assert out["obs"].shape[2] == B, "destination batch does not match the number of indices"
         of, sf = self._fields(out if self.use_same_share_obs else {k: v for k, v in out.items() if k != "share_obs"}), self._store_fields()
+        if extra is not None:
+            sf.valid_transition, of.valid_transition = _lib.ptr(extra[0]).value, _lib.ptr(extra[1]).value
         if timing_events is not None:
             timing_events[0].record()
         if host_inds is not None:

@@ -1,4 +1,6 @@
 """-m gpu: MLP MADDPG / MATD3 through the C-ABI vs the reference's frozen outputs (same gumbel noise stream)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -128,14 +130,14 @@ def test_graphed_step_matches_eager_step():
             for k, m in (("a", policy.actor), ("c", policy.critic), ("ta", policy.target_actor), ("tc", policy.target_critic)):
                 assert torch.equal(m._flat, theta0[k]), k
             for opt in (policy.critic_optimizer, policy.actor_optimizer):
-                assert not opt.exp_avg.any() and not opt.exp_avg_sq.any() and int(opt.step_dev.item()) == 0 and opt.step_count == 0
+                assert not opt.exp_avg.any() and not opt.exp_avg_sq.any() and int(opt.step_dev[0].item()) == 0 and opt.step_count == 0
             assert np.array_equal(np.random.get_state()[1], rng_before)
             info = step(inds)
             res[mode] = (float(info["critic_loss"]), float(info["critic_grad_norm"]))
-            assert int(policy.critic_optimizer.step_dev.item()) == 1 and policy.critic_optimizer.step_count == 1
+            assert int(policy.critic_optimizer.step_dev[0].item()) == 1 and policy.critic_optimizer.step_count == 1
             before = policy.actor._flat.clone()
             losses = [float(step(np.random.RandomState(s).choice(len(buf), len(inds)))["critic_loss"]) for s in range(5)]
-            assert np.all(np.isfinite(losses)) and int(policy.actor_optimizer.step_dev.item()) == 6
+            assert np.all(np.isfinite(losses)) and int(policy.actor_optimizer.step_dev[0].item()) == 6
             assert not torch.equal(before, policy.actor._flat)
     np.testing.assert_allclose(res["graph"], res["eager"], rtol=1e-5)
     np.testing.assert_allclose(res["eager"][0], g["critic_loss"][0], rtol=RTOL)
@@ -148,15 +150,8 @@ def _flat_grads(mod, gvec, n_tail):
     return {name: g[off:off + int(np.prod(shape))].reshape(shape) / cnt for name, (shape, off) in mod.spec().items()}
 
 
-@pytest.mark.parametrize("td3,per", [(False, False), (True, True)])
-def test_config3_batch256_matches_oracle(td3, per):
-    """BASELINE config 3 AT ITS OWN SIZE: MADDPG-MLP (and MATD3-MLP + prioritized replay) on MPE simple_spread
-    (N=3, A=5, D=18, S=54), B=256 transitions: 768 actor rows / 256 and 768 critic rows per update, i.e. the row counts
-    the benchmark runs at (the reference fixtures stop at B=32). Two updates vs oracle/maddpg_oracle.py on the
-    reference's gumbel noise stream: losses, gradient norms, priorities, every gradient tensor of the first update and
-    the parameters after both. (reference: maddpg.py:90-249)"""
-    from oracle import maddpg_oracle as DO
-    from oracle.qmix_oracle import HP
+def config3_setup(td3, per):
+    """MADDPG / MATD3 trainer on MPE simple_spread dims with a filled 1024-transition buffer and perturbed networks."""
     from offpolicy_amd.config import default_args
     from offpolicy_amd.utils.synth import DIMS, policy_info_for
     from offpolicy_amd.utils.mlp_buffer import MlpReplayBuffer
@@ -192,6 +187,20 @@ def test_config3_batch256_matches_oracle(td3, per):
     for mod in (policy.critic, policy.actor):      # away from the targets and the gain-0.01 output layers
         mod._flat.add_((0.05 * torch.randn(mod._flat.numel(), generator=gen)).to(dev))
     torch.cuda.synchronize()
+    return dims, N, A, D, S, B, cap, policy, trainer, buf
+
+
+@pytest.mark.parametrize("td3,per", [(False, False), (True, True)])
+def test_config3_batch256_matches_oracle(td3, per):
+    """BASELINE config 3 AT ITS OWN SIZE: MADDPG-MLP (and MATD3-MLP + prioritized replay) on MPE simple_spread
+    (N=3, A=5, D=18, S=54), B=256 transitions: 768 actor rows / 256 and 768 critic rows per update, i.e. the row counts
+    the benchmark runs at (the reference fixtures stop at B=32). Two updates vs oracle/maddpg_oracle.py on the
+    reference's gumbel noise stream: losses, gradient norms, priorities, every gradient tensor of the first update and
+    the parameters after both. (reference: maddpg.py:90-249)"""
+    from oracle import maddpg_oracle as DO
+    from oracle.qmix_oracle import HP
+    dims, N, A, D, S, B, cap, policy, trainer, buf = config3_setup(td3, per)
+    f = np.float32
     heads = lambda c: (c._head_w.cpu().numpy().reshape(-1, 64).copy(), c._head_b.cpu().numpy().reshape(-1).copy())
     orc = DO.MaddpgOracle(params_of(policy.actor), params_of(policy.critic), heads(policy.critic), params_of(policy.target_actor),
                           params_of(policy.target_critic), heads(policy.target_critic), N, HP(use_per=per), td3=td3)
@@ -250,3 +259,68 @@ def test_soft_and_hard_update_helpers_act_per_parameter():
     hard_update(policy.target_actor, policy.actor)
     for (k, a), (_, b) in zip(policy.target_actor.named_parameters(), policy.actor.named_parameters()):
         assert torch.equal(a, b), k
+
+
+def _noise_worker(out_path):
+    """One MATD3 update at config-3 size with the gumbel noise drawn inside the kernels; dumps the gradients (and, on the
+    unfused path, the sampled actions and their logits)."""
+    dims, N, A, D, S, B, cap, policy, trainer, buf = config3_setup(True, False)
+    trainer.device_noise = True
+    inds = np.random.RandomState(30).choice(cap, B)
+    s = buf.policy_buffers["policy_0"].sample_inds(inds)
+    torch.manual_seed(77)
+    trainer.shared_train_policy_on_batch("policy_0", tuple({"policy_0": a} for a in s) + (None, None))
+    torch.cuda.synchronize()
+    gc, ga, _ = trainer._grads[B]
+    out = dict(gc=gc.cpu().numpy(), ga=ga.cpu().numpy())
+    try:
+        out["act_out"] = trainer.workspace_view(B, "act_out").cpu().numpy().reshape(N * B, A)
+        out["logits"] = trainer.workspace_view(B, "logits").cpu().numpy().reshape(N * B, A)
+        out["avail"] = s[9].cpu().numpy().reshape(N * B, A)
+    except KeyError:
+        pass
+    np.savez(out_path, **out)
+
+
+def test_device_noise_same_stream_on_both_paths_and_right_distribution(tmp_path):
+    """`device_noise`: the kernels draw the gumbel noise themselves (Philox4x32-10 keyed by seed, step count, row, column).
+    (1) The fused small-network path and the general path (OPE_DDPG_FUSED=0) use the SAME stream: their critic and actor
+    gradients agree; this also runs the general path at config-3 size, which the default dispatch never takes.
+    (2) The hard gumbel-softmax actions the general path leaves in its workspace are distributed as softmax(masked logits)
+    (util.py:193-207): per action, the sampled count is within 4.5 sigma of its expectation over the 768 rows."""
+    import subprocess, sys
+    outs = {}
+    for fused in ("1", "0"):
+        path = str(tmp_path / ("g%s.npz" % fused))
+        env = dict(os.environ, OPE_DDPG_FUSED=fused)
+        code = "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_gpu_ddpg as t; t._noise_worker(%r)" % (
+            os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))), path)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[fused] = np.load(path)
+    for k in ("gc", "ga"):
+        a, b = outs["1"][k], outs["0"][k]
+        assert np.abs(b).max() > 0
+        np.testing.assert_allclose(a, b, rtol=0, atol=2e-3 * np.abs(b).max(), err_msg=k)
+    act, lg, av = outs["0"]["act_out"], outs["0"]["logits"], outs["0"]["avail"]
+    onehot = (act > 0.5).astype(np.float64)          # straight-through value: 1 at the sampled action (+- float noise)
+    assert np.all(onehot.sum(1) == 1) and np.all(onehot * (1 - av) == 0)
+    z = np.where(av > 0, lg.astype(np.float64), -1e10)
+    p = np.exp(z - z.max(1, keepdims=True))
+    p /= p.sum(1, keepdims=True)
+    mean, var = p.sum(0), (p * (1 - p)).sum(0)
+    assert np.all(np.abs(onehot.sum(0) - mean) < 4.5 * np.sqrt(var) + 1e-9), (onehot.sum(0), mean)
+
+
+def test_general_path_matches_reference_fixtures():
+    """The small-network dispatch sends every fixture through the fused kernels; the general (tile/MFMA trunk) path, which
+    larger observation / joint-action widths take, is run here on the same reference fixtures with OPE_DDPG_FUSED=0."""
+    import subprocess, sys
+    if os.environ.get("OPE_DDPG_FUSED") == "0":
+        pytest.skip("already on the general path")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                        "construction_and_train_steps or config3_batch256", "-p", "no:cacheprovider"],
+                       env=dict(os.environ, OPE_DDPG_FUSED="0"), capture_output=True, text=True, timeout=1200,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert " passed" in r.stdout

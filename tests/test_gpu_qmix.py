@@ -309,12 +309,12 @@ def test_graphed_step_matches_reference(gather_in_graph):
     opt = trainer.optimizer
     # the capture warm-up trains two throw-away steps; make_graphed_step itself must put the state back
     assert torch.equal(trainer.theta, theta0) and torch.equal(trainer.theta_tgt, tgt0)
-    assert not opt.exp_avg.any() and not opt.exp_avg_sq.any() and int(opt.step_dev.item()) == 0 and opt.step_count == 0
+    assert not opt.exp_avg.any() and not opt.exp_avg_sq.any() and int(opt.step_dev[0].item()) == 0 and opt.step_count == 0
     for s in range(len(g["loss"])):
         info = step(inds)
         np.testing.assert_allclose(float(info["loss"]), g["loss"][s], rtol=RTOL)
         np.testing.assert_allclose(float(info["grad_norm"]), g["grad_norm"][s], rtol=RTOL)
-    assert int(opt.step_dev.item()) == len(g["loss"]) == opt.step_count
+    assert int(opt.step_dev[0].item()) == len(g["loss"]) == opt.step_count
     live, tgt = _flat_named(trainer, trainer.theta), _flat_named(trainer, trainer.theta_tgt)
     for grp, src in (("final_agent/", live), ("final_agent_tgt/", tgt)):
         for k, ref in sub(g, grp).items():

@@ -24,7 +24,9 @@ for _ in range(5):
     trainer.shared_train_policy_on_batch("policy_0", tuple({"policy_0": x} for x in s) + (None, None))
 torch.cuda.synchronize()
 v = trainer.workspace_view(B, "fused_slabs")
-st = v[-64:].view(torch.int64).cpu().numpy()[:9]
-names = ["stage 3 nets", "target actor x N", "target critic fwd", "live critic fwd", "TD + critic bwd", "barrier", "dump", "wg sum + slab"]
+st = v[-64:].view(torch.int64).cpu().numpy()[:24]
+print("staging: issue loads %d, stores %d, issue weights %d, rest %d" % (st[20]-st[0], st[22]-st[20], st[23]-st[22], st[1]-st[23]))
+print("agents:", [int(st[8 + i] - (st[1] if i == 0 else st[7 + i])) for i in range(3)])
+names = ["stage vectors + inputs", "target actor x N", "target critic fwd", "live critic fwd", "TD", "critic bwd"]
 print("cycles:", {n: int(st[i + 1] - st[i]) for i, n in enumerate(names)})
-print("total cycles", int(st[8] - st[0]), "= %.1f us at 2.4 GHz" % ((st[8] - st[0]) / 2400.0))
+print("total", int(st[6] - st[0]), "ticks of s_memtime (100 MHz: x10 ns)")
