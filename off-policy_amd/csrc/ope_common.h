@@ -158,11 +158,15 @@ __device__ __forceinline__ int row16_min_i(int v) {
   return v;
 }
 
-// Sum over the 4 lanes (g = 0..3) that share a data row j in the transposed-chain layout.
+// Sum over the 4 lanes (g = 0..3) that share a data row j in the transposed-chain layout (lanes j, j+16, j+32, j+48), result in
+// all four. gfx950's VALU lane swaps instead of two ds_bpermute round trips through the LDS pipe: v_permlane16_swap pairs row g
+// with row g ^ 1, v_permlane32_swap half with half; with both operands = x the two results are the pair's values, so each step
+// is the same commutative pair sum __shfl_xor gave (bitwise identical results, identical in the 4 lanes).
 __device__ __forceinline__ float rowsum4(float x) {
-  x += __shfl_xor(x, 16, 64);
-  x += __shfl_xor(x, 32, 64);
-  return x;
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  x = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
 // Workgroup barrier that orders LDS traffic only. __syncthreads() also emits s_waitcnt vmcnt(0), which would drain a
