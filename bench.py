@@ -50,6 +50,8 @@ def parse():
                     "of replaying the captured HIP graph")
     ap.add_argument("--host-per", action="store_true", help="prioritized workloads: keep the sum/min trees on the host (numpy, as the "
                     "reference) instead of in HBM")
+    ap.add_argument("--host-indices", action="store_true", help="MLP MADDPG/MATD3 graph replay: draw the batch indices with numpy on the host "
+                    "and upload them every step (default: sample(batch) draws them on the device inside the gather kernel)")
     ap.add_argument("--host-noise", action="store_true", help="MADDPG family: draw the gumbel noise on the reference's CPU generator "
                     "stream (what the parity tests use) instead of on the device")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="budget for each CPU-baseline leg")
@@ -447,9 +449,12 @@ def main_ddpg(a):
         np.random.seed(1000)
         torch.manual_seed(1000 + rank)
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
-        graphed = trainer.make_graphed_step(buf, local_batch) if use_graph else None
+        dev_sampling = use_graph and not a.host_indices
+        graphed = trainer.make_graphed_step(buf, local_batch, device_sampling=dev_sampling) if use_graph else None
 
         def one_step(i=None):
+            if dev_sampling:
+                return graphed()               # sample (drawn in the gather kernel) + critic + actor + soft target updates: one graph launch
             inds = opdist.shard_indices(np.random.choice(len(buf), global_batch), rank, world)
             if graphed is not None:
                 return graphed(inds)           # gather + critic update + actor update + soft target updates: one graph launch
@@ -482,7 +487,8 @@ def main_ddpg(a):
                                       "step = sample + critic update + actor update + soft target updates; reference semantics "
                                       "(frozen critic heads A-4, actor updated every call A-5); gumbel noise drawn on the %s; %s" % (
                                           "MATD3" if td3 else "MADDPG", N, A, D, S, cap, "host (reference stream)" if a.host_noise else "device",
-                                          "whole update replayed as one captured HIP graph" if use_graph else "kernels launched one by one"),
+                                          ("whole step replayed as one captured HIP graph, batch indices drawn %s" % ("on the host (numpy) and uploaded" if a.host_indices else
+                                           "on the device inside the gather (uniform with replacement, as np.random.choice)")) if use_graph else "kernels launched one by one"),
                           "batch_per_gpu": r0["local_batch"], "global_batch": r0["global_batch"], "parallelism": "dp%d" % world,
                           "allreduce": allreduce_name() if world > 1 else None,
                           "optimizer_steps_per_sec": round(steps_per_s, 2)},

@@ -113,6 +113,13 @@ int ope_store_gather(const ope_dims* dims, int32_t capacity, const ope_fields* s
  * outside [0, capacity) returns OPE_EINVAL (numpy's IndexError). */
 int ope_store_gather_host_inds(const ope_dims* dims, int32_t capacity, const ope_fields* store, const int64_t* inds_host,
                                int32_t batch, const ope_fields* out, void* stream);
+/* sample(batch) entirely on the device: the gather draws its own indices -- uniform over [0, filled) with replacement, as
+ * np.random.choice(filled, batch) in the reference's sample() (rec_buffer.py:86, mlp_buffer.py:74), from Philox4x32-10 keyed by
+ * (seed, batch position, DEVICE int32 *counter (0 if NULL)). Same distribution, not numpy's stream. No index upload and no host
+ * work per step; a captured HIP graph replays with fresh indices when the counter advances on the device (e.g.
+ * ope_adam_cfg.step_counter). inds_out (device int64[batch], may be NULL) receives the drawn indices. */
+int ope_store_gather_sampled(const ope_dims* dims, int32_t capacity, int32_t filled, const ope_fields* store, uint64_t seed,
+                             const int32_t* counter, int32_t batch, const ope_fields* out, int64_t* inds_out, void* stream);
 /* Per-dispatch timing of the gather (the roofline leg of bench.py): after ope_store_gather_profile(1) every gather launch
  * carries hipExtLaunchKernel start / stop events (up to 512 launches are kept); ope_store_gather_profile_read waits for them
  * and writes the kernel durations in milliseconds, oldest first, into HOST memory, returns how many (and clears the ring).

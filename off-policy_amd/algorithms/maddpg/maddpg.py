@@ -180,14 +180,17 @@ class MADDPG(object):
         self._last = (obs, cent, acts, rew, nobs, ncent, dones_env, valid, avail, navail, u_t, w)
         return train_info, new_priorities, idxes
 
-    def make_graphed_step(self, buffer, batch_size, policy_id="policy_0"):
+    def make_graphed_step(self, buffer, batch_size, policy_id="policy_0", device_sampling=False):
         """One whole update -- gather of `batch_size` transitions, critic update, actor update, soft target updates -- captured
         once as a HIP graph and replayed with one launch per step. This path is ~45 kernels of a few microseconds each:
         eagerly it is bound by launch latency and host work, not by the GPU (csrc/ope_ddpg.hip). Returns
         `step(inds) -> train_info` where `inds` are the transition indices to train on (numpy int64 [batch_size], e.g.
         np.random.choice(len(buffer), batch_size)) and train_info holds device tensors overwritten by every replay.
         Restrictions: uniform replay (no PER: priorities need the host tree), one process (no gradient all-reduce inside the
-        graph), gumbel noise drawn on the device (`device_noise`), the Adam step counters live on the device."""
+        graph), gumbel noise drawn on the device (`device_noise`), the Adam step counters live on the device.
+        `device_sampling=True`: the batch indices are drawn on the device too (buffer.sample(batch_size) with the uniform draw
+        inside the gather kernel, MlpPolicyBuffer.sample_device): `step()` takes no argument, a replay involves no host data at
+        all, and train_info["indices"] holds the drawn indices."""
         if self.use_per or opdist.is_distributed():
             raise NotImplementedError("graphed step: uniform replay on a single GPU only")
         pid = policy_id
@@ -199,10 +202,16 @@ class MADDPG(object):
             opt.step_dev = torch.tensor([opt.step_count, 0], dtype=torch.int32, device=self.device)    # [count, ticket]
         static_inds = torch.zeros(B, dtype=torch.int64, device=self.device)
 
+        sample_seed = (torch.initial_seed() * 0xD1342543DE82EF95 + 0x9E3779B9) % (1 << 64) | 1
+
         def body():
-            s = pbuf.sample_inds(static_inds)
+            if device_sampling:
+                s, drawn = pbuf.sample_device(B, sample_seed, counter=policy.critic_optimizer.step_dev)
+            else:
+                s, drawn = pbuf.sample_inds(static_inds), static_inds
             info, _, _ = self.shared_train_policy_on_batch(pid, tuple({pid: x} for x in s) + (None, None))
             policy.soft_target_updates()
+            info["indices"] = drawn
             return info
         # The warm-up below really trains (two critic + actor + Polyak updates on a throw-away batch): snapshot networks,
         # targets, Adam moments and step counters and restore them afterwards, so that building a graphed step leaves the
@@ -236,6 +245,12 @@ class MADDPG(object):
         ring = [(torch.empty(B, dtype=torch.int64).pin_memory(), torch.cuda.Event()) for _ in range(8)]
         state = {"k": 0, "used": [False] * 8}
 
+        def step_sampled():
+            graph.replay()
+            for opt in (policy.critic_optimizer, policy.actor_optimizer):
+                opt.step_count += 1
+            return info
+
         def step(inds):
             k = state["k"]
             state["k"] = (k + 1) % 8
@@ -251,7 +266,7 @@ class MADDPG(object):
                 opt.step_count += 1
             return info
         self._graph = (graph, static_inds, ring)      # keep alive
-        return step
+        return step_sampled if device_sampling else step
 
     def prep_training(self):
         pass

@@ -38,6 +38,18 @@ __global__ void __launch_bounds__(kBlock) sumsq_kernel(const float* __restrict__
   if (threadIdx.x == 0) part[blockIdx.x] = t;
 }
 
+// beta^t for an integer t by repeated squaring in double (exact to a few ulp of double; a software pow() is thousands of
+// instructions on the one thread every block waits for)
+__device__ __forceinline__ double ipow(double b, int t) {
+  double r = 1.0;
+  while (t > 0) {
+    if (t & 1) r *= b;
+    b *= b;
+    t >>= 1;
+  }
+  return r;
+}
+
 struct AdamK {
   float lr_t;        // lr / (1 - beta1^t)
   float inv_sqrt_bc2;  // 1 / sqrt(1 - beta2^t)
@@ -60,9 +72,8 @@ __global__ void __launch_bounds__(kBlock) adam_kernel(AdamK c, int64_t n, float*
   if (c.step_counter) {
     if (threadIdx.x == 0) {
       s_t = c.step_counter[0] + 1;       // every block reads the count before it takes its ticket below
-      const double t = (double)s_t;
-      s_bc[0] = (float)((double)c.lr / (1.0 - pow((double)c.beta1, t)));
-      s_bc[1] = (float)(1.0 / sqrt(1.0 - pow((double)c.beta2, t)));
+      s_bc[0] = (float)((double)c.lr / (1.0 - ipow((double)c.beta1, s_t)));
+      s_bc[1] = (float)(1.0 / sqrt(1.0 - ipow((double)c.beta2, s_t)));
     }
     __syncthreads();
     c.lr_t = s_bc[0];

@@ -15,6 +15,7 @@
 #include <hip/hip_ext.h>
 
 #include "ope_common.h"
+#include "ope_rng.h"
 
 namespace {
 
@@ -88,6 +89,23 @@ struct DevIdx {
 struct ArgIdx {
   int32_t v[kMaxArgIdx];
   __device__ __forceinline__ int64_t operator[](int i) const { return (int64_t)v[i]; }
+};
+
+// Uniform sampling with replacement drawn where the data lives (np.random.choice(filled, batch) of the reference's sample(),
+// rec_buffer.py:86 / mlp_buffer.py:74): index i of the batch = Philox4x32-10(seed; i, stream 2, *counter) scaled to [0, filled).
+// Every workgroup that needs index i recomputes it (40 integer instructions) instead of reading an index tensor, so there is no
+// index upload, no host round trip per step, and a captured graph replays with fresh indices as the device counter advances.
+struct RngIdx {
+  uint64_t seed;
+  const int32_t* counter;
+  uint32_t filled;
+  int64_t* out;      // optional: the drawn indices, for the caller (priorities, inspection)
+  __device__ __forceinline__ int64_t operator[](int i) const {
+    const ope::Philox4 x = ope::philox4x32_10((uint32_t)i, 0u, (uint32_t)(counter ? counter[0] : 0), 2u, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const int64_t v = (int64_t)(((uint64_t)x.v[0] * (uint64_t)filled) >> 32);
+    if (out) out[i] = v;
+    return v;
+  }
 };
 
 template <class IDX>
@@ -572,6 +590,18 @@ extern "C" int ope_store_gather(const ope_dims* dims, int32_t capacity, const op
   if (rc != OPE_OK) return rc;
   args.bad_index = bad_index_flag;
   launch_copy<true>(args, DevIdx{inds}, (hipStream_t)stream);
+  OPE_CHECK_LAUNCH();
+  return OPE_OK;
+}
+
+extern "C" int ope_store_gather_sampled(const ope_dims* dims, int32_t capacity, int32_t filled, const ope_fields* store, uint64_t seed,
+                                        const int32_t* counter, int32_t batch, const ope_fields* out, int64_t* inds_out, void* stream) {
+  (void)hipGetLastError();
+  if (capacity < 1 || filled < 1 || filled > capacity || batch < 1) return OPE_EINVAL;
+  CopyArgs args;
+  int rc = build_args(dims, store, out, batch, capacity, true, &args);
+  if (rc != OPE_OK) return rc;
+  launch_copy<true>(args, RngIdx{seed, counter, (uint32_t)filled, inds_out}, (hipStream_t)stream);
   OPE_CHECK_LAUNCH();
   return OPE_OK;
 }

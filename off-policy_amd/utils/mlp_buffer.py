@@ -73,7 +73,13 @@ class MlpPolicyBuffer(object):
         self._keep = (staged, slots)
         return idx_range
 
-    def sample_inds(self, sample_inds, timing_events=None):
+    def sample_device(self, batch_size, seed, counter=None):
+        """The 11-tuple of sample_inds for `batch_size` transitions drawn uniformly on the device (RecPolicyBuffer.sample_device),
+        and the drawn indices."""
+        inds = torch.empty(int(batch_size), dtype=torch.int64, device=self.device)
+        return self.sample_inds(inds, _sampler=(int(seed), counter, int(self.filled_i))), inds
+
+    def sample_inds(self, sample_inds, timing_events=None, _sampler=None):
         """11-tuple of mlp_buffer.py:213-257: obs, share_obs, acts, rewards, next_obs, next_share_obs, dones, dones_env,
         valid_transition, avail_acts, next_avail_acts (CUDA tensors, reference shapes)."""
         if torch.is_tensor(sample_inds):
@@ -85,7 +91,7 @@ class MlpPolicyBuffer(object):
         # the same launch as the 8th field.
         valid = torch.empty((1, self.num_agents, B, 1), dtype=torch.float32, device=self.device)
         obs, share, acts, rew, dones, dones_env, avail = self._ep.sample_inds(inds, timing_events=timing_events,
-                                                                             extra=(self.valid_transition, valid))
+                                                                             extra=(self.valid_transition, valid), _sampler=_sampler)
         if not self.use_same_share_obs:   # per-agent centralized observations: [N, B, S] like the reference's _cast
             share = (share[:, 0], share[:, 1])
         return (obs[:, 0], share[0], acts[:, 0], rew[:, 0], obs[:, 1], share[1], dones[:, 0], dones_env[0], valid[0],

@@ -209,7 +209,16 @@ class RecPolicyBuffer(object):
             out["avail_acts"] = torch.empty((T + 1, N, B, d.act_dim), **e)
         return out
 
-    def sample_inds(self, sample_inds, timing_events=None, out=None, extra=None):
+    def sample_device(self, batch_size, seed, counter=None, out=None, extra=None):
+        """sample(batch_size) drawn on the device: uniform over the filled slots with replacement, like the reference's
+        np.random.choice(filled, batch_size) (rec_buffer.py:86), but from a Philox stream keyed by (`seed`, batch position,
+        the device int32 `counter`[0]) inside the gather kernel -- no index upload, no host work, and a captured HIP graph
+        replays with fresh indices as the counter advances. Returns (7-tuple as sample_inds, int64 device tensor of the drawn
+        indices)."""
+        inds = torch.empty(int(batch_size), dtype=torch.int64, device=self.device)
+        return self.sample_inds(inds, out=out, extra=extra, _sampler=(int(seed), counter, int(self.filled_i))), inds
+
+    def sample_inds(self, sample_inds, timing_events=None, out=None, extra=None, _sampler=None):
         """Gather the given episode slots; same 7-tuple as rec_buffer.py:192-240 (CUDA tensors, reference shapes).
         `timing_events`: optional (start, end) torch.cuda.Event pair recorded tightly around the gather launch.
         `out`: optional destination from `alloc_batch` (HIP-graph replays read the batch from fixed addresses); the
@@ -241,7 +250,12 @@ class RecPolicyBuffer(object):
             sf.valid_transition, of.valid_transition = _lib.ptr(extra[0]).value, _lib.ptr(extra[1]).value
         if timing_events is not None:
             timing_events[0].record()
-        if host_inds is not None:
+        if _sampler is not None:
+            seed, counter, filled = _sampler
+            assert self.use_same_share_obs, "device sampling: shared centralized observations only"
+            _lib.check(_lib.lib.ope_store_gather_sampled(C.byref(d), self.buffer_size, filled, C.byref(sf), seed, _lib.ptr(counter), B,
+                                                         C.byref(of), _lib.ptr(dev_inds), _lib.current_stream()), "ope_store_gather_sampled")
+        elif host_inds is not None:
             _lib.check(_lib.lib.ope_store_gather_host_inds(C.byref(d), self.buffer_size, C.byref(sf), host_inds.ctypes.data_as(C.c_void_p), B,
                                                            C.byref(of), _lib.current_stream()), "ope_store_gather_host_inds")
         else:

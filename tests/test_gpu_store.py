@@ -288,3 +288,41 @@ def test_out_of_range_indices_are_skipped_and_flagged():
     with pytest.raises(IndexError):
         pb.check_indices()
     pb.check_indices()                                      # flag cleared by the raise
+
+
+def test_device_sampled_gather_is_uniform_in_range_and_matches_index_gather():
+    """ope_store_gather_sampled (RecPolicyBuffer.sample_device): sample(batch) with the uniform draw inside the gather kernel.
+    The drawn indices lie in [0, filled) -- NOT the capacity: the buffer is half full --, the gathered batch is bit-identical
+    to sample_inds(those indices), a different counter value gives different indices, the same one the same, and over 64 draws
+    of 512 the histogram over the 40 filled slots passes a chi-square test (reference: np.random.choice(filled, batch),
+    rec_buffer.py:86)."""
+    import torch
+    from offpolicy_amd.utils.rec_buffer import RecReplayBuffer
+    from offpolicy_amd.utils.synth import DIMS, policy_info_for, synth_episodes
+    dims = DIMS["3m"]
+    cap, filled, B = 80, 40, 512
+    buf = RecReplayBuffer(policy_info_for(dims), {"policy_0": list(range(dims.n_agents))}, cap, dims.episode_length, True, True, device="cuda:0")
+    ep = synth_episodes(np.random.RandomState(3), filled, dims)
+    buf.insert(filled, *[{"policy_0": ep[k]} for k in ("obs", "share_obs", "acts", "rewards", "dones", "dones_env", "avail_acts")])
+    pb = buf.policy_buffers["policy_0"]
+    ctr = torch.zeros(2, dtype=torch.int32, device="cuda:0")
+    got, inds = pb.sample_device(B, seed=12345, counter=ctr)
+    torch.cuda.synchronize()
+    iv = inds.cpu().numpy()
+    assert iv.min() >= 0 and iv.max() < filled
+    ref = pb.sample_inds(iv)
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
+    _, again = pb.sample_device(B, seed=12345, counter=ctr)
+    assert torch.equal(again, inds)
+    counts = np.zeros(filled)
+    for t in range(64):
+        ctr[0] = t + 1
+        _, ii = pb.sample_device(B, seed=12345, counter=ctr)
+        v = ii.cpu().numpy()
+        if t == 0:
+            assert not np.array_equal(v, iv)
+        counts += np.bincount(v, minlength=filled)
+    expect = 64 * B / filled
+    chi2 = ((counts - expect) ** 2 / expect).sum()
+    assert chi2 < 39 + 5 * np.sqrt(2 * 39), chi2          # 39 degrees of freedom: mean 39, sd 8.8

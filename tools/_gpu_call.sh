@@ -1,5 +1,11 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests -x -q -m gpu -k "qmix and not graph" 2>&1 | tail -2
-for r in 0 160 224; do
-OPE_WGRAD_ROWS=$r timeout 600 python bench.py --steps 300 --warmup 30 --episodes 256 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-200
+timeout 1500 python -m pytest tests -x -q -m gpu -k "ddpg or graph or store" 2>&1 | tail -5
+for w in maddpg_spread matd3_spread; do
+timeout 300 python bench.py --workload $w --steps 500 --warmup 50 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-260
 done
+timeout 300 python bench.py --workload maddpg_spread --steps 500 --warmup 50 --no-cpu-baseline --host-indices 2>&1 | tail -1 | cut -c1-260
+export TMPDIR=/tmp
+rm -rf /tmp/prof
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof -- python bench.py --workload maddpg_spread --steps 300 --warmup 30 --no-cpu-baseline > /tmp/b.txt 2>&1
+python tools/trace_gaps.py /tmp/prof --last 1500 > gpurun_out/gaps_maddpg.txt
+cat gpurun_out/gaps_maddpg.txt
