@@ -52,6 +52,8 @@ def parse():
                     "reference) instead of in HBM")
     ap.add_argument("--host-indices", action="store_true", help="MLP MADDPG/MATD3 graph replay: draw the batch indices with numpy on the host "
                     "and upload them every step (default: sample(batch) draws them on the device inside the gather kernel)")
+    ap.add_argument("--steps-per-replay", type=int, default=4, help="MLP MADDPG/MATD3 graph replay with device-drawn indices: consecutive "
+                    "training steps captured in one graph (used when it divides --steps and --warmup, else 1)")
     ap.add_argument("--host-noise", action="store_true", help="MADDPG family: draw the gumbel noise on the reference's CPU generator "
                     "stream (what the parity tests use) instead of on the device")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="budget for each CPU-baseline leg")
@@ -450,7 +452,10 @@ def main_ddpg(a):
         torch.manual_seed(1000 + rank)
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
         dev_sampling = use_graph and not a.host_indices
-        graphed = trainer.make_graphed_step(buf, local_batch, device_sampling=dev_sampling) if use_graph else None
+        # with everything drawn on the device a replay can hold several consecutive steps (graph-launch latency amortised);
+        # only when that divides both counts, so that exactly --steps steps are timed
+        spr = a.steps_per_replay if (dev_sampling and a.steps % a.steps_per_replay == 0 and a.warmup % a.steps_per_replay == 0) else 1
+        graphed = trainer.make_graphed_step(buf, local_batch, device_sampling=dev_sampling, steps_per_replay=spr) if use_graph else None
 
         def one_step(i=None):
             if dev_sampling:
@@ -462,7 +467,7 @@ def main_ddpg(a):
             info, _, _ = trainer.shared_train_policy_on_batch("policy_0", tuple({"policy_0": x} for x in s_) + (None, None))
             policy.soft_target_updates()
             return info
-        elapsed, info = timed_steps(one_step, a.steps, a.warmup, world, dev)
+        elapsed, info = timed_steps(one_step, a.steps // spr, a.warmup // spr, world, dev)      # spr steps per call
         if graphed is not None:    # the gather inside the graph cannot carry events: time the same launch on its own afterwards
             ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(50)]
             for e in ev:
@@ -487,7 +492,7 @@ def main_ddpg(a):
                                       "step = sample + critic update + actor update + soft target updates; reference semantics "
                                       "(frozen critic heads A-4, actor updated every call A-5); gumbel noise drawn on the %s; %s" % (
                                           "MATD3" if td3 else "MADDPG", N, A, D, S, cap, "host (reference stream)" if a.host_noise else "device",
-                                          ("whole step replayed as one captured HIP graph, batch indices drawn %s" % ("on the host (numpy) and uploaded" if a.host_indices else
+                                          ("%d consecutive step(s) per captured HIP graph replay, batch indices drawn %s" % (spr, "on the host (numpy) and uploaded" if a.host_indices else
                                            "on the device inside the gather (uniform with replacement, as np.random.choice)")) if use_graph else "kernels launched one by one"),
                           "batch_per_gpu": r0["local_batch"], "global_batch": r0["global_batch"], "parallelism": "dp%d" % world,
                           "allreduce": allreduce_name() if world > 1 else None,

@@ -180,7 +180,7 @@ class MADDPG(object):
         self._last = (obs, cent, acts, rew, nobs, ncent, dones_env, valid, avail, navail, u_t, w)
         return train_info, new_priorities, idxes
 
-    def make_graphed_step(self, buffer, batch_size, policy_id="policy_0", device_sampling=False):
+    def make_graphed_step(self, buffer, batch_size, policy_id="policy_0", device_sampling=False, steps_per_replay=1):
         """One whole update -- gather of `batch_size` transitions, critic update, actor update, soft target updates -- captured
         once as a HIP graph and replayed with one launch per step. This path is ~45 kernels of a few microseconds each:
         eagerly it is bound by launch latency and host work, not by the GPU (csrc/ope_ddpg.hip). Returns
@@ -190,7 +190,11 @@ class MADDPG(object):
         graph), gumbel noise drawn on the device (`device_noise`), the Adam step counters live on the device.
         `device_sampling=True`: the batch indices are drawn on the device too (buffer.sample(batch_size) with the uniform draw
         inside the gather kernel, MlpPolicyBuffer.sample_device): `step()` takes no argument, a replay involves no host data at
-        all, and train_info["indices"] holds the drawn indices."""
+        all, and train_info["indices"] holds the drawn indices. With device sampling a replay may also hold several CONSECUTIVE
+        training steps (`steps_per_replay`; the counters that key indices, noise and Adam's bias correction advance on the device
+        between them), which amortises the graph-launch latency; train_info is then that of the last step of the replay."""
+        steps_per_replay = int(steps_per_replay)
+        assert steps_per_replay == 1 or device_sampling, "several steps per replay need the indices drawn on the device"
         if self.use_per or opdist.is_distributed():
             raise NotImplementedError("graphed step: uniform replay on a single GPU only")
         pid = policy_id
@@ -237,10 +241,13 @@ class MADDPG(object):
         policy._polyak_done = snap_misc[1]
         np.random.set_state(snap_misc[2])
         torch.cuda.synchronize(self.device)
+        count0 = dict(self.num_updates)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            info = body()
-        for opt in (policy.critic_optimizer, policy.actor_optimizer):      # capture ran the host code but no kernels
+            for _ in range(steps_per_replay):
+                info = body()
+        self.num_updates.update(count0)        # capture ran the host code but no kernels
+        for opt in (policy.critic_optimizer, policy.actor_optimizer):
             opt.step_count = int(opt.step_dev[0].item())
         ring = [(torch.empty(B, dtype=torch.int64).pin_memory(), torch.cuda.Event()) for _ in range(8)]
         state = {"k": 0, "used": [False] * 8}
@@ -248,7 +255,9 @@ class MADDPG(object):
         def step_sampled():
             graph.replay()
             for opt in (policy.critic_optimizer, policy.actor_optimizer):
-                opt.step_count += 1
+                opt.step_count += steps_per_replay
+            if self.count_updates:
+                self.num_updates[pid] += steps_per_replay
             return info
 
         def step(inds):

@@ -324,3 +324,26 @@ def test_general_path_matches_reference_fixtures():
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
     assert " passed" in r.stdout
+
+
+def test_device_sampled_graph_steps_are_the_same_alone_or_batched():
+    """Graph replay with everything drawn on the device (batch indices inside the gather, gumbel noise inside the update
+    kernels, Adam step counts): three replays of a one-step graph and ONE replay of a three-step graph leave bit-identical
+    networks, targets and Adam state (every kernel is deterministic and the Philox streams are keyed by the device step
+    count), the drawn indices lie inside the filled part of the buffer, and the step counts advance by three."""
+    finals = []
+    for spr in (1, 3):
+        dims, N, A, D, S, B, cap, policy, trainer, buf = config3_setup(True, False)
+        torch.manual_seed(5)
+        step = trainer.make_graphed_step(buf, B, device_sampling=True, steps_per_replay=spr)
+        for _ in range(3 // spr):
+            info = step()
+        torch.cuda.synchronize()
+        iv = info["indices"].cpu().numpy()
+        assert iv.min() >= 0 and iv.max() < len(buf) and len(np.unique(iv)) > B // 2
+        assert int(policy.critic_optimizer.step_dev[0].item()) == 3 == policy.critic_optimizer.step_count
+        assert np.isfinite(float(info["critic_loss"])) and np.isfinite(float(info["actor_loss"]))
+        finals.append([m._flat.clone() for m in (policy.actor, policy.critic, policy.target_actor, policy.target_critic)] +
+                      [policy.critic_optimizer.exp_avg.clone(), policy.actor_optimizer.exp_avg_sq.clone(), info["indices"].clone()])
+    for a, b in zip(*finals):
+        assert torch.equal(a, b)
