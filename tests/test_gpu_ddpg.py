@@ -150,8 +150,8 @@ def _flat_grads(mod, gvec, n_tail):
     return {name: g[off:off + int(np.prod(shape))].reshape(shape) / cnt for name, (shape, off) in mod.spec().items()}
 
 
-def config3_setup(td3, per):
-    """MADDPG / MATD3 trainer on MPE simple_spread dims with a filled 1024-transition buffer and perturbed networks."""
+def config3_setup(td3, per, dims=None, B=256, cap=1024):
+    """MADDPG / MATD3 trainer (default: MPE simple_spread dims, B = 256) with a filled buffer and perturbed networks."""
     from offpolicy_amd.config import default_args
     from offpolicy_amd.utils.synth import DIMS, policy_info_for
     from offpolicy_amd.utils.mlp_buffer import MlpReplayBuffer
@@ -159,9 +159,8 @@ def config3_setup(td3, per):
     from offpolicy_amd.algorithms.matd3.algorithm.MATD3Policy import MATD3Policy
     from offpolicy_amd.algorithms.maddpg.maddpg import MADDPG
     from offpolicy_amd.algorithms.matd3.matd3 import MATD3
-    dims = DIMS["simple_spread"]
+    dims = dims or DIMS["simple_spread"]
     N, A, D, S = dims.n_agents, dims.act_dim, dims.obs_dim, dims.state_dim
-    B, cap = 256, 1024
     args = default_args(use_per=per)
     dev = torch.device("cuda:0")
     torch.manual_seed(1)
@@ -347,3 +346,50 @@ def test_device_sampled_graph_steps_are_the_same_alone_or_batched():
                       [policy.critic_optimizer.exp_avg.clone(), policy.actor_optimizer.exp_avg_sq.clone(), info["indices"].clone()])
     for a, b in zip(*finals):
         assert torch.equal(a, b)
+
+
+def _shape_worker(out_path, n, a, d, s_dim, B, td3):
+    """One update with in-kernel noise on arbitrary dimensions; dumps both gradients, the losses and the priorities."""
+    from offpolicy_amd.utils.synth import EnvDims
+    dims, N, A, D, S, B, cap, policy, trainer, buf = config3_setup(bool(td3), True, dims=EnvDims("t", n, a, d, s_dim, 1), B=B, cap=max(1024, B))
+    trainer.device_noise = True
+    inds = np.random.RandomState(30).choice(cap, B)
+    w = np.random.RandomState(40).uniform(0.4, 1.0, size=B).astype(np.float32)
+    sm = buf.policy_buffers["policy_0"].sample_inds(inds)
+    torch.manual_seed(77)
+    info, prio, _ = trainer.shared_train_policy_on_batch("policy_0", tuple({"policy_0": x} for x in sm) + (w, inds))
+    torch.cuda.synchronize()
+    gc, ga, _ = trainer._grads[B]
+    np.savez(out_path, gc=gc.cpu().numpy(), ga=ga.cpu().numpy(), prio=np.asarray(prio), closs=float(info["critic_loss"]),
+             aloss=float(info["actor_loss"]), theta_a=policy.actor._flat.cpu().numpy(), theta_c=policy.critic._flat.cpu().numpy())
+
+
+@pytest.mark.parametrize("n,a,d,s_dim,B,td3", [
+    (5, 7, 40, 90, 100, 1),      # actor bucket 4 chunks, critic 8 (Din = 125), B not a multiple of the 16-row tile, 5 agents (two input batches)
+    (6, 3, 100, 60, 48, 0),      # actor bucket 8 chunks (D = 100), critic bucket 5 (Din = 78), 6 agents
+    (1, 16, 20, 12, 33, 1),      # one agent, 16 actions (a full head tile), ragged last tile
+    (2, 4, 10, 16, 9000, 0),     # 1 125 actor tiles > 1 024 workgroups: the grid-stride tile loop and slab accumulation
+])
+def test_fused_tile_path_matches_general_path_on_other_shapes(tmp_path, n, a, d, s_dim, B, td3):
+    """The MFMA tile kernels (default for small networks) against the general launch sequence (OPE_DDPG_FUSED=0) of the same
+    library on shapes the reference fixtures do not cover: every template bucket of the input width, agent counts beyond one
+    staging batch, batches that do not fill the last 16-row tile, a 16-action head, and more tiles than workgroups. Same
+    in-kernel noise stream, prioritized weights: gradients, losses, priorities and the parameters after the update agree."""
+    import subprocess, sys
+    outs = {}
+    for fused in ("1", "0"):
+        path = str(tmp_path / ("s%s.npz" % fused))
+        code = "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_gpu_ddpg as t; t._shape_worker(%r, %d, %d, %d, %d, %d, %d)" % (
+            os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))), path, n, a, d, s_dim, B, td3)
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, OPE_DDPG_FUSED=fused), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[fused] = np.load(path)
+    f, g = outs["1"], outs["0"]
+    np.testing.assert_allclose(f["closs"], g["closs"], rtol=2e-4)
+    np.testing.assert_allclose(f["aloss"], g["aloss"], rtol=5e-4, atol=2e-6)
+    np.testing.assert_allclose(f["prio"], g["prio"], rtol=2e-4, atol=1e-6)
+    for k in ("gc", "ga"):
+        assert np.abs(g[k]).max() > 0
+        np.testing.assert_allclose(f[k], g[k], rtol=0, atol=2e-3 * np.abs(g[k]).max(), err_msg=k)
+    for k in ("theta_a", "theta_c"):
+        np.testing.assert_allclose(f[k], g[k], rtol=0, atol=5e-5, err_msg=k)
