@@ -18,23 +18,46 @@ namespace ope {
 // (maddpg.py:128 for the critic update, 207-227 for the actor update: "mask * actor + (1 - mask) * buffer";
 //  r_maddpg.py:162, 291-301 for the sequence form; the MLP family is T = 1)
 // ---------------------------------------------------------------------------------------------------------
+// A workgroup builds 16 consecutive output rows. Their (t, rep, b) decode -- integer divisions -- is done once per row by 16
+// threads and shared through LDS; the copy itself runs over (row, column pair) with float reciprocals on small integers and, when
+// every width is even (rows then start on 8-byte boundaries), 8-byte accesses; consecutive threads write consecutive addresses.
+// (The first form was one wave per row with 4-byte accesses and an integer division per action element: 2 TB/s.)
+template <int VEC>
 __global__ void __launch_bounds__(256) build_cin_kernel(const float* __restrict__ cent, const float* __restrict__ acts,
                                                          const float* __restrict__ repl, int T, int B, int N, int A, int S, int reps,
                                                          float* __restrict__ out) {
-  // one wave per output row: the row decode (t, rep, b) is done once, lanes stride over the Din columns
+  constexpr int kRows = 16;
+  __shared__ int64_t s_cent[kRows], s_act[kRows], s_repl[kRows];
+  __shared__ int s_rep[kRows];
   const int Din = S + N * A;
-  const int lane = threadIdx.x & 63;
-  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= (int64_t)T * reps * B) return;
-  const int t = (int)(r / (reps * B));
-  const int rem = (int)(r - (int64_t)t * (reps * B));
-  const int rep = rem / B, b = rem - rep * B;
-  const float* crow = cent + ((int64_t)t * B + b) * S;
-  float* orow = out + r * Din;
-  for (int c = lane; c < S; c += 64) orow[c] = crow[c];
-  for (int c = lane; c < N * A; c += 64) {
-    const int a = c / A, j = c - a * A;
-    orow[S + c] = (repl && a == rep) ? repl[r * A + j] : acts[(((int64_t)t * N + a) * B + b) * A + j];
+  const int64_t rows = (int64_t)T * reps * B, r0 = (int64_t)blockIdx.x * kRows;
+  if (threadIdx.x < kRows) {
+    const int64_t r = r0 + threadIdx.x < rows ? r0 + threadIdx.x : rows - 1;
+    const int t = (int)(r / (reps * B));
+    const int rem = (int)(r - (int64_t)t * (reps * B));
+    const int rep = rem / B, b = rem - rep * B;
+    s_cent[threadIdx.x] = ((int64_t)t * B + b) * S;
+    s_act[threadIdx.x] = ((int64_t)t * N * B + b) * A;     // + a * B * A + j
+    s_repl[threadIdx.x] = r * A;
+    s_rep[threadIdx.x] = repl ? rep : -1;
+  }
+  __syncthreads();
+  const int W = Din / VEC;                    // column groups per row
+  const float invW = 1.0f / (float)W, invA = 1.0f / (float)A;
+  const int nrow = (int)(rows - r0 < kRows ? rows - r0 : kRows);
+  for (int e = threadIdx.x; e < nrow * W; e += 256) {
+    const int lr = (int)(((float)e + 0.5f) * invW), c = (e - lr * W) * VEC;
+    float v[VEC];
+    if (c < S) {                              // S % VEC == 0: a group never straddles the two parts
+      const float* p = cent + s_cent[lr] + c;
+      if (VEC == 2) { const f32x2 t2 = *reinterpret_cast<const f32x2*>(p); v[0] = t2[0]; v[VEC - 1] = t2[1]; } else { v[0] = p[0]; }
+    } else {
+      const int k = c - S, a = (int)(((float)k + 0.5f) * invA), j = k - a * A;      // A % VEC == 0: a group stays inside one agent's block
+      const float* p = (a == s_rep[lr]) ? repl + s_repl[lr] + j : acts + s_act[lr] + (int64_t)a * B * A + j;
+      if (VEC == 2) { const f32x2 t2 = *reinterpret_cast<const f32x2*>(p); v[0] = t2[0]; v[VEC - 1] = t2[1]; } else { v[0] = p[0]; }
+    }
+    float* o = out + (r0 + lr) * Din + c;
+    if (VEC == 2) *reinterpret_cast<f32x2*>(o) = f32x2{v[0], v[VEC - 1]}; else o[0] = v[0];
   }
 }
 
@@ -62,8 +85,9 @@ __global__ void __launch_bounds__(256) action_kernel(const float* __restrict__ l
   const int r0 = blockIdx.x * rpb;
   const int nrows = min(rpb, rows - r0);
   const int64_t base = (int64_t)r0 * A;
+  const float invA = 1.0f / (float)A;      // index math on small integers: float reciprocals instead of integer divisions
   for (int e = threadIdx.x; e < nrows * A; e += blockDim.x) {
-    const int rr = e / A, j = e - rr * A;
+    const int rr = (int)(((float)e + 0.5f) * invA), j = e - rr * A;
     float v = logits[base + e];
     if (mode == 1) v += -logf(-logf(U.at(r0 + rr, A, j) + 1e-20f) + 1e-20f);
     if (avail && avail[base + e] == 0.f) v = -1e10f;
@@ -78,31 +102,33 @@ __global__ void __launch_bounds__(256) action_kernel(const float* __restrict__ l
     if (mode == 0) {
       for (int j = 0; j < A; ++j) vr[j] = (vr[j] == mx) ? 1.f : 0.f;
     } else {
+      // one exp and one division per element (the row was evaluated three times before): e_j -> y_j = e_j / den in `sr`
       float den = 0.f;
-      for (int j = 0; j < A; ++j) den += expf(vr[j] - mx);
+      for (int j = 0; j < A; ++j) { const float ej = expf(vr[j] - mx); sr[j] = ej; den += ej; }
       // the one-hot is taken on the softmax output y (onehot_from_logits(y)): y == max(y)
       float ymax = 0.f;
-      for (int j = 0; j < A; ++j) ymax = fmaxf(ymax, expf(vr[j] - mx) / den);
+      for (int j = 0; j < A; ++j) { const float y = sr[j] / den; sr[j] = y; ymax = fmaxf(ymax, y); }
       for (int j = 0; j < A; ++j) {
-        const float y = expf(vr[j] - mx) / den;
+        const float y = sr[j];
         const float hard = (y == ymax) ? 1.f : 0.f;
         vr[j] = (hard - y) + y;
-        if (soft_out) sr[j] = y;
       }
     }
   }
   __syncthreads();
+  const float invNB = 1.0f / (float)(N * B), invB = 1.0f / (float)B;
   for (int e = threadIdx.x; e < nrows * A; e += blockDim.x) {
-    const int rr = e / A, j = e - rr * A;
+    const int rr = (int)(((float)e + 0.5f) * invA), j = e - rr * A;
     const float out = val[rr * pitch + j];
     if (act_out) act_out[base + e] = out;
     if (soft_out) soft_out[base + e] = soft[rr * pitch + j];
     if (cent_nact) {
       const int r = r0 + rr;
-      const int t = r / (N * B);
+      int t = (int)(((float)r + 0.5f) * invNB);        // exact for r < 2^24; corrected below for larger row counts
+      t += (r - t * (N * B) >= N * B) - (r - t * (N * B) < 0);
       if (t >= t_shift) {
         const int rem = r - t * (N * B);
-        const int a = rem / B, b = rem - a * B;
+        const int a = (int)(((float)rem + 0.5f) * invB), b = rem - a * B;
         cent_nact[((int64_t)(t - t_shift) * B + b) * (N * A) + a * A + j] = out;
       }
     }
@@ -366,8 +392,12 @@ static int launch1d(int64_t n) { return ope_cdiv(n, 256); }
 
 int launch_build_cin(const float* cent, const float* acts, const float* repl, int T, int B, int N, int A, int S, int reps, float* out,
                      hipStream_t st) {
-  OPE_L(hipLaunchKernelGGL(build_cin_kernel, dim3(ope_cdiv((int64_t)T * reps * B, 4)), dim3(256), 0, st, cent, acts, repl, T, B, N, A, S,
-                           reps, out));
+  const int64_t rows = (int64_t)T * reps * B;
+  const bool even = !(S & 1) && !(A & 1) && !((uintptr_t)cent & 7) && !((uintptr_t)acts & 7) && !((uintptr_t)out & 7) && !((uintptr_t)repl & 7);
+  if (even)
+    OPE_L(hipLaunchKernelGGL(build_cin_kernel<2>, dim3(ope_cdiv(rows, 16)), dim3(256), 0, st, cent, acts, repl, T, B, N, A, S, reps, out));
+  else
+    OPE_L(hipLaunchKernelGGL(build_cin_kernel<1>, dim3(ope_cdiv(rows, 16)), dim3(256), 0, st, cent, acts, repl, T, B, N, A, S, reps, out));
   return OPE_OK;
 }
 int launch_action(const float* logits, const float* avail, NoiseSrc U, int rows, int B, int A, int N, int mode, int t_shift,

@@ -126,26 +126,112 @@ __global__ void __launch_bounds__(256) gru_cell_bwd_kernel(CellBwdArgs a) {
 
 // ---------------------------------------------------------------------------------------------------------
 // Adjoint of  out = Linear_K(LayerNorm(h))  w.r.t. h for a dense output gradient (every output carries one).
-// One wave per row, lane = feature:  dy = sum_k dout[k] W[k][f] ; dyh = dy gamma ; dh = rstd (dyh - mean dyh - xhat mean(dyh xhat))
+//   dy = sum_k dout[k] W[k][f] ; dyh = dy gamma ; dh = rstd (dyh - mean dyh - xhat mean(dyh xhat))
+// 16 rows per wave in the trunk kernels' lane convention: lane (j, g) holds features 16c + 4g + 0..3 (c = 0..3) of row 16w + j, so a
+// row is four 16-byte loads / stores per lane, the two row means are 16 local values + two VALU lane swaps (rowsum4), and the head
+// weights / gamma sit in LDS. (The first form -- one wave per row, lane = feature, K dependent broadcast loads and 12 ds_bpermute
+// steps per row -- ran at 2.2 TB/s of its own traffic: 60 us for 231 k rows.)
 // ---------------------------------------------------------------------------------------------------------
+constexpr int kHbMaxK = 64;
 __global__ void __launch_bounds__(256) head_bwd_dense_kernel(const float* __restrict__ dout, int ldk, int K, const float* __restrict__ Wq,
                                                               const float* __restrict__ gamma, const float* __restrict__ xhat,
                                                               const float* __restrict__ rstd, int rows, float* __restrict__ dh) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  float dy = 0.f;
-  for (int k = 0; k < K; ++k) dy = fmaf(dout[(int64_t)row * ldk + k], Wq[k * OPE_H + lane], dy);
-  const float dyh = dy * gamma[lane];
-  const float xh = xhat[(int64_t)row * OPE_H + lane];
-  float m1 = dyh, m2 = dyh * xh;
-  for (int o = 32; o > 0; o >>= 1) {
-    m1 += __shfl_xor(m1, o, 64);
-    m2 += __shfl_xor(m2, o, 64);
+  __shared__ __attribute__((aligned(16))) float s_w[(kHbMaxK + 1) * OPE_H];      // [K][64] head weights, then gamma
+  for (int e = threadIdx.x; e < K * OPE_H; e += 256) s_w[e] = Wq[e];
+  if (threadIdx.x < OPE_H) s_w[K * OPE_H + threadIdx.x] = gamma[threadIdx.x];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+  const int64_t row = (int64_t)blockIdx.x * 64 + (threadIdx.x >> 6) * 16 + j;
+  const bool live = row < rows;
+  const int64_t rr = live ? row : 0;
+  f32x4 xh[4], dy[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    xh[c] = *reinterpret_cast<const f32x4*>(xhat + rr * OPE_H + 16 * c + 4 * g);
+    dy[c] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  m1 *= (1.0f / OPE_H);
-  m2 *= (1.0f / OPE_H);
-  dh[(int64_t)row * OPE_H + lane] = rstd[row] * (dyh - m1 - xh * m2);
+  const float rs = rstd[rr];
+  const float* drow = dout + rr * ldk;
+#pragma unroll 2
+  for (int k = 0; k < K; ++k) {
+    const float d = drow[k];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dy[c] += d * *reinterpret_cast<const f32x4*>(s_w + k * OPE_H + 16 * c + 4 * g);
+  }
+  float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    dy[c] *= *reinterpret_cast<const f32x4*>(s_w + K * OPE_H + 16 * c + 4 * g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { m1 += dy[c][r]; m2 = fmaf(dy[c][r], xh[c][r], m2); }
+  }
+  m1 = rowsum4(m1) * (1.0f / OPE_H);
+  m2 = rowsum4(m2) * (1.0f / OPE_H);
+  if (live) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      f32x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = rs * (dy[c][r] - m1 - xh[c][r] * m2);
+      *reinterpret_cast<f32x4*>(dh + row * OPE_H + 16 * c + 4 * g) = o;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// out = Linear_K(LayerNorm(h)) for every row (rnn.norm + the actor's action head / the critic's q heads, r_actor_critic.py:50-56,
+// 108-118), optionally saving the normalised input and 1/std for the adjoint above. Same 16-rows-per-wave layout as
+// head_bwd_dense_kernel: statistics = 16 local values + two lane swaps, every lane forms its 16-feature partial of each output,
+// rowsum4 completes it, lane g stores outputs k = g (mod 4). (The thread-per-row head_fwd_kernel<1> it replaces here walked a
+// 64-long dependent chain per thread: 24 us for 231 k rows x 18 outputs.)
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) head_fwd_dense_kernel(const float* __restrict__ h, int K, const float* __restrict__ Wq,
+                                                              const float* __restrict__ bq, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, int64_t rows, float* __restrict__ out,
+                                                              float* __restrict__ xhat_o, float* __restrict__ rstd_o) {
+  __shared__ __attribute__((aligned(16))) float s_w[(kHbMaxK + 2) * OPE_H];      // [K][64] head weights, gamma, beta
+  for (int e = threadIdx.x; e < K * OPE_H; e += 256) s_w[e] = Wq[e];
+  if (threadIdx.x < OPE_H) { s_w[K * OPE_H + threadIdx.x] = gamma[threadIdx.x]; s_w[(K + 1) * OPE_H + threadIdx.x] = beta[threadIdx.x]; }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+  const int64_t row = (int64_t)blockIdx.x * 64 + (threadIdx.x >> 6) * 16 + j;
+  const bool live = row < rows;
+  const int64_t rr = live ? row : 0;
+  f32x4 x[4];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    x[c] = *reinterpret_cast<const f32x4*>(h + rr * OPE_H + 16 * c + 4 * g);
+    s += (x[c][0] + x[c][1]) + (x[c][2] + x[c][3]);
+  }
+  const float mu = rowsum4(s) * (1.0f / OPE_H);
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { x[c][r] -= mu; q = fmaf(x[c][r], x[c][r], q); }
+  const float rs = 1.0f / sqrtf(rowsum4(q) * (1.0f / OPE_H) + OPE_LN_EPS);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    x[c] *= rs;
+    if (xhat_o && live) *reinterpret_cast<f32x4*>(xhat_o + row * OPE_H + 16 * c + 4 * g) = x[c];
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(s_w + K * OPE_H + 16 * c + 4 * g);
+    const f32x4 be = *reinterpret_cast<const f32x4*>(s_w + (K + 1) * OPE_H + 16 * c + 4 * g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) x[c][r] = fmaf(x[c][r], ga[r], be[r]);
+  }
+  if (rstd_o && live && g == 0) rstd_o[row] = rs;
+  for (int k = 0; k < K; ++k) {
+    float p = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(s_w + k * OPE_H + 16 * c + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) p = fmaf(x[c][r], w[r], p);
+    }
+    p = rowsum4(p) + bq[k];
+    if (live && (k & 3) == g) out[row * K + k] = p;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -355,12 +441,10 @@ static int rscan(const float* gi, int rps, int steps, const float* theta, const 
 // LayerNorm + Linear head on every row: out [rows][Hout]
 static int rhead(const float* h, int64_t rows, int Hout, const float* theta, const AgentLayout& L, float* out, float* W, const SaveSet* save,
                  hipStream_t st) {
-  HeadFwdArgs hf;
-  memset(&hf, 0, sizeof(hf));
-  hf.R = rows; hf.NB = (int)rows; hf.B = (int)rows; hf.N = 1; hf.T = 1; hf.A = Hout; hf.theta0 = theta; hf.theta1 = theta; hf.L = L;
-  hf.h0 = h; hf.q_out = out;
-  if (save) { hf.xhat_o = W + save->xhat_o; hf.rstd_o = W + save->rstd_o; }
-  return launch_head_fwd(hf, 1, st);
+  if (Hout > kHbMaxK) return OPE_EINVAL;
+  OPE_L(hipLaunchKernelGGL(head_fwd_dense_kernel, dim3(ope_cdiv(rows, 64)), dim3(256), 0, st, h, Hout, theta + L.q_w, theta + L.q_b,
+                           theta + L.lno_w, theta + L.lno_b, rows, out, save ? W + save->xhat_o : nullptr, save ? W + save->rstd_o : nullptr));
+  return OPE_OK;
 }
 
 static int rcell(const RPlan& p, const float* gi, const float* hprev, int64_t rows, int reps, int prev_shift, const float* theta,
@@ -391,7 +475,8 @@ static int rnn_backward(const RPlan& p, float* W, const SaveSet& s, const float*
                         hipStream_t st) {
   int rc;
   const int64_t rows = (int64_t)rps * steps;
-  OPE_L(hipLaunchKernelGGL(head_bwd_dense_kernel, dim3(ope_cdiv(rows, 4)), dim3(256), 0, st, dout, ldk, Hout, theta + L.q_w,
+  if (Hout > kHbMaxK) return OPE_EINVAL;
+  OPE_L(hipLaunchKernelGGL(head_bwd_dense_kernel, dim3(ope_cdiv(rows, 64)), dim3(256), 0, st, dout, ldk, Hout, theta + L.q_w,
                            theta + L.lno_w, W + s.xhat_o, W + s.rstd_o, (int)rows, W + p.dh_out));
   GruBwdArgs gb;
   memset(&gb, 0, sizeof(gb));
@@ -592,7 +677,7 @@ extern "C" int ope_rddpg_actor_loss_and_grad(const ope_rddpg_cfg* cfg, const ope
   OPE_L(hipLaunchKernelGGL(ractor_obj_kernel, dim3(launch1d(Ra)), dim3(256), 0, st, W + p.q, p.K, bt->dones, Ra, p.NB, W + p.dq,
                            W + p.loss_part));
   // critic adjoint down to its input (parameters frozen), through the gumbel-softmax into the actor logits
-  OPE_L(hipLaunchKernelGGL(head_bwd_dense_kernel, dim3(ope_cdiv(Ra, 4)), dim3(256), 0, st, W + p.dq, p.K, p.K, theta_critic + p.CL.q_w,
+  OPE_L(hipLaunchKernelGGL(head_bwd_dense_kernel, dim3(ope_cdiv(Ra, 64)), dim3(256), 0, st, W + p.dq, p.K, p.K, theta_critic + p.CL.q_w,
                            theta_critic + p.CL.lno_w, W + p.SC.xhat_o, W + p.SC.rstd_o, Ra, W + p.dh_out));
   CellBwdArgs cb;
   cb.R = Ra; cb.B = p.B; cb.reps = p.N; cb.prev_shift = -1; cb.dh = W + p.dh_out; cb.hprev = W + p.c_h;
