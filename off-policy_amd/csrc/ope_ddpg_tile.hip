@@ -35,7 +35,6 @@ namespace {
 constexpr int kRT = 16;        // data rows per tile
 constexpr int kHS = 68;        // LDS row stride of 64-wide activations (4 x odd: conflict-free operand reads)
 constexpr int kHO = 16;        // max head outputs
-constexpr int kHP = 20;        // row stride of the head partial sums
 constexpr float kEps = OPE_LN_EPS;
 
 // Small vectors of one net staged in LDS (float offsets)
@@ -212,7 +211,7 @@ __device__ __forceinline__ f32x4 mm_frag(const f32x4 (&A)[NC], const f32x4 (&B)[
 // b.x0 holds the raw input rows (zero beyond K0 up to 16 NC). Returns the head outputs i = 4g + r of row j (0 for i >= Hout).
 // SAVE: also leave LN0 / LN1 outputs in b.xn / b.a1 (operands of the weight-gradient products).
 template <bool SAVE, int NC>
-__device__ __forceinline__ f32x4 tile_forward(const TNet& n, const float* lds, const TBuf& b, float* hp, int wave, int lane,
+__device__ __forceinline__ f32x4 tile_forward(const TNet& n, const float* lds, const TBuf& b, int wave, int lane,
                                               const WFwd<NC>& w) {
   const int j = lane & 15, g = lane >> 4;
   const float* v = lds + n.vec;
@@ -243,21 +242,23 @@ __device__ __forceinline__ f32x4 tile_forward(const TNet& n, const float* lds, c
   for (int r = 0; r < 4; ++r) z[r] = fmaxf(z[r], 0.f);
   *reinterpret_cast<f32x4*>(b.r2 + j * kHS + fo) = z;
   lds_barrier();
-  // LN2 + head: every wave multiplies its own 16 input features, the 4 partial sums meet in LDS
+  // LN2 + head. Every wave holds the whole normalised row anyway (the statistics are computed redundantly), so each forms the
+  // complete head output itself: 16 MFMAs on an idle matrix pipe instead of 4 + an LDS exchange behind a third barrier.
   load_frag<4>(b.r2, kHS, j, g, h);
   ln_frag<4>(h, OPE_H, g);
   affine_frag<4>(h, OPE_H, v + V_G2, v + V_BE2, g);
-  f32x4 Ah = {0.f, 0.f, 0.f, 0.f};
-  if (j < n.Hout) Ah = *reinterpret_cast<const f32x4*>(v + V_HW + j * OPE_H + fo);
-  const f32x4 mine = pick(h, wave);
-  f32x4 p = {0.f, 0.f, 0.f, 0.f};
+  f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int r = 0; r < 4; ++r) p = mfma16(Ah[r], mine[r], p);
-  *reinterpret_cast<f32x4*>(hp + (wave * kRT + j) * kHP + 4 * g) = p;
-  lds_barrier();
-  const float* q = hp + j * kHP + 4 * g;
-  f32x4 out = (*reinterpret_cast<const f32x4*>(q) + *reinterpret_cast<const f32x4*>(q + kRT * kHP)) +
-              (*reinterpret_cast<const f32x4*>(q + 2 * kRT * kHP) + *reinterpret_cast<const f32x4*>(q + 3 * kRT * kHP));
+  for (int c = 0; c < 4; ++c) {
+    f32x4 Ah = {0.f, 0.f, 0.f, 0.f};
+    if (j < n.Hout) Ah = *reinterpret_cast<const f32x4*>(v + V_HW + j * OPE_H + 16 * c + 4 * g);
+#pragma unroll
+    for (int r = 0; r < 4; r += 2) {
+      p0 = mfma16(Ah[r], h[c][r], p0);
+      p1 = mfma16(Ah[r + 1], h[c][r + 1], p1);
+    }
+  }
+  f32x4 out = p0 + p1;
 #pragma unroll
   for (int r = 0; r < 4; ++r) out[r] = (4 * g + r < n.Hout) ? out[r] + v[V_HB + 4 * g + r] : 0.f;
   return out;
@@ -504,7 +505,7 @@ struct TileArgs {
   float gamma, huber_delta, per_eps;
   long long* dbg;                 // optional: s_memtime stamps of workgroup 0 / thread 0 (tools/ddpg_phases.py)
   // LDS offsets (floats)
-  int o_xa, o_xna, o_xt, o_xl, o_xnl, o_r1, o_r2, o_r1s, o_a1s, o_r2s, o_r1c, o_r2c, o_dz, o_d1, o_da, o_hp;
+  int o_xa, o_xna, o_xt, o_xl, o_xnl, o_r1, o_r2, o_r1s, o_a1s, o_r2s, o_r1c, o_r2c, o_dz, o_d1, o_da;
 };
 
 // A [16][16 NB] input tile, global -> registers -> LDS in two steps (all loads of a staging phase are issued before the first
@@ -629,7 +630,7 @@ __global__ void __launch_bounds__(256, 1) ddpg_critic_tile_kernel(TileArgs a) {
       if (a.noisy) a.noise.at4(row, A, g, uu);
       lds_barrier();                    // inputs staged (first agent) / head partials of the previous agent consumed
       const TBuf tb{lds + a.o_xa + ag * kRT * xsa, nullptr, lds + a.o_r1, nullptr, lds + a.o_r2};
-      const f32x4 logit = tile_forward<false, NCA>(a.n0, lds, tb, lds + a.o_hp, wave, lane, wa);
+      const f32x4 logit = tile_forward<false, NCA>(a.n0, lds, tb, wave, lane, wa);
       f32x4 y;
       const f32x4 act = select_action_frag(logit, A, g, av, uu, a.noisy ? 1 : 0, y);
       if (wave == (ag & 3)) {
@@ -642,7 +643,7 @@ __global__ void __launch_bounds__(256, 1) ddpg_critic_tile_kernel(TileArgs a) {
     lds_barrier();
     OPE_STAMP(2)
     const TBuf tt{lds + a.o_xt, nullptr, lds + a.o_r1, nullptr, lds + a.o_r2};
-    const f32x4 qt = tile_forward<false, NCC>(a.n1, lds, tt, lds + a.o_hp, wave, lane, wt);
+    const f32x4 qt = tile_forward<false, NCC>(a.n1, lds, tt, wave, lane, wt);
     float qn = 3.0e38f;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -650,7 +651,7 @@ __global__ void __launch_bounds__(256, 1) ddpg_critic_tile_kernel(TileArgs a) {
     qn = -xg_max(-qn);
     OPE_STAMP(3)
     const TBuf tl{lds + a.o_xl, lds + a.o_xnl, lds + a.o_r1s, lds + a.o_a1s, lds + a.o_r2s};
-    const f32x4 q = tile_forward<true, NCC>(a.n2, lds, tl, lds + a.o_hp, wave, lane, wl);
+    const f32x4 q = tile_forward<true, NCC>(a.n2, lds, tl, wave, lane, wl);
     OPE_STAMP(4)
     // TD error (maddpg.py:112-157): target = r + gamma (1 - done) min_k Q'_k ; e_k = target - Q_k
     const float target = rew + a.gamma * (1.0f - den) * qn;
@@ -742,7 +743,7 @@ __global__ void __launch_bounds__(256, 1) ddpg_actor_tile_kernel(TileArgs a) {
     const float vld = live ? a.bt.valid_transition[rr] : 0.f;
     lds_barrier();
     const TBuf ta{lds + a.o_xa, lds + a.o_xna, lds + a.o_r1s, lds + a.o_a1s, lds + a.o_r2s};
-    const f32x4 logit = tile_forward<true, NCA>(a.n0, lds, ta, lds + a.o_hp, wave, lane, wa);
+    const f32x4 logit = tile_forward<true, NCA>(a.n0, lds, ta, wave, lane, wa);
     f32x4 y;
     const f32x4 act = select_action_frag(logit, A, g, av, uu, 1, y);
     // critic input: the agent's own action block replaced by the actor's sample (maddpg.py:207-227)
@@ -753,7 +754,7 @@ __global__ void __launch_bounds__(256, 1) ddpg_actor_tile_kernel(TileArgs a) {
     }
     lds_barrier();
     const TBuf tc{lds + a.o_xl, nullptr, lds + a.o_r1c, nullptr, lds + a.o_r2c};
-    const f32x4 q = tile_forward<false, NCC>(a.n1, lds, tc, lds + a.o_hp, wave, lane, wc);
+    const f32x4 q = tile_forward<false, NCC>(a.n1, lds, tc, wave, lane, wc);
     const float q1 = __shfl(q[0], j, 64);
     ls += row16_sum(-q1 * vld); cs += row16_sum(vld); qs += row16_sum(q1 * vld);     // loss = -sum(Q_1 valid) / sum(valid) (maddpg.py:229-232)
     f32x4 dh = {0.f, 0.f, 0.f, 0.f};
@@ -862,7 +863,7 @@ int plan_critic(TileArgs& a, const float* tat, const float* tct, const float* tc
   const int xa = kRT * a.n0.xs, xc = kRT * a.n1.xs;
   a.o_xa = take(a.N * xa); a.o_xt = take(xc); a.o_xl = take(xc); a.o_xnl = take(xc);
   a.o_r1 = take(kRT * kHS); a.o_r2 = take(kRT * kHS); a.o_r1s = take(kRT * kHS); a.o_a1s = take(kRT * kHS); a.o_r2s = take(kRT * kHS);
-  a.o_dz = take(kRT * kHS); a.o_d1 = take(kRT * kHS); a.o_da = take(xc); a.o_hp = take(4 * kRT * kHP);
+  a.o_dz = take(kRT * kHS); a.o_d1 = take(kRT * kHS); a.o_da = take(xc);
   return o;
 }
 int plan_actor(TileArgs& a, const float* ta, const float* tc) {
@@ -874,7 +875,7 @@ int plan_actor(TileArgs& a, const float* ta, const float* tc) {
   const int xa = kRT * a.n0.xs, xc = kRT * a.n1.xs;
   a.o_xa = take(xa); a.o_xna = take(xa); a.o_xl = take(xc);
   a.o_r1s = take(kRT * kHS); a.o_a1s = take(kRT * kHS); a.o_r2s = take(kRT * kHS); a.o_r1c = take(kRT * kHS); a.o_r2c = take(kRT * kHS);
-  a.o_dz = take(kRT * kHS); a.o_d1 = take(kRT * kHS); a.o_da = take(xc > xa ? xc : xa); a.o_hp = take(4 * kRT * kHP);
+  a.o_dz = take(kRT * kHS); a.o_d1 = take(kRT * kHS); a.o_da = take(xc > xa ? xc : xa);
   return o;
 }
 void fill_dims(TileArgs& a, int N, int A, int D, int S, int K, int B) {
