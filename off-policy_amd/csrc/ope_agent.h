@@ -8,7 +8,25 @@ namespace ope {
 __device__ __forceinline__ int ope_round4_dev(int x) { return (x + 3) & ~3; }
 
 // ---- argument blocks (passed by value to the kernels) -----------------------------------------------------
+// "Replicated rows" input of the trunk (actor update of the MADDPG families, maddpg.py:207-227 / r_maddpg.py:291-301): the R rows
+// are reps = N copies of T*B base rows x = [cent_obs | joint action], copy `rep` differing from its base row only in action block
+// `rep`. The first layer is affine in x once the row's LayerNorm statistics are known, so it is evaluated ONCE per base row
+// (u = W1 (gamma o (x - mean)), mean, M2 = sum (x - mean)^2) and corrected per copy with the 64 x A block of W1 gamma that the copy touches;
+// the [R][D] input (463 MB at MMM2 / B = 128) is never built and the first layer's 7.4 GMAC shrink to 0.74 + 0.27.
+struct RepIn {
+  const float* u;      // [T*B][64]   W1 (gamma o (x_base - mean_base))
+  const float* s12;    // [T*B][2]    mean_base, sum (x_base - mean_base)^2
+  const float* acts;   // [T][N][B][A] buffer actions (the blocks being replaced)
+  const float* repl;   // [R][A]      replacement block of row r = (t*N + rep)*B + b
+  const float* wblk;   // [64][N*A]   (W1 gamma)[:, S:]
+  const float* wsum;   // [64]        W1 gamma
+  const float* cst;    // [64]        W1 beta + b1
+  float* u_out; float* s12_out;    // MODE 2 (producer over the base rows) writes these
+  int T, B, N, A, S;
+};
+
 struct TrunkFwdArgs {
+  RepIn rep;           // only read by the replicated-rows launches
   const float* x;      // [R][D] input rows
   int R, D;
   const float* theta;  // flat parameters of the net being evaluated
@@ -110,6 +128,10 @@ struct TrunkBwdArgs {
 int launch_trunk_fwd(const TrunkFwdArgs& a, bool save, hipStream_t st);
 int launch_trunk_fwd2(const TrunkFwdArgs& a, bool save, hipStream_t st);   // workgroup-cooperative form (ope_trunk2.hip)
 int launch_trunk_fwd3(const TrunkFwdArgs& a, bool save, hipStream_t st);   // persistent, weights in registers (ope_trunk2.hip)
+// Replicated-rows trunk (RepIn): `base` = TrunkFwdArgs over the T*B base rows (x = the base input [T*B][D]), `a` over the R = T*N*B
+// copies (x unused). scratch: 64*N*A + 128 floats. false from trunk_rep_ok = use the plain launch on a materialised input.
+bool trunk_rep_ok(int D, int N, int A);
+int launch_trunk_fwd_rep(const TrunkFwdArgs& base, const TrunkFwdArgs& a, float* scratch, hipStream_t st);
 // scans with at most this many rows use the latency-oriented four-waves-per-row kernels (ope_gru4.hip)
 constexpr int kGru4MaxRows = 1024;
 extern int g_scan_family;   // 0 auto | 1 | 4   (ope_set_scan_kernel / OPE_GRU)

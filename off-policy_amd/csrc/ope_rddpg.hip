@@ -350,7 +350,8 @@ struct RPlan {
   Workspace ws;
   SaveSet SA, SC;               // actor saves (Ra rows) / critic saves (max(TB, Ra) rows)
   int64_t gi_t, h_t, lg_t, cnact, xin, xin_n, gi_n, h_n, nq, q, dq, err_abs, loss_part, lnz, lno, thetaT, raw, rsum,
-      dh_out, dgi, dghn, dz1, dz2, lga, ysoft, actout, xin_a, h_b, cvec, dlg, c_gi, c_h;
+      dh_out, dgi, dghn, dz1, dz2, lga, ysoft, actout, xin_a, h_b, cvec, dlg, c_gi, c_h, rep_u, rep_s12, rep_scratch;
+  bool rep;
 };
 
 static int rddpg_cfg_ok(const ope_rddpg_cfg* c) {
@@ -407,7 +408,10 @@ static void rddpg_plan(const ope_rddpg_cfg* c, RPlan* p) {
   p->dz1 = W.add("dz1", Rc * OPE_H); p->dz2 = W.add("dz2", Rc * OPE_H);
   // actor update
   p->lga = W.add("logits", Ra * p->A); p->ysoft = W.add("y_soft", Ra * p->A); p->actout = W.add("act_out", Ra * p->A);
-  p->xin_a = W.add("xin_a", Ra * p->Din); p->h_b = W.add("h_branch", Ra * OPE_H);
+  p->rep = trunk_rep_ok(p->Din, p->N, p->A);
+  p->xin_a = W.add("xin_a", p->rep ? 4 : Ra * p->Din); p->h_b = W.add("h_branch", Ra * OPE_H);
+  p->rep_u = W.add("rep_u", p->rep ? p->TB * OPE_H : 4); p->rep_s12 = W.add("rep_s12", p->rep ? 2 * p->TB : 4);
+  p->rep_scratch = W.add("rep_scratch", p->rep ? (int64_t)OPE_H * p->N * p->A + 2 * OPE_H : 4);
   p->cvec = W.add("fc1_colsums", 2 * OPE_H); p->dlg = W.add("dlogits", Ra * p->A4);
 }
 
@@ -670,8 +674,23 @@ extern "C" int ope_rddpg_actor_loss_and_grad(const ope_rddpg_cfg* cfg, const ope
   if ((rc = rtrunk(W + p.xin, p.TB, p.Din, theta_critic, p.CL, W + p.c_gi, W, nullptr, st))) return rc;
   if ((rc = rscan(W + p.c_gi, p.B, p.T, theta_critic, p.CL, W + p.c_h, W, nullptr, st))) return rc;
   // sideways cell step on the spliced actions for all (t, agent copy, b) rows at once
-  if ((rc = launch_build_cin(bt->share_obs, bt->acts, W + p.actout, p.T, p.B, p.N, p.A, p.S, p.N, W + p.xin_a, st))) return rc;
-  if ((rc = rtrunk(W + p.xin_a, p.Ra, p.Din, theta_critic, p.CL, W + p.SC.gi, W, &p.SC, st))) return rc;
+  if (p.rep) {
+    // the N copies of a base row differ in one action block: first layer once per base row + a per-copy correction, the
+    // [T*N*B][Din] input is never built (RepIn, ope_agent.h)
+    TrunkFwdArgs tb0, tr;
+    memset(&tb0, 0, sizeof(tb0));
+    tb0.x = W + p.xin; tb0.R = (int)p.TB; tb0.D = p.Din; tb0.theta = theta_critic; tb0.L = p.CL;
+    tb0.rep.u_out = W + p.rep_u; tb0.rep.s12_out = W + p.rep_s12;
+    memset(&tr, 0, sizeof(tr));
+    tr.R = Ra; tr.D = p.Din; tr.theta = theta_critic; tr.L = p.CL; tr.gi = W + p.SC.gi;
+    set_trunk_saves(tr, W, p.SC);
+    tr.rep.u = W + p.rep_u; tr.rep.s12 = W + p.rep_s12; tr.rep.acts = bt->acts; tr.rep.repl = W + p.actout;
+    tr.rep.T = p.T; tr.rep.B = p.B; tr.rep.N = p.N; tr.rep.A = p.A; tr.rep.S = p.S;
+    if ((rc = launch_trunk_fwd_rep(tb0, tr, W + p.rep_scratch, st))) return rc;
+  } else {
+    if ((rc = launch_build_cin(bt->share_obs, bt->acts, W + p.actout, p.T, p.B, p.N, p.A, p.S, p.N, W + p.xin_a, st))) return rc;
+    if ((rc = rtrunk(W + p.xin_a, p.Ra, p.Din, theta_critic, p.CL, W + p.SC.gi, W, &p.SC, st))) return rc;
+  }
   if ((rc = rcell(p, W + p.SC.gi, W + p.c_h, p.Ra, p.N, -1, theta_critic, p.CL, W + p.h_b, W, &p.SC, st))) return rc;
   if ((rc = rhead(W + p.h_b, p.Ra, p.K, theta_critic, p.CL, W + p.q, W, &p.SC, st))) return rc;
   OPE_L(hipLaunchKernelGGL(ractor_obj_kernel, dim3(launch1d(Ra)), dim3(256), 0, st, W + p.q, p.K, bt->dones, Ra, p.NB, W + p.dq,

@@ -21,7 +21,10 @@ namespace ope {
 
 constexpr int kActPitch = OPE_H + 4;   // LDS row pitch of the 64-wide activations (bank shift of 4 per row)
 
-template <int VEC, int RT, bool SAVE>
+// MODE 0: the plain trunk. MODE 2: producer of the replicated-rows form -- no normalisation, xn = gamma o x, stops after the
+// first layer's product and writes u, s1, s2 per base row. MODE 1: consumer -- phase 0 and the first layer's product are replaced
+// by the per-copy correction (RepIn, ope_agent.h), everything after is the plain kernel.
+template <int VEC, int RT, bool SAVE, int MODE = 0>
 __global__ void __launch_bounds__(256) trunk_fwd2_kernel(TrunkFwdArgs a, int Dp) {
   constexpr int TR = 16 * RT;
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -37,7 +40,7 @@ __global__ void __launch_bounds__(256) trunk_fwd2_kernel(TrunkFwdArgs a, int Dp)
 
   // ---- phase 0: input LayerNorm of this wave's TR/4 rows -> LDS. All row loads are issued before the first reduction,
   // so the HBM latency is paid once per wave, not once per row. ----
-  {
+  if constexpr (MODE != 1) {
     constexpr int NI = 8;                  // D <= 512
     constexpr int NR = TR / 4;             // rows per wave
     float v[NR][NI];
@@ -89,8 +92,20 @@ __global__ void __launch_bounds__(256) trunk_fwd2_kernel(TrunkFwdArgs a, int Dp)
       for (int q = 0; q < NR; ++q) rstd[q] += __shfl_xor(rstd[q], o, 64);
 #pragma unroll
     for (int q = 0; q < NR; ++q) {
-      rstd[q] = 1.0f / sqrtf(rstd[q] / (float)D + OPE_LN_EPS);
       const int rr = wave * NR + q;
+      if constexpr (MODE == 2) {       // producer: xn = gamma o (x - mean) (centred, not scaled), plus the row's mean and M2
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const int k = lane + 64 * i;
+          if (k < 16 * KC) xn[rr * Dp + k] = (k < D ? v[q][i] - mean[q] : 0.f) * gam[i];
+        }
+        if (lane == 0 && row0 + rr < a.R) {
+          a.rep.s12_out[2 * (int64_t)(row0 + rr)] = mean[q];
+          a.rep.s12_out[2 * (int64_t)(row0 + rr) + 1] = rstd[q];       // here still sum (x - mean)^2
+        }
+        continue;
+      }
+      rstd[q] = 1.0f / sqrtf(rstd[q] / (float)D + OPE_LN_EPS);
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
         const int k = lane + 64 * i;
@@ -115,8 +130,9 @@ __global__ void __launch_bounds__(256) trunk_fwd2_kernel(TrunkFwdArgs a, int Dp)
   // ---- fc1: this wave's 16 output features, K = D ----
   f32x4 acc[RT];
 #pragma unroll
-  for (int t = 0; t < RT; ++t) acc[t] = *reinterpret_cast<const f32x4*>(th + a.L.fc1_b + 16 * wave + 4 * g);
-  {
+  for (int t = 0; t < RT; ++t)
+    acc[t] = MODE == 2 ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(th + a.L.fc1_b + 16 * wave + 4 * g);
+  if constexpr (MODE != 1) {
     const float* __restrict__ Wr = th + a.L.fc1_w + (int64_t)(16 * wave + j) * D;
     auto wload = [&](int c) { return load4c<VEC>(Wr, 16 * c + 4 * g, D); };   // clamped: chunks past KC-1 re-read the last one
     auto step = [&](const f32x4& wv, int c) {
@@ -148,6 +164,69 @@ __global__ void __launch_bounds__(256) trunk_fwd2_kernel(TrunkFwdArgs a, int Dp)
       __builtin_amdgcn_sched_barrier(0);
       step(w3, c + 3);
       __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  if constexpr (MODE == 2) {      // producer: u = W1 (gamma o x) of the base rows, nothing else
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+      if (valid[t]) *reinterpret_cast<f32x4*>(a.rep.u_out + (int64_t)row[t] * OPE_H + 16 * wave + 4 * g) = acc[t];
+    return;
+  }
+  if constexpr (MODE == 1) {
+    // consumer: row r = (t*N + rep)*B + b is base row t*B + b with action block `rep` replaced by repl[r]:
+    //   z1 = rstd (u + Wblk[:, rep] (new - old) - delta wsum) + cst,  u = W1 gamma (x_base - mean_base), delta = mean' - mean_base
+    const RepIn& R = a.rep;
+    const int NA = R.N * R.A, A = R.A;
+    float* wb = sm;                          // [64][NA]  (W1 gamma)[:, S:]
+    float* dl = sm + OPE_H * NA;             // [TR][A]   new - old action block
+    float* rinfo = dl + TR * A;              // [TR][4]   mean shift, rstd, rep, base row
+    for (int e = threadIdx.x; e < OPE_H * NA; e += 256) wb[e] = R.wblk[e];
+    if ((int)threadIdx.x < TR) {
+      const int lr = threadIdx.x;
+      const int64_t r = row0 + lr < a.R ? row0 + lr : a.R - 1;
+      const int t = (int)(r / (R.N * R.B));
+      const int rem = (int)(r - (int64_t)t * (R.N * R.B));
+      const int rep = rem / R.B, b = rem - rep * R.B;
+      const int64_t rb = (int64_t)t * R.B + b;
+      const float* nw = R.repl + r * A;
+      const float* od = R.acts + (((int64_t)t * R.N + rep) * R.B + b) * A;
+      // exact update of the base row's (mean, M2) for the replaced block: mean' = mean + delta, delta = sum(new - old) / D,
+      // M2' = M2 + sum_blk [(new - mean)^2 - (old - mean)^2] - D delta^2   (all correction terms are small: no cancellation)
+      const float mb = R.s12[2 * rb], M2 = R.s12[2 * rb + 1];
+      float d1 = 0.f, d2 = 0.f;
+      for (int q = 0; q < A; ++q) {
+        const float vn = nw[q], vo = od[q];
+        dl[lr * A + q] = vn - vo;
+        d1 += vn - vo;
+        d2 += (vn - mb) * (vn - mb) - (vo - mb) * (vo - mb);
+      }
+      const float invD = 1.0f / (float)D;
+      const float delta = d1 * invD;
+      const float var = fmaxf((M2 + d2) * invD - delta * delta, 0.f);
+      const float rsd = 1.0f / sqrtf(var + OPE_LN_EPS);
+      const float m = mb + delta;
+      rinfo[4 * lr] = delta; rinfo[4 * lr + 1] = rsd; rinfo[4 * lr + 2] = __int_as_float(rep); rinfo[4 * lr + 3] = __int_as_float((int)rb);
+      if (SAVE && row0 + lr < a.R) { a.mu0[row0 + lr] = m; a.rstd0[row0 + lr] = rsd; }
+    }
+    lds_barrier();
+    const int fo = 16 * wave + 4 * g;
+    const f32x4 ws = *reinterpret_cast<const f32x4*>(R.wsum + fo), cs = *reinterpret_cast<const f32x4*>(R.cst + fo);
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      const int lr = 16 * t + j;
+      const float m = rinfo[4 * lr], rsd = rinfo[4 * lr + 1];
+      const int rep = __float_as_int(rinfo[4 * lr + 2]), rb = __float_as_int(rinfo[4 * lr + 3]);
+      f32x4 uv = *reinterpret_cast<const f32x4*>(R.u + (int64_t)rb * OPE_H + fo);
+      const float* wrow = wb + fo * NA + rep * A;
+      const float* dr = dl + lr * A;
+      for (int q = 0; q < A; ++q) {
+        const float dq = dr[q];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) uv[r] = fmaf(wrow[r * NA + q], dq, uv[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[t][r] = fmaf(rsd, uv[r] - m * ws[r], cs[r]);
     }
   }
 
@@ -344,6 +423,68 @@ static int launch2(const TrunkFwdArgs& a, hipStream_t st) {
     hipLaunchKernelGGL((trunk_fwd2_kernel<VEC, 1, SAVE>), dim3(ope_cdiv(a.R, 16)), dim3(256), lds, st, a, Dp);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   return OPE_OK;
+}
+
+// ---- replicated-rows form (RepIn, ope_agent.h) -----------------------------------------------------------------------------
+// wblk[f][c] = W1[f][S + c] gamma[S + c],  wsum[f] = sum_k W1[f][k] gamma[k],  cst[f] = sum_k W1[f][k] beta[k] + b1[f]
+__global__ void __launch_bounds__(64) trunk_rep_prep_kernel(const float* __restrict__ th, AgentLayout L, int D, int S, float* __restrict__ wblk,
+                                                             float* __restrict__ wsum, float* __restrict__ cst) {
+  const int f = blockIdx.x, lane = threadIdx.x;
+  const float* w = th + L.fc1_w + (int64_t)f * D;
+  float a = 0.f, b = 0.f;
+  for (int k = lane; k < D; k += 64) {
+    const float wg = w[k] * th[L.fn_w + k];
+    a += wg;
+    b = fmaf(w[k], th[L.fn_b + k], b);
+    if (k >= S) wblk[(int64_t)f * (D - S) + (k - S)] = wg;
+  }
+  for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+  if (lane == 0) { wsum[f] = a; cst[f] = b + th[L.fc1_b + f]; }
+}
+
+bool trunk_rep_ok(int D, int N, int A) {
+  static const int on = getenv("OPE_TRUNK_REP") ? atoi(getenv("OPE_TRUNK_REP")) : 1;
+  // LDS of the consumer: 64 N A weights + 32 rows of (A + 4) + the 64-wide activations
+  const size_t lds = ((size_t)OPE_H * N * A + 32 * (A + 4) + 32 * kActPitch + 4 * 32) * sizeof(float);
+  return on && D <= 512 && N >= 2 && lds <= 150 * 1024;
+}
+
+template <int VEC>
+static int launch_rep(const TrunkFwdArgs& base, const TrunkFwdArgs& a0, float* scratch, hipStream_t st) {
+  const RepIn& R = a0.rep;
+  const int D = base.D, NA = R.N * R.A;
+  float* wblk = scratch;
+  float* wsum = scratch + (int64_t)OPE_H * NA;
+  float* cst = wsum + OPE_H;
+  hipLaunchKernelGGL(trunk_rep_prep_kernel, dim3(OPE_H), dim3(64), 0, st, a0.theta, a0.L, D, R.S, wblk, wsum, cst);
+  {   // producer over the T*B base rows
+    const int KC = (D + 15) >> 4, Dp = 16 * KC + 4;
+    const size_t lds = (size_t)(16 * Dp + 16 * kActPitch + 4 * 16) * sizeof(float);
+    hipLaunchKernelGGL((trunk_fwd2_kernel<VEC, 1, false, 2>), dim3(ope_cdiv(base.R, 16)), dim3(256), lds, st, base, Dp);
+  }
+  TrunkFwdArgs a = a0;
+  a.rep.wblk = wblk; a.rep.wsum = wsum; a.rep.cst = cst;
+  a.D = D;
+  {   // consumer over the R = T*N*B copies; "Dp" only sizes the scratch in front of the activation buffers
+    constexpr int TR = 32;
+    const int need = OPE_H * NA + TR * R.A + 4 * TR;
+    const int Dp = ((ope_cdiv(need, TR) + 3) / 4) * 4;
+    const size_t lds = (size_t)(TR * Dp + TR * kActPitch + 4 * TR) * sizeof(float);
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void*)trunk_fwd2_kernel<VEC, 2, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return OPE_ELAUNCH;
+    hipLaunchKernelGGL((trunk_fwd2_kernel<VEC, 2, true, 1>), dim3(ope_cdiv(a.R, TR)), dim3(256), lds, st, a, Dp);
+  }
+  if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
+  return OPE_OK;
+}
+
+int launch_trunk_fwd_rep(const TrunkFwdArgs& base, const TrunkFwdArgs& a, float* scratch, hipStream_t st) {
+  if (base.R < 1 || a.R < 1 || base.D < 1 || base.D > 512 || !scratch) return OPE_EINVAL;
+  const int vec = ope_vec_of(base.D);
+  if (vec == 4) return launch_rep<4>(base, a, scratch, st);
+  if (vec == 2) return launch_rep<2>(base, a, scratch, st);
+  return launch_rep<1>(base, a, scratch, st);
 }
 
 int launch_trunk_fwd2(const TrunkFwdArgs& a, bool save, hipStream_t st) {

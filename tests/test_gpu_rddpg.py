@@ -314,3 +314,18 @@ def test_full_size_mmm2_matches_oracle_one_update(td3, B):
             d = np.abs(v - refp[k].numpy())
             assert d.max() <= lr * 1.01, k
             assert (d <= 2e-5).mean() >= 0.995, (k, float((d <= 2e-5).mean()))
+
+
+def test_materialised_actor_input_path_matches_reference_fixtures():
+    """The actor update evaluates the critic's first layer once per base row plus a per-copy correction (RepIn, ope_agent.h) by
+    default; the fallback that builds the [T*N*B][S+N*A] input and runs the plain trunk on it (single-agent policies, very wide
+    inputs) is run here on the same reference fixtures and per-tensor oracle checks with OPE_TRUNK_REP=0."""
+    import os, subprocess, sys
+    if os.environ.get("OPE_TRUNK_REP") == "0":
+        pytest.skip("already on the materialised path")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                        "construction_and_train_steps or gradients_match_oracle", "-p", "no:cacheprovider"],
+                       env=dict(os.environ, OPE_TRUNK_REP="0"), capture_output=True, text=True, timeout=1800,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert " passed" in r.stdout
