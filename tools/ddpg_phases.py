@@ -1,4 +1,4 @@
-"""Phase stamps (s_memtime, shader cycles) of workgroup 0 / wave 0 of the fused MADDPG critic kernel (OPE_DDPG_DBG=1).
+"""Phase stamps (s_memtime) of workgroup 0 / thread 0 of the MADDPG critic tile kernel (OPE_DDPG_DBG=1).
 Usage: OPE_DDPG_DBG=1 python tools/ddpg_phases.py"""
 import ctypes as C, os, sys
 import numpy as np, torch
@@ -29,4 +29,4 @@ print("staging: issue loads %d, stores %d, issue weights %d, rest %d" % (st[20]-
 print("agents:", [int(st[8 + i] - (st[1] if i == 0 else st[7 + i])) for i in range(3)])
 names = ["stage vectors + inputs", "target actor x N", "target critic fwd", "live critic fwd", "TD", "critic bwd"]
 print("cycles:", {n: int(st[i + 1] - st[i]) for i, n in enumerate(names)})
-print("total", int(st[6] - st[0]), "ticks of s_memtime (100 MHz: x10 ns)")
+print("total", int(st[6] - st[0]), "s_memtime ticks (~2.4 per ns on this part: 81 k ticks = the launch's ~35 us)")
