@@ -140,9 +140,20 @@ def check(rc, what=""):
         raise OpeError("%s failed: %s (%d)" % (what or "ope call", lib.ope_strerror(int(rc)).decode(), rc))
 
 
+_raw_stream = None
+
+
 def current_stream():
-    """hipStream_t of torch's current stream as an integer handle."""
+    """hipStream_t of torch's current stream (of the current device) as an integer handle. Goes through torch's raw-stream
+    accessor when there is one: torch.cuda.current_stream() builds a Stream object behind four Python-level device lookups
+    (~9 us), and a training step asks five times."""
+    global _raw_stream
     import torch
+    if _raw_stream is None:
+        fn = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+        _raw_stream = fn if fn is not None else False
+    if _raw_stream:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

@@ -39,6 +39,7 @@ class MADDPG(object):
         self.actor_update_interval = actor_update_interval
         self.count_updates = bool(count_updates)
         self._noise_ctr = None
+        self._noise_seed = None
         self.device_noise = False     # True: gumbel noise drawn on the device instead of the reference's CPU generator stream
         self.fuse_soft_update = False  # True: Polyak of both target nets inside the Adam kernels; the next
                                        # policy.soft_target_updates() call is then skipped (same values, two launches fewer)
@@ -110,7 +111,14 @@ class MADDPG(object):
          importance_weights, idxes) = batch
         pid = update_policy_id
         policy = self.policies[pid]
-        f = lambda x: None if x is None else torch.as_tensor(x, dtype=torch.float32).to(self.device).contiguous()
+        dev = self.device
+
+        def f(x):       # tensors the engine's own buffer hands over pass through untouched (this runs ten times per update)
+            if x is None:
+                return None
+            if torch.is_tensor(x) and x.dtype is torch.float32 and x.device == dev and x.is_contiguous():
+                return x
+            return torch.as_tensor(x, dtype=torch.float32).to(dev).contiguous()
         obs, cent, acts, rew = f(obs_b[pid]), f(cent_b[pid]), f(act_b[pid]), f(rew_b[pid])
         nobs, ncent, dones_env, valid = f(nobs_b[pid]), f(cent_nobs_b[pid]), f(dones_env_b[pid]), f(valid_b[pid])
         avail = f(avail_b[pid]) if avail_b is not None else None
@@ -137,7 +145,9 @@ class MADDPG(object):
                     self._noise_ctr = torch.zeros(1, dtype=torch.int32, device=self.device)
                 self._noise_ctr += 1
                 ctr = self._noise_ctr
-            cfg.noise_seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + 0x1234567) % (1 << 64) | 1
+            if self._noise_seed is None or self._noise_seed[0] != torch.initial_seed():
+                self._noise_seed = (torch.initial_seed(), (torch.initial_seed() * 0x9E3779B97F4A7C15 + 0x1234567) % (1 << 64) | 1)
+            cfg.noise_seed = self._noise_seed[1]
             cfg.noise_counter = _lib.ptr(ctr).value
         else:
             draw = lambda shape: sample_gumbel_uniform(shape).to(self.device)

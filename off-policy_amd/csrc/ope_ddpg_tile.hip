@@ -922,8 +922,17 @@ static int launch_reduce(const float* slabs, int ns, int64_t stride, const Agent
 template <typename KERN>
 static int launch_tile(KERN kern, const TileArgs& a, int blocks, size_t lds, hipStream_t st) {
   if (lds > 160 * 1024) return OPE_EINVAL;
-  // > 64 KB of dynamic LDS needs the attribute (per kernel; cheap, and the plans of one process rarely differ)
-  if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return OPE_ELAUNCH;
+  // > 64 KB of dynamic LDS needs the attribute, per kernel instantiation; it is set when the request grows (a runtime call per
+  // launch is measurable on a step whose whole host side is ~120 us)
+  static int granted[16];
+  static const void* owner[16];
+  int slot = 0;
+  while (slot < 15 && owner[slot] && owner[slot] != (const void*)kern) ++slot;
+  if (owner[slot] != (const void*)kern) { owner[slot] = (const void*)kern; granted[slot] = 0; }
+  if ((int)lds > granted[slot]) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return OPE_ELAUNCH;
+    granted[slot] = (int)lds;
+  }
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, st, a);
   return hipGetLastError() == hipSuccess ? OPE_OK : OPE_ELAUNCH;
 }

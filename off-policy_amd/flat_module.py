@@ -56,6 +56,9 @@ class FlatModule(_Node):
     def unused_range(self):
         """[begin, end) of the registered-but-unused `fc_h` block in the flat vector (mlp.py:21-23): tensors that never get a
         gradient, which torch's Adam therefore never touches (no weight decay either). (0, 0) if the module has none."""
+        cached = self.__dict__.get("_unused_range")
+        if cached is not None:
+            return cached
         spans = []
         for name, shape, off in self._spec:
             if ".fc_h." in name:
@@ -63,4 +66,6 @@ class FlatModule(_Node):
                 for d in shape:
                     n *= d
                 spans.append((off, off + n))
-        return (min(a for a, _ in spans), max(b for _, b in spans)) if spans else (0, 0)
+        r = (min(a for a, _ in spans), max(b for _, b in spans)) if spans else (0, 0)
+        self.__dict__["_unused_range"] = r
+        return r
