@@ -111,6 +111,14 @@ def fast_allreduce_failed():
     return _fast is not None and _fast.timed_out()
 
 
+def disable_fast_allreduce(reason="disabled"):
+    """Back to torch.distributed's all_reduce (RCCL) for the rest of the run; call it on every rank."""
+    global _fast, _fast_note
+    if _fast is not None:
+        _fast = None
+        _fast_note = "rccl (one-shot xGMI path %s)" % reason
+
+
 def allreduce_backend():
     return "one-shot xGMI push (ope_allreduce_flat)" if _fast is not None else _fast_note
 
