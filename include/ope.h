@@ -321,6 +321,15 @@ typedef struct ope_rddpg_cfg {
   int32_t target_gumbel; /* 1: hard gumbel-softmax target actions (target_noise is not None, rMADDPGPolicy.py:108) */
   int32_t use_huber, use_per;
   float gamma, huber_delta;
+  /* Multi-policy updates (share_policy = False: r_maddpg.py:44-105 loops over `policy_ids`, every policy with its own actor,
+   * critic and buffer; scripts/train_mpe_rmaddpg.sh). All 0 / NULL = one policy for all agents. Otherwise dims.n_agents is the
+   * number of agents of the policy being updated, n_total_agents the number of agents in the joint action (policy order), and
+   * agent_offset the update policy's first agent in it. The batch then carries the update policy's obs / avail_acts / dones /
+   * rewards / share_obs / dones_env, but `acts` of ALL agents: [T][n_total_agents][B][A] (same act_dim for every policy). */
+  int32_t n_total_agents, agent_offset;
+  const float* joint_next_acts; /* DEVICE [T][B][n_total_agents * A] joint target action, filled by one ope_rddpg_target_actions call per
+                                 * policy; when non-NULL the critic call skips its own target-actor pass (theta_actor_tgt, batch obs and
+                                 * target_noise_u are then unused). Required when n_total_agents > dims.n_agents.                    */
 } ope_rddpg_cfg;
 
 /* which = 0 actor, 1 critic: offsets/sizes of its OPE_QMIX_NPARAM_AGENT tensors; returns the padded length. */
@@ -337,8 +346,14 @@ int ope_rddpg_critic_loss_and_grad(const ope_rddpg_cfg* cfg, const ope_fields* b
                                    const float* theta_critic, const float* theta_critic_tgt, const float* target_noise_u,
                                    const float* per_weights, void* workspace, int64_t workspace_bytes, float* grad,
                                    float* td_abs_stats, void* stream);
+/* Target actions of ONE policy's agents (get_update_info, r_maddpg.py:60-97): its target actor scanned over the T+1 observations
+ * of its dims.n_agents agents, first action dropped, written into columns (agent_offset + a) * A of joint_next_acts
+ * [T][B][n_total_agents * A]. cfg / batch are that policy's (only obs and avail_acts are read). */
+int ope_rddpg_target_actions(const ope_rddpg_cfg* cfg, const ope_fields* batch, const float* theta_actor_tgt,
+                             const float* target_noise_u, void* workspace, int64_t workspace_bytes, float* joint_next_acts,
+                             void* stream);
 /* Actor update (r_maddpg.py:236-327): actor scanned over obs[:-1], hard gumbel-softmax (noise gumbel_noise_u [T*N*B][A]),
- * actions spliced into N stacked copies of the joint action; Q_t = head 0 of one critic cell step from the critic's
+ * actions spliced into N stacked copies of the joint action (multi-policy: copy `rep` replaces block agent_offset + rep); Q_t = head 0 of one critic cell step from the critic's
  * buffer-sequence state; loss = -sum(Q (1 - shifted agent dones)) / sum(1 - shifted agent dones). grad w.r.t.
  * theta_actor + tail [loss_sum, mask_count, sum Q, 0]. */
 int ope_rddpg_actor_loss_and_grad(const ope_rddpg_cfg* cfg, const ope_fields* batch, const float* theta_actor,

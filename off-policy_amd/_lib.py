@@ -53,7 +53,8 @@ class DdpgCfg(C.Structure):
 
 class RddpgCfg(C.Structure):
     _fields_ = [("dims", Dims), ("batch", C.c_int32), ("num_q", C.c_int32), ("target_gumbel", C.c_int32),
-                ("use_huber", C.c_int32), ("use_per", C.c_int32), ("gamma", C.c_float), ("huber_delta", C.c_float)]
+                ("use_huber", C.c_int32), ("use_per", C.c_int32), ("gamma", C.c_float), ("huber_delta", C.c_float),
+                ("n_total_agents", C.c_int32), ("agent_offset", C.c_int32), ("joint_next_acts", C.c_void_p)]
 
 
 class AllreduceCtx(C.Structure):
@@ -111,6 +112,7 @@ def _load():
         "ope_rddpg_workspace_bytes": (i64, [C.POINTER(RddpgCfg)]),
         "ope_rddpg_workspace_init": (C.c_int, [C.POINTER(RddpgCfg), p, i64, p]),
         "ope_rddpg_workspace_find": (i64, [C.POINTER(RddpgCfg), C.c_char_p, C.POINTER(i64)]),
+        "ope_rddpg_target_actions": (C.c_int, [C.POINTER(RddpgCfg), C.POINTER(Fields), p, p, p, i64, p, p]),
         "ope_rddpg_critic_loss_and_grad": (C.c_int, [C.POINTER(RddpgCfg), C.POINTER(Fields), p, p, p, p, p, p, i64, p, p, p]),
         "ope_rddpg_actor_loss_and_grad": (C.c_int, [C.POINTER(RddpgCfg), C.POINTER(Fields), p, p, p, p, i64, p, p]),
         "ope_adam_scratch_floats": (i64, [i64]),

@@ -1,10 +1,16 @@
 """Recurrent MADDPG / MATD3 trainer on the HIP engine.
 
 Mirror of offpolicy/algorithms/r_maddpg/r_maddpg.py:9-331 (`R_MADDPG`, shared-observation path
-`shared_train_policy_on_batch`) for one shared policy and discrete one-hot actions. Per update:
+`shared_train_policy_on_batch`) for discrete one-hot actions. Per update:
 
     ope_rddpg_critic_loss_and_grad -> ope_adam_step(critic)
     [every actor_update_interval-th update]  ope_rddpg_actor_loss_and_grad -> ope_adam_step(actor)
+
+One shared policy ('policy_0' for all agents) or one policy per group of agents (share_policy = False, what
+scripts/train_mpe_rmaddpg.sh runs): then every policy has its own actor / critic / buffer, an update of policy p first
+collects the target actions of EVERY policy's target actor (ope_rddpg_target_actions, get_update_info r_maddpg.py:44-105)
+into the joint next action, trains p's critic on it and on the joint buffer action of all agents, and in the actor update
+replaces only p's agents' blocks (act_sequence_replace_ind_start). All policies must have the same act_dim.
 
 The reference walks the target critic (critic update) and the live critic (actor update) through the episode with a
 Python loop of 2*T network calls; the engine runs the buffer-sequence scan once and all "sideways" steps as one
@@ -36,8 +42,15 @@ class R_MADDPG(object):
         self.num_agents, self.policies, self.policy_mapping_fn = num_agents, policies, policy_mapping_fn
         self.policy_ids = sorted(list(self.policies.keys()))
         self.policy_agents = {pid: sorted([a for a in range(num_agents) if policy_mapping_fn(a) == pid]) for pid in self.policies}
-        if self.policy_ids != ["policy_0"] or len(self.policy_agents["policy_0"]) != num_agents:
-            raise NotImplementedError("the accelerated R_MADDPG path handles one shared policy ('policy_0') for all agents")
+        self.multi_policy = len(self.policy_ids) > 1
+        # joint-action order = policy order (get_update_info iterates self.policy_ids), each policy's agents in turn
+        self.agent_offset, off = {}, 0
+        for pid in self.policy_ids:
+            self.agent_offset[pid] = off
+            off += len(self.policy_agents[pid])
+        assert off == num_agents, "every agent must be mapped to a policy"
+        if len({self.policies[pid].act_dim for pid in self.policy_ids}) != 1:
+            raise NotImplementedError("policies with different action dimensions are not on the accelerated path")
         self.actor_update_interval = actor_update_interval
         self.num_updates = {p_id: 0 for p_id in self.policy_ids}
         self.use_same_share_obs = args.use_same_share_obs
@@ -50,7 +63,7 @@ class R_MADDPG(object):
         self._ws, self._grads = {}, {}
 
     def _workspace(self, policy, cfg):
-        B = cfg.batch
+        B = (cfg.batch, cfg.dims.n_agents, cfg.n_total_agents) if cfg.n_total_agents else cfg.batch
         if B not in self._ws:
             need = _lib.lib.ope_rddpg_workspace_bytes(C.byref(cfg))
             if need < 0:
@@ -116,26 +129,58 @@ class R_MADDPG(object):
         dones = self._to_device_layout(dones_b[pid], True)
         dones_env = self._to_device_layout(dones_env_b[pid], False)
         avail = self._to_device_layout(avail_b[pid], True) if (avail_b is not None and avail_b[pid] is not None) else None
-        return self._train_on_device_batch(policy, pid, obs, share, acts, rew, dones, dones_env, avail, importance_weights, idxes)
+        others = None
+        if self.multi_policy:       # every policy's observations (for its target actor) and buffer actions (joint action), policy order
+            others = []
+            for q in self.policy_ids:
+                o_q = obs if q == pid else self._to_device_layout(obs_b[q], True)
+                a_q = acts if q == pid else self._to_device_layout(act_b[q], True)
+                v_q = avail if q == pid else (self._to_device_layout(avail_b[q], True) if (avail_b is not None and avail_b[q] is not None) else None)
+                others.append((q, o_q, a_q, v_q))
+        return self._train_on_device_batch(policy, pid, obs, share, acts, rew, dones, dones_env, avail, importance_weights, idxes, others)
 
-    def _train_on_device_batch(self, policy, pid, obs, share, acts, rew, dones, dones_env, avail, importance_weights, idxes):
+    def _train_on_device_batch(self, policy, pid, obs, share, acts, rew, dones, dones_env, avail, importance_weights, idxes, others=None):
         T1, N, B, D = obs.shape
         T = self.episode_length
-        assert T1 == T + 1 and N == self.num_agents, "batch does not match the trainer's dimensions"
+        assert T1 == T + 1 and N == len(self.policy_agents[pid]), "batch does not match the trainer's dimensions"
         A = policy.act_dim
         cfg = policy.rddpg_cfg(B, T)
+        draw = (lambda shape: torch.rand(shape, **self.tpdv)) if self.device_noise else (lambda shape: sample_gumbel_uniform(shape).to(self.device))
+        st = _lib.current_stream()
+        joint_next = keep = None
+        if others is not None:
+            # joint target action: one ope_rddpg_target_actions per policy (its target actor over its agents' T+1 observations; noise
+            # drawn per policy in policy order, as get_update_info does), scattered into [T][B][N_total * A]
+            NT = self.num_agents
+            joint_next = torch.empty(T, B, NT * A, **self.tpdv)
+            keep = []
+            for q, o_q, a_q, v_q in others:
+                pol_q = self.policies[q]
+                cq = pol_q.rddpg_cfg(B, T)
+                cq.dims.n_agents, cq.n_total_agents, cq.agent_offset = o_q.shape[1], NT, self.agent_offset[q]
+                ws_q, _ = self._workspace(pol_q, cq)
+                fq = _lib.Fields()
+                fq.obs, fq.avail_acts = _lib.ptr(o_q).value, _lib.ptr(v_q).value
+                u_q = draw((T + 1, o_q.shape[1] * B, A)) if pol_q.target_noise is not None else None
+                _lib.check(_lib.lib.ope_rddpg_target_actions(C.byref(cq), C.byref(fq), _lib.ptr(pol_q.target_actor._flat), _lib.ptr(u_q),
+                                                             _lib.ptr(ws_q), ws_q.numel(), _lib.ptr(joint_next), st), "ope_rddpg_target_actions")
+                keep.append((u_q, o_q, v_q))
+            acts = torch.cat([a_q for _, _, a_q, _ in others], dim=1).contiguous()      # [T][N_total][B][A]
+            cfg.dims.n_agents, cfg.n_total_agents, cfg.agent_offset = N, NT, self.agent_offset[pid]
+            cfg.joint_next_acts = _lib.ptr(joint_next).value
         ws, (gc, ga, scratch) = self._workspace(policy, cfg)
         f = _lib.Fields()
         f.obs, f.share_obs, f.acts, f.rewards = _lib.ptr(obs).value, _lib.ptr(share).value, _lib.ptr(acts).value, _lib.ptr(rew).value
         f.dones, f.dones_env, f.avail_acts = _lib.ptr(dones).value, _lib.ptr(dones_env).value, _lib.ptr(avail).value
-        st = _lib.current_stream()
         _, world_size = opdist.world()
         train_info = {}
         update_actor = self.num_updates[pid] % self.actor_update_interval == 0
         # ---- critic ----
-        draw = (lambda shape: torch.rand(shape, **self.tpdv)) if self.device_noise else (lambda shape: sample_gumbel_uniform(shape).to(self.device))
         override, self._noise_override = self._noise_override, None
-        if override is not None:
+        if others is not None:
+            assert override is None, "noise overrides are for the single-policy data-parallel path"
+            u_t = None
+        elif override is not None:
             u_t = None if override[0] is None else override[0].to(self.device, dtype=torch.float32).contiguous()
         else:
             u_t = draw((T + 1, N * B, A)) if policy.target_noise is not None else None
@@ -177,7 +222,7 @@ class R_MADDPG(object):
             train_info["actor_grad_norm"], train_info["actor_loss"] = as_[1], as_[0]
         train_info["update_actor"] = update_actor
         self.num_updates[pid] += 1
-        self._last = (obs, share, acts, rew, dones, dones_env, avail, u_t, u_a, w, td_stats)   # keep alive past the async launches
+        self._last = (obs, share, acts, rew, dones, dones_env, avail, u_t, u_a, w, td_stats, joint_next, keep)   # keep alive past the async launches
         return train_info, new_priorities, idxes
 
     def prep_training(self):

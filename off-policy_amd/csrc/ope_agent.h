@@ -16,13 +16,14 @@ __device__ __forceinline__ int ope_round4_dev(int x) { return (x + 3) & ~3; }
 struct RepIn {
   const float* u;      // [T*B][64]   W1 (gamma o (x_base - mean_base))
   const float* s12;    // [T*B][2]    mean_base, sum (x_base - mean_base)^2
-  const float* acts;   // [T][N][B][A] buffer actions (the blocks being replaced)
-  const float* repl;   // [R][A]      replacement block of row r = (t*N + rep)*B + b
-  const float* wblk;   // [64][N*A]   (W1 gamma)[:, S:]
+  const float* acts;   // [T][NT][B][A] buffer actions of ALL agents (the blocks being replaced)
+  const float* repl;   // [R][A]      replacement block of row r = (t*N + rep)*B + b: joint-action block a0 + rep
+  const float* wblk;   // [64][NT*A]  (W1 gamma)[:, S:]
   const float* wsum;   // [64]        W1 gamma
   const float* cst;    // [64]        W1 beta + b1
   float* u_out; float* s12_out;    // MODE 2 (producer over the base rows) writes these
-  int T, B, N, A, S;
+  int T, B, N, A, S;   // N = copies per base row
+  int NT, a0;          // agents in the joint action, first agent the copies replace (NT = N, a0 = 0: every agent has its copy)
 };
 
 struct TrunkFwdArgs {
@@ -129,8 +130,8 @@ int launch_trunk_fwd(const TrunkFwdArgs& a, bool save, hipStream_t st);
 int launch_trunk_fwd2(const TrunkFwdArgs& a, bool save, hipStream_t st);   // workgroup-cooperative form (ope_trunk2.hip)
 int launch_trunk_fwd3(const TrunkFwdArgs& a, bool save, hipStream_t st);   // persistent, weights in registers (ope_trunk2.hip)
 // Replicated-rows trunk (RepIn): `base` = TrunkFwdArgs over the T*B base rows (x = the base input [T*B][D]), `a` over the R = T*N*B
-// copies (x unused). scratch: 64*N*A + 128 floats. false from trunk_rep_ok = use the plain launch on a materialised input.
-bool trunk_rep_ok(int D, int N, int A);
+// copies (x unused). scratch: 64*NT*A + 128 floats. false from trunk_rep_ok = use the plain launch on a materialised input.
+bool trunk_rep_ok(int D, int NT, int A, int copies);
 int launch_trunk_fwd_rep(const TrunkFwdArgs& base, const TrunkFwdArgs& a, float* scratch, hipStream_t st);
 // scans with at most this many rows use the latency-oriented four-waves-per-row kernels (ope_gru4.hip)
 constexpr int kGru4MaxRows = 1024;

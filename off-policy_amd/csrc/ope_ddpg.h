@@ -22,6 +22,7 @@ struct CriticTdArgs {
 // Fused "critic input gradient restricted to the updating agent's action block" + straight-through gumbel adjoint.
 struct ActGradArgs {
   int R, B, N, A, A4, S, Din;
+  int a_off;                                 // the copies' own action block is agent a_off + rep of the joint action (0: the copies ARE all agents)
   const float* dz1;                          // [R][64] adjoint of the fc1 pre-activation (zero where ReLU is off)
   const float* xhat1; const float* rstd1; const float* mu1;   // LN1 saves: relu(z1) = xhat1/rstd1 + mu1
   const float* mu0; const float* rstd0;      // input-LN saves
@@ -34,10 +35,12 @@ struct ActGradArgs {
 int launch_action_grad(const ActGradArgs& a, hipStream_t st);
 
 // shared with the recurrent family (ope_rddpg.hip)
+// `rep_off`: copy `rep` replaces action block rep_off + rep (multi-policy updates: the update policy's agents sit at an offset)
 int launch_build_cin(const float* cent, const float* acts, const float* repl, int T, int B, int N, int A, int S, int reps, float* out,
-                     hipStream_t st);
+                     hipStream_t st, int rep_off = 0);
+// nact_agents / a_off: the scatter target cent_nact holds nact_agents (default N) agents per row, this launch's agents start at a_off
 int launch_action(const float* logits, const float* avail, NoiseSrc U, int rows, int B, int A, int N, int mode, int t_shift,
-                  float* cent_nact, float* act_out, float* soft_out, hipStream_t st);
+                  float* cent_nact, float* act_out, float* soft_out, hipStream_t st, int nact_agents = 0, int a_off = 0);
 
 // fused small-network path (ope_ddpg_fused.hip): one launch per network update + one slab reduction
 bool ddpg_fused_ok(int N, int A, int D, int S, int K);

@@ -25,7 +25,7 @@ namespace ope {
 template <int VEC>
 __global__ void __launch_bounds__(256) build_cin_kernel(const float* __restrict__ cent, const float* __restrict__ acts,
                                                          const float* __restrict__ repl, int T, int B, int N, int A, int S, int reps,
-                                                         float* __restrict__ out) {
+                                                         int rep_off, float* __restrict__ out) {
   constexpr int kRows = 16;
   __shared__ int64_t s_cent[kRows], s_act[kRows], s_repl[kRows];
   __shared__ int s_rep[kRows];
@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(256) build_cin_kernel(const float* __restrict_
     s_cent[threadIdx.x] = ((int64_t)t * B + b) * S;
     s_act[threadIdx.x] = ((int64_t)t * N * B + b) * A;     // + a * B * A + j
     s_repl[threadIdx.x] = r * A;
-    s_rep[threadIdx.x] = repl ? rep : -1;
+    s_rep[threadIdx.x] = repl ? rep_off + rep : -1;
   }
   __syncthreads();
   const int W = Din / VEC;                    // column groups per row
@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(256) build_cin_kernel(const float* __restrict_
 __global__ void __launch_bounds__(256) action_kernel(const float* __restrict__ logits, const float* __restrict__ avail,
                                                       NoiseSrc U, int rows, int B, int A, int N, int mode, int t_shift,
                                                       int rpb, float* __restrict__ cent_nact, float* __restrict__ act_out,
-                                                      float* __restrict__ soft_out) {
+                                                      float* __restrict__ soft_out, int nact_agents, int a_off) {
   extern __shared__ float sm[];
   const int pitch = A | 1;
   float* val = sm;                      // [rpb][pitch] masked (noisy) logits, overwritten by the output values
@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(256) action_kernel(const float* __restrict__ l
       if (t >= t_shift) {
         const int rem = r - t * (N * B);
         const int a = (int)(((float)rem + 0.5f) * invB), b = rem - a * B;
-        cent_nact[((int64_t)(t - t_shift) * B + b) * (N * A) + a * A + j] = out;
+        cent_nact[((int64_t)(t - t_shift) * B + b) * (nact_agents * A) + (a_off + a) * A + j] = out;
       }
     }
   }
@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(64) fc1_colsum_kernel(ActGradArgs a) {
 __global__ void __launch_bounds__(256) action_grad_kernel(ActGradArgs a) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= a.R) return;
-  const int rep = (r / a.B) % a.N;
+  const int rep = a.a_off + (r / a.B) % a.N;
   const float rs1 = a.rstd1[r], m1u = a.mu1[r], rs0 = a.rstd0[r], mu0 = a.mu0[r];
   const float inv_rs1 = 1.0f / rs1;
   float dz[OPE_H];
@@ -286,7 +286,7 @@ __global__ void __launch_bounds__(256) action_grad_mfma_kernel(ActGradArgs a) {
   const int row = row0 + j;
   const bool valid = row < a.R;
   const int64_t rr = valid ? row : a.R - 1;
-  const int rep = (row0 / a.B) % a.N;          // uniform over the tile
+  const int rep = a.a_off + (row0 / a.B) % a.N;          // uniform over the tile
   const int col0 = a.S + rep * a.A;
   const float rs1 = a.rstd1[rr], mu1 = a.mu1[rr], rs0 = a.rstd0[rr], mu0 = a.mu0[rr];
   const float inv_rs1 = 1.0f / rs1;
@@ -355,7 +355,7 @@ __global__ void __launch_bounds__(256) action_grad_wave_kernel(ActGradArgs a) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= a.R) return;
-  const int rep = (r / a.B) % a.N;
+  const int rep = a.a_off + (r / a.B) % a.N;
   const float rs1 = a.rstd1[r], rs0 = a.rstd0[r], mu0 = a.mu0[r];
   const float dz = a.dz1[(int64_t)r * OPE_H + lane];
   const float z1 = a.xhat1[(int64_t)r * OPE_H + lane] / rs1 + a.mu1[r];
@@ -391,22 +391,22 @@ static int launch1d(int64_t n) { return ope_cdiv(n, 256); }
   } while (0)
 
 int launch_build_cin(const float* cent, const float* acts, const float* repl, int T, int B, int N, int A, int S, int reps, float* out,
-                     hipStream_t st) {
+                     hipStream_t st, int rep_off) {
   const int64_t rows = (int64_t)T * reps * B;
   const bool even = !(S & 1) && !(A & 1) && !((uintptr_t)cent & 7) && !((uintptr_t)acts & 7) && !((uintptr_t)out & 7) && !((uintptr_t)repl & 7);
   if (even)
-    OPE_L(hipLaunchKernelGGL(build_cin_kernel<2>, dim3(ope_cdiv(rows, 16)), dim3(256), 0, st, cent, acts, repl, T, B, N, A, S, reps, out));
+    OPE_L(hipLaunchKernelGGL(build_cin_kernel<2>, dim3(ope_cdiv(rows, 16)), dim3(256), 0, st, cent, acts, repl, T, B, N, A, S, reps, rep_off, out));
   else
-    OPE_L(hipLaunchKernelGGL(build_cin_kernel<1>, dim3(ope_cdiv(rows, 16)), dim3(256), 0, st, cent, acts, repl, T, B, N, A, S, reps, out));
+    OPE_L(hipLaunchKernelGGL(build_cin_kernel<1>, dim3(ope_cdiv(rows, 16)), dim3(256), 0, st, cent, acts, repl, T, B, N, A, S, reps, rep_off, out));
   return OPE_OK;
 }
 int launch_action(const float* logits, const float* avail, NoiseSrc U, int rows, int B, int A, int N, int mode, int t_shift,
-                  float* cent_nact, float* act_out, float* soft_out, hipStream_t st) {
+                  float* cent_nact, float* act_out, float* soft_out, hipStream_t st, int nact_agents, int a_off) {
   const int pitch = A | 1;
   const int rpb = pitch <= 31 ? 256 : 64;
   const size_t lds = (size_t)2 * rpb * pitch * sizeof(float);
   OPE_L(hipLaunchKernelGGL(action_kernel, dim3(ope_cdiv(rows, rpb)), dim3(256), lds, st, logits, avail, U, rows, B, A, N, mode, t_shift,
-                           rpb, cent_nact, act_out, soft_out));
+                           rpb, cent_nact, act_out, soft_out, nact_agents > 0 ? nact_agents : N, a_off));
   return OPE_OK;
 }
 int launch_action_grad(const ActGradArgs& a, hipStream_t st) {
@@ -690,7 +690,7 @@ extern "C" int ope_ddpg_actor_loss_and_grad(const ope_ddpg_cfg* cfg, const ope_m
   // critic backward down to its input, then through the gumbel-softmax into the actor logits
   if ((rc = mlp_backward(p, W, W + p.xin_a, p.Ra, p.Din, p.K, p.K, W + p.dq, theta_critic, p.CL, nullptr, p.ns_a, 0, nullptr, st))) return rc;
   ActGradArgs ag;
-  ag.R = p.Ra; ag.B = p.B; ag.N = p.N; ag.A = p.A; ag.A4 = p.A4; ag.S = p.S; ag.Din = p.Din; ag.dz1 = W + p.dz1;
+  ag.R = p.Ra; ag.B = p.B; ag.N = p.N; ag.A = p.A; ag.A4 = p.A4; ag.S = p.S; ag.Din = p.Din; ag.a_off = 0; ag.dz1 = W + p.dz1;
   ag.xhat1 = W + p.xhat1; ag.rstd1 = W + p.rstd1; ag.mu1 = W + p.mu1; ag.mu0 = W + p.mu0; ag.rstd0 = W + p.rstd0;
   ag.act = W + p.actout; ag.y = W + p.ysoft; ag.theta = theta_critic; ag.fc1_w = p.CL.fc1_w; ag.fc1_b = p.CL.fc1_b; ag.fn_w = p.CL.fn_w;
   ag.fn_b = p.CL.fn_b; ag.cvec = W + p.cvec; ag.dlogits = W + p.dlg;

@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(256) trunk_fwd2_kernel(TrunkFwdArgs a, int Dp)
     // consumer: row r = (t*N + rep)*B + b is base row t*B + b with action block `rep` replaced by repl[r]:
     //   z1 = rstd (u + Wblk[:, rep] (new - old) - delta wsum) + cst,  u = W1 gamma (x_base - mean_base), delta = mean' - mean_base
     const RepIn& R = a.rep;
-    const int NA = R.N * R.A, A = R.A;
+    const int NA = R.NT * R.A, A = R.A;
     float* wb = sm;                          // [64][NA]  (W1 gamma)[:, S:]
     float* dl = sm + OPE_H * NA;             // [TR][A]   new - old action block
     float* rinfo = dl + TR * A;              // [TR][4]   mean shift, rstd, rep, base row
@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(256) trunk_fwd2_kernel(TrunkFwdArgs a, int Dp)
       const int rep = rem / R.B, b = rem - rep * R.B;
       const int64_t rb = (int64_t)t * R.B + b;
       const float* nw = R.repl + r * A;
-      const float* od = R.acts + (((int64_t)t * R.N + rep) * R.B + b) * A;
+      const float* od = R.acts + (((int64_t)t * R.NT + R.a0 + rep) * R.B + b) * A;
       // exact update of the base row's (mean, M2) for the replaced block: mean' = mean + delta, delta = sum(new - old) / D,
       // M2' = M2 + sum_blk [(new - mean)^2 - (old - mean)^2] - D delta^2   (all correction terms are small: no cancellation)
       const float mb = R.s12[2 * rb], M2 = R.s12[2 * rb + 1];
@@ -206,7 +206,7 @@ __global__ void __launch_bounds__(256) trunk_fwd2_kernel(TrunkFwdArgs a, int Dp)
       const float var = fmaxf((M2 + d2) * invD - delta * delta, 0.f);
       const float rsd = 1.0f / sqrtf(var + OPE_LN_EPS);
       const float m = mb + delta;
-      rinfo[4 * lr] = delta; rinfo[4 * lr + 1] = rsd; rinfo[4 * lr + 2] = __int_as_float(rep); rinfo[4 * lr + 3] = __int_as_float((int)rb);
+      rinfo[4 * lr] = delta; rinfo[4 * lr + 1] = rsd; rinfo[4 * lr + 2] = __int_as_float(R.a0 + rep); rinfo[4 * lr + 3] = __int_as_float((int)rb);
       if (SAVE && row0 + lr < a.R) { a.mu0[row0 + lr] = m; a.rstd0[row0 + lr] = rsd; }
     }
     lds_barrier();
@@ -442,17 +442,17 @@ __global__ void __launch_bounds__(64) trunk_rep_prep_kernel(const float* __restr
   if (lane == 0) { wsum[f] = a; cst[f] = b + th[L.fc1_b + f]; }
 }
 
-bool trunk_rep_ok(int D, int N, int A) {
+bool trunk_rep_ok(int D, int NT, int A, int copies) {
   static const int on = getenv("OPE_TRUNK_REP") ? atoi(getenv("OPE_TRUNK_REP")) : 1;
-  // LDS of the consumer: 64 N A weights + 32 rows of (A + 4) + the 64-wide activations
-  const size_t lds = ((size_t)OPE_H * N * A + 32 * (A + 4) + 32 * kActPitch + 4 * 32) * sizeof(float);
-  return on && D <= 512 && N >= 2 && lds <= 150 * 1024;
+  // LDS of the consumer: 64 NT A weights + 32 rows of (A + 4) + the 64-wide activations
+  const size_t lds = ((size_t)OPE_H * NT * A + 32 * (A + 4) + 32 * kActPitch + 4 * 32) * sizeof(float);
+  return on && D <= 512 && copies >= 2 && lds <= 150 * 1024;
 }
 
 template <int VEC>
 static int launch_rep(const TrunkFwdArgs& base, const TrunkFwdArgs& a0, float* scratch, hipStream_t st) {
   const RepIn& R = a0.rep;
-  const int D = base.D, NA = R.N * R.A;
+  const int D = base.D, NA = R.NT * R.A;
   float* wblk = scratch;
   float* wsum = scratch + (int64_t)OPE_H * NA;
   float* cst = wsum + OPE_H;

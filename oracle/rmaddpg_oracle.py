@@ -69,19 +69,37 @@ class RMaddpgOracle(object):
             params[k] = params[k] - (hp.lr / bc1) * (m / (v.sqrt() / np.sqrt(bc2)).add_(hp.opti_eps))
         return float(total)
 
-    def critic_loss(self, live, batch, u_target=None, weights=None):
-        """Returns (loss, errors list [T,B,1] per head, mask_count). batch = sample_inds 7-tuple ([N,T(+1),B,.] agent fields)."""
+    def target_actions(self, batch, u_target=None):
+        """This policy's target actions for its own agents, get_update_info (r_maddpg.py:60-97): list of n [T, B, A] tensors."""
+        hp, N = self.hp, self.N
+        obs, avail = batch[0], batch[6]
+        obs = torch.as_tensor(np.ascontiguousarray(obs))
+        avail = torch.as_tensor(np.ascontiguousarray(avail)) if avail is not None else None
+        B = obs.shape[2]
+        with torch.no_grad():
+            s_obs = torch.cat(list(obs), dim=1)
+            s_av = torch.cat(list(avail), dim=1) if avail is not None else None
+            lg, _ = actor_logits(self.actor_tgt, s_obs, torch.zeros(N * B, hp.hidden_size))
+            nact = gumbel_hard(lg, s_av, torch.as_tensor(u_target)) if self.td3 else onehot_argmax(lg, s_av)
+        return list(nact[1:].split(B, dim=1))
+
+    def critic_loss(self, live, batch, u_target=None, weights=None, joint=None):
+        """Returns (loss, errors list [T,B,1] per head, mask_count). batch = sample_inds 7-tuple ([N,T(+1),B,.] agent fields).
+        `joint` (multi-policy updates) = (cent_act [T,B,NT*A], cent_nact [T,B,NT*A]) over ALL policies' agents."""
         hp, N, K = self.hp, self.N, self.K
         obs, cent, acts, rew, dones, dones_env, avail = [torch.as_tensor(np.ascontiguousarray(x)) if x is not None else None for x in batch]
         T, B = acts.shape[1], acts.shape[2]
         H = hp.hidden_size
-        with torch.no_grad():
-            s_obs = torch.cat(list(obs), dim=1)                          # [T+1, N*B, D]
-            s_av = torch.cat(list(avail), dim=1) if avail is not None else None
-            lg, _ = actor_logits(self.actor_tgt, s_obs, torch.zeros(N * B, H))
-            nact = gumbel_hard(lg, s_av, torch.as_tensor(u_target)) if self.td3 else onehot_argmax(lg, s_av)
-            cent_nact = torch.cat(nact[1:].split(B, dim=1), dim=-1)      # [T, B, N*A]
-        cent_act = torch.cat(list(acts), dim=-1)                         # [T, B, N*A]
+        if joint is not None:
+            cent_act, cent_nact = joint
+        else:
+            with torch.no_grad():
+                s_obs = torch.cat(list(obs), dim=1)                          # [T+1, N*B, D]
+                s_av = torch.cat(list(avail), dim=1) if avail is not None else None
+                lg, _ = actor_logits(self.actor_tgt, s_obs, torch.zeros(N * B, H))
+                nact = gumbel_hard(lg, s_av, torch.as_tensor(u_target)) if self.td3 else onehot_argmax(lg, s_av)
+                cent_nact = torch.cat(nact[1:].split(B, dim=1), dim=-1)      # [T, B, N*A]
+            cent_act = torch.cat(list(acts), dim=-1)                         # [T, B, N*A]
         cent_obs, cent_nobs = cent[:-1], cent[1:]
         q, _ = critic_q(live, K, cent_obs, cent_act, torch.zeros(B, H))
         with torch.no_grad():
@@ -104,7 +122,9 @@ class RMaddpgOracle(object):
             loss = sum(f(e).sum() / cnt for e in errs)
         return loss, errs, cnt
 
-    def actor_loss(self, live, batch, u_actor):
+    def actor_loss(self, live, batch, u_actor, all_acts=None, offset=0):
+        """`all_acts` (multi-policy updates): list of every agent's buffer actions [T,B,A] in joint order; this policy's agents are
+        entries offset .. offset + N - 1 (act_sequence_replace_ind_start, r_maddpg.py:66-67, 291-301)."""
         hp, N, K = self.hp, self.N, self.K
         obs, cent, acts, rew, dones, dones_env, avail = [torch.as_tensor(np.ascontiguousarray(x)) if x is not None else None for x in batch]
         T, B = acts.shape[1], acts.shape[2]
@@ -116,10 +136,11 @@ class RMaddpgOracle(object):
         agent_seqs = pol.split(B, dim=1)
         cent_obs = cent[:-1]
         stacked_obs = cent_obs.repeat(1, N, 1)
-        buf_joint = torch.cat(list(acts), dim=-1).repeat(1, N, 1)        # [T, N*B, N*A]
+        every = list(acts) if all_acts is None else list(all_acts)
+        buf_joint = torch.cat(every, dim=-1).repeat(1, N, 1)             # [T, N*B, NT*A]
         rows = []
         for i in range(N):
-            rows.append(torch.cat([agent_seqs[i] if a == i else acts[a] for a in range(N)], dim=-1))
+            rows.append(torch.cat([agent_seqs[i] if a == offset + i else every[a] for a in range(len(every))], dim=-1))
         repl_joint = torch.cat(rows, dim=1)                              # copy i carries the actor's action for agent i
         h = torch.zeros(N * B, H)
         qs = []
@@ -132,11 +153,11 @@ class RMaddpgOracle(object):
         dm = torch.cat([torch.cat([torch.zeros(1, B, 1), dones[i][:T - 1]], dim=0) for i in range(N)], dim=1)
         return (-(qs * (1 - dm))).sum() / (1 - dm).sum()
 
-    def train_step(self, batch, u_target=None, u_actor=None, weights=None, soft_update=True):
+    def train_step(self, batch, u_target=None, u_actor=None, weights=None, soft_update=True, joint=None, all_acts=None, offset=0):
         hp = self.hp
         update_actor = self.num_updates % self.actor_update_interval == 0
         live = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in self.critic.items())
-        closs, errs, _ = self.critic_loss(live, batch, u_target, weights)
+        closs, errs, _ = self.critic_loss(live, batch, u_target, weights, joint=joint)
         names = [k for k in live if ".fc_h." not in k]
         cg = dict(zip(names, torch.autograd.grad(closs, [live[k] for k in names])))
         cnorm = self._adam_step("critic", self.critic, cg)
@@ -149,7 +170,7 @@ class RMaddpgOracle(object):
                    critic_grads={k: v.numpy() for k, v in cg.items()})
         if update_actor:
             la = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in self.actor.items())
-            aloss = self.actor_loss(la, batch, u_actor)
+            aloss = self.actor_loss(la, batch, u_actor, all_acts=all_acts, offset=offset)
             anames = [k for k in la if ".fc_h." not in k]
             ag = dict(zip(anames, torch.autograd.grad(aloss, [la[k] for k in anames])))
             out.update(actor_loss=float(aloss.detach()), actor_grad_norm=self._adam_step("actor", self.actor, ag),
@@ -161,3 +182,22 @@ class RMaddpgOracle(object):
                 for k in src:
                     dst[k] = dst[k] * (1 - tau) + src[k] * tau
         return out
+
+
+class RMaddpgMultiOracle(object):
+    """share_policy = False: one RMaddpgOracle per policy (own actor, critic, targets, Adam state), agents concatenated in policy
+    order. `train_step(p, batches, u_targets, u_actor)` = R_MADDPG.shared_train_policy_on_batch(policy p, batch)
+    (r_maddpg.py:114-331 with get_update_info 44-105 looping over every policy's target actor)."""
+
+    def __init__(self, oracles):
+        self.pol = list(oracles)
+        self.offsets = np.cumsum([0] + [o.N for o in self.pol])[:-1]
+
+    def train_step(self, p, batches, u_targets=None, u_actor=None, weights=None, soft_update=True):
+        """batches[k] = policy k's sample_inds 7-tuple; u_targets[k] = its target noise (MATD3) or None."""
+        nact, every = [], []
+        for k, o in enumerate(self.pol):
+            nact += o.target_actions(batches[k], None if u_targets is None else u_targets[k])
+            every += [torch.as_tensor(np.ascontiguousarray(a)) for a in batches[k][2]]
+        joint = (torch.cat(every, dim=-1), torch.cat(nact, dim=-1))
+        return self.pol[p].train_step(batches[p], None, u_actor, weights, soft_update, joint=joint, all_acts=every, offset=int(self.offsets[p]))

@@ -77,3 +77,77 @@ def test_policy_construction_reproduces_reference_rng_stream(name):
     # the targets take the live weights (rMADDPGPolicy.py:50-51)
     for k, ref in sub(g, "critic_tgt/").items():
         assert np.array_equal(ref, crit[k])
+
+
+MULTI_CASES = ["rmaddpg_multi_odd", "rmatd3_multi_tiny"]
+
+
+def multi_policy_ids(g):
+    return ["policy_%d" % i for i in range(len(g["groups"]))]
+
+
+def multi_batches(g):
+    """Per-policy sample_inds 7-tuples rebuilt from the stored episodes: agent fields sliced to the policy's agents."""
+    groups = [int(x) for x in g["groups"]]
+    starts = np.cumsum([0] + groups)[:-1]
+    inds = np.asarray(g["inds"])
+    N = int(g["dims"][0])
+    out = []
+    for s0, n in zip(starts, groups):
+        fields = []
+        for k in EP_KEYS:
+            v = g["ep/" + k][:, inds]                                   # [T(+1), B, N, dim] or [T(+1), B, dim]
+            if v.ndim == 4 and v.shape[2] == N and k != "share_obs":
+                fields.append(np.ascontiguousarray(v[:, :, s0:s0 + n].transpose(2, 0, 1, 3)))
+            elif k == "share_obs":
+                fields.append(np.ascontiguousarray(v[:, :, 0] if v.ndim == 4 else v))
+            else:
+                fields.append(np.ascontiguousarray(v))
+        out.append(tuple(fields))
+    return out
+
+
+def multi_noise(g, step, pi, update_actor):
+    """Draws of one train call (torch.manual_seed(1000 + step*P + pi)): target noise of EVERY policy in policy order
+    (get_update_info), then the update policy's actor noise."""
+    _, a, _, _, T = [int(x) for x in g["dims"]]
+    groups = [int(x) for x in g["groups"]]
+    B = len(g["inds"])
+    torch.manual_seed(1000 + step * len(groups) + pi)
+    u_t = [torch.FloatTensor(T + 1, n * B, a).uniform_() for n in groups] if bool(g["td3"]) else None
+    u_a = torch.FloatTensor(T, groups[pi] * B, a).uniform_() if update_actor else None
+    return u_t, u_a
+
+
+def multi_oracle_from(g):
+    hp = HP(gamma=float(g["hp_gamma"]), lr=float(g["hp_lr"]), opti_eps=float(g["hp_eps"]), use_huber_loss=bool(g["hp_huber"]),
+            huber_delta=float(g["hp_delta"]), use_per=bool(g["hp_per"]), per_nu=float(g["hp_nu"]), per_eps=float(g["hp_per_eps"]),
+            tau=float(g["hp_tau"]), max_grad_norm=float(g["hp_maxnorm"]))
+    pol = [RO.RMaddpgOracle(sub(g, p + "/actor/"), sub(g, p + "/critic/"), sub(g, p + "/actor_tgt/"), sub(g, p + "/critic_tgt/"), int(n), hp,
+                            td3=bool(g["td3"])) for p, n in zip(multi_policy_ids(g), g["groups"])]
+    return RO.RMaddpgMultiOracle(pol)
+
+
+@pytest.mark.parametrize("name", MULTI_CASES)
+def test_multi_policy_train_steps_match_reference(name):
+    """share_policy = False (scripts/train_mpe_rmaddpg.sh): per step every policy is updated in turn; each update uses every
+    policy's target actor for the joint target action and only replaces its own agents' blocks in the actor update."""
+    g = load_golden(name)
+    orc = multi_oracle_from(g)
+    batches = multi_batches(g)
+    pids = multi_policy_ids(g)
+    for s in range(g["critic_loss"].shape[0]):
+        for pi in range(len(pids)):
+            upd = bool(g["update_actor"][s, pi])
+            u_t, u_a = multi_noise(g, s, pi, upd)
+            out = orc.train_step(pi, batches, u_t, u_a)
+            assert out["update_actor"] == upd
+            np.testing.assert_allclose(out["critic_loss"], g["critic_loss"][s, pi], rtol=3e-5)
+            np.testing.assert_allclose(out["critic_grad_norm"], g["critic_grad_norm"][s, pi], rtol=5e-5)
+            if upd:
+                np.testing.assert_allclose(out["actor_loss"], g["actor_loss"][s, pi], rtol=1e-4, atol=1e-6)
+                np.testing.assert_allclose(out["actor_grad_norm"], g["actor_grad_norm"][s, pi], rtol=2e-4)
+    for p, o in zip(pids, orc.pol):
+        for grp, dst in (("final_actor/", o.actor), ("final_critic/", o.critic), ("final_actor_tgt/", o.actor_tgt), ("final_critic_tgt/", o.critic_tgt)):
+            for k, ref in sub(g, p + "/" + grp).items():
+                np.testing.assert_allclose(dst[k].numpy(), ref, rtol=0, atol=2e-5, err_msg=p + "/" + grp + k)
