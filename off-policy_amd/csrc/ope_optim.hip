@@ -79,6 +79,19 @@ __global__ void __launch_bounds__(kBlock) adam_kernel(AdamK c, int64_t n, float*
     c.lr_t = s_bc[0];
     c.inv_sqrt_bc2 = s_bc[1];
   }
+  // This thread's four elements (n, every tensor start and the skip range are multiples of 4: all in or all out together), as
+  // 16-byte accesses requested BEFORE the norm's block reduction: the update of 10^4..10^5 parameters is one memory round trip
+  // plus a reduction, and an element-at-a-time loop with early exits serialised it into several.
+  const int64_t base = (int64_t)blockIdx.x * kPerBlock + threadIdx.x * kPerThread;
+  const bool live = base < n;
+  const bool skip = live && base >= c.skip_begin && base < c.skip_end;      // grad-less tensor: torch's Adam does not touch it
+  const int64_t lb = live ? base : 0;
+  const f32x4 th4 = *reinterpret_cast<const f32x4*>(theta + lb);
+  const f32x4 g4 = *reinterpret_cast<const f32x4*>(g + lb);
+  const f32x4 m4 = *reinterpret_cast<const f32x4*>(m + lb);
+  const f32x4 v4 = *reinterpret_cast<const f32x4*>(v + lb);
+  f32x4 tg4 = {0.f, 0.f, 0.f, 0.f};
+  if (c.do_polyak) tg4 = *reinterpret_cast<const f32x4*>(tgt + lb);
   float s = 0.f;
   for (int q = threadIdx.x; q < c.nblocks; q += kBlock) s += part[q];
   // fixed-order: each thread adds a fixed subset, then the same tree everywhere -> identical in all blocks
@@ -94,25 +107,28 @@ __global__ void __launch_bounds__(kBlock) adam_kernel(AdamK c, int64_t n, float*
     stats[3] = cnt;
   }
   const float scale = coef * inv;
-  const int64_t base = (int64_t)blockIdx.x * kPerBlock + threadIdx.x * kPerThread;
-  for (int q = 0; q < kPerThread; ++q) {
-    const int64_t i = base + q;
-    if (i >= n) break;
-    float th = theta[i];
-    if (i >= c.skip_begin && i < c.skip_end) {      // grad-less tensor: torch's Adam does not touch it
-      if (c.do_polyak) tgt[i] = tgt[i] * (1.0f - c.tau) + th * c.tau;
-      continue;
+  if (live) {
+    f32x4 out = th4;
+    if (!skip) {
+      f32x4 mo, vo;
+#pragma unroll
+      for (int q = 0; q < kPerThread; ++q) {
+        float gi = g4[q] * scale;
+        if (c.wd != 0.f) gi = fmaf(c.wd, th4[q], gi);
+        mo[q] = c.beta1 * m4[q] + (1.0f - c.beta1) * gi;
+        vo[q] = c.beta2 * v4[q] + (1.0f - c.beta2) * gi * gi;
+        const float den = sqrtf(vo[q]) * c.inv_sqrt_bc2 + c.eps;
+        out[q] = th4[q] - c.lr_t * (mo[q] / den);
+      }
+      *reinterpret_cast<f32x4*>(m + base) = mo;
+      *reinterpret_cast<f32x4*>(v + base) = vo;
+      *reinterpret_cast<f32x4*>(theta + base) = out;
     }
-    float gi = g[i] * scale;
-    if (c.wd != 0.f) gi = fmaf(c.wd, th, gi);
-    const float mi = c.beta1 * m[i] + (1.0f - c.beta1) * gi;
-    const float vi = c.beta2 * v[i] + (1.0f - c.beta2) * gi * gi;
-    m[i] = mi;
-    v[i] = vi;
-    const float den = sqrtf(vi) * c.inv_sqrt_bc2 + c.eps;
-    th = th - c.lr_t * (mi / den);
-    theta[i] = th;
-    if (c.do_polyak) tgt[i] = tgt[i] * (1.0f - c.tau) + th * c.tau;
+    if (c.do_polyak) {
+#pragma unroll
+      for (int q = 0; q < kPerThread; ++q) tg4[q] = tg4[q] * (1.0f - c.tau) + out[q] * c.tau;
+      *reinterpret_cast<f32x4*>(tgt + base) = tg4;
+    }
   }
   // Device step counter: the LAST block to finish publishes t and resets the ticket, so the update needs no separate
   // "count += 1" launch (and a captured graph of it replays with an advancing bias correction).
@@ -139,6 +155,7 @@ extern "C" int ope_adam_step(const ope_adam_cfg* cfg, int64_t n, float* theta, f
   (void)hipGetLastError();  // drop stale errors from the caller's own HIP use
   if (!cfg || n < 1 || (n & 3) || !theta || !adam_m || !adam_v || !grad || !scratch) return OPE_EINVAL;
   if (cfg->do_polyak && !theta_tgt) return OPE_EINVAL;
+  if ((cfg->skip_begin & 3) || (cfg->skip_end & 3)) return OPE_EINVAL;      // tensors start on multiples of 4 floats
   if (!cfg->step_counter && cfg->step < 1) return OPE_EINVAL;
   const int nb = ope_cdiv(n, kPerBlock);
   hipStream_t st = (hipStream_t)stream;
