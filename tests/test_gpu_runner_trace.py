@@ -122,3 +122,106 @@ def test_reference_runner_call_trace_replays_on_the_engine():
         else:
             raise AssertionError("unknown call in the trace: " + name)
     assert seen["policy.get_actions"] > 20 and seen["buffer.insert"] >= 8 and seen["trainer.train_policy_on_batch"] == 3
+
+
+def test_reference_mpe_runner_multi_policy_trace_replays_on_the_engine():
+    """The reference's MPERunner with ONE POLICY PER AGENT (share_policy = False, scripts/train_mpe_rmaddpg.sh), recorded by
+    oracle/make_runner_trace_mpe.py (tests/golden/runner_trace_rmaddpg_multi.npz): three R_MADDPGPolicy constructions, the
+    R_MADDPG trainer, warm-up through `separated_collect_rollout` (every agent queried through its own policy: random actions +
+    a recurrent state update), three run() cycles (exploring rollout -> three-policy buffer.insert -> per policy buffer.sample ->
+    shared_train_policy_on_batch -> soft updates of every policy) -- 203 calls, replayed against the engine's classes with the
+    recorded arguments and RNG states; every return value is compared, and at the end all 12 networks."""
+    from offpolicy_amd.config import default_args
+    from offpolicy_amd.utils.spaces import Discrete
+    from offpolicy_amd.utils.rec_buffer import RecReplayBuffer
+    from offpolicy_amd.algorithms.r_maddpg.algorithm.rMADDPGPolicy import R_MADDPGPolicy
+    from offpolicy_amd.algorithms.r_maddpg.r_maddpg import R_MADDPG
+    g = load_golden("runner_trace_rmaddpg_multi")
+    calls = [str(x) for x in g["calls"]]
+    N, A, D, S, T = [int(x) for x in g["dims"]]
+    batch_size, buffer_size, lr, eps0, eps1, eps_t = g["hp"]
+    args = default_args(batch_size=int(batch_size), buffer_size=int(buffer_size), lr=float(lr), epsilon_start=float(eps0),
+                        epsilon_finish=float(eps1), epsilon_anneal_time=float(eps_t), episode_length=T)
+    dev = torch.device("cuda:0")
+    pids = ["policy_%d" % i for i in range(N)]
+    pinfo = {p: {"cent_obs_dim": S, "cent_act_dim": A * N, "obs_space": [D], "share_obs_space": [S], "act_space": Discrete(A)} for p in pids}
+    keys = ("obs", "share_obs", "acts", "rewards", "dones", "dones_env")
+    policies, trainer, buf, last_sample = {}, None, None, None
+    seen = {k: 0 for k in set(calls)}
+    to_np = lambda x: x.detach().cpu().numpy() if torch.is_tensor(x) else np.asarray(x)
+    for i, name in enumerate(calls):
+        c = _call(g, i)
+        seen[name] += 1
+        pid = pids[int(c["in/pid"])] if "in/pid" in c else None
+        if name == "policy.__init__":
+            _set_rng(c)
+            pol = R_MADDPGPolicy({"args": args, "device": dev}, pinfo[pid])
+            for grp, mod in (("actor", pol.actor), ("critic", pol.critic)):
+                sd = {k[len("out/sd/%s/" % grp):]: v for k, v in c.items() if k.startswith("out/sd/%s/" % grp)}
+                ours = mod.state_dict()
+                assert list(ours.keys()) == list(sd.keys())
+                for k, v in sd.items():      # same RNG stream -> same initial weights (to LAPACK-QR rounding across hosts)
+                    np.testing.assert_allclose(ours[k].cpu().numpy(), v, rtol=0, atol=3e-5, err_msg="%s %s %s" % (pid, grp, k))
+                mod.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+            pol.hard_target_updates()
+            assert pol.output_dim == A and pol.obs_dim == D and pol.central_obs_dim == S and pol.hidden_size == 64
+            policies[pid] = pol
+        elif name == "trainer.__init__":
+            trainer = R_MADDPG(args, N, policies, lambda a: "policy_%d" % a, device=dev, episode_length=T)
+            buf = RecReplayBuffer(pinfo, {p: [j] for j, p in enumerate(pids)}, int(buffer_size), T, True, False, False, device=dev)
+        elif name == "trainer.prep_rollout":
+            trainer.prep_rollout()
+        elif name == "trainer.prep_training":
+            trainer.prep_training()
+        elif name == "policy.get_random_actions":
+            _set_rng(c)
+            assert np.array_equal(np.asarray(policies[pid].get_random_actions(c["in/obs"])), c["out/actions"]), i
+        elif name == "policy.get_actions":
+            _set_rng(c)
+            explore = bool(c["in/explore"])
+            t_env = int(c["in/t_env"]) if "in/t_env" in c else None
+            acts, h, _ = policies[pid].get_actions(c["in/obs"], c["in/prev_actions"], c["in/rnn_states"], t_env=t_env, explore=explore)
+            np.testing.assert_allclose(to_np(h).reshape(c["out/rnn_states"].shape), c["out/rnn_states"], rtol=1e-4, atol=2e-5, err_msg=str(i))
+            acts = to_np(acts)
+            assert acts.shape == c["out/actions"].shape, (i, acts.shape)
+            if not np.array_equal(acts, c["out/actions"]):
+                # only a near-tie between the two largest (noisy) logits may flip a one-hot action
+                lg, _ = policies[pid].actor(c["in/obs"], c["in/prev_actions"], c["in/rnn_states"])
+                lg = to_np(lg).reshape(acts.shape)
+                for r in np.nonzero((acts != c["out/actions"]).any(-1))[0]:
+                    a0, a1 = int(acts[r].argmax()), int(c["out/actions"][r].argmax())
+                    assert explore or abs(lg[r, a0] - lg[r, a1]) < 1e-4, (i, r, lg[r])
+                assert (acts != c["out/actions"]).any(-1).mean() < 0.05
+        elif name == "buffer.insert":
+            d = {k: {p: c["in/%s/%s" % (p, k)] for p in pids} for k in keys}
+            idx = buf.insert(int(c["in/n"]), d["obs"], d["share_obs"], d["acts"], d["rewards"], d["dones"], d["dones_env"], {p: None for p in pids})
+            assert np.array_equal(np.asarray(idx), c["out/idx_range"]), i
+        elif name == "buffer.sample":
+            _set_rng(c)
+            last_sample = buf.sample(int(c["in/batch_size"]))
+            for p in pids:
+                for j, k in enumerate(keys):
+                    got = last_sample[j][p]
+                    assert tuple(got.shape) == c["out/%s/%s" % (p, k)].shape, (p, k, got.shape)
+                    assert np.array_equal(got.cpu().numpy(), c["out/%s/%s" % (p, k)]), (i, p, k)
+        elif name == "trainer.shared_train_policy_on_batch":
+            _set_rng(c)
+            info, prio, _ = trainer.shared_train_policy_on_batch(pid, last_sample)
+            assert prio is None and bool(info["update_actor"])
+            for k in ("critic_loss", "critic_grad_norm", "actor_loss", "actor_grad_norm"):
+                np.testing.assert_allclose(float(info[k]), float(c["out/" + k]), rtol=2e-3, atol=1e-5, err_msg="%d %s" % (i, k))
+        elif name == "policy.soft_target_updates":
+            policies[pid].soft_target_updates()
+        elif name == "runner.final_state":
+            for p in pids:
+                for grp, mod in (("actor", policies[p].actor), ("critic", policies[p].critic), ("target_actor", policies[p].target_actor),
+                                 ("target_critic", policies[p].target_critic)):
+                    pre = "out/%s/%s/" % (p, grp)
+                    ref = {k[len(pre):]: v for k, v in c.items() if k.startswith(pre)}
+                    ours = mod.state_dict()
+                    assert list(ours.keys()) == list(ref.keys())
+                    for k, v in ref.items():
+                        np.testing.assert_allclose(ours[k].cpu().numpy(), v, rtol=0, atol=1e-4, err_msg="%s %s %s" % (p, grp, k))
+        else:
+            raise AssertionError("unknown call in the trace: " + name)
+    assert seen["policy.get_actions"] > 60 and seen["buffer.insert"] >= 8 and seen["trainer.shared_train_policy_on_batch"] == 9
