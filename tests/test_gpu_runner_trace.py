@@ -225,3 +225,105 @@ def test_reference_mpe_runner_multi_policy_trace_replays_on_the_engine():
         else:
             raise AssertionError("unknown call in the trace: " + name)
     assert seen["policy.get_actions"] > 60 and seen["buffer.insert"] >= 8 and seen["trainer.shared_train_policy_on_batch"] == 9
+
+
+def test_reference_mlp_runner_maddpg_trace_replays_on_the_engine():
+    """The reference's MLP MPERunner (offpolicy/runner/mlp/mpe_runner.py; scripts/train_mpe_maddpg.sh: MADDPG, one shared policy),
+    recorded by oracle/make_runner_trace_mlp.py (tests/golden/runner_trace_maddpg.npz): MADDPGPolicy + MADDPG + MlpReplayBuffer
+    construction, warm-up with random actions, two run() cycles -- per environment step get_actions(explore) -> 12-argument
+    buffer.insert -> every `train_interval` steps buffer.sample -> shared_train_policy_on_batch -> soft_target_updates. 76 calls
+    replayed against the engine's classes with the recorded arguments and RNG states; every return value is compared, and at the end
+    all four networks."""
+    from offpolicy_amd.config import default_args
+    from offpolicy_amd.utils.spaces import Discrete
+    from offpolicy_amd.utils.mlp_buffer import MlpReplayBuffer
+    from offpolicy_amd.algorithms.maddpg.algorithm.MADDPGPolicy import MADDPGPolicy
+    from offpolicy_amd.algorithms.maddpg.maddpg import MADDPG
+    g = load_golden("runner_trace_maddpg")
+    calls = [str(x) for x in g["calls"]]
+    N, A, D, S, T = [int(x) for x in g["dims"]]
+    batch_size, buffer_size, lr, eps0, eps1, eps_t = g["hp"]
+    args = default_args(batch_size=int(batch_size), buffer_size=int(buffer_size), lr=float(lr), epsilon_start=float(eps0),
+                        epsilon_finish=float(eps1), epsilon_anneal_time=float(eps_t), episode_length=T)
+    dev = torch.device("cuda:0")
+    P = "policy_0"
+    pinfo = {P: {"cent_obs_dim": S, "cent_act_dim": A * N, "obs_space": [D], "share_obs_space": [S], "act_space": Discrete(A)}}
+    keys = ("obs", "share_obs", "acts", "rewards", "next_obs", "next_share_obs", "dones", "dones_env", "valid_transition")
+    policy, trainer, buf, last_sample = None, None, None, None
+    seen = {k: 0 for k in set(calls)}
+    to_np = lambda x: x.detach().cpu().numpy() if torch.is_tensor(x) else np.asarray(x)
+    for i, name in enumerate(calls):
+        c = _call(g, i)
+        seen[name] += 1
+        if name == "policy.__init__":
+            _set_rng(c)
+            policy = MADDPGPolicy({"args": args, "device": dev}, pinfo[P])
+            for grp, mod in (("actor", policy.actor), ("critic", policy.critic)):
+                sd = {k[len("out/sd/%s/" % grp):]: v for k, v in c.items() if k.startswith("out/sd/%s/" % grp)}
+                ours = mod.state_dict()
+                assert list(ours.keys()) == list(sd.keys())          # the critic's Q heads are absent, as upstream (A-4)
+                for k, v in sd.items():      # same RNG stream -> same initial weights (to LAPACK-QR rounding across hosts)
+                    np.testing.assert_allclose(ours[k].cpu().numpy(), v, rtol=0, atol=3e-5, err_msg="%s %s" % (grp, k))
+                mod.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+            for crit, pre in ((policy.critic, "out/head/0/"), (policy.target_critic, "out/thead/0/")):       # unsynchronised heads (A-4)
+                np.testing.assert_allclose(crit._head_w.cpu().numpy().reshape(-1), c[pre + "weight"].reshape(-1), rtol=0, atol=3e-5)
+                crit._head_w.copy_(torch.as_tensor(c[pre + "weight"]).reshape(crit._head_w.shape))
+                crit._head_b.copy_(torch.as_tensor(c[pre + "bias"]).reshape(crit._head_b.shape))
+            policy.hard_target_updates()
+            assert policy.output_dim == A and policy.obs_dim == D and policy.central_obs_dim == S
+        elif name == "trainer.__init__":
+            trainer = MADDPG(args, N, {P: policy}, lambda a: P, device=dev)
+            buf = MlpReplayBuffer(pinfo, {P: list(range(N))}, int(buffer_size), True, False, False, device=dev)
+        elif name == "trainer.prep_rollout":
+            trainer.prep_rollout()
+        elif name == "trainer.prep_training":
+            trainer.prep_training()
+        elif name == "policy.get_random_actions":
+            _set_rng(c)
+            assert np.array_equal(np.asarray(policy.get_random_actions(c["in/obs"])), c["out/actions"]), i
+        elif name == "policy.get_actions":
+            _set_rng(c)
+            explore = bool(c["in/explore"])
+            t_env = int(c["in/t_env"]) if "in/t_env" in c else None
+            acts, _ = policy.get_actions(c["in/obs"], t_env=t_env, explore=explore)
+            acts = to_np(acts)
+            assert acts.shape == c["out/actions"].shape, (i, acts.shape)
+            if not np.array_equal(acts, c["out/actions"]):
+                # only a near-tie between the two largest noisy logits may flip a one-hot action
+                lg = to_np(policy.actor(c["in/obs"])).reshape(acts.shape)
+                for r in np.nonzero((acts != c["out/actions"]).any(-1))[0]:
+                    a0, a1 = int(acts[r].argmax()), int(c["out/actions"][r].argmax())
+                    assert explore or abs(lg[r, a0] - lg[r, a1]) < 1e-4, (i, r, lg[r])
+                assert (acts != c["out/actions"]).any(-1).mean() < 0.05
+        elif name == "buffer.insert":
+            d = [{P: c["in/" + k]} for k in keys]
+            idx = buf.insert(int(c["in/n"]), *d, {P: None}, {P: None})
+            assert np.array_equal(np.asarray(idx), c["out/idx_range"]), i
+        elif name == "buffer.sample":
+            _set_rng(c)
+            last_sample = buf.sample(int(c["in/batch_size"]))
+            assert len(last_sample) == 13
+            for j, k in enumerate(keys):
+                got = last_sample[j][P]
+                assert tuple(got.shape) == c["out/" + k].shape, (k, got.shape)
+                assert np.array_equal(got.cpu().numpy(), c["out/" + k]), (i, k)
+        elif name == "trainer.shared_train_policy_on_batch":
+            _set_rng(c)
+            info, prio, _ = trainer.shared_train_policy_on_batch(P, last_sample)
+            assert prio is None and bool(info["update_actor"])
+            for k in ("critic_loss", "critic_grad_norm", "actor_loss", "actor_grad_norm"):
+                np.testing.assert_allclose(float(info[k]), float(c["out/" + k]), rtol=2e-3, atol=1e-5, err_msg="%d %s" % (i, k))
+        elif name == "policy.soft_target_updates":
+            policy.soft_target_updates()
+        elif name == "runner.final_state":
+            for grp, mod in (("actor", policy.actor), ("critic", policy.critic), ("target_actor", policy.target_actor),
+                             ("target_critic", policy.target_critic)):
+                pre = "out/%s/" % grp
+                ref = {k[len(pre):]: v for k, v in c.items() if k.startswith(pre)}
+                ours = mod.state_dict()
+                assert list(ours.keys()) == list(ref.keys())
+                for k, v in ref.items():
+                    np.testing.assert_allclose(ours[k].cpu().numpy(), v, rtol=0, atol=1e-4, err_msg="%s %s" % (grp, k))
+        else:
+            raise AssertionError("unknown call in the trace: " + name)
+    assert seen["policy.get_actions"] == 10 and seen["buffer.insert"] == 25 and seen["trainer.shared_train_policy_on_batch"] == 5
