@@ -155,6 +155,20 @@ typedef struct ope_qmix_cfg {
   int32_t mlp;          /* 1: non-recurrent agent nets on single transitions (M_QMix / M_VDN, mqmix.py:68-218):
                          *    dims.episode_length must be 1; batch.obs = [obs; next_obs], share_obs = [cent; next cent],
                          *    avail_acts = [avail; next avail]                                              */
+  int32_t phase;        /* 0: the whole step. 1..3: one part of a step with SEVERAL POLICIES under one mixer (the
+                         *    `for p_id in self.policy_ids` loops of qmix.py:100-150 / mqmix.py:95-178; policies may differ in
+                         *    obs_dim / act_dim / agent count). Every policy p has its own cfg (dims.n_agents = its agents,
+                         *    vdn = 1: no mixer block in its vector) and workspace; the mixing part has a joint cfg
+                         *    (dims.n_agents = all agents; obs_dim / act_dim of policy 0) and workspace:
+                         *      1  agent networks forward only: leaves "agent_q" / "agent_nq" [T][B][n_p] in the workspace
+                         *         (ope_qmix_workspace_find); grad untouched
+                         *      2  mixer (or VDN sum) + TD loss + mixer gradients only: reads "agent_q" / "agent_nq"
+                         *         [T][B][N] the caller assembled from the policies' slices, leaves "d_agent_q" [T][B][N];
+                         *         writes the mixer block and the tail of `grad`, leaves grad[0 .. agent block) untouched
+                         *      3  agent networks backward only: reads "d_agent_q" [T][B][n_p] (the caller's slice of the
+                         *         joint one) and the activations phase 1 left; writes grad[0 .. P_agent) and NO tail
+                         *    The flat vectors of such a trainer are [agent_0 | agent_1 | ... | mixer | tail]; the joint call
+                         *    gets theta / grad advanced by (mixer offset - agent_0 length) so that its mixer block lines up. */
 } ope_qmix_cfg;
 
 /* Flat parameter vector: the reference's named_parameters() order (agent q-network, then mixer; qmix.py:67-72),

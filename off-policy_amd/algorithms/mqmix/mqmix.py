@@ -37,6 +37,17 @@ class M_QMix(QMix):
         pid = self.policy_ids[0]
         dev = self.device
         f = lambda x: torch.as_tensor(x, dtype=torch.float32).to(dev)
+        if self.multi:       # several policies under one mixer (mqmix.py:95-178)
+            parts = {}
+            for q in self.policy_ids:
+                avail = None
+                if navail_b is not None and navail_b[q] is not None:
+                    cur = avail_b[q] if (avail_b is not None and avail_b[q] is not None) else torch.ones_like(f(navail_b[q]))
+                    avail = _stack_pair(cur, navail_b[q], dev)
+                parts[q] = (_stack_pair(obs_b[q], nobs_b[q], dev), f(act_b[q])[None].contiguous(), avail)
+            cent, ncent = (cent_b[pid], cent_nobs_b[pid]) if use_same_share_obs else (cent_b[pid][0], cent_nobs_b[pid][0])
+            rew = f(rew_b[self.policy_ids[-1]])[None, :1].contiguous()      # mqmix.py:100,181: the LAST policy's agent 0
+            return self._train_multi(parts, _stack_pair(cent, ncent, dev), rew, f(dones_env_b[pid])[None].contiguous(), importance_weights, idxes)
         obs = _stack_pair(obs_b[pid], nobs_b[pid], dev)                      # [2, N, B, D]
         # the mixer's state: the shared centralized observation, or agent 0's when every agent has its own (mqmix.py:78-84)
         cent, ncent = (cent_b[pid], cent_nobs_b[pid]) if use_same_share_obs else (cent_b[pid][0], cent_nobs_b[pid][0])

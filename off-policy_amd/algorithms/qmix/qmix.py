@@ -69,10 +69,18 @@ class QMix(object):
         self.policy_ids = sorted(list(self.policies.keys()))
         self.policy_agents = {pid: sorted([a for a in range(num_agents) if policy_mapping_fn(a) == pid])
                               for pid in self.policies.keys()}
-        if self.policy_ids != ["policy_0"] or len(self.policy_agents["policy_0"]) != num_agents:
-            raise NotImplementedError("the accelerated QMIX path handles one shared policy ('policy_0') for all agents")
         self.use_same_share_obs = args.use_same_share_obs
         self.vdn = bool(vdn)
+        self.multi = self.policy_ids != ["policy_0"] or len(self.policy_agents["policy_0"]) != num_agents
+        self.fuse_soft_update = False       # True: Polyak inside ope_adam_step; soft_target_updates() then skips once
+        self._polyak_done = False
+        self._ws = {}
+        self._gsq = {}
+        if self.multi:
+            self._init_multi()
+            if args.use_double_q:
+                print("double Q learning will be used")
+            return
         policy = self.policies["policy_0"]
         # the kernels see the network's input width: observation (+ previous one-hot action with prev_act_inp)
         self._dims = _lib.Dims(num_agents, policy.act_dim, policy.q_network_input_dim, policy.central_obs_dim, self.episode_length)
@@ -108,12 +116,155 @@ class QMix(object):
         self.grad = torch.zeros(self.numel + _lib.OPE_GRAD_TAIL, **self.tpdv)
         self._scratch = torch.zeros(int(_lib.lib.ope_adam_scratch_floats(self.numel)), **self.tpdv)
         self._stats = torch.zeros(4, **self.tpdv)
-        self._ws = {}
-        self._gsq = {}
-        self.fuse_soft_update = False       # True: Polyak inside ope_adam_step; soft_target_updates() then skips once
-        self._polyak_done = False
         if args.use_double_q:
             print("double Q learning will be used")
+
+    # ---- several policies under one mixer (share_policy = False; qmix.py:100-150, mqmix.py:95-178) ----------------
+    def _init_multi(self):
+        """Flat vectors [agent_0 | agent_1 | ... | mixer] in `policy_ids` order (one Adam over everything, one clip norm:
+        qmix.py:66-72,190-193). Policies may differ in observation width, action count and number of agents; their agents must be
+        numbered policy by policy (the order the reference concatenates the agents' q values in, qmix.py:150)."""
+        args, T = self.args, self.episode_length
+        flat_agents = [a for p in self.policy_ids for a in self.policy_agents[p]]
+        if flat_agents != list(range(self.num_agents)) or any(len(self.policy_agents[p]) == 0 for p in self.policy_ids):
+            raise NotImplementedError("several policies: agents must be numbered policy by policy, every policy with at least one agent")
+        first = self.policies[self.policy_ids[0]]
+        S = first.central_obs_dim
+        self._pdims, self._poff, self._a0 = {}, {}, {}
+        off, a0 = 0, 0
+        for p in self.policy_ids:
+            pol = self.policies[p]
+            self._pdims[p] = _lib.Dims(len(self.policy_agents[p]), pol.act_dim, pol.q_network_input_dim, S, T)
+            self._poff[p], self._a0[p] = off, a0
+            off += pol.q_network.padded_numel
+            a0 += len(self.policy_agents[p])
+        self._dims = _lib.Dims(self.num_agents, first.act_dim, first.q_network_input_dim, S, T)      # the mixing part's cfg
+        self._mixer_off = off
+        self._shift = off - first.q_network.padded_numel      # the joint call's theta / grad start here (ope.h, ope_qmix_cfg.phase)
+        offs = (C.c_int64 * 36)()
+        P = _lib.lib.ope_qmix_param_layout(C.byref(self._cfg(1)), offs, None)
+        if P < 0:
+            _lib.check(int(P), "ope_qmix_param_layout")
+        self.numel = self._shift + int(P)
+        self.theta = torch.zeros(self.numel, **self.tpdv)
+        for p in self.policy_ids:
+            q = self.policies[p].q_network
+            o, n = self._poff[p], q.padded_numel
+            self.theta[o:o + n].copy_(q._flat[:n])
+            q.rebind(self.theta[o:o + n])
+        n_agent_tensors = _lib.OPE_QMIX_NPARAM_AGENT_MLP if self._mlp else _lib.OPE_QMIX_NPARAM_AGENT
+        moffs = [self._shift + int(x) for x in list(offs)[n_agent_tensors:n_agent_tensors + _lib.OPE_QMIX_NPARAM_MIXER]]
+        if self.vdn:
+            self.mixer = VDNMixer(args, self.num_agents, S, self.device)
+        else:
+            self.mixer = QMixer(args, self.num_agents, S, self.device, self.theta, moffs)
+        self.theta_tgt = self.theta.clone()
+        self.target_policies = {}
+        for p in self.policy_ids:
+            q = self.policies[p].q_network
+            o, n = self._poff[p], q.padded_numel
+            self.target_policies[p] = _TargetPolicy(self.policies[p], q.twin(self.theta_tgt[o:o + n]))
+        if self.vdn:
+            self.target_mixer = VDNMixer(args, self.num_agents, S, self.device)
+        else:
+            self.target_mixer = QMixer(args, self.num_agents, S, self.device, self.theta_tgt, moffs, init=False)
+        self.parameters = [x for p in self.policies.values() for x in p.parameters()] + list(self.mixer.parameters())
+        self.optimizer = FlatAdam(self.numel, self.lr, self.opti_eps, self.device)
+        self.grad = torch.zeros(self.numel + _lib.OPE_GRAD_TAIL, **self.tpdv)
+        self._scratch = torch.zeros(int(_lib.lib.ope_adam_scratch_floats(self.numel)), **self.tpdv)
+        self._stats = torch.zeros(4, **self.tpdv)
+
+    def _part_cfg(self, pid, batch, phase):
+        cfg = self._cfg(batch)
+        cfg.dims, cfg.vdn, cfg.phase = self._pdims[pid], 1, phase
+        return cfg
+
+    def _ws_for(self, key, cfg):
+        if key not in self._ws:
+            need = _lib.lib.ope_qmix_workspace_bytes(C.byref(cfg))
+            if need < 0:
+                _lib.check(int(need), "ope_qmix_workspace_bytes")
+            ws = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+            _lib.check(_lib.lib.ope_qmix_workspace_init(C.byref(cfg), _lib.ptr(ws), ws.numel(), _lib.current_stream()), "ope_qmix_workspace_init")
+            views = {}
+            for name in ("agent_q", "agent_nq", "d_agent_q"):
+                n = C.c_int64(0)
+                o = _lib.lib.ope_qmix_workspace_find(C.byref(cfg), name.encode(), C.byref(n))
+                views[name] = ws[o:o + 4 * n.value].view(torch.float32).view(cfg.dims.episode_length, cfg.batch, cfg.dims.n_agents)
+            self._ws[key] = (ws, views)
+        return self._ws[key]
+
+    def _train_multi(self, parts, share, rew, dones_env, importance_weights, idxes):
+        """One update with several policies. parts[pid] = (obs [T+1, n_p, B, D_p], acts [T, n_p, B, A_p], avail or None) in the
+        kernels' layout; share [T+1, B, S]; rew [T, 1, B, 1] (the agents share it); dones_env [T, B, 1]. Three kinds of C-ABI calls
+        (ope_qmix_cfg.phase): every policy's networks forward -> the mixer / VDN sum, TD loss and mixer gradients over all agents'
+        q values -> every policy's networks backward; then ONE all-reduce (data parallel) and ONE clip + Adam over the whole vector."""
+        T, N = self.episode_length, self.num_agents
+        B = int(share.shape[1])
+        st = _lib.current_stream()
+        jcfg = self._cfg(B)
+        jcfg.phase = 2
+        jws, jv = self._ws_for(("joint", B), jcfg)
+        keep = []
+        calls = {}
+        for p in self.policy_ids:
+            obs, acts, avail = parts[p]
+            assert obs.shape[0] == T + 1 and obs.shape[1] == self._pdims[p].n_agents and obs.shape[2] == B, "batch does not match the trainer's dimensions"
+            cfg = self._part_cfg(p, B, 1)
+            ws, v = self._ws_for((p, B), cfg)
+            f = _lib.Fields()
+            f.obs, f.acts, f.avail_acts = _lib.ptr(obs).value, _lib.ptr(acts).value, _lib.ptr(avail).value
+            o, n = self._poff[p], self.policies[p].q_network.padded_numel
+            th, tht, gr = self.theta[o:o + n], self.theta_tgt[o:o + n], self.grad[o:o + n]
+            calls[p] = (cfg, f, th, tht, gr, ws, v)
+            _lib.check(_lib.lib.ope_qmix_loss_and_grad(C.byref(cfg), C.byref(f), _lib.ptr(th), _lib.ptr(tht), None, _lib.ptr(ws), ws.numel(),
+                                                       _lib.ptr(gr), None, st), "ope_qmix_loss_and_grad(phase 1)")
+            a0, n_p = self._a0[p], self._pdims[p].n_agents
+            jv["agent_q"][:, :, a0:a0 + n_p].copy_(v["agent_q"])
+            jv["agent_nq"][:, :, a0:a0 + n_p].copy_(v["agent_nq"])
+            keep.append((obs, acts, avail))
+        w = td_stats = None
+        if self.use_per:
+            w = (importance_weights.to(self.device, dtype=torch.float32).contiguous() if torch.is_tensor(importance_weights) else
+                 torch.as_tensor(np.asarray(importance_weights), dtype=torch.float32).to(self.device).contiguous())
+            td_stats = torch.empty(2 * B, **self.tpdv)
+        rew_all = rew.expand(T, N, B, 1).contiguous()          # the TD kernel reads agent 0's slab of [T][N][B][1]
+        f = _lib.Fields()
+        f.share_obs, f.rewards, f.dones_env = _lib.ptr(share).value, _lib.ptr(rew_all).value, _lib.ptr(dones_env).value
+        th, tht, gr = self.theta[self._shift:], self.theta_tgt[self._shift:], self.grad[self._shift:]
+        _lib.check(_lib.lib.ope_qmix_loss_and_grad(C.byref(jcfg), C.byref(f), _lib.ptr(th), _lib.ptr(tht), _lib.ptr(w), _lib.ptr(jws), jws.numel(),
+                                                   _lib.ptr(gr), _lib.ptr(td_stats), st), "ope_qmix_loss_and_grad(phase 2)")
+        for p in self.policy_ids:
+            cfg, f, th, tht, gr, ws, v = calls[p]
+            a0, n_p = self._a0[p], self._pdims[p].n_agents
+            v["d_agent_q"].copy_(jv["d_agent_q"][:, :, a0:a0 + n_p])
+            cfg.phase = 3
+            _lib.check(_lib.lib.ope_qmix_loss_and_grad(C.byref(cfg), C.byref(f), _lib.ptr(th), _lib.ptr(tht), None, _lib.ptr(ws), ws.numel(),
+                                                       _lib.ptr(gr), None, st), "ope_qmix_loss_and_grad(phase 3)")
+        _, world_size = opdist.world()
+        opdist.allreduce_flat_(self.grad)
+        self.optimizer.step_count += 1
+        ac = _lib.AdamCfg()
+        ac.lr, ac.beta1, ac.beta2, ac.eps = self.lr, self.optimizer.betas[0], self.optimizer.betas[1], self.opti_eps
+        ac.max_grad_norm, ac.weight_decay = float(self.args.max_grad_norm), 0.0
+        ac.tau, ac.do_polyak = float(self.tau), int(self.fuse_soft_update)
+        ac.step = self.optimizer.step_count
+        ac.qtot_denominator = float(T * B * world_size)
+        stats = torch.empty(4, **self.tpdv)
+        _lib.check(_lib.lib.ope_adam_step(C.byref(ac), self.numel, _lib.ptr(self.theta), _lib.ptr(self.theta_tgt),
+                                          _lib.ptr(self.optimizer.exp_avg), _lib.ptr(self.optimizer.exp_avg_sq),
+                                          _lib.ptr(self.grad), _lib.ptr(self._scratch), _lib.ptr(stats), st), "ope_adam_step")
+        self._polyak_done = bool(self.fuse_soft_update)
+        train_info = {"loss": stats[0], "grad_norm": stats[1], "Q_tot": stats[2]}
+        new_priorities = None
+        if self.use_per and torch.is_tensor(importance_weights):
+            s = td_stats.view(B, 2)
+            new_priorities = ((1 - self.args.per_nu) * s[:, 0] + self.args.per_nu * s[:, 1]) + self.per_eps
+        elif self.use_per:
+            s = td_stats.view(B, 2).cpu().numpy().astype(np.float32)
+            new_priorities = ((1 - self.args.per_nu) * s[:, 0] + self.args.per_nu * s[:, 1]).flatten() + self.per_eps
+        self._last = (keep, share, rew_all, dones_env, w, td_stats)    # keep inputs alive past the async launches
+        return train_info, new_priorities, idxes
 
     # ---- helpers --------------------------------------------------------------------------------------------
     def _cfg(self, batch):
@@ -170,6 +321,8 @@ class QMix(object):
         """See offpolicy/algorithms/qmix/qmix.py:77-200. `batch` is the 9-tuple from `buffer.sample()` (CUDA tensors
         from our buffer, or numpy arrays from the reference's). Returns (train_info, new_priorities, idxes)."""
         obs_b, cent_b, act_b, rew_b, dones_b, dones_env_b, avail_b, importance_weights, idxes = batch
+        if self.multi:
+            return self._train_multi_rec(batch)
         pid = self.policy_ids[0]
         obs = self._to_device_layout(obs_b[pid], True)
         # the mixer's state: the shared centralized observation, or agent 0's when every agent has its own (qmix.py:86-90)
@@ -184,6 +337,24 @@ class QMix(object):
             prev = torch.cat((torch.zeros_like(acts[:1]), acts), dim=0)
             obs = torch.cat((obs, prev), dim=-1).contiguous()
         return self._train_on_device_batch(obs, share, acts, rew, dones_env, avail, importance_weights, idxes)
+
+    def _train_multi_rec(self, batch):
+        obs_b, cent_b, act_b, rew_b, dones_b, dones_env_b, avail_b, importance_weights, idxes = batch
+        first, last = self.policy_ids[0], self.policy_ids[-1]
+        parts = {}
+        for pid in self.policy_ids:
+            obs = self._to_device_layout(obs_b[pid], True)
+            acts = self._to_device_layout(act_b[pid], True)
+            avail = self._to_device_layout(avail_b[pid], True) if (avail_b is not None and avail_b[pid] is not None) else None
+            if getattr(self.policies[pid], "prev_act_inp", False):
+                prev = torch.cat((torch.zeros_like(acts[:1]), acts), dim=0)
+                obs = torch.cat((obs, prev), dim=-1).contiguous()
+            parts[pid] = (obs, acts, avail)
+        cent = cent_b[first] if self.use_same_share_obs else cent_b[first][0]            # qmix.py:86-90: the first policy's
+        share = self._to_device_layout(cent, False)
+        dones_env = self._to_device_layout(dones_env_b[first], False)
+        rew = self._to_device_layout(rew_b[last], True)[:, :1]                               # qmix.py:103,159: the LAST policy's agent 0
+        return self._train_multi(parts, share, rew, dones_env, importance_weights, idxes)
 
     def _train_on_device_batch(self, obs, share, acts, rew, dones_env, avail, importance_weights, idxes):
         T1, N, B, D = obs.shape
@@ -251,8 +422,8 @@ class QMix(object):
         events: `step(inds, timing_events=(start, end))`) and the graph holds the 16 training kernels.
         Restrictions: uniform replay (PER's importance weights come from the caller per step), one process (the gradient
         all-reduce is not captured), Adam's step count lives on the device."""
-        if self.use_per or opdist.is_distributed():
-            raise NotImplementedError("graphed step: uniform replay on a single GPU only")
+        if self.use_per or opdist.is_distributed() or self.multi:
+            raise NotImplementedError("graphed step: uniform replay, one shared policy, on a single GPU only")
         pbuf = buffer.policy_buffers[policy_id]
         B = int(batch_size)
         self.fuse_soft_update = True

@@ -16,6 +16,7 @@ bool cfg_ok(const ope_qmix_cfg* c) {
   if (!c) return false;
   const ope_dims& d = c->dims;
   if (c->mlp && d.episode_length != 1) return false;   // MLP (transition) mode = one-step "episodes"
+  if (c->phase < 0 || c->phase > 3) return false;
   return d.n_agents >= 1 && d.act_dim >= 1 && d.obs_dim >= 1 && d.obs_dim <= 512 && d.state_dim >= 1 &&
          d.episode_length >= 1 && c->batch >= 1 && d.n_agents <= 64 && d.act_dim <= 200;
 }
@@ -122,7 +123,7 @@ void make_plan(const ope_qmix_cfg* c, Plan* p) {
     if (const char* e = getenv("OPE_CHUNKS")) C = atoi(e);
     C = clampi(C, 1, kMaxChunks);
     const int L = p->T + 1;
-    if (c->mlp) C = 1;
+    if (c->mlp || c->phase) C = 1;
     while (C > 1 && L / C < 16) --C;
     p->chunks = C;
     for (int q = 0; q <= C; ++q) p->tb[q] = q == C ? L : ((int)((int64_t)q * L / C) / 8) * 8;
@@ -252,8 +253,16 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
                                       int64_t workspace_bytes, float* grad, float* td_abs_stats, void* stream) {
   (void)hipGetLastError();  // drop stale errors from the caller's own HIP use
   if (!cfg_ok(cfg) || !batch || !theta || !theta_tgt || !workspace || !grad) return OPE_EINVAL;
-  if (!batch->obs || !batch->share_obs || !batch->acts || !batch->rewards || !batch->dones_env) return OPE_EINVAL;
-  if (cfg->use_per && !per_weights) return OPE_EINVAL;
+  // Phased calls (several policies under one mixer, see ope.h): 1 = agent networks forward only (leaves "agent_q" /
+  // "agent_nq" in the workspace), 2 = mixer + TD loss + mixer gradients only (reads "agent_q" / "agent_nq" the caller
+  // assembled, leaves "d_agent_q"), 3 = agent networks backward only (reads "d_agent_q"). 0 = the whole step.
+  const int phase = cfg->phase;
+  const bool do_fwd = phase == 0 || phase == 1, do_mix = phase == 0 || phase == 2, do_bwd = phase == 0 || phase == 3;
+  if ((do_fwd || do_bwd) && (!batch->obs || !batch->acts)) return OPE_EINVAL;
+  if (do_mix && (!batch->share_obs || !batch->rewards || !batch->dones_env)) return OPE_EINVAL;
+  if (phase == 2 && cfg->vdn == 0 && cfg->dims.n_agents < 1) return OPE_EINVAL;
+  if ((phase == 1 || phase == 3) && !cfg->vdn) return OPE_EINVAL;   // per-policy parts carry no mixer parameters
+  if (do_mix && cfg->use_per && !per_weights) return OPE_EINVAL;
   Plan p;
   make_plan(cfg, &p);
   if (workspace_bytes < p.ws.total * (int64_t)sizeof(float)) return OPE_ENOSPC;
@@ -286,7 +295,7 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
   if ((rc = sync_to(st, side))) return rc;   // fork: the side stream starts after the caller's prior work (the gather)
 
   // ---- forward ----
-  for (int c = 0; c < C; ++c) {
+  for (int c = 0; c < C && do_fwd; ++c) {
     const int64_t r0 = (int64_t)p.tb[c] * p.NB, rows = (int64_t)(p.tb[c + 1] - p.tb[c]) * p.NB;
     TrunkFwdArgs tf;
     memset(&tf, 0, sizeof(tf));
@@ -325,18 +334,18 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
     auto add = [&](const float* src, int rows, int cols, float* dst) {
       tr.src[nt] = src; tr.dst[nt] = dst; tr.rows[nt] = rows; tr.cols[nt] = cols; tr.begin[nt] = tot; tot += rows * cols; ++nt;
     };
-    if (!p.mlp) add(theta + p.AL.wih, 3 * OPE_H, OPE_H, W + p.thetaT);
-    add(theta + p.AL.fc2_w, OPE_H, OPE_H, W + p.thetaT + OPE_H * 3 * OPE_H);
-    if (!cfg->vdn) {
+    if (!p.mlp && phase != 2) add(theta + p.AL.wih, 3 * OPE_H, OPE_H, W + p.thetaT);
+    if (phase != 2) add(theta + p.AL.fc2_w, OPE_H, OPE_H, W + p.thetaT + OPE_H * 3 * OPE_H);
+    if (!cfg->vdn && phase != 1) {
       add(theta + p.ML.w1b_w, p.NM, OPE_HYP, W + p.mixT);
       add(theta + p.ML.w2b_w, OPE_MIX, OPE_HYP, W + p.mixT + (int64_t)OPE_HYP * p.NM);
     }
     tr.n = nt; tr.total = tot;
   }
-  const bool ride = C == 1 && p.A <= 32;       // launch_head_fwd(mode 0) picks head_fwd_mfma for A <= 32
-  if (!ride)
+  const bool ride = C == 1 && p.A <= 32 && do_fwd;       // launch_head_fwd(mode 0) picks head_fwd_mfma for A <= 32
+  if (!ride && tr.n > 0 && phase != 3)
     if ((rc = launch_transpose4(tr, st))) return rc;
-  for (int c = 0; c < C; ++c) {   // heads of chunk c as soon as its scan is done
+  for (int c = 0; c < C && do_fwd; ++c) {   // heads of chunk c as soon as its scan is done
     if (C > 1 && hipStreamWaitEvent(st, sp->scan_done[c], 0) != hipSuccess) return OPE_ELAUNCH;
     HeadFwdArgs hf;
     memset(&hf, 0, sizeof(hf));
@@ -349,12 +358,14 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
     if (ride) hf.side = tr;
     if ((rc = launch_head_fwd(hf, 0, st))) return rc;
   }
+  if (phase == 1) return OPE_OK;
 
   // ---- mixer forward + TD + mixer backward ----
   TdArgs td;
   td.B = p.B; td.N = p.N; td.gamma = cfg->gamma; td.use_huber = cfg->use_huber; td.huber_delta = cfg->huber_delta;
   td.rewards = batch->rewards; td.dones_env = batch->dones_env; td.per_weights = cfg->use_per ? per_weights : nullptr;
-  if (cfg->vdn) {
+  if (!do_mix) {
+  } else if (cfg->vdn) {
     VdnArgs va;
     va.TB = (int)p.TB; va.N = p.N; va.td = td; va.agent_q = W + p.agent_q; va.agent_nq = W + p.agent_nq;
     va.loss_part = W + p.loss_part; va.err_abs = W + p.err_abs; va.d_agent_q = W + p.d_agent_q;
@@ -374,7 +385,7 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
     mb.d_b1 = W + p.d_b1; mb.d_v2 = W + p.d_v2; mb.d_v1 = W + p.d_v1; mb.d_hw1 = W + p.d_hw1; mb.d_hw2 = W + p.d_hw2; mb.d_hb2 = W + p.d_hb2;
     if ((rc = launch_mixer_bwd(mb, st))) return rc;
   }
-  if (td_abs_stats)
+  if (td_abs_stats && do_mix)
     if ((rc = launch_td_stats(W + p.err_abs, p.T, p.B, td_abs_stats, st))) return rc;
 
   // ---- agent backward ----
@@ -383,7 +394,8 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
   hb.no_ln = p.mlp;
   hb.xhat_o = W + p.xhat_o; hb.rstd_o = W + p.rstd_o; hb.act_idx = (const int*)(W + p.act_idx); hb.d_agent_q = W + p.d_agent_q;
   hb.dh_out = W + p.dh_out; hb.dqoh = W + p.dqoh;
-  if ((rc = launch_head_bwd(hb, st))) return rc;
+  if (do_bwd)
+    if ((rc = launch_head_bwd(hb, st))) return rc;
   if ((rc = sync_to(st, side))) return rc;
 
   // weight-gradient problem tables: mixer problems (K = T*B) go first, on the main stream, while the side stream runs the
@@ -442,7 +454,7 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
   }
   for (int c = C - 1; c >= 0; --c) {   // BPTT, last chunk first, on the side stream
     const int lo = p.tb[c], hi = p.tb[c + 1] < p.T ? p.tb[c + 1] : p.T;
-    if (p.mlp || lo >= hi) continue;
+    if (p.mlp || lo >= hi || !do_bwd) continue;
     GruBwdArgs gb;
     memset(&gb, 0, sizeof(gb));
     gb.NB = p.NB; gb.T = hi; gb.t_lo = lo; gb.theta = theta; gb.whh_off = p.AL.whh; gb.h = W + p.h;
@@ -466,22 +478,26 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
     tb.xhat1 = W + p.xhat1 + r0 * OPE_H; tb.rstd1 = W + p.rstd1 + r0; tb.mask1 = (const uint64_t*)(W + p.mask1) + r0;
     tb.xhat2 = W + p.xhat2 + r0 * OPE_H; tb.rstd2 = W + p.rstd2 + r0; tb.mask2 = (const uint64_t*)(W + p.mask2) + r0;
     tb.dz1 = W + p.dz1 + r0 * OPE_H; tb.dz2 = W + p.dz2 + r0 * OPE_H;
-    if ((rc = launch_trunk_bwd(tb, st))) return rc;
+    if (do_bwd)
+      if ((rc = launch_trunk_bwd(tb, st))) return rc;
     WgTable wt;
     memset(&wt, 0, sizeof(wt));
-    add_agent_problems(wt, r0, K1, p.ns_chunk[c], agent_slabs);
-    if (!use_side && !cfg->vdn) add_mixer_problems(wt);
-    if ((rc = wg_finish(&wt))) return rc;
-    if ((rc = launch_wgrad(wt, W, st))) return rc;
-    agent_slabs += wg_slabs(wt, p.ns_chunk[c]);
-    if (!use_side && !cfg->vdn) mixer_slabs = wg_slabs(wt, p.ns_mixer);
+    if (do_bwd) add_agent_problems(wt, r0, K1, p.ns_chunk[c], agent_slabs);
+    if (!use_side && !cfg->vdn && do_mix) add_mixer_problems(wt);
+    if (wt.n > 0) {
+      if ((rc = wg_finish(&wt))) return rc;
+      if ((rc = launch_wgrad(wt, W, st))) return rc;
+    }
+    if (do_bwd) agent_slabs += wg_slabs(wt, p.ns_chunk[c]);
+    if (!use_side && !cfg->vdn && do_mix) mixer_slabs = wg_slabs(wt, p.ns_mixer);
   }
   {
     SplitRed sr;
     sr.raw0 = W + p.raw_agent; sr.n0 = rw.agent_end; sr.ns0 = agent_slabs;
     sr.raw1 = W + p.raw_mixer; sr.n1 = cfg->vdn ? 0 : rw.mixer_size; sr.ns1 = mixer_slabs;
     sr.rsum = W + p.rsum;
-    if ((rc = launch_split_reduce(sr, st))) return rc;
+    if (!(phase == 2 && cfg->vdn))       // (a VDN mixing part has no parameters: only the loss tail follows)
+      if ((rc = launch_split_reduce(sr, st))) return rc;
   }
 
   // ---- finalize into the flat gradient ----
@@ -494,32 +510,36 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
     FinSeg& s = ft.seg[k++];
     s.begin = begin; s.size = size; s.kind = kind; s.src = src; s.src_s = src_s; s.M = M; s.K = K; s.w = w; s.gamma = gamma; s.beta = beta;
   };
-  seg(L.fn_w, p.D, FIN_LNLIN_G, rw.P1, rw.s1, OPE_H, p.D, L.fc1_w, 0, 0);
-  seg(L.fn_b, p.D, FIN_LNLIN_B, rw.P1, rw.s1, OPE_H, p.D, L.fc1_w, 0, 0);
-  seg(L.fc1_w, OPE_H * p.D, FIN_LNLIN_W, rw.P1, rw.s1, OPE_H, p.D, L.fc1_w, L.fn_w, L.fn_b);
-  seg(L.fc1_b, OPE_H, FIN_COPY, rw.s1, 0, 0, 0, 0, 0, 0);
-  seg(L.ln1_w, OPE_H, FIN_LNLIN_G, rw.P2, rw.s2, OPE_H, OPE_H, L.fc2_w, 0, 0);
-  seg(L.ln1_b, OPE_H, FIN_LNLIN_B, rw.P2, rw.s2, OPE_H, OPE_H, L.fc2_w, 0, 0);
-  seg(L.fch_w, 0, FIN_ZERO, 0, 0, 0, 0, 0, 0, 0);  // fc_h.*: registered, never used (mlp.py:21-23) -> zero gradient
-  seg(L.fc2_w, OPE_H * OPE_H, FIN_LNLIN_W, rw.P2, rw.s2, OPE_H, OPE_H, L.fc2_w, L.ln1_w, L.ln1_b);
-  seg(L.fc2_b, OPE_H, FIN_COPY, rw.s2, 0, 0, 0, 0, 0, 0);
-  if (!p.mlp) {
-    seg(L.ln2_w, OPE_H, FIN_LNLIN_G, rw.P3, rw.s3, 3 * OPE_H, OPE_H, L.wih, 0, 0);
-    seg(L.ln2_b, OPE_H, FIN_LNLIN_B, rw.P3, rw.s3, 3 * OPE_H, OPE_H, L.wih, 0, 0);
-    seg(L.wih, 3 * OPE_H * OPE_H, FIN_LNLIN_W, rw.P3, rw.s3, 3 * OPE_H, OPE_H, L.wih, L.ln2_w, L.ln2_b);
-    seg(L.whh, 3 * OPE_H * OPE_H, FIN_COPY, rw.WHH, 0, 0, 0, 0, 0, 0);
-    seg(L.bih, 3 * OPE_H, FIN_COPY, rw.s3, 0, 0, 0, 0, 0, 0);
-    seg(L.bhh, 3 * OPE_H, FIN_COPY, rw.shh, 0, 0, 0, 0, 0, 0);
-    seg(L.lno_w, OPE_H, FIN_LNLIN_G, srcE, srcSq, p.A, OPE_H, L.q_w, 0, 0);
-    seg(L.lno_b, OPE_H, FIN_LNLIN_B, srcE, srcSq, p.A, OPE_H, L.q_w, 0, 0);
-    seg(L.q_w, p.A * OPE_H, FIN_LNLIN_W, srcE, srcSq, p.A, OPE_H, L.q_w, L.lno_w, L.lno_b);
-  } else {   // MLP nets: LN2 feeds the q head
-    seg(L.ln2_w, OPE_H, FIN_LNLIN_G, srcE, srcSq, p.A, OPE_H, L.q_w, 0, 0);
-    seg(L.ln2_b, OPE_H, FIN_LNLIN_B, srcE, srcSq, p.A, OPE_H, L.q_w, 0, 0);
-    seg(L.q_w, p.A * OPE_H, FIN_LNLIN_W, srcE, srcSq, p.A, OPE_H, L.q_w, L.ln2_w, L.ln2_b);
+  if (phase == 2) {
+    seg(0, L.end, FIN_SKIP, 0, 0, 0, 0, 0, 0, 0);   // the agent block belongs to the per-policy backward calls
+  } else {
+    seg(L.fn_w, p.D, FIN_LNLIN_G, rw.P1, rw.s1, OPE_H, p.D, L.fc1_w, 0, 0);
+    seg(L.fn_b, p.D, FIN_LNLIN_B, rw.P1, rw.s1, OPE_H, p.D, L.fc1_w, 0, 0);
+    seg(L.fc1_w, OPE_H * p.D, FIN_LNLIN_W, rw.P1, rw.s1, OPE_H, p.D, L.fc1_w, L.fn_w, L.fn_b);
+    seg(L.fc1_b, OPE_H, FIN_COPY, rw.s1, 0, 0, 0, 0, 0, 0);
+    seg(L.ln1_w, OPE_H, FIN_LNLIN_G, rw.P2, rw.s2, OPE_H, OPE_H, L.fc2_w, 0, 0);
+    seg(L.ln1_b, OPE_H, FIN_LNLIN_B, rw.P2, rw.s2, OPE_H, OPE_H, L.fc2_w, 0, 0);
+    seg(L.fch_w, 0, FIN_ZERO, 0, 0, 0, 0, 0, 0, 0);  // fc_h.*: registered, never used (mlp.py:21-23) -> zero gradient
+    seg(L.fc2_w, OPE_H * OPE_H, FIN_LNLIN_W, rw.P2, rw.s2, OPE_H, OPE_H, L.fc2_w, L.ln1_w, L.ln1_b);
+    seg(L.fc2_b, OPE_H, FIN_COPY, rw.s2, 0, 0, 0, 0, 0, 0);
+    if (!p.mlp) {
+      seg(L.ln2_w, OPE_H, FIN_LNLIN_G, rw.P3, rw.s3, 3 * OPE_H, OPE_H, L.wih, 0, 0);
+      seg(L.ln2_b, OPE_H, FIN_LNLIN_B, rw.P3, rw.s3, 3 * OPE_H, OPE_H, L.wih, 0, 0);
+      seg(L.wih, 3 * OPE_H * OPE_H, FIN_LNLIN_W, rw.P3, rw.s3, 3 * OPE_H, OPE_H, L.wih, L.ln2_w, L.ln2_b);
+      seg(L.whh, 3 * OPE_H * OPE_H, FIN_COPY, rw.WHH, 0, 0, 0, 0, 0, 0);
+      seg(L.bih, 3 * OPE_H, FIN_COPY, rw.s3, 0, 0, 0, 0, 0, 0);
+      seg(L.bhh, 3 * OPE_H, FIN_COPY, rw.shh, 0, 0, 0, 0, 0, 0);
+      seg(L.lno_w, OPE_H, FIN_LNLIN_G, srcE, srcSq, p.A, OPE_H, L.q_w, 0, 0);
+      seg(L.lno_b, OPE_H, FIN_LNLIN_B, srcE, srcSq, p.A, OPE_H, L.q_w, 0, 0);
+      seg(L.q_w, p.A * OPE_H, FIN_LNLIN_W, srcE, srcSq, p.A, OPE_H, L.q_w, L.lno_w, L.lno_b);
+    } else {   // MLP nets: LN2 feeds the q head
+      seg(L.ln2_w, OPE_H, FIN_LNLIN_G, srcE, srcSq, p.A, OPE_H, L.q_w, 0, 0);
+      seg(L.ln2_b, OPE_H, FIN_LNLIN_B, srcE, srcSq, p.A, OPE_H, L.q_w, 0, 0);
+      seg(L.q_w, p.A * OPE_H, FIN_LNLIN_W, srcE, srcSq, p.A, OPE_H, L.q_w, L.ln2_w, L.ln2_b);
+    }
+    seg(L.q_b, p.A, FIN_COPY, srcSq, 0, 0, 0, 0, 0, 0);
   }
-  seg(L.q_b, p.A, FIN_COPY, srcSq, 0, 0, 0, 0, 0, 0);
-  if (!cfg->vdn) {  // mixer gradients: raw mixer slab has the same relative layout as the parameters
+  if (!cfg->vdn && do_mix) {  // mixer gradients: raw mixer slab has the same relative layout as the parameters
     const MixerLayout& M = p.ML;
     const int mo[OPE_QMIX_NPARAM_MIXER] = {M.w1a_w, M.w1a_b, M.w1b_w, M.w1b_b, M.w2a_w, M.w2a_b, M.w2b_w, M.w2b_b,
                                            M.b1_w, M.b1_b, M.b2a_w, M.b2a_b, M.b2b_w, M.b2b_b};
@@ -528,11 +548,12 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
     for (int q = 0; q < OPE_QMIX_NPARAM_MIXER; ++q)
       seg(mo[q], ms[q], FIN_COPY, rw.agent_end + (mo[q] - p.AL.end), 0, 0, 0, 0, 0, 0);
   }
-  seg((int)p.P, OPE_GRAD_TAIL, FIN_TAIL, 0, 0, 0, 0, 0, 0, 0);
+  if (do_mix) seg((int)p.P, OPE_GRAD_TAIL, FIN_TAIL, 0, 0, 0, 0, 0, 0, 0);
   ft.n = k;
-  ft.total = p.P + OPE_GRAD_TAIL;
+  ft.total = p.P + (do_mix ? OPE_GRAD_TAIL : 0);
   if (finalize_blocks(ft) > p.n_gsq) return OPE_ENOSPC;
-  if ((rc = launch_finalize(ft, W + p.rsum, theta, W + p.loss_part, p.n_loss_tiles, grad, st, W + p.gsq_part))) return rc;
+  // (n_loss_tiles < 0: no loss tail -- an agent-backward part writes its parameter block only)
+  if ((rc = launch_finalize(ft, W + p.rsum, theta, W + p.loss_part, do_mix ? p.n_loss_tiles : -1, grad, st, W + p.gsq_part))) return rc;
   return OPE_OK;
 }
 

@@ -43,7 +43,7 @@ __device__ __forceinline__ void transpose4_element(const Transp4& a, int i) {
   a.dst[m][j] = a.src[m][(int64_t)r * cols + c];
 }
 
-enum FinKind { FIN_ZERO = 0, FIN_COPY = 1, FIN_LNLIN_W = 2, FIN_LNLIN_G = 3, FIN_LNLIN_B = 4, FIN_TAIL = 5 };
+enum FinKind { FIN_ZERO = 0, FIN_COPY = 1, FIN_LNLIN_W = 2, FIN_LNLIN_G = 3, FIN_LNLIN_B = 4, FIN_TAIL = 5, FIN_SKIP = 6 };
 struct FinSeg {
   int begin;   // first flat-gradient index of this segment (segments are sorted, padded to x4)
   int size;    // valid elements (rest of the slot up to the next begin is zero)

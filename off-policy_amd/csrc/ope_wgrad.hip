@@ -268,6 +268,7 @@ int launch_split_reduce(const SplitRed& a, hipStream_t st) {
 //   LNLIN_B  that LayerNorm's bias:     dbeta[k]  = sum_i s[i] W[i][k]
 //   ZERO     registered-but-unused tensors (fc_h) and padding
 //   TAIL     [loss_sum, mask_count, qtot_sum, 0] summed over the per-tile partials
+//   SKIP     left untouched (another call of a phased multi-policy step owns that block)
 // ---------------------------------------------------------------------------------------------------------
 // Sum over the 64 lanes of a wave (fixed order: DPP row sums, then the four rows through readlane), result uniform.
 __device__ __forceinline__ float wave64_sum(float v) {
@@ -332,7 +333,7 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinTable ft, const float*
         for (int c = 0; c < 3; ++c) red[threadIdx.x][c] += red[threadIdx.x + o][c];
       __syncthreads();
     }
-    if (threadIdx.x < 4) grad[ft.total - OPE_GRAD_TAIL + threadIdx.x] = threadIdx.x < 3 ? red[0][threadIdx.x] : 0.f;
+    if (n_loss_tiles >= 0 && threadIdx.x < 4) grad[ft.total - OPE_GRAD_TAIL + threadIdx.x] = threadIdx.x < 3 ? red[0][threadIdx.x] : 0.f;
     if (gsq_part && threadIdx.x == 0) gsq_part[blockIdx.x] = 0.f;   // the tail is not part of the gradient norm
     return;
   }
@@ -363,6 +364,9 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinTable ft, const float*
         break;
       case FIN_TAIL:
         write = false;             // written by the extra block
+        break;
+      case FIN_SKIP:
+        write = false;             // owned by another call (phased multi-policy steps)
         break;
       default:
         out = 0.f;
