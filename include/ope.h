@@ -278,6 +278,15 @@ typedef struct ope_ddpg_cfg {
                                  * target noise, 1 = actor noise). Same distribution as the reference's torch.rand, not the same
                                  * stream; a captured graph replays with fresh noise if the counter advances on the device (e.g.
                                  * the critic's ope_adam_cfg.step_counter). 0 = noise arguments are required as before.          */
+  /* Multi-policy updates (share_policy = False: get_update_info, maddpg.py:40-80, loops over `policy_ids`, every policy with its own
+   * actor, critic and buffer). All 0 / NULL = one policy for all agents. Otherwise dims.n_agents is the number of agents of the policy
+   * being updated, n_total_agents the number of agents in the joint action (policy order) and agent_offset the update policy's first
+   * agent in it. The batch then carries the update policy's fields, but `acts` of ALL agents: [n_total_agents][B][A] (same act_dim for
+   * every policy on this path). */
+  int32_t n_total_agents, agent_offset;
+  const float* joint_next_acts; /* DEVICE [B][n_total_agents * A] joint target action, filled by one ope_ddpg_target_actions call per
+                                 * policy; when non-NULL the critic call skips its own target-actor pass (theta_actor_tgt, next_obs and
+                                 * target_noise_u are then unused). Required when n_total_agents > dims.n_agents.                  */
 } ope_ddpg_cfg;
 
 /* One sampled batch in MlpPolicyBuffer.sample_inds order/shapes (mlp_buffer.py:213-257), device pointers. */
@@ -312,6 +321,12 @@ int ope_ddpg_critic_loss_and_grad(const ope_ddpg_cfg* cfg, const ope_mlp_batch* 
 /* Actor update (maddpg.py:162-247): hard gumbel-softmax actions (noise gumbel_noise_u [N*B][A]) spliced into N stacked
  * copies of the joint action, -sum(Q_1 * valid) objective through the (frozen) critic; grad w.r.t. theta_actor + tail
  * [loss_sum, sum(valid), ...]. */
+/* Target actions of ONE policy's agents (get_update_info, maddpg.py:56-74): its target actor on the next observations of its
+ * dims.n_agents agents, onehot_from_logits or (target_gumbel) hard gumbel-softmax, written into columns (agent_offset + a) * A of
+ * joint_next_acts [B][n_total_agents * A]. cfg / batch are that policy's (only next_obs and next_avail_acts are read). */
+int ope_ddpg_target_actions(const ope_ddpg_cfg* cfg, const ope_mlp_batch* batch, const float* theta_actor_tgt,
+                            const float* target_noise_u, void* workspace, int64_t workspace_bytes, float* joint_next_acts,
+                            void* stream);
 int ope_ddpg_actor_loss_and_grad(const ope_ddpg_cfg* cfg, const ope_mlp_batch* batch, const float* theta_actor,
                                  const float* theta_critic, const float* gumbel_noise_u, void* workspace,
                                  int64_t workspace_bytes, float* grad, void* stream);

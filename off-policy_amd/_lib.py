@@ -48,7 +48,8 @@ class AdamCfg(C.Structure):
 class DdpgCfg(C.Structure):
     _fields_ = [("dims", Dims), ("batch", C.c_int32), ("num_q", C.c_int32), ("target_gumbel", C.c_int32),
                 ("use_huber", C.c_int32), ("use_per", C.c_int32), ("gamma", C.c_float), ("huber_delta", C.c_float),
-                ("per_eps", C.c_float), ("noise_seed", C.c_uint64), ("noise_counter", C.c_void_p)]
+                ("per_eps", C.c_float), ("noise_seed", C.c_uint64), ("noise_counter", C.c_void_p),
+                ("n_total_agents", C.c_int32), ("agent_offset", C.c_int32), ("joint_next_acts", C.c_void_p)]
 
 
 class RddpgCfg(C.Structure):
@@ -107,6 +108,7 @@ def _load():
         "ope_ddpg_workspace_init": (C.c_int, [C.POINTER(DdpgCfg), p, i64, p]),
         "ope_ddpg_workspace_find": (i64, [C.POINTER(DdpgCfg), C.c_char_p, C.POINTER(i64)]),
         "ope_ddpg_critic_loss_and_grad": (C.c_int, [C.POINTER(DdpgCfg), C.POINTER(MlpBatch), p, p, p, p, p, p, i64, p, p, p]),
+        "ope_ddpg_target_actions": (C.c_int, [C.POINTER(DdpgCfg), C.POINTER(MlpBatch), p, p, p, i64, p, p]),
         "ope_ddpg_actor_loss_and_grad": (C.c_int, [C.POINTER(DdpgCfg), C.POINTER(MlpBatch), p, p, p, p, i64, p, p]),
         "ope_rddpg_param_layout": (i64, [C.POINTER(RddpgCfg), i32, C.POINTER(i64), C.POINTER(i64)]),
         "ope_rddpg_workspace_bytes": (i64, [C.POINTER(RddpgCfg)]),

@@ -32,8 +32,19 @@ class MADDPG(object):
         self.num_agents, self.policies, self.policy_mapping_fn = num_agents, policies, policy_mapping_fn
         self.policy_ids = sorted(list(self.policies.keys()))
         self.policy_agents = {pid: sorted([a for a in range(num_agents) if policy_mapping_fn(a) == pid]) for pid in self.policies}
-        if self.policy_ids != ["policy_0"] or len(self.policy_agents["policy_0"]) != num_agents:
-            raise NotImplementedError("the accelerated MADDPG path handles one shared policy ('policy_0') for all agents")
+        # several policies (share_policy = False; get_update_info maddpg.py:40-80): every policy has its own actor, critic and buffer;
+        # the joint action is the agents' blocks in policy order
+        self.multi_policy = self.policy_ids != ["policy_0"] or len(self.policy_agents["policy_0"]) != num_agents
+        self.agent_offset, off = {}, 0
+        for pid in self.policy_ids:
+            self.agent_offset[pid] = off
+            off += len(self.policy_agents[pid])
+        if self.multi_policy:
+            flat_agents = [a for pid in self.policy_ids for a in self.policy_agents[pid]]
+            if flat_agents != list(range(num_agents)) or any(len(self.policy_agents[pid]) == 0 for pid in self.policy_ids):
+                raise NotImplementedError("several policies: agents must be numbered policy by policy, every policy with at least one agent")
+            if len({self.policies[pid].act_dim for pid in self.policy_ids}) != 1:
+                raise NotImplementedError("several policies on the accelerated MADDPG path need one action dimension")
         self.num_updates = {p_id: 0 for p_id in self.policy_ids}
         self.use_same_share_obs = args.use_same_share_obs
         self.actor_update_interval = actor_update_interval
@@ -46,7 +57,7 @@ class MADDPG(object):
         self._ws, self._grads, self._gsq = {}, {}, {}
 
     def _workspace(self, policy, cfg):
-        B = cfg.batch
+        B = (cfg.batch, cfg.dims.n_agents, cfg.n_total_agents, id(policy)) if cfg.n_total_agents else cfg.batch
         if B not in self._ws:
             need = _lib.lib.ope_ddpg_workspace_bytes(C.byref(cfg))
             if need < 0:
@@ -124,8 +135,33 @@ class MADDPG(object):
         avail = f(avail_b[pid]) if avail_b is not None else None
         navail = f(navail_b[pid]) if navail_b is not None else None
         N, B, D = obs.shape
-        assert N == self.num_agents
+        assert N == len(self.policy_agents[pid])
         cfg = policy.ddpg_cfg(B)
+        if self.multi_policy:
+            assert not self.device_noise, "several policies: the gumbel noise comes from the reference's CPU generator stream"
+            NT, A = self.num_agents, policy.act_dim
+            # joint target action: one ope_ddpg_target_actions per policy (its target actor on its agents' next observations; noise
+            # drawn per policy in policy order, as get_update_info does), scattered into [B][N_total * A]
+            joint_next = torch.empty(B, NT * A, **self.tpdv)
+            keep = []
+            for q in self.policy_ids:
+                pol_q = self.policies[q]
+                no_q = nobs if q == pid else f(nobs_b[q])
+                nv_q = navail if q == pid else (f(navail_b[q]) if navail_b is not None else None)
+                cq = pol_q.ddpg_cfg(B)
+                cq.dims.n_agents, cq.n_total_agents, cq.agent_offset = int(no_q.shape[0]), NT, self.agent_offset[q]
+                ws_q, _ = self._workspace(pol_q, cq)
+                mq = _lib.MlpBatch()
+                mq.next_obs, mq.next_avail_acts = _lib.ptr(no_q).value, _lib.ptr(nv_q).value
+                u_q = sample_gumbel_uniform((int(no_q.shape[0]) * B, A)).to(self.device) if pol_q.target_noise is not None else None
+                _lib.check(_lib.lib.ope_ddpg_target_actions(C.byref(cq), C.byref(mq), _lib.ptr(pol_q.target_actor._flat), _lib.ptr(u_q),
+                                                            _lib.ptr(ws_q), ws_q.numel(), _lib.ptr(joint_next), _lib.current_stream()),
+                           "ope_ddpg_target_actions")
+                keep.append((no_q, nv_q, u_q))
+            acts = torch.cat([acts if q == pid else f(act_b[q]) for q in self.policy_ids], dim=0).contiguous()      # [N_total][B][A]
+            cfg.dims.n_agents, cfg.n_total_agents, cfg.agent_offset = N, NT, self.agent_offset[pid]
+            cfg.joint_next_acts = _lib.ptr(joint_next).value
+            self._keep_multi = (joint_next, keep)
         ws, (gc, ga, scratch) = self._workspace(policy, cfg)
         mb = _lib.MlpBatch()
         for k, v in dict(obs=obs, share_obs=cent, acts=acts, rewards=rew, next_obs=nobs, next_share_obs=ncent, dones_env=dones_env,
@@ -151,7 +187,7 @@ class MADDPG(object):
             cfg.noise_counter = _lib.ptr(ctr).value
         else:
             draw = lambda shape: sample_gumbel_uniform(shape).to(self.device)
-        u_t = draw((N * B, policy.act_dim)) if policy.target_noise is not None else None
+        u_t = draw((N * B, policy.act_dim)) if (policy.target_noise is not None and not self.multi_policy) else None
         dev_prio = torch.is_tensor(importance_weights)
         w = None
         if self.use_per:
@@ -191,6 +227,11 @@ class MADDPG(object):
         return train_info, new_priorities, idxes
 
     def make_graphed_step(self, buffer, batch_size, policy_id="policy_0", device_sampling=False, steps_per_replay=1):
+        if self.multi_policy:
+            raise NotImplementedError("graphed step: one shared policy only")
+        return self._make_graphed_step(buffer, batch_size, policy_id, device_sampling, steps_per_replay)
+
+    def _make_graphed_step(self, buffer, batch_size, policy_id="policy_0", device_sampling=False, steps_per_replay=1):
         """One whole update -- gather of `batch_size` transitions, critic update, actor update, soft target updates -- captured
         once as a HIP graph and replayed with one launch per step. This path is ~45 kernels of a few microseconds each:
         eagerly it is bound by launch latency and host work, not by the GPU (csrc/ope_ddpg.hip). Returns

@@ -426,6 +426,7 @@ int launch_action_grad(const ActGradArgs& a, hipStream_t st) {
 
 struct DdpgPlan {
   int N, A, D, S, B, K, K4, A4, Din, Ra;
+  int NT, a0;               // agents in the joint action / the update policy's first agent in it (multi-policy; NT = N, a0 = 0 otherwise)
   AgentLayout AL, CL;       // actor (D -> A), critic (Din -> K)
   Workspace ws;
   int ns_c, ns_a;
@@ -440,7 +441,10 @@ static int ddpg_cfg_ok(const ope_ddpg_cfg* c) {
   if (!c) return 0;
   const ope_dims& d = c->dims;
   if (d.n_agents < 1 || d.n_agents > 64 || d.act_dim < 1 || d.act_dim > 64 || d.obs_dim < 1 || d.obs_dim > 512 || d.state_dim < 1) return 0;
-  if (d.state_dim + d.n_agents * d.act_dim > 512) return 0;
+  const int nt = c->n_total_agents > 0 ? c->n_total_agents : d.n_agents;
+  if (c->n_total_agents < 0 || c->agent_offset < 0 || c->agent_offset + d.n_agents > nt || nt > 64) return 0;
+  if (c->n_total_agents <= 0 && c->agent_offset != 0) return 0;
+  if (d.state_dim + nt * d.act_dim > 512) return 0;
   if (c->batch < 1 || c->num_q < 1 || c->num_q > 4) return 0;
   return 1;
 }
@@ -448,7 +452,8 @@ static int ddpg_cfg_ok(const ope_ddpg_cfg* c) {
 static void ddpg_plan(const ope_ddpg_cfg* c, DdpgPlan* p) {
   const ope_dims& d = c->dims;
   p->N = d.n_agents; p->A = d.act_dim; p->D = d.obs_dim; p->S = d.state_dim; p->B = c->batch; p->K = c->num_q;
-  p->K4 = ope_round4(p->K); p->A4 = ope_round4(p->A); p->Din = p->S + p->N * p->A; p->Ra = p->N * p->B;
+  p->NT = c->n_total_agents > 0 ? c->n_total_agents : p->N; p->a0 = c->agent_offset;
+  p->K4 = ope_round4(p->K); p->A4 = ope_round4(p->A); p->Din = p->S + p->NT * p->A; p->Ra = p->N * p->B;
   p->AL = ope_agent_layout_mlp(p->D, p->A, 0);
   p->CL = ope_agent_layout_mlp(p->Din, p->K, 0);
   const int Dmax = p->D > p->Din ? p->D : p->Din;
@@ -465,7 +470,7 @@ static void ddpg_plan(const ope_ddpg_cfg* c, DdpgPlan* p) {
   Workspace& W = p->ws;
   const int64_t B = p->B, Ra = p->Ra, R = Ra;   // save buffers sized for the larger (actor-side) row count
   p->xin_t = W.add("xin_t", B * p->Din); p->xin = W.add("xin", B * p->Din);
-  p->a2n = W.add("a2n", Ra * OPE_H); p->lgn = W.add("logits_n", Ra * p->A); p->cnact = W.add("cent_nact", B * p->N * p->A);
+  p->a2n = W.add("a2n", Ra * OPE_H); p->lgn = W.add("logits_n", Ra * p->A); p->cnact = W.add("cent_nact", B * p->NT * p->A);
   p->a2t = W.add("a2t", B * OPE_H); p->qt = W.add("q_tgt", B * p->K4);
   p->a2c = W.add("a2c", R * OPE_H); p->qc = W.add("q", R * p->K4);
   p->dq = W.add("dq", R * p->K4); p->da2 = W.add("da2", R * OPE_H); p->dz1 = W.add("dz1", R * OPE_H); p->dz2 = W.add("dz2", R * OPE_H);
@@ -481,7 +486,7 @@ static void ddpg_plan(const ope_ddpg_cfg* c, DdpgPlan* p) {
   p->mu1 = W.add("mu1", R); p->cvec = W.add("fc1_colsums", 2 * OPE_H); p->dlg = W.add("dlogits", Ra * p->A4);
   // second set of trunk saves for the actor's own backward (the critic pass of the actor step reuses the first set)
   p->err = W.add("saves2", Ra * (2 * OPE_H + 8));
-  p->fused = ddpg_fused_ok(p->N, p->A, p->D, p->S, p->K);
+  p->fused = ddpg_fused_ok(p->N, p->A, p->D, p->S, p->K) && p->NT == p->N;   // (the tile kernels are the one-shared-policy form)
   p->fused_slabs = W.add("fused_slabs", p->fused ? ddpg_fused_slab_floats(p->N, p->A, p->D, p->S, p->K, p->B) + 64 : 4);   // + debug stamps
   if (p->fused) {    // per-workgroup sums of squares of the gradient the slab reduction wrote (only the fused path produces them)
     p->gsq_critic = W.add("gsq_critic", 2 * ddpg_fused_gsq_blocks(p->N, p->A, p->D, p->S, p->K, true));
@@ -632,9 +637,12 @@ extern "C" int ope_ddpg_critic_loss_and_grad(const ope_ddpg_cfg* cfg, const ope_
                                              const float* per_weights, void* workspace, int64_t workspace_bytes, float* grad,
                                              float* prio_out, void* stream) {
   (void)hipGetLastError();
-  if (!ddpg_cfg_ok(cfg) || !bt || !theta_actor_tgt || !theta_critic || !theta_critic_tgt || !workspace || !grad) return OPE_EINVAL;
-  if (!bt->share_obs || !bt->acts || !bt->rewards || !bt->next_obs || !bt->next_share_obs || !bt->dones_env) return OPE_EINVAL;
-  if (cfg->target_gumbel && !target_noise_u && !cfg->noise_seed) return OPE_EINVAL;
+  if (!ddpg_cfg_ok(cfg) || !bt || !theta_critic || !theta_critic_tgt || !workspace || !grad) return OPE_EINVAL;
+  const bool joint = cfg->joint_next_acts != nullptr;
+  if (!joint && (!theta_actor_tgt || !bt->next_obs)) return OPE_EINVAL;
+  if (!joint && cfg->n_total_agents > cfg->dims.n_agents) return OPE_EINVAL;   // other policies' target actions must come from the caller
+  if (!bt->share_obs || !bt->acts || !bt->rewards || !bt->next_share_obs || !bt->dones_env) return OPE_EINVAL;
+  if (!joint && cfg->target_gumbel && !target_noise_u && !cfg->noise_seed) return OPE_EINVAL;
   if (cfg->use_per && !per_weights) return OPE_EINVAL;
   DdpgPlan p;
   ddpg_plan(cfg, &p);
@@ -645,13 +653,17 @@ extern "C" int ope_ddpg_critic_loss_and_grad(const ope_ddpg_cfg* cfg, const ope_
   if (p.fused)   // small networks: the whole critic update in one launch + a slab reduction (ope_ddpg_fused.hip)
     return launch_ddpg_critic_fused(cfg, bt, theta_actor_tgt, theta_critic, theta_critic_tgt, target_noise_u, per_weights,
                                     W + p.fused_slabs, grad, prio_out, W + p.gsq_critic, st);
-  // target actor on the next observations -> joint next action
-  if ((rc = trunk_mlp(p, W, bt->next_obs, p.Ra, p.D, theta_actor_tgt, p.AL, W + p.a2n, false, nullptr, W + p.lgn, p.A, st))) return rc;
-  if ((rc = launch_action(W + p.lgn, bt->next_avail_acts, NoiseSrc{target_noise_u, cfg->noise_seed, cfg->noise_counter, 0}, p.Ra, p.B, p.A, p.N, cfg->target_gumbel ? 1 : 0, 0, W + p.cnact,
-                          nullptr, nullptr, st))) return rc;
+  // target actor on the next observations -> joint next action (multi-policy: the caller collected it, one
+  // ope_ddpg_target_actions per policy)
+  if (!joint) {
+    if ((rc = trunk_mlp(p, W, bt->next_obs, p.Ra, p.D, theta_actor_tgt, p.AL, W + p.a2n, false, nullptr, W + p.lgn, p.A, st))) return rc;
+    if ((rc = launch_action(W + p.lgn, bt->next_avail_acts, NoiseSrc{target_noise_u, cfg->noise_seed, cfg->noise_counter, 0}, p.Ra, p.B, p.A, p.N, cfg->target_gumbel ? 1 : 0, 0, W + p.cnact,
+                            nullptr, nullptr, st))) return rc;
+  }
+  const float* cnact = joint ? cfg->joint_next_acts : W + p.cnact;
   // critic inputs
-  if ((rc = launch_build_cin(bt->next_share_obs, W + p.cnact, nullptr, 1, p.B, 1, p.N * p.A, p.S, 1, W + p.xin_t, st))) return rc;
-  if ((rc = launch_build_cin(bt->share_obs, bt->acts, nullptr, 1, p.B, p.N, p.A, p.S, 1, W + p.xin, st))) return rc;
+  if ((rc = launch_build_cin(bt->next_share_obs, cnact, nullptr, 1, p.B, 1, p.NT * p.A, p.S, 1, W + p.xin_t, st))) return rc;
+  if ((rc = launch_build_cin(bt->share_obs, bt->acts, nullptr, 1, p.B, p.NT, p.A, p.S, 1, W + p.xin, st))) return rc;
   // target critic, live critic
   if ((rc = trunk_mlp(p, W, W + p.xin_t, p.B, p.Din, theta_critic_tgt, p.CL, W + p.a2t, false, nullptr, W + p.qt, p.K, st))) return rc;   // [B][K]
   if ((rc = trunk_mlp(p, W, W + p.xin, p.B, p.Din, theta_critic, p.CL, W + p.a2c, true, nullptr, W + p.qc, p.K, st))) return rc;
@@ -661,6 +673,24 @@ extern "C" int ope_ddpg_critic_loss_and_grad(const ope_ddpg_cfg* cfg, const ope_
   td.per_weights = cfg->use_per ? per_weights : nullptr; td.dq = W + p.dq; td.prio_out = prio_out; td.loss_part = W + p.loss_part;
   OPE_L(hipLaunchKernelGGL(critic_td_kernel, dim3(launch1d(p.B)), dim3(256), 0, st, td));
   return mlp_backward(p, W, W + p.xin, p.B, p.Din, p.K, p.K, W + p.dq, theta_critic, p.CL, nullptr, p.ns_c, ope_cdiv(p.B, 16), grad, st);
+}
+
+extern "C" int ope_ddpg_target_actions(const ope_ddpg_cfg* cfg, const ope_mlp_batch* bt, const float* theta_actor_tgt,
+                                       const float* target_noise_u, void* workspace, int64_t workspace_bytes, float* joint_next_acts,
+                                       void* stream) {
+  (void)hipGetLastError();
+  if (!ddpg_cfg_ok(cfg) || !bt || !bt->next_obs || !theta_actor_tgt || !workspace || !joint_next_acts) return OPE_EINVAL;
+  if (cfg->target_gumbel && !target_noise_u && !cfg->noise_seed) return OPE_EINVAL;
+  DdpgPlan p;
+  ddpg_plan(cfg, &p);
+  if (workspace_bytes < p.ws.total * (int64_t)sizeof(float)) return OPE_ENOSPC;
+  hipStream_t st = (hipStream_t)stream;
+  float* W = (float*)workspace;
+  int rc;
+  if ((rc = trunk_mlp(p, W, bt->next_obs, p.Ra, p.D, theta_actor_tgt, p.AL, W + p.a2n, false, nullptr, W + p.lgn, p.A, st))) return rc;
+  // (device-drawn noise: one Philox stream per policy, so that two policies' target noise is not the same numbers)
+  return launch_action(W + p.lgn, bt->next_avail_acts, NoiseSrc{target_noise_u, cfg->noise_seed, cfg->noise_counter, 16 + p.a0}, p.Ra, p.B, p.A,
+                       p.N, cfg->target_gumbel ? 1 : 0, 0, joint_next_acts, nullptr, nullptr, st, p.NT, p.a0);
 }
 
 extern "C" int ope_ddpg_actor_loss_and_grad(const ope_ddpg_cfg* cfg, const ope_mlp_batch* bt, const float* theta_actor,
@@ -682,7 +712,8 @@ extern "C" int ope_ddpg_actor_loss_and_grad(const ope_ddpg_cfg* cfg, const ope_m
   if ((rc = launch_action(W + p.lga, bt->avail_acts, NoiseSrc{gumbel_noise_u, cfg->noise_seed, cfg->noise_counter, 1}, p.Ra, p.B, p.A, p.N, 1, 0, nullptr, W + p.actout, W + p.ysoft, st)))
     return rc;
   // N stacked copies of the joint action, copy i carrying the actor's action for agent i
-  if ((rc = launch_build_cin(bt->share_obs, bt->acts, W + p.actout, 1, p.B, p.N, p.A, p.S, p.N, W + p.xin_a, st))) return rc;
+  // (multi-policy: copy i of the joint action of ALL agents, block agent_offset + i replaced)
+  if ((rc = launch_build_cin(bt->share_obs, bt->acts, W + p.actout, 1, p.B, p.NT, p.A, p.S, p.N, W + p.xin_a, st, p.a0))) return rc;
   // critic (parameters frozen) on the stacked input; only head 0 enters the objective
   if ((rc = trunk_mlp(p, W, W + p.xin_a, p.Ra, p.Din, theta_critic, p.CL, W + p.a2c, true, nullptr, W + p.qc, p.K, st))) return rc;
   OPE_L(hipLaunchKernelGGL(actor_obj_kernel, dim3(launch1d(p.Ra)), dim3(256), 0, st, W + p.qc, p.K, bt->valid_transition, p.Ra,
@@ -690,7 +721,7 @@ extern "C" int ope_ddpg_actor_loss_and_grad(const ope_ddpg_cfg* cfg, const ope_m
   // critic backward down to its input, then through the gumbel-softmax into the actor logits
   if ((rc = mlp_backward(p, W, W + p.xin_a, p.Ra, p.Din, p.K, p.K, W + p.dq, theta_critic, p.CL, nullptr, p.ns_a, 0, nullptr, st))) return rc;
   ActGradArgs ag;
-  ag.R = p.Ra; ag.B = p.B; ag.N = p.N; ag.A = p.A; ag.A4 = p.A4; ag.S = p.S; ag.Din = p.Din; ag.a_off = 0; ag.dz1 = W + p.dz1;
+  ag.R = p.Ra; ag.B = p.B; ag.N = p.N; ag.A = p.A; ag.A4 = p.A4; ag.S = p.S; ag.Din = p.Din; ag.a_off = p.a0; ag.dz1 = W + p.dz1;
   ag.xhat1 = W + p.xhat1; ag.rstd1 = W + p.rstd1; ag.mu1 = W + p.mu1; ag.mu0 = W + p.mu0; ag.rstd0 = W + p.rstd0;
   ag.act = W + p.actout; ag.y = W + p.ysoft; ag.theta = theta_critic; ag.fc1_w = p.CL.fc1_w; ag.fc1_b = p.CL.fc1_b; ag.fn_w = p.CL.fn_w;
   ag.fn_b = p.CL.fn_b; ag.cvec = W + p.cvec; ag.dlogits = W + p.dlg;

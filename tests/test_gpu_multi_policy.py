@@ -120,3 +120,70 @@ def test_several_policies_under_one_mixer_match_reference(name, mlp):
     for grp, src in (("mixer/", live), ("mixer_tgt/", tgt)):
         for k, ref in sub(g, "final/" + grp).items():
             np.testing.assert_allclose(src["mixer/" + k], ref, rtol=0, atol=3e-5, err_msg=grp + k)
+
+
+@pytest.mark.parametrize("name", ["maddpg_multi", "matd3_multi_per"])
+def test_mlp_maddpg_several_policies_match_reference(name):
+    """MLP MADDPG / MATD3 with several policies (share_policy = False; get_update_info maddpg.py:40-80): every policy's own actor,
+    critic and batch, the joint target action assembled from all target actors (ope_ddpg_target_actions per policy), each policy
+    updated in turn as runner/mlp/base_runner.py:196-217 does -- fixtures from oracle/make_golden_ddpg.py (OPE_GOLDEN_ONLY=multi)."""
+    from offpolicy_amd.config import default_args
+    from offpolicy_amd.utils.spaces import Discrete
+    from offpolicy_amd.algorithms.maddpg.algorithm.MADDPGPolicy import MADDPGPolicy
+    from offpolicy_amd.algorithms.matd3.algorithm.MATD3Policy import MATD3Policy
+    from offpolicy_amd.algorithms.maddpg.maddpg import MADDPG
+    from offpolicy_amd.algorithms.matd3.matd3 import MATD3
+    g = load_golden(name)
+    groups, dims_obs, A, S, td3 = [int(x) for x in g["groups"]], [int(x) for x in g["dims_obs"]], int(g["A"]), int(g["S"]), bool(g["td3"])
+    N = sum(groups)
+    args = default_args(gamma=float(g["hp_gamma"]), lr=float(g["hp_lr"]), opti_eps=float(g["hp_eps"]), use_huber_loss=bool(g["hp_huber"]),
+                        huber_delta=float(g["hp_delta"]), use_per=bool(g["hp_per"]), per_eps=float(g["hp_per_eps"]), tau=float(g["hp_tau"]),
+                        max_grad_norm=float(g["hp_maxnorm"]))
+    dev = torch.device("cuda:0")
+    pids = ["policy_%d" % i for i in range(len(groups))]
+    pinfo = {p: {"cent_obs_dim": S, "cent_act_dim": A * N, "obs_space": [d], "share_obs_space": [S], "act_space": Discrete(A)}
+             for p, d in zip(pids, dims_obs)}
+    owner, k = {}, 0
+    for p, m in zip(pids, groups):
+        for a in range(k, k + m):
+            owner[a] = p
+        k += m
+    torch.manual_seed(1)
+    np.random.seed(1)
+    policies = {p: (MATD3Policy if td3 else MADDPGPolicy)({"args": args, "device": dev}, pinfo[p]) for p in pids}
+    trainer = (MATD3 if td3 else MADDPG)(args, N, policies, lambda a: owner[a], device=dev)
+    assert trainer.multi_policy
+    for i, p in enumerate(pids):
+        pol = policies[p]
+        for grp, mod in (("actor/", pol.actor), ("critic/", pol.critic), ("actor_tgt/", pol.target_actor), ("critic_tgt/", pol.target_critic)):
+            ref = sub(g, "p%d/%s" % (i, grp))
+            got = {kk: v.detach().cpu().numpy() for kk, v in mod.named_parameters()}
+            for kk, v in ref.items():       # same RNG stream -> the reference's initial draws (to LAPACK-QR rounding)
+                np.testing.assert_allclose(got[kk], v, rtol=0, atol=3e-5, err_msg="%s %s%s" % (p, grp, kk))
+            mod.load_state_dict({kk: torch.as_tensor(v) for kk, v in ref.items()})
+        for crit, pre in ((pol.critic, "p%d/heads/" % i), (pol.target_critic, "p%d/heads_tgt/" % i)):
+            np.testing.assert_allclose(crit._head_w.cpu().numpy(), g[pre + "w"], atol=3e-5)
+            crit._head_w.copy_(torch.as_tensor(g[pre + "w"]))
+            crit._head_b.copy_(torch.as_tensor(g[pre + "b"]))
+    w = g["per_weights"] if "per_weights" in g else None
+    batch = tuple({p: g["p%d/batch/%s" % (i, kk)] for i, p in enumerate(pids)} for kk in M_KEYS) + (w, g["inds"] if w is not None else None)
+    steps = len(g["p0/critic_loss"])
+    for s in range(steps):
+        for i, p in enumerate(pids):
+            torch.manual_seed(1000 + 10 * s + i)
+            info, prio, _ = trainer.shared_train_policy_on_batch(p, batch)
+            assert info["update_actor"]
+            np.testing.assert_allclose(float(info["critic_loss"]), g["p%d/critic_loss" % i][s], rtol=RTOL, err_msg="%d %s" % (s, p))
+            np.testing.assert_allclose(float(info["critic_grad_norm"]), g["p%d/critic_grad_norm" % i][s], rtol=RTOL, err_msg="%d %s" % (s, p))
+            np.testing.assert_allclose(float(info["actor_loss"]), g["p%d/actor_loss" % i][s], rtol=5e-4, atol=2e-6, err_msg="%d %s" % (s, p))
+            np.testing.assert_allclose(float(info["actor_grad_norm"]), g["p%d/actor_grad_norm" % i][s], rtol=5e-4, err_msg="%d %s" % (s, p))
+            if w is not None:
+                np.testing.assert_allclose(np.asarray(prio), g["p%d/priorities" % i][s], rtol=RTOL)
+        for p in pids:
+            policies[p].soft_target_updates()
+    for i, p in enumerate(pids):
+        pol = policies[p]
+        for grp, mod in (("actor/", pol.actor), ("critic/", pol.critic), ("actor_tgt/", pol.target_actor), ("critic_tgt/", pol.target_critic)):
+            got = {kk: v.detach().cpu().numpy() for kk, v in mod.named_parameters()}
+            for kk, ref in sub(g, "final/p%d/%s" % (i, grp)).items():
+                np.testing.assert_allclose(got[kk], ref, rtol=0, atol=3e-5, err_msg="%s final %s%s" % (p, grp, kk))
