@@ -327,3 +327,102 @@ def test_reference_mlp_runner_maddpg_trace_replays_on_the_engine():
         else:
             raise AssertionError("unknown call in the trace: " + name)
     assert seen["policy.get_actions"] == 10 and seen["buffer.insert"] == 25 and seen["trainer.shared_train_policy_on_batch"] == 5
+
+
+def test_reference_mlp_runner_mvdn_one_policy_per_agent_trace_replays_on_the_engine():
+    """The reference's MLP MPERunner with ONE POLICY PER AGENT under a VDN sum (scripts/train_mpe_mqmix.sh: mvdn on a speaker / listener
+    pair of different observation width and action count), recorded by oracle/make_runner_trace_mvdn.py
+    (tests/golden/runner_trace_mvdn_multi.npz): two M_QMixPolicy constructions, the M_QMix(vdn) trainer, random warm-up through
+    `separated_collect_rollout`, two run() cycles (every agent queried through its own policy -> two-policy 12-argument insert -> every
+    second step, per policy: sample -> train_policy_on_batch over ALL policies' networks -> soft updates). 112 calls replayed against
+    the engine's classes with the recorded arguments and RNG states; every return value is compared, and at the end all four networks."""
+    from offpolicy_amd.config import default_args
+    from offpolicy_amd.utils.spaces import Discrete
+    from offpolicy_amd.utils.mlp_buffer import MlpReplayBuffer
+    from offpolicy_amd.algorithms.mqmix.algorithm.mQMixPolicy import M_QMixPolicy
+    from offpolicy_amd.algorithms.mqmix.mqmix import M_QMix
+    g = load_golden("runner_trace_mvdn_multi")
+    calls = [str(x) for x in g["calls"]]
+    shapes = [tuple(int(x) for x in r) for r in g["shapes"]]
+    N, S, T = [int(x) for x in g["dims"]]
+    batch_size, buffer_size, lr, eps0, eps1, eps_t = g["hp"]
+    args = default_args(batch_size=int(batch_size), buffer_size=int(buffer_size), lr=float(lr), epsilon_start=float(eps0),
+                        epsilon_finish=float(eps1), epsilon_anneal_time=float(eps_t), episode_length=T)
+    dev = torch.device("cuda:0")
+    pids = ["policy_%d" % i for i in range(N)]
+    pinfo = {p: {"cent_obs_dim": S, "cent_act_dim": sum(a for _, a in shapes), "obs_space": [d], "share_obs_space": [S], "act_space": Discrete(a)}
+             for p, (d, a) in zip(pids, shapes)}
+    keys = ("obs", "share_obs", "acts", "rewards", "next_obs", "next_share_obs", "dones", "dones_env", "valid_transition")
+    policies, trainer, buf, last_sample = {}, None, None, None
+    seen = {k: 0 for k in set(calls)}
+    for i, name in enumerate(calls):
+        c = _call(g, i)
+        seen[name] += 1
+        pid = pids[int(c["in/pid"])] if "in/pid" in c else None
+        if name == "policy.__init__":
+            _set_rng(c)
+            pol = M_QMixPolicy({"args": args, "device": dev}, pinfo[pid])
+            sd = {k[len("out/sd/"):]: v for k, v in c.items() if k.startswith("out/sd/")}
+            ours = pol.q_network.state_dict()
+            assert list(ours.keys()) == list(sd.keys())
+            for k, v in sd.items():      # same RNG stream -> same initial weights (to LAPACK-QR rounding across hosts)
+                np.testing.assert_allclose(ours[k].cpu().numpy(), v, rtol=0, atol=3e-5, err_msg="%s %s" % (pid, k))
+            pol.q_network.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+            policies[pid] = pol
+        elif name == "trainer.__init__":
+            trainer = M_QMix(args, N, policies, lambda a: "policy_%d" % a, device=dev, vdn=True)
+            assert trainer.multi and trainer.vdn
+            buf = MlpReplayBuffer(pinfo, {p: [j] for j, p in enumerate(pids)}, int(buffer_size), True, False, False, device=dev)
+        elif name == "trainer.prep_rollout":
+            trainer.prep_rollout()
+        elif name == "trainer.prep_training":
+            trainer.prep_training()
+        elif name == "policy.get_random_actions":
+            _set_rng(c)
+            assert np.array_equal(np.asarray(policies[pid].get_random_actions(c["in/obs"])), c["out/actions"]), i
+        elif name == "policy.get_actions":
+            _set_rng(c)
+            explore = bool(c["in/explore"])
+            t_env = int(c["in/t_env"]) if "in/t_env" in c else None
+            acts, _ = policies[pid].get_actions(c["in/obs"], t_env=t_env, explore=explore)
+            acts = np.asarray(acts)
+            assert acts.shape == c["out/actions"].shape, (i, acts.shape)
+            if not np.array_equal(acts, c["out/actions"]):
+                # only a near-tie between the two largest q values may flip a greedy action
+                q = policies[pid].get_q_values(c["in/obs"]).detach().cpu().numpy().reshape(acts.shape)
+                for r in np.nonzero((acts != c["out/actions"]).any(-1))[0]:
+                    a0, a1 = int(acts[r].argmax()), int(c["out/actions"][r].argmax())
+                    assert abs(q[r, a0] - q[r, a1]) < 1e-4, (i, r, q[r])
+        elif name == "buffer.insert":
+            d = [{p: c["in/%s/%s" % (p, k)] for p in pids} for k in keys]
+            idx = buf.insert(int(c["in/n"]), *d, {p: None for p in pids}, {p: None for p in pids})
+            assert np.array_equal(np.asarray(idx), c["out/idx_range"]), i
+        elif name == "buffer.sample":
+            _set_rng(c)
+            last_sample = buf.sample(int(c["in/batch_size"]))
+            assert len(last_sample) == 13
+            for p in pids:
+                for j, k in enumerate(keys):
+                    got = last_sample[j][p]
+                    assert tuple(got.shape) == c["out/%s/%s" % (p, k)].shape, (p, k, got.shape)
+                    assert np.array_equal(got.cpu().numpy(), c["out/%s/%s" % (p, k)]), (i, p, k)
+        elif name == "trainer.train_policy_on_batch":
+            _set_rng(c)
+            info, prio, _ = trainer.train_policy_on_batch(last_sample, bool(c["in/use_same_share_obs"]))
+            assert prio is None
+            for k in ("loss", "grad_norm", "Q_tot"):
+                np.testing.assert_allclose(float(info[k]), float(c["out/" + k]), rtol=2e-3, atol=1e-5, err_msg="%d %s" % (i, k))
+        elif name == "trainer.soft_target_updates":
+            trainer.soft_target_updates()
+        elif name == "runner.final_state":
+            for p in pids:
+                for grp, mod in (("live", policies[p].q_network), ("target", trainer.target_policies[p].q_network)):
+                    pre = "out/%s/%s/" % (p, grp)
+                    ref = {k[len(pre):]: v for k, v in c.items() if k.startswith(pre)}
+                    ours = mod.state_dict()
+                    assert list(ours.keys()) == list(ref.keys())
+                    for k, v in ref.items():
+                        np.testing.assert_allclose(ours[k].cpu().numpy(), v, rtol=0, atol=1e-4, err_msg="%s %s %s" % (p, grp, k))
+        else:
+            raise AssertionError("unknown call in the trace: " + name)
+    assert seen["policy.get_actions"] == 20 and seen["buffer.insert"] == 25 and seen["trainer.train_policy_on_batch"] == 10
