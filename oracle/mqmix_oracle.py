@@ -52,6 +52,31 @@ def sample_inds(store, inds):
             cast(g("dones")), g("dones_env"), cast(g("valid_transition")), cast(g("avail_acts")), cast(g("next_avail_acts")))
 
 
+def mlp_agent_qs(hp, agent, agent_tgt, obs, acts, nobs, navail):
+    """The per-policy part of M_QMix.train_policy_on_batch (mqmix.py:95-174): q values of the actions taken [B, n] (with grad) and the
+    target network's next-step q values at the greedy actions [B, n] (no grad) for ONE policy's agents (torch tensors, [n, B, .])."""
+    n, B, D = obs.shape
+    s_obs, s_nobs, s_act = torch.cat(list(obs), 0), torch.cat(list(nobs), 0), torch.cat(list(acts), 0)
+    s_nav = torch.cat(list(navail), 0) if navail is not None else None
+    q_all = mlp_agent_q(agent, s_obs)
+    q_taken = torch.gather(q_all, 1, s_act.max(dim=-1)[1].unsqueeze(-1))
+    agent_q = torch.cat(q_taken.split(B, dim=0), dim=-1)                          # [B, n]
+    with torch.no_grad():
+        if hp.use_double_q:
+            nq = mlp_agent_q(agent, s_nobs).detach().clone()
+            if s_nav is not None:
+                nq[s_nav == 0.0] = -1e10
+            nact = nq.max(dim=-1)[1]
+            tq = torch.gather(mlp_agent_q(agent_tgt, s_nobs), 1, nact.unsqueeze(-1))
+        else:
+            tqa = mlp_agent_q(agent_tgt, s_nobs).clone()
+            if s_nav is not None:
+                tqa[s_nav == 0.0] = -1e10
+            tq = tqa.max(dim=-1)[0].unsqueeze(-1)
+        agent_nq = torch.cat(tq.split(B, dim=0), dim=-1)
+    return agent_q, agent_nq
+
+
 class MQMixOracle(object):
     def __init__(self, agent_params, mixer_params, n_agents, hp=None):
         self.hp = hp or HP()
@@ -69,25 +94,12 @@ class MQMixOracle(object):
         hp = self.hp
         obs, cent, acts, rew, nobs, ncent, dones, dones_env, valid, avail, navail = [
             torch.as_tensor(np.ascontiguousarray(x)) if x is not None else None for x in batch]
-        N, B, D = obs.shape
-        s_obs, s_nobs, s_act = torch.cat(list(obs), 0), torch.cat(list(nobs), 0), torch.cat(list(acts), 0)
-        s_nav = torch.cat(list(navail), 0) if navail is not None else None
-        q_all = mlp_agent_q(agent, s_obs)
-        q_taken = torch.gather(q_all, 1, s_act.max(dim=-1)[1].unsqueeze(-1))
-        agent_q = torch.cat(q_taken.split(B, dim=0), dim=-1)                          # [B, N]
-        with torch.no_grad():
-            if hp.use_double_q:
-                nq = mlp_agent_q(agent, s_nobs).detach().clone()
-                if s_nav is not None:
-                    nq[s_nav == 0.0] = -1e10
-                nact = nq.max(dim=-1)[1]
-                tq = torch.gather(mlp_agent_q(self.agent_tgt, s_nobs), 1, nact.unsqueeze(-1))
-            else:
-                tqa = mlp_agent_q(self.agent_tgt, s_nobs).clone()
-                if s_nav is not None:
-                    tqa[s_nav == 0.0] = -1e10
-                tq = tqa.max(dim=-1)[0].unsqueeze(-1)
-            agent_nq = torch.cat(tq.split(B, dim=0), dim=-1)
+        agent_q, agent_nq = mlp_agent_qs(hp, agent, self.agent_tgt, obs, acts, nobs, navail)
+        return self._mix_and_loss(mixer, agent_q, agent_nq, cent, ncent, rew, dones_env, weights)
+
+    def _mix_and_loss(self, mixer, agent_q, agent_nq, cent, ncent, rew, dones_env, weights):
+        """mqmix.py:176-205: mixer (or VDN sum) over all agents' q values, TD target, mean loss."""
+        hp = self.hp
         if hp.vdn:
             q_tot = agent_q.sum(dim=-1, keepdim=True)
             nq_tot = agent_nq.sum(dim=-1, keepdim=True)
@@ -137,3 +149,29 @@ class MQMixOracle(object):
                 for k in src:
                     dst[k] = dst[k] * (1.0 - tau) + src[k] * tau
         return out
+
+
+class MQMixMultiOracle(MQMixOracle):
+    """Several policies under one mixer (share_policy = False: mqmix.py:95-178), policies of different observation width / action count /
+    agent count. Policy i's parameters live under "p{i}/<name>"; one Adam, one clip norm (mqmix.py:58-63,208-210). Pinned by
+    tests/golden/{mqmix,mvdn}_multi*.npz (oracle/make_golden_multi.py)."""
+
+    def __init__(self, agent_params_list, mixer_params, n_agents_total, hp=None):
+        merged = OrderedDict(("p%d/%s" % (i, k), v) for i, P in enumerate(agent_params_list) for k, v in P.items())
+        super().__init__(merged, mixer_params, n_agents_total, hp)
+
+    @staticmethod
+    def _of(params, i):
+        pre = "p%d/" % i
+        return OrderedDict((k[len(pre):], v) for k, v in params.items() if k.startswith(pre))
+
+    def loss(self, agent, mixer, batch, weights=None):
+        """`batch`: list of the policies' 11-tuples. Centralized observations and dones_env are the FIRST policy's (mqmix.py:78-86), the
+        reward the LAST policy's agent 0 (mqmix.py:100,181)."""
+        tb = [[torch.as_tensor(np.ascontiguousarray(x)) if x is not None else None for x in b] for b in batch]
+        qs, nqs = [], []
+        for i, (obs, cent, acts, rew, nobs, ncent, dones, dones_env, valid, avail, navail) in enumerate(tb):
+            q, nq = mlp_agent_qs(self.hp, self._of(agent, i), self._of(self.agent_tgt, i), obs, acts, nobs, navail)
+            qs.append(q)
+            nqs.append(nq)
+        return self._mix_and_loss(mixer, torch.cat(qs, dim=-1), torch.cat(nqs, dim=-1), tb[0][1], tb[0][5], tb[-1][3], tb[0][7], weights)
