@@ -76,7 +76,21 @@ class MaddpgOracle(object):
             params[k] = params[k] - (hp.lr / bc1) * (m / (v.sqrt() / np.sqrt(bc2)).add_(hp.opti_eps))
         return float(total)
 
-    def train_step(self, batch, u_target=None, u_actor=None, weights=None, soft_update=True):
+    def target_actions(self, batch, u_target=None):
+        """This policy's part of get_update_info (maddpg.py:56-74): its target actor on its agents' next observations ->
+        list of per-agent next actions [B, A] (one-hot argmax, or hard gumbel-softmax for MATD3)."""
+        nobs, navail = batch[4], batch[10]
+        nobs = torch.as_tensor(np.ascontiguousarray(nobs))
+        B = nobs.shape[1]
+        s_nav = torch.cat(list(torch.as_tensor(np.ascontiguousarray(navail))), 0) if navail is not None else None
+        with torch.no_grad():
+            lg = self.actor_logits(self.actor_tgt, torch.cat(list(nobs), 0))
+            nact = gumbel_hard(lg, s_nav, torch.as_tensor(u_target)) if self.td3 else onehot_argmax(lg, s_nav)
+        return list(nact.split(B, dim=0))
+
+    def train_step(self, batch, u_target=None, u_actor=None, weights=None, soft_update=True, joint=None, all_acts=None, offset=0):
+        """`joint` / `all_acts` / `offset` (several policies, maddpg.py:40-80): joint = (buffer actions of ALL agents [B, NT*A], next
+        actions of ALL agents' target actors [B, NT*A]); all_acts = the per-agent buffer actions; offset = this policy's first agent."""
         hp, N = self.hp, self.N
         obs, cent, acts, rew, nobs, ncent, dones, dones_env, valid, avail, navail = [
             torch.as_tensor(np.ascontiguousarray(x)) if x is not None else None for x in batch]
@@ -85,12 +99,15 @@ class MaddpgOracle(object):
         s_av = torch.cat(list(avail), 0) if avail is not None else None
         s_nav = torch.cat(list(navail), 0) if navail is not None else None
         with torch.no_grad():
-            lg = self.actor_logits(self.actor_tgt, s_nobs)
-            nact = gumbel_hard(lg, s_nav, torch.as_tensor(u_target)) if self.td3 else onehot_argmax(lg, s_nav)
-            cent_nact = torch.cat(nact.split(B, dim=0), dim=-1)
+            if joint is None:
+                lg = self.actor_logits(self.actor_tgt, s_nobs)
+                nact = gumbel_hard(lg, s_nav, torch.as_tensor(u_target)) if self.td3 else onehot_argmax(lg, s_nav)
+                cent_nact = torch.cat(nact.split(B, dim=0), dim=-1)
+            else:
+                cent_nact = joint[1]
             nq = self.critic_q(self.critic_tgt, self.heads_tgt, ncent, cent_nact).min(dim=-1, keepdim=True)[0]
             target = rew[0].view(-1, 1) + hp.gamma * (1 - dones_env.view(-1, 1)) * nq
-        cent_act = torch.cat(list(acts), dim=-1)
+        cent_act = torch.cat(list(acts), dim=-1) if joint is None else joint[0]
         live = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in self.critic.items())
         q = self.critic_q(live, self.heads, cent, cent_act)
         errs = [target - q[:, k:k + 1] for k in range(q.shape[1])]
@@ -110,8 +127,9 @@ class MaddpgOracle(object):
         pol = gumbel_hard(self.actor_logits(la, s_obs), s_av, torch.as_tensor(u_actor))
         agent_acts = pol.split(B, dim=0)
         rows = []
+        every = list(acts) if all_acts is None else list(all_acts)
         for i in range(N):
-            parts = [agent_acts[i] if a == i else acts[a] for a in range(N)]
+            parts = [agent_acts[i] if a == offset + i else every[a] for a in range(len(every))]
             rows.append(torch.cat(parts, dim=-1))
         joint = torch.cat(rows, dim=0)
         q1 = self.critic_q(self.critic, self.heads, cent.repeat(N, 1), joint)[:, 0:1]
@@ -127,3 +145,29 @@ class MaddpgOracle(object):
                     dst[k] = dst[k] * (1 - tau) + src[k] * tau
         return dict(critic_loss=float(closs.detach()), critic_grad_norm=cnorm, actor_loss=float(aloss.detach()), actor_grad_norm=anorm,
                     priorities=prio, critic_grads={k: v.numpy() for k, v in cg.items()}, actor_grads={k: v.numpy() for k, v in ag.items()})
+
+
+class MaddpgMultiOracle(object):
+    """share_policy = False: one MaddpgOracle per policy (own actor, critic, targets, Adam state), agents concatenated in policy order.
+    `train_step(p, batches, u_targets, u_actor)` = MADDPG.shared_train_policy_on_batch(policy p, batch) (maddpg.py:90-249 with
+    get_update_info 40-80 looping over every policy's target actor). Pinned by tests/golden/{maddpg_multi,matd3_multi_per}.npz."""
+
+    def __init__(self, oracles):
+        self.pol = list(oracles)
+        self.offsets = np.cumsum([0] + [o.N for o in self.pol])[:-1]
+
+    def train_step(self, p, batches, u_targets=None, u_actor=None, weights=None, soft_update=False):
+        """batches[k] = policy k's sample_inds 11-tuple; u_targets[k] = its target noise (MATD3) or None."""
+        nact, every = [], []
+        for k, o in enumerate(self.pol):
+            nact += o.target_actions(batches[k], None if u_targets is None else u_targets[k])
+            every += [torch.as_tensor(np.ascontiguousarray(a)) for a in batches[k][2]]
+        joint = (torch.cat(every, dim=-1), torch.cat(nact, dim=-1))
+        return self.pol[p].train_step(batches[p], None, u_actor, weights, soft_update, joint=joint, all_acts=every, offset=int(self.offsets[p]))
+
+    def soft_target_updates(self):
+        for o in self.pol:
+            tau = o.hp.tau
+            for src, dst in ((o.critic, o.critic_tgt), (o.actor, o.actor_tgt)):
+                for k in src:
+                    dst[k] = dst[k] * (1 - tau) + src[k] * tau

@@ -71,3 +71,39 @@ def test_policy_construction_reproduces_reference_rng_stream(name):
         assert np.array_equal(v.numpy(), ref), k
     assert np.array_equal(cv[14].numpy(), g["heads/w"]) and np.array_equal(tv[14].numpy(), g["heads_tgt/w"])
     assert not np.array_equal(g["heads/w"], g["heads_tgt/w"])          # A-4: live and target heads differ forever
+
+
+@pytest.mark.parametrize("name", ["maddpg_multi", "matd3_multi_per"])
+def test_multi_policy_train_steps_match_reference(name):
+    """share_policy = False (oracle/make_golden_ddpg.py, OPE_GOLDEN_ONLY=multi): every policy updated in turn on its own batch with the
+    joint action assembled from all policies (maddpg.py:40-80), soft updates after all of them (runner/mlp/base_runner.py:196-217)."""
+    g = load_golden(name)
+    groups, A, td3 = [int(x) for x in g["groups"]], int(g["A"]), bool(g["td3"])
+    P = len(groups)
+    hp = lambda: HP(gamma=float(g["hp_gamma"]), lr=float(g["hp_lr"]), opti_eps=float(g["hp_eps"]), use_huber_loss=bool(g["hp_huber"]),
+                    huber_delta=float(g["hp_delta"]), use_per=bool(g["hp_per"]), per_eps=float(g["hp_per_eps"]), tau=float(g["hp_tau"]),
+                    max_grad_norm=float(g["hp_maxnorm"]))
+    pols = [DO.MaddpgOracle(sub(g, "p%d/actor/" % i), sub(g, "p%d/critic/" % i), (g["p%d/heads/w" % i], g["p%d/heads/b" % i]),
+                            sub(g, "p%d/actor_tgt/" % i), sub(g, "p%d/critic_tgt/" % i), (g["p%d/heads_tgt/w" % i], g["p%d/heads_tgt/b" % i]),
+                            groups[i], hp(), td3=td3) for i in range(P)]
+    multi = DO.MaddpgMultiOracle(pols)
+    batches = [tuple(g["p%d/batch/%s" % (i, k)] for k in T_KEYS) for i in range(P)]
+    B = len(g["inds"])
+    w = g["per_weights"] if "per_weights" in g else None
+    for s in range(len(g["p0/critic_loss"])):
+        for i in range(P):
+            torch.manual_seed(1000 + 10 * s + i)         # the reference's draws: target noise per policy in policy order, then the actor's
+            u_ts = [torch.FloatTensor(groups[k] * B, A).uniform_() for k in range(P)] if td3 else None
+            u_a = torch.FloatTensor(groups[i] * B, A).uniform_()
+            out = multi.train_step(i, batches, u_ts, u_a, weights=w)
+            np.testing.assert_allclose(out["critic_loss"], g["p%d/critic_loss" % i][s], rtol=3e-5, err_msg="%d p%d" % (s, i))
+            np.testing.assert_allclose(out["critic_grad_norm"], g["p%d/critic_grad_norm" % i][s], rtol=3e-5)
+            np.testing.assert_allclose(out["actor_loss"], g["p%d/actor_loss" % i][s], rtol=1e-4, atol=1e-6)
+            np.testing.assert_allclose(out["actor_grad_norm"], g["p%d/actor_grad_norm" % i][s], rtol=1e-4)
+            if w is not None:
+                np.testing.assert_allclose(out["priorities"], g["p%d/priorities" % i][s], rtol=3e-5)
+        multi.soft_target_updates()
+    for i, o in enumerate(pols):
+        for grp, dst in (("actor/", o.actor), ("critic/", o.critic), ("actor_tgt/", o.actor_tgt), ("critic_tgt/", o.critic_tgt)):
+            for k, ref in sub(g, "final/p%d/%s" % (i, grp)).items():
+                np.testing.assert_allclose(dst[k].numpy(), ref, rtol=0, atol=2e-5, err_msg="p%d %s%s" % (i, grp, k))
