@@ -8,7 +8,7 @@ from offpolicy_amd.utils.synth import DIMS, policy_info_for, synth_episodes
 from offpolicy_amd.utils.rec_buffer import RecReplayBuffer
 from offpolicy_amd.algorithms.qmix.algorithm.QMixPolicy import QMixPolicy
 from offpolicy_amd.algorithms.qmix.qmix import QMix
-dims = DIMS["3s5z"]; B = 32
+dims = DIMS[os.environ.get("OPE_PHASE_DIMS", "3s5z")]; B = int(os.environ.get("OPE_PHASE_B", "32"))
 dev = torch.device("cuda:0"); pinfo = policy_info_for(dims)
 policy = QMixPolicy({"args": default_args(), "device": dev}, pinfo["policy_0"])
 trainer = QMix(default_args(), dims.n_agents, {"policy_0": policy}, lambda a: "policy_0", device=dev, episode_length=dims.episode_length)
