@@ -638,6 +638,8 @@ def main_rddpg(a):
         gather_ms = float(np.mean(gather_profile_read()))
         gather_profile(False)
         results.append(dict(leg=leg, local_batch=local_batch, global_batch=global_batch, elapsed=elapsed, gather_ms=gather_ms))
+    if not results:
+        raise SystemExit("[bench] --episodes %d is too small for prioritized sampling of a global batch of %d: nothing was measured" % (a.episodes, batch))
     if rank == 0:
         r0 = results[0]
         N, A, D, S, T = dims.n_agents, dims.act_dim, dims.obs_dim, dims.state_dim, dims.episode_length
