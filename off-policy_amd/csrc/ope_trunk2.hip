@@ -533,7 +533,33 @@ __global__ void __launch_bounds__(256, 2) trunk_fwd3_kernel(TrunkFwdArgs a) {
   // fetched where they are used, otherwise the register file spills
   constexpr bool WREG = KCM <= 16;
   f32x4 w1[KCM], w2[4], w3[3][4];
-  {
+  if (VEC == 4 && WREG) {
+    // A fragment is [row j][4 floats at column 4 g] of a 16 x 16 block: read in fragment order, the 16 lanes of a quarter-wave hit 16
+    // DIFFERENT rows (16 lines, 16 bytes of each) and the address unit walks 64 line lookups per instruction -- 128 such loads made
+    // the prologue 14.5 k cycles, 17 % of the launch (s_memtime stamps). Instead lane l FETCHES piece (l & 3) of
+    // row (l >> 2) -- a quarter-wave covers four whole 64-byte row segments -- and the piece travels to the lane that owns it,
+    // 4 j + g -> 16 g + j, through four ds_bpermute (no LDS memory). Same values in the same registers as the direct loads.
+    const int lj = lane >> 2, lg = lane & 3, src = 4 * j + g;
+    auto spread = [&](const f32x4& t) {
+      f32x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = __shfl(t[r], src, 64);
+      return o;
+    };
+    const float* __restrict__ Wl = th + a.L.fc1_w + (int64_t)(16 * wave + lj) * D;
+#pragma unroll
+    for (int c = 0; c < KCM; ++c) w1[c] = spread(load4c<4>(Wl, 16 * c + 4 * lg, D));   // clamped; columns >= D meet zero activations
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft)
+      w2[ft] = spread(*reinterpret_cast<const f32x4*>(th + a.L.fc2_w + (int64_t)(16 * wave + lj) * OPE_H + 16 * ft + 4 * lg));
+    if (!a.a2_out) {
+#pragma unroll
+      for (int u = 0; u < 3; ++u)
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft)
+          w3[u][ft] = spread(*reinterpret_cast<const f32x4*>(th + a.L.wih + (int64_t)(16 * (3 * wave + u) + lj) * OPE_H + 16 * ft + 4 * lg));
+    }
+  } else {
     const float* __restrict__ Wr = th + a.L.fc1_w + (int64_t)(16 * wave + j) * D;
 #pragma unroll
     for (int c = 0; c < KCM; ++c) w1[c] = load4c<VEC>(Wr, 16 * c + 4 * g, D);   // clamped; columns >= D meet zero activations
