@@ -254,6 +254,238 @@ __global__ void __launch_bounds__(256) mixer_fwd2_kernel(MixerFwdArgs a) {
   if (dbg && lane == 0) dbg[5] = __builtin_amdgcn_s_memtime();
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// mixer_fwd3: weights stationary in registers, row tiles streamed (3s5z-sized states: S <= 16 KCM, S % 4 == 0, N <= 8).
+// mixer_fwd2 re-streams the 260 KB of hyper-network weights out of L2 for every 16-row workgroup (156 MB per launch at 3s5z,
+// 600 workgroups reading the same lines at once); its K loop waits on the L2 channels that hold them (stage A = 34 k of a
+// wave's 45 k cycles; deeper prefetch changes nothing). Here the grid is persistent -- one 8-wave
+// workgroup per CU, the even ones on the live net, the odd ones on the target -- every wave loads ITS slice of the weights
+// once and then walks over row tiles; per tile only the 16 state rows (HBM -> registers -> LDS, one tile ahead) and the results
+// move:
+//   stage A   waves 0..6 own two of the 14 first-layer output tiles each (2 x KC fragments = 112 registers at S = 216): two
+//             independent MFMA chains per wave over the state chunks, operands read from the LDS state tile
+//   stage B   wave w = agent w: v1_w = W1b_w hw1 + b (its 8 fragments resident), q_w |v1_w| -> LDS; wave 7 also forms
+//             v2 = W2b hw2 + b; waves 4, 5 the two halves of the b2 head dot
+//   combine   wave 7 adds b1 and the agents' terms in agent order, ELU, dot with |v2|, + b2 -> Q_tot, while the other waves
+//             already run stage A of the next tile. Two workgroup barriers per tile.
+// Summation order differs from mixer_fwd2's (K ascending instead of rotated per workgroup; agents 0..N-1 instead of by wave):
+// rounding-level differences, fixed for a given shape.
+// ---------------------------------------------------------------------------------------------------------
+template <int KCM>
+__global__ void __launch_bounds__(512, 1) mixer_fwd3_kernel(MixerFwdArgs a) {
+  constexpr int TR = 16;
+  constexpr int Sp = 16 * KCM + 4;
+  __shared__ __attribute__((aligned(16))) float xs[TR * Sp];
+  __shared__ __attribute__((aligned(16))) float hw1s[TR * kHwPitch];
+  __shared__ __attribute__((aligned(16))) float hw2s[TR * kHwPitch];
+  __shared__ __attribute__((aligned(16))) float b1s[TR * kHidPitch];
+  __shared__ __attribute__((aligned(16))) float hidp[8][TR * kHidPitch];
+  __shared__ float pbs[2][TR];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, g = lane >> 4;
+  const int net = blockIdx.x & 1, wg = blockIdx.x >> 1, nwg = gridDim.x >> 1;
+  const float* __restrict__ th = net == 0 ? a.theta0 : a.theta1;
+  const MixerLayout& L = a.L;
+  const int S = a.S, N = a.N, S4 = S >> 2;
+  const int KC = (S + 15) >> 4;
+  const int ntiles = (a.TB + TR - 1) / TR;
+  const bool save = (net == 0) && (a.hw1 != nullptr);
+  const float* __restrict__ qsrc = net == 0 ? a.agent_q : a.agent_nq;
+  float* __restrict__ qdst = net == 0 ? a.qtot : a.nqtot;
+
+  // ---- this wave's weights, fetched row-contiguously and spread to their owner lanes (see trunk_fwd3) ----
+  const int lj = lane >> 2, lg = lane & 3, src = 4 * j + g;
+  auto spread = [&](const f32x4& t) {
+    f32x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = __shfl(t[r], src, 64);
+    return o;
+  };
+  f32x4 wA[2][KCM], bA[2];
+  const int itA = 2 * wave;                 // stage-A output tiles 2 wave, 2 wave + 1 (waves 0..6)
+  if (wave < 7) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const float* __restrict__ wr = stageA_row(th, L, S, itA + q, lj);
+#pragma unroll
+      for (int c = 0; c < KCM; ++c) wA[q][c] = spread(load4c<4>(wr, 16 * c + 4 * lg, S));   // clamped; columns >= S meet zeros in xs
+      bA[q] = *reinterpret_cast<const f32x4*>(stageA_bias(th, L, itA + q) + 4 * g);
+    }
+  }
+  const int ag = wave < N ? wave : N - 1;    // stage-B agent of this wave (waves >= N idle there)
+  f32x4 w1b[2][4], b1b[2];
+#pragma unroll
+  for (int kh = 0; kh < 2; ++kh) {
+    b1b[kh] = *reinterpret_cast<const f32x4*>(th + L.w1b_b + ag * OPE_MIX + 16 * kh + 4 * g);
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft)
+      w1b[kh][ft] = spread(*reinterpret_cast<const f32x4*>(th + L.w1b_w + (int64_t)(ag * OPE_MIX + 16 * kh + lj) * OPE_HYP + 16 * ft + 4 * lg));
+  }
+  f32x4 hb2w[2];
+  if (wave == 7) {   // wave 7 has no stage-A tiles: its W2b fragments live in the registers of wA[0][0..7], the bias in bA
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+      bA[kh] = *reinterpret_cast<const f32x4*>(th + L.w2b_b + 16 * kh + 4 * g);
+#pragma unroll
+      for (int ft = 0; ft < 4; ++ft)
+        wA[0][4 * kh + ft] = spread(*reinterpret_cast<const f32x4*>(th + L.w2b_w + (int64_t)(16 * kh + lj) * OPE_HYP + 16 * ft + 4 * lg));
+    }
+  }
+  if (wave == 4 || wave == 5) {              // b2 head weights of this wave's 32 hb2 features
+#pragma unroll
+    for (int q = 0; q < 2; ++q) hb2w[q] = *reinterpret_cast<const f32x4*>(th + L.b2b_w + 16 * ((itA + q) - 8) + 4 * g);
+  }
+  const float b2b_bias = th[L.b2b_b];
+  // zero the padding columns of the state tile once (columns S .. 16 KCM + 3; the tile loads never touch them)
+  for (int p = tid; p < TR * (Sp - S); p += 512) {
+    const int r = p / (Sp - S), c = p - r * (Sp - S);
+    xs[r * Sp + S + c] = 0.f;
+  }
+  // state rows of a tile: 16 rows x S/4 16-byte pieces, at most two per thread (S <= 16 KCM <= 224 -> 896 pieces)
+  constexpr int kPieces = 2;
+  f32x4 pre[kPieces];
+  auto request = [&](int tile) {
+#pragma unroll
+    for (int u = 0; u < kPieces; ++u) {
+      const int p = tid + 512 * u;
+      const int pp = p < TR * S4 ? p : TR * S4 - 1;
+      const int r = pp / S4, c = pp - r * S4;
+      const int m = tile * TR + r;
+      const int mm = m < a.TB ? m : a.TB - 1;
+      const int tt = mm / a.B, b = mm - tt * a.B;
+      pre[u] = *reinterpret_cast<const f32x4*>(a.share + ((int64_t)(tt + net) * a.B + b) * S + 4 * c);
+    }
+  };
+  auto deposit = [&]() {
+#pragma unroll
+    for (int u = 0; u < kPieces; ++u) {
+      const int p = tid + 512 * u;
+      if (p < TR * S4) {
+        const int r = p / S4, c = p - r * S4;
+        *reinterpret_cast<f32x4*>(xs + r * Sp + 4 * c) = pre[u];
+      }
+    }
+  };
+  int tile = wg;
+  if (tile < ntiles) {
+    request(tile);
+    deposit();
+    if (tile + nwg < ntiles) request(tile + nwg);
+  }
+  lds_barrier();
+  for (; tile < ntiles; tile += nwg) {
+    const int m = tile * TR + j;
+    const bool valid = m < a.TB;
+    const int mm = valid ? m : a.TB - 1;
+    // ---- stage A ----
+    f32x4 acc[2];
+    if (wave < 7) {
+      acc[0] = bA[0]; acc[1] = bA[1];
+#pragma unroll
+      for (int c = 0; c < KCM; ++c) {
+        if (c < KC) {
+          const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + j * Sp + 16 * c + 4 * g);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            acc[0] = mfma16(wA[0][c][r], xv[r], acc[0]);
+            acc[1] = mfma16(wA[1][c][r], xv[r], acc[1]);
+          }
+        }
+      }
+      if (wave < 6) {   // ReLU of the three hidden layers (tiles 0..11); saved for backward
+        float* dst = wave < 2 ? a.hw1 : (wave < 4 ? a.hw2 : a.hb2);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[q][r] = fmaxf(acc[q][r], 0.f);
+          const int f0 = 16 * ((itA + q) & 3) + 4 * g;
+          if (save && valid) *reinterpret_cast<f32x4*>(dst + (int64_t)m * OPE_HYP + f0) = acc[q];
+          if (wave < 2) *reinterpret_cast<f32x4*>(hw1s + j * kHwPitch + f0) = acc[q];
+          else if (wave < 4) *reinterpret_cast<f32x4*>(hw2s + j * kHwPitch + f0) = acc[q];
+        }
+        if (wave >= 4) {   // b2 head: this wave's half of b2b_w . relu(hb2)
+          float pb = 0.f;
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pb = fmaf(hb2w[q][r], acc[q][r], pb);
+          pb = rowsum4(pb);
+          if (g == 0) pbs[wave - 4][j] = pb;
+        }
+      } else {          // wave 6: hyper_b1 (no activation)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) *reinterpret_cast<f32x4*>(b1s + j * kHidPitch + 16 * q + 4 * g) = acc[q];
+      }
+    }
+    lds_barrier();      // stage-A results visible; everybody is done reading xs
+    if (tile + nwg < ntiles) {
+      deposit();        // next tile's rows (requested one tile ago)
+      if (tile + 2 * nwg < ntiles) request(tile + 2 * nwg);
+    }
+    // ---- stage B ----
+    f32x4 v2[2], hb1[2];
+    float pbsum = 0.f;
+    if (wave < N) {
+      f32x4 v[2] = {b1b[0], b1b[1]};
+#pragma unroll
+      for (int ft = 0; ft < 4; ++ft) {
+        const f32x4 hv = *reinterpret_cast<const f32x4*>(hw1s + j * kHwPitch + 16 * ft + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int kh = 0; kh < 2; ++kh) v[kh] = mfma16(w1b[kh][ft][r], hv[r], v[kh]);
+      }
+      const float qa = qsrc[(int64_t)mm * N + ag];
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) {
+        if (save && valid) *reinterpret_cast<f32x4*>(a.v1 + (int64_t)m * (N * OPE_MIX) + ag * OPE_MIX + 16 * kh + 4 * g) = v[kh];
+        f32x4 t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[r] = qa * fabsf(v[kh][r]);
+        *reinterpret_cast<f32x4*>(hidp[wave] + j * kHidPitch + 16 * kh + 4 * g) = t;
+      }
+    }
+    if (wave == 7) {   // w2 = |W2b hw2 + b|
+      v2[0] = bA[0]; v2[1] = bA[1];
+#pragma unroll
+      for (int ft = 0; ft < 4; ++ft) {
+        const f32x4 hv = *reinterpret_cast<const f32x4*>(hw2s + j * kHwPitch + 16 * ft + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int kh = 0; kh < 2; ++kh) v2[kh] = mfma16(wA[0][4 * kh + ft][r], hv[r], v2[kh]);
+      }
+      if (save && valid) {
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) *reinterpret_cast<f32x4*>(a.v2 + (int64_t)m * OPE_MIX + 16 * kh + 4 * g) = v2[kh];
+      }
+      // b1 and the b2 head partials are rewritten by the NEXT tile's stage A while this wave combines: take them now
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) hb1[kh] = *reinterpret_cast<const f32x4*>(b1s + j * kHidPitch + 16 * kh + 4 * g);
+      pbsum = pbs[0][j] + pbs[1][j];
+    }
+    lds_barrier();      // agents' terms visible; the next tile's state is in xs
+    if (wave == 7) {    // ---- combine (the other waves go on to the next tile's stage A) ----
+      float part = 0.f;
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) {
+        f32x4 h = hb1[kh];
+        for (int w = 0; w < N; ++w) {
+          const f32x4 o = *reinterpret_cast<const f32x4*>(hidp[w] + j * kHidPitch + 16 * kh + 4 * g);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) h[r] += o[r];
+        }
+        if (save && valid) *reinterpret_cast<f32x4*>(a.hpre + (int64_t)m * OPE_MIX + 16 * kh + 4 * g) = h;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part = fmaf(elu1(h[r]), fabsf(v2[kh][r]), part);
+      }
+      const float qtot = rowsum4(part) + (pbsum + b2b_bias);
+      if (valid && g == 0) qdst[m] = qtot;
+    }
+  }
+}
+
 template <int VEC>
 static void launch_mixer2(const MixerFwdArgs& a0, hipStream_t st) {
   MixerFwdArgs a = a0;
@@ -261,6 +493,17 @@ static void launch_mixer2(const MixerFwdArgs& a0, hipStream_t st) {
   a.k_stagger = stag;
   static const int forced = getenv("OPE_MIXER_RT") ? atoi(getenv("OPE_MIXER_RT")) : 0;
   const int rt = forced ? forced : 1;
+  // weights-in-registers persistent form for 3s5z-sized problems (OPE_MIXER_PERSIST=0: the re-streaming kernel)
+  // (read per launch: tests switch it between calls; 2 = also for small problems, where one workgroup per row tile is as good)
+  const char* pe = getenv("OPE_MIXER_PERSIST");
+  const int persist = pe ? atoi(pe) : 1;
+  if (VEC == 4 && persist && !forced && !a.dbg && a.N <= 8 && a.S <= 16 * 14 && (a.TB >= 16 * 64 || persist == 2)) {
+    const int tiles = ope_cdiv(a.TB, 16);
+    static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256; return n > 1 ? n : 256; }();
+    const int per_net = tiles < cus / 2 ? tiles : cus / 2;
+    hipLaunchKernelGGL((mixer_fwd3_kernel<14>), dim3(2 * per_net), dim3(512), 0, st, a);
+    return;
+  }
   if (rt == 4) hipLaunchKernelGGL((mixer_fwd2_kernel<VEC, 4>), dim3(2 * ope_cdiv(a.TB, 64)), dim3(256), 0, st, a);
   else if (rt == 2) hipLaunchKernelGGL((mixer_fwd2_kernel<VEC, 2>), dim3(2 * ope_cdiv(a.TB, 32)), dim3(256), 0, st, a);
   else hipLaunchKernelGGL((mixer_fwd2_kernel<VEC, 1>), dim3(2 * ope_cdiv(a.TB, 16)), dim3(256), 0, st, a);
