@@ -271,7 +271,7 @@ __global__ void __launch_bounds__(256) mixer_fwd2_kernel(MixerFwdArgs a) {
 // Summation order differs from mixer_fwd2's (K ascending instead of rotated per workgroup; agents 0..N-1 instead of by wave):
 // rounding-level differences, fixed for a given shape.
 // ---------------------------------------------------------------------------------------------------------
-template <int KCM>
+template <int KCM, bool FULL>   // FULL: ceil(S / 16) == KCM exactly (no per-chunk guard: the K loop is straight-line code)
 __global__ void __launch_bounds__(512, 1) mixer_fwd3_kernel(MixerFwdArgs a) {
   constexpr int TR = 16;
   constexpr int Sp = 16 * KCM + 4;
@@ -384,7 +384,7 @@ __global__ void __launch_bounds__(512, 1) mixer_fwd3_kernel(MixerFwdArgs a) {
       acc[0] = bA[0]; acc[1] = bA[1];
 #pragma unroll
       for (int c = 0; c < KCM; ++c) {
-        if (c < KC) {
+        if (FULL || c < KC) {
           const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + j * Sp + 16 * c + 4 * g);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -501,7 +501,8 @@ static void launch_mixer2(const MixerFwdArgs& a0, hipStream_t st) {
     const int tiles = ope_cdiv(a.TB, 16);
     static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256; return n > 1 ? n : 256; }();
     const int per_net = tiles < cus / 2 ? tiles : cus / 2;
-    hipLaunchKernelGGL((mixer_fwd3_kernel<14>), dim3(2 * per_net), dim3(512), 0, st, a);
+    if (((a.S + 15) >> 4) == 14) hipLaunchKernelGGL((mixer_fwd3_kernel<14, true>), dim3(2 * per_net), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((mixer_fwd3_kernel<14, false>), dim3(2 * per_net), dim3(512), 0, st, a);
     return;
   }
   if (rt == 4) hipLaunchKernelGGL((mixer_fwd2_kernel<VEC, 4>), dim3(2 * ope_cdiv(a.TB, 64)), dim3(256), 0, st, a);
