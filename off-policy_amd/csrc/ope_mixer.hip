@@ -293,6 +293,11 @@ __global__ void __launch_bounds__(512, 1) mixer_fwd3_kernel(MixerFwdArgs a) {
   const bool save = (net == 0) && (a.hw1 != nullptr);
   const float* __restrict__ qsrc = net == 0 ? a.agent_q : a.agent_nq;
   float* __restrict__ qdst = net == 0 ? a.qtot : a.nqtot;
+  // optional s_memtime stamps (ope_set_debug; tools/mixer3_phases.py): [workgroup][wave][8] = start, weights + first state tile in
+  // place, then for the FIRST tile: stage A done, after barrier 1, stage B done, after barrier 2; last: end of the wave
+  long long* dbg = a.dbg ? a.dbg + ((int64_t)blockIdx.x * 8 + wave) * 8 : nullptr;
+  auto stamp = [&](int k) { if (dbg && lane == 0) dbg[k] = __builtin_amdgcn_s_memtime(); };
+  stamp(0);
 
   // ---- this wave's weights, fetched row-contiguously and spread to their owner lanes (see trunk_fwd3) ----
   const int lj = lane >> 2, lg = lane & 3, src = 4 * j + g;
@@ -374,7 +379,10 @@ __global__ void __launch_bounds__(512, 1) mixer_fwd3_kernel(MixerFwdArgs a) {
     if (tile + nwg < ntiles) request(tile + nwg);
   }
   lds_barrier();
+  stamp(1);
+  const int first_tile = tile;
   for (; tile < ntiles; tile += nwg) {
+    const bool st1 = tile == first_tile;
     const int m = tile * TR + j;
     const bool valid = m < a.TB;
     const int mm = valid ? m : a.TB - 1;
@@ -418,7 +426,9 @@ __global__ void __launch_bounds__(512, 1) mixer_fwd3_kernel(MixerFwdArgs a) {
         for (int q = 0; q < 2; ++q) *reinterpret_cast<f32x4*>(b1s + j * kHidPitch + 16 * q + 4 * g) = acc[q];
       }
     }
+    if (st1) stamp(2);
     lds_barrier();      // stage-A results visible; everybody is done reading xs
+    if (st1) stamp(3);
     if (tile + nwg < ntiles) {
       deposit();        // next tile's rows (requested one tile ago)
       if (tile + 2 * nwg < ntiles) request(tile + 2 * nwg);
@@ -465,7 +475,9 @@ __global__ void __launch_bounds__(512, 1) mixer_fwd3_kernel(MixerFwdArgs a) {
       for (int kh = 0; kh < 2; ++kh) hb1[kh] = *reinterpret_cast<const f32x4*>(b1s + j * kHidPitch + 16 * kh + 4 * g);
       pbsum = pbs[0][j] + pbs[1][j];
     }
+    if (st1) stamp(4);
     lds_barrier();      // agents' terms visible; the next tile's state is in xs
+    if (st1) stamp(5);
     if (wave == 7) {    // ---- combine (the other waves go on to the next tile's stage A) ----
       float part = 0.f;
 #pragma unroll
@@ -484,6 +496,7 @@ __global__ void __launch_bounds__(512, 1) mixer_fwd3_kernel(MixerFwdArgs a) {
       if (valid && g == 0) qdst[m] = qtot;
     }
   }
+  stamp(6);
 }
 
 template <int VEC>
@@ -497,7 +510,7 @@ static void launch_mixer2(const MixerFwdArgs& a0, hipStream_t st) {
   // (read per launch: tests switch it between calls; 2 = also for small problems, where one workgroup per row tile is as good)
   const char* pe = getenv("OPE_MIXER_PERSIST");
   const int persist = pe ? atoi(pe) : 1;
-  if (VEC == 4 && persist && !forced && !a.dbg && a.N <= 8 && a.S <= 16 * 14 && (a.TB >= 16 * 64 || persist == 2)) {
+  if (VEC == 4 && persist && !forced && a.N <= 8 && a.S <= 16 * 14 && (a.TB >= 16 * 64 || persist == 2)) {
     const int tiles = ope_cdiv(a.TB, 16);
     static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256; return n > 1 ? n : 256; }();
     const int per_net = tiles < cus / 2 ? tiles : cus / 2;

@@ -1,4 +1,5 @@
-"""Per-wave phase timing of mixer_fwd2 from s_memtime stamps (ope_set_debug(1))."""
+"""Per-wave phase timing of mixer_fwd2 from s_memtime stamps (ope_set_debug(1)). Run with OPE_MIXER_PERSIST=0 at 3s5z-sized
+states (the default there is mixer_fwd3: tools/mixer3_phases.py)."""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
