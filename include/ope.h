@@ -117,9 +117,13 @@ int ope_store_gather_host_inds(const ope_dims* dims, int32_t capacity, const ope
  * np.random.choice(filled, batch) in the reference's sample() (rec_buffer.py:86, mlp_buffer.py:74), from Philox4x32-10 keyed by
  * (seed, batch position, DEVICE int32 *counter (0 if NULL)). Same distribution, not numpy's stream. No index upload and no host
  * work per step; a captured HIP graph replays with fresh indices when the counter advances on the device (e.g.
- * ope_adam_cfg.step_counter). inds_out (device int64[batch], may be NULL) receives the drawn indices. */
-int ope_store_gather_sampled(const ope_dims* dims, int32_t capacity, int32_t filled, const ope_fields* store, uint64_t seed,
-                             const int32_t* counter, int32_t batch, const ope_fields* out, int64_t* inds_out, void* stream);
+ * ope_adam_cfg.step_counter). inds_out (device int64[batch], may be NULL) receives the drawn indices.
+ * `filled_dev` (DEVICE int32, may be NULL): when given, the number of filled slots is read from it by the kernel at RUN time
+ * (clamped to [1, capacity]) and `filled` is ignored -- a captured graph then keeps sampling from everything insert() has
+ * written since the capture, as buffer.sample() does, instead of from the slots that were filled when it was captured. */
+int ope_store_gather_sampled(const ope_dims* dims, int32_t capacity, int32_t filled, const int32_t* filled_dev,
+                             const ope_fields* store, uint64_t seed, const int32_t* counter, int32_t batch, const ope_fields* out,
+                             int64_t* inds_out, void* stream);
 /* Per-dispatch timing of the gather (the roofline leg of bench.py): after ope_store_gather_profile(1) every gather launch
  * carries hipExtLaunchKernel start / stop events (up to 512 launches are kept); ope_store_gather_profile_read waits for them
  * and writes the kernel durations in milliseconds, oldest first, into HOST memory, returns how many (and clears the ring).
@@ -405,7 +409,9 @@ int ope_rddpg_actor_loss_and_grad(const ope_rddpg_cfg* cfg, const ope_fields* ba
  * processes by whatever the host side has (torch.distributed.all_gather_object in off-policy_amd/dist.py).
  *   epoch   call counter, identical on all ranks, 1, 2, 3, ... (parity = epoch & 1 picks the half of the buffer);
  *   status  device int32, OR-ed with 1 if a peer's flag did not arrive within ctx.timeout_ms (default 10 s; ranks may be
- *           skewed by host work or lazy initialisation) -- a bounded spin: a dead peer cannot hang the GPU forever.
+ *           skewed by host work or lazy initialisation) -- a bounded spin: a dead peer cannot hang the GPU forever. The
+ *           failure is also visible IN-BAND: every 1024-float chunk whose peers did not arrive is overwritten with NaN
+ *           (never with a sum over stale slots), so the following clip norm / loss / parameters are NaN.
  * world == 1 degenerates to a copy through the own slot. Not capturable in a HIP graph (epoch is a launch argument).
  * ---------------------------------------------------------------------------------------------- */
 #define OPE_AR_MAX_WORLD 16

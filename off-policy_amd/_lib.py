@@ -83,7 +83,7 @@ def _load():
         "ope_store_insert": (C.c_int, [C.POINTER(Dims), i32, C.POINTER(Fields), C.POINTER(Fields), p, i32, p, p]),
         "ope_store_gather": (C.c_int, [C.POINTER(Dims), i32, C.POINTER(Fields), p, i32, C.POINTER(Fields), p, p]),
         "ope_store_gather_host_inds": (C.c_int, [C.POINTER(Dims), i32, C.POINTER(Fields), p, i32, C.POINTER(Fields), p]),
-        "ope_store_gather_sampled": (C.c_int, [C.POINTER(Dims), i32, i32, C.POINTER(Fields), C.c_uint64, p, i32, C.POINTER(Fields), p, p]),
+        "ope_store_gather_sampled": (C.c_int, [C.POINTER(Dims), i32, i32, p, C.POINTER(Fields), C.c_uint64, p, i32, C.POINTER(Fields), p, p]),
         "ope_store_gather_profile": (C.c_int, [i32]),
         "ope_store_gather_profile_read": (C.c_int, [p, i32]),
         "ope_set_gather_params": (None, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),

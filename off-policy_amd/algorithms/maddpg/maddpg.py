@@ -251,6 +251,13 @@ class MADDPG(object):
         pid = policy_id
         policy, pbuf = self.policies[pid], buffer.policy_buffers[pid]
         B = int(batch_size)
+        # `update_actor` is decided on the HOST (num_updates % actor_update_interval, maddpg.py:100) while the graph is being
+        # captured, so the captured launch sequence fixes the actor cadence: it is the eager one only if a replay holds whole
+        # periods of it and starts at the beginning of one. (count_updates=False = the reference's defect A-5: every step updates.)
+        if self.count_updates and self.actor_update_interval > 1:
+            assert steps_per_replay % self.actor_update_interval == 0 and self.num_updates[pid] % self.actor_update_interval == 0, \
+                "graphed step with a delayed actor: steps_per_replay must be a multiple of actor_update_interval (%d) and the " \
+                "update count aligned to it" % self.actor_update_interval
         self.device_noise = True
         self.fuse_soft_update = True
         for opt in (policy.critic_optimizer, policy.actor_optimizer):
@@ -293,10 +300,12 @@ class MADDPG(object):
         np.random.set_state(snap_misc[2])
         torch.cuda.synchronize(self.device)
         count0 = dict(self.num_updates)
+        actor_host0 = policy.actor_optimizer.step_count
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             for _ in range(steps_per_replay):
                 info = body()
+        actor_steps_per_replay = policy.actor_optimizer.step_count - actor_host0     # actor updates one replay performs
         self.num_updates.update(count0)        # capture ran the host code but no kernels
         for opt in (policy.critic_optimizer, policy.actor_optimizer):
             opt.step_count = int(opt.step_dev[0].item())
@@ -305,8 +314,8 @@ class MADDPG(object):
 
         def step_sampled():
             graph.replay()
-            for opt in (policy.critic_optimizer, policy.actor_optimizer):
-                opt.step_count += steps_per_replay
+            policy.critic_optimizer.step_count += steps_per_replay
+            policy.actor_optimizer.step_count += actor_steps_per_replay
             if self.count_updates:
                 self.num_updates[pid] += steps_per_replay
             return info
@@ -322,8 +331,10 @@ class MADDPG(object):
             ev.record()
             state["used"][k] = True
             graph.replay()
-            for opt in (policy.critic_optimizer, policy.actor_optimizer):
-                opt.step_count += 1
+            policy.critic_optimizer.step_count += 1
+            policy.actor_optimizer.step_count += actor_steps_per_replay
+            if self.count_updates:
+                self.num_updates[pid] += 1
             return info
         self._graph = (graph, static_inds, ring)      # keep alive
         return step_sampled if device_sampling else step

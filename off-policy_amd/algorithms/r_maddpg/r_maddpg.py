@@ -63,7 +63,9 @@ class R_MADDPG(object):
         self._ws, self._grads = {}, {}
 
     def _workspace(self, policy, cfg):
-        B = (cfg.batch, cfg.dims.n_agents, cfg.n_total_agents) if cfg.n_total_agents else cfg.batch
+        # one workspace + gradient / Adam-scratch set PER POLICY: the buffers below are sized from this policy's actor and critic
+        # (policies of a multi-policy trainer may differ in observation width while sharing batch size and agent counts)
+        B = (cfg.batch, cfg.dims.n_agents, cfg.n_total_agents, id(policy)) if cfg.n_total_agents else cfg.batch
         if B not in self._ws:
             need = _lib.lib.ope_rddpg_workspace_bytes(C.byref(cfg))
             if need < 0:

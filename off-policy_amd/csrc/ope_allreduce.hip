@@ -63,6 +63,9 @@ __global__ void __launch_bounds__(kBlock) allreduce_push_kernel(ArArgs a, float*
                        __HIP_MEMORY_SCOPE_SYSTEM);
   }
   // wait for the W flags of this chunk in the OWN buffer (bounded)
+  __shared__ int gave_up;
+  if (tid == 0) gave_up = 0;
+  __syncthreads();
   if (tid < a.world) {
     const uint32_t* f = flag_ptr(a.peer[a.rank], a.chunks_max, a.world, parity, tid, chunk);
     const unsigned long long t0 = wall_clock64();
@@ -70,12 +73,22 @@ __global__ void __launch_bounds__(kBlock) allreduce_push_kernel(ArArgs a, float*
       __builtin_amdgcn_s_sleep(2);
       if (wall_clock64() - t0 > a.timeout_ticks) {
         atomicOr(status, 1);
+        gave_up = 1;
         break;
       }
     }
   }
   __threadfence_system();          // acquire side: drop any stale line before the slots are read
   __syncthreads();
+  if (gave_up) {
+    // A peer's chunk never arrived: the slots hold a PREVIOUS epoch's data. Summing them would hand the optimizer a plausible
+    // but wrong gradient on this rank only, and the replicas would drift apart silently. Poison the chunk instead: the clip
+    // norm, the loss and every parameter of this rank go NaN on this very step, and through the next exchange on all ranks.
+    const float qnan = __builtin_nanf("");
+    for (int r = 0; r < 4; ++r)
+      if (i + r < n) flat[i + r] = qnan;
+    return;
+  }
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   for (int q = 0; q < a.world; ++q) {          // FIXED rank order: identical bits on every rank
     const float* sp = slot_ptr(a.peer[a.rank], a.chunks_max, a.world, a.max_floats, parity, q) + i;

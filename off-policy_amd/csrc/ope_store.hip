@@ -99,10 +99,17 @@ struct RngIdx {
   uint64_t seed;
   const int32_t* counter;
   uint32_t filled;
+  const int32_t* filled_dev;   // optional DEVICE count of filled slots, read at run time (a captured graph sees later inserts)
+  uint32_t capacity;
   int64_t* out;      // optional: the drawn indices, for the caller (priorities, inspection)
   __device__ __forceinline__ int64_t operator[](int i) const {
     const ope::Philox4 x = ope::philox4x32_10((uint32_t)i, 0u, (uint32_t)(counter ? counter[0] : 0), 2u, (uint32_t)seed, (uint32_t)(seed >> 32));
-    const int64_t v = (int64_t)(((uint64_t)x.v[0] * (uint64_t)filled) >> 32);
+    uint32_t f = filled;
+    if (filled_dev) {
+      const int32_t fd = filled_dev[0];
+      f = fd < 1 ? 1u : ((uint32_t)fd > capacity ? capacity : (uint32_t)fd);
+    }
+    const int64_t v = (int64_t)(((uint64_t)x.v[0] * (uint64_t)f) >> 32);
     if (out) out[i] = v;
     return v;
   }
@@ -594,14 +601,16 @@ extern "C" int ope_store_gather(const ope_dims* dims, int32_t capacity, const op
   return OPE_OK;
 }
 
-extern "C" int ope_store_gather_sampled(const ope_dims* dims, int32_t capacity, int32_t filled, const ope_fields* store, uint64_t seed,
-                                        const int32_t* counter, int32_t batch, const ope_fields* out, int64_t* inds_out, void* stream) {
+extern "C" int ope_store_gather_sampled(const ope_dims* dims, int32_t capacity, int32_t filled, const int32_t* filled_dev,
+                                        const ope_fields* store, uint64_t seed, const int32_t* counter, int32_t batch,
+                                        const ope_fields* out, int64_t* inds_out, void* stream) {
   (void)hipGetLastError();
-  if (capacity < 1 || filled < 1 || filled > capacity || batch < 1) return OPE_EINVAL;
+  if (capacity < 1 || batch < 1) return OPE_EINVAL;
+  if (!filled_dev && (filled < 1 || filled > capacity)) return OPE_EINVAL;
   CopyArgs args;
   int rc = build_args(dims, store, out, batch, capacity, true, &args);
   if (rc != OPE_OK) return rc;
-  launch_copy<true>(args, RngIdx{seed, counter, (uint32_t)filled, inds_out}, (hipStream_t)stream);
+  launch_copy<true>(args, RngIdx{seed, counter, (uint32_t)(filled > 0 ? filled : 1), filled_dev, (uint32_t)capacity, inds_out}, (hipStream_t)stream);
   OPE_CHECK_LAUNCH();
   return OPE_OK;
 }

@@ -35,7 +35,8 @@ class OneShotAllreduce(object):
     travel through torch.distributed.all_gather_object, every rank maps its peers' buffers, and `__call__` is ONE kernel
     launch on the current stream (push to all peers over xGMI, flag, wait, fixed-rank-order sum). Also usable with
     world == 1 (no process group needed): the vector makes a round trip through the own slot."""
-    MAX_FLOATS = 1 << 18      # 1 MiB slots: every flat gradient vector of the BASELINE configs is < 0.6 MB
+    MAX_FLOATS = 1 << 20      # 4 MiB slots: the BASELINE configs' flat gradients are < 0.6 MB, QMIX 3s5z with the wide
+    #                           --use_global_all_local_state centralized state (S = 2 232) is 2.5 MB
 
     def __init__(self, device, rank=0, world_size=1, max_floats=None, group=None, timeout_ms=0):
         import ctypes as C
@@ -83,7 +84,9 @@ class OneShotAllreduce(object):
 
     def __call__(self, flat):
         assert flat.dtype == torch.float32 and flat.is_contiguous() and flat.device == self.device and flat.numel() <= self.max_floats
-        self.epoch += 1
+        # the C-ABI takes a uint32 epoch and rejects 0; parity (= epoch & 1) picks the buffer half and must keep alternating, so
+        # the counter wraps over an EVEN cycle: 1, 2, ..., 0xFFFFFFFE, 1, ...
+        self.epoch = self.epoch % 0xFFFFFFFE + 1
         self._lib.check(self._lib.lib.ope_allreduce_flat(self._C.byref(self.ctx), self.epoch, self._lib.ptr(flat), flat.numel(),
                                                          self._lib.ptr(self.status), self._lib.current_stream()), "ope_allreduce_flat")
         return flat
@@ -115,8 +118,21 @@ def disable_fast_allreduce(reason="disabled"):
     """Back to torch.distributed's all_reduce (RCCL) for the rest of the run; call it on every rank."""
     global _fast, _fast_note
     if _fast is not None:
-        _fast = None
+        ar, _fast = _fast, None
         _fast_note = "rccl (one-shot xGMI path %s)" % reason
+        _close_after_barrier(ar)
+
+
+def _close_after_barrier(ar, group=None):
+    """Release a OneShotAllreduce that is no longer used: its uncached exchange buffer and the peers' IPC mappings. Every rank
+    calls this at the same point; the barrier makes sure no peer is still pushing into the buffer being freed."""
+    try:
+        if is_distributed():      # (also when THIS rank has nothing to free: its peers wait in the same barrier)
+            torch.distributed.barrier(group=group)
+        if ar is not None:
+            ar.close()
+    except Exception:      # tearing down a broken fast path must not take the (working) RCCL path with it
+        pass
 
 
 def allreduce_backend():
@@ -140,7 +156,7 @@ def setup_fast_allreduce(device, group=None):
     except Exception as e:     # allocation / IPC not available on this system
         ok, err = 0, repr(e)
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
-    for n in (118795, 5, 1 << 18):          # every rank runs the same collectives whatever its local state
+    for n in (118795, 5, 1 << 20):          # every rank runs the same collectives whatever its local state
         x = torch.randn(n, generator=g).to(device)
         ref = x.clone()
         torch.distributed.all_reduce(ref, op=torch.distributed.ReduceOp.SUM, group=group)
@@ -157,6 +173,7 @@ def setup_fast_allreduce(device, group=None):
         _fast = ar
         return True
     _fast_note = "rccl (one-shot xGMI path not verified: %s)" % (err or "another rank failed")
+    _close_after_barrier(ar, group)
     if rank == 0:
         print("[ope.dist] one-shot all-reduce disabled: %s" % (err or "another rank failed"), file=sys.stderr)
     if mode == "oneshot":

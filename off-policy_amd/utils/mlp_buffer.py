@@ -77,7 +77,7 @@ class MlpPolicyBuffer(object):
         """The 11-tuple of sample_inds for `batch_size` transitions drawn uniformly on the device (RecPolicyBuffer.sample_device),
         and the drawn indices."""
         inds = torch.empty(int(batch_size), dtype=torch.int64, device=self.device)
-        return self.sample_inds(inds, _sampler=(int(seed), counter, int(self.filled_i))), inds
+        return self.sample_inds(inds, _sampler=(int(seed), counter, self._ep._filled_device())), inds
 
     def sample_inds(self, sample_inds, timing_events=None, _sampler=None):
         """11-tuple of mlp_buffer.py:213-257: obs, share_obs, acts, rewards, next_obs, next_share_obs, dones, dones_env,

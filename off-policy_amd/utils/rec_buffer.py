@@ -186,6 +186,8 @@ class RecPolicyBuffer(object):
                                                  _lib.current_stream()), "ope_store_insert(share_obs)")
         self._keepalive = (staged, slots)   # until the stream has consumed them
         self._stats_dirty = True
+        if getattr(self, "_filled_dev", None) is not None:
+            self._filled_device()            # captured device-sampling graphs see the new slots from their next replay on
         return idx_range
 
     def check_indices(self):
@@ -216,7 +218,19 @@ class RecPolicyBuffer(object):
         replays with fresh indices as the counter advances. Returns (7-tuple as sample_inds, int64 device tensor of the drawn
         indices)."""
         inds = torch.empty(int(batch_size), dtype=torch.int64, device=self.device)
-        return self.sample_inds(inds, out=out, extra=extra, _sampler=(int(seed), counter, int(self.filled_i))), inds
+        return self.sample_inds(inds, out=out, extra=extra, _sampler=(int(seed), counter, self._filled_device())), inds
+
+    def _filled_device(self):
+        """DEVICE int32 [1] = number of filled slots, refreshed by every insert (stream-ordered): the device-sampling gather reads
+        it at run time, so a captured HIP graph of sample_device() keeps drawing from everything inserted since its capture."""
+        t = getattr(self, "_filled_dev", None)
+        if t is None:
+            t = self._filled_dev = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self._filled_dev_value = -1
+        if self._filled_dev_value != int(self.filled_i):
+            self._filled_dev_value = int(self.filled_i)
+            t.fill_(self._filled_dev_value)
+        return t
 
     def sample_inds(self, sample_inds, timing_events=None, out=None, extra=None, _sampler=None):
         """Gather the given episode slots; same 7-tuple as rec_buffer.py:192-240 (CUDA tensors, reference shapes).
@@ -251,9 +265,10 @@ class RecPolicyBuffer(object):
         if timing_events is not None:
             timing_events[0].record()
         if _sampler is not None:
-            seed, counter, filled = _sampler
+            seed, counter, filled_dev = _sampler
             assert self.use_same_share_obs, "device sampling: shared centralized observations only"
-            _lib.check(_lib.lib.ope_store_gather_sampled(C.byref(d), self.buffer_size, filled, C.byref(sf), seed, _lib.ptr(counter), B,
+            assert int(self.filled_i) >= 1, "sample_device on an empty buffer"
+            _lib.check(_lib.lib.ope_store_gather_sampled(C.byref(d), self.buffer_size, int(self.filled_i), _lib.ptr(filled_dev), C.byref(sf), seed, _lib.ptr(counter), B,
                                                          C.byref(of), _lib.ptr(dev_inds), _lib.current_stream()), "ope_store_gather_sampled")
         elif host_inds is not None:
             _lib.check(_lib.lib.ope_store_gather_host_inds(C.byref(d), self.buffer_size, C.byref(sf), host_inds.ctypes.data_as(C.c_void_p), B,

@@ -331,14 +331,14 @@ def test_materialised_actor_input_path_matches_reference_fixtures():
     assert " passed" in r.stdout
 
 
-@pytest.mark.parametrize("name", ["rmaddpg_multi_odd", "rmatd3_multi_tiny"])
+@pytest.mark.parametrize("name", ["rmaddpg_multi_odd", "rmatd3_multi_tiny", "rmaddpg_multi_hetero", "rmatd3_multi_hetero"])
 def test_multi_policy_updates_match_reference(name):
     """share_policy = False (scripts/train_mpe_rmaddpg.sh): one policy -- own actor, critic, targets, optimisers, buffer -- per
     group of agents; per step every policy is updated in turn, as the runner does. Fixtures from the real reference with groups
     [[0, 1], [2]] (MADDPG: a two-agent policy at offset 0, a one-agent policy at offset 2) and [[0], [1], [2]] (MATD3: target
     noise drawn per policy in get_update_info's order, actor updated every second call). Losses, gradient norms and the final
     parameters of all 4 networks of every policy."""
-    from test_rddpg_oracle_golden import multi_policy_ids
+    from test_rddpg_oracle_golden import multi_policy_ids, multi_obs_dims
     from offpolicy_amd.config import default_args
     from offpolicy_amd.utils.synth import policy_info_for
     from offpolicy_amd.utils.rec_buffer import RecReplayBuffer
@@ -360,7 +360,9 @@ def test_multi_policy_updates_match_reference(name):
         start += int(n)
     pagents = dict(zip(pids, groups))
     agent_pol = {a: p for p, gr in pagents.items() for a in gr}
-    pinfo = {p: policy_info_for(dims)["policy_0"] for p in pids}
+    # (`*_hetero`: the policies differ in observation width -- equal batch size and agent counts, different actor sizes: the
+    # per-policy workspace / gradient buffers of ADVICE r2)
+    pinfo = {p: dict(policy_info_for(dims)["policy_0"], obs_space=[od]) for p, od in zip(pids, multi_obs_dims(g))}
     dev = torch.device("cuda:0")
     torch.manual_seed(1)
     np.random.seed(1)
@@ -376,6 +378,7 @@ def test_multi_policy_updates_match_reference(name):
             mod.load_state_dict({k: torch.as_tensor(v) for k, v in sub(g, p + "/" + grp).items()})
     per_pol = {k: {p: (g["ep/" + k][:, :, pagents[p]] if (g["ep/" + k].ndim == 4 and g["ep/" + k].shape[2] == N) else g["ep/" + k]) for p in pids}
                for k in EP_KEYS}
+    per_pol["obs"] = {p: np.ascontiguousarray(per_pol["obs"][p][..., :od]) for p, od in zip(pids, multi_obs_dims(g))}
     r = buf.insert(len(g["idx_range"]), *[per_pol[k] for k in EP_KEYS])
     assert np.array_equal(r, g["idx_range"])
     sampled = {p: buf.policy_buffers[p].sample_inds(g["inds"]) for p in pids}

@@ -79,11 +79,16 @@ def test_policy_construction_reproduces_reference_rng_stream(name):
         assert np.array_equal(ref, crit[k])
 
 
-MULTI_CASES = ["rmaddpg_multi_odd", "rmatd3_multi_tiny"]
+MULTI_CASES = ["rmaddpg_multi_odd", "rmatd3_multi_tiny", "rmaddpg_multi_hetero", "rmatd3_multi_hetero"]
 
 
 def multi_policy_ids(g):
     return ["policy_%d" % i for i in range(len(g["groups"]))]
+
+
+def multi_obs_dims(g):
+    """Observation width of every policy (fixtures of round 3 on carry `obs_dims`; older ones share dims.obs_dim)."""
+    return [int(x) for x in g["obs_dims"]] if "obs_dims" in g else [int(g["dims"][2])] * len(g["groups"])
 
 
 def multi_batches(g):
@@ -92,11 +97,14 @@ def multi_batches(g):
     starts = np.cumsum([0] + groups)[:-1]
     inds = np.asarray(g["inds"])
     N = int(g["dims"][0])
+    obs_dims = multi_obs_dims(g)
     out = []
-    for s0, n in zip(starts, groups):
+    for s0, n, od in zip(starts, groups, obs_dims):
         fields = []
         for k in EP_KEYS:
             v = g["ep/" + k][:, inds]                                   # [T(+1), B, N, dim] or [T(+1), B, dim]
+            if k == "obs":
+                v = v[..., :od]                                         # policies may differ in observation width
             if v.ndim == 4 and v.shape[2] == N and k != "share_obs":
                 fields.append(np.ascontiguousarray(v[:, :, s0:s0 + n].transpose(2, 0, 1, 3)))
             elif k == "share_obs":
