@@ -32,9 +32,13 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="3s5z", choices=["3m", "3s5z", "MMM2", "maddpg_spread", "matd3_spread", "rmaddpg_3m", "rmatd3_3m", "rmaddpg_3s5z",
-                             "rmatd3_3s5z", "rmaddpg_MMM2", "rmatd3_MMM2"],
-                    help="QMIX-RNN on a SMAC map's dimensions (default 3s5z = the headline config), or MLP MADDPG/MATD3 on MPE simple_spread")
+    ap.add_argument("--workload", default="3s5z", choices=["3m", "3s5z", "MMM2", "3m_gall", "3s5z_gall", "MMM2_gall", "maddpg_spread", "matd3_spread",
+                             "rmaddpg_3m", "rmatd3_3m", "rmaddpg_3s5z", "rmatd3_3s5z", "rmaddpg_MMM2", "rmatd3_MMM2"],
+                    help="QMIX-RNN on a SMAC map's dimensions (default 3s5z = the headline config; <map>_gall = the configuration of the "
+                         "reference's scripts/train_smac_qmix.sh: --use_global_all_local_state, i.e. S = state + N * obs, --gain 1 and hard "
+                         "target updates every 200 steps instead of Polyak steps), or MLP MADDPG/MATD3 on MPE simple_spread")
+    ap.add_argument("--repeats", type=int, default=5, help="the K-step timed window (--steps) is measured this many times back to back, "
+                    "each bracketed by barrier + synchronize; `value` / `ms_per_step` are the MEDIAN window, min / max beside them")
     ap.add_argument("--batch", type=int, default=None, help="samples per training step on ONE GPU (weak) / in total (strong); "
                     "default 32 episodes (QMIX) or 256 transitions (MADDPG)")
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
@@ -86,7 +90,7 @@ def fill_buffer(buf, dims, n_episodes, rng):
         done += n
 
 
-def cpu_baseline(dims, batch, seconds, n_ep=256):
+def cpu_baseline(dims, batch, seconds, n_ep=256, gall=False):
     """Time the CPU path on this box's host cores on a bounded sample of the same workload: sample B of the same 256
     synthetic episodes + train step + soft update, with 1 thread (the reference's default n_training_threads,
     config.py:17) and with 8 / 32 threads; `value` = the fastest, as the >=10x target demands, and the 1-thread figure
@@ -99,7 +103,7 @@ def cpu_baseline(dims, batch, seconds, n_ep=256):
     from offpolicy_amd.algorithms.qmix.algorithm.agent_q_function import init_agent_values, AGENT_PARAM_NAMES
     from offpolicy_amd.algorithms.qmix.algorithm.q_mixer import init_mixer_values, MIXER_PARAM_NAMES
     torch.manual_seed(1)
-    agent = dict(zip(AGENT_PARAM_NAMES, init_agent_values(dims.obs_dim, dims.act_dim)))
+    agent = dict(zip(AGENT_PARAM_NAMES, init_agent_values(dims.obs_dim, dims.act_dim, gain_out=1.0 if gall else 0.01)))
     mixer = dict(zip(MIXER_PARAM_NAMES, init_mixer_values(dims.n_agents, dims.state_dim)))
     ep = synth_episodes(np.random.RandomState(0), n_ep, dims, avail="bernoulli")
     store = {k: (ep[k][:, :, 0] if k == "share_obs" else ep[k]) for k in ("obs", "share_obs", "acts", "rewards", "dones", "dones_env", "avail_acts")}
@@ -115,7 +119,7 @@ def cpu_baseline(dims, batch, seconds, n_ep=256):
         def step():
             inds = rng.choice(n_ep, batch)
             with O.reference_speed_ops():
-                orc.train_step(O.sample_inds(store, inds), fused_gru=True, soft_update=True)
+                orc.train_step(O.sample_inds(store, inds), fused_gru=True, soft_update=not gall)
         step()                                   # warm-up
         t0 = time.perf_counter()
         n = 0
@@ -204,6 +208,48 @@ def timed_steps(one_step, steps, warmup, world, dev, _retry=True):
     return elapsed, info
 
 
+def timed_windows(one_step, steps, warmup, world, dev, repeats):
+    """`repeats` consecutive K-step windows (each timed as timed_steps does); returns (sorted-independent list of seconds, info)."""
+    times, info = [], None
+    for r in range(max(1, repeats)):
+        el, info = timed_steps(one_step, steps, warmup if r == 0 else 0, world, dev)
+        times.append(el)
+    return times, info
+
+
+def median_window(times):
+    return float(np.median(np.asarray(times, dtype=np.float64)))
+
+
+def timing_block(windows, steps):
+    return {"windows": len(windows), "steps_per_window": steps, "statistic": "median",
+            "ms_per_step_windows": [round(1e3 * w / steps, 4) for w in windows],
+            "ms_per_step_min": round(1e3 * min(windows) / steps, 4), "ms_per_step_max": round(1e3 * max(windows) / steps, 4)}
+
+
+F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X dense f32 matrix (= packed f32 vector) peak, MI355X_MICROARCH.md
+
+
+def qmix_flop_per_step(dims, batch):
+    """Algorithmic FLOP of one QMIX-RNN update, SURVEY.md section 8(d): live forward + target forward + 2x for the live backward of the
+    agent network's GEMM-shaped layers over R = (T+1) N B rows and of the mixer over T B rows (LayerNorm / elementwise excluded)."""
+    N, A, D, S, T = dims.n_agents, dims.act_dim, dims.obs_dim, dims.state_dim, dims.episode_length
+    R = (T + 1) * N * batch
+    agent_mac = D * 64 + 64 * 64 + 6 * 64 * 64 + 64 * A
+    mixer_mac = (S * 64 + 64 * N * 32) + (S * 64 + 64 * 32) + S * 32 + (S * 64 + 64) + (N * 32 + 32)
+    return 4 * 2 * R * agent_mac + 4 * 2 * T * batch * mixer_mac
+
+
+def kernel_roofline_table(workload, batch):
+    """Per-kernel share of the f32 matrix roof for this workload from the committed table (profiles/kernel_roofline.json, written by
+    tools/kernel_roofline.py from a rocprofv3 kernel trace of this same command + the analytic FLOP of each kernel); None if absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "kernel_roofline.json")) as f:
+            return json.load(f)["entries"].get("%s:%d" % (workload, batch))
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def gather_profile(enable):
     from offpolicy_amd import _lib
     _lib.check(_lib.lib.ope_store_gather_profile(1 if enable else 0), "ope_store_gather_profile")
@@ -259,7 +305,8 @@ def main():
     import ctypes as C
 
     dims = DIMS[a.workload]
-    args = default_args()
+    gall = a.workload.endswith("_gall")  # scripts/train_smac_qmix.sh: wide state, head gain 1, hard target updates
+    args = default_args(gain=1.0, use_soft_update=False) if gall else default_args()
     torch.manual_seed(1)                 # identical initial weights on every rank
     np.random.seed(1)
     pinfo = policy_info_for(dims)
@@ -267,7 +314,7 @@ def main():
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):     # the trainer echoes the reference's "double Q learning will be used" line
         trainer = QMix(args, dims.n_agents, {"policy_0": policy}, lambda x: "policy_0", device=dev, episode_length=dims.episode_length)
-    trainer.fuse_soft_update = True      # Polyak inside the Adam kernel; soft_target_updates() below then skips
+    trainer.fuse_soft_update = not gall  # Polyak inside the Adam kernel; soft_target_updates() below then skips
     buf = RecReplayBuffer(pinfo, {"policy_0": list(range(dims.n_agents))}, a.episodes, dims.episode_length, True, True, device=dev)
     # every rank holds the SAME replay store (a full replica) and draws the same global index list
     # (same seed); rank r trains on its contiguous share of it (offpolicy_amd.dist.shard_indices)
@@ -283,6 +330,8 @@ def main():
         # HIP-graph replay of the training kernels (--graph; QMix.make_graphed_step) is 1-4 % SLOWER here (measured).
         graphed = trainer.make_graphed_step(buf, local_batch, gather_in_graph=False) if (a.graph and world == 1) else None
 
+        n_trained = [0]
+
         def one_step(i=None):
             inds = opdist.shard_indices(np.random.choice(len(buf), global_batch), rank, world)
             if graphed is not None:
@@ -290,13 +339,20 @@ def main():
             s = pbuf.sample_inds(inds)                       # ope_store_gather, current stream
             batch = tuple({"policy_0": x} for x in s) + (None, None)
             info, _, _ = trainer.train_policy_on_batch(batch)
-            trainer.soft_target_updates()
+            if args.use_soft_update:
+                trainer.soft_target_updates()
+            else:                                            # the runner's rule (base_runner.py:281-284), one train call per episode
+                n_trained[0] += 1
+                if n_trained[0] % args.hard_update_interval_episode == 0:
+                    with contextlib.redirect_stdout(sys.stderr):
+                        trainer.hard_target_updates()
             return info
         for _ in range(a.warmup):        # (timed_steps warms up again: these make the profiled window start warm)
             one_step(None)
         gather_profile(True)
-        elapsed, info = timed_steps(one_step, a.steps, 0, world, dev)
-        kernel_ms = gather_profile_read()[-a.steps:]
+        windows, info = timed_windows(one_step, a.steps, 0, world, dev, a.repeats)
+        elapsed = median_window(windows)
+        kernel_ms = gather_profile_read()[-a.steps * len(windows):]
         gather_profile(False)
         # for reference, the round-1 style measurement on 20 more gathers outside the timed region: two event markers around a launch
         for e0, e1 in ev[:20]:
@@ -307,7 +363,7 @@ def main():
         loss = float(info["loss"])
         assert np.isfinite(loss), "training diverged"
         results.append(dict(leg=leg, local_batch=local_batch, global_batch=global_batch, elapsed=elapsed, gather_ms=gather_ms, loss=loss,
-                            graphed=graphed is not None, bracket_ms=bracket_ms, n_kernel_ms=len(kernel_ms)))
+                            graphed=graphed is not None, bracket_ms=bracket_ms, n_kernel_ms=len(kernel_ms), windows=windows))
 
     if rank == 0:
         r0 = results[0]
@@ -322,10 +378,13 @@ def main():
             "value": round(value, 3), "unit": "training steps/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(1e3 * r0["elapsed"] / a.steps, 4), "higher_is_better": True, "scaling": r0["leg"],
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "timing": timing_block(r0["windows"], a.steps),
             "config": {"workload": "QMIX-RNN SMAC %s (N=%d A=%d D=%d S=%d T=%d), replay filled with %d synthetic episodes (%.2f GB "
-                                   "resident in HBM), step = sample + train_policy_on_batch + soft target update" % (
+                                   "resident in HBM), step = sample + train_policy_on_batch + %s" % (
                                        a.workload, dims.n_agents, dims.act_dim, dims.obs_dim, dims.state_dim, dims.episode_length,
-                                       a.episodes, store_gb),
+                                       a.episodes, store_gb, "soft target update" if args.use_soft_update else
+                                       "hard target update every %d steps (scripts/train_smac_qmix.sh: --use_global_all_local_state --gain 1 "
+                                       "--use_soft_update)" % args.hard_update_interval_episode),
                        "batch_per_gpu": r0["local_batch"], "global_batch": r0["global_batch"], "parallelism": "dp%d" % world,
                        "launch": "eager gather + HIP graph of the training kernels" if r0["graphed"] else "eager",
                        "allreduce": allreduce_name() if world > 1 else None,
@@ -345,6 +404,16 @@ def main():
                                                "the launch: the kernel plus two command-processor boundaries (what round 1 reported)",
                          "traffic_source": "profiles/gather_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)"},
         }
+        flop = qmix_flop_per_step(dims, r0["local_batch"])
+        tfs = flop / (r0["elapsed"] / a.steps) / 1e12
+        out["roofline_step"] = {
+            "bound": "mfma", "what": "the whole training step of one GPU against the dense f32 matrix peak (the step's GEMM-shaped work is f32 "
+                                     "MFMA 16x16x4; there is no xf32 / TF32 on gfx950 and bf16 would break the parity contract)",
+            "flop_per_step": int(flop), "flop_formula": "SURVEY.md 8(d): 4*[2*R*(D*64+64*64+6*64*64+64*A)] + 4*[2*T*B*mixerMAC], R=(T+1)*N*B",
+            "achieved": round(tfs, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tfs / F32_MFMA_PEAK_TFLOPS, 4),
+            "per_kernel": kernel_roofline_table(a.workload, r0["local_batch"]),
+            "per_kernel_source": "profiles/kernel_roofline.json (tools/kernel_roofline.py: rocprofv3 --kernel-trace of this command + analytic "
+                                 "FLOP per kernel; MFMA-busy from the --pmc passes under profiles/r03_pmc/)"}
         if len(results) > 1:
             r1 = results[1]
             sps1 = a.steps / r1["elapsed"]
@@ -353,7 +422,7 @@ def main():
                 "batch_per_gpu": r1["local_batch"], "global_batch": r1["global_batch"], "ms_per_step": round(1e3 * r1["elapsed"] / a.steps, 4),
                 "optimizer_steps_per_sec": round(sps1, 3), "steps": a.steps, "warmup": a.warmup}
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(dims, a.batch, a.cpu_seconds, min(a.episodes, 256))
+            out["cpu_baseline"] = cpu_baseline(dims, a.batch, a.cpu_seconds, min(a.episodes, 256), gall=gall)
             out["config"]["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -474,7 +543,8 @@ def main_ddpg(a):
             info, _, _ = trainer.shared_train_policy_on_batch("policy_0", tuple({"policy_0": x} for x in s_) + (None, None))
             policy.soft_target_updates()
             return info
-        elapsed, info = timed_steps(one_step, a.steps // spr, a.warmup // spr, world, dev)      # spr steps per call
+        windows, info = timed_windows(one_step, a.steps // spr, a.warmup // spr, world, dev, a.repeats)      # spr steps per call
+        elapsed = median_window(windows)
         if graphed is not None:    # the gather inside the graph cannot carry events: time the same launch on its own afterwards
             ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(50)]
             for e in ev:
@@ -482,7 +552,7 @@ def main_ddpg(a):
             torch.cuda.synchronize()
         gather_ms = float(np.mean([s_.elapsed_time(e) for s_, e in ev]))
         assert np.isfinite(float(info["critic_loss"]))
-        results.append(dict(leg=leg, local_batch=local_batch, global_batch=global_batch, elapsed=elapsed, gather_ms=gather_ms))
+        results.append(dict(leg=leg, local_batch=local_batch, global_batch=global_batch, elapsed=elapsed, gather_ms=gather_ms, windows=windows))
     if rank == 0:
         r0 = results[0]
         # algorithmic bytes of the transition gather: every field of a transition once in, once out (964 B/transition)
@@ -494,7 +564,7 @@ def main_ddpg(a):
         out = {"metric": "training steps/sec (batch=%d) %s-MLP simple_spread" % (batch, "MATD3" if td3 else "MADDPG"),
                "value": round(value, 2), "unit": "training steps/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(1e3 * r0["elapsed"] / a.steps, 4), "higher_is_better": True, "scaling": r0["leg"], "vs_baseline": None,
-               "dtype": "f32", "data": "synthetic",
+               "dtype": "f32", "data": "synthetic", "timing": timing_block(r0["windows"], a.steps),
                "config": {"workload": "%s-MLP MPE simple_spread (N=%d A=%d D=%d S=%d), replay filled with %d synthetic transitions, "
                                       "step = sample + critic update + actor update + soft target updates; reference semantics "
                                       "(frozen critic heads A-4, actor updated every call A-5); gumbel noise drawn on the %s; %s" % (
@@ -627,7 +697,8 @@ def main_rddpg(a):
             buf.update_priorities(idxes, opdist.allgather_cat(prio), "policy_0")
             policy.soft_target_updates()
             return info
-        elapsed, info = timed_steps(one_step, a.steps, a.warmup, world, dev)
+        windows, info = timed_windows(one_step, a.steps, a.warmup, world, dev, a.repeats)
+        elapsed = median_window(windows)
         assert np.isfinite(float(info["critic_loss"]))
         # gather roofline leg measured on its own (same launch, HIP events on the launch stream)
         pbuf = buf.policy_buffers["policy_0"]
@@ -637,7 +708,7 @@ def main_rddpg(a):
         torch.cuda.synchronize()
         gather_ms = float(np.mean(gather_profile_read()))
         gather_profile(False)
-        results.append(dict(leg=leg, local_batch=local_batch, global_batch=global_batch, elapsed=elapsed, gather_ms=gather_ms))
+        results.append(dict(leg=leg, local_batch=local_batch, global_batch=global_batch, elapsed=elapsed, gather_ms=gather_ms, windows=windows))
     if not results:
         raise SystemExit("[bench] --episodes %d is too small for prioritized sampling of a global batch of %d: nothing was measured" % (a.episodes, batch))
     if rank == 0:
@@ -652,7 +723,7 @@ def main_rddpg(a):
         out = {"metric": "training steps/sec (batch=%d) %s-RNN + PER %s" % (batch, name, mapname),
                "value": round(value, 3), "unit": "training steps/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(1e3 * r0["elapsed"] / a.steps, 4), "higher_is_better": True, "scaling": r0["leg"], "vs_baseline": None,
-               "dtype": "f32", "data": "synthetic",
+               "dtype": "f32", "data": "synthetic", "timing": timing_block(r0["windows"], a.steps),
                "config": {"workload": "%s-RNN + prioritized replay, SMAC %s (N=%d A=%d D=%d S=%d T=%d), replay filled with %d synthetic "
                                       "episodes (%.2f GB resident in HBM), step = PER sample + critic update + actor update (every %d) + "
                                       "update_priorities + soft target updates; gumbel noise drawn on the %s; PER trees on the %s" % (

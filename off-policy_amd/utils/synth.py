@@ -20,6 +20,11 @@ DIMS = {
     "MMM2": EnvDims("MMM2", 10, 18, 370, 322, 180),
     "simple_spread": EnvDims("simple_spread", 3, 5, 18, 54, 25),
 }
+# --use_global_all_local_state (what the reference's QMIX-SMAC launch script runs, scripts/train_smac_qmix.sh:17): the centralized
+# state also carries every agent's local observation, S = state + N * obs (StarCraft2_Env.py:1314-1315)
+for _m in ("3m", "3s5z", "MMM2"):
+    _d = DIMS[_m]
+    DIMS[_m + "_gall"] = EnvDims(_m + "_gall", _d.n_agents, _d.act_dim, _d.obs_dim, _d.state_dim + _d.n_agents * _d.obs_dim, _d.episode_length)
 
 
 def synth_episodes(rng, num_episodes, dims, avail="ones", runner_padding=False):

@@ -70,7 +70,10 @@ def named(module, prefix):
 
 
 def run_case(name, dims, n_episodes, inds, steps=3, argv=(), vdn=False, avail="ones", runner_padding=False,
-             per_weights=None, store_inputs=True, cap=None, pre_insert=0, per_agent_share=False, **over):
+             per_weights=None, store_inputs=True, cap=None, pre_insert=0, per_agent_share=False, hard_update_after=(), **over):
+    """`hard_update_after`: with `--use_soft_update` given (which turns soft updates OFF, config.py:125) the runner copies the
+    live networks into the targets every `hard_update_interval_episode` episodes instead (base_runner.py:279-284); here: after
+    the listed (0-based) train steps."""
     if per_agent_share:      # every agent has its own centralized observation; QMix's mixer reads agent 0's (qmix.py:86-90)
         over = dict(over, use_same_share_obs=False)
     args, pinfo, policy, trainer = build(dims, argv, vdn=vdn, **over)
@@ -122,6 +125,8 @@ def run_case(name, dims, n_episodes, inds, steps=3, argv=(), vdn=False, avail="o
     out["vdn"] = np.int64(vdn)
     out["hp_prev_act_inp"] = np.int64(bool(getattr(args, "prev_act_inp", False)))
     out["hp_same_share"] = np.int64(not per_agent_share)
+    out["hp_soft_update"], out["hp_gain"] = np.int64(bool(args.use_soft_update)), np.float64(args.gain)
+    out["hard_update_after"] = np.asarray(list(hard_update_after), dtype=np.int64)
     losses, gnorms, qtots, prios = [], [], [], []
     for s in range(steps):
         batch = tuple({"policy_0": a} for a in sampled) + (per_weights, inds if per_weights is not None else None)
@@ -134,7 +139,10 @@ def run_case(name, dims, n_episodes, inds, steps=3, argv=(), vdn=False, avail="o
             if not vdn:
                 for k, v in trainer.mixer.named_parameters():
                     out["grad0/mixer/" + k] = v.grad.detach().numpy().copy()
-        trainer.soft_target_updates()
+        if args.use_soft_update:
+            trainer.soft_target_updates()
+        elif s in hard_update_after:
+            trainer.hard_target_updates()
         losses.append(float(info["loss"])), gnorms.append(float(info["grad_norm"])), qtots.append(float(info["Q_tot"]))
         if new_prio is not None:
             prios.append(np.asarray(new_prio, dtype=np.float64))
@@ -158,6 +166,22 @@ def run_case(name, dims, n_episodes, inds, steps=3, argv=(), vdn=False, avail="o
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     tiny = DIMS["tiny"]
+    if os.environ.get("OPE_GOLDEN_ONLY") == "gall":
+        # round 3: the configuration the reference's ONLY QMIX-SMAC launch script runs (scripts/train_smac_qmix.sh:14-17):
+        # --use_global_all_local_state (the centralized state carries every agent's observation too: S = s + N * D,
+        # StarCraft2_Env.py:1314-1315), --gain 1 (head initialised with gain 1 instead of 0.01, act.py:10-12) and --use_soft_update
+        # (a store_false flag: hard target copies every hard_update_interval_episode episodes instead of Polyak steps)
+        gall = ["--gain", "1", "--use_soft_update"]
+        t = tiny
+        run_case("qmix_gall_tiny", EnvDims("tiny_gall", t.n_agents, t.act_dim, t.obs_dim, t.state_dim + t.n_agents * t.obs_dim, t.episode_length),
+                 n_episodes=5, inds=[3, 0, 4, 3], cap=6, pre_insert=3, avail="bernoulli", steps=4, argv=gall, hard_update_after=(1,))
+        m = DIMS["3m"]
+        run_case("qmix_gall_3m", EnvDims("3m_gall", m.n_agents, m.act_dim, m.obs_dim, m.state_dim + m.n_agents * m.obs_dim, 12),
+                 n_episodes=7, inds=[6, 1, 2, 2, 0, 5], avail="bernoulli", runner_padding=True, steps=4, argv=gall, hard_update_after=(1,))
+        # an odd wide state (nothing a multiple of 4 or 2): the unaligned paths of the wide-state kernels
+        run_case("qmix_gall_odd", EnvDims("odd_gall", 3, 7, 18, 29 + 3 * 18, 5), n_episodes=6, inds=[5, 1, 1, 2, 0], avail="bernoulli", steps=3,
+                 argv=gall, hard_update_after=(0,))
+        return
     if os.environ.get("OPE_GOLDEN_ONLY") == "pershare":      # add the round-2 fixture without rewriting the committed ones
         run_case("qmix_tiny_pershare", tiny, n_episodes=5, inds=[4, 1, 1, 0, 2], cap=6, pre_insert=3, avail="bernoulli", per_agent_share=True)
         return

@@ -14,6 +14,8 @@ def make_args(g, **over):
                      max_grad_norm=float(g["hp_maxnorm"]), use_double_q=bool(g["hp_double_q"]),
                      prev_act_inp=bool(g["hp_prev_act_inp"]) if "hp_prev_act_inp" in g else False,
                      use_same_share_obs=bool(g["hp_same_share"]) if "hp_same_share" in g else True)
+    if "hp_gain" in g:
+        a.gain, a.use_soft_update = float(g["hp_gain"]), bool(g["hp_soft_update"])
     for k, v in over.items():
         setattr(a, k, v)
     return a

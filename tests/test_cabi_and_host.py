@@ -49,7 +49,7 @@ def test_null_arguments_are_rejected_without_a_gpu():
     assert _lib.lib.ope_store_gather(C.byref(d), 4, None, None, 2, None, None, None) == -1
 
 
-@pytest.mark.parametrize("name", ["qmix_tiny", "qmix_3m_katA", "qmix_odd"])
+@pytest.mark.parametrize("name", ["qmix_tiny", "qmix_3m_katA", "qmix_odd", "qmix_gall_tiny", "qmix_gall_3m"])
 def test_initialisation_reproduces_reference_rng_stream(name):
     """torch.manual_seed(1) + our constructors' init draws == the reference modules' initial weights, bit for bit."""
     import torch
@@ -59,7 +59,7 @@ def test_initialisation_reproduces_reference_rng_stream(name):
     n, a, d, s, t = [int(x) for x in g["dims"]]
     torch.manual_seed(1)
     np.random.seed(1)
-    av = init_agent_values(d, a)
+    av = init_agent_values(d, a, gain_out=float(g["hp_gain"]) if "hp_gain" in g else 0.01)     # --gain: the head's init gain (act.py:10-12)
     mv = init_mixer_values(n, s)
     for v, k in zip(av, AGENT_PARAM_NAMES):
         assert np.array_equal(v.numpy(), g["agent/" + k]), k

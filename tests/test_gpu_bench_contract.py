@@ -40,6 +40,20 @@ def test_default_workload_line_has_roofline_and_cpu_baseline():
     cb = out["cpu_baseline"]
     assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] in ("reference", "port") and isinstance(cb["sample"], str) and cb["unit"] == out["unit"]
     assert out["value"] > 10 * cb["value"]                                           # the north-star bar, even on the tiny map
+    tm = out["timing"]                                                               # K steps timed `--repeats` times, median reported
+    assert tm["windows"] == 5 and tm["steps_per_window"] == 6 and len(tm["ms_per_step_windows"]) == 5
+    assert tm["ms_per_step_min"] <= out["ms_per_step"] <= tm["ms_per_step_max"]
+    rs = out["roofline_step"]                                                        # the whole step against the f32 matrix peak
+    assert rs["bound"] == "mfma" and rs["peak"] == 157.3 and rs["flop_per_step"] == 4 * 2 * (61 * 3 * 32 * (64 * 64 + 64 * 64 + 6 * 64 * 64 + 64 * 9)
+                                                                                      + 60 * 32 * ((48 * 64 + 64 * 96) + (48 * 64 + 64 * 32) + 48 * 32 + (48 * 64 + 64) + (96 + 32)))
+    assert abs(rs["frac"] - rs["achieved"] / rs["peak"]) < 1e-3 and abs(rs["achieved"] - rs["flop_per_step"] / out["ms_per_step"] / 1e9) < 0.02 * rs["achieved"]
+
+
+def test_gall_workload_line():
+    """The reference's own QMIX-SMAC launch configuration (scripts/train_smac_qmix.sh): wide state, gain 1, hard target updates."""
+    out = run_bench("--workload", "3m_gall", "--episodes", "64", "--steps", "6", "--warmup", "2", "--repeats", "2", "--no-cpu-baseline")
+    check_common(out, 6, 2)
+    assert "S=240" in out["config"]["workload"] and "hard target update" in out["config"]["workload"]
 
 
 def test_maddpg_workload_line_graph_and_eager():

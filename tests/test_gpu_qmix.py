@@ -12,7 +12,8 @@ from golden_util import oracle_from, reference_store_from
 from gpu_util import build_from_fixture, batch_from
 
 pytestmark = pytest.mark.gpu
-CASES = ["qmix_tiny", "qmix_tiny_huber_per", "qmix_tiny_nodouble", "vdn_tiny", "qmix_odd", "qmix_3m_katA", "qmix_tiny_prevact", "qmix_tiny_pershare"]
+CASES = ["qmix_tiny", "qmix_tiny_huber_per", "qmix_tiny_nodouble", "vdn_tiny", "qmix_odd", "qmix_3m_katA", "qmix_tiny_prevact", "qmix_tiny_pershare",
+         "qmix_gall_tiny", "qmix_gall_3m", "qmix_gall_odd"]   # gall: scripts/train_smac_qmix.sh (wide state, gain 1, hard target updates)
 RTOL = 1e-4
 
 
@@ -36,6 +37,8 @@ def test_train_steps_match_reference(name):
     dims, buf, policy, trainer = build_from_fixture(g)
     w = g["per_weights"] if "per_weights" in g else None
     batch = batch_from(buf, g["inds"], w)
+    soft = bool(g["hp_soft_update"]) if "hp_soft_update" in g else True
+    hard_after = set(int(x) for x in g["hard_update_after"]) if "hard_update_after" in g else set()
     for s in range(len(g["loss"])):
         info, prio, _ = trainer.train_policy_on_batch(batch)
         if s == 0:
@@ -48,7 +51,10 @@ def test_train_steps_match_reference(name):
             for k in got:
                 if ".fc_h." in k:
                     assert not np.any(got[k]), k
-        trainer.soft_target_updates()
+        if soft:
+            trainer.soft_target_updates()
+        elif s in hard_after:                 # --use_soft_update given (= off): the runner's hard copy, base_runner.py:281-284
+            trainer.hard_target_updates()
         np.testing.assert_allclose(float(info["loss"]), g["loss"][s], rtol=RTOL)
         np.testing.assert_allclose(float(info["grad_norm"]), g["grad_norm"][s], rtol=RTOL)
         np.testing.assert_allclose(float(info["Q_tot"]), g["Q_tot"][s], rtol=RTOL, atol=1e-6)
@@ -171,10 +177,12 @@ def test_policy_forward_with_previous_action_input():
     np.testing.assert_allclose(h.cpu().numpy(), h_ref.numpy(), rtol=1e-4, atol=2e-6)
 
 
-@pytest.mark.parametrize("workload,nb", [("3s5z", 32), ("MMM2", 8)])
+@pytest.mark.parametrize("workload,nb", [("3s5z", 32), ("MMM2", 8), ("3s5z_gall", 32), ("MMM2", 32)])
 def test_full_size_3s5z_matches_oracle_one_step(workload, nb):
-    """BASELINE config 4 at full size (N=8, A=14, D=252, S=216, T=150, B=32): one step vs the oracle; and the MMM2
-    dimensions (N=10, A=18, D=370, S=322, T=180: 8-byte vector paths, the 24-chunk trunk) at B=8."""
+    """BASELINE config 4 at full size (N=8, A=14, D=252, S=216, T=150, B=32): one step vs the oracle; the MMM2
+    dimensions (N=10, A=18, D=370, S=322, T=180: 8-byte vector paths, the 24-chunk trunk) at B=8 and at B=32; and 3s5z as the
+    reference's own launch script runs it (scripts/train_smac_qmix.sh:14-17: --use_global_all_local_state -> S = 216 + 8 * 252 =
+    2 232, --gain 1, hard target updates), B=32: the wide-state mixer kernels at their real size."""
     from oracle import qmix_oracle as O
     from offpolicy_amd.config import default_args
     from offpolicy_amd.utils.synth import DIMS, synth_episodes, policy_info_for, as_policy_dicts
@@ -182,7 +190,7 @@ def test_full_size_3s5z_matches_oracle_one_step(workload, nb):
     from offpolicy_amd.algorithms.qmix.algorithm.QMixPolicy import QMixPolicy
     from offpolicy_amd.algorithms.qmix.qmix import QMix
     dims = DIMS[workload]
-    args = default_args()
+    args = default_args(gain=1.0, use_soft_update=False) if workload.endswith("_gall") else default_args()
     torch.manual_seed(1)
     np.random.seed(1)
     dev = torch.device("cuda:0")
