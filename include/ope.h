@@ -173,6 +173,18 @@ typedef struct ope_qmix_cfg {
                          *         joint one) and the activations phase 1 left; writes grad[0 .. P_agent) and NO tail
                          *    The flat vectors of such a trainer are [agent_0 | agent_1 | ... | mixer | tail]; the joint call
                          *    gets theta / grad advanced by (mixer offset - agent_0 length) so that its mixer block lines up. */
+  /* Per-trainer tuning / diagnostics (all 0 = defaults). These travel with the cfg of every call, so two trainers in one process
+   * do not share them (the process-wide setters below and the environment variables only provide the DEFAULTS, read once). The
+   * workspace size depends on mixer_path and time_chunks: use the same values for ope_qmix_workspace_bytes / _init / _find and the
+   * step calls. */
+  int32_t mixer_path;   /* forward mixer kernel: 0 = by shape; 1 = hyper-network weights resident in registers (mixer_fwd3; needs
+                         *  state_dim <= 224, % 4 == 0, <= 8 agents, else falls to 2); 2 = weights streamed per 16-row workgroup
+                         *  (mixer_fwd2); 3 = wide-state form: the first hyper-layers as one stream-K GEMM (ope_mixer_wide.hip;
+                         *  what "by shape" picks for state_dim > 256, e.g. --use_global_all_local_state) */
+  int32_t time_chunks;  /* recurrent nets: time chunks of the two-stream schedule (1 = whole episodes on one stream, the default) */
+  int32_t scan_family;  /* GRU scan kernels: 4 = ope_gru4.hip, 1 = ope_gru1.hip, 0 = by row count                                  */
+  int32_t scan_waves;   /* family 4: compute waves per row, 2 | 4, 0 = by row count                                                */
+  int32_t debug;        /* 1: keep extra intermediates and per-wave phase stamps in the workspace ("q_all", "dbg")               */
 } ope_qmix_cfg;
 
 /* Flat parameter vector: the reference's named_parameters() order (agent q-network, then mixer; qmix.py:67-72),
@@ -189,10 +201,10 @@ int64_t ope_qmix_workspace_bytes(const ope_qmix_cfg* cfg);
 /* One-time initialisation of a freshly allocated workspace (constant regions the kernels only read). Must be called
  * once per workspace buffer before the first ope_qmix_loss_and_grad on it. */
 int ope_qmix_workspace_init(const ope_qmix_cfg* cfg, void* workspace, int64_t workspace_bytes, void* stream);
-/* Diagnostics (tests, tools/): ope_set_debug(1) makes the step functions keep extra intermediates and per-wave phase
- * stamps in the workspace ("q_all", "dbg"). ope_set_scan_kernel(family, waves) pins the GRU-scan kernel family
- * (4: ope_gru4.hip, 1: ope_gru1.hip, 0: by row count) and, for family 4, the compute waves per row (2, 4, 0: by row
- * count); the environment variables OPE_GRU / OPE_GRU4_W set the initial values. */
+/* Process-wide DEFAULTS of the diagnostics above, for callers without a cfg of their own (the recurrent MADDPG entry points share
+ * the scan kernels) and for tools: ope_set_debug(1) = ope_qmix_cfg.debug for every call; ope_set_scan_kernel(family, waves) =
+ * scan_family / scan_waves; the environment variables OPE_GRU / OPE_GRU4_W / OPE_CHUNKS / OPE_MIXER_PERSIST set initial values,
+ * read ONCE. A non-zero field of the cfg always wins. */
 void ope_set_debug(int on);
 void ope_set_scan_kernel(int family, int waves_per_row);
 

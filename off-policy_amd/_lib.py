@@ -34,7 +34,9 @@ class Fields(C.Structure):
 class QmixCfg(C.Structure):
     _fields_ = [("dims", Dims), ("batch", C.c_int32), ("vdn", C.c_int32), ("use_double_q", C.c_int32),
                 ("use_huber", C.c_int32), ("use_per", C.c_int32), ("gamma", C.c_float), ("huber_delta", C.c_float),
-                ("per_nu", C.c_float), ("per_eps", C.c_float), ("mlp", C.c_int32), ("phase", C.c_int32)]
+                ("per_nu", C.c_float), ("per_eps", C.c_float), ("mlp", C.c_int32), ("phase", C.c_int32),
+                ("mixer_path", C.c_int32), ("time_chunks", C.c_int32), ("scan_family", C.c_int32), ("scan_waves", C.c_int32),
+                ("debug", C.c_int32)]
 
 
 class AdamCfg(C.Structure):

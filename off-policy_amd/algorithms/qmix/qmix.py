@@ -74,6 +74,10 @@ class QMix(object):
         self.multi = self.policy_ids != ["policy_0"] or len(self.policy_agents["policy_0"]) != num_agents
         self.fuse_soft_update = False       # True: Polyak inside ope_adam_step; soft_target_updates() then skips once
         self._polyak_done = False
+        # per-trainer kernel choices / diagnostics, sent with every call in ope_qmix_cfg (0 = the library's choice by shape): two
+        # trainers in one process do not share them. `mixer_path`: 1 resident-weight mixer, 2 streamed, 3 wide-state GEMM;
+        # `time_chunks`: two-stream schedule; `scan_family` / `scan_waves`: GRU scan kernels; `debug`: keep intermediates.
+        self.tune = dict(mixer_path=0, time_chunks=0, scan_family=0, scan_waves=0, debug=0)
         self._ws = {}
         self._gsq = {}
         if self.multi:
@@ -279,10 +283,17 @@ class QMix(object):
         cfg.gamma, cfg.huber_delta = float(a.gamma), float(a.huber_delta)
         cfg.per_nu, cfg.per_eps = float(a.per_nu), float(a.per_eps)
         cfg.mlp = int(self._mlp)
+        t = self.tune
+        cfg.mixer_path, cfg.time_chunks = int(t["mixer_path"]), int(t["time_chunks"])
+        cfg.scan_family, cfg.scan_waves, cfg.debug = int(t["scan_family"]), int(t["scan_waves"]), int(t["debug"])
         return cfg
 
     def _workspace(self, cfg):
         B = cfg.batch
+        shape_key = (cfg.mixer_path, cfg.time_chunks)       # the workspace plan depends on these two
+        if self._ws.get("_key") != shape_key:
+            self._ws = {"_key": shape_key}
+            self._gsq = {}
         if B not in self._ws:
             need = _lib.lib.ope_qmix_workspace_bytes(C.byref(cfg))
             if need < 0:

@@ -61,6 +61,8 @@ struct GruFwdArgs {
   long long* dbg;                       // optional per-compute-wave phase cycle sums [rows][4][8] (ope_set_debug; gru4 only)
   int whh_off, bhh_off;
   float* rg; float* zg; float* ng; float* ghn;  // [L][NB][64] gate saves (live) or null
+  int family, waves;                    // scan kernel family (4 | 1) / compute waves per row (4 | 2) asked for by the caller's cfg;
+                                        // 0 = the process default (ope_set_scan_kernel / OPE_GRU, OPE_GRU4_W), then by row count
 };
 
 struct HeadFwdArgs {
@@ -110,6 +112,7 @@ struct GruBwdArgs {
   const float* dh_in;  // [NB][64] adjoint carried in from the later chunk, or null (zeros)
   float* dh_carry;     // [NB][64] adjoint w.r.t. h_{t_lo - 1} handed to the earlier chunk, or null
   long long* dbg;      // optional per-compute-wave phase cycle sums [NB][4][8] (ope_set_debug; gru4 only)
+  int family, waves;   // as GruFwdArgs
 };
 
 struct TrunkBwdArgs {

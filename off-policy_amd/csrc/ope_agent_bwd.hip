@@ -24,7 +24,8 @@ int launch_head_bwd(const HeadBwdArgs& a, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------------------
 int launch_gru_bwd(const GruBwdArgs& a, hipStream_t st) {
   if (a.NB < 1 || a.T < 1 || a.t_lo < 0 || a.t_lo >= a.T) return OPE_EINVAL;
-  const int kind = g_scan_family ? g_scan_family : (a.NB <= kGru4MaxRows ? 4 : 1);
+  const int want = (a.family == 1 || a.family == 4) ? a.family : g_scan_family;
+  const int kind = want ? want : (a.NB <= kGru4MaxRows ? 4 : 1);
   return kind == 4 ? launch_gru_bwd4(a, st) : launch_gru_bwd1(a, st);
 }
 

@@ -246,7 +246,8 @@ int g_scan_waves = env_choice("OPE_GRU4_W", 2, 4);
 int launch_gru_fwd(const GruFwdArgs& a, hipStream_t st) {
   if (a.nets < 1 || a.nets > 2 || a.NB < 1 || a.L < 1) return OPE_EINVAL;
   const int64_t rows = (int64_t)a.nets * a.NB;
-  const int kind = g_scan_family ? g_scan_family : (rows <= kGru4MaxRows ? 4 : 1);
+  const int want = (a.family == 1 || a.family == 4) ? a.family : g_scan_family;
+  const int kind = want ? want : (rows <= kGru4MaxRows ? 4 : 1);
   return kind == 4 ? launch_gru_fwd4(a, st) : launch_gru_fwd1(a, st);
 }
 

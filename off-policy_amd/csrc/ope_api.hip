@@ -11,12 +11,14 @@ using namespace ope;
 namespace {
 
 int g_debug = 0;
+constexpr int kMaxChunksCfg = 8;
 
 bool cfg_ok(const ope_qmix_cfg* c) {
   if (!c) return false;
   const ope_dims& d = c->dims;
   if (c->mlp && d.episode_length != 1) return false;   // MLP (transition) mode = one-step "episodes"
   if (c->phase < 0 || c->phase > 3) return false;
+  if (c->mixer_path < 0 || c->mixer_path > 3 || c->time_chunks < 0 || c->time_chunks > kMaxChunksCfg) return false;
   return d.n_agents >= 1 && d.act_dim >= 1 && d.obs_dim >= 1 && d.obs_dim <= 512 && d.state_dim >= 1 &&
          d.episode_length >= 1 && c->batch >= 1 && d.n_agents <= 64 && d.act_dim <= 200;
 }
@@ -70,8 +72,9 @@ struct Plan {
   int64_t mu0, rstd0, xhat1, rstd1, mask1, xhat2, rstd2, mask2, gi, h, rg, zg, ng, ghn, xhat_o, rstd_o, act_idx,
       agent_q, agent_nq, gi_t, h_t, qtot, nqtot, hw1, hw2, hb2, v1, hpre, v2, loss_part, err_abs, dqtot, d_agent_q,
       d_b1, d_v2, d_v1, d_hw1, d_hw2, d_hb2, dh_out, dqoh, dgi, dghn, dz1, dz2, thetaT, mixT, raw_agent, raw_mixer,
-      rsum, q_all, loss_tot, ln_zero, ln_one, dh_carry, dbg, gsq_part;
+      rsum, q_all, loss_tot, ln_zero, ln_one, dh_carry, dbg, gsq_part, mix_slab;
   int n_gsq;
+  bool wide;
 };
 
 int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
@@ -119,8 +122,8 @@ void make_plan(const ope_qmix_cfg* c, Plan* p) {
     // (0.61 -> 0.73 ms at C = 2, 1.0 ms at C = 4), and kernels run side by side slow each other down about as much as
     // the overlap saves (BPTT beside a weight-gradient launch: 80 -> 150 us). Default: whole episodes, one stream; the
     // chunked two-stream schedule stays available for larger batches (OPE_CHUNKS).
-    int C = 1;
-    if (const char* e = getenv("OPE_CHUNKS")) C = atoi(e);
+    static const int env_chunks = getenv("OPE_CHUNKS") ? atoi(getenv("OPE_CHUNKS")) : 1;    // process default, read once
+    int C = c->time_chunks > 0 ? c->time_chunks : env_chunks;
     C = clampi(C, 1, kMaxChunks);
     const int L = p->T + 1;
     if (c->mlp || c->phase) C = 1;
@@ -171,6 +174,9 @@ void make_plan(const ope_qmix_cfg* c, Plan* p) {
   p->rsum = W.add("rsum", (int64_t)w.agent_end + w.mixer_size + 4);
   p->q_all = W.add("q_all", R * p->A);
   p->dbg = W.add("dbg", 2 * 16 * 4096 + 2 * 16 * 2400);   // per-wave s_memtime stamps (ope_set_debug)
+  // wide-state mixer (ope_mixer_wide.hip): stream-K partial sums of the first hyper-layers
+  p->wide = !c->vdn && c->phase != 1 && c->phase != 3 && (c->mixer_path == 3 || (c->mixer_path == 0 && p->S > kWideAutoS));
+  p->mix_slab = p->wide ? W.add("mix_slab", wide_slab_floats((int)p->TB, p->S)) : -1;
 }
 
 }  // namespace
@@ -257,6 +263,7 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
   // "agent_nq" in the workspace), 2 = mixer + TD loss + mixer gradients only (reads "agent_q" / "agent_nq" the caller
   // assembled, leaves "d_agent_q"), 3 = agent networks backward only (reads "d_agent_q"). 0 = the whole step.
   const int phase = cfg->phase;
+  const int dbg_on = g_debug | cfg->debug;      // per-call request or the process default
   const bool do_fwd = phase == 0 || phase == 1, do_mix = phase == 0 || phase == 2, do_bwd = phase == 0 || phase == 3;
   if ((do_fwd || do_bwd) && (!batch->obs || !batch->acts)) return OPE_EINVAL;
   if (do_mix && (!batch->share_obs || !batch->rewards || !batch->dones_env)) return OPE_EINVAL;
@@ -304,7 +311,7 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
     tf.mu0 = W + p.mu0 + r0; tf.rstd0 = W + p.rstd0 + r0;
     tf.xhat1 = W + p.xhat1 + r0 * OPE_H; tf.rstd1 = W + p.rstd1 + r0; tf.mask1 = (uint64_t*)(W + p.mask1) + r0;
     tf.xhat2 = W + p.xhat2 + r0 * OPE_H; tf.rstd2 = W + p.rstd2 + r0; tf.mask2 = (uint64_t*)(W + p.mask2) + r0;
-    tf.dbg = g_debug ? (long long*)(W + p.dbg) + 16 * 2400 : nullptr;
+    tf.dbg = dbg_on ? (long long*)(W + p.dbg) + 16 * 2400 : nullptr;
     if ((rc = launch_trunk_fwd(tf, true, st))) return rc;
     TrunkFwdArgs tt = tf;
     tt.dbg = nullptr;
@@ -319,9 +326,9 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
     gf.gi0 = W + p.gi + r0 * 3 * OPE_H; gf.gi1 = W + p.gi_t + r0 * 3 * OPE_H;
     gf.h0out = W + p.h + r0 * OPE_H; gf.h1out = W + p.h_t + r0 * OPE_H;
     if (c > 0) { gf.hinit = W + p.h + (r0 - p.NB) * OPE_H; gf.hinit1 = W + p.h_t + (r0 - p.NB) * OPE_H; }
-    gf.whh_off = p.AL.whh; gf.bhh_off = p.AL.bhh;
+    gf.whh_off = p.AL.whh; gf.bhh_off = p.AL.bhh; gf.family = cfg->scan_family; gf.waves = cfg->scan_waves;
     gf.rg = W + p.rg + r0 * OPE_H; gf.zg = W + p.zg + r0 * OPE_H; gf.ng = W + p.ng + r0 * OPE_H; gf.ghn = W + p.ghn + r0 * OPE_H;
-    gf.dbg = g_debug ? (long long*)(W + p.dbg) + 71168 : nullptr;
+    gf.dbg = dbg_on ? (long long*)(W + p.dbg) + 71168 : nullptr;
     if ((rc = launch_gru_fwd(gf, scan_st))) return rc;
     if (C > 1 && hipEventRecord(sp->scan_done[c], side) != hipSuccess) return OPE_ELAUNCH;
   }
@@ -354,7 +361,7 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
     hf.h0 = W + p.h; hf.h1 = W + p.h_t; hf.acts = batch->acts; hf.avail = batch->avail_acts; hf.double_q = cfg->use_double_q;
     hf.no_ln = p.mlp; hf.target_mask_avail = p.mlp;
     hf.agent_q = W + p.agent_q; hf.agent_nq = W + p.agent_nq; hf.act_idx = (int*)(W + p.act_idx);
-    hf.xhat_o = W + p.xhat_o; hf.rstd_o = W + p.rstd_o; hf.q_out = nullptr; hf.q_all = g_debug ? W + p.q_all : nullptr;
+    hf.xhat_o = W + p.xhat_o; hf.rstd_o = W + p.rstd_o; hf.q_out = nullptr; hf.q_all = dbg_on ? W + p.q_all : nullptr;
     if (ride) hf.side = tr;
     if ((rc = launch_head_fwd(hf, 0, st))) return rc;
   }
@@ -375,7 +382,8 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
     mf.TB = (int)p.TB; mf.B = p.B; mf.N = p.N; mf.S = p.S; mf.theta0 = theta; mf.theta1 = theta_tgt; mf.L = p.ML;
     mf.share = batch->share_obs; mf.agent_q = W + p.agent_q; mf.agent_nq = W + p.agent_nq; mf.qtot = W + p.qtot; mf.nqtot = W + p.nqtot;
     mf.hw1 = W + p.hw1; mf.hw2 = W + p.hw2; mf.hb2 = W + p.hb2; mf.v1 = W + p.v1; mf.hpre = W + p.hpre; mf.v2 = W + p.v2;
-    mf.dbg = g_debug ? (long long*)(W + p.dbg) : nullptr;
+    mf.dbg = dbg_on ? (long long*)(W + p.dbg) : nullptr;
+    mf.k_stagger = 1; mf.path = cfg->mixer_path; mf.wide_slab = p.wide ? W + p.mix_slab : nullptr;
     if ((rc = launch_mixer_fwd(mf, st))) return rc;
     MixerBwdArgs mb;
     mb.TB = (int)p.TB; mb.N = p.N; mb.theta = theta; mb.thetaT = W + p.mixT; mb.L = p.ML; mb.td = td;
@@ -461,7 +469,8 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
     gb.rg = W + p.rg; gb.zg = W + p.zg; gb.ng = W + p.ng; gb.ghn = W + p.ghn; gb.dh_out = W + p.dh_out; gb.dgi = W + p.dgi; gb.dghn = W + p.dghn;
     gb.dh_in = hi < p.T ? W + p.dh_carry : nullptr;
     gb.dh_carry = lo > 0 ? W + p.dh_carry : nullptr;
-    gb.dbg = g_debug ? (long long*)(W + p.dbg) + 87552 : nullptr;
+    gb.dbg = dbg_on ? (long long*)(W + p.dbg) + 87552 : nullptr;
+    gb.family = cfg->scan_family; gb.waves = cfg->scan_waves;
     if ((rc = launch_gru_bwd(gb, side))) return rc;
     if (use_side && hipEventRecord(sp->bptt_done[c], side) != hipSuccess) return OPE_ELAUNCH;
   }

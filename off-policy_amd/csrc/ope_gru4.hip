@@ -381,7 +381,8 @@ __global__ void __launch_bounds__((W + 2) * 64) gru_bwd4_kernel(GruBwdArgs a) {
 
 // Compute waves per row: as many as keep the launch at about one compute wave per SIMD (1024 SIMDs): the kernels are
 // bound by the per-step issue/latency chain of a wave, and a second wave on the same SIMD stretches both.
-static int waves_per_row(int64_t rows) {
+static int waves_per_row(int64_t rows, int asked) {
+  if (asked == 2 || asked == 4) return asked;
   if (g_scan_waves) return g_scan_waves;
   return rows <= 512 ? 4 : 2;   // measured: 3s5z (512 / 256 rows) prefers 4, MMM2 (640 / 320 rows) 2 forward
 }
@@ -402,13 +403,13 @@ static void launch_bwd(const GruBwdArgs& a, hipStream_t st) {
 }
 
 int launch_gru_fwd4(const GruFwdArgs& a, hipStream_t st) {
-  if (waves_per_row((int64_t)a.nets * a.NB) == 4) launch_fwd<4>(a, st); else launch_fwd<2>(a, st);
+  if (waves_per_row((int64_t)a.nets * a.NB, a.waves) == 4) launch_fwd<4>(a, st); else launch_fwd<2>(a, st);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   return OPE_OK;
 }
 
 int launch_gru_bwd4(const GruBwdArgs& a, hipStream_t st) {
-  if (waves_per_row(a.NB) == 4) launch_bwd<4>(a, st); else launch_bwd<2>(a, st);
+  if (waves_per_row(a.NB, a.waves) == 4) launch_bwd<4>(a, st); else launch_bwd<2>(a, st);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   return OPE_OK;
 }

@@ -19,7 +19,34 @@ struct MixerFwdArgs {
   float* v2;                             // [TB][32]   pre-abs w2
   long long* dbg;                        // optional per-wave s_memtime stamps [waves][8] (profiling builds of the schedule)
   int k_stagger;                         // cooperative form: workgroups start their K loops at different chunks
+  int path;                              // 0 auto, 1 resident weights (mixer_fwd3), 2 streamed weights (mixer_fwd2), 3 wide-state GEMM
+  float* wide_slab;                      // wide-state path: stream-K partial sums of the first hyper-layers (wide_slab_floats())
 };
+
+// ---- wide-state path (ope_mixer_wide.hip): stream-K decomposition shared by the GEMM kernel, its consumer and the workspace plan ----
+constexpr int kWideBM = 128, kWideBN = 224, kWideMaxWG = 256, kWideStageK = 32;
+constexpr int kWideAutoS = 256;          // auto: states wider than this take the GEMM path
+struct WidePlan { int nrb, ntiles, nst, units, nwg, maxseg; };
+__host__ __device__ inline WidePlan wide_plan(int TB, int S) {
+  WidePlan p;
+  p.nrb = (TB + kWideBM - 1) / kWideBM;            // 128-row blocks of the T*B output rows
+  p.ntiles = 2 * p.nrb;                            // tile = 2 * row block + net
+  p.nst = (S + kWideStageK - 1) / kWideStageK;     // K stages per tile
+  p.units = p.ntiles * p.nst;
+  p.nwg = p.units < kWideMaxWG ? p.units : kWideMaxWG;
+  const int upw = (p.units + p.nwg - 1) / p.nwg;   // most units a workgroup gets
+  p.maxseg = (upw + p.nst - 1) / p.nst + 1;        // most tiles its contiguous range can touch
+  return p;
+}
+// workgroup w covers units [wide_bound(w), wide_bound(w + 1))
+__host__ __device__ inline int wide_bound(const WidePlan& p, int w) { return (int)((int64_t)w * p.units / p.nwg); }
+// the workgroup that covers unit u
+__host__ __device__ inline int wide_owner(const WidePlan& p, int u) { return (int)((((int64_t)u + 1) * p.nwg - 1) / p.units); }
+inline int64_t wide_slab_floats(int TB, int S) {
+  const WidePlan p = wide_plan(TB, S);
+  return (int64_t)p.nwg * p.maxseg * kWideBM * kWideBN;
+}
+int launch_mixer_wide_gemm(const MixerFwdArgs& a, hipStream_t st);
 
 struct TdArgs {
   int B, N;

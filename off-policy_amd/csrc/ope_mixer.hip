@@ -89,7 +89,28 @@ __global__ void __launch_bounds__(256) mixer_fwd2_kernel(MixerFwdArgs a) {
     wrow[q] = stageA_row(th, L, S, tile[q], j);
   }
   const int KC = (S + 15) >> 4;
-  {
+  if (a.wide_slab) {
+    // Wide-state path: the K reduction was done by mixer_wide_gemm_kernel (ope_mixer_wide.hip); add the tile's stream-K partial
+    // slabs in ascending K order on top of the bias. Lane (j, g) takes the four features 16 tile[q] + 4 g .. + 3 of its row.
+    const WidePlan P = wide_plan(a.TB, S);
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      const int mm = valid[t] ? m[t] : a.TB - 1;
+      const int rb = mm / kWideBM, rin = mm - rb * kWideBM;
+      const int wt = 2 * rb + net;
+      const int w_lo = wide_owner(P, wt * P.nst), w_hi = wide_owner(P, (wt + 1) * P.nst - 1);
+      for (int w = w_lo; w <= w_hi; ++w) {
+        const int seg = wt - wide_bound(P, w) / P.nst;
+        const float* __restrict__ sl = a.wide_slab + (((int64_t)w * P.maxseg + seg) * kWideBM + rin) * kWideBN + 4 * g;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(sl + 16 * tile[q]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[t][q][r] += v[r];
+        }
+      }
+    }
+  } else {
     struct Chunk { f32x4 w[4]; f32x4 x[RT]; };
     auto fetch = [&](Chunk& c, int ci) {
       const int k = 16 * ci + 4 * g;
@@ -509,8 +530,8 @@ static void launch_mixer2(const MixerFwdArgs& a0, hipStream_t st) {
   // weights-in-registers persistent form for 3s5z-sized problems (OPE_MIXER_PERSIST=0: the re-streaming kernel)
   // (read per launch: tests switch it between calls; 2 = also for small problems, where one workgroup per row tile is as good)
   const char* pe = getenv("OPE_MIXER_PERSIST");
-  const int persist = pe ? atoi(pe) : 1;
-  if (VEC == 4 && persist && !forced && a.N <= 8 && a.S <= 16 * 14 && (a.TB >= 16 * 64 || persist == 2)) {
+  const int persist = a.path == 1 ? 2 : (a.path == 2 ? 0 : (pe ? atoi(pe) : 1));     // cfg->mixer_path overrides the environment
+  if (VEC == 4 && persist && !forced && !a.wide_slab && a.N <= 8 && a.S <= 16 * 14 && (a.TB >= 16 * 64 || persist == 2)) {
     const int tiles = ope_cdiv(a.TB, 16);
     static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256; return n > 1 ? n : 256; }();
     const int per_net = tiles < cus / 2 ? tiles : cus / 2;
@@ -523,8 +544,17 @@ static void launch_mixer2(const MixerFwdArgs& a0, hipStream_t st) {
   else hipLaunchKernelGGL((mixer_fwd2_kernel<VEC, 1>), dim3(2 * ope_cdiv(a.TB, 16)), dim3(256), 0, st, a);
 }
 
-int launch_mixer_fwd(const MixerFwdArgs& a, hipStream_t st) {
-  if (a.TB < 1 || a.N < 1 || a.S < 1) return OPE_EINVAL;
+int launch_mixer_fwd(const MixerFwdArgs& a0, hipStream_t st) {
+  if (a0.TB < 1 || a0.N < 1 || a0.S < 1) return OPE_EINVAL;
+  MixerFwdArgs a = a0;
+  const bool wide = a.wide_slab && (a.path == 3 || (a.path == 0 && a.S > kWideAutoS));
+  if (wide) {
+    const int rc = launch_mixer_wide_gemm(a, st);
+    if (rc) return rc;
+    a.path = 2;                  // the second stage = mixer_fwd2 reading the slabs
+  } else {
+    a.wide_slab = nullptr;
+  }
   const int vec = ope_vec_of(a.S);
   if (vec == 4) launch_mixer2<4>(a, st);
   else if (vec == 2) launch_mixer2<2>(a, st);

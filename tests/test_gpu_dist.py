@@ -111,6 +111,76 @@ def _rddpg_steps(name, shard):
             None if prios[0] is None else np.asarray(prios))
 
 
+def _allreduce_world_worker(rank, world, port, out_q):
+    """One-shot all-reduce between `world` processes that all sit on cuda:0: every rank maps the world - 1 other exchange buffers
+    through HIP IPC and runs the same kernel a real node runs (there: one rank per GPU, the buffers reached over xGMI)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from offpolicy_amd.dist import OneShotAllreduce
+        dev = torch.device("cuda:0")
+        ar = OneShotAllreduce(dev, rank, world, max_floats=1 << 18, timeout_ms=20000)
+        assert len(ar._mapped) == world - 1
+        g = torch.Generator(device="cpu").manual_seed(4321 + rank)
+        ok, digests = True, []
+        # 8 x ceil(n / 1024) spinning workgroups share ONE GPU here: keep n below the co-residency limit (a node has a GPU per rank)
+        for n in (118795, 5, 1024, 1 << 17, 118795, 33333):
+            x = torch.randn(n, generator=g)
+            ref = x.clone()
+            torch.distributed.all_reduce(ref, op=torch.distributed.ReduceOp.SUM)          # gloo, host
+            y = x.to(dev)
+            ar(y)
+            y = y.cpu()
+            ok = ok and bool(torch.allclose(y, ref, rtol=1e-5, atol=1e-5))
+            digests.append(y.numpy().tobytes())
+        timed_out = ar.timed_out()
+        import hashlib
+        h = hashlib.sha256(b"".join(digests)).hexdigest()
+        torch.distributed.barrier()
+        # a peer that never arrives: rank 0 alone starts one more exchange with a short timeout. It must come back (bounded spin),
+        # raise the status flag AND leave NaN in every chunk instead of a sum over stale slots (ADVICE r2).
+        poisoned = None
+        if rank == 0:
+            ar.ctx.timeout_ms = 200
+            z = torch.ones(5000, device=dev)
+            ar(z)
+            torch.cuda.synchronize()
+            poisoned = bool(torch.isnan(z).all().item()) and ar.timed_out()
+        torch.distributed.barrier()
+        out_q.put((rank, ok, bool(timed_out), h, poisoned, ar.epoch))
+        ar.close()
+    finally:
+        torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [8, 3])
+def test_one_shot_allreduce_eight_ranks_on_one_device(world):
+    """The flag / slot / IPC-mapping logic of the one-shot all-reduce at the world size a node runs (8), before a node ever runs it:
+    8 processes on cuda:0 (gloo rendezvous), 7 IPC-mapped peer buffers each, six exchanges of different lengths (both parities,
+    ragged tails) equal to gloo's sum and BITWISE identical on all ranks (fixed rank-order sums), no timeout; and a 3-rank
+    (non-power-of-two) variant. Then the failure path: a lone caller times out, reports it and poisons its vector with NaN."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_allreduce_world_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        item = q.get(timeout=900)
+        res[item[0]] = item[1:]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert all(res[r][0] for r in range(world)), "a rank's result differs from gloo's sum"
+    assert not any(res[r][1] for r in range(world)), "a wait timed out during the regular exchanges"
+    assert len({res[r][2] for r in range(world)}) == 1, "ranks hold different bits"
+    assert res[0][3] is True, "the lone caller was not poisoned / flagged"
+    assert res[1][4] == 6 and res[0][4] == 7
+
+
 def _spawn(worker, name, mode):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

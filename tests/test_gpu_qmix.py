@@ -76,38 +76,59 @@ def test_train_steps_match_reference(name):
 def test_every_scan_kernel_family_matches_reference(name, family, waves):
     """The GRU scans have three kernel shapes chosen by row count (ope_gru4.hip with 4 or 2 compute waves per row,
     ope_gru1.hip); the fixtures are small, so pin each shape in turn and repeat the reference comparison."""
-    from offpolicy_amd import _lib
     g = load_golden(name)
-    _lib.lib.ope_set_scan_kernel(family, waves)
-    try:
-        dims, buf, policy, trainer = build_from_fixture(g)
-        batch = batch_from(buf, g["inds"])
-        for s in range(len(g["loss"])):
-            info, _, _ = trainer.train_policy_on_batch(batch)
+    dims, buf, policy, trainer = build_from_fixture(g)
+    trainer.tune.update(scan_family=family, scan_waves=waves)      # per trainer (ope_qmix_cfg.scan_family / scan_waves), not process-wide
+    batch = batch_from(buf, g["inds"])
+    for s in range(len(g["loss"])):
+        info, _, _ = trainer.train_policy_on_batch(batch)
+        trainer.soft_target_updates()
+        np.testing.assert_allclose(float(info["loss"]), g["loss"][s], rtol=RTOL)
+        np.testing.assert_allclose(float(info["grad_norm"]), g["grad_norm"][s], rtol=RTOL)
+    live = _flat_named(trainer, trainer.theta)
+    for k, ref in sub(g, "final_agent/").items():
+        np.testing.assert_allclose(live["agent/" + k], ref, rtol=0, atol=3e-5, err_msg=k)
+
+
+@pytest.mark.parametrize("path", [1, 2, 3])
+@pytest.mark.parametrize("name", ["qmix_gall_tiny", "qmix_gall_3m", "qmix_gall_odd", "qmix_tiny", "qmix_odd", "qmix_3m_katA"])
+def test_every_forward_mixer_kernel_matches_reference(name, path):
+    """The forward mixer has three kernels chosen by shape (ope_qmix_cfg.mixer_path: 1 weights resident in registers, 2 weights
+    streamed per 16-row workgroup, 3 the wide-state form -- first hyper-layers as one stream-K GEMM + second stage from its partial
+    slabs, ope_mixer_wide.hip); the fixtures are small, so pin each in turn and repeat the reference comparison: narrow, wide
+    (--use_global_all_local_state: S = 34, 83 -- nothing a multiple of 4 --, 240) and 3m states, several K stages and stream-K
+    segments per tile, partial row blocks."""
+    g = load_golden(name)
+    dims, buf, policy, trainer = build_from_fixture(g)
+    trainer.tune["mixer_path"] = path
+    soft = bool(g["hp_soft_update"]) if "hp_soft_update" in g else True
+    hard_after = set(int(x) for x in g["hard_update_after"]) if "hard_update_after" in g else set()
+    batch = batch_from(buf, g["inds"])
+    for s in range(len(g["loss"])):
+        info, _, _ = trainer.train_policy_on_batch(batch)
+        if soft:
             trainer.soft_target_updates()
-            np.testing.assert_allclose(float(info["loss"]), g["loss"][s], rtol=RTOL)
-            np.testing.assert_allclose(float(info["grad_norm"]), g["grad_norm"][s], rtol=RTOL)
-        live = _flat_named(trainer, trainer.theta)
-        for k, ref in sub(g, "final_agent/").items():
-            np.testing.assert_allclose(live["agent/" + k], ref, rtol=0, atol=3e-5, err_msg=k)
-    finally:
-        _lib.lib.ope_set_scan_kernel(0, 0)
+        elif s in hard_after:
+            trainer.hard_target_updates()
+        np.testing.assert_allclose(float(info["loss"]), g["loss"][s], rtol=RTOL)
+        np.testing.assert_allclose(float(info["grad_norm"]), g["grad_norm"][s], rtol=RTOL)
+        np.testing.assert_allclose(float(info["Q_tot"]), g["Q_tot"][s], rtol=RTOL, atol=1e-6)
+    live, tgt = _flat_named(trainer, trainer.theta), _flat_named(trainer, trainer.theta_tgt)
+    for grp, src, key in (("final_agent/", live, "agent/"), ("final_mixer/", live, "mixer/"), ("final_mixer_tgt/", tgt, "mixer/")):
+        for k, ref in sub(g, grp).items():
+            np.testing.assert_allclose(src[key + k], ref, rtol=0, atol=3e-5, err_msg=grp + k)
 
 
 @pytest.mark.parametrize("name", ["qmix_tiny", "qmix_odd"])
 def test_forward_intermediates_match_oracle(name):
     """Per-stage check (helps localise a failure): live q values, chosen/target agent q, Q_tot of both mixers."""
     from oracle import qmix_oracle as O
-    from offpolicy_amd import _lib
     g = load_golden(name)
     dims, buf, policy, trainer = build_from_fixture(g)
-    _lib.lib.ope_set_debug(1)
-    try:
-        batch = batch_from(buf, g["inds"])
-        trainer.train_policy_on_batch(batch)
-        torch.cuda.synchronize()
-    finally:
-        _lib.lib.ope_set_debug(0)
+    trainer.tune["debug"] = 1               # ope_qmix_cfg.debug: keep "q_all" etc. in the workspace
+    batch = batch_from(buf, g["inds"])
+    trainer.train_policy_on_batch(batch)
+    torch.cuda.synchronize()
     orc, _ = oracle_from(g)
     store, _ = reference_store_from(g)
     ob = O.sample_inds(store, g["inds"])
@@ -213,7 +234,10 @@ def test_full_size_3s5z_matches_oracle_one_step(workload, nb):
     # gradients. At this size (4.9 M ReLU units, 541 k argmax decisions per step) about one pre-activation per step
     # lies within float rounding of 0, and the CPU and GPU reduction orders may put it on different sides: a single
     # such flip moves a handful of gradient elements by a few 1e-5. So: >= 99.5 % of every tensor within 2e-3 of the
-    # tensor's max magnitude, and every element within 2e-2 of it.
+    # tensor's max magnitude, and every element within 2e-2 of it. One exception, by the same mechanism: a flipped ReLU unit h of a
+    # layer changes ROW h of that layer's own weight gradient by one data row's outer-product term, i.e. all `in` columns of one
+    # of its `out` rows at once -- 1 / 64 = 1.6 % of a hyper-network first layer [64, S], whatever S; with S = 2 232 inputs that
+    # single term is ~0.3 % of the tensor's max. So for 2-D tensors the 0.5 % of outliers may instead be confined to at most two rows.
     cnt = float(trainer.grad[trainer.numel + 1])
     got = _flat_named(trainer, trainer.grad[:trainer.numel] / cnt)
     for k, ref in out["grads"].items():
@@ -222,7 +246,12 @@ def test_full_size_3s5z_matches_oracle_one_step(workload, nb):
         scale = max(np.abs(ref).max(), 1e-9)
         d = np.abs(got[k] - ref) / scale
         assert d.max() <= 2e-2, ("grad " + k, float(d.max()))
-        assert (d <= 2e-3).mean() >= 0.995, ("grad " + k, float((d <= 2e-3).mean()))
+        frac_ok = float((d <= 2e-3).mean())
+        if frac_ok < 0.995 and d.ndim == 2:
+            bad_rows = np.nonzero((d > 2e-3).any(axis=1))[0]
+            assert len(bad_rows) <= 2, ("grad " + k, frac_ok, "outliers in rows", bad_rows.tolist())
+            continue
+        assert frac_ok >= 0.995, ("grad " + k, frac_ok)
     # parameters after the first Adam step. The first step is lr * g / (|g| + eps): an element whose gradient is
     # comparable to eps = 1e-5 amplifies a 1e-7 gradient difference, so: >= 99.5 % of each tensor within 2e-5 and every
     # element within lr (the largest possible first-step move).
@@ -231,7 +260,11 @@ def test_full_size_3s5z_matches_oracle_one_step(workload, nb):
         for k, v in src.items():
             d = np.abs(v.detach().cpu().numpy() - ref[k].numpy())
             assert d.max() <= lr * 1.01, k
-            assert (d <= 2e-5).mean() >= 0.995, (k, float((d <= 2e-5).mean()))
+            frac_ok = float((d <= 2e-5).mean())
+            if frac_ok < 0.995 and d.ndim == 2:      # (the flipped unit's row, as above)
+                assert len(np.nonzero((d > 2e-5).any(axis=1))[0]) <= 2, (k, frac_ok)
+                continue
+            assert frac_ok >= 0.995, (k, frac_ok)
 
 
 def test_runner_call_sequence_with_per():
@@ -266,8 +299,8 @@ def test_runner_call_sequence_with_per():
     assert buf.max_priorities["policy_0"] >= 1.0
 
 
-def test_time_chunked_two_stream_schedule_matches_single_stream(monkeypatch):
-    """OPE_CHUNKS > 1 cuts the episode into time chunks and runs the scans on a side stream beside the row-parallel kernels
+def test_time_chunked_two_stream_schedule_matches_single_stream():
+    """ope_qmix_cfg.time_chunks > 1 (trainer.tune["time_chunks"]; process default: OPE_CHUNKS) cuts the episode into time chunks and runs the scans on a side stream beside the row-parallel kernels
     (DESIGN.md section 4). Same kernels, same per-row arithmetic: gradients agree with the single-stream schedule to
     summation-order rounding, and are bit-stable from run to run."""
     from offpolicy_amd.config import default_args
@@ -290,11 +323,10 @@ def test_time_chunked_two_stream_schedule_matches_single_stream(monkeypatch):
     theta0, tgt0 = trainer.theta.clone(), trainer.theta_tgt.clone()
     grads = {}
     for tag, chunks in (("c1", "1"), ("c3", "3"), ("c3b", "3"), ("c2", "2")):
-        monkeypatch.setenv("OPE_CHUNKS", chunks)
+        trainer.tune["time_chunks"] = int(chunks)
         trainer.theta.copy_(theta0)
         trainer.theta_tgt.copy_(tgt0)
         trainer.optimizer.exp_avg.zero_(); trainer.optimizer.exp_avg_sq.zero_(); trainer.optimizer.step_count = 0
-        trainer._ws = {}
         trainer.train_policy_on_batch(batch)
         torch.cuda.synchronize()
         grads[tag] = trainer.grad.cpu().numpy().copy()
