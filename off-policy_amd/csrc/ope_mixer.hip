@@ -552,6 +552,7 @@ int launch_mixer_fwd(const MixerFwdArgs& a0, hipStream_t st) {
     const int rc = launch_mixer_wide_gemm(a, st);
     if (rc) return rc;
     a.path = 2;                  // the second stage = mixer_fwd2 reading the slabs
+    a.dbg = nullptr;             // (the stamp region belongs to the GEMM kernel in this mode)
   } else {
     a.wide_slab = nullptr;
   }

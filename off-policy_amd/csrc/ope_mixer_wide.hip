@@ -32,6 +32,8 @@
 // 28-31} and the same + 32; a group is conflict-free when its 16 16-byte slots differ mod 16. With rows j = lane & 15 at a pitch of
 // 10 slots (40 floats) and K-quarter g = lane >> 4 one slot apart, a group's slots are 10 j + g over j in {0-3, 12-15} and
 // 10 j + g + 1 over j in {4-11}: the eight even and the eight odd residues. (A pitch of 36 floats, the usual "+ 4", is 2-way.)
+#include <stdlib.h>
+
 #include "ope_mixer.h"
 
 namespace ope {
@@ -57,6 +59,15 @@ __global__ void __launch_bounds__(512, 2) mixer_wide_gemm_kernel(MixerFwdArgs a)
   const WidePlan P = wide_plan(a.TB, a.S);
   const int S = a.S;
   const int wg = blockIdx.x;
+  // diagnostics (ope_qmix_cfg.debug; tools/wide_phases.py): [workgroup][8] = s_memtime at start / first segment staged / end of the
+  // last stage loop / end, then the same four points on the constant 100 MHz wall clock (-> effective shader clock)
+  long long* dbg = a.dbg ? a.dbg + (int64_t)wg * 8 : nullptr;
+  auto stamp = [&](int k) {
+    if (dbg && tid == 0) { dbg[k] = __builtin_amdgcn_s_memtime(); dbg[4 + k] = wall_clock64(); }
+  };
+  const int ex = a.k_stagger;      // experiment mask (OPE_WIDE_EXP, timing only -- results are wrong): 1 no global loads in the loop,
+                                   // 2 no MFMAs, 4 no LDS deposits in the loop
+  stamp(0);
   int u = wide_bound(P, wg);
   const int u_end = wide_bound(P, wg + 1);
   const int first_tile = u / P.nst;
@@ -114,14 +125,27 @@ __global__ void __launch_bounds__(512, 2) mixer_wide_gemm_kernel(MixerFwdArgs a)
 #pragma unroll
       for (int ni = 0; ni < 7; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // Stage loop: request stage s + 1, read this stage's 18 fragments, 112 MFMAs, deposit stage s + 1 into the other buffer, barrier.
+    // Measured at 3s5z / S = 2 232 (tools/wide_phases.py; cycles per stage of a workgroup's loop; 7 168 = the two waves of a SIMD issuing
+    // their 224 MFMAs back to back): 9.6 k this form (97.5 us kernel); without the loop's global loads 8.4 k, without MFMAs 3.2 k,
+    // without both 1.6 k -- the deposits (ds_write_b128: 13 cycles of the VGPR -> LDS path each) + masks + fragment reads + barrier
+    // are not hidden behind the other wave of the SIMD, which reaches them at the same time. Two variants that were SLOWER:
+    //  * fragment reads of the next stage's first half hoisted across the barrier, deposit in mid-stage (MFMAs queued on both sides of
+    //    the barrier): 10.1 k (105 us) -- the loads requested at the top of a stage are not back half a stage later under MFMA load;
+    //  * LDS-DMA staging (global_load_lds_dwordx4, three buffers, requests two stages ahead, source-column XOR swizzle for
+    //    conflict-free unpadded rows): 11.9 k (125 us) -- each DMA instruction costs the issuing wave 100-185 cycles beside MFMAs
+    //    (MI355X_MICROARCH.md) and all eight waves pay it together.
+    // What would get to ~7.4 k: the two waves of a SIMD in opposite phases (one issues the stage's MFMAs while the other does all of the
+    // stage's memory work, two barriers per stage) -- next.
     fetch(st0);
     deposit(st0, lds);                                     // (the previous segment's readers left behind its last barrier)
     lds_barrier();
+    if (tile == first_tile) stamp(1);
     for (int st = st0; st < st1; ++st) {
-      float* cur = lds + ((st - st0) & 1) * STAGE_FLOATS;
+      const float* cur = lds + ((st - st0) & 1) * STAGE_FLOATS;
       float* nxt = lds + (((st - st0) & 1) ^ 1) * STAGE_FLOATS;
       const bool more = st + 1 < st1;
-      if (more) fetch(st + 1);                             // in flight behind this stage's MFMAs
+      if (more && !(ex & 1)) fetch(st + 1);                // in flight behind this stage's MFMAs
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         f32x4 xf[2], wf[7];
@@ -129,16 +153,19 @@ __global__ void __launch_bounds__(512, 2) mixer_wide_gemm_kernel(MixerFwdArgs a)
         for (int mi = 0; mi < 2; ++mi) xf[mi] = *reinterpret_cast<const f32x4*>(cur + xoff[mi] + 16 * c);
 #pragma unroll
         for (int ni = 0; ni < 7; ++ni) wf[ni] = *reinterpret_cast<const f32x4*>(cur + woff[ni] + 16 * c);
+        if (!(ex & 2)) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+          for (int r = 0; r < 4; ++r)
 #pragma unroll
-          for (int ni = 0; ni < 7; ++ni)
+            for (int ni = 0; ni < 7; ++ni)
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) acc[mi][ni] = mfma16(wf[ni][r], xf[mi][r], acc[mi][ni]);
+              for (int mi = 0; mi < 2; ++mi) acc[mi][ni] = mfma16(wf[ni][r], xf[mi][r], acc[mi][ni]);
+        }
       }
-      if (more) deposit(st + 1, nxt);
+      if (more && !(ex & 4)) deposit(st + 1, nxt);
       lds_barrier();
     }
+    stamp(2);
 
     // partial accumulators of this (tile, K-range) segment -> this workgroup's slab: [BM][BN] row-major, feature-contiguous 16-byte
     // pieces per lane (lane (j, g) of accumulator tile (mi, ni) = features 112 wn + 16 ni + 4 g .. + 3 of row 32 wm + 16 mi + j)
@@ -150,12 +177,16 @@ __global__ void __launch_bounds__(512, 2) mixer_wide_gemm_kernel(MixerFwdArgs a)
         *reinterpret_cast<f32x4*>(slab + (32 * wm + 16 * mi + j) * BN + 112 * wn + 16 * ni + 4 * g) = acc[mi][ni];
     u += st1 - st0;
   }
+  stamp(3);
 }
 
-int launch_mixer_wide_gemm(const MixerFwdArgs& a, hipStream_t st) {
-  if (a.TB < 1 || a.S < 1 || !a.wide_slab) return OPE_EINVAL;
-  const WidePlan P = wide_plan(a.TB, a.S);
-  const int vec = ope_vec_of(a.S);
+int launch_mixer_wide_gemm(const MixerFwdArgs& a0, hipStream_t st) {
+  if (a0.TB < 1 || a0.S < 1 || !a0.wide_slab) return OPE_EINVAL;
+  const WidePlan P = wide_plan(a0.TB, a0.S);
+  const int vec = ope_vec_of(a0.S);
+  static const int ex = getenv("OPE_WIDE_EXP") ? atoi(getenv("OPE_WIDE_EXP")) : 0;   // timing experiments only (read once)
+  MixerFwdArgs a = a0;
+  a.k_stagger = ex;
   if (vec == 4) hipLaunchKernelGGL(mixer_wide_gemm_kernel<4>, dim3(P.nwg), dim3(512), 0, st, a);
   else if (vec == 2) hipLaunchKernelGGL(mixer_wide_gemm_kernel<2>, dim3(P.nwg), dim3(512), 0, st, a);
   else hipLaunchKernelGGL(mixer_wide_gemm_kernel<1>, dim3(P.nwg), dim3(512), 0, st, a);

@@ -231,40 +231,56 @@ def test_full_size_3s5z_matches_oracle_one_step(workload, nb):
     np.testing.assert_allclose(float(info["loss"]), out["loss"], rtol=RTOL)
     np.testing.assert_allclose(float(info["grad_norm"]), out["grad_norm"], rtol=RTOL)
     np.testing.assert_allclose(float(info["Q_tot"]), out["Q_tot"], rtol=RTOL, atol=1e-6)
-    # gradients. At this size (4.9 M ReLU units, 541 k argmax decisions per step) about one pre-activation per step
-    # lies within float rounding of 0, and the CPU and GPU reduction orders may put it on different sides: a single
-    # such flip moves a handful of gradient elements by a few 1e-5. So: >= 99.5 % of every tensor within 2e-3 of the
-    # tensor's max magnitude, and every element within 2e-2 of it. One exception, by the same mechanism: a flipped ReLU unit h of a
-    # layer changes ROW h of that layer's own weight gradient by one data row's outer-product term, i.e. all `in` columns of one
-    # of its `out` rows at once -- 1 / 64 = 1.6 % of a hyper-network first layer [64, S], whatever S; with S = 2 232 inputs that
-    # single term is ~0.3 % of the tensor's max. So for 2-D tensors the 0.5 % of outliers may instead be confined to at most two rows.
+    # gradients. At this size (4.9 M ReLU units, 1.4 M abs() units in the mixer, 541 k argmax decisions per step) a few
+    # pre-activations per step lie within float rounding of 0, and the CPU and GPU reduction orders may put them on different
+    # sides. Forward values do not notice (ReLU / abs are continuous); gradients do: a flipped unit at data row m changes that
+    # row's adjoint, i.e. the layer's weight gradient by ONE outer product (adjoint change x input row m) and its bias gradient by
+    # the adjoint change -- about 1 / sqrt(rows) of the tensor's scale, but spread over every column of the weight (all S = 2 232
+    # of a wide hyper-network first layer; an abs() unit flips the SIGN of its row's term: twice the size). So: every element
+    # within 2e-2 of the tensor's max magnitude and >= 99.5 % within 2e-3 of it, EITHER directly OR after removing at most four
+    # rank-one terms from the difference [dW | db] of a Linear layer (deviations beyond rounding must have exactly the structure
+    # single-unit flips produce; a wrong kernel does not).
     cnt = float(trainer.grad[trainer.numel + 1])
     got = _flat_named(trainer, trainer.grad[:trainer.numel] / cnt)
-    for k, ref in out["grads"].items():
-        if ref is None:
-            continue
-        scale = max(np.abs(ref).max(), 1e-9)
-        d = np.abs(got[k] - ref) / scale
-        assert d.max() <= 2e-2, ("grad " + k, float(d.max()))
-        frac_ok = float((d <= 2e-3).mean())
-        if frac_ok < 0.995 and d.ndim == 2:
-            bad_rows = np.nonzero((d > 2e-3).any(axis=1))[0]
-            assert len(bad_rows) <= 2, ("grad " + k, frac_ok, "outliers in rows", bad_rows.tolist())
-            continue
-        assert frac_ok >= 0.995, ("grad " + k, frac_ok)
-    # parameters after the first Adam step. The first step is lr * g / (|g| + eps): an element whose gradient is
-    # comparable to eps = 1e-5 amplifies a 1e-7 gradient difference, so: >= 99.5 % of each tensor within 2e-5 and every
-    # element within lr (the largest possible first-step move).
-    lr = args.lr
+    grads = {k: v for k, v in out["grads"].items() if v is not None}
+
+    def within(d):
+        return float(np.abs(d).max()) <= 2e-2 and float((np.abs(d) <= 2e-3).mean()) >= 0.995
+    rel = {k: (got[k] - ref) / max(np.abs(ref).max(), 1e-9) for k, ref in grads.items()}
+    pending = {k: (float(np.abs(d).max()), float((np.abs(d) <= 2e-3).mean())) for k, d in rel.items() if not within(d)}
+    for k in [k for k in pending if grads[k].ndim == 2]:
+        blocks = [rel[k]]
+        kb = k[:-len("weight")] + "bias"
+        if k.endswith("weight") and kb in grads and grads[kb].shape[0] == grads[k].shape[0]:
+            blocks.append(rel[kb][:, None])
+        D = np.concatenate(blocks, axis=1).astype(np.float64)
+        U, sv, Vt = np.linalg.svd(D, full_matrices=False)
+        res = D - (U[:, :4] * sv[:4]) @ Vt[:4]
+        assert within(res), ("grad " + k, pending[k], "after removing 4 rank-one terms", float(np.abs(res).max()), float((np.abs(res) <= 2e-3).mean()),
+                             sv[:6].tolist())
+        pending.pop(k)
+        pending.pop(kb, None)
+    assert not pending, ("gradient tensors outside tolerance (max deviation, share within 2e-3)", pending)
+    # parameters after the first Adam step. (1) The optimizer arithmetic on its own: with zero moments the first step is exactly
+    # theta - lr * g / (|g| + eps), g = the clipped gradient -- recomputed here from the GPU's own gradient vector and pre-clip norm,
+    # element by element (float rounding only: 2e-7). (2) Against the oracle's parameters: the step is lr * g / (|g| + eps), so an
+    # element whose gradient is comparable to eps = 1e-5 -- after the clip by 10 / grad_norm most are, with gain = 1 -- turns a
+    # gradient difference (the flips above) into a visible difference: >= 99 % of every tensor within 2e-5, every element within 2 lr
+    # (a tiny gradient that changes sign moves by up to lr either way).
+    lr, eps = args.lr, args.opti_eps
+    coef = min(1.0, float(args.max_grad_norm) / (float(info["grad_norm"]) + 1e-6))
+    live = _flat_named(trainer, trainer.theta)
+    init = {("agent/" + k): v for k, v in agent0.items()}
+    init.update({("mixer/" + k): v for k, v in mixer0.items()})
+    for k, g in got.items():
+        gg = g.astype(np.float64) * coef
+        want = init[k].astype(np.float64) - lr * gg / (np.abs(gg) + eps)
+        np.testing.assert_allclose(live[k], want, rtol=0, atol=3e-7, err_msg="Adam step " + k)
     for src, ref in ((dict(policy.q_network.named_parameters()), orc.agent), (dict(trainer.mixer.named_parameters()), orc.mixer)):
         for k, v in src.items():
             d = np.abs(v.detach().cpu().numpy() - ref[k].numpy())
-            assert d.max() <= lr * 1.01, k
-            frac_ok = float((d <= 2e-5).mean())
-            if frac_ok < 0.995 and d.ndim == 2:      # (the flipped unit's row, as above)
-                assert len(np.nonzero((d > 2e-5).any(axis=1))[0]) <= 2, (k, frac_ok)
-                continue
-            assert frac_ok >= 0.995, (k, frac_ok)
+            assert d.max() <= 2 * lr * 1.01, k
+            assert (d <= 2e-5).mean() >= 0.99, (k, float((d <= 2e-5).mean()))
 
 
 def test_runner_call_sequence_with_per():
