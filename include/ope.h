@@ -375,6 +375,12 @@ typedef struct ope_rddpg_cfg {
   const float* joint_next_acts; /* DEVICE [T][B][n_total_agents * A] joint target action, filled by one ope_rddpg_target_actions call per
                                  * policy; when non-NULL the critic call skips its own target-actor pass (theta_actor_tgt, batch obs and
                                  * target_noise_u are then unused). Required when n_total_agents > dims.n_agents.                    */
+  const float* actor_row_weight; /* optional DEVICE [N][B]: the actor objective's mask (1 - shifted agent dones) of copy `rep`, episode b is
+                                  * multiplied by weight[rep][b], in the loss, its normaliser and the gradient. NULL = 1. This is how
+                                  * cent_train_policy_on_batch (r_maddpg.py:333-564: every agent has its OWN centralized observation) runs on
+                                  * these entry points: the batch is laid out as N*B episodes -- episode (i, b) = episode b seen through
+                                  * agent i's centralized observation, everything else repeated -- and copy `rep` of episode (i, b) counts
+                                  * only for rep == i.                                                                               */
 } ope_rddpg_cfg;
 
 /* which = 0 actor, 1 critic: offsets/sizes of its OPE_QMIX_NPARAM_AGENT tensors; returns the padded length. */

@@ -10,7 +10,8 @@ import torch  # noqa: F401  -- MUST precede loading libope.so: torch's ROCm whee
 #                          ours first would put a second HIP runtime in the process and every launch on a torch stream fails.
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libope.so")
+# OPE_LIB_PATH: load another build of the same library (the sanitizer build libope_asan.so in tests/test_sanitizer_host.py)
+LIB_PATH = os.environ.get("OPE_LIB_PATH") or os.path.join(_HERE, "libope.so")
 
 OPE_QMIX_NPARAM_AGENT = 22
 OPE_QMIX_NPARAM_AGENT_MLP = 16
@@ -57,7 +58,7 @@ class DdpgCfg(C.Structure):
 class RddpgCfg(C.Structure):
     _fields_ = [("dims", Dims), ("batch", C.c_int32), ("num_q", C.c_int32), ("target_gumbel", C.c_int32),
                 ("use_huber", C.c_int32), ("use_per", C.c_int32), ("gamma", C.c_float), ("huber_delta", C.c_float),
-                ("n_total_agents", C.c_int32), ("agent_offset", C.c_int32), ("joint_next_acts", C.c_void_p)]
+                ("n_total_agents", C.c_int32), ("agent_offset", C.c_int32), ("joint_next_acts", C.c_void_p), ("actor_row_weight", C.c_void_p)]
 
 
 class AllreduceCtx(C.Structure):

@@ -81,7 +81,53 @@ class MADDPG(object):
     def train_policy_on_batch(self, update_policy_id, batch):
         if self.use_same_share_obs:
             return self.shared_train_policy_on_batch(update_policy_id, batch)
-        raise NotImplementedError("cent_train_policy_on_batch is broken upstream (SURVEY A-5) and not on the accelerated path")
+        return self.cent_train_policy_on_batch(update_policy_id, batch)
+
+    def cent_train_policy_on_batch(self, update_policy_id, batch):
+        """Every agent has its OWN centralized observation (use_same_share_obs = False): maddpg.py:251-419. `batch` = the 13-tuple of
+        MlpReplayBuffer.sample() with cent_obs / cent_nobs [N, B, S]. Upstream the function fails on every input (it
+        calls `.reshape` on the critic's LIST of Q heads); with one head (MADDPG) the intended meaning is unambiguous and is what
+        runs here, pinned on outputs of the reference run with that reading (oracle/make_golden_cent.py,
+        tests/golden/maddpg_cent_*.npz). With two heads (MATD3) the code gives no rule for combining them: refused.
+        The critic is trained on the N*B rows (agent i's observation, the joint action), rewards / dones / importance weights
+        repeated per agent (lines 279-288, 306), priorities averaged over the agents (325-326); in the actor update copy i of
+        transition b carries agent i's observation (line 399). Both are the shared-observation update on a batch laid out as N*B
+        transitions with the actor's copy `a` of transition (i, b) masked out unless a == i (through valid_transition): the same
+        C-ABI calls, correct rather than tuned."""
+        (obs_b, cent_b, act_b, rew_b, nobs_b, cent_nobs_b, dones_b, dones_env_b, valid_b, avail_b, navail_b,
+         importance_weights, idxes) = batch
+        pid = update_policy_id
+        policy = self.policies[pid]
+        if self.multi_policy:
+            raise NotImplementedError("cent_train_policy_on_batch with several policies is not on the accelerated path")
+        if policy.num_q != 1:
+            raise NotImplementedError("cent_train_policy_on_batch with two critic heads (MATD3): upstream defines no rule for them (maddpg.py:295)")
+        dev = self.device
+        t = lambda x: None if x is None else torch.as_tensor(np.asarray(x) if not torch.is_tensor(x) else x, dtype=torch.float32).to(dev)
+        obs, cent, acts, rew = t(obs_b[pid]), t(cent_b[pid]), t(act_b[pid]), t(rew_b[pid])
+        nobs, ncent, dones, dones_env, valid = t(nobs_b[pid]), t(cent_nobs_b[pid]), t(dones_b[pid]), t(dones_env_b[pid]), t(valid_b[pid])
+        avail = t(avail_b[pid]) if avail_b is not None else None
+        navail = t(navail_b[pid]) if navail_b is not None else None
+        N, B, _ = obs.shape
+        A = policy.act_dim
+        assert cent.shape[:2] == (N, B), "per-agent centralized observations [N, B, S] expected"
+        tile = lambda x: None if x is None else x.repeat(1, N, 1).contiguous()          # [N, N*B, .]: column (i, b) <- b
+        eye = torch.eye(N, device=dev).repeat_interleave(B, dim=1)[..., None]           # copy a of transition (i, b) counts iff a == i
+        w = importance_weights
+        if self.use_per:
+            w = (w.to(dev, dtype=torch.float32) if torch.is_tensor(w) else torch.as_tensor(np.asarray(w), dtype=torch.float32).to(dev)).repeat(N)
+        # the reference draws the actor's gumbel noise for the N*B real rows: same draws, repeated per copy
+        u = torch.rand((N * B, A), **self.tpdv) if self.device_noise else sample_gumbel_uniform((N * B, A)).to(dev)
+        self._noise_override = (None, u.view(N, B, A).repeat(1, N, 1).view(N * N * B, A).contiguous())
+        vb = ({pid: tile(obs)}, {pid: cent.reshape(N * B, -1).contiguous()}, {pid: tile(acts)}, {pid: tile(rew)}, {pid: tile(nobs)},
+              {pid: ncent.reshape(N * B, -1).contiguous()}, {pid: tile(dones)}, {pid: dones_env.repeat(N, 1).contiguous()},
+              {pid: (tile(valid) * eye).contiguous()}, None if avail is None else {pid: tile(avail)},
+              None if navail is None else {pid: tile(navail)}, w, idxes)
+        info, prio, idxes = self.shared_train_policy_on_batch(pid, vb)
+        if prio is not None:       # maddpg.py:325-326: mean over the agents of |TD|, + per_eps once
+            eps = self.per_eps
+            prio = ((prio - eps).reshape(N, B).mean(0) + eps) if torch.is_tensor(prio) else (np.asarray(prio) - eps).reshape(N, B).mean(0) + eps
+        return info, prio, idxes
 
     def _gsq_region(self, cfg, ws, name, n_opt, n_all):
         """(pointer, count) of the sum-of-squares partials the fused path left for the gradient just computed, or None.
@@ -187,6 +233,7 @@ class MADDPG(object):
             cfg.noise_counter = _lib.ptr(ctr).value
         else:
             draw = lambda shape: sample_gumbel_uniform(shape).to(self.device)
+        override, self._noise_override = getattr(self, "_noise_override", None), None      # (target noise, actor noise) to use instead of drawing
         u_t = draw((N * B, policy.act_dim)) if (policy.target_noise is not None and not self.multi_policy) else None
         dev_prio = torch.is_tensor(importance_weights)
         w = None
@@ -206,7 +253,8 @@ class MADDPG(object):
         new_priorities = (prio if dev_prio else prio.cpu().numpy()) if self.use_per else None
         # ---- actor ----
         if update_actor:
-            u_a = draw((N * B, policy.act_dim))
+            u_a = draw((N * B, policy.act_dim)) if override is None else override[1]
+            assert u_a is None or tuple(u_a.shape) == (N * B, policy.act_dim)
             _lib.check(_lib.lib.ope_ddpg_actor_loss_and_grad(C.byref(cfg), C.byref(mb), _lib.ptr(policy.actor._flat),
                                                              _lib.ptr(policy.critic._flat), _lib.ptr(u_a), _lib.ptr(ws), ws.numel(),
                                                              _lib.ptr(ga), st), "ope_ddpg_actor_loss_and_grad")

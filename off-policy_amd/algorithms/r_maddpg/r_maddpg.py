@@ -90,7 +90,52 @@ class R_MADDPG(object):
     def train_policy_on_batch(self, update_policy_id, batch):
         if self.use_same_share_obs:
             return self.shared_train_policy_on_batch(update_policy_id, batch)
-        raise NotImplementedError("cent_train_policy_on_batch (per-agent centralized observations) is not on the accelerated path")
+        return self.cent_train_policy_on_batch(update_policy_id, batch)
+
+    def cent_train_policy_on_batch(self, update_policy_id, batch):
+        """Every agent has its OWN centralized observation (use_same_share_obs = False): r_maddpg.py:333-564. `batch` = the 9-tuple of
+        RecReplayBuffer.sample() with cent_obs [N, T+1, B, S]. Upstream this function fails on every input (the
+        dispatcher passes one tuple, and lines 355-356 slice the agent axis where the time axis is meant); the semantics here are
+        the ones the code plainly intends, pinned on outputs of the reference run with that reading (oracle/make_golden_cent.py,
+        tests/golden/r*_cent_*.npz).
+        The critic is trained on N*B episodes -- episode (i, b) = episode b seen through agent i's observation, joint actions,
+        rewards and dones repeated (lines 361-379) -- and in the actor update copy i of episode b carries agent i's observation
+        (line 544). Both are the shared-observation update on a batch laid out as N*B episodes, with the actor objective's copy
+        `rep` of episode (i, b) counted only for rep == i (ope_rddpg_cfg.actor_row_weight): the same C-ABI calls, correct rather
+        than tuned -- the actor pass evaluates N times the rows it needs."""
+        obs_b, cent_b, act_b, rew_b, dones_b, dones_env_b, avail_b, importance_weights, idxes = batch
+        pid = update_policy_id
+        if self.multi_policy:
+            raise NotImplementedError("cent_train_policy_on_batch with several policies is not on the accelerated path")
+        if self.use_per:
+            raise NotImplementedError("cent_train_policy_on_batch returns N*B priorities for B indices upstream (r_maddpg.py:447-449), "
+                                      "which the buffer rejects: uniform replay only")
+        policy = self.policies[pid]
+        obs = self._to_device_layout(obs_b[pid], True)                      # [T+1, N, B, D]
+        cent = self._to_device_layout(cent_b[pid], True)                    # [T+1, N, B, S]
+        acts = self._to_device_layout(act_b[pid], True)
+        rew = self._to_device_layout(rew_b[pid], True)
+        dones = self._to_device_layout(dones_b[pid], True)
+        dones_env = self._to_device_layout(dones_env_b[pid], False)         # [T, B, 1]
+        avail = self._to_device_layout(avail_b[pid], True) if (avail_b is not None and avail_b[pid] is not None) else None
+        T1, N, B, _ = obs.shape
+        T, A = self.episode_length, policy.act_dim
+        tile = lambda x: None if x is None else x.repeat(1, 1, N, 1).contiguous()     # [., N, N*B, .]: column (i, b) <- b
+        share_v = cent.reshape(T1, N * B, cent.shape[-1]).contiguous()                 # column (i, b) = agent i's observation of b
+        eye = torch.eye(N, **self.tpdv).repeat_interleave(B, dim=1).contiguous()       # [N, N*B]: copy a of episode (i, b) counts iff a == i
+        # the reference draws its noise for the N*B real rows ([T(+1), N*B, A], target noise first): same draws, repeated per copy
+        draw = (lambda shape: torch.rand(shape, **self.tpdv)) if self.device_noise else (lambda shape: sample_gumbel_uniform(shape).to(self.device))
+        rep = lambda u, L: u.view(L, N, B, A).repeat(1, 1, N, 1).view(L, N * N * B, A).contiguous()
+        u_t = rep(draw((T + 1, N * B, A)), T + 1) if policy.target_noise is not None else None
+        update_actor = self.num_updates[pid] % self.actor_update_interval == 0
+        u_a = rep(draw((T, N * B, A)), T) if update_actor else None
+        self._noise_override = (u_t, u_a)
+        self._actor_row_weight = eye
+        try:
+            return self._train_on_device_batch(policy, pid, tile(obs), share_v, tile(acts), tile(rew), tile(dones),
+                                               dones_env.repeat(1, N, 1).contiguous(), tile(avail), None, idxes)
+        finally:
+            self._actor_row_weight = None
 
     def _adam(self, opt, n, flat, flat_tgt, grad, scratch, qden, skip=(0, 0)):
         opt.step_count += 1
@@ -170,6 +215,9 @@ class R_MADDPG(object):
             acts = torch.cat([a_q for _, _, a_q, _ in others], dim=1).contiguous()      # [T][N_total][B][A]
             cfg.dims.n_agents, cfg.n_total_agents, cfg.agent_offset = N, NT, self.agent_offset[pid]
             cfg.joint_next_acts = _lib.ptr(joint_next).value
+        roww = getattr(self, "_actor_row_weight", None)
+        if roww is not None:
+            cfg.actor_row_weight = _lib.ptr(roww).value
         ws, (gc, ga, scratch) = self._workspace(policy, cfg)
         f = _lib.Fields()
         f.obs, f.share_obs, f.acts, f.rewards = _lib.ptr(obs).value, _lib.ptr(share).value, _lib.ptr(acts).value, _lib.ptr(rew).value
@@ -215,6 +263,7 @@ class R_MADDPG(object):
         u_a = None
         if update_actor:
             u_a = override[1].to(self.device, dtype=torch.float32).contiguous() if override is not None else draw((T, N * B, A))
+            assert u_a.shape == (T, N * B, A)
             _lib.check(_lib.lib.ope_rddpg_actor_loss_and_grad(C.byref(cfg), C.byref(f), _lib.ptr(policy.actor._flat),
                                                               _lib.ptr(policy.critic._flat), _lib.ptr(u_a), _lib.ptr(ws), ws.numel(),
                                                               _lib.ptr(ga), st), "ope_rddpg_actor_loss_and_grad")

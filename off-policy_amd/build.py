@@ -25,31 +25,49 @@ def _stale(out, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True, extra_flags=()):
+SAN_LIB = os.path.join(HERE, "libope_asan.so")
+SAN_FLAGS = ["-O1", "-g", "-Xarch_host", "-fsanitize=address,undefined", "-Xarch_host", "-fno-omit-frame-pointer"]
+
+
+def sanitizer_runtime():
+    """The AddressSanitizer runtime that must be LD_PRELOADed into a Python process that loads libope_asan.so."""
+    import glob
+    hits = sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))
+    return hits[-1] if hits else None
+
+
+def build(force=False, verbose=True, extra_flags=(), sanitize=False):
+    """sanitize=True: the HOST side of the same sources (argument checks, layout / workspace planning, launch orchestration: the
+    C-ABI shim) instrumented with AddressSanitizer + UndefinedBehaviorSanitizer into libope_asan.so (objects under csrc/asan/);
+    device code is compiled as usual. tests/test_sanitizer_host.py drives every entry point that returns before its first launch
+    through it ("sanitizer build of the shim")."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "ope.h"))
     objs = []
     procs = []
+    lib = SAN_LIB if sanitize else LIB
+    flags = [f for f in FLAGS if f != "-O3"] + SAN_FLAGS if sanitize else FLAGS
+    odir = os.path.join(CSRC, "asan") if sanitize else CSRC
+    os.makedirs(odir, exist_ok=True)
     for src in sources():
-        obj = src[:-4] + ".o"
+        obj = os.path.join(odir, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
-            cmd = [hipcc] + FLAGS + list(extra_flags) + ["-c", src, "-o", obj]
+            cmd = [hipcc] + flags + list(extra_flags) + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd)))
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed on " + src)
-    if force or procs or _stale(LIB, objs):
-        cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs
+    if force or procs or _stale(lib, objs):
+        cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", lib] + (["-fsanitize=address,undefined"] if sanitize else []) + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print("built", LIB)
+    print("built", build(force="--force" in sys.argv, sanitize="--sanitize" in sys.argv))

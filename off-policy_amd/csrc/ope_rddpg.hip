@@ -297,11 +297,13 @@ __global__ void __launch_bounds__(256) rcritic_td_kernel(RTdArgs a) {
 // Actor objective (r_maddpg.py:309-313): rows (t, agent i, b); keep = 1 - dones[t-1][i][b] (1 at t = 0);
 //   loss_sum = -sum Q_0 keep ; mask_count = sum keep ; dQ_0 = -keep
 __global__ void __launch_bounds__(256) ractor_obj_kernel(const float* __restrict__ q, int K, const float* __restrict__ dones, int rows,
-                                                          int NB, float* __restrict__ dq, float* __restrict__ loss_part) {
+                                                          int NB, const float* __restrict__ row_weight, float* __restrict__ dq,
+                                                          float* __restrict__ loss_part) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   const bool ok = r < rows;
   const int rr = ok ? r : 0;
-  const float keep = !ok ? 0.f : (rr < NB ? 1.0f : 1.0f - dones[rr - NB]);   // dones [T][N][B][1] has the row order of q
+  float keep = !ok ? 0.f : (rr < NB ? 1.0f : 1.0f - dones[rr - NB]);   // dones [T][N][B][1] has the row order of q
+  if (row_weight) keep *= row_weight[rr % NB];                          // ope_rddpg_cfg.actor_row_weight [N][B] (row within a step)
   const float q0 = ok ? q[(int64_t)rr * K] : 0.f;
   if (ok) {
     dq[(int64_t)r * K] = -keep;
@@ -723,8 +725,8 @@ extern "C" int ope_rddpg_actor_loss_and_grad(const ope_rddpg_cfg* cfg, const ope
   }
   if ((rc = rcell(p, W + p.SC.gi, W + p.c_h, p.Ra, p.N, -1, theta_critic, p.CL, W + p.h_b, W, &p.SC, st))) return rc;
   if ((rc = rhead(W + p.h_b, p.Ra, p.K, theta_critic, p.CL, W + p.q, W, &p.SC, st))) return rc;
-  OPE_L(hipLaunchKernelGGL(ractor_obj_kernel, dim3(launch1d(Ra)), dim3(256), 0, st, W + p.q, p.K, bt->dones, Ra, p.NB, W + p.dq,
-                           W + p.loss_part));
+  OPE_L(hipLaunchKernelGGL(ractor_obj_kernel, dim3(launch1d(Ra)), dim3(256), 0, st, W + p.q, p.K, bt->dones, Ra, p.NB, cfg->actor_row_weight,
+                           W + p.dq, W + p.loss_part));
   // critic adjoint down to its input (parameters frozen), through the gumbel-softmax into the actor logits
   OPE_L(hipLaunchKernelGGL(head_bwd_dense_kernel, dim3(ope_cdiv(Ra, 64)), dim3(256), 0, st, W + p.dq, p.K, p.K, theta_critic + p.CL.q_w,
                            theta_critic + p.CL.lno_w, W + p.SC.xhat_o, W + p.SC.rstd_o, Ra, W + p.dh_out));

@@ -88,9 +88,16 @@ class MaddpgOracle(object):
             nact = gumbel_hard(lg, s_nav, torch.as_tensor(u_target)) if self.td3 else onehot_argmax(lg, s_nav)
         return list(nact.split(B, dim=0))
 
-    def train_step(self, batch, u_target=None, u_actor=None, weights=None, soft_update=True, joint=None, all_acts=None, offset=0):
+    def train_step(self, batch, u_target=None, u_actor=None, weights=None, soft_update=True, joint=None, all_acts=None, offset=0,
+                   per_agent_cent=False):
         """`joint` / `all_acts` / `offset` (several policies, maddpg.py:40-80): joint = (buffer actions of ALL agents [B, NT*A], next
-        actions of ALL agents' target actors [B, NT*A]); all_acts = the per-agent buffer actions; offset = this policy's first agent."""
+        actions of ALL agents' target actors [B, NT*A]); all_acts = the per-agent buffer actions; offset = this policy's first agent.
+        `per_agent_cent` = MADDPG.cent_train_policy_on_batch (maddpg.py:251-419; use_same_share_obs = False): batch[1] / batch[5] are
+        [N, B, S] -- every agent's own centralized observation -- and the critic is trained on the N*B rows (agent i's observation,
+        the joint action; lines 279-286), rewards / dones / importance weights repeated per agent (287-288, 306), priorities
+        averaged over the agents (325-326); the actor's copy i is evaluated on agent i's observation (line 399). Upstream the
+        function crashes on the critic's list of heads; the pinned semantics are those of oracle/make_golden_cent.py's patch: head 0
+        (one head: MADDPG)."""
         hp, N = self.hp, self.N
         obs, cent, acts, rew, nobs, ncent, dones, dones_env, valid, avail, navail = [
             torch.as_tensor(np.ascontiguousarray(x)) if x is not None else None for x in batch]
@@ -105,17 +112,22 @@ class MaddpgOracle(object):
                 cent_nact = torch.cat(nact.split(B, dim=0), dim=-1)
             else:
                 cent_nact = joint[1]
-            nq = self.critic_q(self.critic_tgt, self.heads_tgt, ncent, cent_nact).min(dim=-1, keepdim=True)[0]
-            target = rew[0].view(-1, 1) + hp.gamma * (1 - dones_env.view(-1, 1)) * nq
+            rep = N if per_agent_cent else 1
+            if per_agent_cent:
+                assert not self.td3 and joint is None, "cent variant: one critic head, one policy (see make_golden_cent.py)"
+                cent, ncent = torch.cat(list(cent), 0), torch.cat(list(ncent), 0)            # [N*B, S], row = agent * B + b
+            nq = self.critic_q(self.critic_tgt, self.heads_tgt, ncent, cent_nact.repeat(rep, 1)).min(dim=-1, keepdim=True)[0]
+            target = rew[0].view(-1, 1).repeat(rep, 1) + hp.gamma * (1 - dones_env.view(-1, 1).repeat(rep, 1)) * nq
         cent_act = torch.cat(list(acts), dim=-1) if joint is None else joint[0]
         live = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in self.critic.items())
-        q = self.critic_q(live, self.heads, cent, cent_act)
+        q = self.critic_q(live, self.heads, cent, cent_act.repeat(rep, 1))
         errs = [target - q[:, k:k + 1] for k in range(q.shape[1])]
         f = (lambda e: huber(e, hp.huber_delta)) if hp.use_huber_loss else (lambda e: e ** 2)
         if hp.use_per:
-            w = torch.as_tensor(np.asarray(weights), dtype=torch.float32)
+            w = torch.as_tensor(np.asarray(weights), dtype=torch.float32).repeat(rep)
             closs = sum((f(e).flatten() * w).mean() for e in errs)
-            prio = np.stack([e.abs().detach().numpy().flatten() for e in errs]).mean(axis=0) + hp.per_eps
+            td = np.stack([e.abs().detach().numpy().flatten() for e in errs]).mean(axis=0)
+            prio = (np.mean(np.split(td, rep), axis=0) if rep > 1 else td) + hp.per_eps
         else:
             closs = sum(f(e).mean() for e in errs)
             prio = None
@@ -132,7 +144,7 @@ class MaddpgOracle(object):
             parts = [agent_acts[i] if a == offset + i else every[a] for a in range(len(every))]
             rows.append(torch.cat(parts, dim=-1))
         joint = torch.cat(rows, dim=0)
-        q1 = self.critic_q(self.critic, self.heads, cent.repeat(N, 1), joint)[:, 0:1]
+        q1 = self.critic_q(self.critic, self.heads, cent if per_agent_cent else cent.repeat(N, 1), joint)[:, 0:1]
         vmask = torch.cat(list(valid), dim=0)
         aloss = -(q1 * vmask).sum() / vmask.sum()
         anames = [k for k in la if ".fc_h." not in k]

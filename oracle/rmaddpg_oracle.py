@@ -83,9 +83,13 @@ class RMaddpgOracle(object):
             nact = gumbel_hard(lg, s_av, torch.as_tensor(u_target)) if self.td3 else onehot_argmax(lg, s_av)
         return list(nact[1:].split(B, dim=1))
 
-    def critic_loss(self, live, batch, u_target=None, weights=None, joint=None):
+    def critic_loss(self, live, batch, u_target=None, weights=None, joint=None, per_agent_cent=False):
         """Returns (loss, errors list [T,B,1] per head, mask_count). batch = sample_inds 7-tuple ([N,T(+1),B,.] agent fields).
-        `joint` (multi-policy updates) = (cent_act [T,B,NT*A], cent_nact [T,B,NT*A]) over ALL policies' agents."""
+        `joint` (multi-policy updates) = (cent_act [T,B,NT*A], cent_nact [T,B,NT*A]) over ALL policies' agents.
+        `per_agent_cent` = R_MADDPG.cent_train_policy_on_batch (r_maddpg.py:333-456; use_same_share_obs = False): batch[1] is
+        [N, T+1, B, S]; the agents' sequences are stacked along the batch axis (lines 361-362, with the time-axis reading of the
+        `[:-1]` / `[1:]` slices at 355-356 that oracle/make_golden_cent.py documents) and the joint actions, rewards and dones
+        repeated per agent (376-379): the same loss over N*B episodes."""
         hp, N, K = self.hp, self.N, self.K
         obs, cent, acts, rew, dones, dones_env, avail = [torch.as_tensor(np.ascontiguousarray(x)) if x is not None else None for x in batch]
         T, B = acts.shape[1], acts.shape[2]
@@ -100,6 +104,11 @@ class RMaddpgOracle(object):
                 nact = gumbel_hard(lg, s_av, torch.as_tensor(u_target)) if self.td3 else onehot_argmax(lg, s_av)
                 cent_nact = torch.cat(nact[1:].split(B, dim=1), dim=-1)      # [T, B, N*A]
             cent_act = torch.cat(list(acts), dim=-1)                         # [T, B, N*A]
+        if per_agent_cent:
+            cent = torch.cat(list(cent), dim=1)                              # [T+1, N*B, S], column = agent * B + b
+            cent_act, cent_nact = cent_act.repeat(1, N, 1), cent_nact.repeat(1, N, 1)
+            rew, dones_env = rew.repeat(1, 1, N, 1), dones_env.repeat(1, N, 1)
+            B = N * B
         cent_obs, cent_nobs = cent[:-1], cent[1:]
         q, _ = critic_q(live, K, cent_obs, cent_act, torch.zeros(B, H))
         with torch.no_grad():
@@ -122,9 +131,11 @@ class RMaddpgOracle(object):
             loss = sum(f(e).sum() / cnt for e in errs)
         return loss, errs, cnt
 
-    def actor_loss(self, live, batch, u_actor, all_acts=None, offset=0):
+    def actor_loss(self, live, batch, u_actor, all_acts=None, offset=0, per_agent_cent=False):
         """`all_acts` (multi-policy updates): list of every agent's buffer actions [T,B,A] in joint order; this policy's agents are
-        entries offset .. offset + N - 1 (act_sequence_replace_ind_start, r_maddpg.py:66-67, 291-301)."""
+        entries offset .. offset + N - 1 (act_sequence_replace_ind_start, r_maddpg.py:66-67, 291-301).
+        `per_agent_cent` (r_maddpg.py:458-556): copy i of the batch carries agent i's own centralized observation (line 544 reads
+        `all_agent_cent_obs`) instead of a repeat of the shared one."""
         hp, N, K = self.hp, self.N, self.K
         obs, cent, acts, rew, dones, dones_env, avail = [torch.as_tensor(np.ascontiguousarray(x)) if x is not None else None for x in batch]
         T, B = acts.shape[1], acts.shape[2]
@@ -134,8 +145,7 @@ class RMaddpgOracle(object):
         lg, _ = actor_logits(live, s_obs, torch.zeros(N * B, H))
         pol = gumbel_hard(lg, s_av, torch.as_tensor(u_actor))            # [T, N*B, A]
         agent_seqs = pol.split(B, dim=1)
-        cent_obs = cent[:-1]
-        stacked_obs = cent_obs.repeat(1, N, 1)
+        stacked_obs = torch.cat(list(cent), dim=1)[:-1] if per_agent_cent else cent[:-1].repeat(1, N, 1)
         every = list(acts) if all_acts is None else list(all_acts)
         buf_joint = torch.cat(every, dim=-1).repeat(1, N, 1)             # [T, N*B, NT*A]
         rows = []
@@ -153,11 +163,12 @@ class RMaddpgOracle(object):
         dm = torch.cat([torch.cat([torch.zeros(1, B, 1), dones[i][:T - 1]], dim=0) for i in range(N)], dim=1)
         return (-(qs * (1 - dm))).sum() / (1 - dm).sum()
 
-    def train_step(self, batch, u_target=None, u_actor=None, weights=None, soft_update=True, joint=None, all_acts=None, offset=0):
+    def train_step(self, batch, u_target=None, u_actor=None, weights=None, soft_update=True, joint=None, all_acts=None, offset=0,
+                   per_agent_cent=False):
         hp = self.hp
         update_actor = self.num_updates % self.actor_update_interval == 0
         live = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in self.critic.items())
-        closs, errs, _ = self.critic_loss(live, batch, u_target, weights, joint=joint)
+        closs, errs, _ = self.critic_loss(live, batch, u_target, weights, joint=joint, per_agent_cent=per_agent_cent)
         names = [k for k in live if ".fc_h." not in k]
         cg = dict(zip(names, torch.autograd.grad(closs, [live[k] for k in names])))
         cnorm = self._adam_step("critic", self.critic, cg)
@@ -170,7 +181,7 @@ class RMaddpgOracle(object):
                    critic_grads={k: v.numpy() for k, v in cg.items()})
         if update_actor:
             la = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in self.actor.items())
-            aloss = self.actor_loss(la, batch, u_actor, all_acts=all_acts, offset=offset)
+            aloss = self.actor_loss(la, batch, u_actor, all_acts=all_acts, offset=offset, per_agent_cent=per_agent_cent)
             anames = [k for k in la if ".fc_h." not in k]
             ag = dict(zip(anames, torch.autograd.grad(aloss, [la[k] for k in anames])))
             out.update(actor_loss=float(aloss.detach()), actor_grad_norm=self._adam_step("actor", self.actor, ag),

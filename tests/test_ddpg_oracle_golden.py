@@ -29,7 +29,10 @@ def noise_for(g, step):
     return u_t, u_a
 
 
-@pytest.mark.parametrize("name", CASES)
+CENT_CASES = ["maddpg_cent_small", "maddpg_cent_huber_per"]   # cent_train_policy_on_batch (per-agent centralized observations), oracle/make_golden_cent.py
+
+
+@pytest.mark.parametrize("name", CASES + CENT_CASES)
 def test_train_steps_match_reference(name):
     g = load_golden(name)
     orc = ddpg_oracle_from(g)
@@ -37,7 +40,7 @@ def test_train_steps_match_reference(name):
     w = g["per_weights"] if "per_weights" in g else None
     for s in range(len(g["critic_loss"])):
         u_t, u_a = noise_for(g, s)
-        out = orc.train_step(batch, u_t, u_a, weights=w)
+        out = orc.train_step(batch, u_t, u_a, weights=w, per_agent_cent=name in CENT_CASES)
         np.testing.assert_allclose(out["critic_loss"], g["critic_loss"][s], rtol=3e-5)
         np.testing.assert_allclose(out["critic_grad_norm"], g["critic_grad_norm"][s], rtol=3e-5)
         np.testing.assert_allclose(out["actor_loss"], g["actor_loss"][s], rtol=1e-4, atol=1e-6)

@@ -30,7 +30,10 @@ def rnoise_for(g, step, update_actor=True):
     return u_t, u_a
 
 
-@pytest.mark.parametrize("name", CASES)
+CENT_CASES = ["rmaddpg_cent_tiny", "rmatd3_cent_odd"]      # cent_train_policy_on_batch (per-agent centralized observations), oracle/make_golden_cent.py
+
+
+@pytest.mark.parametrize("name", CASES + CENT_CASES)
 def test_train_steps_match_reference(name):
     g = load_golden(name)
     orc = rddpg_oracle_from(g)
@@ -39,7 +42,7 @@ def test_train_steps_match_reference(name):
     for s in range(len(g["critic_loss"])):
         upd = bool(g["update_actor"][s])
         u_t, u_a = rnoise_for(g, s, upd)
-        out = orc.train_step(batch, u_t, u_a, weights=w)
+        out = orc.train_step(batch, u_t, u_a, weights=w, per_agent_cent=name in CENT_CASES)
         assert out["update_actor"] == upd
         np.testing.assert_allclose(out["critic_loss"], g["critic_loss"][s], rtol=3e-5)
         np.testing.assert_allclose(out["critic_grad_norm"], g["critic_grad_norm"][s], rtol=5e-5)
