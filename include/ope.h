@@ -185,6 +185,10 @@ typedef struct ope_qmix_cfg {
   int32_t scan_family;  /* GRU scan kernels: 4 = ope_gru4.hip, 1 = ope_gru1.hip, 0 = by row count                                  */
   int32_t scan_waves;   /* family 4: compute waves per row, 2 | 4, 0 = by row count                                                */
   int32_t debug;        /* 1: keep extra intermediates and per-wave phase stamps in the workspace ("q_all", "dbg")               */
+  int32_t trunk_path;   /* forward trunk of the live + target agent nets: 0 = by shape; 3 = one trunk_fwd3 launch per net (weights in
+                         *  registers, four waves per 16-row tile); 4 = both nets in one trunk_fwd4 launch (weights in LDS, one wave per
+                         *  tile; recurrent nets whose input width is a multiple of 4 in (48, 64], (112, 128], (176, 192] or (240, 256] -- what "by shape"
+                         *  picks from 16 384 rows on; other widths run path 3)                    */
 } ope_qmix_cfg;
 
 /* Flat parameter vector: the reference's named_parameters() order (agent q-network, then mixer; qmix.py:67-72),

@@ -114,8 +114,9 @@ class MADDPG(object):
         tile = lambda x: None if x is None else x.repeat(1, N, 1).contiguous()          # [N, N*B, .]: column (i, b) <- b
         eye = torch.eye(N, device=dev).repeat_interleave(B, dim=1)[..., None]           # copy a of transition (i, b) counts iff a == i
         w = importance_weights
+        dev_prio = torch.is_tensor(importance_weights)      # device trees hand tensors in and take tensors back; host trees numpy
         if self.use_per:
-            w = (w.to(dev, dtype=torch.float32) if torch.is_tensor(w) else torch.as_tensor(np.asarray(w), dtype=torch.float32).to(dev)).repeat(N)
+            w = (w.to(dev, dtype=torch.float32) if dev_prio else torch.as_tensor(np.asarray(w), dtype=torch.float32).to(dev)).repeat(N)
         # the reference draws the actor's gumbel noise for the N*B real rows: same draws, repeated per copy
         u = torch.rand((N * B, A), **self.tpdv) if self.device_noise else sample_gumbel_uniform((N * B, A)).to(dev)
         self._noise_override = (None, u.view(N, B, A).repeat(1, N, 1).view(N * N * B, A).contiguous())
@@ -127,6 +128,8 @@ class MADDPG(object):
         if prio is not None:       # maddpg.py:325-326: mean over the agents of |TD|, + per_eps once
             eps = self.per_eps
             prio = ((prio - eps).reshape(N, B).mean(0) + eps) if torch.is_tensor(prio) else (np.asarray(prio) - eps).reshape(N, B).mean(0) + eps
+            if torch.is_tensor(prio) and not dev_prio:
+                prio = prio.cpu().numpy()
         return info, prio, idxes
 
     def _gsq_region(self, cfg, ws, name, n_opt, n_all):

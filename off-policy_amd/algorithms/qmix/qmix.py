@@ -77,7 +77,8 @@ class QMix(object):
         # per-trainer kernel choices / diagnostics, sent with every call in ope_qmix_cfg (0 = the library's choice by shape): two
         # trainers in one process do not share them. `mixer_path`: 1 resident-weight mixer, 2 streamed, 3 wide-state GEMM;
         # `time_chunks`: two-stream schedule; `scan_family` / `scan_waves`: GRU scan kernels; `debug`: keep intermediates.
-        self.tune = dict(mixer_path=0, time_chunks=0, scan_family=0, scan_waves=0, debug=0)
+        # `trunk_path`: 3 = one trunk launch per net (weights in registers), 4 = both nets in one launch (weights in LDS).
+        self.tune = dict(mixer_path=0, time_chunks=0, scan_family=0, scan_waves=0, debug=0, trunk_path=0)
         self._ws = {}
         self._gsq = {}
         if self.multi:
@@ -286,6 +287,7 @@ class QMix(object):
         t = self.tune
         cfg.mixer_path, cfg.time_chunks = int(t["mixer_path"]), int(t["time_chunks"])
         cfg.scan_family, cfg.scan_waves, cfg.debug = int(t["scan_family"]), int(t["scan_waves"]), int(t["debug"])
+        cfg.trunk_path = int(t["trunk_path"])
         return cfg
 
     def _workspace(self, cfg):

@@ -130,6 +130,8 @@ struct TrunkBwdArgs {
 };
 
 int launch_trunk_fwd(const TrunkFwdArgs& a, bool save, hipStream_t st);
+// live (saving) + target trunk of the same input rows: one launch of trunk_fwd4 (ope_trunk4.hip) when the shape allows, else two launches
+int launch_trunk_fwd_pair(const TrunkFwdArgs& live, const TrunkFwdArgs& tgt, int path, hipStream_t st);
 int launch_trunk_fwd2(const TrunkFwdArgs& a, bool save, hipStream_t st);   // workgroup-cooperative form (ope_trunk2.hip)
 int launch_trunk_fwd3(const TrunkFwdArgs& a, bool save, hipStream_t st);   // persistent, weights in registers (ope_trunk2.hip)
 // Replicated-rows trunk (RepIn): `base` = TrunkFwdArgs over the T*B base rows (x = the base input [T*B][D]), `a` over the R = T*N*B

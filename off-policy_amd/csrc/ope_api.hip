@@ -19,6 +19,7 @@ bool cfg_ok(const ope_qmix_cfg* c) {
   if (c->mlp && d.episode_length != 1) return false;   // MLP (transition) mode = one-step "episodes"
   if (c->phase < 0 || c->phase > 3) return false;
   if (c->mixer_path < 0 || c->mixer_path > 3 || c->time_chunks < 0 || c->time_chunks > kMaxChunksCfg) return false;
+  if (c->trunk_path != 0 && c->trunk_path != 3 && c->trunk_path != 4) return false;
   return d.n_agents >= 1 && d.act_dim >= 1 && d.obs_dim >= 1 && d.obs_dim <= 512 && d.state_dim >= 1 &&
          d.episode_length >= 1 && c->batch >= 1 && d.n_agents <= 64 && d.act_dim <= 200;
 }
@@ -312,11 +313,10 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
     tf.xhat1 = W + p.xhat1 + r0 * OPE_H; tf.rstd1 = W + p.rstd1 + r0; tf.mask1 = (uint64_t*)(W + p.mask1) + r0;
     tf.xhat2 = W + p.xhat2 + r0 * OPE_H; tf.rstd2 = W + p.rstd2 + r0; tf.mask2 = (uint64_t*)(W + p.mask2) + r0;
     tf.dbg = dbg_on ? (long long*)(W + p.dbg) + 16 * 2400 : nullptr;
-    if ((rc = launch_trunk_fwd(tf, true, st))) return rc;
     TrunkFwdArgs tt = tf;
     tt.dbg = nullptr;
     tt.theta = theta_tgt; tt.gi = p.mlp ? nullptr : W + p.gi_t + r0 * 3 * OPE_H; tt.a2_out = p.mlp ? W + p.h_t + r0 * OPE_H : nullptr;
-    if ((rc = launch_trunk_fwd(tt, false, st))) return rc;
+    if ((rc = launch_trunk_fwd_pair(tf, tt, cfg->trunk_path, st))) return rc;    // one launch for both nets where the shape allows it (ope_trunk4.hip)
     if (p.mlp) continue;
     hipStream_t scan_st = side;
     if ((rc = sync_to(st, side))) return rc;

@@ -1,0 +1,412 @@
+// trunk_fwd4: the agent network's row-parallel trunk (feature LayerNorm -> fc1 -> ReLU -> LN -> fc2 -> ReLU -> LN -> W_ih) of the LIVE and the
+// TARGET net in ONE launch, weights resident in LDS, one wave per 16-row tile.
+//   MLPBase.forward / MLPLayer.forward   offpolicy/algorithms/utils/mlp.py:25-29, 52-89
+//   RNNLayer's input projection (nn.GRU weight_ih_l0 / bias_ih_l0)   offpolicy/algorithms/utils/rnn.py:19-23
+//   called once per net by QMix.train_policy_on_batch   offpolicy/algorithms/qmix/qmix.py:127-148
+//
+// Why another trunk kernel. trunk_fwd3 (ope_trunk2.hip) keeps a net's weights in REGISTERS (128 VGPRs of fragments at D = 252), four waves
+// share a 16-row tile (16 output features each) and meet through LDS behind 4-5 workgroup barriers per tile; with 254 registers only two such
+// workgroups fit a CU, and a tile spends 4.1 k of its 14.4 k cycles issuing MFMAs: 41 + 38 us for the two nets at
+// 3s5z, 39-42 % of the f32 matrix pipe, and the observation rows are read from HBM twice.
+// Here a CU holds ONE net's weights in LDS (fc1 64 x D, fc2, W_ih: 128 KB at D <= 256), staged once per launch, even CUs the live net, odd CUs
+// the target; a WAVE owns whole 16-row tiles and walks them through all three layers alone:
+//   * no barrier after the prologue. A layer's output fragment (lane (j, g): features 16 it + 4 g .. + 3 of row j) IS the next layer's MFMA
+//     B operand (the "transposed chain" convention, ope_common.h), LayerNorm statistics are 16 local values + two lane swaps: nothing of a
+//     tile ever leaves the wave's registers except the saves;
+//   * weights are the MFMA A operand, read from LDS as needed: one ds_read_b128 per four MFMAs (160 reads, 640 LDS-array cycles, per 512 MFMAs
+//     = 16.4 k matrix-pipe cycles of a tile), conflict-free by an XOR swizzle of the 16-byte column slot with 2 (row & 7) (the ds_read_b128
+//     lane groups hold rows {0-3, 12-15} at slot P and {4-11} at P ^ 1: the swizzle spreads each set over the 8 even residues);
+//   * latency is hidden by the OTHER wave of the SIMD (two per SIMD, each in its own tile, in whatever phase it happens to be) and by
+//     requesting the next tile's observation rows right after fc1 has consumed this tile's: they land behind fc2 / W_ih, in the registers
+//     fc1 just freed;
+//   * the two waves of a SIMD draw their tiles from one LDS counter, so a SIMD's share of the 2 416 tiles per net (4.72) is what balances,
+//     not a wave's.
+// The observation rows are still read once per net (the nets sit on different CUs), but within one launch and largely out of L2.
+#include <stdlib.h>
+
+#include "ope_agent.h"
+
+namespace ope {
+
+namespace {
+
+__device__ __forceinline__ int wslot(int row, int p) { return p ^ ((row & 7) << 1); }   // swizzled 16-byte slot of logical slot p in `row`
+
+template <int KCM>
+struct T4 {
+  static constexpr int RS1 = 4 * KCM;                 // 16-byte slots per fc1 row
+  static constexpr int W1F = OPE_H * 16 * KCM;        // floats
+  static constexpr int W2F = OPE_H * OPE_H;
+  static constexpr int W3F = 3 * OPE_H * OPE_H;
+  static constexpr int FNP = 2 * 16 * KCM;            // input LayerNorm gamma / beta, zero beyond D
+  static constexpr int LNP = 6 * OPE_H;               // b1, ln1 w, ln1 b, b2, ln2 w, ln2 b
+  static constexpr int BIH = 3 * OPE_H;
+  static constexpr int TOTAL = W1F + W2F + W3F + FNP + LNP + BIH + 16;
+};
+
+}  // namespace
+
+// lean argument block (two full TrunkFwdArgs cost ~170 spilled SGPRs): what differs between the nets is the parameter vector and the gi
+// destination; the saves belong to net 0
+struct TrunkPairArgs {
+  const float* x; int R, D; int nets;
+  const float* theta[2];
+  float* gi[2];
+  int fn_w, fn_b, fc1_w, fc1_b, ln1_w, ln1_b, fc2_w, fc2_b, ln2_w, ln2_b, wih, bih;
+  float* mu0; float* rstd0; float* xhat1; float* rstd1; float* mu1; uint64_t* mask1; float* xhat2; float* rstd2; uint64_t* mask2;
+  long long* dbg;
+};
+
+// KCM = ceil(D / 16) exactly and D % 4 == 0: every 16-column chunk but the last is complete, and a 16-byte piece of the last one is inside
+// the row or entirely past it -- one per-lane predicate instead of 4 KCM hoisted column masks (which cost ~130 spilled SGPRs + 46 VGPRs)
+// NW = waves per workgroup (8 or 12: two or three per SIMD), PF = request the next tile's rows behind fc1 (keeps the 4 KCM row
+// registers live through the whole tile: 248 VGPRs, two waves per SIMD) or at the top of the tile (<= 168 VGPRs, three per SIMD).
+template <int KCM, int NW, bool PF>
+__global__ void __launch_bounds__(64 * NW, NW / 4) trunk_fwd4_kernel(TrunkPairArgs pa) {
+  using C = T4<KCM>;
+  constexpr int VEC = 4;
+  constexpr int NT = 64 * NW;
+  __shared__ __attribute__((aligned(16))) float sm[C::TOTAL];
+  float* const W1s = sm;
+  float* const W2s = W1s + C::W1F;
+  float* const W3s = W2s + C::W2F;
+  float* const fnp = W3s + C::W3F;
+  float* const lnp = fnp + C::FNP;
+  float* const bih = lnp + C::LNP;
+  int* const ctr = reinterpret_cast<int*>(bih + C::BIH);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, g = lane >> 4;
+  const int net = pa.nets == 2 ? (int)(blockIdx.x & 1) : 0;
+  const int wgn = pa.nets == 2 ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
+  const int nwg = pa.nets == 2 ? (int)(gridDim.x >> 1) : (int)gridDim.x;
+  const TrunkPairArgs& a = pa;
+  const float* __restrict__ th = net ? pa.theta[1] : pa.theta[0];
+  float* __restrict__ gi_out = net ? pa.gi[1] : pa.gi[0];
+  const int D = a.D, R = a.R;
+  const bool save = net == 0;
+
+  // optional s_memtime stamps (ope_qmix_cfg.debug; tools/trunk4_phases.py): [workgroup][wave][16] = start, weights staged, then for the
+  // wave's FIRST tile: rows arrived + statistics, fc1, LN1 + saves, fc2 + LN2 + saves, W_ih + gi stores; last: all tiles done, tiles done
+  long long* dbg = a.dbg ? a.dbg + ((int64_t)blockIdx.x * 12 + wave) * 16 : nullptr;
+  auto stamp = [&](int k) { if (dbg && lane == 0) dbg[k] = __builtin_amdgcn_s_memtime(); };
+  stamp(0);
+  // ---- tiles: the two waves of a SIMD (waves w and w + 4) draw from counter w & 3 ----
+  const int ntiles = (R + 15) >> 4;
+  const int nslots = 4 * nwg, slot0 = 4 * wgn + (wave & 3);
+  auto grab = [&]() -> int {
+    int k = 0;
+    if (lane == 0) k = __hip_atomic_fetch_add(&ctr[wave & 3], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    k = __builtin_amdgcn_readfirstlane(k);
+    const int64_t t = (int64_t)slot0 + (int64_t)nslots * k;
+    return t < ntiles ? (int)t : ntiles;
+  };
+  const float inv_d = 1.0f / (float)D;
+  f32x4 xv[KCM];
+  const bool tail_ok = 16 * (KCM - 1) + 4 * g < D;       // this lane's piece of the last chunk lies inside the row
+  // Every global access of the tile loop is (uniform base pointer) + (32-bit byte offset): all arrays are < 4 GB (R * 768 B the
+  // largest), and 64-bit per-lane addresses cost twice the registers -- the first version spilled five of them, and a scratch
+  // reload is a VMEM load: its vmcnt wait also waits for the 16 row loads just requested for the NEXT tile (13 k cycles per tile).
+  const char* __restrict__ xb = reinterpret_cast<const char*>(a.x);
+  auto request = [&](int tile) {
+    const int row = tile * 16 + j;
+    const uint32_t xo = (uint32_t)(row < R ? row : R - 1) * (uint32_t)(4 * D) + 16u * g;
+    // the last chunk's piece first, its offset recomputed here (a hoisted copy got spilled, and the reload's vmcnt wait sat in the
+    // middle of this burst of loads)
+    int gg = g;
+    asm volatile("" : "+v"(gg));
+    xv[KCM - 1] = *reinterpret_cast<const f32x4*>(xb + (xo + (16 * (KCM - 1) + 4 * gg < D ? 64u * (KCM - 1) : 0u)));   // (zeroed below when outside)
+#pragma unroll
+    for (int c = 0; c < KCM - 1; ++c) xv[c] = *reinterpret_cast<const f32x4*>(xb + (xo + 64u * c));
+  };
+  // every wave's FIRST tile is assigned statically (slot, round = wave / 4), so its rows can be requested before the weights are
+  // staged: the HBM latency of the first tile hides behind the 10 k-cycle prologue
+  int tile;
+  {
+    const int64_t t = (int64_t)slot0 + (int64_t)nslots * (wave >> 2);
+    tile = t < ntiles ? (int)t : ntiles;
+  }
+  if (PF && tile < ntiles) request(tile);
+  // ---- prologue: this net's weights -> LDS (swizzled), parameters, tile counters. Every thread requests ALL its pieces before the
+  // first LDS store (8 KCM / 16 + 2 + 6 independent 16-byte loads in flight per thread instead of one round trip per piece) ----
+  {
+    constexpr int P1 = OPE_H * C::RS1, P2 = OPE_H * 16, P3 = 3 * OPE_H * 16;                       // 16-byte pieces of the three matrices
+    constexpr int N1 = (P1 + NT - 1) / NT, N2 = (P2 + NT - 1) / NT, N3 = (P3 + NT - 1) / NT;       // per thread (a partly used last round)
+    f32x4 p1[N1], p2[N2], p3[N3];
+#pragma unroll
+    for (int u = 0; u < N1; ++u) {
+      const int i = min(tid + NT * u, P1 - 1), row = i / C::RS1, p = i - row * C::RS1;
+      p1[u] = load4c<VEC>(th + a.fc1_w + (int64_t)row * D, 4 * p < D ? 4 * p : 0, D);
+    }
+#pragma unroll
+    for (int u = 0; u < N2; ++u) p2[u] = *reinterpret_cast<const f32x4*>(th + a.fc2_w + 4 * min(tid + NT * u, P2 - 1));
+#pragma unroll
+    for (int u = 0; u < N3; ++u) p3[u] = *reinterpret_cast<const f32x4*>(th + a.wih + 4 * min(tid + NT * u, P3 - 1));
+#pragma unroll
+    for (int u = 0; u < N1; ++u) {
+      const int i = tid + NT * u, row = i / C::RS1, p = i - row * C::RS1;
+      f32x4 v = mask4(p1[u], 4 * p, D);
+      if (4 * p >= D) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (i < P1) *reinterpret_cast<f32x4*>(W1s + row * (4 * C::RS1) + 4 * wslot(row, p)) = v;
+    }
+#pragma unroll
+    for (int u = 0; u < N2; ++u) {
+      const int i = tid + NT * u, row = i >> 4, p = i & 15;
+      if (i < P2) *reinterpret_cast<f32x4*>(W2s + row * OPE_H + 4 * wslot(row, p)) = p2[u];
+    }
+#pragma unroll
+    for (int u = 0; u < N3; ++u) {
+      const int i = tid + NT * u, row = i >> 4, p = i & 15;
+      if (i < P3) *reinterpret_cast<f32x4*>(W3s + row * OPE_H + 4 * wslot(row, p)) = p3[u];
+    }
+  }
+  for (int f = tid; f < 16 * KCM; f += NT) {
+    fnp[f] = f < D ? th[a.fn_w + f] : 0.f;
+    fnp[16 * KCM + f] = f < D ? th[a.fn_b + f] : 0.f;
+  }
+  if (tid < OPE_H) {
+    lnp[tid] = th[a.fc1_b + tid]; lnp[OPE_H + tid] = th[a.ln1_w + tid]; lnp[2 * OPE_H + tid] = th[a.ln1_b + tid];
+    lnp[3 * OPE_H + tid] = th[a.fc2_b + tid]; lnp[4 * OPE_H + tid] = th[a.ln2_w + tid]; lnp[5 * OPE_H + tid] = th[a.ln2_b + tid];
+  }
+  if (tid < 3 * OPE_H) bih[tid] = th[a.bih + tid];
+  if (tid < 4) ctr[tid] = NW / 4;        // every wave's first tile is assigned statically (below): the counters start behind them
+
+  __syncthreads();                       // weights, parameters and counters are in place
+
+  // Weight-fragment addresses. wslot(j, 4 c + g) = 4 (c ^ m) + (g ^ 2 (j & 1)), m = (j >> 1) & 3: only c's two low bits meet the lane, so
+  // FOUR per-lane byte offsets (c & 3 = 0 .. 3) + compile-time immediates address every fragment of the three matrices (rows 16 it + j
+  // and chunks 4 q + cl are immediates of up to 49 920 B). (Left to hipcc: one address register per chunk, 26 in all -- with three
+  // waves per SIMD that alone was 15 % of the budget.)
+  uint32_t wo1[4], wo2[4];
+  {
+    const int m = (j >> 1) & 3, gl = g ^ (2 * (j & 1));
+#pragma unroll
+    for (int cl = 0; cl < 4; ++cl) {
+      wo1[cl] = (uint32_t)j * (64u * KCM) + 64u * (cl ^ m) + 16u * gl;       // fc1 rows: 16 KCM floats
+      wo2[cl] = (uint32_t)j * (4u * OPE_H) + 64u * (cl ^ m) + 16u * gl;      // fc2 / W_ih rows: 64 floats
+    }
+  }
+  const char* const W1b = reinterpret_cast<const char*>(W1s);
+  const char* const W2b = reinterpret_cast<const char*>(W2s);
+  const char* const W3b = reinterpret_cast<const char*>(W3s);
+  auto lnp4 = [&](int i, int it) { return *reinterpret_cast<const f32x4*>(lnp + i * OPE_H + 16 * it + 4 * g); };
+  // ReLU + LayerNorm over the 64 features of row j held as z[it][r] = feature 16 it + 4 g + r: one-pass statistics (sum, sum of
+  // squares of the post-ReLU values; E[x^2] - mean^2 at O(1) magnitudes, as trunk_fwd3), the row's four lanes meet by two lane swaps
+  auto relu_ln = [&](f32x4 (&z)[4], int gi_, int bi_, char* xhat_base, uint32_t xhat_off, float& rs, float& mu, uint64_t& bits) {
+    // ReLU mask, bit f = z[f] > 0 with f = 16 it + 4 g + r: four lane-independent bits per output tile, one lane-dependent shift by 4 g
+    // per 32-bit half (NOT sixteen hoisted per-lane 64-bit constants 1 << f: 32 registers, two of them spilled)
+    uint32_t nib[4];
+    float s = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      nib[it] = 0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        nib[it] |= (z[it][r] > 0.f ? 1u : 0u) << r;
+        z[it][r] = fmaxf(z[it][r], 0.f);
+        s += z[it][r];
+        s2 = fmaf(z[it][r], z[it][r], s2);
+      }
+    }
+    const uint64_t mb = ((uint64_t)((nib[2] | (nib[3] << 16)) << (4 * g)) << 32) | (uint64_t)((nib[0] | (nib[1] << 16)) << (4 * g));
+    s = rowsum4(s);
+    s2 = rowsum4(s2);
+    mu = s * (1.0f / OPE_H);
+    const float var = fmaxf(s2 * (1.0f / OPE_H) - mu * mu, 0.f);
+    rs = __builtin_amdgcn_rsqf(var + OPE_LN_EPS);      // v_rsq_f32 (1 ulp); the IEEE 1 / sqrtf sequence is ~25 dependent instructions
+    bits = mb;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const f32x4 gm = lnp4(gi_, it), bt = lnp4(bi_, it);
+      f32x4 xh;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        xh[r] = (z[it][r] - mu) * rs;
+        z[it][r] = fmaf(xh[r], gm[r], bt[r]);          // z becomes the layer's output = the next layer's B operand
+      }
+      if (xhat_base) *reinterpret_cast<f32x4*>(xhat_base + (xhat_off + 64u * it)) = xh;   // saved for the backward pass (live net, valid rows)
+    }
+  };
+  auto or4 = [&](uint64_t b) -> uint64_t {             // OR over the row's four lanes (j, 0..3)
+    uint32_t lo = (uint32_t)b, hi = (uint32_t)(b >> 32);
+    lo |= __shfl_xor((int)lo, 16, 64); hi |= __shfl_xor((int)hi, 16, 64);
+    lo |= __shfl_xor((int)lo, 32, 64); hi |= __shfl_xor((int)hi, 32, 64);
+    return ((uint64_t)hi << 32) | lo;
+  };
+
+  stamp(1);
+  int done = 0;
+  while (tile < ntiles) {
+    // LDS is read-only after the prologue, so LLVM hoists every parameter fragment read (biases, LayerNorm gamma / beta, b_ih: ~270
+    // registers' worth) out of the tile loop as loop invariants and then spills them; the clobber makes them per-tile reads again
+    asm volatile("" ::: "memory");
+    const int row = tile * 16 + j;
+    const bool valid = row < R;
+    if (!PF) request(tile);
+    // ---- input LayerNorm statistics of row j: 4 lanes x KCM pieces ----
+    float s = 0.f;
+    if (!tail_ok) xv[KCM - 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < KCM; ++c) s += (xv[c][0] + xv[c][1]) + (xv[c][2] + xv[c][3]);
+    const float mean = rowsum4(s) * inv_d;
+    float sq = 0.f;
+#pragma unroll
+    for (int c = 0; c < KCM; ++c) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float d = (c < KCM - 1 || tail_ok) ? xv[c][r] - mean : 0.f;
+        xv[c][r] = d;
+        sq = fmaf(d, d, sq);
+      }
+    }
+    const float rstd = __builtin_amdgcn_rsqf(fmaf(rowsum4(sq), inv_d, OPE_LN_EPS));
+    if (save && valid && g == 0) {
+      a.mu0[row] = mean;
+      a.rstd0[row] = rstd;
+    }
+    // the normalised, affine-transformed row, in place (exactly 0 beyond D): the fc1 loop below is LDS reads and MFMAs only
+#pragma unroll
+    for (int c = 0; c < KCM; ++c) {
+      if ((c & 3) == 0) __builtin_amdgcn_sched_barrier(0);     // (at most 8 parameter reads in flight: all 2 KCM of them are 128 registers)
+      const f32x4 gm = *reinterpret_cast<const f32x4*>(fnp + 16 * c + 4 * g), bt = *reinterpret_cast<const f32x4*>(fnp + 16 * KCM + 16 * c + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xv[c][r] = fmaf(xv[c][r] * rstd, gm[r], bt[r]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (done == 0) stamp(2);
+    // ---- fc1: 4 output tiles x KCM chunks ----
+    f32x4 z[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) z[it] = lnp4(0, it);
+#pragma unroll
+    for (int c = 0; c < KCM; ++c) {
+      // keep the weight reads at most two chunks ahead of their MFMAs (hipcc otherwise hoists all 4 KCM of them: 256 registers, spills)
+      if (PF ? (c & 1) == 0 : true) {
+        // the three-wave variant must not read more than one chunk of weights ahead (168 registers): a compiler-level memory
+        // barrier as well, LLVM otherwise clusters all 64 LDS reads in front of the 256 MFMAs and spills them
+        if (!PF) asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      f32x4 wv[4];
+#pragma unroll
+      for (int it = 0; it < 4; ++it) wv[it] = *reinterpret_cast<const f32x4*>(W1b + (wo1[c & 3] + (uint32_t)(16 * it * 64 * KCM + 256 * (c >> 2))));
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) z[it] = mfma16(wv[it][r], xv[c][r], z[it]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (done == 0) stamp(3);
+    // the observation registers are free: request the next tile's rows now, they arrive behind fc2 / W_ih
+    const int next = grab();
+    if (PF && next < ntiles) request(next);
+
+    float rs, mu;
+    uint64_t bits;
+    const uint32_t xh_off = (uint32_t)row * (4u * OPE_H) + 16u * g;
+    relu_ln(z, 1, 2, (save && valid) ? reinterpret_cast<char*>(a.xhat1) : nullptr, xh_off, rs, mu, bits);
+    if (save) {
+      const uint64_t m = or4(bits);
+      if (valid) {
+        if (g == 0) {
+          a.mask1[row] = m;
+          a.rstd1[row] = rs;
+          if (a.mu1) a.mu1[row] = mu;
+        }
+      }
+    }
+    if (done == 0) stamp(4);
+    // ---- fc2 ----
+    f32x4 z2[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) z2[it] = lnp4(3, it);
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft) {
+      f32x4 wv[4];
+#pragma unroll
+      for (int it = 0; it < 4; ++it) wv[it] = *reinterpret_cast<const f32x4*>(W2b + (wo2[ft] + (uint32_t)(16 * it * 4 * OPE_H)));
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) z2[it] = mfma16(wv[it][r], z[ft][r], z2[it]);
+    }
+    relu_ln(z2, 4, 5, (save && valid) ? reinterpret_cast<char*>(a.xhat2) : nullptr, xh_off, rs, mu, bits);
+    if (save) {
+      const uint64_t m = or4(bits);
+      if (valid) {
+        if (g == 0) {
+          a.mask2[row] = m;
+          a.rstd2[row] = rs;
+        }
+      }
+    }
+    if (done == 0) stamp(5);
+    // ---- gi = W_ih a2 + b_ih: 12 output tiles, four at a time ----
+#pragma unroll
+    for (int u0 = 0; u0 < 12; u0 += 4) {
+      f32x4 o[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) o[u] = *reinterpret_cast<const f32x4*>(bih + 16 * (u0 + u) + 4 * g);
+#pragma unroll
+      for (int ft = 0; ft < 4; ++ft) {
+        if ((ft & 1) == 0) __builtin_amdgcn_sched_barrier(0);
+        f32x4 wv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) wv[u] = *reinterpret_cast<const f32x4*>(W3b + (wo2[ft] + (uint32_t)(16 * (u0 + u) * 4 * OPE_H)));
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) o[u] = mfma16(wv[u][r], z2[ft][r], o[u]);
+      }
+      if (valid) {
+        const uint32_t go = (uint32_t)row * (12u * OPE_H) + 16u * g + 64u * u0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(gi_out) + (go + 64u * u)) = o[u];
+      }
+    }
+    if (done == 0) stamp(6);
+    ++done;
+    tile = next;
+  }
+  stamp(7);
+  if (dbg && lane == 0) dbg[8] = done;
+}
+
+// Both nets' trunks in one launch when the shape allows it (recurrent nets, D <= 256, enough rows to give every SIMD of the chip a few
+// tiles); otherwise the two trunk_fwd3 / trunk_fwd2 launches.
+int launch_trunk_fwd_pair(const TrunkFwdArgs& live, const TrunkFwdArgs& tgt, int path, hipStream_t st) {
+  // path (ope_qmix_cfg.trunk_path): 0 by shape, 3 the two trunk_fwd3 launches, 4 this kernel whenever it can run the shape.
+  // Process default of "by shape": OPE_TRUNK4 = 1 | 0 (read once).
+  static const int on = getenv("OPE_TRUNK4") ? atoi(getenv("OPE_TRUNK4")) : 1;
+  const int KC = (live.D + 15) >> 4;
+  const bool can = live.gi && tgt.gi && !live.a2_out && !tgt.a2_out && live.D == tgt.D && live.R == tgt.R && live.x == tgt.x &&
+                   live.D % 4 == 0 && (KC == 4 || KC == 8 || KC == 12 || KC == 16) && live.xhat1 && live.mu0 && live.rstd0 && live.rstd1 && live.mask1 && live.xhat2 && live.rstd2 && live.mask2;
+  const bool ok = can && (path == 4 || (path == 0 && on && live.R >= 16 * 1024));
+  if (!ok) {
+    int rc = launch_trunk_fwd(live, true, st);
+    if (rc) return rc;
+    return launch_trunk_fwd(tgt, false, st);
+  }
+  TrunkPairArgs pa;
+  pa.x = live.x; pa.R = live.R; pa.D = live.D; pa.nets = 2;
+  pa.theta[0] = live.theta; pa.theta[1] = tgt.theta; pa.gi[0] = live.gi; pa.gi[1] = tgt.gi;
+  const AgentLayout& L = live.L;
+  pa.fn_w = L.fn_w; pa.fn_b = L.fn_b; pa.fc1_w = L.fc1_w; pa.fc1_b = L.fc1_b; pa.ln1_w = L.ln1_w; pa.ln1_b = L.ln1_b;
+  pa.fc2_w = L.fc2_w; pa.fc2_b = L.fc2_b; pa.ln2_w = L.ln2_w; pa.ln2_b = L.ln2_b; pa.wih = L.wih; pa.bih = L.bih;
+  pa.mu0 = live.mu0; pa.rstd0 = live.rstd0; pa.xhat1 = live.xhat1; pa.rstd1 = live.rstd1; pa.mu1 = live.mu1; pa.mask1 = live.mask1;
+  pa.xhat2 = live.xhat2; pa.rstd2 = live.rstd2; pa.mask2 = live.mask2;      // the target net saves nothing
+  pa.dbg = live.dbg;
+  static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256; return n > 1 ? n : 256; }();
+  const int grid = cus & ~1;     // one workgroup per CU, even ones the live net, odd ones the target
+  // Eight waves (two per SIMD, rows prefetched behind fc1). Measured against twelve waves without the prefetch (three per SIMD at the 168
+  // register cap, 78 of them spilled): 59.5 us vs 107 us at 3s5z batch 32, so only this variant is built.
+  if (KC == 4) hipLaunchKernelGGL((trunk_fwd4_kernel<4, 8, true>), dim3(grid), dim3(512), 0, st, pa);
+  else if (KC == 8) hipLaunchKernelGGL((trunk_fwd4_kernel<8, 8, true>), dim3(grid), dim3(512), 0, st, pa);
+  else if (KC == 12) hipLaunchKernelGGL((trunk_fwd4_kernel<12, 8, true>), dim3(grid), dim3(512), 0, st, pa);
+  else hipLaunchKernelGGL((trunk_fwd4_kernel<16, 8, true>), dim3(grid), dim3(512), 0, st, pa);
+  if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
+  return OPE_OK;
+}
+
+}  // namespace ope

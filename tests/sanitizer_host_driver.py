@@ -64,6 +64,8 @@ bad.dims, bad.batch = _lib.Dims(3, 9, 1000, 48, 60), 32
 assert L.ope_qmix_param_layout(C.byref(bad), off, siz) == -1 and L.ope_qmix_workspace_bytes(C.byref(bad)) == -1
 bad.dims, bad.mixer_path = _lib.Dims(3, 9, 64, 48, 60), 7
 assert L.ope_qmix_workspace_bytes(C.byref(bad)) == -1
+bad.mixer_path, bad.trunk_path = 0, 5
+assert L.ope_qmix_workspace_bytes(C.byref(bad)) == -1
 for cap in (1, 2, 64, 8192):
     assert L.ope_per_tree_bytes(cap) > 0
 assert L.ope_per_tree_bytes(3) < 0 or L.ope_per_tree_bytes(3) > 0
