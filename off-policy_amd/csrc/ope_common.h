@@ -179,6 +179,11 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 __device__ __forceinline__ void gload_async(float& dst, const float* p) {
   asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
 }
+// The same with a uniform base (an SGPR pair), a 32-bit per-lane byte offset and an immediate: no per-lane 64-bit address arithmetic.
+template <int IMM>
+__device__ __forceinline__ void gload_async_s(float& dst, const float* base, unsigned voff) {
+  asm volatile("global_load_dword %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(base), "n"(IMM) : "memory");
+}
 // s_waitcnt vmcnt(0) that names 24 destination registers as read-write so they stay put until the data has landed
 #define OPE_GWAIT24(a)                                                                                                   \
   asm volatile("s_waitcnt vmcnt(0)"                                                                                      \

@@ -36,10 +36,29 @@ constexpr int kAhead = 8;   // loader prefetch distance in steps
 __device__ __forceinline__ float hsum4(f32x2 a, f32x2 b) { return (a[0] + a[1]) + (b[0] + b[1]); }
 // sum over the G = 2 or 4 adjacent lanes that share a feature (DPP, every lane ends with the same bits)
 template <int G>
+__device__ __forceinline__ float group_sum_from(float v) {   // the stages after the first (lanes l, l^1 already hold their pair's sum)
+  if (G == 4) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  return v;
+}
+template <int G>
 __device__ __forceinline__ float group_sum(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
-  if (G == 4) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
-  return v;
+  return group_sum_from<G>(v);
+}
+
+// d = w * {hp[HALF], hp[HALF]} + c: a packed FMA whose second operand is one half of a register pair, broadcast by op_sel
+// (hipcc folds most such splats itself but copies some through a v_mov; written out so that none is left on the chain)
+template <int HALF>
+__device__ __forceinline__ f32x2 pk_fma_bcast(f32x2 w, f32x2 hp, f32x2 c) {
+  f32x2 d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,%4,0] op_sel_hi:[1,%4,1]" : "=v"(d) : "v"(w), "v"(hp), "v"(c), "n"(HALF));
+  return d;
+}
+template <int HALF>
+__device__ __forceinline__ f32x2 pk_mul_bcast(f32x2 w, f32x2 hp) {
+  f32x2 d;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,%3] op_sel_hi:[1,%3]" : "=v"(d) : "v"(w), "v"(hp), "n"(HALF));
+  return d;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -50,33 +69,50 @@ __global__ void __launch_bounds__((W + 2) * 64) gru_fwd4_kernel(GruFwdArgs a) {
   constexpr int FPW = OPE_H / W;     // features per compute wave
   constexpr int KS = OPE_H / W;      // K-slice per lane
   constexpr int NP = KS / 2;         // weight pairs per gate per lane
-  __shared__ __attribute__((aligned(16))) float sm[2 * OPE_H + 6 * OPE_H + 8 * OPE_H];
+  // LDS (floats): h_t [2][64] | r, z, n, gh_n' of step t [2][4][64] | gate inputs of step t: gx [2][2][65] = x_r, x_z planes
+  // (x = -log2(e) (gi + b_hh); entry 64 stays zero: the lanes that must not inject read it) | gn [2][64] = -2 log2(e) gi_n |
+  // a dump area the lanes that hold no valid n / h write to (same offsets as the real ones, shifted by kDump)
+  constexpr int kHs = 0, kSv = 2 * OPE_H, kGx = 10 * OPE_H, kGxP = 2 * (OPE_H + 1) + 2, kGxZ = OPE_H + 1, kGn = kGx + 2 * kGxP, kDump = kGn + 2 * OPE_H;
+  __shared__ __attribute__((aligned(16))) float sm[kDump + 10 * OPE_H];
   float(*hs)[OPE_H] = reinterpret_cast<float(*)[OPE_H]>(sm);                        // [2][64]    h_t, parity of t
-  float(*gis)[3][OPE_H] = reinterpret_cast<float(*)[3][OPE_H]>(sm + 2 * OPE_H);     // [2][3][64] gi of step t
-  float(*sv)[4][OPE_H] = reinterpret_cast<float(*)[4][OPE_H]>(sm + 8 * OPE_H);      // [2][4][64] r, z, n, gh_n of step t
-  constexpr int kHs = 0, kSv = 8 * OPE_H;
+  float(*sv)[4][OPE_H] = reinterpret_cast<float(*)[4][OPE_H]>(sm + kSv);            // [2][4][64]
+  constexpr float kL = -1.4426950408889634f;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int rid = blockIdx.x;
   const int net = rid / a.NB;
   const int row = rid - net * a.NB;
   const int L = a.L;
   const int nchunks = (L + kAhead - 1) / kAhead;
+  const float* __restrict__ th = net == 0 ? a.theta0 : a.theta1;
 
   if (wave == W) {   // ---- loader: lane = feature
     const float* __restrict__ gi = net == 0 ? a.gi0 : a.gi1;
     const int64_t stride_t = (int64_t)a.NB * (3 * OPE_H);
-    const float* gp = gi + (int64_t)row * (3 * OPE_H) + lane;
+    const float* gp = gi + (int64_t)row * (3 * OPE_H);          // uniform: the lane enters as the 32-bit offset of the load
+    const unsigned lo4 = 4u * lane;
+    const float brs = th[a.bhh_off + lane] * kL, bzs = th[a.bhh_off + OPE_H + lane] * kL;
     float pre[kAhead][3];
     auto load_step = [&](float (&d)[3], int t) {
       const float* p = gp + (int64_t)min(t, L - 1) * stride_t;
-      gload_async(d[0], p);
-      gload_async(d[1], p + OPE_H);
-      gload_async(d[2], p + 2 * OPE_H);
+      gload_async_s<0>(d[0], p, lo4);
+      gload_async_s<4 * OPE_H>(d[1], p, lo4);
+      gload_async_s<8 * OPE_H>(d[2], p, lo4);
     };
+    // the scaling that turns a sigmoid into rcp(1 + exp2(.)) and the b_hh of the r / z gates are applied here, off the chain
+    auto publish = [&](const float (&d)[3], int q) {
+      // scalar, and to separate planes, on purpose: anything that wants the two values in a register PAIR (a packed FMA, a
+      // ds_write_b64) makes hipcc copy the landed registers into the pair BEFORE the s_waitcnt that guards them
+      float xr = fmaf(d[0], kL, brs), xz = fmaf(d[1], kL, bzs);
+      asm("" : "+v"(xr), "+v"(xz));
+      sm[kGx + q * kGxP + lane] = xr;
+      sm[kGx + q * kGxP + kGxZ + lane] = xz;
+      sm[kGn + q * OPE_H + lane] = d[2] * (2.0f * kL);
+    };
+    if (lane < 4) sm[kGx + (lane >> 1) * kGxP + (lane & 1) * kGxZ + OPE_H] = 0.f;
 #pragma unroll
     for (int s = 0; s < kAhead; ++s) load_step(pre[s], s);
     OPE_GWAIT24(pre);
-    gis[0][0][lane] = pre[0][0]; gis[0][1][lane] = pre[0][1]; gis[0][2][lane] = pre[0][2];
+    publish(pre[0], 0);
     load_step(pre[0], kAhead);
     lds_barrier();
     for (int c = 0; c < nchunks; ++c) {
@@ -86,9 +122,7 @@ __global__ void __launch_bounds__((W + 2) * 64) gru_fwd4_kernel(GruFwdArgs a) {
         if (t < L) {
           float(&d)[3] = pre[(s + 1) % kAhead];      // holds step t+1; 7 x 3 younger loads are in flight behind it
           asm volatile("s_waitcnt vmcnt(21)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2])::"memory");
-          gis[(s + 1) & 1][0][lane] = d[0];
-          gis[(s + 1) & 1][1][lane] = d[1];
-          gis[(s + 1) & 1][2][lane] = d[2];
+          publish(d, (s + 1) & 1);
           load_step(d, t + 1 + kAhead);
           lds_barrier();
         }
@@ -109,7 +143,7 @@ __global__ void __launch_bounds__((W + 2) * 64) gru_fwd4_kernel(GruFwdArgs a) {
           a.rg[o] = sv[p][0][lane];
           a.zg[o] = sv[p][1][lane];
           a.ng[o] = sv[p][2][lane];
-          a.ghn[o] = sv[p][3][lane];
+          a.ghn[o] = sv[p][3][lane] * (1.0f / (2.0f * kL));   // the n rows of W_hh carry the tanh's -2 log2(e)
         }
       }
       if (t < L) lds_barrier();
@@ -120,8 +154,9 @@ __global__ void __launch_bounds__((W + 2) * 64) gru_fwd4_kernel(GruFwdArgs a) {
   // ---- compute wave q: feature f = FPW q + j, K-slice g
   const int j = lane / W, g = lane % W;
   const int f = FPW * wave + j;
-  const float* __restrict__ th = net == 0 ? a.theta0 : a.theta1;
-  f32x2 wr[NP], wz[NP], wn[NP];
+  // Weights of the lane: the r and z rows of feature f PAIRED per k ({W_hr[f][k], W_hz[f][k]}: one packed FMA with h[k] broadcast
+  // to both halves advances both gates, and no horizontal add is needed for them), the n row in k-pairs.
+  f32x2 wrz[KS], wn[NP];
   {
     const float* w = th + a.whh_off + KS * g;
 #pragma unroll
@@ -129,21 +164,33 @@ __global__ void __launch_bounds__((W + 2) * 64) gru_fwd4_kernel(GruFwdArgs a) {
       const f32x4 vr = *reinterpret_cast<const f32x4*>(w + (int64_t)f * OPE_H + 4 * k);
       const f32x4 vz = *reinterpret_cast<const f32x4*>(w + (int64_t)(OPE_H + f) * OPE_H + 4 * k);
       const f32x4 vn = *reinterpret_cast<const f32x4*>(w + (int64_t)(2 * OPE_H + f) * OPE_H + 4 * k);
-      wr[2 * k] = f32x2{vr[0], vr[1]}; wr[2 * k + 1] = f32x2{vr[2], vr[3]};
-      wz[2 * k] = f32x2{vz[0], vz[1]}; wz[2 * k + 1] = f32x2{vz[2], vz[3]};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) wrz[4 * k + e] = f32x2{vr[e], vz[e]};
       wn[2 * k] = f32x2{vn[0], vn[1]}; wn[2 * k + 1] = f32x2{vn[2], vn[3]};
     }
   }
-  const float br = th[a.bhh_off + f], bz = th[a.bhh_off + OPE_H + f], bn = th[a.bhh_off + 2 * OPE_H + f];
+  const float bn = th[a.bhh_off + 2 * OPE_H + f];
   const float* hin = net == 0 ? a.hinit : a.hinit1;
   float h = hin ? hin[(int64_t)row * OPE_H + f] : 0.f;
-  // The sigmoids are evaluated as rcp(1 + exp2(x')) with x' = -log2(e) x: the scale is folded into the r/z rows of W_hh,
-  // their biases and (per step, off the chain) gi, so that after the quad reduction a gate is exp2, add, rcp.
-  constexpr float kL = -1.4426950408889634f;
+  // The sigmoids are evaluated as rcp(1 + exp2(x')) with x' = -log2(e) x and tanh(x) as 2 rcp(1 + exp2(-2 log2(e) x)) - 1
+  // (absolute error ~1e-7): the scales are folded into the rows of W_hh, into b_hn and (by the loader) into gi and the r / z
+  // biases, so that after the quad reduction a gate is exp2, add, rcp. The storer takes the scale out of the saved gh_n.
 #pragma unroll
-  for (int i = 0; i < NP; ++i) { wr[i] *= kL; wz[i] *= kL; }
-  const float brs = br * kL, bzs = bz * kL;
-  const float bn0 = (g == 0) ? bn : 0.f;   // biases and gi enter the sums once per quad: through lane g == 0's accumulator
+  for (int i = 0; i < KS; ++i) wrz[i] *= kL;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) wn[i] *= 2.0f * kL;
+  // gi and the biases enter the sums once per quad: as the addend of lane g == 0's first FMA. The other lanes read zeros
+  // through their own (loop-invariant) address, so no select sits on the chain.
+  const f32x2 bn0 = {(g == 0) ? bn * (2.0f * kL) : 0.f, 0.f};
+  const int gx_off = kGx + (g == 0 ? f : OPE_H);
+  // Lane roles after the reduction: the even lanes of a feature evaluate r, then n and h'; the odd lanes evaluate z (one exp2 / rcp
+  // sequence serves both sigmoids). In the first exchange of the reduction (lane ^ 1) every lane keeps the gate of its role and
+  // hands the other one over; the later stage stays inside a role. Only the even lanes hold a valid n / h': the odd ones write
+  // theirs to the dump area (their h stays a bounded mix of gate values and is never read).
+  constexpr int kSwap = 0xB1;       // quad_perm [1,0,3,2]
+  const bool even = (g & 1) == 0;
+  const int rz_off = kSv + (even ? 0 : OPE_H) + f;      // r from one side, z from the other: one ds_write
+  const int val_off = f + (even ? 0 : kDump);
   if (g == 0) hs[0][f] = h;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   lds_barrier();
@@ -160,42 +207,56 @@ __global__ void __launch_bounds__((W + 2) * 64) gru_fwd4_kernel(GruFwdArgs a) {
   if (DBG) tprev = (long long)__builtin_amdgcn_s_memtime();
   auto step = [&](auto P) {
     constexpr int p = decltype(P)::value;
-    const float gir = gis[p][0][f], giz = gis[p][1][f], gin = gis[p][2][f];   // LDS returns in order: gi first
-    __builtin_amdgcn_sched_barrier(0);
+    // LDS returns in order: what the first FMAs need (h[0..3] of the slice, the injected pair) is asked for first, gi_n last
     const float* hp = &hs[p][KS * g];
     f32x4 hq[KS / 4];
+    hq[0] = *reinterpret_cast<const f32x4*>(hp);
+    __builtin_amdgcn_sched_barrier(0);
+    const f32x2 x = {sm[gx_off + p * kGxP], sm[gx_off + p * kGxP + kGxZ]};      // {x_r, x_z} or zeros (one ds_read2)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int v = 0; v < KS / 4; ++v) hq[v] = *reinterpret_cast<const f32x4*>(hp + 4 * v);
+    for (int v = 1; v < KS / 4; ++v) hq[v] = *reinterpret_cast<const f32x4*>(hp + 4 * v);
+    __builtin_amdgcn_sched_barrier(0);
+    const float gin2 = sm[kGn + p * OPE_H + f];
     __builtin_amdgcn_sched_barrier(0);   // all LDS reads issue before anything waits
-    const float xr0 = (g == 0) ? fmaf(gir, kL, brs) : 0.f;
-    const float xz0 = (g == 0) ? fmaf(giz, kL, bzs) : 0.f;
-    const float gin2 = gin * (2.0f * kL);
-    f32x2 ar0 = {xr0, 0.f}, ar1 = {0.f, 0.f}, az0 = {xz0, 0.f}, az1 = {0.f, 0.f}, an0 = {bn0, 0.f}, an1 = {0.f, 0.f};
+    f32x2 a0, a1, an0, an1;              // {r, z} partials over even / odd k; n partials over the two k-pairs of a quad of k
 #pragma unroll
     for (int v = 0; v < KS / 4; ++v) {
       const f32x2 lo = {hq[v][0], hq[v][1]}, hi = {hq[v][2], hq[v][3]};
-      ar0 = __builtin_elementwise_fma(wr[2 * v], lo, ar0);
-      az0 = __builtin_elementwise_fma(wz[2 * v], lo, az0);
-      an0 = __builtin_elementwise_fma(wn[2 * v], lo, an0);
-      ar1 = __builtin_elementwise_fma(wr[2 * v + 1], hi, ar1);
-      az1 = __builtin_elementwise_fma(wz[2 * v + 1], hi, az1);
-      an1 = __builtin_elementwise_fma(wn[2 * v + 1], hi, an1);
+      if (v == 0) {
+        a0 = pk_fma_bcast<0>(wrz[0], lo, x);
+        a1 = pk_mul_bcast<1>(wrz[1], lo);
+        an0 = __builtin_elementwise_fma(wn[0], lo, bn0);
+        an1 = wn[1] * hi;
+      } else {
+        a0 = pk_fma_bcast<0>(wrz[4 * v], lo, a0);
+        a1 = pk_fma_bcast<1>(wrz[4 * v + 1], lo, a1);
+        an0 = __builtin_elementwise_fma(wn[2 * v], lo, an0);
+        an1 = __builtin_elementwise_fma(wn[2 * v + 1], hi, an1);
+      }
+      a0 = pk_fma_bcast<0>(wrz[4 * v + 2], hi, a0);
+      a1 = pk_fma_bcast<1>(wrz[4 * v + 3], hi, a1);
     }
-    if (DBG) asm volatile("" : "+v"(ar0), "+v"(ar1), "+v"(az0), "+v"(az1), "+v"(an0), "+v"(an1));
+    if (DBG) asm volatile("" : "+v"(a0), "+v"(a1), "+v"(an0), "+v"(an1));
     OPE_PHASE(0)
-    const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(group_sum<W>(hsum4(ar0, ar1))));
-    sm[kSv + (4 * p + 0) * OPE_H + f] = r;     // the saves leave as soon as they exist (4 lanes, same value, same address)
-    const float an = group_sum<W>(hsum4(an0, an1));
+    // quad reduction of {r, z}: every lane keeps the gate of its role and hands the other one to its neighbour
+    const f32x2 t = a0 + a1;
+    const float mine = even ? t[0] : t[1], theirs = even ? t[1] : t[0];
+    float u = mine + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, theirs), kSwap, 0xF, 0xF, true));
+    u = group_sum_from<W>(u);
+    const float y = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u));   // r (even lanes) | z (odd lanes)
+    sm[rz_off + 4 * p * OPE_H] = y;            // the saves leave as soon as they exist (r from one side, z from the other)
+    const f32x2 tn = an0 + an1;
+    float sn = tn[0] + tn[1];
+    const float an = group_sum<W>(sn);         // -2 log2(e) (W_hn h + b_hn), all lanes
     sm[kSv + (4 * p + 3) * OPE_H + f] = an;
-    const float z = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(group_sum<W>(hsum4(az0, az1))));
-    sm[kSv + (4 * p + 1) * OPE_H + f] = z;
-    // tanh(x) = 2 / (1 + exp(-2x)) - 1 (absolute error ~1e-7)
-    const float n = fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(r, an * (2.0f * kL), gin2))), -1.0f);
-    sm[kSv + (4 * p + 2) * OPE_H + f] = n;
+    const float n = fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(y, an, gin2))), -1.0f);
+    sm[kSv + (4 * p + 2) * OPE_H + val_off] = n;
+    const float z = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y), kSwap, 0xF, 0xF, true));
     h = fmaf(z, h - n, n);                     // (1 - z) n + z h
     if (DBG) asm volatile("" : "+v"(h));
     OPE_PHASE(1)
-    sm[kHs + (p ^ 1) * OPE_H + f] = h;
+    sm[kHs + (p ^ 1) * OPE_H + val_off] = h;
     if (DBG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     OPE_PHASE(2)
     lds_barrier();
@@ -222,7 +283,7 @@ __global__ void __launch_bounds__((W + 2) * 64) gru_bwd4_kernel(GruBwdArgs a) {
   constexpr int NP = IS / 2;
   __shared__ __attribute__((aligned(16))) float sm[8 * OPE_H + 12 * OPE_H];
   float(*ds)[4][OPE_H] = reinterpret_cast<float(*)[4][OPE_H]>(sm);                  // [2][4][64] dr_pre, dz_pre, dgn (broadcast) + dn_pre
-  float(*sav)[6][OPE_H] = reinterpret_cast<float(*)[6][OPE_H]>(sm + 8 * OPE_H);     // [2][6][64] r, z, n, gh_n, dh_out, h_prev
+  float(*sav)[6][OPE_H] = reinterpret_cast<float(*)[6][OPE_H]>(sm + 8 * OPE_H);     // [2][6][64] the step's factors (loader): a_n, a_r, a_g, a_z, z, dh_out
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = blockIdx.x;
   const int64_t NB = a.NB;
@@ -241,12 +302,27 @@ __global__ void __launch_bounds__((W + 2) * 64) gru_bwd4_kernel(GruBwdArgs a) {
       gload_async(d[4], a.dh_out + o);
       gload_async(d[5], a.h + (t > 0 ? o - NB * OPE_H : o));
     };
+    // The factors of step i that do not depend on dh are formed here, off the compute waves' chain (every instruction of a
+    // compute wave is on it): with dht = dh_t + dh_out_t,
+    //   dn_pre = a_n dht, a_n = (1 - z)(1 - n^2);  dr_pre = a_r dht, a_r = a_n gh_n r (1 - r);  dgh_n = a_g dht, a_g = a_n r;
+    //   dz_pre = a_z dht, a_z = (h_prev - n) z (1 - z).     (scalar arithmetic on purpose: see the forward loader)
     auto publish = [&](float (&d)[6], int i) {
       const int p = i & 1;
       const int t = a.T - 1 - i;
-#pragma unroll
-      for (int k = 0; k < 5; ++k) sav[p][k][lane] = d[k];
-      sav[p][5][lane] = t > 0 ? d[5] : 0.f;   // h_{-1} = 0
+      const float r = d[0], z = d[1], n = d[2], gn = d[3];
+      const float hp = t > 0 ? d[5] : 0.f;         // h_{-1} = 0
+      const float omz = 1.0f - z;
+      float an = omz * fmaf(-n, n, 1.0f);
+      float ar = an * (gn * (r * (1.0f - r)));
+      float ag = an * r;
+      float az = (hp - n) * (z * omz);
+      asm("" : "+v"(an), "+v"(ar), "+v"(ag), "+v"(az));
+      sav[p][0][lane] = an;
+      sav[p][1][lane] = ar;
+      sav[p][2][lane] = ag;
+      sav[p][3][lane] = az;
+      sav[p][4][lane] = z;
+      sav[p][5][lane] = i < nsteps ? d[4] : 0.f;   // nothing enters behind the last step: the carried value leaves as dh_carry
     };
 #pragma unroll
     for (int s = 0; s < kAhead; ++s) load_step(pre[s], s);
@@ -302,34 +378,25 @@ __global__ void __launch_bounds__((W + 2) * 64) gru_bwd4_kernel(GruBwdArgs a) {
   float dh = a.dh_in ? a.dh_in[(int64_t)row * OPE_H + k] : 0.f;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   lds_barrier();
-  // Per-step factors that do not depend on dh, formed one step ahead (the loader publishes step i+1's saves before
-  // barrier i): A = d n_pre / d h', Bz = d z_pre / d h', Cr = d r_pre / d n_pre.
-  float r, z, dho, A, Bz, Cr;
-  {
-    const float r_ = sav[0][0][k], z_ = sav[0][1][k], n_ = sav[0][2][k];
-    const float gn_ = sav[0][3][k], dho_ = sav[0][4][k], hp_ = sav[0][5][k];
-    const float omz = 1.0f - z_;
-    r = r_; z = z_; dho = dho_;
-    A = omz * (1.0f - n_ * n_);
-    Bz = (hp_ - n_) * z_ * omz;
-    Cr = gn_ * r_ * (1.0f - r_);
-  }
+  // The factors of a step arrive one step ahead (the loader publishes step i+1's before barrier i).
+  f32x2 fnr = {sav[0][0][k], sav[0][1][k]}, fgz = {sav[0][2][k], sav[0][3][k]};   // {a_n, a_r}, {a_g, a_z}
+  float z = sav[0][4][k];
   long long ph[4] = {0, 0, 0, 0}, tprev = 0;   // DBG: cycles in (adjoints | publish | barrier | reads+FMA+reduce)
   if (DBG) tprev = (long long)__builtin_amdgcn_s_memtime();
+  // dht = dh_t + dh_out_t is the loop-carried value: dht' = S + (dht z + dho') where S is the mat-vec sum of this step; the
+  // bracket is formed while the LDS reads are in flight, so one add follows the quad reduction on the chain.
+  float dht = dh + sav[0][5][k];
   auto step = [&](auto P) {
     constexpr int p = decltype(P)::value;
-    const float dht = dh + dho;
-    const float dz_pre = dht * Bz;
-    sm[(4 * p + 1) * OPE_H + k] = dz_pre;       // four lanes of a quad write the same value to the same address
-    const float dn_pre = dht * A;
-    sm[(4 * p + 3) * OPE_H + k] = dn_pre;
-    const float dr_pre = dn_pre * Cr;
-    sm[(4 * p + 0) * OPE_H + k] = dr_pre;
-    float dgn = dn_pre * r;
+    const f32x2 d2 = {dht, dht};
+    const f32x2 nr = fnr * d2, gz = fgz * d2;   // {dn_pre, dr_pre}, {dgh_n, dz_pre}: two packed multiplies
+    sm[(4 * p + 3) * OPE_H + k] = nr[0];        // four lanes of a quad write the same value to the same address
+    sm[(4 * p + 0) * OPE_H + k] = nr[1];
+    sm[(4 * p + 1) * OPE_H + k] = gz[1];
+    float dgn = gz[0];
     if (DBG) asm volatile("" : "+v"(dgn));
     OPE_PHASE(0)
     sm[(4 * p + 2) * OPE_H + k] = dgn;
-    const float c00 = (g == 0) ? dht * z : 0.f;  // the carry term enters the sum through lane g == 0's accumulator
     if (DBG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     OPE_PHASE(1)
     lds_barrier();
@@ -342,35 +409,40 @@ __global__ void __launch_bounds__((W + 2) * 64) gru_bwd4_kernel(GruBwdArgs a) {
       zv[v] = *reinterpret_cast<const f32x4*>(base + OPE_H + 4 * v);
       nv[v] = *reinterpret_cast<const f32x4*>(base + 2 * OPE_H + 4 * v);
     }
-    const float r1 = sav[p ^ 1][0][k], z1 = sav[p ^ 1][1][k], n1 = sav[p ^ 1][2][k];   // next step's saves
-    const float gn1 = sav[p ^ 1][3][k], dho1 = sav[p ^ 1][4][k], hp1 = sav[p ^ 1][5][k];
+    const f32x2 fnr1 = {sav[p ^ 1][0][k], sav[p ^ 1][1][k]}, fgz1 = {sav[p ^ 1][2][k], sav[p ^ 1][3][k]};   // next step's factors
+    const float z1 = sav[p ^ 1][4][k], dho1 = sav[p ^ 1][5][k];
     __builtin_amdgcn_sched_barrier(0);   // all reads in flight before the first FMA waits
-    f32x2 c0 = {c00, 0.f}, c1 = {0.f, 0.f}, c2 = {0.f, 0.f}, c3 = {0.f, 0.f}, c4 = {0.f, 0.f}, c5 = {0.f, 0.f};
+    // three chains (one per gate), eight packed FMAs deep: interleaved they issue back to back, and two packed adds and one
+    // add fold them (six four-deep chains cost nine more instructions per step to fold)
+    f32x2 cr, cz, cn;
 #pragma unroll
     for (int v = 0; v < IS / 4; ++v) {
-      c0 = __builtin_elementwise_fma(wr[2 * v], f32x2{rv[v][0], rv[v][1]}, c0);
-      c1 = __builtin_elementwise_fma(wr[2 * v + 1], f32x2{rv[v][2], rv[v][3]}, c1);
-      c2 = __builtin_elementwise_fma(wz[2 * v], f32x2{zv[v][0], zv[v][1]}, c2);
-      c3 = __builtin_elementwise_fma(wz[2 * v + 1], f32x2{zv[v][2], zv[v][3]}, c3);
-      c4 = __builtin_elementwise_fma(wn[2 * v], f32x2{nv[v][0], nv[v][1]}, c4);
-      c5 = __builtin_elementwise_fma(wn[2 * v + 1], f32x2{nv[v][2], nv[v][3]}, c5);
+      if (v == 0) {
+        cr = wr[0] * f32x2{rv[0][0], rv[0][1]};
+        cz = wz[0] * f32x2{zv[0][0], zv[0][1]};
+        cn = wn[0] * f32x2{nv[0][0], nv[0][1]};
+      } else {
+        cr = __builtin_elementwise_fma(wr[2 * v], f32x2{rv[v][0], rv[v][1]}, cr);
+        cz = __builtin_elementwise_fma(wz[2 * v], f32x2{zv[v][0], zv[v][1]}, cz);
+        cn = __builtin_elementwise_fma(wn[2 * v], f32x2{nv[v][0], nv[v][1]}, cn);
+      }
+      cr = __builtin_elementwise_fma(wr[2 * v + 1], f32x2{rv[v][2], rv[v][3]}, cr);
+      cz = __builtin_elementwise_fma(wz[2 * v + 1], f32x2{zv[v][2], zv[v][3]}, cz);
+      cn = __builtin_elementwise_fma(wn[2 * v + 1], f32x2{nv[v][2], nv[v][3]}, cn);
     }
-    dh = group_sum<W>((hsum4(c0, c1) + hsum4(c2, c3)) + hsum4(c4, c5));
-    {
-      const float omz = 1.0f - z1;
-      r = r1; z = z1; dho = dho1;
-      A = omz * (1.0f - n1 * n1);
-      Bz = (hp1 - n1) * z1 * omz;
-      Cr = gn1 * r1 * (1.0f - r1);
-    }
-    if (DBG) asm volatile("" : "+v"(dh));
+    const f32x2 ct = (cr + cz) + cn;
+    float s1 = ct[0] + ct[1];
+    asm("" : "+v"(s1));                  // keeps the SLP vectoriser from pairing this add with anything else
+    dht = group_sum<W>(s1) + fmaf(dht, z, dho1);   // the loader publishes dho = 0 behind the last step: dht ends as dh_{t_lo - 1}
+    fnr = fnr1; fgz = fgz1; z = z1;
+    if (DBG) asm volatile("" : "+v"(dht));
     OPE_PHASE(3)
   };
   for (int i = 0; i < nsteps; i += 2) {
     step(std::integral_constant<int, 0>{});
     if (i + 1 < nsteps) step(std::integral_constant<int, 1>{});
   }
-  if (a.dh_carry && g == 0) a.dh_carry[(int64_t)row * OPE_H + k] = dh;
+  if (a.dh_carry && g == 0) a.dh_carry[(int64_t)row * OPE_H + k] = dht;
   if (DBG && a.dbg && lane == 0) {
     long long* o = a.dbg + ((int64_t)blockIdx.x * W + wave) * 8;
     o[0] = ph[0]; o[1] = ph[1]; o[2] = ph[2]; o[3] = ph[3]; o[4] = nsteps;
@@ -379,12 +451,14 @@ __global__ void __launch_bounds__((W + 2) * 64) gru_bwd4_kernel(GruBwdArgs a) {
 
 }  // namespace
 
-// Compute waves per row: as many as keep the launch at about one compute wave per SIMD (1024 SIMDs): the kernels are
-// bound by the per-step issue/latency chain of a wave, and a second wave on the same SIMD stretches both.
+// Compute waves per row: four while at most two rows share a CU (512 rows), two beyond (fewer lanes repeat the gate arithmetic).
+// The kernels are bound by the per-step issue / latency chain of a wave until the SIMDs fill up. Measured at 3s5z (512 / 256 rows
+// forward / backward at batch 32, and the 16 / 4 episode shares of a multi-GPU job) and MMM2 (640 / 320 rows); eight waves per row
+// (half the LDS reads and FMAs per lane, a ten-wave barrier) were slower at every size (forward 46 vs 41 us at batch 4, 70 vs 58 at 32).
 static int waves_per_row(int64_t rows, int asked) {
   if (asked == 2 || asked == 4) return asked;
   if (g_scan_waves) return g_scan_waves;
-  return rows <= 512 ? 4 : 2;   // measured: 3s5z (512 / 256 rows) prefers 4, MMM2 (640 / 320 rows) 2 forward
+  return rows <= 512 ? 4 : 2;
 }
 
 template <int W>

@@ -8,7 +8,7 @@ for _ in range(3):
     trainer.train_policy_on_batch(batch)
 torch.cuda.synchronize()
 d = trainer.workspace_view(B, "dbg").view(torch.int64).cpu().numpy()
-Wf = int(os.environ.get("OPE_GRU4_W", "2")); Wb = int(os.environ.get("OPE_GRU4_W", "4"))   # auto rule at 3s5z, B=32
+Wf = int(os.environ.get("OPE_GRU4_W", "4")); Wb = int(os.environ.get("OPE_GRU4_W", "4"))   # auto rule at 3s5z (at most 512 rows)
 for name, off, n, phases in (("gru_fwd4", 71168, 2 * dims.n_agents * B * Wf, ["reads+FMA", "reduce+gates", "publish", "barrier"]),
                               ("gru_bwd4", 87552, dims.n_agents * B * Wb, ["adjoints", "publish", "barrier", "reads+FMA+reduce"])):
     x = d[off:off + 8 * n].reshape(n, 8).astype(np.float64)

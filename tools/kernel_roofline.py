@@ -29,6 +29,7 @@ def flops(dims, B):
     first = 2 * 2 * TB * (S * 224)                       # first hyper-layers of both nets
     f = {
         "trunk_fwd": trunk,                              # per launch (live and target are separate launches)
+        "trunk_fwd_pair": 2 * trunk,                     # trunk_fwd4: both nets in one launch
         "trunk_bwd": 2 * R1 * (192 * 64 + 64 * 64),
         "gru_fwd": 2 * (2 * N * B) * (T + 1) * 192 * 64,  # live + target rows in one launch
         "gru_bwd": 2 * (N * B) * T * 192 * 64,
@@ -49,7 +50,7 @@ def classify(name, have_wide):
         return "mixer_wide_gemm"
     if "mixer_fwd" in n:
         return "mixer_fwd_stage2" if have_wide else "mixer_fwd"
-    for key, pat in (("trunk_fwd", "trunk_fwd"), ("trunk_bwd", "trunk_bwd"), ("gru_fwd", "gru_fwd"), ("gru_bwd", "gru_bwd"),
+    for key, pat in (("trunk_fwd_pair", "trunk_fwd4"), ("trunk_fwd", "trunk_fwd"), ("trunk_bwd", "trunk_bwd"), ("gru_fwd", "gru_fwd"), ("gru_bwd", "gru_bwd"),
                      ("head_fwd", "head_fwd"), ("head_bwd", "head_bwd"), ("mixer_bwd", "mixer_bwd"), ("wgrad", "wgrad_kernel")):
         if pat in n:
             return key
