@@ -2,6 +2,8 @@
 // loss-and-gradient step (QMix.train_policy_on_batch, qmix.py:77-190) and the stand-alone agent forward.
 #include <string.h>
 
+#include <algorithm>
+
 #include "ope_mixer.h"
 #include "ope_wgrad.h"
 #include "ope_workspace.h"
@@ -105,16 +107,41 @@ void make_plan(const ope_qmix_cfg* c, Plan* p) {
   w.E = take(p->A * OPE_H); w.sq = take(p->A4);
   w.agent_end = o;
   w.mixer_size = c->vdn ? 0 : (p->ML.end - p->AL.end);
-  // K-splits: every wave reduces ~160 rows whatever the problem, so workgroups are equally long and spread evenly over
-  // the CUs (multiples of 4: the four waves of a workgroup hold consecutive splits and pre-reduce them)
-  static const int rows_per_split = getenv("OPE_WGRAD_ROWS") ? atoi(getenv("OPE_WGRAD_ROWS")) : 160;
-  auto splits_for = [](int64_t K, int cap) {
-    int s = (int)((K + rows_per_split - 1) / rows_per_split);
+  // K-splits: every wave reduces the same number of rows whatever the problem, so workgroups are equally long (multiples of 4:
+  // the four waves of a workgroup hold consecutive splits and pre-reduce them). Measured on MI355X (tools/_ab sweeps of
+  // OPE_WGRAD_ROWS at 3s5z, 3s5z_gall and MMM2, profiles/r03q_wgrad_rows.txt): the launch takes
+  //     ceil(workgroups / CUs) x rows per split x ~0.1 us
+  // whatever the number of workgroups resident on a CU -- a CU reduces its workgroups' rows at a fixed rate (~58 % of its matrix
+  // pipes), so what matters is the most loaded CU. 160 rows gave the 3s5z launch 896 workgroups = 4 per CU on half the chip
+  // (65.6 us); 192 rows = 754 workgroups = 3 per CU (60.7 us). The row count minimising that product (plus ~40 rows of
+  // per-workgroup prologue / reduction) is searched here among the counts that keep at least three workgroups on the busiest CU
+  // (small problems that cannot: 160 rows); OPE_WGRAD_ROWS pins it instead (read once).
+  static const int rows_env = getenv("OPE_WGRAD_ROWS") ? atoi(getenv("OPE_WGRAD_ROWS")) : 0;
+  static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256; return n > 1 ? n : 256; }();
+  auto splits_for = [](int64_t K, int cap, int rows) {
+    int s = (int)((K + rows - 1) / rows);
     s = s >= 4 ? ((s + 3) / 4) * 4 : s;
     return clampi(s, 1, cap);
   };
-  p->ns_agent = splits_for(p->R1, 256);
-  p->ns_mixer = splits_for(p->TB, 64);
+  // 64 x 64 output tiles of the agent problems (fc1, fc2, W_ih, W_hh in two pieces, q head) and of the mixer problems
+  // (three S-wide first layers of 64 rows, the NM x 64 and 32 x 64 second layers, the 32 x S state bias, the scalar head)
+  const int agent_tiles = ope_cdiv(p->D, 64) + 1 + (c->mlp ? 0 : 3 + 2 + 1) + ope_cdiv(p->A, 64);
+  const int mixer_tiles = c->vdn ? 0 : 4 * ope_cdiv(p->S, 64) + ope_cdiv(p->NM, 64) + 2;
+  int rows_per_split = rows_env > 0 ? rows_env : 160;
+  if (rows_env <= 0) {
+    int64_t best = -1;
+    for (int r = 96; r <= 1024; r += 4) {
+      const int na = splits_for(p->R1, 256, r), nm = splits_for(p->TB, 64, r);
+      const int64_t wgs = (int64_t)agent_tiles * ope_cdiv(na, 4) + (int64_t)mixer_tiles * ope_cdiv(nm, 4);
+      const int64_t len = std::max(ope_cdiv(p->R1, na), c->vdn ? 0 : ope_cdiv(p->TB, nm));     // rows a wave really reduces
+      const int64_t per_cu = ope_cdiv(wgs, cus);
+      if (per_cu < 3) continue;      // the rate above was measured with 2-4 workgroups per CU; fewer leave load latency uncovered
+      const int64_t cost = per_cu * (len + 40);
+      if (best < 0 || cost < best) { best = cost; rows_per_split = r; }
+    }
+  }
+  p->ns_agent = splits_for(p->R1, 256, rows_per_split);
+  p->ns_mixer = splits_for(p->TB, 64, rows_per_split);
   p->n_loss_tiles = ope_cdiv(p->TB, 16);
   // time chunks: boundaries on multiples of 8 steps (the scans prefetch in 8-step groups); short episodes stay whole
   {

@@ -23,7 +23,8 @@ namespace ope {
 template <int VEC>
 __global__ void __launch_bounds__(256, 3) wgrad_kernel(WgTable tb, float* __restrict__ raw) {
   __shared__ __attribute__((aligned(16))) float red[2][17][64][4];   // two partial-tile slots: [quad][lane][4]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: the problem / tile / split indices derived from it live in SGPRs
   const int i = lane & 15, g = lane >> 4;
   const int wid = blockIdx.x * 4 + wave;
   if (wid >= tb.total_waves) return;
