@@ -54,6 +54,8 @@ def parse():
                     "of replaying the captured HIP graph")
     ap.add_argument("--host-per", action="store_true", help="prioritized workloads: keep the sum/min trees on the host (numpy, as the "
                     "reference) instead of in HBM")
+    ap.add_argument("--per", action="store_true", help="MLP MADDPG/MATD3: prioritized replay with the device-resident sum / min trees "
+                    "(sample by priority, importance weights, priorities written back every step); one GPU")
     ap.add_argument("--host-indices", action="store_true", help="MLP MADDPG/MATD3 graph replay: draw the batch indices with numpy on the host "
                     "and upload them every step (default: sample(batch) draws them on the device inside the gather kernel)")
     ap.add_argument("--steps-per-replay", type=int, default=4, help="MLP MADDPG/MATD3 graph replay with device-drawn indices: consecutive "
@@ -509,7 +511,9 @@ def main_ddpg(a):
     td3 = a.workload == "matd3_spread"
     dims = DIMS["simple_spread"]
     batch = a.batch or 256
-    args = default_args()
+    per = bool(a.per)
+    assert not (per and world > 1), "--per: one GPU (the ranks of a prioritized multi-GPU run exchange priorities through the host)"
+    args = default_args(use_per=per)
     torch.manual_seed(1)
     np.random.seed(1)
     pinfo = policy_info_for(dims)
@@ -517,23 +521,36 @@ def main_ddpg(a):
     trainer = (MATD3 if td3 else MADDPG)(args, dims.n_agents, {"policy_0": policy}, lambda x: "policy_0", device=dev)
     trainer.device_noise = not a.host_noise
     cap = 16384
-    buf = MlpReplayBuffer(pinfo, {"policy_0": list(range(dims.n_agents))}, cap, True, True, False, device=dev)
+    if per:
+        from offpolicy_amd.utils.mlp_buffer import PrioritizedMlpReplayBuffer
+        buf = PrioritizedMlpReplayBuffer(args.per_alpha, pinfo, {"policy_0": list(range(dims.n_agents))}, cap, True, True, False, device=dev, device_tree=True)
+    else:
+        buf = MlpReplayBuffer(pinfo, {"policy_0": list(range(dims.n_agents))}, cap, True, True, False, device=dev)
     tr = ddpg_transitions(np.random.RandomState(100), cap, dims)       # identical replica on every rank
     buf.insert(cap, *[{"policy_0": tr[k]} for k in DDPG_KEYS])
     pbuf = buf.policy_buffers["policy_0"]
-    use_graph = world == 1 and not a.no_graph and not a.host_noise
+    # at world > 1 the graph holds the two gradient all-reduces too: only with the one-shot exchange (device-held call counter)
+    use_graph = (world == 1 or opdist.graph_safe_allreduce()) and not a.no_graph and not a.host_noise
     results = []
     for leg, local_batch, global_batch in scaling_legs(a, batch, world):
         np.random.seed(1000)
         torch.manual_seed(1000 + rank)
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
-        dev_sampling = use_graph and not a.host_indices
+        dev_sampling = use_graph and not a.host_indices and not per
         # with everything drawn on the device a replay can hold several consecutive steps (graph-launch latency amortised);
         # only when that divides both counts, so that exactly --steps steps are timed
-        spr = a.steps_per_replay if (dev_sampling and a.steps % a.steps_per_replay == 0 and a.warmup % a.steps_per_replay == 0) else 1
+        spr = a.steps_per_replay if ((dev_sampling or (per and use_graph)) and a.steps % a.steps_per_replay == 0 and a.warmup % a.steps_per_replay == 0) else 1
         graphed = trainer.make_graphed_step(buf, local_batch, device_sampling=dev_sampling, steps_per_replay=spr) if use_graph else None
 
         def one_step(i=None):
+            if per:
+                if graphed is not None:
+                    return graphed(0.5)        # priority sample + gather + updates + priorities written back: one graph launch
+                batch_ = buf.sample(local_batch, beta=0.5, p_id="policy_0")
+                info, prio, idx = trainer.shared_train_policy_on_batch("policy_0", batch_)
+                buf.update_priorities(idx, prio, p_id="policy_0")
+                policy.soft_target_updates()
+                return info
             if dev_sampling:
                 return graphed()               # sample (drawn in the gather kernel) + critic + actor + soft target updates: one graph launch
             inds = opdist.shard_indices(np.random.choice(len(buf), global_batch), rank, world)
@@ -569,8 +586,8 @@ def main_ddpg(a):
                                       "step = sample + critic update + actor update + soft target updates; reference semantics "
                                       "(frozen critic heads A-4, actor updated every call A-5); gumbel noise drawn on the %s; %s" % (
                                           "MATD3" if td3 else "MADDPG", N, A, D, S, cap, "host (reference stream)" if a.host_noise else "device",
-                                          ("%d consecutive step(s) per captured HIP graph replay, batch indices drawn %s" % (spr, "on the host (numpy) and uploaded" if a.host_indices else
-                                           "on the device inside the gather (uniform with replacement, as np.random.choice)")) if use_graph else "kernels launched one by one"),
+                                          ("%d consecutive step(s) per captured HIP graph replay, batch indices drawn %s" % (spr, "by priority from the device-resident trees (importance weights and written-back priorities inside the graph)" if per else ("on the host (numpy) and uploaded" if a.host_indices else
+                                           "on the device inside the gather (uniform with replacement, as np.random.choice)"))) if use_graph else ("kernels launched one by one" + (", prioritized replay through the device trees" if per else ""))),
                           "batch_per_gpu": r0["local_batch"], "global_batch": r0["global_batch"], "parallelism": "dp%d" % world,
                           "allreduce": allreduce_name() if world > 1 else None,
                           "optimizer_steps_per_sec": round(steps_per_s, 2)},

@@ -89,6 +89,11 @@ int ope_per_tree_init(void* trees, int32_t capacity, void* stream);
 int ope_per_tree_set(void* trees, int32_t capacity, const int64_t* idx, const float* priorities, double alpha, int32_t n, void* stream);
 int ope_per_tree_sample(const void* trees, int32_t capacity, int32_t filled, const double* mass01, double beta, int32_t n,
                         int64_t* idx_out, float* weights_out, void* stream);
+/* The same with `filled` (device int32[1], clamped to [2, capacity]) and `beta` (device double[1]) read at run time: the launch
+ * is identical from call to call, so a prioritized update can be captured in a HIP graph (MADDPG.make_graphed_step with PER: the
+ * buffer refreshes `filled` on insert, the caller writes the annealed beta before a replay). */
+int ope_per_tree_sample_dev(const void* trees, int32_t capacity, const int32_t* filled_dev, const double* mass01, const double* beta_dev,
+                            int32_t n, int64_t* idx_out, float* weights_out, void* stream);
 
 /* Reward normalisation (use_reward_normalization): statistics over the FILLED part of the reward ring
  *   episodes  (rec_buffer.py:209-222): nanmean / nanstd over steps whose previous step did not end the episode
@@ -434,7 +439,11 @@ int ope_rddpg_actor_loss_and_grad(const ope_rddpg_cfg* cfg, const ope_fields* ba
  *           skewed by host work or lazy initialisation) -- a bounded spin: a dead peer cannot hang the GPU forever. The
  *           failure is also visible IN-BAND: every 1024-float chunk whose peers did not arrive is overwritten with NaN
  *           (never with a sum over stale slots), so the following clip norm / loss / parameters are NaN.
- * world == 1 degenerates to a copy through the own slot. Not capturable in a HIP graph (epoch is a launch argument).
+ * world == 1 degenerates to a copy through the own slot.
+ * ope_allreduce_flat takes the epoch as a launch argument (not capturable in a HIP graph: a replay would repeat it).
+ * ope_allreduce_flat_dev keeps it on the device instead: `epoch_state_dev` = uint32[2], zero-filled once by the caller and then
+ * owned by the exchange ({epoch of the previous call, ticket}); every launch is identical, so the exchange can sit inside a
+ * captured graph (the MADDPG graphed step at world > 1). Use ONE of the two entry points per context, the same on every rank.
  * ---------------------------------------------------------------------------------------------- */
 #define OPE_AR_MAX_WORLD 16
 #define OPE_AR_IPC_HANDLE_BYTES 64
@@ -454,6 +463,7 @@ int ope_allreduce_ipc_close(void* mapped);
  * enabled counts as success). Called for every peer before its buffer is imported. */
 int ope_allreduce_enable_peer(int32_t peer_device);
 int ope_allreduce_flat(const ope_allreduce_ctx* ctx_host, uint32_t epoch, float* flat, int64_t n, int32_t* status, void* stream);
+int ope_allreduce_flat_dev(const ope_allreduce_ctx* ctx_host, uint32_t* epoch_state_dev, float* flat, int64_t n, int32_t* status, void* stream);
 
 #ifdef __cplusplus
 }

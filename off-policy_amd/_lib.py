@@ -94,6 +94,7 @@ def _load():
         "ope_per_tree_init": (C.c_int, [p, i32, p]),
         "ope_per_tree_set": (C.c_int, [p, i32, p, p, C.c_double, i32, p]),
         "ope_per_tree_sample": (C.c_int, [p, i32, i32, p, C.c_double, i32, p, p, p]),
+        "ope_per_tree_sample_dev": (C.c_int, [p, i32, p, p, p, i32, p, p, p]),
         "ope_reward_stats_scratch_bytes": (i64, []),
         "ope_store_reward_stats": (C.c_int, [C.POINTER(Dims), i32, p, p, p, p, p]),
         "ope_reward_normalize": (C.c_int, [p, i64, p, p]),
@@ -131,6 +132,7 @@ def _load():
         "ope_allreduce_ipc_close": (C.c_int, [p]),
         "ope_allreduce_enable_peer": (C.c_int, [i32]),
         "ope_allreduce_flat": (C.c_int, [C.POINTER(AllreduceCtx), C.c_uint32, p, i64, p, p]),
+        "ope_allreduce_flat_dev": (C.c_int, [C.POINTER(AllreduceCtx), p, p, i64, p, p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError here = a symbol declared in include/ope.h is missing

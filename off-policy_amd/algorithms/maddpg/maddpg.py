@@ -288,17 +288,26 @@ class MADDPG(object):
         eagerly it is bound by launch latency and host work, not by the GPU (csrc/ope_ddpg.hip). Returns
         `step(inds) -> train_info` where `inds` are the transition indices to train on (numpy int64 [batch_size], e.g.
         np.random.choice(len(buffer), batch_size)) and train_info holds device tensors overwritten by every replay.
-        Restrictions: uniform replay (no PER: priorities need the host tree), one process (no gradient all-reduce inside the
-        graph), gumbel noise drawn on the device (`device_noise`), the Adam step counters live on the device.
+        Restrictions: gumbel noise drawn on the device (`device_noise`), the Adam step counters live on the device.
+        Prioritized replay (`use_per`) needs the buffer's DEVICE trees (PrioritizedMlpReplayBuffer(device_tree=True)): sample
+        (masses from torch.rand, tree walk, importance weights), gather, update and update_priorities are all captured;
+        `step(beta)` takes the annealed beta, written to a device scalar before the replay; one process only (the ranks of a
+        multi-process prioritized run exchange their priorities through the host: that step stays eager).
+        In a multi-process run (one rank per GPU) the two gradient all-reduces are
+        captured with the rest: that needs the one-shot xGMI exchange (dist.setup_fast_allreduce verified it; its call counter
+        lives on the device, ope_allreduce_flat_dev) -- with the RCCL fallback the step stays eager. Every rank replays its own
+        graph on its share of the batch (`batch_size` = the local share); device-drawn indices use a per-rank stream.
         `device_sampling=True`: the batch indices are drawn on the device too (buffer.sample(batch_size) with the uniform draw
         inside the gather kernel, MlpPolicyBuffer.sample_device): `step()` takes no argument, a replay involves no host data at
         all, and train_info["indices"] holds the drawn indices. With device sampling a replay may also hold several CONSECUTIVE
         training steps (`steps_per_replay`; the counters that key indices, noise and Adam's bias correction advance on the device
         between them), which amortises the graph-launch latency; train_info is then that of the last step of the replay."""
         steps_per_replay = int(steps_per_replay)
-        assert steps_per_replay == 1 or device_sampling, "several steps per replay need the indices drawn on the device"
-        if self.use_per or opdist.is_distributed():
-            raise NotImplementedError("graphed step: uniform replay on a single GPU only")
+        assert steps_per_replay == 1 or device_sampling or self.use_per, "several steps per replay need the indices drawn on the device"
+        if self.use_per and (opdist.is_distributed() or not getattr(buffer, "device_tree", False)):
+            raise NotImplementedError("graphed prioritized step: one process, device trees (PrioritizedMlpReplayBuffer(device_tree=True))")
+        if opdist.is_distributed() and not opdist.graph_safe_allreduce():
+            raise NotImplementedError("graphed step at world > 1 needs the one-shot all-reduce (%s)" % opdist.allreduce_backend())
         pid = policy_id
         policy, pbuf = self.policies[pid], buffer.policy_buffers[pid]
         B = int(batch_size)
@@ -315,9 +324,18 @@ class MADDPG(object):
             opt.step_dev = torch.tensor([opt.step_count, 0], dtype=torch.int32, device=self.device)    # [count, ticket]
         static_inds = torch.zeros(B, dtype=torch.int64, device=self.device)
 
-        sample_seed = (torch.initial_seed() * 0xD1342543DE82EF95 + 0x9E3779B9) % (1 << 64) | 1
+        sample_seed = ((torch.initial_seed() + 0x632BE59BD9B4E019 * opdist.world()[0]) * 0xD1342543DE82EF95 + 0x9E3779B9) % (1 << 64) | 1   # per rank
+
+        beta_dev = torch.ones(1, dtype=torch.float64, device=self.device) if self.use_per else None
 
         def body():
+            if self.use_per:       # sample by priority, train with the importance weights, write the new priorities back: no host data
+                batch = buffer.sample_device(B, beta_dev, p_id=pid)
+                info, prio, drawn = self.shared_train_policy_on_batch(pid, batch)
+                buffer.update_priorities(drawn, prio, p_id=pid)
+                policy.soft_target_updates()
+                info["indices"], info["priorities"] = drawn, prio
+                return info
             if device_sampling:
                 s, drawn = pbuf.sample_device(B, sample_seed, counter=policy.critic_optimizer.step_dev)
             else:
@@ -334,6 +352,7 @@ class MADDPG(object):
         snap_nets = [m._flat.clone() for m in nets]
         snap_opts = [(o.exp_avg.clone(), o.exp_avg_sq.clone(), o.step_dev.clone(), o.step_count) for o in opts]
         snap_misc = (dict(self.num_updates), getattr(policy, "_polyak_done", False), np.random.get_state())
+        snap_per = (buffer._dtrees[pid].trees.clone(), torch.cuda.get_rng_state(self.device)) if self.use_per else None
         side = torch.cuda.Stream(device=self.device)     # warm-up off the capture: workspaces, allocator pools, lazy init
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
@@ -349,6 +368,9 @@ class MADDPG(object):
         self.num_updates.update(snap_misc[0])
         policy._polyak_done = snap_misc[1]
         np.random.set_state(snap_misc[2])
+        if snap_per is not None:      # the warm-up updates rewrote priorities and drew masses
+            buffer._dtrees[pid].trees.copy_(snap_per[0])
+            torch.cuda.set_rng_state(snap_per[1], self.device)
         torch.cuda.synchronize(self.device)
         count0 = dict(self.num_updates)
         actor_host0 = policy.actor_optimizer.step_count
@@ -363,7 +385,10 @@ class MADDPG(object):
         ring = [(torch.empty(B, dtype=torch.int64).pin_memory(), torch.cuda.Event()) for _ in range(8)]
         state = {"k": 0, "used": [False] * 8}
 
-        def step_sampled():
+        def step_sampled(beta=None):
+            if self.use_per:
+                assert beta is not None and beta > 0, "prioritized graphed step: pass the current beta"
+                beta_dev.fill_(float(beta))
             graph.replay()
             policy.critic_optimizer.step_count += steps_per_replay
             policy.actor_optimizer.step_count += actor_steps_per_replay
@@ -388,7 +413,7 @@ class MADDPG(object):
                 self.num_updates[pid] += 1
             return info
         self._graph = (graph, static_inds, ring)      # keep alive
-        return step_sampled if device_sampling else step
+        return step_sampled if (device_sampling or self.use_per) else step
 
     def prep_training(self):
         pass

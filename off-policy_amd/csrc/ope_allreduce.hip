@@ -28,8 +28,11 @@ struct ArArgs {
   int64_t max_floats;
   int chunks_max;
   uint32_t epoch;
+  uint32_t* epoch_dev;                // if set: {epoch of the previous exchange, finished-workgroup ticket} on the device; epoch ignored
   unsigned long long timeout_ticks;   // wall_clock64 ticks (100 MHz)
 };
+// next epoch of the cycle 1, 2, ..., 0xFFFFFFFE, 1, ... (never 0; parity = epoch & 1 keeps alternating over the even cycle)
+__host__ __device__ __forceinline__ uint32_t next_epoch(uint32_t e) { return e % 0xFFFFFFFEu + 1u; }
 
 __device__ __forceinline__ uint32_t* flag_ptr(float* base, int chunks_max, int world, int parity, int src, int chunk) {
   return reinterpret_cast<uint32_t*>(base) + ((int64_t)(parity * world + src) * chunks_max + chunk);
@@ -40,7 +43,19 @@ __device__ __forceinline__ float* slot_ptr(float* base, int chunks_max, int worl
 
 __global__ void __launch_bounds__(kBlock) allreduce_push_kernel(ArArgs a, float* __restrict__ flat, int64_t n, int32_t* status) {
   const int chunk = blockIdx.x, tid = threadIdx.x;
-  const int parity = a.epoch & 1u;
+  // Device-held epoch (graph-capturable exchange: nothing of a launch changes between replays): every workgroup derives the epoch
+  // from the value the previous exchange left, and the LAST workgroup to finish (ticket) stores it for the next one. No workgroup
+  // can still have to read the old value by then: it would not have finished.
+  const uint32_t epoch = a.epoch_dev ? next_epoch(__hip_atomic_load(a.epoch_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : a.epoch;
+  auto finish = [&]() {
+    if (a.epoch_dev && tid == 0) {
+      if (atomicAdd(a.epoch_dev + 1, 1u) == gridDim.x - 1) {
+        __hip_atomic_store(a.epoch_dev + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.epoch_dev, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  };
+  const int parity = epoch & 1u;
   const int64_t i = (int64_t)chunk * kChunk + 4 * tid;
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
   if (i + 3 < n) {
@@ -59,7 +74,7 @@ __global__ void __launch_bounds__(kBlock) allreduce_push_kernel(ArArgs a, float*
   __syncthreads();                 // ... before any flag of this chunk goes out
   if (tid < a.world) {
     const int dst = (a.rank + 1 + tid) % a.world;
-    __hip_atomic_store(flag_ptr(a.peer[dst], a.chunks_max, a.world, parity, a.rank, chunk), a.epoch, __ATOMIC_RELAXED,
+    __hip_atomic_store(flag_ptr(a.peer[dst], a.chunks_max, a.world, parity, a.rank, chunk), epoch, __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_SYSTEM);
   }
   // wait for the W flags of this chunk in the OWN buffer (bounded)
@@ -69,7 +84,7 @@ __global__ void __launch_bounds__(kBlock) allreduce_push_kernel(ArArgs a, float*
   if (tid < a.world) {
     const uint32_t* f = flag_ptr(a.peer[a.rank], a.chunks_max, a.world, parity, tid, chunk);
     const unsigned long long t0 = wall_clock64();
-    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != a.epoch) {
+    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != epoch) {
       __builtin_amdgcn_s_sleep(2);
       if (wall_clock64() - t0 > a.timeout_ticks) {
         atomicOr(status, 1);
@@ -87,6 +102,7 @@ __global__ void __launch_bounds__(kBlock) allreduce_push_kernel(ArArgs a, float*
     const float qnan = __builtin_nanf("");
     for (int r = 0; r < 4; ++r)
       if (i + r < n) flat[i + r] = qnan;
+    finish();
     return;
   }
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
@@ -105,6 +121,7 @@ __global__ void __launch_bounds__(kBlock) allreduce_push_kernel(ArArgs a, float*
     for (int r = 0; r < 4; ++r)
       if (i + r < n) flat[i + r] = s[r];
   }
+  finish();
 }
 
 inline int64_t chunks_of(int64_t max_floats) { return (max_floats + kChunk - 1) / kChunk; }
@@ -183,9 +200,9 @@ extern "C" int ope_allreduce_ipc_close(void* mapped) {
   return hipIpcCloseMemHandle(mapped) == hipSuccess ? OPE_OK : OPE_EHIP;
 }
 
-extern "C" int ope_allreduce_flat(const ope_allreduce_ctx* ctx, uint32_t epoch, float* flat, int64_t n, int32_t* status, void* stream) {
+static int allreduce_launch(const ope_allreduce_ctx* ctx, uint32_t epoch, uint32_t* epoch_dev, float* flat, int64_t n, int32_t* status, void* stream) {
   (void)hipGetLastError();
-  if (!ctx || !flat || !status || epoch == 0 || ctx->world < 1 || ctx->world > OPE_AR_MAX_WORLD || ctx->rank < 0 ||
+  if (!ctx || !flat || !status || (epoch == 0 && !epoch_dev) || ctx->world < 1 || ctx->world > OPE_AR_MAX_WORLD || ctx->rank < 0 ||
       ctx->rank >= ctx->world || n < 1 || n > ctx->max_floats || ctx->max_floats % kChunk != 0)
     return OPE_EINVAL;
   ArArgs a;
@@ -194,9 +211,18 @@ extern "C" int ope_allreduce_flat(const ope_allreduce_ctx* ctx, uint32_t epoch, 
     a.peer[q] = reinterpret_cast<float*>(ctx->peer[q]);
   }
   a.rank = ctx->rank; a.world = ctx->world; a.max_floats = ctx->max_floats; a.chunks_max = (int)chunks_of(ctx->max_floats);
-  a.epoch = epoch;
+  a.epoch = epoch; a.epoch_dev = epoch_dev;
   a.timeout_ticks = (unsigned long long)(ctx->timeout_ms > 0 ? ctx->timeout_ms : kDefaultTimeoutMs) * 100000ull;
   hipLaunchKernelGGL(allreduce_push_kernel, dim3(ope_cdiv(n, kChunk)), dim3(kBlock), 0, (hipStream_t)stream, a, flat, n, status);
   OPE_CHECK_LAUNCH();
   return OPE_OK;
+}
+
+extern "C" int ope_allreduce_flat(const ope_allreduce_ctx* ctx, uint32_t epoch, float* flat, int64_t n, int32_t* status, void* stream) {
+  return allreduce_launch(ctx, epoch, nullptr, flat, n, status, stream);
+}
+
+extern "C" int ope_allreduce_flat_dev(const ope_allreduce_ctx* ctx, uint32_t* epoch_state_dev, float* flat, int64_t n, int32_t* status, void* stream) {
+  if (!epoch_state_dev) return OPE_EINVAL;
+  return allreduce_launch(ctx, 0, epoch_state_dev, flat, n, status, stream);
 }

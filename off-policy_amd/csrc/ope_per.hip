@@ -91,11 +91,16 @@ __device__ double per_prefix_total(const double* sum, int cap, int end) {
 
 // idx[i] = find_prefixsum_idx(mass01[i] * sum(leaves[0, filled-1)))   (rec_buffer.py:272-276: the last filled leaf is
 // left out of the mass, an upstream quirk kept as is); weights[i] = (p_i * filled)^-beta / max_w, max_w = (p_min * filled)^-beta
+// filled_dev / beta_dev (optional): the two values that change between the replays of a captured graph, read from HBM instead
+// of the launch arguments (filled clamped to [2, capacity]).
 __global__ void per_sample_kernel(const void* trees, int cap, int filled, const double* __restrict__ mass01, double beta, int n,
-                                  int64_t* __restrict__ idx_out, float* __restrict__ w_out) {
+                                  int64_t* __restrict__ idx_out, float* __restrict__ w_out, const int32_t* __restrict__ filled_dev,
+                                  const double* __restrict__ beta_dev) {
   const PerView v = per_view(const_cast<void*>(trees), cap);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (filled_dev) filled = min(max(filled_dev[0], 2), cap);
+  if (beta_dev) beta = beta_dev[0];
   const double total = per_prefix_total(v.sum, cap, filled - 1);
   double p = mass01[i] * total;
   int64_t node = 1;
@@ -149,7 +154,17 @@ extern "C" int ope_per_tree_sample(const void* trees, int32_t capacity, int32_t 
   (void)hipGetLastError();
   if (!trees || !pow2(capacity) || filled < 2 || filled > capacity || !mass01 || !idx_out || n < 1) return OPE_EINVAL;
   hipLaunchKernelGGL(per_sample_kernel, dim3(ope_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, trees, capacity, filled, mass01, beta, n,
-                     idx_out, weights_out);
+                     idx_out, weights_out, (const int32_t*)nullptr, (const double*)nullptr);
+  OPE_CHECK_LAUNCH();
+  return OPE_OK;
+}
+
+extern "C" int ope_per_tree_sample_dev(const void* trees, int32_t capacity, const int32_t* filled_dev, const double* mass01, const double* beta_dev,
+                                       int32_t n, int64_t* idx_out, float* weights_out, void* stream) {
+  (void)hipGetLastError();
+  if (!trees || !pow2(capacity) || !filled_dev || !beta_dev || !mass01 || !idx_out || n < 1) return OPE_EINVAL;
+  hipLaunchKernelGGL(per_sample_kernel, dim3(ope_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, trees, capacity, 2, mass01, 0.0, n, idx_out,
+                     weights_out, filled_dev, beta_dev);
   OPE_CHECK_LAUNCH();
   return OPE_OK;
 }

@@ -45,7 +45,6 @@ class OneShotAllreduce(object):
         self.device = torch.device(device)
         self.rank, self.world = int(rank), int(world_size)
         self.max_floats = int(max_floats or self.MAX_FLOATS)
-        self.epoch = 0
         self._mapped = []
         with torch.cuda.device(self.device):
             nbytes = int(_lib.lib.ope_allreduce_buffer_bytes(self.max_floats, self.world))
@@ -81,14 +80,23 @@ class OneShotAllreduce(object):
             for q in range(self.world):
                 self.ctx.peer[q] = peers[q]
             self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
+            # the call counter lives on the device ({epoch of the previous exchange, ticket}: ope_allreduce_flat_dev), so every
+            # launch is identical and the exchange can be captured in a HIP graph (MADDPG.make_graphed_step at world > 1). It wraps
+            # over the even cycle 1, 2, ..., 0xFFFFFFFE, 1, ... inside the kernel (parity picks the buffer half; 0 is never used).
+            self.epoch_state = torch.zeros(2, dtype=torch.int32, device=self.device)
+
+    graph_safe = True      # nothing of a launch changes from call to call
+
+    @property
+    def epoch(self):
+        """Exchanges completed so far, modulo the wrap (reads the device counter: synchronises)."""
+        return int(self.epoch_state[0].item())
 
     def __call__(self, flat):
         assert flat.dtype == torch.float32 and flat.is_contiguous() and flat.device == self.device and flat.numel() <= self.max_floats
-        # the C-ABI takes a uint32 epoch and rejects 0; parity (= epoch & 1) picks the buffer half and must keep alternating, so
-        # the counter wraps over an EVEN cycle: 1, 2, ..., 0xFFFFFFFE, 1, ...
-        self.epoch = self.epoch % 0xFFFFFFFE + 1
-        self._lib.check(self._lib.lib.ope_allreduce_flat(self._C.byref(self.ctx), self.epoch, self._lib.ptr(flat), flat.numel(),
-                                                         self._lib.ptr(self.status), self._lib.current_stream()), "ope_allreduce_flat")
+        self._lib.check(self._lib.lib.ope_allreduce_flat_dev(self._C.byref(self.ctx), self._lib.ptr(self.epoch_state), self._lib.ptr(flat),
+                                                             flat.numel(), self._lib.ptr(self.status), self._lib.current_stream()),
+                        "ope_allreduce_flat_dev")
         return flat
 
     def timed_out(self):
@@ -133,6 +141,12 @@ def _close_after_barrier(ar, group=None):
             ar.close()
     except Exception:      # tearing down a broken fast path must not take the (working) RCCL path with it
         pass
+
+
+def graph_safe_allreduce():
+    """True when `allreduce_flat_` may be captured in a HIP graph: the one-shot exchange is in use (its launches are identical from
+    call to call); torch.distributed's all_reduce is kept out of captures."""
+    return _fast is not None and getattr(_fast, "graph_safe", False)
 
 
 def allreduce_backend():

@@ -67,6 +67,18 @@ class DevicePerTree(object):
                                                 _lib.ptr(w), _lib.current_stream()), "ope_per_tree_sample")
         return idx, w
 
+    def sample_dev(self, mass01, filled_dev, beta_dev):
+        """`sample` with everything on the device: mass01 float64 [B] tensor (e.g. torch.rand inside a graph capture), the filled
+        count (int32 [1], kept by the buffer) and beta (float64 [1], written by the caller before a replay). No host data, and a
+        launch that is identical from call to call: capturable."""
+        B = int(mass01.numel())
+        assert mass01.dtype == torch.float64 and mass01.is_contiguous() and beta_dev.dtype == torch.float64 and filled_dev.dtype == torch.int32
+        idx = torch.empty(B, dtype=torch.int64, device=self.device)
+        w = torch.empty(B, dtype=torch.float32, device=self.device)
+        _lib.check(_lib.lib.ope_per_tree_sample_dev(_lib.ptr(self.trees), self.capacity, _lib.ptr(filled_dev), _lib.ptr(mass01), _lib.ptr(beta_dev), B,
+                                                    _lib.ptr(idx), _lib.ptr(w), _lib.current_stream()), "ope_per_tree_sample_dev")
+        return idx, w
+
     # host views for tests / checkpoints
     def leaves(self):
         t = self.trees.view(torch.float64).cpu().numpy()

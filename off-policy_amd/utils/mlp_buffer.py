@@ -193,6 +193,15 @@ class PrioritizedMlpReplayBuffer(MlpReplayBuffer):
             return self._gather(_shard(batch_inds, *shard)) + (_shard(weights, *shard), batch_inds)
         return self._gather(batch_inds) + (weights, batch_inds)
 
+    def sample_device(self, batch_size, beta_dev, p_id=None):
+        """Device-tree prioritized sample with no host data (capturable in a HIP graph): masses from torch.rand, the filled count from
+        the buffer's device counter, beta from `beta_dev` (float64 [1] device tensor). Returns the 11-tuple + (weights, indices)."""
+        assert self.device_tree, "device-side prioritized sampling needs device_tree=True"
+        pbuf = self.policy_buffers[p_id]
+        mass = torch.rand(int(batch_size), dtype=torch.float64, device=pbuf.device)
+        inds, weights = self._dtrees[p_id].sample_dev(mass, pbuf._ep._filled_device(), beta_dev)
+        return tuple({p_id: x} for x in pbuf.sample_inds(inds)) + (weights, inds)
+
     def update_priorities(self, idxes, priorities, p_id=None):
         if self.device_tree:    # range checks of the host path would force a device sync; the kernels clamp nothing: callers pass
             self._dtrees[p_id].set(idxes, priorities)   # indices returned by sample()

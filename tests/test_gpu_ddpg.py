@@ -1,5 +1,6 @@
 """-m gpu: MLP MADDPG / MATD3 through the C-ABI vs the reference's frozen outputs (same gumbel noise stream)."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -179,6 +180,67 @@ def test_graphed_step_matches_eager_step():
             assert not torch.equal(before, policy.actor._flat)
     np.testing.assert_allclose(res["graph"], res["eager"], rtol=1e-5)
     np.testing.assert_allclose(res["eager"][0], g["critic_loss"][0], rtol=RTOL)
+
+
+@pytest.mark.parametrize("td3", [False, True])
+def test_graphed_prioritized_step_matches_eager_device_tree_step(td3):
+    """Prioritized replay inside the captured graph: device trees, masses from torch.rand, `filled` and beta
+    read from HBM (ope_per_tree_sample_dev). The replays draw, train and write priorities back exactly like the eager loop over
+    the same device-tree calls started from the same generator state; building the graph leaves trees and generator untouched."""
+    from offpolicy_amd.utils.mlp_buffer import PrioritizedMlpReplayBuffer
+    from offpolicy_amd.utils.synth import policy_info_for
+    res = {}
+    for mode in ("eager", "graph"):
+        dims, N, A, D, S, B, cap, policy, trainer, buf0 = config3_setup(td3, True, B=64, cap=512)
+        pinfo = policy_info_for(dims)
+        buf = PrioritizedMlpReplayBuffer(0.6, pinfo, {"policy_0": list(range(N))}, cap, True, True, False, device=policy.actor._flat.device,
+                                         device_tree=True)
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from bench import ddpg_transitions, DDPG_KEYS
+        data = ddpg_transitions(np.random.RandomState(5), cap - 100, dims)          # 412 of 512 slots filled
+        buf.insert(cap - 100, *[{"policy_0": data[k]} for k in DDPG_KEYS])
+        # uneven priorities to start from
+        buf.update_priorities(np.arange(cap - 100), np.random.RandomState(6).uniform(0.1, 3.0, cap - 100).astype(np.float32), p_id="policy_0")
+        trainer.device_noise = True
+        torch.cuda.manual_seed(1234)
+        betas = [0.4, 0.5, 0.6]
+        drawn, prios = [], []
+        if mode == "eager":
+            beta_dev = torch.ones(1, dtype=torch.float64, device=policy.actor._flat.device)
+            trainer.fuse_soft_update = True
+            for opt in (policy.critic_optimizer, policy.actor_optimizer):      # device step counters, as the graphed step keeps them
+                opt.step_dev = torch.tensor([opt.step_count, 0], dtype=torch.int32, device=policy.actor._flat.device)      # (they key the noise)
+            for beta in betas:
+                beta_dev.fill_(beta)
+                batch = buf.sample_device(B, beta_dev, p_id="policy_0")
+                info, prio, idx = trainer.shared_train_policy_on_batch("policy_0", batch)
+                buf.update_priorities(idx, prio, p_id="policy_0")
+                policy.soft_target_updates()
+                drawn.append(idx.cpu().numpy()); prios.append(prio.cpu().numpy())
+        else:
+            trees0 = buf._dtrees["policy_0"].trees.clone()
+            rng0 = torch.cuda.get_rng_state()
+            theta0 = policy.critic._flat.clone()
+            step = trainer.make_graphed_step(buf, B)
+            assert torch.equal(buf._dtrees["policy_0"].trees, trees0) and torch.equal(torch.cuda.get_rng_state(), rng0)
+            assert torch.equal(policy.critic._flat, theta0)
+            for beta in betas:
+                info = step(beta)
+                drawn.append(info["indices"].cpu().numpy()); prios.append(info["priorities"].cpu().numpy())
+        torch.cuda.synchronize()
+        leaves = buf._dtrees["policy_0"].leaves()[0]
+        res[mode] = (np.asarray(drawn), np.asarray(prios), policy.critic._flat.cpu().numpy(), policy.actor._flat.cpu().numpy(), leaves)
+        assert np.all(res[mode][0] >= 0) and np.all(res[mode][0] < cap - 100)
+        # the leaves of the last draw hold its priorities ** alpha (duplicates: the last one wins)
+        last = {int(i): float(p) for i, p in zip(res[mode][0][-1], res[mode][1][-1])}
+        for i, p in last.items():
+            np.testing.assert_allclose(leaves[i], p ** buf.alpha, rtol=1e-6)
+    e, g = res["eager"], res["graph"]
+    assert np.array_equal(e[0], g[0]), "the graph replays must draw the indices the eager calls draw from the same generator state"
+    np.testing.assert_allclose(g[1], e[1], rtol=1e-5)
+    np.testing.assert_allclose(g[2], e[2], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(g[3], e[3], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(g[4], e[4], rtol=1e-5)
 
 
 def _flat_grads(mod, gvec, n_tail):
