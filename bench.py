@@ -562,7 +562,7 @@ def main_ddpg(a):
             return info
         windows, info = timed_windows(one_step, a.steps // spr, a.warmup // spr, world, dev, a.repeats)      # spr steps per call
         elapsed = median_window(windows)
-        if graphed is not None:    # the gather inside the graph cannot carry events: time the same launch on its own afterwards
+        if graphed is not None or per:    # the gather inside the graph (or behind the priority sample) carries no events: time the same launch on its own afterwards
             ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(50)]
             for e in ev:
                 pbuf.sample_inds(np.random.choice(len(buf), local_batch), timing_events=e)

@@ -69,9 +69,16 @@ __global__ void __launch_bounds__(kBlock) allreduce_push_kernel(ArArgs a, float*
     const int dst = (a.rank + q) % a.world;
     *reinterpret_cast<f32x4*>(slot_ptr(a.peer[dst], a.chunks_max, a.world, a.max_floats, parity, a.rank) + i) = v;
   }
-  __threadfence_system();          // EVERY writer: its slot stores are written back / visible system-wide ...
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (hipcc may drop the wait after buffer_wbl2, MI355X_MICROARCH.md)
-  __syncthreads();                 // ... before any flag of this chunk goes out
+  // Release: every wave waits until ITS slot stores are acknowledged, the workgroup meets, and then ONE wave (the one that raises
+  // the flags) executes the system-scope fence: the write-back it triggers acts on the whole L2, not on the issuing wave's lines, so
+  // one per workgroup orders all four waves' stores before the flags. (Measured at world 1, 464 KB: a fence in every wave on both
+  // sides made the launch 17.7 us, none 6.3 us -- the fences ARE the cost of this kernel; profiles/r03z_allreduce_fences.txt.)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid < 64) {
+    __threadfence_system();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (hipcc may drop the wait after buffer_wbl2, MI355X_MICROARCH.md)
+  }
   if (tid < a.world) {
     const int dst = (a.rank + 1 + tid) % a.world;
     __hip_atomic_store(flag_ptr(a.peer[dst], a.chunks_max, a.world, parity, a.rank, chunk), epoch, __ATOMIC_RELAXED,
@@ -93,7 +100,9 @@ __global__ void __launch_bounds__(kBlock) allreduce_push_kernel(ArArgs a, float*
       }
     }
   }
-  __threadfence_system();          // acquire side: drop any stale line before the slots are read
+  // Acquire: the wave that saw the flags drops stale lines (L2 and this CU's vector cache are shared by the workgroup's waves)
+  // before anybody reads the slots; the slot loads below are system-coherent loads on top of that.
+  if (tid < 64) __threadfence_system();
   __syncthreads();
   if (gave_up) {
     // A peer's chunk never arrived: the slots hold a PREVIOUS epoch's data. Summing them would hand the optimizer a plausible
@@ -105,16 +114,30 @@ __global__ void __launch_bounds__(kBlock) allreduce_push_kernel(ArArgs a, float*
     finish();
     return;
   }
+  // The W slots are read with ONE 16-byte system-coherent load each, ALL issued before the first is waited for (asm: a volatile
+  // C++ load gets an s_waitcnt vmcnt(0) of its own, and four system-scope dword loads per slot -- the first version -- were W
+  // dependent round trips through uncached memory: what an 8-rank exchange spent most of its time in). The registers are
+  // zero-filled first and tied read-write to the loads and to the wait, so hipcc neither copies nor reads them in between.
+  // Summation stays in FIXED rank order: identical bits on every rank.
+  f32x4 x[OPE_AR_MAX_WORLD];
+#pragma unroll
+  for (int q = 0; q < OPE_AR_MAX_WORLD; ++q) x[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < OPE_AR_MAX_WORLD; ++q)
+    if (q < a.world) {
+      const float* sp = slot_ptr(a.peer[a.rank], a.chunks_max, a.world, a.max_floats, parity, q) + i;
+      asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "+v"(x[q]) : "v"(sp) : "memory");
+    }
+  static_assert(OPE_AR_MAX_WORLD == 16, "the wait below names sixteen registers");
+  asm volatile("s_waitcnt vmcnt(0)"
+               : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]), "+v"(x[9]),
+                 "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15])
+               :
+               : "memory");
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  for (int q = 0; q < a.world; ++q) {          // FIXED rank order: identical bits on every rank
-    const float* sp = slot_ptr(a.peer[a.rank], a.chunks_max, a.world, a.max_floats, parity, q) + i;
-    f32x4 x;
-    x[0] = __hip_atomic_load(sp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    x[1] = __hip_atomic_load(sp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    x[2] = __hip_atomic_load(sp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    x[3] = __hip_atomic_load(sp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    s += x;
-  }
+#pragma unroll
+  for (int q = 0; q < OPE_AR_MAX_WORLD; ++q)
+    if (q < a.world) s += x[q];
   if (i + 3 < n) {
     *reinterpret_cast<f32x4*>(flat + i) = s;
   } else {
