@@ -154,6 +154,8 @@ int launch_gru_bwd1(const GruBwdArgs& a, hipStream_t st);
 int launch_gru_bwd4(const GruBwdArgs& a, hipStream_t st);
 int launch_trunk_bwd(const TrunkBwdArgs& a, hipStream_t st);
 int launch_trunk_bwd3(const TrunkBwdArgs& a, hipStream_t st);   // persistent cooperative form (ope_trunk_bwd3.hip)
+// recurrent trunk adjoint: trunk_bwd4 (ope_trunk_bwd4.hip: weights in LDS, a wave per tile) when the shape allows and `path` (ope_qmix_cfg.trunk_path) asks, else trunk_bwd3
+int launch_trunk_bwd_path(const TrunkBwdArgs& a, int path, hipStream_t st);
 int launch_transpose_weights(const float* theta, const AgentLayout& L, float* thetaT, hipStream_t st);
 int launch_transpose(const float* src, int rows, int cols, float* dst, hipStream_t st);
 

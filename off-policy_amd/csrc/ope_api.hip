@@ -515,7 +515,7 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
     tb.xhat2 = W + p.xhat2 + r0 * OPE_H; tb.rstd2 = W + p.rstd2 + r0; tb.mask2 = (const uint64_t*)(W + p.mask2) + r0;
     tb.dz1 = W + p.dz1 + r0 * OPE_H; tb.dz2 = W + p.dz2 + r0 * OPE_H;
     if (do_bwd)
-      if ((rc = launch_trunk_bwd(tb, st))) return rc;
+      if ((rc = launch_trunk_bwd_path(tb, cfg->trunk_path, st))) return rc;
     WgTable wt;
     memset(&wt, 0, sizeof(wt));
     if (do_bwd) add_agent_problems(wt, r0, K1, p.ns_chunk[c], agent_slabs);
