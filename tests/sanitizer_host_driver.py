@@ -85,6 +85,11 @@ f = _lib.Fields()
 assert L.ope_store_gather_host_inds(C.byref(d0), 4, C.byref(f), inds.ctypes.data_as(C.c_void_p), 2, C.byref(f), None) == -1
 ctx = _lib.AllreduceCtx()
 assert L.ope_allreduce_flat(C.byref(ctx), 0, None, 4, None, None) == -1
+assert L.ope_allreduce_flat_dev(C.byref(ctx), None, None, 4, None, None) == -1          # no epoch state
+assert L.ope_allreduce_flat_dev(None, None, None, 4, None, None) == -1
+assert L.ope_per_tree_sample_dev(None, 64, None, None, None, 4, None, None, None) == -1
+assert L.ope_per_tree_sample(None, 64, 8, None, 0.5, 4, None, None, None) == -1
+assert L.ope_per_tree_sample(None, 3, 8, None, 0.5, 4, None, None, None) == -1            # capacity not a power of two
 L.ope_set_debug(0)
 L.ope_set_scan_kernel(4, 2)
 L.ope_set_scan_kernel(0, 0)

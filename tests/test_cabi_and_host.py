@@ -41,6 +41,33 @@ def test_param_layout_and_episode_bytes_match_survey():
     assert _lib.lib.ope_qmix_workspace_bytes(C.byref(cfg)) == -1
 
 
+def test_weight_gradient_split_count_follows_the_cost_model():
+    """The K-split row count of the batched weight-gradient launch is searched per shape (busiest CU's workgroups x rows per split,
+    at least three workgroups on the busiest of 256 CUs; ope_api.hip, profiles/r03q_wgrad_rows.txt): 192 rows at 3s5z batch 32
+    (28 mixer splits of the 4 800 (t, b) rows), 400 rows with the wide centralized state (12), and the 160-row default for
+    launches too small to fill the chip three times (3m: 12 splits of 1 920 rows). Read off the size of the mixer's slab region."""
+    import os
+    if os.environ.get("OPE_WGRAD_ROWS"):
+        pytest.skip("row count pinned by OPE_WGRAD_ROWS")
+    from offpolicy_amd import _lib
+
+    def mixer_splits(dims, batch):
+        cfg = _lib.QmixCfg()
+        cfg.dims, cfg.batch = _lib.Dims(*dims), batch
+        off, siz = (C.c_int64 * 36)(), (C.c_int64 * 36)()
+        total = _lib.lib.ope_qmix_param_layout(C.byref(cfg), off, siz)
+        n = C.c_int64(0)
+        assert _lib.lib.ope_qmix_workspace_find(C.byref(cfg), b"raw_mixer", C.byref(n)) >= 0
+        mixer_size = total - off[22]              # padded mixer block of the flat parameter vector
+        assert n.value % mixer_size == 0
+        return n.value // mixer_size
+
+    assert mixer_splits((8, 14, 252, 216, 150), 32) == 28
+    assert mixer_splits((8, 14, 252, 2232, 150), 32) == 12
+    assert mixer_splits((3, 9, 64, 48, 60), 32) == 12
+    assert mixer_splits((8, 14, 252, 216, 150), 4) == 4       # 600 rows: the default again
+
+
 def test_null_arguments_are_rejected_without_a_gpu():
     from offpolicy_amd import _lib
     assert _lib.lib.ope_adam_step(None, 4, None, None, None, None, None, None, None, None) == -1
