@@ -126,6 +126,7 @@ def run_case(name, dims, n_episodes, inds, steps=3, argv=(), vdn=False, avail="o
     out["hp_prev_act_inp"] = np.int64(bool(getattr(args, "prev_act_inp", False)))
     out["hp_same_share"] = np.int64(not per_agent_share)
     out["hp_soft_update"], out["hp_gain"] = np.int64(bool(args.use_soft_update)), np.float64(args.gain)
+    out["hp_hidden_size"], out["hp_layer_N"], out["hp_hypernet_layers"] = np.int64(args.hidden_size), np.int64(args.layer_N), np.int64(args.hypernet_layers)
     out["hard_update_after"] = np.asarray(list(hard_update_after), dtype=np.int64)
     losses, gnorms, qtots, prios = [], [], [], []
     for s in range(steps):
@@ -181,6 +182,17 @@ def main():
         # an odd wide state (nothing a multiple of 4 or 2): the unaligned paths of the wide-state kernels
         run_case("qmix_gall_odd", EnvDims("odd_gall", 3, 7, 18, 29 + 3 * 18, 5), n_episodes=6, inds=[5, 1, 1, 2, 0], avail="bernoulli", steps=3,
                  argv=gall, hard_update_after=(0,))
+        return
+    if os.environ.get("OPE_GOLDEN_ONLY") == "shapes":
+        # round 3: network shapes other than the reference defaults: one-layer hyper-networks (q_mixer.py:39-44),
+        # two hidden blocks after fc1 (mlp.py:14-28), hidden_size 128. The ORACLE is pinned on them here; the HIP engine still
+        # refuses them (config.py:require_reference_architecture) -- these fixtures are what its generic path will be tested on.
+        run_case("qmix_shape_hyper1", tiny, n_episodes=5, inds=[3, 0, 4, 3], avail="bernoulli", argv=["--hypernet_layers", "1"])
+        run_case("qmix_shape_layer2", tiny, n_episodes=5, inds=[1, 0, 4, 2], avail="bernoulli", argv=["--layer_N", "2"])
+        run_case("qmix_shape_h128", tiny, n_episodes=5, inds=[2, 2, 0, 4], avail="bernoulli", argv=["--hidden_size", "128"])
+        odd = EnvDims("odd", 3, 7, 18, 54, 5)
+        run_case("qmix_shape_all_odd", odd, n_episodes=6, inds=[5, 1, 1, 2, 0], avail="bernoulli", runner_padding=True,
+                 argv=["--hypernet_layers", "1", "--layer_N", "2", "--hidden_size", "128"])
         return
     if os.environ.get("OPE_GOLDEN_ONLY") == "pershare":      # add the round-2 fixture without rewriting the committed ones
         run_case("qmix_tiny_pershare", tiny, n_episodes=5, inds=[4, 1, 1, 0, 2], cap=6, pre_insert=3, avail="bernoulli", per_agent_share=True)

@@ -68,6 +68,21 @@ def test_weight_gradient_split_count_follows_the_cost_model():
     assert mixer_splits((8, 14, 252, 216, 150), 4) == 4       # 600 rows: the default again
 
 
+@pytest.mark.parametrize("name", ["qmix_shape_hyper1", "qmix_shape_layer2", "qmix_shape_h128"])
+def test_non_default_network_shapes_are_refused_loudly(name):
+    """The kernels are specialised to the reference's default network shape. The oracle is pinned on three other shapes
+    (tests/golden/qmix_shape_*.npz, test_oracle_golden.py); until the engine has a path for them the Python layer must refuse
+    them with NotImplementedError naming the option -- never take another path silently."""
+    from conftest import load_golden
+    from offpolicy_amd.config import default_args, require_reference_architecture
+    g = load_golden(name)
+    args = default_args(hidden_size=int(g["hp_hidden_size"]), layer_N=int(g["hp_layer_N"]), hypernet_layers=int(g["hp_hypernet_layers"]))
+    with pytest.raises(NotImplementedError) as e:
+        require_reference_architecture(args)
+    assert any(k in str(e.value) for k in ("hidden_size", "layer_N", "hypernet_layers"))
+    require_reference_architecture(default_args())      # the defaults pass
+
+
 def test_null_arguments_are_rejected_without_a_gpu():
     from offpolicy_amd import _lib
     assert _lib.lib.ope_adam_step(None, 4, None, None, None, None, None, None, None, None) == -1
