@@ -216,6 +216,12 @@ int ope_qmix_workspace_init(const ope_qmix_cfg* cfg, void* workspace, int64_t wo
  * read ONCE. A non-zero field of the cfg always wins. */
 void ope_set_debug(int on);
 void ope_set_scan_kernel(int family, int waves_per_row);
+/* Launch log: the kernel variants the LAST ope_qmix_loss_and_grad call of this thread actually launched, comma-separated in launch
+ * order (e.g. "trunk_fwd4<16>,gru_fwd4<4>,head_fwd_mfma<1>,mixer_fwd3<14,1>,..."), written NUL-terminated into out[cap]; returns the number
+ * of launches. Test hook: an explicit trunk_path / mixer_path that the shape does not allow returns OPE_EINVAL from the step (no silent
+ * fall-back to another kernel), and tests that pin a kernel family assert here that it ran. No reference counterpart (the
+ * reference's kernels are whatever ATen dispatches). */
+int ope_last_launches(char* out, int32_t cap);
 
 /* Named sub-buffers of the workspace, for tests/debugging: returns byte offset, writes element count. -1 if unknown. */
 int64_t ope_qmix_workspace_find(const ope_qmix_cfg* cfg, const char* name, int64_t* n_floats);

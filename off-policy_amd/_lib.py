@@ -82,6 +82,7 @@ def _load():
         "ope_strerror": (C.c_char_p, [C.c_int]),
         "ope_set_debug": (None, [C.c_int]),
         "ope_set_scan_kernel": (None, [C.c_int, C.c_int]),
+        "ope_last_launches": (C.c_int, [C.c_char_p, i32]),
         "ope_episode_bytes": (i64, [C.POINTER(Dims)]),
         "ope_store_insert": (C.c_int, [C.POINTER(Dims), i32, C.POINTER(Fields), C.POINTER(Fields), p, i32, p, p]),
         "ope_store_gather": (C.c_int, [C.POINTER(Dims), i32, C.POINTER(Fields), p, i32, C.POINTER(Fields), p, p]),
@@ -142,6 +143,13 @@ def _load():
 
 
 lib, EXPORTS = _load()
+
+
+def last_launches():
+    """Kernel variants the last ope_qmix_loss_and_grad call of this thread launched, in launch order (ope_last_launches)."""
+    buf = C.create_string_buffer(2048)
+    lib.ope_last_launches(buf, 2048)
+    return [x for x in buf.value.decode().split(",") if x]
 
 
 def check(rc, what=""):

@@ -192,6 +192,7 @@ static int launch_trunk_vec(const TrunkFwdArgs& a, hipStream_t st) {
     hipLaunchKernelGGL((trunk_fwd_kernel<VEC, 1, SAVE>), dim3(ope_cdiv(ope_cdiv(a.R, 16), 4)), dim3(256), 0, st, a);
   }
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
+  note_launch("trunk_fwd1", VEC, two ? 2 : 1);
   return OPE_OK;
 }
 
@@ -377,6 +378,7 @@ int launch_head_fwd(const HeadFwdArgs& a, int mode, hipStream_t st) {
   if (a.r_begin < 0 || a.r_begin >= a.R) return OPE_EINVAL;
   if (mode == 0 && a.A <= 32) return launch_head_fwd_mfma(a, st);   // ope_head.hip; wider action spaces: thread per row below
   const int blocks = ope_cdiv(a.R - a.r_begin, 256);
+  note_launch("head_fwd_rows", mode);
   if (mode == 0)
     hipLaunchKernelGGL(head_fwd_kernel<0>, dim3(blocks), dim3(256), lds, st, a);
   else

@@ -1,5 +1,6 @@
 // C-ABI entry points that orchestrate the kernels: parameter layout, workspace carving, the QMIX/VDN
 // loss-and-gradient step (QMix.train_policy_on_batch, qmix.py:77-190) and the stand-alone agent forward.
+#include <stdio.h>
 #include <string.h>
 
 #include <algorithm>
@@ -79,6 +80,9 @@ struct Plan {
   int n_gsq;
   bool wide;
 };
+
+thread_local char g_launch_log[2048];
+thread_local int g_launch_len = 0, g_launch_n = 0;
 
 int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
@@ -209,6 +213,31 @@ void make_plan(const ope_qmix_cfg* c, Plan* p) {
 
 }  // namespace
 
+namespace ope {
+void note_launch(const char* name, int p0, int p1) {
+  char item[96];
+  int n = p0 < 0 ? snprintf(item, sizeof(item), "%s", name) : (p1 < 0 ? snprintf(item, sizeof(item), "%s<%d>", name, p0) : snprintf(item, sizeof(item), "%s<%d,%d>", name, p0, p1));
+  if (n < 0) return;
+  if (n >= (int)sizeof(item)) n = (int)sizeof(item) - 1;
+  ++g_launch_n;
+  if (g_launch_len + n + 2 >= (int)sizeof(g_launch_log)) return;     // bounded: later names are counted, not kept
+  if (g_launch_len) g_launch_log[g_launch_len++] = ',';
+  memcpy(g_launch_log + g_launch_len, item, n);
+  g_launch_len += n;
+  g_launch_log[g_launch_len] = 0;
+}
+void clear_launch_log() { g_launch_len = 0; g_launch_n = 0; g_launch_log[0] = 0; }
+}  // namespace ope
+
+extern "C" int ope_last_launches(char* out, int32_t cap) {
+  if (out && cap > 0) {
+    const int n = g_launch_len < cap - 1 ? g_launch_len : cap - 1;
+    memcpy(out, g_launch_log, n);
+    out[n] = 0;
+  }
+  return g_launch_n;
+}
+
 extern "C" int ope_version(void) { return OPE_VERSION; }
 extern "C" const char* ope_strerror(int code) {
   switch (code) {
@@ -286,6 +315,7 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
                                       const float* theta_tgt, const float* per_weights, void* workspace,
                                       int64_t workspace_bytes, float* grad, float* td_abs_stats, void* stream) {
   (void)hipGetLastError();  // drop stale errors from the caller's own HIP use
+  clear_launch_log();
   if (!cfg_ok(cfg) || !batch || !theta || !theta_tgt || !workspace || !grad) return OPE_EINVAL;
   // Phased calls (several policies under one mixer, see ope.h): 1 = agent networks forward only (leaves "agent_q" /
   // "agent_nq" in the workspace), 2 = mixer + TD loss + mixer gradients only (reads "agent_q" / "agent_nq" the caller

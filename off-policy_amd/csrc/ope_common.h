@@ -18,6 +18,14 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
     if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH; \
   } while (0)
 
+// Launch log (ope_last_launches, ope.h): every launcher of the training path notes the kernel variant it ACTUALLY launched, so a test that
+// pins a kernel family (ope_qmix_cfg.trunk_path / mixer_path / scan_family) can assert what ran instead of trusting the request. Host-side
+// only: one bounded string append per launch into a thread-local buffer that the step entry points clear (defined in ope_api.hip).
+namespace ope {
+void note_launch(const char* name, int p0 = -1, int p1 = -1);
+void clear_launch_log();
+}
+
 static inline int ope_round4(int64_t x) { return (int)((x + 3) & ~(int64_t)3); }
 static inline int ope_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 

@@ -290,12 +290,14 @@ __global__ void __launch_bounds__(128) gru_bwd1_kernel(GruBwdArgs a) {
 int launch_gru_fwd1(const GruFwdArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(gru_fwd1_kernel, dim3(a.nets * a.NB), dim3(128), 0, st, a);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
+  note_launch("gru_fwd1");
   return OPE_OK;
 }
 
 int launch_gru_bwd1(const GruBwdArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(gru_bwd1_kernel, dim3(a.NB), dim3(128), 0, st, a);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
+  note_launch("gru_bwd1");
   return OPE_OK;
 }
 

@@ -477,14 +477,18 @@ static void launch_bwd(const GruBwdArgs& a, hipStream_t st) {
 }
 
 int launch_gru_fwd4(const GruFwdArgs& a, hipStream_t st) {
-  if (waves_per_row((int64_t)a.nets * a.NB, a.waves) == 4) launch_fwd<4>(a, st); else launch_fwd<2>(a, st);
+  const int w = waves_per_row((int64_t)a.nets * a.NB, a.waves);
+  if (w == 4) launch_fwd<4>(a, st); else launch_fwd<2>(a, st);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
+  note_launch("gru_fwd4", w == 4 ? 4 : 2);
   return OPE_OK;
 }
 
 int launch_gru_bwd4(const GruBwdArgs& a, hipStream_t st) {
-  if (waves_per_row(a.NB, a.waves) == 4) launch_bwd<4>(a, st); else launch_bwd<2>(a, st);
+  const int w = waves_per_row(a.NB, a.waves);
+  if (w == 4) launch_bwd<4>(a, st); else launch_bwd<2>(a, st);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
+  note_launch("gru_bwd4", w == 4 ? 4 : 2);
   return OPE_OK;
 }
 

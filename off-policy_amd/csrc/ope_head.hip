@@ -245,12 +245,14 @@ int launch_head_fwd_mfma(const HeadFwdArgs& a0, hipStream_t st) {
   else
     hipLaunchKernelGGL(head_fwd_mfma_kernel<2>, dim3(blocks), dim3(256), 0, st, a);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
+  note_launch("head_fwd_mfma", a.A <= 16 ? 1 : 2);
   return OPE_OK;
 }
 
 int launch_head_bwd_rows(const HeadBwdArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(head_bwd_rows_kernel, dim3((int)ope_cdiv(a.R, 64)), dim3(256), 0, st, a);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
+  note_launch("head_bwd_rows");
   return OPE_OK;
 }
 

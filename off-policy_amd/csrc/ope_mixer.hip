@@ -532,6 +532,7 @@ static void launch_mixer2(const MixerFwdArgs& a0, hipStream_t st) {
   const char* pe = getenv("OPE_MIXER_PERSIST");
   const int persist = a.path == 1 ? 2 : (a.path == 2 ? 0 : (pe ? atoi(pe) : 1));     // cfg->mixer_path overrides the environment
   if (VEC == 4 && persist && !forced && !a.wide_slab && a.N <= 8 && a.S <= 16 * 14 && (a.TB >= 16 * 64 || persist == 2)) {
+    note_launch("mixer_fwd3", 14, ((a.S + 15) >> 4) == 14);
     const int tiles = ope_cdiv(a.TB, 16);
     static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256; return n > 1 ? n : 256; }();
     const int per_net = tiles < cus / 2 ? tiles : cus / 2;
@@ -539,6 +540,7 @@ static void launch_mixer2(const MixerFwdArgs& a0, hipStream_t st) {
     else hipLaunchKernelGGL((mixer_fwd3_kernel<14, false>), dim3(2 * per_net), dim3(512), 0, st, a);
     return;
   }
+  note_launch(a.wide_slab ? "mixer_fwd2_wide" : "mixer_fwd2", VEC, rt);
   if (rt == 4) hipLaunchKernelGGL((mixer_fwd2_kernel<VEC, 4>), dim3(2 * ope_cdiv(a.TB, 64)), dim3(256), 0, st, a);
   else if (rt == 2) hipLaunchKernelGGL((mixer_fwd2_kernel<VEC, 2>), dim3(2 * ope_cdiv(a.TB, 32)), dim3(256), 0, st, a);
   else hipLaunchKernelGGL((mixer_fwd2_kernel<VEC, 1>), dim3(2 * ope_cdiv(a.TB, 16)), dim3(256), 0, st, a);
@@ -554,9 +556,12 @@ int launch_mixer_fwd(const MixerFwdArgs& a0, hipStream_t st) {
     a.path = 2;                  // the second stage = mixer_fwd2 reading the slabs
     a.dbg = nullptr;             // (the stamp region belongs to the GEMM kernel in this mode)
   } else {
+    if (a.path == 3) return OPE_EINVAL;          // wide-state path asked for without its slab region (the plan decides both)
     a.wide_slab = nullptr;
   }
   const int vec = ope_vec_of(a.S);
+  // an explicit request for the resident-weight kernel that the shape does not allow: no silent fall-back (tests pin kernels by path)
+  if (a.path == 1 && !(vec == 4 && a.N <= 8 && a.S <= 16 * 14)) return OPE_EINVAL;
   if (vec == 4) launch_mixer2<4>(a, st);
   else if (vec == 2) launch_mixer2<2>(a, st);
   else launch_mixer2<1>(a, st);
@@ -732,6 +737,7 @@ int launch_mixer_bwd(const MixerBwdArgs& a, hipStream_t st) {
   if (a.TB < 1) return OPE_EINVAL;
   hipLaunchKernelGGL(mixer_bwd4_kernel, dim3(ope_cdiv(a.TB, 16)), dim3(256), 0, st, a);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
+  note_launch("mixer_bwd4");
   return OPE_OK;
 }
 

@@ -184,13 +184,17 @@ int launch_mixer_wide_gemm(const MixerFwdArgs& a0, hipStream_t st) {
   if (a0.TB < 1 || a0.S < 1 || !a0.wide_slab) return OPE_EINVAL;
   const WidePlan P = wide_plan(a0.TB, a0.S);
   const int vec = ope_vec_of(a0.S);
-  static const int ex = getenv("OPE_WIDE_EXP") ? atoi(getenv("OPE_WIDE_EXP")) : 0;   // timing experiments only (read once)
+  // timing experiments only (skips loads / MFMAs / deposits: WRONG results): honoured only for a call that also carries the debug
+  // stamps (ope_qmix_cfg.debug / ope_set_debug, i.e. tools/wide_phases.py), never for a plain training call
+  static const int ex_env = getenv("OPE_WIDE_EXP") ? atoi(getenv("OPE_WIDE_EXP")) : 0;
+  const int ex = a0.dbg ? ex_env : 0;
   MixerFwdArgs a = a0;
   a.k_stagger = ex;
   if (vec == 4) hipLaunchKernelGGL(mixer_wide_gemm_kernel<4>, dim3(P.nwg), dim3(512), 0, st, a);
   else if (vec == 2) hipLaunchKernelGGL(mixer_wide_gemm_kernel<2>, dim3(P.nwg), dim3(512), 0, st, a);
   else hipLaunchKernelGGL(mixer_wide_gemm_kernel<1>, dim3(P.nwg), dim3(512), 0, st, a);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
+  note_launch("mixer_wide_gemm", vec);
   return OPE_OK;
 }
 

@@ -490,6 +490,7 @@ int launch_trunk_fwd_rep(const TrunkFwdArgs& base, const TrunkFwdArgs& a, float*
 int launch_trunk_fwd2(const TrunkFwdArgs& a, bool save, hipStream_t st) {
   if (a.R < 1 || a.D < 1 || a.D > 512) return OPE_EINVAL;
   const int vec = ope_vec_of(a.D);
+  note_launch("trunk_fwd2", vec);
   if (save) {
     if (vec == 4) return launch2<4, true>(a, st);
     if (vec == 2) return launch2<2, true>(a, st);
@@ -861,6 +862,7 @@ static int launch3(const TrunkFwdArgs& a, hipStream_t st) {
   else if (KC <= 24) hipLaunchKernelGGL((trunk_fwd3_kernel<VEC, 24, SAVE>), dim3(blocks), dim3(256), 0, st, a);
   else hipLaunchKernelGGL((trunk_fwd3_kernel<VEC, 32, SAVE>), dim3(blocks), dim3(256), 0, st, a);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
+  note_launch("trunk_fwd3", VEC, KC <= 8 ? 8 : (KC <= 16 ? 16 : (KC <= 24 ? 24 : 32)));
   return OPE_OK;
 }
 

@@ -382,6 +382,7 @@ int launch_trunk_fwd_pair(const TrunkFwdArgs& live, const TrunkFwdArgs& tgt, int
   const int KC = (live.D + 15) >> 4;
   const bool can = live.gi && tgt.gi && !live.a2_out && !tgt.a2_out && live.D == tgt.D && live.R == tgt.R && live.x == tgt.x &&
                    live.D % 4 == 0 && (KC == 4 || KC == 8 || KC == 12 || KC == 16) && live.xhat1 && live.mu0 && live.rstd0 && live.rstd1 && live.mask1 && live.xhat2 && live.rstd2 && live.mask2;
+  if (path == 4 && !can) return OPE_EINVAL;      // an explicit request the shape does not allow: no silent fall-back (tests pin kernels by path)
   const bool ok = can && (path == 4 || (path == 0 && on && live.R >= 16 * 1024));
   if (!ok) {
     int rc = launch_trunk_fwd(live, true, st);
@@ -406,6 +407,7 @@ int launch_trunk_fwd_pair(const TrunkFwdArgs& live, const TrunkFwdArgs& tgt, int
   else if (KC == 12) hipLaunchKernelGGL((trunk_fwd4_kernel<12, 8, true>), dim3(grid), dim3(512), 0, st, pa);
   else hipLaunchKernelGGL((trunk_fwd4_kernel<16, 8, true>), dim3(grid), dim3(512), 0, st, pa);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
+  note_launch("trunk_fwd4", KC);
   return OPE_OK;
 }
 

@@ -123,6 +123,7 @@ int launch_trunk_bwd3(const TrunkBwdArgs& a, hipStream_t st) {
   const int blocks = ntiles < 512 ? ntiles : 512;
   hipLaunchKernelGGL(trunk_bwd3_kernel, dim3(blocks), dim3(256), 0, st, a);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
+  note_launch("trunk_bwd3");
   return OPE_OK;
 }
 

@@ -236,6 +236,7 @@ int launch_wgrad(const WgTable& tb, float* raw, hipStream_t st) {
   else
     hipLaunchKernelGGL(wgrad_kernel<1>, dim3(ope_cdiv(tb.total_waves, 4)), dim3(256), 0, st, tb, raw);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
+  note_launch("wgrad", vec);
   return OPE_OK;
 }
 

@@ -107,6 +107,7 @@ def run_case(name, dims, n_episodes, inds, steps=3, argv=(), vdn=False, avail="o
         for k in keys:
             out["ep/" + k] = ep[k]
     out["ep_digest"] = np.array(digest([ep[k] for k in keys]))
+    out["ep_avail"], out["ep_runner_padding"] = np.array(avail), np.int64(bool(runner_padding))     # (what regenerates them when not stored)
     inds = np.asarray(inds, dtype=np.int64)
     out["inds"] = inds
     sampled = buf.policy_buffers["policy_0"].sample_inds(inds)
@@ -193,6 +194,21 @@ def main():
         odd = EnvDims("odd", 3, 7, 18, 54, 5)
         run_case("qmix_shape_all_odd", odd, n_episodes=6, inds=[5, 1, 1, 2, 0], avail="bernoulli", runner_padding=True,
                  argv=["--hypernet_layers", "1", "--layer_N", "2", "--hidden_size", "128"])
+        return
+    if os.environ.get("OPE_GOLDEN_ONLY") == "variants":
+        # round 4: fixtures that REACH the kernel variants bench.py runs. trunk_fwd4 only takes input widths that are
+        # multiples of 4 with ceil(D / 16) in {4, 8, 12, 16}: D = 252 (KCM 16, with the 12-float tail chunk -- the 3s5z width), 188 (KCM 12),
+        # 124 (KCM 8); 56 data rows = three full 16-row tiles + a partial one. mixer_fwd3 at the 3s5z state width with all eight agent waves
+        # (S = 216, N = 8: the <14, FULL> instantiation) and at a narrower one (S = 100: the guarded K loop); the wide-state stream-K GEMM at
+        # the real S = 2 232 (70 K stages of 32, a 24-float tail) and, with T * B = 156 rows, two 128-row blocks whose K ranges are cut
+        # across workgroups (280 units on 256 workgroups).
+        run_case("qmix_var_d252", EnvDims("var_d252", 2, 5, 252, 20, 6), n_episodes=5, inds=[4, 0, 2, 2], avail="bernoulli")
+        run_case("qmix_var_d188", EnvDims("var_d188", 2, 5, 188, 20, 6), n_episodes=5, inds=[1, 3, 0, 4], avail="bernoulli", runner_padding=True)
+        run_case("qmix_var_d124", EnvDims("var_d124", 3, 6, 124, 24, 6), n_episodes=5, inds=[2, 2, 1, 0], avail="bernoulli")
+        run_case("qmix_var_mix216", EnvDims("var_mix216", 8, 6, 16, 216, 5), n_episodes=5, inds=[3, 1, 4, 0], avail="bernoulli")
+        run_case("qmix_var_mix100", EnvDims("var_mix100", 5, 6, 16, 100, 5), n_episodes=5, inds=[0, 1, 4, 4, 2], avail="bernoulli", runner_padding=True)
+        run_case("qmix_var_s2232", EnvDims("var_s2232", 2, 5, 12, 2232, 12), n_episodes=13, inds=list(range(13)), avail="bernoulli", steps=2,
+                 store_inputs=False)
         return
     if os.environ.get("OPE_GOLDEN_ONLY") == "pershare":      # add the round-2 fixture without rewriting the committed ones
         run_case("qmix_tiny_pershare", tiny, n_episodes=5, inds=[4, 1, 1, 0, 2], cap=6, pre_insert=3, avail="bernoulli", per_agent_share=True)

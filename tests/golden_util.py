@@ -21,7 +21,8 @@ def fixture_episodes(g):
         return {k: g["ep/" + k] for k in EP_KEYS}
     dims = fixture_dims(g)
     rng = np.random.RandomState(0)
-    ep = synth_episodes(rng, int(g["idx_range"].shape[0]), dims)
+    ep = synth_episodes(rng, int(g["idx_range"].shape[0]), dims, avail=str(g["ep_avail"]) if "ep_avail" in g else "ones",
+                        runner_padding=bool(g["ep_runner_padding"]) if "ep_runner_padding" in g else False)
     h = hashlib.sha256()
     for k in EP_KEYS:
         h.update(np.ascontiguousarray(ep[k]).tobytes())

@@ -13,7 +13,9 @@ from gpu_util import build_from_fixture, batch_from
 
 pytestmark = pytest.mark.gpu
 CASES = ["qmix_tiny", "qmix_tiny_huber_per", "qmix_tiny_nodouble", "vdn_tiny", "qmix_odd", "qmix_3m_katA", "qmix_tiny_prevact", "qmix_tiny_pershare",
-         "qmix_gall_tiny", "qmix_gall_3m", "qmix_gall_odd"]   # gall: scripts/train_smac_qmix.sh (wide state, gain 1, hard target updates)
+         "qmix_gall_tiny", "qmix_gall_3m", "qmix_gall_odd",   # gall: scripts/train_smac_qmix.sh (wide state, gain 1, hard target updates)
+         # round 4: shapes that reach the kernel variants bench.py runs when the kernels are pinned (tests below); here: what "by shape" picks
+         "qmix_var_d252", "qmix_var_d188", "qmix_var_d124", "qmix_var_mix216", "qmix_var_mix100", "qmix_var_s2232"]
 RTOL = 1e-4
 
 
@@ -90,13 +92,28 @@ def test_every_scan_kernel_family_matches_reference(name, family, waves):
         np.testing.assert_allclose(live["agent/" + k], ref, rtol=0, atol=3e-5, err_msg=k)
 
 
-@pytest.mark.parametrize("path", [3, 4])
-@pytest.mark.parametrize("name", ["qmix_tiny", "qmix_odd", "qmix_3m_katA", "qmix_tiny_prevact", "qmix_gall_3m", "qmix_tiny_huber_per"])
+# (fixture, trunk_path) pairs that CAN run: path 3 takes every width; path 4 (trunk_fwd4 / trunk_bwd4) needs an input width that is a
+# multiple of 4 with ceil(D / 16) in {4, 8, 12, 16}: D = 64 (3m), 124, 188, 252 (the 3s5z width: KCM 16 with a 12-float tail chunk)
+TRUNK_CASES = [(n, 3) for n in ("qmix_tiny", "qmix_odd", "qmix_3m_katA", "qmix_tiny_prevact", "qmix_gall_3m", "qmix_tiny_huber_per", "qmix_var_d252")] + \
+              [(n, 4) for n in ("qmix_3m_katA", "qmix_gall_3m", "qmix_var_d124", "qmix_var_d188", "qmix_var_d252")]
+
+
+def _expect_trunk(dims, path):
+    if path == 4:
+        return ["trunk_fwd4<%d>" % ((dims.obs_dim + 15) // 16), "trunk_bwd4"]
+    return ["trunk_fwd3<", "trunk_bwd3"]
+
+
+@pytest.mark.parametrize("name,path", TRUNK_CASES)
 def test_every_forward_trunk_kernel_matches_reference(name, path):
     """The forward trunk of the two agent nets has two kernel families chosen by shape (ope_qmix_cfg.trunk_path: 3 = trunk_fwd3, one
-    launch per net, weights in registers; 4 = trunk_fwd4, both nets in one launch, weights in LDS, a wave per 16-row tile): pin each
-    on the small fixtures -- odd widths (D = 18: 8-byte pieces; 12 + 5: 1-float tail), partial tiles, the ring / PER / Huber variants --
-    and compare with the reference, saved activations included (they feed the backward pass: gradients and final parameters)."""
+    launch per net, weights in registers; 4 = trunk_fwd4, both nets in one launch, weights in LDS, a wave per 16-row tile; the trunk
+    adjoint follows: trunk_bwd3 / trunk_bwd4): pin each on fixtures whose shape it can run -- path 3 on odd widths (D = 18: 8-byte
+    pieces; 12 + 5: 1-float tail), partial tiles, the ring / PER / Huber variants; path 4 on every K-chunk count it is instantiated for
+    (KCM 4, 8, 12, 16 = D 64, 124, 188, 252, the last with the 12-float tail chunk of the 3s5z width) -- compare with the reference,
+    saved activations included (they feed the backward pass: gradients and final parameters), and ASSERT from the launch log that the
+    pinned kernels are the ones that ran (a request the shape does not allow is an error, not a fall-back: next test)."""
+    from offpolicy_amd import _lib
     g = load_golden(name)
     dims, buf, policy, trainer = build_from_fixture(g)
     trainer.tune["trunk_path"] = path
@@ -106,6 +123,10 @@ def test_every_forward_trunk_kernel_matches_reference(name, path):
     batch = batch_from(buf, g["inds"], w)
     for s in range(len(g["loss"])):
         info, _, _ = trainer.train_policy_on_batch(batch)
+        launched = ",".join(_lib.last_launches())
+        in_dim = dims.obs_dim + (dims.act_dim if getattr(policy, "prev_act_inp", False) else 0)
+        for want in _expect_trunk(dims._replace(obs_dim=in_dim), path):
+            assert want in launched, (want, launched)
         if s == 0:
             cnt = float(trainer.grad[trainer.numel + 1])
             coef = min(1.0, float(g["hp_maxnorm"]) / (float(g["grad_norm"][0]) + 1e-6))
@@ -123,22 +144,53 @@ def test_every_forward_trunk_kernel_matches_reference(name, path):
         np.testing.assert_allclose(live["agent/" + k], ref, rtol=0, atol=3e-5, err_msg=k)
 
 
-@pytest.mark.parametrize("path", [1, 2, 3])
-@pytest.mark.parametrize("name", ["qmix_gall_tiny", "qmix_gall_3m", "qmix_gall_odd", "qmix_tiny", "qmix_odd", "qmix_3m_katA"])
+@pytest.mark.parametrize("name,knob,value", [("qmix_tiny", "trunk_path", 4), ("qmix_odd", "trunk_path", 4), ("qmix_odd", "mixer_path", 1),
+                                             ("qmix_gall_3m", "mixer_path", 1), ("qmix_tiny", "mixer_path", 1)])
+def test_pinned_kernel_that_cannot_run_the_shape_is_an_error(name, knob, value):
+    """An explicit ope_qmix_cfg.trunk_path / mixer_path that the shape does not allow (trunk_fwd4 on D = 12 / 18; the resident-weight
+    mixer on S = 54 / 10 -- not multiples of 4 -- or S = 240 > 224) returns OPE_EINVAL: no silent fall-back to another kernel, so a
+    test that pins a kernel cannot pass on a different one (VERDICT r3 "what's weak" 1)."""
+    from offpolicy_amd import _lib
+    g = load_golden(name)
+    dims, buf, policy, trainer = build_from_fixture(g)
+    trainer.tune[knob] = value
+    with pytest.raises(_lib.OpeError):
+        trainer.train_policy_on_batch(batch_from(buf, g["inds"]))
+
+
+# (fixture, mixer_path) pairs that CAN run: 1 = mixer_fwd3 (S % 4 == 0, S <= 224, N <= 8), 2 = mixer_fwd2 (any), 3 = the wide-state GEMM (any)
+MIXER_CASES = [(n, 1) for n in ("qmix_3m_katA", "qmix_var_mix216", "qmix_var_mix100", "qmix_var_d124")] + \
+              [(n, 2) for n in ("qmix_gall_tiny", "qmix_gall_3m", "qmix_gall_odd", "qmix_tiny", "qmix_odd", "qmix_3m_katA", "qmix_var_mix216")] + \
+              [(n, 3) for n in ("qmix_gall_tiny", "qmix_gall_3m", "qmix_gall_odd", "qmix_tiny", "qmix_odd", "qmix_3m_katA", "qmix_var_s2232")]
+
+
+@pytest.mark.parametrize("name,path", MIXER_CASES)
 def test_every_forward_mixer_kernel_matches_reference(name, path):
     """The forward mixer has three kernels chosen by shape (ope_qmix_cfg.mixer_path: 1 weights resident in registers, 2 weights
     streamed per 16-row workgroup, 3 the wide-state form -- first hyper-layers as one stream-K GEMM + second stage from its partial
-    slabs, ope_mixer_wide.hip); the fixtures are small, so pin each in turn and repeat the reference comparison: narrow, wide
-    (--use_global_all_local_state: S = 34, 83 -- nothing a multiple of 4 --, 240) and 3m states, several K stages and stream-K
-    segments per tile, partial row blocks."""
+    slabs, ope_mixer_wide.hip); the fixtures are small, so pin each in turn on shapes it can run and repeat the reference comparison:
+    path 1 at the 3s5z state width with eight agents (S = 216, N = 8: the <14, FULL> instantiation bench.py runs) and at narrower ones
+    (S = 100, 48, 24: the guarded K loop, fewer agents than waves); path 2 / 3 on narrow, wide (--use_global_all_local_state: S = 34, 83
+    -- nothing a multiple of 4 --, 240) and 3m states; path 3 also at the real S = 2 232 (70 K stages, a 24-float tail, two 128-row
+    blocks whose K ranges are cut across workgroups). The launch log must show the pinned kernel."""
+    from offpolicy_amd import _lib
     g = load_golden(name)
     dims, buf, policy, trainer = build_from_fixture(g)
     trainer.tune["mixer_path"] = path
     soft = bool(g["hp_soft_update"]) if "hp_soft_update" in g else True
     hard_after = set(int(x) for x in g["hard_update_after"]) if "hard_update_after" in g else set()
     batch = batch_from(buf, g["inds"])
+    want = {1: "mixer_fwd3<14,%d>" % int((dims.state_dim + 15) // 16 == 14), 2: "mixer_fwd2<", 3: "mixer_wide_gemm<"}[path]
     for s in range(len(g["loss"])):
         info, _, _ = trainer.train_policy_on_batch(batch)
+        launched = ",".join(_lib.last_launches())
+        assert want in launched and (path != 3 or "mixer_fwd2_wide<" in launched), (want, launched)
+        if s == 0:
+            cnt = float(trainer.grad[trainer.numel + 1])
+            coef = min(1.0, float(g["hp_maxnorm"]) / (float(g["grad_norm"][0]) + 1e-6))
+            got = _flat_named(trainer, trainer.grad[:trainer.numel] * (coef / cnt))
+            for k, ref in sub(g, "grad0/").items():
+                np.testing.assert_allclose(got[k], ref, rtol=0, atol=2e-3 * max(np.abs(ref).max(), 1e-6), err_msg="grad " + k)
         if soft:
             trainer.soft_target_updates()
         elif s in hard_after:
@@ -231,13 +283,52 @@ def test_policy_forward_with_previous_action_input():
     np.testing.assert_allclose(h.cpu().numpy(), h_ref.numpy(), rtol=1e-4, atol=2e-6)
 
 
+def _gpu_decisions(trainer, B, dims, avail):
+    """The discrete decisions the HIP step took, read back from its workspace in the oracle's `forced` format (oracle/qmix_oracle.py,
+    "discrete decisions"): ReLU masks of the live trunk (one bit per feature, saved for the backward pass), ReLU masks and abs() signs of
+    the live mixer's hyper-networks (from the saved post-ReLU / pre-abs activations), the double-Q greedy indices (argmax of the kernel's
+    own q values, `q_all`, kept when ope_qmix_cfg.debug is set; first maximum wins on both sides)."""
+    T, N, A = dims.episode_length, dims.n_agents, dims.act_dim
+    NB = N * B
+    bits = torch.arange(64, device="cuda")
+
+    def unpack(name):
+        m = trainer.workspace_view(B, name).view(torch.int64)[:(T + 1) * NB]
+        return ((m[:, None] >> bits[None, :]) & 1).bool().view(T + 1, NB, 64).cpu()
+    d = {"relu1": unpack("mask1"), "relu2_0": unpack("mask2")}
+    if not trainer.vdn:
+        for key, name in (("hyp_w1", "hw1"), ("hyp_w2", "hw2"), ("hyp_b2", "hb2")):
+            d[key] = (trainer.workspace_view(B, name).view(T, B, 64) > 0).cpu()
+        d["abs_w1"] = torch.sign(trainer.workspace_view(B, "v1").view(T, B, N * 32)).cpu()
+        d["abs_w2"] = torch.sign(trainer.workspace_view(B, "v2").view(T, B, 32)).cpu()
+    return d
+
+
+def _gpu_greedy(trainer, B, dims, avail):
+    T, N, A = dims.episode_length, dims.n_agents, dims.act_dim
+    q = trainer.workspace_view(B, "q_all").view(T + 1, N * B, A).clone()
+    if avail is not None:
+        q[avail.reshape(T + 1, N * B, A) == 0] = -1e10
+    return q.max(dim=-1)[1].cpu()
+
+
 @pytest.mark.parametrize("workload,nb", [("3s5z", 32), ("MMM2", 8), ("3s5z_gall", 32), ("MMM2", 32)])
 def test_full_size_3s5z_matches_oracle_one_step(workload, nb):
     """BASELINE config 4 at full size (N=8, A=14, D=252, S=216, T=150, B=32): one step vs the oracle; the MMM2
     dimensions (N=10, A=18, D=370, S=322, T=180: 8-byte vector paths, the 24-chunk trunk) at B=8 and at B=32; and 3s5z as the
     reference's own launch script runs it (scripts/train_smac_qmix.sh:14-17: --use_global_all_local_state -> S = 216 + 8 * 252 =
-    2 232, --gain 1, hard target updates), B=32: the wide-state mixer kernels at their real size."""
+    2 232, --gain 1, hard target updates), B=32: the wide-state mixer kernels at their real size.
+
+    EXACT gradient comparison (round 4; replaces the rank-4 SVD escape of round 3). At this size (4.9 M ReLU units, 1.4 M abs() units
+    in the mixer, 541 k argmax decisions per step) a few pre-activations lie within float rounding of their decision boundary and the
+    CPU and GPU reduction orders may put them on different sides; forward values do not notice, a gradient changes by one rank-one term
+    per flipped unit. So the comparison is made at EQUAL decisions: (1) the decisions the HIP step took are read back from its workspace
+    (saved ReLU masks, hyper-network activations, q values) and compared with the oracle's own -- at most a handful may differ, and
+    they are printed; (2) the oracle's step is re-run with the GPU's decisions forced (oracle `forced=`) and EVERY element of EVERY
+    gradient tensor must then agree within 2e-3 of the tensor's max magnitude -- no rank removal, no percentile; (3) the parameters
+    after the Adam step agree with the forced oracle's within the bound the gradient difference itself implies."""
     from oracle import qmix_oracle as O
+    from offpolicy_amd import _lib
     from offpolicy_amd.config import default_args
     from offpolicy_amd.utils.synth import DIMS, synth_episodes, policy_info_for, as_policy_dicts
     from offpolicy_amd.utils.rec_buffer import RecReplayBuffer
@@ -257,64 +348,72 @@ def test_full_size_3s5z_matches_oracle_one_step(workload, nb):
     inds = np.arange(nb)
     agent0 = {k: v.detach().cpu().numpy().copy() for k, v in policy.q_network.named_parameters()}
     mixer0 = {k: v.detach().cpu().numpy().copy() for k, v in trainer.mixer.named_parameters()}
-    info, _, _ = trainer.train_policy_on_batch(batch_from(buf, inds))
-    orc = O.QMixOracle(agent0, mixer0, dims.n_agents, O.HP())
+    batch = batch_from(buf, inds)
+    avail_dev = batch[6]["policy_0"].permute(1, 0, 2, 3).contiguous()         # [T+1, N, B, A]: the kernels' row order (agent * B + b)
+    # a first, throw-away step with ope_qmix_cfg.debug (keeps the live q values): only the greedy indices are taken from it
+    opt = trainer.optimizer
+    snap = (trainer.theta.clone(), trainer.theta_tgt.clone())
+    trainer.tune["debug"] = 1
+    trainer.train_policy_on_batch(batch)
+    greedy = _gpu_greedy(trainer, nb, dims, avail_dev)
+    trainer.tune["debug"] = 0
+    trainer.theta.copy_(snap[0]); trainer.theta_tgt.copy_(snap[1]); opt.exp_avg.zero_(); opt.exp_avg_sq.zero_(); opt.step_count = 0
+    # the step under test: exactly what bench.py runs
+    info, _, _ = trainer.train_policy_on_batch(batch)
+    launched = _lib.last_launches()
+    if workload == "3s5z":        # the bench line's kernel variants are the ones compared here
+        assert "trunk_fwd4<16>" in launched and "mixer_fwd3<14,1>" in launched and "gru_fwd4<4>" in launched and "trunk_bwd4" in launched, launched
+    gpu = _gpu_decisions(trainer, nb, dims, avail_dev)
+    gpu["greedy"] = greedy
     st = {k: (ep[k][:, :, 0] if k == "share_obs" else ep[k]) for k in ("obs", "share_obs", "acts", "rewards", "dones", "dones_env", "avail_acts")}
-    out = orc.train_step(O.sample_inds(st, inds), fused_gru=True, soft_update=False)
+    ob = O.sample_inds(st, inds)
+    # (1) the oracle's own step and its own decisions
+    own = {}
+    orc = O.QMixOracle(agent0, mixer0, dims.n_agents, O.HP())
+    out = orc.train_step(ob, fused_gru=True, soft_update=False, record=own)
     np.testing.assert_allclose(float(info["loss"]), out["loss"], rtol=RTOL)
     np.testing.assert_allclose(float(info["grad_norm"]), out["grad_norm"], rtol=RTOL)
     np.testing.assert_allclose(float(info["Q_tot"]), out["Q_tot"], rtol=RTOL, atol=1e-6)
-    # gradients. At this size (4.9 M ReLU units, 1.4 M abs() units in the mixer, 541 k argmax decisions per step) a few
-    # pre-activations per step lie within float rounding of 0, and the CPU and GPU reduction orders may put them on different
-    # sides. Forward values do not notice (ReLU / abs are continuous); gradients do: a flipped unit at data row m changes that
-    # row's adjoint, i.e. the layer's weight gradient by ONE outer product (adjoint change x input row m) and its bias gradient by
-    # the adjoint change -- about 1 / sqrt(rows) of the tensor's scale, but spread over every column of the weight (all S = 2 232
-    # of a wide hyper-network first layer; an abs() unit flips the SIGN of its row's term: twice the size). So: every element
-    # within 2e-2 of the tensor's max magnitude and >= 99.5 % within 2e-3 of it, EITHER directly OR after removing at most four
-    # rank-one terms from the difference [dW | db] of a Linear layer (deviations beyond rounding must have exactly the structure
-    # single-unit flips produce; a wrong kernel does not).
+    flips = {k: int((own[k] != gpu[k]).sum()) for k in own}
+    units = sum(int(own[k].numel()) for k in own)
+    print("decisions that differ between the HIP step and the CPU oracle (of %d): %s" % (units, flips))
+    assert sum(flips.values()) <= max(8, units // 200000), flips           # a handful in millions (float rounding at the boundary), not a pattern
+    # (2) gradients at equal decisions: every element
+    orc = O.QMixOracle(agent0, mixer0, dims.n_agents, O.HP())
+    outf = orc.train_step(ob, fused_gru=True, soft_update=False, forced=gpu)
+    np.testing.assert_allclose(float(info["loss"]), outf["loss"], rtol=RTOL)
+    np.testing.assert_allclose(float(info["grad_norm"]), outf["grad_norm"], rtol=RTOL)
     cnt = float(trainer.grad[trainer.numel + 1])
     got = _flat_named(trainer, trainer.grad[:trainer.numel] / cnt)
-    grads = {k: v for k, v in out["grads"].items() if v is not None}
-
-    def within(d):      # (a 64-element LayerNorm / bias vector: one flipped unit = one element = 1.6 % of it -- up to four such elements)
-        ok = float((np.abs(d) <= 2e-3).mean()) >= min(0.995, 1.0 - 4.0 / d.size)
-        return float(np.abs(d).max()) <= 2e-2 and ok
-    rel = {k: (got[k] - ref) / max(np.abs(ref).max(), 1e-9) for k, ref in grads.items()}
-    pending = {k: (float(np.abs(d).max()), float((np.abs(d) <= 2e-3).mean())) for k, d in rel.items() if not within(d)}
-    for k in [k for k in pending if grads[k].ndim == 2]:
-        blocks = [rel[k]]
-        kb = k[:-len("weight")] + "bias"
-        if k.endswith("weight") and kb in grads and grads[kb].shape[0] == grads[k].shape[0]:
-            blocks.append(rel[kb][:, None])
-        D = np.concatenate(blocks, axis=1).astype(np.float64)
-        U, sv, Vt = np.linalg.svd(D, full_matrices=False)
-        res = D - (U[:, :4] * sv[:4]) @ Vt[:4]
-        assert within(res), ("grad " + k, pending[k], "after removing 4 rank-one terms", float(np.abs(res).max()), float((np.abs(res) <= 2e-3).mean()),
-                             sv[:6].tolist())
-        pending.pop(k)
-        pending.pop(kb, None)
-    assert not pending, ("gradient tensors outside tolerance (max deviation, share within 2e-3)", pending)
-    # parameters after the first Adam step. (1) The optimizer arithmetic on its own: with zero moments the first step is exactly
+    grads = {k: v for k, v in outf["grads"].items() if v is not None}
+    worst = {}
+    for k, ref in grads.items():
+        scale = max(np.abs(ref).max(), 1e-9)
+        worst[k] = float(np.abs(got[k] - ref).max() / scale)
+    bad = {k: v for k, v in worst.items() if v > 2e-3}
+    assert not bad, ("gradient elements beyond 2e-3 of their tensor's max magnitude, at equal decisions", bad)
+    # (3) parameters after the first Adam step. (a) The optimizer arithmetic on its own: with zero moments the first step is exactly
     # theta - lr * g / (|g| + eps), g = the clipped gradient -- recomputed here from the GPU's own gradient vector and pre-clip norm,
-    # element by element (float rounding only: 2e-7). (2) Against the oracle's parameters: the step is lr * g / (|g| + eps), so an
-    # element whose gradient is comparable to eps = 1e-5 -- after the clip by 10 / grad_norm most are, with gain = 1 -- turns a
-    # gradient difference (the flips above) into a visible difference: >= 99 % of every tensor within 2e-5, every element within 2 lr
-    # (a tiny gradient that changes sign moves by up to lr either way).
+    # element by element (float rounding only). (b) Against the forced oracle's parameters: f(g) = g / (|g| + eps) has |f'| <= 1 / eps, so
+    # two correct implementations differ by at most lr * |g_gpu - g_oracle| / eps per element (+ rounding) -- checked element by element
+    # with the ACTUAL clipped-gradient difference of that element.
     lr, eps = args.lr, args.opti_eps
     coef = min(1.0, float(args.max_grad_norm) / (float(info["grad_norm"]) + 1e-6))
+    coef_o = min(1.0, float(args.max_grad_norm) / (outf["grad_norm"] + 1e-6))
     live = _flat_named(trainer, trainer.theta)
     init = {("agent/" + k): v for k, v in agent0.items()}
     init.update({("mixer/" + k): v for k, v in mixer0.items()})
-    for k, g in got.items():
-        gg = g.astype(np.float64) * coef
+    for k, gv in got.items():
+        gg = gv.astype(np.float64) * coef
         want = init[k].astype(np.float64) - lr * gg / (np.abs(gg) + eps)
         np.testing.assert_allclose(live[k], want, rtol=0, atol=3e-7, err_msg="Adam step " + k)
-    for src, ref in ((dict(policy.q_network.named_parameters()), orc.agent), (dict(trainer.mixer.named_parameters()), orc.mixer)):
-        for k, v in src.items():
-            d = np.abs(v.detach().cpu().numpy() - ref[k].numpy())
-            assert d.max() <= 2 * lr * 1.01, k
-            assert (d <= 2e-5).mean() >= 0.99, (k, float((d <= 2e-5).mean()))
+    for grp, ref in (("agent/", orc.agent), ("mixer/", orc.mixer)):
+        for k, v in ref.items():
+            if grp + k not in grads:
+                continue                                                     # fc_h: no gradient, untouched on both sides
+            dg = np.abs(got[grp + k].astype(np.float64) * coef - grads[grp + k].astype(np.float64) * coef_o)
+            dth = np.abs(live[grp + k].astype(np.float64) - v.numpy().astype(np.float64))
+            assert (dth <= lr * dg / eps * 1.001 + 3e-7).all(), (grp + k, float((dth - lr * dg / eps).max()))
 
 
 def test_runner_call_sequence_with_per():
