@@ -49,6 +49,8 @@ def parse():
                     "workloads (the reference default buffer_size, config.py:37: 7.5 GB at 3s5z, far beyond the 256 MiB Infinity Cache), 512 "
                     "for the recurrent MADDPG family at MMM2 size (6.5 GB)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-table", action="store_true", help="skip the per-kernel roofline table (10 extra untimed steps with an event "
+                    "pair on every kernel launch, after the timed region)")
     ap.add_argument("--graph", action="store_true", help="QMIX workloads: replay the training kernels of a step as one captured HIP graph")
     ap.add_argument("--no-graph", action="store_true", help="MLP MADDPG/MATD3: launch the ~45 kernels of an update one by one instead "
                     "of replaying the captured HIP graph")
@@ -242,14 +244,69 @@ def qmix_flop_per_step(dims, batch):
     return 4 * 2 * R * agent_mac + 4 * 2 * T * batch * mixer_mac
 
 
-def kernel_roofline_table(workload, batch):
-    """Per-kernel share of the f32 matrix roof for this workload from the committed table (profiles/kernel_roofline.json, written by
-    tools/kernel_roofline.py from a rocprofv3 kernel trace of this same command + the analytic FLOP of each kernel); None if absent."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "kernel_roofline.json")) as f:
-            return json.load(f)["entries"].get("%s:%d" % (workload, batch))
-    except (OSError, ValueError, KeyError):
+def _short_kernel_name(name):
+    import re
+    n = name.replace("(anonymous namespace)::", "").replace("ope::", "")
+    n = re.sub(r"^void ", "", n)
+    depth, out = 0, []
+    for ch in n:                       # cut the argument list: the first '(' outside template brackets
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            break
+        out.append(ch)
+    return "".join(out).strip()[:80]
+
+
+def measured_kernel_table(one_step, n_steps=10):
+    """Per-kernel table of `n_steps` extra (untimed) eager steps MEASURED IN THIS RUN, on this box: every kernel launch of libope.so
+    carries hipExtLaunchKernel start / stop events (ope_kernel_profile, include/ope.h: the dispatch's own duration, what rocprofv3's kernel
+    trace reports) and the algorithmic work its launcher states (GEMM-shaped FLOP = 2 x MACs, LayerNorm / gates / elementwise excluded;
+    bytes read + written once for the bandwidth-bound kernels). frac = work / time / peak (157.3 TFLOP/s dense f32 matrix, 8 TB/s HBM).
+    torch's own kernels (noise generation, small copies) are not libope launches and are not listed."""
+    from offpolicy_amd import _lib
+    torch.cuda.synchronize()
+    _lib.kernel_profile(True, 16384)
+    for _ in range(n_steps):
+        one_step(None)
+    torch.cuda.synchronize()
+    rows = _lib.kernel_profile_read()
+    _lib.kernel_profile(False)
+    table, tot_us, tot_flop = [], 0.0, 0.0
+    for name, calls, total_ms, mn, mx, flop, nbytes in rows:
+        avg_us = 1e3 * total_ms / calls
+        e = {"kernel": _short_kernel_name(name), "launches_per_step": round(calls / float(n_steps), 2), "avg_us": round(avg_us, 2),
+             "us_per_step": round(1e3 * total_ms / n_steps, 2)}
+        if flop > 0:
+            tf = flop / (total_ms * 1e-3) / 1e12
+            e.update(bound="mfma", flop_per_launch=int(flop / calls), tflops=round(tf, 2), frac=round(tf / F32_MFMA_PEAK_TFLOPS, 4))
+        elif nbytes > 0:
+            gbs = nbytes / (total_ms * 1e-3) / 1e9
+            e.update(bound="hbm", bytes_per_launch=int(nbytes / calls), gbs=round(gbs, 1), frac=round(gbs / HBM_PEAK_GBS, 4))
+        table.append(e)
+        tot_us += 1e3 * total_ms / n_steps
+        tot_flop += flop / n_steps
+    table.sort(key=lambda e: -e["us_per_step"])
+    import socket
+    return {"measured": "in this run: %d untimed eager steps after the timed region, hipExtLaunchKernel start/stop events on every libope launch "
+                        "(ope_kernel_profile); host %s, %s" % (n_steps, socket.gethostname(), time.strftime("%Y-%m-%d")),
+            "kernel_us_per_step": round(tot_us, 1), "launcher_stated_flop_per_step": int(tot_flop), "kernels": table}
+
+
+def step_roofline(r0, steps):
+    """Whole-step roofline of a workload without a closed-form FLOP count in SURVEY.md 8(d) (the MADDPG families): the GEMM-shaped FLOP per
+    step is the sum the kernels' launchers state (measured_kernel_table), the time is the timed region's."""
+    pk = r0.get("per_kernel")
+    if not pk:
         return None
+    flop = pk["launcher_stated_flop_per_step"]
+    tfs = flop / (r0["elapsed"] / steps) / 1e12
+    return {"bound": "mfma", "what": "the whole training step of one GPU against the dense f32 matrix peak; FLOP per step = the GEMM-shaped work "
+                                     "stated by the launchers of the step's kernels (2 x MACs; LayerNorm / gates / elementwise excluded)",
+            "flop_per_step": int(flop), "achieved": round(tfs, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tfs / F32_MFMA_PEAK_TFLOPS, 5), "per_kernel": pk}
 
 
 def gather_profile(enable):
@@ -364,8 +421,11 @@ def main():
         gather_ms = float(np.mean(kernel_ms)) if kernel_ms else bracket_ms
         loss = float(info["loss"])
         assert np.isfinite(loss), "training diverged"
+        per_kernel = None
+        if world == 1 and graphed is None and not a.no_kernel_table:
+            per_kernel = measured_kernel_table(one_step)
         results.append(dict(leg=leg, local_batch=local_batch, global_batch=global_batch, elapsed=elapsed, gather_ms=gather_ms, loss=loss,
-                            graphed=graphed is not None, bracket_ms=bracket_ms, n_kernel_ms=len(kernel_ms), windows=windows))
+                            graphed=graphed is not None, bracket_ms=bracket_ms, n_kernel_ms=len(kernel_ms), windows=windows, per_kernel=per_kernel))
 
     if rank == 0:
         r0 = results[0]
@@ -413,9 +473,7 @@ def main():
                                      "MFMA 16x16x4; there is no xf32 / TF32 on gfx950 and bf16 would break the parity contract)",
             "flop_per_step": int(flop), "flop_formula": "SURVEY.md 8(d): 4*[2*R*(D*64+64*64+6*64*64+64*A)] + 4*[2*T*B*mixerMAC], R=(T+1)*N*B",
             "achieved": round(tfs, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tfs / F32_MFMA_PEAK_TFLOPS, 4),
-            "per_kernel": kernel_roofline_table(a.workload, r0["local_batch"]),
-            "per_kernel_source": "profiles/kernel_roofline.json (tools/kernel_roofline.py: rocprofv3 --kernel-trace of this command + analytic "
-                                 "FLOP per kernel; MFMA-busy from the --pmc passes under profiles/r03_pmc/)"}
+            "per_kernel": r0["per_kernel"]}
         if len(results) > 1:
             r1 = results[1]
             sps1 = a.steps / r1["elapsed"]
@@ -569,7 +627,25 @@ def main_ddpg(a):
             torch.cuda.synchronize()
         gather_ms = float(np.mean([s_.elapsed_time(e) for s_, e in ev]))
         assert np.isfinite(float(info["critic_loss"]))
-        results.append(dict(leg=leg, local_batch=local_batch, global_batch=global_batch, elapsed=elapsed, gather_ms=gather_ms, windows=windows))
+        per_kernel = None
+        if world == 1 and not a.no_kernel_table:
+            # the same kernels launched one by one (a captured graph cannot carry per-launch events): host-drawn indices, eager launches
+
+            def eager_step(i=None):
+                if per:
+                    batch_ = buf.sample(local_batch, beta=0.5, p_id="policy_0")
+                    info_, prio, idx = trainer.shared_train_policy_on_batch("policy_0", batch_)
+                    buf.update_priorities(idx, prio, p_id="policy_0")
+                else:
+                    s_ = pbuf.sample_inds(np.random.choice(len(buf), local_batch))
+                    info_, _, _ = trainer.shared_train_policy_on_batch("policy_0", tuple({"policy_0": x} for x in s_) + (None, None))
+                policy.soft_target_updates()
+                return info_
+            for _ in range(3):
+                eager_step()
+            per_kernel = measured_kernel_table(eager_step)
+        results.append(dict(leg=leg, local_batch=local_batch, global_batch=global_batch, elapsed=elapsed, gather_ms=gather_ms, windows=windows,
+                            per_kernel=per_kernel))
     if rank == 0:
         r0 = results[0]
         # algorithmic bytes of the transition gather: every field of a transition once in, once out (964 B/transition)
@@ -595,6 +671,7 @@ def main_ddpg(a):
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(algo / (r0["gather_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
                             "algorithmic_bytes_per_launch": int(algo), "avg_launch_ms": round(r0["gather_ms"], 5),
                             "note": "247 KB per step: launch-latency bound, not bandwidth bound (SURVEY 8(a) a17)"}}
+        out["roofline_step"] = step_roofline(r0, a.steps)
         if len(results) > 1:
             r1 = results[1]
             sps1 = a.steps / r1["elapsed"]
@@ -725,7 +802,9 @@ def main_rddpg(a):
         torch.cuda.synchronize()
         gather_ms = float(np.mean(gather_profile_read()))
         gather_profile(False)
-        results.append(dict(leg=leg, local_batch=local_batch, global_batch=global_batch, elapsed=elapsed, gather_ms=gather_ms, windows=windows))
+        per_kernel = measured_kernel_table(one_step, n_steps=2 * trainer.actor_update_interval) if (world == 1 and not a.no_kernel_table) else None
+        results.append(dict(leg=leg, local_batch=local_batch, global_batch=global_batch, elapsed=elapsed, gather_ms=gather_ms, windows=windows,
+                            per_kernel=per_kernel))
     if not results:
         raise SystemExit("[bench] --episodes %d is too small for prioritized sampling of a global batch of %d: nothing was measured" % (a.episodes, batch))
     if rank == 0:
@@ -756,6 +835,7 @@ def main_rddpg(a):
                             "store_bytes": int(a.episodes * ep_bytes), "hbm_resident": bool(a.episodes * ep_bytes > 4 * 256 * 2 ** 20),
                             "timing": "mean kernel duration of 20 gather dispatches of the same batch size after the timed region, from HIP "
                                       "start/stop events attached to each dispatch (hipExtLaunchKernel)"}}
+        out["roofline_step"] = step_roofline(r0, a.steps)
         if len(results) > 1:
             r1 = results[1]
             sps1 = a.steps / r1["elapsed"]

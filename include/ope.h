@@ -216,8 +216,18 @@ int ope_qmix_workspace_init(const ope_qmix_cfg* cfg, void* workspace, int64_t wo
  * read ONCE. A non-zero field of the cfg always wins. */
 void ope_set_debug(int on);
 void ope_set_scan_kernel(int family, int waves_per_row);
-/* Launch log: the kernel variants the LAST ope_qmix_loss_and_grad call of this thread actually launched, comma-separated in launch
- * order (e.g. "trunk_fwd4<16>,gru_fwd4<4>,head_fwd_mfma<1>,mixer_fwd3<14,1>,..."), written NUL-terminated into out[cap]; returns the number
+/* In-process per-kernel timing (the per-kernel roofline table of bench.py, measured in the run): ope_kernel_profile(1, max_launches)
+ * makes every kernel launch of the library carry hipExtLaunchKernel start / stop events (the dispatch's own duration -- what rocprofv3's
+ * kernel trace reports), up to max_launches (<= 16384) launches; ope_kernel_profile_read waits for them, writes one line per distinct
+ * kernel, in order of first launch, "demangled name \t calls \t total_ms \t min_ms \t max_ms \t flop \t bytes \n" into out[cap]
+ * (NUL-terminated; flop / bytes = the ALGORITHMIC work of those launches as their launchers state it: GEMM-shaped FLOP = 2 x MACs with
+ * LayerNorm / gates / elementwise excluded, bytes for the bandwidth-bound kernels; 0 where none is stated), returns
+ * the number of distinct kernels and clears the ring. ope_kernel_profile(0, 0) turns it off. Eager launches only (not while a HIP graph
+ * is being captured). SURVEY.md section 8(d). */
+int ope_kernel_profile(int32_t enable, int32_t max_launches);
+int ope_kernel_profile_read(char* out, int32_t cap);
+/* Launch log: the kernel variants the LAST ope_qmix_loss_and_grad call of this thread actually launched, separated by ';' in launch
+ * order (e.g. "trunk_fwd4<16>;gru_fwd4<4>;head_fwd_mfma<1>;mixer_fwd3<14,1>;..."), written NUL-terminated into out[cap]; returns the number
  * of launches. Test hook: an explicit trunk_path / mixer_path that the shape does not allow returns OPE_EINVAL from the step (no silent
  * fall-back to another kernel), and tests that pin a kernel family assert here that it ran. No reference counterpart (the
  * reference's kernels are whatever ATen dispatches). */

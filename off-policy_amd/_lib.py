@@ -83,6 +83,8 @@ def _load():
         "ope_set_debug": (None, [C.c_int]),
         "ope_set_scan_kernel": (None, [C.c_int, C.c_int]),
         "ope_last_launches": (C.c_int, [C.c_char_p, i32]),
+        "ope_kernel_profile": (C.c_int, [i32, i32]),
+        "ope_kernel_profile_read": (C.c_int, [C.c_char_p, i32]),
         "ope_episode_bytes": (i64, [C.POINTER(Dims)]),
         "ope_store_insert": (C.c_int, [C.POINTER(Dims), i32, C.POINTER(Fields), C.POINTER(Fields), p, i32, p, p]),
         "ope_store_gather": (C.c_int, [C.POINTER(Dims), i32, C.POINTER(Fields), p, i32, C.POINTER(Fields), p, p]),
@@ -149,7 +151,25 @@ def last_launches():
     """Kernel variants the last ope_qmix_loss_and_grad call of this thread launched, in launch order (ope_last_launches)."""
     buf = C.create_string_buffer(2048)
     lib.ope_last_launches(buf, 2048)
-    return [x for x in buf.value.decode().split(",") if x]
+    return [x for x in buf.value.decode().split(";") if x]
+
+
+def kernel_profile(enable, max_launches=8192):
+    check(lib.ope_kernel_profile(1 if enable else 0, int(max_launches)), "ope_kernel_profile")
+
+
+def kernel_profile_read():
+    """[(demangled kernel name, calls, total_ms, min_ms, max_ms, flop, bytes)] of the launches since kernel_profile(True), in order of first
+    launch; flop / bytes = the algorithmic work of those launches as their launchers state it (0 where none is stated)."""
+    buf = C.create_string_buffer(1 << 18)
+    n = lib.ope_kernel_profile_read(buf, 1 << 18)
+    if n < 0:
+        check(n, "ope_kernel_profile_read")
+    out = []
+    for ln in buf.value.decode().splitlines():
+        name, calls, tot, mn, mx, flop, nbytes = ln.rsplit("\t", 6)
+        out.append((name, int(calls), float(tot), float(mn), float(mx), float(flop), float(nbytes)))
+    return out
 
 
 def check(rc, what=""):

@@ -45,7 +45,7 @@ __global__ void transpose_kernel(const float* __restrict__ src, int rows, int co
 }
 
 int launch_transpose(const float* src, int rows, int cols, float* dst, hipStream_t st) {
-  hipLaunchKernelGGL(transpose_kernel, dim3(ope_cdiv((int64_t)rows * cols, 256)), dim3(256), 0, st, src, rows, cols, dst);
+  OPE_LAUNCH(transpose_kernel, dim3(ope_cdiv((int64_t)rows * cols, 256)), dim3(256), 0, st, src, rows, cols, dst);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   return OPE_OK;
 }

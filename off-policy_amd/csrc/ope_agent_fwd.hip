@@ -186,10 +186,11 @@ static int launch_trunk_vec(const TrunkFwdArgs& a, hipStream_t st) {
   // two row tiles per wave once there is enough work to fill the chip that way (OPE_TRUNK_RT=1|2 overrides, for A/B runs)
   static const int forced = getenv("OPE_TRUNK_RT") ? atoi(getenv("OPE_TRUNK_RT")) : 0;
   const bool two = forced ? forced == 2 : a.R >= 2 * 16 * 4 * 256;
+  kprof_work(2.0 * a.R * ((double)a.D * OPE_H + OPE_H * OPE_H + (a.gi ? 3.0 * OPE_H * OPE_H : 0.0) + (a.head_out ? (double)OPE_H * a.head_dim : 0.0)));
   if (two) {
-    hipLaunchKernelGGL((trunk_fwd_kernel<VEC, 2, SAVE>), dim3(ope_cdiv(ope_cdiv(a.R, 32), 4)), dim3(256), 0, st, a);
+    OPE_LAUNCH((trunk_fwd_kernel<VEC, 2, SAVE>), dim3(ope_cdiv(ope_cdiv(a.R, 32), 4)), dim3(256), 0, st, a);
   } else {
-    hipLaunchKernelGGL((trunk_fwd_kernel<VEC, 1, SAVE>), dim3(ope_cdiv(ope_cdiv(a.R, 16), 4)), dim3(256), 0, st, a);
+    OPE_LAUNCH((trunk_fwd_kernel<VEC, 1, SAVE>), dim3(ope_cdiv(ope_cdiv(a.R, 16), 4)), dim3(256), 0, st, a);
   }
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   note_launch("trunk_fwd1", VEC, two ? 2 : 1);
@@ -380,9 +381,9 @@ int launch_head_fwd(const HeadFwdArgs& a, int mode, hipStream_t st) {
   const int blocks = ope_cdiv(a.R - a.r_begin, 256);
   note_launch("head_fwd_rows", mode);
   if (mode == 0)
-    hipLaunchKernelGGL(head_fwd_kernel<0>, dim3(blocks), dim3(256), lds, st, a);
+    OPE_LAUNCH(head_fwd_kernel<0>, dim3(blocks), dim3(256), lds, st, a);
   else
-    hipLaunchKernelGGL(head_fwd_kernel<1>, dim3(blocks), dim3(256), lds, st, a);
+    OPE_LAUNCH(head_fwd_kernel<1>, dim3(blocks), dim3(256), lds, st, a);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   return OPE_OK;
 }

@@ -236,7 +236,7 @@ static int allreduce_launch(const ope_allreduce_ctx* ctx, uint32_t epoch, uint32
   a.rank = ctx->rank; a.world = ctx->world; a.max_floats = ctx->max_floats; a.chunks_max = (int)chunks_of(ctx->max_floats);
   a.epoch = epoch; a.epoch_dev = epoch_dev;
   a.timeout_ticks = (unsigned long long)(ctx->timeout_ms > 0 ? ctx->timeout_ms : kDefaultTimeoutMs) * 100000ull;
-  hipLaunchKernelGGL(allreduce_push_kernel, dim3(ope_cdiv(n, kChunk)), dim3(kBlock), 0, (hipStream_t)stream, a, flat, n, status);
+  OPE_LAUNCH(allreduce_push_kernel, dim3(ope_cdiv(n, kChunk)), dim3(kBlock), 0, (hipStream_t)stream, a, flat, n, status);
   OPE_CHECK_LAUNCH();
   return OPE_OK;
 }

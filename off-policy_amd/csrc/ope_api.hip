@@ -221,7 +221,7 @@ void note_launch(const char* name, int p0, int p1) {
   if (n >= (int)sizeof(item)) n = (int)sizeof(item) - 1;
   ++g_launch_n;
   if (g_launch_len + n + 2 >= (int)sizeof(g_launch_log)) return;     // bounded: later names are counted, not kept
-  if (g_launch_len) g_launch_log[g_launch_len++] = ',';
+  if (g_launch_len) g_launch_log[g_launch_len++] = ';';
   memcpy(g_launch_log + g_launch_len, item, n);
   g_launch_len += n;
   g_launch_log[g_launch_len] = 0;

@@ -1,6 +1,7 @@
 // Shared device helpers for the ope kernels (gfx950 / CDNA4 only, wave64).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "../../include/ope.h"
@@ -25,6 +26,22 @@ namespace ope {
 void note_launch(const char* name, int p0 = -1, int p1 = -1);
 void clear_launch_log();
 }
+
+// Every kernel launch of the library goes through OPE_LAUNCH: plain hipLaunchKernelGGL, or -- while ope_kernel_profile is on (ope_prof.hip)
+// -- the same launch with a start / stop event pair attached to the dispatch, so per-kernel durations can be read back in-process.
+namespace ope {
+extern bool g_kprof_on;
+bool kprof_events(const void* fn, hipEvent_t* e0, hipEvent_t* e1);
+void kprof_work(double flop, double bytes = 0);     // algorithmic work of the NEXT launch (only recorded while profiling is on)
+}
+#define OPE_LAUNCH(kernel, grid, block, lds, st, ...)                                                   \
+  do {                                                                                                  \
+    hipEvent_t ope_e0_, ope_e1_;                                                                        \
+    if (ope::g_kprof_on && ope::kprof_events((const void*)(kernel), &ope_e0_, &ope_e1_))                \
+      hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)(lds), st, ope_e0_, ope_e1_, 0, __VA_ARGS__); \
+    else                                                                                                \
+      hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                                    \
+  } while (0)
 
 static inline int ope_round4(int64_t x) { return (int)((x + 3) & ~(int64_t)3); }
 static inline int ope_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -395,9 +395,9 @@ int launch_build_cin(const float* cent, const float* acts, const float* repl, in
   const int64_t rows = (int64_t)T * reps * B;
   const bool even = !(S & 1) && !(A & 1) && !((uintptr_t)cent & 7) && !((uintptr_t)acts & 7) && !((uintptr_t)out & 7) && !((uintptr_t)repl & 7);
   if (even)
-    OPE_L(hipLaunchKernelGGL(build_cin_kernel<2>, dim3(ope_cdiv(rows, 16)), dim3(256), 0, st, cent, acts, repl, T, B, N, A, S, reps, rep_off, out));
+    OPE_L(OPE_LAUNCH(build_cin_kernel<2>, dim3(ope_cdiv(rows, 16)), dim3(256), 0, st, cent, acts, repl, T, B, N, A, S, reps, rep_off, out));
   else
-    OPE_L(hipLaunchKernelGGL(build_cin_kernel<1>, dim3(ope_cdiv(rows, 16)), dim3(256), 0, st, cent, acts, repl, T, B, N, A, S, reps, rep_off, out));
+    OPE_L(OPE_LAUNCH(build_cin_kernel<1>, dim3(ope_cdiv(rows, 16)), dim3(256), 0, st, cent, acts, repl, T, B, N, A, S, reps, rep_off, out));
   return OPE_OK;
 }
 int launch_action(const float* logits, const float* avail, NoiseSrc U, int rows, int B, int A, int N, int mode, int t_shift,
@@ -405,22 +405,23 @@ int launch_action(const float* logits, const float* avail, NoiseSrc U, int rows,
   const int pitch = A | 1;
   const int rpb = pitch <= 31 ? 256 : 64;
   const size_t lds = (size_t)2 * rpb * pitch * sizeof(float);
-  OPE_L(hipLaunchKernelGGL(action_kernel, dim3(ope_cdiv(rows, rpb)), dim3(256), lds, st, logits, avail, U, rows, B, A, N, mode, t_shift,
+  OPE_L(OPE_LAUNCH(action_kernel, dim3(ope_cdiv(rows, rpb)), dim3(256), lds, st, logits, avail, U, rows, B, A, N, mode, t_shift,
                            rpb, cent_nact, act_out, soft_out, nact_agents > 0 ? nact_agents : N, a_off));
   return OPE_OK;
 }
 int launch_action_grad(const ActGradArgs& a, hipStream_t st) {
-  OPE_L(hipLaunchKernelGGL(fc1_colsum_kernel, dim3(OPE_H), dim3(64), 0, st, a));
+  OPE_L(OPE_LAUNCH(fc1_colsum_kernel, dim3(OPE_H), dim3(64), 0, st, a));
   // OPE_ACTGRAD = wave | mfma | thread forces a form (tests); default by size
   const char* f = getenv("OPE_ACTGRAD");
   const bool mfma_ok = a.B % 16 == 0 && a.A <= 32;
   const int form = f ? (f[0] == 'w' ? 0 : (f[0] == 'm' && mfma_ok ? 1 : 2)) : (a.R <= 16384 ? 0 : (mfma_ok ? 1 : 2));
   if (form == 0)   // few rows (MLP family): one wave per row, lane = hidden unit -- a 64-long serial chain per thread otherwise
-    OPE_L(hipLaunchKernelGGL(action_grad_wave_kernel, dim3(ope_cdiv(a.R, 4)), dim3(256), 0, st, a));
-  else if (form == 1)
-    OPE_L(hipLaunchKernelGGL(action_grad_mfma_kernel, dim3(ope_cdiv(ope_cdiv(a.R, 16), 4)), dim3(256), 0, st, a));
-  else
-    OPE_L(hipLaunchKernelGGL(action_grad_kernel, dim3(launch1d(a.R)), dim3(256), 0, st, a));
+    OPE_L(OPE_LAUNCH(action_grad_wave_kernel, dim3(ope_cdiv(a.R, 4)), dim3(256), 0, st, a));
+  else if (form == 1) {
+    kprof_work(2.0 * a.R * (2.0 * OPE_H * OPE_H + (double)OPE_H * a.A));     // fc2^T dz2, the 64-long dot products of the LN adjoint, the A action columns of fc1
+    OPE_L(OPE_LAUNCH(action_grad_mfma_kernel, dim3(ope_cdiv(ope_cdiv(a.R, 16), 4)), dim3(256), 0, st, a));
+  } else
+    OPE_L(OPE_LAUNCH(action_grad_kernel, dim3(launch1d(a.R)), dim3(256), 0, st, a));
   return OPE_OK;
 }
 
@@ -671,7 +672,7 @@ extern "C" int ope_ddpg_critic_loss_and_grad(const ope_ddpg_cfg* cfg, const ope_
   td.B = p.B; td.K = p.K; td.K4 = p.K; td.gamma = cfg->gamma; td.use_huber = cfg->use_huber; td.huber_delta = cfg->huber_delta;
   td.per_eps = cfg->per_eps; td.q = W + p.qc; td.q_tgt = W + p.qt; td.rewards = bt->rewards; td.dones_env = bt->dones_env;
   td.per_weights = cfg->use_per ? per_weights : nullptr; td.dq = W + p.dq; td.prio_out = prio_out; td.loss_part = W + p.loss_part;
-  OPE_L(hipLaunchKernelGGL(critic_td_kernel, dim3(launch1d(p.B)), dim3(256), 0, st, td));
+  OPE_L(OPE_LAUNCH(critic_td_kernel, dim3(launch1d(p.B)), dim3(256), 0, st, td));
   return mlp_backward(p, W, W + p.xin, p.B, p.Din, p.K, p.K, W + p.dq, theta_critic, p.CL, nullptr, p.ns_c, ope_cdiv(p.B, 16), grad, st);
 }
 
@@ -716,7 +717,7 @@ extern "C" int ope_ddpg_actor_loss_and_grad(const ope_ddpg_cfg* cfg, const ope_m
   if ((rc = launch_build_cin(bt->share_obs, bt->acts, W + p.actout, 1, p.B, p.NT, p.A, p.S, p.N, W + p.xin_a, st, p.a0))) return rc;
   // critic (parameters frozen) on the stacked input; only head 0 enters the objective
   if ((rc = trunk_mlp(p, W, W + p.xin_a, p.Ra, p.Din, theta_critic, p.CL, W + p.a2c, true, nullptr, W + p.qc, p.K, st))) return rc;
-  OPE_L(hipLaunchKernelGGL(actor_obj_kernel, dim3(launch1d(p.Ra)), dim3(256), 0, st, W + p.qc, p.K, bt->valid_transition, p.Ra,
+  OPE_L(OPE_LAUNCH(actor_obj_kernel, dim3(launch1d(p.Ra)), dim3(256), 0, st, W + p.qc, p.K, bt->valid_transition, p.Ra,
                            W + p.dq, W + p.loss_part));
   // critic backward down to its input, then through the gumbel-softmax into the actor logits
   if ((rc = mlp_backward(p, W, W + p.xin_a, p.Ra, p.Din, p.K, p.K, W + p.dq, theta_critic, p.CL, nullptr, p.ns_a, 0, nullptr, st))) return rc;

@@ -914,7 +914,8 @@ int64_t ddpg_fused_slab_floats(int N, int A, int D, int S, int K, int B) {
 
 static int launch_reduce(const float* slabs, int ns, int64_t stride, const AgentLayout& L, float* grad, float* gsq, hipStream_t st) {
   const int P = L.end;
-  hipLaunchKernelGGL(ddpg_tile_reduce_kernel, dim3(ope_cdiv((int64_t)(P + 4) * 8, 256)), dim3(256), 0, st, slabs, ns, stride, P, P, L.fch_w,
+  kprof_work(0.0, 4.0 * ((double)ns * stride + P));
+  OPE_LAUNCH(ddpg_tile_reduce_kernel, dim3(ope_cdiv((int64_t)(P + 4) * 8, 256)), dim3(256), 0, st, slabs, ns, stride, P, P, L.fch_w,
                      L.fc2_w, L.q_w, grad, gsq);
   return hipGetLastError() == hipSuccess ? OPE_OK : OPE_ELAUNCH;
 }
@@ -933,7 +934,7 @@ static int launch_tile(KERN kern, const TileArgs& a, int blocks, size_t lds, hip
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return OPE_ELAUNCH;
     granted[slot] = (int)lds;
   }
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, st, a);
+  OPE_LAUNCH(kern, dim3(blocks), dim3(256), lds, st, a);
   return hipGetLastError() == hipSuccess ? OPE_OK : OPE_ELAUNCH;
 }
 #define OPE_TILE_DISPATCH(KERNEL, nca, ncc, ...)                                  \
@@ -957,6 +958,10 @@ int launch_ddpg_critic_fused(const ope_ddpg_cfg* cfg, const ope_mlp_batch* bt, c
   static const bool dbg_on = getenv("OPE_DDPG_DBG") != nullptr;
   a.dbg = dbg_on ? reinterpret_cast<long long*>(slabs + ddpg_fused_slab_floats(a.N, a.A, a.D, a.S, a.K, a.B)) : nullptr;
   const int blocks = a.tiles < kMaxTilesPerLaunch ? a.tiles : kMaxTilesPerLaunch;
+  {   // GEMM-shaped work of the launch: N target-actor passes, target critic, live critic forward, its weight gradients and hidden adjoints
+    const double am = (double)a.D * OPE_H + OPE_H * OPE_H + (double)OPE_H * a.A, cm = (double)a.Din * OPE_H + OPE_H * OPE_H + (double)OPE_H * a.K;
+    kprof_work(2.0 * ((double)a.N * a.B * am + 2.0 * a.B * cm + a.B * (cm + OPE_H * OPE_H + (double)OPE_H * a.K)));
+  }
   const int rc = OPE_TILE_DISPATCH(ddpg_critic_tile_kernel, a.n0.nc0, a.n1.nc0, a, blocks, (size_t)lds * sizeof(float), st);
   if (rc) return rc;
   return launch_reduce(slabs, blocks, a.slab_stride, ope_agent_layout_mlp(a.Din, a.K, 0), grad, gsq, st);
@@ -973,6 +978,10 @@ int launch_ddpg_actor_fused(const ope_ddpg_cfg* cfg, const ope_mlp_batch* bt, co
   a.slab_stride = slab_len(a.D, a.A, a.Din, a.K);
   a.tail = ope_agent_layout_mlp(a.D, a.A, 0).end;
   const int blocks = a.tiles < kMaxTilesPerLaunch ? a.tiles : kMaxTilesPerLaunch;
+  {   // actor forward, critic forward on the substituted joint action, critic adjoint down to the action block, actor weight gradients + adjoints
+    const double am = (double)a.D * OPE_H + OPE_H * OPE_H + (double)OPE_H * a.A, cm = (double)a.Din * OPE_H + OPE_H * OPE_H + (double)OPE_H * a.K;
+    kprof_work(2.0 * (double)a.N * a.B * (am + cm + ((double)OPE_H * a.K + OPE_H * OPE_H + (double)OPE_H * a.A) + am + ((double)a.A * OPE_H + OPE_H * OPE_H)));
+  }
   const int rc = OPE_TILE_DISPATCH(ddpg_actor_tile_kernel, a.n0.nc0, a.n1.nc0, a, blocks, (size_t)lds * sizeof(float), st);
   if (rc) return rc;
   return launch_reduce(slabs, blocks, a.slab_stride, ope_agent_layout_mlp(a.D, a.A, 0), grad, gsq, st);

@@ -288,14 +288,16 @@ __global__ void __launch_bounds__(128) gru_bwd1_kernel(GruBwdArgs a) {
 }  // namespace
 
 int launch_gru_fwd1(const GruFwdArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(gru_fwd1_kernel, dim3(a.nets * a.NB), dim3(128), 0, st, a);
+  kprof_work(2.0 * a.nets * a.NB * (double)a.L * 3.0 * OPE_H * OPE_H);
+  OPE_LAUNCH(gru_fwd1_kernel, dim3(a.nets * a.NB), dim3(128), 0, st, a);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   note_launch("gru_fwd1");
   return OPE_OK;
 }
 
 int launch_gru_bwd1(const GruBwdArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(gru_bwd1_kernel, dim3(a.NB), dim3(128), 0, st, a);
+  kprof_work(2.0 * a.NB * (double)(a.T - a.t_lo) * 3.0 * OPE_H * OPE_H);
+  OPE_LAUNCH(gru_bwd1_kernel, dim3(a.NB), dim3(128), 0, st, a);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   note_launch("gru_bwd1");
   return OPE_OK;

@@ -464,20 +464,21 @@ static int waves_per_row(int64_t rows, int asked) {
 template <int W>
 static void launch_fwd(const GruFwdArgs& a, hipStream_t st) {
   if (a.dbg)
-    hipLaunchKernelGGL((gru_fwd4_kernel<W, true>), dim3(a.nets * a.NB), dim3((W + 2) * 64), 0, st, a);
+    OPE_LAUNCH((gru_fwd4_kernel<W, true>), dim3(a.nets * a.NB), dim3((W + 2) * 64), 0, st, a);
   else
-    hipLaunchKernelGGL((gru_fwd4_kernel<W, false>), dim3(a.nets * a.NB), dim3((W + 2) * 64), 0, st, a);
+    OPE_LAUNCH((gru_fwd4_kernel<W, false>), dim3(a.nets * a.NB), dim3((W + 2) * 64), 0, st, a);
 }
 template <int W>
 static void launch_bwd(const GruBwdArgs& a, hipStream_t st) {
   if (a.dbg)
-    hipLaunchKernelGGL((gru_bwd4_kernel<W, true>), dim3(a.NB), dim3((W + 2) * 64), 0, st, a);
+    OPE_LAUNCH((gru_bwd4_kernel<W, true>), dim3(a.NB), dim3((W + 2) * 64), 0, st, a);
   else
-    hipLaunchKernelGGL((gru_bwd4_kernel<W, false>), dim3(a.NB), dim3((W + 2) * 64), 0, st, a);
+    OPE_LAUNCH((gru_bwd4_kernel<W, false>), dim3(a.NB), dim3((W + 2) * 64), 0, st, a);
 }
 
 int launch_gru_fwd4(const GruFwdArgs& a, hipStream_t st) {
   const int w = waves_per_row((int64_t)a.nets * a.NB, a.waves);
+  kprof_work(2.0 * a.nets * a.NB * (double)a.L * 3.0 * OPE_H * OPE_H);      // W_hh h per row and step
   if (w == 4) launch_fwd<4>(a, st); else launch_fwd<2>(a, st);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   note_launch("gru_fwd4", w == 4 ? 4 : 2);
@@ -486,6 +487,7 @@ int launch_gru_fwd4(const GruFwdArgs& a, hipStream_t st) {
 
 int launch_gru_bwd4(const GruBwdArgs& a, hipStream_t st) {
   const int w = waves_per_row(a.NB, a.waves);
+  kprof_work(2.0 * a.NB * (double)(a.T - a.t_lo) * 3.0 * OPE_H * OPE_H);     // W_hh^T (gate adjoints) per row and step
   if (w == 4) launch_bwd<4>(a, st); else launch_bwd<2>(a, st);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   note_launch("gru_bwd4", w == 4 ? 4 : 2);

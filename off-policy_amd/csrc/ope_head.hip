@@ -240,17 +240,19 @@ int launch_head_fwd_mfma(const HeadFwdArgs& a0, hipStream_t st) {
   HeadFwdArgs a = a0;
   a.main_blocks = (int)ope_cdiv(a.R - a.r_begin, 64);
   const int blocks = a.main_blocks + (a.side.total > 0 ? ope_cdiv(a.side.total, 256) : 0);
+  kprof_work(2.0 * 2.0 * (double)(a.R - a.r_begin) * OPE_H * a.A);           // live + target q of every action
   if (a.A <= 16)
-    hipLaunchKernelGGL(head_fwd_mfma_kernel<1>, dim3(blocks), dim3(256), 0, st, a);
+    OPE_LAUNCH(head_fwd_mfma_kernel<1>, dim3(blocks), dim3(256), 0, st, a);
   else
-    hipLaunchKernelGGL(head_fwd_mfma_kernel<2>, dim3(blocks), dim3(256), 0, st, a);
+    OPE_LAUNCH(head_fwd_mfma_kernel<2>, dim3(blocks), dim3(256), 0, st, a);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   note_launch("head_fwd_mfma", a.A <= 16 ? 1 : 2);
   return OPE_OK;
 }
 
 int launch_head_bwd_rows(const HeadBwdArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(head_bwd_rows_kernel, dim3((int)ope_cdiv(a.R, 64)), dim3(256), 0, st, a);
+  kprof_work(0.0, (double)a.R * (2.0 * OPE_H + ope_round4(a.A) + 2.0) * 4.0);   // row-wise adjoint: reads xhat, writes dh_out + the one-hot dq row
+  OPE_LAUNCH(head_bwd_rows_kernel, dim3((int)ope_cdiv(a.R, 64)), dim3(256), 0, st, a);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   note_launch("head_bwd_rows");
   return OPE_OK;

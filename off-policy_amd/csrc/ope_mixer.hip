@@ -531,19 +531,21 @@ static void launch_mixer2(const MixerFwdArgs& a0, hipStream_t st) {
   // (read per launch: tests switch it between calls; 2 = also for small problems, where one workgroup per row tile is as good)
   const char* pe = getenv("OPE_MIXER_PERSIST");
   const int persist = a.path == 1 ? 2 : (a.path == 2 ? 0 : (pe ? atoi(pe) : 1));     // cfg->mixer_path overrides the environment
+  // both nets; with the wide-state slabs the first hyper-layers' products were done by mixer_wide_gemm
+  kprof_work(2.0 * 2.0 * a.TB * (((double)a.S * (3.0 * OPE_HYP + OPE_MIX) + (double)OPE_HYP * a.N * OPE_MIX + OPE_HYP * OPE_MIX + OPE_HYP + (double)a.N * OPE_MIX + OPE_MIX) - (a.wide_slab ? (double)a.S * (3.0 * OPE_HYP + OPE_MIX) : 0.0)));
   if (VEC == 4 && persist && !forced && !a.wide_slab && a.N <= 8 && a.S <= 16 * 14 && (a.TB >= 16 * 64 || persist == 2)) {
     note_launch("mixer_fwd3", 14, ((a.S + 15) >> 4) == 14);
     const int tiles = ope_cdiv(a.TB, 16);
     static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256; return n > 1 ? n : 256; }();
     const int per_net = tiles < cus / 2 ? tiles : cus / 2;
-    if (((a.S + 15) >> 4) == 14) hipLaunchKernelGGL((mixer_fwd3_kernel<14, true>), dim3(2 * per_net), dim3(512), 0, st, a);
-    else hipLaunchKernelGGL((mixer_fwd3_kernel<14, false>), dim3(2 * per_net), dim3(512), 0, st, a);
+    if (((a.S + 15) >> 4) == 14) OPE_LAUNCH((mixer_fwd3_kernel<14, true>), dim3(2 * per_net), dim3(512), 0, st, a);
+    else OPE_LAUNCH((mixer_fwd3_kernel<14, false>), dim3(2 * per_net), dim3(512), 0, st, a);
     return;
   }
   note_launch(a.wide_slab ? "mixer_fwd2_wide" : "mixer_fwd2", VEC, rt);
-  if (rt == 4) hipLaunchKernelGGL((mixer_fwd2_kernel<VEC, 4>), dim3(2 * ope_cdiv(a.TB, 64)), dim3(256), 0, st, a);
-  else if (rt == 2) hipLaunchKernelGGL((mixer_fwd2_kernel<VEC, 2>), dim3(2 * ope_cdiv(a.TB, 32)), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((mixer_fwd2_kernel<VEC, 1>), dim3(2 * ope_cdiv(a.TB, 16)), dim3(256), 0, st, a);
+  if (rt == 4) OPE_LAUNCH((mixer_fwd2_kernel<VEC, 4>), dim3(2 * ope_cdiv(a.TB, 64)), dim3(256), 0, st, a);
+  else if (rt == 2) OPE_LAUNCH((mixer_fwd2_kernel<VEC, 2>), dim3(2 * ope_cdiv(a.TB, 32)), dim3(256), 0, st, a);
+  else OPE_LAUNCH((mixer_fwd2_kernel<VEC, 1>), dim3(2 * ope_cdiv(a.TB, 16)), dim3(256), 0, st, a);
 }
 
 int launch_mixer_fwd(const MixerFwdArgs& a0, hipStream_t st) {
@@ -735,7 +737,8 @@ __global__ void __launch_bounds__(256) mixer_bwd4_kernel(MixerBwdArgs a) {
 
 int launch_mixer_bwd(const MixerBwdArgs& a, hipStream_t st) {
   if (a.TB < 1) return OPE_EINVAL;
-  hipLaunchKernelGGL(mixer_bwd4_kernel, dim3(ope_cdiv(a.TB, 16)), dim3(256), 0, st, a);
+  kprof_work(2.0 * a.TB * ((double)a.N * OPE_MIX * OPE_HYP + OPE_MIX * OPE_HYP));      // W1b^T dv1 and W2b^T dv2
+  OPE_LAUNCH(mixer_bwd4_kernel, dim3(ope_cdiv(a.TB, 16)), dim3(256), 0, st, a);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   note_launch("mixer_bwd4");
   return OPE_OK;
@@ -773,7 +776,7 @@ __global__ void __launch_bounds__(256) vdn_kernel(VdnArgs a) {
 
 int launch_vdn(const VdnArgs& a, hipStream_t st) {
   if (a.TB < 1) return OPE_EINVAL;
-  hipLaunchKernelGGL(vdn_kernel, dim3(ope_cdiv(a.TB, 256)), dim3(256), 0, st, a);
+  OPE_LAUNCH(vdn_kernel, dim3(ope_cdiv(a.TB, 256)), dim3(256), 0, st, a);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   return OPE_OK;
 }
@@ -801,7 +804,7 @@ __global__ void __launch_bounds__(256) td_stats_kernel(const float* __restrict__
 }
 
 int launch_td_stats(const float* err_abs, int T, int B, float* out, hipStream_t st) {
-  hipLaunchKernelGGL(td_stats_kernel, dim3(ope_cdiv(B, 4)), dim3(256), 0, st, err_abs, T, B, out);
+  OPE_LAUNCH(td_stats_kernel, dim3(ope_cdiv(B, 4)), dim3(256), 0, st, err_abs, T, B, out);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   return OPE_OK;
 }

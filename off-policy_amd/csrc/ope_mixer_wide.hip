@@ -190,9 +190,10 @@ int launch_mixer_wide_gemm(const MixerFwdArgs& a0, hipStream_t st) {
   const int ex = a0.dbg ? ex_env : 0;
   MixerFwdArgs a = a0;
   a.k_stagger = ex;
-  if (vec == 4) hipLaunchKernelGGL(mixer_wide_gemm_kernel<4>, dim3(P.nwg), dim3(512), 0, st, a);
-  else if (vec == 2) hipLaunchKernelGGL(mixer_wide_gemm_kernel<2>, dim3(P.nwg), dim3(512), 0, st, a);
-  else hipLaunchKernelGGL(mixer_wide_gemm_kernel<1>, dim3(P.nwg), dim3(512), 0, st, a);
+  kprof_work(2.0 * 2.0 * a.TB * (double)a.S * (3.0 * OPE_HYP + OPE_MIX));
+  if (vec == 4) OPE_LAUNCH(mixer_wide_gemm_kernel<4>, dim3(P.nwg), dim3(512), 0, st, a);
+  else if (vec == 2) OPE_LAUNCH(mixer_wide_gemm_kernel<2>, dim3(P.nwg), dim3(512), 0, st, a);
+  else OPE_LAUNCH(mixer_wide_gemm_kernel<1>, dim3(P.nwg), dim3(512), 0, st, a);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   note_launch("mixer_wide_gemm", vec);
   return OPE_OK;

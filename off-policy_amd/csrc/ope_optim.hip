@@ -161,7 +161,8 @@ extern "C" int ope_adam_step(const ope_adam_cfg* cfg, int64_t n, float* theta, f
   hipStream_t st = (hipStream_t)stream;
   const bool have_parts = cfg->sumsq_partials != nullptr && cfg->n_sumsq_partials > 0;
   if (!have_parts) {
-    hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(kBlock), 0, st, grad, n, scratch);
+    ope::kprof_work(0.0, 4.0 * (double)n);
+    OPE_LAUNCH(sumsq_kernel, dim3(nb), dim3(kBlock), 0, st, grad, n, scratch);
     OPE_CHECK_LAUNCH();
   }
   AdamK c;
@@ -176,7 +177,8 @@ extern "C" int ope_adam_step(const ope_adam_cfg* cfg, int64_t n, float* theta, f
   c.lr = cfg->lr; c.step_counter = cfg->step_counter;
   c.skip_begin = cfg->skip_begin; c.skip_end = cfg->skip_end;
   c.tail = cfg->tail_offset > 0 ? cfg->tail_offset : n;
-  hipLaunchKernelGGL(adam_kernel, dim3(nb), dim3(kBlock), 0, st, c, n, theta, theta_tgt, adam_m, adam_v, grad,
+  ope::kprof_work(0.0, 4.0 * (double)n * (cfg->do_polyak ? 9.0 : 7.0));      // theta, m, v (+ target) read and written, grad read
+  OPE_LAUNCH(adam_kernel, dim3(nb), dim3(kBlock), 0, st, c, n, theta, theta_tgt, adam_m, adam_v, grad,
                      have_parts ? cfg->sumsq_partials : scratch, stats_out);
   OPE_CHECK_LAUNCH();
   return OPE_OK;
@@ -185,7 +187,8 @@ extern "C" int ope_adam_step(const ope_adam_cfg* cfg, int64_t n, float* theta, f
 extern "C" int ope_polyak(int64_t n, const float* theta, float* theta_tgt, float tau, void* stream) {
   (void)hipGetLastError();  // drop stale errors from the caller's own HIP use
   if (n < 1 || !theta || !theta_tgt) return OPE_EINVAL;
-  hipLaunchKernelGGL(polyak_kernel, dim3(ope_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, n, theta, theta_tgt, tau);
+  ope::kprof_work(0.0, 4.0 * 3.0 * (double)n);
+  OPE_LAUNCH(polyak_kernel, dim3(ope_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, n, theta, theta_tgt, tau);
   OPE_CHECK_LAUNCH();
   return OPE_OK;
 }

@@ -130,7 +130,7 @@ extern "C" int64_t ope_per_tree_bytes(int32_t capacity) {
 extern "C" int ope_per_tree_init(void* trees, int32_t capacity, void* stream) {
   (void)hipGetLastError();
   if (!trees || !pow2(capacity)) return OPE_EINVAL;
-  hipLaunchKernelGGL(per_init_kernel, dim3(ope_cdiv(2 * (int64_t)capacity, 256) < 1024 ? ope_cdiv(2 * (int64_t)capacity, 256) : 1024), dim3(256), 0,
+  OPE_LAUNCH(per_init_kernel, dim3(ope_cdiv(2 * (int64_t)capacity, 256) < 1024 ? ope_cdiv(2 * (int64_t)capacity, 256) : 1024), dim3(256), 0,
                      (hipStream_t)stream, trees, capacity);
   OPE_CHECK_LAUNCH();
   return OPE_OK;
@@ -142,7 +142,7 @@ extern "C" int ope_per_tree_set(void* trees, int32_t capacity, const int64_t* id
   if (!trees || !pow2(capacity) || !idx || n < 1) return OPE_EINVAL;
   for (int done = 0; done < n; done += 1024) {      // later chunks overwrite earlier ones: "last wins" across chunks too
     const int m = n - done < 1024 ? n - done : 1024;
-    hipLaunchKernelGGL(per_set_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, trees, capacity, idx + done,
+    OPE_LAUNCH(per_set_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, trees, capacity, idx + done,
                        priorities ? priorities + done : nullptr, alpha, m);
     OPE_CHECK_LAUNCH();
   }
@@ -153,7 +153,7 @@ extern "C" int ope_per_tree_sample(const void* trees, int32_t capacity, int32_t 
                                    int64_t* idx_out, float* weights_out, void* stream) {
   (void)hipGetLastError();
   if (!trees || !pow2(capacity) || filled < 2 || filled > capacity || !mass01 || !idx_out || n < 1) return OPE_EINVAL;
-  hipLaunchKernelGGL(per_sample_kernel, dim3(ope_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, trees, capacity, filled, mass01, beta, n,
+  OPE_LAUNCH(per_sample_kernel, dim3(ope_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, trees, capacity, filled, mass01, beta, n,
                      idx_out, weights_out, (const int32_t*)nullptr, (const double*)nullptr);
   OPE_CHECK_LAUNCH();
   return OPE_OK;
@@ -163,7 +163,7 @@ extern "C" int ope_per_tree_sample_dev(const void* trees, int32_t capacity, cons
                                        int32_t n, int64_t* idx_out, float* weights_out, void* stream) {
   (void)hipGetLastError();
   if (!trees || !pow2(capacity) || !filled_dev || !beta_dev || !mass01 || !idx_out || n < 1) return OPE_EINVAL;
-  hipLaunchKernelGGL(per_sample_kernel, dim3(ope_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, trees, capacity, 2, mass01, 0.0, n, idx_out,
+  OPE_LAUNCH(per_sample_kernel, dim3(ope_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, trees, capacity, 2, mass01, 0.0, n, idx_out,
                      weights_out, filled_dev, beta_dev);
   OPE_CHECK_LAUNCH();
   return OPE_OK;

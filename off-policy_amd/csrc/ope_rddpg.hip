@@ -452,7 +452,8 @@ static int rscan(const float* gi, int rps, int steps, const float* theta, const 
 static int rhead(const float* h, int64_t rows, int Hout, const float* theta, const AgentLayout& L, float* out, float* W, const SaveSet* save,
                  hipStream_t st) {
   if (Hout > kHbMaxK) return OPE_EINVAL;
-  OPE_L(hipLaunchKernelGGL(head_fwd_dense_kernel, dim3(ope_cdiv(rows, 64)), dim3(256), 0, st, h, Hout, theta + L.q_w, theta + L.q_b,
+  kprof_work(2.0 * rows * (double)OPE_H * Hout);
+  OPE_L(OPE_LAUNCH(head_fwd_dense_kernel, dim3(ope_cdiv(rows, 64)), dim3(256), 0, st, h, Hout, theta + L.q_w, theta + L.q_b,
                            theta + L.lno_w, theta + L.lno_b, rows, out, save ? W + save->xhat_o : nullptr, save ? W + save->rstd_o : nullptr));
   return OPE_OK;
 }
@@ -464,7 +465,8 @@ static int rcell(const RPlan& p, const float* gi, const float* hprev, int64_t ro
   ca.R = (int)rows; ca.B = p.B; ca.reps = reps; ca.prev_shift = prev_shift; ca.gi = gi; ca.hprev = hprev; ca.theta = theta;
   ca.whh_off = L.whh; ca.bhh_off = L.bhh; ca.hout = hout;
   if (save) { ca.rg = W + save->rg; ca.zg = W + save->zg; ca.ng = W + save->ng; ca.ghn = W + save->ghn; }
-  OPE_L(hipLaunchKernelGGL(gru_cell_fwd_kernel, dim3(ope_cdiv(rows, 64)), dim3(256), 0, st, ca));
+  kprof_work(2.0 * rows * 3.0 * OPE_H * OPE_H);
+  OPE_L(OPE_LAUNCH(gru_cell_fwd_kernel, dim3(ope_cdiv(rows, 64)), dim3(256), 0, st, ca));
   return OPE_OK;
 }
 
@@ -486,7 +488,8 @@ static int rnn_backward(const RPlan& p, float* W, const SaveSet& s, const float*
   int rc;
   const int64_t rows = (int64_t)rps * steps;
   if (Hout > kHbMaxK) return OPE_EINVAL;
-  OPE_L(hipLaunchKernelGGL(head_bwd_dense_kernel, dim3(ope_cdiv(rows, 64)), dim3(256), 0, st, dout, ldk, Hout, theta + L.q_w,
+  kprof_work(2.0 * rows * (double)OPE_H * Hout);
+  OPE_L(OPE_LAUNCH(head_bwd_dense_kernel, dim3(ope_cdiv(rows, 64)), dim3(256), 0, st, dout, ldk, Hout, theta + L.q_w,
                            theta + L.lno_w, W + s.xhat_o, W + s.rstd_o, (int)rows, W + p.dh_out));
   GruBwdArgs gb;
   memset(&gb, 0, sizeof(gb));
@@ -656,7 +659,7 @@ extern "C" int ope_rddpg_critic_loss_and_grad(const ope_rddpg_cfg* cfg, const op
   td.T = p.T; td.B = p.B; td.N = p.N; td.K = p.K; td.gamma = cfg->gamma; td.use_huber = cfg->use_huber; td.huber_delta = cfg->huber_delta;
   td.q = W + p.q; td.nq = W + p.nq; td.rewards = bt->rewards; td.dones_env = bt->dones_env;
   td.per_weights = cfg->use_per ? per_weights : nullptr; td.dq = W + p.dq; td.err_abs = W + p.err_abs; td.loss_part = W + p.loss_part;
-  OPE_L(hipLaunchKernelGGL(rcritic_td_kernel, dim3(launch1d(p.TB)), dim3(256), 0, st, td));
+  OPE_L(OPE_LAUNCH(rcritic_td_kernel, dim3(launch1d(p.TB)), dim3(256), 0, st, td));
   if (td_abs_stats)
     for (int k = 0; k < p.K; ++k)
       if ((rc = launch_td_stats(W + p.err_abs + (int64_t)k * p.TB, p.T, p.B, td_abs_stats + (int64_t)k * 2 * p.B, st))) return rc;
@@ -725,15 +728,17 @@ extern "C" int ope_rddpg_actor_loss_and_grad(const ope_rddpg_cfg* cfg, const ope
   }
   if ((rc = rcell(p, W + p.SC.gi, W + p.c_h, p.Ra, p.N, -1, theta_critic, p.CL, W + p.h_b, W, &p.SC, st))) return rc;
   if ((rc = rhead(W + p.h_b, p.Ra, p.K, theta_critic, p.CL, W + p.q, W, &p.SC, st))) return rc;
-  OPE_L(hipLaunchKernelGGL(ractor_obj_kernel, dim3(launch1d(Ra)), dim3(256), 0, st, W + p.q, p.K, bt->dones, Ra, p.NB, cfg->actor_row_weight,
+  OPE_L(OPE_LAUNCH(ractor_obj_kernel, dim3(launch1d(Ra)), dim3(256), 0, st, W + p.q, p.K, bt->dones, Ra, p.NB, cfg->actor_row_weight,
                            W + p.dq, W + p.loss_part));
   // critic adjoint down to its input (parameters frozen), through the gumbel-softmax into the actor logits
-  OPE_L(hipLaunchKernelGGL(head_bwd_dense_kernel, dim3(ope_cdiv(Ra, 64)), dim3(256), 0, st, W + p.dq, p.K, p.K, theta_critic + p.CL.q_w,
+  kprof_work(2.0 * Ra * (double)OPE_H * p.K);
+  OPE_L(OPE_LAUNCH(head_bwd_dense_kernel, dim3(ope_cdiv(Ra, 64)), dim3(256), 0, st, W + p.dq, p.K, p.K, theta_critic + p.CL.q_w,
                            theta_critic + p.CL.lno_w, W + p.SC.xhat_o, W + p.SC.rstd_o, Ra, W + p.dh_out));
   CellBwdArgs cb;
   cb.R = Ra; cb.B = p.B; cb.reps = p.N; cb.prev_shift = -1; cb.dh = W + p.dh_out; cb.hprev = W + p.c_h;
   cb.rg = W + p.SC.rg; cb.zg = W + p.SC.zg; cb.ng = W + p.SC.ng; cb.ghn = W + p.SC.ghn; cb.dgi = W + p.dgi;
-  OPE_L(hipLaunchKernelGGL(gru_cell_bwd_kernel, dim3(launch1d((int64_t)Ra * 16)), dim3(256), 0, st, cb));
+  kprof_work(2.0 * Ra * 3.0 * OPE_H * OPE_H);
+  OPE_L(OPE_LAUNCH(gru_cell_bwd_kernel, dim3(launch1d((int64_t)Ra * 16)), dim3(256), 0, st, cb));
   if ((rc = rtranspose(p, theta_critic, p.CL, W, st))) return rc;
   TrunkBwdArgs tb;
   memset(&tb, 0, sizeof(tb));

@@ -362,6 +362,8 @@ struct GatherProf {
   int n = 0;           // pairs recorded since the last read (capped at kProfRing)
 };
 GatherProf g_prof;
+using ope::g_kprof_on;
+using ope::kprof_work;
 
 template <bool GATHER, class IDX>
 void launch_copy(const CopyArgs& args, const IDX& idx, hipStream_t st) {
@@ -373,13 +375,19 @@ void launch_copy(const CopyArgs& args, const IDX& idx, hipStream_t st) {
     hipExtLaunchKernelGGL((episode_copy_kernel<GATHER, 8, 0, IDX>), grid, block, (uint32_t)lds, st, e0, e1, 0, args, idx);
     return;
   }
+  if (g_kprof_on) {     // every byte of the E episodes once in, once out
+    double b = 0;
+    for (int q = 0; q < kFields; ++q)
+      if (args.f[q].src) b += 4.0 * args.f[q].TT * (double)args.f[q].NA * args.f[q].DD;
+    kprof_work(0.0, 2.0 * b * args.n_episodes);
+  }
   // one instantiation per variant: a single kernel holding all of them would be allocated the registers of the largest
-  if (args.unroll == 4) hipLaunchKernelGGL((episode_copy_kernel<GATHER, 4, 0, IDX>), grid, block, lds, st, args, idx);
-  else if (args.unroll == 16) hipLaunchKernelGGL((episode_copy_kernel<GATHER, 16, 0, IDX>), grid, block, lds, st, args, idx);
-  else if (args.nt == 1) hipLaunchKernelGGL((episode_copy_kernel<GATHER, 8, 1, IDX>), grid, block, lds, st, args, idx);
-  else if (args.nt == 2) hipLaunchKernelGGL((episode_copy_kernel<GATHER, 8, 2, IDX>), grid, block, lds, st, args, idx);
-  else if (args.nt == 3) hipLaunchKernelGGL((episode_copy_kernel<GATHER, 8, 3, IDX>), grid, block, lds, st, args, idx);
-  else hipLaunchKernelGGL((episode_copy_kernel<GATHER, 8, 0, IDX>), grid, block, lds, st, args, idx);
+  if (args.unroll == 4) OPE_LAUNCH((episode_copy_kernel<GATHER, 4, 0, IDX>), grid, block, lds, st, args, idx);
+  else if (args.unroll == 16) OPE_LAUNCH((episode_copy_kernel<GATHER, 16, 0, IDX>), grid, block, lds, st, args, idx);
+  else if (args.nt == 1) OPE_LAUNCH((episode_copy_kernel<GATHER, 8, 1, IDX>), grid, block, lds, st, args, idx);
+  else if (args.nt == 2) OPE_LAUNCH((episode_copy_kernel<GATHER, 8, 2, IDX>), grid, block, lds, st, args, idx);
+  else if (args.nt == 3) OPE_LAUNCH((episode_copy_kernel<GATHER, 8, 3, IDX>), grid, block, lds, st, args, idx);
+  else OPE_LAUNCH((episode_copy_kernel<GATHER, 8, 0, IDX>), grid, block, lds, st, args, idx);
 }
 
 int build_args(const ope_dims* d, const ope_fields* src, const ope_fields* dst, int E, int capacity, bool gather, CopyArgs* out) {
@@ -533,10 +541,10 @@ extern "C" int ope_store_reward_stats(const ope_dims* dims, int32_t filled, cons
   const int64_t n = (int64_t)filled * dims->episode_length * dims->n_agents;
   int blocks = (int)((n + 255) / 256);
   if (blocks > kStatBlocks) blocks = kStatBlocks;
-  hipLaunchKernelGGL(reward_stats_partial_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rewards, dones_env, n,
+  OPE_LAUNCH(reward_stats_partial_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rewards, dones_env, n,
                      dims->episode_length, dims->n_agents, (double*)scratch);
   OPE_CHECK_LAUNCH();
-  hipLaunchKernelGGL(reward_stats_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const double*)scratch, blocks, stats_out);
+  OPE_LAUNCH(reward_stats_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const double*)scratch, blocks, stats_out);
   OPE_CHECK_LAUNCH();
   return OPE_OK;
 }
@@ -544,7 +552,7 @@ extern "C" int ope_store_reward_stats(const ope_dims* dims, int32_t filled, cons
 extern "C" int ope_reward_normalize(float* rewards, int64_t n, const float* stats, void* stream) {
   (void)hipGetLastError();
   if (!rewards || n < 1 || !stats) return OPE_EINVAL;
-  hipLaunchKernelGGL(reward_normalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rewards, n, stats);
+  OPE_LAUNCH(reward_normalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rewards, n, stats);
   OPE_CHECK_LAUNCH();
   return OPE_OK;
 }

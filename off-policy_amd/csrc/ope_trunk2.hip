@@ -417,10 +417,11 @@ static int launch2(const TrunkFwdArgs& a, hipStream_t st) {
   const bool two = forced ? forced == 2 : a.R >= 65536;
   const int TR = two ? 32 : 16;
   const size_t lds = (size_t)(TR * Dp + TR * kActPitch + 4 * TR) * sizeof(float);
+  kprof_work(2.0 * a.R * ((double)a.D * OPE_H + OPE_H * OPE_H + (a.gi ? 3.0 * OPE_H * OPE_H : 0.0) + (a.head_out ? (double)OPE_H * a.head_dim : 0.0)));
   if (two)
-    hipLaunchKernelGGL((trunk_fwd2_kernel<VEC, 2, SAVE>), dim3(ope_cdiv(a.R, 32)), dim3(256), lds, st, a, Dp);
+    OPE_LAUNCH((trunk_fwd2_kernel<VEC, 2, SAVE>), dim3(ope_cdiv(a.R, 32)), dim3(256), lds, st, a, Dp);
   else
-    hipLaunchKernelGGL((trunk_fwd2_kernel<VEC, 1, SAVE>), dim3(ope_cdiv(a.R, 16)), dim3(256), lds, st, a, Dp);
+    OPE_LAUNCH((trunk_fwd2_kernel<VEC, 1, SAVE>), dim3(ope_cdiv(a.R, 16)), dim3(256), lds, st, a, Dp);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   return OPE_OK;
 }
@@ -456,11 +457,12 @@ static int launch_rep(const TrunkFwdArgs& base, const TrunkFwdArgs& a0, float* s
   float* wblk = scratch;
   float* wsum = scratch + (int64_t)OPE_H * NA;
   float* cst = wsum + OPE_H;
-  hipLaunchKernelGGL(trunk_rep_prep_kernel, dim3(OPE_H), dim3(64), 0, st, a0.theta, a0.L, D, R.S, wblk, wsum, cst);
+  OPE_LAUNCH(trunk_rep_prep_kernel, dim3(OPE_H), dim3(64), 0, st, a0.theta, a0.L, D, R.S, wblk, wsum, cst);
   {   // producer over the T*B base rows
     const int KC = (D + 15) >> 4, Dp = 16 * KC + 4;
     const size_t lds = (size_t)(16 * Dp + 16 * kActPitch + 4 * 16) * sizeof(float);
-    hipLaunchKernelGGL((trunk_fwd2_kernel<VEC, 1, false, 2>), dim3(ope_cdiv(base.R, 16)), dim3(256), lds, st, base, Dp);
+    kprof_work(2.0 * base.R * (double)D * OPE_H);     // first layer once per base row
+    OPE_LAUNCH((trunk_fwd2_kernel<VEC, 1, false, 2>), dim3(ope_cdiv(base.R, 16)), dim3(256), lds, st, base, Dp);
   }
   TrunkFwdArgs a = a0;
   a.rep.wblk = wblk; a.rep.wsum = wsum; a.rep.cst = cst;
@@ -473,7 +475,9 @@ static int launch_rep(const TrunkFwdArgs& base, const TrunkFwdArgs& a0, float* s
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute((const void*)trunk_fwd2_kernel<VEC, 2, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return OPE_ELAUNCH;
-    hipLaunchKernelGGL((trunk_fwd2_kernel<VEC, 2, true, 1>), dim3(ope_cdiv(a.R, TR)), dim3(256), lds, st, a, Dp);
+    // per copy: the A-column correction of the first layer + the remaining layers (the materialised form would be 2 R (D 64 + ...))
+    kprof_work(2.0 * a.R * ((double)R.A * OPE_H + OPE_H * OPE_H + (a.gi ? 3.0 * OPE_H * OPE_H : 0.0) + (a.head_out ? (double)OPE_H * a.head_dim : 0.0)));
+    OPE_LAUNCH((trunk_fwd2_kernel<VEC, 2, true, 1>), dim3(ope_cdiv(a.R, TR)), dim3(256), lds, st, a, Dp);
   }
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   return OPE_OK;
@@ -857,10 +861,11 @@ static int launch3(const TrunkFwdArgs& a, hipStream_t st) {
   const int ntiles = ope_cdiv(a.R, 16);
   static const int cap = getenv("OPE_TRUNK3_BLOCKS") ? atoi(getenv("OPE_TRUNK3_BLOCKS")) : 512;   // persistent: two workgroups per CU
   const int blocks = ntiles < cap ? ntiles : cap;
-  if (KC <= 8) hipLaunchKernelGGL((trunk_fwd3_kernel<VEC, 8, SAVE>), dim3(blocks), dim3(256), 0, st, a);
-  else if (KC <= 16) hipLaunchKernelGGL((trunk_fwd3_kernel<VEC, 16, SAVE>), dim3(blocks), dim3(256), 0, st, a);
-  else if (KC <= 24) hipLaunchKernelGGL((trunk_fwd3_kernel<VEC, 24, SAVE>), dim3(blocks), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((trunk_fwd3_kernel<VEC, 32, SAVE>), dim3(blocks), dim3(256), 0, st, a);
+  kprof_work(2.0 * a.R * ((double)a.D * OPE_H + OPE_H * OPE_H + (a.gi ? 3.0 * OPE_H * OPE_H : 0.0) + (a.head_out ? (double)OPE_H * a.head_dim : 0.0)));
+  if (KC <= 8) OPE_LAUNCH((trunk_fwd3_kernel<VEC, 8, SAVE>), dim3(blocks), dim3(256), 0, st, a);
+  else if (KC <= 16) OPE_LAUNCH((trunk_fwd3_kernel<VEC, 16, SAVE>), dim3(blocks), dim3(256), 0, st, a);
+  else if (KC <= 24) OPE_LAUNCH((trunk_fwd3_kernel<VEC, 24, SAVE>), dim3(blocks), dim3(256), 0, st, a);
+  else OPE_LAUNCH((trunk_fwd3_kernel<VEC, 32, SAVE>), dim3(blocks), dim3(256), 0, st, a);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   note_launch("trunk_fwd3", VEC, KC <= 8 ? 8 : (KC <= 16 ? 16 : (KC <= 24 ? 24 : 32)));
   return OPE_OK;

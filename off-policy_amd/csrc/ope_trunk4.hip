@@ -402,10 +402,11 @@ int launch_trunk_fwd_pair(const TrunkFwdArgs& live, const TrunkFwdArgs& tgt, int
   const int grid = cus & ~1;     // one workgroup per CU, even ones the live net, odd ones the target
   // Eight waves (two per SIMD, rows prefetched behind fc1). Measured against twelve waves without the prefetch (three per SIMD at the 168
   // register cap, 78 of them spilled): 59.5 us vs 107 us at 3s5z batch 32, so only this variant is built.
-  if (KC == 4) hipLaunchKernelGGL((trunk_fwd4_kernel<4, 8, true>), dim3(grid), dim3(512), 0, st, pa);
-  else if (KC == 8) hipLaunchKernelGGL((trunk_fwd4_kernel<8, 8, true>), dim3(grid), dim3(512), 0, st, pa);
-  else if (KC == 12) hipLaunchKernelGGL((trunk_fwd4_kernel<12, 8, true>), dim3(grid), dim3(512), 0, st, pa);
-  else hipLaunchKernelGGL((trunk_fwd4_kernel<16, 8, true>), dim3(grid), dim3(512), 0, st, pa);
+  kprof_work(2.0 * 2.0 * live.R * ((double)live.D * OPE_H + OPE_H * OPE_H + 3.0 * OPE_H * OPE_H));     // both nets
+  if (KC == 4) OPE_LAUNCH((trunk_fwd4_kernel<4, 8, true>), dim3(grid), dim3(512), 0, st, pa);
+  else if (KC == 8) OPE_LAUNCH((trunk_fwd4_kernel<8, 8, true>), dim3(grid), dim3(512), 0, st, pa);
+  else if (KC == 12) OPE_LAUNCH((trunk_fwd4_kernel<12, 8, true>), dim3(grid), dim3(512), 0, st, pa);
+  else OPE_LAUNCH((trunk_fwd4_kernel<16, 8, true>), dim3(grid), dim3(512), 0, st, pa);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   note_launch("trunk_fwd4", KC);
   return OPE_OK;

@@ -121,7 +121,8 @@ int launch_trunk_bwd3(const TrunkBwdArgs& a, hipStream_t st) {
   if (a.R < 1) return OPE_EINVAL;
   const int ntiles = ope_cdiv(a.R, 16);
   const int blocks = ntiles < 512 ? ntiles : 512;
-  hipLaunchKernelGGL(trunk_bwd3_kernel, dim3(blocks), dim3(256), 0, st, a);
+  kprof_work(2.0 * a.R * ((a.dgi ? 3.0 * OPE_H * OPE_H : 0.0) + OPE_H * OPE_H + (a.dout ? (double)a.hdim * OPE_H : 0.0)));
+  OPE_LAUNCH(trunk_bwd3_kernel, dim3(blocks), dim3(256), 0, st, a);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   note_launch("trunk_bwd3");
   return OPE_OK;

@@ -229,12 +229,17 @@ int launch_wgrad(const WgTable& tb, float* raw, hipStream_t st) {
     else if (P.lda % 2 == 0 && P.ldb % 2 == 0 && P.lda >= 4 && P.ldb >= 4 && !((uintptr_t)P.A & 7) && !((uintptr_t)P.B & 7)) v = 2;
     if (v < vec) vec = v;
   }
+  if (g_kprof_on) {
+    double fl = 0;
+    for (int q = 0; q < tb.n; ++q) fl += 2.0 * tb.p[q].M * (double)tb.p[q].N * tb.p[q].K;
+    kprof_work(fl);
+  }
   if (vec == 4)
-    hipLaunchKernelGGL(wgrad_kernel<4>, dim3(ope_cdiv(tb.total_waves, 4)), dim3(256), 0, st, tb, raw);
+    OPE_LAUNCH(wgrad_kernel<4>, dim3(ope_cdiv(tb.total_waves, 4)), dim3(256), 0, st, tb, raw);
   else if (vec == 2)
-    hipLaunchKernelGGL(wgrad_kernel<2>, dim3(ope_cdiv(tb.total_waves, 4)), dim3(256), 0, st, tb, raw);
+    OPE_LAUNCH(wgrad_kernel<2>, dim3(ope_cdiv(tb.total_waves, 4)), dim3(256), 0, st, tb, raw);
   else
-    hipLaunchKernelGGL(wgrad_kernel<1>, dim3(ope_cdiv(tb.total_waves, 4)), dim3(256), 0, st, tb, raw);
+    OPE_LAUNCH(wgrad_kernel<1>, dim3(ope_cdiv(tb.total_waves, 4)), dim3(256), 0, st, tb, raw);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   note_launch("wgrad", vec);
   return OPE_OK;
@@ -257,7 +262,8 @@ __global__ void split_reduce_kernel(SplitRed a) {
 }
 
 int launch_split_reduce(const SplitRed& a, hipStream_t st) {
-  hipLaunchKernelGGL(split_reduce_kernel, dim3(ope_cdiv(a.n0 + a.n1, 256)), dim3(256), 0, st, a);
+  kprof_work(0.0, 4.0 * ((double)a.n0 * (a.ns0 + 1) + (double)a.n1 * (a.ns1 + 1)));
+  OPE_LAUNCH(split_reduce_kernel, dim3(ope_cdiv(a.n0 + a.n1, 256)), dim3(256), 0, st, a);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   return OPE_OK;
 }
@@ -389,7 +395,7 @@ __global__ void fill_kernel(float* __restrict__ p, int64_t n, float v) {
   if (i < n) p[i] = v;
 }
 int launch_fill(float* p, int64_t n, float v, hipStream_t st) {
-  hipLaunchKernelGGL(fill_kernel, dim3(ope_cdiv(n, 256)), dim3(256), 0, st, p, n, v);
+  OPE_LAUNCH(fill_kernel, dim3(ope_cdiv(n, 256)), dim3(256), 0, st, p, n, v);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   return OPE_OK;
 }
@@ -397,7 +403,7 @@ int launch_fill(float* p, int64_t n, float v, hipStream_t st) {
 // dst[c][r] = src[r][c] for up to 4 matrices in one launch
 __global__ void transpose4_kernel(Transp4 a) { transpose4_element(a, blockIdx.x * blockDim.x + threadIdx.x); }
 int launch_transpose4(const Transp4& a, hipStream_t st) {
-  hipLaunchKernelGGL(transpose4_kernel, dim3(ope_cdiv(a.total, 256)), dim3(256), 0, st, a);
+  OPE_LAUNCH(transpose4_kernel, dim3(ope_cdiv(a.total, 256)), dim3(256), 0, st, a);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   return OPE_OK;
 }
@@ -416,7 +422,8 @@ int launch_finalize(const FinTable& ft0, const float* rsum, const float* theta, 
   const FinTable& ft = t;
   const int n_main = (int)ope_cdiv(ft.total, 256);
   // blocks [0, n_main): one thread per element; block n_main: the loss tail; the rest: one wave per column reduction
-  hipLaunchKernelGGL(finalize_kernel, dim3(finalize_blocks(ft)), dim3(256), 0, st, ft, rsum, theta, loss_part, n_loss_tiles, grad, n_main,
+  kprof_work(0.0, 4.0 * 3.0 * (double)ft.total);       // rsum + theta in, grad out (plus the small column reductions)
+  OPE_LAUNCH(finalize_kernel, dim3(finalize_blocks(ft)), dim3(256), 0, st, ft, rsum, theta, loss_part, n_loss_tiles, grad, n_main,
                      gsq_part);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   return OPE_OK;

@@ -47,6 +47,21 @@ def test_default_workload_line_has_roofline_and_cpu_baseline():
     assert rs["bound"] == "mfma" and rs["peak"] == 157.3 and rs["flop_per_step"] == 4 * 2 * (61 * 3 * 32 * (64 * 64 + 64 * 64 + 6 * 64 * 64 + 64 * 9)
                                                                                       + 60 * 32 * ((48 * 64 + 64 * 96) + (48 * 64 + 64 * 32) + 48 * 32 + (48 * 64 + 64) + (96 + 32)))
     assert abs(rs["frac"] - rs["achieved"] / rs["peak"]) < 1e-3 and abs(rs["achieved"] - rs["flop_per_step"] / out["ms_per_step"] / 1e9) < 0.02 * rs["achieved"]
+    # per-kernel table measured IN THIS RUN (hipExtLaunchKernel events on every libope launch + the launchers' stated work): the kernels of
+    # the step are there, their durations add up to about the step, every GEMM-shaped one has a fraction of the matrix roof
+    pk = rs["per_kernel"]
+    names = [k["kernel"] for k in pk["kernels"]]
+    for want in ("trunk_fwd", "gru_fwd4", "gru_bwd4", "wgrad_kernel", "mixer_fwd", "mixer_bwd4", "head_fwd_mfma", "episode_copy_kernel", "adam_kernel"):
+        assert any(want in n for n in names), (want, names)
+    assert 0.5 * 1e3 * out["ms_per_step"] <= pk["kernel_us_per_step"] <= 1.3 * 1e3 * out["ms_per_step"]
+    for k in pk["kernels"]:
+        assert k["avg_us"] > 0 and k["launches_per_step"] > 0
+        if k.get("bound") == "mfma":
+            assert 0 < k["frac"] <= 1.0 and abs(k["tflops"] - k["flop_per_launch"] / k["avg_us"] / 1e6) <= 0.02 * k["tflops"] + 0.01
+        if k.get("bound") == "hbm":
+            assert 0 < k["frac"] <= 1.0
+    # the launchers' own FLOP count agrees with SURVEY's closed form to a few percent (the head's q tiles and the bias sums differ)
+    assert abs(pk["launcher_stated_flop_per_step"] - rs["flop_per_step"]) <= 0.1 * rs["flop_per_step"]
 
 
 def test_gall_workload_line():
@@ -61,6 +76,10 @@ def test_maddpg_workload_line_graph_and_eager():
         out = run_bench("--workload", "maddpg_spread", "--steps", "8", "--warmup", "4", "--no-cpu-baseline", *extra)
         check_common(out, 8, 4)
         assert "MADDPG" in out["metric"] and "cpu_baseline" not in out
+        rs = out["roofline_step"]                       # BASELINE config 3 carries its whole-step roofline and per-kernel table too
+        assert rs is not None and rs["bound"] == "mfma" and rs["flop_per_step"] > 0 and 0 < rs["frac"] < 1
+        names = [k["kernel"] for k in rs["per_kernel"]["kernels"]]
+        assert any("ddpg_critic_tile_kernel" in n for n in names) and any("ddpg_actor_tile_kernel" in n for n in names), names
 
 
 @pytest.mark.parametrize("workload,batch", [("maddpg_spread", 256), ("rmatd3_3m", 128)])
