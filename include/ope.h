@@ -194,6 +194,11 @@ typedef struct ope_qmix_cfg {
                          *  registers, four waves per 16-row tile); 4 = both nets in one trunk_fwd4 launch (weights in LDS, one wave per
                          *  tile; recurrent nets whose input width is a multiple of 4 in (48, 64], (112, 128], (176, 192] or (240, 256] -- what "by shape"
                          *  picks from 16 384 rows on; other widths run path 3)                    */
+  int32_t chain_path;   /* the (t, b)-row chain between the GRU scan and its adjoint: 0 = by shape; 1 = four launches (head_fwd, mixer_fwd,
+                         *  mixer_bwd, head_bwd); 2 = two launches (mixer_hyp: the mixers' first hyper-layers, a GEMM on the state alone, +
+                         *  qchain: heads, second mixer stage, TD / loss, mixer and head adjoints; ope_chain.hip): whole steps (phase 0) of
+                         *  recurrent nets with <= 16 agents and <= 32 actions, state_dim <= 256 or mixer_path != 3, time_chunks = 1 -- what
+                         *  "by shape" picks; anything else with chain_path = 2 returns OPE_EINVAL)                                  */
 } ope_qmix_cfg;
 
 /* Flat parameter vector: the reference's named_parameters() order (agent q-network, then mixer; qmix.py:67-72),

@@ -78,7 +78,8 @@ class QMix(object):
         # trainers in one process do not share them. `mixer_path`: 1 resident-weight mixer, 2 streamed, 3 wide-state GEMM;
         # `time_chunks`: two-stream schedule; `scan_family` / `scan_waves`: GRU scan kernels; `debug`: keep intermediates.
         # `trunk_path`: 3 = one trunk launch per net (weights in registers), 4 = both nets in one launch (weights in LDS).
-        self.tune = dict(mixer_path=0, time_chunks=0, scan_family=0, scan_waves=0, debug=0, trunk_path=0)
+        # `chain_path`: 1 = head / mixer / TD / adjoints as four launches, 2 = the fused pair mixer_hyp + qchain (ope_chain.hip).
+        self.tune = dict(mixer_path=0, time_chunks=0, scan_family=0, scan_waves=0, debug=0, trunk_path=0, chain_path=0)
         self._ws = {}
         self._gsq = {}
         if self.multi:
@@ -288,6 +289,7 @@ class QMix(object):
         cfg.mixer_path, cfg.time_chunks = int(t["mixer_path"]), int(t["time_chunks"])
         cfg.scan_family, cfg.scan_waves, cfg.debug = int(t["scan_family"]), int(t["scan_waves"]), int(t["debug"])
         cfg.trunk_path = int(t["trunk_path"])
+        cfg.chain_path = int(t.get("chain_path", 0))
         return cfg
 
     def _workspace(self, cfg):

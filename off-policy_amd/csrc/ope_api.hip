@@ -23,6 +23,7 @@ bool cfg_ok(const ope_qmix_cfg* c) {
   if (c->phase < 0 || c->phase > 3) return false;
   if (c->mixer_path < 0 || c->mixer_path > 3 || c->time_chunks < 0 || c->time_chunks > kMaxChunksCfg) return false;
   if (c->trunk_path != 0 && c->trunk_path != 3 && c->trunk_path != 4) return false;
+  if (c->chain_path < 0 || c->chain_path > 2) return false;
   return d.n_agents >= 1 && d.act_dim >= 1 && d.obs_dim >= 1 && d.obs_dim <= 512 && d.state_dim >= 1 &&
          d.episode_length >= 1 && c->batch >= 1 && d.n_agents <= 64 && d.act_dim <= 200;
 }
@@ -79,6 +80,9 @@ struct Plan {
       rsum, q_all, loss_tot, ln_zero, ln_one, dh_carry, dbg, gsq_part, mix_slab;
   int n_gsq;
   bool wide;
+  bool chain;                   // the (t, b)-row chain runs as mixer_hyp + qchain (ope_chain.hip) instead of head_fwd / mixer_fwd / mixer_bwd / head_bwd
+  bool chain_can;               // ... could (shape, phase, schedule)
+  int64_t hb1, hw1_t, hw2_t, hb2_t, hb1_t;
 };
 
 thread_local char g_launch_log[2048];
@@ -209,6 +213,15 @@ void make_plan(const ope_qmix_cfg* c, Plan* p) {
   // wide-state mixer (ope_mixer_wide.hip): stream-K partial sums of the first hyper-layers
   p->wide = !c->vdn && c->phase != 1 && c->phase != 3 && (c->mixer_path == 3 || (c->mixer_path == 0 && p->S > kWideAutoS));
   p->mix_slab = p->wide ? W.add("mix_slab", wide_slab_floats((int)p->TB, p->S)) : -1;
+  // fused (t, b)-row chain: whole steps of one shared recurrent policy on one stream; the wide-state mixer keeps its stream-K GEMM path.
+  // ope_qmix_cfg.chain_path: 0 by shape (process default OPE_CHAIN = 1 | 0, read once), 1 the four separate kernels, 2 the fused pair
+  // (OPE_EINVAL from the step when the configuration cannot run it)
+  static const int chain_env = getenv("OPE_CHAIN") ? atoi(getenv("OPE_CHAIN")) : 1;
+  p->chain_can = c->phase == 0 && !c->mlp && p->chunks == 1 && !p->wide && qchain_shape_ok(p->N, p->A);
+  p->chain = p->chain_can && (c->chain_path == 2 || (c->chain_path == 0 && chain_env != 0));
+  p->hb1 = W.add("hb1", TB * OPE_MIX);
+  p->hw1_t = W.add("hw1_t", TB * OPE_HYP); p->hw2_t = W.add("hw2_t", TB * OPE_HYP); p->hb2_t = W.add("hb2_t", TB * OPE_HYP);
+  p->hb1_t = W.add("hb1_t", TB * OPE_MIX);
 }
 
 }  // namespace
@@ -331,6 +344,7 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
   Plan p;
   make_plan(cfg, &p);
   if (workspace_bytes < p.ws.total * (int64_t)sizeof(float)) return OPE_ENOSPC;
+  if (cfg->chain_path == 2 && !p.chain) return OPE_EINVAL;      // the fused chain was asked for explicitly and cannot run this configuration
   hipStream_t st = (hipStream_t)stream;
   float* W = (float*)workspace;
   int rc;
@@ -359,6 +373,27 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
   };
   if ((rc = sync_to(st, side))) return rc;   // fork: the side stream starts after the caller's prior work (the gather)
 
+  // transposed copies of the matrices the backward chains read column-wise: carried as extra workgroups by the head launch (separate
+  // kernels, MFMA head in one piece) or by the first-hyper-layer launch (fused chain), else one launch of their own
+  Transp4 tr;
+  memset(&tr, 0, sizeof(tr));
+  {
+    int nt = 0, tot = 0;
+    auto add = [&](const float* src, int rows, int cols, float* dst) {
+      tr.src[nt] = src; tr.dst[nt] = dst; tr.rows[nt] = rows; tr.cols[nt] = cols; tr.begin[nt] = tot; tot += rows * cols; ++nt;
+    };
+    if (!p.mlp && phase != 2) add(theta + p.AL.wih, 3 * OPE_H, OPE_H, W + p.thetaT);
+    if (phase != 2) add(theta + p.AL.fc2_w, OPE_H, OPE_H, W + p.thetaT + OPE_H * 3 * OPE_H);
+    if (!cfg->vdn && phase != 1) {
+      add(theta + p.ML.w1b_w, p.NM, OPE_HYP, W + p.mixT);
+      add(theta + p.ML.w2b_w, OPE_MIX, OPE_HYP, W + p.mixT + (int64_t)OPE_HYP * p.NM);
+    }
+    tr.n = nt; tr.total = tot;
+  }
+  TdArgs td;
+  td.B = p.B; td.N = p.N; td.gamma = cfg->gamma; td.use_huber = cfg->use_huber; td.huber_delta = cfg->huber_delta;
+  td.rewards = batch->rewards; td.dones_env = batch->dones_env; td.per_weights = cfg->use_per ? per_weights : nullptr;
+
   // ---- forward ----
   for (int c = 0; c < C && do_fwd; ++c) {
     const int64_t r0 = (int64_t)p.tb[c] * p.NB, rows = (int64_t)(p.tb[c + 1] - p.tb[c]) * p.NB;
@@ -375,6 +410,21 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
     tt.theta = theta_tgt; tt.gi = p.mlp ? nullptr : W + p.gi_t + r0 * 3 * OPE_H; tt.a2_out = p.mlp ? W + p.h_t + r0 * OPE_H : nullptr;
     if ((rc = launch_trunk_fwd_pair(tf, tt, cfg->trunk_path, st))) return rc;    // one launch for both nets where the shape allows it (ope_trunk4.hip)
     if (p.mlp) continue;
+    if (p.chain) {
+      // The mixers' first hyper-layers need the centralized state only: launched here, in front of the scan (whose launch leaves the
+      // matrix pipes idle), with the weight transposes of the backward kernels as passengers. VDN: only the transposes.
+      if (cfg->vdn) {
+        if ((rc = launch_transpose4(tr, st))) return rc;
+      } else {
+        HypFirstArgs hy;
+        memset(&hy, 0, sizeof(hy));
+        hy.TB = (int)p.TB; hy.B = p.B; hy.S = p.S; hy.theta0 = theta; hy.theta1 = theta_tgt; hy.L = p.ML; hy.share = batch->share_obs;
+        hy.hw1[0] = W + p.hw1; hy.hw2[0] = W + p.hw2; hy.hb2[0] = W + p.hb2; hy.hb1[0] = W + p.hb1;
+        hy.hw1[1] = W + p.hw1_t; hy.hw2[1] = W + p.hw2_t; hy.hb2[1] = W + p.hb2_t; hy.hb1[1] = W + p.hb1_t;
+        hy.side = tr;
+        if ((rc = launch_mixer_hyp(hy, st))) return rc;
+      }
+    }
     hipStream_t scan_st = side;
     if ((rc = sync_to(st, side))) return rc;
     GruFwdArgs gf;   // live + target in one launch
@@ -389,27 +439,29 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
     if ((rc = launch_gru_fwd(gf, scan_st))) return rc;
     if (C > 1 && hipEventRecord(sp->scan_done[c], side) != hipSuccess) return OPE_ELAUNCH;
   }
-  // transposed copies of the matrices the backward chains read column-wise: carried by the head launch as extra
-  // workgroups when that is the MFMA head kernel in one piece, else one launch of their own
-  Transp4 tr;
-  memset(&tr, 0, sizeof(tr));
-  {
-    int nt = 0, tot = 0;
-    auto add = [&](const float* src, int rows, int cols, float* dst) {
-      tr.src[nt] = src; tr.dst[nt] = dst; tr.rows[nt] = rows; tr.cols[nt] = cols; tr.begin[nt] = tot; tot += rows * cols; ++nt;
-    };
-    if (!p.mlp && phase != 2) add(theta + p.AL.wih, 3 * OPE_H, OPE_H, W + p.thetaT);
-    if (phase != 2) add(theta + p.AL.fc2_w, OPE_H, OPE_H, W + p.thetaT + OPE_H * 3 * OPE_H);
-    if (!cfg->vdn && phase != 1) {
-      add(theta + p.ML.w1b_w, p.NM, OPE_HYP, W + p.mixT);
-      add(theta + p.ML.w2b_w, OPE_MIX, OPE_HYP, W + p.mixT + (int64_t)OPE_HYP * p.NM);
-    }
-    tr.n = nt; tr.total = tot;
-  }
   const bool ride = C == 1 && p.A <= 32 && do_fwd;       // launch_head_fwd(mode 0) picks head_fwd_mfma for A <= 32
-  if (!ride && tr.n > 0 && phase != 3)
+  if (!ride && !p.chain && tr.n > 0 && phase != 3)
     if ((rc = launch_transpose4(tr, st))) return rc;
-  for (int c = 0; c < C && do_fwd; ++c) {   // heads of chunk c as soon as its scan is done
+  if (p.chain) {
+    ChainArgs ca;
+    memset(&ca, 0, sizeof(ca));
+    ca.TB = (int)p.TB; ca.B = p.B; ca.N = p.N; ca.T = p.T; ca.A = p.A; ca.NB = p.NB; ca.vdn = cfg->vdn; ca.double_q = cfg->use_double_q;
+    ca.theta0 = theta; ca.theta1 = theta_tgt; ca.AL = p.AL; ca.ML = p.ML; ca.mixT = W + p.mixT;
+    ca.h0 = W + p.h; ca.h1 = W + p.h_t; ca.acts = batch->acts; ca.avail = batch->avail_acts;
+    ca.hw1[0] = W + p.hw1; ca.hw2[0] = W + p.hw2; ca.hb2[0] = W + p.hb2; ca.hb1[0] = W + p.hb1;
+    ca.hw1[1] = W + p.hw1_t; ca.hw2[1] = W + p.hw2_t; ca.hb2[1] = W + p.hb2_t; ca.hb1[1] = W + p.hb1_t;
+    ca.td = td;
+    ca.xhat_o = W + p.xhat_o; ca.rstd_o = W + p.rstd_o; ca.act_idx = (int*)(W + p.act_idx);
+    ca.loss_part = W + p.loss_part; ca.err_abs = W + p.err_abs; ca.dqtot = W + p.dqtot;
+    ca.d_v1 = W + p.d_v1; ca.d_v2 = W + p.d_v2; ca.d_b1 = W + p.d_b1; ca.d_hw1 = W + p.d_hw1; ca.d_hw2 = W + p.d_hw2; ca.d_hb2 = W + p.d_hb2;
+    ca.dh_out = W + p.dh_out; ca.dqoh = W + p.dqoh;
+    if (dbg_on) {      // what the separate kernels leave in the workspace anyway: tests and tools read them
+      ca.q_all = W + p.q_all; ca.agent_q = W + p.agent_q; ca.agent_nq = W + p.agent_nq; ca.qtot = W + p.qtot; ca.nqtot = W + p.nqtot;
+      ca.v1 = W + p.v1; ca.v2 = W + p.v2; ca.hpre = W + p.hpre; ca.d_agent_q = W + p.d_agent_q;
+    }
+    if ((rc = launch_qchain(ca, st))) return rc;
+  }
+  for (int c = 0; c < C && do_fwd && !p.chain; ++c) {   // heads of chunk c as soon as its scan is done
     if (C > 1 && hipStreamWaitEvent(st, sp->scan_done[c], 0) != hipSuccess) return OPE_ELAUNCH;
     HeadFwdArgs hf;
     memset(&hf, 0, sizeof(hf));
@@ -425,10 +477,7 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
   if (phase == 1) return OPE_OK;
 
   // ---- mixer forward + TD + mixer backward ----
-  TdArgs td;
-  td.B = p.B; td.N = p.N; td.gamma = cfg->gamma; td.use_huber = cfg->use_huber; td.huber_delta = cfg->huber_delta;
-  td.rewards = batch->rewards; td.dones_env = batch->dones_env; td.per_weights = cfg->use_per ? per_weights : nullptr;
-  if (!do_mix) {
+  if (!do_mix || p.chain) {
   } else if (cfg->vdn) {
     VdnArgs va;
     va.TB = (int)p.TB; va.N = p.N; va.td = td; va.agent_q = W + p.agent_q; va.agent_nq = W + p.agent_nq;
@@ -459,7 +508,7 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
   hb.no_ln = p.mlp;
   hb.xhat_o = W + p.xhat_o; hb.rstd_o = W + p.rstd_o; hb.act_idx = (const int*)(W + p.act_idx); hb.d_agent_q = W + p.d_agent_q;
   hb.dh_out = W + p.dh_out; hb.dqoh = W + p.dqoh;
-  if (do_bwd)
+  if (do_bwd && !p.chain)
     if ((rc = launch_head_bwd(hb, st))) return rc;
   if ((rc = sync_to(st, side))) return rc;
 

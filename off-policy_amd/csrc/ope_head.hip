@@ -16,77 +16,10 @@
 //   * 2 416 waves (3s5z) instead of 604.
 #include <stdlib.h>
 
-#include "ope_agent.h"
+#include "ope_rowops.h"
 
 namespace ope {
 namespace {
-
-constexpr float kNegInf = -3.0e38f;
-
-// LayerNorm (or copy, no_ln) of this lane's 16 features of row `hrow`; optionally saves xhat / rstd (g == 0 stores rstd)
-__device__ __forceinline__ void ln_row16(const float* __restrict__ hrow, const float* __restrict__ th, int lno_w, int lno_b, bool no_ln,
-                                         int g, f32x4 (&y)[4], float* xhat_out, float* rstd_out) {
-  float s = 0.f;
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    y[c] = *reinterpret_cast<const f32x4*>(hrow + 16 * c + 4 * g);
-    s += (y[c][0] + y[c][1]) + (y[c][2] + y[c][3]);
-  }
-  if (no_ln) return;
-  const float mu = rowsum4(s) * (1.0f / OPE_H);
-  float v = 0.f;
-#pragma unroll
-  for (int c = 0; c < 4; ++c)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float d = y[c][r] - mu;
-      v = fmaf(d, d, v);
-    }
-  const float rstd = 1.0f / sqrtf(rowsum4(v) * (1.0f / OPE_H) + OPE_LN_EPS);
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const f32x4 gm = *reinterpret_cast<const f32x4*>(th + lno_w + 16 * c + 4 * g);
-    const f32x4 bt = *reinterpret_cast<const f32x4*>(th + lno_b + 16 * c + 4 * g);
-    f32x4 xh;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      xh[r] = (y[c][r] - mu) * rstd;
-      y[c][r] = fmaf(xh[r], gm[r], bt[r]);
-    }
-    if (xhat_out) *reinterpret_cast<f32x4*>(xhat_out + 16 * c + 4 * g) = xh;
-  }
-  if (rstd_out && g == 0) *rstd_out = rstd;
-}
-
-// q[16 it + 4g + r] of row j for it < NT: bias + W_q y on the matrix pipe
-template <int NT>
-__device__ __forceinline__ void q_tiles(const float* __restrict__ th, const AgentLayout& L, int A, int j, int g, const f32x4 (&y)[4],
-                                        f32x4 (&q)[NT]) {
-#pragma unroll
-  for (int it = 0; it < NT; ++it) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) q[it][r] = (16 * it + 4 * g + r < A) ? th[L.q_b + 16 * it + 4 * g + r] : 0.f;
-    const int m = 16 * it + j;                       // weight row of the A operand held by this lane
-    const float* __restrict__ wrow = th + L.q_w + (int64_t)(m < A ? m : A - 1) * OPE_H + 4 * g;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      f32x4 w = *reinterpret_cast<const f32x4*>(wrow + 16 * c);
-      if (m >= A) w = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int r = 0; r < 4; ++r) q[it] = mfma16(w[r], y[c][r], q[it]);
-    }
-  }
-}
-
-// (value, index) maximum over the 4 lanes of a row: greater value wins, equal values -> lower index (first max)
-__device__ __forceinline__ void row_argmax4(float& v, int& k) {
-#pragma unroll
-  for (int off = 16; off <= 32; off <<= 1) {
-    const float ov = __shfl_xor(v, off, 64);
-    const int ok = __shfl_xor(k, off, 64);
-    if (ov > v || (ov == v && ok < k)) { v = ov; k = ok; }
-  }
-}
 
 template <int NT>
 __global__ void __launch_bounds__(256) head_fwd_mfma_kernel(HeadFwdArgs a) {

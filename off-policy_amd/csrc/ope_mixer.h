@@ -79,6 +79,41 @@ struct VdnArgs {
   float* loss_part; float* err_abs; float* d_agent_q;
 };
 
+// ---- fused (t, b)-row chain (ope_chain.hip) -----------------------------------------------------------------------------------------
+// First hyper-network layers of both nets over the T*B rows: a GEMM on the centralized state alone (no dependence on the agent networks)
+struct HypFirstArgs {
+  int TB, B, S;
+  const float* theta0; const float* theta1;   // live / target flat parameters (MixerLayout offsets)
+  MixerLayout L;
+  const float* share;                         // [T+1][B][S]
+  float* hw1[2]; float* hw2[2]; float* hb2[2];   // [TB][64] post-ReLU hidden layers of hyper_w1 / hyper_w2 / hyper_b2, [0] live on s_t, [1] target on s_{t+1}
+  float* hb1[2];                              // [TB][32] hyper_b1 output
+  Transp4 side;                               // weight transposes carried as extra workgroups (side.total = 0: none)
+  int main_blocks;                            // set by the launcher
+};
+// Agent q heads + chosen / target selection + second mixer stage of both nets + TD / loss + mixer adjoint + head adjoint, one launch
+struct ChainArgs {
+  int TB, B, N, T, A, NB;
+  int vdn, double_q;
+  const float* theta0; const float* theta1;   // full flat vectors [agent | mixer] of the live / target nets
+  AgentLayout AL; MixerLayout ML;
+  const float* mixT;                          // live w1bT [64][N*32] then w2bT [64][32]
+  const float* h0; const float* h1;           // GRU states [T+1][N*B][64] of the live / target net
+  const float* acts; const float* avail;      // [T][N*B][A] one-hot, [T+1][N*B][A] or null
+  const float* hw1[2]; const float* hw2[2]; const float* hb2[2]; const float* hb1[2];   // HypFirstArgs outputs
+  TdArgs td;
+  // saved for the BPTT / trunk adjoint / weight-gradient kernels that follow
+  float* xhat_o; float* rstd_o; int* act_idx;
+  float* loss_part; float* err_abs; float* dqtot;
+  float* d_v1; float* d_v2; float* d_b1; float* d_hw1; float* d_hw2; float* d_hb2;
+  float* dh_out; float* dqoh;
+  // test / debug outputs (null unless ope_qmix_cfg.debug)
+  float* q_all; float* agent_q; float* agent_nq; float* qtot; float* nqtot; float* v1; float* v2; float* hpre; float* d_agent_q;
+};
+bool qchain_shape_ok(int N, int A);
+int launch_mixer_hyp(const HypFirstArgs& a, hipStream_t st);
+int launch_qchain(const ChainArgs& a, hipStream_t st);
+
 int launch_mixer_fwd(const MixerFwdArgs& a, hipStream_t st);
 int launch_mixer_bwd(const MixerBwdArgs& a, hipStream_t st);
 int launch_vdn(const VdnArgs& a, hipStream_t st);

@@ -8,26 +8,9 @@
 // contraction, ELU, |w2| dot and b2 follow with the agents split over the waves (4 lanes share a row: two cross-lane adds).
 #include <stdlib.h>
 
-#include "ope_mixer.h"
+#include "ope_rowops.h"
 
 namespace ope {
-
-__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }
-__device__ __forceinline__ float sgn(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
-
-// first hyper-layers: tiles 0-3 hyper_w1.0, 4-7 hyper_w2.0, 8-11 hyper_b2.0, 12-13 hyper_b1
-__device__ __forceinline__ const float* stageA_row(const float* th, const MixerLayout& L, int S, int it, int i) {
-  if (it < 4) return th + L.w1a_w + (int64_t)(16 * it + i) * S;
-  if (it < 8) return th + L.w2a_w + (int64_t)(16 * (it - 4) + i) * S;
-  if (it < 12) return th + L.b2a_w + (int64_t)(16 * (it - 8) + i) * S;
-  return th + L.b1_w + (int64_t)(16 * (it - 12) + i) * S;
-}
-__device__ __forceinline__ const float* stageA_bias(const float* th, const MixerLayout& L, int it) {
-  if (it < 4) return th + L.w1a_b + 16 * it;
-  if (it < 8) return th + L.w2a_b + 16 * (it - 4);
-  if (it < 12) return th + L.b2a_b + 16 * (it - 8);
-  return th + L.b1_b + 16 * (it - 12);
-}
 
 // ---------------------------------------------------------------------------------------------------------
 // mixer_fwd, workgroup-cooperative form. (One wave per 16 rows was ~600 waves for 3s5z/B=32 -- 0.6 per SIMD -- each a
@@ -569,44 +552,6 @@ int launch_mixer_fwd(const MixerFwdArgs& a0, hipStream_t st) {
   else launch_mixer2<1>(a, st);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   return OPE_OK;
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// TD target, masked error, loss terms and dQ_tot for one (t,b) row (qmix.py:158-176). The loss is NOT divided by
-// the mask count here: gradients are those of the un-normalised sum (ope.h), so data-parallel ranks can add them.
-// ---------------------------------------------------------------------------------------------------------
-struct TdOut { float err, keep, lossel, dq; };
-__device__ __forceinline__ TdOut td_row(const TdArgs& d, int t, int b, float qtot, float nqtot) {
-  TdOut o;
-  const float bad = t == 0 ? 0.f : d.dones_env[(int64_t)(t - 1) * d.B + b];
-  o.keep = 1.0f - bad;
-  const float rew = d.rewards[((int64_t)t * d.N + 0) * d.B + b];   // agents share the reward: agent 0 (qmix.py:159)
-  const float den = d.dones_env[(int64_t)t * d.B + b];
-  const float target = rew + (1.0f - den) * d.gamma * nqtot;
-  const float e = (qtot - target) * o.keep;
-  o.err = e;
-  const float wgt = d.per_weights ? d.per_weights[b] : 1.0f;
-  float fe, dfe;
-  if (d.use_huber) {
-    const float ae = fabsf(e), dl = d.huber_delta;
-    if (ae <= dl) { fe = e * e * 0.5f; dfe = e; }
-    else { fe = dl * (ae - dl * 0.5f); dfe = dl * sgn(e); }
-  } else {
-    fe = e * e;
-    dfe = 2.0f * e;
-  }
-  o.lossel = wgt * fe;
-  o.dq = wgt * dfe * o.keep;
-  return o;
-}
-
-// sum over the 16 rows (lanes j) of a wave-tile; result valid in every lane
-__device__ __forceinline__ float tilesum16(float x) {
-  x += __shfl_xor(x, 1, 64);
-  x += __shfl_xor(x, 2, 64);
-  x += __shfl_xor(x, 4, 64);
-  x += __shfl_xor(x, 8, 64);
-  return x;
 }
 
 // Mixer adjoint: a 16-row tile spread over the 4 waves of a workgroup. (One wave per tile was 300 waves at 3s5z, each a

