@@ -179,7 +179,7 @@ def self_spawn(a):
     mp.spawn(_spawned_rank, args=(a.gpus, port, sys.argv[1:]), nprocs=a.gpus, join=True)
 
 
-def timed_steps(one_step, steps, warmup, world, dev, _retry=True):
+def timed_steps(one_step, steps, warmup, world, dev, _retry=True, on_fallback=None):
     """W untimed warm-up steps, then EXACTLY K steps bracketed by barrier + synchronize on both sides; seconds = MAX over ranks."""
     for _ in range(warmup):
         one_step(None)
@@ -204,6 +204,8 @@ def timed_steps(one_step, steps, warmup, world, dev, _retry=True):
             # a rank gave up waiting for a peer inside the one-shot all-reduce (verified at set-up, so this is a transient):
             # the timing is invalid. Fall back to RCCL on every rank and measure again rather than report a wrong number.
             opdist.disable_fast_allreduce("timed out during the run")
+            if on_fallback is not None:
+                on_fallback()      # a captured graph holds launches of the retired exchange: the caller drops it and steps eagerly on RCCL
             if int(os.environ.get("RANK", "0")) == 0:
                 print("[bench] one-shot all-reduce timed out; repeating the leg on RCCL", file=sys.stderr)
             return timed_steps(one_step, steps, warmup, world, dev, _retry=False)
@@ -212,11 +214,11 @@ def timed_steps(one_step, steps, warmup, world, dev, _retry=True):
     return elapsed, info
 
 
-def timed_windows(one_step, steps, warmup, world, dev, repeats):
+def timed_windows(one_step, steps, warmup, world, dev, repeats, on_fallback=None):
     """`repeats` consecutive K-step windows (each timed as timed_steps does); returns (sorted-independent list of seconds, info)."""
     times, info = [], None
     for r in range(max(1, repeats)):
-        el, info = timed_steps(one_step, steps, warmup if r == 0 else 0, world, dev)
+        el, info = timed_steps(one_step, steps, warmup if r == 0 else 0, world, dev, on_fallback=on_fallback)
         times.append(el)
     return times, info
 
@@ -599,26 +601,33 @@ def main_ddpg(a):
         # only when that divides both counts, so that exactly --steps steps are timed
         spr = a.steps_per_replay if ((dev_sampling or (per and use_graph)) and a.steps % a.steps_per_replay == 0 and a.warmup % a.steps_per_replay == 0) else 1
         graphed = trainer.make_graphed_step(buf, local_batch, device_sampling=dev_sampling, steps_per_replay=spr) if use_graph else None
+        G = {"graphed": graphed}       # (dropped by drop_graph if the exchange it captured is retired during the run)
+
+        def drop_graph():
+            G["graphed"] = None
 
         def one_step(i=None):
+            g = G["graphed"]
             if per:
-                if graphed is not None:
-                    return graphed(0.5)        # priority sample + gather + updates + priorities written back: one graph launch
+                if g is not None:
+                    return g(0.5)              # priority sample + gather + updates + priorities written back: one graph launch
                 batch_ = buf.sample(local_batch, beta=0.5, p_id="policy_0")
                 info, prio, idx = trainer.shared_train_policy_on_batch("policy_0", batch_)
                 buf.update_priorities(idx, prio, p_id="policy_0")
                 policy.soft_target_updates()
                 return info
-            if dev_sampling:
-                return graphed()               # sample (drawn in the gather kernel) + critic + actor + soft target updates: one graph launch
-            inds = opdist.shard_indices(np.random.choice(len(buf), global_batch), rank, world)
-            if graphed is not None:
-                return graphed(inds)           # gather + critic update + actor update + soft target updates: one graph launch
-            s_ = pbuf.sample_inds(inds, timing_events=ev[i] if i is not None else None)
-            info, _, _ = trainer.shared_train_policy_on_batch("policy_0", tuple({"policy_0": x} for x in s_) + (None, None))
-            policy.soft_target_updates()
+            if dev_sampling and g is not None:
+                return g()                     # sample (drawn in the gather kernel) + critic + actor + soft target updates: one graph launch
+            info = None
+            for _ in range(spr if (g is None and graphed is not None) else 1):      # (after drop_graph a call still stands for `spr` steps)
+                inds = opdist.shard_indices(np.random.choice(len(buf), global_batch), rank, world)
+                if g is not None:
+                    return g(inds)             # gather + critic update + actor update + soft target updates: one graph launch
+                s_ = pbuf.sample_inds(inds, timing_events=ev[i] if (i is not None and graphed is None) else None)
+                info, _, _ = trainer.shared_train_policy_on_batch("policy_0", tuple({"policy_0": x} for x in s_) + (None, None))
+                policy.soft_target_updates()
             return info
-        windows, info = timed_windows(one_step, a.steps // spr, a.warmup // spr, world, dev, a.repeats)      # spr steps per call
+        windows, info = timed_windows(one_step, a.steps // spr, a.warmup // spr, world, dev, a.repeats, on_fallback=drop_graph)      # spr steps per call
         elapsed = median_window(windows)
         if graphed is not None or per:    # the gather inside the graph (or behind the priority sample) carries no events: time the same launch on its own afterwards
             ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(50)]

@@ -197,8 +197,9 @@ typedef struct ope_qmix_cfg {
   int32_t chain_path;   /* the (t, b)-row chain between the GRU scan and its adjoint: 0 = by shape; 1 = four launches (head_fwd, mixer_fwd,
                          *  mixer_bwd, head_bwd); 2 = two launches (mixer_hyp: the mixers' first hyper-layers, a GEMM on the state alone, +
                          *  qchain: heads, second mixer stage, TD / loss, mixer and head adjoints; ope_chain.hip): whole steps (phase 0) of
-                         *  recurrent nets with <= 16 agents and <= 32 actions, state_dim <= 256 or mixer_path != 3, time_chunks = 1 -- what
-                         *  "by shape" picks; anything else with chain_path = 2 returns OPE_EINVAL)                                  */
+                         *  recurrent nets with <= 16 agents and <= 32 actions, mixer_path != 3, time_chunks = 1 -- what "by shape" picks for
+                         *  state_dim <= 512 (wider states: the stream-K GEMM of mixer_path 3 + the four launches); any other configuration
+                         *  with chain_path = 2 returns OPE_EINVAL)                                  */
 } ope_qmix_cfg;
 
 /* Flat parameter vector: the reference's named_parameters() order (agent q-network, then mixer; qmix.py:67-72),

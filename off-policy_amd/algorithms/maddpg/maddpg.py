@@ -102,6 +102,9 @@ class MADDPG(object):
             raise NotImplementedError("cent_train_policy_on_batch with several policies is not on the accelerated path")
         if policy.num_q != 1:
             raise NotImplementedError("cent_train_policy_on_batch with two critic heads (MATD3): upstream defines no rule for them (maddpg.py:295)")
+        if getattr(self.args, "use_value_active_masks", False):
+            raise NotImplementedError("cent_train_policy_on_batch with use_value_active_masks: upstream weights the critic loss by the valid-transition "
+                                      "mask there (maddpg.py:314-317, 327-330); the accelerated path takes the plain mean over the N*B rows")
         dev = self.device
         t = lambda x: None if x is None else torch.as_tensor(np.asarray(x) if not torch.is_tensor(x) else x, dtype=torch.float32).to(dev)
         obs, cent, acts, rew = t(obs_b[pid]), t(cent_b[pid]), t(act_b[pid]), t(rew_b[pid])
@@ -306,10 +309,10 @@ class MADDPG(object):
         assert steps_per_replay == 1 or device_sampling or self.use_per, "several steps per replay need the indices drawn on the device"
         if self.use_per and (opdist.is_distributed() or not getattr(buffer, "device_tree", False)):
             raise NotImplementedError("graphed prioritized step: one process, device trees (PrioritizedMlpReplayBuffer(device_tree=True))")
-        if opdist.is_distributed() and not opdist.graph_safe_allreduce():
-            raise NotImplementedError("graphed step at world > 1 needs the one-shot all-reduce (%s)" % opdist.allreduce_backend())
         pid = policy_id
         policy, pbuf = self.policies[pid], buffer.policy_buffers[pid]
+        if opdist.is_distributed() and not opdist.graph_safe_allreduce(max(policy.critic.padded_numel, policy.actor.padded_numel) + 4):
+            raise NotImplementedError("graphed step at world > 1 needs the one-shot all-reduce with slots that hold the gradient vectors (%s)" % opdist.allreduce_backend())
         B = int(batch_size)
         # `update_actor` is decided on the HOST (num_updates % actor_update_interval, maddpg.py:100) while the graph is being
         # captured, so the captured launch sequence fixes the actor cadence: it is the eager one only if a replay holds whole
@@ -384,8 +387,17 @@ class MADDPG(object):
             opt.step_count = int(opt.step_dev[0].item())
         ring = [(torch.empty(B, dtype=torch.int64).pin_memory(), torch.cuda.Event()) for _ in range(8)]
         state = {"k": 0, "used": [False] * 8}
+        # at world > 1 the graph holds launches of the one-shot exchange, i.e. raw pointers into its local and peer buffers: it may only be
+        # replayed while that exchange is the one in use (dist.disable_fast_allreduce retires it)
+        ar_gen = opdist.note_graph_capture() if opdist.is_distributed() else None
+
+        def check_exchange():
+            if ar_gen is not None and opdist.fast_generation() != ar_gen:
+                raise RuntimeError("this graphed step captured the one-shot all-reduce, which has since been disabled (%s): build a new "
+                                   "graphed step or train eagerly" % opdist.allreduce_backend())
 
         def step_sampled(beta=None):
+            check_exchange()
             if self.use_per:
                 assert beta is not None and beta > 0, "prioritized graphed step: pass the current beta"
                 beta_dev.fill_(float(beta))
@@ -397,6 +409,7 @@ class MADDPG(object):
             return info
 
         def step(inds):
+            check_exchange()
             k = state["k"]
             state["k"] = (k + 1) % 8
             host, ev = ring[k]

@@ -81,6 +81,7 @@ class QMix(object):
         # `chain_path`: 1 = head / mixer / TD / adjoints as four launches, 2 = the fused pair mixer_hyp + qchain (ope_chain.hip).
         self.tune = dict(mixer_path=0, time_chunks=0, scan_family=0, scan_waves=0, debug=0, trunk_path=0, chain_path=0)
         self._ws = {}
+        self._ws_multi = {}
         self._gsq = {}
         if self.multi:
             self._init_multi()
@@ -186,7 +187,9 @@ class QMix(object):
         return cfg
 
     def _ws_for(self, key, cfg):
-        if key not in self._ws:
+        # (its own cache, keyed by everything the workspace plan depends on: `_workspace` below replaces its dict when the plan changes)
+        key = key + (cfg.mixer_path, cfg.time_chunks, cfg.chain_path)
+        if key not in self._ws_multi:
             need = _lib.lib.ope_qmix_workspace_bytes(C.byref(cfg))
             if need < 0:
                 _lib.check(int(need), "ope_qmix_workspace_bytes")
@@ -197,8 +200,8 @@ class QMix(object):
                 n = C.c_int64(0)
                 o = _lib.lib.ope_qmix_workspace_find(C.byref(cfg), name.encode(), C.byref(n))
                 views[name] = ws[o:o + 4 * n.value].view(torch.float32).view(cfg.dims.episode_length, cfg.batch, cfg.dims.n_agents)
-            self._ws[key] = (ws, views)
-        return self._ws[key]
+            self._ws_multi[key] = (ws, views)
+        return self._ws_multi[key]
 
     def _train_multi(self, parts, share, rew, dones_env, importance_weights, idxes):
         """One update with several policies. parts[pid] = (obs [T+1, n_p, B, D_p], acts [T, n_p, B, A_p], avail or None) in the
@@ -294,7 +297,7 @@ class QMix(object):
 
     def _workspace(self, cfg):
         B = cfg.batch
-        shape_key = (cfg.mixer_path, cfg.time_chunks)       # the workspace plan depends on these two
+        shape_key = (cfg.mixer_path, cfg.time_chunks, cfg.chain_path)       # the workspace plan depends on these
         if self._ws.get("_key") != shape_key:
             self._ws = {"_key": shape_key}
             self._gsq = {}

@@ -110,6 +110,9 @@ class R_MADDPG(object):
         if self.use_per:
             raise NotImplementedError("cent_train_policy_on_batch returns N*B priorities for B indices upstream (r_maddpg.py:447-449), "
                                       "which the buffer rejects: uniform replay only")
+        if getattr(self.args, "use_value_active_masks", False):
+            raise NotImplementedError("cent_train_policy_on_batch with use_value_active_masks: upstream weights the critic loss by the agents' "
+                                      "active masks there (r_maddpg.py:418-498); the accelerated path takes the plain masked mean")
         policy = self.policies[pid]
         obs = self._to_device_layout(obs_b[pid], True)                      # [T+1, N, B, D]
         cent = self._to_device_layout(cent_b[pid], True)                    # [T+1, N, B, S]

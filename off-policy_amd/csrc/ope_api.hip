@@ -211,14 +211,18 @@ void make_plan(const ope_qmix_cfg* c, Plan* p) {
   p->q_all = W.add("q_all", R * p->A);
   p->dbg = W.add("dbg", 2 * 16 * 4096 + 2 * 16 * 2400);   // per-wave s_memtime stamps (ope_set_debug)
   // wide-state mixer (ope_mixer_wide.hip): stream-K partial sums of the first hyper-layers
-  p->wide = !c->vdn && c->phase != 1 && c->phase != 3 && (c->mixer_path == 3 || (c->mixer_path == 0 && p->S > kWideAutoS));
-  p->mix_slab = p->wide ? W.add("mix_slab", wide_slab_floats((int)p->TB, p->S)) : -1;
-  // fused (t, b)-row chain: whole steps of one shared recurrent policy on one stream; the wide-state mixer keeps its stream-K GEMM path.
-  // ope_qmix_cfg.chain_path: 0 by shape (process default OPE_CHAIN = 1 | 0, read once), 1 the four separate kernels, 2 the fused pair
-  // (OPE_EINVAL from the step when the configuration cannot run it)
+  // fused (t, b)-row chain: whole steps of one shared recurrent policy on one stream. ope_qmix_cfg.chain_path: 0 by shape (process default
+  // OPE_CHAIN = 1 | 0, read once), 1 the four separate kernels, 2 the fused pair (OPE_EINVAL from the step when the configuration cannot run
+  // it). Its first-hyper-layer kernel streams the weights per 16-row wave (fine up to MMM2's S = 322); for the really wide states
+  // (--use_global_all_local_state: S = 2 232) "by shape" keeps the stream-K GEMM + the separate kernels.
   static const int chain_env = getenv("OPE_CHAIN") ? atoi(getenv("OPE_CHAIN")) : 1;
-  p->chain_can = c->phase == 0 && !c->mlp && p->chunks == 1 && !p->wide && qchain_shape_ok(p->N, p->A);
-  p->chain = p->chain_can && (c->chain_path == 2 || (c->chain_path == 0 && chain_env != 0));
+  constexpr int kChainAutoS = 512;
+  p->chain_can = c->phase == 0 && !c->mlp && p->chunks == 1 && c->mixer_path != 3 && qchain_shape_ok(p->N, p->A);
+  // (more than 8 agents = two per wave of the chain kernel, without the register prefetch: measured 0.6091 vs 0.6048 ms at QMIX-MMM2 -- not
+  // picked by shape)
+  p->chain = p->chain_can && (c->chain_path == 2 || (c->chain_path == 0 && chain_env != 0 && p->N <= 8 && (c->vdn || p->S <= kChainAutoS)));
+  p->wide = !c->vdn && !p->chain && c->phase != 1 && c->phase != 3 && (c->mixer_path == 3 || (c->mixer_path == 0 && p->S > kWideAutoS));
+  p->mix_slab = p->wide ? W.add("mix_slab", wide_slab_floats((int)p->TB, p->S)) : -1;
   p->hb1 = W.add("hb1", TB * OPE_MIX);
   p->hw1_t = W.add("hw1_t", TB * OPE_HYP); p->hw2_t = W.add("hw2_t", TB * OPE_HYP); p->hb2_t = W.add("hb2_t", TB * OPE_HYP);
   p->hb1_t = W.add("hb1_t", TB * OPE_MIX);
@@ -394,6 +398,7 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
   td.B = p.B; td.N = p.N; td.gamma = cfg->gamma; td.use_huber = cfg->use_huber; td.huber_delta = cfg->huber_delta;
   td.rewards = batch->rewards; td.dones_env = batch->dones_env; td.per_weights = cfg->use_per ? per_weights : nullptr;
 
+  bool hyp_on_side = false;
   // ---- forward ----
   for (int c = 0; c < C && do_fwd; ++c) {
     const int64_t r0 = (int64_t)p.tb[c] * p.NB, rows = (int64_t)(p.tb[c + 1] - p.tb[c]) * p.NB;
@@ -422,7 +427,15 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
         hy.hw1[0] = W + p.hw1; hy.hw2[0] = W + p.hw2; hy.hb2[0] = W + p.hb2; hy.hb1[0] = W + p.hb1;
         hy.hw1[1] = W + p.hw1_t; hy.hw2[1] = W + p.hw2_t; hy.hb2[1] = W + p.hb2_t; hy.hb1[1] = W + p.hb1_t;
         hy.side = tr;
-        if ((rc = launch_mixer_hyp(hy, st))) return rc;
+        // OPE_CHAIN_SIDE = 1: on the side stream, concurrent with the scan (fork behind the trunk launch, join in front of the chain kernel)
+        static const int side_env = getenv("OPE_CHAIN_SIDE") ? atoi(getenv("OPE_CHAIN_SIDE")) : 0;
+        if (side_env) {
+          if (!sp && !(sp = side_pool())) return OPE_ELAUNCH;
+          if (hipEventRecord(sp->ev[0], st) != hipSuccess || hipStreamWaitEvent(sp->s, sp->ev[0], 0) != hipSuccess) return OPE_ELAUNCH;
+          if ((rc = launch_mixer_hyp(hy, sp->s))) return rc;
+          if (hipEventRecord(sp->ev[1], sp->s) != hipSuccess) return OPE_ELAUNCH;
+          hyp_on_side = true;
+        } else if ((rc = launch_mixer_hyp(hy, st))) return rc;
       }
     }
     hipStream_t scan_st = side;
@@ -458,7 +471,9 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
     if (dbg_on) {      // what the separate kernels leave in the workspace anyway: tests and tools read them
       ca.q_all = W + p.q_all; ca.agent_q = W + p.agent_q; ca.agent_nq = W + p.agent_nq; ca.qtot = W + p.qtot; ca.nqtot = W + p.nqtot;
       ca.v1 = W + p.v1; ca.v2 = W + p.v2; ca.hpre = W + p.hpre; ca.d_agent_q = W + p.d_agent_q;
+      ca.dbg = (long long*)(W + p.dbg);
     }
+    if (hyp_on_side && hipStreamWaitEvent(st, sp->ev[1], 0) != hipSuccess) return OPE_ELAUNCH;
     if ((rc = launch_qchain(ca, st))) return rc;
   }
   for (int c = 0; c < C && do_fwd && !p.chain; ++c) {   // heads of chunk c as soon as its scan is done

@@ -33,22 +33,27 @@ namespace {
 // First hyper-layers of both nets. Wave = 16 (t, b) rows x 7 of the 14 output tiles (tiles as stageA_row: 0-3 hyper_w1.0, 4-7 hyper_w2.0,
 // 8-11 hyper_b2.0, 12-13 hyper_b1); a workgroup = 4 row tiles of one (net, column half), so its waves stream the same weight rows through
 // the CU's L1. K in chunks of 16, two chunks in flight. Extra workgroups carry the weight transposes the backward kernels read.
+// (A persistent, weight-stationary form -- one wave per SIMD owning one (net, output tile) for its whole life and walking over every 37th row
+// tile: 8 400 evenly spread units -- was built and measured SLOWER: 28.9 us against 23.7 us at 3s5z, B = 32; each state row is then re-read
+// by the 14 waves of its net and the launch is bound by how fast the CUs' texture-address units accept the scattered 64-byte row pieces of
+// the MFMA operand layout, not by the matrix pipes. Removed.)
 // ---------------------------------------------------------------------------------------------------------
 template <int VEC>
-__global__ void __launch_bounds__(256) mixer_hyp_kernel(HypFirstArgs a) {
+__global__ void __launch_bounds__(1024) mixer_hyp_kernel(HypFirstArgs a) {
   if ((int)blockIdx.x >= a.main_blocks) {
-    transpose4_element(a.side, ((int)blockIdx.x - a.main_blocks) * 256 + (int)threadIdx.x);
+    transpose4_element(a.side, ((int)blockIdx.x - a.main_blocks) * (int)blockDim.x + (int)threadIdx.x);
     return;
   }
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 15, g = lane >> 4;
   const int tiles = (a.TB + 15) >> 4;
-  const int groups = (tiles + 3) >> 2;
+  const int rpw = (int)(blockDim.x >> 6);        // row tiles per workgroup (set by the launcher so that the grid is ONE round of the chip)
+  const int groups = (tiles + rpw - 1) / rpw;
   int bid = blockIdx.x;
   const int half = bid & 1;
   bid >>= 1;
   const int net = bid / groups, grp = bid - net * groups;
-  const int tile = grp * 4 + wave;
+  const int tile = grp * rpw + wave;
   if (tile >= tiles) return;                    // (no barrier in this kernel)
   const int m = tile * 16 + j;
   const bool valid = m < a.TB;
@@ -117,6 +122,26 @@ constexpr int kCW = 8;                 // waves per workgroup = agents handled s
 constexpr int kHidP = OPE_MIX + 4;     // LDS pitch of a 32-vector row
 constexpr int kPartP = OPE_HYP + 4;    // LDS pitch of a 64-vector row
 constexpr int kQaP = 17;               // [row][agent] pitch (N <= 16)
+constexpr int kMx = 100;               // small mixer vectors staged per net: w2b_b [32], b2b_w [64], b2b_b [1] (+ pad)
+
+// (value, index) maximum over the 4 lanes of a row -- greater value wins, equal values -> lower index (first max) -- with gfx950's VALU
+// lane swaps instead of ds_bpermute round trips: each swap leaves {own, partner} in the two results in a lane-dependent order, the same for
+// the value and the index, so the best of the two pairs is picked without knowing which is which.
+__device__ __forceinline__ void row_argmax4p(float& v, int& k) {
+  auto pick = [&](unsigned v0, unsigned v1, unsigned k0, unsigned k1) {
+    const float f0 = __uint_as_float(v0), f1 = __uint_as_float(v1);
+    const int i0 = (int)k0, i1 = (int)k1;
+    const bool first = f0 > f1 || (f0 == f1 && i0 <= i1);
+    v = first ? f0 : f1;
+    k = first ? i0 : i1;
+  };
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  auto b = __builtin_amdgcn_permlane16_swap((unsigned)k, (unsigned)k, false, false);
+  pick(a[0], a[1], b[0], b[1]);
+  auto c = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  auto d = __builtin_amdgcn_permlane32_swap((unsigned)k, (unsigned)k, false, false);
+  pick(c[0], c[1], d[0], d[1]);
+}
 
 // LayerNorm of this lane's 16 features of a row: y = affine output, xh = normalised row, returns 1 / std
 __device__ __forceinline__ float ln_row16x(const float* __restrict__ hrow, const float* __restrict__ th, int lno_w, int lno_b, int g, f32x4 (&y)[4],
@@ -150,17 +175,38 @@ __device__ __forceinline__ float ln_row16x(const float* __restrict__ hrow, const
   return rstd;
 }
 
+// Latency is what this kernel is about: a tile is ~600 MFMAs and a few thousand vector instructions per wave, but the first version walked
+// ~20 DEPENDENT global round trips (row -> LayerNorm parameters -> head weights -> actions -> ... ) at 1.5-2 us each: 45.6 us per launch at
+// 3s5z. Now everything a wave will need is requested in the first few hundred cycles -- one round trip --:
+//   * what the 8 waves share goes through LDS, staged once per workgroup: both nets' head weights, biases and LayerNorm parameters, W2b of
+//     both mixers, the tile's hw1 rows of both nets;
+//   * what is private to a wave stays in flight in registers: its agent's three GRU-state rows, action / availability rows, its W1b slices of
+//     both nets, the TD scalars of its rows, the rows of its side job (hw2 / hb2 / hyper_b1);
+//   * the agent's W1b^T slice for the adjoint is requested at the end of the forward mixer stage, a phase ahead of its use (its registers
+//     are the forward slices'); the chosen action's W_q row for the head's adjoint is read from the staged copy in LDS.
+// One workgroup per CU (up to 256 registers a wave).
 template <int NT, int APW, bool VDN>     // NT: 16-action tiles of the head (A <= 16 NT); APW: agents per wave (N <= 8 APW)
-__global__ void __launch_bounds__(64 * kCW, APW == 1 ? 2 : 1) qchain_kernel(ChainArgs a) {
+__global__ void __launch_bounds__(64 * kCW, 2) qchain_kernel(ChainArgs a) {
+  constexpr int QR = 16 * NT;                                                    // staged rows of W_q (zero beyond A)
+  constexpr bool PFH = APW == 1;               // GRU-state rows requested at kernel start (one agent per wave: 48 registers)
+  constexpr bool PFW = APW == 1 && NT == 1;    // ... and the agent's W1b slices of both nets (64 registers); else loaded where they are used
+  __shared__ __attribute__((aligned(16))) float wq_s[2][QR * kPartP];            // [net][action][64] head weights
+  __shared__ __attribute__((aligned(16))) float qb_s[2][QR];                     // [net][action] head bias
+  __shared__ __attribute__((aligned(16))) float ln_s[2][2][OPE_H];               // [net][gamma | beta][64] rnn.norm
+  __shared__ __attribute__((aligned(16))) float hw1_s[2][16 * kPartP];           // [net][row][64] relu(hyper_w1.0) of the tile's rows
+  __shared__ __attribute__((aligned(16))) float w2b_s[2][OPE_MIX * kPartP];      // [net][32][64] hyper_w2.2 weights
+  __shared__ __attribute__((aligned(16))) float mx_s[2][kMx];                    // [net][hyper_w2.2 bias 32 | hyper_b2.2 weight 64 | its bias 1]
   __shared__ float qa_s[2][16 * kQaP];                                           // [net][row][agent]: chosen q (live), target q at t+1
   __shared__ __attribute__((aligned(16))) float wk_s[2 * kCW * 16 * kHidP];      // forward: [net][wave][16][36] partial hidden layers;
                                                                                  // backward: [wave][16][68] partial W1b^T dv1 (aliased)
   __shared__ __attribute__((aligned(16))) float hp_s[16 * kHidP];                // pre-ELU hidden layer of the live mixer
+  __shared__ __attribute__((aligned(16))) float hd_s[16 * kHidP];                // ELU of it (the hidden layer itself)
   __shared__ __attribute__((aligned(16))) float v2_s[16 * kHidP];                // pre-abs w2 of the live mixer
-  __shared__ float qt_s[2][16];                                                  // Q_tot of the live net, of the target net
+  __shared__ float qt_s[2][2][16];                                               // [net][kh] halves of hidden . |w2| of the live / target net
   __shared__ float pb_s[2][16];                                                  // hyper_b2 head dot of both nets
   static_assert(2 * kCW * 16 * kHidP >= kCW * 16 * kPartP, "the backward partials alias the forward ones");
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, g = lane >> 4;
   const int A = a.A, N = a.N, B = a.B, NB = a.NB;
   const int tile = blockIdx.x;
@@ -175,6 +221,191 @@ __global__ void __launch_bounds__(64 * kCW, APW == 1 ? 2 : 1) qchain_kernel(Chai
   const float* __restrict__ th1 = a.theta1;
   const int NM = N * OPE_MIX;
   const int A4 = ope_round4_dev(A);
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  // optional s_memtime stamps (ope_qmix_cfg.debug; tools/chain_phases.py): start | requests issued | shared data staged (after the barrier) |
+  // heads done | after barrier | mixer stage 2 done | after the combine's two barriers | TD + adjoints done | after barrier | end
+  long long* dbg = a.dbg ? a.dbg + ((int64_t)tile * kCW + wave) * 10 : nullptr;
+  auto stamp = [&](int k) { if (dbg && lane == 0) dbg[k] = __builtin_amdgcn_s_memtime(); };
+  stamp(0);
+
+  // ---- requests: shared data (one 16-byte piece per thread and array), then this wave's private data ---------------------------------
+  f32x4 st_wq[NT], st_hw1, st_w2b[2];
+  float st_ln = 0.f, st_qb = 0.f;
+#pragma unroll
+  for (int u = 0; u < NT; ++u) {          // W_q of both nets: 2 x QR rows x 16 pieces
+    const int p = tid + 512 * u;
+    const int net = p / (QR * 16), row = (p >> 4) % QR, piece = p & 15;
+    const float* __restrict__ th = net == 0 ? th0 : th1;
+    st_wq[u] = *reinterpret_cast<const f32x4*>(th + AL.q_w + (int64_t)(row < A ? row : A - 1) * OPE_H + 4 * piece);
+  }
+  {                                       // hw1 rows of both nets: 2 x 16 rows x 16 pieces
+    const int net = tid >> 8, row = (tid >> 4) & 15, piece = tid & 15;
+    int mr = tile * 16 + row;
+    mr = mr < a.TB ? mr : a.TB - 1;
+    // (pointer chosen by a select of the two kernel arguments: indexing the argument array with a per-lane value would be a LOAD of the pointer)
+    if (!VDN) st_hw1 = *reinterpret_cast<const f32x4*>((net ? a.hw1[1] : a.hw1[0]) + (int64_t)mr * OPE_HYP + 4 * piece);
+  }
+  if (!VDN) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {         // W2b of both nets: 2 x 32 rows x 16 pieces
+      const int p = tid + 512 * u;
+      const int net = p >> 9, row = (p >> 4) & 31, piece = p & 15;
+      const float* __restrict__ th = net == 0 ? th0 : th1;
+      st_w2b[u] = *reinterpret_cast<const f32x4*>(th + ML.w2b_w + (int64_t)row * OPE_HYP + 4 * piece);
+    }
+  }
+  {   // rnn.norm gamma / beta of both nets (threads 0..255 keep theirs) and the head biases (threads 256 .. 256 + 2 QR): branch-free requests
+      // with clamped addresses -- a load inside a divergent branch makes hipcc drain every outstanding load at the join
+    const int net = (tid >> 7) & 1, which = (tid >> 6) & 1, f = tid & 63;
+    st_ln = (net == 0 ? th0 : th1)[(which ? AL.lno_b : AL.lno_w) + f];
+    const int q = (tid - 256) & (2 * QR - 1), netq = q / QR, k = q - netq * QR;
+    st_qb = (netq == 0 ? th0 : th1)[AL.q_b + (k < A ? k : A - 1)];
+    st_qb = k < A ? st_qb : 0.f;
+  }
+  float st_mx = 0.f;
+  if (!VDN) {   // the mixers' small vectors (threads 0 .. 2 kMx keep theirs)
+    const int e2 = tid < 2 * kMx ? tid : 2 * kMx - 1, net = e2 / kMx, e = e2 - net * kMx;
+    const int off = e < OPE_MIX ? ML.w2b_b + e : (e < OPE_MIX + OPE_HYP ? ML.b2b_w + (e - OPE_MIX) : ML.b2b_b);
+    st_mx = (net == 0 ? th0 : th1)[off];
+  }
+  // private: GRU-state rows (live t, live t + 1, target t + 1), action / availability rows of this wave's agents
+  f32x4 hrow[3][4];
+  float acv[APW][NT][4], avl[APW][NT][4];
+  const float* __restrict__ avp = a.avail ? a.avail : a.h0;      // (no availability mask: read SOMETHING valid of at least that size, select below)
+#pragma unroll
+  for (int ia = 0; ia < APW; ++ia) {
+    const int ag = wave + kCW * ia;
+    const int agc = ag < N ? ag : N - 1;
+    const int64_t r0 = ((int64_t)t * N + agc) * B + b, r1 = r0 + NB;
+    if (PFH) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        hrow[0][c] = *reinterpret_cast<const f32x4*>(a.h0 + r0 * OPE_H + 16 * c + 4 * g);
+        hrow[1][c] = *reinterpret_cast<const f32x4*>(a.h0 + r1 * OPE_H + 16 * c + 4 * g);
+        hrow[2][c] = *reinterpret_cast<const f32x4*>(a.h1 + r1 * OPE_H + 16 * c + 4 * g);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NT; ++it)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int k = 16 * it + 4 * g + rr;
+        const int kc = k < A ? k : A - 1;
+        acv[ia][it][rr] = a.acts[r0 * A + kc];
+        avl[ia][it][rr] = avp[r1 * A + kc];
+      }
+  }
+  // TD scalars of this lane's (t, b) row (qmix.py:159-164)
+  const float td_rew = a.td.rewards[((int64_t)t * N + 0) * B + b];
+  const float td_den = a.td.dones_env[(int64_t)t * B + b];
+  float td_bad = a.td.dones_env[(int64_t)(t > 0 ? t - 1 : 0) * B + b];
+  td_bad = t == 0 ? 0.f : td_bad;
+  float td_w = (a.td.per_weights ? a.td.per_weights : a.td.dones_env)[b];
+  td_w = a.td.per_weights ? td_w : 1.0f;
+  __builtin_amdgcn_sched_barrier(0);      // (keep the requests above where they are: the scheduler must not sink them towards their uses)
+  stamp(1);
+
+  // ---- deposit the shared pieces ---------------------------------------------------------------------------
+#pragma unroll
+  for (int u = 0; u < NT; ++u) {
+    const int p = tid + 512 * u;
+    const int net = p / (QR * 16), row = (p >> 4) % QR, piece = p & 15;
+    *reinterpret_cast<f32x4*>(&wq_s[net][row * kPartP + 4 * piece]) = row < A ? st_wq[u] : zero4;
+  }
+  if (!VDN) {
+    const int net = tid >> 8, row = (tid >> 4) & 15, piece = tid & 15;
+    *reinterpret_cast<f32x4*>(&hw1_s[net][row * kPartP + 4 * piece]) = st_hw1;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int p = tid + 512 * u;
+      const int net2 = p >> 9, row2 = (p >> 4) & 31, piece2 = p & 15;
+      *reinterpret_cast<f32x4*>(&w2b_s[net2][row2 * kPartP + 4 * piece2]) = st_w2b[u];
+    }
+  }
+  if (tid < 256) ln_s[tid >> 7][(tid >> 6) & 1][tid & 63] = st_ln;
+  else if (tid < 256 + 2 * QR) qb_s[(tid - 256) / QR][(tid - 256) % QR] = st_qb;      // (stores in a branch are harmless)
+  if (!VDN && tid < 2 * kMx) mx_s[tid / kMx][tid % kMx] = st_mx;
+  lds_barrier();
+  stamp(2);
+  // ---- second wave of requests, in flight while the heads compute: this wave's agents' W1b slices of both nets (A operand fragments),
+  // their biases, and the rows of the wave's side job:
+  //   waves 0..3 = (net, kh) = (wave >> 1, wave & 1): w2[16 kh ..] = W2b relu(hw2) + b of that net, then that half of the combine;
+  //   waves 4, 5: the hyper_b2 head dot of the live / target net
+  f32x4 w1b[2][2][4], b1b[VDN ? 1 : APW][2][2];
+  f32x4 side[4], hb1v, mk2, mk3;
+  if (!VDN) {
+#pragma unroll
+    for (int ia = 0; ia < APW; ++ia) {
+      const int ag = wave + kCW * ia;
+      const int agc = ag < N ? ag : N - 1;
+#pragma unroll
+      for (int net = 0; net < 2; ++net) {
+        const float* __restrict__ th = net == 0 ? th0 : th1;
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+          b1b[ia][net][kh] = *reinterpret_cast<const f32x4*>(th + ML.w1b_b + agc * OPE_MIX + 16 * kh + 4 * g);
+          if (PFW) {
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft)
+              w1b[net][kh][ft] = *reinterpret_cast<const f32x4*>(th + ML.w1b_w + (int64_t)(agc * OPE_MIX + 16 * kh + j) * OPE_HYP + 16 * ft + 4 * g);
+          }
+        }
+      }
+    }
+    {
+      const int snet = wave < 4 ? (wave >> 1) : (wave & 1);
+      const float* __restrict__ src = (wave < 4 ? (snet ? a.hw2[1] : a.hw2[0]) : (snet ? a.hb2[1] : a.hb2[0])) + (int64_t)mm * OPE_HYP;
+#pragma unroll
+      for (int ft = 0; ft < 4; ++ft) side[ft] = *reinterpret_cast<const f32x4*>(src + 16 * ft + 4 * g);
+      hb1v = *reinterpret_cast<const f32x4*>((snet ? a.hb1[1] : a.hb1[0]) + (int64_t)mm * OPE_MIX + 16 * (wave & 1) + 4 * g);
+      // the live net's relu(hw2) / relu(hb2) at the feature tile waves 0..3 finish in the adjoint (their ReLU masks)
+      const int fo = 16 * (wave & 3) + 4 * g;
+      mk2 = *reinterpret_cast<const f32x4*>(a.hw2[0] + (int64_t)mm * OPE_HYP + fo);
+      mk3 = *reinterpret_cast<const f32x4*>(a.hb2[0] + (int64_t)mm * OPE_HYP + fo);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+
+  // LayerNorm of a prefetched row with the staged parameters: y = affine output, xh = normalised row, returns 1 / std
+  auto ln_regs = [&](const f32x4 (&hr)[4], int net, f32x4 (&y)[4], f32x4 (&xn)[4]) -> float {
+    float s0 = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) s0 += (hr[c][0] + hr[c][1]) + (hr[c][2] + hr[c][3]);
+    const float mu = rowsum4(s0) * (1.0f / OPE_H);
+    float v = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float d = hr[c][r] - mu;
+        v = fmaf(d, d, v);
+      }
+    const float rstd = __builtin_amdgcn_rsqf(rowsum4(v) * (1.0f / OPE_H) + OPE_LN_EPS);      // v_rsq_f32: 1 ulp
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const f32x4 gm = *reinterpret_cast<const f32x4*>(&ln_s[net][0][16 * c + 4 * g]);
+      const f32x4 bt = *reinterpret_cast<const f32x4*>(&ln_s[net][1][16 * c + 4 * g]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        xn[c][r] = (hr[c][r] - mu) * rstd;
+        y[c][r] = fmaf(xn[c][r], gm[r], bt[r]);
+      }
+    }
+    return rstd;
+  };
+  // q[16 it + 4 g + r] of row j: bias + W_q y on the matrix pipe, weights from LDS (rows beyond A are zero)
+  auto q_lds = [&](int net, const f32x4 (&y)[4], f32x4 (&q)[NT]) {
+#pragma unroll
+    for (int it = 0; it < NT; ++it) {
+      q[it] = *reinterpret_cast<const f32x4*>(&qb_s[net][16 * it + 4 * g]);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(&wq_s[net][(16 * it + j) * kPartP + 16 * c + 4 * g]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) q[it] = mfma16(w[r], y[c][r], q[it]);
+      }
+    }
+  };
 
   // ---- phase 1: the q heads of this wave's agents --------------------------------------------------------
   f32x4 xh[APW][4];
@@ -186,22 +417,7 @@ __global__ void __launch_bounds__(64 * kCW, APW == 1 ? 2 : 1) qchain_kernel(Chai
     if (ag < N) {
       const int64_t r0 = ((int64_t)t * N + ag) * B + b;         // row (t, agent, b) of the [T+1][N*B] stacks
       const int64_t r1 = r0 + NB;                               // (t + 1, agent, b)
-      f32x4 y[4], q[NT];
-      // live net at t: q of the action taken
-      rstd_k[ia] = ln_row16x(a.h0 + r0 * OPE_H, th0, AL.lno_w, AL.lno_b, g, y, xh[ia]);
-      if (valid) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) *reinterpret_cast<f32x4*>(a.xhat_o + r0 * OPE_H + 16 * c + 4 * g) = xh[ia][c];
-        if (g == 0) a.rstd_o[r0] = rstd_k[ia];
-      }
-      q_tiles<NT>(th0, AL, A, j, g, y, q);
-      if (a.q_all && valid) {
-#pragma unroll
-        for (int it = 0; it < NT; ++it)
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr)
-            if (16 * it + 4 * g + rr < A) a.q_all[r0 * A + 16 * it + 4 * g + rr] = q[it][rr];
-      }
+      // chosen action = first maximum of the one-hot row (QMixPolicy.q_values_from_actions, QMixPolicy.py:69-93)
       float cv = kNegInf;
       int chosen = 1 << 30;
 #pragma unroll
@@ -209,13 +425,33 @@ __global__ void __launch_bounds__(64 * kCW, APW == 1 ? 2 : 1) qchain_kernel(Chai
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
           const int k = 16 * it + 4 * g + rr;
-          if (k < A) {
-            const float v = a.acts[r0 * A + k];
-            if (v > cv) { cv = v; chosen = k; }      // ascending k within the lane: strict > keeps the first maximum
-          }
+          if (k < A && acv[ia][it][rr] > cv) { cv = acv[ia][it][rr]; chosen = k; }      // ascending k within the lane: strict > keeps the first
         }
-      row_argmax4(cv, chosen);
+      row_argmax4p(cv, chosen);
       chosen_k[ia] = chosen;
+      f32x4 y[4], q[NT];
+      // live net at t: q of the action taken
+      f32x4 hr[4];
+      auto row_of = [&](int which) {      // the prefetched row, or (two agents per wave) the row loaded now
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          hr[c] = PFH ? hrow[which][c] : *reinterpret_cast<const f32x4*>((which == 2 ? a.h1 : a.h0) + (which == 0 ? r0 : r1) * OPE_H + 16 * c + 4 * g);
+      };
+      row_of(0);
+      rstd_k[ia] = ln_regs(hr, 0, y, xh[ia]);
+      if (valid) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) *reinterpret_cast<f32x4*>(a.xhat_o + r0 * OPE_H + 16 * c + 4 * g) = xh[ia][c];
+        if (g == 0) a.rstd_o[r0] = rstd_k[ia];
+      }
+      q_lds(0, y, q);
+      if (a.q_all && valid) {
+#pragma unroll
+        for (int it = 0; it < NT; ++it)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr)
+            if (16 * it + 4 * g + rr < A) a.q_all[r0 * A + 16 * it + 4 * g + rr] = q[it][rr];
+      }
       float qc = 0.f;
 #pragma unroll
       for (int it = 0; it < NT; ++it)
@@ -230,15 +466,11 @@ __global__ void __launch_bounds__(64 * kCW, APW == 1 ? 2 : 1) qchain_kernel(Chai
       // live net at t + 1: greedy action over the available ones (double Q, qmix.py:138-146)
       float gv = kNegInf;
       int greedy = 1 << 30;
-      float avl[NT][4];
-#pragma unroll
-      for (int it = 0; it < NT; ++it)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) avl[it][rr] = 1.f;
+      f32x4 xd[4];
       if (a.double_q) {
-        f32x4 xd[4];
-        ln_row16x(a.h0 + r1 * OPE_H, th0, AL.lno_w, AL.lno_b, g, y, xd);
-        q_tiles<NT>(th0, AL, A, j, g, y, q);
+        row_of(1);
+        ln_regs(hr, 0, y, xd);
+        q_lds(0, y, q);
         if (a.q_all && valid && t + 1 == a.T) {      // (debug output: the rows of the last time step are only ever seen as a "t + 1")
 #pragma unroll
           for (int it = 0; it < NT; ++it)
@@ -252,45 +484,46 @@ __global__ void __launch_bounds__(64 * kCW, APW == 1 ? 2 : 1) qchain_kernel(Chai
           for (int rr = 0; rr < 4; ++rr) {
             const int k = 16 * it + 4 * g + rr;
             if (k < A) {
-              if (a.avail) avl[it][rr] = a.avail[r1 * A + k];
-              const float qm = (avl[it][rr] == 0.f) ? -1e10f : q[it][rr];
+              const float qm = (a.avail && avl[ia][it][rr] == 0.f) ? -1e10f : q[it][rr];      // util.py:297-302
               if (qm > gv) { gv = qm; greedy = k; }
             }
           }
-        row_argmax4(gv, greedy);
+        row_argmax4p(gv, greedy);
       }
       // target net at t + 1: q at the live net's greedy action, or the plain maximum (qmix.py:148)
-      {
-        f32x4 xd[4];
-        ln_row16x(a.h1 + r1 * OPE_H, th1, AL.lno_w, AL.lno_b, g, y, xd);
-        q_tiles<NT>(th1, AL, A, j, g, y, q);
-        float tq;
-        if (a.double_q) {
-          tq = 0.f;
+      row_of(2);
+      ln_regs(hr, 1, y, xd);
+      q_lds(1, y, q);
+      float tq;
+      if (a.double_q) {
+        tq = 0.f;
 #pragma unroll
-          for (int it = 0; it < NT; ++it)
+        for (int it = 0; it < NT; ++it)
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) tq += (16 * it + 4 * g + rr == greedy) ? q[it][rr] : 0.f;
-          tq = rowsum4(tq);
-        } else {
-          tq = kNegInf;
+          for (int rr = 0; rr < 4; ++rr) tq += (16 * it + 4 * g + rr == greedy) ? q[it][rr] : 0.f;
+        tq = rowsum4(tq);
+      } else {
+        tq = kNegInf;
 #pragma unroll
-          for (int it = 0; it < NT; ++it)
+        for (int it = 0; it < NT; ++it)
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr)
-              if (16 * it + 4 * g + rr < A) tq = fmaxf(tq, q[it][rr]);
-          tq = fmaxf(tq, __shfl_xor(tq, 16, 64));
-          tq = fmaxf(tq, __shfl_xor(tq, 32, 64));
-        }
-        if (g == 0) qa_s[1][j * kQaP + ag] = tq;
-        if (first && a.agent_nq) a.agent_nq[(int64_t)m * N + ag] = tq;
+          for (int rr = 0; rr < 4; ++rr)
+            if (16 * it + 4 * g + rr < A) tq = fmaxf(tq, q[it][rr]);
+        tq = fmaxf(tq, __shfl_xor(tq, 16, 64));
+        tq = fmaxf(tq, __shfl_xor(tq, 32, 64));
       }
+      if (g == 0) qa_s[1][j * kQaP + ag] = tq;
+      if (first && a.agent_nq) a.agent_nq[(int64_t)m * N + ag] = tq;
     }
   }
+  stamp(3);
   lds_barrier();
+  stamp(4);
 
   float qtot, nqtot;
   f32x4 v1k[APW][2];          // pre-abs w1 slices of this wave's agents (live mixer): needed again by the adjoint
+  f32x4 w1t[VDN ? 1 : APW][4][2];   // this wave's agents' slices of W1b^T (the adjoint's A operand), requested at the end of phase 2
+  f32x4 w2t[2];                     // ... and feature tile (wave & 3) of W2b^T
   if (VDN) {
     // Q_tot = sum over agents (every wave, redundantly: the TD below is lane-local)
     qtot = 0.f;
@@ -303,24 +536,23 @@ __global__ void __launch_bounds__(64 * kCW, APW == 1 ? 2 : 1) qchain_kernel(Chai
     // ---- phase 2: second stage of both mixers, this wave's agents ----------------------------------------
 #pragma unroll
     for (int net = 0; net < 2; ++net) {
-      const float* __restrict__ th = net == 0 ? th0 : th1;
       f32x4 hv[4];
 #pragma unroll
-      for (int ft = 0; ft < 4; ++ft) hv[ft] = *reinterpret_cast<const f32x4*>(a.hw1[net] + (int64_t)mm * OPE_HYP + 16 * ft + 4 * g);
-      f32x4 hid[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      for (int ft = 0; ft < 4; ++ft) hv[ft] = *reinterpret_cast<const f32x4*>(&hw1_s[net][j * kPartP + 16 * ft + 4 * g]);
+      f32x4 hid[2] = {zero4, zero4};
 #pragma unroll
       for (int ia = 0; ia < APW; ++ia) {
         const int ag = wave + kCW * ia;
         if (ag < N) {
-          f32x4 v[2];
-#pragma unroll
-          for (int kh = 0; kh < 2; ++kh) v[kh] = *reinterpret_cast<const f32x4*>(th + ML.w1b_b + ag * OPE_MIX + 16 * kh + 4 * g);
+          f32x4 v[2] = {b1b[ia][net][0], b1b[ia][net][1]};
+          const float* __restrict__ thn = net == 0 ? th0 : th1;
 #pragma unroll
           for (int ft = 0; ft < 4; ++ft) {
             f32x4 w[2];
 #pragma unroll
             for (int kh = 0; kh < 2; ++kh)
-              w[kh] = *reinterpret_cast<const f32x4*>(th + ML.w1b_w + (int64_t)(ag * OPE_MIX + 16 * kh + j) * OPE_HYP + 16 * ft + 4 * g);
+              w[kh] = PFW ? w1b[net][kh][ft]
+                          : *reinterpret_cast<const f32x4*>(thn + ML.w1b_w + (int64_t)(ag * OPE_MIX + 16 * kh + j) * OPE_HYP + 16 * ft + 4 * g);
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -344,66 +576,101 @@ __global__ void __launch_bounds__(64 * kCW, APW == 1 ? 2 : 1) qchain_kernel(Chai
 #pragma unroll
       for (int kh = 0; kh < 2; ++kh) *reinterpret_cast<f32x4*>(wk_s + ((net * kCW + wave) * 16 + j) * kHidP + 16 * kh + 4 * g) = hid[kh];
     }
-    // side jobs: waves 0 / 1 form w2 = W2b relu(hw2) + b of the live / target net, waves 2 / 3 the hyper_b2 head dots
-    f32x4 v2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    if (wave < 2) {
-      const int net = wave;
-      const float* __restrict__ th = net == 0 ? th0 : th1;
-      f32x4 hv[4];
+    // the adjoint's W1b^T slices: requested now, used after the TD
+    {
+      const float* __restrict__ w1bT = a.mixT;                    // [64][N*32]
 #pragma unroll
-      for (int ft = 0; ft < 4; ++ft) hv[ft] = *reinterpret_cast<const f32x4*>(a.hw2[net] + (int64_t)mm * OPE_HYP + 16 * ft + 4 * g);
+      for (int ia = 0; ia < APW; ++ia) {
+        const int ag = wave + kCW * ia;
+        const int agc = ag < N ? ag : N - 1;
 #pragma unroll
-      for (int kh = 0; kh < 2; ++kh) v2[kh] = *reinterpret_cast<const f32x4*>(th + ML.w2b_b + 16 * kh + 4 * g);
-      gemm64<2>(th + ML.w2b_w, OPE_HYP, j, g, hv, v2);
-    } else if (wave < 4) {
-      const int net = wave - 2;
-      const float* __restrict__ th = net == 0 ? th0 : th1;
+        for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+          for (int kh = 0; kh < 2; ++kh)
+            w1t[ia][ft][kh] = *reinterpret_cast<const f32x4*>(w1bT + (int64_t)(16 * ft + j) * NM + agc * OPE_MIX + 16 * kh + 4 * g);
+      }
+      const float* __restrict__ w2bT = a.mixT + OPE_HYP * NM;     // [64][32]
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) w2t[kh] = *reinterpret_cast<const f32x4*>(w2bT + (int64_t)(16 * (wave & 3) + j) * OPE_MIX + 16 * kh + 4 * g);
+    }
+    // side jobs (see the requests above): waves 0..3 their half of w2 = W2b relu(hw2) + b, waves 4 / 5 the hyper_b2 head dots
+    f32x4 v2h = zero4;
+    if (wave < 4) {
+      const int net = wave >> 1, kh = wave & 1;
+      v2h = *reinterpret_cast<const f32x4*>(&mx_s[net][16 * kh + 4 * g]);
+#pragma unroll
+      for (int ft = 0; ft < 4; ++ft) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(&w2b_s[net][(16 * kh + j) * kPartP + 16 * ft + 4 * g]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v2h = mfma16(w[r], side[ft][r], v2h);
+      }
+    } else if (wave < 6) {
+      const int net = wave & 1;
       float pb = 0.f;
 #pragma unroll
       for (int ft = 0; ft < 4; ++ft) {
-        const f32x4 hv = *reinterpret_cast<const f32x4*>(a.hb2[net] + (int64_t)mm * OPE_HYP + 16 * ft + 4 * g);
-        const f32x4 wv = *reinterpret_cast<const f32x4*>(th + ML.b2b_w + 16 * ft + 4 * g);
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(&mx_s[net][OPE_MIX + 16 * ft + 4 * g]);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) pb = fmaf(wv[r], hv[r], pb);
+        for (int r = 0; r < 4; ++r) pb = fmaf(wv[r], side[ft][r], pb);
       }
       pb = rowsum4(pb);
       if (g == 0) pb_s[net][j] = pb;
     }
+    stamp(5);
     lds_barrier();
 
-    // ---- phase 3: combine (wave 0: live net, wave 1: target net) -----------------------------------------
-    if (wave < 2) {
-      const int net = wave;
-      const float* __restrict__ th = net == 0 ? th0 : th1;
+    // ---- phase 3: combine, one (net, kh) half of the 32 hidden units per wave 0..3 ---------------------------
+    if (wave < 4) {
+      const int net = wave >> 1, kh = wave & 1;
+      f32x4 h = hb1v;
+#pragma unroll
+      for (int w = 0; w < kCW; ++w) {
+        const f32x4 o = *reinterpret_cast<const f32x4*>(wk_s + ((net * kCW + w) * 16 + j) * kHidP + 16 * kh + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] += o[r];
+      }
+      f32x4 hd;
       float part = 0.f;
 #pragma unroll
-      for (int kh = 0; kh < 2; ++kh) {
-        f32x4 h = *reinterpret_cast<const f32x4*>(a.hb1[net] + (int64_t)mm * OPE_MIX + 16 * kh + 4 * g);
-#pragma unroll
-        for (int w = 0; w < kCW; ++w) {
-          const f32x4 o = *reinterpret_cast<const f32x4*>(wk_s + ((net * kCW + w) * 16 + j) * kHidP + 16 * kh + 4 * g);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) h[r] += o[r];
-        }
-        if (net == 0) {
-          *reinterpret_cast<f32x4*>(hp_s + j * kHidP + 16 * kh + 4 * g) = h;
-          *reinterpret_cast<f32x4*>(v2_s + j * kHidP + 16 * kh + 4 * g) = v2[kh];
-          if (a.hpre && valid) *reinterpret_cast<f32x4*>(a.hpre + (int64_t)m * OPE_MIX + 16 * kh + 4 * g) = h;
-          if (a.v2 && valid) *reinterpret_cast<f32x4*>(a.v2 + (int64_t)m * OPE_MIX + 16 * kh + 4 * g) = v2[kh];
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) part = fmaf(elu1(h[r]), fabsf(v2[kh][r]), part);            // ELU(.) |w2|  (q_mixer.py:86-93)
+      for (int r = 0; r < 4; ++r) {
+        hd[r] = elu1(h[r]);
+        part = fmaf(hd[r], fabsf(v2h[r]), part);            // ELU(.) |w2|  (q_mixer.py:86-93)
       }
-      const float qv = rowsum4(part) + (pb_s[net][j] + th[ML.b2b_b]);
-      if (g == 0) qt_s[net][j] = qv;
+      if (net == 0) {
+        *reinterpret_cast<f32x4*>(hp_s + j * kHidP + 16 * kh + 4 * g) = h;
+        *reinterpret_cast<f32x4*>(hd_s + j * kHidP + 16 * kh + 4 * g) = hd;
+        *reinterpret_cast<f32x4*>(v2_s + j * kHidP + 16 * kh + 4 * g) = v2h;
+        if (a.hpre && valid) *reinterpret_cast<f32x4*>(a.hpre + (int64_t)m * OPE_MIX + 16 * kh + 4 * g) = h;
+        if (a.v2 && valid) *reinterpret_cast<f32x4*>(a.v2 + (int64_t)m * OPE_MIX + 16 * kh + 4 * g) = v2h;
+      }
+      part = rowsum4(part);
+      if (g == 0) qt_s[net][kh][j] = part;
     }
     lds_barrier();
-    qtot = qt_s[0][j];
-    nqtot = qt_s[1][j];
+    qtot = (qt_s[0][0][j] + qt_s[0][1][j]) + (pb_s[0][j] + mx_s[0][OPE_MIX + OPE_HYP]);
+    nqtot = (qt_s[1][0][j] + qt_s[1][1][j]) + (pb_s[1][j] + mx_s[1][OPE_MIX + OPE_HYP]);
   }
+  stamp(6);
 
-  // ---- phase 4: TD target, mask, loss (every wave, lane-local) and the adjoints ----------------------------
-  TdOut td = td_row(a.td, t, b, qtot, nqtot);
+  // ---- phase 4: TD target, mask, loss (every wave, lane-local; qmix.py:158-176) and the adjoints ------------
+  TdOut td;
+  {
+    td.keep = 1.0f - td_bad;
+    const float target = td_rew + (1.0f - td_den) * a.td.gamma * nqtot;
+    const float e = (qtot - target) * td.keep;
+    td.err = e;
+    float fe, dfe;
+    if (a.td.use_huber) {
+      const float ae = fabsf(e), dl = a.td.huber_delta;
+      if (ae <= dl) { fe = e * e * 0.5f; dfe = e; }
+      else { fe = dl * (ae - dl * 0.5f); dfe = dl * sgn(e); }
+    } else {
+      fe = e * e;
+      dfe = 2.0f * e;
+    }
+    td.lossel = td_w * fe;
+    td.dq = td_w * dfe * td.keep;
+  }
   if (!valid) { td.err = 0.f; td.keep = 0.f; td.lossel = 0.f; td.dq = 0.f; }
   const float dQ = td.dq;
   if (wave == 0) {
@@ -431,24 +698,22 @@ __global__ void __launch_bounds__(64 * kCW, APW == 1 ? 2 : 1) qchain_kernel(Chai
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh) {
       const f32x4 hp = *reinterpret_cast<const f32x4*>(hp_s + j * kHidP + 16 * kh + 4 * g);
+      const f32x4 hd = *reinterpret_cast<const f32x4*>(hd_s + j * kHidP + 16 * kh + 4 * g);
       const f32x4 vv = *reinterpret_cast<const f32x4*>(v2_s + j * kHidP + 16 * kh + 4 * g);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float hdn = elu1(hp[r]);
-        dv2[kh][r] = dQ * hdn * sgn(vv[r]);
+        dv2[kh][r] = dQ * hd[r] * sgn(vv[r]);
         const float dh = dQ * fabsf(vv[r]);
-        dpre[kh][r] = dh * (hp[r] > 0.f ? 1.0f : expf(hp[r]));
+        dpre[kh][r] = dh * (hp[r] > 0.f ? 1.0f : hd[r] + 1.0f);      // ELU'(x) = exp(x) = ELU(x) + 1 for x <= 0 (the combine's value: no second exponential)
       }
       if (valid && wave == 0) {
         *reinterpret_cast<f32x4*>(a.d_b1 + (int64_t)m * OPE_MIX + 16 * kh + 4 * g) = dpre[kh];
         *reinterpret_cast<f32x4*>(a.d_v2 + (int64_t)m * OPE_MIX + 16 * kh + 4 * g) = dv2[kh];
       }
     }
-    const float* __restrict__ w1bT = a.mixT;                    // [64][N*32]
-    const float* __restrict__ w2bT = a.mixT + OPE_HYP * NM;     // [64][32]
     f32x4 dh1[4];
 #pragma unroll
-    for (int ft = 0; ft < 4; ++ft) dh1[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ft = 0; ft < 4; ++ft) dh1[ft] = zero4;
 #pragma unroll
     for (int ia = 0; ia < APW; ++ia) {
       const int ag = wave + kCW * ia;
@@ -472,32 +737,29 @@ __global__ void __launch_bounds__(64 * kCW, APW == 1 ? 2 : 1) qchain_kernel(Chai
 #pragma unroll
         for (int ft = 0; ft < 4; ++ft)
 #pragma unroll
-          for (int kh = 0; kh < 2; ++kh) {
-            const f32x4 wv = *reinterpret_cast<const f32x4*>(w1bT + (int64_t)(16 * ft + j) * NM + ag * OPE_MIX + 16 * kh + 4 * g);
+          for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dh1[ft] = mfma16(wv[r], dv1[kh][r], dh1[ft]);
-          }
+            for (int r = 0; r < 4; ++r) dh1[ft] = mfma16(w1t[ia][ft][kh][r], dv1[kh][r], dh1[ft]);
       }
     }
     // (all reads of the forward partials in wk_s happened before the barrier that closed phase 3)
 #pragma unroll
     for (int ft = 0; ft < 4; ++ft) *reinterpret_cast<f32x4*>(wk_s + (wave * 16 + j) * kPartP + 16 * ft + 4 * g) = dh1[ft];
-    f32x4 dh2 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 dh2 = zero4;
     if (wave < 4) {          // feature tile `wave` of dhw2 = W2b^T dv2
 #pragma unroll
-      for (int kh = 0; kh < 2; ++kh) {
-        const f32x4 wv = *reinterpret_cast<const f32x4*>(w2bT + (int64_t)(16 * wave + j) * OPE_MIX + 16 * kh + 4 * g);
+      for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dh2 = mfma16(wv[r], dv2[kh][r], dh2);
-      }
+        for (int r = 0; r < 4; ++r) dh2 = mfma16(w2t[kh][r], dv2[kh][r], dh2);
     }
+    stamp(7);
     lds_barrier();
+    stamp(8);
     if (wave < 4 && valid) {   // feature tile `wave` of the three hyper-net adjoints (pre-activation: zero where the ReLU was off)
       const int fo = 16 * wave + 4 * g;
-      const f32x4 h1 = *reinterpret_cast<const f32x4*>(a.hw1[0] + (int64_t)m * OPE_HYP + fo);
-      const f32x4 h2 = *reinterpret_cast<const f32x4*>(a.hw2[0] + (int64_t)m * OPE_HYP + fo);
-      const f32x4 h3 = *reinterpret_cast<const f32x4*>(a.hb2[0] + (int64_t)m * OPE_HYP + fo);
-      const f32x4 wb = *reinterpret_cast<const f32x4*>(th0 + ML.b2b_w + fo);
+      const f32x4 h1 = *reinterpret_cast<const f32x4*>(&hw1_s[0][j * kPartP + fo]);
+      const f32x4 h2 = mk2, h3 = mk3;
+      const f32x4 wb = *reinterpret_cast<const f32x4*>(&mx_s[0][OPE_MIX + fo]);
       f32x4 s1 = *reinterpret_cast<const f32x4*>(wk_s + (0 * 16 + j) * kPartP + fo);
 #pragma unroll
       for (int w = 1; w < kCW; ++w) {
@@ -529,16 +791,15 @@ __global__ void __launch_bounds__(64 * kCW, APW == 1 ? 2 : 1) qchain_kernel(Chai
       for (int k0 = 4 * g; k0 < A4; k0 += 16)
         *reinterpret_cast<f32x4*>(a.dqoh + r0 * A4 + k0) =
             f32x4{k0 == act ? dq : 0.f, k0 + 1 == act ? dq : 0.f, k0 + 2 == act ? dq : 0.f, k0 + 3 == act ? dq : 0.f};
-      const float* __restrict__ wq = th0 + AL.q_w + (int64_t)act * OPE_H + 4 * g;
       f32x4 d[4];
       float m1 = 0.f, m2 = 0.f;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const f32x4 w = *reinterpret_cast<const f32x4*>(wq + 16 * c);
-        const f32x4 gm = *reinterpret_cast<const f32x4*>(th0 + AL.lno_w + 16 * c + 4 * g);
+        const f32x4 gm = *reinterpret_cast<const f32x4*>(&ln_s[0][0][16 * c + 4 * g]);
+        const f32x4 wa = *reinterpret_cast<const f32x4*>(&wq_s[0][act * kPartP + 16 * c + 4 * g]);      // W_q row of the chosen action (staged)
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-          d[c][rr] = dq * w[rr];
+          d[c][rr] = dq * wa[rr];
           d[c][rr] *= gm[rr];
           m1 += d[c][rr];
           m2 = fmaf(d[c][rr], xh[ia][c][rr], m2);
@@ -556,6 +817,7 @@ __global__ void __launch_bounds__(64 * kCW, APW == 1 ? 2 : 1) qchain_kernel(Chai
       }
     }
   }
+  stamp(9);
 }
 
 }  // namespace
@@ -566,13 +828,19 @@ int launch_mixer_hyp(const HypFirstArgs& a0, hipStream_t st) {
   if (a0.TB < 1 || a0.S < 1 || a0.B < 1) return OPE_EINVAL;
   HypFirstArgs a = a0;
   const int tiles = ope_cdiv(a.TB, 16);
-  a.main_blocks = 2 * 2 * ope_cdiv(tiles, 4);
-  const int blocks = a.main_blocks + (a.side.total > 0 ? ope_cdiv(a.side.total, 256) : 0);
+  // Row tiles (= waves) per workgroup: 4, or as many more as it takes for the 4 * ceil(tiles / rpw) workgroups to be at most one per CU.
+  // Measured at 3s5z: 300 workgroups on 256 CUs (B = 32) run as two rounds, 23.7 us, where 228 (B = 24) take 12.9 us.
+  static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256; return n > 1 ? n : 256; }();
+  int rpw = 4;
+  while (rpw < 16 && 4 * ope_cdiv(tiles, rpw) > cus) ++rpw;
+  a.main_blocks = 2 * 2 * ope_cdiv(tiles, rpw);
+  const int threads = 64 * rpw;
+  const int blocks = a.main_blocks + (a.side.total > 0 ? ope_cdiv(a.side.total, threads) : 0);
   const int vec = ope_vec_of(a.S);
   kprof_work(2.0 * 2.0 * a.TB * (double)a.S * (3.0 * OPE_HYP + OPE_MIX));
-  if (vec == 4) OPE_LAUNCH(mixer_hyp_kernel<4>, dim3(blocks), dim3(256), 0, st, a);
-  else if (vec == 2) OPE_LAUNCH(mixer_hyp_kernel<2>, dim3(blocks), dim3(256), 0, st, a);
-  else OPE_LAUNCH(mixer_hyp_kernel<1>, dim3(blocks), dim3(256), 0, st, a);
+  if (vec == 4) OPE_LAUNCH(mixer_hyp_kernel<4>, dim3(blocks), dim3(threads), 0, st, a);
+  else if (vec == 2) OPE_LAUNCH(mixer_hyp_kernel<2>, dim3(blocks), dim3(threads), 0, st, a);
+  else OPE_LAUNCH(mixer_hyp_kernel<1>, dim3(blocks), dim3(threads), 0, st, a);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   note_launch("mixer_hyp", vec);
   return OPE_OK;

@@ -109,6 +109,7 @@ struct ChainArgs {
   float* dh_out; float* dqoh;
   // test / debug outputs (null unless ope_qmix_cfg.debug)
   float* q_all; float* agent_q; float* agent_nq; float* qtot; float* nqtot; float* v1; float* v2; float* hpre; float* d_agent_q;
+  long long* dbg;                             // optional per-wave s_memtime stamps [tile][wave][10] (tools/chain_phases.py)
 };
 bool qchain_shape_ok(int N, int A);
 int launch_mixer_hyp(const HypFirstArgs& a, hipStream_t st);

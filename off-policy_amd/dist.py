@@ -115,6 +115,24 @@ class OneShotAllreduce(object):
 
 _fast = None          # OneShotAllreduce once setup_fast_allreduce() has verified it, else None (torch.distributed / RCCL)
 _fast_note = "rccl (torch.distributed all_reduce)"
+_fast_gen = 0         # bumped whenever the one-shot path is switched on or off: a captured HIP graph holds raw pointers into ITS exchange buffers
+_graph_refs = 0       # captured graphs that reference the current one-shot exchange (note_graph_capture)
+_retired = []         # exchanges that were disabled while a captured graph still pointed into them: kept mapped, never launched again
+
+
+def fast_generation():
+    """Identity of the all-reduce path in use. A graphed step records it at capture and refuses to replay once it has changed
+    (its captured kernels would push into buffers that are no longer part of any exchange)."""
+    return _fast_gen
+
+
+def note_graph_capture():
+    """A HIP graph has just captured launches of the one-shot exchange: its buffers must outlive the graph. Returns the generation to check
+    before every replay."""
+    global _graph_refs
+    if _fast is not None:
+        _graph_refs += 1
+    return _fast_gen
 
 
 def fast_allreduce_failed():
@@ -124,11 +142,20 @@ def fast_allreduce_failed():
 
 def disable_fast_allreduce(reason="disabled"):
     """Back to torch.distributed's all_reduce (RCCL) for the rest of the run; call it on every rank."""
-    global _fast, _fast_note
+    global _fast, _fast_note, _fast_gen, _graph_refs
     if _fast is not None:
         ar, _fast = _fast, None
+        _fast_gen += 1
         _fast_note = "rccl (one-shot xGMI path %s)" % reason
-        _close_after_barrier(ar)
+        if _graph_refs > 0:
+            # captured graphs still hold raw pointers into this exchange's local and peer buffers: unmapping them would turn a stray
+            # replay into writes to freed memory. Keep everything mapped for the life of the process (a few MB); the graphs themselves
+            # refuse to replay from now on (fast_generation() changed), so the buffers are never used again either.
+            _retired.append(ar)
+            _graph_refs = 0
+            _close_after_barrier(None)
+        else:
+            _close_after_barrier(ar)
 
 
 def _close_after_barrier(ar, group=None):
@@ -143,10 +170,11 @@ def _close_after_barrier(ar, group=None):
         pass
 
 
-def graph_safe_allreduce():
-    """True when `allreduce_flat_` may be captured in a HIP graph: the one-shot exchange is in use (its launches are identical from
-    call to call); torch.distributed's all_reduce is kept out of captures."""
-    return _fast is not None and getattr(_fast, "graph_safe", False)
+def graph_safe_allreduce(n_floats=0):
+    """True when `allreduce_flat_` of a float32 CUDA vector of `n_floats` elements may be captured in a HIP graph: the one-shot exchange
+    is in use (its launches are identical from call to call) and the vector fits its slots; torch.distributed's all_reduce is kept out of
+    captures (allreduce_flat_ raises rather than fall back to it while a stream is capturing)."""
+    return _fast is not None and getattr(_fast, "graph_safe", False) and int(n_floats) <= _fast.max_floats
 
 
 def allreduce_backend():
@@ -183,8 +211,10 @@ def setup_fast_allreduce(device, group=None):
     t = torch.tensor([ok], dtype=torch.int32, device=device)
     torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN, group=group)
     if int(t.item()) == 1:
+        global _fast_gen
         ar.ctx.timeout_ms = 0      # default (10 s) from here on: training ranks may be skewed by host work
         _fast = ar
+        _fast_gen += 1
         return True
     _fast_note = "rccl (one-shot xGMI path not verified: %s)" % (err or "another rank failed")
     _close_after_barrier(ar, group)
@@ -200,6 +230,9 @@ def allreduce_flat_(flat, group=None):
     if is_distributed():
         if _fast is not None and group is None and flat.dtype == torch.float32 and flat.numel() <= _fast.max_floats and flat.is_cuda:
             return _fast(flat)
+        if flat.is_cuda and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("allreduce_flat_: a HIP graph is being captured and this vector (%s, %d elements) cannot go through the one-shot "
+                               "exchange (%s): torch.distributed's all_reduce must not be captured" % (flat.dtype, flat.numel(), allreduce_backend()))
         torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.SUM, group=group)
     return flat
 

@@ -207,6 +207,9 @@ def main():
         run_case("qmix_var_d124", EnvDims("var_d124", 3, 6, 124, 24, 6), n_episodes=5, inds=[2, 2, 1, 0], avail="bernoulli")
         run_case("qmix_var_mix216", EnvDims("var_mix216", 8, 6, 16, 216, 5), n_episodes=5, inds=[3, 1, 4, 0], avail="bernoulli")
         run_case("qmix_var_mix100", EnvDims("var_mix100", 5, 6, 16, 100, 5), n_episodes=5, inds=[0, 1, 4, 4, 2], avail="bernoulli", runner_padding=True)
+        # more agents than the fused chain kernel has waves (two agents per wave) and more actions than one 16-action head tile
+        run_case("qmix_var_n10", EnvDims("var_n10", 10, 18, 16, 40, 5), n_episodes=5, inds=[2, 0, 4, 1, 1], avail="bernoulli")
+        run_case("qmix_var_a20", EnvDims("var_a20", 3, 20, 16, 24, 5), n_episodes=5, inds=[3, 3, 0, 1], avail="bernoulli", argv=["--use_double_q"])
         run_case("qmix_var_s2232", EnvDims("var_s2232", 2, 5, 12, 2232, 12), n_episodes=13, inds=list(range(13)), avail="bernoulli", steps=2,
                  store_inputs=False)
         return

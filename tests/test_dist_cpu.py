@@ -74,3 +74,36 @@ def test_single_process_helpers_are_noops():
     assert np.array_equal(opdist.shard_indices(np.arange(6), 1, 3), [2, 3])
     with pytest.raises(AssertionError):
         opdist.shard_indices(np.arange(5), 0, 2)
+
+
+def test_disabling_the_one_shot_exchange_keeps_buffers_that_captured_graphs_point_into():
+    """MADDPG.make_graphed_step at world > 1 captures launches of the one-shot exchange, i.e. raw pointers into its
+    local and peer buffers. `disable_fast_allreduce` must then (a) NOT unmap those buffers, (b) change `fast_generation()` so that the
+    graphed step refuses to replay; without a captured graph it frees them as before. Host logic only: a stand-in exchange object."""
+    from offpolicy_amd import dist as D
+
+    class Fake(object):
+        max_floats, graph_safe, closed = 1000, True, 0
+
+        def close(self):
+            self.closed += 1
+
+        def timed_out(self):
+            return False
+    saved = (D._fast, D._fast_note, D._fast_gen, D._graph_refs, list(D._retired))
+    try:
+        a = Fake()
+        D._fast, D._graph_refs = a, 0
+        assert D.graph_safe_allreduce(1000) and not D.graph_safe_allreduce(1001)      # slots must hold the vector (ADVICE r3, low)
+        gen = D.note_graph_capture()
+        assert gen == D.fast_generation() and D._graph_refs == 1
+        D.disable_fast_allreduce("test")
+        assert D._fast is None and D.fast_generation() != gen and a.closed == 0 and a in D._retired and D._graph_refs == 0
+        assert not D.graph_safe_allreduce(1)
+        b = Fake()
+        D._fast = b
+        D.disable_fast_allreduce("test")            # no graph refers to this one: released
+        assert b.closed == 1 and b not in D._retired
+    finally:
+        D._fast, D._fast_note, D._fast_gen, D._graph_refs = saved[:4]
+        D._retired[:] = saved[4]

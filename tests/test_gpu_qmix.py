@@ -15,7 +15,8 @@ pytestmark = pytest.mark.gpu
 CASES = ["qmix_tiny", "qmix_tiny_huber_per", "qmix_tiny_nodouble", "vdn_tiny", "qmix_odd", "qmix_3m_katA", "qmix_tiny_prevact", "qmix_tiny_pershare",
          "qmix_gall_tiny", "qmix_gall_3m", "qmix_gall_odd",   # gall: scripts/train_smac_qmix.sh (wide state, gain 1, hard target updates)
          # round 4: shapes that reach the kernel variants bench.py runs when the kernels are pinned (tests below); here: what "by shape" picks
-         "qmix_var_d252", "qmix_var_d188", "qmix_var_d124", "qmix_var_mix216", "qmix_var_mix100", "qmix_var_s2232"]
+         "qmix_var_d252", "qmix_var_d188", "qmix_var_d124", "qmix_var_mix216", "qmix_var_mix100", "qmix_var_s2232",
+         "qmix_var_n10", "qmix_var_a20"]       # 10 agents (two per wave of the fused chain kernel), 20 actions (two head tiles; plain-max targets)
 RTOL = 1e-4
 
 
@@ -154,6 +155,7 @@ def test_pinned_kernel_that_cannot_run_the_shape_is_an_error(name, knob, value):
     g = load_golden(name)
     dims, buf, policy, trainer = build_from_fixture(g)
     trainer.tune[knob] = value
+    trainer.tune["chain_path"] = 1
     with pytest.raises(_lib.OpeError):
         trainer.train_policy_on_batch(batch_from(buf, g["inds"]))
 
@@ -177,6 +179,7 @@ def test_every_forward_mixer_kernel_matches_reference(name, path):
     g = load_golden(name)
     dims, buf, policy, trainer = build_from_fixture(g)
     trainer.tune["mixer_path"] = path
+    trainer.tune["chain_path"] = 1           # the forward mixer as a kernel of its own (the fused chain replaces paths 1 / 2: next test)
     soft = bool(g["hp_soft_update"]) if "hp_soft_update" in g else True
     hard_after = set(int(x) for x in g["hard_update_after"]) if "hard_update_after" in g else set()
     batch = batch_from(buf, g["inds"])
@@ -204,13 +207,70 @@ def test_every_forward_mixer_kernel_matches_reference(name, path):
             np.testing.assert_allclose(src[key + k], ref, rtol=0, atol=3e-5, err_msg=grp + k)
 
 
+CHAIN_CASES = ["qmix_tiny", "qmix_tiny_huber_per", "qmix_tiny_nodouble", "vdn_tiny", "qmix_odd", "qmix_3m_katA", "qmix_tiny_prevact", "qmix_tiny_pershare",
+               "qmix_var_mix216", "qmix_var_n10", "qmix_var_a20", "qmix_var_d252"]
+
+
+@pytest.mark.parametrize("path", [1, 2])
+@pytest.mark.parametrize("name", CHAIN_CASES)
+def test_both_forms_of_the_row_chain_match_reference(name, path):
+    """Between the GRU scan and its adjoint the step runs the (t, b)-row chain -- q heads, chosen / double-Q target selection, both mixers,
+    TD target + mask + loss (+ PER weights), the mixer's and the head's adjoints -- either as four launches (ope_qmix_cfg.chain_path = 1:
+    head_fwd, mixer_fwd, mixer_bwd, head_bwd) or as two (2: mixer_hyp = the mixers' first hyper-layers + qchain = everything else,
+    ope_chain.hip; what "by shape" picks). Pin each form and repeat the reference comparison on MSE / Huber + PER weights, plain-max targets,
+    VDN, odd sizes, 3m, previous-action inputs, per-agent centralized observations, 8 agents at the 3s5z state width, 10 agents (two per wave
+    of the fused kernel) with 18 actions and 20 actions (two 16-action head tiles); the launch log must show the pinned form."""
+    from offpolicy_amd import _lib
+    g = load_golden(name)
+    dims, buf, policy, trainer = build_from_fixture(g)
+    trainer.tune["chain_path"] = path
+    w = g["per_weights"] if "per_weights" in g else None
+    batch = batch_from(buf, g["inds"], w)
+    for s in range(len(g["loss"])):
+        info, prio, _ = trainer.train_policy_on_batch(batch)
+        launched = ";".join(_lib.last_launches())
+        if path == 2:
+            assert ("qchain_vdn<" if bool(g["vdn"]) else "qchain<") in launched and "head_fwd" not in launched and "mixer_fwd" not in launched, launched
+            assert bool(g["vdn"]) or "mixer_hyp<" in launched, launched
+        else:
+            assert "qchain" not in launched and "head_fwd" in launched and "head_bwd_rows" in launched, launched
+        if s == 0:
+            cnt = float(trainer.grad[trainer.numel + 1])
+            coef = min(1.0, float(g["hp_maxnorm"]) / (float(g["grad_norm"][0]) + 1e-6))
+            got = _flat_named(trainer, trainer.grad[:trainer.numel] * (coef / cnt))
+            for k, ref in sub(g, "grad0/").items():
+                np.testing.assert_allclose(got[k], ref, rtol=0, atol=2e-3 * max(np.abs(ref).max(), 1e-6), err_msg="grad " + k)
+        trainer.soft_target_updates()
+        np.testing.assert_allclose(float(info["loss"]), g["loss"][s], rtol=RTOL)
+        np.testing.assert_allclose(float(info["grad_norm"]), g["grad_norm"][s], rtol=RTOL)
+        np.testing.assert_allclose(float(info["Q_tot"]), g["Q_tot"][s], rtol=RTOL, atol=1e-6)
+        if w is not None:
+            np.testing.assert_allclose(prio, g["priorities"][s], rtol=RTOL, atol=1e-6)
+    live, tgt = _flat_named(trainer, trainer.theta), _flat_named(trainer, trainer.theta_tgt)
+    for grp, src, key in (("final_agent/", live, "agent/"), ("final_agent_tgt/", tgt, "agent/"), ("final_mixer/", live, "mixer/"), ("final_mixer_tgt/", tgt, "mixer/")):
+        for k, ref in sub(g, grp).items():
+            np.testing.assert_allclose(src[key + k], ref, rtol=0, atol=3e-5, err_msg=grp + k)
+
+
+def test_fused_row_chain_on_a_configuration_it_cannot_run_is_an_error():
+    """chain_path = 2 together with the wide-state mixer (mixer_path = 3) -- which keeps its stream-K GEMM path -- returns OPE_EINVAL."""
+    from offpolicy_amd import _lib
+    g = load_golden("qmix_gall_tiny")
+    dims, buf, policy, trainer = build_from_fixture(g)
+    trainer.tune.update(chain_path=2, mixer_path=3)
+    with pytest.raises(_lib.OpeError):
+        trainer.train_policy_on_batch(batch_from(buf, g["inds"]))
+
+
+@pytest.mark.parametrize("chain", [1, 2])
 @pytest.mark.parametrize("name", ["qmix_tiny", "qmix_odd"])
-def test_forward_intermediates_match_oracle(name):
+def test_forward_intermediates_match_oracle(name, chain):
     """Per-stage check (helps localise a failure): live q values, chosen/target agent q, Q_tot of both mixers."""
     from oracle import qmix_oracle as O
     g = load_golden(name)
     dims, buf, policy, trainer = build_from_fixture(g)
     trainer.tune["debug"] = 1               # ope_qmix_cfg.debug: keep "q_all" etc. in the workspace
+    trainer.tune["chain_path"] = chain
     batch = batch_from(buf, g["inds"])
     trainer.train_policy_on_batch(batch)
     torch.cuda.synchronize()
@@ -283,7 +343,7 @@ def test_policy_forward_with_previous_action_input():
     np.testing.assert_allclose(h.cpu().numpy(), h_ref.numpy(), rtol=1e-4, atol=2e-6)
 
 
-def _gpu_decisions(trainer, B, dims, avail):
+def _gpu_decisions(trainer, B, dims, avail, saved_only=False):
     """The discrete decisions the HIP step took, read back from its workspace in the oracle's `forced` format (oracle/qmix_oracle.py,
     "discrete decisions"): ReLU masks of the live trunk (one bit per feature, saved for the backward pass), ReLU masks and abs() signs of
     the live mixer's hyper-networks (from the saved post-ReLU / pre-abs activations), the double-Q greedy indices (argmax of the kernel's
@@ -299,8 +359,9 @@ def _gpu_decisions(trainer, B, dims, avail):
     if not trainer.vdn:
         for key, name in (("hyp_w1", "hw1"), ("hyp_w2", "hw2"), ("hyp_b2", "hb2")):
             d[key] = (trainer.workspace_view(B, name).view(T, B, 64) > 0).cpu()
-        d["abs_w1"] = torch.sign(trainer.workspace_view(B, "v1").view(T, B, N * 32)).cpu()
-        d["abs_w2"] = torch.sign(trainer.workspace_view(B, "v2").view(T, B, 32)).cpu()
+        if not saved_only:
+            d["abs_w1"] = torch.sign(trainer.workspace_view(B, "v1").view(T, B, N * 32)).cpu()
+            d["abs_w2"] = torch.sign(trainer.workspace_view(B, "v2").view(T, B, 32)).cpu()
     return d
 
 
@@ -312,8 +373,8 @@ def _gpu_greedy(trainer, B, dims, avail):
     return q.max(dim=-1)[1].cpu()
 
 
-@pytest.mark.parametrize("workload,nb", [("3s5z", 32), ("MMM2", 8), ("3s5z_gall", 32), ("MMM2", 32)])
-def test_full_size_3s5z_matches_oracle_one_step(workload, nb):
+@pytest.mark.parametrize("workload,nb,chain", [("3s5z", 32, 2), ("3s5z", 32, 1), ("MMM2", 8, 2), ("3s5z_gall", 32, 0), ("MMM2", 32, 2), ("MMM2", 32, 1)])
+def test_full_size_3s5z_matches_oracle_one_step(workload, nb, chain):
     """BASELINE config 4 at full size (N=8, A=14, D=252, S=216, T=150, B=32): one step vs the oracle; the MMM2
     dimensions (N=10, A=18, D=370, S=322, T=180: 8-byte vector paths, the 24-chunk trunk) at B=8 and at B=32; and 3s5z as the
     reference's own launch script runs it (scripts/train_smac_qmix.sh:14-17: --use_global_all_local_state -> S = 216 + 8 * 252 =
@@ -353,17 +414,23 @@ def test_full_size_3s5z_matches_oracle_one_step(workload, nb):
     # a first, throw-away step with ope_qmix_cfg.debug (keeps the live q values): only the greedy indices are taken from it
     opt = trainer.optimizer
     snap = (trainer.theta.clone(), trainer.theta_tgt.clone())
+    trainer.tune["chain_path"] = chain      # 2: the fused chain, 1: four launches (0: by shape -- the wide-state configuration keeps the separate kernels)
     trainer.tune["debug"] = 1
     trainer.train_policy_on_batch(batch)
     greedy = _gpu_greedy(trainer, nb, dims, avail_dev)
+    gpu = _gpu_decisions(trainer, nb, dims, avail_dev)      # (the fused chain keeps the pre-abs mixer weights only under `debug`)
     trainer.tune["debug"] = 0
     trainer.theta.copy_(snap[0]); trainer.theta_tgt.copy_(snap[1]); opt.exp_avg.zero_(); opt.exp_avg_sq.zero_(); opt.step_count = 0
     # the step under test: exactly what bench.py runs
     info, _, _ = trainer.train_policy_on_batch(batch)
     launched = _lib.last_launches()
     if workload == "3s5z":        # the bench line's kernel variants are the ones compared here
-        assert "trunk_fwd4<16>" in launched and "mixer_fwd3<14,1>" in launched and "gru_fwd4<4>" in launched and "trunk_bwd4" in launched, launched
-    gpu = _gpu_decisions(trainer, nb, dims, avail_dev)
+        assert "trunk_fwd4<16>" in launched and "gru_fwd4<4>" in launched and "trunk_bwd4" in launched, launched
+        assert ("qchain<1,1>" in launched and "mixer_hyp<4>" in launched) if chain == 2 else "mixer_fwd3<14,1>" in launched, launched
+    # the decisions this step saved for its own backward pass are those of the throw-away step (same arithmetic, bit for bit)
+    again = _gpu_decisions(trainer, nb, dims, avail_dev, saved_only=True)
+    for k, v in again.items():
+        assert torch.equal(v, gpu[k]), k
     gpu["greedy"] = greedy
     st = {k: (ep[k][:, :, 0] if k == "share_obs" else ep[k]) for k in ("obs", "share_obs", "acts", "rewards", "dones", "dones_env", "avail_acts")}
     ob = O.sample_inds(st, inds)
