@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--episodes", type=int, default=None, help="synthetic episodes resident in the replay store; default 5000 for the QMIX "
                     "workloads (the reference default buffer_size, config.py:37: 7.5 GB at 3s5z, far beyond the 256 MiB Infinity Cache), 512 "
                     "for the recurrent MADDPG family at MMM2 size (6.5 GB)")
+    ap.add_argument("--dry-run", action="store_true", help="rendezvous only: every rank reports its device, the all-reduce backend it ended up "
+                    "with (one-shot xGMI push verified against RCCL, or RCCL) and a timed 475 KB all-reduce; rank 0 prints them as one JSON line "
+                    "and the job exits -- what to run first on a new multi-GPU node")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-table", action="store_true", help="skip the per-kernel roofline table (10 extra untimed steps with an event "
                     "pair on every kernel launch, after the timed region)")
@@ -342,10 +345,52 @@ def allreduce_name():
     return opdist.allreduce_backend()
 
 
+def dry_run(a):
+    """`bench.py --gpus N --dry-run`: the distributed plumbing alone, so that the first run on a real multi-GPU node is diagnosable from its
+    log: per rank the device, the all-reduce backend chosen (and why, if the one-shot exchange did not verify), bit-equality of a 475 KB
+    SUM all-reduce with torch.distributed's, and its latency."""
+    world, rank, dev = dist_setup()
+    from offpolicy_amd import dist as opdist
+    n = 118795 + 4                       # the QMIX 3s5z flat gradient + tail
+    g = torch.Generator(device="cpu").manual_seed(99 + rank)
+    x = torch.randn(n, generator=g).to(dev)
+    ref = x.clone()
+    if world > 1:
+        torch.distributed.all_reduce(ref, op=torch.distributed.ReduceOp.SUM)
+    y = x.clone()
+    opdist.allreduce_flat_(y)
+    torch.cuda.synchronize()
+    ok = bool(torch.allclose(y, ref, rtol=1e-5, atol=1e-5))
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if world > 1:
+        torch.distributed.barrier()
+    ev0.record()
+    for _ in range(50):
+        opdist.allreduce_flat_(y)
+    ev1.record()
+    torch.cuda.synchronize()
+    me = {"rank": rank, "device": str(dev), "gpu": torch.cuda.get_device_name(dev), "allreduce": allreduce_name() if world > 1 else "none (one rank)",
+          "matches_torch_distributed": ok, "allreduce_us": round(1e3 * ev0.elapsed_time(ev1) / 50, 2),
+          "timed_out": bool(opdist.fast_allreduce_failed()), "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
+    print("[bench dry-run] %s" % json.dumps(me), file=sys.stderr, flush=True)
+    allr = [None] * world
+    if world > 1:
+        torch.distributed.all_gather_object(allr, me)
+    else:
+        allr = [me]
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "payload_floats": n, "ranks": allr,
+                          "all_ok": all(r["matches_torch_distributed"] and not r["timed_out"] for r in allr)}), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_spawn(a)
+    if a.dry_run:
+        return dry_run(a)
     if a.workload in ("maddpg_spread", "matd3_spread"):
         return main_ddpg(a)
     if a.workload.startswith("rma"):
@@ -389,14 +434,19 @@ def main():
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
         # Eager launches by default: the host enqueues a step in ~150 us against 0.4 ms of kernels, so it runs ahead and a
         # HIP-graph replay of the training kernels (--graph; QMix.make_graphed_step) is 1-4 % SLOWER here (measured).
-        graphed = trainer.make_graphed_step(buf, local_batch, gather_in_graph=False) if (a.graph and world == 1) else None
+        graphed = trainer.make_graphed_step(buf, local_batch, gather_in_graph=False) if (
+            a.graph and (world == 1 or opdist.graph_safe_allreduce(trainer.numel + _lib.OPE_GRAD_TAIL))) else None
+        G = {"graphed": graphed}
+
+        def drop_graph():            # (the exchange the graph captured was retired during the run: step eagerly on RCCL)
+            G["graphed"] = None
 
         n_trained = [0]
 
         def one_step(i=None):
             inds = opdist.shard_indices(np.random.choice(len(buf), global_batch), rank, world)
-            if graphed is not None:
-                return graphed(inds)
+            if G["graphed"] is not None:
+                return G["graphed"](inds)
             s = pbuf.sample_inds(inds)                       # ope_store_gather, current stream
             batch = tuple({"policy_0": x} for x in s) + (None, None)
             info, _, _ = trainer.train_policy_on_batch(batch)
@@ -411,7 +461,7 @@ def main():
         for _ in range(a.warmup):        # (timed_steps warms up again: these make the profiled window start warm)
             one_step(None)
         gather_profile(True)
-        windows, info = timed_windows(one_step, a.steps, 0, world, dev, a.repeats)
+        windows, info = timed_windows(one_step, a.steps, 0, world, dev, a.repeats, on_fallback=drop_graph)
         elapsed = median_window(windows)
         kernel_ms = gather_profile_read()[-a.steps * len(windows):]
         gather_profile(False)

@@ -438,10 +438,15 @@ class QMix(object):
         np.random.choice(len(buffer), batch_size); train_info: device tensors overwritten by every replay).
         With gather_in_graph=False the gather stays an eager launch into a fixed batch (so it can be bracketed by timing
         events: `step(inds, timing_events=(start, end))`) and the graph holds the 16 training kernels.
-        Restrictions: uniform replay (PER's importance weights come from the caller per step), one process (the gradient
-        all-reduce is not captured), Adam's step count lives on the device."""
-        if self.use_per or opdist.is_distributed() or self.multi:
-            raise NotImplementedError("graphed step: uniform replay, one shared policy, on a single GPU only")
+        Restrictions: uniform replay (PER's importance weights come from the caller per step), Adam's step count lives on the device.
+        In a multi-process run (one rank per GPU; `batch_size` and `inds` = the rank's share) the gradient all-reduce is captured with the
+        kernels: that needs the one-shot xGMI exchange (dist.setup_fast_allreduce verified it; its call counter lives on the device) --
+        with the RCCL fallback the step stays eager. The graph holds pointers into that exchange's buffers: it refuses to replay once
+        dist.disable_fast_allreduce has retired it."""
+        if self.use_per or self.multi:
+            raise NotImplementedError("graphed step: uniform replay, one shared policy")
+        if opdist.is_distributed() and not opdist.graph_safe_allreduce(self.numel + _lib.OPE_GRAD_TAIL):
+            raise NotImplementedError("graphed step at world > 1 needs the one-shot all-reduce with slots that hold the gradient vector (%s)" % opdist.allreduce_backend())
         pbuf = buffer.policy_buffers[policy_id]
         B = int(batch_size)
         self.fuse_soft_update = True
@@ -486,8 +491,12 @@ class QMix(object):
         opt.step_count = int(opt.step_dev[0].item())      # capture ran the host code but no kernels
         ring = [(torch.empty(B, dtype=torch.int64).pin_memory(), torch.cuda.Event()) for _ in range(8)]
         state = {"k": 0, "used": [False] * 8}
+        ar_gen = opdist.note_graph_capture() if opdist.is_distributed() else None
 
         def step(inds, timing_events=None):
+            if ar_gen is not None and opdist.fast_generation() != ar_gen:
+                raise RuntimeError("this graphed step captured the one-shot all-reduce, which has since been disabled (%s): build a new "
+                                   "graphed step or train eagerly" % opdist.allreduce_backend())
             k = state["k"]
             state["k"] = (k + 1) % 8
             host, ev = ring[k]

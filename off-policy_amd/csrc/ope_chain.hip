@@ -39,7 +39,7 @@ namespace {
 // the MFMA operand layout, not by the matrix pipes. Removed.)
 // ---------------------------------------------------------------------------------------------------------
 template <int VEC>
-__global__ void __launch_bounds__(1024) mixer_hyp_kernel(HypFirstArgs a) {
+__global__ void __launch_bounds__(512) mixer_hyp_kernel(HypFirstArgs a) {
   if ((int)blockIdx.x >= a.main_blocks) {
     transpose4_element(a.side, ((int)blockIdx.x - a.main_blocks) * (int)blockDim.x + (int)threadIdx.x);
     return;
@@ -84,6 +84,8 @@ __global__ void __launch_bounds__(1024) mixer_hyp_kernel(HypFirstArgs a) {
 #pragma unroll
       for (int q = 0; q < 7; ++q) acc[q] = mfma16(c.w[q][r], xs[r], acc[q]);
   };
+  // Two chunks in flight. (A ring of four was measured slower: 23.9 us against 19.6 us at 3s5z -- every workgroup streams the same 96 KB of
+  // weight rows, and more requests in flight only queue up at the L2 channels that hold them.)
   const int KC = (S + 15) >> 4;
   const int NIT = (KC + 1) & ~1;
   Chunk c0, c1;
@@ -832,7 +834,7 @@ int launch_mixer_hyp(const HypFirstArgs& a0, hipStream_t st) {
   // Measured at 3s5z: 300 workgroups on 256 CUs (B = 32) run as two rounds, 23.7 us, where 228 (B = 24) take 12.9 us.
   static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256; return n > 1 ? n : 256; }();
   int rpw = 4;
-  while (rpw < 16 && 4 * ope_cdiv(tiles, rpw) > cus) ++rpw;
+  while (rpw < 8 && 4 * ope_cdiv(tiles, rpw) > cus) ++rpw;
   a.main_blocks = 2 * 2 * ope_cdiv(tiles, rpw);
   const int threads = 64 * rpw;
   const int blocks = a.main_blocks + (a.side.total > 0 ? ope_cdiv(a.side.total, threads) : 0);

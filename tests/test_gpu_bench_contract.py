@@ -118,3 +118,18 @@ def test_two_rank_self_spawn_line_on_one_gpu():
     weak = out["weak_scaling"]
     assert weak["global_batch"] == 64 and weak["batch_per_gpu"] == 32 and weak["value"] > 0
     assert "cpu_baseline" not in out and out["roofline"]["achieved"] > 0
+
+
+def test_two_rank_dry_run_reports_the_backend_per_rank():
+    """`bench.py --gpus 2 --dry-run` (what to run first on a new multi-GPU node): rendezvous, all-reduce backend per rank, a verified and timed
+    475 KB all-reduce, one JSON line -- and nothing else is built."""
+    env = dict(os.environ, OPE_BENCH_SELFTEST="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.lstrip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["dry_run"] is True and out["n_gpus"] == 2 and len(out["ranks"]) == 2 and out["all_ok"] is True
+    for q, rk in enumerate(out["ranks"]):
+        assert rk["rank"] == q and rk["allreduce"] and rk["matches_torch_distributed"] and rk["allreduce_us"] > 0
+    assert r.stderr.count("[bench dry-run]") == 2
