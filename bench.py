@@ -847,7 +847,7 @@ def main_rddpg(a):
         def one_step(i=None):
             batch_t = buf.sample(global_batch, beta=0.4, p_id="policy_0", shard=(rank, world) if world > 1 else None)
             info, prio, idxes = trainer.shared_train_policy_on_batch("policy_0", batch_t)
-            buf.update_priorities(idxes, opdist.allgather_cat(prio), "policy_0")
+            buf.update_priorities(idxes, opdist.allgather_cat(prio, expect=len(idxes)), "policy_0")      # (device trees: already gathered inside the all-reduce)
             policy.soft_target_updates()
             return info
         windows, info = timed_windows(one_step, a.steps, a.warmup, world, dev, a.repeats)

@@ -142,6 +142,17 @@ int ope_store_gather_profile_read(float* ms_out_host, int32_t max_n);
  * twins: OPE_GATHER_FLOATS, OPE_GATHER_XCD, OPE_GATHER_UNROLL, OPE_GATHER_NT, OPE_GATHER_SMALL, OPE_GATHER_TILE (read once,
  * at the first call). */
 void ope_set_gather_params(int floats_per_block, int xcd_run, int unroll, int nontemporal, int small_tiles, int tile_floats);
+/* The same knobs PER CALL (two replay stores in one process need not share them; the setter above and the environment only provide the
+ * process DEFAULTS): every field 0 = keep the default; floats_per_block / xcd_run / unroll / tile_floats as above; nontemporal = 1 + the bit
+ * mask (1: none, 2: loads, 3: stores, 4: both); small_tiles = 1 on, 2 off. ope_store_gather_tuned = ope_store_gather (inds_dev: device
+ * int64[batch], range-checked in the kernel, bad_index_flag as there) or ope_store_gather_host_inds (inds_host: host int64[batch], range-
+ * checked here) -- exactly one of the two index sources non-NULL -- with `tune` (NULL = defaults). RecPolicyBuffer.sample_inds
+ * (rec_buffer.py:192-240). */
+typedef struct ope_gather_tune {
+  int32_t floats_per_block, xcd_run, unroll, nontemporal, small_tiles, tile_floats;
+} ope_gather_tune;
+int ope_store_gather_tuned(const ope_dims* dims, int32_t capacity, const ope_fields* store, const int64_t* inds_dev, const int64_t* inds_host,
+                           int32_t batch, const ope_fields* out, int32_t* bad_index_flag, const ope_gather_tune* tune, void* stream);
 /* Bytes of one episode over all seven fields (SURVEY.md section 8(d) "episode bytes"). */
 int64_t ope_episode_bytes(const ope_dims* dims);
 

@@ -40,6 +40,10 @@ class QmixCfg(C.Structure):
                 ("debug", C.c_int32), ("trunk_path", C.c_int32), ("chain_path", C.c_int32)]
 
 
+class GatherTune(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("floats_per_block", "xcd_run", "unroll", "nontemporal", "small_tiles", "tile_floats")]
+
+
 class AdamCfg(C.Structure):
     _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
                 ("max_grad_norm", C.c_float), ("weight_decay", C.c_float), ("tau", C.c_float),
@@ -90,6 +94,7 @@ def _load():
         "ope_store_gather": (C.c_int, [C.POINTER(Dims), i32, C.POINTER(Fields), p, i32, C.POINTER(Fields), p, p]),
         "ope_store_gather_host_inds": (C.c_int, [C.POINTER(Dims), i32, C.POINTER(Fields), p, i32, C.POINTER(Fields), p]),
         "ope_store_gather_sampled": (C.c_int, [C.POINTER(Dims), i32, i32, p, C.POINTER(Fields), C.c_uint64, p, i32, C.POINTER(Fields), p, p]),
+        "ope_store_gather_tuned": (C.c_int, [C.POINTER(Dims), i32, C.POINTER(Fields), p, p, i32, C.POINTER(Fields), p, C.POINTER(GatherTune), p]),
         "ope_store_gather_profile": (C.c_int, [i32]),
         "ope_store_gather_profile_read": (C.c_int, [p, i32]),
         "ope_set_gather_params": (None, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),

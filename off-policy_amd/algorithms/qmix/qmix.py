@@ -389,11 +389,22 @@ class QMix(object):
                  torch.as_tensor(np.asarray(importance_weights), dtype=torch.float32).to(self.device).contiguous())
             td_stats = torch.empty(2 * B, **self.tpdv)
         st = _lib.current_stream()
+        _, world_size = opdist.world()
+        n_head = self.numel + _lib.OPE_GRAD_TAIL
+        dev_prio = self.use_per and torch.is_tensor(importance_weights)
+        if dev_prio and world_size > 1 and self.grad.numel() < n_head + B * world_size:
+            # room behind the tail for the ranks' per-episode priorities: they ride on the gradient all-reduce (dist.priority_slots)
+            self.grad = torch.zeros(n_head + B * world_size, **self.tpdv)
         _lib.check(_lib.lib.ope_qmix_loss_and_grad(C.byref(cfg), C.byref(f), _lib.ptr(self.theta), _lib.ptr(self.theta_tgt),
                                                    _lib.ptr(w), _lib.ptr(ws), ws.numel(), _lib.ptr(self.grad),
                                                    _lib.ptr(td_stats), st), "ope_qmix_loss_and_grad")
-        _, world_size = opdist.world()
-        opdist.allreduce_flat_(self.grad)           # no-op on one GPU; ONE collective otherwise
+        gathered = None
+        if dev_prio and world_size > 1:
+            s = td_stats.view(B, 2)
+            gathered = opdist.priority_slots(self.grad, n_head, ((1 - self.args.per_nu) * s[:, 0] + self.args.per_nu * s[:, 1]) + self.per_eps)
+            opdist.allreduce_flat_(self.grad[:n_head + B * world_size])
+        else:
+            opdist.allreduce_flat_(self.grad[:n_head])           # no-op on one GPU; ONE collective otherwise
         self.optimizer.step_count += 1
         ac = _lib.AdamCfg()
         ac.lr, ac.beta1, ac.beta2, ac.eps = self.lr, self.optimizer.betas[0], self.optimizer.betas[1], self.opti_eps
@@ -421,7 +432,9 @@ class QMix(object):
         self._polyak_done = bool(self.fuse_soft_update)
         train_info = {"loss": stats[0], "grad_norm": stats[1], "Q_tot": stats[2]}
         new_priorities = None
-        if self.use_per and torch.is_tensor(importance_weights):   # device trees (device_tree=True): priorities stay in HBM
+        if gathered is not None:                                   # all ranks' priorities (rank order = the global batch order), in HBM
+            new_priorities = gathered
+        elif self.use_per and torch.is_tensor(importance_weights):   # device trees (device_tree=True): priorities stay in HBM
             s = td_stats.view(B, 2)
             new_priorities = ((1 - self.args.per_nu) * s[:, 0] + self.args.per_nu * s[:, 1]) + self.per_eps
         elif self.use_per:

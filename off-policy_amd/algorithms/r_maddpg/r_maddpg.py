@@ -75,7 +75,8 @@ class R_MADDPG(object):
                        "ope_rddpg_workspace_init")
             self._ws[B] = ws
             nmax = max(policy.critic.padded_numel, policy.actor.padded_numel)
-            self._grads[B] = (torch.zeros(policy.critic.padded_numel + 4, **self.tpdv), torch.zeros(policy.actor.padded_numel + 4, **self.tpdv),
+            # (the critic's vector has room behind its tail for the ranks' per-episode priorities: dist.priority_slots)
+            self._grads[B] = (torch.zeros(policy.critic.padded_numel + 4 + cfg.batch * opdist.world()[1], **self.tpdv), torch.zeros(policy.actor.padded_numel + 4, **self.tpdv),
                               torch.zeros(int(_lib.lib.ope_adam_scratch_floats(nmax)), **self.tpdv))
         return self._ws[B], self._grads[B]
 
@@ -248,16 +249,19 @@ class R_MADDPG(object):
                                                            _lib.ptr(policy.critic._flat), _lib.ptr(policy.target_critic._flat),
                                                            _lib.ptr(u_t), _lib.ptr(w), _lib.ptr(ws), ws.numel(), _lib.ptr(gc),
                                                            _lib.ptr(td_stats), st), "ope_rddpg_critic_loss_and_grad")
-        opdist.allreduce_flat_(gc)
-        cs = self._adam(policy.critic_optimizer, policy.critic.padded_numel, policy.critic._flat, policy.target_critic._flat, gc, scratch,
-                        T * B * world_size, policy.critic.unused_range)
-        train_info["critic_loss"], train_info["critic_grad_norm"] = cs[0], cs[1]
         new_priorities = None
+        n_head = policy.critic.padded_numel + 4
         if self.use_per and dev_prio:
             s = td_stats.view(K, B, 2)
             nu = self.args.per_nu
             new_priorities = (((1 - nu) * s[:, :, 0] + nu * s[:, :, 1]) + self.per_eps).mean(dim=0) + self.per_eps
-        elif self.use_per:        # r_maddpg.py:216-218: eps is added per head AND after the mean over heads
+            if world_size > 1:      # the ranks' priorities ride on the gradient all-reduce: every rank ends up with all world x B of them, in HBM
+                new_priorities = opdist.priority_slots(gc, n_head, new_priorities)
+        opdist.allreduce_flat_(gc if (self.use_per and dev_prio and world_size > 1) else gc[:n_head])
+        cs = self._adam(policy.critic_optimizer, policy.critic.padded_numel, policy.critic._flat, policy.target_critic._flat, gc, scratch,
+                        T * B * world_size, policy.critic.unused_range)
+        train_info["critic_loss"], train_info["critic_grad_norm"] = cs[0], cs[1]
+        if self.use_per and not dev_prio:        # r_maddpg.py:216-218: eps is added per head AND after the mean over heads
             s = td_stats.view(K, B, 2).cpu().numpy().astype(np.float32)
             nu = self.args.per_nu
             per_head = [((1 - nu) * s[k, :, 0] + nu * s[k, :, 1]).flatten() + self.per_eps for k in range(K)]

@@ -53,6 +53,10 @@ void read_env_once() {
   if (g_tune.floats > 65536) g_tune.floats = 65536;
 }
 
+}  // namespace
+static const GatherTune& g_tune_defaults() { return g_tune; }
+namespace {
+
 struct FieldDesc {
   const float* src;
   float* dst;
@@ -390,11 +394,22 @@ void launch_copy(const CopyArgs& args, const IDX& idx, hipStream_t st) {
   else OPE_LAUNCH((episode_copy_kernel<GATHER, 8, 0, IDX>), grid, block, lds, st, args, idx);
 }
 
-int build_args(const ope_dims* d, const ope_fields* src, const ope_fields* dst, int E, int capacity, bool gather, CopyArgs* out) {
+int build_args(const ope_dims* d, const ope_fields* src, const ope_fields* dst, int E, int capacity, bool gather, CopyArgs* out,
+               const ope_gather_tune* over = nullptr) {
   if (!d || !src || !dst) return OPE_EINVAL;
   const int T = d->episode_length, N = d->n_agents, A = d->act_dim, D = d->obs_dim, S = d->state_dim;
   if (T < 1 || N < 1 || A < 1 || D < 1 || S < 1 || E < 1) return OPE_EINVAL;
   read_env_once();
+  // the process defaults (environment, ope_set_gather_params), overlaid with the caller's per-call knobs: two stores in one process need not share them
+  GatherTune g_tune = ::g_tune_defaults();
+  if (over) {
+    if (over->tile_floats > 0) g_tune.tile = over->tile_floats < 256 ? 256 : (over->tile_floats > kTileMax ? kTileMax : over->tile_floats);
+    if (over->floats_per_block > 0) g_tune.floats = over->floats_per_block < 64 ? 64 : (over->floats_per_block > 65536 ? 65536 : over->floats_per_block);
+    if (over->xcd_run > 0) g_tune.xcd = over->xcd_run;
+    if (over->unroll == 4 || over->unroll == 8 || over->unroll == 16) g_tune.unroll = over->unroll;
+    if (over->nontemporal > 0) g_tune.nt = (over->nontemporal - 1) & 3;
+    if (over->small_tiles > 0) g_tune.small = over->small_tiles == 1 ? 1 : 0;
+  }
   const float* s[kFields] = {src->obs, src->share_obs, src->acts, src->rewards, src->dones, src->dones_env, src->avail_acts,
                              src->valid_transition};
   float* t[kFields] = {dst->obs, dst->share_obs, dst->acts, dst->rewards, dst->dones, dst->dones_env, dst->avail_acts,
@@ -636,6 +651,32 @@ extern "C" int ope_store_gather_host_inds(const ope_dims* dims, int32_t capacity
   int rc = build_args(dims, store, out, batch, capacity, true, &args);
   if (rc != OPE_OK) return rc;
   launch_copy<true>(args, ai, (hipStream_t)stream);
+  OPE_CHECK_LAUNCH();
+  return OPE_OK;
+}
+
+extern "C" int ope_store_gather_tuned(const ope_dims* dims, int32_t capacity, const ope_fields* store, const int64_t* inds_dev,
+                                      const int64_t* inds_host, int32_t batch, const ope_fields* out, int32_t* bad_index_flag,
+                                      const ope_gather_tune* tune, void* stream) {
+  (void)hipGetLastError();
+  if (capacity < 1 || batch < 1 || (!inds_dev) == (!inds_host)) return OPE_EINVAL;      // exactly one index source
+  CopyArgs args;
+  if (inds_host) {
+    if (batch > kMaxArgIdx) return OPE_EINVAL;
+    ArgIdx ai;
+    for (int i = 0; i < batch; ++i) {
+      if (inds_host[i] < 0 || inds_host[i] >= capacity) return OPE_EINVAL;
+      ai.v[i] = (int32_t)inds_host[i];
+    }
+    int rc = build_args(dims, store, out, batch, capacity, true, &args, tune);
+    if (rc != OPE_OK) return rc;
+    launch_copy<true>(args, ai, (hipStream_t)stream);
+  } else {
+    int rc = build_args(dims, store, out, batch, capacity, true, &args, tune);
+    if (rc != OPE_OK) return rc;
+    args.bad_index = bad_index_flag;
+    launch_copy<true>(args, DevIdx{inds_dev}, (hipStream_t)stream);
+  }
   OPE_CHECK_LAUNCH();
   return OPE_OK;
 }

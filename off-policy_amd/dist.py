@@ -225,6 +225,18 @@ def setup_fast_allreduce(device, group=None):
     return False
 
 
+def priority_slots(flat, n_head, local):
+    """Device all-gather riding on the gradient all-reduce: `flat` = [gradient and tail (n_head floats) | world x B slots]; this rank's B
+    per-sample values go into ITS slots, the others are zeroed, and the SUM all-reduce of the whole vector that follows leaves the
+    rank-ordered concatenation in flat[n_head:] on every rank (disjoint slots: x + 0 + ... + 0, exact). Returns that view."""
+    rank, world_size = world()
+    B = int(local.numel())
+    ext = flat[n_head:n_head + world_size * B]
+    ext.zero_()
+    ext[rank * B:(rank + 1) * B].copy_(local)
+    return ext
+
+
 def allreduce_flat_(flat, group=None):
     """In-place SUM all-reduce of one flat tensor; a single collective per training step."""
     if is_distributed():
@@ -237,10 +249,14 @@ def allreduce_flat_(flat, group=None):
     return flat
 
 
-def allgather_cat(x, group=None):
+def allgather_cat(x, group=None, expect=None):
     """Concatenation over ranks (rank order) of a per-sample vector: the per-episode priorities of a sharded prioritized
-    batch, so that every rank updates its replica of the sum/min trees with the same B values."""
+    batch, so that every rank updates its replica of the sum/min trees with the same B values.
+    `expect`: length of the concatenation; a vector that already has it is returned as is -- the trainers gather device-resident
+    priorities themselves, inside the gradient all-reduce (`priority_slots`), with no extra collective and no host trip."""
     if not is_distributed() or x is None:
+        return x
+    if expect is not None and len(x) == int(expect):
         return x
     _, world_size = world()
     if torch.is_tensor(x):

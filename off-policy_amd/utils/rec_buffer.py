@@ -57,6 +57,7 @@ class RecPolicyBuffer(object):
         # normalised to an indexed device ("cuda" -> "cuda:0") so that device comparisons with tensors hold
         self.device = torch.empty(0, device=torch.device(device if device is not None else "cuda:0")).device
         self._bad_index = torch.zeros(1, dtype=torch.int32, device=self.device)   # set by the kernels on an out-of-range index
+        self.gather_tune = None     # this store's gather knobs: dict of ope_gather_tune fields (include/ope.h); None = the process defaults
         self._reward_mask = bool(_reward_mask)      # episodes: skip steps after the episode end; transitions: plain mean/std
         self._stats_dirty = True
         self._ring = RingIndex(self.buffer_size)
@@ -270,6 +271,11 @@ class RecPolicyBuffer(object):
             assert int(self.filled_i) >= 1, "sample_device on an empty buffer"
             _lib.check(_lib.lib.ope_store_gather_sampled(C.byref(d), self.buffer_size, int(self.filled_i), _lib.ptr(filled_dev), C.byref(sf), seed, _lib.ptr(counter), B,
                                                          C.byref(of), _lib.ptr(dev_inds), _lib.current_stream()), "ope_store_gather_sampled")
+        elif self.gather_tune is not None:      # this store's own gather knobs (A/B sweeps; the process defaults otherwise): ope_gather_tune
+            tune = _lib.GatherTune(**{k: int(v) for k, v in self.gather_tune.items()})
+            _lib.check(_lib.lib.ope_store_gather_tuned(C.byref(d), self.buffer_size, C.byref(sf), None if host_inds is not None else _lib.ptr(dev_inds),
+                                                       host_inds.ctypes.data_as(C.c_void_p) if host_inds is not None else None, B, C.byref(of),
+                                                       _lib.ptr(self._bad_index), C.byref(tune), _lib.current_stream()), "ope_store_gather_tuned")
         elif host_inds is not None:
             _lib.check(_lib.lib.ope_store_gather_host_inds(C.byref(d), self.buffer_size, C.byref(sf), host_inds.ctypes.data_as(C.c_void_p), B,
                                                            C.byref(of), _lib.current_stream()), "ope_store_gather_host_inds")

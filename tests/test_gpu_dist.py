@@ -70,13 +70,13 @@ def _qmix_worker(rank, world, port, name, mode, out_q):
 def _rddpg_worker(rank, world, port, name, mode, out_q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", OPE_ALLREDUCE=mode)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", OPE_ALLREDUCE=mode.split("_")[0])
     torch.cuda.set_device(0)
     torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from offpolicy_amd import dist as opdist
         fast = opdist.setup_fast_allreduce(torch.device("cuda:0"))
-        res = _rddpg_steps(name, (rank, world))
+        res = _rddpg_steps(name, (rank, world), dev_w=(mode == "auto_devprio"))
         torch.cuda.synchronize()
         bad = opdist._fast.timed_out() if fast else False
         out_q.put((rank, bool(fast), bad) + res)
@@ -84,8 +84,10 @@ def _rddpg_worker(rank, world, port, name, mode, out_q):
         torch.distributed.destroy_process_group()
 
 
-def _rddpg_steps(name, shard):
-    """Two R_MATD3 updates (+ PER priorities) on the fixture's batch; shard = (rank, world) trains on that share."""
+def _rddpg_steps(name, shard, dev_w=False):
+    """Two R_MATD3 updates (+ PER priorities) on the fixture's batch; shard = (rank, world) trains on that share. dev_w: the importance
+    weights are a DEVICE tensor (device-resident trees): the priorities then stay in HBM and, at world > 1, are gathered inside the
+    critic's gradient all-reduce (dist.priority_slots) instead of through a host all-gather."""
     from conftest import load_golden
     from golden_util import EP_KEYS
     import test_gpu_rddpg as R
@@ -114,10 +116,15 @@ def _rddpg_steps(name, shard):
         trainer._noise_override = (None if u_t is None else u_t[:, :, mine].reshape(T + 1, N * per, A).contiguous(),
                                    u_a[:, :, mine].reshape(T, N * per, A).contiguous())
         s = buf.policy_buffers["policy_0"].sample_inds(inds[mine])
-        batch = tuple({"policy_0": a} for a in s) + (None if w is None else w[mine], inds if w is not None else None)
+        wm = None if w is None else (torch.as_tensor(w[mine], dtype=torch.float32).cuda() if dev_w else w[mine])
+        batch = tuple({"policy_0": a} for a in s) + (wm, inds if w is not None else None)
         info, prio, _ = trainer.shared_train_policy_on_batch("policy_0", batch)
         policy.soft_target_updates()
-        prios.append(opdist.allgather_cat(prio))
+        if dev_w and prio is not None:
+            assert torch.is_tensor(prio) and prio.is_cuda and len(prio) == B, "device priorities of ALL ranks, no host trip"
+            prios.append(prio.cpu().numpy())
+        else:
+            prios.append(opdist.allgather_cat(prio))
     torch.cuda.synchronize()
     return (policy.critic._flat.cpu().numpy(), policy.actor._flat.cpu().numpy(), policy.target_critic._flat.cpu().numpy(),
             None if prios[0] is None else np.asarray(prios))
@@ -384,3 +391,20 @@ def test_two_rank_qmix_graphed_step_equals_eager_distributed_step():
         np.testing.assert_allclose(g0[q], e0[q], rtol=0, atol=2e-6)
     np.testing.assert_allclose(g0[2], e0[2], rtol=2e-5)
     assert g0[3] and g1[3], "a graph that captured a retired exchange must refuse to replay"
+
+
+def test_two_rank_rmatd3_device_priorities_are_gathered_inside_the_gradient_allreduce():
+    """Prioritized multi-process step with device-resident importance weights: every rank writes its per-episode priorities into its own
+    slots behind the critic's gradient tail, the ONE all-reduce of the step sums the disjoint slots, and every rank holds all B priorities
+    in HBM -- no host all-gather. Values equal the single-process full-batch step's."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    name = "rmatd3_odd_per"
+    res = _spawn(_rddpg_worker, name, "auto_devprio")
+    fast0, bad0, c0, a0, tc0, p0 = res[0]
+    fast1, bad1, c1, a1, tc1, p1 = res[1]
+    assert fast0 == fast1 and not bad0 and not bad1
+    assert np.array_equal(c0, c1) and np.array_equal(a0, a1) and np.array_equal(p0, p1)
+    wc, wa, wtc, wp = _rddpg_steps(name, (0, 1))
+    np.testing.assert_allclose(c0, wc, rtol=0, atol=3e-6)
+    np.testing.assert_allclose(a0, wa, rtol=0, atol=3e-6)
+    np.testing.assert_allclose(p0, wp, rtol=2e-5)

@@ -243,17 +243,19 @@ def test_gather_kernel_variants_and_tile_path_are_bit_identical(dims_name, B):
     di = torch.as_tensor(inds, device="cuda:0")
     want = [getattr(pb, k).index_select(0, di) for k in FIELDS]      # [B, T(+1), (N,) dim]
     want = [w.permute(2, 1, 0, 3) if w.dim() == 4 else w.permute(1, 0, 2) for w in want]   # -> [N, T(+1), B, dim] / [T(+1), B, dim]
-    try:
-        for floats, xcd, unroll, nt, small, tile in [(2048, 8, 8, 0, 1, 4096), (2048, 8, 8, 0, 0, 4096), (512, 1, 4, 0, 1, 1024), (8192, 4, 16, 0, 1, 7168),
-                                                     (2048, 8, 8, 1, 1, 2048), (4096, 8, 8, 2, 1, 512), (24576, 16, 8, 3, 0, 4096)]:
-            _lib.lib.ope_set_gather_params(floats, xcd, unroll, nt, small, tile)
-            for src in (inds, di):        # host indices (kernel-argument block) and device-resident indices
-                got = pb.sample_inds(src)
-                for k, a, w in zip(FIELDS, got, want):
-                    assert tuple(a.shape) == tuple(w.shape), (k, a.shape, w.shape)
-                    assert torch.equal(a, w), (k, floats, xcd, unroll, nt, small, tile, torch.is_tensor(src))
-    finally:
-        _lib.lib.ope_set_gather_params(2048, 8, 8, 0, 1, 4096)
+    # the knobs travel PER STORE with the call (ope_gather_tune / ope_store_gather_tuned), not through process state
+    for floats, xcd, unroll, nt, small, tile in [(2048, 8, 8, 0, 1, 4096), (2048, 8, 8, 0, 0, 4096), (512, 1, 4, 0, 1, 1024), (8192, 4, 16, 0, 1, 7168),
+                                                 (2048, 8, 8, 1, 1, 2048), (4096, 8, 8, 2, 1, 512), (24576, 16, 8, 3, 0, 4096)]:
+        pb.gather_tune = dict(floats_per_block=floats, xcd_run=xcd, unroll=unroll, nontemporal=1 + nt, small_tiles=1 if small else 2, tile_floats=tile)
+        for src in (inds, di):        # host indices (kernel-argument block) and device-resident indices
+            got = pb.sample_inds(src)
+            for k, a, w in zip(FIELDS, got, want):
+                assert tuple(a.shape) == tuple(w.shape), (k, a.shape, w.shape)
+                assert torch.equal(a, w), (k, floats, xcd, unroll, nt, small, tile, torch.is_tensor(src))
+    pb.gather_tune = None
+    got = pb.sample_inds(inds)            # and the defaults again
+    for k, a, w in zip(FIELDS, got, want):
+        assert torch.equal(a, w), k
 
 
 def test_out_of_range_indices_are_skipped_and_flagged():

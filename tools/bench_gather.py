@@ -43,7 +43,9 @@ if sweep:
 def apply(over):
     c = dict(DEFAULT)
     c.update({k: v for k, v in over.items() if k != "dev"})
-    _lib.lib.ope_set_gather_params(c["floats"], c["xcd"], c["unroll"], c["nt"], c["small"], c["tile"])
+    # per store, with the call (ope_gather_tune): no process state
+    pb.gather_tune = dict(floats_per_block=c["floats"], xcd_run=c["xcd"], unroll=c["unroll"], nontemporal=1 + c["nt"], small_tiles=1 if c["small"] else 2,
+                          tile_floats=c["tile"])
 
 
 rng = np.random.RandomState(0)
