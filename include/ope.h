@@ -211,6 +211,10 @@ typedef struct ope_qmix_cfg {
                          *  recurrent nets with <= 16 agents and <= 32 actions, mixer_path != 3, time_chunks = 1 -- what "by shape" picks for
                          *  state_dim <= 512 (wider states: the stream-K GEMM of mixer_path 3 + the four launches); any other configuration
                          *  with chain_path = 2 returns OPE_EINVAL)                                  */
+  int32_t hypernet_layers; /* args.hypernet_layers (config.py:146): 0 or 2 = the default two-layer hyper-networks; 1 = hyper_w1 / hyper_w2 as
+                         *  single Linear layers from the state (q_mixer.py:39-44): 10 mixer tensors instead of 14 (ope_qmix_param_layout:
+                         *  hyper_w1.{weight [N*32][S], bias}, hyper_w2.{weight [32][S], bias}, hyper_b1.*, hyper_b2.0.*, hyper_b2.2.*); runs on
+                         *  the fused chain only (whole steps of recurrent nets; chain_path 1, mixer_path 3, mlp, phases: OPE_EINVAL)      */
 } ope_qmix_cfg;
 
 /* Flat parameter vector: the reference's named_parameters() order (agent q-network, then mixer; qmix.py:67-72),
@@ -219,6 +223,7 @@ typedef struct ope_qmix_cfg {
 #define OPE_QMIX_NPARAM_AGENT 22      /* recurrent agent net */
 #define OPE_QMIX_NPARAM_AGENT_MLP 16  /* MLP agent net (no GRU, no rnn.norm) */
 #define OPE_QMIX_NPARAM_MIXER 14
+#define OPE_QMIX_NPARAM_MIXER_1 10    /* hypernet_layers = 1 */
 #define OPE_GRAD_TAIL 4
 /* Fills offsets[i]/sizes[i] (floats) for the 22 (+14 unless vdn) tensors; returns the padded total length. */
 int64_t ope_qmix_param_layout(const ope_qmix_cfg* cfg, int64_t* offsets, int64_t* sizes);

@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("OPE_LIB_PATH") or os.path.join(_HERE, "libope.so")
 OPE_QMIX_NPARAM_AGENT = 22
 OPE_QMIX_NPARAM_AGENT_MLP = 16
 OPE_QMIX_NPARAM_MIXER = 14
+OPE_QMIX_NPARAM_MIXER_1 = 10      # hypernet_layers = 1
 OPE_GRAD_TAIL = 4
 
 
@@ -37,7 +38,7 @@ class QmixCfg(C.Structure):
                 ("use_huber", C.c_int32), ("use_per", C.c_int32), ("gamma", C.c_float), ("huber_delta", C.c_float),
                 ("per_nu", C.c_float), ("per_eps", C.c_float), ("mlp", C.c_int32), ("phase", C.c_int32),
                 ("mixer_path", C.c_int32), ("time_chunks", C.c_int32), ("scan_family", C.c_int32), ("scan_waves", C.c_int32),
-                ("debug", C.c_int32), ("trunk_path", C.c_int32), ("chain_path", C.c_int32)]
+                ("debug", C.c_int32), ("trunk_path", C.c_int32), ("chain_path", C.c_int32), ("hypernet_layers", C.c_int32)]
 
 
 class GatherTune(C.Structure):

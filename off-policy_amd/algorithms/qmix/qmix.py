@@ -52,7 +52,9 @@ class QMix(object):
     def __init__(self, args, num_agents, policies, policy_mapping_fn, device=torch.device("cuda:0"), episode_length=None,
                  vdn=False):
         self.args = args
-        require_reference_architecture(args, allow_prev_act_inp=not self._mlp)   # (the policies check their own support)
+        # (the policies check their own support); one-layer hyper-networks: recurrent nets, one shared policy (checked below)
+        require_reference_architecture(args, allow_prev_act_inp=not self._mlp, allow_hypernet_layers_1=not self._mlp and not vdn)
+        self.hypernet_layers = int(getattr(args, "hypernet_layers", 2)) if not vdn else 2
         self.use_popart = getattr(args, "use_popart", False)
         self.use_value_active_masks = getattr(args, "use_value_active_masks", False)
         self.use_per = args.use_per
@@ -83,6 +85,8 @@ class QMix(object):
         self._ws = {}
         self._ws_multi = {}
         self._gsq = {}
+        if self.multi and self.hypernet_layers == 1:
+            raise NotImplementedError("hypernet_layers=1 with several policies is not on the accelerated path")
         if self.multi:
             self._init_multi()
             if args.use_double_q:
@@ -102,6 +106,7 @@ class QMix(object):
         self.numel = int(P)
         self.theta = torch.zeros(self.numel, **self.tpdv)
         n_agent_tensors = _lib.OPE_QMIX_NPARAM_AGENT_MLP if self._mlp else _lib.OPE_QMIX_NPARAM_AGENT
+        n_mixer_tensors = _lib.OPE_QMIX_NPARAM_MIXER_1 if self.hypernet_layers == 1 else _lib.OPE_QMIX_NPARAM_MIXER
         agent_numel = policy.q_network.padded_numel
         self.theta[:agent_numel].copy_(policy.q_network._flat[:agent_numel])
         policy.q_network.rebind(self.theta)            # live weights now live inside the trainer's flat vector
@@ -109,7 +114,7 @@ class QMix(object):
             self.mixer = VDNMixer(args, num_agents, policy.central_obs_dim, self.device)
         else:
             self.mixer = QMixer(args, num_agents, policy.central_obs_dim, self.device, self.theta,
-                                list(off)[n_agent_tensors:n_agent_tensors + _lib.OPE_QMIX_NPARAM_MIXER])
+                                list(off)[n_agent_tensors:n_agent_tensors + n_mixer_tensors])
         # target networks: deep copies at construction (qmix.py:63-64)
         self.theta_tgt = self.theta.clone()
         self.target_policies = {"policy_0": _TargetPolicy(policy, policy.q_network.twin(self.theta_tgt))}
@@ -117,7 +122,7 @@ class QMix(object):
             self.target_mixer = VDNMixer(args, num_agents, policy.central_obs_dim, self.device)
         else:
             self.target_mixer = QMixer(args, num_agents, policy.central_obs_dim, self.device, self.theta_tgt,
-                                       list(off)[n_agent_tensors:n_agent_tensors + _lib.OPE_QMIX_NPARAM_MIXER], init=False)
+                                       list(off)[n_agent_tensors:n_agent_tensors + n_mixer_tensors], init=False)
         self.parameters = list(policy.parameters()) + list(self.mixer.parameters())
         self.optimizer = FlatAdam(self.numel, self.lr, self.opti_eps, self.device)
         self.grad = torch.zeros(self.numel + _lib.OPE_GRAD_TAIL, **self.tpdv)
@@ -293,6 +298,7 @@ class QMix(object):
         cfg.scan_family, cfg.scan_waves, cfg.debug = int(t["scan_family"]), int(t["scan_waves"]), int(t["debug"])
         cfg.trunk_path = int(t["trunk_path"])
         cfg.chain_path = int(t.get("chain_path", 0))
+        cfg.hypernet_layers = 0 if self.vdn else int(getattr(self, "hypernet_layers", 2))
         return cfg
 
     def _workspace(self, cfg):

@@ -24,6 +24,8 @@ bool cfg_ok(const ope_qmix_cfg* c) {
   if (c->mixer_path < 0 || c->mixer_path > 3 || c->time_chunks < 0 || c->time_chunks > kMaxChunksCfg) return false;
   if (c->trunk_path != 0 && c->trunk_path != 3 && c->trunk_path != 4) return false;
   if (c->chain_path < 0 || c->chain_path > 2) return false;
+  if (c->hypernet_layers < 0 || c->hypernet_layers > 2) return false;
+  if (c->hypernet_layers == 1 && (c->mlp || c->phase != 0 || c->mixer_path == 3 || c->chain_path == 1)) return false;   // one-layer hyper-networks: the fused chain only
   return d.n_agents >= 1 && d.act_dim >= 1 && d.obs_dim >= 1 && d.obs_dim <= 512 && d.state_dim >= 1 &&
          d.episode_length >= 1 && c->batch >= 1 && d.n_agents <= 64 && d.act_dim <= 200;
 }
@@ -82,7 +84,8 @@ struct Plan {
   bool wide;
   bool chain;                   // the (t, b)-row chain runs as mixer_hyp + qchain (ope_chain.hip) instead of head_fwd / mixer_fwd / mixer_bwd / head_bwd
   bool chain_can;               // ... could (shape, phase, schedule)
-  int64_t hb1, hw1_t, hw2_t, hb2_t, hb1_t;
+  bool hyp1;                    // one-layer hyper-networks (hypernet_layers = 1)
+  int64_t hb1, hw1_t, hw2_t, hb2_t, hb1_t, v1_t, v2_t;
 };
 
 thread_local char g_launch_log[2048];
@@ -102,9 +105,10 @@ void make_plan(const ope_qmix_cfg* c, Plan* p) {
     p->ML.end = p->AL.end;
     p->P = p->AL.end;
   } else {
-    p->ML = ope_mixer_layout(p->N, p->S, p->AL.end);
+    p->ML = c->hypernet_layers == 1 ? ope_mixer_layout1(p->N, p->S, p->AL.end) : ope_mixer_layout(p->N, p->S, p->AL.end);
     p->P = p->ML.end;
   }
+  p->hyp1 = !c->vdn && c->hypernet_layers == 1;
   Raw& w = p->raw;
   int o = 0;
   auto take = [&](int n) { int r = o; o += ope_round4(n); return r; };
@@ -134,7 +138,7 @@ void make_plan(const ope_qmix_cfg* c, Plan* p) {
   // 64 x 64 output tiles of the agent problems (fc1, fc2, W_ih, W_hh in two pieces, q head) and of the mixer problems
   // (three S-wide first layers of 64 rows, the NM x 64 and 32 x 64 second layers, the 32 x S state bias, the scalar head)
   const int agent_tiles = ope_cdiv(p->D, 64) + 1 + (c->mlp ? 0 : 3 + 2 + 1) + ope_cdiv(p->A, 64);
-  const int mixer_tiles = c->vdn ? 0 : 4 * ope_cdiv(p->S, 64) + ope_cdiv(p->NM, 64) + 2;
+  const int mixer_tiles = c->vdn ? 0 : (p->hyp1 ? ope_cdiv(p->S, 64) * (ope_cdiv(p->NM, 64) + 3) + 1 : 4 * ope_cdiv(p->S, 64) + ope_cdiv(p->NM, 64) + 2);
   int rows_per_split = rows_env > 0 ? rows_env : 160;
   if (rows_env <= 0) {
     int64_t best = -1;
@@ -220,12 +224,13 @@ void make_plan(const ope_qmix_cfg* c, Plan* p) {
   p->chain_can = c->phase == 0 && !c->mlp && p->chunks == 1 && c->mixer_path != 3 && qchain_shape_ok(p->N, p->A);
   // (more than 8 agents = two per wave of the chain kernel, without the register prefetch: measured 0.6091 vs 0.6048 ms at QMIX-MMM2 -- not
   // picked by shape)
-  p->chain = p->chain_can && (c->chain_path == 2 || (c->chain_path == 0 && chain_env != 0 && p->N <= 8 && (c->vdn || p->S <= kChainAutoS)));
+  p->chain = p->chain_can && (c->chain_path == 2 || p->hyp1 || (c->chain_path == 0 && chain_env != 0 && p->N <= 8 && (c->vdn || p->S <= kChainAutoS)));
   p->wide = !c->vdn && !p->chain && c->phase != 1 && c->phase != 3 && (c->mixer_path == 3 || (c->mixer_path == 0 && p->S > kWideAutoS));
   p->mix_slab = p->wide ? W.add("mix_slab", wide_slab_floats((int)p->TB, p->S)) : -1;
   p->hb1 = W.add("hb1", TB * OPE_MIX);
   p->hw1_t = W.add("hw1_t", TB * OPE_HYP); p->hw2_t = W.add("hw2_t", TB * OPE_HYP); p->hb2_t = W.add("hb2_t", TB * OPE_HYP);
   p->hb1_t = W.add("hb1_t", TB * OPE_MIX);
+  p->v1_t = W.add("v1_t", TB * p->NM); p->v2_t = W.add("v2_t", TB * OPE_MIX);
 }
 
 }  // namespace
@@ -291,6 +296,12 @@ extern "C" int64_t ope_qmix_param_layout(const ope_qmix_cfg* cfg, int64_t* offse
   }
   put(L.q_w, A * OPE_H); put(L.q_b, A);
   if (cfg->vdn) return L.end;
+  if (cfg->hypernet_layers == 1) {     // 10 tensors: hyper_w1.{weight,bias}, hyper_w2.*, hyper_b1.*, hyper_b2.0.*, hyper_b2.2.*
+    const MixerLayout M1 = ope_mixer_layout1(N, S, L.end);
+    put(M1.w1a_w, N * OPE_MIX * S); put(M1.w1a_b, N * OPE_MIX); put(M1.w2a_w, OPE_MIX * S); put(M1.w2a_b, OPE_MIX);
+    put(M1.b1_w, OPE_MIX * S); put(M1.b1_b, OPE_MIX); put(M1.b2a_w, OPE_HYP * S); put(M1.b2a_b, OPE_HYP); put(M1.b2b_w, OPE_HYP); put(M1.b2b_b, 1);
+    return M1.end;
+  }
   const MixerLayout M = ope_mixer_layout(N, S, L.end);
   const int mo[OPE_QMIX_NPARAM_MIXER] = {M.w1a_w, M.w1a_b, M.w1b_w, M.w1b_b, M.w2a_w, M.w2a_b, M.w2b_w, M.w2b_b,
                                          M.b1_w, M.b1_b, M.b2a_w, M.b2a_b, M.b2b_w, M.b2b_b};
@@ -349,6 +360,7 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
   make_plan(cfg, &p);
   if (workspace_bytes < p.ws.total * (int64_t)sizeof(float)) return OPE_ENOSPC;
   if (cfg->chain_path == 2 && !p.chain) return OPE_EINVAL;      // the fused chain was asked for explicitly and cannot run this configuration
+  if (p.hyp1 && !p.chain) return OPE_EINVAL;                    // one-layer hyper-networks exist on the fused chain only
   hipStream_t st = (hipStream_t)stream;
   float* W = (float*)workspace;
   int rc;
@@ -388,7 +400,7 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
     };
     if (!p.mlp && phase != 2) add(theta + p.AL.wih, 3 * OPE_H, OPE_H, W + p.thetaT);
     if (phase != 2) add(theta + p.AL.fc2_w, OPE_H, OPE_H, W + p.thetaT + OPE_H * 3 * OPE_H);
-    if (!cfg->vdn && phase != 1) {
+    if (!cfg->vdn && phase != 1 && !p.hyp1) {
       add(theta + p.ML.w1b_w, p.NM, OPE_HYP, W + p.mixT);
       add(theta + p.ML.w2b_w, OPE_MIX, OPE_HYP, W + p.mixT + (int64_t)OPE_HYP * p.NM);
     }
@@ -423,9 +435,11 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
       } else {
         HypFirstArgs hy;
         memset(&hy, 0, sizeof(hy));
-        hy.TB = (int)p.TB; hy.B = p.B; hy.S = p.S; hy.theta0 = theta; hy.theta1 = theta_tgt; hy.L = p.ML; hy.share = batch->share_obs;
-        hy.hw1[0] = W + p.hw1; hy.hw2[0] = W + p.hw2; hy.hb2[0] = W + p.hb2; hy.hb1[0] = W + p.hb1;
-        hy.hw1[1] = W + p.hw1_t; hy.hw2[1] = W + p.hw2_t; hy.hb2[1] = W + p.hb2_t; hy.hb1[1] = W + p.hb1_t;
+        hy.TB = (int)p.TB; hy.B = p.B; hy.S = p.S; hy.theta0 = theta; hy.theta1 = theta_tgt; hy.share = batch->share_obs;
+        hyp_tiles_for(p.ML, p.N, p.S, &hy);
+        hy.out[0][HYP_HW1] = W + p.hw1; hy.out[0][HYP_HW2] = W + p.hw2; hy.out[0][HYP_HB2] = W + p.hb2; hy.out[0][HYP_HB1] = W + p.hb1;
+        hy.out[1][HYP_HW1] = W + p.hw1_t; hy.out[1][HYP_HW2] = W + p.hw2_t; hy.out[1][HYP_HB2] = W + p.hb2_t; hy.out[1][HYP_HB1] = W + p.hb1_t;
+        hy.out[0][HYP_V1] = W + p.v1; hy.out[0][HYP_V2] = W + p.v2; hy.out[1][HYP_V1] = W + p.v1_t; hy.out[1][HYP_V2] = W + p.v2_t;
         hy.side = tr;
         // OPE_CHAIN_SIDE = 1: on the side stream, concurrent with the scan (fork behind the trunk launch, join in front of the chain kernel)
         static const int side_env = getenv("OPE_CHAIN_SIDE") ? atoi(getenv("OPE_CHAIN_SIDE")) : 0;
@@ -463,6 +477,7 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
     ca.h0 = W + p.h; ca.h1 = W + p.h_t; ca.acts = batch->acts; ca.avail = batch->avail_acts;
     ca.hw1[0] = W + p.hw1; ca.hw2[0] = W + p.hw2; ca.hb2[0] = W + p.hb2; ca.hb1[0] = W + p.hb1;
     ca.hw1[1] = W + p.hw1_t; ca.hw2[1] = W + p.hw2_t; ca.hb2[1] = W + p.hb2_t; ca.hb1[1] = W + p.hb1_t;
+    ca.v1x[0] = W + p.v1; ca.v1x[1] = W + p.v1_t; ca.v2x[0] = W + p.v2; ca.v2x[1] = W + p.v2_t;
     ca.td = td;
     ca.xhat_o = W + p.xhat_o; ca.rstd_o = W + p.rstd_o; ca.act_idx = (int*)(W + p.act_idx);
     ca.loss_part = W + p.loss_part; ca.err_abs = W + p.err_abs; ca.dqtot = W + p.dqtot;
@@ -470,7 +485,8 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
     ca.dh_out = W + p.dh_out; ca.dqoh = W + p.dqoh;
     if (dbg_on) {      // what the separate kernels leave in the workspace anyway: tests and tools read them
       ca.q_all = W + p.q_all; ca.agent_q = W + p.agent_q; ca.agent_nq = W + p.agent_nq; ca.qtot = W + p.qtot; ca.nqtot = W + p.nqtot;
-      ca.v1 = W + p.v1; ca.v2 = W + p.v2; ca.hpre = W + p.hpre; ca.d_agent_q = W + p.d_agent_q;
+      if (!p.hyp1) { ca.v1 = W + p.v1; ca.v2 = W + p.v2; }       // (one-layer hyper-networks: the first-layer kernel wrote them there already)
+      ca.hpre = W + p.hpre; ca.d_agent_q = W + p.d_agent_q;
       ca.dbg = (long long*)(W + p.dbg);
     }
     if (hyp_on_side && hipStreamWaitEvent(st, sp->ev[1], 0) != hipSuccess) return OPE_ELAUNCH;
@@ -543,6 +559,14 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
     const int64_t mb_ = p.raw_mixer, ms = rw.mixer_size;
     const int TBk = (int)p.TB;
     const float* S0 = batch->share_obs;  // rows 0..TB-1 are states at t < T
+    if (p.hyp1) {      // every hyper-network layer reads the state: grad W = (pre-activation adjoint)^T S
+      prob(wt, W + p.d_v1, p.NM, p.NM, S0, p.S, p.S, TBk, M.w1a_w - mbase, p.S, M.w1a_b - mbase, p.ns_mixer, mb_, ms);
+      prob(wt, W + p.d_v2, OPE_MIX, OPE_MIX, S0, p.S, p.S, TBk, M.w2a_w - mbase, p.S, M.w2a_b - mbase, p.ns_mixer, mb_, ms);
+      prob(wt, W + p.d_b1, OPE_MIX, OPE_MIX, S0, p.S, p.S, TBk, M.b1_w - mbase, p.S, M.b1_b - mbase, p.ns_mixer, mb_, ms);
+      prob(wt, W + p.d_hb2, OPE_HYP, OPE_HYP, S0, p.S, p.S, TBk, M.b2a_w - mbase, p.S, M.b2a_b - mbase, p.ns_mixer, mb_, ms);
+      prob(wt, W + p.dqtot, 4, 1, W + p.hb2, OPE_HYP, OPE_HYP, TBk, M.b2b_w - mbase, OPE_HYP, M.b2b_b - mbase, p.ns_mixer, mb_, ms);
+      return;
+    }
     prob(wt, W + p.d_hw1, OPE_HYP, OPE_HYP, S0, p.S, p.S, TBk, M.w1a_w - mbase, p.S, M.w1a_b - mbase, p.ns_mixer, mb_, ms);
     prob(wt, W + p.d_v1, p.NM, p.NM, W + p.hw1, OPE_HYP, OPE_HYP, TBk, M.w1b_w - mbase, OPE_HYP, M.w1b_b - mbase, p.ns_mixer, mb_, ms);
     prob(wt, W + p.d_hw2, OPE_HYP, OPE_HYP, S0, p.S, p.S, TBk, M.w2a_w - mbase, p.S, M.w2a_b - mbase, p.ns_mixer, mb_, ms);
@@ -669,7 +693,12 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
     }
     seg(L.q_b, p.A, FIN_COPY, srcSq, 0, 0, 0, 0, 0, 0);
   }
-  if (!cfg->vdn && do_mix) {  // mixer gradients: raw mixer slab has the same relative layout as the parameters
+  if (!cfg->vdn && do_mix && p.hyp1) {
+    const MixerLayout& M = p.ML;
+    const int mo1[10] = {M.w1a_w, M.w1a_b, M.w2a_w, M.w2a_b, M.b1_w, M.b1_b, M.b2a_w, M.b2a_b, M.b2b_w, M.b2b_b};
+    const int ms1[10] = {p.NM * p.S, p.NM, OPE_MIX * p.S, OPE_MIX, OPE_MIX * p.S, OPE_MIX, OPE_HYP * p.S, OPE_HYP, OPE_HYP, 1};
+    for (int q = 0; q < 10; ++q) seg(mo1[q], ms1[q], FIN_COPY, rw.agent_end + (mo1[q] - p.AL.end), 0, 0, 0, 0, 0, 0);
+  } else if (!cfg->vdn && do_mix) {  // mixer gradients: raw mixer slab has the same relative layout as the parameters
     const MixerLayout& M = p.ML;
     const int mo[OPE_QMIX_NPARAM_MIXER] = {M.w1a_w, M.w1a_b, M.w1b_w, M.w1b_b, M.w2a_w, M.w2a_b, M.w2b_w, M.w2b_b,
                                            M.b1_w, M.b1_b, M.b2a_w, M.b2a_b, M.b2b_w, M.b2b_b};

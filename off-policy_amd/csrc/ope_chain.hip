@@ -30,9 +30,9 @@ namespace ope {
 namespace {
 
 // ---------------------------------------------------------------------------------------------------------
-// First hyper-layers of both nets. Wave = 16 (t, b) rows x 7 of the 14 output tiles (tiles as stageA_row: 0-3 hyper_w1.0, 4-7 hyper_w2.0,
-// 8-11 hyper_b2.0, 12-13 hyper_b1); a workgroup = 4 row tiles of one (net, column half), so its waves stream the same weight rows through
-// the CU's L1. K in chunks of 16, two chunks in flight. Extra workgroups carry the weight transposes the backward kernels read.
+// First hyper-layers of both nets. Wave = 16 (t, b) rows x (up to) 7 of the output tiles (a table, hyp_tiles_for: two-layer hyper-networks
+// 14 = hyper_w1.0 x 4, hyper_w2.0 x 4, hyper_b2.0 x 4, hyper_b1 x 2; one-layer ones 2 N + 8 = hyper_w1 x 2 N, hyper_w2 x 2, hyper_b1 x 2,
+// hyper_b2.0 x 4); a workgroup = 4+ row tiles of one (net, column group), so its waves stream the same weight rows through the CU's L1. K in chunks of 16, two chunks in flight. Extra workgroups carry the weight transposes the backward kernels read.
 // (A persistent, weight-stationary form -- one wave per SIMD owning one (net, output tile) for its whole life and walking over every 37th row
 // tile: 8 400 evenly spread units -- was built and measured SLOWER: 28.9 us against 23.7 us at 3s5z, B = 32; each state row is then re-read
 // by the 14 waves of its net and the launch is bound by how fast the CUs' texture-address units accept the scattered 64-byte row pieces of
@@ -49,9 +49,10 @@ __global__ void __launch_bounds__(512) mixer_hyp_kernel(HypFirstArgs a) {
   const int tiles = (a.TB + 15) >> 4;
   const int rpw = (int)(blockDim.x >> 6);        // row tiles per workgroup (set by the launcher so that the grid is ONE round of the chip)
   const int groups = (tiles + rpw - 1) / rpw;
+  const int ncg = (a.ntiles + 6) / 7;            // column groups of (up to) 7 output tiles
   int bid = blockIdx.x;
-  const int half = bid & 1;
-  bid >>= 1;
+  const int cg = bid % ncg;
+  bid /= ncg;
   const int net = bid / groups, grp = bid - net * groups;
   const int tile = grp * rpw + wave;
   if (tile >= tiles) return;                    // (no barrier in this kernel)
@@ -62,13 +63,15 @@ __global__ void __launch_bounds__(512) mixer_hyp_kernel(HypFirstArgs a) {
   const int S = a.S;
   const float* __restrict__ srow = a.share + ((int64_t)(tt + net) * a.B + b) * S;      // live: s_t, target: s_{t+1} (qmix.py:155-156)
   const float* __restrict__ th = net == 0 ? a.theta0 : a.theta1;
-  const int it0 = 7 * half;
+  const int it0 = 7 * cg;
+  const int cnt = a.ntiles - it0 < 7 ? a.ntiles - it0 : 7;      // (uniform: the last group may hold fewer tiles; its spare slots repeat the last one)
   f32x4 acc[7];
   const float* wrow[7];
 #pragma unroll
   for (int q = 0; q < 7; ++q) {
-    acc[q] = *reinterpret_cast<const f32x4*>(stageA_bias(th, a.L, it0 + q) + 4 * g);
-    wrow[q] = stageA_row(th, a.L, S, it0 + q, j);
+    const HypTile& T = a.tile[it0 + (q < cnt ? q : cnt - 1)];
+    acc[q] = *reinterpret_cast<const f32x4*>(th + T.b_off + 4 * g);
+    wrow[q] = th + T.w_off + (int64_t)j * S;
   }
   struct Chunk { f32x4 w[7]; f32x4 x; };
   auto fetch = [&](Chunk& c, int ci) {           // clamped addresses: chunks past the end re-read valid data and meet a zero-masked state
@@ -103,17 +106,17 @@ __global__ void __launch_bounds__(512) mixer_hyp_kernel(HypFirstArgs a) {
   if (!valid) return;
 #pragma unroll
   for (int q = 0; q < 7; ++q) {
-    const int it = it0 + q;
+    if (q >= cnt) break;
+    const HypTile& T = a.tile[it0 + q];
     f32x4 v = acc[q];
-    float* dst;
-    if (it < 12) {                               // ReLU of the three hidden layers (q_mixer.py:41,46,62)
+    if (T.relu) {                                // the hidden layers (q_mixer.py:41,46,62); hyper_b1 and the one-layer hyper_w1 / hyper_w2 are plain Linears
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-      dst = (it < 4 ? a.hw1[net] : (it < 8 ? a.hw2[net] : a.hb2[net])) + (int64_t)m * OPE_HYP + 16 * (it & 3) + 4 * g;
-    } else {                                     // hyper_b1: a plain Linear (q_mixer.py:55)
-      dst = a.hb1[net] + (int64_t)m * OPE_MIX + 16 * (it - 12) + 4 * g;
     }
-    *reinterpret_cast<f32x4*>(dst) = v;
+    float* base = T.dst == HYP_HW1 ? a.out[net][HYP_HW1] : (T.dst == HYP_HW2 ? a.out[net][HYP_HW2] : (T.dst == HYP_HB2 ? a.out[net][HYP_HB2] :
+                  (T.dst == HYP_HB1 ? a.out[net][HYP_HB1] : (T.dst == HYP_V1 ? a.out[net][HYP_V1] : a.out[net][HYP_V2]))));
+    const int ldo = T.dst == HYP_HB1 || T.dst == HYP_V2 ? OPE_MIX : (T.dst == HYP_V1 ? a.ld[HYP_V1] : OPE_HYP);
+    *reinterpret_cast<f32x4*>(base + (int64_t)m * ldo + T.col + 4 * g) = v;
   }
 }
 
@@ -187,11 +190,13 @@ __device__ __forceinline__ float ln_row16x(const float* __restrict__ hrow, const
 //   * the agent's W1b^T slice for the adjoint is requested at the end of the forward mixer stage, a phase ahead of its use (its registers
 //     are the forward slices'); the chosen action's W_q row for the head's adjoint is read from the staged copy in LDS.
 // One workgroup per CU (up to 256 registers a wave).
-template <int NT, int APW, bool VDN>     // NT: 16-action tiles of the head (A <= 16 NT); APW: agents per wave (N <= 8 APW)
+// H1: one-layer hyper-networks (hypernet_layers = 1, q_mixer.py:39-44): w1 and w2 come straight from the first-layer kernel (pre-abs values in
+// v1x / v2x), so the second-stage products, their transposes in the adjoint and the hw1 / hw2 ReLU masks all drop out.
+template <int NT, int APW, bool VDN, bool H1>     // NT: 16-action tiles of the head (A <= 16 NT); APW: agents per wave (N <= 8 APW)
 __global__ void __launch_bounds__(64 * kCW, 2) qchain_kernel(ChainArgs a) {
   constexpr int QR = 16 * NT;                                                    // staged rows of W_q (zero beyond A)
   constexpr bool PFH = APW == 1;               // GRU-state rows requested at kernel start (one agent per wave: 48 registers)
-  constexpr bool PFW = APW == 1 && NT == 1;    // ... and the agent's W1b slices of both nets (64 registers); else loaded where they are used
+  constexpr bool PFW = APW == 1 && NT == 1 && !H1;    // ... and the agent's W1b slices of both nets (64 registers); else loaded where they are used
   __shared__ __attribute__((aligned(16))) float wq_s[2][QR * kPartP];            // [net][action][64] head weights
   __shared__ __attribute__((aligned(16))) float qb_s[2][QR];                     // [net][action] head bias
   __shared__ __attribute__((aligned(16))) float ln_s[2][2][OPE_H];               // [net][gamma | beta][64] rnn.norm
@@ -245,9 +250,9 @@ __global__ void __launch_bounds__(64 * kCW, 2) qchain_kernel(ChainArgs a) {
     int mr = tile * 16 + row;
     mr = mr < a.TB ? mr : a.TB - 1;
     // (pointer chosen by a select of the two kernel arguments: indexing the argument array with a per-lane value would be a LOAD of the pointer)
-    if (!VDN) st_hw1 = *reinterpret_cast<const f32x4*>((net ? a.hw1[1] : a.hw1[0]) + (int64_t)mr * OPE_HYP + 4 * piece);
+    if (!VDN && !H1) st_hw1 = *reinterpret_cast<const f32x4*>((net ? a.hw1[1] : a.hw1[0]) + (int64_t)mr * OPE_HYP + 4 * piece);
   }
-  if (!VDN) {
+  if (!VDN && !H1) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {         // W2b of both nets: 2 x 32 rows x 16 pieces
       const int p = tid + 512 * u;
@@ -267,7 +272,7 @@ __global__ void __launch_bounds__(64 * kCW, 2) qchain_kernel(ChainArgs a) {
   float st_mx = 0.f;
   if (!VDN) {   // the mixers' small vectors (threads 0 .. 2 kMx keep theirs)
     const int e2 = tid < 2 * kMx ? tid : 2 * kMx - 1, net = e2 / kMx, e = e2 - net * kMx;
-    const int off = e < OPE_MIX ? ML.w2b_b + e : (e < OPE_MIX + OPE_HYP ? ML.b2b_w + (e - OPE_MIX) : ML.b2b_b);
+    const int off = e < OPE_MIX ? (H1 ? ML.b2b_b : ML.w2b_b + e) : (e < OPE_MIX + OPE_HYP ? ML.b2b_w + (e - OPE_MIX) : ML.b2b_b);
     st_mx = (net == 0 ? th0 : th1)[off];
   }
   // private: GRU-state rows (live t, live t + 1, target t + 1), action / availability rows of this wave's agents
@@ -314,7 +319,7 @@ __global__ void __launch_bounds__(64 * kCW, 2) qchain_kernel(ChainArgs a) {
     const int net = p / (QR * 16), row = (p >> 4) % QR, piece = p & 15;
     *reinterpret_cast<f32x4*>(&wq_s[net][row * kPartP + 4 * piece]) = row < A ? st_wq[u] : zero4;
   }
-  if (!VDN) {
+  if (!VDN && !H1) {
     const int net = tid >> 8, row = (tid >> 4) & 15, piece = tid & 15;
     *reinterpret_cast<f32x4*>(&hw1_s[net][row * kPartP + 4 * piece]) = st_hw1;
 #pragma unroll
@@ -345,6 +350,10 @@ __global__ void __launch_bounds__(64 * kCW, 2) qchain_kernel(ChainArgs a) {
         const float* __restrict__ th = net == 0 ? th0 : th1;
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
+          if (H1) {      // the pre-abs w1 slice itself
+            b1b[ia][net][kh] = *reinterpret_cast<const f32x4*>((net ? a.v1x[1] : a.v1x[0]) + (int64_t)mm * NM + agc * OPE_MIX + 16 * kh + 4 * g);
+            continue;
+          }
           b1b[ia][net][kh] = *reinterpret_cast<const f32x4*>(th + ML.w1b_b + agc * OPE_MIX + 16 * kh + 4 * g);
           if (PFW) {
 #pragma unroll
@@ -356,13 +365,18 @@ __global__ void __launch_bounds__(64 * kCW, 2) qchain_kernel(ChainArgs a) {
     }
     {
       const int snet = wave < 4 ? (wave >> 1) : (wave & 1);
-      const float* __restrict__ src = (wave < 4 ? (snet ? a.hw2[1] : a.hw2[0]) : (snet ? a.hb2[1] : a.hb2[0])) + (int64_t)mm * OPE_HYP;
+      if (H1 && wave < 4) {      // this wave's half of the pre-abs w2
+        side[0] = *reinterpret_cast<const f32x4*>((snet ? a.v2x[1] : a.v2x[0]) + (int64_t)mm * OPE_MIX + 16 * (wave & 1) + 4 * g);
+        side[1] = side[2] = side[3] = side[0];
+      } else {
+        const float* __restrict__ src = ((wave < 4 && !H1) ? (snet ? a.hw2[1] : a.hw2[0]) : (snet ? a.hb2[1] : a.hb2[0])) + (int64_t)mm * OPE_HYP;
 #pragma unroll
-      for (int ft = 0; ft < 4; ++ft) side[ft] = *reinterpret_cast<const f32x4*>(src + 16 * ft + 4 * g);
+        for (int ft = 0; ft < 4; ++ft) side[ft] = *reinterpret_cast<const f32x4*>(src + 16 * ft + 4 * g);
+      }
       hb1v = *reinterpret_cast<const f32x4*>((snet ? a.hb1[1] : a.hb1[0]) + (int64_t)mm * OPE_MIX + 16 * (wave & 1) + 4 * g);
       // the live net's relu(hw2) / relu(hb2) at the feature tile waves 0..3 finish in the adjoint (their ReLU masks)
       const int fo = 16 * (wave & 3) + 4 * g;
-      mk2 = *reinterpret_cast<const f32x4*>(a.hw2[0] + (int64_t)mm * OPE_HYP + fo);
+      mk2 = H1 ? zero4 : *reinterpret_cast<const f32x4*>(a.hw2[0] + (int64_t)mm * OPE_HYP + fo);
       mk3 = *reinterpret_cast<const f32x4*>(a.hb2[0] + (int64_t)mm * OPE_HYP + fo);
     }
   }
@@ -539,8 +553,10 @@ __global__ void __launch_bounds__(64 * kCW, 2) qchain_kernel(ChainArgs a) {
 #pragma unroll
     for (int net = 0; net < 2; ++net) {
       f32x4 hv[4];
+      if (!H1) {
 #pragma unroll
-      for (int ft = 0; ft < 4; ++ft) hv[ft] = *reinterpret_cast<const f32x4*>(&hw1_s[net][j * kPartP + 16 * ft + 4 * g]);
+        for (int ft = 0; ft < 4; ++ft) hv[ft] = *reinterpret_cast<const f32x4*>(&hw1_s[net][j * kPartP + 16 * ft + 4 * g]);
+      }
       f32x4 hid[2] = {zero4, zero4};
 #pragma unroll
       for (int ia = 0; ia < APW; ++ia) {
@@ -550,6 +566,7 @@ __global__ void __launch_bounds__(64 * kCW, 2) qchain_kernel(ChainArgs a) {
           const float* __restrict__ thn = net == 0 ? th0 : th1;
 #pragma unroll
           for (int ft = 0; ft < 4; ++ft) {
+            if (H1) break;         // (v is the first-layer kernel's output already)
             f32x4 w[2];
 #pragma unroll
             for (int kh = 0; kh < 2; ++kh)
@@ -579,7 +596,7 @@ __global__ void __launch_bounds__(64 * kCW, 2) qchain_kernel(ChainArgs a) {
       for (int kh = 0; kh < 2; ++kh) *reinterpret_cast<f32x4*>(wk_s + ((net * kCW + wave) * 16 + j) * kHidP + 16 * kh + 4 * g) = hid[kh];
     }
     // the adjoint's W1b^T slices: requested now, used after the TD
-    {
+    if (!H1) {
       const float* __restrict__ w1bT = a.mixT;                    // [64][N*32]
 #pragma unroll
       for (int ia = 0; ia < APW; ++ia) {
@@ -597,7 +614,9 @@ __global__ void __launch_bounds__(64 * kCW, 2) qchain_kernel(ChainArgs a) {
     }
     // side jobs (see the requests above): waves 0..3 their half of w2 = W2b relu(hw2) + b, waves 4 / 5 the hyper_b2 head dots
     f32x4 v2h = zero4;
-    if (wave < 4) {
+    if (wave < 4 && H1) {
+      v2h = side[0];
+    } else if (wave < 4) {
       const int net = wave >> 1, kh = wave & 1;
       v2h = *reinterpret_cast<const f32x4*>(&mx_s[net][16 * kh + 4 * g]);
 #pragma unroll
@@ -736,28 +755,40 @@ __global__ void __launch_bounds__(64 * kCW, 2) qchain_kernel(ChainArgs a) {
         dqa = rowsum4(dqa);
         dqa_k[ia] = dqa;
         if (first && a.d_agent_q) a.d_agent_q[(int64_t)m * N + ag] = dqa;
+        if (!H1) {
 #pragma unroll
-        for (int ft = 0; ft < 4; ++ft)
+          for (int ft = 0; ft < 4; ++ft)
 #pragma unroll
-          for (int kh = 0; kh < 2; ++kh)
+            for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dh1[ft] = mfma16(w1t[ia][ft][kh][r], dv1[kh][r], dh1[ft]);
+              for (int r = 0; r < 4; ++r) dh1[ft] = mfma16(w1t[ia][ft][kh][r], dv1[kh][r], dh1[ft]);
+        }
       }
     }
     // (all reads of the forward partials in wk_s happened before the barrier that closed phase 3)
+    if (!H1) {
 #pragma unroll
-    for (int ft = 0; ft < 4; ++ft) *reinterpret_cast<f32x4*>(wk_s + (wave * 16 + j) * kPartP + 16 * ft + 4 * g) = dh1[ft];
+      for (int ft = 0; ft < 4; ++ft) *reinterpret_cast<f32x4*>(wk_s + (wave * 16 + j) * kPartP + 16 * ft + 4 * g) = dh1[ft];
+    }
     f32x4 dh2 = zero4;
-    if (wave < 4) {          // feature tile `wave` of dhw2 = W2b^T dv2
+    if (wave < 4 && !H1) {          // feature tile `wave` of dhw2 = W2b^T dv2
 #pragma unroll
       for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
         for (int r = 0; r < 4; ++r) dh2 = mfma16(w2t[kh][r], dv2[kh][r], dh2);
     }
     stamp(7);
-    lds_barrier();
+    if (!H1) lds_barrier();
     stamp(8);
-    if (wave < 4 && valid) {   // feature tile `wave` of the three hyper-net adjoints (pre-activation: zero where the ReLU was off)
+    if (wave < 4 && valid && H1) {   // only hyper_b2 has a hidden layer: its pre-activation adjoint
+      const int fo = 16 * wave + 4 * g;
+      const f32x4 wb = *reinterpret_cast<const f32x4*>(&mx_s[0][OPE_MIX + fo]);
+      f32x4 o3;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o3[r] = mk3[r] > 0.f ? dQ * wb[r] : 0.f;
+      *reinterpret_cast<f32x4*>(a.d_hb2 + (int64_t)m * OPE_HYP + fo) = o3;
+    }
+    if (wave < 4 && valid && !H1) {   // feature tile `wave` of the three hyper-net adjoints (pre-activation: zero where the ReLU was off)
       const int fo = 16 * wave + 4 * g;
       const f32x4 h1 = *reinterpret_cast<const f32x4*>(&hw1_s[0][j * kPartP + fo]);
       const f32x4 h2 = mk2, h3 = mk3;
@@ -826,20 +857,46 @@ __global__ void __launch_bounds__(64 * kCW, 2) qchain_kernel(ChainArgs a) {
 
 bool qchain_shape_ok(int N, int A) { return N >= 1 && N <= 2 * kCW && A >= 1 && A <= 32; }
 
+void hyp_tiles_for(const MixerLayout& L, int N, int S, HypFirstArgs* a) {
+  int n = 0;
+  auto add = [&](int w, int b, int rows, int dst, int relu) {
+    for (int r = 0; r < rows; r += 16) {
+      HypTile& T = a->tile[n++];
+      T.w_off = w + r * S; T.b_off = b + r; T.dst = dst; T.col = r; T.relu = relu;
+    }
+  };
+  if (L.one_layer) {
+    add(L.w1a_w, L.w1a_b, N * OPE_MIX, HYP_V1, 0);
+    add(L.w2a_w, L.w2a_b, OPE_MIX, HYP_V2, 0);
+    add(L.b1_w, L.b1_b, OPE_MIX, HYP_HB1, 0);
+    add(L.b2a_w, L.b2a_b, OPE_HYP, HYP_HB2, 1);
+  } else {
+    add(L.w1a_w, L.w1a_b, OPE_HYP, HYP_HW1, 1);
+    add(L.w2a_w, L.w2a_b, OPE_HYP, HYP_HW2, 1);
+    add(L.b2a_w, L.b2a_b, OPE_HYP, HYP_HB2, 1);
+    add(L.b1_w, L.b1_b, OPE_MIX, HYP_HB1, 0);
+  }
+  a->ntiles = n;
+  a->ld[HYP_HW1] = a->ld[HYP_HW2] = a->ld[HYP_HB2] = OPE_HYP;
+  a->ld[HYP_HB1] = a->ld[HYP_V2] = OPE_MIX;
+  a->ld[HYP_V1] = N * OPE_MIX;
+}
+
 int launch_mixer_hyp(const HypFirstArgs& a0, hipStream_t st) {
-  if (a0.TB < 1 || a0.S < 1 || a0.B < 1) return OPE_EINVAL;
+  if (a0.TB < 1 || a0.S < 1 || a0.B < 1 || a0.ntiles < 1 || a0.ntiles > kHypMaxTiles) return OPE_EINVAL;
   HypFirstArgs a = a0;
   const int tiles = ope_cdiv(a.TB, 16);
-  // Row tiles (= waves) per workgroup: 4, or as many more as it takes for the 4 * ceil(tiles / rpw) workgroups to be at most one per CU.
+  const int ncg = ope_cdiv(a.ntiles, 7);
+  // Row tiles (= waves) per workgroup: 4, or as many more as it takes for the 2 * ncg * ceil(tiles / rpw) workgroups to be at most one per CU.
   // Measured at 3s5z: 300 workgroups on 256 CUs (B = 32) run as two rounds, 23.7 us, where 228 (B = 24) take 12.9 us.
   static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256; return n > 1 ? n : 256; }();
   int rpw = 4;
-  while (rpw < 8 && 4 * ope_cdiv(tiles, rpw) > cus) ++rpw;
-  a.main_blocks = 2 * 2 * ope_cdiv(tiles, rpw);
+  while (rpw < 8 && 2 * ncg * ope_cdiv(tiles, rpw) > cus) ++rpw;
+  a.main_blocks = 2 * ncg * ope_cdiv(tiles, rpw);
   const int threads = 64 * rpw;
   const int blocks = a.main_blocks + (a.side.total > 0 ? ope_cdiv(a.side.total, threads) : 0);
   const int vec = ope_vec_of(a.S);
-  kprof_work(2.0 * 2.0 * a.TB * (double)a.S * (3.0 * OPE_HYP + OPE_MIX));
+  kprof_work(2.0 * 2.0 * a.TB * (double)a.S * 16.0 * a.ntiles);
   if (vec == 4) OPE_LAUNCH(mixer_hyp_kernel<4>, dim3(blocks), dim3(threads), 0, st, a);
   else if (vec == 2) OPE_LAUNCH(mixer_hyp_kernel<2>, dim3(blocks), dim3(threads), 0, st, a);
   else OPE_LAUNCH(mixer_hyp_kernel<1>, dim3(blocks), dim3(threads), 0, st, a);
@@ -853,12 +910,13 @@ int launch_qchain(const ChainArgs& a, hipStream_t st) {
   const int blocks = ope_cdiv(a.TB, 16);
   const int nt = a.A <= 16 ? 1 : 2, apw = a.N <= kCW ? 1 : 2;
   // heads (three 16-row evaluations per agent and tile), W1b of both nets, W2b, the two transposed products
-  kprof_work(2.0 * a.TB * ((double)a.N * 3.0 * OPE_H * a.A + (a.vdn ? 0.0 : (2.0 * ((double)a.N * OPE_MIX * OPE_HYP + OPE_MIX * OPE_HYP) +
+  kprof_work(2.0 * a.TB * ((double)a.N * 3.0 * OPE_H * a.A + ((a.vdn || a.ML.one_layer) ? 0.0 : (2.0 * ((double)a.N * OPE_MIX * OPE_HYP + OPE_MIX * OPE_HYP) +
                                                                              (double)a.N * OPE_MIX * OPE_HYP + OPE_MIX * OPE_HYP))));
-#define OPE_QCHAIN(NT_, APW_)                                                                        \
-  do {                                                                                               \
-    if (a.vdn) OPE_LAUNCH((qchain_kernel<NT_, APW_, true>), dim3(blocks), dim3(64 * kCW), 0, st, a); \
-    else OPE_LAUNCH((qchain_kernel<NT_, APW_, false>), dim3(blocks), dim3(64 * kCW), 0, st, a);      \
+#define OPE_QCHAIN(NT_, APW_)                                                                                       \
+  do {                                                                                                              \
+    if (a.vdn) OPE_LAUNCH((qchain_kernel<NT_, APW_, true, false>), dim3(blocks), dim3(64 * kCW), 0, st, a);         \
+    else if (a.ML.one_layer) OPE_LAUNCH((qchain_kernel<NT_, APW_, false, true>), dim3(blocks), dim3(64 * kCW), 0, st, a); \
+    else OPE_LAUNCH((qchain_kernel<NT_, APW_, false, false>), dim3(blocks), dim3(64 * kCW), 0, st, a);              \
   } while (0)
   if (nt == 1 && apw == 1) OPE_QCHAIN(1, 1);
   else if (nt == 2 && apw == 1) OPE_QCHAIN(2, 1);
@@ -866,7 +924,7 @@ int launch_qchain(const ChainArgs& a, hipStream_t st) {
   else OPE_QCHAIN(2, 2);
 #undef OPE_QCHAIN
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
-  note_launch(a.vdn ? "qchain_vdn" : "qchain", nt, apw);
+  note_launch(a.vdn ? "qchain_vdn" : (a.ML.one_layer ? "qchain_h1" : "qchain"), nt, apw);
   return OPE_OK;
 }
 

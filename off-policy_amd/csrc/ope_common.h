@@ -231,6 +231,8 @@ struct AgentLayout {
 struct MixerLayout {
   int w1a_w, w1a_b, w1b_w, w1b_b, w2a_w, w2a_b, w2b_w, w2b_b, b1_w, b1_b, b2a_w, b2a_b, b2b_w, b2b_b;
   int end;
+  int one_layer;     // hypernet_layers = 1 (q_mixer.py:39-44): hyper_w1 / hyper_w2 are single Linear layers from the state -- w1a_* = hyper_w1
+                     // [N*32][S], w2a_* = hyper_w2 [32][S]; w1b_* / w2b_* do not exist (-1)
 };
 
 static inline AgentLayout ope_agent_layout(int D, int A, int base) {
@@ -276,5 +278,21 @@ static inline MixerLayout ope_mixer_layout(int N, int S, int base) {
   L.b2a_w = take(OPE_HYP * S); L.b2a_b = take(OPE_HYP);
   L.b2b_w = take(OPE_HYP); L.b2b_b = take(1);
   L.end = o;
+  L.one_layer = 0;
+  return L;
+}
+// hypernet_layers = 1: named_parameters() order hyper_w1.{weight,bias}, hyper_w2.{weight,bias}, hyper_b1.*, hyper_b2.0.*, hyper_b2.2.*
+static inline MixerLayout ope_mixer_layout1(int N, int S, int base) {
+  MixerLayout L;
+  int o = base;
+  auto take = [&](int n) { int r = o; o += ope_round4(n); return r; };
+  L.w1a_w = take(N * OPE_MIX * S); L.w1a_b = take(N * OPE_MIX);
+  L.w2a_w = take(OPE_MIX * S); L.w2a_b = take(OPE_MIX);
+  L.w1b_w = L.w1b_b = L.w2b_w = L.w2b_b = -1;
+  L.b1_w = take(OPE_MIX * S); L.b1_b = take(OPE_MIX);
+  L.b2a_w = take(OPE_HYP * S); L.b2a_b = take(OPE_HYP);
+  L.b2b_w = take(OPE_HYP); L.b2b_b = take(1);
+  L.end = o;
+  L.one_layer = 1;
   return L;
 }

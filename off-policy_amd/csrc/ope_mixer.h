@@ -81,16 +81,29 @@ struct VdnArgs {
 
 // ---- fused (t, b)-row chain (ope_chain.hip) -----------------------------------------------------------------------------------------
 // First hyper-network layers of both nets over the T*B rows: a GEMM on the centralized state alone (no dependence on the agent networks)
+// One 16-feature output tile of a hyper-network layer that reads the state: rows [16 k, 16 k + 16) of a Linear's weight
+struct HypTile {
+  int w_off;       // theta offset of the tile's first weight row ([.][S] row-major)
+  int b_off;       // theta offset of its 16 biases
+  int dst;         // output array (HypFirstArgs::out index)
+  int col;         // first column inside that array's rows
+  int relu;        // ReLU on the output (the hidden layers of the two-layer hyper-networks and of hyper_b2)
+};
+constexpr int kHypMaxTiles = 48;               // one-layer hyper-networks with 16 agents: 2 * 16 + 8
+// output arrays of the first-layer kernel, per net: post-ReLU hidden layers of hyper_w1 / hyper_w2 / hyper_b2 [TB][64], hyper_b1's output [TB][32],
+// and (one-layer hyper-networks only) the pre-abs w1 [TB][N*32] and w2 [TB][32] themselves
+enum { HYP_HW1 = 0, HYP_HW2 = 1, HYP_HB2 = 2, HYP_HB1 = 3, HYP_V1 = 4, HYP_V2 = 5, HYP_NOUT = 6 };
 struct HypFirstArgs {
   int TB, B, S;
-  const float* theta0; const float* theta1;   // live / target flat parameters (MixerLayout offsets)
-  MixerLayout L;
+  const float* theta0; const float* theta1;   // live / target flat parameters
   const float* share;                         // [T+1][B][S]
-  float* hw1[2]; float* hw2[2]; float* hb2[2];   // [TB][64] post-ReLU hidden layers of hyper_w1 / hyper_w2 / hyper_b2, [0] live on s_t, [1] target on s_{t+1}
-  float* hb1[2];                              // [TB][32] hyper_b1 output
+  float* out[2][HYP_NOUT]; int ld[HYP_NOUT];  // [net][array], row length of each array ([0] live on s_t, [1] target on s_{t+1})
+  int ntiles; HypTile tile[kHypMaxTiles];
   Transp4 side;                               // weight transposes carried as extra workgroups (side.total = 0: none)
   int main_blocks;                            // set by the launcher
 };
+// fills ntiles / tile[] / ld[] for a mixer layout (two-layer: 14 tiles; one-layer: 2 N + 8)
+void hyp_tiles_for(const MixerLayout& L, int N, int S, HypFirstArgs* a);
 // Agent q heads + chosen / target selection + second mixer stage of both nets + TD / loss + mixer adjoint + head adjoint, one launch
 struct ChainArgs {
   int TB, B, N, T, A, NB;
@@ -101,6 +114,7 @@ struct ChainArgs {
   const float* h0; const float* h1;           // GRU states [T+1][N*B][64] of the live / target net
   const float* acts; const float* avail;      // [T][N*B][A] one-hot, [T+1][N*B][A] or null
   const float* hw1[2]; const float* hw2[2]; const float* hb2[2]; const float* hb1[2];   // HypFirstArgs outputs
+  const float* v1x[2]; const float* v2x[2];   // one-layer hyper-networks (ML.one_layer): pre-abs w1 [TB][N*32] / w2 [TB][32] straight from the state
   TdArgs td;
   // saved for the BPTT / trunk adjoint / weight-gradient kernels that follow
   float* xhat_o; float* rstd_o; int* act_idx;

@@ -210,6 +210,12 @@ def main():
         # more agents than the fused chain kernel has waves (two agents per wave) and more actions than one 16-action head tile
         run_case("qmix_var_n10", EnvDims("var_n10", 10, 18, 16, 40, 5), n_episodes=5, inds=[2, 0, 4, 1, 1], avail="bernoulli")
         run_case("qmix_var_a20", EnvDims("var_a20", 3, 20, 16, 24, 5), n_episodes=5, inds=[3, 3, 0, 1], avail="bernoulli", argv=["--use_double_q"])
+        # one-layer hyper-networks (--hypernet_layers 1) beyond the tiny shape fixture: 8 agents at the 3s5z state width (2 N + 8 = 24 first-layer
+        # tiles: three full column groups and a partial one) and an odd state width (scalar loads) with PER weights + Huber
+        run_case("qmix_var_hyper1_mix", EnvDims("var_hyper1_mix", 8, 6, 16, 216, 5), n_episodes=5, inds=[3, 1, 4, 0], avail="bernoulli",
+                 argv=["--hypernet_layers", "1"])
+        run_case("qmix_var_hyper1_odd", EnvDims("var_hyper1_odd", 3, 7, 18, 29, 5), n_episodes=6, inds=[5, 1, 1, 2, 0], avail="bernoulli", runner_padding=True,
+                 per_weights=np.array([1.0, 0.5, 0.25, 0.8, 0.9]), argv=["--hypernet_layers", "1", "--use_huber_loss", "--huber_delta", "1.0", "--use_per"])
         run_case("qmix_var_s2232", EnvDims("var_s2232", 2, 5, 12, 2232, 12), n_episodes=13, inds=list(range(13)), avail="bernoulli", steps=2,
                  store_inputs=False)
         return

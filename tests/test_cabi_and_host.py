@@ -189,3 +189,40 @@ def test_every_environment_switch_is_documented():
     assert names, "scan found nothing: pattern out of date"
     missing = sorted(n for n in names if n not in docs)
     assert not missing, "undocumented switches: %s" % missing
+
+
+def test_one_layer_hyper_networks_layout_and_initialisation_match_the_reference():
+    """hypernet_layers = 1 (q_mixer.py:39-44; round 4: supported by the recurrent QMIX trainer on the fused chain kernels): the C-ABI's
+    parameter layout has the reference's 10 mixer tensors with its shapes, our constructor consumes the init RNG stream exactly as the
+    reference's does (fixture qmix_shape_hyper1 = outputs of the real reference), and the configurations the one-layer form cannot run
+    are refused by cfg validation (no silent other path)."""
+    import torch
+    from offpolicy_amd import _lib
+    from offpolicy_amd.algorithms.qmix.algorithm.agent_q_function import init_agent_values, AGENT_PARAM_NAMES
+    from offpolicy_amd.algorithms.qmix.algorithm.q_mixer import init_mixer_values, MIXER_PARAM_NAMES_1, mixer_param_shapes
+    g = load_golden("qmix_shape_hyper1")
+    n, a, d, s, t = [int(x) for x in g["dims"]]
+    cfg = _lib.QmixCfg()
+    cfg.dims, cfg.batch, cfg.hypernet_layers = _lib.Dims(n, a, d, s, t), 4, 1
+    off, siz = (C.c_int64 * 36)(), (C.c_int64 * 36)()
+    total = _lib.lib.ope_qmix_param_layout(C.byref(cfg), off, siz)
+    assert total > 0
+    got = list(siz)[22:32]
+    want = [int(np.prod(g["mixer/" + k].shape)) for k in MIXER_PARAM_NAMES_1]
+    assert got == want and list(siz)[32] == 0
+    assert [tuple(x) for x in mixer_param_shapes(n, s, 1)] == [g["mixer/" + k].shape for k in MIXER_PARAM_NAMES_1]
+    assert _lib.lib.ope_qmix_workspace_bytes(C.byref(cfg)) > 0
+    torch.manual_seed(1)
+    np.random.seed(1)
+    av = init_agent_values(d, a)
+    mv = init_mixer_values(n, s, hypernet_layers=1)
+    for v, k in zip(av, AGENT_PARAM_NAMES):
+        assert np.array_equal(v.numpy(), g["agent/" + k]), k
+    for v, k in zip(mv, MIXER_PARAM_NAMES_1):
+        assert np.array_equal(v.numpy(), g["mixer/" + k]), k
+    for bad in (dict(mlp=1), dict(phase=2), dict(mixer_path=3), dict(chain_path=1)):
+        c2 = _lib.QmixCfg()
+        c2.dims, c2.batch, c2.hypernet_layers = _lib.Dims(n, a, d, s, 1 if "mlp" in bad else t), 4, 1
+        for k, v in bad.items():
+            setattr(c2, k, v)
+        assert _lib.lib.ope_qmix_workspace_bytes(C.byref(c2)) == -1, bad

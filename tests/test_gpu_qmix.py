@@ -16,7 +16,9 @@ CASES = ["qmix_tiny", "qmix_tiny_huber_per", "qmix_tiny_nodouble", "vdn_tiny", "
          "qmix_gall_tiny", "qmix_gall_3m", "qmix_gall_odd",   # gall: scripts/train_smac_qmix.sh (wide state, gain 1, hard target updates)
          # round 4: shapes that reach the kernel variants bench.py runs when the kernels are pinned (tests below); here: what "by shape" picks
          "qmix_var_d252", "qmix_var_d188", "qmix_var_d124", "qmix_var_mix216", "qmix_var_mix100", "qmix_var_s2232",
-         "qmix_var_n10", "qmix_var_a20"]       # 10 agents (two per wave of the fused chain kernel), 20 actions (two head tiles; plain-max targets)
+         "qmix_var_n10", "qmix_var_a20",       # 10 agents (two per wave of the fused chain kernel), 20 actions (two head tiles; plain-max targets)
+         # one-layer hyper-networks (--hypernet_layers 1, q_mixer.py:39-44): the tiny shape fixture, 8 agents at S = 216, odd S + Huber + PER
+         "qmix_shape_hyper1", "qmix_var_hyper1_mix", "qmix_var_hyper1_odd"]
 RTOL = 1e-4
 
 

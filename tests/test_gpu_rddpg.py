@@ -224,7 +224,8 @@ def test_unnormalised_gradient_is_additive_over_episodes():
         _lib.check(_lib.lib.ope_rddpg_actor_loss_and_grad(C.byref(cfg), C.byref(f), _lib.ptr(policy.actor._flat), _lib.ptr(policy.critic._flat),
                                                           _lib.ptr(ua), _lib.ptr(ws), ws.numel(), _lib.ptr(ga), st), "actor")
         torch.cuda.synchronize()
-        return gc.double().cpu().numpy().copy(), ga.double().cpu().numpy().copy()
+        nc = policy.critic.padded_numel + 4       # (behind the tail the critic's vector carries per-episode priority slots: dist.priority_slots)
+        return gc[:nc].double().cpu().numpy().copy(), ga.double().cpu().numpy().copy()
 
     # perturb the critic away from its (targets == live) initial state so the TD errors are not degenerate
     policy.critic._flat.add_(0.01 * torch.randn_like(policy.critic._flat))
