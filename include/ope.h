@@ -43,6 +43,9 @@ typedef struct ope_dims {
   int32_t obs_dim;        /* D */
   int32_t state_dim;      /* S */
   int32_t episode_length; /* T */
+  int32_t layer_N;        /* args.layer_N (config.py:65): hidden blocks (Linear + ReLU + LayerNorm) behind fc1 in the agent network's MLP base
+                           * (mlp.py:14-28). 0 or 1 = the reference default; 2 = a second block `rnn.mlp.fc2.1.*` (4 more tensors between
+                           * fc2.0 and the GRU): recurrent QMIX / VDN with one shared policy only, anything else returns OPE_EINVAL */
 } ope_dims;
 
 /* Seven per-episode fields, in the order of RecPolicyBuffer.sample_inds' return tuple
@@ -221,11 +224,13 @@ typedef struct ope_qmix_cfg {
  * every tensor padded to a multiple of 4 floats so rows can be read as float4. The gradient vector has the
  * same layout followed by OPE_GRAD_TAIL floats: [loss_sum, mask_count, qtot_sum, 0].                        */
 #define OPE_QMIX_NPARAM_AGENT 22      /* recurrent agent net */
+#define OPE_QMIX_NPARAM_AGENT_2 26    /* ... with layer_N = 2 */
 #define OPE_QMIX_NPARAM_AGENT_MLP 16  /* MLP agent net (no GRU, no rnn.norm) */
 #define OPE_QMIX_NPARAM_MIXER 14
 #define OPE_QMIX_NPARAM_MIXER_1 10    /* hypernet_layers = 1 */
 #define OPE_GRAD_TAIL 4
-/* Fills offsets[i]/sizes[i] (floats) for the 22 (+14 unless vdn) tensors; returns the padded total length. */
+/* Fills offsets[i]/sizes[i] (floats) for the 22 (layer_N = 2: 26) agent + 14 (hypernet_layers = 1: 10; vdn: 0) mixer tensors -- arrays
+ * of at least 48 entries --; returns the padded total length. */
 int64_t ope_qmix_param_layout(const ope_qmix_cfg* cfg, int64_t* offsets, int64_t* sizes);
 /* Workspace (bytes) ope_qmix_loss_and_grad needs. */
 int64_t ope_qmix_workspace_bytes(const ope_qmix_cfg* cfg);

@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OPE_LIB_PATH") or os.path.join(_HERE, "libope.so")
 
 OPE_QMIX_NPARAM_AGENT = 22
+OPE_QMIX_NPARAM_AGENT_2 = 26      # layer_N = 2
 OPE_QMIX_NPARAM_AGENT_MLP = 16
 OPE_QMIX_NPARAM_MIXER = 14
 OPE_QMIX_NPARAM_MIXER_1 = 10      # hypernet_layers = 1
@@ -26,7 +27,7 @@ class OpeError(RuntimeError):
 
 class Dims(C.Structure):
     _fields_ = [("n_agents", C.c_int32), ("act_dim", C.c_int32), ("obs_dim", C.c_int32), ("state_dim", C.c_int32),
-                ("episode_length", C.c_int32)]
+                ("episode_length", C.c_int32), ("layer_N", C.c_int32)]
 
 
 class Fields(C.Structure):

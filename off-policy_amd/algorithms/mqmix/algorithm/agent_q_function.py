@@ -28,7 +28,7 @@ def mlp_agent_layout(obs_dim, act_dim):
     cfg = _lib.QmixCfg()
     cfg.dims = _lib.Dims(1, act_dim, obs_dim, 1, 1)
     cfg.batch, cfg.vdn, cfg.mlp = 1, 1, 1
-    off, siz = (C.c_int64 * 36)(), (C.c_int64 * 36)()
+    off, siz = (C.c_int64 * 48)(), (C.c_int64 * 48)()
     total = _lib.lib.ope_qmix_param_layout(C.byref(cfg), off, siz)
     if total < 0:
         _lib.check(int(total), "ope_qmix_param_layout")

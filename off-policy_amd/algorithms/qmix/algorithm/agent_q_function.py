@@ -28,27 +28,37 @@ AGENT_PARAM_NAMES = [
 ]
 
 
-def agent_param_shapes(obs_dim, act_dim):
+def agent_param_names(layer_N=1):
+    """named_parameters() of AgentQFunction with `layer_N` hidden blocks behind fc1 (mlp.py:14-28: fc2 = layer_N clones of fc_h)."""
+    if layer_N == 1:
+        return list(AGENT_PARAM_NAMES)
+    i = AGENT_PARAM_NAMES.index("rnn.rnn.rnn.weight_ih_l0")
+    extra = ["rnn.mlp.fc2.%d.%s" % (b, t) for b in range(1, layer_N) for t in ("0.weight", "0.bias", "2.weight", "2.bias")]
+    return AGENT_PARAM_NAMES[:i] + extra + AGENT_PARAM_NAMES[i:]
+
+
+def agent_param_shapes(obs_dim, act_dim, layer_N=1):
     D, A = obs_dim, act_dim
-    return [(D,), (D,), (H, D), (H,), (H,), (H,), (H, H), (H,), (H,), (H,), (H, H), (H,), (H,), (H,),
-            (3 * H, H), (3 * H, H), (3 * H,), (3 * H,), (H,), (H,), (A, H), (A,)]
+    return ([(D,), (D,), (H, D), (H,), (H,), (H,), (H, H), (H,), (H,), (H,)] + [(H, H), (H,), (H,), (H,)] * layer_N +
+            [(3 * H, H), (3 * H, H), (3 * H,), (3 * H,), (H,), (H,), (A, H), (A,)])
 
 
-def agent_layout(obs_dim, act_dim):
+def agent_layout(obs_dim, act_dim, layer_N=1):
     """(offsets, sizes, padded_total) of the agent block, from the library (single source of truth)."""
     cfg = _lib.QmixCfg()
-    cfg.dims = _lib.Dims(1, act_dim, obs_dim, 1, 1)
+    cfg.dims = _lib.Dims(1, act_dim, obs_dim, 1, 1, layer_N)
     cfg.batch = 1
     cfg.vdn = 1
-    off = (C.c_int64 * 36)()
-    siz = (C.c_int64 * 36)()
+    off = (C.c_int64 * 48)()
+    siz = (C.c_int64 * 48)()
     total = _lib.lib.ope_qmix_param_layout(C.byref(cfg), off, siz)
     if total < 0:
         _lib.check(int(total), "ope_qmix_param_layout")
-    return list(off)[:22], list(siz)[:22], int(total)
+    n = 22 + 4 * (layer_N - 1)
+    return list(off)[:n], list(siz)[:n], int(total)
 
 
-def init_agent_values(obs_dim, act_dim, use_orthogonal=True, gain_out=0.01, use_ReLU=True):
+def init_agent_values(obs_dim, act_dim, use_orthogonal=True, gain_out=0.01, use_ReLU=True, layer_N=1):
     """Initial values in named_parameters() order, drawn exactly as the reference's constructors draw them:
     nn.Linear default init then orthogonal_/xavier_uniform_ re-init (mlp.py:12-23, util.py:113-116), nn.GRU default
     init then per-parameter re-init (rnn.py:8-16), head with gain=args.gain (act.py:10-12). Biases 0, LayerNorms 1/0."""
@@ -69,7 +79,7 @@ def init_agent_values(obs_dim, act_dim, use_orthogonal=True, gain_out=0.01, use_
     one, zero = torch.ones, torch.zeros
     vals = [one(obs_dim), zero(obs_dim), fc1.weight.data, zero(H), one(H), zero(H),
             fch.weight.data, zero(H), one(H), zero(H),                       # fc_h (registered, unused)
-            fch.weight.data.clone(), zero(H), one(H), zero(H),               # fc2[0] = deepcopy(fc_h) (mlp.py:23)
+            ] + [fch.weight.data.clone(), zero(H), one(H), zero(H)] * layer_N + [        # fc2[i] = deepcopy(fc_h) (mlp.py:23): identical clones
             gru.weight_ih_l0.data, gru.weight_hh_l0.data, zero(3 * H), zero(3 * H), one(H), zero(H),
             qo.weight.data, zero(act_dim)]
     return [v.detach().float() for v in vals]
@@ -78,20 +88,23 @@ def init_agent_values(obs_dim, act_dim, use_orthogonal=True, gain_out=0.01, use_
 class AgentQFunction(FlatModule):
     def __init__(self, args, input_dim, act_dim, device, flat=None, _init=True):
         input_dim, act_dim, device = int(input_dim), int(act_dim), torch.device(device)
-        offs, sizes, total = agent_layout(input_dim, act_dim)
+        self.layer_N = int(getattr(args, "layer_N", 1))
+        if self.layer_N not in (1, 2):
+            raise NotImplementedError("ope kernels support layer_N = 1 or 2 (got %r)" % self.layer_N)
+        offs, sizes, total = agent_layout(input_dim, act_dim, self.layer_N)
         own = flat is None
         if own:
             flat = torch.zeros(total, dtype=torch.float32, device=device)
-        super().__init__(AGENT_PARAM_NAMES, agent_param_shapes(input_dim, act_dim), offs, flat)
+        super().__init__(agent_param_names(self.layer_N), agent_param_shapes(input_dim, act_dim, self.layer_N), offs, flat)
         self.input_dim, self.act_dim, self.hidden_size, self.device = input_dim, act_dim, H, device
         self.padded_numel = total
         self._args = args
         if own and _init:
             vals = init_agent_values(input_dim, act_dim, getattr(args, "use_orthogonal", True),
-                                     getattr(args, "gain", 0.01), getattr(args, "use_ReLU", True))
+                                     getattr(args, "gain", 0.01), getattr(args, "use_ReLU", True), self.layer_N)
             for p, v in zip(self.parameters(), vals):
                 p.data.copy_(v)
-        self._dims = _lib.Dims(1, act_dim, input_dim, 1, 1)
+        self._dims = _lib.Dims(1, act_dim, input_dim, 1, 1, self.layer_N)
         self._ws = None
 
     def twin(self, flat):

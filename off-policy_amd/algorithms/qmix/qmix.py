@@ -53,7 +53,9 @@ class QMix(object):
                  vdn=False):
         self.args = args
         # (the policies check their own support); one-layer hyper-networks: recurrent nets, one shared policy (checked below)
-        require_reference_architecture(args, allow_prev_act_inp=not self._mlp, allow_hypernet_layers_1=not self._mlp and not vdn)
+        require_reference_architecture(args, allow_prev_act_inp=not self._mlp, allow_hypernet_layers_1=not self._mlp and not vdn,
+                                       allow_layer_N_2=not self._mlp)
+        self.layer_N = int(getattr(args, "layer_N", 1))
         self.hypernet_layers = int(getattr(args, "hypernet_layers", 2)) if not vdn else 2
         self.use_popart = getattr(args, "use_popart", False)
         self.use_value_active_masks = getattr(args, "use_value_active_masks", False)
@@ -85,8 +87,8 @@ class QMix(object):
         self._ws = {}
         self._ws_multi = {}
         self._gsq = {}
-        if self.multi and self.hypernet_layers == 1:
-            raise NotImplementedError("hypernet_layers=1 with several policies is not on the accelerated path")
+        if self.multi and (self.hypernet_layers == 1 or self.layer_N != 1):
+            raise NotImplementedError("hypernet_layers=1 / layer_N=2 with several policies is not on the accelerated path")
         if self.multi:
             self._init_multi()
             if args.use_double_q:
@@ -94,18 +96,18 @@ class QMix(object):
             return
         policy = self.policies["policy_0"]
         # the kernels see the network's input width: observation (+ previous one-hot action with prev_act_inp)
-        self._dims = _lib.Dims(num_agents, policy.act_dim, policy.q_network_input_dim, policy.central_obs_dim, self.episode_length)
+        self._dims = _lib.Dims(num_agents, policy.act_dim, policy.q_network_input_dim, policy.central_obs_dim, self.episode_length, self.layer_N)
 
         # ---- flat vectors: [agent | mixer], padded per tensor to 4 floats -------------------------------
         cfg = self._cfg(1)
-        off = (C.c_int64 * 36)()
-        siz = (C.c_int64 * 36)()
+        off = (C.c_int64 * 48)()
+        siz = (C.c_int64 * 48)()
         P = _lib.lib.ope_qmix_param_layout(C.byref(cfg), off, siz)
         if P < 0:
             _lib.check(int(P), "ope_qmix_param_layout")
         self.numel = int(P)
         self.theta = torch.zeros(self.numel, **self.tpdv)
-        n_agent_tensors = _lib.OPE_QMIX_NPARAM_AGENT_MLP if self._mlp else _lib.OPE_QMIX_NPARAM_AGENT
+        n_agent_tensors = _lib.OPE_QMIX_NPARAM_AGENT_MLP if self._mlp else (_lib.OPE_QMIX_NPARAM_AGENT_2 if self.layer_N == 2 else _lib.OPE_QMIX_NPARAM_AGENT)
         n_mixer_tensors = _lib.OPE_QMIX_NPARAM_MIXER_1 if self.hypernet_layers == 1 else _lib.OPE_QMIX_NPARAM_MIXER
         agent_numel = policy.q_network.padded_numel
         self.theta[:agent_numel].copy_(policy.q_network._flat[:agent_numel])
@@ -153,7 +155,7 @@ class QMix(object):
         self._dims = _lib.Dims(self.num_agents, first.act_dim, first.q_network_input_dim, S, T)      # the mixing part's cfg
         self._mixer_off = off
         self._shift = off - first.q_network.padded_numel      # the joint call's theta / grad start here (ope.h, ope_qmix_cfg.phase)
-        offs = (C.c_int64 * 36)()
+        offs = (C.c_int64 * 48)()
         P = _lib.lib.ope_qmix_param_layout(C.byref(self._cfg(1)), offs, None)
         if P < 0:
             _lib.check(int(P), "ope_qmix_param_layout")

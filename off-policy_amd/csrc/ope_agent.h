@@ -129,6 +129,28 @@ struct TrunkBwdArgs {
   float* dz1; float* dz2;  // [R][64]
 };
 
+// ---- second hidden block (layer_N = 2; ope_block.hip) ----------------------------------------------------------------------------
+// forward: a3 = LN(ReLU(fc2.1 a2 + b)) and the GRU input projection gi = W_ih a3 + b_ih (the trunk kernels stop at a2 for such nets)
+struct BlockFwdArgs {
+  int R;
+  const float* x;                 // [R][64] trunk output a2 (LayerNorm output of block fc2.0)
+  const float* theta; AgentLayout L;
+  float* gi;                      // [R][192]
+  float* xhat3; float* rstd3; uint64_t* mask3;   // saved for the backward pass (live net) or null
+};
+// adjoint: dgi -> da3 = W_ih^T dgi -> LayerNorm / ReLU adjoint -> dz3 (pre-activation adjoint of fc2.1: its weight gradient) -> da2 = fc2.1^T dz3
+struct BlockBwdArgs {
+  int R;
+  const float* dgi;               // [R][192]
+  const float* theta; AgentLayout L;
+  const float* wihT;              // [64][192]
+  const float* fc2bT;             // [64][64]
+  const float* xhat3; const float* rstd3; const uint64_t* mask3;
+  float* dz3; float* da2;         // [R][64]
+};
+int launch_block_fwd(const BlockFwdArgs& a, hipStream_t st);
+int launch_block_bwd(const BlockBwdArgs& a, hipStream_t st);
+
 int launch_trunk_fwd(const TrunkFwdArgs& a, bool save, hipStream_t st);
 // live (saving) + target trunk of the same input rows: one launch of trunk_fwd4 (ope_trunk4.hip) when the shape allows, else two launches
 int launch_trunk_fwd_pair(const TrunkFwdArgs& live, const TrunkFwdArgs& tgt, int path, hipStream_t st);

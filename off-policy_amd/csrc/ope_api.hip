@@ -25,6 +25,8 @@ bool cfg_ok(const ope_qmix_cfg* c) {
   if (c->trunk_path != 0 && c->trunk_path != 3 && c->trunk_path != 4) return false;
   if (c->chain_path < 0 || c->chain_path > 2) return false;
   if (c->hypernet_layers < 0 || c->hypernet_layers > 2) return false;
+  if (d.layer_N < 0 || d.layer_N > 2) return false;
+  if (d.layer_N == 2 && (c->mlp || c->phase != 0 || c->time_chunks > 1)) return false;      // a second hidden block: whole steps of recurrent nets
   if (c->hypernet_layers == 1 && (c->mlp || c->phase != 0 || c->mixer_path == 3 || c->chain_path == 1)) return false;   // one-layer hyper-networks: the fused chain only
   return d.n_agents >= 1 && d.act_dim >= 1 && d.obs_dim >= 1 && d.obs_dim <= 512 && d.state_dim >= 1 &&
          d.episode_length >= 1 && c->batch >= 1 && d.n_agents <= 64 && d.act_dim <= 200;
@@ -32,6 +34,7 @@ bool cfg_ok(const ope_qmix_cfg* c) {
 
 struct Raw {  // offsets inside one split slab, agent region then mixer region
   int P1, s1, P2, s2, P3, s3, WHH, shh, E, sq, agent_end;
+  int P2b, s2b;      // layer_N = 2: the second hidden block's weight gradient (against xhat2) and bias gradient
   int mixer_size;
 };
 
@@ -85,6 +88,8 @@ struct Plan {
   bool chain;                   // the (t, b)-row chain runs as mixer_hyp + qchain (ope_chain.hip) instead of head_fwd / mixer_fwd / mixer_bwd / head_bwd
   bool chain_can;               // ... could (shape, phase, schedule)
   bool hyp1;                    // one-layer hyper-networks (hypernet_layers = 1)
+  int layerN;                   // hidden blocks behind fc1 (1 | 2)
+  int64_t a2, a2_t, xhat3, rstd3, mask3, dz3, da2;
   int64_t hb1, hw1_t, hw2_t, hb2_t, hb1_t, v1_t, v2_t;
 };
 
@@ -99,7 +104,8 @@ void make_plan(const ope_qmix_cfg* c, Plan* p) {
   p->NB = p->N * p->B; p->A4 = ope_round4(p->A); p->NM = p->N * OPE_MIX;
   p->R = (int64_t)(p->T + 1) * p->NB; p->R1 = (int64_t)p->T * p->NB; p->TB = (int64_t)p->T * p->B;
   p->mlp = c->mlp;
-  p->AL = c->mlp ? ope_agent_layout_mlp(p->D, p->A, 0) : ope_agent_layout(p->D, p->A, 0);
+  p->layerN = d.layer_N == 2 ? 2 : 1;
+  p->AL = c->mlp ? ope_agent_layout_mlp(p->D, p->A, 0) : ope_agent_layout(p->D, p->A, 0, p->layerN);
   if (c->vdn) {
     memset(&p->ML, 0, sizeof(p->ML));
     p->ML.end = p->AL.end;
@@ -114,6 +120,8 @@ void make_plan(const ope_qmix_cfg* c, Plan* p) {
   auto take = [&](int n) { int r = o; o += ope_round4(n); return r; };
   w.P1 = take(OPE_H * p->D); w.s1 = take(OPE_H);
   w.P2 = take(OPE_H * OPE_H); w.s2 = take(OPE_H);
+  w.P2b = w.s2b = -1;
+  if (p->layerN == 2) { w.P2b = take(OPE_H * OPE_H); w.s2b = take(OPE_H); }
   w.P3 = take(3 * OPE_H * OPE_H); w.s3 = take(3 * OPE_H);
   w.WHH = take(3 * OPE_H * OPE_H); w.shh = take(3 * OPE_H);
   w.E = take(p->A * OPE_H); w.sq = take(p->A4);
@@ -137,7 +145,7 @@ void make_plan(const ope_qmix_cfg* c, Plan* p) {
   };
   // 64 x 64 output tiles of the agent problems (fc1, fc2, W_ih, W_hh in two pieces, q head) and of the mixer problems
   // (three S-wide first layers of 64 rows, the NM x 64 and 32 x 64 second layers, the 32 x S state bias, the scalar head)
-  const int agent_tiles = ope_cdiv(p->D, 64) + 1 + (c->mlp ? 0 : 3 + 2 + 1) + ope_cdiv(p->A, 64);
+  const int agent_tiles = ope_cdiv(p->D, 64) + 1 + (p->layerN == 2 ? 1 : 0) + (c->mlp ? 0 : 3 + 2 + 1) + ope_cdiv(p->A, 64);
   const int mixer_tiles = c->vdn ? 0 : (p->hyp1 ? ope_cdiv(p->S, 64) * (ope_cdiv(p->NM, 64) + 3) + 1 : 4 * ope_cdiv(p->S, 64) + ope_cdiv(p->NM, 64) + 2);
   int rows_per_split = rows_env > 0 ? rows_env : 160;
   if (rows_env <= 0) {
@@ -198,7 +206,7 @@ void make_plan(const ope_qmix_cfg* c, Plan* p) {
   p->ln_one = W.add("ln_one", R);
   // per-workgroup partial sums of grad^2 written by the finalize launch (zero beyond the launch's workgroups: the region
   // is zero-filled once at workspace_init); upper bound of finalize_blocks()
-  p->n_gsq = ope_cdiv((int64_t)p->P + OPE_GRAD_TAIL, 256) + 1 + ope_cdiv((int64_t)2 * (p->D + 3 * OPE_H) * 64, 256) + 4;
+  p->n_gsq = ope_cdiv((int64_t)p->P + OPE_GRAD_TAIL, 256) + 1 + ope_cdiv((int64_t)2 * (p->D + (p->layerN == 2 ? 4 : 3) * OPE_H) * 64, 256) + 4;
   p->gsq_part = W.add("gsq_part", p->n_gsq);
   p->err_abs = W.add("err_abs", TB); p->dqtot = W.add("dqtot", 4 * TB); p->d_agent_q = W.add("d_agent_q", TB * p->N);
   p->d_b1 = W.add("d_b1", TB * OPE_MIX); p->d_v2 = W.add("d_v2", TB * OPE_MIX); p->d_v1 = W.add("d_v1", TB * p->NM);
@@ -206,7 +214,7 @@ void make_plan(const ope_qmix_cfg* c, Plan* p) {
   p->dh_out = W.add("dh_out", R1 * OPE_H); p->dqoh = W.add("dqoh", R1 * p->A4);
   p->dgi = W.add("dgi", R1 * 3 * OPE_H); p->dghn = W.add("dghn", R1 * OPE_H);
   p->dz1 = W.add("dz1", R1 * OPE_H); p->dz2 = W.add("dz2", R1 * OPE_H);
-  p->thetaT = W.add("thetaT", OPE_H * 3 * OPE_H + OPE_H * OPE_H);
+  p->thetaT = W.add("thetaT", OPE_H * 3 * OPE_H + 2 * OPE_H * OPE_H);      // W_ih^T, fc2.0^T (, fc2.1^T)
   p->mixT = W.add("mixT", (int64_t)OPE_HYP * p->NM + OPE_HYP * OPE_MIX);
   p->dh_carry = W.add("dh_carry", (int64_t)p->NB * OPE_H);
   p->raw_agent = W.add("raw_agent", (int64_t)p->ns_agent * p->chunks * w.agent_end);
@@ -231,6 +239,11 @@ void make_plan(const ope_qmix_cfg* c, Plan* p) {
   p->hw1_t = W.add("hw1_t", TB * OPE_HYP); p->hw2_t = W.add("hw2_t", TB * OPE_HYP); p->hb2_t = W.add("hb2_t", TB * OPE_HYP);
   p->hb1_t = W.add("hb1_t", TB * OPE_MIX);
   p->v1_t = W.add("v1_t", TB * p->NM); p->v2_t = W.add("v2_t", TB * OPE_MIX);
+  if (p->layerN == 2) {      // second hidden block: the trunk's output of both nets, the block's saves and adjoints
+    p->a2 = W.add("a2", R * OPE_H); p->a2_t = W.add("a2_t", R * OPE_H);
+    p->xhat3 = W.add("xhat3", R * OPE_H); p->rstd3 = W.add("rstd3", R); p->mask3 = W.add("mask3", 2 * R);
+    p->dz3 = W.add("dz3", R1 * OPE_H); p->da2 = W.add("da2", R1 * OPE_H);
+  }
 }
 
 }  // namespace
@@ -280,7 +293,7 @@ extern "C" void ope_set_scan_kernel(int family, int waves_per_row) {
 extern "C" int64_t ope_qmix_param_layout(const ope_qmix_cfg* cfg, int64_t* offsets, int64_t* sizes) {
   if (!cfg_ok(cfg)) return OPE_EINVAL;
   const int D = cfg->dims.obs_dim, A = cfg->dims.act_dim, N = cfg->dims.n_agents, S = cfg->dims.state_dim;
-  const AgentLayout L = cfg->mlp ? ope_agent_layout_mlp(D, A, 0) : ope_agent_layout(D, A, 0);
+  const AgentLayout L = cfg->mlp ? ope_agent_layout_mlp(D, A, 0) : ope_agent_layout(D, A, 0, cfg->dims.layer_N);
   int na = 0;
   auto put = [&](int off, int size) {
     if (offsets) offsets[na] = off;
@@ -290,6 +303,7 @@ extern "C" int64_t ope_qmix_param_layout(const ope_qmix_cfg* cfg, int64_t* offse
   put(L.fn_w, D); put(L.fn_b, D); put(L.fc1_w, OPE_H * D); put(L.fc1_b, OPE_H); put(L.ln1_w, OPE_H); put(L.ln1_b, OPE_H);
   put(L.fch_w, OPE_H * OPE_H); put(L.fch_b, OPE_H); put(L.lnh_w, OPE_H); put(L.lnh_b, OPE_H);
   put(L.fc2_w, OPE_H * OPE_H); put(L.fc2_b, OPE_H); put(L.ln2_w, OPE_H); put(L.ln2_b, OPE_H);
+  if (L.layer_N == 2) { put(L.fc2b_w, OPE_H * OPE_H); put(L.fc2b_b, OPE_H); put(L.ln2b_w, OPE_H); put(L.ln2b_b, OPE_H); }
   if (!cfg->mlp) {
     put(L.wih, 3 * OPE_H * OPE_H); put(L.whh, 3 * OPE_H * OPE_H); put(L.bih, 3 * OPE_H); put(L.bhh, 3 * OPE_H);
     put(L.lno_w, OPE_H); put(L.lno_b, OPE_H);
@@ -400,6 +414,7 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
     };
     if (!p.mlp && phase != 2) add(theta + p.AL.wih, 3 * OPE_H, OPE_H, W + p.thetaT);
     if (phase != 2) add(theta + p.AL.fc2_w, OPE_H, OPE_H, W + p.thetaT + OPE_H * 3 * OPE_H);
+    if (p.layerN == 2) add(theta + p.AL.fc2b_w, OPE_H, OPE_H, W + p.thetaT + OPE_H * 3 * OPE_H + OPE_H * OPE_H);
     if (!cfg->vdn && phase != 1 && !p.hyp1) {
       add(theta + p.ML.w1b_w, p.NM, OPE_HYP, W + p.mixT);
       add(theta + p.ML.w2b_w, OPE_MIX, OPE_HYP, W + p.mixT + (int64_t)OPE_HYP * p.NM);
@@ -418,6 +433,7 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
     memset(&tf, 0, sizeof(tf));
     tf.x = batch->obs + r0 * p.D; tf.R = (int)rows; tf.D = p.D; tf.theta = theta; tf.L = p.AL;
     tf.gi = p.mlp ? nullptr : W + p.gi + r0 * 3 * OPE_H; tf.a2_out = p.mlp ? W + p.h + r0 * OPE_H : nullptr;
+    if (p.layerN == 2) { tf.gi = nullptr; tf.a2_out = W + p.a2 + r0 * OPE_H; }      // the trunk stops at the first block's output; ope_block.hip continues
     tf.mu0 = W + p.mu0 + r0; tf.rstd0 = W + p.rstd0 + r0;
     tf.xhat1 = W + p.xhat1 + r0 * OPE_H; tf.rstd1 = W + p.rstd1 + r0; tf.mask1 = (uint64_t*)(W + p.mask1) + r0;
     tf.xhat2 = W + p.xhat2 + r0 * OPE_H; tf.rstd2 = W + p.rstd2 + r0; tf.mask2 = (uint64_t*)(W + p.mask2) + r0;
@@ -425,7 +441,19 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
     TrunkFwdArgs tt = tf;
     tt.dbg = nullptr;
     tt.theta = theta_tgt; tt.gi = p.mlp ? nullptr : W + p.gi_t + r0 * 3 * OPE_H; tt.a2_out = p.mlp ? W + p.h_t + r0 * OPE_H : nullptr;
+    if (p.layerN == 2) { tt.gi = nullptr; tt.a2_out = W + p.a2_t + r0 * OPE_H; }
     if ((rc = launch_trunk_fwd_pair(tf, tt, cfg->trunk_path, st))) return rc;    // one launch for both nets where the shape allows it (ope_trunk4.hip)
+    if (p.layerN == 2) {
+      BlockFwdArgs bf;
+      memset(&bf, 0, sizeof(bf));
+      bf.R = (int)rows; bf.x = W + p.a2 + r0 * OPE_H; bf.theta = theta; bf.L = p.AL; bf.gi = W + p.gi + r0 * 3 * OPE_H;
+      bf.xhat3 = W + p.xhat3 + r0 * OPE_H; bf.rstd3 = W + p.rstd3 + r0; bf.mask3 = (uint64_t*)(W + p.mask3) + r0;
+      if ((rc = launch_block_fwd(bf, st))) return rc;
+      BlockFwdArgs bt;
+      memset(&bt, 0, sizeof(bt));
+      bt.R = (int)rows; bt.x = W + p.a2_t + r0 * OPE_H; bt.theta = theta_tgt; bt.L = p.AL; bt.gi = W + p.gi_t + r0 * 3 * OPE_H;
+      if ((rc = launch_block_fwd(bt, st))) return rc;
+    }
     if (p.mlp) continue;
     if (p.chain) {
       // The mixers' first hyper-layers need the centralized state only: launched here, in front of the scan (whose launch leaves the
@@ -585,7 +613,8 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
     prob(wt, W + p.dz2 + r0 * OPE_H, OPE_H, OPE_H, W + p.xhat1 + r0 * OPE_H, OPE_H, OPE_H, K1, rw.P2, OPE_H, rw.s2, nsplit, ab, as);
     if (!p.mlp) {
       const float* dgi = W + p.dgi + r0 * 3 * OPE_H;
-      prob(wt, dgi, 3 * OPE_H, 3 * OPE_H, W + p.xhat2 + r0 * OPE_H, OPE_H, OPE_H, K1, rw.P3, OPE_H, rw.s3, nsplit, ab, as);
+      if (p.layerN == 2) prob(wt, W + p.dz3 + r0 * OPE_H, OPE_H, OPE_H, W + p.xhat2 + r0 * OPE_H, OPE_H, OPE_H, K1, rw.P2b, OPE_H, rw.s2b, nsplit, ab, as);
+      prob(wt, dgi, 3 * OPE_H, 3 * OPE_H, (p.layerN == 2 ? W + p.xhat3 : W + p.xhat2) + r0 * OPE_H, OPE_H, OPE_H, K1, rw.P3, OPE_H, rw.s3, nsplit, ab, as);
       // h_{t-1}: the first chunk shifts inside the kernel (rows of t = 0 see zeros), later chunks start one step back
       const float* hprev = r0 > 0 ? W + p.h + (r0 - p.NB) * OPE_H : W + p.h;
       const int shift = r0 > 0 ? 0 : p.NB;
@@ -629,6 +658,16 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
     memset(&tb, 0, sizeof(tb));
     tb.R = K1; tb.theta = theta; tb.thetaT = W + p.thetaT; tb.L = p.AL;
     tb.dgi = p.mlp ? nullptr : W + p.dgi + r0 * 3 * OPE_H; tb.da2_in = p.mlp ? W + p.dh_out + r0 * OPE_H : nullptr;
+    if (p.layerN == 2 && do_bwd) {      // the second block's adjoint first: dgi -> dz3 (its weight gradient), da2 (what the trunk adjoint continues from)
+      BlockBwdArgs bb;
+      memset(&bb, 0, sizeof(bb));
+      bb.R = K1; bb.dgi = W + p.dgi + r0 * 3 * OPE_H; bb.theta = theta; bb.L = p.AL;
+      bb.wihT = W + p.thetaT; bb.fc2bT = W + p.thetaT + OPE_H * 3 * OPE_H + OPE_H * OPE_H;
+      bb.xhat3 = W + p.xhat3 + r0 * OPE_H; bb.rstd3 = W + p.rstd3 + r0; bb.mask3 = (const uint64_t*)(W + p.mask3) + r0;
+      bb.dz3 = W + p.dz3 + r0 * OPE_H; bb.da2 = W + p.da2 + r0 * OPE_H;
+      if ((rc = launch_block_bwd(bb, st))) return rc;
+      tb.dgi = nullptr; tb.da2_in = W + p.da2 + r0 * OPE_H;
+    }
     tb.xhat1 = W + p.xhat1 + r0 * OPE_H; tb.rstd1 = W + p.rstd1 + r0; tb.mask1 = (const uint64_t*)(W + p.mask1) + r0;
     tb.xhat2 = W + p.xhat2 + r0 * OPE_H; tb.rstd2 = W + p.rstd2 + r0; tb.mask2 = (const uint64_t*)(W + p.mask2) + r0;
     tb.dz1 = W + p.dz1 + r0 * OPE_H; tb.dz2 = W + p.dz2 + r0 * OPE_H;
@@ -676,10 +715,20 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
     seg(L.fch_w, 0, FIN_ZERO, 0, 0, 0, 0, 0, 0, 0);  // fc_h.*: registered, never used (mlp.py:21-23) -> zero gradient
     seg(L.fc2_w, OPE_H * OPE_H, FIN_LNLIN_W, rw.P2, rw.s2, OPE_H, OPE_H, L.fc2_w, L.ln1_w, L.ln1_b);
     seg(L.fc2_b, OPE_H, FIN_COPY, rw.s2, 0, 0, 0, 0, 0, 0);
-    if (!p.mlp) {
+    if (!p.mlp && p.layerN == 2) {      // LN2 feeds the second block, whose LayerNorm feeds W_ih
+      seg(L.ln2_w, OPE_H, FIN_LNLIN_G, rw.P2b, rw.s2b, OPE_H, OPE_H, L.fc2b_w, 0, 0);
+      seg(L.ln2_b, OPE_H, FIN_LNLIN_B, rw.P2b, rw.s2b, OPE_H, OPE_H, L.fc2b_w, 0, 0);
+      seg(L.fc2b_w, OPE_H * OPE_H, FIN_LNLIN_W, rw.P2b, rw.s2b, OPE_H, OPE_H, L.fc2b_w, L.ln2_w, L.ln2_b);
+      seg(L.fc2b_b, OPE_H, FIN_COPY, rw.s2b, 0, 0, 0, 0, 0, 0);
+      seg(L.ln2b_w, OPE_H, FIN_LNLIN_G, rw.P3, rw.s3, 3 * OPE_H, OPE_H, L.wih, 0, 0);
+      seg(L.ln2b_b, OPE_H, FIN_LNLIN_B, rw.P3, rw.s3, 3 * OPE_H, OPE_H, L.wih, 0, 0);
+      seg(L.wih, 3 * OPE_H * OPE_H, FIN_LNLIN_W, rw.P3, rw.s3, 3 * OPE_H, OPE_H, L.wih, L.ln2b_w, L.ln2b_b);
+    } else if (!p.mlp) {
       seg(L.ln2_w, OPE_H, FIN_LNLIN_G, rw.P3, rw.s3, 3 * OPE_H, OPE_H, L.wih, 0, 0);
       seg(L.ln2_b, OPE_H, FIN_LNLIN_B, rw.P3, rw.s3, 3 * OPE_H, OPE_H, L.wih, 0, 0);
       seg(L.wih, 3 * OPE_H * OPE_H, FIN_LNLIN_W, rw.P3, rw.s3, 3 * OPE_H, OPE_H, L.wih, L.ln2_w, L.ln2_b);
+    }
+    if (!p.mlp) {
       seg(L.whh, 3 * OPE_H * OPE_H, FIN_COPY, rw.WHH, 0, 0, 0, 0, 0, 0);
       seg(L.bih, 3 * OPE_H, FIN_COPY, rw.s3, 0, 0, 0, 0, 0, 0);
       seg(L.bhh, 3 * OPE_H, FIN_COPY, rw.shh, 0, 0, 0, 0, 0, 0);
@@ -720,7 +769,7 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
 extern "C" int64_t ope_agent_forward_workspace_bytes(const ope_dims* d, int32_t seq_len, int32_t rows) {
   if (!d || seq_len < 1 || rows < 1) return OPE_EINVAL;
   const int64_t R = (int64_t)seq_len * rows;
-  return (R * 3 * OPE_H + 64) * (int64_t)sizeof(float);
+  return (R * 3 * OPE_H + (d->layer_N == 2 ? R * OPE_H : 0) + 64) * (int64_t)sizeof(float);      // gi (+ the first block's output with layer_N = 2)
 }
 
 extern "C" int ope_agent_forward(const ope_dims* d, int32_t seq_len, int32_t rows, const float* obs, const float* h0,
@@ -732,13 +781,21 @@ extern "C" int ope_agent_forward(const ope_dims* d, int32_t seq_len, int32_t row
   if (workspace_bytes < ope_agent_forward_workspace_bytes(d, seq_len, rows)) return OPE_ENOSPC;
   hipStream_t st = (hipStream_t)stream;
   const int64_t R = (int64_t)seq_len * rows;
-  const AgentLayout L = ope_agent_layout(d->obs_dim, d->act_dim, 0);
+  if (d->layer_N < 0 || d->layer_N > 2) return OPE_EINVAL;
+  const AgentLayout L = ope_agent_layout(d->obs_dim, d->act_dim, 0, d->layer_N);
   float* gi = (float*)workspace;
   int rc;
   TrunkFwdArgs tf;
   memset(&tf, 0, sizeof(tf));
   tf.x = obs; tf.R = (int)R; tf.D = d->obs_dim; tf.theta = theta; tf.L = L; tf.gi = gi;
+  if (L.layer_N == 2) { tf.gi = nullptr; tf.a2_out = gi + R * 3 * OPE_H; }      // the trunk stops at the first block; ope_block.hip continues
   if ((rc = launch_trunk_fwd(tf, false, st))) return rc;
+  if (L.layer_N == 2) {
+    BlockFwdArgs bf;
+    memset(&bf, 0, sizeof(bf));
+    bf.R = (int)R; bf.x = gi + R * 3 * OPE_H; bf.theta = theta; bf.L = L; bf.gi = gi;
+    if ((rc = launch_block_fwd(bf, st))) return rc;
+  }
   GruFwdArgs gf;
   memset(&gf, 0, sizeof(gf));
   gf.nets = 1; gf.NB = rows; gf.L = seq_len; gf.theta0 = theta; gf.theta1 = theta; gf.gi0 = gi; gf.gi1 = gi; gf.h0out = h_out; gf.h1out = h_out;

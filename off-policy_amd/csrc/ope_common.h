@@ -227,6 +227,8 @@ struct AgentLayout {
   int fn_w, fn_b, fc1_w, fc1_b, ln1_w, ln1_b, fch_w, fch_b, lnh_w, lnh_b, fc2_w, fc2_b, ln2_w, ln2_b;
   int wih, whh, bih, bhh, lno_w, lno_b, q_w, q_b;
   int end;
+  int fc2b_w, fc2b_b, ln2b_w, ln2b_b;   // layer_N = 2: the second hidden block rnn.mlp.fc2.1.{0,2} (mlp.py:14-28); -1 otherwise
+  int layer_N;
 };
 struct MixerLayout {
   int w1a_w, w1a_b, w1b_w, w1b_b, w2a_w, w2a_b, w2b_w, w2b_b, b1_w, b1_b, b2a_w, b2a_b, b2b_w, b2b_b;
@@ -235,7 +237,7 @@ struct MixerLayout {
                      // [N*32][S], w2a_* = hyper_w2 [32][S]; w1b_* / w2b_* do not exist (-1)
 };
 
-static inline AgentLayout ope_agent_layout(int D, int A, int base) {
+static inline AgentLayout ope_agent_layout(int D, int A, int base, int layer_N = 1) {
   AgentLayout L;
   int o = base;
   auto take = [&](int n) { int r = o; o += ope_round4(n); return r; };
@@ -243,6 +245,9 @@ static inline AgentLayout ope_agent_layout(int D, int A, int base) {
   L.fc1_w = take(OPE_H * D); L.fc1_b = take(OPE_H); L.ln1_w = take(OPE_H); L.ln1_b = take(OPE_H);
   L.fch_w = take(OPE_H * OPE_H); L.fch_b = take(OPE_H); L.lnh_w = take(OPE_H); L.lnh_b = take(OPE_H);
   L.fc2_w = take(OPE_H * OPE_H); L.fc2_b = take(OPE_H); L.ln2_w = take(OPE_H); L.ln2_b = take(OPE_H);
+  L.fc2b_w = L.fc2b_b = L.ln2b_w = L.ln2b_b = -1;
+  L.layer_N = layer_N == 2 ? 2 : 1;
+  if (layer_N == 2) { L.fc2b_w = take(OPE_H * OPE_H); L.fc2b_b = take(OPE_H); L.ln2b_w = take(OPE_H); L.ln2b_b = take(OPE_H); }
   L.wih = take(3 * OPE_H * OPE_H); L.whh = take(3 * OPE_H * OPE_H); L.bih = take(3 * OPE_H); L.bhh = take(3 * OPE_H);
   L.lno_w = take(OPE_H); L.lno_b = take(OPE_H);
   L.q_w = take(A * OPE_H); L.q_b = take(A);
@@ -261,6 +266,8 @@ static inline AgentLayout ope_agent_layout_mlp(int D, int A, int base) {
   L.fch_w = take(OPE_H * OPE_H); L.fch_b = take(OPE_H); L.lnh_w = take(OPE_H); L.lnh_b = take(OPE_H);
   L.fc2_w = take(OPE_H * OPE_H); L.fc2_b = take(OPE_H); L.ln2_w = take(OPE_H); L.ln2_b = take(OPE_H);
   L.wih = L.whh = L.bih = L.bhh = L.lno_w = L.lno_b = -1;
+  L.fc2b_w = L.fc2b_b = L.ln2b_w = L.ln2b_b = -1;
+  L.layer_N = 1;
   L.q_w = take(A * OPE_H); L.q_b = take(A);
   L.end = o;
   return L;

@@ -26,7 +26,8 @@ int launch_wgrad(const WgTable& tb, float* raw, hipStream_t st);
 int wg_slabs(const WgTable& tb, int nsplit);
 struct SplitRed { const float* raw0; int64_t n0; int ns0; const float* raw1; int64_t n1; int ns1; float* rsum; };
 int launch_split_reduce(const SplitRed& a, hipStream_t st);
-struct Transp4 { const float* src[4]; float* dst[4]; int rows[4], cols[4], begin[4]; int n, total; };
+constexpr int kMaxTransp = 6;
+struct Transp4 { const float* src[kMaxTransp]; float* dst[kMaxTransp]; int rows[kMaxTransp], cols[kMaxTransp], begin[kMaxTransp]; int n, total; };
 int launch_transpose4(const Transp4& a, hipStream_t st);
 // dst[c][r] = src[r][c] for up to 4 small matrices; `i` = flat element index over all of them. Shared by the stand-alone
 // kernel and by kernels that carry the transposes as extra workgroups (a weight transpose costs nothing beside a launch that
@@ -35,7 +36,7 @@ __device__ __forceinline__ void transpose4_element(const Transp4& a, int i) {
   if (i >= a.total) return;
   int m = 0;
 #pragma unroll
-  for (int q = 1; q < 4; ++q)
+  for (int q = 1; q < kMaxTransp; ++q)
     if (q < a.n && i >= a.begin[q]) m = q;
   const int j = i - a.begin[m];
   const int rows = a.rows[m], cols = a.cols[m];
@@ -54,7 +55,7 @@ struct FinSeg {
   int w;       // theta offset of that weight
   int gamma, beta;  // theta offsets of the LayerNorm feeding it
 };
-constexpr int kMaxFinSegs = 40;
+constexpr int kMaxFinSegs = 48;
 struct FinTable {
   FinSeg seg[kMaxFinSegs];
   int begin[kMaxFinSegs];   // seg[q].begin again, INT_MAX beyond n: filled by launch_finalize (one scalar load burst finds a segment)

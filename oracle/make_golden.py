@@ -219,6 +219,20 @@ def main():
         run_case("qmix_var_s2232", EnvDims("var_s2232", 2, 5, 12, 2232, 12), n_episodes=13, inds=list(range(13)), avail="bernoulli", steps=2,
                  store_inputs=False)
         return
+    if os.environ.get("OPE_GOLDEN_ONLY") == "layer2":
+        # round 4: --layer_N 2 beyond the tiny shape fixture: the 3s5z input width (the vectorised trunk kernels end at the first
+        # block's output instead of the GRU projection), VDN, together with one-layer hyper-networks, and with the previous action as an input +
+        # Huber + PER weights on odd sizes
+        run_case("qmix_var_layer2_d252", EnvDims("var_layer2_d252", 2, 5, 252, 20, 6), n_episodes=5, inds=[4, 0, 2, 2], avail="bernoulli",
+                 argv=["--layer_N", "2"])
+        run_case("qmix_var_layer2_hyper1", EnvDims("var_layer2_hyper1", 5, 6, 16, 100, 5), n_episodes=5, inds=[0, 1, 4, 4, 2], avail="bernoulli",
+                 runner_padding=True, argv=["--layer_N", "2", "--hypernet_layers", "1"])
+        run_case("qmix_var_layer2_odd", EnvDims("var_layer2_odd", 3, 7, 18, 29, 5), n_episodes=6, inds=[5, 1, 1, 2, 0], avail="bernoulli",
+                 runner_padding=True, per_weights=np.array([1.0, 0.5, 0.25, 0.8, 0.9]),
+                 argv=["--layer_N", "2", "--prev_act_inp", "--use_huber_loss", "--huber_delta", "1.0", "--use_per"])
+        patch_vdn()
+        run_case("vdn_var_layer2", tiny, n_episodes=4, inds=[2, 1, 0, 3], avail="bernoulli", vdn=True, argv=["--layer_N", "2"])
+        return
     if os.environ.get("OPE_GOLDEN_ONLY") == "pershare":      # add the round-2 fixture without rewriting the committed ones
         run_case("qmix_tiny_pershare", tiny, n_episodes=5, inds=[4, 1, 1, 0, 2], cap=6, pre_insert=3, avail="bernoulli", per_agent_share=True)
         return

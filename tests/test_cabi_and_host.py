@@ -27,7 +27,7 @@ def test_param_layout_and_episode_bytes_match_survey():
     cfg = _lib.QmixCfg()
     cfg.dims = _lib.Dims(8, 14, 252, 216, 150)
     cfg.batch = 32
-    off, siz = (C.c_int64 * 36)(), (C.c_int64 * 36)()
+    off, siz = (C.c_int64 * 48)(), (C.c_int64 * 48)()
     total = _lib.lib.ope_qmix_param_layout(C.byref(cfg), off, siz)
     assert sum(siz) == 118791            # SURVEY.md section 8 a6 (51 398 agent + 67 393 mixer)
     assert sum(list(siz)[:22]) == 51398
@@ -54,7 +54,7 @@ def test_weight_gradient_split_count_follows_the_cost_model():
     def mixer_splits(dims, batch):
         cfg = _lib.QmixCfg()
         cfg.dims, cfg.batch = _lib.Dims(*dims), batch
-        off, siz = (C.c_int64 * 36)(), (C.c_int64 * 36)()
+        off, siz = (C.c_int64 * 48)(), (C.c_int64 * 48)()
         total = _lib.lib.ope_qmix_param_layout(C.byref(cfg), off, siz)
         n = C.c_int64(0)
         assert _lib.lib.ope_qmix_workspace_find(C.byref(cfg), b"raw_mixer", C.byref(n)) >= 0
@@ -81,6 +81,54 @@ def test_non_default_network_shapes_are_refused_loudly(name):
         require_reference_architecture(args)
     assert any(k in str(e.value) for k in ("hidden_size", "layer_N", "hypernet_layers"))
     require_reference_architecture(default_args())      # the defaults pass
+
+
+def test_second_hidden_block_layout_and_initialisation_match_the_reference():
+    """layer_N = 2 (mlp.py:14-28; round 4: supported by the recurrent QMIX / VDN trainer, csrc/ope_block.hip): the C-ABI's parameter
+    layout has the reference's 26 agent tensors in named_parameters() order, our constructor consumes the init RNG stream exactly as
+    the reference's does (fixture qmix_shape_layer2 = outputs of the real reference), and the configurations the second block cannot
+    run are refused by cfg validation."""
+    import torch
+    from conftest import load_golden
+    from offpolicy_amd import _lib
+    from offpolicy_amd.config import default_args, require_reference_architecture
+    from offpolicy_amd.algorithms.qmix.algorithm.agent_q_function import init_agent_values, agent_param_names, agent_param_shapes, agent_layout
+    from offpolicy_amd.algorithms.qmix.algorithm.q_mixer import init_mixer_values, MIXER_PARAM_NAMES
+    g = load_golden("qmix_shape_layer2")
+    n, a, d, s, t = [int(x) for x in g["dims"]]
+    names = agent_param_names(2)
+    assert len(names) == _lib.OPE_QMIX_NPARAM_AGENT_2 and sorted(names) == sorted(k[len("agent/"):] for k in g if k.startswith("agent/"))
+    assert [tuple(x) for x in agent_param_shapes(d, a, 2)] == [g["agent/" + k].shape for k in names]
+    offs, sizes, total = agent_layout(d, a, 2)
+    assert sizes == [int(np.prod(g["agent/" + k].shape)) for k in names]
+    assert all(o % 4 == 0 for o in offs) and offs == sorted(offs)
+    cfg = _lib.QmixCfg()
+    cfg.dims, cfg.batch = _lib.Dims(n, a, d, s, t, 2), 4
+    off, siz = (C.c_int64 * 48)(), (C.c_int64 * 48)()
+    assert _lib.lib.ope_qmix_param_layout(C.byref(cfg), off, siz) > 0
+    assert list(siz)[26:26 + len(MIXER_PARAM_NAMES)] == [int(np.prod(g["mixer/" + k].shape)) for k in MIXER_PARAM_NAMES]
+    assert _lib.lib.ope_qmix_workspace_bytes(C.byref(cfg)) > 0
+    torch.manual_seed(1)
+    np.random.seed(1)
+    av = init_agent_values(d, a, layer_N=2)
+    mv = init_mixer_values(n, s)
+    for v, k in zip(av, names):
+        assert np.array_equal(v.numpy(), g["agent/" + k]), k
+    for v, k in zip(mv, MIXER_PARAM_NAMES):
+        assert np.array_equal(v.numpy(), g["mixer/" + k]), k
+    for bad in (dict(mlp=1), dict(phase=2), dict(time_chunks=2)):
+        c2 = _lib.QmixCfg()
+        c2.dims, c2.batch = _lib.Dims(n, a, d, s, 1 if "mlp" in bad else t, 2), 4
+        for k, v in bad.items():
+            setattr(c2, k, v)
+        assert _lib.lib.ope_qmix_workspace_bytes(C.byref(c2)) == -1, bad
+    c3 = _lib.QmixCfg()
+    c3.dims, c3.batch = _lib.Dims(n, a, d, s, t, 3), 4
+    assert _lib.lib.ope_qmix_workspace_bytes(C.byref(c3)) == -1
+    args = default_args(layer_N=2)
+    require_reference_architecture(args, allow_layer_N_2=True)
+    with pytest.raises(NotImplementedError):
+        require_reference_architecture(default_args(layer_N=3), allow_layer_N_2=True)
 
 
 def test_null_arguments_are_rejected_without_a_gpu():
@@ -204,7 +252,7 @@ def test_one_layer_hyper_networks_layout_and_initialisation_match_the_reference(
     n, a, d, s, t = [int(x) for x in g["dims"]]
     cfg = _lib.QmixCfg()
     cfg.dims, cfg.batch, cfg.hypernet_layers = _lib.Dims(n, a, d, s, t), 4, 1
-    off, siz = (C.c_int64 * 36)(), (C.c_int64 * 36)()
+    off, siz = (C.c_int64 * 48)(), (C.c_int64 * 48)()
     total = _lib.lib.ope_qmix_param_layout(C.byref(cfg), off, siz)
     assert total > 0
     got = list(siz)[22:32]

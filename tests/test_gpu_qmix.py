@@ -18,7 +18,8 @@ CASES = ["qmix_tiny", "qmix_tiny_huber_per", "qmix_tiny_nodouble", "vdn_tiny", "
          "qmix_var_d252", "qmix_var_d188", "qmix_var_d124", "qmix_var_mix216", "qmix_var_mix100", "qmix_var_s2232",
          "qmix_var_n10", "qmix_var_a20",       # 10 agents (two per wave of the fused chain kernel), 20 actions (two head tiles; plain-max targets)
          # one-layer hyper-networks (--hypernet_layers 1, q_mixer.py:39-44): the tiny shape fixture, 8 agents at S = 216, odd S + Huber + PER
-         "qmix_shape_hyper1", "qmix_var_hyper1_mix", "qmix_var_hyper1_odd"]
+         "qmix_shape_hyper1", "qmix_var_hyper1_mix", "qmix_var_hyper1_odd", "qmix_shape_layer2",
+         "qmix_var_layer2_d252", "qmix_var_layer2_hyper1", "qmix_var_layer2_odd", "vdn_var_layer2"]
 RTOL = 1e-4
 
 
@@ -308,10 +309,11 @@ def test_deterministic_bitwise():
     assert np.array_equal(outs[0], outs[1])
 
 
-def test_policy_forward_matches_oracle_single_step_and_sequence():
-    """policy.get_q_values (ope_agent_forward) with a non-zero initial hidden state."""
+@pytest.mark.parametrize("name", ["qmix_tiny", "qmix_shape_layer2", "qmix_var_layer2_d252"])
+def test_policy_forward_matches_oracle_single_step_and_sequence(name):
+    """policy.get_q_values (ope_agent_forward) with a non-zero initial hidden state; with one and with two hidden blocks (layer_N)."""
     from oracle import qmix_oracle as O
-    g = load_golden("qmix_tiny")
+    g = load_golden(name)
     dims, buf, policy, trainer = build_from_fixture(g)
     P = {k: torch.as_tensor(v) for k, v in sub(g, "agent/").items()}
     torch.manual_seed(3)
