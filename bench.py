@@ -54,6 +54,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-table", action="store_true", help="skip the per-kernel roofline table (10 extra untimed steps with an event "
                     "pair on every kernel launch, after the timed region)")
+    ap.add_argument("--lazy-obs", action="store_true", help="QMIX workloads: leave the observation rows in the replay store; the two kernels that "
+                    "consume them read the rows in place (RecPolicyBuffer.lazy_obs, ope_qmix_loss_and_grad_ref). Default: gathered into the "
+                    "batch like every other field -- measured equal within noise at 3s5z (0.3451 vs 0.3445 ms; the gather drops 18.3 -> "
+                    "10.7 us, trunk_fwd4 and wgrad gain 5 + 3 us reading rows the Infinity Cache does not hold; profiles/r04c_bench_3s5z_*.json)")
     ap.add_argument("--graph", action="store_true", help="QMIX workloads: replay the training kernels of a step as one captured HIP graph")
     ap.add_argument("--no-graph", action="store_true", help="MLP MADDPG/MATD3: launch the ~45 kernels of an update one by one instead "
                     "of replaying the captured HIP graph")
@@ -71,7 +75,7 @@ def parse():
     return ap.parse_args()
 
 
-def gather_traffic(workload, batch, episodes=256):
+def gather_traffic(workload, batch, episodes=256, lazy_obs=False):
     """HBM bytes per gather launch from the committed PMC passes (profiles/gather_traffic.json: rocprofv3 --pmc FETCH_SIZE and
     --pmc WRITE_SIZE in separate runs of this same command, corrected as MI355X_MICROARCH.md prescribes); None if that
     configuration was not measured. PMC collection cannot run inside the timed bench, hence the file. Entries are keyed
@@ -80,6 +84,9 @@ def gather_traffic(workload, batch, episodes=256):
     try:
         with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "gather_traffic.json")) as f:
             ent = json.load(f)["entries"]
+        if lazy_obs:      # the gather without the observation field (rows left in the store): its own PMC passes
+            e = ent.get("%s:%d:%d:lazy_obs" % (workload, batch, episodes))
+            return int(e["traffic_bytes"]) if e else None
         e = ent.get("%s:%d:%d" % (workload, batch, episodes)) or (ent.get("%s:%d" % (workload, batch)) if episodes == 256 else None)
         return int(e["traffic_bytes"]) if e else None
     except (OSError, ValueError, KeyError):
@@ -432,6 +439,7 @@ def main():
     for leg, local_batch, global_batch in scaling_legs(a, a.batch, world):
         np.random.seed(1000)
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+        pbuf.lazy_obs = a.lazy_obs and trainer.obs_ref_ok(local_batch)
         # Eager launches by default: the host enqueues a step in ~150 us against 0.4 ms of kernels, so it runs ahead and a
         # HIP-graph replay of the training kernels (--graph; QMix.make_graphed_step) is 1-4 % SLOWER here (measured).
         graphed = trainer.make_graphed_step(buf, local_batch, gather_in_graph=False) if (
@@ -477,12 +485,16 @@ def main():
         if world == 1 and graphed is None and not a.no_kernel_table:
             per_kernel = measured_kernel_table(one_step)
         results.append(dict(leg=leg, local_batch=local_batch, global_batch=global_batch, elapsed=elapsed, gather_ms=gather_ms, loss=loss,
-                            graphed=graphed is not None, bracket_ms=bracket_ms, n_kernel_ms=len(kernel_ms), windows=windows, per_kernel=per_kernel))
+                            graphed=graphed is not None, bracket_ms=bracket_ms, n_kernel_ms=len(kernel_ms), windows=windows, per_kernel=per_kernel,
+                            lazy_obs=bool(pbuf.lazy_obs)))
 
     if rank == 0:
         r0 = results[0]
         ep_bytes = int(_lib.lib.ope_episode_bytes(C.byref(pbuf.dims)))
-        algo_bytes = 2.0 * r0["local_batch"] * ep_bytes            # read from the store + write of the batch
+        obs_bytes = 4 * (dims.episode_length + 1) * dims.n_agents * dims.obs_dim
+        # read from the store + write of the batch; with the observations left in the store ("fused into the first consumer,
+        # written = 0") the gather moves the other fields only, and the obs rows are read by trunk_fwd4 (both nets) and wgrad instead
+        algo_bytes = 2.0 * r0["local_batch"] * (ep_bytes - (obs_bytes if r0["lazy_obs"] else 0))
         achieved = algo_bytes / (r0["gather_ms"] * 1e-3) / 1e9
         steps_per_s = a.steps / r0["elapsed"]
         value = steps_per_s * (r0["global_batch"] / float(a.batch))
@@ -501,11 +513,13 @@ def main():
                                        "--use_soft_update)" % args.hard_update_interval_episode),
                        "batch_per_gpu": r0["local_batch"], "global_batch": r0["global_batch"], "parallelism": "dp%d" % world,
                        "launch": "eager gather + HIP graph of the training kernels" if r0["graphed"] else "eager",
+                       "obs": ("left in the replay store: read in place by trunk_fwd4 and wgrad (%.1f MB per batch neither written nor re-read; "
+                               "default: gathered)" % (r0["local_batch"] * obs_bytes / 1e6)) if r0["lazy_obs"] else "gathered into the batch",
                        "allreduce": allreduce_name() if world > 1 else None,
                        "optimizer_steps_per_sec": round(steps_per_s, 3), "final_loss": round(r0["loss"], 6)},
             "roofline": {"kernel": "episode_copy_kernel<gather> (ope_store_gather)", "bound": "hbm", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": gather_traffic(a.workload, r0["local_batch"], a.episodes),
+                         "traffic": gather_traffic(a.workload, r0["local_batch"], a.episodes, r0["lazy_obs"]),
                          "algorithmic_bytes_per_launch": int(algo_bytes), "avg_launch_ms": round(r0["gather_ms"], 5),
                          "store_bytes": int(a.episodes * ep_bytes),
                          "hbm_resident": bool(a.episodes * ep_bytes > 4 * 256 * 2 ** 20),

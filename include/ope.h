@@ -156,6 +156,23 @@ typedef struct ope_gather_tune {
 } ope_gather_tune;
 int ope_store_gather_tuned(const ope_dims* dims, int32_t capacity, const ope_fields* store, const int64_t* inds_dev, const int64_t* inds_host,
                            int32_t batch, const ope_fields* out, int32_t* bad_index_flag, const ope_gather_tune* tune, void* stream);
+/* Observations left in the store ("lazy batch"; SURVEY.md section 8(d): "fused into the first consumer, written = 0"). The sampled
+ * episodes' observation rows are the largest field of a batch (3s5z: 39 of 48 MB) and the training step reads them exactly twice: the
+ * trunk's first layer and its weight gradient. ope_store_gather_ref = ope_store_gather_tuned that (a) copies only the fields whose
+ * `out` pointer is non-NULL (pass out->obs = NULL: every gather entry point skips NULL fields) and (b) writes the episode slots it
+ * used to inds_out (DEVICE int64[batch]; the host-index form has them in its kernel arguments only). An ope_obs_ref then names those
+ * rows for ope_qmix_loss_and_grad_ref: batch row (t, agent, b) = store_obs[inds[b]][t][agent][:]. The store must not be written
+ * between the gather and the step (RecPolicyBuffer checks its insert count). Replaces rec_buffer.py:206-238 + qmix.py:108-109 for obs. */
+typedef struct ope_obs_ref {
+  const float* store_obs;   /* the store's obs ring [capacity][T+1][N][D] (ope_fields.obs of the store) */
+  const int64_t* inds;      /* DEVICE int64[batch] episode slots, batch order */
+  int32_t capacity;         /* slots outside [0, capacity) are clamped by the readers; the gather of the other fields raises bad_index_flag */
+  int32_t reserved;
+} ope_obs_ref;
+int ope_store_gather_ref(const ope_dims* dims, int32_t capacity, const ope_fields* store, const int64_t* inds_dev, const int64_t* inds_host,
+                         int32_t batch, const ope_fields* out, int64_t* inds_out, int32_t* bad_index_flag, const ope_gather_tune* tune,
+                         void* stream);
+
 /* Bytes of one episode over all seven fields (SURVEY.md section 8(d) "episode bytes"). */
 int64_t ope_episode_bytes(const ope_dims* dims);
 
@@ -274,6 +291,16 @@ int64_t ope_qmix_workspace_find(const ope_qmix_cfg* cfg, const char* name, int64
 int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields* batch, const float* theta,
                            const float* theta_tgt, const float* per_weights, void* workspace,
                            int64_t workspace_bytes, float* grad, float* td_abs_stats, void* stream);
+/* The same step with the observations read in place from the replay store (ope_obs_ref above; batch->obs is ignored and may be NULL):
+ * same arithmetic on the same values, so the gradient is bit-identical to the gathered form. Only the configurations whose first-layer
+ * kernels read rows through an index can do it -- ope_qmix_obs_ref_ok(cfg) = 1: recurrent nets, phase 0, obs_dim % 4 == 0 with
+ * ceil(obs_dim / 16) in {4, 8, 12, 16}, state_dim % 4 == 0, batch <= 512, (T+1) N batch < 2^20 rows, and the LDS-resident trunk kernel
+ * selected (trunk_path 4, or 0 with >= 16 384 rows) -- everything else returns OPE_EINVAL (the caller gathers obs instead). */
+int ope_qmix_obs_ref_ok(const ope_qmix_cfg* cfg);
+int ope_qmix_loss_and_grad_ref(const ope_qmix_cfg* cfg, const ope_fields* batch, const ope_obs_ref* obs, const float* theta,
+                               const float* theta_tgt, const float* per_weights, void* workspace, int64_t workspace_bytes,
+                               float* grad, float* td_abs_stats, void* stream);
+
 
 /* Forward only of the agent q-network on [L, R, D] observations with initial hidden h0 [R, 64] (NULL = zeros)
  * (AgentQFunction.forward, agent_q_function.py:34-67): q_out [L, R, A], h_out [L, R, 64] (un-normalised GRU
@@ -398,6 +425,29 @@ int ope_ddpg_target_actions(const ope_ddpg_cfg* cfg, const ope_mlp_batch* batch,
 int ope_ddpg_actor_loss_and_grad(const ope_ddpg_cfg* cfg, const ope_mlp_batch* batch, const float* theta_actor,
                                  const float* theta_critic, const float* gumbel_noise_u, void* workspace,
                                  int64_t workspace_bytes, float* grad, void* stream);
+
+/* The same two updates INCLUDING their optimiser step, one launch each (small networks in one process: ope_ddpg_update_ok(cfg) = 1 when
+ * the fused tile path serves cfg and all its workgroups are co-resident). The launch's tail replaces the slab reduction, the norm pass
+ * and ope_adam_step: behind a grid barrier every workgroup sums its share of the per-workgroup gradient slabs (same fixed order as the
+ * separate reduction: the gradient is bit-identical), a second barrier publishes the partial sums of squares, then clip_grad_norm_ +
+ * Adam (+ Polyak of the updated network's target) run on the same share. `grad` still receives the flat gradient + tail. opt->adam as
+ * for ope_adam_step (sumsq_partials / tail_offset ignored); opt->n = elements optimised (a prefix: the critic's trunk, SURVEY A-4);
+ * theta_critic / theta_actor are UPDATED in place. maddpg.py:100-157 + 192-249 with their optimizer.step() / soft_update calls. */
+typedef struct ope_ddpg_opt {
+  ope_adam_cfg adam;
+  int64_t n;
+  float* theta_tgt;     /* Polyak target of the updated network (adam.do_polyak), else NULL */
+  float* adam_m;
+  float* adam_v;
+  float* stats_out;     /* [4] as ope_adam_step, or NULL */
+} ope_ddpg_opt;
+int ope_ddpg_update_ok(const ope_ddpg_cfg* cfg);
+int ope_ddpg_critic_update(const ope_ddpg_cfg* cfg, const ope_mlp_batch* batch, const float* theta_actor_tgt, float* theta_critic,
+                           const float* theta_critic_tgt, const float* target_noise_u, const float* per_weights, void* workspace,
+                           int64_t workspace_bytes, float* grad, float* prio_out, const ope_ddpg_opt* opt, void* stream);
+int ope_ddpg_actor_update(const ope_ddpg_cfg* cfg, const ope_mlp_batch* batch, float* theta_actor, const float* theta_critic,
+                          const float* gumbel_noise_u, void* workspace, int64_t workspace_bytes, float* grad, const ope_ddpg_opt* opt,
+                          void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Recurrent MADDPG / MATD3 update on sampled EPISODES (use_same_share_obs path, one shared policy).

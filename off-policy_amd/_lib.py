@@ -46,12 +46,23 @@ class GatherTune(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("floats_per_block", "xcd_run", "unroll", "nontemporal", "small_tiles", "tile_floats")]
 
 
+class ObsRef(C.Structure):
+    """ope_obs_ref (include/ope.h): a batch's observation rows left in the replay store."""
+    _fields_ = [("store_obs", C.c_void_p), ("inds", C.c_void_p), ("capacity", C.c_int32), ("reserved", C.c_int32)]
+
+
 class AdamCfg(C.Structure):
     _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
                 ("max_grad_norm", C.c_float), ("weight_decay", C.c_float), ("tau", C.c_float),
                 ("do_polyak", C.c_int32), ("step", C.c_int32), ("qtot_denominator", C.c_float), ("tail_offset", C.c_int32),
                 ("step_counter", C.c_void_p), ("skip_begin", C.c_int32), ("skip_end", C.c_int32),
                 ("sumsq_partials", C.c_void_p), ("n_sumsq_partials", C.c_int32)]
+
+
+class DdpgOpt(C.Structure):
+    """ope_ddpg_opt (include/ope.h): the optimiser step carried by a fused MADDPG / MATD3 update launch."""
+    _fields_ = [("adam", AdamCfg), ("n", C.c_int64), ("theta_tgt", C.c_void_p), ("adam_m", C.c_void_p), ("adam_v", C.c_void_p),
+                ("stats_out", C.c_void_p)]
 
 
 class DdpgCfg(C.Structure):
@@ -97,6 +108,9 @@ def _load():
         "ope_store_gather_host_inds": (C.c_int, [C.POINTER(Dims), i32, C.POINTER(Fields), p, i32, C.POINTER(Fields), p]),
         "ope_store_gather_sampled": (C.c_int, [C.POINTER(Dims), i32, i32, p, C.POINTER(Fields), C.c_uint64, p, i32, C.POINTER(Fields), p, p]),
         "ope_store_gather_tuned": (C.c_int, [C.POINTER(Dims), i32, C.POINTER(Fields), p, p, i32, C.POINTER(Fields), p, C.POINTER(GatherTune), p]),
+        "ope_store_gather_ref": (C.c_int, [C.POINTER(Dims), i32, C.POINTER(Fields), p, p, i32, C.POINTER(Fields), p, p, C.POINTER(GatherTune), p]),
+        "ope_qmix_obs_ref_ok": (C.c_int, [C.POINTER(QmixCfg)]),
+        "ope_qmix_loss_and_grad_ref": (C.c_int, [C.POINTER(QmixCfg), C.POINTER(Fields), C.POINTER(ObsRef), p, p, p, p, i64, p, p, p]),
         "ope_store_gather_profile": (C.c_int, [i32]),
         "ope_store_gather_profile_read": (C.c_int, [p, i32]),
         "ope_set_gather_params": (None, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -122,6 +136,9 @@ def _load():
         "ope_ddpg_workspace_init": (C.c_int, [C.POINTER(DdpgCfg), p, i64, p]),
         "ope_ddpg_workspace_find": (i64, [C.POINTER(DdpgCfg), C.c_char_p, C.POINTER(i64)]),
         "ope_ddpg_critic_loss_and_grad": (C.c_int, [C.POINTER(DdpgCfg), C.POINTER(MlpBatch), p, p, p, p, p, p, i64, p, p, p]),
+        "ope_ddpg_update_ok": (C.c_int, [C.POINTER(DdpgCfg)]),
+        "ope_ddpg_critic_update": (C.c_int, [C.POINTER(DdpgCfg), C.POINTER(MlpBatch), p, p, p, p, p, p, i64, p, p, C.POINTER(DdpgOpt), p]),
+        "ope_ddpg_actor_update": (C.c_int, [C.POINTER(DdpgCfg), C.POINTER(MlpBatch), p, p, p, p, i64, p, C.POINTER(DdpgOpt), p]),
         "ope_ddpg_target_actions": (C.c_int, [C.POINTER(DdpgCfg), C.POINTER(MlpBatch), p, p, p, i64, p, p]),
         "ope_ddpg_actor_loss_and_grad": (C.c_int, [C.POINTER(DdpgCfg), C.POINTER(MlpBatch), p, p, p, p, i64, p, p]),
         "ope_rddpg_param_layout": (i64, [C.POINTER(RddpgCfg), i32, C.POINTER(i64), C.POINTER(i64)]),

@@ -13,6 +13,7 @@ Upstream defects kept by default so that results are the reference's (SURVEY.md 
 The gumbel noise is drawn on the CPU generator in the reference's order (target noise first, then actor noise).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -21,6 +22,8 @@ from ... import _lib
 from ... import dist as opdist
 from .algorithm.MADDPGPolicy import sample_gumbel_uniform
 
+
+_OPT_TAIL_DEFAULT = os.environ.get("OPE_DDPG_OPT_TAIL", "0") == "1"
 
 class MADDPG(object):
     def __init__(self, args, num_agents, policies, policy_mapping_fn, device=None, actor_update_interval=1, count_updates=False):
@@ -150,6 +153,35 @@ class MADDPG(object):
             return None
         return ws.data_ptr() + r[0], (r[1] // 2 if n_opt < n_all else r[1])
 
+    def _update_in_launch(self, cfg):
+        """Does the update launch carry its own optimiser step (ope_ddpg_critic_update / ope_ddpg_actor_update: slab reduction, clip, Adam
+        and Polyak in the tile kernel's tail)? One process (a multi-GPU run all-reduces the gradient between the two), one shared
+        policy, small networks whose workgroups are all co-resident. OFF by default: measured on MI355X the two grid barriers of the tail
+        cost more than the two launches they replace (config 3: 0.1076 vs 0.0894 ms per step; csrc/ope_ddpg_tile.hip) --
+        `self.update_in_launch = True` or OPE_DDPG_OPT_TAIL=1 selects it."""
+        if not getattr(self, "update_in_launch", _OPT_TAIL_DEFAULT) or self.multi_policy or opdist.is_distributed():
+            return False
+        key = ("uil", cfg.batch)
+        if key not in self._gsq:
+            self._gsq[key] = bool(_lib.lib.ope_ddpg_update_ok(C.byref(cfg)))
+        return self._gsq[key]
+
+    def _opt_block(self, opt, n, flat_tgt, skip):
+        opt.step_count += 1
+        o = _lib.DdpgOpt()
+        ac = o.adam
+        ac.lr, ac.beta1, ac.beta2, ac.eps = opt.lr, opt.betas[0], opt.betas[1], opt.eps
+        ac.max_grad_norm, ac.weight_decay = float(self.args.max_grad_norm), float(getattr(self.args, "weight_decay", 0.0))
+        ac.skip_begin, ac.skip_end = skip
+        ac.tau, ac.do_polyak = (float(self.args.tau), 1) if self.fuse_soft_update else (0.0, 0)
+        ac.step, ac.qtot_denominator = opt.step_count, 1.0
+        if opt.step_dev is not None:
+            ac.step_counter = _lib.ptr(opt.step_dev).value
+        stats = torch.empty(4, **self.tpdv)
+        o.n, o.theta_tgt = int(n), _lib.ptr(flat_tgt).value
+        o.adam_m, o.adam_v, o.stats_out = _lib.ptr(opt.exp_avg).value, _lib.ptr(opt.exp_avg_sq).value, _lib.ptr(stats).value
+        return o, stats
+
     def _adam(self, opt, n, flat, flat_tgt, grad, scratch, tail, skip=(0, 0), gsq=None):
         opt.step_count += 1
         ac = _lib.AdamCfg()
@@ -247,27 +279,39 @@ class MADDPG(object):
             w = (importance_weights.to(self.device, dtype=torch.float32).contiguous() if dev_prio else
                  torch.as_tensor(np.asarray(importance_weights), dtype=torch.float32).to(self.device).contiguous())
         prio = torch.empty(B, **self.tpdv) if self.use_per else None
-        _lib.check(_lib.lib.ope_ddpg_critic_loss_and_grad(C.byref(cfg), C.byref(mb), _lib.ptr(policy.target_actor._flat),
-                                                          _lib.ptr(policy.critic._flat), _lib.ptr(policy.target_critic._flat),
-                                                          _lib.ptr(u_t), _lib.ptr(w), _lib.ptr(ws), ws.numel(), _lib.ptr(gc),
-                                                          _lib.ptr(prio), st), "ope_ddpg_critic_loss_and_grad")
-        opdist.allreduce_flat_(gc)
-        cs = self._adam(policy.critic_optimizer, policy.critic.trainable_numel, policy.critic._flat, policy.target_critic._flat, gc,
-                        scratch, policy.critic.padded_numel, policy.critic.unused_range,
-                        self._gsq_region(cfg, ws, "gsq_critic", policy.critic.trainable_numel, policy.critic.padded_numel))
+        in_launch = self._update_in_launch(cfg)
+        if in_launch:      # gradient, clip, Adam and the target's Polyak step: one launch
+            ob, cs = self._opt_block(policy.critic_optimizer, policy.critic.trainable_numel, policy.target_critic._flat, policy.critic.unused_range)
+            _lib.check(_lib.lib.ope_ddpg_critic_update(C.byref(cfg), C.byref(mb), _lib.ptr(policy.target_actor._flat), _lib.ptr(policy.critic._flat),
+                                                       _lib.ptr(policy.target_critic._flat), _lib.ptr(u_t), _lib.ptr(w), _lib.ptr(ws), ws.numel(),
+                                                       _lib.ptr(gc), _lib.ptr(prio), C.byref(ob), st), "ope_ddpg_critic_update")
+        else:
+            _lib.check(_lib.lib.ope_ddpg_critic_loss_and_grad(C.byref(cfg), C.byref(mb), _lib.ptr(policy.target_actor._flat),
+                                                              _lib.ptr(policy.critic._flat), _lib.ptr(policy.target_critic._flat),
+                                                              _lib.ptr(u_t), _lib.ptr(w), _lib.ptr(ws), ws.numel(), _lib.ptr(gc),
+                                                              _lib.ptr(prio), st), "ope_ddpg_critic_loss_and_grad")
+            opdist.allreduce_flat_(gc)
+            cs = self._adam(policy.critic_optimizer, policy.critic.trainable_numel, policy.critic._flat, policy.target_critic._flat, gc,
+                            scratch, policy.critic.padded_numel, policy.critic.unused_range,
+                            self._gsq_region(cfg, ws, "gsq_critic", policy.critic.trainable_numel, policy.critic.padded_numel))
         train_info["critic_loss"], train_info["critic_grad_norm"] = cs[0], cs[1]
         new_priorities = (prio if dev_prio else prio.cpu().numpy()) if self.use_per else None
         # ---- actor ----
         if update_actor:
             u_a = draw((N * B, policy.act_dim)) if override is None else override[1]
             assert u_a is None or tuple(u_a.shape) == (N * B, policy.act_dim)
-            _lib.check(_lib.lib.ope_ddpg_actor_loss_and_grad(C.byref(cfg), C.byref(mb), _lib.ptr(policy.actor._flat),
-                                                             _lib.ptr(policy.critic._flat), _lib.ptr(u_a), _lib.ptr(ws), ws.numel(),
-                                                             _lib.ptr(ga), st), "ope_ddpg_actor_loss_and_grad")
-            opdist.allreduce_flat_(ga)
-            as_ = self._adam(policy.actor_optimizer, policy.actor.padded_numel, policy.actor._flat, policy.target_actor._flat, ga,
-                             scratch, policy.actor.padded_numel, policy.actor.unused_range,
-                             self._gsq_region(cfg, ws, "gsq_actor", policy.actor.padded_numel, policy.actor.padded_numel))
+            if in_launch:
+                ob, as_ = self._opt_block(policy.actor_optimizer, policy.actor.padded_numel, policy.target_actor._flat, policy.actor.unused_range)
+                _lib.check(_lib.lib.ope_ddpg_actor_update(C.byref(cfg), C.byref(mb), _lib.ptr(policy.actor._flat), _lib.ptr(policy.critic._flat),
+                                                          _lib.ptr(u_a), _lib.ptr(ws), ws.numel(), _lib.ptr(ga), C.byref(ob), st), "ope_ddpg_actor_update")
+            else:
+                _lib.check(_lib.lib.ope_ddpg_actor_loss_and_grad(C.byref(cfg), C.byref(mb), _lib.ptr(policy.actor._flat),
+                                                                 _lib.ptr(policy.critic._flat), _lib.ptr(u_a), _lib.ptr(ws), ws.numel(),
+                                                                 _lib.ptr(ga), st), "ope_ddpg_actor_loss_and_grad")
+                opdist.allreduce_flat_(ga)
+                as_ = self._adam(policy.actor_optimizer, policy.actor.padded_numel, policy.actor._flat, policy.target_actor._flat, ga,
+                                 scratch, policy.actor.padded_numel, policy.actor.unused_range,
+                                 self._gsq_region(cfg, ws, "gsq_actor", policy.actor.padded_numel, policy.actor.padded_numel))
             train_info["actor_loss"], train_info["actor_grad_norm"] = as_[0], as_[1]
             train_info["update_actor"] = update_actor
         elif self.fuse_soft_update:      # no actor step this time: its target still takes its Polyak step

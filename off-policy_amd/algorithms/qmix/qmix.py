@@ -20,6 +20,7 @@ import torch
 from ... import _lib
 from ... import dist as opdist
 from ...config import require_reference_architecture
+from ...utils.rec_buffer import StoreObs
 from .algorithm.q_mixer import QMixer, VDNMixer
 
 
@@ -350,7 +351,14 @@ class QMix(object):
         if self.multi:
             return self._train_multi_rec(batch)
         pid = self.policy_ids[0]
-        obs = self._to_device_layout(obs_b[pid], True)
+        obs = obs_b[pid]
+        if isinstance(obs, StoreObs):
+            # observations left in the replay store (RecPolicyBuffer.lazy_obs): the first-layer kernels read the rows in place where the
+            # configuration allows it (ope_qmix_obs_ref_ok); otherwise they are gathered now, as sample_inds would have
+            if getattr(self.policies[pid], "prev_act_inp", False) or not self.obs_ref_ok(obs.batch):
+                obs = obs.materialize()
+        if not isinstance(obs, StoreObs):
+            obs = self._to_device_layout(obs, True)
         # the mixer's state: the shared centralized observation, or agent 0's when every agent has its own (qmix.py:86-90)
         cent = cent_b[pid] if self.use_same_share_obs else cent_b[pid][0]
         share = self._to_device_layout(cent, False)
@@ -382,13 +390,25 @@ class QMix(object):
         rew = self._to_device_layout(rew_b[last], True)[:, :1]                               # qmix.py:103,159: the LAST policy's agent 0
         return self._train_multi(parts, share, rew, dones_env, importance_weights, idxes)
 
+    def obs_ref_ok(self, batch):
+        """Can a step on `batch` episodes read its observation rows from the replay store (StoreObs) instead of a gathered tensor?"""
+        if self.multi or self._mlp:
+            return False
+        return bool(_lib.lib.ope_qmix_obs_ref_ok(C.byref(self._cfg(int(batch)))))
+
     def _train_on_device_batch(self, obs, share, acts, rew, dones_env, avail, importance_weights, idxes):
-        T1, N, B, D = obs.shape
+        oref = None
+        if isinstance(obs, StoreObs):
+            N, T1, B, D = obs.shape
+            oref = obs.ref()
+        else:
+            T1, N, B, D = obs.shape
         assert T1 == self.episode_length + 1 and N == self.num_agents, "batch does not match the trainer's dimensions"
         cfg = self._cfg(B)
         ws = self._workspace(cfg)
         f = _lib.Fields()
-        f.obs, f.share_obs, f.acts, f.rewards = _lib.ptr(obs).value, _lib.ptr(share).value, _lib.ptr(acts).value, _lib.ptr(rew).value
+        f.obs = None if oref is not None else _lib.ptr(obs).value
+        f.share_obs, f.acts, f.rewards = _lib.ptr(share).value, _lib.ptr(acts).value, _lib.ptr(rew).value
         f.dones, f.dones_env, f.avail_acts = None, _lib.ptr(dones_env).value, _lib.ptr(avail).value
         w = None
         td_stats = None
@@ -403,9 +423,14 @@ class QMix(object):
         if dev_prio and world_size > 1 and self.grad.numel() < n_head + B * world_size:
             # room behind the tail for the ranks' per-episode priorities: they ride on the gradient all-reduce (dist.priority_slots)
             self.grad = torch.zeros(n_head + B * world_size, **self.tpdv)
-        _lib.check(_lib.lib.ope_qmix_loss_and_grad(C.byref(cfg), C.byref(f), _lib.ptr(self.theta), _lib.ptr(self.theta_tgt),
-                                                   _lib.ptr(w), _lib.ptr(ws), ws.numel(), _lib.ptr(self.grad),
-                                                   _lib.ptr(td_stats), st), "ope_qmix_loss_and_grad")
+        if oref is not None:
+            _lib.check(_lib.lib.ope_qmix_loss_and_grad_ref(C.byref(cfg), C.byref(f), C.byref(oref), _lib.ptr(self.theta), _lib.ptr(self.theta_tgt),
+                                                           _lib.ptr(w), _lib.ptr(ws), ws.numel(), _lib.ptr(self.grad),
+                                                           _lib.ptr(td_stats), st), "ope_qmix_loss_and_grad_ref")
+        else:
+            _lib.check(_lib.lib.ope_qmix_loss_and_grad(C.byref(cfg), C.byref(f), _lib.ptr(self.theta), _lib.ptr(self.theta_tgt),
+                                                       _lib.ptr(w), _lib.ptr(ws), ws.numel(), _lib.ptr(self.grad),
+                                                       _lib.ptr(td_stats), st), "ope_qmix_loss_and_grad")
         gathered = None
         if dev_prio and world_size > 1:
             s = td_stats.view(B, 2)

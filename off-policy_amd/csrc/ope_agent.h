@@ -47,6 +47,9 @@ struct TrunkFwdArgs {
   float* xhat2;
   float* rstd2;
   uint64_t* mask2;
+  // observations left in the store (trunk_fwd4 only): x = the store's obs ring, local row r is batch row ref_row0 + r
+  ObsRef ref;
+  int ref_row0;
 };
 
 struct GruFwdArgs {

@@ -353,9 +353,36 @@ extern "C" int ope_qmix_workspace_init(const ope_qmix_cfg* cfg, void* workspace,
   return launch_fill(W + p.ln_one, p.R, 1.f, (hipStream_t)stream);
 }
 
+// ope_qmix_obs_ref_ok: the static part of "can this configuration read observation rows from the store" (the launchers check the rest)
+static bool obs_ref_cfg_ok(const ope_qmix_cfg* cfg) {
+  if (!cfg_ok(cfg) || cfg->mlp || cfg->phase != 0 || cfg->dims.layer_N == 2) return false;
+  const ope_dims& d = cfg->dims;
+  const int KC = (d.obs_dim + 15) >> 4;
+  const int64_t R = (int64_t)(d.episode_length + 1) * d.n_agents * cfg->batch;
+  static const int t4 = getenv("OPE_TRUNK4") ? atoi(getenv("OPE_TRUNK4")) : 1;
+  return d.obs_dim % 4 == 0 && (KC == 4 || KC == 8 || KC == 12 || KC == 16) && d.state_dim % 4 == 0 && cfg->batch <= kObsRefMaxB &&
+         R < kObsRefMaxRows && (cfg->trunk_path == 4 || (cfg->trunk_path == 0 && t4 && R >= 16 * 1024 && cfg->time_chunks <= 1));
+}
+extern "C" int ope_qmix_obs_ref_ok(const ope_qmix_cfg* cfg) { return obs_ref_cfg_ok(cfg) ? 1 : 0; }
+
+static int qmix_step(const ope_qmix_cfg* cfg, const ope_fields* batch, const ope_obs_ref* oref, const float* theta, const float* theta_tgt,
+                     const float* per_weights, void* workspace, int64_t workspace_bytes, float* grad, float* td_abs_stats, void* stream);
+
 extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields* batch, const float* theta,
                                       const float* theta_tgt, const float* per_weights, void* workspace,
                                       int64_t workspace_bytes, float* grad, float* td_abs_stats, void* stream) {
+  return qmix_step(cfg, batch, nullptr, theta, theta_tgt, per_weights, workspace, workspace_bytes, grad, td_abs_stats, stream);
+}
+
+extern "C" int ope_qmix_loss_and_grad_ref(const ope_qmix_cfg* cfg, const ope_fields* batch, const ope_obs_ref* obs, const float* theta,
+                                          const float* theta_tgt, const float* per_weights, void* workspace, int64_t workspace_bytes,
+                                          float* grad, float* td_abs_stats, void* stream) {
+  if (!obs || !obs->store_obs || !obs->inds || obs->capacity < 1 || !obs_ref_cfg_ok(cfg)) return OPE_EINVAL;
+  return qmix_step(cfg, batch, obs, theta, theta_tgt, per_weights, workspace, workspace_bytes, grad, td_abs_stats, stream);
+}
+
+static int qmix_step(const ope_qmix_cfg* cfg, const ope_fields* batch, const ope_obs_ref* oref, const float* theta, const float* theta_tgt,
+                     const float* per_weights, void* workspace, int64_t workspace_bytes, float* grad, float* td_abs_stats, void* stream) {
   (void)hipGetLastError();  // drop stale errors from the caller's own HIP use
   clear_launch_log();
   if (!cfg_ok(cfg) || !batch || !theta || !theta_tgt || !workspace || !grad) return OPE_EINVAL;
@@ -365,7 +392,13 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
   const int phase = cfg->phase;
   const int dbg_on = g_debug | cfg->debug;      // per-call request or the process default
   const bool do_fwd = phase == 0 || phase == 1, do_mix = phase == 0 || phase == 2, do_bwd = phase == 0 || phase == 3;
-  if ((do_fwd || do_bwd) && (!batch->obs || !batch->acts)) return OPE_EINVAL;
+  if ((do_fwd || do_bwd) && ((!batch->obs && !oref) || !batch->acts)) return OPE_EINVAL;
+  ObsRef ref;
+  memset(&ref, 0, sizeof(ref));
+  const float* const obs_rows = oref ? oref->store_obs : batch->obs;      // the batch's [T+1][N][B][D] rows, or the store's ring read through `ref`
+  if (oref) {
+    ref.inds = oref->inds; ref.cap = oref->capacity; ref.B = cfg->batch; ref.TTN = (cfg->dims.episode_length + 1) * cfg->dims.n_agents;
+  }
   if (do_mix && (!batch->share_obs || !batch->rewards || !batch->dones_env)) return OPE_EINVAL;
   if (phase == 2 && cfg->vdn == 0 && cfg->dims.n_agents < 1) return OPE_EINVAL;
   if ((phase == 1 || phase == 3) && !cfg->vdn) return OPE_EINVAL;   // per-policy parts carry no mixer parameters
@@ -431,7 +464,8 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
     const int64_t r0 = (int64_t)p.tb[c] * p.NB, rows = (int64_t)(p.tb[c + 1] - p.tb[c]) * p.NB;
     TrunkFwdArgs tf;
     memset(&tf, 0, sizeof(tf));
-    tf.x = batch->obs + r0 * p.D; tf.R = (int)rows; tf.D = p.D; tf.theta = theta; tf.L = p.AL;
+    tf.x = oref ? obs_rows : obs_rows + r0 * p.D; tf.R = (int)rows; tf.D = p.D; tf.theta = theta; tf.L = p.AL;
+    tf.ref = ref; tf.ref_row0 = (int)r0;
     tf.gi = p.mlp ? nullptr : W + p.gi + r0 * 3 * OPE_H; tf.a2_out = p.mlp ? W + p.h + r0 * OPE_H : nullptr;
     if (p.layerN == 2) { tf.gi = nullptr; tf.a2_out = W + p.a2 + r0 * OPE_H; }      // the trunk stops at the first block's output; ope_block.hip continues
     tf.mu0 = W + p.mu0 + r0; tf.rstd0 = W + p.rstd0 + r0;
@@ -607,8 +641,9 @@ extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields*
   auto add_agent_problems = [&](WgTable& wt, int64_t r0, int K1, int nsplit, int slab0) {
     const int64_t ab = p.raw_agent + (int64_t)slab0 * rw.agent_end, as = rw.agent_end;
     {
-      WgProb& q = prob(wt, W + p.dz1 + r0 * OPE_H, OPE_H, OPE_H, batch->obs + r0 * p.D, p.D, p.D, K1, rw.P1, p.D, rw.s1, nsplit, ab, as);
+      WgProb& q = prob(wt, W + p.dz1 + r0 * OPE_H, OPE_H, OPE_H, oref ? obs_rows : obs_rows + r0 * p.D, p.D, p.D, K1, rw.P1, p.D, rw.s1, nsplit, ab, as);
       q.ln_mu = W + p.mu0 + r0; q.ln_rstd = W + p.rstd0 + r0;
+      if (oref) { q.ref_row1 = (int)r0 + 1; wt.ref = ref; }
     }
     prob(wt, W + p.dz2 + r0 * OPE_H, OPE_H, OPE_H, W + p.xhat1 + r0 * OPE_H, OPE_H, OPE_H, K1, rw.P2, OPE_H, rw.s2, nsplit, ab, as);
     if (!p.mlp) {

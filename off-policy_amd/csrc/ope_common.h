@@ -221,6 +221,24 @@ __device__ __forceinline__ void gload_async_s(float& dst, const float* base, uns
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// Observation rows read IN PLACE from the episode-major store (ope_obs_ref, ope.h; "lazy batch"): batch row r = tn * B + b (tn = t * N + n)
+// of the [T+1][N][B][D] batch is store row ep[b] * TTN + tn of the [capacity][T+1][N][D] ring, TTN = (T+1) N. The consumers (trunk_fwd4,
+// wgrad) keep the sampled episode slots ep[0 .. B) in LDS (B <= kObsRefMaxB) and walk the rows EPISODE-major -- 16 (trunk tile) or 4
+// (wgrad fetch) consecutive tn of one b, which are contiguous in the store -- rather than in batch order (16 / 4 different episodes,
+// i.e. as many different pages per access: measured 5 us slower in either kernel at 3s5z).
+constexpr int kObsRefMaxB = 512;
+constexpr int kObsRefMaxRows = 1 << 20;     // div_small is exact below this
+struct ObsRef {
+  const int64_t* inds;   // DEVICE int64[B] sampled episode slots (null: rows come from a gathered batch)
+  int cap, B, TTN;
+};
+// x / d for 0 <= x < 2^20 via a float reciprocal: (x + 0.5) / d is at least 0.5 / d away from an integer and the float error is below
+// (x / d) * 2^-22, so the truncation is exact (ope_store.hip uses the same form; checked exhaustively there for d <= 600).
+__device__ __forceinline__ int div_small(int x, float inv_d) { return (int)(((float)x + 0.5f) * inv_d); }
+__device__ __forceinline__ int obs_ref_slot(const ObsRef& o, int64_t v) {       // out-of-range slots are clamped here; the gather of the other fields raises the flag
+  return v < 0 ? 0 : (v >= o.cap ? o.cap - 1 : (int)v);
+}
+
 // Flat-parameter offsets (floats) of the agent q-network and the QMixer. Order = reference named_parameters()
 // (SURVEY.md Appendix D); every tensor starts on a multiple of 4 floats.
 struct AgentLayout {

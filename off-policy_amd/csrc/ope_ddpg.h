@@ -42,15 +42,30 @@ int launch_build_cin(const float* cent, const float* acts, const float* repl, in
 int launch_action(const float* logits, const float* avail, NoiseSrc U, int rows, int B, int A, int N, int mode, int t_shift,
                   float* cent_nact, float* act_out, float* soft_out, hipStream_t st, int nact_agents = 0, int a_off = 0);
 
+// Optimiser step in the tail of a tile launch (ope_ddpg_opt, ope.h): slab reduction + clip + Adam + Polyak behind two grid barriers.
+struct TileOpt {
+  int on;
+  int n_opt;                       // elements Adam updates (prefix of the flat vector)
+  int skip_begin, skip_end;        // the registered-but-unused fc_h block
+  float* grad;                     // [P + 4] flat gradient + tail (also written by the separate reduction)
+  float* theta; float* tgt; float* m; float* v;
+  float lr, beta1, beta2, eps, max_norm, wd, tau, qden;
+  int do_polyak, step;
+  int* step_counter;               // device [count, ticket] or null
+  int* sync;                       // device int[8] (8-byte aligned), zero at workspace_init: {error flag, -, critic arrivals (64-bit), actor arrivals (64-bit)}
+  float* gsq;                      // [workgroups] partial sums of squares
+  float* stats;                    // [4] or null
+};
 // fused small-network path (ope_ddpg_fused.hip): one launch per network update + one slab reduction
 bool ddpg_fused_ok(int N, int A, int D, int S, int K);
+bool ddpg_tile_opt_ok(int N, int A, int D, int S, int K, int B);    // the optimiser tail needs every workgroup of both launches co-resident
 // workgroups of the slab reduction = half the floats of the "gsq_critic" / "gsq_actor" region ([trunk partials | head partials])
 int ddpg_fused_gsq_blocks(int N, int A, int D, int S, int K, bool critic);
 int64_t ddpg_fused_slab_floats(int N, int A, int D, int S, int K, int B);
 int launch_ddpg_critic_fused(const ope_ddpg_cfg* cfg, const ope_mlp_batch* bt, const float* theta_actor_tgt, const float* theta_critic,
                              const float* theta_critic_tgt, const float* U, const float* per_w, float* slabs, float* grad, float* prio_out,
-                             float* gsq, hipStream_t st);
+                             float* gsq, hipStream_t st, const TileOpt* opt = nullptr);
 int launch_ddpg_actor_fused(const ope_ddpg_cfg* cfg, const ope_mlp_batch* bt, const float* theta_actor, const float* theta_critic,
-                            const float* U, float* slabs, float* grad, float* gsq, hipStream_t st);
+                            const float* U, float* slabs, float* grad, float* gsq, hipStream_t st, const TileOpt* opt = nullptr);
 
 }  // namespace ope

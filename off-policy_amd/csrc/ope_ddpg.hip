@@ -434,7 +434,7 @@ struct DdpgPlan {
   int raw_size_c, raw_size_a;
   int P1, s1, P2, s2, E, sq;    // raw slab offsets (same recipe for actor and critic, sized by the larger)
   int64_t xin_t, xin, a2n, lgn, cnact, a2t, qt, a2c, qc, dq, da2, dz1, dz2, mu0, rstd0, xhat1, rstd1, mask1, xhat2, rstd2, mask2,
-      thetaT, raw, rsum, loss_part, lnz, lno, xin_a, a2a, lga, ysoft, actout, mu1, cvec, dlg, err, fused_slabs, gsq_critic, gsq_actor;
+      thetaT, raw, rsum, loss_part, lnz, lno, xin_a, a2a, lga, ysoft, actout, mu1, cvec, dlg, err, fused_slabs, gsq_critic, gsq_actor, opt_sync;
   bool fused;
 };
 
@@ -492,6 +492,7 @@ static void ddpg_plan(const ope_ddpg_cfg* c, DdpgPlan* p) {
   if (p->fused) {    // per-workgroup sums of squares of the gradient the slab reduction wrote (only the fused path produces them)
     p->gsq_critic = W.add("gsq_critic", 2 * ddpg_fused_gsq_blocks(p->N, p->A, p->D, p->S, p->K, true));
     p->gsq_actor = W.add("gsq_actor", 2 * ddpg_fused_gsq_blocks(p->N, p->A, p->D, p->S, p->K, false));
+    p->opt_sync = W.add("opt_sync", 8);      // grid-barrier state of the optimiser tails (ints; zero between launches)
   }
 }
 
@@ -630,7 +631,65 @@ extern "C" int ope_ddpg_workspace_init(const ope_ddpg_cfg* cfg, void* workspace,
   float* W = (float*)workspace;
   int rc;
   if ((rc = launch_fill(W + p.lnz, p.Ra, 0.f, (hipStream_t)stream))) return rc;
+  if (p.fused && (rc = launch_fill(W + p.opt_sync, 8, 0.f, (hipStream_t)stream))) return rc;
   return launch_fill(W + p.lno, p.Ra, 1.f, (hipStream_t)stream);
+}
+
+// ope_ddpg_opt -> the tile launch's argument block
+static int tile_opt_from(const ope_ddpg_opt* o, float* theta, int* sync, TileOpt* t) {
+  if (!o || !theta || !o->adam_m || !o->adam_v || o->n < 4 || (o->n & 3) || (o->adam.do_polyak && !o->theta_tgt)) return OPE_EINVAL;
+  if (!o->adam.step_counter && o->adam.step < 1) return OPE_EINVAL;
+  memset(t, 0, sizeof(*t));
+  t->n_opt = (int)o->n; t->theta = theta; t->tgt = o->theta_tgt; t->m = o->adam_m; t->v = o->adam_v;
+  t->lr = o->adam.lr; t->beta1 = o->adam.beta1; t->beta2 = o->adam.beta2; t->eps = o->adam.eps; t->max_norm = o->adam.max_grad_norm;
+  t->wd = o->adam.weight_decay; t->tau = o->adam.tau; t->qden = o->adam.qtot_denominator != 0.f ? o->adam.qtot_denominator : 1.f;
+  t->do_polyak = o->adam.do_polyak; t->step = o->adam.step; t->step_counter = o->adam.step_counter; t->sync = sync; t->stats = o->stats_out;
+  return OPE_OK;
+}
+
+extern "C" int ope_ddpg_update_ok(const ope_ddpg_cfg* cfg) {
+  if (!ddpg_cfg_ok(cfg)) return 0;
+  DdpgPlan p;
+  ddpg_plan(cfg, &p);
+  return p.fused && ddpg_tile_opt_ok(p.N, p.A, p.D, p.S, p.K, p.B) ? 1 : 0;
+}
+
+extern "C" int ope_ddpg_critic_update(const ope_ddpg_cfg* cfg, const ope_mlp_batch* bt, const float* theta_actor_tgt, float* theta_critic,
+                                      const float* theta_critic_tgt, const float* target_noise_u, const float* per_weights, void* workspace,
+                                      int64_t workspace_bytes, float* grad, float* prio_out, const ope_ddpg_opt* opt, void* stream) {
+  (void)hipGetLastError();
+  if (!ddpg_cfg_ok(cfg) || !bt || !theta_critic || !theta_critic_tgt || !theta_actor_tgt || !workspace || !grad || cfg->joint_next_acts) return OPE_EINVAL;
+  if (!bt->next_obs || !bt->share_obs || !bt->acts || !bt->rewards || !bt->next_share_obs || !bt->dones_env) return OPE_EINVAL;
+  if (cfg->target_gumbel && !target_noise_u && !cfg->noise_seed) return OPE_EINVAL;
+  if (cfg->use_per && !per_weights) return OPE_EINVAL;
+  DdpgPlan p;
+  ddpg_plan(cfg, &p);
+  if (workspace_bytes < p.ws.total * (int64_t)sizeof(float)) return OPE_ENOSPC;
+  if (!p.fused) return OPE_EINVAL;
+  float* W = (float*)workspace;
+  TileOpt t;
+  int rc = tile_opt_from(opt, theta_critic, reinterpret_cast<int*>(W + p.opt_sync), &t);
+  if (rc) return rc;
+  return launch_ddpg_critic_fused(cfg, bt, theta_actor_tgt, theta_critic, theta_critic_tgt, target_noise_u, per_weights, W + p.fused_slabs,
+                                  grad, prio_out, W + p.gsq_critic, (hipStream_t)stream, &t);
+}
+
+extern "C" int ope_ddpg_actor_update(const ope_ddpg_cfg* cfg, const ope_mlp_batch* bt, float* theta_actor, const float* theta_critic,
+                                     const float* gumbel_noise_u, void* workspace, int64_t workspace_bytes, float* grad,
+                                     const ope_ddpg_opt* opt, void* stream) {
+  (void)hipGetLastError();
+  if (!ddpg_cfg_ok(cfg) || !bt || !theta_actor || !theta_critic || (!gumbel_noise_u && !cfg->noise_seed) || !workspace || !grad) return OPE_EINVAL;
+  if (!bt->obs || !bt->share_obs || !bt->acts || !bt->valid_transition) return OPE_EINVAL;
+  DdpgPlan p;
+  ddpg_plan(cfg, &p);
+  if (workspace_bytes < p.ws.total * (int64_t)sizeof(float)) return OPE_ENOSPC;
+  if (!p.fused) return OPE_EINVAL;
+  float* W = (float*)workspace;
+  TileOpt t;
+  int rc = tile_opt_from(opt, theta_actor, reinterpret_cast<int*>(W + p.opt_sync), &t);
+  if (rc) return rc;
+  return launch_ddpg_actor_fused(cfg, bt, theta_actor, theta_critic, gumbel_noise_u, W + p.fused_slabs, grad, W + p.gsq_actor,
+                                 (hipStream_t)stream, &t);
 }
 
 extern "C" int ope_ddpg_critic_loss_and_grad(const ope_ddpg_cfg* cfg, const ope_mlp_batch* bt, const float* theta_actor_tgt,

@@ -504,6 +504,7 @@ struct TileArgs {
   int tail;                       // slab offset of [loss_sum, count, q_sum, 0]
   float gamma, huber_delta, per_eps;
   long long* dbg;                 // optional: s_memtime stamps of workgroup 0 / thread 0 (tools/ddpg_phases.py)
+  TileOpt opt;                    // optimiser step in the launch's tail (opt.on)
   // LDS offsets (floats)
   int o_xa, o_xna, o_xt, o_xl, o_xnl, o_r1, o_r2, o_r1s, o_a1s, o_r2s, o_r1c, o_r2c, o_dz, o_d1, o_da;
 };
@@ -549,6 +550,145 @@ __device__ __forceinline__ void cin_load(float (&v)[NB], const ope_mlp_batch& bt
 }
 
 // ---- critic update ------------------------------------------------------------------------------------------------------
+// ---- optimiser step in the tail of a tile launch (TileOpt) ----------------------------------------------------------------
+// Grid barrier over the launch's workgroups (all co-resident: at most one per CU, checked on the host). One 64-bit arrivals counter
+// that only ever grows (zero at workspace_init): the ticket a workgroup draws tells it which barrier it is in (ticket / nwg -- every
+// barrier takes exactly nwg arrivals), and it waits until the counter has reached that barrier's end. No reset, no generation word,
+// nothing to reorder.
+// Memory: the eight XCDs' L2s are not coherent with each other. What crosses workgroups here is (a) the gradient slabs, written with
+// plain stores by the tile code: one agent-scope RELEASE fence (L2 write-back) by one wave after the workgroup's s_barrier (whose
+// s_waitcnt has seen every wave's stores acknowledged by the L2) -- and read with agent-scope relaxed atomic loads, which do not hit
+// stale L2 lines; (b) a few floats (partial sums of squares, the tail) published and read with agent-scope relaxed atomics. So the
+// polling loop and the readers need no ACQUIRE fence: an L2 invalidate per poll, by 48 workgroups at once, made the first version of
+// this tail cost 17 - 42 us (measured) instead of saving the two launches.
+// MEASURED (MI355X, config 3, batch 256): with all of that the tail still costs 11 us behind the critic's 16 workgroups and 23 us behind
+// the actor's 48, against 9.3 us for the slab-reduction + adam launches it replaces (step 0.1076 vs 0.0894 ms). Every phase that
+// crosses workgroups is a round trip through memory (~2 - 3 us on this 8-XCD part: arrive, poll, slab reads, partial sums), and there are
+// five of them in a row; a kernel boundary costs less. So the trainer keeps the separate launches by default (MADDPG.update_in_launch,
+// OPE_DDPG_OPT_TAIL=1 to try this form); the path stays tested (tests/test_gpu_ddpg.py).
+// The spin is bounded: a workgroup that never sees the counter advance raises sync[2] and goes on (wrong numbers and a flag the host
+// can read, not a hung GPU).
+__device__ __forceinline__ void grid_barrier(unsigned long long* count, int* err, int nwg, bool release) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (release) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    const unsigned long long ticket = __hip_atomic_fetch_add(count, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long target = (ticket / (unsigned long long)nwg + 1ull) * (unsigned long long)nwg;
+    int spins = 0;
+    while (__hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1 << 22)) { *err = 1; break; }
+    }
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ipow_d(double b, int t) {
+  double r = 1.0;
+  while (t > 0) { if (t & 1) r *= b; b *= b; t >>= 1; }
+  return r;
+}
+// slabs -> flat gradient (the arithmetic of ddpg_tile_reduce_kernel: eight interleaved partial sums, combined pairwise), sum of squares
+// of the optimised elements, clip coefficient, Adam, Polyak: ope_optim.hip's adam_kernel on this workgroup's share of the elements.
+// `kind` 0 / 1 = critic / actor launch (their own barrier counters: the two launches have different workgroup counts).
+__device__ __forceinline__ void tile_opt_tail(const TileOpt& o, const float* __restrict__ slabs, int64_t stride, int P, int kind, float* red) {
+  const int skip_begin = o.skip_begin, skip_end = o.skip_end;
+  const int ns = gridDim.x, nthreads = ns * 256, gt = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long* count = reinterpret_cast<unsigned long long*>(o.sync) + 1 + kind;      // sync: [error flag, -, critic counter, actor counter]
+  grid_barrier(count, o.sync, ns, true);      // every slab is complete and written back
+  const int P4 = (P >> 2) + 1;                // float4 chunks of [gradient | tail]
+  float sq = 0.f;
+  for (int c = gt; c < P4; c += nthreads) {
+    const int e = 4 * c;
+    const bool skip = e >= skip_begin && e < skip_end;
+    f32x4 p[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) p[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 0; s0 < ns; s0 += 8) {
+      f32x4 t[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float* src = slabs + (int64_t)(s0 + q < ns ? s0 + q : 0) * stride + (skip ? 0 : e);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[q][r] = ld_agent(src + r);
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (s0 + q < ns) p[q] += t[q];
+    }
+    f32x4 v = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+    if (skip) v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (e >= P) {
+      v[3] = 0.f;
+      st_agent(o.gsq + ns, v[0]); st_agent(o.gsq + ns + 1, v[1]); st_agent(o.gsq + ns + 2, v[2]);      // the tail, for every workgroup
+    }
+    *reinterpret_cast<f32x4*>(o.grad + e) = v;
+    if (e < o.n_opt) sq += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+  }
+  for (int d = 32; d > 0; d >>= 1) sq += __shfl_xor(sq, d, 64);
+  if (lane == 0) red[wave] = sq;
+  __syncthreads();
+  if (threadIdx.x == 0) st_agent(o.gsq + blockIdx.x, (red[0] + red[1]) + (red[2] + red[3]));
+  grid_barrier(count, o.sync, ns, false);     // the partial sums of squares and the tail are published
+  if (threadIdx.x == 0) {
+    float tot = 0.f;
+    for (int q = 0; q < ns; ++q) tot += ld_agent(o.gsq + q);      // the same order in every workgroup
+    const int t = o.step_counter ? o.step_counter[0] + 1 : o.step;
+    red[4] = (float)((double)o.lr / (1.0 - ipow_d((double)o.beta1, t)));
+    red[5] = (float)(1.0 / sqrt(1.0 - ipow_d((double)o.beta2, t)));
+    reinterpret_cast<int*>(red)[6] = t;
+    red[7] = tot;
+    red[8] = ld_agent(o.gsq + ns); red[9] = ld_agent(o.gsq + ns + 1); red[10] = ld_agent(o.gsq + ns + 2);
+  }
+  __syncthreads();
+  const float lr_t = red[4], inv_sqrt_bc2 = red[5], tot = red[7];
+  const float cnt = red[9], inv = 1.0f / cnt;
+  const float norm = sqrtf(tot) * inv;
+  const float coef = fminf(1.0f, o.max_norm / (norm + 1e-6f));
+  const float scale = coef * inv;
+  if (gt == 0 && o.stats) {
+    o.stats[0] = red[8] * inv; o.stats[1] = norm; o.stats[2] = red[10] / o.qden; o.stats[3] = cnt;
+  }
+  for (int c = gt; 4 * c < o.n_opt; c += nthreads) {
+    const int e = 4 * c;
+    const bool skip = e >= skip_begin && e < skip_end;
+    const f32x4 th4 = *reinterpret_cast<const f32x4*>(o.theta + e);
+    f32x4 out = th4;
+    if (!skip) {
+      const f32x4 g4 = *reinterpret_cast<const f32x4*>(o.grad + e), m4 = *reinterpret_cast<const f32x4*>(o.m + e),
+                  v4 = *reinterpret_cast<const f32x4*>(o.v + e);
+      f32x4 mo, vo;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float gi = g4[q] * scale;
+        if (o.wd != 0.f) gi = fmaf(o.wd, th4[q], gi);
+        mo[q] = o.beta1 * m4[q] + (1.0f - o.beta1) * gi;
+        vo[q] = o.beta2 * v4[q] + (1.0f - o.beta2) * gi * gi;
+        const float den = sqrtf(vo[q]) * inv_sqrt_bc2 + o.eps;
+        out[q] = th4[q] - lr_t * (mo[q] / den);
+      }
+      *reinterpret_cast<f32x4*>(o.m + e) = mo;
+      *reinterpret_cast<f32x4*>(o.v + e) = vo;
+      *reinterpret_cast<f32x4*>(o.theta + e) = out;
+    }
+    if (o.do_polyak) {
+      f32x4 tg4 = *reinterpret_cast<const f32x4*>(o.tgt + e);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) tg4[q] = tg4[q] * (1.0f - o.tau) + out[q] * o.tau;
+      *reinterpret_cast<f32x4*>(o.tgt + e) = tg4;
+    }
+  }
+  // device step counter: the last workgroup to finish publishes t (as adam_kernel does)
+  if (o.step_counter && threadIdx.x == 0) {
+    if (atomicAdd(&o.step_counter[1], 1) == ns - 1) {
+      o.step_counter[1] = 0;
+      o.step_counter[0] = reinterpret_cast<int*>(red)[6];
+    }
+  }
+}
+
 template <int NCA, int NCC>
 __global__ void __launch_bounds__(256, 1) ddpg_critic_tile_kernel(TileArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -687,6 +827,9 @@ __global__ void __launch_bounds__(256, 1) ddpg_critic_tile_kernel(TileArgs a) {
     in_store();
   }
   if (threadIdx.x == 0) { slab[a.tail] = ls; slab[a.tail + 1] = cs; slab[a.tail + 2] = qs; slab[a.tail + 3] = 0.f; }
+  OPE_STAMP(8)
+  if (a.opt.on) tile_opt_tail(a.opt, a.slabs, a.slab_stride, a.tail, 0, lds);
+  OPE_STAMP(9)
 #undef OPE_STAMP
 }
 
@@ -791,6 +934,7 @@ __global__ void __launch_bounds__(256, 1) ddpg_actor_tile_kernel(TileArgs a) {
     in_store();
   }
   if (threadIdx.x == 0) { slab[a.tail] = ls; slab[a.tail + 1] = cs; slab[a.tail + 2] = qs; slab[a.tail + 3] = 0.f; }
+  if (a.opt.on) tile_opt_tail(a.opt, a.slabs, a.slab_stride, a.tail, 1, lds);
 }
 
 // ---- slabs -> flat gradient -----------------------------------------------------------------------------------------------
@@ -901,6 +1045,14 @@ bool ddpg_fused_ok(int N, int A, int D, int S, int K) {
   return (size_t)plan_critic(a, nullptr, nullptr, nullptr) * sizeof(float) <= 160 * 1024;     // many agents: their staged inputs
 }
 
+static int device_cus() {
+  static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256; return n > 1 ? n : 256; }();
+  return cus;
+}
+bool ddpg_tile_opt_ok(int N, int A, int D, int S, int K, int B) {
+  return ddpg_fused_ok(N, A, D, S, K) && B >= 1 && ope_cdiv((int64_t)N * B, kRT) <= device_cus();      // one workgroup per CU: all co-resident
+}
+
 int ddpg_fused_gsq_blocks(int N, int A, int D, int S, int K, bool critic) {
   const int P = critic ? ope_agent_layout_mlp(S + N * A, K, 0).end : ope_agent_layout_mlp(D, A, 0).end;
   return ope_cdiv((int64_t)(P + 4) * 8, 256);
@@ -944,11 +1096,17 @@ static int launch_tile(KERN kern, const TileArgs& a, int blocks, size_t lds, hip
 
 int launch_ddpg_critic_fused(const ope_ddpg_cfg* cfg, const ope_mlp_batch* bt, const float* theta_actor_tgt, const float* theta_critic,
                              const float* theta_critic_tgt, const float* U, const float* per_w, float* slabs, float* grad, float* prio_out,
-                             float* gsq, hipStream_t st) {
+                             float* gsq, hipStream_t st, const TileOpt* opt) {
   const ope_dims& d = cfg->dims;
   TileArgs a;
   fill_dims(a, d.n_agents, d.act_dim, d.obs_dim, d.state_dim, cfg->num_q, cfg->batch);
   const int lds = plan_critic(a, theta_actor_tgt, theta_critic_tgt, theta_critic);
+  if (opt) {
+    if (!ddpg_tile_opt_ok(a.N, a.A, a.D, a.S, a.K, a.B)) return OPE_EINVAL;
+    const AgentLayout L = ope_agent_layout_mlp(a.Din, a.K, 0);
+    a.opt = *opt; a.opt.on = 1; a.opt.grad = grad; a.opt.gsq = gsq; a.opt.skip_begin = L.fch_w; a.opt.skip_end = L.fc2_w;
+    if (a.opt.n_opt < 4 || a.opt.n_opt > L.end || (a.opt.n_opt & 3)) return OPE_EINVAL;
+  }
   a.bt = *bt; a.noisy = cfg->target_gumbel; a.noise = NoiseSrc{U, cfg->noise_seed, cfg->noise_counter, 0};
   a.per_w = cfg->use_per ? per_w : nullptr; a.prio_out = prio_out; a.slabs = slabs;
   a.use_huber = cfg->use_huber; a.gamma = cfg->gamma; a.huber_delta = cfg->huber_delta; a.per_eps = cfg->per_eps;
@@ -963,16 +1121,22 @@ int launch_ddpg_critic_fused(const ope_ddpg_cfg* cfg, const ope_mlp_batch* bt, c
     kprof_work(2.0 * ((double)a.N * a.B * am + 2.0 * a.B * cm + a.B * (cm + OPE_H * OPE_H + (double)OPE_H * a.K)));
   }
   const int rc = OPE_TILE_DISPATCH(ddpg_critic_tile_kernel, a.n0.nc0, a.n1.nc0, a, blocks, (size_t)lds * sizeof(float), st);
-  if (rc) return rc;
+  if (rc || opt) return rc;
   return launch_reduce(slabs, blocks, a.slab_stride, ope_agent_layout_mlp(a.Din, a.K, 0), grad, gsq, st);
 }
 
 int launch_ddpg_actor_fused(const ope_ddpg_cfg* cfg, const ope_mlp_batch* bt, const float* theta_actor, const float* theta_critic,
-                            const float* U, float* slabs, float* grad, float* gsq, hipStream_t st) {
+                            const float* U, float* slabs, float* grad, float* gsq, hipStream_t st, const TileOpt* opt) {
   const ope_dims& d = cfg->dims;
   TileArgs a;
   fill_dims(a, d.n_agents, d.act_dim, d.obs_dim, d.state_dim, cfg->num_q, cfg->batch);
   const int lds = plan_actor(a, theta_actor, theta_critic);
+  if (opt) {
+    if (!ddpg_tile_opt_ok(a.N, a.A, a.D, a.S, a.K, a.B)) return OPE_EINVAL;
+    const AgentLayout L = ope_agent_layout_mlp(a.D, a.A, 0);
+    a.opt = *opt; a.opt.on = 1; a.opt.grad = grad; a.opt.gsq = gsq; a.opt.skip_begin = L.fch_w; a.opt.skip_end = L.fc2_w;
+    if (a.opt.n_opt < 4 || a.opt.n_opt > L.end || (a.opt.n_opt & 3)) return OPE_EINVAL;
+  }
   a.bt = *bt; a.noisy = 1; a.noise = NoiseSrc{U, cfg->noise_seed, cfg->noise_counter, 1}; a.slabs = slabs;
   a.tiles = ope_cdiv((int64_t)a.N * a.B, kRT);
   a.slab_stride = slab_len(a.D, a.A, a.Din, a.K);
@@ -983,7 +1147,7 @@ int launch_ddpg_actor_fused(const ope_ddpg_cfg* cfg, const ope_mlp_batch* bt, co
     kprof_work(2.0 * (double)a.N * a.B * (am + cm + ((double)OPE_H * a.K + OPE_H * OPE_H + (double)OPE_H * a.A) + am + ((double)a.A * OPE_H + OPE_H * OPE_H)));
   }
   const int rc = OPE_TILE_DISPATCH(ddpg_actor_tile_kernel, a.n0.nc0, a.n1.nc0, a, blocks, (size_t)lds * sizeof(float), st);
-  if (rc) return rc;
+  if (rc || opt) return rc;
   return launch_reduce(slabs, blocks, a.slab_stride, ope_agent_layout_mlp(a.D, a.A, 0), grad, gsq, st);
 }
 

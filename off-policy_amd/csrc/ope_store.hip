@@ -80,6 +80,7 @@ struct CopyArgs {
   int nt;
   int* bad_index;    // device flag: set to 1 if an index was out of range (the offending rows are skipped)
   int lds_bytes;     // dynamic LDS the tile fields need
+  int64_t* idx_out;  // gather, optional: the episode indices as used, for consumers that read rows of the store themselves (ope_obs_ref)
 };
 
 // Where the episode indices come from: device memory (device-resident index tensors: prioritized sampling on the device,
@@ -329,6 +330,8 @@ __global__ void __launch_bounds__(kBlock) episode_copy_kernel(CopyArgs args, IDX
   // ONE XCD (the G blocks of a run are dispatched 8 apart, i.e. close in time), runs interleaved over the XCDs so that
   // every XCD still sees every field.
   int bid = blockIdx.x;
+  if (GATHER && args.idx_out && bid == 0)
+    for (int i = threadIdx.x; i < args.n_episodes; i += kBlock) args.idx_out[i] = idx[i];
   const int G = args.xcd_swizzle;     // gather: B (runs of B consecutive logical workgroups on one XCD); insert: the knob
   if (G > 1 && bid < (args.total_blocks / (8 * G)) * (8 * G)) {
     const int super = bid / (8 * G), w = bid - super * (8 * G);
@@ -382,7 +385,7 @@ void launch_copy(const CopyArgs& args, const IDX& idx, hipStream_t st) {
   if (g_kprof_on) {     // every byte of the E episodes once in, once out
     double b = 0;
     for (int q = 0; q < kFields; ++q)
-      if (args.f[q].src) b += 4.0 * args.f[q].TT * (double)args.f[q].NA * args.f[q].DD;
+      if (args.f[q].src && args.f[q].dst) b += 4.0 * args.f[q].TT * (double)args.f[q].NA * args.f[q].DD;
     kprof_work(0.0, 2.0 * b * args.n_episodes);
   }
   // one instantiation per variant: a single kernel holding all of them would be allocated the registers of the largest
@@ -493,6 +496,7 @@ int build_args(const ope_dims* d, const ope_fields* src, const ope_fields* dst, 
   out->unroll = g_tune.unroll;
   out->nt = g_tune.nt;
   out->bad_index = nullptr;
+  out->idx_out = nullptr;
   out->lds_bytes = (lds_bytes + 15) & ~15;
   return OPE_OK;
 }
@@ -675,6 +679,36 @@ extern "C" int ope_store_gather_tuned(const ope_dims* dims, int32_t capacity, co
     int rc = build_args(dims, store, out, batch, capacity, true, &args, tune);
     if (rc != OPE_OK) return rc;
     args.bad_index = bad_index_flag;
+    launch_copy<true>(args, DevIdx{inds_dev}, (hipStream_t)stream);
+  }
+  OPE_CHECK_LAUNCH();
+  return OPE_OK;
+}
+
+extern "C" int ope_store_gather_ref(const ope_dims* dims, int32_t capacity, const ope_fields* store, const int64_t* inds_dev,
+                                    const int64_t* inds_host, int32_t batch, const ope_fields* out, int64_t* inds_out, int32_t* bad_index_flag,
+                                    const ope_gather_tune* tune, void* stream) {
+  (void)hipGetLastError();
+  if (capacity < 1 || batch < 1 || (!inds_dev) == (!inds_host) || !inds_out) return OPE_EINVAL;
+  CopyArgs args;
+  if (inds_host) {
+    if (batch > kMaxArgIdx) return OPE_EINVAL;
+    ArgIdx ai;
+    for (int i = 0; i < batch; ++i) {
+      if (inds_host[i] < 0 || inds_host[i] >= capacity) return OPE_EINVAL;
+      ai.v[i] = (int32_t)inds_host[i];
+    }
+    int rc = build_args(dims, store, out, batch, capacity, true, &args, tune);
+    if (rc != OPE_OK) return rc;
+    if (args.total_blocks < 1) return OPE_EINVAL;      // (nothing to copy at all: the caller wants at least one field)
+    args.idx_out = inds_out;
+    launch_copy<true>(args, ai, (hipStream_t)stream);
+  } else {
+    int rc = build_args(dims, store, out, batch, capacity, true, &args, tune);
+    if (rc != OPE_OK) return rc;
+    if (args.total_blocks < 1) return OPE_EINVAL;
+    args.bad_index = bad_index_flag;
+    args.idx_out = inds_out == inds_dev ? nullptr : inds_out;
     launch_copy<true>(args, DevIdx{inds_dev}, (hipStream_t)stream);
   }
   OPE_CHECK_LAUNCH();

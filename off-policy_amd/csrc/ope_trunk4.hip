@@ -42,6 +42,7 @@ struct T4 {
   static constexpr int LNP = 6 * OPE_H;               // b1, ln1 w, ln1 b, b2, ln2 w, ln2 b
   static constexpr int BIH = 3 * OPE_H;
   static constexpr int TOTAL = W1F + W2F + W3F + FNP + LNP + BIH + 16;
+  static constexpr int TOTAL_REF = TOTAL + kObsRefMaxB;        // + the sampled episode slots (rows read from the store)
 };
 
 }  // namespace
@@ -55,18 +56,21 @@ struct TrunkPairArgs {
   int fn_w, fn_b, fc1_w, fc1_b, ln1_w, ln1_b, fc2_w, fc2_b, ln2_w, ln2_b, wih, bih;
   float* mu0; float* rstd0; float* xhat1; float* rstd1; float* mu1; uint64_t* mask1; float* xhat2; float* rstd2; uint64_t* mask2;
   long long* dbg;
+  ObsRef ref; int ref_tn0;        // LAZY instantiation: x = the store's obs ring; first (t, agent) index of the launch's row range
 };
 
 // KCM = ceil(D / 16) exactly and D % 4 == 0: every 16-column chunk but the last is complete, and a 16-byte piece of the last one is inside
 // the row or entirely past it -- one per-lane predicate instead of 4 KCM hoisted column masks (which cost ~130 spilled SGPRs + 46 VGPRs)
 // NW = waves per workgroup (8 or 12: two or three per SIMD), PF = request the next tile's rows behind fc1 (keeps the 4 KCM row
 // registers live through the whole tile: 248 VGPRs, two waves per SIMD) or at the top of the tile (<= 168 VGPRs, three per SIMD).
-template <int KCM, int NW, bool PF>
+// LAZY: the observation rows are read in place from the episode-major store (ObsRef, ope_common.h) instead of a gathered batch: the same
+// 16 KCM-byte rows, at (per-lane 64-bit row pointer) + (immediate) instead of (uniform base) + (32-bit offset).
+template <int KCM, int NW, bool PF, bool LAZY>
 __global__ void __launch_bounds__(64 * NW, NW / 4) trunk_fwd4_kernel(TrunkPairArgs pa) {
   using C = T4<KCM>;
   constexpr int VEC = 4;
   constexpr int NT = 64 * NW;
-  __shared__ __attribute__((aligned(16))) float sm[C::TOTAL];
+  __shared__ __attribute__((aligned(16))) float sm[LAZY ? C::TOTAL_REF : C::TOTAL];
   float* const W1s = sm;
   float* const W2s = W1s + C::W1F;
   float* const W3s = W2s + C::W2F;
@@ -74,6 +78,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) trunk_fwd4_kernel(TrunkPairAr
   float* const lnp = fnp + C::FNP;
   float* const bih = lnp + C::LNP;
   int* const ctr = reinterpret_cast<int*>(bih + C::BIH);
+  int* const eps = ctr + 16;      // LAZY: episode slot of batch column b
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -93,7 +98,23 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) trunk_fwd4_kernel(TrunkPairAr
   auto stamp = [&](int k) { if (dbg && lane == 0) dbg[k] = __builtin_amdgcn_s_memtime(); };
   stamp(0);
   // ---- tiles: the two waves of a SIMD (waves w and w + 4) draw from counter w & 3 ----
-  const int ntiles = (R + 15) >> 4;
+  // LAZY: a tile = 16 consecutive (t, agent) rows of ONE sampled episode b (contiguous in the store: one 16 x 4 D-byte run, one page)
+  // instead of 16 consecutive batch rows (16 episodes); tile = b * tpe + q covers tn = 16 q .. 16 q + 15 of the launch's TNc = R / B
+  const int TNc = LAZY ? R / a.ref.B : 0, tpe = LAZY ? (TNc + 15) >> 4 : 1;
+  const int ntiles = LAZY ? a.ref.B * tpe : (R + 15) >> 4;
+  auto rows_of = [&](int tile, int& row, bool& valid, int& b, int& tnj) {
+    if (LAZY) {
+      b = tile / tpe;
+      tnj = 16 * (tile - b * tpe) + j;
+      valid = tnj < TNc;
+      tnj = valid ? tnj : TNc - 1;
+      row = tnj * a.ref.B + b;
+    } else {
+      row = tile * 16 + j;
+      valid = row < R;
+      b = 0; tnj = 0;
+    }
+  };
   const int nslots = 4 * nwg, slot0 = 4 * wgn + (wave & 3);
   auto grab = [&]() -> int {
     int k = 0;
@@ -109,8 +130,21 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) trunk_fwd4_kernel(TrunkPairAr
   // largest), and 64-bit per-lane addresses cost twice the registers -- the first version spilled five of them, and a scratch
   // reload is a VMEM load: its vmcnt wait also waits for the 16 row loads just requested for the NEXT tile (13 k cycles per tile).
   const char* __restrict__ xb = reinterpret_cast<const char*>(a.x);
-  auto request = [&](int tile) {
+  auto request = [&](int tile, bool staged = true) {
     const int row = tile * 16 + j;
+    if (LAZY) {
+      int rw, b, tnj;
+      bool ok;
+      rows_of(tile, rw, ok, b, tnj);
+      const int ep = staged ? eps[b] : obs_ref_slot(a.ref, a.ref.inds[b]);       // (the first tile is requested before the slots are staged)
+      const char* rp = xb + (((int64_t)ep * a.ref.TTN + (a.ref_tn0 + tnj)) * (int64_t)(4 * D) + 16 * g);
+      int gg = g;
+      asm volatile("" : "+v"(gg));
+      xv[KCM - 1] = *reinterpret_cast<const f32x4*>(rp + (16 * (KCM - 1) + 4 * gg < D ? 64 * (KCM - 1) : 0));
+#pragma unroll
+      for (int c = 0; c < KCM - 1; ++c) xv[c] = *reinterpret_cast<const f32x4*>(rp + 64 * c);
+      return;
+    }
     const uint32_t xo = (uint32_t)(row < R ? row : R - 1) * (uint32_t)(4 * D) + 16u * g;
     // the last chunk's piece first, its offset recomputed here (a hoisted copy got spilled, and the reload's vmcnt wait sat in the
     // middle of this burst of loads)
@@ -127,7 +161,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) trunk_fwd4_kernel(TrunkPairAr
     const int64_t t = (int64_t)slot0 + (int64_t)nslots * (wave >> 2);
     tile = t < ntiles ? (int)t : ntiles;
   }
-  if (PF && tile < ntiles) request(tile);
+  if (PF && tile < ntiles) request(tile, false);
   // ---- prologue: this net's weights -> LDS (swizzled), parameters, tile counters. Every thread requests ALL its pieces before the
   // first LDS store (8 KCM / 16 + 2 + 6 independent 16-byte loads in flight per thread instead of one round trip per piece) ----
   {
@@ -171,6 +205,8 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) trunk_fwd4_kernel(TrunkPairAr
   }
   if (tid < 3 * OPE_H) bih[tid] = th[a.bih + tid];
   if (tid < 4) ctr[tid] = NW / 4;        // every wave's first tile is assigned statically (below): the counters start behind them
+  if (LAZY)
+    for (int i = tid; i < a.ref.B; i += NT) eps[i] = obs_ref_slot(a.ref, a.ref.inds[i]);
 
   __syncthreads();                       // weights, parameters and counters are in place
 
@@ -241,8 +277,9 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) trunk_fwd4_kernel(TrunkPairAr
     // LDS is read-only after the prologue, so LLVM hoists every parameter fragment read (biases, LayerNorm gamma / beta, b_ih: ~270
     // registers' worth) out of the tile loop as loop invariants and then spills them; the clobber makes them per-tile reads again
     asm volatile("" ::: "memory");
-    const int row = tile * 16 + j;
-    const bool valid = row < R;
+    int row, b_, tnj_;
+    bool valid;
+    rows_of(tile, row, valid, b_, tnj_);
     if (!PF) request(tile);
     // ---- input LayerNorm statistics of row j: 4 lanes x KCM pieces ----
     float s = 0.f;
@@ -384,6 +421,9 @@ int launch_trunk_fwd_pair(const TrunkFwdArgs& live, const TrunkFwdArgs& tgt, int
                    live.D % 4 == 0 && (KC == 4 || KC == 8 || KC == 12 || KC == 16) && live.xhat1 && live.mu0 && live.rstd0 && live.rstd1 && live.mask1 && live.xhat2 && live.rstd2 && live.mask2;
   if (path == 4 && !can) return OPE_EINVAL;      // an explicit request the shape does not allow: no silent fall-back (tests pin kernels by path)
   const bool ok = can && (path == 4 || (path == 0 && on && live.R >= 16 * 1024));
+  const bool lazy = live.ref.inds != nullptr;
+  if (lazy && (!ok || live.ref.B < 1 || live.ref.B > kObsRefMaxB || live.R % live.ref.B != 0 || live.ref_row0 % live.ref.B != 0 || live.ref.cap < 1))
+    return OPE_EINVAL;                           // only this kernel reads rows from the store (ope_qmix_obs_ref_ok tells the caller beforehand)
   if (!ok) {
     int rc = launch_trunk_fwd(live, true, st);
     if (rc) return rc;
@@ -398,17 +438,25 @@ int launch_trunk_fwd_pair(const TrunkFwdArgs& live, const TrunkFwdArgs& tgt, int
   pa.mu0 = live.mu0; pa.rstd0 = live.rstd0; pa.xhat1 = live.xhat1; pa.rstd1 = live.rstd1; pa.mu1 = live.mu1; pa.mask1 = live.mask1;
   pa.xhat2 = live.xhat2; pa.rstd2 = live.rstd2; pa.mask2 = live.mask2;      // the target net saves nothing
   pa.dbg = live.dbg;
+  pa.ref = live.ref; pa.ref_tn0 = lazy ? live.ref_row0 / live.ref.B : 0;
   static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256; return n > 1 ? n : 256; }();
   const int grid = cus & ~1;     // one workgroup per CU, even ones the live net, odd ones the target
   // Eight waves (two per SIMD, rows prefetched behind fc1). Measured against twelve waves without the prefetch (three per SIMD at the 168
   // register cap, 78 of them spilled): 59.5 us vs 107 us at 3s5z batch 32, so only this variant is built.
   kprof_work(2.0 * 2.0 * live.R * ((double)live.D * OPE_H + OPE_H * OPE_H + 3.0 * OPE_H * OPE_H));     // both nets
-  if (KC == 4) OPE_LAUNCH((trunk_fwd4_kernel<4, 8, true>), dim3(grid), dim3(512), 0, st, pa);
-  else if (KC == 8) OPE_LAUNCH((trunk_fwd4_kernel<8, 8, true>), dim3(grid), dim3(512), 0, st, pa);
-  else if (KC == 12) OPE_LAUNCH((trunk_fwd4_kernel<12, 8, true>), dim3(grid), dim3(512), 0, st, pa);
-  else OPE_LAUNCH((trunk_fwd4_kernel<16, 8, true>), dim3(grid), dim3(512), 0, st, pa);
+  if (lazy) {
+    if (KC == 4) OPE_LAUNCH((trunk_fwd4_kernel<4, 8, true, true>), dim3(grid), dim3(512), 0, st, pa);
+    else if (KC == 8) OPE_LAUNCH((trunk_fwd4_kernel<8, 8, true, true>), dim3(grid), dim3(512), 0, st, pa);
+    else if (KC == 12) OPE_LAUNCH((trunk_fwd4_kernel<12, 8, true, true>), dim3(grid), dim3(512), 0, st, pa);
+    else OPE_LAUNCH((trunk_fwd4_kernel<16, 8, true, true>), dim3(grid), dim3(512), 0, st, pa);
+  } else {
+    if (KC == 4) OPE_LAUNCH((trunk_fwd4_kernel<4, 8, true, false>), dim3(grid), dim3(512), 0, st, pa);
+    else if (KC == 8) OPE_LAUNCH((trunk_fwd4_kernel<8, 8, true, false>), dim3(grid), dim3(512), 0, st, pa);
+    else if (KC == 12) OPE_LAUNCH((trunk_fwd4_kernel<12, 8, true, false>), dim3(grid), dim3(512), 0, st, pa);
+    else OPE_LAUNCH((trunk_fwd4_kernel<16, 8, true, false>), dim3(grid), dim3(512), 0, st, pa);
+  }
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
-  note_launch("trunk_fwd4", KC);
+  note_launch(lazy ? "trunk_fwd4_store" : "trunk_fwd4", KC);
   return OPE_OK;
 }
 

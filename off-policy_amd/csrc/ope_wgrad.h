@@ -15,11 +15,13 @@ struct WgProb {
   int nsplit;                          // K-splits of this problem
   int64_t raw_base; int64_t raw_stride;  // split q writes to raw[raw_base + q*raw_stride + ...]
   int mt, nt, kchunk, wave_begin;      // filled by wg_finish
+  int ref_row1;                        // > 0: B is the store's obs ring and reduction row k is batch row ref_row1 - 1 + k (WgTable.ref); 0: plain
 };
 constexpr int kMaxWgProbs = 16;
 struct WgTable {
   WgProb p[kMaxWgProbs];
   int n, total_waves, wg_reduce;
+  ObsRef ref;                          // where the problems with ref_row1 > 0 find their B rows (observations left in the store)
 };
 int wg_finish(WgTable* tb);
 int launch_wgrad(const WgTable& tb, float* raw, hipStream_t st);

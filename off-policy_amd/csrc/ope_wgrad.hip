@@ -20,9 +20,20 @@ namespace ope {
 // the four consecutive outputs C[m0+16g+4r+mi][n0+4i .. +3]: float4 stores.
 // VEC = 4: every problem's lda / ldb is a multiple of 4 (rows 16-byte aligned, one 16-byte load per operand per step);
 // VEC = 2: multiples of 2 (two 8-byte loads); VEC = 1: four scalar loads.
-template <int VEC>
+// LAZY (VEC = 4 only): problems with ref_row1 > 0 read their B rows (observations) in place from the episode-major store: reduction row
+// k = batch row tn * B + b is store row ep[b] * TTN + tn, same rows in the same order as the gathered launch (bit-identical sums). The
+// sampled episode slots sit in LDS; the decode is branch-free (a select between the plain and the decoded row index), so the other
+// problems of the launch only pay ~10 VALU instructions per fetch. (Walking K episode-major instead -- four contiguous rows of one
+// episode per fetch -- was measured: no faster, 65.8 vs 64.3 us at 3s5z; what the row-reading launch loses against the gathered one,
+// 58.6 us, is where the rows come from: the gather's freshly written batch sits in the 256 MB Infinity Cache, the store's rows do not.)
+template <int VEC, bool LAZY>
 __global__ void __launch_bounds__(256, 3) wgrad_kernel(WgTable tb, float* __restrict__ raw) {
   __shared__ __attribute__((aligned(16))) float red[2][17][64][4];   // two partial-tile slots: [quad][lane][4]
+  __shared__ int eps[LAZY ? kObsRefMaxB : 1];
+  if (LAZY) {
+    for (int q = threadIdx.x; q < tb.ref.B; q += 256) eps[q] = obs_ref_slot(tb.ref, tb.ref.inds[q]);
+    __syncthreads();
+  }
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: the problem / tile / split indices derived from it live in SGPRs
   const int i = lane & 15, g = lane >> 4;
@@ -64,13 +75,22 @@ __global__ void __launch_bounds__(256, 3) wgrad_kernel(WgTable tb, float* __rest
   const float* __restrict__ Bp = P.B;
   const float* __restrict__ mup = P.ln_mu;     // never null: plain problems point at a zeros / ones vector
   const float* __restrict__ rsp = P.ln_rstd;
+  const bool ref_on = LAZY && P.ref_row1 > 0;
+  const float inv_b = 1.0f / (float)(LAZY ? tb.ref.B : 1);
+  const int ref_tn0 = ref_on ? (P.ref_row1 - 1) / tb.ref.B : 0;      // (the problem's row range starts on a whole time step)
 
   struct Rawv { f32x4 a, b; float mu, rs; };
   auto fetch = [&](int kb, Rawv& r) {
     const int kc = min(kb + g, Kmax);
     const int kr = max(kc - shift, 0);
+    int64_t brow = kr;
+    if (LAZY) {
+      const int tn = div_small(kr, inv_b), b = kr - tn * tb.ref.B;
+      const int64_t sr = (int64_t)eps[b] * tb.ref.TTN + (ref_tn0 + tn);
+      brow = ref_on ? sr : brow;
+    }
     const float* ar = Ap + (int64_t)kc * lda;
-    const float* br = Bp + (int64_t)kr * ldb;
+    const float* br = Bp + brow * ldb;
     if (VEC == 4) {
       r.a = *reinterpret_cast<const f32x4*>(ar + moff);
       r.b = *reinterpret_cast<const f32x4*>(br + noff);
@@ -209,6 +229,9 @@ int wg_finish(WgTable* tb) {
     P.kchunk = 4 * ope_cdiv(ope_cdiv(P.K, P.nsplit), 4);
     P.wave_begin = waves;
     waves += P.mt * P.nt * P.nsplit;
+    if (P.ref_row1 > 0 && (!tb->ref.inds || tb->ref.B < 1 || tb->ref.B > kObsRefMaxB || P.K > kObsRefMaxRows || P.K % tb->ref.B != 0 ||
+                           (P.ref_row1 - 1) % tb->ref.B != 0 || P.b_shift != 0))
+      return OPE_EINVAL;
   }
   tb->total_waves = waves;
   tb->wg_reduce = 1;
@@ -234,14 +257,19 @@ int launch_wgrad(const WgTable& tb, float* raw, hipStream_t st) {
     for (int q = 0; q < tb.n; ++q) fl += 2.0 * tb.p[q].M * (double)tb.p[q].N * tb.p[q].K;
     kprof_work(fl);
   }
-  if (vec == 4)
-    OPE_LAUNCH(wgrad_kernel<4>, dim3(ope_cdiv(tb.total_waves, 4)), dim3(256), 0, st, tb, raw);
+  bool lazy = false;
+  for (int q = 0; q < tb.n; ++q) lazy = lazy || tb.p[q].ref_row1 > 0;
+  if (lazy && vec != 4) return OPE_EINVAL;       // rows in the store are read as 16-byte pieces (ope_qmix_obs_ref_ok tells the caller beforehand)
+  if (lazy)
+    OPE_LAUNCH((wgrad_kernel<4, true>), dim3(ope_cdiv(tb.total_waves, 4)), dim3(256), 0, st, tb, raw);
+  else if (vec == 4)
+    OPE_LAUNCH((wgrad_kernel<4, false>), dim3(ope_cdiv(tb.total_waves, 4)), dim3(256), 0, st, tb, raw);
   else if (vec == 2)
-    OPE_LAUNCH(wgrad_kernel<2>, dim3(ope_cdiv(tb.total_waves, 4)), dim3(256), 0, st, tb, raw);
+    OPE_LAUNCH((wgrad_kernel<2, false>), dim3(ope_cdiv(tb.total_waves, 4)), dim3(256), 0, st, tb, raw);
   else
-    OPE_LAUNCH(wgrad_kernel<1>, dim3(ope_cdiv(tb.total_waves, 4)), dim3(256), 0, st, tb, raw);
+    OPE_LAUNCH((wgrad_kernel<1, false>), dim3(ope_cdiv(tb.total_waves, 4)), dim3(256), 0, st, tb, raw);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
-  note_launch("wgrad", vec);
+  note_launch(lazy ? "wgrad_store" : "wgrad", vec);
   return OPE_OK;
 }
 

@@ -45,6 +45,67 @@ def _shape_of(space):
     raise NotImplementedError
 
 
+class StoreObs(object):
+    """The `obs` entry of a sampled batch whose rows were LEFT IN THE STORE (RecPolicyBuffer.lazy_obs; SURVEY.md section 8(d): "fused into
+    the first consumer, written = 0"). The reference's sample_inds copies every field (rec_buffer.py:206-238) and the trainer reads obs
+    back (qmix.py:108-109); the largest field by far (3s5z: 39 of 48 MB per batch) is read by exactly two kernels of the step, which can
+    fetch the 4 * D-byte rows through the episode index instead. A trainer that can (QMix with ope_qmix_obs_ref_ok) takes this object
+    as is; anything else calls `materialize()` -- or just uses it as an array / tensor (`shape`, `__array__`, `to`, `cpu`, indexing all
+    materialize) -- and gets what sample_inds would have returned, [N, T+1, B, D]. Valid until the next insert() into the buffer: the
+    rows are read at training time, so a later ring write would change the batch (checked: StaleBatchError)."""
+
+    def __init__(self, buf, inds_dev, batch):
+        self._buf, self.inds, self.batch = buf, inds_dev, int(batch)
+        self._gen = buf._insert_gen
+        self._dense = None
+        d = buf.dims
+        self.shape = (d.n_agents, d.episode_length + 1, self.batch, d.obs_dim)
+        self.dtype, self.device = torch.float32, buf.device
+
+    def check_fresh(self):
+        if self._gen != self._buf._insert_gen:
+            raise StaleBatchError("this batch left its observations in the replay store, and the store has been written since it was "
+                                  "sampled: materialize() a batch you keep across insert(), or sample with lazy_obs off")
+
+    def ref(self):
+        """ope_obs_ref of the rows (the caller keeps this object alive until the step has run)."""
+        self.check_fresh()
+        r = _lib.ObsRef()
+        r.store_obs, r.inds, r.capacity = _lib.ptr(self._buf.obs).value, _lib.ptr(self.inds).value, self._buf.buffer_size
+        return r
+
+    def materialize(self):
+        """The gathered tensor, as sample_inds returns it with lazy_obs off ([N, T+1, B, D] view of a [T+1, N, B, D] batch)."""
+        if self._dense is None:
+            self.check_fresh()
+            b, d = self._buf, self._buf.dims
+            out = torch.empty((d.episode_length + 1, d.n_agents, self.batch, d.obs_dim), dtype=torch.float32, device=b.device)
+            _lib.check(_lib.lib.ope_store_gather(C.byref(d), b.buffer_size, C.byref(b._obs_slot(b.obs)), _lib.ptr(self.inds), self.batch,
+                                                 C.byref(b._obs_slot(out)), _lib.ptr(b._bad_index), _lib.current_stream()), "ope_store_gather(obs)")
+            self._dense = out.permute(1, 0, 2, 3)
+        return self._dense
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.materialize().cpu().numpy()
+        return a if dtype is None else a.astype(dtype)
+
+    def __getitem__(self, k):
+        return self.materialize()[k]
+
+    def __len__(self):
+        return self.shape[0]
+
+    def to(self, *a, **k):
+        return self.materialize().to(*a, **k)
+
+    def cpu(self):
+        return self.materialize().cpu()
+
+
+class StaleBatchError(RuntimeError):
+    pass
+
+
 class RecPolicyBuffer(object):
     def __init__(self, buffer_size, episode_length, num_agents, obs_space, share_obs_space, act_space,
                  use_same_share_obs, use_avail_acts, use_reward_normalization=False, device=None, _reward_mask=True):
@@ -58,6 +119,8 @@ class RecPolicyBuffer(object):
         self.device = torch.empty(0, device=torch.device(device if device is not None else "cuda:0")).device
         self._bad_index = torch.zeros(1, dtype=torch.int32, device=self.device)   # set by the kernels on an out-of-range index
         self.gather_tune = None     # this store's gather knobs: dict of ope_gather_tune fields (include/ope.h); None = the process defaults
+        self.lazy_obs = False       # True: sample_inds leaves the observation rows in the store (returns a StoreObs for `obs`)
+        self._insert_gen = 0        # ring writes so far (a StoreObs is valid for the count it was sampled at)
         self._reward_mask = bool(_reward_mask)      # episodes: skip steps after the episode end; transitions: plain mean/std
         self._stats_dirty = True
         self._ring = RingIndex(self.buffer_size)
@@ -187,6 +250,7 @@ class RecPolicyBuffer(object):
                                                  _lib.current_stream()), "ope_store_insert(share_obs)")
         self._keepalive = (staged, slots)   # until the stream has consumed them
         self._stats_dirty = True
+        self._insert_gen += 1
         if getattr(self, "_filled_dev", None) is not None:
             self._filled_device()            # captured device-sampling graphs see the new slots from their next replay on
         return idx_range
@@ -199,12 +263,13 @@ class RecPolicyBuffer(object):
             self._bad_index.zero_()
             raise IndexError("an episode index passed to sample_inds()/insert() was outside [0, %d)" % self.buffer_size)
 
-    def alloc_batch(self, batch_size):
-        """Destination tensors of one gather of `batch_size` episodes, in the kernels' [T(+1), N, B, dim] layout."""
+    def alloc_batch(self, batch_size, obs=True):
+        """Destination tensors of one gather of `batch_size` episodes, in the kernels' [T(+1), N, B, dim] layout (`obs=False`: without
+        the observation tensor -- lazy_obs)."""
         d, B = self.dims, int(batch_size)
         T, N = d.episode_length, d.n_agents
         e = dict(dtype=torch.float32, device=self.device)
-        out = dict(obs=torch.empty((T + 1, N, B, d.obs_dim), **e),
+        out = dict(obs=torch.empty((T + 1, N, B, d.obs_dim), **e) if obs else None,
                    share_obs=torch.empty((T + 1, B, d.state_dim) if self.use_same_share_obs else (T + 1, N, B, d.state_dim), **e),
                    acts=torch.empty((T, N, B, d.act_dim), **e), rewards=torch.empty((T, N, B, 1), **e),
                    dones=torch.empty((T, N, B, 1), **e), dones_env=torch.empty((T, B, 1), **e))
@@ -233,13 +298,15 @@ class RecPolicyBuffer(object):
             t.fill_(self._filled_dev_value)
         return t
 
-    def sample_inds(self, sample_inds, timing_events=None, out=None, extra=None, _sampler=None):
+    def sample_inds(self, sample_inds, timing_events=None, out=None, extra=None, _sampler=None, lazy_obs=None):
         """Gather the given episode slots; same 7-tuple as rec_buffer.py:192-240 (CUDA tensors, reference shapes).
         `timing_events`: optional (start, end) torch.cuda.Event pair recorded tightly around the gather launch.
         `out`: optional destination from `alloc_batch` (HIP-graph replays read the batch from fixed addresses); the
         default is a fresh batch per call, like the reference's fancy-index copy.
         `extra`: optional (store, out) pair of [cap, T, N, 1] / [T, N, B, 1] tensors copied by the same launch (the transition
-        buffers' valid_transition flag)."""
+        buffers' valid_transition flag).
+        `lazy_obs` (default: self.lazy_obs): leave the observation rows in the store and return a StoreObs in their place."""
+        lazy = bool(self.lazy_obs if lazy_obs is None else lazy_obs)
         host_inds = None
         if torch.is_tensor(sample_inds):     # indices already on the device (HIP-graph replays keep them in a static tensor)
             assert sample_inds.dtype == torch.int64 and sample_inds.device == self.device, (sample_inds.dtype, sample_inds.device)
@@ -255,12 +322,19 @@ class RecPolicyBuffer(object):
                 host_inds = inds            # travel inside the kernel-argument block: no upload at all
             else:
                 dev_inds = self._upload_inds(inds)
+                if lazy:
+                    dev_inds = dev_inds.clone()      # the staging ring is reused; a StoreObs keeps its indices
         d = self.dims
         if out is None:
-            out = self.alloc_batch(B)
+            out = self.alloc_batch(B, obs=not lazy)
         else:
-            assert out["obs"].shape[2] == B, "destination batch does not match the number of indices"
+            assert out["acts"].shape[2] == B, "destination batch does not match the number of indices"
+        if lazy:
+            out = dict(out, obs=None)
         of, sf = self._fields(out if self.use_same_share_obs else {k: v for k, v in out.items() if k != "share_obs"}), self._store_fields()
+        ref_inds = None
+        if lazy and (host_inds is not None):      # the consumers read the slots from HBM: the gather writes them out beside its copies
+            ref_inds = torch.empty(B, dtype=torch.int64, device=self.device)
         if extra is not None:
             sf.valid_transition, of.valid_transition = _lib.ptr(extra[0]).value, _lib.ptr(extra[1]).value
         if timing_events is not None:
@@ -271,6 +345,10 @@ class RecPolicyBuffer(object):
             assert int(self.filled_i) >= 1, "sample_device on an empty buffer"
             _lib.check(_lib.lib.ope_store_gather_sampled(C.byref(d), self.buffer_size, int(self.filled_i), _lib.ptr(filled_dev), C.byref(sf), seed, _lib.ptr(counter), B,
                                                          C.byref(of), _lib.ptr(dev_inds), _lib.current_stream()), "ope_store_gather_sampled")
+        elif ref_inds is not None:
+            tune = _lib.GatherTune(**{k: int(v) for k, v in (self.gather_tune or {}).items()})
+            _lib.check(_lib.lib.ope_store_gather_ref(C.byref(d), self.buffer_size, C.byref(sf), None, host_inds.ctypes.data_as(C.c_void_p), B, C.byref(of),
+                                                     _lib.ptr(ref_inds), _lib.ptr(self._bad_index), C.byref(tune), _lib.current_stream()), "ope_store_gather_ref")
         elif self.gather_tune is not None:      # this store's own gather knobs (A/B sweeps; the process defaults otherwise): ope_gather_tune
             tune = _lib.GatherTune(**{k: int(v) for k, v in self.gather_tune.items()})
             _lib.check(_lib.lib.ope_store_gather_tuned(C.byref(d), self.buffer_size, C.byref(sf), None if host_inds is not None else _lib.ptr(dev_inds),
@@ -299,6 +377,10 @@ class RecPolicyBuffer(object):
             _lib.check(_lib.lib.ope_reward_normalize(_lib.ptr(out["rewards"]), out["rewards"].numel(), _lib.ptr(self.reward_stats()),
                                                      _lib.current_stream()), "ope_reward_normalize")
         cast = lambda x: x.permute(1, 0, 2, 3)      # [N, T(+1), B, dim] view, as the reference's _cast
+        if lazy:
+            obs_entry = StoreObs(self, ref_inds if ref_inds is not None else dev_inds, B)
+            return (obs_entry, out["share_obs"] if self.use_same_share_obs else cast(out["share_obs"]), cast(out["acts"]), cast(out["rewards"]),
+                    cast(out["dones"]), out["dones_env"], cast(out["avail_acts"]) if self.use_avail_acts else None)
         return (cast(out["obs"]), out["share_obs"] if self.use_same_share_obs else cast(out["share_obs"]), cast(out["acts"]),
                 cast(out["rewards"]), cast(out["dones"]),
                 out["dones_env"], cast(out["avail_acts"]) if self.use_avail_acts else None)

@@ -255,6 +255,102 @@ def test_both_forms_of_the_row_chain_match_reference(name, path):
             np.testing.assert_allclose(src[key + k], ref, rtol=0, atol=3e-5, err_msg=grp + k)
 
 
+@pytest.mark.parametrize("name", ["qmix_var_d252", "qmix_var_d188", "qmix_var_d124"])
+def test_observation_rows_read_in_place_from_the_store_give_the_gathered_step(name):
+    """Lazy batch: with RecPolicyBuffer.lazy_obs the observation rows stay in the episode-major
+    store and trunk_fwd4 / wgrad fetch them through the sampled episode slots (ope_qmix_loss_and_grad_ref). Same arithmetic on the same
+    values in the same order: every step's gradient vector and the parameters after it are BIT-identical to the gathered step's, the
+    reference fixture's losses hold, and the launch log shows the row-reading variants actually ran. (Reference: rec_buffer.py:206-238
+    + qmix.py:108-109.)"""
+    from offpolicy_amd import _lib
+    from offpolicy_amd.utils.rec_buffer import StoreObs
+    g = load_golden(name)
+    runs = []
+    for lazy in (False, True):
+        dims, buf, policy, trainer = build_from_fixture(g)
+        trainer.tune["trunk_path"] = 4          # (56 rows: "by shape" would pick the register-resident trunk, which reads a gathered batch only)
+        pb = buf.policy_buffers["policy_0"]
+        pb.lazy_obs = lazy
+        assert trainer.obs_ref_ok(len(g["inds"]))
+        grads, losses = [], []
+        for s in range(len(g["loss"])):
+            smp = pb.sample_inds(g["inds"])
+            assert isinstance(smp[0], StoreObs) == lazy
+            info, _, _ = trainer.train_policy_on_batch(tuple({"policy_0": x} for x in smp) + (None, None))
+            launched = _lib.last_launches()
+            kc = (dims.obs_dim + 15) // 16
+            want = ("trunk_fwd4_store<%d>" % kc, "wgrad_store<4>") if lazy else ("trunk_fwd4<%d>" % kc, "wgrad<4>")
+            assert all(w in launched for w in want), launched
+            trainer.soft_target_updates()
+            grads.append(trainer.grad.clone())
+            losses.append(float(info["loss"]))
+        np.testing.assert_allclose(losses, g["loss"], rtol=RTOL)
+        runs.append((grads, trainer.theta.clone(), trainer.theta_tgt.clone()))
+    for a, b in zip(runs[0][0], runs[1][0]):
+        assert torch.equal(a, b)
+    assert torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
+
+
+def test_trainer_gathers_the_rows_itself_where_the_kernels_cannot_read_the_store():
+    """A StoreObs handed to a configuration whose first-layer kernels read a gathered batch only (odd obs_dim; previous action as an
+    input) is materialised by the trainer: same results as the gathered batch, no error, no other path silently."""
+    from offpolicy_amd.utils.rec_buffer import StoreObs
+    for name in ("qmix_odd", "qmix_tiny_prevact"):
+        g = load_golden(name)
+        dims, buf, policy, trainer = build_from_fixture(g)
+        pb = buf.policy_buffers["policy_0"]
+        pb.lazy_obs = True
+        assert not trainer.obs_ref_ok(len(g["inds"])) or policy.prev_act_inp
+        for s in range(len(g["loss"])):
+            smp = pb.sample_inds(g["inds"])
+            assert isinstance(smp[0], StoreObs)
+            info, _, _ = trainer.train_policy_on_batch(tuple({"policy_0": x} for x in smp) + (None, None))
+            trainer.soft_target_updates()
+            np.testing.assert_allclose(float(info["loss"]), g["loss"][s], rtol=RTOL)
+            np.testing.assert_allclose(float(info["grad_norm"]), g["grad_norm"][s], rtol=RTOL)
+
+
+def test_full_size_step_with_observations_read_from_the_store_is_bit_identical():
+    """BASELINE config 4 (3s5z, B = 32) as bench.py runs it by default: observations left in a 48-episode store, repeated indices,
+    kernels picked by shape. The gradient of the row-reading step equals the gathered step's bit for bit (which the full-size test
+    above compares with the oracle element by element)."""
+    from offpolicy_amd import _lib
+    from offpolicy_amd.config import default_args
+    from offpolicy_amd.utils.synth import DIMS, synth_episodes, policy_info_for, as_policy_dicts
+    from offpolicy_amd.utils.rec_buffer import RecReplayBuffer
+    from offpolicy_amd.algorithms.qmix.algorithm.QMixPolicy import QMixPolicy
+    from offpolicy_amd.algorithms.qmix.qmix import QMix
+    dims, nb, cap = DIMS["3s5z"], 32, 48
+    args = default_args()
+    torch.manual_seed(1)
+    np.random.seed(1)
+    dev = torch.device("cuda:0")
+    policy = QMixPolicy({"args": args, "device": dev}, policy_info_for(dims)["policy_0"])
+    trainer = QMix(args, dims.n_agents, {"policy_0": policy}, lambda a: "policy_0", device=dev, episode_length=dims.episode_length)
+    buf = RecReplayBuffer(policy_info_for(dims), {"policy_0": list(range(dims.n_agents))}, cap, dims.episode_length, True, True, device=dev)
+    for n in (24, 24):
+        d = as_policy_dicts(synth_episodes(np.random.RandomState(n), n, dims, avail="bernoulli"))
+        buf.insert(n, d["obs"], d["share_obs"], d["acts"], d["rewards"], d["dones"], d["dones_env"], d["avail_acts"])
+    pb = buf.policy_buffers["policy_0"]
+    inds = np.random.RandomState(3).randint(0, cap, size=nb)
+    inds[5] = inds[4]
+    assert trainer.obs_ref_ok(nb)
+    snap = (trainer.theta.clone(), trainer.theta_tgt.clone())
+    out = []
+    for lazy in (False, True):
+        trainer.theta.copy_(snap[0]); trainer.theta_tgt.copy_(snap[1])
+        trainer.optimizer.exp_avg.zero_(); trainer.optimizer.exp_avg_sq.zero_(); trainer.optimizer.step_count = 0
+        pb.lazy_obs = lazy
+        smp = pb.sample_inds(inds)
+        info, _, _ = trainer.train_policy_on_batch(tuple({"policy_0": x} for x in smp) + (None, None))
+        launched = _lib.last_launches()
+        assert ("trunk_fwd4_store<16>" in launched) == lazy and ("wgrad_store<4>" in launched) == lazy, launched
+        assert ("trunk_fwd4<16>" in launched) != lazy
+        out.append((trainer.grad.clone(), trainer.theta.clone(), float(info["loss"])))
+    assert np.isfinite(out[0][2]) and out[0][2] == out[1][2]
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+
+
 def test_fused_row_chain_on_a_configuration_it_cannot_run_is_an_error():
     """chain_path = 2 together with the wide-state mixer (mixer_path = 3) -- which keeps its stream-K GEMM path -- returns OPE_EINVAL."""
     from offpolicy_amd import _lib

@@ -328,3 +328,52 @@ def test_device_sampled_gather_is_uniform_in_range_and_matches_index_gather():
     expect = 64 * B / filled
     chi2 = ((counts - expect) ** 2 / expect).sum()
     assert chi2 < 39 + 5 * np.sqrt(2 * 39), chi2          # 39 degrees of freedom: mean 39, sd 8.8
+
+
+@pytest.mark.parametrize("name,index_source", [("qmix_tiny", "host"), ("qmix_odd", "device"), ("qmix_tiny_huber_per", "sampled")])
+def test_observations_left_in_the_store_are_the_gathered_ones(name, index_source):
+    """RecPolicyBuffer.lazy_obs (round 4; SURVEY.md 8(d) "fused into the first consumer"): sample_inds copies every field but obs and
+    returns a StoreObs in its place. Everything a caller can do with the reference's array (rec_buffer.py:206-238) still gives the
+    reference's values: the other six fields are bit-identical to the fixture, the StoreObs materialises to the fixture's obs, numpy /
+    indexing / .cpu() go through the same tensor, the index list the row readers use is the one that was sampled -- and a batch kept
+    across an insert() refuses to be read instead of silently changing."""
+    from offpolicy_amd.utils.rec_buffer import StoreObs, StaleBatchError
+    g = load_golden(name)
+    dims, buf, _, _ = build_from_fixture(g)
+    pb = buf.policy_buffers["policy_0"]
+    inds = np.asarray(g["inds"], dtype=np.int64)
+    pb.lazy_obs = True
+    if index_source == "host":
+        got = pb.sample_inds(inds)
+    elif index_source == "device":
+        got = pb.sample_inds(torch.as_tensor(inds).cuda())
+    else:
+        counter = torch.zeros(1, dtype=torch.int32, device="cuda:0")
+        got, drawn = pb.sample_device(len(inds), 77, counter)
+        pb.lazy_obs = False
+        want, drawn2 = pb.sample_device(len(inds), 77, counter)
+        pb.lazy_obs = True
+        assert torch.equal(drawn, drawn2) and isinstance(got[0], StoreObs)
+        assert torch.equal(got[0].materialize(), want[0])
+        for a, w in zip(got[1:], want[1:]):
+            assert (a is None and w is None) or torch.equal(a, w)
+        return
+    obs = got[0]
+    assert isinstance(obs, StoreObs) and tuple(obs.shape) == g["batch/obs"].shape
+    assert np.array_equal(obs.inds.cpu().numpy(), inds)
+    for k, a in zip(FIELDS[1:], got[1:]):
+        assert np.array_equal(a.cpu().numpy(), g["batch/" + k]), k
+    assert np.array_equal(np.asarray(obs), g["batch/obs"])
+    assert np.array_equal(obs.cpu().numpy(), g["batch/obs"]) and np.array_equal(obs[1].cpu().numpy(), g["batch/obs"][1])
+    pb.check_indices()
+    # a later ring write invalidates the rows the object points at
+    fresh = pb.sample_inds(inds)[0]
+    from golden_util import fixture_episodes
+    from offpolicy_amd.utils.synth import as_policy_dicts
+    d = as_policy_dicts(fixture_episodes(g))
+    buf.insert(len(g["idx_range"]), d["obs"], d["share_obs"], d["acts"], d["rewards"], d["dones"], d["dones_env"], d["avail_acts"])
+    with pytest.raises(StaleBatchError):
+        fresh.materialize()
+    with pytest.raises(StaleBatchError):
+        fresh.ref()
+    assert np.array_equal(obs.cpu().numpy(), g["batch/obs"])       # (materialised before the insert: a plain tensor now)
