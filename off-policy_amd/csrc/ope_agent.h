@@ -154,7 +154,9 @@ struct BlockBwdArgs {
 int launch_block_fwd(const BlockFwdArgs& a, hipStream_t st);
 int launch_block_bwd(const BlockBwdArgs& a, hipStream_t st);
 
-int launch_trunk_fwd(const TrunkFwdArgs& a, bool save, hipStream_t st);
+// allow4 = false: never the LDS-resident kernel (ope_trunk4.hip) -- the pair launcher's own fall-back, and tests that pin a family
+int launch_trunk_fwd(const TrunkFwdArgs& a, bool save, hipStream_t st, bool allow4 = true);
+int launch_trunk_fwd4_single(const TrunkFwdArgs& a, bool save, hipStream_t st);      // OPE_OK / error, or 1 = not this kernel's launch
 // live (saving) + target trunk of the same input rows: one launch of trunk_fwd4 (ope_trunk4.hip) when the shape allows, else two launches
 int launch_trunk_fwd_pair(const TrunkFwdArgs& live, const TrunkFwdArgs& tgt, int path, hipStream_t st);
 int launch_trunk_fwd2(const TrunkFwdArgs& a, bool save, hipStream_t st);   // workgroup-cooperative form (ope_trunk2.hip)

@@ -197,8 +197,12 @@ static int launch_trunk_vec(const TrunkFwdArgs& a, hipStream_t st) {
   return OPE_OK;
 }
 
-int launch_trunk_fwd(const TrunkFwdArgs& a, bool save, hipStream_t st) {
+int launch_trunk_fwd(const TrunkFwdArgs& a, bool save, hipStream_t st, bool allow4) {
   if (a.R < 1 || a.D < 1) return OPE_EINVAL;
+  if (allow4) {     // many rows of a width the LDS-resident kernel is built for (ope_trunk4.hip); 1 = not its launch
+    const int rc4 = launch_trunk_fwd4_single(a, save, st);
+    if (rc4 != 1) return rc4;
+  }
   // default (OPE_TRUNK2 unset or 3): persistent workgroups with the weights in registers; 2: the non-persistent cooperative
   // form; 0: the one-wave-per-row-tile form below (A/B runs)
   static const int v2 = getenv("OPE_TRUNK2") ? atoi(getenv("OPE_TRUNK2")) : 3;

@@ -820,6 +820,7 @@ extern "C" int ope_agent_forward(const ope_dims* d, int32_t seq_len, int32_t row
   const AgentLayout L = ope_agent_layout(d->obs_dim, d->act_dim, 0, d->layer_N);
   float* gi = (float*)workspace;
   int rc;
+  clear_launch_log();
   TrunkFwdArgs tf;
   memset(&tf, 0, sizeof(tf));
   tf.x = obs; tf.R = (int)R; tf.D = d->obs_dim; tf.theta = theta; tf.L = L; tf.gi = gi;

@@ -23,6 +23,7 @@
 //     not a wave's.
 // The observation rows are still read once per net (the nets sit on different CUs), but within one launch and largely out of L2.
 #include <stdlib.h>
+#include <string.h>
 
 #include "ope_agent.h"
 
@@ -37,7 +38,10 @@ struct T4 {
   static constexpr int RS1 = 4 * KCM;                 // 16-byte slots per fc1 row
   static constexpr int W1F = OPE_H * 16 * KCM;        // floats
   static constexpr int W2F = OPE_H * OPE_H;
-  static constexpr int W3F = 3 * OPE_H * OPE_H;
+  // W_ih rows resident in LDS: all 192, except at the widest input (KCM = 24: fc1 alone is 96 KB) where the last two 16-gate tiles
+  // (8 KB) stay in L2 and are read as MFMA operands straight from there -- 8 loads per lane and tile, requested a phase ahead
+  static constexpr int W3R = KCM > 16 ? 160 : 3 * OPE_H;
+  static constexpr int W3F = W3R * OPE_H;
   static constexpr int FNP = 2 * 16 * KCM;            // input LayerNorm gamma / beta, zero beyond D
   static constexpr int LNP = 6 * OPE_H;               // b1, ln1 w, ln1 b, b2, ln2 w, ln2 b
   static constexpr int BIH = 3 * OPE_H;
@@ -56,6 +60,7 @@ struct TrunkPairArgs {
   int fn_w, fn_b, fc1_w, fc1_b, ln1_w, ln1_b, fc2_w, fc2_b, ln2_w, ln2_b, wih, bih;
   float* mu0; float* rstd0; float* xhat1; float* rstd1; float* mu1; uint64_t* mask1; float* xhat2; float* rstd2; uint64_t* mask2;
   long long* dbg;
+  int save0;                      // net 0 writes the saves (a single-net launch of a target / rollout net does not)
   ObsRef ref; int ref_tn0;        // LAZY instantiation: x = the store's obs ring; first (t, agent) index of the launch's row range
 };
 
@@ -65,10 +70,11 @@ struct TrunkPairArgs {
 // registers live through the whole tile: 248 VGPRs, two waves per SIMD) or at the top of the tile (<= 168 VGPRs, three per SIMD).
 // LAZY: the observation rows are read in place from the episode-major store (ObsRef, ope_common.h) instead of a gathered batch: the same
 // 16 KCM-byte rows, at (per-lane 64-bit row pointer) + (immediate) instead of (uniform base) + (32-bit offset).
-template <int KCM, int NW, bool PF, bool LAZY>
+// VEC = 4: D % 4 == 0, rows and weight rows read as 16-byte pieces; VEC = 2 (D % 2 == 0: MMM2's 370): as two 8-byte halves.
+template <int KCM, int NW, bool PF, bool LAZY, int VEC = 4>
 __global__ void __launch_bounds__(64 * NW, NW / 4) trunk_fwd4_kernel(TrunkPairArgs pa) {
   using C = T4<KCM>;
-  constexpr int VEC = 4;
+  static_assert(!(LAZY && VEC != 4), "rows are read in place from the store as 16-byte pieces only");
   constexpr int NT = 64 * NW;
   __shared__ __attribute__((aligned(16))) float sm[LAZY ? C::TOTAL_REF : C::TOTAL];
   float* const W1s = sm;
@@ -90,7 +96,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) trunk_fwd4_kernel(TrunkPairAr
   const float* __restrict__ th = net ? pa.theta[1] : pa.theta[0];
   float* __restrict__ gi_out = net ? pa.gi[1] : pa.gi[0];
   const int D = a.D, R = a.R;
-  const bool save = net == 0;
+  const bool save = net == 0 && pa.save0;
 
   // optional s_memtime stamps (ope_qmix_cfg.debug; tools/trunk4_phases.py): [workgroup][wave][16] = start, weights staged, then for the
   // wave's FIRST tile: rows arrived + statistics, fc1, LN1 + saves, fc2 + LN2 + saves, W_ih + gi stores; last: all tiles done, tiles done
@@ -126,11 +132,15 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) trunk_fwd4_kernel(TrunkPairAr
   const float inv_d = 1.0f / (float)D;
   f32x4 xv[KCM];
   const bool tail_ok = 16 * (KCM - 1) + 4 * g < D;       // this lane's piece of the last chunk lies inside the row
+  const bool tail_ok1 = VEC == 4 ? tail_ok : 16 * (KCM - 1) + 4 * g + 2 < D;      // ... its second 8-byte half (VEC = 2)
   // Every global access of the tile loop is (uniform base pointer) + (32-bit byte offset): all arrays are < 4 GB (R * 768 B the
   // largest), and 64-bit per-lane addresses cost twice the registers -- the first version spilled five of them, and a scratch
   // reload is a VMEM load: its vmcnt wait also waits for the 16 row loads just requested for the NEXT tile (13 k cycles per tile).
   const char* __restrict__ xb = reinterpret_cast<const char*>(a.x);
-  auto request = [&](int tile, bool staged = true) {
+  // part (KCM > 16 only): 0 = the whole row, 1 = chunks [0, 16) -- what is requested behind fc1 for the NEXT tile and held through fc2 /
+  // W_ih (a whole 24-chunk row would be 96 registers: 89 spilled) --, 2 = the rest, requested at the top of the tile itself
+  constexpr int PFC = KCM > 16 ? 16 : KCM;
+  auto request = [&](int tile, bool staged = true, int part = 0) {
     const int row = tile * 16 + j;
     if (LAZY) {
       int rw, b, tnj;
@@ -146,6 +156,24 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) trunk_fwd4_kernel(TrunkPairAr
       return;
     }
     const uint32_t xo = (uint32_t)(row < R ? row : R - 1) * (uint32_t)(4 * D) + 16u * g;
+    if (VEC == 2) {
+      // two 8-byte halves per piece; the last chunk's halves are clamped to offset 0 of the row when they lie past its end (zeroed below)
+      int gg = g;
+      asm volatile("" : "+v"(gg));
+      const int k0 = 16 * (KCM - 1) + 4 * gg;
+      if (part != 1) {
+        const f32x2 t0 = *reinterpret_cast<const f32x2*>(xb + (xo + (k0 < D ? 64u * (KCM - 1) : 0u)));
+        const f32x2 t1 = *reinterpret_cast<const f32x2*>(xb + (xo + (k0 + 2 < D ? 64u * (KCM - 1) + 8u : 0u)));
+        xv[KCM - 1] = f32x4{t0[0], t0[1], t1[0], t1[1]};
+      }
+#pragma unroll
+      for (int c = 0; c < KCM - 1; ++c) {
+        if ((c < PFC && part == 2) || (c >= PFC && part == 1)) continue;
+        const f32x2 h0 = *reinterpret_cast<const f32x2*>(xb + (xo + 64u * c)), h1 = *reinterpret_cast<const f32x2*>(xb + (xo + 64u * c + 8u));
+        xv[c] = f32x4{h0[0], h0[1], h1[0], h1[1]};
+      }
+      return;
+    }
     // the last chunk's piece first, its offset recomputed here (a hoisted copy got spilled, and the reload's vmcnt wait sat in the
     // middle of this burst of loads)
     int gg = g;
@@ -161,11 +189,11 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) trunk_fwd4_kernel(TrunkPairAr
     const int64_t t = (int64_t)slot0 + (int64_t)nslots * (wave >> 2);
     tile = t < ntiles ? (int)t : ntiles;
   }
-  if (PF && tile < ntiles) request(tile, false);
+  if (PF && tile < ntiles) request(tile, false, KCM > PFC ? 1 : 0);
   // ---- prologue: this net's weights -> LDS (swizzled), parameters, tile counters. Every thread requests ALL its pieces before the
   // first LDS store (8 KCM / 16 + 2 + 6 independent 16-byte loads in flight per thread instead of one round trip per piece) ----
   {
-    constexpr int P1 = OPE_H * C::RS1, P2 = OPE_H * 16, P3 = 3 * OPE_H * 16;                       // 16-byte pieces of the three matrices
+    constexpr int P1 = OPE_H * C::RS1, P2 = OPE_H * 16, P3 = C::W3R * 16;                         // 16-byte pieces of the three matrices (their LDS-resident rows)
     constexpr int N1 = (P1 + NT - 1) / NT, N2 = (P2 + NT - 1) / NT, N3 = (P3 + NT - 1) / NT;       // per thread (a partly used last round)
     f32x4 p1[N1], p2[N2], p3[N3];
 #pragma unroll
@@ -281,9 +309,11 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) trunk_fwd4_kernel(TrunkPairAr
     bool valid;
     rows_of(tile, row, valid, b_, tnj_);
     if (!PF) request(tile);
+    if (PF && KCM > PFC) request(tile, true, 2);       // (unconditional: a "not for the first tile" test keeps the 32 registers live around the loop)
     // ---- input LayerNorm statistics of row j: 4 lanes x KCM pieces ----
     float s = 0.f;
     if (!tail_ok) xv[KCM - 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (VEC == 2 && !tail_ok1) { xv[KCM - 1][2] = 0.f; xv[KCM - 1][3] = 0.f; }
 #pragma unroll
     for (int c = 0; c < KCM; ++c) s += (xv[c][0] + xv[c][1]) + (xv[c][2] + xv[c][3]);
     const float mean = rowsum4(s) * inv_d;
@@ -292,7 +322,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) trunk_fwd4_kernel(TrunkPairAr
     for (int c = 0; c < KCM; ++c) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float d = (c < KCM - 1 || tail_ok) ? xv[c][r] - mean : 0.f;
+        const float d = (c < KCM - 1 || (r < 2 ? tail_ok : tail_ok1)) ? xv[c][r] - mean : 0.f;
         xv[c][r] = d;
         sq = fmaf(d, d, sq);
       }
@@ -309,6 +339,13 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) trunk_fwd4_kernel(TrunkPairAr
       const f32x4 gm = *reinterpret_cast<const f32x4*>(fnp + 16 * c + 4 * g), bt = *reinterpret_cast<const f32x4*>(fnp + 16 * KCM + 16 * c + 4 * g);
 #pragma unroll
       for (int r = 0; r < 4; ++r) xv[c][r] = fmaf(xv[c][r] * rstd, gm[r], bt[r]);
+      // KCM = 24: LLVM sinks these products towards their uses in the fc1 loop (across the scheduling fences, which only bind the machine
+      // scheduler), so all 48 parameter reads -- 192 registers -- end up in flight next to the 96-register row: 89 spills. An empty asm
+      // that "modifies" each product pins it here.
+      if (KCM > 16) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(xv[c][r]));
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     if (done == 0) stamp(2);
@@ -337,7 +374,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) trunk_fwd4_kernel(TrunkPairAr
     if (done == 0) stamp(3);
     // the observation registers are free: request the next tile's rows now, they arrive behind fc2 / W_ih
     const int next = grab();
-    if (PF && next < ntiles) request(next);
+    if (PF && next < ntiles) request(next, true, KCM > PFC ? 1 : 0);
 
     float rs, mu;
     uint64_t bits;
@@ -380,8 +417,17 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) trunk_fwd4_kernel(TrunkPairAr
     }
     if (done == 0) stamp(5);
     // ---- gi = W_ih a2 + b_ih: 12 output tiles, four at a time ----
+    constexpr int NG = (3 * OPE_H - C::W3R) / 16;           // 16-gate tiles read from L2 (0, or 2 at KCM = 24)
+    f32x4 w3g[NG > 0 ? NG : 1][4];
 #pragma unroll
     for (int u0 = 0; u0 < 12; u0 += 4) {
+      if (NG > 0 && u0 == 8) {      // the group that holds the L2-resident tiles: their fragments, requested here (32 registers for a third of the phase)
+#pragma unroll
+        for (int u = 0; u < NG; ++u)
+#pragma unroll
+          for (int ft = 0; ft < 4; ++ft)
+            w3g[u][ft] = *reinterpret_cast<const f32x4*>(th + a.wih + (C::W3R + 16 * u + j) * OPE_H + 16 * ft + 4 * g);
+      }
       f32x4 o[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) o[u] = *reinterpret_cast<const f32x4*>(bih + 16 * (u0 + u) + 4 * g);
@@ -390,7 +436,10 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) trunk_fwd4_kernel(TrunkPairAr
         if ((ft & 1) == 0) __builtin_amdgcn_sched_barrier(0);
         f32x4 wv[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) wv[u] = *reinterpret_cast<const f32x4*>(W3b + (wo2[ft] + (uint32_t)(16 * (u0 + u) * 4 * OPE_H)));
+        for (int u = 0; u < 4; ++u) {
+          if (16 * (u0 + u) < C::W3R) wv[u] = *reinterpret_cast<const f32x4*>(W3b + (wo2[ft] + (uint32_t)(16 * (u0 + u) * 4 * OPE_H)));
+          else wv[u] = w3g[u0 + u - C::W3R / 16][ft];      // (the tiles that stay in L2: requested at the top of the W_ih phase)
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -418,16 +467,16 @@ int launch_trunk_fwd_pair(const TrunkFwdArgs& live, const TrunkFwdArgs& tgt, int
   static const int on = getenv("OPE_TRUNK4") ? atoi(getenv("OPE_TRUNK4")) : 1;
   const int KC = (live.D + 15) >> 4;
   const bool can = live.gi && tgt.gi && !live.a2_out && !tgt.a2_out && live.D == tgt.D && live.R == tgt.R && live.x == tgt.x &&
-                   live.D % 4 == 0 && (KC == 4 || KC == 8 || KC == 12 || KC == 16) && live.xhat1 && live.mu0 && live.rstd0 && live.rstd1 && live.mask1 && live.xhat2 && live.rstd2 && live.mask2;
+                   ((live.D % 4 == 0 && (KC == 4 || KC == 8 || KC == 12 || KC == 16)) || (live.D % 2 == 0 && KC == 24)) && live.xhat1 && live.mu0 && live.rstd0 && live.rstd1 && live.mask1 && live.xhat2 && live.rstd2 && live.mask2;
   if (path == 4 && !can) return OPE_EINVAL;      // an explicit request the shape does not allow: no silent fall-back (tests pin kernels by path)
   const bool ok = can && (path == 4 || (path == 0 && on && live.R >= 16 * 1024));
   const bool lazy = live.ref.inds != nullptr;
-  if (lazy && (!ok || live.ref.B < 1 || live.ref.B > kObsRefMaxB || live.R % live.ref.B != 0 || live.ref_row0 % live.ref.B != 0 || live.ref.cap < 1))
+  if (lazy && (!ok || KC == 24 || live.ref.B < 1 || live.ref.B > kObsRefMaxB || live.R % live.ref.B != 0 || live.ref_row0 % live.ref.B != 0 || live.ref.cap < 1))
     return OPE_EINVAL;                           // only this kernel reads rows from the store (ope_qmix_obs_ref_ok tells the caller beforehand)
   if (!ok) {
-    int rc = launch_trunk_fwd(live, true, st);
+    int rc = launch_trunk_fwd(live, true, st, false);
     if (rc) return rc;
-    return launch_trunk_fwd(tgt, false, st);
+    return launch_trunk_fwd(tgt, false, st, false);
   }
   TrunkPairArgs pa;
   pa.x = live.x; pa.R = live.R; pa.D = live.D; pa.nets = 2;
@@ -438,13 +487,17 @@ int launch_trunk_fwd_pair(const TrunkFwdArgs& live, const TrunkFwdArgs& tgt, int
   pa.mu0 = live.mu0; pa.rstd0 = live.rstd0; pa.xhat1 = live.xhat1; pa.rstd1 = live.rstd1; pa.mu1 = live.mu1; pa.mask1 = live.mask1;
   pa.xhat2 = live.xhat2; pa.rstd2 = live.rstd2; pa.mask2 = live.mask2;      // the target net saves nothing
   pa.dbg = live.dbg;
+  pa.save0 = 1;
   pa.ref = live.ref; pa.ref_tn0 = lazy ? live.ref_row0 / live.ref.B : 0;
   static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256; return n > 1 ? n : 256; }();
   const int grid = cus & ~1;     // one workgroup per CU, even ones the live net, odd ones the target
   // Eight waves (two per SIMD, rows prefetched behind fc1). Measured against twelve waves without the prefetch (three per SIMD at the 168
   // register cap, 78 of them spilled): 59.5 us vs 107 us at 3s5z batch 32, so only this variant is built.
   kprof_work(2.0 * 2.0 * live.R * ((double)live.D * OPE_H + OPE_H * OPE_H + 3.0 * OPE_H * OPE_H));     // both nets
-  if (lazy) {
+  // (KC = 24: rows prefetched behind fc1 up to chunk 16, the rest at the top of the tile: 117.8 us at MMM2 batch 32 against 119.7 us without
+  // any prefetch and 168.6 us for the two trunk_fwd3<2, 24> launches)
+  if (KC == 24) OPE_LAUNCH((trunk_fwd4_kernel<24, 8, true, false, 2>), dim3(grid), dim3(512), 0, st, pa);
+  else if (lazy) {
     if (KC == 4) OPE_LAUNCH((trunk_fwd4_kernel<4, 8, true, true>), dim3(grid), dim3(512), 0, st, pa);
     else if (KC == 8) OPE_LAUNCH((trunk_fwd4_kernel<8, 8, true, true>), dim3(grid), dim3(512), 0, st, pa);
     else if (KC == 12) OPE_LAUNCH((trunk_fwd4_kernel<12, 8, true, true>), dim3(grid), dim3(512), 0, st, pa);
@@ -457,6 +510,40 @@ int launch_trunk_fwd_pair(const TrunkFwdArgs& live, const TrunkFwdArgs& tgt, int
   }
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   note_launch(lazy ? "trunk_fwd4_store" : "trunk_fwd4", KC);
+  return OPE_OK;
+}
+
+// ONE net's trunk on the LDS-resident kernel (every CU that net's weights): the recurrent MADDPG / MATD3 actors, whose live, target and
+// rollout trunks are separate launches over 10^5 rows (config 5: 231 680 rows of MMM2's 370-wide observations). Returns 1 when the
+// launch is not this kernel's (shape, outputs, row count): the caller goes on to the register-resident forms.
+int launch_trunk_fwd4_single(const TrunkFwdArgs& a, bool save, hipStream_t st) {
+  static const int on = getenv("OPE_TRUNK4") ? atoi(getenv("OPE_TRUNK4")) : 1;
+  const int KC = (a.D + 15) >> 4;
+  const bool shape = (a.D % 4 == 0 && (KC == 4 || KC == 8 || KC == 12 || KC == 16)) || (a.D % 2 == 0 && KC == 24);
+  if (!on || !shape || !a.gi || a.a2_out || a.head_out || a.ref.inds || a.R < 16 * 1024) return 1;
+  if (save && !(a.xhat1 && a.mu0 && a.rstd0 && a.rstd1 && a.mask1 && a.xhat2 && a.rstd2 && a.mask2)) return 1;
+  TrunkPairArgs pa;
+  memset(&pa, 0, sizeof(pa));
+  pa.x = a.x; pa.R = a.R; pa.D = a.D; pa.nets = 1;
+  pa.theta[0] = pa.theta[1] = a.theta; pa.gi[0] = pa.gi[1] = a.gi;
+  const AgentLayout& L = a.L;
+  pa.fn_w = L.fn_w; pa.fn_b = L.fn_b; pa.fc1_w = L.fc1_w; pa.fc1_b = L.fc1_b; pa.ln1_w = L.ln1_w; pa.ln1_b = L.ln1_b;
+  pa.fc2_w = L.fc2_w; pa.fc2_b = L.fc2_b; pa.ln2_w = L.ln2_w; pa.ln2_b = L.ln2_b; pa.wih = L.wih; pa.bih = L.bih;
+  pa.save0 = save ? 1 : 0;
+  if (save) {
+    pa.mu0 = a.mu0; pa.rstd0 = a.rstd0; pa.xhat1 = a.xhat1; pa.rstd1 = a.rstd1; pa.mu1 = a.mu1; pa.mask1 = a.mask1;
+    pa.xhat2 = a.xhat2; pa.rstd2 = a.rstd2; pa.mask2 = a.mask2;
+  }
+  pa.dbg = a.dbg;
+  static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256; return n > 1 ? n : 256; }();
+  kprof_work(2.0 * a.R * ((double)a.D * OPE_H + OPE_H * OPE_H + 3.0 * OPE_H * OPE_H));
+  if (KC == 24) OPE_LAUNCH((trunk_fwd4_kernel<24, 8, true, false, 2>), dim3(cus), dim3(512), 0, st, pa);
+  else if (KC == 4) OPE_LAUNCH((trunk_fwd4_kernel<4, 8, true, false>), dim3(cus), dim3(512), 0, st, pa);
+  else if (KC == 8) OPE_LAUNCH((trunk_fwd4_kernel<8, 8, true, false>), dim3(cus), dim3(512), 0, st, pa);
+  else if (KC == 12) OPE_LAUNCH((trunk_fwd4_kernel<12, 8, true, false>), dim3(cus), dim3(512), 0, st, pa);
+  else OPE_LAUNCH((trunk_fwd4_kernel<16, 8, true, false>), dim3(cus), dim3(512), 0, st, pa);
+  if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
+  note_launch("trunk_fwd4_single", KC, save ? 1 : 0);
   return OPE_OK;
 }
 

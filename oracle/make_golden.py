@@ -233,6 +233,11 @@ def main():
         patch_vdn()
         run_case("vdn_var_layer2", tiny, n_episodes=4, inds=[2, 1, 0, 3], avail="bernoulli", vdn=True, argv=["--layer_N", "2"])
         return
+    if os.environ.get("OPE_GOLDEN_ONLY") == "d370":
+        # round 4: the MMM2 observation width (D = 370: 24 chunks, rows 8-byte aligned only) on a small batch, for the LDS-resident trunk
+        # kernel's 24-chunk / 8-byte-load instantiation (trunk_fwd4<24>, csrc/ope_trunk4.hip); 56 rows = three full tiles + a partial one
+        run_case("qmix_var_d370", EnvDims("var_d370", 2, 5, 370, 20, 6), n_episodes=5, inds=[4, 0, 2, 2], avail="bernoulli")
+        return
     if os.environ.get("OPE_GOLDEN_ONLY") == "pershare":      # add the round-2 fixture without rewriting the committed ones
         run_case("qmix_tiny_pershare", tiny, n_episodes=5, inds=[4, 1, 1, 0, 2], cap=6, pre_insert=3, avail="bernoulli", per_agent_share=True)
         return

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 CASES = ["qmix_tiny", "qmix_tiny_huber_per", "qmix_tiny_nodouble", "vdn_tiny", "qmix_odd", "qmix_3m_katA", "qmix_tiny_prevact", "qmix_tiny_pershare",
          "qmix_gall_tiny", "qmix_gall_3m", "qmix_gall_odd",   # gall: scripts/train_smac_qmix.sh (wide state, gain 1, hard target updates)
          # round 4: shapes that reach the kernel variants bench.py runs when the kernels are pinned (tests below); here: what "by shape" picks
-         "qmix_var_d252", "qmix_var_d188", "qmix_var_d124", "qmix_var_mix216", "qmix_var_mix100", "qmix_var_s2232",
+         "qmix_var_d252", "qmix_var_d188", "qmix_var_d124", "qmix_var_d370", "qmix_var_mix216", "qmix_var_mix100", "qmix_var_s2232",
          "qmix_var_n10", "qmix_var_a20",       # 10 agents (two per wave of the fused chain kernel), 20 actions (two head tiles; plain-max targets)
          # one-layer hyper-networks (--hypernet_layers 1, q_mixer.py:39-44): the tiny shape fixture, 8 agents at S = 216, odd S + Huber + PER
          "qmix_shape_hyper1", "qmix_var_hyper1_mix", "qmix_var_hyper1_odd", "qmix_shape_layer2",
@@ -97,9 +97,10 @@ def test_every_scan_kernel_family_matches_reference(name, family, waves):
 
 
 # (fixture, trunk_path) pairs that CAN run: path 3 takes every width; path 4 (trunk_fwd4 / trunk_bwd4) needs an input width that is a
-# multiple of 4 with ceil(D / 16) in {4, 8, 12, 16}: D = 64 (3m), 124, 188, 252 (the 3s5z width: KCM 16 with a 12-float tail chunk)
-TRUNK_CASES = [(n, 3) for n in ("qmix_tiny", "qmix_odd", "qmix_3m_katA", "qmix_tiny_prevact", "qmix_gall_3m", "qmix_tiny_huber_per", "qmix_var_d252")] + \
-              [(n, 4) for n in ("qmix_3m_katA", "qmix_gall_3m", "qmix_var_d124", "qmix_var_d188", "qmix_var_d252")]
+# multiple of 4 with ceil(D / 16) in {4, 8, 12, 16}: D = 64 (3m), 124, 188, 252 (the 3s5z width: KCM 16 with a 12-float tail chunk) -- or an
+# even width with 24 chunks: D = 370, the MMM2 width (rows 8-byte aligned only, a 2-float tail, two W_ih tiles read from L2)
+TRUNK_CASES = [(n, 3) for n in ("qmix_tiny", "qmix_odd", "qmix_3m_katA", "qmix_tiny_prevact", "qmix_gall_3m", "qmix_tiny_huber_per", "qmix_var_d252", "qmix_var_d370")] + \
+              [(n, 4) for n in ("qmix_3m_katA", "qmix_gall_3m", "qmix_var_d124", "qmix_var_d188", "qmix_var_d252", "qmix_var_d370")]
 
 
 def _expect_trunk(dims, path):
@@ -424,6 +425,28 @@ def test_policy_forward_matches_oracle_single_step_and_sequence(name):
     acts, hn, gq = policy.get_actions(obs[0].cuda(), None, h0.cuda(), available_actions=np.ones((7, dims.act_dim)))
     assert acts.shape == (7, dims.act_dim) and np.allclose(acts.sum(-1), 1)
     assert np.array_equal(acts.argmax(-1), q_ref[0].argmax(-1).numpy())
+
+
+@pytest.mark.parametrize("name", ["qmix_var_d370", "qmix_var_d252"])
+def test_single_net_launch_of_the_lds_resident_trunk_matches_oracle(name):
+    """A forward over >= 16 384 rows of a width the LDS-resident trunk kernel is built for runs it on ONE net (trunk_fwd4_single: every CU
+    holds that net's weights) -- what the recurrent MADDPG / MATD3 actors' live / target / rollout trunks are at BASELINE config 5
+    (231 680 rows of MMM2's 370-wide observations; 24 chunks, rows 8-byte aligned) -- here through policy.get_q_values
+    (ope_agent_forward), against the oracle's forward on the same rows, with the launch log naming the kernel."""
+    from oracle import qmix_oracle as O
+    from offpolicy_amd import _lib
+    g = load_golden(name)
+    dims, buf, policy, trainer = build_from_fixture(g)
+    P = {k: torch.as_tensor(v) for k, v in sub(g, "agent/").items()}
+    torch.manual_seed(5)
+    rows = 16 * 1024 + 40                  # (a partial last tile)
+    obs = torch.randn(2, rows, dims.obs_dim) * 0.7 + 0.1
+    h0 = torch.randn(rows, 64) * 0.5
+    q_ref, h_ref = O.agent_q_forward(P, obs, h0)
+    q, h = policy.get_q_values(obs.cuda(), None, h0.cuda())
+    assert "trunk_fwd4_single<%d,0>" % ((dims.obs_dim + 15) // 16) in _lib.last_launches(), _lib.last_launches()
+    np.testing.assert_allclose(q.cpu().numpy(), q_ref.numpy(), rtol=1e-4, atol=3e-6)
+    np.testing.assert_allclose(h.cpu().numpy(), h_ref.numpy(), rtol=1e-4, atol=3e-6)
 
 
 def test_policy_forward_with_previous_action_input():
