@@ -492,7 +492,9 @@ int launch_trunk_fwd_pair(const TrunkFwdArgs& live, const TrunkFwdArgs& tgt, int
   static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256; return n > 1 ? n : 256; }();
   const int grid = cus & ~1;     // one workgroup per CU, even ones the live net, odd ones the target
   // Eight waves (two per SIMD, rows prefetched behind fc1). Measured against twelve waves without the prefetch (three per SIMD at the 168
-  // register cap, 78 of them spilled): 59.5 us vs 107 us at 3s5z batch 32, so only this variant is built.
+  // register cap, 78 of them spilled): 59.5 us vs 107 us at 3s5z batch 32, so only this variant is built. (Round 4: with the input-LayerNorm
+  // products pinned -- see the KCM = 24 note in the kernel -- the twelve-wave forms fit 144 / 168 registers without spills and run 60.8 /
+  // 61.2 us against 61.3 us: a third wave per SIMD buys nothing, the kernel is not waiting on latency.)
   kprof_work(2.0 * 2.0 * live.R * ((double)live.D * OPE_H + OPE_H * OPE_H + 3.0 * OPE_H * OPE_H));     // both nets
   // (KC = 24: rows prefetched behind fc1 up to chunk 16, the rest at the top of the tile: 117.8 us at MMM2 batch 32 against 119.7 us without
   // any prefetch and 168.6 us for the two trunk_fwd3<2, 24> launches)
