@@ -46,7 +46,13 @@ typedef struct ope_dims {
   int32_t layer_N;        /* args.layer_N (config.py:65): hidden blocks (Linear + ReLU + LayerNorm) behind fc1 in the agent network's MLP base
                            * (mlp.py:14-28). 0 or 1 = the reference default; 2 = a second block `rnn.mlp.fc2.1.*` (4 more tensors between
                            * fc2.0 and the GRU): recurrent QMIX / VDN with one shared policy only, anything else returns OPE_EINVAL */
+  int32_t flags;          /* OPE_DIMS_* bits; 0 = the reference defaults */
 } ope_dims;
+/* args.use_feature_normalization = False (config.py:69, mlp.py:60-62, 77-78): the agent network has no input LayerNorm. The flat
+ * parameter layout is UNCHANGED -- the two feature_norm slots stay where they are and must hold ones / zeros (the host mirrors do not
+ * expose them as parameters; their gradient is written as zero) -- and the first-layer kernels take the rows as they are (mean 0,
+ * 1/std 1): x * 1 + 0 is exact, so every other kernel and the weight-gradient identities run unchanged. Recurrent QMIX / VDN nets. */
+#define OPE_DIMS_NO_FEATURE_NORM 1
 
 /* Seven per-episode fields, in the order of RecPolicyBuffer.sample_inds' return tuple
  * (offpolicy/utils/rec_buffer.py:192-240): obs, share_obs, acts, rewards, dones, dones_env, avail_acts -- plus the
@@ -224,7 +230,7 @@ typedef struct ope_qmix_cfg {
   int32_t trunk_path;   /* forward trunk of the live + target agent nets: 0 = by shape; 3 = one trunk_fwd3 launch per net (weights in
                          *  registers, four waves per 16-row tile); 4 = both nets in one trunk_fwd4 launch (weights in LDS, one wave per
                          *  tile; recurrent nets whose input width is a multiple of 4 in (48, 64], (112, 128], (176, 192] or (240, 256] -- what "by shape"
-                         *  picks from 16 384 rows on; other widths run path 3)                    */
+                         *  picks from 2 048 rows on (the adjoint from 16 384); other widths run path 3)                    */
   int32_t chain_path;   /* the (t, b)-row chain between the GRU scan and its adjoint: 0 = by shape; 1 = four launches (head_fwd, mixer_fwd,
                          *  mixer_bwd, head_bwd); 2 = two launches (mixer_hyp: the mixers' first hyper-layers, a GEMM on the state alone, +
                          *  qchain: heads, second mixer stage, TD / loss, mixer and head adjoints; ope_chain.hip): whole steps (phase 0) of
@@ -295,7 +301,7 @@ int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields* batch, con
  * same arithmetic on the same values, so the gradient is bit-identical to the gathered form. Only the configurations whose first-layer
  * kernels read rows through an index can do it -- ope_qmix_obs_ref_ok(cfg) = 1: recurrent nets, phase 0, obs_dim % 4 == 0 with
  * ceil(obs_dim / 16) in {4, 8, 12, 16}, state_dim % 4 == 0, batch <= 512, (T+1) N batch < 2^20 rows, and the LDS-resident trunk kernel
- * selected (trunk_path 4, or 0 with >= 16 384 rows) -- everything else returns OPE_EINVAL (the caller gathers obs instead). */
+ * selected (trunk_path 4, or 0 with >= 2 048 rows) -- everything else returns OPE_EINVAL (the caller gathers obs instead). */
 int ope_qmix_obs_ref_ok(const ope_qmix_cfg* cfg);
 int ope_qmix_loss_and_grad_ref(const ope_qmix_cfg* cfg, const ope_fields* batch, const ope_obs_ref* obs, const float* theta,
                                const float* theta_tgt, const float* per_weights, void* workspace, int64_t workspace_bytes,

@@ -27,7 +27,10 @@ class OpeError(RuntimeError):
 
 class Dims(C.Structure):
     _fields_ = [("n_agents", C.c_int32), ("act_dim", C.c_int32), ("obs_dim", C.c_int32), ("state_dim", C.c_int32),
-                ("episode_length", C.c_int32), ("layer_N", C.c_int32)]
+                ("episode_length", C.c_int32), ("layer_N", C.c_int32), ("flags", C.c_int32)]
+
+
+OPE_DIMS_NO_FEATURE_NORM = 1
 
 
 class Fields(C.Structure):

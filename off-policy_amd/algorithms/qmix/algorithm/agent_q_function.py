@@ -29,12 +29,20 @@ AGENT_PARAM_NAMES = [
 
 
 def agent_param_names(layer_N=1):
-    """named_parameters() of AgentQFunction with `layer_N` hidden blocks behind fc1 (mlp.py:14-28: fc2 = layer_N clones of fc_h)."""
+    """The tensors of the flat agent block, in layout order: named_parameters() of AgentQFunction with `layer_N` hidden blocks behind
+    fc1 (mlp.py:14-28: fc2 = layer_N clones of fc_h). With use_feature_normalization = False the first two slots hold constants and are
+    not parameters (exposed_agent_names)."""
     if layer_N == 1:
         return list(AGENT_PARAM_NAMES)
     i = AGENT_PARAM_NAMES.index("rnn.rnn.rnn.weight_ih_l0")
     extra = ["rnn.mlp.fc2.%d.%s" % (b, t) for b in range(1, layer_N) for t in ("0.weight", "0.bias", "2.weight", "2.bias")]
     return AGENT_PARAM_NAMES[:i] + extra + AGENT_PARAM_NAMES[i:]
+
+
+def exposed_agent_names(layer_N=1, feature_norm=True):
+    """named_parameters() as the reference's module has them: without rnn.feature_norm.* when MLPBase has no input LayerNorm
+    (mlp.py:60-62)."""
+    return [k for k in agent_param_names(layer_N) if feature_norm or not k.startswith("rnn.feature_norm.")]
 
 
 def agent_param_shapes(obs_dim, act_dim, layer_N=1):
@@ -44,7 +52,8 @@ def agent_param_shapes(obs_dim, act_dim, layer_N=1):
 
 
 def agent_layout(obs_dim, act_dim, layer_N=1):
-    """(offsets, sizes, padded_total) of the agent block, from the library (single source of truth)."""
+    """(offsets, sizes, padded_total) of the agent block, from the library (single source of truth). The layout does not depend on
+    use_feature_normalization: the two feature_norm slots stay (OPE_DIMS_NO_FEATURE_NORM, ope.h)."""
     cfg = _lib.QmixCfg()
     cfg.dims = _lib.Dims(1, act_dim, obs_dim, 1, 1, layer_N)
     cfg.batch = 1
@@ -91,20 +100,27 @@ class AgentQFunction(FlatModule):
         self.layer_N = int(getattr(args, "layer_N", 1))
         if self.layer_N not in (1, 2):
             raise NotImplementedError("ope kernels support layer_N = 1 or 2 (got %r)" % self.layer_N)
+        self.feature_norm = bool(getattr(args, "use_feature_normalization", True))
         offs, sizes, total = agent_layout(input_dim, act_dim, self.layer_N)
         own = flat is None
         if own:
             flat = torch.zeros(total, dtype=torch.float32, device=device)
-        super().__init__(agent_param_names(self.layer_N), agent_param_shapes(input_dim, act_dim, self.layer_N), offs, flat)
+        names, shapes = agent_param_names(self.layer_N), agent_param_shapes(input_dim, act_dim, self.layer_N)
+        keep = [i for i, k in enumerate(names) if self.feature_norm or not k.startswith("rnn.feature_norm.")]
+        super().__init__([names[i] for i in keep], [shapes[i] for i in keep], [offs[i] for i in keep], flat)
+        if not self.feature_norm:      # the two slots the kernels still read: gamma = 1, beta = 0, never trained (ope.h, OPE_DIMS_NO_FEATURE_NORM)
+            with torch.no_grad():
+                flat[offs[0]:offs[0] + input_dim] = 1.0
+                flat[offs[1]:offs[1] + input_dim] = 0.0
         self.input_dim, self.act_dim, self.hidden_size, self.device = input_dim, act_dim, H, device
         self.padded_numel = total
         self._args = args
         if own and _init:
             vals = init_agent_values(input_dim, act_dim, getattr(args, "use_orthogonal", True),
                                      getattr(args, "gain", 0.01), getattr(args, "use_ReLU", True), self.layer_N)
-            for p, v in zip(self.parameters(), vals):
+            for p, v in zip(self.parameters(), [vals[i] for i in keep]):
                 p.data.copy_(v)
-        self._dims = _lib.Dims(1, act_dim, input_dim, 1, 1, self.layer_N)
+        self._dims = _lib.Dims(1, act_dim, input_dim, 1, 1, self.layer_N, 0 if self.feature_norm else _lib.OPE_DIMS_NO_FEATURE_NORM)
         self._ws = None
 
     def twin(self, flat):

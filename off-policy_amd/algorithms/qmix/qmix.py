@@ -55,8 +55,9 @@ class QMix(object):
         self.args = args
         # (the policies check their own support); one-layer hyper-networks: recurrent nets, one shared policy (checked below)
         require_reference_architecture(args, allow_prev_act_inp=not self._mlp, allow_hypernet_layers_1=not self._mlp and not vdn,
-                                       allow_layer_N_2=not self._mlp)
+                                       allow_layer_N_2=not self._mlp, allow_no_feature_norm=not self._mlp)
         self.layer_N = int(getattr(args, "layer_N", 1))
+        self.dims_flags = 0 if getattr(args, "use_feature_normalization", True) else _lib.OPE_DIMS_NO_FEATURE_NORM
         self.hypernet_layers = int(getattr(args, "hypernet_layers", 2)) if not vdn else 2
         self.use_popart = getattr(args, "use_popart", False)
         self.use_value_active_masks = getattr(args, "use_value_active_masks", False)
@@ -88,8 +89,10 @@ class QMix(object):
         self._ws = {}
         self._ws_multi = {}
         self._gsq = {}
-        if self.multi and (self.hypernet_layers == 1 or self.layer_N != 1):
-            raise NotImplementedError("hypernet_layers=1 / layer_N=2 with several policies is not on the accelerated path")
+        if self.multi and (self.hypernet_layers == 1 or self.layer_N != 1 or self.dims_flags):
+            raise NotImplementedError("hypernet_layers=1 / layer_N=2 / use_feature_normalization=False with several policies is not on the accelerated path")
+        if self.dims_flags and float(getattr(args, "weight_decay", 0.0) or 0.0) != 0.0:
+            raise NotImplementedError("use_feature_normalization=False with weight_decay: the constant feature_norm slots of the flat vector would decay")
         if self.multi:
             self._init_multi()
             if args.use_double_q:
@@ -97,7 +100,7 @@ class QMix(object):
             return
         policy = self.policies["policy_0"]
         # the kernels see the network's input width: observation (+ previous one-hot action with prev_act_inp)
-        self._dims = _lib.Dims(num_agents, policy.act_dim, policy.q_network_input_dim, policy.central_obs_dim, self.episode_length, self.layer_N)
+        self._dims = _lib.Dims(num_agents, policy.act_dim, policy.q_network_input_dim, policy.central_obs_dim, self.episode_length, self.layer_N, self.dims_flags)
 
         # ---- flat vectors: [agent | mixer], padded per tensor to 4 floats -------------------------------
         cfg = self._cfg(1)

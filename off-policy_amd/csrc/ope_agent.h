@@ -47,6 +47,7 @@ struct TrunkFwdArgs {
   float* xhat2;
   float* rstd2;
   uint64_t* mask2;
+  int no_fn;           // OPE_DIMS_NO_FEATURE_NORM: rows enter fc1 as they are (statistics forced to mean 0, 1/std 1; theta holds gamma = 1, beta = 0)
   // observations left in the store (trunk_fwd4 only): x = the store's obs ring, local row r is batch row ref_row0 + r
   ObsRef ref;
   int ref_row0;
@@ -156,6 +157,7 @@ int launch_block_bwd(const BlockBwdArgs& a, hipStream_t st);
 
 // allow4 = false: never the LDS-resident kernel (ope_trunk4.hip) -- the pair launcher's own fall-back, and tests that pin a family
 int launch_trunk_fwd(const TrunkFwdArgs& a, bool save, hipStream_t st, bool allow4 = true);
+int trunk4_pair_min_rows();      // rows from which "by shape" picks trunk_fwd4 for the live + target pair (ope_trunk4.hip)
 int launch_trunk_fwd4_single(const TrunkFwdArgs& a, bool save, hipStream_t st);      // OPE_OK / error, or 1 = not this kernel's launch
 // live (saving) + target trunk of the same input rows: one launch of trunk_fwd4 (ope_trunk4.hip) when the shape allows, else two launches
 int launch_trunk_fwd_pair(const TrunkFwdArgs& live, const TrunkFwdArgs& tgt, int path, hipStream_t st);

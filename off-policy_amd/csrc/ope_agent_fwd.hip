@@ -77,8 +77,8 @@ __global__ void __launch_bounds__(256) trunk_fwd_kernel(TrunkFwdArgs a) {
     for (int t = 0; t < RT; ++t) {
       const float m = rowsum4(s1[t]) / (float)D;
       const float var = fmaxf(rowsum4(s2[t]) / (float)D - m * m, 0.f);
-      mu[t] = sh[t] + m;
-      rstd[t] = 1.0f / sqrtf(var + OPE_LN_EPS);
+      mu[t] = a.no_fn ? 0.f : sh[t] + m;
+      rstd[t] = a.no_fn ? 1.0f : 1.0f / sqrtf(var + OPE_LN_EPS);
       if (SAVE && valid[t] && g == 0) {
         a.mu0[row[t]] = mu[t];
         a.rstd0[row[t]] = rstd[t];

@@ -26,6 +26,8 @@ bool cfg_ok(const ope_qmix_cfg* c) {
   if (c->chain_path < 0 || c->chain_path > 2) return false;
   if (c->hypernet_layers < 0 || c->hypernet_layers > 2) return false;
   if (d.layer_N < 0 || d.layer_N > 2) return false;
+  if (d.flags & ~OPE_DIMS_NO_FEATURE_NORM) return false;
+  if ((d.flags & OPE_DIMS_NO_FEATURE_NORM) && c->mlp) return false;      // no input LayerNorm: the recurrent nets
   if (d.layer_N == 2 && (c->mlp || c->phase != 0 || c->time_chunks > 1)) return false;      // a second hidden block: whole steps of recurrent nets
   if (c->hypernet_layers == 1 && (c->mlp || c->phase != 0 || c->mixer_path == 3 || c->chain_path == 1)) return false;   // one-layer hyper-networks: the fused chain only
   return d.n_agents >= 1 && d.act_dim >= 1 && d.obs_dim >= 1 && d.obs_dim <= 512 && d.state_dim >= 1 &&
@@ -361,7 +363,7 @@ static bool obs_ref_cfg_ok(const ope_qmix_cfg* cfg) {
   const int64_t R = (int64_t)(d.episode_length + 1) * d.n_agents * cfg->batch;
   static const int t4 = getenv("OPE_TRUNK4") ? atoi(getenv("OPE_TRUNK4")) : 1;
   return d.obs_dim % 4 == 0 && (KC == 4 || KC == 8 || KC == 12 || KC == 16) && d.state_dim % 4 == 0 && cfg->batch <= kObsRefMaxB &&
-         R < kObsRefMaxRows && (cfg->trunk_path == 4 || (cfg->trunk_path == 0 && t4 && R >= 16 * 1024 && cfg->time_chunks <= 1));
+         R < kObsRefMaxRows && (cfg->trunk_path == 4 || (cfg->trunk_path == 0 && t4 && R >= trunk4_pair_min_rows() && cfg->time_chunks <= 1));
 }
 extern "C" int ope_qmix_obs_ref_ok(const ope_qmix_cfg* cfg) { return obs_ref_cfg_ok(cfg) ? 1 : 0; }
 
@@ -466,6 +468,7 @@ static int qmix_step(const ope_qmix_cfg* cfg, const ope_fields* batch, const ope
     memset(&tf, 0, sizeof(tf));
     tf.x = oref ? obs_rows : obs_rows + r0 * p.D; tf.R = (int)rows; tf.D = p.D; tf.theta = theta; tf.L = p.AL;
     tf.ref = ref; tf.ref_row0 = (int)r0;
+    tf.no_fn = (cfg->dims.flags & OPE_DIMS_NO_FEATURE_NORM) ? 1 : 0;
     tf.gi = p.mlp ? nullptr : W + p.gi + r0 * 3 * OPE_H; tf.a2_out = p.mlp ? W + p.h + r0 * OPE_H : nullptr;
     if (p.layerN == 2) { tf.gi = nullptr; tf.a2_out = W + p.a2 + r0 * OPE_H; }      // the trunk stops at the first block's output; ope_block.hip continues
     tf.mu0 = W + p.mu0 + r0; tf.rstd0 = W + p.rstd0 + r0;
@@ -741,8 +744,13 @@ static int qmix_step(const ope_qmix_cfg* cfg, const ope_fields* batch, const ope
   if (phase == 2) {
     seg(0, L.end, FIN_SKIP, 0, 0, 0, 0, 0, 0, 0);   // the agent block belongs to the per-policy backward calls
   } else {
-    seg(L.fn_w, p.D, FIN_LNLIN_G, rw.P1, rw.s1, OPE_H, p.D, L.fc1_w, 0, 0);
-    seg(L.fn_b, p.D, FIN_LNLIN_B, rw.P1, rw.s1, OPE_H, p.D, L.fc1_w, 0, 0);
+    if (cfg->dims.flags & OPE_DIMS_NO_FEATURE_NORM) {      // the constant ones / zeros in the feature_norm slots are not parameters: zero gradient
+      seg(L.fn_w, p.D, FIN_ZERO, 0, 0, 0, 0, 0, 0, 0);
+      seg(L.fn_b, p.D, FIN_ZERO, 0, 0, 0, 0, 0, 0, 0);
+    } else {
+      seg(L.fn_w, p.D, FIN_LNLIN_G, rw.P1, rw.s1, OPE_H, p.D, L.fc1_w, 0, 0);
+      seg(L.fn_b, p.D, FIN_LNLIN_B, rw.P1, rw.s1, OPE_H, p.D, L.fc1_w, 0, 0);
+    }
     seg(L.fc1_w, OPE_H * p.D, FIN_LNLIN_W, rw.P1, rw.s1, OPE_H, p.D, L.fc1_w, L.fn_w, L.fn_b);
     seg(L.fc1_b, OPE_H, FIN_COPY, rw.s1, 0, 0, 0, 0, 0, 0);
     seg(L.ln1_w, OPE_H, FIN_LNLIN_G, rw.P2, rw.s2, OPE_H, OPE_H, L.fc2_w, 0, 0);
@@ -824,6 +832,7 @@ extern "C" int ope_agent_forward(const ope_dims* d, int32_t seq_len, int32_t row
   TrunkFwdArgs tf;
   memset(&tf, 0, sizeof(tf));
   tf.x = obs; tf.R = (int)R; tf.D = d->obs_dim; tf.theta = theta; tf.L = L; tf.gi = gi;
+  tf.no_fn = (d->flags & OPE_DIMS_NO_FEATURE_NORM) ? 1 : 0;
   if (L.layer_N == 2) { tf.gi = nullptr; tf.a2_out = gi + R * 3 * OPE_H; }      // the trunk stops at the first block; ope_block.hip continues
   if ((rc = launch_trunk_fwd(tf, false, st))) return rc;
   if (L.layer_N == 2) {
@@ -854,7 +863,7 @@ extern "C" int ope_agent_forward_mlp(const ope_dims* d, int32_t rows, const floa
                                      int64_t workspace_bytes, float* q_out, void* stream) {
   (void)hipGetLastError();
   if (!d || rows < 1 || !obs || !theta || !workspace || !q_out) return OPE_EINVAL;
-  if (d->obs_dim < 1 || d->obs_dim > 512 || d->act_dim < 1) return OPE_EINVAL;
+  if (d->obs_dim < 1 || d->obs_dim > 512 || d->act_dim < 1 || d->flags) return OPE_EINVAL;
   if (workspace_bytes < ope_agent_forward_mlp_workspace_bytes(d, rows)) return OPE_ENOSPC;
   hipStream_t st = (hipStream_t)stream;
   const AgentLayout L = ope_agent_layout_mlp(d->obs_dim, d->act_dim, 0);

@@ -442,6 +442,7 @@ static int ddpg_cfg_ok(const ope_ddpg_cfg* c) {
   if (!c) return 0;
   const ope_dims& d = c->dims;
   if (d.n_agents < 1 || d.n_agents > 64 || d.act_dim < 1 || d.act_dim > 64 || d.obs_dim < 1 || d.obs_dim > 512 || d.state_dim < 1) return 0;
+  if (d.layer_N > 1 || d.flags) return 0;      // the non-default network shapes (a second hidden block, no input LayerNorm) exist for the Q-learning nets only
   const int nt = c->n_total_agents > 0 ? c->n_total_agents : d.n_agents;
   if (c->n_total_agents < 0 || c->agent_offset < 0 || c->agent_offset + d.n_agents > nt || nt > 64) return 0;
   if (c->n_total_agents <= 0 && c->agent_offset != 0) return 0;

@@ -361,6 +361,7 @@ static int rddpg_cfg_ok(const ope_rddpg_cfg* c) {
   if (!c) return 0;
   const ope_dims& d = c->dims;
   if (d.n_agents < 1 || d.n_agents > 64 || d.act_dim < 1 || d.act_dim > 64 || d.obs_dim < 1 || d.obs_dim > 512 || d.state_dim < 1) return 0;
+  if (d.layer_N > 1 || d.flags) return 0;      // the non-default network shapes (a second hidden block, no input LayerNorm) exist for the Q-learning nets only
   if (d.state_dim + d.n_agents * d.act_dim > 1024 || d.episode_length < 1) return 0;
   if (c->n_total_agents != 0 && (c->n_total_agents < d.n_agents || c->agent_offset < 0 || c->agent_offset + d.n_agents > c->n_total_agents ||
                                  d.state_dim + c->n_total_agents * d.act_dim > 1024 || c->n_total_agents > 64)) return 0;

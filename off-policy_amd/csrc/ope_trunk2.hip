@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(256) trunk_fwd2_kernel(TrunkFwdArgs a, int Dp)
       for (int q = 0; q < NR; ++q) mean[q] += __shfl_xor(mean[q], o, 64);
 #pragma unroll
     for (int q = 0; q < NR; ++q) {
-      mean[q] /= (float)D;
+      mean[q] = a.no_fn ? 0.f : mean[q] / (float)D;
       float sq = 0.f;
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(256) trunk_fwd2_kernel(TrunkFwdArgs a, int Dp)
         }
         continue;
       }
-      rstd[q] = 1.0f / sqrtf(rstd[q] / (float)D + OPE_LN_EPS);
+      rstd[q] = a.no_fn ? 1.0f : 1.0f / sqrtf(rstd[q] / (float)D + OPE_LN_EPS);
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
         const int k = lane + 64 * i;
@@ -484,7 +484,7 @@ static int launch_rep(const TrunkFwdArgs& base, const TrunkFwdArgs& a0, float* s
 }
 
 int launch_trunk_fwd_rep(const TrunkFwdArgs& base, const TrunkFwdArgs& a, float* scratch, hipStream_t st) {
-  if (base.R < 1 || a.R < 1 || base.D < 1 || base.D > 512 || !scratch) return OPE_EINVAL;
+  if (base.R < 1 || a.R < 1 || base.D < 1 || base.D > 512 || !scratch || base.no_fn || a.no_fn) return OPE_EINVAL;
   const int vec = ope_vec_of(base.D);
   if (vec == 4) return launch_rep<4>(base, a, scratch, st);
   if (vec == 2) return launch_rep<2>(base, a, scratch, st);
@@ -708,7 +708,7 @@ __global__ void __launch_bounds__(256, 2) trunk_fwd3_kernel(TrunkFwdArgs a) {
         xv[i] = mask4(xv[i], 4 * c + 64 * i, D);
         s += (xv[i][0] + xv[i][1]) + (xv[i][2] + xv[i][3]);
       }
-      const float mean = row16_sum(s) / (float)D;
+      const float mean = a.no_fn ? 0.f : row16_sum(s) / (float)D;
       if (PF) {   // xraw rows of this wave are in registers now: refill them with the next tile's
         const int nxt = tile + (int)gridDim.x;
         if (nxt < ntiles) request_rows(nxt);
@@ -724,7 +724,7 @@ __global__ void __launch_bounds__(256, 2) trunk_fwd3_kernel(TrunkFwdArgs a) {
           sq = fmaf(d, d, sq);
         }
       }
-      const float rstd = 1.0f / sqrtf(row16_sum(sq) / (float)D + OPE_LN_EPS);
+      const float rstd = a.no_fn ? 1.0f : 1.0f / sqrtf(row16_sum(sq) / (float)D + OPE_LN_EPS);
 #pragma unroll
       for (int i = 0; i < NI4; ++i) {
         const int k = 4 * c + 64 * i;

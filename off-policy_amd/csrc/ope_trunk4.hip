@@ -60,6 +60,7 @@ struct TrunkPairArgs {
   int fn_w, fn_b, fc1_w, fc1_b, ln1_w, ln1_b, fc2_w, fc2_b, ln2_w, ln2_b, wih, bih;
   float* mu0; float* rstd0; float* xhat1; float* rstd1; float* mu1; uint64_t* mask1; float* xhat2; float* rstd2; uint64_t* mask2;
   long long* dbg;
+  int no_fn;                      // no input LayerNorm (OPE_DIMS_NO_FEATURE_NORM)
   int save0;                      // net 0 writes the saves (a single-net launch of a target / rollout net does not)
   ObsRef ref; int ref_tn0;        // LAZY instantiation: x = the store's obs ring; first (t, agent) index of the launch's row range
 };
@@ -316,7 +317,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) trunk_fwd4_kernel(TrunkPairAr
     if (VEC == 2 && !tail_ok1) { xv[KCM - 1][2] = 0.f; xv[KCM - 1][3] = 0.f; }
 #pragma unroll
     for (int c = 0; c < KCM; ++c) s += (xv[c][0] + xv[c][1]) + (xv[c][2] + xv[c][3]);
-    const float mean = rowsum4(s) * inv_d;
+    const float mean = a.no_fn ? 0.f : rowsum4(s) * inv_d;
     float sq = 0.f;
 #pragma unroll
     for (int c = 0; c < KCM; ++c) {
@@ -327,7 +328,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) trunk_fwd4_kernel(TrunkPairAr
         sq = fmaf(d, d, sq);
       }
     }
-    const float rstd = __builtin_amdgcn_rsqf(fmaf(rowsum4(sq), inv_d, OPE_LN_EPS));
+    const float rstd = a.no_fn ? 1.0f : __builtin_amdgcn_rsqf(fmaf(rowsum4(sq), inv_d, OPE_LN_EPS));
     if (save && valid && g == 0) {
       a.mu0[row] = mean;
       a.rstd0[row] = rstd;
@@ -459,6 +460,15 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) trunk_fwd4_kernel(TrunkPairAr
   if (dbg && lane == 0) dbg[8] = done;
 }
 
+// Rows from which "by shape" picks the pair launch. Round 4: 2 048 (it was 16 384, "a few tiles per SIMD"): one launch with the weights
+// staged in LDS also beats the two register-resident launches when most waves get no tile at all -- 3m batch 32 (5 856 rows): 12.8 us
+// against 11.6 + 10.0 us, step 0.1387 -> 0.1305 ms; 3s5z batch 8 (9 664 rows): 27.4 against 17.5 + 15.7 us. (The adjoint kernel keeps its
+// 16 384: trunk_bwd4 9.3 us against trunk_bwd3 7.9 us at 3m.) OPE_TRUNK4_MINROWS overrides.
+int trunk4_pair_min_rows() {
+  static const int v = getenv("OPE_TRUNK4_MINROWS") ? atoi(getenv("OPE_TRUNK4_MINROWS")) : 2048;
+  return v;
+}
+
 // Both nets' trunks in one launch when the shape allows it (recurrent nets, D <= 256, enough rows to give every SIMD of the chip a few
 // tiles); otherwise the two trunk_fwd3 / trunk_fwd2 launches.
 int launch_trunk_fwd_pair(const TrunkFwdArgs& live, const TrunkFwdArgs& tgt, int path, hipStream_t st) {
@@ -466,10 +476,10 @@ int launch_trunk_fwd_pair(const TrunkFwdArgs& live, const TrunkFwdArgs& tgt, int
   // Process default of "by shape": OPE_TRUNK4 = 1 | 0 (read once).
   static const int on = getenv("OPE_TRUNK4") ? atoi(getenv("OPE_TRUNK4")) : 1;
   const int KC = (live.D + 15) >> 4;
-  const bool can = live.gi && tgt.gi && !live.a2_out && !tgt.a2_out && live.D == tgt.D && live.R == tgt.R && live.x == tgt.x &&
+  const bool can = live.gi && tgt.gi && !live.a2_out && !tgt.a2_out && live.D == tgt.D && live.R == tgt.R && live.x == tgt.x && live.no_fn == tgt.no_fn &&
                    ((live.D % 4 == 0 && (KC == 4 || KC == 8 || KC == 12 || KC == 16)) || (live.D % 2 == 0 && KC == 24)) && live.xhat1 && live.mu0 && live.rstd0 && live.rstd1 && live.mask1 && live.xhat2 && live.rstd2 && live.mask2;
   if (path == 4 && !can) return OPE_EINVAL;      // an explicit request the shape does not allow: no silent fall-back (tests pin kernels by path)
-  const bool ok = can && (path == 4 || (path == 0 && on && live.R >= 16 * 1024));
+  const bool ok = can && (path == 4 || (path == 0 && on && live.R >= trunk4_pair_min_rows()));
   const bool lazy = live.ref.inds != nullptr;
   if (lazy && (!ok || KC == 24 || live.ref.B < 1 || live.ref.B > kObsRefMaxB || live.R % live.ref.B != 0 || live.ref_row0 % live.ref.B != 0 || live.ref.cap < 1))
     return OPE_EINVAL;                           // only this kernel reads rows from the store (ope_qmix_obs_ref_ok tells the caller beforehand)
@@ -487,6 +497,7 @@ int launch_trunk_fwd_pair(const TrunkFwdArgs& live, const TrunkFwdArgs& tgt, int
   pa.mu0 = live.mu0; pa.rstd0 = live.rstd0; pa.xhat1 = live.xhat1; pa.rstd1 = live.rstd1; pa.mu1 = live.mu1; pa.mask1 = live.mask1;
   pa.xhat2 = live.xhat2; pa.rstd2 = live.rstd2; pa.mask2 = live.mask2;      // the target net saves nothing
   pa.dbg = live.dbg;
+  pa.no_fn = live.no_fn;
   pa.save0 = 1;
   pa.ref = live.ref; pa.ref_tn0 = lazy ? live.ref_row0 / live.ref.B : 0;
   static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256; return n > 1 ? n : 256; }();
@@ -532,6 +543,7 @@ int launch_trunk_fwd4_single(const TrunkFwdArgs& a, bool save, hipStream_t st) {
   pa.fn_w = L.fn_w; pa.fn_b = L.fn_b; pa.fc1_w = L.fc1_w; pa.fc1_b = L.fc1_b; pa.ln1_w = L.ln1_w; pa.ln1_b = L.ln1_b;
   pa.fc2_w = L.fc2_w; pa.fc2_b = L.fc2_b; pa.ln2_w = L.ln2_w; pa.ln2_b = L.ln2_b; pa.wih = L.wih; pa.bih = L.bih;
   pa.save0 = save ? 1 : 0;
+  pa.no_fn = a.no_fn;
   if (save) {
     pa.mu0 = a.mu0; pa.rstd0 = a.rstd0; pa.xhat1 = a.xhat1; pa.rstd1 = a.rstd1; pa.mu1 = a.mu1; pa.mask1 = a.mask1;
     pa.xhat2 = a.xhat2; pa.rstd2 = a.rstd2; pa.mask2 = a.mask2;

@@ -128,6 +128,7 @@ def run_case(name, dims, n_episodes, inds, steps=3, argv=(), vdn=False, avail="o
     out["hp_same_share"] = np.int64(not per_agent_share)
     out["hp_soft_update"], out["hp_gain"] = np.int64(bool(args.use_soft_update)), np.float64(args.gain)
     out["hp_hidden_size"], out["hp_layer_N"], out["hp_hypernet_layers"] = np.int64(args.hidden_size), np.int64(args.layer_N), np.int64(args.hypernet_layers)
+    out["hp_feature_norm"] = np.int64(bool(args.use_feature_normalization))
     out["hard_update_after"] = np.asarray(list(hard_update_after), dtype=np.int64)
     losses, gnorms, qtots, prios = [], [], [], []
     for s in range(steps):
@@ -237,6 +238,21 @@ def main():
         # round 4: the MMM2 observation width (D = 370: 24 chunks, rows 8-byte aligned only) on a small batch, for the LDS-resident trunk
         # kernel's 24-chunk / 8-byte-load instantiation (trunk_fwd4<24>, csrc/ope_trunk4.hip); 56 rows = three full tiles + a partial one
         run_case("qmix_var_d370", EnvDims("var_d370", 2, 5, 370, 20, 6), n_episodes=5, inds=[4, 0, 2, 2], avail="bernoulli")
+        return
+    if os.environ.get("OPE_GOLDEN_ONLY") == "nofn":
+        # round 4 (tail): --use_feature_normalization (a store_false flag: no LayerNorm on the network input, mlp.py:60-62):
+        # the tiny shape, the 3s5z width (the LDS-resident trunk kernels), odd sizes + previous action + Huber + PER, VDN, and together with
+        # a second hidden block and one-layer hyper-networks
+        run_case("qmix_shape_nofn", tiny, n_episodes=5, inds=[3, 1, 4, 0], avail="bernoulli", argv=["--use_feature_normalization"])
+        run_case("qmix_var_nofn_d252", EnvDims("var_nofn_d252", 2, 5, 252, 20, 6), n_episodes=5, inds=[4, 0, 2, 2], avail="bernoulli",
+                 argv=["--use_feature_normalization"])
+        run_case("qmix_var_nofn_odd", EnvDims("var_nofn_odd", 3, 7, 18, 29, 5), n_episodes=6, inds=[5, 1, 1, 2, 0], avail="bernoulli",
+                 runner_padding=True, per_weights=np.array([1.0, 0.5, 0.25, 0.8, 0.9]),
+                 argv=["--use_feature_normalization", "--prev_act_inp", "--use_huber_loss", "--huber_delta", "1.0", "--use_per"])
+        run_case("qmix_var_nofn_layer2_hyper1", EnvDims("var_nofn_l2h1", 5, 6, 16, 100, 5), n_episodes=5, inds=[0, 1, 4, 4, 2], avail="bernoulli",
+                 runner_padding=True, argv=["--use_feature_normalization", "--layer_N", "2", "--hypernet_layers", "1"])
+        patch_vdn()
+        run_case("vdn_var_nofn", tiny, n_episodes=4, inds=[2, 1, 0, 3], avail="bernoulli", vdn=True, argv=["--use_feature_normalization"])
         return
     if os.environ.get("OPE_GOLDEN_ONLY") == "pershare":      # add the round-2 fixture without rewriting the committed ones
         run_case("qmix_tiny_pershare", tiny, n_episodes=5, inds=[4, 1, 1, 0, 2], cap=6, pre_insert=3, avail="bernoulli", per_agent_share=True)

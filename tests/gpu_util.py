@@ -18,6 +18,8 @@ def make_args(g, **over):
         a.gain, a.use_soft_update = float(g["hp_gain"]), bool(g["hp_soft_update"])
     if "hp_hypernet_layers" in g:      # network-shape flags (the engine supports hypernet_layers 1 | 2; the rest is refused loudly)
         a.hypernet_layers, a.layer_N, a.hidden_size = int(g["hp_hypernet_layers"]), int(g["hp_layer_N"]), int(g["hp_hidden_size"])
+    if "hp_feature_norm" in g:
+        a.use_feature_normalization = bool(g["hp_feature_norm"])
     for k, v in over.items():
         setattr(a, k, v)
     return a

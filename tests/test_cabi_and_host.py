@@ -131,6 +131,49 @@ def test_second_hidden_block_layout_and_initialisation_match_the_reference():
         require_reference_architecture(default_args(layer_N=3), allow_layer_N_2=True)
 
 
+def test_network_without_input_layernorm_keeps_the_layout_and_hides_two_slots():
+    """use_feature_normalization = False (mlp.py:60-62; round 4): the reference's module has no rnn.feature_norm.* parameters. The
+    C-ABI's flat layout is unchanged (OPE_DIMS_NO_FEATURE_NORM only tells the first-layer kernels to take the rows as they are); the
+    Python module exposes the reference's 20 names, initialises from the same RNG stream as the reference (fixture qmix_shape_nofn =
+    outputs of the real reference) and refuses what the flag cannot be combined with."""
+    import torch
+    from conftest import load_golden
+    from offpolicy_amd import _lib
+    from offpolicy_amd.config import default_args, require_reference_architecture
+    from offpolicy_amd.algorithms.qmix.algorithm.agent_q_function import init_agent_values, agent_param_names, exposed_agent_names, agent_layout
+    g = load_golden("qmix_shape_nofn")
+    n, a, d, s, t = [int(x) for x in g["dims"]]
+    assert int(g["hp_feature_norm"]) == 0
+    exposed = exposed_agent_names(1, feature_norm=False)
+    assert exposed == [k[len("agent/"):] for k in g if k.startswith("agent/")] and len(exposed) == 20
+    cfg = _lib.QmixCfg()
+    cfg.dims, cfg.batch = _lib.Dims(n, a, d, s, t, 1, _lib.OPE_DIMS_NO_FEATURE_NORM), 4
+    off, siz = (C.c_int64 * 48)(), (C.c_int64 * 48)()
+    total = _lib.lib.ope_qmix_param_layout(C.byref(cfg), off, siz)
+    cfg0 = _lib.QmixCfg()
+    cfg0.dims, cfg0.batch = _lib.Dims(n, a, d, s, t), 4
+    off0, siz0 = (C.c_int64 * 48)(), (C.c_int64 * 48)()
+    assert total == _lib.lib.ope_qmix_param_layout(C.byref(cfg0), off0, siz0) and list(off) == list(off0) and list(siz) == list(siz0)
+    assert _lib.lib.ope_qmix_workspace_bytes(C.byref(cfg)) > 0
+    torch.manual_seed(1)
+    np.random.seed(1)
+    av = init_agent_values(d, a)
+    for v, k in zip(av, agent_param_names(1)):
+        if not k.startswith("rnn.feature_norm."):
+            assert np.array_equal(v.numpy(), g["agent/" + k]), k
+    cfg.mlp, cfg.dims.episode_length = 1, 1
+    assert _lib.lib.ope_qmix_workspace_bytes(C.byref(cfg)) == -1              # the recurrent nets only
+    cfg.mlp, cfg.dims.episode_length, cfg.dims.flags = 0, t, 2
+    assert _lib.lib.ope_qmix_workspace_bytes(C.byref(cfg)) == -1              # unknown flag bits
+    dd = _lib.DdpgCfg()
+    dd.dims, dd.batch, dd.num_q = _lib.Dims(n, a, d, s, 1, 1, _lib.OPE_DIMS_NO_FEATURE_NORM), 4, 1
+    assert _lib.lib.ope_ddpg_workspace_bytes(C.byref(dd)) == -1                # the MADDPG families: refused
+    args = default_args(use_feature_normalization=False)
+    with pytest.raises(NotImplementedError):
+        require_reference_architecture(args)
+    require_reference_architecture(args, allow_no_feature_norm=True)
+
+
 def test_null_arguments_are_rejected_without_a_gpu():
     from offpolicy_amd import _lib
     assert _lib.lib.ope_adam_step(None, 4, None, None, None, None, None, None, None, None) == -1

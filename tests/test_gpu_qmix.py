@@ -19,7 +19,10 @@ CASES = ["qmix_tiny", "qmix_tiny_huber_per", "qmix_tiny_nodouble", "vdn_tiny", "
          "qmix_var_n10", "qmix_var_a20",       # 10 agents (two per wave of the fused chain kernel), 20 actions (two head tiles; plain-max targets)
          # one-layer hyper-networks (--hypernet_layers 1, q_mixer.py:39-44): the tiny shape fixture, 8 agents at S = 216, odd S + Huber + PER
          "qmix_shape_hyper1", "qmix_var_hyper1_mix", "qmix_var_hyper1_odd", "qmix_shape_layer2",
-         "qmix_var_layer2_d252", "qmix_var_layer2_hyper1", "qmix_var_layer2_odd", "vdn_var_layer2"]
+         "qmix_var_layer2_d252", "qmix_var_layer2_hyper1", "qmix_var_layer2_odd", "vdn_var_layer2",
+         # no input LayerNorm (--use_feature_normalization off, mlp.py:60-62): tiny, the 3s5z width, odd + prev-act + Huber + PER, with a second
+         # block and one-layer hyper-networks, VDN
+         "qmix_shape_nofn", "qmix_var_nofn_d252", "qmix_var_nofn_odd", "qmix_var_nofn_layer2_hyper1", "vdn_var_nofn"]
 RTOL = 1e-4
 
 
@@ -99,8 +102,9 @@ def test_every_scan_kernel_family_matches_reference(name, family, waves):
 # (fixture, trunk_path) pairs that CAN run: path 3 takes every width; path 4 (trunk_fwd4 / trunk_bwd4) needs an input width that is a
 # multiple of 4 with ceil(D / 16) in {4, 8, 12, 16}: D = 64 (3m), 124, 188, 252 (the 3s5z width: KCM 16 with a 12-float tail chunk) -- or an
 # even width with 24 chunks: D = 370, the MMM2 width (rows 8-byte aligned only, a 2-float tail, two W_ih tiles read from L2)
-TRUNK_CASES = [(n, 3) for n in ("qmix_tiny", "qmix_odd", "qmix_3m_katA", "qmix_tiny_prevact", "qmix_gall_3m", "qmix_tiny_huber_per", "qmix_var_d252", "qmix_var_d370")] + \
-              [(n, 4) for n in ("qmix_3m_katA", "qmix_gall_3m", "qmix_var_d124", "qmix_var_d188", "qmix_var_d252", "qmix_var_d370")]
+TRUNK_CASES = [(n, 3) for n in ("qmix_tiny", "qmix_odd", "qmix_3m_katA", "qmix_tiny_prevact", "qmix_gall_3m", "qmix_tiny_huber_per", "qmix_var_d252", "qmix_var_d370",
+                                 "qmix_var_nofn_d252")] + \
+              [(n, 4) for n in ("qmix_3m_katA", "qmix_gall_3m", "qmix_var_d124", "qmix_var_d188", "qmix_var_d252", "qmix_var_d370", "qmix_var_nofn_d252")]
 
 
 def _expect_trunk(dims, path):
@@ -406,7 +410,7 @@ def test_deterministic_bitwise():
     assert np.array_equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("name", ["qmix_tiny", "qmix_shape_layer2", "qmix_var_layer2_d252"])
+@pytest.mark.parametrize("name", ["qmix_tiny", "qmix_shape_layer2", "qmix_var_layer2_d252", "qmix_shape_nofn", "qmix_var_nofn_d252"])
 def test_policy_forward_matches_oracle_single_step_and_sequence(name):
     """policy.get_q_values (ope_agent_forward) with a non-zero initial hidden state; with one and with two hidden blocks (layer_N)."""
     from oracle import qmix_oracle as O
