@@ -72,10 +72,17 @@ __global__ void __launch_bounds__((W + 2) * 64) gru_fwd4_kernel(GruFwdArgs a) {
   // LDS (floats): h_t [2][64] | r, z, n, gh_n' of step t [2][4][64] | gate inputs of step t: gx [2][2][65] = x_r, x_z planes
   // (x = -log2(e) (gi + b_hh); entry 64 stays zero: the lanes that must not inject read it) | gn [2][64] = -2 log2(e) gi_n |
   // a dump area the lanes that hold no valid n / h write to (same offsets as the real ones, shifted by kDump)
-  constexpr int kHs = 0, kSv = 2 * OPE_H, kGx = 10 * OPE_H, kGxP = 2 * (OPE_H + 1) + 2, kGxZ = OPE_H + 1, kGn = kGx + 2 * kGxP, kDump = kGn + 2 * OPE_H;
-  __shared__ __attribute__((aligned(16))) float sm[kDump + 10 * OPE_H];
+  // Bank placement (round 4; PMC: 0.93 M SQ_LDS_BANK_CONFLICT cycles per launch in this kernel, none in the backward one). The LDS
+  // serves a ds_write half a wave at a time over 32 banks (measured: moving the planes by a multiple of 32 floats changes nothing, and
+  // a dump shift of 32 DOUBLED the count); half a wave holds 8 (W = 4) or 16 (W = 2) consecutive features. The r / z publish put z
+  // exactly 64 floats behind r: same bank for the same feature, 2-way on every step. Planes are now kPl = 80 floats apart (z lands 16
+  // banks beside r); the dump shift, 8 banks before, becomes 16 so that it clears the 16-feature half-wave of W = 2 as well.
+  constexpr int kPl = OPE_H + 16;
+  constexpr int kHs = 0, kSv = 2 * OPE_H, kGx = kSv + 8 * kPl, kGxP = 2 * (OPE_H + 1) + 2, kGxZ = OPE_H + 1, kGn = kGx + 2 * kGxP,
+                kDump = ((kGn + 2 * OPE_H + 63) / 64) * 64 + 16;
+  __shared__ __attribute__((aligned(16))) float sm[kDump + kSv + 8 * kPl];
   float(*hs)[OPE_H] = reinterpret_cast<float(*)[OPE_H]>(sm);                        // [2][64]    h_t, parity of t
-  float(*sv)[4][OPE_H] = reinterpret_cast<float(*)[4][OPE_H]>(sm + kSv);            // [2][4][64]
+  float(*sv)[4][kPl] = reinterpret_cast<float(*)[4][kPl]>(sm + kSv);                // [2][4][64 (+ 16 unused)]
   constexpr float kL = -1.4426950408889634f;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int rid = blockIdx.x;
@@ -189,7 +196,7 @@ __global__ void __launch_bounds__((W + 2) * 64) gru_fwd4_kernel(GruFwdArgs a) {
   // theirs to the dump area (their h stays a bounded mix of gate values and is never read).
   constexpr int kSwap = 0xB1;       // quad_perm [1,0,3,2]
   const bool even = (g & 1) == 0;
-  const int rz_off = kSv + (even ? 0 : OPE_H) + f;      // r from one side, z from the other: one ds_write
+  const int rz_off = kSv + (even ? 0 : kPl) + f;        // r from one side, z from the other: one ds_write
   const int val_off = f + (even ? 0 : kDump);
   if (g == 0) hs[0][f] = h;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -245,13 +252,13 @@ __global__ void __launch_bounds__((W + 2) * 64) gru_fwd4_kernel(GruFwdArgs a) {
     float u = mine + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, theirs), kSwap, 0xF, 0xF, true));
     u = group_sum_from<W>(u);
     const float y = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u));   // r (even lanes) | z (odd lanes)
-    sm[rz_off + 4 * p * OPE_H] = y;            // the saves leave as soon as they exist (r from one side, z from the other)
+    sm[rz_off + 4 * p * kPl] = y;              // the saves leave as soon as they exist (r from one side, z from the other)
     const f32x2 tn = an0 + an1;
     float sn = tn[0] + tn[1];
     const float an = group_sum<W>(sn);         // -2 log2(e) (W_hn h + b_hn), all lanes
-    sm[kSv + (4 * p + 3) * OPE_H + f] = an;
+    sm[kSv + (4 * p + 3) * kPl + f] = an;
     const float n = fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(y, an, gin2))), -1.0f);
-    sm[kSv + (4 * p + 2) * OPE_H + val_off] = n;
+    sm[kSv + (4 * p + 2) * kPl + val_off] = n;
     const float z = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y), kSwap, 0xF, 0xF, true));
     h = fmaf(z, h - n, n);                     // (1 - z) n + z h
     if (DBG) asm volatile("" : "+v"(h));
