@@ -388,6 +388,11 @@ typedef struct ope_ddpg_cfg {
   const float* joint_next_acts; /* DEVICE [B][n_total_agents * A] joint target action, filled by one ope_ddpg_target_actions call per
                                  * policy; when non-NULL the critic call skips its own target-actor pass (theta_actor_tgt, next_obs and
                                  * target_noise_u are then unused). Required when n_total_agents > dims.n_agents.                  */
+  int32_t continuous;           /* 1: Box action space (MADDPGPolicy.py:107-116): an action IS the actor's output (act_dim floats), the target
+                                 * action = target actor output + target_noise_u (here ADDITIVE noise, already scaled: gaussian_noise(shape,
+                                 * target_noise) of MATD3, util.py:217-218; NULL = none), the actor update differentiates straight through
+                                 * (gumbel_noise_u unused, may be NULL). No availability masks. General kernel path only. 0 = discrete. */
+  int32_t reserved0;
 } ope_ddpg_cfg;
 
 /* One sampled batch in MlpPolicyBuffer.sample_inds order/shapes (mlp_buffer.py:213-257), device pointers. */

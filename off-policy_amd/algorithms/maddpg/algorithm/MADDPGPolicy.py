@@ -1,6 +1,7 @@
 """MADDPG / MATD3 policy: actor + centralised critic (+ targets, optimizer state) on flat CUDA vectors.
 
-Mirror of offpolicy/algorithms/maddpg/algorithm/MADDPGPolicy.py:11-151 for discrete (one-hot) action spaces. The four
+Mirror of offpolicy/algorithms/maddpg/algorithm/MADDPGPolicy.py:11-151 for discrete (one-hot) and, round 4, continuous (Box) action
+spaces (an action = the actor's output, MADDPGPolicy.py:107-116; multi-discrete spaces are refused). The four
 networks are drawn in the reference's construction order (actor, critic, target actor, target critic) so equal seeds
 give equal weights -- including the target critic's own random Q heads, which upstream never synchronises (A-4).
 """
@@ -19,6 +20,11 @@ from .actor_critic import MADDPG_Actor, MADDPG_Critic, draw_actor_values, draw_c
 def sample_gumbel_uniform(shape):
     """The uniform draw inside sample_gumbel (util.py:178-181): CPU generator, torch.FloatTensor(*shape).uniform_()."""
     return torch.FloatTensor(*shape).uniform_()
+
+
+def gaussian_noise(shape, std):
+    """util.py:217-218: CPU generator, torch.empty(shape).normal_(mean=0, std=std)."""
+    return torch.empty(shape).normal_(mean=0, std=std)
 
 
 def onehot_from_logits(logits, avail=None):
@@ -48,7 +54,10 @@ class MADDPGPolicy(object):
         self.obs_space, self.act_space = policy_config["obs_space"], policy_config["act_space"]
         self.obs_dim, self.act_dim = get_dim_from_space(self.obs_space), get_dim_from_space(self.act_space)
         self.output_dim = self.act_dim
-        self.discrete, self.multidiscrete = True, False
+        kind = self.act_space.__class__.__name__
+        if "MultiDiscrete" in kind:
+            raise NotImplementedError("multi-discrete action spaces are not on the accelerated path")
+        self.discrete, self.multidiscrete = kind != "Box", False      # util.py:271-281 is_discrete / is_multidiscrete
         self.target_noise = target_noise
         self.td3 = bool(td3)
         self.num_q = 2 if td3 else 1
@@ -75,7 +84,8 @@ class MADDPGPolicy(object):
         cfg = _lib.DdpgCfg()
         cfg.dims = _lib.Dims(self.num_agents, self.act_dim, self.obs_dim, self.central_obs_dim, 1)
         cfg.batch, cfg.num_q = int(batch), self.num_q
-        cfg.target_gumbel = int(self.target_noise is not None)
+        cfg.continuous = int(not self.discrete)
+        cfg.target_gumbel = int(self.target_noise is not None and self.discrete)
         cfg.use_huber, cfg.use_per = int(bool(a.use_huber_loss)), int(bool(a.use_per))
         cfg.gamma, cfg.huber_delta, cfg.per_eps = float(a.gamma), float(a.huber_delta), float(a.per_eps)
         return cfg
@@ -85,6 +95,15 @@ class MADDPGPolicy(object):
         batch_size = obs.shape[0]
         eps = None
         actor_out = (self.target_actor if use_target else self.actor)(obs)
+        if not self.discrete:      # MADDPGPolicy.py:107-116
+            if explore:
+                actions = gaussian_noise(actor_out.shape, self.args.act_noise_std).to(actor_out.device) + actor_out
+            elif use_target and self.target_noise is not None:
+                assert isinstance(self.target_noise, float)
+                actions = gaussian_noise(actor_out.shape, self.target_noise).to(actor_out.device) + actor_out
+            else:
+                actions = actor_out
+            return actions, eps
         if use_gumbel or (use_target and self.target_noise is not None):
             actions = gumbel_softmax_hard(actor_out, available_actions, sample_gumbel_uniform(actor_out.shape))
         elif explore:
@@ -103,6 +122,8 @@ class MADDPGPolicy(object):
 
     def get_random_actions(self, obs, available_actions=None):
         batch_size = obs.shape[0]
+        if not self.discrete:      # MADDPGPolicy.py:135-136
+            return np.random.uniform(self.act_space.low, self.act_space.high, size=(batch_size, self.act_dim))
         logits = torch.ones(batch_size, self.act_dim)
         if available_actions is not None:
             logits[torch.as_tensor(np.asarray(available_actions)) == 0] = -1e10

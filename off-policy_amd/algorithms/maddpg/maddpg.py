@@ -105,6 +105,8 @@ class MADDPG(object):
             raise NotImplementedError("cent_train_policy_on_batch with several policies is not on the accelerated path")
         if policy.num_q != 1:
             raise NotImplementedError("cent_train_policy_on_batch with two critic heads (MATD3): upstream defines no rule for them (maddpg.py:295)")
+        if not policy.discrete:
+            raise NotImplementedError("cent_train_policy_on_batch with continuous actions is not on the accelerated path (no reference fixture pins it)")
         if getattr(self.args, "use_value_active_masks", False):
             raise NotImplementedError("cent_train_policy_on_batch with use_value_active_masks: upstream weights the critic loss by the valid-transition "
                                       "mask there (maddpg.py:314-317, 327-330); the accelerated path takes the plain mean over the N*B rows")
@@ -272,7 +274,15 @@ class MADDPG(object):
         else:
             draw = lambda shape: sample_gumbel_uniform(shape).to(self.device)
         override, self._noise_override = getattr(self, "_noise_override", None), None      # (target noise, actor noise) to use instead of drawing
+        if not policy.discrete:
+            # continuous actions (MADDPGPolicy.py:107-116): no gumbel anywhere; the target action carries additive gaussian noise when the
+            # policy has a target noise (MATD3), drawn here on the CPU generator in the reference's order and shape (util.py:217-218)
+            assert not self.device_noise and not self.multi_policy, "continuous actions: host noise, one shared policy"
+            from .algorithm.MADDPGPolicy import gaussian_noise
+            draw = lambda shape: None
         u_t = draw((N * B, policy.act_dim)) if (policy.target_noise is not None and not self.multi_policy) else None
+        if not policy.discrete and policy.target_noise is not None:
+            u_t = gaussian_noise((N * B, policy.act_dim), float(policy.target_noise)).to(self.device)
         dev_prio = torch.is_tensor(importance_weights)
         w = None
         if self.use_per:
@@ -327,6 +337,8 @@ class MADDPG(object):
     def make_graphed_step(self, buffer, batch_size, policy_id="policy_0", device_sampling=False, steps_per_replay=1):
         if self.multi_policy:
             raise NotImplementedError("graphed step: one shared policy only")
+        if not self.policies[policy_id].discrete:
+            raise NotImplementedError("graphed step: discrete action spaces (the continuous target noise is drawn on the host generator)")
         return self._make_graphed_step(buffer, batch_size, policy_id, device_sampling, steps_per_replay)
 
     def _make_graphed_step(self, buffer, batch_size, policy_id="policy_0", device_sampling=False, steps_per_replay=1):

@@ -33,6 +33,9 @@ class R_MADDPGPolicy(object):
         self.obs_dim, self.act_dim = get_dim_from_space(self.obs_space), get_dim_from_space(self.act_space)
         self.output_dim = self.act_dim
         self.hidden_size = a.hidden_size
+        if self.act_space.__class__.__name__ not in ("Discrete", "list", "int"):
+            raise NotImplementedError("recurrent MADDPG / MATD3 on the accelerated path: discrete (one-hot) action spaces only (got %s); "
+                                      "continuous actions are supported by the MLP family" % self.act_space.__class__.__name__)
         self.discrete, self.multidiscrete = True, False
         self.target_noise = target_noise
         self.td3 = bool(td3)

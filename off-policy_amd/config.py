@@ -16,7 +16,7 @@ DEFAULTS = dict(
     episode_length=80, use_reward_normalization=False, use_popart=False, use_per=False, per_nu=0.9, per_alpha=0.6,
     per_eps=1e-6, per_beta_start=0.4, use_value_active_masks=False, epsilon_start=1.0, epsilon_finish=0.05,
     epsilon_anneal_time=50000, use_same_share_obs=True, use_available_actions=True, share_policy=True,
-    train_interval_episode=1, actor_train_interval_step=2, target_action_noise_std=0.2,
+    train_interval_episode=1, actor_train_interval_step=2, target_action_noise_std=0.2, act_noise_std=0.1,
 )
 
 

@@ -31,6 +31,7 @@ struct ActGradArgs {
   const float* theta; int fc1_w, fc1_b, fn_w, fn_b;
   float* cvec;                               // [128] scratch: c_i = sum_k gamma_k W_ik ; cb_i = b_i + sum_k W_ik beta_k
   float* dlogits;                            // [R][A4]
+  int identity;                              // continuous actions: d action / d actor output = 1 (no gumbel-softmax adjoint; `y` unused)
 };
 int launch_action_grad(const ActGradArgs& a, hipStream_t st);
 

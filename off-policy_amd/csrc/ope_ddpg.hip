@@ -90,11 +90,12 @@ __global__ void __launch_bounds__(256) action_kernel(const float* __restrict__ l
     const int rr = (int)(((float)e + 0.5f) * invA), j = e - rr * A;
     float v = logits[base + e];
     if (mode == 1) v += -logf(-logf(U.at(r0 + rr, A, j) + 1e-20f) + 1e-20f);
-    if (avail && avail[base + e] == 0.f) v = -1e10f;
+    if (mode == 2 && U.u) v += U.u[base + e];      // continuous actions: the actor output (+ the caller's additive noise) is the action
+    if (mode != 2 && avail && avail[base + e] == 0.f) v = -1e10f;
     val[rr * pitch + j] = v;
   }
   __syncthreads();
-  if ((int)threadIdx.x < nrows) {
+  if (mode != 2 && (int)threadIdx.x < nrows) {
     float* vr = val + threadIdx.x * pitch;
     float* sr = soft + threadIdx.x * pitch;
     float mx = -3.0e38f;
@@ -121,7 +122,7 @@ __global__ void __launch_bounds__(256) action_kernel(const float* __restrict__ l
     const int rr = (int)(((float)e + 0.5f) * invA), j = e - rr * A;
     const float out = val[rr * pitch + j];
     if (act_out) act_out[base + e] = out;
-    if (soft_out) soft_out[base + e] = soft[rr * pitch + j];
+    if (soft_out && mode != 2) soft_out[base + e] = soft[rr * pitch + j];
     if (cent_nact) {
       const int r = r0 + rr;
       int t = (int)(((float)r + 0.5f) * invNB);        // exact for r < 2^24; corrected below for larger row counts
@@ -268,10 +269,10 @@ __global__ void __launch_bounds__(256) action_grad_kernel(ActGradArgs a) {
     const float dy = s * a.theta[a.fn_w + col0 + j];
     const float xh = (a.act[(int64_t)r * a.A + j] - mu0) * rs0;
     const float dx = rs0 * (dy - m1 - xh * m2);
-    dot = fmaf(dx, a.y[(int64_t)r * a.A + j], dot);
+    if (!a.identity) dot = fmaf(dx, a.y[(int64_t)r * a.A + j], dot);
     out[j] = dx;
   }
-  for (int j = 0; j < a.A4; ++j) out[j] = j < a.A ? a.y[(int64_t)r * a.A + j] * (out[j] - dot) : 0.f;
+  for (int j = 0; j < a.A4; ++j) out[j] = j < a.A ? (a.identity ? out[j] : a.y[(int64_t)r * a.A + j] * (out[j] - dot)) : 0.f;
 }
 
 // Same computation on the matrix pipe, for many rows: a wave owns 16 consecutive rows that share the agent copy (B % 16 == 0),
@@ -414,7 +415,8 @@ int launch_action_grad(const ActGradArgs& a, hipStream_t st) {
   // OPE_ACTGRAD = wave | mfma | thread forces a form (tests); default by size
   const char* f = getenv("OPE_ACTGRAD");
   const bool mfma_ok = a.B % 16 == 0 && a.A <= 32;
-  const int form = f ? (f[0] == 'w' ? 0 : (f[0] == 'm' && mfma_ok ? 1 : 2)) : (a.R <= 16384 ? 0 : (mfma_ok ? 1 : 2));
+  int form = f ? (f[0] == 'w' ? 0 : (f[0] == 'm' && mfma_ok ? 1 : 2)) : (a.R <= 16384 ? 0 : (mfma_ok ? 1 : 2));
+  if (a.identity) form = 2;      // continuous actions: the thread-per-row form carries the identity adjoint
   if (form == 0)   // few rows (MLP family): one wave per row, lane = hidden unit -- a 64-long serial chain per thread otherwise
     OPE_L(OPE_LAUNCH(action_grad_wave_kernel, dim3(ope_cdiv(a.R, 4)), dim3(256), 0, st, a));
   else if (form == 1) {
@@ -442,6 +444,8 @@ static int ddpg_cfg_ok(const ope_ddpg_cfg* c) {
   if (!c) return 0;
   const ope_dims& d = c->dims;
   if (d.n_agents < 1 || d.n_agents > 64 || d.act_dim < 1 || d.act_dim > 64 || d.obs_dim < 1 || d.obs_dim > 512 || d.state_dim < 1) return 0;
+  if (c->continuous != 0 && c->continuous != 1) return 0;
+  if (c->continuous && c->target_gumbel) return 0;      // continuous actions: the target noise is additive (target_noise_u), there is no gumbel
   if (d.layer_N > 1 || d.flags) return 0;      // the non-default network shapes (a second hidden block, no input LayerNorm) exist for the Q-learning nets only
   const int nt = c->n_total_agents > 0 ? c->n_total_agents : d.n_agents;
   if (c->n_total_agents < 0 || c->agent_offset < 0 || c->agent_offset + d.n_agents > nt || nt > 64) return 0;
@@ -488,7 +492,7 @@ static void ddpg_plan(const ope_ddpg_cfg* c, DdpgPlan* p) {
   p->mu1 = W.add("mu1", R); p->cvec = W.add("fc1_colsums", 2 * OPE_H); p->dlg = W.add("dlogits", Ra * p->A4);
   // second set of trunk saves for the actor's own backward (the critic pass of the actor step reuses the first set)
   p->err = W.add("saves2", Ra * (2 * OPE_H + 8));
-  p->fused = ddpg_fused_ok(p->N, p->A, p->D, p->S, p->K) && p->NT == p->N;   // (the tile kernels are the one-shared-policy form)
+  p->fused = ddpg_fused_ok(p->N, p->A, p->D, p->S, p->K) && p->NT == p->N && !c->continuous;   // (the tile kernels are the one-shared-policy, discrete-action form)
   p->fused_slabs = W.add("fused_slabs", p->fused ? ddpg_fused_slab_floats(p->N, p->A, p->D, p->S, p->K, p->B) + 64 : 4);   // + debug stamps
   if (p->fused) {    // per-workgroup sums of squares of the gradient the slab reduction wrote (only the fused path produces them)
     p->gsq_critic = W.add("gsq_critic", 2 * ddpg_fused_gsq_blocks(p->N, p->A, p->D, p->S, p->K, true));
@@ -718,7 +722,7 @@ extern "C" int ope_ddpg_critic_loss_and_grad(const ope_ddpg_cfg* cfg, const ope_
   // ope_ddpg_target_actions per policy)
   if (!joint) {
     if ((rc = trunk_mlp(p, W, bt->next_obs, p.Ra, p.D, theta_actor_tgt, p.AL, W + p.a2n, false, nullptr, W + p.lgn, p.A, st))) return rc;
-    if ((rc = launch_action(W + p.lgn, bt->next_avail_acts, NoiseSrc{target_noise_u, cfg->noise_seed, cfg->noise_counter, 0}, p.Ra, p.B, p.A, p.N, cfg->target_gumbel ? 1 : 0, 0, W + p.cnact,
+    if ((rc = launch_action(W + p.lgn, bt->next_avail_acts, NoiseSrc{target_noise_u, cfg->noise_seed, cfg->noise_counter, 0}, p.Ra, p.B, p.A, p.N, cfg->continuous ? 2 : (cfg->target_gumbel ? 1 : 0), 0, W + p.cnact,
                             nullptr, nullptr, st))) return rc;
   }
   const float* cnact = joint ? cfg->joint_next_acts : W + p.cnact;
@@ -751,14 +755,14 @@ extern "C" int ope_ddpg_target_actions(const ope_ddpg_cfg* cfg, const ope_mlp_ba
   if ((rc = trunk_mlp(p, W, bt->next_obs, p.Ra, p.D, theta_actor_tgt, p.AL, W + p.a2n, false, nullptr, W + p.lgn, p.A, st))) return rc;
   // (device-drawn noise: one Philox stream per policy, so that two policies' target noise is not the same numbers)
   return launch_action(W + p.lgn, bt->next_avail_acts, NoiseSrc{target_noise_u, cfg->noise_seed, cfg->noise_counter, 16 + p.a0}, p.Ra, p.B, p.A,
-                       p.N, cfg->target_gumbel ? 1 : 0, 0, joint_next_acts, nullptr, nullptr, st, p.NT, p.a0);
+                       p.N, cfg->continuous ? 2 : (cfg->target_gumbel ? 1 : 0), 0, joint_next_acts, nullptr, nullptr, st, p.NT, p.a0);
 }
 
 extern "C" int ope_ddpg_actor_loss_and_grad(const ope_ddpg_cfg* cfg, const ope_mlp_batch* bt, const float* theta_actor,
                                             const float* theta_critic, const float* gumbel_noise_u, void* workspace,
                                             int64_t workspace_bytes, float* grad, void* stream) {
   (void)hipGetLastError();
-  if (!ddpg_cfg_ok(cfg) || !bt || !theta_actor || !theta_critic || (!gumbel_noise_u && !cfg->noise_seed) || !workspace || !grad) return OPE_EINVAL;
+  if (!ddpg_cfg_ok(cfg) || !bt || !theta_actor || !theta_critic || (!cfg->continuous && !gumbel_noise_u && !cfg->noise_seed) || !workspace || !grad) return OPE_EINVAL;
   if (!bt->obs || !bt->share_obs || !bt->acts || !bt->valid_transition) return OPE_EINVAL;
   DdpgPlan p;
   ddpg_plan(cfg, &p);
@@ -770,7 +774,7 @@ extern "C" int ope_ddpg_actor_loss_and_grad(const ope_ddpg_cfg* cfg, const ope_m
   float* saves2 = W + p.err;
   // actor forward (saves -> alternate set) and straight-through hard gumbel sample
   if ((rc = trunk_mlp(p, W, bt->obs, p.Ra, p.D, theta_actor, p.AL, W + p.a2a, true, saves2, W + p.lga, p.A, st))) return rc;
-  if ((rc = launch_action(W + p.lga, bt->avail_acts, NoiseSrc{gumbel_noise_u, cfg->noise_seed, cfg->noise_counter, 1}, p.Ra, p.B, p.A, p.N, 1, 0, nullptr, W + p.actout, W + p.ysoft, st)))
+  if ((rc = launch_action(W + p.lga, bt->avail_acts, NoiseSrc{cfg->continuous ? nullptr : gumbel_noise_u, cfg->noise_seed, cfg->noise_counter, 1}, p.Ra, p.B, p.A, p.N, cfg->continuous ? 2 : 1, 0, nullptr, W + p.actout, W + p.ysoft, st)))
     return rc;
   // N stacked copies of the joint action, copy i carrying the actor's action for agent i
   // (multi-policy: copy i of the joint action of ALL agents, block agent_offset + i replaced)
@@ -785,7 +789,7 @@ extern "C" int ope_ddpg_actor_loss_and_grad(const ope_ddpg_cfg* cfg, const ope_m
   ag.R = p.Ra; ag.B = p.B; ag.N = p.N; ag.A = p.A; ag.A4 = p.A4; ag.S = p.S; ag.Din = p.Din; ag.a_off = p.a0; ag.dz1 = W + p.dz1;
   ag.xhat1 = W + p.xhat1; ag.rstd1 = W + p.rstd1; ag.mu1 = W + p.mu1; ag.mu0 = W + p.mu0; ag.rstd0 = W + p.rstd0;
   ag.act = W + p.actout; ag.y = W + p.ysoft; ag.theta = theta_critic; ag.fc1_w = p.CL.fc1_w; ag.fc1_b = p.CL.fc1_b; ag.fn_w = p.CL.fn_w;
-  ag.fn_b = p.CL.fn_b; ag.cvec = W + p.cvec; ag.dlogits = W + p.dlg;
+  ag.fn_b = p.CL.fn_b; ag.cvec = W + p.cvec; ag.dlogits = W + p.dlg; ag.identity = cfg->continuous ? 1 : 0;
   if ((rc = launch_action_grad(ag, st))) return rc;
   // actor backward and gradients
   return mlp_backward(p, W, bt->obs, p.Ra, p.D, p.A, p.A4, W + p.dlg, theta_actor, p.AL, saves2, p.ns_a, ope_cdiv(p.Ra, 16), grad, st);

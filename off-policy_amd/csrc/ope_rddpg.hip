@@ -752,7 +752,7 @@ extern "C" int ope_rddpg_actor_loss_and_grad(const ope_rddpg_cfg* cfg, const ope
   ag.R = Ra; ag.B = p.B; ag.N = p.N; ag.A = p.A; ag.A4 = p.A4; ag.S = p.S; ag.Din = p.Din; ag.a_off = p.a0; ag.dz1 = W + p.dz1;
   ag.xhat1 = W + p.SC.xhat1; ag.rstd1 = W + p.SC.rstd1; ag.mu1 = W + p.SC.mu1; ag.mu0 = W + p.SC.mu0; ag.rstd0 = W + p.SC.rstd0;
   ag.act = W + p.actout; ag.y = W + p.ysoft; ag.theta = theta_critic; ag.fc1_w = p.CL.fc1_w; ag.fc1_b = p.CL.fc1_b; ag.fn_w = p.CL.fn_w;
-  ag.fn_b = p.CL.fn_b; ag.cvec = W + p.cvec; ag.dlogits = W + p.dlg;
+  ag.fn_b = p.CL.fn_b; ag.cvec = W + p.cvec; ag.dlogits = W + p.dlg; ag.identity = 0;
   if ((rc = launch_action_grad(ag, st))) return rc;
   // actor BPTT and gradients
   return rnn_backward(p, W, p.SA, bt->obs, p.NB, p.T, p.D, p.A, p.A4, W + p.dlg, theta_actor, p.AL, p.ns_a, ope_cdiv(Ra, 16), grad, st);

@@ -70,14 +70,16 @@ def synth_episodes(rng, num_episodes, dims, avail="ones", runner_padding=False):
                 lengths=lengths.astype(np.int64))
 
 
-def policy_info_for(dims):
-    """`policy_info` dict in the SMAC style the reference builds at train_smac.py:131-137: list spaces."""
-    from .spaces import Discrete
+def policy_info_for(dims, continuous=False):
+    """`policy_info` dict in the SMAC style the reference builds at train_smac.py:131-137: list spaces. `continuous`: a Box action
+    space of act_dim components in [-1, 1] instead of Discrete(act_dim)."""
+    from .spaces import Discrete, Box
+    act = Box(low=-np.ones(dims.act_dim, np.float32), high=np.ones(dims.act_dim, np.float32)) if continuous else Discrete(dims.act_dim)
     return {"policy_0": {"cent_obs_dim": dims.state_dim,
                          "cent_act_dim": dims.act_dim * dims.n_agents,
                          "obs_space": [dims.obs_dim],
                          "share_obs_space": [dims.state_dim],
-                         "act_space": Discrete(dims.act_dim)}}
+                         "act_space": act}}
 
 
 def as_policy_dicts(ep, p_id="policy_0"):

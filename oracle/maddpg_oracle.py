@@ -36,10 +36,12 @@ def onehot_argmax(logits, avail):
 
 
 class MaddpgOracle(object):
-    def __init__(self, actor, critic, critic_heads, actor_tgt, critic_tgt, critic_heads_tgt, n_agents, hp=None, td3=False):
-        """actor/critic: {name: array} trunks (+ 'act.action_out.*' for the actor); critic_heads: (W [K,64], b [K])."""
+    def __init__(self, actor, critic, critic_heads, actor_tgt, critic_tgt, critic_heads_tgt, n_agents, hp=None, td3=False, continuous=False):
+        """actor/critic: {name: array} trunks (+ 'act.action_out.*' for the actor); critic_heads: (W [K,64], b [K]).
+        `continuous`: Box action space (MADDPGPolicy.py:107-116): the action is the actor's output; the target action of MATD3 adds
+        the gaussian noise passed as `u_target` (gaussian_noise(shape, target_noise), util.py:217-218); no gumbel, no masks."""
         self.hp = hp or HP()
-        self.N, self.td3 = n_agents, td3
+        self.N, self.td3, self.continuous = n_agents, td3, bool(continuous)
         f = lambda d: OrderedDict((k, torch.as_tensor(np.asarray(v), dtype=torch.float32).clone()) for k, v in d.items())
         h = lambda wb: (torch.as_tensor(np.asarray(wb[0]), dtype=torch.float32).clone(), torch.as_tensor(np.asarray(wb[1]), dtype=torch.float32).clone())
         self.actor, self.critic, self.actor_tgt, self.critic_tgt = f(actor), f(critic), f(actor_tgt), f(critic_tgt)
@@ -85,7 +87,10 @@ class MaddpgOracle(object):
         s_nav = torch.cat(list(torch.as_tensor(np.ascontiguousarray(navail))), 0) if navail is not None else None
         with torch.no_grad():
             lg = self.actor_logits(self.actor_tgt, torch.cat(list(nobs), 0))
-            nact = gumbel_hard(lg, s_nav, torch.as_tensor(u_target)) if self.td3 else onehot_argmax(lg, s_nav)
+            if self.continuous:
+                nact = lg + torch.as_tensor(u_target) if u_target is not None else lg
+            else:
+                nact = gumbel_hard(lg, s_nav, torch.as_tensor(u_target)) if self.td3 else onehot_argmax(lg, s_nav)
         return list(nact.split(B, dim=0))
 
     def train_step(self, batch, u_target=None, u_actor=None, weights=None, soft_update=True, joint=None, all_acts=None, offset=0,
@@ -108,7 +113,10 @@ class MaddpgOracle(object):
         with torch.no_grad():
             if joint is None:
                 lg = self.actor_logits(self.actor_tgt, s_nobs)
-                nact = gumbel_hard(lg, s_nav, torch.as_tensor(u_target)) if self.td3 else onehot_argmax(lg, s_nav)
+                if self.continuous:
+                    nact = lg + torch.as_tensor(u_target) if u_target is not None else lg
+                else:
+                    nact = gumbel_hard(lg, s_nav, torch.as_tensor(u_target)) if self.td3 else onehot_argmax(lg, s_nav)
                 cent_nact = torch.cat(nact.split(B, dim=0), dim=-1)
             else:
                 cent_nact = joint[1]
@@ -136,7 +144,7 @@ class MaddpgOracle(object):
         cnorm = self._adam_step("critic", self.critic, cg)
         # ---- actor (through the UPDATED critic, whose parameters are frozen here) ----
         la = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in self.actor.items())
-        pol = gumbel_hard(self.actor_logits(la, s_obs), s_av, torch.as_tensor(u_actor))
+        pol = self.actor_logits(la, s_obs) if self.continuous else gumbel_hard(self.actor_logits(la, s_obs), s_av, torch.as_tensor(u_actor))
         agent_acts = pol.split(B, dim=0)
         rows = []
         every = list(acts) if all_acts is None else list(all_acts)

@@ -8,7 +8,9 @@ from oracle import maddpg_oracle as DO
 from oracle.qmix_oracle import HP
 from test_mlp_oracle_golden import T_KEYS
 
-CASES = ["maddpg_spread", "matd3_spread", "maddpg_small_huber_per", "matd3_small", "maddpg_small_wd"]
+CASES = ["maddpg_spread", "matd3_spread", "maddpg_small_huber_per", "matd3_small", "maddpg_small_wd",
+         # round 4: continuous (Box) action spaces -- the action is the actor's output, MATD3's target noise is additive gaussian
+         "maddpg_cont_small", "matd3_cont_small", "maddpg_cont_spread"]
 
 
 def ddpg_oracle_from(g):
@@ -16,7 +18,8 @@ def ddpg_oracle_from(g):
             huber_delta=float(g["hp_delta"]), use_per=bool(g["hp_per"]), per_eps=float(g["hp_per_eps"]), tau=float(g["hp_tau"]),
             max_grad_norm=float(g["hp_maxnorm"]), weight_decay=float(g["hp_wd"]) if "hp_wd" in g else 0.0)
     return DO.MaddpgOracle(sub(g, "actor/"), sub(g, "critic/"), (g["heads/w"], g["heads/b"]), sub(g, "actor_tgt/"),
-                           sub(g, "critic_tgt/"), (g["heads_tgt/w"], g["heads_tgt/b"]), int(g["dims"][0]), hp, td3=bool(g["td3"]))
+                           sub(g, "critic_tgt/"), (g["heads_tgt/w"], g["heads_tgt/b"]), int(g["dims"][0]), hp, td3=bool(g["td3"]),
+                           continuous=bool(g["continuous"]) if "continuous" in g else False)
 
 
 def noise_for(g, step):
@@ -24,6 +27,8 @@ def noise_for(g, step):
     n, a = int(g["dims"][0]), int(g["dims"][1])
     B = len(g["inds"])
     torch.manual_seed(1000 + step)
+    if "continuous" in g and bool(g["continuous"]):      # gaussian_noise(shape, target_action_noise_std) for MATD3's target action; nothing else is drawn
+        return (torch.empty(n * B, a).normal_(mean=0, std=0.2) if bool(g["td3"]) else None), None
     u_t = torch.FloatTensor(n * B, a).uniform_() if bool(g["td3"]) else None
     u_a = torch.FloatTensor(n * B, a).uniform_()
     return u_t, u_a
