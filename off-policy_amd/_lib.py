@@ -31,6 +31,7 @@ class Dims(C.Structure):
 
 
 OPE_DIMS_NO_FEATURE_NORM = 1
+OPE_DIMS_TANH = 2
 
 
 class Fields(C.Structure):

@@ -37,7 +37,7 @@ class QMixPolicy(object):
     def __init__(self, config, policy_config, train=True):
         self.args = config["args"]
         self.device = torch.device(config["device"])
-        require_reference_architecture(self.args, allow_prev_act_inp=True, allow_hypernet_layers_1=True, allow_layer_N_2=True, allow_no_feature_norm=True)   # (the mixer is the trainer's business: QMix checks it)
+        require_reference_architecture(self.args, allow_prev_act_inp=True, allow_hypernet_layers_1=True, allow_layer_N_2=True, allow_no_feature_norm=True, allow_tanh=True)   # (the mixer is the trainer's business: QMix checks it)
         self.obs_space = policy_config["obs_space"]
         self.obs_dim = get_dim_from_space(self.obs_space)
         self.act_space = policy_config["act_space"]

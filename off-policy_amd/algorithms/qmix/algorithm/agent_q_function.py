@@ -101,6 +101,9 @@ class AgentQFunction(FlatModule):
         if self.layer_N not in (1, 2):
             raise NotImplementedError("ope kernels support layer_N = 1 or 2 (got %r)" % self.layer_N)
         self.feature_norm = bool(getattr(args, "use_feature_normalization", True))
+        self.use_relu = bool(getattr(args, "use_ReLU", True))
+        if not self.use_relu and (self.layer_N != 1 or input_dim > 384):
+            raise NotImplementedError("use_ReLU=False (tanh) on the accelerated path: one hidden block, network input width <= 384")
         offs, sizes, total = agent_layout(input_dim, act_dim, self.layer_N)
         own = flat is None
         if own:
@@ -120,7 +123,8 @@ class AgentQFunction(FlatModule):
                                      getattr(args, "gain", 0.01), getattr(args, "use_ReLU", True), self.layer_N)
             for p, v in zip(self.parameters(), [vals[i] for i in keep]):
                 p.data.copy_(v)
-        self._dims = _lib.Dims(1, act_dim, input_dim, 1, 1, self.layer_N, 0 if self.feature_norm else _lib.OPE_DIMS_NO_FEATURE_NORM)
+        self._dims = _lib.Dims(1, act_dim, input_dim, 1, 1, self.layer_N,
+                               (0 if self.feature_norm else _lib.OPE_DIMS_NO_FEATURE_NORM) | (0 if self.use_relu else _lib.OPE_DIMS_TANH))
         self._ws = None
 
     def twin(self, flat):

@@ -55,9 +55,10 @@ class QMix(object):
         self.args = args
         # (the policies check their own support); one-layer hyper-networks: recurrent nets, one shared policy (checked below)
         require_reference_architecture(args, allow_prev_act_inp=not self._mlp, allow_hypernet_layers_1=not self._mlp and not vdn,
-                                       allow_layer_N_2=not self._mlp, allow_no_feature_norm=not self._mlp)
+                                       allow_layer_N_2=not self._mlp, allow_no_feature_norm=not self._mlp, allow_tanh=not self._mlp)
         self.layer_N = int(getattr(args, "layer_N", 1))
-        self.dims_flags = 0 if getattr(args, "use_feature_normalization", True) else _lib.OPE_DIMS_NO_FEATURE_NORM
+        self.dims_flags = (0 if getattr(args, "use_feature_normalization", True) else _lib.OPE_DIMS_NO_FEATURE_NORM) | \
+                          (0 if getattr(args, "use_ReLU", True) else _lib.OPE_DIMS_TANH)
         self.hypernet_layers = int(getattr(args, "hypernet_layers", 2)) if not vdn else 2
         self.use_popart = getattr(args, "use_popart", False)
         self.use_value_active_masks = getattr(args, "use_value_active_masks", False)

@@ -30,7 +30,7 @@ def default_args(**overrides):
 
 
 def require_reference_architecture(args, allow_prev_act_inp=False, allow_hypernet_layers_1=False, allow_layer_N_2=False,
-                                   allow_no_feature_norm=False):
+                                   allow_no_feature_norm=False, allow_tanh=False):
     """The kernels are specialised to the reference's default network shape; refuse anything else loudly.
     `prev_act_inp` (previous action appended to the agent's observation, config.py:81) only changes the width of the
     network input; the recurrent QMIX / VDN policy supports it (`allow_prev_act_inp`), the other families do not yet.
@@ -38,7 +38,8 @@ def require_reference_architecture(args, allow_prev_act_inp=False, allow_hyperne
     policy (`allow_hypernet_layers_1`; the fused chain kernels, csrc/ope_chain.hip); `layer_N = 2` (a second hidden block behind fc1,
     mlp.py:14-28) by the recurrent QMIX / VDN trainer and its policy (`allow_layer_N_2`; csrc/ope_block.hip);
     `use_feature_normalization = False` (no LayerNorm on the network input, mlp.py:60-62) by the same trainer and policy
-    (`allow_no_feature_norm`; OPE_DIMS_NO_FEATURE_NORM in include/ope.h)."""
+    (`allow_no_feature_norm`; OPE_DIMS_NO_FEATURE_NORM in include/ope.h); `use_ReLU = False` (tanh in the MLP base, mlp.py:9-12)
+    likewise (`allow_tanh`; OPE_DIMS_TANH: one hidden block, input width <= 384)."""
     want = dict(hidden_size=64, layer_N=1, use_ReLU=True, use_feature_normalization=True, use_conv1d=False,
                 prev_act_inp=False, use_rnn_layer=True, recurrent_N=1, hypernet_layers=2, mixer_hidden_dim=32,
                 hypernet_hidden_dim=64, use_popart=False)
@@ -50,6 +51,8 @@ def require_reference_architecture(args, allow_prev_act_inp=False, allow_hyperne
         del want["layer_N"]
     if allow_no_feature_norm:
         del want["use_feature_normalization"]
+    if allow_tanh:
+        del want["use_ReLU"]
     for k, v in want.items():
         got = getattr(args, k, v)
         if got != v:

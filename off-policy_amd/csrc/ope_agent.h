@@ -47,6 +47,7 @@ struct TrunkFwdArgs {
   float* xhat2;
   float* rstd2;
   uint64_t* mask2;
+  int tanh_act;        // OPE_DIMS_TANH: tanh behind fc1 / fc2 (trunk_fwd3 only); the mask slots then hold the row means of the activations
   int no_fn;           // OPE_DIMS_NO_FEATURE_NORM: rows enter fc1 as they are (statistics forced to mean 0, 1/std 1; theta holds gamma = 1, beta = 0)
   // observations left in the store (trunk_fwd4 only): x = the store's obs ring, local row r is batch row ref_row0 + r
   ObsRef ref;
@@ -131,6 +132,7 @@ struct TrunkBwdArgs {
   const float* xhat1; const float* rstd1; const uint64_t* mask1;
   const float* xhat2; const float* rstd2; const uint64_t* mask2;
   float* dz1; float* dz2;  // [R][64]
+  int tanh_act;        // OPE_DIMS_TANH (trunk_bwd3 only): mask1 / mask2 hold the activations' row means (float in the low word), not ReLU bits
 };
 
 // ---- second hidden block (layer_N = 2; ope_block.hip) ----------------------------------------------------------------------------

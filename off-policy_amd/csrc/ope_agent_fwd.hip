@@ -211,6 +211,7 @@ int launch_trunk_fwd(const TrunkFwdArgs& a, bool save, hipStream_t st, bool allo
   // on the re-streaming cooperative form. Up to 384 (96 VGPRs of fragments, fc2 / W_ih fragments re-fetched per tile) the
   // persistent kernel wins since its biases and LayerNorm parameters moved to LDS: MMM2 (D = 370) QMIX 1 308 -> 1 383 steps/s.
   static const int maxd3 = getenv("OPE_TRUNK3_MAXD") ? atoi(getenv("OPE_TRUNK3_MAXD")) : 384;
+  if (a.tanh_act) return (a.D <= 384 && !a.head_out) ? launch_trunk_fwd3(a, save, st) : OPE_EINVAL;      // only trunk_fwd3 carries the tanh activation
   if (v2 == 3 && a.D <= maxd3 && a.D <= 512) return launch_trunk_fwd3(a, save, st);
   if (v2 && a.D <= 512) return launch_trunk_fwd2(a, save, st);
   if (a.head_out) {   // one-wave form: the head is a second launch

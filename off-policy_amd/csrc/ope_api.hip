@@ -26,8 +26,9 @@ bool cfg_ok(const ope_qmix_cfg* c) {
   if (c->chain_path < 0 || c->chain_path > 2) return false;
   if (c->hypernet_layers < 0 || c->hypernet_layers > 2) return false;
   if (d.layer_N < 0 || d.layer_N > 2) return false;
-  if (d.flags & ~OPE_DIMS_NO_FEATURE_NORM) return false;
+  if (d.flags & ~(OPE_DIMS_NO_FEATURE_NORM | OPE_DIMS_TANH)) return false;
   if ((d.flags & OPE_DIMS_NO_FEATURE_NORM) && c->mlp) return false;      // no input LayerNorm: the recurrent nets
+  if ((d.flags & OPE_DIMS_TANH) && (c->mlp || c->phase != 0 || d.layer_N == 2 || d.obs_dim > 384 || c->trunk_path == 4)) return false;   // tanh: trunk_fwd3 / trunk_bwd3
   if (d.layer_N == 2 && (c->mlp || c->phase != 0 || c->time_chunks > 1)) return false;      // a second hidden block: whole steps of recurrent nets
   if (c->hypernet_layers == 1 && (c->mlp || c->phase != 0 || c->mixer_path == 3 || c->chain_path == 1)) return false;   // one-layer hyper-networks: the fused chain only
   return d.n_agents >= 1 && d.act_dim >= 1 && d.obs_dim >= 1 && d.obs_dim <= 512 && d.state_dim >= 1 &&
@@ -357,7 +358,7 @@ extern "C" int ope_qmix_workspace_init(const ope_qmix_cfg* cfg, void* workspace,
 
 // ope_qmix_obs_ref_ok: the static part of "can this configuration read observation rows from the store" (the launchers check the rest)
 static bool obs_ref_cfg_ok(const ope_qmix_cfg* cfg) {
-  if (!cfg_ok(cfg) || cfg->mlp || cfg->phase != 0 || cfg->dims.layer_N == 2) return false;
+  if (!cfg_ok(cfg) || cfg->mlp || cfg->phase != 0 || cfg->dims.layer_N == 2 || (cfg->dims.flags & OPE_DIMS_TANH)) return false;
   const ope_dims& d = cfg->dims;
   const int KC = (d.obs_dim + 15) >> 4;
   const int64_t R = (int64_t)(d.episode_length + 1) * d.n_agents * cfg->batch;
@@ -469,6 +470,7 @@ static int qmix_step(const ope_qmix_cfg* cfg, const ope_fields* batch, const ope
     tf.x = oref ? obs_rows : obs_rows + r0 * p.D; tf.R = (int)rows; tf.D = p.D; tf.theta = theta; tf.L = p.AL;
     tf.ref = ref; tf.ref_row0 = (int)r0;
     tf.no_fn = (cfg->dims.flags & OPE_DIMS_NO_FEATURE_NORM) ? 1 : 0;
+    tf.tanh_act = (cfg->dims.flags & OPE_DIMS_TANH) ? 1 : 0;
     tf.gi = p.mlp ? nullptr : W + p.gi + r0 * 3 * OPE_H; tf.a2_out = p.mlp ? W + p.h + r0 * OPE_H : nullptr;
     if (p.layerN == 2) { tf.gi = nullptr; tf.a2_out = W + p.a2 + r0 * OPE_H; }      // the trunk stops at the first block's output; ope_block.hip continues
     tf.mu0 = W + p.mu0 + r0; tf.rstd0 = W + p.rstd0 + r0;
@@ -695,6 +697,7 @@ static int qmix_step(const ope_qmix_cfg* cfg, const ope_fields* batch, const ope
     TrunkBwdArgs tb;
     memset(&tb, 0, sizeof(tb));
     tb.R = K1; tb.theta = theta; tb.thetaT = W + p.thetaT; tb.L = p.AL;
+    tb.tanh_act = (cfg->dims.flags & OPE_DIMS_TANH) ? 1 : 0;
     tb.dgi = p.mlp ? nullptr : W + p.dgi + r0 * 3 * OPE_H; tb.da2_in = p.mlp ? W + p.dh_out + r0 * OPE_H : nullptr;
     if (p.layerN == 2 && do_bwd) {      // the second block's adjoint first: dgi -> dz3 (its weight gradient), da2 (what the trunk adjoint continues from)
       BlockBwdArgs bb;
@@ -833,6 +836,8 @@ extern "C" int ope_agent_forward(const ope_dims* d, int32_t seq_len, int32_t row
   memset(&tf, 0, sizeof(tf));
   tf.x = obs; tf.R = (int)R; tf.D = d->obs_dim; tf.theta = theta; tf.L = L; tf.gi = gi;
   tf.no_fn = (d->flags & OPE_DIMS_NO_FEATURE_NORM) ? 1 : 0;
+  tf.tanh_act = (d->flags & OPE_DIMS_TANH) ? 1 : 0;
+  if (tf.tanh_act && (L.layer_N == 2 || d->obs_dim > 384)) return OPE_EINVAL;
   if (L.layer_N == 2) { tf.gi = nullptr; tf.a2_out = gi + R * 3 * OPE_H; }      // the trunk stops at the first block; ope_block.hip continues
   if ((rc = launch_trunk_fwd(tf, false, st))) return rc;
   if (L.layer_N == 2) {

@@ -608,7 +608,8 @@ __global__ void __launch_bounds__(256, 2) trunk_fwd3_kernel(TrunkFwdArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       if (z[r] > 0.f) mb |= 1u << (4 * g + r);
-      z[r] = fmaxf(z[r], 0.f);
+      // ReLU, or (OPE_DIMS_TANH) tanh(x) = 2 / (1 + 2^(-2 log2(e) x)) - 1: v_exp_f32 / v_rcp_f32, ~1e-7 absolute, as the GRU gates
+      z[r] = a.tanh_act ? fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * z[r])), -1.0f) : fmaxf(z[r], 0.f);
       s += z[r];
       s2 = fmaf(z[r], z[r], s2);
     }
@@ -765,10 +766,11 @@ __global__ void __launch_bounds__(256, 2) trunk_fwd3_kernel(TrunkFwdArgs a) {
       b |= __shfl_xor((int)b, 16, 64);
       b |= __shfl_xor((int)b, 32, 64);
       if (g == 0 && valid) {
-        reinterpret_cast<uint16_t*>(mask + row)[wave] = (uint16_t)b;
+        if (!a.tanh_act) reinterpret_cast<uint16_t*>(mask + row)[wave] = (uint16_t)b;
         if (wave == 0) {
           rstd_out[row] = rs;
           if (mu_out) mu_out[row] = mu;
+          if (a.tanh_act) reinterpret_cast<float*>(mask + row)[0] = mu;      // no ReLU bits to keep: the adjoint needs the row mean instead
         }
       }
     };

@@ -478,8 +478,8 @@ int launch_trunk_fwd_pair(const TrunkFwdArgs& live, const TrunkFwdArgs& tgt, int
   const int KC = (live.D + 15) >> 4;
   const bool can = live.gi && tgt.gi && !live.a2_out && !tgt.a2_out && live.D == tgt.D && live.R == tgt.R && live.x == tgt.x && live.no_fn == tgt.no_fn &&
                    ((live.D % 4 == 0 && (KC == 4 || KC == 8 || KC == 12 || KC == 16)) || (live.D % 2 == 0 && KC == 24)) && live.xhat1 && live.mu0 && live.rstd0 && live.rstd1 && live.mask1 && live.xhat2 && live.rstd2 && live.mask2;
-  if (path == 4 && !can) return OPE_EINVAL;      // an explicit request the shape does not allow: no silent fall-back (tests pin kernels by path)
-  const bool ok = can && (path == 4 || (path == 0 && on && live.R >= trunk4_pair_min_rows()));
+  if (path == 4 && (!can || live.tanh_act)) return OPE_EINVAL;      // an explicit request the shape does not allow: no silent fall-back (tests pin kernels by path)
+  const bool ok = can && !live.tanh_act && (path == 4 || (path == 0 && on && live.R >= trunk4_pair_min_rows()));
   const bool lazy = live.ref.inds != nullptr;
   if (lazy && (!ok || KC == 24 || live.ref.B < 1 || live.ref.B > kObsRefMaxB || live.R % live.ref.B != 0 || live.ref_row0 % live.ref.B != 0 || live.ref.cap < 1))
     return OPE_EINVAL;                           // only this kernel reads rows from the store (ope_qmix_obs_ref_ok tells the caller beforehand)
@@ -533,7 +533,7 @@ int launch_trunk_fwd4_single(const TrunkFwdArgs& a, bool save, hipStream_t st) {
   static const int on = getenv("OPE_TRUNK4") ? atoi(getenv("OPE_TRUNK4")) : 1;
   const int KC = (a.D + 15) >> 4;
   const bool shape = (a.D % 4 == 0 && (KC == 4 || KC == 8 || KC == 12 || KC == 16)) || (a.D % 2 == 0 && KC == 24);
-  if (!on || !shape || !a.gi || a.a2_out || a.head_out || a.ref.inds || a.R < 16 * 1024) return 1;
+  if (!on || !shape || !a.gi || a.a2_out || a.head_out || a.ref.inds || a.tanh_act || a.R < 16 * 1024) return 1;
   if (save && !(a.xhat1 && a.mu0 && a.rstd0 && a.rstd1 && a.mask1 && a.xhat2 && a.rstd2 && a.mask2)) return 1;
   TrunkPairArgs pa;
   memset(&pa, 0, sizeof(pa));

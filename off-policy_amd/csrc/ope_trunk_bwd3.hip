@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(256, 2) trunk_bwd3_kernel(TrunkBwdArgs a) {
 
   // LayerNorm + ReLU adjoint for this lane's 4 features of row j; the row means over all 64 features meet through LDS
   // (xh, rs, bits: the row's saved normalised values, 1/std and this wave's 16 ReLU bits, loaded at the top of the tile)
-  auto ln_relu_bwd = [&](f32x4& d, const f32x4& gm, const f32x4& xh, float rs, uint32_t bits, float* stat) {
+  auto ln_relu_bwd = [&](f32x4& d, const f32x4& gm, const f32x4& xh, float rs, uint32_t bits, float mu, float* stat) {
     float m1 = 0.f, m2 = 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -58,7 +58,12 @@ __global__ void __launch_bounds__(256, 2) trunk_bwd3_kernel(TrunkBwdArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float v = rs * (d[r] - m1 - xh[r] * m2);
-      d[r] = ((bits >> (4 * g + r)) & 1u) ? v : 0.f;
+      if (a.tanh_act) {      // a = tanh(z) = xhat / rstd + mean (what the LayerNorm normalised); d tanh = 1 - a^2
+        const float act = fmaf(xh[r], 1.0f / rs, mu);
+        d[r] = v * (1.0f - act * act);
+      } else {
+        d[r] = ((bits >> (4 * g + r)) & 1u) ? v : 0.f;
+      }
     }
   };
 
@@ -74,6 +79,7 @@ __global__ void __launch_bounds__(256, 2) trunk_bwd3_kernel(TrunkBwdArgs a) {
     const float rs2 = a.rstd2[rr], rs1 = a.rstd1[rr];
     const uint32_t bits2 = reinterpret_cast<const uint16_t*>(a.mask2 + rr)[wave];   // this wave's 16 ReLU bits of the row
     const uint32_t bits1 = reinterpret_cast<const uint16_t*>(a.mask1 + rr)[wave];
+    const float mu2 = reinterpret_cast<const float*>(a.mask2 + rr)[0], mu1 = reinterpret_cast<const float*>(a.mask1 + rr)[0];   // (OPE_DIMS_TANH: the slots hold row means)
     f32x4 d = {0.f, 0.f, 0.f, 0.f};
     if (recurrent) {
       // stage the tile's dgi rows (16 x 192 floats, contiguous in memory) in LDS: 3 x 16-byte pieces per thread
@@ -101,7 +107,7 @@ __global__ void __launch_bounds__(256, 2) trunk_bwd3_kernel(TrunkBwdArgs a) {
         for (int r = 0; r < 4; ++r) d[r] = fmaf(dk, w[r], d[r]);
       }
     }
-    ln_relu_bwd(d, gm2, xh2, rs2, bits2, stat2[0]);
+    ln_relu_bwd(d, gm2, xh2, rs2, bits2, mu2, stat2[0]);
     if (valid) *reinterpret_cast<f32x4*>(a.dz2 + (int64_t)row * OPE_H + fo) = d;
     *reinterpret_cast<f32x4*>(dzb + j * kDzPitch + fo) = d;
     lds_barrier();
@@ -112,7 +118,7 @@ __global__ void __launch_bounds__(256, 2) trunk_bwd3_kernel(TrunkBwdArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) e = mfma16(wB[ft][r], bv[r], e);
     }
-    ln_relu_bwd(e, gm1, xh1, rs1, bits1, stat2[1]);   // its barrier also orders the dzb reads before the next tile's writes
+    ln_relu_bwd(e, gm1, xh1, rs1, bits1, mu1, stat2[1]);   // its barrier also orders the dzb reads before the next tile's writes
     if (valid) *reinterpret_cast<f32x4*>(a.dz1 + (int64_t)row * OPE_H + fo) = e;
   }
 }

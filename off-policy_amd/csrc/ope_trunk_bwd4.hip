@@ -206,8 +206,8 @@ int launch_trunk_bwd_path(const TrunkBwdArgs& a, int path, hipStream_t st) {
   static const int on = getenv("OPE_TRUNK_BWD4") ? atoi(getenv("OPE_TRUNK_BWD4")) : 1;
   const bool can = a.dgi && a.xhat1 && a.xhat2 && a.rstd1 && a.rstd2 && a.mask1 && a.mask2 && a.dz1 && a.dz2 && a.thetaT &&
                    (int64_t)a.R * (4 * kG) < ((int64_t)1 << 32);
-  if (path == 4 && !can) return OPE_EINVAL;      // explicit request that cannot run: no silent fall-back
-  if (!(can && (path == 4 || (path == 0 && on && a.R >= 16 * 1024)))) return launch_trunk_bwd3(a, st);
+  if (path == 4 && (!can || a.tanh_act)) return OPE_EINVAL;      // explicit request that cannot run: no silent fall-back
+  if (a.tanh_act || !(can && (path == 4 || (path == 0 && on && a.R >= 16 * 1024)))) return launch_trunk_bwd3(a, st);
   static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256; return n > 1 ? n : 256; }();
   kprof_work(2.0 * a.R * ((a.dgi ? 3.0 * OPE_H * OPE_H : 0.0) + OPE_H * OPE_H + (a.dout ? (double)a.hdim * OPE_H : 0.0)));
   OPE_LAUNCH(trunk_bwd4_kernel, dim3(cus), dim3(512), 0, st, a);

@@ -129,6 +129,7 @@ def run_case(name, dims, n_episodes, inds, steps=3, argv=(), vdn=False, avail="o
     out["hp_soft_update"], out["hp_gain"] = np.int64(bool(args.use_soft_update)), np.float64(args.gain)
     out["hp_hidden_size"], out["hp_layer_N"], out["hp_hypernet_layers"] = np.int64(args.hidden_size), np.int64(args.layer_N), np.int64(args.hypernet_layers)
     out["hp_feature_norm"] = np.int64(bool(args.use_feature_normalization))
+    out["hp_use_relu"] = np.int64(bool(args.use_ReLU))
     out["hard_update_after"] = np.asarray(list(hard_update_after), dtype=np.int64)
     losses, gnorms, qtots, prios = [], [], [], []
     for s in range(steps):
@@ -253,6 +254,17 @@ def main():
                  runner_padding=True, argv=["--use_feature_normalization", "--layer_N", "2", "--hypernet_layers", "1"])
         patch_vdn()
         run_case("vdn_var_nofn", tiny, n_episodes=4, inds=[2, 1, 0, 3], avail="bernoulli", vdn=True, argv=["--use_feature_normalization"])
+        return
+    if os.environ.get("OPE_GOLDEN_ONLY") == "tanh":
+        # round 4: --use_ReLU (a store_false flag: tanh behind fc1 / fc2 of the agent network, mlp.py:9-12; orthogonal init with the tanh gain):
+        # the tiny shape, the 3s5z width, odd sizes + previous action + Huber + PER (with no input LayerNorm either), VDN
+        run_case("qmix_shape_tanh", tiny, n_episodes=5, inds=[2, 0, 4, 1], avail="bernoulli", argv=["--use_ReLU"])
+        run_case("qmix_var_tanh_d252", EnvDims("var_tanh_d252", 2, 5, 252, 20, 6), n_episodes=5, inds=[4, 0, 2, 2], avail="bernoulli", argv=["--use_ReLU"])
+        run_case("qmix_var_tanh_odd", EnvDims("var_tanh_odd", 3, 7, 18, 29, 5), n_episodes=6, inds=[5, 1, 1, 2, 0], avail="bernoulli",
+                 runner_padding=True, per_weights=np.array([1.0, 0.5, 0.25, 0.8, 0.9]),
+                 argv=["--use_ReLU", "--use_feature_normalization", "--prev_act_inp", "--use_huber_loss", "--huber_delta", "1.0", "--use_per"])
+        patch_vdn()
+        run_case("vdn_var_tanh", tiny, n_episodes=4, inds=[2, 1, 0, 3], avail="bernoulli", vdn=True, argv=["--use_ReLU"])
         return
     if os.environ.get("OPE_GOLDEN_ONLY") == "pershare":      # add the round-2 fixture without rewriting the committed ones
         run_case("qmix_tiny_pershare", tiny, n_episodes=5, inds=[4, 1, 1, 0, 2], cap=6, pre_insert=3, avail="bernoulli", per_agent_share=True)

@@ -61,6 +61,7 @@ def oracle_from(g):
             use_huber_loss=bool(g["hp_huber"]), huber_delta=float(g["hp_delta"]), use_per=bool(g["hp_per"]),
             per_nu=float(g["hp_nu"]), per_eps=float(g["hp_per_eps"]), tau=float(g["hp_tau"]),
             max_grad_norm=float(g["hp_maxnorm"]), use_double_q=bool(g["hp_double_q"]), vdn=bool(g["vdn"]),
-            prev_act_inp=bool(g["hp_prev_act_inp"]) if "hp_prev_act_inp" in g else False)
+            prev_act_inp=bool(g["hp_prev_act_inp"]) if "hp_prev_act_inp" in g else False,
+            use_relu=bool(g["hp_use_relu"]) if "hp_use_relu" in g else True)
     mixer = sub(g, "mixer/") if not bool(g["vdn"]) else None
     return QMixOracle(sub(g, "agent/"), mixer, dims.n_agents, hp), dims

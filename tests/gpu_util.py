@@ -20,6 +20,8 @@ def make_args(g, **over):
         a.hypernet_layers, a.layer_N, a.hidden_size = int(g["hp_hypernet_layers"]), int(g["hp_layer_N"]), int(g["hp_hidden_size"])
     if "hp_feature_norm" in g:
         a.use_feature_normalization = bool(g["hp_feature_norm"])
+    if "hp_use_relu" in g:
+        a.use_ReLU = bool(g["hp_use_relu"])
     for k, v in over.items():
         setattr(a, k, v)
     return a

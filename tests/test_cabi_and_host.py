@@ -163,7 +163,7 @@ def test_network_without_input_layernorm_keeps_the_layout_and_hides_two_slots():
             assert np.array_equal(v.numpy(), g["agent/" + k]), k
     cfg.mlp, cfg.dims.episode_length = 1, 1
     assert _lib.lib.ope_qmix_workspace_bytes(C.byref(cfg)) == -1              # the recurrent nets only
-    cfg.mlp, cfg.dims.episode_length, cfg.dims.flags = 0, t, 2
+    cfg.mlp, cfg.dims.episode_length, cfg.dims.flags = 0, t, 4
     assert _lib.lib.ope_qmix_workspace_bytes(C.byref(cfg)) == -1              # unknown flag bits
     dd = _lib.DdpgCfg()
     dd.dims, dd.batch, dd.num_q = _lib.Dims(n, a, d, s, 1, 1, _lib.OPE_DIMS_NO_FEATURE_NORM), 4, 1
@@ -172,6 +172,42 @@ def test_network_without_input_layernorm_keeps_the_layout_and_hides_two_slots():
     with pytest.raises(NotImplementedError):
         require_reference_architecture(args)
     require_reference_architecture(args, allow_no_feature_norm=True)
+
+
+def test_tanh_networks_initialise_like_the_reference_and_are_limited_to_what_the_kernels_carry():
+    """use_ReLU = False (mlp.py:9-12; round 4, OPE_DIMS_TANH): the orthogonal initialisation uses the tanh gain -- our constructor
+    consumes the RNG stream as the reference does (fixture qmix_shape_tanh = outputs of the real reference) -- and the C-ABI accepts
+    the flag exactly where trunk_fwd3 / trunk_bwd3 can carry it."""
+    import torch
+    from conftest import load_golden
+    from offpolicy_amd import _lib
+    from offpolicy_amd.config import default_args, require_reference_architecture
+    from offpolicy_amd.algorithms.qmix.algorithm.agent_q_function import init_agent_values, agent_param_names
+    g = load_golden("qmix_shape_tanh")
+    n, a, d, s, t = [int(x) for x in g["dims"]]
+    assert int(g["hp_use_relu"]) == 0
+    torch.manual_seed(1)
+    np.random.seed(1)
+    av = init_agent_values(d, a, use_ReLU=False)
+    for v, k in zip(av, agent_param_names(1)):
+        assert np.array_equal(v.numpy(), g["agent/" + k]), k
+    cfg = _lib.QmixCfg()
+    cfg.dims, cfg.batch = _lib.Dims(n, a, d, s, t, 1, _lib.OPE_DIMS_TANH), 4
+    assert _lib.lib.ope_qmix_workspace_bytes(C.byref(cfg)) > 0
+    for bad in (dict(trunk_path=4), dict(phase=2)):
+        c2 = _lib.QmixCfg()
+        c2.dims, c2.batch = _lib.Dims(n, a, d, s, t, 1, _lib.OPE_DIMS_TANH), 4
+        for k, v in bad.items():
+            setattr(c2, k, v)
+        assert _lib.lib.ope_qmix_workspace_bytes(C.byref(c2)) == -1, bad
+    for dims in (_lib.Dims(n, a, 400, s, t, 1, _lib.OPE_DIMS_TANH), _lib.Dims(n, a, d, s, t, 2, _lib.OPE_DIMS_TANH)):
+        c3 = _lib.QmixCfg()
+        c3.dims, c3.batch = dims, 4
+        assert _lib.lib.ope_qmix_workspace_bytes(C.byref(c3)) == -1      # wider than trunk_fwd3's registers / a second hidden block
+    args = default_args(use_ReLU=False)
+    with pytest.raises(NotImplementedError):
+        require_reference_architecture(args)
+    require_reference_architecture(args, allow_tanh=True)
 
 
 def test_null_arguments_are_rejected_without_a_gpu():

@@ -22,7 +22,9 @@ CASES = ["qmix_tiny", "qmix_tiny_huber_per", "qmix_tiny_nodouble", "vdn_tiny", "
          "qmix_var_layer2_d252", "qmix_var_layer2_hyper1", "qmix_var_layer2_odd", "vdn_var_layer2",
          # no input LayerNorm (--use_feature_normalization off, mlp.py:60-62): tiny, the 3s5z width, odd + prev-act + Huber + PER, with a second
          # block and one-layer hyper-networks, VDN
-         "qmix_shape_nofn", "qmix_var_nofn_d252", "qmix_var_nofn_odd", "qmix_var_nofn_layer2_hyper1", "vdn_var_nofn"]
+         "qmix_shape_nofn", "qmix_var_nofn_d252", "qmix_var_nofn_odd", "qmix_var_nofn_layer2_hyper1", "vdn_var_nofn",
+         # tanh in the agent network's MLP base (--use_ReLU off, mlp.py:9-12): trunk_fwd3 / trunk_bwd3 carry it
+         "qmix_shape_tanh", "qmix_var_tanh_d252", "qmix_var_tanh_odd", "vdn_var_tanh"]
 RTOL = 1e-4
 
 
@@ -410,7 +412,8 @@ def test_deterministic_bitwise():
     assert np.array_equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("name", ["qmix_tiny", "qmix_shape_layer2", "qmix_var_layer2_d252", "qmix_shape_nofn", "qmix_var_nofn_d252"])
+@pytest.mark.parametrize("name", ["qmix_tiny", "qmix_shape_layer2", "qmix_var_layer2_d252", "qmix_shape_nofn", "qmix_var_nofn_d252", "qmix_shape_tanh",
+                                  "qmix_var_tanh_d252"])
 def test_policy_forward_matches_oracle_single_step_and_sequence(name):
     """policy.get_q_values (ope_agent_forward) with a non-zero initial hidden state; with one and with two hidden blocks (layer_N)."""
     from oracle import qmix_oracle as O
@@ -420,7 +423,7 @@ def test_policy_forward_matches_oracle_single_step_and_sequence(name):
     torch.manual_seed(3)
     obs = torch.randn(5, 7, dims.obs_dim)
     h0 = torch.randn(7, 64) * 0.5
-    q_ref, h_ref = O.agent_q_forward(P, obs, h0)
+    q_ref, h_ref = O.agent_q_forward(P, obs, h0, use_relu=bool(g["hp_use_relu"]) if "hp_use_relu" in g else True)
     q, h = policy.get_q_values(obs.cuda(), None, h0.cuda())
     np.testing.assert_allclose(q.cpu().numpy(), q_ref.numpy(), rtol=1e-4, atol=2e-6)
     np.testing.assert_allclose(h.cpu().numpy(), h_ref.numpy(), rtol=1e-4, atol=2e-6)
