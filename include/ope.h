@@ -499,6 +499,9 @@ typedef struct ope_rddpg_cfg {
                                   * these entry points: the batch is laid out as N*B episodes -- episode (i, b) = episode b seen through
                                   * agent i's centralized observation, everything else repeated -- and copy `rep` of episode (i, b) counts
                                   * only for rep == i.                                                                               */
+  int32_t continuous;            /* 1: Box action space (rMADDPGPolicy.py:121-129), as ope_ddpg_cfg.continuous: an action is the actor's output,
+                                  * target_noise_u is ADDITIVE noise (NULL = none), gumbel_noise_u is unused, no availability masks. */
+  int32_t reserved0;
 } ope_rddpg_cfg;
 
 /* which = 0 actor, 1 critic: offsets/sizes of its OPE_QMIX_NPARAM_AGENT tensors; returns the padded length. */

@@ -80,7 +80,8 @@ class DdpgCfg(C.Structure):
 class RddpgCfg(C.Structure):
     _fields_ = [("dims", Dims), ("batch", C.c_int32), ("num_q", C.c_int32), ("target_gumbel", C.c_int32),
                 ("use_huber", C.c_int32), ("use_per", C.c_int32), ("gamma", C.c_float), ("huber_delta", C.c_float),
-                ("n_total_agents", C.c_int32), ("agent_offset", C.c_int32), ("joint_next_acts", C.c_void_p), ("actor_row_weight", C.c_void_p)]
+                ("n_total_agents", C.c_int32), ("agent_offset", C.c_int32), ("joint_next_acts", C.c_void_p), ("actor_row_weight", C.c_void_p),
+                ("continuous", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class AllreduceCtx(C.Structure):

@@ -33,10 +33,10 @@ class R_MADDPGPolicy(object):
         self.obs_dim, self.act_dim = get_dim_from_space(self.obs_space), get_dim_from_space(self.act_space)
         self.output_dim = self.act_dim
         self.hidden_size = a.hidden_size
-        if self.act_space.__class__.__name__ not in ("Discrete", "list", "int"):
-            raise NotImplementedError("recurrent MADDPG / MATD3 on the accelerated path: discrete (one-hot) action spaces only (got %s); "
-                                      "continuous actions are supported by the MLP family" % self.act_space.__class__.__name__)
-        self.discrete, self.multidiscrete = True, False
+        kind = self.act_space.__class__.__name__
+        if "MultiDiscrete" in kind:
+            raise NotImplementedError("multi-discrete action spaces are not on the accelerated path")
+        self.discrete, self.multidiscrete = kind != "Box", False      # util.py:271-281; Box = continuous (rMADDPGPolicy.py:121-129)
         self.target_noise = target_noise
         self.td3 = bool(td3)
         self.num_q = 2 if td3 else 1
@@ -64,7 +64,8 @@ class R_MADDPGPolicy(object):
         cfg = _lib.RddpgCfg()
         cfg.dims = _lib.Dims(self.num_agents, self.act_dim, self.obs_dim, self.central_obs_dim, int(episode_length))
         cfg.batch, cfg.num_q = int(batch), self.num_q
-        cfg.target_gumbel = int(self.target_noise is not None)
+        cfg.continuous = int(not self.discrete)
+        cfg.target_gumbel = int(self.target_noise is not None and self.discrete)
         cfg.use_huber, cfg.use_per = int(bool(a.use_huber_loss)), int(bool(a.use_per))
         cfg.gamma, cfg.huber_delta = float(a.gamma), float(a.huber_delta)
         return cfg
@@ -78,6 +79,17 @@ class R_MADDPGPolicy(object):
         batch_size = obs.shape[0] if no_sequence else obs.shape[1]
         eps = None
         actor_out, new_rnn_states = (self.target_actor if use_target else self.actor)(obs, prev_actions, rnn_states)
+        if not self.discrete:      # rMADDPGPolicy.py:121-129
+            from ...maddpg.algorithm.MADDPGPolicy import gaussian_noise
+            if explore:
+                assert no_sequence, "Cannot do exploration on a sequence!"
+                actions = gaussian_noise(actor_out.shape, self.args.act_noise_std).to(actor_out.device) + actor_out
+            elif use_target and self.target_noise is not None:
+                assert isinstance(self.target_noise, float)
+                actions = gaussian_noise(actor_out.shape, self.target_noise).to(actor_out.device) + actor_out
+            else:
+                actions = actor_out
+            return actions, new_rnn_states, eps
         if use_gumbel or (use_target and self.target_noise is not None):
             actions = gumbel_softmax_hard(actor_out, available_actions, sample_gumbel_uniform(actor_out.shape))
         elif explore:
@@ -102,6 +114,8 @@ class R_MADDPGPolicy(object):
 
     def get_random_actions(self, obs, available_actions=None):
         batch_size = obs.shape[0]
+        if not self.discrete:      # rMADDPGPolicy.py:158-159
+            return np.random.uniform(self.act_space.low, self.act_space.high, size=(batch_size, self.act_dim))
         logits = torch.ones(batch_size, self.act_dim)
         if available_actions is not None:
             logits[torch.as_tensor(np.asarray(available_actions)) == 0] = -1e10

@@ -237,7 +237,13 @@ class R_MADDPG(object):
         elif override is not None:
             u_t = None if override[0] is None else override[0].to(self.device, dtype=torch.float32).contiguous()
         else:
-            u_t = draw((T + 1, N * B, A)) if policy.target_noise is not None else None
+            u_t = draw((T + 1, N * B, A)) if (policy.target_noise is not None and policy.discrete) else None
+        if not policy.discrete:
+            # continuous actions (rMADDPGPolicy.py:121-129): the target action carries additive gaussian noise when the policy has a target
+            # noise (R_MATD3), drawn on the CPU generator in the reference's order and shape; nothing is drawn for the actor update
+            assert others is None and override is None and not self.device_noise, "continuous actions: one shared policy, one process, host noise"
+            from ..maddpg.algorithm.MADDPGPolicy import gaussian_noise
+            u_t = gaussian_noise((T + 1, N * B, A), float(policy.target_noise)).to(self.device) if policy.target_noise is not None else None
         dev_prio = torch.is_tensor(importance_weights)     # device trees: weights in, priorities out stay in HBM
         w = None
         if self.use_per:
@@ -269,8 +275,9 @@ class R_MADDPG(object):
         # ---- actor (through the freshly updated critic) ----
         u_a = None
         if update_actor:
-            u_a = override[1].to(self.device, dtype=torch.float32).contiguous() if override is not None else draw((T, N * B, A))
-            assert u_a.shape == (T, N * B, A)
+            if policy.discrete:
+                u_a = override[1].to(self.device, dtype=torch.float32).contiguous() if override is not None else draw((T, N * B, A))
+                assert u_a.shape == (T, N * B, A)
             _lib.check(_lib.lib.ope_rddpg_actor_loss_and_grad(C.byref(cfg), C.byref(f), _lib.ptr(policy.actor._flat),
                                                               _lib.ptr(policy.critic._flat), _lib.ptr(u_a), _lib.ptr(ws), ws.numel(),
                                                               _lib.ptr(ga), st), "ope_rddpg_actor_loss_and_grad")

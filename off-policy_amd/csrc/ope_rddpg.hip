@@ -367,6 +367,7 @@ static int rddpg_cfg_ok(const ope_rddpg_cfg* c) {
                                  d.state_dim + c->n_total_agents * d.act_dim > 1024 || c->n_total_agents > 64)) return 0;
   if (c->batch < 1 || c->num_q < 1 || c->num_q > 4) return 0;
   if ((int64_t)(d.episode_length + 1) * d.n_agents * c->batch > (int64_t)1 << 24) return 0;
+  if ((c->continuous != 0 && c->continuous != 1) || (c->continuous && c->target_gumbel)) return 0;
   return 1;
 }
 
@@ -638,7 +639,7 @@ extern "C" int ope_rddpg_critic_loss_and_grad(const ope_rddpg_cfg* cfg, const op
     if ((rc = rtrunk(bt->obs, p.Ra1, p.D, theta_actor_tgt, p.AL, W + p.gi_t, W, nullptr, st))) return rc;
     if ((rc = rscan(W + p.gi_t, p.NB, p.T + 1, theta_actor_tgt, p.AL, W + p.h_t, W, nullptr, st))) return rc;
     if ((rc = rhead(W + p.h_t, p.Ra1, p.A, theta_actor_tgt, p.AL, W + p.lg_t, W, nullptr, st))) return rc;
-    if ((rc = launch_action(W + p.lg_t, bt->avail_acts, NoiseSrc{target_noise_u, 0, nullptr, 0}, (int)p.Ra1, p.B, p.A, p.N, cfg->target_gumbel ? 1 : 0, 1,
+    if ((rc = launch_action(W + p.lg_t, bt->avail_acts, NoiseSrc{target_noise_u, 0, nullptr, 0}, (int)p.Ra1, p.B, p.A, p.N, cfg->continuous ? 2 : (cfg->target_gumbel ? 1 : 0), 1,
                             W + p.cnact, nullptr, nullptr, st))) return rc;
     nact = W + p.cnact;
   }
@@ -682,7 +683,7 @@ extern "C" int ope_rddpg_target_actions(const ope_rddpg_cfg* cfg, const ope_fiel
   if ((rc = rtrunk(bt->obs, p.Ra1, p.D, theta_actor_tgt, p.AL, W + p.gi_t, W, nullptr, st))) return rc;
   if ((rc = rscan(W + p.gi_t, p.NB, p.T + 1, theta_actor_tgt, p.AL, W + p.h_t, W, nullptr, st))) return rc;
   if ((rc = rhead(W + p.h_t, p.Ra1, p.A, theta_actor_tgt, p.AL, W + p.lg_t, W, nullptr, st))) return rc;
-  return launch_action(W + p.lg_t, bt->avail_acts, NoiseSrc{target_noise_u, 0, nullptr, 0}, (int)p.Ra1, p.B, p.A, p.N, cfg->target_gumbel ? 1 : 0, 1,
+  return launch_action(W + p.lg_t, bt->avail_acts, NoiseSrc{target_noise_u, 0, nullptr, 0}, (int)p.Ra1, p.B, p.A, p.N, cfg->continuous ? 2 : (cfg->target_gumbel ? 1 : 0), 1,
                        joint_next_acts, nullptr, nullptr, st, p.NT, p.a0);
 }
 
@@ -690,7 +691,7 @@ extern "C" int ope_rddpg_actor_loss_and_grad(const ope_rddpg_cfg* cfg, const ope
                                              const float* theta_critic, const float* gumbel_noise_u, void* workspace,
                                              int64_t workspace_bytes, float* grad, void* stream) {
   (void)hipGetLastError();
-  if (!rddpg_cfg_ok(cfg) || !bt || !theta_actor || !theta_critic || !gumbel_noise_u || !workspace || !grad) return OPE_EINVAL;
+  if (!rddpg_cfg_ok(cfg) || !bt || !theta_actor || !theta_critic || (!cfg->continuous && !gumbel_noise_u) || !workspace || !grad) return OPE_EINVAL;
   if (!bt->obs || !bt->share_obs || !bt->acts || !bt->dones) return OPE_EINVAL;
   RPlan p;
   rddpg_plan(cfg, &p);
@@ -703,7 +704,8 @@ extern "C" int ope_rddpg_actor_loss_and_grad(const ope_rddpg_cfg* cfg, const ope
   if ((rc = rtrunk(bt->obs, p.Ra, p.D, theta_actor, p.AL, W + p.SA.gi, W, &p.SA, st))) return rc;
   if ((rc = rscan(W + p.SA.gi, p.NB, p.T, theta_actor, p.AL, W + p.SA.h, W, &p.SA, st))) return rc;
   if ((rc = rhead(W + p.SA.h, p.Ra, p.A, theta_actor, p.AL, W + p.lga, W, &p.SA, st))) return rc;
-  if ((rc = launch_action(W + p.lga, bt->avail_acts, NoiseSrc{gumbel_noise_u, 0, nullptr, 0}, Ra, p.B, p.A, p.N, 1, 0, nullptr, W + p.actout, W + p.ysoft, st)))
+  if ((rc = launch_action(W + p.lga, bt->avail_acts, NoiseSrc{cfg->continuous ? nullptr : gumbel_noise_u, 0, nullptr, 0}, Ra, p.B, p.A, p.N, cfg->continuous ? 2 : 1, 0, nullptr,
+                          W + p.actout, W + p.ysoft, st)))
     return rc;
   // critic state along the buffer sequence (identical for the N stacked copies)
   if ((rc = launch_build_cin(bt->share_obs, bt->acts, nullptr, p.T, p.B, p.NT, p.A, p.S, 1, W + p.xin, st))) return rc;
@@ -752,7 +754,7 @@ extern "C" int ope_rddpg_actor_loss_and_grad(const ope_rddpg_cfg* cfg, const ope
   ag.R = Ra; ag.B = p.B; ag.N = p.N; ag.A = p.A; ag.A4 = p.A4; ag.S = p.S; ag.Din = p.Din; ag.a_off = p.a0; ag.dz1 = W + p.dz1;
   ag.xhat1 = W + p.SC.xhat1; ag.rstd1 = W + p.SC.rstd1; ag.mu1 = W + p.SC.mu1; ag.mu0 = W + p.SC.mu0; ag.rstd0 = W + p.SC.rstd0;
   ag.act = W + p.actout; ag.y = W + p.ysoft; ag.theta = theta_critic; ag.fc1_w = p.CL.fc1_w; ag.fc1_b = p.CL.fc1_b; ag.fn_w = p.CL.fn_w;
-  ag.fn_b = p.CL.fn_b; ag.cvec = W + p.cvec; ag.dlogits = W + p.dlg; ag.identity = 0;
+  ag.fn_b = p.CL.fn_b; ag.cvec = W + p.cvec; ag.dlogits = W + p.dlg; ag.identity = cfg->continuous ? 1 : 0;
   if ((rc = launch_action_grad(ag, st))) return rc;
   // actor BPTT and gradients
   return rnn_backward(p, W, p.SA, bt->obs, p.NB, p.T, p.D, p.A, p.A4, W + p.dlg, theta_actor, p.AL, p.ns_a, ope_cdiv(Ra, 16), grad, st);

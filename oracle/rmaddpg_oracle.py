@@ -38,9 +38,11 @@ def critic_q(P, K, cent, act, h0):
 
 
 class RMaddpgOracle(object):
-    def __init__(self, actor, critic, actor_tgt, critic_tgt, n_agents, hp=None, td3=False, actor_update_interval=None):
+    def __init__(self, actor, critic, actor_tgt, critic_tgt, n_agents, hp=None, td3=False, actor_update_interval=None, continuous=False):
+        """`continuous`: Box action space (rMADDPGPolicy.py:121-129): the action is the actor's output, R_MATD3's target action adds the
+        gaussian noise passed as `u_target`; no gumbel, no availability masks."""
         self.hp = hp or HP()
-        self.N, self.td3 = n_agents, td3
+        self.N, self.td3, self.continuous = n_agents, td3, bool(continuous)
         self.K = 2 if td3 else 1
         f = lambda d: OrderedDict((k, torch.as_tensor(np.asarray(v), dtype=torch.float32).clone()) for k, v in d.items())
         self.actor, self.critic, self.actor_tgt, self.critic_tgt = f(actor), f(critic), f(actor_tgt), f(critic_tgt)
@@ -80,7 +82,7 @@ class RMaddpgOracle(object):
             s_obs = torch.cat(list(obs), dim=1)
             s_av = torch.cat(list(avail), dim=1) if avail is not None else None
             lg, _ = actor_logits(self.actor_tgt, s_obs, torch.zeros(N * B, hp.hidden_size))
-            nact = gumbel_hard(lg, s_av, torch.as_tensor(u_target)) if self.td3 else onehot_argmax(lg, s_av)
+            nact = ((lg + torch.as_tensor(u_target)) if u_target is not None else lg) if self.continuous else (gumbel_hard(lg, s_av, torch.as_tensor(u_target)) if self.td3 else onehot_argmax(lg, s_av))
         return list(nact[1:].split(B, dim=1))
 
     def critic_loss(self, live, batch, u_target=None, weights=None, joint=None, per_agent_cent=False):
@@ -101,7 +103,7 @@ class RMaddpgOracle(object):
                 s_obs = torch.cat(list(obs), dim=1)                          # [T+1, N*B, D]
                 s_av = torch.cat(list(avail), dim=1) if avail is not None else None
                 lg, _ = actor_logits(self.actor_tgt, s_obs, torch.zeros(N * B, H))
-                nact = gumbel_hard(lg, s_av, torch.as_tensor(u_target)) if self.td3 else onehot_argmax(lg, s_av)
+                nact = ((lg + torch.as_tensor(u_target)) if u_target is not None else lg) if self.continuous else (gumbel_hard(lg, s_av, torch.as_tensor(u_target)) if self.td3 else onehot_argmax(lg, s_av))
                 cent_nact = torch.cat(nact[1:].split(B, dim=1), dim=-1)      # [T, B, N*A]
             cent_act = torch.cat(list(acts), dim=-1)                         # [T, B, N*A]
         if per_agent_cent:
@@ -143,7 +145,7 @@ class RMaddpgOracle(object):
         s_obs = torch.cat(list(obs), dim=1)[:-1]
         s_av = torch.cat(list(avail), dim=1)[:-1] if avail is not None else None
         lg, _ = actor_logits(live, s_obs, torch.zeros(N * B, H))
-        pol = gumbel_hard(lg, s_av, torch.as_tensor(u_actor))            # [T, N*B, A]
+        pol = lg if self.continuous else gumbel_hard(lg, s_av, torch.as_tensor(u_actor))            # [T, N*B, A]
         agent_seqs = pol.split(B, dim=1)
         stacked_obs = torch.cat(list(cent), dim=1)[:-1] if per_agent_cent else cent[:-1].repeat(1, N, 1)
         every = list(acts) if all_acts is None else list(all_acts)

@@ -31,7 +31,7 @@ def build(g, device="cuda:0", dims=None, args=None, td3=None, cap=None, same_sha
                             use_same_share_obs=same_share)
         td3 = bool(g["td3"])
         cap = len(g["idx_range"])
-    pinfo = policy_info_for(dims)
+    pinfo = policy_info_for(dims, continuous=bool(g["continuous"]) if "continuous" in g else False)
     dev = torch.device(device)
     torch.manual_seed(1)
     np.random.seed(1)
@@ -131,7 +131,7 @@ def _flat_grads(mod, gvec):
     return out, g[n] / cnt
 
 
-@pytest.mark.parametrize("name", ["rmatd3_tiny", "rmaddpg_odd_huber_per", "rmaddpg_3m"])
+@pytest.mark.parametrize("name", ["rmatd3_tiny", "rmaddpg_odd_huber_per", "rmaddpg_3m", "rmaddpg_cont_tiny", "rmatd3_cont_odd"])
 def test_gradients_match_oracle_per_tensor(name):
     g = load_golden(name)
     dims, buf, policy, trainer = build(g)

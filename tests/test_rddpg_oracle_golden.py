@@ -8,7 +8,9 @@ from golden_util import EP_KEYS
 from oracle import rmaddpg_oracle as RO
 from oracle.qmix_oracle import HP
 
-CASES = ["rmaddpg_tiny", "rmatd3_tiny", "rmaddpg_odd_huber_per", "rmatd3_odd_per", "rmaddpg_3m"]
+CASES = ["rmaddpg_tiny", "rmatd3_tiny", "rmaddpg_odd_huber_per", "rmatd3_odd_per", "rmaddpg_3m",
+         # round 4: continuous (Box) action spaces (rMADDPGPolicy.py:121-129)
+         "rmaddpg_cont_tiny", "rmatd3_cont_odd"]
 
 
 def rddpg_oracle_from(g):
@@ -16,7 +18,7 @@ def rddpg_oracle_from(g):
             huber_delta=float(g["hp_delta"]), use_per=bool(g["hp_per"]), per_nu=float(g["hp_nu"]), per_eps=float(g["hp_per_eps"]),
             tau=float(g["hp_tau"]), max_grad_norm=float(g["hp_maxnorm"]))
     return RO.RMaddpgOracle(sub(g, "actor/"), sub(g, "critic/"), sub(g, "actor_tgt/"), sub(g, "critic_tgt/"), int(g["dims"][0]), hp,
-                            td3=bool(g["td3"]))
+                            td3=bool(g["td3"]), continuous=bool(g["continuous"]) if "continuous" in g else False)
 
 
 def rnoise_for(g, step, update_actor=True):
@@ -25,6 +27,8 @@ def rnoise_for(g, step, update_actor=True):
     n, a, _, _, T = [int(x) for x in g["dims"]]
     B = len(g["inds"])
     torch.manual_seed(1000 + step)
+    if "continuous" in g and bool(g["continuous"]):      # gaussian_noise(shape, target_action_noise_std) of the target action (R_MATD3); nothing for the actor
+        return (torch.empty(T + 1, n * B, a).normal_(mean=0, std=0.2) if bool(g["td3"]) else None), None
     u_t = torch.FloatTensor(T + 1, n * B, a).uniform_() if bool(g["td3"]) else None
     u_a = torch.FloatTensor(T, n * B, a).uniform_() if update_actor else None
     return u_t, u_a
