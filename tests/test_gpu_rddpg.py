@@ -31,7 +31,7 @@ def build(g, device="cuda:0", dims=None, args=None, td3=None, cap=None, same_sha
                             use_same_share_obs=same_share)
         td3 = bool(g["td3"])
         cap = len(g["idx_range"])
-    pinfo = policy_info_for(dims, continuous=bool(g["continuous"]) if "continuous" in g else False)
+    pinfo = policy_info_for(dims, continuous=bool(g is not None and "continuous" in g and g["continuous"]))
     dev = torch.device(device)
     torch.manual_seed(1)
     np.random.seed(1)
