@@ -397,7 +397,12 @@ typedef struct ope_ddpg_cfg {
                                  * action = target actor output + target_noise_u (here ADDITIVE noise, already scaled: gaussian_noise(shape,
                                  * target_noise) of MATD3, util.py:217-218; NULL = none), the actor update differentiates straight through
                                  * (gumbel_noise_u unused, may be NULL). No availability masks. General kernel path only. 0 = discrete. */
-  int32_t reserved0;
+  int32_t n_act_heads;          /* > 1: MULTI-DISCRETE action space (MADDPGPolicy.py:73-92, act.py:14-17): the act_dim outputs are n_act_heads
+                                 * one-hot blocks of act_head_dims[i] entries (their sum = dims.act_dim); argmax / hard gumbel-softmax and its
+                                 * straight-through adjoint act per block. No availability masks (upstream passes none). General kernel path
+                                 * only; the flat layout is the single-head one (the heads' rows are consecutive). 0 or 1 = one head. */
+  int32_t act_head_dims[6];
+  int32_t reserved1;
 } ope_ddpg_cfg;
 
 /* One sampled batch in MlpPolicyBuffer.sample_inds order/shapes (mlp_buffer.py:213-257), device pointers. */
@@ -501,7 +506,9 @@ typedef struct ope_rddpg_cfg {
                                   * only for rep == i.                                                                               */
   int32_t continuous;            /* 1: Box action space (rMADDPGPolicy.py:121-129), as ope_ddpg_cfg.continuous: an action is the actor's output,
                                   * target_noise_u is ADDITIVE noise (NULL = none), gumbel_noise_u is unused, no availability masks. */
-  int32_t reserved0;
+  int32_t n_act_heads;           /* > 1: multi-discrete action space, as ope_ddpg_cfg.n_act_heads / act_head_dims */
+  int32_t act_head_dims[6];
+  int32_t reserved1;
 } ope_rddpg_cfg;
 
 /* which = 0 actor, 1 critic: offsets/sizes of its OPE_QMIX_NPARAM_AGENT tensors; returns the padded length. */

@@ -74,14 +74,14 @@ class DdpgCfg(C.Structure):
                 ("use_huber", C.c_int32), ("use_per", C.c_int32), ("gamma", C.c_float), ("huber_delta", C.c_float),
                 ("per_eps", C.c_float), ("noise_seed", C.c_uint64), ("noise_counter", C.c_void_p),
                 ("n_total_agents", C.c_int32), ("agent_offset", C.c_int32), ("joint_next_acts", C.c_void_p),
-                ("continuous", C.c_int32), ("reserved0", C.c_int32)]
+                ("continuous", C.c_int32), ("n_act_heads", C.c_int32), ("act_head_dims", C.c_int32 * 6), ("reserved1", C.c_int32)]
 
 
 class RddpgCfg(C.Structure):
     _fields_ = [("dims", Dims), ("batch", C.c_int32), ("num_q", C.c_int32), ("target_gumbel", C.c_int32),
                 ("use_huber", C.c_int32), ("use_per", C.c_int32), ("gamma", C.c_float), ("huber_delta", C.c_float),
                 ("n_total_agents", C.c_int32), ("agent_offset", C.c_int32), ("joint_next_acts", C.c_void_p), ("actor_row_weight", C.c_void_p),
-                ("continuous", C.c_int32), ("reserved0", C.c_int32)]
+                ("continuous", C.c_int32), ("n_act_heads", C.c_int32), ("act_head_dims", C.c_int32 * 6), ("reserved1", C.c_int32)]
 
 
 class AllreduceCtx(C.Structure):

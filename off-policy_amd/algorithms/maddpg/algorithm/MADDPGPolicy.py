@@ -27,6 +27,14 @@ def gaussian_noise(shape, std):
     return torch.empty(shape).normal_(mean=0, std=std)
 
 
+def gumbel_uniform_for(policy, rows):
+    """The uniform noise of one hard gumbel-softmax over `rows` rows of the policy's action vector, drawn as the reference draws it: one
+    torch.FloatTensor(rows, a).uniform_() per (sub-)action head in order (util.py:178-190; MADDPGPolicy.py:75-77), concatenated."""
+    if getattr(policy, "multidiscrete", False):
+        return torch.cat([sample_gumbel_uniform((rows, int(a))) for a in policy.act_dim], dim=-1)
+    return sample_gumbel_uniform((rows, policy.output_dim))
+
+
 def onehot_from_logits(logits, avail=None):
     logits = logits.clone()
     if avail is not None:
@@ -53,16 +61,17 @@ class MADDPGPolicy(object):
         self.central_obs_dim, self.central_act_dim = policy_config["cent_obs_dim"], policy_config["cent_act_dim"]
         self.obs_space, self.act_space = policy_config["obs_space"], policy_config["act_space"]
         self.obs_dim, self.act_dim = get_dim_from_space(self.obs_space), get_dim_from_space(self.act_space)
-        self.output_dim = self.act_dim
         kind = self.act_space.__class__.__name__
-        if "MultiDiscrete" in kind:
-            raise NotImplementedError("multi-discrete action spaces are not on the accelerated path")
-        self.discrete, self.multidiscrete = kind != "Box", False      # util.py:271-281 is_discrete / is_multidiscrete
+        self.discrete, self.multidiscrete = kind != "Box", "MultiDiscrete" in kind      # util.py:271-281 is_discrete / is_multidiscrete
+        # act_dim: as upstream an int, or the ARRAY of a multi-discrete space's sub-action sizes; output_dim: the action vector's length
+        self.output_dim = int(sum(self.act_dim)) if self.multidiscrete else self.act_dim
+        if self.multidiscrete and len(self.act_dim) > 6:
+            raise NotImplementedError("multi-discrete action spaces with more than 6 sub-actions are not on the accelerated path")
         self.target_noise = target_noise
         self.td3 = bool(td3)
         self.num_q = 2 if td3 else 1
-        assert self.central_act_dim % self.act_dim == 0
-        self.num_agents = self.central_act_dim // self.act_dim
+        assert self.central_act_dim % self.output_dim == 0
+        self.num_agents = self.central_act_dim // self.output_dim
         self.frozen_q_head = bool(frozen_q_head)
         cfg = self.ddpg_cfg(1)
         dev, a = self.device, self.args
@@ -82,7 +91,11 @@ class MADDPGPolicy(object):
     def ddpg_cfg(self, batch):
         a = self.args
         cfg = _lib.DdpgCfg()
-        cfg.dims = _lib.Dims(self.num_agents, self.act_dim, self.obs_dim, self.central_obs_dim, 1)
+        cfg.dims = _lib.Dims(self.num_agents, self.output_dim, self.obs_dim, self.central_obs_dim, 1)
+        if self.multidiscrete:      # the action vector = one-hot blocks, argmax / gumbel-softmax per block (ope_ddpg_cfg.n_act_heads)
+            cfg.n_act_heads = len(self.act_dim)
+            for i, a_dim in enumerate(self.act_dim):
+                cfg.act_head_dims[i] = int(a_dim)
         cfg.batch, cfg.num_q = int(batch), self.num_q
         cfg.continuous = int(not self.discrete)
         cfg.target_gumbel = int(self.target_noise is not None and self.discrete)
@@ -104,6 +117,20 @@ class MADDPGPolicy(object):
             else:
                 actions = actor_out
             return actions, eps
+        if self.multidiscrete:      # MADDPGPolicy.py:73-92: every sub-action on its own, no availability masks
+            outs = torch.split(actor_out, [int(x) for x in self.act_dim], dim=-1)
+            if use_gumbel or (use_target and self.target_noise is not None):
+                actions = torch.cat([gumbel_softmax_hard(o, None, sample_gumbel_uniform(o.shape)) for o in outs], dim=-1)
+            elif explore:
+                onehot = torch.cat([gumbel_softmax_hard(o, None, sample_gumbel_uniform(o.shape)) for o in outs], dim=-1)
+                eps = self.exploration.eval(t_env)
+                rand_numbers = np.random.rand(batch_size, 1)
+                take_random = (rand_numbers < eps).astype(int).reshape(-1, 1)
+                random_actions = torch.cat([OneHotCategorical(logits=torch.ones(batch_size, int(x))).sample() for x in self.act_dim], dim=1)
+                actions = (1 - take_random) * onehot.detach().cpu().numpy() + take_random * random_actions.numpy()
+            else:
+                actions = torch.cat([onehot_from_logits(o) for o in outs], dim=-1)
+            return actions, eps
         if use_gumbel or (use_target and self.target_noise is not None):
             actions = gumbel_softmax_hard(actor_out, available_actions, sample_gumbel_uniform(actor_out.shape))
         elif explore:
@@ -124,6 +151,8 @@ class MADDPGPolicy(object):
         batch_size = obs.shape[0]
         if not self.discrete:      # MADDPGPolicy.py:135-136
             return np.random.uniform(self.act_space.low, self.act_space.high, size=(batch_size, self.act_dim))
+        if self.multidiscrete:     # MADDPGPolicy.py:126-129
+            return np.concatenate([OneHotCategorical(logits=torch.ones(batch_size, int(x))).sample().numpy() for x in self.act_dim], axis=-1)
         logits = torch.ones(batch_size, self.act_dim)
         if available_actions is not None:
             logits[torch.as_tensor(np.asarray(available_actions)) == 0] = -1e10

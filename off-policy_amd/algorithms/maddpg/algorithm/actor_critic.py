@@ -9,6 +9,7 @@ of the flat vector but are not registered and the optimizer / Polyak only touch 
 """
 import ctypes as C
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -48,11 +49,17 @@ def _draw_trunk(in_dim, use_orthogonal, use_ReLU):
 
 
 def draw_actor_values(args, obs_dim, act_dim):
+    """`act_dim`: an int, or the array of a multi-discrete space's sub-action sizes -- one Linear head each, constructed in order
+    (ACTLayer, act.py:14-19); the heads' rows are returned stacked ([sum, 64] / [sum]: the flat layout of a single head)."""
     vals = _draw_trunk(obs_dim, getattr(args, "use_orthogonal", True), getattr(args, "use_ReLU", True))
     init_w = nn.init.orthogonal_ if getattr(args, "use_orthogonal", True) else nn.init.xavier_uniform_
-    out = nn.Linear(H, act_dim)
-    init_w(out.weight.data, gain=getattr(args, "gain", 0.01))          # ACTLayer, act.py:10-19
-    return [v.detach().float() for v in vals + [out.weight.data, torch.zeros(act_dim)]]
+    ws = []
+    for a_dim in ([int(act_dim)] if np.ndim(act_dim) == 0 else [int(x) for x in act_dim]):
+        out = nn.Linear(H, a_dim)
+        init_w(out.weight.data, gain=getattr(args, "gain", 0.01))          # ACTLayer, act.py:10-19
+        ws.append(out.weight.data)
+    w = torch.cat(ws, dim=0)
+    return [v.detach().float() for v in vals + [w, torch.zeros(w.shape[0])]]
 
 
 def draw_critic_values(args, in_dim, num_q):
@@ -79,14 +86,30 @@ class MADDPG_Actor(FlatModule):
         device = torch.device(device)
         if flat is None:
             flat = torch.zeros(total, dtype=torch.float32, device=device)
-        names = _TRUNK + ["act.action_out.weight", "act.action_out.bias"]
-        super().__init__(names, _trunk_shapes(obs_dim) + [(act_dim, H), (act_dim,)], offs, flat)
+        heads = None if np.ndim(act_dim) == 0 else [int(x) for x in act_dim]
+        if heads is None:
+            names = _TRUNK + ["act.action_out.weight", "act.action_out.bias"]
+            shapes, o = _trunk_shapes(obs_dim) + [(int(act_dim), H), (int(act_dim),)], offs
+        else:
+            # multi-discrete: act.action_outs.{i}.{weight,bias} (act.py:14-17) are row ranges of the one stacked head the kernels see
+            names, shapes, o, r0 = list(_TRUNK), _trunk_shapes(obs_dim), list(offs[:14]), 0
+            for i, a_dim in enumerate(heads):
+                names += ["act.action_outs.%d.weight" % i, "act.action_outs.%d.bias" % i]
+                shapes += [(a_dim, H), (a_dim,)]
+                o += [offs[14] + r0 * H, offs[15] + r0]
+                r0 += a_dim
+            act_dim = r0
+        super().__init__(names, shapes, o, flat)
+        self.head_dims = heads
         self.obs_dim, self.act_dim, self.device, self.padded_numel = int(obs_dim), int(act_dim), device, total
         self._dims = _lib.Dims(1, int(act_dim), int(obs_dim), 1, 1)
         self._ws = None
         if values is not None:
-            for p, v in zip(self.parameters(), values):
+            for p, v in zip(list(self.parameters())[:14], values[:14]):
                 p.data.copy_(v)
+            A = self.act_dim
+            flat[offs[14]:offs[14] + A * H].view(A, H).copy_(values[14])
+            flat[offs[15]:offs[15] + A].copy_(values[15])
 
     def forward(self, x):
         """Logits for every action (actor_critic.py:28-41) through ope_agent_forward_mlp."""

@@ -20,7 +20,7 @@ import torch
 
 from ... import _lib
 from ... import dist as opdist
-from .algorithm.MADDPGPolicy import sample_gumbel_uniform
+from .algorithm.MADDPGPolicy import sample_gumbel_uniform, gumbel_uniform_for
 
 
 _OPT_TAIL_DEFAULT = os.environ.get("OPE_DDPG_OPT_TAIL", "0") == "1"
@@ -46,7 +46,7 @@ class MADDPG(object):
             flat_agents = [a for pid in self.policy_ids for a in self.policy_agents[pid]]
             if flat_agents != list(range(num_agents)) or any(len(self.policy_agents[pid]) == 0 for pid in self.policy_ids):
                 raise NotImplementedError("several policies: agents must be numbered policy by policy, every policy with at least one agent")
-            if len({self.policies[pid].act_dim for pid in self.policy_ids}) != 1:
+            if len({int(np.sum(self.policies[pid].act_dim)) for pid in self.policy_ids}) != 1 or any(self.policies[pid].multidiscrete for pid in self.policy_ids):
                 raise NotImplementedError("several policies on the accelerated MADDPG path need one action dimension")
         self.num_updates = {p_id: 0 for p_id in self.policy_ids}
         self.use_same_share_obs = args.use_same_share_obs
@@ -105,8 +105,8 @@ class MADDPG(object):
             raise NotImplementedError("cent_train_policy_on_batch with several policies is not on the accelerated path")
         if policy.num_q != 1:
             raise NotImplementedError("cent_train_policy_on_batch with two critic heads (MATD3): upstream defines no rule for them (maddpg.py:295)")
-        if not policy.discrete:
-            raise NotImplementedError("cent_train_policy_on_batch with continuous actions is not on the accelerated path (no reference fixture pins it)")
+        if not policy.discrete or policy.multidiscrete:
+            raise NotImplementedError("cent_train_policy_on_batch with continuous / multi-discrete actions is not on the accelerated path (no reference fixture pins it)")
         if getattr(self.args, "use_value_active_masks", False):
             raise NotImplementedError("cent_train_policy_on_batch with use_value_active_masks: upstream weights the critic loss by the valid-transition "
                                       "mask there (maddpg.py:314-317, 327-330); the accelerated path takes the plain mean over the N*B rows")
@@ -117,7 +117,7 @@ class MADDPG(object):
         avail = t(avail_b[pid]) if avail_b is not None else None
         navail = t(navail_b[pid]) if navail_b is not None else None
         N, B, _ = obs.shape
-        A = policy.act_dim
+        A = policy.output_dim
         assert cent.shape[:2] == (N, B), "per-agent centralized observations [N, B, S] expected"
         tile = lambda x: None if x is None else x.repeat(1, N, 1).contiguous()          # [N, N*B, .]: column (i, b) <- b
         eye = torch.eye(N, device=dev).repeat_interleave(B, dim=1)[..., None]           # copy a of transition (i, b) counts iff a == i
@@ -225,7 +225,7 @@ class MADDPG(object):
         cfg = policy.ddpg_cfg(B)
         if self.multi_policy:
             assert not self.device_noise, "several policies: the gumbel noise comes from the reference's CPU generator stream"
-            NT, A = self.num_agents, policy.act_dim
+            NT, A = self.num_agents, policy.output_dim
             # joint target action: one ope_ddpg_target_actions per policy (its target actor on its agents' next observations; noise
             # drawn per policy in policy order, as get_update_info does), scattered into [B][N_total * A]
             joint_next = torch.empty(B, NT * A, **self.tpdv)
@@ -272,7 +272,8 @@ class MADDPG(object):
             cfg.noise_seed = self._noise_seed[1]
             cfg.noise_counter = _lib.ptr(ctr).value
         else:
-            draw = lambda shape: sample_gumbel_uniform(shape).to(self.device)
+            # (multi-discrete: one uniform block per sub-action head, in the reference's order -- gumbel_uniform_for)
+            draw = lambda shape: gumbel_uniform_for(policy, shape[0]).to(self.device)
         override, self._noise_override = getattr(self, "_noise_override", None), None      # (target noise, actor noise) to use instead of drawing
         if not policy.discrete:
             # continuous actions (MADDPGPolicy.py:107-116): no gumbel anywhere; the target action carries additive gaussian noise when the
@@ -280,9 +281,9 @@ class MADDPG(object):
             assert not self.device_noise and not self.multi_policy, "continuous actions: host noise, one shared policy"
             from .algorithm.MADDPGPolicy import gaussian_noise
             draw = lambda shape: None
-        u_t = draw((N * B, policy.act_dim)) if (policy.target_noise is not None and not self.multi_policy) else None
+        u_t = draw((N * B, policy.output_dim)) if (policy.target_noise is not None and not self.multi_policy) else None
         if not policy.discrete and policy.target_noise is not None:
-            u_t = gaussian_noise((N * B, policy.act_dim), float(policy.target_noise)).to(self.device)
+            u_t = gaussian_noise((N * B, policy.output_dim), float(policy.target_noise)).to(self.device)
         dev_prio = torch.is_tensor(importance_weights)
         w = None
         if self.use_per:
@@ -308,8 +309,8 @@ class MADDPG(object):
         new_priorities = (prio if dev_prio else prio.cpu().numpy()) if self.use_per else None
         # ---- actor ----
         if update_actor:
-            u_a = draw((N * B, policy.act_dim)) if override is None else override[1]
-            assert u_a is None or tuple(u_a.shape) == (N * B, policy.act_dim)
+            u_a = draw((N * B, policy.output_dim)) if override is None else override[1]
+            assert u_a is None or tuple(u_a.shape) == (N * B, policy.output_dim)
             if in_launch:
                 ob, as_ = self._opt_block(policy.actor_optimizer, policy.actor.padded_numel, policy.target_actor._flat, policy.actor.unused_range)
                 _lib.check(_lib.lib.ope_ddpg_actor_update(C.byref(cfg), C.byref(mb), _lib.ptr(policy.actor._flat), _lib.ptr(policy.critic._flat),

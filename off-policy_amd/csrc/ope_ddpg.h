@@ -7,6 +7,22 @@
 
 namespace ope {
 
+// Blocks of a multi-discrete action vector (ope_ddpg_cfg.n_act_heads): n <= 1 = one block of all A entries
+struct ActHeads { int n; int dim[6]; };
+static inline ActHeads act_heads_of(int n, const int32_t* dims, int A) {
+  ActHeads h;
+  h.n = n > 1 ? n : 1;
+  for (int i = 0; i < 6; ++i) h.dim[i] = (n > 1 && i < n) ? dims[i] : (i == 0 ? A : 0);
+  return h;
+}
+static inline bool act_heads_ok(int n, const int32_t* dims, int A) {
+  if (n <= 1) return n >= 0;
+  if (n > 6) return false;
+  int s = 0;
+  for (int i = 0; i < n; ++i) { if (dims[i] < 1) return false; s += dims[i]; }
+  return s == A;
+}
+
 struct CriticTdArgs {
   int B, K, K4;
   float gamma; int use_huber; float huber_delta; float per_eps;
@@ -32,6 +48,7 @@ struct ActGradArgs {
   float* cvec;                               // [128] scratch: c_i = sum_k gamma_k W_ik ; cb_i = b_i + sum_k W_ik beta_k
   float* dlogits;                            // [R][A4]
   int identity;                              // continuous actions: d action / d actor output = 1 (no gumbel-softmax adjoint; `y` unused)
+  ActHeads heads;                            // multi-discrete: the softmax adjoint acts per block (heads.n <= 1: one block of A)
 };
 int launch_action_grad(const ActGradArgs& a, hipStream_t st);
 
@@ -41,7 +58,8 @@ int launch_build_cin(const float* cent, const float* acts, const float* repl, in
                      hipStream_t st, int rep_off = 0);
 // nact_agents / a_off: the scatter target cent_nact holds nact_agents (default N) agents per row, this launch's agents start at a_off
 int launch_action(const float* logits, const float* avail, NoiseSrc U, int rows, int B, int A, int N, int mode, int t_shift,
-                  float* cent_nact, float* act_out, float* soft_out, hipStream_t st, int nact_agents = 0, int a_off = 0);
+                  float* cent_nact, float* act_out, float* soft_out, hipStream_t st, int nact_agents = 0, int a_off = 0,
+                  const ActHeads* heads = nullptr);
 
 // Optimiser step in the tail of a tile launch (ope_ddpg_opt, ope.h): slab reduction + clip + Adam + Polyak behind two grid barriers.
 struct TileOpt {

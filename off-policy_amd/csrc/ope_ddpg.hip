@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(256) build_cin_kernel(const float* __restrict_
 __global__ void __launch_bounds__(256) action_kernel(const float* __restrict__ logits, const float* __restrict__ avail,
                                                       NoiseSrc U, int rows, int B, int A, int N, int mode, int t_shift,
                                                       int rpb, float* __restrict__ cent_nact, float* __restrict__ act_out,
-                                                      float* __restrict__ soft_out, int nact_agents, int a_off) {
+                                                      float* __restrict__ soft_out, int nact_agents, int a_off, ActHeads hd) {
   extern __shared__ float sm[];
   const int pitch = A | 1;
   float* val = sm;                      // [rpb][pitch] masked (noisy) logits, overwritten by the output values
@@ -96,23 +96,30 @@ __global__ void __launch_bounds__(256) action_kernel(const float* __restrict__ l
   }
   __syncthreads();
   if (mode != 2 && (int)threadIdx.x < nrows) {
-    float* vr = val + threadIdx.x * pitch;
-    float* sr = soft + threadIdx.x * pitch;
-    float mx = -3.0e38f;
-    for (int j = 0; j < A; ++j) mx = fmaxf(mx, vr[j]);
-    if (mode == 0) {
-      for (int j = 0; j < A; ++j) vr[j] = (vr[j] == mx) ? 1.f : 0.f;
-    } else {
-      // one exp and one division per element (the row was evaluated three times before): e_j -> y_j = e_j / den in `sr`
-      float den = 0.f;
-      for (int j = 0; j < A; ++j) { const float ej = expf(vr[j] - mx); sr[j] = ej; den += ej; }
-      // the one-hot is taken on the softmax output y (onehot_from_logits(y)): y == max(y)
-      float ymax = 0.f;
-      for (int j = 0; j < A; ++j) { const float y = sr[j] / den; sr[j] = y; ymax = fmaxf(ymax, y); }
-      for (int j = 0; j < A; ++j) {
-        const float y = sr[j];
-        const float hard = (y == ymax) ? 1.f : 0.f;
-        vr[j] = (hard - y) + y;
+    float* vr0 = val + threadIdx.x * pitch;
+    float* sr0 = soft + threadIdx.x * pitch;
+    int j0 = 0;
+    for (int h = 0; h < hd.n; ++h) {        // one block, or the blocks of a multi-discrete action (each its own argmax / softmax)
+      const int Ah = hd.dim[h];
+      float* vr = vr0 + j0;
+      float* sr = sr0 + j0;
+      j0 += Ah;
+      float mx = -3.0e38f;
+      for (int j = 0; j < Ah; ++j) mx = fmaxf(mx, vr[j]);
+      if (mode == 0) {
+        for (int j = 0; j < Ah; ++j) vr[j] = (vr[j] == mx) ? 1.f : 0.f;
+      } else {
+        // one exp and one division per element (the row was evaluated three times before): e_j -> y_j = e_j / den in `sr`
+        float den = 0.f;
+        for (int j = 0; j < Ah; ++j) { const float ej = expf(vr[j] - mx); sr[j] = ej; den += ej; }
+        // the one-hot is taken on the softmax output y (onehot_from_logits(y)): y == max(y)
+        float ymax = 0.f;
+        for (int j = 0; j < Ah; ++j) { const float y = sr[j] / den; sr[j] = y; ymax = fmaxf(ymax, y); }
+        for (int j = 0; j < Ah; ++j) {
+          const float y = sr[j];
+          const float hard = (y == ymax) ? 1.f : 0.f;
+          vr[j] = (hard - y) + y;
+        }
       }
     }
   }
@@ -272,6 +279,18 @@ __global__ void __launch_bounds__(256) action_grad_kernel(ActGradArgs a) {
     if (!a.identity) dot = fmaf(dx, a.y[(int64_t)r * a.A + j], dot);
     out[j] = dx;
   }
+  if (a.heads.n > 1) {      // multi-discrete: the softmax adjoint of every block on its own
+    int j0 = 0;
+    for (int h = 0; h < a.heads.n; ++h) {
+      const int Ah = a.heads.dim[h];
+      float dh = 0.f;
+      for (int j = j0; j < j0 + Ah; ++j) dh = fmaf(out[j], a.y[(int64_t)r * a.A + j], dh);
+      for (int j = j0; j < j0 + Ah; ++j) out[j] = a.y[(int64_t)r * a.A + j] * (out[j] - dh);
+      j0 += Ah;
+    }
+    for (int j = a.A; j < a.A4; ++j) out[j] = 0.f;
+    return;
+  }
   for (int j = 0; j < a.A4; ++j) out[j] = j < a.A ? (a.identity ? out[j] : a.y[(int64_t)r * a.A + j] * (out[j] - dot)) : 0.f;
 }
 
@@ -402,12 +421,14 @@ int launch_build_cin(const float* cent, const float* acts, const float* repl, in
   return OPE_OK;
 }
 int launch_action(const float* logits, const float* avail, NoiseSrc U, int rows, int B, int A, int N, int mode, int t_shift,
-                  float* cent_nact, float* act_out, float* soft_out, hipStream_t st, int nact_agents, int a_off) {
+                  float* cent_nact, float* act_out, float* soft_out, hipStream_t st, int nact_agents, int a_off, const ActHeads* heads) {
+  const ActHeads hd = heads ? *heads : act_heads_of(1, nullptr, A);
+  if (hd.n > 1) avail = nullptr;      // multi-discrete: upstream passes no availability masks (MADDPGPolicy.py:73-92)
   const int pitch = A | 1;
   const int rpb = pitch <= 31 ? 256 : 64;
   const size_t lds = (size_t)2 * rpb * pitch * sizeof(float);
   OPE_L(OPE_LAUNCH(action_kernel, dim3(ope_cdiv(rows, rpb)), dim3(256), lds, st, logits, avail, U, rows, B, A, N, mode, t_shift,
-                           rpb, cent_nact, act_out, soft_out, nact_agents > 0 ? nact_agents : N, a_off));
+                           rpb, cent_nact, act_out, soft_out, nact_agents > 0 ? nact_agents : N, a_off, hd));
   return OPE_OK;
 }
 int launch_action_grad(const ActGradArgs& a, hipStream_t st) {
@@ -416,7 +437,7 @@ int launch_action_grad(const ActGradArgs& a, hipStream_t st) {
   const char* f = getenv("OPE_ACTGRAD");
   const bool mfma_ok = a.B % 16 == 0 && a.A <= 32;
   int form = f ? (f[0] == 'w' ? 0 : (f[0] == 'm' && mfma_ok ? 1 : 2)) : (a.R <= 16384 ? 0 : (mfma_ok ? 1 : 2));
-  if (a.identity) form = 2;      // continuous actions: the thread-per-row form carries the identity adjoint
+  if (a.identity || a.heads.n > 1) form = 2;      // continuous / multi-discrete actions: the thread-per-row form carries those adjoints
   if (form == 0)   // few rows (MLP family): one wave per row, lane = hidden unit -- a 64-long serial chain per thread otherwise
     OPE_L(OPE_LAUNCH(action_grad_wave_kernel, dim3(ope_cdiv(a.R, 4)), dim3(256), 0, st, a));
   else if (form == 1) {
@@ -446,6 +467,7 @@ static int ddpg_cfg_ok(const ope_ddpg_cfg* c) {
   if (d.n_agents < 1 || d.n_agents > 64 || d.act_dim < 1 || d.act_dim > 64 || d.obs_dim < 1 || d.obs_dim > 512 || d.state_dim < 1) return 0;
   if (c->continuous != 0 && c->continuous != 1) return 0;
   if (c->continuous && c->target_gumbel) return 0;      // continuous actions: the target noise is additive (target_noise_u), there is no gumbel
+  if (!act_heads_ok(c->n_act_heads, c->act_head_dims, d.act_dim) || (c->n_act_heads > 1 && c->continuous)) return 0;
   if (d.layer_N > 1 || d.flags) return 0;      // the non-default network shapes (a second hidden block, no input LayerNorm) exist for the Q-learning nets only
   const int nt = c->n_total_agents > 0 ? c->n_total_agents : d.n_agents;
   if (c->n_total_agents < 0 || c->agent_offset < 0 || c->agent_offset + d.n_agents > nt || nt > 64) return 0;
@@ -492,7 +514,7 @@ static void ddpg_plan(const ope_ddpg_cfg* c, DdpgPlan* p) {
   p->mu1 = W.add("mu1", R); p->cvec = W.add("fc1_colsums", 2 * OPE_H); p->dlg = W.add("dlogits", Ra * p->A4);
   // second set of trunk saves for the actor's own backward (the critic pass of the actor step reuses the first set)
   p->err = W.add("saves2", Ra * (2 * OPE_H + 8));
-  p->fused = ddpg_fused_ok(p->N, p->A, p->D, p->S, p->K) && p->NT == p->N && !c->continuous;   // (the tile kernels are the one-shared-policy, discrete-action form)
+  p->fused = ddpg_fused_ok(p->N, p->A, p->D, p->S, p->K) && p->NT == p->N && !c->continuous && c->n_act_heads <= 1;   // (the tile kernels are the one-shared-policy, discrete-action form)
   p->fused_slabs = W.add("fused_slabs", p->fused ? ddpg_fused_slab_floats(p->N, p->A, p->D, p->S, p->K, p->B) + 64 : 4);   // + debug stamps
   if (p->fused) {    // per-workgroup sums of squares of the gradient the slab reduction wrote (only the fused path produces them)
     p->gsq_critic = W.add("gsq_critic", 2 * ddpg_fused_gsq_blocks(p->N, p->A, p->D, p->S, p->K, true));
@@ -720,10 +742,11 @@ extern "C" int ope_ddpg_critic_loss_and_grad(const ope_ddpg_cfg* cfg, const ope_
                                     W + p.fused_slabs, grad, prio_out, W + p.gsq_critic, st);
   // target actor on the next observations -> joint next action (multi-policy: the caller collected it, one
   // ope_ddpg_target_actions per policy)
+  const ActHeads hd = act_heads_of(cfg->n_act_heads, cfg->act_head_dims, p.A);
   if (!joint) {
     if ((rc = trunk_mlp(p, W, bt->next_obs, p.Ra, p.D, theta_actor_tgt, p.AL, W + p.a2n, false, nullptr, W + p.lgn, p.A, st))) return rc;
     if ((rc = launch_action(W + p.lgn, bt->next_avail_acts, NoiseSrc{target_noise_u, cfg->noise_seed, cfg->noise_counter, 0}, p.Ra, p.B, p.A, p.N, cfg->continuous ? 2 : (cfg->target_gumbel ? 1 : 0), 0, W + p.cnact,
-                            nullptr, nullptr, st))) return rc;
+                            nullptr, nullptr, st, 0, 0, &hd))) return rc;
   }
   const float* cnact = joint ? cfg->joint_next_acts : W + p.cnact;
   // critic inputs
@@ -752,10 +775,11 @@ extern "C" int ope_ddpg_target_actions(const ope_ddpg_cfg* cfg, const ope_mlp_ba
   hipStream_t st = (hipStream_t)stream;
   float* W = (float*)workspace;
   int rc;
+  const ActHeads hd = act_heads_of(cfg->n_act_heads, cfg->act_head_dims, p.A);
   if ((rc = trunk_mlp(p, W, bt->next_obs, p.Ra, p.D, theta_actor_tgt, p.AL, W + p.a2n, false, nullptr, W + p.lgn, p.A, st))) return rc;
   // (device-drawn noise: one Philox stream per policy, so that two policies' target noise is not the same numbers)
   return launch_action(W + p.lgn, bt->next_avail_acts, NoiseSrc{target_noise_u, cfg->noise_seed, cfg->noise_counter, 16 + p.a0}, p.Ra, p.B, p.A,
-                       p.N, cfg->continuous ? 2 : (cfg->target_gumbel ? 1 : 0), 0, joint_next_acts, nullptr, nullptr, st, p.NT, p.a0);
+                       p.N, cfg->continuous ? 2 : (cfg->target_gumbel ? 1 : 0), 0, joint_next_acts, nullptr, nullptr, st, p.NT, p.a0, &hd);
 }
 
 extern "C" int ope_ddpg_actor_loss_and_grad(const ope_ddpg_cfg* cfg, const ope_mlp_batch* bt, const float* theta_actor,
@@ -772,9 +796,10 @@ extern "C" int ope_ddpg_actor_loss_and_grad(const ope_ddpg_cfg* cfg, const ope_m
   int rc;
   if (p.fused) return launch_ddpg_actor_fused(cfg, bt, theta_actor, theta_critic, gumbel_noise_u, W + p.fused_slabs, grad, W + p.gsq_actor, st);
   float* saves2 = W + p.err;
+  const ActHeads hd = act_heads_of(cfg->n_act_heads, cfg->act_head_dims, p.A);
   // actor forward (saves -> alternate set) and straight-through hard gumbel sample
   if ((rc = trunk_mlp(p, W, bt->obs, p.Ra, p.D, theta_actor, p.AL, W + p.a2a, true, saves2, W + p.lga, p.A, st))) return rc;
-  if ((rc = launch_action(W + p.lga, bt->avail_acts, NoiseSrc{cfg->continuous ? nullptr : gumbel_noise_u, cfg->noise_seed, cfg->noise_counter, 1}, p.Ra, p.B, p.A, p.N, cfg->continuous ? 2 : 1, 0, nullptr, W + p.actout, W + p.ysoft, st)))
+  if ((rc = launch_action(W + p.lga, bt->avail_acts, NoiseSrc{cfg->continuous ? nullptr : gumbel_noise_u, cfg->noise_seed, cfg->noise_counter, 1}, p.Ra, p.B, p.A, p.N, cfg->continuous ? 2 : 1, 0, nullptr, W + p.actout, W + p.ysoft, st, 0, 0, &hd)))
     return rc;
   // N stacked copies of the joint action, copy i carrying the actor's action for agent i
   // (multi-policy: copy i of the joint action of ALL agents, block agent_offset + i replaced)
@@ -789,7 +814,7 @@ extern "C" int ope_ddpg_actor_loss_and_grad(const ope_ddpg_cfg* cfg, const ope_m
   ag.R = p.Ra; ag.B = p.B; ag.N = p.N; ag.A = p.A; ag.A4 = p.A4; ag.S = p.S; ag.Din = p.Din; ag.a_off = p.a0; ag.dz1 = W + p.dz1;
   ag.xhat1 = W + p.xhat1; ag.rstd1 = W + p.rstd1; ag.mu1 = W + p.mu1; ag.mu0 = W + p.mu0; ag.rstd0 = W + p.rstd0;
   ag.act = W + p.actout; ag.y = W + p.ysoft; ag.theta = theta_critic; ag.fc1_w = p.CL.fc1_w; ag.fc1_b = p.CL.fc1_b; ag.fn_w = p.CL.fn_w;
-  ag.fn_b = p.CL.fn_b; ag.cvec = W + p.cvec; ag.dlogits = W + p.dlg; ag.identity = cfg->continuous ? 1 : 0;
+  ag.fn_b = p.CL.fn_b; ag.cvec = W + p.cvec; ag.dlogits = W + p.dlg; ag.identity = cfg->continuous ? 1 : 0; ag.heads = hd;
   if ((rc = launch_action_grad(ag, st))) return rc;
   // actor backward and gradients
   return mlp_backward(p, W, bt->obs, p.Ra, p.D, p.A, p.A4, W + p.dlg, theta_actor, p.AL, saves2, p.ns_a, ope_cdiv(p.Ra, 16), grad, st);

@@ -368,6 +368,7 @@ static int rddpg_cfg_ok(const ope_rddpg_cfg* c) {
   if (c->batch < 1 || c->num_q < 1 || c->num_q > 4) return 0;
   if ((int64_t)(d.episode_length + 1) * d.n_agents * c->batch > (int64_t)1 << 24) return 0;
   if ((c->continuous != 0 && c->continuous != 1) || (c->continuous && c->target_gumbel)) return 0;
+  if (!act_heads_ok(c->n_act_heads, c->act_head_dims, d.act_dim) || (c->n_act_heads > 1 && c->continuous)) return 0;
   return 1;
 }
 
@@ -634,13 +635,14 @@ extern "C" int ope_rddpg_critic_loss_and_grad(const ope_rddpg_cfg* cfg, const op
   // target actor over all T+1 observations from a zero state; drop the first action (r_maddpg.py:79-96). Multi-policy updates
   // bring the joint target action of ALL policies' target actors (ope_rddpg_target_actions per policy) instead.
   const float* nact = cfg->joint_next_acts;
+  const ActHeads hd = act_heads_of(cfg->n_act_heads, cfg->act_head_dims, p.A);
   if (!nact) {
     if (p.NT != p.N) return OPE_EINVAL;       // a policy's own actor cannot produce the other policies' target actions
     if ((rc = rtrunk(bt->obs, p.Ra1, p.D, theta_actor_tgt, p.AL, W + p.gi_t, W, nullptr, st))) return rc;
     if ((rc = rscan(W + p.gi_t, p.NB, p.T + 1, theta_actor_tgt, p.AL, W + p.h_t, W, nullptr, st))) return rc;
     if ((rc = rhead(W + p.h_t, p.Ra1, p.A, theta_actor_tgt, p.AL, W + p.lg_t, W, nullptr, st))) return rc;
     if ((rc = launch_action(W + p.lg_t, bt->avail_acts, NoiseSrc{target_noise_u, 0, nullptr, 0}, (int)p.Ra1, p.B, p.A, p.N, cfg->continuous ? 2 : (cfg->target_gumbel ? 1 : 0), 1,
-                            W + p.cnact, nullptr, nullptr, st))) return rc;
+                            W + p.cnact, nullptr, nullptr, st, 0, 0, &hd))) return rc;
     nact = W + p.cnact;
   }
   // critic inputs: buffer sequence [cent_obs[t] | acts[t]] and branch rows [cent_obs[t+1] | target actions]
@@ -680,11 +682,12 @@ extern "C" int ope_rddpg_target_actions(const ope_rddpg_cfg* cfg, const ope_fiel
   hipStream_t st = (hipStream_t)stream;
   float* W = (float*)workspace;
   int rc;
+  const ActHeads hd = act_heads_of(cfg->n_act_heads, cfg->act_head_dims, p.A);
   if ((rc = rtrunk(bt->obs, p.Ra1, p.D, theta_actor_tgt, p.AL, W + p.gi_t, W, nullptr, st))) return rc;
   if ((rc = rscan(W + p.gi_t, p.NB, p.T + 1, theta_actor_tgt, p.AL, W + p.h_t, W, nullptr, st))) return rc;
   if ((rc = rhead(W + p.h_t, p.Ra1, p.A, theta_actor_tgt, p.AL, W + p.lg_t, W, nullptr, st))) return rc;
   return launch_action(W + p.lg_t, bt->avail_acts, NoiseSrc{target_noise_u, 0, nullptr, 0}, (int)p.Ra1, p.B, p.A, p.N, cfg->continuous ? 2 : (cfg->target_gumbel ? 1 : 0), 1,
-                       joint_next_acts, nullptr, nullptr, st, p.NT, p.a0);
+                       joint_next_acts, nullptr, nullptr, st, p.NT, p.a0, &hd);
 }
 
 extern "C" int ope_rddpg_actor_loss_and_grad(const ope_rddpg_cfg* cfg, const ope_fields* bt, const float* theta_actor,
@@ -700,12 +703,13 @@ extern "C" int ope_rddpg_actor_loss_and_grad(const ope_rddpg_cfg* cfg, const ope
   float* W = (float*)workspace;
   int rc;
   const int Ra = (int)p.Ra;
+  const ActHeads hd = act_heads_of(cfg->n_act_heads, cfg->act_head_dims, p.A);
   // actor over obs[:-1] from a zero state, straight-through hard gumbel-softmax sample (r_maddpg.py:277-280)
   if ((rc = rtrunk(bt->obs, p.Ra, p.D, theta_actor, p.AL, W + p.SA.gi, W, &p.SA, st))) return rc;
   if ((rc = rscan(W + p.SA.gi, p.NB, p.T, theta_actor, p.AL, W + p.SA.h, W, &p.SA, st))) return rc;
   if ((rc = rhead(W + p.SA.h, p.Ra, p.A, theta_actor, p.AL, W + p.lga, W, &p.SA, st))) return rc;
   if ((rc = launch_action(W + p.lga, bt->avail_acts, NoiseSrc{cfg->continuous ? nullptr : gumbel_noise_u, 0, nullptr, 0}, Ra, p.B, p.A, p.N, cfg->continuous ? 2 : 1, 0, nullptr,
-                          W + p.actout, W + p.ysoft, st)))
+                          W + p.actout, W + p.ysoft, st, 0, 0, &hd)))
     return rc;
   // critic state along the buffer sequence (identical for the N stacked copies)
   if ((rc = launch_build_cin(bt->share_obs, bt->acts, nullptr, p.T, p.B, p.NT, p.A, p.S, 1, W + p.xin, st))) return rc;
@@ -754,7 +758,7 @@ extern "C" int ope_rddpg_actor_loss_and_grad(const ope_rddpg_cfg* cfg, const ope
   ag.R = Ra; ag.B = p.B; ag.N = p.N; ag.A = p.A; ag.A4 = p.A4; ag.S = p.S; ag.Din = p.Din; ag.a_off = p.a0; ag.dz1 = W + p.dz1;
   ag.xhat1 = W + p.SC.xhat1; ag.rstd1 = W + p.SC.rstd1; ag.mu1 = W + p.SC.mu1; ag.mu0 = W + p.SC.mu0; ag.rstd0 = W + p.SC.rstd0;
   ag.act = W + p.actout; ag.y = W + p.ysoft; ag.theta = theta_critic; ag.fc1_w = p.CL.fc1_w; ag.fc1_b = p.CL.fc1_b; ag.fn_w = p.CL.fn_w;
-  ag.fn_b = p.CL.fn_b; ag.cvec = W + p.cvec; ag.dlogits = W + p.dlg; ag.identity = cfg->continuous ? 1 : 0;
+  ag.fn_b = p.CL.fn_b; ag.cvec = W + p.cvec; ag.dlogits = W + p.dlg; ag.identity = cfg->continuous ? 1 : 0; ag.heads = hd;
   if ((rc = launch_action_grad(ag, st))) return rc;
   // actor BPTT and gradients
   return rnn_backward(p, W, p.SA, bt->obs, p.NB, p.T, p.D, p.A, p.A4, W + p.dlg, theta_actor, p.AL, p.ns_a, ope_cdiv(Ra, 16), grad, st);

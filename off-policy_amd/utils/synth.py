@@ -70,11 +70,15 @@ def synth_episodes(rng, num_episodes, dims, avail="ones", runner_padding=False):
                 lengths=lengths.astype(np.int64))
 
 
-def policy_info_for(dims, continuous=False):
+def policy_info_for(dims, continuous=False, multi_discrete=None):
     """`policy_info` dict in the SMAC style the reference builds at train_smac.py:131-137: list spaces. `continuous`: a Box action
-    space of act_dim components in [-1, 1] instead of Discrete(act_dim)."""
-    from .spaces import Discrete, Box
+    space of act_dim components in [-1, 1] instead of Discrete(act_dim); `multi_discrete`: the sizes of the sub-actions of a
+    MultiDiscrete space (their sum = act_dim)."""
+    from .spaces import Discrete, Box, MultiDiscrete
     act = Box(low=-np.ones(dims.act_dim, np.float32), high=np.ones(dims.act_dim, np.float32)) if continuous else Discrete(dims.act_dim)
+    if multi_discrete is not None:
+        assert int(np.sum(multi_discrete)) == dims.act_dim
+        act = MultiDiscrete([[0, int(k) - 1] for k in multi_discrete])
     return {"policy_0": {"cent_obs_dim": dims.state_dim,
                          "cent_act_dim": dims.act_dim * dims.n_agents,
                          "obs_space": [dims.obs_dim],

@@ -36,12 +36,16 @@ def onehot_argmax(logits, avail):
 
 
 class MaddpgOracle(object):
-    def __init__(self, actor, critic, critic_heads, actor_tgt, critic_tgt, critic_heads_tgt, n_agents, hp=None, td3=False, continuous=False):
+    def __init__(self, actor, critic, critic_heads, actor_tgt, critic_tgt, critic_heads_tgt, n_agents, hp=None, td3=False, continuous=False,
+                 head_dims=None):
         """actor/critic: {name: array} trunks (+ 'act.action_out.*' for the actor); critic_heads: (W [K,64], b [K]).
         `continuous`: Box action space (MADDPGPolicy.py:107-116): the action is the actor's output; the target action of MATD3 adds
         the gaussian noise passed as `u_target` (gaussian_noise(shape, target_noise), util.py:217-218); no gumbel, no masks."""
         self.hp = hp or HP()
         self.N, self.td3, self.continuous = n_agents, td3, bool(continuous)
+        # multi-discrete action space (MADDPGPolicy.py:73-92): `head_dims` = sizes of the sub-actions; the actor has one Linear head per
+        # sub-action (act.action_outs.{i}.*, act.py:14-17), the action is the concatenation of their one-hot / gumbel-softmax blocks
+        self.head_dims = [int(x) for x in head_dims] if head_dims is not None else None
         f = lambda d: OrderedDict((k, torch.as_tensor(np.asarray(v), dtype=torch.float32).clone()) for k, v in d.items())
         h = lambda wb: (torch.as_tensor(np.asarray(wb[0]), dtype=torch.float32).clone(), torch.as_tensor(np.asarray(wb[1]), dtype=torch.float32).clone())
         self.actor, self.critic, self.actor_tgt, self.critic_tgt = f(actor), f(critic), f(actor_tgt), f(critic_tgt)
@@ -50,7 +54,26 @@ class MaddpgOracle(object):
 
     @staticmethod
     def actor_logits(P, x):
-        return F.linear(mlp_base(P, x), P["act.action_out.weight"], P["act.action_out.bias"])
+        a2 = mlp_base(P, x)
+        if "act.action_out.weight" in P:
+            return F.linear(a2, P["act.action_out.weight"], P["act.action_out.bias"])
+        outs, i = [], 0
+        while "act.action_outs.%d.weight" % i in P:      # multi-discrete: the heads' outputs side by side
+            outs.append(F.linear(a2, P["act.action_outs.%d.weight" % i], P["act.action_outs.%d.bias" % i]))
+            i += 1
+        return torch.cat(outs, dim=-1)
+
+    def _hard(self, lg, avail, u):
+        """hard gumbel-softmax of the action vector: per sub-action block for a multi-discrete space (no availability masks there)."""
+        if self.head_dims is None:
+            return gumbel_hard(lg, avail, torch.as_tensor(u))
+        u = torch.as_tensor(u)
+        return torch.cat([gumbel_hard(l, None, uu) for l, uu in zip(lg.split(self.head_dims, dim=-1), u.split(self.head_dims, dim=-1))], dim=-1)
+
+    def _argmax(self, lg, avail):
+        if self.head_dims is None:
+            return onehot_argmax(lg, avail)
+        return torch.cat([onehot_argmax(l, None) for l in lg.split(self.head_dims, dim=-1)], dim=-1)
 
     @staticmethod
     def critic_q(P, heads, cent, joint):
@@ -90,7 +113,7 @@ class MaddpgOracle(object):
             if self.continuous:
                 nact = lg + torch.as_tensor(u_target) if u_target is not None else lg
             else:
-                nact = gumbel_hard(lg, s_nav, torch.as_tensor(u_target)) if self.td3 else onehot_argmax(lg, s_nav)
+                nact = self._hard(lg, s_nav, u_target) if self.td3 else self._argmax(lg, s_nav)
         return list(nact.split(B, dim=0))
 
     def train_step(self, batch, u_target=None, u_actor=None, weights=None, soft_update=True, joint=None, all_acts=None, offset=0,
@@ -116,7 +139,7 @@ class MaddpgOracle(object):
                 if self.continuous:
                     nact = lg + torch.as_tensor(u_target) if u_target is not None else lg
                 else:
-                    nact = gumbel_hard(lg, s_nav, torch.as_tensor(u_target)) if self.td3 else onehot_argmax(lg, s_nav)
+                    nact = self._hard(lg, s_nav, u_target) if self.td3 else self._argmax(lg, s_nav)
                 cent_nact = torch.cat(nact.split(B, dim=0), dim=-1)
             else:
                 cent_nact = joint[1]
@@ -144,7 +167,7 @@ class MaddpgOracle(object):
         cnorm = self._adam_step("critic", self.critic, cg)
         # ---- actor (through the UPDATED critic, whose parameters are frozen here) ----
         la = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in self.actor.items())
-        pol = self.actor_logits(la, s_obs) if self.continuous else gumbel_hard(self.actor_logits(la, s_obs), s_av, torch.as_tensor(u_actor))
+        pol = self.actor_logits(la, s_obs) if self.continuous else self._hard(self.actor_logits(la, s_obs), s_av, u_actor)
         agent_acts = pol.split(B, dim=0)
         rows = []
         every = list(acts) if all_acts is None else list(all_acts)

@@ -210,6 +210,33 @@ def test_tanh_networks_initialise_like_the_reference_and_are_limited_to_what_the
     require_reference_architecture(args, allow_tanh=True)
 
 
+def test_action_space_kinds_of_the_maddpg_family_are_validated():
+    """Continuous (Box) and multi-discrete action spaces (round 4; MADDPGPolicy.py:73-116): the space stand-ins give upstream's
+    dimensions, and the C-ABI checks the combinations it is handed."""
+    from offpolicy_amd import _lib
+    from offpolicy_amd.utils.spaces import MultiDiscrete, Box, Discrete, get_dim_from_space
+    md = MultiDiscrete([[0, 2], [0, 3]])
+    assert list(get_dim_from_space(md)) == [3, 4] and get_dim_from_space(Discrete(5)) == 5
+    assert get_dim_from_space(Box(low=-np.ones(3, np.float32), high=np.ones(3, np.float32))) == 3
+
+    def cfg_bytes(**kw):
+        c = _lib.DdpgCfg()
+        c.dims, c.batch, c.num_q = _lib.Dims(2, 7, 10, 12, 1), 6, 1
+        heads = kw.pop("heads", None)
+        if heads:
+            c.n_act_heads = len(heads)
+            for i, k in enumerate(heads):
+                c.act_head_dims[i] = k
+        for k, v in kw.items():
+            setattr(c, k, v)
+        return _lib.lib.ope_ddpg_workspace_bytes(C.byref(c))
+    assert cfg_bytes() > 0 and cfg_bytes(heads=[3, 4]) > 0 and cfg_bytes(continuous=1) > 0
+    assert cfg_bytes(heads=[3, 3]) == -1                          # the blocks must add up to act_dim
+    assert cfg_bytes(heads=[3, 4], continuous=1) == -1            # one or the other
+    assert cfg_bytes(continuous=1, target_gumbel=1) == -1         # continuous target noise is additive, not gumbel
+    assert cfg_bytes(continuous=2) == -1
+
+
 def test_null_arguments_are_rejected_without_a_gpu():
     from offpolicy_amd import _lib
     assert _lib.lib.ope_adam_step(None, 4, None, None, None, None, None, None, None, None) == -1

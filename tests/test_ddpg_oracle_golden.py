@@ -10,7 +10,9 @@ from test_mlp_oracle_golden import T_KEYS
 
 CASES = ["maddpg_spread", "matd3_spread", "maddpg_small_huber_per", "matd3_small", "maddpg_small_wd",
          # round 4: continuous (Box) action spaces -- the action is the actor's output, MATD3's target noise is additive gaussian
-         "maddpg_cont_small", "matd3_cont_small", "maddpg_cont_spread"]
+         "maddpg_cont_small", "matd3_cont_small", "maddpg_cont_spread",
+         # round 4: multi-discrete action spaces -- one Linear head, one argmax / gumbel-softmax per sub-action
+         "maddpg_md_small", "matd3_md_small"]
 
 
 def ddpg_oracle_from(g):
@@ -19,7 +21,8 @@ def ddpg_oracle_from(g):
             max_grad_norm=float(g["hp_maxnorm"]), weight_decay=float(g["hp_wd"]) if "hp_wd" in g else 0.0)
     return DO.MaddpgOracle(sub(g, "actor/"), sub(g, "critic/"), (g["heads/w"], g["heads/b"]), sub(g, "actor_tgt/"),
                            sub(g, "critic_tgt/"), (g["heads_tgt/w"], g["heads_tgt/b"]), int(g["dims"][0]), hp, td3=bool(g["td3"]),
-                           continuous=bool(g["continuous"]) if "continuous" in g else False)
+                           continuous=bool(g["continuous"]) if "continuous" in g else False,
+                           head_dims=[int(x) for x in g["multi_discrete"]] if "multi_discrete" in g else None)
 
 
 def noise_for(g, step):
@@ -29,6 +32,11 @@ def noise_for(g, step):
     torch.manual_seed(1000 + step)
     if "continuous" in g and bool(g["continuous"]):      # gaussian_noise(shape, target_action_noise_std) for MATD3's target action; nothing else is drawn
         return (torch.empty(n * B, a).normal_(mean=0, std=0.2) if bool(g["td3"]) else None), None
+    if "multi_discrete" in g:      # one uniform block per sub-action head, in order (MADDPGPolicy.py:75-77), side by side
+        heads = [int(x) for x in g["multi_discrete"]]
+        blocks = lambda: torch.cat([torch.FloatTensor(n * B, k).uniform_() for k in heads], dim=-1)
+        u_t = blocks() if bool(g["td3"]) else None
+        return u_t, blocks()
     u_t = torch.FloatTensor(n * B, a).uniform_() if bool(g["td3"]) else None
     u_a = torch.FloatTensor(n * B, a).uniform_()
     return u_t, u_a

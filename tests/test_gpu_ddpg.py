@@ -28,7 +28,8 @@ def build(g, device="cuda:0", same_share=True):
                         huber_delta=float(g["hp_delta"]), use_per=bool(g["hp_per"]), per_eps=float(g["hp_per_eps"]), tau=float(g["hp_tau"]),
                         max_grad_norm=float(g["hp_maxnorm"]), weight_decay=float(g["hp_wd"]) if "hp_wd" in g else 0.0,
                         use_same_share_obs=same_share)
-    pinfo = policy_info_for(dims, continuous=bool(g["continuous"]) if "continuous" in g else False)
+    pinfo = policy_info_for(dims, continuous=bool(g["continuous"]) if "continuous" in g else False,
+                            multi_discrete=g["multi_discrete"] if "multi_discrete" in g else None)
     dev = torch.device(device)
     torch.manual_seed(1)
     np.random.seed(1)
