@@ -1,6 +1,6 @@
 """Recurrent MADDPG / MATD3 policy: recurrent actor + centralised recurrent critic (+ targets, optimizer state).
 
-Mirror of offpolicy/algorithms/r_maddpg/algorithm/rMADDPGPolicy.py:11-176 for discrete (one-hot) action spaces. The
+Mirror of offpolicy/algorithms/r_maddpg/algorithm/rMADDPGPolicy.py:11-176 for discrete, multi-discrete and continuous action spaces. The
 four networks are drawn in the reference's construction order (actor, critic, target actor, target critic) and the
 targets then take the live weights, so equal seeds give equal weights.
 """
@@ -31,17 +31,18 @@ class R_MADDPGPolicy(object):
         self.central_obs_dim, self.central_act_dim = policy_config["cent_obs_dim"], policy_config["cent_act_dim"]
         self.obs_space, self.act_space = policy_config["obs_space"], policy_config["act_space"]
         self.obs_dim, self.act_dim = get_dim_from_space(self.obs_space), get_dim_from_space(self.act_space)
-        self.output_dim = self.act_dim
         self.hidden_size = a.hidden_size
         kind = self.act_space.__class__.__name__
-        if "MultiDiscrete" in kind:
-            raise NotImplementedError("multi-discrete action spaces are not on the accelerated path")
-        self.discrete, self.multidiscrete = kind != "Box", False      # util.py:271-281; Box = continuous (rMADDPGPolicy.py:121-129)
+        self.discrete, self.multidiscrete = kind != "Box", "MultiDiscrete" in kind      # util.py:271-281; Box = continuous (rMADDPGPolicy.py:121-129)
+        # act_dim: as upstream an int, or the ARRAY of a multi-discrete space's sub-action sizes; output_dim: the action vector's length
+        self.output_dim = int(sum(self.act_dim)) if self.multidiscrete else self.act_dim
+        if self.multidiscrete and len(self.act_dim) > 6:
+            raise NotImplementedError("multi-discrete action spaces with more than 6 sub-actions are not on the accelerated path")
         self.target_noise = target_noise
         self.td3 = bool(td3)
         self.num_q = 2 if td3 else 1
-        assert self.central_act_dim % self.act_dim == 0
-        self.num_agents = self.central_act_dim // self.act_dim
+        assert self.central_act_dim % self.output_dim == 0
+        self.num_agents = self.central_act_dim // self.output_dim
         cfg = self.rddpg_cfg(1, 1)
         dev = self.device
         cin = self.central_obs_dim + self.central_act_dim
@@ -62,7 +63,11 @@ class R_MADDPGPolicy(object):
     def rddpg_cfg(self, batch, episode_length):
         a = self.args
         cfg = _lib.RddpgCfg()
-        cfg.dims = _lib.Dims(self.num_agents, self.act_dim, self.obs_dim, self.central_obs_dim, int(episode_length))
+        cfg.dims = _lib.Dims(self.num_agents, self.output_dim, self.obs_dim, self.central_obs_dim, int(episode_length))
+        if self.multidiscrete:      # one-hot blocks, argmax / gumbel-softmax per block (ope_rddpg_cfg.n_act_heads)
+            cfg.n_act_heads = len(self.act_dim)
+            for i, a_dim in enumerate(self.act_dim):
+                cfg.act_head_dims[i] = int(a_dim)
         cfg.batch, cfg.num_q = int(batch), self.num_q
         cfg.continuous = int(not self.discrete)
         cfg.target_gumbel = int(self.target_noise is not None and self.discrete)
@@ -90,6 +95,21 @@ class R_MADDPGPolicy(object):
             else:
                 actions = actor_out
             return actions, new_rnn_states, eps
+        if self.multidiscrete:      # rMADDPGPolicy.py:81-102: every sub-action on its own, no availability masks
+            outs = torch.split(actor_out, [int(x) for x in self.act_dim], dim=-1)
+            if use_gumbel or (use_target and self.target_noise is not None):
+                actions = torch.cat([gumbel_softmax_hard(o, None, sample_gumbel_uniform(o.shape)) for o in outs], dim=-1)
+            elif explore:
+                assert no_sequence, "Cannot do exploration on a sequence!"
+                onehot = torch.cat([gumbel_softmax_hard(o, None, sample_gumbel_uniform(o.shape)) for o in outs], dim=-1)
+                eps = self.exploration.eval(t_env)
+                rand_numbers = np.random.rand(batch_size, 1)
+                take_random = (rand_numbers < eps).astype(int).reshape(-1, 1)
+                random_actions = torch.cat([OneHotCategorical(logits=torch.ones(batch_size, int(x))).sample() for x in self.act_dim], dim=1)
+                actions = (1 - take_random) * onehot.detach().cpu().numpy() + take_random * random_actions.numpy()
+            else:
+                actions = torch.cat([onehot_from_logits(o) for o in outs], dim=-1)
+            return actions, new_rnn_states, eps
         if use_gumbel or (use_target and self.target_noise is not None):
             actions = gumbel_softmax_hard(actor_out, available_actions, sample_gumbel_uniform(actor_out.shape))
         elif explore:
@@ -116,6 +136,8 @@ class R_MADDPGPolicy(object):
         batch_size = obs.shape[0]
         if not self.discrete:      # rMADDPGPolicy.py:158-159
             return np.random.uniform(self.act_space.low, self.act_space.high, size=(batch_size, self.act_dim))
+        if self.multidiscrete:     # rMADDPGPolicy.py:147-151
+            return np.concatenate([OneHotCategorical(logits=torch.ones(batch_size, int(x))).sample().numpy() for x in self.act_dim], axis=-1)
         logits = torch.ones(batch_size, self.act_dim)
         if available_actions is not None:
             logits[torch.as_tensor(np.asarray(available_actions)) == 0] = -1e10

@@ -8,6 +8,7 @@ in an nn.ModuleList, so `q_outs.{k}.weight/bias` are registered, trained and sof
 """
 import ctypes as C
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -28,9 +29,21 @@ def rddpg_layout(cfg, which):
 
 
 def draw_ractor_values(args, obs_dim, act_dim):
-    """RNNBase draws then ACTLayer(gain=args.gain) (r_actor_critic.py:28-31): the QMIX agent network's order."""
-    return init_agent_values(obs_dim, act_dim, getattr(args, "use_orthogonal", True), getattr(args, "gain", 0.01),
-                             getattr(args, "use_ReLU", True))
+    """RNNBase draws then ACTLayer(gain=args.gain) (r_actor_critic.py:28-31): the QMIX agent network's order. `act_dim` may be the array
+    of a multi-discrete space's sub-action sizes: one Linear head each, constructed in order (act.py:14-17), returned stacked."""
+    orth, gain = getattr(args, "use_orthogonal", True), getattr(args, "gain", 0.01)
+    if np.ndim(act_dim) == 0:
+        return init_agent_values(obs_dim, int(act_dim), orth, gain, getattr(args, "use_ReLU", True))
+    heads = [int(x) for x in act_dim]
+    vals = init_agent_values(obs_dim, heads[0], orth, gain, getattr(args, "use_ReLU", True))       # body + head 0
+    init_w = nn.init.orthogonal_ if orth else nn.init.xavier_uniform_
+    ws = [vals[20]]
+    for a_dim in heads[1:]:
+        out = nn.Linear(H, a_dim)
+        init_w(out.weight.data, gain=gain)
+        ws.append(out.weight.data.detach().float())
+    w = torch.cat(ws, dim=0)
+    return vals[:20] + [w, torch.zeros(w.shape[0])]
 
 
 def draw_rcritic_values(args, in_dim, num_q):
@@ -83,14 +96,27 @@ class R_MADDPG_Actor(_RnnNet):
         device = torch.device(device)
         if flat is None:
             flat = torch.zeros(total, dtype=torch.float32, device=device)
-        names = _BODY + ["act.action_out.weight", "act.action_out.bias"]
-        super().__init__(names, agent_param_shapes(int(obs_dim), int(act_dim)), offs, flat)
-        self.obs_dim, self.act_dim, self.hidden_size, self.device, self.padded_numel = int(obs_dim), int(act_dim), H, device, total
+        heads = None if np.ndim(act_dim) == 0 else [int(x) for x in act_dim]
+        A = int(act_dim) if heads is None else int(sum(heads))
+        if heads is None:
+            names, shapes, o = _BODY + ["act.action_out.weight", "act.action_out.bias"], agent_param_shapes(int(obs_dim), A), offs
+        else:      # multi-discrete: act.action_outs.{i}.{weight,bias} (act.py:14-17) = row ranges of the one stacked head the kernels see
+            names, shapes, o, r0 = list(_BODY), agent_param_shapes(int(obs_dim), A)[:20], list(offs[:20]), 0
+            for i, a_dim in enumerate(heads):
+                names += ["act.action_outs.%d.weight" % i, "act.action_outs.%d.bias" % i]
+                shapes += [(a_dim, H), (a_dim,)]
+                o += [offs[20] + r0 * H, offs[21] + r0]
+                r0 += a_dim
+        super().__init__(names, shapes, o, flat)
+        self.head_dims = heads
+        self.obs_dim, self.act_dim, self.hidden_size, self.device, self.padded_numel = int(obs_dim), A, H, device, total
         self.take_prev_act = False
-        self._setup_forward(obs_dim, act_dim)
+        self._setup_forward(obs_dim, A)
         if values is not None:
-            for p, v in zip(self.parameters(), values):
+            for p, v in zip(list(self.parameters())[:20], values[:20]):
                 p.data.copy_(v)
+            flat[offs[20]:offs[20] + A * H].view(A, H).copy_(values[20])
+            flat[offs[21]:offs[21] + A].copy_(values[21])
 
     def forward(self, obs, prev_acts, rnn_states):
         """Action logits and the new hidden state (r_actor_critic.py:36-67)."""

@@ -49,8 +49,10 @@ class R_MADDPG(object):
             self.agent_offset[pid] = off
             off += len(self.policy_agents[pid])
         assert off == num_agents, "every agent must be mapped to a policy"
-        if len({self.policies[pid].act_dim for pid in self.policy_ids}) != 1:
+        if len({self.policies[pid].output_dim for pid in self.policy_ids}) != 1:
             raise NotImplementedError("policies with different action dimensions are not on the accelerated path")
+        if self.multi_policy and any(self.policies[pid].multidiscrete for pid in self.policy_ids):
+            raise NotImplementedError("multi-discrete action spaces with several policies are not on the accelerated path")
         self.actor_update_interval = actor_update_interval
         self.num_updates = {p_id: 0 for p_id in self.policy_ids}
         self.use_same_share_obs = args.use_same_share_obs
@@ -115,6 +117,8 @@ class R_MADDPG(object):
             raise NotImplementedError("cent_train_policy_on_batch with use_value_active_masks: upstream weights the critic loss by the agents' "
                                       "active masks there (r_maddpg.py:418-498); the accelerated path takes the plain masked mean")
         policy = self.policies[pid]
+        if policy.multidiscrete:
+            raise NotImplementedError("cent_train_policy_on_batch with a multi-discrete action space is not on the accelerated path")
         obs = self._to_device_layout(obs_b[pid], True)                      # [T+1, N, B, D]
         cent = self._to_device_layout(cent_b[pid], True)                    # [T+1, N, B, S]
         acts = self._to_device_layout(act_b[pid], True)
@@ -123,7 +127,7 @@ class R_MADDPG(object):
         dones_env = self._to_device_layout(dones_env_b[pid], False)         # [T, B, 1]
         avail = self._to_device_layout(avail_b[pid], True) if (avail_b is not None and avail_b[pid] is not None) else None
         T1, N, B, _ = obs.shape
-        T, A = self.episode_length, policy.act_dim
+        T, A = self.episode_length, policy.output_dim
         tile = lambda x: None if x is None else x.repeat(1, 1, N, 1).contiguous()     # [., N, N*B, .]: column (i, b) <- b
         share_v = cent.reshape(T1, N * B, cent.shape[-1]).contiguous()                 # column (i, b) = agent i's observation of b
         eye = torch.eye(N, **self.tpdv).repeat_interleave(B, dim=1).contiguous()       # [N, N*B]: copy a of episode (i, b) counts iff a == i
@@ -194,9 +198,14 @@ class R_MADDPG(object):
         T1, N, B, D = obs.shape
         T = self.episode_length
         assert T1 == T + 1 and N == len(self.policy_agents[pid]), "batch does not match the trainer's dimensions"
-        A = policy.act_dim
+        A = policy.output_dim
         cfg = policy.rddpg_cfg(B, T)
         draw = (lambda shape: torch.rand(shape, **self.tpdv)) if self.device_noise else (lambda shape: sample_gumbel_uniform(shape).to(self.device))
+        if policy.multidiscrete:
+            # one uniform block per sub-action, in order, side by side: the draws of rMADDPGPolicy.py:84-91 (a gumbel_softmax per head)
+            assert others is None and not self.device_noise, "multi-discrete actions: one shared policy, host noise"
+            heads = [int(x) for x in policy.act_dim]
+            draw = lambda shape: torch.cat([sample_gumbel_uniform(shape[:-1] + (k,)) for k in heads], dim=-1).to(self.device).contiguous()
         st = _lib.current_stream()
         joint_next = keep = None
         if others is not None:

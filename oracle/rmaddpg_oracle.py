@@ -27,7 +27,13 @@ def rnn_body(P, x_seq, h0):
 
 def actor_logits(P, obs_seq, h0):
     y, h = rnn_body(P, obs_seq, h0)
-    return F.linear(y, P["act.action_out.weight"], P["act.action_out.bias"]), h
+    if "act.action_out.weight" in P:
+        return F.linear(y, P["act.action_out.weight"], P["act.action_out.bias"]), h
+    outs, i = [], 0
+    while "act.action_outs.%d.weight" % i in P:      # multi-discrete (act.py:14-17): the heads' outputs side by side
+        outs.append(F.linear(y, P["act.action_outs.%d.weight" % i], P["act.action_outs.%d.bias" % i]))
+        i += 1
+    return torch.cat(outs, dim=-1), h
 
 
 def critic_q(P, K, cent, act, h0):
@@ -38,17 +44,31 @@ def critic_q(P, K, cent, act, h0):
 
 
 class RMaddpgOracle(object):
-    def __init__(self, actor, critic, actor_tgt, critic_tgt, n_agents, hp=None, td3=False, actor_update_interval=None, continuous=False):
+    def __init__(self, actor, critic, actor_tgt, critic_tgt, n_agents, hp=None, td3=False, actor_update_interval=None, continuous=False,
+                 head_dims=None):
         """`continuous`: Box action space (rMADDPGPolicy.py:121-129): the action is the actor's output, R_MATD3's target action adds the
         gaussian noise passed as `u_target`; no gumbel, no availability masks."""
         self.hp = hp or HP()
         self.N, self.td3, self.continuous = n_agents, td3, bool(continuous)
+        # multi-discrete action space (rMADDPGPolicy.py:81-102): sizes of the sub-actions; argmax / gumbel-softmax per block, no masks
+        self.head_dims = [int(x) for x in head_dims] if head_dims is not None else None
         self.K = 2 if td3 else 1
         f = lambda d: OrderedDict((k, torch.as_tensor(np.asarray(v), dtype=torch.float32).clone()) for k, v in d.items())
         self.actor, self.critic, self.actor_tgt, self.critic_tgt = f(actor), f(critic), f(actor_tgt), f(critic_tgt)
         self.adam = {"actor": [OrderedDict(), OrderedDict(), 0], "critic": [OrderedDict(), OrderedDict(), 0]}
         self.actor_update_interval = actor_update_interval if actor_update_interval is not None else (2 if td3 else 1)
         self.num_updates = 0
+
+    def _hard(self, lg, avail, u):
+        if self.head_dims is None:
+            return gumbel_hard(lg, avail, torch.as_tensor(u))
+        u = torch.as_tensor(u)
+        return torch.cat([gumbel_hard(l, None, uu) for l, uu in zip(lg.split(self.head_dims, dim=-1), u.split(self.head_dims, dim=-1))], dim=-1)
+
+    def _argmax(self, lg, avail):
+        if self.head_dims is None:
+            return onehot_argmax(lg, avail)
+        return torch.cat([onehot_argmax(l, None) for l in lg.split(self.head_dims, dim=-1)], dim=-1)
 
     def _adam_step(self, which, params, grads):
         hp = self.hp
@@ -82,7 +102,7 @@ class RMaddpgOracle(object):
             s_obs = torch.cat(list(obs), dim=1)
             s_av = torch.cat(list(avail), dim=1) if avail is not None else None
             lg, _ = actor_logits(self.actor_tgt, s_obs, torch.zeros(N * B, hp.hidden_size))
-            nact = ((lg + torch.as_tensor(u_target)) if u_target is not None else lg) if self.continuous else (gumbel_hard(lg, s_av, torch.as_tensor(u_target)) if self.td3 else onehot_argmax(lg, s_av))
+            nact = ((lg + torch.as_tensor(u_target)) if u_target is not None else lg) if self.continuous else (self._hard(lg, s_av, u_target) if self.td3 else self._argmax(lg, s_av))
         return list(nact[1:].split(B, dim=1))
 
     def critic_loss(self, live, batch, u_target=None, weights=None, joint=None, per_agent_cent=False):
@@ -103,7 +123,7 @@ class RMaddpgOracle(object):
                 s_obs = torch.cat(list(obs), dim=1)                          # [T+1, N*B, D]
                 s_av = torch.cat(list(avail), dim=1) if avail is not None else None
                 lg, _ = actor_logits(self.actor_tgt, s_obs, torch.zeros(N * B, H))
-                nact = ((lg + torch.as_tensor(u_target)) if u_target is not None else lg) if self.continuous else (gumbel_hard(lg, s_av, torch.as_tensor(u_target)) if self.td3 else onehot_argmax(lg, s_av))
+                nact = ((lg + torch.as_tensor(u_target)) if u_target is not None else lg) if self.continuous else (self._hard(lg, s_av, u_target) if self.td3 else self._argmax(lg, s_av))
                 cent_nact = torch.cat(nact[1:].split(B, dim=1), dim=-1)      # [T, B, N*A]
             cent_act = torch.cat(list(acts), dim=-1)                         # [T, B, N*A]
         if per_agent_cent:
@@ -145,7 +165,7 @@ class RMaddpgOracle(object):
         s_obs = torch.cat(list(obs), dim=1)[:-1]
         s_av = torch.cat(list(avail), dim=1)[:-1] if avail is not None else None
         lg, _ = actor_logits(live, s_obs, torch.zeros(N * B, H))
-        pol = lg if self.continuous else gumbel_hard(lg, s_av, torch.as_tensor(u_actor))            # [T, N*B, A]
+        pol = lg if self.continuous else self._hard(lg, s_av, u_actor)            # [T, N*B, A]
         agent_seqs = pol.split(B, dim=1)
         stacked_obs = torch.cat(list(cent), dim=1)[:-1] if per_agent_cent else cent[:-1].repeat(1, N, 1)
         every = list(acts) if all_acts is None else list(all_acts)

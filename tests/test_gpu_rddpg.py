@@ -31,7 +31,8 @@ def build(g, device="cuda:0", dims=None, args=None, td3=None, cap=None, same_sha
                             use_same_share_obs=same_share)
         td3 = bool(g["td3"])
         cap = len(g["idx_range"])
-    pinfo = policy_info_for(dims, continuous=bool(g is not None and "continuous" in g and g["continuous"]))
+    pinfo = policy_info_for(dims, continuous=bool(g is not None and "continuous" in g and g["continuous"]),
+                            multi_discrete=[int(x) for x in g["multi_discrete"]] if (g is not None and "multi_discrete" in g) else None)
     dev = torch.device(device)
     torch.manual_seed(1)
     np.random.seed(1)
@@ -131,7 +132,8 @@ def _flat_grads(mod, gvec):
     return out, g[n] / cnt
 
 
-@pytest.mark.parametrize("name", ["rmatd3_tiny", "rmaddpg_odd_huber_per", "rmaddpg_3m", "rmaddpg_cont_tiny", "rmatd3_cont_odd"])
+@pytest.mark.parametrize("name", ["rmatd3_tiny", "rmaddpg_odd_huber_per", "rmaddpg_3m", "rmaddpg_cont_tiny", "rmatd3_cont_odd", "rmaddpg_md_tiny",
+                                  "rmatd3_md_odd"])
 def test_gradients_match_oracle_per_tensor(name):
     g = load_golden(name)
     dims, buf, policy, trainer = build(g)

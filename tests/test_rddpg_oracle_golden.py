@@ -10,7 +10,9 @@ from oracle.qmix_oracle import HP
 
 CASES = ["rmaddpg_tiny", "rmatd3_tiny", "rmaddpg_odd_huber_per", "rmatd3_odd_per", "rmaddpg_3m",
          # round 4: continuous (Box) action spaces (rMADDPGPolicy.py:121-129)
-         "rmaddpg_cont_tiny", "rmatd3_cont_odd"]
+         "rmaddpg_cont_tiny", "rmatd3_cont_odd",
+         # round 4: multi-discrete action spaces (rMADDPGPolicy.py:81-102)
+         "rmaddpg_md_tiny", "rmatd3_md_odd"]
 
 
 def rddpg_oracle_from(g):
@@ -18,7 +20,8 @@ def rddpg_oracle_from(g):
             huber_delta=float(g["hp_delta"]), use_per=bool(g["hp_per"]), per_nu=float(g["hp_nu"]), per_eps=float(g["hp_per_eps"]),
             tau=float(g["hp_tau"]), max_grad_norm=float(g["hp_maxnorm"]))
     return RO.RMaddpgOracle(sub(g, "actor/"), sub(g, "critic/"), sub(g, "actor_tgt/"), sub(g, "critic_tgt/"), int(g["dims"][0]), hp,
-                            td3=bool(g["td3"]), continuous=bool(g["continuous"]) if "continuous" in g else False)
+                            td3=bool(g["td3"]), continuous=bool(g["continuous"]) if "continuous" in g else False,
+                            head_dims=[int(x) for x in g["multi_discrete"]] if "multi_discrete" in g else None)
 
 
 def rnoise_for(g, step, update_actor=True):
@@ -29,6 +32,11 @@ def rnoise_for(g, step, update_actor=True):
     torch.manual_seed(1000 + step)
     if "continuous" in g and bool(g["continuous"]):      # gaussian_noise(shape, target_action_noise_std) of the target action (R_MATD3); nothing for the actor
         return (torch.empty(T + 1, n * B, a).normal_(mean=0, std=0.2) if bool(g["td3"]) else None), None
+    if "multi_discrete" in g:      # one uniform block per sub-action head, in order, side by side
+        heads = [int(x) for x in g["multi_discrete"]]
+        blocks = lambda L: torch.cat([torch.FloatTensor(L, n * B, k).uniform_() for k in heads], dim=-1)
+        u_t = blocks(T + 1) if bool(g["td3"]) else None
+        return u_t, (blocks(T) if update_actor else None)
     u_t = torch.FloatTensor(T + 1, n * B, a).uniform_() if bool(g["td3"]) else None
     u_a = torch.FloatTensor(T, n * B, a).uniform_() if update_actor else None
     return u_t, u_a
