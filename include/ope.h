@@ -33,6 +33,10 @@ extern "C" {
 
 int ope_version(void);
 const char* ope_strerror(int code);
+/* sizeof() of the structs of this header as the library was compiled, for bindings to check their mirror declarations against
+ * (a ctypes / cgo / JNI struct that drifted would otherwise be read as garbage without an error). `name` is the type's name
+ * ("ope_dims", "ope_rddpg_cfg", ...); -1 for an unknown name. */
+int64_t ope_abi_sizeof(const char* name);
 
 /* ------------------------------------------------------------------------------------------------
  * Episode dimensions (one policy): N agents, A actions (one-hot width), D obs, S centralized state, T steps.
@@ -402,7 +406,14 @@ typedef struct ope_ddpg_cfg {
                                  * straight-through adjoint act per block. No availability masks (upstream passes none). General kernel path
                                  * only; the flat layout is the single-head one (the heads' rows are consecutive). 0 or 1 = one head. */
   int32_t act_head_dims[6];
-  int32_t reserved1;
+  /* Multi-policy updates whose policies have DIFFERENT action dimensions (maddpg.py:44-88 and 190-227 concatenate whatever widths the policies
+   * have; MPE simple_speaker_listener). Then n_total_agents = agent_offset = 0 and the joint action is described in COLUMNS: joint_act_dim =
+   * its width (sum over all agents of their policy's act_dim), joint_act_col = the first column of the update policy's first agent, joint_acts
+   * = the buffer's joint action [B][joint_act_dim] (every agent's block side by side in policy order; batch->acts is then unused);
+   * joint_next_acts (required) has the same width and ope_ddpg_target_actions writes a policy's agents at columns joint_act_col + a * act_dim.
+   * General kernel path, caller-provided noise (noise_seed = 0). 0 / NULL = every policy has dims.act_dim actions. */
+  int32_t joint_act_dim, joint_act_col;
+  const float* joint_acts;
 } ope_ddpg_cfg;
 
 /* One sampled batch in MlpPolicyBuffer.sample_inds order/shapes (mlp_buffer.py:213-257), device pointers. */
@@ -508,7 +519,15 @@ typedef struct ope_rddpg_cfg {
                                   * target_noise_u is ADDITIVE noise (NULL = none), gumbel_noise_u is unused, no availability masks. */
   int32_t n_act_heads;           /* > 1: multi-discrete action space, as ope_ddpg_cfg.n_act_heads / act_head_dims */
   int32_t act_head_dims[6];
-  int32_t reserved1;
+  /* Multi-policy updates whose policies have DIFFERENT action dimensions (MPE simple_speaker_listener under scripts/train_mpe_rmaddpg.sh:
+   * a 3-action speaker and a 5-action listener; r_maddpg.py:60-105 and 236-301 concatenate whatever widths the policies have). Then
+   * n_total_agents = agent_offset = 0 and the joint action is described in COLUMNS: joint_act_dim = its width (sum over all agents of their
+   * policy's act_dim), joint_act_col = the first column of the update policy's first agent; dims.act_dim / dims.n_agents stay the update
+   * policy's own. `joint_acts` is the buffer's joint action [T][B][joint_act_dim] (the caller concatenates the policies' action blocks in
+   * policy order; batch->acts is then unused), joint_next_acts (required) has the same width, and ope_rddpg_target_actions writes a policy's
+   * agents at columns joint_act_col + a * act_dim. 0 / NULL = every policy has dims.act_dim actions (the fields above). */
+  int32_t joint_act_dim, joint_act_col;
+  const float* joint_acts;
 } ope_rddpg_cfg;
 
 /* which = 0 actor, 1 critic: offsets/sizes of its OPE_QMIX_NPARAM_AGENT tensors; returns the padded length. */

@@ -74,14 +74,16 @@ class DdpgCfg(C.Structure):
                 ("use_huber", C.c_int32), ("use_per", C.c_int32), ("gamma", C.c_float), ("huber_delta", C.c_float),
                 ("per_eps", C.c_float), ("noise_seed", C.c_uint64), ("noise_counter", C.c_void_p),
                 ("n_total_agents", C.c_int32), ("agent_offset", C.c_int32), ("joint_next_acts", C.c_void_p),
-                ("continuous", C.c_int32), ("n_act_heads", C.c_int32), ("act_head_dims", C.c_int32 * 6), ("reserved1", C.c_int32)]
+                ("continuous", C.c_int32), ("n_act_heads", C.c_int32), ("act_head_dims", C.c_int32 * 6),
+                ("joint_act_dim", C.c_int32), ("joint_act_col", C.c_int32), ("joint_acts", C.c_void_p)]
 
 
 class RddpgCfg(C.Structure):
     _fields_ = [("dims", Dims), ("batch", C.c_int32), ("num_q", C.c_int32), ("target_gumbel", C.c_int32),
                 ("use_huber", C.c_int32), ("use_per", C.c_int32), ("gamma", C.c_float), ("huber_delta", C.c_float),
                 ("n_total_agents", C.c_int32), ("agent_offset", C.c_int32), ("joint_next_acts", C.c_void_p), ("actor_row_weight", C.c_void_p),
-                ("continuous", C.c_int32), ("n_act_heads", C.c_int32), ("act_head_dims", C.c_int32 * 6), ("reserved1", C.c_int32)]
+                ("continuous", C.c_int32), ("n_act_heads", C.c_int32), ("act_head_dims", C.c_int32 * 6),
+                ("joint_act_dim", C.c_int32), ("joint_act_col", C.c_int32), ("joint_acts", C.c_void_p)]
 
 
 class AllreduceCtx(C.Structure):
@@ -93,6 +95,11 @@ class MlpBatch(C.Structure):
                                           "valid_transition", "avail_acts", "next_avail_acts")]
 
 
+ABI_MIRRORS = {"ope_dims": Dims, "ope_fields": Fields, "ope_qmix_cfg": QmixCfg, "ope_gather_tune": GatherTune, "ope_obs_ref": ObsRef,
+               "ope_adam_cfg": AdamCfg, "ope_ddpg_opt": DdpgOpt, "ope_ddpg_cfg": DdpgCfg, "ope_rddpg_cfg": RddpgCfg,
+               "ope_allreduce_ctx": AllreduceCtx, "ope_mlp_batch": MlpBatch}
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise OpeError("libope.so not found at %s -- build it with `python -m offpolicy_amd.build` "
@@ -102,6 +109,7 @@ def _load():
     i32, i64 = C.c_int32, C.c_int64
     sig = {
         "ope_version": (C.c_int, []),
+        "ope_abi_sizeof": (C.c_int64, [C.c_char_p]),
         "ope_strerror": (C.c_char_p, [C.c_int]),
         "ope_set_debug": (None, [C.c_int]),
         "ope_set_scan_kernel": (None, [C.c_int, C.c_int]),
@@ -171,6 +179,12 @@ def _load():
         fn = getattr(lib, name)  # AttributeError here = a symbol declared in include/ope.h is missing
         fn.restype = res
         fn.argtypes = args
+    # the mirror declarations above against the structs the library was compiled with: a drifted field would be read as garbage silently
+    for cname, cls in ABI_MIRRORS.items():
+        want = lib.ope_abi_sizeof(cname.encode())
+        if want != C.sizeof(cls):
+            raise OpeError("%s: sizeof is %d in libope.so but %d in offpolicy_amd._lib.%s -- rebuild the library or fix the mirror"
+                           % (cname, want, C.sizeof(cls), cls.__name__))
     return lib, sorted(sig)
 
 

@@ -70,8 +70,10 @@ class MADDPGPolicy(object):
         self.target_noise = target_noise
         self.td3 = bool(td3)
         self.num_q = 2 if td3 else 1
-        assert self.central_act_dim % self.output_dim == 0
-        self.num_agents = self.central_act_dim // self.output_dim
+        # the joint action is this policy's width times the number of agents, unless policies of OTHER action dimensions share the critic
+        # (share_policy = False on e.g. simple_speaker_listener): then only its total width is known here (ope_ddpg_cfg.joint_act_dim)
+        self.mixed_act_dims = self.central_act_dim % self.output_dim != 0
+        self.num_agents = 1 if self.mixed_act_dims else self.central_act_dim // self.output_dim
         self.frozen_q_head = bool(frozen_q_head)
         cfg = self.ddpg_cfg(1)
         dev, a = self.device, self.args
@@ -92,6 +94,8 @@ class MADDPGPolicy(object):
         a = self.args
         cfg = _lib.DdpgCfg()
         cfg.dims = _lib.Dims(self.num_agents, self.output_dim, self.obs_dim, self.central_obs_dim, 1)
+        if self.mixed_act_dims:
+            cfg.joint_act_dim, cfg.joint_act_col = int(self.central_act_dim), 0
         if self.multidiscrete:      # the action vector = one-hot blocks, argmax / gumbel-softmax per block (ope_ddpg_cfg.n_act_heads)
             cfg.n_act_heads = len(self.act_dim)
             for i, a_dim in enumerate(self.act_dim):

@@ -46,8 +46,16 @@ class MADDPG(object):
             flat_agents = [a for pid in self.policy_ids for a in self.policy_agents[pid]]
             if flat_agents != list(range(num_agents)) or any(len(self.policy_agents[pid]) == 0 for pid in self.policy_ids):
                 raise NotImplementedError("several policies: agents must be numbered policy by policy, every policy with at least one agent")
-            if len({int(np.sum(self.policies[pid].act_dim)) for pid in self.policy_ids}) != 1 or any(self.policies[pid].multidiscrete for pid in self.policy_ids):
-                raise NotImplementedError("several policies on the accelerated MADDPG path need one action dimension")
+            if any(self.policies[pid].multidiscrete or not self.policies[pid].discrete for pid in self.policy_ids):
+                raise NotImplementedError("several policies with continuous / multi-discrete action spaces are not on the accelerated path")
+        # policies of different action dimensions (MPE simple_speaker_listener): the joint action is then described in columns
+        # (ope_ddpg_cfg.joint_act_dim / joint_act_col / joint_acts) instead of equal agent blocks
+        self.mixed_act_dims = len({self.policies[pid].output_dim for pid in self.policy_ids}) != 1
+        self.joint_act_col, col = {}, 0
+        for pid in self.policy_ids:
+            self.joint_act_col[pid] = col
+            col += len(self.policy_agents[pid]) * self.policies[pid].output_dim
+        self.joint_act_dim = col
         self.num_updates = {p_id: 0 for p_id in self.policy_ids}
         self.use_same_share_obs = args.use_same_share_obs
         self.actor_update_interval = actor_update_interval
@@ -60,7 +68,7 @@ class MADDPG(object):
         self._ws, self._grads, self._gsq = {}, {}, {}
 
     def _workspace(self, policy, cfg):
-        B = (cfg.batch, cfg.dims.n_agents, cfg.n_total_agents, id(policy)) if cfg.n_total_agents else cfg.batch
+        B = (cfg.batch, cfg.dims.n_agents, cfg.n_total_agents, cfg.joint_act_dim, id(policy)) if (cfg.n_total_agents or cfg.joint_act_dim) else cfg.batch
         if B not in self._ws:
             need = _lib.lib.ope_ddpg_workspace_bytes(C.byref(cfg))
             if need < 0:
@@ -228,7 +236,8 @@ class MADDPG(object):
             NT, A = self.num_agents, policy.output_dim
             # joint target action: one ope_ddpg_target_actions per policy (its target actor on its agents' next observations; noise
             # drawn per policy in policy order, as get_update_info does), scattered into [B][N_total * A]
-            joint_next = torch.empty(B, NT * A, **self.tpdv)
+            mixed = self.mixed_act_dims
+            joint_next = torch.empty(B, self.joint_act_dim if mixed else NT * A, **self.tpdv)
             keep = []
             for q in self.policy_ids:
                 pol_q = self.policies[q]
@@ -236,16 +245,25 @@ class MADDPG(object):
                 nv_q = navail if q == pid else (f(navail_b[q]) if navail_b is not None else None)
                 cq = pol_q.ddpg_cfg(B)
                 cq.dims.n_agents, cq.n_total_agents, cq.agent_offset = int(no_q.shape[0]), NT, self.agent_offset[q]
+                if mixed:
+                    cq.n_total_agents, cq.agent_offset, cq.joint_act_dim, cq.joint_act_col = 0, 0, self.joint_act_dim, self.joint_act_col[q]
                 ws_q, _ = self._workspace(pol_q, cq)
                 mq = _lib.MlpBatch()
                 mq.next_obs, mq.next_avail_acts = _lib.ptr(no_q).value, _lib.ptr(nv_q).value
-                u_q = sample_gumbel_uniform((int(no_q.shape[0]) * B, A)).to(self.device) if pol_q.target_noise is not None else None
+                u_q = sample_gumbel_uniform((int(no_q.shape[0]) * B, pol_q.output_dim)).to(self.device) if pol_q.target_noise is not None else None
                 _lib.check(_lib.lib.ope_ddpg_target_actions(C.byref(cq), C.byref(mq), _lib.ptr(pol_q.target_actor._flat), _lib.ptr(u_q),
                                                             _lib.ptr(ws_q), ws_q.numel(), _lib.ptr(joint_next), _lib.current_stream()),
                            "ope_ddpg_target_actions")
                 keep.append((no_q, nv_q, u_q))
-            acts = torch.cat([acts if q == pid else f(act_b[q]) for q in self.policy_ids], dim=0).contiguous()      # [N_total][B][A]
-            cfg.dims.n_agents, cfg.n_total_agents, cfg.agent_offset = N, NT, self.agent_offset[pid]
+            if mixed:      # the buffer's joint action [B][sum of widths]: every agent's block side by side, policy order
+                joint_acts = torch.cat([(acts if q == pid else f(act_b[q])).permute(1, 0, 2).reshape(B, -1) for q in self.policy_ids], dim=-1).contiguous()
+                assert joint_acts.shape[-1] == self.joint_act_dim
+                keep.append(joint_acts)
+                cfg.dims.n_agents, cfg.joint_act_dim, cfg.joint_act_col = N, self.joint_act_dim, self.joint_act_col[pid]
+                cfg.joint_acts = _lib.ptr(joint_acts).value
+            else:
+                acts = torch.cat([acts if q == pid else f(act_b[q]) for q in self.policy_ids], dim=0).contiguous()      # [N_total][B][A]
+                cfg.dims.n_agents, cfg.n_total_agents, cfg.agent_offset = N, NT, self.agent_offset[pid]
             cfg.joint_next_acts = _lib.ptr(joint_next).value
             self._keep_multi = (joint_next, keep)
         ws, (gc, ga, scratch) = self._workspace(policy, cfg)

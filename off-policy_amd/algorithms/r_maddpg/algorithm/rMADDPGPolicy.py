@@ -41,8 +41,10 @@ class R_MADDPGPolicy(object):
         self.target_noise = target_noise
         self.td3 = bool(td3)
         self.num_q = 2 if td3 else 1
-        assert self.central_act_dim % self.output_dim == 0
-        self.num_agents = self.central_act_dim // self.output_dim
+        # the joint action is this policy's width times the number of agents, unless policies of OTHER action dimensions share the critic
+        # (share_policy = False on e.g. simple_speaker_listener): then only its total width is known here (ope_rddpg_cfg.joint_act_dim)
+        self.mixed_act_dims = self.central_act_dim % self.output_dim != 0
+        self.num_agents = 1 if self.mixed_act_dims else self.central_act_dim // self.output_dim
         cfg = self.rddpg_cfg(1, 1)
         dev = self.device
         cin = self.central_obs_dim + self.central_act_dim
@@ -64,6 +66,8 @@ class R_MADDPGPolicy(object):
         a = self.args
         cfg = _lib.RddpgCfg()
         cfg.dims = _lib.Dims(self.num_agents, self.output_dim, self.obs_dim, self.central_obs_dim, int(episode_length))
+        if self.mixed_act_dims:
+            cfg.joint_act_dim, cfg.joint_act_col = int(self.central_act_dim), 0
         if self.multidiscrete:      # one-hot blocks, argmax / gumbel-softmax per block (ope_rddpg_cfg.n_act_heads)
             cfg.n_act_heads = len(self.act_dim)
             for i, a_dim in enumerate(self.act_dim):

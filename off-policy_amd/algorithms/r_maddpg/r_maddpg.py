@@ -49,8 +49,14 @@ class R_MADDPG(object):
             self.agent_offset[pid] = off
             off += len(self.policy_agents[pid])
         assert off == num_agents, "every agent must be mapped to a policy"
-        if len({self.policies[pid].output_dim for pid in self.policy_ids}) != 1:
-            raise NotImplementedError("policies with different action dimensions are not on the accelerated path")
+        # policies of different action dimensions (simple_speaker_listener under scripts/train_mpe_rmaddpg.sh): the joint action is then
+        # described in columns (ope_rddpg_cfg.joint_act_dim / joint_act_col / joint_acts) instead of equal agent blocks
+        self.mixed_act_dims = len({self.policies[pid].output_dim for pid in self.policy_ids}) != 1
+        self.joint_act_col, col = {}, 0
+        for pid in self.policy_ids:
+            self.joint_act_col[pid] = col
+            col += len(self.policy_agents[pid]) * self.policies[pid].output_dim
+        self.joint_act_dim = col
         if self.multi_policy and any(self.policies[pid].multidiscrete for pid in self.policy_ids):
             raise NotImplementedError("multi-discrete action spaces with several policies are not on the accelerated path")
         self.actor_update_interval = actor_update_interval
@@ -67,7 +73,7 @@ class R_MADDPG(object):
     def _workspace(self, policy, cfg):
         # one workspace + gradient / Adam-scratch set PER POLICY: the buffers below are sized from this policy's actor and critic
         # (policies of a multi-policy trainer may differ in observation width while sharing batch size and agent counts)
-        B = (cfg.batch, cfg.dims.n_agents, cfg.n_total_agents, id(policy)) if cfg.n_total_agents else cfg.batch
+        B = (cfg.batch, cfg.dims.n_agents, cfg.n_total_agents, cfg.joint_act_dim, id(policy)) if (cfg.n_total_agents or cfg.joint_act_dim) else cfg.batch
         if B not in self._ws:
             need = _lib.lib.ope_rddpg_workspace_bytes(C.byref(cfg))
             if need < 0:
@@ -212,21 +218,31 @@ class R_MADDPG(object):
             # joint target action: one ope_rddpg_target_actions per policy (its target actor over its agents' T+1 observations; noise
             # drawn per policy in policy order, as get_update_info does), scattered into [T][B][N_total * A]
             NT = self.num_agents
-            joint_next = torch.empty(T, B, NT * A, **self.tpdv)
+            mixed = self.mixed_act_dims
+            joint_next = torch.empty(T, B, self.joint_act_dim if mixed else NT * A, **self.tpdv)
             keep = []
             for q, o_q, a_q, v_q in others:
                 pol_q = self.policies[q]
                 cq = pol_q.rddpg_cfg(B, T)
                 cq.dims.n_agents, cq.n_total_agents, cq.agent_offset = o_q.shape[1], NT, self.agent_offset[q]
+                if mixed:
+                    cq.n_total_agents, cq.agent_offset, cq.joint_act_dim, cq.joint_act_col = 0, 0, self.joint_act_dim, self.joint_act_col[q]
                 ws_q, _ = self._workspace(pol_q, cq)
                 fq = _lib.Fields()
                 fq.obs, fq.avail_acts = _lib.ptr(o_q).value, _lib.ptr(v_q).value
-                u_q = draw((T + 1, o_q.shape[1] * B, A)) if pol_q.target_noise is not None else None
+                u_q = draw((T + 1, o_q.shape[1] * B, pol_q.output_dim)) if pol_q.target_noise is not None else None
                 _lib.check(_lib.lib.ope_rddpg_target_actions(C.byref(cq), C.byref(fq), _lib.ptr(pol_q.target_actor._flat), _lib.ptr(u_q),
                                                              _lib.ptr(ws_q), ws_q.numel(), _lib.ptr(joint_next), st), "ope_rddpg_target_actions")
                 keep.append((u_q, o_q, v_q))
-            acts = torch.cat([a_q for _, _, a_q, _ in others], dim=1).contiguous()      # [T][N_total][B][A]
-            cfg.dims.n_agents, cfg.n_total_agents, cfg.agent_offset = N, NT, self.agent_offset[pid]
+            if mixed:      # the buffer's joint action [T][B][sum of widths]: every agent's block side by side, policy order
+                joint_acts = torch.cat([a_q.permute(0, 2, 1, 3).reshape(T, B, -1) for _, _, a_q, _ in others], dim=-1).contiguous()
+                assert joint_acts.shape[-1] == self.joint_act_dim
+                keep.append(joint_acts)
+                cfg.dims.n_agents, cfg.joint_act_dim, cfg.joint_act_col = N, self.joint_act_dim, self.joint_act_col[pid]
+                cfg.joint_acts = _lib.ptr(joint_acts).value
+            else:
+                acts = torch.cat([a_q for _, _, a_q, _ in others], dim=1).contiguous()      # [T][N_total][B][A]
+                cfg.dims.n_agents, cfg.n_total_agents, cfg.agent_offset = N, NT, self.agent_offset[pid]
             cfg.joint_next_acts = _lib.ptr(joint_next).value
         roww = getattr(self, "_actor_row_weight", None)
         if roww is not None:

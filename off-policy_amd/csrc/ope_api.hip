@@ -277,6 +277,14 @@ extern "C" int ope_last_launches(char* out, int32_t cap) {
 }
 
 extern "C" int ope_version(void) { return OPE_VERSION; }
+extern "C" int64_t ope_abi_sizeof(const char* name) {
+  if (!name) return -1;
+#define OPE_SZ(T) if (!strcmp(name, #T)) return (int64_t)sizeof(T)
+  OPE_SZ(ope_dims); OPE_SZ(ope_fields); OPE_SZ(ope_gather_tune); OPE_SZ(ope_obs_ref); OPE_SZ(ope_qmix_cfg); OPE_SZ(ope_adam_cfg);
+  OPE_SZ(ope_ddpg_cfg); OPE_SZ(ope_mlp_batch); OPE_SZ(ope_ddpg_opt); OPE_SZ(ope_rddpg_cfg); OPE_SZ(ope_allreduce_ctx);
+#undef OPE_SZ
+  return -1;
+}
 extern "C" const char* ope_strerror(int code) {
   switch (code) {
     case OPE_OK: return "ok";

@@ -39,6 +39,7 @@ struct CriticTdArgs {
 struct ActGradArgs {
   int R, B, N, A, A4, S, Din;
   int a_off;                                 // the copies' own action block is agent a_off + rep of the joint action (0: the copies ARE all agents)
+  int a_col;                                 // ... plus this many columns (joint actions of blocks of different widths: a_off = 0, a_col = first column)
   const float* dz1;                          // [R][64] adjoint of the fc1 pre-activation (zero where ReLU is off)
   const float* xhat1; const float* rstd1; const float* mu1;   // LN1 saves: relu(z1) = xhat1/rstd1 + mu1
   const float* mu0; const float* rstd0;      // input-LN saves
@@ -59,7 +60,9 @@ int launch_build_cin(const float* cent, const float* acts, const float* repl, in
 // nact_agents / a_off: the scatter target cent_nact holds nact_agents (default N) agents per row, this launch's agents start at a_off
 int launch_action(const float* logits, const float* avail, NoiseSrc U, int rows, int B, int A, int N, int mode, int t_shift,
                   float* cent_nact, float* act_out, float* soft_out, hipStream_t st, int nact_agents = 0, int a_off = 0,
-                  const ActHeads* heads = nullptr);
+                  const ActHeads* heads = nullptr, int nact_stride = 0, int nact_col = 0);      // nact_stride > 0: row stride / first column in floats instead
+int launch_build_cin_joint(const float* cent, const float* joint, const float* repl, int T, int B, int J, int S, int reps, int Ar, int col0,
+                           float* out, hipStream_t st);
 
 // Optimiser step in the tail of a tile launch (ope_ddpg_opt, ope.h): slab reduction + clip + Adam + Polyak behind two grid barriers.
 struct TileOpt {

@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(256) build_cin_kernel(const float* __restrict_
 __global__ void __launch_bounds__(256) action_kernel(const float* __restrict__ logits, const float* __restrict__ avail,
                                                       NoiseSrc U, int rows, int B, int A, int N, int mode, int t_shift,
                                                       int rpb, float* __restrict__ cent_nact, float* __restrict__ act_out,
-                                                      float* __restrict__ soft_out, int nact_agents, int a_off, ActHeads hd) {
+                                                      float* __restrict__ soft_out, int nact_stride, int nact_col, ActHeads hd) {
   extern __shared__ float sm[];
   const int pitch = A | 1;
   float* val = sm;                      // [rpb][pitch] masked (noisy) logits, overwritten by the output values
@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(256) action_kernel(const float* __restrict__ l
       if (t >= t_shift) {
         const int rem = r - t * (N * B);
         const int a = (int)(((float)rem + 0.5f) * invB), b = rem - a * B;
-        cent_nact[((int64_t)(t - t_shift) * B + b) * (nact_agents * A) + (a_off + a) * A + j] = out;
+        cent_nact[((int64_t)(t - t_shift) * B + b) * nact_stride + nact_col + a * A + j] = out;
       }
     }
   }
@@ -265,7 +265,7 @@ __global__ void __launch_bounds__(256) action_grad_kernel(ActGradArgs a) {
   const float invD = 1.0f / (float)a.Din;
   m1 *= invD;
   m2 *= invD;
-  const int col0 = a.S + rep * a.A;
+  const int col0 = a.S + a.a_col + rep * a.A;
   const float* W = a.theta + a.fc1_w + col0;
   float* out = a.dlogits + (int64_t)r * a.A4;
   float dot = 0.f;
@@ -307,7 +307,7 @@ __global__ void __launch_bounds__(256) action_grad_mfma_kernel(ActGradArgs a) {
   const bool valid = row < a.R;
   const int64_t rr = valid ? row : a.R - 1;
   const int rep = a.a_off + (row0 / a.B) % a.N;          // uniform over the tile
-  const int col0 = a.S + rep * a.A;
+  const int col0 = a.S + a.a_col + rep * a.A;
   const float rs1 = a.rstd1[rr], mu1 = a.mu1[rr], rs0 = a.rstd0[rr], mu0 = a.mu0[rr];
   const float inv_rs1 = 1.0f / rs1;
   f32x4 dz[4];
@@ -387,7 +387,7 @@ __global__ void __launch_bounds__(256) action_grad_wave_kernel(ActGradArgs a) {
   const float invD = 1.0f / (float)a.Din;
   m1 *= invD;
   m2 *= invD;
-  const int col0 = a.S + rep * a.A;
+  const int col0 = a.S + a.a_col + rep * a.A;
   const float* W = a.theta + a.fc1_w + (int64_t)lane * a.Din + col0;
   float mine = 0.f, dot = 0.f;   // lane j (< A) keeps dx_j
   for (int j = 0; j < a.A; ++j) {
@@ -410,6 +410,36 @@ static int launch1d(int64_t n) { return ope_cdiv(n, 256); }
     if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;   \
   } while (0)
 
+// The same rows over a joint action of blocks of DIFFERENT widths (policies with different action dimensions, r_maddpg.py:236-301):
+//   out[r] = [ cent[t][b] (S) | joint[t][b] (J) ],  r = (t*reps + rep)*B + b,  columns [col0 + rep*Ar, + Ar) of the joint part <- repl[r]
+// One thread per output element (small environments; the equal-width form above is the fast one).
+__global__ void __launch_bounds__(256) build_cin_joint_kernel(const float* __restrict__ cent, const float* __restrict__ joint,
+                                                               const float* __restrict__ repl, int T, int B, int J, int S, int reps, int Ar,
+                                                               int col0, float* __restrict__ out) {
+  const int Din = S + J;
+  const int64_t total = (int64_t)T * reps * B * Din;
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int64_t r = e / Din;
+  const int c = (int)(e - r * Din);
+  const int t = (int)(r / ((int64_t)reps * B));
+  const int rem = (int)(r - (int64_t)t * reps * B);
+  const int rep = rem / B, b = rem - rep * B;
+  float v;
+  if (c < S) {
+    v = cent[((int64_t)t * B + b) * S + c];
+  } else {
+    const int k = c - S, lo = col0 + rep * Ar;
+    v = (repl && k >= lo && k < lo + Ar) ? repl[r * Ar + (k - lo)] : joint[((int64_t)t * B + b) * J + k];
+  }
+  out[e] = v;
+}
+int launch_build_cin_joint(const float* cent, const float* joint, const float* repl, int T, int B, int J, int S, int reps, int Ar, int col0,
+                           float* out, hipStream_t st) {
+  const int64_t total = (int64_t)T * reps * B * (S + J);
+  OPE_L(OPE_LAUNCH(build_cin_joint_kernel, dim3(ope_cdiv(total, 256)), dim3(256), 0, st, cent, joint, repl, T, B, J, S, reps, Ar, col0, out));
+  return OPE_OK;
+}
 int launch_build_cin(const float* cent, const float* acts, const float* repl, int T, int B, int N, int A, int S, int reps, float* out,
                      hipStream_t st, int rep_off) {
   const int64_t rows = (int64_t)T * reps * B;
@@ -421,14 +451,16 @@ int launch_build_cin(const float* cent, const float* acts, const float* repl, in
   return OPE_OK;
 }
 int launch_action(const float* logits, const float* avail, NoiseSrc U, int rows, int B, int A, int N, int mode, int t_shift,
-                  float* cent_nact, float* act_out, float* soft_out, hipStream_t st, int nact_agents, int a_off, const ActHeads* heads) {
+                  float* cent_nact, float* act_out, float* soft_out, hipStream_t st, int nact_agents, int a_off, const ActHeads* heads,
+                  int nact_stride, int nact_col) {
   const ActHeads hd = heads ? *heads : act_heads_of(1, nullptr, A);
   if (hd.n > 1) avail = nullptr;      // multi-discrete: upstream passes no availability masks (MADDPGPolicy.py:73-92)
   const int pitch = A | 1;
   const int rpb = pitch <= 31 ? 256 : 64;
   const size_t lds = (size_t)2 * rpb * pitch * sizeof(float);
   OPE_L(OPE_LAUNCH(action_kernel, dim3(ope_cdiv(rows, rpb)), dim3(256), lds, st, logits, avail, U, rows, B, A, N, mode, t_shift,
-                           rpb, cent_nact, act_out, soft_out, nact_agents > 0 ? nact_agents : N, a_off, hd));
+                           rpb, cent_nact, act_out, soft_out, nact_stride > 0 ? nact_stride : (nact_agents > 0 ? nact_agents : N) * A,
+                           nact_stride > 0 ? nact_col : a_off * A, hd));
   return OPE_OK;
 }
 int launch_action_grad(const ActGradArgs& a, hipStream_t st) {
@@ -451,6 +483,8 @@ int launch_action_grad(const ActGradArgs& a, hipStream_t st) {
 struct DdpgPlan {
   int N, A, D, S, B, K, K4, A4, Din, Ra;
   int NT, a0;               // agents in the joint action / the update policy's first agent in it (multi-policy; NT = N, a0 = 0 otherwise)
+  int J, c0;                // width of the joint action / first column of the update policy's first agent
+  bool hetero;              // joint action given in columns (policies of different action dimensions: ope_ddpg_cfg.joint_act_dim)
   AgentLayout AL, CL;       // actor (D -> A), critic (Din -> K)
   Workspace ws;
   int ns_c, ns_a;
@@ -473,6 +507,9 @@ static int ddpg_cfg_ok(const ope_ddpg_cfg* c) {
   if (c->n_total_agents < 0 || c->agent_offset < 0 || c->agent_offset + d.n_agents > nt || nt > 64) return 0;
   if (c->n_total_agents <= 0 && c->agent_offset != 0) return 0;
   if (d.state_dim + nt * d.act_dim > 512) return 0;
+  if (c->joint_act_dim != 0 && (c->n_total_agents != 0 || c->joint_act_col < 0 || c->joint_act_col + d.n_agents * d.act_dim > c->joint_act_dim ||
+                                d.state_dim + c->joint_act_dim > 512 || c->noise_seed))
+    return 0;
   if (c->batch < 1 || c->num_q < 1 || c->num_q > 4) return 0;
   return 1;
 }
@@ -481,7 +518,9 @@ static void ddpg_plan(const ope_ddpg_cfg* c, DdpgPlan* p) {
   const ope_dims& d = c->dims;
   p->N = d.n_agents; p->A = d.act_dim; p->D = d.obs_dim; p->S = d.state_dim; p->B = c->batch; p->K = c->num_q;
   p->NT = c->n_total_agents > 0 ? c->n_total_agents : p->N; p->a0 = c->agent_offset;
-  p->K4 = ope_round4(p->K); p->A4 = ope_round4(p->A); p->Din = p->S + p->NT * p->A; p->Ra = p->N * p->B;
+  p->hetero = c->joint_act_dim > 0;
+  p->J = p->hetero ? c->joint_act_dim : p->NT * p->A; p->c0 = p->hetero ? c->joint_act_col : p->a0 * p->A;
+  p->K4 = ope_round4(p->K); p->A4 = ope_round4(p->A); p->Din = p->S + p->J; p->Ra = p->N * p->B;
   p->AL = ope_agent_layout_mlp(p->D, p->A, 0);
   p->CL = ope_agent_layout_mlp(p->Din, p->K, 0);
   const int Dmax = p->D > p->Din ? p->D : p->Din;
@@ -498,7 +537,7 @@ static void ddpg_plan(const ope_ddpg_cfg* c, DdpgPlan* p) {
   Workspace& W = p->ws;
   const int64_t B = p->B, Ra = p->Ra, R = Ra;   // save buffers sized for the larger (actor-side) row count
   p->xin_t = W.add("xin_t", B * p->Din); p->xin = W.add("xin", B * p->Din);
-  p->a2n = W.add("a2n", Ra * OPE_H); p->lgn = W.add("logits_n", Ra * p->A); p->cnact = W.add("cent_nact", B * p->NT * p->A);
+  p->a2n = W.add("a2n", Ra * OPE_H); p->lgn = W.add("logits_n", Ra * p->A); p->cnact = W.add("cent_nact", B * p->J);
   p->a2t = W.add("a2t", B * OPE_H); p->qt = W.add("q_tgt", B * p->K4);
   p->a2c = W.add("a2c", R * OPE_H); p->qc = W.add("q", R * p->K4);
   p->dq = W.add("dq", R * p->K4); p->da2 = W.add("da2", R * OPE_H); p->dz1 = W.add("dz1", R * OPE_H); p->dz2 = W.add("dz2", R * OPE_H);
@@ -514,7 +553,7 @@ static void ddpg_plan(const ope_ddpg_cfg* c, DdpgPlan* p) {
   p->mu1 = W.add("mu1", R); p->cvec = W.add("fc1_colsums", 2 * OPE_H); p->dlg = W.add("dlogits", Ra * p->A4);
   // second set of trunk saves for the actor's own backward (the critic pass of the actor step reuses the first set)
   p->err = W.add("saves2", Ra * (2 * OPE_H + 8));
-  p->fused = ddpg_fused_ok(p->N, p->A, p->D, p->S, p->K) && p->NT == p->N && !c->continuous && c->n_act_heads <= 1;   // (the tile kernels are the one-shared-policy, discrete-action form)
+  p->fused = ddpg_fused_ok(p->N, p->A, p->D, p->S, p->K) && p->NT == p->N && !p->hetero && !c->continuous && c->n_act_heads <= 1;   // (the tile kernels are the one-shared-policy, discrete-action form)
   p->fused_slabs = W.add("fused_slabs", p->fused ? ddpg_fused_slab_floats(p->N, p->A, p->D, p->S, p->K, p->B) + 64 : 4);   // + debug stamps
   if (p->fused) {    // per-workgroup sums of squares of the gradient the slab reduction wrote (only the fused path produces them)
     p->gsq_critic = W.add("gsq_critic", 2 * ddpg_fused_gsq_blocks(p->N, p->A, p->D, p->S, p->K, true));
@@ -706,7 +745,8 @@ extern "C" int ope_ddpg_actor_update(const ope_ddpg_cfg* cfg, const ope_mlp_batc
                                      const ope_ddpg_opt* opt, void* stream) {
   (void)hipGetLastError();
   if (!ddpg_cfg_ok(cfg) || !bt || !theta_actor || !theta_critic || (!gumbel_noise_u && !cfg->noise_seed) || !workspace || !grad) return OPE_EINVAL;
-  if (!bt->obs || !bt->share_obs || !bt->acts || !bt->valid_transition) return OPE_EINVAL;
+  if (!bt->obs || !bt->share_obs || (!bt->acts && !cfg->joint_acts) || !bt->valid_transition) return OPE_EINVAL;
+  if (cfg->joint_act_dim > 0 && !cfg->joint_acts) return OPE_EINVAL;
   DdpgPlan p;
   ddpg_plan(cfg, &p);
   if (workspace_bytes < p.ws.total * (int64_t)sizeof(float)) return OPE_ENOSPC;
@@ -728,7 +768,8 @@ extern "C" int ope_ddpg_critic_loss_and_grad(const ope_ddpg_cfg* cfg, const ope_
   const bool joint = cfg->joint_next_acts != nullptr;
   if (!joint && (!theta_actor_tgt || !bt->next_obs)) return OPE_EINVAL;
   if (!joint && cfg->n_total_agents > cfg->dims.n_agents) return OPE_EINVAL;   // other policies' target actions must come from the caller
-  if (!bt->share_obs || !bt->acts || !bt->rewards || !bt->next_share_obs || !bt->dones_env) return OPE_EINVAL;
+  if (!bt->share_obs || (!bt->acts && !cfg->joint_acts) || !bt->rewards || !bt->next_share_obs || !bt->dones_env) return OPE_EINVAL;
+  if (cfg->joint_act_dim > 0 && (!joint || !cfg->joint_acts)) return OPE_EINVAL;
   if (!joint && cfg->target_gumbel && !target_noise_u && !cfg->noise_seed) return OPE_EINVAL;
   if (cfg->use_per && !per_weights) return OPE_EINVAL;
   DdpgPlan p;
@@ -750,8 +791,10 @@ extern "C" int ope_ddpg_critic_loss_and_grad(const ope_ddpg_cfg* cfg, const ope_
   }
   const float* cnact = joint ? cfg->joint_next_acts : W + p.cnact;
   // critic inputs
-  if ((rc = launch_build_cin(bt->next_share_obs, cnact, nullptr, 1, p.B, 1, p.NT * p.A, p.S, 1, W + p.xin_t, st))) return rc;
-  if ((rc = launch_build_cin(bt->share_obs, bt->acts, nullptr, 1, p.B, p.NT, p.A, p.S, 1, W + p.xin, st))) return rc;
+  if ((rc = launch_build_cin(bt->next_share_obs, cnact, nullptr, 1, p.B, 1, p.J, p.S, 1, W + p.xin_t, st))) return rc;
+  if ((rc = launch_build_cin(bt->share_obs, p.hetero ? cfg->joint_acts : bt->acts, nullptr, 1, p.B, p.hetero ? 1 : p.NT, p.hetero ? p.J : p.A, p.S, 1,
+                             W + p.xin, st)))
+    return rc;
   // target critic, live critic
   if ((rc = trunk_mlp(p, W, W + p.xin_t, p.B, p.Din, theta_critic_tgt, p.CL, W + p.a2t, false, nullptr, W + p.qt, p.K, st))) return rc;   // [B][K]
   if ((rc = trunk_mlp(p, W, W + p.xin, p.B, p.Din, theta_critic, p.CL, W + p.a2c, true, nullptr, W + p.qc, p.K, st))) return rc;
@@ -779,7 +822,8 @@ extern "C" int ope_ddpg_target_actions(const ope_ddpg_cfg* cfg, const ope_mlp_ba
   if ((rc = trunk_mlp(p, W, bt->next_obs, p.Ra, p.D, theta_actor_tgt, p.AL, W + p.a2n, false, nullptr, W + p.lgn, p.A, st))) return rc;
   // (device-drawn noise: one Philox stream per policy, so that two policies' target noise is not the same numbers)
   return launch_action(W + p.lgn, bt->next_avail_acts, NoiseSrc{target_noise_u, cfg->noise_seed, cfg->noise_counter, 16 + p.a0}, p.Ra, p.B, p.A,
-                       p.N, cfg->continuous ? 2 : (cfg->target_gumbel ? 1 : 0), 0, joint_next_acts, nullptr, nullptr, st, p.NT, p.a0, &hd);
+                       p.N, cfg->continuous ? 2 : (cfg->target_gumbel ? 1 : 0), 0, joint_next_acts, nullptr, nullptr, st, p.NT, p.a0, &hd,
+                       p.hetero ? p.J : 0, p.c0);
 }
 
 extern "C" int ope_ddpg_actor_loss_and_grad(const ope_ddpg_cfg* cfg, const ope_mlp_batch* bt, const float* theta_actor,
@@ -787,7 +831,8 @@ extern "C" int ope_ddpg_actor_loss_and_grad(const ope_ddpg_cfg* cfg, const ope_m
                                             int64_t workspace_bytes, float* grad, void* stream) {
   (void)hipGetLastError();
   if (!ddpg_cfg_ok(cfg) || !bt || !theta_actor || !theta_critic || (!cfg->continuous && !gumbel_noise_u && !cfg->noise_seed) || !workspace || !grad) return OPE_EINVAL;
-  if (!bt->obs || !bt->share_obs || !bt->acts || !bt->valid_transition) return OPE_EINVAL;
+  if (!bt->obs || !bt->share_obs || (!bt->acts && !cfg->joint_acts) || !bt->valid_transition) return OPE_EINVAL;
+  if (cfg->joint_act_dim > 0 && !cfg->joint_acts) return OPE_EINVAL;
   DdpgPlan p;
   ddpg_plan(cfg, &p);
   if (workspace_bytes < p.ws.total * (int64_t)sizeof(float)) return OPE_ENOSPC;
@@ -803,7 +848,11 @@ extern "C" int ope_ddpg_actor_loss_and_grad(const ope_ddpg_cfg* cfg, const ope_m
     return rc;
   // N stacked copies of the joint action, copy i carrying the actor's action for agent i
   // (multi-policy: copy i of the joint action of ALL agents, block agent_offset + i replaced)
-  if ((rc = launch_build_cin(bt->share_obs, bt->acts, W + p.actout, 1, p.B, p.NT, p.A, p.S, p.N, W + p.xin_a, st, p.a0))) return rc;
+  if (p.hetero) {
+    if ((rc = launch_build_cin_joint(bt->share_obs, cfg->joint_acts, W + p.actout, 1, p.B, p.J, p.S, p.N, p.A, p.c0, W + p.xin_a, st))) return rc;
+  } else if ((rc = launch_build_cin(bt->share_obs, bt->acts, W + p.actout, 1, p.B, p.NT, p.A, p.S, p.N, W + p.xin_a, st, p.a0))) {
+    return rc;
+  }
   // critic (parameters frozen) on the stacked input; only head 0 enters the objective
   if ((rc = trunk_mlp(p, W, W + p.xin_a, p.Ra, p.Din, theta_critic, p.CL, W + p.a2c, true, nullptr, W + p.qc, p.K, st))) return rc;
   OPE_L(OPE_LAUNCH(actor_obj_kernel, dim3(launch1d(p.Ra)), dim3(256), 0, st, W + p.qc, p.K, bt->valid_transition, p.Ra,
@@ -811,7 +860,7 @@ extern "C" int ope_ddpg_actor_loss_and_grad(const ope_ddpg_cfg* cfg, const ope_m
   // critic backward down to its input, then through the gumbel-softmax into the actor logits
   if ((rc = mlp_backward(p, W, W + p.xin_a, p.Ra, p.Din, p.K, p.K, W + p.dq, theta_critic, p.CL, nullptr, p.ns_a, 0, nullptr, st))) return rc;
   ActGradArgs ag;
-  ag.R = p.Ra; ag.B = p.B; ag.N = p.N; ag.A = p.A; ag.A4 = p.A4; ag.S = p.S; ag.Din = p.Din; ag.a_off = p.a0; ag.dz1 = W + p.dz1;
+  ag.R = p.Ra; ag.B = p.B; ag.N = p.N; ag.A = p.A; ag.A4 = p.A4; ag.S = p.S; ag.Din = p.Din; ag.a_off = p.hetero ? 0 : p.a0; ag.a_col = p.hetero ? p.c0 : 0; ag.dz1 = W + p.dz1;
   ag.xhat1 = W + p.xhat1; ag.rstd1 = W + p.rstd1; ag.mu1 = W + p.mu1; ag.mu0 = W + p.mu0; ag.rstd0 = W + p.rstd0;
   ag.act = W + p.actout; ag.y = W + p.ysoft; ag.theta = theta_critic; ag.fc1_w = p.CL.fc1_w; ag.fc1_b = p.CL.fc1_b; ag.fn_w = p.CL.fn_w;
   ag.fn_b = p.CL.fn_b; ag.cvec = W + p.cvec; ag.dlogits = W + p.dlg; ag.identity = cfg->continuous ? 1 : 0; ag.heads = hd;

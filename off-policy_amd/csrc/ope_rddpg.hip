@@ -346,6 +346,8 @@ struct SaveSet {
 struct RPlan {
   int T, N, A, D, S, B, K, A4, Din, NB;
   int NT, a0;                   // agents in the joint action / first agent of this policy (multi-policy: N < NT)
+  int J, c0;                    // width of the joint action / first column of this policy's first agent in it
+  bool hetero;                  // joint action given as [T][B][J] (policies of different action dimensions: ope_rddpg_cfg.joint_act_dim)
   int64_t TB, Ra, Ra1;          // critic rows, actor rows (T steps), target-actor rows (T+1 steps)
   AgentLayout AL, CL;
   int raw_size, ns_c, ns_a;
@@ -365,6 +367,9 @@ static int rddpg_cfg_ok(const ope_rddpg_cfg* c) {
   if (d.state_dim + d.n_agents * d.act_dim > 1024 || d.episode_length < 1) return 0;
   if (c->n_total_agents != 0 && (c->n_total_agents < d.n_agents || c->agent_offset < 0 || c->agent_offset + d.n_agents > c->n_total_agents ||
                                  d.state_dim + c->n_total_agents * d.act_dim > 1024 || c->n_total_agents > 64)) return 0;
+  if (c->joint_act_dim != 0 && (c->n_total_agents != 0 || c->joint_act_col < 0 || c->joint_act_col + d.n_agents * d.act_dim > c->joint_act_dim ||
+                                d.state_dim + c->joint_act_dim > 1024 || c->actor_row_weight))
+    return 0;
   if (c->batch < 1 || c->num_q < 1 || c->num_q > 4) return 0;
   if ((int64_t)(d.episode_length + 1) * d.n_agents * c->batch > (int64_t)1 << 24) return 0;
   if ((c->continuous != 0 && c->continuous != 1) || (c->continuous && c->target_gumbel)) return 0;
@@ -378,7 +383,9 @@ static void rddpg_plan(const ope_rddpg_cfg* c, RPlan* p) {
   const ope_dims& d = c->dims;
   p->T = d.episode_length; p->N = d.n_agents; p->A = d.act_dim; p->D = d.obs_dim; p->S = d.state_dim; p->B = c->batch; p->K = c->num_q;
   p->NT = c->n_total_agents > 0 ? c->n_total_agents : p->N; p->a0 = c->n_total_agents > 0 ? c->agent_offset : 0;
-  p->A4 = ope_round4(p->A); p->Din = p->S + p->NT * p->A; p->NB = p->N * p->B;
+  p->hetero = c->joint_act_dim > 0;
+  p->J = p->hetero ? c->joint_act_dim : p->NT * p->A; p->c0 = p->hetero ? c->joint_act_col : p->a0 * p->A;
+  p->A4 = ope_round4(p->A); p->Din = p->S + p->J; p->NB = p->N * p->B;
   p->TB = (int64_t)p->T * p->B; p->Ra = (int64_t)p->T * p->NB; p->Ra1 = (int64_t)(p->T + 1) * p->NB;
   p->AL = ope_agent_layout(p->D, p->A, 0);
   p->CL = ope_agent_layout(p->Din, p->K, 0);
@@ -401,7 +408,7 @@ static void rddpg_plan(const ope_rddpg_cfg* c, RPlan* p) {
   p->gi_t = W.add("gi_t", Ra1 * 3 * OPE_H);      // target actor (T+1 steps); reused for the target critic (TB rows)
   p->h_t = W.add("h_t", Ra1 * OPE_H);
   p->lg_t = W.add("logits_n", Ra1 * p->A);
-  p->cnact = W.add("cent_nact", TB * p->NT * p->A);
+  p->cnact = W.add("cent_nact", TB * p->J);
   p->xin = W.add("xin", TB * p->Din); p->xin_n = W.add("xin_n", TB * p->Din);
   p->c_gi = W.add("tc_gi", TB * 3 * OPE_H); p->c_h = W.add("tc_h", TB * OPE_H);
   p->gi_n = W.add("gi_n", TB * 3 * OPE_H); p->h_n = W.add("h_n", TB * OPE_H);
@@ -417,7 +424,7 @@ static void rddpg_plan(const ope_rddpg_cfg* c, RPlan* p) {
   p->dz1 = W.add("dz1", Rc * OPE_H); p->dz2 = W.add("dz2", Rc * OPE_H);
   // actor update
   p->lga = W.add("logits", Ra * p->A); p->ysoft = W.add("y_soft", Ra * p->A); p->actout = W.add("act_out", Ra * p->A);
-  p->rep = trunk_rep_ok(p->Din, p->NT, p->A, p->N);
+  p->rep = !p->hetero && trunk_rep_ok(p->Din, p->NT, p->A, p->N);
   p->xin_a = W.add("xin_a", p->rep ? 4 : Ra * p->Din); p->h_b = W.add("h_branch", Ra * OPE_H);
   p->rep_u = W.add("rep_u", p->rep ? p->TB * OPE_H : 4); p->rep_s12 = W.add("rep_s12", p->rep ? 2 * p->TB : 4);
   p->rep_scratch = W.add("rep_scratch", p->rep ? (int64_t)OPE_H * p->NT * p->A + 2 * OPE_H : 4);
@@ -623,7 +630,8 @@ extern "C" int ope_rddpg_critic_loss_and_grad(const ope_rddpg_cfg* cfg, const op
   (void)hipGetLastError();
   if (!rddpg_cfg_ok(cfg) || !bt || (!theta_actor_tgt && !cfg->joint_next_acts) || !theta_critic || !theta_critic_tgt || !workspace || !grad)
     return OPE_EINVAL;
-  if ((!bt->obs && !cfg->joint_next_acts) || !bt->share_obs || !bt->acts || !bt->rewards || !bt->dones_env) return OPE_EINVAL;
+  if ((!bt->obs && !cfg->joint_next_acts) || !bt->share_obs || (!bt->acts && !cfg->joint_acts) || !bt->rewards || !bt->dones_env) return OPE_EINVAL;
+  if (cfg->joint_act_dim > 0 && (!cfg->joint_next_acts || !cfg->joint_acts)) return OPE_EINVAL;
   if (cfg->target_gumbel && !target_noise_u && !cfg->joint_next_acts) return OPE_EINVAL;
   if (cfg->use_per && !per_weights) return OPE_EINVAL;
   RPlan p;
@@ -646,8 +654,10 @@ extern "C" int ope_rddpg_critic_loss_and_grad(const ope_rddpg_cfg* cfg, const op
     nact = W + p.cnact;
   }
   // critic inputs: buffer sequence [cent_obs[t] | acts[t]] and branch rows [cent_obs[t+1] | target actions]
-  if ((rc = launch_build_cin(bt->share_obs, bt->acts, nullptr, p.T, p.B, p.NT, p.A, p.S, 1, W + p.xin, st))) return rc;
-  if ((rc = launch_build_cin(bt->share_obs + (int64_t)p.B * p.S, nact, nullptr, p.T, p.B, 1, p.NT * p.A, p.S, 1, W + p.xin_n, st)))
+  if ((rc = launch_build_cin(bt->share_obs, p.hetero ? cfg->joint_acts : bt->acts, nullptr, p.T, p.B, p.hetero ? 1 : p.NT, p.hetero ? p.J : p.A, p.S, 1,
+                             W + p.xin, st)))
+    return rc;
+  if ((rc = launch_build_cin(bt->share_obs + (int64_t)p.B * p.S, nact, nullptr, p.T, p.B, 1, p.J, p.S, 1, W + p.xin_n, st)))
     return rc;
   // live critic over the buffer sequence (saved for backward)
   if ((rc = rtrunk(W + p.xin, p.TB, p.Din, theta_critic, p.CL, W + p.SC.gi, W, &p.SC, st))) return rc;
@@ -687,7 +697,7 @@ extern "C" int ope_rddpg_target_actions(const ope_rddpg_cfg* cfg, const ope_fiel
   if ((rc = rscan(W + p.gi_t, p.NB, p.T + 1, theta_actor_tgt, p.AL, W + p.h_t, W, nullptr, st))) return rc;
   if ((rc = rhead(W + p.h_t, p.Ra1, p.A, theta_actor_tgt, p.AL, W + p.lg_t, W, nullptr, st))) return rc;
   return launch_action(W + p.lg_t, bt->avail_acts, NoiseSrc{target_noise_u, 0, nullptr, 0}, (int)p.Ra1, p.B, p.A, p.N, cfg->continuous ? 2 : (cfg->target_gumbel ? 1 : 0), 1,
-                       joint_next_acts, nullptr, nullptr, st, p.NT, p.a0, &hd);
+                       joint_next_acts, nullptr, nullptr, st, p.NT, p.a0, &hd, p.hetero ? p.J : 0, p.c0);
 }
 
 extern "C" int ope_rddpg_actor_loss_and_grad(const ope_rddpg_cfg* cfg, const ope_fields* bt, const float* theta_actor,
@@ -695,7 +705,8 @@ extern "C" int ope_rddpg_actor_loss_and_grad(const ope_rddpg_cfg* cfg, const ope
                                              int64_t workspace_bytes, float* grad, void* stream) {
   (void)hipGetLastError();
   if (!rddpg_cfg_ok(cfg) || !bt || !theta_actor || !theta_critic || (!cfg->continuous && !gumbel_noise_u) || !workspace || !grad) return OPE_EINVAL;
-  if (!bt->obs || !bt->share_obs || !bt->acts || !bt->dones) return OPE_EINVAL;
+  if (!bt->obs || !bt->share_obs || (!bt->acts && !cfg->joint_acts) || !bt->dones) return OPE_EINVAL;
+  if (cfg->joint_act_dim > 0 && !cfg->joint_acts) return OPE_EINVAL;
   RPlan p;
   rddpg_plan(cfg, &p);
   if (workspace_bytes < p.ws.total * (int64_t)sizeof(float)) return OPE_ENOSPC;
@@ -712,7 +723,9 @@ extern "C" int ope_rddpg_actor_loss_and_grad(const ope_rddpg_cfg* cfg, const ope
                           W + p.actout, W + p.ysoft, st, 0, 0, &hd)))
     return rc;
   // critic state along the buffer sequence (identical for the N stacked copies)
-  if ((rc = launch_build_cin(bt->share_obs, bt->acts, nullptr, p.T, p.B, p.NT, p.A, p.S, 1, W + p.xin, st))) return rc;
+  if ((rc = launch_build_cin(bt->share_obs, p.hetero ? cfg->joint_acts : bt->acts, nullptr, p.T, p.B, p.hetero ? 1 : p.NT, p.hetero ? p.J : p.A, p.S, 1,
+                             W + p.xin, st)))
+    return rc;
   if ((rc = rtrunk(W + p.xin, p.TB, p.Din, theta_critic, p.CL, W + p.c_gi, W, nullptr, st))) return rc;
   if ((rc = rscan(W + p.c_gi, p.B, p.T, theta_critic, p.CL, W + p.c_h, W, nullptr, st))) return rc;
   // sideways cell step on the spliced actions for all (t, agent copy, b) rows at once
@@ -730,7 +743,11 @@ extern "C" int ope_rddpg_actor_loss_and_grad(const ope_rddpg_cfg* cfg, const ope
     tr.rep.T = p.T; tr.rep.B = p.B; tr.rep.N = p.N; tr.rep.A = p.A; tr.rep.S = p.S; tr.rep.NT = p.NT; tr.rep.a0 = p.a0;
     if ((rc = launch_trunk_fwd_rep(tb0, tr, W + p.rep_scratch, st))) return rc;
   } else {
-    if ((rc = launch_build_cin(bt->share_obs, bt->acts, W + p.actout, p.T, p.B, p.NT, p.A, p.S, p.N, W + p.xin_a, st, p.a0))) return rc;
+    if (p.hetero) {
+      if ((rc = launch_build_cin_joint(bt->share_obs, cfg->joint_acts, W + p.actout, p.T, p.B, p.J, p.S, p.N, p.A, p.c0, W + p.xin_a, st))) return rc;
+    } else if ((rc = launch_build_cin(bt->share_obs, bt->acts, W + p.actout, p.T, p.B, p.NT, p.A, p.S, p.N, W + p.xin_a, st, p.a0))) {
+      return rc;
+    }
     if ((rc = rtrunk(W + p.xin_a, p.Ra, p.Din, theta_critic, p.CL, W + p.SC.gi, W, &p.SC, st))) return rc;
   }
   if ((rc = rcell(p, W + p.SC.gi, W + p.c_h, p.Ra, p.N, -1, theta_critic, p.CL, W + p.h_b, W, &p.SC, st))) return rc;
@@ -755,7 +772,7 @@ extern "C" int ope_rddpg_actor_loss_and_grad(const ope_rddpg_cfg* cfg, const ope
   tb.dz1 = W + p.dz1; tb.dz2 = W + p.dz2;
   if ((rc = launch_trunk_bwd(tb, st))) return rc;
   ActGradArgs ag;
-  ag.R = Ra; ag.B = p.B; ag.N = p.N; ag.A = p.A; ag.A4 = p.A4; ag.S = p.S; ag.Din = p.Din; ag.a_off = p.a0; ag.dz1 = W + p.dz1;
+  ag.R = Ra; ag.B = p.B; ag.N = p.N; ag.A = p.A; ag.A4 = p.A4; ag.S = p.S; ag.Din = p.Din; ag.a_off = p.hetero ? 0 : p.a0; ag.a_col = p.hetero ? p.c0 : 0; ag.dz1 = W + p.dz1;
   ag.xhat1 = W + p.SC.xhat1; ag.rstd1 = W + p.SC.rstd1; ag.mu1 = W + p.SC.mu1; ag.mu0 = W + p.SC.mu0; ag.rstd0 = W + p.SC.rstd0;
   ag.act = W + p.actout; ag.y = W + p.ysoft; ag.theta = theta_critic; ag.fc1_w = p.CL.fc1_w; ag.fc1_b = p.CL.fc1_b; ag.fn_w = p.CL.fn_w;
   ag.fn_b = p.CL.fn_b; ag.cvec = W + p.cvec; ag.dlogits = W + p.dlg; ag.identity = cfg->continuous ? 1 : 0; ag.heads = hd;

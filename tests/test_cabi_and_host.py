@@ -237,6 +237,42 @@ def test_action_space_kinds_of_the_maddpg_family_are_validated():
     assert cfg_bytes(continuous=2) == -1
 
 
+def test_struct_mirrors_match_the_compiled_library():
+    """ope_abi_sizeof: every ctypes mirror in offpolicy_amd._lib has the size the library was compiled with (also checked at import)."""
+    from offpolicy_amd import _lib
+    assert len(_lib.ABI_MIRRORS) == 11
+    for cname, cls in _lib.ABI_MIRRORS.items():
+        assert _lib.lib.ope_abi_sizeof(cname.encode()) == C.sizeof(cls), cname
+    assert _lib.lib.ope_abi_sizeof(b"ope_no_such_struct") == -1 and _lib.lib.ope_abi_sizeof(None) == -1
+
+
+def test_joint_action_of_policies_with_different_action_dimensions_is_validated():
+    """ope_rddpg_cfg.joint_act_dim / joint_act_col (round 4; simple_speaker_listener under scripts/train_mpe_rmaddpg.sh: a 3-action speaker and
+    a 5-action listener): the critic's first layer is S + joint_act_dim wide whatever the update policy's own act_dim, and the combinations
+    that make no sense are refused."""
+    from offpolicy_amd import _lib
+
+    def cfg(**kw):
+        c = _lib.RddpgCfg()
+        c.dims, c.batch, c.num_q = _lib.Dims(1, 3, 3, 14, 5), 4, 1       # the speaker: 1 agent, 3 actions, 3 observations, S = 14
+        for k, v in kw.items():
+            setattr(c, k, v)
+        return c
+
+    def critic_fc1_width(c):
+        offs, sizes = (C.c_int64 * 22)(), (C.c_int64 * 22)()
+        assert _lib.lib.ope_rddpg_param_layout(C.byref(c), 1, offs, sizes) > 0
+        return sizes[0]                                                  # feature_norm.weight: one entry per input column
+    assert critic_fc1_width(cfg()) == 14 + 3
+    assert critic_fc1_width(cfg(joint_act_dim=8, joint_act_col=0)) == 14 + 8
+    assert critic_fc1_width(cfg(joint_act_dim=8, joint_act_col=5)) == 14 + 8
+    assert _lib.lib.ope_rddpg_workspace_bytes(C.byref(cfg(joint_act_dim=8, joint_act_col=0))) > 0
+    assert _lib.lib.ope_rddpg_workspace_bytes(C.byref(cfg(joint_act_dim=8, joint_act_col=6))) == -1       # 6 + 1 * 3 > 8
+    assert _lib.lib.ope_rddpg_workspace_bytes(C.byref(cfg(joint_act_dim=8, joint_act_col=-1))) == -1
+    assert _lib.lib.ope_rddpg_workspace_bytes(C.byref(cfg(joint_act_dim=8, n_total_agents=2))) == -1      # columns OR equal agent blocks
+    assert _lib.lib.ope_rddpg_workspace_bytes(C.byref(cfg(joint_act_dim=2000))) == -1
+
+
 def test_null_arguments_are_rejected_without_a_gpu():
     from offpolicy_amd import _lib
     assert _lib.lib.ope_adam_step(None, 4, None, None, None, None, None, None, None, None) == -1

@@ -89,13 +89,14 @@ def test_policy_construction_reproduces_reference_rng_stream(name):
     assert not np.array_equal(g["heads/w"], g["heads_tgt/w"])          # A-4: live and target heads differ forever
 
 
-@pytest.mark.parametrize("name", ["maddpg_multi", "matd3_multi_per"])
+@pytest.mark.parametrize("name", ["maddpg_multi", "matd3_multi_per", "maddpg_multi_sl", "matd3_multi_actdims"])
 def test_multi_policy_train_steps_match_reference(name):
     """share_policy = False (oracle/make_golden_ddpg.py, OPE_GOLDEN_ONLY=multi): every policy updated in turn on its own batch with the
     joint action assembled from all policies (maddpg.py:40-80), soft updates after all of them (runner/mlp/base_runner.py:196-217)."""
     g = load_golden(name)
     groups, A, td3 = [int(x) for x in g["groups"]], int(g["A"]), bool(g["td3"])
     P = len(groups)
+    As = [int(x) for x in g["act_dims"]] if "act_dims" in g else [A] * P      # policies may differ in their number of actions (`*_sl`, `*_actdims`)
     hp = lambda: HP(gamma=float(g["hp_gamma"]), lr=float(g["hp_lr"]), opti_eps=float(g["hp_eps"]), use_huber_loss=bool(g["hp_huber"]),
                     huber_delta=float(g["hp_delta"]), use_per=bool(g["hp_per"]), per_eps=float(g["hp_per_eps"]), tau=float(g["hp_tau"]),
                     max_grad_norm=float(g["hp_maxnorm"]))
@@ -109,8 +110,8 @@ def test_multi_policy_train_steps_match_reference(name):
     for s in range(len(g["p0/critic_loss"])):
         for i in range(P):
             torch.manual_seed(1000 + 10 * s + i)         # the reference's draws: target noise per policy in policy order, then the actor's
-            u_ts = [torch.FloatTensor(groups[k] * B, A).uniform_() for k in range(P)] if td3 else None
-            u_a = torch.FloatTensor(groups[i] * B, A).uniform_()
+            u_ts = [torch.FloatTensor(groups[k] * B, As[k]).uniform_() for k in range(P)] if td3 else None
+            u_a = torch.FloatTensor(groups[i] * B, As[i]).uniform_()
             out = multi.train_step(i, batches, u_ts, u_a, weights=w)
             np.testing.assert_allclose(out["critic_loss"], g["p%d/critic_loss" % i][s], rtol=3e-5, err_msg="%d p%d" % (s, i))
             np.testing.assert_allclose(out["critic_grad_norm"], g["p%d/critic_grad_norm" % i][s], rtol=3e-5)

@@ -122,7 +122,7 @@ def test_several_policies_under_one_mixer_match_reference(name, mlp):
             np.testing.assert_allclose(src["mixer/" + k], ref, rtol=0, atol=3e-5, err_msg=grp + k)
 
 
-@pytest.mark.parametrize("name", ["maddpg_multi", "matd3_multi_per"])
+@pytest.mark.parametrize("name", ["maddpg_multi", "matd3_multi_per", "maddpg_multi_sl", "matd3_multi_actdims"])
 def test_mlp_maddpg_several_policies_match_reference(name):
     """MLP MADDPG / MATD3 with several policies (share_policy = False; get_update_info maddpg.py:40-80): every policy's own actor,
     critic and batch, the joint target action assembled from all target actors (ope_ddpg_target_actions per policy), each policy
@@ -141,8 +141,11 @@ def test_mlp_maddpg_several_policies_match_reference(name):
                         max_grad_norm=float(g["hp_maxnorm"]))
     dev = torch.device("cuda:0")
     pids = ["policy_%d" % i for i in range(len(groups))]
-    pinfo = {p: {"cent_obs_dim": S, "cent_act_dim": A * N, "obs_space": [d], "share_obs_space": [S], "act_space": Discrete(A)}
-             for p, d in zip(pids, dims_obs)}
+    # (`maddpg_multi_sl`, `matd3_multi_actdims`: the policies differ in their NUMBER OF ACTIONS too -- simple_speaker_listener's 3 and 5;
+    # the joint action is then described in columns, ope_ddpg_cfg.joint_act_dim)
+    As = [int(x) for x in g["act_dims"]] if "act_dims" in g else [A] * len(groups)
+    pinfo = {p: {"cent_obs_dim": S, "cent_act_dim": sum(a * m for a, m in zip(As, groups)), "obs_space": [d], "share_obs_space": [S],
+                 "act_space": Discrete(a)} for p, d, a in zip(pids, dims_obs, As)}
     owner, k = {}, 0
     for p, m in zip(pids, groups):
         for a in range(k, k + m):

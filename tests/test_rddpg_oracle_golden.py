@@ -94,7 +94,7 @@ def test_policy_construction_reproduces_reference_rng_stream(name):
         assert np.array_equal(ref, crit[k])
 
 
-MULTI_CASES = ["rmaddpg_multi_odd", "rmatd3_multi_tiny", "rmaddpg_multi_hetero", "rmatd3_multi_hetero"]
+MULTI_CASES = ["rmaddpg_multi_odd", "rmatd3_multi_tiny", "rmaddpg_multi_hetero", "rmatd3_multi_hetero", "rmaddpg_multi_sl", "rmatd3_multi_actdims"]
 
 
 def multi_policy_ids(g):
@@ -106,20 +106,27 @@ def multi_obs_dims(g):
     return [int(x) for x in g["obs_dims"]] if "obs_dims" in g else [int(g["dims"][2])] * len(g["groups"])
 
 
+def multi_act_dims(g):
+    """Number of actions of every policy (`act_dims`: fixtures whose policies differ in it -- simple_speaker_listener's 3 and 5)."""
+    return [int(x) for x in g["act_dims"]] if "act_dims" in g else [int(g["dims"][1])] * len(g["groups"])
+
+
 def multi_batches(g):
     """Per-policy sample_inds 7-tuples rebuilt from the stored episodes: agent fields sliced to the policy's agents."""
     groups = [int(x) for x in g["groups"]]
     starts = np.cumsum([0] + groups)[:-1]
     inds = np.asarray(g["inds"])
     N = int(g["dims"][0])
-    obs_dims = multi_obs_dims(g)
+    obs_dims, act_dims = multi_obs_dims(g), multi_act_dims(g)
     out = []
-    for s0, n, od in zip(starts, groups, obs_dims):
+    for s0, n, od, ad in zip(starts, groups, obs_dims, act_dims):
         fields = []
         for k in EP_KEYS:
             v = g["ep/" + k][:, inds]                                   # [T(+1), B, N, dim] or [T(+1), B, dim]
             if k == "obs":
                 v = v[..., :od]                                         # policies may differ in observation width
+            if k in ("acts", "avail_acts"):
+                v = v[..., :ad]                                         # ... and in their number of actions
             if v.ndim == 4 and v.shape[2] == N and k != "share_obs":
                 fields.append(np.ascontiguousarray(v[:, :, s0:s0 + n].transpose(2, 0, 1, 3)))
             elif k == "share_obs":
@@ -137,8 +144,9 @@ def multi_noise(g, step, pi, update_actor):
     groups = [int(x) for x in g["groups"]]
     B = len(g["inds"])
     torch.manual_seed(1000 + step * len(groups) + pi)
-    u_t = [torch.FloatTensor(T + 1, n * B, a).uniform_() for n in groups] if bool(g["td3"]) else None
-    u_a = torch.FloatTensor(T, groups[pi] * B, a).uniform_() if update_actor else None
+    ads = multi_act_dims(g)
+    u_t = [torch.FloatTensor(T + 1, n * B, ad).uniform_() for n, ad in zip(groups, ads)] if bool(g["td3"]) else None
+    u_a = torch.FloatTensor(T, groups[pi] * B, ads[pi]).uniform_() if update_actor else None
     return u_t, u_a
 
 
