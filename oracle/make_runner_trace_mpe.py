@@ -35,7 +35,15 @@ import offpolicy.algorithms.r_maddpg.r_maddpg as ref_trainer_mod  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden", "runner_trace_rmaddpg_multi.npz")
 N, A, D, T = 3, 5, 6, 5
-S = N * D          # the MPE runner's shared observation = all agents' observations concatenated (mpe_runner.py:163-164)
+AS, DS = [A] * N, [D] * N
+if os.environ.get("OPE_TRACE") == "sl":
+    # the shapes of MPE simple_speaker_listener, the scenario scripts/train_mpe_rmaddpg.sh names: agent 0 (speaker) sees 3 numbers and has 3
+    # actions, agent 1 (listener) sees 11 and has 5; PYTHONDONTWRITEBYTECODE=1 OPE_TRACE=sl python oracle/make_runner_trace_mpe.py
+    OUT = os.path.join(ROOT, "tests", "golden", "runner_trace_rmaddpg_sl.npz")
+    N, T = 2, 5
+    AS, DS = [3, 5], [3, 11]
+    A, D = max(AS), max(DS)
+S = sum(DS)        # the MPE runner's shared observation = all agents' observations concatenated (mpe_runner.py:163-164)
 PIDS = ["policy_%d" % i for i in range(N)]
 KEYS = ("obs", "share_obs", "acts", "rewards", "dones", "dones_env")
 LOG = []
@@ -76,7 +84,12 @@ class StubEnv(object):
         self.t = 0
 
     def _obs(self):
-        return self.rng.standard_normal((1, N, D)).astype(np.float32)
+        if len(set(DS)) == 1:
+            return self.rng.standard_normal((1, N, D)).astype(np.float32)
+        obs = np.empty((1, N), dtype=object)      # agents of different observation widths: an object array, as the MPE wrappers return
+        for i in range(N):
+            obs[0, i] = self.rng.standard_normal(DS[i]).astype(np.float32)
+        return obs
 
     def reset(self):
         self.t = 0
@@ -85,8 +98,7 @@ class StubEnv(object):
 
     def step(self, env_acts):
         self.t += 1
-        acts = np.asarray(env_acts[0])
-        r = float(acts.argmax(-1).sum()) * 0.1 + float(self.rng.standard_normal()) * 0.05
+        r = float(sum(int(np.argmax(a)) for a in env_acts[0])) * 0.1 + float(self.rng.standard_normal()) * 0.05
         rewards = np.full((1, N, 1), r, np.float32)
         dones = np.full((1, N), self.t >= self.end, dtype=bool)
         return self._obs(), rewards, dones, [[{} for _ in range(N)]]
@@ -173,7 +185,8 @@ def main():
                            "--share_policy", "--actor_train_interval_step", "1"],
                           scenario_name="stub", experiment_name="trace", use_wandb=False, use_eval=False, save_interval=10 ** 9, log_interval=10 ** 9)
     assert args.share_policy is False
-    pinfo = {p: {"cent_obs_dim": S, "cent_act_dim": A * N, "obs_space": [D], "share_obs_space": [S], "act_space": Discrete(A)} for p in PIDS}
+    pinfo = {p: {"cent_obs_dim": S, "cent_act_dim": sum(AS), "obs_space": [d], "share_obs_space": [S], "act_space": Discrete(a)}
+             for p, d, a in zip(PIDS, DS, AS)}
     torch.manual_seed(3)
     np.random.seed(3)
     with tempfile.TemporaryDirectory() as tmp:
@@ -190,6 +203,8 @@ def main():
         log_call("runner.final_state", {}, final)
     STORE["calls"] = np.array(LOG)
     STORE["dims"] = np.array([N, A, D, S, T])
+    if len(set(DS)) > 1 or len(set(AS)) > 1:
+        STORE["obs_dims"], STORE["act_dims"] = np.array(DS), np.array(AS)
     STORE["hp"] = np.array([args.batch_size, args.buffer_size, args.lr, args.epsilon_start, args.epsilon_finish, args.epsilon_anneal_time],
                            dtype=np.float64)
     np.savez_compressed(OUT, **STORE)

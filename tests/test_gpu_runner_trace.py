@@ -124,27 +124,33 @@ def test_reference_runner_call_trace_replays_on_the_engine():
     assert seen["policy.get_actions"] > 20 and seen["buffer.insert"] >= 8 and seen["trainer.train_policy_on_batch"] == 3
 
 
-def test_reference_mpe_runner_multi_policy_trace_replays_on_the_engine():
+@pytest.mark.parametrize("trace", ["runner_trace_rmaddpg_multi", "runner_trace_rmaddpg_sl"])
+def test_reference_mpe_runner_multi_policy_trace_replays_on_the_engine(trace):
     """The reference's MPERunner with ONE POLICY PER AGENT (share_policy = False, scripts/train_mpe_rmaddpg.sh), recorded by
     oracle/make_runner_trace_mpe.py (tests/golden/runner_trace_rmaddpg_multi.npz): three R_MADDPGPolicy constructions, the
     R_MADDPG trainer, warm-up through `separated_collect_rollout` (every agent queried through its own policy: random actions +
     a recurrent state update), three run() cycles (exploring rollout -> three-policy buffer.insert -> per policy buffer.sample ->
     shared_train_policy_on_batch -> soft updates of every policy) -- 203 calls, replayed against the engine's classes with the
-    recorded arguments and RNG states; every return value is compared, and at the end all 12 networks."""
+    recorded arguments and RNG states; every return value is compared, and at the end all 12 networks.
+    `runner_trace_rmaddpg_sl` (OPE_TRACE=sl): the same life cycle with the shapes of simple_speaker_listener, the scenario that script names --
+    two agents, 3 / 11 observations, 3 / 5 actions: policies that differ in observation AND action width (151 calls, 8 networks)."""
     from offpolicy_amd.config import default_args
     from offpolicy_amd.utils.spaces import Discrete
     from offpolicy_amd.utils.rec_buffer import RecReplayBuffer
     from offpolicy_amd.algorithms.r_maddpg.algorithm.rMADDPGPolicy import R_MADDPGPolicy
     from offpolicy_amd.algorithms.r_maddpg.r_maddpg import R_MADDPG
-    g = load_golden("runner_trace_rmaddpg_multi")
+    g = load_golden(trace)
     calls = [str(x) for x in g["calls"]]
     N, A, D, S, T = [int(x) for x in g["dims"]]
+    As = [int(x) for x in g["act_dims"]] if "act_dims" in g else [A] * N
+    Ds = [int(x) for x in g["obs_dims"]] if "obs_dims" in g else [D] * N
     batch_size, buffer_size, lr, eps0, eps1, eps_t = g["hp"]
     args = default_args(batch_size=int(batch_size), buffer_size=int(buffer_size), lr=float(lr), epsilon_start=float(eps0),
                         epsilon_finish=float(eps1), epsilon_anneal_time=float(eps_t), episode_length=T)
     dev = torch.device("cuda:0")
     pids = ["policy_%d" % i for i in range(N)]
-    pinfo = {p: {"cent_obs_dim": S, "cent_act_dim": A * N, "obs_space": [D], "share_obs_space": [S], "act_space": Discrete(A)} for p in pids}
+    pinfo = {p: {"cent_obs_dim": S, "cent_act_dim": sum(As), "obs_space": [d], "share_obs_space": [S], "act_space": Discrete(a)}
+             for p, d, a in zip(pids, Ds, As)}
     keys = ("obs", "share_obs", "acts", "rewards", "dones", "dones_env")
     policies, trainer, buf, last_sample = {}, None, None, None
     seen = {k: 0 for k in set(calls)}
@@ -164,7 +170,7 @@ def test_reference_mpe_runner_multi_policy_trace_replays_on_the_engine():
                     np.testing.assert_allclose(ours[k].cpu().numpy(), v, rtol=0, atol=3e-5, err_msg="%s %s %s" % (pid, grp, k))
                 mod.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
             pol.hard_target_updates()
-            assert pol.output_dim == A and pol.obs_dim == D and pol.central_obs_dim == S and pol.hidden_size == 64
+            assert pol.output_dim == As[pids.index(pid)] and pol.obs_dim == Ds[pids.index(pid)] and pol.central_obs_dim == S and pol.hidden_size == 64
             policies[pid] = pol
         elif name == "trainer.__init__":
             trainer = R_MADDPG(args, N, policies, lambda a: "policy_%d" % a, device=dev, episode_length=T)
@@ -224,7 +230,7 @@ def test_reference_mpe_runner_multi_policy_trace_replays_on_the_engine():
                         np.testing.assert_allclose(ours[k].cpu().numpy(), v, rtol=0, atol=1e-4, err_msg="%s %s %s" % (p, grp, k))
         else:
             raise AssertionError("unknown call in the trace: " + name)
-    assert seen["policy.get_actions"] > 60 and seen["buffer.insert"] >= 8 and seen["trainer.shared_train_policy_on_batch"] == 9
+    assert seen["policy.get_actions"] > 60 and seen["buffer.insert"] >= 8 and seen["trainer.shared_train_policy_on_batch"] == 3 * N
 
 
 def test_reference_mlp_runner_maddpg_trace_replays_on_the_engine():
