@@ -35,6 +35,17 @@ def gumbel_uniform_for(policy, rows):
     return sample_gumbel_uniform((rows, policy.output_dim))
 
 
+def target_noise_for(policy, rows):
+    """What policy.get_actions(use_target=True) draws for `rows` rows, on the generator the reference uses (MADDPGPolicy.py:73-116): nothing
+    without a target noise (MADDPG), the uniform block(s) of a hard gumbel-softmax for discrete / multi-discrete actions, additive gaussian
+    noise for continuous ones."""
+    if policy.target_noise is None:
+        return None
+    if policy.discrete:
+        return gumbel_uniform_for(policy, rows)
+    return gaussian_noise((rows, policy.output_dim), float(policy.target_noise))
+
+
 def onehot_from_logits(logits, avail=None):
     logits = logits.clone()
     if avail is not None:

@@ -20,7 +20,7 @@ import torch
 
 from ... import _lib
 from ... import dist as opdist
-from .algorithm.MADDPGPolicy import sample_gumbel_uniform, gumbel_uniform_for
+from .algorithm.MADDPGPolicy import sample_gumbel_uniform, gumbel_uniform_for, target_noise_for
 
 
 _OPT_TAIL_DEFAULT = os.environ.get("OPE_DDPG_OPT_TAIL", "0") == "1"
@@ -46,8 +46,6 @@ class MADDPG(object):
             flat_agents = [a for pid in self.policy_ids for a in self.policy_agents[pid]]
             if flat_agents != list(range(num_agents)) or any(len(self.policy_agents[pid]) == 0 for pid in self.policy_ids):
                 raise NotImplementedError("several policies: agents must be numbered policy by policy, every policy with at least one agent")
-            if any(self.policies[pid].multidiscrete or not self.policies[pid].discrete for pid in self.policy_ids):
-                raise NotImplementedError("several policies with continuous / multi-discrete action spaces are not on the accelerated path")
         # policies of different action dimensions (MPE simple_speaker_listener): the joint action is then described in columns
         # (ope_ddpg_cfg.joint_act_dim / joint_act_col / joint_acts) instead of equal agent blocks
         self.mixed_act_dims = len({self.policies[pid].output_dim for pid in self.policy_ids}) != 1
@@ -250,7 +248,8 @@ class MADDPG(object):
                 ws_q, _ = self._workspace(pol_q, cq)
                 mq = _lib.MlpBatch()
                 mq.next_obs, mq.next_avail_acts = _lib.ptr(no_q).value, _lib.ptr(nv_q).value
-                u_q = sample_gumbel_uniform((int(no_q.shape[0]) * B, pol_q.output_dim)).to(self.device) if pol_q.target_noise is not None else None
+                u_q = target_noise_for(pol_q, int(no_q.shape[0]) * B)      # per policy, in policy order: get_update_info's draws
+                u_q = None if u_q is None else u_q.to(self.device)
                 _lib.check(_lib.lib.ope_ddpg_target_actions(C.byref(cq), C.byref(mq), _lib.ptr(pol_q.target_actor._flat), _lib.ptr(u_q),
                                                             _lib.ptr(ws_q), ws_q.numel(), _lib.ptr(joint_next), _lib.current_stream()),
                            "ope_ddpg_target_actions")
@@ -296,11 +295,11 @@ class MADDPG(object):
         if not policy.discrete:
             # continuous actions (MADDPGPolicy.py:107-116): no gumbel anywhere; the target action carries additive gaussian noise when the
             # policy has a target noise (MATD3), drawn here on the CPU generator in the reference's order and shape (util.py:217-218)
-            assert not self.device_noise and not self.multi_policy, "continuous actions: host noise, one shared policy"
+            assert not self.device_noise, "continuous actions: host noise"
             from .algorithm.MADDPGPolicy import gaussian_noise
             draw = lambda shape: None
         u_t = draw((N * B, policy.output_dim)) if (policy.target_noise is not None and not self.multi_policy) else None
-        if not policy.discrete and policy.target_noise is not None:
+        if not policy.discrete and policy.target_noise is not None and not self.multi_policy:
             u_t = gaussian_noise((N * B, policy.output_dim), float(policy.target_noise)).to(self.device)
         dev_prio = torch.is_tensor(importance_weights)
         w = None

@@ -57,8 +57,6 @@ class R_MADDPG(object):
             self.joint_act_col[pid] = col
             col += len(self.policy_agents[pid]) * self.policies[pid].output_dim
         self.joint_act_dim = col
-        if self.multi_policy and any(self.policies[pid].multidiscrete for pid in self.policy_ids):
-            raise NotImplementedError("multi-discrete action spaces with several policies are not on the accelerated path")
         self.actor_update_interval = actor_update_interval
         self.num_updates = {p_id: 0 for p_id in self.policy_ids}
         self.use_same_share_obs = args.use_same_share_obs
@@ -207,11 +205,19 @@ class R_MADDPG(object):
         A = policy.output_dim
         cfg = policy.rddpg_cfg(B, T)
         draw = (lambda shape: torch.rand(shape, **self.tpdv)) if self.device_noise else (lambda shape: sample_gumbel_uniform(shape).to(self.device))
-        if policy.multidiscrete:
-            # one uniform block per sub-action, in order, side by side: the draws of rMADDPGPolicy.py:84-91 (a gumbel_softmax per head)
-            assert others is None and not self.device_noise, "multi-discrete actions: one shared policy, host noise"
-            heads = [int(x) for x in policy.act_dim]
-            draw = lambda shape: torch.cat([sample_gumbel_uniform(shape[:-1] + (k,)) for k in heads], dim=-1).to(self.device).contiguous()
+
+        def noise_for(pol, L, rows, target):
+            """What pol.get_actions draws for L steps of `rows` rows (rMADDPGPolicy.py:81-129), on the generator the reference uses: a
+            multi-discrete policy one uniform block per sub-action in order (a gumbel_softmax per head), a continuous one gaussian noise on its
+            TARGET actions only, a discrete one one uniform block."""
+            if not pol.discrete:
+                from ..maddpg.algorithm.MADDPGPolicy import gaussian_noise
+                assert not self.device_noise, "continuous actions: host noise"
+                return gaussian_noise((L, rows, pol.output_dim), float(pol.target_noise)).to(self.device) if (target and pol.target_noise is not None) else None
+            if pol.multidiscrete:
+                assert not self.device_noise, "multi-discrete actions: host noise"
+                return torch.cat([sample_gumbel_uniform((L, rows, int(k))) for k in pol.act_dim], dim=-1).to(self.device).contiguous()
+            return draw((L, rows, pol.output_dim))
         st = _lib.current_stream()
         joint_next = keep = None
         if others is not None:
@@ -230,7 +236,7 @@ class R_MADDPG(object):
                 ws_q, _ = self._workspace(pol_q, cq)
                 fq = _lib.Fields()
                 fq.obs, fq.avail_acts = _lib.ptr(o_q).value, _lib.ptr(v_q).value
-                u_q = draw((T + 1, o_q.shape[1] * B, pol_q.output_dim)) if pol_q.target_noise is not None else None
+                u_q = noise_for(pol_q, T + 1, o_q.shape[1] * B, True) if pol_q.target_noise is not None else None
                 _lib.check(_lib.lib.ope_rddpg_target_actions(C.byref(cq), C.byref(fq), _lib.ptr(pol_q.target_actor._flat), _lib.ptr(u_q),
                                                              _lib.ptr(ws_q), ws_q.numel(), _lib.ptr(joint_next), st), "ope_rddpg_target_actions")
                 keep.append((u_q, o_q, v_q))
@@ -262,13 +268,11 @@ class R_MADDPG(object):
         elif override is not None:
             u_t = None if override[0] is None else override[0].to(self.device, dtype=torch.float32).contiguous()
         else:
-            u_t = draw((T + 1, N * B, A)) if (policy.target_noise is not None and policy.discrete) else None
+            # (continuous actions, rMADDPGPolicy.py:121-129: additive gaussian noise on the target action when the policy has a target noise
+            #  -- R_MATD3 --, drawn on the CPU generator in the reference's order and shape; nothing is drawn for the actor update)
+            u_t = noise_for(policy, T + 1, N * B, True) if policy.target_noise is not None else None
         if not policy.discrete:
-            # continuous actions (rMADDPGPolicy.py:121-129): the target action carries additive gaussian noise when the policy has a target
-            # noise (R_MATD3), drawn on the CPU generator in the reference's order and shape; nothing is drawn for the actor update
-            assert others is None and override is None and not self.device_noise, "continuous actions: one shared policy, one process, host noise"
-            from ..maddpg.algorithm.MADDPGPolicy import gaussian_noise
-            u_t = gaussian_noise((T + 1, N * B, A), float(policy.target_noise)).to(self.device) if policy.target_noise is not None else None
+            assert override is None, "continuous actions: one process"
         dev_prio = torch.is_tensor(importance_weights)     # device trees: weights in, priorities out stay in HBM
         w = None
         if self.use_per:
@@ -301,7 +305,7 @@ class R_MADDPG(object):
         u_a = None
         if update_actor:
             if policy.discrete:
-                u_a = override[1].to(self.device, dtype=torch.float32).contiguous() if override is not None else draw((T, N * B, A))
+                u_a = override[1].to(self.device, dtype=torch.float32).contiguous() if override is not None else noise_for(policy, T, N * B, False)
                 assert u_a.shape == (T, N * B, A)
             _lib.check(_lib.lib.ope_rddpg_actor_loss_and_grad(C.byref(cfg), C.byref(f), _lib.ptr(policy.actor._flat),
                                                               _lib.ptr(policy.critic._flat), _lib.ptr(u_a), _lib.ptr(ws), ws.numel(),

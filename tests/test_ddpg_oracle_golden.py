@@ -89,7 +89,16 @@ def test_policy_construction_reproduces_reference_rng_stream(name):
     assert not np.array_equal(g["heads/w"], g["heads_tgt/w"])          # A-4: live and target heads differ forever
 
 
-@pytest.mark.parametrize("name", ["maddpg_multi", "matd3_multi_per", "maddpg_multi_sl", "matd3_multi_actdims"])
+def mlp_multi_kinds(g):
+    """Action-space kind of every policy: None (Discrete), ("md", sub-action sizes) or "cont" (`*_multi_kinds`, `*_multi_md` fixtures)."""
+    P = len(g["groups"])
+    if "kind_cont" not in g:
+        return [None] * P
+    return ["cont" if int(g["kind_cont"][i]) else (("md", [int(x) for x in g["kind_heads/%d" % i]]) if "kind_heads/%d" % i in g else None)
+            for i in range(P)]
+
+
+@pytest.mark.parametrize("name", ["maddpg_multi", "matd3_multi_per", "maddpg_multi_sl", "matd3_multi_actdims", "matd3_multi_kinds", "maddpg_multi_md"])
 def test_multi_policy_train_steps_match_reference(name):
     """share_policy = False (oracle/make_golden_ddpg.py, OPE_GOLDEN_ONLY=multi): every policy updated in turn on its own batch with the
     joint action assembled from all policies (maddpg.py:40-80), soft updates after all of them (runner/mlp/base_runner.py:196-217)."""
@@ -97,12 +106,22 @@ def test_multi_policy_train_steps_match_reference(name):
     groups, A, td3 = [int(x) for x in g["groups"]], int(g["A"]), bool(g["td3"])
     P = len(groups)
     As = [int(x) for x in g["act_dims"]] if "act_dims" in g else [A] * P      # policies may differ in their number of actions (`*_sl`, `*_actdims`)
+    kinds = mlp_multi_kinds(g)                                                # ... and in the kind of their action space (`*_kinds`, `*_md`)
+
+    def draw(k, target):      # what policy k's get_actions draws: gaussian (continuous targets), one uniform block per head, or one block
+        rows = groups[k] * B
+        if kinds[k] == "cont":
+            return torch.empty(rows, As[k]).normal_(mean=0, std=0.2) if target else None
+        if kinds[k] is not None:
+            return torch.cat([torch.FloatTensor(rows, a).uniform_() for a in kinds[k][1]], dim=-1)
+        return torch.FloatTensor(rows, As[k]).uniform_()
     hp = lambda: HP(gamma=float(g["hp_gamma"]), lr=float(g["hp_lr"]), opti_eps=float(g["hp_eps"]), use_huber_loss=bool(g["hp_huber"]),
                     huber_delta=float(g["hp_delta"]), use_per=bool(g["hp_per"]), per_eps=float(g["hp_per_eps"]), tau=float(g["hp_tau"]),
                     max_grad_norm=float(g["hp_maxnorm"]))
     pols = [DO.MaddpgOracle(sub(g, "p%d/actor/" % i), sub(g, "p%d/critic/" % i), (g["p%d/heads/w" % i], g["p%d/heads/b" % i]),
                             sub(g, "p%d/actor_tgt/" % i), sub(g, "p%d/critic_tgt/" % i), (g["p%d/heads_tgt/w" % i], g["p%d/heads_tgt/b" % i]),
-                            groups[i], hp(), td3=td3) for i in range(P)]
+                            groups[i], hp(), td3=td3, continuous=kinds[i] == "cont", head_dims=kinds[i][1] if isinstance(kinds[i], tuple) else None)
+            for i in range(P)]
     multi = DO.MaddpgMultiOracle(pols)
     batches = [tuple(g["p%d/batch/%s" % (i, k)] for k in T_KEYS) for i in range(P)]
     B = len(g["inds"])
@@ -110,8 +129,8 @@ def test_multi_policy_train_steps_match_reference(name):
     for s in range(len(g["p0/critic_loss"])):
         for i in range(P):
             torch.manual_seed(1000 + 10 * s + i)         # the reference's draws: target noise per policy in policy order, then the actor's
-            u_ts = [torch.FloatTensor(groups[k] * B, As[k]).uniform_() for k in range(P)] if td3 else None
-            u_a = torch.FloatTensor(groups[i] * B, As[i]).uniform_()
+            u_ts = [draw(k, True) for k in range(P)] if td3 else None
+            u_a = draw(i, False)
             out = multi.train_step(i, batches, u_ts, u_a, weights=w)
             np.testing.assert_allclose(out["critic_loss"], g["p%d/critic_loss" % i][s], rtol=3e-5, err_msg="%d p%d" % (s, i))
             np.testing.assert_allclose(out["critic_grad_norm"], g["p%d/critic_grad_norm" % i][s], rtol=3e-5)

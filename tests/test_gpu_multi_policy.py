@@ -122,13 +122,14 @@ def test_several_policies_under_one_mixer_match_reference(name, mlp):
             np.testing.assert_allclose(src["mixer/" + k], ref, rtol=0, atol=3e-5, err_msg=grp + k)
 
 
-@pytest.mark.parametrize("name", ["maddpg_multi", "matd3_multi_per", "maddpg_multi_sl", "matd3_multi_actdims"])
+@pytest.mark.parametrize("name", ["maddpg_multi", "matd3_multi_per", "maddpg_multi_sl", "matd3_multi_actdims", "matd3_multi_kinds", "maddpg_multi_md"])
 def test_mlp_maddpg_several_policies_match_reference(name):
     """MLP MADDPG / MATD3 with several policies (share_policy = False; get_update_info maddpg.py:40-80): every policy's own actor,
     critic and batch, the joint target action assembled from all target actors (ope_ddpg_target_actions per policy), each policy
     updated in turn as runner/mlp/base_runner.py:196-217 does -- fixtures from oracle/make_golden_ddpg.py (OPE_GOLDEN_ONLY=multi)."""
     from offpolicy_amd.config import default_args
-    from offpolicy_amd.utils.spaces import Discrete
+    from offpolicy_amd.utils.spaces import Discrete, Box, MultiDiscrete
+    from test_ddpg_oracle_golden import mlp_multi_kinds
     from offpolicy_amd.algorithms.maddpg.algorithm.MADDPGPolicy import MADDPGPolicy
     from offpolicy_amd.algorithms.matd3.algorithm.MATD3Policy import MATD3Policy
     from offpolicy_amd.algorithms.maddpg.maddpg import MADDPG
@@ -144,8 +145,11 @@ def test_mlp_maddpg_several_policies_match_reference(name):
     # (`maddpg_multi_sl`, `matd3_multi_actdims`: the policies differ in their NUMBER OF ACTIONS too -- simple_speaker_listener's 3 and 5;
     # the joint action is then described in columns, ope_ddpg_cfg.joint_act_dim)
     As = [int(x) for x in g["act_dims"]] if "act_dims" in g else [A] * len(groups)
+    # (`matd3_multi_kinds`, `maddpg_multi_md`: policies of different action-space KINDS -- discrete, multi-discrete, continuous -- under one trainer)
+    space_of = lambda a, kd: (Discrete(a) if kd is None else Box(low=-np.ones(a, np.float32), high=np.ones(a, np.float32)) if kd == "cont"
+                              else MultiDiscrete([[0, k - 1] for k in kd[1]]))
     pinfo = {p: {"cent_obs_dim": S, "cent_act_dim": sum(a * m for a, m in zip(As, groups)), "obs_space": [d], "share_obs_space": [S],
-                 "act_space": Discrete(a)} for p, d, a in zip(pids, dims_obs, As)}
+                 "act_space": space_of(a, kd)} for p, d, a, kd in zip(pids, dims_obs, As, mlp_multi_kinds(g))}
     owner, k = {}, 0
     for p, m in zip(pids, groups):
         for a in range(k, k + m):

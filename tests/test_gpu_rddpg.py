@@ -363,15 +363,15 @@ def test_materialised_actor_input_path_matches_reference_fixtures():
 
 
 @pytest.mark.parametrize("name", ["rmaddpg_multi_odd", "rmatd3_multi_tiny", "rmaddpg_multi_hetero", "rmatd3_multi_hetero", "rmaddpg_multi_sl",
-                                  "rmatd3_multi_actdims"])
+                                  "rmatd3_multi_actdims", "rmatd3_multi_kinds", "rmaddpg_multi_md"])
 def test_multi_policy_updates_match_reference(name):
     """share_policy = False (scripts/train_mpe_rmaddpg.sh): one policy -- own actor, critic, targets, optimisers, buffer -- per
     group of agents; per step every policy is updated in turn, as the runner does. Fixtures from the real reference with groups
     [[0, 1], [2]] (MADDPG: a two-agent policy at offset 0, a one-agent policy at offset 2) and [[0], [1], [2]] (MATD3: target
     noise drawn per policy in get_update_info's order, actor updated every second call). Losses, gradient norms and the final
     parameters of all 4 networks of every policy."""
-    from test_rddpg_oracle_golden import multi_policy_ids, multi_obs_dims, multi_act_dims
-    from offpolicy_amd.utils.spaces import Discrete
+    from test_rddpg_oracle_golden import multi_policy_ids, multi_obs_dims, multi_act_dims, multi_kinds
+    from offpolicy_amd.utils.spaces import Discrete, Box, MultiDiscrete
     from offpolicy_amd.config import default_args
     from offpolicy_amd.utils.synth import policy_info_for
     from offpolicy_amd.utils.rec_buffer import RecReplayBuffer
@@ -399,8 +399,12 @@ def test_multi_policy_updates_match_reference(name):
     # 5-action listener under scripts/train_mpe_rmaddpg.sh -- the joint action is described in columns, ope_rddpg_cfg.joint_act_dim)
     act_dims = multi_act_dims(g)
     cent_act = sum(ad * len(gr) for ad, gr in zip(act_dims, groups))
-    pinfo = {p: dict(policy_info_for(dims)["policy_0"], obs_space=[od], act_space=Discrete(ad), cent_act_dim=cent_act)
-             for p, od, ad in zip(pids, multi_obs_dims(g), act_dims)}
+    # (`rmatd3_multi_kinds`, `rmaddpg_multi_md`: policies of different action-space KINDS -- discrete, multi-discrete, continuous -- under one trainer)
+    kinds = multi_kinds(g)
+    space_of = lambda ad, kd: (Discrete(ad) if kd is None else Box(low=-np.ones(ad, np.float32), high=np.ones(ad, np.float32)) if kd == "cont"
+                               else MultiDiscrete([[0, k - 1] for k in kd[1]]))
+    pinfo = {p: dict(policy_info_for(dims)["policy_0"], obs_space=[od], act_space=space_of(ad, kd), cent_act_dim=cent_act)
+             for p, od, ad, kd in zip(pids, multi_obs_dims(g), act_dims, kinds)}
     dev = torch.device("cuda:0")
     torch.manual_seed(1)
     np.random.seed(1)
@@ -419,6 +423,9 @@ def test_multi_policy_updates_match_reference(name):
     per_pol["obs"] = {p: np.ascontiguousarray(per_pol["obs"][p][..., :od]) for p, od in zip(pids, multi_obs_dims(g))}
     for k in ("acts", "avail_acts"):
         per_pol[k] = {p: np.ascontiguousarray(per_pol[k][p][..., :ad]) for p, ad in zip(pids, act_dims)}
+    for i, p in enumerate(pids):
+        if "pol_acts/%d" % i in g:
+            per_pol["acts"][p] = g["pol_acts/%d" % i]
     r = buf.insert(len(g["idx_range"]), *[per_pol[k] for k in EP_KEYS])
     assert np.array_equal(r, g["idx_range"])
     sampled = {p: buf.policy_buffers[p].sample_inds(g["inds"]) for p in pids}

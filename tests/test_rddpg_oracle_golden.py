@@ -94,7 +94,8 @@ def test_policy_construction_reproduces_reference_rng_stream(name):
         assert np.array_equal(ref, crit[k])
 
 
-MULTI_CASES = ["rmaddpg_multi_odd", "rmatd3_multi_tiny", "rmaddpg_multi_hetero", "rmatd3_multi_hetero", "rmaddpg_multi_sl", "rmatd3_multi_actdims"]
+MULTI_CASES = ["rmaddpg_multi_odd", "rmatd3_multi_tiny", "rmaddpg_multi_hetero", "rmatd3_multi_hetero", "rmaddpg_multi_sl", "rmatd3_multi_actdims",
+               "rmatd3_multi_kinds", "rmaddpg_multi_md"]
 
 
 def multi_policy_ids(g):
@@ -111,6 +112,15 @@ def multi_act_dims(g):
     return [int(x) for x in g["act_dims"]] if "act_dims" in g else [int(g["dims"][1])] * len(g["groups"])
 
 
+def multi_kinds(g):
+    """Action-space kind of every policy: None (Discrete), ("md", sub-action sizes) or "cont" (`*_multi_kinds`, `*_multi_md` fixtures)."""
+    P = len(g["groups"])
+    if "kind_cont" not in g:
+        return [None] * P
+    return ["cont" if int(g["kind_cont"][i]) else (("md", [int(x) for x in g["kind_heads/%d" % i]]) if "kind_heads/%d" % i in g else None)
+            for i in range(P)]
+
+
 def multi_batches(g):
     """Per-policy sample_inds 7-tuples rebuilt from the stored episodes: agent fields sliced to the policy's agents."""
     groups = [int(x) for x in g["groups"]]
@@ -119,10 +129,13 @@ def multi_batches(g):
     N = int(g["dims"][0])
     obs_dims, act_dims = multi_obs_dims(g), multi_act_dims(g)
     out = []
-    for s0, n, od, ad in zip(starts, groups, obs_dims, act_dims):
+    for pi, (s0, n, od, ad) in enumerate(zip(starts, groups, obs_dims, act_dims)):
         fields = []
         for k in EP_KEYS:
             v = g["ep/" + k][:, inds]                                   # [T(+1), B, N, dim] or [T(+1), B, dim]
+            if k == "acts" and "pol_acts/%d" % pi in g:                 # multi-discrete / continuous policies: their own stored actions
+                fields.append(np.ascontiguousarray(g["pol_acts/%d" % pi][:, inds].transpose(2, 0, 1, 3)))
+                continue
             if k == "obs":
                 v = v[..., :od]                                         # policies may differ in observation width
             if k in ("acts", "avail_acts"):
@@ -144,9 +157,16 @@ def multi_noise(g, step, pi, update_actor):
     groups = [int(x) for x in g["groups"]]
     B = len(g["inds"])
     torch.manual_seed(1000 + step * len(groups) + pi)
-    ads = multi_act_dims(g)
-    u_t = [torch.FloatTensor(T + 1, n * B, ad).uniform_() for n, ad in zip(groups, ads)] if bool(g["td3"]) else None
-    u_a = torch.FloatTensor(T, groups[pi] * B, ads[pi]).uniform_() if update_actor else None
+    ads, kinds = multi_act_dims(g), multi_kinds(g)
+
+    def draw(L, n, ad, kind, target):      # what that policy's get_actions draws: gaussian (continuous targets), one uniform block per head, or one block
+        if kind == "cont":
+            return torch.empty(L, n * B, ad).normal_(mean=0, std=0.2) if target else None
+        if kind is not None:
+            return torch.cat([torch.FloatTensor(L, n * B, k).uniform_() for k in kind[1]], dim=-1)
+        return torch.FloatTensor(L, n * B, ad).uniform_()
+    u_t = [draw(T + 1, n, ad, kd, True) for n, ad, kd in zip(groups, ads, kinds)] if bool(g["td3"]) else None
+    u_a = draw(T, groups[pi], ads[pi], kinds[pi], False) if update_actor else None
     return u_t, u_a
 
 
@@ -155,7 +175,8 @@ def multi_oracle_from(g):
             huber_delta=float(g["hp_delta"]), use_per=bool(g["hp_per"]), per_nu=float(g["hp_nu"]), per_eps=float(g["hp_per_eps"]),
             tau=float(g["hp_tau"]), max_grad_norm=float(g["hp_maxnorm"]))
     pol = [RO.RMaddpgOracle(sub(g, p + "/actor/"), sub(g, p + "/critic/"), sub(g, p + "/actor_tgt/"), sub(g, p + "/critic_tgt/"), int(n), hp,
-                            td3=bool(g["td3"])) for p, n in zip(multi_policy_ids(g), g["groups"])]
+                            td3=bool(g["td3"]), continuous=kd == "cont", head_dims=kd[1] if isinstance(kd, tuple) else None)
+           for p, n, kd in zip(multi_policy_ids(g), g["groups"], multi_kinds(g))]
     return RO.RMaddpgMultiOracle(pol)
 
 
