@@ -121,8 +121,9 @@ class R_MADDPG(object):
             raise NotImplementedError("cent_train_policy_on_batch with use_value_active_masks: upstream weights the critic loss by the agents' "
                                       "active masks there (r_maddpg.py:418-498); the accelerated path takes the plain masked mean")
         policy = self.policies[pid]
-        if policy.multidiscrete:
-            raise NotImplementedError("cent_train_policy_on_batch with a multi-discrete action space is not on the accelerated path")
+        if policy.multidiscrete or not policy.discrete:
+            raise NotImplementedError("cent_train_policy_on_batch with a continuous / multi-discrete action space is not on the accelerated path "
+                                      "(no reference fixture pins it)")
         obs = self._to_device_layout(obs_b[pid], True)                      # [T+1, N, B, D]
         cent = self._to_device_layout(cent_b[pid], True)                    # [T+1, N, B, S]
         acts = self._to_device_layout(act_b[pid], True)
