@@ -89,8 +89,8 @@ __global__ void __launch_bounds__(256, 3) wgrad_kernel(WgTable tb, float* __rest
       const int64_t sr = (int64_t)eps[b] * tb.ref.TTN + (ref_tn0 + tn);
       brow = ref_on ? sr : brow;
     }
-    const float* ar = Ap + (int64_t)kc * lda;
-    const float* br = Bp + brow * ldb;
+    const float* ar = Ap + (int64_t)((tb.exp & 1) ? (kc & 63) : kc) * lda;
+    const float* br = Bp + ((tb.exp & 2) ? (brow & 63) : brow) * ldb;
     if (VEC == 4) {
       r.a = *reinterpret_cast<const f32x4*>(ar + moff);
       r.b = *reinterpret_cast<const f32x4*>(br + noff);
@@ -259,15 +259,28 @@ int launch_wgrad(const WgTable& tb, float* raw, hipStream_t st) {
   }
   bool lazy = false;
   for (int q = 0; q < tb.n; ++q) lazy = lazy || tb.p[q].ref_row1 > 0;
+  // where does the time go -- the matrix pipe or the operand traffic? OPE_WGRAD_EXP serves the A (bit 0) and / or B (bit 1) rows from a 64-row
+  // window, i.e. from the caches. The results are WRONG: honoured only while the in-process kernel timer is on (bench.py's per-kernel table),
+  // never for a plain training call, and announced on stderr.
+  static const int exp_env = getenv("OPE_WGRAD_EXP") ? atoi(getenv("OPE_WGRAD_EXP")) : 0;
+  WgTable tbx;
+  const WgTable* use = &tb;
+  if (exp_env && g_kprof_on && !lazy) {
+    static bool warned = false;
+    if (!warned) { fprintf(stderr, "libope: OPE_WGRAD_EXP=%d -- wgrad reads its operands from a 64-row window: TIMING ONLY, gradients are wrong\n", exp_env); warned = true; }
+    tbx = tb;
+    tbx.exp = exp_env & 3;
+    use = &tbx;
+  }
   if (lazy && vec != 4) return OPE_EINVAL;       // rows in the store are read as 16-byte pieces (ope_qmix_obs_ref_ok tells the caller beforehand)
   if (lazy)
-    OPE_LAUNCH((wgrad_kernel<4, true>), dim3(ope_cdiv(tb.total_waves, 4)), dim3(256), 0, st, tb, raw);
+    OPE_LAUNCH((wgrad_kernel<4, true>), dim3(ope_cdiv(tb.total_waves, 4)), dim3(256), 0, st, *use, raw);
   else if (vec == 4)
-    OPE_LAUNCH((wgrad_kernel<4, false>), dim3(ope_cdiv(tb.total_waves, 4)), dim3(256), 0, st, tb, raw);
+    OPE_LAUNCH((wgrad_kernel<4, false>), dim3(ope_cdiv(tb.total_waves, 4)), dim3(256), 0, st, *use, raw);
   else if (vec == 2)
-    OPE_LAUNCH((wgrad_kernel<2, false>), dim3(ope_cdiv(tb.total_waves, 4)), dim3(256), 0, st, tb, raw);
+    OPE_LAUNCH((wgrad_kernel<2, false>), dim3(ope_cdiv(tb.total_waves, 4)), dim3(256), 0, st, *use, raw);
   else
-    OPE_LAUNCH((wgrad_kernel<1, false>), dim3(ope_cdiv(tb.total_waves, 4)), dim3(256), 0, st, tb, raw);
+    OPE_LAUNCH((wgrad_kernel<1, false>), dim3(ope_cdiv(tb.total_waves, 4)), dim3(256), 0, st, *use, raw);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   note_launch(lazy ? "wgrad_store" : "wgrad", vec);
   return OPE_OK;
