@@ -26,7 +26,10 @@ namespace ope {
 // problems of the launch only pay ~10 VALU instructions per fetch. (Walking K episode-major instead -- four contiguous rows of one
 // episode per fetch -- was measured: no faster, 65.8 vs 64.3 us at 3s5z; what the row-reading launch loses against the gathered one,
 // 58.6 us, is where the rows come from: the gather's freshly written batch sits in the 256 MB Infinity Cache, the store's rows do not.)
-template <int VEC, bool LAZY>
+// EXP (timing experiments, OPE_WGRAD_EXP, results wrong): 4 = the MFMAs are left out (operands kept alive), 16 = the VALU work beside them is
+// (masks, LayerNorm-on-load, column sums), 4 + 8 = also without the two per-row scalar loads, 4 + 32 = no K loop at all (the launch's ramp), 4 + 8 + 64 = only the A operand is loaded:
+// what each part of the kernel costs on its own. EXP = 0 is the kernel.
+template <int VEC, bool LAZY, int EXP = 0>
 __global__ void __launch_bounds__(256, 3) wgrad_kernel(WgTable tb, float* __restrict__ raw) {
   __shared__ __attribute__((aligned(16))) float red[2][17][64][4];   // two partial-tile slots: [quad][lane][4]
   __shared__ int eps[LAZY ? kObsRefMaxB : 1];
@@ -93,7 +96,8 @@ __global__ void __launch_bounds__(256, 3) wgrad_kernel(WgTable tb, float* __rest
     const float* br = Bp + ((tb.exp & 2) ? (brow & 63) : brow) * ldb;
     if (VEC == 4) {
       r.a = *reinterpret_cast<const f32x4*>(ar + moff);
-      r.b = *reinterpret_cast<const f32x4*>(br + noff);
+      if (EXP & 64) r.b = f32x4{1.f, 1.f, 1.f, 1.f};      // (experiment: half the operand bytes through the vector-memory path)
+      else r.b = *reinterpret_cast<const f32x4*>(br + noff);
     } else if (VEC == 2) {
       const f32x2 a0 = *reinterpret_cast<const f32x2*>(ar + moff), a1 = *reinterpret_cast<const f32x2*>(ar + moff1);
       const f32x2 b0 = *reinterpret_cast<const f32x2*>(br + noff), b1 = *reinterpret_cast<const f32x2*>(br + noff1);
@@ -106,8 +110,13 @@ __global__ void __launch_bounds__(256, 3) wgrad_kernel(WgTable tb, float* __rest
         r.b[q] = br[min(noff + q, P.N - 1)];
       }
     }
-    r.mu = mup[kr];
-    r.rs = rsp[kr];
+    if (EXP & 8) {      // (experiment: without the two per-row scalar loads)
+      r.mu = 0.f;
+      r.rs = 1.f;
+    } else {
+      r.mu = mup[kr];
+      r.rs = rsp[kr];
+    }
   };
   auto compute = [&](const Rawv& c, int kb) {
     const int k = kb + g;
@@ -115,12 +124,21 @@ __global__ void __launch_bounds__(256, 3) wgrad_kernel(WgTable tb, float* __rest
     const float ka = (k < k1) ? 1.f : 0.f;
     const float kbm = (k < k1 && k - shift >= 0) ? 1.f : 0.f;
     f32x4 av, bv;
+    if (EXP & 16) {
+      av = c.a;
+      bv = c.b;
+    } else {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      av[q] = c.a[q] * (ka * mokf[q]);
-      bv[q] = ((c.b[q] - c.mu) * c.rs) * (kbm * nokf[q]);
+      for (int q = 0; q < 4; ++q) {
+        av[q] = c.a[q] * (ka * mokf[q]);
+        bv[q] = ((c.b[q] - c.mu) * c.rs) * (kbm * nokf[q]);
+      }
+      cs += av;
     }
-    cs += av;
+    if (EXP & 4) {
+      asm volatile("" ::"v"(av), "v"(bv));
+      return;
+    }
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -134,7 +152,7 @@ __global__ void __launch_bounds__(256, 3) wgrad_kernel(WgTable tb, float* __rest
   fetch(k0, b0);
   fetch(k0 + 4, b1);
   fetch(k0 + 8, b2);
-  for (int kb = k0; kb < k1; kb += 16) {
+  for (int kb = k0; kb < ((EXP & 32) ? k0 : k1); kb += 16) {      // (experiment 32: no loop at all -- the launch's ramp)
     fetch(kb + 12, b3);
     __builtin_amdgcn_sched_barrier(0);
     compute(b0, kb);
@@ -271,6 +289,18 @@ int launch_wgrad(const WgTable& tb, float* raw, hipStream_t st) {
     tbx = tb;
     tbx.exp = exp_env & 3;
     use = &tbx;
+    if (vec == 4 && (exp_env & 20)) {
+      const int e = exp_env & 20;
+      if (e == 4 && (exp_env & 64)) OPE_LAUNCH((wgrad_kernel<4, false, 76>), dim3(ope_cdiv(tb.total_waves, 4)), dim3(256), 0, st, *use, raw);
+      else if (e == 4 && (exp_env & 32)) OPE_LAUNCH((wgrad_kernel<4, false, 36>), dim3(ope_cdiv(tb.total_waves, 4)), dim3(256), 0, st, *use, raw);
+      else if (e == 4 && (exp_env & 8)) OPE_LAUNCH((wgrad_kernel<4, false, 12>), dim3(ope_cdiv(tb.total_waves, 4)), dim3(256), 0, st, *use, raw);
+      else if (e == 4) OPE_LAUNCH((wgrad_kernel<4, false, 4>), dim3(ope_cdiv(tb.total_waves, 4)), dim3(256), 0, st, *use, raw);
+      else if (e == 16) OPE_LAUNCH((wgrad_kernel<4, false, 16>), dim3(ope_cdiv(tb.total_waves, 4)), dim3(256), 0, st, *use, raw);
+      else OPE_LAUNCH((wgrad_kernel<4, false, 20>), dim3(ope_cdiv(tb.total_waves, 4)), dim3(256), 0, st, *use, raw);
+      if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
+      note_launch("wgrad", vec);
+      return OPE_OK;
+    }
   }
   if (lazy && vec != 4) return OPE_EINVAL;       // rows in the store are read as 16-byte pieces (ope_qmix_obs_ref_ok tells the caller beforehand)
   if (lazy)
