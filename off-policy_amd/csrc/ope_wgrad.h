@@ -21,8 +21,6 @@ constexpr int kMaxWgProbs = 16;
 struct WgTable {
   WgProb p[kMaxWgProbs];
   int n, total_waves, wg_reduce;
-  int exp;                             // timing experiments only (OPE_WGRAD_EXP under the in-process kernel timer; WRONG results): bit 0 = A rows,
-                                       // bit 1 = B rows come from a 64-row window (served by the caches, no fabric traffic)
   ObsRef ref;                          // where the problems with ref_row1 > 0 find their B rows (observations left in the store)
 };
 int wg_finish(WgTable* tb);

@@ -26,7 +26,7 @@ namespace ope {
 // problems of the launch only pay ~10 VALU instructions per fetch. (Walking K episode-major instead -- four contiguous rows of one
 // episode per fetch -- was measured: no faster, 65.8 vs 64.3 us at 3s5z; what the row-reading launch loses against the gathered one,
 // 58.6 us, is where the rows come from: the gather's freshly written batch sits in the 256 MB Infinity Cache, the store's rows do not.)
-// EXP (timing experiments, OPE_WGRAD_EXP, results wrong): 4 = the MFMAs are left out (operands kept alive), 16 = the VALU work beside them is
+// EXP (timing experiments, OPE_WGRAD_EXP, results wrong): 1 / 2 = the A / B rows come from a 64-row window (the caches), 4 = the MFMAs are left out (operands kept alive), 16 = the VALU work beside them is
 // (masks, LayerNorm-on-load, column sums), 4 + 8 = also without the two per-row scalar loads, 4 + 32 = no K loop at all (the launch's ramp), 4 + 8 + 64 = only the A operand is loaded:
 // what each part of the kernel costs on its own. EXP = 0 is the kernel.
 template <int VEC, bool LAZY, int EXP = 0>
@@ -92,8 +92,8 @@ __global__ void __launch_bounds__(256, 3) wgrad_kernel(WgTable tb, float* __rest
       const int64_t sr = (int64_t)eps[b] * tb.ref.TTN + (ref_tn0 + tn);
       brow = ref_on ? sr : brow;
     }
-    const float* ar = Ap + (int64_t)((tb.exp & 1) ? (kc & 63) : kc) * lda;
-    const float* br = Bp + ((tb.exp & 2) ? (brow & 63) : brow) * ldb;
+    const float* ar = Ap + (int64_t)((EXP & 1) ? (kc & 63) : kc) * lda;
+    const float* br = Bp + ((EXP & 2) ? (brow & 63) : brow) * ldb;
     if (VEC == 4) {
       r.a = *reinterpret_cast<const f32x4*>(ar + moff);
       if (EXP & 64) r.b = f32x4{1.f, 1.f, 1.f, 1.f};      // (experiment: half the operand bytes through the vector-memory path)
@@ -281,36 +281,28 @@ int launch_wgrad(const WgTable& tb, float* raw, hipStream_t st) {
   // window, i.e. from the caches. The results are WRONG: honoured only while the in-process kernel timer is on (bench.py's per-kernel table),
   // never for a plain training call, and announced on stderr.
   static const int exp_env = getenv("OPE_WGRAD_EXP") ? atoi(getenv("OPE_WGRAD_EXP")) : 0;
-  WgTable tbx;
-  const WgTable* use = &tb;
-  if (exp_env && g_kprof_on && !lazy) {
+  if (exp_env && g_kprof_on && !lazy && vec == 4) {
     static bool warned = false;
-    if (!warned) { fprintf(stderr, "libope: OPE_WGRAD_EXP=%d -- wgrad reads its operands from a 64-row window: TIMING ONLY, gradients are wrong\n", exp_env); warned = true; }
-    tbx = tb;
-    tbx.exp = exp_env & 3;
-    use = &tbx;
-    if (vec == 4 && (exp_env & 20)) {
-      const int e = exp_env & 20;
-      if (e == 4 && (exp_env & 64)) OPE_LAUNCH((wgrad_kernel<4, false, 76>), dim3(ope_cdiv(tb.total_waves, 4)), dim3(256), 0, st, *use, raw);
-      else if (e == 4 && (exp_env & 32)) OPE_LAUNCH((wgrad_kernel<4, false, 36>), dim3(ope_cdiv(tb.total_waves, 4)), dim3(256), 0, st, *use, raw);
-      else if (e == 4 && (exp_env & 8)) OPE_LAUNCH((wgrad_kernel<4, false, 12>), dim3(ope_cdiv(tb.total_waves, 4)), dim3(256), 0, st, *use, raw);
-      else if (e == 4) OPE_LAUNCH((wgrad_kernel<4, false, 4>), dim3(ope_cdiv(tb.total_waves, 4)), dim3(256), 0, st, *use, raw);
-      else if (e == 16) OPE_LAUNCH((wgrad_kernel<4, false, 16>), dim3(ope_cdiv(tb.total_waves, 4)), dim3(256), 0, st, *use, raw);
-      else OPE_LAUNCH((wgrad_kernel<4, false, 20>), dim3(ope_cdiv(tb.total_waves, 4)), dim3(256), 0, st, *use, raw);
-      if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
-      note_launch("wgrad", vec);
-      return OPE_OK;
+    if (!warned) { fprintf(stderr, "libope: OPE_WGRAD_EXP=%d -- a timing-only variant of wgrad_kernel runs: the gradients are WRONG\n", exp_env); warned = true; }
+    const dim3 grid(ope_cdiv(tb.total_waves, 4));
+#define OPE_WG_EXP(E) case E: OPE_LAUNCH((wgrad_kernel<4, false, E>), grid, dim3(256), 0, st, tb, raw); break
+    switch (exp_env) {
+      OPE_WG_EXP(1); OPE_WG_EXP(2); OPE_WG_EXP(3); OPE_WG_EXP(4); OPE_WG_EXP(12); OPE_WG_EXP(16); OPE_WG_EXP(20); OPE_WG_EXP(36); OPE_WG_EXP(76);
+      default: return OPE_EINVAL;
     }
+#undef OPE_WG_EXP
+    if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
+    note_launch("wgrad", vec);
+    return OPE_OK;
   }
-  if (lazy && vec != 4) return OPE_EINVAL;       // rows in the store are read as 16-byte pieces (ope_qmix_obs_ref_ok tells the caller beforehand)
   if (lazy)
-    OPE_LAUNCH((wgrad_kernel<4, true>), dim3(ope_cdiv(tb.total_waves, 4)), dim3(256), 0, st, *use, raw);
+    OPE_LAUNCH((wgrad_kernel<4, true>), dim3(ope_cdiv(tb.total_waves, 4)), dim3(256), 0, st, tb, raw);
   else if (vec == 4)
-    OPE_LAUNCH((wgrad_kernel<4, false>), dim3(ope_cdiv(tb.total_waves, 4)), dim3(256), 0, st, *use, raw);
+    OPE_LAUNCH((wgrad_kernel<4, false>), dim3(ope_cdiv(tb.total_waves, 4)), dim3(256), 0, st, tb, raw);
   else if (vec == 2)
-    OPE_LAUNCH((wgrad_kernel<2, false>), dim3(ope_cdiv(tb.total_waves, 4)), dim3(256), 0, st, *use, raw);
+    OPE_LAUNCH((wgrad_kernel<2, false>), dim3(ope_cdiv(tb.total_waves, 4)), dim3(256), 0, st, tb, raw);
   else
-    OPE_LAUNCH((wgrad_kernel<1, false>), dim3(ope_cdiv(tb.total_waves, 4)), dim3(256), 0, st, *use, raw);
+    OPE_LAUNCH((wgrad_kernel<1, false>), dim3(ope_cdiv(tb.total_waves, 4)), dim3(256), 0, st, tb, raw);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   note_launch(lazy ? "wgrad_store" : "wgrad", vec);
   return OPE_OK;
