@@ -120,9 +120,13 @@ class MADDPGPolicy(object):
 
     # ---- rollout-side API (host logic around the HIP actor forward) ---------------------------------------
     def get_actions(self, obs, available_actions=None, t_env=None, explore=False, use_target=False, use_gumbel=False):
-        batch_size = obs.shape[0]
-        eps = None
         actor_out = (self.target_actor if use_target else self.actor)(obs)
+        return self._actions_from_actor_out(actor_out, obs.shape[0], available_actions, t_env, explore, use_target, use_gumbel)
+
+    def _actions_from_actor_out(self, actor_out, batch_size, available_actions=None, t_env=None, explore=False, use_target=False, use_gumbel=False):
+        """Everything of get_actions behind the actor network (MADDPGPolicy.py:72-119): host logic, the numpy and torch generators consumed in
+        the reference's order (pinned by tests/test_rollout_actions.py on the reference's own outputs)."""
+        eps = None
         if not self.discrete:      # MADDPGPolicy.py:107-116
             if explore:
                 actions = gaussian_noise(actor_out.shape, self.args.act_noise_std).to(actor_out.device) + actor_out

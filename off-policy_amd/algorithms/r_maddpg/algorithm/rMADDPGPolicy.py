@@ -86,8 +86,15 @@ class R_MADDPGPolicy(object):
         obs = np.asarray(obs) if not torch.is_tensor(obs) else obs
         no_sequence = len(obs.shape) == 2
         batch_size = obs.shape[0] if no_sequence else obs.shape[1]
-        eps = None
         actor_out, new_rnn_states = (self.target_actor if use_target else self.actor)(obs, prev_actions, rnn_states)
+        actions, eps = self._actions_from_actor_out(actor_out, batch_size, no_sequence, available_actions, t_env, explore, use_target, use_gumbel)
+        return actions, new_rnn_states, eps
+
+    def _actions_from_actor_out(self, actor_out, batch_size, no_sequence, available_actions=None, t_env=None, explore=False, use_target=False,
+                                use_gumbel=False):
+        """Everything of get_actions behind the actor network (rMADDPGPolicy.py:81-131): host logic, the numpy and torch generators consumed
+        in the reference's order (pinned by tests/test_rollout_actions.py on the reference's own outputs)."""
+        eps = None
         if not self.discrete:      # rMADDPGPolicy.py:121-129
             from ...maddpg.algorithm.MADDPGPolicy import gaussian_noise
             if explore:
@@ -98,7 +105,7 @@ class R_MADDPGPolicy(object):
                 actions = gaussian_noise(actor_out.shape, self.target_noise).to(actor_out.device) + actor_out
             else:
                 actions = actor_out
-            return actions, new_rnn_states, eps
+            return actions, eps
         if self.multidiscrete:      # rMADDPGPolicy.py:81-102: every sub-action on its own, no availability masks
             outs = torch.split(actor_out, [int(x) for x in self.act_dim], dim=-1)
             if use_gumbel or (use_target and self.target_noise is not None):
@@ -113,7 +120,7 @@ class R_MADDPGPolicy(object):
                 actions = (1 - take_random) * onehot.detach().cpu().numpy() + take_random * random_actions.numpy()
             else:
                 actions = torch.cat([onehot_from_logits(o) for o in outs], dim=-1)
-            return actions, new_rnn_states, eps
+            return actions, eps
         if use_gumbel or (use_target and self.target_noise is not None):
             actions = gumbel_softmax_hard(actor_out, available_actions, sample_gumbel_uniform(actor_out.shape))
         elif explore:
@@ -129,7 +136,7 @@ class R_MADDPGPolicy(object):
             actions = (1 - take_random) * onehot.detach().cpu().numpy() + take_random * random_actions
         else:
             actions = onehot_from_logits(actor_out, available_actions)
-        return actions, new_rnn_states, eps
+        return actions, eps
 
     def init_hidden(self, num_agents, batch_size):
         if num_agents == -1:
