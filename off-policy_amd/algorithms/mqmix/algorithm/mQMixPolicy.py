@@ -18,6 +18,10 @@ class M_QMixPolicy(object):
         self.obs_dim = get_dim_from_space(self.obs_space)
         self.act_space = policy_config["act_space"]
         self.act_dim = get_dim_from_space(self.act_space)
+        if np.ndim(self.act_dim) != 0 or self.act_space.__class__.__name__ == "Box":
+            # upstream gives a MultiDiscrete space one Q head per sub-action and the mixer one input per (agent, sub-action)
+            # (QMixPolicy.py:76-93, qmix.py:49-57); the kernels carry one head per agent. Box spaces are not Q-learning's (upstream asserts)
+            raise NotImplementedError("the Q-learning families take Discrete action spaces on the accelerated path (got %s)" % self.act_space.__class__.__name__)
         self.output_dim = self.act_dim
         self.hidden_size = self.args.hidden_size
         self.central_obs_dim = policy_config["cent_obs_dim"]

@@ -235,6 +235,15 @@ def test_action_space_kinds_of_the_maddpg_family_are_validated():
     assert cfg_bytes(heads=[3, 4], continuous=1) == -1            # one or the other
     assert cfg_bytes(continuous=1, target_gumbel=1) == -1         # continuous target noise is additive, not gumbel
     assert cfg_bytes(continuous=2) == -1
+    # the Q-learning families carry one Q head per agent: MultiDiscrete (one head per sub-action upstream) and Box spaces are refused at
+    # construction, before anything touches the GPU
+    from offpolicy_amd.config import default_args
+    from offpolicy_amd.algorithms.qmix.algorithm.QMixPolicy import QMixPolicy
+    from offpolicy_amd.algorithms.mqmix.algorithm.mQMixPolicy import M_QMixPolicy
+    for P in (QMixPolicy, M_QMixPolicy):
+        for sp in (md, Box(low=-np.ones(3, np.float32), high=np.ones(3, np.float32))):
+            with pytest.raises(NotImplementedError, match="Discrete action spaces"):
+                P({"args": default_args(), "device": "cpu"}, {"cent_obs_dim": 9, "cent_act_dim": 14, "obs_space": [6], "share_obs_space": [9], "act_space": sp})
 
 
 def test_struct_mirrors_match_the_compiled_library():
