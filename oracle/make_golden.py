@@ -51,13 +51,18 @@ def patch_vdn():
     vdn_mixer_mod.VDNMixer.forward = forward
 
 
-def build(dims, argv=(), vdn=False, **over):
+def build(dims, argv=(), vdn=False, multi_discrete=None, **over):
     args = reference_args(argv, **over)
     torch.manual_seed(1)
     np.random.seed(1)
+    act_space = Discrete(dims.act_dim)
+    if multi_discrete is not None:      # sub-action sizes (their sum = dims.act_dim): one q head each, one mixer input per (agent, sub-action)
+        from offpolicy.utils.util import MultiDiscrete
+        assert sum(multi_discrete) == dims.act_dim
+        act_space = MultiDiscrete([[0, k - 1] for k in multi_discrete])
     pinfo = {"policy_0": {"cent_obs_dim": dims.state_dim, "cent_act_dim": dims.act_dim * dims.n_agents,
                           "obs_space": [dims.obs_dim], "share_obs_space": [dims.state_dim],
-                          "act_space": Discrete(dims.act_dim)}}
+                          "act_space": act_space}}
     device = torch.device("cpu")
     policy = QMixPolicy({"args": args, "device": device}, pinfo["policy_0"])
     trainer = QMix(args, dims.n_agents, {"policy_0": policy}, lambda a: "policy_0", device=device,
@@ -70,16 +75,17 @@ def named(module, prefix):
 
 
 def run_case(name, dims, n_episodes, inds, steps=3, argv=(), vdn=False, avail="ones", runner_padding=False,
-             per_weights=None, store_inputs=True, cap=None, pre_insert=0, per_agent_share=False, hard_update_after=(), **over):
+             per_weights=None, store_inputs=True, cap=None, pre_insert=0, per_agent_share=False, hard_update_after=(), multi_discrete=None, **over):
     """`hard_update_after`: with `--use_soft_update` given (which turns soft updates OFF, config.py:125) the runner copies the
     live networks into the targets every `hard_update_interval_episode` episodes instead (base_runner.py:279-284); here: after
     the listed (0-based) train steps."""
     if per_agent_share:      # every agent has its own centralized observation; QMix's mixer reads agent 0's (qmix.py:86-90)
         over = dict(over, use_same_share_obs=False)
-    args, pinfo, policy, trainer = build(dims, argv, vdn=vdn, **over)
+    args, pinfo, policy, trainer = build(dims, argv, vdn=vdn, multi_discrete=multi_discrete, **over)
     cap = cap or n_episodes
     agents = {"policy_0": list(range(dims.n_agents))}
-    buf = RecReplayBuffer(pinfo, agents, cap, dims.episode_length, not per_agent_share, True, False)
+    # (MultiDiscrete spaces come without availability masks: upstream's avail_choose on the list of q heads fails)
+    buf = RecReplayBuffer(pinfo, agents, cap, dims.episode_length, not per_agent_share, multi_discrete is None, False)
     rng = np.random.RandomState(0)
     out = {}
     if pre_insert:
@@ -93,6 +99,9 @@ def run_case(name, dims, n_episodes, inds, steps=3, argv=(), vdn=False, avail="o
             for k in ("obs", "share_obs", "acts", "rewards", "dones", "dones_env", "avail_acts"):
                 out["pre_ep/" + k] = ep0[k]
     ep = synth_episodes(rng, n_episodes, dims, avail=avail, runner_padding=runner_padding)
+    if multi_discrete is not None:      # stored actions: one one-hot block per sub-action
+        ep["acts"] = np.concatenate([np.eye(k, dtype=np.float32)[rng.randint(0, k, size=ep["acts"].shape[:3])] for k in multi_discrete], axis=-1)
+        out["multi_discrete"] = np.asarray(multi_discrete, dtype=np.int64)
     if per_agent_share:      # make the agents' copies differ, so that using any other than agent 0's shows
         ep["share_obs"] = ep["share_obs"] + 0.25 * np.arange(dims.n_agents, dtype=np.float32)[None, None, :, None]
     d = as_policy_dicts(ep)
@@ -113,8 +122,9 @@ def run_case(name, dims, n_episodes, inds, steps=3, argv=(), vdn=False, avail="o
     sampled = buf.policy_buffers["policy_0"].sample_inds(inds)
     if store_inputs:
         for k, a in zip(("obs", "share_obs", "acts", "rewards", "dones", "dones_env", "avail_acts"), sampled):
-            out["batch/" + k] = np.ascontiguousarray(a)
-    out["batch_digest"] = np.array(digest(sampled))
+            if a is not None:
+                out["batch/" + k] = np.ascontiguousarray(a)
+    out["batch_digest"] = np.array(digest([a for a in sampled if a is not None]))
     out.update(named(policy.q_network, "agent/"))
     if not vdn:
         out.update(named(trainer.mixer, "mixer/"))
@@ -170,6 +180,13 @@ def run_case(name, dims, n_episodes, inds, steps=3, argv=(), vdn=False, avail="o
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     tiny = DIMS["tiny"]
+    if os.environ.get("OPE_GOLDEN_ONLY") == "multidiscrete":      # round 4: MultiDiscrete action spaces (oracle only; the engine refuses them)
+        run_case("qmix_md_tiny", EnvDims("md_tiny", 2, 5, 6, 7, 4), n_episodes=5, inds=[0, 3, 1, 4], multi_discrete=[2, 3])
+        run_case("qmix_md_odd_huber_per", EnvDims("md_odd", 3, 9, 7, 9, 6), n_episodes=6, inds=[1, 2, 5, 4], multi_discrete=[4, 2, 3],
+                 argv=["--use_huber_loss", "--huber_delta", "0.5", "--use_per"], per_weights=np.array([0.3, 1.0, 0.6, 0.9]), steps=4)
+        run_case("qmix_md_nodouble", EnvDims("md_tiny", 2, 5, 6, 7, 4), n_episodes=5, inds=[0, 3, 1, 4], multi_discrete=[2, 3], argv=["--use_double_q"])
+        # (VDN: upstream's VDNMixer.forward with `multidiscrete_list` fails on the RNN trainer's [T, B, n] input, as A-2 does without -- no fixture)
+        return
     if os.environ.get("OPE_GOLDEN_ONLY") == "gall":
         # round 3: the configuration the reference's ONLY QMIX-SMAC launch script runs (scripts/train_smac_qmix.sh:14-17):
         # --use_global_all_local_state (the centralized state carries every agent's observation too: S = s + N * D,
