@@ -13,7 +13,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from .qmix_oracle import layer_norm, qmixer_forward, huber, HP
+from .qmix_oracle import layer_norm, qmixer_forward, huber, HP, q_head_dims
 
 
 def mlp_agent_param_shapes(obs_dim, act_dim, hidden=64):
@@ -41,7 +41,11 @@ def mlp_base(P, x, prefix="mlp."):
 
 
 def mlp_agent_q(P, x):
-    return F.linear(mlp_base(P, x), P["q.action_out.weight"], P["q.action_out.bias"])
+    y = mlp_base(P, x)
+    if "q.action_out.weight" in P:
+        return F.linear(y, P["q.action_out.weight"], P["q.action_out.bias"])
+    # MultiDiscrete action space (act.py:14-17, 28-33): one Linear head per sub-action, their q blocks side by side
+    return torch.cat([F.linear(y, P["q.action_outs.%d.weight" % i], P["q.action_outs.%d.bias" % i]) for i in range(len(q_head_dims(P)))], dim=-1)
 
 
 def sample_inds(store, inds):
@@ -59,6 +63,19 @@ def mlp_agent_qs(hp, agent, agent_tgt, obs, acts, nobs, navail):
     s_obs, s_nobs, s_act = torch.cat(list(obs), 0), torch.cat(list(nobs), 0), torch.cat(list(acts), 0)
     s_nav = torch.cat(list(navail), 0) if navail is not None else None
     q_all = mlp_agent_q(agent, s_obs)
+    heads = q_head_dims(agent)
+    if len(heads) > 1:
+        # MultiDiscrete (mqmix.py:116-130, 144-155; mQMixPolicy.py:47-55): chosen / greedy / target q per sub-action head, one mixer input per
+        # (agent, sub-action), agent-major; double-Q only (upstream's other branch reduces over the heads and then fails in the mixer), no masks
+        assert s_nav is None and hp.use_double_q
+        q_taken = torch.cat([torch.gather(qb, 1, ab.max(dim=-1)[1].unsqueeze(-1)) for qb, ab in zip(q_all.split(heads, -1), s_act.split(heads, -1))], dim=-1)
+        agent_q = torch.cat(q_taken.split(B, dim=0), dim=-1)                      # [B, n * heads]
+        with torch.no_grad():
+            nq_blocks = mlp_agent_q(agent, s_nobs).detach().split(heads, -1)
+            tq_blocks = mlp_agent_q(agent_tgt, s_nobs).split(heads, -1)
+            tq = torch.cat([torch.gather(tb, 1, nb.max(dim=-1)[1].unsqueeze(-1)) for tb, nb in zip(tq_blocks, nq_blocks)], dim=-1)
+            agent_nq = torch.cat(tq.split(B, dim=0), dim=-1)
+        return agent_q, agent_nq
     q_taken = torch.gather(q_all, 1, s_act.max(dim=-1)[1].unsqueeze(-1))
     agent_q = torch.cat(q_taken.split(B, dim=0), dim=-1)                          # [B, n]
     with torch.no_grad():
@@ -104,9 +121,9 @@ class MQMixOracle(object):
             q_tot = agent_q.sum(dim=-1, keepdim=True)
             nq_tot = agent_nq.sum(dim=-1, keepdim=True)
         else:
-            q_tot = qmixer_forward(mixer, agent_q[None], cent[None], self.n_agents, hp.mixer_hidden_dim)[0]
+            q_tot = qmixer_forward(mixer, agent_q[None], cent[None], agent_q.shape[-1], hp.mixer_hidden_dim)[0]      # inputs: one per agent (x sub-action)
             with torch.no_grad():
-                nq_tot = qmixer_forward(self.mixer_tgt, agent_nq[None], ncent[None], self.n_agents, hp.mixer_hidden_dim)[0]
+                nq_tot = qmixer_forward(self.mixer_tgt, agent_nq[None], ncent[None], agent_nq.shape[-1], hp.mixer_hidden_dim)[0]
         target = rew[0] + (1 - dones_env) * hp.gamma * nq_tot
         err = q_tot - target.detach()
         el = huber(err, hp.huber_delta) if hp.use_huber_loss else err ** 2

@@ -59,6 +59,32 @@ def test_sample_and_train_match_reference(name):
             np.testing.assert_allclose(dst[k].numpy(), ref, rtol=0, atol=2e-5, err_msg=grp + k)
 
 
+@pytest.mark.parametrize("name", ["mqmix_md_small", "mqmix_md_huber_per"])
+def test_multi_discrete_train_steps_match_reference(name):
+    """MultiDiscrete action spaces under MLP QMIX (mqmix.py:41-51, 116-130, 144-155; mQMixPolicy.py:47-55): one q head per sub-action, chosen /
+    greedy / target q per head, one mixer input per (agent, sub-action). Oracle only -- the engine's Q-learning policies refuse these spaces
+    (DESIGN.md section 2). Double-Q only and no availability masks: upstream's other branches fail on the list of heads."""
+    g = load_golden(name)
+    orc = mlp_oracle_from(g)
+    heads = [int(x) for x in g["multi_discrete"]]
+    assert MO.q_head_dims(orc.agent) == heads
+    assert orc.mixer["hyper_w1.2.weight"].shape[0] == int(g["dims"][0]) * len(heads) * 32
+    batch = tuple(g["batch/" + k] if "batch/" + k in g else None for k in T_KEYS)
+    assert batch[9] is None and batch[10] is None
+    w = g["per_weights"] if "per_weights" in g else None
+    for st in range(len(g["loss"])):
+        out = orc.train_step(batch, weights=w)
+        np.testing.assert_allclose(out["loss"], g["loss"][st], rtol=2e-5)
+        np.testing.assert_allclose(out["grad_norm"], g["grad_norm"][st], rtol=2e-5)
+        np.testing.assert_allclose(out["Q_tot"], g["Q_tot"][st], rtol=2e-5, atol=1e-7)
+        if w is not None:
+            np.testing.assert_allclose(out["priorities"], g["priorities"][st], rtol=2e-5, atol=1e-7)
+    for grp, dst in (("final_agent/", orc.agent), ("final_agent_tgt/", orc.agent_tgt), ("final_mixer/", orc.mixer),
+                     ("final_mixer_tgt/", orc.mixer_tgt)):
+        for k, ref in sub(g, grp).items():
+            np.testing.assert_allclose(dst[k].numpy(), ref, rtol=0, atol=2e-5, err_msg=grp + k)
+
+
 def test_mlp_init_reproduces_reference_rng_stream():
     import torch
     from offpolicy_amd.algorithms.mqmix.algorithm.agent_q_function import init_mlp_agent_values, MLP_AGENT_PARAM_NAMES
