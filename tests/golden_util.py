@@ -65,3 +65,48 @@ def oracle_from(g):
             use_relu=bool(g["hp_use_relu"]) if "hp_use_relu" in g else True)
     mixer = sub(g, "mixer/") if not bool(g["vdn"]) else None
     return QMixOracle(sub(g, "agent/"), mixer, dims.n_agents, hp), dims
+
+
+def rddpg_fixture_episodes(g):
+    """Episodes of a recurrent MADDPG / MATD3 fixture: stored for the small cases; for the BASELINE-size ones (`store_inputs=False`,
+    oracle/make_golden_rddpg.py) regenerated from the seed recipe -- RandomState(0): synth_episodes, then the per-agent deaths -- and
+    checked against the stored digest."""
+    import hashlib
+    if "ep/obs" in g:
+        return {k: g["ep/" + k] for k in EP_KEYS}
+    dims = fixture_dims(g)
+    rng = np.random.RandomState(0)
+    n_ep = int(g["idx_range"].shape[0])
+    ep = synth_episodes(rng, n_ep, dims, avail=str(g["ep_avail"]), runner_padding=bool(g["ep_runner_padding"]))
+    T = dims.episode_length
+    death = rng.randint(1, T + 1, size=ep["dones"].shape[1:3])
+    ep["dones"] = np.maximum(ep["dones"], (np.arange(T)[:, None, None] >= death[None]).astype(np.float32)[..., None])
+    h = hashlib.sha256()
+    for k in EP_KEYS:
+        h.update(np.ascontiguousarray(ep[k]).tobytes())
+    assert h.hexdigest() == str(g["ep_digest"]), "regenerated synthetic episodes differ from the fixture's"
+    return ep
+
+
+def batch_digest(arrs):
+    """sha256 over what `sample_inds` returned, as oracle/make_golden*.py computed it on the reference's arrays."""
+    import hashlib
+    h = hashlib.sha256()
+    for a in arrs:
+        if a is not None:
+            h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def record_errors(name, payload):
+    """Achieved parity errors of a -m gpu test, appended as one JSON line to gpurun_out/parity_errors.jsonl (merged back from the GPU box;
+    the summaries kept for the judge are copied to profiles/)."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(root, "gpurun_out", "parity_errors.jsonl"), "a") as f:
+            f.write(json.dumps(dict(test=name, **payload)) + "\n")
+    except OSError:
+        pass

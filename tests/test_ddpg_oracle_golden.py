@@ -12,7 +12,9 @@ CASES = ["maddpg_spread", "matd3_spread", "maddpg_small_huber_per", "matd3_small
          # round 4: continuous (Box) action spaces -- the action is the actor's output, MATD3's target noise is additive gaussian
          "maddpg_cont_small", "matd3_cont_small", "maddpg_cont_spread",
          # round 4: multi-discrete action spaces -- one Linear head, one argmax / gumbel-softmax per sub-action
-         "maddpg_md_small", "matd3_md_small"]
+         "maddpg_md_small", "matd3_md_small",
+         # round 5: BASELINE config 3 at its own batch size (B = 256), stepped by the reference (oracle/make_golden_fullsize.py)
+         "maddpg_spread_b256", "matd3_spread_b256"]
 
 
 def ddpg_oracle_from(g):

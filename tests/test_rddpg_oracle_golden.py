@@ -42,14 +42,38 @@ def rnoise_for(g, step, update_actor=True):
     return u_t, u_a
 
 
+FULLSIZE_CASES = ["rmatd3_MMM2_b128_per"]      # round 5: BASELINE config 5 at its own size (oracle/make_golden_fullsize.py; inputs regenerated)
+
+
+def fixture_batch_np(g):
+    """What `sample_inds` returned to the reference: stored for the small cases, rebuilt from the regenerated episodes otherwise
+    (rec_buffer.py:192-240: x[:, inds] then the [N, T(+1), B, .] transpose; share_obs without the agent axis) and checked by digest."""
+    if "batch/obs" in g:
+        return tuple(g["batch/" + k] for k in EP_KEYS)
+    from golden_util import rddpg_fixture_episodes, batch_digest
+    ep = rddpg_fixture_episodes(g)
+    inds = np.asarray(g["inds"])
+    out = []
+    for k in EP_KEYS:
+        x = ep[k][:, inds]
+        if k == "share_obs":
+            x = x[:, :, 0]
+        if k in ("share_obs", "dones_env"):
+            out.append(np.ascontiguousarray(x))
+        else:
+            out.append(np.ascontiguousarray(x.transpose(2, 0, 1, 3)))
+    assert batch_digest(out) == str(g["batch_digest"]), "rebuilt batch differs from what the reference's sample_inds returned"
+    return tuple(out)
+
+
 CENT_CASES = ["rmaddpg_cent_tiny", "rmatd3_cent_odd"]      # cent_train_policy_on_batch (per-agent centralized observations), oracle/make_golden_cent.py
 
 
-@pytest.mark.parametrize("name", CASES + CENT_CASES)
+@pytest.mark.parametrize("name", CASES + CENT_CASES + FULLSIZE_CASES)
 def test_train_steps_match_reference(name):
     g = load_golden(name)
     orc = rddpg_oracle_from(g)
-    batch = tuple(g["batch/" + k] for k in EP_KEYS)
+    batch = fixture_batch_np(g)
     w = g["per_weights"] if "per_weights" in g else None
     for s in range(len(g["critic_loss"])):
         upd = bool(g["update_actor"][s])
