@@ -250,6 +250,11 @@ typedef struct ope_qmix_cfg {
                          *  single Linear layers from the state (q_mixer.py:39-44): 10 mixer tensors instead of 14 (ope_qmix_param_layout:
                          *  hyper_w1.{weight [N*32][S], bias}, hyper_w2.{weight [32][S], bias}, hyper_b1.*, hyper_b2.0.*, hyper_b2.2.*); runs on
                          *  the fused chain only (whole steps of recurrent nets; chain_path 1, mixer_path 3, mlp, phases: OPE_EINVAL)      */
+  int32_t wgrad_path;   /* weight-gradient launch (grad_W = grad_out^T input of every Linear, qmix.py:190-191): 0 = by shape; 1 = one 64 x 64
+                         *  tile per wave (wgrad_kernel + split_reduce, ope_wgrad.hip); 2 = register-blocked, up to four tiles that share an
+                         *  operand per wave (wgrad2_kernel + w2_reduce, ope_wgrad2.hip): whole steps on one stream with 8-byte aligned rows of
+                         *  at most 1 024 floats and the observations gathered -- what "by shape" picks then (process default OPE_WGRAD2 = 1 | 0,
+                         *  read once); any other configuration with wgrad_path = 2 returns OPE_EINVAL                               */
 } ope_qmix_cfg;
 
 /* Flat parameter vector: the reference's named_parameters() order (agent q-network, then mixer; qmix.py:67-72),

@@ -43,7 +43,7 @@ class QmixCfg(C.Structure):
                 ("use_huber", C.c_int32), ("use_per", C.c_int32), ("gamma", C.c_float), ("huber_delta", C.c_float),
                 ("per_nu", C.c_float), ("per_eps", C.c_float), ("mlp", C.c_int32), ("phase", C.c_int32),
                 ("mixer_path", C.c_int32), ("time_chunks", C.c_int32), ("scan_family", C.c_int32), ("scan_waves", C.c_int32),
-                ("debug", C.c_int32), ("trunk_path", C.c_int32), ("chain_path", C.c_int32), ("hypernet_layers", C.c_int32)]
+                ("debug", C.c_int32), ("trunk_path", C.c_int32), ("chain_path", C.c_int32), ("hypernet_layers", C.c_int32), ("wgrad_path", C.c_int32)]
 
 
 class GatherTune(C.Structure):

@@ -86,7 +86,7 @@ class QMix(object):
         # `time_chunks`: two-stream schedule; `scan_family` / `scan_waves`: GRU scan kernels; `debug`: keep intermediates.
         # `trunk_path`: 3 = one trunk launch per net (weights in registers), 4 = both nets in one launch (weights in LDS).
         # `chain_path`: 1 = head / mixer / TD / adjoints as four launches, 2 = the fused pair mixer_hyp + qchain (ope_chain.hip).
-        self.tune = dict(mixer_path=0, time_chunks=0, scan_family=0, scan_waves=0, debug=0, trunk_path=0, chain_path=0)
+        self.tune = dict(mixer_path=0, time_chunks=0, scan_family=0, scan_waves=0, debug=0, trunk_path=0, chain_path=0, wgrad_path=0)
         self._ws = {}
         self._ws_multi = {}
         self._gsq = {}
@@ -305,6 +305,7 @@ class QMix(object):
         cfg.scan_family, cfg.scan_waves, cfg.debug = int(t["scan_family"]), int(t["scan_waves"]), int(t["debug"])
         cfg.trunk_path = int(t["trunk_path"])
         cfg.chain_path = int(t.get("chain_path", 0))
+        cfg.wgrad_path = int(t.get("wgrad_path", 0))      # 1 = one tile per wave (wgrad), 2 = register-blocked (wgrad2), 0 = by shape
         cfg.hypernet_layers = 0 if self.vdn else int(getattr(self, "hypernet_layers", 2))
         return cfg
 

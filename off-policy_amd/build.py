@@ -36,7 +36,10 @@ def sanitizer_runtime():
     return hits[-1] if hits else None
 
 
-def build(force=False, verbose=True, extra_flags=(), sanitize=False):
+EXP_LIB = os.path.join(HERE, "libope_exp.so")
+
+
+def build(force=False, verbose=True, extra_flags=(), sanitize=False, experiments=False):
     """sanitize=True: the HOST side of the same sources (argument checks, layout / workspace planning, launch orchestration: the
     C-ABI shim) instrumented with AddressSanitizer + UndefinedBehaviorSanitizer into libope_asan.so (objects under csrc/asan/);
     device code is compiled as usual. tests/test_sanitizer_host.py drives every entry point that returns before its first launch
@@ -46,9 +49,12 @@ def build(force=False, verbose=True, extra_flags=(), sanitize=False):
     headers.append(os.path.join(os.path.dirname(HERE), "include", "ope.h"))
     objs = []
     procs = []
-    lib = SAN_LIB if sanitize else LIB
-    flags = [f for f in FLAGS if f != "-O3"] + SAN_FLAGS if sanitize else FLAGS
-    odir = os.path.join(CSRC, "asan") if sanitize else CSRC
+    # experiments=True: libope_exp.so, the same sources with -DOPE_EXPERIMENTS -- the timing-only kernel variants behind OPE_WGRAD_EXP /
+    # OPE_W2_EXP / OPE_WIDE_EXP (loops with the loads, the MFMAs or the reductions left out: WRONG results, announced on stderr). They exist
+    # only there; load it with OPE_LIB_PATH for a decomposition run (tools/, profiles/r05_*). libope.so has none of them compiled in.
+    lib = SAN_LIB if sanitize else (EXP_LIB if experiments else LIB)
+    flags = [f for f in FLAGS if f != "-O3"] + SAN_FLAGS if sanitize else (FLAGS + ["-DOPE_EXPERIMENTS"] if experiments else FLAGS)
+    odir = os.path.join(CSRC, "asan") if sanitize else (os.path.join(CSRC, "exp") if experiments else CSRC)
     os.makedirs(odir, exist_ok=True)
     for src in sources():
         obj = os.path.join(odir, os.path.basename(src)[:-4] + ".o")
@@ -70,4 +76,4 @@ def build(force=False, verbose=True, extra_flags=(), sanitize=False):
 
 
 if __name__ == "__main__":
-    print("built", build(force="--force" in sys.argv, sanitize="--sanitize" in sys.argv))
+    print("built", build(force="--force" in sys.argv, sanitize="--sanitize" in sys.argv, experiments="--experiments" in sys.argv))

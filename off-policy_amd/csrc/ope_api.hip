@@ -85,7 +85,7 @@ struct Plan {
   int64_t mu0, rstd0, xhat1, rstd1, mask1, xhat2, rstd2, mask2, gi, h, rg, zg, ng, ghn, xhat_o, rstd_o, act_idx,
       agent_q, agent_nq, gi_t, h_t, qtot, nqtot, hw1, hw2, hb2, v1, hpre, v2, loss_part, err_abs, dqtot, d_agent_q,
       d_b1, d_v2, d_v1, d_hw1, d_hw2, d_hb2, dh_out, dqoh, dgi, dghn, dz1, dz2, thetaT, mixT, raw_agent, raw_mixer,
-      rsum, q_all, loss_tot, ln_zero, ln_one, dh_carry, dbg, gsq_part, mix_slab;
+      rsum, q_all, loss_tot, ln_zero, ln_one, dh_carry, dbg, gsq_part, mix_slab, raw2;
   int n_gsq;
   bool wide;
   bool chain;                   // the (t, b)-row chain runs as mixer_hyp + qchain (ope_chain.hip) instead of head_fwd / mixer_fwd / mixer_bwd / head_bwd
@@ -223,6 +223,7 @@ void make_plan(const ope_qmix_cfg* c, Plan* p) {
   p->raw_agent = W.add("raw_agent", (int64_t)p->ns_agent * p->chunks * w.agent_end);
   p->raw_mixer = W.add("raw_mixer", (int64_t)p->ns_mixer * (w.mixer_size > 0 ? w.mixer_size : 4));
   p->rsum = W.add("rsum", (int64_t)w.agent_end + w.mixer_size + 4);
+  p->raw2 = W.add("raw2", (int64_t)w2_max_workgroups() * kW2Slab);      // one slab per workgroup of the register-blocked weight-gradient launch
   p->q_all = W.add("q_all", R * p->A);
   p->dbg = W.add("dbg", 2 * 16 * 4096 + 2 * 16 * 2400);   // per-wave s_memtime stamps (ope_set_debug)
   // wide-state mixer (ope_mixer_wide.hip): stream-K partial sums of the first hyper-layers
@@ -626,6 +627,7 @@ static int qmix_step(const ope_qmix_cfg* cfg, const ope_fields* batch, const ope
     WgProb& q = wt.p[wt.n++];
     q.A = A; q.lda = lda; q.M = M; q.B = Bm; q.ldb = ldb; q.N = N; q.K = K; q.b_shift = 0; q.ln_mu = W + p.ln_zero; q.ln_rstd = W + p.ln_one;
     q.out_off = out_off; q.ldc = ldc; q.s_off = s_off; q.nsplit = nsplit; q.raw_base = base; q.raw_stride = stride;
+    q.rs_base = base == p.raw_mixer ? rw.agent_end : 0;      // (where launch_split_reduce puts the two regions in `rsum`)
     return q;
   };
   auto add_mixer_problems = [&](WgTable& wt) {
@@ -651,11 +653,17 @@ static int qmix_step(const ope_qmix_cfg* cfg, const ope_fields* batch, const ope
     prob(wt, W + p.dqtot, 4, 1, W + p.hb2, OPE_HYP, OPE_HYP, TBk, M.b2b_w - mbase, OPE_HYP, M.b2b_b - mbase, p.ns_mixer, mb_, ms);
   };
   // agent problems over the rows [r0, r0 + K1) (whole time steps), slabs starting at `slab0`
+  // the register-blocked weight-gradient launch (ope_wgrad2.hip) takes whole steps on one stream: no time chunks, no rows read in place
+  static const int w2_env = getenv("OPE_WGRAD2") ? atoi(getenv("OPE_WGRAD2")) : 1;
+  const bool w2_can = C == 1 && !use_side && !oref && p.D % 2 == 0 && p.D <= 1024 && (cfg->vdn || (p.S % 2 == 0 && p.S <= 1024)) && p.NM <= 1024;      // (rows 8-byte aligned at least; at most four units per problem)
+  if (cfg->wgrad_path == 2 && !w2_can) return OPE_EINVAL;
+  const bool want_w2 = w2_can && (cfg->wgrad_path == 2 || (cfg->wgrad_path == 0 && w2_env));
+  const bool merge_hh = want_w2;
   auto add_agent_problems = [&](WgTable& wt, int64_t r0, int K1, int nsplit, int slab0) {
     const int64_t ab = p.raw_agent + (int64_t)slab0 * rw.agent_end, as = rw.agent_end;
     {
       WgProb& q = prob(wt, W + p.dz1 + r0 * OPE_H, OPE_H, OPE_H, oref ? obs_rows : obs_rows + r0 * p.D, p.D, p.D, K1, rw.P1, p.D, rw.s1, nsplit, ab, as);
-      q.ln_mu = W + p.mu0 + r0; q.ln_rstd = W + p.rstd0 + r0;
+      q.ln_mu = W + p.mu0 + r0; q.ln_rstd = W + p.rstd0 + r0; q.ln_on = 1;
       if (oref) { q.ref_row1 = (int)r0 + 1; wt.ref = ref; }
     }
     prob(wt, W + p.dz2 + r0 * OPE_H, OPE_H, OPE_H, W + p.xhat1 + r0 * OPE_H, OPE_H, OPE_H, K1, rw.P2, OPE_H, rw.s2, nsplit, ab, as);
@@ -666,14 +674,20 @@ static int qmix_step(const ope_qmix_cfg* cfg, const ope_fields* batch, const ope
       // h_{t-1}: the first chunk shifts inside the kernel (rows of t = 0 see zeros), later chunks start one step back
       const float* hprev = r0 > 0 ? W + p.h + (r0 - p.NB) * OPE_H : W + p.h;
       const int shift = r0 > 0 ? 0 : p.NB;
-      prob(wt, dgi, 3 * OPE_H, 2 * OPE_H, hprev, OPE_H, OPE_H, K1, rw.WHH, OPE_H, rw.shh, nsplit, ab, as).b_shift = shift;
-      prob(wt, W + p.dghn + r0 * OPE_H, OPE_H, OPE_H, hprev, OPE_H, OPE_H, K1, rw.WHH + 2 * OPE_H * OPE_H, OPE_H, rw.shh + 2 * OPE_H, nsplit, ab,
-           as).b_shift = shift;
+      if (merge_hh) {      // register-blocked launch: one problem, dgi's r / z panels and dghn as the third panel, h_{t-1} read once for all three
+        WgProb& q = prob(wt, dgi, 3 * OPE_H, 3 * OPE_H, hprev, OPE_H, OPE_H, K1, rw.WHH, OPE_H, rw.shh, nsplit, ab, as);
+        q.b_shift = shift; q.A2 = W + p.dghn + r0 * OPE_H; q.lda2 = OPE_H; q.a2_from = 2;
+      } else {
+        prob(wt, dgi, 3 * OPE_H, 2 * OPE_H, hprev, OPE_H, OPE_H, K1, rw.WHH, OPE_H, rw.shh, nsplit, ab, as).b_shift = shift;
+        prob(wt, W + p.dghn + r0 * OPE_H, OPE_H, OPE_H, hprev, OPE_H, OPE_H, K1, rw.WHH + 2 * OPE_H * OPE_H, OPE_H, rw.shh + 2 * OPE_H, nsplit, ab,
+             as).b_shift = shift;
+      }
     }
     // q head: fed by rnn.norm (recurrent) or directly by the trunk's LN2 (MLP) -- both "Linear after LayerNorm"
     prob(wt, W + p.dqoh + r0 * p.A4, p.A4, p.A, (p.mlp ? W + p.xhat2 : W + p.xhat_o) + r0 * OPE_H, OPE_H, OPE_H, K1, rw.E, OPE_H, rw.sq, nsplit, ab, as);
   };
   int agent_slabs = 0, mixer_slabs = 0;
+  bool reduced = false;      // the weight-gradient launch summed its own slabs into `rsum`
   if (use_side && !cfg->vdn) {   // main stream, beside the BPTT of the last chunk on the side stream
     WgTable wm;
     memset(&wm, 0, sizeof(wm));
@@ -728,7 +742,32 @@ static int qmix_step(const ope_qmix_cfg* cfg, const ope_fields* batch, const ope
     if (!use_side && !cfg->vdn && do_mix) add_mixer_problems(wt);
     if (wt.n > 0) {
       if ((rc = wg_finish(&wt))) return rc;
-      if ((rc = launch_wgrad(wt, W, st))) return rc;
+      // whole step in one launch (no time chunks, no side stream): the register-blocked form, which also sums its slabs into `rsum`
+      if (want_w2) {
+        if (!w2_ok(wt)) return OPE_EINVAL;      // (8-byte aligned rows at least: every table of this step has them, ope_dims are checked at create)
+        // (units and workgroup shares depend on the problems' shapes only: planned once per configuration -- the greedy passes cost ~15 us
+        // of host time, which a short step like 3m's cannot hide; the pointers are refreshed on every call)
+        static thread_local int w2_key[kMaxWgProbs * 10 + 1];
+        static thread_local W2Table w2;
+        int key[kMaxWgProbs * 10 + 1];
+        memset(key, 0, sizeof(key));
+        key[0] = wt.n;
+        for (int q = 0; q < wt.n; ++q) {
+          const WgProb& P = wt.p[q];
+          int same = q;      // first problem that walks the same A rows (what the XCD pairing looks at)
+          for (int r = q - 1; r >= 0; --r)
+            if (wt.p[r].A == P.A) same = r;
+          const int f[10] = {P.M, P.N, P.K, P.lda, P.ldb, P.b_shift, P.s_off >= 0, same, P.A2 ? P.a2_from + 1 : 0, P.lda2};
+          memcpy(key + 1 + 10 * q, f, sizeof(f));
+        }
+        if (memcmp(w2_key, key, sizeof(key)) != 0) {
+          if ((rc = w2_build(wt, &w2))) return rc;
+          memcpy(w2_key, key, sizeof(key));
+        }
+        for (int q = 0; q < wt.n; ++q) w2.p[q] = wt.p[q];
+        if ((rc = launch_wgrad2(w2, W + p.raw2, W + p.rsum, st))) return rc;
+        reduced = true;
+      } else if ((rc = launch_wgrad(wt, W, st))) return rc;
     }
     if (do_bwd) agent_slabs += wg_slabs(wt, p.ns_chunk[c]);
     if (!use_side && !cfg->vdn && do_mix) mixer_slabs = wg_slabs(wt, p.ns_mixer);
@@ -738,7 +777,7 @@ static int qmix_step(const ope_qmix_cfg* cfg, const ope_fields* batch, const ope
     sr.raw0 = W + p.raw_agent; sr.n0 = rw.agent_end; sr.ns0 = agent_slabs;
     sr.raw1 = W + p.raw_mixer; sr.n1 = cfg->vdn ? 0 : rw.mixer_size; sr.ns1 = mixer_slabs;
     sr.rsum = W + p.rsum;
-    if (!(phase == 2 && cfg->vdn))       // (a VDN mixing part has no parameters: only the loss tail follows)
+    if (!(phase == 2 && cfg->vdn) && !reduced)       // (a VDN mixing part has no parameters: only the loss tail follows)
       if ((rc = launch_split_reduce(sr, st))) return rc;
   }
 

@@ -618,7 +618,7 @@ static int mlp_backward(const DdpgPlan& p, float* W, const float* x, int rows, i
   };
   {
     WgProb& q = prob(W + p.dz1, OPE_H, OPE_H, x, Dw, Dw, p.P1, Dw, p.s1);
-    q.ln_mu = mu0; q.ln_rstd = rstd0;
+    q.ln_mu = mu0; q.ln_rstd = rstd0; q.ln_on = 1;
   }
   prob(W + p.dz2, OPE_H, OPE_H, xhat1, OPE_H, OPE_H, p.P2, OPE_H, p.s2);
   prob(dout, ldk, Hout, xhat2, OPE_H, OPE_H, p.E, OPE_H, p.sq);

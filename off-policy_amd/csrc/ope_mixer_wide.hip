@@ -186,8 +186,12 @@ int launch_mixer_wide_gemm(const MixerFwdArgs& a0, hipStream_t st) {
   const int vec = ope_vec_of(a0.S);
   // timing experiments only (skips loads / MFMAs / deposits: WRONG results): honoured only for a call that also carries the debug
   // stamps (ope_qmix_cfg.debug / ope_set_debug, i.e. tools/wide_phases.py), never for a plain training call
+#ifdef OPE_EXPERIMENTS      // (libope_exp.so only: the release library never skips loads / MFMAs / deposits)
   static const int ex_env = getenv("OPE_WIDE_EXP") ? atoi(getenv("OPE_WIDE_EXP")) : 0;
   const int ex = a0.dbg ? ex_env : 0;
+#else
+  const int ex = 0;
+#endif
   MixerFwdArgs a = a0;
   a.k_stagger = ex;
   kprof_work(2.0 * 2.0 * a.TB * (double)a.S * (3.0 * OPE_HYP + OPE_MIX));

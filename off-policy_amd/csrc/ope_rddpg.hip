@@ -527,7 +527,7 @@ static int rnn_backward(const RPlan& p, float* W, const SaveSet& s, const float*
   };
   {
     WgProb& q = prob(W + p.dz1, OPE_H, OPE_H, x, Dw, Dw, p.P1, Dw, p.s1);
-    q.ln_mu = W + s.mu0; q.ln_rstd = W + s.rstd0;
+    q.ln_mu = W + s.mu0; q.ln_rstd = W + s.rstd0; q.ln_on = 1;
   }
   prob(W + p.dz2, OPE_H, OPE_H, W + s.xhat1, OPE_H, OPE_H, p.P2, OPE_H, p.s2);
   prob(W + p.dgi, 3 * OPE_H, 3 * OPE_H, W + s.xhat2, OPE_H, OPE_H, p.P3, OPE_H, p.s3);

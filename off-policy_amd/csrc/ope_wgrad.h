@@ -16,6 +16,9 @@ struct WgProb {
   int64_t raw_base; int64_t raw_stride;  // split q writes to raw[raw_base + q*raw_stride + ...]
   int mt, nt, kchunk, wave_begin;      // filled by wg_finish
   int ref_row1;                        // > 0: B is the store's obs ring and reduction row k is batch row ref_row1 - 1 + k (WgTable.ref); 0: plain
+  int ln_on;                           // 1: ln_mu / ln_rstd are a real LayerNorm (0: the zeros / ones vectors of a plain problem; wgrad2 skips the loads)
+  int rs_base;                         // wgrad2: offset of this problem's region in the reduced vector `rsum` (out_off / s_off are relative to it)
+  const float* A2; int lda2; int a2_from;  // wgrad2: 64-column panels >= a2_from of A come from A2 (column 64 * (panel - a2_from)); null: one matrix
 };
 constexpr int kMaxWgProbs = 16;
 struct WgTable {
@@ -26,6 +29,25 @@ struct WgTable {
 int wg_finish(WgTable* tb);
 int launch_wgrad(const WgTable& tb, float* raw, hipStream_t st);
 int wg_slabs(const WgTable& tb, int nsplit);
+// ---- register-blocked form (ope_wgrad2.hip): units of up to four tiles per wave, one slab per workgroup ----
+constexpr int kW2Slab = 4 * 4096 + 4 * 64;      // floats a workgroup writes: four 64 x 64 tiles + four 64-float column sums
+constexpr int kMaxW2Units = 40;
+struct W2Unit {
+  int prob;                            // index into W2Table.p
+  short mp0, np0, pa, pb;              // first m / n panel (64 columns each) and panels per side, pa * pb <= 4
+  int wg_begin, nwg, kchunk;           // workgroups [wg_begin, wg_begin + nwg); wave c of the unit reduces rows [c * kchunk, (c + 1) * kchunk)
+  int red_rows;                        // 64-float rows the slab-sum launch adds for this unit (tile rows + column-sum vectors)
+};
+struct W2Table {
+  WgProb p[kMaxWgProbs];
+  W2Unit u[kMaxW2Units];
+  int ubegin[kMaxW2Units];             // u[q].wg_begin again, contiguous (INT_MAX beyond nu): what a workgroup searches
+  int np, nu, total_wg, red_blocks;
+};
+bool w2_ok(const WgTable& tb);
+int w2_max_workgroups();
+int w2_build(const WgTable& tb, W2Table* out);
+int launch_wgrad2(const W2Table& w, float* raw, float* rsum, hipStream_t st);
 struct SplitRed { const float* raw0; int64_t n0; int ns0; const float* raw1; int64_t n1; int ns1; float* rsum; };
 int launch_split_reduce(const SplitRed& a, hipStream_t st);
 constexpr int kMaxTransp = 6;

@@ -277,6 +277,8 @@ int launch_wgrad(const WgTable& tb, float* raw, hipStream_t st) {
   }
   bool lazy = false;
   for (int q = 0; q < tb.n; ++q) lazy = lazy || tb.p[q].ref_row1 > 0;
+#ifdef OPE_EXPERIMENTS
+  // (only in libope_exp.so, built with -DOPE_EXPERIMENTS: the release library carries no wrong-result instantiation)
   // where does the time go -- the matrix pipe or the operand traffic? OPE_WGRAD_EXP serves the A (bit 0) and / or B (bit 1) rows from a 64-row
   // window, i.e. from the caches. The results are WRONG: honoured only while the in-process kernel timer is on (bench.py's per-kernel table),
   // never for a plain training call, and announced on stderr.
@@ -295,6 +297,7 @@ int launch_wgrad(const WgTable& tb, float* raw, hipStream_t st) {
     note_launch("wgrad", vec);
     return OPE_OK;
   }
+#endif
   if (lazy)
     OPE_LAUNCH((wgrad_kernel<4, true>), dim3(ope_cdiv(tb.total_waves, 4)), dim3(256), 0, st, tb, raw);
   else if (vec == 4)

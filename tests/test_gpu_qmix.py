@@ -276,6 +276,7 @@ def test_observation_rows_read_in_place_from_the_store_give_the_gathered_step(na
     for lazy in (False, True):
         dims, buf, policy, trainer = build_from_fixture(g)
         trainer.tune["trunk_path"] = 4          # (56 rows: "by shape" would pick the register-resident trunk, which reads a gathered batch only)
+        trainer.tune["wgrad_path"] = 1          # (the row-reading form exists for the tile-per-wave kernel: compare it with THAT kernel on gathered rows)
         pb = buf.policy_buffers["policy_0"]
         pb.lazy_obs = lazy
         assert trainer.obs_ref_ok(len(g["inds"]))
@@ -342,6 +343,7 @@ def test_full_size_step_with_observations_read_from_the_store_is_bit_identical()
     inds = np.random.RandomState(3).randint(0, cap, size=nb)
     inds[5] = inds[4]
     assert trainer.obs_ref_ok(nb)
+    trainer.tune["wgrad_path"] = 1          # (the row-reading form belongs to the tile-per-wave kernel; "by shape" takes the register-blocked one on gathered rows)
     snap = (trainer.theta.clone(), trainer.theta_tgt.clone())
     out = []
     for lazy in (False, True):
