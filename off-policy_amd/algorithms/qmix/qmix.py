@@ -470,8 +470,13 @@ class QMix(object):
         self._polyak_done = bool(self.fuse_soft_update)
         train_info = {"loss": stats[0], "grad_norm": stats[1], "Q_tot": stats[2]}
         new_priorities = None
-        if gathered is not None:                                   # all ranks' priorities (rank order = the global batch order), in HBM
-            new_priorities = gathered
+        # Uniform contract (dist.allgather_cat): the LOCAL share's priorities are returned, whatever the world size; what the all-reduce
+        # already gathered is kept beside them (a view into the gradient vector, valid until the next step) for callers that want to
+        # skip the extra collective: dist.allgather_cat(new_priorities, have=trainer.gathered_priorities)
+        self.gathered_priorities = gathered
+        if gathered is not None:
+            rank, _ = opdist.world()
+            new_priorities = gathered[rank * B:(rank + 1) * B].clone()
         elif self.use_per and torch.is_tensor(importance_weights):   # device trees (device_tree=True): priorities stay in HBM
             s = td_stats.view(B, 2)
             new_priorities = ((1 - self.args.per_nu) * s[:, 0] + self.args.per_nu * s[:, 1]) + self.per_eps

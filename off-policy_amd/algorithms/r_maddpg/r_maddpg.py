@@ -286,13 +286,16 @@ class R_MADDPG(object):
                                                            _lib.ptr(u_t), _lib.ptr(w), _lib.ptr(ws), ws.numel(), _lib.ptr(gc),
                                                            _lib.ptr(td_stats), st), "ope_rddpg_critic_loss_and_grad")
         new_priorities = None
+        self.gathered_priorities = None      # (what the all-reduce gathered: dist.allgather_cat(new_priorities, have=trainer.gathered_priorities))
         n_head = policy.critic.padded_numel + 4
         if self.use_per and dev_prio:
             s = td_stats.view(K, B, 2)
             nu = self.args.per_nu
             new_priorities = (((1 - nu) * s[:, :, 0] + nu * s[:, :, 1]) + self.per_eps).mean(dim=0) + self.per_eps
             if world_size > 1:      # the ranks' priorities ride on the gradient all-reduce: every rank ends up with all world x B of them, in HBM
-                new_priorities = opdist.priority_slots(gc, n_head, new_priorities)
+                # (uniform contract, dist.allgather_cat: the LOCAL share's priorities are what this call returns)
+                new_priorities = new_priorities.clone()
+                self.gathered_priorities = opdist.priority_slots(gc, n_head, new_priorities)
         opdist.allreduce_flat_(gc if (self.use_per and dev_prio and world_size > 1) else gc[:n_head])
         cs = self._adam(policy.critic_optimizer, policy.critic.padded_numel, policy.critic._flat, policy.target_critic._flat, gc, scratch,
                         T * B * world_size, policy.critic.unused_range)

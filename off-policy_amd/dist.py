@@ -249,15 +249,22 @@ def allreduce_flat_(flat, group=None):
     return flat
 
 
-def allgather_cat(x, group=None, expect=None):
+def allgather_cat(x, group=None, have=None):
     """Concatenation over ranks (rank order) of a per-sample vector: the per-episode priorities of a sharded prioritized
     batch, so that every rank updates its replica of the sum/min trees with the same B values.
-    `expect`: length of the concatenation; a vector that already has it is returned as is -- the trainers gather device-resident
-    priorities themselves, inside the gradient all-reduce (`priority_slots`), with no extra collective and no host trip."""
+
+    Contract (every trainer, every world size): `train_policy_on_batch` / `shared_train_policy_on_batch` return THIS RANK's
+    priorities (length = its share of the batch); `allgather_cat(new_priorities)` is the documented next call and always works.
+    `have`: a trainer that already holds the concatenation -- with device-resident importance weights at world > 1 the priorities
+    ride on the gradient all-reduce (`priority_slots`) and the trainer keeps the result in `trainer.gathered_priorities` -- can be
+    passed here to skip the extra collective: `allgather_cat(prio, have=trainer.gathered_priorities)` returns a copy of it (the
+    view itself lives in the gradient vector and is overwritten by the next step)."""
     if not is_distributed() or x is None:
         return x
-    if expect is not None and len(x) == int(expect):
-        return x
+    if have is not None:
+        _, ws = world()
+        assert len(have) == ws * len(x), "gathered_priorities does not belong to this step"
+        return have.clone() if torch.is_tensor(have) else np.array(have)
     _, world_size = world()
     if torch.is_tensor(x):
         out = [torch.empty_like(x) for _ in range(world_size)]

@@ -466,7 +466,8 @@ class PrioritizedRecReplayBuffer(RecReplayBuffer):
     def sample(self, batch_size, beta=0, p_id=None, shard=None):
         """rec_buffer.py:285-304. Data-parallel use: with `shard=(rank, world)` every rank draws the same `batch_size` global
         indices from its replica of the trees and gets back the episodes and importance weights of ITS contiguous share
-        plus the GLOBAL index list; after the update, `dist.allgather_cat(new_priorities)` rebuilds the global priority
+        plus the GLOBAL index list; after the update, `dist.allgather_cat(new_priorities)` (the trainers return the LOCAL share's
+        priorities; `have=trainer.gathered_priorities` skips the collective where the trainer gathered them itself) rebuilds the global priority
         vector so that `update_priorities(global_idxes, ...)` changes every replica identically."""
         assert len(self) > batch_size, "Cannot sample with no completed episodes in the buffer!"
         assert beta > 0

@@ -90,3 +90,41 @@ def as_policy_dicts(ep, p_id="policy_0"):
     """Wrap arrays the way runners hand them to `buffer.insert` (dict keyed by policy id)."""
     keys = ("obs", "share_obs", "acts", "rewards", "dones", "dones_env", "avail_acts")
     return {k: {p_id: ep[k]} for k in keys}
+
+
+def synth_fill_device(pbuf, n_episodes, dims, seed, avail="bernoulli", chunk=256):
+    """Fill a device-resident RecPolicyBuffer (utils/rec_buffer.py) with `n_episodes` synthetic episodes generated ON THE DEVICE, in place
+    in the store's episode-major rings: the same distributions as `synth_episodes` (obs / share_obs ~ N(0,1), uniform one-hot actions,
+    rewards ~ N(0,1) shared by the agents, lengths uniform in [T/2, T] with dones_env = 1 from step L-1 on, Bernoulli(0.8) availability
+    with action 0 always available), from torch's device generator seeded with `seed` -- every rank of a multi-GPU run gets the SAME
+    store without pushing 7.5 GB of host-generated numbers through PCIe per rank (bench.py --gpus N). The ring
+    counters advance exactly as `n_episodes` inserts would. Not a counterpart of anything in the reference: benchmark plumbing."""
+    import torch
+    T, N, A = dims.episode_length, dims.n_agents, dims.act_dim
+    gen = torch.Generator(device=pbuf.device)
+    gen.manual_seed(int(seed))
+    done = 0
+    while done < n_episodes:
+        n = min(chunk, n_episodes - done)
+        slots = torch.as_tensor(np.asarray(pbuf._ring.next_slots(n), dtype=np.int64), device=pbuf.device)
+        pbuf.obs[slots] = torch.randn((n,) + tuple(pbuf.obs.shape[1:]), generator=gen, device=pbuf.device)
+        pbuf.share_obs[slots] = torch.randn((n,) + tuple(pbuf.share_obs.shape[1:]), generator=gen, device=pbuf.device)
+        idx = torch.randint(0, A, (n, T, N, 1), generator=gen, device=pbuf.device)
+        pbuf.acts[slots] = torch.zeros((n, T, N, A), device=pbuf.device).scatter_(3, idx, 1.0)
+        pbuf.rewards[slots] = torch.randn((n, T, 1, 1), generator=gen, device=pbuf.device).expand(n, T, N, 1)
+        L = torch.randint(T // 2, T + 1, (n, 1), generator=gen, device=pbuf.device)
+        de = (torch.arange(T, device=pbuf.device)[None, :] >= (L - 1)).to(torch.float32)          # [n, T]
+        pbuf.dones_env[slots] = de[:, :, None]
+        pbuf.dones[slots] = de[:, :, None, None].expand(n, T, N, 1)
+        if pbuf.avail_acts is not None:
+            if avail == "bernoulli":
+                av = (torch.rand((n, T + 1, N, A), generator=gen, device=pbuf.device) < 0.8).to(torch.float32)
+                av[..., 0] = 1.0
+            else:
+                av = torch.ones((n, T + 1, N, A), device=pbuf.device)
+            pbuf.avail_acts[slots] = av
+        done += n
+    pbuf._stats_dirty = True
+    pbuf._insert_gen += 1
+    if getattr(pbuf, "_filled_dev", None) is not None:
+        pbuf._filled_device()

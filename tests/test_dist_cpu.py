@@ -66,6 +66,66 @@ def test_sharded_gradients_allreduce_to_full_batch(name):
     np.testing.assert_allclose(res[0], want, rtol=2e-4, atol=1e-5)
 
 
+def _world8_worker(rank, world, port, out_q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from offpolicy_amd import dist as opdist
+        B, n_head = 4, 12                       # global batch 32 over 8 ranks (BASELINE config 4's partition: 4 episodes per GPU)
+        inds = np.random.RandomState(5).choice(1000, B * world)        # same draw on every rank
+        mine = opdist.shard_indices(inds)
+        assert np.array_equal(mine, inds[rank * B:(rank + 1) * B])
+        uneven = None
+        try:
+            opdist.shard_indices(np.arange(B * world + 3))
+        except AssertionError as e:
+            uneven = str(e)
+        # [gradient + tail | world x B priority slots]: the rank's share of the "gradient", its own priorities in its own slots
+        flat = torch.zeros(n_head + B * world)
+        flat[:n_head] = torch.arange(n_head, dtype=torch.float32) * (rank + 1)
+        local = torch.as_tensor(mine, dtype=torch.float32) * 0.5 + 1.0
+        view = opdist.priority_slots(flat, n_head, local)
+        assert view.data_ptr() == flat[n_head:].data_ptr() and torch.count_nonzero(view) == B
+        opdist.allreduce_flat_(flat)
+        full = opdist.allgather_cat(local)                       # the documented call
+        again = opdist.allgather_cat(local, have=view)           # the shortcut for what the all-reduce already gathered
+        out_q.put((rank, flat.numpy(), full.numpy(), again.numpy(), uneven))
+    finally:
+        torch.distributed.destroy_process_group()
+
+
+def test_world8_shares_priority_slots_and_uneven_batches():
+    """Eight ranks over gloo (the node the driver scales to): contiguous shares of one global index draw, the ranks'
+    priorities gathered INSIDE the gradient all-reduce through disjoint slots (exact: x + 0 + ... + 0), the same values from the
+    documented `allgather_cat`, and a batch that does not divide over the ranks refused by `shard_indices`."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + ((os.getpid() + 977) % 2000)
+    procs = [ctx.Process(target=_world8_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        item = q.get(timeout=300)
+        res[item[0]] = item[1:]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    inds = np.random.RandomState(5).choice(1000, 4 * world)
+    want_prio = inds.astype(np.float32) * 0.5 + 1.0
+    want_head = np.arange(12, dtype=np.float32) * sum(range(1, world + 1))
+    for r in range(world):
+        flat, full, again, uneven = res[r]
+        np.testing.assert_array_equal(flat[:12], want_head)
+        np.testing.assert_array_equal(flat[12:], want_prio)          # rank order = global batch order, bit-exact
+        np.testing.assert_array_equal(full, want_prio)
+        np.testing.assert_array_equal(again, want_prio)
+        assert uneven and "multiple of the number of ranks" in uneven
+
+
 def test_single_process_helpers_are_noops():
     from offpolicy_amd import dist as opdist
     assert not opdist.is_distributed() and opdist.world() == (0, 1)

@@ -121,8 +121,14 @@ def _rddpg_steps(name, shard, dev_w=False):
         info, prio, _ = trainer.shared_train_policy_on_batch("policy_0", batch)
         policy.soft_target_updates()
         if dev_w and prio is not None:
-            assert torch.is_tensor(prio) and prio.is_cuda and len(prio) == B, "device priorities of ALL ranks, no host trip"
-            prios.append(prio.cpu().numpy())
+            # uniform contract: the call returns THIS rank's share; what the gradient all-reduce gathered (all ranks, in HBM, no host trip)
+            # is kept in trainer.gathered_priorities, and the documented follow-up call works with or without it
+            assert torch.is_tensor(prio) and prio.is_cuda and len(prio) == per, len(prio)
+            have = trainer.gathered_priorities
+            assert torch.is_tensor(have) and have.is_cuda and len(have) == B
+            full = opdist.allgather_cat(prio, have=have)
+            assert torch.equal(full, opdist.allgather_cat(prio)) and torch.equal(full[mine], prio)
+            prios.append(full.cpu().numpy())
         else:
             prios.append(opdist.allgather_cat(prio))
     torch.cuda.synchronize()
@@ -280,6 +286,67 @@ def _spawn(worker, name, mode):
         p.join(timeout=120)
         assert p.exitcode == 0
     return res
+
+
+def _documented_per_flow_worker(rank, world, port, name, mode, out_q):
+    """INTEGRATION.md "Data parallel": sample the rank's share, train, `dist.allgather_cat(new_priorities)`, update_priorities -- as written
+    there, for QMix (host and device-resident importance weights) and MLP MADDPG."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", OPE_ALLREDUCE="auto")
+    torch.cuda.set_device(0)
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from conftest import load_golden
+        from offpolicy_amd import dist as opdist
+        opdist.setup_fast_allreduce(torch.device("cuda:0"))
+        g = load_golden(name)
+        dev_w = mode == "device_weights"
+        if name.startswith("qmix"):
+            from gpu_util import build_from_fixture
+            dims, buf, policy, trainer = build_from_fixture(g)
+            inds = np.asarray(g["inds"])[:4]
+            w = np.asarray(g["per_weights"])[:4]
+            mine = opdist.shard_indices(np.arange(4))
+            smp = buf.policy_buffers["policy_0"].sample_inds(inds[mine])
+            wm = torch.as_tensor(w[mine], dtype=torch.float32).cuda() if dev_w else w[mine]
+            batch = tuple({"policy_0": a} for a in smp) + (wm, inds)
+            info, prio, idxes = trainer.train_policy_on_batch(batch)
+        else:
+            import test_gpu_ddpg as D
+            from test_mlp_oracle_golden import T_KEYS
+            dims, buf, policy, trainer = D.build(g)
+            inds = np.asarray(g["inds"])[:6]
+            w = np.asarray(g["per_weights"])[:6]
+            mine = opdist.shard_indices(np.arange(6))
+            smp = buf.policy_buffers["policy_0"].sample_inds(inds[mine])
+            batch = tuple({"policy_0": a} for a in smp) + (w[mine], inds)
+            torch.manual_seed(1000)
+            info, prio, idxes = trainer.shared_train_policy_on_batch("policy_0", batch)
+        assert len(prio) == len(mine), (len(prio), len(mine))          # the LOCAL share, whatever the trainer
+        full = opdist.allgather_cat(prio)                                # the documented call, no extra argument
+        assert len(full) == len(inds) and len(idxes) == len(inds)
+        have = getattr(trainer, "gathered_priorities", None)
+        if have is not None:                                             # (device weights: gathered inside the gradient all-reduce)
+            again = opdist.allgather_cat(prio, have=have)
+            assert torch.equal(torch.as_tensor(again).cpu(), torch.as_tensor(full).cpu())
+        torch.cuda.synchronize()
+        full = full.cpu().numpy() if torch.is_tensor(full) else np.asarray(full)
+        out_q.put((rank, full.astype(np.float64), have is not None))
+    finally:
+        torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,mode", [("qmix_tiny_huber_per", "host_weights"), ("qmix_tiny_huber_per", "device_weights"),
+                                       ("maddpg_small_huber_per", "host_weights")])
+def test_two_rank_documented_priority_flow(name, mode):
+    """every trainer returns its LOCAL priorities and `dist.allgather_cat(new_priorities)` rebuilds the global vector,
+    identically on both ranks; where the trainer gathered them itself (`gathered_priorities`) the shortcut gives the same values."""
+    res = _spawn(_documented_per_flow_worker, name, mode)
+    (p0, had0), (p1, had1) = res[0], res[1]
+    assert np.array_equal(p0, p1) and had0 == had1
+    assert had0 == (mode == "device_weights")
+    assert np.all(np.isfinite(p0)) and np.all(p0 > 0)
 
 
 @pytest.mark.parametrize("mode", ["auto", "rccl"])

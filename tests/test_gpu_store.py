@@ -377,3 +377,35 @@ def test_observations_left_in_the_store_are_the_gathered_ones(name, index_source
     with pytest.raises(StaleBatchError):
         fresh.ref()
     assert np.array_equal(obs.cpu().numpy(), g["batch/obs"])       # (materialised before the insert: a plain tensor now)
+
+
+def test_device_synthesised_store_has_the_shape_of_host_synthesised_episodes():
+    """bench.py fills its 5 000-episode store on the device (utils/synth.synth_fill_device) so that eight ranks do not each push 7.5 GB of
+    host-generated numbers: the result must look like `synth_episodes` + insert -- one-hot actions, rewards shared by the agents, dones_env
+    a step function that reaches 1 between T/2 - 1 and T - 1 and stays there, dones = dones_env per agent, action 0 always available, ring
+    counters advanced with wrap-around -- and be the same on every call with the same seed."""
+    from offpolicy_amd.utils.synth import DIMS, policy_info_for, synth_fill_device
+    from offpolicy_amd.utils.rec_buffer import RecReplayBuffer
+    dims = DIMS["3m"]
+    T, N, A = dims.episode_length, dims.n_agents, dims.act_dim
+    outs = []
+    for _ in range(2):
+        buf = RecReplayBuffer(policy_info_for(dims), {"policy_0": list(range(N))}, 48, T, True, True, device="cuda:0")
+        pb = buf.policy_buffers["policy_0"]
+        synth_fill_device(pb, 60, dims, seed=100, chunk=25)          # 60 episodes into 48 slots: wraps
+        assert len(buf) == 48 and pb.filled_i == 48 and pb.current_i == 12
+        outs.append([x.clone() for x in (pb.obs, pb.share_obs, pb.acts, pb.rewards, pb.dones, pb.dones_env, pb.avail_acts)])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    obs, share, acts, rew, dones, de, av = outs[0]
+    assert abs(float(obs.mean())) < 0.01 and abs(float(obs.std()) - 1.0) < 0.01
+    assert torch.equal(acts.sum(-1), torch.ones_like(acts[..., 0])) and set(acts.unique().tolist()) == {0.0, 1.0}
+    assert torch.equal(rew, rew[:, :, :1].expand_as(rew))
+    d = de[:, :, 0]
+    assert torch.all(d[:, 1:] >= d[:, :-1]) and torch.all(d[:, -1] == 1)
+    L = (d == 0).sum(1) + 1
+    assert int(L.min()) >= T // 2 and int(L.max()) <= T
+    assert torch.equal(dones, de[:, :, None, :].expand_as(dones))
+    assert torch.all(av[..., 0] == 1) and 0.75 < float(av[..., 1:].mean()) < 0.85
+    s = pb.sample_inds(np.array([0, 47, 12]))
+    assert tuple(s[0].shape) == (N, T + 1, 3, dims.obs_dim)

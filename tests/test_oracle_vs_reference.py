@@ -1,5 +1,7 @@
 """Live pin of the oracle and of our host-side logic against the REAL reference (only where /root/reference exists,
 i.e. the build container; skipped on the GPU box)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -102,16 +104,18 @@ def test_ring_bookkeeping_matches_reference_buffer():
         assert ring.current_i == buf.policy_buffers["policy_0"].current_i
 
 
-def test_timed_oracle_path_runs_at_reference_speed():
+@pytest.mark.parametrize("workload,n_threads", [("3m", 1), ("3s5z", 8)])
+def test_timed_oracle_path_runs_at_reference_speed(workload, n_threads):
     """bench.py's cpu_baseline times oracle.qmix_oracle under `reference_speed_ops()` + `fused_gru=True` because the
     GPU box has no /root/reference. That timed path must (a) give the values of the explicit-formula oracle and (b) run
-    at the real reference's speed: >= 0.9x its steps/s here, interleaved best-of-5, same data, same indices, 1 thread
-    (the reference's default n_training_threads, config.py:17). SMAC 3m dimensions, B=32."""
+    at the real reference's speed: >= 0.9x its steps/s here, interleaved best-of-5, same data, same indices -- at SMAC 3m with
+    1 thread (the reference's default n_training_threads, config.py:17) and at 3s5z with 8 threads, the configuration and
+    thread count the bench's `speedup_vs_cpu` divides by. B=32."""
     import time
     from oracle import qmix_oracle as O
     from offpolicy_amd.utils.synth import DIMS, synth_episodes, as_policy_dicts
-    dims = DIMS["3m"]
-    n_ep, B = 64, 32
+    dims = DIMS[workload]
+    n_ep, B = (64, 32) if workload == "3m" else (40, 32)
     load_reference()
     from gym.spaces import Discrete
     from offpolicy.algorithms.qmix.algorithm.QMixPolicy import QMixPolicy
@@ -144,7 +148,7 @@ def test_timed_oracle_path_runs_at_reference_speed():
         np.testing.assert_allclose(fast.agent[k].numpy(), slow.agent[k].numpy(), atol=1e-6, err_msg=k)
 
     threads = torch.get_num_threads()
-    torch.set_num_threads(1)
+    torch.set_num_threads(min(n_threads, os.cpu_count() or 1))
     try:
         rng = np.random.RandomState(2)
 
@@ -158,7 +162,7 @@ def test_timed_oracle_path_runs_at_reference_speed():
                 fast.train_step(O.sample_inds(store, rng.choice(n_ep, B)), fused_gru=True, soft_update=True)
         best = {"ref": 1e9, "orc": 1e9}
         ref_step(); orc_step()
-        for _ in range(5):
+        for _ in range(5 if workload == "3m" else 3):
             for name, f in (("ref", ref_step), ("orc", orc_step)):
                 t0 = time.perf_counter()
                 f(); f()
