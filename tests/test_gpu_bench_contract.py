@@ -51,8 +51,11 @@ def test_default_workload_line_has_roofline_and_cpu_baseline():
     # the step are there, their durations add up to about the step, every GEMM-shaped one has a fraction of the matrix roof
     pk = rs["per_kernel"]
     names = [k["kernel"] for k in pk["kernels"]]
-    for want in ("trunk_fwd", "gru_fwd4", "gru_bwd4", "wgrad_kernel", "episode_copy_kernel", "adam_kernel"):
+    for want in ("trunk_fwd", "gru_fwd4", "gru_bwd4", "episode_copy_kernel", "adam_kernel"):
         assert any(want in n for n in names), (want, names)
+    # the weight gradients: the register-blocked launch + its slab sum, or the tile-per-wave one + split_reduce
+    assert all(any(w in n for n in names) for w in ("wgrad2_kernel", "w2_reduce_kernel")) or \
+        all(any(w in n for n in names) for w in ("wgrad_kernel", "split_reduce_kernel")), names
     # the (t, b)-row chain: the fused pair, or the four separate launches
     assert all(any(w in n for n in names) for w in ("qchain_kernel", "mixer_hyp_kernel")) or \
         all(any(w in n for n in names) for w in ("mixer_fwd", "mixer_bwd4", "head_fwd_mfma", "head_bwd_rows")), names
