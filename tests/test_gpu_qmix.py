@@ -26,6 +26,7 @@ CASES = ["qmix_tiny", "qmix_tiny_huber_per", "qmix_tiny_nodouble", "vdn_tiny", "
          # tanh in the agent network's MLP base (--use_ReLU off, mlp.py:9-12): trunk_fwd3 / trunk_bwd3 carry it
          "qmix_shape_tanh", "qmix_var_tanh_d252", "qmix_var_tanh_odd", "vdn_var_tanh"]
 RTOL = 1e-4
+GRAD_TOL = 2e-3      # of the tensor's max magnitude (achieved errors: profiles/r05_parity_errors.txt)
 
 
 def _flat_named(trainer, flat):
@@ -56,9 +57,13 @@ def test_train_steps_match_reference(name):
             cnt = float(trainer.grad[trainer.numel + 1])
             coef = min(1.0, float(g["hp_maxnorm"]) / (float(g["grad_norm"][0]) + 1e-6))
             got = _flat_named(trainer, trainer.grad[:trainer.numel] * (coef / cnt))
+            worst = {}
             for k, ref in sub(g, "grad0/").items():
-                tol = 2e-3 * max(np.abs(ref).max(), 1e-6)
+                tol = GRAD_TOL * max(np.abs(ref).max(), 1e-6)
+                worst[k] = float(np.abs(got[k] - ref).max() / max(np.abs(ref).max(), 1e-6))
                 np.testing.assert_allclose(got[k], ref, rtol=0, atol=tol, err_msg="grad " + k)
+            from golden_util import record_errors
+            record_errors("qmix_grad0:" + name, {"worst": max(worst.values()), "tensor": max(worst, key=worst.get)})
             for k in got:
                 if ".fc_h." in k:
                     assert not np.any(got[k]), k
