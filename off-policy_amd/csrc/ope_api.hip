@@ -470,7 +470,9 @@ static int qmix_step(const ope_qmix_cfg* cfg, const ope_fields* batch, const ope
   td.B = p.B; td.N = p.N; td.gamma = cfg->gamma; td.use_huber = cfg->use_huber; td.huber_delta = cfg->huber_delta;
   td.rewards = batch->rewards; td.dones_env = batch->dones_env; td.per_weights = cfg->use_per ? per_weights : nullptr;
 
-  bool hyp_on_side = false;
+  bool hyp_on_side = false, hyp_late = false;
+  HypFirstArgs hyp_args;
+  memset(&hyp_args, 0, sizeof(hyp_args));
   // ---- forward ----
   for (int c = 0; c < C && do_fwd; ++c) {
     const int64_t r0 = (int64_t)p.tb[c] * p.NB, rows = (int64_t)(p.tb[c + 1] - p.tb[c]) * p.NB;
@@ -517,13 +519,20 @@ static int qmix_step(const ope_qmix_cfg* cfg, const ope_fields* batch, const ope
         hy.out[1][HYP_HW1] = W + p.hw1_t; hy.out[1][HYP_HW2] = W + p.hw2_t; hy.out[1][HYP_HB2] = W + p.hb2_t; hy.out[1][HYP_HB1] = W + p.hb1_t;
         hy.out[0][HYP_V1] = W + p.v1; hy.out[0][HYP_V2] = W + p.v2; hy.out[1][HYP_V1] = W + p.v1_t; hy.out[1][HYP_V2] = W + p.v2_t;
         hy.side = tr;
-        // OPE_CHAIN_SIDE = 1: on the side stream, concurrent with the scan (fork behind the trunk launch, join in front of the chain kernel)
+        // OPE_CHAIN_SIDE = 1: on the side stream, concurrent with the scan (fork behind the trunk launch, join in front of the chain kernel);
+        // 2: the same, but launched BEHIND the scan (below), so that the scan's workgroups are resident first and the GEMM's workgroups
+        // take the slots that are left (the scan waves run at s_setprio 3)
         static const int side_env = getenv("OPE_CHAIN_SIDE") ? atoi(getenv("OPE_CHAIN_SIDE")) : 0;
         if (side_env) {
           if (!sp && !(sp = side_pool())) return OPE_ELAUNCH;
           if (hipEventRecord(sp->ev[0], st) != hipSuccess || hipStreamWaitEvent(sp->s, sp->ev[0], 0) != hipSuccess) return OPE_ELAUNCH;
-          if ((rc = launch_mixer_hyp(hy, sp->s))) return rc;
-          if (hipEventRecord(sp->ev[1], sp->s) != hipSuccess) return OPE_ELAUNCH;
+          if (side_env == 2) {
+            hyp_late = true;
+            hyp_args = hy;
+          } else {
+            if ((rc = launch_mixer_hyp(hy, sp->s))) return rc;
+            if (hipEventRecord(sp->ev[1], sp->s) != hipSuccess) return OPE_ELAUNCH;
+          }
           hyp_on_side = true;
         } else if ((rc = launch_mixer_hyp(hy, st))) return rc;
       }
@@ -540,6 +549,11 @@ static int qmix_step(const ope_qmix_cfg* cfg, const ope_fields* batch, const ope
     gf.rg = W + p.rg + r0 * OPE_H; gf.zg = W + p.zg + r0 * OPE_H; gf.ng = W + p.ng + r0 * OPE_H; gf.ghn = W + p.ghn + r0 * OPE_H;
     gf.dbg = dbg_on ? (long long*)(W + p.dbg) + 71168 : nullptr;
     if ((rc = launch_gru_fwd(gf, scan_st))) return rc;
+    if (hyp_late) {
+      if ((rc = launch_mixer_hyp(hyp_args, sp->s))) return rc;
+      if (hipEventRecord(sp->ev[1], sp->s) != hipSuccess) return OPE_ELAUNCH;
+      hyp_late = false;
+    }
     if (C > 1 && hipEventRecord(sp->scan_done[c], side) != hipSuccess) return OPE_ELAUNCH;
   }
   const bool ride = C == 1 && p.A <= 32 && do_fwd;       // launch_head_fwd(mode 0) picks head_fwd_mfma for A <= 32

@@ -84,6 +84,7 @@ __global__ void __launch_bounds__((W + 2) * 64) gru_fwd4_kernel(GruFwdArgs a) {
   float(*hs)[OPE_H] = reinterpret_cast<float(*)[OPE_H]>(sm);                        // [2][64]    h_t, parity of t
   float(*sv)[4][kPl] = reinterpret_cast<float(*)[4][kPl]>(sm + kSv);                // [2][4][64 (+ 16 unused)]
   constexpr float kL = -1.4426950408889634f;
+  __builtin_amdgcn_s_setprio(3);      // every instruction of a scan wave is on the step chain: win the issue arbitration against whatever shares the CU
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int rid = blockIdx.x;
   const int net = rid / a.NB;
@@ -291,6 +292,7 @@ __global__ void __launch_bounds__((W + 2) * 64) gru_bwd4_kernel(GruBwdArgs a) {
   __shared__ __attribute__((aligned(16))) float sm[8 * OPE_H + 12 * OPE_H];
   float(*ds)[4][OPE_H] = reinterpret_cast<float(*)[4][OPE_H]>(sm);                  // [2][4][64] dr_pre, dz_pre, dgn (broadcast) + dn_pre
   float(*sav)[6][OPE_H] = reinterpret_cast<float(*)[6][OPE_H]>(sm + 8 * OPE_H);     // [2][6][64] the step's factors (loader): a_n, a_r, a_g, a_z, z, dh_out
+  __builtin_amdgcn_s_setprio(3);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = blockIdx.x;
   const int64_t NB = a.NB;
