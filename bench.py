@@ -42,9 +42,11 @@ def parse():
     ap.add_argument("--batch", type=int, default=None, help="samples per training step on ONE GPU (weak) / in total (strong); "
                     "default 32 episodes (QMIX) or 256 transitions (MADDPG)")
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
-                    help="N > 1: what `value` reports. Default strong = BASELINE.json's multi-GPU configs (ONE batch of B samples "
-                         "sharded over the N GPUs, B/N per GPU); the weak-scaling throughput (B per GPU) is measured in the same run "
-                         "and reported beside it as `weak_scaling`. --scaling weak swaps the two.")
+                    help="N > 1: what `value` reports. Default weak: every GPU trains on its own B sampled episodes (per-GPU work fixed, global batch "
+                         "N x B, one gradient all-reduce per step) and `value` = batch-B steps/s over all GPUs = optimizer steps/s x N -- the units "
+                         "all ranks processed / the time, as the bench contract defines it for a path that shards. The strong-scaling number "
+                         "(ONE batch of B sharded over the N GPUs, B/N per GPU: BASELINE.json's 'batch_size=32, grads sharded over 8' read literally) "
+                         "is measured in the same run and reported beside it as `strong_scaling`. --scaling strong swaps the two.")
     ap.add_argument("--episodes", type=int, default=None, help="synthetic episodes resident in the replay store; default 5000 for the QMIX "
                     "workloads (the reference default buffer_size, config.py:37: 7.5 GB at 3s5z, far beyond the 256 MiB Infinity Cache), 512 "
                     "for the recurrent MADDPG family at MMM2 size (6.5 GB)")
@@ -387,8 +389,8 @@ def scaling_legs(a, batch, world):
     if world == 1:
         return [("weak", batch, batch)]
     assert batch % world == 0, "--batch must be a multiple of --gpus for the strong-scaling leg"
-    legs = [("strong", batch // world, batch), ("weak", batch, batch * world)]
-    return legs[::-1] if a.scaling == "weak" else legs
+    legs = [("weak", batch, batch * world), ("strong", batch // world, batch)]
+    return legs[::-1] if a.scaling == "strong" else legs
 
 
 def allreduce_name():

@@ -43,6 +43,7 @@ struct W2Table {
   W2Unit u[kMaxW2Units];
   int ubegin[kMaxW2Units];             // u[q].wg_begin again, contiguous (INT_MAX beyond nu): what a workgroup searches
   int np, nu, total_wg, red_blocks;
+  int vec;                             // 4 | 2: widest load every operand row of the table allows (picks the kernel and its ring depth)
 };
 bool w2_ok(const WgTable& tb);
 int w2_max_workgroups();

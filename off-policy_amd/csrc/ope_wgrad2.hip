@@ -35,7 +35,9 @@ namespace {
 // (116 per 192 MFMAs in the 4-tile bodies); a tied "+a" operand cannot be renamed. The statement is not volatile: the scheduler still moves
 // loads and VALU work between the MFMAs. Hazards the compiler no longer sees: none inside the loop (an accumulator is touched again >= 16
 // MFMAs later; A / B operands are read at issue), after it w2_mfma_drain() before the first accumulator read.
-constexpr int kW2Ring = 6;
+// operand buffers of the software pipeline: 4 with 16-byte loads, 6 with 8-byte ones (twice the load instructions per stage want the longer run-up;
+// measured, same box: 3s5z (VEC 4) 54.1-54.9 us with 4 against 56.2-56.5 with 6, MMM2 (VEC 2) 99.8-100.5 with 4 against 89.8-90.0 with 6)
+constexpr int w2_ring(int vec) { return vec == 4 ? 4 : 6; }
 __device__ __forceinline__ void w2_mfma(float a, float b, f32x4& c) {
   asm("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 }
@@ -65,7 +67,7 @@ __device__ __forceinline__ void w2_body(const WgProb& P, int mp0, int np0, int k
   constexpr int NT = PA * PB, F = PA + PB;
   constexpr int SUB = NT == 1 ? 2 : 1;          // groups of 4 rows per stage
   constexpr int SR = 4 * SUB;                   // rows per stage
-  constexpr int NB = kW2Ring;                   // operand buffers in rotation: the fetch of stage s + NB - 1 goes out during stage s
+  constexpr int NB = w2_ring(VEC);              // operand buffers in rotation: the fetch of stage s + NB - 1 goes out during stage s
   constexpr int NG = NT * 8 * SUB;              // pairs of MFMAs per stage
   constexpr int NPF = SUB * (F + 2);            // fetch pieces per stage: per row group the row indices, one load per fragment, the LayerNorm pair
   constexpr int NP = NPF + SUB * F;             // + one preparation per fragment
@@ -379,6 +381,15 @@ bool w2_ok(const WgTable& tb) {
   return true;
 }
 
+// 16-byte loads when every operand row of the table allows them, 8-byte ones otherwise (w2_ok has checked that much)
+static int w2_vec(const WgTable& tb) {
+  for (int q = 0; q < tb.n; ++q) {
+    const WgProb& P = tb.p[q];
+    if (!(P.lda % 4 == 0 && P.ldb % 4 == 0 && !((uintptr_t)P.A & 15) && !((uintptr_t)P.B & 15) && (!P.A2 || (P.lda2 % 4 == 0 && !((uintptr_t)P.A2 & 15))))) return 2;
+  }
+  return 4;
+}
+
 // Units and their workgroups. `tb` must have gone through wg_finish (mt / nt). Returns OPE_EINVAL when the table does not fit.
 int w2_build(const WgTable& tb, W2Table* out) {
   W2Table& w = *out;
@@ -412,7 +423,8 @@ int w2_build(const WgTable& tb, W2Table* out) {
   // workgroups: greedy on the per-wave cost tiles x (rows per wave + a fixed prologue), one more workgroup at a time to the unit
   // whose waves are longest; a wave keeps at least 32 rows
   const int cap = w2_max_workgroups();
-  auto rows_of = [&](const W2Unit& U) { const int gr = (U.pa * U.pb == 1 ? 8 : 4) * kW2Ring; return gr * ope_cdiv(ope_cdiv(w.p[U.prob].K, 4 * U.nwg), gr); };      // (whole rotations of the operand ring)
+  const int ring = w2_ring(w2_vec(tb));
+  auto rows_of = [&](const W2Unit& U) { const int gr = (U.pa * U.pb == 1 ? 8 : 4) * ring; return gr * ope_cdiv(ope_cdiv(w.p[U.prob].K, 4 * U.nwg), gr); };      // (whole rotations of the operand ring)
   auto cost_of = [&](const W2Unit& U) { return (int64_t)U.pa * U.pb * (rows_of(U) + 16); };
   if (w.nu > cap) return OPE_EINVAL;
   bool frozen[kMaxW2Units] = {};
@@ -424,7 +436,7 @@ int w2_build(const WgTable& tb, W2Table* out) {
       int64_t bc = -1;
       for (int q = 0; q < w.nu; ++q) {
         const W2Unit& U = w.u[q];
-        if (frozen[q] || rows_of(U) <= 8 * kW2Ring) continue;
+        if (frozen[q] || rows_of(U) <= 8 * ring) continue;
         const int64_t c = cost_of(U);
         if (c > bc) { bc = c; best = q; }
       }
@@ -488,16 +500,13 @@ int w2_build(const WgTable& tb, W2Table* out) {
   for (int q = 0; q < kMaxW2Units; ++q) w.ubegin[q] = q < w.nu ? w.u[q].wg_begin : 0x7fffffff;
   w.total_wg = wg;
   w.red_blocks = rb;
+  w.vec = w2_vec(tb);
   return OPE_OK;
 }
 
 int launch_wgrad2(const W2Table& w, float* raw, float* rsum, hipStream_t st) {
   if (w.nu < 1 || w.total_wg < 1) return OPE_EINVAL;
-  bool v4 = true;
-  for (int q = 0; q < w.np; ++q) {
-    const WgProb& P = w.p[q];
-    v4 = v4 && P.lda % 4 == 0 && P.ldb % 4 == 0 && !((uintptr_t)P.A & 15) && !((uintptr_t)P.B & 15);
-  }
+  const bool v4 = w.vec == 4;
   if (g_kprof_on) {
     double fl = 0;
     for (int q = 0; q < w.np; ++q) fl += 2.0 * w.p[q].M * (double)w.p[q].N * w.p[q].K;
