@@ -1,7 +1,8 @@
 """MADDPG / MATD3 policy: actor + centralised critic (+ targets, optimizer state) on flat CUDA vectors.
 
 Mirror of offpolicy/algorithms/maddpg/algorithm/MADDPGPolicy.py:11-151 for discrete (one-hot) and, round 4, continuous (Box) action
-spaces (an action = the actor's output, MADDPGPolicy.py:107-116; multi-discrete spaces are refused). The four
+spaces (an action = the actor's output, MADDPGPolicy.py:107-116) and multi-discrete ones (MADDPGPolicy.py:73-92: one argmax / hard
+gumbel-softmax per sub-action block of the one stacked head; up to six sub-actions). The four
 networks are drawn in the reference's construction order (actor, critic, target actor, target critic) so equal seeds
 give equal weights -- including the target critic's own random Q heads, which upstream never synchronises (A-4).
 """
@@ -83,8 +84,12 @@ class MADDPGPolicy(object):
         self.num_q = 2 if td3 else 1
         # the joint action is this policy's width times the number of agents, unless policies of OTHER action dimensions share the critic
         # (share_policy = False on e.g. simple_speaker_listener): then only its total width is known here (ope_ddpg_cfg.joint_act_dim)
+        # `policy_config["num_agents"]` (optional, what a caller that knows it should pass) settles it; without it the guess below holds for one
+        # shared policy and can be WRONG for policies of different widths that happen to divide the total (2 and 4 of 8) -- the trainers
+        # overwrite dims.n_agents / joint_act_dim with the real layout before any launch, so nothing on the update path reads the guess
         self.mixed_act_dims = self.central_act_dim % self.output_dim != 0
-        self.num_agents = 1 if self.mixed_act_dims else self.central_act_dim // self.output_dim
+        self.num_agents = int(policy_config["num_agents"]) if "num_agents" in policy_config else (
+            1 if self.mixed_act_dims else self.central_act_dim // self.output_dim)
         self.frozen_q_head = bool(frozen_q_head)
         cfg = self.ddpg_cfg(1)
         dev, a = self.device, self.args

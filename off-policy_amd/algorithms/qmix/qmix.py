@@ -54,7 +54,8 @@ class QMix(object):
                  vdn=False):
         self.args = args
         # (the policies check their own support); one-layer hyper-networks: recurrent nets, one shared policy (checked below)
-        require_reference_architecture(args, allow_prev_act_inp=not self._mlp, allow_hypernet_layers_1=not self._mlp and not vdn,
+        # (VDN has no hyper-networks: args.hypernet_layers is irrelevant there and is ignored -- ADVICE r4)
+        require_reference_architecture(args, allow_prev_act_inp=not self._mlp, allow_hypernet_layers_1=vdn or not self._mlp,
                                        allow_layer_N_2=not self._mlp, allow_no_feature_norm=not self._mlp, allow_tanh=not self._mlp)
         self.layer_N = int(getattr(args, "layer_N", 1))
         self.dims_flags = (0 if getattr(args, "use_feature_normalization", True) else _lib.OPE_DIMS_NO_FEATURE_NORM) | \
@@ -92,7 +93,7 @@ class QMix(object):
         self._gsq = {}
         if self.multi and (self.hypernet_layers == 1 or self.layer_N != 1 or self.dims_flags):
             raise NotImplementedError("hypernet_layers=1 / layer_N=2 / use_feature_normalization=False with several policies is not on the accelerated path")
-        if self.dims_flags and float(getattr(args, "weight_decay", 0.0) or 0.0) != 0.0:
+        if (self.dims_flags & _lib.OPE_DIMS_NO_FEATURE_NORM) and float(getattr(args, "weight_decay", 0.0) or 0.0) != 0.0:
             raise NotImplementedError("use_feature_normalization=False with weight_decay: the constant feature_norm slots of the flat vector would decay")
         if self.multi:
             self._init_multi()

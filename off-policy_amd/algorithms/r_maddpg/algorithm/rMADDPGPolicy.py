@@ -43,8 +43,11 @@ class R_MADDPGPolicy(object):
         self.num_q = 2 if td3 else 1
         # the joint action is this policy's width times the number of agents, unless policies of OTHER action dimensions share the critic
         # (share_policy = False on e.g. simple_speaker_listener): then only its total width is known here (ope_rddpg_cfg.joint_act_dim)
+        # (`policy_config["num_agents"]`, optional, settles it; the guess can be wrong for policies of different widths that divide the total --
+        # the trainer overwrites dims.n_agents / joint_act_dim with the real layout before any launch: MADDPGPolicy.py has the same note)
         self.mixed_act_dims = self.central_act_dim % self.output_dim != 0
-        self.num_agents = 1 if self.mixed_act_dims else self.central_act_dim // self.output_dim
+        self.num_agents = int(policy_config["num_agents"]) if "num_agents" in policy_config else (
+            1 if self.mixed_act_dims else self.central_act_dim // self.output_dim)
         cfg = self.rddpg_cfg(1, 1)
         dev = self.device
         cin = self.central_obs_dim + self.central_act_dim

@@ -311,6 +311,11 @@ class RecPolicyBuffer(object):
         if torch.is_tensor(sample_inds):     # indices already on the device (HIP-graph replays keep them in a static tensor)
             assert sample_inds.dtype == torch.int64 and sample_inds.device == self.device, (sample_inds.dtype, sample_inds.device)
             dev_inds, B = sample_inds.contiguous(), int(sample_inds.shape[0])
+            if lazy:
+                # a StoreObs keeps its indices past this call (the step reads the rows through them): it gets its OWN copy, so that a
+                # caller that rewrites its index tensor before the step runs cannot redirect the rows (the graphed steps pass
+                # lazy_obs=False: their kernels read the static tensor on purpose)
+                dev_inds = dev_inds.clone()
         else:
             inds = np.ascontiguousarray(np.asarray(sample_inds, dtype=np.int64))
             B = int(inds.shape[0])

@@ -712,3 +712,39 @@ def test_graphed_step_matches_reference(gather_in_graph):
     for grp, src in (("final_agent/", live), ("final_agent_tgt/", tgt)):
         for k, ref in sub(g, grp).items():
             np.testing.assert_allclose(src["agent/" + k], ref, rtol=0, atol=3e-5, err_msg=grp + k)
+
+
+def test_vdn_ignores_hypernet_layers_and_tanh_accepts_weight_decay():
+    """VDN has no hyper-networks, so `--hypernet_layers 1` must not be refused for it (the reference runs it; same results
+    as the default); and `use_ReLU = False` alone leaves no constant slot in the flat vector, so a non-zero args.weight_decay (which QMix's
+    Adam ignores anyway, A-8) is no reason to refuse the configuration."""
+    from gpu_util import make_args
+    from offpolicy_amd.utils.synth import policy_info_for
+    from offpolicy_amd.algorithms.qmix.algorithm.QMixPolicy import QMixPolicy
+    from offpolicy_amd.algorithms.qmix.qmix import QMix
+    g = load_golden("vdn_tiny")
+    dims, buf, policy, trainer = build_from_fixture(g)
+    args = make_args(g, hypernet_layers=1)
+    dev = torch.device("cuda:0")
+    pol1 = QMixPolicy({"args": args, "device": dev}, policy_info_for(dims)["policy_0"])
+    tr1 = QMix(args, dims.n_agents, {"policy_0": pol1}, lambda a: "policy_0", device=dev, episode_length=dims.episode_length, vdn=True)
+    pol1.q_network.load_state_dict(policy.q_network.state_dict())
+    tr1.hard_target_updates()
+    batch = batch_from(buf, g["inds"])
+    a, _, _ = trainer.train_policy_on_batch(batch)
+    b, _, _ = tr1.train_policy_on_batch(batch)
+    assert float(a["loss"]) == float(b["loss"]) and torch.equal(trainer.theta, tr1.theta)
+    np.testing.assert_allclose(float(a["loss"]), g["loss"][0], rtol=RTOL)
+    gt = load_golden("qmix_shape_tanh")
+    args_t = make_args(gt, weight_decay=0.01)
+    pol_t = QMixPolicy({"args": args_t, "device": dev}, policy_info_for(fixture_dims_of(gt))["policy_0"])
+    QMix(args_t, int(gt["dims"][0]), {"policy_0": pol_t}, lambda a: "policy_0", device=dev, episode_length=int(gt["dims"][4]))
+    with pytest.raises(NotImplementedError):
+        args_n = make_args(load_golden("qmix_shape_nofn"), weight_decay=0.01)
+        pol_n = QMixPolicy({"args": args_n, "device": dev}, policy_info_for(fixture_dims_of(gt))["policy_0"])
+        QMix(args_n, int(gt["dims"][0]), {"policy_0": pol_n}, lambda a: "policy_0", device=dev, episode_length=int(gt["dims"][4]))
+
+
+def fixture_dims_of(g):
+    from golden_util import fixture_dims
+    return fixture_dims(g)
