@@ -62,6 +62,11 @@ typedef struct ope_dims {
  * register-resident trunk kernels (trunk_fwd3 / trunk_bwd3) carry the activation -- tanh as 2 / (1 + 2^(-2 log2(e) x)) - 1, its
  * derivative 1 - a^2 rebuilt from the saved normalised activation, 1/std and the row mean (kept in the slot of the unused ReLU mask). */
 #define OPE_DIMS_TANH 2
+/* Plain (non double-Q) targets take the maximum over the AVAILABLE actions only (avail_acts at t + 1), as the double-Q greedy choice
+ * always does. The reference's Discrete QMIX / VDN does not (qmix.py:148: target_policy.get_actions(..., available_actions=None)); the
+ * flag exists for MultiDiscrete action spaces on the accelerated path, where every (agent, sub-action) pair is presented to the kernels
+ * as one agent whose availability mask is its sub-action's block of the stacked q head (QMixPolicy.py:76-93: per-head max). */
+#define OPE_DIMS_MASK_TARGET_MAX 4
 
 /* Seven per-episode fields, in the order of RecPolicyBuffer.sample_inds' return tuple
  * (offpolicy/utils/rec_buffer.py:192-240): obs, share_obs, acts, rewards, dones, dones_env, avail_acts -- plus the

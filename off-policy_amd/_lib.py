@@ -32,6 +32,7 @@ class Dims(C.Structure):
 
 OPE_DIMS_NO_FEATURE_NORM = 1
 OPE_DIMS_TANH = 2
+OPE_DIMS_MASK_TARGET_MAX = 4
 
 
 class Fields(C.Structure):

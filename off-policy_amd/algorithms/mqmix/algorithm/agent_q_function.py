@@ -35,7 +35,7 @@ def mlp_agent_layout(obs_dim, act_dim):
     return list(off)[:16], list(siz)[:16], int(total)
 
 
-def init_mlp_agent_values(obs_dim, act_dim, use_orthogonal=True, gain_out=0.01, use_ReLU=True):
+def init_mlp_agent_values(obs_dim, act_dim, use_orthogonal=True, gain_out=0.01, use_ReLU=True, head_dims=None):
     """MLPBase (mlp.py:52-74) then ACTLayer (act.py:5-19), drawn in the reference's order."""
     init_w = nn.init.orthogonal_ if use_orthogonal else nn.init.xavier_uniform_
     gain = nn.init.calculate_gain("relu" if use_ReLU else "tanh")
@@ -43,35 +43,71 @@ def init_mlp_agent_values(obs_dim, act_dim, use_orthogonal=True, gain_out=0.01, 
     init_w(fc1.weight.data, gain=gain)
     fch = nn.Linear(H, H)
     init_w(fch.weight.data, gain=gain)
-    qo = nn.Linear(H, act_dim)
-    init_w(qo.weight.data, gain=gain_out)
+    if head_dims is None:
+        qo = nn.Linear(H, act_dim)
+        init_w(qo.weight.data, gain=gain_out)
+        qw = qo.weight.data
+    else:      # MultiDiscrete (act.py:14-17): one Linear per sub-action, in order; stacked = the kernels' one head
+        heads = []
+        for d in head_dims:
+            lin = nn.Linear(H, int(d))
+            init_w(lin.weight.data, gain=gain_out)
+            heads.append(lin.weight.data)
+        qw = torch.cat(heads, dim=0)
     one, zero = torch.ones, torch.zeros
     vals = [one(obs_dim), zero(obs_dim), fc1.weight.data, zero(H), one(H), zero(H), fch.weight.data, zero(H), one(H), zero(H),
-            fch.weight.data.clone(), zero(H), one(H), zero(H), qo.weight.data, zero(act_dim)]
+            fch.weight.data.clone(), zero(H), one(H), zero(H), qw, zero(act_dim)]
     return [v.detach().float() for v in vals]
 
 
 class AgentQFunction(FlatModule):
     def __init__(self, args, input_dim, act_dim, device, flat=None, _init=True):
+        """`act_dim`: an int, or the array of a MultiDiscrete space's sub-action sizes: the one stacked head's row blocks are then exposed
+        under upstream's names `q.action_outs.{i}.weight / .bias` (act.py:14-17), as in the recurrent module."""
+        import numpy as np
+        head_dims = None
+        if np.ndim(act_dim) != 0:
+            head_dims = [int(d) for d in np.asarray(act_dim).reshape(-1)]
+            act_dim = int(sum(head_dims))
+        self.head_dims = head_dims
         input_dim, act_dim, device = int(input_dim), int(act_dim), torch.device(device)
         offs, sizes, total = mlp_agent_layout(input_dim, act_dim)
         own = flat is None
         if own:
             flat = torch.zeros(total, dtype=torch.float32, device=device)
-        super().__init__(MLP_AGENT_PARAM_NAMES, mlp_agent_param_shapes(input_dim, act_dim), offs, flat)
+        names, shapes = list(MLP_AGENT_PARAM_NAMES), mlp_agent_param_shapes(input_dim, act_dim)
+        if head_dims is not None:
+            ow, ob = offs[-2], offs[-1]
+            names, shapes, offs = names[:-2], shapes[:-2], list(offs[:-2])
+            lo = 0
+            for i, d in enumerate(head_dims):
+                names += ["q.action_outs.%d.weight" % i, "q.action_outs.%d.bias" % i]
+                shapes += [(d, H), (d,)]
+                offs += [ow + lo * H, ob + lo]
+                lo += d
+        super().__init__(names, shapes, offs, flat)
         self.input_dim, self.act_dim, self.hidden_size, self.device = input_dim, act_dim, H, device
         self.padded_numel = total
         self._args = args
         if own and _init:
             vals = init_mlp_agent_values(input_dim, act_dim, getattr(args, "use_orthogonal", True), getattr(args, "gain", 0.01),
-                                         getattr(args, "use_ReLU", True))
+                                         getattr(args, "use_ReLU", True), head_dims=head_dims)
+            if head_dims is not None:
+                qw, qb = vals[-2], vals[-1]
+                vals = vals[:-2]
+                lo = 0
+                for d in head_dims:
+                    vals += [qw[lo:lo + d], qb[lo:lo + d]]
+                    lo += d
             for p, v in zip(self.parameters(), vals):
                 p.data.copy_(v)
         self._dims = _lib.Dims(1, act_dim, input_dim, 1, 1)
         self._ws = None
 
     def twin(self, flat):
-        return AgentQFunction(self._args, self.input_dim, self.act_dim, self.device, flat=flat, _init=False)
+        import numpy as np
+        return AgentQFunction(self._args, self.input_dim, np.asarray(self.head_dims) if self.head_dims is not None else self.act_dim, self.device,
+                              flat=flat, _init=False)
 
     def forward(self, x):
         x = torch.as_tensor(x, dtype=torch.float32, device=self.device).contiguous()

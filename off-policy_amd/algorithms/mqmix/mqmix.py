@@ -59,4 +59,6 @@ class M_QMix(QMix):
         if navail_b is not None and navail_b[pid] is not None:
             cur = avail_b[pid] if (avail_b is not None and avail_b[pid] is not None) else torch.ones_like(f(navail_b[pid]))
             avail = _stack_pair(cur, navail_b[pid], dev)                     # only the NEXT slice is read (mqmix.py:158-160)
+        if self._md_heads is not None:      # MultiDiscrete: one kernel-level agent per (agent, sub-action) (QMix._md_expand)
+            obs, acts, rew, avail = self._md_expand(obs, acts, rew, avail)
         return self._train_on_device_batch(obs, share, acts, rew, dones_env, avail, importance_weights, idxes)

@@ -67,7 +67,7 @@ def agent_layout(obs_dim, act_dim, layer_N=1):
     return list(off)[:n], list(siz)[:n], int(total)
 
 
-def init_agent_values(obs_dim, act_dim, use_orthogonal=True, gain_out=0.01, use_ReLU=True, layer_N=1):
+def init_agent_values(obs_dim, act_dim, use_orthogonal=True, gain_out=0.01, use_ReLU=True, layer_N=1, head_dims=None):
     """Initial values in named_parameters() order, drawn exactly as the reference's constructors draw them:
     nn.Linear default init then orthogonal_/xavier_uniform_ re-init (mlp.py:12-23, util.py:113-116), nn.GRU default
     init then per-parameter re-init (rnn.py:8-16), head with gain=args.gain (act.py:10-12). Biases 0, LayerNorms 1/0."""
@@ -83,19 +83,37 @@ def init_agent_values(obs_dim, act_dim, use_orthogonal=True, gain_out=0.01, use_
             nn.init.constant_(p, 0)
         elif "weight" in name:
             init_w(p)
-    qo = nn.Linear(H, act_dim)
-    init_w(qo.weight.data, gain=gain_out)
+    if head_dims is None:
+        qo = nn.Linear(H, act_dim)
+        init_w(qo.weight.data, gain=gain_out)
+        qw = qo.weight.data
+    else:      # MultiDiscrete (act.py:14-17): one Linear per sub-action, constructed (and re-initialised) in order; stacked = the kernels' one head
+        heads = []
+        for d in head_dims:
+            lin = nn.Linear(H, int(d))
+            init_w(lin.weight.data, gain=gain_out)
+            heads.append(lin.weight.data)
+        qw = torch.cat(heads, dim=0)
+        assert qw.shape[0] == act_dim
     one, zero = torch.ones, torch.zeros
     vals = [one(obs_dim), zero(obs_dim), fc1.weight.data, zero(H), one(H), zero(H),
             fch.weight.data, zero(H), one(H), zero(H),                       # fc_h (registered, unused)
             ] + [fch.weight.data.clone(), zero(H), one(H), zero(H)] * layer_N + [        # fc2[i] = deepcopy(fc_h) (mlp.py:23): identical clones
             gru.weight_ih_l0.data, gru.weight_hh_l0.data, zero(3 * H), zero(3 * H), one(H), zero(H),
-            qo.weight.data, zero(act_dim)]
+            qw, zero(act_dim)]
     return [v.detach().float() for v in vals]
 
 
 class AgentQFunction(FlatModule):
     def __init__(self, args, input_dim, act_dim, device, flat=None, _init=True):
+        """`act_dim`: an int (Discrete), or the array of a MultiDiscrete space's sub-action sizes (agent_q_function.py:27 hands it to ACTLayer,
+        act.py:14-17: one Linear head per sub-action). The kernels carry ONE stacked head of sum(act_dim) rows; this module exposes its row
+        blocks under upstream's names `q.action_outs.{i}.weight / .bias` (same names, shapes and order in named_parameters() / state_dict())."""
+        head_dims = None
+        if np.ndim(act_dim) != 0:
+            head_dims = [int(d) for d in np.asarray(act_dim).reshape(-1)]
+            act_dim = int(sum(head_dims))
+        self.head_dims = head_dims
         input_dim, act_dim, device = int(input_dim), int(act_dim), torch.device(device)
         self.layer_N = int(getattr(args, "layer_N", 1))
         if self.layer_N not in (1, 2):
@@ -110,7 +128,18 @@ class AgentQFunction(FlatModule):
             flat = torch.zeros(total, dtype=torch.float32, device=device)
         names, shapes = agent_param_names(self.layer_N), agent_param_shapes(input_dim, act_dim, self.layer_N)
         keep = [i for i, k in enumerate(names) if self.feature_norm or not k.startswith("rnn.feature_norm.")]
-        super().__init__([names[i] for i in keep], [shapes[i] for i in keep], [offs[i] for i in keep], flat)
+        names, shapes, offs_k = [names[i] for i in keep], [shapes[i] for i in keep], [offs[i] for i in keep]
+        if head_dims is not None:      # the stacked head's row blocks under upstream's per-head names (weight, bias per head, in order)
+            assert names[-2:] == ["q.action_out.weight", "q.action_out.bias"]
+            ow, ob = offs_k[-2], offs_k[-1]
+            names, shapes, offs_k = names[:-2], shapes[:-2], offs_k[:-2]
+            lo = 0
+            for i, d in enumerate(head_dims):
+                names += ["q.action_outs.%d.weight" % i, "q.action_outs.%d.bias" % i]
+                shapes += [(d, H), (d,)]
+                offs_k += [ow + lo * H, ob + lo]
+                lo += d
+        super().__init__(names, shapes, offs_k, flat)
         if not self.feature_norm:      # the two slots the kernels still read: gamma = 1, beta = 0, never trained (ope.h, OPE_DIMS_NO_FEATURE_NORM)
             with torch.no_grad():
                 flat[offs[0]:offs[0] + input_dim] = 1.0
@@ -120,8 +149,16 @@ class AgentQFunction(FlatModule):
         self._args = args
         if own and _init:
             vals = init_agent_values(input_dim, act_dim, getattr(args, "use_orthogonal", True),
-                                     getattr(args, "gain", 0.01), getattr(args, "use_ReLU", True), self.layer_N)
-            for p, v in zip(self.parameters(), [vals[i] for i in keep]):
+                                     getattr(args, "gain", 0.01), getattr(args, "use_ReLU", True), self.layer_N, head_dims=head_dims)
+            vals = [vals[i] for i in keep]
+            if head_dims is not None:      # split the stacked head's values the way its rows are exposed
+                qw, qb = vals[-2], vals[-1]
+                vals = vals[:-2]
+                lo = 0
+                for d in head_dims:
+                    vals += [qw[lo:lo + d], qb[lo:lo + d]]
+                    lo += d
+            for p, v in zip(self.parameters(), vals):
                 p.data.copy_(v)
         self._dims = _lib.Dims(1, act_dim, input_dim, 1, 1, self.layer_N,
                                (0 if self.feature_norm else _lib.OPE_DIMS_NO_FEATURE_NORM) | (0 if self.use_relu else _lib.OPE_DIMS_TANH))
@@ -129,7 +166,8 @@ class AgentQFunction(FlatModule):
 
     def twin(self, flat):
         """Same structure bound to another flat vector (used for target networks)."""
-        return AgentQFunction(self._args, self.input_dim, self.act_dim, self.device, flat=flat, _init=False)
+        return AgentQFunction(self._args, self.input_dim, np.asarray(self.head_dims) if self.head_dims is not None else self.act_dim, self.device,
+                              flat=flat, _init=False)
 
     def forward(self, obs, rnn_states):
         """q values for every action and the new hidden state (agent_q_function.py:34-67).

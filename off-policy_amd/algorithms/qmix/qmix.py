@@ -101,8 +101,22 @@ class QMix(object):
                 print("double Q learning will be used")
             return
         policy = self.policies["policy_0"]
+        # MultiDiscrete action space (qmix.py:49-57, QMixPolicy.py:76-93): one q head per sub-action, one mixer input per (agent, sub-action).
+        # The kernels know one head and one q value per agent, so every (agent, sub-action) pair is presented to them as an agent of its
+        # own -- same observation rows, the stacked head of sum(act_dim) outputs, and an availability mask that is 1 on the sub-action's
+        # block only (upstream passes no masks for these spaces), which restricts the greedy / target choices to that block; the chosen
+        # action's q comes from the block's part of the stored one-hot row (`_md_expand`). Parameter gradients are sums over rows, so the
+        # shared trunk / GRU, evaluated once per pair, gets exactly the sum of the heads' contributions. Costs n_heads x the agent-network
+        # work: these spaces are MPE-sized.
+        self._md_heads = list(policy.head_dims) if getattr(policy, "multidiscrete", False) else None
+        if self._md_heads is not None:
+            if self.vdn:
+                raise NotImplementedError("VDN with a MultiDiscrete action space (upstream's VDNMixer fails on the recurrent trainer's input there too)")
+            self.dims_flags |= _lib.OPE_DIMS_MASK_TARGET_MAX      # plain (non double-Q) targets: the per-head maximum
+        self._n_kernel_agents = num_agents * (len(self._md_heads) if self._md_heads is not None else 1)
+        self.num_mixer_q_inps = self._n_kernel_agents
         # the kernels see the network's input width: observation (+ previous one-hot action with prev_act_inp)
-        self._dims = _lib.Dims(num_agents, policy.act_dim, policy.q_network_input_dim, policy.central_obs_dim, self.episode_length, self.layer_N, self.dims_flags)
+        self._dims = _lib.Dims(self._n_kernel_agents, policy.output_dim, policy.q_network_input_dim, policy.central_obs_dim, self.episode_length, self.layer_N, self.dims_flags)
 
         # ---- flat vectors: [agent | mixer], padded per tensor to 4 floats -------------------------------
         cfg = self._cfg(1)
@@ -121,7 +135,7 @@ class QMix(object):
         if self.vdn:
             self.mixer = VDNMixer(args, num_agents, policy.central_obs_dim, self.device)
         else:
-            self.mixer = QMixer(args, num_agents, policy.central_obs_dim, self.device, self.theta,
+            self.mixer = QMixer(args, self._n_kernel_agents, policy.central_obs_dim, self.device, self.theta,
                                 list(off)[n_agent_tensors:n_agent_tensors + n_mixer_tensors])
         # target networks: deep copies at construction (qmix.py:63-64)
         self.theta_tgt = self.theta.clone()
@@ -129,7 +143,7 @@ class QMix(object):
         if self.vdn:
             self.target_mixer = VDNMixer(args, num_agents, policy.central_obs_dim, self.device)
         else:
-            self.target_mixer = QMixer(args, num_agents, policy.central_obs_dim, self.device, self.theta_tgt,
+            self.target_mixer = QMixer(args, self._n_kernel_agents, policy.central_obs_dim, self.device, self.theta_tgt,
                                        list(off)[n_agent_tensors:n_agent_tensors + n_mixer_tensors], init=False)
         self.parameters = list(policy.parameters()) + list(self.mixer.parameters())
         self.optimizer = FlatAdam(self.numel, self.lr, self.opti_eps, self.device)
@@ -376,7 +390,31 @@ class QMix(object):
             # qmix.py:123-124: the network input at step t is [obs_t | action taken at t-1], zeros at t = 0
             prev = torch.cat((torch.zeros_like(acts[:1]), acts), dim=0)
             obs = torch.cat((obs, prev), dim=-1).contiguous()
+        if self._md_heads is not None:
+            obs, acts, rew, avail = self._md_expand(obs, acts, rew, avail)
         return self._train_on_device_batch(obs, share, acts, rew, dones_env, avail, importance_weights, idxes)
+
+    def _md_expand(self, obs, acts, rew, avail):
+        """MultiDiscrete: the batch as the kernels see it -- one "agent" per (agent, sub-action), agent-major (the order upstream concatenates
+        the heads' q values in, QMixPolicy.py:76-93 + qmix.py:134-136). obs / rewards rows repeated per head; the stored action row keeps the
+        head's one-hot block only (its first maximum is then the sub-action taken); the availability mask is the head's block."""
+        assert avail is None, "MultiDiscrete action spaces come without availability masks"
+        if isinstance(obs, StoreObs):
+            obs = self._to_device_layout(obs.materialize(), True)
+        heads = self._md_heads
+        Hn, A = len(heads), int(sum(heads))
+        T1, N, B, _ = obs.shape
+        block = torch.zeros(Hn, A, **self.tpdv)
+        lo = 0
+        for h, d in enumerate(heads):
+            block[h, lo:lo + d] = 1.0
+            lo += d
+        mask = block.repeat(N, 1)[None, :, None, :]                                  # [1, N * Hn, 1, A]: row p = agent * Hn + head
+        obs_x = obs.repeat_interleave(Hn, dim=1).contiguous()
+        acts_x = (acts.repeat_interleave(Hn, dim=1) * mask).contiguous()
+        rew_x = rew.repeat_interleave(Hn, dim=1).contiguous()
+        avail_x = mask.expand(T1, N * Hn, B, A).contiguous()
+        return obs_x, acts_x, rew_x, avail_x
 
     def _train_multi_rec(self, batch):
         obs_b, cent_b, act_b, rew_b, dones_b, dones_env_b, avail_b, importance_weights, idxes = batch
@@ -398,7 +436,7 @@ class QMix(object):
 
     def obs_ref_ok(self, batch):
         """Can a step on `batch` episodes read its observation rows from the replay store (StoreObs) instead of a gathered tensor?"""
-        if self.multi or self._mlp:
+        if self.multi or self._mlp or getattr(self, "_md_heads", None) is not None:
             return False
         return bool(_lib.lib.ope_qmix_obs_ref_ok(C.byref(self._cfg(int(batch)))))
 
@@ -409,7 +447,7 @@ class QMix(object):
             oref = obs.ref()
         else:
             T1, N, B, D = obs.shape
-        assert T1 == self.episode_length + 1 and N == self.num_agents, "batch does not match the trainer's dimensions"
+        assert T1 == self.episode_length + 1 and N == getattr(self, "_n_kernel_agents", self.num_agents), "batch does not match the trainer's dimensions"
         cfg = self._cfg(B)
         ws = self._workspace(cfg)
         f = _lib.Fields()
@@ -500,8 +538,8 @@ class QMix(object):
         kernels: that needs the one-shot xGMI exchange (dist.setup_fast_allreduce verified it; its call counter lives on the device) --
         with the RCCL fallback the step stays eager. The graph holds pointers into that exchange's buffers: it refuses to replay once
         dist.disable_fast_allreduce has retired it."""
-        if self.use_per or self.multi:
-            raise NotImplementedError("graphed step: uniform replay, one shared policy")
+        if self.use_per or self.multi or getattr(self, "_md_heads", None) is not None:
+            raise NotImplementedError("graphed step: uniform replay, one shared policy, Discrete actions")
         if opdist.is_distributed() and not opdist.graph_safe_allreduce(self.numel + _lib.OPE_GRAD_TAIL):
             raise NotImplementedError("graphed step at world > 1 needs the one-shot all-reduce with slots that hold the gradient vector (%s)" % opdist.allreduce_backend())
         pbuf = buffer.policy_buffers[policy_id]

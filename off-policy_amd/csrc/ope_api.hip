@@ -26,7 +26,7 @@ bool cfg_ok(const ope_qmix_cfg* c) {
   if (c->chain_path < 0 || c->chain_path > 2) return false;
   if (c->hypernet_layers < 0 || c->hypernet_layers > 2) return false;
   if (d.layer_N < 0 || d.layer_N > 2) return false;
-  if (d.flags & ~(OPE_DIMS_NO_FEATURE_NORM | OPE_DIMS_TANH)) return false;
+  if (d.flags & ~(OPE_DIMS_NO_FEATURE_NORM | OPE_DIMS_TANH | OPE_DIMS_MASK_TARGET_MAX)) return false;
   if ((d.flags & OPE_DIMS_NO_FEATURE_NORM) && c->mlp) return false;      // no input LayerNorm: the recurrent nets
   if ((d.flags & OPE_DIMS_TANH) && (c->mlp || c->phase != 0 || d.layer_N == 2 || d.obs_dim > 384 || c->trunk_path == 4)) return false;   // tanh: trunk_fwd3 / trunk_bwd3
   if (d.layer_N == 2 && (c->mlp || c->phase != 0 || c->time_chunks > 1)) return false;      // a second hidden block: whole steps of recurrent nets
@@ -569,6 +569,7 @@ static int qmix_step(const ope_qmix_cfg* cfg, const ope_fields* batch, const ope
     ca.hw1[1] = W + p.hw1_t; ca.hw2[1] = W + p.hw2_t; ca.hb2[1] = W + p.hb2_t; ca.hb1[1] = W + p.hb1_t;
     ca.v1x[0] = W + p.v1; ca.v1x[1] = W + p.v1_t; ca.v2x[0] = W + p.v2; ca.v2x[1] = W + p.v2_t;
     ca.td = td;
+    ca.mask_target_max = (cfg->dims.flags & OPE_DIMS_MASK_TARGET_MAX) ? 1 : 0;
     ca.xhat_o = W + p.xhat_o; ca.rstd_o = W + p.rstd_o; ca.act_idx = (int*)(W + p.act_idx);
     ca.loss_part = W + p.loss_part; ca.err_abs = W + p.err_abs; ca.dqtot = W + p.dqtot;
     ca.d_v1 = W + p.d_v1; ca.d_v2 = W + p.d_v2; ca.d_b1 = W + p.d_b1; ca.d_hw1 = W + p.d_hw1; ca.d_hw2 = W + p.d_hw2; ca.d_hb2 = W + p.d_hb2;
@@ -589,7 +590,7 @@ static int qmix_step(const ope_qmix_cfg* cfg, const ope_fields* batch, const ope
     hf.r_begin = (int64_t)p.tb[c] * p.NB; hf.R = (int64_t)p.tb[c + 1] * p.NB;
     hf.NB = p.NB; hf.B = p.B; hf.N = p.N; hf.T = p.T; hf.A = p.A; hf.theta0 = theta; hf.theta1 = theta_tgt; hf.L = p.AL;
     hf.h0 = W + p.h; hf.h1 = W + p.h_t; hf.acts = batch->acts; hf.avail = batch->avail_acts; hf.double_q = cfg->use_double_q;
-    hf.no_ln = p.mlp; hf.target_mask_avail = p.mlp;
+    hf.no_ln = p.mlp; hf.target_mask_avail = p.mlp || (cfg->dims.flags & OPE_DIMS_MASK_TARGET_MAX) != 0;
     hf.agent_q = W + p.agent_q; hf.agent_nq = W + p.agent_nq; hf.act_idx = (int*)(W + p.act_idx);
     hf.xhat_o = W + p.xhat_o; hf.rstd_o = W + p.rstd_o; hf.q_out = nullptr; hf.q_all = dbg_on ? W + p.q_all : nullptr;
     if (ride) hf.side = tr;

@@ -524,7 +524,7 @@ __global__ void __launch_bounds__(64 * kCW, 2) qchain_kernel(ChainArgs a) {
         for (int it = 0; it < NT; ++it)
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr)
-            if (16 * it + 4 * g + rr < A) tq = fmaxf(tq, q[it][rr]);
+            if (16 * it + 4 * g + rr < A) tq = fmaxf(tq, (a.mask_target_max && a.avail && avl[ia][it][rr] == 0.f) ? -1e10f : q[it][rr]);
         tq = fmaxf(tq, __shfl_xor(tq, 16, 64));
         tq = fmaxf(tq, __shfl_xor(tq, 32, 64));
       }

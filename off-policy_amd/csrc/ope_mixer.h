@@ -108,6 +108,7 @@ void hyp_tiles_for(const MixerLayout& L, int N, int S, HypFirstArgs* a);
 struct ChainArgs {
   int TB, B, N, T, A, NB;
   int vdn, double_q;
+  int mask_target_max;                        // plain (non double-Q) targets: maximum over the available actions only (OPE_DIMS_MASK_TARGET_MAX)
   const float* theta0; const float* theta1;   // full flat vectors [agent | mixer] of the live / target nets
   AgentLayout AL; MixerLayout ML;
   const float* mixT;                          // live w1bT [64][N*32] then w2bT [64][32]

@@ -35,10 +35,11 @@ def build_from_fixture(g, device="cuda:0"):
     from offpolicy_amd.algorithms.qmix.qmix import QMix
     dims = fixture_dims(g)
     args = make_args(g)
-    pinfo = policy_info_for(dims)
+    md = [int(x) for x in g["multi_discrete"]] if "multi_discrete" in g else None      # sub-action sizes: no availability masks upstream
+    pinfo = policy_info_for(dims, multi_discrete=md)
     n_pre = int(g["pre_idx_range"].shape[0]) if "pre_idx_range" in g else 0
     cap = max(int(g["filled_i"]), int(g["idx_range"].max()) + 1)
-    buf = RecReplayBuffer(pinfo, {"policy_0": list(range(dims.n_agents))}, cap, dims.episode_length, bool(args.use_same_share_obs), True,
+    buf = RecReplayBuffer(pinfo, {"policy_0": list(range(dims.n_agents))}, cap, dims.episode_length, bool(args.use_same_share_obs), md is None,
                           False, device=device)
     if n_pre:
         d0 = as_policy_dicts({k: g["pre_ep/" + k] for k in EP_KEYS})

@@ -163,7 +163,7 @@ def test_network_without_input_layernorm_keeps_the_layout_and_hides_two_slots():
             assert np.array_equal(v.numpy(), g["agent/" + k]), k
     cfg.mlp, cfg.dims.episode_length = 1, 1
     assert _lib.lib.ope_qmix_workspace_bytes(C.byref(cfg)) == -1              # the recurrent nets only
-    cfg.mlp, cfg.dims.episode_length, cfg.dims.flags = 0, t, 4
+    cfg.mlp, cfg.dims.episode_length, cfg.dims.flags = 0, t, 8
     assert _lib.lib.ope_qmix_workspace_bytes(C.byref(cfg)) == -1              # unknown flag bits
     dd = _lib.DdpgCfg()
     dd.dims, dd.batch, dd.num_q = _lib.Dims(n, a, d, s, 1, 1, _lib.OPE_DIMS_NO_FEATURE_NORM), 4, 1
@@ -235,15 +235,25 @@ def test_action_space_kinds_of_the_maddpg_family_are_validated():
     assert cfg_bytes(heads=[3, 4], continuous=1) == -1            # one or the other
     assert cfg_bytes(continuous=1, target_gumbel=1) == -1         # continuous target noise is additive, not gumbel
     assert cfg_bytes(continuous=2) == -1
-    # the Q-learning families carry one Q head per agent: MultiDiscrete (one head per sub-action upstream) and Box spaces are refused at
-    # construction, before anything touches the GPU
+    # the Q-learning families: Box spaces are refused at construction, before anything touches the GPU (upstream asserts a discrete space);
+    # MultiDiscrete ones are taken (round 5): the policy exposes upstream's per-head parameter names, the trainer one mixer input per
+    # (agent, sub-action); what upstream itself cannot run with them (VDN, the previous action as an input) is refused
     from offpolicy_amd.config import default_args
     from offpolicy_amd.algorithms.qmix.algorithm.QMixPolicy import QMixPolicy
     from offpolicy_amd.algorithms.mqmix.algorithm.mQMixPolicy import M_QMixPolicy
+    pc = lambda sp: {"cent_obs_dim": 9, "cent_act_dim": 14, "obs_space": [6], "share_obs_space": [9], "act_space": sp}
     for P in (QMixPolicy, M_QMixPolicy):
-        for sp in (md, Box(low=-np.ones(3, np.float32), high=np.ones(3, np.float32))):
-            with pytest.raises(NotImplementedError, match="Discrete action spaces"):
-                P({"args": default_args(), "device": "cpu"}, {"cent_obs_dim": 9, "cent_act_dim": 14, "obs_space": [6], "share_obs_space": [9], "act_space": sp})
+        with pytest.raises(NotImplementedError, match="Discrete / MultiDiscrete action spaces"):
+            P({"args": default_args(), "device": "cpu"}, pc(Box(low=-np.ones(3, np.float32), high=np.ones(3, np.float32))))
+        pol = P({"args": default_args(), "device": "cpu"}, pc(md))
+        assert pol.multidiscrete and pol.head_dims == [3, 4] and pol.output_dim == 7
+        names = [k for k, _ in pol.q_network.named_parameters()]
+        assert names[-4:] == ["q.action_outs.0.weight", "q.action_outs.0.bias", "q.action_outs.1.weight", "q.action_outs.1.bias"]
+        assert [tuple(v.shape) for _, v in pol.q_network.named_parameters()][-4:] == [(3, 64), (3,), (4, 64), (4,)]
+        ra = pol.get_random_actions(np.zeros((5, 6), np.float32))
+        assert ra.shape == (5, 7) and np.array_equal(ra[:, :3].sum(1), np.ones(5)) and np.array_equal(ra[:, 3:].sum(1), np.ones(5))
+    with pytest.raises(NotImplementedError, match="prev_act_inp with a MultiDiscrete"):
+        QMixPolicy({"args": default_args(prev_act_inp=True), "device": "cpu"}, pc(md))
 
 
 def test_struct_mirrors_match_the_compiled_library():
@@ -425,3 +435,31 @@ def test_one_layer_hyper_networks_layout_and_initialisation_match_the_reference(
         for k, v in bad.items():
             setattr(c2, k, v)
         assert _lib.lib.ope_qmix_workspace_bytes(C.byref(c2)) == -1, bad
+
+
+@pytest.mark.parametrize("name,mlp", [("qmix_md_tiny", False), ("qmix_md_odd_huber_per", False), ("mqmix_md_small", True)])
+def test_multi_discrete_policies_reproduce_the_reference_initialisation(name, mlp):
+    """MultiDiscrete action spaces for the Q-learning families (round 5): with equal seeds our policy constructor draws the reference's
+    initial weights -- one Linear head per sub-action, constructed and re-initialised in order (act.py:14-17) -- exposes them under the
+    reference's parameter names in its order, and the mixer is one sized for n_agents x n_heads inputs (qmix.py:49-57). The fixtures hold
+    the real reference's initial weights (seeds 1 / 1, policy then trainer)."""
+    import torch
+    from offpolicy_amd.config import default_args
+    from offpolicy_amd.utils.synth import EnvDims, policy_info_for
+    from offpolicy_amd.algorithms.qmix.algorithm.QMixPolicy import QMixPolicy
+    from offpolicy_amd.algorithms.mqmix.algorithm.mQMixPolicy import M_QMixPolicy
+    from offpolicy_amd.algorithms.qmix.algorithm.q_mixer import init_mixer_values, MIXER_PARAM_NAMES
+    g = load_golden(name)
+    n, a, d, s, t = [int(x) for x in g["dims"]]
+    heads = [int(x) for x in g["multi_discrete"]]
+    torch.manual_seed(1)
+    np.random.seed(1)
+    pol = (M_QMixPolicy if mlp else QMixPolicy)({"args": default_args(), "device": "cpu"}, policy_info_for(EnvDims("fx", n, a, d, s, t), multi_discrete=heads)["policy_0"])
+    got = dict(pol.q_network.named_parameters())
+    want = sub(g, "agent/")
+    assert list(got.keys()) == list(want.keys())
+    for k, ref in want.items():
+        assert np.array_equal(got[k].detach().numpy(), ref), k
+    mv = init_mixer_values(n * len(heads), s)
+    for v, k in zip(mv, MIXER_PARAM_NAMES):
+        assert np.array_equal(v.numpy(), g["mixer/" + k]), k

@@ -127,3 +127,51 @@ def test_per_agent_centralized_observations_use_agent_zero():
         trainer.soft_target_updates()
         np.testing.assert_allclose(float(info["loss"]), g["loss"][st], rtol=RTOL)
         np.testing.assert_allclose(float(info["grad_norm"]), g["grad_norm"][st], rtol=RTOL)
+
+
+@pytest.mark.parametrize("name", ["mqmix_md_small", "mqmix_md_huber_per"])
+def test_multi_discrete_train_steps_match_reference(name):
+    """Round 5: MultiDiscrete action spaces under MLP QMIX on the engine (mqmix.py:41-51, 116-130, 144-155; mQMixPolicy.py:47-55): one q head per
+    sub-action, one mixer input per (agent, sub-action) -- run by the Discrete kernels with every (agent, sub-action) pair presented as an
+    agent whose availability mask is the sub-action's block (QMix._md_expand). The reference buffer's numpy 13-tuple (no availability
+    masks) through M_QMix: losses, gradient norms, Q_tot, priorities and the parameters after the fixture's steps."""
+    from offpolicy_amd.config import default_args
+    from offpolicy_amd.utils.synth import EnvDims, policy_info_for
+    from offpolicy_amd.algorithms.mqmix.algorithm.mQMixPolicy import M_QMixPolicy
+    from offpolicy_amd.algorithms.mqmix.mqmix import M_QMix
+    g = load_golden(name)
+    n, a, d, s, _ = [int(x) for x in g["dims"]]
+    heads = [int(x) for x in g["multi_discrete"]]
+    dims = EnvDims("fx", n, a, d, s, 1)
+    args = default_args(gamma=float(g["hp_gamma"]), lr=float(g["hp_lr"]), opti_eps=float(g["hp_eps"]),
+                        use_huber_loss=bool(g["hp_huber"]), huber_delta=float(g["hp_delta"]), use_per=bool(g["hp_per"]),
+                        per_nu=float(g["hp_nu"]), per_eps=float(g["hp_per_eps"]), tau=float(g["hp_tau"]),
+                        max_grad_norm=float(g["hp_maxnorm"]), use_double_q=bool(g["hp_double_q"]))
+    dev = torch.device("cuda:0")
+    pinfo = policy_info_for(dims, multi_discrete=heads)
+    policy = M_QMixPolicy({"args": args, "device": dev}, pinfo["policy_0"])
+    assert policy.multidiscrete and policy.head_dims == heads and policy.output_dim == a
+    trainer = M_QMix(args, n, {"policy_0": policy}, lambda x: "policy_0", device=dev)
+    assert trainer.num_mixer_q_inps == n * len(heads)
+    assert list(policy.q_network.state_dict().keys()) == list(sub(g, "agent/").keys())      # upstream's per-head names, in order
+    policy.q_network.load_state_dict({k: torch.as_tensor(v) for k, v in sub(g, "agent/").items()})
+    trainer.mixer.load_state_dict({k: torch.as_tensor(v) for k, v in sub(g, "mixer/").items()})
+    trainer.hard_target_updates()
+    w = g["per_weights"] if "per_weights" in g else None
+    batch = tuple(({"policy_0": g["batch/" + k]} if "batch/" + k in g else None) for k in T_KEYS) + (w, g["inds"] if w is not None else None)
+    for st in range(len(g["loss"])):
+        info, prio, _ = trainer.train_policy_on_batch(batch, True)
+        trainer.soft_target_updates()
+        np.testing.assert_allclose(float(info["loss"]), g["loss"][st], rtol=RTOL)
+        np.testing.assert_allclose(float(info["grad_norm"]), g["grad_norm"][st], rtol=RTOL)
+        np.testing.assert_allclose(float(info["Q_tot"]), g["Q_tot"][st], rtol=RTOL, atol=1e-6)
+        if w is not None:
+            np.testing.assert_allclose(prio, g["priorities"][st], rtol=RTOL, atol=1e-6)
+    live = dict(policy.q_network.named_parameters())
+    tgt = dict(trainer.target_policies["policy_0"].q_network.named_parameters())
+    for k, ref in sub(g, "final_agent/").items():
+        np.testing.assert_allclose(live[k].detach().cpu().numpy(), ref, rtol=0, atol=3e-5, err_msg=k)
+    for k, ref in sub(g, "final_agent_tgt/").items():
+        np.testing.assert_allclose(tgt[k].detach().cpu().numpy(), ref, rtol=0, atol=3e-5, err_msg="tgt " + k)
+    for k, ref in sub(g, "final_mixer/").items():
+        np.testing.assert_allclose(dict(trainer.mixer.named_parameters())[k].detach().cpu().numpy(), ref, rtol=0, atol=3e-5, err_msg=k)

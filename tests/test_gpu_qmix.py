@@ -24,7 +24,10 @@ CASES = ["qmix_tiny", "qmix_tiny_huber_per", "qmix_tiny_nodouble", "vdn_tiny", "
          # block and one-layer hyper-networks, VDN
          "qmix_shape_nofn", "qmix_var_nofn_d252", "qmix_var_nofn_odd", "qmix_var_nofn_layer2_hyper1", "vdn_var_nofn",
          # tanh in the agent network's MLP base (--use_ReLU off, mlp.py:9-12): trunk_fwd3 / trunk_bwd3 carry it
-         "qmix_shape_tanh", "qmix_var_tanh_d252", "qmix_var_tanh_odd", "vdn_var_tanh"]
+         "qmix_shape_tanh", "qmix_var_tanh_d252", "qmix_var_tanh_odd", "vdn_var_tanh",
+         # round 5: MultiDiscrete action spaces (one q head per sub-action, one mixer input per (agent, sub-action): QMixPolicy.py:76-93,
+         # qmix.py:49-57): two and three heads, Huber + PER weights, plain (non double-Q) per-head targets
+         "qmix_md_tiny", "qmix_md_odd_huber_per", "qmix_md_nodouble"]
 RTOL = 1e-4
 GRAD_TOL = 2e-3      # of the tensor's max magnitude (achieved errors: profiles/r05_parity_errors.txt)
 
@@ -84,7 +87,8 @@ def test_train_steps_match_reference(name):
     # the nn.Module views see the same memory (checkpoint path of the reference runner)
     sd = policy.q_network.state_dict()
     assert list(sd.keys()) == list(sub(g, "agent/").keys())
-    np.testing.assert_array_equal(sd["q.action_out.weight"].cpu().numpy(), live["agent/q.action_out.weight"])
+    head = "q.action_out.weight" if "q.action_out.weight" in sd else "q.action_outs.1.weight"      # (MultiDiscrete: upstream's per-head names)
+    np.testing.assert_array_equal(sd[head].cpu().numpy(), live["agent/" + head])
 
 
 @pytest.mark.parametrize("family,waves", [(4, 4), (4, 2), (1, 0)])
@@ -748,3 +752,31 @@ def test_vdn_ignores_hypernet_layers_and_tanh_accepts_weight_decay():
 def fixture_dims_of(g):
     from golden_util import fixture_dims
     return fixture_dims(g)
+
+
+def test_multi_discrete_policy_forward_and_actions_match_oracle():
+    """MultiDiscrete (round 5): the rollout forward returns the list of per-head q tensors (upstream's ACTLayer, act.py:23-31) -- the column
+    blocks of the one stacked head the kernels evaluate --, q_values_from_actions picks one q per head from the concatenated one-hot
+    blocks, and greedy actions are chosen per head."""
+    from oracle import qmix_oracle as O
+    g = load_golden("qmix_md_odd_huber_per")
+    dims, buf, policy, trainer = build_from_fixture(g)
+    heads = [int(x) for x in g["multi_discrete"]]
+    P = {k: torch.as_tensor(v) for k, v in sub(g, "agent/").items()}
+    torch.manual_seed(3)
+    obs = torch.randn(5, 7, dims.obs_dim)
+    h0 = torch.randn(7, 64) * 0.5
+    q_ref, h_ref = O.agent_q_forward(P, obs, h0)                      # [5, 7, sum(heads)]: the heads' blocks side by side
+    q, h = policy.get_q_values(obs.cuda(), None, h0.cuda())
+    assert isinstance(q, list) and [int(x.shape[-1]) for x in q] == heads
+    np.testing.assert_allclose(torch.cat(q, dim=-1).cpu().numpy(), q_ref.numpy(), rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(h.cpu().numpy(), h_ref.numpy(), rtol=1e-4, atol=2e-6)
+    acts, hn, gq = policy.get_actions(obs[0].cuda(), None, h0.cuda())
+    assert acts.shape == (7, sum(heads)) and tuple(gq.shape) == (7, len(heads))
+    lo = 0
+    for k, d in enumerate(heads):
+        assert np.array_equal(acts[:, lo:lo + d].argmax(-1), q_ref[0][:, lo:lo + d].argmax(-1).numpy()) and np.allclose(acts[:, lo:lo + d].sum(-1), 1)
+        np.testing.assert_allclose(gq[:, k].cpu().numpy(), q_ref[0][:, lo:lo + d].max(-1)[0].numpy(), rtol=1e-4, atol=2e-6)
+        lo += d
+    taken, _ = policy.get_q_values(obs.cuda(), None, h0.cuda(), action_batch=torch.as_tensor(np.tile(acts[None], (5, 1, 1))))
+    assert tuple(taken.shape) == (5, 7, len(heads))

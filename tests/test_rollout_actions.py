@@ -72,3 +72,46 @@ def test_rollout_post_processing_matches_the_reference_call_by_call():
             np.testing.assert_allclose(float(eps), ref_eps, rtol=1e-12, err_msg=name)
         seen.add((fam, algo, kind, bool(is_random), bool(explore), bool(use_target), bool(use_gumbel)))
     assert len(seen) == 56      # every (family, algorithm, kind, call flavour) combination was exercised (the two exploring calls differ in t_env only)
+
+
+def test_q_learning_rollout_post_processing_matches_the_reference_call_by_call():
+    """The Q-learning policies (QMixPolicy, M_QMixPolicy; round 5: also MultiDiscrete action spaces, one greedy choice and one pair of
+    exploration draws per sub-action head): actions_from_q / get_random_actions on the reference network's recorded q values under the
+    recorded generator states (tests/golden/rollout_actions_q.npz, oracle/make_golden_rollout_q.py) -- the one-hot actions and the greedy
+    q values the reference returned, exactly."""
+    from offpolicy_amd.config import default_args
+    from offpolicy_amd.utils.spaces import Discrete, MultiDiscrete
+    from offpolicy_amd.algorithms.qmix.algorithm.QMixPolicy import QMixPolicy
+    from offpolicy_amd.algorithms.mqmix.algorithm.mQMixPolicy import M_QMixPolicy
+    g = load_golden("rollout_actions_q")
+    eps0, eps1, eps_t = [float(x) for x in g["hp"]]
+    args = default_args(epsilon_start=eps0, epsilon_finish=eps1, epsilon_anneal_time=eps_t)
+    names = [str(x) for x in g["names"]]
+    assert len(names) == 16
+    pols = {}
+    for name in names:
+        pre = name + "/"
+        fam, kind = name.split("/")[0].split("_")
+        heads = [int(x) for x in g[fam + "_" + kind + "/heads"]]
+        width = int(g[fam + "_" + kind + "/width"][0])
+        if (fam, kind) not in pols:
+            space = MultiDiscrete([[0, k - 1] for k in heads]) if kind == "md" else Discrete(width)
+            pols[(fam, kind)] = (QMixPolicy if fam == "rnn" else M_QMixPolicy)(
+                {"args": args, "device": "cpu"}, {"cent_obs_dim": 9, "cent_act_dim": 2 * width, "obs_space": [6], "share_obs_space": [9], "act_space": space})
+        pol = pols[(fam, kind)]
+        is_random, explore, t_env = [int(x) for x in g[pre + "flags"]]
+        avail = g[pre + "avail"] if pre + "avail" in g else None
+        q = torch.as_tensor(g[pre + "q"])
+        B = q.shape[0]
+        qq = list(torch.split(q, heads, dim=-1)) if kind == "md" else q
+        _set_rng(g, pre)
+        if is_random:
+            got, gq = pol.get_random_actions(np.zeros((B, 6), np.float32), avail), None
+        elif fam == "rnn":
+            got, gq = pol.actions_from_q(qq, available_actions=avail, explore=bool(explore), t_env=t_env if t_env >= 0 else None)
+        else:
+            got, gq = pol.actions_from_q(qq, B, avail, t_env if t_env >= 0 else None, bool(explore))
+        ref = g[pre + "actions"]
+        assert np.asarray(got).shape == ref.shape and np.array_equal(np.asarray(got, dtype=np.float64), ref.astype(np.float64)), name
+        if gq is not None:
+            np.testing.assert_array_equal(gq.detach().numpy(), g[pre + "greedy_q"], err_msg=name)
