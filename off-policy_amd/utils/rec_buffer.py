@@ -311,7 +311,7 @@ class RecPolicyBuffer(object):
         if torch.is_tensor(sample_inds):     # indices already on the device (HIP-graph replays keep them in a static tensor)
             assert sample_inds.dtype == torch.int64 and sample_inds.device == self.device, (sample_inds.dtype, sample_inds.device)
             dev_inds, B = sample_inds.contiguous(), int(sample_inds.shape[0])
-            if lazy:
+            if lazy and _sampler is None:      # (device sampling: the kernel WRITES the drawn slots into this tensor, which sample_device allocated for the call)
                 # a StoreObs keeps its indices past this call (the step reads the rows through them): it gets its OWN copy, so that a
                 # caller that rewrites its index tensor before the step runs cannot redirect the rows (the graphed steps pass
                 # lazy_obs=False: their kernels read the static tensor on purpose)

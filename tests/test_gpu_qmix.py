@@ -29,7 +29,7 @@ CASES = ["qmix_tiny", "qmix_tiny_huber_per", "qmix_tiny_nodouble", "vdn_tiny", "
          # qmix.py:49-57): two and three heads, Huber + PER weights, plain (non double-Q) per-head targets
          "qmix_md_tiny", "qmix_md_odd_huber_per", "qmix_md_nodouble"]
 RTOL = 1e-4
-GRAD_TOL = 2e-3      # of the tensor's max magnitude (achieved errors: profiles/r05_parity_errors.txt)
+GRAD_TOL = 5e-5      # of the tensor's max magnitude: 10x the worst error any of the 40 fixtures shows on the GPU (5.0e-6, qmix_var_s2232; most: 6e-7 .. 1.2e-6; profiles/r05_parity_errors.txt)
 
 
 def _flat_named(trainer, flat):
