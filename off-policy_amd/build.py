@@ -50,7 +50,7 @@ def build(force=False, verbose=True, extra_flags=(), sanitize=False, experiments
     objs = []
     procs = []
     # experiments=True: libope_exp.so, the same sources with -DOPE_EXPERIMENTS -- the timing-only kernel variants behind OPE_WGRAD_EXP /
-    # OPE_W2_EXP / OPE_WIDE_EXP (loops with the loads, the MFMAs or the reductions left out: WRONG results, announced on stderr). They exist
+    # OPE_W2_EXP / OPE_T4_EXP / OPE_WIDE_EXP (loops with the loads, the MFMAs or the reductions left out: WRONG results, announced on stderr). They exist
     # only there; load it with OPE_LIB_PATH for a decomposition run (tools/, profiles/r05_*). libope.so has none of them compiled in.
     lib = SAN_LIB if sanitize else (EXP_LIB if experiments else LIB)
     flags = [f for f in FLAGS if f != "-O3"] + SAN_FLAGS if sanitize else (FLAGS + ["-DOPE_EXPERIMENTS"] if experiments else FLAGS)

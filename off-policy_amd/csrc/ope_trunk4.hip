@@ -22,6 +22,7 @@
 //   * the two waves of a SIMD draw their tiles from one LDS counter, so a SIMD's share of the 2 416 tiles per net (4.72) is what balances,
 //     not a wave's.
 // The observation rows are still read once per net (the nets sit on different CUs), but within one launch and largely out of L2.
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -32,6 +33,15 @@ namespace ope {
 namespace {
 
 __device__ __forceinline__ int wslot(int row, int p) { return p ^ ((row & 7) << 1); }   // swizzled 16-byte slot of logical slot p in `row`
+
+template <int EXP>
+__device__ __forceinline__ f32x4 t4_mfma(float w, float x, f32x4 acc) {
+  if (EXP & 1) {
+    asm volatile("" : "+v"(acc) : "v"(w), "v"(x));      // the operands stay live (the LDS reads are not dead code), the matrix pipe stays idle
+    return acc;
+  }
+  return mfma16(w, x, acc);
+}
 
 template <int KCM>
 struct T4 {
@@ -72,7 +82,10 @@ struct TrunkPairArgs {
 // LAZY: the observation rows are read in place from the episode-major store (ObsRef, ope_common.h) instead of a gathered batch: the same
 // 16 KCM-byte rows, at (per-lane 64-bit row pointer) + (immediate) instead of (uniform base) + (32-bit offset).
 // VEC = 4: D % 4 == 0, rows and weight rows read as 16-byte pieces; VEC = 2 (D % 2 == 0: MMM2's 370): as two 8-byte halves.
-template <int KCM, int NW, bool PF, bool LAZY, int VEC = 4>
+// EXP (instantiated only in builds with -DOPE_EXPERIMENTS; TIMING variants, results WRONG; OPE_T4_EXP, profiles/r05_trunk4_decomposition.txt):
+// 1 no MFMAs (their LDS weight reads stay), 2 no saves for the backward pass, 4 no weight staging, 8 no gi stores, 16 no ReLU / LayerNorm
+// between the layers, 32 no observation-row loads
+template <int KCM, int NW, bool PF, bool LAZY, int VEC = 4, int EXP = 0>
 __global__ void __launch_bounds__(64 * NW, NW / 4) trunk_fwd4_kernel(TrunkPairArgs pa) {
   using C = T4<KCM>;
   static_assert(!(LAZY && VEC != 4), "rows are read in place from the store as 16-byte pieces only");
@@ -97,7 +110,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) trunk_fwd4_kernel(TrunkPairAr
   const float* __restrict__ th = net ? pa.theta[1] : pa.theta[0];
   float* __restrict__ gi_out = net ? pa.gi[1] : pa.gi[0];
   const int D = a.D, R = a.R;
-  const bool save = net == 0 && pa.save0;
+  const bool save = net == 0 && pa.save0 && !(EXP & 2);
 
   // optional s_memtime stamps (ope_qmix_cfg.debug; tools/trunk4_phases.py): [workgroup][wave][16] = start, weights staged, then for the
   // wave's FIRST tile: rows arrived + statistics, fc1, LN1 + saves, fc2 + LN2 + saves, W_ih + gi stores; last: all tiles done, tiles done
@@ -141,7 +154,12 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) trunk_fwd4_kernel(TrunkPairAr
   // part (KCM > 16 only): 0 = the whole row, 1 = chunks [0, 16) -- what is requested behind fc1 for the NEXT tile and held through fc2 /
   // W_ih (a whole 24-chunk row would be 96 registers: 89 spilled) --, 2 = the rest, requested at the top of the tile itself
   constexpr int PFC = KCM > 16 ? 16 : KCM;
+  if (EXP & 32) {
+#pragma unroll
+    for (int c = 0; c < KCM; ++c) xv[c] = f32x4{0.01f * (float)(lane + c), -0.02f * (float)(j + 3 * c), 0.5f - 0.03f * (float)g, 0.25f * (float)(c & 3)};
+  }
   auto request = [&](int tile, bool staged = true, int part = 0) {
+    if (EXP & 32) return;
     const int row = tile * 16 + j;
     if (LAZY) {
       int rw, b, tnj;
@@ -193,7 +211,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) trunk_fwd4_kernel(TrunkPairAr
   if (PF && tile < ntiles) request(tile, false, KCM > PFC ? 1 : 0);
   // ---- prologue: this net's weights -> LDS (swizzled), parameters, tile counters. Every thread requests ALL its pieces before the
   // first LDS store (8 KCM / 16 + 2 + 6 independent 16-byte loads in flight per thread instead of one round trip per piece) ----
-  {
+  if (!(EXP & 4)) {
     constexpr int P1 = OPE_H * C::RS1, P2 = OPE_H * 16, P3 = C::W3R * 16;                         // 16-byte pieces of the three matrices (their LDS-resident rows)
     constexpr int N1 = (P1 + NT - 1) / NT, N2 = (P2 + NT - 1) / NT, N3 = (P3 + NT - 1) / NT;       // per thread (a partly used last round)
     f32x4 p1[N1], p2[N2], p3[N3];
@@ -369,7 +387,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) trunk_fwd4_kernel(TrunkPairAr
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int it = 0; it < 4; ++it) z[it] = mfma16(wv[it][r], xv[c][r], z[it]);
+        for (int it = 0; it < 4; ++it) z[it] = t4_mfma<EXP>(wv[it][r], xv[c][r], z[it]);
     }
     __builtin_amdgcn_sched_barrier(0);
     if (done == 0) stamp(3);
@@ -380,7 +398,8 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) trunk_fwd4_kernel(TrunkPairAr
     float rs, mu;
     uint64_t bits;
     const uint32_t xh_off = (uint32_t)row * (4u * OPE_H) + 16u * g;
-    relu_ln(z, 1, 2, (save && valid) ? reinterpret_cast<char*>(a.xhat1) : nullptr, xh_off, rs, mu, bits);
+    if (EXP & 16) { rs = 1.0f; mu = 0.f; bits = 0; }
+    else relu_ln(z, 1, 2, (save && valid) ? reinterpret_cast<char*>(a.xhat1) : nullptr, xh_off, rs, mu, bits);
     if (save) {
       const uint64_t m = or4(bits);
       if (valid) {
@@ -404,9 +423,10 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) trunk_fwd4_kernel(TrunkPairAr
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int it = 0; it < 4; ++it) z2[it] = mfma16(wv[it][r], z[ft][r], z2[it]);
+        for (int it = 0; it < 4; ++it) z2[it] = t4_mfma<EXP>(wv[it][r], z[ft][r], z2[it]);
     }
-    relu_ln(z2, 4, 5, (save && valid) ? reinterpret_cast<char*>(a.xhat2) : nullptr, xh_off, rs, mu, bits);
+    if (EXP & 16) { rs = 1.0f; mu = 0.f; bits = 0; }
+    else relu_ln(z2, 4, 5, (save && valid) ? reinterpret_cast<char*>(a.xhat2) : nullptr, xh_off, rs, mu, bits);
     if (save) {
       const uint64_t m = or4(bits);
       if (valid) {
@@ -444,9 +464,12 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) trunk_fwd4_kernel(TrunkPairAr
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-          for (int u = 0; u < 4; ++u) o[u] = mfma16(wv[u][r], z2[ft][r], o[u]);
+          for (int u = 0; u < 4; ++u) o[u] = t4_mfma<EXP>(wv[u][r], z2[ft][r], o[u]);
       }
-      if (valid) {
+      if (EXP & 8) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) asm volatile("" ::"v"(o[u]));
+      } else if (valid) {
         const uint32_t go = (uint32_t)row * (12u * OPE_H) + 16u * g + 64u * u0;
 #pragma unroll
         for (int u = 0; u < 4; ++u) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(gi_out) + (go + 64u * u)) = o[u];
@@ -509,6 +532,22 @@ int launch_trunk_fwd_pair(const TrunkFwdArgs& live, const TrunkFwdArgs& tgt, int
   kprof_work(2.0 * 2.0 * live.R * ((double)live.D * OPE_H + OPE_H * OPE_H + 3.0 * OPE_H * OPE_H));     // both nets
   // (KC = 24: rows prefetched behind fc1 up to chunk 16, the rest at the top of the tile: 117.8 us at MMM2 batch 32 against 119.7 us without
   // any prefetch and 168.6 us for the two trunk_fwd3<2, 24> launches)
+#ifdef OPE_EXPERIMENTS
+  static const int t4exp = getenv("OPE_T4_EXP") ? atoi(getenv("OPE_T4_EXP")) : 0;
+  if (t4exp && KC == 16 && !lazy) {
+    static bool warned = false;
+    if (!warned) { fprintf(stderr, "libope: OPE_T4_EXP=%d -- a timing-only variant of trunk_fwd4_kernel runs: its outputs are WRONG\n", t4exp); warned = true; }
+#define OPE_T4_CASE(E) case E: OPE_LAUNCH((trunk_fwd4_kernel<16, 8, true, false, 4, E>), dim3(grid), dim3(512), 0, st, pa); break;
+    switch (t4exp) {
+      OPE_T4_CASE(1) OPE_T4_CASE(2) OPE_T4_CASE(4) OPE_T4_CASE(8) OPE_T4_CASE(16) OPE_T4_CASE(32) OPE_T4_CASE(17) OPE_T4_CASE(58) OPE_T4_CASE(62) OPE_T4_CASE(59) OPE_T4_CASE(63)
+      default: return OPE_EINVAL;
+    }
+#undef OPE_T4_CASE
+    if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
+    note_launch("trunk_fwd4", KC);
+    return OPE_OK;
+  }
+#endif
   if (KC == 24) OPE_LAUNCH((trunk_fwd4_kernel<24, 8, true, false, 2>), dim3(grid), dim3(512), 0, st, pa);
   else if (lazy) {
     if (KC == 4) OPE_LAUNCH((trunk_fwd4_kernel<4, 8, true, true>), dim3(grid), dim3(512), 0, st, pa);
