@@ -111,11 +111,30 @@ __global__ void t_bf16k_issue(Out* o, int iters, unsigned seed) {      // the K 
 
 __device__ __forceinline__ unsigned hash(unsigned x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; }
 // whole chip, random register data refreshed every 32 MFMAs (a cheap xorshift per register keeps the operands toggling)
-template <int FORM>   // 0: f32 16x16x4, 1: bf16 16x16x32
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <int FORM>   // 0: f32 16x16x4, 1: bf16 16x16x32, 2: f32 32x32x2 (two 16-register accumulators... eight here: 128 registers)
 __global__ void __launch_bounds__(256) t_full(float* sink, int iters) {
   const unsigned t = blockIdx.x * 256 + threadIdx.x;
   u32x4 a, b;
   for (int i = 0; i < 4; ++i) { a[i] = (hash(t * 8 + i) & 0x007F007Fu) | 0x3F803F80u; b[i] = (hash(t * 8 + 4 + i) & 0x807F807Fu) | 0x3F003F00u; }
+  if (FORM == 2) {
+    f32x16 d[8];
+    for (int i = 0; i < 8; ++i) for (int e = 0; e < 16; ++e) d[i][e] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          d[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a[(i + k) & 3]), __builtin_bit_cast(float, b[(i ^ k) & 3]), d[i], 0, 0, 0);
+        a[k] = (a[k] ^ (a[k] << 3) ^ (unsigned)it) & 0x007F007Fu | 0x3F803F80u;
+        b[k] = (b[k] ^ (b[k] >> 2) ^ (unsigned)it) & 0x807F807Fu | 0x3F003F00u;
+      }
+    }
+    float s = 0;
+    for (int i = 0; i < 8; ++i) for (int e = 0; e < 16; ++e) s += d[i][e];
+    if (s == 123.456f) sink[t] = s;
+    return;
+  }
   f32x4 c[8];
   for (int i = 0; i < 8; ++i) c[i] = (f32x4){0, 0, 0, 0};
   for (int it = 0; it < iters; ++it) {
@@ -179,16 +198,17 @@ int main() {
   printf("Part 3: whole chip (256 workgroups x 4 waves, one wave per SIMD), 8 accumulators per wave, operands refreshed every 8 MFMAs\n");
   float* dS; CK(hipMalloc(&dS, 256 * 256 * 4));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int form = 0; form < 2; ++form) {
-    const int iters = form == 0 ? 100 : 400;       // 32 MFMAs per iteration per wave
+  for (int form = 0; form < 3; ++form) {
+    const int iters = form == 0 ? 100 : (form == 1 ? 400 : 50);       // 32 MFMAs per iteration per wave
     for (int rep = 0; rep < 3; ++rep) {
       CK(hipEventRecord(e0));
-      if (form == 0) t_full<0><<<256, 256>>>(dS, iters); else t_full<1><<<256, 256>>>(dS, iters);
+      if (form == 0) t_full<0><<<256, 256>>>(dS, iters); else if (form == 1) t_full<1><<<256, 256>>>(dS, iters); else t_full<2><<<256, 256>>>(dS, iters);
       CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-      const double n = 32.0 * iters, flop = n * 1024 * (form == 0 ? 2048.0 : 16384.0);
-      if (rep) printf("  %s: %.1f us for %d MFMAs per wave = %.1f ns each = %.1f TFLOP/s (at 1 MFMA per %d cycles: %.2f GHz)\n", form == 0 ? "f32 16x16x4 " : "bf16 16x16x32",
-                      ms * 1e3, (int)n, ms * 1e6 / n, flop / ms / 1e9, form == 0 ? 32 : 16, n * (form == 0 ? 32 : 16) / (ms * 1e6));
+      const double n = 32.0 * iters, flop = n * 1024 * (form == 0 ? 2048.0 : (form == 1 ? 16384.0 : 4096.0));
+      const int cyc = form == 0 ? 32 : (form == 1 ? 16 : 64);
+      if (rep) printf("  %s: %.1f us for %d MFMAs per wave = %.1f ns each = %.1f TFLOP/s (at 1 MFMA per %d cycles: %.2f GHz)\n", form == 0 ? "f32 16x16x4 " : (form == 1 ? "bf16 16x16x32" : "f32 32x32x2 "),
+                      ms * 1e3, (int)n, ms * 1e6 / n, flop / ms / 1e9, cyc, n * cyc / (ms * 1e6));
     }
   }
   return 0;
