@@ -353,6 +353,8 @@ class QMix(object):
         """Bring one batch field to the kernels' layout: [T(+1), N, B, dim] (agent fields) or [T(+1), B, dim]."""
         if x is None:
             return None
+        if isinstance(x, StoreObs):      # observations left in the store (RecPolicyBuffer.lazy_obs): gathered on the device, no host trip
+            x = x.materialize()
         if torch.is_tensor(x):
             t = x.to(self.device, dtype=torch.float32)
             if agent_axis:

@@ -24,6 +24,8 @@ import ctypes as C
 import numpy as np
 import torch
 
+from ...utils.rec_buffer import StoreObs
+
 from ... import _lib
 from ... import dist as opdist
 from ..maddpg.algorithm.MADDPGPolicy import sample_gumbel_uniform
@@ -167,6 +169,8 @@ class R_MADDPG(object):
         """[N, T(+1), B, dim] (reference's per-agent stacking) -> the kernels' [T(+1), N, B, dim]; [T(+1), B, dim] as is."""
         if x is None:
             return None
+        if isinstance(x, StoreObs):      # observations left in the store (RecPolicyBuffer.lazy_obs): gathered on the device, no host trip
+            x = x.materialize()
         if torch.is_tensor(x):
             t = x.to(self.device, dtype=torch.float32)
             if agent_axis:

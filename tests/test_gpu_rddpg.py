@@ -447,3 +447,29 @@ def test_multi_policy_updates_match_reference(name):
             got = params_of(mod)
             for k, ref in sub(g, p + "/" + grp).items():
                 np.testing.assert_allclose(got[k], ref, rtol=0, atol=3e-5, err_msg=p + "/" + grp + k)
+
+
+def test_store_resident_observations_train_like_gathered_ones(monkeypatch):
+    """RecPolicyBuffer.lazy_obs hands R_MADDPG a StoreObs in place of the observation array: the trainer materialises it ON THE DEVICE
+    (no `__array__` round trip through the host) and the step is the gathered batch's step, bit for bit."""
+    from offpolicy_amd.utils.rec_buffer import StoreObs
+    g = load_golden("rmaddpg_tiny")
+    outs = []
+    for lazy in (False, True):
+        dims, buf, policy, trainer = build(g)
+        load_fixture_weights(g, policy, check=False)
+        d = {k: {"policy_0": g["ep/" + k]} for k in EP_KEYS}
+        buf.insert(len(g["idx_range"]), *[d[k] for k in EP_KEYS])
+        pb = buf.policy_buffers["policy_0"]
+        pb.lazy_obs = lazy
+        s = pb.sample_inds(g["inds"])
+        assert isinstance(s[0], StoreObs) == lazy
+        if lazy:
+            monkeypatch.setattr(StoreObs, "__array__", lambda self, *a, **k: (_ for _ in ()).throw(AssertionError("StoreObs went through the host")))
+        batch = tuple({"policy_0": a} for a in s) + (None, None)
+        torch.manual_seed(1000)
+        info, _, _ = trainer.shared_train_policy_on_batch("policy_0", batch)
+        outs.append(([float(info[k]) for k in ("critic_loss", "critic_grad_norm", "actor_loss", "actor_grad_norm")],
+                     torch.cat([p.detach().flatten() for p in list(policy.actor.parameters()) + list(policy.critic.parameters())]).cpu()))
+    assert outs[0][0] == outs[1][0]
+    assert torch.equal(outs[0][1], outs[1][1])
