@@ -532,7 +532,7 @@ def main():
         bracket_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev[:20]]))
         gather_ms = float(np.mean(kernel_ms)) if kernel_ms else bracket_ms
         loss = float(info["loss"])
-        assert np.isfinite(loss) or os.environ.get("OPE_W2_EXP") or os.environ.get("OPE_T4_EXP"), "training diverged"
+        assert np.isfinite(loss) or os.environ.get("OPE_W2_EXP") or os.environ.get("OPE_T4_EXP") or os.environ.get("OPE_FIN_EXP"), "training diverged"
         per_kernel = None
         if world == 1 and graphed is None and not a.no_kernel_table:
             per_kernel = measured_kernel_table(one_step)

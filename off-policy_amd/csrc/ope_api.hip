@@ -772,7 +772,8 @@ static int qmix_step(const ope_qmix_cfg* cfg, const ope_fields* batch, const ope
           int same = q;      // first problem that walks the same A rows (what the XCD pairing looks at)
           for (int r = q - 1; r >= 0; --r)
             if (wt.p[r].A == P.A) same = r;
-          const int f[10] = {P.M, P.N, P.K, P.lda, P.ldb, P.b_shift, P.s_off >= 0, same, P.A2 ? P.a2_from + 1 : 0, P.lda2};
+          const int al = (((uintptr_t)P.A & 15) ? 2 : 0) | (((uintptr_t)P.B & 15) ? 4 : 0) | ((P.A2 && ((uintptr_t)P.A2 & 15)) ? 8 : 0);      // (the load width follows the operands' alignment)
+          const int f[10] = {P.M, P.N, P.K, P.lda, P.ldb, P.b_shift, (P.s_off >= 0 ? 1 : 0) | al, same, P.A2 ? P.a2_from + 1 : 0, P.lda2};
           memcpy(key + 1 + 10 * q, f, sizeof(f));
         }
         if (memcmp(w2_key, key, sizeof(key)) != 0) {

@@ -938,28 +938,41 @@ __global__ void __launch_bounds__(256, 1) ddpg_actor_tile_kernel(TileArgs a) {
 }
 
 // ---- slabs -> flat gradient -----------------------------------------------------------------------------------------------
-// 8 adjacent lanes share an output element: lane s sums slabs s, s + 8, ... (fixed order), the 8 partial sums meet through three
-// xor-shuffles (fixed order): deterministic, and the slab walk is 8x shorter than one thread per element. The registered-but-
-// unused fc_h block [skip_begin, skip_end) is never written by the tile kernels: zero. Each workgroup also leaves the sum of
-// squares of the gradient elements it produced -- gsq[block] for the trunk, gsq[nb + block] for the head block (frozen upstream
-// for the critic, SURVEY A-4, so the optimiser may want the trunk alone): the clip norm of ope_adam_step without a pass of
-// its own over the gradient.
+// Workgroup = 64 consecutive output elements (lane = element: every load is one 256-byte run of a slab) x four waves: wave w forms
+// the partial sums 2 w and 2 w + 1 of EIGHT interleaved ones (partial q = slabs q, q + 8, ... in that order), all of a lane's loads in
+// flight before its first add, and the four pairs meet through LDS as ((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (p6 + p7)) -- the
+// arithmetic of the first version (8 adjacent lanes per element and three xor-shuffles: 32-byte pieces of 8 slabs per load, the slab
+// walk as a load / wait / add loop) and of tile_opt_tail, bit for bit. The registered-but-unused fc_h block [skip_begin, skip_end) is
+// never written by the tile kernels: zero. Each workgroup also leaves the sum of squares of the gradient elements it produced --
+// gsq[block] for the trunk, gsq[nb + block] for the head block (frozen upstream for the critic, SURVEY A-4, so the optimiser may want
+// the trunk alone): the clip norm of ope_adam_step without a pass of its own over the gradient.
 __global__ void __launch_bounds__(256) ddpg_tile_reduce_kernel(const float* __restrict__ slabs, int ns, int64_t stride, int P, int tail,
                                                                 int skip_begin, int skip_end, int head_begin, float* __restrict__ grad,
                                                                 float* __restrict__ gsq) {
-  __shared__ float sm[2][4];
-  const int gid = blockIdx.x * 256 + threadIdx.x;
-  const int e = gid >> 3, s8 = gid & 7;
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + lane;
   const bool live = e < P + 4;
   const bool skip = e >= skip_begin && e < skip_end;
   const int ee = (live && !skip) ? e : 0;
-  float v = 0.f;
-  for (int s = s8; s < ns; s += 8) v += slabs[s * stride + ee];
-  v += __shfl_xor(v, 1, 64);
-  v += __shfl_xor(v, 2, 64);
-  v += __shfl_xor(v, 4, 64);
+  float p0 = 0.f, p1 = 0.f;
+  for (int s0 = 2 * wave; s0 < ns; s0 += 32) {
+    float t0[4], t1[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int sa = s0 + 8 * u;
+      t0[u] = sa < ns ? slabs[(int64_t)sa * stride + ee] : 0.f;
+      t1[u] = sa + 1 < ns ? slabs[(int64_t)(sa + 1) * stride + ee] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { p0 += t0[u]; p1 += t1[u]; }
+  }
+  part[wave][lane] = p0 + p1;
+  __syncthreads();
+  if (wave != 0) return;
+  float v = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
   float sq_trunk = 0.f, sq_head = 0.f;
-  if (live && s8 == 0) {
+  if (live) {
     if (skip) v = 0.f;
     if (e >= P) {
       grad[tail + (e - P)] = e - P < 3 ? v : 0.f;
@@ -972,11 +985,9 @@ __global__ void __launch_bounds__(256) ddpg_tile_reduce_kernel(const float* __re
     sq_trunk += __shfl_xor(sq_trunk, o, 64);
     sq_head += __shfl_xor(sq_head, o, 64);
   }
-  if ((threadIdx.x & 63) == 0) { sm[0][threadIdx.x >> 6] = sq_trunk; sm[1][threadIdx.x >> 6] = sq_head; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    gsq[blockIdx.x] = (sm[0][0] + sm[0][1]) + (sm[0][2] + sm[0][3]);
-    gsq[gridDim.x + blockIdx.x] = (sm[1][0] + sm[1][1]) + (sm[1][2] + sm[1][3]);
+  if (lane == 0) {
+    gsq[blockIdx.x] = sq_trunk;
+    gsq[gridDim.x + blockIdx.x] = sq_head;
   }
 }
 
@@ -1055,7 +1066,7 @@ bool ddpg_tile_opt_ok(int N, int A, int D, int S, int K, int B) {
 
 int ddpg_fused_gsq_blocks(int N, int A, int D, int S, int K, bool critic) {
   const int P = critic ? ope_agent_layout_mlp(S + N * A, K, 0).end : ope_agent_layout_mlp(D, A, 0).end;
-  return ope_cdiv((int64_t)(P + 4) * 8, 256);
+  return ope_cdiv((int64_t)(P + 4), 64);      // workgroups of the slab-sum launch (64 elements each)
 }
 
 int64_t ddpg_fused_slab_floats(int N, int A, int D, int S, int K, int B) {
@@ -1067,7 +1078,7 @@ int64_t ddpg_fused_slab_floats(int N, int A, int D, int S, int K, int B) {
 static int launch_reduce(const float* slabs, int ns, int64_t stride, const AgentLayout& L, float* grad, float* gsq, hipStream_t st) {
   const int P = L.end;
   kprof_work(0.0, 4.0 * ((double)ns * stride + P));
-  OPE_LAUNCH(ddpg_tile_reduce_kernel, dim3(ope_cdiv((int64_t)(P + 4) * 8, 256)), dim3(256), 0, st, slabs, ns, stride, P, P, L.fch_w,
+  OPE_LAUNCH(ddpg_tile_reduce_kernel, dim3(ope_cdiv((int64_t)(P + 4), 64)), dim3(256), 0, st, slabs, ns, stride, P, P, L.fch_w,
                      L.fc2_w, L.q_w, grad, gsq);
   return hipGetLastError() == hipSuccess ? OPE_OK : OPE_ELAUNCH;
 }

@@ -93,7 +93,14 @@ __global__ void __launch_bounds__(kBlock) adam_kernel(AdamK c, int64_t n, float*
   f32x4 tg4 = {0.f, 0.f, 0.f, 0.f};
   if (c.do_polyak) tg4 = *reinterpret_cast<const f32x4*>(tgt + lb);
   float s = 0.f;
-  for (int q = threadIdx.x; q < c.nblocks; q += kBlock) s += part[q];
+  // (four partials requested per pass before the first add: a load / wait / add loop is one memory round trip per ~kBlock partials)
+  for (int q0 = threadIdx.x; q0 < c.nblocks; q0 += 4 * kBlock) {
+    float pv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) pv[u] = q0 + u * kBlock < c.nblocks ? part[q0 + u * kBlock] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s += pv[u];
+  }
   // fixed-order: each thread adds a fixed subset, then the same tree everywhere -> identical in all blocks
   const float tot = block_sum(s, sm);
   const float cnt = g[c.tail + 1];

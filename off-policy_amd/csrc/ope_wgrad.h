@@ -24,6 +24,7 @@ constexpr int kMaxWgProbs = 16;
 struct WgTable {
   WgProb p[kMaxWgProbs];
   int n, total_waves, wg_reduce;
+  int wbegin[kMaxWgProbs];             // p[q].wave_begin again, contiguous (INT_MAX beyond n): one burst of scalar loads finds a wave's problem
   ObsRef ref;                          // where the problems with ref_row1 > 0 find their B rows (observations left in the store)
 };
 int wg_finish(WgTable* tb);
@@ -86,7 +87,12 @@ struct FinTable {
   int begin[kMaxFinSegs];   // seg[q].begin again, INT_MAX beyond n: filled by launch_finalize (one scalar load burst finds a segment)
   int n;
   int64_t total;  // length of the flat gradient including the tail
+  // column-reduction workgroup b -> segment (low 6 bits) and 16-column block of it: filled by launch_finalize when they fit (ncb > 0); a
+  // workgroup otherwise walks the segment table itself (a serial chain of scalar loads: 3 us at 40 segments)
+  int ncb;
+  unsigned short cb[128];
 };
+constexpr int kMaxColBlocks = 128;
 int launch_fill(float* p, int64_t n, float v, hipStream_t st);
 // workgroups of a finalize launch = number of floats `gsq_part` must hold
 int finalize_blocks(const FinTable& ft);

@@ -43,9 +43,9 @@ __global__ void __launch_bounds__(256, 3) wgrad_kernel(WgTable tb, float* __rest
   const int wid = blockIdx.x * 4 + wave;
   if (wid >= tb.total_waves) return;
   int p = 0;
-#pragma unroll 1
-  for (int q = 1; q < tb.n; ++q)
-    if (wid >= tb.p[q].wave_begin) p = q;
+#pragma unroll
+  for (int q = 1; q < kMaxWgProbs; ++q)      // (a loop over p[q].wave_begin is one dependent scalar load per problem: ~1 us for 13)
+    if (wid >= tb.wbegin[q]) p = q;
   const WgProb& P = tb.p[p];
   const int local = wid - P.wave_begin;
   const int split = local % P.nsplit;
@@ -252,6 +252,7 @@ int wg_finish(WgTable* tb) {
       return OPE_EINVAL;
   }
   tb->total_waves = waves;
+  for (int q = 0; q < kMaxWgProbs; ++q) tb->wbegin[q] = q < tb->n ? tb->p[q].wave_begin : 0x7fffffff;
   tb->wg_reduce = 1;
   for (int q = 0; q < tb->n; ++q)
     if (tb->p[q].nsplit % 4 != 0) tb->wg_reduce = 0;
@@ -358,37 +359,63 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinTable ft, const float*
                                                        int n_main, float* __restrict__ gsq_part) {
   __shared__ float sq[4];
   if ((int)blockIdx.x > n_main) {
-    // Column reductions of the LayerNorm-fed Linears (LNLIN_G / LNLIN_B: M = 14 .. 192 rows, two loads per row). One WAVE
-    // per element: lane l takes rows l, l + 64, ... (at most 3) and the 64 partial sums meet by DPP + readlane (fixed
-    // order). hipcc emits load / wait / fma per row of such a loop, so the rows a lane walks serially are what the launch
-    // waits for: 16 lanes per element (up to 12 rows each) made these blocks the 13 us tail of the launch.
-    const int gid = ((int)blockIdx.x - n_main - 1) * 256 + (int)threadIdx.x;
-    const int sub = gid & 63;
-    int e = gid >> 6, s = -1, local = 0;
+    // Column reductions of the LayerNorm-fed Linears (LNLIN_G / LNLIN_B: M = 14 .. 192 rows, two loads per row). Workgroup = 16
+    // consecutive elements (columns k) of ONE segment: thread (c, rg) = (tid & 15, tid >> 4) takes column k0 + c and rows rg, rg + 16, ...
+    // -- a wave's load touches 4 rows x 64 contiguous bytes (round 5; one wave per element with lane = row read 64 lines per load:
+    // these blocks were 3.3 of the launch's 7.8 us) -- all of a thread's loads (<= 12 per array per pass) issue before the first FMA, the
+    // 16 partial sums of a column meet by two lane swaps and one LDS exchange. Fixed order.
+    __shared__ float red[4][16];
+    int blk = (int)blockIdx.x - n_main - 1, s = -1, k0 = 0;
+    if (ft.ncb > 0) {
+      if (blk < ft.ncb) { const int e = ft.cb[blk]; s = e & 63; k0 = 16 * (e >> 6); }
+    } else {
 #pragma unroll 1
-    for (int q = 0; q < ft.n; ++q) {
-      const int kind = ft.seg[q].kind;
-      if (kind != FIN_LNLIN_G && kind != FIN_LNLIN_B) continue;
-      if (s < 0) {
-        if (e < ft.seg[q].size) { s = q; local = e; }
-        else e -= ft.seg[q].size;
+      for (int q = 0; q < ft.n; ++q) {
+        const int kind = ft.seg[q].kind;
+        if (kind != FIN_LNLIN_G && kind != FIN_LNLIN_B) continue;
+        const int nb = (ft.seg[q].size + 15) >> 4;
+        if (s < 0) {
+          if (blk < nb) { s = q; k0 = 16 * blk; }
+          else blk -= nb;
+        }
       }
     }
     const bool live = s >= 0;
     const FinSeg& F = ft.seg[live ? s : 0];
+    const int c = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int k = k0 + c;
     const int M = live ? F.M : 0, K = F.K;
     const bool colsum = F.kind == FIN_LNLIN_B;
+    const bool ok = live && k < F.size;
     float acc = 0.f;
-    for (int i = sub; i < M; i += 64) {
-      const float w = theta[F.w + (int64_t)i * K + local];
-      acc = colsum ? fmaf(rsum[F.src_s + i], w, acc) : fmaf(w, rsum[F.src + (int64_t)i * K + local], acc);
+    if (ok) {
+      for (int i0 = 0; i0 < M; i0 += 192) {
+        float wv[12], pv[12];
+#pragma unroll
+        for (int u = 0; u < 12; ++u) {
+          const int i = min(i0 + rg + 16 * u, M - 1);
+          wv[u] = theta[F.w + (int64_t)i * K + k];
+          pv[u] = colsum ? rsum[F.src_s + i] : rsum[F.src + (int64_t)i * K + k];
+        }
+#pragma unroll
+        for (int u = 0; u < 12; ++u) acc = (i0 + rg + 16 * u < M) ? fmaf(wv[u], pv[u], acc) : acc;
+      }
     }
-    acc = wave64_sum(acc);
-    if (live && sub == 0) grad[F.begin + local] = acc;
+    acc += __shfl_xor(acc, 16, 64);
+    acc += __shfl_xor(acc, 32, 64);
+    const int wv_ = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) < 16) red[wv_][c] = acc;
+    __syncthreads();
+    float tot = 0.f;
+    if (threadIdx.x < 16) {
+      tot = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+      if (ok) grad[F.begin + k] = tot;
+      else tot = 0.f;
+    }
     if (gsq_part) {
-      if (sub == 0) sq[threadIdx.x >> 6] = live ? acc * acc : 0.f;
-      __syncthreads();
-      if (threadIdx.x == 0) gsq_part[blockIdx.x] = (sq[0] + sq[1]) + (sq[2] + sq[3]);
+      float v = threadIdx.x < 16 ? tot * tot : 0.f;
+      if (threadIdx.x < 64) v = wave64_sum(v);
+      if (threadIdx.x == 0) gsq_part[blockIdx.x] = v;
     }
     return;
   }
@@ -477,19 +504,38 @@ int launch_transpose4(const Transp4& a, hipStream_t st) {
 int finalize_blocks(const FinTable& ft) {
   int64_t n_red = 0;
   for (int q = 0; q < ft.n; ++q)
-    if (ft.seg[q].kind == FIN_LNLIN_G || ft.seg[q].kind == FIN_LNLIN_B) n_red += ft.seg[q].size;
-  return (int)ope_cdiv(ft.total, 256) + 1 + (int)ope_cdiv(n_red * 64, 256);
+    if (ft.seg[q].kind == FIN_LNLIN_G || ft.seg[q].kind == FIN_LNLIN_B) n_red += ope_cdiv(ft.seg[q].size, 16);      // one workgroup per 16 columns
+  return (int)ope_cdiv(ft.total, 256) + 1 + (int)n_red;
 }
 
 int launch_finalize(const FinTable& ft0, const float* rsum, const float* theta, const float* loss_part, int n_loss_tiles,
                     float* grad, hipStream_t st, float* gsq_part) {
   FinTable t = ft0;
   for (int q = 0; q < kMaxFinSegs; ++q) t.begin[q] = q < t.n ? t.seg[q].begin : 0x7fffffff;
+  t.ncb = 0;
+  {
+    int n = 0;
+    bool fits = true;
+    for (int q = 0; q < t.n && fits; ++q) {
+      if (t.seg[q].kind != FIN_LNLIN_G && t.seg[q].kind != FIN_LNLIN_B) continue;
+      const int nb = (int)ope_cdiv(t.seg[q].size, 16);
+      if (q >= 64 || nb > 1024 || n + nb > kMaxColBlocks) { fits = false; break; }
+      for (int b = 0; b < nb; ++b) t.cb[n++] = (unsigned short)(q | (b << 6));
+    }
+    t.ncb = fits ? n : 0;
+  }
   const FinTable& ft = t;
   const int n_main = (int)ope_cdiv(ft.total, 256);
-  // blocks [0, n_main): one thread per element; block n_main: the loss tail; the rest: one wave per column reduction
+  // blocks [0, n_main): one thread per element; block n_main: the loss tail; the rest: one workgroup per 16 column reductions
   kprof_work(0.0, 4.0 * 3.0 * (double)ft.total);       // rsum + theta in, grad out (plus the small column reductions)
-  OPE_LAUNCH(finalize_kernel, dim3(finalize_blocks(ft)), dim3(256), 0, st, ft, rsum, theta, loss_part, n_loss_tiles, grad, n_main,
+  int blocks = finalize_blocks(ft);
+#ifdef OPE_EXPERIMENTS
+  // OPE_FIN_EXP (timing only, the gradient is INCOMPLETE): 1 = the element-wise blocks alone, 2 = + the loss-tail block (no column reductions)
+  static const int fexp = getenv("OPE_FIN_EXP") ? atoi(getenv("OPE_FIN_EXP")) : 0;
+  if (fexp == 1) blocks = n_main;
+  if (fexp == 2) blocks = n_main + 1;
+#endif
+  OPE_LAUNCH(finalize_kernel, dim3(blocks), dim3(256), 0, st, ft, rsum, theta, loss_part, n_loss_tiles, grad, n_main,
                      gsq_part);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   return OPE_OK;
