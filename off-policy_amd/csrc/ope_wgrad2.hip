@@ -315,46 +315,63 @@ __global__ void __launch_bounds__(256, 1) wgrad2_kernel(W2Table tb, float* __res
   }
 }
 
-// rsum[...] = sum over a unit's workgroup slabs. Workgroup = (unit, ONE 64-float row of a tile or of the column sums): wave w of eight
-// sums the slabs w, w + 8, ... in that order (a lane = one column: 256-byte coalesced reads, at most nine loads in flight per lane -- the
-// chain of a lane that walks all ~70 slabs alone is what the first version waited for), the partial sums meet through LDS as
-// ((w0 + w1) + (w2 + w3)) + ((w4 + w5) + (w6 + w7)). Fixed order.
+// rsum[...] = sum over a unit's workgroup slabs. Workgroup = (unit, FOUR 64-float rows of its tiles / column sums): wave w of eight
+// sums the slabs w, w + 8, ... in that order for each of the four rows (a lane = one column: 256-byte coalesced reads, up to 36 loads in
+// flight per lane -- the chain of a lane that walks all ~70 slabs alone is what the first version waited for, and one row per workgroup
+// (3 120 workgroups of 512 threads, three residency rounds of a ~2 us latency chain each) what the second one did), the partial sums meet
+// through LDS as ((w0 + w1) + (w2 + w3)) + ((w4 + w5) + (w6 + w7)), wave r finishing row r. Fixed order.
+constexpr int kRedRows = 4;
 __global__ void __launch_bounds__(512) w2_reduce_kernel(W2Table tb, const float* __restrict__ raw, float* __restrict__ rsum) {
-  __shared__ float part[8][64];
-  const W2Unit& U = tb.u[blockIdx.y];      // grid = (rows of the largest unit, units): no search
+  __shared__ float part[kRedRows][8][64];
+  const W2Unit& U = tb.u[blockIdx.y];      // grid = (row quads of the largest unit, units): no search
   const WgProb& P = tb.p[U.prob];
-  const int local = blockIdx.x;
   const int ntile = U.pa * U.pb;
-  if (local >= U.red_rows) return;
+  if ((int)blockIdx.x * kRedRows >= U.red_rows) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float* __restrict__ src = raw + (int64_t)U.wg_begin * kW2Slab;
   float* __restrict__ dst = rsum + P.rs_base;
   const int nwg = U.nwg;
-  const float* s;
-  int64_t out;
-  bool live;
-  if (local >= ntile * 64) {      // a panel's column sums
-    const int a = local - ntile * 64;
-    const int m = 64 * (U.mp0 + a) + lane;
-    s = src + 4 * 4096 + a * 64 + lane;
-    out = P.s_off + m;
-    live = m < P.M;
-  } else {
-    const int t = local >> 6, ml = local & 63;
-    const int a = t / U.pb, b = t - a * U.pb;
-    const int m = 64 * (U.mp0 + a) + ml, n = 64 * (U.np0 + b) + lane;
-    if (m >= P.M) return;      // (uniform)
-    s = src + t * 4096 + ml * 64 + lane;
-    out = P.out_off + (int64_t)m * P.ldc + n;
-    live = n < P.N;
+  const float* s[kRedRows];
+  int64_t out[kRedRows];
+  bool live[kRedRows];
+#pragma unroll
+  for (int r = 0; r < kRedRows; ++r) {
+    const int local = (int)blockIdx.x * kRedRows + r;
+    if (local >= U.red_rows) {              // (uniform) past the unit's rows: reads row 0 again, writes nothing
+      s[r] = src + lane; out[r] = 0; live[r] = false;
+    } else if (local >= ntile * 64) {       // a panel's column sums
+      const int a = local - ntile * 64;
+      const int m = 64 * (U.mp0 + a) + lane;
+      s[r] = src + 4 * 4096 + a * 64 + lane;
+      out[r] = P.s_off + m;
+      live[r] = m < P.M;
+    } else {
+      const int t = local >> 6, ml = local & 63;
+      const int a = t / U.pb, b = t - a * U.pb;
+      const int m = 64 * (U.mp0 + a) + ml, n = 64 * (U.np0 + b) + lane;
+      s[r] = src + t * 4096 + ml * 64 + lane;
+      out[r] = P.out_off + (int64_t)m * P.ldc + n;
+      live[r] = m < P.M && n < P.N;
+    }
   }
-  float v = 0.f;
+  float v[kRedRows] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 9
-  for (int q = wave; q < nwg; q += 8) v += s[(int64_t)q * kW2Slab];
-  part[wave][lane] = v;
+  for (int q = wave; q < nwg; q += 8) {
+#pragma unroll
+    for (int r = 0; r < kRedRows; ++r) v[r] += s[r][(int64_t)q * kW2Slab];
+  }
+#pragma unroll
+  for (int r = 0; r < kRedRows; ++r) part[r][wave][lane] = v[r];
   __syncthreads();
-  if (wave == 0 && live)
-    dst[out] = ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])) + ((part[4][lane] + part[5][lane]) + (part[6][lane] + part[7][lane]));
+  int64_t o = 0;
+  bool lv = false;
+#pragma unroll
+  for (int r = 0; r < kRedRows; ++r)      // (selects, not an index: the arrays stay in registers)
+    if (wave == r) { o = out[r]; lv = live[r]; }
+  if (lv) {
+    const float(&p)[8][64] = part[wave];
+    dst[o] = ((p[0][lane] + p[1][lane]) + (p[2][lane] + p[3][lane])) + ((p[4][lane] + p[5][lane]) + (p[6][lane] + p[7][lane]));
+  }
 }
 
 }  // namespace
@@ -539,7 +556,7 @@ int launch_wgrad2(const W2Table& w, float* raw, float* rsum, hipStream_t st) {
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   note_launch("wgrad2", v4 ? 4 : 2);
   kprof_work(0.0, 4.0 * (double)w.total_wg * kW2Slab);
-  OPE_LAUNCH(w2_reduce_kernel, dim3(w.red_blocks, w.nu), dim3(512), 0, st, w, raw, rsum);
+  OPE_LAUNCH(w2_reduce_kernel, dim3((w.red_blocks + kRedRows - 1) / kRedRows, w.nu), dim3(512), 0, st, w, raw, rsum);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   return OPE_OK;
 }

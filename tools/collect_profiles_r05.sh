@@ -6,7 +6,7 @@
 # Counter passes never carry a trace domain besides --kernel-trace (--pmc with sys/hip/hsa traces is refused on this pool).
 cd ${GRAFT_REPO_ROOT:-.}
 export TMPDIR=/tmp
-TAG=${1:-r05e}
+TAG=${1:-r05g}
 O=gpurun_out/$TAG
 mkdir -p $O
 eps() { case $1 in 3m|MMM2|3s5z_gall) echo "--episodes 1000";; *) echo "";; esac; }
