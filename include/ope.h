@@ -55,10 +55,11 @@ typedef struct ope_dims {
 /* args.use_feature_normalization = False (config.py:69, mlp.py:60-62, 77-78): the agent network has no input LayerNorm. The flat
  * parameter layout is UNCHANGED -- the two feature_norm slots stay where they are and must hold ones / zeros (the host mirrors do not
  * expose them as parameters; their gradient is written as zero) -- and the first-layer kernels take the rows as they are (mean 0,
- * 1/std 1): x * 1 + 0 is exact, so every other kernel and the weight-gradient identities run unchanged. Recurrent QMIX / VDN nets. */
+ * 1/std 1): x * 1 + 0 is exact, so every other kernel and the weight-gradient identities run unchanged. Recurrent and (round 5) MLP
+ * QMIX / VDN nets (ope_qmix_cfg with or without .mlp, ope_agent_forward, ope_agent_forward_mlp). */
 #define OPE_DIMS_NO_FEATURE_NORM 1
 /* args.use_ReLU = False (config.py:67, mlp.py:9-12): tanh instead of ReLU behind fc1 and fc2 of the agent network's MLP base (the
- * hyper-networks keep their ReLU, q_mixer.py). Recurrent QMIX / VDN nets with one hidden block and an input width <= 384: the
+ * hyper-networks keep their ReLU, q_mixer.py). Recurrent and (round 5) MLP QMIX / VDN nets with one hidden block and an input width <= 384: the
  * register-resident trunk kernels (trunk_fwd3 / trunk_bwd3) carry the activation -- tanh as 2 / (1 + 2^(-2 log2(e) x)) - 1, its
  * derivative 1 - a^2 rebuilt from the saved normalised activation, 1/std and the row mean (kept in the slot of the unused ReLU mask). */
 #define OPE_DIMS_TANH 2

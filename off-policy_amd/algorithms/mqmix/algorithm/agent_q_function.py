@@ -71,11 +71,20 @@ class AgentQFunction(FlatModule):
             act_dim = int(sum(head_dims))
         self.head_dims = head_dims
         input_dim, act_dim, device = int(input_dim), int(act_dim), torch.device(device)
+        # use_feature_normalization = False (mlp.py:60-62) / use_ReLU = False (mlp.py:9-12), as the recurrent module: the two feature_norm
+        # slots of the flat vector stay (ones / zeros, not parameters: OPE_DIMS_NO_FEATURE_NORM), tanh rides on OPE_DIMS_TANH (input <= 384)
+        self.feature_norm = bool(getattr(args, "use_feature_normalization", True))
+        self.use_relu = bool(getattr(args, "use_ReLU", True))
+        if not self.use_relu and input_dim > 384:
+            raise NotImplementedError("use_ReLU=False (tanh) on the accelerated path: network input width <= 384")
         offs, sizes, total = mlp_agent_layout(input_dim, act_dim)
+        offs_all = list(offs)
         own = flat is None
         if own:
             flat = torch.zeros(total, dtype=torch.float32, device=device)
         names, shapes = list(MLP_AGENT_PARAM_NAMES), mlp_agent_param_shapes(input_dim, act_dim)
+        keep = [i for i, k in enumerate(names) if self.feature_norm or not k.startswith("mlp.feature_norm.")]
+        names, shapes, offs = [names[i] for i in keep], [shapes[i] for i in keep], [offs[i] for i in keep]
         if head_dims is not None:
             ow, ob = offs[-2], offs[-1]
             names, shapes, offs = names[:-2], shapes[:-2], list(offs[:-2])
@@ -86,12 +95,17 @@ class AgentQFunction(FlatModule):
                 offs += [ow + lo * H, ob + lo]
                 lo += d
         super().__init__(names, shapes, offs, flat)
+        if not self.feature_norm:
+            with torch.no_grad():
+                flat[offs_all[0]:offs_all[0] + input_dim] = 1.0
+                flat[offs_all[1]:offs_all[1] + input_dim] = 0.0
         self.input_dim, self.act_dim, self.hidden_size, self.device = input_dim, act_dim, H, device
         self.padded_numel = total
         self._args = args
         if own and _init:
             vals = init_mlp_agent_values(input_dim, act_dim, getattr(args, "use_orthogonal", True), getattr(args, "gain", 0.01),
                                          getattr(args, "use_ReLU", True), head_dims=head_dims)
+            vals = [vals[i] for i in keep]
             if head_dims is not None:
                 qw, qb = vals[-2], vals[-1]
                 vals = vals[:-2]
@@ -101,7 +115,8 @@ class AgentQFunction(FlatModule):
                     lo += d
             for p, v in zip(self.parameters(), vals):
                 p.data.copy_(v)
-        self._dims = _lib.Dims(1, act_dim, input_dim, 1, 1)
+        self._dims = _lib.Dims(1, act_dim, input_dim, 1, 1, 1,
+                               (0 if self.feature_norm else _lib.OPE_DIMS_NO_FEATURE_NORM) | (0 if self.use_relu else _lib.OPE_DIMS_TANH))
         self._ws = None
 
     def twin(self, flat):

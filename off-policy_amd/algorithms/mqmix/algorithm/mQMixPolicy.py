@@ -13,7 +13,7 @@ class M_QMixPolicy(object):
     def __init__(self, config, policy_config, train=True):
         self.args = config["args"]
         self.device = torch.device(config["device"])
-        require_reference_architecture(self.args)
+        require_reference_architecture(self.args, allow_no_feature_norm=True, allow_tanh=True)      # (round 5: the two flags that only touch the first layer / the activation)
         self.obs_space = policy_config["obs_space"]
         self.obs_dim = get_dim_from_space(self.obs_space)
         self.act_space = policy_config["act_space"]

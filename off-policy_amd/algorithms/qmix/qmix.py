@@ -56,7 +56,7 @@ class QMix(object):
         # (the policies check their own support); one-layer hyper-networks: recurrent nets, one shared policy (checked below)
         # (VDN has no hyper-networks: args.hypernet_layers is irrelevant there and is ignored -- ADVICE r4)
         require_reference_architecture(args, allow_prev_act_inp=not self._mlp, allow_hypernet_layers_1=vdn or not self._mlp,
-                                       allow_layer_N_2=not self._mlp, allow_no_feature_norm=not self._mlp, allow_tanh=not self._mlp)
+                                       allow_layer_N_2=not self._mlp, allow_no_feature_norm=True, allow_tanh=True)
         self.layer_N = int(getattr(args, "layer_N", 1))
         self.dims_flags = (0 if getattr(args, "use_feature_normalization", True) else _lib.OPE_DIMS_NO_FEATURE_NORM) | \
                           (0 if getattr(args, "use_ReLU", True) else _lib.OPE_DIMS_TANH)

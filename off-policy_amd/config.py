@@ -37,9 +37,9 @@ def require_reference_architecture(args, allow_prev_act_inp=False, allow_hyperne
     `hypernet_layers = 1` (one-layer hyper-networks, q_mixer.py:39-44) is supported by the recurrent QMIX trainer with one shared
     policy (`allow_hypernet_layers_1`; the fused chain kernels, csrc/ope_chain.hip); `layer_N = 2` (a second hidden block behind fc1,
     mlp.py:14-28) by the recurrent QMIX / VDN trainer and its policy (`allow_layer_N_2`; csrc/ope_block.hip);
-    `use_feature_normalization = False` (no LayerNorm on the network input, mlp.py:60-62) by the same trainer and policy
-    (`allow_no_feature_norm`; OPE_DIMS_NO_FEATURE_NORM in include/ope.h); `use_ReLU = False` (tanh in the MLP base, mlp.py:9-12)
-    likewise (`allow_tanh`; OPE_DIMS_TANH: one hidden block, input width <= 384)."""
+    `use_feature_normalization = False` (no LayerNorm on the network input, mlp.py:60-62) by the same trainer and policy and by the MLP
+    Q-learning family (`allow_no_feature_norm`; OPE_DIMS_NO_FEATURE_NORM in include/ope.h); `use_ReLU = False` (tanh in the MLP base,
+    mlp.py:9-12) likewise (`allow_tanh`; OPE_DIMS_TANH: one hidden block, input width <= 384)."""
     want = dict(hidden_size=64, layer_N=1, use_ReLU=True, use_feature_normalization=True, use_conv1d=False,
                 prev_act_inp=False, use_rnn_layer=True, recurrent_N=1, hypernet_layers=2, mixer_hidden_dim=32,
                 hypernet_hidden_dim=64, use_popart=False)

@@ -27,8 +27,7 @@ bool cfg_ok(const ope_qmix_cfg* c) {
   if (c->hypernet_layers < 0 || c->hypernet_layers > 2) return false;
   if (d.layer_N < 0 || d.layer_N > 2) return false;
   if (d.flags & ~(OPE_DIMS_NO_FEATURE_NORM | OPE_DIMS_TANH | OPE_DIMS_MASK_TARGET_MAX)) return false;
-  if ((d.flags & OPE_DIMS_NO_FEATURE_NORM) && c->mlp) return false;      // no input LayerNorm: the recurrent nets
-  if ((d.flags & OPE_DIMS_TANH) && (c->mlp || c->phase != 0 || d.layer_N == 2 || d.obs_dim > 384 || c->trunk_path == 4)) return false;   // tanh: trunk_fwd3 / trunk_bwd3
+  if ((d.flags & OPE_DIMS_TANH) && (c->phase != 0 || d.layer_N == 2 || d.obs_dim > 384 || c->trunk_path == 4)) return false;   // tanh: trunk_fwd3 / trunk_bwd3
   if (d.layer_N == 2 && (c->mlp || c->phase != 0 || c->time_chunks > 1)) return false;      // a second hidden block: whole steps of recurrent nets
   if (c->hypernet_layers == 1 && (c->mlp || c->phase != 0 || c->mixer_path == 3 || c->chain_path == 1)) return false;   // one-layer hyper-networks: the fused chain only
   return d.n_agents >= 1 && d.act_dim >= 1 && d.obs_dim >= 1 && d.obs_dim <= 512 && d.state_dim >= 1 &&
@@ -931,7 +930,8 @@ extern "C" int ope_agent_forward_mlp(const ope_dims* d, int32_t rows, const floa
                                      int64_t workspace_bytes, float* q_out, void* stream) {
   (void)hipGetLastError();
   if (!d || rows < 1 || !obs || !theta || !workspace || !q_out) return OPE_EINVAL;
-  if (d->obs_dim < 1 || d->obs_dim > 512 || d->act_dim < 1 || d->flags) return OPE_EINVAL;
+  if (d->obs_dim < 1 || d->obs_dim > 512 || d->act_dim < 1 || (d->flags & ~(OPE_DIMS_NO_FEATURE_NORM | OPE_DIMS_TANH | OPE_DIMS_MASK_TARGET_MAX))) return OPE_EINVAL;
+  if ((d->flags & OPE_DIMS_TANH) && d->obs_dim > 384) return OPE_EINVAL;      // (only trunk_fwd3 carries the activation)
   if (workspace_bytes < ope_agent_forward_mlp_workspace_bytes(d, rows)) return OPE_ENOSPC;
   hipStream_t st = (hipStream_t)stream;
   const AgentLayout L = ope_agent_layout_mlp(d->obs_dim, d->act_dim, 0);
@@ -940,6 +940,8 @@ extern "C" int ope_agent_forward_mlp(const ope_dims* d, int32_t rows, const floa
   TrunkFwdArgs tf;
   memset(&tf, 0, sizeof(tf));
   tf.x = obs; tf.R = rows; tf.D = d->obs_dim; tf.theta = theta; tf.L = L; tf.a2_out = a2;
+  tf.no_fn = (d->flags & OPE_DIMS_NO_FEATURE_NORM) ? 1 : 0;
+  tf.tanh_act = (d->flags & OPE_DIMS_TANH) ? 1 : 0;
   if ((rc = launch_trunk_fwd(tf, false, st))) return rc;
   HeadFwdArgs hf;
   memset(&hf, 0, sizeof(hf));

@@ -16,10 +16,9 @@ import torch.nn.functional as F
 from .qmix_oracle import layer_norm, qmixer_forward, huber, HP, q_head_dims
 
 
-def mlp_agent_param_shapes(obs_dim, act_dim, hidden=64):
+def mlp_agent_param_shapes(obs_dim, act_dim, hidden=64, feature_norm=True):
     H = hidden
-    return OrderedDict([
-        ("mlp.feature_norm.weight", (obs_dim,)), ("mlp.feature_norm.bias", (obs_dim,)),
+    return OrderedDict(([("mlp.feature_norm.weight", (obs_dim,)), ("mlp.feature_norm.bias", (obs_dim,))] if feature_norm else []) + [   # mlp.py:60-62
         ("mlp.mlp.fc1.0.weight", (H, obs_dim)), ("mlp.mlp.fc1.0.bias", (H,)),
         ("mlp.mlp.fc1.2.weight", (H,)), ("mlp.mlp.fc1.2.bias", (H,)),
         ("mlp.mlp.fc_h.0.weight", (H, H)), ("mlp.mlp.fc_h.0.bias", (H,)),
@@ -30,18 +29,21 @@ def mlp_agent_param_shapes(obs_dim, act_dim, hidden=64):
     ])
 
 
-def mlp_base(P, x, prefix="mlp."):
-    """MLPBase.forward, layer_N = 1 (algorithms/utils/mlp.py:76-89)."""
-    x = layer_norm(x, P[prefix + "feature_norm.weight"], P[prefix + "feature_norm.bias"])
-    x = layer_norm(F.relu(F.linear(x, P[prefix + "mlp.fc1.0.weight"], P[prefix + "mlp.fc1.0.bias"])),
+def mlp_base(P, x, prefix="mlp.", use_relu=True):
+    """MLPBase.forward, layer_N = 1 (algorithms/utils/mlp.py:76-89). The input LayerNorm only with use_feature_normalization (mlp.py:60-62,
+    77-78: absent from the parameter dict otherwise); active_func = [nn.Tanh(), nn.ReLU()][use_ReLU] (mlp.py:9-12)."""
+    act = F.relu if use_relu else torch.tanh
+    if prefix + "feature_norm.weight" in P:
+        x = layer_norm(x, P[prefix + "feature_norm.weight"], P[prefix + "feature_norm.bias"])
+    x = layer_norm(act(F.linear(x, P[prefix + "mlp.fc1.0.weight"], P[prefix + "mlp.fc1.0.bias"])),
                    P[prefix + "mlp.fc1.2.weight"], P[prefix + "mlp.fc1.2.bias"])
-    x = layer_norm(F.relu(F.linear(x, P[prefix + "mlp.fc2.0.0.weight"], P[prefix + "mlp.fc2.0.0.bias"])),
+    x = layer_norm(act(F.linear(x, P[prefix + "mlp.fc2.0.0.weight"], P[prefix + "mlp.fc2.0.0.bias"])),
                    P[prefix + "mlp.fc2.0.2.weight"], P[prefix + "mlp.fc2.0.2.bias"])
     return x
 
 
-def mlp_agent_q(P, x):
-    y = mlp_base(P, x)
+def mlp_agent_q(P, x, use_relu=True):
+    y = mlp_base(P, x, use_relu=use_relu)
     if "q.action_out.weight" in P:
         return F.linear(y, P["q.action_out.weight"], P["q.action_out.bias"])
     # MultiDiscrete action space (act.py:14-17, 28-33): one Linear head per sub-action, their q blocks side by side
@@ -60,9 +62,10 @@ def mlp_agent_qs(hp, agent, agent_tgt, obs, acts, nobs, navail):
     """The per-policy part of M_QMix.train_policy_on_batch (mqmix.py:95-174): q values of the actions taken [B, n] (with grad) and the
     target network's next-step q values at the greedy actions [B, n] (no grad) for ONE policy's agents (torch tensors, [n, B, .])."""
     n, B, D = obs.shape
+    relu = bool(getattr(hp, "use_relu", True))
     s_obs, s_nobs, s_act = torch.cat(list(obs), 0), torch.cat(list(nobs), 0), torch.cat(list(acts), 0)
     s_nav = torch.cat(list(navail), 0) if navail is not None else None
-    q_all = mlp_agent_q(agent, s_obs)
+    q_all = mlp_agent_q(agent, s_obs, relu)
     heads = q_head_dims(agent)
     if len(heads) > 1:
         # MultiDiscrete (mqmix.py:116-130, 144-155; mQMixPolicy.py:47-55): chosen / greedy / target q per sub-action head, one mixer input per
@@ -71,8 +74,8 @@ def mlp_agent_qs(hp, agent, agent_tgt, obs, acts, nobs, navail):
         q_taken = torch.cat([torch.gather(qb, 1, ab.max(dim=-1)[1].unsqueeze(-1)) for qb, ab in zip(q_all.split(heads, -1), s_act.split(heads, -1))], dim=-1)
         agent_q = torch.cat(q_taken.split(B, dim=0), dim=-1)                      # [B, n * heads]
         with torch.no_grad():
-            nq_blocks = mlp_agent_q(agent, s_nobs).detach().split(heads, -1)
-            tq_blocks = mlp_agent_q(agent_tgt, s_nobs).split(heads, -1)
+            nq_blocks = mlp_agent_q(agent, s_nobs, relu).detach().split(heads, -1)
+            tq_blocks = mlp_agent_q(agent_tgt, s_nobs, relu).split(heads, -1)
             tq = torch.cat([torch.gather(tb, 1, nb.max(dim=-1)[1].unsqueeze(-1)) for tb, nb in zip(tq_blocks, nq_blocks)], dim=-1)
             agent_nq = torch.cat(tq.split(B, dim=0), dim=-1)
         return agent_q, agent_nq
@@ -80,13 +83,13 @@ def mlp_agent_qs(hp, agent, agent_tgt, obs, acts, nobs, navail):
     agent_q = torch.cat(q_taken.split(B, dim=0), dim=-1)                          # [B, n]
     with torch.no_grad():
         if hp.use_double_q:
-            nq = mlp_agent_q(agent, s_nobs).detach().clone()
+            nq = mlp_agent_q(agent, s_nobs, relu).detach().clone()
             if s_nav is not None:
                 nq[s_nav == 0.0] = -1e10
             nact = nq.max(dim=-1)[1]
-            tq = torch.gather(mlp_agent_q(agent_tgt, s_nobs), 1, nact.unsqueeze(-1))
+            tq = torch.gather(mlp_agent_q(agent_tgt, s_nobs, relu), 1, nact.unsqueeze(-1))
         else:
-            tqa = mlp_agent_q(agent_tgt, s_nobs).clone()
+            tqa = mlp_agent_q(agent_tgt, s_nobs, relu).clone()
             if s_nav is not None:
                 tqa[s_nav == 0.0] = -1e10
             tq = tqa.max(dim=-1)[0].unsqueeze(-1)

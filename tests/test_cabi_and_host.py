@@ -162,7 +162,7 @@ def test_network_without_input_layernorm_keeps_the_layout_and_hides_two_slots():
         if not k.startswith("rnn.feature_norm."):
             assert np.array_equal(v.numpy(), g["agent/" + k]), k
     cfg.mlp, cfg.dims.episode_length = 1, 1
-    assert _lib.lib.ope_qmix_workspace_bytes(C.byref(cfg)) == -1              # the recurrent nets only
+    assert _lib.lib.ope_qmix_workspace_bytes(C.byref(cfg)) > 0                # round 5: the MLP Q-learning nets too (fixtures mqmix_shape_nofn, ...)
     cfg.mlp, cfg.dims.episode_length, cfg.dims.flags = 0, t, 8
     assert _lib.lib.ope_qmix_workspace_bytes(C.byref(cfg)) == -1              # unknown flag bits
     dd = _lib.DdpgCfg()
@@ -463,3 +463,32 @@ def test_multi_discrete_policies_reproduce_the_reference_initialisation(name, ml
     mv = init_mixer_values(n * len(heads), s)
     for v, k in zip(mv, MIXER_PARAM_NAMES):
         assert np.array_equal(v.numpy(), g["mixer/" + k]), k
+
+
+@pytest.mark.parametrize("name", ["mqmix_shape_nofn", "mqmix_shape_tanh", "mqmix_var_tanh_nofn_huber_per"])
+def test_mlp_q_networks_with_shape_flags_initialise_like_the_reference(name):
+    """Round 5: use_feature_normalization = False / use_ReLU = False for the MLP Q-learning family. Same RNG stream as the reference's
+    constructor (the tanh gain included), the input LayerNorm's two tensors absent from the exposed parameters, and the C-ABI takes the flags
+    in MLP mode (tanh up to the 384 inputs trunk_fwd3 carries)."""
+    import torch
+    from conftest import load_golden
+    from offpolicy_amd import _lib
+    from offpolicy_amd.algorithms.mqmix.algorithm.agent_q_function import init_mlp_agent_values, MLP_AGENT_PARAM_NAMES
+    g = load_golden(name)
+    n, a, d, s, _ = [int(x) for x in g["dims"]]
+    relu, fn = bool(g["hp_use_relu"]), "agent/mlp.feature_norm.weight" in g
+    torch.manual_seed(1)
+    np.random.seed(1)
+    vals = init_mlp_agent_values(d, a, use_ReLU=relu)
+    for v, k in zip(vals, MLP_AGENT_PARAM_NAMES):
+        if fn or not k.startswith("mlp.feature_norm."):
+            assert np.array_equal(v.numpy(), g["agent/" + k]), k
+    assert [k[len("agent/"):] for k in g if k.startswith("agent/")] == [k for k in MLP_AGENT_PARAM_NAMES if fn or not k.startswith("mlp.feature_norm.")]
+    cfg = _lib.QmixCfg()
+    flags = (0 if fn else _lib.OPE_DIMS_NO_FEATURE_NORM) | (0 if relu else _lib.OPE_DIMS_TANH)
+    cfg.dims, cfg.batch, cfg.mlp = _lib.Dims(n, a, d, s, 1, 1, flags), 6, 1
+    assert _lib.lib.ope_qmix_workspace_bytes(C.byref(cfg)) > 0
+    cfg.dims.obs_dim = 400
+    assert (_lib.lib.ope_qmix_workspace_bytes(C.byref(cfg)) > 0) == relu      # tanh: network input <= 384
+    cfg.dims.obs_dim, cfg.dims.layer_N = d, 2
+    assert _lib.lib.ope_qmix_workspace_bytes(C.byref(cfg)) == -1              # a second hidden block: the recurrent nets only

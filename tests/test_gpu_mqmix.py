@@ -23,6 +23,8 @@ def build(g, device="cuda:0"):
                         use_huber_loss=bool(g["hp_huber"]), huber_delta=float(g["hp_delta"]), use_per=bool(g["hp_per"]),
                         per_nu=float(g["hp_nu"]), per_eps=float(g["hp_per_eps"]), tau=float(g["hp_tau"]),
                         max_grad_norm=float(g["hp_maxnorm"]), use_double_q=bool(g["hp_double_q"]))
+    args.use_ReLU = bool(g["hp_use_relu"]) if "hp_use_relu" in g else True
+    args.use_feature_normalization = "agent/mlp.feature_norm.weight" in g
     pinfo = policy_info_for(dims)
     buf = MlpReplayBuffer(pinfo, {"policy_0": list(range(n))}, int(g["cap"]), True, True, False, device=device)
     wrap = lambda pre: [{"policy_0": g[pre + k]} for k in T_KEYS]
@@ -82,14 +84,16 @@ def test_numpy_batch_from_reference_buffer_is_accepted():
     np.testing.assert_allclose(float(info["loss"]), g["loss"][0], rtol=RTOL)
 
 
-def test_policy_q_values_match_oracle():
+@pytest.mark.parametrize("name", ["mqmix_spread", "mqmix_shape_nofn", "mqmix_shape_tanh", "mqmix_var_tanh_nofn_huber_per"])
+def test_policy_q_values_match_oracle(name):
     from oracle import mqmix_oracle as MO
-    g = load_golden("mqmix_spread")
+    g = load_golden(name)
     dims, buf, policy, trainer = build(g)
+    assert list(policy.q_network.state_dict().keys()) == list(sub(g, "agent/").keys())      # (no feature_norm.* without the input LayerNorm)
     P = {k: torch.as_tensor(v) for k, v in sub(g, "agent/").items()}
     torch.manual_seed(0)
     x = torch.randn(37, dims.obs_dim)
-    ref = MO.mlp_agent_q(P, x)
+    ref = MO.mlp_agent_q(P, x, use_relu=bool(g["hp_use_relu"]) if "hp_use_relu" in g else True)
     got = policy.get_q_values(x.cuda())
     np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=2e-6)
     acts, gq = policy.get_actions(x.cuda())

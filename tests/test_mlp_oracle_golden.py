@@ -6,7 +6,9 @@ from conftest import load_golden, sub
 from oracle import mqmix_oracle as MO
 from oracle.qmix_oracle import HP
 
-CASES = ["mqmix_spread", "mqmix_small_huber_per", "mqmix_small_nodouble", "mvdn_spread"]
+CASES = ["mqmix_spread", "mqmix_small_huber_per", "mqmix_small_nodouble", "mvdn_spread",
+         # round 5: use_feature_normalization = False / use_ReLU = False (tanh) for the MLP family (oracle/make_golden_mlp.py, OPE_GOLDEN_ONLY=shapes)
+         "mqmix_shape_nofn", "mqmix_shape_tanh", "mqmix_var_tanh_nofn_huber_per", "mvdn_var_tanh_nofn"]
 T_KEYS = ("obs", "share_obs", "acts", "rewards", "next_obs", "next_share_obs", "dones", "dones_env", "valid_transition",
           "avail_acts", "next_avail_acts")
 
@@ -32,6 +34,7 @@ def mlp_oracle_from(g):
     hp = HP(gamma=float(g["hp_gamma"]), lr=float(g["hp_lr"]), opti_eps=float(g["hp_eps"]), use_huber_loss=bool(g["hp_huber"]),
             huber_delta=float(g["hp_delta"]), use_per=bool(g["hp_per"]), per_nu=float(g["hp_nu"]), per_eps=float(g["hp_per_eps"]),
             tau=float(g["hp_tau"]), max_grad_norm=float(g["hp_maxnorm"]), use_double_q=bool(g["hp_double_q"]), vdn=bool(g["vdn"]))
+    hp.use_relu = bool(g["hp_use_relu"]) if "hp_use_relu" in g else True
     return MO.MQMixOracle(sub(g, "agent/"), sub(g, "mixer/") if not bool(g["vdn"]) else None, int(g["dims"][0]), hp)
 
 
@@ -39,7 +42,7 @@ def mlp_oracle_from(g):
 def test_sample_and_train_match_reference(name):
     g = load_golden(name)
     n, a, d, s, _ = [int(x) for x in g["dims"]]
-    assert list(sub(g, "agent/").keys()) == list(MO.mlp_agent_param_shapes(d, a).keys())
+    assert list(sub(g, "agent/").keys()) == list(MO.mlp_agent_param_shapes(d, a, feature_norm="agent/mlp.feature_norm.weight" in g).keys())
     store = mlp_store_from(g)
     batch = MO.sample_inds(store, g["inds"])
     for k, got in zip(T_KEYS, batch):
