@@ -162,11 +162,16 @@ def test_timed_oracle_path_runs_at_reference_speed(workload, n_threads):
                 fast.train_step(O.sample_inds(store, rng.choice(n_ep, B)), fused_gru=True, soft_update=True)
         best = {"ref": 1e9, "orc": 1e9}
         ref_step(); orc_step()
-        for _ in range(5 if workload == "3m" else 3):
-            for name, f in (("ref", ref_step), ("orc", orc_step)):
-                t0 = time.perf_counter()
-                f(); f()
-                best[name] = min(best[name], (time.perf_counter() - t0) / 2)
+        # best-of timing, interleaved; a shared container's noise only ever makes a sample slower, so the comparison is repeated (up to three
+        # rounds, keeping every sample's minimum) before the bound is declared missed
+        for attempt in range(3):
+            for _ in range(5 if workload == "3m" else 3):
+                for name, f in (("ref", ref_step), ("orc", orc_step)):
+                    t0 = time.perf_counter()
+                    f(); f()
+                    best[name] = min(best[name], (time.perf_counter() - t0) / 2)
+            if best["ref"] / best["orc"] >= 0.9:
+                break
     finally:
         torch.set_num_threads(threads)
     assert best["ref"] / best["orc"] >= 0.9, "timed oracle path %.1f ms/step vs reference %.1f ms/step" % (1e3 * best["orc"], 1e3 * best["ref"])
