@@ -367,9 +367,11 @@ def step_roofline(r0, steps):
             "frac": round(tfs / F32_MFMA_PEAK_TFLOPS, 5), "per_kernel": pk}
 
 
-def gather_profile(enable):
+def gather_profile(enable, every=1):
+    """`every` = N: every N-th gather launch of the region carries the event pair (a pair costs the stream ~3.5 us -- timing all of them taxed
+    the timed region by 1 %: 0.3410 vs 0.3375 ms per step, measured as the step the 513th launch of a run, the first one without events)."""
     from offpolicy_amd import _lib
-    _lib.check(_lib.lib.ope_store_gather_profile(1 if enable else 0), "ope_store_gather_profile")
+    _lib.check(_lib.lib.ope_store_gather_profile(int(every) if enable else 0), "ope_store_gather_profile")
 
 
 def gather_profile_read():
@@ -520,10 +522,13 @@ def main():
             return info
         for _ in range(a.warmup):        # (timed_steps warms up again: these make the profiled window start warm)
             one_step(None)
-        gather_profile(True)
+        # every 4th gather launch of the timed region carries the HIP event pair (>= 8 samples per window from 32 steps on; all of them in
+        # shorter windows)
+        every = 4 if a.steps >= 16 else 1
+        gather_profile(True, every)
         windows, info = timed_windows(one_step, a.steps, 0, world, dev, a.repeats, on_fallback=drop_graph)
         elapsed = median_window(windows)
-        kernel_ms = gather_profile_read()[-a.steps * len(windows):]
+        kernel_ms = gather_profile_read()
         gather_profile(False)
         # for reference, the round-1 style measurement on 20 more gathers outside the timed region: two event markers around a launch
         for e0, e1 in ev[:20]:
@@ -575,9 +580,9 @@ def main():
                          "algorithmic_bytes_per_launch": int(algo_bytes), "avg_launch_ms": round(r0["gather_ms"], 5),
                          "store_bytes": int(a.episodes * ep_bytes),
                          "hbm_resident": bool(a.episodes * ep_bytes > 4 * 256 * 2 ** 20),
-                         "timing": "mean kernel duration of the %d gather dispatches of the timed region, from HIP start/stop events "
-                                   "attached to each dispatch on its launch stream (hipExtLaunchKernel): the quantity rocprofv3's kernel "
-                                   "trace reports" % r0["n_kernel_ms"],
+                         "timing": "mean kernel duration of %d gather dispatches of the timed region (every 4th launch from 16-step windows on: "
+                                   "an event pair costs the stream ~3.5 us), from HIP start/stop events attached to the dispatch on its launch "
+                                   "stream (hipExtLaunchKernel): the quantity rocprofv3's kernel trace reports" % r0["n_kernel_ms"],
                          "avg_event_bracket_ms": round(r0["bracket_ms"], 5),
                          "frac_event_bracket": round(algo_bytes / (r0["bracket_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "event_bracket_note": "20 gathers after the timed region, interval between two HIP event markers recorded around "

@@ -154,6 +154,7 @@ int ope_store_gather_sampled(const ope_dims* dims, int32_t capacity, int32_t fil
                              const ope_fields* store, uint64_t seed, const int32_t* counter, int32_t batch, const ope_fields* out,
                              int64_t* inds_out, void* stream);
 /* Per-dispatch timing of the gather (the roofline leg of bench.py): after ope_store_gather_profile(1) every gather launch
+ * (after ope_store_gather_profile(N), N > 1: every N-th one -- an event pair costs the stream ~3.5 us, 1 % of a 0.34 ms step)
  * carries hipExtLaunchKernel start / stop events (up to 512 launches are kept); ope_store_gather_profile_read waits for them
  * and writes the kernel durations in milliseconds, oldest first, into HOST memory, returns how many (and clears the ring).
  * These time the dispatch itself -- what rocprofv3's kernel trace reports -- not the gap between two event markers. */

@@ -367,6 +367,8 @@ struct GatherProf {
   hipEvent_t ev[kProfRing][2];
   bool made = false;
   int n = 0;           // pairs recorded since the last read (capped at kProfRing)
+  int stride = 1;      // every stride-th gather launch carries the events (the pair costs the step ~3.5 us: a 1 % tax on a timed region that times all of them)
+  unsigned seen = 0;   // gather launches since profiling was switched on
 };
 GatherProf g_prof;
 using ope::g_kprof_on;
@@ -376,7 +378,7 @@ template <bool GATHER, class IDX>
 void launch_copy(const CopyArgs& args, const IDX& idx, hipStream_t st) {
   const dim3 grid(args.total_blocks), block(kBlock);
   const size_t lds = (size_t)args.lds_bytes;
-  if (GATHER && g_prof.on && g_prof.n < kProfRing && args.unroll == 8 && args.nt == 0) {
+  if (GATHER && g_prof.on && g_prof.n < kProfRing && args.unroll == 8 && args.nt == 0 && (g_prof.seen++ % (unsigned)g_prof.stride) == 0) {
     hipEvent_t e0 = g_prof.ev[g_prof.n][0], e1 = g_prof.ev[g_prof.n][1];
     ++g_prof.n;
     hipExtLaunchKernelGGL((episode_copy_kernel<GATHER, 8, 0, IDX>), grid, block, (uint32_t)lds, st, e0, e1, 0, args, idx);
@@ -590,6 +592,8 @@ extern "C" int ope_store_gather_profile(int32_t enable) {
     g_prof.made = true;
   }
   g_prof.on = enable != 0;
+  g_prof.stride = enable > 1 ? enable : 1;      // enable = N > 1: every N-th gather launch is timed
+  g_prof.seen = 0;
   g_prof.n = 0;
   return OPE_OK;
 }
