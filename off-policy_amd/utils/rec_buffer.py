@@ -210,8 +210,14 @@ class RecPolicyBuffer(object):
         return f
 
     def _store_fields(self):
-        return self._fields(dict(obs=self.obs, share_obs=self.share_obs if self.use_same_share_obs else None, acts=self.acts,
-                                 rewards=self.rewards, dones=self.dones, dones_env=self.dones_env, avail_acts=self.avail_acts))
+        # (the rings are allocated once: their pointers are read once; a copy is returned because callers add fields to it)
+        f = getattr(self, "_store_fields_cache", None)
+        if f is None or f.obs != self.obs.data_ptr():
+            f = self._store_fields_cache = self._fields(dict(obs=self.obs, share_obs=self.share_obs if self.use_same_share_obs else None, acts=self.acts,
+                                                             rewards=self.rewards, dones=self.dones, dones_env=self.dones_env, avail_acts=self.avail_acts))
+        g = _lib.Fields()
+        C.memmove(C.byref(g), C.byref(f), C.sizeof(g))
+        return g
 
     def _obs_slot(self, t):
         """Fields block with only the agent-indexed `obs` slot set (per-agent centralized observations use it with obs_dim = S)."""
@@ -330,8 +336,14 @@ class RecPolicyBuffer(object):
                 if lazy:
                     dev_inds = dev_inds.clone()      # the staging ring is reused; a StoreObs keeps its indices
         d = self.dims
-        if out is None:
-            out = self.alloc_batch(B, obs=not lazy)
+        fresh = out is None
+        if fresh:
+            # a fresh batch per call, as the reference's fancy-index copy -- taken from the spare that the previous call allocated BEHIND
+            # its gather launch (seven torch.empty calls are ~35 us of host time: in front of the launch they are time the GPU idles
+            # whenever the host is not running ahead, e.g. at the first step after a synchronize)
+            spare = getattr(self, "_spare_batch", None)
+            self._spare_batch = None
+            out = spare[1] if (spare is not None and spare[0] == (B, not lazy)) else self.alloc_batch(B, obs=not lazy)
         else:
             assert out["acts"].shape[2] == B, "destination batch does not match the number of indices"
         if lazy:
@@ -376,6 +388,8 @@ class RecPolicyBuffer(object):
                                                      C.byref(so), _lib.ptr(self._bad_index), _lib.current_stream()), "ope_store_gather(share_obs)")
         if timing_events is not None:
             timing_events[1].record()
+        if fresh:
+            self._spare_batch = ((B, not lazy), self.alloc_batch(B, obs=not lazy))      # the next call's destination (never handed out twice)
         if host_inds is None and not torch.is_tensor(sample_inds):
             self._release_inds()
         if self.use_reward_normalization:
