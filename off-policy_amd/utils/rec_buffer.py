@@ -343,7 +343,8 @@ class RecPolicyBuffer(object):
             # whenever the host is not running ahead, e.g. at the first step after a synchronize)
             spare = getattr(self, "_spare_batch", None)
             self._spare_batch = None
-            out = spare[1] if (spare is not None and spare[0] == (B, not lazy)) else self.alloc_batch(B, obs=not lazy)
+            skey = (B, not lazy, _lib.current_stream().value)      # (the caching allocator ties a block to the stream it was allocated on)
+            out = spare[1] if (spare is not None and spare[0] == skey) else self.alloc_batch(B, obs=not lazy)
         else:
             assert out["acts"].shape[2] == B, "destination batch does not match the number of indices"
         if lazy:
@@ -389,7 +390,7 @@ class RecPolicyBuffer(object):
         if timing_events is not None:
             timing_events[1].record()
         if fresh:
-            self._spare_batch = ((B, not lazy), self.alloc_batch(B, obs=not lazy))      # the next call's destination (never handed out twice)
+            self._spare_batch = (skey, self.alloc_batch(B, obs=not lazy))      # the next call's destination (never handed out twice)
         if host_inds is None and not torch.is_tensor(sample_inds):
             self._release_inds()
         if self.use_reward_normalization:
