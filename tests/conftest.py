@@ -14,6 +14,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The oracles work on small CPU tensors: with the full core count of a GPU box (hundreds of threads) every ATen call is thread hand-offs
+    # -- 150 oracle steps at 3m dims took 465 s there and 4 s with 8 threads. Tests that time something set their own count.
+    import torch
+    if torch.get_num_threads() > 8:
+        torch.set_num_threads(8)
 
 
 def load_golden(name):
