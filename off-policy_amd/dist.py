@@ -51,19 +51,21 @@ class OneShotAllreduce(object):
             if nbytes < 0:
                 _lib.check(nbytes, "ope_allreduce_buffer_bytes")
             buf = C.c_void_p(0)
-            _lib.check(_lib.lib.ope_allreduce_alloc(nbytes, C.byref(buf)), "ope_allreduce_alloc")
+            rc_alloc = int(_lib.lib.ope_allreduce_alloc(nbytes, C.byref(buf)))
+            if rc_alloc != 0 and self.world == 1:
+                _lib.check(rc_alloc, "ope_allreduce_alloc")
             self._buf = buf
             handle = (C.c_ubyte * 64)()
             peers = [None] * self.world
             if self.world > 1:
-                # every rank takes part in the handle exchange even if its own export failed (None), so that a local failure
-                # cannot leave the other ranks stuck in the collective
-                rc = _lib.lib.ope_allreduce_ipc_export(buf, handle)
+                # every rank takes part in the handle exchange even if its own allocation or export failed (None), so that a local
+                # failure cannot leave the other ranks stuck in the collective
+                rc = _lib.lib.ope_allreduce_ipc_export(buf, handle) if rc_alloc == 0 else rc_alloc
                 handles = [None] * self.world
                 me = (bytes(handle), int(self.device.index if self.device.index is not None else torch.cuda.current_device())) if rc == 0 else None
                 torch.distributed.all_gather_object(handles, me, group=group)
                 if any(h is None for h in handles):
-                    raise _lib.OpeError("hipIpcGetMemHandle failed on rank(s) %s" % [q for q, h in enumerate(handles) if h is None])
+                    raise _lib.OpeError("exchange buffer allocation / hipIpcGetMemHandle failed on rank(s) %s" % [q for q, h in enumerate(handles) if h is None])
                 for q, (h, peer_dev) in enumerate(handles):
                     if q == self.rank:
                         continue
