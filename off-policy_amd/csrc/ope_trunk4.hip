@@ -103,8 +103,12 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) trunk_fwd4_kernel(TrunkPairAr
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, g = lane >> 4;
-  const int net = pa.nets == 2 ? (int)(blockIdx.x & 1) : 0;
-  const int wgn = pa.nets == 2 ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
+  // Two nets: workgroups b and b + 8 form a pair -- the same tiles (same wgn), one net each, and the SAME XCD (a workgroup lands on XCD
+  // b % 8), so the observation rows one of them has fetched are in that XCD's L2 when the other asks for them (they walk their tiles
+  // at about the same pace). (With net = b & 1 the pair sat on neighbouring XCDs and every row crossed the fabric twice.)
+  const bool paired = pa.nets == 2 && (gridDim.x & 15) == 0;
+  const int net = pa.nets == 2 ? (paired ? (int)((blockIdx.x >> 3) & 1) : (int)(blockIdx.x & 1)) : 0;
+  const int wgn = pa.nets == 2 ? (paired ? (int)((blockIdx.x & 7) | ((blockIdx.x >> 4) << 3)) : (int)(blockIdx.x >> 1)) : (int)blockIdx.x;
   const int nwg = pa.nets == 2 ? (int)(gridDim.x >> 1) : (int)gridDim.x;
   const TrunkPairArgs& a = pa;
   const float* __restrict__ th = net ? pa.theta[1] : pa.theta[0];
