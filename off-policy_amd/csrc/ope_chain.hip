@@ -50,9 +50,17 @@ __global__ void __launch_bounds__(512) mixer_hyp_kernel(HypFirstArgs a) {
   const int rpw = (int)(blockDim.x >> 6);        // row tiles per workgroup (set by the launcher so that the grid is ONE round of the chip)
   const int groups = (tiles + rpw - 1) / rpw;
   const int ncg = (a.ntiles + 6) / 7;            // column groups of (up to) 7 output tiles
+  // The column groups of one (net, row group) read the same state rows: with two of them, blocks b and b + 8 form the pair, so that both
+  // run on the same XCD (a workgroup lands on XCD b % 8) and the second reader finds the rows in its L2.
   int bid = blockIdx.x;
-  const int cg = bid % ncg;
-  bid /= ncg;
+  int cg;
+  if (ncg == 2 && (a.main_blocks & 15) == 0) {
+    cg = (bid >> 3) & 1;
+    bid = (bid & 7) | ((bid >> 4) << 3);
+  } else {
+    cg = bid % ncg;
+    bid /= ncg;
+  }
   const int net = bid / groups, grp = bid - net * groups;
   const int tile = grp * rpw + wave;
   if (tile >= tiles) return;                    // (no barrier in this kernel)
