@@ -261,7 +261,23 @@ typedef struct ope_qmix_cfg {
                          *  tile per wave (wgrad_kernel + split_reduce, ope_wgrad.hip); 2 = register-blocked, up to four tiles that share an
                          *  operand per wave (wgrad2_kernel + w2_reduce, ope_wgrad2.hip): whole steps on one stream with 8-byte aligned rows of
                          *  at most 1 024 floats and the observations gathered -- what "by shape" picks then (process default OPE_WGRAD2 = 1 | 0,
-                         *  read once); any other configuration with wgrad_path = 2 returns OPE_EINVAL                               */
+                         *  read once); any other configuration with wgrad_path = 2 returns OPE_EINVAL. A table the register-blocked
+                         *  form cannot plan (more than 40 units, 4-byte aligned operands) runs form 1 under "by shape" and fails
+                         *  BEFORE the step's first launch under wgrad_path = 2                                       */
+  int32_t live_rows;    /* rows of the padded batch that are computed: 0 = by shape; 1 = every row (T steps of every episode, as the
+                         *  reference does); 2 = the LIVE rows only. The reference pads every sampled episode to episode_length steps and
+                         *  multiplies the Bellman error of every (t, b) with dones_env[t-1, b] = 1 by 1 - bad_transitions_mask = 0
+                         *  (qmix.py:161-166), leaves it out of the loss normaliser (:184-186), the priorities (:177-181) and Q_tot's mean
+                         *  (:198): such rows contribute exactly nothing. With live rows a small kernel finds, ON THE DEVICE at the start
+                         *  of every step, each episode's length from the sampled dones_env (nothing is cached across steps or taken from the
+                         *  host), ranks the episodes by it and packs the rows that matter; the agent trunk, the GRU scans, the mixer /
+                         *  TD chain and every weight-gradient reduction then run on the packed rows (same per-row arithmetic; sums
+                         *  over rows in a different order). Needs whole steps (phase 0, time_chunks 1) of one shared recurrent policy
+                         *  on the fused chain (chain_path), trunk_fwd4 / trunk_bwd4 (trunk_path), the four-wave scans and wgrad2, no
+                         *  debug outputs, batch <= 256, episode_length <= 1022 -- what "by shape" picks then (process default
+                         *  OPE_LIVE_ROWS = 1 | 0, read once); any other configuration with live_rows = 2 returns OPE_EINVAL before
+                         *  the first launch. Workspace region "live_plan" (int32): [0..2] = live agent rows, those with t < T, live
+                         *  (t, b) rows of the last step; [8..15] as four int64 = their sums over all steps so far and the step count */
 } ope_qmix_cfg;
 
 /* Flat parameter vector: the reference's named_parameters() order (agent q-network, then mixer; qmix.py:67-72),
@@ -324,6 +340,16 @@ int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields* batch, con
  * ceil(obs_dim / 16) in {4, 8, 12, 16}, state_dim % 4 == 0, batch <= 512, (T+1) N batch < 2^20 rows, and the LDS-resident trunk kernel
  * selected (trunk_path 4, or 0 with >= 2 048 rows) -- everything else returns OPE_EINVAL (the caller gathers obs instead). */
 int ope_qmix_obs_ref_ok(const ope_qmix_cfg* cfg);
+/* The live-row plan of a batch on its own (what ope_qmix_loss_and_grad builds at the start of a step that runs on live rows -- see
+ * ope_qmix_cfg.live_rows and the reference lines cited there): from dones_env [T][B][1] (DEVICE, the gather's layout) into the
+ * workspace region "live_plan" (int32): [0] live agent-network rows = N * sum_b len_b, [1] those with t < T, [2] live (t, b) rows,
+ * [3] the longest len_b, where len_b = 2 + the last t with dones_env[t, b] != 1 (1 if there is none), then the ranking and the row
+ * maps the kernels read. Also zero-fills the regions "err_abs" and "loss_part". ope_qmix_live_rows_ok(cfg) = 1 when a whole step of
+ * this configuration would run on live rows "by shape" (the same test the step makes); OPE_EINVAL from the plan call when the
+ * workspace of `cfg` holds no plan region (MLP nets, phases, batch > 256, episode_length > 1022). Diagnostics / tests / bench.py's
+ * executed-row accounting; training never needs to call it. */
+int ope_qmix_live_rows_ok(const ope_qmix_cfg* cfg);
+int ope_qmix_live_plan(const ope_qmix_cfg* cfg, const float* dones_env, void* workspace, int64_t workspace_bytes, void* stream);
 int ope_qmix_loss_and_grad_ref(const ope_qmix_cfg* cfg, const ope_fields* batch, const ope_obs_ref* obs, const float* theta,
                                const float* theta_tgt, const float* per_weights, void* workspace, int64_t workspace_bytes,
                                float* grad, float* td_abs_stats, void* stream);

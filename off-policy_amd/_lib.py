@@ -44,7 +44,8 @@ class QmixCfg(C.Structure):
                 ("use_huber", C.c_int32), ("use_per", C.c_int32), ("gamma", C.c_float), ("huber_delta", C.c_float),
                 ("per_nu", C.c_float), ("per_eps", C.c_float), ("mlp", C.c_int32), ("phase", C.c_int32),
                 ("mixer_path", C.c_int32), ("time_chunks", C.c_int32), ("scan_family", C.c_int32), ("scan_waves", C.c_int32),
-                ("debug", C.c_int32), ("trunk_path", C.c_int32), ("chain_path", C.c_int32), ("hypernet_layers", C.c_int32), ("wgrad_path", C.c_int32)]
+                ("debug", C.c_int32), ("trunk_path", C.c_int32), ("chain_path", C.c_int32), ("hypernet_layers", C.c_int32), ("wgrad_path", C.c_int32),
+                ("live_rows", C.c_int32)]
 
 
 class GatherTune(C.Structure):
@@ -125,6 +126,8 @@ def _load():
         "ope_store_gather_tuned": (C.c_int, [C.POINTER(Dims), i32, C.POINTER(Fields), p, p, i32, C.POINTER(Fields), p, C.POINTER(GatherTune), p]),
         "ope_store_gather_ref": (C.c_int, [C.POINTER(Dims), i32, C.POINTER(Fields), p, p, i32, C.POINTER(Fields), p, p, C.POINTER(GatherTune), p]),
         "ope_qmix_obs_ref_ok": (C.c_int, [C.POINTER(QmixCfg)]),
+        "ope_qmix_live_rows_ok": (C.c_int, [C.POINTER(QmixCfg)]),
+        "ope_qmix_live_plan": (C.c_int, [C.POINTER(QmixCfg), p, p, i64, p]),
         "ope_qmix_loss_and_grad_ref": (C.c_int, [C.POINTER(QmixCfg), C.POINTER(Fields), C.POINTER(ObsRef), p, p, p, p, i64, p, p, p]),
         "ope_store_gather_profile": (C.c_int, [i32]),
         "ope_store_gather_profile_read": (C.c_int, [p, i32]),

@@ -87,7 +87,10 @@ class QMix(object):
         # `time_chunks`: two-stream schedule; `scan_family` / `scan_waves`: GRU scan kernels; `debug`: keep intermediates.
         # `trunk_path`: 3 = one trunk launch per net (weights in registers), 4 = both nets in one launch (weights in LDS).
         # `chain_path`: 1 = head / mixer / TD / adjoints as four launches, 2 = the fused pair mixer_hyp + qchain (ope_chain.hip).
-        self.tune = dict(mixer_path=0, time_chunks=0, scan_family=0, scan_waves=0, debug=0, trunk_path=0, chain_path=0, wgrad_path=0)
+        # `live_rows`: 1 = every padded row of the batch is computed (as the reference does), 2 = only the rows before each episode's
+        # termination (every other row is multiplied by a zero mask in the loss, qmix.py:161-166; found on the device from the sampled
+        # dones_env every step), 0 = the library's choice by shape (ope_qmix_cfg.live_rows).
+        self.tune = dict(mixer_path=0, time_chunks=0, scan_family=0, scan_waves=0, debug=0, trunk_path=0, chain_path=0, wgrad_path=0, live_rows=0)
         self._ws = {}
         self._ws_multi = {}
         self._gsq = {}
@@ -321,6 +324,7 @@ class QMix(object):
         cfg.trunk_path = int(t["trunk_path"])
         cfg.chain_path = int(t.get("chain_path", 0))
         cfg.wgrad_path = int(t.get("wgrad_path", 0))      # 1 = one tile per wave (wgrad), 2 = register-blocked (wgrad2), 0 = by shape
+        cfg.live_rows = int(t.get("live_rows", 0))
         cfg.hypernet_layers = 0 if self.vdn else int(getattr(self, "hypernet_layers", 2))
         return cfg
 

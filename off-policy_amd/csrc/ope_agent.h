@@ -52,6 +52,7 @@ struct TrunkFwdArgs {
   // observations left in the store (trunk_fwd4 only): x = the store's obs ring, local row r is batch row ref_row0 + r
   ObsRef ref;
   int ref_row0;
+  LivePlan lp;         // lp.hdr != null (trunk_fwd4 pair only): R and every output are the plan's packed rows, x is read through lp.srcrow
 };
 
 struct GruFwdArgs {
@@ -68,6 +69,8 @@ struct GruFwdArgs {
   float* rg; float* zg; float* ng; float* ghn;  // [L][NB][64] gate saves (live) or null
   int family, waves;                    // scan kernel family (4 | 1) / compute waves per row (4 | 2) asked for by the caller's cfg;
                                         // 0 = the process default (ope_set_scan_kernel / OPE_GRU, OPE_GRU4_W), then by row count
+  LivePlan lp; int B, N;                // lp.hdr != null (gru4 only): packed rows -- row r = agent * B + j walks the lp.len[j] steps of the
+                                        // episode ranked j; step t's gi / h / saves are at row N * cum[t] + agent * n[t] + j
 };
 
 struct HeadFwdArgs {
@@ -118,6 +121,7 @@ struct GruBwdArgs {
   float* dh_carry;     // [NB][64] adjoint w.r.t. h_{t_lo - 1} handed to the earlier chunk, or null
   long long* dbg;      // optional per-compute-wave phase cycle sums [NB][4][8] (ope_set_debug; gru4 only)
   int family, waves;   // as GruFwdArgs
+  LivePlan lp; int B, N;   // as GruFwdArgs: row r = agent * B + j walks t = min(lp.len[j], T) - 1 .. 0 (gru4 only; t_lo = 0, no carries)
 };
 
 struct TrunkBwdArgs {
@@ -133,6 +137,7 @@ struct TrunkBwdArgs {
   const float* xhat2; const float* rstd2; const uint64_t* mask2;
   float* dz1; float* dz2;  // [R][64]
   int tanh_act;        // OPE_DIMS_TANH (trunk_bwd3 only): mask1 / mask2 hold the activations' row means (float in the low word), not ReLU bits
+  const int* R_dev;    // non-null (trunk_bwd4 only): the rows of this launch, read on the device (<= R; the live plan's R1L)
 };
 
 // ---- second hidden block (layer_N = 2; ope_block.hip) ----------------------------------------------------------------------------
@@ -159,6 +164,7 @@ int launch_block_bwd(const BlockBwdArgs& a, hipStream_t st);
 
 // allow4 = false: never the LDS-resident kernel (ope_trunk4.hip) -- the pair launcher's own fall-back, and tests that pin a family
 int launch_trunk_fwd(const TrunkFwdArgs& a, bool save, hipStream_t st, bool allow4 = true);
+bool trunk4_pair_can(int D, int64_t R, int path, bool tanh_act);      // would the pair launch run trunk_fwd4 on a gathered batch of this shape
 int trunk4_pair_min_rows();      // rows from which "by shape" picks trunk_fwd4 for the live + target pair (ope_trunk4.hip)
 int launch_trunk_fwd4_single(const TrunkFwdArgs& a, bool save, hipStream_t st);      // OPE_OK / error, or 1 = not this kernel's launch
 // live (saving) + target trunk of the same input rows: one launch of trunk_fwd4 (ope_trunk4.hip) when the shape allows, else two launches
@@ -187,6 +193,7 @@ int launch_trunk_bwd(const TrunkBwdArgs& a, hipStream_t st);
 int launch_trunk_bwd3(const TrunkBwdArgs& a, hipStream_t st);   // persistent cooperative form (ope_trunk_bwd3.hip)
 // recurrent trunk adjoint: trunk_bwd4 (ope_trunk_bwd4.hip: weights in LDS, a wave per tile) when the shape allows and `path` (ope_qmix_cfg.trunk_path) asks, else trunk_bwd3
 int launch_trunk_bwd_path(const TrunkBwdArgs& a, int path, hipStream_t st);
+bool trunk_bwd4_can(int64_t R, int path, bool tanh_act);      // would launch_trunk_bwd_path run trunk_bwd4 on R rows
 int launch_transpose_weights(const float* theta, const AgentLayout& L, float* thetaT, hipStream_t st);
 int launch_transpose(const float* src, int rows, int cols, float* dst, hipStream_t st);
 

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 
+#include "ope_live.h"
 #include "ope_mixer.h"
 #include "ope_wgrad.h"
 #include "ope_workspace.h"
@@ -25,6 +26,7 @@ bool cfg_ok(const ope_qmix_cfg* c) {
   if (c->trunk_path != 0 && c->trunk_path != 3 && c->trunk_path != 4) return false;
   if (c->chain_path < 0 || c->chain_path > 2) return false;
   if (c->hypernet_layers < 0 || c->hypernet_layers > 2) return false;
+  if (c->wgrad_path < 0 || c->wgrad_path > 2 || c->live_rows < 0 || c->live_rows > 2) return false;
   if (d.layer_N < 0 || d.layer_N > 2) return false;
   if (d.flags & ~(OPE_DIMS_NO_FEATURE_NORM | OPE_DIMS_TANH | OPE_DIMS_MASK_TARGET_MAX)) return false;
   if ((d.flags & OPE_DIMS_TANH) && (c->phase != 0 || d.layer_N == 2 || d.obs_dim > 384 || c->trunk_path == 4)) return false;   // tanh: trunk_fwd3 / trunk_bwd3
@@ -84,7 +86,7 @@ struct Plan {
   int64_t mu0, rstd0, xhat1, rstd1, mask1, xhat2, rstd2, mask2, gi, h, rg, zg, ng, ghn, xhat_o, rstd_o, act_idx,
       agent_q, agent_nq, gi_t, h_t, qtot, nqtot, hw1, hw2, hb2, v1, hpre, v2, loss_part, err_abs, dqtot, d_agent_q,
       d_b1, d_v2, d_v1, d_hw1, d_hw2, d_hb2, dh_out, dqoh, dgi, dghn, dz1, dz2, thetaT, mixT, raw_agent, raw_mixer,
-      rsum, q_all, loss_tot, ln_zero, ln_one, dh_carry, dbg, gsq_part, mix_slab, raw2;
+      rsum, q_all, loss_tot, ln_zero, ln_one, dh_carry, dbg, gsq_part, mix_slab, raw2, live;
   int n_gsq;
   bool wide;
   bool chain;                   // the (t, b)-row chain runs as mixer_hyp + qchain (ope_chain.hip) instead of head_fwd / mixer_fwd / mixer_bwd / head_bwd
@@ -242,6 +244,8 @@ void make_plan(const ope_qmix_cfg* c, Plan* p) {
   p->hw1_t = W.add("hw1_t", TB * OPE_HYP); p->hw2_t = W.add("hw2_t", TB * OPE_HYP); p->hb2_t = W.add("hb2_t", TB * OPE_HYP);
   p->hb1_t = W.add("hb1_t", TB * OPE_MIX);
   p->v1_t = W.add("v1_t", TB * p->NM); p->v2_t = W.add("v2_t", TB * OPE_MIX);
+  // live-row plan (ope_live.hip): int32 tables, built on the device at the start of every whole recurrent step that runs on packed rows
+  p->live = (!c->mlp && c->phase == 0 && live_plan_shape_ok(p->T, p->N, p->B)) ? W.add("live_plan", live_plan_ints(p->T, p->N, p->B)) : -1;
   if (p->layerN == 2) {      // second hidden block: the trunk's output of both nets, the block's saves and adjoints
     p->a2 = W.add("a2", R * OPE_H); p->a2_t = W.add("a2_t", R * OPE_H);
     p->xhat3 = W.add("xhat3", R * OPE_H); p->rstd3 = W.add("rstd3", R); p->mask3 = W.add("mask3", 2 * R);
@@ -361,7 +365,47 @@ extern "C" int ope_qmix_workspace_init(const ope_qmix_cfg* cfg, void* workspace,
   int rc;
   if ((rc = launch_fill(W + p.ln_zero, p.R, 0.f, (hipStream_t)stream))) return rc;
   if ((rc = launch_fill(W + p.gsq_part, p.n_gsq, 0.f, (hipStream_t)stream))) return rc;
+  if (p.live >= 0 && (rc = launch_fill(W + p.live, 16, 0.f, (hipStream_t)stream))) return rc;      // (header + the executed-row accumulators)
   return launch_fill(W + p.ln_one, p.R, 1.f, (hipStream_t)stream);
+}
+
+// Live rows (LivePlan, ope_common.h; ope_qmix_cfg.live_rows): whole steps of one shared recurrent policy on the kernels that know packed
+// rows -- trunk_fwd4 (pair), gru_fwd4 / gru_bwd4, mixer_hyp + qchain, trunk_bwd4, wgrad2. This is the part of the decision that depends on the
+// configuration alone (the step adds: observations gathered, no debug outputs, a weight-gradient table wgrad2 can plan).
+// Process default of "by shape": OPE_LIVE_ROWS = 1 | 0 (read once).
+static bool w2_shape_can(const ope_qmix_cfg* cfg, const Plan& p) {
+  return p.chunks == 1 && p.D % 2 == 0 && p.D <= 1024 && (cfg->vdn || (p.S % 2 == 0 && p.S <= 1024)) && p.NM <= 1024;      // (rows 8-byte aligned at least)
+}
+static bool w2_wanted(const ope_qmix_cfg* cfg) {
+  static const int w2_env = getenv("OPE_WGRAD2") ? atoi(getenv("OPE_WGRAD2")) : 1;
+  return cfg->wgrad_path == 2 || (cfg->wgrad_path == 0 && w2_env);
+}
+static bool live_cfg_ok(const ope_qmix_cfg* cfg, const Plan& p) {
+  static const int live_env = getenv("OPE_LIVE_ROWS") ? atoi(getenv("OPE_LIVE_ROWS")) : 1;
+  auto scan4 = [&](int64_t rows) { const int want = (cfg->scan_family == 1 || cfg->scan_family == 4) ? cfg->scan_family : g_scan_family; return (want ? want : (rows <= kGru4MaxRows ? 4 : 1)) == 4; };
+  const bool tanh_on = (cfg->dims.flags & OPE_DIMS_TANH) != 0;
+  return p.live >= 0 && p.chain && cfg->phase == 0 && !p.mlp && p.chunks == 1 && p.layerN == 1 && !tanh_on && !cfg->debug && w2_shape_can(cfg, p) && w2_wanted(cfg) &&
+         trunk4_pair_can(p.D, p.R, cfg->trunk_path, tanh_on) && trunk_bwd4_can(p.R1, cfg->trunk_path, tanh_on) && scan4(2 * (int64_t)p.NB) && scan4(p.NB) &&
+         (cfg->live_rows == 2 || (cfg->live_rows == 0 && live_env));
+}
+extern "C" int ope_qmix_live_rows_ok(const ope_qmix_cfg* cfg) {
+  if (!cfg_ok(cfg)) return 0;
+  Plan p;
+  make_plan(cfg, &p);
+  return live_cfg_ok(cfg, p) ? 1 : 0;
+}
+extern "C" int ope_qmix_live_plan(const ope_qmix_cfg* cfg, const float* dones_env, void* workspace, int64_t workspace_bytes, void* stream) {
+  (void)hipGetLastError();
+  if (!cfg_ok(cfg) || !dones_env || !workspace) return OPE_EINVAL;
+  Plan p;
+  make_plan(cfg, &p);
+  if (workspace_bytes < p.ws.total * (int64_t)sizeof(float)) return OPE_ENOSPC;
+  if (p.live < 0) return OPE_EINVAL;
+  float* W = (float*)workspace;
+  LiveArgs la;
+  la.T = p.T; la.N = p.N; la.B = p.B; la.dones_env = dones_env; la.plan = reinterpret_cast<int*>(W + p.live);
+  la.err_abs = W + p.err_abs; la.loss_part = W + p.loss_part; la.n_loss_part = p.n_loss_tiles * 4;
+  return launch_live_plan(la, (hipStream_t)stream);
 }
 
 // ope_qmix_obs_ref_ok: the static part of "can this configuration read observation rows from the store" (the launchers check the rest)
@@ -469,6 +513,133 @@ static int qmix_step(const ope_qmix_cfg* cfg, const ope_fields* batch, const ope
   td.B = p.B; td.N = p.N; td.gamma = cfg->gamma; td.use_huber = cfg->use_huber; td.huber_delta = cfg->huber_delta;
   td.rewards = batch->rewards; td.dones_env = batch->dones_env; td.per_weights = cfg->use_per ? per_weights : nullptr;
 
+  // ---- decisions that must be taken before the first launch (nothing may fail between two kernels of a step) -------------------------
+  // the register-blocked weight-gradient launch (ope_wgrad2.hip) takes whole steps on one stream: no time chunks, no rows read in place
+  const bool w2_can = !use_side && !oref && w2_shape_can(cfg, p);
+  if (cfg->wgrad_path == 2 && !w2_can) return OPE_EINVAL;
+  bool want_w2 = w2_can && w2_wanted(cfg);
+  bool merge_hh = want_w2;
+  // live rows: any configuration live_cfg_ok refuses computes every padded row as before (live_rows = 2 then returns OPE_EINVAL)
+  bool live = want_w2 && !oref && !dbg_on && batch->obs && live_cfg_ok(cfg, p);
+  LivePlan lp;
+  memset(&lp, 0, sizeof(lp));
+  if (live) lp = live_plan_view(reinterpret_cast<const int*>(W + p.live), p.T, p.N, p.B);
+  const Raw& rw = p.raw;
+  // weight-gradient problem tables: mixer problems (K = T*B) go first, on the main stream, while the side stream runs the
+  // BPTT of the last chunk; the agent problems are cut into the same time chunks (each chunk = its own K-splits/slabs)
+  auto prob = [&](WgTable& wt, const float* A, int lda, int M, const float* Bm, int ldb, int N, int K, int out_off, int ldc, int s_off,
+                  int nsplit, int64_t base, int64_t stride) -> WgProb& {
+    WgProb& q = wt.p[wt.n++];
+    q.A = A; q.lda = lda; q.M = M; q.B = Bm; q.ldb = ldb; q.N = N; q.K = K; q.b_shift = 0; q.ln_mu = W + p.ln_zero; q.ln_rstd = W + p.ln_one;
+    q.out_off = out_off; q.ldc = ldc; q.s_off = s_off; q.nsplit = nsplit; q.raw_base = base; q.raw_stride = stride;
+    q.rs_base = base == p.raw_mixer ? rw.agent_end : 0;      // (where launch_split_reduce puts the two regions in `rsum`)
+    if (live) {      // packed rows: the live count from the plan's header; operands that are batch fields get their row map below
+      q.K_dev = lp.hdr + (base == p.raw_mixer ? 2 : 1);
+      q.b_map = lp.srcrow; q.map_on = 0;
+    }
+    return q;
+  };
+  auto batch_rows = [&](WgProb& q, const int* map) { if (live) { q.b_map = map; q.map_on = 1; } };
+  auto add_mixer_problems = [&](WgTable& wt) {
+    const MixerLayout& M = p.ML;
+    const int mbase = p.AL.end;
+    const int64_t mb_ = p.raw_mixer, ms = rw.mixer_size;
+    const int TBk = (int)p.TB;
+    const float* S0 = batch->share_obs;  // rows 0..TB-1 are states at t < T
+    if (p.hyp1) {      // every hyper-network layer reads the state: grad W = (pre-activation adjoint)^T S
+      batch_rows(prob(wt, W + p.d_v1, p.NM, p.NM, S0, p.S, p.S, TBk, M.w1a_w - mbase, p.S, M.w1a_b - mbase, p.ns_mixer, mb_, ms), lp.tbsrc);
+      batch_rows(prob(wt, W + p.d_v2, OPE_MIX, OPE_MIX, S0, p.S, p.S, TBk, M.w2a_w - mbase, p.S, M.w2a_b - mbase, p.ns_mixer, mb_, ms), lp.tbsrc);
+      batch_rows(prob(wt, W + p.d_b1, OPE_MIX, OPE_MIX, S0, p.S, p.S, TBk, M.b1_w - mbase, p.S, M.b1_b - mbase, p.ns_mixer, mb_, ms), lp.tbsrc);
+      batch_rows(prob(wt, W + p.d_hb2, OPE_HYP, OPE_HYP, S0, p.S, p.S, TBk, M.b2a_w - mbase, p.S, M.b2a_b - mbase, p.ns_mixer, mb_, ms), lp.tbsrc);
+      prob(wt, W + p.dqtot, 4, 1, W + p.hb2, OPE_HYP, OPE_HYP, TBk, M.b2b_w - mbase, OPE_HYP, M.b2b_b - mbase, p.ns_mixer, mb_, ms);
+      return;
+    }
+    batch_rows(prob(wt, W + p.d_hw1, OPE_HYP, OPE_HYP, S0, p.S, p.S, TBk, M.w1a_w - mbase, p.S, M.w1a_b - mbase, p.ns_mixer, mb_, ms), lp.tbsrc);
+    prob(wt, W + p.d_v1, p.NM, p.NM, W + p.hw1, OPE_HYP, OPE_HYP, TBk, M.w1b_w - mbase, OPE_HYP, M.w1b_b - mbase, p.ns_mixer, mb_, ms);
+    batch_rows(prob(wt, W + p.d_hw2, OPE_HYP, OPE_HYP, S0, p.S, p.S, TBk, M.w2a_w - mbase, p.S, M.w2a_b - mbase, p.ns_mixer, mb_, ms), lp.tbsrc);
+    prob(wt, W + p.d_v2, OPE_MIX, OPE_MIX, W + p.hw2, OPE_HYP, OPE_HYP, TBk, M.w2b_w - mbase, OPE_HYP, M.w2b_b - mbase, p.ns_mixer, mb_, ms);
+    batch_rows(prob(wt, W + p.d_b1, OPE_MIX, OPE_MIX, S0, p.S, p.S, TBk, M.b1_w - mbase, p.S, M.b1_b - mbase, p.ns_mixer, mb_, ms), lp.tbsrc);
+    batch_rows(prob(wt, W + p.d_hb2, OPE_HYP, OPE_HYP, S0, p.S, p.S, TBk, M.b2a_w - mbase, p.S, M.b2a_b - mbase, p.ns_mixer, mb_, ms), lp.tbsrc);
+    prob(wt, W + p.dqtot, 4, 1, W + p.hb2, OPE_HYP, OPE_HYP, TBk, M.b2b_w - mbase, OPE_HYP, M.b2b_b - mbase, p.ns_mixer, mb_, ms);
+  };
+  // agent problems over the rows [r0, r0 + K1) (whole time steps), slabs starting at `slab0`
+  // the register-blocked weight-gradient launch (ope_wgrad2.hip) takes whole steps on one stream: no time chunks, no rows read in place
+  auto add_agent_problems = [&](WgTable& wt, int64_t r0, int K1, int nsplit, int slab0) {
+    const int64_t ab = p.raw_agent + (int64_t)slab0 * rw.agent_end, as = rw.agent_end;
+    {
+      WgProb& q = prob(wt, W + p.dz1 + r0 * OPE_H, OPE_H, OPE_H, oref ? obs_rows : obs_rows + r0 * p.D, p.D, p.D, K1, rw.P1, p.D, rw.s1, nsplit, ab, as);
+      q.ln_mu = W + p.mu0 + r0; q.ln_rstd = W + p.rstd0 + r0; q.ln_on = 1;
+      if (oref) { q.ref_row1 = (int)r0 + 1; wt.ref = ref; }
+      batch_rows(q, lp.srcrow);      // (packed rows: the observation row of packed row k is batch row srcrow[k])
+    }
+    prob(wt, W + p.dz2 + r0 * OPE_H, OPE_H, OPE_H, W + p.xhat1 + r0 * OPE_H, OPE_H, OPE_H, K1, rw.P2, OPE_H, rw.s2, nsplit, ab, as);
+    if (!p.mlp) {
+      const float* dgi = W + p.dgi + r0 * 3 * OPE_H;
+      if (p.layerN == 2) prob(wt, W + p.dz3 + r0 * OPE_H, OPE_H, OPE_H, W + p.xhat2 + r0 * OPE_H, OPE_H, OPE_H, K1, rw.P2b, OPE_H, rw.s2b, nsplit, ab, as);
+      prob(wt, dgi, 3 * OPE_H, 3 * OPE_H, (p.layerN == 2 ? W + p.xhat3 : W + p.xhat2) + r0 * OPE_H, OPE_H, OPE_H, K1, rw.P3, OPE_H, rw.s3, nsplit, ab, as);
+      // h_{t-1}: the first chunk shifts inside the kernel (rows of t = 0 see zeros), later chunks start one step back
+      const float* hprev = r0 > 0 ? W + p.h + (r0 - p.NB) * OPE_H : W + p.h;
+      const int shift = r0 > 0 ? 0 : p.NB;
+      if (merge_hh) {      // register-blocked launch: one problem, dgi's r / z panels and dghn as the third panel, h_{t-1} read once for all three
+        WgProb& q = prob(wt, dgi, 3 * OPE_H, 3 * OPE_H, hprev, OPE_H, OPE_H, K1, rw.WHH, OPE_H, rw.shh, nsplit, ab, as);
+        q.b_shift = shift; q.A2 = W + p.dghn + r0 * OPE_H; q.lda2 = OPE_H; q.a2_from = 2;
+        if (live) { q.b_shift = 0; q.b_map = lp.prevrow; q.map_on = 1; }      // h_{t-1} of packed row k sits at packed row prevrow[k] (none at t = 0)
+      } else {
+        prob(wt, dgi, 3 * OPE_H, 2 * OPE_H, hprev, OPE_H, OPE_H, K1, rw.WHH, OPE_H, rw.shh, nsplit, ab, as).b_shift = shift;
+        prob(wt, W + p.dghn + r0 * OPE_H, OPE_H, OPE_H, hprev, OPE_H, OPE_H, K1, rw.WHH + 2 * OPE_H * OPE_H, OPE_H, rw.shh + 2 * OPE_H, nsplit, ab,
+             as).b_shift = shift;
+      }
+    }
+    // q head: fed by rnn.norm (recurrent) or directly by the trunk's LN2 (MLP) -- both "Linear after LayerNorm"
+    prob(wt, W + p.dqoh + r0 * p.A4, p.A4, p.A, (p.mlp ? W + p.xhat2 : W + p.xhat_o) + r0 * OPE_H, OPE_H, OPE_H, K1, rw.E, OPE_H, rw.sq, nsplit, ab, as);
+  };
+  // whole step in one launch (no time chunks, no side stream): the problem table of the register-blocked form is built -- and its plan found or
+  // rebuilt -- HERE, so that a table it cannot take (too many units, an operand that is only 4-byte aligned) falls back to the one-tile-per-wave
+  // launch before anything runs ("by shape"), or fails before anything runs (wgrad_path = 2 / live rows asked for explicitly)
+  WgTable wt2;
+  memset(&wt2, 0, sizeof(wt2));
+  static thread_local int w2_key[kMaxWgProbs * 10 + 1];
+  static thread_local W2Table w2;
+  auto plan_w2 = [&]() -> bool {
+    memset(&wt2, 0, sizeof(wt2));
+    if (do_bwd) add_agent_problems(wt2, 0, (int)p.R1, p.ns_chunk[0], 0);
+    if (!cfg->vdn && do_mix) add_mixer_problems(wt2);
+    if (wt2.n < 1) return true;
+    if (wg_finish(&wt2) || !w2_ok(wt2)) return false;
+    // (units and workgroup shares depend on the problems' shapes only: planned once per configuration -- the greedy passes cost ~15 us
+    // of host time, which a short step like 3m's cannot hide; the pointers are refreshed on every call)
+    int key[kMaxWgProbs * 10 + 1];
+    memset(key, 0, sizeof(key));
+    key[0] = wt2.n;
+    for (int q = 0; q < wt2.n; ++q) {
+      const WgProb& P = wt2.p[q];
+      int same = q;      // first problem that walks the same A rows (what the XCD pairing looks at)
+      for (int r = q - 1; r >= 0; --r)
+        if (wt2.p[r].A == P.A) same = r;
+      const int al = (((uintptr_t)P.A & 15) ? 2 : 0) | (((uintptr_t)P.B & 15) ? 4 : 0) | ((P.A2 && ((uintptr_t)P.A2 & 15)) ? 8 : 0);      // (the load width follows the operands' alignment)
+      const int f[10] = {P.M, P.N, P.K, P.lda, P.ldb, P.b_shift, (P.s_off >= 0 ? 1 : 0) | al, same, P.A2 ? P.a2_from + 1 : 0, P.lda2};
+      memcpy(key + 1 + 10 * q, f, sizeof(f));
+    }
+    if (memcmp(w2_key, key, sizeof(key)) != 0) {
+      if (w2_build(wt2, &w2)) { w2_key[0] = -1; return false; }
+      memcpy(w2_key, key, sizeof(key));
+    }
+    for (int q = 0; q < wt2.n; ++q) w2.p[q] = wt2.p[q];
+    return true;
+  };
+  if (want_w2 && !plan_w2()) {
+    if (cfg->wgrad_path == 2 || cfg->live_rows == 2) return OPE_EINVAL;
+    want_w2 = merge_hh = live = false;      // "by shape": the one-tile-per-wave launch on every padded row
+    memset(&lp, 0, sizeof(lp));
+  }
+  if (cfg->live_rows == 2 && !live) return OPE_EINVAL;
+  if (live) {
+    LiveArgs la;
+    la.T = p.T; la.N = p.N; la.B = p.B; la.dones_env = batch->dones_env; la.plan = reinterpret_cast<int*>(W + p.live);
+    la.err_abs = W + p.err_abs; la.loss_part = W + p.loss_part; la.n_loss_part = p.n_loss_tiles * 4;
+    if ((rc = launch_live_plan(la, st))) return rc;
+  }
+
   bool hyp_on_side = false, hyp_late = false;
   HypFirstArgs hyp_args;
   memset(&hyp_args, 0, sizeof(hyp_args));
@@ -481,6 +652,7 @@ static int qmix_step(const ope_qmix_cfg* cfg, const ope_fields* batch, const ope
     tf.ref = ref; tf.ref_row0 = (int)r0;
     tf.no_fn = (cfg->dims.flags & OPE_DIMS_NO_FEATURE_NORM) ? 1 : 0;
     tf.tanh_act = (cfg->dims.flags & OPE_DIMS_TANH) ? 1 : 0;
+    tf.lp = lp;
     tf.gi = p.mlp ? nullptr : W + p.gi + r0 * 3 * OPE_H; tf.a2_out = p.mlp ? W + p.h + r0 * OPE_H : nullptr;
     if (p.layerN == 2) { tf.gi = nullptr; tf.a2_out = W + p.a2 + r0 * OPE_H; }      // the trunk stops at the first block's output; ope_block.hip continues
     tf.mu0 = W + p.mu0 + r0; tf.rstd0 = W + p.rstd0 + r0;
@@ -518,6 +690,7 @@ static int qmix_step(const ope_qmix_cfg* cfg, const ope_fields* batch, const ope
         hy.out[1][HYP_HW1] = W + p.hw1_t; hy.out[1][HYP_HW2] = W + p.hw2_t; hy.out[1][HYP_HB2] = W + p.hb2_t; hy.out[1][HYP_HB1] = W + p.hb1_t;
         hy.out[0][HYP_V1] = W + p.v1; hy.out[0][HYP_V2] = W + p.v2; hy.out[1][HYP_V1] = W + p.v1_t; hy.out[1][HYP_V2] = W + p.v2_t;
         hy.side = tr;
+        hy.lp = lp;
         // OPE_CHAIN_SIDE = 1: on the side stream, concurrent with the scan (fork behind the trunk launch, join in front of the chain kernel);
         // 2: the same, but launched BEHIND the scan (below), so that the scan's workgroups are resident first and the GEMM's workgroups
         // take the slots that are left (the scan waves run at s_setprio 3)
@@ -547,6 +720,7 @@ static int qmix_step(const ope_qmix_cfg* cfg, const ope_fields* batch, const ope
     gf.whh_off = p.AL.whh; gf.bhh_off = p.AL.bhh; gf.family = cfg->scan_family; gf.waves = cfg->scan_waves;
     gf.rg = W + p.rg + r0 * OPE_H; gf.zg = W + p.zg + r0 * OPE_H; gf.ng = W + p.ng + r0 * OPE_H; gf.ghn = W + p.ghn + r0 * OPE_H;
     gf.dbg = dbg_on ? (long long*)(W + p.dbg) + 71168 : nullptr;
+    gf.lp = lp; gf.B = p.B; gf.N = p.N;
     if ((rc = launch_gru_fwd(gf, scan_st))) return rc;
     if (hyp_late) {
       if ((rc = launch_mixer_hyp(hyp_args, sp->s))) return rc;
@@ -569,6 +743,7 @@ static int qmix_step(const ope_qmix_cfg* cfg, const ope_fields* batch, const ope
     ca.v1x[0] = W + p.v1; ca.v1x[1] = W + p.v1_t; ca.v2x[0] = W + p.v2; ca.v2x[1] = W + p.v2_t;
     ca.td = td;
     ca.mask_target_max = (cfg->dims.flags & OPE_DIMS_MASK_TARGET_MAX) ? 1 : 0;
+    ca.lp = lp;
     ca.xhat_o = W + p.xhat_o; ca.rstd_o = W + p.rstd_o; ca.act_idx = (int*)(W + p.act_idx);
     ca.loss_part = W + p.loss_part; ca.err_abs = W + p.err_abs; ca.dqtot = W + p.dqtot;
     ca.d_v1 = W + p.d_v1; ca.d_v2 = W + p.d_v2; ca.d_b1 = W + p.d_b1; ca.d_hw1 = W + p.d_hw1; ca.d_hw2 = W + p.d_hw2; ca.d_hb2 = W + p.d_hb2;
@@ -633,73 +808,6 @@ static int qmix_step(const ope_qmix_cfg* cfg, const ope_fields* batch, const ope
     if ((rc = launch_head_bwd(hb, st))) return rc;
   if ((rc = sync_to(st, side))) return rc;
 
-  // weight-gradient problem tables: mixer problems (K = T*B) go first, on the main stream, while the side stream runs the
-  // BPTT of the last chunk; the agent problems are cut into the same time chunks (each chunk = its own K-splits/slabs)
-  const Raw& rw = p.raw;
-  auto prob = [&](WgTable& wt, const float* A, int lda, int M, const float* Bm, int ldb, int N, int K, int out_off, int ldc, int s_off,
-                  int nsplit, int64_t base, int64_t stride) -> WgProb& {
-    WgProb& q = wt.p[wt.n++];
-    q.A = A; q.lda = lda; q.M = M; q.B = Bm; q.ldb = ldb; q.N = N; q.K = K; q.b_shift = 0; q.ln_mu = W + p.ln_zero; q.ln_rstd = W + p.ln_one;
-    q.out_off = out_off; q.ldc = ldc; q.s_off = s_off; q.nsplit = nsplit; q.raw_base = base; q.raw_stride = stride;
-    q.rs_base = base == p.raw_mixer ? rw.agent_end : 0;      // (where launch_split_reduce puts the two regions in `rsum`)
-    return q;
-  };
-  auto add_mixer_problems = [&](WgTable& wt) {
-    const MixerLayout& M = p.ML;
-    const int mbase = p.AL.end;
-    const int64_t mb_ = p.raw_mixer, ms = rw.mixer_size;
-    const int TBk = (int)p.TB;
-    const float* S0 = batch->share_obs;  // rows 0..TB-1 are states at t < T
-    if (p.hyp1) {      // every hyper-network layer reads the state: grad W = (pre-activation adjoint)^T S
-      prob(wt, W + p.d_v1, p.NM, p.NM, S0, p.S, p.S, TBk, M.w1a_w - mbase, p.S, M.w1a_b - mbase, p.ns_mixer, mb_, ms);
-      prob(wt, W + p.d_v2, OPE_MIX, OPE_MIX, S0, p.S, p.S, TBk, M.w2a_w - mbase, p.S, M.w2a_b - mbase, p.ns_mixer, mb_, ms);
-      prob(wt, W + p.d_b1, OPE_MIX, OPE_MIX, S0, p.S, p.S, TBk, M.b1_w - mbase, p.S, M.b1_b - mbase, p.ns_mixer, mb_, ms);
-      prob(wt, W + p.d_hb2, OPE_HYP, OPE_HYP, S0, p.S, p.S, TBk, M.b2a_w - mbase, p.S, M.b2a_b - mbase, p.ns_mixer, mb_, ms);
-      prob(wt, W + p.dqtot, 4, 1, W + p.hb2, OPE_HYP, OPE_HYP, TBk, M.b2b_w - mbase, OPE_HYP, M.b2b_b - mbase, p.ns_mixer, mb_, ms);
-      return;
-    }
-    prob(wt, W + p.d_hw1, OPE_HYP, OPE_HYP, S0, p.S, p.S, TBk, M.w1a_w - mbase, p.S, M.w1a_b - mbase, p.ns_mixer, mb_, ms);
-    prob(wt, W + p.d_v1, p.NM, p.NM, W + p.hw1, OPE_HYP, OPE_HYP, TBk, M.w1b_w - mbase, OPE_HYP, M.w1b_b - mbase, p.ns_mixer, mb_, ms);
-    prob(wt, W + p.d_hw2, OPE_HYP, OPE_HYP, S0, p.S, p.S, TBk, M.w2a_w - mbase, p.S, M.w2a_b - mbase, p.ns_mixer, mb_, ms);
-    prob(wt, W + p.d_v2, OPE_MIX, OPE_MIX, W + p.hw2, OPE_HYP, OPE_HYP, TBk, M.w2b_w - mbase, OPE_HYP, M.w2b_b - mbase, p.ns_mixer, mb_, ms);
-    prob(wt, W + p.d_b1, OPE_MIX, OPE_MIX, S0, p.S, p.S, TBk, M.b1_w - mbase, p.S, M.b1_b - mbase, p.ns_mixer, mb_, ms);
-    prob(wt, W + p.d_hb2, OPE_HYP, OPE_HYP, S0, p.S, p.S, TBk, M.b2a_w - mbase, p.S, M.b2a_b - mbase, p.ns_mixer, mb_, ms);
-    prob(wt, W + p.dqtot, 4, 1, W + p.hb2, OPE_HYP, OPE_HYP, TBk, M.b2b_w - mbase, OPE_HYP, M.b2b_b - mbase, p.ns_mixer, mb_, ms);
-  };
-  // agent problems over the rows [r0, r0 + K1) (whole time steps), slabs starting at `slab0`
-  // the register-blocked weight-gradient launch (ope_wgrad2.hip) takes whole steps on one stream: no time chunks, no rows read in place
-  static const int w2_env = getenv("OPE_WGRAD2") ? atoi(getenv("OPE_WGRAD2")) : 1;
-  const bool w2_can = C == 1 && !use_side && !oref && p.D % 2 == 0 && p.D <= 1024 && (cfg->vdn || (p.S % 2 == 0 && p.S <= 1024)) && p.NM <= 1024;      // (rows 8-byte aligned at least; at most four units per problem)
-  if (cfg->wgrad_path == 2 && !w2_can) return OPE_EINVAL;
-  const bool want_w2 = w2_can && (cfg->wgrad_path == 2 || (cfg->wgrad_path == 0 && w2_env));
-  const bool merge_hh = want_w2;
-  auto add_agent_problems = [&](WgTable& wt, int64_t r0, int K1, int nsplit, int slab0) {
-    const int64_t ab = p.raw_agent + (int64_t)slab0 * rw.agent_end, as = rw.agent_end;
-    {
-      WgProb& q = prob(wt, W + p.dz1 + r0 * OPE_H, OPE_H, OPE_H, oref ? obs_rows : obs_rows + r0 * p.D, p.D, p.D, K1, rw.P1, p.D, rw.s1, nsplit, ab, as);
-      q.ln_mu = W + p.mu0 + r0; q.ln_rstd = W + p.rstd0 + r0; q.ln_on = 1;
-      if (oref) { q.ref_row1 = (int)r0 + 1; wt.ref = ref; }
-    }
-    prob(wt, W + p.dz2 + r0 * OPE_H, OPE_H, OPE_H, W + p.xhat1 + r0 * OPE_H, OPE_H, OPE_H, K1, rw.P2, OPE_H, rw.s2, nsplit, ab, as);
-    if (!p.mlp) {
-      const float* dgi = W + p.dgi + r0 * 3 * OPE_H;
-      if (p.layerN == 2) prob(wt, W + p.dz3 + r0 * OPE_H, OPE_H, OPE_H, W + p.xhat2 + r0 * OPE_H, OPE_H, OPE_H, K1, rw.P2b, OPE_H, rw.s2b, nsplit, ab, as);
-      prob(wt, dgi, 3 * OPE_H, 3 * OPE_H, (p.layerN == 2 ? W + p.xhat3 : W + p.xhat2) + r0 * OPE_H, OPE_H, OPE_H, K1, rw.P3, OPE_H, rw.s3, nsplit, ab, as);
-      // h_{t-1}: the first chunk shifts inside the kernel (rows of t = 0 see zeros), later chunks start one step back
-      const float* hprev = r0 > 0 ? W + p.h + (r0 - p.NB) * OPE_H : W + p.h;
-      const int shift = r0 > 0 ? 0 : p.NB;
-      if (merge_hh) {      // register-blocked launch: one problem, dgi's r / z panels and dghn as the third panel, h_{t-1} read once for all three
-        WgProb& q = prob(wt, dgi, 3 * OPE_H, 3 * OPE_H, hprev, OPE_H, OPE_H, K1, rw.WHH, OPE_H, rw.shh, nsplit, ab, as);
-        q.b_shift = shift; q.A2 = W + p.dghn + r0 * OPE_H; q.lda2 = OPE_H; q.a2_from = 2;
-      } else {
-        prob(wt, dgi, 3 * OPE_H, 2 * OPE_H, hprev, OPE_H, OPE_H, K1, rw.WHH, OPE_H, rw.shh, nsplit, ab, as).b_shift = shift;
-        prob(wt, W + p.dghn + r0 * OPE_H, OPE_H, OPE_H, hprev, OPE_H, OPE_H, K1, rw.WHH + 2 * OPE_H * OPE_H, OPE_H, rw.shh + 2 * OPE_H, nsplit, ab,
-             as).b_shift = shift;
-      }
-    }
-    // q head: fed by rnn.norm (recurrent) or directly by the trunk's LN2 (MLP) -- both "Linear after LayerNorm"
-    prob(wt, W + p.dqoh + r0 * p.A4, p.A4, p.A, (p.mlp ? W + p.xhat2 : W + p.xhat_o) + r0 * OPE_H, OPE_H, OPE_H, K1, rw.E, OPE_H, rw.sq, nsplit, ab, as);
-  };
   int agent_slabs = 0, mixer_slabs = 0;
   bool reduced = false;      // the weight-gradient launch summed its own slabs into `rsum`
   if (use_side && !cfg->vdn) {   // main stream, beside the BPTT of the last chunk on the side stream
@@ -721,6 +829,7 @@ static int qmix_step(const ope_qmix_cfg* cfg, const ope_fields* batch, const ope
     gb.dh_carry = lo > 0 ? W + p.dh_carry : nullptr;
     gb.dbg = dbg_on ? (long long*)(W + p.dbg) + 87552 : nullptr;
     gb.family = cfg->scan_family; gb.waves = cfg->scan_waves;
+    gb.lp = lp; gb.B = p.B; gb.N = p.N;
     if ((rc = launch_gru_bwd(gb, side))) return rc;
     if (use_side && hipEventRecord(sp->bptt_done[c], side) != hipSuccess) return OPE_ELAUNCH;
   }
@@ -734,6 +843,7 @@ static int qmix_step(const ope_qmix_cfg* cfg, const ope_fields* batch, const ope
     memset(&tb, 0, sizeof(tb));
     tb.R = K1; tb.theta = theta; tb.thetaT = W + p.thetaT; tb.L = p.AL;
     tb.tanh_act = (cfg->dims.flags & OPE_DIMS_TANH) ? 1 : 0;
+    tb.R_dev = live ? lp.hdr + 1 : nullptr;
     tb.dgi = p.mlp ? nullptr : W + p.dgi + r0 * 3 * OPE_H; tb.da2_in = p.mlp ? W + p.dh_out + r0 * OPE_H : nullptr;
     if (p.layerN == 2 && do_bwd) {      // the second block's adjoint first: dgi -> dz3 (its weight gradient), da2 (what the trunk adjoint continues from)
       BlockBwdArgs bb;
@@ -752,37 +862,18 @@ static int qmix_step(const ope_qmix_cfg* cfg, const ope_fields* batch, const ope
       if ((rc = launch_trunk_bwd_path(tb, cfg->trunk_path, st))) return rc;
     WgTable wt;
     memset(&wt, 0, sizeof(wt));
+    if (want_w2) {      // (C = 1: this is the only pass; the table and its plan were made before the first launch)
+      if (wt2.n > 0) {
+        if ((rc = launch_wgrad2(w2, W + p.raw2, W + p.rsum, st))) return rc;
+        reduced = true;
+      }
+      continue;
+    }
     if (do_bwd) add_agent_problems(wt, r0, K1, p.ns_chunk[c], agent_slabs);
     if (!use_side && !cfg->vdn && do_mix) add_mixer_problems(wt);
     if (wt.n > 0) {
       if ((rc = wg_finish(&wt))) return rc;
-      // whole step in one launch (no time chunks, no side stream): the register-blocked form, which also sums its slabs into `rsum`
-      if (want_w2) {
-        if (!w2_ok(wt)) return OPE_EINVAL;      // (8-byte aligned rows at least: every table of this step has them, ope_dims are checked at create)
-        // (units and workgroup shares depend on the problems' shapes only: planned once per configuration -- the greedy passes cost ~15 us
-        // of host time, which a short step like 3m's cannot hide; the pointers are refreshed on every call)
-        static thread_local int w2_key[kMaxWgProbs * 10 + 1];
-        static thread_local W2Table w2;
-        int key[kMaxWgProbs * 10 + 1];
-        memset(key, 0, sizeof(key));
-        key[0] = wt.n;
-        for (int q = 0; q < wt.n; ++q) {
-          const WgProb& P = wt.p[q];
-          int same = q;      // first problem that walks the same A rows (what the XCD pairing looks at)
-          for (int r = q - 1; r >= 0; --r)
-            if (wt.p[r].A == P.A) same = r;
-          const int al = (((uintptr_t)P.A & 15) ? 2 : 0) | (((uintptr_t)P.B & 15) ? 4 : 0) | ((P.A2 && ((uintptr_t)P.A2 & 15)) ? 8 : 0);      // (the load width follows the operands' alignment)
-          const int f[10] = {P.M, P.N, P.K, P.lda, P.ldb, P.b_shift, (P.s_off >= 0 ? 1 : 0) | al, same, P.A2 ? P.a2_from + 1 : 0, P.lda2};
-          memcpy(key + 1 + 10 * q, f, sizeof(f));
-        }
-        if (memcmp(w2_key, key, sizeof(key)) != 0) {
-          if ((rc = w2_build(wt, &w2))) return rc;
-          memcpy(w2_key, key, sizeof(key));
-        }
-        for (int q = 0; q < wt.n; ++q) w2.p[q] = wt.p[q];
-        if ((rc = launch_wgrad2(w2, W + p.raw2, W + p.rsum, st))) return rc;
-        reduced = true;
-      } else if ((rc = launch_wgrad(wt, W, st))) return rc;
+      if ((rc = launch_wgrad(wt, W, st))) return rc;
     }
     if (do_bwd) agent_slabs += wg_slabs(wt, p.ns_chunk[c]);
     if (!use_side && !cfg->vdn && do_mix) mixer_slabs = wg_slabs(wt, p.ns_mixer);

@@ -38,7 +38,11 @@ namespace {
 // by the 14 waves of its net and the launch is bound by how fast the CUs' texture-address units accept the scattered 64-byte row pieces of
 // the MFMA operand layout, not by the matrix pipes. Removed.)
 // ---------------------------------------------------------------------------------------------------------
-template <int VEC>
+// PK: the packed (t, b) rows of the live plan. The grid is what the padded batch needs (the host does not know the live count); the live
+// tiles are dealt out over the launch's row groups again on the device -- rpw_live = ceil(live tiles / groups) waves of a workgroup work, the
+// rest leave at once -- so a batch with a quarter of its rows dead runs four waves per CU instead of five (at 3s5z the launch is bound by
+// the weight rows its waves stream through the CU's L1: 12.9 us with four waves at B = 24 against 20.7 us with five at B = 32).
+template <int VEC, bool PK>
 __global__ void __launch_bounds__(512) mixer_hyp_kernel(HypFirstArgs a) {
   if ((int)blockIdx.x >= a.main_blocks) {
     transpose4_element(a.side, ((int)blockIdx.x - a.main_blocks) * (int)blockDim.x + (int)threadIdx.x);
@@ -46,9 +50,11 @@ __global__ void __launch_bounds__(512) mixer_hyp_kernel(HypFirstArgs a) {
   }
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 15, g = lane >> 4;
-  const int tiles = (a.TB + 15) >> 4;
-  const int rpw = (int)(blockDim.x >> 6);        // row tiles per workgroup (set by the launcher so that the grid is ONE round of the chip)
-  const int groups = (tiles + rpw - 1) / rpw;
+  const int TBr = PK ? a.lp.hdr[2] : a.TB;        // rows of this launch
+  const int rpw_full = (int)(blockDim.x >> 6);    // row tiles per workgroup (set by the launcher so that the grid is ONE round of the chip)
+  const int groups = ((a.TB + 15) / 16 + rpw_full - 1) / rpw_full;
+  const int tiles = (TBr + 15) >> 4;
+  const int rpw = PK ? (tiles + groups - 1) / groups : rpw_full;
   const int ncg = (a.ntiles + 6) / 7;            // column groups of (up to) 7 output tiles
   // The column groups of one (net, row group) read the same state rows: with two of them, blocks b and b + 8 form the pair, so that both
   // run on the same XCD (a workgroup lands on XCD b % 8) and the second reader finds the rows in its L2.
@@ -63,11 +69,17 @@ __global__ void __launch_bounds__(512) mixer_hyp_kernel(HypFirstArgs a) {
   }
   const int net = bid / groups, grp = bid - net * groups;
   const int tile = grp * rpw + wave;
-  if (tile >= tiles) return;                    // (no barrier in this kernel)
+  if (wave >= rpw || tile >= tiles) return;     // (no barrier in this kernel)
   const int m = tile * 16 + j;
-  const bool valid = m < a.TB;
-  const int mm = valid ? m : a.TB - 1;
-  const int tt = mm / a.B, b = mm - tt * a.B;
+  const bool valid = m < TBr;
+  const int mm = valid ? m : TBr - 1;
+  int tt, b;
+  if (PK) {
+    const int2 tb = *reinterpret_cast<const int2*>(a.lp.tbrec + 8 * (int64_t)mm);
+    tt = tb.x; b = tb.y;
+  } else {
+    tt = mm / a.B; b = mm - tt * a.B;
+  }
   const int S = a.S;
   const float* __restrict__ srow = a.share + ((int64_t)(tt + net) * a.B + b) * S;      // live: s_t, target: s_{t+1} (qmix.py:155-156)
   const float* __restrict__ th = net == 0 ? a.theta0 : a.theta1;
@@ -200,7 +212,12 @@ __device__ __forceinline__ float ln_row16x(const float* __restrict__ hrow, const
 // One workgroup per CU (up to 256 registers a wave).
 // H1: one-layer hyper-networks (hypernet_layers = 1, q_mixer.py:39-44): w1 and w2 come straight from the first-layer kernel (pre-abs values in
 // v1x / v2x), so the second-stage products, their transposes in the adjoint and the hw1 / hw2 ReLU masks all drop out.
-template <int NT, int APW, bool VDN, bool H1>     // NT: 16-action tiles of the head (A <= 16 NT); APW: agents per wave (N <= 8 APW)
+// PK: the packed rows of the live plan (LivePlan, ope_common.h). A workgroup takes 16 consecutive PACKED (t, b) rows -- the grid is sized for
+// the padded batch, workgroups past the live rows leave at once (300 -> 225 workgroups at 3s5z, B = 32 with a quarter of the rows dead: ONE
+// round on 256 CUs instead of two) --; a row's record gives its (t, b) in the batch (actions, availability, rewards, flags, PER weight) and
+// the packed agent rows of steps t and t + 1 (GRU states in, saves and adjoints out). Where step t + 1 of the episode is not computed
+// (t + 1 >= len_b, i.e. dones_env[t, b] = 1) the reference multiplies the target by 1 - dones_env = 0: the rows of step t stand in, finite.
+template <int NT, int APW, bool VDN, bool H1, bool PK>     // NT: 16-action tiles of the head (A <= 16 NT); APW: agents per wave (N <= 8 APW)
 __global__ void __launch_bounds__(64 * kCW, 2) qchain_kernel(ChainArgs a) {
   constexpr int QR = 16 * NT;                                                    // staged rows of W_q (zero beyond A)
   constexpr bool PFH = APW == 1;               // GRU-state rows requested at kernel start (one agent per wave: 48 registers)
@@ -225,10 +242,23 @@ __global__ void __launch_bounds__(64 * kCW, 2) qchain_kernel(ChainArgs a) {
   const int j = lane & 15, g = lane >> 4;
   const int A = a.A, N = a.N, B = a.B, NB = a.NB;
   const int tile = blockIdx.x;
+  const int TBr = PK ? __builtin_amdgcn_readfirstlane(a.lp.hdr[2]) : a.TB;
+  if (PK && tile * 16 >= TBr) return;      // (the plan kernel zero-filled loss_part and err_abs)
   const int m = tile * 16 + j;
-  const bool valid = m < a.TB;
-  const int mm = valid ? m : a.TB - 1;
-  const int t = mm / B, b = mm - t * B;
+  const bool valid = m < TBr;
+  const int mm = valid ? m : TBr - 1;
+  int t, b, pr0 = 0, pn0 = 0, pr1 = 0, pn1 = 0;
+  if (PK) {
+    const int4 q0 = reinterpret_cast<const int4*>(a.lp.tbrec)[2 * (int64_t)mm], q1 = reinterpret_cast<const int4*>(a.lp.tbrec)[2 * (int64_t)mm + 1];
+    t = q0.x; b = q0.y; pr0 = q0.z; pn0 = q0.w;
+    pr1 = q1.z ? q1.x : q0.z; pn1 = q1.z ? q1.y : q0.w;      // no step t + 1: step t's rows stand in (their weight is exactly zero)
+  } else {
+    t = mm / B; b = mm - t * B;
+  }
+  // agent `ag`'s rows of steps t / t + 1: in the batch (r0s: actions; + NB: availability at t + 1) and where the step's arrays hold them
+  auto row_s = [&](int ag) -> int64_t { return ((int64_t)t * N + ag) * B + b; };
+  auto row_0 = [&](int ag) -> int64_t { return PK ? (int64_t)pr0 + (int64_t)ag * pn0 : ((int64_t)t * N + ag) * B + b; };
+  auto row_1 = [&](int ag) -> int64_t { return PK ? (int64_t)pr1 + (int64_t)ag * pn1 : ((int64_t)t * N + ag) * B + b + NB; };
   const bool first = valid && g == 0;
   const AgentLayout& AL = a.AL;
   const MixerLayout& ML = a.ML;
@@ -256,7 +286,7 @@ __global__ void __launch_bounds__(64 * kCW, 2) qchain_kernel(ChainArgs a) {
   {                                       // hw1 rows of both nets: 2 x 16 rows x 16 pieces
     const int net = tid >> 8, row = (tid >> 4) & 15, piece = tid & 15;
     int mr = tile * 16 + row;
-    mr = mr < a.TB ? mr : a.TB - 1;
+    mr = mr < TBr ? mr : TBr - 1;
     // (pointer chosen by a select of the two kernel arguments: indexing the argument array with a per-lane value would be a LOAD of the pointer)
     if (!VDN && !H1) st_hw1 = *reinterpret_cast<const f32x4*>((net ? a.hw1[1] : a.hw1[0]) + (int64_t)mr * OPE_HYP + 4 * piece);
   }
@@ -291,7 +321,8 @@ __global__ void __launch_bounds__(64 * kCW, 2) qchain_kernel(ChainArgs a) {
   for (int ia = 0; ia < APW; ++ia) {
     const int ag = wave + kCW * ia;
     const int agc = ag < N ? ag : N - 1;
-    const int64_t r0 = ((int64_t)t * N + agc) * B + b, r1 = r0 + NB;
+    const int64_t r0 = row_0(agc), r1 = row_1(agc);
+    const int64_t r0s = row_s(agc), r1s = r0s + NB;
     if (PFH) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
@@ -306,8 +337,8 @@ __global__ void __launch_bounds__(64 * kCW, 2) qchain_kernel(ChainArgs a) {
       for (int rr = 0; rr < 4; ++rr) {
         const int k = 16 * it + 4 * g + rr;
         const int kc = k < A ? k : A - 1;
-        acv[ia][it][rr] = a.acts[r0 * A + kc];
-        avl[ia][it][rr] = avp[r1 * A + kc];
+        acv[ia][it][rr] = a.acts[r0s * A + kc];
+        avl[ia][it][rr] = avp[r1s * A + kc];      // (no mask: inside h0's allocation, which is sized for the padded batch; never used)
       }
   }
   // TD scalars of this lane's (t, b) row (qmix.py:159-164)
@@ -439,8 +470,8 @@ __global__ void __launch_bounds__(64 * kCW, 2) qchain_kernel(ChainArgs a) {
   for (int ia = 0; ia < APW; ++ia) {
     const int ag = wave + kCW * ia;
     if (ag < N) {
-      const int64_t r0 = ((int64_t)t * N + ag) * B + b;         // row (t, agent, b) of the [T+1][N*B] stacks
-      const int64_t r1 = r0 + NB;                               // (t + 1, agent, b)
+      const int64_t r0 = row_0(ag);                             // row (t, agent, b) of the [T+1][N*B] stacks (or its packed place)
+      const int64_t r1 = row_1(ag);                             // (t + 1, agent, b)
       // chosen action = first maximum of the one-hot row (QMixPolicy.q_values_from_actions, QMixPolicy.py:69-93)
       float cv = kNegInf;
       int chosen = 1 << 30;
@@ -713,7 +744,7 @@ __global__ void __launch_bounds__(64 * kCW, 2) qchain_kernel(ChainArgs a) {
       a.loss_part[tile * 4 + 3] = 0.f;
     }
     if (first) {
-      a.err_abs[m] = fabsf(td.err);
+      a.err_abs[PK ? t * B + b : m] = fabsf(td.err);
       if (!VDN) *reinterpret_cast<f32x4*>(a.dqtot + 4 * (int64_t)m) = f32x4{dQ, 0.f, 0.f, 0.f};       // [TB][4]: lda = 4 for the wgrad kernel
       if (a.qtot) { a.qtot[m] = qtot; a.nqtot[m] = nqtot; }
     }
@@ -826,7 +857,7 @@ __global__ void __launch_bounds__(64 * kCW, 2) qchain_kernel(ChainArgs a) {
   for (int ia = 0; ia < APW; ++ia) {
     const int ag = wave + kCW * ia;
     if (ag < N && valid) {
-      const int64_t r0 = ((int64_t)t * N + ag) * B + b;
+      const int64_t r0 = row_0(ag);
       const float dq = dqa_k[ia];
       const int act = chosen_k[ia];
       for (int k0 = 4 * g; k0 < A4; k0 += 16)
@@ -905,11 +936,18 @@ int launch_mixer_hyp(const HypFirstArgs& a0, hipStream_t st) {
   const int blocks = a.main_blocks + (a.side.total > 0 ? ope_cdiv(a.side.total, threads) : 0);
   const int vec = ope_vec_of(a.S);
   kprof_work(2.0 * 2.0 * a.TB * (double)a.S * 16.0 * a.ntiles);
-  if (vec == 4) OPE_LAUNCH(mixer_hyp_kernel<4>, dim3(blocks), dim3(threads), 0, st, a);
-  else if (vec == 2) OPE_LAUNCH(mixer_hyp_kernel<2>, dim3(blocks), dim3(threads), 0, st, a);
-  else OPE_LAUNCH(mixer_hyp_kernel<1>, dim3(blocks), dim3(threads), 0, st, a);
+  const bool pk = a.lp.hdr != nullptr;
+  if (pk) {
+    if (vec == 4) OPE_LAUNCH((mixer_hyp_kernel<4, true>), dim3(blocks), dim3(threads), 0, st, a);
+    else if (vec == 2) OPE_LAUNCH((mixer_hyp_kernel<2, true>), dim3(blocks), dim3(threads), 0, st, a);
+    else OPE_LAUNCH((mixer_hyp_kernel<1, true>), dim3(blocks), dim3(threads), 0, st, a);
+  } else {
+    if (vec == 4) OPE_LAUNCH((mixer_hyp_kernel<4, false>), dim3(blocks), dim3(threads), 0, st, a);
+    else if (vec == 2) OPE_LAUNCH((mixer_hyp_kernel<2, false>), dim3(blocks), dim3(threads), 0, st, a);
+    else OPE_LAUNCH((mixer_hyp_kernel<1, false>), dim3(blocks), dim3(threads), 0, st, a);
+  }
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
-  note_launch("mixer_hyp", vec);
+  note_launch(pk ? "mixer_hyp_live" : "mixer_hyp", vec);
   return OPE_OK;
 }
 
@@ -920,19 +958,27 @@ int launch_qchain(const ChainArgs& a, hipStream_t st) {
   // heads (three 16-row evaluations per agent and tile), W1b of both nets, W2b, the two transposed products
   kprof_work(2.0 * a.TB * ((double)a.N * 3.0 * OPE_H * a.A + ((a.vdn || a.ML.one_layer) ? 0.0 : (2.0 * ((double)a.N * OPE_MIX * OPE_HYP + OPE_MIX * OPE_HYP) +
                                                                              (double)a.N * OPE_MIX * OPE_HYP + OPE_MIX * OPE_HYP))));
-#define OPE_QCHAIN(NT_, APW_)                                                                                       \
+  const bool pk = a.lp.hdr != nullptr;
+  if (pk && (a.q_all || a.agent_q || a.agent_nq || a.qtot || a.v1 || a.v2 || a.hpre || a.d_agent_q)) return OPE_EINVAL;      // (the debug outputs are batch-indexed)
+#define OPE_QCHAIN2(NT_, APW_, PK_)                                                                                 \
   do {                                                                                                              \
-    if (a.vdn) OPE_LAUNCH((qchain_kernel<NT_, APW_, true, false>), dim3(blocks), dim3(64 * kCW), 0, st, a);         \
-    else if (a.ML.one_layer) OPE_LAUNCH((qchain_kernel<NT_, APW_, false, true>), dim3(blocks), dim3(64 * kCW), 0, st, a); \
-    else OPE_LAUNCH((qchain_kernel<NT_, APW_, false, false>), dim3(blocks), dim3(64 * kCW), 0, st, a);              \
+    if (a.vdn) OPE_LAUNCH((qchain_kernel<NT_, APW_, true, false, PK_>), dim3(blocks), dim3(64 * kCW), 0, st, a);    \
+    else if (a.ML.one_layer) OPE_LAUNCH((qchain_kernel<NT_, APW_, false, true, PK_>), dim3(blocks), dim3(64 * kCW), 0, st, a); \
+    else OPE_LAUNCH((qchain_kernel<NT_, APW_, false, false, PK_>), dim3(blocks), dim3(64 * kCW), 0, st, a);         \
+  } while (0)
+#define OPE_QCHAIN(NT_, APW_)                   \
+  do {                                          \
+    if (pk) OPE_QCHAIN2(NT_, APW_, true);       \
+    else OPE_QCHAIN2(NT_, APW_, false);         \
   } while (0)
   if (nt == 1 && apw == 1) OPE_QCHAIN(1, 1);
   else if (nt == 2 && apw == 1) OPE_QCHAIN(2, 1);
   else if (nt == 1) OPE_QCHAIN(1, 2);
   else OPE_QCHAIN(2, 2);
 #undef OPE_QCHAIN
+#undef OPE_QCHAIN2
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
-  note_launch(a.vdn ? "qchain_vdn" : (a.ML.one_layer ? "qchain_h1" : "qchain"), nt, apw);
+  note_launch(pk ? (a.vdn ? "qchain_vdn_live" : (a.ML.one_layer ? "qchain_h1_live" : "qchain_live")) : (a.vdn ? "qchain_vdn" : (a.ML.one_layer ? "qchain_h1" : "qchain")), nt, apw);
   return OPE_OK;
 }
 

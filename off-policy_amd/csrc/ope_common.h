@@ -239,6 +239,29 @@ __device__ __forceinline__ int obs_ref_slot(const ObsRef& o, int64_t v) {       
   return v < 0 ? 0 : (v >= o.cap ? o.cap - 1 : (int)v);
 }
 
+// Live-row plan of one batch (ope_live.hip; built on the device from dones_env at the start of every step, never read by the host).
+// The reference pads every sampled episode to T steps; every (t, b) with dones_env[t-1, b] = 1 is multiplied by 1 - bad_transitions_mask = 0
+// (qmix.py:161-166), excluded from the loss normaliser (:184-186) and from Q_tot's mean (:198): no contribution to any output or gradient.
+// Episode b needs the agent-network rows t < len_b, len_b = 2 + (last t' with dones_env[t', b] != 1) (1 when there is none; T + 1 for an
+// episode that never ends), and the (t, b) rows t < min(len_b, T). Episodes are ranked by len_b, longest first (stable): the live episodes
+// of a time step are then a PREFIX j < n[t] of the ranking, and rows are packed time-major:
+//   agent row  (t, a, j) -> N * cum[t] + a * n[t] + j        RL = N * cum[T + 1] rows, the t < T ones are the first R1L = N * cum[T]
+//   (t, b) row (t, j)    -> cum[t] + j                        TBL = cum[T] rows
+// with cum[t] = n[0] + ... + n[t - 1]. Every intermediate of the step lives in that packed index space; only the batch itself (the
+// reference's layout, untouched) is read through `srcrow` / `tbsrc` / the records.
+struct LivePlan {
+  const int* hdr;       // [16]: RL, R1L, TBL, max len, 0 ...        (null: no plan -- every padded row is computed)
+  const int* len;       // [B]   len of the episode ranked j
+  const int* perm;      // [B]   its batch column b
+  const int* cum;       // [T+2]
+  const int* nn;        // [T+2] n[t] (n[T+1] = 0)
+  const int* tbrec;     // [T*B][8] per packed (t, b) row: t, b, agent-0 row at t, n[t], agent-0 row at t+1, n[t+1], t+1 < len_b, 0
+  const int* tbsrc;     // [T*B] packed (t, b) row -> t * B + b
+  const int* srcrow;    // [(T+1)*N*B] packed agent row -> batch row (t * N + a) * B + b
+  const int* prevrow;   // [(T+1)*N*B] packed agent row -> packed row of (t - 1, a, j), -1 at t = 0
+};
+constexpr int kLiveMaxB = 256, kLiveMaxT = 1022;      // what the plan kernel's LDS tables hold
+
 // Flat-parameter offsets (floats) of the agent q-network and the QMixer. Order = reference named_parameters()
 // (SURVEY.md Appendix D); every tensor starts on a multiple of 4 floats.
 struct AgentLayout {

@@ -64,7 +64,10 @@ __device__ __forceinline__ f32x2 pk_mul_bcast(f32x2 w, f32x2 hp) {
 // ---------------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------------
-template <int W, bool DBG>   // W = compute waves per row = lanes per feature (2 or 4)
+// PK: packed rows of the live plan (LivePlan, ope_common.h): the workgroup of (agent, ranked episode j) walks the len[j] steps the episode
+// needs and stops -- every later (t, b) of that episode is multiplied by a zero mask in the loss (qmix.py:161-166) --; step t's rows are
+// at N * cum[t] + agent * n[t] + j, a table the workgroup builds in LDS before the chain starts (the loader / storer read it, off the chain).
+template <int W, bool DBG, bool PK>   // W = compute waves per row = lanes per feature (2 or 4)
 __global__ void __launch_bounds__((W + 2) * 64) gru_fwd4_kernel(GruFwdArgs a) {
   constexpr int FPW = OPE_H / W;     // features per compute wave
   constexpr int KS = OPE_H / W;      // K-slice per lane
@@ -89,7 +92,14 @@ __global__ void __launch_bounds__((W + 2) * 64) gru_fwd4_kernel(GruFwdArgs a) {
   const int rid = blockIdx.x;
   const int net = rid / a.NB;
   const int row = rid - net * a.NB;
-  const int L = a.L;
+  __shared__ int rows_s[PK ? kLiveMaxT + 2 : 1];
+  int L = a.L;
+  if (PK) {
+    const int ag = row / a.B, jj = row - ag * a.B;
+    L = __builtin_amdgcn_readfirstlane(a.lp.len[jj]);
+    for (int t = threadIdx.x; t < L; t += (W + 2) * 64) rows_s[t] = a.N * a.lp.cum[t] + ag * a.lp.nn[t] + jj;
+    __syncthreads();
+  }
   const int nchunks = (L + kAhead - 1) / kAhead;
   const float* __restrict__ th = net == 0 ? a.theta0 : a.theta1;
 
@@ -101,7 +111,7 @@ __global__ void __launch_bounds__((W + 2) * 64) gru_fwd4_kernel(GruFwdArgs a) {
     const float brs = th[a.bhh_off + lane] * kL, bzs = th[a.bhh_off + OPE_H + lane] * kL;
     float pre[kAhead][3];
     auto load_step = [&](float (&d)[3], int t) {
-      const float* p = gp + (int64_t)min(t, L - 1) * stride_t;
+      const float* p = PK ? gi + (int64_t)__builtin_amdgcn_readfirstlane(rows_s[min(t, L - 1)]) * (3 * OPE_H) : gp + (int64_t)min(t, L - 1) * stride_t;
       gload_async_s<0>(d[0], p, lo4);
       gload_async_s<4 * OPE_H>(d[1], p, lo4);
       gload_async_s<8 * OPE_H>(d[2], p, lo4);
@@ -145,7 +155,7 @@ __global__ void __launch_bounds__((W + 2) * 64) gru_fwd4_kernel(GruFwdArgs a) {
     for (int t = 0; t <= L; ++t) {
       if (t > 0) {
         const int p = (t - 1) & 1;
-        const int64_t o = ((int64_t)(t - 1) * a.NB + row) * OPE_H + lane;
+        const int64_t o = (PK ? (int64_t)rows_s[t - 1] : (int64_t)(t - 1) * a.NB + row) * OPE_H + lane;
         hout[o] = hs[p ^ 1][lane];   // h_t was published as the next step's input
         if (save) {
           a.rg[o] = sv[p][0][lane];
@@ -284,7 +294,7 @@ __global__ void __launch_bounds__((W + 2) * 64) gru_fwd4_kernel(GruFwdArgs a) {
 // BPTT, step i = 0 .. T-1-t_lo at time tt = T-1-i:
 //   dh_{tt-1}[k] = dh_tt[k] z[k] + sum_i ( W_hr[i][k] dr_pre[i] + W_hz[i][k] dz_pre[i] + W_hn[i][k] dghn[i] )
 // ---------------------------------------------------------------------------------------------------------
-template <int W, bool DBG>
+template <int W, bool DBG, bool PK>   // PK: as gru_fwd4_kernel -- the chain starts at the episode's last live step, min(len[j], T) - 1
 __global__ void __launch_bounds__((W + 2) * 64) gru_bwd4_kernel(GruBwdArgs a) {
   constexpr int FPW = OPE_H / W;     // features per compute wave
   constexpr int IS = OPE_H / W;      // gate rows per gate per lane
@@ -296,20 +306,28 @@ __global__ void __launch_bounds__((W + 2) * 64) gru_bwd4_kernel(GruBwdArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = blockIdx.x;
   const int64_t NB = a.NB;
-  const int nsteps = a.T - a.t_lo;
+  __shared__ int rows_s[PK ? kLiveMaxT + 2 : 1];
+  int Tl = a.T;                       // the chain walks t = Tl - 1 .. t_lo
+  if (PK) {
+    const int ag = row / a.B, jj = row - ag * a.B;
+    Tl = min(__builtin_amdgcn_readfirstlane(a.lp.len[jj]), a.T);
+    for (int t = threadIdx.x; t < Tl; t += (W + 2) * 64) rows_s[t] = a.N * a.lp.cum[t] + ag * a.lp.nn[t] + jj;
+    __syncthreads();
+  }
+  const int nsteps = Tl - a.t_lo;
   const int nchunks = (nsteps + kAhead - 1) / kAhead;
 
   if (wave == W) {   // ---- loader
     float pre[kAhead][6];
     auto load_step = [&](float (&d)[6], int i) {
-      const int t = max(a.T - 1 - i, a.t_lo);
-      const int64_t o = ((int64_t)t * NB + row) * OPE_H + lane;
+      const int t = max(Tl - 1 - i, a.t_lo);
+      const int64_t o = (PK ? (int64_t)rows_s[t] : (int64_t)t * NB + row) * OPE_H + lane;
       gload_async(d[0], a.rg + o);
       gload_async(d[1], a.zg + o);
       gload_async(d[2], a.ng + o);
       gload_async(d[3], a.ghn + o);
       gload_async(d[4], a.dh_out + o);
-      gload_async(d[5], a.h + (t > 0 ? o - NB * OPE_H : o));
+      gload_async(d[5], a.h + (t > 0 ? (PK ? (int64_t)rows_s[t - 1] * OPE_H + lane : o - NB * OPE_H) : o));
     };
     // The factors of step i that do not depend on dh are formed here, off the compute waves' chain (every instruction of a
     // compute wave is on it): with dht = dh_t + dh_out_t,
@@ -317,7 +335,7 @@ __global__ void __launch_bounds__((W + 2) * 64) gru_bwd4_kernel(GruBwdArgs a) {
     //   dz_pre = a_z dht, a_z = (h_prev - n) z (1 - z).     (scalar arithmetic on purpose: see the forward loader)
     auto publish = [&](float (&d)[6], int i) {
       const int p = i & 1;
-      const int t = a.T - 1 - i;
+      const int t = Tl - 1 - i;
       const float r = d[0], z = d[1], n = d[2], gn = d[3];
       const float hp = t > 0 ? d[5] : 0.f;         // h_{-1} = 0
       const float omz = 1.0f - z;
@@ -359,12 +377,13 @@ __global__ void __launch_bounds__((W + 2) * 64) gru_bwd4_kernel(GruBwdArgs a) {
     for (int i = 0; i <= nsteps; ++i) {
       if (i > 0) {
         const int p = (i - 1) & 1;
-        const int t = a.T - i;
-        float* gout = a.dgi + ((int64_t)t * NB + row) * (3 * OPE_H) + lane;
+        const int t = Tl - i;
+        const int64_t ro = PK ? (int64_t)rows_s[t] : (int64_t)t * NB + row;
+        float* gout = a.dgi + ro * (3 * OPE_H) + lane;
         gout[0] = ds[p][0][lane];
         gout[OPE_H] = ds[p][1][lane];
         gout[2 * OPE_H] = ds[p][3][lane];
-        a.dghn[((int64_t)t * NB + row) * OPE_H + lane] = ds[p][2][lane];
+        a.dghn[ro * OPE_H + lane] = ds[p][2][lane];
       }
       if (i < nsteps) lds_barrier();
     }
@@ -472,34 +491,40 @@ static int waves_per_row(int64_t rows, int asked) {
 
 template <int W>
 static void launch_fwd(const GruFwdArgs& a, hipStream_t st) {
-  if (a.dbg)
-    OPE_LAUNCH((gru_fwd4_kernel<W, true>), dim3(a.nets * a.NB), dim3((W + 2) * 64), 0, st, a);
+  if (a.lp.hdr)
+    OPE_LAUNCH((gru_fwd4_kernel<W, false, true>), dim3(a.nets * a.NB), dim3((W + 2) * 64), 0, st, a);
+  else if (a.dbg)
+    OPE_LAUNCH((gru_fwd4_kernel<W, true, false>), dim3(a.nets * a.NB), dim3((W + 2) * 64), 0, st, a);
   else
-    OPE_LAUNCH((gru_fwd4_kernel<W, false>), dim3(a.nets * a.NB), dim3((W + 2) * 64), 0, st, a);
+    OPE_LAUNCH((gru_fwd4_kernel<W, false, false>), dim3(a.nets * a.NB), dim3((W + 2) * 64), 0, st, a);
 }
 template <int W>
 static void launch_bwd(const GruBwdArgs& a, hipStream_t st) {
-  if (a.dbg)
-    OPE_LAUNCH((gru_bwd4_kernel<W, true>), dim3(a.NB), dim3((W + 2) * 64), 0, st, a);
+  if (a.lp.hdr)
+    OPE_LAUNCH((gru_bwd4_kernel<W, false, true>), dim3(a.NB), dim3((W + 2) * 64), 0, st, a);
+  else if (a.dbg)
+    OPE_LAUNCH((gru_bwd4_kernel<W, true, false>), dim3(a.NB), dim3((W + 2) * 64), 0, st, a);
   else
-    OPE_LAUNCH((gru_bwd4_kernel<W, false>), dim3(a.NB), dim3((W + 2) * 64), 0, st, a);
+    OPE_LAUNCH((gru_bwd4_kernel<W, false, false>), dim3(a.NB), dim3((W + 2) * 64), 0, st, a);
 }
 
 int launch_gru_fwd4(const GruFwdArgs& a, hipStream_t st) {
   const int w = waves_per_row((int64_t)a.nets * a.NB, a.waves);
   kprof_work(2.0 * a.nets * a.NB * (double)a.L * 3.0 * OPE_H * OPE_H);      // W_hh h per row and step
+  if (a.lp.hdr && (a.dbg || a.hinit || a.hinit1 || a.B < 1 || a.N < 1 || a.NB != a.N * a.B || a.L > kLiveMaxT + 1)) return OPE_EINVAL;
   if (w == 4) launch_fwd<4>(a, st); else launch_fwd<2>(a, st);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
-  note_launch("gru_fwd4", w == 4 ? 4 : 2);
+  note_launch(a.lp.hdr ? "gru_fwd4_live" : "gru_fwd4", w == 4 ? 4 : 2);
   return OPE_OK;
 }
 
 int launch_gru_bwd4(const GruBwdArgs& a, hipStream_t st) {
   const int w = waves_per_row(a.NB, a.waves);
   kprof_work(2.0 * a.NB * (double)(a.T - a.t_lo) * 3.0 * OPE_H * OPE_H);     // W_hh^T (gate adjoints) per row and step
+  if (a.lp.hdr && (a.dbg || a.dh_in || a.dh_carry || a.t_lo != 0 || a.B < 1 || a.N < 1 || a.NB != a.N * a.B || a.T > kLiveMaxT)) return OPE_EINVAL;
   if (w == 4) launch_bwd<4>(a, st); else launch_bwd<2>(a, st);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
-  note_launch("gru_bwd4", w == 4 ? 4 : 2);
+  note_launch(a.lp.hdr ? "gru_bwd4_live" : "gru_bwd4", w == 4 ? 4 : 2);
   return OPE_OK;
 }
 

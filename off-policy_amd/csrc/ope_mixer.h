@@ -101,6 +101,7 @@ struct HypFirstArgs {
   int ntiles; HypTile tile[kHypMaxTiles];
   Transp4 side;                               // weight transposes carried as extra workgroups (side.total = 0: none)
   int main_blocks;                            // set by the launcher
+  LivePlan lp;                                // lp.hdr != null: the packed (t, b) rows of the live plan (outputs in packed order)
 };
 // fills ntiles / tile[] / ld[] for a mixer layout (two-layer: 14 tiles; one-layer: 2 N + 8)
 void hyp_tiles_for(const MixerLayout& L, int N, int S, HypFirstArgs* a);
@@ -125,6 +126,8 @@ struct ChainArgs {
   // test / debug outputs (null unless ope_qmix_cfg.debug)
   float* q_all; float* agent_q; float* agent_nq; float* qtot; float* nqtot; float* v1; float* v2; float* hpre; float* d_agent_q;
   long long* dbg;                             // optional per-wave s_memtime stamps [tile][wave][10] (tools/chain_phases.py)
+  LivePlan lp;                                // lp.hdr != null: packed rows (LivePlan, ope_common.h) -- h0 / h1 and every output except err_abs
+                                              // are indexed by packed rows, the batch fields (acts, avail, td.*) by the batch's own
 };
 bool qchain_shape_ok(int N, int A);
 int launch_mixer_hyp(const HypFirstArgs& a, hipStream_t st);

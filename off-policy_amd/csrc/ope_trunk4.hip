@@ -73,6 +73,7 @@ struct TrunkPairArgs {
   int no_fn;                      // no input LayerNorm (OPE_DIMS_NO_FEATURE_NORM)
   int save0;                      // net 0 writes the saves (a single-net launch of a target / rollout net does not)
   ObsRef ref; int ref_tn0;        // LAZY instantiation: x = the store's obs ring; first (t, agent) index of the launch's row range
+  const int* live_hdr; const int* live_src;   // PK instantiation: the live plan's header (hdr[0] = rows of this launch) and packed row -> batch row
 };
 
 // KCM = ceil(D / 16) exactly and D % 4 == 0: every 16-column chunk but the last is complete, and a 16-byte piece of the last one is inside
@@ -85,10 +86,15 @@ struct TrunkPairArgs {
 // EXP (instantiated only in builds with -DOPE_EXPERIMENTS; TIMING variants, results WRONG; OPE_T4_EXP, profiles/r05_trunk4_decomposition.txt):
 // 1 no MFMAs (their LDS weight reads stay), 2 no saves for the backward pass, 4 no weight staging, 8 no gi stores, 16 no ReLU / LayerNorm
 // between the layers, 32 no observation-row loads
-template <int KCM, int NW, bool PF, bool LAZY, int VEC = 4, int EXP = 0>
+// PK: the packed rows of the live plan (LivePlan, ope_common.h). The row count comes from the plan's header on the device; packed row p reads
+// batch row live_src[p] (the batch keeps the reference's padded layout) and writes every output at p. A tile's 16 source indices are
+// requested one tile ahead -- at the top of the tile before, where the next tile is now drawn -- so they have landed when the rows
+// themselves are requested behind fc1.
+template <int KCM, int NW, bool PF, bool LAZY, int VEC = 4, int EXP = 0, bool PK = false>
 __global__ void __launch_bounds__(64 * NW, NW / 4) trunk_fwd4_kernel(TrunkPairArgs pa) {
   using C = T4<KCM>;
   static_assert(!(LAZY && VEC != 4), "rows are read in place from the store as 16-byte pieces only");
+  static_assert(!(PK && (LAZY || !PF)), "packed rows: gathered batch, rows prefetched behind fc1");
   constexpr int NT = 64 * NW;
   __shared__ __attribute__((aligned(16))) float sm[LAZY ? C::TOTAL_REF : C::TOTAL];
   float* const W1s = sm;
@@ -113,7 +119,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) trunk_fwd4_kernel(TrunkPairAr
   const TrunkPairArgs& a = pa;
   const float* __restrict__ th = net ? pa.theta[1] : pa.theta[0];
   float* __restrict__ gi_out = net ? pa.gi[1] : pa.gi[0];
-  const int D = a.D, R = a.R;
+  const int D = a.D, R = PK ? __builtin_amdgcn_readfirstlane(pa.live_hdr[0]) : a.R;
   const bool save = net == 0 && pa.save0 && !(EXP & 2);
 
   // optional s_memtime stamps (ope_qmix_cfg.debug; tools/trunk4_phases.py): [workgroup][wave][16] = start, weights staged, then for the
@@ -162,7 +168,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) trunk_fwd4_kernel(TrunkPairAr
 #pragma unroll
     for (int c = 0; c < KCM; ++c) xv[c] = f32x4{0.01f * (float)(lane + c), -0.02f * (float)(j + 3 * c), 0.5f - 0.03f * (float)g, 0.25f * (float)(c & 3)};
   }
-  auto request = [&](int tile, bool staged = true, int part = 0) {
+  auto request = [&](int tile, bool staged = true, int part = 0, int src = 0) {
     if (EXP & 32) return;
     const int row = tile * 16 + j;
     if (LAZY) {
@@ -178,7 +184,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) trunk_fwd4_kernel(TrunkPairAr
       for (int c = 0; c < KCM - 1; ++c) xv[c] = *reinterpret_cast<const f32x4*>(rp + 64 * c);
       return;
     }
-    const uint32_t xo = (uint32_t)(row < R ? row : R - 1) * (uint32_t)(4 * D) + 16u * g;
+    const uint32_t xo = (uint32_t)(PK ? src : (row < R ? row : R - 1)) * (uint32_t)(4 * D) + 16u * g;
     if (VEC == 2) {
       // two 8-byte halves per piece; the last chunk's halves are clamped to offset 0 of the row when they lie past its end (zeroed below)
       int gg = g;
@@ -212,7 +218,9 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) trunk_fwd4_kernel(TrunkPairAr
     const int64_t t = (int64_t)slot0 + (int64_t)nslots * (wave >> 2);
     tile = t < ntiles ? (int)t : ntiles;
   }
-  if (PF && tile < ntiles) request(tile, false, KCM > PFC ? 1 : 0);
+  int src_cur = 0, src_next = 0;      // PK: batch rows of this lane's row of the current / the next tile
+  if (PK) src_cur = pa.live_src[min(tile * 16 + j, R - 1)];
+  if (PF && tile < ntiles) request(tile, false, KCM > PFC ? 1 : 0, src_cur);
   // ---- prologue: this net's weights -> LDS (swizzled), parameters, tile counters. Every thread requests ALL its pieces before the
   // first LDS store (8 KCM / 16 + 2 + 6 independent 16-byte loads in flight per thread instead of one round trip per piece) ----
   if (!(EXP & 4)) {
@@ -332,7 +340,12 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) trunk_fwd4_kernel(TrunkPairAr
     bool valid;
     rows_of(tile, row, valid, b_, tnj_);
     if (!PF) request(tile);
-    if (PF && KCM > PFC) request(tile, true, 2);       // (unconditional: a "not for the first tile" test keeps the 32 registers live around the loop)
+    if (PF && KCM > PFC) request(tile, true, 2, src_cur);       // (unconditional: a "not for the first tile" test keeps the 32 registers live around the loop)
+    int next = 0;
+    if (PK) {      // the next tile is drawn a phase early: its source rows' indices travel while fc1 runs
+      next = grab();
+      src_next = pa.live_src[min(next * 16 + j, R - 1)];
+    }
     // ---- input LayerNorm statistics of row j: 4 lanes x KCM pieces ----
     float s = 0.f;
     if (!tail_ok) xv[KCM - 1] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -396,8 +409,8 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) trunk_fwd4_kernel(TrunkPairAr
     __builtin_amdgcn_sched_barrier(0);
     if (done == 0) stamp(3);
     // the observation registers are free: request the next tile's rows now, they arrive behind fc2 / W_ih
-    const int next = grab();
-    if (PF && next < ntiles) request(next, true, KCM > PFC ? 1 : 0);
+    if (!PK) next = grab();
+    if (PF && next < ntiles) request(next, true, KCM > PFC ? 1 : 0, src_next);
 
     float rs, mu;
     uint64_t bits;
@@ -482,6 +495,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) trunk_fwd4_kernel(TrunkPairAr
     if (done == 0) stamp(6);
     ++done;
     tile = next;
+    src_cur = src_next;
   }
   stamp(7);
   if (dbg && lane == 0) dbg[8] = done;
@@ -527,6 +541,9 @@ int launch_trunk_fwd_pair(const TrunkFwdArgs& live, const TrunkFwdArgs& tgt, int
   pa.no_fn = live.no_fn;
   pa.save0 = 1;
   pa.ref = live.ref; pa.ref_tn0 = lazy ? live.ref_row0 / live.ref.B : 0;
+  const bool pk = live.lp.hdr != nullptr;
+  if (pk && (lazy || !ok)) return OPE_EINVAL;      // (the caller checks trunk4_pair_can first)
+  pa.live_hdr = live.lp.hdr; pa.live_src = live.lp.srcrow;
   static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256; return n > 1 ? n : 256; }();
   const int grid = cus & ~1;     // one workgroup per CU, even ones the live net, odd ones the target
   // Eight waves (two per SIMD, rows prefetched behind fc1). Measured against twelve waves without the prefetch (three per SIMD at the 168
@@ -552,7 +569,13 @@ int launch_trunk_fwd_pair(const TrunkFwdArgs& live, const TrunkFwdArgs& tgt, int
     return OPE_OK;
   }
 #endif
-  if (KC == 24) OPE_LAUNCH((trunk_fwd4_kernel<24, 8, true, false, 2>), dim3(grid), dim3(512), 0, st, pa);
+  if (pk) {
+    if (KC == 24) OPE_LAUNCH((trunk_fwd4_kernel<24, 8, true, false, 2, 0, true>), dim3(grid), dim3(512), 0, st, pa);
+    else if (KC == 4) OPE_LAUNCH((trunk_fwd4_kernel<4, 8, true, false, 4, 0, true>), dim3(grid), dim3(512), 0, st, pa);
+    else if (KC == 8) OPE_LAUNCH((trunk_fwd4_kernel<8, 8, true, false, 4, 0, true>), dim3(grid), dim3(512), 0, st, pa);
+    else if (KC == 12) OPE_LAUNCH((trunk_fwd4_kernel<12, 8, true, false, 4, 0, true>), dim3(grid), dim3(512), 0, st, pa);
+    else OPE_LAUNCH((trunk_fwd4_kernel<16, 8, true, false, 4, 0, true>), dim3(grid), dim3(512), 0, st, pa);
+  } else if (KC == 24) OPE_LAUNCH((trunk_fwd4_kernel<24, 8, true, false, 2>), dim3(grid), dim3(512), 0, st, pa);
   else if (lazy) {
     if (KC == 4) OPE_LAUNCH((trunk_fwd4_kernel<4, 8, true, true>), dim3(grid), dim3(512), 0, st, pa);
     else if (KC == 8) OPE_LAUNCH((trunk_fwd4_kernel<8, 8, true, true>), dim3(grid), dim3(512), 0, st, pa);
@@ -565,8 +588,16 @@ int launch_trunk_fwd_pair(const TrunkFwdArgs& live, const TrunkFwdArgs& tgt, int
     else OPE_LAUNCH((trunk_fwd4_kernel<16, 8, true, false>), dim3(grid), dim3(512), 0, st, pa);
   }
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
-  note_launch(lazy ? "trunk_fwd4_store" : "trunk_fwd4", KC);
+  note_launch(lazy ? "trunk_fwd4_store" : (pk ? "trunk_fwd4_live" : "trunk_fwd4"), KC);
   return OPE_OK;
+}
+
+// Would launch_trunk_fwd_pair run trunk_fwd4 on a gathered batch of this shape? (what the live-row path needs to know before it plans)
+bool trunk4_pair_can(int D, int64_t R, int path, bool tanh_act) {
+  static const int on = getenv("OPE_TRUNK4") ? atoi(getenv("OPE_TRUNK4")) : 1;
+  const int KC = (D + 15) >> 4;
+  const bool shape = (D % 4 == 0 && (KC == 4 || KC == 8 || KC == 12 || KC == 16)) || (D % 2 == 0 && KC == 24);
+  return shape && !tanh_act && (path == 4 || (path == 0 && on && R >= trunk4_pair_min_rows()));
 }
 
 // ONE net's trunk on the LDS-resident kernel (every CU that net's weights): the recurrent MADDPG / MATD3 actors, whose live, target and
@@ -587,6 +618,7 @@ int launch_trunk_fwd4_single(const TrunkFwdArgs& a, bool save, hipStream_t st) {
   pa.fc2_w = L.fc2_w; pa.fc2_b = L.fc2_b; pa.ln2_w = L.ln2_w; pa.ln2_b = L.ln2_b; pa.wih = L.wih; pa.bih = L.bih;
   pa.save0 = save ? 1 : 0;
   pa.no_fn = a.no_fn;
+  if (a.lp.hdr) return OPE_EINVAL;
   if (save) {
     pa.mu0 = a.mu0; pa.rstd0 = a.rstd0; pa.xhat1 = a.xhat1; pa.rstd1 = a.rstd1; pa.mu1 = a.mu1; pa.mask1 = a.mask1;
     pa.xhat2 = a.xhat2; pa.rstd2 = a.rstd2; pa.mask2 = a.mask2;

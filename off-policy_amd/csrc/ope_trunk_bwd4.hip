@@ -36,7 +36,7 @@ __global__ void __launch_bounds__(512, 2) trunk_bwd4_kernel(TrunkBwdArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, g = lane >> 4;
-  const int R = a.R;
+  const int R = a.R_dev ? min(__builtin_amdgcn_readfirstlane(*a.R_dev), a.R) : a.R;      // (the live plan's packed rows with a loss term)
   const int ntiles = (R + 15) >> 4;
   const int nslots = 4 * (int)gridDim.x, slot0 = 4 * (int)blockIdx.x + (wave & 3);
   auto grab = [&]() -> int {
@@ -207,13 +207,18 @@ int launch_trunk_bwd_path(const TrunkBwdArgs& a, int path, hipStream_t st) {
   const bool can = a.dgi && a.xhat1 && a.xhat2 && a.rstd1 && a.rstd2 && a.mask1 && a.mask2 && a.dz1 && a.dz2 && a.thetaT &&
                    (int64_t)a.R * (4 * kG) < ((int64_t)1 << 32);
   if (path == 4 && (!can || a.tanh_act)) return OPE_EINVAL;      // explicit request that cannot run: no silent fall-back
-  if (a.tanh_act || !(can && (path == 4 || (path == 0 && on && a.R >= 16 * 1024)))) return launch_trunk_bwd3(a, st);
+  if (a.tanh_act || !(can && (path == 4 || (path == 0 && on && a.R >= 16 * 1024)))) return a.R_dev ? OPE_EINVAL : launch_trunk_bwd3(a, st);
   static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256; return n > 1 ? n : 256; }();
   kprof_work(2.0 * a.R * ((a.dgi ? 3.0 * OPE_H * OPE_H : 0.0) + OPE_H * OPE_H + (a.dout ? (double)a.hdim * OPE_H : 0.0)));
   OPE_LAUNCH(trunk_bwd4_kernel, dim3(cus), dim3(512), 0, st, a);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
-  note_launch("trunk_bwd4");
+  note_launch(a.R_dev ? "trunk_bwd4_live" : "trunk_bwd4");
   return OPE_OK;
+}
+
+bool trunk_bwd4_can(int64_t R, int path, bool tanh_act) {
+  static const int on = getenv("OPE_TRUNK_BWD4") ? atoi(getenv("OPE_TRUNK_BWD4")) : 1;
+  return !tanh_act && R * (4 * kG) < ((int64_t)1 << 32) && (path == 4 || (path == 0 && on && R >= 16 * 1024));
 }
 
 }  // namespace ope

@@ -19,6 +19,10 @@ struct WgProb {
   int ln_on;                           // 1: ln_mu / ln_rstd are a real LayerNorm (0: the zeros / ones vectors of a plain problem; wgrad2 skips the loads)
   int rs_base;                         // wgrad2: offset of this problem's region in the reduced vector `rsum` (out_off / s_off are relative to it)
   const float* A2; int lda2; int a2_from;  // wgrad2: 64-column panels >= a2_from of A come from A2 (column 64 * (panel - a2_from)); null: one matrix
+  // wgrad2 on the packed rows of a live plan (LivePlan, ope_common.h; the MAP instantiation runs when any problem of the table sets K_dev):
+  const int* K_dev;                    // rows reduced over, read on the device (<= K; the units' row chunks are re-derived from it in the kernel)
+  const int* b_map; int map_on;        // map_on: B's row for reduction row k is b_map[k], no contribution where that is negative (b_shift must
+                                       // be 0); LayerNorm statistics stay indexed by k. map_on = 0: b_map still points at >= K readable ints
 };
 constexpr int kMaxWgProbs = 16;
 struct WgTable {

@@ -62,7 +62,10 @@ __device__ __forceinline__ f32x4 w2_load(const float* __restrict__ row, int off,
 // has just finished with -- both cut into pieces that sit between groups of four MFMAs (sched_barriers pin them; the matrix pipe takes
 // 128 cycles per group, a piece issues in 20-60). A stage is 1-2 k cycles long, a fetch has three of them to land.
 // EXP (only in builds with -DOPE_EXPERIMENTS; timing variants, results WRONG): 1 = no MFMAs, 2 = no loads inside the loop, 4 = no operand preparation
-template <int VEC, int PA, int PB, int EXP>
+// MAP (packed rows of a live plan): B's row of reduction row k comes from P.b_map -- the batch row of a packed observation / state row, the
+// packed row of the step before (h_{t-1} for dW_hh; negative at t = 0: no contribution) --, fetched ONE STAGE AHEAD of the operand fetch that
+// uses it (a stage is 1-2 k cycles: the index has landed), into the index slot of the buffer the running stage computes from.
+template <int VEC, int PA, int PB, int EXP, bool MAP>
 __device__ __forceinline__ void w2_body(const WgProb& P, int mp0, int np0, int k0, int k1, f32x4 (&acc)[PA * PB][4][4], f32x4 (&cs)[PA]) {
   constexpr int NT = PA * PB, F = PA + PB;
   constexpr int SUB = NT == 1 ? 2 : 1;          // groups of 4 rows per stage
@@ -74,7 +77,9 @@ __device__ __forceinline__ void w2_body(const WgProb& P, int mp0, int np0, int k
   static_assert(NP <= NG, "more pieces than MFMA pairs");
   const int lane = threadIdx.x & 63;
   const int i = lane & 15, g = lane >> 4;
-  const int shift = P.b_shift;
+  const int shift = MAP ? 0 : P.b_shift;
+  const int* __restrict__ mapp = P.b_map;
+  const bool map_on = MAP && P.map_on != 0;
   // per A panel: base pointer, leading dimension and this lane's column offsets (panels >= a2_from come from the second matrix A2)
   const float* abase[PA];
   int alda[PA], moff[PA], moff1[PA], noff[PB], noff1[PB];
@@ -99,42 +104,45 @@ __device__ __forceinline__ void w2_body(const WgProb& P, int mp0, int np0, int k
   const float* __restrict__ rsp = P.ln_rstd;   // splits it into blocks and the accumulators then travel through copies at every block boundary)
   struct Buf { f32x4 a[SUB][PA]; f32x4 b[SUB][PB]; float mu[SUB], rs[SUB]; };
   int kcS[SUB], krS[SUB];      // row indices of the fetch in progress (set by its first piece)
-  auto fetch_piece = [&](int kb, int q, int r, Buf& s) {      // rows kb + 4 q + g of every panel, one piece at a time
+  int ixr[NB][SUB];            // MAP: b_map entries of the stage each buffer holds / is about to be fetched for
+  auto idx_load = [&](int kb, int q) -> int { return mapp[min(kb + 4 * q + g, k1 - 1)]; };
+  auto fetch_piece = [&](int kb, int q, int r, Buf& s, const int (&ixf)[SUB]) {      // rows kb + 4 q + g of every panel, one piece at a time
     if (r == 0) {
       kcS[q] = min(kb + 4 * q + g, k1 - 1);      // (the ring runs three stages past the chunk: those fetches hit the last row again, in L1)
-      krS[q] = max(kcS[q] - shift, 0);
+      krS[q] = MAP ? max(map_on ? ixf[q] : kcS[q], 0) : max(kcS[q] - shift, 0);
     } else if (r <= PA) {
       s.a[q][r - 1] = w2_load<VEC>(abase[r - 1] + (int64_t)kcS[q] * alda[r - 1], moff[r - 1], moff1[r - 1]);
     } else if (r <= F) {
       s.b[q][r - 1 - PA] = w2_load<VEC>(Bp + (int64_t)krS[q] * ldb, noff[r - 1 - PA], noff1[r - 1 - PA]);
     } else {
-      s.mu[q] = mup[krS[q]];
-      s.rs[q] = rsp[krS[q]];
+      s.mu[q] = mup[MAP ? kcS[q] : krS[q]];      // (LayerNorm statistics were saved per packed row)
+      s.rs[q] = rsp[MAP ? kcS[q] : krS[q]];
     }
   };
-  auto fetch = [&](int kb, int q, Buf& s) {
+  auto fetch = [&](int kb, int q, Buf& s, const int (&ixf)[SUB]) {
 #pragma unroll
-    for (int r = 0; r < F + 2; ++r) fetch_piece(kb, q, r, s);
+    for (int r = 0; r < F + 2; ++r) fetch_piece(kb, q, r, s, ixf);
   };
-  auto prep = [&](int kb, int q, int f, Buf& s) {      // fragment f of row group q becomes an MFMA operand, in place
+  auto prep = [&](int kb, int q, int f, Buf& s, const int (&ixp)[SUB]) {      // fragment f of row group q becomes an MFMA operand, in place
     const int k = kb + 4 * q + g;
     if (f < PA) {
       const float ka = (k < k1) ? 1.f : 0.f;           // rows beyond the chunk contribute nothing (B rows are clamped to real data)
       s.a[q][f] = s.a[q][f] * ka;
       cs[f] += s.a[q][f];
     } else {
-      const float kbm = (k - shift >= 0) ? 1.f : 0.f;
+      const float kbm = MAP ? ((map_on ? ixp[q] : 0) >= 0 ? 1.f : 0.f) : ((k - shift >= 0) ? 1.f : 0.f);
       s.b[q][f - PA] = (s.b[q][f - PA] - s.mu[q]) * (s.rs[q] * kbm);
     }
   };
-  auto piece = [&](int pz, int kb, Buf& nxt, Buf& fet) {
+  auto piece = [&](int pz, int kb, Buf& nxt, Buf& fet, const int (&ixf)[SUB], const int (&ixp)[SUB], int (&ixn)[SUB]) {
     if (pz < NPF) {
-      if (!(EXP & 2)) fetch_piece(kb + (NB - 1) * SR, pz / (F + 2), pz % (F + 2), fet);
+      if (!(EXP & 2)) fetch_piece(kb + (NB - 1) * SR, pz / (F + 2), pz % (F + 2), fet, ixf);
+      if (MAP && pz % (F + 2) == 0) ixn[pz / (F + 2)] = idx_load(kb + NB * SR, pz / (F + 2));      // the index of the fetch one stage on
     } else if (!(EXP & 4)) {
-      prep(kb + SR, (pz - NPF) / F, (pz - NPF) % F, nxt);
+      prep(kb + SR, (pz - NPF) / F, (pz - NPF) % F, nxt, ixp);
     }
   };
-  auto stage = [&](int kb, Buf& cur, Buf& nxt, Buf& fet) {
+  auto stage = [&](int kb, Buf& cur, Buf& nxt, Buf& fet, const int (&ixf)[SUB], const int (&ixp)[SUB], int (&ixn)[SUB]) {
 #pragma unroll
     for (int grp = 0; grp < NG; ++grp) {
 #pragma unroll
@@ -146,7 +154,7 @@ __device__ __forceinline__ void w2_body(const WgProb& P, int mp0, int np0, int k
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int pz = 0; pz < NP; ++pz)
-        if (pz * NG / NP == grp) piece(pz, kb, nxt, fet);
+        if (pz * NG / NP == grp) piece(pz, kb, nxt, fet, ixf, ixp, ixn);
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -166,14 +174,18 @@ __device__ __forceinline__ void w2_body(const WgProb& P, int mp0, int np0, int k
       }
   } else {
 #pragma unroll
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+      for (int q = 0; q < SUB; ++q) ixr[n][q] = MAP ? idx_load(k0 + n * SR, q) : 0;
+#pragma unroll
     for (int n = 0; n < NB - 1; ++n)
 #pragma unroll
-      for (int q = 0; q < SUB; ++q) fetch(k0 + n * SR, q, bufs[n]);
+      for (int q = 0; q < SUB; ++q) fetch(k0 + n * SR, q, bufs[n], ixr[n]);
   }
 #pragma unroll
   for (int q = 0; q < SUB; ++q)
 #pragma unroll
-    for (int f = 0; f < F; ++f) prep(k0, q, f, bufs[0]);
+    for (int f = 0; f < F; ++f) prep(k0, q, f, bufs[0], ixr[0]);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int q = 0; q < SUB; ++q) {      // (VALU -> f32 MFMA needs two wait states the compiler does not see behind inline asm)
@@ -185,7 +197,7 @@ __device__ __forceinline__ void w2_body(const WgProb& P, int mp0, int np0, int k
 #pragma unroll 1
   for (int kb = k0; kb < k1; kb += NB * SR) {      // (kchunk is a multiple of NB stages)
 #pragma unroll
-    for (int n = 0; n < NB; ++n) stage(kb + n * SR, bufs[n], bufs[(n + 1) % NB], bufs[(n + NB - 1) % NB]);
+    for (int n = 0; n < NB; ++n) stage(kb + n * SR, bufs[n], bufs[(n + 1) % NB], bufs[(n + NB - 1) % NB], ixr[(n + NB - 1) % NB], ixr[(n + 1) % NB], ixr[n]);
   }
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -248,14 +260,20 @@ __device__ __forceinline__ void w2_sum_store(f32x4 (&acc)[NT][4][4], W2Lds& L, i
 }
 
 // One workgroup, one unit of shape PA x PB.
-template <int VEC, int PA, int PB, int EXP>
+template <int VEC, int PA, int PB, int EXP, bool MAP>
 __device__ __forceinline__ void w2_unit(const WgProb& P, const W2Unit& U, int wg, int wave, W2Lds& L, float* __restrict__ raw) {
   constexpr int NT = PA * PB;
   const int lane = threadIdx.x & 63;
   const int i = lane & 15, g = lane >> 4;
   const int chunk = (wg - U.wg_begin) * 4 + wave;
-  const int k0 = min(chunk * U.kchunk, P.K);
-  const int k1 = min(P.K, k0 + U.kchunk);
+  int K = P.K, kchunk = U.kchunk;
+  if (MAP && P.K_dev) {      // the rows of this step, known on the device only: the same split rule as w2_build's rows_of()
+    K = min(__builtin_amdgcn_readfirstlane(*P.K_dev), P.K);
+    constexpr int gr = (NT == 1 ? 8 : 4) * w2_ring(VEC);
+    kchunk = gr * ((((K + 4 * U.nwg - 1) / (4 * U.nwg)) + gr - 1) / gr);
+  }
+  const int k0 = min(chunk * kchunk, K);
+  const int k1 = min(K, k0 + kchunk);
   f32x4 acc[NT][4][4];
   f32x4 cs[PA];
 #pragma unroll
@@ -266,7 +284,7 @@ __device__ __forceinline__ void w2_unit(const WgProb& P, const W2Unit& U, int wg
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) acc[t][mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-  w2_body<VEC, PA, PB, EXP>(P, U.mp0, U.np0, k0, k1, acc, cs);
+  w2_body<VEC, PA, PB, EXP, MAP>(P, U.mp0, U.np0, k0, k1, acc, cs);
   float* __restrict__ slab = raw + (int64_t)wg * kW2Slab;
   const bool colsum = P.s_off >= 0 && U.np0 == 0;
   if (EXP & 8) {
@@ -292,7 +310,7 @@ __device__ __forceinline__ void w2_unit(const WgProb& P, const W2Unit& U, int wg
   }
 }
 
-template <int VEC, int EXP = 0>
+template <int VEC, int EXP = 0, bool MAP = false>
 __global__ void __launch_bounds__(256, 1) wgrad2_kernel(W2Table tb, float* __restrict__ raw) {
   __shared__ __attribute__((aligned(16))) W2Lds L;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -304,14 +322,14 @@ __global__ void __launch_bounds__(256, 1) wgrad2_kernel(W2Table tb, float* __res
   const W2Unit& U = tb.u[u];
   const WgProb& P = tb.p[U.prob];
   switch (U.pa * 8 + U.pb) {
-    case 1 * 8 + 1: w2_unit<VEC, 1, 1, EXP>(P, U, wg, wave, L, raw); break;
-    case 1 * 8 + 2: w2_unit<VEC, 1, 2, EXP>(P, U, wg, wave, L, raw); break;
-    case 1 * 8 + 3: w2_unit<VEC, 1, 3, EXP>(P, U, wg, wave, L, raw); break;
-    case 1 * 8 + 4: w2_unit<VEC, 1, 4, EXP>(P, U, wg, wave, L, raw); break;
-    case 2 * 8 + 1: w2_unit<VEC, 2, 1, EXP>(P, U, wg, wave, L, raw); break;
-    case 3 * 8 + 1: w2_unit<VEC, 3, 1, EXP>(P, U, wg, wave, L, raw); break;
-    case 4 * 8 + 1: w2_unit<VEC, 4, 1, EXP>(P, U, wg, wave, L, raw); break;
-    default: w2_unit<VEC, 2, 2, EXP>(P, U, wg, wave, L, raw); break;
+    case 1 * 8 + 1: w2_unit<VEC, 1, 1, EXP, MAP>(P, U, wg, wave, L, raw); break;
+    case 1 * 8 + 2: w2_unit<VEC, 1, 2, EXP, MAP>(P, U, wg, wave, L, raw); break;
+    case 1 * 8 + 3: w2_unit<VEC, 1, 3, EXP, MAP>(P, U, wg, wave, L, raw); break;
+    case 1 * 8 + 4: w2_unit<VEC, 1, 4, EXP, MAP>(P, U, wg, wave, L, raw); break;
+    case 2 * 8 + 1: w2_unit<VEC, 2, 1, EXP, MAP>(P, U, wg, wave, L, raw); break;
+    case 3 * 8 + 1: w2_unit<VEC, 3, 1, EXP, MAP>(P, U, wg, wave, L, raw); break;
+    case 4 * 8 + 1: w2_unit<VEC, 4, 1, EXP, MAP>(P, U, wg, wave, L, raw); break;
+    default: w2_unit<VEC, 2, 2, EXP, MAP>(P, U, wg, wave, L, raw); break;
   }
 }
 
@@ -524,6 +542,10 @@ int w2_build(const WgTable& tb, W2Table* out) {
 int launch_wgrad2(const W2Table& w, float* raw, float* rsum, hipStream_t st) {
   if (w.nu < 1 || w.total_wg < 1) return OPE_EINVAL;
   const bool v4 = w.vec == 4;
+  bool mapped = false;
+  for (int q = 0; q < w.np; ++q) mapped = mapped || w.p[q].K_dev != nullptr;
+  for (int q = 0; q < w.np && mapped; ++q)      // a live-plan table: every problem carries the device row count and something readable as its map
+    if (!w.p[q].K_dev || !w.p[q].b_map || w.p[q].b_shift != 0) return OPE_EINVAL;
   if (g_kprof_on) {
     double fl = 0;
     for (int q = 0; q < w.np; ++q) fl += 2.0 * w.p[q].M * (double)w.p[q].N * w.p[q].K;
@@ -531,7 +553,7 @@ int launch_wgrad2(const W2Table& w, float* raw, float* rsum, hipStream_t st) {
   }
 #ifdef OPE_EXPERIMENTS
   static const int exp_env = getenv("OPE_W2_EXP") ? atoi(getenv("OPE_W2_EXP")) : 0;
-  if (exp_env && v4) {
+  if (exp_env && v4 && !mapped) {
     static bool warned = false;
     if (!warned) { fprintf(stderr, "libope: OPE_W2_EXP=%d -- a timing-only variant of wgrad2_kernel runs: the gradients are WRONG\n", exp_env); warned = true; }
     switch (exp_env) {
@@ -549,12 +571,15 @@ int launch_wgrad2(const W2Table& w, float* raw, float* rsum, hipStream_t st) {
     }
   } else
 #endif
-  if (v4)
+  if (mapped) {
+    if (v4) OPE_LAUNCH((wgrad2_kernel<4, 0, true>), dim3(w.total_wg), dim3(256), 0, st, w, raw);
+    else OPE_LAUNCH((wgrad2_kernel<2, 0, true>), dim3(w.total_wg), dim3(256), 0, st, w, raw);
+  } else if (v4)
     OPE_LAUNCH((wgrad2_kernel<4>), dim3(w.total_wg), dim3(256), 0, st, w, raw);
   else
     OPE_LAUNCH((wgrad2_kernel<2>), dim3(w.total_wg), dim3(256), 0, st, w, raw);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
-  note_launch("wgrad2", v4 ? 4 : 2);
+  note_launch(mapped ? "wgrad2_live" : "wgrad2", v4 ? 4 : 2);
   kprof_work(0.0, 4.0 * (double)w.total_wg * kW2Slab);
   OPE_LAUNCH(w2_reduce_kernel, dim3((w.red_blocks + kRedRows - 1) / kRedRows, w.nu), dim3(512), 0, st, w, raw, rsum);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;

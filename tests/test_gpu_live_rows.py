@@ -1,0 +1,337 @@
+"""-m gpu: live rows (ope_qmix_cfg.live_rows, off-policy_amd/csrc/ope_live.hip).
+
+The reference pads every sampled episode to episode_length steps and multiplies the Bellman error of every (t, b) with
+dones_env[t-1, b] = 1 by zero (offpolicy/algorithms/qmix/qmix.py:161-166; normaliser :184-186, priorities :177-181, Q_tot :198). The
+engine finds those rows on the device at the start of every step and runs its kernels on the packed remainder. Checked here:
+  * the plan kernel against a numpy restatement, on monotone, non-monotone, all-dead, never-ending and tied patterns;
+  * a step on live rows against the SAME step on every padded row (same trainer state, same batch) -- with the workspace poisoned with
+    NaN in between, so any read of a row the live step did not write shows --, for every option the chain kernels carry;
+  * the reference's own fixtures, with the live path pinned;
+  * several steps on changing batches (stale rows of earlier steps in the workspace).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, sub
+from gpu_util import build_from_fixture, batch_from
+
+pytestmark = pytest.mark.gpu
+LIVE_LAUNCHES = ("live_plan", "trunk_fwd4_live<", "mixer_hyp_live<", "gru_fwd4_live<", "qchain", "gru_bwd4_live<", "trunk_bwd4_live", "wgrad2_live<")
+
+
+def plan_reference(dones_env, N):
+    """numpy restatement of live_plan_kernel (LivePlan, ope_common.h). dones_env: [T, B]."""
+    T, B = dones_env.shape
+    lens = np.ones(B, np.int64)
+    for b in range(B):
+        nz = np.nonzero(dones_env[:, b] != 1.0)[0]
+        lens[b] = 1 if len(nz) == 0 else nz[-1] + 2
+    perm = sorted(range(B), key=lambda b: (-lens[b], b))
+    inv = np.empty(B, np.int64)
+    inv[perm] = np.arange(B)
+    ls = lens[perm]
+    nn = np.array([(ls > t).sum() for t in range(T + 2)], np.int64)
+    cum = np.concatenate(([0], np.cumsum(nn)))[:T + 2]
+    RL, R1L, TBL = N * cum[T + 1], N * cum[T], cum[T]
+    srcrow = -np.ones(RL, np.int64)
+    prevrow = -np.ones(RL, np.int64)
+    for t in range(T + 1):
+        for a in range(N):
+            for b in range(B):
+                if t < lens[b]:
+                    j = inv[b]
+                    p = N * cum[t] + a * nn[t] + j
+                    srcrow[p] = (t * N + a) * B + b
+                    prevrow[p] = N * cum[t - 1] + a * nn[t - 1] + j if t > 0 else -1
+    tbrec = np.zeros((TBL, 8), np.int64)
+    tbsrc = np.zeros(TBL, np.int64)
+    for t in range(T):
+        for b in range(B):
+            if t < lens[b]:
+                j = inv[b]
+                q = cum[t] + j
+                tbrec[q] = [t, b, N * cum[t] + j, nn[t], N * cum[t + 1] + j, nn[t + 1], int(j < nn[t + 1]), j]
+                tbsrc[q] = t * B + b
+    return dict(hdr=np.array([RL, R1L, TBL, ls[0]]), len=ls, perm=np.array(perm), cum=cum, nn=nn, srcrow=srcrow, prevrow=prevrow, tbrec=tbrec, tbsrc=tbsrc)
+
+
+def _patterns(T, B, rng):
+    t = np.arange(T)[:, None]
+    L = rng.randint(1, T + 1, size=B)
+    mono = (t >= (L[None, :] - 1)).astype(np.float32)
+    out = {"monotone": mono, "all_dead": np.ones((T, B), np.float32), "never_ends": np.zeros((T, B), np.float32)}
+    tied = mono.copy()
+    tied[:, 1::2] = tied[:, :1]                      # equal lengths: the ranking must keep batch order among them
+    out["ties"] = tied
+    holes = mono.copy()                              # flags that go back to 0 after a 1, fractional flags (the mask is 1 - dones_env)
+    holes[rng.randint(0, T, size=B), np.arange(B)] = 0.0
+    holes[rng.randint(0, T, size=B), np.arange(B)] = 0.5
+    out["holes"] = holes
+    return out
+
+
+@pytest.mark.parametrize("T,N,B", [(12, 3, 7), (150, 8, 32), (5, 2, 1), (60, 3, 200)])
+def test_plan_kernel_matches_numpy(T, N, B):
+    from offpolicy_amd import _lib
+    cfg = _lib.QmixCfg()
+    cfg.dims = _lib.Dims(N, 6, 64, 48, T, 1, 0)
+    cfg.batch, cfg.use_double_q, cfg.gamma = B, 1, 0.99
+    need = _lib.lib.ope_qmix_workspace_bytes(C.byref(cfg))
+    assert need > 0
+    ws = torch.empty(int(need), dtype=torch.uint8, device="cuda")
+    ws.fill_(0xFF)
+    _lib.check(_lib.lib.ope_qmix_workspace_init(C.byref(cfg), _lib.ptr(ws), ws.numel(), _lib.current_stream()), "init")
+    n = C.c_int64(0)
+    off = _lib.lib.ope_qmix_workspace_find(C.byref(cfg), b"live_plan", C.byref(n))
+    assert off >= 0
+    plan = ws[off:off + 4 * n.value].view(torch.int32)
+    steps = 0
+    for name, de in _patterns(T, B, np.random.RandomState(T + B)).items():
+        d = torch.from_numpy(de).cuda().contiguous()
+        _lib.check(_lib.lib.ope_qmix_live_plan(C.byref(cfg), _lib.ptr(d), _lib.ptr(ws), ws.numel(), _lib.current_stream()), "plan")
+        steps += 1
+        torch.cuda.synchronize()
+        got = plan.cpu().numpy().astype(np.int64)
+        ref = plan_reference(de, N)
+        r4 = lambda x: (x + 3) & ~3
+        o = 16
+        np.testing.assert_array_equal(got[:4], ref["hdr"], err_msg=name)
+        np.testing.assert_array_equal(got[o:o + B], ref["len"], err_msg=name); o += r4(B)
+        np.testing.assert_array_equal(got[o:o + B], ref["perm"], err_msg=name); o += r4(B)
+        np.testing.assert_array_equal(got[o:o + T + 2], ref["cum"], err_msg=name); o += r4(T + 2)
+        np.testing.assert_array_equal(got[o:o + T + 2], ref["nn"], err_msg=name); o += r4(T + 2)
+        RL, R1L, TBL = ref["hdr"][:3]
+        np.testing.assert_array_equal(got[o:o + 8 * TBL].reshape(TBL, 8), ref["tbrec"], err_msg=name); o += 8 * T * B
+        np.testing.assert_array_equal(got[o:o + TBL], ref["tbsrc"], err_msg=name); o += r4(T * B)
+        np.testing.assert_array_equal(got[o:o + RL], ref["srcrow"], err_msg=name); o += r4((T + 1) * N * B)
+        np.testing.assert_array_equal(got[o:o + RL], ref["prevrow"], err_msg=name)
+        acc = plan[8:16].view(torch.int64).cpu().numpy()
+        assert acc[3] == steps and acc[0] >= RL
+        # the zero-filled regions
+        for reg in (b"err_abs", b"loss_part"):
+            m = C.c_int64(0)
+            ro = _lib.lib.ope_qmix_workspace_find(C.byref(cfg), reg, C.byref(m))
+            assert not ws[ro:ro + 4 * m.value].view(torch.float32).any()
+
+
+# ---- a step on live rows against the same step on every padded row --------------------------------------------------------------
+def _make(dims, args, B, seed, vdn=False, dones=None, avail="bernoulli"):
+    from offpolicy_amd.utils.synth import synth_episodes, policy_info_for, as_policy_dicts
+    from offpolicy_amd.utils.rec_buffer import RecReplayBuffer
+    from offpolicy_amd.algorithms.qmix.algorithm.QMixPolicy import QMixPolicy
+    from offpolicy_amd.algorithms.qmix.qmix import QMix
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    dev = torch.device("cuda:0")
+    pinfo = policy_info_for(dims)
+    policy = QMixPolicy({"args": args, "device": dev}, pinfo["policy_0"])
+    trainer = QMix(args, dims.n_agents, {"policy_0": policy}, lambda a: "policy_0", device=dev, episode_length=dims.episode_length, vdn=vdn)
+    # a target net that differs from the live one, as after some training
+    trainer.theta_tgt.add_(0.01 * torch.randn_like(trainer.theta_tgt))
+    n_ep = 3 * B
+    buf = RecReplayBuffer(pinfo, {"policy_0": list(range(dims.n_agents))}, n_ep, dims.episode_length, True, True, device=dev)
+    ep = synth_episodes(np.random.RandomState(seed), n_ep, dims, avail=avail)
+    if dones is not None:
+        ep["dones_env"] = dones(ep["dones_env"])
+        ep["dones"] = np.repeat(ep["dones_env"][:, :, None, :], dims.n_agents, axis=2)
+    d = as_policy_dicts(ep)
+    buf.insert(n_ep, d["obs"], d["share_obs"], d["acts"], d["rewards"], d["dones"], d["dones_env"], d["avail_acts"])
+    return policy, trainer, buf
+
+
+def _poison(trainer, B):
+    from offpolicy_amd import _lib
+    ws = trainer._ws[B]
+    ws.fill_(0xFF)                      # 0xFFFFFFFF is a NaN as float32 and -1 as an index
+    cfg = trainer._cfg(B)
+    _lib.check(_lib.lib.ope_qmix_workspace_init(C.byref(cfg), _lib.ptr(ws), ws.numel(), _lib.current_stream()), "ope_qmix_workspace_init")
+
+
+def _one(trainer, batch, live):
+    from offpolicy_amd import _lib
+    trainer.tune["live_rows"] = 2 if live else 1
+    info, prio, _ = trainer.train_policy_on_batch(batch)
+    launched = ",".join(_lib.last_launches())
+    torch.cuda.synchronize()
+    return {k: float(v) for k, v in info.items()}, (None if prio is None else np.asarray(prio.cpu() if torch.is_tensor(prio) else prio).copy()), \
+        trainer.grad[:trainer.numel + 4].clone(), launched
+
+
+def _snapshot(trainer):
+    o = trainer.optimizer
+    return trainer.theta.clone(), trainer.theta_tgt.clone(), o.exp_avg.clone(), o.exp_avg_sq.clone(), o.step_count
+
+
+def _restore(trainer, s):
+    o = trainer.optimizer
+    trainer.theta.copy_(s[0]); trainer.theta_tgt.copy_(s[1]); o.exp_avg.copy_(s[2]); o.exp_avg_sq.copy_(s[3]); o.step_count = s[4]
+
+
+def _compare(a, b, trainer, tag, gtol=2e-5):
+    """(info, priorities, gradient) of two runs of the same step: same row-wise arithmetic, different summation order over rows."""
+    for k in a[0]:
+        np.testing.assert_allclose(b[0][k], a[0][k], rtol=2e-5, atol=1e-7, err_msg="%s %s" % (tag, k))
+    if a[1] is not None:
+        np.testing.assert_allclose(b[1], a[1], rtol=1e-5, atol=1e-7, err_msg=tag + " priorities")
+    ga, gb = a[2].cpu().numpy(), b[2].cpu().numpy()
+    assert np.isfinite(gb).all(), tag
+    assert ga[trainer.numel + 1] == gb[trainer.numel + 1], (tag, "mask count")
+    worst = 0.0
+    for name, p in _segments(trainer):
+        x, y = ga[p], gb[p]
+        scale = max(np.abs(x).max(), 1e-12)
+        err = np.abs(x - y).max() / scale
+        worst = max(worst, err)
+        assert err <= gtol, (tag, name, err)
+    return worst
+
+
+def _segments(trainer):
+    pol = trainer.policies["policy_0"]
+    for name, (shape, off) in pol.q_network.spec().items():
+        yield "agent/" + name, slice(off, off + int(np.prod(shape)))
+    if not trainer.vdn:
+        for name, (shape, off) in trainer.mixer.spec().items():
+            yield "mixer/" + name, slice(off, off + int(np.prod(shape)))
+
+
+def _holes(de):
+    de = de.copy()
+    rng = np.random.RandomState(5)
+    T, E = de.shape[:2]
+    de[rng.randint(0, T, size=E), np.arange(E), 0] = 0.0
+    de[:, 0] = 1.0           # an episode with no live step but the first
+    de[:, 1] = 0.0           # one that never ends: all T + 1 agent rows
+    return de
+
+
+CONFIGS = {
+    # name: (dims, B, args overrides, vdn, dones transform)
+    "3m": (("3m",), 8, {}, False, None),
+    "3m_vdn": (("3m",), 8, {}, True, None),
+    "3m_huber_per": (("3m",), 8, dict(use_huber_loss=True, huber_delta=0.5, use_per=True), False, None),
+    "3m_nodouble": (("3m",), 6, dict(use_double_q=False), False, None),
+    "3m_hyper1": (("3m",), 8, dict(hypernet_layers=1), False, None),
+    "3m_holes": (("3m",), 9, {}, False, _holes),
+    "3m_nofn": (("3m",), 5, dict(use_feature_normalization=False), False, None),
+    "d124_n5": ((5, 6, 124, 100, 20), 7, {}, False, None),
+    "d188_a20": ((3, 20, 188, 40, 9), 5, {}, False, _holes),             # two head tiles
+    "d370": ((4, 7, 370, 322, 11), 6, {}, False, None),                  # the 24-chunk trunk, 8-byte rows; S % 4 != 0: 8-byte state rows
+    "d252_n10": ((10, 9, 252, 216, 7), 4, {}, False, _holes),            # two agents per wave of the chain kernel (pinned chain_path = 2)
+}
+
+
+def _dims_of(spec):
+    from offpolicy_amd.utils.synth import DIMS, EnvDims
+    return DIMS[spec[0]] if len(spec) == 1 else EnvDims("custom", *spec)
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_live_step_equals_padded_step(name):
+    from offpolicy_amd.config import default_args
+    spec, B, over, vdn, dones = CONFIGS[name]
+    dims = _dims_of(spec)
+    args = default_args(**over)
+    policy, trainer, buf = _make(dims, args, B, seed=3, vdn=vdn, dones=dones)
+    trainer.tune.update(trunk_path=4, chain_path=2, wgrad_path=2, scan_family=4)
+    snap = _snapshot(trainer)
+    rng = np.random.RandomState(11)
+    worst = 0.0
+    for step in range(3):                # changing batches: rows of earlier steps stay in the workspace
+        inds = rng.choice(len(buf), B, replace=False)
+        w = rng.uniform(0.2, 1.0, size=B).astype(np.float32) if args.use_per else None
+        batch = batch_from(buf, inds, w)
+        s0 = _snapshot(trainer)
+        ref = _one(trainer, batch, live=False)
+        assert "_live" not in ref[3] and "live_plan" not in ref[3], ref[3]
+        s1 = _snapshot(trainer)
+        _restore(trainer, s0)
+        _poison(trainer, B)
+        got = _one(trainer, batch, live=True)
+        for want in LIVE_LAUNCHES:
+            assert want in got[3] or (vdn and want.startswith("mixer_hyp")), (want, got[3])      # (VDN: no hyper-networks)
+        assert "_live" in [x for x in got[3].split(",") if x.startswith("qchain")][0], got[3]
+        worst = max(worst, _compare(ref, got, trainer, "%s step %d" % (name, step)))
+        # the optimizer saw the same gradient: parameters agree too
+        np.testing.assert_allclose(trainer.theta.cpu().numpy(), s1[0].cpu().numpy(), rtol=0, atol=2e-6)
+        trainer.soft_target_updates()
+    from golden_util import record_errors
+    record_errors("live_vs_padded:" + name, {"worst_grad": float(worst)})
+    _restore(trainer, snap)
+
+
+def test_full_length_episodes_take_every_row():
+    """Episodes that never end: the plan is the identity ranking, every one of the (T + 1) N B rows is live."""
+    from offpolicy_amd.config import default_args
+    from offpolicy_amd.utils.synth import DIMS
+    dims, B = DIMS["3m"], 8
+    policy, trainer, buf = _make(dims, default_args(), B, seed=4, dones=lambda de: np.zeros_like(de))
+    trainer.tune.update(trunk_path=4, chain_path=2, wgrad_path=2, scan_family=4)
+    batch = batch_from(buf, np.arange(B))
+    s0 = _snapshot(trainer)
+    ref = _one(trainer, batch, live=False)
+    _restore(trainer, s0)
+    _poison(trainer, B)
+    got = _one(trainer, batch, live=True)
+    _compare(ref, got, trainer, "full length")
+    hdr = trainer.workspace_view(B, "live_plan").view(torch.int32)[:4].cpu().numpy()
+    T, N = dims.episode_length, dims.n_agents
+    assert list(hdr) == [(T + 1) * N * B, T * N * B, T * B, T + 1]
+
+
+def test_live_rows_that_cannot_run_are_an_error_or_a_fallback():
+    """live_rows = 2 on a configuration the packed kernels do not take (D = 12: no trunk_fwd4) fails before the first launch; "by shape"
+    (0) quietly computes every padded row there."""
+    from offpolicy_amd import _lib
+    g = load_golden("qmix_tiny")
+    dims, buf, policy, trainer = build_from_fixture(g)
+    batch = batch_from(buf, g["inds"])
+    trainer.tune["live_rows"] = 2
+    with pytest.raises(_lib.OpeError):
+        trainer.train_policy_on_batch(batch)
+    assert _lib.last_launches() == []
+    trainer.tune["live_rows"] = 0
+    info, _, _ = trainer.train_policy_on_batch(batch)
+    assert "live_plan" not in _lib.last_launches()
+    np.testing.assert_allclose(float(info["loss"]), g["loss"][0], rtol=1e-4)
+
+
+# ---- the reference's own fixtures on the live path ------------------------------------------------------------------------------------
+REF_CASES = ["qmix_3m_katA", "qmix_gall_3m", "qmix_var_d124", "qmix_var_d188", "qmix_var_d252", "qmix_var_d370", "qmix_var_nofn_d252"]
+
+
+@pytest.mark.parametrize("name", REF_CASES)
+def test_reference_fixtures_on_live_rows(name):
+    from offpolicy_amd import _lib
+    from test_gpu_qmix import _flat_named, RTOL, GRAD_TOL
+    g = load_golden(name)
+    dims, buf, policy, trainer = build_from_fixture(g)
+    trainer.tune.update(trunk_path=4, chain_path=2, wgrad_path=2, scan_family=4, live_rows=2)
+    soft = bool(g["hp_soft_update"]) if "hp_soft_update" in g else True
+    hard_after = set(int(x) for x in g["hard_update_after"]) if "hard_update_after" in g else set()
+    batch = batch_from(buf, g["inds"])
+    for s in range(len(g["loss"])):
+        info, _, _ = trainer.train_policy_on_batch(batch)
+        launched = ",".join(_lib.last_launches())
+        for want in LIVE_LAUNCHES:
+            assert want in launched, (want, launched)
+        if s == 0:
+            cnt = float(trainer.grad[trainer.numel + 1])
+            coef = min(1.0, float(g["hp_maxnorm"]) / (float(g["grad_norm"][0]) + 1e-6))
+            got = _flat_named(trainer, trainer.grad[:trainer.numel] * (coef / cnt))
+            for k, ref in sub(g, "grad0/").items():
+                np.testing.assert_allclose(got[k], ref, rtol=0, atol=GRAD_TOL * max(np.abs(ref).max(), 1e-6), err_msg="grad " + k)
+        if soft:
+            trainer.soft_target_updates()
+        elif s in hard_after:
+            trainer.hard_target_updates()
+        np.testing.assert_allclose(float(info["loss"]), g["loss"][s], rtol=RTOL)
+        np.testing.assert_allclose(float(info["grad_norm"]), g["grad_norm"][s], rtol=RTOL)
+        np.testing.assert_allclose(float(info["Q_tot"]), g["Q_tot"][s], rtol=RTOL, atol=1e-6)
+    live = _flat_named(trainer, trainer.theta)
+    for grp, key in (("final_agent/", "agent/"), ("final_mixer/", "mixer/")):
+        for k, ref in sub(g, grp).items():
+            np.testing.assert_allclose(live[key + k], ref, rtol=0, atol=3e-5, err_msg=grp + k)

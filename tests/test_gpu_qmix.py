@@ -556,6 +556,10 @@ def test_full_size_3s5z_matches_oracle_one_step(workload, nb, chain):
     opt = trainer.optimizer
     snap = (trainer.theta.clone(), trainer.theta_tgt.clone())
     trainer.tune["chain_path"] = chain      # 2: the fused chain, 1: four launches (0: by shape -- the wide-state configuration keeps the separate kernels)
+    # every padded row (rounds 1-5's path): the decisions are read back from the workspace in the batch's own row order. The live-row path
+    # (what "by shape" picks at 3s5z since round 6) is compared with this one at the end, and with the reference's own numbers in
+    # test_gpu_fullsize_reference.py / test_gpu_live_rows.py.
+    trainer.tune["live_rows"] = 1
     trainer.tune["debug"] = 1
     trainer.train_policy_on_batch(batch)
     greedy = _gpu_greedy(trainer, nb, dims, avail_dev)
@@ -622,6 +626,20 @@ def test_full_size_3s5z_matches_oracle_one_step(workload, nb, chain):
             dg = np.abs(got[grp + k].astype(np.float64) * coef - grads[grp + k].astype(np.float64) * coef_o)
             dth = np.abs(live[grp + k].astype(np.float64) - v.numpy().astype(np.float64))
             assert (dth <= lr * dg / eps * 1.001 + 3e-7).all(), (grp + k, float((dth - lr * dg / eps).max()))
+    # (4) the same step on live rows only (round 6): same per-row arithmetic, another summation order over rows
+    if chain != 1 and trainer.vdn is False and workload == "3s5z":
+        padded = trainer.grad[:trainer.numel + 4].clone()
+        trainer.theta.copy_(snap[0]); trainer.theta_tgt.copy_(snap[1]); opt.exp_avg.zero_(); opt.exp_avg_sq.zero_(); opt.step_count = 0
+        trainer.tune["live_rows"] = 2
+        info2, _, _ = trainer.train_policy_on_batch(batch)
+        assert "qchain_live<1,1>" in _lib.last_launches() and "wgrad2_live<4>" in _lib.last_launches(), _lib.last_launches()
+        np.testing.assert_allclose(float(info2["loss"]), float(info["loss"]), rtol=1e-5)
+        np.testing.assert_allclose(float(info2["grad_norm"]), float(info["grad_norm"]), rtol=1e-5)
+        a_, b_ = padded.cpu().numpy(), trainer.grad[:trainer.numel + 4].cpu().numpy()
+        assert a_[trainer.numel + 1] == b_[trainer.numel + 1]
+        got2 = _flat_named(trainer, trainer.grad[:trainer.numel] / cnt)
+        for k, ref in got.items():
+            assert np.abs(got2[k] - ref).max() <= 2e-5 * max(np.abs(ref).max(), 1e-9), k
 
 
 def test_runner_call_sequence_with_per():
