@@ -42,11 +42,11 @@ def parse():
     ap.add_argument("--batch", type=int, default=None, help="samples per training step on ONE GPU (weak) / in total (strong); "
                     "default 32 episodes (QMIX) or 256 transitions (MADDPG)")
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
-                    help="N > 1: what `value` reports. Default weak: every GPU trains on its own B sampled episodes (per-GPU work fixed, global batch "
-                         "N x B, one gradient all-reduce per step) and `value` = batch-B steps/s over all GPUs = optimizer steps/s x N -- the units "
-                         "all ranks processed / the time, as the bench contract defines it for a path that shards. The strong-scaling number "
-                         "(ONE batch of B sharded over the N GPUs, B/N per GPU: BASELINE.json's 'batch_size=32, grads sharded over 8' read literally) "
-                         "is measured in the same run and reported beside it as `strong_scaling`. --scaling strong swaps the two.")
+                    help="N > 1: what `value` reports. Default strong (round 6; VERDICT r5 item 3): BASELINE.json's configuration read literally -- "
+                         "ONE batch of B episodes per optimizer step, sharded over the N GPUs (B/N each), one gradient all-reduce per step; `value` = "
+                         "optimizer steps/s at that fixed global batch, the same quantity as at N = 1. The weak-scaling number (every GPU trains "
+                         "on its own B episodes: global batch N x B, `value` = optimizer steps/s x N) is measured in the same run and reported "
+                         "beside it as `weak_scaling` with its global batch spelled out. --scaling weak swaps the two.")
     ap.add_argument("--episodes", type=int, default=None, help="synthetic episodes resident in the replay store; default 5000 for the QMIX "
                     "workloads (the reference default buffer_size, config.py:37: 7.5 GB at 3s5z, far beyond the 256 MiB Infinity Cache), 512 "
                     "for the recurrent MADDPG family at MMM2 size (6.5 GB)")
@@ -54,6 +54,8 @@ def parse():
                     "with (one-shot xGMI push verified against RCCL, or RCCL) and a timed 475 KB all-reduce; rank 0 prints them as one JSON line "
                     "and the job exits -- what to run first on a new multi-GPU node")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-full-length", action="store_true", help="QMIX workloads, one GPU: skip the second timed leg on a store of full-length "
+                    "episodes (`value_full_length`: the step when no row of the padded batch is dead)")
     ap.add_argument("--no-kernel-table", action="store_true", help="skip the per-kernel roofline table (10 extra untimed steps with an event "
                     "pair on every kernel launch, after the timed region)")
     ap.add_argument("--host-fill", action="store_true", help="QMIX workloads: fill the replay store from host-generated numpy episodes (the path of "
@@ -302,6 +304,28 @@ def qmix_flop_per_step(dims, batch):
     return 4 * 2 * R * agent_mac + 4 * 2 * T * batch * mixer_mac
 
 
+def qmix_flop_executed(dims, batch, rows_fwd, rows_bwd, rows_tb):
+    """The same count over the rows a step actually ran (live rows, ope_qmix_cfg.live_rows): both forward passes over `rows_fwd` agent rows,
+    the backward (2x) over `rows_bwd`, the mixers (forward of both nets + 2x backward) over `rows_tb` (t, b) rows. With every padded row
+    computed (rows_fwd = (T+1) N B, rows_bwd ~ rows_fwd, rows_tb = T B) it is qmix_flop_per_step."""
+    N, A, D, S = dims.n_agents, dims.act_dim, dims.obs_dim, dims.state_dim
+    agent_mac = D * 64 + 64 * 64 + 6 * 64 * 64 + 64 * A
+    mixer_mac = (S * 64 + 64 * N * 32) + (S * 64 + 64 * 32) + S * 32 + (S * 64 + 64) + (N * 32 + 32)
+    return 2 * 2 * rows_fwd * agent_mac + 2 * 2 * rows_bwd * agent_mac + 4 * 2 * rows_tb * mixer_mac
+
+
+def live_row_stats(trainer, batch):
+    """(mean live agent rows, mean live agent rows with t < T, mean live (t, b) rows, steps) over every step this trainer's workspace of
+    `batch` episodes has run on live rows (the plan kernel's device-side accumulators, ope.h: ope_qmix_cfg.live_rows); None if none did."""
+    try:
+        acc = trainer.workspace_view(batch, "live_plan").view(torch.int32)[8:16].view(torch.int64).cpu().numpy()
+    except KeyError:
+        return None
+    if acc[3] <= 0:
+        return None
+    return float(acc[0]) / acc[3], float(acc[1]) / acc[3], float(acc[2]) / acc[3], int(acc[3])
+
+
 def _short_kernel_name(name):
     import re
     n = name.replace("(anonymous namespace)::", "").replace("ope::", "")
@@ -318,28 +342,35 @@ def _short_kernel_name(name):
     return "".join(out).strip()[:80]
 
 
-def measured_kernel_table(one_step, n_steps=10):
+def measured_kernel_table(one_step, n_steps=10, live_ratio=None):
     """Per-kernel table of `n_steps` extra (untimed) eager steps MEASURED IN THIS RUN, on this box: every kernel launch of libope.so
     carries hipExtLaunchKernel start / stop events (ope_kernel_profile, include/ope.h: the dispatch's own duration, what rocprofv3's kernel
     trace reports) and the algorithmic work its launcher states (GEMM-shaped FLOP = 2 x MACs, LayerNorm / gates / elementwise excluded;
     bytes read + written once for the bandwidth-bound kernels). frac = work / time / peak (157.3 TFLOP/s dense f32 matrix, 8 TB/s HBM).
-    torch's own kernels (noise generation, small copies) are not libope launches and are not listed."""
+    torch's own kernels (noise generation, small copies) are not libope launches and are not listed. `live_ratio()` -> (live agent rows /
+    (T+1) N B, those with t < T / T N B, live (t, b) rows / T B) of the steps measured here: a launch on live rows (ope_qmix_cfg.live_rows)
+    ran that share of the padded batch its launcher stated the work for, and its FLOP are scaled accordingly (EXECUTED work)."""
     from offpolicy_amd import _lib
     torch.cuda.synchronize()
     _lib.kernel_profile(True, 16384)
     for _ in range(n_steps):
         one_step(None)
     torch.cuda.synchronize()
-    rows = _lib.kernel_profile_read()
+    rows = _lib.kernel_profile_read(with_rows=True)
     _lib.kernel_profile(False)
+    ratio = live_ratio() if live_ratio is not None else None
     table, tot_us, tot_flop = [], 0.0, 0.0
-    for name, calls, total_ms, mn, mx, flop, nbytes in rows:
+    for name, calls, total_ms, mn, mx, flop, nbytes, kind in rows:
+        if kind and ratio:
+            flop *= ratio[kind - 1]
         avg_us = 1e3 * total_ms / calls
         e = {"kernel": _short_kernel_name(name), "launches_per_step": round(calls / float(n_steps), 2), "avg_us": round(avg_us, 2),
              "us_per_step": round(1e3 * total_ms / n_steps, 2)}
         if flop > 0:
             tf = flop / (total_ms * 1e-3) / 1e12
             e.update(bound="mfma", flop_per_launch=int(flop / calls), tflops=round(tf, 2), frac=round(tf / F32_MFMA_PEAK_TFLOPS, 4))
+            if kind and ratio:
+                e["rows_live_frac"] = round(ratio[kind - 1], 4)
         elif nbytes > 0:
             gbs = nbytes / (total_ms * 1e-3) / 1e9
             e.update(bound="hbm", bytes_per_launch=int(nbytes / calls), gbs=round(gbs, 1), frac=round(gbs / HBM_PEAK_GBS, 4))
@@ -391,8 +422,8 @@ def scaling_legs(a, batch, world):
     if world == 1:
         return [("weak", batch, batch)]
     assert batch % world == 0, "--batch must be a multiple of --gpus for the strong-scaling leg"
-    legs = [("weak", batch, batch * world), ("strong", batch // world, batch)]
-    return legs[::-1] if a.scaling == "strong" else legs
+    legs = [("strong", batch // world, batch), ("weak", batch, batch * world)]
+    return legs[::-1] if a.scaling == "weak" else legs
 
 
 def allreduce_name():
@@ -509,6 +540,9 @@ def main():
             inds = opdist.shard_indices(np.random.choice(len(buf), global_batch), rank, world)
             if G["graphed"] is not None:
                 return G["graphed"](inds)
+            # (sample_inds(inds, live_for=trainer) would build the step's live-row plan inside the gather launch: measured, the riders make
+            # the gather 7 us longer -- their chain of dependent round trips queues behind the copy's traffic -- for an 8.4 us plan launch
+            # saved, and the gather's own roofline line would carry them: not used here)
             s = pbuf.sample_inds(inds)                       # ope_store_gather, current stream
             batch = tuple({"policy_0": x} for x in s) + (None, None)
             info, _, _ = trainer.train_policy_on_batch(batch)
@@ -537,13 +571,51 @@ def main():
         bracket_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev[:20]]))
         gather_ms = float(np.mean(kernel_ms)) if kernel_ms else bracket_ms
         loss = float(info["loss"])
-        assert np.isfinite(loss) or os.environ.get("OPE_W2_EXP") or os.environ.get("OPE_T4_EXP") or os.environ.get("OPE_FIN_EXP"), "training diverged"
+        # (timing-only kernel variants exist in libope_exp.so alone -- build.py --experiments, loaded through OPE_LIB_PATH --: only THAT library
+        # may produce a non-finite loss without failing the run, and its lines are marked invalid below)
+        experiments_lib = "libope_exp" in os.path.basename(_lib.LIB_PATH)
+        assert np.isfinite(loss) or experiments_lib, "training diverged"
         per_kernel = None
         if world == 1 and graphed is None and not a.no_kernel_table:
-            per_kernel = measured_kernel_table(one_step)
+            T_, NB_ = dims.episode_length, dims.n_agents * local_batch
+            seen = live_row_stats(trainer, local_batch)
+
+            def live_ratio():      # of the table's own steps: the accumulators' increase since `seen`
+                now = live_row_stats(trainer, local_batch)
+                if now is None or (seen is not None and now[3] <= seen[3]):
+                    return None
+                n0 = seen[3] if seen else 0
+                d = [(now[i] * now[3] - (seen[i] * seen[3] if seen else 0.0)) / (now[3] - n0) for i in range(3)]
+                return d[0] / ((T_ + 1) * NB_), d[1] / (T_ * NB_), d[2] / (T_ * local_batch)
+            per_kernel = measured_kernel_table(one_step, live_ratio=live_ratio)
+        live = live_row_stats(trainer, local_batch)       # rows the steps of this leg really ran (None: every padded row)
         results.append(dict(leg=leg, local_batch=local_batch, global_batch=global_batch, elapsed=elapsed, gather_ms=gather_ms, loss=loss,
                             graphed=graphed is not None, bracket_ms=bracket_ms, n_kernel_ms=len(kernel_ms), windows=windows, per_kernel=per_kernel,
-                            lazy_obs=bool(pbuf.lazy_obs)))
+                            lazy_obs=bool(pbuf.lazy_obs), live=live))
+    # The same command on a store whose episodes all run the full T steps (dones_env = 1 at the last step only): nothing to skip, every row
+    # of the padded batch is live -- what the step costs when the data offers no dead rows (guardrail ii). After every
+    # other measurement: the store's flags are overwritten.
+    full = None
+    if world == 1 and not a.no_full_length:
+        pbuf.dones_env.zero_()
+        pbuf.dones_env[:, -1] = 1.0
+        if getattr(pbuf, "dones", None) is not None:
+            pbuf.dones.zero_()
+            pbuf.dones[:, -1] = 1.0
+        torch.cuda.synchronize()
+        lb = results[0]["local_batch"]
+        before = live_row_stats(trainer, lb)
+        w_full, _ = timed_windows(one_step, a.steps, max(4, a.warmup // 2), world, dev, max(1, min(a.repeats, 3)))
+        after = live_row_stats(trainer, lb)
+        rows = None
+        if after is not None:
+            n0 = before[3] if before else 0
+            tot0 = before[0] * before[3] if before else 0.0
+            rows = (after[0] * after[3] - tot0) / max(after[3] - n0, 1)
+        full = dict(elapsed=median_window(w_full), windows=w_full, rows=rows)
+        if results[0]["per_kernel"] is not None:      # the same in-run table for this leg: what each packed-row kernel costs when every row is live
+            pk_full = measured_kernel_table(one_step)
+            full["kernels"] = {k["kernel"]: k["avg_us"] for k in pk_full["kernels"]}
 
     if rank == 0:
         r0 = results[0]
@@ -557,7 +629,9 @@ def main():
         value = steps_per_s * (r0["global_batch"] / float(a.batch))
         store_gb = a.episodes * ep_bytes / 1e9
         out = {
-            "metric": "training steps/sec (batch=%d) QMIX-RNN %s" % (a.batch, a.workload),
+            "metric": "training steps/sec (batch=%d) QMIX-RNN %s" % (a.batch, a.workload) + (
+                "" if world == 1 else (" -- one batch of %d sharded over %d GPUs" % (a.batch, world) if r0["leg"] == "strong" else
+                                       " -- WEAK scaling: %d GPUs x %d episodes, global batch %d, value = optimizer steps/s x %d" % (world, a.batch, r0["global_batch"], world))),
             "value": round(value, 3), "unit": "training steps/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(1e3 * r0["elapsed"] / a.steps, 4), "higher_is_better": True, "scaling": r0["leg"],
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -589,18 +663,41 @@ def main():
                                                "the launch: the kernel plus two command-processor boundaries (what round 1 reported)",
                          "traffic_source": "profiles/gather_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)"},
         }
-        flop = qmix_flop_per_step(dims, r0["local_batch"])
+        T1NB = (dims.episode_length + 1) * dims.n_agents * r0["local_batch"]
+        lv = r0["live"]
+        # FLOP the step EXECUTED: on live rows the count follows the rows the plan kernel reported (mean over the run's steps), so skipping
+        # dead rows cannot inflate the fraction; with every padded row computed it is the closed form of SURVEY.md 8(d)
+        flop_padded = qmix_flop_per_step(dims, r0["local_batch"])
+        flop = qmix_flop_executed(dims, r0["local_batch"], lv[0], lv[1], lv[2]) if lv else flop_padded
         tfs = flop / (r0["elapsed"] / a.steps) / 1e12
+        out["rows_live_frac"] = round(lv[0] / T1NB, 4) if lv else 1.0
+        out["config"]["rows"] = ("live rows only: the %.1f %% of the padded batch's (T+1) N B = %d agent rows before each sampled episode's "
+                                 "termination, found on the device from dones_env at the start of every step (mean over %d steps); every "
+                                 "other row is multiplied by a zero mask in the reference's loss (qmix.py:161-166,184-198)" % (
+                                     100.0 * lv[0] / T1NB, T1NB, lv[3])) if lv else "every padded row"
+        if full is not None:
+            out["value_full_length"] = round(a.steps / full["elapsed"], 3)
+            out["full_length"] = {"what": "the same command on the same store with every episode running the full T steps (dones_env = 1 at the last step "
+                                          "only): no dead rows to skip", "ms_per_step": round(1e3 * full["elapsed"] / a.steps, 4),
+                                  "rows_live_frac": round(full["rows"] / T1NB, 4) if full["rows"] else 1.0,
+                                  "ms_per_step_windows": [round(1e3 * w / a.steps, 4) for w in full["windows"]],
+                                  "kernel_avg_us": full.get("kernels")}
         out["roofline_step"] = {
             "bound": "mfma", "what": "the whole training step of one GPU against the dense f32 matrix peak (the step's GEMM-shaped work is f32 "
                                      "MFMA 16x16x4; there is no xf32 / TF32 on gfx950 and bf16 would break the parity contract)",
-            "flop_per_step": int(flop), "flop_formula": "SURVEY.md 8(d): 4*[2*R*(D*64+64*64+6*64*64+64*A)] + 4*[2*T*B*mixerMAC], R=(T+1)*N*B",
+            "flop_per_step": int(flop), "flop_per_step_padded": int(flop_padded),
+            "flop_formula": "SURVEY.md 8(d): 4*[2*R*(D*64+64*64+6*64*64+64*A)] + 4*[2*T*B*mixerMAC], R=(T+1)*N*B -- evaluated on the rows the step "
+                            "EXECUTED (R = mean live agent rows of the run, T*B = mean live (t, b) rows) when it ran on live rows",
             "achieved": round(tfs, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tfs / F32_MFMA_PEAK_TFLOPS, 4),
             "per_kernel": r0["per_kernel"]}
+        if "libope_exp" in os.path.basename(_lib.LIB_PATH):
+            out["invalid"] = "measured on libope_exp.so (timing-only kernel variants may have run: results are not those of the shipped library)"
         if len(results) > 1:
             r1 = results[1]
             sps1 = a.steps / r1["elapsed"]
             out["%s_scaling" % r1["leg"]] = {
+                "what": ("every GPU trains on its own %d episodes: global batch %d, value = optimizer steps/s x %d" % (a.batch, r1["global_batch"], world))
+                        if r1["leg"] == "weak" else "one batch of %d episodes sharded over the %d GPUs" % (a.batch, world),
                 "value": round(sps1 * (r1["global_batch"] / float(a.batch)), 3), "unit": "batch-%d training steps/sec (episodes/s / %d)" % (a.batch, a.batch),
                 "batch_per_gpu": r1["local_batch"], "global_batch": r1["global_batch"], "ms_per_step": round(1e3 * r1["elapsed"] / a.steps, 4),
                 "optimizer_steps_per_sec": round(sps1, 3), "steps": a.steps, "warmup": a.warmup}

@@ -265,7 +265,8 @@ typedef struct ope_qmix_cfg {
                          *  form cannot plan (more than 40 units, 4-byte aligned operands) runs form 1 under "by shape" and fails
                          *  BEFORE the step's first launch under wgrad_path = 2                                       */
   int32_t live_rows;    /* rows of the padded batch that are computed: 0 = by shape; 1 = every row (T steps of every episode, as the
-                         *  reference does); 2 = the LIVE rows only. The reference pads every sampled episode to episode_length steps and
+                         *  reference does); 2 = the LIVE rows only; 3 = as 2, and the plan region already holds this batch's plan
+                         *  (ope_store_gather_attach_live below: built by the gather launch the batch came from). The reference pads every sampled episode to episode_length steps and
                          *  multiplies the Bellman error of every (t, b) with dones_env[t-1, b] = 1 by 1 - bad_transitions_mask = 0
                          *  (qmix.py:161-166), leaves it out of the loss normaliser (:184-186), the priorities (:177-181) and Q_tot's mean
                          *  (:198): such rows contribute exactly nothing. With live rows a small kernel finds, ON THE DEVICE at the start
@@ -308,7 +309,9 @@ void ope_set_scan_kernel(int family, int waves_per_row);
  * kernel trace reports), up to max_launches (<= 16384) launches; ope_kernel_profile_read waits for them, writes one line per distinct
  * kernel, in order of first launch, "demangled name \t calls \t total_ms \t min_ms \t max_ms \t flop \t bytes \n" into out[cap]
  * (NUL-terminated; flop / bytes = the ALGORITHMIC work of those launches as their launchers state it: GEMM-shaped FLOP = 2 x MACs with
- * LayerNorm / gates / elementwise excluded, bytes for the bandwidth-bound kernels; 0 where none is stated), returns
+ * LayerNorm / gates / elementwise excluded, bytes for the bandwidth-bound kernels; 0 where none is stated -- an 8th column " \t rows" follows
+ * the bytes: 0, or for a launch on the LIVE rows of a step (ope_qmix_cfg.live_rows) which of the plan's counts scales the stated work, which is
+ * that of the padded batch: 1 live agent rows / (T+1) N B, 2 those with t < T / T N B, 3 live (t, b) rows / T B), returns
  * the number of distinct kernels and clears the ring. ope_kernel_profile(0, 0) turns it off. Eager launches only (not while a HIP graph
  * is being captured). SURVEY.md section 8(d). */
 int ope_kernel_profile(int32_t enable, int32_t max_launches);
@@ -349,6 +352,24 @@ int ope_qmix_obs_ref_ok(const ope_qmix_cfg* cfg);
  * workspace of `cfg` holds no plan region (MLP nets, phases, batch > 256, episode_length > 1022). Diagnostics / tests / bench.py's
  * executed-row accounting; training never needs to call it. */
 int ope_qmix_live_rows_ok(const ope_qmix_cfg* cfg);
+/* The plan built INSIDE the gather launch that produces the batch (off the training step's critical path: as a launch of its own in front
+ * of the step it costs ~8 us of a 0.3 ms step). ope_qmix_live_target fills where a plan for (cfg, workspace) goes; with
+ * ope_store_gather_attach_live(&target) the NEXT ope_store_gather* launched from the calling thread gets a few extra workgroups that read the
+ * STORE's dones_env of the sampled episodes through the launch's own indices and write the plan (and the zero-filled regions) there -- the
+ * same computation, on the same flags the copy is moving into the batch. The attachment is consumed by that one launch; it is ignored (the
+ * step then has no plan: do not promise one) unless the store's episode_length, the batch size and the shape limits match the target.
+ * The step is then told so with ope_qmix_cfg.live_rows = 3: "live rows, and the plan region already holds THIS batch's plan" -- the caller's
+ * promise that the batch is what that gather wrote, unmodified (off-policy_amd: RecPolicyBuffer.sample_inds(..., live_for=trainer) attaches
+ * and tags the batch, QMix.train_policy_on_batch checks the tag). NULL cancels a pending attachment. */
+typedef struct ope_live_target {
+  int32_t* plan;        /* workspace region "live_plan" */
+  float* err_abs;       /* workspace region "err_abs" [T*B]  (zero-filled with the plan) */
+  float* loss_part;     /* workspace region "loss_part"      (zero-filled with the plan) */
+  int32_t n_loss_part;
+  int32_t n_agents, episode_length, batch;
+} ope_live_target;
+int ope_qmix_live_target(const ope_qmix_cfg* cfg, void* workspace, int64_t workspace_bytes, ope_live_target* out);
+int ope_store_gather_attach_live(const ope_live_target* target);
 int ope_qmix_live_plan(const ope_qmix_cfg* cfg, const float* dones_env, void* workspace, int64_t workspace_bytes, void* stream);
 int ope_qmix_loss_and_grad_ref(const ope_qmix_cfg* cfg, const ope_fields* batch, const ope_obs_ref* obs, const float* theta,
                                const float* theta_tgt, const float* per_weights, void* workspace, int64_t workspace_bytes,

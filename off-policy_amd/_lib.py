@@ -48,6 +48,11 @@ class QmixCfg(C.Structure):
                 ("live_rows", C.c_int32)]
 
 
+class LiveTarget(C.Structure):
+    _fields_ = [("plan", C.c_void_p), ("err_abs", C.c_void_p), ("loss_part", C.c_void_p), ("n_loss_part", C.c_int32),
+                ("n_agents", C.c_int32), ("episode_length", C.c_int32), ("batch", C.c_int32)]
+
+
 class GatherTune(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("floats_per_block", "xcd_run", "unroll", "nontemporal", "small_tiles", "tile_floats")]
 
@@ -97,7 +102,7 @@ class MlpBatch(C.Structure):
                                           "valid_transition", "avail_acts", "next_avail_acts")]
 
 
-ABI_MIRRORS = {"ope_dims": Dims, "ope_fields": Fields, "ope_qmix_cfg": QmixCfg, "ope_gather_tune": GatherTune, "ope_obs_ref": ObsRef,
+ABI_MIRRORS = {"ope_live_target": LiveTarget, "ope_dims": Dims, "ope_fields": Fields, "ope_qmix_cfg": QmixCfg, "ope_gather_tune": GatherTune, "ope_obs_ref": ObsRef,
                "ope_adam_cfg": AdamCfg, "ope_ddpg_opt": DdpgOpt, "ope_ddpg_cfg": DdpgCfg, "ope_rddpg_cfg": RddpgCfg,
                "ope_allreduce_ctx": AllreduceCtx, "ope_mlp_batch": MlpBatch}
 
@@ -128,6 +133,8 @@ def _load():
         "ope_qmix_obs_ref_ok": (C.c_int, [C.POINTER(QmixCfg)]),
         "ope_qmix_live_rows_ok": (C.c_int, [C.POINTER(QmixCfg)]),
         "ope_qmix_live_plan": (C.c_int, [C.POINTER(QmixCfg), p, p, i64, p]),
+        "ope_qmix_live_target": (C.c_int, [C.POINTER(QmixCfg), p, i64, C.POINTER(LiveTarget)]),
+        "ope_store_gather_attach_live": (C.c_int, [C.POINTER(LiveTarget)]),
         "ope_qmix_loss_and_grad_ref": (C.c_int, [C.POINTER(QmixCfg), C.POINTER(Fields), C.POINTER(ObsRef), p, p, p, p, i64, p, p, p]),
         "ope_store_gather_profile": (C.c_int, [i32]),
         "ope_store_gather_profile_read": (C.c_int, [p, i32]),
@@ -206,17 +213,19 @@ def kernel_profile(enable, max_launches=8192):
     check(lib.ope_kernel_profile(1 if enable else 0, int(max_launches)), "ope_kernel_profile")
 
 
-def kernel_profile_read():
+def kernel_profile_read(with_rows=False):
     """[(demangled kernel name, calls, total_ms, min_ms, max_ms, flop, bytes)] of the launches since kernel_profile(True), in order of first
-    launch; flop / bytes = the algorithmic work of those launches as their launchers state it (0 where none is stated)."""
+    launch; flop / bytes = the algorithmic work of those launches as their launchers state it (0 where none is stated). with_rows: an 8th
+    entry, the live-row count that scales the stated work of a launch on live rows (0 none; ope.h, ope_kernel_profile_read)."""
     buf = C.create_string_buffer(1 << 18)
     n = lib.ope_kernel_profile_read(buf, 1 << 18)
     if n < 0:
         check(n, "ope_kernel_profile_read")
     out = []
     for ln in buf.value.decode().splitlines():
-        name, calls, tot, mn, mx, flop, nbytes = ln.rsplit("\t", 6)
-        out.append((name, int(calls), float(tot), float(mn), float(mx), float(flop), float(nbytes)))
+        name, calls, tot, mn, mx, flop, nbytes, rows = ln.rsplit("\t", 7)
+        rec = (name, int(calls), float(tot), float(mn), float(mx), float(flop), float(nbytes))
+        out.append(rec + (int(rows),) if with_rows else rec)
     return out
 
 

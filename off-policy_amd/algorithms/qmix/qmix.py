@@ -94,6 +94,7 @@ class QMix(object):
         self._ws = {}
         self._ws_multi = {}
         self._gsq = {}
+        self._live_seq = 0          # tickets of the plans built for this trainer by gather launches (RecPolicyBuffer.sample_inds(live_for=))
         if self.multi and (self.hypernet_layers == 1 or self.layer_N != 1 or self.dims_flags):
             raise NotImplementedError("hypernet_layers=1 / layer_N=2 / use_feature_normalization=False with several policies is not on the accelerated path")
         if (self.dims_flags & _lib.OPE_DIMS_NO_FEATURE_NORM) and float(getattr(args, "weight_decay", 0.0) or 0.0) != 0.0:
@@ -344,6 +345,22 @@ class QMix(object):
             self._ws[B] = ws
         return self._ws[B]
 
+    def live_target(self, batch):
+        """(ope_live_target, tag) where a gather launch may build the live-row plan of this trainer's next step on `batch` episodes
+        (RecPolicyBuffer.sample_inds(live_for=trainer); ope.h: ope_store_gather_attach_live), or None where the step would not run on live
+        rows "by shape" (or the trainer pins every padded row / is one of the multi-policy, MLP, MultiDiscrete forms)."""
+        if self.multi or self._mlp or int(self.tune.get("live_rows", 0)) == 1 or int(self.tune.get("debug", 0)):
+            return None
+        cfg = self._cfg(int(batch))
+        if not _lib.lib.ope_qmix_live_rows_ok(C.byref(cfg)):
+            return None
+        ws = self._workspace(cfg)
+        tgt = _lib.LiveTarget()
+        if _lib.lib.ope_qmix_live_target(C.byref(cfg), _lib.ptr(ws), ws.numel(), C.byref(tgt)) != 0:
+            return None
+        self._live_seq += 1
+        return tgt, (int(ws.data_ptr()), self._live_seq)
+
     def workspace_view(self, batch, name):
         """Debug/test access to a named intermediate of the last step with this batch size (float32 view)."""
         cfg = self._cfg(batch)
@@ -391,6 +408,7 @@ class QMix(object):
         acts = self._to_device_layout(act_b[pid], True)
         rew = self._to_device_layout(rew_b[pid], True)
         dones_env = self._to_device_layout(dones_env_b[pid], False)
+        live_tag = getattr(dones_env_b[pid], "_ope_live", None)      # the gather that wrote this batch built the step's row plan (sample_inds(live_for=))
         avail = self._to_device_layout(avail_b[pid], True) if (avail_b is not None and avail_b[pid] is not None) else None
         if getattr(self.policies[pid], "prev_act_inp", False):
             # qmix.py:123-124: the network input at step t is [obs_t | action taken at t-1], zeros at t = 0
@@ -398,7 +416,7 @@ class QMix(object):
             obs = torch.cat((obs, prev), dim=-1).contiguous()
         if self._md_heads is not None:
             obs, acts, rew, avail = self._md_expand(obs, acts, rew, avail)
-        return self._train_on_device_batch(obs, share, acts, rew, dones_env, avail, importance_weights, idxes)
+        return self._train_on_device_batch(obs, share, acts, rew, dones_env, avail, importance_weights, idxes, live_tag=live_tag)
 
     def _md_expand(self, obs, acts, rew, avail):
         """MultiDiscrete: the batch as the kernels see it -- one "agent" per (agent, sub-action), agent-major (the order upstream concatenates
@@ -446,7 +464,7 @@ class QMix(object):
             return False
         return bool(_lib.lib.ope_qmix_obs_ref_ok(C.byref(self._cfg(int(batch)))))
 
-    def _train_on_device_batch(self, obs, share, acts, rew, dones_env, avail, importance_weights, idxes):
+    def _train_on_device_batch(self, obs, share, acts, rew, dones_env, avail, importance_weights, idxes, live_tag=None):
         oref = None
         if isinstance(obs, StoreObs):
             N, T1, B, D = obs.shape
@@ -456,6 +474,8 @@ class QMix(object):
         assert T1 == self.episode_length + 1 and N == getattr(self, "_n_kernel_agents", self.num_agents), "batch does not match the trainer's dimensions"
         cfg = self._cfg(B)
         ws = self._workspace(cfg)
+        if live_tag is not None and oref is None and cfg.live_rows in (0, 2) and live_tag == (int(ws.data_ptr()), self._live_seq):
+            cfg.live_rows = 3       # the plan region holds THIS batch's plan (the latest one built for this workspace): no plan launch
         f = _lib.Fields()
         f.obs = None if oref is not None else _lib.ptr(obs).value
         f.share_obs, f.acts, f.rewards = _lib.ptr(share).value, _lib.ptr(acts).value, _lib.ptr(rew).value

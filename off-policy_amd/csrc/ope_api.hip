@@ -26,7 +26,7 @@ bool cfg_ok(const ope_qmix_cfg* c) {
   if (c->trunk_path != 0 && c->trunk_path != 3 && c->trunk_path != 4) return false;
   if (c->chain_path < 0 || c->chain_path > 2) return false;
   if (c->hypernet_layers < 0 || c->hypernet_layers > 2) return false;
-  if (c->wgrad_path < 0 || c->wgrad_path > 2 || c->live_rows < 0 || c->live_rows > 2) return false;
+  if (c->wgrad_path < 0 || c->wgrad_path > 2 || c->live_rows < 0 || c->live_rows > 3) return false;
   if (d.layer_N < 0 || d.layer_N > 2) return false;
   if (d.flags & ~(OPE_DIMS_NO_FEATURE_NORM | OPE_DIMS_TANH | OPE_DIMS_MASK_TARGET_MAX)) return false;
   if ((d.flags & OPE_DIMS_TANH) && (c->phase != 0 || d.layer_N == 2 || d.obs_dim > 384 || c->trunk_path == 4)) return false;   // tanh: trunk_fwd3 / trunk_bwd3
@@ -285,7 +285,7 @@ extern "C" int64_t ope_abi_sizeof(const char* name) {
   if (!name) return -1;
 #define OPE_SZ(T) if (!strcmp(name, #T)) return (int64_t)sizeof(T)
   OPE_SZ(ope_dims); OPE_SZ(ope_fields); OPE_SZ(ope_gather_tune); OPE_SZ(ope_obs_ref); OPE_SZ(ope_qmix_cfg); OPE_SZ(ope_adam_cfg);
-  OPE_SZ(ope_ddpg_cfg); OPE_SZ(ope_mlp_batch); OPE_SZ(ope_ddpg_opt); OPE_SZ(ope_rddpg_cfg); OPE_SZ(ope_allreduce_ctx);
+  OPE_SZ(ope_ddpg_cfg); OPE_SZ(ope_mlp_batch); OPE_SZ(ope_ddpg_opt); OPE_SZ(ope_rddpg_cfg); OPE_SZ(ope_allreduce_ctx); OPE_SZ(ope_live_target);
 #undef OPE_SZ
   return -1;
 }
@@ -386,13 +386,25 @@ static bool live_cfg_ok(const ope_qmix_cfg* cfg, const Plan& p) {
   const bool tanh_on = (cfg->dims.flags & OPE_DIMS_TANH) != 0;
   return p.live >= 0 && p.chain && cfg->phase == 0 && !p.mlp && p.chunks == 1 && p.layerN == 1 && !tanh_on && !cfg->debug && w2_shape_can(cfg, p) && w2_wanted(cfg) &&
          trunk4_pair_can(p.D, p.R, cfg->trunk_path, tanh_on) && trunk_bwd4_can(p.R1, cfg->trunk_path, tanh_on) && scan4(2 * (int64_t)p.NB) && scan4(p.NB) &&
-         (cfg->live_rows == 2 || (cfg->live_rows == 0 && live_env));
+         (int64_t)p.R * 1024 < ((int64_t)1 << 32) &&      // (row byte offsets are 32-bit in the scan kernels)
+         (cfg->live_rows >= 2 || (cfg->live_rows == 0 && live_env));
 }
 extern "C" int ope_qmix_live_rows_ok(const ope_qmix_cfg* cfg) {
   if (!cfg_ok(cfg)) return 0;
   Plan p;
   make_plan(cfg, &p);
   return live_cfg_ok(cfg, p) ? 1 : 0;
+}
+extern "C" int ope_qmix_live_target(const ope_qmix_cfg* cfg, void* workspace, int64_t workspace_bytes, ope_live_target* out) {
+  if (!cfg_ok(cfg) || !workspace || !out) return OPE_EINVAL;
+  Plan p;
+  make_plan(cfg, &p);
+  if (workspace_bytes < p.ws.total * (int64_t)sizeof(float)) return OPE_ENOSPC;
+  if (p.live < 0) return OPE_EINVAL;
+  float* W = (float*)workspace;
+  out->plan = reinterpret_cast<int32_t*>(W + p.live); out->err_abs = W + p.err_abs; out->loss_part = W + p.loss_part; out->n_loss_part = p.n_loss_tiles * 4;
+  out->n_agents = p.N; out->episode_length = p.T; out->batch = p.B;
+  return OPE_OK;
 }
 extern "C" int ope_qmix_live_plan(const ope_qmix_cfg* cfg, const float* dones_env, void* workspace, int64_t workspace_bytes, void* stream) {
   (void)hipGetLastError();
@@ -628,12 +640,12 @@ static int qmix_step(const ope_qmix_cfg* cfg, const ope_fields* batch, const ope
     return true;
   };
   if (want_w2 && !plan_w2()) {
-    if (cfg->wgrad_path == 2 || cfg->live_rows == 2) return OPE_EINVAL;
+    if (cfg->wgrad_path == 2 || cfg->live_rows >= 2) return OPE_EINVAL;
     want_w2 = merge_hh = live = false;      // "by shape": the one-tile-per-wave launch on every padded row
     memset(&lp, 0, sizeof(lp));
   }
-  if (cfg->live_rows == 2 && !live) return OPE_EINVAL;
-  if (live) {
+  if (cfg->live_rows >= 2 && !live) return OPE_EINVAL;
+  if (live && cfg->live_rows != 3) {      // (3: the gather launch that wrote this batch built the plan -- ope_store_gather_attach_live)
     LiveArgs la;
     la.T = p.T; la.N = p.N; la.B = p.B; la.dones_env = batch->dones_env; la.plan = reinterpret_cast<int*>(W + p.live);
     la.err_abs = W + p.err_abs; la.loss_part = W + p.loss_part; la.n_loss_part = p.n_loss_tiles * 4;

@@ -936,6 +936,7 @@ int launch_mixer_hyp(const HypFirstArgs& a0, hipStream_t st) {
   const int blocks = a.main_blocks + (a.side.total > 0 ? ope_cdiv(a.side.total, threads) : 0);
   const int vec = ope_vec_of(a.S);
   kprof_work(2.0 * 2.0 * a.TB * (double)a.S * 16.0 * a.ntiles);
+  if (a.lp.hdr) kprof_rows(3);
   const bool pk = a.lp.hdr != nullptr;
   if (pk) {
     if (vec == 4) OPE_LAUNCH((mixer_hyp_kernel<4, true>), dim3(blocks), dim3(threads), 0, st, a);
@@ -966,6 +967,7 @@ int launch_qchain(const ChainArgs& a, hipStream_t st) {
     else if (a.ML.one_layer) OPE_LAUNCH((qchain_kernel<NT_, APW_, false, true, PK_>), dim3(blocks), dim3(64 * kCW), 0, st, a); \
     else OPE_LAUNCH((qchain_kernel<NT_, APW_, false, false, PK_>), dim3(blocks), dim3(64 * kCW), 0, st, a);         \
   } while (0)
+  if (pk) kprof_rows(3);
 #define OPE_QCHAIN(NT_, APW_)                   \
   do {                                          \
     if (pk) OPE_QCHAIN2(NT_, APW_, true);       \

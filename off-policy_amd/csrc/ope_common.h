@@ -33,6 +33,7 @@ namespace ope {
 extern bool g_kprof_on;
 bool kprof_events(const void* fn, hipEvent_t* e0, hipEvent_t* e1);
 void kprof_work(double flop, double bytes = 0);     // algorithmic work of the NEXT launch (only recorded while profiling is on)
+void kprof_rows(int kind);                          // ... which runs on live rows: 1 agent rows, 2 those with t < T, 3 (t, b) rows (ope.h)
 }
 #define OPE_LAUNCH(kernel, grid, block, lds, st, ...)                                                   \
   do {                                                                                                  \

@@ -94,24 +94,29 @@ __global__ void __launch_bounds__((W + 2) * 64) gru_fwd4_kernel(GruFwdArgs a) {
   const int row = rid - net * a.NB;
   __shared__ int rows_s[PK ? kLiveMaxT + 2 : 1];
   int L = a.L;
-  if (PK) {
-    const int ag = row / a.B, jj = row - ag * a.B;
-    L = __builtin_amdgcn_readfirstlane(a.lp.len[jj]);
-    for (int t = threadIdx.x; t < L; t += (W + 2) * 64) rows_s[t] = a.N * a.lp.cum[t] + ag * a.lp.nn[t] + jj;
+  const int pk_ag = PK ? row / a.B : 0, pk_j = PK ? row - pk_ag * a.B : 0;
+  if (PK) L = __builtin_amdgcn_readfirstlane(a.lp.len[pk_j]);
+  // The step -> row table: every wave fills its share and meets the others at ONE extra barrier -- the loader and the storer at once, the
+  // compute waves behind the requests for their W_hh rows (the table's round trip to L2 then overlaps the weights').
+  auto build_rows = [&]() {
+    if (!PK) return;
+    for (int t = threadIdx.x; t < L; t += (W + 2) * 64) rows_s[t] = (a.N * a.lp.cum[t] + pk_ag * a.lp.nn[t] + pk_j) * (4 * OPE_H);      // byte offset of the row in a [rows][64] array
     __syncthreads();
-  }
+  };
   const int nchunks = (L + kAhead - 1) / kAhead;
   const float* __restrict__ th = net == 0 ? a.theta0 : a.theta1;
 
   if (wave == W) {   // ---- loader: lane = feature
+    build_rows();
     const float* __restrict__ gi = net == 0 ? a.gi0 : a.gi1;
     const int64_t stride_t = (int64_t)a.NB * (3 * OPE_H);
     const float* gp = gi + (int64_t)row * (3 * OPE_H);          // uniform: the lane enters as the 32-bit offset of the load
     const unsigned lo4 = 4u * lane;
     const float brs = th[a.bhh_off + lane] * kL, bzs = th[a.bhh_off + OPE_H + lane] * kL;
     float pre[kAhead][3];
-    auto load_step = [&](float (&d)[3], int t) {
-      const float* p = PK ? gi + (int64_t)__builtin_amdgcn_readfirstlane(rows_s[min(t, L - 1)]) * (3 * OPE_H) : gp + (int64_t)min(t, L - 1) * stride_t;
+    auto row_at = [&](int t) -> int { return PK ? rows_s[min(t, L - 1)] : 0; };
+    auto load_step = [&](float (&d)[3], int t, int prow) {      // prow (PK): the step's row, read from the table ahead of time
+      const float* p = PK ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(gi) + 3ull * (unsigned)__builtin_amdgcn_readfirstlane(prow)) : gp + (int64_t)min(t, L - 1) * stride_t;
       gload_async_s<0>(d[0], p, lo4);
       gload_async_s<4 * OPE_H>(d[1], p, lo4);
       gload_async_s<8 * OPE_H>(d[2], p, lo4);
@@ -128,10 +133,10 @@ __global__ void __launch_bounds__((W + 2) * 64) gru_fwd4_kernel(GruFwdArgs a) {
     };
     if (lane < 4) sm[kGx + (lane >> 1) * kGxP + (lane & 1) * kGxZ + OPE_H] = 0.f;
 #pragma unroll
-    for (int s = 0; s < kAhead; ++s) load_step(pre[s], s);
+    for (int s = 0; s < kAhead; ++s) load_step(pre[s], s, row_at(s));
     OPE_GWAIT24(pre);
     publish(pre[0], 0);
-    load_step(pre[0], kAhead);
+    load_step(pre[0], kAhead, row_at(kAhead));
     lds_barrier();
     for (int c = 0; c < nchunks; ++c) {
 #pragma unroll
@@ -139,9 +144,12 @@ __global__ void __launch_bounds__((W + 2) * 64) gru_fwd4_kernel(GruFwdArgs a) {
         const int t = c * kAhead + s;
         if (t < L) {
           float(&d)[3] = pre[(s + 1) % kAhead];      // holds step t+1; 7 x 3 younger loads are in flight behind it
+          // the table entry of the step requested below: asked for before the wait, so the LDS round trip hides behind it
+          const int prow = row_at(t + 1 + kAhead);
+          if (PK) __builtin_amdgcn_sched_barrier(0);
           asm volatile("s_waitcnt vmcnt(21)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2])::"memory");
           publish(d, (s + 1) & 1);
-          load_step(d, t + 1 + kAhead);
+          load_step(d, t + 1 + kAhead, prow);
           lds_barrier();
         }
       }
@@ -149,13 +157,14 @@ __global__ void __launch_bounds__((W + 2) * 64) gru_fwd4_kernel(GruFwdArgs a) {
     return;
   }
   if (wave == W + 1) {   // ---- storer: lane = feature; step t-1's results leave during step t
+    build_rows();
     float* __restrict__ hout = net == 0 ? a.h0out : a.h1out;
     const bool save = (net == 0) && (a.rg != nullptr);
     lds_barrier();
     for (int t = 0; t <= L; ++t) {
       if (t > 0) {
         const int p = (t - 1) & 1;
-        const int64_t o = (PK ? (int64_t)rows_s[t - 1] : (int64_t)(t - 1) * a.NB + row) * OPE_H + lane;
+        const int64_t o = (PK ? (int64_t)((unsigned)__builtin_amdgcn_readfirstlane(rows_s[t - 1]) >> 2) : ((int64_t)(t - 1) * a.NB + row) * OPE_H) + lane;
         hout[o] = hs[p ^ 1][lane];   // h_t was published as the next step's input
         if (save) {
           a.rg[o] = sv[p][0][lane];
@@ -188,6 +197,7 @@ __global__ void __launch_bounds__((W + 2) * 64) gru_fwd4_kernel(GruFwdArgs a) {
     }
   }
   const float bn = th[a.bhh_off + 2 * OPE_H + f];
+  build_rows();
   const float* hin = net == 0 ? a.hinit : a.hinit1;
   float h = hin ? hin[(int64_t)row * OPE_H + f] : 0.f;
   // The sigmoids are evaluated as rcp(1 + exp2(x')) with x' = -log2(e) x and tanh(x) as 2 rcp(1 + exp2(-2 log2(e) x)) - 1
@@ -308,26 +318,39 @@ __global__ void __launch_bounds__((W + 2) * 64) gru_bwd4_kernel(GruBwdArgs a) {
   const int64_t NB = a.NB;
   __shared__ int rows_s[PK ? kLiveMaxT + 2 : 1];
   int Tl = a.T;                       // the chain walks t = Tl - 1 .. t_lo
-  if (PK) {
-    const int ag = row / a.B, jj = row - ag * a.B;
-    Tl = min(__builtin_amdgcn_readfirstlane(a.lp.len[jj]), a.T);
-    for (int t = threadIdx.x; t < Tl; t += (W + 2) * 64) rows_s[t] = a.N * a.lp.cum[t] + ag * a.lp.nn[t] + jj;
+  const int pk_ag = PK ? row / a.B : 0, pk_j = PK ? row - pk_ag * a.B : 0;
+  if (PK) Tl = min(__builtin_amdgcn_readfirstlane(a.lp.len[pk_j]), a.T);
+  auto build_rows = [&]() {           // (as in gru_fwd4_kernel)
+    if (!PK) return;
+    for (int t = threadIdx.x; t < Tl; t += (W + 2) * 64) rows_s[t] = (a.N * a.lp.cum[t] + pk_ag * a.lp.nn[t] + pk_j) * (4 * OPE_H);      // byte offsets, as in gru_fwd4_kernel
     __syncthreads();
-  }
+  };
   const int nsteps = Tl - a.t_lo;
   const int nchunks = (nsteps + kAhead - 1) / kAhead;
 
   if (wave == W) {   // ---- loader
+    build_rows();
     float pre[kAhead][6];
-    auto load_step = [&](float (&d)[6], int i) {
+    auto row_at = [&](int i, int back) -> int { return PK ? rows_s[max(max(Tl - 1 - i, a.t_lo) - back, 0)] : 0; };      // row of step i's t (- back)
+    auto load_step = [&](float (&d)[6], int i, int prow, int prow1) {      // prow / prow1 (PK): rows of steps t / t - 1, read from the table ahead of time
       const int t = max(Tl - 1 - i, a.t_lo);
-      const int64_t o = (PK ? (int64_t)rows_s[t] : (int64_t)t * NB + row) * OPE_H + lane;
+      if (PK) {      // (uniform array base) + (32-bit byte offset of the row + lane): two vector adds for the six loads of a step
+        const unsigned vo = (unsigned)prow + 4u * lane, vo1 = (unsigned)prow1 + 4u * lane;
+        gload_async_s<0>(d[0], a.rg, vo);
+        gload_async_s<0>(d[1], a.zg, vo);
+        gload_async_s<0>(d[2], a.ng, vo);
+        gload_async_s<0>(d[3], a.ghn, vo);
+        gload_async_s<0>(d[4], a.dh_out, vo);
+        gload_async_s<0>(d[5], a.h, vo1);      // (t = 0: row 0's own h, unused)
+        return;
+      }
+      const int64_t o = ((int64_t)t * NB + row) * OPE_H + lane;
       gload_async(d[0], a.rg + o);
       gload_async(d[1], a.zg + o);
       gload_async(d[2], a.ng + o);
       gload_async(d[3], a.ghn + o);
       gload_async(d[4], a.dh_out + o);
-      gload_async(d[5], a.h + (t > 0 ? (PK ? (int64_t)rows_s[t - 1] * OPE_H + lane : o - NB * OPE_H) : o));
+      gload_async(d[5], a.h + (t > 0 ? o - NB * OPE_H : o));
     };
     // The factors of step i that do not depend on dh are formed here, off the compute waves' chain (every instruction of a
     // compute wave is on it): with dht = dh_t + dh_out_t,
@@ -352,10 +375,10 @@ __global__ void __launch_bounds__((W + 2) * 64) gru_bwd4_kernel(GruBwdArgs a) {
       sav[p][5][lane] = i < nsteps ? d[4] : 0.f;   // nothing enters behind the last step: the carried value leaves as dh_carry
     };
 #pragma unroll
-    for (int s = 0; s < kAhead; ++s) load_step(pre[s], s);
+    for (int s = 0; s < kAhead; ++s) load_step(pre[s], s, row_at(s, 0), row_at(s, 1));
     asm volatile("s_waitcnt vmcnt(42)" : "+v"(pre[0][0]), "+v"(pre[0][1]), "+v"(pre[0][2]), "+v"(pre[0][3]), "+v"(pre[0][4]), "+v"(pre[0][5])::"memory");
     publish(pre[0], 0);
-    load_step(pre[0], kAhead);
+    load_step(pre[0], kAhead, row_at(kAhead, 0), row_at(kAhead, 1));
     lds_barrier();
     for (int c = 0; c < nchunks; ++c) {
 #pragma unroll
@@ -363,9 +386,12 @@ __global__ void __launch_bounds__((W + 2) * 64) gru_bwd4_kernel(GruBwdArgs a) {
         const int i = c * kAhead + s;
         if (i < nsteps) {
           float(&d)[6] = pre[(s + 1) % kAhead];   // holds step i+1; 7 x 6 younger loads behind it
+          // the table entries of the step requested below, asked for before the wait
+          const int prow = row_at(i + 1 + kAhead, 0), prow1 = row_at(i + 1 + kAhead, 1);
+          if (PK) __builtin_amdgcn_sched_barrier(0);
           asm volatile("s_waitcnt vmcnt(42)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5])::"memory");
           publish(d, i + 1);
-          load_step(d, i + 1 + kAhead);
+          load_step(d, i + 1 + kAhead, prow, prow1);
           lds_barrier();
         }
       }
@@ -373,17 +399,18 @@ __global__ void __launch_bounds__((W + 2) * 64) gru_bwd4_kernel(GruBwdArgs a) {
     return;
   }
   if (wave == W + 1) {   // ---- storer: step i-1's adjoints leave during step i
+    build_rows();
     lds_barrier();
     for (int i = 0; i <= nsteps; ++i) {
       if (i > 0) {
         const int p = (i - 1) & 1;
         const int t = Tl - i;
-        const int64_t ro = PK ? (int64_t)rows_s[t] : (int64_t)t * NB + row;
-        float* gout = a.dgi + ro * (3 * OPE_H) + lane;
+        const int64_t ro64 = PK ? (int64_t)((unsigned)__builtin_amdgcn_readfirstlane(rows_s[t]) >> 2) : ((int64_t)t * NB + row) * OPE_H;      // float offset of the row in a [rows][64] array
+        float* gout = a.dgi + 3 * ro64 + lane;
         gout[0] = ds[p][0][lane];
         gout[OPE_H] = ds[p][1][lane];
         gout[2 * OPE_H] = ds[p][3][lane];
-        a.dghn[ro * OPE_H + lane] = ds[p][2][lane];
+        a.dghn[ro64 + lane] = ds[p][2][lane];
       }
       if (i < nsteps) lds_barrier();
     }
@@ -403,6 +430,7 @@ __global__ void __launch_bounds__((W + 2) * 64) gru_bwd4_kernel(GruBwdArgs a) {
       wn[i] = f32x2{w[(int64_t)(2 * OPE_H + 2 * i) * OPE_H], w[(int64_t)(2 * OPE_H + 2 * i + 1) * OPE_H]};
     }
   }
+  build_rows();
   float dh = a.dh_in ? a.dh_in[(int64_t)row * OPE_H + k] : 0.f;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   lds_barrier();
@@ -512,6 +540,7 @@ int launch_gru_fwd4(const GruFwdArgs& a, hipStream_t st) {
   const int w = waves_per_row((int64_t)a.nets * a.NB, a.waves);
   kprof_work(2.0 * a.nets * a.NB * (double)a.L * 3.0 * OPE_H * OPE_H);      // W_hh h per row and step
   if (a.lp.hdr && (a.dbg || a.hinit || a.hinit1 || a.B < 1 || a.N < 1 || a.NB != a.N * a.B || a.L > kLiveMaxT + 1)) return OPE_EINVAL;
+  if (a.lp.hdr) kprof_rows(1);
   if (w == 4) launch_fwd<4>(a, st); else launch_fwd<2>(a, st);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   note_launch(a.lp.hdr ? "gru_fwd4_live" : "gru_fwd4", w == 4 ? 4 : 2);
@@ -522,6 +551,7 @@ int launch_gru_bwd4(const GruBwdArgs& a, hipStream_t st) {
   const int w = waves_per_row(a.NB, a.waves);
   kprof_work(2.0 * a.NB * (double)(a.T - a.t_lo) * 3.0 * OPE_H * OPE_H);     // W_hh^T (gate adjoints) per row and step
   if (a.lp.hdr && (a.dbg || a.dh_in || a.dh_carry || a.t_lo != 0 || a.B < 1 || a.N < 1 || a.NB != a.N * a.B || a.T > kLiveMaxT)) return OPE_EINVAL;
+  if (a.lp.hdr) kprof_rows(2);
   if (w == 4) launch_bwd<4>(a, st); else launch_bwd<2>(a, st);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   note_launch(a.lp.hdr ? "gru_bwd4_live" : "gru_bwd4", w == 4 ? 4 : 2);

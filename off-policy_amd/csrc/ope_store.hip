@@ -14,7 +14,10 @@
 
 #include <hip/hip_ext.h>
 
+#include <algorithm>
+
 #include "ope_common.h"
+#include "ope_live_dev.h"
 #include "ope_rng.h"
 
 namespace {
@@ -81,6 +84,21 @@ struct CopyArgs {
   int* bad_index;    // device flag: set to 1 if an index was out of range (the offending rows are skipped)
   int lds_bytes;     // dynamic LDS the tile fields need
   int64_t* idx_out;  // gather, optional: the episode indices as used, for consumers that read rows of the store themselves (ope_obs_ref)
+  // gather, optional (ope_store_gather_attach_live): `live_blocks` rider workgroups behind the copy's build the live-row plan of this batch
+  // (LivePlan, ope_common.h) from the STORE's dones_env through the sampled slots -- the plan of the training step that follows, off its
+  // critical path (as a launch of its own it costs the step ~8 us)
+  int live_blocks, live_T, live_N, live_nlp;
+  ope::LiveW live_w;
+  float* live_err_abs; float* live_loss_part;
+};
+// the store's termination flags of the sampled episodes: [capacity][T][1]
+template <class IDX>
+struct StoreDones {
+  const float* ring; const IDX* idx; int capacity, T;
+  __device__ __forceinline__ float operator()(int t, int b) const {
+    const int64_t slot = (*idx)[b];
+    return (slot < 0 || slot >= capacity) ? 1.0f : ring[slot * T + t];      // (an index out of range: the copy raises the flag; here the episode counts as over)
+  }
 };
 
 // Where the episode indices come from: device memory (device-resident index tensors: prioritized sampling on the device,
@@ -330,6 +348,18 @@ __global__ void __launch_bounds__(kBlock) episode_copy_kernel(CopyArgs args, IDX
   // ONE XCD (the G blocks of a run are dispatched 8 apart, i.e. close in time), runs interleaved over the XCDs so that
   // every XCD still sees every field.
   int bid = blockIdx.x;
+  if (GATHER && args.live_blocks > 0) {
+    // riders: the live-row plan of this batch (uniform per workgroup). They are the launch's FIRST workgroups: dispatched at once, their
+    // chain of a few dependent round trips runs beside the copy (as its last workgroups they started when the copy was nearly done and
+    // made the launch 15 us longer)
+    if (bid < args.live_blocks) {
+      StoreDones<IDX> dn{args.f[5].src, &idx, args.capacity, args.live_T};
+      ope::live_plan_body<true, 20>(args.live_w, args.live_err_abs, args.live_loss_part, args.live_nlp, args.live_T, args.live_N, args.n_episodes, dn,
+                                reinterpret_cast<int*>(lds), bid, args.live_blocks);
+      return;
+    }
+    bid -= args.live_blocks;
+  }
   if (GATHER && args.idx_out && bid == 0)
     for (int i = threadIdx.x; i < args.n_episodes; i += kBlock) args.idx_out[i] = idx[i];
   const int G = args.xcd_swizzle;     // gather: B (runs of B consecutive logical workgroups on one XCD); insert: the knob
@@ -374,10 +404,31 @@ GatherProf g_prof;
 using ope::g_kprof_on;
 using ope::kprof_work;
 
+// ope_store_gather_attach_live: the target of the NEXT gather launched from this thread (consumed by it, whatever its outcome)
+thread_local ope_live_target g_live_next;
+thread_local bool g_live_pending = false;
+
 template <bool GATHER, class IDX>
-void launch_copy(const CopyArgs& args, const IDX& idx, hipStream_t st) {
-  const dim3 grid(args.total_blocks), block(kBlock);
-  const size_t lds = (size_t)args.lds_bytes;
+void launch_copy(const CopyArgs& args0, const IDX& idx, hipStream_t st) {
+  CopyArgs args = args0;
+  args.live_blocks = 0;
+  size_t lds = (size_t)args.lds_bytes;
+  if (GATHER && g_live_pending) {
+    g_live_pending = false;
+    const ope_live_target& t = g_live_next;
+    const FieldDesc& de = args.f[5];      // the store's dones_env ring
+    if (t.plan && de.src && de.NA == 1 && de.DD == 1 && de.TT == t.episode_length && args.n_episodes == t.batch && ope::live_plan_shape_ok(de.TT, t.n_agents, t.batch)) {
+      // (a multiple of 8: the copy's workgroups keep their XCD -- blockIdx.x % 8 -- and with it the placement of the writers of one
+      // destination range on one L2; 38 riders in front of them made the copy 9 us slower)
+      args.live_blocks = (ope::live_plan_blocks(de.TT, t.n_agents, t.batch) + 7) & ~7;
+      args.live_T = de.TT; args.live_N = t.n_agents; args.live_nlp = t.n_loss_part;
+      args.live_w = ope::live_views(t.plan, de.TT, t.n_agents, t.batch);
+      args.live_err_abs = t.err_abs; args.live_loss_part = t.loss_part;
+      lds = std::max(lds, (size_t)4 * ope::live_lds_ints(de.TT, t.batch));
+      ope::note_launch("gather+live_plan");
+    }
+  }
+  const dim3 grid(args.total_blocks + args.live_blocks), block(kBlock);
   if (GATHER && g_prof.on && g_prof.n < kProfRing && args.unroll == 8 && args.nt == 0 && (g_prof.seen++ % (unsigned)g_prof.stride) == 0) {
     hipEvent_t e0 = g_prof.ev[g_prof.n][0], e1 = g_prof.ev[g_prof.n][1];
     ++g_prof.n;
@@ -617,6 +668,14 @@ extern "C" void ope_set_gather_params(int floats_per_block, int xcd_run, int unr
   if (unroll == 4 || unroll == 8 || unroll == 16) g_tune.unroll = unroll;
   if (nontemporal >= 0) g_tune.nt = nontemporal & 3;
   if (small_tiles >= 0) g_tune.small = small_tiles ? 1 : 0;
+}
+
+extern "C" int ope_store_gather_attach_live(const ope_live_target* target) {
+  if (!target) { g_live_pending = false; return OPE_OK; }
+  if (!target->plan || target->n_agents < 1 || target->batch < 1 || target->episode_length < 1) return OPE_EINVAL;
+  g_live_next = *target;
+  g_live_pending = true;
+  return OPE_OK;
 }
 
 extern "C" int ope_store_gather(const ope_dims* dims, int32_t capacity, const ope_fields* store, const int64_t* inds,

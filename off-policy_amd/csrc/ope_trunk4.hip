@@ -569,6 +569,7 @@ int launch_trunk_fwd_pair(const TrunkFwdArgs& live, const TrunkFwdArgs& tgt, int
     return OPE_OK;
   }
 #endif
+  if (pk) kprof_rows(1);
   if (pk) {
     if (KC == 24) OPE_LAUNCH((trunk_fwd4_kernel<24, 8, true, false, 2, 0, true>), dim3(grid), dim3(512), 0, st, pa);
     else if (KC == 4) OPE_LAUNCH((trunk_fwd4_kernel<4, 8, true, false, 4, 0, true>), dim3(grid), dim3(512), 0, st, pa);

@@ -210,6 +210,7 @@ int launch_trunk_bwd_path(const TrunkBwdArgs& a, int path, hipStream_t st) {
   if (a.tanh_act || !(can && (path == 4 || (path == 0 && on && a.R >= 16 * 1024)))) return a.R_dev ? OPE_EINVAL : launch_trunk_bwd3(a, st);
   static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256; return n > 1 ? n : 256; }();
   kprof_work(2.0 * a.R * ((a.dgi ? 3.0 * OPE_H * OPE_H : 0.0) + OPE_H * OPE_H + (a.dout ? (double)a.hdim * OPE_H : 0.0)));
+  if (a.R_dev) kprof_rows(2);
   OPE_LAUNCH(trunk_bwd4_kernel, dim3(cus), dim3(512), 0, st, a);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   note_launch(a.R_dev ? "trunk_bwd4_live" : "trunk_bwd4");

@@ -571,6 +571,7 @@ int launch_wgrad2(const W2Table& w, float* raw, float* rsum, hipStream_t st) {
     }
   } else
 #endif
+  if (mapped) kprof_rows(2);      // (the agent problems' count; the mixer problems' live share is the same to within a row per episode)
   if (mapped) {
     if (v4) OPE_LAUNCH((wgrad2_kernel<4, 0, true>), dim3(w.total_wg), dim3(256), 0, st, w, raw);
     else OPE_LAUNCH((wgrad2_kernel<2, 0, true>), dim3(w.total_wg), dim3(256), 0, st, w, raw);

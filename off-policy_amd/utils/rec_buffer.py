@@ -304,14 +304,19 @@ class RecPolicyBuffer(object):
             t.fill_(self._filled_dev_value)
         return t
 
-    def sample_inds(self, sample_inds, timing_events=None, out=None, extra=None, _sampler=None, lazy_obs=None):
+    def sample_inds(self, sample_inds, timing_events=None, out=None, extra=None, _sampler=None, lazy_obs=None, live_for=None):
         """Gather the given episode slots; same 7-tuple as rec_buffer.py:192-240 (CUDA tensors, reference shapes).
         `timing_events`: optional (start, end) torch.cuda.Event pair recorded tightly around the gather launch.
         `out`: optional destination from `alloc_batch` (HIP-graph replays read the batch from fixed addresses); the
         default is a fresh batch per call, like the reference's fancy-index copy.
         `extra`: optional (store, out) pair of [cap, T, N, 1] / [T, N, B, 1] tensors copied by the same launch (the transition
         buffers' valid_transition flag).
-        `lazy_obs` (default: self.lazy_obs): leave the observation rows in the store and return a StoreObs in their place."""
+        `lazy_obs` (default: self.lazy_obs): leave the observation rows in the store and return a StoreObs in their place.
+        `live_for`: the trainer this batch is sampled for (QMix). Where its step runs on live rows (ope_qmix_cfg.live_rows: only the rows
+        before each episode's termination are computed, qmix.py:161-166), the gather launch also builds that step's row plan -- from the
+        store's dones_env of the sampled episodes, in a few extra workgroups beside the copy (ope_store_gather_attach_live) -- and the batch
+        is tagged so that `trainer.train_policy_on_batch` skips its own plan launch (~8 us of a 0.3 ms step). The tag is good for the NEXT
+        train call on this batch only; any other use of the batch is unaffected (the arrays are what the reference returns)."""
         lazy = bool(self.lazy_obs if lazy_obs is None else lazy_obs)
         host_inds = None
         if torch.is_tensor(sample_inds):     # indices already on the device (HIP-graph replays keep them in a static tensor)
@@ -355,6 +360,12 @@ class RecPolicyBuffer(object):
             ref_inds = torch.empty(B, dtype=torch.int64, device=self.device)
         if extra is not None:
             sf.valid_transition, of.valid_transition = _lib.ptr(extra[0]).value, _lib.ptr(extra[1]).value
+        live_tag = None
+        if live_for is not None and getattr(live_for, "live_target", None) is not None and self.use_same_share_obs:
+            tgt = live_for.live_target(B)
+            if tgt is not None and int(tgt[0].episode_length) == int(self.episode_length) and int(tgt[0].batch) == B:
+                _lib.check(_lib.lib.ope_store_gather_attach_live(C.byref(tgt[0])), "ope_store_gather_attach_live")
+                live_tag = tgt[1]
         if timing_events is not None:
             timing_events[0].record()
         if _sampler is not None:
@@ -397,6 +408,7 @@ class RecPolicyBuffer(object):
             _lib.check(_lib.lib.ope_reward_normalize(_lib.ptr(out["rewards"]), out["rewards"].numel(), _lib.ptr(self.reward_stats()),
                                                      _lib.current_stream()), "ope_reward_normalize")
         cast = lambda x: x.permute(1, 0, 2, 3)      # [N, T(+1), B, dim] view, as the reference's _cast
+        out["dones_env"]._ope_live = live_tag       # (None: no plan rides with this batch)
         if lazy:
             obs_entry = StoreObs(self, ref_inds if ref_inds is not None else dev_inds, B)
             return (obs_entry, out["share_obs"] if self.use_same_share_obs else cast(out["share_obs"]), cast(out["acts"]), cast(out["rewards"]),

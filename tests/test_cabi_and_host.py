@@ -259,7 +259,7 @@ def test_action_space_kinds_of_the_maddpg_family_are_validated():
 def test_struct_mirrors_match_the_compiled_library():
     """ope_abi_sizeof: every ctypes mirror in offpolicy_amd._lib has the size the library was compiled with (also checked at import)."""
     from offpolicy_amd import _lib
-    assert len(_lib.ABI_MIRRORS) == 11
+    assert len(_lib.ABI_MIRRORS) == 12
     for cname, cls in _lib.ABI_MIRRORS.items():
         assert _lib.lib.ope_abi_sizeof(cname.encode()) == C.sizeof(cls), cname
     assert _lib.lib.ope_abi_sizeof(b"ope_no_such_struct") == -1 and _lib.lib.ope_abi_sizeof(None) == -1

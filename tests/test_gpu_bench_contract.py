@@ -99,15 +99,16 @@ def test_two_rank_self_spawn_other_workloads(workload, batch):
     lines = [ln for ln in r.stdout.splitlines() if ln.lstrip().startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["value"] > 0 and out["scaling"] == "weak"
-    assert out["config"]["global_batch"] == 2 * batch and out["config"]["batch_per_gpu"] == batch and out["config"]["allreduce"]
-    assert out["strong_scaling"]["global_batch"] == batch and out["strong_scaling"]["batch_per_gpu"] == batch // 2 and out["strong_scaling"]["value"] > 0
+    # (round 6: `value` is the STRONG leg -- BASELINE's fixed global batch sharded over the ranks --, the weak leg beside it)
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["scaling"] == "strong"
+    assert out["config"]["global_batch"] == batch and out["config"]["batch_per_gpu"] == batch // 2 and out["config"]["allreduce"]
+    assert out["weak_scaling"]["global_batch"] == 2 * batch and out["weak_scaling"]["batch_per_gpu"] == batch and out["weak_scaling"]["value"] > 0
 
 
 def test_two_rank_self_spawn_line_on_one_gpu():
     """`python bench.py --gpus 2` without a launcher starts the two ranks itself. OPE_BENCH_SELFTEST=1 puts both on cuda:0 over gloo, so
     the N > 1 branches (rendezvous, index sharding, the gradient all-reduce between loss_and_grad and the optimizer, max-over-ranks timing,
-    weak leg = `value` (per-GPU work fixed), strong leg as a second field) run on a 1-GPU box."""
+    strong leg = `value` (ONE batch of 32 sharded over the ranks: BASELINE.json's configuration), weak leg as a second field) run on a 1-GPU box."""
     env = dict(os.environ, OPE_BENCH_SELFTEST="1")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "3m", "--episodes", "64", "--steps", "4",
                         "--warmup", "2", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
@@ -116,10 +117,10 @@ def test_two_rank_self_spawn_line_on_one_gpu():
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 4 and out["warmup"] == 2 and out["value"] > 0
-    assert out["scaling"] == "weak" and out["config"]["global_batch"] == 64 and out["config"]["batch_per_gpu"] == 32
-    assert out["config"]["parallelism"] == "dp2" and out["config"]["allreduce"]
-    strong = out["strong_scaling"]
-    assert strong["global_batch"] == 32 and strong["batch_per_gpu"] == 16 and strong["value"] > 0
+    assert out["scaling"] == "strong" and out["config"]["global_batch"] == 32 and out["config"]["batch_per_gpu"] == 16
+    assert out["config"]["parallelism"] == "dp2" and out["config"]["allreduce"] and "sharded over 2 GPUs" in out["metric"]
+    weak = out["weak_scaling"]
+    assert weak["global_batch"] == 64 and weak["batch_per_gpu"] == 32 and weak["value"] > 0
     assert "cpu_baseline" not in out and out["roofline"]["achieved"] > 0
 
 

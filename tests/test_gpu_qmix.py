@@ -143,7 +143,9 @@ def test_every_forward_trunk_kernel_matches_reference(name, path):
     batch = batch_from(buf, g["inds"], w)
     for s in range(len(g["loss"])):
         info, _, _ = trainer.train_policy_on_batch(batch)
-        launched = ",".join(_lib.last_launches())
+        # (with the LDS-resident trunk pinned, "by shape" may run the step on live rows -- the `_live` instantiations of the same kernels,
+        # round 6 -- where the rest of the configuration allows it: the family pinned here is what is asserted)
+        launched = ",".join(_lib.last_launches()).replace("_live", "")
         in_dim = dims.obs_dim + (dims.act_dim if getattr(policy, "prev_act_inp", False) else 0)
         for want in _expect_trunk(dims._replace(obs_dim=in_dim), path):
             assert want in launched, (want, launched)
