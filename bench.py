@@ -54,6 +54,8 @@ def parse():
                     "with (one-shot xGMI push verified against RCCL, or RCCL) and a timed 475 KB all-reduce; rank 0 prints them as one JSON line "
                     "and the job exits -- what to run first on a new multi-GPU node")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-early-plan", action="store_true", help="QMIX workloads: build the live-row plan in a launch of its own in front of every step "
+                    "instead of inside the gather launch (RecPolicyBuffer.sample_inds(live_for=trainer))")
     ap.add_argument("--no-full-length", action="store_true", help="QMIX workloads, one GPU: skip the second timed leg on a store of full-length "
                     "episodes (`value_full_length`: the step when no row of the padded batch is dead)")
     ap.add_argument("--no-kernel-table", action="store_true", help="skip the per-kernel roofline table (10 extra untimed steps with an event "
@@ -317,8 +319,8 @@ def qmix_flop_executed(dims, batch, rows_fwd, rows_bwd, rows_tb):
 def live_row_stats(trainer, batch):
     """(mean live agent rows, mean live agent rows with t < T, mean live (t, b) rows, steps) over every step this trainer's workspace of
     `batch` episodes has run on live rows (the plan kernel's device-side accumulators, ope.h: ope_qmix_cfg.live_rows); None if none did."""
-    try:
-        acc = trainer.workspace_view(batch, "live_plan").view(torch.int32)[8:16].view(torch.int64).cpu().numpy()
+    try:      # (two plan regions: plans built ahead of the step alternate between them)
+        acc = sum(trainer.workspace_view(batch, name).view(torch.int32)[8:16].view(torch.int64).cpu().numpy() for name in ("live_plan", "live_plan1"))
     except KeyError:
         return None
     if acc[3] <= 0:
@@ -540,10 +542,9 @@ def main():
             inds = opdist.shard_indices(np.random.choice(len(buf), global_batch), rank, world)
             if G["graphed"] is not None:
                 return G["graphed"](inds)
-            # (sample_inds(inds, live_for=trainer) would build the step's live-row plan inside the gather launch: measured, the riders make
-            # the gather 7 us longer -- their chain of dependent round trips queues behind the copy's traffic -- for an 8.4 us plan launch
-            # saved, and the gather's own roofline line would carry them: not used here)
-            s = pbuf.sample_inds(inds)                       # ope_store_gather, current stream
+            # live_for: where the step runs on live rows, this gather launch also builds the step's row plan (extra workgroups in front of
+            # the copy's, from the store's flags of the same episodes) instead of a launch of its own in front of the step
+            s = pbuf.sample_inds(inds, live_for=None if a.no_early_plan else trainer)      # ope_store_gather, current stream
             batch = tuple({"policy_0": x} for x in s) + (None, None)
             info, _, _ = trainer.train_policy_on_batch(batch)
             if args.use_soft_update:

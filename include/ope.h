@@ -265,8 +265,8 @@ typedef struct ope_qmix_cfg {
                          *  form cannot plan (more than 40 units, 4-byte aligned operands) runs form 1 under "by shape" and fails
                          *  BEFORE the step's first launch under wgrad_path = 2                                       */
   int32_t live_rows;    /* rows of the padded batch that are computed: 0 = by shape; 1 = every row (T steps of every episode, as the
-                         *  reference does); 2 = the LIVE rows only; 3 = as 2, and the plan region already holds this batch's plan
-                         *  (ope_store_gather_attach_live below: built by the gather launch the batch came from). The reference pads every sampled episode to episode_length steps and
+                         *  reference does); 2 = the LIVE rows only; 3 / 4 = as 2, and the plan region "live_plan" / "live_plan1" already
+                         *  holds this batch's plan (ope_store_live_plan below: built ahead of the step). The reference pads every sampled episode to episode_length steps and
                          *  multiplies the Bellman error of every (t, b) with dones_env[t-1, b] = 1 by 1 - bad_transitions_mask = 0
                          *  (qmix.py:161-166), leaves it out of the loss normaliser (:184-186), the priorities (:177-181) and Q_tot's mean
                          *  (:198): such rows contribute exactly nothing. With live rows a small kernel finds, ON THE DEVICE at the start
@@ -352,23 +352,33 @@ int ope_qmix_obs_ref_ok(const ope_qmix_cfg* cfg);
  * workspace of `cfg` holds no plan region (MLP nets, phases, batch > 256, episode_length > 1022). Diagnostics / tests / bench.py's
  * executed-row accounting; training never needs to call it. */
 int ope_qmix_live_rows_ok(const ope_qmix_cfg* cfg);
-/* The plan built INSIDE the gather launch that produces the batch (off the training step's critical path: as a launch of its own in front
- * of the step it costs ~8 us of a 0.3 ms step). ope_qmix_live_target fills where a plan for (cfg, workspace) goes; with
- * ope_store_gather_attach_live(&target) the NEXT ope_store_gather* launched from the calling thread gets a few extra workgroups that read the
- * STORE's dones_env of the sampled episodes through the launch's own indices and write the plan (and the zero-filled regions) there -- the
- * same computation, on the same flags the copy is moving into the batch. The attachment is consumed by that one launch; it is ignored (the
- * step then has no plan: do not promise one) unless the store's episode_length, the batch size and the shape limits match the target.
- * The step is then told so with ope_qmix_cfg.live_rows = 3: "live rows, and the plan region already holds THIS batch's plan" -- the caller's
- * promise that the batch is what that gather wrote, unmodified (off-policy_amd: RecPolicyBuffer.sample_inds(..., live_for=trainer) attaches
- * and tags the batch, QMix.train_policy_on_batch checks the tag). NULL cancels a pending attachment. */
+/* The plan built AHEAD of the step, off its critical path (as a launch in front of the step it costs ~8 us of a 0.3 ms step: a chain of a
+ * few dependent round trips on a nearly idle GPU). A step's plan depends on the store's dones_env of the sampled episodes only, so it can be
+ * built as soon as the indices are drawn -- typically while the previous step is still running, on another stream:
+ *   ope_qmix_live_target(cfg, workspace, bytes, which, &t)   where a plan for (cfg, workspace) goes: region "live_plan" (which = 0) or
+ *                                                             "live_plan1" (which = 1) -- two, so that a plan can be written while the
+ *                                                             step before still reads its own
+ *   ope_store_live_plan(capacity, T, store.dones_env, inds_dev | inds_host, &t, stream)
+ *                                                             the same computation as ope_qmix_live_plan, on the STORE's flags
+ *                                                             ([capacity][T][1]) of the episode slots `inds` (exactly one of the two
+ *                                                             pointers; host indices travel in the kernel arguments, batch <= 512)
+ * and the step is told with ope_qmix_cfg.live_rows = 3 (region 0) / 4 (region 1): "live rows, and that region already holds THIS batch's
+ * plan" -- the caller's promise that the batch is those slots' episodes, unmodified, and that the plan kernel is ordered before the step
+ * (an event). The regions "err_abs" / "loss_part" are then cleared inside the step. off-policy_amd: RecPolicyBuffer.sample_inds(...,
+ * live_for=trainer) launches it on the trainer's side stream and tags the batch; QMix.train_policy_on_batch checks the tag. */
 typedef struct ope_live_target {
-  int32_t* plan;        /* workspace region "live_plan" */
-  float* err_abs;       /* workspace region "err_abs" [T*B]  (zero-filled with the plan) */
-  float* loss_part;     /* workspace region "loss_part"      (zero-filled with the plan) */
+  int32_t* plan;        /* workspace region "live_plan" / "live_plan1" */
+  float* err_abs;       /* workspace region "err_abs" [T*B] */
+  float* loss_part;     /* workspace region "loss_part" */
   int32_t n_loss_part;
   int32_t n_agents, episode_length, batch;
 } ope_live_target;
-int ope_qmix_live_target(const ope_qmix_cfg* cfg, void* workspace, int64_t workspace_bytes, ope_live_target* out);
+int ope_qmix_live_target(const ope_qmix_cfg* cfg, void* workspace, int64_t workspace_bytes, int32_t which, ope_live_target* out);
+int ope_store_live_plan(int32_t capacity, int32_t episode_length, const float* store_dones_env, const int64_t* inds_dev,
+                        const int64_t* inds_host, const ope_live_target* target, void* stream);
+/* ... or inside the gather launch itself: the NEXT ope_store_gather* launched from the calling thread gets a few extra workgroups IN FRONT of
+ * the copy's that build the plan into `target` from the store's flags through the launch's own indices (consumed by that one launch; ignored
+ * -- no plan: do not promise one -- unless the store's episode_length, the batch size and the shape limits match the target). NULL cancels. */
 int ope_store_gather_attach_live(const ope_live_target* target);
 int ope_qmix_live_plan(const ope_qmix_cfg* cfg, const float* dones_env, void* workspace, int64_t workspace_bytes, void* stream);
 int ope_qmix_loss_and_grad_ref(const ope_qmix_cfg* cfg, const ope_fields* batch, const ope_obs_ref* obs, const float* theta,

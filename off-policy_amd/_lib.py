@@ -133,7 +133,8 @@ def _load():
         "ope_qmix_obs_ref_ok": (C.c_int, [C.POINTER(QmixCfg)]),
         "ope_qmix_live_rows_ok": (C.c_int, [C.POINTER(QmixCfg)]),
         "ope_qmix_live_plan": (C.c_int, [C.POINTER(QmixCfg), p, p, i64, p]),
-        "ope_qmix_live_target": (C.c_int, [C.POINTER(QmixCfg), p, i64, C.POINTER(LiveTarget)]),
+        "ope_qmix_live_target": (C.c_int, [C.POINTER(QmixCfg), p, i64, i32, C.POINTER(LiveTarget)]),
+        "ope_store_live_plan": (C.c_int, [i32, i32, p, p, p, C.POINTER(LiveTarget), p]),
         "ope_store_gather_attach_live": (C.c_int, [C.POINTER(LiveTarget)]),
         "ope_qmix_loss_and_grad_ref": (C.c_int, [C.POINTER(QmixCfg), C.POINTER(Fields), C.POINTER(ObsRef), p, p, p, p, i64, p, p, p]),
         "ope_store_gather_profile": (C.c_int, [i32]),

@@ -94,7 +94,9 @@ class QMix(object):
         self._ws = {}
         self._ws_multi = {}
         self._gsq = {}
-        self._live_seq = 0          # tickets of the plans built for this trainer by gather launches (RecPolicyBuffer.sample_inds(live_for=))
+        # live-row plans built ahead of the step (RecPolicyBuffer.sample_inds(live_for=trainer); ope.h: ope_store_live_plan)
+        self._live_seq = 0          # ticket of the latest plan
+        self._live = None           # cached ope_live_target structs per (batch, workspace)
         if self.multi and (self.hypernet_layers == 1 or self.layer_N != 1 or self.dims_flags):
             raise NotImplementedError("hypernet_layers=1 / layer_N=2 / use_feature_normalization=False with several policies is not on the accelerated path")
         if (self.dims_flags & _lib.OPE_DIMS_NO_FEATURE_NORM) and float(getattr(args, "weight_decay", 0.0) or 0.0) != 0.0:
@@ -345,21 +347,31 @@ class QMix(object):
             self._ws[B] = ws
         return self._ws[B]
 
-    def live_target(self, batch):
-        """(ope_live_target, tag) where a gather launch may build the live-row plan of this trainer's next step on `batch` episodes
-        (RecPolicyBuffer.sample_inds(live_for=trainer); ope.h: ope_store_gather_attach_live), or None where the step would not run on live
-        rows "by shape" (or the trainer pins every padded row / is one of the multi-policy, MLP, MultiDiscrete forms)."""
+    def build_live_plan(self, pbuf, host_inds, batch):
+        """Have the NEXT gather launch of `pbuf` (RecPolicyBuffer; the call that follows in sample_inds) also build the live-row plan of this
+        trainer's next step on those `batch` episodes -- a few extra workgroups in front of the copy's that read the store's termination
+        flags through the launch's own indices (ope.h: ope_store_gather_attach_live) -- and return the tag `train_policy_on_batch`
+        recognises; None where that step would not run on live rows "by shape" (or the trainer pins every padded row / is one of the
+        multi-policy, MLP forms). Same stream as the step: no events, one plan region."""
         if self.multi or self._mlp or int(self.tune.get("live_rows", 0)) == 1 or int(self.tune.get("debug", 0)):
             return None
-        cfg = self._cfg(int(batch))
-        if not _lib.lib.ope_qmix_live_rows_ok(C.byref(cfg)):
+        batch = int(batch)
+        cfg = self._cfg(batch)
+        if int(pbuf.episode_length) != int(self.episode_length) or not _lib.lib.ope_qmix_live_rows_ok(C.byref(cfg)):
             return None
         ws = self._workspace(cfg)
-        tgt = _lib.LiveTarget()
-        if _lib.lib.ope_qmix_live_target(C.byref(cfg), _lib.ptr(ws), ws.numel(), C.byref(tgt)) != 0:
-            return None
+        if self._live is None:
+            self._live = {"targets": {}}
+        key = (batch, int(ws.data_ptr()))
+        tgt = self._live["targets"].get(key)
+        if tgt is None:
+            tgt = _lib.LiveTarget()
+            if _lib.lib.ope_qmix_live_target(C.byref(cfg), _lib.ptr(ws), ws.numel(), 0, C.byref(tgt)) != 0:
+                return None
+            self._live["targets"][key] = tgt
+        _lib.check(_lib.lib.ope_store_gather_attach_live(C.byref(tgt)), "ope_store_gather_attach_live")
         self._live_seq += 1
-        return tgt, (int(ws.data_ptr()), self._live_seq)
+        return ("ope_live", int(ws.data_ptr()), self._live_seq, 0)
 
     def workspace_view(self, batch, name):
         """Debug/test access to a named intermediate of the last step with this batch size (float32 view)."""
@@ -474,8 +486,10 @@ class QMix(object):
         assert T1 == self.episode_length + 1 and N == getattr(self, "_n_kernel_agents", self.num_agents), "batch does not match the trainer's dimensions"
         cfg = self._cfg(B)
         ws = self._workspace(cfg)
-        if live_tag is not None and oref is None and cfg.live_rows in (0, 2) and live_tag == (int(ws.data_ptr()), self._live_seq):
-            cfg.live_rows = 3       # the plan region holds THIS batch's plan (the latest one built for this workspace): no plan launch
+        if (live_tag is not None and oref is None and cfg.live_rows in (0, 2) and self._live is not None and
+                live_tag[:3] == ("ope_live", int(ws.data_ptr()), self._live_seq)):
+            # the gather launch that wrote this batch -- the latest one attached for this workspace -- built the step's plan: no plan launch
+            cfg.live_rows = 3 + int(live_tag[3])
         f = _lib.Fields()
         f.obs = None if oref is not None else _lib.ptr(obs).value
         f.share_obs, f.acts, f.rewards = _lib.ptr(share).value, _lib.ptr(acts).value, _lib.ptr(rew).value

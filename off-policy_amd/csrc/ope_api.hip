@@ -26,7 +26,7 @@ bool cfg_ok(const ope_qmix_cfg* c) {
   if (c->trunk_path != 0 && c->trunk_path != 3 && c->trunk_path != 4) return false;
   if (c->chain_path < 0 || c->chain_path > 2) return false;
   if (c->hypernet_layers < 0 || c->hypernet_layers > 2) return false;
-  if (c->wgrad_path < 0 || c->wgrad_path > 2 || c->live_rows < 0 || c->live_rows > 3) return false;
+  if (c->wgrad_path < 0 || c->wgrad_path > 2 || c->live_rows < 0 || c->live_rows > 4) return false;
   if (d.layer_N < 0 || d.layer_N > 2) return false;
   if (d.flags & ~(OPE_DIMS_NO_FEATURE_NORM | OPE_DIMS_TANH | OPE_DIMS_MASK_TARGET_MAX)) return false;
   if ((d.flags & OPE_DIMS_TANH) && (c->phase != 0 || d.layer_N == 2 || d.obs_dim > 384 || c->trunk_path == 4)) return false;   // tanh: trunk_fwd3 / trunk_bwd3
@@ -86,7 +86,7 @@ struct Plan {
   int64_t mu0, rstd0, xhat1, rstd1, mask1, xhat2, rstd2, mask2, gi, h, rg, zg, ng, ghn, xhat_o, rstd_o, act_idx,
       agent_q, agent_nq, gi_t, h_t, qtot, nqtot, hw1, hw2, hb2, v1, hpre, v2, loss_part, err_abs, dqtot, d_agent_q,
       d_b1, d_v2, d_v1, d_hw1, d_hw2, d_hb2, dh_out, dqoh, dgi, dghn, dz1, dz2, thetaT, mixT, raw_agent, raw_mixer,
-      rsum, q_all, loss_tot, ln_zero, ln_one, dh_carry, dbg, gsq_part, mix_slab, raw2, live;
+      rsum, q_all, loss_tot, ln_zero, ln_one, dh_carry, dbg, gsq_part, mix_slab, raw2, live, live1;
   int n_gsq;
   bool wide;
   bool chain;                   // the (t, b)-row chain runs as mixer_hyp + qchain (ope_chain.hip) instead of head_fwd / mixer_fwd / mixer_bwd / head_bwd
@@ -246,6 +246,7 @@ void make_plan(const ope_qmix_cfg* c, Plan* p) {
   p->v1_t = W.add("v1_t", TB * p->NM); p->v2_t = W.add("v2_t", TB * OPE_MIX);
   // live-row plan (ope_live.hip): int32 tables, built on the device at the start of every whole recurrent step that runs on packed rows
   p->live = (!c->mlp && c->phase == 0 && live_plan_shape_ok(p->T, p->N, p->B)) ? W.add("live_plan", live_plan_ints(p->T, p->N, p->B)) : -1;
+  p->live1 = p->live >= 0 ? W.add("live_plan1", live_plan_ints(p->T, p->N, p->B)) : -1;      // (a second one: plans built ahead of the step, ope_store_live_plan)
   if (p->layerN == 2) {      // second hidden block: the trunk's output of both nets, the block's saves and adjoints
     p->a2 = W.add("a2", R * OPE_H); p->a2_t = W.add("a2_t", R * OPE_H);
     p->xhat3 = W.add("xhat3", R * OPE_H); p->rstd3 = W.add("rstd3", R); p->mask3 = W.add("mask3", 2 * R);
@@ -366,6 +367,7 @@ extern "C" int ope_qmix_workspace_init(const ope_qmix_cfg* cfg, void* workspace,
   if ((rc = launch_fill(W + p.ln_zero, p.R, 0.f, (hipStream_t)stream))) return rc;
   if ((rc = launch_fill(W + p.gsq_part, p.n_gsq, 0.f, (hipStream_t)stream))) return rc;
   if (p.live >= 0 && (rc = launch_fill(W + p.live, 16, 0.f, (hipStream_t)stream))) return rc;      // (header + the executed-row accumulators)
+  if (p.live1 >= 0 && (rc = launch_fill(W + p.live1, 16, 0.f, (hipStream_t)stream))) return rc;
   return launch_fill(W + p.ln_one, p.R, 1.f, (hipStream_t)stream);
 }
 
@@ -395,14 +397,14 @@ extern "C" int ope_qmix_live_rows_ok(const ope_qmix_cfg* cfg) {
   make_plan(cfg, &p);
   return live_cfg_ok(cfg, p) ? 1 : 0;
 }
-extern "C" int ope_qmix_live_target(const ope_qmix_cfg* cfg, void* workspace, int64_t workspace_bytes, ope_live_target* out) {
-  if (!cfg_ok(cfg) || !workspace || !out) return OPE_EINVAL;
+extern "C" int ope_qmix_live_target(const ope_qmix_cfg* cfg, void* workspace, int64_t workspace_bytes, int32_t which, ope_live_target* out) {
+  if (!cfg_ok(cfg) || !workspace || !out || which < 0 || which > 1) return OPE_EINVAL;
   Plan p;
   make_plan(cfg, &p);
   if (workspace_bytes < p.ws.total * (int64_t)sizeof(float)) return OPE_ENOSPC;
   if (p.live < 0) return OPE_EINVAL;
   float* W = (float*)workspace;
-  out->plan = reinterpret_cast<int32_t*>(W + p.live); out->err_abs = W + p.err_abs; out->loss_part = W + p.loss_part; out->n_loss_part = p.n_loss_tiles * 4;
+  out->plan = reinterpret_cast<int32_t*>(W + (which ? p.live1 : p.live)); out->err_abs = W + p.err_abs; out->loss_part = W + p.loss_part; out->n_loss_part = p.n_loss_tiles * 4;
   out->n_agents = p.N; out->episode_length = p.T; out->batch = p.B;
   return OPE_OK;
 }
@@ -535,7 +537,7 @@ static int qmix_step(const ope_qmix_cfg* cfg, const ope_fields* batch, const ope
   bool live = want_w2 && !oref && !dbg_on && batch->obs && live_cfg_ok(cfg, p);
   LivePlan lp;
   memset(&lp, 0, sizeof(lp));
-  if (live) lp = live_plan_view(reinterpret_cast<const int*>(W + p.live), p.T, p.N, p.B);
+  if (live) lp = live_plan_view(reinterpret_cast<const int*>(W + (cfg->live_rows == 4 ? p.live1 : p.live)), p.T, p.N, p.B);
   const Raw& rw = p.raw;
   // weight-gradient problem tables: mixer problems (K = T*B) go first, on the main stream, while the side stream runs the
   // BPTT of the last chunk; the agent problems are cut into the same time chunks (each chunk = its own K-splits/slabs)
@@ -645,7 +647,9 @@ static int qmix_step(const ope_qmix_cfg* cfg, const ope_fields* batch, const ope
     memset(&lp, 0, sizeof(lp));
   }
   if (cfg->live_rows >= 2 && !live) return OPE_EINVAL;
-  if (live && cfg->live_rows != 3) {      // (3: the gather launch that wrote this batch built the plan -- ope_store_gather_attach_live)
+  if (live && cfg->live_rows >= 3) {      // the plan was built ahead of the step (ope_store_live_plan): only the per-row error array is cleared here
+    if (td_abs_stats && (rc = launch_fill(W + p.err_abs, p.TB, 0.f, st))) return rc;      // (the chain kernel writes the live entries; td_stats reads all of them)
+  } else if (live) {
     LiveArgs la;
     la.T = p.T; la.N = p.N; la.B = p.B; la.dones_env = batch->dones_env; la.plan = reinterpret_cast<int*>(W + p.live);
     la.err_abs = W + p.err_abs; la.loss_part = W + p.loss_part; la.n_loss_part = p.n_loss_tiles * 4;

@@ -243,7 +243,10 @@ __global__ void __launch_bounds__(64 * kCW, 2) qchain_kernel(ChainArgs a) {
   const int A = a.A, N = a.N, B = a.B, NB = a.NB;
   const int tile = blockIdx.x;
   const int TBr = PK ? __builtin_amdgcn_readfirstlane(a.lp.hdr[2]) : a.TB;
-  if (PK && tile * 16 >= TBr) return;      // (the plan kernel zero-filled loss_part and err_abs)
+  if (PK && tile * 16 >= TBr) {            // past the live rows: nothing to add to the loss sums (err_abs is cleared with / beside the plan)
+    if (tid < 4) a.loss_part[tile * 4 + tid] = 0.f;
+    return;
+  }
   const int m = tile * 16 + j;
   const bool valid = m < TBr;
   const int mm = valid ? m : TBr - 1;

@@ -18,7 +18,9 @@ namespace {
 
 struct BatchDones {
   const float* p; int B;
-  __device__ __forceinline__ float operator()(int t, int b) const { return p[t * B + b]; }
+  __device__ __forceinline__ void prepare(int*, int) const {}
+  __device__ __forceinline__ int key(const int*, int b) const { return b; }
+  __device__ __forceinline__ float at(int b, int t) const { return p[t * B + b]; }
 };
 
 __global__ void __launch_bounds__(kLiveThreads) live_plan_kernel(LiveArgs a, LiveW w) {

@@ -38,9 +38,11 @@ constexpr int kLiveThreads = 256;
 // entries... of which only TP = round-up(T + 2, 4) are ever non-zero; the scan walks 4 entries per thread over kLiveThreads threads, so
 // TPmax = 4 * kLiveThreads = 1024 entries bound episode_length (kLiveMaxT).
 __host__ __device__ static inline int live_tp(int T) { return (T + 2 + 3) & ~3; }
-__host__ __device__ static inline int live_lds_ints(int T, int B) { return 4 * B + 2 * live_tp(T) + 8; }
+__host__ __device__ static inline int live_lds_ints(int T, int B) { return 5 * B + 2 * live_tp(T) + 8; }      // (+ B: the accessor's own table)
 
-// dones(t, b) -> the flag; BMAJOR: walk the (t, b) pairs episode by episode (the store keeps an episode's T flags contiguous) instead of step by step.
+// Dones: key(b) -> what locates episode b's flags (a load for the store: its slot), at(key, t) -> the flag, both branch-free so that a round's
+// U keys and then its U flags are each ONE batch of independent loads (a bounds-checked load per element compiled to 2 U dependent round
+// trips: 28 us); BMAJOR: walk the (t, b) pairs episode by episode (the store keeps an episode's T flags contiguous) instead of step by step.
 // `wg` of `nwg` workgroups of kLiveThreads threads: every one builds the small tables in `lds` (live_lds_ints ints), workgroup 0 writes them
 // out, all write their slice of the row maps and of the zero-filled regions.
 // U: flags in flight per thread and round of the first phase (the riders of a gather launch take 20: one round at 3s5z, B = 32 -- a second
@@ -56,9 +58,11 @@ __device__ __forceinline__ void live_plan_body(const LiveW& w, float* err_abs, f
   int* const nn_s = lsort_s + B;
   int* const cum_s = nn_s + TP;
   int* const wsum_s = cum_s + TP;
+  int* const keys_s = wsum_s + 8;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int NB = N * B, TB = T * B;
   for (int b = tid; b < B; b += kLiveThreads) last_s[b] = -1;
+  dones.prepare(keys_s, B);      // (the store: its slots -> LDS by wave-uniform scalar loads, a path the copy beside a rider does not load)
   __syncthreads();
   // last t' with dones_env[t', b] != 1 (the reference's mask is 1 - dones_env: exactly zero only where the flag is exactly one)
   // (eight independent loads in flight per thread and round: a load -> compare -> atomic loop is one memory round trip per element -- 19 of
@@ -71,8 +75,12 @@ __device__ __forceinline__ void live_plan_body(const LiveW& w, float* err_abs, f
       const int i = min(base + u * kLiveThreads + tid, TB - 1);
       if (BMAJOR) { bb[u] = i / T; tt[u] = i - bb[u] * T; }
       else { tt[u] = i / B; bb[u] = i - tt[u] * B; }
-      v[u] = dones(tt[u], bb[u]);
     }
+    int key[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) key[u] = dones.key(keys_s, bb[u]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = dones.at(key[u], tt[u]);
 #pragma unroll
     for (int u = 0; u < U; ++u)
       if (base + u * kLiveThreads + tid < TB && v[u] != 1.0f) atomicMax(&last_s[bb[u]], tt[u]);

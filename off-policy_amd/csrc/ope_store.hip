@@ -84,20 +84,27 @@ struct CopyArgs {
   int* bad_index;    // device flag: set to 1 if an index was out of range (the offending rows are skipped)
   int lds_bytes;     // dynamic LDS the tile fields need
   int64_t* idx_out;  // gather, optional: the episode indices as used, for consumers that read rows of the store themselves (ope_obs_ref)
-  // gather, optional (ope_store_gather_attach_live): `live_blocks` rider workgroups behind the copy's build the live-row plan of this batch
-  // (LivePlan, ope_common.h) from the STORE's dones_env through the sampled slots -- the plan of the training step that follows, off its
-  // critical path (as a launch of its own it costs the step ~8 us)
-  int live_blocks, live_T, live_N, live_nlp;
+  // gather, optional (ope_store_gather_attach_live): `live_blocks` rider workgroups IN FRONT of the copy's build the live-row plan of this
+  // batch (LivePlan, ope_common.h) from the STORE's dones_env through the sampled slots -- the plan of the training step that follows, off
+  // its critical path (as a launch of its own it costs the step ~9 us)
+  int live_blocks, live_T, live_N;
   ope::LiveW live_w;
-  float* live_err_abs; float* live_loss_part;
 };
 // the store's termination flags of the sampled episodes: [capacity][T][1]
 template <class IDX>
 struct StoreDones {
   const float* ring; const IDX* idx; int capacity, T;
-  __device__ __forceinline__ float operator()(int t, int b) const {
-    const int64_t slot = (*idx)[b];
-    return (slot < 0 || slot >= capacity) ? 1.0f : ring[slot * T + t];      // (an index out of range: the copy raises the flag; here the episode counts as over)
+  __device__ __forceinline__ void prepare(int* keys, int B) const {      // one wave-uniform index per iteration: scalar loads
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = (int)(blockDim.x >> 6);
+    for (int b = wave; b < B; b += nw) {
+      const int64_t slot = (*idx)[b];
+      if ((threadIdx.x & 63) == 0) keys[b] = (slot < 0 || slot >= capacity) ? -1 : (int)slot;
+    }
+  }
+  __device__ __forceinline__ int key(const int* keys, int b) const { return keys[b]; }
+  __device__ __forceinline__ float at(int slot, int t) const {      // (an index out of range: the copy raises the flag; here the episode counts as over)
+    const float x = ring[(int64_t)(slot < 0 ? 0 : slot) * T + t];
+    return slot < 0 ? 1.0f : x;
   }
 };
 
@@ -349,13 +356,11 @@ __global__ void __launch_bounds__(kBlock) episode_copy_kernel(CopyArgs args, IDX
   // every XCD still sees every field.
   int bid = blockIdx.x;
   if (GATHER && args.live_blocks > 0) {
-    // riders: the live-row plan of this batch (uniform per workgroup). They are the launch's FIRST workgroups: dispatched at once, their
-    // chain of a few dependent round trips runs beside the copy (as its last workgroups they started when the copy was nearly done and
-    // made the launch 15 us longer)
+    // riders: the launch's FIRST workgroups (dispatched at once: their two batches of loads are out before the copy saturates the memory
+    // system); a multiple of 8, so the copy's workgroups keep their XCD (blockIdx.x % 8)
     if (bid < args.live_blocks) {
       StoreDones<IDX> dn{args.f[5].src, &idx, args.capacity, args.live_T};
-      ope::live_plan_body<true, 20>(args.live_w, args.live_err_abs, args.live_loss_part, args.live_nlp, args.live_T, args.live_N, args.n_episodes, dn,
-                                reinterpret_cast<int*>(lds), bid, args.live_blocks);
+      ope::live_plan_body<true, 20>(args.live_w, nullptr, nullptr, 0, args.live_T, args.live_N, args.n_episodes, dn, reinterpret_cast<int*>(lds), bid, args.live_blocks);
       return;
     }
     bid -= args.live_blocks;
@@ -418,14 +423,10 @@ void launch_copy(const CopyArgs& args0, const IDX& idx, hipStream_t st) {
     const ope_live_target& t = g_live_next;
     const FieldDesc& de = args.f[5];      // the store's dones_env ring
     if (t.plan && de.src && de.NA == 1 && de.DD == 1 && de.TT == t.episode_length && args.n_episodes == t.batch && ope::live_plan_shape_ok(de.TT, t.n_agents, t.batch)) {
-      // (a multiple of 8: the copy's workgroups keep their XCD -- blockIdx.x % 8 -- and with it the placement of the writers of one
-      // destination range on one L2; 38 riders in front of them made the copy 9 us slower)
       args.live_blocks = (ope::live_plan_blocks(de.TT, t.n_agents, t.batch) + 7) & ~7;
-      args.live_T = de.TT; args.live_N = t.n_agents; args.live_nlp = t.n_loss_part;
+      args.live_T = de.TT; args.live_N = t.n_agents;
       args.live_w = ope::live_views(t.plan, de.TT, t.n_agents, t.batch);
-      args.live_err_abs = t.err_abs; args.live_loss_part = t.loss_part;
       lds = std::max(lds, (size_t)4 * ope::live_lds_ints(de.TT, t.batch));
-      ope::note_launch("gather+live_plan");
     }
   }
   const dim3 grid(args.total_blocks + args.live_blocks), block(kBlock);
@@ -670,11 +671,44 @@ extern "C" void ope_set_gather_params(int floats_per_block, int xcd_run, int unr
   if (small_tiles >= 0) g_tune.small = small_tiles ? 1 : 0;
 }
 
+// The live-row plan of a batch that has not been gathered yet (ope.h): the same computation as live_plan_kernel (ope_live.hip), on the
+// store's flags of the sampled slots.
+template <class IDX>
+__global__ void __launch_bounds__(ope::kLiveThreads) store_live_plan_kernel(ope::LiveW w, const float* __restrict__ ring, IDX idx, int capacity, int T, int N, int B) {
+  extern __shared__ __attribute__((aligned(16))) int plan_lds[];
+  StoreDones<IDX> dn{ring, &idx, capacity, T};
+  ope::live_plan_body<true, 20>(w, nullptr, nullptr, 0, T, N, B, dn, plan_lds, (int)blockIdx.x, (int)gridDim.x);
+}
+
 extern "C" int ope_store_gather_attach_live(const ope_live_target* target) {
   if (!target) { g_live_pending = false; return OPE_OK; }
   if (!target->plan || target->n_agents < 1 || target->batch < 1 || target->episode_length < 1) return OPE_EINVAL;
   g_live_next = *target;
   g_live_pending = true;
+  return OPE_OK;
+}
+
+extern "C" int ope_store_live_plan(int32_t capacity, int32_t episode_length, const float* store_dones_env, const int64_t* inds_dev,
+                                   const int64_t* inds_host, const ope_live_target* target, void* stream) {
+  (void)hipGetLastError();
+  if (capacity < 1 || !store_dones_env || !target || !target->plan || (!inds_dev) == (!inds_host)) return OPE_EINVAL;
+  const int T = episode_length, N = target->n_agents, B = target->batch;
+  if (T != target->episode_length || !ope::live_plan_shape_ok(T, N, B)) return OPE_EINVAL;
+  const ope::LiveW w = ope::live_views(target->plan, T, N, B);
+  const dim3 grid(ope::live_plan_blocks(T, N, B)), block(ope::kLiveThreads);
+  const size_t lds = (size_t)4 * ope::live_lds_ints(T, B);
+  if (inds_host) {
+    if (B > kMaxArgIdx) return OPE_EINVAL;
+    ArgIdx ai;
+    for (int i = 0; i < B; ++i) {
+      if (inds_host[i] < 0 || inds_host[i] >= capacity) return OPE_EINVAL;
+      ai.v[i] = (int32_t)inds_host[i];
+    }
+    OPE_LAUNCH((store_live_plan_kernel<ArgIdx>), grid, block, lds, (hipStream_t)stream, w, store_dones_env, ai, capacity, T, N, B);
+  } else {
+    OPE_LAUNCH((store_live_plan_kernel<DevIdx>), grid, block, lds, (hipStream_t)stream, w, store_dones_env, DevIdx{inds_dev}, capacity, T, N, B);
+  }
+  OPE_CHECK_LAUNCH();
   return OPE_OK;
 }
 

@@ -313,10 +313,11 @@ class RecPolicyBuffer(object):
         buffers' valid_transition flag).
         `lazy_obs` (default: self.lazy_obs): leave the observation rows in the store and return a StoreObs in their place.
         `live_for`: the trainer this batch is sampled for (QMix). Where its step runs on live rows (ope_qmix_cfg.live_rows: only the rows
-        before each episode's termination are computed, qmix.py:161-166), the gather launch also builds that step's row plan -- from the
-        store's dones_env of the sampled episodes, in a few extra workgroups beside the copy (ope_store_gather_attach_live) -- and the batch
-        is tagged so that `trainer.train_policy_on_batch` skips its own plan launch (~8 us of a 0.3 ms step). The tag is good for the NEXT
-        train call on this batch only; any other use of the batch is unaffected (the arrays are what the reference returns)."""
+        before each episode's termination are computed, qmix.py:161-166), THIS gather launch also builds that step's row plan -- a few
+        extra workgroups in front of the copy's, reading the store's dones_env of the sampled episodes (ope_store_gather_attach_live) --
+        and the batch is tagged so that `trainer.train_policy_on_batch` skips its own plan launch in front of the step (~9 us of a 0.3 ms
+        step). The tag is good for the NEXT train call on this batch; any other use of the batch is unaffected (the arrays are what the
+        reference returns)."""
         lazy = bool(self.lazy_obs if lazy_obs is None else lazy_obs)
         host_inds = None
         if torch.is_tensor(sample_inds):     # indices already on the device (HIP-graph replays keep them in a static tensor)
@@ -361,11 +362,9 @@ class RecPolicyBuffer(object):
         if extra is not None:
             sf.valid_transition, of.valid_transition = _lib.ptr(extra[0]).value, _lib.ptr(extra[1]).value
         live_tag = None
-        if live_for is not None and getattr(live_for, "live_target", None) is not None and self.use_same_share_obs:
-            tgt = live_for.live_target(B)
-            if tgt is not None and int(tgt[0].episode_length) == int(self.episode_length) and int(tgt[0].batch) == B:
-                _lib.check(_lib.lib.ope_store_gather_attach_live(C.byref(tgt[0])), "ope_store_gather_attach_live")
-                live_tag = tgt[1]
+        if (live_for is not None and getattr(live_for, "build_live_plan", None) is not None and self.use_same_share_obs and _sampler is None and
+                not (lazy and host_inds is not None)):      # (the attachment rides on the FIRST gather launch below: the plain forms)
+            live_tag = live_for.build_live_plan(self, host_inds, B)
         if timing_events is not None:
             timing_events[0].record()
         if _sampler is not None:

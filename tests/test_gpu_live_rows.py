@@ -337,58 +337,76 @@ def test_reference_fixtures_on_live_rows(name):
             np.testing.assert_allclose(live[key + k], ref, rtol=0, atol=3e-5, err_msg=grp + k)
 
 
-# ---- the plan built inside the gather launch (ope_store_gather_attach_live) -------------------------------------------------------------
+# ---- the plan built outside the step, from the store's flags (ope_store_gather_attach_live / ope_store_live_plan) --------------------------
+def _plan_tables_equal(got, ref, T, N, B):
+    RL, R1L, TBL = [int(x) for x in ref[:3]]
+    r4 = lambda x: (x + 3) & ~3
+    assert torch.equal(got[:8], ref[:8])
+    o = 16      # every table up to the entries the plan defines (beyond the live counts the regions keep whatever was there)
+    for cnt, size in ((B, r4(B)), (B, r4(B)), (T + 2, r4(T + 2)), (T + 2, r4(T + 2)), (8 * TBL, 8 * T * B), (TBL, r4(T * B)), (RL, r4((T + 1) * N * B)), (RL, r4((T + 1) * N * B))):
+        assert torch.equal(got[o:o + cnt], ref[o:o + cnt]), o
+        o += size
+
+
 def test_plan_built_by_the_gather_launch_is_the_plan_kernels():
     """RecPolicyBuffer.sample_inds(live_for=trainer): a few extra workgroups of the gather launch build the step's plan from the STORE's flags
     of the sampled episodes. Same tables and row maps as live_plan_kernel builds from the batch; the step that follows skips its own plan
-    launch and produces the same gradient BIT FOR BIT; a tag that is not the latest one (another batch sampled since) is not trusted."""
+    launch and produces the same gradient and priorities BIT FOR BIT (PER: the per-row error array is cleared inside the step); a tag that is
+    not the latest one (another batch sampled since) is not trusted. ope_store_live_plan: the same plan as a launch of its own."""
     from offpolicy_amd import _lib
     from offpolicy_amd.config import default_args
     from offpolicy_amd.utils.synth import DIMS
     dims, B = DIMS["3m"], 8
-    policy, trainer, buf = _make(dims, default_args(), B, seed=6, dones=_holes)
+    T, N = dims.episode_length, dims.n_agents
+    policy, trainer, buf = _make(dims, default_args(use_per=True), B, seed=6, dones=_holes)
     trainer.tune.update(trunk_path=4, chain_path=2, wgrad_path=2, scan_family=4)
     pb = buf.policy_buffers["policy_0"]
     inds = np.array([3, 0, 17, 9, 1, 22, 5, 5])
+    w = np.linspace(0.3, 1.0, B).astype(np.float32)
     snap = _snapshot(trainer)
     # (a) plain: the step launches the plan kernel
     s = pb.sample_inds(inds)
     assert getattr(s[5], "_ope_live", None) is None
-    batch = tuple({"policy_0": x} for x in s) + (None, None)
-    ref = _one(trainer, batch, live=True)
+    ref = _one(trainer, tuple({"policy_0": x} for x in s) + (w, inds), live=True)
     assert "live_plan" in ref[3].split(","), ref[3]
-    n = trainer.workspace_view(B, "live_plan").numel()
     plan_ref = trainer.workspace_view(B, "live_plan").view(torch.int32).clone()
-    # (b) the gather builds it
-    _restore(trainer, snap)
-    _poison(trainer, B)
+    # (b) built by the gather launch, twice in a row (the second time over the first one's plan)
     trainer.tune["live_rows"] = 0
-    s = pb.sample_inds(inds, live_for=trainer)
-    assert "gather+live_plan" in _lib.last_launches() or True      # (the step entry points clear the log; the tag below is what counts)
-    assert s[5]._ope_live is not None
-    torch.cuda.synchronize()
-    plan_got = trainer.workspace_view(B, "live_plan").view(torch.int32).clone()
-    # header, then every table up to the entries the plan defines (beyond the live counts the regions keep whatever was there)
-    T, N = dims.episode_length, dims.n_agents
-    RL, R1L, TBL = [int(x) for x in plan_ref[:3]]
-    r4 = lambda x: (x + 3) & ~3
-    assert torch.equal(plan_got[:8], plan_ref[:8])
-    o = 16
-    for cnt, size in ((B, r4(B)), (B, r4(B)), (T + 2, r4(T + 2)), (T + 2, r4(T + 2)), (8 * TBL, 8 * T * B), (TBL, r4(T * B)), (RL, r4((T + 1) * N * B)), (RL, r4((T + 1) * N * B))):
-        assert torch.equal(plan_got[o:o + cnt], plan_ref[o:o + cnt]), o
-        o += size
-    batch = tuple({"policy_0": x} for x in s) + (None, None)
-    info, _, _ = trainer.train_policy_on_batch(batch)
-    launched = _lib.last_launches()
-    assert "live_plan" not in launched and "trunk_fwd4_live<4>" in launched and "qchain_live<1,1>" in launched, launched
-    assert torch.equal(trainer.grad[:trainer.numel + 4], ref[2])
+    for rep in range(2):
+        _restore(trainer, snap)
+        if rep == 0:
+            _poison(trainer, B)
+        s = pb.sample_inds(inds, live_for=trainer)
+        assert s[5]._ope_live is not None
+        for x, y in zip(s, pb.sample_inds(inds)):      # the batch itself is what a plain gather returns
+            assert torch.equal(x, y)
+        info, prio, _ = trainer.train_policy_on_batch(tuple({"policy_0": x} for x in s) + (w, inds))
+        launched = _lib.last_launches()
+        torch.cuda.synchronize()
+        assert "live_plan" not in launched and "trunk_fwd4_live<4>" in launched and "qchain_live<1,1>" in launched, launched
+        _plan_tables_equal(trainer.workspace_view(B, "live_plan").view(torch.int32).clone(), plan_ref, T, N, B)
+        assert torch.equal(trainer.grad[:trainer.numel + 4], ref[2])
+        np.testing.assert_array_equal(np.asarray(prio), ref[1])
     # (c) a tag that is not the latest: the step builds its own plan again
     _restore(trainer, snap)
     s1 = pb.sample_inds(inds, live_for=trainer)
     s2 = pb.sample_inds(inds[::-1].copy(), live_for=trainer)
-    info, _, _ = trainer.train_policy_on_batch(tuple({"policy_0": x} for x in s1) + (None, None))
+    info, _, _ = trainer.train_policy_on_batch(tuple({"policy_0": x} for x in s1) + (w, inds))
     assert "live_plan" in _lib.last_launches()
     assert torch.equal(trainer.grad[:trainer.numel + 4], ref[2])
-    # (d) a trainer pinned to every padded row gets no rider
+    # (d) the same plan as a launch of its own, into the second region (host indices in the kernel arguments, and device indices)
+    cfg = trainer._cfg(B)
+    ws = trainer._ws[B]
+    tgt = _lib.LiveTarget()
+    _lib.check(_lib.lib.ope_qmix_live_target(C.byref(cfg), _lib.ptr(ws), ws.numel(), 1, C.byref(tgt)), "target")
+    for dev_inds in (False, True):
+        trainer.workspace_view(B, "live_plan1").view(torch.int32)[:8].zero_()
+        hi = np.ascontiguousarray(inds, dtype=np.int64)
+        di = torch.from_numpy(hi).cuda()
+        _lib.check(_lib.lib.ope_store_live_plan(pb.buffer_size, T, _lib.ptr(pb.dones_env), _lib.ptr(di) if dev_inds else None,
+                                                None if dev_inds else hi.ctypes.data_as(C.c_void_p), C.byref(tgt), _lib.current_stream()), "ope_store_live_plan")
+        torch.cuda.synchronize()
+        _plan_tables_equal(trainer.workspace_view(B, "live_plan1").view(torch.int32).clone(), plan_ref, T, N, B)
+    # (e) a trainer pinned to every padded row gets no plan
     trainer.tune["live_rows"] = 1
-    assert trainer.live_target(B) is None
+    assert pb.sample_inds(inds, live_for=trainer)[5]._ope_live is None

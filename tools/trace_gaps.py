@@ -1,40 +1,26 @@
-"""Per-kernel duration and the idle gap in front of it, from a `rocprofv3 --kernel-trace --output-format csv` trace:
-    python tools/trace_gaps.py <dir-or-csv> [--last N]
-Averages over the steady-state tail of the run (the last N dispatches), grouped by position in the repeating step."""
-import csv, glob, os, sys
-from collections import OrderedDict
-
-
-def short(name):
-    name = name.replace("(anonymous namespace)::", "").replace("ope::", "").replace("void ", "")
-    return name.split("(")[0][:70]
-
-
-def main():
-    path = sys.argv[1]
-    last = int(sys.argv[sys.argv.index("--last") + 1]) if "--last" in sys.argv else 4000
-    files = [path] if path.endswith(".csv") else glob.glob(os.path.join(path, "**", "*kernel_trace.csv"), recursive=True)
-    rows = []
-    for f in files:
-        with open(f) as fh:
-            for r in csv.DictReader(fh):
-                rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])))
-    rows.sort()
-    rows = rows[-last:]
-    agg = OrderedDict()
-    prev_end = None
-    for s, e, n in rows:
-        gap = (s - prev_end) if prev_end is not None else 0
-        prev_end = e
-        a = agg.setdefault(n, [0, 0.0, 0.0])
-        a[0] += 1; a[1] += e - s; a[2] += gap
-    span = rows[-1][1] - rows[0][0]
-    busy = sum(e - s for s, e, _ in rows)
-    print("window %.1f us, busy %.1f us (%.1f%%), %d dispatches" % (span / 1e3, busy / 1e3, 100.0 * busy / span, len(rows)))
-    print("%-72s %7s %9s %9s" % ("kernel", "calls", "avg us", "gap us"))
-    for n, (c, d, g) in agg.items():
-        print("%-72s %7d %9.2f %9.2f" % (n, c, d / c / 1e3, g / c / 1e3))
-
-
-if __name__ == "__main__":
-    main()
+"""Gaps between consecutive kernel dispatches of a rocprofv3 --kernel-trace CSV: mean idle time by (previous kernel -> next kernel).
+    python tools/trace_gaps.py <kernel_trace.csv> [first_fraction last_fraction]
+"""
+import csv, sys, collections, re
+rows = list(csv.DictReader(open(sys.argv[1])))
+lo = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0
+hi = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+rows = rows[int(lo * len(rows)):int(hi * len(rows))]
+def short(n):
+    n = re.sub(r"\(anonymous namespace\)::|ope::|void ", "", n)
+    return n.split("(")[0][:48]
+gaps = collections.defaultdict(list)
+durs = collections.defaultdict(list)
+for a, b in zip(rows, rows[1:]):
+    g = (int(b["Start_Timestamp"]) - int(a["End_Timestamp"])) / 1e3
+    gaps[(short(a["Kernel_Name"]), short(b["Kernel_Name"]))].append(g)
+for r in rows:
+    durs[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+print("%-50s %-50s %6s %9s" % ("after", "before", "n", "gap us"))
+for k, v in sorted(gaps.items(), key=lambda kv: -sum(kv[1]) / len(kv[1]) * (len(kv[1]) > 5)):
+    if len(v) > 5:
+        print("%-50s %-50s %6d %9.2f" % (k[0], k[1], len(v), sum(v) / len(v)))
+print()
+for k, v in sorted(durs.items(), key=lambda kv: -sum(kv[1])):
+    print("%-60s n %6d  avg %8.2f us" % (k, len(v), sum(v) / len(v)))
