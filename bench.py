@@ -571,6 +571,14 @@ def main():
         torch.cuda.synchronize()
         bracket_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev[:20]]))
         gather_ms = float(np.mean(kernel_ms)) if kernel_ms else bracket_ms
+        # the copy on its own (no plan riders): 20 plain gather dispatches after the timed region, the same per-dispatch events
+        gather_profile(True, 1)
+        for _ in range(20):
+            pbuf.sample_inds(opdist.shard_indices(np.random.choice(len(buf), global_batch), rank, world))
+        torch.cuda.synchronize()
+        copy_ms = gather_profile_read()
+        gather_profile(False)
+        copy_only_ms = float(np.mean(copy_ms)) if copy_ms else None
         loss = float(info["loss"])
         # (timing-only kernel variants exist in libope_exp.so alone -- build.py --experiments, loaded through OPE_LIB_PATH --: only THAT library
         # may produce a non-finite loss without failing the run, and its lines are marked invalid below)
@@ -592,7 +600,7 @@ def main():
         live = live_row_stats(trainer, local_batch)       # rows the steps of this leg really ran (None: every padded row)
         results.append(dict(leg=leg, local_batch=local_batch, global_batch=global_batch, elapsed=elapsed, gather_ms=gather_ms, loss=loss,
                             graphed=graphed is not None, bracket_ms=bracket_ms, n_kernel_ms=len(kernel_ms), windows=windows, per_kernel=per_kernel,
-                            lazy_obs=bool(pbuf.lazy_obs), live=live))
+                            lazy_obs=bool(pbuf.lazy_obs), live=live, copy_only_ms=copy_only_ms, riders=bool(live) and not a.no_early_plan))
     # The same command on a store whose episodes all run the full T steps (dones_env = 1 at the last step only): nothing to skip, every row
     # of the padded batch is live -- what the step costs when the data offers no dead rows (guardrail ii). After every
     # other measurement: the store's flags are overwritten.
@@ -658,6 +666,13 @@ def main():
                          "timing": "mean kernel duration of %d gather dispatches of the timed region (every 4th launch from 16-step windows on: "
                                    "an event pair costs the stream ~3.5 us), from HIP start/stop events attached to the dispatch on its launch "
                                    "stream (hipExtLaunchKernel): the quantity rocprofv3's kernel trace reports" % r0["n_kernel_ms"],
+                         "carries": ("the launches of the timed region also build the step's live-row plan (rider workgroups in front of the copy's, "
+                                     "RecPolicyBuffer.sample_inds(live_for=trainer)): their duration is what `achieved` divides by; `copy_only` = the same "
+                                     "gather without them") if r0["riders"] else None,
+                         "copy_only": None if r0["copy_only_ms"] is None else {
+                             "avg_launch_ms": round(r0["copy_only_ms"], 5), "achieved": round(algo_bytes / (r0["copy_only_ms"] * 1e-3) / 1e9, 2),
+                             "frac": round(algo_bytes / (r0["copy_only_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                             "timing": "20 plain gather dispatches after the timed region, per-dispatch events"},
                          "avg_event_bracket_ms": round(r0["bracket_ms"], 5),
                          "frac_event_bracket": round(algo_bytes / (r0["bracket_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "event_bracket_note": "20 gathers after the timed region, interval between two HIP event markers recorded around "

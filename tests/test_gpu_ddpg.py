@@ -12,6 +12,7 @@ from test_ddpg_oracle_golden import CASES
 
 pytestmark = pytest.mark.gpu
 RTOL = 2e-4
+GRAD_TOL = 2e-5      # of each tensor's max magnitude: ~10x the worst error measured on the GPU, 1.5e-6 (config 3 at B = 256, both families; fused vs separate / graph vs eager: 2e-7) (round 6; was a blanket 2e-3; profiles/r06_parity_errors.txt)
 
 
 def build(g, device="cuda:0", same_share=True):
@@ -327,11 +328,8 @@ def test_config3_batch256_matches_oracle(td3, per):
             gc, ga, _ = trainer._grads[B]
             for mod, gvec, rg in ((policy.critic, gc, ref["critic_grads"]), (policy.actor, ga, ref["actor_grads"])):
                 got = _flat_grads(mod, gvec, mod.padded_numel)
-                for k, r in rg.items():
-                    if k not in got:
-                        continue
-                    scale = max(np.abs(r).max(), 1e-9)
-                    np.testing.assert_allclose(got[k], r, rtol=0, atol=2e-3 * scale + 1e-9, err_msg=k)
+                from golden_util import assert_grads_close
+                assert_grads_close("ddpg_config3:td3=%d" % int(td3), got, rg, GRAD_TOL, skip_missing=True)
     for mod, refp in ((policy.critic, orc.critic), (policy.actor, orc.actor), (policy.target_critic, orc.critic_tgt),
                       (policy.target_actor, orc.actor_tgt)):
         for k, v in params_of(mod).items():
@@ -401,7 +399,8 @@ def test_device_noise_same_stream_on_both_paths_and_right_distribution(tmp_path)
     for k in ("gc", "ga"):
         a, b = outs["1"][k], outs["0"][k]
         assert np.abs(b).max() > 0
-        np.testing.assert_allclose(a, b, rtol=0, atol=2e-3 * np.abs(b).max(), err_msg=k)
+        from golden_util import assert_grads_close
+        assert_grads_close("ddpg_fused_vs_separate", {k: a}, {k: b}, GRAD_TOL)
     act, lg, av = outs["0"]["act_out"], outs["0"]["logits"], outs["0"]["avail"]
     onehot = (act > 0.5).astype(np.float64)          # straight-through value: 1 at the sampled action (+- float noise)
     assert np.all(onehot.sum(1) == 1) and np.all(onehot * (1 - av) == 0)
@@ -491,7 +490,8 @@ def test_fused_tile_path_matches_general_path_on_other_shapes(tmp_path, n, a, d,
     np.testing.assert_allclose(f["prio"], g["prio"], rtol=2e-4, atol=1e-6)
     for k in ("gc", "ga"):
         assert np.abs(g[k]).max() > 0
-        np.testing.assert_allclose(f[k], g[k], rtol=0, atol=2e-3 * np.abs(g[k]).max(), err_msg=k)
+        from golden_util import assert_grads_close
+        assert_grads_close("ddpg_graph_vs_eager", {k: f[k]}, {k: g[k]}, GRAD_TOL)
     for k in ("theta_a", "theta_c"):
         np.testing.assert_allclose(f[k], g[k], rtol=0, atol=5e-5, err_msg=k)
 

@@ -10,6 +10,7 @@ from conftest import load_golden, sub
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-4
+GRAD_TOL = 2e-5      # of each tensor's max magnitude: ~10x the worst error measured on the GPU, 1.6e-6 (round 6; was a blanket 2e-3; profiles/r06_parity_errors.txt)
 M_KEYS = ("obs", "share_obs", "acts", "rewards", "next_obs", "next_share_obs", "dones", "dones_env", "valid_transition",
           "avail_acts", "next_avail_acts")
 R_KEYS = ("obs", "share_obs", "acts", "rewards", "dones", "dones_env", "avail_acts")
@@ -95,9 +96,8 @@ def test_several_policies_under_one_mixer_match_reference(name, mlp):
             got = named(trainer, pids, trainer.grad[:trainer.numel] * (coef / cnt))
             refs = sub(g, "grad0/")
             assert len(refs) > 10 * len(pids)
-            for k, ref in refs.items():
-                tol = 2e-3 * max(np.abs(ref).max(), 1e-6)
-                np.testing.assert_allclose(got[k], ref, rtol=0, atol=tol, err_msg="grad " + k)
+            from golden_util import assert_grads_close
+            assert_grads_close("multi_policy:" + name, got, refs, GRAD_TOL, floor=1e-6)
             for k in got:
                 if ".fc_h." in k:
                     assert not np.any(got[k]), k

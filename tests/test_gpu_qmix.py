@@ -1,7 +1,8 @@
 """-m gpu: the HIP QMIX/VDN training step (through the C-ABI) against the reference's frozen outputs and the oracle.
 
 Tolerances (fp32, different reduction orders): loss / grad_norm / Q_tot rtol 1e-4,
-priorities rtol 1e-4, gradients rtol 2e-3 of the tensor's max magnitude, parameters after 3 Adam steps atol 3e-5.
+priorities rtol 1e-4, gradients 5e-5 of the tensor's max magnitude (GRAD_TOL: ~10x the worst measured, also for the pinned-kernel tests since
+round 6), parameters after 3 Adam steps atol 3e-5.
 """
 import numpy as np
 import pytest
@@ -153,8 +154,8 @@ def test_every_forward_trunk_kernel_matches_reference(name, path):
             cnt = float(trainer.grad[trainer.numel + 1])
             coef = min(1.0, float(g["hp_maxnorm"]) / (float(g["grad_norm"][0]) + 1e-6))
             got = _flat_named(trainer, trainer.grad[:trainer.numel] * (coef / cnt))
-            for k, ref in sub(g, "grad0/").items():
-                np.testing.assert_allclose(got[k], ref, rtol=0, atol=2e-3 * max(np.abs(ref).max(), 1e-6), err_msg="grad " + k)
+            from golden_util import assert_grads_close
+            assert_grads_close("qmix_pinned:" + name, got, sub(g, "grad0/"), GRAD_TOL, floor=1e-6)
         if soft:
             trainer.soft_target_updates()
         elif s in hard_after:
@@ -213,8 +214,8 @@ def test_every_forward_mixer_kernel_matches_reference(name, path):
             cnt = float(trainer.grad[trainer.numel + 1])
             coef = min(1.0, float(g["hp_maxnorm"]) / (float(g["grad_norm"][0]) + 1e-6))
             got = _flat_named(trainer, trainer.grad[:trainer.numel] * (coef / cnt))
-            for k, ref in sub(g, "grad0/").items():
-                np.testing.assert_allclose(got[k], ref, rtol=0, atol=2e-3 * max(np.abs(ref).max(), 1e-6), err_msg="grad " + k)
+            from golden_util import assert_grads_close
+            assert_grads_close("qmix_pinned:" + name, got, sub(g, "grad0/"), GRAD_TOL, floor=1e-6)
         if soft:
             trainer.soft_target_updates()
         elif s in hard_after:
@@ -259,8 +260,8 @@ def test_both_forms_of_the_row_chain_match_reference(name, path):
             cnt = float(trainer.grad[trainer.numel + 1])
             coef = min(1.0, float(g["hp_maxnorm"]) / (float(g["grad_norm"][0]) + 1e-6))
             got = _flat_named(trainer, trainer.grad[:trainer.numel] * (coef / cnt))
-            for k, ref in sub(g, "grad0/").items():
-                np.testing.assert_allclose(got[k], ref, rtol=0, atol=2e-3 * max(np.abs(ref).max(), 1e-6), err_msg="grad " + k)
+            from golden_util import assert_grads_close
+            assert_grads_close("qmix_pinned:" + name, got, sub(g, "grad0/"), GRAD_TOL, floor=1e-6)
         trainer.soft_target_updates()
         np.testing.assert_allclose(float(info["loss"]), g["loss"][s], rtol=RTOL)
         np.testing.assert_allclose(float(info["grad_norm"]), g["grad_norm"][s], rtol=RTOL)

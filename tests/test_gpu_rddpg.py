@@ -13,6 +13,7 @@ from test_rddpg_oracle_golden import CASES, rddpg_oracle_from, rnoise_for
 
 pytestmark = pytest.mark.gpu
 RTOL = 3e-4
+GRAD_TOL = 6e-5      # of each tensor's max magnitude: ~10x the worst error measured on the GPU, 6.3e-6 (round 6; was a blanket 2e-3; profiles/r06_parity_errors.txt)
 
 
 def build(g, device="cuda:0", dims=None, args=None, td3=None, cap=None, same_share=True):
@@ -150,9 +151,8 @@ def test_gradients_match_oracle_per_tensor(name):
     for mod, gvec, rg, loss in ((policy.critic, gc, ref["critic_grads"], ref["critic_loss"]), (policy.actor, ga, ref["actor_grads"], ref["actor_loss"])):
         got, got_loss = _flat_grads(mod, gvec)
         np.testing.assert_allclose(got_loss, loss, rtol=2e-4, atol=2e-6)
-        for k, r in rg.items():
-            scale = max(np.abs(r).max(), 1e-6)
-            np.testing.assert_allclose(got[k], r, rtol=0, atol=2e-3 * scale + 1e-7, err_msg=k)
+        from golden_util import assert_grads_close
+        assert_grads_close("rddpg_grads:" + name, got, rg, GRAD_TOL, floor=1e-6)
         for k in got:
             if ".fc_h." in k:
                 assert not got[k].any()
