@@ -101,7 +101,10 @@ class QMix(object):
             raise NotImplementedError("hypernet_layers=1 / layer_N=2 / use_feature_normalization=False with several policies is not on the accelerated path")
         if (self.dims_flags & _lib.OPE_DIMS_NO_FEATURE_NORM) and float(getattr(args, "weight_decay", 0.0) or 0.0) != 0.0:
             raise NotImplementedError("use_feature_normalization=False with weight_decay: the constant feature_norm slots of the flat vector would decay")
+        self._md_heads = None
         if self.multi:
+            if any(getattr(p, "multidiscrete", False) for p in self.policies.values()):
+                raise NotImplementedError("several policies under one mixer with a MultiDiscrete action space are not on the accelerated path")
             self._init_multi()
             if args.use_double_q:
                 print("double Q learning will be used")

@@ -224,7 +224,9 @@ void make_plan(const ope_qmix_cfg* c, Plan* p) {
   p->raw_agent = W.add("raw_agent", (int64_t)p->ns_agent * p->chunks * w.agent_end);
   p->raw_mixer = W.add("raw_mixer", (int64_t)p->ns_mixer * (w.mixer_size > 0 ? w.mixer_size : 4));
   p->rsum = W.add("rsum", (int64_t)w.agent_end + w.mixer_size + 4);
-  p->raw2 = W.add("raw2", (int64_t)w2_max_workgroups() * kW2Slab);      // one slab per workgroup of the register-blocked weight-gradient launch
+  // one slab per workgroup of the register-blocked weight-gradient launch -- only where a step of this configuration can take it (w2_shape_can)
+  p->raw2 = (p->chunks == 1 && p->D % 2 == 0 && p->D <= 1024 && (c->vdn || (p->S % 2 == 0 && p->S <= 1024)) && p->NM <= 1024)
+                ? W.add("raw2", (int64_t)w2_max_workgroups() * kW2Slab) : -1;
   p->q_all = W.add("q_all", R * p->A);
   p->dbg = W.add("dbg", 2 * 16 * 4096 + 2 * 16 * 2400);   // per-wave s_memtime stamps (ope_set_debug)
   // wide-state mixer (ope_mixer_wide.hip): stream-K partial sums of the first hyper-layers
@@ -529,7 +531,7 @@ static int qmix_step(const ope_qmix_cfg* cfg, const ope_fields* batch, const ope
 
   // ---- decisions that must be taken before the first launch (nothing may fail between two kernels of a step) -------------------------
   // the register-blocked weight-gradient launch (ope_wgrad2.hip) takes whole steps on one stream: no time chunks, no rows read in place
-  const bool w2_can = !use_side && !oref && w2_shape_can(cfg, p);
+  const bool w2_can = !use_side && !oref && p.raw2 >= 0 && w2_shape_can(cfg, p);
   if (cfg->wgrad_path == 2 && !w2_can) return OPE_EINVAL;
   bool want_w2 = w2_can && w2_wanted(cfg);
   bool merge_hh = want_w2;

@@ -74,7 +74,10 @@ __device__ __forceinline__ void w2_body(const WgProb& P, int mp0, int np0, int k
   constexpr int NG = NT * 8 * SUB;              // pairs of MFMAs per stage
   constexpr int NPF = SUB * (F + 2);            // fetch pieces per stage: per row group the row indices, one load per fragment, the LayerNorm pair
   constexpr int NP = NPF + SUB * F;             // + one preparation per fragment
-  static_assert(NP <= NG, "more pieces than MFMA pairs");
+  // (strictly fewer pieces than MFMA pairs: the last preparation of a stage then sits at least one MFMA group in front of the next stage's
+  // first MFMA, which covers the two wait states a VALU write -> f32 MFMA read needs and the compiler does not see behind inline asm; the
+  // prologue's w2_settle covers the first stage)
+  static_assert(NP < NG, "a preparation piece directly in front of the next stage's first MFMA (VALU -> MFMA hazard)");
   const int lane = threadIdx.x & 63;
   const int i = lane & 15, g = lane >> 4;
   const int shift = MAP ? 0 : P.b_shift;

@@ -836,3 +836,41 @@ def test_long_horizon_tracks_the_oracle(name):
     for k, v in policy.q_network.named_parameters():
         np.testing.assert_allclose(v.detach().cpu().numpy(), orc.agent[k].numpy(), rtol=0, atol=2e-4, err_msg=k)
     record_errors("qmix_long_horizon:" + name, {"worst_scaled_rel": worst})
+
+
+def test_weight_gradient_table_the_register_blocked_kernel_cannot_plan_falls_back_before_the_first_launch():
+    """one-layer hyper-networks with 16 agents and a wide state make hyper_w1 a 512 x 800 problem = 28 units of the register-blocked
+    weight-gradient launch, 46 with the others -- more than its table holds. "By shape" (wgrad_path 0) must then run the whole step on the
+    tile-per-wave kernel (same results as pinning it), decided BEFORE the first launch; pinning wgrad2 (wgrad_path 2) is an error with
+    nothing launched."""
+    from offpolicy_amd import _lib
+    from offpolicy_amd.config import default_args
+    from offpolicy_amd.utils.synth import EnvDims, synth_episodes, policy_info_for, as_policy_dicts
+    from offpolicy_amd.utils.rec_buffer import RecReplayBuffer
+    from offpolicy_amd.algorithms.qmix.algorithm.QMixPolicy import QMixPolicy
+    from offpolicy_amd.algorithms.qmix.qmix import QMix
+    dims, B = EnvDims("wide16", 16, 6, 16, 800, 5), 4
+    args = default_args(hypernet_layers=1)
+    out = {}
+    for path in (0, 1):
+        torch.manual_seed(5)
+        np.random.seed(5)
+        dev = torch.device("cuda:0")
+        policy = QMixPolicy({"args": args, "device": dev}, policy_info_for(dims)["policy_0"])
+        trainer = QMix(args, dims.n_agents, {"policy_0": policy}, lambda a: "policy_0", device=dev, episode_length=dims.episode_length)
+        buf = RecReplayBuffer(policy_info_for(dims), {"policy_0": list(range(dims.n_agents))}, B, dims.episode_length, True, True, device=dev)
+        d = as_policy_dicts(synth_episodes(np.random.RandomState(0), B, dims, avail="bernoulli"))
+        buf.insert(B, d["obs"], d["share_obs"], d["acts"], d["rewards"], d["dones"], d["dones_env"], d["avail_acts"])
+        batch = batch_from(buf, np.arange(B))
+        trainer.tune["wgrad_path"] = path
+        info, _, _ = trainer.train_policy_on_batch(batch)
+        launched = _lib.last_launches()
+        assert any(k.startswith("wgrad<") for k in launched) and not any(k.startswith("wgrad2") for k in launched), launched
+        assert np.isfinite(float(info["loss"]))
+        out[path] = trainer.grad.clone()
+        if path == 0:
+            trainer.tune["wgrad_path"] = 2
+            with pytest.raises(_lib.OpeError):
+                trainer.train_policy_on_batch(batch)
+            assert _lib.last_launches() == []
+    assert torch.equal(out[0], out[1])
