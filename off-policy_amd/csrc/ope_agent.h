@@ -69,6 +69,7 @@ struct GruFwdArgs {
   float* rg; float* zg; float* ng; float* ghn;  // [L][NB][64] gate saves (live) or null
   int family, waves;                    // scan kernel family (4 | 1) / compute waves per row (4 | 2) asked for by the caller's cfg;
                                         // 0 = the process default (ope_set_scan_kernel / OPE_GRU, OPE_GRU4_W), then by row count
+  int pair_cus;                         // packed rows: > 0 = CUs of the device, the chains are dealt out longest-beside-shortest (set by the launcher)
   LivePlan lp; int B, N;                // lp.hdr != null (gru4 only): packed rows -- row r = agent * B + j walks the lp.len[j] steps of the
                                         // episode ranked j; step t's gi / h / saves are at row N * cum[t] + agent * n[t] + j
 };

@@ -22,6 +22,7 @@
 // Fixed summation order (four partial sums per lane, pairwise; quad reduction commutative-symmetric), so all four lanes
 // of a quad hold bit-identical values and results are deterministic.
 //   r = sigma(gi_r + gh_r), z = sigma(gi_z + gh_z), n = tanh(gi_n + r*gh_n), h' = (1-z) n + z h      (nn.GRU)
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <type_traits>
@@ -67,7 +68,11 @@ __device__ __forceinline__ f32x2 pk_mul_bcast(f32x2 w, f32x2 hp) {
 // PK: packed rows of the live plan (LivePlan, ope_common.h): the workgroup of (agent, ranked episode j) walks the len[j] steps the episode
 // needs and stops -- every later (t, b) of that episode is multiplied by a zero mask in the loss (qmix.py:161-166) --; step t's rows are
 // at N * cum[t] + agent * n[t] + j, a table the workgroup builds in LDS before the chain starts (the loader / storer read it, off the chain).
-template <int W, bool DBG, bool PK>   // W = compute waves per row = lanes per feature (2 or 4)
+// EXP (instantiated only in builds with -DOPE_EXPERIMENTS; TIMING variants, results WRONG; OPE_GRU_EXP, profiles/r06_gru4_decomposition.txt):
+// leave one part of the step out and see what the launch loses -- 1 the gates (exp2 / rcp chains become one FMA each), 2 the per-step barrier
+// (all roles run free: races), 4 the saves' LDS publishes (r, z, n, gh_n: h only), 8 the h reads from LDS (registers instead: no exchange
+// latency), 16 the 24 packed FMAs of the mat-vec.
+template <int W, bool DBG, bool PK, int EXP = 0>   // W = compute waves per row = lanes per feature (2 or 4)
 __global__ void __launch_bounds__((W + 2) * 64) gru_fwd4_kernel(GruFwdArgs a) {
   constexpr int FPW = OPE_H / W;     // features per compute wave
   constexpr int KS = OPE_H / W;      // K-slice per lane
@@ -89,12 +94,30 @@ __global__ void __launch_bounds__((W + 2) * 64) gru_fwd4_kernel(GruFwdArgs a) {
   constexpr float kL = -1.4426950408889634f;
   __builtin_amdgcn_s_setprio(3);      // every instruction of a scan wave is on the step chain: win the issue arbitration against whatever shares the CU
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int rid = blockIdx.x;
-  const int net = rid / a.NB;
-  const int row = rid - net * a.NB;
+  // Which (net, agent, ranked episode) a workgroup walks. Padded rows: block = net * NB + row. Packed rows (PK): the dispatcher hands block b to
+  // CU b % 256 (tools/microbench_placement.hip: blocks b and b + 256 of this launch shape share a CU on every run, XCD = b % 8), two
+  // workgroups per CU at 512 rows, and a step costs a scan 0.41 us beside a neighbour, 0.29 us alone -- so the launch ends earliest when every
+  // CU holds a LONG episode beside a SHORT one (the same episode of both nets side by side, the plain mapping, keeps the 16 longest chains
+  // paired for all of their steps: 60 us against 54). The 2 NB chains, ordered by length (episode rank major), are dealt out in a snake over
+  // the CUs: slot s = b / C takes entries s C .. s C + C - 1, odd slots backwards. Placement only: any other assignment is as correct.
+  int net, pk_ag = 0, pk_j = 0, row;
+  if (PK && a.pair_cus > 0) {
+    const int C = a.pair_cus, G = a.nets * a.NB;
+    const int s = blockIdx.x / C, c = blockIdx.x - s * C;
+    const int lo = s * C, cnt = min(C, G - lo);
+    const int idx = lo + ((s & 1) ? cnt - 1 - c : c);
+    pk_j = idx / (a.nets * a.N);
+    const int r = idx - pk_j * (a.nets * a.N);
+    net = r / a.N;
+    pk_ag = r - net * a.N;
+    row = pk_ag * a.B + pk_j;
+  } else {
+    net = blockIdx.x / a.NB;
+    row = blockIdx.x - net * a.NB;
+    if (PK) { pk_ag = row / a.B; pk_j = row - pk_ag * a.B; }
+  }
   __shared__ int rows_s[PK ? kLiveMaxT + 2 : 1];
   int L = a.L;
-  const int pk_ag = PK ? row / a.B : 0, pk_j = PK ? row - pk_ag * a.B : 0;
   if (PK) L = __builtin_amdgcn_readfirstlane(a.lp.len[pk_j]);
   // The step -> row table: every wave fills its share and meets the others at ONE extra barrier -- the loader and the storer at once, the
   // compute waves behind the requests for their W_hh rows (the table's round trip to L2 then overlaps the weights').
@@ -150,7 +173,7 @@ __global__ void __launch_bounds__((W + 2) * 64) gru_fwd4_kernel(GruFwdArgs a) {
           asm volatile("s_waitcnt vmcnt(21)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2])::"memory");
           publish(d, (s + 1) & 1);
           load_step(d, t + 1 + kAhead, prow);
-          lds_barrier();
+          if (!(EXP & 2)) lds_barrier();
         }
       }
     }
@@ -173,7 +196,7 @@ __global__ void __launch_bounds__((W + 2) * 64) gru_fwd4_kernel(GruFwdArgs a) {
           a.ghn[o] = sv[p][3][lane] * (1.0f / (2.0f * kL));   // the n rows of W_hh carry the tanh's -2 log2(e)
         }
       }
-      if (t < L) lds_barrier();
+      if (t < L && !(EXP & 2)) lds_barrier();
     }
     return;
   }
@@ -238,16 +261,25 @@ __global__ void __launch_bounds__((W + 2) * 64) gru_fwd4_kernel(GruFwdArgs a) {
     // LDS returns in order: what the first FMAs need (h[0..3] of the slice, the injected pair) is asked for first, gi_n last
     const float* hp = &hs[p][KS * g];
     f32x4 hq[KS / 4];
+    if (EXP & 8) {      // no exchange: every value from the lane's own state (timing only)
+#pragma unroll
+      for (int v = 0; v < KS / 4; ++v) hq[v] = f32x4{h, h * 0.5f, -h, h * 0.25f};
+    } else
     hq[0] = *reinterpret_cast<const f32x4*>(hp);
     __builtin_amdgcn_sched_barrier(0);
     const f32x2 x = {sm[gx_off + p * kGxP], sm[gx_off + p * kGxP + kGxZ]};      // {x_r, x_z} or zeros (one ds_read2)
     __builtin_amdgcn_sched_barrier(0);
+    if (!(EXP & 8)) {
 #pragma unroll
     for (int v = 1; v < KS / 4; ++v) hq[v] = *reinterpret_cast<const f32x4*>(hp + 4 * v);
+    }
     __builtin_amdgcn_sched_barrier(0);
     const float gin2 = sm[kGn + p * OPE_H + f];
     __builtin_amdgcn_sched_barrier(0);   // all LDS reads issue before anything waits
     f32x2 a0, a1, an0, an1;              // {r, z} partials over even / odd k; n partials over the two k-pairs of a quad of k
+    if (EXP & 16) {      // no mat-vec: the partials from one value each (timing only)
+      a0 = f32x2{hq[0][0], hq[0][1]} + x; a1 = f32x2{hq[0][2], hq[0][3]}; an0 = f32x2{hq[KS / 4 - 1][0], hq[KS / 4 - 1][1]} + bn0; an1 = f32x2{hq[KS / 4 - 1][2], hq[KS / 4 - 1][3]};
+    } else
 #pragma unroll
     for (int v = 0; v < KS / 4; ++v) {
       const f32x2 lo = {hq[v][0], hq[v][1]}, hi = {hq[v][2], hq[v][3]};
@@ -272,14 +304,14 @@ __global__ void __launch_bounds__((W + 2) * 64) gru_fwd4_kernel(GruFwdArgs a) {
     const float mine = even ? t[0] : t[1], theirs = even ? t[1] : t[0];
     float u = mine + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, theirs), kSwap, 0xF, 0xF, true));
     u = group_sum_from<W>(u);
-    const float y = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u));   // r (even lanes) | z (odd lanes)
-    sm[rz_off + 4 * p * kPl] = y;              // the saves leave as soon as they exist (r from one side, z from the other)
+    const float y = (EXP & 1) ? fmaf(u, 0.001f, 0.5f) : __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u));   // r (even lanes) | z (odd lanes)
+    if (!(EXP & 4)) sm[rz_off + 4 * p * kPl] = y;              // the saves leave as soon as they exist (r from one side, z from the other)
     const f32x2 tn = an0 + an1;
     float sn = tn[0] + tn[1];
     const float an = group_sum<W>(sn);         // -2 log2(e) (W_hn h + b_hn), all lanes
-    sm[kSv + (4 * p + 3) * kPl + f] = an;
-    const float n = fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(y, an, gin2))), -1.0f);
-    sm[kSv + (4 * p + 2) * kPl + val_off] = n;
+    if (!(EXP & 4)) sm[kSv + (4 * p + 3) * kPl + f] = an;
+    const float n = (EXP & 1) ? fmaf(fmaf(y, an, gin2), 0.001f, 0.1f) : fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(y, an, gin2))), -1.0f);
+    if (!(EXP & 4)) sm[kSv + (4 * p + 2) * kPl + val_off] = n;
     const float z = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y), kSwap, 0xF, 0xF, true));
     h = fmaf(z, h - n, n);                     // (1 - z) n + z h
     if (DBG) asm volatile("" : "+v"(h));
@@ -287,7 +319,7 @@ __global__ void __launch_bounds__((W + 2) * 64) gru_fwd4_kernel(GruFwdArgs a) {
     sm[kHs + (p ^ 1) * OPE_H + val_off] = h;
     if (DBG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     OPE_PHASE(2)
-    lds_barrier();
+    if (!(EXP & 2)) lds_barrier();
     OPE_PHASE(3)
   };
   for (int t = 0; t < L; t += 2) {
@@ -304,7 +336,9 @@ __global__ void __launch_bounds__((W + 2) * 64) gru_fwd4_kernel(GruFwdArgs a) {
 // BPTT, step i = 0 .. T-1-t_lo at time tt = T-1-i:
 //   dh_{tt-1}[k] = dh_tt[k] z[k] + sum_i ( W_hr[i][k] dr_pre[i] + W_hz[i][k] dz_pre[i] + W_hn[i][k] dghn[i] )
 // ---------------------------------------------------------------------------------------------------------
-template <int W, bool DBG, bool PK>   // PK: as gru_fwd4_kernel -- the chain starts at the episode's last live step, min(len[j], T) - 1
+// EXP: timing-only variants as in gru_fwd4_kernel -- 2 no per-step barrier, 4 no publishes of the gate adjoints (the storer stores stale values), 8 the 12
+// broadcast reads of the adjoints replaced by register values, 16 the 24 packed FMAs left out.
+template <int W, bool DBG, bool PK, int EXP = 0>   // PK: as gru_fwd4_kernel -- the chain starts at the episode's last live step, min(len[j], T) - 1
 __global__ void __launch_bounds__((W + 2) * 64) gru_bwd4_kernel(GruBwdArgs a) {
   constexpr int FPW = OPE_H / W;     // features per compute wave
   constexpr int IS = OPE_H / W;      // gate rows per gate per lane
@@ -392,7 +426,7 @@ __global__ void __launch_bounds__((W + 2) * 64) gru_bwd4_kernel(GruBwdArgs a) {
           asm volatile("s_waitcnt vmcnt(42)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5])::"memory");
           publish(d, i + 1);
           load_step(d, i + 1 + kAhead, prow, prow1);
-          lds_barrier();
+          if (!(EXP & 2)) lds_barrier();
         }
       }
     }
@@ -412,7 +446,7 @@ __global__ void __launch_bounds__((W + 2) * 64) gru_bwd4_kernel(GruBwdArgs a) {
         gout[2 * OPE_H] = ds[p][3][lane];
         a.dghn[ro64 + lane] = ds[p][2][lane];
       }
-      if (i < nsteps) lds_barrier();
+      if (i < nsteps && !(EXP & 2)) lds_barrier();
     }
     return;
   }
@@ -446,21 +480,27 @@ __global__ void __launch_bounds__((W + 2) * 64) gru_bwd4_kernel(GruBwdArgs a) {
     constexpr int p = decltype(P)::value;
     const f32x2 d2 = {dht, dht};
     const f32x2 nr = fnr * d2, gz = fgz * d2;   // {dn_pre, dr_pre}, {dgh_n, dz_pre}: two packed multiplies
+    if (!(EXP & 4)) {
     sm[(4 * p + 3) * OPE_H + k] = nr[0];        // four lanes of a quad write the same value to the same address
     sm[(4 * p + 0) * OPE_H + k] = nr[1];
     sm[(4 * p + 1) * OPE_H + k] = gz[1];
+    }
     float dgn = gz[0];
     if (DBG) asm volatile("" : "+v"(dgn));
     OPE_PHASE(0)
-    sm[(4 * p + 2) * OPE_H + k] = dgn;
+    if (!(EXP & 4)) sm[(4 * p + 2) * OPE_H + k] = dgn;
     if (DBG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     OPE_PHASE(1)
-    lds_barrier();
+    if (!(EXP & 2)) lds_barrier();
     OPE_PHASE(2)
     const float* base = &ds[p][0][IS * g];
     f32x4 rv[IS / 4], zv[IS / 4], nv[IS / 4];
 #pragma unroll
     for (int v = 0; v < IS / 4; ++v) {
+      if (EXP & 8) {      // no exchange (timing only)
+        rv[v] = f32x4{nr[1], nr[1] * 0.5f, -nr[1], nr[1] * 0.25f}; zv[v] = f32x4{gz[1], gz[1] * 0.5f, -gz[1], gz[1] * 0.25f}; nv[v] = f32x4{dgn, dgn * 0.5f, -dgn, dgn * 0.25f};
+        continue;
+      }
       rv[v] = *reinterpret_cast<const f32x4*>(base + 4 * v);
       zv[v] = *reinterpret_cast<const f32x4*>(base + OPE_H + 4 * v);
       nv[v] = *reinterpret_cast<const f32x4*>(base + 2 * OPE_H + 4 * v);
@@ -471,6 +511,9 @@ __global__ void __launch_bounds__((W + 2) * 64) gru_bwd4_kernel(GruBwdArgs a) {
     // three chains (one per gate), eight packed FMAs deep: interleaved they issue back to back, and two packed adds and one
     // add fold them (six four-deep chains cost nine more instructions per step to fold)
     f32x2 cr, cz, cn;
+    if (EXP & 16) {      // no mat-vec (timing only)
+      cr = f32x2{rv[0][0], rv[IS / 4 - 1][1]}; cz = f32x2{zv[0][2], zv[IS / 4 - 1][3]}; cn = f32x2{nv[0][0], nv[IS / 4 - 1][3]};
+    } else
 #pragma unroll
     for (int v = 0; v < IS / 4; ++v) {
       if (v == 0) {
@@ -517,17 +560,52 @@ static int waves_per_row(int64_t rows, int asked) {
   return rows <= 512 ? 4 : 2;
 }
 
+static int scan_device_cus() {
+  static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256; return n > 1 ? n : 256; }();
+  return cus;
+}
+
 template <int W>
 static void launch_fwd(const GruFwdArgs& a, hipStream_t st) {
-  if (a.lp.hdr)
-    OPE_LAUNCH((gru_fwd4_kernel<W, false, true>), dim3(a.nets * a.NB), dim3((W + 2) * 64), 0, st, a);
-  else if (a.dbg)
+#ifdef OPE_EXPERIMENTS
+  static const int gexp = getenv("OPE_GRU_EXP") ? atoi(getenv("OPE_GRU_EXP")) : 0;
+  if (gexp && !a.lp.hdr && !a.dbg && W == 4) {
+    static bool warned = false;
+    if (!warned) { fprintf(stderr, "libope: OPE_GRU_EXP=%d -- a timing-only variant of gru_fwd4_kernel runs: its outputs are WRONG\n", gexp); warned = true; }
+    const int nets = (gexp & 32) ? 1 : a.nets;      // 32: the live net's rows only (one workgroup per CU at 256 rows)
+#define OPE_GRU_CASE(E) case E: OPE_LAUNCH((gru_fwd4_kernel<4, false, false, E>), dim3(nets * a.NB), dim3((4 + 2) * 64), 0, st, a); return;
+    switch (gexp & 31) {
+      OPE_GRU_CASE(0) OPE_GRU_CASE(1) OPE_GRU_CASE(2) OPE_GRU_CASE(4) OPE_GRU_CASE(8) OPE_GRU_CASE(16) OPE_GRU_CASE(3) OPE_GRU_CASE(10) OPE_GRU_CASE(17) OPE_GRU_CASE(31)
+      default: break;
+    }
+#undef OPE_GRU_CASE
+  }
+#endif
+  if (a.lp.hdr) {
+    static const int pair_env = getenv("OPE_GRU_PAIR") ? atoi(getenv("OPE_GRU_PAIR")) : 1;      // 0: the plain block -> (net, row) mapping (A/B runs)
+    GruFwdArgs b = a;
+    b.pair_cus = pair_env ? scan_device_cus() : 0;
+    OPE_LAUNCH((gru_fwd4_kernel<W, false, true>), dim3(a.nets * a.NB), dim3((W + 2) * 64), 0, st, b);
+  } else if (a.dbg)
     OPE_LAUNCH((gru_fwd4_kernel<W, true, false>), dim3(a.nets * a.NB), dim3((W + 2) * 64), 0, st, a);
   else
     OPE_LAUNCH((gru_fwd4_kernel<W, false, false>), dim3(a.nets * a.NB), dim3((W + 2) * 64), 0, st, a);
 }
 template <int W>
 static void launch_bwd(const GruBwdArgs& a, hipStream_t st) {
+#ifdef OPE_EXPERIMENTS
+  static const int gexp = getenv("OPE_GRUB_EXP") ? atoi(getenv("OPE_GRUB_EXP")) : 0;
+  if (gexp && !a.lp.hdr && !a.dbg && W == 4) {
+    static bool warned = false;
+    if (!warned) { fprintf(stderr, "libope: OPE_GRUB_EXP=%d -- a timing-only variant of gru_bwd4_kernel runs: its outputs are WRONG\n", gexp); warned = true; }
+#define OPE_GRU_CASE(E) case E: OPE_LAUNCH((gru_bwd4_kernel<4, false, false, E>), dim3(a.NB), dim3((4 + 2) * 64), 0, st, a); return;
+    switch (gexp) {
+      OPE_GRU_CASE(2) OPE_GRU_CASE(4) OPE_GRU_CASE(8) OPE_GRU_CASE(16) OPE_GRU_CASE(24) OPE_GRU_CASE(30)
+      default: break;
+    }
+#undef OPE_GRU_CASE
+  }
+#endif
   if (a.lp.hdr)
     OPE_LAUNCH((gru_bwd4_kernel<W, false, true>), dim3(a.NB), dim3((W + 2) * 64), 0, st, a);
   else if (a.dbg)
