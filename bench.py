@@ -54,6 +54,11 @@ def parse():
                     "with (one-shot xGMI push verified against RCCL, or RCCL) and a timed 475 KB all-reduce; rank 0 prints them as one JSON line "
                     "and the job exits -- what to run first on a new multi-GPU node")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather-extras", action="store_true", help="QMIX workloads: skip the 40 plain gather dispatches after the timed region (event-bracket and "
+                    "copy-only references of the roofline block): counter passes that average over every gather launch of the process use it")
+    ap.add_argument("--whole-batch", action="store_true", help="QMIX workloads: the gather copies every padded time entry of obs / share_obs (what the "
+                    "reference's sample() returns) instead of stopping at each sampled episode's termination (RecPolicyBuffer.sample_inds(live_for=trainer, "
+                    "live_only=True): the entries the live-row step reads)")
     ap.add_argument("--no-early-plan", action="store_true", help="QMIX workloads: build the live-row plan in a launch of its own in front of every step "
                     "instead of inside the gather launch (RecPolicyBuffer.sample_inds(live_for=trainer))")
     ap.add_argument("--no-full-length", action="store_true", help="QMIX workloads, one GPU: skip the second timed leg on a store of full-length "
@@ -83,7 +88,7 @@ def parse():
     return ap.parse_args()
 
 
-def gather_traffic(workload, batch, episodes=256, lazy_obs=False):
+def gather_traffic(workload, batch, episodes=256, lazy_obs=False, live_only=False):
     """HBM bytes per gather launch from the committed PMC passes (profiles/gather_traffic.json: rocprofv3 --pmc FETCH_SIZE and
     --pmc WRITE_SIZE in separate runs of this same command, corrected as MI355X_MICROARCH.md prescribes); None if that
     configuration was not measured. PMC collection cannot run inside the timed bench, hence the file. Entries are keyed
@@ -92,8 +97,8 @@ def gather_traffic(workload, batch, episodes=256, lazy_obs=False):
     try:
         with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "gather_traffic.json")) as f:
             ent = json.load(f)["entries"]
-        if lazy_obs:      # the gather without the observation field (rows left in the store): its own PMC passes
-            e = ent.get("%s:%d:%d:lazy_obs" % (workload, batch, episodes))
+        if lazy_obs or live_only:      # the gather without the observation field (rows left in the store) / of the live time entries only: their own PMC passes
+            e = ent.get("%s:%d:%d:%s" % (workload, batch, episodes, "lazy_obs" if lazy_obs else "live_only"))
             return int(e["traffic_bytes"]) if e else None
         e = ent.get("%s:%d:%d" % (workload, batch, episodes)) or (ent.get("%s:%d" % (workload, batch)) if episodes == 256 else None)
         return int(e["traffic_bytes"]) if e else None
@@ -544,7 +549,8 @@ def main():
                 return G["graphed"](inds)
             # live_for: where the step runs on live rows, this gather launch also builds the step's row plan (extra workgroups in front of
             # the copy's, from the store's flags of the same episodes) instead of a launch of its own in front of the step
-            s = pbuf.sample_inds(inds, live_for=None if a.no_early_plan else trainer)      # ope_store_gather, current stream
+            # live_only: ... and the copy stops at each episode's termination (the post-terminal entries of obs / share_obs are never read)
+            s = pbuf.sample_inds(inds, live_for=None if a.no_early_plan else trainer, live_only=not (a.whole_batch or a.no_early_plan))      # ope_store_gather, current stream
             batch = tuple({"policy_0": x} for x in s) + (None, None)
             info, _, _ = trainer.train_policy_on_batch(batch)
             if args.use_soft_update:
@@ -566,14 +572,15 @@ def main():
         kernel_ms = gather_profile_read()
         gather_profile(False)
         # for reference, the round-1 style measurement on 20 more gathers outside the timed region: two event markers around a launch
-        for e0, e1 in ev[:20]:
+        n_extra = 0 if (a.no_gather_extras and kernel_ms) else 20
+        for e0, e1 in ev[:n_extra]:
             pbuf.sample_inds(opdist.shard_indices(np.random.choice(len(buf), global_batch), rank, world), timing_events=(e0, e1))
         torch.cuda.synchronize()
-        bracket_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev[:20]]))
+        bracket_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev[:n_extra]])) if n_extra else float(np.mean(kernel_ms))
         gather_ms = float(np.mean(kernel_ms)) if kernel_ms else bracket_ms
         # the copy on its own (no plan riders): 20 plain gather dispatches after the timed region, the same per-dispatch events
         gather_profile(True, 1)
-        for _ in range(20):
+        for _ in range(n_extra):
             pbuf.sample_inds(opdist.shard_indices(np.random.choice(len(buf), global_batch), rank, world))
         torch.cuda.synchronize()
         copy_ms = gather_profile_read()
@@ -600,7 +607,8 @@ def main():
         live = live_row_stats(trainer, local_batch)       # rows the steps of this leg really ran (None: every padded row)
         results.append(dict(leg=leg, local_batch=local_batch, global_batch=global_batch, elapsed=elapsed, gather_ms=gather_ms, loss=loss,
                             graphed=graphed is not None, bracket_ms=bracket_ms, n_kernel_ms=len(kernel_ms), windows=windows, per_kernel=per_kernel,
-                            lazy_obs=bool(pbuf.lazy_obs), live=live, copy_only_ms=copy_only_ms, riders=bool(live) and not a.no_early_plan))
+                            lazy_obs=bool(pbuf.lazy_obs), live=live, copy_only_ms=copy_only_ms, riders=bool(live) and not a.no_early_plan,
+                            live_only=bool(live) and not (a.whole_batch or a.no_early_plan or pbuf.lazy_obs)))
     # The same command on a store whose episodes all run the full T steps (dones_env = 1 at the last step only): nothing to skip, every row
     # of the padded batch is live -- what the step costs when the data offers no dead rows (guardrail ii). After every
     # other measurement: the store's flags are overwritten.
@@ -633,6 +641,14 @@ def main():
         # read from the store + write of the batch; with the observations left in the store ("fused into the first consumer,
         # written = 0") the gather moves the other fields only, and the obs rows are read by trunk_fwd4 (both nets) and wgrad instead
         algo_bytes = 2.0 * r0["local_batch"] * (ep_bytes - (obs_bytes if r0["lazy_obs"] else 0))
+        padded_bytes = algo_bytes      # what the copy-only dispatches after the timed region (plain sample_inds: every padded entry) move
+        if r0["live_only"]:
+            # the launches of the timed region stop at each episode's termination: obs and share_obs move their live time entries only --
+            # N * sum_b len_b agent rows and sum_b len_b state rows, the plan's own count (mean over the run's steps); the short-row fields whole
+            share_bytes = 4 * (dims.episode_length + 1) * dims.state_dim
+            len_sum = r0["live"][0] / dims.n_agents
+            # (state: one entry more per episode that ends before T -- the target mixer of its last live step reads it; counted for every episode: <= 0.1 %)
+            algo_bytes = 2.0 * (r0["local_batch"] * (ep_bytes - obs_bytes - share_bytes) + len_sum * 4.0 * (dims.n_agents * dims.obs_dim + dims.state_dim))
         achieved = algo_bytes / (r0["gather_ms"] * 1e-3) / 1e9
         steps_per_s = a.steps / r0["elapsed"]
         value = steps_per_s * (r0["global_batch"] / float(a.batch))
@@ -659,8 +675,10 @@ def main():
                        "optimizer_steps_per_sec": round(steps_per_s, 3), "final_loss": round(r0["loss"], 6)},
             "roofline": {"kernel": "episode_copy_kernel<gather> (ope_store_gather)", "bound": "hbm", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": gather_traffic(a.workload, r0["local_batch"], a.episodes, r0["lazy_obs"]),
+                         "traffic": gather_traffic(a.workload, r0["local_batch"], a.episodes, r0["lazy_obs"], r0["live_only"]),
                          "algorithmic_bytes_per_launch": int(algo_bytes), "avg_launch_ms": round(r0["gather_ms"], 5),
+                         "bytes_moved": ("live time entries only: obs and share_obs stop at each sampled episode's termination (mean of the run's "
+                                         "launches, from the plan's row counts); the whole padded batch would be %d bytes" % int(padded_bytes)) if r0["live_only"] else "the whole padded batch",
                          "store_bytes": int(a.episodes * ep_bytes),
                          "hbm_resident": bool(a.episodes * ep_bytes > 4 * 256 * 2 ** 20),
                          "timing": "mean kernel duration of %d gather dispatches of the timed region (every 4th launch from 16-step windows on: "
@@ -670,9 +688,9 @@ def main():
                                      "RecPolicyBuffer.sample_inds(live_for=trainer)): their duration is what `achieved` divides by; `copy_only` = the same "
                                      "gather without them") if r0["riders"] else None,
                          "copy_only": None if r0["copy_only_ms"] is None else {
-                             "avg_launch_ms": round(r0["copy_only_ms"], 5), "achieved": round(algo_bytes / (r0["copy_only_ms"] * 1e-3) / 1e9, 2),
-                             "frac": round(algo_bytes / (r0["copy_only_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                             "timing": "20 plain gather dispatches after the timed region, per-dispatch events"},
+                             "avg_launch_ms": round(r0["copy_only_ms"], 5), "achieved": round(padded_bytes / (r0["copy_only_ms"] * 1e-3) / 1e9, 2),
+                             "frac": round(padded_bytes / (r0["copy_only_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "bytes_per_launch": int(padded_bytes),
+                             "timing": "20 plain gather dispatches (every padded entry) after the timed region, per-dispatch events"},
                          "avg_event_bracket_ms": round(r0["bracket_ms"], 5),
                          "frac_event_bracket": round(algo_bytes / (r0["bracket_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "event_bracket_note": "20 gathers after the timed region, interval between two HIP event markers recorded around "

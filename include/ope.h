@@ -372,6 +372,10 @@ typedef struct ope_live_target {
   float* loss_part;     /* workspace region "loss_part" */
   int32_t n_loss_part;
   int32_t n_agents, episode_length, batch;
+  int32_t copy_live_only;   /* ope_store_gather_attach_live only: 1 = the copy of that launch writes, of the long-row fields (obs, share_obs: the
+                             * episode-contiguous step path), only the time entries t < len_b (share_obs: t <= len_b) of each sampled episode -- the rows the live-row
+                             * step reads; every later entry of the destination keeps whatever it held (those (t, b) carry a zero mask in the
+                             * loss, qmix.py:161-166). The caller's promise: this batch is consumed by the live-row step of this plan only. */
 } ope_live_target;
 int ope_qmix_live_target(const ope_qmix_cfg* cfg, void* workspace, int64_t workspace_bytes, int32_t which, ope_live_target* out);
 int ope_store_live_plan(int32_t capacity, int32_t episode_length, const float* store_dones_env, const int64_t* inds_dev,

@@ -50,7 +50,7 @@ class QmixCfg(C.Structure):
 
 class LiveTarget(C.Structure):
     _fields_ = [("plan", C.c_void_p), ("err_abs", C.c_void_p), ("loss_part", C.c_void_p), ("n_loss_part", C.c_int32),
-                ("n_agents", C.c_int32), ("episode_length", C.c_int32), ("batch", C.c_int32)]
+                ("n_agents", C.c_int32), ("episode_length", C.c_int32), ("batch", C.c_int32), ("copy_live_only", C.c_int32)]
 
 
 class GatherTune(C.Structure):

@@ -350,12 +350,13 @@ class QMix(object):
             self._ws[B] = ws
         return self._ws[B]
 
-    def build_live_plan(self, pbuf, host_inds, batch):
+    def build_live_plan(self, pbuf, host_inds, batch, live_only=False):
         """Have the NEXT gather launch of `pbuf` (RecPolicyBuffer; the call that follows in sample_inds) also build the live-row plan of this
         trainer's next step on those `batch` episodes -- a few extra workgroups in front of the copy's that read the store's termination
         flags through the launch's own indices (ope.h: ope_store_gather_attach_live) -- and return the tag `train_policy_on_batch`
         recognises; None where that step would not run on live rows "by shape" (or the trainer pins every padded row / is one of the
-        multi-policy, MLP forms). Same stream as the step: no events, one plan region."""
+        multi-policy, MLP forms). Same stream as the step: no events, one plan region. `live_only`: that launch's copy also leaves the time
+        entries at and behind each episode's length unwritten in obs / share_obs (ope_live_target.copy_live_only; tag[4])."""
         if self.multi or self._mlp or int(self.tune.get("live_rows", 0)) == 1 or int(self.tune.get("debug", 0)):
             return None
         batch = int(batch)
@@ -372,9 +373,10 @@ class QMix(object):
             if _lib.lib.ope_qmix_live_target(C.byref(cfg), _lib.ptr(ws), ws.numel(), 0, C.byref(tgt)) != 0:
                 return None
             self._live["targets"][key] = tgt
+        tgt.copy_live_only = 1 if live_only else 0
         _lib.check(_lib.lib.ope_store_gather_attach_live(C.byref(tgt)), "ope_store_gather_attach_live")
         self._live_seq += 1
-        return ("ope_live", int(ws.data_ptr()), self._live_seq, 0)
+        return ("ope_live", int(ws.data_ptr()), self._live_seq, 0, bool(live_only))
 
     def workspace_view(self, batch, name):
         """Debug/test access to a named intermediate of the last step with this batch size (float32 view)."""
@@ -493,6 +495,10 @@ class QMix(object):
                 live_tag[:3] == ("ope_live", int(ws.data_ptr()), self._live_seq)):
             # the gather launch that wrote this batch -- the latest one attached for this workspace -- built the step's plan: no plan launch
             cfg.live_rows = 3 + int(live_tag[3])
+        elif live_tag is not None and len(live_tag) > 4 and live_tag[4]:
+            # the gather left the post-terminal entries of obs / share_obs unwritten for the live-row step of ITS plan: no other step may read them
+            raise RuntimeError("this batch was gathered with live_only=True: only the live-row step it was sampled for (the trainer's next "
+                               "train_policy_on_batch, same batch size and tuning) can consume it")
         f = _lib.Fields()
         f.obs = None if oref is not None else _lib.ptr(obs).value
         f.share_obs, f.acts, f.rewards = _lib.ptr(share).value, _lib.ptr(acts).value, _lib.ptr(rew).value

@@ -407,7 +407,7 @@ extern "C" int ope_qmix_live_target(const ope_qmix_cfg* cfg, void* workspace, in
   if (p.live < 0) return OPE_EINVAL;
   float* W = (float*)workspace;
   out->plan = reinterpret_cast<int32_t*>(W + (which ? p.live1 : p.live)); out->err_abs = W + p.err_abs; out->loss_part = W + p.loss_part; out->n_loss_part = p.n_loss_tiles * 4;
-  out->n_agents = p.N; out->episode_length = p.T; out->batch = p.B;
+  out->n_agents = p.N; out->episode_length = p.T; out->batch = p.B; out->copy_live_only = 0;
   return OPE_OK;
 }
 extern "C" int ope_qmix_live_plan(const ope_qmix_cfg* cfg, const float* dones_env, void* workspace, int64_t workspace_bytes, void* stream) {

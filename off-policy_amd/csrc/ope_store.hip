@@ -25,7 +25,8 @@ namespace {
 constexpr int kFields = 8;
 constexpr int kBlock = 256;
 constexpr int kTargetFloats = 6144;  // insert (row path): ~24 KB of payload per workgroup
-constexpr int kStepBytes = 8192;     // gather: a workgroup reads about this many contiguous bytes of ONE episode
+constexpr int kStepBytes = 16384;    // gather: a workgroup reads about this many contiguous bytes of ONE episode (round 6, 3s5z B = 32, same box: 8 KB 23.7 us / 22.3 copy-only,
+                                     // 12 KB 20.6 / 20.3, 16 KB 21.1 / 20.3; round 2 had measured 8 KB best on the kernel of that time)
 constexpr int kTileMax = 7168;       // short-row tiles staged in LDS: at most 28 KB (+ padding)
 
 // tuning knobs (defaults = measured best; ope_set_gather_params / OPE_GATHER_* for A/B runs)
@@ -89,6 +90,9 @@ struct CopyArgs {
   // its critical path (as a launch of its own it costs the step ~9 us)
   int live_blocks, live_T, live_N;
   ope::LiveW live_w;
+  // ... and (ope_live_target.copy_live_only) the step path leaves the time entries at and behind len_b of the sampled episode unwritten: the
+  // rows the live-row step never reads (every (t, b) there is multiplied by a zero mask in the loss, qmix.py:161-166)
+  int live_skip;
 };
 // the store's termination flags of the sampled episodes: [capacity][T][1]
 template <class IDX>
@@ -308,14 +312,31 @@ __device__ __forceinline__ void gather_tile(const FieldDesc& F, const CopyArgs& 
 // (workgroup = one contiguous destination range, 1008-byte source rows from B different episodes): 3s5z obs 17.2 -> 14.5 us
 // (5.4 TB/s, 96 % of a plain contiguous copy of the same bytes), MMM2 obs (8-byte vectors) 183 -> 130 us
 // (tools/microbench_gather.hip, profiles/r02_microbench_gather_*.txt).
-template <int VEC, int UNROLL, bool NTL, bool NTS, class IDX>
-__device__ __forceinline__ void gather_steps(const FieldDesc& F, const CopyArgs& A, const IDX& idx, int E, int blk) {
+template <int VEC, int UNROLL, bool NTL, bool NTS, bool SKIP, class IDX>
+__device__ __forceinline__ void gather_steps(const FieldDesc& F, const CopyArgs& A, const IDX& idx, int E, int blk, int EXTRA = 0) {
   typedef float vec_t __attribute__((ext_vector_type(VEC)));
   const int KT = F.rows_per_block;
   const int tb = blk / E, b = blk - tb * E;
-  const int t0 = tb * KT, nt = min(KT, F.TT - t0);
+  const int t0 = tb * KT;
+  int nt = min(KT, F.TT - t0);
   const int64_t e = checked_index(idx, b, A.capacity, A.bad_index);
   if (e < 0) return;
+  if (SKIP) {
+    // len_b exactly as the plan computes it (live_plan_body: 2 + the last t with dones_env[t, b] != 1, 1 if there is none), from the flags at
+    // and behind t0 - 1 only: ONE batch of independent loads per wave in front of the copy's (every wave for itself: no barrier)
+    const float* fl = A.f[5].src + e * A.live_T;
+    const int lane = threadIdx.x & 63;
+    int last = -1;      // (anything before t0 - 1 changes nothing: the block is live then anyway)
+    for (int base = max(t0 - 1, 0); base < A.live_T; base += 64) {
+      const int t = base + lane;
+      const unsigned long long m = __ballot(t < A.live_T && fl[t] != 1.0f);
+      if (m) last = base + 63 - __builtin_clzll(m);
+    }
+    // (EXTRA = 1, the state: the chain kernels evaluate the target mixer of the last live (t, b) on state entry t + 1 = len_b and multiply
+    // the result by 1 - dones_env[t] = 0 -- the value must be the store's (finite), not whatever the destination held)
+    nt = min(nt, max(last + 2, 1) + EXTRA - t0);
+    if (nt <= 0) return;
+  }
   const int pieces = F.DD / VEC, total = nt * F.NA * pieces;
   const float* sbase = F.src + ((int64_t)e * F.TT + t0) * F.NA * F.DD;
   float* dbase = F.dst + ((int64_t)t0 * F.NA * E + b) * F.DD;      // row (k = (t - t0)*NA + a) at dbase + k*E*DD
@@ -385,9 +406,16 @@ __global__ void __launch_bounds__(kBlock) episode_copy_kernel(CopyArgs args, IDX
       return;
     }
     const int vec = (F.DD % 4 == 0) ? 4 : ((F.DD % 2 == 0) ? 2 : 1);
-    if (vec == 4) gather_steps<4, UNROLL, (NT & 1) != 0, (NT & 2) != 0>(F, args, idx, args.n_episodes, blk);
-    else if (vec == 2) gather_steps<2, UNROLL, (NT & 1) != 0, (NT & 2) != 0>(F, args, idx, args.n_episodes, blk);
-    else gather_steps<1, UNROLL, (NT & 1) != 0, (NT & 2) != 0>(F, args, idx, args.n_episodes, blk);
+    if (args.live_skip && f != 5 && f != 7) {      // (the flags themselves and the transition buffers' extra field are copied whole)
+      const int extra = f == 1 ? 1 : 0;
+      if (vec == 4) gather_steps<4, UNROLL, (NT & 1) != 0, (NT & 2) != 0, true>(F, args, idx, args.n_episodes, blk, extra);
+      else if (vec == 2) gather_steps<2, UNROLL, (NT & 1) != 0, (NT & 2) != 0, true>(F, args, idx, args.n_episodes, blk, extra);
+      else gather_steps<1, UNROLL, (NT & 1) != 0, (NT & 2) != 0, true>(F, args, idx, args.n_episodes, blk, extra);
+      return;
+    }
+    if (vec == 4) gather_steps<4, UNROLL, (NT & 1) != 0, (NT & 2) != 0, false>(F, args, idx, args.n_episodes, blk);
+    else if (vec == 2) gather_steps<2, UNROLL, (NT & 1) != 0, (NT & 2) != 0, false>(F, args, idx, args.n_episodes, blk);
+    else gather_steps<1, UNROLL, (NT & 1) != 0, (NT & 2) != 0, false>(F, args, idx, args.n_episodes, blk);
     return;
   }
   copy_dispatch<GATHER, UNROLL, (NT & 1) != 0, (NT & 2) != 0>(F, args, idx, blk);
@@ -396,6 +424,9 @@ __global__ void __launch_bounds__(kBlock) episode_copy_kernel(CopyArgs args, IDX
 // Per-dispatch timing of the gather (bench.py's roofline leg): when enabled, every gather is launched with
 // hipExtLaunchKernel's start / stop events, which time the DISPATCH itself (what rocprofv3's kernel trace reports) instead of
 // the interval between two event markers around it (that interval carries two command-processor boundaries, ~4.7 us).
+// ope_store_gather_attach_live: the target of the NEXT gather launched from this thread (consumed by it, whatever its outcome)
+thread_local ope_live_target g_live_next;
+thread_local bool g_live_pending = false;
 constexpr int kProfRing = 512;
 struct GatherProf {
   bool on = false;
@@ -409,14 +440,12 @@ GatherProf g_prof;
 using ope::g_kprof_on;
 using ope::kprof_work;
 
-// ope_store_gather_attach_live: the target of the NEXT gather launched from this thread (consumed by it, whatever its outcome)
-thread_local ope_live_target g_live_next;
-thread_local bool g_live_pending = false;
 
 template <bool GATHER, class IDX>
 void launch_copy(const CopyArgs& args0, const IDX& idx, hipStream_t st) {
   CopyArgs args = args0;
   args.live_blocks = 0;
+  args.live_skip = 0;
   size_t lds = (size_t)args.lds_bytes;
   if (GATHER && g_live_pending) {
     g_live_pending = false;
@@ -427,6 +456,7 @@ void launch_copy(const CopyArgs& args0, const IDX& idx, hipStream_t st) {
       args.live_T = de.TT; args.live_N = t.n_agents;
       args.live_w = ope::live_views(t.plan, de.TT, t.n_agents, t.batch);
       lds = std::max(lds, (size_t)4 * ope::live_lds_ints(de.TT, t.batch));
+      args.live_skip = t.copy_live_only ? 1 : 0;
     }
   }
   const dim3 grid(args.total_blocks + args.live_blocks), block(kBlock);
@@ -467,6 +497,10 @@ int build_args(const ope_dims* d, const ope_fields* src, const ope_fields* dst, 
     if (over->nontemporal > 0) g_tune.nt = (over->nontemporal - 1) & 3;
     if (over->small_tiles > 0) g_tune.small = over->small_tiles == 1 ? 1 : 0;
   }
+  // a launch that stops at each episode's termination (ope_live_target.copy_live_only) pays one dependent round trip for the flags in front of a
+  // workgroup's copy: four times the bytes per workgroup amortise it (3s5z, B = 32: 26.8 us at 2 048 floats, 20.2 at 4 096, 19.2 at 6 144, 19.9 at 8 192, 21.9 at
+  // 16 384; the whole batch: 23.6 / 21.5 / 23.6 / 23.4)
+  if (gather && g_live_pending && g_live_next.copy_live_only && !(over && over->floats_per_block > 0) && !getenv("OPE_GATHER_FLOATS")) g_tune.floats = 6144;
   const float* s[kFields] = {src->obs, src->share_obs, src->acts, src->rewards, src->dones, src->dones_env, src->avail_acts,
                              src->valid_transition};
   float* t[kFields] = {dst->obs, dst->share_obs, dst->acts, dst->rewards, dst->dones, dst->dones_env, dst->avail_acts,

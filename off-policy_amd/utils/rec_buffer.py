@@ -304,7 +304,7 @@ class RecPolicyBuffer(object):
             t.fill_(self._filled_dev_value)
         return t
 
-    def sample_inds(self, sample_inds, timing_events=None, out=None, extra=None, _sampler=None, lazy_obs=None, live_for=None):
+    def sample_inds(self, sample_inds, timing_events=None, out=None, extra=None, _sampler=None, lazy_obs=None, live_for=None, live_only=False):
         """Gather the given episode slots; same 7-tuple as rec_buffer.py:192-240 (CUDA tensors, reference shapes).
         `timing_events`: optional (start, end) torch.cuda.Event pair recorded tightly around the gather launch.
         `out`: optional destination from `alloc_batch` (HIP-graph replays read the batch from fixed addresses); the
@@ -317,7 +317,12 @@ class RecPolicyBuffer(object):
         extra workgroups in front of the copy's, reading the store's dones_env of the sampled episodes (ope_store_gather_attach_live) --
         and the batch is tagged so that `trainer.train_policy_on_batch` skips its own plan launch in front of the step (~9 us of a 0.3 ms
         step). The tag is good for the NEXT train call on this batch; any other use of the batch is unaffected (the arrays are what the
-        reference returns)."""
+        reference returns).
+        `live_only` (with `live_for`; default off): the copy itself stops at each episode's termination -- of obs and share_obs (90 % of the
+        batch's bytes) only the time entries t < len_b (share_obs: t <= len_b) are moved, the ones the live-row step reads; the later entries of those two arrays
+        keep whatever the freshly allocated batch held. Every such (t, b) is multiplied by a zero mask in the reference's loss
+        (qmix.py:161-166), and `live_for.train_policy_on_batch` refuses the batch if its step would not run on this plan's live rows. Use
+        it when the batch goes straight into that call (bench.py does); leave it off to get the reference's arrays, padding included."""
         lazy = bool(self.lazy_obs if lazy_obs is None else lazy_obs)
         host_inds = None
         if torch.is_tensor(sample_inds):     # indices already on the device (HIP-graph replays keep them in a static tensor)
@@ -364,7 +369,8 @@ class RecPolicyBuffer(object):
         live_tag = None
         if (live_for is not None and getattr(live_for, "build_live_plan", None) is not None and self.use_same_share_obs and _sampler is None and
                 not (lazy and host_inds is not None)):      # (the attachment rides on the FIRST gather launch below: the plain forms)
-            live_tag = live_for.build_live_plan(self, host_inds, B)
+            live_tag = (live_for.build_live_plan(self, host_inds, B, live_only=True) if live_only else
+                        live_for.build_live_plan(self, host_inds, B))
         if timing_events is not None:
             timing_events[0].record()
         if _sampler is not None:

@@ -410,3 +410,66 @@ def test_plan_built_by_the_gather_launch_is_the_plan_kernels():
     # (e) a trainer pinned to every padded row gets no plan
     trainer.tune["live_rows"] = 1
     assert pb.sample_inds(inds, live_for=trainer)[5]._ope_live is None
+
+
+def test_live_only_gather_moves_the_live_entries_and_nothing_else():
+    """RecPolicyBuffer.sample_inds(live_for=trainer, live_only=True): of obs and share_obs the gather launch writes only the time entries
+    t < len_b (len_b as the plan defines it -- non-monotone flags included, _holes). Checked: (i) into a destination filled with NaN, every
+    live entry equals the plain gather's bit for bit and every dead entry is still NaN (nothing else was moved), the short-row fields are
+    whole; (ii) the step on that batch -- NaN in every row it must not read -- gives the plain batch's gradient and priorities BIT FOR BIT;
+    (iii) a step that would not run on this plan's live rows refuses the batch."""
+    from offpolicy_amd import _lib
+    from offpolicy_amd.config import default_args
+    from offpolicy_amd.utils.synth import EnvDims
+    dims, B = EnvDims("custom", 3, 9, 188, 216, 24), 8      # obs and state rows long enough for the episode-contiguous step path (>= 32 16-byte pieces)
+    T, N = dims.episode_length, dims.n_agents
+    policy, trainer, buf = _make(dims, default_args(use_per=True), B, seed=6, dones=_holes)
+    trainer.tune.update(trunk_path=4, chain_path=2, wgrad_path=2, scan_family=4)
+    pb = buf.policy_buffers["policy_0"]
+    inds = np.array([3, 0, 17, 9, 1, 22, 5, 5])
+    w = np.linspace(0.3, 1.0, B).astype(np.float32)
+    snap = _snapshot(trainer)
+    plain = pb.sample_inds(inds)
+    ref = _one(trainer, tuple({"policy_0": x} for x in plain) + (w, inds), live=True)
+    trainer.tune["live_rows"] = 0
+    de = plain[5][:, :, 0].cpu().numpy()      # [T, B]
+    lens = plan_reference(de, N)
+    len_b = np.empty(B, np.int64)
+    len_b[lens["perm"]] = lens["len"]
+    assert len_b.min() < T, "the case needs dead entries"
+    _restore(trainer, snap)
+    out = pb.alloc_batch(B)
+    for v in out.values():
+        if torch.is_tensor(v):
+            v.fill_(float("nan"))
+    s = pb.sample_inds(inds, live_for=trainer, live_only=True, out=out)
+    assert s[5]._ope_live is not None and s[5]._ope_live[4] is True
+    torch.cuda.synchronize()
+    obs, share = s[0].cpu().numpy(), s[1].cpu().numpy()              # [N, T+1, B, D], [T+1, B, S]
+    pobs, pshare = plain[0].cpu().numpy(), plain[1].cpu().numpy()
+    for b in range(B):
+        L = int(len_b[b])
+        np.testing.assert_array_equal(obs[:, :L, b], pobs[:, :L, b])
+        np.testing.assert_array_equal(share[:L + 1, b], pshare[:L + 1, b])      # (the target mixer of the last live step reads state entry len_b: times zero)
+        assert np.isnan(obs[:, L:, b]).all() and np.isnan(share[L + 1:, b]).all(), b
+    for k in (2, 3, 4, 5, 6):      # acts, rewards, dones, dones_env, avail_acts: whole
+        assert torch.equal(s[k], plain[k]), k
+    info, prio, _ = trainer.train_policy_on_batch(tuple({"policy_0": x} for x in s) + (w, inds))
+    launched = _lib.last_launches()
+    torch.cuda.synchronize()
+    assert "live_plan" not in launched and any(k.startswith("trunk_fwd4_live<") for k in launched), launched
+    assert torch.equal(trainer.grad[:trainer.numel + 4], ref[2])
+    np.testing.assert_array_equal(np.asarray(prio), ref[1])
+    assert np.isfinite(float(info["loss"]))
+    # (iii) the tag is not the latest one any more: a step that would build its own plan over every row of this batch must not run
+    _restore(trainer, snap)
+    s1 = pb.sample_inds(inds, live_for=trainer, live_only=True)
+    pb.sample_inds(inds[::-1].copy(), live_for=trainer)
+    with pytest.raises(RuntimeError, match="live_only"):
+        trainer.train_policy_on_batch(tuple({"policy_0": x} for x in s1) + (w, inds))
+    # a trainer pinned to every padded row gets a whole batch whatever was asked
+    trainer.tune["live_rows"] = 1
+    s2 = pb.sample_inds(inds, live_for=trainer, live_only=True)
+    assert s2[5]._ope_live is None
+    for x, y in zip(s2, plain):
+        assert torch.equal(x, y)
