@@ -689,7 +689,10 @@ __device__ __forceinline__ void tile_opt_tail(const TileOpt& o, const float* __r
   }
 }
 
-template <int NCA, int NCC>
+// ONE: the launch has one workgroup per tile (tiles <= kMaxTilesPerLaunch: config 3's 16 / 48) -- no tile loop, so nothing is hoisted out of one
+// and kept alive across the whole chain (round 6: the looped form of <2, 5> carried 449 spilled SGPRs -- Philox keys, null-pointer masks, row
+// masks of the NEXT tile's staging -- through 14.6 k instructions; `first` is a constant here)
+template <int NCA, int NCC, bool ONE>
 __global__ void __launch_bounds__(256, 1) ddpg_critic_tile_kernel(TileArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave: uniform (SGPR)
@@ -819,6 +822,7 @@ __global__ void __launch_bounds__(256, 1) ddpg_critic_tile_kernel(TileArgs a) {
     f32x4 dxu[NCC];
     tile_backward<true, false, NCC>(a.n2, lds, tl, lds + a.o_dz, lds + a.o_d1, lds + a.o_da, dq, slab, first, wave, lane, wb, dxu);
     OPE_STAMP(6)
+    if (ONE) break;
     first = false;
     tile += gridDim.x;
     if (tile >= a.tiles) break;
@@ -834,7 +838,7 @@ __global__ void __launch_bounds__(256, 1) ddpg_critic_tile_kernel(TileArgs a) {
 }
 
 // ---- actor update -------------------------------------------------------------------------------------------------------
-template <int NCA, int NCC>
+template <int NCA, int NCC, bool ONE>
 __global__ void __launch_bounds__(256, 1) ddpg_actor_tile_kernel(TileArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave: uniform (SGPR)
@@ -926,6 +930,7 @@ __global__ void __launch_bounds__(256, 1) ddpg_actor_tile_kernel(TileArgs a) {
     lds_barrier();                      // `da` is free again
     f32x4 dxa[NCA];
     tile_backward<true, false, NCA>(a.n0, lds, ta, lds + a.o_dz, lds + a.o_d1, lds + a.o_da, dl, slab, first, wave, lane, wab, dxa);
+    if (ONE) break;
     first = false;
     tile += gridDim.x;
     if (tile >= a.tiles) break;
@@ -1100,10 +1105,11 @@ static int launch_tile(KERN kern, const TileArgs& a, int blocks, size_t lds, hip
   OPE_LAUNCH(kern, dim3(blocks), dim3(256), lds, st, a);
   return hipGetLastError() == hipSuccess ? OPE_OK : OPE_ELAUNCH;
 }
-#define OPE_TILE_DISPATCH(KERNEL, nca, ncc, ...)                                  \
-  ((nca) == 2 ? ((ncc) == 5 ? launch_tile(KERNEL<2, 5>, __VA_ARGS__) : launch_tile(KERNEL<2, 8>, __VA_ARGS__))    \
-   : (nca) == 4 ? ((ncc) == 5 ? launch_tile(KERNEL<4, 5>, __VA_ARGS__) : launch_tile(KERNEL<4, 8>, __VA_ARGS__))  \
-                : ((ncc) == 5 ? launch_tile(KERNEL<8, 5>, __VA_ARGS__) : launch_tile(KERNEL<8, 8>, __VA_ARGS__)))
+#define OPE_TILE_DISPATCH1(KERNEL, ONE, nca, ncc, ...)                                  \
+  ((nca) == 2 ? ((ncc) == 5 ? launch_tile(KERNEL<2, 5, ONE>, __VA_ARGS__) : launch_tile(KERNEL<2, 8, ONE>, __VA_ARGS__))    \
+   : (nca) == 4 ? ((ncc) == 5 ? launch_tile(KERNEL<4, 5, ONE>, __VA_ARGS__) : launch_tile(KERNEL<4, 8, ONE>, __VA_ARGS__))  \
+                : ((ncc) == 5 ? launch_tile(KERNEL<8, 5, ONE>, __VA_ARGS__) : launch_tile(KERNEL<8, 8, ONE>, __VA_ARGS__)))
+#define OPE_TILE_DISPATCH(KERNEL, one, nca, ncc, ...) ((one) ? OPE_TILE_DISPATCH1(KERNEL, true, nca, ncc, __VA_ARGS__) : OPE_TILE_DISPATCH1(KERNEL, false, nca, ncc, __VA_ARGS__))
 
 int launch_ddpg_critic_fused(const ope_ddpg_cfg* cfg, const ope_mlp_batch* bt, const float* theta_actor_tgt, const float* theta_critic,
                              const float* theta_critic_tgt, const float* U, const float* per_w, float* slabs, float* grad, float* prio_out,
@@ -1131,7 +1137,7 @@ int launch_ddpg_critic_fused(const ope_ddpg_cfg* cfg, const ope_mlp_batch* bt, c
     const double am = (double)a.D * OPE_H + OPE_H * OPE_H + (double)OPE_H * a.A, cm = (double)a.Din * OPE_H + OPE_H * OPE_H + (double)OPE_H * a.K;
     kprof_work(2.0 * ((double)a.N * a.B * am + 2.0 * a.B * cm + a.B * (cm + OPE_H * OPE_H + (double)OPE_H * a.K)));
   }
-  const int rc = OPE_TILE_DISPATCH(ddpg_critic_tile_kernel, a.n0.nc0, a.n1.nc0, a, blocks, (size_t)lds * sizeof(float), st);
+  const int rc = OPE_TILE_DISPATCH(ddpg_critic_tile_kernel, blocks == a.tiles, a.n0.nc0, a.n1.nc0, a, blocks, (size_t)lds * sizeof(float), st);
   if (rc || opt) return rc;
   return launch_reduce(slabs, blocks, a.slab_stride, ope_agent_layout_mlp(a.Din, a.K, 0), grad, gsq, st);
 }
@@ -1157,7 +1163,7 @@ int launch_ddpg_actor_fused(const ope_ddpg_cfg* cfg, const ope_mlp_batch* bt, co
     const double am = (double)a.D * OPE_H + OPE_H * OPE_H + (double)OPE_H * a.A, cm = (double)a.Din * OPE_H + OPE_H * OPE_H + (double)OPE_H * a.K;
     kprof_work(2.0 * (double)a.N * a.B * (am + cm + ((double)OPE_H * a.K + OPE_H * OPE_H + (double)OPE_H * a.A) + am + ((double)a.A * OPE_H + OPE_H * OPE_H)));
   }
-  const int rc = OPE_TILE_DISPATCH(ddpg_actor_tile_kernel, a.n0.nc0, a.n1.nc0, a, blocks, (size_t)lds * sizeof(float), st);
+  const int rc = OPE_TILE_DISPATCH(ddpg_actor_tile_kernel, blocks == a.tiles, a.n0.nc0, a.n1.nc0, a, blocks, (size_t)lds * sizeof(float), st);
   if (rc || opt) return rc;
   return launch_reduce(slabs, blocks, a.slab_stride, ope_agent_layout_mlp(a.D, a.A, 0), grad, gsq, st);
 }

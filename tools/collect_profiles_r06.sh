@@ -12,10 +12,10 @@ mkdir -p $O
 eps() { case $1 in 3m|MMM2|3s5z_gall) echo "--episodes 1000";; *) echo "";; esac; }
 steps() { case $1 in rmatd3_MMM2) echo "--steps 12 --warmup 4";; maddpg_spread|matd3_spread) echo "--steps 200 --warmup 40";; *) echo "--steps 40 --warmup 10";; esac; }
 bench() { w=$1; shift; timeout 400 python bench.py --workload $w $(eps $w) $(steps $w) --no-cpu-baseline "$@" > $O/bench_$w.json 2> $O/bench_$w.err; echo "bench $w rc=$? $(grep -o '"ms_per_step": [0-9.]*' $O/bench_$w.json | head -1)"; }
-kt() { w=$1; shift; timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$w -o p -- python bench.py --workload $w $(eps $w) $(steps $w) --repeats 2 --no-cpu-baseline --no-kernel-table "$@" > $O/kt_$w.json 2> $O/kt_$w.log
+kt() { w=$1; shift; timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$w -o p -- python bench.py --workload $w $(eps $w) $(steps $w) --repeats 2 --no-cpu-baseline --no-kernel-table --no-full-length --no-gather-extras "$@" > $O/kt_$w.json 2> $O/kt_$w.log
   echo "kt $w rc=$?"; cp "$(find $O/kt_$w -name '*kernel_stats.csv' | head -1)" $O/${w}_kernel_stats.csv; rm -rf $O/kt_$w; }
 pass() { w=$1; n=$2; shift; shift
-  timeout 300 rocprofv3 --pmc "$@" --output-format csv -d $O/pmc_${w}_$n -o p -- python bench.py --workload $w $(eps $w) --steps 8 --warmup 4 --repeats 1 --no-cpu-baseline --no-kernel-table > $O/pmc_${w}_$n.json 2> $O/pmc_${w}_$n.log
+  timeout 300 rocprofv3 --pmc "$@" --output-format csv -d $O/pmc_${w}_$n -o p -- python bench.py --workload $w $(eps $w) --steps 8 --warmup 4 --repeats 1 --no-cpu-baseline --no-kernel-table --no-full-length $(case $w in 3s5z) echo --no-gather-extras;; esac) > $O/pmc_${w}_$n.json 2> $O/pmc_${w}_$n.log
   echo "pmc $w $n rc=$?"; cp "$(find $O/pmc_${w}_$n -name '*counter_collection.csv' | head -1)" $O/${w}_pmc_${n}_raw.csv 2>/dev/null
   python tools/pmc_table.py "$(find $O/pmc_${w}_$n -name '*counter_collection.csv' | head -1)" > $O/${w}_pmc_$n.txt; rm -rf $O/pmc_${w}_$n; }
 timeout 300 python bench.py > $O/bench_default_with_cpu.json 2> $O/bench_default_with_cpu.err; echo "default bench rc=$? $(grep -o '"ms_per_step": [0-9.]*' $O/bench_default_with_cpu.json | head -1)"
@@ -26,7 +26,8 @@ for w in 3s5z maddpg_spread; do
   pass $w fetch FETCH_SIZE
   pass $w write WRITE_SIZE
 done
-python tools/gather_traffic.py 3s5z:32:5000:r06 95563264 $O/3s5z_pmc_fetch_raw.csv $O/3s5z_pmc_write_raw.csv > $O/gather_traffic.txt 2>&1
+# (every gather launch of those passes stops at the sampled episodes' terminations -- live_only, --no-gather-extras: no plain gathers in the process)
+python tools/gather_traffic.py 3s5z:32:5000:live_only $(python -c "import json;print(json.load(open('$O/bench_3s5z.json'))['roofline']['algorithmic_bytes_per_launch'])") $O/3s5z_pmc_fetch_raw.csv $O/3s5z_pmc_write_raw.csv > $O/gather_traffic.txt 2>&1
 cp profiles/gather_traffic.json $O/gather_traffic.json
 rm -f $O/*_raw.csv
 ls $O | head -80
