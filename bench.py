@@ -56,6 +56,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather-extras", action="store_true", help="QMIX workloads: skip the 40 plain gather dispatches after the timed region (event-bracket and "
                     "copy-only references of the roofline block): counter passes that average over every gather launch of the process use it")
+    ap.add_argument("--prefetch", type=int, default=0, metavar="AT", help="QMIX workloads: the gather of step k + 1 runs on a side stream from the point AT of step k "
+                    "on (RecPolicyBuffer.sample_inds_ahead(after=midstep_event(AT)): 1 the GRU scan, 2 the chain kernel, 3 the scan's adjoint, 4 the weight "
+                    "gradients, 5 their reduction; 9 = from the start of step k): one gather and one train step per call as before, the same indices in "
+                    "the same order, but the HBM-bound copy runs beside latency-bound kernels. 0 (default): `value` is the sequential step")
     ap.add_argument("--whole-batch", action="store_true", help="QMIX workloads: the gather copies every padded time entry of obs / share_obs (what the "
                     "reference's sample() returns) instead of stopping at each sampled episode's termination (RecPolicyBuffer.sample_inds(live_for=trainer, "
                     "live_only=True): the entries the live-row step reads)")
@@ -543,10 +547,31 @@ def main():
 
         n_trained = [0]
 
+        ahead = {"cur": None, "at": a.prefetch}
+
         def one_step(i=None):
             inds = opdist.shard_indices(np.random.choice(len(buf), global_batch), rank, world)
             if G["graphed"] is not None:
                 return G["graphed"](inds)
+            if ahead["at"]:
+                # software pipeline over consecutive updates: train on the batch whose gather was submitted one call ago, then submit the next one
+                # (the very first call submits its own first). Every call launches exactly one gather and one train step.
+                if ahead["cur"] is None:
+                    ahead["cur"] = pbuf.sample_inds_ahead(inds, live_for=trainer, live_only=not a.whole_batch)
+                    inds = opdist.shard_indices(np.random.choice(len(buf), global_batch), rank, world)
+                nxt = None
+                if ahead["at"] == 9:
+                    nxt = pbuf.sample_inds_ahead(inds, live_for=trainer, live_only=not a.whole_batch)
+                s = ahead["cur"].get()
+                mid = pbuf.midstep_event(ahead["at"]) if ahead["at"] != 9 else None
+                batch = tuple({"policy_0": x} for x in s) + (None, None)
+                info, _, _ = trainer.train_policy_on_batch(batch)
+                if nxt is None:
+                    nxt = pbuf.sample_inds_ahead(inds, live_for=trainer, live_only=not a.whole_batch, after=mid)
+                ahead["cur"] = nxt
+                if args.use_soft_update:
+                    trainer.soft_target_updates()
+                return info
             # live_for: where the step runs on live rows, this gather launch also builds the step's row plan (extra workgroups in front of
             # the copy's, from the store's flags of the same episodes) instead of a launch of its own in front of the step
             # live_only: ... and the copy stops at each episode's termination (the post-terminal entries of obs / share_obs are never read)
@@ -604,11 +629,20 @@ def main():
                 d = [(now[i] * now[3] - (seen[i] * seen[3] if seen else 0.0)) / (now[3] - n0) for i in range(3)]
                 return d[0] / ((T_ + 1) * NB_), d[1] / (T_ * NB_), d[2] / (T_ * local_batch)
             per_kernel = measured_kernel_table(one_step, live_ratio=live_ratio)
+        # The same steps as a two-stage pipeline (RecPolicyBuffer.sample_inds_ahead): the gather of step k + 1 on a side stream beside step k's GRU
+        # scan. Reported beside `value` (value_prefetch), never as `value`: the sequential sample -> train step is the headline.
+        pre = None
+        if world == 1 and graphed is None and not a.prefetch and not a.no_early_plan and not pbuf.lazy_obs and live_row_stats(trainer, local_batch) is not None:
+            ahead["at"], ahead["cur"] = 1, None
+            w_pre, _ = timed_windows(one_step, a.steps, max(4, a.warmup // 2), world, dev, max(1, min(a.repeats, 3)))
+            torch.cuda.synchronize()
+            ahead["at"], ahead["cur"] = 0, None
+            pre = dict(elapsed=median_window(w_pre), windows=w_pre)
         live = live_row_stats(trainer, local_batch)       # rows the steps of this leg really ran (None: every padded row)
         results.append(dict(leg=leg, local_batch=local_batch, global_batch=global_batch, elapsed=elapsed, gather_ms=gather_ms, loss=loss,
                             graphed=graphed is not None, bracket_ms=bracket_ms, n_kernel_ms=len(kernel_ms), windows=windows, per_kernel=per_kernel,
                             lazy_obs=bool(pbuf.lazy_obs), live=live, copy_only_ms=copy_only_ms, riders=bool(live) and not a.no_early_plan,
-                            live_only=bool(live) and not (a.whole_batch or a.no_early_plan or pbuf.lazy_obs)))
+                            live_only=bool(live) and not (a.whole_batch or a.no_early_plan or pbuf.lazy_obs), pre=pre))
     # The same command on a store whose episodes all run the full T steps (dones_env = 1 at the last step only): nothing to skip, every row
     # of the padded batch is live -- what the step costs when the data offers no dead rows (guardrail ii). After every
     # other measurement: the store's flags are overwritten.
@@ -709,6 +743,13 @@ def main():
                                  "termination, found on the device from dones_env at the start of every step (mean over %d steps); every "
                                  "other row is multiplied by a zero mask in the reference's loss (qmix.py:161-166,184-198)" % (
                                      100.0 * lv[0] / T1NB, T1NB, lv[3])) if lv else "every padded row"
+        if r0.get("pre") is not None:
+            out["value_prefetch"] = round(a.steps / r0["pre"]["elapsed"], 3)
+            out["prefetch"] = {"what": "the same steps as a two-stage pipeline over consecutive updates: the gather of step k + 1 runs on a side stream beside step k's "
+                                       "GRU scan (RecPolicyBuffer.sample_inds_ahead(after=midstep_event(1)), ope_qmix_signal_event) instead of in front of step "
+                                       "k + 1 -- one gather and one train step per call, the same indices and batches in the same order; NOT `value`",
+                               "ms_per_step": round(1e3 * r0["pre"]["elapsed"] / a.steps, 4),
+                               "ms_per_step_windows": [round(1e3 * w / a.steps, 4) for w in r0["pre"]["windows"]]}
         if full is not None:
             out["value_full_length"] = round(a.steps / full["elapsed"], 3)
             out["full_length"] = {"what": "the same command on the same store with every episode running the full T steps (dones_env = 1 at the last step "

@@ -385,6 +385,13 @@ int ope_store_live_plan(int32_t capacity, int32_t episode_length, const float* s
  * -- no plan: do not promise one -- unless the store's episode_length, the batch size and the shape limits match the target). NULL cancels. */
 int ope_store_gather_attach_live(const ope_live_target* target);
 int ope_qmix_live_plan(const ope_qmix_cfg* cfg, const float* dones_env, void* workspace, int64_t workspace_bytes, void* stream);
+/* A hook for work that wants to start in the MIDDLE of a step (a gather of the next batch on another stream, beside the latency-bound half of
+ * this one): the next ope_qmix_loss_and_grad[_ref] launched from the calling thread records `event` (a hipEvent_t) on its stream directly in
+ * front of launch `at` -- 1 the GRU scan, 2 the (t, b)-row chain, 3 the scan's adjoint, 4 the weight gradients, 5 their reduction -- or behind
+ * its last launch when its path has no such point. Consumed by that one step; NULL cancels. The caller makes its other stream wait on the
+ * event AFTER the step call has returned (hipStreamWaitEvent on an event not yet recorded is a no-op). off-policy_amd:
+ * RecPolicyBuffer.sample_inds_ahead(after=...). */
+int ope_qmix_signal_event(void* event, int32_t at);
 int ope_qmix_loss_and_grad_ref(const ope_qmix_cfg* cfg, const ope_fields* batch, const ope_obs_ref* obs, const float* theta,
                                const float* theta_tgt, const float* per_weights, void* workspace, int64_t workspace_bytes,
                                float* grad, float* td_abs_stats, void* stream);

@@ -136,6 +136,7 @@ def _load():
         "ope_qmix_live_target": (C.c_int, [C.POINTER(QmixCfg), p, i64, i32, C.POINTER(LiveTarget)]),
         "ope_store_live_plan": (C.c_int, [i32, i32, p, p, p, C.POINTER(LiveTarget), p]),
         "ope_store_gather_attach_live": (C.c_int, [C.POINTER(LiveTarget)]),
+        "ope_qmix_signal_event": (C.c_int, [p, i32]),
         "ope_qmix_loss_and_grad_ref": (C.c_int, [C.POINTER(QmixCfg), C.POINTER(Fields), C.POINTER(ObsRef), p, p, p, p, i64, p, p, p]),
         "ope_store_gather_profile": (C.c_int, [i32]),
         "ope_store_gather_profile_read": (C.c_int, [p, i32]),

@@ -350,13 +350,15 @@ class QMix(object):
             self._ws[B] = ws
         return self._ws[B]
 
-    def build_live_plan(self, pbuf, host_inds, batch, live_only=False):
+    def build_live_plan(self, pbuf, host_inds, batch, live_only=False, region=0):
         """Have the NEXT gather launch of `pbuf` (RecPolicyBuffer; the call that follows in sample_inds) also build the live-row plan of this
         trainer's next step on those `batch` episodes -- a few extra workgroups in front of the copy's that read the store's termination
         flags through the launch's own indices (ope.h: ope_store_gather_attach_live) -- and return the tag `train_policy_on_batch`
         recognises; None where that step would not run on live rows "by shape" (or the trainer pins every padded row / is one of the
         multi-policy, MLP forms). Same stream as the step: no events, one plan region. `live_only`: that launch's copy also leaves the time
-        entries at and behind each episode's length unwritten in obs / share_obs (ope_live_target.copy_live_only; tag[4])."""
+        entries at and behind each episode's length unwritten in obs / share_obs (ope_live_target.copy_live_only; tag[4]). `region` (0 | 1):
+        which of the workspace's two plan regions (ope_qmix_live_target) -- a batch gathered AHEAD, while the step before still reads its own
+        plan, goes to the other one (RecPolicyBuffer.sample_inds_ahead alternates them); a tag stays good until the next plan for its region."""
         if self.multi or self._mlp or int(self.tune.get("live_rows", 0)) == 1 or int(self.tune.get("debug", 0)):
             return None
         batch = int(batch)
@@ -366,17 +368,19 @@ class QMix(object):
         ws = self._workspace(cfg)
         if self._live is None:
             self._live = {"targets": {}}
-        key = (batch, int(ws.data_ptr()))
+        region = int(region) & 1
+        key = (batch, int(ws.data_ptr()), region)
         tgt = self._live["targets"].get(key)
         if tgt is None:
             tgt = _lib.LiveTarget()
-            if _lib.lib.ope_qmix_live_target(C.byref(cfg), _lib.ptr(ws), ws.numel(), 0, C.byref(tgt)) != 0:
+            if _lib.lib.ope_qmix_live_target(C.byref(cfg), _lib.ptr(ws), ws.numel(), region, C.byref(tgt)) != 0:
                 return None
             self._live["targets"][key] = tgt
         tgt.copy_live_only = 1 if live_only else 0
         _lib.check(_lib.lib.ope_store_gather_attach_live(C.byref(tgt)), "ope_store_gather_attach_live")
         self._live_seq += 1
-        return ("ope_live", int(ws.data_ptr()), self._live_seq, 0, bool(live_only))
+        self._live.setdefault("latest", {})[(int(ws.data_ptr()), region)] = self._live_seq
+        return ("ope_live", int(ws.data_ptr()), self._live_seq, region, bool(live_only))
 
     def workspace_view(self, batch, name):
         """Debug/test access to a named intermediate of the last step with this batch size (float32 view)."""
@@ -491,8 +495,8 @@ class QMix(object):
         assert T1 == self.episode_length + 1 and N == getattr(self, "_n_kernel_agents", self.num_agents), "batch does not match the trainer's dimensions"
         cfg = self._cfg(B)
         ws = self._workspace(cfg)
-        if (live_tag is not None and oref is None and cfg.live_rows in (0, 2) and self._live is not None and
-                live_tag[:3] == ("ope_live", int(ws.data_ptr()), self._live_seq)):
+        if (live_tag is not None and oref is None and cfg.live_rows in (0, 2) and self._live is not None and live_tag[0] == "ope_live" and
+                live_tag[1] == int(ws.data_ptr()) and self._live.get("latest", {}).get((live_tag[1], int(live_tag[3]))) == live_tag[2]):
             # the gather launch that wrote this batch -- the latest one attached for this workspace -- built the step's plan: no plan launch
             cfg.live_rows = 3 + int(live_tag[3])
         elif live_tag is not None and len(live_tag) > 4 and live_tag[4]:

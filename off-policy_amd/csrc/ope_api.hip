@@ -439,6 +439,22 @@ extern "C" int ope_qmix_obs_ref_ok(const ope_qmix_cfg* cfg) { return obs_ref_cfg
 static int qmix_step(const ope_qmix_cfg* cfg, const ope_fields* batch, const ope_obs_ref* oref, const float* theta, const float* theta_tgt,
                      const float* per_weights, void* workspace, int64_t workspace_bytes, float* grad, float* td_abs_stats, void* stream);
 
+// ope_qmix_signal_event: an event the NEXT step launched from this thread records on its stream in front of one of its launches
+static thread_local hipEvent_t g_signal_ev = nullptr;
+static thread_local int g_signal_at = 0;
+extern "C" int ope_qmix_signal_event(void* event, int32_t at) {
+  if (event && (at < 1 || at > 5)) return OPE_EINVAL;
+  g_signal_ev = (hipEvent_t)event;
+  g_signal_at = event ? at : 0;
+  return OPE_OK;
+}
+static int step_signal(int point, hipStream_t st) {
+  if (g_signal_at != point || !g_signal_ev) return OPE_OK;
+  const hipEvent_t ev = g_signal_ev;
+  g_signal_ev = nullptr; g_signal_at = 0;
+  return hipEventRecord(ev, st) == hipSuccess ? OPE_OK : OPE_ELAUNCH;
+}
+
 extern "C" int ope_qmix_loss_and_grad(const ope_qmix_cfg* cfg, const ope_fields* batch, const float* theta,
                                       const float* theta_tgt, const float* per_weights, void* workspace,
                                       int64_t workspace_bytes, float* grad, float* td_abs_stats, void* stream) {
@@ -739,6 +755,7 @@ static int qmix_step(const ope_qmix_cfg* cfg, const ope_fields* batch, const ope
     gf.rg = W + p.rg + r0 * OPE_H; gf.zg = W + p.zg + r0 * OPE_H; gf.ng = W + p.ng + r0 * OPE_H; gf.ghn = W + p.ghn + r0 * OPE_H;
     gf.dbg = dbg_on ? (long long*)(W + p.dbg) + 71168 : nullptr;
     gf.lp = lp; gf.B = p.B; gf.N = p.N;
+    if (c == 0 && (rc = step_signal(1, st))) return rc;
     if ((rc = launch_gru_fwd(gf, scan_st))) return rc;
     if (hyp_late) {
       if ((rc = launch_mixer_hyp(hyp_args, sp->s))) return rc;
@@ -773,7 +790,9 @@ static int qmix_step(const ope_qmix_cfg* cfg, const ope_fields* batch, const ope
       ca.dbg = (long long*)(W + p.dbg);
     }
     if (hyp_on_side && hipStreamWaitEvent(st, sp->ev[1], 0) != hipSuccess) return OPE_ELAUNCH;
+    if ((rc = step_signal(2, st))) return rc;
     if ((rc = launch_qchain(ca, st))) return rc;
+    if ((rc = step_signal(3, st))) return rc;
   }
   for (int c = 0; c < C && do_fwd && !p.chain; ++c) {   // heads of chunk c as soon as its scan is done
     if (C > 1 && hipStreamWaitEvent(st, sp->scan_done[c], 0) != hipSuccess) return OPE_ELAUNCH;
@@ -882,7 +901,9 @@ static int qmix_step(const ope_qmix_cfg* cfg, const ope_fields* batch, const ope
     memset(&wt, 0, sizeof(wt));
     if (want_w2) {      // (C = 1: this is the only pass; the table and its plan were made before the first launch)
       if (wt2.n > 0) {
+        if ((rc = step_signal(4, st))) return rc;
         if ((rc = launch_wgrad2(w2, W + p.raw2, W + p.rsum, st))) return rc;
+        if ((rc = step_signal(5, st))) return rc;
         reduced = true;
       }
       continue;
@@ -979,6 +1000,10 @@ static int qmix_step(const ope_qmix_cfg* cfg, const ope_fields* batch, const ope
   if (finalize_blocks(ft) > p.n_gsq) return OPE_ENOSPC;
   // (n_loss_tiles < 0: no loss tail -- an agent-backward part writes its parameter block only)
   if ((rc = launch_finalize(ft, W + p.rsum, theta, W + p.loss_part, do_mix ? p.n_loss_tiles : -1, grad, st, W + p.gsq_part))) return rc;
+  if (g_signal_ev) {      // (a point this step's path does not pass: the event still fires, behind the step's last launch)
+    const int at = g_signal_at;
+    if ((rc = step_signal(at, st))) return rc;
+  }
   return OPE_OK;
 }
 

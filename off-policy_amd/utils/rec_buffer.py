@@ -304,7 +304,8 @@ class RecPolicyBuffer(object):
             t.fill_(self._filled_dev_value)
         return t
 
-    def sample_inds(self, sample_inds, timing_events=None, out=None, extra=None, _sampler=None, lazy_obs=None, live_for=None, live_only=False):
+    def sample_inds(self, sample_inds, timing_events=None, out=None, extra=None, _sampler=None, lazy_obs=None, live_for=None, live_only=False,
+                    live_region=0):
         """Gather the given episode slots; same 7-tuple as rec_buffer.py:192-240 (CUDA tensors, reference shapes).
         `timing_events`: optional (start, end) torch.cuda.Event pair recorded tightly around the gather launch.
         `out`: optional destination from `alloc_batch` (HIP-graph replays read the batch from fixed addresses); the
@@ -369,7 +370,7 @@ class RecPolicyBuffer(object):
         live_tag = None
         if (live_for is not None and getattr(live_for, "build_live_plan", None) is not None and self.use_same_share_obs and _sampler is None and
                 not (lazy and host_inds is not None)):      # (the attachment rides on the FIRST gather launch below: the plain forms)
-            live_tag = (live_for.build_live_plan(self, host_inds, B, live_only=True) if live_only else
+            live_tag = (live_for.build_live_plan(self, host_inds, B, live_only=bool(live_only), region=int(live_region)) if (live_only or live_region) else
                         live_for.build_live_plan(self, host_inds, B))
         if timing_events is not None:
             timing_events[0].record()
@@ -421,6 +422,66 @@ class RecPolicyBuffer(object):
         return (cast(out["obs"]), out["share_obs"] if self.use_same_share_obs else cast(out["share_obs"]), cast(out["acts"]),
                 cast(out["rewards"]), cast(out["dones"]),
                 out["dones_env"], cast(out["avail_acts"]) if self.use_avail_acts else None)
+
+    def sample_inds_ahead(self, sample_inds, live_for=None, live_only=False, after=None, **kw):
+        """The gather of `sample_inds` launched NOW on this buffer's side stream, to be consumed later: returns a handle whose `.get()` makes
+        the (then) current stream wait for the copy and returns the 7-tuple of sample_inds. For a loop of consecutive updates with no insert
+        in between (several train steps per collected episode):
+            cur = buf.sample_inds_ahead(inds_0, live_for=trainer)
+            for k in ...:
+                batch = cur.get(); mid = buf.midstep_event(at=3)          # optional: an event the step records in its middle (ope_qmix_signal_event)
+                trainer.train_policy_on_batch(batch)
+                cur = buf.sample_inds_ahead(inds_{k+1}, live_for=trainer, after=mid)
+        the HBM-bound copy of batch k + 1 then runs beside step k's latency-bound kernels (the scan's adjoint, the optimizer tail) instead of
+        in front of step k + 1: same indices, same batches, same arithmetic, in the same order. `after`: the event the side stream waits for
+        (default: everything enqueued on the current stream so far). The batch is written into one of TWO destination batches this buffer
+        keeps for the purpose, alternately (no allocation, no allocator events on the stream): a handle's arrays are overwritten by the
+        second sample_inds_ahead call after its own -- and the live plans alternate between the workspace's two regions the same way, so
+        `after` must not fire before the step that consumed the handle two calls back has finished (the default and a mid-step event of the
+        step just enqueued both satisfy that). A batch sampled ahead does not see episodes inserted after this call."""
+        main = torch.cuda.current_stream(self.device)
+        st = getattr(self, "_ahead", None)
+        B = int(len(sample_inds))
+        if st is None or st["B"] != B:
+            st = self._ahead = {"B": B, "stream": torch.cuda.Stream(device=self.device), "n": 0,
+                                "out": [self.alloc_batch(B), self.alloc_batch(B)]}
+            torch.cuda.current_stream(self.device).synchronize()      # (the two batches exist before the side stream first writes one)
+        st["n"] += 1
+        slot = st["n"] & 1
+        side = st["stream"]
+        if after is not None:
+            side.wait_event(after)
+        else:
+            side.wait_stream(main)
+        with torch.cuda.stream(side):
+            s = self.sample_inds(sample_inds, live_for=live_for, live_only=live_only, live_region=slot, out=st["out"][slot], **kw)
+            done = torch.cuda.Event()
+            done.record(side)
+        return _AheadBatch(s, done, self.device)
+
+    def midstep_event(self, at=3):
+        """An event the NEXT QMIX step launched from this thread records in front of its launch `at` (ope.h: ope_qmix_signal_event: 1 the GRU
+        scan, 2 the (t, b)-row chain, 3 the scan's adjoint, 4 the weight gradients, 5 their reduction); pass it to sample_inds_ahead(after=)
+        AFTER the train call has returned."""
+        ring = getattr(self, "_mid_events", None)
+        if ring is None:
+            ring = self._mid_events = {"n": 0, "ev": [torch.cuda.Event(), torch.cuda.Event()]}
+            for e in ring["ev"]:
+                e.record(torch.cuda.current_stream(self.device))      # (creates the hipEvent_t; every step records it again)
+        ring["n"] += 1
+        ev = ring["ev"][ring["n"] & 1]
+        _lib.check(_lib.lib.ope_qmix_signal_event(C.c_void_p(ev.cuda_event), int(at)), "ope_qmix_signal_event")
+        return ev
+
+
+class _AheadBatch(object):
+    """A batch whose gather is in flight on the buffer's side stream (RecPolicyBuffer.sample_inds_ahead)."""
+    def __init__(self, batch, done, device):
+        self._batch, self._done, self._device = batch, done, device
+
+    def get(self):
+        torch.cuda.current_stream(self._device).wait_event(self._done)
+        return self._batch
 
 
 class RecReplayBuffer(object):

@@ -473,3 +473,43 @@ def test_live_only_gather_moves_the_live_entries_and_nothing_else():
     assert s2[5]._ope_live is None
     for x, y in zip(s2, plain):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("at", [0, 1, 3])
+def test_batches_gathered_ahead_on_a_side_stream_train_the_same(at):
+    """RecPolicyBuffer.sample_inds_ahead (+ midstep_event / ope_qmix_signal_event): four consecutive updates with the gather of step k + 1
+    launched on the side stream -- behind everything enqueued so far (at = 0) or from launch `at` of step k on -- against the same four updates
+    with sample_inds in front of every step: the parameters after the last step are equal BIT FOR BIT (same batches, same plans -- in
+    alternating plan regions --, same arithmetic), no step launches a plan kernel of its own, and the handles' arrays are the plain gather's."""
+    from offpolicy_amd import _lib
+    from offpolicy_amd.config import default_args
+    from offpolicy_amd.utils.synth import EnvDims
+    dims, B = EnvDims("custom", 3, 9, 188, 216, 24), 8
+    policy, trainer, buf = _make(dims, default_args(), B, seed=11, dones=_holes)
+    trainer.tune.update(trunk_path=4, chain_path=2, wgrad_path=2, scan_family=4)
+    pb = buf.policy_buffers["policy_0"]
+    rng = np.random.RandomState(3)
+    inds = [rng.randint(0, 3 * B, size=B) for _ in range(4)]
+    snap = _snapshot(trainer)
+    for ix in inds:      # sequential
+        s = pb.sample_inds(ix, live_for=trainer, live_only=True)
+        trainer.train_policy_on_batch(tuple({"policy_0": x} for x in s) + (None, None))
+        trainer.soft_target_updates()
+    torch.cuda.synchronize()
+    ref = trainer.theta.clone(), trainer.theta_tgt.clone()
+    _restore(trainer, snap)
+    cur = pb.sample_inds_ahead(inds[0], live_for=trainer, live_only=True)
+    for k in range(4):
+        s = cur.get()
+        if k == 0:
+            for x, y in zip(s, pb.sample_inds(inds[0])):      # the live entries are the plain gather's (dead ones: whatever the slot held)
+                if x.shape == y.shape and x.dim() == 3 and x.shape[-1] == 1:
+                    assert torch.equal(x, y)
+        mid = pb.midstep_event(at) if at else None
+        trainer.train_policy_on_batch(tuple({"policy_0": x} for x in s) + (None, None))
+        assert "live_plan" not in _lib.last_launches(), _lib.last_launches()
+        if k + 1 < 4:
+            cur = pb.sample_inds_ahead(inds[k + 1], live_for=trainer, live_only=True, after=mid)
+        trainer.soft_target_updates()
+    torch.cuda.synchronize()
+    assert torch.equal(trainer.theta, ref[0]) and torch.equal(trainer.theta_tgt, ref[1])
