@@ -211,6 +211,8 @@ void make_plan(const ope_qmix_cfg* c, Plan* p) {
   // per-workgroup partial sums of grad^2 written by the finalize launch (zero beyond the launch's workgroups: the region
   // is zero-filled once at workspace_init); upper bound of finalize_blocks()
   p->n_gsq = ope_cdiv((int64_t)p->P + OPE_GRAD_TAIL, 256) + 1 + ope_cdiv((int64_t)2 * (p->D + (p->layerN == 2 ? 4 : 3) * OPE_H) * 64, 256) + 4;
+  // ... or of launch_wgrad2_fin's live workgroups: 4 rows each of at most 4 tiles + column sums + column partials per unit, + tail + zero blocks
+  p->n_gsq = std::max(p->n_gsq, kMaxW2Units * ((4 * 64 + 4 + 8 + 3) / 4) + 1 + (int)ope_cdiv((int64_t)p->P, 2048) + 1);
   p->gsq_part = W.add("gsq_part", p->n_gsq);
   p->err_abs = W.add("err_abs", TB); p->dqtot = W.add("dqtot", 4 * TB); p->d_agent_q = W.add("d_agent_q", TB * p->N);
   p->d_b1 = W.add("d_b1", TB * OPE_MIX); p->d_v2 = W.add("d_v2", TB * OPE_MIX); p->d_v1 = W.add("d_v1", TB * p->NM);
@@ -846,7 +848,8 @@ static int qmix_step(const ope_qmix_cfg* cfg, const ope_fields* batch, const ope
   if ((rc = sync_to(st, side))) return rc;
 
   int agent_slabs = 0, mixer_slabs = 0;
-  bool reduced = false;      // the weight-gradient launch summed its own slabs into `rsum`
+  bool reduced = false;
+  bool w2_pending = false;      // the weight-gradient launch summed its own slabs into `rsum`
   if (use_side && !cfg->vdn) {   // main stream, beside the BPTT of the last chunk on the side stream
     WgTable wm;
     memset(&wm, 0, sizeof(wm));
@@ -902,8 +905,7 @@ static int qmix_step(const ope_qmix_cfg* cfg, const ope_fields* batch, const ope
     if (want_w2) {      // (C = 1: this is the only pass; the table and its plan were made before the first launch)
       if (wt2.n > 0) {
         if ((rc = step_signal(4, st))) return rc;
-        if ((rc = launch_wgrad2(w2, W + p.raw2, W + p.rsum, st))) return rc;
-        if ((rc = step_signal(5, st))) return rc;
+        w2_pending = true;      // (launched below, once the segment table says whether the finalize step can be folded in)
         reduced = true;
       }
       continue;
@@ -997,9 +999,28 @@ static int qmix_step(const ope_qmix_cfg* cfg, const ope_fields* batch, const ope
   if (do_mix) seg((int)p.P, OPE_GRAD_TAIL, FIN_TAIL, 0, 0, 0, 0, 0, 0, 0);
   ft.n = k;
   ft.total = p.P + (do_mix ? OPE_GRAD_TAIL : 0);
+  if (w2_pending) {
+    // wgrad2 with the finalize step folded in (ope_wgrad2.hip: launch_wgrad2_fin): the slabs of a LayerNorm-fed Linear hold dW = C gamma + s (x) beta
+    // and the column partials of dgamma / dbeta, and ONE launch sums every slab straight into the flat gradient (+ loss tail, zero ranges, the
+    // clip norm's partial sums of squares) -- instead of w2_reduce -> rsum -> finalize. Falls back when a segment has no producer in the table.
+    static const int fin_env = getenv("OPE_W2_FIN") ? atoi(getenv("OPE_W2_FIN")) : 1;
+    FinMisc misc;
+    if (fin_env && phase == 0 && do_mix && w2_attach_fin(&w2, ft, &misc) && w2_fin_blocks(w2, misc) <= p.n_gsq) {
+      misc.loss_part = W + p.loss_part; misc.n_loss_tiles = p.n_loss_tiles; misc.n_gsq_total = p.n_gsq;
+      if ((rc = launch_wgrad2_fin(w2, W + p.raw2, theta, grad, W + p.gsq_part, misc, st))) return rc;
+      if ((rc = step_signal(5, st))) return rc;
+      if (g_signal_ev) {
+        const int at = g_signal_at;
+        if ((rc = step_signal(at, st))) return rc;
+      }
+      return OPE_OK;
+    }
+    if ((rc = launch_wgrad2(w2, W + p.raw2, W + p.rsum, st))) return rc;
+    if ((rc = step_signal(5, st))) return rc;
+  }
   if (finalize_blocks(ft) > p.n_gsq) return OPE_ENOSPC;
   // (n_loss_tiles < 0: no loss tail -- an agent-backward part writes its parameter block only)
-  if ((rc = launch_finalize(ft, W + p.rsum, theta, W + p.loss_part, do_mix ? p.n_loss_tiles : -1, grad, st, W + p.gsq_part))) return rc;
+  if ((rc = launch_finalize(ft, W + p.rsum, theta, W + p.loss_part, do_mix ? p.n_loss_tiles : -1, grad, st, W + p.gsq_part, p.n_gsq))) return rc;
   if (g_signal_ev) {      // (a point this step's path does not pass: the event still fires, behind the step's last launch)
     const int at = g_signal_at;
     if ((rc = step_signal(at, st))) return rc;

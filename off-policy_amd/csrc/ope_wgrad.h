@@ -23,6 +23,12 @@ struct WgProb {
   const int* K_dev;                    // rows reduced over, read on the device (<= K; the units' row chunks are re-derived from it in the kernel)
   const int* b_map; int map_on;        // map_on: B's row for reduction row k is b_map[k], no contribution where that is negative (b_shift must
                                        // be 0); LayerNorm statistics stay indexed by k. map_on = 0: b_map still points at >= K readable ints
+  // wgrad2 with the finalize step folded in (launch_wgrad2_fin; filled by w2_attach_fin from the step's FinTable): where this problem's results
+  // go in the FLAT GRADIENT (= the parameter vector's layout), and whether its Linear is fed by a LayerNorm
+  int fin_kind;                        // 0: C is the gradient as it is; 1: dW = C gamma + s (x) beta, dgamma[n] = sum_m W[m][n] C[m][n], dbeta[n] = sum_m s[m] W[m][n]
+  int g_off;                           // flat-gradient (and parameter) offset of W [M][ldc], or -1: C is not a parameter's gradient
+  int gs_off;                          // ... of the vector colsum(A) is the gradient of (the Linear's bias), or -1
+  int gam_off, bet_off;                // fin_kind 1: parameter offsets of the LayerNorm's weight / bias = where dgamma / dbeta go
 };
 constexpr int kMaxWgProbs = 16;
 struct WgTable {
@@ -35,13 +41,15 @@ int wg_finish(WgTable* tb);
 int launch_wgrad(const WgTable& tb, float* raw, hipStream_t st);
 int wg_slabs(const WgTable& tb, int nsplit);
 // ---- register-blocked form (ope_wgrad2.hip): units of up to four tiles per wave, one slab per workgroup ----
-constexpr int kW2Slab = 4 * 4096 + 4 * 64;      // floats a workgroup writes: four 64 x 64 tiles + four 64-float column sums
+constexpr int kW2Slab = 4 * 4096 + 4 * 64 + 8 * 64;      // floats a workgroup writes: four 64 x 64 tiles + four 64-float column sums + (fin) the column partials of dgamma / dbeta, four panels each
+constexpr int kW2CpOff = 4 * 4096 + 4 * 64;
 constexpr int kMaxW2Units = 40;
 struct W2Unit {
   int prob;                            // index into W2Table.p
   short mp0, np0, pa, pb;              // first m / n panel (64 columns each) and panels per side, pa * pb <= 4
   int wg_begin, nwg, kchunk;           // workgroups [wg_begin, wg_begin + nwg); wave c of the unit reduces rows [c * kchunk, (c + 1) * kchunk)
   int red_rows;                        // 64-float rows the slab-sum launch adds for this unit (tile rows + column-sum vectors)
+  int fin_rows, fin_blk;               // launch_wgrad2_fin: rows incl. the dgamma / dbeta partial vectors; index of the unit's first workgroup among the launch's live ones
 };
 struct W2Table {
   WgProb p[kMaxWgProbs];
@@ -49,7 +57,18 @@ struct W2Table {
   int ubegin[kMaxW2Units];             // u[q].wg_begin again, contiguous (INT_MAX beyond nu): what a workgroup searches
   int np, nu, total_wg, red_blocks;
   int vec;                             // 4 | 2: widest load every operand row of the table allows (picks the kernel and its ring depth)
+  int fin;                             // 1: every problem carries its flat-gradient placement (w2_attach_fin succeeded): launch_wgrad2_fin may run
+  int fin_blocks_x, fin_live_blocks;   // grid.x of the fin launch / its workgroups that write something (= sum-of-squares partials it leaves)
 };
+struct FinTable;
+// zero ranges of the flat gradient nobody's result lands in (grad-less tensors, padding), and where the loss tail goes
+constexpr int kMaxFinZero = 24;
+struct FinMisc { int zbegin[kMaxFinZero], zlen[kMaxFinZero], zcum[kMaxFinZero + 1]; int nz; int tail_off; int n_loss_tiles; const float* loss_part; int n_gsq_total; };
+// Fills the problems' placements and `misc` from the step's segment table; false (fin = 0) if some segment has no producer among the problems or a
+// LayerNorm-fed Linear is split over several row blocks: the caller then runs launch_wgrad2 + launch_finalize as before.
+bool w2_attach_fin(W2Table* w, const FinTable& ft, FinMisc* misc);
+int w2_fin_blocks(const W2Table& w, const FinMisc& misc);
+int launch_wgrad2_fin(const W2Table& w, float* raw, const float* theta, float* grad, float* gsq_part, const FinMisc& misc, hipStream_t st);
 bool w2_ok(const WgTable& tb);
 int w2_max_workgroups();
 int w2_build(const WgTable& tb, W2Table* out);
@@ -101,6 +120,6 @@ int launch_fill(float* p, int64_t n, float v, hipStream_t st);
 // workgroups of a finalize launch = number of floats `gsq_part` must hold
 int finalize_blocks(const FinTable& ft);
 int launch_finalize(const FinTable& ft, const float* rsum, const float* theta, const float* loss_part, int n_loss_tiles,
-                    float* grad, hipStream_t st, float* gsq_part = nullptr);
+                    float* grad, hipStream_t st, float* gsq_part = nullptr, int n_gsq_total = 0);
 
 }  // namespace ope

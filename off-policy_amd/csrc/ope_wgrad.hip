@@ -356,7 +356,7 @@ __device__ __forceinline__ float wave64_sum(float v) {
 // (single-GPU path only: a multi-GPU run all-reduces the gradient between this kernel and the optimizer).
 __global__ void __launch_bounds__(256) finalize_kernel(FinTable ft, const float* __restrict__ rsum, const float* __restrict__ theta,
                                                        const float* __restrict__ loss_part, int n_loss_tiles, float* __restrict__ grad,
-                                                       int n_main, float* __restrict__ gsq_part) {
+                                                       int n_main, float* __restrict__ gsq_part, int n_gsq_total) {
   __shared__ float sq[4];
   if ((int)blockIdx.x > n_main) {
     // Column reductions of the LayerNorm-fed Linears (LNLIN_G / LNLIN_B: M = 14 .. 192 rows, two loads per row). Workgroup = 16
@@ -436,6 +436,9 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinTable ft, const float*
     }
     if (n_loss_tiles >= 0 && threadIdx.x < 4) grad[ft.total - OPE_GRAD_TAIL + threadIdx.x] = threadIdx.x < 3 ? red[0][threadIdx.x] : 0.f;
     if (gsq_part && threadIdx.x == 0) gsq_part[blockIdx.x] = 0.f;   // the tail is not part of the gradient norm
+    // (a step that took launch_wgrad2_fin on this workspace before left more partials than this launch has workgroups)
+    if (gsq_part)
+      for (int q = (int)gridDim.x + (int)threadIdx.x; q < n_gsq_total; q += 256) gsq_part[q] = 0.f;
     return;
   }
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -509,7 +512,7 @@ int finalize_blocks(const FinTable& ft) {
 }
 
 int launch_finalize(const FinTable& ft0, const float* rsum, const float* theta, const float* loss_part, int n_loss_tiles,
-                    float* grad, hipStream_t st, float* gsq_part) {
+                    float* grad, hipStream_t st, float* gsq_part, int n_gsq_total) {
   FinTable t = ft0;
   for (int q = 0; q < kMaxFinSegs; ++q) t.begin[q] = q < t.n ? t.seg[q].begin : 0x7fffffff;
   t.ncb = 0;
@@ -536,7 +539,7 @@ int launch_finalize(const FinTable& ft0, const float* rsum, const float* theta, 
   if (fexp == 2) blocks = n_main + 1;
 #endif
   OPE_LAUNCH(finalize_kernel, dim3(blocks), dim3(256), 0, st, ft, rsum, theta, loss_part, n_loss_tiles, grad, n_main,
-                     gsq_part);
+                     gsq_part, n_gsq_total);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   return OPE_OK;
 }

@@ -216,14 +216,21 @@ constexpr int kXchgVecs = 32;
 struct W2Lds {
   float x[4][kXchgVecs][64][4];      // 128 KB
   float cs[4][4][64][4];             // 16 KB
+  float stot[4][64];                 // fin: the workgroup's column sums of A, by panel
+  float cp[2][4][4][64];             // fin: per wave, the column partials of dgamma / dbeta by B panel (8 KB)
 };
+// what the epilogue needs to fold the LayerNorm-fed-Linear identities into the slab (launch_wgrad2_fin; ope_wgrad.h: WgProb.fin_kind)
+struct W2Fin { const float* theta; const WgProb* P; int mp0, np0; bool on; };
 
 // The four waves of a workgroup hold four consecutive K chunks of the unit. Their sum, in rounds of 32 accumulator vectors: every wave
 // publishes its copy of the round's vectors, then wave w adds the four copies of ITS share (two of the round's eight (tile, mi) groups) as
 // (w0 + w2) + (w1 + w3) in temporaries and stores them -- all four waves add and store (the first version's serial tree, where one wave
 // ended up adding and storing everything, took 4.9 us), and no accumulator register is indexed by the wave number (one code path).
-template <int NT>
-__device__ __forceinline__ void w2_sum_store(f32x4 (&acc)[NT][4][4], W2Lds& L, int wave, int lane, float* __restrict__ slab) {
+// fin.on (a LayerNorm-fed Linear, finalize folded in): what is stored is this workgroup's share of the FINAL gradient, dW = C gamma + s (x) beta
+// with C, s its partial sums (the identities are linear in them), and the column partials sum_m W[m][n] C[m][n] / sum_m s[m] W[m][n] of dgamma /
+// dbeta are collected per wave in LDS on the way (fixed order: groups in program order, waves summed by the caller).
+template <int NT, int PB>
+__device__ __forceinline__ void w2_sum_store(f32x4 (&acc)[NT][4][4], W2Lds& L, int wave, int lane, float* __restrict__ slab, const W2Fin& fin) {
   constexpr int NV = NT * 16;
   const int i = lane & 15, g = lane >> 4;
 #pragma unroll
@@ -245,6 +252,32 @@ __device__ __forceinline__ void w2_sum_store(f32x4 (&acc)[NT][4][4], W2Lds& L, i
     for (int gq = 0; gq < 2; ++gq)
       if (gq < per) {
         const int grp = wave * per + gq;                           // group of the round (runtime: only an LDS address and a store address)
+        // s[ni][r] = C[64 a + 16 g + 4 r + mi][64 b + 4 i + ni]: per r one float4 over ni, row 16 g + 4 r + mi of tile t
+        const int idx = v0 + grp * 4, t = idx >> 4, mi = (idx >> 2) & 3;
+        // fin: the parameter values of the group (gamma, beta of its columns; W of its rows x columns), requested in front of the LDS reads --
+        // 16-byte pieces where the layout allows (inside the row or entirely past it)
+        f32x4 pgam = {0.f, 0.f, 0.f, 0.f}, pbet = pgam, pw[4] = {pgam, pgam, pgam, pgam};
+        if (fin.on) {
+          const WgProb& P = *fin.P;
+          const int a = t / PB, b = t - a * PB;
+          const int nb = 64 * (fin.np0 + b) + 4 * i, mb = 64 * (fin.mp0 + a) + 16 * g + mi;
+          if (((P.ldc | P.N | P.g_off | P.gam_off | P.bet_off) & 3) == 0) {
+            const int nc = min(nb, P.N - 4);
+            pgam = *reinterpret_cast<const f32x4*>(fin.theta + P.gam_off + nc);
+            pbet = *reinterpret_cast<const f32x4*>(fin.theta + P.bet_off + nc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pw[r] = *reinterpret_cast<const f32x4*>(fin.theta + P.g_off + (int64_t)min(mb + 4 * r, P.M - 1) * P.ldc + nc);
+          } else {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+              const int c = min(nb + ni, P.N - 1);
+              pgam[ni] = fin.theta[P.gam_off + c];
+              pbet[ni] = fin.theta[P.bet_off + c];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) pw[r][ni] = fin.theta[P.g_off + (int64_t)min(mb + 4 * r, P.M - 1) * P.ldc + c];
+            }
+          }
+        }
         f32x4 s[4];
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
@@ -253,8 +286,34 @@ __device__ __forceinline__ void w2_sum_store(f32x4 (&acc)[NT][4][4], W2Lds& L, i
                       c2 = *reinterpret_cast<const f32x4*>(L.x[2][j][lane]), c3 = *reinterpret_cast<const f32x4*>(L.x[3][j][lane]);
           s[ni] = (c0 + c2) + (c1 + c3);
         }
-        // s[ni][r] = C[64 a + 16 g + 4 r + mi][64 b + 4 i + ni]: per r one float4 over ni, row 16 g + 4 r + mi of tile t
-        const int idx = v0 + grp * 4, t = idx >> 4, mi = (idx >> 2) & 3;
+        if (fin.on) {
+          const WgProb& P = *fin.P;
+          const int a = t / PB, b = t - a * PB;
+          const int mb = 64 * (fin.mp0 + a) + 16 * g + mi;
+          float st[4], cg[4] = {0.f, 0.f, 0.f, 0.f}, cb[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) st[r] = L.stot[a][16 * g + 4 * r + mi];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool ok = mb + 4 * r < P.M;      // (rows past M hold sums of clamped columns: never stored, and kept out of the column partials)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+              const float wv = pw[r][ni];
+              cg[ni] = ok ? fmaf(wv, s[ni][r], cg[ni]) : cg[ni];
+              cb[ni] = ok ? fmaf(wv, st[r], cb[ni]) : cb[ni];
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) s[ni][r] = fmaf(s[ni][r], pgam[ni], st[r] * pbet[ni]);
+          }
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) { cg[ni] = rowsum4(cg[ni]); cb[ni] = rowsum4(cb[ni]); }
+          if (g == 0) {
+            f32x4* p0 = reinterpret_cast<f32x4*>(&L.cp[0][wave][b][4 * i]);
+            f32x4* p1 = reinterpret_cast<f32x4*>(&L.cp[1][wave][b][4 * i]);
+            *p0 = *p0 + f32x4{cg[0], cg[1], cg[2], cg[3]};
+            *p1 = *p1 + f32x4{cb[0], cb[1], cb[2], cb[3]};
+          }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           *reinterpret_cast<f32x4*>(slab + t * 4096 + (16 * g + 4 * r + mi) * 64 + 4 * i) = f32x4{s[0][r], s[1][r], s[2][r], s[3][r]};
@@ -264,7 +323,7 @@ __device__ __forceinline__ void w2_sum_store(f32x4 (&acc)[NT][4][4], W2Lds& L, i
 
 // One workgroup, one unit of shape PA x PB.
 template <int VEC, int PA, int PB, int EXP, bool MAP>
-__device__ __forceinline__ void w2_unit(const WgProb& P, const W2Unit& U, int wg, int wave, W2Lds& L, float* __restrict__ raw) {
+__device__ __forceinline__ void w2_unit(const WgProb& P, const W2Unit& U, int wg, int wave, W2Lds& L, float* __restrict__ raw, const float* __restrict__ theta) {
   constexpr int NT = PA * PB;
   const int lane = threadIdx.x & 63;
   const int i = lane & 15, g = lane >> 4;
@@ -294,11 +353,39 @@ __device__ __forceinline__ void w2_unit(const WgProb& P, const W2Unit& U, int wg
     if (acc[0][0][0][0] == 123.456f) raw[0] = 1.f;
     return;
   }
-  if (colsum) {
+  W2Fin fin;
+  fin.theta = theta; fin.P = &P; fin.mp0 = U.mp0; fin.np0 = U.np0;
+  fin.on = theta != nullptr && P.fin_kind == 1;      // (uniform over the workgroup)
+  if (colsum || fin.on) {
 #pragma unroll
     for (int a = 0; a < PA; ++a) *reinterpret_cast<f32x4*>(L.cs[wave][a][lane]) = cs[a];
   }
-  w2_sum_store<NT>(acc, L, wave, lane, slab);
+  if (fin.on) {
+    // the workgroup's column sums of A, needed by every wave in front of its stores; the per-wave partial vectors start at zero
+    for (int q = threadIdx.x; q < 2 * 4 * 4 * 64; q += 256) (&L.cp[0][0][0][0])[q] = 0.f;
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int a = 0; a < PA; ++a) {
+        const f32x4 c0 = cs[a], c1 = *reinterpret_cast<const f32x4*>(L.cs[1][a][lane]), c2 = *reinterpret_cast<const f32x4*>(L.cs[2][a][lane]),
+                    c3 = *reinterpret_cast<const f32x4*>(L.cs[3][a][lane]);
+        const f32x4 c = (c0 + c2) + (c1 + c3);
+        f32x4 sv;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sv[q] = rowsum4(c[q]);
+        if (g == 0) *reinterpret_cast<f32x4*>(&L.stot[a][4 * i]) = sv;
+      }
+    }
+    // (the first round's barrier inside w2_sum_store, behind the publishes, orders stot / cp in front of their first use)
+  }
+  w2_sum_store<NT, PB>(acc, L, wave, lane, slab, fin);
+  if (fin.on) {      // dgamma / dbeta partials of the workgroup: (w0 + w2) + (w1 + w3) per column
+    __syncthreads();
+    for (int q = threadIdx.x; q < 2 * PB * 64; q += 256) {
+      const int which = q / (PB * 64), rem = q - which * (PB * 64), b = rem >> 6, c = rem & 63;
+      slab[kW2CpOff + which * 256 + b * 64 + c] = (L.cp[which][0][b][c] + L.cp[which][2][b][c]) + (L.cp[which][1][b][c] + L.cp[which][3][b][c]);
+    }
+  }
   if (colsum && wave == 0) {      // column sums of A: (w0 + w2) + (w1 + w3), then the four k-row groups g
 #pragma unroll
     for (int a = 0; a < PA; ++a) {
@@ -314,7 +401,7 @@ __device__ __forceinline__ void w2_unit(const WgProb& P, const W2Unit& U, int wg
 }
 
 template <int VEC, int EXP = 0, bool MAP = false>
-__global__ void __launch_bounds__(256, 1) wgrad2_kernel(W2Table tb, float* __restrict__ raw) {
+__global__ void __launch_bounds__(256, 1) wgrad2_kernel(W2Table tb, float* __restrict__ raw, const float* __restrict__ theta) {
   __shared__ __attribute__((aligned(16))) W2Lds L;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wg = blockIdx.x;
@@ -325,14 +412,14 @@ __global__ void __launch_bounds__(256, 1) wgrad2_kernel(W2Table tb, float* __res
   const W2Unit& U = tb.u[u];
   const WgProb& P = tb.p[U.prob];
   switch (U.pa * 8 + U.pb) {
-    case 1 * 8 + 1: w2_unit<VEC, 1, 1, EXP, MAP>(P, U, wg, wave, L, raw); break;
-    case 1 * 8 + 2: w2_unit<VEC, 1, 2, EXP, MAP>(P, U, wg, wave, L, raw); break;
-    case 1 * 8 + 3: w2_unit<VEC, 1, 3, EXP, MAP>(P, U, wg, wave, L, raw); break;
-    case 1 * 8 + 4: w2_unit<VEC, 1, 4, EXP, MAP>(P, U, wg, wave, L, raw); break;
-    case 2 * 8 + 1: w2_unit<VEC, 2, 1, EXP, MAP>(P, U, wg, wave, L, raw); break;
-    case 3 * 8 + 1: w2_unit<VEC, 3, 1, EXP, MAP>(P, U, wg, wave, L, raw); break;
-    case 4 * 8 + 1: w2_unit<VEC, 4, 1, EXP, MAP>(P, U, wg, wave, L, raw); break;
-    default: w2_unit<VEC, 2, 2, EXP, MAP>(P, U, wg, wave, L, raw); break;
+    case 1 * 8 + 1: w2_unit<VEC, 1, 1, EXP, MAP>(P, U, wg, wave, L, raw, theta); break;
+    case 1 * 8 + 2: w2_unit<VEC, 1, 2, EXP, MAP>(P, U, wg, wave, L, raw, theta); break;
+    case 1 * 8 + 3: w2_unit<VEC, 1, 3, EXP, MAP>(P, U, wg, wave, L, raw, theta); break;
+    case 1 * 8 + 4: w2_unit<VEC, 1, 4, EXP, MAP>(P, U, wg, wave, L, raw, theta); break;
+    case 2 * 8 + 1: w2_unit<VEC, 2, 1, EXP, MAP>(P, U, wg, wave, L, raw, theta); break;
+    case 3 * 8 + 1: w2_unit<VEC, 3, 1, EXP, MAP>(P, U, wg, wave, L, raw, theta); break;
+    case 4 * 8 + 1: w2_unit<VEC, 4, 1, EXP, MAP>(P, U, wg, wave, L, raw, theta); break;
+    default: w2_unit<VEC, 2, 2, EXP, MAP>(P, U, wg, wave, L, raw, theta); break;
   }
 }
 
@@ -395,7 +482,232 @@ __global__ void __launch_bounds__(512) w2_reduce_kernel(W2Table tb, const float*
   }
 }
 
+// The slab sum with the finalize step folded in (launch_wgrad2_fin): what w2_reduce_kernel does, but the sums land in the FLAT GRADIENT -- a
+// tile row at its weight's place (a LayerNorm-fed Linear's slabs already hold dW = C gamma + s (x) beta per workgroup), a column-sum vector at
+// its bias', the dgamma / dbeta column partials at the LayerNorm's parameters -- and every workgroup leaves the sum of squares of what it
+// wrote (the clip norm's partials: ope_adam_step needs no pass of its own). Row y = nu of the grid: workgroup 0 the loss tail (as
+// finalize_kernel's), the next ones the zero ranges (grad-less tensors, padding). One launch instead of w2_reduce + finalize.
+__global__ void __launch_bounds__(512) w2_fin_kernel(W2Table tb, const float* __restrict__ raw, float* __restrict__ grad, float* __restrict__ gsq, FinMisc mz) {
+  __shared__ float part[kRedRows][8][64];
+  __shared__ float sq[8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if ((int)blockIdx.y == tb.nu) {      // ---- tail, zero ranges
+    const int nzb = (mz.zcum[mz.nz] + 2047) / 2048;
+    const int x = blockIdx.x;
+    if (x > nzb) return;
+    const int gidx = tb.fin_live_blocks - (nzb + 1) + x;
+    if (x == 0) {
+      __shared__ float red[512][3];
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+      for (int q = threadIdx.x; q < mz.n_loss_tiles; q += 512) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(mz.loss_part + (int64_t)q * 4);
+        a0 += v[0]; a1 += v[1]; a2 += v[2];
+      }
+      red[threadIdx.x][0] = a0; red[threadIdx.x][1] = a1; red[threadIdx.x][2] = a2;
+      __syncthreads();
+      for (int o = 256; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o)
+          for (int c = 0; c < 3; ++c) red[threadIdx.x][c] += red[threadIdx.x + o][c];
+        __syncthreads();
+      }
+      if (mz.n_loss_tiles >= 0 && threadIdx.x < 4) grad[mz.tail_off + threadIdx.x] = threadIdx.x < 3 ? red[0][threadIdx.x] : 0.f;
+      // whatever another path of the step left behind this launch's partials
+      for (int q = tb.fin_live_blocks + (int)threadIdx.x; q < mz.n_gsq_total; q += 512) gsq[q] = 0.f;
+    } else {
+      for (int e = (x - 1) * 2048 + (int)threadIdx.x; e < min(x * 2048, mz.zcum[mz.nz]); e += 512) {
+        int r = 0;
+#pragma unroll
+        for (int q = 1; q < kMaxFinZero; ++q)
+          if (q < mz.nz && e >= mz.zcum[q]) r = q;
+        grad[mz.zbegin[r] + (e - mz.zcum[r])] = 0.f;
+      }
+    }
+    if (threadIdx.x == 0) gsq[gidx] = 0.f;
+    return;
+  }
+  const W2Unit& U = tb.u[blockIdx.y];
+  const WgProb& P = tb.p[U.prob];
+  const int ntile = U.pa * U.pb;
+  if ((int)blockIdx.x * kRedRows >= U.fin_rows) return;
+  const float* __restrict__ src = raw + (int64_t)U.wg_begin * kW2Slab;
+  const int nwg = U.nwg;
+  const int ncs = U.red_rows - ntile * 64;      // column-sum vectors of this unit (0 or pa)
+  const float* s[kRedRows];
+  int64_t out[kRedRows];
+  bool live[kRedRows];
+#pragma unroll
+  for (int r = 0; r < kRedRows; ++r) {
+    const int local = (int)blockIdx.x * kRedRows + r;
+    if (local >= U.fin_rows) {
+      s[r] = src + lane; out[r] = 0; live[r] = false;
+    } else if (local >= ntile * 64 + ncs) {      // dgamma / dbeta partial vectors: [which][b]
+      const int q = local - ntile * 64 - ncs, which = q / U.pb, b = q - which * U.pb;
+      const int n = 64 * (U.np0 + b) + lane;
+      s[r] = src + kW2CpOff + which * 256 + b * 64 + lane;
+      out[r] = (which == 0 ? P.gam_off : P.bet_off) + n;
+      live[r] = n < P.N;
+    } else if (local >= ntile * 64) {
+      const int a = local - ntile * 64;
+      const int m = 64 * (U.mp0 + a) + lane;
+      s[r] = src + 4 * 4096 + a * 64 + lane;
+      out[r] = P.gs_off + m;
+      live[r] = m < P.M && P.gs_off >= 0;
+    } else {
+      const int t = local >> 6, ml = local & 63;
+      const int a = t / U.pb, b = t - a * U.pb;
+      const int m = 64 * (U.mp0 + a) + ml, n = 64 * (U.np0 + b) + lane;
+      s[r] = src + t * 4096 + ml * 64 + lane;
+      out[r] = P.g_off + (int64_t)m * P.ldc + n;
+      live[r] = m < P.M && n < P.N;
+    }
+  }
+  float v[kRedRows] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 9
+  for (int q = wave; q < nwg; q += 8) {
+#pragma unroll
+    for (int r = 0; r < kRedRows; ++r) v[r] += s[r][(int64_t)q * kW2Slab];
+  }
+#pragma unroll
+  for (int r = 0; r < kRedRows; ++r) part[r][wave][lane] = v[r];
+  __syncthreads();
+  int64_t o = 0;
+  bool lv = false;
+#pragma unroll
+  for (int r = 0; r < kRedRows; ++r)
+    if (wave == r) { o = out[r]; lv = live[r]; }
+  float w = 0.f;
+  if (lv) {
+    const float(&p)[8][64] = part[wave];
+    w = ((p[0][lane] + p[1][lane]) + (p[2][lane] + p[3][lane])) + ((p[4][lane] + p[5][lane]) + (p[6][lane] + p[7][lane]));
+    grad[o] = w;
+  }
+  // sum of squares of the (up to four) rows this workgroup wrote: waves 0 .. 3, fixed order
+  float q2 = w * w;
+  q2 = row16_sum(q2);
+  q2 = (__shfl(q2, 0, 64) + __shfl(q2, 16, 64)) + (__shfl(q2, 32, 64) + __shfl(q2, 48, 64));
+  if (lane == 0) sq[wave] = q2;
+  __syncthreads();
+  if (threadIdx.x == 0) gsq[U.fin_blk + blockIdx.x] = (sq[0] + sq[1]) + (sq[2] + sq[3]);
+}
+
 }  // namespace
+
+static int launch_wgrad2_impl(const W2Table& w, float* raw, float* rsum, const float* fin_theta, hipStream_t st);
+
+bool w2_attach_fin(W2Table* wp, const FinTable& ft, FinMisc* misc) {
+  W2Table& w = *wp;
+  w.fin = 0;
+  memset(misc, 0, sizeof(*misc));
+  misc->tail_off = -1;
+  if (ft.n < 1 || ft.n > kMaxFinSegs) return false;
+  bool claimed[kMaxFinSegs] = {};
+  auto find = [&](int kind, int src) -> int {
+    for (int q = 0; q < ft.n; ++q)
+      if (ft.seg[q].kind == kind && ft.seg[q].src == src && ft.seg[q].size > 0) return q;
+    return -1;
+  };
+  auto find_begin = [&](int kind, int begin) -> int {
+    for (int q = 0; q < ft.n; ++q)
+      if (ft.seg[q].kind == kind && ft.seg[q].begin == begin) return q;
+    return -1;
+  };
+  for (int q = 0; q < w.np; ++q) {
+    WgProb& P = w.p[q];
+    P.fin_kind = 0; P.g_off = -1; P.gs_off = -1; P.gam_off = P.bet_off = 0;
+    const int cstart = P.rs_base + P.out_off;
+    int sw = find(FIN_LNLIN_W, cstart);
+    if (sw >= 0) {
+      const FinSeg& F = ft.seg[sw];
+      if (F.M != P.M || F.K != P.ldc || P.N > P.ldc || F.size != P.M * P.ldc || F.w != F.begin || P.s_off < 0 || F.src_s != P.rs_base + P.s_off) return false;
+      P.fin_kind = 1; P.g_off = F.begin; P.gam_off = F.gamma; P.bet_off = F.beta;
+      claimed[sw] = true;
+      // the LayerNorm's own gradients: present unless its slots are constants (no feature norm: FIN_ZERO there)
+      const int sg = find_begin(FIN_LNLIN_G, F.gamma), sb = find_begin(FIN_LNLIN_B, F.beta);
+      if ((sg >= 0) != (sb >= 0)) return false;
+      if (sg >= 0) {
+        if (ft.seg[sg].src != cstart || ft.seg[sb].src_s != F.src_s || ft.seg[sg].size != P.N || ft.seg[sb].size != P.N) return false;
+        claimed[sg] = claimed[sb] = true;
+      } else {
+        P.fin_kind = 2;      // transform only: nothing is stored for the LayerNorm
+      }
+    } else {
+      sw = find(FIN_COPY, cstart);
+      if (sw < 0 || ft.seg[sw].size != P.M * P.ldc || P.N > P.ldc) return false;
+      P.g_off = ft.seg[sw].begin;
+      claimed[sw] = true;
+    }
+    if (P.s_off >= 0) {
+      const int ss = find(FIN_COPY, P.rs_base + P.s_off);
+      if (ss >= 0) {
+        if (ft.seg[ss].size != P.M) return false;
+        P.gs_off = ft.seg[ss].begin;
+        claimed[ss] = true;
+      }
+    }
+  }
+  // every segment with a value has a producer; order by position for the gaps
+  int order[kMaxFinSegs];
+  for (int q = 0; q < ft.n; ++q) order[q] = q;
+  std::sort(order, order + ft.n, [&](int x, int y) { return ft.seg[x].begin < ft.seg[y].begin; });
+  int nz = 0, zc = 0;
+  auto zero = [&](int begin, int len) -> bool {
+    if (len <= 0) return true;
+    if (nz >= kMaxFinZero) return false;
+    misc->zbegin[nz] = begin; misc->zlen[nz] = len; misc->zcum[nz] = zc;
+    zc += len; ++nz;
+    return true;
+  };
+  for (int oi = 0; oi < ft.n; ++oi) {
+    const FinSeg& F = ft.seg[order[oi]];
+    const int next = oi + 1 < ft.n ? ft.seg[order[oi + 1]].begin : (int)ft.total;
+    switch (F.kind) {
+      case FIN_ZERO: if (!zero(F.begin, next - F.begin)) return false; break;
+      case FIN_TAIL: misc->tail_off = F.begin; break;
+      case FIN_SKIP: return false;
+      default:
+        if (F.size > 0 && !claimed[order[oi]]) return false;
+        if (!zero(F.begin + F.size, next - (F.begin + F.size))) return false;
+    }
+  }
+  if (ft.seg[order[0]].begin != 0 && !zero(0, ft.seg[order[0]].begin)) return false;
+  misc->nz = nz;
+  misc->zcum[nz] = zc;
+  for (int q = nz + 1; q <= kMaxFinZero; ++q) misc->zcum[q] = zc;
+  if (misc->tail_off < 0) return false;
+  // a LayerNorm-fed Linear: all of its rows in ONE row block (the column partials of a unit are then complete for its columns)
+  int blk = 0, bx = 0;
+  for (int q = 0; q < w.nu; ++q) {
+    W2Unit& U = w.u[q];
+    const WgProb& P = w.p[U.prob];
+    if (P.fin_kind && (U.mp0 != 0 || U.pa != P.mt)) return false;
+    U.fin_rows = U.red_rows + (P.fin_kind == 1 ? 2 * U.pb : 0);
+    U.fin_blk = blk;
+    const int nb = (U.fin_rows + kRedRows - 1) / kRedRows;
+    blk += nb;
+    bx = std::max(bx, nb);
+  }
+  const int nzb = (zc + 2047) / 2048;
+  w.fin_blocks_x = std::max(bx, nzb + 1);
+  w.fin_live_blocks = blk + nzb + 1;
+  w.fin = 1;
+  return true;
+}
+
+int w2_fin_blocks(const W2Table& w, const FinMisc&) { return w.fin ? w.fin_live_blocks : 0; }
+
+int launch_wgrad2_fin(const W2Table& w0, float* raw, const float* theta, float* grad, float* gsq_part, const FinMisc& misc, hipStream_t st) {
+  if (!w0.fin || !theta || !grad || !gsq_part) return OPE_EINVAL;
+  W2Table w = w0;
+  for (int q = 0; q < w.np; ++q)
+    if (w.p[q].fin_kind == 2) w.p[q].fin_kind = 1;      // (the kernels' transform is the same; the unit's fin_rows say whether the partial vectors are stored)
+  int rc = launch_wgrad2_impl(w, raw, nullptr, theta, st);
+  if (rc) return rc;
+  kprof_work(0.0, 4.0 * (double)w.total_wg * kW2Slab);
+  OPE_LAUNCH(w2_fin_kernel, dim3(w.fin_blocks_x, w.nu + 1), dim3(512), 0, st, w, raw, grad, gsq_part, misc);
+  if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
+  note_launch("w2_fin", 0);
+  return OPE_OK;
+}
 
 int w2_max_workgroups() {
   static const int cus = [] {
@@ -542,7 +854,7 @@ int w2_build(const WgTable& tb, W2Table* out) {
   return OPE_OK;
 }
 
-int launch_wgrad2(const W2Table& w, float* raw, float* rsum, hipStream_t st) {
+static int launch_wgrad2_impl(const W2Table& w, float* raw, float* rsum, const float* fin_theta, hipStream_t st) {
   if (w.nu < 1 || w.total_wg < 1) return OPE_EINVAL;
   const bool v4 = w.vec == 4;
   bool mapped = false;
@@ -560,34 +872,38 @@ int launch_wgrad2(const W2Table& w, float* raw, float* rsum, hipStream_t st) {
     static bool warned = false;
     if (!warned) { fprintf(stderr, "libope: OPE_W2_EXP=%d -- a timing-only variant of wgrad2_kernel runs: the gradients are WRONG\n", exp_env); warned = true; }
     switch (exp_env) {
-      case 1: OPE_LAUNCH((wgrad2_kernel<4, 1>), dim3(w.total_wg), dim3(256), 0, st, w, raw); break;
-      case 2: OPE_LAUNCH((wgrad2_kernel<4, 2>), dim3(w.total_wg), dim3(256), 0, st, w, raw); break;
-      case 3: OPE_LAUNCH((wgrad2_kernel<4, 3>), dim3(w.total_wg), dim3(256), 0, st, w, raw); break;
-      case 4: OPE_LAUNCH((wgrad2_kernel<4, 4>), dim3(w.total_wg), dim3(256), 0, st, w, raw); break;
-      case 6: OPE_LAUNCH((wgrad2_kernel<4, 6>), dim3(w.total_wg), dim3(256), 0, st, w, raw); break;
-      case 7: OPE_LAUNCH((wgrad2_kernel<4, 7>), dim3(w.total_wg), dim3(256), 0, st, w, raw); break;
-      case 15: OPE_LAUNCH((wgrad2_kernel<4, 15>), dim3(w.total_wg), dim3(256), 0, st, w, raw); break;
-      case 31: OPE_LAUNCH((wgrad2_kernel<4, 31>), dim3(w.total_wg), dim3(256), 0, st, w, raw); break;
-      case 63: OPE_LAUNCH((wgrad2_kernel<4, 63>), dim3(w.total_wg), dim3(256), 0, st, w, raw); break;
-      case 39: OPE_LAUNCH((wgrad2_kernel<4, 39>), dim3(w.total_wg), dim3(256), 0, st, w, raw); break;
+      case 1: OPE_LAUNCH((wgrad2_kernel<4, 1>), dim3(w.total_wg), dim3(256), 0, st, w, raw, (const float*)nullptr); break;
+      case 2: OPE_LAUNCH((wgrad2_kernel<4, 2>), dim3(w.total_wg), dim3(256), 0, st, w, raw, (const float*)nullptr); break;
+      case 3: OPE_LAUNCH((wgrad2_kernel<4, 3>), dim3(w.total_wg), dim3(256), 0, st, w, raw, (const float*)nullptr); break;
+      case 4: OPE_LAUNCH((wgrad2_kernel<4, 4>), dim3(w.total_wg), dim3(256), 0, st, w, raw, (const float*)nullptr); break;
+      case 6: OPE_LAUNCH((wgrad2_kernel<4, 6>), dim3(w.total_wg), dim3(256), 0, st, w, raw, (const float*)nullptr); break;
+      case 7: OPE_LAUNCH((wgrad2_kernel<4, 7>), dim3(w.total_wg), dim3(256), 0, st, w, raw, (const float*)nullptr); break;
+      case 15: OPE_LAUNCH((wgrad2_kernel<4, 15>), dim3(w.total_wg), dim3(256), 0, st, w, raw, (const float*)nullptr); break;
+      case 31: OPE_LAUNCH((wgrad2_kernel<4, 31>), dim3(w.total_wg), dim3(256), 0, st, w, raw, (const float*)nullptr); break;
+      case 63: OPE_LAUNCH((wgrad2_kernel<4, 63>), dim3(w.total_wg), dim3(256), 0, st, w, raw, (const float*)nullptr); break;
+      case 39: OPE_LAUNCH((wgrad2_kernel<4, 39>), dim3(w.total_wg), dim3(256), 0, st, w, raw, (const float*)nullptr); break;
       default: return OPE_EINVAL;
     }
   } else
 #endif
   if (mapped) kprof_rows(2);      // (the agent problems' count; the mixer problems' live share is the same to within a row per episode)
+  const float* theta = fin_theta;      // (null: the slabs hold the raw products, w2_reduce + finalize follow)
   if (mapped) {
-    if (v4) OPE_LAUNCH((wgrad2_kernel<4, 0, true>), dim3(w.total_wg), dim3(256), 0, st, w, raw);
-    else OPE_LAUNCH((wgrad2_kernel<2, 0, true>), dim3(w.total_wg), dim3(256), 0, st, w, raw);
+    if (v4) OPE_LAUNCH((wgrad2_kernel<4, 0, true>), dim3(w.total_wg), dim3(256), 0, st, w, raw, theta);
+    else OPE_LAUNCH((wgrad2_kernel<2, 0, true>), dim3(w.total_wg), dim3(256), 0, st, w, raw, theta);
   } else if (v4)
-    OPE_LAUNCH((wgrad2_kernel<4>), dim3(w.total_wg), dim3(256), 0, st, w, raw);
+    OPE_LAUNCH((wgrad2_kernel<4>), dim3(w.total_wg), dim3(256), 0, st, w, raw, theta);
   else
-    OPE_LAUNCH((wgrad2_kernel<2>), dim3(w.total_wg), dim3(256), 0, st, w, raw);
+    OPE_LAUNCH((wgrad2_kernel<2>), dim3(w.total_wg), dim3(256), 0, st, w, raw, theta);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   note_launch(mapped ? "wgrad2_live" : "wgrad2", v4 ? 4 : 2);
+  if (fin_theta) return OPE_OK;      // (launch_wgrad2_fin sums the slabs itself)
   kprof_work(0.0, 4.0 * (double)w.total_wg * kW2Slab);
   OPE_LAUNCH(w2_reduce_kernel, dim3((w.red_blocks + kRedRows - 1) / kRedRows, w.nu), dim3(512), 0, st, w, raw, rsum);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
   return OPE_OK;
 }
+
+int launch_wgrad2(const W2Table& w, float* raw, float* rsum, hipStream_t st) { return launch_wgrad2_impl(w, raw, rsum, nullptr, st); }
 
 }  // namespace ope
