@@ -304,6 +304,11 @@ int ope_qmix_workspace_init(const ope_qmix_cfg* cfg, void* workspace, int64_t wo
  * read ONCE. A non-zero field of the cfg always wins. */
 void ope_set_debug(int on);
 void ope_set_scan_kernel(int family, int waves_per_row);
+/* 1 (default; OPE_W2_FIN) | 0: where the register-blocked weight-gradient launch runs (wgrad2), fold the finalize step into its slab sum -- the
+ * slabs of a LayerNorm-fed Linear then hold dW = C gamma + s (x) beta and the column partials of dgamma / dbeta, and ONE launch (w2_fin) sums
+ * every slab straight into the flat gradient, with the loss tail, the zero ranges and the clip norm's partial sums of squares -- instead of
+ * w2_reduce -> finalize. Same gradient to rounding (the identities are applied per workgroup instead of to the total). A/B runs and tests. */
+void ope_set_w2_fin(int on);
 /* In-process per-kernel timing (the per-kernel roofline table of bench.py, measured in the run): ope_kernel_profile(1, max_launches)
  * makes every kernel launch of the library carry hipExtLaunchKernel start / stop events (the dispatch's own duration -- what rocprofv3's
  * kernel trace reports), up to max_launches (<= 16384) launches; ope_kernel_profile_read waits for them, writes one line per distinct

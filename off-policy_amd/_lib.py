@@ -120,6 +120,7 @@ def _load():
         "ope_strerror": (C.c_char_p, [C.c_int]),
         "ope_set_debug": (None, [C.c_int]),
         "ope_set_scan_kernel": (None, [C.c_int, C.c_int]),
+        "ope_set_w2_fin": (None, [C.c_int]),
         "ope_last_launches": (C.c_int, [C.c_char_p, i32]),
         "ope_kernel_profile": (C.c_int, [i32, i32]),
         "ope_kernel_profile_read": (C.c_int, [C.c_char_p, i32]),

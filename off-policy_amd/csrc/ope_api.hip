@@ -305,6 +305,9 @@ extern "C" const char* ope_strerror(int code) {
   }
 }
 extern "C" void ope_set_debug(int on) { g_debug = on; }
+// process default of "fold the finalize step into the wgrad2 slab sum" (launch_wgrad2_fin): 1 | 0; OPE_W2_FIN sets the initial value
+static int g_w2_fin = getenv("OPE_W2_FIN") ? atoi(getenv("OPE_W2_FIN")) : 1;
+extern "C" void ope_set_w2_fin(int on) { g_w2_fin = on ? 1 : 0; }
 extern "C" void ope_set_scan_kernel(int family, int waves_per_row) {
   ope::g_scan_family = (family == 1 || family == 4) ? family : 0;
   ope::g_scan_waves = (waves_per_row == 2 || waves_per_row == 4) ? waves_per_row : 0;
@@ -1003,9 +1006,8 @@ static int qmix_step(const ope_qmix_cfg* cfg, const ope_fields* batch, const ope
     // wgrad2 with the finalize step folded in (ope_wgrad2.hip: launch_wgrad2_fin): the slabs of a LayerNorm-fed Linear hold dW = C gamma + s (x) beta
     // and the column partials of dgamma / dbeta, and ONE launch sums every slab straight into the flat gradient (+ loss tail, zero ranges, the
     // clip norm's partial sums of squares) -- instead of w2_reduce -> rsum -> finalize. Falls back when a segment has no producer in the table.
-    static const int fin_env = getenv("OPE_W2_FIN") ? atoi(getenv("OPE_W2_FIN")) : 1;
     FinMisc misc;
-    if (fin_env && phase == 0 && do_mix && w2_attach_fin(&w2, ft, &misc) && w2_fin_blocks(w2, misc) <= p.n_gsq) {
+    if (g_w2_fin && phase == 0 && do_mix && w2_attach_fin(&w2, ft, &misc) && w2_fin_blocks(w2, misc) <= p.n_gsq) {
       misc.loss_part = W + p.loss_part; misc.n_loss_tiles = p.n_loss_tiles; misc.n_gsq_total = p.n_gsq;
       if ((rc = launch_wgrad2_fin(w2, W + p.raw2, theta, grad, W + p.gsq_part, misc, st))) return rc;
       if ((rc = step_signal(5, st))) return rc;

@@ -254,30 +254,6 @@ __device__ __forceinline__ void w2_sum_store(f32x4 (&acc)[NT][4][4], W2Lds& L, i
         const int grp = wave * per + gq;                           // group of the round (runtime: only an LDS address and a store address)
         // s[ni][r] = C[64 a + 16 g + 4 r + mi][64 b + 4 i + ni]: per r one float4 over ni, row 16 g + 4 r + mi of tile t
         const int idx = v0 + grp * 4, t = idx >> 4, mi = (idx >> 2) & 3;
-        // fin: the parameter values of the group (gamma, beta of its columns; W of its rows x columns), requested in front of the LDS reads --
-        // 16-byte pieces where the layout allows (inside the row or entirely past it)
-        f32x4 pgam = {0.f, 0.f, 0.f, 0.f}, pbet = pgam, pw[4] = {pgam, pgam, pgam, pgam};
-        if (fin.on) {
-          const WgProb& P = *fin.P;
-          const int a = t / PB, b = t - a * PB;
-          const int nb = 64 * (fin.np0 + b) + 4 * i, mb = 64 * (fin.mp0 + a) + 16 * g + mi;
-          if (((P.ldc | P.N | P.g_off | P.gam_off | P.bet_off) & 3) == 0) {
-            const int nc = min(nb, P.N - 4);
-            pgam = *reinterpret_cast<const f32x4*>(fin.theta + P.gam_off + nc);
-            pbet = *reinterpret_cast<const f32x4*>(fin.theta + P.bet_off + nc);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) pw[r] = *reinterpret_cast<const f32x4*>(fin.theta + P.g_off + (int64_t)min(mb + 4 * r, P.M - 1) * P.ldc + nc);
-          } else {
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-              const int c = min(nb + ni, P.N - 1);
-              pgam[ni] = fin.theta[P.gam_off + c];
-              pbet[ni] = fin.theta[P.bet_off + c];
-#pragma unroll
-              for (int r = 0; r < 4; ++r) pw[r][ni] = fin.theta[P.g_off + (int64_t)min(mb + 4 * r, P.M - 1) * P.ldc + c];
-            }
-          }
-        }
         f32x4 s[4];
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
@@ -289,21 +265,31 @@ __device__ __forceinline__ void w2_sum_store(f32x4 (&acc)[NT][4][4], W2Lds& L, i
         if (fin.on) {
           const WgProb& P = *fin.P;
           const int a = t / PB, b = t - a * PB;
-          const int mb = 64 * (fin.mp0 + a) + 16 * g + mi;
-          float st[4], cg[4] = {0.f, 0.f, 0.f, 0.f}, cb[4] = {0.f, 0.f, 0.f, 0.f};
+          // (the parameter values are requested HERE, behind the LDS reads: hoisted in front of them -- as scalars or as 16-byte pieces -- they
+          // stay live across the sums and the kernel's accumulator array goes to scratch: wgrad2 47 -> 110 us, measured)
+          const int nb = 64 * (fin.np0 + b) + 4 * i, mb = 64 * (fin.mp0 + a) + 16 * g + mi;
+          float gam[4], bet[4], st[4], cg[4] = {0.f, 0.f, 0.f, 0.f}, cb[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) {
+            const int c = min(nb + ni, P.N - 1);
+            gam[ni] = fin.theta[P.gam_off + c];
+            bet[ni] = fin.theta[P.bet_off + c];
+          }
 #pragma unroll
           for (int r = 0; r < 4; ++r) st[r] = L.stot[a][16 * g + 4 * r + mi];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const bool ok = mb + 4 * r < P.M;      // (rows past M hold sums of clamped columns: never stored, and kept out of the column partials)
+            const int m = mb + 4 * r;
+            const bool ok = m < P.M;      // (rows past M hold sums of clamped columns: never stored, and kept out of the column partials)
+            const float* wr = fin.theta + P.g_off + (int64_t)min(m, P.M - 1) * P.ldc;
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
-              const float wv = pw[r][ni];
+              const float wv = wr[min(nb + ni, P.N - 1)];
               cg[ni] = ok ? fmaf(wv, s[ni][r], cg[ni]) : cg[ni];
               cb[ni] = ok ? fmaf(wv, st[r], cb[ni]) : cb[ni];
             }
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) s[ni][r] = fmaf(s[ni][r], pgam[ni], st[r] * pbet[ni]);
+            for (int ni = 0; ni < 4; ++ni) s[ni][r] = fmaf(s[ni][r], gam[ni], st[r] * bet[ni]);
           }
 #pragma unroll
           for (int ni = 0; ni < 4; ++ni) { cg[ni] = rowsum4(cg[ni]); cb[ni] = rowsum4(cb[ni]); }

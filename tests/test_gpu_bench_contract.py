@@ -53,8 +53,9 @@ def test_default_workload_line_has_roofline_and_cpu_baseline():
     names = [k["kernel"] for k in pk["kernels"]]
     for want in ("trunk_fwd", "gru_fwd4", "gru_bwd4", "episode_copy_kernel", "adam_kernel"):
         assert any(want in n for n in names), (want, names)
-    # the weight gradients: the register-blocked launch + its slab sum, or the tile-per-wave one + split_reduce
-    assert all(any(w in n for n in names) for w in ("wgrad2_kernel", "w2_reduce_kernel")) or \
+    # the weight gradients: the register-blocked launch + its slab sum (with the finalize step folded in, or followed by it), or the tile-per-wave one + split_reduce
+    assert all(any(w in n for n in names) for w in ("wgrad2_kernel", "w2_fin_kernel")) or \
+        all(any(w in n for n in names) for w in ("wgrad2_kernel", "w2_reduce_kernel")) or \
         all(any(w in n for n in names) for w in ("wgrad_kernel", "split_reduce_kernel")), names
     # the (t, b)-row chain: the fused pair, or the four separate launches
     assert all(any(w in n for n in names) for w in ("qchain_kernel", "mixer_hyp_kernel")) or \

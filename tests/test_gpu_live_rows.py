@@ -513,3 +513,37 @@ def test_batches_gathered_ahead_on_a_side_stream_train_the_same(at):
         trainer.soft_target_updates()
     torch.cuda.synchronize()
     assert torch.equal(trainer.theta, ref[0]) and torch.equal(trainer.theta_tgt, ref[1])
+
+
+@pytest.mark.parametrize("name", ["3m", "3m_holes", "3m_nofn", "d370", "3m_huber_per"])
+def test_finalize_folded_into_the_slab_sum_gives_the_same_gradient(name):
+    """ope_set_w2_fin: wgrad2 + w2_fin (the LayerNorm-fed-Linear identities applied per workgroup slab, one launch sums the slabs into the flat
+    gradient and leaves the clip norm's partials) against wgrad2 + w2_reduce + finalize -- same gradient to rounding, same loss tail, the same
+    parameters after the optimizer step (the norm partials of either path feed ope_adam_step), on live rows and on every padded row; and a
+    step of the other path afterwards is not disturbed by the partials this one left (the workspace is shared)."""
+    from offpolicy_amd import _lib
+    from offpolicy_amd.config import default_args
+    spec, B, over, vdn, dones = CONFIGS[name]
+    dims = _dims_of(spec)
+    policy, trainer, buf = _make(dims, default_args(**over), B, seed=4, vdn=vdn, dones=dones)
+    trainer.tune.update(trunk_path=4, chain_path=2, wgrad_path=2, scan_family=4)
+    pb = buf.policy_buffers["policy_0"]
+    inds = np.arange(B)
+    w = np.linspace(0.3, 1.0, B).astype(np.float32) if over.get("use_per") else None
+    batch = tuple({"policy_0": x} for x in pb.sample_inds(inds)) + (w, inds if w is not None else None)
+    snap = _snapshot(trainer)
+    try:
+        for live in (True, False):
+            res = {}
+            for fin in (0, 1, 0):
+                _lib.lib.ope_set_w2_fin(fin)
+                _restore(trainer, snap)
+                out = _one(trainer, batch, live)
+                assert ("w2_fin<" in out[3]) == bool(fin), out[3]
+                res.setdefault(fin, []).append((out, trainer.theta.clone()))
+            a, b, a2 = res[0][0], res[1][0], res[0][1]
+            _compare(a[0], b[0], trainer, "%s live=%s fin" % (name, live), gtol=2e-5)
+            assert (a[1] - b[1]).abs().max() <= 2e-6 * max(float(a[1].abs().max()), 1.0), "parameters after the step"
+            assert torch.equal(a[0][2], a2[0][2]) and torch.equal(a[1], a2[1]), "the unfused path after a fused step on the same workspace"
+    finally:
+        _lib.lib.ope_set_w2_fin(1)
