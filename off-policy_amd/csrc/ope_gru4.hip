@@ -38,7 +38,8 @@ __device__ __forceinline__ float hsum4(f32x2 a, f32x2 b) { return (a[0] + a[1]) 
 // sum over the G = 2 or 4 adjacent lanes that share a feature (DPP, every lane ends with the same bits)
 template <int G>
 __device__ __forceinline__ float group_sum_from(float v) {   // the stages after the first (lanes l, l^1 already hold their pair's sum)
-  if (G == 4) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  if (G >= 4) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  if (G == 8) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror: the other quad of the eight
   return v;
 }
 template <int G>
@@ -592,6 +593,19 @@ static void launch_fwd(const GruFwdArgs& a, hipStream_t st) {
     OPE_LAUNCH((gru_fwd4_kernel<W, false, false>), dim3(a.nets * a.NB), dim3((W + 2) * 64), 0, st, a);
 }
 template <int W>
+static void launch_bwd(const GruBwdArgs& a, hipStream_t st);
+// Eight compute waves per row, BACKWARD scan only, "by shape" only (no pinned wave count) and only while every row has a CU to itself: half
+// the broadcast reads (6 instead of 12 ds_read_b128) and packed FMAs (12 instead of 24) per wave, a ten-wave barrier. Round 6, 3s5z, B = 32 (256
+// rows): 45.5 -> 43.8 us (two same-box pairs). The FORWARD scan with eight waves is slower (57.6 vs 48.8 us at two rows per CU: the gate
+// arithmetic is repeated by twice the lanes and twenty waves share a CU), as round 3 had found. OPE_GRUB_W = 4 keeps four.
+static bool launch_bwd8(const GruBwdArgs& a, hipStream_t st) {
+  static const int w8 = getenv("OPE_GRUB_W") ? atoi(getenv("OPE_GRUB_W")) : 8;
+  if (w8 != 8 || a.dbg || a.waves || g_scan_waves || a.NB > scan_device_cus()) return false;
+  if (a.lp.hdr) OPE_LAUNCH((gru_bwd4_kernel<8, false, true>), dim3(a.NB), dim3((8 + 2) * 64), 0, st, a);
+  else OPE_LAUNCH((gru_bwd4_kernel<8, false, false>), dim3(a.NB), dim3((8 + 2) * 64), 0, st, a);
+  return true;
+}
+template <int W>
 static void launch_bwd(const GruBwdArgs& a, hipStream_t st) {
 #ifdef OPE_EXPERIMENTS
   static const int gexp = getenv("OPE_GRUB_EXP") ? atoi(getenv("OPE_GRUB_EXP")) : 0;
@@ -630,9 +644,11 @@ int launch_gru_bwd4(const GruBwdArgs& a, hipStream_t st) {
   kprof_work(2.0 * a.NB * (double)(a.T - a.t_lo) * 3.0 * OPE_H * OPE_H);     // W_hh^T (gate adjoints) per row and step
   if (a.lp.hdr && (a.dbg || a.dh_in || a.dh_carry || a.t_lo != 0 || a.B < 1 || a.N < 1 || a.NB != a.N * a.B || a.T > kLiveMaxT)) return OPE_EINVAL;
   if (a.lp.hdr) kprof_rows(2);
-  if (w == 4) launch_bwd<4>(a, st); else launch_bwd<2>(a, st);
+  const bool w8 = w == 4 && launch_bwd8(a, st);
+  if (w8) { /* launched */ }
+  else if (w == 4) launch_bwd<4>(a, st); else launch_bwd<2>(a, st);
   if (hipGetLastError() != hipSuccess) return OPE_ELAUNCH;
-  note_launch(a.lp.hdr ? "gru_bwd4_live" : "gru_bwd4", w == 4 ? 4 : 2);
+  note_launch(a.lp.hdr ? "gru_bwd4_live" : "gru_bwd4", w8 ? 8 : (w == 4 ? 4 : 2));
   return OPE_OK;
 }
 
