@@ -633,11 +633,17 @@ def main():
         # scan. Reported beside `value` (value_prefetch), never as `value`: the sequential sample -> train step is the headline.
         pre = None
         if world == 1 and graphed is None and not a.prefetch and not a.no_early_plan and not pbuf.lazy_obs and live_row_stats(trainer, local_batch) is not None:
-            ahead["at"], ahead["cur"] = 1, None
-            w_pre, _ = timed_windows(one_step, a.steps, max(4, a.warmup // 2), world, dev, max(1, min(a.repeats, 3)))
-            torch.cuda.synchronize()
-            ahead["at"], ahead["cur"] = 0, None
-            pre = dict(elapsed=median_window(w_pre), windows=w_pre)
+            try:      # (a side leg: whatever goes wrong in it must not cost the run its headline line)
+                ahead["at"], ahead["cur"] = 1, None
+                w_pre, _ = timed_windows(one_step, a.steps, max(4, a.warmup // 2), world, dev, max(1, min(a.repeats, 3)))
+                torch.cuda.synchronize()
+                pre = dict(elapsed=median_window(w_pre), windows=w_pre)
+            except Exception as e:      # noqa: BLE001
+                print("[bench] prefetch leg failed: %r" % (e,), file=sys.stderr)
+                pre = None
+            finally:
+                ahead["at"], ahead["cur"] = 0, None
+                torch.cuda.synchronize()
         live = live_row_stats(trainer, local_batch)       # rows the steps of this leg really ran (None: every padded row)
         results.append(dict(leg=leg, local_batch=local_batch, global_batch=global_batch, elapsed=elapsed, gather_ms=gather_ms, loss=loss,
                             graphed=graphed is not None, bracket_ms=bracket_ms, n_kernel_ms=len(kernel_ms), windows=windows, per_kernel=per_kernel,
