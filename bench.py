@@ -735,7 +735,9 @@ def main():
                          "frac_event_bracket": round(algo_bytes / (r0["bracket_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "event_bracket_note": "20 gathers after the timed region, interval between two HIP event markers recorded around "
                                                "the launch: the kernel plus two command-processor boundaries (what round 1 reported)",
-                         "traffic_source": "profiles/gather_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)"},
+                         "traffic_source": "profiles/gather_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)",
+                         "plain_copy_note": "a plain contiguous device-to-device copy of the same bytes that streams its source out of HBM reaches 4.4-4.6 TB/s "
+                                            "(read + write) on this part, 6.7 TB/s cache-resident (tools/copy_ceiling.py, profiles/r06_copy_ceiling.txt)"},
         }
         T1NB = (dims.episode_length + 1) * dims.n_agents * r0["local_batch"]
         lv = r0["live"]
